@@ -1,0 +1,387 @@
+"""Seeded synthetic VLP-16 + IMU + mono streams for the calibration solve.
+
+Also holds a vectorised numpy evaluator of the split R3 + SO3 uniform cubic B-spline
+(reference: kontiki/trajectories/uniform_{r3,so3}_spline_trajectory.h, spline_base.h:19-29)
+that is used to synthesise measurements which are exactly consistent with a ground-truth state.
+All quaternions are stored (x, y, z, w) like Eigen::Map<Quaternion> (spline_base.h:118-127).
+"""
+import numpy as np
+
+GRAVITY = -9.79  # kontiki/sensors/imu.h:25
+
+M = np.array([[1, 4, 1, 0], [-3, 0, 3, 0], [3, -6, 3, 0], [-1, 3, -3, 1]], dtype=np.float64) / 6.0
+M_CUMUL = np.array([[6, 5, 1, 0], [0, 3, 3, 0], [0, -3, 3, 0], [0, 1, -2, 1]], dtype=np.float64) / 6.0
+
+
+# ---------------------------------------------------------------------------------------------
+# quaternion helpers, (x, y, z, w) storage, Hamilton product
+# ---------------------------------------------------------------------------------------------
+def qmul(a, b):
+    ax, ay, az, aw = np.moveaxis(np.asarray(a, dtype=np.float64), -1, 0)
+    bx, by, bz, bw = np.moveaxis(np.asarray(b, dtype=np.float64), -1, 0)
+    return np.stack([aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by + ay * bw + az * bx - ax * bz,
+                     aw * bz + az * bw + ax * by - ay * bx,
+                     aw * bw - ax * bx - ay * by - az * bz], axis=-1)
+
+
+def qconj(q):
+    q = np.asarray(q, dtype=np.float64)
+    return q * np.array([-1.0, -1.0, -1.0, 1.0])
+
+
+def qrot(q, v):
+    q = np.asarray(q, dtype=np.float64)
+    v = np.asarray(v, dtype=np.float64)
+    qv = q[..., :3]
+    uv = 2.0 * np.cross(qv, v)
+    return v + q[..., 3:4] * uv + np.cross(qv, uv)
+
+
+def qexp_half(v):
+    """exp of a pure quaternion with vector part v (half-angle vector)."""
+    v = np.asarray(v, dtype=np.float64)
+    n = np.linalg.norm(v, axis=-1, keepdims=True)
+    s = np.where(n > 1e-8, np.sin(n) / np.where(n > 1e-8, n, 1.0), 1.0)
+    return np.concatenate([s * v, np.cos(n)], axis=-1)
+
+
+def qlog_half(q):
+    """log of a unit quaternion -> half-angle vector (no hemisphere handling, as the reference)."""
+    q = np.asarray(q, dtype=np.float64)
+    v = q[..., :3]
+    n = np.linalg.norm(v, axis=-1, keepdims=True)
+    k = np.where(n > 1e-8, np.arctan2(n, q[..., 3:4]) / np.where(n > 1e-8, n, 1.0), 1.0)
+    return k * v
+
+
+def q_from_rotvec(phi):
+    return qexp_half(0.5 * np.asarray(phi, dtype=np.float64))
+
+
+def q_from_rpy(roll, pitch, yaw):
+    qx = q_from_rotvec([roll, 0, 0])
+    qy = q_from_rotvec([0, pitch, 0])
+    qz = q_from_rotvec([0, 0, yaw])
+    return qmul(qz, qmul(qy, qx))
+
+
+# ---------------------------------------------------------------------------------------------
+# numpy spline evaluator
+# ---------------------------------------------------------------------------------------------
+class Spline:
+    def __init__(self, t0, dt, r3, so3):
+        self.t0, self.dt = float(t0), float(dt)
+        self.r3 = np.ascontiguousarray(r3, dtype=np.float64)
+        self.so3 = np.ascontiguousarray(so3, dtype=np.float64)
+        self.n = len(self.r3)
+
+    @property
+    def t_min(self):
+        return self.t0
+
+    @property
+    def t_max(self):
+        return self.t0 + (self.n - 3) * self.dt
+
+    def _iu(self, t):
+        s = (np.asarray(t, dtype=np.float64) - self.t0) / self.dt
+        i0 = np.floor(s).astype(np.int64)
+        if np.any(i0 < 0) or np.any(i0 > self.n - 4):
+            raise IndexError("time out of range for spline")
+        return i0, s - i0
+
+    def eval(self, t):
+        t = np.atleast_1d(np.asarray(t, dtype=np.float64))
+        i0, u = self._iu(t)
+        one = np.ones_like(u)
+        zero = np.zeros_like(u)
+        U = np.stack([one, u, u * u, u * u * u], axis=-1)
+        dU = np.stack([zero, one, 2 * u, 3 * u * u], axis=-1) / self.dt
+        ddU = np.stack([zero, zero, 2 * one, 6 * u], axis=-1) / self.dt ** 2
+        idx = i0[:, None] + np.arange(4)[None, :]
+        cp = self.r3[idx]  # (n, 4, 3)
+        pos = np.einsum("nj,njk->nk", U @ M, cp)
+        vel = np.einsum("nj,njk->nk", dU @ M, cp)
+        acc = np.einsum("nj,njk->nk", ddU @ M, cp)
+        B = U @ M_CUMUL
+        dB = dU @ M_CUMUL
+        qc = self.so3[idx]  # (n, 4, 4)
+        q = qc[:, 0]
+        parts = [np.tile(np.array([0.0, 0, 0, 1.0]), (len(t), 1)) for _ in range(3)]
+        for j in range(1, 4):
+            om = qlog_half(qmul(qconj(qc[:, j - 1]), qc[:, j]))
+            e = qexp_half(B[:, j:j + 1] * om)
+            q = qmul(q, e)
+            for m in range(3):
+                if m == j - 1:
+                    w = np.concatenate([dB[:, j:j + 1] * om, np.zeros((len(t), 1))], axis=-1)
+                    parts[m] = qmul(parts[m], w)
+                parts[m] = qmul(parts[m], e)
+        dq = qmul(qc[:, 0], parts[0] + parts[1] + parts[2])
+        angvel = 2.0 * qmul(dq, qconj(q))[:, :3]
+        return {"pos": pos, "vel": vel, "acc": acc, "quat": q, "angvel": angvel}
+
+
+# ---------------------------------------------------------------------------------------------
+# state packing (layout documented in include/lvx.h)
+# ---------------------------------------------------------------------------------------------
+def pack_state(r3, so3, imu, lidar, cam, rho):
+    return np.concatenate([np.ravel(r3), np.ravel(so3), np.ravel(imu), np.ravel(lidar), np.ravel(cam), np.ravel(rho)]).astype(np.float64)
+
+
+def unpack_state(state, n_knots, n_landmarks):
+    s = np.asarray(state, dtype=np.float64)
+    o = 0
+    r3 = s[o:o + 3 * n_knots].reshape(n_knots, 3); o += 3 * n_knots
+    so3 = s[o:o + 4 * n_knots].reshape(n_knots, 4); o += 4 * n_knots
+    imu = s[o:o + 16]; o += 16
+    lidar = s[o:o + 8]; o += 8
+    cam = s[o:o + 8]; o += 8
+    rho = s[o:o + n_landmarks]
+    return {"r3": r3, "so3": so3, "imu": imu, "lidar": lidar, "cam": cam, "rho": rho}
+
+
+def imu_block(roll=0.01, pitch=0.01, ba=(0, 0, 0), bg=(0, 0, 0)):
+    """q_rel(x,y,z,w)=identity, p_rel=0, tau=0, roll, pitch, b_a, b_g (sensors.h:99-110, imu.h:126-127)."""
+    return np.array([0, 0, 0, 1, 0, 0, 0, 0, roll, pitch, *ba, *bg], dtype=np.float64)
+
+
+def sensor_block(q_xyzw, p, tau=0.0):
+    return np.array([*q_xyzw, *p, tau], dtype=np.float64)
+
+
+def gravity_vec(roll, pitch):
+    cr, sr, cp, sp = np.cos(roll), np.sin(roll), np.cos(pitch), np.sin(pitch)
+    return np.array([-sp * cr * GRAVITY, sr * GRAVITY, -cr * cp * GRAVITY])
+
+
+DEFAULT_CAMERA = dict(rows=720, cols=1280, readout=0.0666, fx=530.174987792968, fy=530.094970703125,
+                      cx=635.119995117187, cy=356.522003173828, k1=0.0, k2=0.0, p1=0.0, p2=0.0, k3=0.0)  # cfg/lvi.yaml:54-78
+
+
+def _unproject(cam, uv):
+    return np.stack([(uv[..., 0] - cam["cx"]) / cam["fx"], (uv[..., 1] - cam["cy"]) / cam["fy"], np.ones(uv.shape[:-1])], axis=-1)
+
+
+def _project(cam, X):
+    return np.stack([cam["fx"] * X[..., 0] / X[..., 2] + cam["cx"], cam["fy"] * X[..., 1] / X[..., 2] + cam["cy"]], axis=-1)
+
+
+def make_trajectory(n_knots, t0, dt, rng, pos_amp=2.0, rot_amp=0.6):
+    """Smooth sum-of-sinusoids control points (pos <= 0.5 Hz, rot <= 0.7 Hz)."""
+    tk = t0 + dt * (np.arange(n_knots) - 1.0)
+    r3 = np.zeros((n_knots, 3))
+    phi = np.zeros((n_knots, 3))
+    for ax in range(3):
+        for _ in range(3):
+            f = rng.uniform(0.05, 0.5)
+            r3[:, ax] += pos_amp / 3 * rng.uniform(0.3, 1.0) * np.sin(2 * np.pi * f * tk + rng.uniform(0, 2 * np.pi))
+            f = rng.uniform(0.05, 0.7)
+            phi[:, ax] += rot_amp / 3 * rng.uniform(0.3, 1.0) * np.sin(2 * np.pi * f * tk + rng.uniform(0, 2 * np.pi))
+    so3 = q_from_rotvec(phi)
+    so3 /= np.linalg.norm(so3, axis=1, keepdims=True)
+    return r3, so3
+
+
+def make_problem(seed=4, duration=10.0, dt=0.02, imu_rate=400.0, n_surfel=2000, n_planes=40, n_landmarks=50, views_per_lm=10,
+                 cam_rate=20.0, n_camsurf=0, pad=0.2, noise=True, camera=None, t_start=100.0, state_noise=1e-2):
+    """Build a consistent synthetic calibration problem.  Returns a dict with measurement arrays, the
+    ground-truth state ("state_true") and a perturbed state ("state0")."""
+    rng = np.random.default_rng(seed)
+    cam = dict(DEFAULT_CAMERA if camera is None else camera)
+    t0 = t_start - pad
+    t_end = t_start + duration
+    n_knots = 4
+    while t0 + (n_knots - 3) * dt < t_end + pad:  # SplineEntity::ExtendTo (spline_base.h:374-378)
+        n_knots += 1
+    r3, so3 = make_trajectory(n_knots, t0, dt, rng)
+    sp = Spline(t0, dt, r3, so3)
+    # true calibration
+    q_LI = q_from_rpy(np.deg2rad(2.0), np.deg2rad(-3.0), np.deg2rad(91.0))
+    p_LI = np.array([0.05, -0.10, 0.12])
+    q_CI = qmul(q_from_rpy(np.deg2rad(-90.0), 0.0, np.deg2rad(-90.0)), q_from_rotvec(np.deg2rad([2.0, 0, 0])))
+    p_CI = np.array([-0.22, 0.02, 0.22])
+    roll, pitch = 0.02, -0.015
+    ba = np.array([0.05, 0.02, -0.03]); bg = np.array([0.01, -0.02, 0.005])
+    g = gravity_vec(roll, pitch)
+    ns = 1.0 if noise else 0.0
+    # --- IMU ---
+    n_imu = int(round(duration * imu_rate))
+    t_imu = t_start + np.arange(n_imu) / imu_rate
+    e = sp.eval(t_imu)
+    gyro = qrot(qconj(e["quat"]), e["angvel"]) + bg + ns * 1.745e-4 * np.sqrt(imu_rate) * rng.standard_normal((n_imu, 3))
+    acc = qrot(qconj(e["quat"]), e["acc"] + g) + ba + ns * 5.88e-4 * np.sqrt(imu_rate) * rng.standard_normal((n_imu, 3))
+    # --- planes + surfel points ---
+    t_map = t_start + 0.05
+    e0 = sp.eval([t_map])
+    R0q, p0 = e0["quat"][0], e0["pos"][0]
+    nrm = rng.standard_normal((n_planes, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    dist = rng.uniform(2.0, 12.0, n_planes)
+    Pi = nrm * dist[:, None]  # closest point to the origin of L0; plane: n.x - d = 0
+    planes = [Pi]
+    sid = rng.integers(0, n_planes, n_surfel)
+    t_s = np.sort(rng.uniform(t_map + 1e-3, t_end - 1e-3, n_surfel))
+    n_s = nrm[sid]
+    e1 = np.cross(n_s, np.array([0.3, -0.5, 0.8])); e1 /= np.linalg.norm(e1, axis=1, keepdims=True)
+    e2 = np.cross(n_s, e1)
+    pM = Pi[sid] + rng.uniform(-5, 5, (n_surfel, 1)) * e1 + rng.uniform(-5, 5, (n_surfel, 1)) * e2
+
+    def map_to_lidar(pM_, t_k):
+        ek = sp.eval(t_k)
+        pI0 = qrot(q_LI, pM_) + p_LI
+        pG = qrot(R0q, pI0) + p0
+        pIk = qrot(qconj(ek["quat"]), pG - ek["pos"])
+        return qrot(qconj(q_LI), pIk - p_LI)
+
+    pt_s = map_to_lidar(pM, t_s) + ns * 0.02 * rng.standard_normal((n_surfel, 3)) if n_surfel else np.zeros((0, 3))
+    # --- landmarks + reprojection ---
+    row_d = cam["readout"] / cam["rows"]
+    t_frames = np.arange(t_start + 0.1, t_end - 0.2, 1.0 / cam_rate)
+
+    def cam_pose(t):
+        ee = sp.eval(t)
+        return qmul(ee["quat"], np.broadcast_to(q_CI, ee["quat"].shape)), qrot(ee["quat"], p_CI) + ee["pos"]
+
+    lm_uv = np.zeros((n_landmarks, 2)); lm_t0 = np.zeros(n_landmarks); rho = np.zeros(n_landmarks)
+    rep_lm, rep_uv, rep_t0 = [], [], []
+    PW = np.zeros((n_landmarks, 3))
+    n_first = max(1, len(t_frames) - views_per_lm)
+    for l in range(n_landmarks):
+        f0 = int(rng.integers(0, n_first))
+        uv = np.array([rng.uniform(100, cam["cols"] - 100), rng.uniform(100, cam["rows"] - 100)])
+        z = rng.uniform(2.0, 15.0)
+        tr = t_frames[f0] + uv[1] * row_d
+        qc, pc = cam_pose(np.array([tr]))
+        Pw = qrot(qc[0], _unproject(cam, uv) * z) + pc[0]
+        PW[l] = Pw
+        lm_uv[l], lm_t0[l], rho[l] = uv, t_frames[f0], 1.0 / z
+        for v in range(views_per_lm):
+            fi = f0 + v
+            if fi >= len(t_frames):
+                break
+            if v == 0:
+                o = uv.copy()
+            else:
+                vv = cam["cy"]
+                ok = True
+                for _ in range(4):  # rolling-shutter fixed point on the row time
+                    qo, po = cam_pose(np.array([t_frames[fi] + vv * row_d]))
+                    Xc = qrot(qconj(qo[0]), Pw - po[0])
+                    if Xc[2] < 0.2:
+                        ok = False
+                        break
+                    o = _project(cam, Xc)
+                    vv = o[1]
+                if not ok or not (0 <= o[0] < cam["cols"] and 0 <= o[1] < cam["rows"]):
+                    continue
+                o = o + ns * 0.5 * rng.standard_normal(2)
+            rep_lm.append(l); rep_uv.append(o); rep_t0.append(t_frames[fi])
+    rep_lm = np.array(rep_lm, dtype=np.int32); rep_uv = np.array(rep_uv).reshape(-1, 2); rep_t0 = np.array(rep_t0)
+    # --- camera-landmark-to-surfel: define a plane through the landmark's map-frame point ---
+    cs_lm = np.zeros(0, dtype=np.int32); cs_plane = np.zeros(0, dtype=np.int32)
+    if n_camsurf and n_landmarks:
+        cs_lm = rng.choice(n_landmarks, size=min(n_camsurf, n_landmarks), replace=False).astype(np.int32)
+        extra = []
+        for l in cs_lm:
+            # map-frame point exactly as camera_surfel_landmark.h:38-76 sees it (pose at the view's t0, no row time)
+            ek = sp.eval([lm_t0[l]])
+            p_I = qrot(q_CI, _unproject(cam, lm_uv[l]) / (rho[l] + 1e-8)) + p_CI
+            pI0 = qrot(qconj(R0q), qrot(ek["quat"][0], p_I) + ek["pos"][0] - p0)
+            pM_ = qrot(qconj(q_LI), pI0 - p_LI)
+            n_ = rng.standard_normal(3); n_ /= np.linalg.norm(n_)
+            d_ = float(n_ @ pM_)
+            if abs(d_) < 0.5:
+                n_ = pM_ / np.linalg.norm(pM_); d_ = float(n_ @ pM_)
+            extra.append(n_ * d_)
+        cs_plane = (n_planes + np.arange(len(cs_lm))).astype(np.int32)
+        planes.append(np.array(extra))
+    planes = np.concatenate(planes, axis=0)
+    imu_true = imu_block(roll, pitch, ba, bg)
+    state_true = pack_state(r3, so3, imu_true, sensor_block(q_LI, p_LI), sensor_block(q_CI, p_CI), rho)
+    # perturbed start: control points noise, extrinsics 3 deg / 5 cm, biases 0, default gravity guess
+    r3p = r3 + state_noise * rng.standard_normal(r3.shape)
+    so3p = qmul(q_from_rotvec(state_noise * rng.standard_normal((n_knots, 3))), so3)
+    so3p /= np.linalg.norm(so3p, axis=1, keepdims=True)
+    dqL = q_from_rotvec(np.deg2rad(3.0) * np.array([0.6, -0.5, 0.62]))
+    dqC = q_from_rotvec(np.deg2rad(3.0) * np.array([-0.4, 0.7, 0.59]))
+    state0 = pack_state(r3p, so3p, imu_block(0.01, 0.01), sensor_block(qmul(dqL, q_LI), p_LI + np.array([0.03, -0.03, 0.03])),
+                        sensor_block(qmul(dqC, q_CI), p_CI + np.array([-0.03, 0.03, 0.03])), rho * (1.0 + 0.05 * rng.standard_normal(n_landmarks)))
+    return dict(t0=t0, dt=dt, n_knots=n_knots, camera=cam, t_imu=t_imu, gyro=gyro, acc=acc, w_gyro=28.0, w_acc=18.0,
+                planes=planes, surf_pt=pt_s, surf_t=t_s, surf_plane=sid.astype(np.int32), t_map=t_map, huber_surf=5.0, w_surf=10.0,
+                n_landmarks=n_landmarks, lm_uv=lm_uv, lm_t0=lm_t0, rep_lm=rep_lm, rep_uv=rep_uv, rep_t0=rep_t0,
+                huber_rep=5.0, w_rep=1.0,  # quirk: w_cam lands in the Huber slot, weight = 1 (trajectory_manager_lvi.cpp:525)
+                cs_lm=cs_lm, cs_plane=cs_plane, huber_cs=5.0, w_cs=30.0,
+                state_true=state_true, state0=state0, t_start=t_start, t_end=t_end)
+
+
+def make_bench_problem(seed=4, n_imu=200_000, n_surfel=1_000_000, n_reproj=50_000, n_planes=2000, dt=0.02, imu_rate=400.0,
+                       views_per_lm=10, cam_rate=20.0, pad=0.2, t_start=100.0):
+    """BASELINE.json config 4 shapes (1 M surfel / 200 k IMU / 50 k ORB) generated fully vectorised.
+    Landmarks are synthesised without the rolling-shutter fixed point (observations = reprojection with the row
+    time of the reference row + pixel noise); parity/throughput do not depend on exact consistency."""
+    rng = np.random.default_rng(seed)
+    cam = dict(DEFAULT_CAMERA)
+    duration = n_imu / imu_rate
+    t0 = t_start - pad
+    t_end = t_start + duration
+    n_knots = int(np.ceil((t_end + pad - t0) / dt)) + 3
+    while t0 + (n_knots - 3) * dt < t_end + pad:
+        n_knots += 1
+    r3, so3 = make_trajectory(n_knots, t0, dt, rng)
+    sp = Spline(t0, dt, r3, so3)
+    q_LI = q_from_rpy(np.deg2rad(2.0), np.deg2rad(-3.0), np.deg2rad(91.0)); p_LI = np.array([0.05, -0.10, 0.12])
+    q_CI = qmul(q_from_rpy(np.deg2rad(-90.0), 0.0, np.deg2rad(-90.0)), q_from_rotvec(np.deg2rad([2.0, 0, 0]))); p_CI = np.array([-0.22, 0.02, 0.22])
+    roll, pitch = 0.02, -0.015
+    ba = np.array([0.05, 0.02, -0.03]); bg = np.array([0.01, -0.02, 0.005])
+    g = gravity_vec(roll, pitch)
+    t_imu = t_start + np.arange(n_imu) / imu_rate
+    e = sp.eval(t_imu)
+    gyro = qrot(qconj(e["quat"]), e["angvel"]) + bg + 1.745e-4 * np.sqrt(imu_rate) * rng.standard_normal((n_imu, 3))
+    acc = qrot(qconj(e["quat"]), e["acc"] + g) + ba + 5.88e-4 * np.sqrt(imu_rate) * rng.standard_normal((n_imu, 3))
+    t_map = t_start + 0.05
+    e0 = sp.eval([t_map]); R0q, p0 = e0["quat"][0], e0["pos"][0]
+    nrm = rng.standard_normal((n_planes, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    Pi = nrm * rng.uniform(2.0, 12.0, n_planes)[:, None]
+    sid = rng.integers(0, n_planes, n_surfel)
+    t_s = np.sort(rng.uniform(t_map + 1e-3, t_end - 1e-3, n_surfel))
+    n_s = nrm[sid]
+    e1 = np.cross(n_s, np.array([0.3, -0.5, 0.8])); e1 /= np.linalg.norm(e1, axis=1, keepdims=True)
+    e2 = np.cross(n_s, e1)
+    pM = Pi[sid] + rng.uniform(-5, 5, (n_surfel, 1)) * e1 + rng.uniform(-5, 5, (n_surfel, 1)) * e2
+    ek = sp.eval(t_s)
+    pG = qrot(R0q, qrot(q_LI, pM) + p_LI) + p0
+    pt_s = qrot(qconj(q_LI), qrot(qconj(ek["quat"]), pG - ek["pos"]) - p_LI) + 0.02 * rng.standard_normal((n_surfel, 3))
+    # landmarks
+    n_landmarks = n_reproj // views_per_lm
+    row_d = cam["readout"] / cam["rows"]
+    t_frames = np.arange(t_start + 0.1, t_end - 0.2, 1.0 / cam_rate)
+    f0 = rng.integers(0, len(t_frames) - views_per_lm, n_landmarks)
+    lm_uv = np.stack([rng.uniform(100, cam["cols"] - 100, n_landmarks), rng.uniform(100, cam["rows"] - 100, n_landmarks)], axis=1)
+    z = rng.uniform(2.0, 15.0, n_landmarks)
+    lm_t0 = t_frames[f0]
+    er = sp.eval(lm_t0 + lm_uv[:, 1] * row_d)
+    qc = qmul(er["quat"], np.broadcast_to(q_CI, er["quat"].shape)); pc = qrot(er["quat"], p_CI) + er["pos"]
+    PW = qrot(qc, _unproject(cam, lm_uv) * z[:, None]) + pc
+    rep_lm = np.repeat(np.arange(n_landmarks, dtype=np.int32), views_per_lm)
+    fi = (f0[:, None] + np.arange(views_per_lm)[None, :]).ravel()
+    rep_t0 = t_frames[fi]
+    eo = sp.eval(rep_t0 + cam["cy"] * row_d)
+    qo = qmul(eo["quat"], np.broadcast_to(q_CI, eo["quat"].shape)); po = qrot(eo["quat"], p_CI) + eo["pos"]
+    Xc = qrot(qconj(qo), PW[rep_lm] - po)
+    Xc[:, 2] = np.maximum(Xc[:, 2], 0.5)
+    rep_uv = _project(cam, Xc) + 0.5 * rng.standard_normal((len(rep_lm), 2))
+    rep_uv[:, 0] = np.clip(rep_uv[:, 0], 0, cam["cols"] - 1); rep_uv[:, 1] = np.clip(rep_uv[:, 1], 0, cam["rows"] - 1)
+    first = np.arange(n_landmarks) * views_per_lm
+    rep_uv[first] = lm_uv
+    rho = 1.0 / z
+    state_true = pack_state(r3, so3, imu_block(roll, pitch, ba, bg), sensor_block(q_LI, p_LI), sensor_block(q_CI, p_CI), rho)
+    r3p = r3 + 1e-2 * rng.standard_normal(r3.shape)
+    so3p = qmul(q_from_rotvec(1e-2 * rng.standard_normal((n_knots, 3))), so3); so3p /= np.linalg.norm(so3p, axis=1, keepdims=True)
+    dqL = q_from_rotvec(np.deg2rad(3.0) * np.array([0.6, -0.5, 0.62])); dqC = q_from_rotvec(np.deg2rad(3.0) * np.array([-0.4, 0.7, 0.59]))
+    state0 = pack_state(r3p, so3p, imu_block(0.01, 0.01), sensor_block(qmul(dqL, q_LI), p_LI + 0.03), sensor_block(qmul(dqC, q_CI), p_CI - 0.03), rho)
+    return dict(t0=t0, dt=dt, n_knots=n_knots, camera=cam, t_imu=t_imu, gyro=gyro, acc=acc, w_gyro=28.0, w_acc=18.0,
+                planes=Pi, surf_pt=pt_s, surf_t=t_s, surf_plane=sid.astype(np.int32), t_map=t_map, huber_surf=5.0, w_surf=10.0,
+                n_landmarks=n_landmarks, lm_uv=lm_uv, lm_t0=lm_t0, rep_lm=rep_lm, rep_uv=rep_uv, rep_t0=rep_t0, huber_rep=5.0, w_rep=1.0,
+                cs_lm=np.zeros(0, dtype=np.int32), cs_plane=np.zeros(0, dtype=np.int32), huber_cs=5.0, w_cs=30.0,
+                state_true=state_true, state0=state0, t_start=t_start, t_end=t_end)

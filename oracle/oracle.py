@@ -1,0 +1,182 @@
+"""ctypes binding of the CPU oracle (oracle/liblvx_oracle.so).
+
+TEST INFRASTRUCTURE ONLY — PARITY UNPINNED (see oracle/orc_core.hpp).  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+FAM_GYRO, FAM_ACCEL, FAM_PRIOR, FAM_SURFEL, FAM_REPROJ, FAM_CAMSURF = range(6)
+
+LOCK_TRAJ = 1 << 0
+LOCK_R3 = 1 << 1
+LOCK_LIDAR_Q = 1 << 2
+LOCK_LIDAR_P = 1 << 3
+LOCK_LIDAR_TAU = 1 << 4
+LOCK_CAM_Q = 1 << 5
+LOCK_CAM_P = 1 << 6
+LOCK_CAM_TAU = 1 << 7
+LOCK_ACC_BIAS = 1 << 8
+LOCK_GYRO_BIAS = 1 << 9
+LOCK_LANDMARKS = 1 << 10
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liblvx_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".hpp"))]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_create.restype = C.c_void_p
+        for name in ("orc_state_size", "orc_tangent_size", "orc_num_residuals", "orc_num_blocks", "orc_max_cols"):
+            getattr(_LIB, name).restype = C.c_int
+    return _LIB
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    """Flat problem description -> residuals / Jacobians / normal equations on the CPU."""
+
+    def __init__(self):
+        self._l = lib()
+        self._h = C.c_void_p(self._l.orc_create())
+        self._keep = []
+
+    def __del__(self):
+        try:
+            self._l.orc_destroy(self._h)
+        except Exception:
+            pass
+
+    def set_spline(self, t0, dt, n_knots):
+        self._l.orc_set_spline(self._h, C.c_double(t0), C.c_double(dt), C.c_int(n_knots))
+
+    def set_camera(self, rows, cols, readout, fx, fy, cx, cy, k1=0.0, k2=0.0, p1=0.0, p2=0.0, k3=0.0):
+        self._l.orc_set_camera(self._h, C.c_int(rows), C.c_int(cols), *[C.c_double(v) for v in (readout, fx, fy, cx, cy, k1, k2, p1, p2, k3)])
+
+    def set_imu(self, t, gyro, acc, w_g, w_a):
+        t, gyro, acc = _d(t), _d(gyro), _d(acc)
+        self._l.orc_set_imu(self._h, C.c_int(len(t)), _p(t), _p(gyro), _p(acc), C.c_double(w_g), C.c_double(w_a))
+
+    def set_orientation_prior(self, t, q_wxyz, w, enable=True):
+        q = _d(q_wxyz)
+        self._l.orc_set_orientation_prior(self._h, C.c_int(1 if enable else 0), C.c_double(t), _p(q), C.c_double(w))
+
+    def set_planes(self, pi3):
+        pi3 = _d(pi3)
+        self._l.orc_set_planes(self._h, C.c_int(len(pi3)), _p(pi3))
+
+    def set_surfel(self, pt, t, plane_id, t_map, huber, w):
+        pt, t, plane_id = _d(pt), _d(t), _i(plane_id)
+        self._l.orc_set_surfel(self._h, C.c_int(len(t)), _p(pt), _p(t), _p(plane_id), C.c_double(t_map), C.c_double(huber), C.c_double(w))
+
+    def set_landmarks(self, uv_ref, t0_ref):
+        uv_ref, t0_ref = _d(uv_ref), _d(t0_ref)
+        self._l.orc_set_landmarks(self._h, C.c_int(len(t0_ref)), _p(uv_ref), _p(t0_ref))
+
+    def set_reproj(self, lm, uv_obs, t0_obs, huber, w):
+        lm, uv_obs, t0_obs = _i(lm), _d(uv_obs), _d(t0_obs)
+        self._l.orc_set_reproj(self._h, C.c_int(len(lm)), _p(lm), _p(uv_obs), _p(t0_obs), C.c_double(huber), C.c_double(w))
+
+    def set_camsurf(self, lm, plane_id, t_map, huber, w):
+        lm, plane_id = _i(lm), _i(plane_id)
+        self._l.orc_set_camsurf(self._h, C.c_int(len(lm)), _p(lm), _p(plane_id), C.c_double(t_map), C.c_double(huber), C.c_double(w))
+
+    def set_locks(self, mask):
+        self._l.orc_set_locks(self._h, C.c_uint32(mask))
+
+    def set_so3_only(self, flag):
+        self._l.orc_set_so3_only(self._h, C.c_int(1 if flag else 0))
+
+    def set_threads(self, n):
+        self._l.orc_set_threads(self._h, C.c_int(n))
+
+    @property
+    def state_size(self):
+        return self._l.orc_state_size(self._h)
+
+    @property
+    def tangent_size(self):
+        return self._l.orc_tangent_size(self._h)
+
+    @property
+    def num_residuals(self):
+        return self._l.orc_num_residuals(self._h)
+
+    @property
+    def num_blocks(self):
+        return self._l.orc_num_blocks(self._h)
+
+    def evaluate(self, state, jac=False, normal_eq=False):
+        """Returns dict(cost, residuals[, jac_cols, jac_vals][, H, g]); raises on range / non-unit errors."""
+        state = _d(state)
+        assert state.size == self.state_size
+        nr = self.num_residuals
+        mc = self._l.orc_max_cols()
+        cost = C.c_double(0)
+        res = np.zeros(nr)
+        jc = np.full((nr, mc), -1, dtype=np.int32) if jac else None
+        jv = np.zeros((nr, mc)) if jac else None
+        nt = self.tangent_size
+        H = np.zeros((nt, nt)) if normal_eq else None
+        g = np.zeros(nt) if normal_eq else None
+        rc = self._l.orc_evaluate(self._h, _p(state), C.byref(cost), _p(res), _p(jc), _p(jv), _p(H), _p(g))
+        if rc == -1:
+            raise IndexError("oracle: time span out of range for trajectory (std::range_error)")
+        if rc == -2:
+            raise ValueError("oracle: logq of a non-unit quaternion (std::runtime_error)")
+        out = {"cost": cost.value, "residuals": res}
+        if jac:
+            out["jac_cols"], out["jac_vals"] = jc, jv
+        if normal_eq:
+            out["H"], out["g"] = H, g
+        return out
+
+    def plus(self, state, delta):
+        state, delta = _d(state), _d(delta)
+        out = np.zeros_like(state)
+        self._l.orc_plus(self._h, _p(state), _p(delta), _p(out))
+        return out
+
+    def eval_pose(self, state, t):
+        state, t = _d(state), _d(np.atleast_1d(t))
+        n = len(t)
+        pos, quat, vel, acc, w = np.zeros((n, 3)), np.zeros((n, 4)), np.zeros((n, 3)), np.zeros((n, 3)), np.zeros((n, 3))
+        rc = self._l.orc_eval_pose(self._h, _p(state), C.c_int(n), _p(t), _p(pos), _p(quat), _p(vel), _p(acc), _p(w))
+        if rc:
+            raise IndexError("oracle: pose evaluation out of range")
+        return {"pos": pos, "quat": quat, "vel": vel, "acc": acc, "angvel": w}
+
+
+def dense_jacobian(jac_cols, jac_vals, n_tangent):
+    """Scatter the fixed-width (cols, vals) rows into a dense (rows, n_tangent) matrix."""
+    nr = jac_cols.shape[0]
+    J = np.zeros((nr, n_tangent))
+    rows = np.repeat(np.arange(nr), jac_cols.shape[1])
+    c = jac_cols.ravel()
+    m = c >= 0
+    np.add.at(J, (rows[m], c[m]), jac_vals.ravel()[m])
+    return J
