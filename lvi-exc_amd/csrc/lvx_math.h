@@ -1,0 +1,294 @@
+// lvx_math.h — split R3 + SO3 uniform cubic B-spline evaluation with ANALYTIC Jacobians.
+//
+// Device math of the MI355X evaluator (FP64).  The functions are __host__ __device__ only so that
+// tests/native can check them on the CPU against the oracle's dual numbers; the product library
+// (liblvx.so) only ever runs them inside HIP kernels.
+//
+// Reference behaviour restated (citations into /root/reference/src/lvi_exc/thirdparty/Kontiki/include/kontiki/):
+//   basis matrices                      trajectories/spline_base.h:19-29
+//   index / interpolation amount        trajectories/spline_base.h:153-157
+//   segment dispatch, t-1e-5 retry      trajectories/spline_base.h:194-222 (segment built at :398-424)
+//   R3 evaluation                       trajectories/uniform_r3_spline_trajectory.h:36-103
+//   SO3 cumulative evaluation           trajectories/uniform_so3_spline_trajectory.h:46-125
+//   logq / expq (eps = 1e-16)           math/quaternion_math.h:16-89
+// The reference differentiates with ceres::Jet; here derivatives are closed form on the group:
+// control point k is perturbed as c_k <- Exp(2 delta_k) (x) c_k, which is exactly
+// ceres::EigenQuaternionParameterization::Plus (delta is a half-angle vector, left-multiplied).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define LVX_HD __host__ __device__ __forceinline__
+#else
+#define LVX_HD inline
+#endif
+
+namespace lvx {
+
+struct v3 { double x, y, z; };
+struct quat { double x, y, z, w; };   // Eigen coefficient order
+struct m3 { double a[9]; };           // row-major
+
+LVX_HD v3 mk(double x, double y, double z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+LVX_HD v3 operator+(v3 a, v3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+LVX_HD v3 operator-(v3 a, v3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+LVX_HD v3 operator-(v3 a) { return mk(-a.x, -a.y, -a.z); }
+LVX_HD v3 operator*(double s, v3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+LVX_HD double dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+LVX_HD v3 cross(v3 a, v3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+LVX_HD double comp(v3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+LVX_HD quat mkq(double w, double x, double y, double z) { quat q; q.x = x; q.y = y; q.z = z; q.w = w; return q; }
+LVX_HD quat qconj(quat q) { return mkq(q.w, -q.x, -q.y, -q.z); }
+LVX_HD quat qmul(quat a, quat b) {  // Hamilton product, Eigen's scalar order
+  return mkq(a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z,
+             a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+             a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+             a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x);
+}
+LVX_HD v3 qrot(quat q, v3 v) {  // Eigen _transformVector
+  v3 qv = mk(q.x, q.y, q.z);
+  v3 uv = cross(qv, v);
+  uv = uv + uv;
+  return v + q.w * uv + cross(qv, uv);
+}
+LVX_HD v3 qrot_inv(quat q, v3 v) { return qrot(qconj(q), v); }
+
+LVX_HD m3 m3_identity() { m3 r; for (int i = 0; i < 9; ++i) r.a[i] = 0.0; r.a[0] = r.a[4] = r.a[8] = 1.0; return r; }
+LVX_HD m3 m3_zero() { m3 r; for (int i = 0; i < 9; ++i) r.a[i] = 0.0; return r; }
+LVX_HD m3 operator*(const m3& A, const m3& B) {
+  m3 r;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r.a[3 * i + j] = A.a[3 * i] * B.a[j] + A.a[3 * i + 1] * B.a[3 + j] + A.a[3 * i + 2] * B.a[6 + j];
+  return r;
+}
+LVX_HD m3 mul_t(const m3& A, const m3& B) {  // A * B^T
+  m3 r;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r.a[3 * i + j] = A.a[3 * i] * B.a[3 * j] + A.a[3 * i + 1] * B.a[3 * j + 1] + A.a[3 * i + 2] * B.a[3 * j + 2];
+  return r;
+}
+LVX_HD m3 tmul(const m3& A, const m3& B) {  // A^T * B
+  m3 r;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r.a[3 * i + j] = A.a[i] * B.a[j] + A.a[3 + i] * B.a[3 + j] + A.a[6 + i] * B.a[6 + j];
+  return r;
+}
+LVX_HD m3 operator+(const m3& A, const m3& B) { m3 r; for (int i = 0; i < 9; ++i) r.a[i] = A.a[i] + B.a[i]; return r; }
+LVX_HD m3 operator-(const m3& A, const m3& B) { m3 r; for (int i = 0; i < 9; ++i) r.a[i] = A.a[i] - B.a[i]; return r; }
+LVX_HD m3 operator*(double s, const m3& A) { m3 r; for (int i = 0; i < 9; ++i) r.a[i] = s * A.a[i]; return r; }
+LVX_HD m3 transpose(const m3& A) { m3 r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.a[3 * i + j] = A.a[3 * j + i]; return r; }
+LVX_HD v3 operator*(const m3& A, v3 v) {
+  return mk(A.a[0] * v.x + A.a[1] * v.y + A.a[2] * v.z, A.a[3] * v.x + A.a[4] * v.y + A.a[5] * v.z, A.a[6] * v.x + A.a[7] * v.y + A.a[8] * v.z);
+}
+LVX_HD v3 tmulv(const m3& A, v3 v) {  // A^T v  (== row vector v^T A, transposed)
+  return mk(A.a[0] * v.x + A.a[3] * v.y + A.a[6] * v.z, A.a[1] * v.x + A.a[4] * v.y + A.a[7] * v.z, A.a[2] * v.x + A.a[5] * v.y + A.a[8] * v.z);
+}
+LVX_HD m3 skew(v3 v) { m3 r; r.a[0] = 0; r.a[1] = -v.z; r.a[2] = v.y; r.a[3] = v.z; r.a[4] = 0; r.a[5] = -v.x; r.a[6] = -v.y; r.a[7] = v.x; r.a[8] = 0; return r; }
+// rotation matrix of a (unit) quaternion
+LVX_HD m3 rotmat(quat q) {
+  const double xx = q.x * q.x, yy = q.y * q.y, zz = q.z * q.z, xy = q.x * q.y, xz = q.x * q.z, yz = q.y * q.z, wx = q.w * q.x, wy = q.w * q.y, wz = q.w * q.z;
+  m3 r;
+  r.a[0] = 1.0 - 2.0 * (yy + zz); r.a[1] = 2.0 * (xy - wz); r.a[2] = 2.0 * (xz + wy);
+  r.a[3] = 2.0 * (xy + wz); r.a[4] = 1.0 - 2.0 * (xx + zz); r.a[5] = 2.0 * (yz - wx);
+  r.a[6] = 2.0 * (xz - wy); r.a[7] = 2.0 * (yz + wx); r.a[8] = 1.0 - 2.0 * (xx + yy);
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SO(3)/S^3 Jacobians for a rotation vector phi (angle th = |phi|, may reach (pi, 2pi) because the
+// reference's logq does no hemisphere handling: quaternion_math.h:46-52).
+//   Jr(phi)    = I - c1 [phi]x + c2 [phi]x^2,  c1 = (1-cos th)/th^2, c2 = (th - sin th)/th^3
+//   Jr^-1(phi) = I + 1/2 [phi]x + c3 [phi]x^2, c3 = 1/th^2 - (1+cos th)/(2 th sin th)
+// Series below |phi| < 0.05 (truncation < 1e-17).
+// ---------------------------------------------------------------------------------------------
+LVX_HD m3 so3_Jr(v3 phi) {
+  const double t2 = dot(phi, phi);
+  double c1, c2;
+  if (t2 < 2.5e-3) {
+    c1 = 0.5 - t2 * (1.0 / 24.0 - t2 * (1.0 / 720.0 - t2 / 40320.0));
+    c2 = 1.0 / 6.0 - t2 * (1.0 / 120.0 - t2 * (1.0 / 5040.0 - t2 / 362880.0));
+  } else {
+    const double th = sqrt(t2);
+    c1 = (1.0 - cos(th)) / t2;
+    c2 = (th - sin(th)) / (t2 * th);
+  }
+  const m3 K = skew(phi);
+  return m3_identity() - c1 * K + c2 * (K * K);
+}
+LVX_HD m3 so3_Jr_inv(v3 phi) {
+  const double t2 = dot(phi, phi);
+  double c3;
+  if (t2 < 2.5e-3) {
+    c3 = 1.0 / 12.0 + t2 * (1.0 / 720.0 + t2 * (1.0 / 30240.0 + t2 / 1209600.0));
+  } else {
+    const double th = sqrt(t2);
+    const double h = 0.5 * th;
+    c3 = 1.0 / t2 - cos(h) / (2.0 * th * sin(h));   // (1+cos th)/sin th = cot(th/2)
+  }
+  const m3 K = skew(phi);
+  return m3_identity() + 0.5 * K + c3 * (K * K);
+}
+
+// quaternion_math.h:16-59 — returns the half-angle vector Omega (pure quaternion part); *ok=false if non-unit
+LVX_HD v3 logq_half(quat q, bool* ok) {
+  const double qn = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  if (fabs(qn - 1.0) > 1e-5) *ok = false;
+  const double v2 = q.x * q.x + q.y * q.y + q.z * q.z;
+  double k;
+  if (v2 > 1e-16) { const double vn = sqrt(v2); k = atan2(vn, q.w) / vn; }
+  else k = 1.0;
+  return mk(q.x * k, q.y * k, q.z * k);
+}
+// quaternion_math.h:62-89 with a pure-quaternion argument (w = 0 => exp(w) = 1)
+LVX_HD quat expq_half(v3 v) {
+  const double v2 = v.x * v.x + v.y * v.y + v.z * v.z;
+  double ka, kv;
+  if (v2 > 1e-16) { const double vn = sqrt(v2); ka = cos(vn); kv = sin(vn) / vn; }
+  else { ka = 1.0; kv = 1.0; }
+  return mkq(ka, kv * v.x, kv * v.y, kv * v.z);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Knot lookup with the reference's segment semantics.  A residual's spline segment starts at the master
+// knot i1 = floor((t_span - t0)/dt) (spline_base.h:387-401) and has t0_seg = t0 + dt*i1; evaluation checks
+// t in [t0_seg, t0_seg + (n-3) dt) and otherwise retries t - 1e-5 (:196-203), then recomputes u against the
+// SEGMENT origin (:153-157).  n_seg = 4 for single-time spans.  Returns false on std::range_error.
+// ---------------------------------------------------------------------------------------------
+struct KnotRef { int i0; double u; };   // master index of the first of the four control points; interpolation amount
+
+LVX_HD bool knot_lookup_seg(double t0_seg, double dt, int n_seg, int i1, double t, KnotRef* out) {
+  const double tmin = t0_seg, tmax = t0_seg + (double)(n_seg - 3) * dt;
+  double te = t;
+  if (!((te >= tmin) && (te < tmax))) {
+    te = t - 0.00001;
+    if (!((te >= tmin) && (te < tmax))) return false;
+  }
+  const double s = (te - t0_seg) / dt;
+  const int il = (int)floor(s);
+  if ((n_seg < 4) || (il < 0) || (il > (n_seg - 4))) return false;
+  out->i0 = i1 + il;
+  out->u = s - (double)il;
+  return true;
+}
+// single-time span {{t_span, t_span}} evaluated at t_eval (= t_span + time offset): 4-knot segment
+LVX_HD bool knot_lookup(double t0, double dt, int n_knots, double t_span, double t_eval, KnotRef* out) {
+  const double tmax_master = t0 + (double)(n_knots - 3) * dt;
+  if (n_knots < 4 || t_span < t0 || t_span >= tmax_master) return false;   // CheckTimeSpans, trajectory_estimator.h:102-127
+  const int i1 = (int)floor((t_span - t0) / dt);
+  return knot_lookup_seg(t0 + dt * (double)i1, dt, 4, i1, t_eval, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// R3: basis weights (uniform_r3_spline_trajectory.h:51-94). p = sum B[j] c_j etc.; d(p)/d(c_j) = B[j] I.
+// ---------------------------------------------------------------------------------------------
+struct R3Basis { double Bp[4], Bv[4], Ba[4]; };
+LVX_HD void r3_basis(double u, double dt, R3Basis* b) {
+  const double u2 = u * u, u3 = u2 * u;
+  const double di = 1.0 / dt, di2 = di * di;
+  // [1 u u2 u3] * M,  M from spline_base.h:19-23
+  b->Bp[0] = 1.0 / 6.0 + u * (-3.0 / 6.0) + u2 * (3.0 / 6.0) + u3 * (-1.0 / 6.0);
+  b->Bp[1] = 4.0 / 6.0 + u2 * (-6.0 / 6.0) + u3 * (3.0 / 6.0);
+  b->Bp[2] = 1.0 / 6.0 + u * (3.0 / 6.0) + u2 * (3.0 / 6.0) + u3 * (-3.0 / 6.0);
+  b->Bp[3] = u3 * (1.0 / 6.0);
+  const double U1 = di, U2 = di * (2.0 * u), U3 = di * (3.0 * u2);
+  b->Bv[0] = U1 * (-3.0 / 6.0) + U2 * (3.0 / 6.0) + U3 * (-1.0 / 6.0);
+  b->Bv[1] = U2 * (-6.0 / 6.0) + U3 * (3.0 / 6.0);
+  b->Bv[2] = U1 * (3.0 / 6.0) + U2 * (3.0 / 6.0) + U3 * (-3.0 / 6.0);
+  b->Bv[3] = U3 * (1.0 / 6.0);
+  const double A2 = di2 * 2.0, A3 = di2 * (6.0 * u);
+  b->Ba[0] = A2 * (3.0 / 6.0) + A3 * (-1.0 / 6.0);
+  b->Ba[1] = A2 * (-6.0 / 6.0) + A3 * (3.0 / 6.0);
+  b->Ba[2] = A2 * (3.0 / 6.0) + A3 * (-3.0 / 6.0);
+  b->Ba[3] = A3 * (1.0 / 6.0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// SO3 cumulative spline: value + analytic Jacobians.
+//   q = c0 E1 E2 E3,  E_j = expq(B_j Omega_j),  Omega_j = logq(c_{j-1}^* c_j)        (:75-104)
+//   w_body = q^* (2 vec(qdot q^*)) q = R3^T R2^T dB1 d1 + R3^T dB2 d2 + dB3 d3,  d_j = 2 Omega_j  (:92-121)
+// Jacobians w.r.t. the ceres tangent delta_k of control point k (k = 0..3):
+//   q(delta) = q (x) Exp(xi),  xi = sum_k dxi[k] delta_k      (body-frame rotation-vector perturbation)
+//   w_body(delta) = w_body + sum_k dw[k] delta_k
+// ---------------------------------------------------------------------------------------------
+struct So3Eval {
+  quat q;
+  v3 w_body;
+  m3 dxi[4];
+  m3 dw[4];
+};
+
+template <bool NEED_W, bool NEED_J>
+LVX_HD bool so3_eval(const quat c[4], double u, double dt, So3Eval* out) {
+  const double u2 = u * u, u3 = u2 * u;
+  // [1 u u2 u3] * M_cumul (spline_base.h:25-29); B[0] = 1
+  double B[4], dB[4];
+  B[1] = 5.0 / 6.0 + u * (3.0 / 6.0) + u2 * (-3.0 / 6.0) + u3 * (1.0 / 6.0);
+  B[2] = 1.0 / 6.0 + u * (3.0 / 6.0) + u2 * (3.0 / 6.0) + u3 * (-2.0 / 6.0);
+  B[3] = u3 * (1.0 / 6.0);
+  if (NEED_W) {
+    const double di = 1.0 / dt;
+    const double U1 = di, U2 = di * (2.0 * u), U3 = di * (3.0 * u2);
+    dB[1] = U1 * (3.0 / 6.0) + U2 * (-3.0 / 6.0) + U3 * (1.0 / 6.0);
+    dB[2] = U1 * (3.0 / 6.0) + U2 * (3.0 / 6.0) + U3 * (-2.0 / 6.0);
+    dB[3] = U3 * (1.0 / 6.0);
+  }
+  bool ok = true;
+  v3 d[4];        // rotation vectors d_j = 2 Omega_j
+  quat E[4];
+  quat q = c[0];
+  for (int j = 1; j < 4; ++j) {
+    const v3 Om = logq_half(qmul(qconj(c[j - 1]), c[j]), &ok);
+    d[j] = 2.0 * Om;
+    E[j] = expq_half(B[j] * Om);
+    q = qmul(q, E[j]);
+  }
+  out->q = q;
+  if (!NEED_W && !NEED_J) return ok;
+  const m3 R2 = rotmat(E[2]), R3 = rotmat(E[3]);
+  v3 w1, w2r, w2, w3r;
+  if (NEED_W) {
+    w1 = dB[1] * d[1];
+    w2r = tmulv(R2, w1);            // R2^T w1
+    w2 = w2r + dB[2] * d[2];
+    w3r = tmulv(R3, w2);            // R3^T w2
+    out->w_body = w3r + dB[3] * d[3];
+  }
+  if (!NEED_J) return ok;
+  const m3 R1 = rotmat(E[1]);
+  m3 Jri[4], P[4];
+  for (int j = 1; j < 4; ++j) {
+    Jri[j] = so3_Jr_inv(d[j]);
+    P[j] = B[j] * so3_Jr(B[j] * d[j]);
+  }
+  const m3 R3t = transpose(R3);
+  const m3 R32t = tmul(R3, transpose(R2));      // R3^T R2^T
+  // coefficient of delta d_j in xi
+  const m3 T1 = R32t * P[1], T2 = R3t * P[2], T3 = P[3];
+  // d xi / d eta_k  (eta_k: right perturbation of control point k)
+  m3 Xe[4];
+  Xe[0] = tmul(R1 * (R2 * R3), m3_identity()) - mul_t(T1, Jri[1]);
+  Xe[1] = T1 * Jri[1] - mul_t(T2, Jri[2]);
+  Xe[2] = T2 * Jri[2] - mul_t(T3, Jri[3]);
+  Xe[3] = T3 * Jri[3];
+  m3 We[4];
+  if (NEED_W) {
+    const m3 W1 = dB[1] * R32t;
+    const m3 W2 = R3t * (skew(w2r) * P[2] + dB[2] * m3_identity());
+    const m3 W3 = skew(w3r) * P[3] + dB[3] * m3_identity();
+    We[0] = -1.0 * mul_t(W1, Jri[1]);
+    We[1] = W1 * Jri[1] - mul_t(W2, Jri[2]);
+    We[2] = W2 * Jri[2] - mul_t(W3, Jri[3]);
+    We[3] = W3 * Jri[3];
+  }
+  // eta_k = R(c_k)^T (2 delta_k)
+  for (int k = 0; k < 4; ++k) {
+    const m3 Rk = rotmat(c[k]);
+    out->dxi[k] = 2.0 * mul_t(Xe[k], Rk);
+    if (NEED_W) out->dw[k] = 2.0 * mul_t(We[k], Rk);
+  }
+  return ok;
+}
+
+}  // namespace lvx
