@@ -1,0 +1,149 @@
+/* lvx.h — C ABI of the MI355X-native evaluator for LVI-ExC's continuous-time calibration solve.
+ *
+ * Drop-in boundary.  The reference has no FFI layer; its seam is the Ceres cost-functor surface that every
+ * Kontiki measurement builds in AddToEstimator and that ceres::Solve drives per residual block
+ * (reference: src/lvi_exc/thirdparty/Kontiki/include/kontiki/trajectory_estimator.h:38-74).  A per-block FFI
+ * would serialise the GPU, so this ABI is BATCHED: the host hands over whole measurement arrays once
+ * (lvx_set_*: what TrajectoryManagerLVI::add*Measurement loops build, src/lvi_exc/src/core/trajectory_manager_lvi.cpp:464-606)
+ * and then asks for one evaluation of all residual blocks + Jacobians + J^T J / J^T r per iterate
+ * (lvx_evaluate: what ceres::Problem::Evaluate does through DynamicAutoDiffCostFunction::Evaluate).
+ * INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions: every pointer is a HOST pointer unless the name ends in _d; the caller owns host buffers,
+ * the context owns device buffers; a context is bound to one GPU and is not thread-safe; no exceptions
+ * cross the ABI — the reference's std::range_error / std::runtime_error become LVX_E_RANGE / LVX_E_NONUNIT_QUAT.
+ * All arithmetic is FP64.  Quaternions are stored (x, y, z, w) like Eigen::Map<Quaternion>
+ * (kontiki/trajectories/spline_base.h:118-127, kontiki/sensors/sensors.h:36-43).
+ *
+ * STATE vector (flat doubles), n = n_knots, L = n_landmarks:
+ *   r3_cp[n][3] | so3_cp[n][4] | imu{q4,p3,tau,roll,pitch,b_a3,b_g3} (16) | lidar{q4,p3,tau} (8) | cam{q4,p3,tau} (8) | rho[L]
+ * TANGENT vector (what delta / gradient / normal equations are expressed in):
+ *   knot k: 6k..6k+2 position, 6k+3..6k+5 rotation (ceres::EigenQuaternionParameterization delta)
+ *   | 6n + {0 roll, 1 pitch, 2..4 b_a, 5..7 b_g, 8..10 lidar theta, 11..13 lidar p, 14 lidar tau,
+ *           15..17 cam theta, 18..20 cam p, 21 cam tau} | 6n + 22 + l : rho_l
+ */
+#ifndef LVX_H
+#define LVX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lvx_ctx lvx_ctx;
+
+/* error codes (0 = success) */
+#define LVX_OK 0
+#define LVX_E_RANGE (-1)         /* std::range_error: time outside the spline / unordered spans (spline_base.h:207-221, trajectory_estimator.h:102-127) */
+#define LVX_E_NONUNIT_QUAT (-2)  /* std::runtime_error in logq (kontiki/math/quaternion_math.h:19-23) */
+#define LVX_E_ALLOC (-3)
+#define LVX_E_HIP (-4)
+#define LVX_E_RCCL (-5)
+#define LVX_E_ARG (-6)
+#define LVX_E_STATE (-7)         /* call order (e.g. evaluate before set_spline) */
+#define LVX_E_NODEVICE (-8)      /* no HIP device: the product path never falls back to the CPU */
+#define LVX_E_NOTPD (-9)         /* damped normal equations not positive definite */
+
+/* lock mask: mirrors Lock / IsLocked flags (kontiki/sensors/sensors.h:113-135, kontiki/trajectories/trajectory.h:149-155,
+ * kontiki/sensors/constant_bias_imu.h:68-81, kontiki/sfm/landmark.h Lock).  IMU q_rel/p_rel/tau are always constant, as in the reference. */
+#define LVX_LOCK_TRAJ (1u << 0)
+#define LVX_LOCK_R3 (1u << 1)        /* R3 spline absent: TrajectoryEstimator<UniformSO3SplineTrajectory> of Solve #0 */
+#define LVX_LOCK_LIDAR_Q (1u << 2)
+#define LVX_LOCK_LIDAR_P (1u << 3)
+#define LVX_LOCK_LIDAR_TAU (1u << 4)
+#define LVX_LOCK_CAM_Q (1u << 5)
+#define LVX_LOCK_CAM_P (1u << 6)
+#define LVX_LOCK_CAM_TAU (1u << 7)
+#define LVX_LOCK_ACC_BIAS (1u << 8)
+#define LVX_LOCK_GYRO_BIAS (1u << 9)
+#define LVX_LOCK_LANDMARKS (1u << 10)
+
+/* lvx_evaluate `what` bits */
+#define LVX_EVAL_COST (1u << 0)
+#define LVX_EVAL_RESIDUALS (1u << 1)
+#define LVX_EVAL_NORMAL_EQ (1u << 2)
+#define LVX_EVAL_JACOBIAN (1u << 3)   /* debug: per-row (cols, vals) in tangent coordinates, see lvx_get_jacobian */
+
+/* residual families, in the order residual rows are laid out */
+#define LVX_FAM_GYRO 0
+#define LVX_FAM_ACCEL 1
+#define LVX_FAM_PRIOR 2
+#define LVX_FAM_SURFEL 3
+#define LVX_FAM_REPROJ 4
+#define LVX_FAM_CAMSURF 5
+#define LVX_NUM_FAM 6
+
+#define LVX_JAC_WIDTH 64   /* columns per row of the debug Jacobian */
+
+/* PinholeMeta (kontiki/sensors/pinhole_camera.h:20-41) + CameraMeta (kontiki/sensors/camera.h:25-29) */
+typedef struct lvx_pinhole {
+  int32_t rows, cols;
+  double readout;
+  double fx, fy, cx, cy;
+  double k1, k2, p1, p2, k3;
+} lvx_pinhole;
+
+/* layout of the structured normal equations kept on the device */
+typedef struct lvx_layout {
+  int32_t n_knots, n_landmarks, n_tangent;
+  int32_t n_band;      /* variables in the banded part (non-hub knots interleaved with landmarks) */
+  int32_t bandwidth;   /* scalar half-bandwidth of the banded part */
+  int32_t n_border;    /* dense border: hub knots (6 each) then the 22 calibration scalars */
+  int32_t n_hub_knots, hub_knot0;
+  int64_t n_blocks;    /* residual blocks per evaluation */
+  int64_t n_residuals; /* residual rows per evaluation */
+} lvx_layout;
+
+/* lifetime ------------------------------------------------------------------------------------------------*/
+int lvx_create(lvx_ctx** out, int device, uint32_t flags);
+void lvx_destroy(lvx_ctx* ctx);
+const char* lvx_version(void);
+const char* lvx_last_error(const lvx_ctx* ctx);
+
+/* problem description ---------------------------------------------------------------------------------------*/
+/* SplineSegmentMeta of both splines (kontiki/trajectories/spline_base.h:31-39; split_trajectory.h:76-82: same dt, t0) */
+int lvx_set_spline(lvx_ctx* ctx, double t0, double dt, int n_knots);
+int lvx_set_camera(lvx_ctx* ctx, const lvx_pinhole* cam);
+/* IO::IMUData stream (src/lvi_exc/include/utils/dataset_reader.h:45-50): one gyro block and one accel block per sample
+ * (trajectory_manager_lvi.cpp:464-503); weights = CalibParamManager::global_opt_{gyro,acce}_weight */
+int lvx_set_imu(lvx_ctx* ctx, int n, const double* t, const double* gyro3, const double* acc3, double w_gyro, double w_acc);
+/* OrientationMeasurement of initialSO3TrajWithGyro (trajectory_manager_lvi.cpp:52-58); q as (w, x, y, z); enable = 0 removes it */
+int lvx_set_orientation_prior(lvx_ctx* ctx, int enable, double t, const double* q_wxyz, double weight);
+/* closest-point plane parameters Pi[3] of SurfelAssociation::get_surfel_planes() (trajectory_manager_lvi.cpp:567-569) */
+int lvx_set_planes(lvx_ctx* ctx, int n_planes, const double* plane_pi3);
+/* SurfelPoint list (src/lvi_exc/include/core/surfel_association.h:41-46) -> LiDARSurfelPoint blocks (trajectory_manager_lvi.cpp:571-581) */
+int lvx_set_surfel(lvx_ctx* ctx, int n, const double* pt3, const double* t, const int32_t* plane_id, double t_map, double huber, double weight);
+/* sfm::Landmark table: reference observation uv and its view's t0 (kontiki/sfm/landmark.h:50-53, observation.h:35-37, view.h:34-35);
+ * inverse depths live in the state vector */
+int lvx_set_landmarks(lvx_ctx* ctx, int n_landmarks, const double* uv_ref2, const double* t0_ref);
+/* StaticRsCameraMeasurement blocks (trajectory_manager_lvi.cpp:505-531): huber = w_cam, weight = 1 reproduces the reference's argument swap */
+int lvx_set_reproj(lvx_ctx* ctx, int n, const int32_t* landmark_id, const double* uv_obs2, const double* t0_obs, double huber, double weight);
+/* CameraSurfelLandmark blocks (trajectory_manager_lvi.cpp:584-606) */
+int lvx_set_camsurf(lvx_ctx* ctx, int n, const int32_t* landmark_id, const int32_t* plane_id, double t_map, double huber, double weight);
+int lvx_set_locks(lvx_ctx* ctx, uint32_t lock_mask);
+/* max |time offset| bounds used to widen spans when a time offset is free (sensors.h:161-162; trajectory_manager_lvi.h:118-119) */
+int lvx_set_time_offset_bounds(lvx_ctx* ctx, double imu_max, double sensor_max);
+
+int lvx_state_size(const lvx_ctx* ctx);
+int lvx_tangent_size(const lvx_ctx* ctx);
+int lvx_get_layout(lvx_ctx* ctx, lvx_layout* out);
+
+/* evaluation -------------------------------------------------------------------------------------------------*/
+/* One pass over every residual block at `state`: cost = sum 1/2 rho(|r|^2) (HuberLoss where the reference attaches one),
+ * raw weighted residuals (family-major, input order inside a family), and — for LVX_EVAL_NORMAL_EQ — the robustified
+ * J^T J and J^T r in tangent coordinates, left on the device in the structured layout.  residuals may be NULL. */
+int lvx_evaluate(lvx_ctx* ctx, const double* state, uint32_t what, double* cost, double* residuals);
+/* same, state already resident on the device; nothing is copied back except *cost (if not NULL) */
+int lvx_evaluate_d(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cost);
+/* debug / parity: expand the structured normal equations into dense host arrays (n_tangent^2 and n_tangent); small problems only */
+int lvx_get_normal_eq_dense(lvx_ctx* ctx, double* H, double* g);
+/* debug / parity: rows of the last LVX_EVAL_JACOBIAN evaluation: cols[n_residuals][LVX_JAC_WIDTH] (-1 = unused), vals likewise (pre-loss) */
+int lvx_get_jacobian(lvx_ctx* ctx, int32_t* cols, double* vals);
+/* x (+) delta with ceres::EigenQuaternionParameterization::Plus on quaternion blocks */
+int lvx_plus(lvx_ctx* ctx, const double* state, const double* delta, double* state_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LVX_H */

@@ -1,0 +1,100 @@
+// lvx_ctx.h — context shared by the translation units of liblvx.so (evaluator, solver, upstream kernels).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/lvx.h"
+#include "lvx_resid.h"
+
+#define LVX_NREP 64                 // replicas of the dense border accumulators (spreads same-address atomics)
+#define LVX_DEAD (-2147483647 - 1)  // ord[] value of a constant (locked) tangent scalar
+
+namespace lvx {
+
+// device view handed to every kernel
+struct DevCommon {
+  const double* state;
+  int N, L;
+  double t0, dt;
+  uint32_t locks;
+  uint32_t what;
+  double imu_mto, sensor_mto;
+  CamIntr cam;
+  // layout
+  const int* ord;
+  int nb, bw, nbd;
+  double* Hb;    // [nb][bw+1] lower band, column-major by column
+  double* gb;    // [nb]
+  double* Bd;    // [nbd][nb]
+  double* C;     // [LVX_NREP][nbd*nbd] (lower triangle used)
+  double* gc;    // [LVX_NREP][nbd]
+  double* cost;  // [LVX_NREP]
+  int* err;      // bit0 range, bit1 non-unit quaternion, bit2 band overflow
+  // outputs (may be null)
+  double* residuals;
+  int32_t* jcols;
+  double* jvals;
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct Family {
+  int n = 0;
+  // host copies (original order)
+  std::vector<double> t, a3, b3;        // imu: t, gyro, acc | surfel: t, pt | reproj: t0_obs, uv_obs(2)
+  std::vector<int32_t> id0, id1;        // surfel: plane | reproj: landmark | camsurf: landmark, plane
+  double huber = 0, weight = 1;
+  // device (sorted by key)
+  DevBuf d_t, d_a3, d_b3, d_id0, d_id1, d_perm;
+};
+
+}  // namespace lvx
+
+struct lvx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string last_error;
+  // problem
+  bool have_spline = false;
+  double t0 = 0, dt = 1;
+  int N = 0, L = 0;
+  uint32_t locks = LVX_LOCK_LIDAR_TAU | LVX_LOCK_CAM_TAU;
+  double imu_mto = 0.01, sensor_mto = 0.001;
+  lvx::CamIntr cam{};
+  lvx::Family imu, surf, rep, cs;
+  bool has_prior = false;
+  double prior_t = 0, prior_q[4] = {1, 0, 0, 0}, prior_w = 1;
+  double t_map = 0;
+  std::vector<double> planes, lm_uv, lm_t0;
+  lvx::DevBuf d_planes, d_lm_uv, d_lm_t0;
+  // layout
+  bool layout_dirty = true;
+  std::vector<int> ord;
+  int nb = 0, bw = 0, nbd = 0, n_hub = 0, hub0 = 0;
+  lvx::DevBuf d_ord, d_Hb, d_gb, d_Bd, d_C, d_gc, d_cost, d_err, d_state, d_res, d_jcols, d_jvals, d_pairs[LVX_NUM_FAM];
+  // solver workspace (lvx_solver.hip)
+  lvx::DevBuf d_L, d_Y, d_S, d_delta, d_diag, d_scal, d_state_try, d_zero;
+  int64_t n_blocks = 0, n_residuals = 0;
+  int64_t fam_row0[LVX_NUM_FAM + 1] = {0};
+  uint32_t last_what = 0;
+};
+
+namespace lvx {
+int fail(lvx_ctx* ctx, int code, const std::string& msg);
+int dev_alloc(lvx_ctx* ctx, DevBuf& b, size_t bytes);
+int upload(lvx_ctx* ctx, DevBuf& b, const void* src, size_t bytes);
+int ensure_layout(lvx_ctx* ctx);
+DevCommon make_common(lvx_ctx* ctx, const double* state_d, uint32_t what);
+}  // namespace lvx
+
+#define LVX_HIP(ctx, expr)                                                                  \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) return lvx::fail(ctx, LVX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)

@@ -1,0 +1,770 @@
+// lvx_eval.hip — fused residual + analytic Jacobian + J^T J / J^T r assembly kernels (gfx950, FP64) and the
+// evaluation half of the C ABI (include/lvx.h).
+//
+// One generic kernel serves every residual family.  A workgroup is ONE wavefront (64 lanes):
+//   phase 1  lane = measurement (arrays pre-sorted by knot interval, coalesced loads): residual + local Jacobian
+//            rows in registers (lvx_resid.h), Huber scaling, rows transposed into an LDS tile Jt[col][row];
+//   phase 2  lane = (column pair): for every run of lanes that share the same active control points (a
+//            "segment": same knot interval => same 4 control points), sum_r J[r][a] J[r][b] from LDS and ONE
+//            f64 atomic per entry into the structured normal equations (band / border rows / dense border).
+// The reference does this with one DynamicAutoDiffCostFunction::Evaluate per block on CPU threads and Ceres'
+// block-sparse J^T J (kontiki/trajectory_estimator.h:38-68).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include "lvx_ctx.h"
+
+namespace lvx {
+
+struct Keys { int k0, k1, lm; };
+LVX_HD bool same(const Keys& a, const Keys& b) { return a.k0 == b.k0 && a.k1 == b.k1 && a.lm == b.lm; }
+
+struct Cal { ImuCal imu; SensorCal lidar, cam; const double* rho; };
+__device__ __forceinline__ Cal load_cal(const DevCommon& cm) {
+  const double* s = cm.state + 7 * (size_t)cm.N;
+  Cal c;
+  c.imu.tau = s[7]; c.imu.roll = s[8]; c.imu.pitch = s[9]; c.imu.ba = load_v3(s + 10); c.imu.bg = load_v3(s + 13);
+  c.lidar.q = load_q(s + 16); c.lidar.p = load_v3(s + 20); c.lidar.tau = s[23];
+  c.cam.q = load_q(s + 24); c.cam.p = load_v3(s + 28); c.cam.tau = s[31];
+  c.rho = s + 32;
+  return c;
+}
+
+struct HubShared { PoseEval A; int ok; };
+
+// ---------------------------------------------------------------------------------------------------------
+// family policies
+// ---------------------------------------------------------------------------------------------------------
+struct GyroFam {
+  enum { NC = GYRO_NC, NR = GYRO_NR, USES_HUB = 0 };
+  int n; const double* t; const double* m3; const int* perm; double weight, huber;
+  __device__ void make_hub(const DevCommon&, const SplineRef&, const Cal&, HubShared*) const {}
+  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared&, int si, double r[NR], double (*J)[NC], Keys& k) const {
+    k.k1 = 0; k.lm = 0;
+    return gyro_residual<true>(sp, cal.imu, t[si], load_v3(m3 + 3 * (size_t)si), weight, &k.k0, r, J);
+  }
+  __device__ int col(int c, const Keys& k, int N) const { return gyro_col(c, k.k0, N); }
+};
+struct AccelFam {
+  enum { NC = ACC_NC, NR = ACC_NR, USES_HUB = 0 };
+  int n; const double* t; const double* m3; const int* perm; double weight, huber;
+  __device__ void make_hub(const DevCommon&, const SplineRef&, const Cal&, HubShared*) const {}
+  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared&, int si, double r[NR], double (*J)[NC], Keys& k) const {
+    k.k1 = 0; k.lm = 0;
+    return accel_residual<true>(sp, cal.imu, t[si], load_v3(m3 + 3 * (size_t)si), weight, &k.k0, r, J);
+  }
+  __device__ int col(int c, const Keys& k, int N) const { return acc_col(c, k.k0, N); }
+};
+struct PriorFam {
+  enum { NC = PRI_NC, NR = PRI_NR, USES_HUB = 0 };
+  int n; double t; quat q; const int* perm; double weight, huber;
+  __device__ void make_hub(const DevCommon&, const SplineRef&, const Cal&, HubShared*) const {}
+  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal&, const HubShared&, int, double r[NR], double (*J)[NC], Keys& k) const {
+    k.k1 = 0; k.lm = 0;
+    return prior_residual<true>(sp, t, q, weight, &k.k0, r, J);
+  }
+  __device__ int col(int c, const Keys& k, int N) const { return pri_col(c, k.k0, N); }
+};
+
+LVX_HD void hub_spans(double t_map, bool tau_locked, double mto, double sp1[1][2]) {
+  if (tau_locked) { sp1[0][0] = t_map; sp1[0][1] = t_map; } else { sp1[0][0] = t_map - mto; sp1[0][1] = t_map + mto; }
+}
+
+struct SurfFam {
+  enum { NC = SURF_NC, NR = SURF_NR, USES_HUB = 1 };
+  int n; const double* t; const double* pt; const int* plane; const int* perm; const double* planes; double t_map, weight, huber;
+  __device__ void make_hub(const DevCommon& cm, const SplineRef& sp, const Cal& cal, HubShared* h) const {
+    double s1[1][2]; hub_spans(t_map, (cm.locks & LVX_LOCK_LIDAR_TAU) != 0, cm.sensor_mto, s1);
+    Segs sg; KnotRef kh; h->ok = 0;
+    if (!build_segments(sp, s1, 1, &sg)) return;
+    if (!seg_lookup(sp, sg, t_map + cal.lidar.tau, &kh)) return;
+    if (!pose_eval<true>(sp, kh, &h->A)) { h->ok = -RES_NONUNIT; return; }
+    h->ok = 1;
+  }
+  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared& hub, int si, double r[NR], double (*J)[NC], Keys& k) const {
+    const bool tl = (cm.locks & LVX_LOCK_LIDAR_TAU) != 0;
+    const double tk = t[si];
+    const double pad = tl ? 0.0 : cm.sensor_mto;
+    const double spans[2][2] = {{t_map - pad, t_map + pad}, {tk - pad, tk + pad}};
+    Segs segs;
+    if (!build_segments(sp, spans, 2, &segs)) return RES_RANGE;
+    KnotRef kh;
+    if (!seg_lookup(sp, segs, t_map + cal.lidar.tau, &kh)) return RES_RANGE;
+    const PoseEval* hp = &hub.A;
+    PoseEval own;
+    if (hub.ok != 1 || kh.i0 != hub.A.k.i0 || kh.u != hub.A.k.u) {   // merged-segment corner (spline_base.h:196-203)
+      if (!pose_eval<true>(sp, kh, &own)) return RES_NONUNIT;
+      hp = &own;
+    }
+    k.k0 = kh.i0; k.lm = 0;
+    const int pid = plane[si];
+    return surfel_residual<true>(sp, *hp, segs, cal.lidar, tk, load_v3(pt + 3 * (size_t)si), load_v3(planes + 3 * (size_t)pid), weight, &k.k1, r, J);
+  }
+  __device__ int col(int c, const Keys& k, int N) const { return surf_col(c, k.k0, k.k1, N); }
+};
+struct CamSurfFam {
+  enum { NC = CS_NC, NR = CS_NR, USES_HUB = 1 };
+  int n; const int* lm; const int* plane; const int* perm; const double* planes; const double* lm_uv; const double* lm_t0; double t_map, weight, huber;
+  __device__ void make_hub(const DevCommon& cm, const SplineRef& sp, const Cal& cal, HubShared* h) const {
+    double s1[1][2]; hub_spans(t_map, (cm.locks & LVX_LOCK_CAM_TAU) != 0, cm.sensor_mto, s1);
+    Segs sg; KnotRef kh; h->ok = 0;
+    if (!build_segments(sp, s1, 1, &sg)) return;
+    if (!seg_lookup(sp, sg, t_map + cal.cam.tau, &kh)) return;
+    if (!pose_eval<true>(sp, kh, &h->A)) { h->ok = -RES_NONUNIT; return; }
+    h->ok = 1;
+  }
+  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared& hub, int si, double r[NR], double (*J)[NC], Keys& k) const {
+    const bool tl = (cm.locks & LVX_LOCK_CAM_TAU) != 0;
+    const int l = lm[si];
+    const double tk = lm_t0[l];
+    const double pad = tl ? 0.0 : cm.sensor_mto;
+    const double spans[2][2] = {{t_map - pad, t_map + pad}, {tk - pad, tk + pad}};
+    Segs segs;
+    if (!build_segments(sp, spans, 2, &segs)) return RES_RANGE;
+    KnotRef kh;
+    if (!seg_lookup(sp, segs, t_map + cal.cam.tau, &kh)) return RES_RANGE;
+    const PoseEval* hp = &hub.A;
+    PoseEval own;
+    if (hub.ok != 1 || kh.i0 != hub.A.k.i0 || kh.u != hub.A.k.u) {
+      if (!pose_eval<true>(sp, kh, &own)) return RES_NONUNIT;
+      hp = &own;
+    }
+    k.k0 = kh.i0; k.lm = 0;
+    return camsurf_residual<true>(sp, *hp, segs, cm.cam, cal.cam, cal.lidar, lm_uv[2 * l], lm_uv[2 * l + 1], tk, cal.rho[l],
+                                  load_v3(planes + 3 * (size_t)plane[si]), weight, &k.k1, r, J);
+  }
+  __device__ int col(int c, const Keys& k, int N) const { return cs_col(c, k.k0, k.k1, N); }
+};
+struct ReprojFam {
+  enum { NC = REP_NC, NR = REP_NR, USES_HUB = 0 };
+  int n; const int* lm; const double* uv; const double* t0o; const int* perm; const double* lm_uv; const double* lm_t0; double weight, huber;
+  __device__ void make_hub(const DevCommon&, const SplineRef&, const Cal&, HubShared*) const {}
+  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared&, int si, double r[NR], double (*J)[NC], Keys& k) const {
+    const int l = lm[si];
+    k.lm = l;
+    return reproj_residual<true>(sp, cm.cam, cal.cam, (cm.locks & LVX_LOCK_CAM_TAU) != 0, cm.sensor_mto, lm_uv[2 * l], lm_uv[2 * l + 1], lm_t0[l],
+                                 uv[2 * (size_t)si], uv[2 * (size_t)si + 1], t0o[si], cal.rho[l], weight, &k.k0, &k.k1, r, J);
+  }
+  __device__ int col(int c, const Keys& k, int N) const { return rep_col(c, k.k0, k.k1, N, k.lm); }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// routing of one normal-equation entry into the structured storage
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void add_H(const DevCommon& cm, int pa, int pb, double v, int rep) {
+  if (pa >= 0 && pb >= 0) {
+    const int i = pa > pb ? pa : pb, j = pa > pb ? pb : pa, d = i - j;
+    if (d > cm.bw) { atomicOr(cm.err, 4); return; }
+    atomicAdd(&cm.Hb[(size_t)j * (cm.bw + 1) + d], v);
+  } else if (pa < 0 && pb < 0) {
+    const int ba = -1 - pa, bb = -1 - pb;
+    const int i = ba > bb ? ba : bb, j = ba > bb ? bb : ba;
+    atomicAdd(&cm.C[(size_t)rep * cm.nbd * cm.nbd + (size_t)i * cm.nbd + j], v);
+  } else {
+    const int b = pa < 0 ? -1 - pa : -1 - pb, p = pa < 0 ? pb : pa;
+    atomicAdd(&cm.Bd[(size_t)b * cm.nb + p], v);
+  }
+}
+__device__ __forceinline__ void add_g(const DevCommon& cm, int pc, double v, int rep) {
+  if (pc >= 0) atomicAdd(&cm.gb[pc], v);
+  else atomicAdd(&cm.gc[(size_t)rep * cm.nbd + (-1 - pc)], v);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <class F>
+__global__ __launch_bounds__(64) void k_family(F fam, DevCommon cm, const uint16_t* __restrict__ pairs, long long row0) {
+  constexpr int NC = F::NC, NR = F::NR, TS = NR * 64 + 1, NP = NC * (NC + 1) / 2;
+  __shared__ double Jt[NC * TS];
+  __shared__ double rs[NR * 64];
+  __shared__ int cpos[NC];
+  __shared__ HubShared hub;
+  const int lane = threadIdx.x;
+  const int si = blockIdx.x * 64 + lane;
+  const bool in = si < fam.n;
+  const SplineRef sp{cm.t0, cm.dt, cm.N, cm.state, cm.state + 3 * (size_t)cm.N};
+  const Cal cal = load_cal(cm);
+  if (F::USES_HUB) {
+    if (lane == 0) fam.make_hub(cm, sp, cal, &hub);
+    __syncthreads();
+  }
+  double r[NR];
+  double J[NR][NC];
+  Keys key{-1, -1, -1};
+  bool valid = false;
+  if (in) {
+    const int status = fam.eval(cm, sp, cal, hub, si, r, J, key);
+    valid = status == RES_OK;
+    if (!valid) { atomicOr(cm.err, status); key = Keys{-1, -1, -1}; }
+  }
+  double mycost = 0.0;
+  if (valid) {
+    double s = 0.0;
+#pragma unroll
+    for (int a = 0; a < NR; ++a) s += r[a] * r[a];
+    double scale;
+    mycost = 0.5 * huber_rho(fam.huber, s, &scale);
+    const long long orow = row0 + (long long)fam.perm[si] * NR;
+    if (cm.residuals) {
+#pragma unroll
+      for (int a = 0; a < NR; ++a) cm.residuals[orow + a] = r[a];
+    }
+    if (cm.jcols) {
+#pragma unroll
+      for (int a = 0; a < NR; ++a) {
+        int32_t* jc = cm.jcols + (orow + a) * LVX_JAC_WIDTH;
+        double* jv = cm.jvals + (orow + a) * LVX_JAC_WIDTH;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const int g = fam.col(c, key, cm.N);
+          const bool dead = tangent_locked(g, cm.N, cm.L, cm.locks);
+          jc[c] = dead ? -1 : g;
+          jv[c] = dead ? 0.0 : J[a][c];
+        }
+        for (int c = NC; c < LVX_JAC_WIDTH; ++c) { jc[c] = -1; jv[c] = 0.0; }
+      }
+    }
+    if (scale != 1.0) {
+#pragma unroll
+      for (int a = 0; a < NR; ++a) {
+        r[a] *= scale;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) J[a][c] *= scale;
+      }
+    }
+  }
+  mycost = wave_sum(mycost);
+  if (lane == 0) atomicAdd(&cm.cost[blockIdx.x % LVX_NREP], mycost);
+  if (!(cm.what & LVX_EVAL_NORMAL_EQ)) return;
+#pragma unroll
+  for (int a = 0; a < NR; ++a) {
+    rs[lane * NR + a] = valid ? r[a] : 0.0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) Jt[c * TS + lane * NR + a] = valid ? J[a][c] : 0.0;
+  }
+  __syncthreads();
+  // segment heads: first lane of every run of equal keys
+  Keys pk;
+  pk.k0 = __shfl_up(key.k0, 1); pk.k1 = __shfl_up(key.k1, 1); pk.lm = __shfl_up(key.lm, 1);
+  const bool head = (lane == 0) || !same(pk, key);
+  unsigned long long heads = __ballot(head);
+  const int rep = blockIdx.x % LVX_NREP;
+  while (heads) {
+    const int l0 = __ffsll((long long)heads) - 1;
+    heads &= heads - 1;
+    const int l1 = heads ? (__ffsll((long long)heads) - 1) : 64;
+    Keys sk;
+    sk.k0 = __shfl(key.k0, l0); sk.k1 = __shfl(key.k1, l0); sk.lm = __shfl(key.lm, l0);
+    const int sv = __shfl((int)valid, l0);
+    if (!sv) continue;
+    if (lane < NC) cpos[lane] = cm.ord[fam.col(lane, sk, cm.N)];
+    __syncthreads();
+    const int rb = l0 * NR, re = l1 * NR;
+    for (int p = lane; p < NP + NC; p += 64) {
+      if (p < NP) {
+        const unsigned ab = pairs[p];
+        const int a = ab & 0xff, b = ab >> 8;
+        const int pa = cpos[a], pb = cpos[b];
+        if (pa == LVX_DEAD || pb == LVX_DEAD) continue;
+        const double* ja = &Jt[a * TS];
+        const double* jb = &Jt[b * TS];
+        double acc = 0.0;
+        for (int row = rb; row < re; ++row) acc += ja[row] * jb[row];
+        if (a != b && pa == pb) acc *= 2.0;
+        add_H(cm, pa, pb, acc, rep);
+      } else {
+        const int c = p - NP;
+        const int pc = cpos[c];
+        if (pc == LVX_DEAD) continue;
+        const double* jc = &Jt[c * TS];
+        double acc = 0.0;
+        for (int row = rb; row < re; ++row) acc += jc[row] * rs[row];
+        add_g(cm, pc, acc, rep);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// fold the replicas of the dense border accumulators into replica 0
+__global__ void k_fold_replicas(DevCommon cm) {
+  const int n2 = cm.nbd * cm.nbd;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n2) { double s = 0; for (int r = 0; r < LVX_NREP; ++r) s += cm.C[(size_t)r * n2 + i]; cm.C[i] = s; }
+  if (i < cm.nbd) { double s = 0; for (int r = 0; r < LVX_NREP; ++r) s += cm.gc[(size_t)r * cm.nbd + i]; cm.gc[i] = s; }
+  if (i == 0) { double s = 0; for (int r = 0; r < LVX_NREP; ++r) s += cm.cost[r]; cm.cost[0] = s; }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+int fail(lvx_ctx* ctx, int code, const std::string& msg) { if (ctx) ctx->last_error = msg; return code; }
+
+int dev_alloc(lvx_ctx* ctx, DevBuf& b, size_t bytes) {
+  if (bytes == 0) bytes = 8;
+  if (b.p && b.bytes >= bytes) return LVX_OK;
+  if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+  if (hipMalloc(&b.p, bytes) != hipSuccess) { b.p = nullptr; return fail(ctx, LVX_E_ALLOC, "hipMalloc failed"); }
+  b.bytes = bytes;
+  return LVX_OK;
+}
+int upload(lvx_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
+  int rc = dev_alloc(ctx, b, bytes);
+  if (rc) return rc;
+  if (bytes) LVX_HIP(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return LVX_OK;
+}
+
+namespace {
+
+template <class T> std::vector<T> gather(const std::vector<T>& v, const std::vector<int>& perm, int width) {
+  std::vector<T> o(perm.size() * width);
+  for (size_t i = 0; i < perm.size(); ++i) for (int k = 0; k < width; ++k) o[i * width + k] = v[(size_t)perm[i] * width + k];
+  return o;
+}
+
+int upload_pairs(lvx_ctx* ctx, DevBuf& b, int NC) {
+  std::vector<uint16_t> tab;
+  for (int a = 0; a < NC; ++a) for (int c = a; c < NC; ++c) tab.push_back((uint16_t)(a | (c << 8)));
+  return upload(ctx, b, tab.data(), tab.size() * sizeof(uint16_t));
+}
+
+// host-side knot index of a single-time lookup (tau = 0), -1 if out of range
+int host_i0(const lvx_ctx* c, double t) {
+  KnotRef k;
+  if (!knot_lookup(c->t0, c->dt, c->N, t, t, &k)) return -1;
+  return k.i0;
+}
+
+}  // namespace
+
+int ensure_layout(lvx_ctx* ctx) {
+  if (!ctx->layout_dirty) return LVX_OK;
+  if (!ctx->have_spline) return fail(ctx, LVX_E_STATE, "lvx_set_spline has not been called");
+  const int N = ctx->N, L = ctx->L;
+  const uint32_t locks = ctx->locks;
+  int rc;
+  const SplineRef sp{ctx->t0, ctx->dt, N, nullptr, nullptr};
+  // ---- sort every family by knot interval and upload ----
+  {
+    Family& f = ctx->imu;
+    std::vector<int> key(f.n), perm(f.n);
+    for (int i = 0; i < f.n; ++i) key[i] = host_i0(ctx, f.t[i]);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
+    auto ts = gather(f.t, perm, 1); auto g = gather(f.a3, perm, 3); auto a = gather(f.b3, perm, 3);
+    if ((rc = upload(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
+    if ((rc = upload(ctx, f.d_a3, g.data(), g.size() * 8))) return rc;
+    if ((rc = upload(ctx, f.d_b3, a.data(), a.size() * 8))) return rc;
+    if ((rc = upload(ctx, f.d_perm, perm.data(), perm.size() * 4))) return rc;
+  }
+  {
+    Family& f = ctx->surf;
+    std::vector<int> key(f.n), perm(f.n);
+    for (int i = 0; i < f.n; ++i) key[i] = host_i0(ctx, f.t[i]);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
+    auto ts = gather(f.t, perm, 1); auto pt = gather(f.a3, perm, 3); auto pl = gather(f.id0, perm, 1);
+    if ((rc = upload(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
+    if ((rc = upload(ctx, f.d_a3, pt.data(), pt.size() * 8))) return rc;
+    if ((rc = upload(ctx, f.d_id0, pl.data(), pl.size() * 4))) return rc;
+    if ((rc = upload(ctx, f.d_perm, perm.data(), perm.size() * 4))) return rc;
+  }
+  {
+    Family& f = ctx->rep;   // sorted by landmark then observation time: neighbouring lanes touch neighbouring memory
+    std::vector<int> perm(f.n);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return f.id0[a] != f.id0[b] ? f.id0[a] < f.id0[b] : f.t[a] < f.t[b]; });
+    auto ts = gather(f.t, perm, 1); auto uv = gather(f.a3, perm, 2); auto lm = gather(f.id0, perm, 1);
+    if ((rc = upload(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
+    if ((rc = upload(ctx, f.d_a3, uv.data(), uv.size() * 8))) return rc;
+    if ((rc = upload(ctx, f.d_id0, lm.data(), lm.size() * 4))) return rc;
+    if ((rc = upload(ctx, f.d_perm, perm.data(), perm.size() * 4))) return rc;
+  }
+  {
+    Family& f = ctx->cs;
+    std::vector<int> key(f.n), perm(f.n);
+    for (int i = 0; i < f.n; ++i) key[i] = (f.id0[i] >= 0 && f.id0[i] < L) ? host_i0(ctx, ctx->lm_t0[f.id0[i]]) : -1;
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
+    auto lm = gather(f.id0, perm, 1); auto pl = gather(f.id1, perm, 1);
+    if ((rc = upload(ctx, f.d_id0, lm.data(), lm.size() * 4))) return rc;
+    if ((rc = upload(ctx, f.d_id1, pl.data(), pl.size() * 4))) return rc;
+    if ((rc = upload(ctx, f.d_perm, perm.data(), perm.size() * 4))) return rc;
+  }
+  if ((rc = upload(ctx, ctx->d_planes, ctx->planes.data(), ctx->planes.size() * 8))) return rc;
+  if ((rc = upload(ctx, ctx->d_lm_uv, ctx->lm_uv.data(), ctx->lm_uv.size() * 8))) return rc;
+  if ((rc = upload(ctx, ctx->d_lm_t0, ctx->lm_t0.data(), ctx->lm_t0.size() * 8))) return rc;
+  // ---- hub knots (all surfel / cam-surfel residuals evaluate the trajectory at t_map: arrowhead) ----
+  ctx->n_hub = 0; ctx->hub0 = 0;
+  if (ctx->surf.n > 0 || ctx->cs.n > 0) {
+    const bool any_free = !(locks & LVX_LOCK_LIDAR_TAU) || !(locks & LVX_LOCK_CAM_TAU);
+    const double pad = any_free ? ctx->sensor_mto : 0.0;
+    const double tl = ctx->t_map - pad, th = ctx->t_map + pad;
+    const double tmax = ctx->t0 + (double)(N - 3) * ctx->dt;
+    if (tl < ctx->t0 || th >= tmax) return fail(ctx, LVX_E_RANGE, "t_map outside the spline");
+    const int i1 = (int)std::floor((tl - ctx->t0) / ctx->dt), i2 = (int)std::floor((th - ctx->t0) / ctx->dt);
+    ctx->hub0 = i1;
+    ctx->n_hub = std::min(N, i2 + 4 + 1) - i1;   // one spare knot for the merged-segment corner of spline_base.h:196-203
+  }
+  const int nh = ctx->n_hub, h0 = ctx->hub0;
+  ctx->nbd = 6 * nh + 22;
+  // ---- band ordering: non-hub knots in time order, each landmark right after its first knot ----
+  const int nt = 6 * N + 22 + L;
+  ctx->ord.assign(nt, LVX_DEAD);
+  std::vector<int> lm_first(L, N), lm_last(L, -1);
+  const bool cam_tau_locked = (locks & LVX_LOCK_CAM_TAU) != 0;
+  std::vector<int> rep_kmin(ctx->rep.n, 0), rep_kmax(ctx->rep.n, 0);
+  for (int i = 0; i < ctx->rep.n; ++i) {
+    const int l = ctx->rep.id0[i];
+    if (l < 0 || l >= L) return fail(ctx, LVX_E_ARG, "reprojection landmark id out of range");
+    double t1 = std::min(ctx->lm_t0[l], ctx->rep.t[i]), t2 = std::max(ctx->lm_t0[l], ctx->rep.t[i]);
+    if (!cam_tau_locked) { t1 -= ctx->sensor_mto; t2 += ctx->sensor_mto; }
+    const double spans[2][2] = {{t1 - 1e-3, t1 + ctx->cam.readout + 1e-3}, {t2 - 1e-3, t2 + ctx->cam.readout + 1e-3}};
+    Segs sg;
+    if (!build_segments(sp, spans, 2, &sg)) return fail(ctx, LVX_E_RANGE, "reprojection time span out of range for trajectory");
+    int kmin = sg.i1[0], kmax = sg.i1[sg.nseg - 1] + sg.n[sg.nseg - 1] - 1;
+    rep_kmin[i] = kmin; rep_kmax[i] = kmax;
+    lm_first[l] = std::min(lm_first[l], kmin); lm_last[l] = std::max(lm_last[l], kmax);
+  }
+  std::vector<std::vector<int>> lm_at(N + 1);
+  if (!(locks & LVX_LOCK_LANDMARKS)) for (int l = 0; l < L; ++l) lm_at[std::min(lm_first[l], N)].push_back(l);
+  int pos = 0;
+  auto is_hub = [&](int k) { return nh > 0 && k >= h0 && k < h0 + nh; };
+  for (int k = 0; k <= N; ++k) {
+    if (k < N) {
+      if (is_hub(k)) {
+        for (int d = 0; d < 6; ++d) if (!tangent_locked(6 * k + d, N, L, locks)) ctx->ord[6 * k + d] = -1 - (6 * (k - h0) + d);
+      } else {
+        for (int d = 0; d < 6; ++d) if (!tangent_locked(6 * k + d, N, L, locks)) ctx->ord[6 * k + d] = pos++;
+      }
+    }
+    for (int l : lm_at[k]) ctx->ord[6 * N + 22 + l] = pos++;
+  }
+  ctx->nb = pos;
+  for (int c = 0; c < 22; ++c) if (!tangent_locked(6 * N + c, N, L, locks)) ctx->ord[6 * N + c] = -1 - (6 * nh + c);
+  // ---- scalar half-bandwidth ----
+  int bw = 0;
+  auto span_pos = [&](int ka, int kb, int& lo, int& hi) {
+    for (int k = ka; k <= kb && k < N; ++k) for (int d = 0; d < 6; ++d) { const int o = ctx->ord[6 * k + d]; if (o >= 0) { lo = std::min(lo, o); hi = std::max(hi, o); } }
+  };
+  for (int k = 0; k + 3 < N; ++k) { int lo = 1 << 30, hi = -1; span_pos(k, k + 3, lo, hi); if (hi >= lo) bw = std::max(bw, hi - lo); }
+  for (int i = 0; i < ctx->rep.n; ++i) {
+    int lo = 1 << 30, hi = -1;
+    span_pos(rep_kmin[i], rep_kmax[i], lo, hi);
+    const int ol = ctx->ord[6 * N + 22 + ctx->rep.id0[i]];
+    if (ol >= 0) { lo = std::min(lo, ol); hi = std::max(hi, ol); }
+    if (hi >= lo) bw = std::max(bw, hi - lo);
+  }
+  // the landmark elimination couples everything a landmark touches
+  for (int l = 0; l < L; ++l) if (lm_last[l] >= 0) {
+    int lo = 1 << 30, hi = -1; span_pos(lm_first[l], lm_last[l], lo, hi);
+    const int ol = ctx->ord[6 * N + 22 + l];
+    if (ol >= 0) { lo = std::min(lo, ol); hi = std::max(hi, ol); }
+    if (hi >= lo) bw = std::max(bw, hi - lo);
+  }
+  ctx->bw = std::min(std::max(bw, 0), std::max(ctx->nb - 1, 0));
+  // ---- buffers ----
+  if ((rc = upload(ctx, ctx->d_ord, ctx->ord.data(), ctx->ord.size() * 4))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_Hb, (size_t)std::max(ctx->nb, 1) * (ctx->bw + 1) * 8))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_gb, (size_t)std::max(ctx->nb, 1) * 8))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_Bd, (size_t)ctx->nbd * std::max(ctx->nb, 1) * 8))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_C, (size_t)LVX_NREP * ctx->nbd * ctx->nbd * 8))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_gc, (size_t)LVX_NREP * ctx->nbd * 8))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_cost, LVX_NREP * 8))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_err, 16))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_state, (size_t)lvx_state_size(ctx) * 8))) return rc;
+  const int ncs[LVX_NUM_FAM] = {GYRO_NC, ACC_NC, PRI_NC, SURF_NC, REP_NC, CS_NC};
+  for (int f = 0; f < LVX_NUM_FAM; ++f) if ((rc = upload_pairs(ctx, ctx->d_pairs[f], ncs[f]))) return rc;
+  // ---- residual row offsets ----
+  const int64_t cnt[LVX_NUM_FAM] = {ctx->imu.n, (locks & LVX_LOCK_R3) ? 0 : ctx->imu.n, ctx->has_prior ? 1 : 0, ctx->surf.n, ctx->rep.n, ctx->cs.n};
+  const int nrs[LVX_NUM_FAM] = {3, 3, 1, 1, 2, 1};
+  ctx->n_blocks = 0; ctx->fam_row0[0] = 0;
+  for (int f = 0; f < LVX_NUM_FAM; ++f) { ctx->fam_row0[f + 1] = ctx->fam_row0[f] + cnt[f] * nrs[f]; ctx->n_blocks += cnt[f]; }
+  ctx->n_residuals = ctx->fam_row0[LVX_NUM_FAM];
+  ctx->layout_dirty = false;
+  return LVX_OK;
+}
+
+DevCommon make_common(lvx_ctx* ctx, const double* state_d, uint32_t what) {
+  DevCommon cm{};
+  cm.state = state_d; cm.N = ctx->N; cm.L = ctx->L; cm.t0 = ctx->t0; cm.dt = ctx->dt; cm.locks = ctx->locks; cm.what = what;
+  cm.imu_mto = ctx->imu_mto; cm.sensor_mto = ctx->sensor_mto; cm.cam = ctx->cam;
+  cm.ord = (const int*)ctx->d_ord.p; cm.nb = ctx->nb; cm.bw = ctx->bw; cm.nbd = ctx->nbd;
+  cm.Hb = (double*)ctx->d_Hb.p; cm.gb = (double*)ctx->d_gb.p; cm.Bd = (double*)ctx->d_Bd.p; cm.C = (double*)ctx->d_C.p; cm.gc = (double*)ctx->d_gc.p;
+  cm.cost = (double*)ctx->d_cost.p; cm.err = (int*)ctx->d_err.p;
+  cm.residuals = nullptr; cm.jcols = nullptr; cm.jvals = nullptr;
+  return cm;
+}
+
+static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cost, bool want_res_buffer) {
+  int rc = ensure_layout(ctx);
+  if (rc) return rc;
+  hipStream_t st = ctx->stream;
+  DevCommon cm = make_common(ctx, state_d, what);
+  if (want_res_buffer) {
+    if ((rc = dev_alloc(ctx, ctx->d_res, (size_t)std::max<int64_t>(ctx->n_residuals, 1) * 8))) return rc;
+    cm.residuals = (double*)ctx->d_res.p;
+  }
+  if (what & LVX_EVAL_JACOBIAN) {
+    const size_t nrow = (size_t)std::max<int64_t>(ctx->n_residuals, 1);
+    if ((rc = dev_alloc(ctx, ctx->d_jcols, nrow * LVX_JAC_WIDTH * 4))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->d_jvals, nrow * LVX_JAC_WIDTH * 8))) return rc;
+    cm.jcols = (int32_t*)ctx->d_jcols.p; cm.jvals = (double*)ctx->d_jvals.p;
+    LVX_HIP(ctx, hipMemsetAsync(cm.jcols, 0xff, nrow * LVX_JAC_WIDTH * 4, st));
+    LVX_HIP(ctx, hipMemsetAsync(cm.jvals, 0, nrow * LVX_JAC_WIDTH * 8, st));
+  }
+  LVX_HIP(ctx, hipMemsetAsync(cm.cost, 0, LVX_NREP * 8, st));
+  LVX_HIP(ctx, hipMemsetAsync(cm.err, 0, 16, st));
+  if (what & LVX_EVAL_NORMAL_EQ) {
+    LVX_HIP(ctx, hipMemsetAsync(cm.Hb, 0, (size_t)std::max(ctx->nb, 1) * (ctx->bw + 1) * 8, st));
+    LVX_HIP(ctx, hipMemsetAsync(cm.gb, 0, (size_t)std::max(ctx->nb, 1) * 8, st));
+    LVX_HIP(ctx, hipMemsetAsync(cm.Bd, 0, (size_t)ctx->nbd * std::max(ctx->nb, 1) * 8, st));
+    LVX_HIP(ctx, hipMemsetAsync(cm.C, 0, (size_t)LVX_NREP * ctx->nbd * ctx->nbd * 8, st));
+    LVX_HIP(ctx, hipMemsetAsync(cm.gc, 0, (size_t)LVX_NREP * ctx->nbd * 8, st));
+  }
+  auto grid = [](int n) { return dim3((unsigned)((n + 63) / 64)); };
+  if (ctx->imu.n > 0) {
+    GyroFam g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
+    hipLaunchKernelGGL(k_family<GyroFam>, grid(g.n), dim3(64), 0, st, g, cm, (const uint16_t*)ctx->d_pairs[0].p, (long long)ctx->fam_row0[0]);
+    if (!(ctx->locks & LVX_LOCK_R3)) {
+      AccelFam a{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.huber /*w_acc*/, 0.0};
+      hipLaunchKernelGGL(k_family<AccelFam>, grid(a.n), dim3(64), 0, st, a, cm, (const uint16_t*)ctx->d_pairs[1].p, (long long)ctx->fam_row0[1]);
+    }
+  }
+  if (ctx->has_prior) {
+    static const int zero = 0;
+    DevBuf& pb = ctx->d_zero;   // identity permutation for the single prior block
+    if ((rc = upload(ctx, pb, &zero, 4))) return rc;
+    PriorFam p{1, ctx->prior_t, mkq(ctx->prior_q[0], ctx->prior_q[1], ctx->prior_q[2], ctx->prior_q[3]), (const int*)pb.p, ctx->prior_w, 0.0};
+    hipLaunchKernelGGL(k_family<PriorFam>, dim3(1), dim3(64), 0, st, p, cm, (const uint16_t*)ctx->d_pairs[2].p, (long long)ctx->fam_row0[2]);
+  }
+  if (ctx->surf.n > 0) {
+    SurfFam s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
+              (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
+    hipLaunchKernelGGL(k_family<SurfFam>, grid(s.n), dim3(64), 0, st, s, cm, (const uint16_t*)ctx->d_pairs[3].p, (long long)ctx->fam_row0[3]);
+  }
+  if (ctx->rep.n > 0) {
+    ReprojFam r{ctx->rep.n, (const int*)ctx->rep.d_id0.p, (const double*)ctx->rep.d_a3.p, (const double*)ctx->rep.d_t.p, (const int*)ctx->rep.d_perm.p,
+                (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->rep.weight, ctx->rep.huber};
+    hipLaunchKernelGGL(k_family<ReprojFam>, grid(r.n), dim3(64), 0, st, r, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
+  }
+  if (ctx->cs.n > 0) {
+    CamSurfFam c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
+                 (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
+    hipLaunchKernelGGL(k_family<CamSurfFam>, grid(c.n), dim3(64), 0, st, c, cm, (const uint16_t*)ctx->d_pairs[5].p, (long long)ctx->fam_row0[5]);
+  }
+  hipLaunchKernelGGL(k_fold_replicas, dim3((unsigned)((ctx->nbd * ctx->nbd + 255) / 256)), dim3(256), 0, st, cm);
+  LVX_HIP(ctx, hipGetLastError());
+  ctx->last_what = what;
+  if (cost) {
+    double c = 0; int err[4] = {0, 0, 0, 0};
+    LVX_HIP(ctx, hipMemcpyAsync(&c, cm.cost, 8, hipMemcpyDeviceToHost, st));
+    LVX_HIP(ctx, hipMemcpyAsync(err, cm.err, 4, hipMemcpyDeviceToHost, st));
+    LVX_HIP(ctx, hipStreamSynchronize(st));
+    *cost = c;
+    if (err[0] & RES_RANGE) return fail(ctx, LVX_E_RANGE, "time span out of range for trajectory");
+    if (err[0] & RES_NONUNIT) return fail(ctx, LVX_E_NONUNIT_QUAT, "logq: only implemented for unit quaternions");
+    if (err[0] & 4) return fail(ctx, LVX_E_STATE, "normal-equation entry outside the computed bandwidth");
+  }
+  return LVX_OK;
+}
+
+}  // namespace lvx
+
+using namespace lvx;
+
+extern "C" {
+
+const char* lvx_version(void) { return "lvx 0.1 (gfx950)"; }
+const char* lvx_last_error(const lvx_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int lvx_create(lvx_ctx** out, int device, uint32_t /*flags*/) {
+  if (!out) return LVX_E_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return LVX_E_NODEVICE;
+  if (device < 0 || device >= ndev) return LVX_E_ARG;
+  if (hipSetDevice(device) != hipSuccess) return LVX_E_HIP;
+  lvx_ctx* c = new (std::nothrow) lvx_ctx();
+  if (!c) return LVX_E_ALLOC;
+  c->device = device;
+  if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return LVX_E_HIP; }
+  *out = c;
+  return LVX_OK;
+}
+
+static void free_family(Family& f) { for (DevBuf* b : {&f.d_t, &f.d_a3, &f.d_b3, &f.d_id0, &f.d_id1, &f.d_perm}) if (b->p) (void)hipFree(b->p); }
+
+void lvx_destroy(lvx_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  free_family(c->imu); free_family(c->surf); free_family(c->rep); free_family(c->cs);
+  for (DevBuf* b : {&c->d_planes, &c->d_lm_uv, &c->d_lm_t0, &c->d_ord, &c->d_Hb, &c->d_gb, &c->d_Bd, &c->d_C, &c->d_gc, &c->d_cost, &c->d_err, &c->d_state,
+                    &c->d_res, &c->d_jcols, &c->d_jvals, &c->d_L, &c->d_Y, &c->d_S, &c->d_delta, &c->d_diag, &c->d_scal, &c->d_state_try, &c->d_zero})
+    if (b->p) (void)hipFree(b->p);
+  for (auto& b : c->d_pairs) if (b.p) (void)hipFree(b.p);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int lvx_set_spline(lvx_ctx* c, double t0, double dt, int n_knots) {
+  if (!c || !(dt > 0) || n_knots < 4) return c ? fail(c, LVX_E_ARG, "spline needs dt > 0 and >= 4 control points (spline_base.h:58-62)") : LVX_E_ARG;
+  c->t0 = t0; c->dt = dt; c->N = n_knots; c->have_spline = true; c->layout_dirty = true; return LVX_OK;
+}
+int lvx_set_camera(lvx_ctx* c, const lvx_pinhole* p) {
+  if (!c || !p) return LVX_E_ARG;
+  CamIntr& k = c->cam;
+  k.fx = p->fx; k.fy = p->fy; k.cx = p->cx; k.cy = p->cy; k.k1 = p->k1; k.k2 = p->k2; k.p1 = p->p1; k.p2 = p->p2; k.k3 = p->k3; k.readout = p->readout;
+  k.rows = p->rows; k.cols = p->cols;
+  k.inv_K11 = 1.0 / k.fx; k.inv_K13 = -k.cx / k.fx; k.inv_K22 = 1.0 / k.fy; k.inv_K23 = -k.cy / k.fy;   // pinhole_camera.h:59-75
+  k.do_distortion = (std::fabs(k.k1) > 1e-5 || std::fabs(k.k2) > 1e-5 || std::fabs(k.p1) > 1e-5 || std::fabs(k.p1) > 1e-5) ? 1 : 0;  // sic (:78)
+  c->layout_dirty = true; return LVX_OK;
+}
+int lvx_set_imu(lvx_ctx* c, int n, const double* t, const double* gyro3, const double* acc3, double w_gyro, double w_acc) {
+  if (!c || n < 0 || (n > 0 && (!t || !gyro3 || !acc3))) return LVX_E_ARG;
+  Family& f = c->imu; f.n = n; f.t.assign(t, t + n); f.a3.assign(gyro3, gyro3 + 3 * (size_t)n); f.b3.assign(acc3, acc3 + 3 * (size_t)n);
+  f.weight = w_gyro; f.huber = w_acc;   // (huber slot reused for the accelerometer weight; IMU blocks have no loss function)
+  c->layout_dirty = true; return LVX_OK;
+}
+int lvx_set_orientation_prior(lvx_ctx* c, int enable, double t, const double* q_wxyz, double weight) {
+  if (!c) return LVX_E_ARG;
+  c->has_prior = enable != 0; c->prior_t = t; if (q_wxyz) std::memcpy(c->prior_q, q_wxyz, 32); c->prior_w = weight; c->layout_dirty = true; return LVX_OK;
+}
+int lvx_set_planes(lvx_ctx* c, int n, const double* pi3) {
+  if (!c || n < 0 || (n > 0 && !pi3)) return LVX_E_ARG;
+  c->planes.assign(pi3, pi3 + 3 * (size_t)n); c->layout_dirty = true; return LVX_OK;
+}
+int lvx_set_surfel(lvx_ctx* c, int n, const double* pt3, const double* t, const int32_t* plane_id, double t_map, double huber, double weight) {
+  if (!c || n < 0 || (n > 0 && (!pt3 || !t || !plane_id))) return LVX_E_ARG;
+  Family& f = c->surf; f.n = n; f.t.assign(t, t + n); f.a3.assign(pt3, pt3 + 3 * (size_t)n); f.id0.assign(plane_id, plane_id + n);
+  for (int i = 0; i < n; ++i) if (plane_id[i] < 0 || (size_t)plane_id[i] * 3 >= c->planes.size()) return fail(c, LVX_E_ARG, "plane id out of range (call lvx_set_planes first)");
+  f.huber = huber; f.weight = weight; c->t_map = t_map; c->layout_dirty = true; return LVX_OK;
+}
+int lvx_set_landmarks(lvx_ctx* c, int n, const double* uv_ref2, const double* t0_ref) {
+  if (!c || n < 0 || (n > 0 && (!uv_ref2 || !t0_ref))) return LVX_E_ARG;
+  c->L = n; c->lm_uv.assign(uv_ref2, uv_ref2 + 2 * (size_t)n); c->lm_t0.assign(t0_ref, t0_ref + n); c->layout_dirty = true; return LVX_OK;
+}
+int lvx_set_reproj(lvx_ctx* c, int n, const int32_t* lm, const double* uv_obs2, const double* t0_obs, double huber, double weight) {
+  if (!c || n < 0 || (n > 0 && (!lm || !uv_obs2 || !t0_obs))) return LVX_E_ARG;
+  Family& f = c->rep; f.n = n; f.t.assign(t0_obs, t0_obs + n); f.a3.assign(uv_obs2, uv_obs2 + 2 * (size_t)n); f.id0.assign(lm, lm + n);
+  f.huber = huber; f.weight = weight; c->layout_dirty = true; return LVX_OK;
+}
+int lvx_set_camsurf(lvx_ctx* c, int n, const int32_t* lm, const int32_t* plane_id, double t_map, double huber, double weight) {
+  if (!c || n < 0 || (n > 0 && (!lm || !plane_id))) return LVX_E_ARG;
+  Family& f = c->cs; f.n = n; f.id0.assign(lm, lm + n); f.id1.assign(plane_id, plane_id + n);
+  for (int i = 0; i < n; ++i) {
+    if (plane_id[i] < 0 || (size_t)plane_id[i] * 3 >= c->planes.size()) return fail(c, LVX_E_ARG, "plane id out of range (call lvx_set_planes first)");
+    if (lm[i] < 0 || lm[i] >= c->L) return fail(c, LVX_E_ARG, "landmark id out of range (call lvx_set_landmarks first)");
+  }
+  f.huber = huber; f.weight = weight; c->t_map = t_map; c->layout_dirty = true; return LVX_OK;
+}
+int lvx_set_locks(lvx_ctx* c, uint32_t mask) { if (!c) return LVX_E_ARG; if (c->locks != mask) { c->locks = mask; c->layout_dirty = true; } return LVX_OK; }
+int lvx_set_time_offset_bounds(lvx_ctx* c, double imu_max, double sensor_max) { if (!c) return LVX_E_ARG; c->imu_mto = imu_max; c->sensor_mto = sensor_max; c->layout_dirty = true; return LVX_OK; }
+
+int lvx_state_size(const lvx_ctx* c) { return c ? 7 * c->N + 32 + c->L : 0; }
+int lvx_tangent_size(const lvx_ctx* c) { return c ? 6 * c->N + 22 + c->L : 0; }
+
+int lvx_get_layout(lvx_ctx* c, lvx_layout* o) {
+  if (!c || !o) return LVX_E_ARG;
+  int rc = ensure_layout(c); if (rc) return rc;
+  o->n_knots = c->N; o->n_landmarks = c->L; o->n_tangent = lvx_tangent_size(c); o->n_band = c->nb; o->bandwidth = c->bw; o->n_border = c->nbd;
+  o->n_hub_knots = c->n_hub; o->hub_knot0 = c->hub0; o->n_blocks = c->n_blocks; o->n_residuals = c->n_residuals;
+  return LVX_OK;
+}
+
+int lvx_evaluate_d(lvx_ctx* c, const double* state_d, uint32_t what, double* cost) {
+  if (!c || !state_d) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  return run_evaluate(c, state_d, what, cost, false);
+}
+
+int lvx_evaluate(lvx_ctx* c, const double* state, uint32_t what, double* cost, double* residuals) {
+  if (!c || !state) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  int rc = ensure_layout(c); if (rc) return rc;
+  LVX_HIP(c, hipMemcpyAsync(c->d_state.p, state, (size_t)lvx_state_size(c) * 8, hipMemcpyHostToDevice, c->stream));
+  double cst = 0;
+  const bool want_res = residuals != nullptr || (what & LVX_EVAL_RESIDUALS);
+  rc = run_evaluate(c, (const double*)c->d_state.p, what, &cst, want_res);
+  if (cost) *cost = cst;
+  if (rc) return rc;
+  if (residuals && c->n_residuals > 0) {
+    LVX_HIP(c, hipMemcpyAsync(residuals, c->d_res.p, (size_t)c->n_residuals * 8, hipMemcpyDeviceToHost, c->stream));
+    LVX_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  return LVX_OK;
+}
+
+int lvx_get_jacobian(lvx_ctx* c, int32_t* cols, double* vals) {
+  if (!c || !cols || !vals) return LVX_E_ARG;
+  if (!(c->last_what & LVX_EVAL_JACOBIAN)) return fail(c, LVX_E_STATE, "last evaluation did not request LVX_EVAL_JACOBIAN");
+  LVX_HIP(c, hipSetDevice(c->device));
+  const size_t n = (size_t)c->n_residuals * LVX_JAC_WIDTH;
+  LVX_HIP(c, hipMemcpy(cols, c->d_jcols.p, n * 4, hipMemcpyDeviceToHost));
+  LVX_HIP(c, hipMemcpy(vals, c->d_jvals.p, n * 8, hipMemcpyDeviceToHost));
+  return LVX_OK;
+}
+
+int lvx_get_normal_eq_dense(lvx_ctx* c, double* H, double* g) {
+  if (!c || !H || !g) return LVX_E_ARG;
+  if (!(c->last_what & LVX_EVAL_NORMAL_EQ)) return fail(c, LVX_E_STATE, "last evaluation did not request LVX_EVAL_NORMAL_EQ");
+  const int nt = lvx_tangent_size(c);
+  if (nt > 20000) return fail(c, LVX_E_ARG, "dense expansion is a parity/debug path for small problems");
+  LVX_HIP(c, hipSetDevice(c->device));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  const int nb = c->nb, bw = c->bw, nbd = c->nbd;
+  std::vector<double> Hb((size_t)std::max(nb, 1) * (bw + 1)), gb(std::max(nb, 1)), Bd((size_t)nbd * std::max(nb, 1)), C((size_t)nbd * nbd), gc(nbd);
+  LVX_HIP(c, hipMemcpy(Hb.data(), c->d_Hb.p, Hb.size() * 8, hipMemcpyDeviceToHost));
+  LVX_HIP(c, hipMemcpy(gb.data(), c->d_gb.p, gb.size() * 8, hipMemcpyDeviceToHost));
+  LVX_HIP(c, hipMemcpy(Bd.data(), c->d_Bd.p, Bd.size() * 8, hipMemcpyDeviceToHost));
+  LVX_HIP(c, hipMemcpy(C.data(), c->d_C.p, C.size() * 8, hipMemcpyDeviceToHost));
+  LVX_HIP(c, hipMemcpy(gc.data(), c->d_gc.p, gc.size() * 8, hipMemcpyDeviceToHost));
+  std::memset(H, 0, sizeof(double) * (size_t)nt * nt);
+  std::memset(g, 0, sizeof(double) * nt);
+  std::vector<int> band_var(std::max(nb, 1), -1), bord_var(nbd, -1);
+  for (int v = 0; v < nt; ++v) { const int o = c->ord[v]; if (o == LVX_DEAD) continue; if (o >= 0) band_var[o] = v; else bord_var[-1 - o] = v; }
+  for (int j = 0; j < nb; ++j) {
+    g[band_var[j]] = gb[j];
+    for (int d = 0; d <= bw && j + d < nb; ++d) { const double v = Hb[(size_t)j * (bw + 1) + d]; const int a = band_var[j + d], b = band_var[j]; H[(size_t)a * nt + b] = v; H[(size_t)b * nt + a] = v; }
+  }
+  for (int b = 0; b < nbd; ++b) {
+    if (bord_var[b] < 0) continue;
+    g[bord_var[b]] = gc[b];
+    for (int j = 0; j < nb; ++j) { const double v = Bd[(size_t)b * nb + j]; H[(size_t)bord_var[b] * nt + band_var[j]] = v; H[(size_t)band_var[j] * nt + bord_var[b]] = v; }
+    for (int b2 = 0; b2 <= b; ++b2) { if (bord_var[b2] < 0) continue; const double v = C[(size_t)b * nbd + b2]; H[(size_t)bord_var[b] * nt + bord_var[b2]] = v; H[(size_t)bord_var[b2] * nt + bord_var[b]] = v; }
+  }
+  return LVX_OK;
+}
+
+int lvx_plus(lvx_ctx* c, const double* s, const double* d, double* o) {
+  if (!c || !s || !d || !o) return LVX_E_ARG;
+  const int N = c->N;
+  std::memcpy(o, s, sizeof(double) * (size_t)lvx_state_size(c));
+  auto qplus = [](const double* x, const double* dl, double* out) {   // ceres::EigenQuaternionParameterization::Plus (restated)
+    const double nd = std::sqrt(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
+    if (nd > 0.0) {
+      const double sd = std::sin(nd) / nd;
+      const quat r = qmul(mkq(std::cos(nd), sd * dl[0], sd * dl[1], sd * dl[2]), load_q(x));
+      out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+    } else { for (int k = 0; k < 4; ++k) out[k] = x[k]; }
+  };
+  for (int k = 0; k < N; ++k) {
+    for (int j = 0; j < 3; ++j) o[3 * k + j] = s[3 * k + j] + d[6 * k + j];
+    qplus(s + 3 * N + 4 * k, d + 6 * k + 3, o + 3 * N + 4 * k);
+  }
+  const double* si = s + 7 * N; double* oi = o + 7 * N; const double* di = d + 6 * N;
+  oi[8] = si[8] + di[0]; oi[9] = si[9] + di[1];
+  for (int j = 0; j < 3; ++j) { oi[10 + j] = si[10 + j] + di[2 + j]; oi[13 + j] = si[13 + j] + di[5 + j]; }
+  qplus(si + 16, di + 8, oi + 16); for (int j = 0; j < 3; ++j) oi[20 + j] = si[20 + j] + di[11 + j]; oi[23] = si[23] + di[14];
+  qplus(si + 24, di + 15, oi + 24); for (int j = 0; j < 3; ++j) oi[28 + j] = si[28 + j] + di[18 + j]; oi[31] = si[31] + di[21];
+  for (int l = 0; l < c->L; ++l) oi[32 + l] = si[32 + l] + di[22 + l];
+  return LVX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,204 @@
+"""ctypes binding of the C ABI in include/lvx.h (liblvx.so, HIP / gfx950).
+
+Plumbing only: the product is the shared library.  There is NO CPU fallback — creating a context
+without a HIP device raises, as does a missing liblvx.so.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+OK, E_RANGE, E_NONUNIT_QUAT, E_ALLOC, E_HIP, E_RCCL, E_ARG, E_STATE, E_NODEVICE, E_NOTPD = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9
+
+LOCK_TRAJ = 1 << 0
+LOCK_R3 = 1 << 1
+LOCK_LIDAR_Q = 1 << 2
+LOCK_LIDAR_P = 1 << 3
+LOCK_LIDAR_TAU = 1 << 4
+LOCK_CAM_Q = 1 << 5
+LOCK_CAM_P = 1 << 6
+LOCK_CAM_TAU = 1 << 7
+LOCK_ACC_BIAS = 1 << 8
+LOCK_GYRO_BIAS = 1 << 9
+LOCK_LANDMARKS = 1 << 10
+
+EVAL_COST, EVAL_RESIDUALS, EVAL_NORMAL_EQ, EVAL_JACOBIAN = 1, 2, 4, 8
+JAC_WIDTH = 64
+
+
+class Pinhole(C.Structure):
+    _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("readout", C.c_double), ("fx", C.c_double), ("fy", C.c_double),
+                ("cx", C.c_double), ("cy", C.c_double), ("k1", C.c_double), ("k2", C.c_double), ("p1", C.c_double),
+                ("p2", C.c_double), ("k3", C.c_double)]
+
+
+class Layout(C.Structure):
+    _fields_ = [("n_knots", C.c_int32), ("n_landmarks", C.c_int32), ("n_tangent", C.c_int32), ("n_band", C.c_int32),
+                ("bandwidth", C.c_int32), ("n_border", C.c_int32), ("n_hub_knots", C.c_int32), ("hub_knot0", C.c_int32),
+                ("n_blocks", C.c_int64), ("n_residuals", C.c_int64)]
+
+
+class LvxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("lvx error %d: %s" % (code, msg))
+        self.code = code
+
+
+def library_path():
+    return os.path.join(_HERE, "liblvx.so")
+
+
+def lib():
+    """Load liblvx.so; raises if it has not been built (python lvi-exc_amd/build.py)."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise FileNotFoundError("liblvx.so is missing: build it with `python lvi-exc_amd/build.py` (hipcc, gfx950)")
+        _LIB = C.CDLL(path)
+        _LIB.lvx_version.restype = C.c_char_p
+        _LIB.lvx_last_error.restype = C.c_char_p
+        _LIB.lvx_last_error.argtypes = [C.c_void_p]
+    return _LIB
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One evaluator context bound to one GPU (thin wrapper over lvx_ctx)."""
+
+    def __init__(self, device=0):
+        self._l = lib()
+        h = C.c_void_p()
+        rc = self._l.lvx_create(C.byref(h), C.c_int(device), C.c_uint32(0))
+        if rc != OK:
+            raise LvxError(rc, "lvx_create failed (no HIP device?)" if rc == E_NODEVICE else "lvx_create failed")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.lvx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != OK:
+            raise LvxError(rc, self._l.lvx_last_error(self._h).decode())
+
+    # --- problem description (same argument meaning as oracle.Oracle) ---
+    def set_spline(self, t0, dt, n_knots):
+        self._ck(self._l.lvx_set_spline(self._h, C.c_double(t0), C.c_double(dt), C.c_int(n_knots)))
+
+    def set_camera(self, rows, cols, readout, fx, fy, cx, cy, k1=0.0, k2=0.0, p1=0.0, p2=0.0, k3=0.0):
+        ph = Pinhole(rows, cols, readout, fx, fy, cx, cy, k1, k2, p1, p2, k3)
+        self._ck(self._l.lvx_set_camera(self._h, C.byref(ph)))
+
+    def set_imu(self, t, gyro, acc, w_g, w_a):
+        t, gyro, acc = _d(t), _d(gyro), _d(acc)
+        self._ck(self._l.lvx_set_imu(self._h, C.c_int(len(t)), _p(t), _p(gyro), _p(acc), C.c_double(w_g), C.c_double(w_a)))
+
+    def set_orientation_prior(self, t, q_wxyz, w, enable=True):
+        q = _d(q_wxyz)
+        self._ck(self._l.lvx_set_orientation_prior(self._h, C.c_int(1 if enable else 0), C.c_double(t), _p(q), C.c_double(w)))
+
+    def set_planes(self, pi3):
+        pi3 = _d(pi3)
+        self._ck(self._l.lvx_set_planes(self._h, C.c_int(len(pi3)), _p(pi3)))
+
+    def set_surfel(self, pt, t, plane_id, t_map, huber, w):
+        pt, t, plane_id = _d(pt), _d(t), _i(plane_id)
+        self._ck(self._l.lvx_set_surfel(self._h, C.c_int(len(t)), _p(pt), _p(t), _p(plane_id), C.c_double(t_map), C.c_double(huber), C.c_double(w)))
+
+    def set_landmarks(self, uv_ref, t0_ref):
+        uv_ref, t0_ref = _d(uv_ref), _d(t0_ref)
+        self._ck(self._l.lvx_set_landmarks(self._h, C.c_int(len(t0_ref)), _p(uv_ref), _p(t0_ref)))
+
+    def set_reproj(self, lm, uv_obs, t0_obs, huber, w):
+        lm, uv_obs, t0_obs = _i(lm), _d(uv_obs), _d(t0_obs)
+        self._ck(self._l.lvx_set_reproj(self._h, C.c_int(len(lm)), _p(lm), _p(uv_obs), _p(t0_obs), C.c_double(huber), C.c_double(w)))
+
+    def set_camsurf(self, lm, plane_id, t_map, huber, w):
+        lm, plane_id = _i(lm), _i(plane_id)
+        self._ck(self._l.lvx_set_camsurf(self._h, C.c_int(len(lm)), _p(lm), _p(plane_id), C.c_double(t_map), C.c_double(huber), C.c_double(w)))
+
+    def set_locks(self, mask):
+        self._ck(self._l.lvx_set_locks(self._h, C.c_uint32(mask)))
+
+    def set_so3_only(self, flag):
+        """Solve #0 estimator (TrajectoryEstimator<UniformSO3SplineTrajectory>): R3 spline absent, gyro + prior only."""
+        self._so3_only = bool(flag)
+
+    @property
+    def state_size(self):
+        return self._l.lvx_state_size(self._h)
+
+    @property
+    def tangent_size(self):
+        return self._l.lvx_tangent_size(self._h)
+
+    def layout(self):
+        lo = Layout()
+        self._ck(self._l.lvx_get_layout(self._h, C.byref(lo)))
+        return {k: getattr(lo, k) for k, _ in Layout._fields_}
+
+    # --- evaluation ---
+    def evaluate(self, state, jac=False, normal_eq=False, dense=True, residuals=True):
+        state = _d(state)
+        assert state.size == self.state_size
+        lo = self.layout()
+        what = EVAL_COST | (EVAL_RESIDUALS if residuals else 0) | (EVAL_NORMAL_EQ if normal_eq else 0) | (EVAL_JACOBIAN if jac else 0)
+        cost = C.c_double(0)
+        res = np.zeros(lo["n_residuals"]) if residuals else None
+        self._ck(self._l.lvx_evaluate(self._h, _p(state), C.c_uint32(what), C.byref(cost), _p(res)))
+        out = {"cost": cost.value, "residuals": res}
+        if jac:
+            jc = np.full((lo["n_residuals"], JAC_WIDTH), -1, dtype=np.int32)
+            jv = np.zeros((lo["n_residuals"], JAC_WIDTH))
+            self._ck(self._l.lvx_get_jacobian(self._h, _p(jc), _p(jv)))
+            out["jac_cols"], out["jac_vals"] = jc, jv
+        if normal_eq and dense:
+            nt = self.tangent_size
+            H = np.zeros((nt, nt))
+            g = np.zeros(nt)
+            self._ck(self._l.lvx_get_normal_eq_dense(self._h, _p(H), _p(g)))
+            out["H"], out["g"] = H, g
+        return out
+
+    def plus(self, state, delta):
+        state, delta = _d(state), _d(delta)
+        out = np.zeros_like(state)
+        self._ck(self._l.lvx_plus(self._h, _p(state), _p(delta), _p(out)))
+        return out
+
+
+def load_problem(obj, P, locks=None):
+    """Feed a synth.make_problem() dict into an lvx.Context or an oracle.Oracle (same setter names)."""
+    obj.set_spline(P["t0"], P["dt"], P["n_knots"])
+    c = P["camera"]
+    obj.set_camera(c["rows"], c["cols"], c["readout"], c["fx"], c["fy"], c["cx"], c["cy"], c["k1"], c["k2"], c["p1"], c["p2"], c["k3"])
+    obj.set_imu(P["t_imu"], P["gyro"], P["acc"], P["w_gyro"], P["w_acc"])
+    obj.set_planes(P["planes"])
+    obj.set_surfel(P["surf_pt"], P["surf_t"], P["surf_plane"], P["t_map"], P["huber_surf"], P["w_surf"])
+    obj.set_landmarks(P["lm_uv"], P["lm_t0"])
+    obj.set_reproj(P["rep_lm"], P["rep_uv"], P["rep_t0"], P["huber_rep"], P["w_rep"])
+    obj.set_camsurf(P["cs_lm"], P["cs_plane"], P["t_map"], P["huber_cs"], P["w_cs"])
+    if locks is not None:
+        obj.set_locks(locks)

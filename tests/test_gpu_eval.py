@@ -1,0 +1,123 @@
+"""GPU parity: HIP evaluator (through the C ABI) vs the CPU oracle on identical seeded inputs.
+
+Tolerances (FP64): residuals 1e-11 relative to the largest residual, Jacobian rows 1e-9 relative to the
+largest Jacobian entry, normal equations 1e-10 relative to max|H| (atomic summation order differs run to run).
+"""
+import numpy as np
+import pytest
+
+import lvx
+import synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TAU_LOCKS = lvx.LOCK_LIDAR_TAU | lvx.LOCK_CAM_TAU
+
+
+def _pair(P, locks, prior=True):
+    o = O.Oracle()
+    g = lvx.Context(0)
+    for obj in (o, g):
+        lvx.load_problem(obj, P, locks)
+        if prior:
+            obj.set_orientation_prior(P["t0"], np.array([np.cos(5e-5), 0, 0, np.sin(5e-5)]), 28.0)
+    return o, g
+
+
+def _compare(o, g, state, check_jac=True):
+    ro = o.evaluate(state, jac=True, normal_eq=True)
+    rg = g.evaluate(state, jac=check_jac, normal_eq=True)
+    nt = o.tangent_size
+    assert rg["residuals"].shape == ro["residuals"].shape
+    rs = np.abs(ro["residuals"]).max()
+    assert np.abs(rg["residuals"] - ro["residuals"]).max() <= 1e-11 * rs
+    assert abs(rg["cost"] - ro["cost"]) <= 1e-12 * abs(ro["cost"])
+    if check_jac:
+        Jo = O.dense_jacobian(ro["jac_cols"], ro["jac_vals"], nt)
+        Jg = O.dense_jacobian(rg["jac_cols"], rg["jac_vals"], nt)
+        assert np.abs(Jo - Jg).max() <= 1e-9 * np.abs(Jo).max()
+    Hs = np.abs(ro["H"]).max()
+    assert np.abs(rg["H"] - ro["H"]).max() <= 1e-10 * Hs
+    assert np.abs(rg["g"] - ro["g"]).max() <= 1e-10 * np.abs(ro["g"]).max()
+    return ro, rg
+
+
+@pytest.mark.parametrize("seed", [4, 5])
+def test_full_lvi_parity(seed):
+    P = synth.make_problem(seed=seed, duration=2.0, n_surfel=700, n_planes=12, n_landmarks=30, n_camsurf=10)
+    o, g = _pair(P, TAU_LOCKS)
+    _compare(o, g, P["state0"])
+    _compare(o, g, P["state_true"])
+    g.close()
+
+
+def test_imu_only_config3_shape():
+    P = synth.make_problem(seed=3, duration=3.0, n_surfel=0, n_planes=1, n_landmarks=0)
+    o, g = _pair(P, TAU_LOCKS, prior=False)
+    _compare(o, g, P["state0"])
+    g.close()
+
+
+@pytest.mark.parametrize("locks", [
+    TAU_LOCKS | lvx.LOCK_CAM_Q | lvx.LOCK_CAM_P,                                  # Solve #1: camera locked
+    TAU_LOCKS | lvx.LOCK_TRAJ | lvx.LOCK_LIDAR_Q | lvx.LOCK_LIDAR_P,              # Solve #3: trajectory + lidar locked
+    TAU_LOCKS | lvx.LOCK_ACC_BIAS | lvx.LOCK_GYRO_BIAS | lvx.LOCK_LANDMARKS,
+])
+def test_lock_masks(locks):
+    P = synth.make_problem(seed=7, duration=1.5, n_surfel=300, n_planes=8, n_landmarks=20, n_camsurf=6)
+    o, g = _pair(P, locks)
+    _compare(o, g, P["state0"])
+    g.close()
+
+
+def test_so3_only_solve0():
+    P = synth.make_problem(seed=8, duration=1.5, n_surfel=0, n_planes=1, n_landmarks=0)
+    o, g = _pair(P, TAU_LOCKS | lvx.LOCK_R3 | lvx.LOCK_ACC_BIAS | lvx.LOCK_GYRO_BIAS)
+    o.set_so3_only(True)
+    _compare(o, g, P["state0"])
+    g.close()
+
+
+def test_distortion_camera():
+    cam = dict(synth.DEFAULT_CAMERA, k1=-0.0397646985948, k2=0.00802944041788, p1=-0.0043042199686, p2=-0.0001040279967, k3=0.00030608999077)
+    P = synth.make_problem(seed=9, duration=1.5, n_surfel=100, n_planes=5, n_landmarks=25, n_camsurf=5, camera=cam)
+    o, g = _pair(P, TAU_LOCKS)
+    _compare(o, g, P["state0"])
+    g.close()
+
+
+def test_range_error_maps_to_code():
+    P = synth.make_problem(seed=10, duration=1.0, n_surfel=50, n_planes=4, n_landmarks=0)
+    P["t_imu"] = P["t_imu"].copy()
+    P["t_imu"][-1] = P["t0"] + (P["n_knots"] - 3) * P["dt"] + 0.5     # beyond MaxTime -> std::range_error in the reference
+    o, g = _pair(P, TAU_LOCKS, prior=False)
+    with pytest.raises(IndexError):
+        o.evaluate(P["state0"])
+    with pytest.raises(lvx.LvxError) as ei:
+        g.evaluate(P["state0"])
+    assert ei.value.code == lvx.E_RANGE
+    g.close()
+
+
+def test_nonunit_quaternion_maps_to_code():
+    P = synth.make_problem(seed=11, duration=1.0, n_surfel=0, n_planes=1, n_landmarks=0)
+    s = P["state0"].copy()
+    N = P["n_knots"]
+    s[3 * N + 4 * (N // 2): 3 * N + 4 * (N // 2) + 4] *= 1.01
+    o, g = _pair(P, TAU_LOCKS, prior=False)
+    with pytest.raises(ValueError):
+        o.evaluate(s)
+    with pytest.raises(lvx.LvxError) as ei:
+        g.evaluate(s)
+    assert ei.value.code == lvx.E_NONUNIT_QUAT
+    g.close()
+
+
+def test_empty_problem():
+    P = synth.make_problem(seed=12, duration=1.0, n_surfel=0, n_planes=1, n_landmarks=0)
+    g = lvx.Context(0)
+    g.set_spline(P["t0"], P["dt"], P["n_knots"])
+    r = g.evaluate(P["state0"][: 7 * P["n_knots"] + 32], normal_eq=True)
+    assert r["cost"] == 0.0 and r["residuals"].size == 0 and not r["H"].any()
+    g.close()
