@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""bench.py — residual+Jacobian+normal-equation evaluations per second of the LVI-ExC calibration solve on MI355X.
+
+One "step" = one pass of the hot path over the whole synthetic problem of BASELINE.json config 4
+(1 M LiDAR surfel + 200 k IMU samples [= 200 k gyro + 200 k accel blocks] + 50 k ORB reprojection blocks):
+every residual block's residual, analytic Jacobian, Huber scaling, and the J^T J / J^T r assembly into the
+structured normal equations, with the state and all measurement arrays already resident in HBM.
+N > 1: one independent calibration sequence per GPU (weak scaling, seed 40 + rank), no data-path collective;
+the only exchange is one RCCL all-reduce per step of the shared-calibration block of the normal equations.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel
+(LiDAR surfel, measured with HIP events on the library's own stream) and `cpu_baseline` (the oracle — a
+restatement of the reference's per-block autodiff evaluator — timed on a bounded sample on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "lvi-exc_amd"))
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_VALU_PEAK_TFLOPS = 78.6  # SURVEY.md §8d (vector FP64; the solve is VALU-bound, not HBM-bound)
+# algorithmic bytes per residual block, SURVEY.md §8(d)
+BYTES_PER_EVAL = {"imu": 32, "surfel": 60, "reproj": 60}
+
+
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (os.cpu_count() reports the host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(P, seconds_budget=20.0):
+    """Oracle (port of the reference's per-block dual-number evaluator) on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    import lvx
+    import synth
+    ns, ni, nr = 20000, 4000, 1000   # same 20 : 4(+4) : 1 mix as the full problem
+    rng = np.random.default_rng(0)
+    si = np.sort(rng.choice(len(P["surf_t"]), ns, replace=False))
+    ii = np.sort(rng.choice(len(P["t_imu"]), ni, replace=False))
+    lm_sel = np.arange(nr // 10)
+    rmask = np.isin(P["rep_lm"], lm_sel)
+    Q = dict(P)
+    Q.update(surf_pt=P["surf_pt"][si], surf_t=P["surf_t"][si], surf_plane=P["surf_plane"][si], t_imu=P["t_imu"][ii], gyro=P["gyro"][ii], acc=P["acc"][ii],
+             rep_lm=P["rep_lm"][rmask], rep_uv=P["rep_uv"][rmask], rep_t0=P["rep_t0"][rmask])
+    o = O.Oracle()
+    lvx.load_problem(o, Q, lvx.LOCK_LIDAR_TAU | lvx.LOCK_CAM_TAU)
+    cores = usable_cores()
+    o.set_threads(cores)
+    blocks = o.num_blocks
+    o.evaluate(P["state0"], jac=True)  # warm
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        o.evaluate(P["state0"], jac=True)
+        reps += 1
+        if time.perf_counter() - t0 > seconds_budget or reps >= 50:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": blocks * reps / dt / 1e6, "unit": "Mevals/s", "cores": cores, "kind": "port",
+            "sample": "%d surfel + %d gyro + %d accel + %d reprojection blocks x %d passes: residual + stride-4 dual-number Jacobian per block "
+                      "(cost profile of ceres::DynamicAutoDiffCostFunction), OpenMP over blocks; J^T J not included" % (ns, ni, ni, int(rmask.sum()), reps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--small", action="store_true", help="1/10 size problem (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import lvx
+    import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+
+    scale = 10 if args.small else 1
+    n_surf, n_imu, n_rep = 1_000_000 // scale, 200_000 // scale, 50_000 // scale
+    P = synth.make_bench_problem(seed=4 if world == 1 else 40 + rank, n_imu=n_imu, n_surfel=n_surf, n_reproj=n_rep, n_planes=2000 // scale)
+    ctx = lvx.Context(local_rank)
+    lvx.load_problem(ctx, P, lvx.LOCK_LIDAR_TAU | lvx.LOCK_CAM_TAU)
+    lo = ctx.layout()
+    ctx.set_state(P["state0"])
+    if world > 1:
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)   # evaluation, export and the all-reduce share one stream
+    what = lvx.EVAL_COST | lvx.EVAL_NORMAL_EQ
+    nbd = lo["n_border"]
+    red = torch.zeros(nbd * nbd + nbd + 1, dtype=torch.float64, device="cuda") if world > 1 else None
+
+    def step():
+        ctx.evaluate_resident(what)
+        if world > 1:
+            ctx.export_border(red.data_ptr())   # shared-calibration block of J^T J, J^T r, cost
+            dist.all_reduce(red)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize()
+    ctx.set_profiling(True)
+    ctx.kernel_ms()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ms, launches = ctx.kernel_ms()
+    ctx.set_profiling(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    cost = ctx.evaluate_resident(lvx.EVAL_COST, want_cost=True)
+
+    blocks = lo["n_blocks"]
+    value = blocks * world * args.steps / elapsed / 1e6
+    out = {
+        "metric": "M residual+Jacobian evals/s per GN iter", "value": value, "unit": "Mevals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "config4-full-LVI: %d surfel + %d IMU samples (gyro+accel blocks) + %d ORB reprojection blocks, %d knots @ dt=0.02; "
+                               "step = residuals + analytic Jacobians + Huber + J^T J/J^T r assembly (no linear solve)" % (n_surf, n_imu, len(P["rep_lm"]), lo["n_knots"]),
+                   "blocks_per_step_per_gpu": int(blocks), "n_tangent": lo["n_tangent"], "bandwidth": lo["bandwidth"], "n_border": lo["n_border"],
+                   "parallelism": "sequence-per-gpu x%d" % world, "cost": cost},
+    }
+    if rank == 0:
+        k = lvx.FAM_SURFEL
+        surf_ms = ms[k] / max(1, launches[k])
+        alg_bytes = BYTES_PER_EVAL["surfel"] * n_surf
+        achieved = alg_bytes / (surf_ms * 1e-3) / 1e9 if surf_ms > 0 else 0.0
+        out["roofline"] = {"bound": "hbm", "kernel": "k_family<SurfFam>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                           "traffic": None, "avg_launch_ms": surf_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                           "note": "the fused residual+Jacobian+J^T J kernel is FP64-VALU/atomic bound, not HBM bound (SURVEY.md 8d): ~9 kFLOP per 60 B",
+                           "fp64_valu": {"achieved_tflops": 9e3 * n_surf / (surf_ms * 1e-3) / 1e12 if surf_ms > 0 else 0.0, "peak_tflops": FP64_VALU_PEAK_TFLOPS}}
+        names = ["gyro", "accel", "prior", "surfel", "reproj", "camsurf", "fold", "solve"]
+        out["kernel_ms"] = {names[i]: ms[i] / max(1, launches[i]) for i in range(8) if launches[i]}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(P)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -140,6 +140,24 @@ int lvx_evaluate_d(lvx_ctx* ctx, const double* state_d, uint32_t what, double* c
 int lvx_get_normal_eq_dense(lvx_ctx* ctx, double* H, double* g);
 /* debug / parity: rows of the last LVX_EVAL_JACOBIAN evaluation: cols[n_residuals][LVX_JAC_WIDTH] (-1 = unused), vals likewise (pre-loss) */
 int lvx_get_jacobian(lvx_ctx* ctx, int32_t* cols, double* vals);
+/* run on a caller-owned HIP stream (e.g. torch's current stream) instead of the context's own; NULL restores the own stream */
+int lvx_set_stream(lvx_ctx* ctx, void* hip_stream);
+/* multi-GPU (one calibration sequence per GPU): copy the dense border block of the last normal equations —
+ * C[n_border^2] (lower triangle), g_c[n_border], cost — into a caller-owned DEVICE buffer of n_border^2 + n_border + 1 doubles,
+ * queued on the context's stream, ready for one RCCL all-reduce */
+int lvx_export_border_d(lvx_ctx* ctx, double* out_d);
+/* keep `state` resident in the context's device buffer; lvx_evaluate_d(ctx, NULL, ...) then evaluates it without any host traffic */
+int lvx_set_state(lvx_ctx* ctx, const double* state);
+int lvx_get_state(lvx_ctx* ctx, double* state_out);
+/* block until every launch queued on the context's stream has finished; returns the first device-side error of the last evaluation */
+int lvx_synchronize(lvx_ctx* ctx);
+/* per-kernel timing with HIP events recorded on the context's own stream around every launch (no host sync until read).
+ * lvx_get_kernel_ms: sum of durations [ms] and launch counts since the last call, indexed by LVX_FAM_* (+ LVX_KERNEL_* below). */
+#define LVX_KERNEL_FOLD 6
+#define LVX_KERNEL_SOLVE 7
+#define LVX_NUM_KERNELS 8
+int lvx_set_profiling(lvx_ctx* ctx, int enable);
+int lvx_get_kernel_ms(lvx_ctx* ctx, double* ms_sum, int64_t* launches);
 /* x (+) delta with ceres::EigenQuaternionParameterization::Plus on quaternion blocks */
 int lvx_plus(lvx_ctx* ctx, const double* state, const double* delta, double* state_out);
 

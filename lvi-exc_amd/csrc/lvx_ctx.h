@@ -59,6 +59,7 @@ struct Family {
 struct lvx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;
   std::string last_error;
   // problem
   bool have_spline = false;
@@ -83,6 +84,12 @@ struct lvx_ctx {
   int64_t n_blocks = 0, n_residuals = 0;
   int64_t fam_row0[LVX_NUM_FAM + 1] = {0};
   uint32_t last_what = 0;
+  // profiling: (start, stop) event pairs per launch, read lazily by lvx_get_kernel_ms
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  struct EvRec { int kernel; size_t e0, e1; };
+  std::vector<EvRec> ev_recs;
 };
 
 namespace lvx {
@@ -91,6 +98,12 @@ int dev_alloc(lvx_ctx* ctx, DevBuf& b, size_t bytes);
 int upload(lvx_ctx* ctx, DevBuf& b, const void* src, size_t bytes);
 int ensure_layout(lvx_ctx* ctx);
 DevCommon make_common(lvx_ctx* ctx, const double* state_d, uint32_t what);
+// profiling scope: records a (start, stop) HIP event pair on ctx->stream around a launch when profiling is on
+struct ProfScope {
+  lvx_ctx* c; int kernel; size_t e0 = 0; bool on;
+  ProfScope(lvx_ctx* ctx, int k);
+  ~ProfScope();
+};
 }  // namespace lvx
 
 #define LVX_HIP(ctx, expr)                                                                  \

@@ -502,6 +502,24 @@ DevCommon make_common(lvx_ctx* ctx, const double* state_d, uint32_t what) {
   return cm;
 }
 
+static size_t next_event(lvx_ctx* c) {
+  if (c->ev_used == c->ev_pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return (size_t)-1; c->ev_pool.push_back(e); }
+  return c->ev_used++;
+}
+ProfScope::ProfScope(lvx_ctx* ctx, int k) : c(ctx), kernel(k), on(ctx->profiling) {
+  if (!on) return;
+  e0 = next_event(c);
+  if (e0 == (size_t)-1) { on = false; return; }
+  (void)hipEventRecord(c->ev_pool[e0], c->stream);
+}
+ProfScope::~ProfScope() {
+  if (!on) return;
+  const size_t e1 = next_event(c);
+  if (e1 == (size_t)-1) return;
+  (void)hipEventRecord(c->ev_pool[e1], c->stream);
+  c->ev_recs.push_back(lvx_ctx::EvRec{kernel, e0, e1});
+}
+
 static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cost, bool want_res_buffer) {
   int rc = ensure_layout(ctx);
   if (rc) return rc;
@@ -531,9 +549,11 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
   auto grid = [](int n) { return dim3((unsigned)((n + 63) / 64)); };
   if (ctx->imu.n > 0) {
     GyroFam g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
-    hipLaunchKernelGGL(k_family<GyroFam>, grid(g.n), dim3(64), 0, st, g, cm, (const uint16_t*)ctx->d_pairs[0].p, (long long)ctx->fam_row0[0]);
+    { ProfScope ps(ctx, LVX_FAM_GYRO);
+    hipLaunchKernelGGL(k_family<GyroFam>, grid(g.n), dim3(64), 0, st, g, cm, (const uint16_t*)ctx->d_pairs[0].p, (long long)ctx->fam_row0[0]); }
     if (!(ctx->locks & LVX_LOCK_R3)) {
       AccelFam a{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.huber /*w_acc*/, 0.0};
+      ProfScope ps(ctx, LVX_FAM_ACCEL);
       hipLaunchKernelGGL(k_family<AccelFam>, grid(a.n), dim3(64), 0, st, a, cm, (const uint16_t*)ctx->d_pairs[1].p, (long long)ctx->fam_row0[1]);
     }
   }
@@ -542,24 +562,29 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     DevBuf& pb = ctx->d_zero;   // identity permutation for the single prior block
     if ((rc = upload(ctx, pb, &zero, 4))) return rc;
     PriorFam p{1, ctx->prior_t, mkq(ctx->prior_q[0], ctx->prior_q[1], ctx->prior_q[2], ctx->prior_q[3]), (const int*)pb.p, ctx->prior_w, 0.0};
+    ProfScope ps(ctx, LVX_FAM_PRIOR);
     hipLaunchKernelGGL(k_family<PriorFam>, dim3(1), dim3(64), 0, st, p, cm, (const uint16_t*)ctx->d_pairs[2].p, (long long)ctx->fam_row0[2]);
   }
   if (ctx->surf.n > 0) {
     SurfFam s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
               (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
+    ProfScope ps(ctx, LVX_FAM_SURFEL);
     hipLaunchKernelGGL(k_family<SurfFam>, grid(s.n), dim3(64), 0, st, s, cm, (const uint16_t*)ctx->d_pairs[3].p, (long long)ctx->fam_row0[3]);
   }
   if (ctx->rep.n > 0) {
     ReprojFam r{ctx->rep.n, (const int*)ctx->rep.d_id0.p, (const double*)ctx->rep.d_a3.p, (const double*)ctx->rep.d_t.p, (const int*)ctx->rep.d_perm.p,
                 (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->rep.weight, ctx->rep.huber};
+    ProfScope ps(ctx, LVX_FAM_REPROJ);
     hipLaunchKernelGGL(k_family<ReprojFam>, grid(r.n), dim3(64), 0, st, r, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
   }
   if (ctx->cs.n > 0) {
     CamSurfFam c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
                  (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
+    ProfScope ps(ctx, LVX_FAM_CAMSURF);
     hipLaunchKernelGGL(k_family<CamSurfFam>, grid(c.n), dim3(64), 0, st, c, cm, (const uint16_t*)ctx->d_pairs[5].p, (long long)ctx->fam_row0[5]);
   }
-  hipLaunchKernelGGL(k_fold_replicas, dim3((unsigned)((ctx->nbd * ctx->nbd + 255) / 256)), dim3(256), 0, st, cm);
+  { ProfScope ps(ctx, LVX_KERNEL_FOLD);
+  hipLaunchKernelGGL(k_fold_replicas, dim3((unsigned)((ctx->nbd * ctx->nbd + 255) / 256)), dim3(256), 0, st, cm); }
   LVX_HIP(ctx, hipGetLastError());
   ctx->last_what = what;
   if (cost) {
@@ -594,7 +619,8 @@ int lvx_create(lvx_ctx** out, int device, uint32_t /*flags*/) {
   lvx_ctx* c = new (std::nothrow) lvx_ctx();
   if (!c) return LVX_E_ALLOC;
   c->device = device;
-  if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return LVX_E_HIP; }
+  if (hipStreamCreate(&c->own_stream) != hipSuccess) { delete c; return LVX_E_HIP; }
+  c->stream = c->own_stream;
   *out = c;
   return LVX_OK;
 }
@@ -609,7 +635,8 @@ void lvx_destroy(lvx_ctx* c) {
                     &c->d_res, &c->d_jcols, &c->d_jvals, &c->d_L, &c->d_Y, &c->d_S, &c->d_delta, &c->d_diag, &c->d_scal, &c->d_state_try, &c->d_zero})
     if (b->p) (void)hipFree(b->p);
   for (auto& b : c->d_pairs) if (b.p) (void)hipFree(b.p);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
 
@@ -679,8 +706,9 @@ int lvx_get_layout(lvx_ctx* c, lvx_layout* o) {
 }
 
 int lvx_evaluate_d(lvx_ctx* c, const double* state_d, uint32_t what, double* cost) {
-  if (!c || !state_d) return LVX_E_ARG;
+  if (!c) return LVX_E_ARG;
   LVX_HIP(c, hipSetDevice(c->device));
+  if (!state_d) { int rc = ensure_layout(c); if (rc) return rc; state_d = (const double*)c->d_state.p; }
   return run_evaluate(c, state_d, what, cost, false);
 }
 
@@ -698,6 +726,65 @@ int lvx_evaluate(lvx_ctx* c, const double* state, uint32_t what, double* cost, d
     LVX_HIP(c, hipMemcpyAsync(residuals, c->d_res.p, (size_t)c->n_residuals * 8, hipMemcpyDeviceToHost, c->stream));
     LVX_HIP(c, hipStreamSynchronize(c->stream));
   }
+  return LVX_OK;
+}
+
+int lvx_set_stream(lvx_ctx* c, void* s) {
+  if (!c) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return LVX_OK;
+}
+int lvx_export_border_d(lvx_ctx* c, double* out_d) {
+  if (!c || !out_d) return LVX_E_ARG;
+  if (!(c->last_what & LVX_EVAL_NORMAL_EQ)) return fail(c, LVX_E_STATE, "last evaluation did not request LVX_EVAL_NORMAL_EQ");
+  LVX_HIP(c, hipSetDevice(c->device));
+  const size_t n2 = (size_t)c->nbd * c->nbd;
+  LVX_HIP(c, hipMemcpyAsync(out_d, c->d_C.p, n2 * 8, hipMemcpyDeviceToDevice, c->stream));
+  LVX_HIP(c, hipMemcpyAsync(out_d + n2, c->d_gc.p, (size_t)c->nbd * 8, hipMemcpyDeviceToDevice, c->stream));
+  LVX_HIP(c, hipMemcpyAsync(out_d + n2 + c->nbd, c->d_cost.p, 8, hipMemcpyDeviceToDevice, c->stream));
+  return LVX_OK;
+}
+int lvx_set_state(lvx_ctx* c, const double* state) {
+  if (!c || !state) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  int rc = ensure_layout(c); if (rc) return rc;
+  LVX_HIP(c, hipMemcpyAsync(c->d_state.p, state, (size_t)lvx_state_size(c) * 8, hipMemcpyHostToDevice, c->stream));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  return LVX_OK;
+}
+int lvx_get_state(lvx_ctx* c, double* out) {
+  if (!c || !out) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  int rc = ensure_layout(c); if (rc) return rc;
+  LVX_HIP(c, hipMemcpyAsync(out, c->d_state.p, (size_t)lvx_state_size(c) * 8, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  return LVX_OK;
+}
+int lvx_synchronize(lvx_ctx* c) {
+  if (!c) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  if (!c->d_err.p) return LVX_OK;
+  int err = 0;
+  LVX_HIP(c, hipMemcpy(&err, c->d_err.p, 4, hipMemcpyDeviceToHost));
+  if (err & RES_RANGE) return fail(c, LVX_E_RANGE, "time span out of range for trajectory");
+  if (err & RES_NONUNIT) return fail(c, LVX_E_NONUNIT_QUAT, "logq: only implemented for unit quaternions");
+  if (err & 4) return fail(c, LVX_E_STATE, "normal-equation entry outside the computed bandwidth");
+  return LVX_OK;
+}
+int lvx_set_profiling(lvx_ctx* c, int enable) { if (!c) return LVX_E_ARG; c->profiling = enable != 0; return LVX_OK; }
+int lvx_get_kernel_ms(lvx_ctx* c, double* ms_sum, int64_t* launches) {
+  if (!c || !ms_sum || !launches) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  for (int k = 0; k < LVX_NUM_KERNELS; ++k) { ms_sum[k] = 0.0; launches[k] = 0; }
+  for (const auto& r : c->ev_recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev_pool[r.e0], c->ev_pool[r.e1]) == hipSuccess && r.kernel >= 0 && r.kernel < LVX_NUM_KERNELS) { ms_sum[r.kernel] += ms; launches[r.kernel] += 1; }
+  }
+  c->ev_recs.clear(); c->ev_used = 0;
   return LVX_OK;
 }
 

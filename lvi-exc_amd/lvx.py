@@ -26,6 +26,7 @@ LOCK_GYRO_BIAS = 1 << 9
 LOCK_LANDMARKS = 1 << 10
 
 EVAL_COST, EVAL_RESIDUALS, EVAL_NORMAL_EQ, EVAL_JACOBIAN = 1, 2, 4, 8
+FAM_GYRO, FAM_ACCEL, FAM_PRIOR, FAM_SURFEL, FAM_REPROJ, FAM_CAMSURF, KERNEL_FOLD, KERNEL_SOLVE = range(8)
 JAC_WIDTH = 64
 
 
@@ -181,6 +182,44 @@ class Context:
             self._ck(self._l.lvx_get_normal_eq_dense(self._h, _p(H), _p(g)))
             out["H"], out["g"] = H, g
         return out
+
+    def set_state(self, state):
+        state = _d(state)
+        assert state.size == self.state_size
+        self._ck(self._l.lvx_set_state(self._h, _p(state)))
+
+    def get_state(self):
+        out = np.zeros(self.state_size)
+        self._ck(self._l.lvx_get_state(self._h, _p(out)))
+        return out
+
+    def evaluate_resident(self, what=EVAL_COST | EVAL_NORMAL_EQ, want_cost=False):
+        """Queue one evaluation of the resident state on the context's stream (asynchronous unless want_cost)."""
+        if want_cost:
+            cost = C.c_double(0)
+            self._ck(self._l.lvx_evaluate_d(self._h, None, C.c_uint32(what), C.byref(cost)))
+            return cost.value
+        self._ck(self._l.lvx_evaluate_d(self._h, None, C.c_uint32(what), None))
+        return None
+
+    def set_stream(self, stream_handle):
+        """Use a caller-owned HIP stream (int handle, e.g. torch.cuda.current_stream().cuda_stream); 0/None = own stream."""
+        self._ck(self._l.lvx_set_stream(self._h, C.c_void_p(stream_handle or None)))
+
+    def export_border(self, device_ptr):
+        self._ck(self._l.lvx_export_border_d(self._h, C.c_void_p(device_ptr)))
+
+    def synchronize(self):
+        self._ck(self._l.lvx_synchronize(self._h))
+
+    def set_profiling(self, on):
+        self._ck(self._l.lvx_set_profiling(self._h, C.c_int(1 if on else 0)))
+
+    def kernel_ms(self):
+        ms = np.zeros(8)
+        n = np.zeros(8, dtype=np.int64)
+        self._ck(self._l.lvx_get_kernel_ms(self._h, _p(ms), _p(n)))
+        return ms, n
 
     def plus(self, state, delta):
         state, delta = _d(state), _d(delta)

@@ -335,7 +335,9 @@ def make_bench_problem(seed=4, n_imu=200_000, n_surfel=1_000_000, n_reproj=50_00
     roll, pitch = 0.02, -0.015
     ba = np.array([0.05, 0.02, -0.03]); bg = np.array([0.01, -0.02, 0.005])
     g = gravity_vec(roll, pitch)
-    t_imu = t_start + np.arange(n_imu) / imu_rate
+    # +0.37 sample: real IMU stamps never sit exactly on knot times; exact coincidences make the reference throw
+    # "No segment found" through the 4-knot segment bounds (spline_base.h:196-221) depending on rounding
+    t_imu = t_start + (np.arange(n_imu) + 0.37) / imu_rate
     e = sp.eval(t_imu)
     gyro = qrot(qconj(e["quat"]), e["angvel"]) + bg + 1.745e-4 * np.sqrt(imu_rate) * rng.standard_normal((n_imu, 3))
     acc = qrot(qconj(e["quat"]), e["acc"] + g) + ba + 5.88e-4 * np.sqrt(imu_rate) * rng.standard_normal((n_imu, 3))
