@@ -158,6 +158,43 @@ int lvx_synchronize(lvx_ctx* ctx);
 #define LVX_NUM_KERNELS 8
 int lvx_set_profiling(lvx_ctx* ctx, int enable);
 int lvx_get_kernel_ms(lvx_ctx* ctx, double* ms_sum, int64_t* launches);
+/* Levenberg-Marquardt --------------------------------------------------------------------------------------------
+ * Replaces ceres::Solve as configured by TrajectoryEstimator::Solve (kontiki/trajectory_estimator.h:38-68: TRUST_REGION,
+ * LEVENBERG_MARQUARDT, SPARSE_SCHUR, max_num_iterations per stage; everything else Ceres defaults).  The trust-region loop,
+ * LM damping and Jacobi scaling are restated from Ceres' public semantics (out-of-tree, parity unpinned). */
+typedef struct lvx_lm_options {
+  int32_t max_iterations;          /* options.max_num_iterations (30 / 50 / 80 / 200 per stage: trajectory_manager_lvi.cpp:60,86,125,182,244,340) */
+  double initial_radius;           /* 1e4  */
+  double max_radius;               /* 1e16 */
+  double min_radius;               /* 1e-32 */
+  double min_relative_decrease;    /* 1e-3 */
+  double min_lm_diagonal;          /* 1e-6 */
+  double max_lm_diagonal;          /* 1e32 */
+  double function_tolerance;       /* 1e-6 */
+  double gradient_tolerance;       /* 1e-10 */
+  double parameter_tolerance;      /* 1e-8 */
+  int32_t jacobi_scaling;          /* 1 */
+  int32_t verbose;
+} lvx_lm_options;
+#define LVX_LM_NO_CONVERGENCE 0
+#define LVX_LM_FUNCTION_TOLERANCE 1
+#define LVX_LM_PARAMETER_TOLERANCE 2
+#define LVX_LM_GRADIENT_TOLERANCE 3
+#define LVX_LM_MAX_ITERATIONS 4
+#define LVX_LM_FAILURE 5
+typedef struct lvx_lm_summary {
+  int32_t iterations, successful_steps, termination;
+  double initial_cost, final_cost, final_radius;
+} lvx_lm_summary;
+int lvx_lm_default_options(lvx_lm_options* opt);
+/* minimise from `state` (in/out, host); summary may be NULL */
+int lvx_lm_solve(lvx_ctx* ctx, double* state, const lvx_lm_options* opt, lvx_lm_summary* summary);
+/* per-iteration trace of the last lvx_lm_solve: cost after the iteration, trust-region radius, accepted (1) / rejected (0) / invalid (-1); returns count */
+int lvx_lm_get_history(lvx_ctx* ctx, int max_n, double* cost, double* radius, int32_t* accepted);
+/* one damped solve on the normal equations of the last LVX_EVAL_NORMAL_EQ evaluation:
+ * (S H S + clamp(diag(S H S), 1e-6, 1e32) / radius) y = -S g, delta = S y (S = Jacobi scaling or identity); delta[n_tangent] on the host */
+int lvx_solve_step(lvx_ctx* ctx, double radius, int jacobi_scaling, double* delta, double* model_cost_change);
+
 /* x (+) delta with ceres::EigenQuaternionParameterization::Plus on quaternion blocks */
 int lvx_plus(lvx_ctx* ctx, const double* state, const double* delta, double* state_out);
 

@@ -84,6 +84,8 @@ struct lvx_ctx {
   int64_t n_blocks = 0, n_residuals = 0;
   int64_t fam_row0[LVX_NUM_FAM + 1] = {0};
   uint32_t last_what = 0;
+  std::vector<double> lm_cost, lm_radius;
+  std::vector<int> lm_accept;
   // profiling: (start, stop) event pairs per launch, read lazily by lvx_get_kernel_ms
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;

@@ -295,8 +295,10 @@ __global__ __launch_bounds__(64) void k_family(F fam, DevCommon cm, const uint16
 __global__ void k_fold_replicas(DevCommon cm) {
   const int n2 = cm.nbd * cm.nbd;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n2) { double s = 0; for (int r = 0; r < LVX_NREP; ++r) s += cm.C[(size_t)r * n2 + i]; cm.C[i] = s; }
-  if (i < cm.nbd) { double s = 0; for (int r = 0; r < LVX_NREP; ++r) s += cm.gc[(size_t)r * cm.nbd + i]; cm.gc[i] = s; }
+  if (cm.what & LVX_EVAL_NORMAL_EQ) {
+    if (i < n2) { double s = 0; for (int r = 0; r < LVX_NREP; ++r) s += cm.C[(size_t)r * n2 + i]; cm.C[i] = s; }
+    if (i < cm.nbd) { double s = 0; for (int r = 0; r < LVX_NREP; ++r) s += cm.gc[(size_t)r * cm.nbd + i]; cm.gc[i] = s; }
+  }
   if (i == 0) { double s = 0; for (int r = 0; r < LVX_NREP; ++r) s += cm.cost[r]; cm.cost[0] = s; }
 }
 

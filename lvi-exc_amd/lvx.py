@@ -42,6 +42,21 @@ class Layout(C.Structure):
                 ("n_blocks", C.c_int64), ("n_residuals", C.c_int64)]
 
 
+class LmOptions(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("initial_radius", C.c_double), ("max_radius", C.c_double), ("min_radius", C.c_double),
+                ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+                ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+                ("jacobi_scaling", C.c_int32), ("verbose", C.c_int32)]
+
+
+class LmSummary(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("successful_steps", C.c_int32), ("termination", C.c_int32),
+                ("initial_cost", C.c_double), ("final_cost", C.c_double), ("final_radius", C.c_double)]
+
+
+LM_TERMINATION = ["no_convergence", "function_tolerance", "parameter_tolerance", "gradient_tolerance", "max_iterations", "failure"]
+
+
 class LvxError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("lvx error %d: %s" % (code, msg))
@@ -220,6 +235,31 @@ class Context:
         n = np.zeros(8, dtype=np.int64)
         self._ck(self._l.lvx_get_kernel_ms(self._h, _p(ms), _p(n)))
         return ms, n
+
+    def solve_step(self, radius, jacobi_scaling=True):
+        """One damped solve on the normal equations of the last evaluate(normal_eq=True): returns (delta, model_cost_change)."""
+        delta = np.zeros(self.tangent_size)
+        mcc = C.c_double(0)
+        self._ck(self._l.lvx_solve_step(self._h, C.c_double(radius), C.c_int(1 if jacobi_scaling else 0), _p(delta), C.byref(mcc)))
+        return delta, mcc.value
+
+    def lm_solve(self, state, max_iterations=50, **kw):
+        """TrajectoryEstimator::Solve(max_iterations) equivalent.  Returns (state, summary dict with per-iteration history)."""
+        opt = LmOptions()
+        self._l.lvx_lm_default_options(C.byref(opt))
+        opt.max_iterations = max_iterations
+        for k, v in kw.items():
+            setattr(opt, k, v)
+        x = _d(state).copy()
+        sm = LmSummary()
+        self._ck(self._l.lvx_lm_solve(self._h, _p(x), C.byref(opt), C.byref(sm)))
+        n = 4 * max_iterations + 8
+        cost, rad, acc = np.zeros(n), np.zeros(n), np.zeros(n, dtype=np.int32)
+        k = self._l.lvx_lm_get_history(self._h, C.c_int(n), _p(cost), _p(rad), _p(acc))
+        out = {f: getattr(sm, f) for f, _ in LmSummary._fields_}
+        out["termination"] = LM_TERMINATION[sm.termination]
+        out.update(cost_history=cost[:k], radius_history=rad[:k], accepted=acc[:k])
+        return x, out
 
     def plus(self, state, delta):
         state, delta = _d(state), _d(delta)

@@ -1,0 +1,86 @@
+"""GPU parity of the LM step and loop (lvx_solve_step / lvx_lm_solve) vs the numpy/oracle restatement (oracle/lm.py).
+
+Tolerances: one damped solve — step within 1e-7 of the dense numpy solve relative to the largest step entry (the
+damped systems have condition numbers ~1e9-1e12); full LM from the same start — same accept/reject sequence, cost
+history within 1e-7 relative, converged extrinsics within 1e-6 rad / 1e-4 m (BASELINE.json north_star).
+"""
+import numpy as np
+import pytest
+
+import lvx
+import synth
+from oracle import lm
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+TAU_LOCKS = lvx.LOCK_LIDAR_TAU | lvx.LOCK_CAM_TAU
+
+
+def _qang(a, b):
+    d = synth.qmul(a, synth.qconj(b))
+    return 2 * np.arctan2(np.linalg.norm(d[:3]), abs(d[3]))
+
+
+@pytest.mark.parametrize("scaling", [True, False])
+@pytest.mark.parametrize("radius", [1e4, 3.0])
+def test_solve_step_matches_dense(scaling, radius):
+    P = synth.make_problem(seed=14, duration=2.0, n_surfel=500, n_planes=10, n_landmarks=25, n_camsurf=5)
+    o = O.Oracle(); g = lvx.Context(0)
+    for obj in (o, g):
+        lvx.load_problem(obj, P, TAU_LOCKS)
+    ro = o.evaluate(P["state0"], normal_eq=True)
+    g.evaluate(P["state0"], normal_eq=True, dense=False)
+    d_gpu, m_gpu = g.solve_step(radius, scaling)
+    free = lm.free_tangent_indices(P["n_knots"], P["n_landmarks"], TAU_LOCKS)
+    scale = 1.0 / (1.0 + np.sqrt(np.maximum(np.diag(ro["H"])[free], 0))) if scaling else None
+    d_ref, m_ref, _ = lm.solve_step(ro["H"], ro["g"], free, radius, scale)
+    assert np.abs(d_gpu - d_ref).max() <= 1e-7 * np.abs(d_ref).max()
+    assert abs(m_gpu - m_ref) <= 1e-8 * abs(m_ref)
+    g.close()
+
+
+@pytest.mark.parametrize("locks,stage", [
+    (TAU_LOCKS | lvx.LOCK_CAM_Q | lvx.LOCK_CAM_P | lvx.LOCK_LANDMARKS, "solve1"),   # trajInitFromSurfel: gyro + accel + surfel, camera locked
+    (TAU_LOCKS, "solve2"),                                                           # trajInitFromLVIdata: + reprojection
+])
+def test_lm_matches_oracle(locks, stage):
+    P = synth.make_problem(seed=15, duration=2.0, n_surfel=600, n_planes=12, n_landmarks=30 if stage == "solve2" else 0, n_camsurf=0)
+    o = O.Oracle(); g = lvx.Context(0)
+    for obj in (o, g):
+        lvx.load_problem(obj, P, locks)
+    free = lm.free_tangent_indices(P["n_knots"], P["n_landmarks"], locks)
+    xo, so = lm.lm_solve(o, P["state0"], free, max_iterations=12, n_knots=P["n_knots"], n_landmarks=P["n_landmarks"])
+    xg, sg = g.lm_solve(P["state0"], max_iterations=12)
+    assert sg["iterations"] == so["iterations"] and sg["termination"] == so["termination"]
+    assert list(sg["accepted"]) == list(so["accepted"])
+    assert np.abs(sg["cost_history"] - so["cost_history"]).max() <= 1e-7 * so["cost_history"].max()
+    N, L = P["n_knots"], P["n_landmarks"]
+    ug, uo = synth.unpack_state(xg, N, L), synth.unpack_state(xo, N, L)
+    for s in ("lidar", "cam"):
+        assert _qang(ug[s][:4], uo[s][:4]) <= 1e-6
+        assert np.abs(ug[s][4:7] - uo[s][4:7]).max() <= 1e-4
+    assert sg["final_cost"] < 1e-3 * sg["initial_cost"]
+    g.close()
+
+
+def test_lm_so3_only_solve0():
+    """initialSO3TrajWithGyro: SO3-only estimator, gyro + one orientation prior (trajectory_manager_lvi.cpp:43-62)."""
+    P = synth.make_problem(seed=16, duration=2.0, n_surfel=0, n_planes=1, n_landmarks=0)
+    locks = TAU_LOCKS | lvx.LOCK_R3 | lvx.LOCK_ACC_BIAS | lvx.LOCK_GYRO_BIAS
+    N = P["n_knots"]
+    s0 = P["state0"].copy()
+    s0[3 * N:7 * N] = np.tile([0.0, 0, 0, 1], N)          # trajectory starts at identity (trajectory_manager_lvi.cpp:31-36)
+    s0[7 * N + 8:7 * N + 16] = [0.01, 0.01, 0, 0, 0, 0, 0, 0]
+    q0 = np.array([np.cos(5e-5), 0, 0, np.sin(5e-5)])
+    o = O.Oracle(); g = lvx.Context(0)
+    for obj in (o, g):
+        lvx.load_problem(obj, P, locks)
+        obj.set_orientation_prior(P["t0"], q0, 28.0)
+    o.set_so3_only(True)
+    free = lm.free_tangent_indices(N, 0, locks)
+    xo, so = lm.lm_solve(o, s0, free, max_iterations=8, n_knots=N, n_landmarks=0)
+    xg, sg = g.lm_solve(s0, max_iterations=8)
+    assert list(sg["accepted"]) == list(so["accepted"])
+    assert np.abs(sg["cost_history"] - so["cost_history"]).max() <= 1e-7 * so["cost_history"].max()
+    assert np.abs(xg - xo).max() <= 1e-6
+    g.close()
