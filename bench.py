@@ -164,8 +164,7 @@ def main():
                            "traffic": None, "avg_launch_ms": surf_ms, "algorithmic_bytes_per_launch": alg_bytes,
                            "note": "the fused residual+Jacobian+J^T J kernel is FP64-VALU/atomic bound, not HBM bound (SURVEY.md 8d): ~9 kFLOP per 60 B",
                            "fp64_valu": {"achieved_tflops": 9e3 * n_surf / (surf_ms * 1e-3) / 1e12 if surf_ms > 0 else 0.0, "peak_tflops": FP64_VALU_PEAK_TFLOPS}}
-        names = ["gyro", "accel", "prior", "surfel", "reproj", "camsurf", "fold", "solve"]
-        out["kernel_ms"] = {names[i]: ms[i] / max(1, launches[i]) for i in range(8) if launches[i]}
+        out["kernel_ms"] = {lvx.KERNEL_NAMES[i]: ms[i] / max(1, launches[i]) for i in range(len(ms)) if launches[i]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(P)
         print(json.dumps(out), flush=True)

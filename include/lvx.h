@@ -155,7 +155,8 @@ int lvx_synchronize(lvx_ctx* ctx);
  * lvx_get_kernel_ms: sum of durations [ms] and launch counts since the last call, indexed by LVX_FAM_* (+ LVX_KERNEL_* below). */
 #define LVX_KERNEL_FOLD 6
 #define LVX_KERNEL_SOLVE 7
-#define LVX_NUM_KERNELS 8
+#define LVX_KERNEL_UPSTREAM 8
+#define LVX_NUM_KERNELS 9
 int lvx_set_profiling(lvx_ctx* ctx, int enable);
 int lvx_get_kernel_ms(lvx_ctx* ctx, double* ms_sum, int64_t* launches);
 /* Levenberg-Marquardt --------------------------------------------------------------------------------------------
@@ -197,6 +198,51 @@ int lvx_solve_step(lvx_ctx* ctx, double radius, int jacobi_scaling, double* delt
 
 /* x (+) delta with ceres::EigenQuaternionParameterization::Plus on quaternion blocks */
 int lvx_plus(lvx_ctx* ctx, const double* state, const double* delta, double* state_out);
+
+/* upstream point-cloud kernels ---------------------------------------------------------------------------------------*/
+/* RsPointXYZIRT as the reference's scanRegistration receives it (src/aloam/src/scanRegistration.cpp:57-66), 32 bytes */
+typedef struct lvx_rs_point {
+  float x, y, z, pad;
+  uint8_t intensity, pad2;
+  uint16_t ring;
+  uint32_t pad3;
+  double timestamp;
+} lvx_rs_point;
+/* caller-owned host buffers with capacity n_in (scan_start/scan_end: n_rings); any pointer may be NULL.  Mirrors the globals
+ * cloudCurvature / cloudSortInd / cloudNeighborPicked / cloudLabel (scanRegistration.cpp:82-85) and the four published clouds
+ * as index lists into `cloud` (less_flat BEFORE the 0.2 m VoxelGrid of :440-444) */
+typedef struct lvx_scanreg_out {
+  int32_t n;            /* points kept after the range / NaN filter = laserCloud size */
+  float* cloud;         /* [n][4] x, y, z, intensity = ring + (t - t_first) */
+  float* curvature;     /* [n] */
+  int32_t* label;       /* [n] 2 sharp, 1 less sharp, 0 none, -1 flat */
+  int32_t* sort_ind;    /* [n] */
+  int32_t* picked;      /* [n] */
+  int32_t* scan_start;  /* [n_rings] */
+  int32_t* scan_end;    /* [n_rings] */
+  int32_t* sharp; int32_t* less_sharp; int32_t* flat; int32_t* less_flat;
+  int32_t counts[4];
+} lvx_scanreg_out;
+int lvx_scan_register(lvx_ctx* ctx, int n, const lvx_rs_point* pts, int n_rings, float min_range, lvx_scanreg_out* out);
+
+/* pclomp::VoxelGridCovariance::applyFilter (src/ndt_omp/include/pclomp/voxel_grid_covariance_omp_impl.hpp:49-374): the grid stays on the
+ * device inside the context; leaves are numbered in ascending voxel-key order (std::map iteration order of the reference) */
+typedef struct lvx_voxel_info { int32_t n_leaves, n_points; int32_t min_b[3], max_b[3], div_b[3], divb_mul[3]; } lvx_voxel_info;
+int lvx_voxel_build(lvx_ctx* ctx, int n, const float* xyzi4, float leaf_size, int min_points_per_voxel, double min_covar_eigvalue_mult, lvx_voxel_info* info);
+int lvx_voxel_build_d(lvx_ctx* ctx, int n, const float* xyzi4_d, float leaf_size, int min_points_per_voxel, double min_covar_eigvalue_mult);
+/* Leaf fields (voxel_grid_covariance_omp.h:92-190): nr_points (-1 = rejected), mean_, cov_, icov_, evecs_ (columns), evals_, centroid, pointList_
+ * as offsets[n_leaves + 1] into point_ids (input indices, input order inside a leaf); any pointer may be NULL */
+int lvx_voxel_get(lvx_ctx* ctx, int32_t* leaf_key, int32_t* leaf_n, double* mean3, double* cov9, double* icov9, double* evecs9, double* evals3, float* centroid3,
+                  int32_t* offsets, int32_t* point_ids);
+/* getNeighborhoodAtPoint7 (:423-438): leaf index per displacement {0,+x,-x,+y,-y,+z,-z} or -1 */
+int lvx_voxel_lookup7(lvx_ctx* ctx, int nq, const float* xyzi4, int32_t* leaf_ids7);
+int lvx_voxel_lookup7_d(lvx_ctx* ctx, int nq, const float* xyzi4_d, int32_t* leaf_ids7_d);
+/* SurfelAssociation::getAssociation flag pass (src/lvi_exc/src/core/surfel_association.cpp:111-138): plane_of_point[H*W] = surfel id or -1.
+ * Conflicts resolve as the reference's SERIAL plane loop (highest plane id wins); W <= 4096 */
+int lvx_surfel_assoc(lvx_ctx* ctx, int H, int W, const float* scan_map_xyzi4, int n_planes, const double* plane_p4, const double* box_min3, const double* box_max3,
+                     double radius, int sel_per_ring, int32_t* plane_of_point);
+/* device-resident variant: planes10_d = p4[P][4] | box_min[P][3] | box_max[P][3] */
+int lvx_surfel_assoc_d(lvx_ctx* ctx, int H, int W, const float* scan_d, int n_planes, const double* planes10_d, double radius, int sel_per_ring, int32_t* plane_of_point_d);
 
 #ifdef __cplusplus
 }

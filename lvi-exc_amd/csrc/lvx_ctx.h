@@ -84,6 +84,13 @@ struct lvx_ctx {
   int64_t n_blocks = 0, n_residuals = 0;
   int64_t fam_row0[LVX_NUM_FAM + 1] = {0};
   uint32_t last_what = 0;
+  // upstream kernels (lvx_upstream.hip)
+  lvx::DevBuf d_up[8];
+  struct Voxels {
+    float leaf = 0; int min_pts = 0, n_points = 0, n_leaves = 0;
+    int grid[13] = {0};   // VxGrid: min_b, max_b, div_b, mul, inv(float bits)
+    lvx::DevBuf misc, keys, vals, runs, cells, tmp, leaf_i, leaf_d, leaf_f;
+  } vox;
   std::vector<double> lm_cost, lm_radius;
   std::vector<int> lm_accept;
   // profiling: (start, stop) event pairs per launch, read lazily by lvx_get_kernel_ms

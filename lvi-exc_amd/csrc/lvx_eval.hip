@@ -637,6 +637,8 @@ void lvx_destroy(lvx_ctx* c) {
                     &c->d_res, &c->d_jcols, &c->d_jvals, &c->d_L, &c->d_Y, &c->d_S, &c->d_delta, &c->d_diag, &c->d_scal, &c->d_state_try, &c->d_zero})
     if (b->p) (void)hipFree(b->p);
   for (auto& b : c->d_pairs) if (b.p) (void)hipFree(b.p);
+  for (auto& b : c->d_up) if (b.p) (void)hipFree(b.p);
+  for (DevBuf* b : {&c->vox.misc, &c->vox.keys, &c->vox.vals, &c->vox.runs, &c->vox.cells, &c->vox.tmp, &c->vox.leaf_i, &c->vox.leaf_d, &c->vox.leaf_f}) if (b->p) (void)hipFree(b->p);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;

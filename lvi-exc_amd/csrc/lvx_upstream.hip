@@ -1,0 +1,575 @@
+// lvx_upstream.hip — upstream point-cloud kernels of the LVI-ExC pipeline (gfx950):
+//   lvx_scan_register   A-LOAM scanRegistration core: range/NaN filter, ring bucketing, 11-tap float curvature, per-ring
+//                       6-sector sort + greedy edge/plane pick     (reference: src/aloam/src/scanRegistration.cpp:101-131,199-447)
+//   lvx_voxel_build     ndt_omp VoxelGridCovariance::applyFilter    (src/ndt_omp/include/pclomp/voxel_grid_covariance_omp_impl.hpp:49-374)
+//   lvx_voxel_lookup7   getNeighborhoodAtPoint7                     (same file :378-438)
+//   lvx_surfel_assoc    SurfelAssociation::getAssociation           (src/lvi_exc/src/core/surfel_association.cpp:111-138,296-331)
+// These are HBM/latency-bound integer + float kernels (no MFMA).  Float expressions keep the reference's evaluation order and the
+// library is built with -ffp-contract=off, so scan registration is bit-exact against the serial code.
+#include <string.h>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "lvx_ctx.h"
+
+namespace lvx {
+
+struct RsPoint { float x, y, z, pad; uint8_t intensity; uint8_t pad2; uint16_t ring; uint32_t pad3; double timestamp; };
+static_assert(sizeof(RsPoint) == 32, "RsPointXYZIRT layout (scanRegistration.cpp:57-66)");
+
+// ------------------------------------------------------------------------------------------------------------------------
+// scan registration
+// ------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool sr_keep(const RsPoint& p, float thr) {   // removeClosedPointCloud (:101-131)
+  if (p.x * p.x + p.y * p.y + p.z * p.z < thr * thr) return false;
+  if (isnan(p.x) || isnan(p.y) || isnan(p.z)) return false;
+  return true;
+}
+__global__ void k_sr_count(const RsPoint* pts, int n, int n_rings, float thr, int* ring_count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const RsPoint p = pts[i]; if (sr_keep(p, thr) && p.ring < n_rings) atomicAdd(&ring_count[p.ring], 1); }
+}
+// one workgroup per ring: order-preserving compaction of the ring's points to src[ring_start + k]
+__global__ __launch_bounds__(1024) void k_sr_bucket(const RsPoint* pts, int n, int n_rings, float thr, const int* ring_count, int* src, int* scan_start, int* scan_end) {
+  const int r = blockIdx.x;
+  __shared__ int wsum[16];
+  __shared__ int base_s;
+  int start = 0;
+  for (int k = 0; k < r; ++k) start += ring_count[k];
+  if (threadIdx.x == 0) { base_s = 0; scan_start[r] = start + 5; scan_end[r] = start + ring_count[r] - 6; }   // :284-290
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < n; c0 += 1024) {
+    const int i = c0 + threadIdx.x;
+    bool f = false;
+    if (i < n) { const RsPoint p = pts[i]; f = sr_keep(p, thr) && p.ring == r; }
+    const unsigned long long m = __ballot(f);
+    const int within = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wv] = __popcll(m);
+    __syncthreads();
+    int off = 0;
+    for (int k = 0; k < wv; ++k) off += wsum[k];
+    int tot = 0;
+    for (int k = 0; k < 16; ++k) tot += wsum[k];
+    const int base = base_s;
+    if (f) src[start + base + off + within] = i;
+    __syncthreads();
+    if (threadIdx.x == 0) base_s = base + tot;
+    __syncthreads();
+  }
+}
+__global__ void k_sr_gather(const RsPoint* pts, const int* src, int m, float4* cloud, float* curv, int* label, int* sort_ind, int* picked) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const RsPoint p = pts[src[j]];
+  const double rel = p.timestamp - pts[0].timestamp;                       // :161, :277
+  cloud[j] = make_float4(p.x, p.y, p.z, (float)((double)p.ring + rel));     // intensity = ring + relTime (:278)
+  curv[j] = 0.f; label[j] = 0; sort_ind[j] = j; picked[j] = 0;
+}
+// 11-tap curvature, float, reference evaluation order (:295-305); LDS tile with a halo of 5
+__global__ __launch_bounds__(256) void k_sr_curv(const float4* cloud, int m, float* curv) {
+  __shared__ float sx[256 + 10], sy[256 + 10], sz[256 + 10];
+  const int i0 = blockIdx.x * 256;
+  for (int t = threadIdx.x; t < 266; t += 256) {
+    const int j = i0 - 5 + t;
+    float4 p = make_float4(0, 0, 0, 0);
+    if (j >= 0 && j < m) p = cloud[j];
+    sx[t] = p.x; sy[t] = p.y; sz[t] = p.z;
+  }
+  __syncthreads();
+  const int i = i0 + threadIdx.x;
+  if (i < 5 || i >= m - 5) return;
+  const int c = threadIdx.x + 5;
+  const float dX = sx[c - 5] + sx[c - 4] + sx[c - 3] + sx[c - 2] + sx[c - 1] - 10 * sx[c] + sx[c + 1] + sx[c + 2] + sx[c + 3] + sx[c + 4] + sx[c + 5];
+  const float dY = sy[c - 5] + sy[c - 4] + sy[c - 3] + sy[c - 2] + sy[c - 1] - 10 * sy[c] + sy[c + 1] + sy[c + 2] + sy[c + 3] + sy[c + 4] + sy[c + 5];
+  const float dZ = sz[c - 5] + sz[c - 4] + sz[c - 3] + sz[c - 2] + sz[c - 1] - 10 * sz[c] + sz[c + 1] + sz[c + 2] + sz[c + 3] + sz[c + 4] + sz[c + 5];
+  curv[i] = dX * dX + dY * dY + dZ * dZ;
+}
+#define SR_SEC_MAX 2048
+__device__ __forceinline__ float sr_gap2(const float4* c, int a, int b) {
+  const float dx = c[a].x - c[b].x, dy = c[a].y - c[b].y, dz = c[a].z - c[b].z;
+  return dx * dx + dy * dy + dz * dz;
+}
+// one workgroup per ring: six sectors in order (marks of one sector influence the next); per sector a bitonic sort of
+// (curvature bits, index) in LDS, then the reference's serial greedy pick on one lane (:316-447)
+__global__ __launch_bounds__(512) void k_sr_classify(const float4* cloud, const float* curv, const int* scan_start, const int* scan_end, int* label, int* sort_ind,
+                                                    int* picked, int* sharp_r, int* lsharp_r, int* flat_r, int* lflat_r, int* cnt_r, int* err) {
+  __shared__ unsigned long long key[SR_SEC_MAX];
+  __shared__ int cnt[4];
+  const int r = blockIdx.x;
+  const int s0 = scan_start[r], e0 = scan_end[r];
+  if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  if (e0 - s0 >= 6) {
+    for (int j = 0; j < 6; ++j) {
+      const int sp = s0 + (e0 - s0) * j / 6;
+      const int ep = s0 + (e0 - s0) * (j + 1) / 6 - 1;
+      const int len = ep - sp + 1;
+      if (len > SR_SEC_MAX) { if (threadIdx.x == 0) atomicOr(err, 8); break; }
+      int np2 = 1; while (np2 < len) np2 <<= 1;
+      for (int t = threadIdx.x; t < np2; t += 512)
+        key[t] = t < len ? (((unsigned long long)__float_as_uint(curv[sp + t])) << 32) | (unsigned)(sp + t) : ~0ull;   // curvature >= 0: bit order == value order
+      __syncthreads();
+      for (int k = 2; k <= np2; k <<= 1)
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+          for (int t = threadIdx.x; t < np2; t += 512) {
+            const int x = t ^ jj;
+            if (x > t) {
+              const unsigned long long a = key[t], b = key[x];
+              const bool up = (t & k) == 0;
+              if ((a > b) == up) { key[t] = b; key[x] = a; }
+            }
+          }
+          __syncthreads();
+        }
+      for (int t = threadIdx.x; t < len; t += 512) sort_ind[sp + t] = (int)(key[t] & 0xffffffffu);
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int largest = 0;
+        for (int k = ep; k >= sp; k--) {
+          const int ind = sort_ind[k];
+          if (picked[ind] == 0 && curv[ind] > 0.1) {
+            largest++;
+            if (largest <= 2) { label[ind] = 2; sharp_r[r * 16 + cnt[0]++] = ind; lsharp_r[r * 128 + cnt[1]++] = ind; }
+            else if (largest <= 20) { label[ind] = 1; lsharp_r[r * 128 + cnt[1]++] = ind; }
+            else break;
+            picked[ind] = 1;
+            for (int l = 1; l <= 5; l++) { if (sr_gap2(cloud, ind + l, ind + l - 1) > 0.05) break; picked[ind + l] = 1; }
+            for (int l = -1; l >= -5; l--) { if (sr_gap2(cloud, ind + l, ind + l + 1) > 0.05) break; picked[ind + l] = 1; }
+          }
+        }
+        int smallest = 0;
+        for (int k = sp; k <= ep; k++) {
+          const int ind = sort_ind[k];
+          if (picked[ind] == 0 && curv[ind] < 0.1) {
+            label[ind] = -1; flat_r[r * 32 + cnt[2]++] = ind;
+            smallest++;
+            if (smallest >= 4) break;
+            picked[ind] = 1;
+            for (int l = 1; l <= 5; l++) { if (sr_gap2(cloud, ind + l, ind + l - 1) > 0.05) break; picked[ind + l] = 1; }
+            for (int l = -1; l >= -5; l--) { if (sr_gap2(cloud, ind + l, ind + l + 1) > 0.05) break; picked[ind + l] = 1; }
+          }
+        }
+        for (int k = sp; k <= ep; k++) if (label[k] <= 0) lflat_r[(s0 - 5) + cnt[3]++] = k;
+      }
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x < 4) cnt_r[r * 4 + threadIdx.x] = cnt[threadIdx.x];
+}
+// ring-major concatenation of the per-ring lists (reference push order)
+__global__ void k_sr_compact(int n_rings, const int* scan_start, const int* cnt_r, const int* sharp_r, const int* lsharp_r, const int* flat_r, const int* lflat_r,
+                             int* sharp, int* lsharp, int* flat, int* lflat, int* counts) {
+  __shared__ int off[4];
+  if (threadIdx.x < 4) off[threadIdx.x] = 0;
+  __syncthreads();
+  for (int r = 0; r < n_rings; ++r) {
+    const int c0 = cnt_r[r * 4], c1 = cnt_r[r * 4 + 1], c2 = cnt_r[r * 4 + 2], c3 = cnt_r[r * 4 + 3];
+    for (int t = threadIdx.x; t < c0; t += blockDim.x) sharp[off[0] + t] = sharp_r[r * 16 + t];
+    for (int t = threadIdx.x; t < c1; t += blockDim.x) lsharp[off[1] + t] = lsharp_r[r * 128 + t];
+    for (int t = threadIdx.x; t < c2; t += blockDim.x) flat[off[2] + t] = flat_r[r * 32 + t];
+    for (int t = threadIdx.x; t < c3; t += blockDim.x) lflat[off[3] + t] = lflat_r[(scan_start[r] - 5) + t];
+    __syncthreads();
+    if (threadIdx.x == 0) { off[0] += c0; off[1] += c1; off[2] += c2; off[3] += c3; }
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) counts[threadIdx.x] = off[threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// voxel covariance grid
+// ------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int f2ord(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }   // monotone float -> int
+__host__ __device__ __forceinline__ float ord2f(int i) { const int j = i >= 0 ? i : i ^ 0x7fffffff; float f; memcpy(&f, &j, 4); return f; }
+__global__ void k_vx_minmax(const float4* p, int n, int* mm) {   // mm[0..2] = min (ordered ints), mm[3..5] = max
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 q = p[i];
+  if (!isfinite(q.x) || !isfinite(q.y) || !isfinite(q.z)) return;
+  atomicMin(&mm[0], f2ord(q.x)); atomicMin(&mm[1], f2ord(q.y)); atomicMin(&mm[2], f2ord(q.z));
+  atomicMax(&mm[3], f2ord(q.x)); atomicMax(&mm[4], f2ord(q.y)); atomicMax(&mm[5], f2ord(q.z));
+}
+struct VxGrid { int min_b[3], max_b[3], div_b[3], mul[3]; float inv; };
+__global__ void k_vx_keys(const float4* p, int n, VxGrid g, unsigned* keys, int* vals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 q = p[i];
+  unsigned k = 0xffffffffu;
+  if (isfinite(q.x) && isfinite(q.y) && isfinite(q.z)) {
+    const int i0 = (int)(floorf(q.x * g.inv) - (float)g.min_b[0]);   // :220-222
+    const int i1 = (int)(floorf(q.y * g.inv) - (float)g.min_b[1]);
+    const int i2 = (int)(floorf(q.z * g.inv) - (float)g.min_b[2]);
+    k = (unsigned)(i0 * g.mul[0] + i1 * g.mul[1] + i2 * g.mul[2]);
+  }
+  keys[i] = k; vals[i] = i;
+}
+__device__ void vx_eig3(const double A[9], double ev[3], double V[9]) {   // cyclic Jacobi, ascending eigenvalues (Eigen SelfAdjointEigenSolver stand-in)
+  double a[3][3] = {{A[0], A[1], A[2]}, {A[3], A[4], A[5]}, {A[6], A[7], A[8]}};
+  double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 2; ++p) for (int q = p + 1; q < 3; ++q) {
+      if (a[p][q] == 0.0) continue;
+      const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+      const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+      const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+      for (int k = 0; k < 3; ++k) { const double akp = a[k][p], akq = a[k][q]; a[k][p] = c * akp - s * akq; a[k][q] = s * akp + c * akq; }
+      for (int k = 0; k < 3; ++k) { const double apk = a[p][k], aqk = a[q][k]; a[p][k] = c * apk - s * aqk; a[q][k] = s * apk + c * aqk; }
+      for (int k = 0; k < 3; ++k) { const double vkp = v[k][p], vkq = v[k][q]; v[k][p] = c * vkp - s * vkq; v[k][q] = s * vkp + c * vkq; }
+    }
+  }
+  int i0 = 0, i1 = 1, i2 = 2;
+  if (a[i1][i1] < a[i0][i0]) { int t = i0; i0 = i1; i1 = t; }
+  if (a[i2][i2] < a[i1][i1]) { int t = i1; i1 = i2; i2 = t; if (a[i1][i1] < a[i0][i0]) { int u = i0; i0 = i1; i1 = u; } }
+  const int idx[3] = {i0, i1, i2};
+  for (int k = 0; k < 3; ++k) { ev[k] = a[idx[k]][idx[k]]; for (int r = 0; r < 3; ++r) V[3 * r + k] = v[r][idx[k]]; }
+}
+// one thread per leaf: in-order sums over the leaf's (stable-sorted) points, then the finalize of :286-371
+__global__ void k_vx_leaf(const float4* p, const unsigned* ukeys, const unsigned* counts, const unsigned* offs, const int* sorted_ids, int nl, int min_pts, double eig_mult,
+                          int* grid, int* leaf_key, int* leaf_n, double* mean, double* cov, double* icov, double* evecs, double* evals, float* centroid) {
+  const int li = blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= nl) return;
+  const unsigned key = ukeys[li];
+  const int n = (int)counts[li];
+  const int o = (int)offs[li];
+  double s[3] = {0, 0, 0}, c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  float cen[3] = {0, 0, 0};
+  for (int k = 0; k < n; ++k) {
+    const float4 q = p[sorted_ids[o + k]];
+    const double x[3] = {q.x, q.y, q.z};
+    for (int a = 0; a < 3; ++a) { s[a] += x[a]; for (int b = 0; b < 3; ++b) c[3 * a + b] += x[a] * x[b]; }
+    cen[0] += q.x; cen[1] += q.y; cen[2] += q.z;
+  }
+  leaf_key[li] = (int)key;
+  grid[key] = li;
+  double* M = mean + 3 * (size_t)li; double* Cv = cov + 9 * (size_t)li; double* IC = icov + 9 * (size_t)li; double* EV = evecs + 9 * (size_t)li; double* EL = evals + 3 * (size_t)li;
+  for (int a = 0; a < 3; ++a) { centroid[3 * (size_t)li + a] = cen[a] / (float)n; M[a] = s[a] / n; EL[a] = 0.0; }
+  for (int a = 0; a < 9; ++a) { Cv[a] = (a % 4 == 0) ? 1.0 : 0.0; IC[a] = 0.0; EV[a] = (a % 4 == 0) ? 1.0 : 0.0; }
+  int nr = n;
+  if (n >= min_pts) {
+    double C[9];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[3 * a + b] = (c[3 * a + b] - 2 * (s[a] * M[b])) / n + M[a] * M[b];
+    for (int a = 0; a < 9; ++a) C[a] *= (n - 1.0) / n;
+    double ev[3], V[9];
+    vx_eig3(C, ev, V);
+    for (int a = 0; a < 9; ++a) EV[a] = V[a];
+    if (ev[0] < 0 || ev[1] < 0 || ev[2] <= 0) { nr = -1; for (int a = 0; a < 9; ++a) Cv[a] = C[a]; }
+    else {
+      const double min_ev = eig_mult * ev[2];
+      if (ev[0] < min_ev) {
+        ev[0] = min_ev; if (ev[1] < min_ev) ev[1] = min_ev;
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[3 * a + b] = V[3 * a] * ev[0] * V[3 * b] + V[3 * a + 1] * ev[1] * V[3 * b + 1] + V[3 * a + 2] * ev[2] * V[3 * b + 2];
+      }
+      for (int a = 0; a < 3; ++a) EL[a] = ev[a];
+      for (int a = 0; a < 9; ++a) Cv[a] = C[a];
+      const double c00 = C[4] * C[8] - C[5] * C[7], c01 = C[5] * C[6] - C[3] * C[8], c02 = C[3] * C[7] - C[4] * C[6];
+      const double id = 1.0 / (C[0] * c00 + C[1] * c01 + C[2] * c02);
+      IC[0] = c00 * id; IC[1] = (C[2] * C[7] - C[1] * C[8]) * id; IC[2] = (C[1] * C[5] - C[2] * C[4]) * id;
+      IC[3] = c01 * id; IC[4] = (C[0] * C[8] - C[2] * C[6]) * id; IC[5] = (C[2] * C[3] - C[0] * C[5]) * id;
+      IC[6] = c02 * id; IC[7] = (C[1] * C[6] - C[0] * C[7]) * id; IC[8] = (C[0] * C[4] - C[1] * C[3]) * id;
+      double mxv = IC[0], mnv = IC[0];
+      for (int a = 1; a < 9; ++a) { mxv = fmax(mxv, IC[a]); mnv = fmin(mnv, IC[a]); }
+      if (mxv == (double)INFINITY || mnv == -(double)INFINITY) nr = -1;
+    }
+  }
+  leaf_n[li] = nr;
+}
+__global__ void k_vx_lookup7(const float4* q, int nq, float leaf, int min_pts, VxGrid g, const int* grid, const int* leaf_n, int* ids7) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  const float4 p = q[i];
+  const int ijk[3] = {(int)floorf(p.x / leaf), (int)floorf(p.y / leaf), (int)floorf(p.z / leaf)};   // :383-385
+  const int disp[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+  for (int k = 0; k < 7; ++k) {
+    int id = -1;
+    bool in = true;
+    for (int a = 0; a < 3; ++a) in = in && (g.min_b[a] - ijk[a] <= disp[k][a]) && (g.max_b[a] - ijk[a] >= disp[k][a]);
+    if (in) {
+      const int key = (ijk[0] + disp[k][0] - g.min_b[0]) * g.mul[0] + (ijk[1] + disp[k][1] - g.min_b[1]) * g.mul[1] + (ijk[2] + disp[k][2] - g.min_b[2]) * g.mul[2];
+      const int li = grid[key];
+      if (li >= 0 && leaf_n[li] >= min_pts) id = li;
+    }
+    ids7[7 * (size_t)i + k] = id;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// scan -> surfel association: thread = (plane, ring); the ring's points staged in LDS; two passes (count, then the
+// evenly spaced ranks step*(s+1)-1); conflicts resolved as the serial plane loop does (highest plane id wins).
+// ------------------------------------------------------------------------------------------------------------------------
+#define SA_PLANES 64
+#define SA_WMAX 4096
+__global__ __launch_bounds__(SA_PLANES) void k_surfel_assoc(const float4* scan, int H, int W, int P, const double* p4, const double* bmin, const double* bmax, double radius, int sel, int* flag) {
+  __shared__ float sx[SA_WMAX], sy[SA_WMAX], sz[SA_WMAX];
+  const int h = blockIdx.y;
+  for (int w = threadIdx.x; w < W; w += SA_PLANES) { const float4 q = scan[(size_t)h * W + w]; sx[w] = q.x; sy[w] = q.y; sz[w] = q.z; }
+  __syncthreads();
+  const int pid = blockIdx.x * SA_PLANES + threadIdx.x;
+  if (pid >= P) return;
+  const double n0 = p4[4 * pid], n1 = p4[4 * pid + 1], n2 = p4[4 * pid + 2], d = p4[4 * pid + 3];
+  const double lo0 = bmin[3 * pid], lo1 = bmin[3 * pid + 1], lo2 = bmin[3 * pid + 2], hi0 = bmax[3 * pid], hi1 = bmax[3 * pid + 1], hi2 = bmax[3 * pid + 2];
+  auto hit = [&](int w) -> bool {
+    const float x = sx[w], y = sy[w], z = sz[w];
+    if (!(!isnan(x) && x > lo0 && x < hi0 && y > lo1 && y < hi1 && z > lo2 && z < hi2)) return false;
+    double dist = (double)x * n0 + (double)y * n1 + (double)z * n2 + d;
+    dist = dist > 0 ? dist : -dist;
+    return dist <= radius;
+  };
+  int cnt = 0;
+  for (int w = 0; w < W; ++w) cnt += hit(w) ? 1 : 0;
+  if (cnt < sel * 2) return;
+  int step = cnt / (sel + 1);
+  step = step > 1 ? step : 1;
+  int rank = 0, s = 0;
+  for (int w = 0; w < W && s < sel; ++w) {
+    if (hit(w)) {
+      if (rank == step * (s + 1) - 1) { atomicMax(&flag[(size_t)h * W + w], pid); ++s; }
+      ++rank;
+    }
+  }
+}
+
+}  // namespace lvx
+
+using namespace lvx;
+
+extern "C" {
+
+int lvx_scan_register(lvx_ctx* c, int n, const lvx_rs_point* pts, int n_rings, float min_range, lvx_scanreg_out* out) {
+  if (!c || !out || n < 0 || n_rings <= 0 || n_rings > 1024 || (n > 0 && !pts)) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  std::memset(out->counts, 0, sizeof(out->counts));
+  out->n = 0;
+  if (n == 0) return LVX_OK;
+  hipStream_t st = c->stream;
+  int rc;
+  DevBuf& B = c->d_up[0];
+  // layout of the scratch buffer
+  const size_t o_pts = 0, o_cloud = o_pts + (size_t)n * 32, o_curv = o_cloud + (size_t)n * 16, o_label = o_curv + (size_t)n * 4, o_sort = o_label + (size_t)n * 4,
+               o_pick = o_sort + (size_t)n * 4, o_src = o_pick + (size_t)n * 4, o_lists = o_src + (size_t)n * 4, o_lflat_r = o_lists + (size_t)n * 16,
+               o_ring = o_lflat_r + (size_t)n * 4, o_end = o_ring + (size_t)n_rings * (4 + 4 + 4 + 16 + 64 + 512 + 128) + 64;
+  if ((rc = dev_alloc(c, B, o_end))) return rc;
+  char* base = (char*)B.p;
+  RsPoint* d_pts = (RsPoint*)(base + o_pts); float4* d_cloud = (float4*)(base + o_cloud); float* d_curv = (float*)(base + o_curv);
+  int* d_label = (int*)(base + o_label); int* d_sort = (int*)(base + o_sort); int* d_pick = (int*)(base + o_pick); int* d_src = (int*)(base + o_src);
+  int* d_lists = (int*)(base + o_lists); int* d_lflat_r = (int*)(base + o_lflat_r);
+  int* d_rc = (int*)(base + o_ring); int* d_ss = d_rc + n_rings; int* d_se = d_ss + n_rings; int* d_cnt = d_se + n_rings; int* d_sharp_r = d_cnt + 4 * n_rings;
+  int* d_lsharp_r = d_sharp_r + 16 * n_rings; int* d_flat_r = d_lsharp_r + 128 * n_rings; int* d_counts = d_flat_r + 32 * n_rings; int* d_err = d_counts + 4;
+  ProfScope ps(c, LVX_KERNEL_UPSTREAM);
+  LVX_HIP(c, hipMemcpyAsync(d_pts, pts, (size_t)n * 32, hipMemcpyHostToDevice, st));
+  LVX_HIP(c, hipMemsetAsync(d_rc, 0, (size_t)n_rings * 4, st));
+  LVX_HIP(c, hipMemsetAsync(d_counts, 0, 32, st));
+  hipLaunchKernelGGL(k_sr_count, dim3((n + 255) / 256), dim3(256), 0, st, (const RsPoint*)d_pts, n, n_rings, min_range, d_rc);
+  hipLaunchKernelGGL(k_sr_bucket, dim3(n_rings), dim3(1024), 0, st, (const RsPoint*)d_pts, n, n_rings, min_range, (const int*)d_rc, d_src, d_ss, d_se);
+  std::vector<int> hrc(n_rings);
+  LVX_HIP(c, hipMemcpyAsync(hrc.data(), d_rc, (size_t)n_rings * 4, hipMemcpyDeviceToHost, st));
+  LVX_HIP(c, hipStreamSynchronize(st));
+  int m = 0; for (int v : hrc) m += v;
+  out->n = m;
+  if (m > 0) {
+    hipLaunchKernelGGL(k_sr_gather, dim3((m + 255) / 256), dim3(256), 0, st, (const RsPoint*)d_pts, (const int*)d_src, m, d_cloud, d_curv, d_label, d_sort, d_pick);
+    hipLaunchKernelGGL(k_sr_curv, dim3((m + 255) / 256), dim3(256), 0, st, (const float4*)d_cloud, m, d_curv);
+    hipLaunchKernelGGL(k_sr_classify, dim3(n_rings), dim3(512), 0, st, (const float4*)d_cloud, (const float*)d_curv, (const int*)d_ss, (const int*)d_se, d_label, d_sort, d_pick,
+                       d_sharp_r, d_lsharp_r, d_flat_r, d_lflat_r, d_cnt, d_err);
+    hipLaunchKernelGGL(k_sr_compact, dim3(1), dim3(256), 0, st, n_rings, (const int*)d_ss, (const int*)d_cnt, (const int*)d_sharp_r, (const int*)d_lsharp_r, (const int*)d_flat_r,
+                       (const int*)d_lflat_r, d_lists, d_lists + n, d_lists + 2 * (size_t)n, d_lists + 3 * (size_t)n, d_counts);
+  }
+  LVX_HIP(c, hipGetLastError());
+  int herr = 0;
+  LVX_HIP(c, hipMemcpyAsync(out->counts, d_counts, 16, hipMemcpyDeviceToHost, st));
+  LVX_HIP(c, hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, st));
+  if (out->scan_start) LVX_HIP(c, hipMemcpyAsync(out->scan_start, d_ss, (size_t)n_rings * 4, hipMemcpyDeviceToHost, st));
+  if (out->scan_end) LVX_HIP(c, hipMemcpyAsync(out->scan_end, d_se, (size_t)n_rings * 4, hipMemcpyDeviceToHost, st));
+  if (m > 0) {
+    if (out->cloud) LVX_HIP(c, hipMemcpyAsync(out->cloud, d_cloud, (size_t)m * 16, hipMemcpyDeviceToHost, st));
+    if (out->curvature) LVX_HIP(c, hipMemcpyAsync(out->curvature, d_curv, (size_t)m * 4, hipMemcpyDeviceToHost, st));
+    if (out->label) LVX_HIP(c, hipMemcpyAsync(out->label, d_label, (size_t)m * 4, hipMemcpyDeviceToHost, st));
+    if (out->sort_ind) LVX_HIP(c, hipMemcpyAsync(out->sort_ind, d_sort, (size_t)m * 4, hipMemcpyDeviceToHost, st));
+    if (out->picked) LVX_HIP(c, hipMemcpyAsync(out->picked, d_pick, (size_t)m * 4, hipMemcpyDeviceToHost, st));
+  }
+  LVX_HIP(c, hipStreamSynchronize(st));
+  if (herr & 8) return fail(c, LVX_E_ARG, "scan sector longer than the LDS sort capacity");
+  int* lists[4] = {out->sharp, out->less_sharp, out->flat, out->less_flat};
+  for (int k = 0; k < 4; ++k) if (lists[k] && out->counts[k] > 0) LVX_HIP(c, hipMemcpy(lists[k], d_lists + (size_t)k * n, (size_t)out->counts[k] * 4, hipMemcpyDeviceToHost));
+  return LVX_OK;
+}
+
+// voxel grid kept on the device in the context
+static int voxel_build_device(lvx_ctx* c, const float4* d_pts, int n, float leaf, int min_pts, double eig_mult) {
+  hipStream_t st = c->stream;
+  int rc;
+  lvx_ctx::Voxels& V = c->vox;
+  V.leaf = leaf; V.min_pts = min_pts; V.n_points = n; V.n_leaves = 0;
+  if ((rc = dev_alloc(c, V.misc, 256))) return rc;
+  int* d_mm = (int*)V.misc.p;
+  const int init[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+  LVX_HIP(c, hipMemcpyAsync(d_mm, init, 24, hipMemcpyHostToDevice, st));
+  if (n > 0) hipLaunchKernelGGL(k_vx_minmax, dim3((n + 255) / 256), dim3(256), 0, st, d_pts, n, d_mm);
+  int mm[6];
+  LVX_HIP(c, hipMemcpyAsync(mm, d_mm, 24, hipMemcpyDeviceToHost, st));
+  LVX_HIP(c, hipStreamSynchronize(st));
+  if (n == 0 || mm[0] == 0x7fffffff) { std::memset(&V.grid, 0, sizeof(V.grid)); return LVX_OK; }
+  VxGrid g;
+  g.inv = 1.0f / leaf;
+  for (int k = 0; k < 3; ++k) {
+    g.min_b[k] = (int)std::floor(ord2f(mm[k]) * g.inv); g.max_b[k] = (int)std::floor(ord2f(mm[3 + k]) * g.inv);   // :86-95
+    g.div_b[k] = g.max_b[k] - g.min_b[k] + 1;
+  }
+  const int64_t cells = (int64_t)g.div_b[0] * g.div_b[1] * g.div_b[2];
+  if (cells > 2147483647LL) return fail(c, LVX_E_ARG, "Leaf size is too small for the input dataset. Integer indices would overflow.");   // :80-85
+  g.mul[0] = 1; g.mul[1] = g.div_b[0]; g.mul[2] = g.div_b[0] * g.div_b[1];
+  std::memcpy(&V.grid, &g, sizeof(g));
+  if ((rc = dev_alloc(c, V.keys, (size_t)n * 4 * 2))) return rc;
+  if ((rc = dev_alloc(c, V.vals, (size_t)n * 4 * 2))) return rc;
+  if ((rc = dev_alloc(c, V.runs, ((size_t)n * 3 + 8) * 4))) return rc;
+  if ((rc = dev_alloc(c, V.cells, (size_t)cells * 4))) return rc;
+  unsigned* k_in = (unsigned*)V.keys.p; unsigned* k_out = k_in + n;
+  int* v_in = (int*)V.vals.p; int* v_out = v_in + n;
+  unsigned* ukeys = (unsigned*)V.runs.p; unsigned* counts = ukeys + n; unsigned* offs = counts + n; unsigned* d_nruns = offs + n;
+  LVX_HIP(c, hipMemsetAsync(V.cells.p, 0xff, (size_t)cells * 4, st));
+  hipLaunchKernelGGL(k_vx_keys, dim3((n + 255) / 256), dim3(256), 0, st, d_pts, n, g, k_in, v_in);
+  size_t tmp1 = 0, tmp2 = 0, tmp3 = 0;
+  LVX_HIP(c, rocprim::radix_sort_pairs(nullptr, tmp1, k_in, k_out, v_in, v_out, (size_t)n, 0, 32, st));
+  LVX_HIP(c, rocprim::run_length_encode(nullptr, tmp2, k_out, (size_t)n, ukeys, counts, d_nruns, st));
+  LVX_HIP(c, rocprim::exclusive_scan(nullptr, tmp3, counts, offs, 0u, (size_t)n, rocprim::plus<unsigned>(), st));
+  if ((rc = dev_alloc(c, V.tmp, std::max(tmp1, std::max(tmp2, tmp3)) + 16))) return rc;
+  LVX_HIP(c, rocprim::radix_sort_pairs(V.tmp.p, tmp1, k_in, k_out, v_in, v_out, (size_t)n, 0, 32, st));   // stable: input order kept inside a leaf
+  LVX_HIP(c, rocprim::run_length_encode(V.tmp.p, tmp2, k_out, (size_t)n, ukeys, counts, d_nruns, st));
+  unsigned nruns = 0;
+  LVX_HIP(c, hipMemcpyAsync(&nruns, d_nruns, 4, hipMemcpyDeviceToHost, st));
+  LVX_HIP(c, hipStreamSynchronize(st));
+  // the last run may be the invalid-key bucket (non-finite points)
+  unsigned last_key = 0;
+  if (nruns > 0) LVX_HIP(c, hipMemcpy(&last_key, ukeys + (nruns - 1), 4, hipMemcpyDeviceToHost));
+  int nl = (int)nruns - ((nruns > 0 && last_key == 0xffffffffu) ? 1 : 0);
+  V.n_leaves = nl;
+  if (nl > 0) {
+    LVX_HIP(c, rocprim::exclusive_scan(V.tmp.p, tmp3, counts, offs, 0u, (size_t)nruns, rocprim::plus<unsigned>(), st));
+    if ((rc = dev_alloc(c, V.leaf_i, (size_t)nl * 2 * 4))) return rc;
+    if ((rc = dev_alloc(c, V.leaf_d, (size_t)nl * 33 * 8))) return rc;
+    if ((rc = dev_alloc(c, V.leaf_f, (size_t)nl * 3 * 4))) return rc;
+    int* lk = (int*)V.leaf_i.p; int* ln = lk + nl;
+    double* mean = (double*)V.leaf_d.p; double* cov = mean + 3 * (size_t)nl; double* icov = cov + 9 * (size_t)nl; double* evecs = icov + 9 * (size_t)nl; double* evals = evecs + 9 * (size_t)nl;
+    hipLaunchKernelGGL(k_vx_leaf, dim3((nl + 127) / 128), dim3(128), 0, st, d_pts, (const unsigned*)ukeys, (const unsigned*)counts, (const unsigned*)offs, (const int*)v_out, nl, min_pts,
+                       eig_mult, (int*)V.cells.p, lk, ln, mean, cov, icov, evecs, evals, (float*)V.leaf_f.p);
+  }
+  LVX_HIP(c, hipGetLastError());
+  return LVX_OK;
+}
+
+int lvx_voxel_build(lvx_ctx* c, int n, const float* xyzi4, float leaf, int min_pts, double eig_mult, lvx_voxel_info* info) {
+  if (!c || n < 0 || !(leaf > 0) || (n > 0 && !xyzi4)) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = upload(c, c->d_up[1], xyzi4, (size_t)n * 16))) return rc;
+  { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
+    if ((rc = voxel_build_device(c, (const float4*)c->d_up[1].p, n, leaf, min_pts, eig_mult))) return rc; }
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  if (info) {
+    VxGrid g; std::memcpy(&g, &c->vox.grid, sizeof(g));
+    info->n_leaves = c->vox.n_leaves; info->n_points = n;
+    for (int k = 0; k < 3; ++k) { info->min_b[k] = g.min_b[k]; info->max_b[k] = g.max_b[k]; info->div_b[k] = g.div_b[k]; info->divb_mul[k] = g.mul[k]; }
+  }
+  return LVX_OK;
+}
+int lvx_voxel_build_d(lvx_ctx* c, int n, const float* xyzi4_d, float leaf, int min_pts, double eig_mult) {
+  if (!c || n < 0 || !(leaf > 0) || (n > 0 && !xyzi4_d)) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  ProfScope ps(c, LVX_KERNEL_UPSTREAM);
+  return voxel_build_device(c, (const float4*)xyzi4_d, n, leaf, min_pts, eig_mult);
+}
+int lvx_voxel_get(lvx_ctx* c, int32_t* leaf_key, int32_t* leaf_n, double* mean, double* cov, double* icov, double* evecs, double* evals, float* centroid,
+                  int32_t* offsets, int32_t* point_ids) {
+  if (!c) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  const lvx_ctx::Voxels& V = c->vox;
+  const size_t nl = (size_t)V.n_leaves, n = (size_t)V.n_points;
+  if (nl == 0) { if (offsets) offsets[0] = 0; return LVX_OK; }
+  const int* lk = (const int*)V.leaf_i.p;
+  const double* d = (const double*)V.leaf_d.p;
+  if (leaf_key) LVX_HIP(c, hipMemcpy(leaf_key, lk, nl * 4, hipMemcpyDeviceToHost));
+  if (leaf_n) LVX_HIP(c, hipMemcpy(leaf_n, lk + nl, nl * 4, hipMemcpyDeviceToHost));
+  if (mean) LVX_HIP(c, hipMemcpy(mean, d, nl * 24, hipMemcpyDeviceToHost));
+  if (cov) LVX_HIP(c, hipMemcpy(cov, d + 3 * nl, nl * 72, hipMemcpyDeviceToHost));
+  if (icov) LVX_HIP(c, hipMemcpy(icov, d + 12 * nl, nl * 72, hipMemcpyDeviceToHost));
+  if (evecs) LVX_HIP(c, hipMemcpy(evecs, d + 21 * nl, nl * 72, hipMemcpyDeviceToHost));
+  if (evals) LVX_HIP(c, hipMemcpy(evals, d + 30 * nl, nl * 24, hipMemcpyDeviceToHost));
+  if (centroid) LVX_HIP(c, hipMemcpy(centroid, V.leaf_f.p, nl * 12, hipMemcpyDeviceToHost));
+  if (offsets) {
+    const unsigned* offs = (const unsigned*)V.runs.p + 2 * n;
+    const unsigned* counts = (const unsigned*)V.runs.p + n;
+    LVX_HIP(c, hipMemcpy(offsets, offs, nl * 4, hipMemcpyDeviceToHost));
+    unsigned lc = 0; LVX_HIP(c, hipMemcpy(&lc, counts + (nl - 1), 4, hipMemcpyDeviceToHost));
+    offsets[nl] = offsets[nl - 1] + (int)lc;
+  }
+  if (point_ids && n > 0) LVX_HIP(c, hipMemcpy(point_ids, (const int*)V.vals.p + n, n * 4, hipMemcpyDeviceToHost));
+  return LVX_OK;
+}
+static int lookup_device(lvx_ctx* c, const float4* q_d, int nq, int* ids_d) {
+  const lvx_ctx::Voxels& V = c->vox;
+  if (!V.cells.p || V.n_leaves == 0) { LVX_HIP(c, hipMemsetAsync(ids_d, 0xff, (size_t)nq * 28, c->stream)); return LVX_OK; }
+  VxGrid g; std::memcpy(&g, &V.grid, sizeof(g));
+  hipLaunchKernelGGL(k_vx_lookup7, dim3((nq + 255) / 256), dim3(256), 0, c->stream, q_d, nq, V.leaf, V.min_pts, g, (const int*)V.cells.p,
+                     (const int*)V.leaf_i.p + V.n_leaves, ids_d);
+  LVX_HIP(c, hipGetLastError());
+  return LVX_OK;
+}
+int lvx_voxel_lookup7(lvx_ctx* c, int nq, const float* xyzi4, int32_t* leaf_ids7) {
+  if (!c || nq < 0 || (nq > 0 && (!xyzi4 || !leaf_ids7))) return LVX_E_ARG;
+  if (nq == 0) return LVX_OK;
+  LVX_HIP(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = upload(c, c->d_up[2], xyzi4, (size_t)nq * 16))) return rc;
+  if ((rc = dev_alloc(c, c->d_up[3], (size_t)nq * 28))) return rc;
+  { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
+    if ((rc = lookup_device(c, (const float4*)c->d_up[2].p, nq, (int*)c->d_up[3].p))) return rc; }
+  LVX_HIP(c, hipMemcpyAsync(leaf_ids7, c->d_up[3].p, (size_t)nq * 28, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  return LVX_OK;
+}
+int lvx_voxel_lookup7_d(lvx_ctx* c, int nq, const float* xyzi4_d, int32_t* leaf_ids7_d) {
+  if (!c || nq <= 0 || !xyzi4_d || !leaf_ids7_d) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  ProfScope ps(c, LVX_KERNEL_UPSTREAM);
+  return lookup_device(c, (const float4*)xyzi4_d, nq, leaf_ids7_d);
+}
+
+static int assoc_device(lvx_ctx* c, const float4* scan_d, int H, int W, int P, const double* planes_d, double radius, int sel, int* flag_d) {
+  LVX_HIP(c, hipMemsetAsync(flag_d, 0xff, (size_t)H * W * 4, c->stream));
+  if (P > 0 && H > 0 && W > 0)
+    hipLaunchKernelGGL(k_surfel_assoc, dim3((P + SA_PLANES - 1) / SA_PLANES, H), dim3(SA_PLANES), 0, c->stream, scan_d, H, W, P, planes_d, planes_d + 4 * (size_t)P,
+                       planes_d + 7 * (size_t)P, radius, sel, flag_d);
+  LVX_HIP(c, hipGetLastError());
+  return LVX_OK;
+}
+int lvx_surfel_assoc(lvx_ctx* c, int H, int W, const float* scan_map_xyzi4, int n_planes, const double* plane_p4, const double* box_min3, const double* box_max3,
+                     double radius, int sel_per_ring, int32_t* plane_of_point) {
+  if (!c || H < 0 || W < 0 || W > SA_WMAX || n_planes < 0 || !plane_of_point || ((size_t)H * W > 0 && !scan_map_xyzi4)) return c ? fail(c, LVX_E_ARG, "bad surfel_assoc arguments (W <= 4096)") : LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  int rc;
+  const size_t npt = (size_t)H * W;
+  if ((rc = upload(c, c->d_up[4], scan_map_xyzi4, npt * 16))) return rc;
+  std::vector<double> pl((size_t)n_planes * 10);
+  if (n_planes > 0) { std::memcpy(pl.data(), plane_p4, (size_t)n_planes * 32); std::memcpy(pl.data() + 4 * (size_t)n_planes, box_min3, (size_t)n_planes * 24); std::memcpy(pl.data() + 7 * (size_t)n_planes, box_max3, (size_t)n_planes * 24); }
+  if ((rc = upload(c, c->d_up[5], pl.data(), pl.size() * 8))) return rc;
+  if ((rc = dev_alloc(c, c->d_up[6], npt * 4))) return rc;
+  { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
+    if ((rc = assoc_device(c, (const float4*)c->d_up[4].p, H, W, n_planes, (const double*)c->d_up[5].p, radius, sel_per_ring, (int*)c->d_up[6].p))) return rc; }
+  if (npt) LVX_HIP(c, hipMemcpyAsync(plane_of_point, c->d_up[6].p, npt * 4, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  return LVX_OK;
+}
+int lvx_surfel_assoc_d(lvx_ctx* c, int H, int W, const float* scan_d, int n_planes, const double* planes10_d, double radius, int sel_per_ring, int32_t* plane_of_point_d) {
+  if (!c || H <= 0 || W <= 0 || W > SA_WMAX || n_planes < 0 || !scan_d || !plane_of_point_d || (n_planes > 0 && !planes10_d)) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  ProfScope ps(c, LVX_KERNEL_UPSTREAM);
+  return assoc_device(c, (const float4*)scan_d, H, W, n_planes, planes10_d, radius, sel_per_ring, plane_of_point_d);
+}
+
+}  // extern "C"

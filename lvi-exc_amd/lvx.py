@@ -26,7 +26,8 @@ LOCK_GYRO_BIAS = 1 << 9
 LOCK_LANDMARKS = 1 << 10
 
 EVAL_COST, EVAL_RESIDUALS, EVAL_NORMAL_EQ, EVAL_JACOBIAN = 1, 2, 4, 8
-FAM_GYRO, FAM_ACCEL, FAM_PRIOR, FAM_SURFEL, FAM_REPROJ, FAM_CAMSURF, KERNEL_FOLD, KERNEL_SOLVE = range(8)
+FAM_GYRO, FAM_ACCEL, FAM_PRIOR, FAM_SURFEL, FAM_REPROJ, FAM_CAMSURF, KERNEL_FOLD, KERNEL_SOLVE, KERNEL_UPSTREAM = range(9)
+KERNEL_NAMES = ["gyro", "accel", "prior", "surfel", "reproj", "camsurf", "fold", "solve", "upstream"]
 JAC_WIDTH = 64
 
 
@@ -231,8 +232,8 @@ class Context:
         self._ck(self._l.lvx_set_profiling(self._h, C.c_int(1 if on else 0)))
 
     def kernel_ms(self):
-        ms = np.zeros(8)
-        n = np.zeros(8, dtype=np.int64)
+        ms = np.zeros(9)
+        n = np.zeros(9, dtype=np.int64)
         self._ck(self._l.lvx_get_kernel_ms(self._h, _p(ms), _p(n)))
         return ms, n
 
@@ -266,6 +267,70 @@ class Context:
         out = np.zeros_like(state)
         self._ck(self._l.lvx_plus(self._h, _p(state), _p(delta), _p(out)))
         return out
+
+
+RS_POINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad", "<f4"), ("intensity", "u1"), ("pad2", "u1"), ("ring", "<u2"),
+                     ("pad3", "<u4"), ("timestamp", "<f8")])
+
+
+class ScanRegOut(C.Structure):
+    _fields_ = [("n", C.c_int32)] + [(k, C.c_void_p) for k in ("cloud", "curvature", "label", "sort_ind", "picked", "scan_start", "scan_end",
+                                                                 "sharp", "less_sharp", "flat", "less_flat")] + [("counts", C.c_int32 * 4)]
+
+
+class VoxelInfo(C.Structure):
+    _fields_ = [("n_leaves", C.c_int32), ("n_points", C.c_int32), ("min_b", C.c_int32 * 3), ("max_b", C.c_int32 * 3), ("div_b", C.c_int32 * 3), ("divb_mul", C.c_int32 * 3)]
+
+
+def scan_register(ctx, pts, n_rings, min_range):
+    """A-LOAM scanRegistration core on the GPU; same result dict as oracle.scan_register."""
+    pts = np.ascontiguousarray(pts, dtype=RS_POINT)
+    n = len(pts)
+    cap = max(n, 1)
+    out = dict(cloud=np.zeros((cap, 4), np.float32), curvature=np.zeros(cap, np.float32), label=np.zeros(cap, np.int32), sort_ind=np.zeros(cap, np.int32),
+               picked=np.zeros(cap, np.int32), scan_start=np.zeros(n_rings, np.int32), scan_end=np.zeros(n_rings, np.int32),
+               sharp=np.zeros(cap, np.int32), less_sharp=np.zeros(cap, np.int32), flat=np.zeros(cap, np.int32), less_flat=np.zeros(cap, np.int32))
+    so = ScanRegOut()
+    for k in out:
+        setattr(so, k, out[k].ctypes.data)
+    ctx._ck(ctx._l.lvx_scan_register(ctx._h, C.c_int(n), _p(pts), C.c_int(n_rings), C.c_float(min_range), C.byref(so)))
+    m = so.n
+    for k in ("cloud", "curvature", "label", "sort_ind", "picked"):
+        out[k] = out[k][:m]
+    for i, k in enumerate(("sharp", "less_sharp", "flat", "less_flat")):
+        out[k] = out[k][:so.counts[i]].copy()
+    out["n"] = m
+    return out
+
+
+def voxel_build(ctx, xyzi, leaf, min_pts=6, eig_mult=0.01, fetch=True):
+    xyzi = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)
+    info = VoxelInfo()
+    ctx._ck(ctx._l.lvx_voxel_build(ctx._h, C.c_int(len(xyzi)), _p(xyzi), C.c_float(leaf), C.c_int(min_pts), C.c_double(eig_mult), C.byref(info)))
+    nl, n = info.n_leaves, len(xyzi)
+    o = dict(n_leaves=nl, grid=np.array(list(info.min_b) + list(info.max_b) + list(info.div_b) + list(info.divb_mul), np.int32))
+    if fetch:
+        o.update(leaf_key=np.zeros(nl, np.int32), leaf_n=np.zeros(nl, np.int32), mean=np.zeros((nl, 3)), cov=np.zeros((nl, 9)), icov=np.zeros((nl, 9)),
+                 evecs=np.zeros((nl, 9)), evals=np.zeros((nl, 3)), centroid=np.zeros((nl, 3), np.float32), offsets=np.zeros(nl + 1, np.int32),
+                 point_ids=np.zeros(max(n, 1), np.int32))
+        ctx._ck(ctx._l.lvx_voxel_get(ctx._h, *[_p(o[k]) for k in ("leaf_key", "leaf_n", "mean", "cov", "icov", "evecs", "evals", "centroid", "offsets", "point_ids")]))
+    return o
+
+
+def voxel_lookup7(ctx, queries):
+    q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, 4)
+    ids = np.full((len(q), 7), -1, np.int32)
+    ctx._ck(ctx._l.lvx_voxel_lookup7(ctx._h, C.c_int(len(q)), _p(q), _p(ids)))
+    return ids
+
+
+def surfel_assoc(ctx, scan_hw4, p4, box_min, box_max, radius=0.05, sel=2):
+    scan = np.ascontiguousarray(scan_hw4, dtype=np.float32)
+    H, W = scan.shape[0], scan.shape[1]
+    p4, box_min, box_max = _d(p4), _d(box_min), _d(box_max)
+    flag = np.full(H * W, -1, np.int32)
+    ctx._ck(ctx._l.lvx_surfel_assoc(ctx._h, C.c_int(H), C.c_int(W), _p(scan), C.c_int(len(p4)), _p(p4), _p(box_min), _p(box_max), C.c_double(radius), C.c_int(sel), _p(flag)))
+    return flag.reshape(H, W)
 
 
 def load_problem(obj, P, locks=None):

@@ -387,3 +387,111 @@ def make_bench_problem(seed=4, n_imu=200_000, n_surfel=1_000_000, n_reproj=50_00
                 n_landmarks=n_landmarks, lm_uv=lm_uv, lm_t0=lm_t0, rep_lm=rep_lm, rep_uv=rep_uv, rep_t0=rep_t0, huber_rep=5.0, w_rep=1.0,
                 cs_lm=np.zeros(0, dtype=np.int32), cs_plane=np.zeros(0, dtype=np.int32), huber_cs=5.0, w_cs=30.0,
                 state_true=state_true, state0=state0, t_start=t_start, t_end=t_end)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# upstream kernels: synthetic VLP-16 sweep, voxel cloud, organised scan + surfel planes
+# ---------------------------------------------------------------------------------------------------------
+RS_POINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad", "<f4"), ("intensity", "u1"), ("pad2", "u1"), ("ring", "<u2"),
+                     ("pad3", "<u4"), ("timestamp", "<f8")])   # RsPointXYZIRT (aloam scanRegistration.cpp:57-66), 32 bytes
+
+
+def _raycast_room(dirs, origin, half=(10.0, 7.5), z_lo=-1.5, z_hi=1.5, pillars=((3, 2, 0.3), (-4, 3, 0.4), (5, -3, 0.35), (-2, -4, 0.3))):
+    """Range along unit rays to the inside of a box room (20 x 15 x 3 m) with 4 vertical cylinders."""
+    o = np.asarray(origin, dtype=np.float64)
+    d = dirs.astype(np.float64)
+    t = np.full(len(d), np.inf)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for ax, (lo, hi) in enumerate(((-half[0], half[0]), (-half[1], half[1]), (z_lo, z_hi))):
+            for wall in (lo, hi):
+                tt = (wall - o[ax]) / d[:, ax]
+                p = o[None, :] + tt[:, None] * d
+                ok = (tt > 0) & (np.abs(p[:, 0]) <= half[0] + 1e-9) & (np.abs(p[:, 1]) <= half[1] + 1e-9) & (p[:, 2] >= z_lo - 1e-9) & (p[:, 2] <= z_hi + 1e-9)
+                t = np.where(ok & (tt < t), tt, t)
+        for cx, cy, r in pillars:
+            a = d[:, 0] ** 2 + d[:, 1] ** 2
+            b = 2 * ((o[0] - cx) * d[:, 0] + (o[1] - cy) * d[:, 1])
+            c = (o[0] - cx) ** 2 + (o[1] - cy) ** 2 - r * r
+            disc = b * b - 4 * a * c
+            tt = (-b - np.sqrt(np.maximum(disc, 0))) / (2 * a)
+            z = o[2] + tt * d[:, 2]
+            ok = (disc > 0) & (tt > 0) & (z >= z_lo) & (z <= z_hi)
+            t = np.where(ok & (tt < t), tt, t)
+    return t
+
+
+def make_vlp16_sweep(seed=1, n_az=1800, n_rings=16, noise=0.02, drop_frac=0.01):
+    """One VLP-16-like sweep, azimuth-major firing order (all rings per azimuth step), range noise, a few NaN and near returns."""
+    rng = np.random.default_rng(seed)
+    az = np.deg2rad(np.arange(n_az) * (360.0 / n_az))
+    el = np.deg2rad(np.linspace(-15.0, 15.0, n_rings))
+    A, E = np.meshgrid(az, el, indexing="ij")   # (n_az, n_rings)
+    dirs = np.stack([np.cos(E) * np.cos(A), np.cos(E) * np.sin(A), np.sin(E)], axis=-1).reshape(-1, 3)
+    rngs = _raycast_room(dirs, (0.3, -0.2, 0.0)) + noise * rng.standard_normal(len(dirs))
+    pts = np.zeros(len(dirs), dtype=RS_POINT)
+    xyz = (dirs * rngs[:, None]).astype(np.float32)
+    pts["x"], pts["y"], pts["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    pts["ring"] = np.tile(np.arange(n_rings, dtype=np.uint16), n_az)
+    pts["intensity"] = rng.integers(0, 255, len(dirs)).astype(np.uint8)
+    pts["timestamp"] = 1638000000.0 + np.repeat(np.arange(n_az) / n_az * 0.1, n_rings)
+    k = rng.random(len(dirs))
+    pts["x"][k < drop_frac] = np.nan                       # dropped returns
+    near = (k > 1 - drop_frac / 2)
+    pts["x"][near] *= 0.01; pts["y"][near] *= 0.01; pts["z"][near] *= 0.01   # inside minimum_range
+    return pts
+
+
+def make_voxel_cloud(seed=2, n=100_000):
+    """60 % on 12 planes (sigma 2 cm), 30 % on 6 cylinders, 10 % uniform in 40 x 40 x 6 m; float32 xyzi."""
+    rng = np.random.default_rng(seed)
+    n_pl, n_cy = int(0.6 * n), int(0.3 * n)
+    n_un = n - n_pl - n_cy
+    out = []
+    pid = rng.integers(0, 12, n_pl)
+    nrm = rng.standard_normal((12, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    ctr = rng.uniform([-15, -15, -2], [15, 15, 2], (12, 3))
+    e1 = np.cross(nrm, [0.3, -0.5, 0.8]); e1 /= np.linalg.norm(e1, axis=1, keepdims=True); e2 = np.cross(nrm, e1)
+    uv = rng.uniform(-4, 4, (n_pl, 2))
+    out.append(ctr[pid] + uv[:, :1] * e1[pid] + uv[:, 1:] * e2[pid] + 0.02 * rng.standard_normal((n_pl, 1)) * nrm[pid])
+    cid = rng.integers(0, 6, n_cy)
+    cc = rng.uniform([-15, -15], [15, 15], (6, 2)); cr = rng.uniform(0.2, 0.8, 6)
+    th = rng.uniform(0, 2 * np.pi, n_cy); zz = rng.uniform(-3, 3, n_cy)
+    out.append(np.stack([cc[cid, 0] + cr[cid] * np.cos(th), cc[cid, 1] + cr[cid] * np.sin(th), zz], axis=1) + 0.01 * rng.standard_normal((n_cy, 3)))
+    out.append(rng.uniform([-20, -20, -3], [20, 20, 3], (n_un, 3)))
+    xyz = np.concatenate(out)[rng.permutation(n)]
+    return np.concatenate([xyz, rng.uniform(0, 255, (n, 1))], axis=1).astype(np.float32)
+
+
+def rigid_move(xyzi, t=(0.1, 0.05, 0.02), yaw_deg=1.0):
+    c, s = np.cos(np.deg2rad(yaw_deg)), np.sin(np.deg2rad(yaw_deg))
+    R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+    out = np.array(xyzi, dtype=np.float32)
+    out[:, :3] = (xyzi[:, :3].astype(np.float64) @ R.T + np.asarray(t)).astype(np.float32)
+    return out
+
+
+def make_assoc_problem(seed=5, H=16, W=1800, n_planes=400):
+    """Organised scan (H x W, float xyzi, NaN holes) in the map frame + surfel planes (p4, AABB) cut from the room's surfaces."""
+    rng = np.random.default_rng(seed)
+    az = np.deg2rad(np.arange(W) * (360.0 / W)); el = np.deg2rad(np.linspace(-15, 15, H))
+    E, A = np.meshgrid(el, az, indexing="ij")
+    dirs = np.stack([np.cos(E) * np.cos(A), np.cos(E) * np.sin(A), np.sin(E)], axis=-1).reshape(-1, 3)
+    r = _raycast_room(dirs, (0.3, -0.2, 0.0)) + 0.01 * rng.standard_normal(H * W)
+    xyz = dirs * r[:, None]
+    scan = np.concatenate([xyz, np.zeros((H * W, 1))], axis=1).astype(np.float32).reshape(H, W, 4)
+    scan[rng.random((H, W)) < 0.02, 0] = np.nan
+    # surfels: 0.5 m voxels around random scan points, plane = local wall
+    p4 = np.zeros((n_planes, 4)); bmin = np.zeros((n_planes, 3)); bmax = np.zeros((n_planes, 3))
+    valid = np.argwhere(~np.isnan(scan[..., 0]))
+    walls = np.array([[1, 0, 0, -10.0], [1, 0, 0, 10.0], [0, 1, 0, -7.5], [0, 1, 0, 7.5], [0, 0, 1, -1.5], [0, 0, 1, 1.5]])
+    for i in range(n_planes):
+        h, w = valid[rng.integers(len(valid))]
+        c = scan[h, w, :3].astype(np.float64)
+        d = np.abs(walls[:, :3] @ c - walls[:, 3])
+        k = int(np.argmin(d))
+        n_ = walls[k, :3] * (1 if rng.random() < 0.5 else -1)
+        off = -n_ @ (walls[k, :3] * walls[k, 3])
+        p4[i] = [n_[0], n_[1], n_[2], off + 0.005 * rng.standard_normal()]
+        lo = np.floor(c / 1.0) * 1.0
+        bmin[i] = lo + rng.uniform(0, 0.05, 3); bmax[i] = lo + 1.0 - rng.uniform(0, 0.05, 3)
+    return scan, p4, bmin, bmax

@@ -180,3 +180,68 @@ def dense_jacobian(jac_cols, jac_vals, n_tangent):
     m = c >= 0
     np.add.at(J, (rows[m], c[m]), jac_vals.ravel()[m])
     return J
+
+
+# ---------------------------------------------------------------------------------------------------------
+# upstream kernels (oracle/orc_upstream.cpp)
+# ---------------------------------------------------------------------------------------------------------
+RS_POINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad", "<f4"), ("intensity", "u1"), ("pad2", "u1"), ("ring", "<u2"),
+                     ("pad3", "<u4"), ("timestamp", "<f8")])   # RsPointXYZIRT, scanRegistration.cpp:57-66 (32 bytes)
+assert RS_POINT.itemsize == 32
+
+
+def scan_register(pts, n_rings, min_range):
+    pts = np.ascontiguousarray(pts, dtype=RS_POINT)
+    n = len(pts)
+    out = dict(cloud=np.zeros((n, 4), np.float32), curvature=np.zeros(n, np.float32), label=np.zeros(n, np.int32), sort_ind=np.zeros(n, np.int32),
+               picked=np.zeros(n, np.int32), scan_start=np.zeros(n_rings, np.int32), scan_end=np.zeros(n_rings, np.int32))
+    lists = [np.zeros(max(n, 1), np.int32) for _ in range(4)]
+    counts = np.zeros(4, np.int32)
+    l = lib()
+    l.orc_scan_register.restype = C.c_int
+    m = l.orc_scan_register(C.c_int(n), _p(pts), C.c_int(n_rings), C.c_float(min_range), _p(out["cloud"]), _p(out["curvature"]), _p(out["label"]),
+                            _p(out["sort_ind"]), _p(out["picked"]), _p(out["scan_start"]), _p(out["scan_end"]), *[_p(a) for a in lists], _p(counts))
+    for k in ("cloud", "curvature", "label", "sort_ind", "picked"):
+        out[k] = out[k][:m]
+    out["n"] = m
+    for name, a, c in zip(("sharp", "less_sharp", "flat", "less_flat"), lists, counts):
+        out[name] = a[:c].copy()
+    return out
+
+
+def voxel_build(xyzi, leaf, min_pts=6, eig_mult=0.01):
+    xyzi = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)
+    n = len(xyzi)
+    cap = max(n, 1)
+    grid = np.zeros(12, np.int32)
+    o = dict(leaf_key=np.zeros(cap, np.int32), leaf_n=np.zeros(cap, np.int32), mean=np.zeros((cap, 3)), cov=np.zeros((cap, 9)), icov=np.zeros((cap, 9)),
+             evecs=np.zeros((cap, 9)), evals=np.zeros((cap, 3)), centroid=np.zeros((cap, 3), np.float32), offsets=np.zeros(cap + 1, np.int32),
+             point_ids=np.zeros(cap, np.int32))
+    l = lib()
+    l.orc_voxel_build.restype = C.c_int
+    nl = l.orc_voxel_build(C.c_int(n), _p(xyzi), C.c_float(leaf), C.c_int(min_pts), C.c_double(eig_mult), _p(grid), _p(o["leaf_key"]), _p(o["leaf_n"]),
+                           _p(o["mean"]), _p(o["cov"]), _p(o["icov"]), _p(o["evecs"]), _p(o["evals"]), _p(o["centroid"]), _p(o["offsets"]), _p(o["point_ids"]), C.c_int(cap))
+    assert nl >= 0
+    for k in ("leaf_key", "leaf_n", "mean", "cov", "icov", "evecs", "evals", "centroid"):
+        o[k] = o[k][:nl]
+    o["offsets"] = o["offsets"][:nl + 1]
+    o["grid"] = grid
+    o["n_leaves"] = nl
+    return o
+
+
+def voxel_lookup7(vox, queries, leaf, min_pts=6):
+    q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, 4)
+    ids = np.full((len(q), 7), -1, np.int32)
+    lk, ln = np.ascontiguousarray(vox["leaf_key"]), np.ascontiguousarray(vox["leaf_n"])
+    lib().orc_voxel_lookup7(C.c_int(len(q)), _p(q), C.c_float(leaf), C.c_int(min_pts), _p(vox["grid"]), C.c_int(vox["n_leaves"]), _p(lk), _p(ln), _p(ids))
+    return ids
+
+
+def surfel_assoc(scan_hw4, p4, box_min, box_max, radius=0.05, sel=2):
+    scan = np.ascontiguousarray(scan_hw4, dtype=np.float32)
+    H, W = scan.shape[0], scan.shape[1]
+    p4, box_min, box_max = _d(p4), _d(box_min), _d(box_max)
+    flag = np.full(H * W, -1, np.int32)
+    lib().orc_surfel_assoc(C.c_int(H), C.c_int(W), _p(scan), C.c_int(len(p4)), _p(p4), _p(box_min), _p(box_max), C.c_double(radius), C.c_int(sel), _p(flag))
+    return flag.reshape(H, W)

@@ -1,0 +1,131 @@
+"""GPU parity of the upstream point-cloud kernels vs the serial CPU oracle (oracle/orc_upstream.cpp).
+
+scanRegistration: bit-exact (float curvature bits, labels, sorted indices, the four index lists) on tie-free sweeps.
+voxel grid: leaf keys / counts / point lists exact; mean, cov 1e-12 rel; eigenvalues 1e-10 rel; eigenvectors up to sign;
+inverse covariance 1e-8 rel.  DIRECT7 lookup and surfel association: exact integers.
+"""
+import numpy as np
+import pytest
+
+import lvx
+import synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = lvx.Context(0)
+    yield c
+    c.close()
+
+
+def _check_scanreg(ctx, pts, n_rings, min_range, strict=True):
+    ro = O.scan_register(pts, n_rings, min_range)
+    rg = lvx.scan_register(ctx, pts, n_rings, min_range)
+    assert rg["n"] == ro["n"]
+    assert np.array_equal(rg["scan_start"], ro["scan_start"]) and np.array_equal(rg["scan_end"], ro["scan_end"])
+    assert np.array_equal(rg["cloud"].view(np.uint32), ro["cloud"].view(np.uint32))
+    assert np.array_equal(rg["curvature"].view(np.uint32), ro["curvature"].view(np.uint32))
+    if strict:
+        for k in ("label", "picked", "sort_ind", "sharp", "less_sharp", "flat", "less_flat"):
+            assert np.array_equal(rg[k], ro[k]), k
+    else:   # equal curvatures inside a sector: std::sort (unstable) may order them differently -> compare modulo tie permutation
+        c = ro["curvature"]
+        assert np.array_equal(c[rg["sort_ind"]].view(np.uint32), c[ro["sort_ind"]].view(np.uint32))
+        assert np.array_equal(np.sort(rg["sort_ind"]), np.sort(ro["sort_ind"]))
+    return ro
+
+
+@pytest.mark.parametrize("seed", [1, 3, 4])
+def test_scan_register_vlp16_bit_exact(ctx, seed):
+    pts = synth.make_vlp16_sweep(seed=seed)
+    ro = _check_scanreg(ctx, pts, 16, 0.3)
+    c = ro["curvature"]
+    for i in range(16):            # the comparison is only meaningful on tie-free sectors (std::sort is unstable)
+        s, e = ro["scan_start"][i], ro["scan_end"][i]
+        for j in range(6):
+            sp, ep = s + (e - s) * j // 6, s + (e - s) * (j + 1) // 6 - 1
+            assert len(np.unique(c[sp:ep + 1])) == ep - sp + 1
+    assert len(ro["sharp"]) > 100 and len(ro["flat"]) > 300
+
+
+def test_scan_register_with_curvature_ties(ctx):
+    """Seed 2 has one pair of equal curvatures in a sector; the GPU orders ties by index (what a stable sort gives)."""
+    _check_scanreg(ctx, synth.make_vlp16_sweep(seed=2), 16, 0.3, strict=False)
+
+
+def test_scan_register_edge_cases(ctx):
+    pts = synth.make_vlp16_sweep(seed=4, n_az=40)           # rings too short for 6 sectors of >= 1 point after the +-5 margin
+    _check_scanreg(ctx, pts, 16, 0.3)
+    pts = synth.make_vlp16_sweep(seed=5, n_az=300)
+    pts["ring"][:] = 3                                        # everything on one ring, 15 rings empty
+    _check_scanreg(ctx, pts, 16, 0.3)
+    r = lvx.scan_register(ctx, pts[:0], 16, 0.3)
+    assert r["n"] == 0 and len(r["sharp"]) == 0
+    pts = synth.make_vlp16_sweep(seed=6, n_az=200)
+    _check_scanreg(ctx, pts, 16, 100.0)                       # min range removes every point
+
+
+def _check_voxels(vg, vo):
+    assert vg["n_leaves"] == vo["n_leaves"] and np.array_equal(vg["grid"], vo["grid"])
+    assert np.array_equal(vg["leaf_key"], vo["leaf_key"]) and np.array_equal(vg["leaf_n"], vo["leaf_n"])
+    assert np.array_equal(vg["offsets"], vo["offsets"]) and np.array_equal(vg["point_ids"][:vo["offsets"][-1]], vo["point_ids"][:vo["offsets"][-1]])
+    assert np.allclose(vg["mean"], vo["mean"], rtol=1e-12, atol=1e-12)
+    assert np.array_equal(vg["centroid"].view(np.uint32), vo["centroid"].view(np.uint32))
+    ok = vo["leaf_n"] >= 6
+    sc = np.abs(vo["cov"][ok]).max(axis=1, keepdims=True)
+    assert (np.abs(vg["cov"][ok] - vo["cov"][ok]) <= 1e-12 * sc + 1e-18).all()
+    assert np.allclose(vg["evals"][ok], vo["evals"][ok], rtol=1e-10, atol=1e-16)
+    si = np.abs(vo["icov"][ok]).max(axis=1, keepdims=True)
+    assert (np.abs(vg["icov"][ok] - vo["icov"][ok]) <= 1e-8 * si).all()
+    Vg, Vo = vg["evecs"][ok].reshape(-1, 3, 3), vo["evecs"][ok].reshape(-1, 3, 3)
+    ev = vo["evals"][ok]
+    sep = (np.diff(ev, axis=1).min(axis=1) > 1e-6 * ev[:, 2])       # eigenvectors only comparable for separated eigenvalues
+    dots = np.abs(np.einsum("nij,nij->nj", Vg[sep], Vo[sep]))
+    assert (dots > 1 - 1e-8).all()
+
+
+def test_voxel_build_and_lookup_config2(ctx):
+    cloud = synth.make_voxel_cloud(seed=2, n=100_000)
+    vo = O.voxel_build(cloud, 0.5)
+    vg = lvx.voxel_build(ctx, cloud, 0.5)
+    _check_voxels(vg, vo)
+    q = synth.rigid_move(cloud)
+    assert np.array_equal(lvx.voxel_lookup7(ctx, q), O.voxel_lookup7(vo, q, 0.5))
+
+
+def test_voxel_edge_cases(ctx):
+    cloud = synth.make_voxel_cloud(seed=7, n=5000)
+    cloud[::97, 0] = np.nan
+    cloud[5::131, 2] = np.inf
+    vo = O.voxel_build(cloud, 1.0)
+    vg = lvx.voxel_build(ctx, cloud, 1.0)
+    _check_voxels(vg, vo)
+    far = cloud.copy(); far[:, :3] += 500.0                   # queries outside the grid
+    far[::7, 0] = np.nan
+    assert np.array_equal(lvx.voxel_lookup7(ctx, far), O.voxel_lookup7(vo, far, 1.0))
+    one = np.array([[0.1, 0.2, 0.3, 0.0]] * 7, np.float32)    # a single voxel, 7 coincident points: singular covariance
+    vo1, vg1 = O.voxel_build(one, 0.5), lvx.voxel_build(ctx, one, 0.5)
+    assert np.array_equal(vg1["leaf_n"], vo1["leaf_n"]) and vg1["n_leaves"] == 1
+    assert lvx.voxel_build(ctx, one[:0], 0.5)["n_leaves"] == 0
+
+
+@pytest.mark.parametrize("n_planes", [1, 400, 3000])
+def test_surfel_assoc_exact(ctx, n_planes):
+    scan, p4, bmin, bmax = synth.make_assoc_problem(seed=5, n_planes=n_planes)
+    fo = O.surfel_assoc(scan, p4, bmin, bmax, 0.05, 2)
+    fg = lvx.surfel_assoc(ctx, scan, p4, bmin, bmax, 0.05, 2)
+    assert np.array_equal(fg, fo)
+    if n_planes >= 400:
+        assert (fo >= 0).sum() > 50
+
+
+def test_surfel_assoc_overlapping_planes_serial_rule(ctx):
+    scan, p4, bmin, bmax = synth.make_assoc_problem(seed=6, n_planes=50)
+    p4 = np.concatenate([p4, p4]); bmin = np.concatenate([bmin, bmin]); bmax = np.concatenate([bmax, bmax])   # duplicates: higher id must win
+    fo = O.surfel_assoc(scan, p4, bmin, bmax, 0.05, 2)
+    fg = lvx.surfel_assoc(ctx, scan, p4, bmin, bmax, 0.05, 2)
+    assert np.array_equal(fg, fo)
+    assert (fo[fo >= 0] >= 50).all()
