@@ -1,0 +1,69 @@
+"""CPU check of the DEVICE math: the __host__ __device__ analytic-Jacobian functions of lvx_math.h / lvx_resid.h, built with
+g++ (tests/native), against the oracle's dual-number Jacobians.  No GPU needed; this is not a product code path."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import lvx
+import synth
+from oracle import oracle as O
+
+TAU = O.LOCK_LIDAR_TAU | O.LOCK_CAM_TAU
+
+
+def _hc_eval(hc, o, state):
+    nr, mc = o.num_residuals, 128
+    cost = C.c_double(0)
+    res = np.zeros(nr); jc = np.full((nr, mc), -1, np.int32); jv = np.zeros((nr, mc))
+    rc = hc.hc_evaluate(o._h, O._p(O._d(state)), C.byref(cost), O._p(res), O._p(jc), O._p(jv))
+    return rc, cost.value, res, jc, jv
+
+
+def _compare(hc, P, locks, prior=True, so3_only=False):
+    o = O.Oracle(); lvx.load_problem(o, P, locks)
+    if prior:
+        o.set_orientation_prior(P["t0"], np.array([np.cos(5e-5), 0, 0, np.sin(5e-5)]), 28.0)
+    o.set_so3_only(so3_only)
+    for name in ("state0", "state_true"):
+        r = o.evaluate(P[name], jac=True)
+        rc, cost, res, jc, jv = _hc_eval(hc, o, P[name])
+        assert rc == 0
+        assert abs(cost - r["cost"]) <= 1e-12 * abs(r["cost"])
+        assert np.abs(res - r["residuals"]).max() <= 1e-11 * np.abs(r["residuals"]).max()
+        Jo = O.dense_jacobian(r["jac_cols"], r["jac_vals"], o.tangent_size)
+        Jh = O.dense_jacobian(jc, jv, o.tangent_size)
+        assert np.abs(Jo - Jh).max() <= 1e-12 * np.abs(Jo).max()
+
+
+@pytest.mark.parametrize("seed,noise", [(4, True), (5, False)])
+def test_all_families(host_check_lib, seed, noise):
+    P = synth.make_problem(seed=seed, duration=2.0, n_surfel=400, n_planes=10, n_landmarks=30, n_camsurf=10, noise=noise)
+    _compare(host_check_lib, P, TAU)
+
+
+def test_locks_and_so3_only(host_check_lib):
+    P = synth.make_problem(seed=6, duration=1.0, n_surfel=100, n_planes=5, n_landmarks=10, n_camsurf=4)
+    _compare(host_check_lib, P, TAU | O.LOCK_TRAJ | O.LOCK_LIDAR_Q | O.LOCK_LIDAR_P)
+    P2 = synth.make_problem(seed=7, duration=1.0, n_surfel=0, n_planes=1, n_landmarks=0)
+    _compare(host_check_lib, P2, TAU | O.LOCK_R3 | O.LOCK_ACC_BIAS | O.LOCK_GYRO_BIAS, so3_only=True)
+
+
+def test_distortion(host_check_lib):
+    cam = dict(synth.DEFAULT_CAMERA, k1=-0.0397646985948, k2=0.00802944041788, p1=-0.0043042199686, p2=-0.0001040279967, k3=0.00030608999077)
+    P = synth.make_problem(seed=8, duration=1.0, n_surfel=50, n_planes=4, n_landmarks=20, n_camsurf=5, camera=cam)
+    _compare(host_check_lib, P, TAU)
+
+
+def test_large_relative_rotation_between_control_points(host_check_lib):
+    """logq has no hemisphere handling (quaternion_math.h:46-52): exercise relative rotations well past the series region."""
+    P = synth.make_problem(seed=9, duration=1.0, n_surfel=60, n_planes=4, n_landmarks=0)
+    N = P["n_knots"]
+    rng = np.random.default_rng(1)
+    for key in ("state0", "state_true"):
+        s = P[key].copy()
+        so3 = s[3 * N:7 * N].reshape(N, 4)
+        so3[:] = synth.qmul(synth.q_from_rotvec(0.9 * rng.standard_normal((N, 3))), so3)
+        so3 /= np.linalg.norm(so3, axis=1, keepdims=True)
+        P[key] = s
+    _compare(host_check_lib, P, TAU, prior=False)
