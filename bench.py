@@ -112,7 +112,7 @@ def main():
     if world > 1:
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)   # evaluation, export and the all-reduce share one stream
     what = lvx.EVAL_COST | lvx.EVAL_NORMAL_EQ
-    nbd = lo["n_border"]
+    nbd = lo["border_ld"]
     red = torch.zeros(nbd * nbd + nbd + 1, dtype=torch.float64, device="cuda") if world > 1 else None
 
     def step():
@@ -160,9 +160,9 @@ def main():
         surf_ms = ms[k] / max(1, launches[k])
         alg_bytes = BYTES_PER_EVAL["surfel"] * n_surf
         achieved = alg_bytes / (surf_ms * 1e-3) / 1e9 if surf_ms > 0 else 0.0
-        out["roofline"] = {"bound": "hbm", "kernel": "k_family<SurfFam>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        out["roofline"] = {"bound": "hbm", "kernel": "k_family_acc<SurfAcc>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": None, "avg_launch_ms": surf_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                           "note": "the fused residual+Jacobian+J^T J kernel is FP64-VALU/atomic bound, not HBM bound (SURVEY.md 8d): ~9 kFLOP per 60 B",
+                           "note": "fused residual+Jacobian+J^T J kernel: FP64-VALU / LDS / atomic bound, not HBM bound (SURVEY.md 8d: ~9 kFLOP per 60 B); duration measured while the gyro/accel/reprojection kernels run concurrently on sibling streams",
                            "fp64_valu": {"achieved_tflops": 9e3 * n_surf / (surf_ms * 1e-3) / 1e12 if surf_ms > 0 else 0.0, "peak_tflops": FP64_VALU_PEAK_TFLOPS}}
         out["kernel_ms"] = {lvx.KERNEL_NAMES[i]: ms[i] / max(1, launches[i]) for i in range(len(ms)) if launches[i]}
         if not args.no_cpu_baseline and world == 1:

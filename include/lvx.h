@@ -90,6 +90,7 @@ typedef struct lvx_layout {
   int32_t n_band;      /* variables in the banded part (non-hub knots interleaved with landmarks) */
   int32_t bandwidth;   /* scalar half-bandwidth of the banded part */
   int32_t n_border;    /* dense border: hub knots (6 each) then the 22 calibration scalars */
+  int32_t border_ld;   /* leading dimension of the border block as exported by lvx_export_border_d (n_border + pseudo-pose rows) */
   int32_t n_hub_knots, hub_knot0;
   int64_t n_blocks;    /* residual blocks per evaluation */
   int64_t n_residuals; /* residual rows per evaluation */
@@ -143,7 +144,7 @@ int lvx_get_jacobian(lvx_ctx* ctx, int32_t* cols, double* vals);
 /* run on a caller-owned HIP stream (e.g. torch's current stream) instead of the context's own; NULL restores the own stream */
 int lvx_set_stream(lvx_ctx* ctx, void* hip_stream);
 /* multi-GPU (one calibration sequence per GPU): copy the dense border block of the last normal equations —
- * C[n_border^2] (lower triangle), g_c[n_border], cost — into a caller-owned DEVICE buffer of n_border^2 + n_border + 1 doubles,
+ * C[border_ld^2] (lower triangle), g_c[border_ld], cost — into a caller-owned DEVICE buffer of border_ld^2 + border_ld + 1 doubles,
  * queued on the context's stream, ready for one RCCL all-reduce */
 int lvx_export_border_d(lvx_ctx* ctx, double* out_d);
 /* keep `state` resident in the context's device buffer; lvx_evaluate_d(ctx, NULL, ...) then evaluates it without any host traffic */

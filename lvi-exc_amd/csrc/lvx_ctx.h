@@ -11,6 +11,8 @@
 
 #define LVX_NREP 64                 // replicas of the dense border accumulators (spreads same-address atomics)
 #define LVX_DEAD (-2147483647 - 1)  // ord[] value of a constant (locked) tangent scalar
+#define LVX_CHUNK_R 16              // knot intervals per workgroup of the LDS-accumulating assembly kernel
+#define LVX_ERR_FALLBACK 16         // device error bit: fast assembly kernel met a corner it does not handle; re-run with the legacy kernels
 
 namespace lvx {
 
@@ -25,7 +27,9 @@ struct DevCommon {
   CamIntr cam;
   // layout
   const int* ord;
-  int nb, bw, nbd;
+  int nb, bw, nbd;   // nbd: assembly border size (solve border + pseudo rows) = leading dimension of C
+  int nbd_solve;
+  const void* hubs;  // HubShared[2]: surfel (tau_L) and cam-surfel (tau_C) poses at t_map
   double* Hb;    // [nb][bw+1] lower band, column-major by column
   double* gb;    // [nb]
   double* Bd;    // [nbd][nb]
@@ -60,6 +64,8 @@ struct lvx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;
+  hipStream_t fam_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // concurrent family kernels
+  hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   std::string last_error;
   // problem
   bool have_spline = false;
@@ -77,7 +83,10 @@ struct lvx_ctx {
   // layout
   bool layout_dirty = true;
   std::vector<int> ord;
-  int nb = 0, bw = 0, nbd = 0, n_hub = 0, hub0 = 0;
+  int nb = 0, bw = 0, nbd = 0, nbd_ext = 0, n_hub = 0, hub0 = 0;   // nbd: solve border (hub knots + 22 calib); nbd_ext = nbd + 12 pseudo rows
+  bool force_legacy = false;   // set when the fast assembly kernels hit a case only the per-segment kernels handle exactly
+  lvx::DevBuf d_hubs, d_chunk[LVX_NUM_FAM], d_pairs_acc[2];
+  int n_chunk[LVX_NUM_FAM] = {0};
   lvx::DevBuf d_ord, d_Hb, d_gb, d_Bd, d_C, d_gc, d_cost, d_err, d_state, d_res, d_jcols, d_jvals, d_pairs[LVX_NUM_FAM];
   // solver workspace (lvx_solver.hip)
   lvx::DevBuf d_L, d_Y, d_S, d_delta, d_diag, d_scal, d_state_try, d_zero;
@@ -109,8 +118,8 @@ int ensure_layout(lvx_ctx* ctx);
 DevCommon make_common(lvx_ctx* ctx, const double* state_d, uint32_t what);
 // profiling scope: records a (start, stop) HIP event pair on ctx->stream around a launch when profiling is on
 struct ProfScope {
-  lvx_ctx* c; int kernel; size_t e0 = 0; bool on;
-  ProfScope(lvx_ctx* ctx, int k);
+  lvx_ctx* c; int kernel; size_t e0 = 0; bool on; hipStream_t st;
+  ProfScope(lvx_ctx* ctx, int k, hipStream_t stream = nullptr);
   ~ProfScope();
 };
 }  // namespace lvx

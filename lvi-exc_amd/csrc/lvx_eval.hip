@@ -13,11 +13,13 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <cstdlib>
 
 #include "lvx_ctx.h"
 
 namespace lvx {
 
+#define LVX_PW 4   // wavefronts per workgroup of k_family
 struct Keys { int k0, k1, lm; };
 LVX_HD bool same(const Keys& a, const Keys& b) { return a.k0 == b.k0 && a.k1 == b.k1 && a.lm == b.lm; }
 
@@ -177,21 +179,30 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-template <class F>
-__global__ __launch_bounds__(64) void k_family(F fam, DevCommon cm, const uint16_t* __restrict__ pairs, long long row0) {
+// PW = wavefronts per workgroup: wave 0 evaluates the 64 measurements (phase 1), all PW waves share the pair work of phase 2
+template <class F, int PW>
+__global__ __launch_bounds__(64 * PW) void k_family(F fam, DevCommon cm, const uint16_t* __restrict__ pairs, long long row0) {
   constexpr int NC = F::NC, NR = F::NR, TS = NR * 64 + 1, NP = NC * (NC + 1) / 2;
   __shared__ double Jt[NC * TS];
   __shared__ double rs[NR * 64];
-  __shared__ int cpos[NC];
+  __shared__ int cpos[64 * NC];
+  __shared__ int seg_l0[64], seg_ok[64];
+  __shared__ Keys seg_keys[64];
   __shared__ HubShared hub;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int rep = blockIdx.x % LVX_NREP;
+  __shared__ int nseg_s;
+  if (wave == 0) {
   const int si = blockIdx.x * 64 + lane;
   const bool in = si < fam.n;
   const SplineRef sp{cm.t0, cm.dt, cm.N, cm.state, cm.state + 3 * (size_t)cm.N};
   const Cal cal = load_cal(cm);
   if (F::USES_HUB) {
     if (lane == 0) fam.make_hub(cm, sp, cal, &hub);
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
   double r[NR];
   double J[NR][NC];
@@ -239,37 +250,49 @@ __global__ __launch_bounds__(64) void k_family(F fam, DevCommon cm, const uint16
     }
   }
   mycost = wave_sum(mycost);
-  if (lane == 0) atomicAdd(&cm.cost[blockIdx.x % LVX_NREP], mycost);
-  if (!(cm.what & LVX_EVAL_NORMAL_EQ)) return;
+  if (lane == 0) atomicAdd(&cm.cost[rep], mycost);
+  if (cm.what & LVX_EVAL_NORMAL_EQ) {
 #pragma unroll
-  for (int a = 0; a < NR; ++a) {
-    rs[lane * NR + a] = valid ? r[a] : 0.0;
+    for (int a = 0; a < NR; ++a) {
+      rs[lane * NR + a] = valid ? r[a] : 0.0;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) Jt[c * TS + lane * NR + a] = valid ? J[a][c] : 0.0;
+      for (int c = 0; c < NC; ++c) Jt[c * TS + lane * NR + a] = valid ? J[a][c] : 0.0;
+    }
+    // segment heads: first lane of every run of equal keys
+    Keys pk;
+    pk.k0 = __shfl_up(key.k0, 1); pk.k1 = __shfl_up(key.k1, 1); pk.lm = __shfl_up(key.lm, 1);
+    const bool head = (lane == 0) || !same(pk, key);
+    const unsigned long long heads = __ballot(head);
+    const int myseg = __popcll(heads & ((2ull << lane) - 1ull)) - 1;
+    if (head) { seg_l0[myseg] = lane; seg_ok[myseg] = valid ? 1 : 0; seg_keys[myseg] = key; }
+    if (lane == 0) nseg_s = __popcll(heads);
   }
+  }   // wave 0
+  if (!(cm.what & LVX_EVAL_NORMAL_EQ)) return;
   __syncthreads();
-  // segment heads: first lane of every run of equal keys
-  Keys pk;
-  pk.k0 = __shfl_up(key.k0, 1); pk.k1 = __shfl_up(key.k1, 1); pk.lm = __shfl_up(key.lm, 1);
-  const bool head = (lane == 0) || !same(pk, key);
-  unsigned long long heads = __ballot(head);
-  const int rep = blockIdx.x % LVX_NREP;
-  while (heads) {
-    const int l0 = __ffsll((long long)heads) - 1;
-    heads &= heads - 1;
-    const int l1 = heads ? (__ffsll((long long)heads) - 1) : 64;
-    Keys sk;
-    sk.k0 = __shfl(key.k0, l0); sk.k1 = __shfl(key.k1, l0); sk.lm = __shfl(key.lm, l0);
-    const int sv = __shfl((int)valid, l0);
-    if (!sv) continue;
-    if (lane < NC) cpos[lane] = cm.ord[fam.col(lane, sk, cm.N)];
-    __syncthreads();
+  const int nseg = nseg_s;
+  const int tid = threadIdx.x;
+  constexpr int NT = 64 * PW;
+  // column positions of every segment, computed once (no barriers inside the segment loop below)
+  for (int e = tid; e < nseg * NC; e += NT) { const int sg = e / NC, c = e % NC; cpos[e] = seg_ok[sg] ? cm.ord[fam.col(c, seg_keys[sg], cm.N)] : LVX_DEAD; }
+  // this thread's pair codes, reused for every segment
+  constexpr int ITER = (NP + NC + NT - 1) / NT;
+  unsigned code[ITER];
+#pragma unroll
+  for (int i = 0; i < ITER; ++i) { const int p = tid + NT * i; code[i] = p < NP ? pairs[p] : 0u; }
+  __syncthreads();
+  for (int sg = 0; sg < nseg; ++sg) {
+    if (!seg_ok[sg]) continue;
+    const int l0 = seg_l0[sg];
+    const int l1 = sg + 1 < nseg ? seg_l0[sg + 1] : 64;
     const int rb = l0 * NR, re = l1 * NR;
-    for (int p = lane; p < NP + NC; p += 64) {
+    const int* cp = &cpos[sg * NC];
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int p = tid + NT * i;
       if (p < NP) {
-        const unsigned ab = pairs[p];
-        const int a = ab & 0xff, b = ab >> 8;
-        const int pa = cpos[a], pb = cpos[b];
+        const int a = code[i] & 0xff, b = code[i] >> 8;
+        const int pa = cp[a], pb = cp[b];
         if (pa == LVX_DEAD || pb == LVX_DEAD) continue;
         const double* ja = &Jt[a * TS];
         const double* jb = &Jt[b * TS];
@@ -277,9 +300,9 @@ __global__ __launch_bounds__(64) void k_family(F fam, DevCommon cm, const uint16
         for (int row = rb; row < re; ++row) acc += ja[row] * jb[row];
         if (a != b && pa == pb) acc *= 2.0;
         add_H(cm, pa, pb, acc, rep);
-      } else {
+      } else if (p < NP + NC) {
         const int c = p - NP;
-        const int pc = cpos[c];
+        const int pc = cp[c];
         if (pc == LVX_DEAD) continue;
         const double* jc = &Jt[c * TS];
         double acc = 0.0;
@@ -287,8 +310,292 @@ __global__ __launch_bounds__(64) void k_family(F fam, DevCommon cm, const uint16
         add_g(cm, pc, acc, rep);
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fast assembly path.  A workgroup OWNS a range of LVX_CHUNK_R knot intervals: its 4 wavefronts evaluate the range's
+// measurements in batches of 256, transpose rows into per-wave LDS tiles, and accumulate J^T J of every segment into
+// workgroup-shared LDS accumulators (band window, border rows, dense border) with LDS atomics.  One flush of the
+// accumulators to HBM per workgroup replaces the per-segment global atomics of k_family (x6 fewer for surfels).
+// The pose at t_map, common to every surfel / cam-surfel residual, enters through 6 pseudo variables (d p_0, xi_0):
+// J_hub = g0^T M_hub, folded back onto the hub control points by k_fold_border.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_hub_eval(DevCommon cm, double t_map, int want_surf, int want_cs, HubShared* hubs) {
+  const int s = threadIdx.x;
+  if (s > 1) return;
+  if ((s == 0 && !want_surf) || (s == 1 && !want_cs)) { hubs[s].ok = 0; return; }
+  const SplineRef sp{cm.t0, cm.dt, cm.N, cm.state, cm.state + 3 * (size_t)cm.N};
+  const Cal cal = load_cal(cm);
+  const bool tl = s == 0 ? (cm.locks & LVX_LOCK_LIDAR_TAU) != 0 : (cm.locks & LVX_LOCK_CAM_TAU) != 0;
+  const double tau = s == 0 ? cal.lidar.tau : cal.cam.tau;
+  double s1[1][2]; hub_spans(t_map, tl, cm.sensor_mto, s1);
+  Segs sg; KnotRef kh; hubs[s].ok = 0;
+  if (!build_segments(sp, s1, 1, &sg)) return;
+  if (!seg_lookup(sp, sg, t_map + tau, &kh)) return;
+  if (!pose_eval<true>(sp, kh, &hubs[s].A)) { hubs[s].ok = -RES_NONUNIT; return; }
+  hubs[s].ok = 1;
+}
+
+struct GyroAcc {
+  enum { NK = 12, NG = 3, NR = 3, HUB = -1 };
+  int n; const double* t; const double* m3; const int* perm; double weight, huber;
+  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared*, int si, double r[NR], double (*J)[NK + NG], int& key) const {
+    return gyro_residual<true>(sp, cal.imu, t[si], load_v3(m3 + 3 * (size_t)si), weight, &key, r, J);
+  }
+  __device__ static int klv(int c) { return 6 * (c / 3) + 3 + c % 3; }
+  __device__ static int gcol(int g, int N, int nt) { return 6 * N + 5 + g; }
+};
+struct AccelAcc {
+  enum { NK = 24, NG = 5, NR = 3, HUB = -1 };
+  int n; const double* t; const double* m3; const int* perm; double weight, huber;
+  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared*, int si, double r[NR], double (*J)[NK + NG], int& key) const {
+    return accel_residual<true>(sp, cal.imu, t[si], load_v3(m3 + 3 * (size_t)si), weight, &key, r, J);
+  }
+  __device__ static int klv(int c) { return c; }
+  __device__ static int gcol(int g, int N, int nt) { return 6 * N + g; }
+};
+struct SurfAcc {
+  enum { NK = 24, NG = 12, NR = 1, HUB = 0 };
+  int n; const double* t; const double* pt; const int* plane; const int* perm; const double* planes; double t_map, weight, huber;
+  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared* hub, int si, double r[NR], double (*J)[NK + NG], int& key) const {
+    const bool tl = (cm.locks & LVX_LOCK_LIDAR_TAU) != 0;
+    const double tk = t[si];
+    const double pad = tl ? 0.0 : cm.sensor_mto;
+    const double spans[2][2] = {{t_map - pad, t_map + pad}, {tk - pad, tk + pad}};
+    Segs segs;
+    if (!build_segments(sp, spans, 2, &segs)) return RES_RANGE;
+    KnotRef kh;
+    if (!seg_lookup(sp, segs, t_map + cal.lidar.tau, &kh)) return RES_RANGE;
+    if (hub->ok != 1) return hub->ok < 0 ? RES_NONUNIT : RES_RANGE;
+    if (kh.i0 != hub->A.k.i0 || kh.u != hub->A.k.u) return LVX_ERR_FALLBACK;   // merged-segment corner: only the legacy kernel is exact
+    return surfel_residual_pseudo(sp, hub->A, segs, cal.lidar, tk, load_v3(pt + 3 * (size_t)si), load_v3(planes + 3 * (size_t)plane[si]), weight, &key, r, J);
+  }
+  __device__ static int klv(int c) { return c; }
+  __device__ static int gcol(int g, int N, int nt) { return g < 6 ? nt + g : 6 * N + 8 + (g - 6); }
+};
+struct CamSurfAcc {
+  enum { NK = 24, NG = 18, NR = 1, HUB = 1 };
+  int n; const int* lm; const int* plane; const int* perm; const double* planes; const double* lm_uv; const double* lm_t0; double t_map, weight, huber;
+  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared* hub, int si, double r[NR], double (*J)[NK + NG], int& key) const {
+    const bool tl = (cm.locks & LVX_LOCK_CAM_TAU) != 0;
+    const int l = lm[si];
+    const double tk = lm_t0[l];
+    const double pad = tl ? 0.0 : cm.sensor_mto;
+    const double spans[2][2] = {{t_map - pad, t_map + pad}, {tk - pad, tk + pad}};
+    Segs segs;
+    if (!build_segments(sp, spans, 2, &segs)) return RES_RANGE;
+    KnotRef kh;
+    if (!seg_lookup(sp, segs, t_map + cal.cam.tau, &kh)) return RES_RANGE;
+    if (hub->ok != 1) return hub->ok < 0 ? RES_NONUNIT : RES_RANGE;
+    if (kh.i0 != hub->A.k.i0 || kh.u != hub->A.k.u) return LVX_ERR_FALLBACK;
+    return camsurf_residual_pseudo(sp, hub->A, segs, cm.cam, cal.cam, cal.lidar, lm_uv[2 * l], lm_uv[2 * l + 1], tk, cal.rho[l],
+                                   load_v3(planes + 3 * (size_t)plane[si]), weight, &key, r, J);
+  }
+  __device__ static int klv(int c) { return c; }
+  __device__ static int gcol(int g, int N, int nt) { return g < 6 ? nt + 6 + g : (g < 12 ? 6 * N + 15 + (g - 6) : 6 * N + 8 + (g - 12)); }
+};
+
+#define ACC_LV ((LVX_CHUNK_R + 5) * 6)   // local variables of a chunk: knots [c R - 1, c R + R + 4)
+#define ACC_BW 24
+
+template <class F>
+__global__ __launch_bounds__(256) void k_family_acc(F fam, DevCommon cm, const int* __restrict__ chunk_off, const uint16_t* __restrict__ pairs, long long row0) {
+  constexpr int NK = F::NK, NG = F::NG, NC = NK + NG, NR = F::NR, TS = 65, NP = NC * (NC + 1) / 2;
+  extern __shared__ double sm[];
+  double* acc_band = sm;                              // [ACC_LV][ACC_BW]
+  double* acc_bd = acc_band + ACC_LV * ACC_BW;        // [NG][ACC_LV]
+  double* acc_gg = acc_bd + NG * ACC_LV;              // [NG][NG]
+  double* acc_gk = acc_gg + NG * NG;                  // [ACC_LV]
+  double* acc_gG = acc_gk + ACC_LV;                   // [NG]
+  double* tiles = acc_gG + NG;                        // 4 x ([NC][TS] + [64])
+  int* kpos = (int*)(tiles + 4 * (NC * TS + 64));     // [ACC_LV]
+  int* gpos = kpos + ACC_LV;                          // [NG]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int ch = blockIdx.x;
+  const int m0 = chunk_off[ch], m1 = chunk_off[ch + 1];
+  if (m0 >= m1) return;
+  const int k_lo = ch * LVX_CHUNK_R - 1;
+  const int nt = 6 * cm.N + 22 + cm.L;
+  const bool want_ne = (cm.what & LVX_EVAL_NORMAL_EQ) != 0;
+  for (int e = tid; e < ACC_LV * ACC_BW + NG * ACC_LV + NG * NG + ACC_LV + NG; e += 256) sm[e] = 0.0;
+  for (int e = tid; e < ACC_LV; e += 256) { const int k = k_lo + e / 6; kpos[e] = (k >= 0 && k < cm.N) ? cm.ord[6 * k + e % 6] : LVX_DEAD; }
+  if (tid < NG) gpos[tid] = cm.ord[F::gcol(tid, cm.N, nt)];
+  const SplineRef sp{cm.t0, cm.dt, cm.N, cm.state, cm.state + 3 * (size_t)cm.N};
+  const Cal cal = load_cal(cm);
+  const HubShared* hub = F::HUB >= 0 ? ((const HubShared*)cm.hubs) + F::HUB : nullptr;
+  double* Jt = tiles + wv * (NC * TS + 64);
+  double* rs = Jt + NC * TS;
+  const int rep = blockIdx.x % LVX_NREP;
+  double mycost = 0.0;
+  __syncthreads();
+  for (int base = m0; base < m1; base += 256) {
+    const int si = base + tid;
+    const bool in = si < m1;
+    double r[NR];
+    double J[NR][NC];
+    int key = -1;
+    bool valid = false;
+    if (in) {
+      const int status = fam.eval(cm, sp, cal, hub, si, r, J, key);
+      valid = status == RES_OK;
+      if (valid && (key < k_lo || key - k_lo > LVX_CHUNK_R + 1)) { valid = false; atomicOr(cm.err, LVX_ERR_FALLBACK); }
+      else if (!valid) atomicOr(cm.err, status);
+      if (!valid) key = -1;
+    }
+    if (valid) {
+      double s = 0.0;
+#pragma unroll
+      for (int a = 0; a < NR; ++a) s += r[a] * r[a];
+      double scale;
+      mycost += 0.5 * huber_rho(fam.huber, s, &scale);
+      if (cm.residuals) {
+        const long long orow = row0 + (long long)fam.perm[si] * NR;
+#pragma unroll
+        for (int a = 0; a < NR; ++a) cm.residuals[orow + a] = r[a];
+      }
+      if (scale != 1.0) {
+#pragma unroll
+        for (int a = 0; a < NR; ++a) {
+          r[a] *= scale;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) J[a][c] *= scale;
+        }
+      }
+    }
+    if (!want_ne) continue;
+    // segments of this wave's 64 rows
+    const int pk = __shfl_up(key, 1);
+    const bool head = (lane == 0) || pk != key;
+    const unsigned long long heads0 = __ballot(head);
+#pragma unroll
+    for (int a = 0; a < NR; ++a) {
+      __syncthreads();   // previous pass has finished reading the tiles
+      rs[lane] = valid ? r[a] : 0.0;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) Jt[c * TS + lane] = valid ? J[a][c] : 0.0;
+      __syncthreads();
+      unsigned long long heads = heads0;
+      while (heads) {
+        const int l0 = __ffsll((long long)heads) - 1;
+        heads &= heads - 1;
+        const int l1 = heads ? (__ffsll((long long)heads) - 1) : 64;
+        const int skey = __shfl(key, l0);
+        if (skey < 0) continue;
+        const int lvb = (skey - k_lo) * 6;
+        for (int p = lane; p < NP + NC; p += 64) {
+          if (p < NP) {
+            const unsigned ab = pairs[p];
+            const int ca = ab & 0xff, cb = ab >> 8;
+            const double* ja = &Jt[ca * TS];
+            const double* jb = &Jt[cb * TS];
+            double acc = 0.0;
+            for (int row = l0; row < l1; ++row) acc += ja[row] * jb[row];
+            if (cb < NK) { const int la = lvb + F::klv(ca), lb = lvb + F::klv(cb); atomicAdd(&acc_band[la * ACC_BW + (lb - la)], acc); }
+            else if (ca < NK) atomicAdd(&acc_bd[(cb - NK) * ACC_LV + lvb + F::klv(ca)], acc);
+            else atomicAdd(&acc_gg[(ca - NK) * NG + (cb - NK)], acc);
+          } else {
+            const int c = p - NP;
+            const double* jc = &Jt[c * TS];
+            double acc = 0.0;
+            for (int row = l0; row < l1; ++row) acc += jc[row] * rs[row];
+            if (c < NK) atomicAdd(&acc_gk[lvb + F::klv(c)], acc); else atomicAdd(&acc_gG[c - NK], acc);
+          }
+        }
+      }
+    }
+  }
+  mycost = wave_sum(mycost);
+  if (lane == 0) atomicAdd(&cm.cost[rep], mycost);
+  if (!want_ne) return;
+  __syncthreads();
+  // flush the workgroup's accumulators: ONE global atomic per touched entry
+  for (int e = tid; e < ACC_LV * ACC_BW; e += 256) {
+    const double v = acc_band[e];
+    if (v == 0.0) continue;
+    const int la = e / ACC_BW, lb = la + e % ACC_BW;
+    if (lb >= ACC_LV) continue;
+    const int pa = kpos[la], pb = kpos[lb];
+    if (pa == LVX_DEAD || pb == LVX_DEAD) continue;
+    add_H(cm, pa, pb, v, rep);
+  }
+  for (int e = tid; e < NG * ACC_LV; e += 256) {
+    const double v = acc_bd[e];
+    if (v == 0.0) continue;
+    const int pg = gpos[e / ACC_LV], pk2 = kpos[e % ACC_LV];
+    if (pg == LVX_DEAD || pk2 == LVX_DEAD) continue;
+    add_H(cm, pg, pk2, v, rep);
+  }
+  for (int e = tid; e < NG * NG; e += 256) {
+    const int ga = e / NG, gb2 = e % NG;
+    if (gb2 < ga) continue;
+    const double v = acc_gg[e];
+    if (v == 0.0 || gpos[ga] == LVX_DEAD || gpos[gb2] == LVX_DEAD) continue;
+    add_H(cm, gpos[ga], gpos[gb2], v, rep);
+  }
+  for (int e = tid; e < ACC_LV; e += 256) { const double v = acc_gk[e]; if (v != 0.0 && kpos[e] != LVX_DEAD) add_g(cm, kpos[e], v, rep); }
+  if (tid < NG) { const double v = acc_gG[tid]; if (v != 0.0 && gpos[tid] != LVX_DEAD) add_g(cm, gpos[tid], v, rep); }
+}
+
+// fold the pseudo-pose rows of the border back onto the hub control points: x_pseudo = M_hub x_hub  =>
+//   Bd[hub] += M^T Bd[pseudo],  C <- (I + E) C (I + E)^T,  g_c[hub] += M^T g_c[pseudo]      (E = M^T placed at [hub rows, pseudo cols])
+__global__ void k_fold_border_rows(DevCommon cm, int set) {
+  const HubShared* hub = ((const HubShared*)cm.hubs) + set;
+  if (hub->ok != 1) return;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cm.nb) return;
+  double M[6][24]; hub_matrix(hub->A, M);
+  double P[6];
+  bool any = false;
+  for (int p = 0; p < 6; ++p) { P[p] = cm.Bd[(size_t)(cm.nbd_solve + 6 * set + p) * cm.nb + j]; any = any || P[p] != 0.0; }
+  if (!any) return;
+  const int i0 = hub->A.k.i0;
+  for (int c = 0; c < 24; ++c) {
+    const int o = cm.ord[6 * (i0 + c / 6) + c % 6];
+    if (o == LVX_DEAD || o >= 0) continue;   // hub control points are border variables
+    double s = 0.0;
+    for (int p = 0; p < 6; ++p) s += M[p][c] * P[p];
+    cm.Bd[(size_t)(-1 - o) * cm.nb + j] += s;
+  }
+}
+__global__ __launch_bounds__(256) void k_fold_border_dense(DevCommon cm) {
+  extern __shared__ double Cf[];   // full symmetric [n][n] then g[n]
+  const int n = cm.nbd;
+  double* g = Cf + n * n;
+  for (int e = threadIdx.x; e < n * n; e += 256) { const int a = e / n, b = e % n; Cf[e] = a >= b ? cm.C[(size_t)a * n + b] : cm.C[(size_t)b * n + a]; }
+  for (int e = threadIdx.x; e < n; e += 256) g[e] = cm.gc[e];
+  __syncthreads();
+  for (int set = 0; set < 2; ++set) {
+    const HubShared* hub = ((const HubShared*)cm.hubs) + set;
+    if (hub->ok != 1) continue;   // uniform
+    __shared__ double M[6][24];
+    __shared__ int hrow[24];
+    if (threadIdx.x == 0) hub_matrix(hub->A, M);
+    if (threadIdx.x < 24) { const int o = cm.ord[6 * (hub->A.k.i0 + threadIdx.x / 6) + threadIdx.x % 6]; hrow[threadIdx.x] = (o != LVX_DEAD && o < 0) ? -1 - o : -1; }
+    __syncthreads();
+    const int p0 = cm.nbd_solve + 6 * set;
+    // rows: C[hub_c][:] += sum_p M[p][c] C[p0+p][:]
+    for (int e = threadIdx.x; e < 24 * n; e += 256) {
+      const int c = e / n, col = e % n;
+      if (hrow[c] < 0) continue;
+      double s = 0.0;
+      for (int p = 0; p < 6; ++p) s += M[p][c] * Cf[(p0 + p) * n + col];
+      Cf[hrow[c] * n + col] += s;   // distinct (c, col) -> distinct destination, pseudo rows are read-only here
+    }
+    if (threadIdx.x < 24 && hrow[threadIdx.x] >= 0) { double s = 0.0; for (int p = 0; p < 6; ++p) s += M[p][threadIdx.x] * g[p0 + p]; g[hrow[threadIdx.x]] += s; }
+    __syncthreads();
+    // columns: C[:][hub_c] += sum_p C[:][p0+p] M[p][c]
+    for (int e = threadIdx.x; e < 24 * n; e += 256) {
+      const int c = e / n, row = e % n;
+      if (hrow[c] < 0) continue;
+      double s = 0.0;
+      for (int p = 0; p < 6; ++p) s += Cf[row * n + p0 + p] * M[p][c];
+      Cf[row * n + hrow[c]] += s;
+    }
     __syncthreads();
   }
+  for (int e = threadIdx.x; e < n * n; e += 256) { const int a = e / n, b = e % n; if (a >= b) cm.C[(size_t)a * n + b] = Cf[e]; }
+  for (int e = threadIdx.x; e < n; e += 256) cm.gc[e] = g[e];
 }
 
 // fold the replicas of the dense border accumulators into replica 0
@@ -330,9 +637,17 @@ template <class T> std::vector<T> gather(const std::vector<T>& v, const std::vec
   return o;
 }
 
-int upload_pairs(lvx_ctx* ctx, DevBuf& b, int NC) {
+// Pair table of a family's local columns, ORDERED FOR COALESCED ATOMICS: consecutive lanes of phase 2 take consecutive pairs, so
+// the order decides the address pattern (measured on MI355X: coalesced f64 atomics 140-180 G/s, scattered 23 G/s).
+// cls[c] = 0: band variable (knot / landmark), 1: border variable.  (band, band): a-major -> runs along the band column;
+// (band, border): border-major -> runs along a border row; (border, border) last.
+int upload_pairs(lvx_ctx* ctx, DevBuf& b, int NC, const std::vector<int>& border_cols = {}) {
+  std::vector<int> cls(NC, 0);
+  for (int c : border_cols) if (c >= 0 && c < NC) cls[c] = 1;
   std::vector<uint16_t> tab;
-  for (int a = 0; a < NC; ++a) for (int c = a; c < NC; ++c) tab.push_back((uint16_t)(a | (c << 8)));
+  for (int a = 0; a < NC; ++a) for (int c = a; c < NC; ++c) if (!cls[a] && !cls[c]) tab.push_back((uint16_t)(a | (c << 8)));
+  for (int g = 0; g < NC; ++g) if (cls[g]) for (int k = 0; k < NC; ++k) if (!cls[k]) tab.push_back((uint16_t)(std::min(g, k) | (std::max(g, k) << 8)));
+  for (int a = 0; a < NC; ++a) for (int c = a; c < NC; ++c) if (cls[a] && cls[c]) tab.push_back((uint16_t)(a | (c << 8)));
   return upload(ctx, b, tab.data(), tab.size() * sizeof(uint16_t));
 }
 
@@ -344,6 +659,16 @@ int host_i0(const lvx_ctx* c, double t) {
 }
 
 }  // namespace
+
+static int upload_chunks(lvx_ctx* ctx, int fam, const std::vector<int>& sorted_keys) {
+  const int nch = (ctx->N + LVX_CHUNK_R - 1) / LVX_CHUNK_R + 1;
+  std::vector<int> off(nch + 1);
+  for (int c = 0; c <= nch; ++c)
+    off[c] = c == 0 ? 0 : (int)(std::lower_bound(sorted_keys.begin(), sorted_keys.end(), c * LVX_CHUNK_R) - sorted_keys.begin());
+  off[nch] = (int)sorted_keys.size();
+  ctx->n_chunk[fam] = nch;
+  return upload(ctx, ctx->d_chunk[fam], off.data(), off.size() * 4);
+}
 
 int ensure_layout(lvx_ctx* ctx) {
   if (!ctx->layout_dirty) return LVX_OK;
@@ -359,6 +684,7 @@ int ensure_layout(lvx_ctx* ctx) {
     for (int i = 0; i < f.n; ++i) key[i] = host_i0(ctx, f.t[i]);
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_GYRO, sk))) return rc; }
     auto ts = gather(f.t, perm, 1); auto g = gather(f.a3, perm, 3); auto a = gather(f.b3, perm, 3);
     if ((rc = upload(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
     if ((rc = upload(ctx, f.d_a3, g.data(), g.size() * 8))) return rc;
@@ -371,6 +697,7 @@ int ensure_layout(lvx_ctx* ctx) {
     for (int i = 0; i < f.n; ++i) key[i] = host_i0(ctx, f.t[i]);
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_SURFEL, sk))) return rc; }
     auto ts = gather(f.t, perm, 1); auto pt = gather(f.a3, perm, 3); auto pl = gather(f.id0, perm, 1);
     if ((rc = upload(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
     if ((rc = upload(ctx, f.d_a3, pt.data(), pt.size() * 8))) return rc;
@@ -394,6 +721,7 @@ int ensure_layout(lvx_ctx* ctx) {
     for (int i = 0; i < f.n; ++i) key[i] = (f.id0[i] >= 0 && f.id0[i] < L) ? host_i0(ctx, ctx->lm_t0[f.id0[i]]) : -1;
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_CAMSURF, sk))) return rc; }
     auto lm = gather(f.id0, perm, 1); auto pl = gather(f.id1, perm, 1);
     if ((rc = upload(ctx, f.d_id0, lm.data(), lm.size() * 4))) return rc;
     if ((rc = upload(ctx, f.d_id1, pl.data(), pl.size() * 4))) return rc;
@@ -416,9 +744,11 @@ int ensure_layout(lvx_ctx* ctx) {
   }
   const int nh = ctx->n_hub, h0 = ctx->hub0;
   ctx->nbd = 6 * nh + 22;
+  ctx->nbd_ext = ctx->nbd + 12;   // + pseudo pose rows: surfel hub (6), cam-surfel hub (6)
   // ---- band ordering: non-hub knots in time order, each landmark right after its first knot ----
   const int nt = 6 * N + 22 + L;
-  ctx->ord.assign(nt, LVX_DEAD);
+  ctx->ord.assign(nt + 12, LVX_DEAD);
+  for (int k = 0; k < 12; ++k) ctx->ord[nt + k] = -1 - (ctx->nbd + k);
   std::vector<int> lm_first(L, N), lm_last(L, -1);
   const bool cam_tau_locked = (locks & LVX_LOCK_CAM_TAU) != 0;
   std::vector<int> rep_kmin(ctx->rep.n, 0), rep_kmax(ctx->rep.n, 0);
@@ -475,14 +805,24 @@ int ensure_layout(lvx_ctx* ctx) {
   if ((rc = upload(ctx, ctx->d_ord, ctx->ord.data(), ctx->ord.size() * 4))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_Hb, (size_t)std::max(ctx->nb, 1) * (ctx->bw + 1) * 8))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_gb, (size_t)std::max(ctx->nb, 1) * 8))) return rc;
-  if ((rc = dev_alloc(ctx, ctx->d_Bd, (size_t)ctx->nbd * std::max(ctx->nb, 1) * 8))) return rc;
-  if ((rc = dev_alloc(ctx, ctx->d_C, (size_t)LVX_NREP * ctx->nbd * ctx->nbd * 8))) return rc;
-  if ((rc = dev_alloc(ctx, ctx->d_gc, (size_t)LVX_NREP * ctx->nbd * 8))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_Bd, (size_t)ctx->nbd_ext * std::max(ctx->nb, 1) * 8))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_C, (size_t)LVX_NREP * ctx->nbd_ext * ctx->nbd_ext * 8))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_gc, (size_t)LVX_NREP * ctx->nbd_ext * 8))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_hubs, 2 * sizeof(HubShared)))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_cost, LVX_NREP * 8))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_err, 16))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_state, (size_t)lvx_state_size(ctx) * 8))) return rc;
-  const int ncs[LVX_NUM_FAM] = {GYRO_NC, ACC_NC, PRI_NC, SURF_NC, REP_NC, CS_NC};
-  for (int f = 0; f < LVX_NUM_FAM; ++f) if ((rc = upload_pairs(ctx, ctx->d_pairs[f], ncs[f]))) return rc;
+  auto range = [](int a, int b) { std::vector<int> v; for (int i = a; i < b; ++i) v.push_back(i); return v; };
+  auto cat = [](std::vector<int> a, const std::vector<int>& b) { a.insert(a.end(), b.begin(), b.end()); return a; };
+  if ((rc = upload_pairs(ctx, ctx->d_pairs[0], GYRO_NC, range(12, 15)))) return rc;
+  if ((rc = upload_pairs(ctx, ctx->d_pairs[1], ACC_NC, range(24, 29)))) return rc;
+  if ((rc = upload_pairs(ctx, ctx->d_pairs[2], PRI_NC))) return rc;
+  if ((rc = upload_pairs(ctx, ctx->d_pairs[3], SURF_NC, cat(range(0, 24), range(48, 54))))) return rc;
+  if ((rc = upload_pairs(ctx, ctx->d_pairs[4], REP_NC, range(48, 54)))) return rc;
+  if ((rc = upload_pairs(ctx, ctx->d_pairs[5], CS_NC, cat(range(0, 24), range(48, 60))))) return rc;
+  if ((rc = upload_pairs(ctx, ctx->d_pairs_acc[0], SURFP_NC))) return rc;
+  if ((rc = upload_pairs(ctx, ctx->d_pairs_acc[1], CSP_NC))) return rc;
+  ctx->force_legacy = false;
   // ---- residual row offsets ----
   const int64_t cnt[LVX_NUM_FAM] = {ctx->imu.n, (locks & LVX_LOCK_R3) ? 0 : ctx->imu.n, ctx->has_prior ? 1 : 0, ctx->surf.n, ctx->rep.n, ctx->cs.n};
   const int nrs[LVX_NUM_FAM] = {3, 3, 1, 1, 2, 1};
@@ -497,7 +837,7 @@ DevCommon make_common(lvx_ctx* ctx, const double* state_d, uint32_t what) {
   DevCommon cm{};
   cm.state = state_d; cm.N = ctx->N; cm.L = ctx->L; cm.t0 = ctx->t0; cm.dt = ctx->dt; cm.locks = ctx->locks; cm.what = what;
   cm.imu_mto = ctx->imu_mto; cm.sensor_mto = ctx->sensor_mto; cm.cam = ctx->cam;
-  cm.ord = (const int*)ctx->d_ord.p; cm.nb = ctx->nb; cm.bw = ctx->bw; cm.nbd = ctx->nbd;
+  cm.ord = (const int*)ctx->d_ord.p; cm.nb = ctx->nb; cm.bw = ctx->bw; cm.nbd = ctx->nbd_ext; cm.nbd_solve = ctx->nbd; cm.hubs = ctx->d_hubs.p;
   cm.Hb = (double*)ctx->d_Hb.p; cm.gb = (double*)ctx->d_gb.p; cm.Bd = (double*)ctx->d_Bd.p; cm.C = (double*)ctx->d_C.p; cm.gc = (double*)ctx->d_gc.p;
   cm.cost = (double*)ctx->d_cost.p; cm.err = (int*)ctx->d_err.p;
   cm.residuals = nullptr; cm.jcols = nullptr; cm.jvals = nullptr;
@@ -508,17 +848,17 @@ static size_t next_event(lvx_ctx* c) {
   if (c->ev_used == c->ev_pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return (size_t)-1; c->ev_pool.push_back(e); }
   return c->ev_used++;
 }
-ProfScope::ProfScope(lvx_ctx* ctx, int k) : c(ctx), kernel(k), on(ctx->profiling) {
+ProfScope::ProfScope(lvx_ctx* ctx, int k, hipStream_t stream) : c(ctx), kernel(k), on(ctx->profiling), st(stream ? stream : ctx->stream) {
   if (!on) return;
   e0 = next_event(c);
   if (e0 == (size_t)-1) { on = false; return; }
-  (void)hipEventRecord(c->ev_pool[e0], c->stream);
+  (void)hipEventRecord(c->ev_pool[e0], st);
 }
 ProfScope::~ProfScope() {
   if (!on) return;
   const size_t e1 = next_event(c);
   if (e1 == (size_t)-1) return;
-  (void)hipEventRecord(c->ev_pool[e1], c->stream);
+  (void)hipEventRecord(c->ev_pool[e1], st);
   c->ev_recs.push_back(lvx_ctx::EvRec{kernel, e0, e1});
 }
 
@@ -544,19 +884,45 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
   if (what & LVX_EVAL_NORMAL_EQ) {
     LVX_HIP(ctx, hipMemsetAsync(cm.Hb, 0, (size_t)std::max(ctx->nb, 1) * (ctx->bw + 1) * 8, st));
     LVX_HIP(ctx, hipMemsetAsync(cm.gb, 0, (size_t)std::max(ctx->nb, 1) * 8, st));
-    LVX_HIP(ctx, hipMemsetAsync(cm.Bd, 0, (size_t)ctx->nbd * std::max(ctx->nb, 1) * 8, st));
-    LVX_HIP(ctx, hipMemsetAsync(cm.C, 0, (size_t)LVX_NREP * ctx->nbd * ctx->nbd * 8, st));
-    LVX_HIP(ctx, hipMemsetAsync(cm.gc, 0, (size_t)LVX_NREP * ctx->nbd * 8, st));
+    LVX_HIP(ctx, hipMemsetAsync(cm.Bd, 0, (size_t)ctx->nbd_ext * std::max(ctx->nb, 1) * 8, st));
+    LVX_HIP(ctx, hipMemsetAsync(cm.C, 0, (size_t)LVX_NREP * ctx->nbd_ext * ctx->nbd_ext * 8, st));
+    LVX_HIP(ctx, hipMemsetAsync(cm.gc, 0, (size_t)LVX_NREP * ctx->nbd_ext * 8, st));
   }
   auto grid = [](int n) { return dim3((unsigned)((n + 63) / 64)); };
+  // fast path: LDS-accumulating kernels for the segment-structured families; legacy per-segment kernels for reprojection, the prior,
+  // the debug Jacobian, and as the exact fallback for the merged-hub-segment corner
+  const bool fast = !ctx->force_legacy && !(what & LVX_EVAL_JACOBIAN) && !getenv("LVX_FORCE_LEGACY");
+  auto acc_lds = [](int NC, int NG) { return (size_t)(ACC_LV * ACC_BW + NG * ACC_LV + NG * NG + ACC_LV + NG + 4 * (NC * 65 + 64)) * 8 + (size_t)(ACC_LV + NG) * 4 + 64; };
+  if (fast && (ctx->surf.n > 0 || ctx->cs.n > 0))
+    hipLaunchKernelGGL(k_hub_eval, dim3(1), dim3(64), 0, st, cm, ctx->t_map, ctx->surf.n > 0 ? 1 : 0, ctx->cs.n > 0 ? 1 : 0, (HubShared*)ctx->d_hubs.p);
+  // fork: the independent family kernels run concurrently (each is latency / occupancy limited on its own)
+  LVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
+  for (int k = 0; k < 4; ++k) LVX_HIP(ctx, hipStreamWaitEvent(ctx->fam_stream[k], ctx->ev_fork, 0));
+  hipStream_t s_imu = ctx->fam_stream[0], s_acc = ctx->fam_stream[1], s_surf = ctx->fam_stream[2], s_rep = ctx->fam_stream[3];
+  const bool imu_fast = false;   // 8 samples per knot interval: the per-segment kernel wins for the IMU (measured)
   if (ctx->imu.n > 0) {
-    GyroFam g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
-    { ProfScope ps(ctx, LVX_FAM_GYRO);
-    hipLaunchKernelGGL(k_family<GyroFam>, grid(g.n), dim3(64), 0, st, g, cm, (const uint16_t*)ctx->d_pairs[0].p, (long long)ctx->fam_row0[0]); }
-    if (!(ctx->locks & LVX_LOCK_R3)) {
-      AccelFam a{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.huber /*w_acc*/, 0.0};
-      ProfScope ps(ctx, LVX_FAM_ACCEL);
-      hipLaunchKernelGGL(k_family<AccelFam>, grid(a.n), dim3(64), 0, st, a, cm, (const uint16_t*)ctx->d_pairs[1].p, (long long)ctx->fam_row0[1]);
+    if (fast && imu_fast) {
+      GyroAcc g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
+      { ProfScope ps(ctx, LVX_FAM_GYRO, s_imu);
+        const size_t lds = acc_lds(GyroAcc::NK + GyroAcc::NG, GyroAcc::NG);
+        LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_acc<GyroAcc>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_family_acc<GyroAcc>, dim3(ctx->n_chunk[LVX_FAM_GYRO]), dim3(256), lds, s_imu, g, cm, (const int*)ctx->d_chunk[LVX_FAM_GYRO].p, (const uint16_t*)ctx->d_pairs[0].p, (long long)ctx->fam_row0[0]); }
+      if (!(ctx->locks & LVX_LOCK_R3)) {
+        AccelAcc a{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.huber /*w_acc*/, 0.0};
+        ProfScope ps(ctx, LVX_FAM_ACCEL, s_acc);
+        const size_t lds = acc_lds(AccelAcc::NK + AccelAcc::NG, AccelAcc::NG);
+        LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_acc<AccelAcc>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_family_acc<AccelAcc>, dim3(ctx->n_chunk[LVX_FAM_GYRO]), dim3(256), lds, s_acc, a, cm, (const int*)ctx->d_chunk[LVX_FAM_GYRO].p, (const uint16_t*)ctx->d_pairs[1].p, (long long)ctx->fam_row0[1]);
+      }
+    } else {
+      GyroFam g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
+      { ProfScope ps(ctx, LVX_FAM_GYRO, s_imu);
+      hipLaunchKernelGGL((k_family<GyroFam, 1>), grid(g.n), dim3(64), 0, s_imu, g, cm, (const uint16_t*)ctx->d_pairs[0].p, (long long)ctx->fam_row0[0]); }
+      if (!(ctx->locks & LVX_LOCK_R3)) {
+        AccelFam a{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.huber /*w_acc*/, 0.0};
+        ProfScope ps(ctx, LVX_FAM_ACCEL, s_acc);
+        hipLaunchKernelGGL((k_family<AccelFam, LVX_PW>), grid(a.n), dim3(64 * LVX_PW), 0, s_acc, a, cm, (const uint16_t*)ctx->d_pairs[1].p, (long long)ctx->fam_row0[1]);
+      }
     }
   }
   if (ctx->has_prior) {
@@ -564,29 +930,53 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     DevBuf& pb = ctx->d_zero;   // identity permutation for the single prior block
     if ((rc = upload(ctx, pb, &zero, 4))) return rc;
     PriorFam p{1, ctx->prior_t, mkq(ctx->prior_q[0], ctx->prior_q[1], ctx->prior_q[2], ctx->prior_q[3]), (const int*)pb.p, ctx->prior_w, 0.0};
-    ProfScope ps(ctx, LVX_FAM_PRIOR);
-    hipLaunchKernelGGL(k_family<PriorFam>, dim3(1), dim3(64), 0, st, p, cm, (const uint16_t*)ctx->d_pairs[2].p, (long long)ctx->fam_row0[2]);
+    ProfScope ps(ctx, LVX_FAM_PRIOR, s_imu);
+    hipLaunchKernelGGL((k_family<PriorFam, 1>), dim3(1), dim3(64), 0, s_imu, p, cm, (const uint16_t*)ctx->d_pairs[2].p, (long long)ctx->fam_row0[2]);
   }
   if (ctx->surf.n > 0) {
-    SurfFam s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
-              (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
-    ProfScope ps(ctx, LVX_FAM_SURFEL);
-    hipLaunchKernelGGL(k_family<SurfFam>, grid(s.n), dim3(64), 0, st, s, cm, (const uint16_t*)ctx->d_pairs[3].p, (long long)ctx->fam_row0[3]);
+    ProfScope ps(ctx, LVX_FAM_SURFEL, s_surf);
+    if (fast) {
+      SurfAcc s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
+                (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
+      const size_t lds = acc_lds(SurfAcc::NK + SurfAcc::NG, SurfAcc::NG);
+      LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_acc<SurfAcc>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_family_acc<SurfAcc>, dim3(ctx->n_chunk[LVX_FAM_SURFEL]), dim3(256), lds, s_surf, s, cm, (const int*)ctx->d_chunk[LVX_FAM_SURFEL].p, (const uint16_t*)ctx->d_pairs_acc[0].p, (long long)ctx->fam_row0[3]);
+    } else {
+      SurfFam s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
+                (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
+      hipLaunchKernelGGL((k_family<SurfFam, 1>), grid(s.n), dim3(64), 0, s_surf, s, cm, (const uint16_t*)ctx->d_pairs[3].p, (long long)ctx->fam_row0[3]);
+    }
   }
   if (ctx->rep.n > 0) {
     ReprojFam r{ctx->rep.n, (const int*)ctx->rep.d_id0.p, (const double*)ctx->rep.d_a3.p, (const double*)ctx->rep.d_t.p, (const int*)ctx->rep.d_perm.p,
                 (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->rep.weight, ctx->rep.huber};
-    ProfScope ps(ctx, LVX_FAM_REPROJ);
-    hipLaunchKernelGGL(k_family<ReprojFam>, grid(r.n), dim3(64), 0, st, r, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
+    ProfScope ps(ctx, LVX_FAM_REPROJ, s_rep);
+    hipLaunchKernelGGL((k_family<ReprojFam, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, r, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
   }
   if (ctx->cs.n > 0) {
-    CamSurfFam c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
-                 (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
-    ProfScope ps(ctx, LVX_FAM_CAMSURF);
-    hipLaunchKernelGGL(k_family<CamSurfFam>, grid(c.n), dim3(64), 0, st, c, cm, (const uint16_t*)ctx->d_pairs[5].p, (long long)ctx->fam_row0[5]);
+    ProfScope ps(ctx, LVX_FAM_CAMSURF, s_surf);
+    if (fast) {
+      CamSurfAcc c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
+                   (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
+      const size_t lds = acc_lds(CamSurfAcc::NK + CamSurfAcc::NG, CamSurfAcc::NG);
+      LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_acc<CamSurfAcc>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_family_acc<CamSurfAcc>, dim3(ctx->n_chunk[LVX_FAM_CAMSURF]), dim3(256), lds, s_surf, c, cm, (const int*)ctx->d_chunk[LVX_FAM_CAMSURF].p, (const uint16_t*)ctx->d_pairs_acc[1].p, (long long)ctx->fam_row0[5]);
+    } else {
+      CamSurfFam c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
+                   (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
+      hipLaunchKernelGGL((k_family<CamSurfFam, 1>), grid(c.n), dim3(64), 0, s_surf, c, cm, (const uint16_t*)ctx->d_pairs[5].p, (long long)ctx->fam_row0[5]);
+    }
   }
+  for (int k = 0; k < 4; ++k) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[k], ctx->fam_stream[k])); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[k], 0)); }
   { ProfScope ps(ctx, LVX_KERNEL_FOLD);
-  hipLaunchKernelGGL(k_fold_replicas, dim3((unsigned)((ctx->nbd * ctx->nbd + 255) / 256)), dim3(256), 0, st, cm); }
+  hipLaunchKernelGGL(k_fold_replicas, dim3((unsigned)((ctx->nbd_ext * ctx->nbd_ext + 255) / 256)), dim3(256), 0, st, cm);
+  if (fast && (what & LVX_EVAL_NORMAL_EQ) && (ctx->surf.n > 0 || ctx->cs.n > 0)) {
+    for (int set = 0; set < 2; ++set) if (ctx->nb > 0 && ((set == 0 && ctx->surf.n > 0) || (set == 1 && ctx->cs.n > 0)))
+      hipLaunchKernelGGL(k_fold_border_rows, dim3((unsigned)((ctx->nb + 255) / 256)), dim3(256), 0, st, cm, set);
+    const size_t lds = ((size_t)ctx->nbd_ext * ctx->nbd_ext + ctx->nbd_ext) * 8;
+    LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_fold_border_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_fold_border_dense, dim3(1), dim3(256), lds, st, cm);
+  } }
   LVX_HIP(ctx, hipGetLastError());
   ctx->last_what = what;
   if (cost) {
@@ -595,6 +985,10 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     LVX_HIP(ctx, hipMemcpyAsync(err, cm.err, 4, hipMemcpyDeviceToHost, st));
     LVX_HIP(ctx, hipStreamSynchronize(st));
     *cost = c;
+    if ((err[0] & LVX_ERR_FALLBACK) && !ctx->force_legacy) {   // corner only the per-segment kernels handle exactly: redo this evaluation with them
+      ctx->force_legacy = true;
+      return run_evaluate(ctx, state_d, what, cost, want_res_buffer);
+    }
     if (err[0] & RES_RANGE) return fail(ctx, LVX_E_RANGE, "time span out of range for trajectory");
     if (err[0] & RES_NONUNIT) return fail(ctx, LVX_E_NONUNIT_QUAT, "logq: only implemented for unit quaternions");
     if (err[0] & 4) return fail(ctx, LVX_E_STATE, "normal-equation entry outside the computed bandwidth");
@@ -623,6 +1017,8 @@ int lvx_create(lvx_ctx** out, int device, uint32_t /*flags*/) {
   c->device = device;
   if (hipStreamCreate(&c->own_stream) != hipSuccess) { delete c; return LVX_E_HIP; }
   c->stream = c->own_stream;
+  for (int k = 0; k < 4; ++k) { if (hipStreamCreateWithFlags(&c->fam_stream[k], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming) != hipSuccess) { delete c; return LVX_E_HIP; } }
+  if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { delete c; return LVX_E_HIP; }
   *out = c;
   return LVX_OK;
 }
@@ -638,8 +1034,13 @@ void lvx_destroy(lvx_ctx* c) {
     if (b->p) (void)hipFree(b->p);
   for (auto& b : c->d_pairs) if (b.p) (void)hipFree(b.p);
   for (auto& b : c->d_up) if (b.p) (void)hipFree(b.p);
+  for (auto& b : c->d_chunk) if (b.p) (void)hipFree(b.p);
+  for (auto& b : c->d_pairs_acc) if (b.p) (void)hipFree(b.p);
+  if (c->d_hubs.p) (void)hipFree(c->d_hubs.p);
   for (DevBuf* b : {&c->vox.misc, &c->vox.keys, &c->vox.vals, &c->vox.runs, &c->vox.cells, &c->vox.tmp, &c->vox.leaf_i, &c->vox.leaf_d, &c->vox.leaf_f}) if (b->p) (void)hipFree(b->p);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+  for (int k = 0; k < 4; ++k) { if (c->fam_stream[k]) (void)hipStreamDestroy(c->fam_stream[k]); if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]); }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -704,7 +1105,7 @@ int lvx_tangent_size(const lvx_ctx* c) { return c ? 6 * c->N + 22 + c->L : 0; }
 int lvx_get_layout(lvx_ctx* c, lvx_layout* o) {
   if (!c || !o) return LVX_E_ARG;
   int rc = ensure_layout(c); if (rc) return rc;
-  o->n_knots = c->N; o->n_landmarks = c->L; o->n_tangent = lvx_tangent_size(c); o->n_band = c->nb; o->bandwidth = c->bw; o->n_border = c->nbd;
+  o->n_knots = c->N; o->n_landmarks = c->L; o->n_tangent = lvx_tangent_size(c); o->n_band = c->nb; o->bandwidth = c->bw; o->n_border = c->nbd; o->border_ld = c->nbd_ext;
   o->n_hub_knots = c->n_hub; o->hub_knot0 = c->hub0; o->n_blocks = c->n_blocks; o->n_residuals = c->n_residuals;
   return LVX_OK;
 }
@@ -744,10 +1145,10 @@ int lvx_export_border_d(lvx_ctx* c, double* out_d) {
   if (!c || !out_d) return LVX_E_ARG;
   if (!(c->last_what & LVX_EVAL_NORMAL_EQ)) return fail(c, LVX_E_STATE, "last evaluation did not request LVX_EVAL_NORMAL_EQ");
   LVX_HIP(c, hipSetDevice(c->device));
-  const size_t n2 = (size_t)c->nbd * c->nbd;
+  const size_t n2 = (size_t)c->nbd_ext * c->nbd_ext;
   LVX_HIP(c, hipMemcpyAsync(out_d, c->d_C.p, n2 * 8, hipMemcpyDeviceToDevice, c->stream));
-  LVX_HIP(c, hipMemcpyAsync(out_d + n2, c->d_gc.p, (size_t)c->nbd * 8, hipMemcpyDeviceToDevice, c->stream));
-  LVX_HIP(c, hipMemcpyAsync(out_d + n2 + c->nbd, c->d_cost.p, 8, hipMemcpyDeviceToDevice, c->stream));
+  LVX_HIP(c, hipMemcpyAsync(out_d + n2, c->d_gc.p, (size_t)c->nbd_ext * 8, hipMemcpyDeviceToDevice, c->stream));
+  LVX_HIP(c, hipMemcpyAsync(out_d + n2 + c->nbd_ext, c->d_cost.p, 8, hipMemcpyDeviceToDevice, c->stream));
   return LVX_OK;
 }
 int lvx_set_state(lvx_ctx* c, const double* state) {
@@ -773,6 +1174,7 @@ int lvx_synchronize(lvx_ctx* c) {
   if (!c->d_err.p) return LVX_OK;
   int err = 0;
   LVX_HIP(c, hipMemcpy(&err, c->d_err.p, 4, hipMemcpyDeviceToHost));
+  if (err & LVX_ERR_FALLBACK) { c->force_legacy = true; return fail(c, LVX_E_STATE, "fast assembly kernels hit the merged-hub-segment corner: evaluate again (the exact per-segment kernels are now selected)"); }
   if (err & RES_RANGE) return fail(c, LVX_E_RANGE, "time span out of range for trajectory");
   if (err & RES_NONUNIT) return fail(c, LVX_E_NONUNIT_QUAT, "logq: only implemented for unit quaternions");
   if (err & 4) return fail(c, LVX_E_STATE, "normal-equation entry outside the computed bandwidth");
@@ -809,8 +1211,8 @@ int lvx_get_normal_eq_dense(lvx_ctx* c, double* H, double* g) {
   if (nt > 20000) return fail(c, LVX_E_ARG, "dense expansion is a parity/debug path for small problems");
   LVX_HIP(c, hipSetDevice(c->device));
   LVX_HIP(c, hipStreamSynchronize(c->stream));
-  const int nb = c->nb, bw = c->bw, nbd = c->nbd;
-  std::vector<double> Hb((size_t)std::max(nb, 1) * (bw + 1)), gb(std::max(nb, 1)), Bd((size_t)nbd * std::max(nb, 1)), C((size_t)nbd * nbd), gc(nbd);
+  const int nb = c->nb, bw = c->bw, nbd = c->nbd, ldc = c->nbd_ext;
+  std::vector<double> Hb((size_t)std::max(nb, 1) * (bw + 1)), gb(std::max(nb, 1)), Bd((size_t)nbd * std::max(nb, 1)), C((size_t)ldc * ldc), gc(nbd);
   LVX_HIP(c, hipMemcpy(Hb.data(), c->d_Hb.p, Hb.size() * 8, hipMemcpyDeviceToHost));
   LVX_HIP(c, hipMemcpy(gb.data(), c->d_gb.p, gb.size() * 8, hipMemcpyDeviceToHost));
   LVX_HIP(c, hipMemcpy(Bd.data(), c->d_Bd.p, Bd.size() * 8, hipMemcpyDeviceToHost));
@@ -819,7 +1221,7 @@ int lvx_get_normal_eq_dense(lvx_ctx* c, double* H, double* g) {
   std::memset(H, 0, sizeof(double) * (size_t)nt * nt);
   std::memset(g, 0, sizeof(double) * nt);
   std::vector<int> band_var(std::max(nb, 1), -1), bord_var(nbd, -1);
-  for (int v = 0; v < nt; ++v) { const int o = c->ord[v]; if (o == LVX_DEAD) continue; if (o >= 0) band_var[o] = v; else bord_var[-1 - o] = v; }
+  for (int v = 0; v < nt; ++v) { const int o = c->ord[v]; if (o == LVX_DEAD) continue; if (o >= 0) band_var[o] = v; else if (-1 - o < nbd) bord_var[-1 - o] = v; }
   for (int j = 0; j < nb; ++j) {
     g[band_var[j]] = gb[j];
     for (int d = 0; d <= bw && j + d < nb; ++d) { const double v = Hb[(size_t)j * (bw + 1) + d]; const int a = band_var[j + d], b = band_var[j]; H[(size_t)a * nt + b] = v; H[(size_t)b * nt + a] = v; }
@@ -828,7 +1230,7 @@ int lvx_get_normal_eq_dense(lvx_ctx* c, double* H, double* g) {
     if (bord_var[b] < 0) continue;
     g[bord_var[b]] = gc[b];
     for (int j = 0; j < nb; ++j) { const double v = Bd[(size_t)b * nb + j]; H[(size_t)bord_var[b] * nt + band_var[j]] = v; H[(size_t)band_var[j] * nt + bord_var[b]] = v; }
-    for (int b2 = 0; b2 <= b; ++b2) { if (bord_var[b2] < 0) continue; const double v = C[(size_t)b * nbd + b2]; H[(size_t)bord_var[b] * nt + bord_var[b2]] = v; H[(size_t)bord_var[b2] * nt + bord_var[b]] = v; }
+    for (int b2 = 0; b2 <= b; ++b2) { if (bord_var[b2] < 0) continue; const double v = C[(size_t)b * ldc + b2]; H[(size_t)bord_var[b] * nt + bord_var[b2]] = v; H[(size_t)bord_var[b2] * nt + bord_var[b]] = v; }
   }
   return LVX_OK;
 }

@@ -206,19 +206,28 @@ LVX_HD void plane_chain(const PoseEval& h, const PoseEval& k, const SensorCal& l
   o->nL = qrot(lidar.q, n);                                   // n^T R_L^T = (R_L n)^T
   o->m = qrot_inv(k.so3.q, qrot(h.so3.q, o->nL));            // Rk^T R0 nL
 }
+// gradients of a two-pose point-to-plane residual w.r.t. the poses: gp = d r / d p_k (= - d r / d p_0), gx0 = d r / d xi_0, gxk = d r / d xi_k
+struct PlaneGrads { v3 gp, gx0, gxk; };
+LVX_HD PlaneGrads plane_grads(const PoseEval& h, const PlaneChain& pc, v3 p_I, double w) {
+  PlaneGrads g;
+  g.gp = w * qrot(h.so3.q, pc.nL);
+  g.gx0 = w * cross(pc.nL, pc.ptemp);
+  g.gxk = w * cross(p_I, pc.m);
+  return g;
+}
+// expand pose gradients to the 4 control points of one evaluation: position weight Bp[j] * gpos, rotation dxi[j]^T gxi
+LVX_HD void pose_to_knots(const PoseEval& e, v3 gpos, v3 gxi, double* J24) {
+  for (int j = 0; j < 4; ++j) {
+    J24[6 * j + 0] = e.Bp[j] * gpos.x; J24[6 * j + 1] = e.Bp[j] * gpos.y; J24[6 * j + 2] = e.Bp[j] * gpos.z;
+    const v3 a = tmulv(e.so3.dxi[j], gxi);
+    J24[6 * j + 3] = a.x; J24[6 * j + 4] = a.y; J24[6 * j + 5] = a.z;
+  }
+}
 // knot columns of a two-pose point-to-plane residual: d r / d(hub knots), d r / d(k knots)
 LVX_HD void plane_knot_jac(const PoseEval& h, const PoseEval& k, const PlaneChain& pc, v3 p_I, double w, double* Jhub, double* Jk) {
-  const v3 gp = w * qrot(h.so3.q, pc.nL);           // d r / d p_k  (= - d r / d p_0)
-  const v3 gx0 = w * cross(pc.nL, pc.ptemp);        // d r / d xi_0
-  const v3 gxk = w * cross(p_I, pc.m);              // d r / d xi_k
-  for (int j = 0; j < 4; ++j) {
-    Jhub[6 * j + 0] = -h.Bp[j] * gp.x; Jhub[6 * j + 1] = -h.Bp[j] * gp.y; Jhub[6 * j + 2] = -h.Bp[j] * gp.z;
-    const v3 a = tmulv(h.so3.dxi[j], gx0);
-    Jhub[6 * j + 3] = a.x; Jhub[6 * j + 4] = a.y; Jhub[6 * j + 5] = a.z;
-    Jk[6 * j + 0] = k.Bp[j] * gp.x; Jk[6 * j + 1] = k.Bp[j] * gp.y; Jk[6 * j + 2] = k.Bp[j] * gp.z;
-    const v3 b = tmulv(k.so3.dxi[j], gxk);
-    Jk[6 * j + 3] = b.x; Jk[6 * j + 4] = b.y; Jk[6 * j + 5] = b.z;
-  }
+  const PlaneGrads g = plane_grads(h, pc, p_I, w);
+  pose_to_knots(h, -g.gp, g.gx0, Jhub);
+  pose_to_knots(k, g.gp, g.gxk, Jk);
 }
 
 template <bool NEED_J>
@@ -241,6 +250,38 @@ LVX_HD int surfel_residual(const SplineRef& sp, const PoseEval& hub, const Segs&
     J[0][51] = jp.x; J[0][52] = jp.y; J[0][53] = jp.z;
   }
   return RES_OK;
+}
+
+// Same residual with the hub pose represented by 6 PSEUDO variables (d p_0 (3), xi_0 (3)) instead of 24 hub-knot columns:
+// J_hub = g0^T M_hub with M_hub identical for every residual of a launch, so J^T J is assembled over g0 and folded back
+// with M_hub afterwards (lvx_eval.hip: k_fold_border).  local columns: [k knot j: 6j.. (24) | g0 24..29 | lidar theta 30..32 | lidar p 33..35]
+enum { SURFP_NC = 36 };
+LVX_HD int surfel_residual_pseudo(const SplineRef& sp, const PoseEval& hub, const Segs& segs, const SensorCal& lidar, double t_k, v3 p_L, v3 Pi,
+                                  double weight, int* i0_k, double r[1], double J[1][SURFP_NC]) {
+  KnotRef kr;
+  if (!seg_lookup(sp, segs, t_k + lidar.tau, &kr)) return RES_RANGE;
+  *i0_k = kr.i0;
+  PoseEval k;
+  if (!pose_eval<true>(sp, kr, &k)) return RES_NONUNIT;
+  const v3 pLr = qrot(lidar.q, p_L);
+  const v3 p_I = pLr + lidar.p;
+  PlaneChain pc; plane_chain(hub, k, lidar, p_I, Pi, &pc);
+  r[0] = weight * pc.r_unweighted;
+  const PlaneGrads g = plane_grads(hub, pc, p_I, weight);
+  pose_to_knots(k, g.gp, g.gxk, &J[0][0]);
+  J[0][24] = -g.gp.x; J[0][25] = -g.gp.y; J[0][26] = -g.gp.z; J[0][27] = g.gx0.x; J[0][28] = g.gx0.y; J[0][29] = g.gx0.z;
+  const v3 jq = (2.0 * weight) * (cross(pc.nL, pc.x) - cross(pc.m, pLr));
+  const v3 jp = weight * (pc.m - pc.nL);
+  J[0][30] = jq.x; J[0][31] = jq.y; J[0][32] = jq.z; J[0][33] = jp.x; J[0][34] = jp.y; J[0][35] = jp.z;
+  return RES_OK;
+}
+// M_hub (6 x 24): pseudo pose perturbation (d p_0, xi_0) per unit tangent of the 4 hub control points
+LVX_HD void hub_matrix(const PoseEval& h, double M[6][24]) {
+  for (int a = 0; a < 6; ++a) for (int c = 0; c < 24; ++c) M[a][c] = 0.0;
+  for (int j = 0; j < 4; ++j) {
+    for (int a = 0; a < 3; ++a) M[a][6 * j + a] = h.Bp[j];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) M[3 + a][6 * j + 3 + b] = h.so3.dxi[j].a[3 * a + b];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -401,6 +442,34 @@ LVX_HD int camsurf_residual(const SplineRef& sp, const PoseEval& hub, const Segs
     J[0][48] = jcq.x; J[0][49] = jcq.y; J[0][50] = jcq.z; J[0][51] = jcp.x; J[0][52] = jcp.y; J[0][53] = jcp.z;
     J[0][54] = jlq.x; J[0][55] = jlq.y; J[0][56] = jlq.z; J[0][57] = jlp.x; J[0][58] = jlp.y; J[0][59] = jlp.z;
   }
+  return RES_OK;
+}
+
+// pseudo-hub variant: local columns [k knot j: 6j.. (24) | g0 24..29 | cam theta 30..32 | cam p 33..35 | lidar theta 36..38 | lidar p 39..41]
+enum { CSP_NC = 42 };
+LVX_HD int camsurf_residual_pseudo(const SplineRef& sp, const PoseEval& hub, const Segs& segs, const CamIntr& ci, const SensorCal& cam, const SensorCal& lidar,
+                                   double u_ref, double v_ref, double t0_ref, double rho, v3 Pi, double weight, int* i0_k, double r[1], double J[1][CSP_NC]) {
+  KnotRef kr;
+  if (!seg_lookup(sp, segs, t0_ref + cam.tau, &kr)) return RES_RANGE;
+  *i0_k = kr.i0;
+  PoseEval k;
+  if (!pose_eval<true>(sp, kr, &k)) return RES_NONUNIT;
+  const double s = 1.0 / (rho + 1e-8);
+  const v3 yu = cam_unproject(ci, u_ref, v_ref);
+  const v3 yh = mk(yu.x * s, yu.y * s, yu.z * s);
+  const v3 RCyh = qrot(cam.q, yh);
+  const v3 p_I = RCyh + cam.p;
+  PlaneChain pc; plane_chain(hub, k, lidar, p_I, Pi, &pc);
+  r[0] = weight * pc.r_unweighted;
+  const PlaneGrads g = plane_grads(hub, pc, p_I, weight);
+  pose_to_knots(k, g.gp, g.gxk, &J[0][0]);
+  J[0][24] = -g.gp.x; J[0][25] = -g.gp.y; J[0][26] = -g.gp.z; J[0][27] = g.gx0.x; J[0][28] = g.gx0.y; J[0][29] = g.gx0.z;
+  const v3 jcq = (-2.0 * weight) * cross(pc.m, RCyh);
+  const v3 jcp = weight * pc.m;
+  const v3 jlq = (2.0 * weight) * cross(pc.nL, pc.x);
+  const v3 jlp = (-weight) * pc.nL;
+  J[0][30] = jcq.x; J[0][31] = jcq.y; J[0][32] = jcq.z; J[0][33] = jcp.x; J[0][34] = jcp.y; J[0][35] = jcp.z;
+  J[0][36] = jlq.x; J[0][37] = jlq.y; J[0][38] = jlq.z; J[0][39] = jlp.x; J[0][40] = jlp.y; J[0][41] = jlp.z;
   return RES_OK;
 }
 

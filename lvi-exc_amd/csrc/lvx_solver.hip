@@ -24,10 +24,10 @@ namespace lvx {
 // small kernels
 // ---------------------------------------------------------------------------------------------------------
 // diag[0..nb) from the band, diag[nb..nb+nbd) from C
-__global__ void k_diag(const double* Hb, const double* C, int nb, int bw, int nbd, double* diag) {
+__global__ void k_diag(const double* Hb, const double* C, int nb, int bw, int nbd, int ldc, double* diag) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nb) diag[i] = Hb[(size_t)i * (bw + 1)];
-  else if (i < nb + nbd) { const int b = i - nb; diag[i] = C[(size_t)b * nbd + b]; }
+  else if (i < nb + nbd) { const int b = i - nb; diag[i] = C[(size_t)b * ldc + b]; }
 }
 // Jacobi scaling 1/(1+sqrt(diag)) (ceres TrustRegionMinimizer, jacobi_scaling = true; computed at the first iterate only)
 __global__ void k_scale_from_diag(const double* diag, int n, double* scale, int use_scaling) {
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64) void k_band_bwd(const double* __restrict__ Lb, 
 }
 
 // S = Cs - Z_B Z_B^T (lower), rhs = f_c - Z_B z : one workgroup per (row a); dot products over nb
-__global__ __launch_bounds__(256) void k_schur(const double* __restrict__ Z, const double* C, const double* gc, const double* scale, int nb, int nbd,
+__global__ __launch_bounds__(256) void k_schur(const double* __restrict__ Z, const double* C, const double* gc, const double* scale, int nb, int nbd, int ldc,
                                                const double* lmd, double inv_radius, double* S, double* rhs) {
   const int a = blockIdx.x;
   __shared__ double red[256];
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void k_schur(const double* __restrict__ Z, con
     for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) {
       if (b < nbd) {
-        double c = C[(size_t)a * nbd + b] * scale[nb + a] * scale[nb + b];
+        double c = C[(size_t)a * ldc + b] * scale[nb + a] * scale[nb + b];
         if (a == b) c += lmd[nb + a] * inv_radius;
         S[(size_t)a * nbd + b] = c - red[0];
       } else {
@@ -375,7 +375,7 @@ static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double* ou
     hipLaunchKernelGGL(k_band_fwd, dim3((unsigned)((nbd + 1 + FW_R - 1) / FW_R)), dim3(64), lds_fw, st, (const double*)w.L, nb, bw, w.Z, nbd + 1);
   }
   hipLaunchKernelGGL(k_schur, dim3(nbd), dim3(256), 0, st, (const double*)w.Z, (const double*)c->d_C.p, (const double*)c->d_gc.p, (const double*)w.scale,
-                     nb > 0 ? nb : 0, nbd, (const double*)w.lmd, ir, w.S, w.rhs);
+                     nb > 0 ? nb : 0, nbd, c->nbd_ext, (const double*)w.lmd, ir, w.S, w.rhs);
   hipLaunchKernelGGL(k_dense_solve, dim3(1), dim3(256), 0, st, w.S, w.rhs, nbd, w.info);
   double* zb = w.Z + (size_t)nbd * std::max(nb, 1);
   if (nb > 0) {
@@ -399,7 +399,7 @@ static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double* ou
 static int prepare_diag(lvx_ctx* c, SolveWork& w, bool compute_scale, int use_scaling, double mn, double mx) {
   const int n = c->nb + c->nbd;
   hipStream_t st = c->stream;
-  hipLaunchKernelGGL(k_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)c->d_C.p, c->nb, c->bw, c->nbd, w.diag);
+  hipLaunchKernelGGL(k_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)c->d_C.p, c->nb, c->bw, c->nbd, c->nbd_ext, w.diag);
   if (compute_scale) hipLaunchKernelGGL(k_scale_from_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)w.diag, n, w.scale, use_scaling);
   hipLaunchKernelGGL(k_lm_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)w.diag, (const double*)w.scale, n, mn, mx, w.lmd);
   LVX_HIP(c, hipGetLastError());
