@@ -1,0 +1,242 @@
+// lvx_bcr.hip — block cyclic reduction (nested-dissection Cholesky) of the banded SPD part of the LM system.
+//
+// The band (n_band x n_band, half-bandwidth bw) is viewed as block tridiagonal with block size b >= bw; the chain of
+// n_blk blocks is eliminated in log2(n_blk) levels: at level l the blocks j = 2^l - 1 + 2^(l+1) k are eliminated in parallel,
+//     C_j C_j^T = D_j,   X+_k = A_{j+s,j} C_j^-T,   Y_k = C_j^-1 A_{j,j-s},
+//     D_{j+s} -= X+ X+^T,   D_{j-s} -= Y^T Y,   A_{j+s,j-s} = -X+ Y        (s = 2^l)
+// which replaces a 155 k-long sequential dependency chain by ~10 rounds of BATCHED dense b x b operations — plain library
+// BLAS-3, executed with rocSOLVER potrf_strided_batched and rocBLAS trsm / syrk / gemm_strided_batched (FP64).
+// This is what Ceres' SPARSE_SCHUR + sparse Cholesky does for the reference (kontiki/trajectory_estimator.h:44), restructured for a GPU.
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+#include "lvx_ctx.h"
+
+namespace lvx {
+
+#define LVX_BLAS(ctx, expr)                                                                                     \
+  do {                                                                                                          \
+    rocblas_status s_ = (expr);                                                                                 \
+    if (s_ != rocblas_status_success) return fail(ctx, LVX_E_HIP, std::string(#expr) + ": rocblas status " + std::to_string((int)s_)); \
+  } while (0)
+
+// band (scaled + damped) -> dense blocks.  D_i lower triangle (column-major b x b), G0_i = A_{i+1,i}; padding blocks are identity / zero
+__global__ void k_bcr_build(const double* __restrict__ Hb, const double* __restrict__ scale, const double* __restrict__ lmd, double inv_radius,
+                            int nb, int bw, int b, int nblk, double* D, double* G0) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t bb = (size_t)b * b;
+  if (e >= 2 * (size_t)nblk * bb) return;
+  const bool isG = e >= (size_t)nblk * bb;
+  const size_t e2 = isG ? e - (size_t)nblk * bb : e;
+  const int i = (int)(e2 / bb);
+  const int cc = (int)((e2 % bb) / b), rr = (int)(e2 % b);   // column-major
+  const long long c = (long long)i * b + cc;
+  const long long r = (long long)(isG ? i + 1 : i) * b + rr;
+  double v = 0.0;
+  if (!isG) {
+    if (rr >= cc) {
+      if (r < nb) { const long long d = r - c; if (d <= bw) { const double hv = Hb[(size_t)c * (bw + 1) + d]; v = hv * scale[r] * scale[c]; if (d == 0) v = hv == 0.0 ? 1.0 : v + lmd[c] * inv_radius; } }   // untouched variable (zero row, zero gradient): any pivot gives y = 0; use 1 instead of 1e-6/radius
+      else if (r == c) v = 1.0;
+    }
+    D[e2] = v;
+  } else {
+    if (r < nb && c < nb) { const long long d = r - c; if (d <= bw) v = Hb[(size_t)c * (bw + 1) + d] * scale[r] * scale[c]; }
+    G0[e2] = v;
+  }
+}
+__global__ void k_bcr_info(const int* info, int n, int* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && info[i] != 0) atomicMax(out, 2000000000 + i);   // reported ahead of the dense border pivot codes (1e9 + k)
+}
+
+static int bcr_handle(lvx_ctx* c, rocblas_handle* h) {
+  if (!c->blas) { rocblas_handle hh; LVX_BLAS(c, rocblas_create_handle(&hh)); c->blas = hh; }
+  *h = (rocblas_handle)c->blas;
+  LVX_BLAS(c, rocblas_set_stream(*h, c->stream));
+  LVX_BLAS(c, rocblas_set_pointer_mode(*h, rocblas_pointer_mode_host));
+  return LVX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Batched multi-vector triangular solve with a dense lower factor L (b x b, column-major): in place L w = v (TRANS = false) or
+// L^T w = v (TRANS = true) for `nvec` vectors per batch element.  Vector k, element i lives at V[k * sv + i * se].
+// One wavefront per (64 vectors, batch element); the vectors sit in LDS (row-major, padded), L streams through LDS in
+// 16-column panels.  (rocBLAS' strided-batched TRSM turns into thousands of tiny launches at b ~ 200, and explicit inverses
+// lose positive definiteness of the Schur complements on weakly constrained problems, so this step is hand-written.)
+// ---------------------------------------------------------------------------------------------------------
+#define TRS_PANEL 16
+template <bool TRANS>
+__global__ __launch_bounds__(64) void k_trsv_batched(const double* __restrict__ Lm, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec) {
+  extern __shared__ double lds[];
+  double* W = lds;                        // [b][65]
+  double* P = lds + (size_t)b * 65;       // [TRS_PANEL][b] panel of L columns
+  const int t = threadIdx.x;
+  const int vec = blockIdx.x * 64 + t;
+  const bool act = vec < nvec;
+  const double* L = Lm + (size_t)blockIdx.y * strideL;
+  double* v = V + (size_t)blockIdx.y * strideV + (size_t)vec * sv;
+  for (int i = 0; i < b; ++i) W[i * 65 + t] = act ? v[(size_t)i * se] : 0.0;
+  if (!TRANS) {
+    for (int k0 = 0; k0 < b; k0 += TRS_PANEL) {
+      const int nk = min(TRS_PANEL, b - k0);
+      __syncthreads();
+      for (int e = t; e < nk * b; e += 64) { const int kk = e / b, i = e % b; P[kk * b + i] = i >= k0 + kk ? L[(size_t)(k0 + kk) * b + i] : 0.0; }
+      __syncthreads();
+      for (int kk = 0; kk < nk; ++kk) {
+        const int k = k0 + kk;
+        const double wk = W[k * 65 + t] / P[kk * b + k];
+        W[k * 65 + t] = wk;
+        const double* col = &P[kk * b];
+        for (int i = k + 1; i < b; ++i) W[i * 65 + t] -= col[i] * wk;
+      }
+    }
+  } else {
+    for (int k1 = b; k1 > 0; k1 -= TRS_PANEL) {
+      const int k0 = max(0, k1 - TRS_PANEL), nk = k1 - k0;
+      __syncthreads();
+      for (int e = t; e < nk * b; e += 64) { const int kk = e / b, i = e % b; P[kk * b + i] = i >= k0 + kk ? L[(size_t)(k0 + kk) * b + i] : 0.0; }
+      __syncthreads();
+      for (int kk = nk - 1; kk >= 0; --kk) {
+        const int k = k0 + kk;
+        const double* col = &P[kk * b];
+        double sacc = W[k * 65 + t];
+        for (int i = k + 1; i < b; ++i) sacc -= col[i] * W[i * 65 + t];
+        W[k * 65 + t] = sacc / col[k];
+      }
+    }
+  }
+  if (act) for (int i = 0; i < b; ++i) v[(size_t)i * se] = W[i * 65 + t];
+}
+template <bool TRANS>
+static int trsv_batched(lvx_ctx* c, const double* L, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, int batch) {
+  if (batch <= 0 || nvec <= 0) return LVX_OK;
+  const size_t lds = ((size_t)b * 65 + (size_t)TRS_PANEL * b) * 8;
+  if (lds > 158 * 1024) return fail(c, LVX_E_ARG, "block size too large for the LDS-resident triangular solve");
+  LVX_HIP(c, hipFuncSetAttribute((const void*)k_trsv_batched<TRANS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_trsv_batched<TRANS>, dim3((unsigned)((nvec + 63) / 64), (unsigned)batch), dim3(64), lds, c->stream, L, b, strideL, V, se, sv, strideV, nvec);
+  LVX_HIP(c, hipGetLastError());
+  return LVX_OK;
+}
+
+int bcr_plan(lvx_ctx* c) {
+  const int b = std::max(16, ((c->bw + 3) / 4) * 4);
+  int nblk = 1;
+  while ((long long)nblk * b < c->nb) nblk <<= 1;
+  nblk = std::max(nblk, 2);
+  c->bcr_b = b; c->bcr_nblk = nblk;
+  int rc;
+  const size_t bb = (size_t)b * b;
+  const size_t guard = 1;
+  if ((rc = dev_alloc(c, c->d_bcrD, guard * (size_t)nblk * bb * 8))) return rc;       // diagonal blocks -> Cholesky factors C_j
+  if ((rc = dev_alloc(c, c->d_bcrG, guard * (size_t)2 * nblk * bb * 8))) return rc;   // couplings per level -> X+ (even slots) / Y (odd slots)
+  if ((rc = dev_alloc(c, c->d_bcrInfo, guard * (size_t)(2 * nblk + 8) * 4))) return rc;
+  return LVX_OK;
+}
+// start of level l's blocks inside the per-level array (level l holds nblk >> l blocks)
+static inline size_t g_off(int nblk, int l, size_t bb) { size_t o = 0; for (int k = 0; k < l; ++k) o += (size_t)(nblk >> k) * bb; return o; }
+
+int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_radius, int* info_out_d) {
+  rocblas_handle h; int rc = bcr_handle(c, &h); if (rc) return rc;
+  const int b = c->bcr_b, nblk = c->bcr_nblk;
+  const size_t bb = (size_t)b * b;
+  double* D = (double*)c->d_bcrD.p; double* G = (double*)c->d_bcrG.p; int* info = (int*)c->d_bcrInfo.p;
+  hipStream_t st = c->stream;
+  const size_t tot = 2 * (size_t)nblk * bb;
+  hipLaunchKernelGGL(k_bcr_build, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, scale, lmd, inv_radius, c->nb, c->bw, b, nblk, D, G);
+  LVX_HIP(c, hipMemsetAsync(info, 0, (size_t)(2 * nblk + 8) * 4, st));
+  const double one = 1.0, mone = -1.0, zero = 0.0;
+  int L = 0; while ((1 << L) < nblk) ++L;
+  int info_pos = 0;
+  for (int l = 0; l < L; ++l) {
+    const int s = 1 << l, n2 = (nblk >> l) / 2;
+    const long long sD = (long long)2 * s * bb, sG = (long long)2 * bb;
+    double* Dj = D + (size_t)(s - 1) * bb;
+    double* Dr = D + (size_t)(2 * s - 1) * bb;
+    double* Gl = G + g_off(nblk, l, bb);
+    double* Gn = G + g_off(nblk, l + 1, bb);
+    LVX_BLAS(c, rocsolver_dpotrf_strided_batched(h, rocblas_fill_lower, b, Dj, b, sD, info + info_pos, n2));
+    info_pos += n2;
+    // X+_k = G[2k] C_k^-T : every ROW x of G[2k] solves C x^T = g^T
+    if ((rc = trsv_batched<false>(c, Dj, b, sD, Gl, /*se*/ b, /*sv*/ 1, sG, b, n2))) return rc;
+    // Y_k = C_k^-1 G[2k-1], k = 1..n2-1 : every COLUMN
+    if (n2 > 1 && (rc = trsv_batched<false>(c, Dj + sD, b, sD, Gl + bb, 1, b, sG, b, n2 - 1))) return rc;
+    // D_{j+s} -= X+ X+^T
+    LVX_BLAS(c, rocblas_dsyrk_strided_batched(h, rocblas_fill_lower, rocblas_operation_none, b, b, &mone, Gl, b, sG, &one, Dr, b, sD, n2));
+    if (n2 > 1) {
+      // D_{j-s} -= Y^T Y   (left neighbour of eliminated k is the right neighbour of eliminated k-1)
+      LVX_BLAS(c, rocblas_dsyrk_strided_batched(h, rocblas_fill_lower, rocblas_operation_transpose, b, b, &mone, Gl + bb, b, sG, &one, Dr, b, sD, n2 - 1));
+      // next level's coupling A_{j+s,j-s} = -X+_k Y_k
+      LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, b, b, &mone, Gl + 2 * bb, b, sG, Gl + bb, b, sG, &zero, Gn, b, (rocblas_stride)bb, n2 - 1));
+    }
+  }
+  LVX_BLAS(c, rocsolver_dpotrf_strided_batched(h, rocblas_fill_lower, b, D + (size_t)(nblk - 1) * bb, b, (rocblas_stride)bb, info + info_pos, 1));
+  info_pos += 1;
+  hipLaunchKernelGGL(k_bcr_info, dim3((info_pos + 255) / 256), dim3(256), 0, st, (const int*)info, info_pos, info_out_d);
+  LVX_HIP(c, hipGetLastError());
+  return LVX_OK;
+}
+
+// Zin: column-major [ldz x nrhs] right-hand sides; in place Zin <- L^-1 Zin (Zy aliases Zin; kept in the signature for the caller's bookkeeping)
+int bcr_forward(lvx_ctx* c, double* Zin, double* Zy, int ldz, int nrhs) {
+  rocblas_handle h; int rc = bcr_handle(c, &h); if (rc) return rc;
+  (void)Zy;
+  double* Z = Zin;
+  const int b = c->bcr_b, nblk = c->bcr_nblk;
+  const size_t bb = (size_t)b * b;
+  double* D = (double*)c->d_bcrD.p; double* G = (double*)c->d_bcrG.p;
+  const double one = 1.0, mone = -1.0;
+  int L = 0; while ((1 << L) < nblk) ++L;
+  for (int l = 0; l < L; ++l) {
+    const int s = 1 << l, n2 = (nblk >> l) / 2;
+    const long long sD = (long long)2 * s * bb, sG = (long long)2 * bb, sZ = (long long)2 * s * b;
+    double* Dj = D + (size_t)(s - 1) * bb;
+    double* Gl = G + g_off(nblk, l, bb);
+    double* Zj = Z + (size_t)(s - 1) * b;
+    double* Zr = Z + (size_t)(2 * s - 1) * b;
+    if ((rc = trsv_batched<false>(c, Dj, b, sD, Zj, 1, ldz, sZ, nrhs, n2))) return rc;                      // y_j = C_j^-1 b_j
+    LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, nrhs, b, &mone, Gl, b, sG, Zj, ldz, sZ, &one, Zr, ldz, sZ, n2));
+    if (n2 > 1)
+      LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, nrhs, b, &mone, Gl + bb, b, sG, Zj + sZ, ldz, sZ, &one, Zr, ldz, sZ, n2 - 1));
+  }
+  return trsv_batched<false>(c, D + (size_t)(nblk - 1) * bb, b, 0, Z + (size_t)(nblk - 1) * b, 1, ldz, 0, nrhs, 1);
+}
+// in place Zy <- L^-T Zy (Zx aliases Zy)
+int bcr_backward(lvx_ctx* c, double* Zy, double* Zx, int ldz, int nrhs) {
+  rocblas_handle h; int rc = bcr_handle(c, &h); if (rc) return rc;
+  (void)Zx;
+  double* Z = Zy;
+  const int b = c->bcr_b, nblk = c->bcr_nblk;
+  const size_t bb = (size_t)b * b;
+  double* D = (double*)c->d_bcrD.p; double* G = (double*)c->d_bcrG.p;
+  const double one = 1.0, mone = -1.0;
+  int L = 0; while ((1 << L) < nblk) ++L;
+  if ((rc = trsv_batched<true>(c, D + (size_t)(nblk - 1) * bb, b, 0, Z + (size_t)(nblk - 1) * b, 1, ldz, 0, nrhs, 1))) return rc;
+  for (int l = L - 1; l >= 0; --l) {
+    const int s = 1 << l, n2 = (nblk >> l) / 2;
+    const long long sD = (long long)2 * s * bb, sG = (long long)2 * bb, sZ = (long long)2 * s * b;
+    double* Dj = D + (size_t)(s - 1) * bb;
+    double* Gl = G + g_off(nblk, l, bb);
+    double* Zj = Z + (size_t)(s - 1) * b;
+    double* Zr = Z + (size_t)(2 * s - 1) * b;
+    LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, nrhs, b, &mone, Gl, b, sG, Zr, ldz, sZ, &one, Zj, ldz, sZ, n2));
+    if (n2 > 1)
+      LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, nrhs, b, &mone, Gl + bb, b, sG, Zr, ldz, sZ, &one, Zj + sZ, ldz, sZ, n2 - 1));
+    if ((rc = trsv_batched<true>(c, Dj, b, sD, Zj, 1, ldz, sZ, nrhs, n2))) return rc;
+  }
+  return LVX_OK;
+}
+// M (n x n, column-major) = Z^T Z for the tall-skinny Z [ldz x n]
+int bcr_gram(lvx_ctx* c, const double* Z, int ldz, int n, double* M) {
+  rocblas_handle h; int rc = bcr_handle(c, &h); if (rc) return rc;
+  const double one = 1.0, zero = 0.0;
+  LVX_BLAS(c, rocblas_dgemm(h, rocblas_operation_transpose, rocblas_operation_none, n, n, ldz, &one, Z, ldz, Z, ldz, &zero, M, n));
+  return LVX_OK;
+}
+
+void bcr_destroy(lvx_ctx* c) { if (c->blas) { (void)rocblas_destroy_handle((rocblas_handle)c->blas); c->blas = nullptr; } }
+
+}  // namespace lvx

@@ -90,6 +90,10 @@ struct lvx_ctx {
   lvx::DevBuf d_ord, d_Hb, d_gb, d_Bd, d_C, d_gc, d_cost, d_err, d_state, d_res, d_jcols, d_jvals, d_pairs[LVX_NUM_FAM];
   // solver workspace (lvx_solver.hip)
   lvx::DevBuf d_L, d_Y, d_S, d_delta, d_diag, d_scal, d_state_try, d_zero;
+  // block cyclic reduction (lvx_bcr.hip): diagonal blocks, per-level coupling blocks, pivot info; rocBLAS handle
+  lvx::DevBuf d_bcrD, d_bcrG, d_bcrInfo, d_Y2, d_gram;
+  void* blas = nullptr;
+  int bcr_b = 0, bcr_nblk = 0;
   int64_t n_blocks = 0, n_residuals = 0;
   int64_t fam_row0[LVX_NUM_FAM + 1] = {0};
   uint32_t last_what = 0;
@@ -116,6 +120,12 @@ int dev_alloc(lvx_ctx* ctx, DevBuf& b, size_t bytes);
 int upload(lvx_ctx* ctx, DevBuf& b, const void* src, size_t bytes);
 int ensure_layout(lvx_ctx* ctx);
 DevCommon make_common(lvx_ctx* ctx, const double* state_d, uint32_t what);
+int bcr_plan(lvx_ctx* c);
+int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_radius, int* info_out_d);
+int bcr_forward(lvx_ctx* c, double* Zin, double* Zy, int ldz, int nrhs);
+int bcr_backward(lvx_ctx* c, double* Zy, double* Zx, int ldz, int nrhs);
+int bcr_gram(lvx_ctx* c, const double* Z, int ldz, int n, double* M);
+void bcr_destroy(lvx_ctx* c);
 // profiling scope: records a (start, stop) HIP event pair on ctx->stream around a launch when profiling is on
 struct ProfScope {
   lvx_ctx* c; int kernel; size_t e0 = 0; bool on; hipStream_t st;

@@ -1038,6 +1038,8 @@ void lvx_destroy(lvx_ctx* c) {
   for (auto& b : c->d_pairs_acc) if (b.p) (void)hipFree(b.p);
   if (c->d_hubs.p) (void)hipFree(c->d_hubs.p);
   for (DevBuf* b : {&c->vox.misc, &c->vox.keys, &c->vox.vals, &c->vox.runs, &c->vox.cells, &c->vox.tmp, &c->vox.leaf_i, &c->vox.leaf_d, &c->vox.leaf_f}) if (b->p) (void)hipFree(b->p);
+  bcr_destroy(c);
+  for (DevBuf* b : {&c->d_bcrD, &c->d_bcrG, &c->d_bcrInfo, &c->d_Y2, &c->d_gram}) if (b->p) (void)hipFree(b->p);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   for (int k = 0; k < 4; ++k) { if (c->fam_stream[k]) (void)hipStreamDestroy(c->fam_stream[k]); if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);

@@ -491,8 +491,11 @@ LVX_HD int prior_residual(const SplineRef& sp, double t, quat q_meas, double wei
   r[0] = weight * (2.0 * atan2(vn, fabs(d.w)));
   if (NEED_J) {
     // theta(d Exp(zeta)) ~ theta + axis . zeta, zeta = -R(q) xi ; axis taken with d.w >= 0
+    // at vn == 0 the distance has a kink (|x|); autodiff yields 0/0 there.  LM reaches it exactly when the prior is the only gauge
+    // constraint (Solve #0), so the zero sub-gradient is used instead of propagating NaN into J^T J
     const double sgn = d.w < 0.0 ? -1.0 : 1.0;
-    const v3 axis = mk(sgn * d.x / vn, sgn * d.y / vn, sgn * d.z / vn);
+    const double ivn = vn > 0.0 ? 1.0 / vn : 0.0;
+    const v3 axis = mk(sgn * d.x * ivn, sgn * d.y * ivn, sgn * d.z * ivn);
     // d * (q Exp(-xi) q^*) : world-frame increment -R xi applied on the right of d
     const v3 gxi = (-weight) * qrot_inv(e.q, axis);
     for (int j = 0; j < 4; ++j) {

@@ -15,6 +15,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
+#include <vector>
 
 #include "lvx_ctx.h"
 
@@ -51,12 +53,14 @@ __global__ void k_build_band(const double* Hb, const double* scale, const double
   Lb[idx] = v;
 }
 // Z rows 0..nbd-1 = S_c B S_b ; row nbd = -S_b g_b
-__global__ void k_build_rhs(const double* Bd, const double* gb, const double* scale, int nb, int nbd, double* Z) {
+__global__ void k_build_rhs(const double* Bd, const double* gb, const double* scale, int nb, int nbd, int ldz, double* Z) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t tot = (size_t)(nbd + 1) * nb;
+  const size_t tot = (size_t)(nbd + 1) * ldz;
   if (idx >= tot) return;
-  const int r = (int)(idx / nb), j = (int)(idx % nb);
-  Z[idx] = r < nbd ? Bd[idx] * scale[nb + r] * scale[j] : -gb[j] * scale[j];
+  const int r = (int)(idx / ldz), j = (int)(idx % ldz);
+  double v = 0.0;
+  if (j < nb) v = r < nbd ? Bd[(size_t)r * nb + j] * scale[nb + r] * scale[j] : -gb[j] * scale[j];
+  Z[idx] = v;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -147,14 +151,14 @@ __global__ __launch_bounds__(CH_T) void k_band_chol(double* Lb, int nb, int bw, 
 
 // forward substitution Z[r][:] <- L^-1 Z[r][:] for FW_R right-hand sides per wavefront; window of bw+1 entries in LDS
 #define FW_R 4
-__global__ __launch_bounds__(64) void k_band_fwd(const double* __restrict__ Lb, int nb, int bw, double* Z, int nrhs) {
+__global__ __launch_bounds__(64) void k_band_fwd(const double* __restrict__ Lb, int nb, int bw, double* Z, int nrhs, int ldz) {
   extern __shared__ double W[];   // [FW_R][bw + 1] ring buffers
   const int lane = threadIdx.x;
   const int r0 = blockIdx.x * FW_R;
   const int nr = min(FW_R, nrhs - r0);
   const int wl = bw + 1;
   for (int r = 0; r < nr; ++r)
-    for (int d = lane; d < wl; d += 64) W[r * wl + d] = d < nb ? Z[(size_t)(r0 + r) * nb + d] : 0.0;
+    for (int d = lane; d < wl; d += 64) W[r * wl + d] = d < nb ? Z[(size_t)(r0 + r) * ldz + d] : 0.0;
   __syncthreads();
   int head = 0;   // ring position of row j
   for (int j = 0; j < nb; ++j) {
@@ -173,9 +177,9 @@ __global__ __launch_bounds__(64) void k_band_fwd(const double* __restrict__ Lb, 
     if (lane == 0) {
 #pragma unroll
       for (int r = 0; r < FW_R; ++r) if (r < nr) {
-        Z[(size_t)(r0 + r) * nb + j] = zj[r];
+        Z[(size_t)(r0 + r) * ldz + j] = zj[r];
         const int jn = j + wl;   // row entering the window takes the slot just vacated
-        W[r * wl + head] = jn < nb ? Z[(size_t)(r0 + r) * nb + jn] : 0.0;
+        W[r * wl + head] = jn < nb ? Z[(size_t)(r0 + r) * ldz + jn] : 0.0;
       }
     }
     head += 1; if (head == wl) head = 0;
@@ -207,15 +211,15 @@ __global__ __launch_bounds__(64) void k_band_bwd(const double* __restrict__ Lb, 
 }
 
 // S = Cs - Z_B Z_B^T (lower), rhs = f_c - Z_B z : one workgroup per (row a); dot products over nb
-__global__ __launch_bounds__(256) void k_schur(const double* __restrict__ Z, const double* C, const double* gc, const double* scale, int nb, int nbd, int ldc,
+__global__ __launch_bounds__(256) void k_schur(const double* __restrict__ Z, const double* C, const double* gc, const double* scale, int nb, int nbd, int ldc, int ldz,
                                                const double* lmd, double inv_radius, double* S, double* rhs) {
   const int a = blockIdx.x;
   __shared__ double red[256];
   for (int b = 0; b <= nbd; ++b) {   // b == nbd: the right-hand side column z
     if (b < nbd && b > a) continue;
     double s = 0.0;
-    const double* za = Z + (size_t)a * nb;
-    const double* zb = Z + (size_t)b * nb;
+    const double* za = Z + (size_t)a * ldz;
+    const double* zb = Z + (size_t)b * ldz;
     for (int j = threadIdx.x; j < nb; j += 256) s += za[j] * zb[j];
     red[threadIdx.x] = s;
     __syncthreads();
@@ -232,12 +236,28 @@ __global__ __launch_bounds__(256) void k_schur(const double* __restrict__ Z, con
     __syncthreads();
   }
 }
+// S and rhs from the Gram matrix M = [Z_B, z]^T [Z_B, z] ((nbd+1) x (nbd+1), column-major)
+__global__ void k_schur_from_gram(const double* M, const double* C, const double* gc, const double* scale, int nb, int nbd, int ldc,
+                                  const double* lmd, double inv_radius, double* S, double* rhs) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n1 = nbd + 1;
+  if (e >= nbd * n1) return;
+  const int a = e / n1, b = e % n1;
+  if (b < nbd) {
+    if (b > a) return;
+    double cv = C[(size_t)a * ldc + b] * scale[nb + a] * scale[nb + b];
+    if (a == b) cv += lmd[nb + a] * inv_radius;
+    S[(size_t)a * nbd + b] = cv - M[(size_t)b * n1 + a];
+  } else {
+    rhs[a] = -gc[a] * scale[nb + a] - M[(size_t)nbd * n1 + a];
+  }
+}
 // dense Cholesky solve of the border system (n <= 128), one workgroup; unused border slots have S_aa = lmd/radius > 0
 __global__ __launch_bounds__(256) void k_dense_solve(double* S, double* rhs, int n, int* info) {
   const int tid = threadIdx.x;
   for (int k = 0; k < n; ++k) {
     __syncthreads();
-    if (tid == 0) { const double d = S[(size_t)k * n + k]; if (!(d > 0.0)) { atomicMax(info, 1000000000 + k); S[(size_t)k * n + k] = 1.0; } else S[(size_t)k * n + k] = sqrt(d); }
+    if (tid == 0) { const double d = S[(size_t)k * n + k]; if (!(d > 0.0)) { if (info[1] == 0) { info[1] = k + 1; ((double*)(info + 2))[0] = d; } S[(size_t)k * n + k] = 1.0; } else S[(size_t)k * n + k] = sqrt(d); }
     __syncthreads();
     const double inv = 1.0 / S[(size_t)k * n + k];
     for (int r = k + 1 + tid; r < n; r += 256) S[(size_t)r * n + k] *= inv;
@@ -252,11 +272,11 @@ __global__ __launch_bounds__(256) void k_dense_solve(double* S, double* rhs, int
   }
 }
 // z <- z - Z_B^T y_c
-__global__ void k_sub_border(const double* Z, const double* yc, int nb, int nbd, double* z) {
+__global__ void k_sub_border(const double* Z, const double* yc, int nb, int nbd, int ldz, double* z) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nb) return;
   double s = z[j];
-  for (int b = 0; b < nbd; ++b) s -= Z[(size_t)b * nb + j] * yc[b];
+  for (int b = 0; b < nbd; ++b) s -= Z[(size_t)b * ldz + j] * yc[b];
   z[j] = s;
 }
 // delta (tangent layout) from the scaled solution; also accumulates g_s.y and y^T D^2 y for the model cost change
@@ -279,6 +299,31 @@ __global__ void k_unscale(const int* ord, int nt, const double* yb, const double
   }
   for (int o = 32; o > 0; o >>= 1) { gy += __shfl_xor(gy, o); ydy += __shfl_xor(ydy, o); }
   if ((threadIdx.x & 63) == 0) { atomicAdd(&sums[0], gy); atomicAdd(&sums[1], ydy); }
+}
+// sums[5] += delta^T H delta for the UNSCALED step (H = J^T J in band / border storage): the model cost change is then
+// -(g.delta + 1/2 delta^T H delta), what ceres computes from J * step — valid for any (also inexact) step
+__global__ void k_quad(const double* __restrict__ Hb, const double* __restrict__ Bd, const double* __restrict__ C, int ldc, const double* yb, const double* yc,
+                       const double* scale, int nb, int bw, int nbd, double* sums) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double q = 0.0;
+  if (i < nb) {
+    const double di = yb[i] * scale[i];
+    double t = 0.0;
+    const double* col = Hb + (size_t)i * (bw + 1);
+    for (int d = 0; d <= bw && i + d < nb; ++d) t += col[d] * (yb[i + d] * scale[i + d]);                       // A(i+d, i) delta_{i+d}
+    for (int d = 1; d <= bw && i - d >= 0; ++d) t += Hb[(size_t)(i - d) * (bw + 1) + d] * (yb[i - d] * scale[i - d]);   // A(i, i-d) delta_{i-d}
+    double u = 0.0;
+    for (int b = 0; b < nbd; ++b) u += Bd[(size_t)b * nb + i] * (yc[b] * scale[nb + b]);
+    q = di * (t + 2.0 * u);
+  } else if (i < nb + nbd) {
+    const int a = i - nb;
+    const double da = yc[a] * scale[nb + a];
+    double t = 0.0;
+    for (int b = 0; b < nbd; ++b) t += (a >= b ? C[(size_t)a * ldc + b] : C[(size_t)b * ldc + a]) * (yc[b] * scale[nb + b]);
+    q = da * t;
+  }
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  if ((threadIdx.x & 63) == 0 && q != 0.0) atomicAdd(&sums[5], q);
 }
 __device__ __forceinline__ void qplus_dev(const double* x, const double* d, double* o) {   // EigenQuaternionParameterization::Plus
   const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
@@ -335,13 +380,18 @@ using namespace lvx;
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
-struct SolveWork { double *L, *Z, *S, *rhs, *delta, *diag, *scale, *lmd, *sums; int* info; };
+struct SolveWork { double *L, *Z, *S, *rhs, *delta, *diag, *scale, *lmd, *sums, *Z2, *gram; int* info; int ldz; bool use_bcr; };
 
 static int solver_alloc(lvx_ctx* c, SolveWork& w) {
   int rc;
   const size_t nb = (size_t)std::max(c->nb, 1), nbd = c->nbd, nt = (size_t)lvx_tangent_size(c);
-  if ((rc = dev_alloc(c, c->d_L, nb * (c->bw + 1) * 8))) return rc;
-  if ((rc = dev_alloc(c, c->d_Y, (nbd + 1) * nb * 8))) return rc;
+  const bool use_bcr = !getenv("LVX_SOLVER_SEQ");
+  size_t ldz = nb;
+  if (use_bcr && c->nb > 0) { if ((rc = bcr_plan(c))) return rc; ldz = (size_t)c->bcr_nblk * c->bcr_b; }
+  w.ldz = (int)ldz; w.use_bcr = use_bcr && c->nb > 0;
+  if ((rc = dev_alloc(c, c->d_Y, (nbd + 1) * ldz * 8))) return rc;
+  if (w.use_bcr) { if ((rc = dev_alloc(c, c->d_gram, (nbd + 1) * (nbd + 1) * 8))) return rc; }
+  w.Z2 = (double*)c->d_Y2.p; w.gram = (double*)c->d_gram.p;
   if ((rc = dev_alloc(c, c->d_S, (nbd * nbd + nbd + 16) * 8))) return rc;
   if ((rc = dev_alloc(c, c->d_delta, nt * 8))) return rc;
   if ((rc = dev_alloc(c, c->d_diag, 3 * (nb + nbd) * 8))) return rc;
@@ -355,45 +405,79 @@ static int solver_alloc(lvx_ctx* c, SolveWork& w) {
 
 // Solve the damped, scaled system for the normal equations of the last evaluation.  Leaves delta (tangent layout) on the device.
 // out[0] = model cost change, out[1] = g_s.y, out[2] = y^T D^2 y
-static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double* out) {
+static int solve_step_device_impl(lvx_ctx* c, SolveWork& w, double radius, double* out, bool force_seq) {
   hipStream_t st = c->stream;
   const int nb = c->nb, bw = c->bw, nbd = c->nbd, nt = lvx_tangent_size(c);
   const double ir = 1.0 / radius;
   ProfScope ps(c, LVX_KERNEL_SOLVE);
   LVX_HIP(c, hipMemsetAsync(w.sums, 0, 64 * 8, st));
+  const bool use_bcr = w.use_bcr && !force_seq;
+  if (!use_bcr && nb > 0) { int rca = dev_alloc(c, c->d_L, (size_t)nb * (bw + 1) * 8); if (rca) return rca; w.L = (double*)c->d_L.p; }
+  const int ldz = w.ldz;
   if (nb > 0) {
-    const size_t tot = (size_t)nb * (bw + 1);
-    hipLaunchKernelGGL(k_build_band, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, w.scale, w.lmd, ir, nb, bw, w.L);
-    const size_t tr = (size_t)(nbd + 1) * nb;
-    hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)((tr + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Bd.p, (const double*)c->d_gb.p, w.scale, nb, nbd, w.Z);
-    const size_t lds_ch = (size_t)(bw + CH_NB) * (CH_NB + 1) * 8;
-    if (lds_ch > 150 * 1024) return fail(c, LVX_E_ARG, "bandwidth too large for the single-workgroup band Cholesky panel");
-    LVX_HIP(c, hipFuncSetAttribute((const void*)k_band_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ch));
-    hipLaunchKernelGGL(k_band_chol, dim3(1), dim3(CH_T), lds_ch, st, w.L, nb, bw, w.info);
-    const size_t lds_fw = (size_t)FW_R * (bw + 1) * 8;
-    LVX_HIP(c, hipFuncSetAttribute((const void*)k_band_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fw));
-    hipLaunchKernelGGL(k_band_fwd, dim3((unsigned)((nbd + 1 + FW_R - 1) / FW_R)), dim3(64), lds_fw, st, (const double*)w.L, nb, bw, w.Z, nbd + 1);
+    const size_t tr = (size_t)(nbd + 1) * ldz;
+    hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)((tr + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Bd.p, (const double*)c->d_gb.p, w.scale, nb, nbd, ldz, w.Z);
+    if (use_bcr) {
+      int rc2;
+      if ((rc2 = bcr_factor(c, w.scale, w.lmd, ir, w.info))) return rc2;
+      if ((rc2 = bcr_forward(c, w.Z, w.Z, ldz, nbd + 1))) return rc2;   // Z <- L^-1 [B^T, f_b] (in place)
+    } else {
+      const size_t tot = (size_t)nb * (bw + 1);
+      hipLaunchKernelGGL(k_build_band, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, w.scale, w.lmd, ir, nb, bw, w.L);
+      const size_t lds_ch = (size_t)(bw + CH_NB) * (CH_NB + 1) * 8;
+      if (lds_ch > 150 * 1024) return fail(c, LVX_E_ARG, "bandwidth too large for the single-workgroup band Cholesky panel");
+      LVX_HIP(c, hipFuncSetAttribute((const void*)k_band_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ch));
+      hipLaunchKernelGGL(k_band_chol, dim3(1), dim3(CH_T), lds_ch, st, w.L, nb, bw, w.info);
+      const size_t lds_fw = (size_t)FW_R * (bw + 1) * 8;
+      LVX_HIP(c, hipFuncSetAttribute((const void*)k_band_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fw));
+      hipLaunchKernelGGL(k_band_fwd, dim3((unsigned)((nbd + 1 + FW_R - 1) / FW_R)), dim3(64), lds_fw, st, (const double*)w.L, nb, bw, w.Z, nbd + 1, ldz);
+    }
   }
-  hipLaunchKernelGGL(k_schur, dim3(nbd), dim3(256), 0, st, (const double*)w.Z, (const double*)c->d_C.p, (const double*)c->d_gc.p, (const double*)w.scale,
-                     nb > 0 ? nb : 0, nbd, c->nbd_ext, (const double*)w.lmd, ir, w.S, w.rhs);
+  double* Zf = w.Z;   // forward-substituted right-hand sides
+  if (use_bcr && nb > 0) {
+    int rc2;
+    if ((rc2 = bcr_gram(c, Zf, ldz, nbd + 1, w.gram))) return rc2;
+    hipLaunchKernelGGL(k_schur_from_gram, dim3((unsigned)((nbd * (nbd + 1) + 255) / 256)), dim3(256), 0, st, (const double*)w.gram, (const double*)c->d_C.p, (const double*)c->d_gc.p,
+                       (const double*)w.scale, nb, nbd, c->nbd_ext, (const double*)w.lmd, ir, w.S, w.rhs);
+  } else {
+    hipLaunchKernelGGL(k_schur, dim3(nbd), dim3(256), 0, st, (const double*)Zf, (const double*)c->d_C.p, (const double*)c->d_gc.p, (const double*)w.scale,
+                       nb > 0 ? nb : 0, nbd, c->nbd_ext, ldz, (const double*)w.lmd, ir, w.S, w.rhs);
+  }
   hipLaunchKernelGGL(k_dense_solve, dim3(1), dim3(256), 0, st, w.S, w.rhs, nbd, w.info);
-  double* zb = w.Z + (size_t)nbd * std::max(nb, 1);
+  double* zb = Zf + (size_t)nbd * std::max(ldz, 1);
   if (nb > 0) {
-    hipLaunchKernelGGL(k_sub_border, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const double*)w.Z, (const double*)w.rhs, nb, nbd, zb);
-    const size_t lds_bw = (size_t)(bw + 1) * 8;
-    hipLaunchKernelGGL(k_band_bwd, dim3(1), dim3(64), lds_bw, st, (const double*)w.L, nb, bw, zb);
+    hipLaunchKernelGGL(k_sub_border, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const double*)Zf, (const double*)w.rhs, nb, nbd, ldz, zb);
+    if (use_bcr) {
+      int rc2;
+      if ((rc2 = bcr_backward(c, zb, zb, ldz, 1))) return rc2;
+    } else {
+      const size_t lds_bw = (size_t)(bw + 1) * 8;
+      hipLaunchKernelGGL(k_band_bwd, dim3(1), dim3(64), lds_bw, st, (const double*)w.L, nb, bw, zb);
+    }
   }
   hipLaunchKernelGGL(k_unscale, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, (const int*)c->d_ord.p, nt, (const double*)zb, (const double*)w.rhs, (const double*)w.scale,
                      (const double*)w.lmd, ir, (const double*)c->d_gb.p, (const double*)c->d_gc.p, nb, w.delta, w.sums);
+  hipLaunchKernelGGL(k_quad, dim3((unsigned)((nb + nbd + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)c->d_Bd.p, (const double*)c->d_C.p, c->nbd_ext,
+                     (const double*)zb, (const double*)w.rhs, (const double*)w.scale, nb, bw, nbd, w.sums);
   LVX_HIP(c, hipGetLastError());
-  double h[8]; int info = 0;
+  double h[8]; int info[4] = {0, 0, 0, 0};
   LVX_HIP(c, hipMemcpyAsync(h, w.sums, 8 * 8, hipMemcpyDeviceToHost, st));
-  LVX_HIP(c, hipMemcpyAsync(&info, w.info, 4, hipMemcpyDeviceToHost, st));
+  LVX_HIP(c, hipMemcpyAsync(info, w.info, 16, hipMemcpyDeviceToHost, st));
   LVX_HIP(c, hipStreamSynchronize(st));
-  if (info) return fail(c, LVX_E_NOTPD, "damped normal equations not positive definite (pivot " + std::to_string(info) + ")");
-  // model_cost_change = -(g.delta + 1/2 delta^T H delta) = -1/2 g_s.y + 1/2 y^T D^2 y   (exact for an exact solve)
-  out[0] = -0.5 * h[0] + 0.5 * h[1]; out[1] = h[0]; out[2] = h[1];
+  if (info[0] || info[1]) { double dv; memcpy(&dv, info + 2, 8); return fail(c, LVX_E_NOTPD, "damped normal equations not positive definite (band pivot code " + std::to_string(info[0]) + ", first border pivot " + std::to_string(info[1]) + " value " + std::to_string(dv) + ")"); }
+  // model_cost_change = -(g.delta + 1/2 delta^T H delta)   (TrustRegionMinimizer: -model_residuals.(residuals + model_residuals / 2))
+  out[0] = -h[0] - 0.5 * h[5]; out[1] = h[0]; out[2] = h[1];
   return LVX_OK;
+}
+
+static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double* out) {
+  int rc = solve_step_device_impl(c, w, radius, out, false);
+  if (rc == LVX_E_NOTPD && w.use_bcr) {
+    // the cyclic-reduction elimination order can lose positive definiteness in floating point on nearly singular systems
+    // (huge trust radius at convergence); the sequential band Cholesky is the exact fallback
+    rc = solve_step_device_impl(c, w, radius, out, true);
+  }
+  return rc;
 }
 
 static int prepare_diag(lvx_ctx* c, SolveWork& w, bool compute_scale, int use_scaling, double mn, double mx) {
@@ -469,6 +553,7 @@ int lvx_lm_solve(lvx_ctx* c, double* state, const lvx_lm_options* opt_in, lvx_lm
     rc = solve_step_device(c, w, radius, out);
     bool step_valid = (rc == LVX_OK) && std::isfinite(out[0]) && out[0] > 0.0;
     if (rc != LVX_OK && rc != LVX_E_NOTPD) return rc;
+    if (!step_valid && o.verbose) fprintf(stderr, "[lvx lm] it %3d invalid step: rc %d (%s) model_cost_change %.6e g.delta %.6e dHd %.6e\n", it, rc, c->last_error.c_str(), out[0], out[1], 0.0);
     if (!step_valid) {   // TrustRegionMinimizer::HandleInvalidStep + LevenbergMarquardtStrategy::StepIsInvalid
       if (++invalid > 5) { s.termination = LVX_LM_FAILURE; break; }
       radius *= 0.5; reuse_diagonal = true;
