@@ -69,55 +69,63 @@ static int bcr_handle(lvx_ctx* c, rocblas_handle* h) {
 // lose positive definiteness of the Schur complements on weakly constrained problems, so this step is hand-written.)
 // ---------------------------------------------------------------------------------------------------------
 #define TRS_PANEL 16
+#define TRS_G 4   // wavefronts per workgroup: each handles every TRS_G-th row of the 64 vectors
 template <bool TRANS>
-__global__ __launch_bounds__(64) void k_trsv_batched(const double* __restrict__ Lm, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec) {
+__global__ __launch_bounds__(64 * TRS_G) void k_trsv_batched(const double* __restrict__ Lm, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec) {
   extern __shared__ double lds[];
   double* W = lds;                        // [b][65]
   double* P = lds + (size_t)b * 65;       // [TRS_PANEL][b] panel of L columns
-  const int t = threadIdx.x;
+  double* R = P + (size_t)TRS_PANEL * b;  // [TRS_G][64] partial sums (TRANS)
+  const int t = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int vec = blockIdx.x * 64 + t;
   const bool act = vec < nvec;
   const double* L = Lm + (size_t)blockIdx.y * strideL;
   double* v = V + (size_t)blockIdx.y * strideV + (size_t)vec * sv;
-  for (int i = 0; i < b; ++i) W[i * 65 + t] = act ? v[(size_t)i * se] : 0.0;
+  for (int i = g; i < b; i += TRS_G) W[i * 65 + t] = act ? v[(size_t)i * se] : 0.0;
   if (!TRANS) {
     for (int k0 = 0; k0 < b; k0 += TRS_PANEL) {
       const int nk = min(TRS_PANEL, b - k0);
       __syncthreads();
-      for (int e = t; e < nk * b; e += 64) { const int kk = e / b, i = e % b; P[kk * b + i] = i >= k0 + kk ? L[(size_t)(k0 + kk) * b + i] : 0.0; }
+      for (int e = threadIdx.x; e < nk * b; e += 64 * TRS_G) { const int kk = e / b, i = e % b; P[kk * b + i] = i >= k0 + kk ? L[(size_t)(k0 + kk) * b + i] : 0.0; }
       __syncthreads();
       for (int kk = 0; kk < nk; ++kk) {
         const int k = k0 + kk;
-        const double wk = W[k * 65 + t] / P[kk * b + k];
-        W[k * 65 + t] = wk;
         const double* col = &P[kk * b];
-        for (int i = k + 1; i < b; ++i) W[i * 65 + t] -= col[i] * wk;
+        const double wk = W[k * 65 + t] / col[k];
+        __syncthreads();                       // everyone has read v_k before it is replaced by w_k
+        if (g == 0) W[k * 65 + t] = wk;
+        for (int i = k + 1 + g; i < b; i += TRS_G) W[i * 65 + t] -= col[i] * wk;
+        __syncthreads();                       // row k + 1 is final
       }
     }
   } else {
     for (int k1 = b; k1 > 0; k1 -= TRS_PANEL) {
       const int k0 = max(0, k1 - TRS_PANEL), nk = k1 - k0;
       __syncthreads();
-      for (int e = t; e < nk * b; e += 64) { const int kk = e / b, i = e % b; P[kk * b + i] = i >= k0 + kk ? L[(size_t)(k0 + kk) * b + i] : 0.0; }
+      for (int e = threadIdx.x; e < nk * b; e += 64 * TRS_G) { const int kk = e / b, i = e % b; P[kk * b + i] = i >= k0 + kk ? L[(size_t)(k0 + kk) * b + i] : 0.0; }
       __syncthreads();
       for (int kk = nk - 1; kk >= 0; --kk) {
         const int k = k0 + kk;
         const double* col = &P[kk * b];
-        double sacc = W[k * 65 + t];
-        for (int i = k + 1; i < b; ++i) sacc -= col[i] * W[i * 65 + t];
-        W[k * 65 + t] = sacc / col[k];
+        double part = 0.0;
+        for (int i = k + 1 + g; i < b; i += TRS_G) part += col[i] * W[i * 65 + t];
+        R[g * 64 + t] = part;
+        __syncthreads();
+        if (g == 0) { double sacc = W[k * 65 + t]; for (int q = 0; q < TRS_G; ++q) sacc -= R[q * 64 + t]; W[k * 65 + t] = sacc / col[k]; }
+        __syncthreads();
       }
     }
   }
-  if (act) for (int i = 0; i < b; ++i) v[(size_t)i * se] = W[i * 65 + t];
+  __syncthreads();
+  if (act) for (int i = g; i < b; i += TRS_G) v[(size_t)i * se] = W[i * 65 + t];
 }
 template <bool TRANS>
 static int trsv_batched(lvx_ctx* c, const double* L, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, int batch) {
   if (batch <= 0 || nvec <= 0) return LVX_OK;
-  const size_t lds = ((size_t)b * 65 + (size_t)TRS_PANEL * b) * 8;
+  const size_t lds = ((size_t)b * 65 + (size_t)TRS_PANEL * b + (size_t)TRS_G * 64) * 8;
   if (lds > 158 * 1024) return fail(c, LVX_E_ARG, "block size too large for the LDS-resident triangular solve");
   LVX_HIP(c, hipFuncSetAttribute((const void*)k_trsv_batched<TRANS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_trsv_batched<TRANS>, dim3((unsigned)((nvec + 63) / 64), (unsigned)batch), dim3(64), lds, c->stream, L, b, strideL, V, se, sv, strideV, nvec);
+  hipLaunchKernelGGL(k_trsv_batched<TRANS>, dim3((unsigned)((nvec + 63) / 64), (unsigned)batch), dim3(64 * TRS_G), lds, c->stream, L, b, strideL, V, se, sv, strideV, nvec);
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
 }
@@ -229,11 +237,26 @@ int bcr_backward(lvx_ctx* c, double* Zy, double* Zx, int ldz, int nrhs) {
   }
   return LVX_OK;
 }
-// M (n x n, column-major) = Z^T Z for the tall-skinny Z [ldz x n]
+// M (n x n, column-major) = Z^T Z for the tall-skinny Z [ldz x n], ldz = nblk * b.  Split-K by hand: one small GEMM per row block
+// (strided batched) into partial[nblk][n*n], then a reduction — rocBLAS' single GEMM picks a one-tile kernel for m = n = 53, k = 2e5.
+__global__ void k_sum_partials(const double* P, int nn, int nparts, double* M) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nn) return;
+  double s = 0.0;
+  for (int p = 0; p < nparts; ++p) s += P[(size_t)p * nn + e];
+  M[e] = s;
+}
 int bcr_gram(lvx_ctx* c, const double* Z, int ldz, int n, double* M) {
   rocblas_handle h; int rc = bcr_handle(c, &h); if (rc) return rc;
+  const int b = c->bcr_b, nblk = c->bcr_nblk;
+  const size_t nn = (size_t)n * n;
+  if ((rc = dev_alloc(c, c->d_Y2, (size_t)nblk * nn * 8))) return rc;
+  double* P = (double*)c->d_Y2.p;
   const double one = 1.0, zero = 0.0;
-  LVX_BLAS(c, rocblas_dgemm(h, rocblas_operation_transpose, rocblas_operation_none, n, n, ldz, &one, Z, ldz, Z, ldz, &zero, M, n));
+  LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, n, n, b, &one, Z, ldz, (rocblas_stride)b, Z, ldz, (rocblas_stride)b,
+                                            &zero, P, n, (rocblas_stride)nn, nblk));
+  hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, c->stream, (const double*)P, (int)nn, nblk, M);
+  LVX_HIP(c, hipGetLastError());
   return LVX_OK;
 }
 
