@@ -30,6 +30,45 @@ FP64_VALU_PEAK_TFLOPS = 78.6  # SURVEY.md §8d (vector FP64; the solve is VALU-b
 BYTES_PER_EVAL = {"imu": 32, "surfel": 60, "reproj": 60}
 
 
+def secondary_metrics(ctx, P, lo):
+    """Side measurements (not the headline value): one full LM iteration incl. the linear solve, and the upstream kernels of
+    BASELINE.json configs 1-2 / the surfel-association metric, inputs resident in HBM, wall-clock over repeated calls."""
+    import lvx
+    import synth
+    sec = {}
+    try:
+        import time
+        t0 = time.perf_counter()
+        _, sm = ctx.lm_solve(P["state0"], max_iterations=3)
+        dt = time.perf_counter() - t0
+        it = max(1, sm["iterations"])
+        sec["lm_iteration"] = {"ms_per_iteration": 1e3 * dt / it, "iterations": it, "Mevals_per_s_incl_solve": lo["n_blocks"] * (it + sm["successful_steps"] + 1) / dt / 1e6,
+                               "note": "evaluate(+J^T J) + block-cyclic-reduction solve + candidate cost evaluation per iteration; host-synchronised"}
+    except Exception as e:   # noqa: BLE001
+        sec["lm_iteration"] = {"error": str(e)[:200]}
+    try:
+        scan, p4, bmin, bmax = synth.make_assoc_problem(seed=5, H=16, W=1800, n_planes=2000)
+        t = lvx.upstream_bench(ctx, "surfel_assoc", (scan, p4, bmin, bmax))
+        sec["surfel_assoc"] = {"Mpts_per_s": scan.shape[0] * scan.shape[1] / t / 1e6, "planes": 2000, "points": scan.shape[0] * scan.shape[1], "ms": 1e3 * t,
+                               "hbm_frac": (20.0 * scan.shape[0] * scan.shape[1] + 80.0 * 2000) / t / 1e9 / HBM_PEAK_GBS}
+        cloud = synth.make_voxel_cloud(seed=2, n=100_000)
+        t = lvx.upstream_bench(ctx, "voxel_build", (cloud, 0.5))
+        sec["voxel_build"] = {"Mpts_per_s": len(cloud) / t / 1e6, "points": len(cloud), "ms": 1e3 * t}
+        t = lvx.upstream_bench(ctx, "voxel_lookup7", synth.rigid_move(cloud))
+        sec["voxel_lookup7"] = {"Mqueries_per_s": len(cloud) / t / 1e6, "ms": 1e3 * t, "hbm_frac": 100.0 * len(cloud) / t / 1e9 / HBM_PEAK_GBS}
+        pts = synth.make_vlp16_sweep(seed=1)
+        import time
+        lvx.scan_register(ctx, pts, 16, 0.3)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            lvx.scan_register(ctx, pts, 16, 0.3)
+        t = (time.perf_counter() - t0) / 10
+        sec["scan_registration"] = {"ms_per_sweep": 1e3 * t, "points": len(pts), "note": "host buffers in/out (PCIe inclusive), reference budget 100 ms per sweep"}
+    except Exception as e:   # noqa: BLE001
+        sec["upstream_error"] = str(e)[:200]
+    return sec
+
+
 def usable_cores():
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (os.cpu_count() reports the host)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -82,6 +121,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--small", action="store_true", help="1/10 size problem (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the LM-iteration and upstream-kernel side measurements")
     args = ap.parse_args()
 
     import torch
@@ -165,6 +205,8 @@ def main():
                            "note": "fused residual+Jacobian+J^T J kernel: FP64-VALU / LDS / atomic bound, not HBM bound (SURVEY.md 8d: ~9 kFLOP per 60 B); duration measured while the gyro/accel/reprojection kernels run concurrently on sibling streams",
                            "fp64_valu": {"achieved_tflops": 9e3 * n_surf / (surf_ms * 1e-3) / 1e12 if surf_ms > 0 else 0.0, "peak_tflops": FP64_VALU_PEAK_TFLOPS}}
         out["kernel_ms"] = {lvx.KERNEL_NAMES[i]: ms[i] / max(1, launches[i]) for i in range(len(ms)) if launches[i]}
+        if world == 1 and not args.no_secondary:
+            out["secondary"] = secondary_metrics(ctx, P, lo)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(P)
         print(json.dumps(out), flush=True)

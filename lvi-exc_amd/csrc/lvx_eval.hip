@@ -396,12 +396,13 @@ struct CamSurfAcc {
   __device__ static int gcol(int g, int N, int nt) { return g < 6 ? nt + 6 + g : (g < 12 ? 6 * N + 15 + (g - 6) : 6 * N + 8 + (g - 12)); }
 };
 
-#define ACC_LV ((LVX_CHUNK_R + 5) * 6)   // local variables of a chunk: knots [c R - 1, c R + R + 4)
 #define ACC_BW 24
+#define LVX_CHUNK_R_IMU 32   // 8 IMU samples per knot interval: 32 intervals = one 256-sample batch per workgroup
 
-template <class F>
+template <class F, int CR>
 __global__ __launch_bounds__(256) void k_family_acc(F fam, DevCommon cm, const int* __restrict__ chunk_off, const uint16_t* __restrict__ pairs, long long row0) {
   constexpr int NK = F::NK, NG = F::NG, NC = NK + NG, NR = F::NR, TS = 65, NP = NC * (NC + 1) / 2;
+  constexpr int ACC_LV = (CR + 5) * 6;   // local variables of a chunk: knots [c CR - 1, c CR + CR + 4)
   extern __shared__ double sm[];
   double* acc_band = sm;                              // [ACC_LV][ACC_BW]
   double* acc_bd = acc_band + ACC_LV * ACC_BW;        // [NG][ACC_LV]
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(256) void k_family_acc(F fam, DevCommon cm, const i
   const int ch = blockIdx.x;
   const int m0 = chunk_off[ch], m1 = chunk_off[ch + 1];
   if (m0 >= m1) return;
-  const int k_lo = ch * LVX_CHUNK_R - 1;
+  const int k_lo = ch * CR - 1;
   const int nt = 6 * cm.N + 22 + cm.L;
   const bool want_ne = (cm.what & LVX_EVAL_NORMAL_EQ) != 0;
   for (int e = tid; e < ACC_LV * ACC_BW + NG * ACC_LV + NG * NG + ACC_LV + NG; e += 256) sm[e] = 0.0;
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(256) void k_family_acc(F fam, DevCommon cm, const i
     if (in) {
       const int status = fam.eval(cm, sp, cal, hub, si, r, J, key);
       valid = status == RES_OK;
-      if (valid && (key < k_lo || key - k_lo > LVX_CHUNK_R + 1)) { valid = false; atomicOr(cm.err, LVX_ERR_FALLBACK); }
+      if (valid && (key < k_lo || key - k_lo > CR + 1)) { valid = false; atomicOr(cm.err, LVX_ERR_FALLBACK); }
       else if (!valid) atomicOr(cm.err, status);
       if (!valid) key = -1;
     }
@@ -660,11 +661,11 @@ int host_i0(const lvx_ctx* c, double t) {
 
 }  // namespace
 
-static int upload_chunks(lvx_ctx* ctx, int fam, const std::vector<int>& sorted_keys) {
-  const int nch = (ctx->N + LVX_CHUNK_R - 1) / LVX_CHUNK_R + 1;
+static int upload_chunks(lvx_ctx* ctx, int fam, const std::vector<int>& sorted_keys, int R) {
+  const int nch = (ctx->N + R - 1) / R + 1;
   std::vector<int> off(nch + 1);
   for (int c = 0; c <= nch; ++c)
-    off[c] = c == 0 ? 0 : (int)(std::lower_bound(sorted_keys.begin(), sorted_keys.end(), c * LVX_CHUNK_R) - sorted_keys.begin());
+    off[c] = c == 0 ? 0 : (int)(std::lower_bound(sorted_keys.begin(), sorted_keys.end(), c * R) - sorted_keys.begin());
   off[nch] = (int)sorted_keys.size();
   ctx->n_chunk[fam] = nch;
   return upload(ctx, ctx->d_chunk[fam], off.data(), off.size() * 4);
@@ -684,7 +685,7 @@ int ensure_layout(lvx_ctx* ctx) {
     for (int i = 0; i < f.n; ++i) key[i] = host_i0(ctx, f.t[i]);
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
-    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_GYRO, sk))) return rc; }
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_GYRO, sk, LVX_CHUNK_R_IMU))) return rc; }
     auto ts = gather(f.t, perm, 1); auto g = gather(f.a3, perm, 3); auto a = gather(f.b3, perm, 3);
     if ((rc = upload(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
     if ((rc = upload(ctx, f.d_a3, g.data(), g.size() * 8))) return rc;
@@ -697,7 +698,7 @@ int ensure_layout(lvx_ctx* ctx) {
     for (int i = 0; i < f.n; ++i) key[i] = host_i0(ctx, f.t[i]);
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
-    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_SURFEL, sk))) return rc; }
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_SURFEL, sk, LVX_CHUNK_R))) return rc; }
     auto ts = gather(f.t, perm, 1); auto pt = gather(f.a3, perm, 3); auto pl = gather(f.id0, perm, 1);
     if ((rc = upload(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
     if ((rc = upload(ctx, f.d_a3, pt.data(), pt.size() * 8))) return rc;
@@ -721,7 +722,7 @@ int ensure_layout(lvx_ctx* ctx) {
     for (int i = 0; i < f.n; ++i) key[i] = (f.id0[i] >= 0 && f.id0[i] < L) ? host_i0(ctx, ctx->lm_t0[f.id0[i]]) : -1;
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
-    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_CAMSURF, sk))) return rc; }
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_CAMSURF, sk, LVX_CHUNK_R))) return rc; }
     auto lm = gather(f.id0, perm, 1); auto pl = gather(f.id1, perm, 1);
     if ((rc = upload(ctx, f.d_id0, lm.data(), lm.size() * 4))) return rc;
     if ((rc = upload(ctx, f.d_id1, pl.data(), pl.size() * 4))) return rc;
@@ -892,27 +893,27 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
   // fast path: LDS-accumulating kernels for the segment-structured families; legacy per-segment kernels for reprojection, the prior,
   // the debug Jacobian, and as the exact fallback for the merged-hub-segment corner
   const bool fast = !ctx->force_legacy && !(what & LVX_EVAL_JACOBIAN) && !getenv("LVX_FORCE_LEGACY");
-  auto acc_lds = [](int NC, int NG) { return (size_t)(ACC_LV * ACC_BW + NG * ACC_LV + NG * NG + ACC_LV + NG + 4 * (NC * 65 + 64)) * 8 + (size_t)(ACC_LV + NG) * 4 + 64; };
+  auto acc_lds = [](int NC, int NG, int R) { const int LV = (R + 5) * 6; return (size_t)(LV * ACC_BW + NG * LV + NG * NG + LV + NG + 4 * (NC * 65 + 64)) * 8 + (size_t)(LV + NG) * 4 + 64; };
   if (fast && (ctx->surf.n > 0 || ctx->cs.n > 0))
     hipLaunchKernelGGL(k_hub_eval, dim3(1), dim3(64), 0, st, cm, ctx->t_map, ctx->surf.n > 0 ? 1 : 0, ctx->cs.n > 0 ? 1 : 0, (HubShared*)ctx->d_hubs.p);
   // fork: the independent family kernels run concurrently (each is latency / occupancy limited on its own)
   LVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
   for (int k = 0; k < 4; ++k) LVX_HIP(ctx, hipStreamWaitEvent(ctx->fam_stream[k], ctx->ev_fork, 0));
   hipStream_t s_imu = ctx->fam_stream[0], s_acc = ctx->fam_stream[1], s_surf = ctx->fam_stream[2], s_rep = ctx->fam_stream[3];
-  const bool imu_fast = false;   // 8 samples per knot interval: the per-segment kernel wins for the IMU (measured)
+  const bool imu_fast = getenv("LVX_IMU_FAST") != nullptr;   // measured: with 8 samples per knot interval the per-segment kernels are slightly faster for the IMU
   if (ctx->imu.n > 0) {
     if (fast && imu_fast) {
       GyroAcc g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
       { ProfScope ps(ctx, LVX_FAM_GYRO, s_imu);
-        const size_t lds = acc_lds(GyroAcc::NK + GyroAcc::NG, GyroAcc::NG);
-        LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_acc<GyroAcc>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_family_acc<GyroAcc>, dim3(ctx->n_chunk[LVX_FAM_GYRO]), dim3(256), lds, s_imu, g, cm, (const int*)ctx->d_chunk[LVX_FAM_GYRO].p, (const uint16_t*)ctx->d_pairs[0].p, (long long)ctx->fam_row0[0]); }
+        const size_t lds = acc_lds(GyroAcc::NK + GyroAcc::NG, GyroAcc::NG, LVX_CHUNK_R_IMU);
+        LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_acc<GyroAcc, LVX_CHUNK_R_IMU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_family_acc<GyroAcc, LVX_CHUNK_R_IMU>), dim3(ctx->n_chunk[LVX_FAM_GYRO]), dim3(256), lds, s_imu, g, cm, (const int*)ctx->d_chunk[LVX_FAM_GYRO].p, (const uint16_t*)ctx->d_pairs[0].p, (long long)ctx->fam_row0[0]); }
       if (!(ctx->locks & LVX_LOCK_R3)) {
         AccelAcc a{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.huber /*w_acc*/, 0.0};
         ProfScope ps(ctx, LVX_FAM_ACCEL, s_acc);
-        const size_t lds = acc_lds(AccelAcc::NK + AccelAcc::NG, AccelAcc::NG);
-        LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_acc<AccelAcc>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_family_acc<AccelAcc>, dim3(ctx->n_chunk[LVX_FAM_GYRO]), dim3(256), lds, s_acc, a, cm, (const int*)ctx->d_chunk[LVX_FAM_GYRO].p, (const uint16_t*)ctx->d_pairs[1].p, (long long)ctx->fam_row0[1]);
+        const size_t lds = acc_lds(AccelAcc::NK + AccelAcc::NG, AccelAcc::NG, LVX_CHUNK_R_IMU);
+        LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_acc<AccelAcc, LVX_CHUNK_R_IMU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_family_acc<AccelAcc, LVX_CHUNK_R_IMU>), dim3(ctx->n_chunk[LVX_FAM_GYRO]), dim3(256), lds, s_acc, a, cm, (const int*)ctx->d_chunk[LVX_FAM_GYRO].p, (const uint16_t*)ctx->d_pairs[1].p, (long long)ctx->fam_row0[1]);
       }
     } else {
       GyroFam g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
@@ -938,9 +939,9 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     if (fast) {
       SurfAcc s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
                 (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
-      const size_t lds = acc_lds(SurfAcc::NK + SurfAcc::NG, SurfAcc::NG);
-      LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_acc<SurfAcc>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k_family_acc<SurfAcc>, dim3(ctx->n_chunk[LVX_FAM_SURFEL]), dim3(256), lds, s_surf, s, cm, (const int*)ctx->d_chunk[LVX_FAM_SURFEL].p, (const uint16_t*)ctx->d_pairs_acc[0].p, (long long)ctx->fam_row0[3]);
+      const size_t lds = acc_lds(SurfAcc::NK + SurfAcc::NG, SurfAcc::NG, LVX_CHUNK_R);
+      LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_acc<SurfAcc, LVX_CHUNK_R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((k_family_acc<SurfAcc, LVX_CHUNK_R>), dim3(ctx->n_chunk[LVX_FAM_SURFEL]), dim3(256), lds, s_surf, s, cm, (const int*)ctx->d_chunk[LVX_FAM_SURFEL].p, (const uint16_t*)ctx->d_pairs_acc[0].p, (long long)ctx->fam_row0[3]);
     } else {
       SurfFam s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
                 (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
@@ -958,9 +959,9 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     if (fast) {
       CamSurfAcc c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
                    (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
-      const size_t lds = acc_lds(CamSurfAcc::NK + CamSurfAcc::NG, CamSurfAcc::NG);
-      LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_acc<CamSurfAcc>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k_family_acc<CamSurfAcc>, dim3(ctx->n_chunk[LVX_FAM_CAMSURF]), dim3(256), lds, s_surf, c, cm, (const int*)ctx->d_chunk[LVX_FAM_CAMSURF].p, (const uint16_t*)ctx->d_pairs_acc[1].p, (long long)ctx->fam_row0[5]);
+      const size_t lds = acc_lds(CamSurfAcc::NK + CamSurfAcc::NG, CamSurfAcc::NG, LVX_CHUNK_R);
+      LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_acc<CamSurfAcc, LVX_CHUNK_R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((k_family_acc<CamSurfAcc, LVX_CHUNK_R>), dim3(ctx->n_chunk[LVX_FAM_CAMSURF]), dim3(256), lds, s_surf, c, cm, (const int*)ctx->d_chunk[LVX_FAM_CAMSURF].p, (const uint16_t*)ctx->d_pairs_acc[1].p, (long long)ctx->fam_row0[5]);
     } else {
       CamSurfFam c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
                    (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};

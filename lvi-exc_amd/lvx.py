@@ -333,6 +333,42 @@ def surfel_assoc(ctx, scan_hw4, p4, box_min, box_max, radius=0.05, sel=2):
     return flag.reshape(H, W)
 
 
+def upstream_bench(ctx, kind, arrays, reps=20):
+    """Time one upstream kernel with its inputs RESIDENT on the device (torch tensors; `_d` entry points).  Returns seconds per call."""
+    import torch
+    l = ctx._l
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if kind == "surfel_assoc":
+        scan, p4, bmin, bmax = arrays
+        H, W = scan.shape[0], scan.shape[1]
+        P = len(p4)
+        scan_d = torch.from_numpy(np.ascontiguousarray(scan, np.float32)).to(dev)
+        pl_d = torch.from_numpy(np.concatenate([_d(p4).ravel(), _d(bmin).ravel(), _d(bmax).ravel()])).to(dev)
+        flag_d = torch.empty(H * W, dtype=torch.int32, device=dev)
+        call = lambda: ctx._ck(l.lvx_surfel_assoc_d(ctx._h, C.c_int(H), C.c_int(W), C.c_void_p(scan_d.data_ptr()), C.c_int(P), C.c_void_p(pl_d.data_ptr()),
+                                                    C.c_double(0.05), C.c_int(2), C.c_void_p(flag_d.data_ptr())))
+    elif kind == "voxel_build":
+        cloud, leaf = arrays
+        n = len(cloud)
+        cloud_d = torch.from_numpy(np.ascontiguousarray(cloud, np.float32)).to(dev)
+        call = lambda: ctx._ck(l.lvx_voxel_build_d(ctx._h, C.c_int(n), C.c_void_p(cloud_d.data_ptr()), C.c_float(leaf), C.c_int(6), C.c_double(0.01)))
+    elif kind == "voxel_lookup7":
+        q = arrays
+        n = len(q)
+        q_d = torch.from_numpy(np.ascontiguousarray(q, np.float32)).to(dev)
+        ids_d = torch.empty(n * 7, dtype=torch.int32, device=dev)
+        call = lambda: ctx._ck(l.lvx_voxel_lookup7_d(ctx._h, C.c_int(n), C.c_void_p(q_d.data_ptr()), C.c_void_p(ids_d.data_ptr())))
+    else:
+        raise ValueError(kind)
+    import time
+    call(); ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        call()
+    ctx.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
 def load_problem(obj, P, locks=None):
     """Feed a synth.make_problem() dict into an lvx.Context or an oracle.Oracle (same setter names)."""
     obj.set_spline(P["t0"], P["dt"], P["n_knots"])
