@@ -27,6 +27,9 @@ sys.path.insert(0, os.path.join(ROOT, "lvi-exc_amd"))
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VALU_PEAK_TFLOPS = 78.6  # SURVEY.md §8d (vector FP64; the solve is VALU-bound, not HBM-bound)
 # algorithmic bytes per residual block, SURVEY.md §8(d)
+# HBM bytes per launch of k_family_acc<SurfAcc> at config 4 from the PMC counters (FETCH_SIZE 21.1 MB + WRITE_SIZE 47.2 MB per dispatch;
+# FETCH_SIZE is not doubled: these are 8-byte strided reads, not the 16 B/lane streams the guide's x2 correction was calibrated on)
+PMC_TRAFFIC_BYTES = 68.3e6
 BYTES_PER_EVAL = {"imu": 32, "surfel": 60, "reproj": 60}
 
 
@@ -201,7 +204,7 @@ def main():
         alg_bytes = BYTES_PER_EVAL["surfel"] * n_surf
         achieved = alg_bytes / (surf_ms * 1e-3) / 1e9 if surf_ms > 0 else 0.0
         out["roofline"] = {"bound": "hbm", "kernel": "k_family_acc<SurfAcc>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": None, "avg_launch_ms": surf_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                           "traffic": PMC_TRAFFIC_BYTES if scale == 1 else None, "traffic_source": "profiles/r01_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per dispatch)", "avg_launch_ms": surf_ms, "algorithmic_bytes_per_launch": alg_bytes,
                            "note": "fused residual+Jacobian+J^T J kernel: FP64-VALU / LDS / atomic bound, not HBM bound (SURVEY.md 8d: ~9 kFLOP per 60 B); duration measured while the gyro/accel/reprojection kernels run concurrently on sibling streams",
                            "fp64_valu": {"achieved_tflops": 9e3 * n_surf / (surf_ms * 1e-3) / 1e12 if surf_ms > 0 else 0.0, "peak_tflops": FP64_VALU_PEAK_TFLOPS}}
         out["kernel_ms"] = {lvx.KERNEL_NAMES[i]: ms[i] / max(1, launches[i]) for i in range(len(ms)) if launches[i]}
