@@ -245,6 +245,16 @@ int lvx_surfel_assoc(lvx_ctx* ctx, int H, int W, const float* scan_map_xyzi4, in
 /* device-resident variant: planes10_d = p4[P][4] | box_min[P][3] | box_max[P][3] */
 int lvx_surfel_assoc_d(lvx_ctx* ctx, int H, int W, const float* scan_d, int n_planes, const double* planes10_d, double radius, int sel_per_ring, int32_t* plane_of_point_d);
 
+/* scan de-skew ------------------------------------------------------------------------------------*/
+/* licalib PointXYZIT (src/lvi_exc/include/utils/pcl_utils.h:39-44), 32 bytes */
+typedef struct lvx_point_xyzit { float x, y, z, pad; float intensity; float pad2; double timestamp; } lvx_point_xyzit;
+/* TrajectoryManagerLVI::evaluateLidarPose for a batch of times (trajectory_manager_lvi.cpp:398-408): q_LtoG (x,y,z,w), p_LinG, valid = 0 outside the spline */
+int lvx_evaluate_lidar_pose(lvx_ctx* ctx, const double* state, int n, const double* t, double* q_xyzw4, double* p3, int32_t* valid);
+/* ScanUndistortion::undistort (src/lvi_exc/include/core/scan_undistortion.h:132-180): every point is moved with the spline pose at ITS timestamp into the
+ * target frame (q_G_to_target, p_target_in_G); out = float xyzi per point */
+int lvx_undistort_scan(lvx_ctx* ctx, const double* state, int n, const lvx_point_xyzit* raw, const double* q_G_to_target_xyzw, const double* p_target_in_G3,
+                       int correct_position, float* out_xyzi4);
+
 #ifdef __cplusplus
 }
 #endif

@@ -338,7 +338,7 @@ __global__ void k_hub_eval(DevCommon cm, double t_map, int want_surf, int want_c
 }
 
 struct GyroAcc {
-  enum { NK = 12, NG = 3, NR = 3, HUB = -1 };
+  enum { NK = 12, NG = 3, NR = 3, HUB = -1, KPK = 3, LVO = 3, WS = 1, GL = 8 };   // KPK columns per knot at offset LVO of its 6 tangent scalars; WS = knot intervals per MFMA window; GL = lanes per panel
   int n; const double* t; const double* m3; const int* perm; double weight, huber;
   __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared*, int si, double r[NR], double (*J)[NK + NG], int& key) const {
     return gyro_residual<true>(sp, cal.imu, t[si], load_v3(m3 + 3 * (size_t)si), weight, &key, r, J);
@@ -347,7 +347,7 @@ struct GyroAcc {
   __device__ static int gcol(int g, int N, int nt) { return 6 * N + 5 + g; }
 };
 struct AccelAcc {
-  enum { NK = 24, NG = 5, NR = 3, HUB = -1 };
+  enum { NK = 24, NG = 5, NR = 3, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 8 };
   int n; const double* t; const double* m3; const int* perm; double weight, huber;
   __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared*, int si, double r[NR], double (*J)[NK + NG], int& key) const {
     return accel_residual<true>(sp, cal.imu, t[si], load_v3(m3 + 3 * (size_t)si), weight, &key, r, J);
@@ -356,7 +356,7 @@ struct AccelAcc {
   __device__ static int gcol(int g, int N, int nt) { return 6 * N + g; }
 };
 struct SurfAcc {
-  enum { NK = 24, NG = 12, NR = 1, HUB = 0 };
+  enum { NK = 24, NG = 12, NR = 1, HUB = 0, KPK = 6, LVO = 0, WS = 2, GL = 16 };
   int n; const double* t; const double* pt; const int* plane; const int* perm; const double* planes; double t_map, weight, huber;
   __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared* hub, int si, double r[NR], double (*J)[NK + NG], int& key) const {
     const bool tl = (cm.locks & LVX_LOCK_LIDAR_TAU) != 0;
@@ -375,7 +375,7 @@ struct SurfAcc {
   __device__ static int gcol(int g, int N, int nt) { return g < 6 ? nt + g : 6 * N + 8 + (g - 6); }
 };
 struct CamSurfAcc {
-  enum { NK = 24, NG = 18, NR = 1, HUB = 1 };
+  enum { NK = 24, NG = 18, NR = 1, HUB = 1, KPK = 6, LVO = 0, WS = 1, GL = 16 };
   int n; const int* lm; const int* plane; const int* perm; const double* planes; const double* lm_uv; const double* lm_t0; double t_map, weight, huber;
   __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared* hub, int si, double r[NR], double (*J)[NK + NG], int& key) const {
     const bool tl = (cm.locks & LVX_LOCK_CAM_TAU) != 0;
@@ -504,6 +504,215 @@ __global__ __launch_bounds__(256) void k_family_acc(F fam, DevCommon cm, const i
           }
         }
       }
+    }
+  }
+  mycost = wave_sum(mycost);
+  if (lane == 0) atomicAdd(&cm.cost[rep], mycost);
+  if (!want_ne) return;
+  __syncthreads();
+  // flush the workgroup's accumulators: ONE global atomic per touched entry
+  for (int e = tid; e < ACC_LV * ACC_BW; e += 256) {
+    const double v = acc_band[e];
+    if (v == 0.0) continue;
+    const int la = e / ACC_BW, lb = la + e % ACC_BW;
+    if (lb >= ACC_LV) continue;
+    const int pa = kpos[la], pb = kpos[lb];
+    if (pa == LVX_DEAD || pb == LVX_DEAD) continue;
+    add_H(cm, pa, pb, v, rep);
+  }
+  for (int e = tid; e < NG * ACC_LV; e += 256) {
+    const double v = acc_bd[e];
+    if (v == 0.0) continue;
+    const int pg = gpos[e / ACC_LV], pk2 = kpos[e % ACC_LV];
+    if (pg == LVX_DEAD || pk2 == LVX_DEAD) continue;
+    add_H(cm, pg, pk2, v, rep);
+  }
+  for (int e = tid; e < NG * NG; e += 256) {
+    const int ga = e / NG, gb2 = e % NG;
+    if (gb2 < ga) continue;
+    const double v = acc_gg[e];
+    if (v == 0.0 || gpos[ga] == LVX_DEAD || gpos[gb2] == LVX_DEAD) continue;
+    add_H(cm, gpos[ga], gpos[gb2], v, rep);
+  }
+  for (int e = tid; e < ACC_LV; e += 256) { const double v = acc_gk[e]; if (v != 0.0 && kpos[e] != LVX_DEAD) add_g(cm, kpos[e], v, rep); }
+  if (tid < NG) { const double v = acc_gG[tid]; if (v != 0.0 && gpos[tid] != LVX_DEAD) add_g(cm, gpos[tid], v, rep); }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MFMA assembly path (the production fast path).  Same ownership as k_family_acc — a workgroup owns CR knot intervals and
+// accumulates into LDS — but J^T J is a tall-skinny FP64 matrix product on the matrix cores:
+//   * rows are sorted by knot interval, so a run of rows whose intervals fall into a WINDOW of WS consecutive intervals shares
+//     one local column space  [ (WS+3) knots x KPK | NG globals | residual ]  (<= 48 columns = 3 MFMA column tiles);
+//   * GL lanes at a time write their rows, shifted to their knot offset inside the window and zero elsewhere, into a per-wave
+//     LDS panel P[GL*NR][LDP]; every 4 panel rows are one k-step of v_mfma_f64_16x16x4_f64 for each upper-triangular tile pair
+//     (operand of tile c at lane l = P[4 ks + (l >> 4)][16 c + (l & 15)]; it is both the A fragment of J^T and the B fragment of J);
+//   * the residual rides along as one more column, so J^T r falls out of the same products;
+//   * at the end of a window the accumulator tiles (D: col = lane & 15, row = (lane >> 4) + 4 reg) are added to the workgroup's
+//     LDS accumulators, which are flushed to HBM once per workgroup.
+// ---------------------------------------------------------------------------------------------------------
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+template <class F> struct MfmaGeom {
+  static constexpr int NKL = (F::WS + 3) * F::KPK;           // knot columns of a window
+  static constexpr int NCL = NKL + F::NG + 1;                // + globals + residual
+  static constexpr int NT = (NCL + 15) / 16;                 // 16-column tiles
+  static constexpr int LDP = NT * 16 + 1;                    // odd row stride: conflict-free row writes and fragment reads
+  static constexpr int PR = F::GL * F::NR;                   // panel rows
+  static_assert(PR % 4 == 0, "panel rows must be a multiple of the MFMA k-step");
+  static constexpr int NTP = NT * (NT + 1) / 2;
+};
+template <class F, int CR> constexpr size_t mfma_lds_bytes() {
+  constexpr int LV = (CR + 5) * 6;
+  return (size_t)(LV * ACC_BW + F::NG * LV + F::NG * F::NG + LV + F::NG + 4 * MfmaGeom<F>::PR * MfmaGeom<F>::LDP) * 8 + (size_t)(LV + F::NG) * 4 + 64;
+}
+
+template <class F, int CR, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, const int* __restrict__ chunk_off, long long row0) {
+  using G = MfmaGeom<F>;
+  constexpr int NK = F::NK, NG = F::NG, NC = NK + NG, NR = F::NR, KPK = F::KPK, WS = F::WS, GL = F::GL;
+  constexpr int NKL = G::NKL, NT = G::NT, LDP = G::LDP, PR = G::PR;
+  constexpr int ACC_LV = (CR + 5) * 6;
+  extern __shared__ double sm[];
+  double* acc_band = sm;                              // [ACC_LV][ACC_BW]
+  double* acc_bd = acc_band + ACC_LV * ACC_BW;        // [NG][ACC_LV]
+  double* acc_gg = acc_bd + NG * ACC_LV;              // [NG][NG]
+  double* acc_gk = acc_gg + NG * NG;                  // [ACC_LV]
+  double* acc_gG = acc_gk + ACC_LV;                   // [NG]
+  double* panels = acc_gG + NG;                       // 4 x [PR][LDP]
+  int* kpos = (int*)(panels + 4 * PR * LDP);          // [ACC_LV]
+  int* gpos = kpos + ACC_LV;                          // [NG]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int ch = blockIdx.x;
+  const int m0 = chunk_off[ch], m1 = chunk_off[ch + 1];
+  if (m0 >= m1) return;
+  const int k_lo = ch * CR - 1;
+  const int nt = 6 * cm.N + 22 + cm.L;
+  const bool want_ne = (cm.what & LVX_EVAL_NORMAL_EQ) != 0;
+  for (int e = tid; e < ACC_LV * ACC_BW + NG * ACC_LV + NG * NG + ACC_LV + NG + 4 * PR * LDP; e += 256) sm[e] = 0.0;
+  for (int e = tid; e < ACC_LV; e += 256) { const int k = k_lo + e / 6; kpos[e] = (k >= 0 && k < cm.N) ? cm.ord[6 * k + e % 6] : LVX_DEAD; }
+  if (tid < NG) gpos[tid] = cm.ord[F::gcol(tid, cm.N, nt)];
+  const SplineRef sp{cm.t0, cm.dt, cm.N, cm.state, cm.state + 3 * (size_t)cm.N};
+  const Cal cal = load_cal(cm);
+  const HubShared* hub = F::HUB >= 0 ? ((const HubShared*)cm.hubs) + F::HUB : nullptr;
+  double* P = panels + wv * (PR * LDP);
+  const int rep = blockIdx.x % LVX_NREP;
+  // class of a window-local column: >= 0 knot scalar (offset inside the window, in units of tangent scalars), -1-g global g, -100 residual, -200 padding
+  auto cls = [](int lc) { return lc < NKL ? 6 * (lc / KPK) + F::LVO + lc % KPK : (lc < NKL + NG ? -1 - (lc - NKL) : (lc == NKL + NG ? -100 : -200)); };
+  int colcls[NT], rowcls[NT][4];
+#pragma unroll
+  for (int c = 0; c < NT; ++c) {
+    colcls[c] = cls(c * 16 + (lane & 15));
+#pragma unroll
+    for (int v = 0; v < 4; ++v) rowcls[c][v] = cls(c * 16 + (lane >> 4) + 4 * v);
+  }
+  const int frag_off = (lane >> 4) * LDP + (lane & 15);
+  double mycost = 0.0;
+  __syncthreads();
+  for (int base = m0 + wv * 64; base < m1; base += 256) {
+    const int si = base + lane;
+    const bool in = si < m1;
+    double r[NR];
+    double J[NR][NC];
+    int key = -1;
+    bool valid = false;
+    if (in) {
+      const int status = fam.eval(cm, sp, cal, hub, si, r, J, key);
+      valid = status == RES_OK;
+      if (valid && (key < k_lo || key - k_lo > CR + 1)) { valid = false; atomicOr(cm.err, LVX_ERR_FALLBACK); }
+      else if (!valid) atomicOr(cm.err, status);
+    }
+    if (valid) {
+      double s = 0.0;
+#pragma unroll
+      for (int a = 0; a < NR; ++a) s += r[a] * r[a];
+      double scale;
+      mycost += 0.5 * huber_rho(fam.huber, s, &scale);
+      if (cm.residuals) {
+        const long long orow = row0 + (long long)fam.perm[si] * NR;
+#pragma unroll
+        for (int a = 0; a < NR; ++a) cm.residuals[orow + a] = r[a];
+      }
+      if (scale != 1.0) {
+#pragma unroll
+        for (int a = 0; a < NR; ++a) {
+          r[a] *= scale;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) J[a][c] *= scale;
+        }
+      }
+    }
+    if (!want_ne) continue;
+    unsigned long long rem = __ballot(valid);
+    while (rem) {                                            // one window per iteration (wave-uniform control flow)
+      const int l0 = __ffsll((long long)rem) - 1;
+      const int kw = __builtin_amdgcn_readfirstlane(__shfl(key, l0));
+      const bool inw = valid && key >= kw && key < kw + WS;
+      const unsigned long long wm = __ballot(inw);
+      rem &= ~wm;
+      const int lhi = 63 - __clzll((long long)wm);
+      const int sh = inw ? (key - kw) * KPK : 0;
+      d4 D[G::NTP];
+#pragma unroll
+      for (int t = 0; t < G::NTP; ++t) D[t] = d4{0.0, 0.0, 0.0, 0.0};
+      for (int g0 = l0; g0 <= lhi; g0 += GL) {
+        const int gs = min(g0, 64 - GL);                     // the panel always maps GL existing lanes, so every panel row is rewritten
+        if (lane >= gs && lane < gs + GL) {
+          const int li = lane - gs;
+          const bool mrow = inw && lane >= g0;               // lanes before g0 belong to the previous panel of this window
+#pragma unroll
+          for (int a = 0; a < NR; ++a) {
+            double* prow = P + (li * NR + a) * LDP;
+#pragma unroll
+            for (int c = 0; c < NK; ++c) prow[sh + c] = mrow ? J[a][c] : 0.0;
+#pragma unroll
+            for (int z = 0; z < (WS - 1) * KPK; ++z) prow[z < sh ? z : z + NK] = 0.0;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) prow[NKL + g] = mrow ? J[a][NK + g] : 0.0;
+            prow[NKL + NG] = mrow ? r[a] : 0.0;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int cnt = min(GL, lhi + 1 - gs);
+        const int nks = (cnt * NR + 3) >> 2;
+        for (int ks = 0; ks < nks; ++ks) {
+          double f[NT];
+#pragma unroll
+          for (int c = 0; c < NT; ++c) f[c] = P[ks * 4 * LDP + frag_off + c * 16];
+          int t = 0;
+#pragma unroll
+          for (int ci = 0; ci < NT; ++ci)
+#pragma unroll
+            for (int cj = ci; cj < NT; ++cj, ++t) D[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[ci], f[cj], D[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      // window accumulators -> workgroup accumulators (LDS atomics; other waves work on overlapping windows)
+      const int wb = (kw - k_lo) * 6;
+      int t = 0;
+#pragma unroll
+      for (int ci = 0; ci < NT; ++ci)
+#pragma unroll
+        for (int cj = ci; cj < NT; ++cj, ++t)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const double val = D[t][v];
+            if (val == 0.0) continue;
+            if (ci == cj && (lane & 15) < (lane >> 4) + 4 * v) continue;   // lower triangle of a diagonal tile
+            const int ra = rowcls[ci][v], cb = colcls[cj];
+            if (ra >= 0) {
+              const int la = wb + ra;
+              if (la >= ACC_LV) continue;
+              if (cb >= 0) { const int d = cb - ra; if (d < ACC_BW && wb + cb < ACC_LV) atomicAdd(&acc_band[la * ACC_BW + d], val); }
+              else if (cb > -100) atomicAdd(&acc_bd[(-1 - cb) * ACC_LV + la], val);
+              else if (cb == -100) atomicAdd(&acc_gk[la], val);
+            } else if (ra > -100) {
+              if (cb > -100) atomicAdd(&acc_gg[(-1 - ra) * NG + (-1 - cb)], val);
+              else if (cb == -100) atomicAdd(&acc_gG[-1 - ra], val);
+            }
+          }
     }
   }
   mycost = wave_sum(mycost);
@@ -900,20 +1109,35 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
   LVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
   for (int k = 0; k < 4; ++k) LVX_HIP(ctx, hipStreamWaitEvent(ctx->fam_stream[k], ctx->ev_fork, 0));
   hipStream_t s_imu = ctx->fam_stream[0], s_acc = ctx->fam_stream[1], s_surf = ctx->fam_stream[2], s_rep = ctx->fam_stream[3];
-  const bool imu_fast = getenv("LVX_IMU_FAST") != nullptr;   // measured: with 8 samples per knot interval the per-segment kernels are slightly faster for the IMU
+  if (getenv("LVX_SERIAL")) s_imu = s_acc = s_surf = s_rep = st;   // profiling aid: solo kernel durations
+  const bool mfma = !getenv("LVX_NO_MFMA");
+  static const int occ = getenv("LVX_OCC") ? atoi(getenv("LVX_OCC")) : 1;
+#define LVX_LAUNCH_MFMA1(FT, CRV, OCCV, fam_obj, famid, stream, row0v)                                                                        \
+  do {                                                                                                                                     \
+    const size_t lds_ = mfma_lds_bytes<FT, CRV>();                                                                                         \
+    LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_mfma<FT, CRV, OCCV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));  \
+    hipLaunchKernelGGL((k_family_mfma<FT, CRV, OCCV>), dim3(ctx->n_chunk[famid]), dim3(256), lds_, stream, fam_obj, cm, (const int*)ctx->d_chunk[famid].p, (long long)(row0v)); \
+  } while (0)
+#define LVX_LAUNCH_MFMA(FT, CRV, fam_obj, famid, stream, row0v)                                                                              \
+  do { if (occ == 1) LVX_LAUNCH_MFMA1(FT, CRV, 1, fam_obj, famid, stream, row0v); else LVX_LAUNCH_MFMA1(FT, CRV, 2, fam_obj, famid, stream, row0v); } while (0)
+  const bool imu_fast = !getenv("LVX_IMU_LEGACY");
   if (ctx->imu.n > 0) {
     if (fast && imu_fast) {
       GyroAcc g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
-      { ProfScope ps(ctx, LVX_FAM_GYRO, s_imu);
+      if (mfma) { ProfScope ps(ctx, LVX_FAM_GYRO, s_imu); LVX_LAUNCH_MFMA(GyroAcc, LVX_CHUNK_R_IMU, g, LVX_FAM_GYRO, s_imu, ctx->fam_row0[0]); }
+      else { ProfScope ps(ctx, LVX_FAM_GYRO, s_imu);
         const size_t lds = acc_lds(GyroAcc::NK + GyroAcc::NG, GyroAcc::NG, LVX_CHUNK_R_IMU);
         LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_acc<GyroAcc, LVX_CHUNK_R_IMU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((k_family_acc<GyroAcc, LVX_CHUNK_R_IMU>), dim3(ctx->n_chunk[LVX_FAM_GYRO]), dim3(256), lds, s_imu, g, cm, (const int*)ctx->d_chunk[LVX_FAM_GYRO].p, (const uint16_t*)ctx->d_pairs[0].p, (long long)ctx->fam_row0[0]); }
       if (!(ctx->locks & LVX_LOCK_R3)) {
         AccelAcc a{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.huber /*w_acc*/, 0.0};
         ProfScope ps(ctx, LVX_FAM_ACCEL, s_acc);
+        if (mfma) LVX_LAUNCH_MFMA(AccelAcc, LVX_CHUNK_R_IMU, a, LVX_FAM_GYRO, s_acc, ctx->fam_row0[1]);
+        else {
         const size_t lds = acc_lds(AccelAcc::NK + AccelAcc::NG, AccelAcc::NG, LVX_CHUNK_R_IMU);
         LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_acc<AccelAcc, LVX_CHUNK_R_IMU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((k_family_acc<AccelAcc, LVX_CHUNK_R_IMU>), dim3(ctx->n_chunk[LVX_FAM_GYRO]), dim3(256), lds, s_acc, a, cm, (const int*)ctx->d_chunk[LVX_FAM_GYRO].p, (const uint16_t*)ctx->d_pairs[1].p, (long long)ctx->fam_row0[1]);
+        }
       }
     } else {
       GyroFam g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
@@ -939,9 +1163,12 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     if (fast) {
       SurfAcc s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
                 (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
+      if (mfma) LVX_LAUNCH_MFMA(SurfAcc, LVX_CHUNK_R, s, LVX_FAM_SURFEL, s_surf, ctx->fam_row0[3]);
+      else {
       const size_t lds = acc_lds(SurfAcc::NK + SurfAcc::NG, SurfAcc::NG, LVX_CHUNK_R);
       LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_acc<SurfAcc, LVX_CHUNK_R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((k_family_acc<SurfAcc, LVX_CHUNK_R>), dim3(ctx->n_chunk[LVX_FAM_SURFEL]), dim3(256), lds, s_surf, s, cm, (const int*)ctx->d_chunk[LVX_FAM_SURFEL].p, (const uint16_t*)ctx->d_pairs_acc[0].p, (long long)ctx->fam_row0[3]);
+      }
     } else {
       SurfFam s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
                 (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
@@ -959,9 +1186,12 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     if (fast) {
       CamSurfAcc c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
                    (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
+      if (mfma) LVX_LAUNCH_MFMA(CamSurfAcc, LVX_CHUNK_R, c, LVX_FAM_CAMSURF, s_surf, ctx->fam_row0[5]);
+      else {
       const size_t lds = acc_lds(CamSurfAcc::NK + CamSurfAcc::NG, CamSurfAcc::NG, LVX_CHUNK_R);
       LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_acc<CamSurfAcc, LVX_CHUNK_R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((k_family_acc<CamSurfAcc, LVX_CHUNK_R>), dim3(ctx->n_chunk[LVX_FAM_CAMSURF]), dim3(256), lds, s_surf, c, cm, (const int*)ctx->d_chunk[LVX_FAM_CAMSURF].p, (const uint16_t*)ctx->d_pairs_acc[1].p, (long long)ctx->fam_row0[5]);
+      }
     } else {
       CamSurfFam c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
                    (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};

@@ -334,6 +334,52 @@ __global__ __launch_bounds__(SA_PLANES) void k_surfel_assoc(const float4* scan, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// batched lidar pose evaluation + scan de-skew: HBM-streaming reuse of the spline evaluator (no Jacobians)
+// ------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool lidar_pose_dev(const double* state, int N, double t0, double dt, double t, quat* q_LtoG, v3* p_LinG) {
+  const double* sl = state + 7 * (size_t)N + 16;
+  const double tt = t + sl[7];
+  const double tmax = t0 + (double)(N - 3) * dt;
+  if (t0 > tt || tmax <= tt) return false;                         // evaluateLidarPose range test (trajectory_manager_lvi.cpp:401-402)
+  const double s = (tt - t0) / dt;
+  const int i0 = (int)floor(s);
+  if (N < 4 || i0 < 0 || i0 > N - 4) return false;
+  const SplineRef sp{t0, dt, N, state, state + 3 * (size_t)N};
+  KnotRef k; k.i0 = i0; k.u = s - (double)i0;
+  PoseEval e;
+  if (!pose_eval<false>(sp, k, &e)) return false;
+  const quat qL = load_q(sl); const v3 pL = load_v3(sl + 4);
+  *q_LtoG = qmul(e.so3.q, qL);
+  *p_LinG = qrot(e.so3.q, pL) + e.p;
+  return true;
+}
+__global__ void k_lidar_pose(const double* state, int N, double t0, double dt, int n, const double* t, double* q4, double* p3, int* valid) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  quat q; v3 p;
+  const bool ok = lidar_pose_dev(state, N, t0, dt, t[i], &q, &p);
+  valid[i] = ok ? 1 : 0;
+  if (ok) { q4[4 * (size_t)i] = q.x; q4[4 * (size_t)i + 1] = q.y; q4[4 * (size_t)i + 2] = q.z; q4[4 * (size_t)i + 3] = q.w; p3[3 * (size_t)i] = p.x; p3[3 * (size_t)i + 1] = p.y; p3[3 * (size_t)i + 2] = p.z; }
+}
+struct PointXYZIT { float x, y, z, pad; float intensity; float pad2; double timestamp; };
+static_assert(sizeof(PointXYZIT) == 32, "PointXYZIT layout (pcl_utils.h:39-44)");
+__global__ void k_undistort(const double* state, int N, double t0, double dt, int n, const PointXYZIT* raw, quat qGt, v3 pT, int correct_position, float4* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const PointXYZIT r = raw[i];
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (isnan(r.x)) { o.x = o.y = o.z = NAN; out[i] = o; return; }
+  quat q; v3 p;
+  if (lidar_pose_dev(state, N, t0, dt, r.timestamp, &q, &p)) {
+    const quat qk0 = qmul(qGt, q);
+    v3 po = qrot(qk0, mk((double)r.x, (double)r.y, (double)r.z));
+    if (correct_position) po = po + qrot(qGt, p - pT);
+    o = make_float4((float)po.x, (float)po.y, (float)po.z, r.intensity);
+  }
+  out[i] = o;
+}
+
 }  // namespace lvx
 
 using namespace lvx;
@@ -570,6 +616,43 @@ int lvx_surfel_assoc_d(lvx_ctx* c, int H, int W, const float* scan_d, int n_plan
   LVX_HIP(c, hipSetDevice(c->device));
   ProfScope ps(c, LVX_KERNEL_UPSTREAM);
   return assoc_device(c, (const float4*)scan_d, H, W, n_planes, planes10_d, radius, sel_per_ring, plane_of_point_d);
+}
+
+int lvx_evaluate_lidar_pose(lvx_ctx* c, const double* state, int n, const double* t, double* q4, double* p3, int32_t* valid) {
+  if (!c || !state || n < 0 || (n > 0 && (!t || !q4 || !p3 || !valid))) return LVX_E_ARG;
+  if (!c->have_spline) return fail(c, LVX_E_STATE, "lvx_set_spline has not been called");
+  if (n == 0) return LVX_OK;
+  LVX_HIP(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = upload(c, c->d_up[7], state, (size_t)lvx_state_size(c) * 8))) return rc;
+  if ((rc = upload(c, c->d_up[2], t, (size_t)n * 8))) return rc;
+  if ((rc = dev_alloc(c, c->d_up[3], (size_t)n * (32 + 24 + 4)))) return rc;
+  double* dq = (double*)c->d_up[3].p; double* dp = dq + 4 * (size_t)n; int* dv = (int*)(dp + 3 * (size_t)n);
+  { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
+    hipLaunchKernelGGL(k_lidar_pose, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const double*)c->d_up[7].p, c->N, c->t0, c->dt, n, (const double*)c->d_up[2].p, dq, dp, dv); }
+  LVX_HIP(c, hipGetLastError());
+  LVX_HIP(c, hipMemcpyAsync(q4, dq, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipMemcpyAsync(p3, dp, (size_t)n * 24, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipMemcpyAsync(valid, dv, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  return LVX_OK;
+}
+int lvx_undistort_scan(lvx_ctx* c, const double* state, int n, const lvx_point_xyzit* raw, const double* qGt, const double* pT, int correct_position, float* out) {
+  if (!c || !state || n < 0 || !qGt || !pT || (n > 0 && (!raw || !out))) return LVX_E_ARG;
+  if (!c->have_spline) return fail(c, LVX_E_STATE, "lvx_set_spline has not been called");
+  if (n == 0) return LVX_OK;
+  LVX_HIP(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = upload(c, c->d_up[7], state, (size_t)lvx_state_size(c) * 8))) return rc;
+  if ((rc = upload(c, c->d_up[2], raw, (size_t)n * 32))) return rc;
+  if ((rc = dev_alloc(c, c->d_up[3], (size_t)n * 16))) return rc;
+  { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
+    hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const double*)c->d_up[7].p, c->N, c->t0, c->dt, n, (const PointXYZIT*)c->d_up[2].p,
+                       load_q(qGt), load_v3(pT), correct_position, (float4*)c->d_up[3].p); }
+  LVX_HIP(c, hipGetLastError());
+  LVX_HIP(c, hipMemcpyAsync(out, c->d_up[3].p, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  return LVX_OK;
 }
 
 }  // extern "C"

@@ -369,6 +369,24 @@ def upstream_bench(ctx, kind, arrays, reps=20):
     return (time.perf_counter() - t0) / reps
 
 
+POINT_XYZIT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad", "<f4"), ("intensity", "<f4"), ("pad2", "<f4"), ("timestamp", "<f8")])
+
+
+def eval_lidar_pose(ctx, state, t):
+    state, t = _d(state), _d(np.atleast_1d(t))
+    n = len(t)
+    q, p, ok = np.zeros((n, 4)), np.zeros((n, 3)), np.zeros(n, np.int32)
+    ctx._ck(ctx._l.lvx_evaluate_lidar_pose(ctx._h, _p(state), C.c_int(n), _p(t), _p(q), _p(p), _p(ok)))
+    return q, p, ok.astype(bool)
+
+
+def undistort(ctx, state, raw, q_G_to_target, p_target_in_G, correct_position=True):
+    raw = np.ascontiguousarray(raw, dtype=POINT_XYZIT)
+    out = np.zeros((len(raw), 4), np.float32)
+    ctx._ck(ctx._l.lvx_undistort_scan(ctx._h, _p(_d(state)), C.c_int(len(raw)), _p(raw), _p(_d(q_G_to_target)), _p(_d(p_target_in_G)), C.c_int(1 if correct_position else 0), _p(out)))
+    return out
+
+
 def load_problem(obj, P, locks=None):
     """Feed a synth.make_problem() dict into an lvx.Context or an oracle.Oracle (same setter names)."""
     obj.set_spline(P["t0"], P["dt"], P["n_knots"])

@@ -495,4 +495,61 @@ int orc_eval_pose(const orc_problem* p, const double* state, int n, const double
   return 0;
 }
 
+// TrajectoryManagerLVI::evaluateLidarPose (L/src/core/trajectory_manager_lvi.cpp:398-408): q_LtoG = q(t) q_LtoI, p_LinG = q(t) p_LinI + p(t);
+// valid iff MinTime <= t + tau_L < MaxTime.  Concrete (single-segment) trajectory: SplineView::Evaluate over the whole spline.
+static bool lidar_pose(const orc_problem* p, const double* state, double t, Quat<double>& q_LtoG, V3<double>& p_LinG) {
+  const int N = p->n_knots;
+  const double* sl = state + 7 * N + 16;
+  const double tt = t + sl[7];
+  const double tmin = p->t0, tmax = p->t0 + (N - 3) * p->dt;
+  if (tmin > tt || tmax <= tt) return false;
+  SplitMeta meta;
+  meta.r3.segments.push_back(SegMeta{p->t0, p->dt, N});
+  meta.so3.segments.push_back(SegMeta{p->t0, p->dt, N});
+  std::vector<const double*> pd(2 * N);
+  for (int k = 0; k < N; ++k) { pd[k] = state + 3 * k; pd[N + k] = state + 3 * N + 4 * k; }
+  TrajView<double> traj{&meta, pd.data(), false};
+  Eval<double> e;
+  traj.Evaluate(tt, EvalOrientation | EvalPosition, e);
+  const Quat<double> q_LtoI = Quat<double>::from_coeffs(sl);
+  const V3<double> p_LinI(sl[4], sl[5], sl[6]);
+  q_LtoG = e.orientation * q_LtoI;
+  p_LinG = e.orientation * p_LinI + e.position;
+  return true;
+}
+int orc_eval_lidar_pose(const orc_problem* p, const double* state, int n, const double* t, double* q_xyzw, double* pos, int32_t* valid) {
+  try {
+    for (int i = 0; i < n; ++i) {
+      Quat<double> q; V3<double> pp;
+      const bool ok = lidar_pose(p, state, t[i], q, pp);
+      valid[i] = ok ? 1 : 0;
+      if (ok) { q_xyzw[4 * i] = q.x; q_xyzw[4 * i + 1] = q.y; q_xyzw[4 * i + 2] = q.z; q_xyzw[4 * i + 3] = q.w; pos[3 * i] = pp.x; pos[3 * i + 1] = pp.y; pos[3 * i + 2] = pp.z; }
+    }
+  } catch (const orc::nonunit_quat_error&) { return -2; } catch (const orc::range_error&) { return -1; }
+  return 0;
+}
+// ScanUndistortion::undistort (L/include/core/scan_undistortion.h:132-180).  raw: PointXYZIT {float x,y,z,pad; float intensity; (pad); double timestamp} (32 B);
+// out: float xyzi per point (NaN point for NaN input; zeros where the pose is unavailable, like the default-constructed VPoint)
+int orc_undistort(const orc_problem* p, const double* state, int n, const void* raw_v, const double* q_G_to_target_xyzw, const double* p_target_in_G, int correct_position, float* out) {
+  struct PT { float x, y, z, pad; float intensity; float pad2; double timestamp; };
+  const PT* raw = static_cast<const PT*>(raw_v);
+  const Quat<double> qGt = Quat<double>::from_coeffs(q_G_to_target_xyzw);
+  const V3<double> pT(p_target_in_G[0], p_target_in_G[1], p_target_in_G[2]);
+  try {
+    for (int i = 0; i < n; ++i) {
+      float* o = out + 4 * i;
+      o[0] = o[1] = o[2] = o[3] = 0.f;
+      if (std::isnan(raw[i].x)) { o[0] = o[1] = o[2] = NAN; continue; }
+      Quat<double> q_LktoG; V3<double> p_LkinG;
+      if (!lidar_pose(p, state, raw[i].timestamp, q_LktoG, p_LkinG)) continue;
+      const Quat<double> q_LktoL0 = qGt * q_LktoG;
+      const V3<double> p_Lk(raw[i].x, raw[i].y, raw[i].z);
+      V3<double> po = q_LktoL0 * p_Lk;
+      if (correct_position) po = po + qGt * (p_LkinG - pT);
+      o[0] = static_cast<float>(po.x); o[1] = static_cast<float>(po.y); o[2] = static_cast<float>(po.z); o[3] = raw[i].intensity;
+    }
+  } catch (const orc::nonunit_quat_error&) { return -2; } catch (const orc::range_error&) { return -1; }
+  return 0;
+}
+
 }  // extern "C"

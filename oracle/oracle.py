@@ -171,6 +171,25 @@ class Oracle:
         return {"pos": pos, "quat": quat, "vel": vel, "acc": acc, "angvel": w}
 
 
+POINT_XYZIT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad", "<f4"), ("intensity", "<f4"), ("pad2", "<f4"), ("timestamp", "<f8")])   # pcl_utils.h:39-44
+
+
+def eval_lidar_pose(o, state, t):
+    state, t = _d(state), _d(np.atleast_1d(t))
+    n = len(t)
+    q, p, ok = np.zeros((n, 4)), np.zeros((n, 3)), np.zeros(n, np.int32)
+    lib().orc_eval_lidar_pose(o._h, _p(state), C.c_int(n), _p(t), _p(q), _p(p), _p(ok))
+    return q, p, ok.astype(bool)
+
+
+def undistort(o, state, raw, q_G_to_target, p_target_in_G, correct_position=True):
+    raw = np.ascontiguousarray(raw, dtype=POINT_XYZIT)
+    out = np.zeros((len(raw), 4), np.float32)
+    rc = lib().orc_undistort(o._h, _p(_d(state)), C.c_int(len(raw)), _p(raw), _p(_d(q_G_to_target)), _p(_d(p_target_in_G)), C.c_int(1 if correct_position else 0), _p(out))
+    assert rc == 0
+    return out
+
+
 def dense_jacobian(jac_cols, jac_vals, n_tangent):
     """Scatter the fixed-width (cols, vals) rows into a dense (rows, n_tangent) matrix."""
     nr = jac_cols.shape[0]

@@ -129,3 +129,34 @@ def test_surfel_assoc_overlapping_planes_serial_rule(ctx):
     fg = lvx.surfel_assoc(ctx, scan, p4, bmin, bmax, 0.05, 2)
     assert np.array_equal(fg, fo)
     assert (fo[fo >= 0] >= 50).all()
+
+
+def test_lidar_pose_and_undistort(ctx):
+    """Scan de-skew: per-point spline pose (FP64) then float output, vs the oracle; includes NaN points and timestamps outside the spline."""
+    P = synth.make_problem(seed=41, duration=1.5, n_surfel=0, n_planes=1, n_landmarks=0)
+    o = O.Oracle(); lvx.load_problem(o, P, lvx.LOCK_LIDAR_TAU | lvx.LOCK_CAM_TAU)
+    c2 = lvx.Context(0); lvx.load_problem(c2, P, lvx.LOCK_LIDAR_TAU | lvx.LOCK_CAM_TAU)
+    s = P["state_true"]
+    rng = np.random.default_rng(3)
+    t = np.concatenate([rng.uniform(P["t_start"], P["t_end"], 500), [P["t0"] - 1.0, P["t0"] + (P["n_knots"] - 3) * P["dt"], P["t0"]]])
+    qo, po, oko = O.eval_lidar_pose(o, s, t)
+    qg, pg, okg = lvx.eval_lidar_pose(c2, s, t)
+    assert np.array_equal(oko, okg) and oko[:500].all() and not oko[500] and not oko[501] and oko[502]
+    assert np.abs(qo[oko] - qg[okg]).max() < 1e-13 and np.abs(po[oko] - pg[okg]).max() < 1e-12
+    n = 5000
+    raw = np.zeros(n, dtype=lvx.POINT_XYZIT)
+    raw["x"], raw["y"], raw["z"] = (rng.uniform(-20, 20, (3, n))).astype(np.float32)
+    raw["intensity"] = rng.uniform(0, 255, n).astype(np.float32)
+    raw["timestamp"] = rng.uniform(P["t_start"], P["t_end"], n)
+    raw["x"][::97] = np.nan
+    raw["timestamp"][5::131] = P["t0"] - 3.0
+    q0, p0, _ = O.eval_lidar_pose(o, s, [P["t_map"]])
+    qGt = synth.qconj(q0[0])
+    for cp in (True, False):
+        uo = O.undistort(o, s, raw, qGt, p0[0], cp)
+        ug = lvx.undistort(c2, s, raw, qGt, p0[0], cp)
+        assert np.array_equal(np.isnan(uo), np.isnan(ug))
+        m = ~np.isnan(uo)
+        assert np.abs(uo[m] - ug[m]).max() <= 4e-6      # float32 outputs of FP64 poses: at most an ulp or two at |x| ~ 30 m
+        assert np.array_equal(uo[:, 3], ug[:, 3])
+    c2.close()
