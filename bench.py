@@ -25,12 +25,15 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "lvi-exc_amd"))
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-FP64_VALU_PEAK_TFLOPS = 78.6  # SURVEY.md §8d (vector FP64; the solve is VALU-bound, not HBM-bound)
+FP64_PEAK_TFLOPS = 78.6      # MI355X FP64: vector 78.6 TFLOP/s = matrix (v_mfma_f64_16x16x4_f64) 78.6 TFLOP/s
 # algorithmic bytes per residual block, SURVEY.md §8(d)
-# HBM bytes per launch of k_family_acc<SurfAcc> at config 4 from the PMC counters (FETCH_SIZE 21.1 MB + WRITE_SIZE 47.2 MB per dispatch;
-# FETCH_SIZE is not doubled: these are 8-byte strided reads, not the 16 B/lane streams the guide's x2 correction was calibrated on)
-PMC_TRAFFIC_BYTES = 68.3e6
+# HBM bytes per launch of k_family_mfma<SurfAcc> at config 4 from the PMC counters (FETCH_SIZE 21.1 MB + WRITE_SIZE 54.8 MB per dispatch with
+# normal equations; KiB -> bytes; FETCH_SIZE is not doubled: these are 8-byte strided reads, not the 16 B/lane streams the guide's x2
+# correction was calibrated on)
+PMC_TRAFFIC_BYTES = 75.8e6
+PMC_SOURCE = "profiles/r01b_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per dispatch)"
 BYTES_PER_EVAL = {"imu": 32, "surfel": 60, "reproj": 60}
+FLOPS_PER_EVAL = {"imu": 4e3, "surfel": 9e3, "reproj": 11e3}
 
 
 def secondary_metrics(ctx, P, lo):
@@ -202,12 +205,26 @@ def main():
         k = lvx.FAM_SURFEL
         surf_ms = ms[k] / max(1, launches[k])
         alg_bytes = BYTES_PER_EVAL["surfel"] * n_surf
-        achieved = alg_bytes / (surf_ms * 1e-3) / 1e9 if surf_ms > 0 else 0.0
-        out["roofline"] = {"bound": "hbm", "kernel": "k_family_acc<SurfAcc>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": PMC_TRAFFIC_BYTES if scale == 1 else None, "traffic_source": "profiles/r01_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per dispatch)", "avg_launch_ms": surf_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                           "note": "fused residual+Jacobian+J^T J kernel: FP64-VALU / LDS / atomic bound, not HBM bound (SURVEY.md 8d: ~9 kFLOP per 60 B); duration measured while the gyro/accel/reprojection kernels run concurrently on sibling streams",
-                           "fp64_valu": {"achieved_tflops": 9e3 * n_surf / (surf_ms * 1e-3) / 1e12 if surf_ms > 0 else 0.0, "peak_tflops": FP64_VALU_PEAK_TFLOPS}}
+        alg_flops = FLOPS_PER_EVAL["surfel"] * n_surf
+        achieved = alg_flops / (surf_ms * 1e-3) / 1e12 if surf_ms > 0 else 0.0
+        out["roofline"] = {"bound": "mfma", "kernel": "k_family_mfma<SurfAcc>", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
+                           "traffic": PMC_TRAFFIC_BYTES if scale == 1 else None, "traffic_source": PMC_SOURCE, "avg_launch_ms": surf_ms,
+                           "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
+                           "hbm": {"achieved_GBps": alg_bytes / (surf_ms * 1e-3) / 1e9 if surf_ms > 0 else 0.0, "peak_GBps": HBM_PEAK_GBS},
+                           "note": "fused residual + analytic Jacobian + FP64-MFMA J^T J kernel of the LiDAR surfel family (1 M of the 1.45 M blocks); FP64 matrix = FP64 vector peak = 78.6 TFLOP/s on MI355X; "
+                                   "9 kFLOP / 60 B per block (SURVEY.md 8d) => compute bound, the HBM figure is reported for completeness; duration from HIP events on the kernel's own stream while the "
+                                   "sibling family kernels run concurrently (solo durations: kernel_ms_solo)"}
         out["kernel_ms"] = {lvx.KERNEL_NAMES[i]: ms[i] / max(1, launches[i]) for i in range(len(ms)) if launches[i]}
+        if world == 1:   # solo durations: the same step with every family kernel on one stream (outside the timed region)
+            os.environ["LVX_SERIAL"] = "1"
+            ctx.set_profiling(True); ctx.kernel_ms()
+            for _ in range(5):
+                step()
+            ctx.synchronize()
+            ms1, l1 = ctx.kernel_ms()
+            ctx.set_profiling(False)
+            del os.environ["LVX_SERIAL"]
+            out["kernel_ms_solo"] = {lvx.KERNEL_NAMES[i]: ms1[i] / max(1, l1[i]) for i in range(len(ms1)) if l1[i]}
         if world == 1 and not args.no_secondary:
             out["secondary"] = secondary_metrics(ctx, P, lo)
         if not args.no_cpu_baseline and world == 1:

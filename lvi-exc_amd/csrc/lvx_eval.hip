@@ -1103,13 +1103,13 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
   // the debug Jacobian, and as the exact fallback for the merged-hub-segment corner
   const bool fast = !ctx->force_legacy && !(what & LVX_EVAL_JACOBIAN) && !getenv("LVX_FORCE_LEGACY");
   auto acc_lds = [](int NC, int NG, int R) { const int LV = (R + 5) * 6; return (size_t)(LV * ACC_BW + NG * LV + NG * NG + LV + NG + 4 * (NC * 65 + 64)) * 8 + (size_t)(LV + NG) * 4 + 64; };
-  if (fast && (ctx->surf.n > 0 || ctx->cs.n > 0))
-    hipLaunchKernelGGL(k_hub_eval, dim3(1), dim3(64), 0, st, cm, ctx->t_map, ctx->surf.n > 0 ? 1 : 0, ctx->cs.n > 0 ? 1 : 0, (HubShared*)ctx->d_hubs.p);
   // fork: the independent family kernels run concurrently (each is latency / occupancy limited on its own)
   LVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
   for (int k = 0; k < 4; ++k) LVX_HIP(ctx, hipStreamWaitEvent(ctx->fam_stream[k], ctx->ev_fork, 0));
   hipStream_t s_imu = ctx->fam_stream[0], s_acc = ctx->fam_stream[1], s_surf = ctx->fam_stream[2], s_rep = ctx->fam_stream[3];
   if (getenv("LVX_SERIAL")) s_imu = s_acc = s_surf = s_rep = st;   // profiling aid: solo kernel durations
+  if (fast && (ctx->surf.n > 0 || ctx->cs.n > 0))   // only the surfel / cam-surfel stream waits for the shared t_map pose
+    hipLaunchKernelGGL(k_hub_eval, dim3(1), dim3(64), 0, s_surf, cm, ctx->t_map, ctx->surf.n > 0 ? 1 : 0, ctx->cs.n > 0 ? 1 : 0, (HubShared*)ctx->d_hubs.p);
   const bool mfma = !getenv("LVX_NO_MFMA");
   static const int occ = getenv("LVX_OCC") ? atoi(getenv("LVX_OCC")) : 1;
 #define LVX_LAUNCH_MFMA1(FT, CRV, OCCV, fam_obj, famid, stream, row0v)                                                                        \
