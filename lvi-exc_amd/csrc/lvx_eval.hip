@@ -74,15 +74,15 @@ LVX_HD void hub_spans(double t_map, bool tau_locked, double mto, double sp1[1][2
   if (tau_locked) { sp1[0][0] = t_map; sp1[0][1] = t_map; } else { sp1[0][0] = t_map - mto; sp1[0][1] = t_map + mto; }
 }
 
-struct SurfFam {
-  enum { NC = SURF_NC, NR = SURF_NR, USES_HUB = 1 };
+template <bool TAU> struct SurfFamT {
+  enum { NC = SURF_NC + (TAU ? 1 : 0), NR = SURF_NR, USES_HUB = 1 };
   int n; const double* t; const double* pt; const int* plane; const int* perm; const double* planes; double t_map, weight, huber;
   __device__ void make_hub(const DevCommon& cm, const SplineRef& sp, const Cal& cal, HubShared* h) const {
     double s1[1][2]; hub_spans(t_map, (cm.locks & LVX_LOCK_LIDAR_TAU) != 0, cm.sensor_mto, s1);
     Segs sg; KnotRef kh; h->ok = 0;
     if (!build_segments(sp, s1, 1, &sg)) return;
     if (!seg_lookup(sp, sg, t_map + cal.lidar.tau, &kh)) return;
-    if (!pose_eval<true>(sp, kh, &h->A)) { h->ok = -RES_NONUNIT; return; }
+    if (!pose_eval<true, TAU>(sp, kh, &h->A)) { h->ok = -RES_NONUNIT; return; }
     h->ok = 1;
   }
   __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared& hub, int si, double r[NR], double (*J)[NC], Keys& k) const {
@@ -97,24 +97,25 @@ struct SurfFam {
     const PoseEval* hp = &hub.A;
     PoseEval own;
     if (hub.ok != 1 || kh.i0 != hub.A.k.i0 || kh.u != hub.A.k.u) {   // merged-segment corner (spline_base.h:196-203)
-      if (!pose_eval<true>(sp, kh, &own)) return RES_NONUNIT;
+      if (!pose_eval<true, TAU>(sp, kh, &own)) return RES_NONUNIT;
       hp = &own;
     }
     k.k0 = kh.i0; k.lm = 0;
     const int pid = plane[si];
-    return surfel_residual<true>(sp, *hp, segs, cal.lidar, tk, load_v3(pt + 3 * (size_t)si), load_v3(planes + 3 * (size_t)pid), weight, &k.k1, r, J);
+    return surfel_residual<true, TAU>(sp, *hp, segs, cal.lidar, tk, load_v3(pt + 3 * (size_t)si), load_v3(planes + 3 * (size_t)pid), weight, &k.k1, r, J);
   }
   __device__ int col(int c, const Keys& k, int N) const { return surf_col(c, k.k0, k.k1, N); }
 };
-struct CamSurfFam {
-  enum { NC = CS_NC, NR = CS_NR, USES_HUB = 1 };
+using SurfFam = SurfFamT<false>;
+template <bool TAU> struct CamSurfFamT {
+  enum { NC = CS_NC + (TAU ? 1 : 0), NR = CS_NR, USES_HUB = 1 };
   int n; const int* lm; const int* plane; const int* perm; const double* planes; const double* lm_uv; const double* lm_t0; double t_map, weight, huber;
   __device__ void make_hub(const DevCommon& cm, const SplineRef& sp, const Cal& cal, HubShared* h) const {
     double s1[1][2]; hub_spans(t_map, (cm.locks & LVX_LOCK_CAM_TAU) != 0, cm.sensor_mto, s1);
     Segs sg; KnotRef kh; h->ok = 0;
     if (!build_segments(sp, s1, 1, &sg)) return;
     if (!seg_lookup(sp, sg, t_map + cal.cam.tau, &kh)) return;
-    if (!pose_eval<true>(sp, kh, &h->A)) { h->ok = -RES_NONUNIT; return; }
+    if (!pose_eval<true, TAU>(sp, kh, &h->A)) { h->ok = -RES_NONUNIT; return; }
     h->ok = 1;
   }
   __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared& hub, int si, double r[NR], double (*J)[NC], Keys& k) const {
@@ -130,27 +131,29 @@ struct CamSurfFam {
     const PoseEval* hp = &hub.A;
     PoseEval own;
     if (hub.ok != 1 || kh.i0 != hub.A.k.i0 || kh.u != hub.A.k.u) {
-      if (!pose_eval<true>(sp, kh, &own)) return RES_NONUNIT;
+      if (!pose_eval<true, TAU>(sp, kh, &own)) return RES_NONUNIT;
       hp = &own;
     }
     k.k0 = kh.i0; k.lm = 0;
-    return camsurf_residual<true>(sp, *hp, segs, cm.cam, cal.cam, cal.lidar, lm_uv[2 * l], lm_uv[2 * l + 1], tk, cal.rho[l],
+    return camsurf_residual<true, TAU>(sp, *hp, segs, cm.cam, cal.cam, cal.lidar, lm_uv[2 * l], lm_uv[2 * l + 1], tk, cal.rho[l],
                                   load_v3(planes + 3 * (size_t)plane[si]), weight, &k.k1, r, J);
   }
   __device__ int col(int c, const Keys& k, int N) const { return cs_col(c, k.k0, k.k1, N); }
 };
-struct ReprojFam {
-  enum { NC = REP_NC, NR = REP_NR, USES_HUB = 0 };
+using CamSurfFam = CamSurfFamT<false>;
+template <bool TAU> struct ReprojFamT {
+  enum { NC = REP_NC + (TAU ? 1 : 0), NR = REP_NR, USES_HUB = 0 };
   int n; const int* lm; const double* uv; const double* t0o; const int* perm; const double* lm_uv; const double* lm_t0; double weight, huber;
   __device__ void make_hub(const DevCommon&, const SplineRef&, const Cal&, HubShared*) const {}
   __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared&, int si, double r[NR], double (*J)[NC], Keys& k) const {
     const int l = lm[si];
     k.lm = l;
-    return reproj_residual<true>(sp, cm.cam, cal.cam, (cm.locks & LVX_LOCK_CAM_TAU) != 0, cm.sensor_mto, lm_uv[2 * l], lm_uv[2 * l + 1], lm_t0[l],
+    return reproj_residual<true, TAU>(sp, cm.cam, cal.cam, (cm.locks & LVX_LOCK_CAM_TAU) != 0, cm.sensor_mto, lm_uv[2 * l], lm_uv[2 * l + 1], lm_t0[l],
                                  uv[2 * (size_t)si], uv[2 * (size_t)si + 1], t0o[si], cal.rho[l], weight, &k.k0, &k.k1, r, J);
   }
   __device__ int col(int c, const Keys& k, int N) const { return rep_col(c, k.k0, k.k1, N, k.lm); }
 };
+using ReprojFam = ReprojFamT<false>;
 
 // ---------------------------------------------------------------------------------------------------------
 // routing of one normal-equation entry into the structured storage
@@ -1027,9 +1030,11 @@ int ensure_layout(lvx_ctx* ctx) {
   if ((rc = upload_pairs(ctx, ctx->d_pairs[0], GYRO_NC, range(12, 15)))) return rc;
   if ((rc = upload_pairs(ctx, ctx->d_pairs[1], ACC_NC, range(24, 29)))) return rc;
   if ((rc = upload_pairs(ctx, ctx->d_pairs[2], PRI_NC))) return rc;
-  if ((rc = upload_pairs(ctx, ctx->d_pairs[3], SURF_NC, cat(range(0, 24), range(48, 54))))) return rc;
-  if ((rc = upload_pairs(ctx, ctx->d_pairs[4], REP_NC, range(48, 54)))) return rc;
-  if ((rc = upload_pairs(ctx, ctx->d_pairs[5], CS_NC, cat(range(0, 24), range(48, 60))))) return rc;
+  // a free sensor time offset adds one (border) column to the per-segment kernels of the families that evaluate at t + tau
+  const int tL = (locks & LVX_LOCK_LIDAR_TAU) ? 0 : 1, tC = (locks & LVX_LOCK_CAM_TAU) ? 0 : 1;
+  if ((rc = upload_pairs(ctx, ctx->d_pairs[3], SURF_NC + tL, cat(range(0, 24), range(48, 54 + tL))))) return rc;
+  if ((rc = upload_pairs(ctx, ctx->d_pairs[4], REP_NC + tC, cat(range(48, 54), range(55, 55 + tC))))) return rc;
+  if ((rc = upload_pairs(ctx, ctx->d_pairs[5], CS_NC + tC, cat(range(0, 24), range(48, 60 + tC))))) return rc;
   if ((rc = upload_pairs(ctx, ctx->d_pairs_acc[0], SURFP_NC))) return rc;
   if ((rc = upload_pairs(ctx, ctx->d_pairs_acc[1], CSP_NC))) return rc;
   ctx->force_legacy = false;
@@ -1108,8 +1113,11 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
   for (int k = 0; k < 4; ++k) LVX_HIP(ctx, hipStreamWaitEvent(ctx->fam_stream[k], ctx->ev_fork, 0));
   hipStream_t s_imu = ctx->fam_stream[0], s_acc = ctx->fam_stream[1], s_surf = ctx->fam_stream[2], s_rep = ctx->fam_stream[3];
   if (getenv("LVX_SERIAL")) s_imu = s_acc = s_surf = s_rep = st;   // profiling aid: solo kernel durations
-  if (fast && (ctx->surf.n > 0 || ctx->cs.n > 0))   // only the surfel / cam-surfel stream waits for the shared t_map pose
-    hipLaunchKernelGGL(k_hub_eval, dim3(1), dim3(64), 0, s_surf, cm, ctx->t_map, ctx->surf.n > 0 ? 1 : 0, ctx->cs.n > 0 ? 1 : 0, (HubShared*)ctx->d_hubs.p);
+  // free time offsets need d pose / d t at both evaluations: those problems take the per-segment kernels (TAU variants)
+  const bool tauL = !(ctx->locks & LVX_LOCK_LIDAR_TAU), tauC = !(ctx->locks & LVX_LOCK_CAM_TAU);
+  const bool fast_surf = fast && !tauL && ctx->surf.n > 0, fast_cs = fast && !tauC && ctx->cs.n > 0;
+  if (fast_surf || fast_cs)   // only the surfel / cam-surfel stream waits for the shared t_map pose
+    hipLaunchKernelGGL(k_hub_eval, dim3(1), dim3(64), 0, s_surf, cm, ctx->t_map, fast_surf ? 1 : 0, fast_cs ? 1 : 0, (HubShared*)ctx->d_hubs.p);
   const bool mfma = !getenv("LVX_NO_MFMA");
   static const int occ = getenv("LVX_OCC") ? atoi(getenv("LVX_OCC")) : 1;
 #define LVX_LAUNCH_MFMA1(FT, CRV, OCCV, fam_obj, famid, stream, row0v)                                                                        \
@@ -1160,7 +1168,11 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
   }
   if (ctx->surf.n > 0) {
     ProfScope ps(ctx, LVX_FAM_SURFEL, s_surf);
-    if (fast) {
+    if (tauL) {
+      SurfFamT<true> s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
+                       (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
+      hipLaunchKernelGGL((k_family<SurfFamT<true>, 1>), grid(s.n), dim3(64), 0, s_surf, s, cm, (const uint16_t*)ctx->d_pairs[3].p, (long long)ctx->fam_row0[3]);
+    } else if (fast_surf) {
       SurfAcc s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
                 (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
       if (mfma) LVX_LAUNCH_MFMA(SurfAcc, LVX_CHUNK_R, s, LVX_FAM_SURFEL, s_surf, ctx->fam_row0[3]);
@@ -1179,11 +1191,19 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     ReprojFam r{ctx->rep.n, (const int*)ctx->rep.d_id0.p, (const double*)ctx->rep.d_a3.p, (const double*)ctx->rep.d_t.p, (const int*)ctx->rep.d_perm.p,
                 (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->rep.weight, ctx->rep.huber};
     ProfScope ps(ctx, LVX_FAM_REPROJ, s_rep);
+    if (tauC) {
+      ReprojFamT<true> rt{r.n, r.lm, r.uv, r.t0o, r.perm, r.lm_uv, r.lm_t0, r.weight, r.huber};
+      hipLaunchKernelGGL((k_family<ReprojFamT<true>, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, rt, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
+    } else
     hipLaunchKernelGGL((k_family<ReprojFam, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, r, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
   }
   if (ctx->cs.n > 0) {
     ProfScope ps(ctx, LVX_FAM_CAMSURF, s_surf);
-    if (fast) {
+    if (tauC) {
+      CamSurfFamT<true> c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
+                          (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
+      hipLaunchKernelGGL((k_family<CamSurfFamT<true>, 1>), grid(c.n), dim3(64), 0, s_surf, c, cm, (const uint16_t*)ctx->d_pairs[5].p, (long long)ctx->fam_row0[5]);
+    } else if (fast_cs) {
       CamSurfAcc c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
                    (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
       if (mfma) LVX_LAUNCH_MFMA(CamSurfAcc, LVX_CHUNK_R, c, LVX_FAM_CAMSURF, s_surf, ctx->fam_row0[5]);
@@ -1201,8 +1221,8 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
   for (int k = 0; k < 4; ++k) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[k], ctx->fam_stream[k])); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[k], 0)); }
   { ProfScope ps(ctx, LVX_KERNEL_FOLD);
   hipLaunchKernelGGL(k_fold_replicas, dim3((unsigned)((ctx->nbd_ext * ctx->nbd_ext + 255) / 256)), dim3(256), 0, st, cm);
-  if (fast && (what & LVX_EVAL_NORMAL_EQ) && (ctx->surf.n > 0 || ctx->cs.n > 0)) {
-    for (int set = 0; set < 2; ++set) if (ctx->nb > 0 && ((set == 0 && ctx->surf.n > 0) || (set == 1 && ctx->cs.n > 0)))
+  if ((what & LVX_EVAL_NORMAL_EQ) && (fast_surf || fast_cs)) {
+    for (int set = 0; set < 2; ++set) if (ctx->nb > 0 && ((set == 0 && fast_surf) || (set == 1 && fast_cs)))
       hipLaunchKernelGGL(k_fold_border_rows, dim3((unsigned)((ctx->nb + 255) / 256)), dim3(256), 0, st, cm, set);
     const size_t lds = ((size_t)ctx->nbd_ext * ctx->nbd_ext + ctx->nbd_ext) * 8;
     LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_fold_border_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -219,7 +219,7 @@ struct So3Eval {
   m3 dw[4];
 };
 
-template <bool NEED_W, bool NEED_J>
+template <bool NEED_W, bool NEED_J, bool NEED_DW = (NEED_W && NEED_J)>
 LVX_HD bool so3_eval(const quat c[4], double u, double dt, So3Eval* out) {
   const double u2 = u * u, u3 = u2 * u;
   // [1 u u2 u3] * M_cumul (spline_base.h:25-29); B[0] = 1
@@ -273,7 +273,7 @@ LVX_HD bool so3_eval(const quat c[4], double u, double dt, So3Eval* out) {
   Xe[2] = T2 * Jri[2] - mul_t(T3, Jri[3]);
   Xe[3] = T3 * Jri[3];
   m3 We[4];
-  if (NEED_W) {
+  if (NEED_DW) {
     const m3 W1 = dB[1] * R32t;
     const m3 W2 = R3t * (skew(w2r) * P[2] + dB[2] * m3_identity());
     const m3 W3 = skew(w3r) * P[3] + dB[3] * m3_identity();
@@ -286,7 +286,7 @@ LVX_HD bool so3_eval(const quat c[4], double u, double dt, So3Eval* out) {
   for (int k = 0; k < 4; ++k) {
     const m3 Rk = rotmat(c[k]);
     out->dxi[k] = 2.0 * mul_t(Xe[k], Rk);
-    if (NEED_W) out->dw[k] = 2.0 * mul_t(We[k], Rk);
+    if (NEED_DW) out->dw[k] = 2.0 * mul_t(We[k], Rk);
   }
   return ok;
 }

@@ -90,18 +90,26 @@ LVX_HD void load_so3_cp(const SplineRef& sp, int i0, quat c[4]) {
 struct PoseEval {
   KnotRef k;
   v3 p;
+  v3 v;              // world-frame velocity, only with NEED_V (time-offset Jacobians)
   double Bp[4];
-  So3Eval so3;
+  So3Eval so3;       // so3.w_body only with NEED_V
 };
-template <bool NEED_J>
+// NEED_V: also the time derivative of the pose — d p / d t = v, q(t + e) = q (x) Exp(w_body e) — which is what a free sensor time
+// offset differentiates through (the reference's Jets carry it through the spline time argument, sensors.h:36-85)
+template <bool NEED_J, bool NEED_V = false>
 LVX_HD bool pose_eval(const SplineRef& sp, const KnotRef& k, PoseEval* out) {
   out->k = k;
   R3Basis b; r3_basis(k.u, sp.dt, &b);
-  v3 p = mk(0, 0, 0);
-  for (int j = 0; j < 4; ++j) { out->Bp[j] = b.Bp[j]; p = p + b.Bp[j] * load_v3(sp.r3 + 3 * (k.i0 + j)); }
+  v3 p = mk(0, 0, 0), v = mk(0, 0, 0);
+  for (int j = 0; j < 4; ++j) {
+    const v3 cj = load_v3(sp.r3 + 3 * (k.i0 + j));
+    out->Bp[j] = b.Bp[j]; p = p + b.Bp[j] * cj;
+    if (NEED_V) v = v + b.Bv[j] * cj;
+  }
   out->p = p;
+  if (NEED_V) out->v = v;
   quat c[4]; load_so3_cp(sp, k.i0, c);
-  return so3_eval<false, NEED_J>(c, k.u, sp.dt, &out->so3);
+  return so3_eval<NEED_V, NEED_J, false>(c, k.u, sp.dt, &out->so3);
 }
 
 // error codes shared with include/lvx.h
@@ -192,7 +200,7 @@ LVX_HD void plane_nd(v3 Pi, v3* n, double* d) {
 // local columns: [hub knot j: 6j..6j+5 | k knot j: 24+6j.. | lidar theta 48..50 | lidar p 51..53]
 // The hub evaluation is identical for every surfel residual and is passed in precomputed.
 // ---------------------------------------------------------------------------------------------
-enum { SURF_NC = 54, SURF_NR = 1 };
+enum { SURF_NC = 54, SURF_NR = 1 };   // + 1 column (lidar time offset) in the TAU variants
 
 // shared tail of surfel / cam-surfel: given p_I (point in IMU frame at time k) and hub/k poses
 struct PlaneChain { v3 nL, m, x, ptemp; double r_unweighted; };
@@ -230,14 +238,20 @@ LVX_HD void plane_knot_jac(const PoseEval& h, const PoseEval& k, const PlaneChai
   pose_to_knots(k, g.gp, g.gxk, Jk);
 }
 
-template <bool NEED_J>
+// time-offset column of a two-pose point-to-plane residual: both poses move with tau
+LVX_HD double plane_tau_jac(const PoseEval& h, const PoseEval& k, const PlaneGrads& g) {
+  return dot(g.gp, k.v - h.v) + dot(g.gx0, h.so3.w_body) + dot(g.gxk, k.so3.w_body);
+}
+
+// TAU: the hub must have been evaluated with NEED_V; adds column SURF_NC = d r / d tau_lidar
+template <bool NEED_J, bool TAU = false>
 LVX_HD int surfel_residual(const SplineRef& sp, const PoseEval& hub, const Segs& segs, const SensorCal& lidar, double t_k, v3 p_L, v3 Pi,
-                           double weight, int* i0_k, double r[1], double J[1][SURF_NC]) {
+                           double weight, int* i0_k, double r[1], double J[1][SURF_NC + (TAU ? 1 : 0)]) {
   KnotRef kr;
   if (!seg_lookup(sp, segs, t_k + lidar.tau, &kr)) return RES_RANGE;
   *i0_k = kr.i0;
   PoseEval k;
-  if (!pose_eval<NEED_J>(sp, kr, &k)) return RES_NONUNIT;
+  if (!pose_eval<NEED_J, TAU>(sp, kr, &k)) return RES_NONUNIT;
   const v3 pLr = qrot(lidar.q, p_L);
   const v3 p_I = pLr + lidar.p;
   PlaneChain pc; plane_chain(hub, k, lidar, p_I, Pi, &pc);
@@ -248,6 +262,7 @@ LVX_HD int surfel_residual(const SplineRef& sp, const PoseEval& hub, const Segs&
     const v3 jp = weight * (pc.m - pc.nL);
     J[0][48] = jq.x; J[0][49] = jq.y; J[0][50] = jq.z;
     J[0][51] = jp.x; J[0][52] = jp.y; J[0][53] = jp.z;
+    if (TAU) J[0][SURF_NC] = plane_tau_jac(hub, k, plane_grads(hub, pc, p_I, weight));
   }
   return RES_OK;
 }
@@ -343,10 +358,10 @@ LVX_HD void cam_project(const CamIntr& c, v3 X, double y[2], double G[2][3]) {
 // local columns: [ref knot j: 6j.. | obs knot j: 24+6j.. | cam theta 48..50 | cam p 51..53 | rho 54]
 // ---------------------------------------------------------------------------------------------
 enum { REP_NC = 55, REP_NR = 2 };
-template <bool NEED_J>
+template <bool NEED_J, bool TAU = false>
 LVX_HD int reproj_residual(const SplineRef& sp, const CamIntr& ci, const SensorCal& cam, bool tau_locked, double max_time_offset,
                            double u_ref, double v_ref, double t0_ref, double u_obs, double v_obs, double t0_obs, double rho, double weight,
-                           int* i0_ref, int* i0_obs, double r[2], double J[2][REP_NC]) {
+                           int* i0_ref, int* i0_obs, double r[2], double J[2][REP_NC + (TAU ? 1 : 0)]) {
   // spans (:148-172): sorted (t0_ref, t0_obs), padded by the time-offset bound if free, then [-1e-3, readout + 1e-3]
   double t1, t2;
   if (t0_ref <= t0_obs) { t1 = t0_ref; t2 = t0_obs; } else { t1 = t0_obs; t2 = t0_ref; }
@@ -363,8 +378,8 @@ LVX_HD int reproj_residual(const SplineRef& sp, const CamIntr& ci, const SensorC
   if (!seg_lookup(sp, segs, t_obs, &ko)) return RES_RANGE;
   *i0_ref = kr.i0; *i0_obs = ko.i0;
   PoseEval er, eo;
-  if (!pose_eval<NEED_J>(sp, kr, &er)) return RES_NONUNIT;
-  if (!pose_eval<NEED_J>(sp, ko, &eo)) return RES_NONUNIT;
+  if (!pose_eval<NEED_J, TAU>(sp, kr, &er)) return RES_NONUNIT;
+  if (!pose_eval<NEED_J, TAU>(sp, ko, &eo)) return RES_NONUNIT;
   const v3 p_ct = qrot_inv(cam.q, -cam.p);
   const v3 yh = cam_unproject(ci, u_ref, v_ref);
   const v3 X_ref = qrot(cam.q, yh - rho * p_ct);
@@ -407,6 +422,7 @@ LVX_HD int reproj_residual(const SplineRef& sp, const CamIntr& ci, const SensorC
       J[a][48] = jq.x; J[a][49] = jq.y; J[a][50] = jq.z;
       J[a][51] = jp.x; J[a][52] = jp.y; J[a][53] = jp.z;
       J[a][54] = dot(g, dXc_drho);
+      if (TAU) J[a][REP_NC] = rho * dot(gX, er.v - eo.v) + dot(gxr, er.so3.w_body) + dot(gxo, eo.so3.w_body);   // both views move with tau_cam
     }
   }
   return RES_OK;
@@ -418,14 +434,14 @@ LVX_HD int reproj_residual(const SplineRef& sp, const CamIntr& ci, const SensorC
 // local columns: [hub knot j: 6j.. | k knot j: 24+6j.. | cam theta 48..50 | cam p 51..53 | lidar theta 54..56 | lidar p 57..59]
 // ---------------------------------------------------------------------------------------------
 enum { CS_NC = 60, CS_NR = 1 };
-template <bool NEED_J>
+template <bool NEED_J, bool TAU = false>
 LVX_HD int camsurf_residual(const SplineRef& sp, const PoseEval& hub, const Segs& segs, const CamIntr& ci, const SensorCal& cam, const SensorCal& lidar,
-                            double u_ref, double v_ref, double t0_ref, double rho, v3 Pi, double weight, int* i0_k, double r[1], double J[1][CS_NC]) {
+                            double u_ref, double v_ref, double t0_ref, double rho, v3 Pi, double weight, int* i0_k, double r[1], double J[1][CS_NC + (TAU ? 1 : 0)]) {
   KnotRef kr;
   if (!seg_lookup(sp, segs, t0_ref + cam.tau, &kr)) return RES_RANGE;
   *i0_k = kr.i0;
   PoseEval k;
-  if (!pose_eval<NEED_J>(sp, kr, &k)) return RES_NONUNIT;
+  if (!pose_eval<NEED_J, TAU>(sp, kr, &k)) return RES_NONUNIT;
   const double s = 1.0 / (rho + 1e-8);
   const v3 yu = cam_unproject(ci, u_ref, v_ref);
   const v3 yh = mk(yu.x * s, yu.y * s, yu.z * s);
@@ -441,6 +457,7 @@ LVX_HD int camsurf_residual(const SplineRef& sp, const PoseEval& hub, const Segs
     const v3 jlp = (-weight) * pc.nL;
     J[0][48] = jcq.x; J[0][49] = jcq.y; J[0][50] = jcq.z; J[0][51] = jcp.x; J[0][52] = jcp.y; J[0][53] = jcp.z;
     J[0][54] = jlq.x; J[0][55] = jlq.y; J[0][56] = jlq.z; J[0][57] = jlp.x; J[0][58] = jlp.y; J[0][59] = jlp.z;
+    if (TAU) J[0][CS_NC] = plane_tau_jac(hub, k, plane_grads(hub, pc, p_I, weight));   // tau_cam moves both the hub and the landmark's reference pose
   }
   return RES_OK;
 }
@@ -514,11 +531,11 @@ LVX_HD int prior_residual(const SplineRef& sp, double t, quat q_meas, double wei
 LVX_HD int gyro_col(int c, int i0, int N) { return c < 12 ? 6 * (i0 + c / 3) + 3 + c % 3 : 6 * N + 5 + (c - 12); }
 LVX_HD int acc_col(int c, int i0, int N) { return c < 24 ? 6 * (i0 + c / 6) + c % 6 : (c < 26 ? 6 * N + (c - 24) : 6 * N + 2 + (c - 26)); }
 LVX_HD int surf_col(int c, int i0h, int i0k, int N) {
-  return c < 24 ? 6 * (i0h + c / 6) + c % 6 : (c < 48 ? 6 * (i0k + (c - 24) / 6) + (c - 24) % 6 : 6 * N + 8 + (c - 48)); }
+  return c < 24 ? 6 * (i0h + c / 6) + c % 6 : (c < 48 ? 6 * (i0k + (c - 24) / 6) + (c - 24) % 6 : 6 * N + 8 + (c - 48)); }   // c == 54: lidar tau
 LVX_HD int rep_col(int c, int i0r, int i0o, int N, int lm) {
-  return c < 24 ? 6 * (i0r + c / 6) + c % 6 : (c < 48 ? 6 * (i0o + (c - 24) / 6) + (c - 24) % 6 : (c < 54 ? 6 * N + 15 + (c - 48) : 6 * N + 22 + lm)); }
+  return c < 24 ? 6 * (i0r + c / 6) + c % 6 : (c < 48 ? 6 * (i0o + (c - 24) / 6) + (c - 24) % 6 : (c < 54 ? 6 * N + 15 + (c - 48) : (c == 54 ? 6 * N + 22 + lm : 6 * N + 21))); }   // c == 55: cam tau
 LVX_HD int cs_col(int c, int i0h, int i0k, int N) {
-  return c < 24 ? 6 * (i0h + c / 6) + c % 6 : (c < 48 ? 6 * (i0k + (c - 24) / 6) + (c - 24) % 6 : (c < 54 ? 6 * N + 15 + (c - 48) : 6 * N + 8 + (c - 54))); }
+  return c < 24 ? 6 * (i0h + c / 6) + c % 6 : (c < 48 ? 6 * (i0k + (c - 24) / 6) + (c - 24) % 6 : (c < 54 ? 6 * N + 15 + (c - 48) : (c < 60 ? 6 * N + 8 + (c - 54) : 6 * N + 21))); }   // c == 60: cam tau
 LVX_HD int pri_col(int c, int i0, int N) { return 6 * (i0 + c / 3) + 3 + c % 3; }
 
 // lock mask (include/lvx.h LVX_LOCK_*) -> is global tangent index g constant?

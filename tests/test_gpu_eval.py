@@ -40,6 +40,11 @@ def _compare(o, g, state, check_jac=True):
     Hs = np.abs(ro["H"]).max()
     assert np.abs(rg["H"] - ro["H"]).max() <= 1e-10 * Hs
     assert np.abs(rg["g"] - ro["g"]).max() <= 1e-10 * np.abs(ro["g"]).max()
+    if check_jac:   # the debug-Jacobian evaluation takes the per-segment kernels; without it the MFMA assembly path runs
+        rf = g.evaluate(state, jac=False, normal_eq=True)
+        assert np.abs(rf["residuals"] - ro["residuals"]).max() <= 1e-11 * rs
+        assert np.abs(rf["H"] - ro["H"]).max() <= 1e-10 * Hs
+        assert np.abs(rf["g"] - ro["g"]).max() <= 1e-10 * np.abs(ro["g"]).max()
     return ro, rg
 
 
@@ -68,6 +73,27 @@ def test_lock_masks(locks):
     P = synth.make_problem(seed=7, duration=1.5, n_surfel=300, n_planes=8, n_landmarks=20, n_camsurf=6)
     o, g = _pair(P, locks)
     _compare(o, g, P["state0"])
+    g.close()
+
+
+@pytest.mark.parametrize("locks", [0, lvx.LOCK_LIDAR_TAU, lvx.LOCK_CAM_TAU])
+def test_free_time_offsets(locks):
+    """Free sensor time offsets (Sensor::LockTimeOffset(false), sensors.h:70-85): spans are padded by the offset bound and the residuals
+    are differentiated through the spline time argument; tau columns vs the oracle's dual numbers."""
+    P = synth.make_problem(seed=9, duration=1.5, n_surfel=300, n_planes=8, n_landmarks=20, n_camsurf=6)
+    o, g = _pair(P, locks)
+    N = P["n_knots"]
+    for state in (P["state0"], P["state_true"]):
+        s = state.copy()
+        if not (locks & lvx.LOCK_LIDAR_TAU):
+            s[7 * N + 16 + 7] = 3e-4      # lidar tau (a LOCKED non-zero offset leaves the 4-knot segment of {t, t} spans: range_error, as the reference)
+        if not (locks & lvx.LOCK_CAM_TAU):
+            s[7 * N + 24 + 7] = -2e-4     # cam tau
+        ro, rg = _compare(o, g, s)
+        nt = o.tangent_size
+        Jo = O.dense_jacobian(ro["jac_cols"], ro["jac_vals"], nt)
+        for col, bit in ((6 * N + 14, lvx.LOCK_LIDAR_TAU), (6 * N + 21, lvx.LOCK_CAM_TAU)):
+            assert (np.abs(Jo[:, col]).max() > 0) == (not (locks & bit))
     g.close()
 
 

@@ -42,9 +42,10 @@ def test_solve_step_matches_dense(scaling, radius):
 @pytest.mark.parametrize("locks,stage", [
     (TAU_LOCKS | lvx.LOCK_CAM_Q | lvx.LOCK_CAM_P | lvx.LOCK_LANDMARKS, "solve1"),   # trajInitFromSurfel: gyro + accel + surfel, camera locked
     (TAU_LOCKS, "solve2"),                                                           # trajInitFromLVIdata: + reprojection
+    (0, "solve2_free_tau"),                                                          # same with both sensor time offsets free (lvi.yaml:32 keeps them locked)
 ])
 def test_lm_matches_oracle(locks, stage):
-    P = synth.make_problem(seed=15, duration=2.0, n_surfel=600, n_planes=12, n_landmarks=30 if stage == "solve2" else 0, n_camsurf=0)
+    P = synth.make_problem(seed=15, duration=2.0, n_surfel=600, n_planes=12, n_landmarks=30 if stage.startswith("solve2") else 0, n_camsurf=0)
     o = O.Oracle(); g = lvx.Context(0)
     for obj in (o, g):
         lvx.load_problem(obj, P, locks)
