@@ -138,11 +138,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("LVX_BENCH_BACKEND", "nccl")   # "gloo": functional check of the N > 1 path with several ranks on one GPU
+    if torch.cuda.is_available() and backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
     if not torch.cuda.is_available():
@@ -190,6 +196,26 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     cost = ctx.evaluate_resident(lvx.EVAL_COST, want_cost=True)
+    joint = None
+    if world > 1 and not args.no_secondary:
+        # side measurement (outside the timed region): LM iterations of the JOINT problem — shared rig extrinsics, one sequence per GPU;
+        # per iteration ONE all-reduce of the 14 x 14 reduced system + a few scalars (lvx_lm_solve_shared)
+        try:
+            import sharded
+            sj = P["state0"].copy()
+            Nk = lo["n_knots"]
+            ext = torch.from_numpy(sj[7 * Nk + 16:7 * Nk + 32].copy()).cuda()
+            dist.broadcast(ext, src=0)                      # the shared extrinsics start from rank 0's guess
+            sj[7 * Nk + 16:7 * Nk + 32] = ext.cpu().numpy()
+            dist.barrier(); torch.cuda.synchronize()
+            tj = time.perf_counter()
+            _, smj = ctx.lm_solve_shared(sj, sharded.dist_all_reduce(dist, torch.device("cuda", local_rank)), max_iterations=3)
+            torch.cuda.synchronize(); dist.barrier()
+            tj = time.perf_counter() - tj
+            joint = {"ms_per_iteration": 1e3 * tj / max(1, smj["iterations"]), "iterations": smj["iterations"], "initial_cost": smj["initial_cost"], "final_cost": smj["final_cost"],
+                     "note": "joint LM over %d sequences with shared extrinsics: evaluate + private elimination per GPU, one 211-double all-reduce + 4 scalar reductions per iteration" % world}
+        except Exception as e:   # noqa: BLE001
+            joint = {"error": str(e)[:300]}
 
     blocks = lo["n_blocks"]
     value = blocks * world * args.steps / elapsed / 1e6
@@ -227,6 +253,8 @@ def main():
             out["kernel_ms_solo"] = {lvx.KERNEL_NAMES[i]: ms1[i] / max(1, l1[i]) for i in range(len(ms1)) if l1[i]}
         if world == 1 and not args.no_secondary:
             out["secondary"] = secondary_metrics(ctx, P, lo)
+        if joint is not None:
+            out["secondary"] = {"joint_lm_iteration": joint}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(P)
         print(json.dumps(out), flush=True)

@@ -39,7 +39,8 @@ typedef struct lvx_ctx lvx_ctx;
 #define LVX_E_NONUNIT_QUAT (-2)  /* std::runtime_error in logq (kontiki/math/quaternion_math.h:19-23) */
 #define LVX_E_ALLOC (-3)
 #define LVX_E_HIP (-4)
-#define LVX_E_RCCL (-5)
+#define LVX_E_COMM (-5)          /* the host-supplied all-reduce callback failed (lvx_lm_solve_shared) */
+#define LVX_E_RCCL LVX_E_COMM
 #define LVX_E_ARG (-6)
 #define LVX_E_STATE (-7)         /* call order (e.g. evaluate before set_spline) */
 #define LVX_E_NODEVICE (-8)      /* no HIP device: the product path never falls back to the CPU */
@@ -244,6 +245,21 @@ int lvx_surfel_assoc(lvx_ctx* ctx, int H, int W, const float* scan_map_xyzi4, in
                      double radius, int sel_per_ring, int32_t* plane_of_point);
 /* device-resident variant: planes10_d = p4[P][4] | box_min[P][3] | box_max[P][3] */
 int lvx_surfel_assoc_d(lvx_ctx* ctx, int H, int W, const float* scan_d, int n_planes, const double* planes10_d, double radius, int sel_per_ring, int32_t* plane_of_point_d);
+
+/* sequence-per-GPU joint solve (BASELINE config 5) ---------------------------------------------------------*/
+/* Every rank owns one calibration sequence (trajectory, gravity, biases, landmarks are private); the rig extrinsics — lidar theta(3) p(3)
+ * tau, camera theta(3) p(3) tau = 14 tangent scalars — are shared.  One LM iteration of the JOINT problem: every rank eliminates its private
+ * variables on its GPU, ONE all-reduce of the 14 x 14 reduced system (+ rhs + flags, 211 doubles), every rank solves it and back-substitutes;
+ * plus tiny reductions of the cost, the model cost change and the step / gradient norms so that all ranks take the same accept / reject and
+ * termination decisions.  The library does not link a communication library: the host supplies the reduction over HOST buffers (RCCL via
+ * torch.distributed, MPI, ...); messages are <= 211 doubles and latency-bound.  All ranks must use the same lock mask and options. */
+#define LVX_N_SHARED 14
+#define LVX_REDUCE_SUM 0
+#define LVX_REDUCE_MAX 1
+typedef int (*lvx_allreduce_fn)(void* user, double* buf, int n, int op);   /* in-place over all ranks; returns 0 on success */
+/* lvx_solve_step / lvx_lm_solve of the joint problem; fn == NULL degenerates to the single-sequence calls */
+int lvx_solve_step_shared(lvx_ctx* ctx, double radius, int jacobi_scaling, lvx_allreduce_fn fn, void* user, double* delta, double* model_cost_change);
+int lvx_lm_solve_shared(lvx_ctx* ctx, double* state, const lvx_lm_options* opt, lvx_allreduce_fn fn, void* user, lvx_lm_summary* summary);
 
 /* scan de-skew ------------------------------------------------------------------------------------*/
 /* licalib PointXYZIT (src/lvi_exc/include/utils/pcl_utils.h:39-44), 32 bytes */

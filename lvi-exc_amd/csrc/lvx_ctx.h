@@ -106,6 +106,12 @@ struct lvx_ctx {
   } vox;
   std::vector<double> lm_cost, lm_radius;
   std::vector<int> lm_accept;
+  // sequence-per-GPU joint solve: host all-reduce hook, shared-extrinsics bookkeeping (lvx_solver.hip)
+  lvx_allreduce_fn ar_fn = nullptr;
+  void* ar_user = nullptr;
+  int ns = 0;                 // free shared scalars = the last ns border variables
+  int sh_slot[LVX_N_SHARED] = {0};   // canonical slot (0..13: lidar theta p tau, cam theta p tau) of each of them
+  double sh_lmd[LVX_N_SHARED] = {0}; // LM diagonal of the shared scalars (from the JOINT diagonal), added once after the reduction
   // profiling: (start, stop) event pairs per launch, read lazily by lvx_get_kernel_ms
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;

@@ -252,10 +252,13 @@ __global__ void k_schur_from_gram(const double* M, const double* C, const double
     rhs[a] = -gc[a] * scale[nb + a] - M[(size_t)nbd * n1 + a];
   }
 }
-// dense Cholesky solve of the border system (n <= 128), one workgroup; unused border slots have S_aa = lmd/radius > 0
-__global__ __launch_bounds__(256) void k_dense_solve(double* S, double* rhs, int n, int* info) {
+// dense Cholesky of the border system (n <= 128), one workgroup; unused border slots have S_aa = lmd/radius > 0.
+// Columns 0..np-1 are eliminated (right-looking, so the trailing (n-np) x (n-np) block ends up holding the Schur complement onto the
+// SHARED variables) and the right-hand side is forward-substituted: rhs[0..np) = L_pp^-1 b_p, rhs[np..n) = b_s - L_sp z_p.
+// np == n is the plain factorisation + forward substitution.
+__global__ __launch_bounds__(256) void k_dense_partial(double* S, double* rhs, int n, int np, int* info) {
   const int tid = threadIdx.x;
-  for (int k = 0; k < n; ++k) {
+  for (int k = 0; k < np; ++k) {
     __syncthreads();
     if (tid == 0) { const double d = S[(size_t)k * n + k]; if (!(d > 0.0)) { if (info[1] == 0) { info[1] = k + 1; ((double*)(info + 2))[0] = d; } S[(size_t)k * n + k] = 1.0; } else S[(size_t)k * n + k] = sqrt(d); }
     __syncthreads();
@@ -267,9 +270,14 @@ __global__ __launch_bounds__(256) void k_dense_solve(double* S, double* rhs, int
   }
   __syncthreads();
   if (tid == 0) {
-    for (int i = 0; i < n; ++i) { double s = rhs[i]; for (int k = 0; k < i; ++k) s -= S[(size_t)i * n + k] * rhs[k]; rhs[i] = s / S[(size_t)i * n + i]; }
-    for (int i = n - 1; i >= 0; --i) { double s = rhs[i]; for (int k = i + 1; k < n; ++k) s -= S[(size_t)k * n + i] * rhs[k]; rhs[i] = s / S[(size_t)i * n + i]; }
+    for (int i = 0; i < np; ++i) { double s = rhs[i]; for (int k = 0; k < i; ++k) s -= S[(size_t)i * n + k] * rhs[k]; rhs[i] = s / S[(size_t)i * n + i]; }
+    for (int i = np; i < n; ++i) { double s = rhs[i]; for (int k = 0; k < np; ++k) s -= S[(size_t)i * n + k] * rhs[k]; rhs[i] = s; }
   }
+}
+// backward substitution of the eliminated part given the solution of the trailing (shared) variables in rhs[np..n)
+__global__ void k_dense_back(const double* S, double* rhs, int n, int np) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int i = np - 1; i >= 0; --i) { double s = rhs[i]; for (int k = i + 1; k < n; ++k) s -= S[(size_t)k * n + i] * rhs[k]; rhs[i] = s / S[(size_t)i * n + i]; }
 }
 // z <- z - Z_B^T y_c
 __global__ void k_sub_border(const double* Z, const double* yc, int nb, int nbd, int ldz, double* z) {
@@ -333,8 +341,9 @@ __device__ __forceinline__ void qplus_dev(const double* x, const double* d, doub
     o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w;
   } else { o[0] = x[0]; o[1] = x[1]; o[2] = x[2]; o[3] = x[3]; }
 }
-// x_out = x (+) delta ; sums[2] += |x_out - x|^2, sums[3] += |x|^2 over the free parameter blocks (ambient)
-__global__ void k_plus(const double* x, const double* delta, int N, int L, uint32_t locks, double* xo, double* sums) {
+// x_out = x (+) delta ; sums[2] += |x_out - x|^2, sums[3] += |x|^2 over the free parameter blocks (ambient); the lidar / camera
+// blocks (shared between sequences in the joint solve) go to sums[6], sums[7] instead when split_shared
+__global__ void k_plus(const double* x, const double* delta, int N, int L, uint32_t locks, double* xo, double* sums, int split_shared) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double dn = 0.0, xn = 0.0;
   if (i < N) {
@@ -349,8 +358,10 @@ __global__ void k_plus(const double* x, const double* delta, int N, int L, uint3
     auto addv = [&](int so, int to, int n) { const bool fr = !tangent_locked(cb + to, N, L, locks); for (int j = 0; j < n; ++j) { const double a = s[so + j], b = a + d[to + j]; o[so + j] = b; if (fr) { dn += (b - a) * (b - a); xn += a * a; } } };
     auto addq = [&](int so, int to) { const bool fr = !tangent_locked(cb + to, N, L, locks); double q[4]; qplus_dev(s + so, d + to, q); for (int j = 0; j < 4; ++j) { const double a = s[so + j]; o[so + j] = q[j]; if (fr) { dn += (q[j] - a) * (q[j] - a); xn += a * a; } } };
     addv(8, 0, 1); addv(9, 1, 1); addv(10, 2, 3); addv(13, 5, 3);
+    const double dn_p = dn, xn_p = xn;
     addq(16, 8); addv(20, 11, 3); addv(23, 14, 1);
     addq(24, 15); addv(28, 18, 3); addv(31, 21, 1);
+    if (split_shared) { atomicAdd(&sums[6], dn - dn_p); atomicAdd(&sums[7], xn - xn_p); dn = dn_p; xn = xn_p; }
   } else if (i < N + 1 + L) {
     const int l = i - N - 1;
     const bool fr = !tangent_locked(6 * N + 22 + l, N, L, locks);
@@ -362,7 +373,7 @@ __global__ void k_plus(const double* x, const double* delta, int N, int L, uint3
   if ((threadIdx.x & 63) == 0 && (dn != 0.0 || xn != 0.0)) { atomicAdd(&sums[2], dn); atomicAdd(&sums[3], xn); }
 }
 // max |g| over free scalars
-__global__ void k_gmax(const double* gb, const double* gc, int nb, int nbd, double* sums) {
+__global__ void k_gmax(const double* gb, const double* gc, int nb, int nbd, double* sums) {   // nbd: border entries to include (the shared tail is excluded in the joint solve)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double v = 0.0;
   if (i < nb) v = fabs(gb[i]); else if (i < nb + nbd) v = fabs(gc[i - nb]);
@@ -382,6 +393,13 @@ using namespace lvx;
 // ---------------------------------------------------------------------------------------------------------
 struct SolveWork { double *L, *Z, *S, *rhs, *delta, *diag, *scale, *lmd, *sums, *Z2, *gram; int* info; int ldz; bool use_bcr; };
 
+// host all-reduce hook of the joint (sequence-per-GPU) solve; identity for a single sequence
+static int reduce(lvx_ctx* c, double* buf, int n, int op) {
+  if (!c->ar_fn) return LVX_OK;
+  if (c->ar_fn(c->ar_user, buf, n, op) != 0) return fail(c, LVX_E_COMM, "all-reduce callback failed");
+  return LVX_OK;
+}
+
 static int solver_alloc(lvx_ctx* c, SolveWork& w) {
   int rc;
   const size_t nb = (size_t)std::max(c->nb, 1), nbd = c->nbd, nt = (size_t)lvx_tangent_size(c);
@@ -400,18 +418,29 @@ static int solver_alloc(lvx_ctx* c, SolveWork& w) {
   w.L = (double*)c->d_L.p; w.Z = (double*)c->d_Y.p; w.S = (double*)c->d_S.p; w.rhs = w.S + nbd * nbd; w.delta = (double*)c->d_delta.p;
   w.diag = (double*)c->d_diag.p; w.scale = w.diag + (nb + nbd); w.lmd = w.scale + (nb + nbd);
   w.sums = (double*)c->d_scal.p; w.info = (int*)(w.sums + 32);
+  // shared extrinsics of the joint solve: tangent 6N+8 .. 6N+21 own the LAST 14 border slots (ensure_layout gives every calibration
+  // scalar a fixed slot after the hub knots; a locked one keeps an inert slot with S_aa = lmd / radius)
+  c->ns = 0;
+  if (c->ar_fn) {
+    c->ns = LVX_N_SHARED;
+    for (int k = 0; k < LVX_N_SHARED; ++k) {
+      c->sh_slot[k] = k;
+      const int o = c->ord[6 * (size_t)c->N + 8 + k];
+      if (o != LVX_DEAD && -1 - o != c->nbd - LVX_N_SHARED + k) return fail(c, LVX_E_STATE, "shared extrinsics are not the tail of the border");
+    }
+  }
   return LVX_OK;
 }
 
-// Solve the damped, scaled system for the normal equations of the last evaluation.  Leaves delta (tangent layout) on the device.
-// out[0] = model cost change, out[1] = g_s.y, out[2] = y^T D^2 y
-static int solve_step_device_impl(lvx_ctx* c, SolveWork& w, double radius, double* out, bool force_seq) {
+// Local half of one damped solve: factor the band, eliminate it and the private border variables.  On return the trailing ns x ns block
+// of w.S / w.rhs holds this sequence's contribution to the reduced system of the shared variables (all of the border system when ns = 0).
+static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, bool* bcr_used) {
   hipStream_t st = c->stream;
-  const int nb = c->nb, bw = c->bw, nbd = c->nbd, nt = lvx_tangent_size(c);
+  const int nb = c->nb, bw = c->bw, nbd = c->nbd;
   const double ir = 1.0 / radius;
-  ProfScope ps(c, LVX_KERNEL_SOLVE);
   LVX_HIP(c, hipMemsetAsync(w.sums, 0, 64 * 8, st));
   const bool use_bcr = w.use_bcr && !force_seq;
+  *bcr_used = use_bcr;
   if (!use_bcr && nb > 0) { int rca = dev_alloc(c, c->d_L, (size_t)nb * (bw + 1) * 8); if (rca) return rca; w.L = (double*)c->d_L.p; }
   const int ldz = w.ldz;
   if (nb > 0) {
@@ -443,11 +472,73 @@ static int solve_step_device_impl(lvx_ctx* c, SolveWork& w, double radius, doubl
     hipLaunchKernelGGL(k_schur, dim3(nbd), dim3(256), 0, st, (const double*)Zf, (const double*)c->d_C.p, (const double*)c->d_gc.p, (const double*)w.scale,
                        nb > 0 ? nb : 0, nbd, c->nbd_ext, ldz, (const double*)w.lmd, ir, w.S, w.rhs);
   }
-  hipLaunchKernelGGL(k_dense_solve, dim3(1), dim3(256), 0, st, w.S, w.rhs, nbd, w.info);
+  hipLaunchKernelGGL(k_dense_partial, dim3(1), dim3(256), 0, st, w.S, w.rhs, nbd, nbd - c->ns, w.info);
+  LVX_HIP(c, hipGetLastError());
+  int info[4] = {0, 0, 0, 0};
+  LVX_HIP(c, hipMemcpyAsync(info, w.info, 16, hipMemcpyDeviceToHost, st));
+  LVX_HIP(c, hipStreamSynchronize(st));
+  if (info[0] || info[1]) { double dv; memcpy(&dv, info + 2, 8); return fail(c, LVX_E_NOTPD, "damped normal equations not positive definite (band pivot code " + std::to_string(info[0]) + ", first border pivot " + std::to_string(info[1]) + " value " + std::to_string(dv) + ")"); }
+  return LVX_OK;
+}
+
+// Solve the damped, scaled system for the normal equations of the last evaluation.  Leaves delta (tangent layout) on the device.
+// out[0] = model cost change (of the JOINT problem when an all-reduce hook is set), out[1] = g.delta, out[2] = y^T D^2 y
+static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double* out) {
+  hipStream_t st = c->stream;
+  const int nb = c->nb, bw = c->bw, nbd = c->nbd, nt = lvx_tangent_size(c), ns = c->ns, np = nbd - ns;
+  const double ir = 1.0 / radius;
+  ProfScope ps(c, LVX_KERNEL_SOLVE);
+  bool bcr_used = false;
+  int rc = solve_local(c, w, radius, false, &bcr_used);
+  if (rc == LVX_E_NOTPD && w.use_bcr) {
+    // the cyclic-reduction elimination order can lose positive definiteness in floating point on nearly singular systems
+    // (huge trust radius at convergence); the sequential band Cholesky is the exact fallback.  Purely local: no collective yet.
+    rc = solve_local(c, w, radius, true, &bcr_used);
+  }
+  if (rc != LVX_OK && rc != LVX_E_NOTPD) return rc;
+  bool notpd = rc == LVX_E_NOTPD;
+  if (c->ar_fn) {
+    // [S (14 x 14, canonical slots) | rhs (14) | not-positive-definite votes]: ONE sum over the ranks
+    double buf[LVX_N_SHARED * LVX_N_SHARED + LVX_N_SHARED + 1] = {0};
+    double hs[LVX_N_SHARED * LVX_N_SHARED], hr[LVX_N_SHARED];
+    if (ns > 0 && !notpd) {
+      LVX_HIP(c, hipMemcpy2DAsync(hs, (size_t)ns * 8, w.S + (size_t)np * nbd + np, (size_t)nbd * 8, (size_t)ns * 8, ns, hipMemcpyDeviceToHost, st));
+      LVX_HIP(c, hipMemcpyAsync(hr, w.rhs + np, (size_t)ns * 8, hipMemcpyDeviceToHost, st));
+      LVX_HIP(c, hipStreamSynchronize(st));
+      for (int a = 0; a < ns; ++a) {
+        for (int b = 0; b <= a; ++b) buf[c->sh_slot[a] * LVX_N_SHARED + c->sh_slot[b]] = hs[a * ns + b];
+        buf[LVX_N_SHARED * LVX_N_SHARED + c->sh_slot[a]] = hr[a];
+      }
+    }
+    buf[LVX_N_SHARED * LVX_N_SHARED + LVX_N_SHARED] = notpd ? 1.0 : 0.0;
+    if ((rc = reduce(c, buf, LVX_N_SHARED * LVX_N_SHARED + LVX_N_SHARED + 1, LVX_REDUCE_SUM))) return rc;
+    if (buf[LVX_N_SHARED * LVX_N_SHARED + LVX_N_SHARED] > 0.0) notpd = true;
+    if (!notpd && ns > 0) {
+      // the same ns x ns Cholesky on every rank (identical inputs): shared damping is added once, here
+      double A[LVX_N_SHARED][LVX_N_SHARED], y[LVX_N_SHARED];
+      for (int a = 0; a < ns; ++a) { for (int b = 0; b <= a; ++b) A[a][b] = buf[c->sh_slot[a] * LVX_N_SHARED + c->sh_slot[b]]; A[a][a] += c->sh_lmd[a] * ir; y[a] = buf[LVX_N_SHARED * LVX_N_SHARED + c->sh_slot[a]]; }
+      for (int k = 0; k < ns && !notpd; ++k) {
+        if (!(A[k][k] > 0.0)) { notpd = true; break; }
+        A[k][k] = std::sqrt(A[k][k]);
+        for (int r = k + 1; r < ns; ++r) A[r][k] /= A[k][k];
+        for (int r = k + 1; r < ns; ++r) for (int q = k + 1; q <= r; ++q) A[r][q] -= A[r][k] * A[q][k];
+      }
+      if (!notpd) {
+        for (int i = 0; i < ns; ++i) { double t = y[i]; for (int k = 0; k < i; ++k) t -= A[i][k] * y[k]; y[i] = t / A[i][i]; }
+        for (int i = ns - 1; i >= 0; --i) { double t = y[i]; for (int k = i + 1; k < ns; ++k) t -= A[k][i] * y[k]; y[i] = t / A[i][i]; }
+        LVX_HIP(c, hipMemcpyAsync(w.rhs + np, y, (size_t)ns * 8, hipMemcpyHostToDevice, st));
+        LVX_HIP(c, hipStreamSynchronize(st));   // y lives on this stack frame
+      }
+    }
+  }
+  if (notpd) { if (rc == LVX_OK) fail(c, LVX_E_NOTPD, "joint reduced system not positive definite"); out[0] = out[1] = out[2] = 0.0; return LVX_E_NOTPD; }
+  hipLaunchKernelGGL(k_dense_back, dim3(1), dim3(64), 0, st, (const double*)w.S, w.rhs, nbd, np);
+  const int ldz = w.ldz;
+  double* Zf = w.Z;
   double* zb = Zf + (size_t)nbd * std::max(ldz, 1);
   if (nb > 0) {
     hipLaunchKernelGGL(k_sub_border, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const double*)Zf, (const double*)w.rhs, nb, nbd, ldz, zb);
-    if (use_bcr) {
+    if (bcr_used) {
       int rc2;
       if ((rc2 = bcr_backward(c, zb, zb, ldz, 1))) return rc2;
     } else {
@@ -460,35 +551,47 @@ static int solve_step_device_impl(lvx_ctx* c, SolveWork& w, double radius, doubl
   hipLaunchKernelGGL(k_quad, dim3((unsigned)((nb + nbd + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)c->d_Bd.p, (const double*)c->d_C.p, c->nbd_ext,
                      (const double*)zb, (const double*)w.rhs, (const double*)w.scale, nb, bw, nbd, w.sums);
   LVX_HIP(c, hipGetLastError());
-  double h[8]; int info[4] = {0, 0, 0, 0};
+  double h[8];
   LVX_HIP(c, hipMemcpyAsync(h, w.sums, 8 * 8, hipMemcpyDeviceToHost, st));
-  LVX_HIP(c, hipMemcpyAsync(info, w.info, 16, hipMemcpyDeviceToHost, st));
   LVX_HIP(c, hipStreamSynchronize(st));
-  if (info[0] || info[1]) { double dv; memcpy(&dv, info + 2, 8); return fail(c, LVX_E_NOTPD, "damped normal equations not positive definite (band pivot code " + std::to_string(info[0]) + ", first border pivot " + std::to_string(info[1]) + " value " + std::to_string(dv) + ")"); }
-  // model_cost_change = -(g.delta + 1/2 delta^T H delta)   (TrustRegionMinimizer: -model_residuals.(residuals + model_residuals / 2))
-  out[0] = -h[0] - 0.5 * h[5]; out[1] = h[0]; out[2] = h[1];
+  // model_cost_change = -(g.delta + 1/2 delta^T H delta)   (TrustRegionMinimizer: -model_residuals.(residuals + model_residuals / 2));
+  // joint problem: H = sum_r H_r, g = sum_r g_r with delta_r = [private_r | shared]  =>  both terms are sums over the ranks
+  double m[3] = {h[0], h[5], h[1]};
+  if ((rc = reduce(c, m, 3, LVX_REDUCE_SUM))) return rc;
+  out[0] = -m[0] - 0.5 * m[1]; out[1] = m[0]; out[2] = m[2];
   return LVX_OK;
-}
-
-static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double* out) {
-  int rc = solve_step_device_impl(c, w, radius, out, false);
-  if (rc == LVX_E_NOTPD && w.use_bcr) {
-    // the cyclic-reduction elimination order can lose positive definiteness in floating point on nearly singular systems
-    // (huge trust radius at convergence); the sequential band Cholesky is the exact fallback
-    rc = solve_step_device_impl(c, w, radius, out, true);
-  }
-  return rc;
 }
 
 static int prepare_diag(lvx_ctx* c, SolveWork& w, bool compute_scale, int use_scaling, double mn, double mx) {
   const int n = c->nb + c->nbd;
   hipStream_t st = c->stream;
   hipLaunchKernelGGL(k_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)c->d_C.p, c->nb, c->bw, c->nbd, c->nbd_ext, w.diag);
+  const int ns = c->ns;
+  double* dsh = w.diag + (n - ns);
+  if (c->ar_fn) {   // diagonal of the JOINT normal equations at the shared scalars: Jacobi scaling and LM damping must agree on every rank
+    double buf[LVX_N_SHARED] = {0}, h[LVX_N_SHARED];
+    if (ns > 0) { LVX_HIP(c, hipMemcpyAsync(h, dsh, (size_t)ns * 8, hipMemcpyDeviceToHost, st)); LVX_HIP(c, hipStreamSynchronize(st)); }
+    for (int i = 0; i < ns; ++i) buf[c->sh_slot[i]] = h[i];
+    int rc = reduce(c, buf, LVX_N_SHARED, LVX_REDUCE_SUM); if (rc) return rc;
+    for (int i = 0; i < ns; ++i) h[i] = buf[c->sh_slot[i]];
+    if (ns > 0) { LVX_HIP(c, hipMemcpyAsync(dsh, h, (size_t)ns * 8, hipMemcpyHostToDevice, st)); LVX_HIP(c, hipStreamSynchronize(st)); }
+  }
   if (compute_scale) hipLaunchKernelGGL(k_scale_from_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)w.diag, n, w.scale, use_scaling);
   hipLaunchKernelGGL(k_lm_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)w.diag, (const double*)w.scale, n, mn, mx, w.lmd);
+  if (c->ar_fn && ns > 0) {   // shared damping is applied once to the reduced system (solve_step_device), not per rank
+    LVX_HIP(c, hipMemcpyAsync(c->sh_lmd, w.lmd + (n - ns), (size_t)ns * 8, hipMemcpyDeviceToHost, st));
+    LVX_HIP(c, hipStreamSynchronize(st));
+    LVX_HIP(c, hipMemsetAsync(w.lmd + (n - ns), 0, (size_t)ns * 8, st));
+  }
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
 }
+
+struct HookScope {   // installs the all-reduce hook for the duration of one API call
+  lvx_ctx* c;
+  HookScope(lvx_ctx* ctx, lvx_allreduce_fn fn, void* user) : c(ctx) { c->ar_fn = fn; c->ar_user = user; }
+  ~HookScope() { c->ar_fn = nullptr; c->ar_user = nullptr; c->ns = 0; }
+};
 
 extern "C" {
 
@@ -500,10 +603,11 @@ int lvx_lm_default_options(lvx_lm_options* o) {
   return LVX_OK;
 }
 
-int lvx_solve_step(lvx_ctx* c, double radius, int jacobi_scaling, double* delta, double* model_cost_change) {
+int lvx_solve_step_shared(lvx_ctx* c, double radius, int jacobi_scaling, lvx_allreduce_fn fn, void* user, double* delta, double* model_cost_change) {
   if (!c || !(radius > 0)) return LVX_E_ARG;
   if (!(c->last_what & LVX_EVAL_NORMAL_EQ)) return fail(c, LVX_E_STATE, "lvx_solve_step needs a preceding LVX_EVAL_NORMAL_EQ evaluation");
   LVX_HIP(c, hipSetDevice(c->device));
+  HookScope hook(c, fn, user);
   SolveWork w; int rc = solver_alloc(c, w); if (rc) return rc;
   if ((rc = prepare_diag(c, w, true, jacobi_scaling, 1e-6, 1e32))) return rc;
   double out[3];
@@ -512,12 +616,16 @@ int lvx_solve_step(lvx_ctx* c, double radius, int jacobi_scaling, double* delta,
   if (delta) LVX_HIP(c, hipMemcpy(delta, w.delta, (size_t)lvx_tangent_size(c) * 8, hipMemcpyDeviceToHost));
   return LVX_OK;
 }
+int lvx_solve_step(lvx_ctx* c, double radius, int jacobi_scaling, double* delta, double* model_cost_change) {
+  return lvx_solve_step_shared(c, radius, jacobi_scaling, nullptr, nullptr, delta, model_cost_change);
+}
 
-int lvx_lm_solve(lvx_ctx* c, double* state, const lvx_lm_options* opt_in, lvx_lm_summary* sum) {
+int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in, lvx_allreduce_fn fn, void* user, lvx_lm_summary* sum) {
   if (!c || !state) return LVX_E_ARG;
   lvx_lm_options o; lvx_lm_default_options(&o); if (opt_in) o = *opt_in;
   LVX_HIP(c, hipSetDevice(c->device));
   int rc = ensure_layout(c); if (rc) return rc;
+  HookScope hook(c, fn, user);
   SolveWork w; if ((rc = solver_alloc(c, w))) return rc;
   hipStream_t st = c->stream;
   const size_t sbytes = (size_t)lvx_state_size(c) * 8;
@@ -526,20 +634,34 @@ int lvx_lm_solve(lvx_ctx* c, double* state, const lvx_lm_options* opt_in, lvx_lm
   LVX_HIP(c, hipMemcpyAsync(x, state, sbytes, hipMemcpyHostToDevice, st));
   c->lm_cost.clear(); c->lm_radius.clear(); c->lm_accept.clear();
   lvx_lm_summary s{}; s.termination = LVX_LM_NO_CONVERGENCE;
+  const bool joint = fn != nullptr;
+  // cost of the joint problem = sum of the sequences' costs; a rank whose candidate cannot be evaluated contributes +inf
+  auto joint_cost = [&](double* v) -> int { return reduce(c, v, 1, LVX_REDUCE_SUM); };
   double cost = 0;
   if ((rc = lvx_evaluate_d(c, x, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &cost))) return rc;
+  if ((rc = joint_cost(&cost))) return rc;
   s.initial_cost = cost;
   if ((rc = prepare_diag(c, w, true, o.jacobi_scaling, o.min_lm_diagonal, o.max_lm_diagonal))) return rc;
   double radius = o.initial_radius, decrease_factor = 2.0;
   bool reuse_diagonal = false;
   int invalid = 0;
-  const int nt = lvx_tangent_size(c), N = c->N, L = c->L;
+  const int N = c->N, L = c->L;
+  // max |g| over the free scalars; joint problem: the shared entries of g are sums over the ranks
   auto gmax = [&](double* g) -> int {
     LVX_HIP(c, hipMemsetAsync(w.sums + 4, 0, 8, st));
-    const int n = c->nb + c->nbd;
-    hipLaunchKernelGGL(k_gmax, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)c->d_gb.p, (const double*)c->d_gc.p, c->nb, c->nbd, w.sums);
+    const int n = c->nb + c->nbd - c->ns;
+    hipLaunchKernelGGL(k_gmax, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)c->d_gb.p, (const double*)c->d_gc.p, c->nb, c->nbd - c->ns, w.sums);
+    double gs[LVX_N_SHARED] = {0}, hsh[LVX_N_SHARED];
     LVX_HIP(c, hipMemcpyAsync(g, w.sums + 4, 8, hipMemcpyDeviceToHost, st));
+    if (c->ns > 0) LVX_HIP(c, hipMemcpyAsync(hsh, (const double*)c->d_gc.p + (c->nbd - c->ns), (size_t)c->ns * 8, hipMemcpyDeviceToHost, st));
     LVX_HIP(c, hipStreamSynchronize(st));
+    if (joint) {
+      int r2;
+      for (int i = 0; i < c->ns; ++i) gs[c->sh_slot[i]] = hsh[i];
+      if ((r2 = reduce(c, gs, LVX_N_SHARED, LVX_REDUCE_SUM))) return r2;
+      if ((r2 = reduce(c, g, 1, LVX_REDUCE_MAX))) return r2;
+      for (int k = 0; k < LVX_N_SHARED; ++k) *g = std::max(*g, std::fabs(gs[k]));
+    }
     return LVX_OK;
   };
   double g0 = 0; if ((rc = gmax(&g0))) return rc;
@@ -553,7 +675,7 @@ int lvx_lm_solve(lvx_ctx* c, double* state, const lvx_lm_options* opt_in, lvx_lm
     rc = solve_step_device(c, w, radius, out);
     bool step_valid = (rc == LVX_OK) && std::isfinite(out[0]) && out[0] > 0.0;
     if (rc != LVX_OK && rc != LVX_E_NOTPD) return rc;
-    if (!step_valid && o.verbose) fprintf(stderr, "[lvx lm] it %3d invalid step: rc %d (%s) model_cost_change %.6e g.delta %.6e dHd %.6e\n", it, rc, c->last_error.c_str(), out[0], out[1], 0.0);
+    if (!step_valid && o.verbose) fprintf(stderr, "[lvx lm] it %3d invalid step: rc %d (%s) model_cost_change %.6e g.delta %.6e\n", it, rc, c->last_error.c_str(), out[0], out[1]);
     if (!step_valid) {   // TrustRegionMinimizer::HandleInvalidStep + LevenbergMarquardtStrategy::StepIsInvalid
       if (++invalid > 5) { s.termination = LVX_LM_FAILURE; break; }
       radius *= 0.5; reuse_diagonal = true;
@@ -561,14 +683,20 @@ int lvx_lm_solve(lvx_ctx* c, double* state, const lvx_lm_options* opt_in, lvx_lm
       continue;
     }
     invalid = 0;
-    LVX_HIP(c, hipMemsetAsync(w.sums + 2, 0, 16, st));
-    hipLaunchKernelGGL(k_plus, dim3((unsigned)((N + 1 + L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, N, L, c->locks, xt, w.sums);
+    LVX_HIP(c, hipMemsetAsync(w.sums + 2, 0, 48, st));
+    hipLaunchKernelGGL(k_plus, dim3((unsigned)((N + 1 + L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, N, L, c->locks, xt, w.sums, joint ? 1 : 0);
     double cand = 0;
     // cost-only evaluation of the candidate must not clobber the normal equations of x: LVX_EVAL_COST alone leaves them untouched
     if ((rc = lvx_evaluate_d(c, xt, LVX_EVAL_COST, &cand))) { if (rc == LVX_E_RANGE || rc == LVX_E_NONUNIT_QUAT) cand = INFINITY; else return rc; }
     c->last_what |= LVX_EVAL_NORMAL_EQ;
-    double h[2];
-    LVX_HIP(c, hipMemcpy(h, w.sums + 2, 16, hipMemcpyDeviceToHost));
+    if ((rc = joint_cost(&cand))) return rc;
+    double h[6];
+    LVX_HIP(c, hipMemcpy(h, w.sums + 2, 48, hipMemcpyDeviceToHost));
+    if (joint) {   // private blocks summed over the ranks, the shared blocks (identical on every rank) counted once
+      double pn[2] = {h[0], h[1]};
+      if ((rc = reduce(c, pn, 2, LVX_REDUCE_SUM))) return rc;
+      h[0] = pn[0] + h[4]; h[1] = pn[1] + h[5];
+    }
     const double step_norm = std::sqrt(h[0]), x_norm = std::sqrt(h[1]);
     if (step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) { s.termination = LVX_LM_PARAMETER_TOLERANCE; c->lm_cost.push_back(cost); c->lm_radius.push_back(radius); c->lm_accept.push_back(0); break; }
     const double cost_change = cost - cand;
@@ -598,8 +726,10 @@ int lvx_lm_solve(lvx_ctx* c, double* state, const lvx_lm_options* opt_in, lvx_lm
   LVX_HIP(c, hipMemcpyAsync(state, x, sbytes, hipMemcpyDeviceToHost, st));
   LVX_HIP(c, hipStreamSynchronize(st));
   if (sum) *sum = s;
-  (void)nt;
   return LVX_OK;
+}
+int lvx_lm_solve(lvx_ctx* c, double* state, const lvx_lm_options* opt_in, lvx_lm_summary* sum) {
+  return lvx_lm_solve_shared(c, state, opt_in, nullptr, nullptr, sum);
 }
 
 int lvx_lm_get_history(lvx_ctx* c, int max_n, double* cost, double* radius, int32_t* accepted) {

@@ -262,11 +262,54 @@ class Context:
         out.update(cost_history=cost[:k], radius_history=rad[:k], accepted=acc[:k])
         return x, out
 
+    # ---- joint solve over sequences that share the rig extrinsics (one context / GPU per sequence) ----
+    @staticmethod
+    def _hook(allreduce):
+        """ctypes trampoline for lvx_allreduce_fn: allreduce(vec: np.ndarray[float64], op: 'sum' | 'max') reduces IN PLACE over all ranks."""
+        def fn(_user, buf, n, op):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(n,)), "sum" if op == 0 else "max")
+                return 0
+            except Exception:   # noqa: BLE001 — must not unwind through C
+                import traceback
+                traceback.print_exc()
+                return 1
+        return ALLREDUCE_FN(fn)
+
+    def solve_step_shared(self, radius, allreduce, jacobi_scaling=True):
+        delta = np.zeros(self.tangent_size)
+        mcc = C.c_double(0)
+        cb = self._hook(allreduce)
+        self._ck(self._l.lvx_solve_step_shared(self._h, C.c_double(radius), C.c_int(1 if jacobi_scaling else 0), cb, None, _p(delta), C.byref(mcc)))
+        return delta, mcc.value
+
+    def lm_solve_shared(self, state, allreduce, max_iterations=50, **kw):
+        """LM on the JOINT problem of all ranks' sequences; every rank calls this with its own sequence loaded and the same options."""
+        opt = LmOptions()
+        self._l.lvx_lm_default_options(C.byref(opt))
+        opt.max_iterations = max_iterations
+        for k, v in kw.items():
+            setattr(opt, k, v)
+        x = _d(state).copy()
+        sm = LmSummary()
+        cb = self._hook(allreduce)
+        self._ck(self._l.lvx_lm_solve_shared(self._h, _p(x), C.byref(opt), cb, None, C.byref(sm)))
+        n = 4 * max_iterations + 8
+        cost, rad, acc = np.zeros(n), np.zeros(n), np.zeros(n, dtype=np.int32)
+        k = self._l.lvx_lm_get_history(self._h, C.c_int(n), _p(cost), _p(rad), _p(acc))
+        out = {f: getattr(sm, f) for f, _ in LmSummary._fields_}
+        out["termination"] = LM_TERMINATION[sm.termination]
+        out.update(cost_history=cost[:k], radius_history=rad[:k], accepted=acc[:k])
+        return x, out
+
     def plus(self, state, delta):
         state, delta = _d(state), _d(delta)
         out = np.zeros_like(state)
         self._ck(self._l.lvx_plus(self._h, _p(state), _p(delta), _p(out)))
         return out
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
 
 
 RS_POINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad", "<f4"), ("intensity", "u1"), ("pad2", "u1"), ("ring", "<u2"),

@@ -68,3 +68,40 @@ def torch_all_reduce(dist):
         dist.all_reduce(t)
         return vec
     return fn
+
+
+def dist_all_reduce(dist, device=None):
+    """allreduce(vec, op) for lvx.Context.lm_solve_shared over torch.distributed: 'gloo' reduces the host buffer directly,
+    'nccl' (= RCCL on ROCm) stages the <= 211 doubles through a device tensor."""
+    import torch
+
+    def fn(vec, op):
+        rop = dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX
+        if device is None:
+            dist.all_reduce(torch.from_numpy(vec), op=rop)
+        else:
+            t = torch.from_numpy(vec).to(device)
+            dist.all_reduce(t, op=rop)
+            vec[:] = t.cpu().numpy()
+    return fn
+
+
+class ThreadAllReduce:
+    """In-process all-reduce between `world` threads (one lvx.Context per thread): used to drive several sequences on ONE GPU,
+    e.g. the single-GPU parity test of the joint solve."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.bar = threading.Barrier(world)
+        self.slots = [None] * world
+
+    def rank_fn(self, rank):
+        def fn(vec, op):
+            self.slots[rank] = vec.copy()
+            self.bar.wait()
+            stack = np.stack(self.slots)
+            res = stack.sum(axis=0) if op == "sum" else stack.max(axis=0)
+            self.bar.wait()
+            vec[:] = res
+        return fn

@@ -51,10 +51,11 @@ def solve_step(H, g, free, radius, scale=None, lm_diag=None, min_diag=1e-6, max_
 
 
 def lm_solve(oracle, state, free, max_iterations=50, initial_radius=1e4, max_radius=1e16, min_radius=1e-32, min_relative_decrease=1e-3,
-             function_tolerance=1e-6, gradient_tolerance=1e-10, parameter_tolerance=1e-8, jacobi_scaling=True, n_knots=None, n_landmarks=0):
+             function_tolerance=1e-6, gradient_tolerance=1e-10, parameter_tolerance=1e-8, jacobi_scaling=True, n_knots=None, n_landmarks=0, mask=None):
     x = np.array(state, dtype=np.float64)
     free = np.asarray(free)
-    mask = free_state_mask(n_knots, n_landmarks, free)
+    if mask is None:   # ambient entries of the free parameter blocks (a joint multi-sequence problem passes its own)
+        mask = free_state_mask(n_knots, n_landmarks, free)
     ev = oracle.evaluate(x, normal_eq=True)
     cost, H, g = ev["cost"], ev["H"], ev["g"]
     scale = 1.0 / (1.0 + np.sqrt(np.maximum(np.diag(H)[free], 0.0))) if jacobi_scaling else np.ones(len(free))

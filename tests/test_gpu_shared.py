@@ -1,0 +1,155 @@
+"""GPU parity of the sequence-per-GPU JOINT solve (lvx_solve_step_shared / lvx_lm_solve_shared): two calibration
+sequences with private trajectories / biases / landmarks and SHARED rig extrinsics.  Each sequence lives in its own lvx.Context; the two
+ranks run in two threads of this process (one GPU) and meet in an in-process all-reduce (sharded.ThreadAllReduce) — the same callback
+ABI takes torch.distributed (RCCL) on a multi-GPU node.  Reference: the joint problem assembled densely from the oracle's per-sequence
+J^T J (private blocks block-diagonal, shared block summed) and solved by the numpy LM of oracle/lm.py.
+
+Tolerances: one damped step within 1e-7 of the dense joint solve (relative to the largest entry); LM — same accept / reject sequence,
+cost history within 1e-7 relative, extrinsics within 1e-6 rad / 1e-4 m, and bitwise-identical shared variables on both ranks.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+import lvx
+import sharded
+import synth
+from oracle import lm
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+TAU = lvx.LOCK_LIDAR_TAU | lvx.LOCK_CAM_TAU
+WORLD = 2
+
+
+def _sequences():
+    seqs = []
+    ref = None
+    for r in range(WORLD):
+        P = synth.make_problem(seed=40 + r, duration=1.0 + 0.3 * r, n_surfel=250, n_planes=8, n_landmarks=12, n_camsurf=0)
+        N = P["n_knots"]
+        s = P["state0"].copy()
+        if ref is None:
+            ref = s[7 * N + 16:7 * N + 32].copy()
+        s[7 * N + 16:7 * N + 32] = ref          # the shared extrinsics start from ONE guess
+        seqs.append((P, s))
+    return seqs
+
+
+class JointOracle:
+    """The joint problem for oracle/lm.py: state = [state_0 | state_1], tangent = [tangent_0 | tangent_1] with rank 1's shared scalars
+    aliased onto rank 0's."""
+
+    def __init__(self, seqs):
+        self.P = [p for p, _ in seqs]
+        self.o = []
+        for P in self.P:
+            o = O.Oracle(); lvx.load_problem(o, P, TAU); self.o.append(o)
+        self.ns = [len(s) for _, s in seqs]
+        self.nt = [o.tangent_size for o in self.o]
+        self.sh = [sharded.shared_tangent_indices(P["n_knots"]) for P in self.P]
+        free = [lm.free_tangent_indices(P["n_knots"], P["n_landmarks"], TAU) for P in self.P]
+        self.free = np.concatenate([free[0], self.nt[0] + np.setdiff1d(free[1], self.sh[1])])
+        m0 = lm.free_state_mask(self.P[0]["n_knots"], self.P[0]["n_landmarks"], free[0])
+        m1 = lm.free_state_mask(self.P[1]["n_knots"], self.P[1]["n_landmarks"], free[1])
+        N1 = self.P[1]["n_knots"]
+        m1[7 * N1 + 16:7 * N1 + 32] = False     # shared blocks counted once
+        self.mask = np.concatenate([m0, m1])
+
+    def split(self, x):
+        return x[:self.ns[0]], x[self.ns[0]:]
+
+    def evaluate(self, x, normal_eq=False):
+        xs = self.split(x)
+        ev = [o.evaluate(xi, normal_eq=normal_eq) for o, xi in zip(self.o, xs)]
+        out = {"cost": ev[0]["cost"] + ev[1]["cost"]}
+        if normal_eq:
+            n0, n1 = self.nt
+            H = np.zeros((n0 + n1, n0 + n1)); g = np.zeros(n0 + n1)
+            H[:n0, :n0] = ev[0]["H"]; g[:n0] = ev[0]["g"]
+            H1, g1 = ev[1]["H"], ev[1]["g"]
+            idx = n0 + np.arange(n1)
+            idx[self.sh[1]] = self.sh[0]        # alias
+            np.add.at(H, (idx[:, None], idx[None, :]), H1)
+            np.add.at(g, idx, g1)
+            out["H"], out["g"] = H, g
+        return out
+
+    def plus(self, x, delta):
+        n0 = self.nt[0]
+        d0 = delta[:n0]
+        d1 = delta[n0:].copy()
+        d1[self.sh[1]] = d0[self.sh[0]]
+        xs = self.split(x)
+        return np.concatenate([self.o[0].plus(xs[0], d0), self.o[1].plus(xs[1], d1)])
+
+
+def _run_ranks(seqs, body):
+    """body(rank, ctx, allreduce) in one thread per rank; returns the per-rank results."""
+    ar = sharded.ThreadAllReduce(WORLD)
+    res, err = [None] * WORLD, [None] * WORLD
+
+    def work(r):
+        try:
+            g = lvx.Context(0)
+            lvx.load_problem(g, seqs[r][0], TAU)
+            res[r] = body(r, g, ar.rank_fn(r))
+            g.close()
+        except BaseException as e:   # noqa: BLE001
+            err[r] = e
+            ar.bar.abort()
+    th = [threading.Thread(target=work, args=(r,)) for r in range(WORLD)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    for e in err:
+        if e is not None:
+            raise e
+    return res
+
+
+@pytest.mark.parametrize("radius", [1e4, 3.0])
+def test_shared_step_equals_joint_dense_step(radius):
+    seqs = _sequences()
+    J = JointOracle(seqs)
+    x = np.concatenate([s for _, s in seqs])
+    ev = J.evaluate(x, normal_eq=True)
+    scale = 1.0 / (1.0 + np.sqrt(np.maximum(np.diag(ev["H"])[J.free], 0)))
+    d_ref, m_ref, _ = lm.solve_step(ev["H"], ev["g"], J.free, radius, scale)
+
+    def body(r, g, allreduce):
+        g.evaluate(seqs[r][1], normal_eq=True, dense=False)
+        return g.solve_step_shared(radius, allreduce)
+    res = _run_ranks(seqs, body)
+    n0 = J.nt[0]
+    d1_ref = d_ref[n0:].copy(); d1_ref[J.sh[1]] = d_ref[:n0][J.sh[0]]
+    tol = 1e-7 * np.abs(d_ref).max()
+    assert np.abs(res[0][0] - d_ref[:n0]).max() <= tol
+    assert np.abs(res[1][0] - d1_ref).max() <= tol
+    assert np.array_equal(res[0][0][J.sh[0]], res[1][0][J.sh[1]])       # the shared step is bitwise identical on both ranks
+    for r in range(WORLD):
+        assert abs(res[r][1] - m_ref) <= 1e-8 * abs(m_ref)               # model cost change of the JOINT problem
+
+
+def test_shared_lm_matches_joint_oracle_lm():
+    seqs = _sequences()
+    J = JointOracle(seqs)
+    x0 = np.concatenate([s for _, s in seqs])
+    xo, so = lm.lm_solve(J, x0, J.free, max_iterations=12, mask=J.mask)
+    res = _run_ranks(seqs, lambda r, g, allreduce: g.lm_solve_shared(seqs[r][1], allreduce, max_iterations=12))
+    for r in range(WORLD):
+        sg = res[r][1]
+        assert sg["iterations"] == so["iterations"] and sg["termination"] == so["termination"]
+        assert list(sg["accepted"]) == list(so["accepted"])
+        assert np.abs(sg["cost_history"] - so["cost_history"]).max() <= 1e-7 * so["cost_history"].max()
+    N = [P["n_knots"] for P, _ in seqs]
+    e = [res[r][0][7 * N[r] + 16:7 * N[r] + 32] for r in range(WORLD)]
+    assert np.array_equal(e[0], e[1])                                    # one set of extrinsics
+    eo = J.split(xo)[0][7 * N[0] + 16:7 * N[0] + 32]
+    for off in (0, 8):
+        d = synth.qmul(e[0][off:off + 4], synth.qconj(eo[off:off + 4]))
+        assert 2 * np.arctan2(np.linalg.norm(d[:3]), abs(d[3])) <= 1e-6
+        assert np.abs(e[0][off + 4:off + 7] - eo[off + 4:off + 7]).max() <= 1e-4
+    assert res[0][1]["final_cost"] < 1e-2 * res[0][1]["initial_cost"]

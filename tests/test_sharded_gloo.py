@@ -94,3 +94,36 @@ def test_two_sequences_sharded_step_equals_joint_step():
         assert abs(cost - sum(s[1]["cost"] for s in seqs)) <= 1e-9 * cost
         off += m
     assert np.abs(res[0][0][shared[0]] - res[1][0][shared[1]]).max() <= 1e-12 * np.abs(y_joint).max()   # every rank gets the same shared step
+
+
+def _ar_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fn = sharded.dist_all_reduce(dist)          # the callback lvx.Context.lm_solve_shared hands to lvx_lm_solve_shared
+    a = np.arange(5, dtype=np.float64) + 10 * rank
+    b = a.copy()
+    fn(a, "sum"); fn(b, "max")
+    out.put((rank, a, b))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allreduce_callback_sum_and_max():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ar_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, a, b in got:
+        assert np.array_equal(a, 2 * np.arange(5) + 10.0) and np.array_equal(b, np.arange(5) + 10.0)
+    th = sharded.ThreadAllReduce(1).rank_fn(0)
+    v = np.array([1.0, 2.0]); th(v, "sum")
+    assert np.array_equal(v, [1.0, 2.0])
