@@ -64,68 +64,122 @@ static int bcr_handle(lvx_ctx* c, rocblas_handle* h) {
 // ---------------------------------------------------------------------------------------------------------
 // Batched multi-vector triangular solve with a dense lower factor L (b x b, column-major): in place L w = v (TRANS = false) or
 // L^T w = v (TRANS = true) for `nvec` vectors per batch element.  Vector k, element i lives at V[k * sv + i * se].
-// One wavefront per (64 vectors, batch element); the vectors sit in LDS (row-major, padded), L streams through LDS in
-// 16-column panels.  (rocBLAS' strided-batched TRSM turns into thousands of tiny launches at b ~ 200, and explicit inverses
-// lose positive definiteness of the Schur complements on weakly constrained problems, so this step is hand-written.)
+// A workgroup holds 64 vectors of one batch element in LDS (W[row][vector]); each of its 4 wavefronts owns 16 of them, so the waves only
+// meet to load L, which streams through LDS in 16-column panels.  Per panel: the 16 x 16 diagonal triangle is solved by substitution
+// (lanes 0..15, one vector each), everything else is a rank-16 update on the FP64 matrix cores (v_mfma_f64_16x16x4_f64):
+//   forward : W[i0.., vectors] -= L[i0.., panel] w[panel, vectors]        one 16 x 16 tile per 16 rows below the panel
+//   backward: v[panel, vectors] -= L[rows below, panel]^T w[rows below]   one accumulator tile, k-steps over the rows below
+// (rocBLAS' strided-batched TRSM turns into thousands of tiny launches at b ~ 200, and explicit inverses of the blocks lose positive
+// definiteness of the Schur complements on weakly constrained problems, so this step is hand-written; no inverse is formed.)
 // ---------------------------------------------------------------------------------------------------------
-#define TRS_PANEL 16
-#define TRS_G 4   // wavefronts per workgroup: each handles every TRS_G-th row of the 64 vectors
+typedef double d4 __attribute__((ext_vector_type(4)));
+#define TRS_WS 65   // row stride of W (odd: conflict-free for lane = vector and for lane = row)
 template <bool TRANS>
-__global__ __launch_bounds__(64 * TRS_G) void k_trsv_batched(const double* __restrict__ Lm, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec) {
+__global__ __launch_bounds__(256) void k_trsm_batched(const double* __restrict__ Lm, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec) {
   extern __shared__ double lds[];
-  double* W = lds;                        // [b][65]
-  double* P = lds + (size_t)b * 65;       // [TRS_PANEL][b] panel of L columns
-  double* R = P + (size_t)TRS_PANEL * b;  // [TRS_G][64] partial sums (TRANS)
-  const int t = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int vec = blockIdx.x * 64 + t;
-  const bool act = vec < nvec;
+  const int bp = (b + 15) & ~15;           // rows padded to whole MFMA tiles
+  const int PS = bp | 1;                   // panel row stride (odd)
+  double* W = lds;                         // [bp][TRS_WS]
+  double* P = W + (size_t)bp * TRS_WS;     // [16][PS]: P[kk][i] = L[i][k0 + kk] for i >= k0 + kk, zero above the diagonal and in the padding
+  double* dinv = P + 16 * PS;              // [16] reciprocals of the panel's diagonal
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int t0 = wv * 16;                  // this wave's 16 vectors
+  const int vec0 = blockIdx.x * 64;
   const double* L = Lm + (size_t)blockIdx.y * strideL;
-  double* v = V + (size_t)blockIdx.y * strideV + (size_t)vec * sv;
-  for (int i = g; i < b; i += TRS_G) W[i * 65 + t] = act ? v[(size_t)i * se] : 0.0;
+  double* v0 = V + (size_t)blockIdx.y * strideV + (size_t)vec0 * sv;
+  const int nv = min(64, nvec - vec0);
+  for (int e = tid; e < bp * TRS_WS; e += 256) W[e] = 0.0;
+  __syncthreads();
+  if (se == 1) { for (int e = tid; e < nv * b; e += 256) { const int i = e % b, t = e / b; W[i * TRS_WS + t] = v0[(size_t)t * sv + i]; } }
+  else { for (int e = tid; e < 64 * b; e += 256) { const int t = e & 63, i = e >> 6; if (t < nv) W[i * TRS_WS + t] = v0[(size_t)t * sv + (size_t)i * se]; } }
+  const int fk = lane >> 4, fi = lane & 15;
+  auto load_panel = [&](int k0) {
+    __syncthreads();                       // the previous panel is no longer read
+    for (int e = tid; e < 16 * bp; e += 256) {
+      const int kk = e / bp, i = e % bp, k = k0 + kk;
+      double v = 0.0;
+      if (k < b) { if (i >= k && i < b) v = L[(size_t)k * b + i]; } else if (i == k) v = 1.0;
+      P[kk * PS + i] = v;
+    }
+    __syncthreads();
+    if (tid < 16) dinv[tid] = 1.0 / P[tid * PS + k0 + tid];
+    __syncthreads();
+  };
   if (!TRANS) {
-    for (int k0 = 0; k0 < b; k0 += TRS_PANEL) {
-      const int nk = min(TRS_PANEL, b - k0);
-      __syncthreads();
-      for (int e = threadIdx.x; e < nk * b; e += 64 * TRS_G) { const int kk = e / b, i = e % b; P[kk * b + i] = i >= k0 + kk ? L[(size_t)(k0 + kk) * b + i] : 0.0; }
-      __syncthreads();
-      for (int kk = 0; kk < nk; ++kk) {
-        const int k = k0 + kk;
-        const double* col = &P[kk * b];
-        const double wk = W[k * 65 + t] / col[k];
-        __syncthreads();                       // everyone has read v_k before it is replaced by w_k
-        if (g == 0) W[k * 65 + t] = wk;
-        for (int i = k + 1 + g; i < b; i += TRS_G) W[i * 65 + t] -= col[i] * wk;
-        __syncthreads();                       // row k + 1 is final
+    for (int k0 = 0; k0 < b; k0 += 16) {
+      load_panel(k0);
+      if (lane < 16) {                     // 16 x 16 lower-triangular solve, column oriented: 15 - q independent updates per step
+        double x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = W[(k0 + r) * TRS_WS + t0 + lane];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          x[q] *= dinv[q];
+#pragma unroll
+          for (int r = q + 1; r < 16; ++r) x[r] -= P[q * PS + k0 + r] * x[q];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) W[(k0 + r) * TRS_WS + t0 + lane] = x[r];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      double Bf[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) Bf[ks] = W[(k0 + ks * 4 + fk) * TRS_WS + t0 + fi];
+      for (int i0 = k0 + 16; i0 < bp; i0 += 16) {
+        d4 Cc;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Cc[v] = W[(i0 + fk + 4 * v) * TRS_WS + t0 + fi];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) Cc = __builtin_amdgcn_mfma_f64_16x16x4f64(-P[(ks * 4 + fk) * PS + i0 + fi], Bf[ks], Cc, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) W[(i0 + fk + 4 * v) * TRS_WS + t0 + fi] = Cc[v];
       }
     }
   } else {
-    for (int k1 = b; k1 > 0; k1 -= TRS_PANEL) {
-      const int k0 = max(0, k1 - TRS_PANEL), nk = k1 - k0;
-      __syncthreads();
-      for (int e = threadIdx.x; e < nk * b; e += 64 * TRS_G) { const int kk = e / b, i = e % b; P[kk * b + i] = i >= k0 + kk ? L[(size_t)(k0 + kk) * b + i] : 0.0; }
-      __syncthreads();
-      for (int kk = nk - 1; kk >= 0; --kk) {
-        const int k = k0 + kk;
-        const double* col = &P[kk * b];
-        double part = 0.0;
-        for (int i = k + 1 + g; i < b; i += TRS_G) part += col[i] * W[i * 65 + t];
-        R[g * 64 + t] = part;
-        __syncthreads();
-        if (g == 0) { double sacc = W[k * 65 + t]; for (int q = 0; q < TRS_G; ++q) sacc -= R[q * 64 + t]; W[k * 65 + t] = sacc / col[k]; }
-        __syncthreads();
+    for (int k0 = bp - 16; k0 >= 0; k0 -= 16) {
+      load_panel(k0);
+      d4 Cc;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) Cc[v] = W[(k0 + fk + 4 * v) * TRS_WS + t0 + fi];
+      for (int i0 = k0 + 16; i0 < bp; i0 += 4)
+        Cc = __builtin_amdgcn_mfma_f64_16x16x4f64(-P[fi * PS + i0 + fk], W[(i0 + fk) * TRS_WS + t0 + fi], Cc, 0, 0, 0);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) W[(k0 + fk + 4 * v) * TRS_WS + t0 + fi] = Cc[v];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (lane < 16) {                     // 16 x 16 transposed-triangular solve, rows 15 .. 0
+        double x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = W[(k0 + r) * TRS_WS + t0 + lane];
+#pragma unroll
+        for (int q = 15; q >= 0; --q) {
+          x[q] *= dinv[q];
+#pragma unroll
+          for (int r = 0; r < q; ++r) x[r] -= P[r * PS + k0 + q] * x[q];   // L[k0+q][k0+r]
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) W[(k0 + r) * TRS_WS + t0 + lane] = x[r];
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   }
   __syncthreads();
-  if (act) for (int i = g; i < b; i += TRS_G) v[(size_t)i * se] = W[i * 65 + t];
+  if (se == 1) { for (int e = tid; e < nv * b; e += 256) { const int i = e % b, t = e / b; v0[(size_t)t * sv + i] = W[i * TRS_WS + t]; } }
+  else { for (int e = tid; e < 64 * b; e += 256) { const int t = e & 63, i = e >> 6; if (t < nv) v0[(size_t)t * sv + (size_t)i * se] = W[i * TRS_WS + t]; } }
 }
 template <bool TRANS>
 static int trsv_batched(lvx_ctx* c, const double* L, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, int batch) {
   if (batch <= 0 || nvec <= 0) return LVX_OK;
-  const size_t lds = ((size_t)b * 65 + (size_t)TRS_PANEL * b + (size_t)TRS_G * 64) * 8;
+  const int bp = (b + 15) & ~15;
+  const size_t lds = ((size_t)bp * TRS_WS + (size_t)16 * (bp | 1) + 16) * 8;
   if (lds > 158 * 1024) return fail(c, LVX_E_ARG, "block size too large for the LDS-resident triangular solve");
-  LVX_HIP(c, hipFuncSetAttribute((const void*)k_trsv_batched<TRANS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_trsv_batched<TRANS>, dim3((unsigned)((nvec + 63) / 64), (unsigned)batch), dim3(64 * TRS_G), lds, c->stream, L, b, strideL, V, se, sv, strideV, nvec);
+  LVX_HIP(c, hipFuncSetAttribute((const void*)k_trsm_batched<TRANS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_trsm_batched<TRANS>, dim3((unsigned)((nvec + 63) / 64), (unsigned)batch), dim3(256), lds, c->stream, L, b, strideL, V, se, sv, strideV, nvec);
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
 }

@@ -18,6 +18,8 @@
 #include <cstdlib>
 #include <vector>
 
+#include <chrono>
+
 #include "lvx_ctx.h"
 
 namespace lvx {
@@ -434,8 +436,15 @@ static int solver_alloc(lvx_ctx* c, SolveWork& w) {
 
 // Local half of one damped solve: factor the band, eliminate it and the private border variables.  On return the trailing ns x ns block
 // of w.S / w.rhs holds this sequence's contribution to the reduced system of the shared variables (all of the border system when ns = 0).
+struct StageTimer {   // LVX_SOLVER_TIMING=1: host wall time per stage (enqueue cost) and at the synchronisation points
+  bool on; std::chrono::steady_clock::time_point t;
+  StageTimer() : on(getenv("LVX_SOLVER_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void lap(const char* what) { if (!on) return; const auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[lvx solver] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count()); t = n; }
+};
+
 static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, bool* bcr_used) {
   hipStream_t st = c->stream;
+  StageTimer tm;
   const int nb = c->nb, bw = c->bw, nbd = c->nbd;
   const double ir = 1.0 / radius;
   LVX_HIP(c, hipMemsetAsync(w.sums, 0, 64 * 8, st));
@@ -448,8 +457,11 @@ static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, 
     hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)((tr + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Bd.p, (const double*)c->d_gb.p, w.scale, nb, nbd, ldz, w.Z);
     if (use_bcr) {
       int rc2;
+      tm.lap("enqueue build_rhs");
       if ((rc2 = bcr_factor(c, w.scale, w.lmd, ir, w.info))) return rc2;
+      tm.lap("enqueue bcr_factor");
       if ((rc2 = bcr_forward(c, w.Z, w.Z, ldz, nbd + 1))) return rc2;   // Z <- L^-1 [B^T, f_b] (in place)
+      tm.lap("enqueue bcr_forward");
     } else {
       const size_t tot = (size_t)nb * (bw + 1);
       hipLaunchKernelGGL(k_build_band, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, w.scale, w.lmd, ir, nb, bw, w.L);
@@ -475,8 +487,10 @@ static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, 
   hipLaunchKernelGGL(k_dense_partial, dim3(1), dim3(256), 0, st, w.S, w.rhs, nbd, nbd - c->ns, w.info);
   LVX_HIP(c, hipGetLastError());
   int info[4] = {0, 0, 0, 0};
+  tm.lap("enqueue gram+schur+dense");
   LVX_HIP(c, hipMemcpyAsync(info, w.info, 16, hipMemcpyDeviceToHost, st));
   LVX_HIP(c, hipStreamSynchronize(st));
+  tm.lap("sync (GPU drain)");
   if (info[0] || info[1]) { double dv; memcpy(&dv, info + 2, 8); return fail(c, LVX_E_NOTPD, "damped normal equations not positive definite (band pivot code " + std::to_string(info[0]) + ", first border pivot " + std::to_string(info[1]) + " value " + std::to_string(dv) + ")"); }
   return LVX_OK;
 }
