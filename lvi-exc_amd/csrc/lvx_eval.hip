@@ -317,10 +317,9 @@ __global__ __launch_bounds__(64 * PW) void k_family(F fam, DevCommon cm, const u
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Fast assembly path.  A workgroup OWNS a range of LVX_CHUNK_R knot intervals: its 4 wavefronts evaluate the range's
-// measurements in batches of 256, transpose rows into per-wave LDS tiles, and accumulate J^T J of every segment into
-// workgroup-shared LDS accumulators (band window, border rows, dense border) with LDS atomics.  One flush of the
-// accumulators to HBM per workgroup replaces the per-segment global atomics of k_family (x6 fewer for surfels).
+// Fast assembly path (k_family_mfma below).  A workgroup OWNS a range of LVX_CHUNK_R knot intervals: its 4 wavefronts evaluate the
+// range's measurements in batches of 256 and accumulate J^T J into workgroup-shared LDS accumulators (band window, border rows,
+// dense border).  One flush of the accumulators to HBM per workgroup replaces the per-segment global atomics of k_family.
 // The pose at t_map, common to every surfel / cam-surfel residual, enters through 6 pseudo variables (d p_0, xi_0):
 // J_hub = g0^T M_hub, folded back onto the hub control points by k_fold_border.
 // ---------------------------------------------------------------------------------------------------------
@@ -340,28 +339,37 @@ __global__ void k_hub_eval(DevCommon cm, double t_map, int want_surf, int want_c
   hubs[s].ok = 1;
 }
 
+// per-row extras of the MFMA path: window id (rows with wid in [w, w + WS) share a window; default = knot interval), and for the
+// reprojection families the knot interval of the OTHER pose and the landmark
+struct Aux { int wid, xk, lm; };
+// traits: NK knot columns (4 knots x KPK, at offset LVO of the knot's 6 tangent scalars) | NG global columns | NX cross columns (kept in the
+// panel for the direct cross-term scatter); WS knot intervals per MFMA window; GL lanes per panel; SKIP_GG: global x global and the global
+// gradient are assembled by another pass; SECONDARY: no cost / residual output; LMCOL: global column that is the window's landmark (or -1)
 struct GyroAcc {
-  enum { NK = 12, NG = 3, NR = 3, HUB = -1, KPK = 3, LVO = 3, WS = 1, GL = 8 };   // KPK columns per knot at offset LVO of its 6 tangent scalars; WS = knot intervals per MFMA window; GL = lanes per panel
+  enum { NK = 12, NG = 3, NR = 3, HUB = -1, KPK = 3, LVO = 3, WS = 1, GL = 8, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 15 };
+  __device__ static constexpr int jm(int c) { return c; }   // KPK columns per knot at offset LVO of its 6 tangent scalars; WS = knot intervals per MFMA window; GL = lanes per panel
   int n; const double* t; const double* m3; const int* perm; double weight, huber;
-  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared*, int si, double r[NR], double (*J)[NK + NG], int& key) const {
+  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared*, int si, double r[NR], double (*J)[NCP], int& key, Aux&) const {
     return gyro_residual<true>(sp, cal.imu, t[si], load_v3(m3 + 3 * (size_t)si), weight, &key, r, J);
   }
   __device__ static int klv(int c) { return 6 * (c / 3) + 3 + c % 3; }
   __device__ static int gcol(int g, int N, int nt) { return 6 * N + 5 + g; }
 };
 struct AccelAcc {
-  enum { NK = 24, NG = 5, NR = 3, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 8 };
+  enum { NK = 24, NG = 5, NR = 3, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 8, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 29 };
+  __device__ static constexpr int jm(int c) { return c; }
   int n; const double* t; const double* m3; const int* perm; double weight, huber;
-  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared*, int si, double r[NR], double (*J)[NK + NG], int& key) const {
+  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared*, int si, double r[NR], double (*J)[NCP], int& key, Aux&) const {
     return accel_residual<true>(sp, cal.imu, t[si], load_v3(m3 + 3 * (size_t)si), weight, &key, r, J);
   }
   __device__ static int klv(int c) { return c; }
   __device__ static int gcol(int g, int N, int nt) { return 6 * N + g; }
 };
 struct SurfAcc {
-  enum { NK = 24, NG = 12, NR = 1, HUB = 0, KPK = 6, LVO = 0, WS = 2, GL = 16 };
+  enum { NK = 24, NG = 12, NR = 1, HUB = 0, KPK = 6, LVO = 0, WS = 2, GL = 16, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 36 };
+  __device__ static constexpr int jm(int c) { return c; }
   int n; const double* t; const double* pt; const int* plane; const int* perm; const double* planes; double t_map, weight, huber;
-  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared* hub, int si, double r[NR], double (*J)[NK + NG], int& key) const {
+  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared* hub, int si, double r[NR], double (*J)[NCP], int& key, Aux&) const {
     const bool tl = (cm.locks & LVX_LOCK_LIDAR_TAU) != 0;
     const double tk = t[si];
     const double pad = tl ? 0.0 : cm.sensor_mto;
@@ -378,9 +386,10 @@ struct SurfAcc {
   __device__ static int gcol(int g, int N, int nt) { return g < 6 ? nt + g : 6 * N + 8 + (g - 6); }
 };
 struct CamSurfAcc {
-  enum { NK = 24, NG = 18, NR = 1, HUB = 1, KPK = 6, LVO = 0, WS = 1, GL = 16 };
+  enum { NK = 24, NG = 18, NR = 1, HUB = 1, KPK = 6, LVO = 0, WS = 1, GL = 16, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 42 };
+  __device__ static constexpr int jm(int c) { return c; }
   int n; const int* lm; const int* plane; const int* perm; const double* planes; const double* lm_uv; const double* lm_t0; double t_map, weight, huber;
-  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared* hub, int si, double r[NR], double (*J)[NK + NG], int& key) const {
+  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared* hub, int si, double r[NR], double (*J)[NCP], int& key, Aux&) const {
     const bool tl = (cm.locks & LVX_LOCK_CAM_TAU) != 0;
     const int l = lm[si];
     const double tk = lm_t0[l];
@@ -399,150 +408,90 @@ struct CamSurfAcc {
   __device__ static int gcol(int g, int N, int nt) { return g < 6 ? nt + 6 + g : (g < 12 ? 6 * N + 15 + (g - 6) : 6 * N + 8 + (g - 12)); }
 };
 
-#define ACC_BW 24
-#define LVX_CHUNK_R_IMU 32   // 8 IMU samples per knot interval: 32 intervals = one 256-sample batch per workgroup
+// Rolling-shutter reprojection on the MFMA path, in two passes over the same blocks (the Jacobians are evaluated twice; the kernel is bound
+// by atomics, not arithmetic):
+//   RepObsAcc: rows sorted by the OBSERVATION's knot interval.  [obs knots | camera] go through the chunk accumulators (views of one frame
+//              share them); the cross terms obs x [ref knots | rho] — unique to a (landmark, view) pair — are scattered directly.
+//   RepRefAcc: rows sorted by (reference interval, landmark); window = one landmark.  [ref knots | camera | rho] x same + the gradient of
+//              all three; rho's entries leave at the end of the landmark's window.
+// Together 600 direct atomics per block + the chunk flushes instead of 1595 per block in k_family<ReprojFam>.
+struct RepJac { const double* J; const double* r; const int* k; int n; };   // k_reproj_jac output, observation order: J[(a * REP_NC + c) * n + i], r[a * n + i], k[i] = ref interval, k[n + i] = obs interval (-1: skipped)
+__device__ __forceinline__ int repjac_load(const RepJac& b, int i, double r[2], double (*J)[REP_NC], int* k0, int* k1) {
+  *k0 = b.k[i]; *k1 = b.k[b.n + i];
+  if (*k1 < 0) return -1;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    r[a] = b.r[(size_t)a * b.n + i];
+#pragma unroll
+    for (int c = 0; c < REP_NC; ++c) J[a][c] = b.J[(size_t)(a * REP_NC + c) * b.n + i];
+  }
+  return RES_OK;
+}
+struct RepObsAcc {
+  enum { NK = 24, NG = 6, NR = 2, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 8, NX = 25, SKIP_GG = 1, SECONDARY = 1, LMCOL = -1, LB = 16, NCP = REP_NC };
+  __device__ static constexpr int jm(int c) { return c < 24 ? 24 + c : (c < 30 ? 48 + (c - 24) : (c < 54 ? c - 30 : 54)); }   // [obs | cam | ref | rho] of reproj_residual's [ref | obs | cam | rho]
+  int n; const int* lm; const int* perm; RepJac jac; double huber;
+  __device__ int eval(const DevCommon&, const SplineRef&, const Cal&, const HubShared*, int si, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
+    int k0, k1;
+    const int st = repjac_load(jac, si, r, J, &k0, &k1);
+    key = k1; aux.wid = k1; aux.xk = k0; aux.lm = lm[si];
+    return st;
+  }
+  __device__ static int gcol(int g, int N, int nt) { return 6 * N + 15 + g; }
+  __device__ static int xcol(int x, const Aux& a, int N) { return x < 24 ? 6 * (a.xk + x / 6) + x % 6 : 6 * N + 22 + a.lm; }
+};
+struct RepRefAcc {
+  enum { NK = 24, NG = 7, NR = 2, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 8, NX = 0, SKIP_GG = 0, SECONDARY = 1, LMCOL = 6, LB = 16, NCP = REP_NC };
+  __device__ static constexpr int jm(int c) { return c < 24 ? c : 48 + (c - 24); }   // [ref | cam | rho]
+  int n; const int* lm; const int* idxA; RepJac jac; double huber;   // rows in (reference interval, landmark) order; idxA: their position in the observation order
+  __device__ int eval(const DevCommon&, const SplineRef&, const Cal&, const HubShared*, int sj, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
+    int k0, k1;
+    const int st = repjac_load(jac, idxA[sj], r, J, &k0, &k1);
+    key = k0; aux.wid = lm[sj]; aux.xk = k1; aux.lm = lm[sj];
+    return st;
+  }
+  __device__ static int gcol(int g, int N, int nt) { return 6 * N + 15 + (g < 6 ? g : 0); }
+};
 
-template <class F, int CR>
-__global__ __launch_bounds__(256) void k_family_acc(F fam, DevCommon cm, const int* __restrict__ chunk_off, const uint16_t* __restrict__ pairs, long long row0) {
-  constexpr int NK = F::NK, NG = F::NG, NC = NK + NG, NR = F::NR, TS = 65, NP = NC * (NC + 1) / 2;
-  constexpr int ACC_LV = (CR + 5) * 6;   // local variables of a chunk: knots [c CR - 1, c CR + CR + 4)
-  extern __shared__ double sm[];
-  double* acc_band = sm;                              // [ACC_LV][ACC_BW]
-  double* acc_bd = acc_band + ACC_LV * ACC_BW;        // [NG][ACC_LV]
-  double* acc_gg = acc_bd + NG * ACC_LV;              // [NG][NG]
-  double* acc_gk = acc_gg + NG * NG;                  // [ACC_LV]
-  double* acc_gG = acc_gk + ACC_LV;                   // [NG]
-  double* tiles = acc_gG + NG;                        // 4 x ([NC][TS] + [64])
-  int* kpos = (int*)(tiles + 4 * (NC * TS + 64));     // [ACC_LV]
-  int* gpos = kpos + ACC_LV;                          // [NG]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int ch = blockIdx.x;
-  const int m0 = chunk_off[ch], m1 = chunk_off[ch + 1];
-  if (m0 >= m1) return;
-  const int k_lo = ch * CR - 1;
-  const int nt = 6 * cm.N + 22 + cm.L;
-  const bool want_ne = (cm.what & LVX_EVAL_NORMAL_EQ) != 0;
-  for (int e = tid; e < ACC_LV * ACC_BW + NG * ACC_LV + NG * NG + ACC_LV + NG; e += 256) sm[e] = 0.0;
-  for (int e = tid; e < ACC_LV; e += 256) { const int k = k_lo + e / 6; kpos[e] = (k >= 0 && k < cm.N) ? cm.ord[6 * k + e % 6] : LVX_DEAD; }
-  if (tid < NG) gpos[tid] = cm.ord[F::gcol(tid, cm.N, nt)];
-  const SplineRef sp{cm.t0, cm.dt, cm.N, cm.state, cm.state + 3 * (size_t)cm.N};
-  const Cal cal = load_cal(cm);
-  const HubShared* hub = F::HUB >= 0 ? ((const HubShared*)cm.hubs) + F::HUB : nullptr;
-  double* Jt = tiles + wv * (NC * TS + 64);
-  double* rs = Jt + NC * TS;
+// Reprojection phase 1 on its own: residual + Jacobian of every block (observation order), Huber-scaled, to HBM (0.9 KB per block);
+// cost and residual output happen here.  The two-pose rolling-shutter residual needs > 512 registers when it shares a kernel with the
+// assembly, so the MFMA passes read the rows back instead (2 x 45 MB at config 4, nothing against their atomics).
+__global__ __launch_bounds__(64) void k_reproj_jac(ReprojFam fam, DevCommon cm, double* Jb, double* rb, int* kb, long long row0) {
+  const int lane = threadIdx.x, si = blockIdx.x * 64 + lane, n = fam.n;
   const int rep = blockIdx.x % LVX_NREP;
   double mycost = 0.0;
-  __syncthreads();
-  for (int base = m0; base < m1; base += 256) {
-    const int si = base + tid;
-    const bool in = si < m1;
-    double r[NR];
-    double J[NR][NC];
-    int key = -1;
-    bool valid = false;
-    if (in) {
-      const int status = fam.eval(cm, sp, cal, hub, si, r, J, key);
-      valid = status == RES_OK;
-      if (valid && (key < k_lo || key - k_lo > CR + 1)) { valid = false; atomicOr(cm.err, LVX_ERR_FALLBACK); }
-      else if (!valid) atomicOr(cm.err, status);
-      if (!valid) key = -1;
-    }
-    if (valid) {
-      double s = 0.0;
-#pragma unroll
-      for (int a = 0; a < NR; ++a) s += r[a] * r[a];
+  if (si < n) {
+    const SplineRef sp{cm.t0, cm.dt, cm.N, cm.state, cm.state + 3 * (size_t)cm.N};
+    const Cal cal = load_cal(cm);
+    HubShared none;
+    double r[2], J[2][REP_NC];
+    Keys key{-1, -1, -1};
+    const int status = fam.eval(cm, sp, cal, none, si, r, J, key);
+    if (status != RES_OK) { atomicOr(cm.err, status); kb[si] = -1; kb[n + si] = -1; }
+    else {
       double scale;
-      mycost += 0.5 * huber_rho(fam.huber, s, &scale);
-      if (cm.residuals) {
-        const long long orow = row0 + (long long)fam.perm[si] * NR;
+      mycost = 0.5 * huber_rho(fam.huber, r[0] * r[0] + r[1] * r[1], &scale);
+      if (cm.residuals) { const long long orow = row0 + (long long)fam.perm[si] * 2; cm.residuals[orow] = r[0]; cm.residuals[orow + 1] = r[1]; }
+      kb[si] = key.k0; kb[n + si] = key.k1;
+      if (cm.what & LVX_EVAL_NORMAL_EQ) {
 #pragma unroll
-        for (int a = 0; a < NR; ++a) cm.residuals[orow + a] = r[a];
-      }
-      if (scale != 1.0) {
+        for (int a = 0; a < 2; ++a) {
+          rb[(size_t)a * n + si] = r[a] * scale;
 #pragma unroll
-        for (int a = 0; a < NR; ++a) {
-          r[a] *= scale;
-#pragma unroll
-          for (int c = 0; c < NC; ++c) J[a][c] *= scale;
-        }
-      }
-    }
-    if (!want_ne) continue;
-    // segments of this wave's 64 rows
-    const int pk = __shfl_up(key, 1);
-    const bool head = (lane == 0) || pk != key;
-    const unsigned long long heads0 = __ballot(head);
-#pragma unroll
-    for (int a = 0; a < NR; ++a) {
-      __syncthreads();   // previous pass has finished reading the tiles
-      rs[lane] = valid ? r[a] : 0.0;
-#pragma unroll
-      for (int c = 0; c < NC; ++c) Jt[c * TS + lane] = valid ? J[a][c] : 0.0;
-      __syncthreads();
-      unsigned long long heads = heads0;
-      while (heads) {
-        const int l0 = __ffsll((long long)heads) - 1;
-        heads &= heads - 1;
-        const int l1 = heads ? (__ffsll((long long)heads) - 1) : 64;
-        const int skey = __shfl(key, l0);
-        if (skey < 0) continue;
-        const int lvb = (skey - k_lo) * 6;
-        for (int p = lane; p < NP + NC; p += 64) {
-          if (p < NP) {
-            const unsigned ab = pairs[p];
-            const int ca = ab & 0xff, cb = ab >> 8;
-            const double* ja = &Jt[ca * TS];
-            const double* jb = &Jt[cb * TS];
-            double acc = 0.0;
-            for (int row = l0; row < l1; ++row) acc += ja[row] * jb[row];
-            if (cb < NK) { const int la = lvb + F::klv(ca), lb = lvb + F::klv(cb); atomicAdd(&acc_band[la * ACC_BW + (lb - la)], acc); }
-            else if (ca < NK) atomicAdd(&acc_bd[(cb - NK) * ACC_LV + lvb + F::klv(ca)], acc);
-            else atomicAdd(&acc_gg[(ca - NK) * NG + (cb - NK)], acc);
-          } else {
-            const int c = p - NP;
-            const double* jc = &Jt[c * TS];
-            double acc = 0.0;
-            for (int row = l0; row < l1; ++row) acc += jc[row] * rs[row];
-            if (c < NK) atomicAdd(&acc_gk[lvb + F::klv(c)], acc); else atomicAdd(&acc_gG[c - NK], acc);
-          }
+          for (int c = 0; c < REP_NC; ++c) Jb[(size_t)(a * REP_NC + c) * n + si] = J[a][c] * scale;
         }
       }
     }
   }
   mycost = wave_sum(mycost);
   if (lane == 0) atomicAdd(&cm.cost[rep], mycost);
-  if (!want_ne) return;
-  __syncthreads();
-  // flush the workgroup's accumulators: ONE global atomic per touched entry
-  for (int e = tid; e < ACC_LV * ACC_BW; e += 256) {
-    const double v = acc_band[e];
-    if (v == 0.0) continue;
-    const int la = e / ACC_BW, lb = la + e % ACC_BW;
-    if (lb >= ACC_LV) continue;
-    const int pa = kpos[la], pb = kpos[lb];
-    if (pa == LVX_DEAD || pb == LVX_DEAD) continue;
-    add_H(cm, pa, pb, v, rep);
-  }
-  for (int e = tid; e < NG * ACC_LV; e += 256) {
-    const double v = acc_bd[e];
-    if (v == 0.0) continue;
-    const int pg = gpos[e / ACC_LV], pk2 = kpos[e % ACC_LV];
-    if (pg == LVX_DEAD || pk2 == LVX_DEAD) continue;
-    add_H(cm, pg, pk2, v, rep);
-  }
-  for (int e = tid; e < NG * NG; e += 256) {
-    const int ga = e / NG, gb2 = e % NG;
-    if (gb2 < ga) continue;
-    const double v = acc_gg[e];
-    if (v == 0.0 || gpos[ga] == LVX_DEAD || gpos[gb2] == LVX_DEAD) continue;
-    add_H(cm, gpos[ga], gpos[gb2], v, rep);
-  }
-  for (int e = tid; e < ACC_LV; e += 256) { const double v = acc_gk[e]; if (v != 0.0 && kpos[e] != LVX_DEAD) add_g(cm, kpos[e], v, rep); }
-  if (tid < NG) { const double v = acc_gG[tid]; if (v != 0.0 && gpos[tid] != LVX_DEAD) add_g(cm, gpos[tid], v, rep); }
 }
 
+#define ACC_BW 24
+#define LVX_CHUNK_R_IMU 32   // 8 IMU samples per knot interval: 32 intervals = one 256-sample batch per workgroup
+
 // ---------------------------------------------------------------------------------------------------------
-// MFMA assembly path (the production fast path).  Same ownership as k_family_acc — a workgroup owns CR knot intervals and
+// MFMA assembly path (the production fast path).  A workgroup owns CR knot intervals and
 // accumulates into LDS — but J^T J is a tall-skinny FP64 matrix product on the matrix cores:
 //   * rows are sorted by knot interval, so a run of rows whose intervals fall into a WINDOW of WS consecutive intervals shares
 //     one local column space  [ (WS+3) knots x KPK | NG globals | residual ]  (<= 48 columns = 3 MFMA column tiles);
@@ -559,21 +508,23 @@ template <class F> struct MfmaGeom {
   static constexpr int NKL = (F::WS + 3) * F::KPK;           // knot columns of a window
   static constexpr int NCL = NKL + F::NG + 1;                // + globals + residual
   static constexpr int NT = (NCL + 15) / 16;                 // 16-column tiles
-  static constexpr int LDP = NT * 16 + 1;                    // odd row stride: conflict-free row writes and fragment reads
+  static constexpr int XOFF = NT * 16;                       // cross columns (not part of the MFMA product) sit behind the tiles
+  static constexpr int LDP = (XOFF + F::NX) | 1;             // odd row stride: conflict-free row writes and fragment reads
   static constexpr int PR = F::GL * F::NR;                   // panel rows
   static_assert(PR % 4 == 0, "panel rows must be a multiple of the MFMA k-step");
+  static_assert(F::NX == 0 || F::WS == 1, "cross-term scatter assumes one knot interval per window");
   static constexpr int NTP = NT * (NT + 1) / 2;
 };
 template <class F, int CR> constexpr size_t mfma_lds_bytes() {
   constexpr int LV = (CR + 5) * 6;
-  return (size_t)(LV * ACC_BW + F::NG * LV + F::NG * F::NG + LV + F::NG + 4 * MfmaGeom<F>::PR * MfmaGeom<F>::LDP) * 8 + (size_t)(LV + F::NG) * 4 + 64;
+  return (size_t)(LV * ACC_BW + F::NG * LV + F::NG * F::NG + LV + F::NG + 4 * MfmaGeom<F>::PR * MfmaGeom<F>::LDP) * 8 + (size_t)(LV + F::NG + 4 * (F::NX + 1) * F::GL) * 4 + 64;
 }
 
 template <class F, int CR, int OCC>
 __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, const int* __restrict__ chunk_off, long long row0) {
   using G = MfmaGeom<F>;
-  constexpr int NK = F::NK, NG = F::NG, NC = NK + NG, NR = F::NR, KPK = F::KPK, WS = F::WS, GL = F::GL;
-  constexpr int NKL = G::NKL, NT = G::NT, LDP = G::LDP, PR = G::PR;
+  constexpr int NK = F::NK, NG = F::NG, NX = F::NX, NC = F::NCP, NR = F::NR, KPK = F::KPK, WS = F::WS, GL = F::GL, LB = F::LB;
+  constexpr int NKL = G::NKL, NT = G::NT, LDP = G::LDP, PR = G::PR, XOFF = G::XOFF;
   constexpr int ACC_LV = (CR + 5) * 6;
   extern __shared__ double sm[];
   double* acc_band = sm;                              // [ACC_LV][ACC_BW]
@@ -584,6 +535,7 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
   double* panels = acc_gG + NG;                       // 4 x [PR][LDP]
   int* kpos = (int*)(panels + 4 * PR * LDP);          // [ACC_LV]
   int* gpos = kpos + ACC_LV;                          // [NG]
+  int* xinfo = gpos + NG;                             // 4 x [GL][NX + 1]: ordering positions of the panel blocks' cross columns, [NX] = block in window
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int ch = blockIdx.x;
   const int m0 = chunk_off[ch], m1 = chunk_off[ch + 1];
@@ -598,6 +550,7 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
   const Cal cal = load_cal(cm);
   const HubShared* hub = F::HUB >= 0 ? ((const HubShared*)cm.hubs) + F::HUB : nullptr;
   double* P = panels + wv * (PR * LDP);
+  int* xi = xinfo + wv * ((NX + 1) * GL);
   const int rep = blockIdx.x % LVX_NREP;
   // class of a window-local column: >= 0 knot scalar (offset inside the window, in units of tangent scalars), -1-g global g, -100 residual, -200 padding
   auto cls = [](int lc) { return lc < NKL ? 6 * (lc / KPK) + F::LVO + lc % KPK : (lc < NKL + NG ? -1 - (lc - NKL) : (lc == NKL + NG ? -100 : -200)); };
@@ -611,29 +564,39 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
   const int frag_off = (lane >> 4) * LDP + (lane & 15);
   double mycost = 0.0;
   __syncthreads();
-  for (int base = m0 + wv * 64; base < m1; base += 256) {
+  for (int base = m0 + wv * LB; base < m1; base += 4 * LB) {   // LB rows per wave batch: sparse families spread their rows over the 4 waves
     const int si = base + lane;
-    const bool in = si < m1;
+    const bool in = lane < LB && si < m1;
     double r[NR];
     double J[NR][NC];
     int key = -1;
+    Aux aux{-1, 0, 0};
     bool valid = false;
     if (in) {
-      const int status = fam.eval(cm, sp, cal, hub, si, r, J, key);
+      const int status = fam.eval(cm, sp, cal, hub, si, r, J, key, aux);
+      if (aux.wid < 0) aux.wid = key;
       valid = status == RES_OK;
       if (valid && (key < k_lo || key - k_lo > CR + 1)) { valid = false; atomicOr(cm.err, LVX_ERR_FALLBACK); }
-      else if (!valid) atomicOr(cm.err, status);
+      else if (!valid && status > 0) atomicOr(cm.err, status);   // status < 0: row skipped (reported by the kernel that produced it)
+    }
+    int xpos[NX > 0 ? NX : 1];
+    if constexpr (NX > 0) {   // ordering positions of this block's cross columns: independent loads, issued together
+#pragma unroll
+      for (int x = 0; x < NX; ++x) xpos[x] = valid ? cm.ord[F::xcol(x, aux, cm.N)] : LVX_DEAD;
     }
     if (valid) {
       double s = 0.0;
 #pragma unroll
       for (int a = 0; a < NR; ++a) s += r[a] * r[a];
       double scale;
-      mycost += 0.5 * huber_rho(fam.huber, s, &scale);
-      if (cm.residuals) {
-        const long long orow = row0 + (long long)fam.perm[si] * NR;
+      const double rho_s = huber_rho(fam.huber, s, &scale);
+      if constexpr (!F::SECONDARY) {
+        mycost += 0.5 * rho_s;
+        if (cm.residuals) {
+          const long long orow = row0 + (long long)fam.perm[si] * NR;
 #pragma unroll
-        for (int a = 0; a < NR; ++a) cm.residuals[orow + a] = r[a];
+          for (int a = 0; a < NR; ++a) cm.residuals[orow + a] = r[a];
+        }
       }
       if (scale != 1.0) {
 #pragma unroll
@@ -649,11 +612,13 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
     while (rem) {                                            // one window per iteration (wave-uniform control flow)
       const int l0 = __ffsll((long long)rem) - 1;
       const int kw = __builtin_amdgcn_readfirstlane(__shfl(key, l0));
-      const bool inw = valid && key >= kw && key < kw + WS;
+      const int ww = __builtin_amdgcn_readfirstlane(__shfl(aux.wid, l0));
+      const bool inw = valid && aux.wid >= ww && aux.wid < ww + WS && key >= kw && key < kw + WS;
       const unsigned long long wm = __ballot(inw);
       rem &= ~wm;
       const int lhi = 63 - __clzll((long long)wm);
       const int sh = inw ? (key - kw) * KPK : 0;
+      const int wb = (kw - k_lo) * 6;
       d4 D[G::NTP];
 #pragma unroll
       for (int t = 0; t < G::NTP; ++t) D[t] = d4{0.0, 0.0, 0.0, 0.0};
@@ -666,12 +631,19 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
           for (int a = 0; a < NR; ++a) {
             double* prow = P + (li * NR + a) * LDP;
 #pragma unroll
-            for (int c = 0; c < NK; ++c) prow[sh + c] = mrow ? J[a][c] : 0.0;
+            for (int c = 0; c < NK; ++c) prow[sh + c] = mrow ? J[a][F::jm(c)] : 0.0;
 #pragma unroll
             for (int z = 0; z < (WS - 1) * KPK; ++z) prow[z < sh ? z : z + NK] = 0.0;
 #pragma unroll
-            for (int g = 0; g < NG; ++g) prow[NKL + g] = mrow ? J[a][NK + g] : 0.0;
+            for (int g = 0; g < NG; ++g) prow[NKL + g] = mrow ? J[a][F::jm(NK + g)] : 0.0;
             prow[NKL + NG] = mrow ? r[a] : 0.0;
+#pragma unroll
+            for (int x = 0; x < NX; ++x) prow[XOFF + x] = mrow ? J[a][F::jm(NK + NG + x)] : 0.0;
+          }
+          if constexpr (NX > 0) {
+#pragma unroll
+            for (int x = 0; x < NX; ++x) xi[li * (NX + 1) + x] = xpos[x];
+            xi[li * (NX + 1) + NX] = mrow ? 1 : 0;
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -689,11 +661,27 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
 #pragma unroll
             for (int cj = ci; cj < NT; ++cj, ++t) D[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[ci], f[cj], D[t], 0, 0, 0);
         }
+        if constexpr (NX > 0) {
+          // cross terms knot columns x cross columns of every block of the panel: unique to the block, one global atomic each;
+          // consecutive lanes take consecutive knot columns => runs along a band column
+          for (int e = lane; e < cnt * NK * NX; e += 64) {
+            const int bl = e / (NK * NX), rm = e - bl * (NK * NX), x = rm / NK, a = rm - x * NK;
+            if (!xi[bl * (NX + 1) + NX]) continue;
+            const int pa = kpos[wb + 6 * (a / KPK) + F::LVO + a % KPK];
+            const int pb = xi[bl * (NX + 1) + x];
+            if (pa == LVX_DEAD || pb == LVX_DEAD) continue;
+            double v = 0.0;
+#pragma unroll
+            for (int q = 0; q < NR; ++q) v += P[(bl * NR + q) * LDP + a] * P[(bl * NR + q) * LDP + XOFF + x];
+            if (v == 0.0) continue;
+            add_H(cm, pa, pb, pa == pb ? 2.0 * v : v, rep);   // the same variable through both poses: both orders of the pair land on the diagonal
+          }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
       // window accumulators -> workgroup accumulators (LDS atomics; other waves work on overlapping windows)
-      const int wb = (kw - k_lo) * 6;
+      const int plm = F::LMCOL >= 0 ? cm.ord[6 * cm.N + 22 + ww] : LVX_DEAD;   // the window's landmark column
       int t = 0;
 #pragma unroll
       for (int ci = 0; ci < NT; ++ci)
@@ -709,17 +697,29 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
               const int la = wb + ra;
               if (la >= ACC_LV) continue;
               if (cb >= 0) { const int d = cb - ra; if (d < ACC_BW && wb + cb < ACC_LV) atomicAdd(&acc_band[la * ACC_BW + d], val); }
-              else if (cb > -100) atomicAdd(&acc_bd[(-1 - cb) * ACC_LV + la], val);
+              else if (cb > -100) {
+                if (F::LMCOL >= 0 && -1 - cb == F::LMCOL) { if (plm != LVX_DEAD && kpos[la] != LVX_DEAD) add_H(cm, kpos[la], plm, val, rep); }
+                else atomicAdd(&acc_bd[(-1 - cb) * ACC_LV + la], val);
+              }
               else if (cb == -100) atomicAdd(&acc_gk[la], val);
             } else if (ra > -100) {
-              if (cb > -100) atomicAdd(&acc_gg[(-1 - ra) * NG + (-1 - cb)], val);
-              else if (cb == -100) atomicAdd(&acc_gG[-1 - ra], val);
+              const int ga = -1 - ra;
+              if (cb > -100) {
+                const int gb = -1 - cb;
+                if (F::LMCOL >= 0 && gb == F::LMCOL) { if (plm != LVX_DEAD) { if (ga == F::LMCOL) add_H(cm, plm, plm, val, rep); else if (gpos[ga] != LVX_DEAD) add_H(cm, gpos[ga], plm, val, rep); } }
+                else if (!F::SKIP_GG) atomicAdd(&acc_gg[ga * NG + gb], val);
+              } else if (cb == -100) {
+                if (F::LMCOL >= 0 && ga == F::LMCOL) { if (plm != LVX_DEAD) add_g(cm, plm, val, rep); }
+                else if (!F::SKIP_GG) atomicAdd(&acc_gG[ga], val);
+              }
             }
           }
     }
   }
-  mycost = wave_sum(mycost);
-  if (lane == 0) atomicAdd(&cm.cost[rep], mycost);
+  if (!F::SECONDARY) {
+    mycost = wave_sum(mycost);
+    if (lane == 0) atomicAdd(&cm.cost[rep], mycost);
+  }
   if (!want_ne) return;
   __syncthreads();
   // flush the workgroup's accumulators: ONE global atomic per touched entry
@@ -918,15 +918,38 @@ int ensure_layout(lvx_ctx* ctx) {
     if ((rc = upload(ctx, f.d_perm, perm.data(), perm.size() * 4))) return rc;
   }
   {
-    Family& f = ctx->rep;   // sorted by landmark then observation time: neighbouring lanes touch neighbouring memory
-    std::vector<int> perm(f.n);
+    Family& f = ctx->rep;
+    // two device orders of the same blocks (see RepObsAcc / RepRefAcc): A = by the observation's knot interval (also used by the
+    // per-segment kernel), B = by (reference knot interval, landmark).  Rolling shutter: the evaluation time is t0 + v * readout / rows.
+    const double row_delta = ctx->cam.rows > 0 ? ctx->cam.readout / (double)ctx->cam.rows : 0.0;
+    std::vector<int> k1(f.n), k0(f.n), perm(f.n);
+    for (int i = 0; i < f.n; ++i) {
+      const int l = f.id0[i];
+      k1[i] = host_i0(ctx, f.t[i] + f.a3[2 * (size_t)i + 1] * row_delta);
+      k0[i] = (l >= 0 && l < L) ? host_i0(ctx, ctx->lm_t0[l] + ctx->lm_uv[2 * (size_t)l + 1] * row_delta) : -1;
+    }
     std::iota(perm.begin(), perm.end(), 0);
-    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return f.id0[a] != f.id0[b] ? f.id0[a] < f.id0[b] : f.t[a] < f.t[b]; });
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return k1[a] != k1[b] ? k1[a] < k1[b] : f.id0[a] < f.id0[b]; });
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = k1[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_REPROJ, sk, LVX_CHUNK_R))) return rc; }
     auto ts = gather(f.t, perm, 1); auto uv = gather(f.a3, perm, 2); auto lm = gather(f.id0, perm, 1);
     if ((rc = upload(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
     if ((rc = upload(ctx, f.d_a3, uv.data(), uv.size() * 8))) return rc;
     if ((rc = upload(ctx, f.d_id0, lm.data(), lm.size() * 4))) return rc;
     if ((rc = upload(ctx, f.d_perm, perm.data(), perm.size() * 4))) return rc;
+    std::vector<int> permB(f.n);
+    std::iota(permB.begin(), permB.end(), 0);
+    std::stable_sort(permB.begin(), permB.end(), [&](int a, int b) { return k0[a] != k0[b] ? k0[a] < k0[b] : (f.id0[a] != f.id0[b] ? f.id0[a] < f.id0[b] : f.t[a] < f.t[b]); });
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = k0[permB[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_PRIOR /* slot reused: the prior has no chunks */, sk, LVX_CHUNK_R))) return rc; }
+    auto tsB = gather(f.t, permB, 1); auto uvB = gather(f.a3, permB, 2); auto lmB = gather(f.id0, permB, 1);
+    if ((rc = upload(ctx, ctx->d_repB[0], tsB.data(), tsB.size() * 8))) return rc;
+    if ((rc = upload(ctx, ctx->d_repB[1], uvB.data(), uvB.size() * 8))) return rc;
+    if ((rc = upload(ctx, ctx->d_repB[2], lmB.data(), lmB.size() * 4))) return rc;
+    std::vector<int> posA(f.n), idxA(f.n);
+    for (int i = 0; i < f.n; ++i) posA[perm[i]] = i;
+    for (int j = 0; j < f.n; ++j) idxA[j] = posA[permB[j]];
+    if ((rc = upload(ctx, ctx->d_repB[3], idxA.data(), idxA.size() * 4))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->d_repB[0], (size_t)std::max(f.n, 1) * (2 * REP_NC + 2) * 8))) return rc;   // materialised Jacobians + residuals
+    if ((rc = dev_alloc(ctx, ctx->d_repB[1], (size_t)std::max(f.n, 1) * 2 * 4))) return rc;                    // knot intervals
   }
   {
     Family& f = ctx->cs;
@@ -1035,8 +1058,6 @@ int ensure_layout(lvx_ctx* ctx) {
   if ((rc = upload_pairs(ctx, ctx->d_pairs[3], SURF_NC + tL, cat(range(0, 24), range(48, 54 + tL))))) return rc;
   if ((rc = upload_pairs(ctx, ctx->d_pairs[4], REP_NC + tC, cat(range(48, 54), range(55, 55 + tC))))) return rc;
   if ((rc = upload_pairs(ctx, ctx->d_pairs[5], CS_NC + tC, cat(range(0, 24), range(48, 60 + tC))))) return rc;
-  if ((rc = upload_pairs(ctx, ctx->d_pairs_acc[0], SURFP_NC))) return rc;
-  if ((rc = upload_pairs(ctx, ctx->d_pairs_acc[1], CSP_NC))) return rc;
   ctx->force_legacy = false;
   // ---- residual row offsets ----
   const int64_t cnt[LVX_NUM_FAM] = {ctx->imu.n, (locks & LVX_LOCK_R3) ? 0 : ctx->imu.n, ctx->has_prior ? 1 : 0, ctx->surf.n, ctx->rep.n, ctx->cs.n};
@@ -1107,7 +1128,6 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
   // fast path: LDS-accumulating kernels for the segment-structured families; legacy per-segment kernels for reprojection, the prior,
   // the debug Jacobian, and as the exact fallback for the merged-hub-segment corner
   const bool fast = !ctx->force_legacy && !(what & LVX_EVAL_JACOBIAN) && !getenv("LVX_FORCE_LEGACY");
-  auto acc_lds = [](int NC, int NG, int R) { const int LV = (R + 5) * 6; return (size_t)(LV * ACC_BW + NG * LV + NG * NG + LV + NG + 4 * (NC * 65 + 64)) * 8 + (size_t)(LV + NG) * 4 + 64; };
   // fork: the independent family kernels run concurrently (each is latency / occupancy limited on its own)
   LVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
   for (int k = 0; k < 4; ++k) LVX_HIP(ctx, hipStreamWaitEvent(ctx->fam_stream[k], ctx->ev_fork, 0));
@@ -1118,34 +1138,24 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
   const bool fast_surf = fast && !tauL && ctx->surf.n > 0, fast_cs = fast && !tauC && ctx->cs.n > 0;
   if (fast_surf || fast_cs)   // only the surfel / cam-surfel stream waits for the shared t_map pose
     hipLaunchKernelGGL(k_hub_eval, dim3(1), dim3(64), 0, s_surf, cm, ctx->t_map, fast_surf ? 1 : 0, fast_cs ? 1 : 0, (HubShared*)ctx->d_hubs.p);
-  const bool mfma = !getenv("LVX_NO_MFMA");
-  static const int occ = getenv("LVX_OCC") ? atoi(getenv("LVX_OCC")) : 1;
-#define LVX_LAUNCH_MFMA1(FT, CRV, OCCV, fam_obj, famid, stream, row0v)                                                                        \
+  static const int occ = getenv("LVX_OCC") ? atoi(getenv("LVX_OCC")) : 1;   // 1 wave / SIMD: phase 1 spills at the 256-register budget of 2
+#define LVX_LAUNCH_MFMA1(FT, CRV, OCCV, fam_obj, chunk_slot, stream, row0v)                                                                   \
   do {                                                                                                                                     \
     const size_t lds_ = mfma_lds_bytes<FT, CRV>();                                                                                         \
     LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_mfma<FT, CRV, OCCV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));  \
-    hipLaunchKernelGGL((k_family_mfma<FT, CRV, OCCV>), dim3(ctx->n_chunk[famid]), dim3(256), lds_, stream, fam_obj, cm, (const int*)ctx->d_chunk[famid].p, (long long)(row0v)); \
+    hipLaunchKernelGGL((k_family_mfma<FT, CRV, OCCV>), dim3(ctx->n_chunk[chunk_slot]), dim3(256), lds_, stream, fam_obj, cm, (const int*)ctx->d_chunk[chunk_slot].p, (long long)(row0v)); \
   } while (0)
-#define LVX_LAUNCH_MFMA(FT, CRV, fam_obj, famid, stream, row0v)                                                                              \
-  do { if (occ == 1) LVX_LAUNCH_MFMA1(FT, CRV, 1, fam_obj, famid, stream, row0v); else LVX_LAUNCH_MFMA1(FT, CRV, 2, fam_obj, famid, stream, row0v); } while (0)
-  const bool imu_fast = !getenv("LVX_IMU_LEGACY");
+#define LVX_LAUNCH_MFMA(FT, CRV, fam_obj, chunk_slot, stream, row0v)                                                                          \
+  do { if (occ == 1) LVX_LAUNCH_MFMA1(FT, CRV, 1, fam_obj, chunk_slot, stream, row0v); else LVX_LAUNCH_MFMA1(FT, CRV, 2, fam_obj, chunk_slot, stream, row0v); } while (0)
+  const bool imu_fast = fast && !getenv("LVX_IMU_LEGACY");
   if (ctx->imu.n > 0) {
-    if (fast && imu_fast) {
+    if (imu_fast) {
       GyroAcc g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
-      if (mfma) { ProfScope ps(ctx, LVX_FAM_GYRO, s_imu); LVX_LAUNCH_MFMA(GyroAcc, LVX_CHUNK_R_IMU, g, LVX_FAM_GYRO, s_imu, ctx->fam_row0[0]); }
-      else { ProfScope ps(ctx, LVX_FAM_GYRO, s_imu);
-        const size_t lds = acc_lds(GyroAcc::NK + GyroAcc::NG, GyroAcc::NG, LVX_CHUNK_R_IMU);
-        LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_acc<GyroAcc, LVX_CHUNK_R_IMU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_family_acc<GyroAcc, LVX_CHUNK_R_IMU>), dim3(ctx->n_chunk[LVX_FAM_GYRO]), dim3(256), lds, s_imu, g, cm, (const int*)ctx->d_chunk[LVX_FAM_GYRO].p, (const uint16_t*)ctx->d_pairs[0].p, (long long)ctx->fam_row0[0]); }
+      { ProfScope ps(ctx, LVX_FAM_GYRO, s_imu); LVX_LAUNCH_MFMA(GyroAcc, LVX_CHUNK_R_IMU, g, LVX_FAM_GYRO, s_imu, ctx->fam_row0[0]); }
       if (!(ctx->locks & LVX_LOCK_R3)) {
         AccelAcc a{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.huber /*w_acc*/, 0.0};
         ProfScope ps(ctx, LVX_FAM_ACCEL, s_acc);
-        if (mfma) LVX_LAUNCH_MFMA(AccelAcc, LVX_CHUNK_R_IMU, a, LVX_FAM_GYRO, s_acc, ctx->fam_row0[1]);
-        else {
-        const size_t lds = acc_lds(AccelAcc::NK + AccelAcc::NG, AccelAcc::NG, LVX_CHUNK_R_IMU);
-        LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_acc<AccelAcc, LVX_CHUNK_R_IMU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_family_acc<AccelAcc, LVX_CHUNK_R_IMU>), dim3(ctx->n_chunk[LVX_FAM_GYRO]), dim3(256), lds, s_acc, a, cm, (const int*)ctx->d_chunk[LVX_FAM_GYRO].p, (const uint16_t*)ctx->d_pairs[1].p, (long long)ctx->fam_row0[1]);
-        }
+        LVX_LAUNCH_MFMA(AccelAcc, LVX_CHUNK_R_IMU, a, LVX_FAM_GYRO, s_acc, ctx->fam_row0[1]);
       }
     } else {
       GyroFam g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
@@ -1175,12 +1185,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     } else if (fast_surf) {
       SurfAcc s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
                 (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
-      if (mfma) LVX_LAUNCH_MFMA(SurfAcc, LVX_CHUNK_R, s, LVX_FAM_SURFEL, s_surf, ctx->fam_row0[3]);
-      else {
-      const size_t lds = acc_lds(SurfAcc::NK + SurfAcc::NG, SurfAcc::NG, LVX_CHUNK_R);
-      LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_acc<SurfAcc, LVX_CHUNK_R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((k_family_acc<SurfAcc, LVX_CHUNK_R>), dim3(ctx->n_chunk[LVX_FAM_SURFEL]), dim3(256), lds, s_surf, s, cm, (const int*)ctx->d_chunk[LVX_FAM_SURFEL].p, (const uint16_t*)ctx->d_pairs_acc[0].p, (long long)ctx->fam_row0[3]);
-      }
+      LVX_LAUNCH_MFMA(SurfAcc, LVX_CHUNK_R, s, LVX_FAM_SURFEL, s_surf, ctx->fam_row0[3]);
     } else {
       SurfFam s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
                 (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
@@ -1194,6 +1199,16 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     if (tauC) {
       ReprojFamT<true> rt{r.n, r.lm, r.uv, r.t0o, r.perm, r.lm_uv, r.lm_t0, r.weight, r.huber};
       hipLaunchKernelGGL((k_family<ReprojFamT<true>, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, rt, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
+    } else if (fast && !getenv("LVX_REPROJ_LEGACY")) {
+      double* Jb = (double*)ctx->d_repB[0].p; double* rb = Jb + (size_t)2 * REP_NC * r.n; int* kb = (int*)ctx->d_repB[1].p;
+      hipLaunchKernelGGL(k_reproj_jac, grid(r.n), dim3(64), 0, s_rep, r, cm, Jb, rb, kb, (long long)ctx->fam_row0[4]);
+      if (what & LVX_EVAL_NORMAL_EQ) {
+        const RepJac jac{Jb, rb, kb, r.n};
+        RepObsAcc ra{r.n, r.lm, r.perm, jac, 0.0};
+        LVX_LAUNCH_MFMA1(RepObsAcc, LVX_CHUNK_R, 1, ra, LVX_FAM_REPROJ, s_rep, ctx->fam_row0[4]);   // measured: a second workgroup per CU does not help, the cross-term atomics bound this pass
+        RepRefAcc rb2{r.n, (const int*)ctx->d_repB[2].p, (const int*)ctx->d_repB[3].p, jac, 0.0};
+        LVX_LAUNCH_MFMA1(RepRefAcc, LVX_CHUNK_R, 1, rb2, LVX_FAM_PRIOR, s_rep, ctx->fam_row0[4]);
+      }
     } else
     hipLaunchKernelGGL((k_family<ReprojFam, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, r, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
   }
@@ -1206,12 +1221,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     } else if (fast_cs) {
       CamSurfAcc c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
                    (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
-      if (mfma) LVX_LAUNCH_MFMA(CamSurfAcc, LVX_CHUNK_R, c, LVX_FAM_CAMSURF, s_surf, ctx->fam_row0[5]);
-      else {
-      const size_t lds = acc_lds(CamSurfAcc::NK + CamSurfAcc::NG, CamSurfAcc::NG, LVX_CHUNK_R);
-      LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_acc<CamSurfAcc, LVX_CHUNK_R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((k_family_acc<CamSurfAcc, LVX_CHUNK_R>), dim3(ctx->n_chunk[LVX_FAM_CAMSURF]), dim3(256), lds, s_surf, c, cm, (const int*)ctx->d_chunk[LVX_FAM_CAMSURF].p, (const uint16_t*)ctx->d_pairs_acc[1].p, (long long)ctx->fam_row0[5]);
-      }
+      LVX_LAUNCH_MFMA(CamSurfAcc, LVX_CHUNK_R, c, LVX_FAM_CAMSURF, s_surf, ctx->fam_row0[5]);
     } else {
       CamSurfFam c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
                    (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
@@ -1286,7 +1296,7 @@ void lvx_destroy(lvx_ctx* c) {
   for (auto& b : c->d_pairs) if (b.p) (void)hipFree(b.p);
   for (auto& b : c->d_up) if (b.p) (void)hipFree(b.p);
   for (auto& b : c->d_chunk) if (b.p) (void)hipFree(b.p);
-  for (auto& b : c->d_pairs_acc) if (b.p) (void)hipFree(b.p);
+  for (auto& b : c->d_repB) if (b.p) (void)hipFree(b.p);
   if (c->d_hubs.p) (void)hipFree(c->d_hubs.p);
   for (DevBuf* b : {&c->vox.misc, &c->vox.keys, &c->vox.vals, &c->vox.runs, &c->vox.cells, &c->vox.tmp, &c->vox.leaf_i, &c->vox.leaf_d, &c->vox.leaf_f}) if (b->p) (void)hipFree(b->p);
   bcr_destroy(c);

@@ -238,6 +238,7 @@ LVX_HD bool so3_eval(const quat c[4], double u, double dt, So3Eval* out) {
   v3 d[4];        // rotation vectors d_j = 2 Omega_j
   quat E[4];
   quat q = c[0];
+#pragma unroll
   for (int j = 1; j < 4; ++j) {
     const v3 Om = logq_half(qmul(qconj(c[j - 1]), c[j]), &ok);
     d[j] = 2.0 * Om;
@@ -258,6 +259,7 @@ LVX_HD bool so3_eval(const quat c[4], double u, double dt, So3Eval* out) {
   if (!NEED_J) return ok;
   const m3 R1 = rotmat(E[1]);
   m3 Jri[4], P[4];
+#pragma unroll
   for (int j = 1; j < 4; ++j) {
     Jri[j] = so3_Jr_inv(d[j]);
     P[j] = B[j] * so3_Jr(B[j] * d[j]);
@@ -283,6 +285,7 @@ LVX_HD bool so3_eval(const quat c[4], double u, double dt, So3Eval* out) {
     We[3] = W3 * Jri[3];
   }
   // eta_k = R(c_k)^T (2 delta_k)
+#pragma unroll
   for (int k = 0; k < 4; ++k) {
     const m3 Rk = rotmat(c[k]);
     out->dxi[k] = 2.0 * mul_t(Xe[k], Rk);

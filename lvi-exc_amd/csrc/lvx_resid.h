@@ -101,6 +101,7 @@ LVX_HD bool pose_eval(const SplineRef& sp, const KnotRef& k, PoseEval* out) {
   out->k = k;
   R3Basis b; r3_basis(k.u, sp.dt, &b);
   v3 p = mk(0, 0, 0), v = mk(0, 0, 0);
+#pragma unroll
   for (int j = 0; j < 4; ++j) {
     const v3 cj = load_v3(sp.r3 + 3 * (k.i0 + j));
     out->Bp[j] = b.Bp[j]; p = p + b.Bp[j] * cj;
@@ -225,6 +226,7 @@ LVX_HD PlaneGrads plane_grads(const PoseEval& h, const PlaneChain& pc, v3 p_I, d
 }
 // expand pose gradients to the 4 control points of one evaluation: position weight Bp[j] * gpos, rotation dxi[j]^T gxi
 LVX_HD void pose_to_knots(const PoseEval& e, v3 gpos, v3 gxi, double* J24) {
+#pragma unroll
   for (int j = 0; j < 4; ++j) {
     J24[6 * j + 0] = e.Bp[j] * gpos.x; J24[6 * j + 1] = e.Bp[j] * gpos.y; J24[6 * j + 2] = e.Bp[j] * gpos.z;
     const v3 a = tmulv(e.so3.dxi[j], gxi);
@@ -404,10 +406,12 @@ LVX_HD int reproj_residual(const SplineRef& sp, const CamIntr& ci, const SensorC
     const m3 dXc_deps = RCt * skew(xo) - A_Xref * skew(RCyh);
     const m3 dXc_dpC = rho * (A_Xref - RCt);
     const v3 dXc_drho = RCt * (tmulv(Ro, (Rr * cam.p) + er.p - eo.p) - cam.p);
+#pragma unroll
     for (int a = 0; a < 2; ++a) {
       const v3 g = mk(-weight * G[a][0], -weight * G[a][1], -weight * G[a][2]);   // d r_a / d Xc
       const v3 gX = tmulv(A_X, g);               // d r / d X
       const v3 gxr = tmulv(dXc_dxr, g), gxo = tmulv(dXc_dxo, g);
+#pragma unroll
       for (int j = 0; j < 4; ++j) {
         const double br = rho * er.Bp[j], bo = -rho * eo.Bp[j];
         J[a][6 * j + 0] = br * gX.x; J[a][6 * j + 1] = br * gX.y; J[a][6 * j + 2] = br * gX.z;
