@@ -341,35 +341,35 @@ __global__ void k_hub_eval(DevCommon cm, double t_map, int want_surf, int want_c
 
 // per-row extras of the MFMA path: window id (rows with wid in [w, w + WS) share a window; default = knot interval), and for the
 // reprojection families the knot interval of the OTHER pose and the landmark
-struct Aux { int wid, xk, lm; };
+struct Aux { int wid, xk, lm; const PreWin* pw; };   // pw: the workgroup's precomputed control-point-pair table (lvx_math.h: So3Pre)
 // traits: NK knot columns (4 knots x KPK, at offset LVO of the knot's 6 tangent scalars) | NG global columns | NX cross columns (kept in the
 // panel for the direct cross-term scatter); WS knot intervals per MFMA window; GL lanes per panel; SKIP_GG: global x global and the global
 // gradient are assembled by another pass; SECONDARY: no cost / residual output; LMCOL: global column that is the window's landmark (or -1)
 struct GyroAcc {
-  enum { NK = 12, NG = 3, NR = 3, HUB = -1, KPK = 3, LVO = 3, WS = 1, GL = 8, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 15 };
+  enum { NK = 12, NG = 3, NR = 3, HUB = -1, KPK = 3, LVO = 3, WS = 1, GL = 8, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 15, USE_PRE = 1 };
   __device__ static constexpr int jm(int c) { return c; }   // KPK columns per knot at offset LVO of its 6 tangent scalars; WS = knot intervals per MFMA window; GL = lanes per panel
   int n; const double* t; const double* m3; const int* perm; double weight, huber;
-  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared*, int si, double r[NR], double (*J)[NCP], int& key, Aux&) const {
-    return gyro_residual<true>(sp, cal.imu, t[si], load_v3(m3 + 3 * (size_t)si), weight, &key, r, J);
+  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared*, int si, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
+    return gyro_residual<true, true>(sp, cal.imu, t[si], load_v3(m3 + 3 * (size_t)si), weight, &key, r, J, aux.pw);
   }
   __device__ static int klv(int c) { return 6 * (c / 3) + 3 + c % 3; }
   __device__ static int gcol(int g, int N, int nt) { return 6 * N + 5 + g; }
 };
 struct AccelAcc {
-  enum { NK = 24, NG = 5, NR = 3, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 8, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 29 };
+  enum { NK = 24, NG = 5, NR = 3, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 8, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 29, USE_PRE = 1 };
   __device__ static constexpr int jm(int c) { return c; }
   int n; const double* t; const double* m3; const int* perm; double weight, huber;
-  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared*, int si, double r[NR], double (*J)[NCP], int& key, Aux&) const {
-    return accel_residual<true>(sp, cal.imu, t[si], load_v3(m3 + 3 * (size_t)si), weight, &key, r, J);
+  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared*, int si, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
+    return accel_residual<true, true>(sp, cal.imu, t[si], load_v3(m3 + 3 * (size_t)si), weight, &key, r, J, aux.pw);
   }
   __device__ static int klv(int c) { return c; }
   __device__ static int gcol(int g, int N, int nt) { return 6 * N + g; }
 };
 struct SurfAcc {
-  enum { NK = 24, NG = 12, NR = 1, HUB = 0, KPK = 6, LVO = 0, WS = 2, GL = 16, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 36 };
+  enum { NK = 24, NG = 12, NR = 1, HUB = 0, KPK = 6, LVO = 0, WS = 2, GL = 16, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 36, USE_PRE = 1 };
   __device__ static constexpr int jm(int c) { return c; }
   int n; const double* t; const double* pt; const int* plane; const int* perm; const double* planes; double t_map, weight, huber;
-  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared* hub, int si, double r[NR], double (*J)[NCP], int& key, Aux&) const {
+  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared* hub, int si, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
     const bool tl = (cm.locks & LVX_LOCK_LIDAR_TAU) != 0;
     const double tk = t[si];
     const double pad = tl ? 0.0 : cm.sensor_mto;
@@ -380,16 +380,16 @@ struct SurfAcc {
     if (!seg_lookup(sp, segs, t_map + cal.lidar.tau, &kh)) return RES_RANGE;
     if (hub->ok != 1) return hub->ok < 0 ? RES_NONUNIT : RES_RANGE;
     if (kh.i0 != hub->A.k.i0 || kh.u != hub->A.k.u) return LVX_ERR_FALLBACK;   // merged-segment corner: only the legacy kernel is exact
-    return surfel_residual_pseudo(sp, hub->A, segs, cal.lidar, tk, load_v3(pt + 3 * (size_t)si), load_v3(planes + 3 * (size_t)plane[si]), weight, &key, r, J);
+    return surfel_residual_pseudo<true>(sp, hub->A, segs, cal.lidar, tk, load_v3(pt + 3 * (size_t)si), load_v3(planes + 3 * (size_t)plane[si]), weight, &key, r, J, aux.pw);
   }
   __device__ static int klv(int c) { return c; }
   __device__ static int gcol(int g, int N, int nt) { return g < 6 ? nt + g : 6 * N + 8 + (g - 6); }
 };
 struct CamSurfAcc {
-  enum { NK = 24, NG = 18, NR = 1, HUB = 1, KPK = 6, LVO = 0, WS = 1, GL = 16, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 42 };
+  enum { NK = 24, NG = 18, NR = 1, HUB = 1, KPK = 6, LVO = 0, WS = 1, GL = 16, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 42, USE_PRE = 1 };
   __device__ static constexpr int jm(int c) { return c; }
   int n; const int* lm; const int* plane; const int* perm; const double* planes; const double* lm_uv; const double* lm_t0; double t_map, weight, huber;
-  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared* hub, int si, double r[NR], double (*J)[NCP], int& key, Aux&) const {
+  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared* hub, int si, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
     const bool tl = (cm.locks & LVX_LOCK_CAM_TAU) != 0;
     const int l = lm[si];
     const double tk = lm_t0[l];
@@ -401,8 +401,8 @@ struct CamSurfAcc {
     if (!seg_lookup(sp, segs, t_map + cal.cam.tau, &kh)) return RES_RANGE;
     if (hub->ok != 1) return hub->ok < 0 ? RES_NONUNIT : RES_RANGE;
     if (kh.i0 != hub->A.k.i0 || kh.u != hub->A.k.u) return LVX_ERR_FALLBACK;
-    return camsurf_residual_pseudo(sp, hub->A, segs, cm.cam, cal.cam, cal.lidar, lm_uv[2 * l], lm_uv[2 * l + 1], tk, cal.rho[l],
-                                   load_v3(planes + 3 * (size_t)plane[si]), weight, &key, r, J);
+    return camsurf_residual_pseudo<true>(sp, hub->A, segs, cm.cam, cal.cam, cal.lidar, lm_uv[2 * l], lm_uv[2 * l + 1], tk, cal.rho[l],
+                                         load_v3(planes + 3 * (size_t)plane[si]), weight, &key, r, J, aux.pw);
   }
   __device__ static int klv(int c) { return c; }
   __device__ static int gcol(int g, int N, int nt) { return g < 6 ? nt + 6 + g : (g < 12 ? 6 * N + 15 + (g - 6) : 6 * N + 8 + (g - 12)); }
@@ -428,7 +428,7 @@ __device__ __forceinline__ int repjac_load(const RepJac& b, int i, double r[2], 
   return RES_OK;
 }
 struct RepObsAcc {
-  enum { NK = 24, NG = 6, NR = 2, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 8, NX = 25, SKIP_GG = 1, SECONDARY = 1, LMCOL = -1, LB = 16, NCP = REP_NC };
+  enum { NK = 24, NG = 6, NR = 2, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 8, NX = 25, SKIP_GG = 1, SECONDARY = 1, LMCOL = -1, LB = 16, NCP = REP_NC, USE_PRE = 0 };
   __device__ static constexpr int jm(int c) { return c < 24 ? 24 + c : (c < 30 ? 48 + (c - 24) : (c < 54 ? c - 30 : 54)); }   // [obs | cam | ref | rho] of reproj_residual's [ref | obs | cam | rho]
   int n; const int* lm; const int* perm; RepJac jac; double huber;
   __device__ int eval(const DevCommon&, const SplineRef&, const Cal&, const HubShared*, int si, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
@@ -441,7 +441,7 @@ struct RepObsAcc {
   __device__ static int xcol(int x, const Aux& a, int N) { return x < 24 ? 6 * (a.xk + x / 6) + x % 6 : 6 * N + 22 + a.lm; }
 };
 struct RepRefAcc {
-  enum { NK = 24, NG = 7, NR = 2, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 8, NX = 0, SKIP_GG = 0, SECONDARY = 1, LMCOL = 6, LB = 16, NCP = REP_NC };
+  enum { NK = 24, NG = 7, NR = 2, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 8, NX = 0, SKIP_GG = 0, SECONDARY = 1, LMCOL = 6, LB = 16, NCP = REP_NC, USE_PRE = 0 };
   __device__ static constexpr int jm(int c) { return c < 24 ? c : 48 + (c - 24); }   // [ref | cam | rho]
   int n; const int* lm; const int* idxA; RepJac jac; double huber;   // rows in (reference interval, landmark) order; idxA: their position in the observation order
   __device__ int eval(const DevCommon&, const SplineRef&, const Cal&, const HubShared*, int sj, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
@@ -536,6 +536,7 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
   int* kpos = (int*)(panels + 4 * PR * LDP);          // [ACC_LV]
   int* gpos = kpos + ACC_LV;                          // [NG]
   int* xinfo = gpos + NG;                             // 4 x [GL][NX + 1]: ordering positions of the panel blocks' cross columns, [NX] = block in window
+  __shared__ So3Pre pre_tab[F::USE_PRE ? CR + 4 : 1];   // control-point pairs (k_lo + e, k_lo + e + 1)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int ch = blockIdx.x;
   const int m0 = chunk_off[ch], m1 = chunk_off[ch + 1];
@@ -547,6 +548,12 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
   for (int e = tid; e < ACC_LV; e += 256) { const int k = k_lo + e / 6; kpos[e] = (k >= 0 && k < cm.N) ? cm.ord[6 * k + e % 6] : LVX_DEAD; }
   if (tid < NG) gpos[tid] = cm.ord[F::gcol(tid, cm.N, nt)];
   const SplineRef sp{cm.t0, cm.dt, cm.N, cm.state, cm.state + 3 * (size_t)cm.N};
+  if (F::USE_PRE && tid < CR + 4) {
+    const int ka = k_lo + tid;
+    if (ka >= 0 && ka + 1 < cm.N) so3_pre(load_q(sp.so3 + 4 * (size_t)ka), load_q(sp.so3 + 4 * (size_t)(ka + 1)), &pre_tab[tid]);
+    else { pre_tab[tid].Om = mk(0, 0, 0); pre_tab[tid].on = 0.0; pre_tab[tid].Jri = m3_identity(); pre_tab[tid].ok = 1; }
+  }
+  const PreWin pwin{pre_tab, k_lo, CR + 4};
   const Cal cal = load_cal(cm);
   const HubShared* hub = F::HUB >= 0 ? ((const HubShared*)cm.hubs) + F::HUB : nullptr;
   double* P = panels + wv * (PR * LDP);
@@ -570,7 +577,7 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
     double r[NR];
     double J[NR][NC];
     int key = -1;
-    Aux aux{-1, 0, 0};
+    Aux aux{-1, 0, 0, &pwin};
     bool valid = false;
     if (in) {
       const int status = fam.eval(cm, sp, cal, hub, si, r, J, key, aux);
@@ -752,23 +759,28 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
 
 // fold the pseudo-pose rows of the border back onto the hub control points: x_pseudo = M_hub x_hub  =>
 //   Bd[hub] += M^T Bd[pseudo],  C <- (I + E) C (I + E)^T,  g_c[hub] += M^T g_c[pseudo]      (E = M^T placed at [hub rows, pseudo cols])
-__global__ void k_fold_border_rows(DevCommon cm, int set) {
+__global__ __launch_bounds__(256) void k_fold_border_rows(DevCommon cm, int set) {
   const HubShared* hub = ((const HubShared*)cm.hubs) + set;
   if (hub->ok != 1) return;
+  __shared__ double M[6][24];
+  __shared__ int hrow[24];
+  if (threadIdx.x == 0) hub_matrix(hub->A, M);
+  if (threadIdx.x < 24) { const int o = cm.ord[6 * (hub->A.k.i0 + threadIdx.x / 6) + threadIdx.x % 6]; hrow[threadIdx.x] = (o != LVX_DEAD && o < 0) ? -1 - o : -1; }   // hub control points are border variables
+  __syncthreads();
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= cm.nb) return;
-  double M[6][24]; hub_matrix(hub->A, M);
   double P[6];
   bool any = false;
+#pragma unroll
   for (int p = 0; p < 6; ++p) { P[p] = cm.Bd[(size_t)(cm.nbd_solve + 6 * set + p) * cm.nb + j]; any = any || P[p] != 0.0; }
   if (!any) return;
-  const int i0 = hub->A.k.i0;
+#pragma unroll
   for (int c = 0; c < 24; ++c) {
-    const int o = cm.ord[6 * (i0 + c / 6) + c % 6];
-    if (o == LVX_DEAD || o >= 0) continue;   // hub control points are border variables
+    if (hrow[c] < 0) continue;
     double s = 0.0;
+#pragma unroll
     for (int p = 0; p < 6; ++p) s += M[p][c] * P[p];
-    cm.Bd[(size_t)(-1 - o) * cm.nb + j] += s;
+    cm.Bd[(size_t)hrow[c] * cm.nb + j] += s;
   }
 }
 __global__ __launch_bounds__(256) void k_fold_border_dense(DevCommon cm) {

@@ -294,4 +294,105 @@ LVX_HD bool so3_eval(const quat c[4], double u, double dt, So3Eval* out) {
   return ok;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The same evaluation with the u-independent part hoisted.  Omega_j = logq(c_{j-1}^* c_j) and J_r^-1(2 Omega_j) depend only on two
+// neighbouring control points, not on the evaluation time: every measurement of a knot interval (tens of rows) shares them, so the fused
+// kernels compute them once per control-point pair into LDS (So3Pre) and each row is left with three sincos:
+//   E_j = (cos a, sinc(a) B_j Omega_j), a = B_j |Omega_j|;   J_r(B_j d_j) = I - c1 K + c2 K^2 with theta = 2 a:
+//   c1 = (1 - cos theta)/theta^2 = sinc(a)^2 / 2,   c2 = (theta - sin theta)/theta^3 = (1 - sinc(a) cos a) / (4 a^2)   (double-angle forms)
+// Same series switches as so3_Jr / expq_half; results agree with so3_eval to rounding (tests/test_host_math.py).
+// ---------------------------------------------------------------------------------------------
+struct So3Pre { v3 Om; double on; m3 Jri; int ok; };   // Omega, |Omega|, J_r^-1(2 Omega), unit-norm check of logq
+LVX_HD void so3_pre(quat ca, quat cb, So3Pre* o) {
+  bool ok = true;
+  o->Om = logq_half(qmul(qconj(ca), cb), &ok);
+  o->on = sqrt(dot(o->Om, o->Om));
+  o->Jri = so3_Jr_inv(2.0 * o->Om);
+  o->ok = ok ? 1 : 0;
+}
+template <bool NEED_W, bool NEED_J, bool NEED_DW = (NEED_W && NEED_J)>
+LVX_HD bool so3_eval_pre(const quat c[4], const So3Pre* pre, double u, double dt, So3Eval* out) {
+  const double u2 = u * u, u3 = u2 * u;
+  double B[4], dB[4];
+  B[1] = 5.0 / 6.0 + u * (3.0 / 6.0) + u2 * (-3.0 / 6.0) + u3 * (1.0 / 6.0);
+  B[2] = 1.0 / 6.0 + u * (3.0 / 6.0) + u2 * (3.0 / 6.0) + u3 * (-2.0 / 6.0);
+  B[3] = u3 * (1.0 / 6.0);
+  if (NEED_W) {
+    const double di = 1.0 / dt;
+    const double U1 = di, U2 = di * (2.0 * u), U3 = di * (3.0 * u2);
+    dB[1] = U1 * (3.0 / 6.0) + U2 * (-3.0 / 6.0) + U3 * (1.0 / 6.0);
+    dB[2] = U1 * (3.0 / 6.0) + U2 * (3.0 / 6.0) + U3 * (-2.0 / 6.0);
+    dB[3] = U3 * (1.0 / 6.0);
+  }
+  bool ok = true;
+  v3 d[4];
+  quat E[4];
+  m3 P[4];
+  quat q = c[0];
+#pragma unroll
+  for (int j = 1; j < 4; ++j) {
+    const So3Pre& pj = pre[j - 1];
+    ok = ok && pj.ok != 0;
+    d[j] = 2.0 * pj.Om;
+    const v3 v = B[j] * pj.Om;
+    const double a = B[j] * pj.on, a2 = a * a;
+    double ka, kv;
+    if (a2 > 1e-16) { ka = cos(a); kv = sin(a) / a; } else { ka = 1.0; kv = 1.0; }   // expq_half's switch
+    E[j] = mkq(ka, kv * v.x, kv * v.y, kv * v.z);
+    q = qmul(q, E[j]);
+    if (NEED_J) {
+      const double t2 = 4.0 * a2;          // |B_j d_j|^2
+      double c1, c2;
+      if (t2 < 2.5e-3) {
+        c1 = 0.5 - t2 * (1.0 / 24.0 - t2 * (1.0 / 720.0 - t2 / 40320.0));
+        c2 = 1.0 / 6.0 - t2 * (1.0 / 120.0 - t2 * (1.0 / 5040.0 - t2 / 362880.0));
+      } else {
+        c1 = 0.5 * kv * kv;
+        c2 = (1.0 - kv * ka) / t2;
+      }
+      const m3 K = skew(B[j] * d[j]);
+      P[j] = B[j] * (m3_identity() - c1 * K + c2 * (K * K));
+    }
+  }
+  out->q = q;
+  if (!NEED_W && !NEED_J) return ok;
+  const m3 R2 = rotmat(E[2]), R3 = rotmat(E[3]);
+  v3 w1, w2r, w2, w3r;
+  if (NEED_W) {
+    w1 = dB[1] * d[1];
+    w2r = tmulv(R2, w1);
+    w2 = w2r + dB[2] * d[2];
+    w3r = tmulv(R3, w2);
+    out->w_body = w3r + dB[3] * d[3];
+  }
+  if (!NEED_J) return ok;
+  const m3 R1 = rotmat(E[1]);
+  const m3 R3t = transpose(R3);
+  const m3 R32t = tmul(R3, transpose(R2));
+  const m3 T1 = R32t * P[1], T2 = R3t * P[2], T3 = P[3];
+  m3 Xe[4];
+  Xe[0] = tmul(R1 * (R2 * R3), m3_identity()) - mul_t(T1, pre[0].Jri);
+  Xe[1] = T1 * pre[0].Jri - mul_t(T2, pre[1].Jri);
+  Xe[2] = T2 * pre[1].Jri - mul_t(T3, pre[2].Jri);
+  Xe[3] = T3 * pre[2].Jri;
+  m3 We[4];
+  if (NEED_DW) {
+    const m3 W1 = dB[1] * R32t;
+    const m3 W2 = R3t * (skew(w2r) * P[2] + dB[2] * m3_identity());
+    const m3 W3 = skew(w3r) * P[3] + dB[3] * m3_identity();
+    We[0] = -1.0 * mul_t(W1, pre[0].Jri);
+    We[1] = W1 * pre[0].Jri - mul_t(W2, pre[1].Jri);
+    We[2] = W2 * pre[1].Jri - mul_t(W3, pre[2].Jri);
+    We[3] = W3 * pre[2].Jri;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const m3 Rk = rotmat(c[k]);
+    out->dxi[k] = 2.0 * mul_t(Xe[k], Rk);
+    if (NEED_DW) out->dw[k] = 2.0 * mul_t(We[k], Rk);
+  }
+  return ok;
+}
+
 }  // namespace lvx

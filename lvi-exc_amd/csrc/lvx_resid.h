@@ -96,8 +96,8 @@ struct PoseEval {
 };
 // NEED_V: also the time derivative of the pose — d p / d t = v, q(t + e) = q (x) Exp(w_body e) — which is what a free sensor time
 // offset differentiates through (the reference's Jets carry it through the spline time argument, sensors.h:36-85)
-template <bool NEED_J, bool NEED_V = false>
-LVX_HD bool pose_eval(const SplineRef& sp, const KnotRef& k, PoseEval* out) {
+template <bool NEED_J, bool NEED_V = false, bool PRE = false>
+LVX_HD bool pose_eval(const SplineRef& sp, const KnotRef& k, PoseEval* out, const So3Pre* pre = nullptr) {
   out->k = k;
   R3Basis b; r3_basis(k.u, sp.dt, &b);
   v3 p = mk(0, 0, 0), v = mk(0, 0, 0);
@@ -110,8 +110,14 @@ LVX_HD bool pose_eval(const SplineRef& sp, const KnotRef& k, PoseEval* out) {
   out->p = p;
   if (NEED_V) out->v = v;
   quat c[4]; load_so3_cp(sp, k.i0, c);
+  if (PRE) return so3_eval_pre<NEED_V, NEED_J, false>(c, pre, k.u, sp.dt, &out->so3);   // pre: the entries of control-point pairs (i0, i0+1) .. (i0+2, i0+3)
   return so3_eval<NEED_V, NEED_J, false>(c, k.u, sp.dt, &out->so3);
 }
+// window of precomputed control-point-pair quantities handed to the residuals of the fused kernels: entry e belongs to the pair
+// (k0 + e, k0 + e + 1); a row whose knot interval falls outside is reported as RES_OUTSIDE (the kernel then takes the exact fallback)
+struct PreWin { const So3Pre* p; int k0, n; };
+enum { RES_OUTSIDE = 16 };   // = LVX_ERR_FALLBACK
+LVX_HD const So3Pre* pre_at(const PreWin& w, int i0) { return (i0 >= w.k0 && i0 + 2 < w.k0 + w.n) ? w.p + (i0 - w.k0) : nullptr; }
 
 // error codes shared with include/lvx.h
 enum { RES_OK = 0, RES_RANGE = 1, RES_NONUNIT = 2 };
@@ -122,14 +128,18 @@ enum { RES_OK = 0, RES_RANGE = 1, RES_NONUNIT = 2 };
 // local columns: [SO3 knot j: 3j..3j+2 (j=0..3) | b_g: 12..14]; R3 / roll / pitch / b_a columns are structurally zero.
 // ---------------------------------------------------------------------------------------------
 enum { GYRO_NC = 15, GYRO_NR = 3 };
-template <bool NEED_J>
-LVX_HD int gyro_residual(const SplineRef& sp, const ImuCal& imu, double t, v3 w_meas, double weight, int* i0, double r[3], double J[3][GYRO_NC]) {
+template <bool NEED_J, bool PRE = false>
+LVX_HD int gyro_residual(const SplineRef& sp, const ImuCal& imu, double t, v3 w_meas, double weight, int* i0, double r[3], double J[3][GYRO_NC], const PreWin* pw = nullptr) {
   KnotRef k;
   if (!knot_lookup(sp.t0, sp.dt, sp.n, t, t + imu.tau, &k)) return RES_RANGE;
   *i0 = k.i0;
   quat c[4]; load_so3_cp(sp, k.i0, c);
   So3Eval e;
-  if (!so3_eval<true, NEED_J>(c, k.u, sp.dt, &e)) return RES_NONUNIT;
+  if (PRE) {
+    const So3Pre* pre = pre_at(*pw, k.i0);
+    if (!pre) return RES_OUTSIDE;
+    if (!so3_eval_pre<true, NEED_J>(c, pre, k.u, sp.dt, &e)) return RES_NONUNIT;
+  } else if (!so3_eval<true, NEED_J>(c, k.u, sp.dt, &e)) return RES_NONUNIT;
   const v3 pred = e.w_body + imu.bg;
   r[0] = weight * (w_meas.x - pred.x); r[1] = weight * (w_meas.y - pred.y); r[2] = weight * (w_meas.z - pred.z);
   if (NEED_J) {
@@ -148,8 +158,8 @@ LVX_HD int gyro_residual(const SplineRef& sp, const ImuCal& imu, double t, v3 w_
 // local columns: [knot j: R3 6j..6j+2, SO3 6j+3..6j+5 | roll 24 | pitch 25 | b_a 26..28]
 // ---------------------------------------------------------------------------------------------
 enum { ACC_NC = 29, ACC_NR = 3 };
-template <bool NEED_J>
-LVX_HD int accel_residual(const SplineRef& sp, const ImuCal& imu, double t, v3 a_meas, double weight, int* i0, double r[3], double J[3][ACC_NC]) {
+template <bool NEED_J, bool PRE = false>
+LVX_HD int accel_residual(const SplineRef& sp, const ImuCal& imu, double t, v3 a_meas, double weight, int* i0, double r[3], double J[3][ACC_NC], const PreWin* pw = nullptr) {
   KnotRef k;
   if (!knot_lookup(sp.t0, sp.dt, sp.n, t, t + imu.tau, &k)) return RES_RANGE;
   *i0 = k.i0;
@@ -158,7 +168,11 @@ LVX_HD int accel_residual(const SplineRef& sp, const ImuCal& imu, double t, v3 a
   for (int j = 0; j < 4; ++j) acc = acc + b.Ba[j] * load_v3(sp.r3 + 3 * (k.i0 + j));
   quat c[4]; load_so3_cp(sp, k.i0, c);
   So3Eval e;
-  if (!so3_eval<false, NEED_J>(c, k.u, sp.dt, &e)) return RES_NONUNIT;
+  if (PRE) {
+    const So3Pre* pre = pre_at(*pw, k.i0);
+    if (!pre) return RES_OUTSIDE;
+    if (!so3_eval_pre<false, NEED_J>(c, pre, k.u, sp.dt, &e)) return RES_NONUNIT;
+  } else if (!so3_eval<false, NEED_J>(c, k.u, sp.dt, &e)) return RES_NONUNIT;
   const double G = -9.79;   // imu.h:25
   const double cr = cos(imu.roll), sr = sin(imu.roll), cp = cos(imu.pitch), sp_ = sin(imu.pitch);
   const v3 g = mk(-sp_ * cr * G, sr * G, -cr * cp * G);
@@ -273,13 +287,16 @@ LVX_HD int surfel_residual(const SplineRef& sp, const PoseEval& hub, const Segs&
 // J_hub = g0^T M_hub with M_hub identical for every residual of a launch, so J^T J is assembled over g0 and folded back
 // with M_hub afterwards (lvx_eval.hip: k_fold_border).  local columns: [k knot j: 6j.. (24) | g0 24..29 | lidar theta 30..32 | lidar p 33..35]
 enum { SURFP_NC = 36 };
+template <bool PRE = false>
 LVX_HD int surfel_residual_pseudo(const SplineRef& sp, const PoseEval& hub, const Segs& segs, const SensorCal& lidar, double t_k, v3 p_L, v3 Pi,
-                                  double weight, int* i0_k, double r[1], double J[1][SURFP_NC]) {
+                                  double weight, int* i0_k, double r[1], double J[1][SURFP_NC], const PreWin* pw = nullptr) {
   KnotRef kr;
   if (!seg_lookup(sp, segs, t_k + lidar.tau, &kr)) return RES_RANGE;
   *i0_k = kr.i0;
   PoseEval k;
-  if (!pose_eval<true>(sp, kr, &k)) return RES_NONUNIT;
+  const So3Pre* pre = PRE ? pre_at(*pw, kr.i0) : nullptr;
+  if (PRE && !pre) return RES_OUTSIDE;
+  if (!pose_eval<true, false, PRE>(sp, kr, &k, pre)) return RES_NONUNIT;
   const v3 pLr = qrot(lidar.q, p_L);
   const v3 p_I = pLr + lidar.p;
   PlaneChain pc; plane_chain(hub, k, lidar, p_I, Pi, &pc);
@@ -468,13 +485,16 @@ LVX_HD int camsurf_residual(const SplineRef& sp, const PoseEval& hub, const Segs
 
 // pseudo-hub variant: local columns [k knot j: 6j.. (24) | g0 24..29 | cam theta 30..32 | cam p 33..35 | lidar theta 36..38 | lidar p 39..41]
 enum { CSP_NC = 42 };
+template <bool PRE = false>
 LVX_HD int camsurf_residual_pseudo(const SplineRef& sp, const PoseEval& hub, const Segs& segs, const CamIntr& ci, const SensorCal& cam, const SensorCal& lidar,
-                                   double u_ref, double v_ref, double t0_ref, double rho, v3 Pi, double weight, int* i0_k, double r[1], double J[1][CSP_NC]) {
+                                   double u_ref, double v_ref, double t0_ref, double rho, v3 Pi, double weight, int* i0_k, double r[1], double J[1][CSP_NC], const PreWin* pw = nullptr) {
   KnotRef kr;
   if (!seg_lookup(sp, segs, t0_ref + cam.tau, &kr)) return RES_RANGE;
   *i0_k = kr.i0;
   PoseEval k;
-  if (!pose_eval<true>(sp, kr, &k)) return RES_NONUNIT;
+  const So3Pre* pre = PRE ? pre_at(*pw, kr.i0) : nullptr;
+  if (PRE && !pre) return RES_OUTSIDE;
+  if (!pose_eval<true, false, PRE>(sp, kr, &k, pre)) return RES_NONUNIT;
   const double s = 1.0 / (rho + 1e-8);
   const v3 yu = cam_unproject(ci, u_ref, v_ref);
   const v3 yh = mk(yu.x * s, yu.y * s, yu.z * s);

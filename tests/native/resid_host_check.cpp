@@ -5,6 +5,7 @@
 // not a CPU fallback: nothing here is linked into liblvx.so and no product entry point can reach it.
 // It reads its inputs from an oracle Problem (tests may use oracle/), and writes the same
 // (residuals, jac_cols, jac_vals) layout as orc_evaluate.
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -127,4 +128,23 @@ extern "C" int hc_evaluate(const orc_problem* p, const double* state, double* co
   (void)two_pose_hub;
   if (cost) *cost = total;
   return -err;
+}
+
+// so3_eval (reference arithmetic order) vs so3_eval_pre (u-independent part hoisted, double-angle forms): largest absolute difference
+// of q, w_body, dxi and dw for the 4 control points cps[4][4] (x,y,z,w).  Returns 0 when both report the same unit-norm status.
+extern "C" int hc_so3_pre_diff(const double* cps, double u, double dt, double* out4) {
+  quat c[4];
+  for (int j = 0; j < 4; ++j) c[j] = load_q(cps + 4 * j);
+  So3Pre pre[3];
+  for (int j = 0; j < 3; ++j) so3_pre(c[j], c[j + 1], &pre[j]);
+  So3Eval a, b;
+  const bool oka = so3_eval<true, true>(c, u, dt, &a);
+  const bool okb = so3_eval_pre<true, true>(c, pre, u, dt, &b);
+  auto mx = [](double x, double y) { return x > y ? x : y; };
+  out4[0] = mx(mx(std::fabs(a.q.x - b.q.x), std::fabs(a.q.y - b.q.y)), mx(std::fabs(a.q.z - b.q.z), std::fabs(a.q.w - b.q.w)));
+  out4[1] = mx(mx(std::fabs(a.w_body.x - b.w_body.x), std::fabs(a.w_body.y - b.w_body.y)), std::fabs(a.w_body.z - b.w_body.z));
+  out4[2] = 0.0; out4[3] = 0.0;
+  for (int k = 0; k < 4; ++k)
+    for (int e = 0; e < 9; ++e) { out4[2] = mx(out4[2], std::fabs(a.dxi[k].a[e] - b.dxi[k].a[e])); out4[3] = mx(out4[3], std::fabs(a.dw[k].a[e] - b.dw[k].a[e])); }
+  return oka == okb ? 0 : 1;
 }

@@ -67,3 +67,24 @@ def test_large_relative_rotation_between_control_points(host_check_lib):
         so3 /= np.linalg.norm(so3, axis=1, keepdims=True)
         P[key] = s
     _compare(host_check_lib, P, TAU, prior=False)
+
+
+@pytest.mark.parametrize("spread", [1e-9, 1e-3, 0.05, 0.9, 2.5])
+def test_so3_precomputed_pairs_match_direct_evaluation(host_check_lib, spread):
+    """so3_eval_pre (what the fused kernels run: log / J_r^-1 per control-point pair hoisted, double-angle forms for J_r) against so3_eval
+    (the reference's arithmetic order), from the series region up to relative rotations > pi/2."""
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    out = np.zeros(4)
+    worst = np.zeros(4)
+    for _ in range(200):
+        base = synth.q_from_rotvec(rng.standard_normal(3))
+        cps = np.stack([synth.qmul(synth.q_from_rotvec(spread * rng.standard_normal(3)), base) for _ in range(4)])
+        cps /= np.linalg.norm(cps, axis=1, keepdims=True)
+        u = rng.uniform(0, 1)
+        rc = host_check_lib.hc_so3_pre_diff(cps.ctypes.data_as(C.c_void_p), C.c_double(u), C.c_double(0.02), out.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        worst = np.maximum(worst, out)
+    # q, dxi are O(1); w_body and dw carry 1/dt = 50
+    assert worst[0] <= 1e-14 and worst[2] <= 2e-12
+    assert worst[1] <= 1e-11 * max(1.0, spread / 0.02) and worst[3] <= 1e-9 * max(1.0, spread / 0.02)

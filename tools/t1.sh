@@ -1,3 +1,4 @@
-for v in "LVX_SERIAL=1" "LVX_SERIAL=1 LVX_REP_OCC1=1"; do
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+for v in "LVX_SERIAL=1" ""; do
 env $v python bench.py --steps 10 --warmup 2 --no-secondary --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', round(d['value']), round(d['ms_per_step'],3), {k:round(v,3) for k,v in d['kernel_ms'].items()})"
 done
