@@ -213,6 +213,7 @@ int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_ra
   const double one = 1.0, mone = -1.0, zero = 0.0;
   int L = 0; while ((1 << L) < nblk) ++L;
   int info_pos = 0;
+  const bool use_gemm = !getenv("LVX_BCR_SYRK");
   for (int l = 0; l < L; ++l) {
     const int s = 1 << l, n2 = (nblk >> l) / 2;
     const long long sD = (long long)2 * s * bb, sG = (long long)2 * bb;
@@ -227,10 +228,13 @@ int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_ra
     // Y_k = C_k^-1 G[2k-1], k = 1..n2-1 : every COLUMN
     if (n2 > 1 && (rc = trsv_batched<false>(c, Dj + sD, b, sD, Gl + bb, 1, b, sG, b, n2 - 1))) return rc;
     // D_{j+s} -= X+ X+^T
-    LVX_BLAS(c, rocblas_dsyrk_strided_batched(h, rocblas_fill_lower, rocblas_operation_none, b, b, &mone, Gl, b, sG, &one, Dr, b, sD, n2));
+    // (full GEMM instead of SYRK: rocBLAS' batched SYRK runs as many small launches; the upper triangle of D is never read)
+    if (use_gemm) LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, b, b, b, &mone, Gl, b, sG, Gl, b, sG, &one, Dr, b, sD, n2));
+    else LVX_BLAS(c, rocblas_dsyrk_strided_batched(h, rocblas_fill_lower, rocblas_operation_none, b, b, &mone, Gl, b, sG, &one, Dr, b, sD, n2));
     if (n2 > 1) {
       // D_{j-s} -= Y^T Y   (left neighbour of eliminated k is the right neighbour of eliminated k-1)
-      LVX_BLAS(c, rocblas_dsyrk_strided_batched(h, rocblas_fill_lower, rocblas_operation_transpose, b, b, &mone, Gl + bb, b, sG, &one, Dr, b, sD, n2 - 1));
+      if (use_gemm) LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, b, b, &mone, Gl + bb, b, sG, Gl + bb, b, sG, &one, Dr, b, sD, n2 - 1));
+      else LVX_BLAS(c, rocblas_dsyrk_strided_batched(h, rocblas_fill_lower, rocblas_operation_transpose, b, b, &mone, Gl + bb, b, sG, &one, Dr, b, sD, n2 - 1));
       // next level's coupling A_{j+s,j-s} = -X+_k Y_k
       LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, b, b, &mone, Gl + 2 * bb, b, sG, Gl + bb, b, sG, &zero, Gn, b, (rocblas_stride)bb, n2 - 1));
     }
