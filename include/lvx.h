@@ -261,6 +261,14 @@ typedef int (*lvx_allreduce_fn)(void* user, double* buf, int n, int op);   /* in
 int lvx_solve_step_shared(lvx_ctx* ctx, double radius, int jacobi_scaling, lvx_allreduce_fn fn, void* user, double* delta, double* model_cost_change);
 int lvx_lm_solve_shared(lvx_ctx* ctx, double* state, const lvx_lm_options* opt, lvx_allreduce_fn fn, void* user, lvx_lm_summary* summary);
 
+/* surfel map extraction ------------------------------------------------------------------------------*/
+/* SurfelAssociation::setSurfelMap + checkPlaneType (src/lvi_exc/src/core/surfel_association.cpp:50-86, 246-266) over the leaves of the last
+ * lvx_voxel_build of this context (the cloud passed to it must still be alive): leaves with >= min_leaf_points points and planarity >= p_lambda,
+ * plane fit, Pi = -d n, AABB of the leaf's points; output in voxel-key (std::map) order.  The reference fits with pcl RANSAC (random); this is
+ * the deterministic variant documented in DESIGN.md: leaf PCA plane -> inliers within dist_threshold -> PCA refit -> reselect. */
+typedef struct lvx_surfel_plane { double p4[4]; double Pi[3]; double box_min[3]; double box_max[3]; int32_t leaf, n_points, n_inliers, plane_type; } lvx_surfel_plane;
+int lvx_surfel_extract(lvx_ctx* ctx, double p_lambda, double dist_threshold, int min_leaf_points, int min_inliers, int max_planes, lvx_surfel_plane* planes, int32_t* n_planes);
+
 /* scan de-skew ------------------------------------------------------------------------------------*/
 /* licalib PointXYZIT (src/lvi_exc/include/utils/pcl_utils.h:39-44), 32 bytes */
 typedef struct lvx_point_xyzit { float x, y, z, pad; float intensity; float pad2; double timestamp; } lvx_point_xyzit;

@@ -101,6 +101,7 @@ struct lvx_ctx {
   lvx::DevBuf d_up[8];
   struct Voxels {
     float leaf = 0; int min_pts = 0, n_points = 0, n_leaves = 0;
+    const void* d_pts = nullptr;   // the cloud of the last build (device; caller- or context-owned), read again by lvx_surfel_extract
     int grid[13] = {0};   // VxGrid: min_b, max_b, div_b, mul, inv(float bits)
     lvx::DevBuf misc, keys, vals, runs, cells, tmp, leaf_i, leaf_d, leaf_f;
   } vox;

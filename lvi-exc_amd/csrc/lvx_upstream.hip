@@ -279,6 +279,62 @@ __global__ void k_vx_leaf(const float4* p, const unsigned* ukeys, const unsigned
   }
   leaf_n[li] = nr;
 }
+// surfel map extraction: one thread per leaf (tens to hundreds of points each), three passes over the leaf's points
+struct SurfelPlaneDev { double p4[4], Pi[3], bmin[3], bmax[3]; int leaf, n_points, n_inliers, plane_type; };
+__global__ void k_surfel_extract(const float4* p, const unsigned* counts, const unsigned* offs, const int* sorted_ids, int nl, const int* leaf_n, const double* mean,
+                                 const double* evecs, const double* evals, double p_lambda, double thr, int min_leaf, int min_inl, SurfelPlaneDev* out, int* flag) {
+  const int li = blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= nl) return;
+  flag[li] = 0;
+  const int n = leaf_n[li];
+  if (n < min_leaf) return;
+  const double* ev = evals + 3 * (size_t)li;
+  int i0 = 0, i1 = 1, i2 = 2;   // descending by value (Eigen::sort_vec)
+  if (ev[i1] > ev[i0]) { const int t = i0; i0 = i1; i1 = t; }
+  if (ev[i2] > ev[i1]) { const int t = i1; i1 = i2; i2 = t; if (ev[i1] > ev[i0]) { const int u = i0; i0 = i1; i1 = u; } }
+  const double pl = 2.0 * (ev[i1] - ev[i2]) / (ev[i2] + ev[i1] + ev[i0]);
+  if (pl < p_lambda) return;
+  const double* V = evecs + 9 * (size_t)li;
+  double nrm[3] = {V[0 + i2], V[3 + i2], V[6 + i2]};
+  const double an[3] = {fabs(nrm[0]), fabs(nrm[1]), fabs(nrm[2])};
+  int t0 = 0, t1 = 1, t2 = 2;
+  if (an[t1] > an[t0]) { const int t = t0; t0 = t1; t1 = t; }
+  if (an[t2] > an[t1]) { const int t = t1; t1 = t2; t2 = t; if (an[t1] > an[t0]) { const int u = t0; t0 = t1; t1 = u; } }
+  const int o = (int)offs[li], cnt = (int)counts[li];
+  double d = -(nrm[0] * mean[3 * (size_t)li] + nrm[1] * mean[3 * (size_t)li + 1] + nrm[2] * mean[3 * (size_t)li + 2]);
+  int nin = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    double sm[3] = {0, 0, 0}, cc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    nin = 0;
+    for (int k = 0; k < cnt; ++k) {
+      const float4 q = p[sorted_ids[o + k]];
+      const double x[3] = {q.x, q.y, q.z};
+      if (!(fabs(nrm[0] * x[0] + nrm[1] * x[1] + nrm[2] * x[2] + d) < thr)) continue;
+      ++nin;
+      for (int a = 0; a < 3; ++a) { sm[a] += x[a]; for (int b = 0; b < 3; ++b) cc[3 * a + b] += x[a] * x[b]; }
+    }
+    if (pass == 1 || nin < 3) break;
+    const double mu[3] = {sm[0] / nin, sm[1] / nin, sm[2] / nin};
+    double C[9];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[3 * a + b] = cc[3 * a + b] / nin - mu[a] * mu[b];
+    double e2[3], V2[9];
+    vx_eig3(C, e2, V2);
+    nrm[0] = V2[0]; nrm[1] = V2[3]; nrm[2] = V2[6];
+    d = -(nrm[0] * mu[0] + nrm[1] * mu[1] + nrm[2] * mu[2]);
+  }
+  if (nin < min_inl) return;
+  if (d > 0 || (d == 0 && (nrm[0] < 0 || (nrm[0] == 0 && (nrm[1] < 0 || (nrm[1] == 0 && nrm[2] < 0)))))) { nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2]; d = -d; }
+  float bmin[3] = {3.402823466e38f, 3.402823466e38f, 3.402823466e38f}, bmax[3] = {-3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
+  for (int k = 0; k < cnt; ++k) {
+    const float4 q = p[sorted_ids[o + k]];
+    bmin[0] = fminf(bmin[0], q.x); bmin[1] = fminf(bmin[1], q.y); bmin[2] = fminf(bmin[2], q.z);
+    bmax[0] = fmaxf(bmax[0], q.x); bmax[1] = fmaxf(bmax[1], q.y); bmax[2] = fmaxf(bmax[2], q.z);
+  }
+  SurfelPlaneDev& P = out[li];
+  for (int a = 0; a < 3; ++a) { P.p4[a] = nrm[a]; P.Pi[a] = -d * nrm[a]; P.bmin[a] = bmin[a]; P.bmax[a] = bmax[a]; }
+  P.p4[3] = d; P.leaf = li; P.n_points = n; P.n_inliers = nin; P.plane_type = t2;
+  flag[li] = 1;
+}
 __global__ void k_vx_lookup7(const float4* q, int nq, float leaf, int min_pts, VxGrid g, const int* grid, const int* leaf_n, int* ids7) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
@@ -515,6 +571,7 @@ int lvx_voxel_build(lvx_ctx* c, int n, const float* xyzi4, float leaf, int min_p
   if ((rc = upload(c, c->d_up[1], xyzi4, (size_t)n * 16))) return rc;
   { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
     if ((rc = voxel_build_device(c, (const float4*)c->d_up[1].p, n, leaf, min_pts, eig_mult))) return rc; }
+  c->vox.d_pts = c->d_up[1].p;
   LVX_HIP(c, hipStreamSynchronize(c->stream));
   if (info) {
     VxGrid g; std::memcpy(&g, &c->vox.grid, sizeof(g));
@@ -527,6 +584,7 @@ int lvx_voxel_build_d(lvx_ctx* c, int n, const float* xyzi4_d, float leaf, int m
   if (!c || n < 0 || !(leaf > 0) || (n > 0 && !xyzi4_d)) return LVX_E_ARG;
   LVX_HIP(c, hipSetDevice(c->device));
   ProfScope ps(c, LVX_KERNEL_UPSTREAM);
+  c->vox.d_pts = xyzi4_d;
   return voxel_build_device(c, (const float4*)xyzi4_d, n, leaf, min_pts, eig_mult);
 }
 int lvx_voxel_get(lvx_ctx* c, int32_t* leaf_key, int32_t* leaf_n, double* mean, double* cov, double* icov, double* evecs, double* evals, float* centroid,
@@ -652,6 +710,34 @@ int lvx_undistort_scan(lvx_ctx* c, const double* state, int n, const lvx_point_x
   LVX_HIP(c, hipGetLastError());
   LVX_HIP(c, hipMemcpyAsync(out, c->d_up[3].p, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
   LVX_HIP(c, hipStreamSynchronize(c->stream));
+  return LVX_OK;
+}
+
+int lvx_surfel_extract(lvx_ctx* c, double p_lambda, double dist_threshold, int min_leaf_points, int min_inliers, int max_planes, lvx_surfel_plane* planes, int32_t* n_planes) {
+  static_assert(sizeof(lvx_surfel_plane) == sizeof(SurfelPlaneDev), "plane record layout");
+  if (!c || !n_planes || max_planes < 0 || (max_planes > 0 && !planes)) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  const lvx_ctx::Voxels& V = c->vox;
+  *n_planes = 0;
+  const int nl = V.n_leaves, n = V.n_points;
+  if (nl == 0) return LVX_OK;
+  if (!V.d_pts) return fail(c, LVX_E_STATE, "lvx_voxel_build has not been called");
+  int rc;
+  if ((rc = dev_alloc(c, c->d_up[4], (size_t)nl * sizeof(SurfelPlaneDev)))) return rc;
+  if ((rc = dev_alloc(c, c->d_up[5], (size_t)nl * 4))) return rc;
+  const unsigned* counts = (const unsigned*)V.runs.p + n; const unsigned* offs = (const unsigned*)V.runs.p + 2 * (size_t)n;
+  const int* lk = (const int*)V.leaf_i.p; const double* d = (const double*)V.leaf_d.p;
+  { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
+    hipLaunchKernelGGL(k_surfel_extract, dim3((nl + 127) / 128), dim3(128), 0, c->stream, (const float4*)V.d_pts, counts, offs, (const int*)V.vals.p + n, nl, lk + nl, d, d + 21 * (size_t)nl,
+                       d + 30 * (size_t)nl, p_lambda, dist_threshold, min_leaf_points, min_inliers, (SurfelPlaneDev*)c->d_up[4].p, (int*)c->d_up[5].p); }
+  LVX_HIP(c, hipGetLastError());
+  std::vector<SurfelPlaneDev> all(nl); std::vector<int> flag(nl);
+  LVX_HIP(c, hipMemcpyAsync(all.data(), c->d_up[4].p, (size_t)nl * sizeof(SurfelPlaneDev), hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipMemcpyAsync(flag.data(), c->d_up[5].p, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  int np = 0;
+  for (int li = 0; li < nl; ++li) if (flag[li]) { if (np < max_planes) std::memcpy(&planes[np], &all[li], sizeof(SurfelPlaneDev)); ++np; }   // leaf order = voxel key order (std::map)
+  *n_planes = np;
   return LVX_OK;
 }
 

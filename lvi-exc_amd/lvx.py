@@ -412,6 +412,18 @@ def upstream_bench(ctx, kind, arrays, reps=20):
     return (time.perf_counter() - t0) / reps
 
 
+SURFEL_PLANE = np.dtype([("p4", "<f8", 4), ("Pi", "<f8", 3), ("box_min", "<f8", 3), ("box_max", "<f8", 3), ("leaf", "<i4"), ("n_points", "<i4"), ("n_inliers", "<i4"),
+                         ("plane_type", "<i4")])
+
+
+def surfel_extract(ctx, max_planes, p_lambda=0.7, dist_threshold=0.05, min_leaf_points=10, min_inliers=20):
+    """Surfel planes of the context's last voxel_build (setSurfelMap): structured array in voxel-key order."""
+    out = np.zeros(max(max_planes, 1), dtype=SURFEL_PLANE)
+    n = C.c_int32(0)
+    ctx._ck(ctx._l.lvx_surfel_extract(ctx._h, C.c_double(p_lambda), C.c_double(dist_threshold), C.c_int(min_leaf_points), C.c_int(min_inliers), C.c_int(max_planes), _p(out), C.byref(n)))
+    return out[:min(n.value, max_planes)], n.value
+
+
 POINT_XYZIT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad", "<f4"), ("intensity", "<f4"), ("pad2", "<f4"), ("timestamp", "<f8")])
 
 

@@ -249,6 +249,21 @@ def voxel_build(xyzi, leaf, min_pts=6, eig_mult=0.01):
     return o
 
 
+def surfel_extract(xyzi, vox, p_lambda=0.7, dist_threshold=0.05, min_leaf_points=10, min_inliers=20):
+    xyzi = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)
+    nl = vox["n_leaves"]
+    planes = np.zeros((max(nl, 1), 16))
+    types = np.zeros(max(nl, 1), np.int32)
+    l = lib()
+    l.orc_surfel_extract.restype = C.c_int
+    arrs = [np.ascontiguousarray(vox[k]) for k in ("leaf_n", "offsets", "point_ids", "mean", "evecs", "evals")]
+    n = l.orc_surfel_extract(C.c_int(nl), _p(xyzi), *[_p(a) for a in arrs], C.c_double(p_lambda), C.c_double(dist_threshold), C.c_int(min_leaf_points),
+                             C.c_int(min_inliers), _p(planes), _p(types), C.c_int(len(planes)))
+    P = planes[:n]
+    return dict(p4=P[:, 0:4].copy(), Pi=P[:, 4:7].copy(), box_min=P[:, 7:10].copy(), box_max=P[:, 10:13].copy(), leaf=P[:, 13].astype(np.int32),
+                n_points=P[:, 14].astype(np.int32), n_inliers=P[:, 15].astype(np.int32), plane_type=types[:n].copy())
+
+
 def voxel_lookup7(vox, queries, leaf, min_pts=6):
     q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, 4)
     ids = np.full((len(q), 7), -1, np.int32)

@@ -255,4 +255,67 @@ void orc_surfel_assoc(int H, int W, const float* scan, int P, const double* p4, 
   }
 }
 
+// SurfelAssociation::setSurfelMap (/root/reference/src/lvi_exc/src/core/surfel_association.cpp:50-86) with checkPlaneType (:246-266): walk the
+// NDT leaves in std::map (voxel key) order; keep a leaf with nr_points >= min_leaf_points whose planarity 2 (l_mid - l_min) / (l_min + l_mid + l_max)
+// of the (inflated) NDT eigenvalues reaches p_lambda; fit a plane; Pi = -d n; AABB of ALL the leaf's points (pcl::getMinMax3D, float).
+// DEVIATION (documented): fitPlane (:268-294) is pcl RANSAC + optimizeCoefficients — random sampling, float PCA.  Here the plane search is
+// deterministic: start from the leaf's own PCA plane (normal = eigenvector of the smallest eigenvalue through the mean), take the points
+// closer than dist_threshold, refit by PCA of those inliers in double (what pcl's optimizeModelCoefficients + final selectWithinDistance
+// do after the sampling stage), reselect; reject below min_inliers.  p4 is signed so that d <= 0.
+// planes: per accepted leaf 16 doubles {p4[4], Pi[3], box_min[3], box_max[3], leaf, n_points, n_inliers} + plane_type in types[]
+int orc_surfel_extract(int n_leaves, const float* xyzi, const int32_t* leaf_n, const int32_t* offsets, const int32_t* point_ids, const double* mean, const double* evecs,
+                       const double* evals, double p_lambda, double dist_threshold, int min_leaf_points, int min_inliers, double* planes16, int32_t* types, int max_planes) {
+  int np = 0;
+  for (int li = 0; li < n_leaves; ++li) {
+    const int n = leaf_n[li];
+    if (n < min_leaf_points) continue;
+    const double* ev = evals + 3 * li;
+    // Eigen::sort_vec: indices sorted by DESCENDING value (std::sort on 3 elements)
+    int ind[3] = {0, 1, 2};
+    std::sort(ind, ind + 3, [&](int a, int b) { return ev[a] > ev[b]; });
+    const double p = 2.0 * (ev[ind[1]] - ev[ind[2]]) / (ev[ind[2]] + ev[ind[1]] + ev[ind[0]]);
+    if (p < p_lambda) continue;
+    const double* V = evecs + 9 * li;   // row-major, eigenvector k = column k
+    double nrm[3] = {V[0 + ind[2]], V[3 + ind[2]], V[6 + ind[2]]};
+    double an[3] = {std::fabs(nrm[0]), std::fabs(nrm[1]), std::fabs(nrm[2])};
+    int ti[3] = {0, 1, 2};
+    std::sort(ti, ti + 3, [&](int a, int b) { return an[a] > an[b]; });
+    const int plane_type = ti[2];
+    const int o = offsets[li], cnt = offsets[li + 1] - offsets[li];
+    double d = -(nrm[0] * mean[3 * li] + nrm[1] * mean[3 * li + 1] + nrm[2] * mean[3 * li + 2]);
+    int nin = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+      double sm[3] = {0, 0, 0}, cc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      nin = 0;
+      for (int k = 0; k < cnt; ++k) {
+        const float* q = xyzi + 4 * point_ids[o + k];
+        const double x[3] = {q[0], q[1], q[2]};
+        if (!(std::fabs(nrm[0] * x[0] + nrm[1] * x[1] + nrm[2] * x[2] + d) < dist_threshold)) continue;
+        ++nin;
+        for (int a = 0; a < 3; ++a) { sm[a] += x[a]; for (int b = 0; b < 3; ++b) cc[3 * a + b] += x[a] * x[b]; }
+      }
+      if (pass == 1 || nin < 3) break;
+      double mu[3] = {sm[0] / nin, sm[1] / nin, sm[2] / nin}, C[9];
+      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[3 * a + b] = cc[3 * a + b] / nin - mu[a] * mu[b];
+      double e2[3], V2[9];
+      eig3(C, e2, V2);                                 // ascending: column 0 = normal
+      nrm[0] = V2[0]; nrm[1] = V2[3]; nrm[2] = V2[6];
+      d = -(nrm[0] * mu[0] + nrm[1] * mu[1] + nrm[2] * mu[2]);
+    }
+    if (nin < min_inliers) continue;
+    if (d > 0 || (d == 0 && (nrm[0] < 0 || (nrm[0] == 0 && (nrm[1] < 0 || (nrm[1] == 0 && nrm[2] < 0)))))) { nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2]; d = -d; }
+    float bmin[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()}, bmax[3] = {-bmin[0], -bmin[1], -bmin[2]};
+    for (int k = 0; k < cnt; ++k) { const float* q = xyzi + 4 * point_ids[o + k]; for (int a = 0; a < 3; ++a) { bmin[a] = std::min(bmin[a], q[a]); bmax[a] = std::max(bmax[a], q[a]); } }
+    if (np < max_planes) {
+      double* P = planes16 + 16 * np;
+      P[0] = nrm[0]; P[1] = nrm[1]; P[2] = nrm[2]; P[3] = d;
+      for (int a = 0; a < 3; ++a) { P[4 + a] = -d * nrm[a]; P[7 + a] = bmin[a]; P[10 + a] = bmax[a]; }
+      P[13] = li; P[14] = n; P[15] = nin;
+      types[np] = plane_type;
+    }
+    ++np;
+  }
+  return np;
+}
+
 }  // extern "C"

@@ -160,3 +160,33 @@ def test_lidar_pose_and_undistort(ctx):
         assert np.abs(uo[m] - ug[m]).max() <= 4e-6      # float32 outputs of FP64 poses: at most an ulp or two at |x| ~ 30 m
         assert np.array_equal(uo[:, 3], ug[:, 3])
     c2.close()
+
+
+def test_surfel_map_extraction(ctx):
+    """setSurfelMap (deterministic plane-fit variant): same leaves in the same (voxel key) order as the serial restatement, planes to
+    rounding, boxes and inlier counts exact; then the extracted planes drive the association kernel."""
+    cloud = synth.make_voxel_cloud(seed=2, n=100_000)
+    vo = O.voxel_build(cloud, 0.5)
+    ro = O.surfel_extract(cloud, vo)
+    lvx.voxel_build(ctx, cloud, 0.5, fetch=False)
+    rg, n = lvx.surfel_extract(ctx, max_planes=vo["n_leaves"])
+    assert n == len(ro["leaf"]) and n > 200
+    assert np.array_equal(rg["leaf"], ro["leaf"]) and np.array_equal(rg["n_points"], ro["n_points"])
+    assert np.array_equal(rg["n_inliers"], ro["n_inliers"]) and np.array_equal(rg["plane_type"], ro["plane_type"])
+    assert np.abs(rg["p4"] - ro["p4"]).max() <= 1e-9 and np.abs(rg["Pi"] - ro["Pi"]).max() <= 1e-9 * np.abs(ro["Pi"]).max()
+    assert np.array_equal(rg["box_min"], ro["box_min"]) and np.array_equal(rg["box_max"], ro["box_max"])
+    # properties of the reference's definition (surfel_association.cpp:70-80): Pi = -d n, unit normals, at least 20 inliers, at least 10 points
+    assert np.abs(np.linalg.norm(rg["p4"][:, :3], axis=1) - 1).max() <= 1e-12
+    assert np.abs(rg["Pi"] + rg["p4"][:, 3:4] * rg["p4"][:, :3]).max() <= 1e-12
+    assert rg["n_inliers"].min() >= 20 and rg["n_points"].min() >= 10
+    # capacity smaller than the number of planes: count still reported, first planes returned
+    r2, n2 = lvx.surfel_extract(ctx, max_planes=5)
+    assert n2 == n and len(r2) == 5 and np.array_equal(r2["leaf"], rg["leaf"][:5])
+    # stricter planarity keeps a subset
+    r3, n3 = lvx.surfel_extract(ctx, max_planes=vo["n_leaves"], p_lambda=0.95)
+    assert 0 < n3 < n and set(r3["leaf"]) <= set(rg["leaf"])
+    # feed the association kernel with the extracted planes (one sweep standing at the origin of the same scene)
+    scan = cloud[:16 * 1800].reshape(16, 1800, 4)
+    fg = lvx.surfel_assoc(ctx, scan, rg["p4"], rg["box_min"], rg["box_max"], 0.05, 2)
+    fo = O.surfel_assoc(scan, ro["p4"], ro["box_min"], ro["box_max"], 0.05, 2)
+    assert np.array_equal(fg, fo) and (fg >= 0).sum() > 0
