@@ -46,9 +46,40 @@ def upstream():
     np.savez_compressed(os.path.join(HERE, "assoc_small.npz"), scan=scan, p4=p4, bmin=bmin, bmax=bmax, flag=O.surfel_assoc(scan, p4, bmin, bmax, 0.05, 2))
 
 
+def next_rows():
+    """Rows added after the first fixtures: scan de-skew, surfel map extraction, free time-offset Jacobian columns."""
+    P = synth.make_problem(seed=78, duration=0.8, n_surfel=60, n_planes=4, n_landmarks=6, n_camsurf=2)
+    o = O.Oracle()
+    lvx.load_problem(o, P, 0)                               # both sensor time offsets free
+    N = P["n_knots"]
+    s = P["state0"].copy(); s[7 * N + 23] = 2e-4; s[7 * N + 31] = -3e-4
+    r = o.evaluate(s, jac=True, normal_eq=True)
+    J = O.dense_jacobian(r["jac_cols"], r["jac_vals"], o.tangent_size)
+    keep = {k: P[k] for k in ("t0", "dt", "n_knots", "t_imu", "gyro", "acc", "w_gyro", "w_acc", "planes", "surf_pt", "surf_t", "surf_plane", "t_map", "huber_surf",
+                              "w_surf", "n_landmarks", "lm_uv", "lm_t0", "rep_lm", "rep_uv", "rep_t0", "huber_rep", "w_rep", "cs_lm", "cs_plane", "huber_cs", "w_cs")}
+    keep["camera"] = np.array([P["camera"][k] for k in ("rows", "cols", "readout", "fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3")], dtype=np.float64)
+    rng = np.random.default_rng(5)
+    raw = np.zeros(400, dtype=lvx.POINT_XYZIT)
+    raw["x"], raw["y"], raw["z"] = rng.uniform(-15, 15, (3, 400)).astype(np.float32)
+    raw["intensity"] = rng.uniform(0, 200, 400).astype(np.float32)
+    raw["timestamp"] = rng.uniform(P["t_start"], P["t_end"], 400)
+    raw["x"][::41] = np.nan
+    raw["timestamp"][7::53] = P["t0"] - 1.0
+    st = P["state_true"]
+    q0, p0, _ = O.eval_lidar_pose(o, st, [P["t_map"]])
+    und = O.undistort(o, st, raw, synth.qconj(q0[0]), p0[0], True)
+    np.savez_compressed(os.path.join(HERE, "tau_deskew_small.npz"), state=s, cost=r["cost"], residuals=r["residuals"], J_tau_lidar=J[:, 6 * N + 14].copy(),
+                        J_tau_cam=J[:, 6 * N + 21].copy(), g=r["g"], raw=raw.view(np.uint8), state_true=st, q_map=q0[0], p_map=p0[0], undistorted=und, **keep)
+    cloud = synth.make_voxel_cloud(seed=3, n=20000)
+    v = O.voxel_build(cloud, 0.5)
+    e = O.surfel_extract(cloud, v)
+    np.savez_compressed(os.path.join(HERE, "surfel_extract_small.npz"), cloud=cloud, **e)
+
+
 if __name__ == "__main__":
     solve_problem()
     upstream()
+    next_rows()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -53,6 +53,49 @@ def test_oracle_reproduces_upstream_golden():
     assert np.array_equal(O.surfel_assoc(z["scan"], z["p4"], z["bmin"], z["bmax"], 0.05, 2), z["flag"])
 
 
+def _check_next_rows(obj, mod, ctx_for_upstream):
+    z = np.load(os.path.join(G, "tau_deskew_small.npz"))
+    P = _problem(z)
+    lvx.load_problem(obj, P, 0)
+    r = obj.evaluate(z["state"], jac=True, normal_eq=True)
+    N = P["n_knots"]
+    J = O.dense_jacobian(r["jac_cols"], r["jac_vals"], obj.tangent_size)
+    assert abs(r["cost"] - float(z["cost"])) <= 1e-12 * float(z["cost"])
+    assert np.abs(r["residuals"] - z["residuals"]).max() <= 1e-11 * np.abs(z["residuals"]).max()
+    for col, key in ((6 * N + 14, "J_tau_lidar"), (6 * N + 21, "J_tau_cam")):
+        assert np.abs(z[key]).max() > 0 and np.abs(J[:, col] - z[key]).max() <= 1e-9 * np.abs(z[key]).max()
+    assert np.abs(r["g"] - z["g"]).max() <= 1e-10 * np.abs(z["g"]).max()
+    raw = z["raw"].view(lvx.POINT_XYZIT)
+    und = mod.undistort(obj, z["state_true"], raw, synth_qconj(z["q_map"]), z["p_map"], True)
+    assert np.array_equal(np.isnan(und), np.isnan(z["undistorted"]))
+    m = ~np.isnan(und)
+    assert np.abs(und[m] - z["undistorted"][m]).max() <= 4e-6
+    z = np.load(os.path.join(G, "surfel_extract_small.npz"))
+    if ctx_for_upstream is None:
+        e = O.surfel_extract(z["cloud"], O.voxel_build(z["cloud"], 0.5))
+    else:
+        lvx.voxel_build(ctx_for_upstream, z["cloud"], 0.5, fetch=False)
+        e, n = lvx.surfel_extract(ctx_for_upstream, max_planes=len(z["leaf"]) + 8)
+        assert n == len(z["leaf"])
+    assert np.array_equal(e["leaf"], z["leaf"]) and np.array_equal(e["n_inliers"], z["n_inliers"]) and np.array_equal(e["plane_type"], z["plane_type"])
+    assert np.abs(e["p4"] - z["p4"]).max() <= 1e-9 and np.array_equal(e["box_min"], z["box_min"]) and np.array_equal(e["box_max"], z["box_max"])
+
+
+def synth_qconj(q):
+    return np.array([-q[0], -q[1], -q[2], q[3]])
+
+
+def test_oracle_reproduces_next_rows_golden():
+    _check_next_rows(O.Oracle(), O, None)
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_next_rows_golden():
+    ctx = lvx.Context(0)
+    _check_next_rows(ctx, lvx, ctx)
+    ctx.close()
+
+
 @pytest.mark.gpu
 def test_gpu_reproduces_golden():
     ctx = lvx.Context(0)
