@@ -11,7 +11,6 @@
 
 #define LVX_NREP 64                 // replicas of the dense border accumulators (spreads same-address atomics)
 #define LVX_DEAD (-2147483647 - 1)  // ord[] value of a constant (locked) tangent scalar
-#define LVX_CHUNK_R 16              // knot intervals per workgroup of the LDS-accumulating assembly kernel
 #define LVX_ERR_FALLBACK 16         // device error bit: fast assembly kernel met a corner it does not handle; re-run with the legacy kernels
 
 namespace lvx {
@@ -86,7 +85,7 @@ struct lvx_ctx {
   int nb = 0, bw = 0, nbd = 0, nbd_ext = 0, n_hub = 0, hub0 = 0;   // nbd: solve border (hub knots + 22 calib); nbd_ext = nbd + 12 pseudo rows
   bool force_legacy = false;   // set when the fast assembly kernels hit a case only the per-segment kernels handle exactly
   lvx::DevBuf d_hubs, d_chunk[LVX_NUM_FAM], d_repB[4];   // reprojection MFMA path: [0] materialised Jacobians + residuals, [1] knot intervals, [2] landmark and [3] observation-order index of the rows in (reference interval, landmark) order
-  int n_chunk[LVX_NUM_FAM] = {0};
+  int n_chunk[LVX_NUM_FAM] = {0}, chunk_r[LVX_NUM_FAM] = {0};   // workgroups and knot intervals per workgroup of the MFMA assembly kernels (pick_chunk)
   lvx::DevBuf d_ord, d_Hb, d_gb, d_Bd, d_C, d_gc, d_cost, d_err, d_state, d_res, d_jcols, d_jvals, d_pairs[LVX_NUM_FAM];
   // solver workspace (lvx_solver.hip)
   lvx::DevBuf d_L, d_Y, d_S, d_delta, d_diag, d_scal, d_state_try, d_zero;

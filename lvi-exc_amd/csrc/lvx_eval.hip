@@ -488,7 +488,6 @@ __global__ __launch_bounds__(64) void k_reproj_jac(ReprojFam fam, DevCommon cm, 
 }
 
 #define ACC_BW 24
-#define LVX_CHUNK_R_IMU 32   // 8 IMU samples per knot interval: 32 intervals = one 256-sample batch per workgroup
 
 // ---------------------------------------------------------------------------------------------------------
 // MFMA assembly path (the production fast path).  A workgroup owns CR knot intervals and
@@ -515,17 +514,19 @@ template <class F> struct MfmaGeom {
   static_assert(F::NX == 0 || F::WS == 1, "cross-term scatter assumes one knot interval per window");
   static constexpr int NTP = NT * (NT + 1) / 2;
 };
-template <class F, int CR> constexpr size_t mfma_lds_bytes() {
-  constexpr int LV = (CR + 5) * 6;
-  return (size_t)(LV * ACC_BW + F::NG * LV + F::NG * F::NG + LV + F::NG + 4 * MfmaGeom<F>::PR * MfmaGeom<F>::LDP) * 8 + (size_t)(LV + F::NG + 4 * (F::NX + 1) * F::GL) * 4 + 64;
+template <class F> size_t mfma_lds_bytes(int cr) {
+  const int LV = (cr + 5) * 6;
+  return (size_t)(LV * ACC_BW + F::NG * LV + F::NG * F::NG + LV + F::NG + 4 * MfmaGeom<F>::PR * MfmaGeom<F>::LDP) * 8 + (F::USE_PRE ? (size_t)(cr + 4) * sizeof(So3Pre) : 0) +
+         (size_t)(LV + F::NG + 4 * (F::NX + 1) * F::GL) * 4 + 64;
 }
 
-template <class F, int CR, int OCC>
-__global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, const int* __restrict__ chunk_off, long long row0) {
+// CR = knot intervals per workgroup, chosen per problem by the host (pick_chunk) so that the workgroup count fills whole rounds of the CUs
+template <class F, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, const int* __restrict__ chunk_off, long long row0, int CR) {
   using G = MfmaGeom<F>;
   constexpr int NK = F::NK, NG = F::NG, NX = F::NX, NC = F::NCP, NR = F::NR, KPK = F::KPK, WS = F::WS, GL = F::GL, LB = F::LB;
   constexpr int NKL = G::NKL, NT = G::NT, LDP = G::LDP, PR = G::PR, XOFF = G::XOFF;
-  constexpr int ACC_LV = (CR + 5) * 6;
+  const int ACC_LV = (CR + 5) * 6;
   extern __shared__ double sm[];
   double* acc_band = sm;                              // [ACC_LV][ACC_BW]
   double* acc_bd = acc_band + ACC_LV * ACC_BW;        // [NG][ACC_LV]
@@ -533,10 +534,10 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
   double* acc_gk = acc_gg + NG * NG;                  // [ACC_LV]
   double* acc_gG = acc_gk + ACC_LV;                   // [NG]
   double* panels = acc_gG + NG;                       // 4 x [PR][LDP]
-  int* kpos = (int*)(panels + 4 * PR * LDP);          // [ACC_LV]
+  So3Pre* pre_tab = (So3Pre*)(panels + 4 * PR * LDP); // [CR + 4] control-point pairs (k_lo + e, k_lo + e + 1), families with USE_PRE
+  int* kpos = (int*)(pre_tab + (F::USE_PRE ? CR + 4 : 0));   // [ACC_LV]
   int* gpos = kpos + ACC_LV;                          // [NG]
   int* xinfo = gpos + NG;                             // 4 x [GL][NX + 1]: ordering positions of the panel blocks' cross columns, [NX] = block in window
-  __shared__ So3Pre pre_tab[F::USE_PRE ? CR + 4 : 1];   // control-point pairs (k_lo + e, k_lo + e + 1)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int ch = blockIdx.x;
   const int m0 = chunk_off[ch], m1 = chunk_off[ch + 1];
@@ -885,6 +886,22 @@ int host_i0(const lvx_ctx* c, double t) {
 
 }  // namespace
 
+// Knot intervals per workgroup of the MFMA assembly kernels: every workgroup has the same expected work (~ R intervals), the launch runs in
+// ceil(workgroups / CUs) rounds, so pick R in [lo, hi] that minimises rounds * R (e.g. 25 k intervals on 256 CUs: R = 20 -> 1252 workgroups =
+// 4.9 rounds instead of 6.1 half-empty ones at R = 16).  LVX_CHUNK_R / LVX_CHUNK_R_REP / LVX_CHUNK_R_IMU (env) force a value.
+static int pick_chunk(const lvx_ctx* ctx, int lo, int hi, const char* env) {
+  if (const char* e = getenv(env)) { const int v = atoi(e); if (v >= 4 && v <= 64) return v; }
+  int ncu = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+  int best = lo; long long best_cost = -1;
+  for (int r = lo; r <= hi; ++r) {
+    const long long nwg = (ctx->N + r - 1) / r + 1;
+    const long long cost = ((nwg + ncu - 1) / ncu) * r;
+    if (best_cost < 0 || cost < best_cost) { best = r; best_cost = cost; }
+  }
+  return best;
+}
 static int upload_chunks(lvx_ctx* ctx, int fam, const std::vector<int>& sorted_keys, int R) {
   const int nch = (ctx->N + R - 1) / R + 1;
   std::vector<int> off(nch + 1);
@@ -892,6 +909,7 @@ static int upload_chunks(lvx_ctx* ctx, int fam, const std::vector<int>& sorted_k
     off[c] = c == 0 ? 0 : (int)(std::lower_bound(sorted_keys.begin(), sorted_keys.end(), c * R) - sorted_keys.begin());
   off[nch] = (int)sorted_keys.size();
   ctx->n_chunk[fam] = nch;
+  ctx->chunk_r[fam] = R;
   return upload(ctx, ctx->d_chunk[fam], off.data(), off.size() * 4);
 }
 
@@ -909,7 +927,7 @@ int ensure_layout(lvx_ctx* ctx) {
     for (int i = 0; i < f.n; ++i) key[i] = host_i0(ctx, f.t[i]);
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
-    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_GYRO, sk, LVX_CHUNK_R_IMU))) return rc; }
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_GYRO, sk, pick_chunk(ctx, 24, 40, "LVX_CHUNK_R_IMU")))) return rc; }
     auto ts = gather(f.t, perm, 1); auto g = gather(f.a3, perm, 3); auto a = gather(f.b3, perm, 3);
     if ((rc = upload(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
     if ((rc = upload(ctx, f.d_a3, g.data(), g.size() * 8))) return rc;
@@ -922,7 +940,7 @@ int ensure_layout(lvx_ctx* ctx) {
     for (int i = 0; i < f.n; ++i) key[i] = host_i0(ctx, f.t[i]);
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
-    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_SURFEL, sk, LVX_CHUNK_R))) return rc; }
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_SURFEL, sk, pick_chunk(ctx, 16, 32, "LVX_CHUNK_R")))) return rc; }
     auto ts = gather(f.t, perm, 1); auto pt = gather(f.a3, perm, 3); auto pl = gather(f.id0, perm, 1);
     if ((rc = upload(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
     if ((rc = upload(ctx, f.d_a3, pt.data(), pt.size() * 8))) return rc;
@@ -942,7 +960,7 @@ int ensure_layout(lvx_ctx* ctx) {
     }
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return k1[a] != k1[b] ? k1[a] < k1[b] : f.id0[a] < f.id0[b]; });
-    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = k1[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_REPROJ, sk, LVX_CHUNK_R))) return rc; }
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = k1[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_REPROJ, sk, pick_chunk(ctx, 24, 40, "LVX_CHUNK_R_REP")))) return rc; }
     auto ts = gather(f.t, perm, 1); auto uv = gather(f.a3, perm, 2); auto lm = gather(f.id0, perm, 1);
     if ((rc = upload(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
     if ((rc = upload(ctx, f.d_a3, uv.data(), uv.size() * 8))) return rc;
@@ -951,7 +969,7 @@ int ensure_layout(lvx_ctx* ctx) {
     std::vector<int> permB(f.n);
     std::iota(permB.begin(), permB.end(), 0);
     std::stable_sort(permB.begin(), permB.end(), [&](int a, int b) { return k0[a] != k0[b] ? k0[a] < k0[b] : (f.id0[a] != f.id0[b] ? f.id0[a] < f.id0[b] : f.t[a] < f.t[b]); });
-    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = k0[permB[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_PRIOR /* slot reused: the prior has no chunks */, sk, LVX_CHUNK_R))) return rc; }
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = k0[permB[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_PRIOR /* slot reused: the prior has no chunks */, sk, pick_chunk(ctx, 24, 40, "LVX_CHUNK_R_REP")))) return rc; }
     auto tsB = gather(f.t, permB, 1); auto uvB = gather(f.a3, permB, 2); auto lmB = gather(f.id0, permB, 1);
     if ((rc = upload(ctx, ctx->d_repB[0], tsB.data(), tsB.size() * 8))) return rc;
     if ((rc = upload(ctx, ctx->d_repB[1], uvB.data(), uvB.size() * 8))) return rc;
@@ -969,7 +987,7 @@ int ensure_layout(lvx_ctx* ctx) {
     for (int i = 0; i < f.n; ++i) key[i] = (f.id0[i] >= 0 && f.id0[i] < L) ? host_i0(ctx, ctx->lm_t0[f.id0[i]]) : -1;
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
-    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_CAMSURF, sk, LVX_CHUNK_R))) return rc; }
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_CAMSURF, sk, pick_chunk(ctx, 16, 32, "LVX_CHUNK_R")))) return rc; }
     auto lm = gather(f.id0, perm, 1); auto pl = gather(f.id1, perm, 1);
     if ((rc = upload(ctx, f.d_id0, lm.data(), lm.size() * 4))) return rc;
     if ((rc = upload(ctx, f.d_id1, pl.data(), pl.size() * 4))) return rc;
@@ -1151,23 +1169,24 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
   if (fast_surf || fast_cs)   // only the surfel / cam-surfel stream waits for the shared t_map pose
     hipLaunchKernelGGL(k_hub_eval, dim3(1), dim3(64), 0, s_surf, cm, ctx->t_map, fast_surf ? 1 : 0, fast_cs ? 1 : 0, (HubShared*)ctx->d_hubs.p);
   static const int occ = getenv("LVX_OCC") ? atoi(getenv("LVX_OCC")) : 1;   // 1 wave / SIMD: phase 1 spills at the 256-register budget of 2
-#define LVX_LAUNCH_MFMA1(FT, CRV, OCCV, fam_obj, chunk_slot, stream, row0v)                                                                   \
+#define LVX_LAUNCH_MFMA1(FT, OCCV, fam_obj, chunk_slot, stream, row0v)                                                                        \
   do {                                                                                                                                     \
-    const size_t lds_ = mfma_lds_bytes<FT, CRV>();                                                                                         \
-    LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_mfma<FT, CRV, OCCV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));  \
-    hipLaunchKernelGGL((k_family_mfma<FT, CRV, OCCV>), dim3(ctx->n_chunk[chunk_slot]), dim3(256), lds_, stream, fam_obj, cm, (const int*)ctx->d_chunk[chunk_slot].p, (long long)(row0v)); \
+    const size_t lds_ = mfma_lds_bytes<FT>(ctx->chunk_r[chunk_slot]);                                                                      \
+    LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_mfma<FT, OCCV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));       \
+    hipLaunchKernelGGL((k_family_mfma<FT, OCCV>), dim3(ctx->n_chunk[chunk_slot]), dim3(256), lds_, stream, fam_obj, cm, (const int*)ctx->d_chunk[chunk_slot].p, (long long)(row0v), \
+                       ctx->chunk_r[chunk_slot]);                                                                                          \
   } while (0)
-#define LVX_LAUNCH_MFMA(FT, CRV, fam_obj, chunk_slot, stream, row0v)                                                                          \
-  do { if (occ == 1) LVX_LAUNCH_MFMA1(FT, CRV, 1, fam_obj, chunk_slot, stream, row0v); else LVX_LAUNCH_MFMA1(FT, CRV, 2, fam_obj, chunk_slot, stream, row0v); } while (0)
+#define LVX_LAUNCH_MFMA(FT, fam_obj, chunk_slot, stream, row0v)                                                                               \
+  do { if (occ == 1) LVX_LAUNCH_MFMA1(FT, 1, fam_obj, chunk_slot, stream, row0v); else LVX_LAUNCH_MFMA1(FT, 2, fam_obj, chunk_slot, stream, row0v); } while (0)
   const bool imu_fast = fast && !getenv("LVX_IMU_LEGACY");
   if (ctx->imu.n > 0) {
     if (imu_fast) {
       GyroAcc g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
-      { ProfScope ps(ctx, LVX_FAM_GYRO, s_imu); LVX_LAUNCH_MFMA(GyroAcc, LVX_CHUNK_R_IMU, g, LVX_FAM_GYRO, s_imu, ctx->fam_row0[0]); }
+      { ProfScope ps(ctx, LVX_FAM_GYRO, s_imu); LVX_LAUNCH_MFMA(GyroAcc, g, LVX_FAM_GYRO, s_imu, ctx->fam_row0[0]); }
       if (!(ctx->locks & LVX_LOCK_R3)) {
         AccelAcc a{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.huber /*w_acc*/, 0.0};
         ProfScope ps(ctx, LVX_FAM_ACCEL, s_acc);
-        LVX_LAUNCH_MFMA(AccelAcc, LVX_CHUNK_R_IMU, a, LVX_FAM_GYRO, s_acc, ctx->fam_row0[1]);
+        LVX_LAUNCH_MFMA(AccelAcc, a, LVX_FAM_GYRO, s_acc, ctx->fam_row0[1]);
       }
     } else {
       GyroFam g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
@@ -1197,7 +1216,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     } else if (fast_surf) {
       SurfAcc s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
                 (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
-      LVX_LAUNCH_MFMA(SurfAcc, LVX_CHUNK_R, s, LVX_FAM_SURFEL, s_surf, ctx->fam_row0[3]);
+      LVX_LAUNCH_MFMA(SurfAcc, s, LVX_FAM_SURFEL, s_surf, ctx->fam_row0[3]);
     } else {
       SurfFam s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
                 (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
@@ -1217,9 +1236,9 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
       if (what & LVX_EVAL_NORMAL_EQ) {
         const RepJac jac{Jb, rb, kb, r.n};
         RepObsAcc ra{r.n, r.lm, r.perm, jac, 0.0};
-        LVX_LAUNCH_MFMA1(RepObsAcc, LVX_CHUNK_R, 1, ra, LVX_FAM_REPROJ, s_rep, ctx->fam_row0[4]);   // measured: a second workgroup per CU does not help, the cross-term atomics bound this pass
+        LVX_LAUNCH_MFMA1(RepObsAcc, 1, ra, LVX_FAM_REPROJ, s_rep, ctx->fam_row0[4]);   // measured: a second workgroup per CU does not help, the cross-term atomics bound this pass
         RepRefAcc rb2{r.n, (const int*)ctx->d_repB[2].p, (const int*)ctx->d_repB[3].p, jac, 0.0};
-        LVX_LAUNCH_MFMA1(RepRefAcc, LVX_CHUNK_R, 1, rb2, LVX_FAM_PRIOR, s_rep, ctx->fam_row0[4]);
+        LVX_LAUNCH_MFMA1(RepRefAcc, 1, rb2, LVX_FAM_PRIOR, s_rep, ctx->fam_row0[4]);
       }
     } else
     hipLaunchKernelGGL((k_family<ReprojFam, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, r, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
@@ -1233,7 +1252,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     } else if (fast_cs) {
       CamSurfAcc c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
                    (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
-      LVX_LAUNCH_MFMA(CamSurfAcc, LVX_CHUNK_R, c, LVX_FAM_CAMSURF, s_surf, ctx->fam_row0[5]);
+      LVX_LAUNCH_MFMA(CamSurfAcc, c, LVX_FAM_CAMSURF, s_surf, ctx->fam_row0[5]);
     } else {
       CamSurfFam c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
                    (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};

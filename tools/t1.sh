@@ -1,5 +1,4 @@
-cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
-rm -rf gpurun_out/lmprof
-rocprofv3 --kernel-trace -d gpurun_out/lmprof -o lm -- python tools/lm_scale_probe.py > gpurun_out/lmprof.log 2>&1
-python tools/rocpd_summary.py $(find gpurun_out/lmprof -name "*.db" | head -1) > gpurun_out/lmprof_stats.txt
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+for v in "LVX_SERIAL=1" "" ""; do
+env $v python bench.py --steps 20 --warmup 3 --no-secondary --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', round(d['value']), round(d['ms_per_step'],3), {k:round(v,3) for k,v in d['kernel_ms'].items()})"
+done
