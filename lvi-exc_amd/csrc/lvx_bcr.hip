@@ -93,21 +93,40 @@ __global__ __launch_bounds__(256) void k_trsm_batched(const double* __restrict__
   if (se == 1) { for (int e = tid; e < nv * b; e += 256) { const int i = e % b, t = e / b; W[i * TRS_WS + t] = v0[(size_t)t * sv + i]; } }
   else { for (int e = tid; e < 64 * b; e += 256) { const int t = e & 63, i = e >> 6; if (t < nv) W[i * TRS_WS + t] = v0[(size_t)t * sv + (size_t)i * se]; } }
   const int fk = lane >> 4, fi = lane & 15;
-  auto load_panel = [&](int k0) {
-    __syncthreads();                       // the previous panel is no longer read
-    for (int e = tid; e < 16 * bp; e += 256) {
-      const int kk = e / bp, i = e % bp, k = k0 + kk;
+  // panel k0 = columns k0 .. k0+15 of L below the diagonal.  Double buffered through registers: the loads of the NEXT panel are issued
+  // before the current one is used, so their latency overlaps the substitution + MFMA work (the chain of 13 panels is latency bound).
+  constexpr int NPRE = 16;                 // 16 * bp / 256 values per thread, bp <= 256 (LDS bound)
+  double pre[NPRE];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) {
+      const int e = tid + 256 * j;
       double v = 0.0;
-      if (k < b) { if (i >= k && i < b) v = L[(size_t)k * b + i]; } else if (i == k) v = 1.0;
-      P[kk * PS + i] = v;
+      if (e < 16 * bp) {
+        const int kk = e / bp, i = e - kk * bp, k = k0 + kk;
+        if (k < b) { if (i >= k && i < b) v = L[(size_t)k * b + i]; } else if (i == k) v = 1.0;
+      }
+      pre[j] = v;
     }
-    __syncthreads();
-    if (tid < 16) dinv[tid] = 1.0 / P[tid * PS + k0 + tid];
+  };
+  auto commit = [&](int k0) {
+    __syncthreads();                       // the previous panel is no longer read
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) {
+      const int e = tid + 256 * j;
+      if (e < 16 * bp) {
+        const int kk = e / bp, i = e - kk * bp;
+        P[kk * PS + i] = pre[j];
+        if (i == k0 + kk) dinv[kk] = 1.0 / pre[j];
+      }
+    }
     __syncthreads();
   };
   if (!TRANS) {
+    fetch(0);
     for (int k0 = 0; k0 < b; k0 += 16) {
-      load_panel(k0);
+      commit(k0);
+      if (k0 + 16 < b) fetch(k0 + 16);
       if (lane < 16) {                     // 16 x 16 lower-triangular solve, column oriented: 15 - q independent updates per step
         double x[16];
 #pragma unroll
@@ -127,7 +146,20 @@ __global__ __launch_bounds__(256) void k_trsm_batched(const double* __restrict__
       double Bf[4];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) Bf[ks] = W[(k0 + ks * 4 + fk) * TRS_WS + t0 + fi];
-      for (int i0 = k0 + 16; i0 < bp; i0 += 16) {
+      int i0 = k0 + 16;
+      for (; i0 + 16 < bp; i0 += 32) {     // two independent row tiles per step: their MFMA chains interleave
+        d4 Ca, Cb;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { Ca[v] = W[(i0 + fk + 4 * v) * TRS_WS + t0 + fi]; Cb[v] = W[(i0 + 16 + fk + 4 * v) * TRS_WS + t0 + fi]; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          Ca = __builtin_amdgcn_mfma_f64_16x16x4f64(-P[(ks * 4 + fk) * PS + i0 + fi], Bf[ks], Ca, 0, 0, 0);
+          Cb = __builtin_amdgcn_mfma_f64_16x16x4f64(-P[(ks * 4 + fk) * PS + i0 + 16 + fi], Bf[ks], Cb, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { W[(i0 + fk + 4 * v) * TRS_WS + t0 + fi] = Ca[v]; W[(i0 + 16 + fk + 4 * v) * TRS_WS + t0 + fi] = Cb[v]; }
+      }
+      for (; i0 < bp; i0 += 16) {
         d4 Cc;
 #pragma unroll
         for (int v = 0; v < 4; ++v) Cc[v] = W[(i0 + fk + 4 * v) * TRS_WS + t0 + fi];
@@ -138,15 +170,21 @@ __global__ __launch_bounds__(256) void k_trsm_batched(const double* __restrict__
       }
     }
   } else {
+    fetch(bp - 16);
     for (int k0 = bp - 16; k0 >= 0; k0 -= 16) {
-      load_panel(k0);
-      d4 Cc;
+      commit(k0);
+      if (k0 >= 16) fetch(k0 - 16);
+      d4 Cc, Cd = d4{0.0, 0.0, 0.0, 0.0};   // two accumulators over alternating k-steps: independent MFMA chains
 #pragma unroll
       for (int v = 0; v < 4; ++v) Cc[v] = W[(k0 + fk + 4 * v) * TRS_WS + t0 + fi];
-      for (int i0 = k0 + 16; i0 < bp; i0 += 4)
+      int i0 = k0 + 16;
+      for (; i0 + 4 < bp; i0 += 8) {
         Cc = __builtin_amdgcn_mfma_f64_16x16x4f64(-P[fi * PS + i0 + fk], W[(i0 + fk) * TRS_WS + t0 + fi], Cc, 0, 0, 0);
+        Cd = __builtin_amdgcn_mfma_f64_16x16x4f64(-P[fi * PS + i0 + 4 + fk], W[(i0 + 4 + fk) * TRS_WS + t0 + fi], Cd, 0, 0, 0);
+      }
+      for (; i0 < bp; i0 += 4) Cc = __builtin_amdgcn_mfma_f64_16x16x4f64(-P[fi * PS + i0 + fk], W[(i0 + fk) * TRS_WS + t0 + fi], Cc, 0, 0, 0);
 #pragma unroll
-      for (int v = 0; v < 4; ++v) W[(k0 + fk + 4 * v) * TRS_WS + t0 + fi] = Cc[v];
+      for (int v = 0; v < 4; ++v) W[(k0 + fk + 4 * v) * TRS_WS + t0 + fi] = Cc[v] + Cd[v];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -177,7 +215,7 @@ static int trsv_batched(lvx_ctx* c, const double* L, int b, long long strideL, d
   if (batch <= 0 || nvec <= 0) return LVX_OK;
   const int bp = (b + 15) & ~15;
   const size_t lds = ((size_t)bp * TRS_WS + (size_t)16 * (bp | 1) + 16) * 8;
-  if (lds > 158 * 1024) return fail(c, LVX_E_ARG, "block size too large for the LDS-resident triangular solve");
+  if (lds > 158 * 1024 || bp > 256) return fail(c, LVX_E_ARG, "block size too large for the LDS-resident triangular solve");
   LVX_HIP(c, hipFuncSetAttribute((const void*)k_trsm_batched<TRANS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_trsm_batched<TRANS>, dim3((unsigned)((nvec + 63) / 64), (unsigned)batch), dim3(256), lds, c->stream, L, b, strideL, V, se, sv, strideV, nvec);
   LVX_HIP(c, hipGetLastError());
