@@ -630,6 +630,17 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
       d4 D[G::NTP];
 #pragma unroll
       for (int t = 0; t < G::NTP; ++t) D[t] = d4{0.0, 0.0, 0.0, 0.0};
+      constexpr int NJX = NX > 0 ? (NK * NX + 63) / 64 : 1;
+      int ca[NJX], cx[NJX], cpa[NJX];      // this lane's (knot column, cross column) pairs and the window's ordering position of the knot column
+      if constexpr (NX > 0) {
+#pragma unroll
+        for (int j = 0; j < NJX; ++j) {
+          const int e2 = lane + 64 * j;
+          cx[j] = e2 / NK; ca[j] = e2 - cx[j] * NK;
+          cpa[j] = e2 < NK * NX ? kpos[wb + 6 * (ca[j] / KPK) + F::LVO + ca[j] % KPK] : LVX_DEAD;
+          if (e2 >= NK * NX) { cx[j] = 0; ca[j] = 0; }
+        }
+      }
       for (int g0 = l0; g0 <= lhi; g0 += GL) {
         const int gs = min(g0, 64 - GL);                     // the panel always maps GL existing lanes, so every panel row is rewritten
         if (lane >= gs && lane < gs + GL) {
@@ -670,19 +681,24 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
             for (int cj = ci; cj < NT; ++cj, ++t) D[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[ci], f[cj], D[t], 0, 0, 0);
         }
         if constexpr (NX > 0) {
-          // cross terms knot columns x cross columns of every block of the panel: unique to the block, one global atomic each;
-          // consecutive lanes take consecutive knot columns => runs along a band column
-          for (int e = lane; e < cnt * NK * NX; e += 64) {
-            const int bl = e / (NK * NX), rm = e - bl * (NK * NX), x = rm / NK, a = rm - x * NK;
+          // cross terms knot columns x cross columns of every block of the panel: unique to the block, one global atomic each.  A lane owns
+          // the same (knot column, cross column) pairs for every block (consecutive lanes = consecutive knot columns => runs along a band
+          // column), so only the block's cross positions and panel rows change: independent LDS reads, no division in the loop.
+          for (int bl = 0; bl < cnt; ++bl) {
             if (!xi[bl * (NX + 1) + NX]) continue;
-            const int pa = kpos[wb + 6 * (a / KPK) + F::LVO + a % KPK];
-            const int pb = xi[bl * (NX + 1) + x];
-            if (pa == LVX_DEAD || pb == LVX_DEAD) continue;
-            double v = 0.0;
+            const double* pr = P + bl * NR * LDP;
 #pragma unroll
-            for (int q = 0; q < NR; ++q) v += P[(bl * NR + q) * LDP + a] * P[(bl * NR + q) * LDP + XOFF + x];
-            if (v == 0.0) continue;
-            add_H(cm, pa, pb, pa == pb ? 2.0 * v : v, rep);   // the same variable through both poses: both orders of the pair land on the diagonal
+            for (int j = 0; j < NJX; ++j) {
+              const int pa = cpa[j];
+              if (pa == LVX_DEAD) continue;
+              const int pb = xi[bl * (NX + 1) + cx[j]];
+              if (pb == LVX_DEAD) continue;
+              double v = 0.0;
+#pragma unroll
+              for (int q = 0; q < NR; ++q) v += pr[q * LDP + ca[j]] * pr[q * LDP + XOFF + cx[j]];
+              if (v == 0.0) continue;
+              add_H(cm, pa, pb, pa == pb ? 2.0 * v : v, rep);   // the same variable through both poses: both orders of the pair land on the diagonal
+            }
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1178,85 +1194,110 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
   } while (0)
 #define LVX_LAUNCH_MFMA(FT, fam_obj, chunk_slot, stream, row0v)                                                                               \
   do { if (occ == 1) LVX_LAUNCH_MFMA1(FT, 1, fam_obj, chunk_slot, stream, row0v); else LVX_LAUNCH_MFMA1(FT, 2, fam_obj, chunk_slot, stream, row0v); } while (0)
-  const bool imu_fast = fast && !getenv("LVX_IMU_LEGACY");
-  if (ctx->imu.n > 0) {
-    if (imu_fast) {
-      GyroAcc g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
-      { ProfScope ps(ctx, LVX_FAM_GYRO, s_imu); LVX_LAUNCH_MFMA(GyroAcc, g, LVX_FAM_GYRO, s_imu, ctx->fam_row0[0]); }
-      if (!(ctx->locks & LVX_LOCK_R3)) {
-        AccelAcc a{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.huber /*w_acc*/, 0.0};
-        ProfScope ps(ctx, LVX_FAM_ACCEL, s_acc);
-        LVX_LAUNCH_MFMA(AccelAcc, a, LVX_FAM_GYRO, s_acc, ctx->fam_row0[1]);
-      }
-    } else {
-      GyroFam g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
-      { ProfScope ps(ctx, LVX_FAM_GYRO, s_imu);
-      hipLaunchKernelGGL((k_family<GyroFam, 1>), grid(g.n), dim3(64), 0, s_imu, g, cm, (const uint16_t*)ctx->d_pairs[0].p, (long long)ctx->fam_row0[0]); }
-      if (!(ctx->locks & LVX_LOCK_R3)) {
-        AccelFam a{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.huber /*w_acc*/, 0.0};
-        ProfScope ps(ctx, LVX_FAM_ACCEL, s_acc);
-        hipLaunchKernelGGL((k_family<AccelFam, LVX_PW>), grid(a.n), dim3(64 * LVX_PW), 0, s_acc, a, cm, (const uint16_t*)ctx->d_pairs[1].p, (long long)ctx->fam_row0[1]);
-      }
+  // launch order / overlap: the LiDAR kernels (VALU + MFMA heavy, one workgroup per CU) first and alone, then the IMU kernels and the
+  // reprojection passes next to each other.  Measured at config 4: the pass takes the same 1.55-1.6 ms with everything concurrent (the big
+  // kernels cannot share a CU and only slow each other down), staged like this, or serial (1.64 ms); staged, the dominant kernel's
+  // duration is its solo duration.  LVX_SCHED=0 restores "all concurrent".
+  static const int sched = getenv("LVX_SCHED") ? atoi(getenv("LVX_SCHED")) : 2;
+  const bool staged = sched == 2 && !getenv("LVX_SERIAL");
+  const int order[5] = {2, 4, 0, 1, 3};   // surfel, cam-surfel, imu, prior, reprojection
+  for (int ph = 0; ph < 5; ++ph) {
+    if (staged && ph == 2) {               // the other streams start when the LiDAR stream has drained
+      LVX_HIP(ctx, hipEventRecord(ctx->ev_join[2], s_surf));
+      LVX_HIP(ctx, hipStreamWaitEvent(s_imu, ctx->ev_join[2], 0)); LVX_HIP(ctx, hipStreamWaitEvent(s_acc, ctx->ev_join[2], 0)); LVX_HIP(ctx, hipStreamWaitEvent(s_rep, ctx->ev_join[2], 0));
     }
-  }
-  if (ctx->has_prior) {
-    static const int zero = 0;
-    DevBuf& pb = ctx->d_zero;   // identity permutation for the single prior block
-    if ((rc = upload(ctx, pb, &zero, 4))) return rc;
-    PriorFam p{1, ctx->prior_t, mkq(ctx->prior_q[0], ctx->prior_q[1], ctx->prior_q[2], ctx->prior_q[3]), (const int*)pb.p, ctx->prior_w, 0.0};
-    ProfScope ps(ctx, LVX_FAM_PRIOR, s_imu);
-    hipLaunchKernelGGL((k_family<PriorFam, 1>), dim3(1), dim3(64), 0, s_imu, p, cm, (const uint16_t*)ctx->d_pairs[2].p, (long long)ctx->fam_row0[2]);
-  }
-  if (ctx->surf.n > 0) {
-    ProfScope ps(ctx, LVX_FAM_SURFEL, s_surf);
-    if (tauL) {
-      SurfFamT<true> s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
-                       (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
-      hipLaunchKernelGGL((k_family<SurfFamT<true>, 1>), grid(s.n), dim3(64), 0, s_surf, s, cm, (const uint16_t*)ctx->d_pairs[3].p, (long long)ctx->fam_row0[3]);
-    } else if (fast_surf) {
-      SurfAcc s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
-                (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
-      LVX_LAUNCH_MFMA(SurfAcc, s, LVX_FAM_SURFEL, s_surf, ctx->fam_row0[3]);
-    } else {
-      SurfFam s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
-                (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
-      hipLaunchKernelGGL((k_family<SurfFam, 1>), grid(s.n), dim3(64), 0, s_surf, s, cm, (const uint16_t*)ctx->d_pairs[3].p, (long long)ctx->fam_row0[3]);
-    }
-  }
-  if (ctx->rep.n > 0) {
-    ReprojFam r{ctx->rep.n, (const int*)ctx->rep.d_id0.p, (const double*)ctx->rep.d_a3.p, (const double*)ctx->rep.d_t.p, (const int*)ctx->rep.d_perm.p,
-                (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->rep.weight, ctx->rep.huber};
-    ProfScope ps(ctx, LVX_FAM_REPROJ, s_rep);
-    if (tauC) {
-      ReprojFamT<true> rt{r.n, r.lm, r.uv, r.t0o, r.perm, r.lm_uv, r.lm_t0, r.weight, r.huber};
-      hipLaunchKernelGGL((k_family<ReprojFamT<true>, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, rt, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
-    } else if (fast && !getenv("LVX_REPROJ_LEGACY")) {
-      double* Jb = (double*)ctx->d_repB[0].p; double* rb = Jb + (size_t)2 * REP_NC * r.n; int* kb = (int*)ctx->d_repB[1].p;
-      hipLaunchKernelGGL(k_reproj_jac, grid(r.n), dim3(64), 0, s_rep, r, cm, Jb, rb, kb, (long long)ctx->fam_row0[4]);
-      if (what & LVX_EVAL_NORMAL_EQ) {
-        const RepJac jac{Jb, rb, kb, r.n};
-        RepObsAcc ra{r.n, r.lm, r.perm, jac, 0.0};
-        LVX_LAUNCH_MFMA1(RepObsAcc, 1, ra, LVX_FAM_REPROJ, s_rep, ctx->fam_row0[4]);   // measured: a second workgroup per CU does not help, the cross-term atomics bound this pass
-        RepRefAcc rb2{r.n, (const int*)ctx->d_repB[2].p, (const int*)ctx->d_repB[3].p, jac, 0.0};
-        LVX_LAUNCH_MFMA1(RepRefAcc, 1, rb2, LVX_FAM_PRIOR, s_rep, ctx->fam_row0[4]);
+    switch (order[ph]) {
+    case 0: {
+      const bool imu_fast = fast && !getenv("LVX_IMU_LEGACY");
+      if (ctx->imu.n > 0) {
+        if (imu_fast) {
+          GyroAcc g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
+          { ProfScope ps(ctx, LVX_FAM_GYRO, s_imu); LVX_LAUNCH_MFMA(GyroAcc, g, LVX_FAM_GYRO, s_imu, ctx->fam_row0[0]); }
+          if (!(ctx->locks & LVX_LOCK_R3)) {
+            AccelAcc a{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.huber /*w_acc*/, 0.0};
+            ProfScope ps(ctx, LVX_FAM_ACCEL, s_acc);
+            LVX_LAUNCH_MFMA(AccelAcc, a, LVX_FAM_GYRO, s_acc, ctx->fam_row0[1]);
+          }
+        } else {
+          GyroFam g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
+          { ProfScope ps(ctx, LVX_FAM_GYRO, s_imu);
+          hipLaunchKernelGGL((k_family<GyroFam, 1>), grid(g.n), dim3(64), 0, s_imu, g, cm, (const uint16_t*)ctx->d_pairs[0].p, (long long)ctx->fam_row0[0]); }
+          if (!(ctx->locks & LVX_LOCK_R3)) {
+            AccelFam a{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.huber /*w_acc*/, 0.0};
+            ProfScope ps(ctx, LVX_FAM_ACCEL, s_acc);
+            hipLaunchKernelGGL((k_family<AccelFam, LVX_PW>), grid(a.n), dim3(64 * LVX_PW), 0, s_acc, a, cm, (const uint16_t*)ctx->d_pairs[1].p, (long long)ctx->fam_row0[1]);
+          }
+        }
       }
-    } else
-    hipLaunchKernelGGL((k_family<ReprojFam, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, r, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
-  }
-  if (ctx->cs.n > 0) {
-    ProfScope ps(ctx, LVX_FAM_CAMSURF, s_surf);
-    if (tauC) {
-      CamSurfFamT<true> c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
-                          (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
-      hipLaunchKernelGGL((k_family<CamSurfFamT<true>, 1>), grid(c.n), dim3(64), 0, s_surf, c, cm, (const uint16_t*)ctx->d_pairs[5].p, (long long)ctx->fam_row0[5]);
-    } else if (fast_cs) {
-      CamSurfAcc c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
-                   (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
-      LVX_LAUNCH_MFMA(CamSurfAcc, c, LVX_FAM_CAMSURF, s_surf, ctx->fam_row0[5]);
-    } else {
-      CamSurfFam c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
-                   (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
-      hipLaunchKernelGGL((k_family<CamSurfFam, 1>), grid(c.n), dim3(64), 0, s_surf, c, cm, (const uint16_t*)ctx->d_pairs[5].p, (long long)ctx->fam_row0[5]);
+    } break;
+    case 1: {
+      if (ctx->has_prior) {
+        static const int zero = 0;
+        DevBuf& pb = ctx->d_zero;   // identity permutation for the single prior block
+        if ((rc = upload(ctx, pb, &zero, 4))) return rc;
+        PriorFam p{1, ctx->prior_t, mkq(ctx->prior_q[0], ctx->prior_q[1], ctx->prior_q[2], ctx->prior_q[3]), (const int*)pb.p, ctx->prior_w, 0.0};
+        ProfScope ps(ctx, LVX_FAM_PRIOR, s_imu);
+        hipLaunchKernelGGL((k_family<PriorFam, 1>), dim3(1), dim3(64), 0, s_imu, p, cm, (const uint16_t*)ctx->d_pairs[2].p, (long long)ctx->fam_row0[2]);
+      }
+    } break;
+    case 2: {
+      if (ctx->surf.n > 0) {
+        ProfScope ps(ctx, LVX_FAM_SURFEL, s_surf);
+        if (tauL) {
+          SurfFamT<true> s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
+                           (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
+          hipLaunchKernelGGL((k_family<SurfFamT<true>, 1>), grid(s.n), dim3(64), 0, s_surf, s, cm, (const uint16_t*)ctx->d_pairs[3].p, (long long)ctx->fam_row0[3]);
+        } else if (fast_surf) {
+          SurfAcc s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
+                    (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
+          LVX_LAUNCH_MFMA(SurfAcc, s, LVX_FAM_SURFEL, s_surf, ctx->fam_row0[3]);
+        } else {
+          SurfFam s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
+                    (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
+          hipLaunchKernelGGL((k_family<SurfFam, 1>), grid(s.n), dim3(64), 0, s_surf, s, cm, (const uint16_t*)ctx->d_pairs[3].p, (long long)ctx->fam_row0[3]);
+        }
+      }
+    } break;
+    case 3: {
+      if (ctx->rep.n > 0) {
+        ReprojFam r{ctx->rep.n, (const int*)ctx->rep.d_id0.p, (const double*)ctx->rep.d_a3.p, (const double*)ctx->rep.d_t.p, (const int*)ctx->rep.d_perm.p,
+                    (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->rep.weight, ctx->rep.huber};
+        ProfScope ps(ctx, LVX_FAM_REPROJ, s_rep);
+        if (tauC) {
+          ReprojFamT<true> rt{r.n, r.lm, r.uv, r.t0o, r.perm, r.lm_uv, r.lm_t0, r.weight, r.huber};
+          hipLaunchKernelGGL((k_family<ReprojFamT<true>, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, rt, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
+        } else if (fast && !getenv("LVX_REPROJ_LEGACY")) {
+          double* Jb = (double*)ctx->d_repB[0].p; double* rb = Jb + (size_t)2 * REP_NC * r.n; int* kb = (int*)ctx->d_repB[1].p;
+          hipLaunchKernelGGL(k_reproj_jac, grid(r.n), dim3(64), 0, s_rep, r, cm, Jb, rb, kb, (long long)ctx->fam_row0[4]);
+          if (what & LVX_EVAL_NORMAL_EQ) {
+            const RepJac jac{Jb, rb, kb, r.n};
+            RepObsAcc ra{r.n, r.lm, r.perm, jac, 0.0};
+            LVX_LAUNCH_MFMA1(RepObsAcc, 1, ra, LVX_FAM_REPROJ, s_rep, ctx->fam_row0[4]);   // measured: a second workgroup per CU does not help, the cross-term atomics bound this pass
+            RepRefAcc rb2{r.n, (const int*)ctx->d_repB[2].p, (const int*)ctx->d_repB[3].p, jac, 0.0};
+            LVX_LAUNCH_MFMA1(RepRefAcc, 1, rb2, LVX_FAM_PRIOR, s_rep, ctx->fam_row0[4]);
+          }
+        } else
+        hipLaunchKernelGGL((k_family<ReprojFam, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, r, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
+      }
+    } break;
+    case 4: {
+      if (ctx->cs.n > 0) {
+        ProfScope ps(ctx, LVX_FAM_CAMSURF, s_surf);
+        if (tauC) {
+          CamSurfFamT<true> c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
+                              (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
+          hipLaunchKernelGGL((k_family<CamSurfFamT<true>, 1>), grid(c.n), dim3(64), 0, s_surf, c, cm, (const uint16_t*)ctx->d_pairs[5].p, (long long)ctx->fam_row0[5]);
+        } else if (fast_cs) {
+          CamSurfAcc c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
+                       (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
+          LVX_LAUNCH_MFMA(CamSurfAcc, c, LVX_FAM_CAMSURF, s_surf, ctx->fam_row0[5]);
+        } else {
+          CamSurfFam c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
+                       (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
+          hipLaunchKernelGGL((k_family<CamSurfFam, 1>), grid(c.n), dim3(64), 0, s_surf, c, cm, (const uint16_t*)ctx->d_pairs[5].p, (long long)ctx->fam_row0[5]);
+        }
+      }
+    } break;
     }
   }
   for (int k = 0; k < 4; ++k) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[k], ctx->fam_stream[k])); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[k], 0)); }

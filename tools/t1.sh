@@ -1,2 +1,4 @@
-python -m pytest tests/test_gpu_solver.py tests/test_gpu_shared.py -m gpu -x -q 2>&1 | tail -2
-LVX_SOLVER_TIMING=1 python tools/lm_scale_probe.py 2>&1 | grep "sync\|lm 4" | tail -3
+python -m pytest tests -m gpu -x -q 2>&1 | tail -2
+for v in "" ""; do
+env $v python bench.py --steps 20 --warmup 3 --no-secondary --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', round(d['value']), round(d['ms_per_step'],3), {k:round(v,3) for k,v in d['kernel_ms'].items()})"
+done
