@@ -43,9 +43,10 @@ def test_solve_step_matches_dense(scaling, radius):
     (TAU_LOCKS | lvx.LOCK_CAM_Q | lvx.LOCK_CAM_P | lvx.LOCK_LANDMARKS, "solve1"),   # trajInitFromSurfel: gyro + accel + surfel, camera locked
     (TAU_LOCKS, "solve2"),                                                           # trajInitFromLVIdata: + reprojection
     (0, "solve2_free_tau"),                                                          # same with both sensor time offsets free (lvi.yaml:32 keeps them locked)
+    (TAU_LOCKS | lvx.LOCK_TRAJ | lvx.LOCK_LIDAR_Q | lvx.LOCK_LIDAR_P, "solve3"),     # refineCameraExtrinsics-style stage: trajectory and lidar locked, + camera-surfel landmarks
 ])
 def test_lm_matches_oracle(locks, stage):
-    P = synth.make_problem(seed=15, duration=2.0, n_surfel=600, n_planes=12, n_landmarks=30 if stage.startswith("solve2") else 0, n_camsurf=0)
+    P = synth.make_problem(seed=15, duration=2.0, n_surfel=600, n_planes=12, n_landmarks=30 if stage != "solve1" else 0, n_camsurf=12 if stage == "solve3" else 0)
     o = O.Oracle(); g = lvx.Context(0)
     for obj in (o, g):
         lvx.load_problem(obj, P, locks)
@@ -60,7 +61,8 @@ def test_lm_matches_oracle(locks, stage):
     for s in ("lidar", "cam"):
         assert _qang(ug[s][:4], uo[s][:4]) <= 1e-6
         assert np.abs(ug[s][4:7] - uo[s][4:7]).max() <= 1e-4
-    assert sg["final_cost"] < 1e-3 * sg["initial_cost"]
+    # with the trajectory locked at the perturbed start the IMU residuals keep the cost up; the free stages must fit
+    assert sg["final_cost"] < (1.0 if stage == "solve3" else 1e-3) * sg["initial_cost"]
     g.close()
 
 
