@@ -1592,6 +1592,10 @@ int lvx_plus(lvx_ctx* c, const double* s, const double* d, double* o) {
   qplus(si + 16, di + 8, oi + 16); for (int j = 0; j < 3; ++j) oi[20 + j] = si[20 + j] + di[11 + j]; oi[23] = si[23] + di[14];
   qplus(si + 24, di + 15, oi + 24); for (int j = 0; j < 3; ++j) oi[28 + j] = si[28 + j] + di[18 + j]; oi[31] = si[31] + di[21];
   for (int l = 0; l < c->L; ++l) oi[32 + l] = si[32 + l] + di[22 + l];
+  // box constraints, applied by projection as ceres::ParameterBlock::Plus does (see k_plus)
+  if (!(c->locks & LVX_LOCK_LIDAR_TAU)) oi[23] = std::min(std::max(oi[23], -c->sensor_mto), c->sensor_mto);
+  if (!(c->locks & LVX_LOCK_CAM_TAU)) oi[31] = std::min(std::max(oi[31], -c->sensor_mto), c->sensor_mto);
+  if (!(c->locks & LVX_LOCK_LANDMARKS)) for (int l = 0; l < c->L; ++l) oi[32 + l] = std::max(oi[32 + l], 0.0);
   return LVX_OK;
 }
 

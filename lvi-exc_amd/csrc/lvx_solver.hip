@@ -345,7 +345,9 @@ __device__ __forceinline__ void qplus_dev(const double* x, const double* d, doub
 }
 // x_out = x (+) delta ; sums[2] += |x_out - x|^2, sums[3] += |x|^2 over the free parameter blocks (ambient); the lidar / camera
 // blocks (shared between sequences in the joint solve) go to sums[6], sums[7] instead when split_shared
-__global__ void k_plus(const double* x, const double* delta, int N, int L, uint32_t locks, double* xo, double* sums, int split_shared) {
+// Box constraints (inverse depth >= 0: static_rscamera_measurement.h:185, camera_surfel_landmark.h:232; |free time offset| <= mto: sensors.h:161-162)
+// are enforced by projection of the candidate, as ceres::ParameterBlock::Plus does.
+__global__ void k_plus(const double* x, const double* delta, int N, int L, uint32_t locks, double* xo, double* sums, int split_shared, double mto) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double dn = 0.0, xn = 0.0;
   if (i < N) {
@@ -357,17 +359,19 @@ __global__ void k_plus(const double* x, const double* delta, int N, int L, uint3
     const double* s = x + 7 * (size_t)N; double* o = xo + 7 * (size_t)N; const double* d = delta + 6 * (size_t)N;
     const int cb = 6 * N;
     for (int j = 0; j < 8; ++j) o[j] = s[j];
-    auto addv = [&](int so, int to, int n) { const bool fr = !tangent_locked(cb + to, N, L, locks); for (int j = 0; j < n; ++j) { const double a = s[so + j], b = a + d[to + j]; o[so + j] = b; if (fr) { dn += (b - a) * (b - a); xn += a * a; } } };
+    auto addv = [&](int so, int to, int n, double bound = 0.0) { const bool fr = !tangent_locked(cb + to, N, L, locks); for (int j = 0; j < n; ++j) { const double a = s[so + j]; double b = a + d[to + j]; if (fr && bound > 0.0) b = fmin(fmax(b, -bound), bound); o[so + j] = b; if (fr) { dn += (b - a) * (b - a); xn += a * a; } } };
     auto addq = [&](int so, int to) { const bool fr = !tangent_locked(cb + to, N, L, locks); double q[4]; qplus_dev(s + so, d + to, q); for (int j = 0; j < 4; ++j) { const double a = s[so + j]; o[so + j] = q[j]; if (fr) { dn += (q[j] - a) * (q[j] - a); xn += a * a; } } };
     addv(8, 0, 1); addv(9, 1, 1); addv(10, 2, 3); addv(13, 5, 3);
     const double dn_p = dn, xn_p = xn;
-    addq(16, 8); addv(20, 11, 3); addv(23, 14, 1);
-    addq(24, 15); addv(28, 18, 3); addv(31, 21, 1);
+    addq(16, 8); addv(20, 11, 3); addv(23, 14, 1, mto);
+    addq(24, 15); addv(28, 18, 3); addv(31, 21, 1, mto);
     if (split_shared) { atomicAdd(&sums[6], dn - dn_p); atomicAdd(&sums[7], xn - xn_p); dn = dn_p; xn = xn_p; }
   } else if (i < N + 1 + L) {
     const int l = i - N - 1;
     const bool fr = !tangent_locked(6 * N + 22 + l, N, L, locks);
-    const double a = x[7 * (size_t)N + 32 + l], b = a + delta[6 * (size_t)N + 22 + l];
+    const double a = x[7 * (size_t)N + 32 + l];
+    double b = a + delta[6 * (size_t)N + 22 + l];
+    if (fr) b = fmax(b, 0.0);
     xo[7 * (size_t)N + 32 + l] = b;
     if (fr) { dn += (b - a) * (b - a); xn += a * a; }
   }
@@ -698,7 +702,7 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
     }
     invalid = 0;
     LVX_HIP(c, hipMemsetAsync(w.sums + 2, 0, 48, st));
-    hipLaunchKernelGGL(k_plus, dim3((unsigned)((N + 1 + L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, N, L, c->locks, xt, w.sums, joint ? 1 : 0);
+    hipLaunchKernelGGL(k_plus, dim3((unsigned)((N + 1 + L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, N, L, c->locks, xt, w.sums, joint ? 1 : 0, c->sensor_mto);
     double cand = 0;
     // cost-only evaluation of the candidate must not clobber the normal equations of x: LVX_EVAL_COST alone leaves them untouched
     if ((rc = lvx_evaluate_d(c, xt, LVX_EVAL_COST, &cand))) { if (rc == LVX_E_RANGE || rc == LVX_E_NONUNIT_QUAT) cand = INFINITY; else return rc; }

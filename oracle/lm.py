@@ -6,7 +6,8 @@ otherwise): Jacobi scaling computed at the first iterate, LM diagonal clamp(diag
 (reused after a rejected step), step acceptance by relative decrease > 1e-3, radius update
 r / max(1/3, 1 - (2 rho - 1)^3), rejection r / decrease_factor (2, 4, ...), and the parameter / function / gradient
 tolerance tests in the order of TrustRegionMinimizer::Minimize.  Dense numpy linear algebra on the oracle's J^T J.
-Bounds (rho >= 0, |tau| <= max) are not enforced.
+Bounds (rho >= 0, |free tau| <= max) are enforced by projection inside oracle.plus (ceres::ParameterBlock::Plus); the projected line search
+Ceres adds for constrained problems is not restated.
 """
 import numpy as np
 

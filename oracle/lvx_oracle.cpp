@@ -472,6 +472,12 @@ void orc_plus(const orc_problem* p, const double* state, const double* delta, do
   qplus(s + 16, d + 8, o + 16); for (int j = 0; j < 3; ++j) o[20 + j] = s[20 + j] + d[11 + j]; o[23] = s[23] + d[14];
   qplus(s + 24, d + 15, o + 24); for (int j = 0; j < 3; ++j) o[28 + j] = s[28 + j] + d[18 + j]; o[31] = s[31] + d[21];
   for (int l = 0; l < p->n_landmarks; ++l) o[32 + l] = s[32 + l] + d[22 + l];
+  // ceres::ParameterBlock::Plus projects onto the box constraints the measurements set: inverse depth >= 0 (static_rscamera_measurement.h:185,
+  // camera_surfel_landmark.h:232), |time offset| <= max_time_offset for a free offset (sensors.h:161-162)
+  const double mto = p->sensor_max_time_offset;
+  if (!(p->locks & LVXO_LOCK_LIDAR_TAU)) o[23] = std::min(std::max(o[23], -mto), mto);
+  if (!(p->locks & LVXO_LOCK_CAM_TAU)) o[31] = std::min(std::max(o[31], -mto), mto);
+  if (!(p->locks & LVXO_LOCK_LANDMARKS)) for (int l = 0; l < p->n_landmarks; ++l) o[32 + l] = std::max(o[32 + l], 0.0);
 }
 
 // Batch pose evaluation (position + orientation (x,y,z,w) [+ velocity, accel, angular velocity]) — used by KAT tests.

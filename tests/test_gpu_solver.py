@@ -87,3 +87,27 @@ def test_lm_so3_only_solve0():
     assert np.abs(sg["cost_history"] - so["cost_history"]).max() <= 1e-7 * so["cost_history"].max()
     assert np.abs(xg - xo).max() <= 1e-6
     g.close()
+
+
+def test_box_constraints_are_enforced_by_projection():
+    """ceres::ParameterBlock::Plus projects onto the bounds the measurements set (inverse depth >= 0, |free time offset| <= max_time_offset).
+    LiDAR stamps shifted by 3 ms make the solve want tau_lidar = +3 ms, three times the bound: both LMs must stop at the bound, in step."""
+    P = synth.make_problem(seed=23, duration=2.0, n_surfel=600, n_planes=12, n_landmarks=0, n_camsurf=0)
+    keep = P["surf_t"] - 0.003 >= P["t_map"] + 1e-3
+    P["surf_t"] = P["surf_t"][keep] - 0.003; P["surf_pt"] = P["surf_pt"][keep]; P["surf_plane"] = P["surf_plane"][keep]
+    locks = lvx.LOCK_CAM_TAU | lvx.LOCK_CAM_Q | lvx.LOCK_CAM_P | lvx.LOCK_LANDMARKS
+    o = O.Oracle(); g = lvx.Context(0)
+    for obj in (o, g):
+        lvx.load_problem(obj, P, locks)
+    N, L = P["n_knots"], P["n_landmarks"]
+    # the host-side Plus of both agrees, including the projection
+    d = np.zeros(o.tangent_size); d[6 * N + 14] = 0.01
+    assert o.plus(P["state0"], d)[7 * N + 23] == 0.001 and g.plus(P["state0"], d)[7 * N + 23] == 0.001
+    assert o.plus(P["state0"], -d)[7 * N + 23] == -0.001 and g.plus(P["state0"], -d)[7 * N + 23] == -0.001
+    free = lm.free_tangent_indices(N, L, locks)
+    xo, so = lm.lm_solve(o, P["state_true"], free, max_iterations=8, n_knots=N, n_landmarks=L)
+    xg, sg = g.lm_solve(P["state_true"], max_iterations=8)
+    assert list(sg["accepted"]) == list(so["accepted"]) and sg["termination"] == so["termination"]
+    assert np.abs(sg["cost_history"] - so["cost_history"]).max() <= 1e-7 * so["cost_history"].max()
+    assert xo[7 * N + 23] == 0.001 and xg[7 * N + 23] == 0.001          # at the bound exactly, on both
+    g.close()
