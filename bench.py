@@ -27,11 +27,11 @@ sys.path.insert(0, os.path.join(ROOT, "lvi-exc_amd"))
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6      # MI355X FP64: vector 78.6 TFLOP/s = matrix (v_mfma_f64_16x16x4_f64) 78.6 TFLOP/s
 # algorithmic bytes per residual block, SURVEY.md §8(d)
-# HBM bytes per launch of k_family_mfma<SurfAcc> at config 4 from the PMC counters (FETCH_SIZE 21.1 MB + WRITE_SIZE 54.8 MB per dispatch with
+# HBM bytes per launch of k_family_mfma<SurfAcc> at config 4 from the PMC counters (FETCH_SIZE 20.8 MB + WRITE_SIZE 53.1 MB per dispatch with
 # normal equations; KiB -> bytes; FETCH_SIZE is not doubled: these are 8-byte strided reads, not the 16 B/lane streams the guide's x2
 # correction was calibrated on)
-PMC_TRAFFIC_BYTES = 75.8e6
-PMC_SOURCE = "profiles/r01c_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per dispatch)"
+PMC_TRAFFIC_BYTES = 73.9e6
+PMC_SOURCE = "profiles/r01d_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per dispatch)"
 BYTES_PER_EVAL = {"imu": 32, "surfel": 60, "reproj": 60}
 FLOPS_PER_EVAL = {"imu": 4e3, "surfel": 9e3, "reproj": 11e3}
 
@@ -239,8 +239,8 @@ def main():
                            "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
                            "hbm": {"achieved_GBps": alg_bytes / (surf_ms * 1e-3) / 1e9 if surf_ms > 0 else 0.0, "peak_GBps": HBM_PEAK_GBS},
                            "note": "fused residual + analytic Jacobian + FP64-MFMA J^T J kernel of the LiDAR surfel family (1 M of the 1.45 M blocks); FP64 matrix = FP64 vector peak = 78.6 TFLOP/s on MI355X; "
-                                   "9 kFLOP / 60 B per block (SURVEY.md 8d) => compute bound, the HBM figure is reported for completeness; duration from HIP events on the kernel's own stream while the "
-                                   "sibling family kernels run concurrently (solo durations: kernel_ms_solo)"}
+                                   "9 kFLOP / 60 B per block (SURVEY.md 8d) => compute bound, the HBM figure is reported for completeness; duration from HIP events on the kernel's own stream; the LiDAR kernels run first and alone, the IMU and "
+                                   "reprojection kernels concurrently after them (solo durations of all kernels: kernel_ms_solo)"}
         out["kernel_ms"] = {lvx.KERNEL_NAMES[i]: ms[i] / max(1, launches[i]) for i in range(len(ms)) if launches[i]}
         if world == 1:   # solo durations: the same step with every family kernel on one stream (outside the timed region)
             os.environ["LVX_SERIAL"] = "1"
