@@ -261,6 +261,14 @@ typedef int (*lvx_allreduce_fn)(void* user, double* buf, int n, int op);   /* in
 int lvx_solve_step_shared(lvx_ctx* ctx, double radius, int jacobi_scaling, lvx_allreduce_fn fn, void* user, double* delta, double* model_cost_change);
 int lvx_lm_solve_shared(lvx_ctx* ctx, double* state, const lvx_lm_options* opt, lvx_allreduce_fn fn, void* user, lvx_lm_summary* summary);
 
+/* NDT registration derivatives ------------------------------------------------------------------------*/
+/* pclomp::NormalDistributionsTransform::computeDerivatives with DIRECT7 search (src/ndt_omp/include/pclomp/ndt_omp_impl.hpp:180-285, 289-430, 484-536)
+ * against the voxel grid of the last lvx_voxel_build of this context (resolution = its leaf size): score, 6-gradient and 6 x 6 Hessian (row-major)
+ * of the NDT objective at the transform vector p6 = (tx, ty, tz, rx, ry, rz); input = source cloud, trans = the same cloud already transformed by p6
+ * (pcl::transformPointCloud, as the caller does before every call).  Per-point arithmetic in float like the reference, accumulation in double. */
+int lvx_ndt_derivatives(lvx_ctx* ctx, int n, const float* input_xyzi4, const float* trans_xyzi4, const double* p6, double outlier_ratio, int compute_hessian,
+                        double* score, double* gradient6, double* hessian36);
+
 /* surfel map extraction ------------------------------------------------------------------------------*/
 /* SurfelAssociation::setSurfelMap + checkPlaneType (src/lvi_exc/src/core/surfel_association.cpp:50-86, 246-266) over the leaves of the last
  * lvx_voxel_build of this context (the cloud passed to it must still be alive): leaves with >= min_leaf_points points and planarity >= p_lambda,

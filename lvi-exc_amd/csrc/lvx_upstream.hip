@@ -279,6 +279,86 @@ __global__ void k_vx_leaf(const float4* p, const unsigned* ukeys, const unsigned
   }
   leaf_n[li] = nr;
 }
+// NDT derivatives: one thread per point (float arithmetic in the reference's order of operations), 43 doubles reduced per workgroup
+struct NdtConst { float j_ang[8][3]; float h_ang[15][3]; float gd2; double gauss_d1; };
+__global__ __launch_bounds__(256) void k_ndt_derivatives(const float4* src, const float4* trn, int n, float leaf, int min_pts, VxGrid g, const int* grid, const int* leaf_n,
+                                                         const double* mean, const double* icov, NdtConst K, int compute_hessian, double* out43) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  double acc[43];
+#pragma unroll
+  for (int e = 0; e < 43; ++e) acc[e] = 0.0;
+  if (idx < n) {
+    const float4 xi = src[idx], xt = trn[idx];
+    float pg[3][6] = {{1, 0, 0, 0, 0, 0}, {0, 1, 0, 0, 0, 0}, {0, 0, 1, 0, 0, 0}};
+    float xj[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) xj[r] = (K.j_ang[r][0] * xi.x + K.j_ang[r][1] * xi.y) + K.j_ang[r][2] * xi.z;
+    pg[1][3] = xj[0]; pg[2][3] = xj[1]; pg[0][4] = xj[2]; pg[1][4] = xj[3]; pg[2][4] = xj[4]; pg[0][5] = xj[5]; pg[1][5] = xj[6]; pg[2][5] = xj[7];
+    float hv[6][3];   // a, b, c, d, e, f of Equation 6.21
+#pragma unroll
+    for (int r = 0; r < 6; ++r) hv[r][0] = hv[r][1] = hv[r][2] = 0.0f;
+    if (compute_hessian) {
+      float xh[15];
+#pragma unroll
+      for (int r = 0; r < 15; ++r) xh[r] = (K.h_ang[r][0] * xi.x + K.h_ang[r][1] * xi.y) + K.h_ang[r][2] * xi.z;
+      hv[0][1] = xh[0]; hv[0][2] = xh[1]; hv[1][1] = xh[2]; hv[1][2] = xh[3]; hv[2][1] = xh[4]; hv[2][2] = xh[5];
+      hv[3][0] = xh[6]; hv[3][1] = xh[7]; hv[3][2] = xh[8]; hv[4][0] = xh[9]; hv[4][1] = xh[10]; hv[4][2] = xh[11]; hv[5][0] = xh[12]; hv[5][1] = xh[13]; hv[5][2] = xh[14];
+    }
+    // second-derivative block (i, j), i, j in 3..5: a b c / b d e / c e f
+    const int hsel[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+    const int ijk[3] = {(int)floorf(xt.x / leaf), (int)floorf(xt.y / leaf), (int)floorf(xt.z / leaf)};
+    const int disp[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+    for (int nb = 0; nb < 7; ++nb) {
+      bool in = true;
+      for (int a = 0; a < 3; ++a) in = in && (g.min_b[a] - ijk[a] <= disp[nb][a]) && (g.max_b[a] - ijk[a] >= disp[nb][a]);
+      if (!in) continue;
+      const int key = (ijk[0] + disp[nb][0] - g.min_b[0]) * g.mul[0] + (ijk[1] + disp[nb][1] - g.min_b[1]) * g.mul[1] + (ijk[2] + disp[nb][2] - g.min_b[2]) * g.mul[2];
+      const int li = grid[key];
+      if (li < 0 || leaf_n[li] < min_pts) continue;
+      const double* mu = mean + 3 * (size_t)li; const double* ic = icov + 9 * (size_t)li;
+      const float x4[3] = {(float)((double)xt.x - mu[0]), (float)((double)xt.y - mu[1]), (float)((double)xt.z - mu[2])};
+      float ci[3][3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) ci[r][cc] = (float)ic[3 * r + cc];
+      float xc[3];
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) xc[cc] = (x4[0] * ci[0][cc] + x4[1] * ci[1][cc]) + x4[2] * ci[2][cc];
+      const float q = (x4[0] * xc[0] + x4[1] * xc[1]) + x4[2] * xc[2];
+      float e_x = expf(-K.gd2 * q * 0.5f);
+      const float score_inc = (float)(-K.gauss_d1 * e_x);
+      e_x = K.gd2 * e_x;
+      if (e_x > 1 || e_x < 0 || e_x != e_x) continue;
+      e_x = (float)(e_x * K.gauss_d1);
+      float cpg[3][6], xcpg[6];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) for (int j = 0; j < 6; ++j) cpg[r][j] = (ci[r][0] * pg[0][j] + ci[r][1] * pg[1][j]) + ci[r][2] * pg[2][j];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) { xcpg[j] = (x4[0] * cpg[0][j] + x4[1] * cpg[1][j]) + x4[2] * cpg[2][j]; acc[1 + j] += (double)(e_x * xcpg[j]); }
+      if (compute_hessian) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            const float pgcpg = (pg[0][j] * cpg[0][i] + pg[1][j] * cpg[1][i]) + pg[2][j] * cpg[2][i];   // (point_gradient^T C^-1 point_gradient)(j, i)
+            float v = 0.0f;
+            if (i >= 3 && j >= 3) { const float* h3 = hv[hsel[i - 3][j - 3]]; v = (xc[0] * h3[0] + xc[1] * h3[1]) + xc[2] * h3[2]; }
+            acc[7 + 6 * i + j] += (double)(e_x * (-K.gd2 * xcpg[i] * xcpg[j] + v + pgcpg));
+          }
+      }
+      acc[0] += (double)score_inc;
+    }
+  }
+  __shared__ double red[4][43];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int e = 0; e < 43; ++e) {
+    double v = acc[e];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) red[wv][e] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 43) { const double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]; if (v != 0.0) atomicAdd(&out43[threadIdx.x], v); }
+}
 // surfel map extraction: one thread per leaf (tens to hundreds of points each), three passes over the leaf's points
 struct SurfelPlaneDev { double p4[4], Pi[3], bmin[3], bmax[3]; int leaf, n_points, n_inliers, plane_type; };
 __global__ void k_surfel_extract(const float4* p, const unsigned* counts, const unsigned* offs, const int* sorted_ids, int nl, const int* leaf_n, const double* mean,
@@ -738,6 +818,55 @@ int lvx_surfel_extract(lvx_ctx* c, double p_lambda, double dist_threshold, int m
   int np = 0;
   for (int li = 0; li < nl; ++li) if (flag[li]) { if (np < max_planes) std::memcpy(&planes[np], &all[li], sizeof(SurfelPlaneDev)); ++np; }   // leaf order = voxel key order (std::map)
   *n_planes = np;
+  return LVX_OK;
+}
+
+int lvx_ndt_derivatives(lvx_ctx* c, int n, const float* input_xyzi4, const float* trans_xyzi4, const double* p6, double outlier_ratio, int compute_hessian,
+                        double* score, double* gradient6, double* hessian36) {
+  if (!c || n < 0 || !p6 || !score || !gradient6 || (compute_hessian && !hessian36) || (n > 0 && (!input_xyzi4 || !trans_xyzi4))) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  const lvx_ctx::Voxels& V = c->vox;
+  *score = 0.0;
+  for (int j = 0; j < 6; ++j) gradient6[j] = 0.0;
+  if (hessian36) for (int e = 0; e < 36; ++e) hessian36[e] = 0.0;
+  if (n == 0 || V.n_leaves == 0) return LVX_OK;
+  // Gaussian fitting parameters (eq. 6.8 [Magnusson 2009]; ndt_omp_impl.hpp:63-67), angular derivative tables (:289-383)
+  NdtConst K;
+  const double res = (double)V.leaf;
+  const double gauss_c1 = 10.0 * (1 - outlier_ratio), gauss_c2 = outlier_ratio / std::pow(res, 3);
+  const double gauss_d3 = -std::log(gauss_c2);
+  K.gauss_d1 = -std::log(gauss_c1 + gauss_c2) - gauss_d3;
+  K.gd2 = (float)(-2 * std::log((-std::log(gauss_c1 * std::exp(-0.5) + gauss_c2) - gauss_d3) / K.gauss_d1));
+  double cx, cy, cz, sx, sy, sz;
+  if (std::fabs(p6[3]) < 10e-5) { cx = 1.0; sx = 0.0; } else { cx = std::cos(p6[3]); sx = std::sin(p6[3]); }
+  if (std::fabs(p6[4]) < 10e-5) { cy = 1.0; sy = 0.0; } else { cy = std::cos(p6[4]); sy = std::sin(p6[4]); }
+  if (std::fabs(p6[5]) < 10e-5) { cz = 1.0; sz = 0.0; } else { cz = std::cos(p6[5]); sz = std::sin(p6[5]); }
+  const double ja[8][3] = {{-sx * sz + cx * sy * cz, -sx * cz - cx * sy * sz, -cx * cy}, {cx * sz + sx * sy * cz, cx * cz - sx * sy * sz, -sx * cy}, {-sy * cz, sy * sz, cy}, {sx * cy * cz, -sx * cy * sz, sx * sy},
+                           {-cx * cy * cz, cx * cy * sz, -cx * sy}, {-cy * sz, -cy * cz, 0}, {cx * cz - sx * sy * sz, -cx * sz - sx * sy * cz, 0}, {sx * cz + cx * sy * sz, cx * sy * cz - sx * sz, 0}};
+  const double ha[15][3] = {{-cx * sz - sx * sy * cz, -cx * cz + sx * sy * sz, sx * cy}, {-sx * sz + cx * sy * cz, -cx * sy * sz - sx * cz, -cx * cy}, {cx * cy * cz, -cx * cy * sz, cx * sy},
+                            {sx * cy * cz, -sx * cy * sz, sx * sy}, {-sx * cz - cx * sy * sz, sx * sz - cx * sy * cz, 0}, {cx * cz - sx * sy * sz, -sx * sy * cz - cx * sz, 0}, {-cy * cz, cy * sz, sy},
+                            {-sx * sy * cz, sx * sy * sz, sx * cy}, {cx * sy * cz, -cx * sy * sz, -cx * cy}, {sy * sz, sy * cz, 0}, {-sx * cy * sz, -sx * cy * cz, 0}, {cx * cy * sz, cx * cy * cz, 0},
+                            {-cy * cz, cy * sz, 0}, {-cx * sz - sx * sy * cz, -cx * cz + sx * sy * sz, 0}, {-sx * sz + cx * sy * cz, -cx * sy * sz - sx * cz, 0}};
+  for (int r = 0; r < 8; ++r) for (int k = 0; k < 3; ++k) K.j_ang[r][k] = (float)ja[r][k];
+  for (int r = 0; r < 15; ++r) for (int k = 0; k < 3; ++k) K.h_ang[r][k] = (float)ha[r][k];
+  int rc;
+  if ((rc = upload(c, c->d_up[2], input_xyzi4, (size_t)n * 16))) return rc;
+  if ((rc = upload(c, c->d_up[3], trans_xyzi4, (size_t)n * 16))) return rc;
+  if ((rc = dev_alloc(c, c->d_up[6], 43 * 8))) return rc;
+  LVX_HIP(c, hipMemsetAsync(c->d_up[6].p, 0, 43 * 8, c->stream));
+  VxGrid g; std::memcpy(&g, &V.grid, sizeof(g));
+  const int* lk = (const int*)V.leaf_i.p; const double* d = (const double*)V.leaf_d.p;
+  const size_t nl = (size_t)V.n_leaves;
+  { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
+    hipLaunchKernelGGL(k_ndt_derivatives, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const float4*)c->d_up[2].p, (const float4*)c->d_up[3].p, n, V.leaf, V.min_pts, g, (const int*)V.cells.p,
+                       lk + nl, d, d + 12 * nl, K, compute_hessian, (double*)c->d_up[6].p); }
+  LVX_HIP(c, hipGetLastError());
+  double h[43];
+  LVX_HIP(c, hipMemcpyAsync(h, c->d_up[6].p, 43 * 8, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  *score = h[0];
+  for (int j = 0; j < 6; ++j) gradient6[j] = h[1 + j];
+  if (hessian36) for (int e = 0; e < 36; ++e) hessian36[e] = h[7 + e];
   return LVX_OK;
 }
 

@@ -412,6 +412,16 @@ def upstream_bench(ctx, kind, arrays, reps=20):
     return (time.perf_counter() - t0) / reps
 
 
+def ndt_derivatives(ctx, src, trans, p6, outlier_ratio=0.55, compute_hessian=True):
+    """Score, gradient, Hessian of the NDT objective against the context's last voxel_build (computeDerivatives, DIRECT7)."""
+    src = np.ascontiguousarray(src, dtype=np.float32).reshape(-1, 4)
+    trans = np.ascontiguousarray(trans, dtype=np.float32).reshape(-1, 4)
+    score = C.c_double(0)
+    g, H = np.zeros(6), np.zeros((6, 6))
+    ctx._ck(ctx._l.lvx_ndt_derivatives(ctx._h, C.c_int(len(src)), _p(src), _p(trans), _p(_d(p6)), C.c_double(outlier_ratio), C.c_int(1 if compute_hessian else 0), C.byref(score), _p(g), _p(H)))
+    return score.value, g, H
+
+
 SURFEL_PLANE = np.dtype([("p4", "<f8", 4), ("Pi", "<f8", 3), ("box_min", "<f8", 3), ("box_max", "<f8", 3), ("leaf", "<i4"), ("n_points", "<i4"), ("n_inliers", "<i4"),
                          ("plane_type", "<i4")])
 

@@ -264,6 +264,17 @@ def surfel_extract(xyzi, vox, p_lambda=0.7, dist_threshold=0.05, min_leaf_points
                 n_points=P[:, 14].astype(np.int32), n_inliers=P[:, 15].astype(np.int32), plane_type=types[:n].copy())
 
 
+def ndt_derivatives(vox, leaf, src, trans, p6, outlier_ratio=0.55, compute_hessian=True, min_pts=6):
+    src = np.ascontiguousarray(src, dtype=np.float32).reshape(-1, 4)
+    trans = np.ascontiguousarray(trans, dtype=np.float32).reshape(-1, 4)
+    ids = voxel_lookup7(vox, trans, leaf, min_pts)
+    score = C.c_double(0)
+    g, H = np.zeros(6), np.zeros((6, 6))
+    lib().orc_ndt_derivatives(C.c_int(len(src)), _p(src), _p(trans), _p(ids), _p(np.ascontiguousarray(vox["mean"])), _p(np.ascontiguousarray(vox["icov"])), _p(_d(p6)),
+                              C.c_double(leaf), C.c_double(outlier_ratio), C.c_int(1 if compute_hessian else 0), C.byref(score), _p(g), _p(H))
+    return score.value, g, H
+
+
 def voxel_lookup7(vox, queries, leaf, min_pts=6):
     q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, 4)
     ids = np.full((len(q), 7), -1, np.int32)

@@ -318,4 +318,88 @@ int orc_surfel_extract(int n_leaves, const float* xyzi, const int32_t* leaf_n, c
   return np;
 }
 
+// pclomp::NormalDistributionsTransform::computeDerivatives with DIRECT7 (/root/reference/src/ndt_omp/include/pclomp/ndt_omp_impl.hpp:180-285),
+// computeAngleDerivatives (:289-383), computePointDerivatives float form (:387-430), updateDerivatives (:484-536), Gaussian constants (:63-67).
+// The per-point arithmetic is FLOAT as in the reference (Eigen float matrices; sums here run left to right — Eigen's vectorised order is not
+// restated, so agreement with the real library is to float rounding), the accumulation over cells and points is double, points in index order.
+// ids7: orc_voxel_lookup7 of the TRANSFORMED points; leaf arrays from orc_voxel_build.
+void orc_ndt_derivatives(int n, const float* input_xyzi, const float* trans_xyzi, const int32_t* ids7, const double* mean, const double* icov, const double* p6,
+                         double resolution, double outlier_ratio, int compute_hessian, double* score_out, double* grad6, double* hess36) {
+  const double gauss_c1 = 10.0 * (1 - outlier_ratio), gauss_c2 = outlier_ratio / std::pow(resolution, 3);
+  const double gauss_d3 = -std::log(gauss_c2), gauss_d1 = -std::log(gauss_c1 + gauss_c2) - gauss_d3;
+  const double gauss_d2 = -2 * std::log((-std::log(gauss_c1 * std::exp(-0.5) + gauss_c2) - gauss_d3) / gauss_d1);
+  double cx, cy, cz, sx, sy, sz;
+  if (std::fabs(p6[3]) < 10e-5) { cx = 1.0; sx = 0.0; } else { cx = std::cos(p6[3]); sx = std::sin(p6[3]); }
+  if (std::fabs(p6[4]) < 10e-5) { cy = 1.0; sy = 0.0; } else { cy = std::cos(p6[4]); sy = std::sin(p6[4]); }
+  if (std::fabs(p6[5]) < 10e-5) { cz = 1.0; sz = 0.0; } else { cz = std::cos(p6[5]); sz = std::sin(p6[5]); }
+  const float j_ang[8][3] = {{(float)(-sx * sz + cx * sy * cz), (float)(-sx * cz - cx * sy * sz), (float)(-cx * cy)}, {(float)(cx * sz + sx * sy * cz), (float)(cx * cz - sx * sy * sz), (float)(-sx * cy)},
+                             {(float)(-sy * cz), (float)(sy * sz), (float)cy}, {(float)(sx * cy * cz), (float)(-sx * cy * sz), (float)(sx * sy)},
+                             {(float)(-cx * cy * cz), (float)(cx * cy * sz), (float)(-cx * sy)}, {(float)(-cy * sz), (float)(-cy * cz), 0.0f},
+                             {(float)(cx * cz - sx * sy * sz), (float)(-cx * sz - sx * sy * cz), 0.0f}, {(float)(sx * cz + cx * sy * sz), (float)(cx * sy * cz - sx * sz), 0.0f}};
+  const float h_ang[15][3] = {{(float)(-cx * sz - sx * sy * cz), (float)(-cx * cz + sx * sy * sz), (float)(sx * cy)}, {(float)(-sx * sz + cx * sy * cz), (float)(-cx * sy * sz - sx * cz), (float)(-cx * cy)},
+                              {(float)(cx * cy * cz), (float)(-cx * cy * sz), (float)(cx * sy)}, {(float)(sx * cy * cz), (float)(-sx * cy * sz), (float)(sx * sy)},
+                              {(float)(-sx * cz - cx * sy * sz), (float)(sx * sz - cx * sy * cz), 0.0f}, {(float)(cx * cz - sx * sy * sz), (float)(-sx * sy * cz - cx * sz), 0.0f},
+                              {(float)(-cy * cz), (float)(cy * sz), (float)sy}, {(float)(-sx * sy * cz), (float)(sx * sy * sz), (float)(sx * cy)}, {(float)(cx * sy * cz), (float)(-cx * sy * sz), (float)(-cx * cy)},
+                              {(float)(sy * sz), (float)(sy * cz), 0.0f}, {(float)(-sx * cy * sz), (float)(-sx * cy * cz), 0.0f}, {(float)(cx * cy * sz), (float)(cx * cy * cz), 0.0f},
+                              {(float)(-cy * cz), (float)(cy * sz), 0.0f}, {(float)(-cx * sz - sx * sy * cz), (float)(-cx * cz + sx * sy * sz), 0.0f}, {(float)(-sx * sz + cx * sy * cz), (float)(-cx * sy * sz - sx * cz), 0.0f}};
+  double score = 0.0, G[6] = {0, 0, 0, 0, 0, 0}, H[36];
+  for (int e = 0; e < 36; ++e) H[e] = 0.0;
+  const float gd2 = (float)gauss_d2;
+  for (int idx = 0; idx < n; ++idx) {
+    const float* xi = input_xyzi + 4 * idx; const float* xt = trans_xyzi + 4 * idx;
+    // point gradient (3 x 6) and point hessian blocks, float
+    float pg[3][6] = {{1, 0, 0, 0, 0, 0}, {0, 1, 0, 0, 0, 0}, {0, 0, 1, 0, 0, 0}};
+    float xj[8];
+    for (int r = 0; r < 8; ++r) xj[r] = (j_ang[r][0] * xi[0] + j_ang[r][1] * xi[1]) + j_ang[r][2] * xi[2];
+    pg[1][3] = xj[0]; pg[2][3] = xj[1]; pg[0][4] = xj[2]; pg[1][4] = xj[3]; pg[2][4] = xj[4]; pg[0][5] = xj[5]; pg[1][5] = xj[6]; pg[2][5] = xj[7];
+    float ph[6][3][6];   // ph[i][.][j] = second derivative block (i, j)
+    for (int i = 0; i < 6; ++i) for (int k = 0; k < 3; ++k) for (int j = 0; j < 6; ++j) ph[i][k][j] = 0.0f;
+    if (compute_hessian) {
+      float xh[15];
+      for (int r = 0; r < 15; ++r) xh[r] = (h_ang[r][0] * xi[0] + h_ang[r][1] * xi[1]) + h_ang[r][2] * xi[2];
+      const float a[3] = {0, xh[0], xh[1]}, b[3] = {0, xh[2], xh[3]}, c[3] = {0, xh[4], xh[5]}, d[3] = {xh[6], xh[7], xh[8]}, e[3] = {xh[9], xh[10], xh[11]}, f[3] = {xh[12], xh[13], xh[14]};
+      for (int k = 0; k < 3; ++k) { ph[3][k][3] = a[k]; ph[4][k][3] = b[k]; ph[5][k][3] = c[k]; ph[3][k][4] = b[k]; ph[4][k][4] = d[k]; ph[5][k][4] = e[k]; ph[3][k][5] = c[k]; ph[4][k][5] = e[k]; ph[5][k][5] = f[k]; }
+    }
+    double score_pt = 0.0, g_pt[6] = {0, 0, 0, 0, 0, 0}, h_pt[36];
+    for (int e = 0; e < 36; ++e) h_pt[e] = 0.0;
+    for (int nb = 0; nb < 7; ++nb) {
+      const int li = ids7[7 * idx + nb];
+      if (li < 0) continue;
+      const double xd[3] = {(double)xt[0] - mean[3 * li], (double)xt[1] - mean[3 * li + 1], (double)xt[2] - mean[3 * li + 2]};   // x_trans -= cell->getMean() in double
+      const float x4[3] = {(float)xd[0], (float)xd[1], (float)xd[2]};
+      float ci[3][3];
+      for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) ci[r][cc] = (float)icov[9 * li + 3 * r + cc];
+      float xc[3];   // x^T C^-1
+      for (int cc = 0; cc < 3; ++cc) xc[cc] = (x4[0] * ci[0][cc] + x4[1] * ci[1][cc]) + x4[2] * ci[2][cc];
+      const float q = (x4[0] * xc[0] + x4[1] * xc[1]) + x4[2] * xc[2];
+      float e_x = std::exp(-gd2 * q * 0.5f);
+      const float score_inc = (float)(-gauss_d1 * e_x);
+      e_x = gd2 * e_x;
+      if (e_x > 1 || e_x < 0 || e_x != e_x) continue;
+      e_x = (float)(e_x * gauss_d1);
+      float cpg[3][6];   // C^-1 * point_gradient
+      for (int r = 0; r < 3; ++r) for (int j = 0; j < 6; ++j) cpg[r][j] = (ci[r][0] * pg[0][j] + ci[r][1] * pg[1][j]) + ci[r][2] * pg[2][j];
+      float xcpg[6];
+      for (int j = 0; j < 6; ++j) xcpg[j] = (x4[0] * cpg[0][j] + x4[1] * cpg[1][j]) + x4[2] * cpg[2][j];
+      for (int j = 0; j < 6; ++j) g_pt[j] += (double)(e_x * xcpg[j]);
+      if (compute_hessian) {
+        float pgcpg[6][6];   // point_gradient^T C^-1 point_gradient
+        for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) pgcpg[i][j] = (pg[0][i] * cpg[0][j] + pg[1][i] * cpg[1][j]) + pg[2][i] * cpg[2][j];
+        for (int i = 0; i < 6; ++i) {
+          float v[6];
+          for (int j = 0; j < 6; ++j) v[j] = (xc[0] * ph[i][0][j] + xc[1] * ph[i][1][j]) + xc[2] * ph[i][2][j];
+          for (int j = 0; j < 6; ++j) h_pt[6 * i + j] += (double)(e_x * (-gd2 * xcpg[i] * xcpg[j] + v[j] + pgcpg[j][i]));
+        }
+      }
+      score_pt += (double)score_inc;
+    }
+    score += score_pt;
+    for (int j = 0; j < 6; ++j) G[j] += g_pt[j];
+    for (int e = 0; e < 36; ++e) H[e] += h_pt[e];
+  }
+  *score_out = score;
+  for (int j = 0; j < 6; ++j) grad6[j] = G[j];
+  for (int e = 0; e < 36; ++e) hess36[e] = H[e];
+}
+
 }  // extern "C"

@@ -190,3 +190,43 @@ def test_surfel_map_extraction(ctx):
     fg = lvx.surfel_assoc(ctx, scan, rg["p4"], rg["box_min"], rg["box_max"], 0.05, 2)
     fo = O.surfel_assoc(scan, ro["p4"], ro["box_min"], ro["box_max"], 0.05, 2)
     assert np.array_equal(fg, fo) and (fg >= 0).sum() > 0
+
+
+def _ndt_transform(cloud, p6):
+    """pcl::transformPointCloud with T = Translation(p0..2) * Rx(p3) * Ry(p4) * Rz(p5) in float (ndt_omp_impl.hpp:139-146)."""
+    cx, sx, cy, sy, cz, sz = np.cos(p6[3]), np.sin(p6[3]), np.cos(p6[4]), np.sin(p6[4]), np.cos(p6[5]), np.sin(p6[5])
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]); Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]); Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    R = (Rx @ Ry @ Rz).astype(np.float32)
+    out = cloud.copy()
+    out[:, :3] = (cloud[:, :3] @ R.T + np.asarray(p6[:3], np.float32)).astype(np.float32)
+    return out
+
+
+def test_ndt_derivatives(ctx):
+    """computeDerivatives (DIRECT7): float per-point arithmetic, double accumulation; GPU vs the serial restatement, and the gradient against
+    finite differences of the score (loose: the objective is evaluated in float)."""
+    cloud = synth.make_voxel_cloud(seed=2, n=60_000)
+    src = synth.make_voxel_cloud(seed=2, n=60_000)[::7].copy()           # a sub-sampled scan of the same scene
+    vo = O.voxel_build(cloud, 1.0)
+    lvx.voxel_build(ctx, cloud, 1.0, fetch=False)
+    for p6 in (np.zeros(6), np.array([0.12, -0.07, 0.03, 0.01, -0.015, 0.02])):
+        tr = _ndt_transform(src, p6)
+        so, go, Ho = O.ndt_derivatives(vo, 1.0, src, tr, p6)
+        sg, gg, Hg = lvx.ndt_derivatives(ctx, src, tr, p6)
+        assert so > 0 and abs(sg - so) <= 1e-6 * abs(so)        # gauss_d1 < 0: the score is a likelihood to maximise
+        assert np.abs(gg - go).max() <= 1e-5 * np.abs(go).max() and np.abs(Hg - Ho).max() <= 1e-5 * np.abs(Ho).max()
+        s2, g2, _ = lvx.ndt_derivatives(ctx, src, tr, p6, compute_hessian=False)
+        assert s2 == pytest.approx(sg, rel=1e-12) and np.allclose(g2, gg, rtol=1e-12)
+    # finite differences of the score along each parameter (translation 1e-3 m, rotation 1e-4 rad)
+    p0 = np.array([0.12, -0.07, 0.03, 0.01, -0.015, 0.02])
+    _, g0, H0 = lvx.ndt_derivatives(ctx, src, _ndt_transform(src, p0), p0)
+    for k in range(6):
+        h = 1e-3 if k < 3 else 1e-4
+        pp, pm = p0.copy(), p0.copy(); pp[k] += h; pm[k] -= h
+        fd = (lvx.ndt_derivatives(ctx, src, _ndt_transform(src, pp), pp, compute_hessian=False)[0] - lvx.ndt_derivatives(ctx, src, _ndt_transform(src, pm), pm, compute_hessian=False)[0]) / (2 * h)
+        # the objective jumps whenever a point changes its voxel neighbourhood; rotations move the far points by millimetres per step
+        assert abs(fd - g0[k]) <= (0.05 if k < 3 else 0.25) * np.abs(g0).max()
+    assert np.abs(H0 - H0.T).max() <= 1e-3 * np.abs(H0).max()
+    # empty input
+    s0, g00, _ = lvx.ndt_derivatives(ctx, np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32), p0)
+    assert s0 == 0 and not g00.any()
