@@ -212,7 +212,7 @@ typedef struct lvx_rs_point {
 } lvx_rs_point;
 /* caller-owned host buffers with capacity n_in (scan_start/scan_end: n_rings); any pointer may be NULL.  Mirrors the globals
  * cloudCurvature / cloudSortInd / cloudNeighborPicked / cloudLabel (scanRegistration.cpp:82-85) and the four published clouds
- * as index lists into `cloud` (less_flat BEFORE the 0.2 m VoxelGrid of :440-444) */
+ * as index lists into `cloud` (less_flat BEFORE the 0.2 m VoxelGrid of :440-444, which lvx_scan_less_flat_downsample applies) */
 typedef struct lvx_scanreg_out {
   int32_t n;            /* points kept after the range / NaN filter = laserCloud size */
   float* cloud;         /* [n][4] x, y, z, intensity = ring + (t - t_first) */
@@ -226,6 +226,10 @@ typedef struct lvx_scanreg_out {
   int32_t counts[4];
 } lvx_scanreg_out;
 int lvx_scan_register(lvx_ctx* ctx, int n, const lvx_rs_point* pts, int n_rings, float min_range, lvx_scanreg_out* out);
+/* The published less-flat cloud: pcl::VoxelGrid (leaf_size 0.2 m) over every ring's less-flat points, rings concatenated (scanRegistration.cpp:425-447),
+ * for the sweep of the last lvx_scan_register of this context.  out_xyzi4 [max_out][4], ring_counts [n_rings] (may be NULL), *n_out = total
+ * (also when larger than max_out).  Points of a voxel are averaged in their input order (pcl's std::sort leaves the order of equal keys open). */
+int lvx_scan_less_flat_downsample(lvx_ctx* ctx, float leaf_size, int max_out, float* out_xyzi4, int32_t* ring_counts, int32_t* n_out);
 
 /* pclomp::VoxelGridCovariance::applyFilter (src/ndt_omp/include/pclomp/voxel_grid_covariance_omp_impl.hpp:49-374): the grid stays on the
  * device inside the context; leaves are numbered in ascending voxel-key order (std::map iteration order of the reference) */

@@ -98,6 +98,7 @@ struct lvx_ctx {
   uint32_t last_what = 0;
   // upstream kernels (lvx_upstream.hip)
   lvx::DevBuf d_up[8];
+  int sr_n = 0, sr_rings = 0, sr_m = 0;   // input size, rings and kept points of the last lvx_scan_register (its results stay in d_up[0])
   struct Voxels {
     float leaf = 0; int min_pts = 0, n_points = 0, n_leaves = 0;
     const void* d_pts = nullptr;   // the cloud of the last build (device; caller- or context-owned), read again by lvx_surfel_extract

@@ -180,6 +180,62 @@ __global__ void k_sr_compact(int n_rings, const int* scan_start, const int* cnt_
   if (threadIdx.x < 4) counts[threadIdx.x] = off[threadIdx.x];
 }
 
+// pcl::VoxelGrid over one ring's less-flat points: one workgroup per ring; (voxel index, input position) pairs sorted in LDS (bitonic on a
+// 64-bit composite key => equal voxel indices keep their input order), run heads sum their run in float, outputs land in the ring's own slice
+#define SRV_CAP 4096
+__global__ __launch_bounds__(256) void k_sr_voxelgrid(const float4* cloud, const int* scan_start, const int* cnt_r, const int* lflat_r, float leaf, float4* out_r, int* out_cnt, int* err) {
+  __shared__ unsigned long long key[SRV_CAP];
+  __shared__ float red[6][256];
+  __shared__ int head_pos[SRV_CAP];
+  __shared__ int nout_s;
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const int n = cnt_r[4 * r + 3];
+  const int* list = lflat_r + (scan_start[r] - 5);
+  if (tid == 0) { out_cnt[r] = 0; nout_s = 0; }
+  if (n <= 0) return;
+  if (n > SRV_CAP) { if (tid == 0) atomicOr(err, 16); return; }
+  float mn[3] = {3.402823466e38f, 3.402823466e38f, 3.402823466e38f}, mx[3] = {-3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
+  for (int t = tid; t < n; t += 256) { const float4 q = cloud[list[t]]; mn[0] = fminf(mn[0], q.x); mn[1] = fminf(mn[1], q.y); mn[2] = fminf(mn[2], q.z); mx[0] = fmaxf(mx[0], q.x); mx[1] = fmaxf(mx[1], q.y); mx[2] = fmaxf(mx[2], q.z); }
+  for (int k = 0; k < 3; ++k) { red[k][tid] = mn[k]; red[3 + k][tid] = mx[k]; }
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) { if (tid < s2) for (int k = 0; k < 3; ++k) { red[k][tid] = fminf(red[k][tid], red[k][tid + s2]); red[3 + k][tid] = fmaxf(red[3 + k][tid], red[3 + k][tid + s2]); } __syncthreads(); }
+  const float inv = 1.0f / leaf;
+  int min_b[3], mul[3];
+  { int div_b[3]; for (int k = 0; k < 3; ++k) { min_b[k] = (int)floorf(red[k][0] * inv); div_b[k] = (int)floorf(red[3 + k][0] * inv) - min_b[k] + 1; } mul[0] = 1; mul[1] = div_b[0]; mul[2] = div_b[0] * div_b[1]; }
+  int np2 = 1; while (np2 < n) np2 <<= 1;
+  for (int t = tid; t < np2; t += 256) {
+    unsigned long long kv = ~0ull;
+    if (t < n) {
+      const float4 q = cloud[list[t]];
+      const int idx = (int)(floorf(q.x * inv) - (float)min_b[0]) * mul[0] + (int)(floorf(q.y * inv) - (float)min_b[1]) * mul[1] + (int)(floorf(q.z * inv) - (float)min_b[2]) * mul[2];
+      kv = ((unsigned long long)(unsigned)idx << 32) | (unsigned)t;
+    }
+    key[t] = kv;
+  }
+  __syncthreads();
+  for (int k2 = 2; k2 <= np2; k2 <<= 1)
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < np2; t += 256) {
+        const int p = t ^ j;
+        if (p > t) { const bool up = (t & k2) == 0; const unsigned long long a = key[t], b = key[p]; if ((a > b) == up) { key[t] = b; key[p] = a; } }
+      }
+      __syncthreads();
+    }
+  // run heads -> output positions (serial scan by one thread: a ring has a few thousand points at most)
+  if (tid == 0) { int no = 0; for (int t = 0; t < n; ++t) { const bool head = t == 0 || (key[t] >> 32) != (key[t - 1] >> 32); if (head) { head_pos[t] = no; ++no; } else head_pos[t] = -1; } nout_s = no; out_cnt[r] = no; }
+  __syncthreads();
+  float4* out = out_r + (scan_start[r] - 5);
+  for (int t = tid; t < n; t += 256) {
+    if (head_pos[t] < 0) continue;
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    int e = t;
+    const unsigned vk = (unsigned)(key[t] >> 32);
+    for (; e < n && (unsigned)(key[e] >> 32) == vk; ++e) { const float4 q = cloud[list[(unsigned)key[e]]]; c[0] += q.x; c[1] += q.y; c[2] += q.z; c[3] += q.w; }
+    const float cnt = (float)(e - t);
+    out[head_pos[t]] = make_float4(c[0] / cnt, c[1] / cnt, c[2] / cnt, c[3] / cnt);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 // voxel covariance grid
 // ------------------------------------------------------------------------------------------------------------------------
@@ -553,6 +609,7 @@ int lvx_scan_register(lvx_ctx* c, int n, const lvx_rs_point* pts, int n_rings, f
   LVX_HIP(c, hipStreamSynchronize(st));
   int m = 0; for (int v : hrc) m += v;
   out->n = m;
+  c->sr_n = n; c->sr_rings = n_rings; c->sr_m = m;
   if (m > 0) {
     hipLaunchKernelGGL(k_sr_gather, dim3((m + 255) / 256), dim3(256), 0, st, (const RsPoint*)d_pts, (const int*)d_src, m, d_cloud, d_curv, d_label, d_sort, d_pick);
     hipLaunchKernelGGL(k_sr_curv, dim3((m + 255) / 256), dim3(256), 0, st, (const float4*)d_cloud, m, d_curv);
@@ -867,6 +924,44 @@ int lvx_ndt_derivatives(lvx_ctx* c, int n, const float* input_xyzi4, const float
   *score = h[0];
   for (int j = 0; j < 6; ++j) gradient6[j] = h[1 + j];
   if (hessian36) for (int e = 0; e < 36; ++e) hessian36[e] = h[7 + e];
+  return LVX_OK;
+}
+
+int lvx_scan_less_flat_downsample(lvx_ctx* c, float leaf, int max_out, float* out_xyzi4, int32_t* ring_counts, int32_t* n_out) {
+  if (!c || !n_out || !(leaf > 0) || max_out < 0 || (max_out > 0 && !out_xyzi4)) return LVX_E_ARG;
+  *n_out = 0;
+  if (c->sr_rings <= 0 || !c->d_up[0].p) return fail(c, LVX_E_STATE, "lvx_scan_register has not been called");
+  LVX_HIP(c, hipSetDevice(c->device));
+  const int n = c->sr_n, n_rings = c->sr_rings, m = c->sr_m;
+  if (ring_counts) for (int r = 0; r < n_rings; ++r) ring_counts[r] = 0;
+  if (m == 0) return LVX_OK;
+  // same scratch layout as lvx_scan_register
+  const size_t o_cloud = (size_t)n * 32, o_curv = o_cloud + (size_t)n * 16, o_label = o_curv + (size_t)n * 4, o_sort = o_label + (size_t)n * 4, o_pick = o_sort + (size_t)n * 4,
+               o_src = o_pick + (size_t)n * 4, o_lists = o_src + (size_t)n * 4, o_lflat_r = o_lists + (size_t)n * 16, o_ring = o_lflat_r + (size_t)n * 4;
+  char* base = (char*)c->d_up[0].p;
+  const float4* d_cloud = (const float4*)(base + o_cloud); const int* d_lflat_r = (const int*)(base + o_lflat_r);
+  const int* d_rc = (const int*)(base + o_ring); const int* d_ss = d_rc + n_rings; const int* d_cnt = d_ss + 2 * (size_t)n_rings;
+  int rc;
+  if ((rc = dev_alloc(c, c->d_up[4], (size_t)n * 16))) return rc;
+  if ((rc = dev_alloc(c, c->d_up[5], (size_t)(n_rings + 1) * 4))) return rc;
+  int* d_oc = (int*)c->d_up[5].p; int* d_err = d_oc + n_rings;
+  LVX_HIP(c, hipMemsetAsync(d_err, 0, 4, c->stream));
+  { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
+    hipLaunchKernelGGL(k_sr_voxelgrid, dim3(n_rings), dim3(256), 0, c->stream, d_cloud, d_ss, d_cnt, d_lflat_r, leaf, (float4*)c->d_up[4].p, d_oc, d_err); }
+  LVX_HIP(c, hipGetLastError());
+  std::vector<int> oc(n_rings + 1), ss(n_rings);
+  LVX_HIP(c, hipMemcpyAsync(oc.data(), d_oc, (size_t)(n_rings + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipMemcpyAsync(ss.data(), d_ss, (size_t)n_rings * 4, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  if (oc[n_rings] & 16) return fail(c, LVX_E_ARG, "more less-flat points in one ring than the LDS sort capacity (4096)");
+  int total = 0;
+  for (int r = 0; r < n_rings; ++r) {
+    if (ring_counts) ring_counts[r] = oc[r];
+    const int room = std::max(0, std::min(oc[r], max_out - total));
+    if (room > 0) LVX_HIP(c, hipMemcpy(out_xyzi4 + 4 * (size_t)total, (const float4*)c->d_up[4].p + (ss[r] - 5), (size_t)room * 16, hipMemcpyDeviceToHost));
+    total += oc[r];
+  }
+  *n_out = total;
   return LVX_OK;
 }
 

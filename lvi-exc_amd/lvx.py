@@ -412,6 +412,15 @@ def upstream_bench(ctx, kind, arrays, reps=20):
     return (time.perf_counter() - t0) / reps
 
 
+def scan_less_flat_downsample(ctx, n_rings, max_out, leaf=0.2):
+    """The published less-flat cloud of the context's last scan_register: (xyzi [n][4], per-ring counts)."""
+    out = np.zeros((max(max_out, 1), 4), np.float32)
+    rc = np.zeros(n_rings, np.int32)
+    n = C.c_int32(0)
+    ctx._ck(ctx._l.lvx_scan_less_flat_downsample(ctx._h, C.c_float(leaf), C.c_int(max_out), _p(out), _p(rc), C.byref(n)))
+    return out[:min(n.value, max_out)], rc, n.value
+
+
 def ndt_derivatives(ctx, src, trans, p6, outlier_ratio=0.55, compute_hessian=True):
     """Score, gradient, Hessian of the NDT objective against the context's last voxel_build (computeDerivatives, DIRECT7)."""
     src = np.ascontiguousarray(src, dtype=np.float32).reshape(-1, 4)

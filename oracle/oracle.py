@@ -275,6 +275,15 @@ def ndt_derivatives(vox, leaf, src, trans, p6, outlier_ratio=0.55, compute_hessi
     return score.value, g, H
 
 
+def voxelgrid_xyzi(xyzi, leaf=0.2):
+    xyzi = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)
+    out = np.zeros((max(len(xyzi), 1), 4), np.float32)
+    l = lib()
+    l.orc_voxelgrid_xyzi.restype = C.c_int
+    n = l.orc_voxelgrid_xyzi(C.c_int(len(xyzi)), _p(xyzi), C.c_float(leaf), _p(out))
+    return out[:n]
+
+
 def voxel_lookup7(vox, queries, leaf, min_pts=6):
     q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, 4)
     ids = np.full((len(q), 7), -1, np.int32)

@@ -402,4 +402,37 @@ void orc_ndt_derivatives(int n, const float* input_xyzi, const float* trans_xyzi
   for (int e = 0; e < 36; ++e) hess36[e] = H[e];
 }
 
+// pcl::VoxelGrid<pcl::PointXYZI>::applyFilter as scanRegistration.cpp:440-444 uses it on one ring's less-flat points (leaf 0.2 m, all fields
+// averaged, no minimum point count, no field filter): min / max of the points, voxel index floor(x * inv) - min_b per axis in float, sort by
+// voxel index, centroid of every run in float.  pcl sorts with std::sort, whose order of EQUAL keys is implementation-defined; here equal keys
+// keep their input order, so a centroid can differ from a pcl build in the last float digit (same points, different summation order).
+// Returns the number of output points; out is xyzi per point.
+int orc_voxelgrid_xyzi(int n, const float* xyzi, float leaf, float* out) {
+  if (n <= 0) return 0;
+  const float inv = 1.0f / leaf;
+  float mn[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()}, mx[3] = {-mn[0], -mn[1], -mn[2]};
+  for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], xyzi[4 * i + k]); mx[k] = std::max(mx[k], xyzi[4 * i + k]); }
+  int min_b[3], max_b[3], div_b[3];
+  for (int k = 0; k < 3; ++k) { min_b[k] = static_cast<int>(std::floor(mn[k] * inv)); max_b[k] = static_cast<int>(std::floor(mx[k] * inv)); div_b[k] = max_b[k] - min_b[k] + 1; }
+  const int mul[3] = {1, div_b[0], div_b[0] * div_b[1]};
+  std::vector<std::pair<int, int>> iv(n);
+  for (int i = 0; i < n; ++i) {
+    int idx = 0;
+    for (int k = 0; k < 3; ++k) idx += static_cast<int>(std::floor(xyzi[4 * i + k] * inv) - static_cast<float>(min_b[k])) * mul[k];
+    iv[i] = {idx, i};
+  }
+  std::stable_sort(iv.begin(), iv.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first < b.first; });
+  int no = 0;
+  for (int a = 0; a < n;) {
+    int b = a + 1;
+    while (b < n && iv[b].first == iv[a].first) ++b;
+    float c[4] = {0, 0, 0, 0};
+    for (int k = a; k < b; ++k) for (int f = 0; f < 4; ++f) c[f] += xyzi[4 * iv[k].second + f];
+    const float cnt = static_cast<float>(b - a);
+    for (int f = 0; f < 4; ++f) out[4 * no + f] = c[f] / cnt;
+    ++no; a = b;
+  }
+  return no;
+}
+
 }  // extern "C"

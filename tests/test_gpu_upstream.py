@@ -230,3 +230,27 @@ def test_ndt_derivatives(ctx):
     # empty input
     s0, g00, _ = lvx.ndt_derivatives(ctx, np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32), p0)
     assert s0 == 0 and not g00.any()
+
+
+def test_less_flat_voxelgrid_downsample(ctx):
+    """The published less-flat cloud (scanRegistration.cpp:425-447): pcl::VoxelGrid 0.2 m per ring, rings concatenated; bit-exact against the
+    serial restatement (both average a voxel's points in input order)."""
+    pts = synth.make_vlp16_sweep(seed=1)
+    r = lvx.scan_register(ctx, pts, 16, 0.3)
+    ds, ring_counts, n = lvx.scan_less_flat_downsample(ctx, 16, max_out=len(r["less_flat"]))
+    cloud = r["cloud"]
+    exp = []
+    for ring in range(16):
+        idx = r["less_flat"][(r["less_flat"] >= r["scan_start"][ring] - 5) & (r["less_flat"] <= r["scan_end"][ring] + 5)]
+        e = O.voxelgrid_xyzi(cloud[idx], 0.2)
+        assert ring_counts[ring] == len(e)
+        exp.append(e)
+    exp = np.concatenate(exp)
+    assert n == len(exp) and 0 < n < len(r["less_flat"])
+    assert np.array_equal(ds.view(np.uint32), exp.view(np.uint32))
+    # a smaller output buffer: the total is still reported
+    d2, _, n2 = lvx.scan_less_flat_downsample(ctx, 16, max_out=100)
+    assert n2 == n and np.array_equal(d2, ds[:100])
+    # coarser leaf => fewer points
+    _, _, n3 = lvx.scan_less_flat_downsample(ctx, 16, max_out=10, leaf=1.0)
+    assert n3 < n
