@@ -366,7 +366,7 @@ struct AccelAcc {
   __device__ static int gcol(int g, int N, int nt) { return 6 * N + g; }
 };
 struct SurfAcc {
-  enum { NK = 24, NG = 12, NR = 1, HUB = 0, KPK = 6, LVO = 0, WS = 2, GL = 16, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 36, USE_PRE = 1 };
+  enum { NK = 24, NG = 12, NR = 1, HUB = 0, KPK = 6, LVO = 0, WS = 2, GL = 32, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 36, USE_PRE = 1 };
   __device__ static constexpr int jm(int c) { return c; }
   int n; const double* t; const double* pt; const int* plane; const int* perm; const double* planes; double t_map, weight, huber;
   __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared* hub, int si, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
