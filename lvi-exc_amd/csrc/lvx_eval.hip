@@ -346,7 +346,7 @@ struct Aux { int wid, xk, lm; const PreWin* pw; };   // pw: the workgroup's prec
 // panel for the direct cross-term scatter); WS knot intervals per MFMA window; GL lanes per panel; SKIP_GG: global x global and the global
 // gradient are assembled by another pass; SECONDARY: no cost / residual output; LMCOL: global column that is the window's landmark (or -1)
 struct GyroAcc {
-  enum { NK = 12, NG = 3, NR = 3, HUB = -1, KPK = 3, LVO = 3, WS = 1, GL = 8, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 15, USE_PRE = 1 };
+  enum { NK = 12, NG = 3, NR = 3, HUB = -1, KPK = 3, LVO = 3, WS = 1, GL = 8, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 15, USE_PRE = 1, OCC = 1 };
   __device__ static constexpr int jm(int c) { return c; }   // KPK columns per knot at offset LVO of its 6 tangent scalars; WS = knot intervals per MFMA window; GL = lanes per panel
   int n; const double* t; const double* m3; const int* perm; double weight, huber;
   __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared*, int si, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
@@ -356,7 +356,7 @@ struct GyroAcc {
   __device__ static int gcol(int g, int N, int nt) { return 6 * N + 5 + g; }
 };
 struct AccelAcc {
-  enum { NK = 24, NG = 5, NR = 3, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 8, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 29, USE_PRE = 1 };
+  enum { NK = 24, NG = 5, NR = 3, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 8, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 29, USE_PRE = 1, OCC = 1 };
   __device__ static constexpr int jm(int c) { return c; }
   int n; const double* t; const double* m3; const int* perm; double weight, huber;
   __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared*, int si, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
@@ -366,7 +366,7 @@ struct AccelAcc {
   __device__ static int gcol(int g, int N, int nt) { return 6 * N + g; }
 };
 struct SurfAcc {
-  enum { NK = 24, NG = 12, NR = 1, HUB = 0, KPK = 6, LVO = 0, WS = 2, GL = 32, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 36, USE_PRE = 1 };
+  enum { NK = 24, NG = 12, NR = 1, HUB = 0, KPK = 6, LVO = 0, WS = 2, GL = 16, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 36, USE_PRE = 1, OCC = 2 };   // reverse-mode Jacobian: fits two wavefronts per SIMD with a few spills, and two workgroups per CU hide its latencies
   __device__ static constexpr int jm(int c) { return c; }
   int n; const double* t; const double* pt; const int* plane; const int* perm; const double* planes; double t_map, weight, huber;
   __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared* hub, int si, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
@@ -386,7 +386,7 @@ struct SurfAcc {
   __device__ static int gcol(int g, int N, int nt) { return g < 6 ? nt + g : 6 * N + 8 + (g - 6); }
 };
 struct CamSurfAcc {
-  enum { NK = 24, NG = 18, NR = 1, HUB = 1, KPK = 6, LVO = 0, WS = 1, GL = 16, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 42, USE_PRE = 1 };
+  enum { NK = 24, NG = 18, NR = 1, HUB = 1, KPK = 6, LVO = 0, WS = 1, GL = 16, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 42, USE_PRE = 1, OCC = 2 };
   __device__ static constexpr int jm(int c) { return c; }
   int n; const int* lm; const int* plane; const int* perm; const double* planes; const double* lm_uv; const double* lm_t0; double t_map, weight, huber;
   __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared* hub, int si, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
@@ -904,8 +904,8 @@ int host_i0(const lvx_ctx* c, double t) {
 
 // Knot intervals per workgroup of the MFMA assembly kernels: every workgroup has the same expected work (~ R intervals), the launch runs in
 // ceil(workgroups / CUs) rounds, so pick R in [lo, hi] that minimises rounds * R (e.g. 25 k intervals on 256 CUs: R = 20 -> 1252 workgroups =
-// 4.9 rounds instead of 6.1 half-empty ones at R = 16).  LVX_CHUNK_R / LVX_CHUNK_R_REP / LVX_CHUNK_R_IMU (env) force a value.
-static int pick_chunk(const lvx_ctx* ctx, int lo, int hi, const char* env) {
+// 4.9 rounds instead of 6.1 half-empty ones at R = 16; families that run two workgroups per CU count 2 slots per CU).  LVX_CHUNK_R / LVX_CHUNK_R_REP / LVX_CHUNK_R_IMU (env) force a value.
+static int pick_chunk(const lvx_ctx* ctx, int lo, int hi, const char* env, int wg_per_cu = 1) {
   if (const char* e = getenv(env)) { const int v = atoi(e); if (v >= 4 && v <= 64) return v; }
   int ncu = 256;
   hipDeviceProp_t prop;
@@ -913,7 +913,8 @@ static int pick_chunk(const lvx_ctx* ctx, int lo, int hi, const char* env) {
   int best = lo; long long best_cost = -1;
   for (int r = lo; r <= hi; ++r) {
     const long long nwg = (ctx->N + r - 1) / r + 1;
-    const long long cost = ((nwg + ncu - 1) / ncu) * r;
+    const long long slots = (long long)ncu * wg_per_cu;
+    const long long cost = ((nwg + slots - 1) / slots) * r;
     if (best_cost < 0 || cost < best_cost) { best = r; best_cost = cost; }
   }
   return best;
@@ -956,7 +957,7 @@ int ensure_layout(lvx_ctx* ctx) {
     for (int i = 0; i < f.n; ++i) key[i] = host_i0(ctx, f.t[i]);
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
-    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_SURFEL, sk, pick_chunk(ctx, 16, 32, "LVX_CHUNK_R")))) return rc; }
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_SURFEL, sk, pick_chunk(ctx, 8, 16, "LVX_CHUNK_R", 2)))) return rc; }
     auto ts = gather(f.t, perm, 1); auto pt = gather(f.a3, perm, 3); auto pl = gather(f.id0, perm, 1);
     if ((rc = upload(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
     if ((rc = upload(ctx, f.d_a3, pt.data(), pt.size() * 8))) return rc;
@@ -1003,7 +1004,7 @@ int ensure_layout(lvx_ctx* ctx) {
     for (int i = 0; i < f.n; ++i) key[i] = (f.id0[i] >= 0 && f.id0[i] < L) ? host_i0(ctx, ctx->lm_t0[f.id0[i]]) : -1;
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
-    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_CAMSURF, sk, pick_chunk(ctx, 16, 32, "LVX_CHUNK_R")))) return rc; }
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_CAMSURF, sk, pick_chunk(ctx, 8, 16, "LVX_CHUNK_R", 2)))) return rc; }
     auto lm = gather(f.id0, perm, 1); auto pl = gather(f.id1, perm, 1);
     if ((rc = upload(ctx, f.d_id0, lm.data(), lm.size() * 4))) return rc;
     if ((rc = upload(ctx, f.d_id1, pl.data(), pl.size() * 4))) return rc;
@@ -1184,7 +1185,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
   const bool fast_surf = fast && !tauL && ctx->surf.n > 0, fast_cs = fast && !tauC && ctx->cs.n > 0;
   if (fast_surf || fast_cs)   // only the surfel / cam-surfel stream waits for the shared t_map pose
     hipLaunchKernelGGL(k_hub_eval, dim3(1), dim3(64), 0, s_surf, cm, ctx->t_map, fast_surf ? 1 : 0, fast_cs ? 1 : 0, (HubShared*)ctx->d_hubs.p);
-  static const int occ = getenv("LVX_OCC") ? atoi(getenv("LVX_OCC")) : 1;   // 1 wave / SIMD: phase 1 spills at the 256-register budget of 2
+  static const int occ_env = getenv("LVX_OCC") ? atoi(getenv("LVX_OCC")) : 0;   // 0: the family's own choice (F::OCC wavefronts per SIMD)
 #define LVX_LAUNCH_MFMA1(FT, OCCV, fam_obj, chunk_slot, stream, row0v)                                                                        \
   do {                                                                                                                                     \
     const size_t lds_ = mfma_lds_bytes<FT>(ctx->chunk_r[chunk_slot]);                                                                      \
@@ -1193,7 +1194,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
                        ctx->chunk_r[chunk_slot]);                                                                                          \
   } while (0)
 #define LVX_LAUNCH_MFMA(FT, fam_obj, chunk_slot, stream, row0v)                                                                               \
-  do { if (occ == 1) LVX_LAUNCH_MFMA1(FT, 1, fam_obj, chunk_slot, stream, row0v); else LVX_LAUNCH_MFMA1(FT, 2, fam_obj, chunk_slot, stream, row0v); } while (0)
+  do { if ((occ_env ? occ_env : (int)FT::OCC) == 1) LVX_LAUNCH_MFMA1(FT, 1, fam_obj, chunk_slot, stream, row0v); else LVX_LAUNCH_MFMA1(FT, 2, fam_obj, chunk_slot, stream, row0v); } while (0)
   // launch order / overlap: the LiDAR kernels (VALU + MFMA heavy, one workgroup per CU) first and alone, then the IMU kernels and the
   // reprojection passes next to each other.  Measured at config 4: the pass takes the same 1.55-1.6 ms with everything concurrent (the big
   // kernels cannot share a CU and only slow each other down), staged like this, or serial (1.64 ms); staged, the dominant kernel's

@@ -303,12 +303,15 @@ LVX_HD bool so3_eval(const quat c[4], double u, double dt, So3Eval* out) {
 //   c1 = (1 - cos theta)/theta^2 = sinc(a)^2 / 2,   c2 = (theta - sin theta)/theta^3 = (1 - sinc(a) cos a) / (4 a^2)   (double-angle forms)
 // Same series switches as so3_Jr / expq_half; results agree with so3_eval to rounding (tests/test_host_math.py).
 // ---------------------------------------------------------------------------------------------
-struct So3Pre { v3 Om; double on; m3 Jri; int ok; };   // Omega, |Omega|, J_r^-1(2 Omega), unit-norm check of logq
+struct So3Pre { v3 Om; double on; m3 Jri; double c3; int ok; };   // Omega, |Omega|, J_r^-1(2 Omega) and its coefficient c3 (J_r^-1 = I + K/2 + c3 K^2), unit-norm check of logq
 LVX_HD void so3_pre(quat ca, quat cb, So3Pre* o) {
   bool ok = true;
   o->Om = logq_half(qmul(qconj(ca), cb), &ok);
   o->on = sqrt(dot(o->Om, o->Om));
   o->Jri = so3_Jr_inv(2.0 * o->Om);
+  { const double t2 = 4.0 * o->on * o->on;   // same switch as so3_Jr_inv
+    if (t2 < 2.5e-3) o->c3 = 1.0 / 12.0 + t2 * (1.0 / 720.0 + t2 * (1.0 / 30240.0 + t2 / 1209600.0));
+    else { const double th = sqrt(t2), h = 0.5 * th; o->c3 = 1.0 / t2 - cos(h) / (2.0 * th * sin(h)); } }
   o->ok = ok ? 1 : 0;
 }
 template <bool NEED_W, bool NEED_J, bool NEED_DW = (NEED_W && NEED_J)>
@@ -393,6 +396,66 @@ LVX_HD bool so3_eval_pre(const quat c[4], const So3Pre* pre, double u, double dt
     if (NEED_DW) out->dw[k] = 2.0 * mul_t(We[k], Rk);
   }
   return ok;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Reverse mode for single-row residuals.  A scalar residual needs, per control point k, only the VECTOR dxi[k]^T g (g = d r / d xi): with
+//   u3 = g, u2 = R3 g, u1 = R2 u2, u0 = R1 u1,   a_j = P_j^T u_j,
+//   y0 = u0 - Jri1 a1,  y1 = Jri1^T a1 - Jri2 a2,  y2 = Jri2^T a2 - Jri3 a3,  y3 = Jri3^T a3,     dxi[k]^T g = 2 R(c_k) y_k
+// (the transposes of Xe[k] in so3_eval), and every product is a rotation by a quaternion or a pair of cross products:
+//   J_r(phi)^T v = v + c1 phi x v + c2 phi x (phi x v),   J_r^-1(d) v = v + d x v / 2 + c3 d x (d x v),   (J_r^-1)^T v = v - d x v / 2 + c3 d x (d x v).
+// 16 matrix-vector-sized operations instead of ~14 3x3 matrix products, and no 3x3 matrix is kept in registers.
+// ---------------------------------------------------------------------------------------------
+struct So3Val { quat q; quat E[4]; v3 phi[4]; double c1[4], c2[4]; };   // value, factors E_j, phi_j = B_j d_j and the J_r coefficients (j = 1..3)
+LVX_HD bool so3_value_pre(const quat c[4], const So3Pre* pre, double u, So3Val* o) {
+  const double u2 = u * u, u3 = u2 * u;
+  double B[4];
+  B[1] = 5.0 / 6.0 + u * (3.0 / 6.0) + u2 * (-3.0 / 6.0) + u3 * (1.0 / 6.0);
+  B[2] = 1.0 / 6.0 + u * (3.0 / 6.0) + u2 * (3.0 / 6.0) + u3 * (-2.0 / 6.0);
+  B[3] = u3 * (1.0 / 6.0);
+  bool ok = true;
+  quat q = c[0];
+#pragma unroll
+  for (int j = 1; j < 4; ++j) {
+    const So3Pre& pj = pre[j - 1];
+    ok = ok && pj.ok != 0;
+    const v3 v = B[j] * pj.Om;
+    const double a = B[j] * pj.on, a2 = a * a;
+    double ka, kv;
+    if (a2 > 1e-16) { ka = cos(a); kv = sin(a) / a; } else { ka = 1.0; kv = 1.0; }
+    o->E[j] = mkq(ka, kv * v.x, kv * v.y, kv * v.z);
+    q = qmul(q, o->E[j]);
+    const double t2 = 4.0 * a2;
+    if (t2 < 2.5e-3) {
+      o->c1[j] = 0.5 - t2 * (1.0 / 24.0 - t2 * (1.0 / 720.0 - t2 / 40320.0));
+      o->c2[j] = 1.0 / 6.0 - t2 * (1.0 / 120.0 - t2 * (1.0 / 5040.0 - t2 / 362880.0));
+    } else { o->c1[j] = 0.5 * kv * kv; o->c2[j] = (1.0 - kv * ka) / t2; }
+    o->phi[j] = (2.0 * B[j]) * pj.Om;
+    o->c1[j] *= B[j]; o->c2[j] *= B[j];       // P_j = B_j J_r(phi_j); the leading B_j is applied to v separately below
+  }
+  o->phi[0] = mk(B[1], B[2], B[3]);           // slot 0 carries the cumulative basis values
+  o->q = q;
+  return ok;
+}
+// y[k] = dxi[k]^T g for the four control points
+LVX_HD void so3_pullback_pre(const quat c[4], const So3Pre* pre, const So3Val& s, v3 g, v3 y[4]) {
+  const double B[4] = {0.0, s.phi[0].x, s.phi[0].y, s.phi[0].z};
+  v3 uv[4];
+  uv[3] = g; uv[2] = qrot(s.E[3], uv[3]); uv[1] = qrot(s.E[2], uv[2]); uv[0] = qrot(s.E[1], uv[1]);
+  v3 a[4], fw[4], bw[4];   // a_j = P_j^T u_j ; fw_j = Jri_j a_j ; bw_j = Jri_j^T a_j
+#pragma unroll
+  for (int j = 1; j < 4; ++j) {
+    const v3 p1 = cross(s.phi[j], uv[j]);
+    a[j] = B[j] * uv[j] + s.c1[j] * p1 + s.c2[j] * cross(s.phi[j], p1);
+    const v3 d = 2.0 * pre[j - 1].Om;
+    const v3 k1 = cross(d, a[j]);
+    const v3 k2 = pre[j - 1].c3 * cross(d, k1);
+    fw[j] = a[j] + 0.5 * k1 + k2;
+    bw[j] = a[j] - 0.5 * k1 + k2;
+  }
+  const v3 y0 = uv[0] - fw[1], y1 = bw[1] - fw[2], y2 = bw[2] - fw[3], y3 = bw[3];
+  y[0] = 2.0 * qrot(c[0], y0); y[1] = 2.0 * qrot(c[1], y1); y[2] = 2.0 * qrot(c[2], y2); y[3] = 2.0 * qrot(c[3], y3);
 }
 
 }  // namespace lvx

@@ -287,6 +287,28 @@ LVX_HD int surfel_residual(const SplineRef& sp, const PoseEval& hub, const Segs&
 // J_hub = g0^T M_hub with M_hub identical for every residual of a launch, so J^T J is assembled over g0 and folded back
 // with M_hub afterwards (lvx_eval.hip: k_fold_border).  local columns: [k knot j: 6j.. (24) | g0 24..29 | lidar theta 30..32 | lidar p 33..35]
 enum { SURFP_NC = 36 };
+// pose value + what the reverse-mode knot gradients need (no 3x3 Jacobian blocks): used by the single-row residuals of the fused kernels
+struct PoseVal { v3 p; double Bp[4]; quat c[4]; So3Val s; };
+LVX_HD bool pose_value_pre(const SplineRef& sp, const KnotRef& k, const So3Pre* pre, PoseVal* out) {
+  R3Basis b; r3_basis(k.u, sp.dt, &b);
+  v3 p = mk(0, 0, 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { out->Bp[j] = b.Bp[j]; p = p + b.Bp[j] * load_v3(sp.r3 + 3 * (k.i0 + j)); }
+  out->p = p;
+  load_so3_cp(sp, k.i0, out->c);
+  return so3_value_pre(out->c, pre, k.u, &out->s);
+}
+// knot columns of a scalar residual with pose gradients (gpos, gxi): position weights and the SO3 pull-back
+LVX_HD void pose_pull_to_knots(const PoseVal& e, const So3Pre* pre, v3 gpos, v3 gxi, double* J24) {
+  v3 y[4];
+  so3_pullback_pre(e.c, pre, e.s, gxi, y);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    J24[6 * j + 0] = e.Bp[j] * gpos.x; J24[6 * j + 1] = e.Bp[j] * gpos.y; J24[6 * j + 2] = e.Bp[j] * gpos.z;
+    J24[6 * j + 3] = y[j].x; J24[6 * j + 4] = y[j].y; J24[6 * j + 5] = y[j].z;
+  }
+}
+
 template <bool PRE = false>
 LVX_HD int surfel_residual_pseudo(const SplineRef& sp, const PoseEval& hub, const Segs& segs, const SensorCal& lidar, double t_k, v3 p_L, v3 Pi,
                                   double weight, int* i0_k, double r[1], double J[1][SURFP_NC], const PreWin* pw = nullptr) {
@@ -294,15 +316,17 @@ LVX_HD int surfel_residual_pseudo(const SplineRef& sp, const PoseEval& hub, cons
   if (!seg_lookup(sp, segs, t_k + lidar.tau, &kr)) return RES_RANGE;
   *i0_k = kr.i0;
   PoseEval k;
+  PoseVal kv;
   const So3Pre* pre = PRE ? pre_at(*pw, kr.i0) : nullptr;
   if (PRE && !pre) return RES_OUTSIDE;
-  if (!pose_eval<true, false, PRE>(sp, kr, &k, pre)) return RES_NONUNIT;
+  if (PRE) { if (!pose_value_pre(sp, kr, pre, &kv)) return RES_NONUNIT; k.p = kv.p; k.so3.q = kv.s.q; }
+  else if (!pose_eval<true, false, false>(sp, kr, &k)) return RES_NONUNIT;
   const v3 pLr = qrot(lidar.q, p_L);
   const v3 p_I = pLr + lidar.p;
   PlaneChain pc; plane_chain(hub, k, lidar, p_I, Pi, &pc);
   r[0] = weight * pc.r_unweighted;
   const PlaneGrads g = plane_grads(hub, pc, p_I, weight);
-  pose_to_knots(k, g.gp, g.gxk, &J[0][0]);
+  if (PRE) pose_pull_to_knots(kv, pre, g.gp, g.gxk, &J[0][0]); else pose_to_knots(k, g.gp, g.gxk, &J[0][0]);
   J[0][24] = -g.gp.x; J[0][25] = -g.gp.y; J[0][26] = -g.gp.z; J[0][27] = g.gx0.x; J[0][28] = g.gx0.y; J[0][29] = g.gx0.z;
   const v3 jq = (2.0 * weight) * (cross(pc.nL, pc.x) - cross(pc.m, pLr));
   const v3 jp = weight * (pc.m - pc.nL);
@@ -492,9 +516,11 @@ LVX_HD int camsurf_residual_pseudo(const SplineRef& sp, const PoseEval& hub, con
   if (!seg_lookup(sp, segs, t0_ref + cam.tau, &kr)) return RES_RANGE;
   *i0_k = kr.i0;
   PoseEval k;
+  PoseVal kv;
   const So3Pre* pre = PRE ? pre_at(*pw, kr.i0) : nullptr;
   if (PRE && !pre) return RES_OUTSIDE;
-  if (!pose_eval<true, false, PRE>(sp, kr, &k, pre)) return RES_NONUNIT;
+  if (PRE) { if (!pose_value_pre(sp, kr, pre, &kv)) return RES_NONUNIT; k.p = kv.p; k.so3.q = kv.s.q; }
+  else if (!pose_eval<true, false, false>(sp, kr, &k)) return RES_NONUNIT;
   const double s = 1.0 / (rho + 1e-8);
   const v3 yu = cam_unproject(ci, u_ref, v_ref);
   const v3 yh = mk(yu.x * s, yu.y * s, yu.z * s);
@@ -503,7 +529,7 @@ LVX_HD int camsurf_residual_pseudo(const SplineRef& sp, const PoseEval& hub, con
   PlaneChain pc; plane_chain(hub, k, lidar, p_I, Pi, &pc);
   r[0] = weight * pc.r_unweighted;
   const PlaneGrads g = plane_grads(hub, pc, p_I, weight);
-  pose_to_knots(k, g.gp, g.gxk, &J[0][0]);
+  if (PRE) pose_pull_to_knots(kv, pre, g.gp, g.gxk, &J[0][0]); else pose_to_knots(k, g.gp, g.gxk, &J[0][0]);
   J[0][24] = -g.gp.x; J[0][25] = -g.gp.y; J[0][26] = -g.gp.z; J[0][27] = g.gx0.x; J[0][28] = g.gx0.y; J[0][29] = g.gx0.z;
   const v3 jcq = (-2.0 * weight) * cross(pc.m, RCyh);
   const v3 jcp = weight * pc.m;
