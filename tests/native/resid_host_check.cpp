@@ -148,3 +148,23 @@ extern "C" int hc_so3_pre_diff(const double* cps, double u, double dt, double* o
     for (int e = 0; e < 9; ++e) { out4[2] = mx(out4[2], std::fabs(a.dxi[k].a[e] - b.dxi[k].a[e])); out4[3] = mx(out4[3], std::fabs(a.dw[k].a[e] - b.dw[k].a[e])); }
   return oka == okb ? 0 : 1;
 }
+
+// reverse mode (so3_value_pre + so3_pullback_pre) vs the forward Jacobian blocks of so3_eval: max |dxi[k]^T g - y[k]| and |q - q_fwd|
+extern "C" int hc_so3_pull_diff(const double* cps, double u, double dt, const double* g3, double* out2) {
+  quat c[4];
+  for (int j = 0; j < 4; ++j) c[j] = load_q(cps + 4 * j);
+  So3Pre pre[3];
+  for (int j = 0; j < 3; ++j) so3_pre(c[j], c[j + 1], &pre[j]);
+  So3Eval a;
+  const bool oka = so3_eval<false, true>(c, u, dt, &a);
+  So3Val s;
+  const bool okb = so3_value_pre(c, pre, u, &s);
+  v3 y[4];
+  const v3 g = mk(g3[0], g3[1], g3[2]);
+  so3_pullback_pre(c, pre, s, g, y);
+  auto mx = [](double x, double z) { return x > z ? x : z; };
+  out2[0] = mx(mx(std::fabs(a.q.x - s.q.x), std::fabs(a.q.y - s.q.y)), mx(std::fabs(a.q.z - s.q.z), std::fabs(a.q.w - s.q.w)));
+  out2[1] = 0.0;
+  for (int k = 0; k < 4; ++k) { const v3 f = tmulv(a.dxi[k], g); out2[1] = mx(out2[1], mx(mx(std::fabs(f.x - y[k].x), std::fabs(f.y - y[k].y)), std::fabs(f.z - y[k].z))); }
+  return oka == okb ? 0 : 1;
+}

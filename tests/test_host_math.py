@@ -88,3 +88,22 @@ def test_so3_precomputed_pairs_match_direct_evaluation(host_check_lib, spread):
     # q, dxi are O(1); w_body and dw carry 1/dt = 50
     assert worst[0] <= 1e-14 and worst[2] <= 2e-12
     assert worst[1] <= 1e-11 * max(1.0, spread / 0.02) and worst[3] <= 1e-9 * max(1.0, spread / 0.02)
+
+
+@pytest.mark.parametrize("spread", [1e-9, 1e-3, 0.05, 0.9, 2.5])
+def test_so3_reverse_mode_pullback_matches_forward_jacobian(host_check_lib, spread):
+    """so3_pullback_pre (what the single-row LiDAR residuals of the fused kernels use: dxi[k]^T g by rotations and cross products) against
+    the 3x3 Jacobian blocks of so3_eval."""
+    import ctypes as C
+    rng = np.random.default_rng(12)
+    out = np.zeros(2)
+    worst = np.zeros(2)
+    for _ in range(200):
+        base = synth.q_from_rotvec(rng.standard_normal(3))
+        cps = np.stack([synth.qmul(synth.q_from_rotvec(spread * rng.standard_normal(3)), base) for _ in range(4)])
+        cps /= np.linalg.norm(cps, axis=1, keepdims=True)
+        g = rng.standard_normal(3)
+        rc = host_check_lib.hc_so3_pull_diff(cps.ctypes.data_as(C.c_void_p), C.c_double(rng.uniform(0, 1)), C.c_double(0.02), g.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        worst = np.maximum(worst, out)
+    assert worst[0] <= 1e-14 and worst[1] <= 5e-12
