@@ -687,17 +687,21 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
           for (int bl = 0; bl < cnt; ++bl) {
             if (!xi[bl * (NX + 1) + NX]) continue;
             const double* pr = P + bl * NR * LDP;
+            int pbv[NJX]; double vv[NJX];
+#pragma unroll
+            for (int j = 0; j < NJX; ++j) pbv[j] = xi[bl * (NX + 1) + cx[j]];          // all LDS reads of the block first, branch-free: they overlap
 #pragma unroll
             for (int j = 0; j < NJX; ++j) {
-              const int pa = cpa[j];
-              if (pa == LVX_DEAD) continue;
-              const int pb = xi[bl * (NX + 1) + cx[j]];
-              if (pb == LVX_DEAD) continue;
               double v = 0.0;
 #pragma unroll
               for (int q = 0; q < NR; ++q) v += pr[q * LDP + ca[j]] * pr[q * LDP + XOFF + cx[j]];
-              if (v == 0.0) continue;
-              add_H(cm, pa, pb, pa == pb ? 2.0 * v : v, rep);   // the same variable through both poses: both orders of the pair land on the diagonal
+              vv[j] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < NJX; ++j) {
+              const int pa = cpa[j], pb = pbv[j];
+              if (pa == LVX_DEAD || pb == LVX_DEAD || vv[j] == 0.0) continue;
+              add_H(cm, pa, pb, pa == pb ? 2.0 * vv[j] : vv[j], rep);   // the same variable through both poses: both orders of the pair land on the diagonal
             }
           }
         }
