@@ -562,13 +562,6 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
   const int rep = blockIdx.x % LVX_NREP;
   // class of a window-local column: >= 0 knot scalar (offset inside the window, in units of tangent scalars), -1-g global g, -100 residual, -200 padding
   auto cls = [](int lc) { return lc < NKL ? 6 * (lc / KPK) + F::LVO + lc % KPK : (lc < NKL + NG ? -1 - (lc - NKL) : (lc == NKL + NG ? -100 : -200)); };
-  int colcls[NT], rowcls[NT][4];
-#pragma unroll
-  for (int c = 0; c < NT; ++c) {
-    colcls[c] = cls(c * 16 + (lane & 15));
-#pragma unroll
-    for (int v = 0; v < 4; ++v) rowcls[c][v] = cls(c * 16 + (lane >> 4) + 4 * v);
-  }
   const int frag_off = (lane >> 4) * LDP + (lane & 15);
   double mycost = 0.0;
   __syncthreads();
@@ -720,7 +713,7 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
             const double val = D[t][v];
             if (val == 0.0) continue;
             if (ci == cj && (lane & 15) < (lane >> 4) + 4 * v) continue;   // lower triangle of a diagonal tile
-            const int ra = rowcls[ci][v], cb = colcls[cj];
+            const int ra = cls(ci * 16 + (lane >> 4) + 4 * v), cb = cls(cj * 16 + (lane & 15));   // recomputed here: keeping them across phase 1 costs registers
             if (ra >= 0) {
               const int la = wb + ra;
               if (la >= ACC_LV) continue;
