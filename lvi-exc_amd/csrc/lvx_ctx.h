@@ -105,6 +105,10 @@ struct lvx_ctx {
     int grid[13] = {0};   // VxGrid: min_b, max_b, div_b, mul, inv(float bits)
     lvx::DevBuf misc, keys, vals, runs, cells, tmp, leaf_i, leaf_d, leaf_f;
   } vox;
+  // captured evaluation passes (lvx_eval.hip: run_evaluate), keyed by state buffer / request / flags / configuration version
+  struct GraphEntry { const double* state; uint32_t what; int flags; uint64_t cfg; void* exec; };
+  std::vector<GraphEntry> graphs;
+  uint64_t cfg_version = 0;   // bumped by every lvx_set_* and every layout rebuild
   std::vector<double> lm_cost, lm_radius;
   std::vector<int> lm_accept;
   // sequence-per-GPU joint solve: host all-reduce hook, shared-extrinsics bookkeeping (lvx_solver.hip)

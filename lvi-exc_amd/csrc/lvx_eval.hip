@@ -412,6 +412,9 @@ struct CamSurfAcc {
 // by atomics, not arithmetic):
 //   RepObsAcc: rows sorted by the OBSERVATION's knot interval.  [obs knots | camera] go through the chunk accumulators (views of one frame
 //              share them); the cross terms obs x [ref knots | rho] — unique to a (landmark, view) pair — are scattered directly.
+//              Cycle counters inside this pass: 40 % of its time is the issue of those atomics — a CU retires one FP64 atomic lane every
+//              ~3.75 cycles (tools/probes/atomic_bw.hip: 143 G/s over 256 CUs), i.e. 240 cycles per 64-lane instruction — so 30 M atomics
+//              cost >= 0.21 ms however they are arranged; the pass takes 0.41 ms.
 //   RepRefAcc: rows sorted by (reference interval, landmark); window = one landmark.  [ref knots | camera | rho] x same + the gradient of
 //              all three; rho's entries leave at the end of the landmark's window.
 // Together 600 direct atomics per block + the chunk flushes instead of 1595 per block in k_family<ReprojFam>.
@@ -1103,6 +1106,8 @@ int ensure_layout(lvx_ctx* ctx) {
   if ((rc = upload_pairs(ctx, ctx->d_pairs[4], REP_NC + tC, cat(range(48, 54), range(55, 55 + tC))))) return rc;
   if ((rc = upload_pairs(ctx, ctx->d_pairs[5], CS_NC + tC, cat(range(0, 24), range(48, 60 + tC))))) return rc;
   ctx->force_legacy = false;
+  { static const int zero = 0; if ((rc = upload(ctx, ctx->d_zero, &zero, 4))) return rc; }
+  ctx->cfg_version++;   // captured evaluation graphs of the previous layout are stale
   // ---- residual row offsets ----
   const int64_t cnt[LVX_NUM_FAM] = {ctx->imu.n, (locks & LVX_LOCK_R3) ? 0 : ctx->imu.n, ctx->has_prior ? 1 : 0, ctx->surf.n, ctx->rep.n, ctx->cs.n};
   const int nrs[LVX_NUM_FAM] = {3, 3, 1, 1, 2, 1};
@@ -1159,156 +1164,185 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     LVX_HIP(ctx, hipMemsetAsync(cm.jcols, 0xff, nrow * LVX_JAC_WIDTH * 4, st));
     LVX_HIP(ctx, hipMemsetAsync(cm.jvals, 0, nrow * LVX_JAC_WIDTH * 8, st));
   }
-  LVX_HIP(ctx, hipMemsetAsync(cm.cost, 0, LVX_NREP * 8, st));
-  LVX_HIP(ctx, hipMemsetAsync(cm.err, 0, 16, st));
-  if (what & LVX_EVAL_NORMAL_EQ) {
-    LVX_HIP(ctx, hipMemsetAsync(cm.Hb, 0, (size_t)std::max(ctx->nb, 1) * (ctx->bw + 1) * 8, st));
-    LVX_HIP(ctx, hipMemsetAsync(cm.gb, 0, (size_t)std::max(ctx->nb, 1) * 8, st));
-    LVX_HIP(ctx, hipMemsetAsync(cm.Bd, 0, (size_t)ctx->nbd_ext * std::max(ctx->nb, 1) * 8, st));
-    LVX_HIP(ctx, hipMemsetAsync(cm.C, 0, (size_t)LVX_NREP * ctx->nbd_ext * ctx->nbd_ext * 8, st));
-    LVX_HIP(ctx, hipMemsetAsync(cm.gc, 0, (size_t)LVX_NREP * ctx->nbd_ext * 8, st));
-  }
-  auto grid = [](int n) { return dim3((unsigned)((n + 63) / 64)); };
-  // fast path: LDS-accumulating kernels for the segment-structured families; legacy per-segment kernels for reprojection, the prior,
-  // the debug Jacobian, and as the exact fallback for the merged-hub-segment corner
-  const bool fast = !ctx->force_legacy && !(what & LVX_EVAL_JACOBIAN) && !getenv("LVX_FORCE_LEGACY");
-  // fork: the independent family kernels run concurrently (each is latency / occupancy limited on its own)
-  LVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
-  for (int k = 0; k < 4; ++k) LVX_HIP(ctx, hipStreamWaitEvent(ctx->fam_stream[k], ctx->ev_fork, 0));
-  hipStream_t s_imu = ctx->fam_stream[0], s_acc = ctx->fam_stream[1], s_surf = ctx->fam_stream[2], s_rep = ctx->fam_stream[3];
-  if (getenv("LVX_SERIAL")) s_imu = s_acc = s_surf = s_rep = st;   // profiling aid: solo kernel durations
-  // free time offsets need d pose / d t at both evaluations: those problems take the per-segment kernels (TAU variants)
-  const bool tauL = !(ctx->locks & LVX_LOCK_LIDAR_TAU), tauC = !(ctx->locks & LVX_LOCK_CAM_TAU);
-  const bool fast_surf = fast && !tauL && ctx->surf.n > 0, fast_cs = fast && !tauC && ctx->cs.n > 0;
-  if (fast_surf || fast_cs)   // only the surfel / cam-surfel stream waits for the shared t_map pose
-    hipLaunchKernelGGL(k_hub_eval, dim3(1), dim3(64), 0, s_surf, cm, ctx->t_map, fast_surf ? 1 : 0, fast_cs ? 1 : 0, (HubShared*)ctx->d_hubs.p);
-  static const int occ_env = getenv("LVX_OCC") ? atoi(getenv("LVX_OCC")) : 0;   // 0: the family's own choice (F::OCC wavefronts per SIMD)
-#define LVX_LAUNCH_MFMA1(FT, OCCV, fam_obj, chunk_slot, stream, row0v)                                                                        \
-  do {                                                                                                                                     \
-    const size_t lds_ = mfma_lds_bytes<FT>(ctx->chunk_r[chunk_slot]);                                                                      \
-    LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_mfma<FT, OCCV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));       \
-    hipLaunchKernelGGL((k_family_mfma<FT, OCCV>), dim3(ctx->n_chunk[chunk_slot]), dim3(256), lds_, stream, fam_obj, cm, (const int*)ctx->d_chunk[chunk_slot].p, (long long)(row0v), \
-                       ctx->chunk_r[chunk_slot]);                                                                                          \
-  } while (0)
-#define LVX_LAUNCH_MFMA(FT, fam_obj, chunk_slot, stream, row0v)                                                                               \
-  do { if ((occ_env ? occ_env : (int)FT::OCC) == 1) LVX_LAUNCH_MFMA1(FT, 1, fam_obj, chunk_slot, stream, row0v); else LVX_LAUNCH_MFMA1(FT, 2, fam_obj, chunk_slot, stream, row0v); } while (0)
-  // launch order / overlap: the LiDAR kernels (VALU + MFMA heavy, one workgroup per CU) first and alone, then the IMU kernels and the
-  // reprojection passes next to each other.  Measured at config 4: the pass takes the same 1.55-1.6 ms with everything concurrent (the big
-  // kernels cannot share a CU and only slow each other down), staged like this, or serial (1.64 ms); staged, the dominant kernel's
-  // duration is its solo duration.  LVX_SCHED=0 restores "all concurrent".
-  static const int sched = getenv("LVX_SCHED") ? atoi(getenv("LVX_SCHED")) : 2;
-  const bool staged = sched == 2 && !getenv("LVX_SERIAL");
-  const int order[5] = {2, 4, 0, 1, 3};   // surfel, cam-surfel, imu, prior, reprojection
-  for (int ph = 0; ph < 5; ++ph) {
-    if (staged && ph == 2) {               // the other streams start when the LiDAR stream has drained
-      LVX_HIP(ctx, hipEventRecord(ctx->ev_join[2], s_surf));
-      LVX_HIP(ctx, hipStreamWaitEvent(s_imu, ctx->ev_join[2], 0)); LVX_HIP(ctx, hipStreamWaitEvent(s_acc, ctx->ev_join[2], 0)); LVX_HIP(ctx, hipStreamWaitEvent(s_rep, ctx->ev_join[2], 0));
+  // Everything from the clears to the fold kernels is one static launch sequence for a given (state buffer, request, configuration):
+  // it is captured once into a HIP graph and replayed — a pass is ~35 API calls (memsets, cross-stream events, ~12 launches), which bounds small
+  // problems at ~370 us per evaluation when issued call by call.  LVX_NO_GRAPH=1 issues the calls directly; profiling and the debug
+  // Jacobian always do.
+  auto enqueue = [&]() -> int {
+    int rc = LVX_OK;
+    LVX_HIP(ctx, hipMemsetAsync(cm.cost, 0, LVX_NREP * 8, st));
+    LVX_HIP(ctx, hipMemsetAsync(cm.err, 0, 16, st));
+    if (what & LVX_EVAL_NORMAL_EQ) {
+      LVX_HIP(ctx, hipMemsetAsync(cm.Hb, 0, (size_t)std::max(ctx->nb, 1) * (ctx->bw + 1) * 8, st));
+      LVX_HIP(ctx, hipMemsetAsync(cm.gb, 0, (size_t)std::max(ctx->nb, 1) * 8, st));
+      LVX_HIP(ctx, hipMemsetAsync(cm.Bd, 0, (size_t)ctx->nbd_ext * std::max(ctx->nb, 1) * 8, st));
+      LVX_HIP(ctx, hipMemsetAsync(cm.C, 0, (size_t)LVX_NREP * ctx->nbd_ext * ctx->nbd_ext * 8, st));
+      LVX_HIP(ctx, hipMemsetAsync(cm.gc, 0, (size_t)LVX_NREP * ctx->nbd_ext * 8, st));
     }
-    switch (order[ph]) {
-    case 0: {
-      const bool imu_fast = fast && !getenv("LVX_IMU_LEGACY");
-      if (ctx->imu.n > 0) {
-        if (imu_fast) {
-          GyroAcc g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
-          { ProfScope ps(ctx, LVX_FAM_GYRO, s_imu); LVX_LAUNCH_MFMA(GyroAcc, g, LVX_FAM_GYRO, s_imu, ctx->fam_row0[0]); }
-          if (!(ctx->locks & LVX_LOCK_R3)) {
-            AccelAcc a{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.huber /*w_acc*/, 0.0};
-            ProfScope ps(ctx, LVX_FAM_ACCEL, s_acc);
-            LVX_LAUNCH_MFMA(AccelAcc, a, LVX_FAM_GYRO, s_acc, ctx->fam_row0[1]);
-          }
-        } else {
-          GyroFam g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
-          { ProfScope ps(ctx, LVX_FAM_GYRO, s_imu);
-          hipLaunchKernelGGL((k_family<GyroFam, 1>), grid(g.n), dim3(64), 0, s_imu, g, cm, (const uint16_t*)ctx->d_pairs[0].p, (long long)ctx->fam_row0[0]); }
-          if (!(ctx->locks & LVX_LOCK_R3)) {
-            AccelFam a{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.huber /*w_acc*/, 0.0};
-            ProfScope ps(ctx, LVX_FAM_ACCEL, s_acc);
-            hipLaunchKernelGGL((k_family<AccelFam, LVX_PW>), grid(a.n), dim3(64 * LVX_PW), 0, s_acc, a, cm, (const uint16_t*)ctx->d_pairs[1].p, (long long)ctx->fam_row0[1]);
+    auto grid = [](int n) { return dim3((unsigned)((n + 63) / 64)); };
+    // fast path: LDS-accumulating kernels for the segment-structured families; legacy per-segment kernels for reprojection, the prior,
+    // the debug Jacobian, and as the exact fallback for the merged-hub-segment corner
+    const bool fast = !ctx->force_legacy && !(what & LVX_EVAL_JACOBIAN) && !getenv("LVX_FORCE_LEGACY");
+    // fork: the independent family kernels run concurrently (each is latency / occupancy limited on its own)
+    LVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
+    for (int k = 0; k < 4; ++k) LVX_HIP(ctx, hipStreamWaitEvent(ctx->fam_stream[k], ctx->ev_fork, 0));
+    hipStream_t s_imu = ctx->fam_stream[0], s_acc = ctx->fam_stream[1], s_surf = ctx->fam_stream[2], s_rep = ctx->fam_stream[3];
+    if (getenv("LVX_SERIAL")) s_imu = s_acc = s_surf = s_rep = st;   // profiling aid: solo kernel durations
+    // free time offsets need d pose / d t at both evaluations: those problems take the per-segment kernels (TAU variants)
+    const bool tauL = !(ctx->locks & LVX_LOCK_LIDAR_TAU), tauC = !(ctx->locks & LVX_LOCK_CAM_TAU);
+    const bool fast_surf = fast && !tauL && ctx->surf.n > 0, fast_cs = fast && !tauC && ctx->cs.n > 0;
+    if (fast_surf || fast_cs)   // only the surfel / cam-surfel stream waits for the shared t_map pose
+      hipLaunchKernelGGL(k_hub_eval, dim3(1), dim3(64), 0, s_surf, cm, ctx->t_map, fast_surf ? 1 : 0, fast_cs ? 1 : 0, (HubShared*)ctx->d_hubs.p);
+    static const int occ_env = getenv("LVX_OCC") ? atoi(getenv("LVX_OCC")) : 0;   // 0: the family's own choice (F::OCC wavefronts per SIMD)
+  #define LVX_LAUNCH_MFMA1(FT, OCCV, fam_obj, chunk_slot, stream, row0v)                                                                        \
+    do {                                                                                                                                     \
+      const size_t lds_ = mfma_lds_bytes<FT>(ctx->chunk_r[chunk_slot]);                                                                      \
+      LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_mfma<FT, OCCV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));       \
+      hipLaunchKernelGGL((k_family_mfma<FT, OCCV>), dim3(ctx->n_chunk[chunk_slot]), dim3(256), lds_, stream, fam_obj, cm, (const int*)ctx->d_chunk[chunk_slot].p, (long long)(row0v), \
+                         ctx->chunk_r[chunk_slot]);                                                                                          \
+    } while (0)
+  #define LVX_LAUNCH_MFMA(FT, fam_obj, chunk_slot, stream, row0v)                                                                               \
+    do { if ((occ_env ? occ_env : (int)FT::OCC) == 1) LVX_LAUNCH_MFMA1(FT, 1, fam_obj, chunk_slot, stream, row0v); else LVX_LAUNCH_MFMA1(FT, 2, fam_obj, chunk_slot, stream, row0v); } while (0)
+    // launch order / overlap: the LiDAR kernels (VALU + MFMA heavy, one workgroup per CU) first and alone, then the IMU kernels and the
+    // reprojection passes next to each other.  Measured at config 4: the pass takes the same 1.55-1.6 ms with everything concurrent (the big
+    // kernels cannot share a CU and only slow each other down), staged like this, or serial (1.64 ms); staged, the dominant kernel's
+    // duration is its solo duration.  LVX_SCHED=0 restores "all concurrent".
+    static const int sched = getenv("LVX_SCHED") ? atoi(getenv("LVX_SCHED")) : 2;
+    const bool staged = sched == 2 && !getenv("LVX_SERIAL");
+    const int order[5] = {2, 4, 0, 1, 3};   // surfel, cam-surfel, imu, prior, reprojection
+    for (int ph = 0; ph < 5; ++ph) {
+      if (staged && ph == 2) {               // the other streams start when the LiDAR stream has drained
+        LVX_HIP(ctx, hipEventRecord(ctx->ev_join[2], s_surf));
+        LVX_HIP(ctx, hipStreamWaitEvent(s_imu, ctx->ev_join[2], 0)); LVX_HIP(ctx, hipStreamWaitEvent(s_acc, ctx->ev_join[2], 0)); LVX_HIP(ctx, hipStreamWaitEvent(s_rep, ctx->ev_join[2], 0));
+      }
+      switch (order[ph]) {
+      case 0: {
+        const bool imu_fast = fast && !getenv("LVX_IMU_LEGACY");
+        if (ctx->imu.n > 0) {
+          if (imu_fast) {
+            GyroAcc g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
+            { ProfScope ps(ctx, LVX_FAM_GYRO, s_imu); LVX_LAUNCH_MFMA(GyroAcc, g, LVX_FAM_GYRO, s_imu, ctx->fam_row0[0]); }
+            if (!(ctx->locks & LVX_LOCK_R3)) {
+              AccelAcc a{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.huber /*w_acc*/, 0.0};
+              ProfScope ps(ctx, LVX_FAM_ACCEL, s_acc);
+              LVX_LAUNCH_MFMA(AccelAcc, a, LVX_FAM_GYRO, s_acc, ctx->fam_row0[1]);
+            }
+          } else {
+            GyroFam g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
+            { ProfScope ps(ctx, LVX_FAM_GYRO, s_imu);
+            hipLaunchKernelGGL((k_family<GyroFam, 1>), grid(g.n), dim3(64), 0, s_imu, g, cm, (const uint16_t*)ctx->d_pairs[0].p, (long long)ctx->fam_row0[0]); }
+            if (!(ctx->locks & LVX_LOCK_R3)) {
+              AccelFam a{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.huber /*w_acc*/, 0.0};
+              ProfScope ps(ctx, LVX_FAM_ACCEL, s_acc);
+              hipLaunchKernelGGL((k_family<AccelFam, LVX_PW>), grid(a.n), dim3(64 * LVX_PW), 0, s_acc, a, cm, (const uint16_t*)ctx->d_pairs[1].p, (long long)ctx->fam_row0[1]);
+            }
           }
         }
-      }
-    } break;
-    case 1: {
-      if (ctx->has_prior) {
-        static const int zero = 0;
-        DevBuf& pb = ctx->d_zero;   // identity permutation for the single prior block
-        if ((rc = upload(ctx, pb, &zero, 4))) return rc;
-        PriorFam p{1, ctx->prior_t, mkq(ctx->prior_q[0], ctx->prior_q[1], ctx->prior_q[2], ctx->prior_q[3]), (const int*)pb.p, ctx->prior_w, 0.0};
-        ProfScope ps(ctx, LVX_FAM_PRIOR, s_imu);
-        hipLaunchKernelGGL((k_family<PriorFam, 1>), dim3(1), dim3(64), 0, s_imu, p, cm, (const uint16_t*)ctx->d_pairs[2].p, (long long)ctx->fam_row0[2]);
-      }
-    } break;
-    case 2: {
-      if (ctx->surf.n > 0) {
-        ProfScope ps(ctx, LVX_FAM_SURFEL, s_surf);
-        if (tauL) {
-          SurfFamT<true> s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
-                           (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
-          hipLaunchKernelGGL((k_family<SurfFamT<true>, 1>), grid(s.n), dim3(64), 0, s_surf, s, cm, (const uint16_t*)ctx->d_pairs[3].p, (long long)ctx->fam_row0[3]);
-        } else if (fast_surf) {
-          SurfAcc s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
-                    (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
-          LVX_LAUNCH_MFMA(SurfAcc, s, LVX_FAM_SURFEL, s_surf, ctx->fam_row0[3]);
-        } else {
-          SurfFam s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
-                    (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
-          hipLaunchKernelGGL((k_family<SurfFam, 1>), grid(s.n), dim3(64), 0, s_surf, s, cm, (const uint16_t*)ctx->d_pairs[3].p, (long long)ctx->fam_row0[3]);
+      } break;
+      case 1: {
+        if (ctx->has_prior) {
+          DevBuf& pb = ctx->d_zero;   // identity permutation for the single prior block (zeroed by ensure_layout)
+          PriorFam p{1, ctx->prior_t, mkq(ctx->prior_q[0], ctx->prior_q[1], ctx->prior_q[2], ctx->prior_q[3]), (const int*)pb.p, ctx->prior_w, 0.0};
+          ProfScope ps(ctx, LVX_FAM_PRIOR, s_imu);
+          hipLaunchKernelGGL((k_family<PriorFam, 1>), dim3(1), dim3(64), 0, s_imu, p, cm, (const uint16_t*)ctx->d_pairs[2].p, (long long)ctx->fam_row0[2]);
         }
-      }
-    } break;
-    case 3: {
-      if (ctx->rep.n > 0) {
-        ReprojFam r{ctx->rep.n, (const int*)ctx->rep.d_id0.p, (const double*)ctx->rep.d_a3.p, (const double*)ctx->rep.d_t.p, (const int*)ctx->rep.d_perm.p,
-                    (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->rep.weight, ctx->rep.huber};
-        ProfScope ps(ctx, LVX_FAM_REPROJ, s_rep);
-        if (tauC) {
-          ReprojFamT<true> rt{r.n, r.lm, r.uv, r.t0o, r.perm, r.lm_uv, r.lm_t0, r.weight, r.huber};
-          hipLaunchKernelGGL((k_family<ReprojFamT<true>, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, rt, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
-        } else if (fast && !getenv("LVX_REPROJ_LEGACY")) {
-          double* Jb = (double*)ctx->d_repB[0].p; double* rb = Jb + (size_t)2 * REP_NC * r.n; int* kb = (int*)ctx->d_repB[1].p;
-          hipLaunchKernelGGL(k_reproj_jac, grid(r.n), dim3(64), 0, s_rep, r, cm, Jb, rb, kb, (long long)ctx->fam_row0[4]);
-          if (what & LVX_EVAL_NORMAL_EQ) {
-            const RepJac jac{Jb, rb, kb, r.n};
-            RepObsAcc ra{r.n, r.lm, r.perm, jac, 0.0};
-            LVX_LAUNCH_MFMA1(RepObsAcc, 1, ra, LVX_FAM_REPROJ, s_rep, ctx->fam_row0[4]);   // measured: a second workgroup per CU does not help, the cross-term atomics bound this pass
-            RepRefAcc rb2{r.n, (const int*)ctx->d_repB[2].p, (const int*)ctx->d_repB[3].p, jac, 0.0};
-            LVX_LAUNCH_MFMA1(RepRefAcc, 1, rb2, LVX_FAM_PRIOR, s_rep, ctx->fam_row0[4]);
+      } break;
+      case 2: {
+        if (ctx->surf.n > 0) {
+          ProfScope ps(ctx, LVX_FAM_SURFEL, s_surf);
+          if (tauL) {
+            SurfFamT<true> s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
+                             (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
+            hipLaunchKernelGGL((k_family<SurfFamT<true>, 1>), grid(s.n), dim3(64), 0, s_surf, s, cm, (const uint16_t*)ctx->d_pairs[3].p, (long long)ctx->fam_row0[3]);
+          } else if (fast_surf) {
+            SurfAcc s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
+                      (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
+            LVX_LAUNCH_MFMA(SurfAcc, s, LVX_FAM_SURFEL, s_surf, ctx->fam_row0[3]);
+          } else {
+            SurfFam s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
+                      (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
+            hipLaunchKernelGGL((k_family<SurfFam, 1>), grid(s.n), dim3(64), 0, s_surf, s, cm, (const uint16_t*)ctx->d_pairs[3].p, (long long)ctx->fam_row0[3]);
           }
-        } else
-        hipLaunchKernelGGL((k_family<ReprojFam, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, r, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
-      }
-    } break;
-    case 4: {
-      if (ctx->cs.n > 0) {
-        ProfScope ps(ctx, LVX_FAM_CAMSURF, s_surf);
-        if (tauC) {
-          CamSurfFamT<true> c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
-                              (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
-          hipLaunchKernelGGL((k_family<CamSurfFamT<true>, 1>), grid(c.n), dim3(64), 0, s_surf, c, cm, (const uint16_t*)ctx->d_pairs[5].p, (long long)ctx->fam_row0[5]);
-        } else if (fast_cs) {
-          CamSurfAcc c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
-                       (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
-          LVX_LAUNCH_MFMA(CamSurfAcc, c, LVX_FAM_CAMSURF, s_surf, ctx->fam_row0[5]);
-        } else {
-          CamSurfFam c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
-                       (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
-          hipLaunchKernelGGL((k_family<CamSurfFam, 1>), grid(c.n), dim3(64), 0, s_surf, c, cm, (const uint16_t*)ctx->d_pairs[5].p, (long long)ctx->fam_row0[5]);
         }
+      } break;
+      case 3: {
+        if (ctx->rep.n > 0) {
+          ReprojFam r{ctx->rep.n, (const int*)ctx->rep.d_id0.p, (const double*)ctx->rep.d_a3.p, (const double*)ctx->rep.d_t.p, (const int*)ctx->rep.d_perm.p,
+                      (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->rep.weight, ctx->rep.huber};
+          ProfScope ps(ctx, LVX_FAM_REPROJ, s_rep);
+          if (tauC) {
+            ReprojFamT<true> rt{r.n, r.lm, r.uv, r.t0o, r.perm, r.lm_uv, r.lm_t0, r.weight, r.huber};
+            hipLaunchKernelGGL((k_family<ReprojFamT<true>, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, rt, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
+          } else if (fast && !getenv("LVX_REPROJ_LEGACY")) {
+            double* Jb = (double*)ctx->d_repB[0].p; double* rb = Jb + (size_t)2 * REP_NC * r.n; int* kb = (int*)ctx->d_repB[1].p;
+            hipLaunchKernelGGL(k_reproj_jac, grid(r.n), dim3(64), 0, s_rep, r, cm, Jb, rb, kb, (long long)ctx->fam_row0[4]);
+            if (what & LVX_EVAL_NORMAL_EQ) {
+              const RepJac jac{Jb, rb, kb, r.n};
+              RepObsAcc ra{r.n, r.lm, r.perm, jac, 0.0};
+              LVX_LAUNCH_MFMA1(RepObsAcc, 1, ra, LVX_FAM_REPROJ, s_rep, ctx->fam_row0[4]);   // measured: a second workgroup per CU does not help, the cross-term atomics bound this pass
+              RepRefAcc rb2{r.n, (const int*)ctx->d_repB[2].p, (const int*)ctx->d_repB[3].p, jac, 0.0};
+              LVX_LAUNCH_MFMA1(RepRefAcc, 1, rb2, LVX_FAM_PRIOR, s_rep, ctx->fam_row0[4]);
+            }
+          } else
+          hipLaunchKernelGGL((k_family<ReprojFam, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, r, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
+        }
+      } break;
+      case 4: {
+        if (ctx->cs.n > 0) {
+          ProfScope ps(ctx, LVX_FAM_CAMSURF, s_surf);
+          if (tauC) {
+            CamSurfFamT<true> c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
+                                (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
+            hipLaunchKernelGGL((k_family<CamSurfFamT<true>, 1>), grid(c.n), dim3(64), 0, s_surf, c, cm, (const uint16_t*)ctx->d_pairs[5].p, (long long)ctx->fam_row0[5]);
+          } else if (fast_cs) {
+            CamSurfAcc c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
+                         (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
+            LVX_LAUNCH_MFMA(CamSurfAcc, c, LVX_FAM_CAMSURF, s_surf, ctx->fam_row0[5]);
+          } else {
+            CamSurfFam c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
+                         (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
+            hipLaunchKernelGGL((k_family<CamSurfFam, 1>), grid(c.n), dim3(64), 0, s_surf, c, cm, (const uint16_t*)ctx->d_pairs[5].p, (long long)ctx->fam_row0[5]);
+          }
+        }
+      } break;
       }
-    } break;
     }
+    for (int k = 0; k < 4; ++k) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[k], ctx->fam_stream[k])); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[k], 0)); }
+    { ProfScope ps(ctx, LVX_KERNEL_FOLD);
+    hipLaunchKernelGGL(k_fold_replicas, dim3((unsigned)((ctx->nbd_ext * ctx->nbd_ext + 255) / 256)), dim3(256), 0, st, cm);
+    if ((what & LVX_EVAL_NORMAL_EQ) && (fast_surf || fast_cs)) {
+      for (int set = 0; set < 2; ++set) if (ctx->nb > 0 && ((set == 0 && fast_surf) || (set == 1 && fast_cs)))
+        hipLaunchKernelGGL(k_fold_border_rows, dim3((unsigned)((ctx->nb + 255) / 256)), dim3(256), 0, st, cm, set);
+      const size_t lds = ((size_t)ctx->nbd_ext * ctx->nbd_ext + ctx->nbd_ext) * 8;
+      LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_fold_border_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_fold_border_dense, dim3(1), dim3(256), lds, st, cm);
+    } }
+    LVX_HIP(ctx, hipGetLastError());
+    return rc;
+  };
+  static const bool no_graph = getenv("LVX_NO_GRAPH") != nullptr;
+  const bool use_graph = !no_graph && !ctx->profiling && !(what & LVX_EVAL_JACOBIAN);
+  if (!use_graph) { if ((rc = enqueue())) return rc; }
+  else {
+    const int flags = (want_res_buffer ? 1 : 0) | (ctx->force_legacy ? 2 : 0) | (getenv("LVX_FORCE_LEGACY") ? 4 : 0) | (getenv("LVX_SERIAL") ? 8 : 0) | (getenv("LVX_IMU_LEGACY") ? 16 : 0) |
+                      (getenv("LVX_REPROJ_LEGACY") ? 32 : 0);
+    hipGraphExec_t exec = nullptr;
+    for (const auto& e : ctx->graphs) if (e.state == state_d && e.what == what && e.flags == flags && e.cfg == ctx->cfg_version) { exec = (hipGraphExec_t)e.exec; break; }
+    if (!exec) {
+      if (ctx->graphs.size() >= 16) { for (auto& e : ctx->graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.exec); ctx->graphs.clear(); }
+      hipGraph_t graph = nullptr;
+      LVX_HIP(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+      rc = enqueue();
+      const hipError_t ce = hipStreamEndCapture(st, &graph);
+      if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+      if (ce != hipSuccess || !graph) return fail(ctx, LVX_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+      const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (ie != hipSuccess) return fail(ctx, LVX_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
+      ctx->graphs.push_back({state_d, what, flags, ctx->cfg_version, (void*)exec});
+    }
+    LVX_HIP(ctx, hipGraphLaunch(exec, st));
   }
-  for (int k = 0; k < 4; ++k) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[k], ctx->fam_stream[k])); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[k], 0)); }
-  { ProfScope ps(ctx, LVX_KERNEL_FOLD);
-  hipLaunchKernelGGL(k_fold_replicas, dim3((unsigned)((ctx->nbd_ext * ctx->nbd_ext + 255) / 256)), dim3(256), 0, st, cm);
-  if ((what & LVX_EVAL_NORMAL_EQ) && (fast_surf || fast_cs)) {
-    for (int set = 0; set < 2; ++set) if (ctx->nb > 0 && ((set == 0 && fast_surf) || (set == 1 && fast_cs)))
-      hipLaunchKernelGGL(k_fold_border_rows, dim3((unsigned)((ctx->nb + 255) / 256)), dim3(256), 0, st, cm, set);
-    const size_t lds = ((size_t)ctx->nbd_ext * ctx->nbd_ext + ctx->nbd_ext) * 8;
-    LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_fold_border_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_fold_border_dense, dim3(1), dim3(256), lds, st, cm);
-  } }
-  LVX_HIP(ctx, hipGetLastError());
   ctx->last_what = what;
   if (cost) {
     double c = 0; int err[4] = {0, 0, 0, 0};
@@ -1371,6 +1405,7 @@ void lvx_destroy(lvx_ctx* c) {
   for (DevBuf* b : {&c->vox.misc, &c->vox.keys, &c->vox.vals, &c->vox.runs, &c->vox.cells, &c->vox.tmp, &c->vox.leaf_i, &c->vox.leaf_d, &c->vox.leaf_f}) if (b->p) (void)hipFree(b->p);
   bcr_destroy(c);
   for (DevBuf* b : {&c->d_bcrD, &c->d_bcrG, &c->d_bcrInfo, &c->d_Y2, &c->d_gram}) if (b->p) (void)hipFree(b->p);
+  for (auto& e : c->graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.exec);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   for (int k = 0; k < 4; ++k) { if (c->fam_stream[k]) (void)hipStreamDestroy(c->fam_stream[k]); if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1378,11 +1413,11 @@ void lvx_destroy(lvx_ctx* c) {
   delete c;
 }
 
-int lvx_set_spline(lvx_ctx* c, double t0, double dt, int n_knots) {
+int lvx_set_spline(lvx_ctx* c, double t0, double dt, int n_knots) { if (c) c->cfg_version++;
   if (!c || !(dt > 0) || n_knots < 4) return c ? fail(c, LVX_E_ARG, "spline needs dt > 0 and >= 4 control points (spline_base.h:58-62)") : LVX_E_ARG;
   c->t0 = t0; c->dt = dt; c->N = n_knots; c->have_spline = true; c->layout_dirty = true; return LVX_OK;
 }
-int lvx_set_camera(lvx_ctx* c, const lvx_pinhole* p) {
+int lvx_set_camera(lvx_ctx* c, const lvx_pinhole* p) { if (c) c->cfg_version++;
   if (!c || !p) return LVX_E_ARG;
   CamIntr& k = c->cam;
   k.fx = p->fx; k.fy = p->fy; k.cx = p->cx; k.cy = p->cy; k.k1 = p->k1; k.k2 = p->k2; k.p1 = p->p1; k.p2 = p->p2; k.k3 = p->k3; k.readout = p->readout;
@@ -1391,36 +1426,36 @@ int lvx_set_camera(lvx_ctx* c, const lvx_pinhole* p) {
   k.do_distortion = (std::fabs(k.k1) > 1e-5 || std::fabs(k.k2) > 1e-5 || std::fabs(k.p1) > 1e-5 || std::fabs(k.p1) > 1e-5) ? 1 : 0;  // sic (:78)
   c->layout_dirty = true; return LVX_OK;
 }
-int lvx_set_imu(lvx_ctx* c, int n, const double* t, const double* gyro3, const double* acc3, double w_gyro, double w_acc) {
+int lvx_set_imu(lvx_ctx* c, int n, const double* t, const double* gyro3, const double* acc3, double w_gyro, double w_acc) { if (c) c->cfg_version++;
   if (!c || n < 0 || (n > 0 && (!t || !gyro3 || !acc3))) return LVX_E_ARG;
   Family& f = c->imu; f.n = n; f.t.assign(t, t + n); f.a3.assign(gyro3, gyro3 + 3 * (size_t)n); f.b3.assign(acc3, acc3 + 3 * (size_t)n);
   f.weight = w_gyro; f.huber = w_acc;   // (huber slot reused for the accelerometer weight; IMU blocks have no loss function)
   c->layout_dirty = true; return LVX_OK;
 }
-int lvx_set_orientation_prior(lvx_ctx* c, int enable, double t, const double* q_wxyz, double weight) {
+int lvx_set_orientation_prior(lvx_ctx* c, int enable, double t, const double* q_wxyz, double weight) { if (c) c->cfg_version++;
   if (!c) return LVX_E_ARG;
   c->has_prior = enable != 0; c->prior_t = t; if (q_wxyz) std::memcpy(c->prior_q, q_wxyz, 32); c->prior_w = weight; c->layout_dirty = true; return LVX_OK;
 }
-int lvx_set_planes(lvx_ctx* c, int n, const double* pi3) {
+int lvx_set_planes(lvx_ctx* c, int n, const double* pi3) { if (c) c->cfg_version++;
   if (!c || n < 0 || (n > 0 && !pi3)) return LVX_E_ARG;
   c->planes.assign(pi3, pi3 + 3 * (size_t)n); c->layout_dirty = true; return LVX_OK;
 }
-int lvx_set_surfel(lvx_ctx* c, int n, const double* pt3, const double* t, const int32_t* plane_id, double t_map, double huber, double weight) {
+int lvx_set_surfel(lvx_ctx* c, int n, const double* pt3, const double* t, const int32_t* plane_id, double t_map, double huber, double weight) { if (c) c->cfg_version++;
   if (!c || n < 0 || (n > 0 && (!pt3 || !t || !plane_id))) return LVX_E_ARG;
   Family& f = c->surf; f.n = n; f.t.assign(t, t + n); f.a3.assign(pt3, pt3 + 3 * (size_t)n); f.id0.assign(plane_id, plane_id + n);
   for (int i = 0; i < n; ++i) if (plane_id[i] < 0 || (size_t)plane_id[i] * 3 >= c->planes.size()) return fail(c, LVX_E_ARG, "plane id out of range (call lvx_set_planes first)");
   f.huber = huber; f.weight = weight; c->t_map = t_map; c->layout_dirty = true; return LVX_OK;
 }
-int lvx_set_landmarks(lvx_ctx* c, int n, const double* uv_ref2, const double* t0_ref) {
+int lvx_set_landmarks(lvx_ctx* c, int n, const double* uv_ref2, const double* t0_ref) { if (c) c->cfg_version++;
   if (!c || n < 0 || (n > 0 && (!uv_ref2 || !t0_ref))) return LVX_E_ARG;
   c->L = n; c->lm_uv.assign(uv_ref2, uv_ref2 + 2 * (size_t)n); c->lm_t0.assign(t0_ref, t0_ref + n); c->layout_dirty = true; return LVX_OK;
 }
-int lvx_set_reproj(lvx_ctx* c, int n, const int32_t* lm, const double* uv_obs2, const double* t0_obs, double huber, double weight) {
+int lvx_set_reproj(lvx_ctx* c, int n, const int32_t* lm, const double* uv_obs2, const double* t0_obs, double huber, double weight) { if (c) c->cfg_version++;
   if (!c || n < 0 || (n > 0 && (!lm || !uv_obs2 || !t0_obs))) return LVX_E_ARG;
   Family& f = c->rep; f.n = n; f.t.assign(t0_obs, t0_obs + n); f.a3.assign(uv_obs2, uv_obs2 + 2 * (size_t)n); f.id0.assign(lm, lm + n);
   f.huber = huber; f.weight = weight; c->layout_dirty = true; return LVX_OK;
 }
-int lvx_set_camsurf(lvx_ctx* c, int n, const int32_t* lm, const int32_t* plane_id, double t_map, double huber, double weight) {
+int lvx_set_camsurf(lvx_ctx* c, int n, const int32_t* lm, const int32_t* plane_id, double t_map, double huber, double weight) { if (c) c->cfg_version++;
   if (!c || n < 0 || (n > 0 && (!lm || !plane_id))) return LVX_E_ARG;
   Family& f = c->cs; f.n = n; f.id0.assign(lm, lm + n); f.id1.assign(plane_id, plane_id + n);
   for (int i = 0; i < n; ++i) {
@@ -1429,8 +1464,8 @@ int lvx_set_camsurf(lvx_ctx* c, int n, const int32_t* lm, const int32_t* plane_i
   }
   f.huber = huber; f.weight = weight; c->t_map = t_map; c->layout_dirty = true; return LVX_OK;
 }
-int lvx_set_locks(lvx_ctx* c, uint32_t mask) { if (!c) return LVX_E_ARG; if (c->locks != mask) { c->locks = mask; c->layout_dirty = true; } return LVX_OK; }
-int lvx_set_time_offset_bounds(lvx_ctx* c, double imu_max, double sensor_max) { if (!c) return LVX_E_ARG; c->imu_mto = imu_max; c->sensor_mto = sensor_max; c->layout_dirty = true; return LVX_OK; }
+int lvx_set_locks(lvx_ctx* c, uint32_t mask) { if (c) c->cfg_version++; if (!c) return LVX_E_ARG; if (c->locks != mask) { c->locks = mask; c->layout_dirty = true; } return LVX_OK; }
+int lvx_set_time_offset_bounds(lvx_ctx* c, double imu_max, double sensor_max) { if (c) c->cfg_version++; if (!c) return LVX_E_ARG; c->imu_mto = imu_max; c->sensor_mto = sensor_max; c->layout_dirty = true; return LVX_OK; }
 
 int lvx_state_size(const lvx_ctx* c) { return c ? 7 * c->N + 32 + c->L : 0; }
 int lvx_tangent_size(const lvx_ctx* c) { return c ? 6 * c->N + 22 + c->L : 0; }
