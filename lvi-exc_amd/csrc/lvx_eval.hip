@@ -1086,11 +1086,11 @@ int ensure_layout(lvx_ctx* ctx) {
   ctx->bw = std::min(std::max(bw, 0), std::max(ctx->nb - 1, 0));
   // ---- buffers ----
   if ((rc = upload(ctx, ctx->d_ord, ctx->ord.data(), ctx->ord.size() * 4))) return rc;
-  if ((rc = dev_alloc(ctx, ctx->d_Hb, (size_t)std::max(ctx->nb, 1) * (ctx->bw + 1) * 8))) return rc;
-  if ((rc = dev_alloc(ctx, ctx->d_gb, (size_t)std::max(ctx->nb, 1) * 8))) return rc;
-  if ((rc = dev_alloc(ctx, ctx->d_Bd, (size_t)ctx->nbd_ext * std::max(ctx->nb, 1) * 8))) return rc;
-  if ((rc = dev_alloc(ctx, ctx->d_C, (size_t)LVX_NREP * ctx->nbd_ext * ctx->nbd_ext * 8))) return rc;
-  if ((rc = dev_alloc(ctx, ctx->d_gc, (size_t)LVX_NREP * ctx->nbd_ext * 8))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_Hb, (size_t)std::max(ctx->nb, 1) * (ctx->bw + 1) * 8 + 16))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_gb, (size_t)std::max(ctx->nb, 1) * 8 + 16))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_Bd, (size_t)ctx->nbd_ext * std::max(ctx->nb, 1) * 8 + 16))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_C, (size_t)LVX_NREP * ctx->nbd_ext * ctx->nbd_ext * 8 + 16))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_gc, (size_t)LVX_NREP * ctx->nbd_ext * 8 + 16))) return rc;   // + 16 each: k_clear works in 16-byte words
   if ((rc = dev_alloc(ctx, ctx->d_hubs, 2 * sizeof(HubShared)))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_cost, LVX_NREP * 8))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_err, 16))) return rc;
@@ -1147,6 +1147,14 @@ ProfScope::~ProfScope() {
   c->ev_recs.push_back(lvx_ctx::EvRec{kernel, e0, e1});
 }
 
+// clears up to 8 device buffers (sizes rounded up to 16 bytes: every buffer is allocated with that slack by dev_alloc's callers) in one launch
+struct ClearList { uint4* p[8]; size_t words[8]; int n; };
+__global__ __launch_bounds__(256) void k_clear(ClearList cl) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int b = 0; b < cl.n; ++b)
+    for (size_t i = t0; i < cl.words[b]; i += stride) cl.p[b][i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cost, bool want_res_buffer) {
   int rc = ensure_layout(ctx);
   if (rc) return rc;
@@ -1170,14 +1178,17 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
   // Jacobian always do.
   auto enqueue = [&]() -> int {
     int rc = LVX_OK;
-    LVX_HIP(ctx, hipMemsetAsync(cm.cost, 0, LVX_NREP * 8, st));
-    LVX_HIP(ctx, hipMemsetAsync(cm.err, 0, 16, st));
-    if (what & LVX_EVAL_NORMAL_EQ) {
-      LVX_HIP(ctx, hipMemsetAsync(cm.Hb, 0, (size_t)std::max(ctx->nb, 1) * (ctx->bw + 1) * 8, st));
-      LVX_HIP(ctx, hipMemsetAsync(cm.gb, 0, (size_t)std::max(ctx->nb, 1) * 8, st));
-      LVX_HIP(ctx, hipMemsetAsync(cm.Bd, 0, (size_t)ctx->nbd_ext * std::max(ctx->nb, 1) * 8, st));
-      LVX_HIP(ctx, hipMemsetAsync(cm.C, 0, (size_t)LVX_NREP * ctx->nbd_ext * ctx->nbd_ext * 8, st));
-      LVX_HIP(ctx, hipMemsetAsync(cm.gc, 0, (size_t)LVX_NREP * ctx->nbd_ext * 8, st));
+    {   // one launch clears every accumulator of the pass (cost, error flags, and for the normal equations band, gradient, border rows, dense border)
+      ClearList cl{};
+      auto add = [&](void* p, size_t bytes) { cl.p[cl.n] = (uint4*)p; cl.words[cl.n] = (bytes + 15) / 16; cl.n++; };
+      add(cm.cost, LVX_NREP * 8); add(cm.err, 16);
+      if (what & LVX_EVAL_NORMAL_EQ) {
+        add(cm.Hb, (size_t)std::max(ctx->nb, 1) * (ctx->bw + 1) * 8); add(cm.gb, (size_t)std::max(ctx->nb, 1) * 8);
+        add(cm.Bd, (size_t)ctx->nbd_ext * std::max(ctx->nb, 1) * 8); add(cm.C, (size_t)LVX_NREP * ctx->nbd_ext * ctx->nbd_ext * 8); add(cm.gc, (size_t)LVX_NREP * ctx->nbd_ext * 8);
+      }
+      size_t total = 0; for (int i = 0; i < cl.n; ++i) total += cl.words[i];
+      const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
+      hipLaunchKernelGGL(k_clear, dim3(blocks), dim3(256), 0, st, cl);
     }
     auto grid = [](int n) { return dim3((unsigned)((n + 63) / 64)); };
     // fast path: LDS-accumulating kernels for the segment-structured families; legacy per-segment kernels for reprojection, the prior,
