@@ -222,6 +222,148 @@ static int trsv_batched(lvx_ctx* c, const double* L, int b, long long strideL, d
   return LVX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Batched Cholesky of the b x b diagonal blocks (lower, column-major in place), one workgroup per block with the whole lower triangle
+// resident in LDS (packed rows: b (b + 1) / 2 doubles = 154 KB at b = 196, so b <= 201).  Right-looking with 16-column panels:
+//   1. the 16 x 16 diagonal block by 16 lanes of wavefront 0 (lane = row, columns in registers, cross-lane broadcasts),
+//   2. the rows below: one thread per row, forward substitution against the 16 x 16 factor,
+//   3. the trailing update A22 -= L21 L21^T as 16 x 16 tiles on v_mfma_f64_16x16x4_f64, tiles dealt round-robin to the 4 wavefronts.
+// rocSOLVER's strided-batched potrf runs each level as several dozen launches of small kernels (~5 ms per solve at config 4).
+// info[batch] = 1-based column of the first non-positive pivot (the factorisation continues with pivot 1 so that nothing turns into NaN).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tri(int i, int j) { return ((i * (i + 1)) >> 1) + j; }
+__device__ __forceinline__ double readlane_f64(double v, int l) {   // v_readlane: the value of lane l as a wave-uniform scalar (l must be uniform)
+  const long long u = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(u & 0xffffffffll), l), hi = __builtin_amdgcn_readlane((int)(u >> 32), l);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double rsqrt_f64(double x) {             // hardware estimate + two Newton steps: full double precision for x in the normal range
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+}
+__global__ __launch_bounds__(256) void k_potrf_batched(double* Dm, int b, long long strideD, int* info) {
+  extern __shared__ double T[];             // packed lower triangle, row-major
+  double* dinv = T + ((b * (b + 1)) >> 1);  // [16]
+  __shared__ int bad;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  double* D = Dm + (size_t)blockIdx.x * strideD;
+  if (tid == 0) bad = 0;
+  for (int c0 = 0; c0 < b; c0 += 4) {       // lower triangle, 4 columns per step so that the loads are in flight together
+    double v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int cc = c0 + q, r = cc + tid; v[q] = (cc < b && r < b) ? D[(size_t)cc * b + r] : 0.0; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int cc = c0 + q, r = cc + tid; if (cc < b && r < b) T[tri(r, cc)] = v[q]; }
+  }
+  __syncthreads();
+  const int fk = lane >> 4, fi = lane & 15;
+  for (int k0 = 0; k0 < b; k0 += 16) {
+    const int nk = min(16, b - k0);
+    if (wv == 0) {                          // 1. diagonal block
+      double a[16];
+      const int r = lane;
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc) a[cc] = (r < nk && cc <= r) ? T[tri(k0 + r, k0 + cc)] : ((r == cc) ? 1.0 : 0.0);
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc) {
+        double dc = readlane_f64(a[cc], cc);
+        if (!(dc > 0.0)) { if (lane == 0 && cc < nk) atomicCAS(&bad, 0, k0 + cc + 1); dc = 1.0; }
+        const double inv = rsqrt_f64(dc), sq = dc * inv;
+        a[cc] = (r == cc) ? sq : a[cc] * inv;
+        if (lane == 0) dinv[cc] = inv;
+#pragma unroll
+        for (int c2 = cc + 1; c2 < 16; ++c2) { const double l2 = readlane_f64(a[cc], c2); a[c2] -= a[cc] * l2; }
+      }
+      if (r < nk) {
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) if (cc <= r) T[tri(k0 + r, k0 + cc)] = a[cc];
+      }
+    }
+    __syncthreads();
+    {                                       // 2. rows below the diagonal block: x L11^T = a
+      const int i = k0 + nk + tid;
+      if (i < b) {
+        double x[16];
+        double* row = &T[tri(i, k0)];
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) x[cc] = cc < nk ? row[cc] : 0.0;
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) {
+          if (cc < nk) {
+            const double* lrow = &T[tri(k0 + cc, k0)];
+            double sacc = x[cc];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) if (q < cc) sacc -= x[q] * lrow[q];
+            x[cc] = sacc * dinv[cc];
+          }
+        }
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) if (cc < nk) row[cc] = x[cc];
+      }
+    }
+    __syncthreads();
+    const int r0 = k0 + 16;
+    if (r0 < b) {                           // 3. trailing update on the matrix cores
+      const int m = (b - r0 + 15) >> 4;
+      // tile rows dealt to the wavefronts longest first (row ti has ti + 1 tiles): wave w takes m-1-w, m-1-w-4, ... ; the A fragments of a
+      // row are loaded once, two tiles are in flight so that their MFMA chains interleave
+      for (int ti = m - 1 - wv; ti >= 0; ti -= 4) {
+        const int i0 = r0 + 16 * ti, ai = i0 + fi;
+        const int abase = ai < b ? tri(ai, k0 + fk) : -1;
+        double av[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) av[ks] = abase >= 0 ? -T[abase + 4 * ks] : 0.0;
+        int rowb[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { const int ci = i0 + fk + 4 * v; rowb[v] = ci < b ? tri(ci, 0) : -1; }
+        for (int tj = 0; tj <= ti; tj += 2) {
+          const bool two = tj + 1 <= ti;
+          const int j0 = r0 + 16 * tj, j1 = j0 + 16;
+          const int cj0 = j0 + fi, cj1 = j1 + fi;
+          const int bb0 = cj0 < b ? tri(cj0, k0 + fk) : -1, bb1 = (two && cj1 < b) ? tri(cj1, k0 + fk) : -1;
+          d4 C0, C1;
+          int x0[4], x1[4];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int ci = i0 + fk + 4 * v;
+            x0[v] = (rowb[v] >= 0 && cj0 <= ci) ? rowb[v] + cj0 : -1;
+            x1[v] = (two && rowb[v] >= 0 && cj1 <= ci) ? rowb[v] + cj1 : -1;
+            C0[v] = x0[v] >= 0 ? T[x0[v]] : 0.0; C1[v] = x1[v] >= 0 ? T[x1[v]] : 0.0;
+          }
+          double b0[4], b1[4];
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) { b0[ks] = bb0 >= 0 ? T[bb0 + 4 * ks] : 0.0; b1[ks] = bb1 >= 0 ? T[bb1 + 4 * ks] : 0.0; }
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            C0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], b0[ks], C0, 0, 0, 0);
+            if (two) C1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], b1[ks], C1, 0, 0, 0);
+          }
+#pragma unroll
+          for (int v = 0; v < 4; ++v) { if (x0[v] >= 0) T[x0[v]] = C0[v]; if (x1[v] >= 0) T[x1[v]] = C1[v]; }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int cc = 0; cc < b; ++cc) { const int r = cc + tid; if (r < b) D[(size_t)cc * b + r] = T[tri(r, cc)]; }
+  if (tid == 0) info[blockIdx.x] = bad;
+}
+// potrf of `batch` blocks: own kernel when the triangle fits into LDS, rocSOLVER otherwise (or with LVX_BCR_ROCSOLVER_POTRF)
+static int potrf_batched(lvx_ctx* c, rocblas_handle h, double* D, int b, long long strideD, int* info, int batch) {
+  static const bool force_lib = getenv("LVX_BCR_ROCSOLVER_POTRF") != nullptr;
+  const size_t lds = ((size_t)b * (b + 1) / 2 + 16) * 8;
+  if (force_lib || lds > 159 * 1024) {
+    LVX_BLAS(c, rocsolver_dpotrf_strided_batched(h, rocblas_fill_lower, b, D, b, (rocblas_stride)strideD, info, batch));
+    return LVX_OK;
+  }
+  LVX_HIP(c, hipFuncSetAttribute((const void*)k_potrf_batched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_potrf_batched, dim3((unsigned)batch), dim3(256), lds, c->stream, D, b, strideD, info);
+  LVX_HIP(c, hipGetLastError());
+  return LVX_OK;
+}
+
 int bcr_plan(lvx_ctx* c) {
   const int b = std::max(16, ((c->bw + 3) / 4) * 4);
   int nblk = 1;
@@ -259,7 +401,7 @@ int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_ra
     double* Dr = D + (size_t)(2 * s - 1) * bb;
     double* Gl = G + g_off(nblk, l, bb);
     double* Gn = G + g_off(nblk, l + 1, bb);
-    LVX_BLAS(c, rocsolver_dpotrf_strided_batched(h, rocblas_fill_lower, b, Dj, b, sD, info + info_pos, n2));
+    if ((rc = potrf_batched(c, h, Dj, b, sD, info + info_pos, n2))) return rc;
     info_pos += n2;
     // X+_k = G[2k] C_k^-T : every ROW x of G[2k] solves C x^T = g^T
     if ((rc = trsv_batched<false>(c, Dj, b, sD, Gl, /*se*/ b, /*sv*/ 1, sG, b, n2))) return rc;
@@ -277,7 +419,7 @@ int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_ra
       LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, b, b, &mone, Gl + 2 * bb, b, sG, Gl + bb, b, sG, &zero, Gn, b, (rocblas_stride)bb, n2 - 1));
     }
   }
-  LVX_BLAS(c, rocsolver_dpotrf_strided_batched(h, rocblas_fill_lower, b, D + (size_t)(nblk - 1) * bb, b, (rocblas_stride)bb, info + info_pos, 1));
+  if ((rc = potrf_batched(c, h, D + (size_t)(nblk - 1) * bb, b, (long long)bb, info + info_pos, 1))) return rc;
   info_pos += 1;
   hipLaunchKernelGGL(k_bcr_info, dim3((info_pos + 255) / 256), dim3(256), 0, st, (const int*)info, info_pos, info_out_d);
   LVX_HIP(c, hipGetLastError());
