@@ -210,9 +210,149 @@ __global__ __launch_bounds__(256) void k_trsm_batched(const double* __restrict__
   if (se == 1) { for (int e = tid; e < nv * b; e += 256) { const int i = e % b, t = e / b; v0[(size_t)t * sv + i] = W[i * TRS_WS + t]; } }
   else { for (int e = tid; e < 64 * b; e += 256) { const int t = e & 63, i = e >> 6; if (t < nv) v0[(size_t)t * sv + (size_t)i * se] = W[i * TRS_WS + t]; } }
 }
+// Register-resident variant: the 64 vectors of a workgroup never touch LDS.  A wavefront keeps its 16 vectors as NT accumulator tiles
+// (tile t = rows 16 t .. 16 t + 15, MFMA C layout: col = lane & 15 = vector, row = (lane >> 4) + 4 reg).  The B fragment of k-step ks of a
+// solved tile is exactly its register ks (row (lane >> 4) + 4 ks), so the rank-16 updates read their right-hand operand from registers; only
+// the 16-column panel of L (shared by the 4 wavefronts) and a 16 x 16 staging tile per wavefront for the diagonal solve live in LDS (35 KB
+// instead of 135 KB => 3-4 workgroups per CU instead of 1).  NT is a compile-time bound on ceil(b / 16); everything is unrolled so that no
+// tile is indexed dynamically.
+template <bool TRANS, int NT>
+__global__ __launch_bounds__(256, 2) void k_trsm_reg(const double* __restrict__ Lm, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec) {
+  extern __shared__ double lds[];
+  constexpr int bp = 16 * NT, PS = bp | 1;
+  double* P = lds;                         // [16][PS]
+  double* dinv = P + 16 * PS;              // [16]
+  double* Sall = dinv + 16;                // 4 x [16][17]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  double* S = Sall + wv * (16 * 17);
+  const int fk = lane >> 4, fi = lane & 15;
+  const int vec = blockIdx.x * 64 + wv * 16 + fi;
+  const bool vact = vec < nvec;
+  const double* L = Lm + (size_t)blockIdx.y * strideL;
+  double* v0 = V + (size_t)blockIdx.y * strideV + (size_t)vec * sv;
+  d4 W[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { const int i = 16 * t + fk + 4 * v; W[t][v] = (vact && i < b) ? v0[(size_t)i * se] : 0.0; }
+  constexpr int NPRE = (16 * bp + 255) / 256;
+  double pre[NPRE];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) {
+      const int e = tid + 256 * j;
+      double v = 0.0;
+      if (e < 16 * bp) {
+        const int kk = e / bp, i = e - kk * bp, k = k0 + kk;
+        if (k < b) { if (i >= k && i < b) v = L[(size_t)k * b + i]; } else if (i == k) v = 1.0;
+      }
+      pre[j] = v;
+    }
+  };
+  auto commit = [&](int k0) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) {
+      const int e = tid + 256 * j;
+      if (e < 16 * bp) {
+        const int kk = e / bp, i = e - kk * bp;
+        P[kk * PS + i] = pre[j];
+        if (i == k0 + kk) dinv[kk] = 1.0 / pre[j];
+      }
+    }
+    __syncthreads();
+  };
+  auto wave_sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+  if (!TRANS) {
+    fetch(0);
+#pragma clang loop unroll(full)
+    for (int p = 0; p < NT; ++p) {
+      const int k0 = 16 * p;
+      if (k0 < b) {                         // uniform
+        commit(k0);
+        if (k0 + 16 < b) fetch(k0 + 16);
+        {   // 16 x 16 triangular solve in the accumulator layout: the 16 rows of a vector sit in 4 lanes (16 apart) x 4 registers; the
+            // solved entry is broadcast to the vector's other 3 lanes and every lane updates its own 4 rows
+          double lq[4];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) lq[v] = P[q * PS + k0 + fk + 4 * v];           // L[k0 + row][k0 + q], rows of this lane
+            const double cand = W[p][q >> 2] * dinv[q];
+            const double xq = __shfl(cand, ((q & 3) << 4) + fi);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { const int r = fk + 4 * v; W[p][v] = r == q ? xq : (r > q ? W[p][v] - lq[v] * xq : W[p][v]); }
+          }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int t = p + 1; t < NT; ++t)
+            W[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-P[(ks * 4 + fk) * PS + 16 * t + fi], W[p][ks], W[t], 0, 0, 0);
+      }
+    }
+  } else {
+    const int plast = (b - 1) >> 4;
+    fetch(16 * plast);
+#pragma clang loop unroll(full)
+    for (int p = NT - 1; p >= 0; --p) {
+      const int k0 = 16 * p;
+      if (p <= plast) {                     // uniform
+        commit(k0);
+        if (p > 0) fetch(k0 - 16);
+        d4 Ca = W[p], Cb = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t = p + 1; t < NT; ++t)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const double av = -P[fi * PS + 16 * t + 4 * ks + fk];
+            if (((t - p) & 1) != 0) Ca = __builtin_amdgcn_mfma_f64_16x16x4f64(av, W[t][ks], Ca, 0, 0, 0);
+            else Cb = __builtin_amdgcn_mfma_f64_16x16x4f64(av, W[t][ks], Cb, 0, 0, 0);
+          }
+        {   // transposed 16 x 16 triangular solve, rows 15 .. 0, in the accumulator layout
+          d4 X;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) X[v] = Ca[v] + Cb[v];
+          double lq[4];
+#pragma unroll
+          for (int q = 15; q >= 0; --q) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) lq[v] = P[(fk + 4 * v) * PS + k0 + q];         // L[k0 + q][k0 + row]
+            const double cand = X[q >> 2] * dinv[q];
+            const double xq = __shfl(cand, ((q & 3) << 4) + fi);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { const int r = fk + 4 * v; X[v] = r == q ? xq : (r < q ? X[v] - lq[v] * xq : X[v]); }
+          }
+          W[p] = X;
+        }
+      }
+    }
+  }
+  if (vact) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) { const int i = 16 * t + fk + 4 * v; if (i < b) v0[(size_t)i * se] = W[t][v]; }
+  }
+}
+template <bool TRANS, int NT>
+static int launch_trsm_reg(lvx_ctx* c, const double* L, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, int batch) {
+  const size_t lds = ((size_t)16 * ((16 * NT) | 1) + 16 + 4 * 16 * 17) * 8;
+  LVX_HIP(c, hipFuncSetAttribute((const void*)k_trsm_reg<TRANS, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_trsm_reg<TRANS, NT>), dim3((unsigned)((nvec + 63) / 64), (unsigned)batch), dim3(256), lds, c->stream, L, b, strideL, V, se, sv, strideV, nvec);
+  LVX_HIP(c, hipGetLastError());
+  return LVX_OK;
+}
+
 template <bool TRANS>
 static int trsv_batched(lvx_ctx* c, const double* L, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, int batch) {
   if (batch <= 0 || nvec <= 0) return LVX_OK;
+  static const bool lds_variant = getenv("LVX_TRSM_LDS") != nullptr;
+  if (!lds_variant) {
+    if (b <= 128) return launch_trsm_reg<TRANS, 8>(c, L, b, strideL, V, se, sv, strideV, nvec, batch);
+    if (b <= 208) return launch_trsm_reg<TRANS, 13>(c, L, b, strideL, V, se, sv, strideV, nvec, batch);
+    if (b <= 256) return launch_trsm_reg<TRANS, 16>(c, L, b, strideL, V, se, sv, strideV, nvec, batch);
+  }
   const int bp = (b + 15) & ~15;
   const size_t lds = ((size_t)bp * TRS_WS + (size_t)16 * (bp | 1) + 16) * 8;
   if (lds > 158 * 1024 || bp > 256) return fail(c, LVX_E_ARG, "block size too large for the LDS-resident triangular solve");
