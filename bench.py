@@ -32,7 +32,7 @@ FP64_PEAK_TFLOPS = 78.6      # MI355X FP64: vector 78.6 TFLOP/s = matrix (v_mfma
 # correction was calibrated on).  Of the writes ~55 MB are the accumulator flushes (atomics); the rest is register-spill scratch: the kernel
 # runs two wavefronts per SIMD with 48 spilled VGPRs (192 B per lane and batch), which is 11 % faster than one wavefront without spills.
 PMC_TRAFFIC_BYTES = 276.2e6
-PMC_SOURCE = "profiles/r01e_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per dispatch)"
+PMC_SOURCE = "profiles/r01f_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per dispatch)"
 BYTES_PER_EVAL = {"imu": 32, "surfel": 60, "reproj": 60}
 FLOPS_PER_EVAL = {"imu": 4e3, "surfel": 9e3, "reproj": 11e3}
 
