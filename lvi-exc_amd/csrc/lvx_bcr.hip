@@ -64,157 +64,19 @@ static int bcr_handle(lvx_ctx* c, rocblas_handle* h) {
 // ---------------------------------------------------------------------------------------------------------
 // Batched multi-vector triangular solve with a dense lower factor L (b x b, column-major): in place L w = v (TRANS = false) or
 // L^T w = v (TRANS = true) for `nvec` vectors per batch element.  Vector k, element i lives at V[k * sv + i * se].
-// A workgroup holds 64 vectors of one batch element in LDS (W[row][vector]); each of its 4 wavefronts owns 16 of them, so the waves only
-// meet to load L, which streams through LDS in 16-column panels.  Per panel: the 16 x 16 diagonal triangle is solved by substitution
-// (lanes 0..15, one vector each), everything else is a rank-16 update on the FP64 matrix cores (v_mfma_f64_16x16x4_f64):
-//   forward : W[i0.., vectors] -= L[i0.., panel] w[panel, vectors]        one 16 x 16 tile per 16 rows below the panel
-//   backward: v[panel, vectors] -= L[rows below, panel]^T w[rows below]   one accumulator tile, k-steps over the rows below
+// A workgroup handles 64 vectors of one batch element, each of its 4 wavefronts 16 of them; L streams through LDS in 16-column panels
+// (register double-buffered).  Per panel: the 16 x 16 diagonal triangle by substitution, everything else a rank-16 update on the FP64
+// matrix cores (v_mfma_f64_16x16x4_f64):
+//   forward : W[rows below, vectors] -= L[rows below, panel] w[panel, vectors]     one 16 x 16 tile per 16 rows below the panel
+//   backward: v[panel, vectors]      -= L[rows below, panel]^T w[rows below]       accumulator tiles, k-steps over the rows below
 // (rocBLAS' strided-batched TRSM turns into thousands of tiny launches at b ~ 200, and explicit inverses of the blocks lose positive
 // definiteness of the Schur complements on weakly constrained problems, so this step is hand-written; no inverse is formed.)
 // ---------------------------------------------------------------------------------------------------------
 typedef double d4 __attribute__((ext_vector_type(4)));
-#define TRS_WS 65   // row stride of W (odd: conflict-free for lane = vector and for lane = row)
-template <bool TRANS>
-__global__ __launch_bounds__(256) void k_trsm_batched(const double* __restrict__ Lm, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec) {
-  extern __shared__ double lds[];
-  const int bp = (b + 15) & ~15;           // rows padded to whole MFMA tiles
-  const int PS = bp | 1;                   // panel row stride (odd)
-  double* W = lds;                         // [bp][TRS_WS]
-  double* P = W + (size_t)bp * TRS_WS;     // [16][PS]: P[kk][i] = L[i][k0 + kk] for i >= k0 + kk, zero above the diagonal and in the padding
-  double* dinv = P + 16 * PS;              // [16] reciprocals of the panel's diagonal
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int t0 = wv * 16;                  // this wave's 16 vectors
-  const int vec0 = blockIdx.x * 64;
-  const double* L = Lm + (size_t)blockIdx.y * strideL;
-  double* v0 = V + (size_t)blockIdx.y * strideV + (size_t)vec0 * sv;
-  const int nv = min(64, nvec - vec0);
-  for (int e = tid; e < bp * TRS_WS; e += 256) W[e] = 0.0;
-  __syncthreads();
-  if (se == 1) { for (int e = tid; e < nv * b; e += 256) { const int i = e % b, t = e / b; W[i * TRS_WS + t] = v0[(size_t)t * sv + i]; } }
-  else { for (int e = tid; e < 64 * b; e += 256) { const int t = e & 63, i = e >> 6; if (t < nv) W[i * TRS_WS + t] = v0[(size_t)t * sv + (size_t)i * se]; } }
-  const int fk = lane >> 4, fi = lane & 15;
-  // panel k0 = columns k0 .. k0+15 of L below the diagonal.  Double buffered through registers: the loads of the NEXT panel are issued
-  // before the current one is used, so their latency overlaps the substitution + MFMA work (the chain of 13 panels is latency bound).
-  constexpr int NPRE = 16;                 // 16 * bp / 256 values per thread, bp <= 256 (LDS bound)
-  double pre[NPRE];
-  auto fetch = [&](int k0) {
-#pragma unroll
-    for (int j = 0; j < NPRE; ++j) {
-      const int e = tid + 256 * j;
-      double v = 0.0;
-      if (e < 16 * bp) {
-        const int kk = e / bp, i = e - kk * bp, k = k0 + kk;
-        if (k < b) { if (i >= k && i < b) v = L[(size_t)k * b + i]; } else if (i == k) v = 1.0;
-      }
-      pre[j] = v;
-    }
-  };
-  auto commit = [&](int k0) {
-    __syncthreads();                       // the previous panel is no longer read
-#pragma unroll
-    for (int j = 0; j < NPRE; ++j) {
-      const int e = tid + 256 * j;
-      if (e < 16 * bp) {
-        const int kk = e / bp, i = e - kk * bp;
-        P[kk * PS + i] = pre[j];
-        if (i == k0 + kk) dinv[kk] = 1.0 / pre[j];
-      }
-    }
-    __syncthreads();
-  };
-  if (!TRANS) {
-    fetch(0);
-    for (int k0 = 0; k0 < b; k0 += 16) {
-      commit(k0);
-      if (k0 + 16 < b) fetch(k0 + 16);
-      if (lane < 16) {                     // 16 x 16 lower-triangular solve, column oriented: 15 - q independent updates per step
-        double x[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = W[(k0 + r) * TRS_WS + t0 + lane];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          x[q] *= dinv[q];
-#pragma unroll
-          for (int r = q + 1; r < 16; ++r) x[r] -= P[q * PS + k0 + r] * x[q];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) W[(k0 + r) * TRS_WS + t0 + lane] = x[r];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      double Bf[4];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) Bf[ks] = W[(k0 + ks * 4 + fk) * TRS_WS + t0 + fi];
-      int i0 = k0 + 16;
-      for (; i0 + 16 < bp; i0 += 32) {     // two independent row tiles per step: their MFMA chains interleave
-        d4 Ca, Cb;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) { Ca[v] = W[(i0 + fk + 4 * v) * TRS_WS + t0 + fi]; Cb[v] = W[(i0 + 16 + fk + 4 * v) * TRS_WS + t0 + fi]; }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          Ca = __builtin_amdgcn_mfma_f64_16x16x4f64(-P[(ks * 4 + fk) * PS + i0 + fi], Bf[ks], Ca, 0, 0, 0);
-          Cb = __builtin_amdgcn_mfma_f64_16x16x4f64(-P[(ks * 4 + fk) * PS + i0 + 16 + fi], Bf[ks], Cb, 0, 0, 0);
-        }
-#pragma unroll
-        for (int v = 0; v < 4; ++v) { W[(i0 + fk + 4 * v) * TRS_WS + t0 + fi] = Ca[v]; W[(i0 + 16 + fk + 4 * v) * TRS_WS + t0 + fi] = Cb[v]; }
-      }
-      for (; i0 < bp; i0 += 16) {
-        d4 Cc;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) Cc[v] = W[(i0 + fk + 4 * v) * TRS_WS + t0 + fi];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) Cc = __builtin_amdgcn_mfma_f64_16x16x4f64(-P[(ks * 4 + fk) * PS + i0 + fi], Bf[ks], Cc, 0, 0, 0);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) W[(i0 + fk + 4 * v) * TRS_WS + t0 + fi] = Cc[v];
-      }
-    }
-  } else {
-    fetch(bp - 16);
-    for (int k0 = bp - 16; k0 >= 0; k0 -= 16) {
-      commit(k0);
-      if (k0 >= 16) fetch(k0 - 16);
-      d4 Cc, Cd = d4{0.0, 0.0, 0.0, 0.0};   // two accumulators over alternating k-steps: independent MFMA chains
-#pragma unroll
-      for (int v = 0; v < 4; ++v) Cc[v] = W[(k0 + fk + 4 * v) * TRS_WS + t0 + fi];
-      int i0 = k0 + 16;
-      for (; i0 + 4 < bp; i0 += 8) {
-        Cc = __builtin_amdgcn_mfma_f64_16x16x4f64(-P[fi * PS + i0 + fk], W[(i0 + fk) * TRS_WS + t0 + fi], Cc, 0, 0, 0);
-        Cd = __builtin_amdgcn_mfma_f64_16x16x4f64(-P[fi * PS + i0 + 4 + fk], W[(i0 + 4 + fk) * TRS_WS + t0 + fi], Cd, 0, 0, 0);
-      }
-      for (; i0 < bp; i0 += 4) Cc = __builtin_amdgcn_mfma_f64_16x16x4f64(-P[fi * PS + i0 + fk], W[(i0 + fk) * TRS_WS + t0 + fi], Cc, 0, 0, 0);
-#pragma unroll
-      for (int v = 0; v < 4; ++v) W[(k0 + fk + 4 * v) * TRS_WS + t0 + fi] = Cc[v] + Cd[v];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (lane < 16) {                     // 16 x 16 transposed-triangular solve, rows 15 .. 0
-        double x[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = W[(k0 + r) * TRS_WS + t0 + lane];
-#pragma unroll
-        for (int q = 15; q >= 0; --q) {
-          x[q] *= dinv[q];
-#pragma unroll
-          for (int r = 0; r < q; ++r) x[r] -= P[r * PS + k0 + q] * x[q];   // L[k0+q][k0+r]
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) W[(k0 + r) * TRS_WS + t0 + lane] = x[r];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-  }
-  __syncthreads();
-  if (se == 1) { for (int e = tid; e < nv * b; e += 256) { const int i = e % b, t = e / b; v0[(size_t)t * sv + i] = W[i * TRS_WS + t]; } }
-  else { for (int e = tid; e < 64 * b; e += 256) { const int t = e & 63, i = e >> 6; if (t < nv) v0[(size_t)t * sv + (size_t)i * se] = W[i * TRS_WS + t]; } }
-}
-// Register-resident variant: the 64 vectors of a workgroup never touch LDS.  A wavefront keeps its 16 vectors as NT accumulator tiles
+// The 64 vectors of a workgroup never touch LDS: a wavefront keeps its 16 vectors as NT accumulator tiles
 // (tile t = rows 16 t .. 16 t + 15, MFMA C layout: col = lane & 15 = vector, row = (lane >> 4) + 4 reg).  The B fragment of k-step ks of a
 // solved tile is exactly its register ks (row (lane >> 4) + 4 ks), so the rank-16 updates read their right-hand operand from registers; only
-// the 16-column panel of L (shared by the 4 wavefronts) and a 16 x 16 staging tile per wavefront for the diagonal solve live in LDS (35 KB
-// instead of 135 KB => 3-4 workgroups per CU instead of 1).  NT is a compile-time bound on ceil(b / 16); everything is unrolled so that no
+// the 16-column panel of L (shared by the 4 wavefronts) lives in LDS (27 KB; the predecessor kept the vectors in LDS, 135 KB).  NT is a compile-time bound on ceil(b / 16); everything is unrolled so that no
 // tile is indexed dynamically.
 template <bool TRANS, int NT>
 __global__ __launch_bounds__(256, 2) void k_trsm_reg(const double* __restrict__ Lm, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec) {
@@ -222,9 +84,7 @@ __global__ __launch_bounds__(256, 2) void k_trsm_reg(const double* __restrict__ 
   constexpr int bp = 16 * NT, PS = bp | 1;
   double* P = lds;                         // [16][PS]
   double* dinv = P + 16 * PS;              // [16]
-  double* Sall = dinv + 16;                // 4 x [16][17]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  double* S = Sall + wv * (16 * 17);
   const int fk = lane >> 4, fi = lane & 15;
   const int vec = blockIdx.x * 64 + wv * 16 + fi;
   const bool vact = vec < nvec;
@@ -262,7 +122,6 @@ __global__ __launch_bounds__(256, 2) void k_trsm_reg(const double* __restrict__ 
     }
     __syncthreads();
   };
-  auto wave_sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
   if (!TRANS) {
     fetch(0);
 #pragma clang loop unroll(full)
@@ -337,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void k_trsm_reg(const double* __restrict__ 
 }
 template <bool TRANS, int NT>
 static int launch_trsm_reg(lvx_ctx* c, const double* L, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, int batch) {
-  const size_t lds = ((size_t)16 * ((16 * NT) | 1) + 16 + 4 * 16 * 17) * 8;
+  const size_t lds = ((size_t)16 * ((16 * NT) | 1) + 16) * 8;
   LVX_HIP(c, hipFuncSetAttribute((const void*)k_trsm_reg<TRANS, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((k_trsm_reg<TRANS, NT>), dim3((unsigned)((nvec + 63) / 64), (unsigned)batch), dim3(256), lds, c->stream, L, b, strideL, V, se, sv, strideV, nvec);
   LVX_HIP(c, hipGetLastError());
@@ -347,19 +206,10 @@ static int launch_trsm_reg(lvx_ctx* c, const double* L, int b, long long strideL
 template <bool TRANS>
 static int trsv_batched(lvx_ctx* c, const double* L, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, int batch) {
   if (batch <= 0 || nvec <= 0) return LVX_OK;
-  static const bool lds_variant = getenv("LVX_TRSM_LDS") != nullptr;
-  if (!lds_variant) {
-    if (b <= 128) return launch_trsm_reg<TRANS, 8>(c, L, b, strideL, V, se, sv, strideV, nvec, batch);
-    if (b <= 208) return launch_trsm_reg<TRANS, 13>(c, L, b, strideL, V, se, sv, strideV, nvec, batch);
-    if (b <= 256) return launch_trsm_reg<TRANS, 16>(c, L, b, strideL, V, se, sv, strideV, nvec, batch);
-  }
-  const int bp = (b + 15) & ~15;
-  const size_t lds = ((size_t)bp * TRS_WS + (size_t)16 * (bp | 1) + 16) * 8;
-  if (lds > 158 * 1024 || bp > 256) return fail(c, LVX_E_ARG, "block size too large for the LDS-resident triangular solve");
-  LVX_HIP(c, hipFuncSetAttribute((const void*)k_trsm_batched<TRANS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_trsm_batched<TRANS>, dim3((unsigned)((nvec + 63) / 64), (unsigned)batch), dim3(256), lds, c->stream, L, b, strideL, V, se, sv, strideV, nvec);
-  LVX_HIP(c, hipGetLastError());
-  return LVX_OK;
+  if (b <= 128) return launch_trsm_reg<TRANS, 8>(c, L, b, strideL, V, se, sv, strideV, nvec, batch);
+  if (b <= 208) return launch_trsm_reg<TRANS, 13>(c, L, b, strideL, V, se, sv, strideV, nvec, batch);
+  if (b <= 256) return launch_trsm_reg<TRANS, 16>(c, L, b, strideL, V, se, sv, strideV, nvec, batch);
+  return fail(c, LVX_E_ARG, "block size too large for the batched triangular solve (half-bandwidth > 256)");
 }
 
 // ---------------------------------------------------------------------------------------------------------
