@@ -95,6 +95,8 @@ typedef struct lvx_layout {
   int32_t n_hub_knots, hub_knot0;
   int64_t n_blocks;    /* residual blocks per evaluation */
   int64_t n_residuals; /* residual rows per evaluation */
+  int32_t exact_fallback; /* 1 once an evaluation hit a case only the per-segment kernels handle exactly (merged map-time segment): they are used from then on */
+  int32_t reserved;
 } lvx_layout;
 
 /* lifetime ------------------------------------------------------------------------------------------------*/

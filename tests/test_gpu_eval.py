@@ -147,3 +147,28 @@ def test_empty_problem():
     r = g.evaluate(P["state0"][: 7 * P["n_knots"] + 32], normal_eq=True)
     assert r["cost"] == 0.0 and r["residuals"].size == 0 and not r["H"].any()
     g.close()
+
+
+def test_merged_hub_segment_corner_takes_the_exact_fallback():
+    """t_map 5 us before a knot and a locked lidar offset of 8 us: evaluated alone, the map-time pose leaves its 4-knot segment and is found by
+    the reference's t - 1e-5 retry (spline_base.h:196-203); in a residual whose point time lies in the next interval the two spans MERGE into
+    a longer segment that contains t_map + tau directly, i.e. a different interpolation amount.  The shared-hub fast path detects the
+    mismatch and the evaluation is redone by the per-segment kernels; either way the result must equal the oracle's."""
+    P = synth.make_problem(seed=31, duration=1.0, n_surfel=400, n_planes=6, n_landmarks=0, n_camsurf=0)
+    P["t_map"] = P["t0"] + 12 * P["dt"] - 5e-6
+    assert P["surf_t"].min() > P["t_map"]
+    # some rows in the interval right after t_map (merged segment), most further away (separate segments)
+    P["surf_t"] = np.sort(np.concatenate([P["t_map"] + np.linspace(2e-3, 0.03, 40), P["surf_t"][40:]]))
+    o, g = _pair(P, TAU_LOCKS, prior=False)
+    N = P["n_knots"]
+    s = P["state0"].copy()
+    s[7 * N + 16 + 7] = 8e-6
+    ro = o.evaluate(s, normal_eq=True)
+    assert g.layout()["exact_fallback"] == 0
+    for jac in (False, True, False):
+        rg = g.evaluate(s, jac=jac, normal_eq=True)
+        assert abs(rg["cost"] - ro["cost"]) <= 1e-12 * abs(ro["cost"])
+        assert np.abs(rg["residuals"] - ro["residuals"]).max() <= 1e-11 * np.abs(ro["residuals"]).max()
+        assert np.abs(rg["H"] - ro["H"]).max() <= 1e-10 * np.abs(ro["H"]).max()
+    assert g.layout()["exact_fallback"] == 1          # the corner was detected, not missed
+    g.close()
