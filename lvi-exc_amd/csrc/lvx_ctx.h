@@ -64,7 +64,7 @@ struct lvx_ctx {
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;
   hipStream_t fam_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // concurrent family kernels
-  hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr}, ev_jac = nullptr;   // ev_jac: reprojection Jacobians materialised
   std::string last_error;
   // problem
   bool have_spline = false;

@@ -1288,11 +1288,14 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
             double* Jb = (double*)ctx->d_repB[0].p; double* rb = Jb + (size_t)2 * REP_NC * r.n; int* kb = (int*)ctx->d_repB[1].p;
             hipLaunchKernelGGL(k_reproj_jac, grid(r.n), dim3(64), 0, s_rep, r, cm, Jb, rb, kb, (long long)ctx->fam_row0[4]);
             if (what & LVX_EVAL_NORMAL_EQ) {
+              LVX_HIP(ctx, hipEventRecord(ctx->ev_jac, s_rep));
               const RepJac jac{Jb, rb, kb, r.n};
               RepObsAcc ra{r.n, r.lm, r.perm, jac, 0.0};
               LVX_LAUNCH_MFMA1(RepObsAcc, 1, ra, LVX_FAM_REPROJ, s_rep, ctx->fam_row0[4]);   // measured: a second workgroup per CU does not help, the cross-term atomics bound this pass
+              // the reference-side pass only reads the materialised rows: it runs next to the observation-side pass, behind the accelerometer kernel
               RepRefAcc rb2{r.n, (const int*)ctx->d_repB[2].p, (const int*)ctx->d_repB[3].p, jac, 0.0};
-              LVX_LAUNCH_MFMA1(RepRefAcc, 1, rb2, LVX_FAM_PRIOR, s_rep, ctx->fam_row0[4]);
+              LVX_HIP(ctx, hipStreamWaitEvent(s_acc, ctx->ev_jac, 0));
+              LVX_LAUNCH_MFMA1(RepRefAcc, 1, rb2, LVX_FAM_PRIOR, s_acc, ctx->fam_row0[4]);
             }
           } else
           hipLaunchKernelGGL((k_family<ReprojFam, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, r, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
@@ -1395,6 +1398,7 @@ int lvx_create(lvx_ctx** out, int device, uint32_t /*flags*/) {
   c->stream = c->own_stream;
   for (int k = 0; k < 4; ++k) { if (hipStreamCreateWithFlags(&c->fam_stream[k], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming) != hipSuccess) { delete c; return LVX_E_HIP; } }
   if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { delete c; return LVX_E_HIP; }
+  if (hipEventCreateWithFlags(&c->ev_jac, hipEventDisableTiming) != hipSuccess) { delete c; return LVX_E_HIP; }
   *out = c;
   return LVX_OK;
 }
@@ -1420,6 +1424,7 @@ void lvx_destroy(lvx_ctx* c) {
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   for (int k = 0; k < 4; ++k) { if (c->fam_stream[k]) (void)hipStreamDestroy(c->fam_stream[k]); if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_jac) (void)hipEventDestroy(c->ev_jac);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
