@@ -1326,13 +1326,19 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     }
     for (int k = 0; k < 4; ++k) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[k], ctx->fam_stream[k])); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[k], 0)); }
     { ProfScope ps(ctx, LVX_KERNEL_FOLD);
+    const bool fold_fast = (what & LVX_EVAL_NORMAL_EQ) && (fast_surf || fast_cs);
+    if (fold_fast && !getenv("LVX_SERIAL")) LVX_HIP(ctx, hipEventRecord(ctx->ev_jac, st));   // st has joined every family stream here
     hipLaunchKernelGGL(k_fold_replicas, dim3((unsigned)((ctx->nbd_ext * ctx->nbd_ext + 255) / 256)), dim3(256), 0, st, cm);
-    if ((what & LVX_EVAL_NORMAL_EQ) && (fast_surf || fast_cs)) {
+    if (fold_fast) {
+      // the border-row fold (Bd, streaming) and the dense fold (C, g_c; one workgroup, behind k_fold_replicas) touch disjoint buffers: side by side
+      hipStream_t s_side = getenv("LVX_SERIAL") ? st : ctx->fam_stream[0];
+      if (s_side != st) LVX_HIP(ctx, hipStreamWaitEvent(s_side, ctx->ev_jac, 0));
       for (int set = 0; set < 2; ++set) if (ctx->nb > 0 && ((set == 0 && fast_surf) || (set == 1 && fast_cs)))
-        hipLaunchKernelGGL(k_fold_border_rows, dim3((unsigned)((ctx->nb + 255) / 256)), dim3(256), 0, st, cm, set);
+        hipLaunchKernelGGL(k_fold_border_rows, dim3((unsigned)((ctx->nb + 255) / 256)), dim3(256), 0, s_side, cm, set);
       const size_t lds = ((size_t)ctx->nbd_ext * ctx->nbd_ext + ctx->nbd_ext) * 8;
       LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_fold_border_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(k_fold_border_dense, dim3(1), dim3(256), lds, st, cm);
+      if (s_side != st) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[0], s_side)); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[0], 0)); }
     } }
     LVX_HIP(ctx, hipGetLastError());
     return rc;
