@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liblvx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wno-unused-result"] + os.environ.get("LVX_DEFINES", "").split()   # e.g. LVX_DEFINES=-DLVX_KTIME: cycle counters of the MFMA family kernel (debug print)
 # FP contraction: the upstream kernels reproduce the reference's float arithmetic bit for bit (no FMA formation); the FP64
 # residual / Jacobian / solver kernels are compared at 1e-12 relative and use FMAs.
 CONTRACT = {"lvx_upstream.hip": "off"}

@@ -368,10 +368,14 @@ struct AccelAcc {
 struct SurfAcc {
   enum { NK = 24, NG = 12, NR = 1, HUB = 0, KPK = 6, LVO = 0, WS = 2, GL = 16, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 36, USE_PRE = 1, OCC = 2 };   // reverse-mode Jacobian: fits two wavefronts per SIMD with a few spills, and two workgroups per CU hide its latencies
   __device__ static constexpr int jm(int c) { return c; }
-  int n; const double* t; const double* pt; const int* plane; const int* perm; const double* planes; double t_map, weight, huber;
-  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared* hub, int si, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
+  int n; const double* t; const double* pt; const double* rowpl; const int* perm; double t_map, weight, huber;   // rowpl: the row's plane (gathered at layout time: no dependent load)
+  // raw inputs of a row, loaded one batch ahead of their use: the HBM latency hides behind the previous batch's assembly
+  struct Row { double t; v3 p, Pi; };
+  enum { PREFETCH = 1 };
+  __device__ Row load(int si) const { return Row{t[si], load_v3(pt + 3 * (size_t)si), load_v3(rowpl + 3 * (size_t)si)}; }
+  __device__ int eval_row(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared* hub, const Row& row, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
     const bool tl = (cm.locks & LVX_LOCK_LIDAR_TAU) != 0;
-    const double tk = t[si];
+    const double tk = row.t;
     const double pad = tl ? 0.0 : cm.sensor_mto;
     const double spans[2][2] = {{t_map - pad, t_map + pad}, {tk - pad, tk + pad}};
     Segs segs;
@@ -380,7 +384,8 @@ struct SurfAcc {
     if (!seg_lookup(sp, segs, t_map + cal.lidar.tau, &kh)) return RES_RANGE;
     if (hub->ok != 1) return hub->ok < 0 ? RES_NONUNIT : RES_RANGE;
     if (kh.i0 != hub->A.k.i0 || kh.u != hub->A.k.u) return LVX_ERR_FALLBACK;   // merged-segment corner: only the legacy kernel is exact
-    return surfel_residual_pseudo<true>(sp, hub->A, segs, cal.lidar, tk, load_v3(pt + 3 * (size_t)si), load_v3(planes + 3 * (size_t)plane[si]), weight, &key, r, J, aux.pw);
+    LVX_KT(aux.pw, 8)
+    return surfel_residual_pseudo<true>(sp, hub->A, segs, cal.lidar, tk, row.p, row.Pi, weight, &key, r, J, aux.pw);
   }
   __device__ static int klv(int c) { return c; }
   __device__ static int gcol(int g, int N, int nt) { return g < 6 ? nt + g : 6 * N + 8 + (g - 6); }
@@ -506,6 +511,11 @@ __global__ __launch_bounds__(64) void k_reproj_jac(ReprojFam fam, DevCommon cm, 
 // ---------------------------------------------------------------------------------------------------------
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// families with F::Row / F::load / F::eval_row have their raw row inputs loaded one batch ahead
+struct NoRow {};
+template <class F, class = void> struct RowOf { using type = NoRow; static constexpr bool prefetch = false; };
+template <class F> struct RowOf<F, std::void_t<typename F::Row>> { using type = typename F::Row; static constexpr bool prefetch = true; };
+
 template <class F> struct MfmaGeom {
   static constexpr int NKL = (F::WS + 3) * F::KPK;           // knot columns of a window
   static constexpr int NCL = NKL + F::NG + 1;                // + globals + residual
@@ -545,6 +555,12 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
   const int ch = blockIdx.x;
   const int m0 = chunk_off[ch], m1 = chunk_off[ch + 1];
   if (m0 >= m1) return;
+#ifdef LVX_KTIME
+  long long kt_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long kt0_ = __builtin_amdgcn_s_memtime(), kts_ = kt0_;
+#define KT(i) { const long long n_ = __builtin_amdgcn_s_memtime(); kt_[i] += n_ - kt0_; kt0_ = n_; }
+#else
+#define KT(i)
+#endif
   const int k_lo = ch * CR - 1;
   const int nt = 6 * cm.N + 22 + cm.L;
   const bool want_ne = (cm.what & LVX_EVAL_NORMAL_EQ) != 0;
@@ -557,7 +573,11 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
     if (ka >= 0 && ka + 1 < cm.N) so3_pre(load_q(sp.so3 + 4 * (size_t)ka), load_q(sp.so3 + 4 * (size_t)(ka + 1)), &pre_tab[tid]);
     else { pre_tab[tid].Om = mk(0, 0, 0); pre_tab[tid].on = 0.0; pre_tab[tid].Jri = m3_identity(); pre_tab[tid].ok = 1; }
   }
+#ifdef LVX_KTIME
+  const PreWin pwin{pre_tab, k_lo, CR + 4, kt_};
+#else
   const PreWin pwin{pre_tab, k_lo, CR + 4};
+#endif
   const Cal cal = load_cal(cm);
   const HubShared* hub = F::HUB >= 0 ? ((const HubShared*)cm.hubs) + F::HUB : nullptr;
   double* P = panels + wv * (PR * LDP);
@@ -567,22 +587,32 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
   auto cls = [](int lc) { return lc < NKL ? 6 * (lc / KPK) + F::LVO + lc % KPK : (lc < NKL + NG ? -1 - (lc - NKL) : (lc == NKL + NG ? -100 : -200)); };
   const int frag_off = (lane >> 4) * LDP + (lane & 15);
   double mycost = 0.0;
+  typename RowOf<F>::type nxt{};
+  if constexpr (RowOf<F>::prefetch) { const int s0 = m0 + wv * LB + lane; if (lane < LB && s0 < m1) nxt = fam.load(s0); }
   __syncthreads();
+  KT(0)
   for (int base = m0 + wv * LB; base < m1; base += 4 * LB) {   // LB rows per wave batch: sparse families spread their rows over the 4 waves
     const int si = base + lane;
     const bool in = lane < LB && si < m1;
+    const typename RowOf<F>::type cur = nxt;
     double r[NR];
     double J[NR][NC];
     int key = -1;
     Aux aux{-1, 0, 0, &pwin};
     bool valid = false;
+#ifdef LVX_KTIME
+    kt_[15] = __builtin_amdgcn_s_memtime();
+#endif
     if (in) {
-      const int status = fam.eval(cm, sp, cal, hub, si, r, J, key, aux);
+      int status;
+      if constexpr (RowOf<F>::prefetch) status = fam.eval_row(cm, sp, cal, hub, cur, r, J, key, aux);
+      else status = fam.eval(cm, sp, cal, hub, si, r, J, key, aux);
       if (aux.wid < 0) aux.wid = key;
       valid = status == RES_OK;
       if (valid && (key < k_lo || key - k_lo > CR + 1)) { valid = false; atomicOr(cm.err, LVX_ERR_FALLBACK); }
       else if (!valid && status > 0) atomicOr(cm.err, status);   // status < 0: row skipped (reported by the kernel that produced it)
     }
+    if constexpr (RowOf<F>::prefetch) { const int sn = si + 4 * LB; if (lane < LB && sn < m1) nxt = fam.load(sn); }   // next batch's rows: in flight during this batch's assembly
     int xpos[NX > 0 ? NX : 1];
     if constexpr (NX > 0) {   // ordering positions of this block's cross columns: independent loads, issued together
 #pragma unroll
@@ -612,6 +642,7 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
       }
     }
     if (!want_ne) continue;
+    KT(1)
     unsigned long long rem = __ballot(valid);
     while (rem) {                                            // one window per iteration (wave-uniform control flow)
       const int l0 = __ffsll((long long)rem) - 1;
@@ -664,6 +695,7 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        KT(2)
         const int cnt = min(GL, lhi + 1 - gs);
         const int nks = (cnt * NR + 3) >> 2;
         for (int ks = 0; ks < nks; ++ks) {
@@ -703,6 +735,7 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        KT(3)
       }
       // window accumulators -> workgroup accumulators (LDS atomics; other waves work on overlapping windows)
       const int plm = F::LMCOL >= 0 ? cm.ord[6 * cm.N + 22 + ww] : LVX_DEAD;   // the window's landmark column
@@ -738,6 +771,7 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
               }
             }
           }
+      KT(4)
     }
   }
   if (!F::SECONDARY) {
@@ -745,7 +779,9 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
     if (lane == 0) atomicAdd(&cm.cost[rep], mycost);
   }
   if (!want_ne) return;
+  KT(5)
   __syncthreads();
+  KT(6)
   // flush the workgroup's accumulators: ONE global atomic per touched entry
   for (int e = tid; e < ACC_LV * ACC_BW; e += 256) {
     const double v = acc_band[e];
@@ -772,6 +808,12 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
   }
   for (int e = tid; e < ACC_LV; e += 256) { const double v = acc_gk[e]; if (v != 0.0 && kpos[e] != LVX_DEAD) add_g(cm, kpos[e], v, rep); }
   if (tid < NG) { const double v = acc_gG[tid]; if (v != 0.0 && gpos[tid] != LVX_DEAD) add_g(cm, gpos[tid], v, rep); }
+#ifdef LVX_KTIME
+  KT(7)
+  if (F::HUB == 0 && lane == 0 && blockIdx.x % 311 == 5)
+    printf("KT wg %d wv %d rows %d CR %d: init %lld eval %lld [seg %lld lookup %lld value %lld chain %lld pull %lld] panel %lld mfma %lld wflush %lld tail %lld sync %lld flush %lld total %lld\n", (int)blockIdx.x, wv, m1 - m0, CR,
+           kt_[0], kt_[1], kt_[8], kt_[9], kt_[10], kt_[11], kt_[12], kt_[2], kt_[3], kt_[4], kt_[5], kt_[6], kt_[7], (long long)__builtin_amdgcn_s_memtime() - kts_);
+#endif
 }
 
 // fold the pseudo-pose rows of the border back onto the hub control points: x_pseudo = M_hub x_hub  =>
@@ -963,6 +1005,11 @@ int ensure_layout(lvx_ctx* ctx) {
     if ((rc = upload(ctx, f.d_a3, pt.data(), pt.size() * 8))) return rc;
     if ((rc = upload(ctx, f.d_id0, pl.data(), pl.size() * 4))) return rc;
     if ((rc = upload(ctx, f.d_perm, perm.data(), perm.size() * 4))) return rc;
+    // the fused kernel reads each row's plane from a row-ordered copy (planes are inputs, fixed between layouts): no dependent gather
+    std::vector<double> rowpl((size_t)f.n * 3, 0.0);
+    const long long npl = (long long)ctx->planes.size() / 3;
+    for (int i = 0; i < f.n; ++i) if (pl[i] >= 0 && pl[i] < npl) for (int c = 0; c < 3; ++c) rowpl[3 * (size_t)i + c] = ctx->planes[3 * (size_t)pl[i] + c];
+    if ((rc = upload(ctx, f.d_b3, rowpl.data(), rowpl.size() * 8))) return rc;
   }
   {
     Family& f = ctx->rep;
@@ -1268,8 +1315,8 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
                              (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
             hipLaunchKernelGGL((k_family<SurfFamT<true>, 1>), grid(s.n), dim3(64), 0, s_surf, s, cm, (const uint16_t*)ctx->d_pairs[3].p, (long long)ctx->fam_row0[3]);
           } else if (fast_surf) {
-            SurfAcc s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
-                      (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
+            SurfAcc s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const double*)ctx->surf.d_b3.p, (const int*)ctx->surf.d_perm.p,
+                      ctx->t_map, ctx->surf.weight, ctx->surf.huber};
             LVX_LAUNCH_MFMA(SurfAcc, s, LVX_FAM_SURFEL, s_surf, ctx->fam_row0[3]);
           } else {
             SurfFam s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,

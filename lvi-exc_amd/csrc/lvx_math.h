@@ -158,6 +158,18 @@ LVX_HD quat expq_half(v3 v) {
 // ---------------------------------------------------------------------------------------------
 struct KnotRef { int i0; double u; };   // master index of the first of the four control points; interpolation amount
 
+// x / dt for the knot lookups, whose floor() classifies a measurement into its knot interval and must agree with the division's.
+// q = x * (1/dt) is within 2 ulp of the exact quotient, so floor(q) = floor(RN(x/dt)) unless q lies that close to an integer; only those
+// lanes divide (FP64 division is a ~12-instruction dependent chain; 1/dt is wave-uniform and hoisted).  The interpolation amount
+// u = q - floor(q) may differ from the divided one in its last bit — deterministic, and the same function serves every kernel.
+LVX_HD double quot_dt(double x, double dt) {
+  const double inv = 1.0 / dt;
+  double q = x * inv;
+  const double n = rint(q);
+  if (fabs(q - n) <= 1e-9 * fmax(1.0, fabs(q))) q = x / dt;
+  return q;
+}
+
 LVX_HD bool knot_lookup_seg(double t0_seg, double dt, int n_seg, int i1, double t, KnotRef* out) {
   const double tmin = t0_seg, tmax = t0_seg + (double)(n_seg - 3) * dt;
   double te = t;
@@ -165,7 +177,7 @@ LVX_HD bool knot_lookup_seg(double t0_seg, double dt, int n_seg, int i1, double 
     te = t - 0.00001;
     if (!((te >= tmin) && (te < tmax))) return false;
   }
-  const double s = (te - t0_seg) / dt;
+  const double s = quot_dt(te - t0_seg, dt);
   const int il = (int)floor(s);
   if ((n_seg < 4) || (il < 0) || (il > (n_seg - 4))) return false;
   out->i0 = i1 + il;
@@ -176,7 +188,7 @@ LVX_HD bool knot_lookup_seg(double t0_seg, double dt, int n_seg, int i1, double 
 LVX_HD bool knot_lookup(double t0, double dt, int n_knots, double t_span, double t_eval, KnotRef* out) {
   const double tmax_master = t0 + (double)(n_knots - 3) * dt;
   if (n_knots < 4 || t_span < t0 || t_span >= tmax_master) return false;   // CheckTimeSpans, trajectory_estimator.h:102-127
-  const int i1 = (int)floor((t_span - t0) / dt);
+  const int i1 = (int)floor(quot_dt(t_span - t0, dt));
   return knot_lookup_seg(t0 + dt * (double)i1, dt, 4, i1, t_eval, out);
 }
 
@@ -303,6 +315,7 @@ LVX_HD bool so3_eval(const quat c[4], double u, double dt, So3Eval* out) {
 //   c1 = (1 - cos theta)/theta^2 = sinc(a)^2 / 2,   c2 = (theta - sin theta)/theta^3 = (1 - sinc(a) cos a) / (4 a^2)   (double-angle forms)
 // Same series switches as so3_Jr / expq_half; results agree with so3_eval to rounding (tests/test_host_math.py).
 // ---------------------------------------------------------------------------------------------
+constexpr double SO3_SMALL_A = 0.8;   // largest |Omega| served by the small-angle polynomials (so3_small_coeffs)
 struct So3Pre { v3 Om; double on; m3 Jri; double c3; int ok; };   // Omega, |Omega|, J_r^-1(2 Omega) and its coefficient c3 (J_r^-1 = I + K/2 + c3 K^2), unit-norm check of logq
 LVX_HD void so3_pre(quat ca, quat cb, So3Pre* o) {
   bool ok = true;
@@ -312,7 +325,7 @@ LVX_HD void so3_pre(quat ca, quat cb, So3Pre* o) {
   { const double t2 = 4.0 * o->on * o->on;   // same switch as so3_Jr_inv
     if (t2 < 2.5e-3) o->c3 = 1.0 / 12.0 + t2 * (1.0 / 720.0 + t2 * (1.0 / 30240.0 + t2 / 1209600.0));
     else { const double th = sqrt(t2), h = 0.5 * th; o->c3 = 1.0 / t2 - cos(h) / (2.0 * th * sin(h)); } }
-  o->ok = ok ? 1 : 0;
+  o->ok = ok ? (o->on <= SO3_SMALL_A ? 1 : 2) : 0;   // 2: valid, but beyond the small-angle polynomials of so3_value_pre
 }
 template <bool NEED_W, bool NEED_J, bool NEED_DW = (NEED_W && NEED_J)>
 LVX_HD bool so3_eval_pre(const quat c[4], const So3Pre* pre, double u, double dt, So3Eval* out) {
@@ -407,36 +420,45 @@ LVX_HD bool so3_eval_pre(const quat c[4], const So3Pre* pre, double u, double dt
 //   J_r(phi)^T v = v + c1 phi x v + c2 phi x (phi x v),   J_r^-1(d) v = v + d x v / 2 + c3 d x (d x v),   (J_r^-1)^T v = v - d x v / 2 + c3 d x (d x v).
 // 16 matrix-vector-sized operations instead of ~14 3x3 matrix products, and no 3x3 matrix is kept in registers.
 // ---------------------------------------------------------------------------------------------
+// The factor angles a = B_j |Omega_j| <= |Omega_j| are small (Omega_j is the half-angle vector between neighbouring control points), so
+// Taylor polynomials in a^2 give sin(a)/a, cos(a) and c2 = (theta - sin theta)/theta^3 (theta = 2a) to double precision for |a| <= 0.8
+// (first dropped terms: 1.5e-19, 3e-21, 8e-22) — no range reduction, no division, no series / closed-form switch.  Pairs with
+// |Omega| > SO3_SMALL_A are marked in the table (So3Pre::ok == 2) and their rows take the exact fallback kernel.
+LVX_HD void so3_small_coeffs(double a2, double* kv, double* ka, double* c2) {
+  *kv = 1.0 + a2 * (-1.0 / 6.0 + a2 * (1.0 / 120.0 + a2 * (-1.0 / 5040.0 + a2 * (1.0 / 362880.0 + a2 * (-1.0 / 39916800.0 + a2 * (1.0 / 6227020800.0 +
+        a2 * (-1.0 / 1307674368000.0 + a2 * (1.0 / 355687428096000.0))))))));
+  *ka = 1.0 + a2 * (-0.5 + a2 * (1.0 / 24.0 + a2 * (-1.0 / 720.0 + a2 * (1.0 / 40320.0 + a2 * (-1.0 / 3628800.0 + a2 * (1.0 / 479001600.0 +
+        a2 * (-1.0 / 87178291200.0 + a2 * (1.0 / 20922789888000.0 + a2 * (-1.0 / 6402373705728000.0)))))))));
+  const double t2 = 4.0 * a2;
+  *c2 = 1.0 / 6.0 + t2 * (-1.0 / 120.0 + t2 * (1.0 / 5040.0 + t2 * (-1.0 / 362880.0 + t2 * (1.0 / 39916800.0 + t2 * (-1.0 / 6227020800.0 +
+        t2 * (1.0 / 1307674368000.0 + t2 * (-1.0 / 355687428096000.0 + t2 * (1.0 / 121645100408832000.0 + t2 * (-1.0 / 51090942171709440000.0)))))))));
+}
 struct So3Val { quat q; quat E[4]; v3 phi[4]; double c1[4], c2[4]; };   // value, factors E_j, phi_j = B_j d_j and the J_r coefficients (j = 1..3)
-LVX_HD bool so3_value_pre(const quat c[4], const So3Pre* pre, double u, So3Val* o) {
+// returns 0, or 1 when a control-point pair failed logq's unit-norm check, or 2 when a pair's angle is beyond the small-angle polynomials
+LVX_HD int so3_value_pre(const quat c[4], const So3Pre* pre, double u, So3Val* o) {
   const double u2 = u * u, u3 = u2 * u;
   double B[4];
   B[1] = 5.0 / 6.0 + u * (3.0 / 6.0) + u2 * (-3.0 / 6.0) + u3 * (1.0 / 6.0);
   B[2] = 1.0 / 6.0 + u * (3.0 / 6.0) + u2 * (3.0 / 6.0) + u3 * (-2.0 / 6.0);
   B[3] = u3 * (1.0 / 6.0);
-  bool ok = true;
+  int bad = 0;
   quat q = c[0];
 #pragma unroll
   for (int j = 1; j < 4; ++j) {
     const So3Pre& pj = pre[j - 1];
-    ok = ok && pj.ok != 0;
+    bad |= pj.ok == 1 ? 0 : (pj.ok == 0 ? 1 : 2);
     const v3 v = B[j] * pj.Om;
     const double a = B[j] * pj.on, a2 = a * a;
-    double ka, kv;
-    if (a2 > 1e-16) { ka = cos(a); kv = sin(a) / a; } else { ka = 1.0; kv = 1.0; }
+    double ka, kv, c2;
+    so3_small_coeffs(a2, &kv, &ka, &c2);
     o->E[j] = mkq(ka, kv * v.x, kv * v.y, kv * v.z);
     q = qmul(q, o->E[j]);
-    const double t2 = 4.0 * a2;
-    if (t2 < 2.5e-3) {
-      o->c1[j] = 0.5 - t2 * (1.0 / 24.0 - t2 * (1.0 / 720.0 - t2 / 40320.0));
-      o->c2[j] = 1.0 / 6.0 - t2 * (1.0 / 120.0 - t2 * (1.0 / 5040.0 - t2 / 362880.0));
-    } else { o->c1[j] = 0.5 * kv * kv; o->c2[j] = (1.0 - kv * ka) / t2; }
     o->phi[j] = (2.0 * B[j]) * pj.Om;
-    o->c1[j] *= B[j]; o->c2[j] *= B[j];       // P_j = B_j J_r(phi_j); the leading B_j is applied to v separately below
+    o->c1[j] = B[j] * (0.5 * kv * kv); o->c2[j] = B[j] * c2;       // P_j = B_j J_r(phi_j) = B_j (I - c1 K + c2 K^2), c1 = (1 - cos theta)/theta^2 = sinc(a)^2 / 2
   }
   o->phi[0] = mk(B[1], B[2], B[3]);           // slot 0 carries the cumulative basis values
   o->q = q;
-  return ok;
+  return bad;
 }
 // y[k] = dxi[k]^T g for the four control points
 LVX_HD void so3_pullback_pre(const quat c[4], const So3Pre* pre, const So3Val& s, v3 g, v3 y[4]) {

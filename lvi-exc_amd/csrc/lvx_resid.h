@@ -49,8 +49,8 @@ LVX_HD bool build_segments(const SplineRef& sp, const double spans[][2], int nsp
     if (t1 > t2) return false;
     if (k > 0 && t1 < t1_prev) return false;
     t1_prev = t1;
-    int i1 = (int)floor((t1 - sp.t0) / sp.dt);
-    const int i2 = (int)floor((t2 - sp.t0) / sp.dt);
+    int i1 = (int)floor(quot_dt(t1 - sp.t0, sp.dt));
+    const int i2 = (int)floor(quot_dt(t2 - sp.t0, sp.dt));
     if (i1 > cur_end) {
       s->i1[s->nseg] = i1; s->n[s->nseg] = 0; s->nseg += 1;
       cur_start = i1;
@@ -71,7 +71,7 @@ LVX_HD bool seg_lookup(const SplineRef& sp, const Segs& s, double t, KnotRef* ou
     bool in = (te >= t0s) && (te < tmax);
     if (!in) { te = t - 0.00001; in = (te >= t0s) && (te < tmax); }
     if (in) {
-      const double sc = (te - t0s) / sp.dt;
+      const double sc = quot_dt(te - t0s, sp.dt);
       const int il = (int)floor(sc);
       if ((s.n[k] < 4) || (il < 0) || (il > (s.n[k] - 4))) return false;
       out->i0 = s.i1[k] + il;
@@ -115,7 +115,13 @@ LVX_HD bool pose_eval(const SplineRef& sp, const KnotRef& k, PoseEval* out, cons
 }
 // window of precomputed control-point-pair quantities handed to the residuals of the fused kernels: entry e belongs to the pair
 // (k0 + e, k0 + e + 1); a row whose knot interval falls outside is reported as RES_OUTSIDE (the kernel then takes the exact fallback)
+#ifdef LVX_KTIME
+struct PreWin { const So3Pre* p; int k0, n; long long* kt; };
+#define LVX_KT(pw, i) { const long long n_ = __builtin_amdgcn_s_memtime(); (pw)->kt[i] += n_ - (pw)->kt[15]; (pw)->kt[15] = n_; }
+#else
 struct PreWin { const So3Pre* p; int k0, n; };
+#define LVX_KT(pw, i)
+#endif
 enum { RES_OUTSIDE = 16 };   // = LVX_ERR_FALLBACK
 LVX_HD const So3Pre* pre_at(const PreWin& w, int i0) { return (i0 >= w.k0 && i0 + 2 < w.k0 + w.n) ? w.p + (i0 - w.k0) : nullptr; }
 
@@ -289,7 +295,7 @@ LVX_HD int surfel_residual(const SplineRef& sp, const PoseEval& hub, const Segs&
 enum { SURFP_NC = 36 };
 // pose value + what the reverse-mode knot gradients need (no 3x3 Jacobian blocks): used by the single-row residuals of the fused kernels
 struct PoseVal { v3 p; double Bp[4]; quat c[4]; So3Val s; };
-LVX_HD bool pose_value_pre(const SplineRef& sp, const KnotRef& k, const So3Pre* pre, PoseVal* out) {
+LVX_HD int pose_value_pre(const SplineRef& sp, const KnotRef& k, const So3Pre* pre, PoseVal* out) {   // 0 | 1 non-unit | 2 large angle (so3_value_pre)
   R3Basis b; r3_basis(k.u, sp.dt, &b);
   v3 p = mk(0, 0, 0);
 #pragma unroll
@@ -319,14 +325,18 @@ LVX_HD int surfel_residual_pseudo(const SplineRef& sp, const PoseEval& hub, cons
   PoseVal kv;
   const So3Pre* pre = PRE ? pre_at(*pw, kr.i0) : nullptr;
   if (PRE && !pre) return RES_OUTSIDE;
-  if (PRE) { if (!pose_value_pre(sp, kr, pre, &kv)) return RES_NONUNIT; k.p = kv.p; k.so3.q = kv.s.q; }
+  LVX_KT(pw, 9)
+  if (PRE) { const int bad = pose_value_pre(sp, kr, pre, &kv); if (bad) return (bad & 1) ? RES_NONUNIT : RES_OUTSIDE; k.p = kv.p; k.so3.q = kv.s.q; }
   else if (!pose_eval<true, false, false>(sp, kr, &k)) return RES_NONUNIT;
+  LVX_KT(pw, 10)
   const v3 pLr = qrot(lidar.q, p_L);
   const v3 p_I = pLr + lidar.p;
   PlaneChain pc; plane_chain(hub, k, lidar, p_I, Pi, &pc);
   r[0] = weight * pc.r_unweighted;
   const PlaneGrads g = plane_grads(hub, pc, p_I, weight);
+  LVX_KT(pw, 11)
   if (PRE) pose_pull_to_knots(kv, pre, g.gp, g.gxk, &J[0][0]); else pose_to_knots(k, g.gp, g.gxk, &J[0][0]);
+  LVX_KT(pw, 12)
   J[0][24] = -g.gp.x; J[0][25] = -g.gp.y; J[0][26] = -g.gp.z; J[0][27] = g.gx0.x; J[0][28] = g.gx0.y; J[0][29] = g.gx0.z;
   const v3 jq = (2.0 * weight) * (cross(pc.nL, pc.x) - cross(pc.m, pLr));
   const v3 jp = weight * (pc.m - pc.nL);
@@ -519,7 +529,7 @@ LVX_HD int camsurf_residual_pseudo(const SplineRef& sp, const PoseEval& hub, con
   PoseVal kv;
   const So3Pre* pre = PRE ? pre_at(*pw, kr.i0) : nullptr;
   if (PRE && !pre) return RES_OUTSIDE;
-  if (PRE) { if (!pose_value_pre(sp, kr, pre, &kv)) return RES_NONUNIT; k.p = kv.p; k.so3.q = kv.s.q; }
+  if (PRE) { const int bad = pose_value_pre(sp, kr, pre, &kv); if (bad) return (bad & 1) ? RES_NONUNIT : RES_OUTSIDE; k.p = kv.p; k.so3.q = kv.s.q; }
   else if (!pose_eval<true, false, false>(sp, kr, &k)) return RES_NONUNIT;
   const double s = 1.0 / (rho + 1e-8);
   const v3 yu = cam_unproject(ci, u_ref, v_ref);

@@ -158,7 +158,9 @@ extern "C" int hc_so3_pull_diff(const double* cps, double u, double dt, const do
   So3Eval a;
   const bool oka = so3_eval<false, true>(c, u, dt, &a);
   So3Val s;
-  const bool okb = so3_value_pre(c, pre, u, &s);
+  const int bad = so3_value_pre(c, pre, u, &s);   // 0 | 1 non-unit | 2 angle beyond the small-angle polynomials
+  if (bad & 2) return 2;
+  const bool okb = bad == 0;
   v3 y[4];
   const v3 g = mk(g3[0], g3[1], g3[2]);
   so3_pullback_pre(c, pre, s, g, y);

@@ -98,12 +98,17 @@ def test_so3_reverse_mode_pullback_matches_forward_jacobian(host_check_lib, spre
     rng = np.random.default_rng(12)
     out = np.zeros(2)
     worst = np.zeros(2)
+    n_large = 0
     for _ in range(200):
         base = synth.q_from_rotvec(rng.standard_normal(3))
         cps = np.stack([synth.qmul(synth.q_from_rotvec(spread * rng.standard_normal(3)), base) for _ in range(4)])
         cps /= np.linalg.norm(cps, axis=1, keepdims=True)
         g = rng.standard_normal(3)
         rc = host_check_lib.hc_so3_pull_diff(cps.ctypes.data_as(C.c_void_p), C.c_double(rng.uniform(0, 1)), C.c_double(0.02), g.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
-        assert rc == 0
-        worst = np.maximum(worst, out)
+        # rc 2: a control-point pair beyond the small-angle polynomials (|Omega| > 0.8 rad half-angle) — such rows take the exact kernel
+        assert rc == 0 or (rc == 2 and spread >= 0.5)
+        n_large += rc == 2
+        if rc == 0:
+            worst = np.maximum(worst, out)
     assert worst[0] <= 1e-14 and worst[1] <= 5e-12
+    assert n_large < 200 and (spread < 2.0 or n_large > 0)
