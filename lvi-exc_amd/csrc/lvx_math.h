@@ -327,8 +327,22 @@ LVX_HD void so3_pre(quat ca, quat cb, So3Pre* o) {
     else { const double th = sqrt(t2), h = 0.5 * th; o->c3 = 1.0 / t2 - cos(h) / (2.0 * th * sin(h)); } }
   o->ok = ok ? (o->on <= SO3_SMALL_A ? 1 : 2) : 0;   // 2: valid, but beyond the small-angle polynomials of so3_value_pre
 }
+// The factor angles a = B_j |Omega_j| <= |Omega_j| are small (Omega_j is the half-angle vector between neighbouring control points), so
+// Taylor polynomials in a^2 give sin(a)/a, cos(a) and c2 = (theta - sin theta)/theta^3 (theta = 2a) to double precision for |a| <= 0.8
+// (first dropped terms: 1.5e-19, 3e-21, 8e-22) — no range reduction, no division, no series / closed-form switch.  Pairs with
+// |Omega| > SO3_SMALL_A are marked in the table (So3Pre::ok == 2) and their rows take the exact fallback kernel.
+LVX_HD void so3_small_coeffs(double a2, double* kv, double* ka, double* c2) {
+  *kv = 1.0 + a2 * (-1.0 / 6.0 + a2 * (1.0 / 120.0 + a2 * (-1.0 / 5040.0 + a2 * (1.0 / 362880.0 + a2 * (-1.0 / 39916800.0 + a2 * (1.0 / 6227020800.0 +
+        a2 * (-1.0 / 1307674368000.0 + a2 * (1.0 / 355687428096000.0))))))));
+  *ka = 1.0 + a2 * (-0.5 + a2 * (1.0 / 24.0 + a2 * (-1.0 / 720.0 + a2 * (1.0 / 40320.0 + a2 * (-1.0 / 3628800.0 + a2 * (1.0 / 479001600.0 +
+        a2 * (-1.0 / 87178291200.0 + a2 * (1.0 / 20922789888000.0 + a2 * (-1.0 / 6402373705728000.0)))))))));
+  const double t2 = 4.0 * a2;
+  *c2 = 1.0 / 6.0 + t2 * (-1.0 / 120.0 + t2 * (1.0 / 5040.0 + t2 * (-1.0 / 362880.0 + t2 * (1.0 / 39916800.0 + t2 * (-1.0 / 6227020800.0 +
+        t2 * (1.0 / 1307674368000.0 + t2 * (-1.0 / 355687428096000.0 + t2 * (1.0 / 121645100408832000.0 + t2 * (-1.0 / 51090942171709440000.0)))))))));
+}
+// returns 0, or 1 (a pair failed logq's unit-norm check), or 2 (a pair's angle is beyond the small-angle polynomials: exact fallback)
 template <bool NEED_W, bool NEED_J, bool NEED_DW = (NEED_W && NEED_J)>
-LVX_HD bool so3_eval_pre(const quat c[4], const So3Pre* pre, double u, double dt, So3Eval* out) {
+LVX_HD int so3_eval_pre(const quat c[4], const So3Pre* pre, double u, double dt, So3Eval* out) {
   const double u2 = u * u, u3 = u2 * u;
   double B[4], dB[4];
   B[1] = 5.0 / 6.0 + u * (3.0 / 6.0) + u2 * (-3.0 / 6.0) + u3 * (1.0 / 6.0);
@@ -341,7 +355,7 @@ LVX_HD bool so3_eval_pre(const quat c[4], const So3Pre* pre, double u, double dt
     dB[2] = U1 * (3.0 / 6.0) + U2 * (3.0 / 6.0) + U3 * (-2.0 / 6.0);
     dB[3] = U3 * (1.0 / 6.0);
   }
-  bool ok = true;
+  int bad = 0;
   v3 d[4];
   quat E[4];
   m3 P[4];
@@ -349,30 +363,22 @@ LVX_HD bool so3_eval_pre(const quat c[4], const So3Pre* pre, double u, double dt
 #pragma unroll
   for (int j = 1; j < 4; ++j) {
     const So3Pre& pj = pre[j - 1];
-    ok = ok && pj.ok != 0;
+    bad |= pj.ok == 1 ? 0 : (pj.ok == 0 ? 1 : 2);
     d[j] = 2.0 * pj.Om;
     const v3 v = B[j] * pj.Om;
     const double a = B[j] * pj.on, a2 = a * a;
-    double ka, kv;
-    if (a2 > 1e-16) { ka = cos(a); kv = sin(a) / a; } else { ka = 1.0; kv = 1.0; }   // expq_half's switch
+    double ka, kv, c2;
+    so3_small_coeffs(a2, &kv, &ka, &c2);
     E[j] = mkq(ka, kv * v.x, kv * v.y, kv * v.z);
     q = qmul(q, E[j]);
     if (NEED_J) {
-      const double t2 = 4.0 * a2;          // |B_j d_j|^2
-      double c1, c2;
-      if (t2 < 2.5e-3) {
-        c1 = 0.5 - t2 * (1.0 / 24.0 - t2 * (1.0 / 720.0 - t2 / 40320.0));
-        c2 = 1.0 / 6.0 - t2 * (1.0 / 120.0 - t2 * (1.0 / 5040.0 - t2 / 362880.0));
-      } else {
-        c1 = 0.5 * kv * kv;
-        c2 = (1.0 - kv * ka) / t2;
-      }
+      const double c1 = 0.5 * kv * kv;     // (1 - cos theta)/theta^2 with theta = 2 a
       const m3 K = skew(B[j] * d[j]);
       P[j] = B[j] * (m3_identity() - c1 * K + c2 * (K * K));
     }
   }
   out->q = q;
-  if (!NEED_W && !NEED_J) return ok;
+  if (!NEED_W && !NEED_J) return bad;
   const m3 R2 = rotmat(E[2]), R3 = rotmat(E[3]);
   v3 w1, w2r, w2, w3r;
   if (NEED_W) {
@@ -382,7 +388,7 @@ LVX_HD bool so3_eval_pre(const quat c[4], const So3Pre* pre, double u, double dt
     w3r = tmulv(R3, w2);
     out->w_body = w3r + dB[3] * d[3];
   }
-  if (!NEED_J) return ok;
+  if (!NEED_J) return bad;
   const m3 R1 = rotmat(E[1]);
   const m3 R3t = transpose(R3);
   const m3 R32t = tmul(R3, transpose(R2));
@@ -408,7 +414,7 @@ LVX_HD bool so3_eval_pre(const quat c[4], const So3Pre* pre, double u, double dt
     out->dxi[k] = 2.0 * mul_t(Xe[k], Rk);
     if (NEED_DW) out->dw[k] = 2.0 * mul_t(We[k], Rk);
   }
-  return ok;
+  return bad;
 }
 
 
@@ -420,19 +426,6 @@ LVX_HD bool so3_eval_pre(const quat c[4], const So3Pre* pre, double u, double dt
 //   J_r(phi)^T v = v + c1 phi x v + c2 phi x (phi x v),   J_r^-1(d) v = v + d x v / 2 + c3 d x (d x v),   (J_r^-1)^T v = v - d x v / 2 + c3 d x (d x v).
 // 16 matrix-vector-sized operations instead of ~14 3x3 matrix products, and no 3x3 matrix is kept in registers.
 // ---------------------------------------------------------------------------------------------
-// The factor angles a = B_j |Omega_j| <= |Omega_j| are small (Omega_j is the half-angle vector between neighbouring control points), so
-// Taylor polynomials in a^2 give sin(a)/a, cos(a) and c2 = (theta - sin theta)/theta^3 (theta = 2a) to double precision for |a| <= 0.8
-// (first dropped terms: 1.5e-19, 3e-21, 8e-22) — no range reduction, no division, no series / closed-form switch.  Pairs with
-// |Omega| > SO3_SMALL_A are marked in the table (So3Pre::ok == 2) and their rows take the exact fallback kernel.
-LVX_HD void so3_small_coeffs(double a2, double* kv, double* ka, double* c2) {
-  *kv = 1.0 + a2 * (-1.0 / 6.0 + a2 * (1.0 / 120.0 + a2 * (-1.0 / 5040.0 + a2 * (1.0 / 362880.0 + a2 * (-1.0 / 39916800.0 + a2 * (1.0 / 6227020800.0 +
-        a2 * (-1.0 / 1307674368000.0 + a2 * (1.0 / 355687428096000.0))))))));
-  *ka = 1.0 + a2 * (-0.5 + a2 * (1.0 / 24.0 + a2 * (-1.0 / 720.0 + a2 * (1.0 / 40320.0 + a2 * (-1.0 / 3628800.0 + a2 * (1.0 / 479001600.0 +
-        a2 * (-1.0 / 87178291200.0 + a2 * (1.0 / 20922789888000.0 + a2 * (-1.0 / 6402373705728000.0)))))))));
-  const double t2 = 4.0 * a2;
-  *c2 = 1.0 / 6.0 + t2 * (-1.0 / 120.0 + t2 * (1.0 / 5040.0 + t2 * (-1.0 / 362880.0 + t2 * (1.0 / 39916800.0 + t2 * (-1.0 / 6227020800.0 +
-        t2 * (1.0 / 1307674368000.0 + t2 * (-1.0 / 355687428096000.0 + t2 * (1.0 / 121645100408832000.0 + t2 * (-1.0 / 51090942171709440000.0)))))))));
-}
 struct So3Val { quat q; quat E[4]; v3 phi[4]; double c1[4], c2[4]; };   // value, factors E_j, phi_j = B_j d_j and the J_r coefficients (j = 1..3)
 // returns 0, or 1 when a control-point pair failed logq's unit-norm check, or 2 when a pair's angle is beyond the small-angle polynomials
 LVX_HD int so3_value_pre(const quat c[4], const So3Pre* pre, double u, So3Val* o) {

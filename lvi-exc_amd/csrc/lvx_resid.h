@@ -110,7 +110,7 @@ LVX_HD bool pose_eval(const SplineRef& sp, const KnotRef& k, PoseEval* out, cons
   out->p = p;
   if (NEED_V) out->v = v;
   quat c[4]; load_so3_cp(sp, k.i0, c);
-  if (PRE) return so3_eval_pre<NEED_V, NEED_J, false>(c, pre, k.u, sp.dt, &out->so3);   // pre: the entries of control-point pairs (i0, i0+1) .. (i0+2, i0+3)
+  if (PRE) return so3_eval_pre<NEED_V, NEED_J, false>(c, pre, k.u, sp.dt, &out->so3) == 0;   // pre: the entries of control-point pairs (i0, i0+1) .. (i0+2, i0+3)
   return so3_eval<NEED_V, NEED_J, false>(c, k.u, sp.dt, &out->so3);
 }
 // window of precomputed control-point-pair quantities handed to the residuals of the fused kernels: entry e belongs to the pair
@@ -144,7 +144,8 @@ LVX_HD int gyro_residual(const SplineRef& sp, const ImuCal& imu, double t, v3 w_
   if (PRE) {
     const So3Pre* pre = pre_at(*pw, k.i0);
     if (!pre) return RES_OUTSIDE;
-    if (!so3_eval_pre<true, NEED_J>(c, pre, k.u, sp.dt, &e)) return RES_NONUNIT;
+    const int bad = so3_eval_pre<true, NEED_J>(c, pre, k.u, sp.dt, &e);
+    if (bad) return (bad & 1) ? RES_NONUNIT : RES_OUTSIDE;
   } else if (!so3_eval<true, NEED_J>(c, k.u, sp.dt, &e)) return RES_NONUNIT;
   const v3 pred = e.w_body + imu.bg;
   r[0] = weight * (w_meas.x - pred.x); r[1] = weight * (w_meas.y - pred.y); r[2] = weight * (w_meas.z - pred.z);
@@ -177,7 +178,8 @@ LVX_HD int accel_residual(const SplineRef& sp, const ImuCal& imu, double t, v3 a
   if (PRE) {
     const So3Pre* pre = pre_at(*pw, k.i0);
     if (!pre) return RES_OUTSIDE;
-    if (!so3_eval_pre<false, NEED_J>(c, pre, k.u, sp.dt, &e)) return RES_NONUNIT;
+    const int bad = so3_eval_pre<false, NEED_J>(c, pre, k.u, sp.dt, &e);
+    if (bad) return (bad & 1) ? RES_NONUNIT : RES_OUTSIDE;
   } else if (!so3_eval<false, NEED_J>(c, k.u, sp.dt, &e)) return RES_NONUNIT;
   const double G = -9.79;   // imu.h:25
   const double cr = cos(imu.roll), sr = sin(imu.roll), cp = cos(imu.pitch), sp_ = sin(imu.pitch);

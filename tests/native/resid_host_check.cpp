@@ -139,7 +139,9 @@ extern "C" int hc_so3_pre_diff(const double* cps, double u, double dt, double* o
   for (int j = 0; j < 3; ++j) so3_pre(c[j], c[j + 1], &pre[j]);
   So3Eval a, b;
   const bool oka = so3_eval<true, true>(c, u, dt, &a);
-  const bool okb = so3_eval_pre<true, true>(c, pre, u, dt, &b);
+  const int bad = so3_eval_pre<true, true>(c, pre, u, dt, &b);   // 0 | 1 non-unit | 2 angle beyond the small-angle polynomials
+  if (bad & 2) return 2;
+  const bool okb = bad == 0;
   auto mx = [](double x, double y) { return x > y ? x : y; };
   out4[0] = mx(mx(std::fabs(a.q.x - b.q.x), std::fabs(a.q.y - b.q.y)), mx(std::fabs(a.q.z - b.q.z), std::fabs(a.q.w - b.q.w)));
   out4[1] = mx(mx(std::fabs(a.w_body.x - b.w_body.x), std::fabs(a.w_body.y - b.w_body.y)), std::fabs(a.w_body.z - b.w_body.z));

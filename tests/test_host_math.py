@@ -77,17 +77,22 @@ def test_so3_precomputed_pairs_match_direct_evaluation(host_check_lib, spread):
     rng = np.random.default_rng(11)
     out = np.zeros(4)
     worst = np.zeros(4)
+    n_large = 0
     for _ in range(200):
         base = synth.q_from_rotvec(rng.standard_normal(3))
         cps = np.stack([synth.qmul(synth.q_from_rotvec(spread * rng.standard_normal(3)), base) for _ in range(4)])
         cps /= np.linalg.norm(cps, axis=1, keepdims=True)
         u = rng.uniform(0, 1)
         rc = host_check_lib.hc_so3_pre_diff(cps.ctypes.data_as(C.c_void_p), C.c_double(u), C.c_double(0.02), out.ctypes.data_as(C.c_void_p))
-        assert rc == 0
-        worst = np.maximum(worst, out)
+        # rc 2: a control-point pair beyond the small-angle polynomials (|Omega| > 0.8 rad half-angle) — such rows take the exact kernel
+        assert rc == 0 or (rc == 2 and spread >= 0.5)
+        n_large += rc == 2
+        if rc == 0:
+            worst = np.maximum(worst, out)
     # q, dxi are O(1); w_body and dw carry 1/dt = 50
     assert worst[0] <= 1e-14 and worst[2] <= 2e-12
     assert worst[1] <= 1e-11 * max(1.0, spread / 0.02) and worst[3] <= 1e-9 * max(1.0, spread / 0.02)
+    assert (n_large < 200 or spread >= 2.0) and (spread < 2.0 or n_large > 0)
 
 
 @pytest.mark.parametrize("spread", [1e-9, 1e-3, 0.05, 0.9, 2.5])
@@ -111,4 +116,4 @@ def test_so3_reverse_mode_pullback_matches_forward_jacobian(host_check_lib, spre
         if rc == 0:
             worst = np.maximum(worst, out)
     assert worst[0] <= 1e-14 and worst[1] <= 5e-12
-    assert n_large < 200 and (spread < 2.0 or n_large > 0)
+    assert (n_large < 200 or spread >= 2.0) and (spread < 2.0 or n_large > 0)
