@@ -1290,11 +1290,17 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     // fast path: LDS-accumulating kernels for the segment-structured families; legacy per-segment kernels for reprojection, the prior,
     // the debug Jacobian, and as the exact fallback for the merged-hub-segment corner
     const bool fast = !ctx->force_legacy && !(what & LVX_EVAL_JACOBIAN) && !getenv("LVX_FORCE_LEGACY");
-    // fork: the independent family kernels run concurrently (each is latency / occupancy limited on its own)
-    LVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
-    for (int k = 0; k < 4; ++k) LVX_HIP(ctx, hipStreamWaitEvent(ctx->fam_stream[k], ctx->ev_fork, 0));
-    hipStream_t s_imu = ctx->fam_stream[0], s_acc = ctx->fam_stream[1], s_surf = ctx->fam_stream[2], s_rep = ctx->fam_stream[3];
+    // Streams.  A hand-over between streams costs 25-40 us inside the replayed graph (rocprofv3 timeline: clear -> hub, LiDAR -> second
+    // stage, last kernel -> fold each showed such a gap), so the critical chain  clear -> hub pose -> LiDAR kernels -> reprojection Jacobian
+    // -> observation pass -> fold  stays on the caller's stream and only the kernels that run NEXT to it (gyroscope, accelerometer,
+    // reference pass) fork off; they finish before the observation pass does, so the join is already satisfied when the chain gets there.
+    static const int sched = getenv("LVX_SCHED") ? atoi(getenv("LVX_SCHED")) : 2;
+    const bool staged = sched == 2 && !getenv("LVX_SERIAL");
+    hipStream_t s_imu = ctx->fam_stream[0], s_acc = ctx->fam_stream[1], s_surf = staged ? st : ctx->fam_stream[2], s_rep = staged ? st : ctx->fam_stream[3];
     if (getenv("LVX_SERIAL")) s_imu = s_acc = s_surf = s_rep = st;   // profiling aid: solo kernel durations
+    const hipStream_t side[4] = {s_imu, s_acc, s_surf, s_rep};
+    LVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
+    for (int k = 0; k < 4; ++k) if (side[k] != st) LVX_HIP(ctx, hipStreamWaitEvent(side[k], ctx->ev_fork, 0));
     // free time offsets need d pose / d t at both evaluations: those problems take the per-segment kernels (TAU variants)
     const bool tauL = !(ctx->locks & LVX_LOCK_LIDAR_TAU), tauC = !(ctx->locks & LVX_LOCK_CAM_TAU);
     const bool fast_surf = fast && !tauL && ctx->surf.n > 0, fast_cs = fast && !tauC && ctx->cs.n > 0;
@@ -1314,15 +1320,13 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     // reprojection passes next to each other.  Measured at config 4: the pass takes the same 1.55-1.6 ms with everything concurrent (the big
     // kernels cannot share a CU and only slow each other down), staged like this, or serial (1.64 ms); staged, the dominant kernel's
     // duration is its solo duration.  LVX_SCHED=0 restores "all concurrent".
-    static const int sched = getenv("LVX_SCHED") ? atoi(getenv("LVX_SCHED")) : 2;
-    const bool staged = sched == 2 && !getenv("LVX_SERIAL");
     static const bool jac_early = !getenv("LVX_JAC_LATE");   // the (small, register-bound) reprojection Jacobian kernel runs next to the LiDAR kernels: -2.5 % per pass, surfel kernel unaffected
     const int order[5] = {2, 4, 0, 1, 3};   // surfel, cam-surfel, imu, prior, reprojection
     for (int ph = 0; ph < 5; ++ph) {
       if (staged && ph == 2) {               // the other streams start when the LiDAR stream has drained
         LVX_HIP(ctx, hipEventRecord(ctx->ev_join[2], s_surf));
         LVX_HIP(ctx, hipStreamWaitEvent(s_imu, ctx->ev_join[2], 0)); LVX_HIP(ctx, hipStreamWaitEvent(s_acc, ctx->ev_join[2], 0));
-        if (!jac_early) LVX_HIP(ctx, hipStreamWaitEvent(s_rep, ctx->ev_join[2], 0));
+        if (!jac_early && s_rep != s_surf) LVX_HIP(ctx, hipStreamWaitEvent(s_rep, ctx->ev_join[2], 0));
       }
       switch (order[ph]) {
       case 0: {
@@ -1385,7 +1389,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
           } else if (fast && !getenv("LVX_REPROJ_LEGACY")) {
             double* Jb = (double*)ctx->d_repB[0].p; double* rb = Jb + (size_t)2 * REP_NC * r.n; int* kb = (int*)ctx->d_repB[1].p;
             hipLaunchKernelGGL(k_reproj_jac, grid(r.n), dim3(64), 0, s_rep, r, cm, Jb, rb, kb, (long long)ctx->fam_row0[4]);
-            if (staged && jac_early) LVX_HIP(ctx, hipStreamWaitEvent(s_rep, ctx->ev_join[2], 0));
+            if (staged && jac_early && s_rep != s_surf) LVX_HIP(ctx, hipStreamWaitEvent(s_rep, ctx->ev_join[2], 0));
             if (what & LVX_EVAL_NORMAL_EQ) {
               LVX_HIP(ctx, hipEventRecord(ctx->ev_jac, s_rep));
               const RepJac jac{Jb, rb, kb, r.n};
@@ -1420,7 +1424,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
       } break;
       }
     }
-    for (int k = 0; k < 4; ++k) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[k], ctx->fam_stream[k])); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[k], 0)); }
+    for (int k = 0; k < 4; ++k) if (side[k] != st) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[k], side[k])); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[k], 0)); }
     { ProfScope ps(ctx, LVX_KERNEL_FOLD);
     const bool fold_fast = (what & LVX_EVAL_NORMAL_EQ) && (fast_surf || fast_cs);
     if (fold_fast && !getenv("LVX_SERIAL")) LVX_HIP(ctx, hipEventRecord(ctx->ev_jac, st));   // st has joined every family stream here
