@@ -1274,6 +1274,16 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
   // Jacobian always do.
   auto enqueue = [&]() -> int {
     int rc = LVX_OK;
+    const bool fast = !ctx->force_legacy && !(what & LVX_EVAL_JACOBIAN) && !getenv("LVX_FORCE_LEGACY");
+    // free time offsets need d pose / d t at both evaluations: those problems take the per-segment kernels (TAU variants)
+    const bool tauL = !(ctx->locks & LVX_LOCK_LIDAR_TAU), tauC = !(ctx->locks & LVX_LOCK_CAM_TAU);
+    const bool fast_surf = fast && !tauL && ctx->surf.n > 0, fast_cs = fast && !tauC && ctx->cs.n > 0;
+    if (fast_surf || fast_cs) {   // the shared t_map pose (one thread, ~25 us) depends on the state only: next to the clear, not behind it
+      hipStream_t s_hub = getenv("LVX_SERIAL") ? st : ctx->fam_stream[0];
+      if (s_hub != st) { LVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st)); LVX_HIP(ctx, hipStreamWaitEvent(s_hub, ctx->ev_fork, 0)); }
+      hipLaunchKernelGGL(k_hub_eval, dim3(1), dim3(64), 0, s_hub, cm, ctx->t_map, fast_surf ? 1 : 0, fast_cs ? 1 : 0, (HubShared*)ctx->d_hubs.p);
+      if (s_hub != st) LVX_HIP(ctx, hipEventRecord(ctx->ev_join[3], s_hub));
+    }
     {   // one launch clears every accumulator of the pass (cost, error flags, and for the normal equations band, gradient, border rows, dense border)
       ClearList cl{};
       auto add = [&](void* p, size_t bytes) { cl.p[cl.n] = (uint4*)p; cl.words[cl.n] = (bytes + 15) / 16; cl.n++; };
@@ -1286,10 +1296,10 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
       const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
       hipLaunchKernelGGL(k_clear, dim3(blocks), dim3(256), 0, st, cl);
     }
+    if ((fast_surf || fast_cs) && !getenv("LVX_SERIAL")) LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[3], 0));
     auto grid = [](int n) { return dim3((unsigned)((n + 63) / 64)); };
     // fast path: LDS-accumulating kernels for the segment-structured families; legacy per-segment kernels for reprojection, the prior,
     // the debug Jacobian, and as the exact fallback for the merged-hub-segment corner
-    const bool fast = !ctx->force_legacy && !(what & LVX_EVAL_JACOBIAN) && !getenv("LVX_FORCE_LEGACY");
     // Streams.  A hand-over between streams costs 25-40 us inside the replayed graph (rocprofv3 timeline: clear -> hub, LiDAR -> second
     // stage, last kernel -> fold each showed such a gap), so the critical chain  clear -> hub pose -> LiDAR kernels -> reprojection Jacobian
     // -> observation pass -> fold  stays on the caller's stream and only the kernels that run NEXT to it (gyroscope, accelerometer,
@@ -1301,11 +1311,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     const hipStream_t side[4] = {s_imu, s_acc, s_surf, s_rep};
     LVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
     for (int k = 0; k < 4; ++k) if (side[k] != st) LVX_HIP(ctx, hipStreamWaitEvent(side[k], ctx->ev_fork, 0));
-    // free time offsets need d pose / d t at both evaluations: those problems take the per-segment kernels (TAU variants)
-    const bool tauL = !(ctx->locks & LVX_LOCK_LIDAR_TAU), tauC = !(ctx->locks & LVX_LOCK_CAM_TAU);
-    const bool fast_surf = fast && !tauL && ctx->surf.n > 0, fast_cs = fast && !tauC && ctx->cs.n > 0;
-    if (fast_surf || fast_cs)   // only the surfel / cam-surfel stream waits for the shared t_map pose
-      hipLaunchKernelGGL(k_hub_eval, dim3(1), dim3(64), 0, s_surf, cm, ctx->t_map, fast_surf ? 1 : 0, fast_cs ? 1 : 0, (HubShared*)ctx->d_hubs.p);
+    if ((fast_surf || fast_cs) && s_surf != st && !getenv("LVX_SERIAL")) LVX_HIP(ctx, hipStreamWaitEvent(s_surf, ctx->ev_join[3], 0));   // only the LiDAR stream needs the t_map pose
     static const int occ_env = getenv("LVX_OCC") ? atoi(getenv("LVX_OCC")) : 0;   // 0: the family's own choice (F::OCC wavefronts per SIMD)
   #define LVX_LAUNCH_MFMA1(FT, OCCV, fam_obj, chunk_slot, stream, row0v)                                                                        \
     do {                                                                                                                                     \
