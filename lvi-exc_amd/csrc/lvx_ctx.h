@@ -29,6 +29,7 @@ struct DevCommon {
   int nb, bw, nbd;   // nbd: assembly border size (solve border + pseudo rows) = leading dimension of C
   int nbd_solve;
   const void* hubs;  // HubShared[2]: surfel (tau_L) and cam-surfel (tau_C) poses at t_map
+  const So3Pre* pre; // [N]: u-independent SO3 quantities of the control-point pairs (k, k+1), rebuilt from the state at the start of every pass (k_so3_pre_table)
   double* Hb;    // [nb][bw+1] lower band, column-major by column
   double* gb;    // [nb]
   double* Bd;    // [nbd][nb]
@@ -84,6 +85,7 @@ struct lvx_ctx {
   std::vector<int> ord;
   int nb = 0, bw = 0, nbd = 0, nbd_ext = 0, n_hub = 0, hub0 = 0;   // nbd: solve border (hub knots + 22 calib); nbd_ext = nbd + 12 pseudo rows
   bool force_legacy = false;   // set when the fast assembly kernels hit a case only the per-segment kernels handle exactly
+  lvx::DevBuf d_pre;   // So3Pre[N]
   lvx::DevBuf d_hubs, d_chunk[LVX_NUM_FAM], d_repB[4];   // reprojection MFMA path: [0] materialised Jacobians + residuals, [1] knot intervals, [2] landmark and [3] observation-order index of the rows in (reference interval, landmark) order
   int n_chunk[LVX_NUM_FAM] = {0}, chunk_r[LVX_NUM_FAM] = {0};   // workgroups and knot intervals per workgroup of the MFMA assembly kernels (pick_chunk)
   lvx::DevBuf d_ord, d_Hb, d_gb, d_Bd, d_C, d_gc, d_cost, d_err, d_state, d_res, d_jcols, d_jvals, d_pairs[LVX_NUM_FAM];

@@ -151,6 +151,13 @@ template <bool TAU> struct ReprojFamT {
     return reproj_residual<true, TAU>(sp, cm.cam, cal.cam, (cm.locks & LVX_LOCK_CAM_TAU) != 0, cm.sensor_mto, lm_uv[2 * l], lm_uv[2 * l + 1], lm_t0[l],
                                  uv[2 * (size_t)si], uv[2 * (size_t)si + 1], t0o[si], cal.rho[l], weight, &k.k0, &k.k1, r, J);
   }
+  // fused path only (k_reproj_jac): SO3 parts from the pass's control-point-pair table
+  __device__ int eval_pre(const DevCommon& cm, const SplineRef& sp, const Cal& cal, int si, double r[NR], double (*J)[NC], Keys& k) const {
+    const int l = lm[si];
+    k.lm = l;
+    return reproj_residual<true, TAU>(sp, cm.cam, cal.cam, (cm.locks & LVX_LOCK_CAM_TAU) != 0, cm.sensor_mto, lm_uv[2 * l], lm_uv[2 * l + 1], lm_t0[l],
+                                 uv[2 * (size_t)si], uv[2 * (size_t)si + 1], t0o[si], cal.rho[l], weight, &k.k0, &k.k1, r, J, cm.pre);
+  }
   __device__ int col(int c, const Keys& k, int N) const { return rep_col(c, k.k0, k.k1, N, k.lm); }
 };
 using ReprojFam = ReprojFamT<false>;
@@ -323,6 +330,17 @@ __global__ __launch_bounds__(64 * PW) void k_family(F fam, DevCommon cm, const u
 // The pose at t_map, common to every surfel / cam-surfel residual, enters through 6 pseudo variables (d p_0, xi_0):
 // J_hub = g0^T M_hub, folded back onto the hub control points by k_fold_border.
 // ---------------------------------------------------------------------------------------------------------
+// u-independent SO3 quantities of every control-point pair (k, k+1) — log, |Omega|, J_r^-1 — once per pass instead of once per workgroup
+// (the fused kernels copy their CR + 4 entries into LDS) and once per row (reprojection Jacobian kernel)
+__global__ __launch_bounds__(256) void k_so3_pre_table(DevCommon cm, So3Pre* tab) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cm.N) return;
+  const double* so3 = cm.state + 3 * (size_t)cm.N;
+  So3Pre e;
+  if (k + 1 < cm.N) so3_pre(load_q(so3 + 4 * (size_t)k), load_q(so3 + 4 * (size_t)(k + 1)), &e);
+  else { e.Om = mk(0, 0, 0); e.on = 0.0; e.Jri = m3_identity(); e.c3 = 1.0 / 12.0; e.ok = 1; }
+  tab[k] = e;
+}
 __global__ void k_hub_eval(DevCommon cm, double t_map, int want_surf, int want_cs, HubShared* hubs) {
   const int s = threadIdx.x;
   if (s > 1) return;
@@ -474,7 +492,7 @@ __global__ __launch_bounds__(64) void k_reproj_jac(ReprojFam fam, DevCommon cm, 
     HubShared none;
     double r[2], J[2][REP_NC];
     Keys key{-1, -1, -1};
-    const int status = fam.eval(cm, sp, cal, none, si, r, J, key);
+    const int status = fam.eval_pre(cm, sp, cal, si, r, J, key);
     if (status != RES_OK) { atomicOr(cm.err, status); kb[si] = -1; kb[n + si] = -1; }
     else {
       double scale;
@@ -598,10 +616,10 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
     }
   }
   const SplineRef sp{cm.t0, cm.dt, cm.N, cm.state, cm.state + 3 * (size_t)cm.N};
-  if (F::USE_PRE && tid < CR + 4) {
+  if (F::USE_PRE && tid < CR + 4) {   // this chunk's slice of the pass's control-point-pair table
     const int ka = k_lo + tid;
-    if (ka >= 0 && ka + 1 < cm.N) so3_pre(load_q(sp.so3 + 4 * (size_t)ka), load_q(sp.so3 + 4 * (size_t)(ka + 1)), &pre_tab[tid]);
-    else { pre_tab[tid].Om = mk(0, 0, 0); pre_tab[tid].on = 0.0; pre_tab[tid].Jri = m3_identity(); pre_tab[tid].ok = 1; }
+    if (ka >= 0 && ka + 1 < cm.N) pre_tab[tid] = cm.pre[ka];
+    else { pre_tab[tid].Om = mk(0, 0, 0); pre_tab[tid].on = 0.0; pre_tab[tid].Jri = m3_identity(); pre_tab[tid].c3 = 1.0 / 12.0; pre_tab[tid].ok = 1; }
   }
 #ifdef LVX_KTIME
   const PreWin pwin{pre_tab, k_lo, CR + 4, kt_};
@@ -1188,6 +1206,7 @@ int ensure_layout(lvx_ctx* ctx) {
   if ((rc = dev_alloc(ctx, ctx->d_C, (size_t)LVX_NREP * ctx->nbd_ext * ctx->nbd_ext * 8 + 16))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_gc, (size_t)LVX_NREP * ctx->nbd_ext * 8 + 16))) return rc;   // + 16 each: k_clear works in 16-byte words
   if ((rc = dev_alloc(ctx, ctx->d_hubs, 2 * sizeof(HubShared)))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_pre, (size_t)std::max(N, 1) * sizeof(So3Pre)))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_cost, LVX_NREP * 8))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_err, 16))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_state, (size_t)lvx_state_size(ctx) * 8))) return rc;
@@ -1218,7 +1237,7 @@ DevCommon make_common(lvx_ctx* ctx, const double* state_d, uint32_t what) {
   DevCommon cm{};
   cm.state = state_d; cm.N = ctx->N; cm.L = ctx->L; cm.t0 = ctx->t0; cm.dt = ctx->dt; cm.locks = ctx->locks; cm.what = what;
   cm.imu_mto = ctx->imu_mto; cm.sensor_mto = ctx->sensor_mto; cm.cam = ctx->cam;
-  cm.ord = (const int*)ctx->d_ord.p; cm.nb = ctx->nb; cm.bw = ctx->bw; cm.nbd = ctx->nbd_ext; cm.nbd_solve = ctx->nbd; cm.hubs = ctx->d_hubs.p;
+  cm.ord = (const int*)ctx->d_ord.p; cm.nb = ctx->nb; cm.bw = ctx->bw; cm.nbd = ctx->nbd_ext; cm.nbd_solve = ctx->nbd; cm.hubs = ctx->d_hubs.p; cm.pre = (const So3Pre*)ctx->d_pre.p;
   cm.Hb = (double*)ctx->d_Hb.p; cm.gb = (double*)ctx->d_gb.p; cm.Bd = (double*)ctx->d_Bd.p; cm.C = (double*)ctx->d_C.p; cm.gc = (double*)ctx->d_gc.p;
   cm.cost = (double*)ctx->d_cost.p; cm.err = (int*)ctx->d_err.p;
   cm.residuals = nullptr; cm.jcols = nullptr; cm.jvals = nullptr;
@@ -1278,10 +1297,12 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     // free time offsets need d pose / d t at both evaluations: those problems take the per-segment kernels (TAU variants)
     const bool tauL = !(ctx->locks & LVX_LOCK_LIDAR_TAU), tauC = !(ctx->locks & LVX_LOCK_CAM_TAU);
     const bool fast_surf = fast && !tauL && ctx->surf.n > 0, fast_cs = fast && !tauC && ctx->cs.n > 0;
-    if (fast_surf || fast_cs) {   // the shared t_map pose (one thread, ~25 us) depends on the state only: next to the clear, not behind it
+    if (fast) {   // the control-point-pair table and the shared t_map pose (one thread, ~25 us) depend on the state only: next to the clear, not behind it
       hipStream_t s_hub = getenv("LVX_SERIAL") ? st : ctx->fam_stream[0];
       if (s_hub != st) { LVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st)); LVX_HIP(ctx, hipStreamWaitEvent(s_hub, ctx->ev_fork, 0)); }
-      hipLaunchKernelGGL(k_hub_eval, dim3(1), dim3(64), 0, s_hub, cm, ctx->t_map, fast_surf ? 1 : 0, fast_cs ? 1 : 0, (HubShared*)ctx->d_hubs.p);
+      hipLaunchKernelGGL(k_so3_pre_table, dim3((unsigned)((ctx->N + 255) / 256)), dim3(256), 0, s_hub, cm, (So3Pre*)ctx->d_pre.p);
+      if (fast_surf || fast_cs)
+        hipLaunchKernelGGL(k_hub_eval, dim3(1), dim3(64), 0, s_hub, cm, ctx->t_map, fast_surf ? 1 : 0, fast_cs ? 1 : 0, (HubShared*)ctx->d_hubs.p);
       if (s_hub != st) LVX_HIP(ctx, hipEventRecord(ctx->ev_join[3], s_hub));
     }
     {   // one launch clears every accumulator of the pass (cost, error flags, and for the normal equations band, gradient, border rows, dense border)
@@ -1296,7 +1317,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
       const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
       hipLaunchKernelGGL(k_clear, dim3(blocks), dim3(256), 0, st, cl);
     }
-    if ((fast_surf || fast_cs) && !getenv("LVX_SERIAL")) LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[3], 0));
+    if (fast && !getenv("LVX_SERIAL")) LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[3], 0));
     auto grid = [](int n) { return dim3((unsigned)((n + 63) / 64)); };
     // fast path: LDS-accumulating kernels for the segment-structured families; legacy per-segment kernels for reprojection, the prior,
     // the debug Jacobian, and as the exact fallback for the merged-hub-segment corner
@@ -1311,7 +1332,6 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     const hipStream_t side[4] = {s_imu, s_acc, s_surf, s_rep};
     LVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
     for (int k = 0; k < 4; ++k) if (side[k] != st) LVX_HIP(ctx, hipStreamWaitEvent(side[k], ctx->ev_fork, 0));
-    if ((fast_surf || fast_cs) && s_surf != st && !getenv("LVX_SERIAL")) LVX_HIP(ctx, hipStreamWaitEvent(s_surf, ctx->ev_join[3], 0));   // only the LiDAR stream needs the t_map pose
     static const int occ_env = getenv("LVX_OCC") ? atoi(getenv("LVX_OCC")) : 0;   // 0: the family's own choice (F::OCC wavefronts per SIMD)
   #define LVX_LAUNCH_MFMA1(FT, OCCV, fam_obj, chunk_slot, stream, row0v)                                                                        \
     do {                                                                                                                                     \
@@ -1532,6 +1552,7 @@ void lvx_destroy(lvx_ctx* c) {
   for (auto& b : c->d_chunk) if (b.p) (void)hipFree(b.p);
   for (auto& b : c->d_repB) if (b.p) (void)hipFree(b.p);
   if (c->d_hubs.p) (void)hipFree(c->d_hubs.p);
+  if (c->d_pre.p) (void)hipFree(c->d_pre.p);
   for (DevBuf* b : {&c->vox.misc, &c->vox.keys, &c->vox.vals, &c->vox.runs, &c->vox.cells, &c->vox.tmp, &c->vox.leaf_i, &c->vox.leaf_d, &c->vox.leaf_f}) if (b->p) (void)hipFree(b->p);
   bcr_destroy(c);
   for (DevBuf* b : {&c->d_bcrD, &c->d_bcrG, &c->d_bcrInfo, &c->d_Y2, &c->d_gram}) if (b->p) (void)hipFree(b->p);

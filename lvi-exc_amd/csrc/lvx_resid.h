@@ -113,6 +113,18 @@ LVX_HD bool pose_eval(const SplineRef& sp, const KnotRef& k, PoseEval* out, cons
   if (PRE) return so3_eval_pre<NEED_V, NEED_J, false>(c, pre, k.u, sp.dt, &out->so3) == 0;   // pre: the entries of control-point pairs (i0, i0+1) .. (i0+2, i0+3)
   return so3_eval<NEED_V, NEED_J, false>(c, k.u, sp.dt, &out->so3);
 }
+// pose with the SO3 part from precomputed control-point pairs (pre[0..2] = pairs (i0, i0+1) .. (i0+2, i0+3)); returns so3_eval_pre's status
+template <bool NEED_J>
+LVX_HD int pose_eval_pre(const SplineRef& sp, const KnotRef& k, PoseEval* out, const So3Pre* pre) {
+  out->k = k;
+  R3Basis b; r3_basis(k.u, sp.dt, &b);
+  v3 p = mk(0, 0, 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { out->Bp[j] = b.Bp[j]; p = p + b.Bp[j] * load_v3(sp.r3 + 3 * (k.i0 + j)); }
+  out->p = p;
+  quat c[4]; load_so3_cp(sp, k.i0, c);
+  return so3_eval_pre<false, NEED_J, false>(c, pre, k.u, sp.dt, &out->so3);
+}
 // window of precomputed control-point-pair quantities handed to the residuals of the fused kernels: entry e belongs to the pair
 // (k0 + e, k0 + e + 1); a row whose knot interval falls outside is reported as RES_OUTSIDE (the kernel then takes the exact fallback)
 #ifdef LVX_KTIME
@@ -413,10 +425,12 @@ LVX_HD void cam_project(const CamIntr& c, v3 X, double y[2], double G[2][3]) {
 // local columns: [ref knot j: 6j.. | obs knot j: 24+6j.. | cam theta 48..50 | cam p 51..53 | rho 54]
 // ---------------------------------------------------------------------------------------------
 enum { REP_NC = 55, REP_NR = 2 };
+// gpre (fused path, !TAU): the pass's table of control-point-pair quantities, entry k = pair (k, k+1); the poses then take so3_eval_pre
+// (small-angle polynomials; a pair beyond them returns RES_OUTSIDE and the pass falls back to the exact kernels)
 template <bool NEED_J, bool TAU = false>
 LVX_HD int reproj_residual(const SplineRef& sp, const CamIntr& ci, const SensorCal& cam, bool tau_locked, double max_time_offset,
                            double u_ref, double v_ref, double t0_ref, double u_obs, double v_obs, double t0_obs, double rho, double weight,
-                           int* i0_ref, int* i0_obs, double r[2], double J[2][REP_NC + (TAU ? 1 : 0)]) {
+                           int* i0_ref, int* i0_obs, double r[2], double J[2][REP_NC + (TAU ? 1 : 0)], const So3Pre* gpre = nullptr) {
   // spans (:148-172): sorted (t0_ref, t0_obs), padded by the time-offset bound if free, then [-1e-3, readout + 1e-3]
   double t1, t2;
   if (t0_ref <= t0_obs) { t1 = t0_ref; t2 = t0_obs; } else { t1 = t0_obs; t2 = t0_ref; }
@@ -433,8 +447,13 @@ LVX_HD int reproj_residual(const SplineRef& sp, const CamIntr& ci, const SensorC
   if (!seg_lookup(sp, segs, t_obs, &ko)) return RES_RANGE;
   *i0_ref = kr.i0; *i0_obs = ko.i0;
   PoseEval er, eo;
-  if (!pose_eval<NEED_J, TAU>(sp, kr, &er)) return RES_NONUNIT;
-  if (!pose_eval<NEED_J, TAU>(sp, ko, &eo)) return RES_NONUNIT;
+  if (!TAU && gpre) {
+    const int bad = pose_eval_pre<NEED_J>(sp, kr, &er, gpre + kr.i0) | pose_eval_pre<NEED_J>(sp, ko, &eo, gpre + ko.i0);
+    if (bad) return (bad & 1) ? RES_NONUNIT : RES_OUTSIDE;
+  } else {
+    if (!pose_eval<NEED_J, TAU>(sp, kr, &er)) return RES_NONUNIT;
+    if (!pose_eval<NEED_J, TAU>(sp, ko, &eo)) return RES_NONUNIT;
+  }
   const v3 p_ct = qrot_inv(cam.q, -cam.p);
   const v3 yh = cam_unproject(ci, u_ref, v_ref);
   const v3 X_ref = qrot(cam.q, yh - rho * p_ct);
