@@ -29,7 +29,7 @@ struct DevCommon {
   int nb, bw, nbd;   // nbd: assembly border size (solve border + pseudo rows) = leading dimension of C
   int nbd_solve;
   const void* hubs;  // HubShared[2]: surfel (tau_L) and cam-surfel (tau_C) poses at t_map
-  const So3Pre* pre; // [N]: u-independent SO3 quantities of the control-point pairs (k, k+1), rebuilt from the state at the start of every pass (k_so3_pre_table)
+  const So3Pre* pre; // [N]: u-independent SO3 quantities of the control-point pairs (k, k+1), rebuilt from the state at the start of every pass (k_state_prepass)
   double* Hb;    // [nb][bw+1] lower band, column-major by column
   double* gb;    // [nb]
   double* Bd;    // [nbd][nb]

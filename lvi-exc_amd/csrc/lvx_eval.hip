@@ -331,18 +331,8 @@ __global__ __launch_bounds__(64 * PW) void k_family(F fam, DevCommon cm, const u
 // J_hub = g0^T M_hub, folded back onto the hub control points by k_fold_border.
 // ---------------------------------------------------------------------------------------------------------
 // u-independent SO3 quantities of every control-point pair (k, k+1) — log, |Omega|, J_r^-1 — once per pass instead of once per workgroup
-// (the fused kernels copy their CR + 4 entries into LDS) and once per row (reprojection Jacobian kernel)
-__global__ __launch_bounds__(256) void k_so3_pre_table(DevCommon cm, So3Pre* tab) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= cm.N) return;
-  const double* so3 = cm.state + 3 * (size_t)cm.N;
-  So3Pre e;
-  if (k + 1 < cm.N) so3_pre(load_q(so3 + 4 * (size_t)k), load_q(so3 + 4 * (size_t)(k + 1)), &e);
-  else { e.Om = mk(0, 0, 0); e.on = 0.0; e.Jri = m3_identity(); e.c3 = 1.0 / 12.0; e.ok = 1; }
-  tab[k] = e;
-}
-__global__ void k_hub_eval(DevCommon cm, double t_map, int want_surf, int want_cs, HubShared* hubs) {
-  const int s = threadIdx.x;
+// (the fused kernels copy their CR + 4 entries into LDS) and once per row (reprojection Jacobian kernel): k_state_prepass below
+__device__ void hub_eval_thread(const DevCommon& cm, double t_map, int want_surf, int want_cs, HubShared* hubs, int s) {
   if (s > 1) return;
   if ((s == 0 && !want_surf) || (s == 1 && !want_cs)) { hubs[s].ok = 0; return; }
   const SplineRef sp{cm.t0, cm.dt, cm.N, cm.state, cm.state + 3 * (size_t)cm.N};
@@ -355,6 +345,18 @@ __global__ void k_hub_eval(DevCommon cm, double t_map, int want_surf, int want_c
   if (!seg_lookup(sp, sg, t_map + tau, &kh)) return;
   if (!pose_eval<true>(sp, kh, &hubs[s].A)) { hubs[s].ok = -RES_NONUNIT; return; }
   hubs[s].ok = 1;
+}
+// one launch for everything that depends on the state only: blocks [0, nblk_tab) fill the control-point-pair table, the last block
+// evaluates the shared t_map poses (hubs != nullptr)
+__global__ __launch_bounds__(256) void k_state_prepass(DevCommon cm, So3Pre* tab, int nblk_tab, double t_map, int want_surf, int want_cs, HubShared* hubs) {
+  if ((int)blockIdx.x >= nblk_tab) { hub_eval_thread(cm, t_map, want_surf, want_cs, hubs, threadIdx.x); return; }
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cm.N) return;
+  const double* so3 = cm.state + 3 * (size_t)cm.N;
+  So3Pre e;
+  if (k + 1 < cm.N) so3_pre(load_q(so3 + 4 * (size_t)k), load_q(so3 + 4 * (size_t)(k + 1)), &e);
+  else { e.Om = mk(0, 0, 0); e.on = 0.0; e.Jri = m3_identity(); e.c3 = 1.0 / 12.0; e.ok = 1; }
+  tab[k] = e;
 }
 
 // per-row extras of the MFMA path: window id (rows with wid in [w, w + WS) share a window; default = knot interval), and for the
@@ -1300,9 +1302,9 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     if (fast) {   // the control-point-pair table and the shared t_map pose (one thread, ~25 us) depend on the state only: next to the clear, not behind it
       hipStream_t s_hub = getenv("LVX_SERIAL") ? st : ctx->fam_stream[0];
       if (s_hub != st) { LVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st)); LVX_HIP(ctx, hipStreamWaitEvent(s_hub, ctx->ev_fork, 0)); }
-      hipLaunchKernelGGL(k_so3_pre_table, dim3((unsigned)((ctx->N + 255) / 256)), dim3(256), 0, s_hub, cm, (So3Pre*)ctx->d_pre.p);
-      if (fast_surf || fast_cs)
-        hipLaunchKernelGGL(k_hub_eval, dim3(1), dim3(64), 0, s_hub, cm, ctx->t_map, fast_surf ? 1 : 0, fast_cs ? 1 : 0, (HubShared*)ctx->d_hubs.p);
+      const int nblk_tab = (ctx->N + 255) / 256;
+      hipLaunchKernelGGL(k_state_prepass, dim3((unsigned)(nblk_tab + ((fast_surf || fast_cs) ? 1 : 0))), dim3(256), 0, s_hub, cm, (So3Pre*)ctx->d_pre.p, nblk_tab,
+                         ctx->t_map, fast_surf ? 1 : 0, fast_cs ? 1 : 0, (HubShared*)ctx->d_hubs.p);
       if (s_hub != st) LVX_HIP(ctx, hipEventRecord(ctx->ev_join[3], s_hub));
     }
     {   // one launch clears every accumulator of the pass (cost, error flags, and for the normal equations band, gradient, border rows, dense border)
