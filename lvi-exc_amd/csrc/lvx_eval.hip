@@ -346,11 +346,11 @@ __device__ void hub_eval_thread(const DevCommon& cm, double t_map, int want_surf
   if (!pose_eval<true>(sp, kh, &hubs[s].A)) { hubs[s].ok = -RES_NONUNIT; return; }
   hubs[s].ok = 1;
 }
-// one launch for everything that depends on the state only: blocks [0, nblk_tab) fill the control-point-pair table, the last block
-// evaluates the shared t_map poses (hubs != nullptr)
-__global__ __launch_bounds__(256) void k_state_prepass(DevCommon cm, So3Pre* tab, int nblk_tab, double t_map, int want_surf, int want_cs, HubShared* hubs) {
-  if ((int)blockIdx.x >= nblk_tab) { hub_eval_thread(cm, t_map, want_surf, want_cs, hubs, threadIdx.x); return; }
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+// everything that depends on the state only: blocks [0, nblk_tab) fill the control-point-pair table, the next block evaluates the shared
+// t_map poses; run by the first blocks of the pass's clear kernel (k_clear)
+__device__ __forceinline__ void state_prepass_block(const DevCommon& cm, So3Pre* tab, int nblk_tab, double t_map, int want_surf, int want_cs, HubShared* hubs, int blk) {
+  if (blk >= nblk_tab) { hub_eval_thread(cm, t_map, want_surf, want_cs, hubs, threadIdx.x); return; }
+  const int k = blk * blockDim.x + threadIdx.x;
   if (k >= cm.N) return;
   const double* so3 = cm.state + 3 * (size_t)cm.N;
   So3Pre e;
@@ -1266,8 +1266,11 @@ ProfScope::~ProfScope() {
 
 // clears up to 8 device buffers (sizes rounded up to 16 bytes: every buffer is allocated with that slack by dev_alloc's callers) in one launch
 struct ClearList { uint4* p[8]; size_t words[8]; int n; };
-__global__ __launch_bounds__(256) void k_clear(ClearList cl) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// First launch of a pass.  Its first npre blocks do what depends on the state only (control-point-pair table, hub poses: k_state_prepass's
+// work — a separate kernel on a side stream costs a ~30 us cross-stream join before the LiDAR kernels); the rest clear the accumulators.
+__global__ __launch_bounds__(256) void k_clear(ClearList cl, int npre, DevCommon cm, So3Pre* tab, int nblk_tab, double t_map, int want_surf, int want_cs, HubShared* hubs) {
+  if ((int)blockIdx.x < npre) { state_prepass_block(cm, tab, nblk_tab, t_map, want_surf, want_cs, hubs, blockIdx.x); return; }
+  const size_t stride = (size_t)(gridDim.x - npre) * blockDim.x, t0 = (size_t)(blockIdx.x - npre) * blockDim.x + threadIdx.x;
   for (int b = 0; b < cl.n; ++b)
     for (size_t i = t0; i < cl.words[b]; i += stride) cl.p[b][i] = make_uint4(0u, 0u, 0u, 0u);
 }
@@ -1299,14 +1302,8 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     // free time offsets need d pose / d t at both evaluations: those problems take the per-segment kernels (TAU variants)
     const bool tauL = !(ctx->locks & LVX_LOCK_LIDAR_TAU), tauC = !(ctx->locks & LVX_LOCK_CAM_TAU);
     const bool fast_surf = fast && !tauL && ctx->surf.n > 0, fast_cs = fast && !tauC && ctx->cs.n > 0;
-    if (fast) {   // the control-point-pair table and the shared t_map pose (one thread, ~25 us) depend on the state only: next to the clear, not behind it
-      hipStream_t s_hub = getenv("LVX_SERIAL") ? st : ctx->fam_stream[0];
-      if (s_hub != st) { LVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st)); LVX_HIP(ctx, hipStreamWaitEvent(s_hub, ctx->ev_fork, 0)); }
-      const int nblk_tab = (ctx->N + 255) / 256;
-      hipLaunchKernelGGL(k_state_prepass, dim3((unsigned)(nblk_tab + ((fast_surf || fast_cs) ? 1 : 0))), dim3(256), 0, s_hub, cm, (So3Pre*)ctx->d_pre.p, nblk_tab,
-                         ctx->t_map, fast_surf ? 1 : 0, fast_cs ? 1 : 0, (HubShared*)ctx->d_hubs.p);
-      if (s_hub != st) LVX_HIP(ctx, hipEventRecord(ctx->ev_join[3], s_hub));
-    }
+    // the control-point-pair table and the shared t_map poses (one thread, ~25 us) depend on the state only: the first blocks of the clear kernel
+    const int nblk_tab = fast ? (ctx->N + 255) / 256 : 0, npre = fast ? nblk_tab + ((fast_surf || fast_cs) ? 1 : 0) : 0;
     {   // one launch clears every accumulator of the pass (cost, error flags, and for the normal equations band, gradient, border rows, dense border)
       ClearList cl{};
       auto add = [&](void* p, size_t bytes) { cl.p[cl.n] = (uint4*)p; cl.words[cl.n] = (bytes + 15) / 16; cl.n++; };
@@ -1317,9 +1314,9 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
       }
       size_t total = 0; for (int i = 0; i < cl.n; ++i) total += cl.words[i];
       const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
-      hipLaunchKernelGGL(k_clear, dim3(blocks), dim3(256), 0, st, cl);
+      hipLaunchKernelGGL(k_clear, dim3(blocks + (unsigned)npre), dim3(256), 0, st, cl, npre, cm, (So3Pre*)ctx->d_pre.p, nblk_tab, ctx->t_map, fast_surf ? 1 : 0, fast_cs ? 1 : 0,
+                         (HubShared*)ctx->d_hubs.p);
     }
-    if (fast && !getenv("LVX_SERIAL")) LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[3], 0));
     auto grid = [](int n) { return dim3((unsigned)((n + 63) / 64)); };
     // fast path: LDS-accumulating kernels for the segment-structured families; legacy per-segment kernels for reprojection, the prior,
     // the debug Jacobian, and as the exact fallback for the merged-hub-segment corner
