@@ -1271,8 +1271,15 @@ struct ClearList { uint4* p[8]; size_t words[8]; int n; };
 __global__ __launch_bounds__(256) void k_clear(ClearList cl, int npre, DevCommon cm, So3Pre* tab, int nblk_tab, double t_map, int want_surf, int want_cs, HubShared* hubs) {
   if ((int)blockIdx.x < npre) { state_prepass_block(cm, tab, nblk_tab, t_map, want_surf, want_cs, hubs, blockIdx.x); return; }
   const size_t stride = (size_t)(gridDim.x - npre) * blockDim.x, t0 = (size_t)(blockIdx.x - npre) * blockDim.x + threadIdx.x;
-  for (int b = 0; b < cl.n; ++b)
-    for (size_t i = t0; i < cl.words[b]; i += stride) cl.p[b][i] = make_uint4(0u, 0u, 0u, 0u);
+  for (int b = 0; b < cl.n; ++b) {   // 4 stores per trip: the prepass code leaves this kernel 2 wavefronts per SIMD, the stores keep HBM busy anyway
+    const size_t nw = cl.words[b];
+    size_t i = t0;
+    for (; i + 3 * stride < nw; i += 4 * stride) {
+      cl.p[b][i] = make_uint4(0u, 0u, 0u, 0u); cl.p[b][i + stride] = make_uint4(0u, 0u, 0u, 0u);
+      cl.p[b][i + 2 * stride] = make_uint4(0u, 0u, 0u, 0u); cl.p[b][i + 3 * stride] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    for (; i < nw; i += stride) cl.p[b][i] = make_uint4(0u, 0u, 0u, 0u);
+  }
 }
 
 static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cost, bool want_res_buffer) {
