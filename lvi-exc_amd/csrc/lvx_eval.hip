@@ -1334,6 +1334,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     static const int sched = getenv("LVX_SCHED") ? atoi(getenv("LVX_SCHED")) : 2;
     const bool staged = sched == 2 && !getenv("LVX_SERIAL");
     hipStream_t s_imu = ctx->fam_stream[0], s_acc = ctx->fam_stream[1], s_surf = staged ? st : ctx->fam_stream[2], s_rep = staged ? st : ctx->fam_stream[3];
+    if (getenv("LVX_IMU_ONE_STREAM")) s_acc = s_imu;
     if (getenv("LVX_SERIAL")) s_imu = s_acc = s_surf = s_rep = st;   // profiling aid: solo kernel durations
     const hipStream_t side[4] = {s_imu, s_acc, s_surf, s_rep};
     LVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
@@ -1429,8 +1430,9 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
               LVX_LAUNCH_MFMA1(RepObsAcc, 1, ra, LVX_FAM_REPROJ, s_rep, ctx->fam_row0[4]);   // measured: a second workgroup per CU does not help, the cross-term atomics bound this pass
               // the reference-side pass only reads the materialised rows: it runs next to the observation-side pass, behind the accelerometer kernel
               RepRefAcc rb2{r.n, (const int*)ctx->d_repB[2].p, (const int*)ctx->d_repB[3].p, jac, 0.0};
-              LVX_HIP(ctx, hipStreamWaitEvent(s_acc, ctx->ev_jac, 0));
-              LVX_LAUNCH_MFMA1(RepRefAcc, 1, rb2, LVX_FAM_PRIOR, s_acc, ctx->fam_row0[4]);
+              hipStream_t s_ref = getenv("LVX_IMU_ONE_STREAM") ? s_rep : s_acc;
+              if (s_ref != s_rep) LVX_HIP(ctx, hipStreamWaitEvent(s_ref, ctx->ev_jac, 0));
+              LVX_LAUNCH_MFMA1(RepRefAcc, 1, rb2, LVX_FAM_PRIOR, s_ref, ctx->fam_row0[4]);
             }
           } else
           hipLaunchKernelGGL((k_family<ReprojFam, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, r, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
