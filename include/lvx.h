@@ -161,6 +161,8 @@ int lvx_synchronize(lvx_ctx* ctx);
 #define LVX_KERNEL_SOLVE 7
 #define LVX_KERNEL_UPSTREAM 8
 #define LVX_NUM_KERNELS 9
+/* enable: 0 off | 1 every launch | 2 + k: only the launches of kernel k (e.g. 2 + LVX_FAM_SURFEL: the dominant kernel — two event
+ * records per pass instead of ~20, which cost ~5 % of a config-4 pass).  While profiling is on, passes are issued launch by launch (no graph replay). */
 int lvx_set_profiling(lvx_ctx* ctx, int enable);
 int lvx_get_kernel_ms(lvx_ctx* ctx, double* ms_sum, int64_t* launches);
 /* Levenberg-Marquardt --------------------------------------------------------------------------------------------

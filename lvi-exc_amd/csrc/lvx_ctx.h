@@ -121,6 +121,7 @@ struct lvx_ctx {
   double sh_lmd[LVX_N_SHARED] = {0}; // LM diagonal of the shared scalars (from the JOINT diagonal), added once after the reduction
   // profiling: (start, stop) event pairs per launch, read lazily by lvx_get_kernel_ms
   bool profiling = false;
+  int profile_only = -1;   // >= 0: only this kernel's launches are timed
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
   struct EvRec { int kernel; size_t e0, e1; };

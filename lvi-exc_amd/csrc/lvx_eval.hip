@@ -1246,11 +1246,14 @@ DevCommon make_common(lvx_ctx* ctx, const double* state_d, uint32_t what) {
   return cm;
 }
 
+// events that order kernels of this context's streams.  LVX_SYNC_NOFENCE=1 drops their system-scope fence (-2 % per pass; experimental)
+#define LVX_SYNC_EVENT_FLAGS (hipEventDisableTiming | (getenv("LVX_SYNC_NOFENCE") ? hipEventDisableSystemFence : 0u))
 static size_t next_event(lvx_ctx* c) {
-  if (c->ev_used == c->ev_pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return (size_t)-1; c->ev_pool.push_back(e); }
+  // timing only: no system-scope fence (cache writeback + invalidation) at every record
+  if (c->ev_used == c->ev_pool.size()) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) return (size_t)-1; c->ev_pool.push_back(e); }
   return c->ev_used++;
 }
-ProfScope::ProfScope(lvx_ctx* ctx, int k, hipStream_t stream) : c(ctx), kernel(k), on(ctx->profiling), st(stream ? stream : ctx->stream) {
+ProfScope::ProfScope(lvx_ctx* ctx, int k, hipStream_t stream) : c(ctx), kernel(k), on(ctx->profiling && (ctx->profile_only < 0 || ctx->profile_only == k)), st(stream ? stream : ctx->stream) {
   if (!on) return;
   e0 = next_event(c);
   if (e0 == (size_t)-1) { on = false; return; }
@@ -1539,9 +1542,9 @@ int lvx_create(lvx_ctx** out, int device, uint32_t /*flags*/) {
   c->device = device;
   if (hipStreamCreate(&c->own_stream) != hipSuccess) { delete c; return LVX_E_HIP; }
   c->stream = c->own_stream;
-  for (int k = 0; k < 4; ++k) { if (hipStreamCreateWithFlags(&c->fam_stream[k], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming) != hipSuccess) { delete c; return LVX_E_HIP; } }
-  if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { delete c; return LVX_E_HIP; }
-  if (hipEventCreateWithFlags(&c->ev_jac, hipEventDisableTiming) != hipSuccess) { delete c; return LVX_E_HIP; }
+  for (int k = 0; k < 4; ++k) { if (hipStreamCreateWithFlags(&c->fam_stream[k], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_join[k], LVX_SYNC_EVENT_FLAGS) != hipSuccess) { delete c; return LVX_E_HIP; } }
+  if (hipEventCreateWithFlags(&c->ev_fork, LVX_SYNC_EVENT_FLAGS) != hipSuccess) { delete c; return LVX_E_HIP; }
+  if (hipEventCreateWithFlags(&c->ev_jac, LVX_SYNC_EVENT_FLAGS) != hipSuccess) { delete c; return LVX_E_HIP; }
   *out = c;
   return LVX_OK;
 }
@@ -1709,7 +1712,7 @@ int lvx_synchronize(lvx_ctx* c) {
   if (err & 4) return fail(c, LVX_E_STATE, "normal-equation entry outside the computed bandwidth");
   return LVX_OK;
 }
-int lvx_set_profiling(lvx_ctx* c, int enable) { if (!c) return LVX_E_ARG; c->profiling = enable != 0; return LVX_OK; }
+int lvx_set_profiling(lvx_ctx* c, int enable) { if (!c) return LVX_E_ARG; c->profiling = enable != 0; c->profile_only = enable >= 2 ? enable - 2 : -1; return LVX_OK; }
 int lvx_get_kernel_ms(lvx_ctx* c, double* ms_sum, int64_t* launches) {
   if (!c || !ms_sum || !launches) return LVX_E_ARG;
   LVX_HIP(c, hipSetDevice(c->device));

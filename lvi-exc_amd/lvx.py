@@ -228,8 +228,9 @@ class Context:
     def synchronize(self):
         self._ck(self._l.lvx_synchronize(self._h))
 
-    def set_profiling(self, on):
-        self._ck(self._l.lvx_set_profiling(self._h, C.c_int(1 if on else 0)))
+    def set_profiling(self, on, only=None):
+        """on: time every launch with HIP events; only=<kernel index>: just that kernel's launches (cheap enough for a timed region)."""
+        self._ck(self._l.lvx_set_profiling(self._h, C.c_int((2 + int(only)) if (on and only is not None) else (1 if on else 0))))
 
     def kernel_ms(self):
         ms = np.zeros(9)
