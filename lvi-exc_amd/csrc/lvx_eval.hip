@@ -1337,11 +1337,15 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     static const int sched = getenv("LVX_SCHED") ? atoi(getenv("LVX_SCHED")) : 2;
     const bool staged = sched == 2 && !getenv("LVX_SERIAL");
     hipStream_t s_imu = ctx->fam_stream[0], s_acc = ctx->fam_stream[1], s_surf = staged ? st : ctx->fam_stream[2], s_rep = staged ? st : ctx->fam_stream[3];
-    if (getenv("LVX_IMU_ONE_STREAM")) s_acc = s_imu;
+    // one side stream (gyroscope, then accelerometer) next to the chain (Jacobian, observation pass, reference pass): both ends finish
+    // together and one fan-out / fan-in less than with a stream per IMU kernel (-1.5 % per pass); LVX_IMU_TWO_STREAMS=1 restores that
+    static const bool one_side = getenv("LVX_IMU_TWO_STREAMS") == nullptr;
+    if (one_side) s_acc = s_imu;
     if (getenv("LVX_SERIAL")) s_imu = s_acc = s_surf = s_rep = st;   // profiling aid: solo kernel durations
     const hipStream_t side[4] = {s_imu, s_acc, s_surf, s_rep};
     LVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
-    for (int k = 0; k < 4; ++k) if (side[k] != st) LVX_HIP(ctx, hipStreamWaitEvent(side[k], ctx->ev_fork, 0));
+    auto first_use = [&](int k) { for (int j = 0; j < k; ++j) if (side[j] == side[k]) return false; return side[k] != st; };   // each side stream forks / joins once
+    for (int k = 0; k < 4; ++k) if (first_use(k)) LVX_HIP(ctx, hipStreamWaitEvent(side[k], ctx->ev_fork, 0));
     static const int occ_env = getenv("LVX_OCC") ? atoi(getenv("LVX_OCC")) : 0;   // 0: the family's own choice (F::OCC wavefronts per SIMD)
   #define LVX_LAUNCH_MFMA1(FT, OCCV, fam_obj, chunk_slot, stream, row0v)                                                                        \
     do {                                                                                                                                     \
@@ -1433,7 +1437,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
               LVX_LAUNCH_MFMA1(RepObsAcc, 1, ra, LVX_FAM_REPROJ, s_rep, ctx->fam_row0[4]);   // measured: a second workgroup per CU does not help, the cross-term atomics bound this pass
               // the reference-side pass only reads the materialised rows: it runs next to the observation-side pass, behind the accelerometer kernel
               RepRefAcc rb2{r.n, (const int*)ctx->d_repB[2].p, (const int*)ctx->d_repB[3].p, jac, 0.0};
-              hipStream_t s_ref = getenv("LVX_IMU_ONE_STREAM") ? s_rep : s_acc;
+              hipStream_t s_ref = (one_side && staged) ? s_rep : s_acc;
               if (s_ref != s_rep) LVX_HIP(ctx, hipStreamWaitEvent(s_ref, ctx->ev_jac, 0));
               LVX_LAUNCH_MFMA1(RepRefAcc, 1, rb2, LVX_FAM_PRIOR, s_ref, ctx->fam_row0[4]);
             }
@@ -1461,7 +1465,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
       } break;
       }
     }
-    for (int k = 0; k < 4; ++k) if (side[k] != st) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[k], side[k])); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[k], 0)); }
+    for (int k = 0; k < 4; ++k) if (first_use(k)) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[k], side[k])); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[k], 0)); }
     { ProfScope ps(ctx, LVX_KERNEL_FOLD);
     const bool fold_fast = (what & LVX_EVAL_NORMAL_EQ) && (fast_surf || fast_cs);
     if (fold_fast && !getenv("LVX_SERIAL")) LVX_HIP(ctx, hipEventRecord(ctx->ev_jac, st));   // st has joined every family stream here
