@@ -1343,9 +1343,13 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     if (one_side) s_acc = s_imu;
     if (getenv("LVX_SERIAL")) s_imu = s_acc = s_surf = s_rep = st;   // profiling aid: solo kernel durations
     const hipStream_t side[4] = {s_imu, s_acc, s_surf, s_rep};
-    LVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
     auto first_use = [&](int k) { for (int j = 0; j < k; ++j) if (side[j] == side[k]) return false; return side[k] != st; };   // each side stream forks / joins once
-    for (int k = 0; k < 4; ++k) if (first_use(k)) LVX_HIP(ctx, hipStreamWaitEvent(side[k], ctx->ev_fork, 0));
+    // staged: the side stream's first operation is its wait for the LiDAR stage (ev_join[2]) — that is its fork; an event record on the
+    // chain costs a ~13 us bubble (barrier packet + system-scope fence), so no extra fork event there
+    if (!staged) {
+      LVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
+      for (int k = 0; k < 4; ++k) if (first_use(k)) LVX_HIP(ctx, hipStreamWaitEvent(side[k], ctx->ev_fork, 0));
+    }
     static const int occ_env = getenv("LVX_OCC") ? atoi(getenv("LVX_OCC")) : 0;   // 0: the family's own choice (F::OCC wavefronts per SIMD)
   #define LVX_LAUNCH_MFMA1(FT, OCCV, fam_obj, chunk_slot, stream, row0v)                                                                        \
     do {                                                                                                                                     \
@@ -1468,11 +1472,11 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     for (int k = 0; k < 4; ++k) if (first_use(k)) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[k], side[k])); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[k], 0)); }
     { ProfScope ps(ctx, LVX_KERNEL_FOLD);
     const bool fold_fast = (what & LVX_EVAL_NORMAL_EQ) && (fast_surf || fast_cs);
-    if (fold_fast && !getenv("LVX_SERIAL")) LVX_HIP(ctx, hipEventRecord(ctx->ev_jac, st));   // st has joined every family stream here
+    if (fold_fast && !getenv("LVX_SERIAL") && !getenv("LVX_FOLD_INLINE")) LVX_HIP(ctx, hipEventRecord(ctx->ev_jac, st));   // st has joined every family stream here
     hipLaunchKernelGGL(k_fold_replicas, dim3((unsigned)((ctx->nbd_ext * ctx->nbd_ext + 255) / 256)), dim3(256), 0, st, cm);
     if (fold_fast) {
       // the border-row fold (Bd, streaming) and the dense fold (C, g_c; one workgroup, behind k_fold_replicas) touch disjoint buffers: side by side
-      hipStream_t s_side = getenv("LVX_SERIAL") ? st : ctx->fam_stream[0];
+      hipStream_t s_side = (getenv("LVX_SERIAL") || getenv("LVX_FOLD_INLINE")) ? st : ctx->fam_stream[0];
       if (s_side != st) LVX_HIP(ctx, hipStreamWaitEvent(s_side, ctx->ev_jac, 0));
       for (int set = 0; set < 2; ++set) if (ctx->nb > 0 && ((set == 0 && fast_surf) || (set == 1 && fast_cs)))
         hipLaunchKernelGGL(k_fold_border_rows, dim3((unsigned)((ctx->nb + 255) / 256)), dim3(256), 0, s_side, cm, set);
