@@ -885,7 +885,7 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
 
 // fold the pseudo-pose rows of the border back onto the hub control points: x_pseudo = M_hub x_hub  =>
 //   Bd[hub] += M^T Bd[pseudo],  C <- (I + E) C (I + E)^T,  g_c[hub] += M^T g_c[pseudo]      (E = M^T placed at [hub rows, pseudo cols])
-__global__ __launch_bounds__(256) void k_fold_border_rows(DevCommon cm, int set) {
+__device__ __forceinline__ void fold_border_rows_block(const DevCommon& cm, int set, int blk) {
   const HubShared* hub = ((const HubShared*)cm.hubs) + set;
   if (hub->ok != 1) return;
   __shared__ double M[6][24];
@@ -893,23 +893,27 @@ __global__ __launch_bounds__(256) void k_fold_border_rows(DevCommon cm, int set)
   if (threadIdx.x == 0) hub_matrix(hub->A, M);
   if (threadIdx.x < 24) { const int o = cm.ord[6 * (hub->A.k.i0 + threadIdx.x / 6) + threadIdx.x % 6]; hrow[threadIdx.x] = (o != LVX_DEAD && o < 0) ? -1 - o : -1; }   // hub control points are border variables
   __syncthreads();
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= cm.nb) return;
+  const int j = blk * blockDim.x + threadIdx.x;
   double P[6];
   bool any = false;
+  if (j < cm.nb) {
 #pragma unroll
-  for (int p = 0; p < 6; ++p) { P[p] = cm.Bd[(size_t)(cm.nbd_solve + 6 * set + p) * cm.nb + j]; any = any || P[p] != 0.0; }
-  if (!any) return;
-#pragma unroll
-  for (int c = 0; c < 24; ++c) {
-    if (hrow[c] < 0) continue;
-    double s = 0.0;
-#pragma unroll
-    for (int p = 0; p < 6; ++p) s += M[p][c] * P[p];
-    cm.Bd[(size_t)hrow[c] * cm.nb + j] += s;
+    for (int p = 0; p < 6; ++p) { P[p] = cm.Bd[(size_t)(cm.nbd_solve + 6 * set + p) * cm.nb + j]; any = any || P[p] != 0.0; }
   }
+  if (any) {
+#pragma unroll
+    for (int c = 0; c < 24; ++c) {
+      if (hrow[c] < 0) continue;
+      double s = 0.0;
+#pragma unroll
+      for (int p = 0; p < 6; ++p) s += M[p][c] * P[p];
+      cm.Bd[(size_t)hrow[c] * cm.nb + j] += s;   // the two sets may share hub rows: a thread folds them one after the other (k_fold_all)
+    }
+  }
+  __syncthreads();   // M / hrow are reused by the next set
 }
-__global__ __launch_bounds__(256) void k_fold_border_dense(DevCommon cm) {
+__global__ __launch_bounds__(256) void k_fold_border_rows(DevCommon cm, int set) { fold_border_rows_block(cm, set, (int)blockIdx.x); }
+__device__ __forceinline__ void fold_border_dense_block(const DevCommon& cm) {
   extern __shared__ double Cf[];   // full symmetric [n][n] then g[n]
   const int n = cm.nbd;
   double* g = Cf + n * n;
@@ -949,15 +953,34 @@ __global__ __launch_bounds__(256) void k_fold_border_dense(DevCommon cm) {
   for (int e = threadIdx.x; e < n; e += 256) cm.gc[e] = g[e];
 }
 
+__global__ __launch_bounds__(256) void k_fold_border_dense(DevCommon cm) { fold_border_dense_block(cm); }
+
 // fold the replicas of the dense border accumulators into replica 0
-__global__ void k_fold_replicas(DevCommon cm) {
+__device__ __forceinline__ void fold_replicas_block(const DevCommon& cm, int blk) {
   const int n2 = cm.nbd * cm.nbd;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blk * blockDim.x + threadIdx.x;
   if (cm.what & LVX_EVAL_NORMAL_EQ) {
     if (i < n2) { double s = 0; for (int r = 0; r < LVX_NREP; ++r) s += cm.C[(size_t)r * n2 + i]; cm.C[i] = s; }
     if (i < cm.nbd) { double s = 0; for (int r = 0; r < LVX_NREP; ++r) s += cm.gc[(size_t)r * cm.nbd + i]; cm.gc[i] = s; }
   }
   if (i == 0) { double s = 0; for (int r = 0; r < LVX_NREP; ++r) s += cm.cost[r]; cm.cost[0] = s; }
+}
+__global__ void k_fold_replicas(DevCommon cm) { fold_replicas_block(cm, (int)blockIdx.x); }
+// The whole fold in one launch (three kernels on two streams cost a fork and a join on the pass's critical path): blocks [0, nrep) sum the
+// replicas — the last of them to finish (device-scope fence + counter in err[1], cleared with the error flags) then folds the dense block —
+// and the remaining blocks fold the border rows (both sets in the same thread: they may add into the same hub rows).
+__global__ __launch_bounds__(256) void k_fold_all(DevCommon cm, int nrep, int sets) {
+  const int b = blockIdx.x;
+  if (b >= nrep) { if (sets & 1) fold_border_rows_block(cm, 0, b - nrep); if (sets & 2) fold_border_rows_block(cm, 1, b - nrep); return; }
+  fold_replicas_block(cm, b);
+  __shared__ int last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(&cm.err[1], 1) == nrep - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  fold_border_dense_block(cm);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1472,6 +1495,13 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     for (int k = 0; k < 4; ++k) if (first_use(k)) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[k], side[k])); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[k], 0)); }
     { ProfScope ps(ctx, LVX_KERNEL_FOLD);
     const bool fold_fast = (what & LVX_EVAL_NORMAL_EQ) && (fast_surf || fast_cs);
+    static const bool fold_split = getenv("LVX_FOLD_SPLIT") != nullptr;   // the former three-kernel fold
+    if (fold_fast && ctx->nb > 0 && !fold_split) {
+      const int nrep = (ctx->nbd_ext * ctx->nbd_ext + 255) / 256, nrows = (ctx->nb + 255) / 256;
+      const size_t lds = ((size_t)ctx->nbd_ext * ctx->nbd_ext + ctx->nbd_ext) * 8;
+      LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_fold_all, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_fold_all, dim3((unsigned)(nrep + nrows)), dim3(256), lds, st, cm, nrep, (fast_surf ? 1 : 0) | (fast_cs ? 2 : 0));
+    } else {
     if (fold_fast && !getenv("LVX_SERIAL") && !getenv("LVX_FOLD_INLINE")) LVX_HIP(ctx, hipEventRecord(ctx->ev_jac, st));   // st has joined every family stream here
     hipLaunchKernelGGL(k_fold_replicas, dim3((unsigned)((ctx->nbd_ext * ctx->nbd_ext + 255) / 256)), dim3(256), 0, st, cm);
     if (fold_fast) {
@@ -1484,7 +1514,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
       LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_fold_border_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(k_fold_border_dense, dim3(1), dim3(256), lds, st, cm);
       if (s_side != st) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[0], s_side)); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[0], 0)); }
-    } }
+    } } }
     LVX_HIP(ctx, hipGetLastError());
     return rc;
   };
