@@ -34,7 +34,7 @@ __device__ __forceinline__ Cal load_cal(const DevCommon& cm) {
   return c;
 }
 
-struct HubShared { PoseEval A; int ok; };
+struct HubShared { PoseEval A; int ok; double M[6][24]; };   // M: hub_matrix(A), filled by the pass's prepass for the fold kernel
 
 // ---------------------------------------------------------------------------------------------------------
 // family policies
@@ -344,6 +344,7 @@ __device__ void hub_eval_thread(const DevCommon& cm, double t_map, int want_surf
   if (!build_segments(sp, s1, 1, &sg)) return;
   if (!seg_lookup(sp, sg, t_map + tau, &kh)) return;
   if (!pose_eval<true>(sp, kh, &hubs[s].A)) { hubs[s].ok = -RES_NONUNIT; return; }
+  hub_matrix(hubs[s].A, hubs[s].M);   // once here instead of by one thread of each of the fold's ~600 workgroups
   hubs[s].ok = 1;
 }
 // everything that depends on the state only: blocks [0, nblk_tab) fill the control-point-pair table, the next block evaluates the shared
@@ -890,7 +891,7 @@ __device__ __forceinline__ void fold_border_rows_block(const DevCommon& cm, int 
   if (hub->ok != 1) return;
   __shared__ double M[6][24];
   __shared__ int hrow[24];
-  if (threadIdx.x == 0) hub_matrix(hub->A, M);
+  if (threadIdx.x < 144) M[threadIdx.x / 24][threadIdx.x % 24] = hub->M[threadIdx.x / 24][threadIdx.x % 24];
   if (threadIdx.x < 24) { const int o = cm.ord[6 * (hub->A.k.i0 + threadIdx.x / 6) + threadIdx.x % 6]; hrow[threadIdx.x] = (o != LVX_DEAD && o < 0) ? -1 - o : -1; }   // hub control points are border variables
   __syncthreads();
   const int j = blk * blockDim.x + threadIdx.x;
@@ -917,7 +918,14 @@ __device__ __forceinline__ void fold_border_dense_block(const DevCommon& cm) {
   extern __shared__ double Cf[];   // full symmetric [n][n] then g[n]
   const int n = cm.nbd;
   double* g = Cf + n * n;
-  for (int e = threadIdx.x; e < n * n; e += 256) { const int a = e / n, b = e % n; Cf[e] = a >= b ? cm.C[(size_t)a * n + b] : cm.C[(size_t)b * n + a]; }
+  // one workgroup, latency bound: issue a batch of 8 independent loads per thread before the first LDS store
+  for (int e0 = threadIdx.x; e0 < n * n; e0 += 8 * 256) {
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int e = e0 + 256 * q; if (e < n * n) { const int a = e / n, b = e % n; v[q] = a >= b ? cm.C[(size_t)a * n + b] : cm.C[(size_t)b * n + a]; } }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int e = e0 + 256 * q; if (e < n * n) Cf[e] = v[q]; }
+  }
   for (int e = threadIdx.x; e < n; e += 256) g[e] = cm.gc[e];
   __syncthreads();
   for (int set = 0; set < 2; ++set) {
@@ -925,7 +933,7 @@ __device__ __forceinline__ void fold_border_dense_block(const DevCommon& cm) {
     if (hub->ok != 1) continue;   // uniform
     __shared__ double M[6][24];
     __shared__ int hrow[24];
-    if (threadIdx.x == 0) hub_matrix(hub->A, M);
+    if (threadIdx.x < 144) M[threadIdx.x / 24][threadIdx.x % 24] = hub->M[threadIdx.x / 24][threadIdx.x % 24];
     if (threadIdx.x < 24) { const int o = cm.ord[6 * (hub->A.k.i0 + threadIdx.x / 6) + threadIdx.x % 6]; hrow[threadIdx.x] = (o != LVX_DEAD && o < 0) ? -1 - o : -1; }
     __syncthreads();
     const int p0 = cm.nbd_solve + 6 * set;
