@@ -1047,7 +1047,9 @@ int host_i0(const lvx_ctx* c, double t) {
 // 4.9 rounds instead of 6.1 half-empty ones at R = 16; families that run two workgroups per CU count 2 slots per CU).  LVX_CHUNK_R / LVX_CHUNK_R_REP / LVX_CHUNK_R_IMU (env) force a value.
 // (Measured against a finer work model — fixed cost + cost per interval + cost per batch of 4 x LB rows: the plain rule picks the faster sizes,
 // e.g. IMU R = 33 (3 rounds, 264 rows = a second batch for 8 rows) beats R = 25 (4 rounds of one batch) by 7 %.)
-static int pick_chunk(const lvx_ctx* ctx, int lo, int hi, const char* env, int wg_per_cu = 1) {
+// fixed: a workgroup's setup + accumulator flush in units of one interval's work (LiDAR kernel: 19 k of its cycles against 8.6 k per interval
+// => 2.2; with it 13 intervals = 3.8 rounds beat 10 = 4.9 rounds, measured 0.232 vs 0.241 ms)
+static int pick_chunk(const lvx_ctx* ctx, int lo, int hi, const char* env, int wg_per_cu = 1, double fixed = 0.0) {
   if (const char* e = getenv(env)) { const int v = atoi(e); if (v >= 4 && v <= 64) return v; }
   int ncu = 256;
   hipDeviceProp_t prop;
@@ -1056,7 +1058,7 @@ static int pick_chunk(const lvx_ctx* ctx, int lo, int hi, const char* env, int w
   for (int r = lo; r <= hi; ++r) {
     const long long nwg = (ctx->N + r - 1) / r + 1;
     const long long slots = (long long)ncu * wg_per_cu;
-    const long long cost = ((nwg + slots - 1) / slots) * r;
+    const long long cost = (long long)(((nwg + slots - 1) / slots) * (r + fixed) * 64.0);
     if (best_cost < 0 || cost < best_cost) { best = r; best_cost = cost; }
   }
   return best;
@@ -1116,7 +1118,7 @@ int ensure_layout(lvx_ctx* ctx) {
     for (int i = 0; i < f.n; ++i) key[i] = host_i0(ctx, f.t[i]);
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
-    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_SURFEL, sk, pick_chunk(ctx, 8, 16, "LVX_CHUNK_R", 2)))) return rc; }
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_SURFEL, sk, pick_chunk(ctx, 8, 16, "LVX_CHUNK_R", 2, 2.2)))) return rc; }
     auto ts = gather(f.t, perm, 1); auto pt = gather(f.a3, perm, 3); auto pl = gather(f.id0, perm, 1);
     if ((rc = upload(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
     if ((rc = upload(ctx, f.d_a3, pt.data(), pt.size() * 8))) return rc;
@@ -1168,7 +1170,7 @@ int ensure_layout(lvx_ctx* ctx) {
     for (int i = 0; i < f.n; ++i) key[i] = (f.id0[i] >= 0 && f.id0[i] < L) ? host_i0(ctx, ctx->lm_t0[f.id0[i]]) : -1;
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
-    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_CAMSURF, sk, pick_chunk(ctx, 8, 16, "LVX_CHUNK_R", 2)))) return rc; }
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_CAMSURF, sk, pick_chunk(ctx, 8, 16, "LVX_CHUNK_R", 2, 2.2)))) return rc; }
     auto lm = gather(f.id0, perm, 1); auto pl = gather(f.id1, perm, 1);
     if ((rc = upload(ctx, f.d_id0, lm.data(), lm.size() * 4))) return rc;
     if ((rc = upload(ctx, f.d_id1, pl.data(), pl.size() * 4))) return rc;
