@@ -1010,6 +1010,14 @@ int upload(lvx_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
   if (bytes) LVX_HIP(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   return LVX_OK;
 }
+// layout-time uploads come from temporaries (sorted copies, tables) that die right after the call: a copy from pageable memory may still be
+// reading its source when hipMemcpyAsync returns (large copies are pinned in place and DMA'd), so these wait for it
+int upload_tmp(lvx_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
+  int rc = upload(ctx, b, src, bytes);
+  if (rc) return rc;
+  LVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LVX_OK;
+}
 
 namespace {
 
@@ -1030,7 +1038,7 @@ int upload_pairs(lvx_ctx* ctx, DevBuf& b, int NC, const std::vector<int>& border
   for (int a = 0; a < NC; ++a) for (int c = a; c < NC; ++c) if (!cls[a] && !cls[c]) tab.push_back((uint16_t)(a | (c << 8)));
   for (int g = 0; g < NC; ++g) if (cls[g]) for (int k = 0; k < NC; ++k) if (!cls[k]) tab.push_back((uint16_t)(std::min(g, k) | (std::max(g, k) << 8)));
   for (int a = 0; a < NC; ++a) for (int c = a; c < NC; ++c) if (cls[a] && cls[c]) tab.push_back((uint16_t)(a | (c << 8)));
-  return upload(ctx, b, tab.data(), tab.size() * sizeof(uint16_t));
+  return upload_tmp(ctx, b, tab.data(), tab.size() * sizeof(uint16_t));
 }
 
 // host-side knot index of a single-time lookup (tau = 0), -1 if out of range
@@ -1088,7 +1096,7 @@ static int upload_chunks(lvx_ctx* ctx, int fam, const std::vector<int>& sorted_k
   off[nch] = (int)sorted_keys.size();
   ctx->n_chunk[fam] = nch;
   ctx->chunk_r[fam] = R;
-  return upload(ctx, ctx->d_chunk[fam], off.data(), off.size() * 4);
+  return upload_tmp(ctx, ctx->d_chunk[fam], off.data(), off.size() * 4);
 }
 
 int ensure_layout(lvx_ctx* ctx) {
@@ -1107,10 +1115,10 @@ int ensure_layout(lvx_ctx* ctx) {
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
     { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_GYRO, sk, pick_chunk_batches(16, 64, "LVX_CHUNK_R_IMU", (double)f.n / std::max(1, N - 3), 4 * (int)GyroAcc::LB)))) return rc; }
     auto ts = gather(f.t, perm, 1); auto g = gather(f.a3, perm, 3); auto a = gather(f.b3, perm, 3);
-    if ((rc = upload(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
-    if ((rc = upload(ctx, f.d_a3, g.data(), g.size() * 8))) return rc;
-    if ((rc = upload(ctx, f.d_b3, a.data(), a.size() * 8))) return rc;
-    if ((rc = upload(ctx, f.d_perm, perm.data(), perm.size() * 4))) return rc;
+    if ((rc = upload_tmp(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
+    if ((rc = upload_tmp(ctx, f.d_a3, g.data(), g.size() * 8))) return rc;
+    if ((rc = upload_tmp(ctx, f.d_b3, a.data(), a.size() * 8))) return rc;
+    if ((rc = upload_tmp(ctx, f.d_perm, perm.data(), perm.size() * 4))) return rc;
   }
   {
     Family& f = ctx->surf;
@@ -1120,15 +1128,15 @@ int ensure_layout(lvx_ctx* ctx) {
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
     { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_SURFEL, sk, pick_chunk(ctx, 8, 16, "LVX_CHUNK_R", 2, 2.2)))) return rc; }
     auto ts = gather(f.t, perm, 1); auto pt = gather(f.a3, perm, 3); auto pl = gather(f.id0, perm, 1);
-    if ((rc = upload(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
-    if ((rc = upload(ctx, f.d_a3, pt.data(), pt.size() * 8))) return rc;
-    if ((rc = upload(ctx, f.d_id0, pl.data(), pl.size() * 4))) return rc;
-    if ((rc = upload(ctx, f.d_perm, perm.data(), perm.size() * 4))) return rc;
+    if ((rc = upload_tmp(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
+    if ((rc = upload_tmp(ctx, f.d_a3, pt.data(), pt.size() * 8))) return rc;
+    if ((rc = upload_tmp(ctx, f.d_id0, pl.data(), pl.size() * 4))) return rc;
+    if ((rc = upload_tmp(ctx, f.d_perm, perm.data(), perm.size() * 4))) return rc;
     // the fused kernel reads each row's plane from a row-ordered copy (planes are inputs, fixed between layouts): no dependent gather
     std::vector<double> rowpl((size_t)f.n * 3, 0.0);
     const long long npl = (long long)ctx->planes.size() / 3;
     for (int i = 0; i < f.n; ++i) if (pl[i] >= 0 && pl[i] < npl) for (int c = 0; c < 3; ++c) rowpl[3 * (size_t)i + c] = ctx->planes[3 * (size_t)pl[i] + c];
-    if ((rc = upload(ctx, f.d_b3, rowpl.data(), rowpl.size() * 8))) return rc;
+    if ((rc = upload_tmp(ctx, f.d_b3, rowpl.data(), rowpl.size() * 8))) return rc;
   }
   {
     Family& f = ctx->rep;
@@ -1145,22 +1153,22 @@ int ensure_layout(lvx_ctx* ctx) {
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return k1[a] != k1[b] ? k1[a] < k1[b] : f.id0[a] < f.id0[b]; });
     { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = k1[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_REPROJ, sk, pick_chunk(ctx, 24, 40, "LVX_CHUNK_R_REP")))) return rc; }
     auto ts = gather(f.t, perm, 1); auto uv = gather(f.a3, perm, 2); auto lm = gather(f.id0, perm, 1);
-    if ((rc = upload(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
-    if ((rc = upload(ctx, f.d_a3, uv.data(), uv.size() * 8))) return rc;
-    if ((rc = upload(ctx, f.d_id0, lm.data(), lm.size() * 4))) return rc;
-    if ((rc = upload(ctx, f.d_perm, perm.data(), perm.size() * 4))) return rc;
+    if ((rc = upload_tmp(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
+    if ((rc = upload_tmp(ctx, f.d_a3, uv.data(), uv.size() * 8))) return rc;
+    if ((rc = upload_tmp(ctx, f.d_id0, lm.data(), lm.size() * 4))) return rc;
+    if ((rc = upload_tmp(ctx, f.d_perm, perm.data(), perm.size() * 4))) return rc;
     std::vector<int> permB(f.n);
     std::iota(permB.begin(), permB.end(), 0);
     std::stable_sort(permB.begin(), permB.end(), [&](int a, int b) { return k0[a] != k0[b] ? k0[a] < k0[b] : (f.id0[a] != f.id0[b] ? f.id0[a] < f.id0[b] : f.t[a] < f.t[b]); });
     { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = k0[permB[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_PRIOR /* slot reused: the prior has no chunks */, sk, pick_chunk(ctx, 24, 40, "LVX_CHUNK_R_REP")))) return rc; }
     auto tsB = gather(f.t, permB, 1); auto uvB = gather(f.a3, permB, 2); auto lmB = gather(f.id0, permB, 1);
-    if ((rc = upload(ctx, ctx->d_repB[0], tsB.data(), tsB.size() * 8))) return rc;
-    if ((rc = upload(ctx, ctx->d_repB[1], uvB.data(), uvB.size() * 8))) return rc;
-    if ((rc = upload(ctx, ctx->d_repB[2], lmB.data(), lmB.size() * 4))) return rc;
+    if ((rc = upload_tmp(ctx, ctx->d_repB[0], tsB.data(), tsB.size() * 8))) return rc;
+    if ((rc = upload_tmp(ctx, ctx->d_repB[1], uvB.data(), uvB.size() * 8))) return rc;
+    if ((rc = upload_tmp(ctx, ctx->d_repB[2], lmB.data(), lmB.size() * 4))) return rc;
     std::vector<int> posA(f.n), idxA(f.n);
     for (int i = 0; i < f.n; ++i) posA[perm[i]] = i;
     for (int j = 0; j < f.n; ++j) idxA[j] = posA[permB[j]];
-    if ((rc = upload(ctx, ctx->d_repB[3], idxA.data(), idxA.size() * 4))) return rc;
+    if ((rc = upload_tmp(ctx, ctx->d_repB[3], idxA.data(), idxA.size() * 4))) return rc;
     if ((rc = dev_alloc(ctx, ctx->d_repB[0], (size_t)std::max(f.n, 1) * (2 * REP_NC + 2) * 8))) return rc;   // materialised Jacobians + residuals
     if ((rc = dev_alloc(ctx, ctx->d_repB[1], (size_t)std::max(f.n, 1) * 2 * 4))) return rc;                    // knot intervals
   }
@@ -1172,13 +1180,13 @@ int ensure_layout(lvx_ctx* ctx) {
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
     { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_CAMSURF, sk, pick_chunk(ctx, 8, 16, "LVX_CHUNK_R", 2, 2.2)))) return rc; }
     auto lm = gather(f.id0, perm, 1); auto pl = gather(f.id1, perm, 1);
-    if ((rc = upload(ctx, f.d_id0, lm.data(), lm.size() * 4))) return rc;
-    if ((rc = upload(ctx, f.d_id1, pl.data(), pl.size() * 4))) return rc;
-    if ((rc = upload(ctx, f.d_perm, perm.data(), perm.size() * 4))) return rc;
+    if ((rc = upload_tmp(ctx, f.d_id0, lm.data(), lm.size() * 4))) return rc;
+    if ((rc = upload_tmp(ctx, f.d_id1, pl.data(), pl.size() * 4))) return rc;
+    if ((rc = upload_tmp(ctx, f.d_perm, perm.data(), perm.size() * 4))) return rc;
   }
-  if ((rc = upload(ctx, ctx->d_planes, ctx->planes.data(), ctx->planes.size() * 8))) return rc;
-  if ((rc = upload(ctx, ctx->d_lm_uv, ctx->lm_uv.data(), ctx->lm_uv.size() * 8))) return rc;
-  if ((rc = upload(ctx, ctx->d_lm_t0, ctx->lm_t0.data(), ctx->lm_t0.size() * 8))) return rc;
+  if ((rc = upload_tmp(ctx, ctx->d_planes, ctx->planes.data(), ctx->planes.size() * 8))) return rc;
+  if ((rc = upload_tmp(ctx, ctx->d_lm_uv, ctx->lm_uv.data(), ctx->lm_uv.size() * 8))) return rc;
+  if ((rc = upload_tmp(ctx, ctx->d_lm_t0, ctx->lm_t0.data(), ctx->lm_t0.size() * 8))) return rc;
   // ---- hub knots (all surfel / cam-surfel residuals evaluate the trajectory at t_map: arrowhead) ----
   ctx->n_hub = 0; ctx->hub0 = 0;
   if (ctx->surf.n > 0 || ctx->cs.n > 0) {
@@ -1251,7 +1259,7 @@ int ensure_layout(lvx_ctx* ctx) {
   }
   ctx->bw = std::min(std::max(bw, 0), std::max(ctx->nb - 1, 0));
   // ---- buffers ----
-  if ((rc = upload(ctx, ctx->d_ord, ctx->ord.data(), ctx->ord.size() * 4))) return rc;
+  if ((rc = upload_tmp(ctx, ctx->d_ord, ctx->ord.data(), ctx->ord.size() * 4))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_Hb, (size_t)std::max(ctx->nb, 1) * (ctx->bw + 1) * 8 + 16))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_gb, (size_t)std::max(ctx->nb, 1) * 8 + 16))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_Bd, (size_t)ctx->nbd_ext * std::max(ctx->nb, 1) * 8 + 16))) return rc;
@@ -1273,7 +1281,7 @@ int ensure_layout(lvx_ctx* ctx) {
   if ((rc = upload_pairs(ctx, ctx->d_pairs[4], REP_NC + tC, cat(range(48, 54), range(55, 55 + tC))))) return rc;
   if ((rc = upload_pairs(ctx, ctx->d_pairs[5], CS_NC + tC, cat(range(0, 24), range(48, 60 + tC))))) return rc;
   ctx->force_legacy = false;
-  { static const int zero = 0; if ((rc = upload(ctx, ctx->d_zero, &zero, 4))) return rc; }
+  { static const int zero = 0; if ((rc = upload_tmp(ctx, ctx->d_zero, &zero, 4))) return rc; }
   ctx->cfg_version++;   // captured evaluation graphs of the previous layout are stale
   // ---- residual row offsets ----
   const int64_t cnt[LVX_NUM_FAM] = {ctx->imu.n, (locks & LVX_LOCK_R3) ? 0 : ctx->imu.n, ctx->has_prior ? 1 : 0, ctx->surf.n, ctx->rep.n, ctx->cs.n};
