@@ -87,6 +87,7 @@ struct lvx_ctx {
   bool force_legacy = false;   // set when the fast assembly kernels hit a case only the per-segment kernels handle exactly
   lvx::DevBuf d_pre;   // So3Pre[N]
   lvx::DevBuf d_hubs, d_chunk[LVX_NUM_FAM], d_repB[4];   // reprojection MFMA path: [0] materialised Jacobians + residuals, [1] knot intervals, [2] landmark and [3] observation-order index of the rows in (reference interval, landmark) order
+  int chunk_var[LVX_NUM_FAM] = {0};   // != 0: chunks of equal ROW count (first interval of chunk c at d_chunk[n_chunk + 1 + c]) instead of equal interval count
   int n_chunk[LVX_NUM_FAM] = {0}, chunk_r[LVX_NUM_FAM] = {0};   // workgroups and knot intervals per workgroup of the MFMA assembly kernels (pick_chunk)
   lvx::DevBuf d_ord, d_Hb, d_gb, d_Bd, d_C, d_gc, d_cost, d_err, d_state, d_res, d_jcols, d_jvals, d_pairs[LVX_NUM_FAM];
   // solver workspace (lvx_solver.hip)

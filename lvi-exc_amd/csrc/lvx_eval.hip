@@ -561,7 +561,7 @@ template <class F> size_t mfma_lds_bytes(int cr) {
 
 // CR = knot intervals per workgroup, chosen per problem by the host (pick_chunk) so that the workgroup count fills whole rounds of the CUs
 template <class F, int OCC>
-__global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, const int* __restrict__ chunk_off, long long row0, int CR) {
+__global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, const int* __restrict__ chunk_off, long long row0, int CR, int var_nch) {
   using G = MfmaGeom<F>;
   constexpr int NK = F::NK, NG = F::NG, NX = F::NX, NC = F::NCP, NR = F::NR, KPK = F::KPK, WS = F::WS, GL = F::GL, LB = F::LB;
   constexpr int NKL = G::NKL, NT = G::NT, LDP = G::LDP, PR = G::PR, XOFF = G::XOFF;
@@ -588,7 +588,8 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
 #else
 #define KT(i)
 #endif
-  const int k_lo = ch * CR - 1;
+  // var_nch == 0: chunk c covers the intervals [c CR, (c + 1) CR); else: chunks of equal row count, their first interval in the table behind the offsets
+  const int k_lo = (var_nch ? chunk_off[var_nch + 1 + ch] : ch * CR) - 1;
   const int nt = 6 * cm.N + 22 + cm.L;
   const bool want_ne = (cm.what & LVX_EVAL_NORMAL_EQ) != 0;
   for (int e = tid; e < ACC_LV * ACC_BW + NG * ACC_LV + NG * NG + ACC_LV + NG + 4 * PR * LDP; e += 256) sm[e] = 0.0;
@@ -1088,6 +1089,28 @@ static int pick_chunk_batches(int lo, int hi, const char* env, double rows_per_i
   }
   return best;
 }
+// Chunks of equal ROW count for the dense LiDAR families: a workgroup processes its rows in batches of 256 (4 wavefronts x 64), and chunks of
+// R intervals hold 40 R +- a few rows — e.g. 527 at R = 13: a third batch for 15 rows on one wavefront while three wait (15 % of the kernel).
+// Here every chunk has exactly `rows` rows (the last one fewer); a chunk may start or end inside an interval (the accumulators are
+// added to HBM atomically anyway) and spans at most rmax intervals (LDS accumulator size).
+static int upload_chunks_rows(lvx_ctx* ctx, int fam, const std::vector<int>& sorted_keys, int rmax, int rows) {
+  const int n = (int)sorted_keys.size();
+  std::vector<int> off, k0;
+  int i = 0;
+  do {
+    off.push_back(i);
+    const int kf = n > 0 ? std::max(0, sorted_keys[std::min(i, n - 1)]) : 0;
+    k0.push_back(kf);
+    int e = std::min(n, i + rows);
+    while (e > i + 1 && sorted_keys[e - 1] >= kf + rmax) --e;   // span limit (always at least one row)
+    i = std::max(e, i + (n > 0 ? 1 : 0));
+  } while (i < n);
+  off.push_back(n);
+  const int nch = (int)k0.size();
+  ctx->n_chunk[fam] = nch; ctx->chunk_r[fam] = rmax; ctx->chunk_var[fam] = 1;
+  off.insert(off.end(), k0.begin(), k0.end());
+  return upload_tmp(ctx, ctx->d_chunk[fam], off.data(), off.size() * 4);
+}
 static int upload_chunks(lvx_ctx* ctx, int fam, const std::vector<int>& sorted_keys, int R) {
   const int nch = (ctx->N + R - 1) / R + 1;
   std::vector<int> off(nch + 1);
@@ -1095,7 +1118,7 @@ static int upload_chunks(lvx_ctx* ctx, int fam, const std::vector<int>& sorted_k
     off[c] = c == 0 ? 0 : (int)(std::lower_bound(sorted_keys.begin(), sorted_keys.end(), c * R) - sorted_keys.begin());
   off[nch] = (int)sorted_keys.size();
   ctx->n_chunk[fam] = nch;
-  ctx->chunk_r[fam] = R;
+  ctx->chunk_r[fam] = R; ctx->chunk_var[fam] = 0;
   return upload_tmp(ctx, ctx->d_chunk[fam], off.data(), off.size() * 4);
 }
 
@@ -1126,7 +1149,9 @@ int ensure_layout(lvx_ctx* ctx) {
     for (int i = 0; i < f.n; ++i) key[i] = host_i0(ctx, f.t[i]);
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
-    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_SURFEL, sk, pick_chunk(ctx, 8, 16, "LVX_CHUNK_R", 2, 2.2)))) return rc; }
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if (getenv("LVX_CHUNK_R")) rc = upload_chunks(ctx, LVX_FAM_SURFEL, sk, pick_chunk(ctx, 8, 16, "LVX_CHUNK_R", 2, 2.2));
+      else rc = upload_chunks_rows(ctx, LVX_FAM_SURFEL, sk, 16, getenv("LVX_CHUNK_ROWS") ? atoi(getenv("LVX_CHUNK_ROWS")) : 512);
+      if (rc) return rc; }
     auto ts = gather(f.t, perm, 1); auto pt = gather(f.a3, perm, 3); auto pl = gather(f.id0, perm, 1);
     if ((rc = upload_tmp(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
     if ((rc = upload_tmp(ctx, f.d_a3, pt.data(), pt.size() * 8))) return rc;
@@ -1178,7 +1203,9 @@ int ensure_layout(lvx_ctx* ctx) {
     for (int i = 0; i < f.n; ++i) key[i] = (f.id0[i] >= 0 && f.id0[i] < L) ? host_i0(ctx, ctx->lm_t0[f.id0[i]]) : -1;
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
-    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_CAMSURF, sk, pick_chunk(ctx, 8, 16, "LVX_CHUNK_R", 2, 2.2)))) return rc; }
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if (getenv("LVX_CHUNK_R")) rc = upload_chunks(ctx, LVX_FAM_CAMSURF, sk, pick_chunk(ctx, 8, 16, "LVX_CHUNK_R", 2, 2.2));
+      else rc = upload_chunks_rows(ctx, LVX_FAM_CAMSURF, sk, 16, getenv("LVX_CHUNK_ROWS") ? atoi(getenv("LVX_CHUNK_ROWS")) : 512);
+      if (rc) return rc; }
     auto lm = gather(f.id0, perm, 1); auto pl = gather(f.id1, perm, 1);
     if ((rc = upload_tmp(ctx, f.d_id0, lm.data(), lm.size() * 4))) return rc;
     if ((rc = upload_tmp(ctx, f.d_id1, pl.data(), pl.size() * 4))) return rc;
@@ -1414,7 +1441,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
       const size_t lds_ = mfma_lds_bytes<FT>(ctx->chunk_r[chunk_slot]);                                                                      \
       LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_mfma<FT, OCCV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));       \
       hipLaunchKernelGGL((k_family_mfma<FT, OCCV>), dim3(ctx->n_chunk[chunk_slot]), dim3(256), lds_, stream, fam_obj, cm, (const int*)ctx->d_chunk[chunk_slot].p, (long long)(row0v), \
-                         ctx->chunk_r[chunk_slot]);                                                                                          \
+                         ctx->chunk_r[chunk_slot], ctx->chunk_var[chunk_slot] ? ctx->n_chunk[chunk_slot] : 0);                                \
     } while (0)
   #define LVX_LAUNCH_MFMA(FT, fam_obj, chunk_slot, stream, row0v)                                                                               \
     do { if ((occ_env ? occ_env : (int)FT::OCC) == 1) LVX_LAUNCH_MFMA1(FT, 1, fam_obj, chunk_slot, stream, row0v); else LVX_LAUNCH_MFMA1(FT, 2, fam_obj, chunk_slot, stream, row0v); } while (0)
