@@ -397,9 +397,20 @@ struct SurfAcc {
   __device__ int eval_row(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared* hub, const Row& row, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
     const bool tl = (cm.locks & LVX_LOCK_LIDAR_TAU) != 0;
     const double tk = row.t;
+    Segs segs;
+    if (tl) {   // locked offset: two point spans — the segment bookkeeping reduces to two interval indices unless the segments merge
+      KnotRef kr;
+      const int st = two_point_lookup(sp, t_map, tk, tk + cal.lidar.tau, &kr);
+      if (st >= 0) {
+        if (st == 1) return RES_RANGE;
+        if (hub->ok != 1) return hub->ok < 0 ? RES_NONUNIT : RES_RANGE;   // the hub's own lookup in its segment is the generic path's first lookup
+        if (st == 2) return RES_RANGE;
+        LVX_KT(aux.pw, 8)
+        return surfel_residual_pseudo<true>(sp, hub->A, segs, cal.lidar, tk, row.p, row.Pi, weight, &key, r, J, aux.pw, &kr);
+      }
+    }
     const double pad = tl ? 0.0 : cm.sensor_mto;
     const double spans[2][2] = {{t_map - pad, t_map + pad}, {tk - pad, tk + pad}};
-    Segs segs;
     if (!build_segments(sp, spans, 2, &segs)) return RES_RANGE;
     KnotRef kh;
     if (!seg_lookup(sp, segs, t_map + cal.lidar.tau, &kh)) return RES_RANGE;

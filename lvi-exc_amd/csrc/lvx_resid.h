@@ -82,6 +82,39 @@ LVX_HD bool seg_lookup(const SplineRef& sp, const Segs& s, double t, KnotRef* ou
   return false;
 }
 
+// Two point spans {t_a, t_a}, {t_b, t_b} (locked time offset: the hub time and a measurement time) and the lookup of te_b = t_b + offset:
+// exactly what build_segments + seg_lookup give for them, without building the segments, when the two 4-knot segments do not merge
+// (i1_b > i1_a + 3) and te_b does not fall into the first one.  Returns 0 (kb set as seg_lookup would), 1 (build_segments would fail),
+// 2 (seg_lookup(te_b) would fail), or -1: merged / overlapping segments — the caller takes the generic path.
+LVX_HD int two_point_lookup(const SplineRef& sp, double t_a, double t_b, double te_b, KnotRef* kb) {
+  if (sp.n < 4) return 1;
+  const double tmin = sp.t0, tmax = sp.t0 + (double)(sp.n - 3) * sp.dt;
+  if ((t_a < tmin) || (t_a >= tmax)) return 1;
+  if ((t_b < tmin) || (t_b >= tmax)) return 1;
+  if (t_b < t_a) return 1;
+  const int ia = (int)floor(quot_dt(t_a - sp.t0, sp.dt));
+  const int ib = (int)floor(quot_dt(t_b - sp.t0, sp.dt));
+  if (ib <= ia + 3) return -1;
+  {
+    const double t0s = sp.t0 + sp.dt * (double)ia, tm = t0s + (double)(4 - 3) * sp.dt;
+    double te = te_b;
+    bool in = (te >= t0s) && (te < tm);
+    if (!in) { te = te_b - 0.00001; in = (te >= t0s) && (te < tm); }
+    if (in) return -1;
+  }
+  const double t0s = sp.t0 + sp.dt * (double)ib, tm = t0s + (double)(4 - 3) * sp.dt;
+  double te = te_b;
+  bool in = (te >= t0s) && (te < tm);
+  if (!in) { te = te_b - 0.00001; in = (te >= t0s) && (te < tm); }
+  if (!in) return 2;
+  const double sc = quot_dt(te - t0s, sp.dt);
+  const int il = (int)floor(sc);
+  if (il != 0) return 2;
+  kb->i0 = ib + il;
+  kb->u = sc - (double)il;
+  return 0;
+}
+
 LVX_HD void load_so3_cp(const SplineRef& sp, int i0, quat c[4]) {
   for (int j = 0; j < 4; ++j) c[j] = load_q(sp.so3 + 4 * (i0 + j));
 }
@@ -331,9 +364,10 @@ LVX_HD void pose_pull_to_knots(const PoseVal& e, const So3Pre* pre, v3 gpos, v3 
 
 template <bool PRE = false>
 LVX_HD int surfel_residual_pseudo(const SplineRef& sp, const PoseEval& hub, const Segs& segs, const SensorCal& lidar, double t_k, v3 p_L, v3 Pi,
-                                  double weight, int* i0_k, double r[1], double J[1][SURFP_NC], const PreWin* pw = nullptr) {
+                                  double weight, int* i0_k, double r[1], double J[1][SURFP_NC], const PreWin* pw = nullptr, const KnotRef* kr_in = nullptr) {
   KnotRef kr;
-  if (!seg_lookup(sp, segs, t_k + lidar.tau, &kr)) return RES_RANGE;
+  if (kr_in) kr = *kr_in;   // the caller has done the lookup (two_point_lookup)
+  else if (!seg_lookup(sp, segs, t_k + lidar.tau, &kr)) return RES_RANGE;
   *i0_k = kr.i0;
   PoseEval k;
   PoseVal kv;

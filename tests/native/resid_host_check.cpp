@@ -172,3 +172,22 @@ extern "C" int hc_so3_pull_diff(const double* cps, double u, double dt, const do
   for (int k = 0; k < 4; ++k) { const v3 f = tmulv(a.dxi[k], g); out2[1] = mx(out2[1], mx(mx(std::fabs(f.x - y[k].x), std::fabs(f.y - y[k].y)), std::fabs(f.z - y[k].z))); }
   return oka == okb ? 0 : 1;
 }
+
+// two_point_lookup (fast path of the locked-offset LiDAR rows) against build_segments + seg_lookup: 0 = same outcome (or the fast path
+// defers to the generic one), 1 = different status, 2 = different knot reference; *code = the fast path's status
+extern "C" int hc_two_point_check(double t0, double dt, int n, double t_a, double t_b, double tau, int* code) {
+  const SplineRef sp{t0, dt, n, nullptr, nullptr};
+  KnotRef kf{0, 0.0}, kg{0, 0.0};
+  const int st = two_point_lookup(sp, t_a, t_b, t_b + tau, &kf);
+  const double spans[2][2] = {{t_a, t_a}, {t_b, t_b}};
+  Segs segs;
+  int g;
+  if (!build_segments(sp, spans, 2, &segs)) g = 1;
+  else if (!seg_lookup(sp, segs, t_b + tau, &kg)) g = 2;
+  else g = 0;
+  *code = st;
+  if (st == -1) return 0;
+  if (st != g) return 1;
+  if (st == 0 && (kf.i0 != kg.i0 || kf.u != kg.u)) return 2;
+  return 0;
+}

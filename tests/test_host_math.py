@@ -117,3 +117,29 @@ def test_so3_reverse_mode_pullback_matches_forward_jacobian(host_check_lib, spre
             worst = np.maximum(worst, out)
     assert worst[0] <= 1e-14 and worst[1] <= 5e-12
     assert (n_large < 200 or spread >= 2.0) and (spread < 2.0 or n_large > 0)
+
+
+def test_two_point_lookup_matches_segment_construction(host_check_lib):
+    """The locked-offset LiDAR rows skip build_segments / seg_lookup (lvx_resid.h: two_point_lookup): same status and bit-identical knot
+    reference on random times, knot-aligned times, offsets that leave the segment, out-of-range and unsorted spans."""
+    import ctypes as C
+    rng = np.random.default_rng(21)
+    t0, dt, n = 3.25, 0.02, 200
+    tmax = t0 + (n - 3) * dt
+    code = C.c_int(0)
+    seen = {-1: 0, 0: 0, 1: 0, 2: 0}
+    for it in range(20000):
+        mode = it % 5
+        if mode == 0:
+            ta, tb = np.sort(rng.uniform(t0 - 0.1, tmax + 0.1, 2))
+        elif mode == 1:   # knot-aligned times
+            ta = t0 + dt * rng.integers(0, n - 3); tb = t0 + dt * rng.integers(0, n - 3)
+        elif mode == 2:   # close together (merged segments)
+            ta = rng.uniform(t0, tmax - 0.2); tb = ta + rng.uniform(-0.01, 0.12)
+        else:
+            ta = rng.uniform(t0, t0 + 0.5); tb = rng.uniform(ta, tmax)
+        tau = [0.0, 1e-3, -1e-3, 0.019, -0.019, 1e-5, -1e-5, 0.07, -0.07, 5e-6][it % 10] if mode != 3 else rng.uniform(-0.03, 0.03)
+        rc = host_check_lib.hc_two_point_check(C.c_double(t0), C.c_double(dt), C.c_int(n), C.c_double(ta), C.c_double(tb), C.c_double(tau), C.byref(code))
+        assert rc == 0, (ta, tb, tau, code.value)
+        seen[code.value] += 1
+    assert seen[0] > 8000 and seen[-1] > 100 and seen[1] > 100 and seen[2] > 100, seen
