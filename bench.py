@@ -250,7 +250,7 @@ def main():
         # the surfel entry is the live one
         ctx.set_profiling(True); ctx.kernel_ms()
         for _ in range(5):
-            step()
+            ctx.evaluate_resident(what)   # rank 0 only: no collective here
         ctx.synchronize()
         msa, la = ctx.kernel_ms()
         ctx.set_profiling(False)
