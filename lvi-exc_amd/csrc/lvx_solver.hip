@@ -343,7 +343,10 @@ __global__ __launch_bounds__(256) void k_quad_band(const double* __restrict__ Hb
     q += (yb[i] * scale[i]) * t;
   }
   for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-  if (lane == 0 && q != 0.0) atomicAdd(&sums[5], q);
+  __shared__ double part[4];   // one atomic per workgroup: thousands of same-address atomics serialise in L2
+  if (lane == 0) part[threadIdx.x >> 6] = q;
+  __syncthreads();
+  if (threadIdx.x == 0) { const double t = part[0] + part[1] + part[2] + part[3]; if (t != 0.0) atomicAdd(&sums[5], t); }
 }
 __device__ __forceinline__ void qplus_dev(const double* x, const double* d, double* o) {   // EigenQuaternionParameterization::Plus
   const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
@@ -576,7 +579,7 @@ static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double* ou
   }
   hipLaunchKernelGGL(k_unscale, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, (const int*)c->d_ord.p, nt, (const double*)zb, (const double*)w.rhs, (const double*)w.scale,
                      (const double*)w.lmd, ir, (const double*)c->d_gb.p, (const double*)c->d_gc.p, nb, w.delta, w.sums);
-  if (nb > 0) hipLaunchKernelGGL(k_quad_band, dim3((unsigned)std::min(4096, (nb + 3) / 4)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)zb, (const double*)w.scale, nb, bw, w.sums);
+  if (nb > 0) hipLaunchKernelGGL(k_quad_band, dim3((unsigned)std::min(2048, (nb + 3) / 4)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)zb, (const double*)w.scale, nb, bw, w.sums);
   hipLaunchKernelGGL(k_quad, dim3((unsigned)((nb + nbd + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)c->d_Bd.p, (const double*)c->d_C.p, c->nbd_ext,
                      (const double*)zb, (const double*)w.rhs, (const double*)w.scale, nb, bw, nbd, w.sums);
   LVX_HIP(c, hipGetLastError());
