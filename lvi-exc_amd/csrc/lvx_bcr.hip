@@ -467,12 +467,15 @@ int bcr_backward(lvx_ctx* c, double* Zy, double* Zx, int ldz, int nrhs) {
 }
 // M (n x n, column-major) = Z^T Z for the tall-skinny Z [ldz x n], ldz = nblk * b.  Split-K by hand: one small GEMM per row block
 // (strided batched) into partial[nblk][n*n], then a reduction — rocBLAS' single GEMM picks a one-tile kernel for m = n = 53, k = 2e5.
-__global__ void k_sum_partials(const double* P, int nn, int nparts, double* M) {
+// (n*n is a few thousand entries, nparts ~ 800: the parts are split over blockIdx.y and added atomically into the zeroed M — one thread per
+// entry walking all parts was a 250 us latency chain on 11 workgroups)
+__global__ void k_sum_partials(const double* P, int nn, int nparts, int per, double* M) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nn) return;
+  const int p0 = blockIdx.y * per, p1 = min(nparts, p0 + per);
   double s = 0.0;
-  for (int p = 0; p < nparts; ++p) s += P[(size_t)p * nn + e];
-  M[e] = s;
+  for (int p = p0; p < p1; ++p) s += P[(size_t)p * nn + e];
+  if (s != 0.0) atomicAdd(&M[e], s);
 }
 int bcr_gram(lvx_ctx* c, const double* Z, int ldz, int n, double* M) {
   rocblas_handle h; int rc = bcr_handle(c, &h); if (rc) return rc;
@@ -483,7 +486,9 @@ int bcr_gram(lvx_ctx* c, const double* Z, int ldz, int n, double* M) {
   const double one = 1.0, zero = 0.0;
   LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, n, n, b, &one, Z, ldz, (rocblas_stride)b, Z, ldz, (rocblas_stride)b,
                                             &zero, P, n, (rocblas_stride)nn, nblk));
-  hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, c->stream, (const double*)P, (int)nn, nblk, M);
+  LVX_HIP(c, hipMemsetAsync(M, 0, nn * 8, c->stream));
+  const int per = 16;
+  hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((nn + 255) / 256), (unsigned)((nblk + per - 1) / per)), dim3(256), 0, c->stream, (const double*)P, (int)nn, nblk, per, M);
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
 }
