@@ -1187,7 +1187,10 @@ int ensure_layout(lvx_ctx* ctx) {
     }
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return k1[a] != k1[b] ? k1[a] < k1[b] : f.id0[a] < f.id0[b]; });
-    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = k1[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_REPROJ, sk, pick_chunk(ctx, 24, 40, "LVX_CHUNK_R_REP")))) return rc; }
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = k1[perm[i]]; // equal row count here too: 64 rows = one batch of 4 wavefronts x LB = 16 rows (33 intervals x 2 rows was 66: a second batch for 2 rows)
+      if (!getenv("LVX_CHUNK_R_REP")) rc = upload_chunks_rows(ctx, LVX_FAM_REPROJ, sk, 48, getenv("LVX_REP_ROWS") ? atoi(getenv("LVX_REP_ROWS")) : 4 * (int)RepObsAcc::LB);
+      else rc = upload_chunks(ctx, LVX_FAM_REPROJ, sk, pick_chunk(ctx, 24, 40, "LVX_CHUNK_R_REP"));
+      if (rc) return rc; }
     auto ts = gather(f.t, perm, 1); auto uv = gather(f.a3, perm, 2); auto lm = gather(f.id0, perm, 1);
     if ((rc = upload_tmp(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
     if ((rc = upload_tmp(ctx, f.d_a3, uv.data(), uv.size() * 8))) return rc;
@@ -1196,7 +1199,9 @@ int ensure_layout(lvx_ctx* ctx) {
     std::vector<int> permB(f.n);
     std::iota(permB.begin(), permB.end(), 0);
     std::stable_sort(permB.begin(), permB.end(), [&](int a, int b) { return k0[a] != k0[b] ? k0[a] < k0[b] : (f.id0[a] != f.id0[b] ? f.id0[a] < f.id0[b] : f.t[a] < f.t[b]); });
-    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = k0[permB[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_PRIOR /* slot reused: the prior has no chunks */, sk, pick_chunk(ctx, 24, 40, "LVX_CHUNK_R_REP")))) return rc; }
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = k0[permB[i]]; if (!getenv("LVX_CHUNK_R_REP")) rc = upload_chunks_rows(ctx, LVX_FAM_PRIOR /* slot reused: the prior has no chunks */, sk, 48, getenv("LVX_REP_ROWS") ? atoi(getenv("LVX_REP_ROWS")) : 4 * (int)RepRefAcc::LB);
+      else rc = upload_chunks(ctx, LVX_FAM_PRIOR, sk, pick_chunk(ctx, 24, 40, "LVX_CHUNK_R_REP"));
+      if (rc) return rc; }
     auto tsB = gather(f.t, permB, 1); auto uvB = gather(f.a3, permB, 2); auto lmB = gather(f.id0, permB, 1);
     if ((rc = upload_tmp(ctx, ctx->d_repB[0], tsB.data(), tsB.size() * 8))) return rc;
     if ((rc = upload_tmp(ctx, ctx->d_repB[1], uvB.data(), uvB.size() * 8))) return rc;
