@@ -172,3 +172,26 @@ def test_merged_hub_segment_corner_takes_the_exact_fallback():
         assert np.abs(rg["H"] - ro["H"]).max() <= 1e-10 * np.abs(ro["H"]).max()
     assert g.layout()["exact_fallback"] == 1          # the corner was detected, not missed
     g.close()
+
+
+def test_large_control_point_rotation_takes_the_exact_fallback():
+    """The fused kernels evaluate the SO3 factors with small-angle polynomials (|Omega| <= 0.8 rad half-angle between neighbouring control
+    points); a control point 2 rad away from its neighbours is marked in the pass's pair table and the evaluation is redone by the per-segment
+    kernels (generic sin / cos / log) — the result must equal the oracle's either way."""
+    P = synth.make_problem(seed=33, duration=1.5, n_surfel=500, n_planes=8, n_landmarks=20, n_camsurf=6)
+    o, g = _pair(P, TAU_LOCKS, prior=False)
+    N = P["n_knots"]
+    s = P["state0"].copy()
+    k = N // 2
+    q = s[3 * N + 4 * k:3 * N + 4 * k + 4].copy()            # (x, y, z, w) of control point k
+    s[3 * N + 4 * k:3 * N + 4 * k + 4] = synth.qmul(synth.q_from_rotvec(np.array([0.0, 0.0, 2.0])), q)
+    ro = o.evaluate(s, normal_eq=True)
+    assert g.layout()["exact_fallback"] == 0
+    for jac in (False, True, False):
+        rg = g.evaluate(s, jac=jac, normal_eq=True)
+        assert abs(rg["cost"] - ro["cost"]) <= 1e-12 * abs(ro["cost"])
+        assert np.abs(rg["residuals"] - ro["residuals"]).max() <= 1e-11 * np.abs(ro["residuals"]).max()
+        assert np.abs(rg["H"] - ro["H"]).max() <= 1e-10 * np.abs(ro["H"]).max()
+        assert np.abs(rg["g"] - ro["g"]).max() <= 1e-10 * np.abs(ro["g"]).max()
+    assert g.layout()["exact_fallback"] == 1
+    g.close()
