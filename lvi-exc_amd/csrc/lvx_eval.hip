@@ -430,9 +430,20 @@ struct CamSurfAcc {
     const bool tl = (cm.locks & LVX_LOCK_CAM_TAU) != 0;
     const int l = lm[si];
     const double tk = lm_t0[l];
+    Segs segs;
+    if (tl) {   // locked offset: two point spans (see SurfAcc::eval_row)
+      KnotRef kr;
+      const int st = two_point_lookup(sp, t_map, tk, tk + cal.cam.tau, &kr);
+      if (st >= 0) {
+        if (st == 1) return RES_RANGE;
+        if (hub->ok != 1) return hub->ok < 0 ? RES_NONUNIT : RES_RANGE;
+        if (st == 2) return RES_RANGE;
+        return camsurf_residual_pseudo<true>(sp, hub->A, segs, cm.cam, cal.cam, cal.lidar, lm_uv[2 * l], lm_uv[2 * l + 1], tk, cal.rho[l],
+                                             load_v3(planes + 3 * (size_t)plane[si]), weight, &key, r, J, aux.pw, &kr);
+      }
+    }
     const double pad = tl ? 0.0 : cm.sensor_mto;
     const double spans[2][2] = {{t_map - pad, t_map + pad}, {tk - pad, tk + pad}};
-    Segs segs;
     if (!build_segments(sp, spans, 2, &segs)) return RES_RANGE;
     KnotRef kh;
     if (!seg_lookup(sp, segs, t_map + cal.cam.tau, &kh)) return RES_RANGE;

@@ -576,9 +576,11 @@ LVX_HD int camsurf_residual(const SplineRef& sp, const PoseEval& hub, const Segs
 enum { CSP_NC = 42 };
 template <bool PRE = false>
 LVX_HD int camsurf_residual_pseudo(const SplineRef& sp, const PoseEval& hub, const Segs& segs, const CamIntr& ci, const SensorCal& cam, const SensorCal& lidar,
-                                   double u_ref, double v_ref, double t0_ref, double rho, v3 Pi, double weight, int* i0_k, double r[1], double J[1][CSP_NC], const PreWin* pw = nullptr) {
+                                   double u_ref, double v_ref, double t0_ref, double rho, v3 Pi, double weight, int* i0_k, double r[1], double J[1][CSP_NC], const PreWin* pw = nullptr,
+                                   const KnotRef* kr_in = nullptr) {
   KnotRef kr;
-  if (!seg_lookup(sp, segs, t0_ref + cam.tau, &kr)) return RES_RANGE;
+  if (kr_in) kr = *kr_in;   // the caller has done the lookup (two_point_lookup)
+  else if (!seg_lookup(sp, segs, t0_ref + cam.tau, &kr)) return RES_RANGE;
   *i0_k = kr.i0;
   PoseEval k;
   PoseVal kv;
