@@ -41,7 +41,8 @@ LVX_HD bool build_segments(const SplineRef& sp, const double spans[][2], int nsp
   if (sp.n < 4) return false;
   const double tmin = sp.t0, tmax = sp.t0 + (double)(sp.n - 3) * sp.dt;
   double t1_prev = 0.0;
-  s->nseg = 0;
+  // at most two segments: kept in scalars (a dynamically indexed i1[] / n[] would live in scratch memory on the GPU)
+  int nseg = 0, i1a = 0, i1b = 0, na = 0, nb = 0;
   int cur_start = 0, cur_end = -1;
   for (int k = 0; k < nspans; ++k) {
     const double t1 = spans[k][0], t2 = spans[k][1];
@@ -52,29 +53,34 @@ LVX_HD bool build_segments(const SplineRef& sp, const double spans[][2], int nsp
     int i1 = (int)floor(quot_dt(t1 - sp.t0, sp.dt));
     const int i2 = (int)floor(quot_dt(t2 - sp.t0, sp.dt));
     if (i1 > cur_end) {
-      s->i1[s->nseg] = i1; s->n[s->nseg] = 0; s->nseg += 1;
+      if (nseg == 0) { i1a = i1; na = 0; } else { i1b = i1; nb = 0; }
+      nseg += 1;
       cur_start = i1;
     } else {
       i1 = cur_end + 1;
     }
-    const int cs = s->nseg - 1;
-    if (i2 + 4 > i1) s->n[cs] += (i2 + 4 - i1);
-    cur_end = cur_start + s->n[cs] - 1;
+    const int add = (i2 + 4 > i1) ? (i2 + 4 - i1) : 0;
+    if (nseg == 1) na += add; else nb += add;
+    cur_end = cur_start + (nseg == 1 ? na : nb) - 1;
   }
+  s->nseg = nseg; s->i1[0] = i1a; s->i1[1] = i1b; s->n[0] = na; s->n[1] = nb;
   return true;
 }
 LVX_HD bool seg_lookup(const SplineRef& sp, const Segs& s, double t, KnotRef* out) {
-  for (int k = 0; k < s.nseg; ++k) {
-    const double t0s = sp.t0 + sp.dt * (double)s.i1[k];
-    const double tmax = t0s + (double)(s.n[k] - 3) * sp.dt;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {   // constant indices: the two segments stay in registers
+    if (k >= s.nseg) break;
+    const int i1 = k == 0 ? s.i1[0] : s.i1[1], n = k == 0 ? s.n[0] : s.n[1];
+    const double t0s = sp.t0 + sp.dt * (double)i1;
+    const double tmax = t0s + (double)(n - 3) * sp.dt;
     double te = t;
     bool in = (te >= t0s) && (te < tmax);
     if (!in) { te = t - 0.00001; in = (te >= t0s) && (te < tmax); }
     if (in) {
       const double sc = quot_dt(te - t0s, sp.dt);
       const int il = (int)floor(sc);
-      if ((s.n[k] < 4) || (il < 0) || (il > (s.n[k] - 4))) return false;
-      out->i0 = s.i1[k] + il;
+      if ((n < 4) || (il < 0) || (il > (n - 4))) return false;
+      out->i0 = i1 + il;
       out->u = sc - (double)il;
       return true;
     }
