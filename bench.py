@@ -27,13 +27,13 @@ sys.path.insert(0, os.path.join(ROOT, "lvi-exc_amd"))
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6      # MI355X FP64: vector 78.6 TFLOP/s = matrix (v_mfma_f64_16x16x4_f64) 78.6 TFLOP/s
 # algorithmic bytes per residual block, SURVEY.md §8(d)
-# HBM bytes per launch of k_family_mfma<SurfAcc> at config 4 from the PMC counters (FETCH_SIZE 33.1 MB + WRITE_SIZE 69.3 MB per dispatch with
+# HBM bytes per launch of k_family_mfma<SurfAcc> at config 4 from the PMC counters (FETCH_SIZE 32.8 MB + WRITE_SIZE 59.0 MB per dispatch with
 # normal equations; KiB -> bytes; FETCH_SIZE is not doubled: these are 8-byte strided reads, not the 16 B/lane streams the guide's x2
 # correction was calibrated on).  Reads: 56 B of row inputs per block (t, point, row-ordered plane) = 56 MB would be the cold figure, the
 # counter sees 33 MB (the rest hits the 256 MB Infinity Cache from the previous pass); writes: the accumulator flushes (one atomic per touched
 # band / border entry per workgroup, 1954 workgroups) — the register-spill scratch of the earlier rounds (232 MB) is gone.
-PMC_TRAFFIC_BYTES = 102.4e6
-PMC_SOURCE = "profiles/r01i_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per dispatch)"
+PMC_TRAFFIC_BYTES = 91.8e6
+PMC_SOURCE = "profiles/r01j_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per dispatch)"
 BYTES_PER_EVAL = {"imu": 32, "surfel": 60, "reproj": 60}
 FLOPS_PER_EVAL = {"imu": 4e3, "surfel": 9e3, "reproj": 11e3}
 
