@@ -168,7 +168,7 @@ def main():
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)   # evaluation, export and the all-reduce share one stream
     what = lvx.EVAL_COST | lvx.EVAL_NORMAL_EQ
     nbd = lo["border_ld"]
-    red = torch.zeros(nbd * nbd + nbd + 1, dtype=torch.float64, device="cuda") if world > 1 else None
+    red = torch.zeros(nbd * nbd + nbd + 2, dtype=torch.float64, device="cuda") if world > 1 else None
 
     def step():
         ctx.evaluate_resident(what)
@@ -257,14 +257,14 @@ def main():
         out["kernel_ms"] = {lvx.KERNEL_NAMES[i]: msa[i] / max(1, la[i]) for i in range(len(msa)) if la[i]}
         out["kernel_ms"][lvx.KERNEL_NAMES[k]] = surf_ms
         if world == 1:   # solo durations: the same step with every family kernel on one stream (outside the timed region)
-            os.environ["LVX_SERIAL"] = "1"
+            ctx.set_switch("SERIAL", 1)
             ctx.set_profiling(True); ctx.kernel_ms()
             for _ in range(5):
                 step()
             ctx.synchronize()
             ms1, l1 = ctx.kernel_ms()
             ctx.set_profiling(False)
-            del os.environ["LVX_SERIAL"]
+            ctx.set_switch("SERIAL", 0)
             out["kernel_ms_solo"] = {lvx.KERNEL_NAMES[i]: ms1[i] / max(1, l1[i]) for i in range(len(ms1)) if l1[i]}
         if world == 1 and not args.no_secondary:
             out["secondary"] = secondary_metrics(ctx, P, lo)

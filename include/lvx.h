@@ -126,6 +126,9 @@ int lvx_set_reproj(lvx_ctx* ctx, int n, const int32_t* landmark_id, const double
 /* CameraSurfelLandmark blocks (trajectory_manager_lvi.cpp:584-606) */
 int lvx_set_camsurf(lvx_ctx* ctx, int n, const int32_t* landmark_id, const int32_t* plane_id, double t_map, double huber, double weight);
 int lvx_set_locks(lvx_ctx* ctx, uint32_t lock_mask);
+/* experiment / debug switches.  They are read once from the environment (LVX_<NAME>) by lvx_create; this call changes one on a
+ * live context (name with or without the LVX_ prefix, e.g. "FORCE_LEGACY", 1).  Unknown name: LVX_E_ARG. */
+int lvx_set_switch(lvx_ctx* ctx, const char* name, int value);
 /* max |time offset| bounds used to widen spans when a time offset is free (sensors.h:161-162; trajectory_manager_lvi.h:118-119) */
 int lvx_set_time_offset_bounds(lvx_ctx* ctx, double imu_max, double sensor_max);
 
@@ -147,8 +150,10 @@ int lvx_get_jacobian(lvx_ctx* ctx, int32_t* cols, double* vals);
 /* run on a caller-owned HIP stream (e.g. torch's current stream) instead of the context's own; NULL restores the own stream */
 int lvx_set_stream(lvx_ctx* ctx, void* hip_stream);
 /* multi-GPU (one calibration sequence per GPU): copy the dense border block of the last normal equations —
- * C[border_ld^2] (lower triangle), g_c[border_ld], cost — into a caller-owned DEVICE buffer of border_ld^2 + border_ld + 1 doubles,
- * queued on the context's stream, ready for one RCCL all-reduce */
+ * C[border_ld^2] (lower triangle), g_c[border_ld], cost, error word — into a caller-owned DEVICE buffer of border_ld^2 + border_ld + 2 doubles,
+ * queued on the context's stream, ready for one RCCL all-reduce.  The last double is the pass's device error word (0 = every residual block
+ * was evaluated): after a sum over the ranks a non-zero value tells EVERY rank that some rank's sums are incomplete, with no host
+ * synchronisation in between (lvx_synchronize returns the matching error code on the rank that produced it). */
 int lvx_export_border_d(lvx_ctx* ctx, double* out_d);
 /* keep `state` resident in the context's device buffer; lvx_evaluate_d(ctx, NULL, ...) then evaluates it without any host traffic */
 int lvx_set_state(lvx_ctx* ctx, const double* state);
@@ -198,7 +203,8 @@ int lvx_lm_default_options(lvx_lm_options* opt);
 int lvx_lm_solve(lvx_ctx* ctx, double* state, const lvx_lm_options* opt, lvx_lm_summary* summary);
 /* per-iteration trace of the last lvx_lm_solve: cost after the iteration, trust-region radius, accepted (1) / rejected (0) / invalid (-1); returns count */
 int lvx_lm_get_history(lvx_ctx* ctx, int max_n, double* cost, double* radius, int32_t* accepted);
-/* one damped solve on the normal equations of the last LVX_EVAL_NORMAL_EQ evaluation:
+/* one damped solve on the normal equations of the last LVX_EVAL_NORMAL_EQ evaluation (if that evaluation was queued without a cost pointer its
+ * device error word is read first: the exact kernels re-run a pass that needs them, a range / unit-quaternion error is returned):
  * (S H S + clamp(diag(S H S), 1e-6, 1e32) / radius) y = -S g, delta = S y (S = Jacobi scaling or identity); delta[n_tangent] on the host */
 int lvx_solve_step(lvx_ctx* ctx, double radius, int jacobi_scaling, double* delta, double* model_cost_change);
 

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void k_potrf_batched(double* Dm, int b, long l
 }
 // potrf of `batch` blocks: own kernel when the triangle fits into LDS, rocSOLVER otherwise (or with LVX_BCR_ROCSOLVER_POTRF)
 static int potrf_batched(lvx_ctx* c, rocblas_handle h, double* D, int b, long long strideD, int* info, int batch) {
-  static const bool force_lib = getenv("LVX_BCR_ROCSOLVER_POTRF") != nullptr;
+  const bool force_lib = c->sw.bcr_rocsolver_potrf != 0;
   const size_t lds = ((size_t)b * (b + 1) / 2 + 16) * 8;
   if (force_lib || lds > 159 * 1024) {
     LVX_BLAS(c, rocsolver_dpotrf_strided_batched(h, rocblas_fill_lower, b, D, b, (rocblas_stride)strideD, info, batch));
@@ -378,12 +378,12 @@ int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_ra
   double* D = (double*)c->d_bcrD.p; double* G = (double*)c->d_bcrG.p; int* info = (int*)c->d_bcrInfo.p;
   hipStream_t st = c->stream;
   const size_t tot = 2 * (size_t)nblk * bb;
-  hipLaunchKernelGGL(k_bcr_build, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, scale, lmd, inv_radius, c->nb, c->bw, b, nblk, D, G);
+  hipLaunchKernelGGL(k_bcr_build, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, c->p_Hs ? c->p_Hs : (const double*)c->d_Hb.p, scale, lmd, inv_radius, c->nb, c->bw, b, nblk, D, G);
   LVX_HIP(c, hipMemsetAsync(info, 0, (size_t)(2 * nblk + 8) * 4, st));
   const double one = 1.0, mone = -1.0, zero = 0.0;
   int L = 0; while ((1 << L) < nblk) ++L;
   int info_pos = 0;
-  const bool use_gemm = !getenv("LVX_BCR_SYRK");
+  const bool use_gemm = !c->sw.bcr_syrk;
   for (int l = 0; l < L; ++l) {
     const int s = 1 << l, n2 = (nblk >> l) / 2;
     const long long sD = (long long)2 * s * bb, sG = (long long)2 * bb;

@@ -11,6 +11,7 @@
 
 #define LVX_NREP 64                 // replicas of the dense border accumulators (spreads same-address atomics)
 #define LVX_DEAD (-2147483647 - 1)  // ord[] value of a constant (locked) tangent scalar
+#define LVX_LM_BASE 0x40000000       // ord[] value of landmark l (inverse depth): LVX_LM_BASE + l — landmarks live in their own rows (DevCommon::lmH), not in the band
 #define LVX_ERR_FALLBACK 16         // device error bit: fast assembly kernel met a corner it does not handle; re-run with the legacy kernels
 
 namespace lvx {
@@ -35,6 +36,11 @@ struct DevCommon {
   double* Bd;    // [nbd][nb]
   double* C;     // [LVX_NREP][nbd*nbd] (lower triangle used)
   double* gc;    // [LVX_NREP][nbd]
+  // landmark rows: the inverse depth of landmark l couples to the band positions [lm_p0[l], lm_p0[l] + lm_wl) (the knots its views touch), to
+  // border variables (camera extrinsics, hub knots) and to itself; no two landmarks share a residual, so the landmark block of J^T J is
+  // diagonal and the solver eliminates it first (what Ceres' SPARSE_SCHUR does with its e-blocks).
+  // lmH[l * lm_ls + ...] = [ band couplings (lm_wl) | border couplings (nbd) | H_ll | g_l ]
+  double* lmH; const int* lm_p0; int lm_wl, lm_ls;
   double* cost;  // [LVX_NREP]
   int* err;      // bit0 range, bit1 non-unit quaternion, bit2 band overflow
   // outputs (may be null)
@@ -47,6 +53,16 @@ struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
 };
+
+// Experiment / debug switches: read ONCE from the environment (LVX_<NAME>) when the context is created and changed afterwards only
+// through lvx_set_switch — the evaluation path never calls getenv.
+struct Switches {
+  int force_legacy = 0, imu_legacy = 0, reproj_legacy = 0, serial = 0, sched = 2, imu_two_streams = 0, occ = 0, jac_late = 0, fold_one = 0, fold_inline = 0,
+      no_graph = 0, sync_nofence = 0, chunk_r = 0, chunk_r_imu = 0, chunk_r_rep = 0, chunk_rows = 0, rep_rows = 0, solver_seq = 0, solver_timing = 0,
+      bcr_rocsolver_potrf = 0, bcr_syrk = 0, deterministic = 0, clear_all = 0, cross_dbg = 0;
+};
+struct SwitchName { const char* name; int Switches::*field; bool relayout; };
+const SwitchName* switch_table(int* count);
 
 struct Family {
   int n = 0;
@@ -84,8 +100,12 @@ struct lvx_ctx {
   bool layout_dirty = true;
   std::vector<int> ord;
   int nb = 0, bw = 0, nbd = 0, nbd_ext = 0, n_hub = 0, hub0 = 0;   // nbd: solve border (hub knots + 22 calib); nbd_ext = nbd + 12 pseudo rows
+  lvx::Switches sw;
+  int rep_groups = 0;          // (reference window, observation window) groups of the reprojection cross-term kernel (d_repB[2])
   bool force_legacy = false;   // set when the fast assembly kernels hit a case only the per-segment kernels handle exactly
   lvx::DevBuf d_pre;   // So3Pre[N]
+  lvx::DevBuf d_lmH, d_lm_p0, d_Hr, d_Br, d_red; int lm_wl = 0, lm_ls = 0; const double* p_Hs = nullptr;   // landmark rows (DevCommon::lmH); solver: band / border rows / [g_b | C | g_c] after the landmark elimination
+  lvx::DevBuf d_colfull; int clear_npre = 0; std::vector<uint8_t> bd_row_live;   // structural clear of the band / border rows (k_clear)
   lvx::DevBuf d_hubs, d_chunk[LVX_NUM_FAM], d_repB[4];   // reprojection MFMA path: [0] materialised Jacobians + residuals, [1] knot intervals, [2] landmark and [3] observation-order index of the rows in (reference interval, landmark) order
   int chunk_var[LVX_NUM_FAM] = {0};   // != 0: chunks of equal ROW count (first interval of chunk c at d_chunk[n_chunk + 1 + c]) instead of equal interval count
   int n_chunk[LVX_NUM_FAM] = {0}, chunk_r[LVX_NUM_FAM] = {0};   // workgroups and knot intervals per workgroup of the MFMA assembly kernels (pick_chunk)
@@ -99,6 +119,7 @@ struct lvx_ctx {
   int64_t n_blocks = 0, n_residuals = 0;
   int64_t fam_row0[LVX_NUM_FAM + 1] = {0};
   uint32_t last_what = 0;
+  const double* last_state_d = nullptr; bool last_want_res = false, err_unchecked = false;   // see check_last_eval
   // upstream kernels (lvx_upstream.hip)
   lvx::DevBuf d_up[8];
   int sr_n = 0, sr_rings = 0, sr_m = 0;   // input size, rings and kept points of the last lvx_scan_register (its results stay in d_up[0])
@@ -134,6 +155,7 @@ int fail(lvx_ctx* ctx, int code, const std::string& msg);
 int dev_alloc(lvx_ctx* ctx, DevBuf& b, size_t bytes);
 int upload(lvx_ctx* ctx, DevBuf& b, const void* src, size_t bytes);
 int ensure_layout(lvx_ctx* ctx);
+int check_last_eval(lvx_ctx* ctx);
 DevCommon make_common(lvx_ctx* ctx, const double* state_d, uint32_t what);
 int bcr_plan(lvx_ctx* c);
 int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_radius, int* info_out_d);

@@ -166,6 +166,14 @@ using ReprojFam = ReprojFamT<false>;
 // routing of one normal-equation entry into the structured storage
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void add_H(const DevCommon& cm, int pa, int pb, double v, int rep) {
+  if (pa >= LVX_LM_BASE || pb >= LVX_LM_BASE) {   // an entry of a landmark's row
+    const int l = (pa >= LVX_LM_BASE ? pa : pb) - LVX_LM_BASE, o = pa >= LVX_LM_BASE ? pb : pa;
+    double* row = cm.lmH + (size_t)l * cm.lm_ls;
+    if (o >= LVX_LM_BASE) atomicAdd(&row[cm.lm_wl + cm.nbd], v);
+    else if (o >= 0) { const int k = o - cm.lm_p0[l]; if (k < 0 || k >= cm.lm_wl) { atomicOr(cm.err, 4); return; } atomicAdd(&row[k], v); }
+    else atomicAdd(&row[cm.lm_wl + (-1 - o)], v);
+    return;
+  }
   if (pa >= 0 && pb >= 0) {
     const int i = pa > pb ? pa : pb, j = pa > pb ? pb : pa, d = i - j;
     if (d > cm.bw) { atomicOr(cm.err, 4); return; }
@@ -180,7 +188,8 @@ __device__ __forceinline__ void add_H(const DevCommon& cm, int pa, int pb, doubl
   }
 }
 __device__ __forceinline__ void add_g(const DevCommon& cm, int pc, double v, int rep) {
-  if (pc >= 0) atomicAdd(&cm.gb[pc], v);
+  if (pc >= LVX_LM_BASE) atomicAdd(&cm.lmH[(size_t)(pc - LVX_LM_BASE) * cm.lm_ls + cm.lm_wl + cm.nbd + 1], v);
+  else if (pc >= 0) atomicAdd(&cm.gb[pc], v);
   else atomicAdd(&cm.gc[(size_t)rep * cm.nbd + (-1 - pc)], v);
 }
 
@@ -363,11 +372,10 @@ __device__ __forceinline__ void state_prepass_block(const DevCommon& cm, So3Pre*
 // per-row extras of the MFMA path: window id (rows with wid in [w, w + WS) share a window; default = knot interval), and for the
 // reprojection families the knot interval of the OTHER pose and the landmark
 struct Aux { int wid, xk, lm; const PreWin* pw; };   // pw: the workgroup's precomputed control-point-pair table (lvx_math.h: So3Pre)
-// traits: NK knot columns (4 knots x KPK, at offset LVO of the knot's 6 tangent scalars) | NG global columns | NX cross columns (kept in the
-// panel for the direct cross-term scatter); WS knot intervals per MFMA window; GL lanes per panel; SKIP_GG: global x global and the global
-// gradient are assembled by another pass; SECONDARY: no cost / residual output; LMCOL: global column that is the window's landmark (or -1)
+// traits: NK knot columns (4 knots x KPK, at offset LVO of the knot's 6 tangent scalars) | NG global columns; WS knot intervals per MFMA window; GL lanes per panel;
+// SKIP_GG: global x global and the global gradient are assembled by another pass; SECONDARY: no cost / residual output
 struct GyroAcc {
-  enum { NK = 12, NG = 3, NR = 3, HUB = -1, KPK = 3, LVO = 3, WS = 1, GL = 8, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 15, USE_PRE = 1, OCC = 1 };
+  enum { NK = 12, NG = 3, NR = 3, HUB = -1, KPK = 3, LVO = 3, WS = 1, GL = 8, SKIP_GG = 0, SECONDARY = 0, LB = 64, NCP = 15, USE_PRE = 1, OCC = 1 };
   __device__ static constexpr int jm(int c) { return c; }   // KPK columns per knot at offset LVO of its 6 tangent scalars; WS = knot intervals per MFMA window; GL = lanes per panel
   int n; const double* t; const double* m3; const int* perm; double weight, huber;
   __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared*, int si, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
@@ -377,7 +385,7 @@ struct GyroAcc {
   __device__ static int gcol(int g, int N, int nt) { return 6 * N + 5 + g; }
 };
 struct AccelAcc {
-  enum { NK = 24, NG = 5, NR = 3, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 8, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 29, USE_PRE = 1, OCC = 1 };
+  enum { NK = 24, NG = 5, NR = 3, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 8, SKIP_GG = 0, SECONDARY = 0, LB = 64, NCP = 29, USE_PRE = 1, OCC = 1 };
   __device__ static constexpr int jm(int c) { return c; }
   int n; const double* t; const double* m3; const int* perm; double weight, huber;
   __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared*, int si, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
@@ -387,7 +395,7 @@ struct AccelAcc {
   __device__ static int gcol(int g, int N, int nt) { return 6 * N + g; }
 };
 struct SurfAcc {
-  enum { NK = 24, NG = 12, NR = 1, HUB = 0, KPK = 6, LVO = 0, WS = 2, GL = 16, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 36, USE_PRE = 1, OCC = 2 };   // reverse-mode Jacobian: fits two wavefronts per SIMD with a few spills, and two workgroups per CU hide its latencies
+  enum { NK = 24, NG = 12, NR = 1, HUB = 0, KPK = 6, LVO = 0, WS = 2, GL = 16, SKIP_GG = 0, SECONDARY = 0, LB = 64, NCP = 36, USE_PRE = 1, OCC = 2 };   // reverse-mode Jacobian: fits two wavefronts per SIMD with a few spills, and two workgroups per CU hide its latencies
   __device__ static constexpr int jm(int c) { return c; }
   int n; const double* t; const double* pt; const double* rowpl; const int* perm; double t_map, weight, huber;   // rowpl: the row's plane (gathered at layout time: no dependent load)
   // raw inputs of a row, loaded one batch ahead of their use: the HBM latency hides behind the previous batch's assembly
@@ -423,7 +431,7 @@ struct SurfAcc {
   __device__ static int gcol(int g, int N, int nt) { return g < 6 ? nt + g : 6 * N + 8 + (g - 6); }
 };
 struct CamSurfAcc {
-  enum { NK = 24, NG = 18, NR = 1, HUB = 1, KPK = 6, LVO = 0, WS = 1, GL = 16, NX = 0, SKIP_GG = 0, SECONDARY = 0, LMCOL = -1, LB = 64, NCP = 42, USE_PRE = 1, OCC = 2 };
+  enum { NK = 24, NG = 18, NR = 1, HUB = 1, KPK = 6, LVO = 0, WS = 1, GL = 16, SKIP_GG = 0, SECONDARY = 0, LB = 64, NCP = 42, USE_PRE = 1, OCC = 2 };
   __device__ static constexpr int jm(int c) { return c; }
   int n; const int* lm; const int* plane; const int* perm; const double* planes; const double* lm_uv; const double* lm_t0; double t_map, weight, huber;
   __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared* hub, int si, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
@@ -456,52 +464,38 @@ struct CamSurfAcc {
   __device__ static int gcol(int g, int N, int nt) { return g < 6 ? nt + 6 + g : (g < 12 ? 6 * N + 15 + (g - 6) : 6 * N + 8 + (g - 12)); }
 };
 
-// Rolling-shutter reprojection on the MFMA path, in two passes over the same blocks (the Jacobians are evaluated twice; the kernel is bound
-// by atomics, not arithmetic):
-//   RepObsAcc: rows sorted by the OBSERVATION's knot interval.  [obs knots | camera] go through the chunk accumulators (views of one frame
-//              share them); the cross terms obs x [ref knots | rho] — unique to a (landmark, view) pair — are scattered directly.
-//              Cycle counters inside this pass: 40 % of its time is the issue of those atomics — a CU retires one FP64 atomic lane every
-//              ~3.75 cycles (tools/probes/atomic_bw.hip: 143 G/s over 256 CUs), i.e. 240 cycles per 64-lane instruction — so 30 M atomics
-//              cost >= 0.21 ms however they are arranged; the pass takes 0.41 ms.
-//   RepRefAcc: rows sorted by (reference interval, landmark); window = one landmark.  [ref knots | camera | rho] x same + the gradient of
-//              all three; rho's entries leave at the end of the landmark's window.
-// Together 600 direct atomics per block + the chunk flushes instead of 1595 per block in k_family<ReprojFam>.
-struct RepJac { const double* J; const double* r; const int* k; int n; };   // k_reproj_jac output, observation order: J[(a * REP_NC + c) * n + i], r[a * n + i], k[i] = ref interval, k[n + i] = obs interval (-1: skipped)
-__device__ __forceinline__ int repjac_load(const RepJac& b, int i, double r[2], double (*J)[REP_NC], int* k0, int* k1) {
-  *k0 = b.k[i]; *k1 = b.k[b.n + i];
-  if (*k1 < 0) return -1;
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    r[a] = b.r[(size_t)a * b.n + i];
-#pragma unroll
-    for (int c = 0; c < REP_NC; ++c) J[a][c] = b.J[(size_t)(a * REP_NC + c) * b.n + i];
-  }
-  return RES_OK;
-}
-struct RepObsAcc {
-  enum { NK = 24, NG = 6, NR = 2, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 8, NX = 25, SKIP_GG = 1, SECONDARY = 1, LMCOL = -1, LB = 16, NCP = REP_NC, USE_PRE = 0, FTAB = 1 };
-  __device__ static constexpr int jm(int c) { return c < 24 ? 24 + c : (c < 30 ? 48 + (c - 24) : (c < 54 ? c - 30 : 54)); }   // [obs | cam | ref | rho] of reproj_residual's [ref | obs | cam | rho]
-  int n; const int* lm; const int* perm; RepJac jac; double huber;
+// Rolling-shutter reprojection on the fast path.  k_reproj_jac evaluates residual + Jacobian of every block once and stores the Huber-scaled
+// rows; three assembly kernels read them back, all in ONE row order — sorted by (observation window, reference window, landmark), a window
+// being 4 aligned knot intervals — so every pass reads the rows coalesced:
+//   RepSideAcc<1>: [obs knots | camera] x same through the chunk accumulators (views of one frame share them);
+//   RepSideAcc<0>: [ref knots | camera] x same + camera x camera + the gradient of all three;
+//   k_reproj_cross: what is unique to a (reference frame, observation frame) pair or to a landmark — the cross block ref knots x obs knots,
+//              accumulated per (reference window, observation window) GROUP on the matrix cores (a 42 x 42 tile: 7 knots on either side) and
+//              added to HBM once per group, and the landmark's own row rho x [ref | obs | camera | rho | gradient] (56 entries per block).
+// With ORB-like tracks (>= 100 observations per frame, co-visible frame pairs) a group holds tens of blocks and the cross terms cost
+// ~1.8 k atomics per group instead of 576 per block; with one block per frame pair it degenerates to the per-block scatter (576 + 56 atomics
+// per block, bound by the atomic rate: a CU retires one FP64 atomic lane every ~3.75 cycles, tools/probes/atomic_bw.hip).
+struct RepJac { const double* J; const double* r; const int* k; int n; };   // k_reproj_jac output: J[(a * REP_NC + c) * n + i], r[a * n + i], k[i] = ref interval, k[n + i] = obs interval (-1: skipped)
+template <int SIDE> struct RepSideAcc {   // SIDE 0: the reference view's pose, 1: the observation's
+  enum { NK = 24, NG = 6, NR = 2, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 8, SKIP_GG = SIDE, SECONDARY = 1, LB = 16, NCP = 31, USE_PRE = 0, FTAB = 1, OCC = 1 };
+  __device__ static constexpr int jm(int c) { return c; }   // [knots of this side | camera]
+  int n; RepJac jac;
+  double huber;
   __device__ int eval(const DevCommon&, const SplineRef&, const Cal&, const HubShared*, int si, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
-    int k0, k1;
-    const int st = repjac_load(jac, si, r, J, &k0, &k1);
-    key = k1; aux.wid = k1; aux.xk = k0; aux.lm = lm[si];
-    return st;
+    const int k = jac.k[(size_t)SIDE * jac.n + si];
+    if (jac.k[(size_t)jac.n + si] < 0) return -1;
+    key = k; aux.wid = k;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      r[a] = jac.r[(size_t)a * jac.n + si];
+#pragma unroll
+      for (int c = 0; c < 24; ++c) J[a][c] = jac.J[(size_t)(a * REP_NC + 24 * SIDE + c) * jac.n + si];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) J[a][24 + c] = jac.J[(size_t)(a * REP_NC + 48 + c) * jac.n + si];
+    }
+    return RES_OK;
   }
   __device__ static int gcol(int g, int N, int nt) { return 6 * N + 15 + g; }
-  __device__ static int xcol(int x, const Aux& a, int N) { return x < 24 ? 6 * (a.xk + x / 6) + x % 6 : 6 * N + 22 + a.lm; }
-};
-struct RepRefAcc {
-  enum { NK = 24, NG = 7, NR = 2, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 8, NX = 0, SKIP_GG = 0, SECONDARY = 1, LMCOL = 6, LB = 16, NCP = REP_NC, USE_PRE = 0 };
-  __device__ static constexpr int jm(int c) { return c < 24 ? c : 48 + (c - 24); }   // [ref | cam | rho]
-  int n; const int* lm; const int* idxA; RepJac jac; double huber;   // rows in (reference interval, landmark) order; idxA: their position in the observation order
-  __device__ int eval(const DevCommon&, const SplineRef&, const Cal&, const HubShared*, int sj, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
-    int k0, k1;
-    const int st = repjac_load(jac, idxA[sj], r, J, &k0, &k1);
-    key = k0; aux.wid = lm[sj]; aux.xk = k1; aux.lm = lm[sj];
-    return st;
-  }
-  __device__ static int gcol(int g, int N, int nt) { return 6 * N + 15 + (g < 6 ? g : 0); }
 };
 
 // Reprojection phase 1 on its own: residual + Jacobian of every block (observation order), Huber-scaled, to HBM (0.9 KB per block);
@@ -538,6 +532,137 @@ __global__ __launch_bounds__(64) void k_reproj_jac(ReprojFam fam, DevCommon cm, 
   if (lane == 0) atomicAdd(&cm.cost[rep], mycost);
 }
 
+// Reprojection cross terms (see the comment above RepSideAcc).  A wavefront owns one GROUP = the blocks whose reference interval lies in
+// the aligned window [4 w0, 4 w0 + 4) and whose observation interval lies in [4 w1, 4 w1 + 4): both sides have a 7-knot (42-column) local
+// space.  Eight blocks at a time, 8 lanes per block (side, residual row, half of the 24 knot columns) load the materialised rows into two
+// LDS panels; T = J_ref^T J_obs accumulates in 3 x 3 MFMA tiles over the whole group and leaves with one atomic per non-zero entry.
+// The landmark's own row (rho x everything, 56 entries per block) is formed from the same registers with one lane exchange.
+typedef double d4 __attribute__((ext_vector_type(4)));
+struct RepCross { RepJac jac; const int* lm; const int* goff; const int* gw; int ng; int dbg; };   // gw[g] = w0, gw[ng + g] = w1
+__global__ __launch_bounds__(256) void k_reproj_cross(RepCross rc, DevCommon cm) {
+  constexpr int LDP = 49, BR = 16;   // panel: 16 rows (8 blocks x 2 residual rows) x 48 columns, odd stride
+  __shared__ double pan[4][2][BR * LDP];
+  __shared__ double tbuf[4][8 * 56];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int rep = blockIdx.x % LVX_NREP;
+  const int part = lane & 7, b = lane >> 3, side = part >> 2, a = (part >> 1) & 1, h = part & 1;
+  const int n = rc.jac.n, N = cm.N;
+  double* Pr = pan[wv][0];
+  double* Po = pan[wv][1];
+  const int frag_off = (lane >> 4) * LDP + (lane & 15);
+  const bool lm_free = !(cm.locks & LVX_LOCK_LANDMARKS);
+  for (int g = blockIdx.x * 4 + wv; g < rc.ng; g += gridDim.x * 4) {
+    const int m0 = rc.goff[g], m1 = rc.goff[g + 1], w0 = rc.gw[g], w1 = rc.gw[rc.ng + g];
+    d4 D[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) D[t] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int base = m0; base < m1; base += 8) {
+      const int i = base + b;
+      const bool in = i < m1;
+      const int k0 = in ? rc.jac.k[i] : -1, k1 = in ? rc.jac.k[(size_t)n + i] : -1;
+      bool valid = in && k1 >= 0;
+      const int o0 = k0 - 4 * w0, o1 = k1 - 4 * w1;
+      if (valid && (o0 < 0 || o0 > 3 || o1 < 0 || o1 > 3)) { valid = false; atomicOr(cm.err, LVX_ERR_FALLBACK); }   // a locked camera time offset moved the row out of its window
+      double v[12], jr = 0.0;
+      if (valid) {
+        const double* src = rc.jac.J + (size_t)(a * REP_NC + 24 * side + 12 * h) * n + i;
+#pragma unroll
+        for (int c = 0; c < 12; ++c) v[c] = src[(size_t)c * n];
+        jr = rc.jac.J[(size_t)(a * REP_NC + 54) * n + i];
+      } else {
+#pragma unroll
+        for (int c = 0; c < 12; ++c) v[c] = 0.0;
+      }
+      for (int e = lane; e < 2 * BR * LDP; e += 64) Pr[e] = 0.0;   // both panels are contiguous
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      {
+        double* dst = (side ? Po : Pr) + (2 * b + a) * LDP + 6 * (side ? o1 : o0) + 12 * h;
+        if (valid) {
+#pragma unroll
+          for (int c = 0; c < 12; ++c) dst[c] = v[c];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int nks = (2 * min(8, m1 - base) + 3) >> 2;
+      for (int ks = 0; ks < nks; ++ks) {
+        double fr[3], fo[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { fr[c] = Pr[ks * 4 * LDP + frag_off + c * 16]; fo[c] = Po[ks * 4 * LDP + frag_off + c * 16]; }
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+          for (int cj = 0; cj < 3; ++cj) D[ci * 3 + cj] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[ci], fo[cj], D[ci * 3 + cj], 0, 0, 0);
+      }
+      // the landmark's row: rho x [ref knots | obs knots | camera | rho | gradient] = 56 entries per block.  Every lane forms the products of
+      // its 12 knot columns (summed over the two residual rows: lanes part and part ^ 2), three spare lanes the rest; the 8 x 56 values pass
+      // through LDS so that CONSECUTIVE LANES add CONSECUTIVE ENTRIES of one landmark row (scattered FP64 atomics run at a sixth of the rate)
+      const int prho = (valid && lm_free) ? cm.ord[6 * N + 22 + rc.lm[i]] : LVX_DEAD;
+      if (!(rc.dbg & 1)) {
+        double t[12];
+#pragma unroll
+        for (int c = 0; c < 12; ++c) { t[c] = jr * v[c]; t[c] += __shfl_xor(t[c], 2); }
+        double* tb = tbuf[wv] + b * 56;
+        if (a == 0) {
+#pragma unroll
+          for (int c = 0; c < 12; ++c) tb[24 * side + 12 * h + c] = t[c];
+        } else if (valid) {
+          const double* J0 = rc.jac.J + i; const double* J1 = rc.jac.J + (size_t)REP_NC * n + i;
+          const double r0 = J0[(size_t)54 * n], r1 = J1[(size_t)54 * n];
+          if (side == 0) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { const int cc = 48 + 3 * h + q; tb[cc] = r0 * J0[(size_t)cc * n] + r1 * J1[(size_t)cc * n]; }
+          } else if (h == 0) {
+            tb[54] = r0 * r0 + r1 * r1;
+            tb[55] = r0 * rc.jac.r[i] + r1 * rc.jac.r[(size_t)n + i];
+          }
+        } else if (side == 0) { tb[48 + 3 * h] = 0.0; tb[49 + 3 * h] = 0.0; tb[50 + 3 * h] = 0.0; }
+        else if (h == 0) { tb[54] = 0.0; tb[55] = 0.0; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int bl = 0; bl < 8; ++bl) {
+          const int pr = __shfl(prho, 8 * bl), kr = __shfl(k0, 8 * bl), ko = __shfl(k1, 8 * bl);
+          if (pr == LVX_DEAD) continue;   // wave-uniform
+          if (lane < 56) {
+            const double val = tbuf[wv][bl * 56 + lane];
+            if (lane < 55) {
+              const int q = lane < 24 ? lane : lane - 24;
+              const int pc = lane < 48 ? cm.ord[6 * ((lane < 24 ? kr : ko) + q / 6) + q % 6] : (lane < 54 ? cm.ord[6 * N + 15 + (lane - 48)] : pr);
+              if (pc != LVX_DEAD && val != 0.0) add_H(cm, pr, pc, val, rep);
+            } else if (val != 0.0) add_g(cm, pr, val, rep);
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // T[x][y], x in the reference window, y in the observation window: one atomic per non-zero entry.  The same variable can sit in both
+    // windows (views closer than 7 knots): both orders of a pair land on the same stored entry, the diagonal takes both.
+    if (rc.dbg & 2) continue;
+    int pcol[3], prow[12];
+#pragma unroll
+    for (int cj = 0; cj < 3; ++cj) { const int y = cj * 16 + (lane & 15); pcol[cj] = y < 42 ? cm.ord[24 * w1 + y] : LVX_DEAD; }
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+      for (int vv = 0; vv < 4; ++vv) { const int x = ci * 16 + (lane >> 4) + 4 * vv; prow[ci * 4 + vv] = x < 42 ? cm.ord[24 * w0 + x] : LVX_DEAD; }
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+      for (int cj = 0; cj < 3; ++cj)
+#pragma unroll
+        for (int vv = 0; vv < 4; ++vv) {
+          const double val = D[ci * 3 + cj][vv];
+          const int pa = prow[ci * 4 + vv], pb = pcol[cj];
+          if (val == 0.0 || pa == LVX_DEAD || pb == LVX_DEAD) continue;
+          add_H(cm, pa, pb, pa == pb ? 2.0 * val : val, rep);
+        }
+  }
+}
+
 #define ACC_BW 24
 
 // ---------------------------------------------------------------------------------------------------------
@@ -552,7 +677,6 @@ __global__ __launch_bounds__(64) void k_reproj_jac(ReprojFam fam, DevCommon cm, 
 //   * at the end of a window the accumulator tiles (D: col = lane & 15, row = (lane >> 4) + 4 reg) are added to the workgroup's
 //     LDS accumulators, which are flushed to HBM once per workgroup.
 // ---------------------------------------------------------------------------------------------------------
-typedef double d4 __attribute__((ext_vector_type(4)));
 
 // families with F::Row / F::load / F::eval_row have their raw row inputs loaded one batch ahead
 struct NoRow {};
@@ -562,31 +686,29 @@ template <class F> struct RowOf<F, std::void_t<typename F::Row>> { using type = 
 // F::FTAB: the end-of-window scatter of the accumulator tiles reads its LDS targets from a per-workgroup table instead of recomputing
 // the column classes (measured: 3 % faster for the reprojection observation pass, slower for the LiDAR and IMU families — LDS-bound)
 template <class F, class = void> struct FlushTab { static constexpr bool on = false; };
-template <class F> struct FlushTab<F, std::enable_if_t<(F::FTAB > 0)>> { static constexpr bool on = F::LMCOL < 0; };
+template <class F> struct FlushTab<F, std::enable_if_t<(F::FTAB > 0)>> { static constexpr bool on = true; };
 
 template <class F> struct MfmaGeom {
   static constexpr int NKL = (F::WS + 3) * F::KPK;           // knot columns of a window
   static constexpr int NCL = NKL + F::NG + 1;                // + globals + residual
   static constexpr int NT = (NCL + 15) / 16;                 // 16-column tiles
-  static constexpr int XOFF = NT * 16;                       // cross columns (not part of the MFMA product) sit behind the tiles
-  static constexpr int LDP = (XOFF + F::NX) | 1;             // odd row stride: conflict-free row writes and fragment reads
+  static constexpr int LDP = (NT * 16) | 1;                  // odd row stride: conflict-free row writes and fragment reads
   static constexpr int PR = F::GL * F::NR;                   // panel rows
   static_assert(PR % 4 == 0, "panel rows must be a multiple of the MFMA k-step");
-  static_assert(F::NX == 0 || F::WS == 1, "cross-term scatter assumes one knot interval per window");
   static constexpr int NTP = NT * (NT + 1) / 2;
 };
 template <class F> size_t mfma_lds_bytes(int cr) {
   const int LV = (cr + 5) * 6;
   return (size_t)(LV * ACC_BW + F::NG * LV + F::NG * F::NG + LV + F::NG + 4 * MfmaGeom<F>::PR * MfmaGeom<F>::LDP) * 8 + (F::USE_PRE ? (size_t)(cr + 4) * sizeof(So3Pre) : 0) +
-         (size_t)(LV + F::NG + 4 * (F::NX + 1) * F::GL + (FlushTab<F>::on ? MfmaGeom<F>::NTP * 256 : 0)) * 4 + 64;
+         (size_t)(LV + F::NG + (FlushTab<F>::on ? MfmaGeom<F>::NTP * 256 : 0)) * 4 + 64;
 }
 
 // CR = knot intervals per workgroup, chosen per problem by the host (pick_chunk) so that the workgroup count fills whole rounds of the CUs
 template <class F, int OCC>
 __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, const int* __restrict__ chunk_off, long long row0, int CR, int var_nch) {
   using G = MfmaGeom<F>;
-  constexpr int NK = F::NK, NG = F::NG, NX = F::NX, NC = F::NCP, NR = F::NR, KPK = F::KPK, WS = F::WS, GL = F::GL, LB = F::LB;
-  constexpr int NKL = G::NKL, NT = G::NT, LDP = G::LDP, PR = G::PR, XOFF = G::XOFF;
+  constexpr int NK = F::NK, NG = F::NG, NC = F::NCP, NR = F::NR, KPK = F::KPK, WS = F::WS, GL = F::GL, LB = F::LB;
+  constexpr int NKL = G::NKL, NT = G::NT, LDP = G::LDP, PR = G::PR;
   const int ACC_LV = (CR + 5) * 6;
   extern __shared__ double sm[];
   double* acc_band = sm;                              // [ACC_LV][ACC_BW]
@@ -598,8 +720,7 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
   So3Pre* pre_tab = (So3Pre*)(panels + 4 * PR * LDP); // [CR + 4] control-point pairs (k_lo + e, k_lo + e + 1), families with USE_PRE
   int* kpos = (int*)(pre_tab + (F::USE_PRE ? CR + 4 : 0));   // [ACC_LV]
   int* gpos = kpos + ACC_LV;                          // [NG]
-  int* xinfo = gpos + NG;                             // 4 x [GL][NX + 1]: ordering positions of the panel blocks' cross columns, [NX] = block in window
-  int* ftab = xinfo + 4 * (NX + 1) * GL;              // [NTP * 4][64]: where accumulator register (tile pair, v) of each lane goes at the end of a window
+  int* ftab = gpos + NG;              // [NTP * 4][64]: where accumulator register (tile pair, v) of each lane goes at the end of a window
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int ch = blockIdx.x;
   const int m0 = chunk_off[ch], m1 = chunk_off[ch + 1];
@@ -655,7 +776,6 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
   const Cal cal = load_cal(cm);
   const HubShared* hub = F::HUB >= 0 ? ((const HubShared*)cm.hubs) + F::HUB : nullptr;
   double* P = panels + wv * (PR * LDP);
-  int* xi = xinfo + wv * ((NX + 1) * GL);
   const int rep = blockIdx.x % LVX_NREP;
   // class of a window-local column: >= 0 knot scalar (offset inside the window, in units of tangent scalars), -1-g global g, -100 residual, -200 padding
   auto cls = [](int lc) { return lc < NKL ? 6 * (lc / KPK) + F::LVO + lc % KPK : (lc < NKL + NG ? -1 - (lc - NKL) : (lc == NKL + NG ? -100 : -200)); };
@@ -687,11 +807,6 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
       else if (!valid && status > 0) atomicOr(cm.err, status);   // status < 0: row skipped (reported by the kernel that produced it)
     }
     if constexpr (RowOf<F>::prefetch) { const int sn = si + 4 * LB; if (lane < LB && sn < m1) nxt = fam.load(sn); }   // next batch's rows: in flight during this batch's assembly
-    int xpos[NX > 0 ? NX : 1];
-    if constexpr (NX > 0) {   // ordering positions of this block's cross columns: independent loads, issued together
-#pragma unroll
-      for (int x = 0; x < NX; ++x) xpos[x] = valid ? cm.ord[F::xcol(x, aux, cm.N)] : LVX_DEAD;
-    }
     if (valid) {
       double s = 0.0;
 #pragma unroll
@@ -731,17 +846,6 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
       d4 D[G::NTP];
 #pragma unroll
       for (int t = 0; t < G::NTP; ++t) D[t] = d4{0.0, 0.0, 0.0, 0.0};
-      constexpr int NJX = NX > 0 ? (NK * NX + 63) / 64 : 1;
-      int ca[NJX], cx[NJX], cpa[NJX];      // this lane's (knot column, cross column) pairs and the window's ordering position of the knot column
-      if constexpr (NX > 0) {
-#pragma unroll
-        for (int j = 0; j < NJX; ++j) {
-          const int e2 = lane + 64 * j;
-          cx[j] = e2 / NK; ca[j] = e2 - cx[j] * NK;
-          cpa[j] = e2 < NK * NX ? kpos[wb + 6 * (ca[j] / KPK) + F::LVO + ca[j] % KPK] : LVX_DEAD;
-          if (e2 >= NK * NX) { cx[j] = 0; ca[j] = 0; }
-        }
-      }
       for (int g0 = l0; g0 <= lhi; g0 += GL) {
         const int gs = min(g0, 64 - GL);                     // the panel always maps GL existing lanes, so every panel row is rewritten
         if (lane >= gs && lane < gs + GL) {
@@ -757,13 +861,6 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
 #pragma unroll
             for (int g = 0; g < NG; ++g) prow[NKL + g] = mrow ? J[a][F::jm(NK + g)] : 0.0;
             prow[NKL + NG] = mrow ? r[a] : 0.0;
-#pragma unroll
-            for (int x = 0; x < NX; ++x) prow[XOFF + x] = mrow ? J[a][F::jm(NK + NG + x)] : 0.0;
-          }
-          if constexpr (NX > 0) {
-#pragma unroll
-            for (int x = 0; x < NX; ++x) xi[li * (NX + 1) + x] = xpos[x];
-            xi[li * (NX + 1) + NX] = mrow ? 1 : 0;
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -781,31 +878,6 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
           for (int ci = 0; ci < NT; ++ci)
 #pragma unroll
             for (int cj = ci; cj < NT; ++cj, ++t) D[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[ci], f[cj], D[t], 0, 0, 0);
-        }
-        if constexpr (NX > 0) {
-          // cross terms knot columns x cross columns of every block of the panel: unique to the block, one global atomic each.  A lane owns
-          // the same (knot column, cross column) pairs for every block (consecutive lanes = consecutive knot columns => runs along a band
-          // column), so only the block's cross positions and panel rows change: independent LDS reads, no division in the loop.
-          for (int bl = 0; bl < cnt; ++bl) {
-            if (!xi[bl * (NX + 1) + NX]) continue;
-            const double* pr = P + bl * NR * LDP;
-            int pbv[NJX]; double vv[NJX];
-#pragma unroll
-            for (int j = 0; j < NJX; ++j) pbv[j] = xi[bl * (NX + 1) + cx[j]];          // all LDS reads of the block first, branch-free: they overlap
-#pragma unroll
-            for (int j = 0; j < NJX; ++j) {
-              double v = 0.0;
-#pragma unroll
-              for (int q = 0; q < NR; ++q) v += pr[q * LDP + ca[j]] * pr[q * LDP + XOFF + cx[j]];
-              vv[j] = v;
-            }
-#pragma unroll
-            for (int j = 0; j < NJX; ++j) {
-              const int pa = cpa[j], pb = pbv[j];
-              if (pa == LVX_DEAD || pb == LVX_DEAD || vv[j] == 0.0) continue;
-              add_H(cm, pa, pb, pa == pb ? 2.0 * vv[j] : vv[j], rep);   // the same variable through both poses: both orders of the pair land on the diagonal
-            }
-          }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -825,7 +897,6 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
             atomicAdd(&sm[(te & 0xffff) + (m == 2 ? wbB : (m == 1 ? wb : 0))], val);
           }
       } else {
-      const int plm = F::LMCOL >= 0 ? cm.ord[6 * cm.N + 22 + ww] : LVX_DEAD;   // the window's landmark column
       int t = 0;
 #pragma unroll
       for (int ci = 0; ci < NT; ++ci)
@@ -841,20 +912,15 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
               const int la = wb + ra;
               if (la >= ACC_LV) continue;
               if (cb >= 0) { const int d = cb - ra; if (d < ACC_BW && wb + cb < ACC_LV) atomicAdd(&acc_band[la * ACC_BW + d], val); }
-              else if (cb > -100) {
-                if (F::LMCOL >= 0 && -1 - cb == F::LMCOL) { if (plm != LVX_DEAD && kpos[la] != LVX_DEAD) add_H(cm, kpos[la], plm, val, rep); }
-                else atomicAdd(&acc_bd[(-1 - cb) * ACC_LV + la], val);
-              }
+              else if (cb > -100) atomicAdd(&acc_bd[(-1 - cb) * ACC_LV + la], val);
               else if (cb == -100) atomicAdd(&acc_gk[la], val);
             } else if (ra > -100) {
               const int ga = -1 - ra;
               if (cb > -100) {
                 const int gb = -1 - cb;
-                if (F::LMCOL >= 0 && gb == F::LMCOL) { if (plm != LVX_DEAD) { if (ga == F::LMCOL) add_H(cm, plm, plm, val, rep); else if (gpos[ga] != LVX_DEAD) add_H(cm, gpos[ga], plm, val, rep); } }
-                else if (!F::SKIP_GG) atomicAdd(&acc_gg[ga * NG + gb], val);
+                if (!F::SKIP_GG) atomicAdd(&acc_gg[ga * NG + gb], val);
               } else if (cb == -100) {
-                if (F::LMCOL >= 0 && ga == F::LMCOL) { if (plm != LVX_DEAD) add_g(cm, plm, val, rep); }
-                else if (!F::SKIP_GG) atomicAdd(&acc_gG[ga], val);
+                if (!F::SKIP_GG) atomicAdd(&acc_gG[ga], val);
               }
             }
           }
@@ -1017,6 +1083,27 @@ __global__ __launch_bounds__(256) void k_fold_all(DevCommon cm, int nrep, int se
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
+const SwitchName* switch_table(int* count) {
+  static const SwitchName tab[] = {
+    {"FORCE_LEGACY", &Switches::force_legacy, false}, {"IMU_LEGACY", &Switches::imu_legacy, false}, {"REPROJ_LEGACY", &Switches::reproj_legacy, false},
+    {"SERIAL", &Switches::serial, false}, {"SCHED", &Switches::sched, false}, {"IMU_TWO_STREAMS", &Switches::imu_two_streams, false}, {"OCC", &Switches::occ, false},
+    {"JAC_LATE", &Switches::jac_late, false}, {"FOLD_ONE", &Switches::fold_one, false}, {"FOLD_INLINE", &Switches::fold_inline, false}, {"NO_GRAPH", &Switches::no_graph, false},
+    {"SYNC_NOFENCE", &Switches::sync_nofence, false}, {"CHUNK_R", &Switches::chunk_r, true}, {"CHUNK_R_IMU", &Switches::chunk_r_imu, true},
+    {"CHUNK_R_REP", &Switches::chunk_r_rep, true}, {"CHUNK_ROWS", &Switches::chunk_rows, true}, {"REP_ROWS", &Switches::rep_rows, true},
+    {"SOLVER_SEQ", &Switches::solver_seq, false}, {"SOLVER_TIMING", &Switches::solver_timing, false}, {"BCR_ROCSOLVER_POTRF", &Switches::bcr_rocsolver_potrf, false},
+    {"BCR_SYRK", &Switches::bcr_syrk, false}, {"DETERMINISTIC", &Switches::deterministic, true}, {"CLEAR_ALL", &Switches::clear_all, false}, {"CROSS_DBG", &Switches::cross_dbg, false},
+  };
+  *count = (int)(sizeof(tab) / sizeof(tab[0]));
+  return tab;
+}
+static void read_env_switches(lvx_ctx* c) {
+  int n; const SwitchName* t = switch_table(&n);
+  for (int i = 0; i < n; ++i) {
+    const std::string name = std::string("LVX_") + t[i].name;
+    if (const char* e = std::getenv(name.c_str())) c->sw.*(t[i].field) = (*e == 0) ? 1 : atoi(e);
+  }
+}
+
 int fail(lvx_ctx* ctx, int code, const std::string& msg) { if (ctx) ctx->last_error = msg; return code; }
 
 int dev_alloc(lvx_ctx* ctx, DevBuf& b, size_t bytes) {
@@ -1080,8 +1167,8 @@ int host_i0(const lvx_ctx* c, double t) {
 // e.g. IMU R = 33 (3 rounds, 264 rows = a second batch for 8 rows) beats R = 25 (4 rounds of one batch) by 7 %.)
 // fixed: a workgroup's setup + accumulator flush in units of one interval's work (LiDAR kernel: 19 k of its cycles against 8.6 k per interval
 // => 2.2; with it 13 intervals = 3.8 rounds beat 10 = 4.9 rounds, measured 0.232 vs 0.241 ms)
-static int pick_chunk(const lvx_ctx* ctx, int lo, int hi, const char* env, int wg_per_cu = 1, double fixed = 0.0) {
-  if (const char* e = getenv(env)) { const int v = atoi(e); if (v >= 4 && v <= 64) return v; }
+static int pick_chunk(const lvx_ctx* ctx, int lo, int hi, int forced, int wg_per_cu = 1, double fixed = 0.0) {
+  if (forced >= 4 && forced <= 64) return forced;
   int ncu = 256;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
@@ -1098,8 +1185,8 @@ static int pick_chunk(const lvx_ctx* ctx, int lo, int hi, const char* env, int w
 // batches: a workgroup processes its rows in batches of 4 wavefronts x LB rows, and a chunk of 33 intervals x 8 IMU samples = 264 rows pays a
 // whole second batch for 8 rows (measured: R = 32 instead of 33 takes 3 % off the pass although the kernels alone get slower).  Largest R
 // whose expected rows fill nb batches to >= 90 %, smallest nb first.
-static int pick_chunk_batches(int lo, int hi, const char* env, double rows_per_interval, int rows_per_batch) {
-  if (const char* e = getenv(env)) { const int v = atoi(e); if (v >= 4 && v <= 64) return v; }
+static int pick_chunk_batches(int lo, int hi, int forced, double rows_per_interval, int rows_per_batch) {
+  if (forced >= 4 && forced <= 64) return forced;
   if (!(rows_per_interval > 0.0)) return lo;
   int best = lo; double best_eff = 0.0;
   for (int nb = 1; nb <= 4; ++nb) {
@@ -1133,6 +1220,28 @@ static int upload_chunks_rows(lvx_ctx* ctx, int fam, const std::vector<int>& sor
   off.insert(off.end(), k0.begin(), k0.end());
   return upload_tmp(ctx, ctx->d_chunk[fam], off.data(), off.size() * 4);
 }
+// Same for rows whose keys are only grouped, not sorted (the reprojection passes share one row order): a chunk is a run of at most `rows` rows
+// whose keys span at most rmax intervals; its first interval is the smallest key of the run.
+static int upload_chunks_rows_grouped(lvx_ctx* ctx, int fam, const std::vector<int>& keys, int rmax, int rows) {
+  const int n = (int)keys.size();
+  std::vector<int> off, k0;
+  int i = 0;
+  do {
+    off.push_back(i);
+    int lo = 1 << 30, hi = -1, e = i;
+    while (e < n && e - i < rows) {
+      const int k = keys[e];
+      if (k >= 0) { const int nlo = std::min(lo, k), nhi = std::max(hi, k); if (nhi - nlo + 1 > rmax && e > i) break; lo = nlo; hi = nhi; }
+      ++e;
+    }
+    k0.push_back(hi >= 0 ? lo : 0);
+    i = std::max(e, i + (n > 0 ? 1 : 0));
+  } while (i < n);
+  off.push_back(n);
+  ctx->n_chunk[fam] = (int)k0.size(); ctx->chunk_r[fam] = rmax; ctx->chunk_var[fam] = 1;
+  off.insert(off.end(), k0.begin(), k0.end());
+  return upload_tmp(ctx, ctx->d_chunk[fam], off.data(), off.size() * 4);
+}
 static int upload_chunks(lvx_ctx* ctx, int fam, const std::vector<int>& sorted_keys, int R) {
   const int nch = (ctx->N + R - 1) / R + 1;
   std::vector<int> off(nch + 1);
@@ -1150,6 +1259,14 @@ int ensure_layout(lvx_ctx* ctx) {
   const int N = ctx->N, L = ctx->L;
   const uint32_t locks = ctx->locks;
   int rc;
+  {   // the plane / landmark tables may have been replaced (shrunk) after the families that index them were set
+    const long long npl = (long long)ctx->planes.size() / 3;
+    for (int i = 0; i < ctx->surf.n; ++i) if (ctx->surf.id0[i] < 0 || ctx->surf.id0[i] >= npl) return fail(ctx, LVX_E_ARG, "surfel plane id out of range for the current plane table");
+    for (int i = 0; i < ctx->cs.n; ++i) {
+      if (ctx->cs.id1[i] < 0 || ctx->cs.id1[i] >= npl) return fail(ctx, LVX_E_ARG, "cam-surfel plane id out of range for the current plane table");
+      if (ctx->cs.id0[i] < 0 || ctx->cs.id0[i] >= L) return fail(ctx, LVX_E_ARG, "cam-surfel landmark id out of range for the current landmark table");
+    }
+  }
   const SplineRef sp{ctx->t0, ctx->dt, N, nullptr, nullptr};
   // ---- sort every family by knot interval and upload ----
   {
@@ -1158,7 +1275,7 @@ int ensure_layout(lvx_ctx* ctx) {
     for (int i = 0; i < f.n; ++i) key[i] = host_i0(ctx, f.t[i]);
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
-    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_GYRO, sk, pick_chunk_batches(16, 64, "LVX_CHUNK_R_IMU", (double)f.n / std::max(1, N - 3), 4 * (int)GyroAcc::LB)))) return rc; }
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_GYRO, sk, pick_chunk_batches(16, 64, ctx->sw.chunk_r_imu, (double)f.n / std::max(1, N - 3), 4 * (int)GyroAcc::LB)))) return rc; }
     auto ts = gather(f.t, perm, 1); auto g = gather(f.a3, perm, 3); auto a = gather(f.b3, perm, 3);
     if ((rc = upload_tmp(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
     if ((rc = upload_tmp(ctx, f.d_a3, g.data(), g.size() * 8))) return rc;
@@ -1171,8 +1288,8 @@ int ensure_layout(lvx_ctx* ctx) {
     for (int i = 0; i < f.n; ++i) key[i] = host_i0(ctx, f.t[i]);
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
-    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if (getenv("LVX_CHUNK_R")) rc = upload_chunks(ctx, LVX_FAM_SURFEL, sk, pick_chunk(ctx, 8, 16, "LVX_CHUNK_R", 2, 2.2));
-      else rc = upload_chunks_rows(ctx, LVX_FAM_SURFEL, sk, 16, getenv("LVX_CHUNK_ROWS") ? atoi(getenv("LVX_CHUNK_ROWS")) : 512);
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if (ctx->sw.chunk_r) rc = upload_chunks(ctx, LVX_FAM_SURFEL, sk, pick_chunk(ctx, 8, 16, ctx->sw.chunk_r, 2, 2.2));
+      else rc = upload_chunks_rows(ctx, LVX_FAM_SURFEL, sk, 16, ctx->sw.chunk_rows > 0 ? ctx->sw.chunk_rows : 512);
       if (rc) return rc; }
     auto ts = gather(f.t, perm, 1); auto pt = gather(f.a3, perm, 3); auto pl = gather(f.id0, perm, 1);
     if ((rc = upload_tmp(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
@@ -1187,40 +1304,50 @@ int ensure_layout(lvx_ctx* ctx) {
   }
   {
     Family& f = ctx->rep;
-    // two device orders of the same blocks (see RepObsAcc / RepRefAcc): A = by the observation's knot interval (also used by the
-    // per-segment kernel), B = by (reference knot interval, landmark).  Rolling shutter: the evaluation time is t0 + v * readout / rows.
+    // One device order for every reprojection pass (see RepSideAcc / k_reproj_cross): (observation window, reference window, observation
+    // interval, reference interval, landmark), a window being 4 aligned knot intervals.  Rolling shutter: the evaluation time is
+    // t0 + v * readout / rows.  The per-segment kernel uses the same arrays.
     const double row_delta = ctx->cam.rows > 0 ? ctx->cam.readout / (double)ctx->cam.rows : 0.0;
     std::vector<int> k1(f.n), k0(f.n), perm(f.n);
     for (int i = 0; i < f.n; ++i) {
       const int l = f.id0[i];
       k1[i] = host_i0(ctx, f.t[i] + f.a3[2 * (size_t)i + 1] * row_delta);
       k0[i] = (l >= 0 && l < L) ? host_i0(ctx, ctx->lm_t0[l] + ctx->lm_uv[2 * (size_t)l + 1] * row_delta) : -1;
+      if (k0[i] < 0 || k1[i] < 0) k0[i] = k1[i] = -1;   // out of range: reported by the Jacobian kernel, skipped by the assembly
     }
     std::iota(perm.begin(), perm.end(), 0);
-    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return k1[a] != k1[b] ? k1[a] < k1[b] : f.id0[a] < f.id0[b]; });
-    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = k1[perm[i]]; // equal row count here too: 64 rows = one batch of 4 wavefronts x LB = 16 rows (33 intervals x 2 rows was 66: a second batch for 2 rows)
-      if (!getenv("LVX_CHUNK_R_REP")) rc = upload_chunks_rows(ctx, LVX_FAM_REPROJ, sk, 48, getenv("LVX_REP_ROWS") ? atoi(getenv("LVX_REP_ROWS")) : 4 * (int)RepObsAcc::LB);
-      else rc = upload_chunks(ctx, LVX_FAM_REPROJ, sk, pick_chunk(ctx, 24, 40, "LVX_CHUNK_R_REP"));
-      if (rc) return rc; }
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) {
+      const int wa1 = k1[a] >> 2, wb1 = k1[b] >> 2, wa0 = k0[a] >> 2, wb0 = k0[b] >> 2;
+      if (wa1 != wb1) return wa1 < wb1;
+      if (wa0 != wb0) return wa0 < wb0;
+      if (k1[a] != k1[b]) return k1[a] < k1[b];
+      if (k0[a] != k0[b]) return k0[a] < k0[b];
+      return f.id0[a] < f.id0[b];
+    });
+    {
+      std::vector<int> s1(f.n), s0(f.n);
+      for (int i = 0; i < f.n; ++i) { s1[i] = k1[perm[i]]; s0[i] = k0[perm[i]]; }
+      const int rows = ctx->sw.rep_rows > 0 ? ctx->sw.rep_rows : 4 * (int)RepSideAcc<1>::LB;   // 64 rows = one batch of 4 wavefronts x LB = 16 rows
+      if ((rc = upload_chunks_rows_grouped(ctx, LVX_FAM_REPROJ, s1, 48, rows))) return rc;
+      if ((rc = upload_chunks_rows_grouped(ctx, LVX_FAM_PRIOR /* slot reused: the prior has no chunks */, s0, 48, rows))) return rc;
+      // groups of the cross-term kernel: runs of equal (reference window, observation window); rows that are out of range form no group
+      std::vector<int> goff, gw0, gw1;
+      for (int i = 0; i < f.n; ++i) {
+        if (s1[i] < 0) continue;
+        const int a0 = s0[i] >> 2, a1 = s1[i] >> 2;
+        // a wavefront walks its group 8 blocks at a time: at most 32 blocks per group, a larger (window, window) pair is shared by several
+        if (goff.empty() || gw0.back() != a0 || gw1.back() != a1 || i - goff.back() >= 32) { goff.push_back(i); gw0.push_back(a0); gw1.push_back(a1); }
+      }
+      ctx->rep_groups = (int)goff.size();
+      goff.push_back(f.n);
+      goff.insert(goff.end(), gw0.begin(), gw0.end()); goff.insert(goff.end(), gw1.begin(), gw1.end());
+      if ((rc = upload_tmp(ctx, ctx->d_repB[2], goff.data(), goff.size() * 4))) return rc;
+    }
     auto ts = gather(f.t, perm, 1); auto uv = gather(f.a3, perm, 2); auto lm = gather(f.id0, perm, 1);
     if ((rc = upload_tmp(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
     if ((rc = upload_tmp(ctx, f.d_a3, uv.data(), uv.size() * 8))) return rc;
     if ((rc = upload_tmp(ctx, f.d_id0, lm.data(), lm.size() * 4))) return rc;
     if ((rc = upload_tmp(ctx, f.d_perm, perm.data(), perm.size() * 4))) return rc;
-    std::vector<int> permB(f.n);
-    std::iota(permB.begin(), permB.end(), 0);
-    std::stable_sort(permB.begin(), permB.end(), [&](int a, int b) { return k0[a] != k0[b] ? k0[a] < k0[b] : (f.id0[a] != f.id0[b] ? f.id0[a] < f.id0[b] : f.t[a] < f.t[b]); });
-    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = k0[permB[i]]; if (!getenv("LVX_CHUNK_R_REP")) rc = upload_chunks_rows(ctx, LVX_FAM_PRIOR /* slot reused: the prior has no chunks */, sk, 48, getenv("LVX_REP_ROWS") ? atoi(getenv("LVX_REP_ROWS")) : 4 * (int)RepRefAcc::LB);
-      else rc = upload_chunks(ctx, LVX_FAM_PRIOR, sk, pick_chunk(ctx, 24, 40, "LVX_CHUNK_R_REP"));
-      if (rc) return rc; }
-    auto tsB = gather(f.t, permB, 1); auto uvB = gather(f.a3, permB, 2); auto lmB = gather(f.id0, permB, 1);
-    if ((rc = upload_tmp(ctx, ctx->d_repB[0], tsB.data(), tsB.size() * 8))) return rc;
-    if ((rc = upload_tmp(ctx, ctx->d_repB[1], uvB.data(), uvB.size() * 8))) return rc;
-    if ((rc = upload_tmp(ctx, ctx->d_repB[2], lmB.data(), lmB.size() * 4))) return rc;
-    std::vector<int> posA(f.n), idxA(f.n);
-    for (int i = 0; i < f.n; ++i) posA[perm[i]] = i;
-    for (int j = 0; j < f.n; ++j) idxA[j] = posA[permB[j]];
-    if ((rc = upload_tmp(ctx, ctx->d_repB[3], idxA.data(), idxA.size() * 4))) return rc;
     if ((rc = dev_alloc(ctx, ctx->d_repB[0], (size_t)std::max(f.n, 1) * (2 * REP_NC + 2) * 8))) return rc;   // materialised Jacobians + residuals
     if ((rc = dev_alloc(ctx, ctx->d_repB[1], (size_t)std::max(f.n, 1) * 2 * 4))) return rc;                    // knot intervals
   }
@@ -1230,8 +1357,8 @@ int ensure_layout(lvx_ctx* ctx) {
     for (int i = 0; i < f.n; ++i) key[i] = (f.id0[i] >= 0 && f.id0[i] < L) ? host_i0(ctx, ctx->lm_t0[f.id0[i]]) : -1;
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
-    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if (getenv("LVX_CHUNK_R")) rc = upload_chunks(ctx, LVX_FAM_CAMSURF, sk, pick_chunk(ctx, 8, 16, "LVX_CHUNK_R", 2, 2.2));
-      else rc = upload_chunks_rows(ctx, LVX_FAM_CAMSURF, sk, 16, getenv("LVX_CHUNK_ROWS") ? atoi(getenv("LVX_CHUNK_ROWS")) : 512);
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if (ctx->sw.chunk_r) rc = upload_chunks(ctx, LVX_FAM_CAMSURF, sk, pick_chunk(ctx, 8, 16, ctx->sw.chunk_r, 2, 2.2));
+      else rc = upload_chunks_rows(ctx, LVX_FAM_CAMSURF, sk, 16, ctx->sw.chunk_rows > 0 ? ctx->sw.chunk_rows : 512);
       if (rc) return rc; }
     auto lm = gather(f.id0, perm, 1); auto pl = gather(f.id1, perm, 1);
     if ((rc = upload_tmp(ctx, f.d_id0, lm.data(), lm.size() * 4))) return rc;
@@ -1256,7 +1383,7 @@ int ensure_layout(lvx_ctx* ctx) {
   const int nh = ctx->n_hub, h0 = ctx->hub0;
   ctx->nbd = 6 * nh + 22;
   ctx->nbd_ext = ctx->nbd + 12;   // + pseudo pose rows: surfel hub (6), cam-surfel hub (6)
-  // ---- band ordering: non-hub knots in time order, each landmark right after its first knot ----
+  // ---- band ordering: non-hub knots in time order; landmarks have their own rows (DevCommon::lmH) ----
   const int nt = 6 * N + 22 + L;
   ctx->ord.assign(nt + 12, LVX_DEAD);
   for (int k = 0; k < 12; ++k) ctx->ord[nt + k] = -1 - (ctx->nbd + k);
@@ -1275,8 +1402,6 @@ int ensure_layout(lvx_ctx* ctx) {
     rep_kmin[i] = kmin; rep_kmax[i] = kmax;
     lm_first[l] = std::min(lm_first[l], kmin); lm_last[l] = std::max(lm_last[l], kmax);
   }
-  std::vector<std::vector<int>> lm_at(N + 1);
-  if (!(locks & LVX_LOCK_LANDMARKS)) for (int l = 0; l < L; ++l) lm_at[std::min(lm_first[l], N)].push_back(l);
   int pos = 0;
   auto is_hub = [&](int k) { return nh > 0 && k >= h0 && k < h0 + nh; };
   for (int k = 0; k <= N; ++k) {
@@ -1287,31 +1412,41 @@ int ensure_layout(lvx_ctx* ctx) {
         for (int d = 0; d < 6; ++d) if (!tangent_locked(6 * k + d, N, L, locks)) ctx->ord[6 * k + d] = pos++;
       }
     }
-    for (int l : lm_at[k]) ctx->ord[6 * N + 22 + l] = pos++;
   }
   ctx->nb = pos;
+  if (!(locks & LVX_LOCK_LANDMARKS)) for (int l = 0; l < L; ++l) ctx->ord[6 * N + 22 + l] = LVX_LM_BASE + l;
   for (int c = 0; c < 22; ++c) if (!tangent_locked(6 * N + c, N, L, locks)) ctx->ord[6 * N + c] = -1 - (6 * nh + c);
   // ---- scalar half-bandwidth ----
   int bw = 0;
   auto span_pos = [&](int ka, int kb, int& lo, int& hi) {
     for (int k = ka; k <= kb && k < N; ++k) for (int d = 0; d < 6; ++d) { const int o = ctx->ord[6 * k + d]; if (o >= 0) { lo = std::min(lo, o); hi = std::max(hi, o); } }
   };
-  for (int k = 0; k + 3 < N; ++k) { int lo = 1 << 30, hi = -1; span_pos(k, k + 3, lo, hi); if (hi >= lo) bw = std::max(bw, hi - lo); }
+  const int kspan = (!(locks & LVX_LOCK_LIDAR_TAU) || !(locks & LVX_LOCK_CAM_TAU)) ? 4 : 3;   // a free time offset pads the spans: segments of up to 5 control points
+  for (int k = 0; k + 3 < N; ++k) { int lo = 1 << 30, hi = -1; span_pos(k, k + kspan, lo, hi); if (hi >= lo) bw = std::max(bw, hi - lo); }
+  const int bw_near = bw;   // reach of the families that touch 4 neighbouring knots only (IMU, LiDAR, prior)
+  std::vector<uint8_t> colfull((size_t)std::max(ctx->nb, 1), 0);   // band columns a reprojection block / a landmark reaches further from (k_clear)
   for (int i = 0; i < ctx->rep.n; ++i) {
     int lo = 1 << 30, hi = -1;
     span_pos(rep_kmin[i], rep_kmax[i], lo, hi);
-    const int ol = ctx->ord[6 * N + 22 + ctx->rep.id0[i]];
-    if (ol >= 0) { lo = std::min(lo, ol); hi = std::max(hi, ol); }
-    if (hi >= lo) bw = std::max(bw, hi - lo);
+    if (hi >= lo) { bw = std::max(bw, hi - lo); if (hi - lo > bw_near) std::fill(colfull.begin() + lo, colfull.begin() + hi + 1, (uint8_t)1); }
   }
-  // the landmark elimination couples everything a landmark touches
+  // the landmark elimination couples everything a landmark touches (fill of the reduced band); a landmark's row covers the same positions
+  std::vector<int> lm_p0((size_t)std::max(L, 1), 0);
+  int lm_wl = 1;
   for (int l = 0; l < L; ++l) if (lm_last[l] >= 0) {
     int lo = 1 << 30, hi = -1; span_pos(lm_first[l], lm_last[l], lo, hi);
-    const int ol = ctx->ord[6 * N + 22 + l];
-    if (ol >= 0) { lo = std::min(lo, ol); hi = std::max(hi, ol); }
-    if (hi >= lo) bw = std::max(bw, hi - lo);
+    if (hi >= lo) { if (!(locks & LVX_LOCK_LANDMARKS)) bw = std::max(bw, hi - lo); lm_p0[l] = lo; lm_wl = std::max(lm_wl, hi - lo + 1); }
   }
+  ctx->lm_wl = lm_wl; ctx->lm_ls = lm_wl + ctx->nbd_ext + 2;
+  if ((rc = upload_tmp(ctx, ctx->d_lm_p0, lm_p0.data(), lm_p0.size() * 4))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_lmH, (size_t)std::max(L, 1) * ctx->lm_ls * 8 + 16))) return rc;
   ctx->bw = std::min(std::max(bw, 0), std::max(ctx->nb - 1, 0));
+  ctx->clear_npre = std::min(bw_near, ctx->bw) + 1;
+  if ((rc = upload_tmp(ctx, ctx->d_colfull, colfull.data(), colfull.size()))) return rc;
+  ctx->bd_row_live.assign((size_t)ctx->nbd_ext, 0);
+  for (int b = 0; b < 6 * nh; ++b) ctx->bd_row_live[b] = 1;
+  for (int c = 0; c < 22; ++c) if (ctx->ord[6 * N + c] != LVX_DEAD) ctx->bd_row_live[6 * nh + c] = 1;
+  for (int p = 0; p < 6; ++p) { ctx->bd_row_live[ctx->nbd + p] = ctx->surf.n > 0; ctx->bd_row_live[ctx->nbd + 6 + p] = ctx->cs.n > 0; }
   // ---- buffers ----
   if ((rc = upload_tmp(ctx, ctx->d_ord, ctx->ord.data(), ctx->ord.size() * 4))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_Hb, (size_t)std::max(ctx->nb, 1) * (ctx->bw + 1) * 8 + 16))) return rc;
@@ -1319,6 +1454,10 @@ int ensure_layout(lvx_ctx* ctx) {
   if ((rc = dev_alloc(ctx, ctx->d_Bd, (size_t)ctx->nbd_ext * std::max(ctx->nb, 1) * 8 + 16))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_C, (size_t)LVX_NREP * ctx->nbd_ext * ctx->nbd_ext * 8 + 16))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_gc, (size_t)LVX_NREP * ctx->nbd_ext * 8 + 16))) return rc;   // + 16 each: k_clear works in 16-byte words
+  // the per-pass clear is structural (k_clear): what it never touches must be zero from the start
+  LVX_HIP(ctx, hipMemsetAsync(ctx->d_Hb.p, 0, ctx->d_Hb.bytes, ctx->stream));
+  LVX_HIP(ctx, hipMemsetAsync(ctx->d_Bd.p, 0, ctx->d_Bd.bytes, ctx->stream));
+  LVX_HIP(ctx, hipMemsetAsync(ctx->d_lmH.p, 0, ctx->d_lmH.bytes, ctx->stream));
   if ((rc = dev_alloc(ctx, ctx->d_hubs, 2 * sizeof(HubShared)))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_pre, (size_t)std::max(N, 1) * sizeof(So3Pre)))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_cost, LVX_NREP * 8))) return rc;
@@ -1354,12 +1493,13 @@ DevCommon make_common(lvx_ctx* ctx, const double* state_d, uint32_t what) {
   cm.ord = (const int*)ctx->d_ord.p; cm.nb = ctx->nb; cm.bw = ctx->bw; cm.nbd = ctx->nbd_ext; cm.nbd_solve = ctx->nbd; cm.hubs = ctx->d_hubs.p; cm.pre = (const So3Pre*)ctx->d_pre.p;
   cm.Hb = (double*)ctx->d_Hb.p; cm.gb = (double*)ctx->d_gb.p; cm.Bd = (double*)ctx->d_Bd.p; cm.C = (double*)ctx->d_C.p; cm.gc = (double*)ctx->d_gc.p;
   cm.cost = (double*)ctx->d_cost.p; cm.err = (int*)ctx->d_err.p;
+  cm.lmH = (double*)ctx->d_lmH.p; cm.lm_p0 = (const int*)ctx->d_lm_p0.p; cm.lm_wl = ctx->lm_wl; cm.lm_ls = ctx->lm_ls;
   cm.residuals = nullptr; cm.jcols = nullptr; cm.jvals = nullptr;
   return cm;
 }
 
 // events that order kernels of this context's streams.  LVX_SYNC_NOFENCE=1 drops their system-scope fence (-2 % per pass; experimental)
-#define LVX_SYNC_EVENT_FLAGS (hipEventDisableTiming | (getenv("LVX_SYNC_NOFENCE") ? hipEventDisableSystemFence : 0u))
+#define LVX_SYNC_EVENT_FLAGS(c) (hipEventDisableTiming | ((c)->sw.sync_nofence ? hipEventDisableSystemFence : 0u))
 static size_t next_event(lvx_ctx* c) {
   // timing only: no system-scope fence (cache writeback + invalidation) at every record
   if (c->ev_used == c->ev_pool.size()) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) return (size_t)-1; c->ev_pool.push_back(e); }
@@ -1379,13 +1519,27 @@ ProfScope::~ProfScope() {
   c->ev_recs.push_back(lvx_ctx::EvRec{kernel, e0, e1});
 }
 
-// clears up to 8 device buffers (sizes rounded up to 16 bytes: every buffer is allocated with that slack by dev_alloc's callers) in one launch
-struct ClearList { uint4* p[8]; size_t words[8]; int n; };
+// clears up to 16 device buffers (sizes rounded up to 16 bytes: every buffer is allocated with that slack by dev_alloc's callers) in one launch
+struct ClearList { uint4* p[16]; size_t words[16]; int n; };
+// The band is cleared STRUCTURALLY: every column's first `npre` entries (what the IMU / LiDAR families can touch: 4 neighbouring knots and
+// the landmarks ordered between them), whole columns only where `colfull` says a reprojection block or a landmark reaches further
+// (ensure_layout).  Everything else was zeroed once at layout time and is never written.  Config 4 with ORB-like tracks: 60 MB instead of 242 MB.
+struct BandClear { double* Hb; const uint8_t* colfull; int nb, ld, npre, nblk; };
 // First launch of a pass.  Its first npre blocks do what depends on the state only (control-point-pair table, hub poses: k_state_prepass's
 // work — a separate kernel on a side stream costs a ~30 us cross-stream join before the LiDAR kernels); the rest clear the accumulators.
-__global__ __launch_bounds__(256) void k_clear(ClearList cl, int npre, DevCommon cm, So3Pre* tab, int nblk_tab, double t_map, int want_surf, int want_cs, HubShared* hubs) {
+__global__ __launch_bounds__(256) void k_clear(ClearList cl, BandClear bc, int npre, DevCommon cm, So3Pre* tab, int nblk_tab, double t_map, int want_surf, int want_cs, HubShared* hubs) {
   if ((int)blockIdx.x < npre) { state_prepass_block(cm, tab, nblk_tab, t_map, want_surf, want_cs, hubs, blockIdx.x); return; }
-  const size_t stride = (size_t)(gridDim.x - npre) * blockDim.x, t0 = (size_t)(blockIdx.x - npre) * blockDim.x + threadIdx.x;
+  if ((int)blockIdx.x < npre + bc.nblk) {   // 16 lanes per band column, 16 columns per workgroup
+    const int j = ((int)blockIdx.x - npre) * 16 + (threadIdx.x >> 4);
+    if (j < bc.nb) {
+      const int len = bc.colfull[j] ? bc.ld : bc.npre;
+      double* col = bc.Hb + (size_t)j * bc.ld;
+      for (int e = threadIdx.x & 15; e < len; e += 16) col[e] = 0.0;
+    }
+    return;
+  }
+  const int first = npre + bc.nblk;
+  const size_t stride = (size_t)(gridDim.x - first) * blockDim.x, t0 = (size_t)(blockIdx.x - first) * blockDim.x + threadIdx.x;
   for (int b = 0; b < cl.n; ++b) {   // 4 stores per trip: the prepass code leaves this kernel 2 wavefronts per SIMD, the stores keep HBM busy anyway
     const size_t nw = cl.words[b];
     size_t i = t0;
@@ -1420,7 +1574,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
   // Jacobian always do.
   auto enqueue = [&]() -> int {
     int rc = LVX_OK;
-    const bool fast = !ctx->force_legacy && !(what & LVX_EVAL_JACOBIAN) && !getenv("LVX_FORCE_LEGACY");
+    const bool fast = !ctx->force_legacy && !(what & LVX_EVAL_JACOBIAN) && !ctx->sw.force_legacy;
     // free time offsets need d pose / d t at both evaluations: those problems take the per-segment kernels (TAU variants)
     const bool tauL = !(ctx->locks & LVX_LOCK_LIDAR_TAU), tauC = !(ctx->locks & LVX_LOCK_CAM_TAU);
     const bool fast_surf = fast && !tauL && ctx->surf.n > 0, fast_cs = fast && !tauC && ctx->cs.n > 0;
@@ -1428,15 +1582,28 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     const int nblk_tab = fast ? (ctx->N + 255) / 256 : 0, npre = fast ? nblk_tab + ((fast_surf || fast_cs) ? 1 : 0) : 0;
     {   // one launch clears every accumulator of the pass (cost, error flags, and for the normal equations band, gradient, border rows, dense border)
       ClearList cl{};
-      auto add = [&](void* p, size_t bytes) { cl.p[cl.n] = (uint4*)p; cl.words[cl.n] = (bytes + 15) / 16; cl.n++; };
+      BandClear bc{};
+      auto add = [&](void* p, size_t bytes) { if (cl.n < 16) { cl.p[cl.n] = (uint4*)p; cl.words[cl.n] = (bytes + 15) / 16; cl.n++; } };
       add(cm.cost, LVX_NREP * 8); add(cm.err, 16);
       if (what & LVX_EVAL_NORMAL_EQ) {
-        add(cm.Hb, (size_t)std::max(ctx->nb, 1) * (ctx->bw + 1) * 8); add(cm.gb, (size_t)std::max(ctx->nb, 1) * 8);
-        add(cm.Bd, (size_t)ctx->nbd_ext * std::max(ctx->nb, 1) * 8); add(cm.C, (size_t)LVX_NREP * ctx->nbd_ext * ctx->nbd_ext * 8); add(cm.gc, (size_t)LVX_NREP * ctx->nbd_ext * 8);
+        const size_t nb1 = (size_t)std::max(ctx->nb, 1);
+        if (ctx->sw.clear_all || ctx->nb == 0) add(cm.Hb, nb1 * (ctx->bw + 1) * 8);
+        else { bc.Hb = cm.Hb; bc.colfull = (const uint8_t*)ctx->d_colfull.p; bc.nb = ctx->nb; bc.ld = ctx->bw + 1; bc.npre = ctx->clear_npre; bc.nblk = (ctx->nb + 15) / 16; }
+        add(cm.gb, nb1 * 8);
+        // border rows: only the rows some residual can reach (a locked calibration scalar and an unused pseudo-pose set keep their zeros); 16-byte words: whole rows when nb is even
+        if (ctx->sw.clear_all || (nb1 & 1)) add(cm.Bd, (size_t)ctx->nbd_ext * nb1 * 8);
+        else for (int b0 = 0; b0 < ctx->nbd_ext;) {
+          if (!ctx->bd_row_live[b0]) { ++b0; continue; }
+          int b1 = b0; while (b1 < ctx->nbd_ext && ctx->bd_row_live[b1]) ++b1;
+          add(cm.Bd + (size_t)b0 * nb1, (size_t)(b1 - b0) * nb1 * 8);
+          b0 = b1;
+        }
+        add(cm.C, (size_t)LVX_NREP * ctx->nbd_ext * ctx->nbd_ext * 8); add(cm.gc, (size_t)LVX_NREP * ctx->nbd_ext * 8);
+        if (ctx->L > 0 && ctx->rep.n > 0 && !(ctx->locks & LVX_LOCK_LANDMARKS)) add(cm.lmH, (size_t)ctx->L * ctx->lm_ls * 8);
       }
       size_t total = 0; for (int i = 0; i < cl.n; ++i) total += cl.words[i];
       const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
-      hipLaunchKernelGGL(k_clear, dim3(blocks + (unsigned)npre), dim3(256), 0, st, cl, npre, cm, (So3Pre*)ctx->d_pre.p, nblk_tab, ctx->t_map, fast_surf ? 1 : 0, fast_cs ? 1 : 0,
+      hipLaunchKernelGGL(k_clear, dim3(blocks + (unsigned)npre + (unsigned)bc.nblk), dim3(256), 0, st, cl, bc, npre, cm, (So3Pre*)ctx->d_pre.p, nblk_tab, ctx->t_map, fast_surf ? 1 : 0, fast_cs ? 1 : 0,
                          (HubShared*)ctx->d_hubs.p);
     }
     auto grid = [](int n) { return dim3((unsigned)((n + 63) / 64)); };
@@ -1446,14 +1613,14 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     // stage, last kernel -> fold each showed such a gap), so the critical chain  clear -> hub pose -> LiDAR kernels -> reprojection Jacobian
     // -> observation pass -> fold  stays on the caller's stream and only the kernels that run NEXT to it (gyroscope, accelerometer,
     // reference pass) fork off; they finish before the observation pass does, so the join is already satisfied when the chain gets there.
-    static const int sched = getenv("LVX_SCHED") ? atoi(getenv("LVX_SCHED")) : 2;
-    const bool staged = sched == 2 && !getenv("LVX_SERIAL");
+    const lvx::Switches& sw = ctx->sw;
+    const bool staged = sw.sched == 2 && !sw.serial;
     hipStream_t s_imu = ctx->fam_stream[0], s_acc = ctx->fam_stream[1], s_surf = staged ? st : ctx->fam_stream[2], s_rep = staged ? st : ctx->fam_stream[3];
     // one side stream (gyroscope, then accelerometer) next to the chain (Jacobian, observation pass, reference pass): both ends finish
     // together and one fan-out / fan-in less than with a stream per IMU kernel (-1.5 % per pass); LVX_IMU_TWO_STREAMS=1 restores that
-    static const bool one_side = getenv("LVX_IMU_TWO_STREAMS") == nullptr;
+    const bool one_side = !sw.imu_two_streams;
     if (one_side) s_acc = s_imu;
-    if (getenv("LVX_SERIAL")) s_imu = s_acc = s_surf = s_rep = st;   // profiling aid: solo kernel durations
+    if (sw.serial) s_imu = s_acc = s_surf = s_rep = st;   // profiling aid: solo kernel durations
     const hipStream_t side[4] = {s_imu, s_acc, s_surf, s_rep};
     auto first_use = [&](int k) { for (int j = 0; j < k; ++j) if (side[j] == side[k]) return false; return side[k] != st; };   // each side stream forks / joins once
     // staged: the side stream's first operation is its wait for the LiDAR stage (ev_join[2]) — that is its fork; an event record on the
@@ -1462,7 +1629,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
       LVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
       for (int k = 0; k < 4; ++k) if (first_use(k)) LVX_HIP(ctx, hipStreamWaitEvent(side[k], ctx->ev_fork, 0));
     }
-    static const int occ_env = getenv("LVX_OCC") ? atoi(getenv("LVX_OCC")) : 0;   // 0: the family's own choice (F::OCC wavefronts per SIMD)
+    const int occ_env = sw.occ;   // 0: the family's own choice (F::OCC wavefronts per SIMD)
   #define LVX_LAUNCH_MFMA1(FT, OCCV, fam_obj, chunk_slot, stream, row0v)                                                                        \
     do {                                                                                                                                     \
       const size_t lds_ = mfma_lds_bytes<FT>(ctx->chunk_r[chunk_slot]);                                                                      \
@@ -1476,7 +1643,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     // reprojection passes next to each other.  Measured at config 4: the pass takes the same 1.55-1.6 ms with everything concurrent (the big
     // kernels cannot share a CU and only slow each other down), staged like this, or serial (1.64 ms); staged, the dominant kernel's
     // duration is its solo duration.  LVX_SCHED=0 restores "all concurrent".
-    static const bool jac_early = !getenv("LVX_JAC_LATE");   // the (small, register-bound) reprojection Jacobian kernel runs next to the LiDAR kernels: -2.5 % per pass, surfel kernel unaffected
+    const bool jac_early = !sw.jac_late;   // the (small, register-bound) reprojection Jacobian kernel runs next to the LiDAR kernels: -2.5 % per pass, surfel kernel unaffected
     const int order[5] = {2, 4, 0, 1, 3};   // surfel, cam-surfel, imu, prior, reprojection
     for (int ph = 0; ph < 5; ++ph) {
       if (staged && ph == 2) {               // the other streams start when the LiDAR stream has drained
@@ -1486,7 +1653,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
       }
       switch (order[ph]) {
       case 0: {
-        const bool imu_fast = fast && !getenv("LVX_IMU_LEGACY");
+        const bool imu_fast = fast && !sw.imu_legacy;
         if (ctx->imu.n > 0) {
           if (imu_fast) {
             GyroAcc g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
@@ -1542,7 +1709,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
           if (tauC) {
             ReprojFamT<true> rt{r.n, r.lm, r.uv, r.t0o, r.perm, r.lm_uv, r.lm_t0, r.weight, r.huber};
             hipLaunchKernelGGL((k_family<ReprojFamT<true>, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, rt, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
-          } else if (fast && !getenv("LVX_REPROJ_LEGACY")) {
+          } else if (fast && !sw.reproj_legacy) {
             double* Jb = (double*)ctx->d_repB[0].p; double* rb = Jb + (size_t)2 * REP_NC * r.n; int* kb = (int*)ctx->d_repB[1].p;
             hipLaunchKernelGGL(k_reproj_jac, grid(r.n), dim3(64), 0, s_rep, r, cm, Jb, rb, kb, (long long)ctx->fam_row0[4]);
             if (staged && jac_early && s_rep != s_surf) LVX_HIP(ctx, hipStreamWaitEvent(s_rep, ctx->ev_join[2], 0));
@@ -1550,12 +1717,17 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
               hipStream_t s_ref = (one_side && staged) ? s_rep : s_acc;
               if (s_ref != s_rep) LVX_HIP(ctx, hipEventRecord(ctx->ev_jac, s_rep));   // an event record on the chain is a bubble: only when another stream waits for it
               const RepJac jac{Jb, rb, kb, r.n};
-              RepObsAcc ra{r.n, r.lm, r.perm, jac, 0.0};
-              LVX_LAUNCH_MFMA1(RepObsAcc, 1, ra, LVX_FAM_REPROJ, s_rep, ctx->fam_row0[4]);   // measured: a second workgroup per CU does not help, the cross-term atomics bound this pass
-              // the reference-side pass only reads the materialised rows: it runs next to the observation-side pass, behind the accelerometer kernel
-              RepRefAcc rb2{r.n, (const int*)ctx->d_repB[2].p, (const int*)ctx->d_repB[3].p, jac, 0.0};
+              RepSideAcc<1> ra{r.n, jac, 0.0};
+              LVX_LAUNCH_MFMA1(RepSideAcc<1>, 1, ra, LVX_FAM_REPROJ, s_rep, ctx->fam_row0[4]);
+              // the other two passes only read the materialised rows: they can run next to the observation-side pass, behind the accelerometer kernel
+              RepSideAcc<0> rb2{r.n, jac, 0.0};
               if (s_ref != s_rep) LVX_HIP(ctx, hipStreamWaitEvent(s_ref, ctx->ev_jac, 0));
-              LVX_LAUNCH_MFMA1(RepRefAcc, 1, rb2, LVX_FAM_PRIOR, s_ref, ctx->fam_row0[4]);
+              LVX_LAUNCH_MFMA1(RepSideAcc<0>, 1, rb2, LVX_FAM_PRIOR, s_ref, ctx->fam_row0[4]);
+              if (ctx->rep_groups > 0) {
+                const int* gt = (const int*)ctx->d_repB[2].p;
+                const RepCross rx{jac, r.lm, gt, gt + ctx->rep_groups + 1, ctx->rep_groups, ctx->sw.cross_dbg};
+                hipLaunchKernelGGL(k_reproj_cross, dim3((unsigned)std::min((ctx->rep_groups + 3) / 4, 256 * 8)), dim3(256), 0, s_ref, rx, cm);
+              }
             }
           } else
           hipLaunchKernelGGL((k_family<ReprojFam, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, r, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
@@ -1587,18 +1759,18 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     // default: three kernels (replica sums -> dense block, border rows beside them on the side stream).  LVX_FOLD_ONE=1: one launch whose
     // last replica block folds the dense block (device-scope fence + counter), -0.5 % per pass; kept optional — one unexplained parity
     // failure in ~45 suite runs while it was the default
-    static const bool fold_split = getenv("LVX_FOLD_ONE") == nullptr;
+    const bool fold_split = !sw.fold_one;
     if (fold_fast && ctx->nb > 0 && !fold_split) {
       const int nrep = (ctx->nbd_ext * ctx->nbd_ext + 255) / 256, nrows = (ctx->nb + 255) / 256;
       const size_t lds = ((size_t)ctx->nbd_ext * ctx->nbd_ext + ctx->nbd_ext) * 8;
       LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_fold_all, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(k_fold_all, dim3((unsigned)(nrep + nrows)), dim3(256), lds, st, cm, nrep, (fast_surf ? 1 : 0) | (fast_cs ? 2 : 0));
     } else {
-    if (fold_fast && !getenv("LVX_SERIAL") && !getenv("LVX_FOLD_INLINE")) LVX_HIP(ctx, hipEventRecord(ctx->ev_jac, st));   // st has joined every family stream here
+    if (fold_fast && !sw.serial && !sw.fold_inline) LVX_HIP(ctx, hipEventRecord(ctx->ev_jac, st));   // st has joined every family stream here
     hipLaunchKernelGGL(k_fold_replicas, dim3((unsigned)((ctx->nbd_ext * ctx->nbd_ext + 255) / 256)), dim3(256), 0, st, cm);
     if (fold_fast) {
       // the border-row fold (Bd, streaming) and the dense fold (C, g_c; one workgroup, behind k_fold_replicas) touch disjoint buffers: side by side
-      hipStream_t s_side = (getenv("LVX_SERIAL") || getenv("LVX_FOLD_INLINE")) ? st : ctx->fam_stream[0];
+      hipStream_t s_side = (sw.serial || sw.fold_inline) ? st : ctx->fam_stream[0];
       if (s_side != st) LVX_HIP(ctx, hipStreamWaitEvent(s_side, ctx->ev_jac, 0));
       for (int set = 0; set < 2; ++set) if (ctx->nb > 0 && ((set == 0 && fast_surf) || (set == 1 && fast_cs)))
         hipLaunchKernelGGL(k_fold_border_rows, dim3((unsigned)((ctx->nb + 255) / 256)), dim3(256), 0, s_side, cm, set);
@@ -1610,12 +1782,10 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     LVX_HIP(ctx, hipGetLastError());
     return rc;
   };
-  static const bool no_graph = getenv("LVX_NO_GRAPH") != nullptr;
-  const bool use_graph = !no_graph && !ctx->profiling && !(what & LVX_EVAL_JACOBIAN);
+  const bool use_graph = !ctx->sw.no_graph && !ctx->profiling && !(what & LVX_EVAL_JACOBIAN);
   if (!use_graph) { if ((rc = enqueue())) return rc; }
   else {
-    const int flags = (want_res_buffer ? 1 : 0) | (ctx->force_legacy ? 2 : 0) | (getenv("LVX_FORCE_LEGACY") ? 4 : 0) | (getenv("LVX_SERIAL") ? 8 : 0) | (getenv("LVX_IMU_LEGACY") ? 16 : 0) |
-                      (getenv("LVX_REPROJ_LEGACY") ? 32 : 0);
+    const int flags = (want_res_buffer ? 1 : 0) | (ctx->force_legacy ? 2 : 0);   // a switch change bumps cfg_version
     hipGraphExec_t exec = nullptr;
     for (const auto& e : ctx->graphs) if (e.state == state_d && e.what == what && e.flags == flags && e.cfg == ctx->cfg_version) { exec = (hipGraphExec_t)e.exec; break; }
     if (!exec) {
@@ -1634,6 +1804,8 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     LVX_HIP(ctx, hipGraphLaunch(exec, st));
   }
   ctx->last_what = what;
+  ctx->last_state_d = state_d; ctx->last_want_res = want_res_buffer;
+  ctx->err_unchecked = cost == nullptr;   // the device error word of this pass has not been looked at yet (check_last_eval)
   if (cost) {
     double c = 0; int err[4] = {0, 0, 0, 0};
     LVX_HIP(ctx, hipMemcpyAsync(&c, cm.cost, 8, hipMemcpyDeviceToHost, st));
@@ -1650,6 +1822,28 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
   }
   return LVX_OK;
 }
+
+// An evaluation queued without a cost pointer returns before its device error word exists.  Everything that consumes its normal equations
+// on the host side (solve step, dense export) calls this first: a pass that met the merged-hub-segment corner is repeated with the exact
+// per-segment kernels, a range / unit-quaternion error is returned instead of a step computed from incomplete sums.
+int check_last_eval(lvx_ctx* c) {
+  if (!c->err_unchecked || !c->d_err.p) return LVX_OK;
+  int err = 0;
+  LVX_HIP(c, hipMemcpyAsync(&err, c->d_err.p, 4, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  c->err_unchecked = false;
+  if ((err & LVX_ERR_FALLBACK) && !c->force_legacy) {
+    c->force_legacy = true;
+    double cost = 0;
+    return run_evaluate(c, c->last_state_d, c->last_what, &cost, c->last_want_res);
+  }
+  if (err & RES_RANGE) return fail(c, LVX_E_RANGE, "time span out of range for trajectory");
+  if (err & RES_NONUNIT) return fail(c, LVX_E_NONUNIT_QUAT, "logq: only implemented for unit quaternions");
+  if (err & 4) return fail(c, LVX_E_STATE, "normal-equation entry outside the computed bandwidth");
+  return LVX_OK;
+}
+
+__global__ void k_export_tail(const double* cost, const int* err, double* out) { out[0] = cost[0]; out[1] = (double)err[0]; }
 
 }  // namespace lvx
 
@@ -1670,11 +1864,12 @@ int lvx_create(lvx_ctx** out, int device, uint32_t /*flags*/) {
   lvx_ctx* c = new (std::nothrow) lvx_ctx();
   if (!c) return LVX_E_ALLOC;
   c->device = device;
+  read_env_switches(c);
   if (hipStreamCreate(&c->own_stream) != hipSuccess) { delete c; return LVX_E_HIP; }
   c->stream = c->own_stream;
-  for (int k = 0; k < 4; ++k) { if (hipStreamCreateWithFlags(&c->fam_stream[k], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_join[k], LVX_SYNC_EVENT_FLAGS) != hipSuccess) { delete c; return LVX_E_HIP; } }
-  if (hipEventCreateWithFlags(&c->ev_fork, LVX_SYNC_EVENT_FLAGS) != hipSuccess) { delete c; return LVX_E_HIP; }
-  if (hipEventCreateWithFlags(&c->ev_jac, LVX_SYNC_EVENT_FLAGS) != hipSuccess) { delete c; return LVX_E_HIP; }
+  for (int k = 0; k < 4; ++k) { if (hipStreamCreateWithFlags(&c->fam_stream[k], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_join[k], LVX_SYNC_EVENT_FLAGS(c)) != hipSuccess) { delete c; return LVX_E_HIP; } }
+  if (hipEventCreateWithFlags(&c->ev_fork, LVX_SYNC_EVENT_FLAGS(c)) != hipSuccess) { delete c; return LVX_E_HIP; }
+  if (hipEventCreateWithFlags(&c->ev_jac, LVX_SYNC_EVENT_FLAGS(c)) != hipSuccess) { delete c; return LVX_E_HIP; }
   *out = c;
   return LVX_OK;
 }
@@ -1694,6 +1889,8 @@ void lvx_destroy(lvx_ctx* c) {
   for (auto& b : c->d_repB) if (b.p) (void)hipFree(b.p);
   if (c->d_hubs.p) (void)hipFree(c->d_hubs.p);
   if (c->d_pre.p) (void)hipFree(c->d_pre.p);
+  if (c->d_colfull.p) (void)hipFree(c->d_colfull.p);
+  for (DevBuf* b : {&c->d_lmH, &c->d_lm_p0, &c->d_Hr, &c->d_Br, &c->d_red}) if (b->p) (void)hipFree(b->p);
   for (DevBuf* b : {&c->vox.misc, &c->vox.keys, &c->vox.vals, &c->vox.runs, &c->vox.cells, &c->vox.tmp, &c->vox.leaf_i, &c->vox.leaf_d, &c->vox.leaf_f}) if (b->p) (void)hipFree(b->p);
   bcr_destroy(c);
   for (DevBuf* b : {&c->d_bcrD, &c->d_bcrG, &c->d_bcrInfo, &c->d_Y2, &c->d_gram}) if (b->p) (void)hipFree(b->p);
@@ -1735,8 +1932,8 @@ int lvx_set_planes(lvx_ctx* c, int n, const double* pi3) { if (c) c->cfg_version
 }
 int lvx_set_surfel(lvx_ctx* c, int n, const double* pt3, const double* t, const int32_t* plane_id, double t_map, double huber, double weight) { if (c) c->cfg_version++;
   if (!c || n < 0 || (n > 0 && (!pt3 || !t || !plane_id))) return LVX_E_ARG;
-  Family& f = c->surf; f.n = n; f.t.assign(t, t + n); f.a3.assign(pt3, pt3 + 3 * (size_t)n); f.id0.assign(plane_id, plane_id + n);
   for (int i = 0; i < n; ++i) if (plane_id[i] < 0 || (size_t)plane_id[i] * 3 >= c->planes.size()) return fail(c, LVX_E_ARG, "plane id out of range (call lvx_set_planes first)");
+  Family& f = c->surf; f.n = n; f.t.assign(t, t + n); f.a3.assign(pt3, pt3 + 3 * (size_t)n); f.id0.assign(plane_id, plane_id + n);
   f.huber = huber; f.weight = weight; c->t_map = t_map; c->layout_dirty = true; return LVX_OK;
 }
 int lvx_set_landmarks(lvx_ctx* c, int n, const double* uv_ref2, const double* t0_ref) { if (c) c->cfg_version++;
@@ -1750,12 +1947,23 @@ int lvx_set_reproj(lvx_ctx* c, int n, const int32_t* lm, const double* uv_obs2, 
 }
 int lvx_set_camsurf(lvx_ctx* c, int n, const int32_t* lm, const int32_t* plane_id, double t_map, double huber, double weight) { if (c) c->cfg_version++;
   if (!c || n < 0 || (n > 0 && (!lm || !plane_id))) return LVX_E_ARG;
-  Family& f = c->cs; f.n = n; f.id0.assign(lm, lm + n); f.id1.assign(plane_id, plane_id + n);
   for (int i = 0; i < n; ++i) {
     if (plane_id[i] < 0 || (size_t)plane_id[i] * 3 >= c->planes.size()) return fail(c, LVX_E_ARG, "plane id out of range (call lvx_set_planes first)");
     if (lm[i] < 0 || lm[i] >= c->L) return fail(c, LVX_E_ARG, "landmark id out of range (call lvx_set_landmarks first)");
   }
+  Family& f = c->cs; f.n = n; f.id0.assign(lm, lm + n); f.id1.assign(plane_id, plane_id + n);
   f.huber = huber; f.weight = weight; c->t_map = t_map; c->layout_dirty = true; return LVX_OK;
+}
+int lvx_set_switch(lvx_ctx* c, const char* name, int value) {
+  if (!c || !name) return LVX_E_ARG;
+  if (!strncmp(name, "LVX_", 4)) name += 4;
+  int n; const SwitchName* t = switch_table(&n);
+  for (int i = 0; i < n; ++i) if (!strcmp(t[i].name, name)) {
+    c->sw.*(t[i].field) = value; c->cfg_version++;   // captured graphs are stale
+    if (t[i].relayout) c->layout_dirty = true;
+    return LVX_OK;
+  }
+  return fail(c, LVX_E_ARG, std::string("unknown switch ") + name);
 }
 int lvx_set_locks(lvx_ctx* c, uint32_t mask) { if (c) c->cfg_version++; if (!c) return LVX_E_ARG; if (c->locks != mask) { c->locks = mask; c->layout_dirty = true; } return LVX_OK; }
 int lvx_set_time_offset_bounds(lvx_ctx* c, double imu_max, double sensor_max) { if (c) c->cfg_version++; if (!c) return LVX_E_ARG; c->imu_mto = imu_max; c->sensor_mto = sensor_max; c->layout_dirty = true; return LVX_OK; }
@@ -1810,7 +2018,10 @@ int lvx_export_border_d(lvx_ctx* c, double* out_d) {
   const size_t n2 = (size_t)c->nbd_ext * c->nbd_ext;
   LVX_HIP(c, hipMemcpyAsync(out_d, c->d_C.p, n2 * 8, hipMemcpyDeviceToDevice, c->stream));
   LVX_HIP(c, hipMemcpyAsync(out_d + n2, c->d_gc.p, (size_t)c->nbd_ext * 8, hipMemcpyDeviceToDevice, c->stream));
-  LVX_HIP(c, hipMemcpyAsync(out_d + n2 + c->nbd_ext, c->d_cost.p, 8, hipMemcpyDeviceToDevice, c->stream));
+  // cost and the pass's device error word (as a double: 0 = clean) ride along, so that after the all-reduce EVERY rank sees whether any
+  // rank's sums are incomplete — without a host synchronisation here
+  hipLaunchKernelGGL(k_export_tail, dim3(1), dim3(1), 0, c->stream, (const double*)c->d_cost.p, (const int*)c->d_err.p, out_d + n2 + c->nbd_ext);
+  LVX_HIP(c, hipGetLastError());
   return LVX_OK;
 }
 int lvx_set_state(lvx_ctx* c, const double* state) {
@@ -1836,6 +2047,7 @@ int lvx_synchronize(lvx_ctx* c) {
   if (!c->d_err.p) return LVX_OK;
   int err = 0;
   LVX_HIP(c, hipMemcpy(&err, c->d_err.p, 4, hipMemcpyDeviceToHost));
+  c->err_unchecked = false;
   if (err & LVX_ERR_FALLBACK) { c->force_legacy = true; return fail(c, LVX_E_STATE, "fast assembly kernels hit the merged-hub-segment corner: evaluate again (the exact per-segment kernels are now selected)"); }
   if (err & RES_RANGE) return fail(c, LVX_E_RANGE, "time span out of range for trajectory");
   if (err & RES_NONUNIT) return fail(c, LVX_E_NONUNIT_QUAT, "logq: only implemented for unit quaternions");
@@ -1872,6 +2084,7 @@ int lvx_get_normal_eq_dense(lvx_ctx* c, double* H, double* g) {
   const int nt = lvx_tangent_size(c);
   if (nt > 20000) return fail(c, LVX_E_ARG, "dense expansion is a parity/debug path for small problems");
   LVX_HIP(c, hipSetDevice(c->device));
+  { const int rce = check_last_eval(c); if (rce) return rce; }
   LVX_HIP(c, hipStreamSynchronize(c->stream));
   const int nb = c->nb, bw = c->bw, nbd = c->nbd, ldc = c->nbd_ext;
   std::vector<double> Hb((size_t)std::max(nb, 1) * (bw + 1)), gb(std::max(nb, 1)), Bd((size_t)nbd * std::max(nb, 1)), C((size_t)ldc * ldc), gc(nbd);
@@ -1883,7 +2096,7 @@ int lvx_get_normal_eq_dense(lvx_ctx* c, double* H, double* g) {
   std::memset(H, 0, sizeof(double) * (size_t)nt * nt);
   std::memset(g, 0, sizeof(double) * nt);
   std::vector<int> band_var(std::max(nb, 1), -1), bord_var(nbd, -1);
-  for (int v = 0; v < nt; ++v) { const int o = c->ord[v]; if (o == LVX_DEAD) continue; if (o >= 0) band_var[o] = v; else if (-1 - o < nbd) bord_var[-1 - o] = v; }
+  for (int v = 0; v < nt; ++v) { const int o = c->ord[v]; if (o == LVX_DEAD || o >= LVX_LM_BASE) continue; if (o >= 0) band_var[o] = v; else if (-1 - o < nbd) bord_var[-1 - o] = v; }
   for (int j = 0; j < nb; ++j) {
     g[band_var[j]] = gb[j];
     for (int d = 0; d <= bw && j + d < nb; ++d) { const double v = Hb[(size_t)j * (bw + 1) + d]; const int a = band_var[j + d], b = band_var[j]; H[(size_t)a * nt + b] = v; H[(size_t)b * nt + a] = v; }
@@ -1893,6 +2106,19 @@ int lvx_get_normal_eq_dense(lvx_ctx* c, double* H, double* g) {
     g[bord_var[b]] = gc[b];
     for (int j = 0; j < nb; ++j) { const double v = Bd[(size_t)b * nb + j]; H[(size_t)bord_var[b] * nt + band_var[j]] = v; H[(size_t)band_var[j] * nt + bord_var[b]] = v; }
     for (int b2 = 0; b2 <= b; ++b2) { if (bord_var[b2] < 0) continue; const double v = C[(size_t)b * ldc + b2]; H[(size_t)bord_var[b] * nt + bord_var[b2]] = v; H[(size_t)bord_var[b2] * nt + bord_var[b]] = v; }
+  }
+  if (c->L > 0 && c->rep.n > 0 && !(c->locks & LVX_LOCK_LANDMARKS)) {   // landmark rows
+    const int wl = c->lm_wl, ls = c->lm_ls;
+    std::vector<double> R((size_t)c->L * ls); std::vector<int> p0(c->L);
+    LVX_HIP(c, hipMemcpy(R.data(), c->d_lmH.p, R.size() * 8, hipMemcpyDeviceToHost));
+    LVX_HIP(c, hipMemcpy(p0.data(), c->d_lm_p0.p, p0.size() * 4, hipMemcpyDeviceToHost));
+    for (int l = 0; l < c->L; ++l) {
+      const double* row = &R[(size_t)l * ls];
+      const int vl = 6 * c->N + 22 + l;
+      H[(size_t)vl * nt + vl] = row[wl + ldc]; g[vl] = row[wl + ldc + 1];
+      for (int k = 0; k < wl; ++k) if (row[k] != 0.0 && p0[l] + k < nb) { const int vk = band_var[p0[l] + k]; H[(size_t)vl * nt + vk] = row[k]; H[(size_t)vk * nt + vl] = row[k]; }
+      for (int b = 0; b < nbd; ++b) if (row[wl + b] != 0.0 && bord_var[b] >= 0) { H[(size_t)vl * nt + bord_var[b]] = row[wl + b]; H[(size_t)bord_var[b] * nt + vl] = row[wl + b]; }
+    }
   }
   return LVX_OK;
 }

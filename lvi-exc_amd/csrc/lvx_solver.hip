@@ -297,7 +297,7 @@ __global__ void k_unscale(const int* ord, int nt, const double* yb, const double
   if (v < nt) {
     const int o = ord[v];
     double d = 0.0;
-    if (o != LVX_DEAD) {
+    if (o != LVX_DEAD && o < LVX_LM_BASE) {   // landmark entries: k_lm_back
       const int i = o >= 0 ? o : nb + (-1 - o);
       const double y = o >= 0 ? yb[o] : yc[-1 - o];
       const double g = o >= 0 ? gb[o] : gc[-1 - o];
@@ -391,6 +391,79 @@ __global__ void k_plus(const double* x, const double* delta, int N, int L, uint3
   for (int o = 32; o > 0; o >>= 1) { dn += __shfl_xor(dn, o); xn += __shfl_xor(xn, o); }
   if ((threadIdx.x & 63) == 0 && (dn != 0.0 || xn != 0.0)) { atomicAdd(&sums[2], dn); atomicAdd(&sums[3], xn); }
 }
+// ---------------------------------------------------------------------------------------------------------
+// Landmark elimination.  Every landmark (inverse depth) is a 1 x 1 diagonal block of J^T J coupled to the knots its views touch and to the
+// camera extrinsics (DevCommon::lmH); ceres' SPARSE_SCHUR eliminates exactly these e-blocks first.  With Jacobi scaling s and LM damping,
+//   d_l = s_l^2 H_ll + lmd_l / radius,  w_l = s_l^2 / d_l :   A' = A - sum_l w_l E_l^T E_l,   g' = g - sum_l w_l E_l^T g_l
+// on the UNSCALED band / border rows / dense border / gradients (copies: a rejected step solves the same normal equations again with another
+// radius), and after the reduced solve  delta_l = -w_l (g_l + E_l . delta).
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_lm_fetch_diag(const double* lmH, int L, int ls, int off, double* out) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l < L) out[l] = lmH[(size_t)l * ls + off];
+}
+__global__ __launch_bounds__(256) void k_lm_schur(const double* __restrict__ lmH, const int* __restrict__ p0s, int wl, int nbd, int ls, const double* __restrict__ scale_l,
+                                                  const double* __restrict__ lmd_l, double inv_radius, double* Hr, int bw, double* Br, int nb, double* Cr, int ldc, double* gbr, double* gcr) {
+  extern __shared__ double e[];            // the landmark's row, then the indices of its non-zero couplings
+  const int l = blockIdx.x, ne = wl + nbd;
+  int* idx = (int*)(e + ne + 2);
+  __shared__ int nn_s;
+  const double* row = lmH + (size_t)l * ls;
+  if (threadIdx.x == 0) nn_s = 0;
+  for (int k = threadIdx.x; k < ne + 2; k += 256) e[k] = row[k];
+  __syncthreads();
+  const double Hll = e[ne], gl = e[ne + 1];
+  if (!(Hll > 0.0)) return;                 // no observation reached this landmark: nothing to eliminate
+  for (int k = threadIdx.x; k < ne; k += 256) if (e[k] != 0.0) idx[atomicAdd(&nn_s, 1)] = k;
+  __syncthreads();
+  const int nn = nn_s, p0 = p0s[l];
+  const double s = scale_l[l], w = s * s / (s * s * Hll + lmd_l[l] * inv_radius);
+  for (int t = threadIdx.x; t < nn * nn; t += 256) {
+    const int ia = t / nn, ib = t - ia * nn;
+    if (ib > ia) continue;
+    const int ka = idx[ia], kb = idx[ib];
+    const double val = -w * e[ka] * e[kb];
+    const int lo = ka < kb ? ka : kb, hi = ka < kb ? kb : ka;
+    if (hi < wl) atomicAdd(&Hr[(size_t)(p0 + lo) * (bw + 1) + (hi - lo)], val);
+    else if (lo < wl) atomicAdd(&Br[(size_t)(hi - wl) * nb + p0 + lo], val);
+    else atomicAdd(&Cr[(size_t)(hi - wl) * ldc + (lo - wl)], val);
+  }
+  for (int t = threadIdx.x; t < nn; t += 256) {
+    const int k = idx[t];
+    const double val = -w * e[k] * gl;
+    if (k < wl) atomicAdd(&gbr[p0 + k], val); else atomicAdd(&gcr[k - wl], val);
+  }
+}
+// delta_l = -w_l (g_l + E_l . delta) and the landmark's terms of g.delta (sums[0]), y^T D^2 y (sums[1]) and delta^T H delta (sums[5]); a wavefront per landmark
+__global__ __launch_bounds__(256) void k_lm_back(const double* __restrict__ lmH, const int* __restrict__ p0s, int L, int wl, int nbd_solve, int nbd, int ls, const double* __restrict__ scale_l,
+                                                 const double* __restrict__ lmd_l, double inv_radius, const double* __restrict__ yb, const double* __restrict__ yc, const double* __restrict__ scale,
+                                                 int nb, double* delta_l, double* sums) {
+  const int l = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (l >= L) return;
+  const double* row = lmH + (size_t)l * ls;
+  const int p0 = p0s[l];
+  double dot = 0.0;
+  for (int k = lane; k < wl; k += 64) { const double ev = row[k]; if (ev != 0.0) dot += ev * yb[p0 + k] * scale[p0 + k]; }
+  for (int b = lane; b < nbd_solve; b += 64) { const double ev = row[wl + b]; if (ev != 0.0) dot += ev * yc[b] * scale[nb + b]; }
+  for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+  if (lane != 0) return;
+  const double Hll = row[wl + nbd], gl = row[wl + nbd + 1];
+  double d = 0.0;
+  if (Hll > 0.0) {
+    const double s = scale_l[l], dmp = lmd_l[l] * inv_radius, w = s * s / (s * s * Hll + dmp);
+    d = -w * (gl + dot);
+    const double y = d / s;
+    atomicAdd(&sums[0], gl * d); atomicAdd(&sums[1], y * y * dmp); atomicAdd(&sums[5], d * (Hll * d + 2.0 * dot));
+  }
+  delta_l[l] = d;
+}
+__global__ void k_gmax_lm(const double* lmH, int L, int ls, int off, double* sums) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  double v = l < L ? fabs(lmH[(size_t)l * ls + off]) : 0.0;
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long*)&sums[4], (unsigned long long)__double_as_longlong(v));
+}
+
 // max |g| over free scalars
 __global__ void k_gmax(const double* gb, const double* gc, int nb, int nbd, double* sums) {   // nbd: border entries to include (the shared tail is excluded in the joint solve)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -410,7 +483,9 @@ using namespace lvx;
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
-struct SolveWork { double *L, *Z, *S, *rhs, *delta, *diag, *scale, *lmd, *sums, *Z2, *gram; int* info; int ldz; bool use_bcr; };
+struct SolveWork { double *L, *Z, *S, *rhs, *delta, *diag, *scale, *lmd, *sums, *Z2, *gram; int* info; int ldz; bool use_bcr;
+                   bool lm;                                   // landmarks are eliminated first (k_lm_schur)
+                   const double *Hs, *Bs, *Cs, *gbs, *gcs; };   // what the band / border solve reads: the normal equations, or their copies after the landmark elimination
 
 // host all-reduce hook of the joint (sequence-per-GPU) solve; identity for a single sequence
 static int reduce(lvx_ctx* c, double* buf, int n, int op) {
@@ -422,7 +497,7 @@ static int reduce(lvx_ctx* c, double* buf, int n, int op) {
 static int solver_alloc(lvx_ctx* c, SolveWork& w) {
   int rc;
   const size_t nb = (size_t)std::max(c->nb, 1), nbd = c->nbd, nt = (size_t)lvx_tangent_size(c);
-  const bool use_bcr = !getenv("LVX_SOLVER_SEQ");
+  const bool use_bcr = !c->sw.solver_seq;
   size_t ldz = nb;
   if (use_bcr && c->nb > 0) { if ((rc = bcr_plan(c))) return rc; ldz = (size_t)c->bcr_nblk * c->bcr_b; }
   w.ldz = (int)ldz; w.use_bcr = use_bcr && c->nb > 0;
@@ -431,11 +506,22 @@ static int solver_alloc(lvx_ctx* c, SolveWork& w) {
   w.Z2 = (double*)c->d_Y2.p; w.gram = (double*)c->d_gram.p;
   if ((rc = dev_alloc(c, c->d_S, (nbd * nbd + nbd + 16) * 8))) return rc;
   if ((rc = dev_alloc(c, c->d_delta, nt * 8))) return rc;
-  if ((rc = dev_alloc(c, c->d_diag, 3 * (nb + nbd) * 8))) return rc;
+  const size_t nall = nb + nbd + (size_t)std::max(c->L, 0);
+  if ((rc = dev_alloc(c, c->d_diag, 3 * nall * 8))) return rc;
+  w.lm = c->L > 0 && c->rep.n > 0 && !(c->locks & LVX_LOCK_LANDMARKS);
+  w.Hs = (const double*)c->d_Hb.p; w.Bs = (const double*)c->d_Bd.p; w.Cs = (const double*)c->d_C.p; w.gbs = (const double*)c->d_gb.p; w.gcs = (const double*)c->d_gc.p;
+  if (w.lm) {
+    const size_t ldc = c->nbd_ext;
+    if ((rc = dev_alloc(c, c->d_Hr, c->d_Hb.bytes))) return rc;
+    if ((rc = dev_alloc(c, c->d_Br, (size_t)nbd * nb * 8))) return rc;
+    if ((rc = dev_alloc(c, c->d_red, (nb + ldc * ldc + ldc) * 8))) return rc;
+    w.Hs = (const double*)c->d_Hr.p; w.Bs = (const double*)c->d_Br.p; w.gbs = (const double*)c->d_red.p; w.Cs = w.gbs + nb; w.gcs = w.Cs + ldc * ldc;
+  }
+  c->p_Hs = w.Hs;
   if ((rc = dev_alloc(c, c->d_scal, 64 * 8))) return rc;
   if ((rc = dev_alloc(c, c->d_state_try, (size_t)lvx_state_size(c) * 8))) return rc;
   w.L = (double*)c->d_L.p; w.Z = (double*)c->d_Y.p; w.S = (double*)c->d_S.p; w.rhs = w.S + nbd * nbd; w.delta = (double*)c->d_delta.p;
-  w.diag = (double*)c->d_diag.p; w.scale = w.diag + (nb + nbd); w.lmd = w.scale + (nb + nbd);
+  w.diag = (double*)c->d_diag.p; w.scale = w.diag + nall; w.lmd = w.scale + nall;
   w.sums = (double*)c->d_scal.p; w.info = (int*)(w.sums + 32);
   // shared extrinsics of the joint solve: tangent 6N+8 .. 6N+21 own the LAST 14 border slots (ensure_layout gives every calibration
   // scalar a fixed slot after the hub knots; a locked one keeps an inert slot with S_aa = lmd / radius)
@@ -455,13 +541,13 @@ static int solver_alloc(lvx_ctx* c, SolveWork& w) {
 // of w.S / w.rhs holds this sequence's contribution to the reduced system of the shared variables (all of the border system when ns = 0).
 struct StageTimer {   // LVX_SOLVER_TIMING=1: host wall time per stage (enqueue cost) and at the synchronisation points
   bool on; std::chrono::steady_clock::time_point t;
-  StageTimer() : on(getenv("LVX_SOLVER_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+  explicit StageTimer(const lvx_ctx* c) : on(c->sw.solver_timing != 0), t(std::chrono::steady_clock::now()) {}
   void lap(const char* what) { if (!on) return; const auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[lvx solver] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count()); t = n; }
 };
 
 static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, bool* bcr_used) {
   hipStream_t st = c->stream;
-  StageTimer tm;
+  StageTimer tm(c);
   const int nb = c->nb, bw = c->bw, nbd = c->nbd;
   const double ir = 1.0 / radius;
   LVX_HIP(c, hipMemsetAsync(w.sums, 0, 64 * 8, st));
@@ -469,9 +555,21 @@ static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, 
   *bcr_used = use_bcr;
   if (!use_bcr && nb > 0) { int rca = dev_alloc(c, c->d_L, (size_t)nb * (bw + 1) * 8); if (rca) return rca; w.L = (double*)c->d_L.p; }
   const int ldz = w.ldz;
+  if (w.lm) {   // copies of the normal equations, then A' = A - sum_l w_l E_l^T E_l, g' = g - sum_l w_l E_l^T g_l
+    const size_t nb1 = (size_t)std::max(nb, 1), ldc = c->nbd_ext;
+    LVX_HIP(c, hipMemcpyAsync((void*)w.Hs, c->d_Hb.p, nb1 * (bw + 1) * 8, hipMemcpyDeviceToDevice, st));
+    LVX_HIP(c, hipMemcpyAsync((void*)w.Bs, c->d_Bd.p, (size_t)nbd * nb1 * 8, hipMemcpyDeviceToDevice, st));
+    LVX_HIP(c, hipMemcpyAsync((void*)w.gbs, c->d_gb.p, nb1 * 8, hipMemcpyDeviceToDevice, st));
+    LVX_HIP(c, hipMemcpyAsync((void*)w.Cs, c->d_C.p, ldc * ldc * 8, hipMemcpyDeviceToDevice, st));
+    LVX_HIP(c, hipMemcpyAsync((void*)w.gcs, c->d_gc.p, ldc * 8, hipMemcpyDeviceToDevice, st));
+    const size_t lds = (size_t)(c->lm_wl + c->nbd_ext + 2) * 8 + (size_t)(c->lm_wl + c->nbd_ext) * 4 + 16;
+    LVX_HIP(c, hipFuncSetAttribute((const void*)k_lm_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_lm_schur, dim3((unsigned)c->L), dim3(256), lds, st, (const double*)c->d_lmH.p, (const int*)c->d_lm_p0.p, c->lm_wl, c->nbd_ext, c->lm_ls, w.scale + (nb + nbd), w.lmd + (nb + nbd), ir,
+                       (double*)w.Hs, bw, (double*)w.Bs, nb, (double*)w.Cs, c->nbd_ext, (double*)w.gbs, (double*)w.gcs);
+  }
   if (nb > 0) {
     const size_t tr = (size_t)(nbd + 1) * ldz;
-    hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)((tr + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Bd.p, (const double*)c->d_gb.p, w.scale, nb, nbd, ldz, w.Z);
+    hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)((tr + 255) / 256)), dim3(256), 0, st, w.Bs, w.gbs, w.scale, nb, nbd, ldz, w.Z);
     if (use_bcr) {
       int rc2;
       tm.lap("enqueue build_rhs");
@@ -481,7 +579,7 @@ static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, 
       tm.lap("enqueue bcr_forward");
     } else {
       const size_t tot = (size_t)nb * (bw + 1);
-      hipLaunchKernelGGL(k_build_band, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, w.scale, w.lmd, ir, nb, bw, w.L);
+      hipLaunchKernelGGL(k_build_band, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, w.Hs, w.scale, w.lmd, ir, nb, bw, w.L);
       const size_t lds_ch = (size_t)(bw + CH_NB) * (CH_NB + 1) * 8;
       if (lds_ch > 150 * 1024) return fail(c, LVX_E_ARG, "bandwidth too large for the single-workgroup band Cholesky panel");
       LVX_HIP(c, hipFuncSetAttribute((const void*)k_band_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ch));
@@ -495,10 +593,10 @@ static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, 
   if (use_bcr && nb > 0) {
     int rc2;
     if ((rc2 = bcr_gram(c, Zf, ldz, nbd + 1, w.gram))) return rc2;
-    hipLaunchKernelGGL(k_schur_from_gram, dim3((unsigned)((nbd * (nbd + 1) + 255) / 256)), dim3(256), 0, st, (const double*)w.gram, (const double*)c->d_C.p, (const double*)c->d_gc.p,
+    hipLaunchKernelGGL(k_schur_from_gram, dim3((unsigned)((nbd * (nbd + 1) + 255) / 256)), dim3(256), 0, st, (const double*)w.gram, w.Cs, w.gcs,
                        (const double*)w.scale, nb, nbd, c->nbd_ext, (const double*)w.lmd, ir, w.S, w.rhs);
   } else {
-    hipLaunchKernelGGL(k_schur, dim3(nbd), dim3(256), 0, st, (const double*)Zf, (const double*)c->d_C.p, (const double*)c->d_gc.p, (const double*)w.scale,
+    hipLaunchKernelGGL(k_schur, dim3(nbd), dim3(256), 0, st, (const double*)Zf, w.Cs, w.gcs, (const double*)w.scale,
                        nb > 0 ? nb : 0, nbd, c->nbd_ext, ldz, (const double*)w.lmd, ir, w.S, w.rhs);
   }
   hipLaunchKernelGGL(k_dense_partial, dim3(1), dim3(256), 0, st, w.S, w.rhs, nbd, nbd - c->ns, w.info);
@@ -579,6 +677,9 @@ static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double* ou
   }
   hipLaunchKernelGGL(k_unscale, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, (const int*)c->d_ord.p, nt, (const double*)zb, (const double*)w.rhs, (const double*)w.scale,
                      (const double*)w.lmd, ir, (const double*)c->d_gb.p, (const double*)c->d_gc.p, nb, w.delta, w.sums);
+  if (w.lm) hipLaunchKernelGGL(k_lm_back, dim3((unsigned)((c->L + 3) / 4)), dim3(256), 0, st, (const double*)c->d_lmH.p, (const int*)c->d_lm_p0.p, c->L, c->lm_wl, nbd, c->nbd_ext, c->lm_ls,
+                               (const double*)(w.scale + (nb + nbd)), (const double*)(w.lmd + (nb + nbd)), ir, (const double*)zb, (const double*)w.rhs, (const double*)w.scale, nb,
+                               w.delta + 6 * (size_t)c->N + 22, w.sums);
   if (nb > 0) hipLaunchKernelGGL(k_quad_band, dim3((unsigned)std::min(2048, (nb + 3) / 4)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)zb, (const double*)w.scale, nb, bw, w.sums);
   hipLaunchKernelGGL(k_quad, dim3((unsigned)((nb + nbd + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)c->d_Bd.p, (const double*)c->d_C.p, c->nbd_ext,
                      (const double*)zb, (const double*)w.rhs, (const double*)w.scale, nb, bw, nbd, w.sums);
@@ -598,6 +699,8 @@ static int prepare_diag(lvx_ctx* c, SolveWork& w, bool compute_scale, int use_sc
   const int n = c->nb + c->nbd;
   hipStream_t st = c->stream;
   hipLaunchKernelGGL(k_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)c->d_C.p, c->nb, c->bw, c->nbd, c->nbd_ext, w.diag);
+  const int nl = w.lm ? c->L : 0;   // landmark diagonal behind the band / border entries
+  if (nl > 0) hipLaunchKernelGGL(k_lm_fetch_diag, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, (const double*)c->d_lmH.p, nl, c->lm_ls, c->lm_wl + c->nbd_ext, w.diag + n);
   const int ns = c->ns;
   double* dsh = w.diag + (n - ns);
   if (c->ar_fn) {   // diagonal of the JOINT normal equations at the shared scalars: Jacobi scaling and LM damping must agree on every rank
@@ -608,8 +711,8 @@ static int prepare_diag(lvx_ctx* c, SolveWork& w, bool compute_scale, int use_sc
     for (int i = 0; i < ns; ++i) h[i] = buf[c->sh_slot[i]];
     if (ns > 0) { LVX_HIP(c, hipMemcpyAsync(dsh, h, (size_t)ns * 8, hipMemcpyHostToDevice, st)); LVX_HIP(c, hipStreamSynchronize(st)); }
   }
-  if (compute_scale) hipLaunchKernelGGL(k_scale_from_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)w.diag, n, w.scale, use_scaling);
-  hipLaunchKernelGGL(k_lm_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)w.diag, (const double*)w.scale, n, mn, mx, w.lmd);
+  if (compute_scale) hipLaunchKernelGGL(k_scale_from_diag, dim3((unsigned)((n + nl + 255) / 256)), dim3(256), 0, st, (const double*)w.diag, n + nl, w.scale, use_scaling);
+  hipLaunchKernelGGL(k_lm_diag, dim3((unsigned)((n + nl + 255) / 256)), dim3(256), 0, st, (const double*)w.diag, (const double*)w.scale, n + nl, mn, mx, w.lmd);
   if (c->ar_fn && ns > 0) {   // shared damping is applied once to the reduced system (solve_step_device), not per rank
     LVX_HIP(c, hipMemcpyAsync(c->sh_lmd, w.lmd + (n - ns), (size_t)ns * 8, hipMemcpyDeviceToHost, st));
     LVX_HIP(c, hipStreamSynchronize(st));
@@ -639,8 +742,15 @@ int lvx_solve_step_shared(lvx_ctx* c, double radius, int jacobi_scaling, lvx_all
   if (!c || !(radius > 0)) return LVX_E_ARG;
   if (!(c->last_what & LVX_EVAL_NORMAL_EQ)) return fail(c, LVX_E_STATE, "lvx_solve_step needs a preceding LVX_EVAL_NORMAL_EQ evaluation");
   LVX_HIP(c, hipSetDevice(c->device));
+  int rc = check_last_eval(c);   // an evaluation queued without a cost pointer has not had its device error word read yet
   HookScope hook(c, fn, user);
-  SolveWork w; int rc = solver_alloc(c, w); if (rc) return rc;
+  if (fn) {   // joint solve: every rank must leave together
+    double e = rc ? 1.0 : 0.0;
+    if (fn(user, &e, 1, LVX_REDUCE_MAX) != 0) return fail(c, LVX_E_COMM, "all-reduce callback failed");
+    if (e != 0.0 && !rc) return fail(c, LVX_E_COMM, "another rank's evaluation failed");
+  }
+  if (rc) return rc;
+  SolveWork w; if ((rc = solver_alloc(c, w))) return rc;
   if ((rc = prepare_diag(c, w, true, jacobi_scaling, 1e-6, 1e32))) return rc;
   double out[3];
   if ((rc = solve_step_device(c, w, radius, out))) return rc;
@@ -683,6 +793,7 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
     LVX_HIP(c, hipMemsetAsync(w.sums + 4, 0, 8, st));
     const int n = c->nb + c->nbd - c->ns;
     hipLaunchKernelGGL(k_gmax, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)c->d_gb.p, (const double*)c->d_gc.p, c->nb, c->nbd - c->ns, w.sums);
+    if (w.lm) hipLaunchKernelGGL(k_gmax_lm, dim3((unsigned)((c->L + 255) / 256)), dim3(256), 0, st, (const double*)c->d_lmH.p, c->L, c->lm_ls, c->lm_wl + c->nbd_ext + 1, w.sums);
     double gs[LVX_N_SHARED] = {0}, hsh[LVX_N_SHARED];
     LVX_HIP(c, hipMemcpyAsync(g, w.sums + 4, 8, hipMemcpyDeviceToHost, st));
     if (c->ns > 0) LVX_HIP(c, hipMemcpyAsync(hsh, (const double*)c->d_gc.p + (c->nbd - c->ns), (size_t)c->ns * 8, hipMemcpyDeviceToHost, st));

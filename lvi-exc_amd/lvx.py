@@ -159,6 +159,10 @@ class Context:
     def set_locks(self, mask):
         self._ck(self._l.lvx_set_locks(self._h, C.c_uint32(mask)))
 
+    def set_switch(self, name, value=1):
+        """Experiment / debug switch of this context, e.g. set_switch("FORCE_LEGACY", 1)."""
+        self._ck(self._l.lvx_set_switch(self._h, C.c_char_p(name.encode()), C.c_int(int(value))))
+
     def set_so3_only(self, flag):
         """Solve #0 estimator (TrajectoryEstimator<UniformSO3SplineTrajectory>): R3 spline absent, gyro + prior only."""
         self._so3_only = bool(flag)

@@ -315,11 +315,80 @@ def make_problem(seed=4, duration=10.0, dt=0.02, imu_rate=400.0, n_surfel=2000, 
                 state_true=state_true, state0=state0, t_start=t_start, t_end=t_end)
 
 
+def _bench_visual(sp, cam, rng, t_start, t_end, n_reproj, q_CI, p_CI, tracks, views_per_lm, cam_rate, obs_per_frame, noise_px=0.5):
+    """Landmarks + rolling-shutter observations, exactly consistent with the trajectory up to pixel noise (vectorised).
+
+    tracks = "orb": ORB-SLAM-like co-visibility: the frames come in windows of `views_per_lm` consecutive frames (1 / cam_rate apart) that
+        all see the same ~obs_per_frame map points (>= 100 observations per frame, every frame pair of a window co-visible); the windows are
+        spread evenly over the sequence.  The reference observation of a map point is its first view (70 %) or the second / third one.
+    tracks = "sparse": SURVEY 8d's literal reading (n_reproj / views landmarks, each first seen in a random frame of a continuous 20 Hz
+        stream and tracked over the next views_per_lm frames: ~5 observations per frame, no two blocks share a frame pair).
+    Observations that leave the image or come closer than 0.5 m are dropped; landmarks keep the reference's rule of > 5 observations
+    (trajectory_manager_lvi.cpp:518-524); the result is trimmed to n_reproj blocks (whole landmarks)."""
+    row_d = cam["readout"] / cam["rows"]
+    t_frames = np.arange(t_start + 0.1, t_end - 0.2, 1.0 / cam_rate)
+    over = 1.5
+    if tracks == "orb":
+        n_win = max(1, int(round(n_reproj / float(views_per_lm * obs_per_frame))))
+        w0 = np.linspace(0, len(t_frames) - views_per_lm - 1, n_win).astype(np.int64)
+        per = int(obs_per_frame * over)
+        win = np.repeat(np.arange(n_win), per)
+        n_lm = len(win)
+        ref_k = rng.choice(3, size=n_lm, p=[0.7, 0.2, 0.1])
+        f_first = w0[win]
+    else:
+        n_lm = int(n_reproj // views_per_lm * over)
+        f_first = rng.integers(0, len(t_frames) - views_per_lm, n_lm)
+        ref_k = np.zeros(n_lm, dtype=np.int64)
+    lm_uv = np.stack([rng.uniform(150, cam["cols"] - 150, n_lm), rng.uniform(100, cam["rows"] - 100, n_lm)], axis=1)
+    z = rng.uniform(3.0, 15.0, n_lm)
+    lm_t0 = t_frames[f_first + ref_k]
+
+    def cam_pose(t):
+        e = sp.eval(t)
+        return qmul(e["quat"], np.broadcast_to(q_CI, e["quat"].shape)), qrot(e["quat"], p_CI) + e["pos"]
+
+    qc, pc = cam_pose(lm_t0 + lm_uv[:, 1] * row_d)
+    PW = qrot(qc, _unproject(cam, lm_uv) * z[:, None]) + pc
+    lm = np.repeat(np.arange(n_lm), views_per_lm)
+    view = np.tile(np.arange(views_per_lm), n_lm)
+    t0o = t_frames[f_first[lm] + view]
+    vv = np.full(len(lm), cam["cy"])
+    for _ in range(5):   # fixed point on the row time: the observation's row decides when the pose is sampled
+        qo, po = cam_pose(t0o + vv * row_d)
+        Xc = qrot(qconj(qo), PW[lm] - po)
+        uv = _project(cam, np.where(Xc[:, 2:3] > 1e-3, Xc, np.array([0.0, 0.0, 1.0])))
+        vv = np.clip(uv[:, 1], 0.0, cam["rows"] - 1.0)
+    is_ref = view == ref_k[lm]
+    ok = (Xc[:, 2] > 0.5) & (uv[:, 0] >= 1) & (uv[:, 0] < cam["cols"] - 1) & (uv[:, 1] >= 1) & (uv[:, 1] < cam["rows"] - 1)
+    uv = uv + noise_px * rng.standard_normal(uv.shape)
+    uv[is_ref] = lm_uv[lm[is_ref]]   # the reference observation itself is one of the blocks (r = 0 rows)
+    ok |= is_ref
+    cnt = np.bincount(lm[ok], minlength=n_lm)
+    keep_lm = cnt > 5
+    if tracks == "orb":   # the same number of map points per window
+        order = np.argsort(np.where(keep_lm, 0, 1) * n_lm + np.arange(n_lm), kind="stable")
+        rank_in_win = np.empty(n_lm, dtype=np.int64)
+        for w in range(n_win):
+            idx = order[win[order] == w]
+            rank_in_win[idx] = np.arange(len(idx))
+        budget = np.cumsum(np.where(keep_lm, cnt, 0)[np.lexsort((np.arange(n_lm), rank_in_win))])
+        sel = np.zeros(n_lm, dtype=bool)
+        sel[np.lexsort((np.arange(n_lm), rank_in_win))[budget <= n_reproj]] = True
+        keep_lm &= sel
+    else:
+        csum = np.cumsum(np.where(keep_lm, cnt, 0))
+        keep_lm &= csum <= n_reproj
+    new_id = np.cumsum(keep_lm) - 1
+    rows = ok & keep_lm[lm]
+    return dict(n_landmarks=int(keep_lm.sum()), lm_uv=lm_uv[keep_lm], lm_t0=lm_t0[keep_lm], rho=1.0 / z[keep_lm],
+                rep_lm=new_id[lm[rows]].astype(np.int32), rep_uv=uv[rows], rep_t0=t0o[rows])
+
+
 def make_bench_problem(seed=4, n_imu=200_000, n_surfel=1_000_000, n_reproj=50_000, n_planes=2000, dt=0.02, imu_rate=400.0,
-                       views_per_lm=10, cam_rate=20.0, pad=0.2, t_start=100.0):
-    """BASELINE.json config 4 shapes (1 M surfel / 200 k IMU / 50 k ORB) generated fully vectorised.
-    Landmarks are synthesised without the rolling-shutter fixed point (observations = reprojection with the row
-    time of the reference row + pixel noise); parity/throughput do not depend on exact consistency."""
+                       views_per_lm=10, cam_rate=20.0, pad=0.2, t_start=100.0, tracks="orb", obs_per_frame=100):
+    """BASELINE.json config 4 shapes (1 M surfel / 200 k IMU / 50 k ORB) generated fully vectorised; every measurement is consistent with
+    the ground-truth state up to its sensor noise, so the problem can be solved to convergence.  `tracks`: see _bench_visual."""
     rng = np.random.default_rng(seed)
     cam = dict(DEFAULT_CAMERA)
     duration = n_imu / imu_rate
@@ -354,39 +423,19 @@ def make_bench_problem(seed=4, n_imu=200_000, n_surfel=1_000_000, n_reproj=50_00
     ek = sp.eval(t_s)
     pG = qrot(R0q, qrot(q_LI, pM) + p_LI) + p0
     pt_s = qrot(qconj(q_LI), qrot(qconj(ek["quat"]), pG - ek["pos"]) - p_LI) + 0.02 * rng.standard_normal((n_surfel, 3))
-    # landmarks
-    n_landmarks = n_reproj // views_per_lm
-    row_d = cam["readout"] / cam["rows"]
-    t_frames = np.arange(t_start + 0.1, t_end - 0.2, 1.0 / cam_rate)
-    f0 = rng.integers(0, len(t_frames) - views_per_lm, n_landmarks)
-    lm_uv = np.stack([rng.uniform(100, cam["cols"] - 100, n_landmarks), rng.uniform(100, cam["rows"] - 100, n_landmarks)], axis=1)
-    z = rng.uniform(2.0, 15.0, n_landmarks)
-    lm_t0 = t_frames[f0]
-    er = sp.eval(lm_t0 + lm_uv[:, 1] * row_d)
-    qc = qmul(er["quat"], np.broadcast_to(q_CI, er["quat"].shape)); pc = qrot(er["quat"], p_CI) + er["pos"]
-    PW = qrot(qc, _unproject(cam, lm_uv) * z[:, None]) + pc
-    rep_lm = np.repeat(np.arange(n_landmarks, dtype=np.int32), views_per_lm)
-    fi = (f0[:, None] + np.arange(views_per_lm)[None, :]).ravel()
-    rep_t0 = t_frames[fi]
-    eo = sp.eval(rep_t0 + cam["cy"] * row_d)
-    qo = qmul(eo["quat"], np.broadcast_to(q_CI, eo["quat"].shape)); po = qrot(eo["quat"], p_CI) + eo["pos"]
-    Xc = qrot(qconj(qo), PW[rep_lm] - po)
-    Xc[:, 2] = np.maximum(Xc[:, 2], 0.5)
-    rep_uv = _project(cam, Xc) + 0.5 * rng.standard_normal((len(rep_lm), 2))
-    rep_uv[:, 0] = np.clip(rep_uv[:, 0], 0, cam["cols"] - 1); rep_uv[:, 1] = np.clip(rep_uv[:, 1], 0, cam["rows"] - 1)
-    first = np.arange(n_landmarks) * views_per_lm
-    rep_uv[first] = lm_uv
-    rho = 1.0 / z
+    V = _bench_visual(sp, cam, rng, t_start, t_end, n_reproj, q_CI, p_CI, tracks, views_per_lm, cam_rate, obs_per_frame)
+    rho = V["rho"]
     state_true = pack_state(r3, so3, imu_block(roll, pitch, ba, bg), sensor_block(q_LI, p_LI), sensor_block(q_CI, p_CI), rho)
     r3p = r3 + 1e-2 * rng.standard_normal(r3.shape)
     so3p = qmul(q_from_rotvec(1e-2 * rng.standard_normal((n_knots, 3))), so3); so3p /= np.linalg.norm(so3p, axis=1, keepdims=True)
     dqL = q_from_rotvec(np.deg2rad(3.0) * np.array([0.6, -0.5, 0.62])); dqC = q_from_rotvec(np.deg2rad(3.0) * np.array([-0.4, 0.7, 0.59]))
-    state0 = pack_state(r3p, so3p, imu_block(0.01, 0.01), sensor_block(qmul(dqL, q_LI), p_LI + 0.03), sensor_block(qmul(dqC, q_CI), p_CI - 0.03), rho)
+    state0 = pack_state(r3p, so3p, imu_block(0.01, 0.01), sensor_block(qmul(dqL, q_LI), p_LI + 0.03), sensor_block(qmul(dqC, q_CI), p_CI - 0.03),
+                        rho * (1.0 + 0.05 * rng.standard_normal(len(rho))))
     return dict(t0=t0, dt=dt, n_knots=n_knots, camera=cam, t_imu=t_imu, gyro=gyro, acc=acc, w_gyro=28.0, w_acc=18.0,
                 planes=Pi, surf_pt=pt_s, surf_t=t_s, surf_plane=sid.astype(np.int32), t_map=t_map, huber_surf=5.0, w_surf=10.0,
-                n_landmarks=n_landmarks, lm_uv=lm_uv, lm_t0=lm_t0, rep_lm=rep_lm, rep_uv=rep_uv, rep_t0=rep_t0, huber_rep=5.0, w_rep=1.0,
+                n_landmarks=V["n_landmarks"], lm_uv=V["lm_uv"], lm_t0=V["lm_t0"], rep_lm=V["rep_lm"], rep_uv=V["rep_uv"], rep_t0=V["rep_t0"], huber_rep=5.0, w_rep=1.0,
                 cs_lm=np.zeros(0, dtype=np.int32), cs_plane=np.zeros(0, dtype=np.int32), huber_cs=5.0, w_cs=30.0,
-                state_true=state_true, state0=state0, t_start=t_start, t_end=t_end)
+                state_true=state_true, state0=state0, t_start=t_start, t_end=t_end, tracks=tracks)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -27,12 +27,14 @@ def bench_problem():
 
 def _border(ctx, lo):
     n = lo["border_ld"]
-    buf = torch.zeros(n * n + n + 1, dtype=torch.float64, device="cuda")
+    buf = torch.zeros(n * n + n + 2, dtype=torch.float64, device="cuda")
     ctx.evaluate_resident(lvx.EVAL_COST | lvx.EVAL_NORMAL_EQ)
     ctx.export_border(buf.data_ptr())
     ctx.synchronize()
     torch.cuda.synchronize()
-    return buf.cpu().numpy()
+    out = buf.cpu().numpy()
+    assert out[-1] == 0.0          # device error word of the pass
+    return out
 
 
 def test_mfma_path_equals_per_segment_kernels_at_full_size(bench_problem):
@@ -42,13 +44,9 @@ def test_mfma_path_equals_per_segment_kernels_at_full_size(bench_problem):
     g.set_state(P["state0"])
     out = {}
     for mode in ("mfma", "legacy"):
-        if mode == "legacy":
-            os.environ["LVX_FORCE_LEGACY"] = "1"
-        try:
-            c = g.evaluate_resident(lvx.EVAL_COST | lvx.EVAL_NORMAL_EQ, want_cost=True)
-            d, m = g.solve_step(1e4, True)
-        finally:
-            os.environ.pop("LVX_FORCE_LEGACY", None)
+        g.set_switch("FORCE_LEGACY", 1 if mode == "legacy" else 0)
+        c = g.evaluate_resident(lvx.EVAL_COST | lvx.EVAL_NORMAL_EQ, want_cost=True)
+        d, m = g.solve_step(1e4, True)
         out[mode] = (c, d, m)
     (c1, d1, m1), (c2, d2, m2) = out["mfma"], out["legacy"]
     assert abs(c1 - c2) <= 1e-12 * abs(c2)
