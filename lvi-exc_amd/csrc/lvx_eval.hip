@@ -538,7 +538,7 @@ __global__ __launch_bounds__(64) void k_reproj_jac(ReprojFam fam, DevCommon cm, 
 // LDS panels; T = J_ref^T J_obs accumulates in 3 x 3 MFMA tiles over the whole group and leaves with one atomic per non-zero entry.
 // The landmark's own row (rho x everything, 56 entries per block) is formed from the same registers with one lane exchange.
 typedef double d4 __attribute__((ext_vector_type(4)));
-struct RepCross { RepJac jac; const int* lm; const int* goff; const int* gw; int ng; int dbg; };   // gw[g] = w0, gw[ng + g] = w1
+struct RepCross { RepJac jac; const int* lm; const int* goff; const int* gw; int ng; int dbg; double* T; };   // T[i][56]: the landmark-row products of block i (k_reproj_lmrows)   // gw[g] = w0, gw[ng + g] = w1
 __global__ __launch_bounds__(256) void k_reproj_cross(RepCross rc, DevCommon cm) {
   constexpr int LDP = 49, BR = 16;   // panel: 16 rows (8 blocks x 2 residual rows) x 48 columns, odd stride
   __shared__ double pan[4][2][BR * LDP];
@@ -596,10 +596,9 @@ __global__ __launch_bounds__(256) void k_reproj_cross(RepCross rc, DevCommon cm)
 #pragma unroll
           for (int cj = 0; cj < 3; ++cj) D[ci * 3 + cj] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[ci], fo[cj], D[ci * 3 + cj], 0, 0, 0);
       }
-      // the landmark's row: rho x [ref knots | obs knots | camera | rho | gradient] = 56 entries per block.  Every lane forms the products of
-      // its 12 knot columns (summed over the two residual rows: lanes part and part ^ 2), three spare lanes the rest; the 8 x 56 values pass
-      // through LDS so that CONSECUTIVE LANES add CONSECUTIVE ENTRIES of one landmark row (scattered FP64 atomics run at a sixth of the rate)
-      const int prho = (valid && lm_free) ? cm.ord[6 * N + 22 + rc.lm[i]] : LVX_DEAD;
+      // the landmark's row: rho x [ref knots | obs knots | camera | rho | gradient] = 56 products per block.  Every lane forms those of its 12
+      // knot columns (summed over the two residual rows: lanes part and part ^ 2), three spare lanes the rest; the 8 x 56 values pass through
+      // LDS and leave as one contiguous 448-byte record per block — k_reproj_lmrows sums a landmark's records into its row without atomics
       if (!(rc.dbg & 1)) {
         double t[12];
 #pragma unroll
@@ -623,18 +622,8 @@ __global__ __launch_bounds__(256) void k_reproj_cross(RepCross rc, DevCommon cm)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int bl = 0; bl < 8; ++bl) {
-          const int pr = __shfl(prho, 8 * bl), kr = __shfl(k0, 8 * bl), ko = __shfl(k1, 8 * bl);
-          if (pr == LVX_DEAD) continue;   // wave-uniform
-          if (lane < 56) {
-            const double val = tbuf[wv][bl * 56 + lane];
-            if (lane < 55) {
-              const int q = lane < 24 ? lane : lane - 24;
-              const int pc = lane < 48 ? cm.ord[6 * ((lane < 24 ? kr : ko) + q / 6) + q % 6] : (lane < 54 ? cm.ord[6 * N + 15 + (lane - 48)] : pr);
-              if (pc != LVX_DEAD && val != 0.0) add_H(cm, pr, pc, val, rep);
-            } else if (val != 0.0) add_g(cm, pr, val, rep);
-          }
-        }
+        const int nblk8 = min(8, m1 - base);
+        for (int e2 = lane; e2 < nblk8 * 56; e2 += 64) rc.T[(size_t)base * 56 + e2] = tbuf[wv][e2];   // records of consecutive blocks are contiguous
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -661,6 +650,51 @@ __global__ __launch_bounds__(256) void k_reproj_cross(RepCross rc, DevCommon cm)
           add_H(cm, pa, pb, pa == pb ? 2.0 * val : val, rep);
         }
   }
+}
+
+// Landmark rows from the per-block records of k_reproj_cross: a wavefront OWNS landmark l — it sums the records of the landmark's blocks into
+// an LDS image of the row [band couplings | border couplings | H_ll | g_l] and stores the whole row (no atomics, nothing to clear beforehand).
+struct RepLmRows { const double* T; const int* k; int n; const int* ptr; const int* rows; int L; };   // blocks of landmark l: rows[ptr[l] .. ptr[l + 1])
+__global__ __launch_bounds__(256) void k_reproj_lmrows(RepLmRows q, DevCommon cm) {
+  extern __shared__ double rowbuf[];   // 4 x [lm_ls]
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l = blockIdx.x * 4 + wv;
+  if (l >= q.L) return;
+  double* rb = rowbuf + (size_t)wv * cm.lm_ls;
+  for (int k = lane; k < cm.lm_ls; k += 64) rb[k] = 0.0;
+  const int j0 = q.ptr[l], j1 = q.ptr[l + 1], p0 = cm.lm_p0[l], N = cm.N;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int jb = j0; jb < j1; jb += 4) {   // 4 blocks in flight
+    double val[4]; int pc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      val[u] = 0.0; pc[u] = LVX_DEAD;
+      if (jb + u < j1 && lane < 56) {
+        const int i = q.rows[jb + u];
+        const int kr = q.k[i], ko = q.k[(size_t)q.n + i];
+        if (ko >= 0) {
+          val[u] = q.T[(size_t)i * 56 + lane];
+          const int c = lane < 24 ? lane : lane - 24;
+          pc[u] = lane < 48 ? cm.ord[6 * ((lane < 24 ? kr : ko) + c / 6) + c % 6] : (lane < 54 ? cm.ord[6 * N + 15 + (lane - 48)] : LVX_LM_BASE);   // 54: H_ll, 55: g_l
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (pc[u] == LVX_DEAD || val[u] == 0.0) continue;
+      int slot;
+      if (lane >= 54) slot = cm.lm_wl + cm.nbd + (lane - 54);
+      else if (pc[u] >= 0) { slot = pc[u] - p0; if (slot < 0 || slot >= cm.lm_wl) { atomicOr(cm.err, 4); continue; } }
+      else slot = cm.lm_wl + (-1 - pc[u]);
+      atomicAdd(&rb[slot], val[u]);   // LDS: the same variable can appear through both poses of a block
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  double* row = cm.lmH + (size_t)l * cm.lm_ls;
+  for (int k = lane; k < cm.lm_ls; k += 64) row[k] = rb[k];
 }
 
 #define ACC_BW 24
@@ -1327,7 +1361,7 @@ int ensure_layout(lvx_ctx* ctx) {
     {
       std::vector<int> s1(f.n), s0(f.n);
       for (int i = 0; i < f.n; ++i) { s1[i] = k1[perm[i]]; s0[i] = k0[perm[i]]; }
-      const int rows = ctx->sw.rep_rows > 0 ? ctx->sw.rep_rows : 4 * (int)RepSideAcc<1>::LB;   // 64 rows = one batch of 4 wavefronts x LB = 16 rows
+      const int rows = ctx->sw.rep_rows > 0 ? ctx->sw.rep_rows : 16 * (int)RepSideAcc<1>::LB;   // 256 rows = four batches of 4 wavefronts x LB = 16 rows (measured: 64 rows 73 + 88 us, 256 rows 52 + 62 us)
       if ((rc = upload_chunks_rows_grouped(ctx, LVX_FAM_REPROJ, s1, 48, rows))) return rc;
       if ((rc = upload_chunks_rows_grouped(ctx, LVX_FAM_PRIOR /* slot reused: the prior has no chunks */, s0, 48, rows))) return rc;
       // groups of the cross-term kernel: runs of equal (reference window, observation window); rows that are out of range form no group
@@ -1337,6 +1371,15 @@ int ensure_layout(lvx_ctx* ctx) {
         const int a0 = s0[i] >> 2, a1 = s1[i] >> 2;
         // a wavefront walks its group 8 blocks at a time: at most 32 blocks per group, a larger (window, window) pair is shared by several
         if (goff.empty() || gw0.back() != a0 || gw1.back() != a1 || i - goff.back() >= 32) { goff.push_back(i); gw0.push_back(a0); gw1.push_back(a1); }
+      }
+      {   // blocks of every landmark (k_reproj_lmrows), positions in this row order
+        std::vector<int> ptr((size_t)L + 1, 0), rows((size_t)std::max(f.n, 1));
+        for (int i = 0; i < f.n; ++i) { const int l = f.id0[perm[i]]; if (l >= 0 && l < L) ptr[l + 1]++; }
+        for (int l = 0; l < L; ++l) ptr[l + 1] += ptr[l];
+        std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+        for (int i = 0; i < f.n; ++i) { const int l = f.id0[perm[i]]; if (l >= 0 && l < L) rows[fill[l]++] = i; }
+        ptr.insert(ptr.end(), rows.begin(), rows.end());
+        if ((rc = upload_tmp(ctx, ctx->d_repB[3], ptr.data(), ptr.size() * 4))) return rc;
       }
       ctx->rep_groups = (int)goff.size();
       goff.push_back(f.n);
@@ -1350,6 +1393,7 @@ int ensure_layout(lvx_ctx* ctx) {
     if ((rc = upload_tmp(ctx, f.d_perm, perm.data(), perm.size() * 4))) return rc;
     if ((rc = dev_alloc(ctx, ctx->d_repB[0], (size_t)std::max(f.n, 1) * (2 * REP_NC + 2) * 8))) return rc;   // materialised Jacobians + residuals
     if ((rc = dev_alloc(ctx, ctx->d_repB[1], (size_t)std::max(f.n, 1) * 2 * 4))) return rc;                    // knot intervals
+    if ((rc = dev_alloc(ctx, ctx->d_repT, (size_t)std::max(f.n, 1) * 56 * 8))) return rc;                      // landmark-row records
   }
   {
     Family& f = ctx->cs;
@@ -1599,7 +1643,8 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
           b0 = b1;
         }
         add(cm.C, (size_t)LVX_NREP * ctx->nbd_ext * ctx->nbd_ext * 8); add(cm.gc, (size_t)LVX_NREP * ctx->nbd_ext * 8);
-        if (ctx->L > 0 && ctx->rep.n > 0 && !(ctx->locks & LVX_LOCK_LANDMARKS)) add(cm.lmH, (size_t)ctx->L * ctx->lm_ls * 8);
+        const bool rep_fast = fast && !(!(ctx->locks & LVX_LOCK_CAM_TAU)) && !ctx->sw.reproj_legacy && ctx->rep_groups > 0;   // k_reproj_lmrows stores whole rows: nothing to clear
+        if (ctx->L > 0 && ctx->rep.n > 0 && !(ctx->locks & LVX_LOCK_LANDMARKS) && !rep_fast) add(cm.lmH, (size_t)ctx->L * ctx->lm_ls * 8);
       }
       size_t total = 0; for (int i = 0; i < cl.n; ++i) total += cl.words[i];
       const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
@@ -1725,8 +1770,15 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
               LVX_LAUNCH_MFMA1(RepSideAcc<0>, 1, rb2, LVX_FAM_PRIOR, s_ref, ctx->fam_row0[4]);
               if (ctx->rep_groups > 0) {
                 const int* gt = (const int*)ctx->d_repB[2].p;
-                const RepCross rx{jac, r.lm, gt, gt + ctx->rep_groups + 1, ctx->rep_groups, ctx->sw.cross_dbg};
+                const RepCross rx{jac, r.lm, gt, gt + ctx->rep_groups + 1, ctx->rep_groups, ctx->sw.cross_dbg, (double*)ctx->d_repT.p};
                 hipLaunchKernelGGL(k_reproj_cross, dim3((unsigned)std::min((ctx->rep_groups + 3) / 4, 256 * 8)), dim3(256), 0, s_ref, rx, cm);
+                if (ctx->L > 0 && !(ctx->locks & LVX_LOCK_LANDMARKS)) {
+                  const int* lp = (const int*)ctx->d_repB[3].p;
+                  const RepLmRows lq{(const double*)ctx->d_repT.p, kb, r.n, lp, lp + ctx->L + 1, ctx->L};
+                  const size_t lds = (size_t)4 * ctx->lm_ls * 8;
+                  LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_reproj_lmrows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                  hipLaunchKernelGGL(k_reproj_lmrows, dim3((unsigned)((ctx->L + 3) / 4)), dim3(256), lds, s_ref, lq, cm);
+                }
               }
             }
           } else
@@ -1890,7 +1942,7 @@ void lvx_destroy(lvx_ctx* c) {
   if (c->d_hubs.p) (void)hipFree(c->d_hubs.p);
   if (c->d_pre.p) (void)hipFree(c->d_pre.p);
   if (c->d_colfull.p) (void)hipFree(c->d_colfull.p);
-  for (DevBuf* b : {&c->d_lmH, &c->d_lm_p0, &c->d_Hr, &c->d_Br, &c->d_red}) if (b->p) (void)hipFree(b->p);
+  for (DevBuf* b : {&c->d_lmH, &c->d_lm_p0, &c->d_Hr, &c->d_Br, &c->d_red, &c->d_repT}) if (b->p) (void)hipFree(b->p);
   for (DevBuf* b : {&c->vox.misc, &c->vox.keys, &c->vox.vals, &c->vox.runs, &c->vox.cells, &c->vox.tmp, &c->vox.leaf_i, &c->vox.leaf_d, &c->vox.leaf_f}) if (b->p) (void)hipFree(b->p);
   bcr_destroy(c);
   for (DevBuf* b : {&c->d_bcrD, &c->d_bcrG, &c->d_bcrInfo, &c->d_Y2, &c->d_gram}) if (b->p) (void)hipFree(b->p);
