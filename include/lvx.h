@@ -135,6 +135,8 @@ int lvx_set_time_offset_bounds(lvx_ctx* ctx, double imu_max, double sensor_max);
 int lvx_state_size(const lvx_ctx* ctx);
 int lvx_tangent_size(const lvx_ctx* ctx);
 int lvx_get_layout(lvx_ctx* ctx, lvx_layout* out);
+/* first residual row of every family (LVX_FAM_* order) and, at [LVX_NUM_FAM], the total: block i of family f owns rows row0[f] + i * rows_per_block */
+int lvx_get_family_rows(lvx_ctx* ctx, int64_t row0[LVX_NUM_FAM + 1]);
 
 /* evaluation -------------------------------------------------------------------------------------------------*/
 /* One pass over every residual block at `state`: cost = sum 1/2 rho(|r|^2) (HuberLoss where the reference attaches one),
@@ -253,6 +255,9 @@ int lvx_voxel_get(lvx_ctx* ctx, int32_t* leaf_key, int32_t* leaf_n, double* mean
 /* getNeighborhoodAtPoint7 (:423-438): leaf index per displacement {0,+x,-x,+y,-y,+z,-z} or -1 */
 int lvx_voxel_lookup7(lvx_ctx* ctx, int nq, const float* xyzi4, int32_t* leaf_ids7);
 int lvx_voxel_lookup7_d(lvx_ctx* ctx, int nq, const float* xyzi4_d, int32_t* leaf_ids7_d);
+/* getNeighborhoodAtPoint1 (:440-446): the leaf of the query's own cell or -1 */
+int lvx_voxel_lookup1(lvx_ctx* ctx, int nq, const float* xyzi4, int32_t* leaf_ids1);
+int lvx_voxel_lookup1_d(lvx_ctx* ctx, int nq, const float* xyzi4_d, int32_t* leaf_ids1_d);
 /* SurfelAssociation::getAssociation flag pass (src/lvi_exc/src/core/surfel_association.cpp:111-138): plane_of_point[H*W] = surfel id or -1.
  * Conflicts resolve as the reference's SERIAL plane loop (highest plane id wins); W <= 4096 */
 int lvx_surfel_assoc(lvx_ctx* ctx, int H, int W, const float* scan_map_xyzi4, int n_planes, const double* plane_p4, const double* box_min3, const double* box_max3,

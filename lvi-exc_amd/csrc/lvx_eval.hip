@@ -2032,6 +2032,13 @@ int lvx_get_layout(lvx_ctx* c, lvx_layout* o) {
   return LVX_OK;
 }
 
+int lvx_get_family_rows(lvx_ctx* c, int64_t row0[LVX_NUM_FAM + 1]) {
+  if (!c || !row0) return LVX_E_ARG;
+  int rc = ensure_layout(c); if (rc) return rc;
+  for (int f = 0; f <= LVX_NUM_FAM; ++f) row0[f] = c->fam_row0[f];
+  return LVX_OK;
+}
+
 int lvx_evaluate_d(lvx_ctx* c, const double* state_d, uint32_t what, double* cost) {
   if (!c) return LVX_E_ARG;
   LVX_HIP(c, hipSetDevice(c->device));

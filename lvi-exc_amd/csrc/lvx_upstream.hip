@@ -471,13 +471,15 @@ __global__ void k_surfel_extract(const float4* p, const unsigned* counts, const 
   P.p4[3] = d; P.leaf = li; P.n_points = n; P.n_inliers = nin; P.plane_type = t2;
   flag[li] = 1;
 }
-__global__ void k_vx_lookup7(const float4* q, int nq, float leaf, int min_pts, VxGrid g, const int* grid, const int* leaf_n, int* ids7) {
+// K = 7: getNeighborhoodAtPoint7 (:423-438), K = 1: getNeighborhoodAtPoint1 (:440-446, the cell of the point only)
+template <int K>
+__global__ void k_vx_lookup(const float4* q, int nq, float leaf, int min_pts, VxGrid g, const int* grid, const int* leaf_n, int* ids7) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
   const float4 p = q[i];
   const int ijk[3] = {(int)floorf(p.x / leaf), (int)floorf(p.y / leaf), (int)floorf(p.z / leaf)};   // :383-385
   const int disp[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
-  for (int k = 0; k < 7; ++k) {
+  for (int k = 0; k < K; ++k) {
     int id = -1;
     bool in = true;
     for (int a = 0; a < 3; ++a) in = in && (g.min_b[a] - ijk[a] <= disp[k][a]) && (g.max_b[a] - ijk[a] >= disp[k][a]);
@@ -486,7 +488,7 @@ __global__ void k_vx_lookup7(const float4* q, int nq, float leaf, int min_pts, V
       const int li = grid[key];
       if (li >= 0 && leaf_n[li] >= min_pts) id = li;
     }
-    ids7[7 * (size_t)i + k] = id;
+    ids7[K * (size_t)i + k] = id;
   }
 }
 
@@ -752,33 +754,41 @@ int lvx_voxel_get(lvx_ctx* c, int32_t* leaf_key, int32_t* leaf_n, double* mean, 
   if (point_ids && n > 0) LVX_HIP(c, hipMemcpy(point_ids, (const int*)V.vals.p + n, n * 4, hipMemcpyDeviceToHost));
   return LVX_OK;
 }
-static int lookup_device(lvx_ctx* c, const float4* q_d, int nq, int* ids_d) {
+static int lookup_device(lvx_ctx* c, const float4* q_d, int nq, int* ids_d, int K) {
   const lvx_ctx::Voxels& V = c->vox;
-  if (!V.cells.p || V.n_leaves == 0) { LVX_HIP(c, hipMemsetAsync(ids_d, 0xff, (size_t)nq * 28, c->stream)); return LVX_OK; }
+  if (!V.cells.p || V.n_leaves == 0) { LVX_HIP(c, hipMemsetAsync(ids_d, 0xff, (size_t)nq * 4 * K, c->stream)); return LVX_OK; }
   VxGrid g; std::memcpy(&g, &V.grid, sizeof(g));
-  hipLaunchKernelGGL(k_vx_lookup7, dim3((nq + 255) / 256), dim3(256), 0, c->stream, q_d, nq, V.leaf, V.min_pts, g, (const int*)V.cells.p,
-                     (const int*)V.leaf_i.p + V.n_leaves, ids_d);
+  if (K == 7) hipLaunchKernelGGL(k_vx_lookup<7>, dim3((nq + 255) / 256), dim3(256), 0, c->stream, q_d, nq, V.leaf, V.min_pts, g, (const int*)V.cells.p, (const int*)V.leaf_i.p + V.n_leaves, ids_d);
+  else hipLaunchKernelGGL(k_vx_lookup<1>, dim3((nq + 255) / 256), dim3(256), 0, c->stream, q_d, nq, V.leaf, V.min_pts, g, (const int*)V.cells.p, (const int*)V.leaf_i.p + V.n_leaves, ids_d);
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
 }
-int lvx_voxel_lookup7(lvx_ctx* c, int nq, const float* xyzi4, int32_t* leaf_ids7) {
-  if (!c || nq < 0 || (nq > 0 && (!xyzi4 || !leaf_ids7))) return LVX_E_ARG;
+static int lookup_host(lvx_ctx* c, int nq, const float* xyzi4, int32_t* leaf_ids, int K) {
+  if (!c || nq < 0 || (nq > 0 && (!xyzi4 || !leaf_ids))) return LVX_E_ARG;
   if (nq == 0) return LVX_OK;
   LVX_HIP(c, hipSetDevice(c->device));
   int rc;
   if ((rc = upload(c, c->d_up[2], xyzi4, (size_t)nq * 16))) return rc;
-  if ((rc = dev_alloc(c, c->d_up[3], (size_t)nq * 28))) return rc;
+  if ((rc = dev_alloc(c, c->d_up[3], (size_t)nq * 4 * K))) return rc;
   { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
-    if ((rc = lookup_device(c, (const float4*)c->d_up[2].p, nq, (int*)c->d_up[3].p))) return rc; }
-  LVX_HIP(c, hipMemcpyAsync(leaf_ids7, c->d_up[3].p, (size_t)nq * 28, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = lookup_device(c, (const float4*)c->d_up[2].p, nq, (int*)c->d_up[3].p, K))) return rc; }
+  LVX_HIP(c, hipMemcpyAsync(leaf_ids, c->d_up[3].p, (size_t)nq * 4 * K, hipMemcpyDeviceToHost, c->stream));
   LVX_HIP(c, hipStreamSynchronize(c->stream));
   return LVX_OK;
 }
+int lvx_voxel_lookup7(lvx_ctx* c, int nq, const float* xyzi4, int32_t* leaf_ids7) { return lookup_host(c, nq, xyzi4, leaf_ids7, 7); }
+int lvx_voxel_lookup1(lvx_ctx* c, int nq, const float* xyzi4, int32_t* leaf_ids1) { return lookup_host(c, nq, xyzi4, leaf_ids1, 1); }
 int lvx_voxel_lookup7_d(lvx_ctx* c, int nq, const float* xyzi4_d, int32_t* leaf_ids7_d) {
   if (!c || nq <= 0 || !xyzi4_d || !leaf_ids7_d) return LVX_E_ARG;
   LVX_HIP(c, hipSetDevice(c->device));
   ProfScope ps(c, LVX_KERNEL_UPSTREAM);
-  return lookup_device(c, (const float4*)xyzi4_d, nq, leaf_ids7_d);
+  return lookup_device(c, (const float4*)xyzi4_d, nq, leaf_ids7_d, 7);
+}
+int lvx_voxel_lookup1_d(lvx_ctx* c, int nq, const float* xyzi4_d, int32_t* leaf_ids1_d) {
+  if (!c || nq <= 0 || !xyzi4_d || !leaf_ids1_d) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  ProfScope ps(c, LVX_KERNEL_UPSTREAM);
+  return lookup_device(c, (const float4*)xyzi4_d, nq, leaf_ids1_d, 1);
 }
 
 static int assoc_device(lvx_ctx* c, const float4* scan_d, int H, int W, int P, const double* planes_d, double radius, int sel, int* flag_d) {

@@ -372,6 +372,13 @@ def voxel_lookup7(ctx, queries):
     return ids
 
 
+def voxel_lookup1(ctx, queries):
+    q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, 4)
+    ids = np.full(len(q), -1, np.int32)
+    ctx._ck(ctx._l.lvx_voxel_lookup1(ctx._h, C.c_int(len(q)), _p(q), _p(ids)))
+    return ids
+
+
 def surfel_assoc(ctx, scan_hw4, p4, box_min, box_max, radius=0.05, sel=2):
     scan = np.ascontiguousarray(scan_hw4, dtype=np.float32)
     H, W = scan.shape[0], scan.shape[1]

@@ -1,0 +1,419 @@
+#!/usr/bin/env python
+"""Second, INDEPENDENT restatement of the residual functors of the path — written against the reference's headers, not against oracle/ —
+in the AMBIENT parameterisation Ceres sees (4-wide quaternion blocks, flat state layout of include/lvx.h), evaluated in 50-digit
+arithmetic (mpmath) with Jacobians by central differences (h = 1e-25: truncation and rounding both below 1e-24 relative).
+Writes tests/golden/ambient_small.npz; run here (no GPU, no reference needed): python tests/golden/make_ambient.py
+
+What is restated, and from where (K/ = src/lvi_exc/thirdparty/Kontiki/include/kontiki/):
+  spline bases M, M_cumul                         K/trajectories/spline_base.h:19-29
+  segment construction from time spans            K/trajectories/spline_base.h:380-424 (SplineEntity::AddToProblem)
+  segment dispatch incl. the t - 1e-5 retry       K/trajectories/spline_base.h:194-203
+  index / interpolation amount                    K/trajectories/spline_base.h:153-157
+  R3 evaluate (p, v, a)                           K/trajectories/uniform_r3_spline_trajectory.h:36-103
+  SO3 cumulative evaluate (q, omega)              K/trajectories/uniform_so3_spline_trajectory.h:46-125
+  logq / expq / angular_velocity                  K/math/quaternion_math.h:16-95
+  gyroscope / accelerometer model, gravity        K/sensors/imu.h:61-101, K/sensors/constant_bias_imu.h:51-61
+  gyro / accel residuals                          K/measurements/gyroscope_measurement.h:36-38, accelerometer_measurement.h:39-41
+  LiDAR surfel residual                           K/measurements/lidar_surfel_point.h:31-82
+  rolling-shutter reprojection residual           K/measurements/static_rscamera_measurement.h:20-60, 93-99, 148-172
+  pinhole Unproject / spaceToPlane / distortion   K/sensors/pinhole_camera.h:113-124, 131-191, 199-238
+  camera-landmark-to-surfel residual              K/measurements/camera_surfel_landmark.h:29-103
+  orientation prior                               K/measurements/orientation_measurement.h:30-33 (Eigen 3.3 angularDistance)
+Third-party semantics used by the TEST that consumes the fixture (restated there, from Ceres' public documentation):
+  HuberLoss corrector, EigenQuaternionParameterization::Plus.
+Eigen conventions: Quaternion storage (x, y, z, w); q * v = v + w t + qv x t with t = 2 qv x v (no normalisation anywhere).
+"""
+import os
+import sys
+
+import mpmath as mp
+import numpy as np
+
+mp.mp.dps = 50
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+F = mp.mpf
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Eigen quaternion / vector algebra on lists of mpf; quaternions are [x, y, z, w]
+# ---------------------------------------------------------------------------------------------------------
+def cross(a, b):
+    return [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]]
+
+
+def add(a, b):
+    return [x + y for x, y in zip(a, b)]
+
+
+def sub(a, b):
+    return [x - y for x, y in zip(a, b)]
+
+
+def scl(s, a):
+    return [s * x for x in a]
+
+
+def dot(a, b):
+    return sum(x * y for x, y in zip(a, b))
+
+
+def qmul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return [aw * bx + ax * bw + ay * bz - az * by, aw * by + ay * bw + az * bx - ax * bz, aw * bz + az * bw + ax * by - ay * bx, aw * bw - ax * bx - ay * by - az * bz]
+
+
+def qconj(a):
+    return [-a[0], -a[1], -a[2], a[3]]
+
+
+def qrot(q, v):   # Eigen::QuaternionBase::_transformVector
+    uv = scl(2, cross(q[:3], v))
+    return add(add(v, scl(q[3], uv)), cross(q[:3], uv))
+
+
+EPS = F("1e-16")
+
+
+def logq(q):      # quaternion_math.h:16-59
+    qn = mp.sqrt(dot(q, q))
+    if abs(qn - 1) > F("1e-5"):
+        raise RuntimeError("logq: Only implemented for unit quaternions")
+    v2 = dot(q[:3], q[:3])
+    if v2 > EPS:
+        vn = mp.sqrt(v2)
+        k = mp.atan2(vn, q[3]) / vn
+    else:
+        k = F(1)
+    return [q[0] * k, q[1] * k, q[2] * k, F(0)]
+
+
+def expq(q):      # quaternion_math.h:62-89
+    v2 = dot(q[:3], q[:3])
+    ea = mp.exp(q[3])
+    if v2 > EPS:
+        vn = mp.sqrt(v2)
+        ka, kv = ea * mp.cos(vn), ea * mp.sin(vn) / vn
+    else:
+        ka, kv = ea, ea
+    return [kv * q[0], kv * q[1], kv * q[2], ka]
+
+
+M = [[F(1) / 6, F(4) / 6, F(1) / 6, F(0)], [F(-3) / 6, F(0), F(3) / 6, F(0)], [F(3) / 6, F(-6) / 6, F(3) / 6, F(0)], [F(-1) / 6, F(3) / 6, F(-3) / 6, F(1) / 6]]
+MC = [[F(6) / 6, F(5) / 6, F(1) / 6, F(0)], [F(0), F(3) / 6, F(3) / 6, F(0)], [F(0), F(-3) / 6, F(3) / 6, F(0)], [F(0), F(1) / 6, F(-2) / 6, F(1) / 6]]
+
+
+def vecmat(u, m):   # row vector times 4 x 4
+    return [sum(u[i] * m[i][j] for i in range(4)) for j in range(4)]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the problem: flat state as in include/lvx.h, measurement arrays as lvx_set_* take them
+# ---------------------------------------------------------------------------------------------------------
+class Problem:
+    def __init__(self, P, locks_tau=True):
+        self.t0, self.dt, self.N = float(P["t0"]), float(P["dt"]), int(P["n_knots"])
+        self.L = int(P["n_landmarks"])
+        self.P = P
+        self.cam = P["camera"]
+
+    # state accessors ------------------------------------------------------------------------------------
+    def r3(self, x, k):
+        return x[3 * k:3 * k + 3]
+
+    def so3(self, x, k):
+        o = 3 * self.N + 4 * k
+        return x[o:o + 4]
+
+    def imu(self, x):
+        return x[7 * self.N:7 * self.N + 16]
+
+    def lidar(self, x):
+        return x[7 * self.N + 16:7 * self.N + 24]
+
+    def camx(self, x):
+        return x[7 * self.N + 24:7 * self.N + 32]
+
+    def rho(self, x, l):
+        return x[7 * self.N + 32 + l]
+
+    # SplineEntity::AddToProblem (spline_base.h:380-424): segments [(first master knot, number of knots)] from sorted spans ----------------
+    def segments(self, spans):
+        tmax = self.t0 + (self.N - 3) * self.dt
+        prev = None
+        for (a, b) in spans:   # TrajectoryEstimator::CheckTimeSpans (trajectory_estimator.h:102-127)
+            if a < self.t0 or b >= tmax or a > b or (prev is not None and a < prev):
+                raise IndexError("time span out of range / unordered")
+            prev = a
+        segs = []
+        cur_start, cur_end = 0, -1
+        for (a, b) in spans:
+            i1 = int(np.floor((a - self.t0) / self.dt))
+            i2 = int(np.floor((b - self.t0) / self.dt))
+            if i1 > cur_end:
+                segs.append([i1, 0])
+                cur_start = i1
+            else:
+                i1 = cur_end + 1
+            for _ in range(i1, i2 + 4):
+                segs[-1][1] += 1
+            cur_end = cur_start + segs[-1][1] - 1
+        return segs
+
+    # SplineView::Evaluate dispatch (spline_base.h:194-203) + CalculateIndexAndInterpolationAmount against the SEGMENT origin ------------------
+    def locate(self, segs, t):
+        for (i1, n) in segs:
+            t0s = self.t0 + self.dt * i1          # SplineSegmentMeta(master_dt, master_t0 + master_dt * i1): double arithmetic
+            tmin, tmax = t0s, t0s + (n - 3) * self.dt
+            tt = None
+            if tmin <= t < tmax:
+                tt = t
+            else:
+                t2 = t - 1e-5
+                if tmin <= t2 < tmax:
+                    tt = t2
+            if tt is not None:
+                s = (tt - t0s) / self.dt           # double arithmetic, as the reference evaluates it on doubles / Jet value parts
+                i0 = int(np.floor(s))
+                u = s - i0
+                if n < 4 or i0 < 0 or i0 > n - 4:
+                    raise IndexError("out of range for spline segment")
+                return i1 + i0, F(u), (i1, n)
+        raise IndexError("No segment found for time t")
+
+    def eval_r3(self, x, k0, u):                   # uniform_r3_spline_trajectory.h:51-94
+        dti = F(1) / F(self.dt)
+        u2, u3 = u ** 2, u ** 3
+        Bp = vecmat([F(1), u, u2, u3], M)
+        Bv = vecmat([F(0), dti, dti * 2 * u, dti * 3 * u2], M)
+        Ba = vecmat([F(0), F(0), dti ** 2 * 2, dti ** 2 * 6 * u], M)
+        p, v, a = [F(0)] * 3, [F(0)] * 3, [F(0)] * 3
+        for j in range(4):
+            cp = self.r3(x, k0 + j)
+            p, v, a = add(p, scl(Bp[j], cp)), add(v, scl(Bv[j], cp)), add(a, scl(Ba[j], cp))
+        return p, v, a
+
+    def eval_so3(self, x, k0, u):                  # uniform_so3_spline_trajectory.h:75-122
+        dti = F(1) / F(self.dt)
+        u2, u3 = u ** 2, u ** 3
+        B = vecmat([F(1), u, u2, u3], MC)
+        dB = vecmat([F(0), dti, dti * 2 * u, dti * 3 * u2], MC)
+        q = list(self.so3(x, k0))
+        parts = [[F(0), F(0), F(0), F(1)] for _ in range(3)]
+        for i in range(1, 4):
+            qa, qb = self.so3(x, k0 + i - 1), self.so3(x, k0 + i)
+            om = logq(qmul(qconj(qa), qb))
+            e = expq(scl(B[i], om))
+            q = qmul(q, e)
+            for m in range(3):
+                if m == i - 1:
+                    parts[m] = qmul(parts[m], scl(dB[i], om))
+                parts[m] = qmul(parts[m], e)
+        dq = qmul(self.so3(x, k0), add(add(parts[0], parts[1]), parts[2]))
+        w = scl(2, qmul(dq, qconj(q)))[:3]          # quaternion_math.h:92-95
+        return q, w
+
+    # camera model (pinhole_camera.h) ------------------------------------------------------------------------
+    def distortion(self, pu):
+        c = self.cam
+        k1, k2, p1, p2, k3 = (F(c[k]) for k in ("k1", "k2", "p1", "p2", "k3"))
+        mx2, my2, mxy = pu[0] * pu[0], pu[1] * pu[1], pu[0] * pu[1]
+        r2 = mx2 + my2
+        rad = k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2
+        return [pu[0] * rad + 2 * p1 * mxy + p2 * (r2 + 2 * mx2), pu[1] * rad + 2 * p2 * mxy + p1 * (r2 + 2 * my2)]
+
+    def do_distortion(self):
+        c = self.cam
+        return abs(c["k1"]) > 1e-5 or abs(c["k2"]) > 1e-5 or abs(c["p1"]) > 1e-5 or abs(c["p1"]) > 1e-5   # sic: p1 twice (pinhole_camera.h:78-80)
+
+    def unproject(self, y):
+        c = self.cam
+        fx, fy, cx, cy = F(c["fx"]), F(c["fy"]), F(c["cx"]), F(c["cy"])
+        if not self.do_distortion():
+            return [(y[0] - cx) / fx, (y[1] - cy) / fy, F(1)]   # camera_matrix().inverse() * (u, v, 1)
+        mxd, myd = (F(1) / fx) * y[0] + (-cx / fx), (F(1) / fy) * y[1] + (-cy / fy)
+        du = self.distortion([mxd, myd])
+        mxu, myu = mxd - du[0], myd - du[1]
+        for _ in range(1, 8):
+            du = self.distortion([mxu, myu])
+            mxu, myu = mxd - du[0], myd - du[1]
+        return [mxu, myu, F(1)]
+
+    def project(self, X):
+        c = self.cam
+        eps = F("1e-32")
+        pu = [X[0] / (eps + X[2]), X[1] / (eps + X[2])]
+        pd = pu if not self.do_distortion() else add(pu, self.distortion(pu))
+        return [F(c["fx"]) * pd[0] + F(c["cx"]), F(c["fy"]) * pd[1] + F(c["cy"])]
+
+    # pose at t through the segments of one residual block
+    def pose(self, x, segs, t, want):
+        k0, u, _ = self.locate(segs, t)
+        out = {}
+        if "p" in want or "a" in want:
+            p, v, a = self.eval_r3(x, k0, u)
+            out.update(p=p, a=a)
+        if "q" in want or "w" in want:
+            q, w = self.eval_so3(x, k0, u)
+            out.update(q=q, w=w)
+        out["knots"] = k0
+        return out
+
+    # ---- residual blocks: each returns (residual list, segments) as a function of the flat state x --------------------------------------------
+    def gyro(self, x, i):
+        P = self.P
+        t = float(P["t_imu"][i])
+        segs = self.segments([(t, t)])
+        im = self.imu(x)
+        e = self.pose(x, segs, t + float(im[7]), "qw")
+        pred = add(qrot(qconj(e["q"]), e["w"]), im[13:16])
+        return scl(F(P["w_gyro"]), sub([F(v) for v in P["gyro"][i]], pred)), segs
+
+    def accel(self, x, i):
+        P = self.P
+        t = float(P["t_imu"][i])
+        segs = self.segments([(t, t)])
+        im = self.imu(x)
+        e = self.pose(x, segs, t + float(im[7]), "qa")
+        roll, pitch = im[8], im[9]
+        G = F("-9.79")
+        grav = [-mp.sin(pitch) * mp.cos(roll) * G, mp.sin(roll) * G, -mp.cos(roll) * mp.cos(pitch) * G]   # imu.h:61-70
+        pred = add(qrot(qconj(e["q"]), add(e["a"], grav)), im[10:13])
+        return scl(F(P["w_acc"]), sub([F(v) for v in P["acc"][i]], pred)), segs
+
+    def _plane_dist(self, pM, Pi):
+        d = mp.sqrt(dot(Pi, Pi))
+        n = [Pi[0] / d, Pi[1] / d, Pi[2] / d]
+        return dot(n, pM) - d
+
+    def surfel(self, x, i):
+        P = self.P
+        tm, tk = float(P["t_map"]), float(P["surf_t"][i])
+        segs = self.segments([(tm, tm), (tk, tk)])
+        ld = self.lidar(x)
+        qL, pL, tau = ld[0:4], ld[4:7], float(ld[7])
+        e0, ek = self.pose(x, segs, tm + tau, "pq"), self.pose(x, segs, tk + tau, "pq")
+        pI = add(qrot(qL, [F(v) for v in P["surf_pt"][i]]), pL)
+        ptmp = qrot(qconj(e0["q"]), sub(add(qrot(ek["q"], pI), ek["p"]), e0["p"]))
+        pM = qrot(qconj(qL), sub(ptmp, pL))
+        Pi = [F(v) for v in P["planes"][P["surf_plane"][i]]]
+        return [F(P["w_surf"]) * self._plane_dist(pM, Pi)], segs
+
+    def reproj(self, x, i):
+        P, c = self.P, self.cam
+        l = int(P["rep_lm"][i])
+        t0r, t0o = float(P["lm_t0"][l]), float(P["rep_t0"][i])
+        t1, t2 = (t0r, t0o) if t0r <= t0o else (t0o, t0r)
+        mg, ro = 1e-3, float(c["readout"])
+        segs = self.segments([(t1 - mg, t1 + ro + mg), (t2 - mg, t2 + ro + mg)])
+        cm = self.camx(x)
+        qC, pC, tau = cm[0:4], cm[4:7], float(cm[7])
+        rowd = ro / float(c["rows"])
+        uvr, uvo = P["lm_uv"][l], P["rep_uv"][i]
+        er = self.pose(x, segs, t0r + tau + float(uvr[1]) * rowd, "pq")
+        eo = self.pose(x, segs, t0o + tau + float(uvo[1]) * rowd, "pq")
+        rho = self.rho(x, l)
+        pct = qrot(qconj(qC), scl(-1, pC))
+        qct = qconj(qC)
+        yh = self.unproject([F(uvr[0]), F(uvr[1])])
+        Xref = qrot(qconj(qct), sub(yh, scl(rho, pct)))
+        X = add(qrot(er["q"], Xref), scl(rho, er["p"]))
+        Xobs = qrot(qconj(eo["q"]), sub(X, scl(rho, eo["p"])))
+        Xc = add(qrot(qct, Xobs), scl(rho, pct))
+        yhat = self.project(Xc)
+        return scl(F(P["w_rep"]), sub([F(uvo[0]), F(uvo[1])], yhat)), segs
+
+    def camsurf(self, x, i):
+        P = self.P
+        l = int(P["cs_lm"][i])
+        tm, tk = float(P["t_map"]), float(P["lm_t0"][l])
+        segs = self.segments([(tm, tm), (tk, tk)])
+        cm, ld = self.camx(x), self.lidar(x)
+        qC, pC, tau = cm[0:4], cm[4:7], float(cm[7])
+        qL, pL = ld[0:4], ld[4:7]
+        e0, ek = self.pose(x, segs, tm + tau, "pq"), self.pose(x, segs, tk + tau, "pq")
+        rho = F(float(self.rho(x, l)))          # read as a constant double (camera_surfel_landmark.h:159-161)
+        yh = scl(F(1) / (rho + F("1e-8")), self.unproject([F(v) for v in P["lm_uv"][l]]))
+        pI = add(qrot(qC, yh), pC)
+        ptmp = qrot(qconj(e0["q"]), sub(add(qrot(ek["q"], pI), ek["p"]), e0["p"]))
+        pM = qrot(qconj(qL), sub(ptmp, pL))
+        Pi = [F(v) for v in P["planes"][P["cs_plane"][i]]]
+        return [F(P["w_cs"]) * self._plane_dist(pM, Pi)], segs
+
+    def prior(self, x, t, q_wxyz, w):
+        segs = self.segments([(t, t)])
+        e = self.pose(x, segs, t, "q")
+        qm = [F(q_wxyz[1]), F(q_wxyz[2]), F(q_wxyz[3]), F(q_wxyz[0])]
+        d = qmul(qm, qconj(e["q"]))                # Eigen 3.3 angularDistance: 2 atan2(|vec(d)|, |d.w|)
+        return [F(w) * 2 * mp.atan2(mp.sqrt(dot(d[:3], d[:3])), abs(d[3]))], segs
+
+    # state entries a block depends on: control points of its segments + every sensor / landmark entry (zero columns cost nothing)
+    def deps(self, segs, extra):
+        idx = []
+        for (i1, n) in segs:
+            for k in range(i1, i1 + n):
+                idx += list(range(3 * k, 3 * k + 3)) + list(range(3 * self.N + 4 * k, 3 * self.N + 4 * k + 4))
+        return sorted(set(idx + extra))
+
+
+def jacobian(fn, x, deps, h=F("1e-25")):
+    r0, _ = fn(x)
+    J = np.zeros((len(r0), len(x)))
+    for j in deps:
+        xp, xm = list(x), list(x)
+        xp[j] = x[j] + h
+        xm[j] = x[j] - h
+        rp, _ = fn(xp)
+        rm, _ = fn(xm)
+        for a in range(len(r0)):
+            J[a, j] = float((rp[a] - rm[a]) / (2 * h))
+    return [float(v) for v in r0], J
+
+
+def main():
+    sys.path.insert(0, os.path.join(ROOT, "lvi-exc_amd"))
+    import synth   # only the seeded DATA generator; nothing below uses its evaluator
+    P = synth.make_problem(seed=31, duration=0.6, n_surfel=14, n_planes=5, n_landmarks=3, views_per_lm=5, n_camsurf=2, imu_rate=20.0)
+    # one reprojection block whose two views share a frame already exists (the reference observation); make one landmark's second view the
+    # NEXT frame (50 ms: the padded spans of ref and obs merge into one 5-7 knot segment, spline_base.h:398-424)
+    pr = Problem(P)
+    N, L = pr.N, pr.L
+    state = P["state0"].copy()
+    state[7 * N + 8:7 * N + 10] = [0.013, -0.021]          # gravity roll / pitch away from the symmetric default
+    x = [F(float(v)) for v in state]
+    sens = list(range(7 * N, 7 * N + 32))
+    blocks = []   # (family, index, residual, J)
+    prior = (float(P["t0"]), np.array([np.cos(5e-5), 0.0, 0.0, np.sin(5e-5)]), 28.0)
+    for i in range(len(P["t_imu"])):
+        fn = lambda xx, i=i: pr.gyro(xx, i)
+        blocks.append(("gyro", i) + jacobian(fn, x, pr.deps(fn(x)[1], sens)))
+    for i in range(len(P["t_imu"])):
+        fn = lambda xx, i=i: pr.accel(xx, i)
+        blocks.append(("accel", i) + jacobian(fn, x, pr.deps(fn(x)[1], sens)))
+    fn = lambda xx: pr.prior(xx, *prior)
+    blocks.append(("prior", 0) + jacobian(fn, x, pr.deps(fn(x)[1], [])))
+    for i in range(len(P["surf_t"])):
+        fn = lambda xx, i=i: pr.surfel(xx, i)
+        blocks.append(("surfel", i) + jacobian(fn, x, pr.deps(fn(x)[1], sens)))
+    for i in range(len(P["rep_lm"])):
+        fn = lambda xx, i=i: pr.reproj(xx, i)
+        blocks.append(("reproj", i) + jacobian(fn, x, pr.deps(fn(x)[1], sens + [7 * N + 32 + int(P["rep_lm"][i])])))
+    for i in range(len(P["cs_lm"])):
+        fn = lambda xx, i=i: pr.camsurf(xx, i)
+        blocks.append(("camsurf", i) + jacobian(fn, x, pr.deps(fn(x)[1], sens)))
+    res = np.concatenate([np.array(b[2]) for b in blocks])
+    J = np.concatenate([b[3] for b in blocks], axis=0)
+    fam = np.concatenate([[["gyro", "accel", "prior", "surfel", "reproj", "camsurf"].index(b[0])] * len(b[2]) for b in blocks]).astype(np.int32)
+    blk = np.concatenate([[k] * len(b[2]) for k, b in enumerate(blocks)]).astype(np.int32)
+    keys = ["t0", "dt", "n_knots", "t_imu", "gyro", "acc", "w_gyro", "w_acc", "planes", "surf_pt", "surf_t", "surf_plane", "t_map", "huber_surf", "w_surf", "n_landmarks",
+            "lm_uv", "lm_t0", "rep_lm", "rep_uv", "rep_t0", "huber_rep", "w_rep", "cs_lm", "cs_plane", "huber_cs", "w_cs"]
+    out = {k: np.asarray(P[k]) for k in keys}
+    out.update({"camera_" + k: np.asarray(v) for k, v in P["camera"].items()})
+    out.update(state=state, residuals=res, J_ambient=J, row_family=fam, row_block=blk, prior_t=prior[0], prior_q_wxyz=prior[1], prior_w=prior[2])
+    np.savez_compressed(os.path.join(HERE, "ambient_small.npz"), **out)
+    print("ambient_small.npz: %d blocks, %d residual rows, state size %d, max |r| %.3e, max |J| %.3e" % (len(blocks), len(res), len(state), np.abs(res).max(), np.abs(J).max()))
+
+
+if __name__ == "__main__":
+    main()

@@ -93,7 +93,9 @@ def test_voxel_build_and_lookup_config2(ctx):
     vg = lvx.voxel_build(ctx, cloud, 0.5)
     _check_voxels(vg, vo)
     q = synth.rigid_move(cloud)
-    assert np.array_equal(lvx.voxel_lookup7(ctx, q), O.voxel_lookup7(vo, q, 0.5))
+    ids7 = O.voxel_lookup7(vo, q, 0.5)
+    assert np.array_equal(lvx.voxel_lookup7(ctx, q), ids7)
+    assert np.array_equal(lvx.voxel_lookup1(ctx, q), ids7[:, 0])      # getNeighborhoodAtPoint1 = the zero displacement of DIRECT7
 
 
 def test_voxel_edge_cases(ctx):
@@ -106,6 +108,7 @@ def test_voxel_edge_cases(ctx):
     far = cloud.copy(); far[:, :3] += 500.0                   # queries outside the grid
     far[::7, 0] = np.nan
     assert np.array_equal(lvx.voxel_lookup7(ctx, far), O.voxel_lookup7(vo, far, 1.0))
+    assert np.array_equal(lvx.voxel_lookup1(ctx, far), O.voxel_lookup7(vo, far, 1.0)[:, 0])
     one = np.array([[0.1, 0.2, 0.3, 0.0]] * 7, np.float32)    # a single voxel, 7 coincident points: singular covariance
     vo1, vg1 = O.voxel_build(one, 0.5), lvx.voxel_build(ctx, one, 0.5)
     assert np.array_equal(vg1["leaf_n"], vo1["leaf_n"]) and vg1["n_leaves"] == 1
