@@ -8,9 +8,12 @@ structured normal equations, with the state and all measurement arrays already r
 N > 1: one independent calibration sequence per GPU (weak scaling, seed 40 + rank), no data-path collective;
 the only exchange is one RCCL all-reduce per step of the shared-calibration block of the normal equations.
 
-Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel
-(LiDAR surfel, measured with HIP events on the library's own stream) and `cpu_baseline` (the oracle — a
-restatement of the reference's per-block autodiff evaluator — timed on a bounded sample on the host cores).
+The second half of BASELINE.json's metric — surfel association Mpts/s at 1/2/4/8 GPUs — is measured in the same run (`secondary.surfel_assoc`):
+every rank associates its own shard of scans against the same surfel map (lvx_surfel_assoc_batch_d) and the per-point flags are all-gathered.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the time-dominant kernel
+(measured with HIP events on the library's own stream) plus every family's and the whole pass's fraction, and `cpu_baseline`
+(the oracle — a restatement of the reference's per-block autodiff evaluator — timed on a bounded sample on the host cores).
 """
 import argparse
 import json
@@ -32,41 +35,118 @@ FP64_PEAK_TFLOPS = 78.6      # MI355X FP64: vector 78.6 TFLOP/s = matrix (v_mfma
 # correction was calibrated on).  Reads: 56 B of row inputs per block (t, point, row-ordered plane) = 56 MB would be the cold figure, the
 # counter sees 33 MB (the rest hits the 256 MB Infinity Cache from the previous pass); writes: the accumulator flushes (one atomic per touched
 # band / border entry per workgroup, 1954 workgroups) — the register-spill scratch of the earlier rounds (232 MB) is gone.
-PMC_TRAFFIC_BYTES = 91.8e6
+PMC_TRAFFIC_BYTES = 91.8e6   # a constant copied from the profile named below, not measured by this run
 PMC_SOURCE = "profiles/r01j_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per dispatch)"
 BYTES_PER_EVAL = {"imu": 32, "surfel": 60, "reproj": 60}
 FLOPS_PER_EVAL = {"imu": 4e3, "surfel": 9e3, "reproj": 11e3}
 
 
+def assoc_metric(ctx, world, rank, scans_per_gpu=64):
+    """surfel-assoc Mpts/s: every rank associates its own shard of scans (weak scaling: scans_per_gpu each) against one surfel map, flags all-gathered
+    (scan-level kernels shard by scan, no arithmetic collective)."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    import lvx
+    import sharded
+    import synth
+    scan, p4, bmin, bmax = synth.make_assoc_problem(seed=5, H=16, W=1800, n_planes=2000)
+    H, W, P = scan.shape[0], scan.shape[1], len(p4)
+    n_scans = scans_per_gpu * world
+    lo, hi = sharded.scan_shard(n_scans, rank, world)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    local = torch.from_numpy(np.ascontiguousarray(scan, np.float32)).to(dev).unsqueeze(0).repeat(hi - lo, 1, 1, 1).contiguous()
+    local[:, :, :, 0] += 1e-3 * torch.arange(lo, hi, device=dev, dtype=torch.float32).view(-1, 1, 1)     # the scans differ
+    pl = torch.from_numpy(np.concatenate([p4.ravel(), bmin.ravel(), bmax.ravel()])).to(dev)
+    flags = torch.empty((hi - lo, H * W), dtype=torch.int32, device=dev)
+
+    def step():
+        ctx._ck(ctx._l.lvx_surfel_assoc_batch_d(ctx._h, C.c_int(hi - lo), C.c_int(H), C.c_int(W), C.c_void_p(local.data_ptr()), C.c_int(P), C.c_void_p(pl.data_ptr()), C.c_double(0.05), C.c_int(2),
+                                                C.c_void_p(flags.data_ptr())))
+        return sharded.all_gather_scan_results(dist, flags, n_scans) if world > 1 else flags
+    for _ in range(3):
+        step()
+    ctx.synchronize(); torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = step()
+    ctx.synchronize(); torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tm = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(tm, op=dist.ReduceOp.MAX); dt = float(tm.item())
+    pts = n_scans * H * W
+    res = {"Mpts_per_s": pts * reps / dt / 1e6, "scans": n_scans, "scans_per_gpu": scans_per_gpu, "points_per_scan": H * W, "planes": P, "ms_per_call": 1e3 * dt / reps,
+           "associated_points": int((out >= 0).sum().item()), "scaling": "weak",
+           "roofline": {"bound": "hbm", "achieved": 20.0 * pts * reps / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 20.0 * pts * reps / dt / 1e9 / HBM_PEAK_GBS,
+                        "note": "20 B per point algorithmic (16 B read + 4 B flag, SURVEY 8d); the kernels are bound by dependent lookups (cell -> list -> box) and the bitmask atomics, not by HBM"}}
+    if rank == 0:   # the reference's OpenMP loop over planes (restated in the oracle) on the host cores, one scan
+        from oracle import oracle as O
+        cores = usable_cores()
+        O.surfel_assoc_omp(scan, p4, bmin, bmax, 0.05, 2, cores)
+        t0 = time.perf_counter(); n = 0
+        while time.perf_counter() - t0 < 3.0:
+            O.surfel_assoc_omp(scan, p4, bmin, bmax, 0.05, 2, cores); n += 1
+        res["cpu_openmp"] = {"Mpts_per_s": H * W * n / (time.perf_counter() - t0) / 1e6, "cores": cores, "kind": "port", "sample": "%d passes over one scan, OpenMP over planes as surfel_association.cpp:122" % n}
+    return res
+
+
 def secondary_metrics(ctx, P, lo):
-    """Side measurements (not the headline value): one full LM iteration incl. the linear solve, and the upstream kernels of
-    BASELINE.json configs 1-2 / the surfel-association metric, inputs resident in HBM, wall-clock over repeated calls."""
+    """Side measurements (not the headline value): one full LM iteration incl. the linear solve, the converged two-stage solve, a pass with
+    free sensor time offsets, and the upstream kernels of BASELINE.json configs 1-2, inputs resident in HBM, wall-clock over repeated calls."""
     import lvx
     import synth
     sec = {}
     try:
-        import time
-        ctx.lm_solve(P["state0"], max_iterations=1)      # untimed: rocBLAS / rocSOLVER handle creation and kernel loading (~160 ms, once per process)
+        ctx.lm_solve(P["state0"], max_iterations=1)      # untimed: rocBLAS handle creation and kernel loading (~160 ms, once per process)
         t0 = time.perf_counter()
         _, sm = ctx.lm_solve(P["state0"], max_iterations=3)
         dt = time.perf_counter() - t0
         it = max(1, sm["iterations"])
         sec["lm_iteration"] = {"ms_per_iteration": 1e3 * dt / it, "iterations": it, "Mevals_per_s_incl_solve": lo["n_blocks"] * (it + sm["successful_steps"] + 1) / dt / 1e6,
-                               "note": "evaluate(+J^T J) + block-cyclic-reduction solve + candidate cost evaluation per iteration; host-synchronised"}
+                               "note": "evaluate(+J^T J) + landmark elimination + block-cyclic-reduction solve + candidate cost evaluation per iteration; host-synchronised"}
     except Exception as e:   # noqa: BLE001
         sec["lm_iteration"] = {"error": str(e)[:200]}
+    try:   # config 4 "to convergence": the reference's stage schedule to a Ceres termination (tests/calib_stages.py, tests/test_gpu_converge.py)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import calib_stages as cs
+        x, log = cs.run_stages_gpu(P, P["state0"])
+        sec["converged_solve"] = {"seconds": sum(dt for _, _, dt in log), "stages": [{"stage": n, "iterations": s["iterations"], "termination": s["termination"], "final_cost": s["final_cost"], "seconds": dt}
+                                                                                        for n, s, dt in log],
+                                  "distance_to_truth": cs.extrinsic_errors(x, P["state_true"], P["n_knots"]),
+                                  "note": "trajInitFromSurfel (<= 30 it) then trajInitFromLVIdata (<= 80 it) from the 3 deg / 3 cm perturbed start, wall time incl. problem upload"}
+    except Exception as e:   # noqa: BLE001
+        sec["converged_solve"] = {"error": str(e)[:200]}
+    try:   # free LiDAR / camera time offsets (the reference's opt_time_offset_ stages): surfel and reprojection take the per-segment TAU kernels
+        g = lvx.Context(0)
+        lvx.load_problem(g, P, 0)
+        g.set_state(P["state0"])
+        for _ in range(2):
+            g.evaluate_resident(lvx.EVAL_COST | lvx.EVAL_NORMAL_EQ)
+        g.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            g.evaluate_resident(lvx.EVAL_COST | lvx.EVAL_NORMAL_EQ)
+        g.synchronize()
+        dtf = (time.perf_counter() - t0) / 5
+        g.close()
+        sec["free_time_offsets"] = {"ms_per_step": 1e3 * dtf, "Mevals_per_s": lo["n_blocks"] / dtf / 1e6, "note": "lock mask 0: both sensor time offsets free (not the headline configuration)"}
+    except Exception as e:   # noqa: BLE001
+        sec["free_time_offsets"] = {"error": str(e)[:200]}
     try:
-        scan, p4, bmin, bmax = synth.make_assoc_problem(seed=5, H=16, W=1800, n_planes=2000)
-        t = lvx.upstream_bench(ctx, "surfel_assoc", (scan, p4, bmin, bmax))
-        sec["surfel_assoc"] = {"Mpts_per_s": scan.shape[0] * scan.shape[1] / t / 1e6, "planes": 2000, "points": scan.shape[0] * scan.shape[1], "ms": 1e3 * t,
-                               "hbm_frac": (20.0 * scan.shape[0] * scan.shape[1] + 80.0 * 2000) / t / 1e9 / HBM_PEAK_GBS}
+        from oracle import oracle as O
         cloud = synth.make_voxel_cloud(seed=2, n=100_000)
         t = lvx.upstream_bench(ctx, "voxel_build", (cloud, 0.5))
-        sec["voxel_build"] = {"Mpts_per_s": len(cloud) / t / 1e6, "points": len(cloud), "ms": 1e3 * t}
+        t0 = time.perf_counter(); O.voxel_build(cloud, 0.5); tc = time.perf_counter() - t0
+        sec["voxel_build"] = {"Mpts_per_s": len(cloud) / t / 1e6, "points": len(cloud), "ms": 1e3 * t, "hbm_frac": (36.0 * len(cloud)) / t / 1e9 / HBM_PEAK_GBS,
+                              "cpu": {"Mpts_per_s": len(cloud) / tc / 1e6, "cores": 1, "kind": "port", "sample": "one build (the reference's applyFilter is serial)"}}
         t = lvx.upstream_bench(ctx, "voxel_lookup7", synth.rigid_move(cloud))
         sec["voxel_lookup7"] = {"Mqueries_per_s": len(cloud) / t / 1e6, "ms": 1e3 * t, "hbm_frac": 100.0 * len(cloud) / t / 1e9 / HBM_PEAK_GBS}
         pts = synth.make_vlp16_sweep(seed=1)
-        import time
         lvx.scan_register(ctx, pts, 16, 0.3)
         t0 = time.perf_counter()
         for _ in range(10):
@@ -202,6 +282,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     cost = ctx.evaluate_resident(lvx.EVAL_COST, want_cost=True)
+    if world > 1 and float(red[-1].item()) != 0.0:     # summed device error words of the last step: some rank's sums were incomplete
+        raise SystemExit("a rank reported a device-side evaluation error (range / non-unit quaternion / fallback)")
     joint = None
     if world > 1 and not args.no_secondary:
         # side measurement (outside the timed region): LM iterations of the JOINT problem — shared rig extrinsics, one sequence per GPU;
@@ -223,6 +305,12 @@ def main():
         except Exception as e:   # noqa: BLE001
             joint = {"error": str(e)[:300]}
 
+    assoc = None
+    if not args.no_secondary:
+        try:
+            assoc = assoc_metric(ctx, world, rank)      # every rank takes part (all-gather of the flags)
+        except Exception as e:   # noqa: BLE001
+            assoc = {"error": str(e)[:300]}
     blocks = lo["n_blocks"]
     value = blocks * world * args.steps / elapsed / 1e6
     out = {
@@ -231,22 +319,13 @@ def main():
         "config": {"workload": "config4-full-LVI: %d surfel + %d IMU samples (gyro+accel blocks) + %d ORB reprojection blocks, %d knots @ dt=0.02; "
                                "step = residuals + analytic Jacobians + Huber + J^T J/J^T r assembly (no linear solve)" % (n_surf, n_imu, len(P["rep_lm"]), lo["n_knots"]),
                    "blocks_per_step_per_gpu": int(blocks), "n_tangent": lo["n_tangent"], "bandwidth": lo["bandwidth"], "n_border": lo["n_border"],
-                   "parallelism": "sequence-per-gpu x%d" % world, "cost": cost},
+                   "locks": "LIDAR_TAU | CAM_TAU (sensor time offsets constant, everything else free: trajInitFromLVIdata with lvi.yaml's opt_time_offset false)",
+                   "tracks": P.get("tracks", "orb"), "parallelism": "sequence-per-gpu x%d" % world, "cost": cost},
     }
     if rank == 0:
         k = lvx.FAM_SURFEL
         surf_ms = ms[k] / max(1, launches[k])
-        alg_bytes = BYTES_PER_EVAL["surfel"] * n_surf
-        alg_flops = FLOPS_PER_EVAL["surfel"] * n_surf
-        achieved = alg_flops / (surf_ms * 1e-3) / 1e12 if surf_ms > 0 else 0.0
-        out["roofline"] = {"bound": "mfma", "kernel": "k_family_mfma<SurfAcc>", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                           "traffic": PMC_TRAFFIC_BYTES if scale == 1 else None, "traffic_source": PMC_SOURCE, "avg_launch_ms": surf_ms,
-                           "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
-                           "hbm": {"achieved_GBps": alg_bytes / (surf_ms * 1e-3) / 1e9 if surf_ms > 0 else 0.0, "peak_GBps": HBM_PEAK_GBS},
-                           "note": "fused residual + analytic Jacobian + FP64-MFMA J^T J kernel of the LiDAR surfel family (1 M of the 1.45 M blocks); FP64 matrix = FP64 vector peak = 78.6 TFLOP/s on MI355X; "
-                                   "9 kFLOP / 60 B per block (SURVEY.md 8d) => compute bound, the HBM figure is reported for completeness; duration from HIP events on the kernel's own stream around every launch of the timed region; the LiDAR kernels run first and alone, the IMU and "
-                                   "reprojection kernels concurrently after them (solo durations of all kernels: kernel_ms_solo)"}
-        # durations of every kernel in the pass's own schedule: a separate run with an event pair around every launch (outside the timed region);
+        # durations of every kernel family in the pass's own schedule: a separate run with an event pair around every launch (outside the timed region);
         # the surfel entry is the live one
         ctx.set_profiling(True); ctx.kernel_ms()
         for _ in range(5):
@@ -256,6 +335,7 @@ def main():
         ctx.set_profiling(False)
         out["kernel_ms"] = {lvx.KERNEL_NAMES[i]: msa[i] / max(1, la[i]) for i in range(len(msa)) if la[i]}
         out["kernel_ms"][lvx.KERNEL_NAMES[k]] = surf_ms
+        solo = dict(out["kernel_ms"])
         if world == 1:   # solo durations: the same step with every family kernel on one stream (outside the timed region)
             ctx.set_switch("SERIAL", 1)
             ctx.set_profiling(True); ctx.kernel_ms()
@@ -265,11 +345,42 @@ def main():
             ms1, l1 = ctx.kernel_ms()
             ctx.set_profiling(False)
             ctx.set_switch("SERIAL", 0)
-            out["kernel_ms_solo"] = {lvx.KERNEL_NAMES[i]: ms1[i] / max(1, l1[i]) for i in range(len(ms1)) if l1[i]}
+            solo = {lvx.KERNEL_NAMES[i]: ms1[i] / max(1, l1[i]) for i in range(len(ms1)) if l1[i]}
+            out["kernel_ms_solo"] = solo
+        # algorithmic work of every family against its solo duration, and of the whole pass against the step time
+        work = {"surfel": (FLOPS_PER_EVAL["surfel"] * n_surf, BYTES_PER_EVAL["surfel"] * n_surf), "gyro": (FLOPS_PER_EVAL["imu"] * n_imu, BYTES_PER_EVAL["imu"] * n_imu),
+                "accel": (FLOPS_PER_EVAL["imu"] * n_imu, BYTES_PER_EVAL["imu"] * n_imu), "reproj": (FLOPS_PER_EVAL["reproj"] * len(P["rep_lm"]), BYTES_PER_EVAL["reproj"] * len(P["rep_lm"]))}
+        rep_parts = ["reproj", "reproj_jac", "reproj_obs", "reproj_ref", "reproj_cross", "reproj_lmrows"]   # the fused reprojection path is five kernels
+        solo["reproj_all"] = sum(solo.get(k2, 0.0) for k2 in rep_parts)
+        fam = {}
+        for name, (fl, by) in work.items():
+            d = (surf_ms if name == "surfel" else solo.get("reproj_all" if name == "reproj" else name, 0.0)) * 1e-3
+            if d > 0:
+                fam[name] = {"ms": 1e3 * d, "TFLOPs": fl / d / 1e12, "frac_fp64_peak": fl / d / 1e12 / FP64_PEAK_TFLOPS, "GBps": by / d / 1e9}
+        # the time-dominant KERNEL: a family's duration is one kernel's except for reprojection (five kernels, the longest counts)
+        longest = {n: (max(solo.get(k2, 0.0) for k2 in rep_parts) if n == "reproj" else fam[n]["ms"]) for n in fam}
+        dominant = max(fam, key=lambda n: longest[n])
+        step_s = elapsed / args.steps
+        tot_fl = sum(v[0] for v in work.values())
+        names = {"surfel": "k_family_mfma<SurfAcc>", "gyro": "k_family_mfma<GyroAcc>", "accel": "k_family_mfma<AccelAcc>",
+                 "reproj": "reprojection path (k_reproj_jac + k_family_mfma<RepSideAcc<1>> + k_family_mfma<RepSideAcc<0>> + k_reproj_cross + k_reproj_lmrows)"}
+        fl_d, by_d = work[dominant]
+        out["roofline"] = {"bound": "mfma", "kernel": names[dominant], "achieved": fam[dominant]["TFLOPs"], "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fam[dominant]["frac_fp64_peak"],
+                           "traffic": PMC_TRAFFIC_BYTES if (scale == 1 and dominant == "surfel") else None, "traffic_source": PMC_SOURCE + " — a constant copied from that profile, not measured in this run",
+                           "avg_launch_ms": fam[dominant]["ms"], "algorithmic_flops_per_launch": fl_d, "algorithmic_bytes_per_launch": by_d,
+                           "hbm": {"achieved_GBps": fam[dominant]["GBps"], "peak_GBps": HBM_PEAK_GBS},
+                           "families": fam,
+                           "whole_pass": {"TFLOPs": tot_fl / step_s / 1e12, "frac_fp64_peak": tot_fl / step_s / 1e12 / FP64_PEAK_TFLOPS, "ms": 1e3 * step_s},
+                           "note": "time-dominant kernel family of the pass (solo durations; the surfel kernel's from HIP events on its own stream around every launch of the timed region); "
+                                   "ALGORITHMIC FP64 work per block from SURVEY.md 8d (surfel 9 k, IMU 4 k, reprojection 11 k FLOP) over the duration — the kernels execute less than that "
+                                   "(hoisted hub pose, precomputed control-point pairs); FP64 matrix = FP64 vector peak = 78.6 TFLOP/s on MI355X; `families` has every family's fraction, "
+                                   "`whole_pass` the sum over the step time"}
         if world == 1 and not args.no_secondary:
             out["secondary"] = secondary_metrics(ctx, P, lo)
         if joint is not None:
             out["secondary"] = {"joint_lm_iteration": joint}
+        if assoc is not None:
+            out.setdefault("secondary", {})["surfel_assoc"] = assoc
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(P)
         print(json.dumps(out), flush=True)

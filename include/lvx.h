@@ -167,7 +167,13 @@ int lvx_synchronize(lvx_ctx* ctx);
 #define LVX_KERNEL_FOLD 6
 #define LVX_KERNEL_SOLVE 7
 #define LVX_KERNEL_UPSTREAM 8
-#define LVX_NUM_KERNELS 9
+#define LVX_KERNEL_CLEAR 9          /* k_clear: structural clear of the accumulators + the state-only prepass */
+#define LVX_KERNEL_REP_JAC 10       /* the five kernels of the fused reprojection path (LVX_FAM_REPROJ then times only the per-segment kernel) */
+#define LVX_KERNEL_REP_OBS 11
+#define LVX_KERNEL_REP_REF 12
+#define LVX_KERNEL_REP_CROSS 13
+#define LVX_KERNEL_REP_LMROWS 14
+#define LVX_NUM_KERNELS 15
 /* enable: 0 off | 1 every launch | 2 + k: only the launches of kernel k (e.g. 2 + LVX_FAM_SURFEL: the dominant kernel — two event
  * records per pass instead of ~20, which cost ~5 % of a config-4 pass).  While profiling is on, passes are issued launch by launch (no graph replay). */
 int lvx_set_profiling(lvx_ctx* ctx, int enable);
@@ -265,6 +271,10 @@ int lvx_surfel_assoc(lvx_ctx* ctx, int H, int W, const float* scan_map_xyzi4, in
 /* device-resident variant: planes10_d = p4[P][4] | box_min[P][3] | box_max[P][3] */
 int lvx_surfel_assoc_d(lvx_ctx* ctx, int H, int W, const float* scan_d, int n_planes, const double* planes10_d, double radius, int sel_per_ring, int32_t* plane_of_point_d);
 
+/* n_scans organised scans [n_scans][H][W] against one surfel table in one call (scans are independent: this is also the unit that shards over GPUs) */
+int lvx_surfel_assoc_batch_d(lvx_ctx* ctx, int n_scans, int H, int W, const float* scans_d, int n_planes, const double* planes10_d, double radius, int sel_per_ring,
+                             int32_t* plane_of_point_d);
+
 /* sequence-per-GPU joint solve (BASELINE config 5) ---------------------------------------------------------*/
 /* Every rank owns one calibration sequence (trajectory, gravity, biases, landmarks are private); the rig extrinsics — lidar theta(3) p(3)
  * tau, camera theta(3) p(3) tau = 14 tangent scalars — are shared.  One LM iteration of the JOINT problem: every rank eliminates its private
@@ -299,6 +309,17 @@ int lvx_surfel_extract(lvx_ctx* ctx, double p_lambda, double dist_threshold, int
 /* scan de-skew ------------------------------------------------------------------------------------*/
 /* licalib PointXYZIT (src/lvi_exc/include/utils/pcl_utils.h:39-44), 32 bytes */
 typedef struct lvx_point_xyzit { float x, y, z, pad; float intensity; float pad2; double timestamp; } lvx_point_xyzit;
+/* The chronological SurfelPoint emission of getAssociation (src/lvi_exc/src/core/surfel_association.cpp:141-158) for n_scans associated scans (flags from
+ * lvx_surfel_assoc_batch_d), all device-resident: per scan column-major (w outer, h inner), points with a flag and a non-zero raw timestamp; scans concatenated.
+ * SurfelPoint fields as arrays: raw point (LiDAR frame), point in the map frame, timestamp, plane id.  *n_out = total (also when larger than max_out: nothing is
+ * written then; size the outputs and call again); per_scan_counts[n_scans] may be NULL. */
+int lvx_surfel_emit_d(lvx_ctx* ctx, int n_scans, int H, int W, const int32_t* flags_d, const float* scans_map_d, const lvx_point_xyzit* scans_raw_d, int max_out,
+                      double* pt3_d, double* pt_map3_d, double* t_d, int32_t* plane_d, int32_t* n_out, int32_t* per_scan_counts);
+/* SurfelAssociation::associateVisualPointsWithPlanes (surfel_association.cpp:161-214) over the landmark table of lvx_set_landmarks and the inverse depths in `state`:
+ * plane_of_landmark[l] = index of the surfel whose AABB strictly contains the landmark (map frame) within 2 * radius of its plane — the highest such index, as the
+ * reference's loop leaves it — or -1 (also for rho < 0.05 and for reference views outside the spline).  q_LtoC (x, y, z, w), t_LinC: LiDAR pose in the camera frame. */
+int lvx_landmark_assoc(lvx_ctx* ctx, const double* state, const double* q_LtoC_xyzw, const double* t_LinC3, double map_time, int n_planes, const double* plane_p4,
+                       const double* box_min3, const double* box_max3, double radius, int32_t* plane_of_landmark);
 /* TrajectoryManagerLVI::evaluateLidarPose for a batch of times (trajectory_manager_lvi.cpp:398-408): q_LtoG (x,y,z,w), p_LinG, valid = 0 outside the spline */
 int lvx_evaluate_lidar_pose(lvx_ctx* ctx, const double* state, int n, const double* t, double* q_xyzw4, double* p3, int32_t* valid);
 /* ScanUndistortion::undistort (src/lvi_exc/include/core/scan_undistortion.h:132-180): every point is moved with the spline pose at ITS timestamp into the

@@ -123,6 +123,8 @@ struct lvx_ctx {
   const double* last_state_d = nullptr; bool last_want_res = false, err_unchecked = false;   // see check_last_eval
   // upstream kernels (lvx_upstream.hip)
   lvx::DevBuf d_up[8];
+  size_t assoc_rings = 0; int assoc_wpr = 0;   // shape the association work buffer (d_up[7]) was cleared for
+  lvx::DevBuf d_assoc[3];   // surfel association: grid geometry + cell counts / offsets, cell lists, emission counters
   int sr_n = 0, sr_rings = 0, sr_m = 0;   // input size, rings and kept points of the last lvx_scan_register (its results stay in d_up[0])
   struct Voxels {
     float leaf = 0; int min_pts = 0, n_points = 0, n_leaves = 0;

@@ -1648,6 +1648,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
       }
       size_t total = 0; for (int i = 0; i < cl.n; ++i) total += cl.words[i];
       const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
+      ProfScope ps(ctx, LVX_KERNEL_CLEAR, st);
       hipLaunchKernelGGL(k_clear, dim3(blocks + (unsigned)npre + (unsigned)bc.nblk), dim3(256), 0, st, cl, bc, npre, cm, (So3Pre*)ctx->d_pre.p, nblk_tab, ctx->t_map, fast_surf ? 1 : 0, fast_cs ? 1 : 0,
                          (HubShared*)ctx->d_hubs.p);
     }
@@ -1750,39 +1751,44 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
         if (ctx->rep.n > 0) {
           ReprojFam r{ctx->rep.n, (const int*)ctx->rep.d_id0.p, (const double*)ctx->rep.d_a3.p, (const double*)ctx->rep.d_t.p, (const int*)ctx->rep.d_perm.p,
                       (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->rep.weight, ctx->rep.huber};
-          ProfScope ps(ctx, LVX_FAM_REPROJ, s_rep);
           if (tauC) {
+            ProfScope ps(ctx, LVX_FAM_REPROJ, s_rep);
             ReprojFamT<true> rt{r.n, r.lm, r.uv, r.t0o, r.perm, r.lm_uv, r.lm_t0, r.weight, r.huber};
             hipLaunchKernelGGL((k_family<ReprojFamT<true>, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, rt, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
           } else if (fast && !sw.reproj_legacy) {
             double* Jb = (double*)ctx->d_repB[0].p; double* rb = Jb + (size_t)2 * REP_NC * r.n; int* kb = (int*)ctx->d_repB[1].p;
-            hipLaunchKernelGGL(k_reproj_jac, grid(r.n), dim3(64), 0, s_rep, r, cm, Jb, rb, kb, (long long)ctx->fam_row0[4]);
+            { ProfScope ps(ctx, LVX_KERNEL_REP_JAC, s_rep);
+              hipLaunchKernelGGL(k_reproj_jac, grid(r.n), dim3(64), 0, s_rep, r, cm, Jb, rb, kb, (long long)ctx->fam_row0[4]); }
             if (staged && jac_early && s_rep != s_surf) LVX_HIP(ctx, hipStreamWaitEvent(s_rep, ctx->ev_join[2], 0));
             if (what & LVX_EVAL_NORMAL_EQ) {
               hipStream_t s_ref = (one_side && staged) ? s_rep : s_acc;
               if (s_ref != s_rep) LVX_HIP(ctx, hipEventRecord(ctx->ev_jac, s_rep));   // an event record on the chain is a bubble: only when another stream waits for it
               const RepJac jac{Jb, rb, kb, r.n};
               RepSideAcc<1> ra{r.n, jac, 0.0};
-              LVX_LAUNCH_MFMA1(RepSideAcc<1>, 1, ra, LVX_FAM_REPROJ, s_rep, ctx->fam_row0[4]);
+              { ProfScope ps(ctx, LVX_KERNEL_REP_OBS, s_rep); LVX_LAUNCH_MFMA1(RepSideAcc<1>, 1, ra, LVX_FAM_REPROJ, s_rep, ctx->fam_row0[4]); }
               // the other two passes only read the materialised rows: they can run next to the observation-side pass, behind the accelerometer kernel
               RepSideAcc<0> rb2{r.n, jac, 0.0};
               if (s_ref != s_rep) LVX_HIP(ctx, hipStreamWaitEvent(s_ref, ctx->ev_jac, 0));
-              LVX_LAUNCH_MFMA1(RepSideAcc<0>, 1, rb2, LVX_FAM_PRIOR, s_ref, ctx->fam_row0[4]);
+              { ProfScope ps(ctx, LVX_KERNEL_REP_REF, s_ref); LVX_LAUNCH_MFMA1(RepSideAcc<0>, 1, rb2, LVX_FAM_PRIOR, s_ref, ctx->fam_row0[4]); }
               if (ctx->rep_groups > 0) {
                 const int* gt = (const int*)ctx->d_repB[2].p;
                 const RepCross rx{jac, r.lm, gt, gt + ctx->rep_groups + 1, ctx->rep_groups, ctx->sw.cross_dbg, (double*)ctx->d_repT.p};
-                hipLaunchKernelGGL(k_reproj_cross, dim3((unsigned)std::min((ctx->rep_groups + 3) / 4, 256 * 8)), dim3(256), 0, s_ref, rx, cm);
+                { ProfScope ps(ctx, LVX_KERNEL_REP_CROSS, s_ref);
+                  hipLaunchKernelGGL(k_reproj_cross, dim3((unsigned)std::min((ctx->rep_groups + 3) / 4, 256 * 8)), dim3(256), 0, s_ref, rx, cm); }
                 if (ctx->L > 0 && !(ctx->locks & LVX_LOCK_LANDMARKS)) {
                   const int* lp = (const int*)ctx->d_repB[3].p;
                   const RepLmRows lq{(const double*)ctx->d_repT.p, kb, r.n, lp, lp + ctx->L + 1, ctx->L};
                   const size_t lds = (size_t)4 * ctx->lm_ls * 8;
                   LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_reproj_lmrows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                  ProfScope ps(ctx, LVX_KERNEL_REP_LMROWS, s_ref);
                   hipLaunchKernelGGL(k_reproj_lmrows, dim3((unsigned)((ctx->L + 3) / 4)), dim3(256), lds, s_ref, lq, cm);
                 }
               }
             }
-          } else
-          hipLaunchKernelGGL((k_family<ReprojFam, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, r, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
+          } else {
+            ProfScope ps(ctx, LVX_FAM_REPROJ, s_rep);
+            hipLaunchKernelGGL((k_family<ReprojFam, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, r, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
+          }
         }
       } break;
       case 4: {
@@ -1937,6 +1943,7 @@ void lvx_destroy(lvx_ctx* c) {
     if (b->p) (void)hipFree(b->p);
   for (auto& b : c->d_pairs) if (b.p) (void)hipFree(b.p);
   for (auto& b : c->d_up) if (b.p) (void)hipFree(b.p);
+  for (auto& b : c->d_assoc) if (b.p) (void)hipFree(b.p);
   for (auto& b : c->d_chunk) if (b.p) (void)hipFree(b.p);
   for (auto& b : c->d_repB) if (b.p) (void)hipFree(b.p);
   if (c->d_hubs.p) (void)hipFree(c->d_hubs.p);

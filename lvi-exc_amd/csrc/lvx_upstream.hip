@@ -241,13 +241,24 @@ __global__ __launch_bounds__(256) void k_sr_voxelgrid(const float4* cloud, const
 // ------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int f2ord(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }   // monotone float -> int
 __host__ __device__ __forceinline__ float ord2f(int i) { const int j = i >= 0 ? i : i ^ 0x7fffffff; float f; memcpy(&f, &j, 4); return f; }
-__global__ void k_vx_minmax(const float4* p, int n, int* mm) {   // mm[0..2] = min (ordered ints), mm[3..5] = max
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float4 q = p[i];
-  if (!isfinite(q.x) || !isfinite(q.y) || !isfinite(q.z)) return;
-  atomicMin(&mm[0], f2ord(q.x)); atomicMin(&mm[1], f2ord(q.y)); atomicMin(&mm[2], f2ord(q.z));
-  atomicMax(&mm[3], f2ord(q.x)); atomicMax(&mm[4], f2ord(q.y)); atomicMax(&mm[5], f2ord(q.z));
+__global__ __launch_bounds__(256) void k_vx_minmax(const float4* p, int n, int* mm) {   // mm[0..2] = min (ordered ints), mm[3..5] = max
+  // per-thread over a grid-stride range, wavefront shuffles, one atomic per workgroup and bound (100 k threads on 6 addresses took 110 us)
+  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4 q = p[i];
+    if (!isfinite(q.x) || !isfinite(q.y) || !isfinite(q.z)) continue;
+    const int o[3] = {f2ord(q.x), f2ord(q.y), f2ord(q.z)};
+    for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], o[a]); hi[a] = max(hi[a], o[a]); }
+  }
+  for (int s = 32; s > 0; s >>= 1) for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], __shfl_xor(lo[a], s)); hi[a] = max(hi[a], __shfl_xor(hi[a], s)); }
+  __shared__ int red[4][6];
+  if ((threadIdx.x & 63) == 0) for (int a = 0; a < 3; ++a) { red[threadIdx.x >> 6][a] = lo[a]; red[threadIdx.x >> 6][3 + a] = hi[a]; }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    int v = red[0][threadIdx.x];
+    for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? min(v, red[w][threadIdx.x]) : max(v, red[w][threadIdx.x]);
+    if (threadIdx.x < 3) atomicMin(&mm[threadIdx.x], v); else atomicMax(&mm[threadIdx.x], v);
+  }
 }
 struct VxGrid { int min_b[3], max_b[3], div_b[3], mul[3]; float inv; };
 __global__ void k_vx_keys(const float4* p, int n, VxGrid g, unsigned* keys, int* vals) {
@@ -285,8 +296,11 @@ __device__ void vx_eig3(const double A[9], double ev[3], double V[9]) {   // cyc
   const int idx[3] = {i0, i1, i2};
   for (int k = 0; k < 3; ++k) { ev[k] = a[idx[k]][idx[k]]; for (int r = 0; r < 3; ++r) V[3 * r + k] = v[r][idx[k]]; }
 }
-// one thread per leaf: in-order sums over the leaf's (stable-sorted) points, then the finalize of :286-371
-__global__ void k_vx_leaf(const float4* p, const unsigned* ukeys, const unsigned* counts, const unsigned* offs, const int* sorted_ids, int nl, int min_pts, double eig_mult,
+// one thread per leaf: sums over the leaf's (stable-sorted) points IN INPUT ORDER — cov = (sum x x^T - 2 sum x mu^T) / n + mu mu^T cancels ~6 digits
+// (coordinates of tens of metres, spreads of centimetres), so only the reference's summation order reproduces it to 1e-12 of its own scale; the float
+// centroid is compared bit for bit — then the finalize of :286-371.  The points are scattered: 8 indices, then 8 points, are in flight at a time
+// (one dependent load per point made this kernel 79 us for 12 k leaves).
+__global__ void k_vx_leaf(const float4* __restrict__ p, const unsigned* ukeys, const unsigned* counts, const unsigned* offs, const int* __restrict__ sorted_ids, int nl, int min_pts, double eig_mult,
                           int* grid, int* leaf_key, int* leaf_n, double* mean, double* cov, double* icov, double* evecs, double* evals, float* centroid) {
   const int li = blockIdx.x * blockDim.x + threadIdx.x;
   if (li >= nl) return;
@@ -295,11 +309,19 @@ __global__ void k_vx_leaf(const float4* p, const unsigned* ukeys, const unsigned
   const int o = (int)offs[li];
   double s[3] = {0, 0, 0}, c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   float cen[3] = {0, 0, 0};
-  for (int k = 0; k < n; ++k) {
-    const float4 q = p[sorted_ids[o + k]];
-    const double x[3] = {q.x, q.y, q.z};
-    for (int a = 0; a < 3; ++a) { s[a] += x[a]; for (int b = 0; b < 3; ++b) c[3 * a + b] += x[a] * x[b]; }
-    cen[0] += q.x; cen[1] += q.y; cen[2] += q.z;
+  for (int k0 = 0; k0 < n; k0 += 8) {
+    int id[8]; float4 q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) id[u] = sorted_ids[o + min(k0 + u, n - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) q[u] = p[id[u]];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (k0 + u >= n) break;
+      const double x[3] = {q[u].x, q[u].y, q[u].z};
+      for (int a = 0; a < 3; ++a) { s[a] += x[a]; for (int b = 0; b < 3; ++b) c[3 * a + b] += x[a] * x[b]; }
+      cen[0] += q[u].x; cen[1] += q[u].y; cen[2] += q[u].z;
+    }
   }
   leaf_key[li] = (int)key;
   grid[key] = li;
@@ -493,39 +515,197 @@ __global__ void k_vx_lookup(const float4* q, int nq, float leaf, int min_pts, Vx
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// scan -> surfel association: thread = (plane, ring); the ring's points staged in LDS; two passes (count, then the
-// evenly spaced ranks step*(s+1)-1); conflicts resolved as the serial plane loop does (highest plane id wins).
+// scan -> surfel association (getAssociation + associateScanToSurfel, surfel_association.cpp:111-138,296-331), S scans per launch.
+// Phase 1 (k_assoc_hits): thread = scan point; it meets the surfels listed for its cell of a uniform grid over the surfels' boxes (below); a
+//   hit (not NaN, strictly inside the AABB, |n.p + d| <= radius — double arithmetic on the float coordinates, as the reference) sets the
+//   point's bit in the (scan, plane, ring) bitmask and bumps that ring's hit count.  16 B read per point, no write for the ~all misses.
+//   (All pairs through an LDS plane table — 57.6 M exact tests per scan at P = 2000 — ran at the FP64 VALU limit: 16 us per scan.)
+// Phase 2 (k_assoc_select): thread = (scan, plane, ring) with >= 2 sel hits: the evenly spaced ranks step (s + 1) - 1 of the ring's hit
+//   list are found by popcount over the bitmask words; conflicts resolve as the reference's SERIAL plane loop (highest plane id wins:
+//   atomicMax; the reference's OpenMP loop races here).
+// The previous kernel walked a ring's W points twice in one thread per (plane, ring): 512 wavefronts, 0.37 ms per scan.
 // ------------------------------------------------------------------------------------------------------------------------
-#define SA_PLANES 64
 #define SA_WMAX 4096
-__global__ __launch_bounds__(SA_PLANES) void k_surfel_assoc(const float4* scan, int H, int W, int P, const double* p4, const double* bmin, const double* bmax, double radius, int sel, int* flag) {
-  __shared__ float sx[SA_WMAX], sy[SA_WMAX], sz[SA_WMAX];
-  const int h = blockIdx.y;
-  for (int w = threadIdx.x; w < W; w += SA_PLANES) { const float4 q = scan[(size_t)h * W + w]; sx[w] = q.x; sy[w] = q.y; sz[w] = q.z; }
+// A uniform grid over the surfels' AABBs (64 x 64 x 8 cells) lists, per cell, the surfels whose AABB reaches it; a point only meets the surfels of its
+// own cell.  The cell index is the same monotone function of a coordinate for boxes and points, so a point strictly inside a box always finds that box in
+// its cell's list: the candidate set is a superset of the reference's hits and the exact tests decide — results are identical to the all-pairs loop.
+#define SA_GX 64
+#define SA_GY 64
+#define SA_GZ 8
+#define SA_CELLS (SA_GX * SA_GY * SA_GZ)
+struct AssocGrid { double g0[3], inv[3]; };
+__device__ __forceinline__ int sa_cell(double v, double g0, double inv, int n) { const double f = floor((v - g0) * inv); return f < 0.0 ? 0 : (f >= (double)n ? n - 1 : (int)f); }
+// one workgroup: bounds of all boxes -> grid geometry
+__global__ __launch_bounds__(256) void k_assoc_grid_geom(int P, const double* planes10, AssocGrid* g) {
+  __shared__ double lo[3][256], hi[3][256];
+  double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
+  for (int k = threadIdx.x; k < P; k += 256)
+    for (int a = 0; a < 3; ++a) { l[a] = fmin(l[a], planes10[4 * (size_t)P + 3 * (size_t)k + a]); h[a] = fmax(h[a], planes10[7 * (size_t)P + 3 * (size_t)k + a]); }
+  for (int a = 0; a < 3; ++a) { lo[a][threadIdx.x] = l[a]; hi[a][threadIdx.x] = h[a]; }
   __syncthreads();
-  const int pid = blockIdx.x * SA_PLANES + threadIdx.x;
-  if (pid >= P) return;
-  const double n0 = p4[4 * pid], n1 = p4[4 * pid + 1], n2 = p4[4 * pid + 2], d = p4[4 * pid + 3];
-  const double lo0 = bmin[3 * pid], lo1 = bmin[3 * pid + 1], lo2 = bmin[3 * pid + 2], hi0 = bmax[3 * pid], hi1 = bmax[3 * pid + 1], hi2 = bmax[3 * pid + 2];
-  auto hit = [&](int w) -> bool {
-    const float x = sx[w], y = sy[w], z = sz[w];
-    if (!(!isnan(x) && x > lo0 && x < hi0 && y > lo1 && y < hi1 && z > lo2 && z < hi2)) return false;
-    double dist = (double)x * n0 + (double)y * n1 + (double)z * n2 + d;
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) for (int a = 0; a < 3; ++a) { lo[a][threadIdx.x] = fmin(lo[a][threadIdx.x], lo[a][threadIdx.x + o]); hi[a][threadIdx.x] = fmax(hi[a][threadIdx.x], hi[a][threadIdx.x + o]); } __syncthreads(); }
+  if (threadIdx.x < 3) {
+    const int a = threadIdx.x, n = a == 0 ? SA_GX : (a == 1 ? SA_GY : SA_GZ);
+    const double ext = hi[a][0] - lo[a][0];
+    g->g0[a] = lo[a][0]; g->inv[a] = ext > 0.0 ? (double)n / ext : 0.0;
+  }
+}
+// mode 0: count the cells every box reaches; mode 1: write the box into its cells' lists (cursor = running offsets)
+__global__ void k_assoc_grid_fill(int P, const double* planes10, const AssocGrid* gp, int* cell_cnt, int* cursor, int* list, int mode) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= P) return;
+  const AssocGrid g = *gp;
+  int c0[3], c1[3];
+  const int nn[3] = {SA_GX, SA_GY, SA_GZ};
+  for (int a = 0; a < 3; ++a) {
+    const double lo = planes10[4 * (size_t)P + 3 * (size_t)k + a], hi = planes10[7 * (size_t)P + 3 * (size_t)k + a];
+    if (!(lo < hi)) return;                          // an empty box holds no point
+    c0[a] = sa_cell(lo, g.g0[a], g.inv[a], nn[a]); c1[a] = sa_cell(hi, g.g0[a], g.inv[a], nn[a]);
+  }
+  for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x) {
+    const int cell = (z * SA_GY + y) * SA_GX + x;
+    if (mode == 0) atomicAdd(&cell_cnt[cell], 1); else list[atomicAdd(&cursor[cell], 1)] = k;
+  }
+}
+// exclusive scan of the cell counts (one workgroup: each of its 16 wavefronts owns 2048 consecutive cells, read 64 at a time), total behind the last cell;
+// cursor = copy of the offsets
+__global__ __launch_bounds__(1024) void k_assoc_grid_scan(const int* cnt, int* off, int* cursor) {
+  __shared__ int wtot[16];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, base = wv * (SA_CELLS / 16);
+  int v[SA_CELLS / 1024], tot = 0;
+#pragma unroll
+  for (int j = 0; j < SA_CELLS / 1024; ++j) { v[j] = cnt[base + 64 * j + lane]; tot += v[j]; }
+  for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+  if (lane == 0) wtot[wv] = tot;
+  __syncthreads();
+  int running = 0;
+  for (int k = 0; k < wv; ++k) running += wtot[k];
+#pragma unroll
+  for (int j = 0; j < SA_CELLS / 1024; ++j) {
+    int inc = v[j];
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    const int ex = running + inc - v[j];
+    off[base + 64 * j + lane] = ex; cursor[base + 64 * j + lane] = ex;
+    running += __shfl(inc, 63);
+  }
+  if (threadIdx.x == 1023) off[SA_CELLS] = running;
+}
+// all pairs: thread = scan point, the plane table of the block's chunk (256 planes) in LDS, read as broadcasts.  57.6 M exact tests per scan at P = 2000
+// (FP64 VALU bound, 36 us) — cheaper than building the grid when only one or two scans are associated in a call.
+#define SA_PC 256
+__global__ __launch_bounds__(256) void k_assoc_hits_allpairs(const float4* __restrict__ scans, int H, int W, int P, const double* __restrict__ planes10, double radius,
+                                                             unsigned* bits, int* counts, int wpr) {
+  __shared__ double pl[10][SA_PC];
+  const int p0 = blockIdx.y * SA_PC, np = min(SA_PC, P - p0), sc = blockIdx.z;
+  for (int e = threadIdx.x; e < 10 * SA_PC; e += 256) {
+    const int f = e / SA_PC, k = e % SA_PC;
+    if (k < np) pl[f][k] = f < 4 ? planes10[4 * (size_t)(p0 + k) + f] : (f < 7 ? planes10[4 * (size_t)P + 3 * (size_t)(p0 + k) + (f - 4)] : planes10[7 * (size_t)P + 3 * (size_t)(p0 + k) + (f - 7)]);
+  }
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= H * W) return;
+  const float4 q = scans[(size_t)sc * H * W + i];
+  if (isnan(q.x)) return;
+  const double x = q.x, y = q.y, z = q.z;
+  const int h = i / W, w = i - h * W;
+  for (int k = 0; k < np; ++k) {
+    if (!(x > pl[4][k] && x < pl[7][k] && y > pl[5][k] && y < pl[8][k] && z > pl[6][k] && z < pl[9][k])) continue;
+    double dist = x * pl[0][k] + y * pl[1][k] + z * pl[2][k] + pl[3][k];
     dist = dist > 0 ? dist : -dist;
-    return dist <= radius;
-  };
-  int cnt = 0;
-  for (int w = 0; w < W; ++w) cnt += hit(w) ? 1 : 0;
-  if (cnt < sel * 2) return;
-  int step = cnt / (sel + 1);
-  step = step > 1 ? step : 1;
-  int rank = 0, s = 0;
-  for (int w = 0; w < W && s < sel; ++w) {
-    if (hit(w)) {
-      if (rank == step * (s + 1) - 1) { atomicMax(&flag[(size_t)h * W + w], pid); ++s; }
-      ++rank;
+    if (dist <= radius) {
+      const size_t ring = ((size_t)sc * P + p0 + k) * H + h;
+      atomicOr(&bits[ring * wpr + (w >> 5)], 1u << (w & 31));
+      atomicAdd(&counts[ring], 1);
     }
   }
+}
+__global__ __launch_bounds__(256) void k_assoc_hits(const float4* __restrict__ scans, int H, int W, int P, const double* __restrict__ planes10, double radius, const AssocGrid* gp,
+                                                    const int* __restrict__ off, const int* __restrict__ list, unsigned* bits, int* counts, int wpr) {
+  const int i = blockIdx.x * 256 + threadIdx.x, sc = blockIdx.y;
+  if (i >= H * W) return;
+  const float4 q = scans[(size_t)sc * H * W + i];
+  if (isnan(q.x)) return;
+  const double x = q.x, y = q.y, z = q.z;
+  const AssocGrid g = *gp;
+  // outside the bounds of all boxes: no box can hold the point (sa_cell would clamp it into a border cell)
+  if (!((x - g.g0[0]) * g.inv[0] >= 0.0 && (x - g.g0[0]) * g.inv[0] <= (double)SA_GX && (y - g.g0[1]) * g.inv[1] >= 0.0 && (y - g.g0[1]) * g.inv[1] <= (double)SA_GY &&
+        (z - g.g0[2]) * g.inv[2] >= 0.0 && (z - g.g0[2]) * g.inv[2] <= (double)SA_GZ)) return;
+  const int cell = (sa_cell(z, g.g0[2], g.inv[2], SA_GZ) * SA_GY + sa_cell(y, g.g0[1], g.inv[1], SA_GY)) * SA_GX + sa_cell(x, g.g0[0], g.inv[0], SA_GX);
+  const int h = i / W, w = i - h * W;
+  for (int e = off[cell]; e < off[cell + 1]; ++e) {
+    const int k = list[e];
+    const double* lo = planes10 + 4 * (size_t)P + 3 * (size_t)k; const double* hi = planes10 + 7 * (size_t)P + 3 * (size_t)k; const double* pl = planes10 + 4 * (size_t)k;
+    if (!(x > lo[0] && x < hi[0] && y > lo[1] && y < hi[1] && z > lo[2] && z < hi[2])) continue;
+    double dist = x * pl[0] + y * pl[1] + z * pl[2] + pl[3];
+    dist = dist > 0 ? dist : -dist;
+    if (dist <= radius) {
+      const size_t ring = ((size_t)sc * P + k) * H + h;
+      atomicOr(&bits[ring * wpr + (w >> 5)], 1u << (w & 31));
+      atomicAdd(&counts[ring], 1);
+    }
+  }
+}
+// (it also returns the ring's words and count to zero: the work buffer is cleared once, when it is allocated, not 7 MB per scan and call)
+__global__ void k_assoc_select(unsigned* __restrict__ bits, int* __restrict__ counts, int S, int H, int W, int P, int wpr, int sel, int* flags) {
+  const size_t ring = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ring >= (size_t)S * P * H) return;
+  const int cnt = counts[ring];
+  if (cnt == 0) return;
+  counts[ring] = 0;
+  if (cnt < sel * 2) { unsigned* bz = bits + ring * wpr; for (int k = 0; k < wpr; ++k) if (bz[k]) bz[k] = 0u; return; }
+  const int h = (int)(ring % H), pid = (int)((ring / H) % P), sc = (int)(ring / ((size_t)H * P));
+  int step = cnt / (sel + 1);
+  step = step > 1 ? step : 1;
+  unsigned* bw = bits + ring * wpr;
+  int seen = 0, s = 0, target = step - 1;
+  for (int k = 0; k < wpr; ++k) {
+    unsigned word = bw[k];
+    if (word == 0u) continue;
+    bw[k] = 0u;
+    int pc = __popc(word);
+    while (s < sel && target < seen + pc) {       // the (target - seen)-th set bit of this word
+      unsigned t = word;
+      for (int r = target - seen; r > 0; --r) t &= t - 1;
+      const int w = 32 * k + (__ffs(t) - 1);
+      atomicMax(&flags[(size_t)sc * H * W + (size_t)h * W + w], pid);
+      ++s; target = step * (s + 1) - 1;
+    }
+    seen += pc;
+  }
+}
+// Chronological SurfelPoint emission (surfel_association.cpp:141-158): column-major (w outer, h inner), points with a flag and a non-zero raw
+// timestamp.  One workgroup per scan; order-preserving compaction by ballots + a running offset.  mode 0: count only; mode 1: write at offs[scan].
+struct SurfelOut { double* pt; double* pt_map; double* t; int* plane; };
+__global__ __launch_bounds__(1024) void k_assoc_emit(const int* __restrict__ flags, const float4* __restrict__ scans_map, const void* __restrict__ raw_v, int H, int W, int* counts, const int* offs, int mode, SurfelOut o) {
+  struct Raw { float x, y, z, pad; float intensity; float pad2; double timestamp; };
+  const Raw* raw = (const Raw*)raw_v;
+  __shared__ int wsum[16];
+  __shared__ int running;
+  const int sc = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = H * W;
+  if (threadIdx.x == 0) running = 0;
+  __syncthreads();
+  const int base_out = mode ? offs[sc] : 0;
+  for (int e0 = 0; e0 < n; e0 += 1024) {
+    const int e = e0 + threadIdx.x;                 // position in the emission order: e = w * H + h
+    bool keep = false; int idx = 0, pid = -1;
+    if (e < n) { const int w = e / H, h = e - w * H; idx = h * W + w; pid = flags[(size_t)sc * n + idx]; keep = pid != -1 && raw[(size_t)sc * n + idx].timestamp != 0.0; }
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) wsum[wv] = __popcll(m);
+    __syncthreads();
+    int before = running;
+    for (int k = 0; k < wv; ++k) before += wsum[k];
+    if (keep && mode) {
+      const int pos = base_out + before + __popcll(m & ((1ull << lane) - 1ull));
+      const Raw r = raw[(size_t)sc * n + idx]; const float4 q = scans_map[(size_t)sc * n + idx];
+      o.pt[3 * (size_t)pos] = r.x; o.pt[3 * (size_t)pos + 1] = r.y; o.pt[3 * (size_t)pos + 2] = r.z;
+      o.pt_map[3 * (size_t)pos] = q.x; o.pt_map[3 * (size_t)pos + 1] = q.y; o.pt_map[3 * (size_t)pos + 2] = q.z;
+      o.t[pos] = r.timestamp; o.plane[pos] = pid;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = running; for (int k = 0; k < 16; ++k) t += wsum[k]; running = t; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && !mode) counts[sc] = running;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -547,6 +727,55 @@ __device__ __forceinline__ bool lidar_pose_dev(const double* state, int N, doubl
   *q_LtoG = qmul(e.so3.q, qL);
   *p_LinG = qrot(e.so3.q, pL) + e.p;
   return true;
+}
+// evaluateCameraPose (trajectory_manager_lvi.cpp:430-440)
+__device__ __forceinline__ bool camera_pose_dev(const double* state, int N, double t0, double dt, double t, quat* q_CtoG, v3* p_CinG) {
+  const double* sc = state + 7 * (size_t)N + 24;
+  const double tt = t + sc[7];
+  const double tmax = t0 + (double)(N - 3) * dt;
+  if (t0 > tt || tmax <= tt) return false;
+  const double s = (tt - t0) / dt;
+  const int i0 = (int)floor(s);
+  if (N < 4 || i0 < 0 || i0 > N - 4) return false;
+  const SplineRef sp{t0, dt, N, state, state + 3 * (size_t)N};
+  KnotRef k; k.i0 = i0; k.u = s - (double)i0;
+  PoseEval e;
+  if (!pose_eval<false>(sp, k, &e)) return false;
+  const quat qC = load_q(sc); const v3 pC = load_v3(sc + 4);
+  *q_CtoG = qmul(e.so3.q, qC);
+  *p_CinG = qrot(e.so3.q, pC) + e.p;
+  return true;
+}
+// associateVisualPointsWithPlanes (surfel_association.cpp:161-214): thread = landmark; its reference observation is back-projected at depth 1 / rho with the
+// camera pose at the view's t0, moved into the LiDAR map frame (pose of the camera at the map time, q_LtoC / t_LinC), and tested against every surfel:
+// strictly inside the AABB and within 2 radius of the plane; the last (highest) matching surfel stays, as in the reference's loop.
+__global__ void k_landmark_assoc(const double* state, int N, double t0, double dt, CamIntr cam, const double* lm_uv, const double* lm_t0, int L, double map_time,
+                                 quat q_LtoC, v3 t_LinC, int P, const double* planes10, double radius, int* out) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= L) return;
+  int res = -1;
+  quat q_CtoG; v3 p_CinG;
+  if (camera_pose_dev(state, N, t0, dt, map_time, &q_CtoG, &p_CinG)) {
+    const quat q_L0_G = qmul(q_CtoG, q_LtoC);
+    const v3 t_L0_G = qrot(q_CtoG, t_LinC) + p_CinG;
+    const double n2 = q_L0_G.x * q_L0_G.x + q_L0_G.y * q_L0_G.y + q_L0_G.z * q_L0_G.z + q_L0_G.w * q_L0_G.w;
+    const quat q_inv = mkq(q_L0_G.w / n2, -q_L0_G.x / n2, -q_L0_G.y / n2, -q_L0_G.z / n2);
+    const double rho = state[7 * (size_t)N + 32 + l];
+    if (!(rho < 0.05) && camera_pose_dev(state, N, t0, dt, lm_t0[l], &q_CtoG, &p_CinG)) {
+      const v3 yu = cam_unproject(cam, lm_uv[2 * (size_t)l], lm_uv[2 * (size_t)l + 1]);
+      const v3 p3d_C = mk(yu.x / rho, yu.y / rho, yu.z / rho);
+      const v3 q = qrot(q_inv, (qrot(q_CtoG, p3d_C) + p_CinG) - t_L0_G);
+      for (int k = 0; k < P; ++k) {
+        const double* lo = planes10 + 4 * (size_t)P + 3 * (size_t)k; const double* hi = planes10 + 7 * (size_t)P + 3 * (size_t)k; const double* pl = planes10 + 4 * (size_t)k;
+        if (q.x > lo[0] && q.x < hi[0] && q.y > lo[1] && q.y < hi[1] && q.z > lo[2] && q.z < hi[2]) {
+          double dst = q.x * pl[0] + q.y * pl[1] + q.z * pl[2] + pl[3];
+          dst = dst > 0 ? dst : -dst;
+          if (dst <= radius * 2) res = k;
+        }
+      }
+    }
+  }
+  out[l] = res;
 }
 __global__ void k_lidar_pose(const double* state, int N, double t0, double dt, int n, const double* t, double* q4, double* p3, int* valid) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -650,7 +879,7 @@ static int voxel_build_device(lvx_ctx* c, const float4* d_pts, int n, float leaf
   int* d_mm = (int*)V.misc.p;
   const int init[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
   LVX_HIP(c, hipMemcpyAsync(d_mm, init, 24, hipMemcpyHostToDevice, st));
-  if (n > 0) hipLaunchKernelGGL(k_vx_minmax, dim3((n + 255) / 256), dim3(256), 0, st, d_pts, n, d_mm);
+  if (n > 0) hipLaunchKernelGGL(k_vx_minmax, dim3((unsigned)std::min((n + 255) / 256, 256)), dim3(256), 0, st, d_pts, n, d_mm);
   int mm[6];
   LVX_HIP(c, hipMemcpyAsync(mm, d_mm, 24, hipMemcpyDeviceToHost, st));
   LVX_HIP(c, hipStreamSynchronize(st));
@@ -696,7 +925,7 @@ static int voxel_build_device(lvx_ctx* c, const float4* d_pts, int n, float leaf
     if ((rc = dev_alloc(c, V.leaf_f, (size_t)nl * 3 * 4))) return rc;
     int* lk = (int*)V.leaf_i.p; int* ln = lk + nl;
     double* mean = (double*)V.leaf_d.p; double* cov = mean + 3 * (size_t)nl; double* icov = cov + 9 * (size_t)nl; double* evecs = icov + 9 * (size_t)nl; double* evals = evecs + 9 * (size_t)nl;
-    hipLaunchKernelGGL(k_vx_leaf, dim3((nl + 127) / 128), dim3(128), 0, st, d_pts, (const unsigned*)ukeys, (const unsigned*)counts, (const unsigned*)offs, (const int*)v_out, nl, min_pts,
+    hipLaunchKernelGGL(k_vx_leaf, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, st, d_pts, (const unsigned*)ukeys, (const unsigned*)counts, (const unsigned*)offs, (const int*)v_out, nl, min_pts,
                        eig_mult, (int*)V.cells.p, lk, ln, mean, cov, icov, evecs, evals, (float*)V.leaf_f.p);
   }
   LVX_HIP(c, hipGetLastError());
@@ -791,11 +1020,41 @@ int lvx_voxel_lookup1_d(lvx_ctx* c, int nq, const float* xyzi4_d, int32_t* leaf_
   return lookup_device(c, (const float4*)xyzi4_d, nq, leaf_ids1_d, 1);
 }
 
-static int assoc_device(lvx_ctx* c, const float4* scan_d, int H, int W, int P, const double* planes_d, double radius, int sel, int* flag_d) {
-  LVX_HIP(c, hipMemsetAsync(flag_d, 0xff, (size_t)H * W * 4, c->stream));
-  if (P > 0 && H > 0 && W > 0)
-    hipLaunchKernelGGL(k_surfel_assoc, dim3((P + SA_PLANES - 1) / SA_PLANES, H), dim3(SA_PLANES), 0, c->stream, scan_d, H, W, P, planes_d, planes_d + 4 * (size_t)P,
-                       planes_d + 7 * (size_t)P, radius, sel, flag_d);
+// S scans [S][H][W] against one plane table; flags [S][H * W].  Work buffers (bitmasks 4 P H ceil(W / 32) bytes per scan, counts) live in d_up[7].
+static int assoc_device(lvx_ctx* c, const float4* scans_d, int S, int H, int W, int P, const double* planes_d, double radius, int sel, int* flags_d) {
+  LVX_HIP(c, hipMemsetAsync(flags_d, 0xff, (size_t)S * H * W * 4, c->stream));
+  if (P <= 0 || H <= 0 || W <= 0 || S <= 0) return LVX_OK;
+  const int wpr = (W + 31) / 32;
+  const size_t rings = (size_t)S * P * H, bytes = rings * wpr * 4 + rings * 4;
+  int rc;
+  if (!c->d_up[7].p || c->d_up[7].bytes < bytes || c->assoc_rings != rings || c->assoc_wpr != wpr) {   // (re)allocated or re-shaped: clear once; k_assoc_select leaves it clean
+    if ((rc = dev_alloc(c, c->d_up[7], bytes))) return rc;
+    LVX_HIP(c, hipMemsetAsync(c->d_up[7].p, 0, c->d_up[7].bytes, c->stream));
+    c->assoc_rings = rings; c->assoc_wpr = wpr;
+  }
+  unsigned* bits = (unsigned*)c->d_up[7].p; int* counts = (int*)(bits + rings * wpr);
+  if (S <= 2) {   // a scan or two: all pairs beat the grid build
+    hipLaunchKernelGGL(k_assoc_hits_allpairs, dim3((unsigned)((H * W + 255) / 256), (unsigned)((P + SA_PC - 1) / SA_PC), (unsigned)S), dim3(256), 0, c->stream, scans_d, H, W, P, planes_d, radius, bits, counts, wpr);
+    hipLaunchKernelGGL(k_assoc_select, dim3((unsigned)((rings + 255) / 256)), dim3(256), 0, c->stream, bits, counts, S, H, W, P, wpr, sel, flags_d);
+    LVX_HIP(c, hipGetLastError());
+    return LVX_OK;
+  }
+  // the surfel grid (depends on the plane table only): geometry, per-cell counts, offsets, lists
+  if ((rc = dev_alloc(c, c->d_assoc[0], sizeof(AssocGrid) + (size_t)(3 * SA_CELLS + 8) * 4))) return rc;
+  AssocGrid* gd = (AssocGrid*)c->d_assoc[0].p; int* ccnt = (int*)(gd + 1); int* coff = ccnt + SA_CELLS; int* ccur = coff + SA_CELLS + 1;
+  LVX_HIP(c, hipMemsetAsync(ccnt, 0, (size_t)SA_CELLS * 4, c->stream));
+  hipLaunchKernelGGL(k_assoc_grid_geom, dim3(1), dim3(256), 0, c->stream, P, planes_d, gd);
+  hipLaunchKernelGGL(k_assoc_grid_fill, dim3((unsigned)((P + 127) / 128)), dim3(128), 0, c->stream, P, planes_d, (const AssocGrid*)gd, ccnt, ccur, (int*)nullptr, 0);
+  hipLaunchKernelGGL(k_assoc_grid_scan, dim3(1), dim3(1024), 0, c->stream, (const int*)ccnt, coff, ccur);
+  int total = 0;
+  LVX_HIP(c, hipMemcpyAsync(&total, coff + SA_CELLS, 4, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  if ((rc = dev_alloc(c, c->d_assoc[1], (size_t)std::max(total, 1) * 4))) return rc;
+  int* clist = (int*)c->d_assoc[1].p;
+  hipLaunchKernelGGL(k_assoc_grid_fill, dim3((unsigned)((P + 127) / 128)), dim3(128), 0, c->stream, P, planes_d, (const AssocGrid*)gd, ccnt, ccur, clist, 1);
+  hipLaunchKernelGGL(k_assoc_hits, dim3((unsigned)((H * W + 255) / 256), (unsigned)S), dim3(256), 0, c->stream, scans_d, H, W, P, planes_d, radius, (const AssocGrid*)gd, (const int*)coff, (const int*)clist,
+                     bits, counts, wpr);
+  hipLaunchKernelGGL(k_assoc_select, dim3((unsigned)((rings + 255) / 256)), dim3(256), 0, c->stream, bits, counts, S, H, W, P, wpr, sel, flags_d);
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
 }
@@ -809,18 +1068,77 @@ int lvx_surfel_assoc(lvx_ctx* c, int H, int W, const float* scan_map_xyzi4, int 
   std::vector<double> pl((size_t)n_planes * 10);
   if (n_planes > 0) { std::memcpy(pl.data(), plane_p4, (size_t)n_planes * 32); std::memcpy(pl.data() + 4 * (size_t)n_planes, box_min3, (size_t)n_planes * 24); std::memcpy(pl.data() + 7 * (size_t)n_planes, box_max3, (size_t)n_planes * 24); }
   if ((rc = upload(c, c->d_up[5], pl.data(), pl.size() * 8))) return rc;
+  LVX_HIP(c, hipStreamSynchronize(c->stream));   // pl dies with this frame
   if ((rc = dev_alloc(c, c->d_up[6], npt * 4))) return rc;
   { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
-    if ((rc = assoc_device(c, (const float4*)c->d_up[4].p, H, W, n_planes, (const double*)c->d_up[5].p, radius, sel_per_ring, (int*)c->d_up[6].p))) return rc; }
+    if ((rc = assoc_device(c, (const float4*)c->d_up[4].p, 1, H, W, n_planes, (const double*)c->d_up[5].p, radius, sel_per_ring, (int*)c->d_up[6].p))) return rc; }
   if (npt) LVX_HIP(c, hipMemcpyAsync(plane_of_point, c->d_up[6].p, npt * 4, hipMemcpyDeviceToHost, c->stream));
   LVX_HIP(c, hipStreamSynchronize(c->stream));
   return LVX_OK;
 }
 int lvx_surfel_assoc_d(lvx_ctx* c, int H, int W, const float* scan_d, int n_planes, const double* planes10_d, double radius, int sel_per_ring, int32_t* plane_of_point_d) {
-  if (!c || H <= 0 || W <= 0 || W > SA_WMAX || n_planes < 0 || !scan_d || !plane_of_point_d || (n_planes > 0 && !planes10_d)) return LVX_E_ARG;
+  return lvx_surfel_assoc_batch_d(c, 1, H, W, scan_d, n_planes, planes10_d, radius, sel_per_ring, plane_of_point_d);
+}
+int lvx_surfel_assoc_batch_d(lvx_ctx* c, int n_scans, int H, int W, const float* scans_d, int n_planes, const double* planes10_d, double radius, int sel_per_ring, int32_t* plane_of_point_d) {
+  if (!c || n_scans <= 0 || H <= 0 || W <= 0 || W > SA_WMAX || n_planes < 0 || !scans_d || !plane_of_point_d || (n_planes > 0 && !planes10_d)) return LVX_E_ARG;
   LVX_HIP(c, hipSetDevice(c->device));
   ProfScope ps(c, LVX_KERNEL_UPSTREAM);
-  return assoc_device(c, (const float4*)scan_d, H, W, n_planes, planes10_d, radius, sel_per_ring, plane_of_point_d);
+  const int chunk = 64;   // scans per launch: bounds the bitmask work buffer (7 MB per scan at P = 2000, 16 x 1800)
+  for (int s0 = 0; s0 < n_scans; s0 += chunk) {
+    const int ns = std::min(chunk, n_scans - s0);
+    int rc = assoc_device(c, (const float4*)scans_d + (size_t)s0 * H * W, ns, H, W, n_planes, planes10_d, radius, sel_per_ring, plane_of_point_d + (size_t)s0 * H * W);
+    if (rc) return rc;
+  }
+  return LVX_OK;
+}
+// SurfelPoint lists of S associated scans, concatenated in scan order, every scan in the reference's chronological (column-major) order
+int lvx_surfel_emit_d(lvx_ctx* c, int n_scans, int H, int W, const int32_t* flags_d, const float* scans_map_d, const lvx_point_xyzit* scans_raw_d, int max_out,
+                      double* pt3_d, double* pt_map3_d, double* t_d, int32_t* plane_d, int32_t* n_out, int32_t* per_scan_counts) {
+  if (!c || n_scans <= 0 || H <= 0 || W <= 0 || !flags_d || !scans_map_d || !scans_raw_d || !n_out || max_out < 0) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  int rc = dev_alloc(c, c->d_assoc[2], (size_t)n_scans * 8 + 16); if (rc) return rc;
+  int* cnt_d = (int*)c->d_assoc[2].p; int* off_d = cnt_d + n_scans;
+  ProfScope ps(c, LVX_KERNEL_UPSTREAM);
+  SurfelOut o{pt3_d, pt_map3_d, t_d, plane_d};
+  hipLaunchKernelGGL(k_assoc_emit, dim3((unsigned)n_scans), dim3(1024), 0, c->stream, flags_d, (const float4*)scans_map_d, (const void*)scans_raw_d, H, W, cnt_d, (const int*)off_d, 0, o);
+  std::vector<int> cnt((size_t)n_scans), off((size_t)n_scans);
+  LVX_HIP(c, hipMemcpyAsync(cnt.data(), cnt_d, (size_t)n_scans * 4, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  int total = 0;
+  for (int s = 0; s < n_scans; ++s) { off[s] = total; total += cnt[s]; if (per_scan_counts) per_scan_counts[s] = cnt[s]; }
+  *n_out = total;
+  if (total > max_out || total == 0) return LVX_OK;   // the caller sizes the outputs from *n_out and calls again
+  if (!pt3_d || !pt_map3_d || !t_d || !plane_d) return LVX_E_ARG;
+  LVX_HIP(c, hipMemcpyAsync(off_d, off.data(), (size_t)n_scans * 4, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_assoc_emit, dim3((unsigned)n_scans), dim3(1024), 0, c->stream, flags_d, (const float4*)scans_map_d, (const void*)scans_raw_d, H, W, cnt_d, (const int*)off_d, 1, o);
+  LVX_HIP(c, hipGetLastError());
+  LVX_HIP(c, hipStreamSynchronize(c->stream));      // off lives on this frame
+  return LVX_OK;
+}
+
+int lvx_landmark_assoc(lvx_ctx* c, const double* state, const double* q_LtoC_xyzw, const double* t_LinC3, double map_time, int n_planes, const double* plane_p4, const double* box_min3,
+                       const double* box_max3, double radius, int32_t* plane_of_landmark) {
+  if (!c || !state || !q_LtoC_xyzw || !t_LinC3 || n_planes < 0 || (c->L > 0 && !plane_of_landmark) || (n_planes > 0 && (!plane_p4 || !box_min3 || !box_max3))) return LVX_E_ARG;
+  if (!c->have_spline) return fail(c, LVX_E_STATE, "lvx_set_spline has not been called");
+  if (c->L == 0) return LVX_OK;
+  LVX_HIP(c, hipSetDevice(c->device));
+  int rc;
+  const int L = c->L;
+  std::vector<double> pl((size_t)std::max(n_planes, 1) * 10, 0.0);
+  if (n_planes > 0) { std::memcpy(pl.data(), plane_p4, (size_t)n_planes * 32); std::memcpy(pl.data() + 4 * (size_t)n_planes, box_min3, (size_t)n_planes * 24); std::memcpy(pl.data() + 7 * (size_t)n_planes, box_max3, (size_t)n_planes * 24); }
+  if ((rc = upload(c, c->d_up[5], pl.data(), pl.size() * 8))) return rc;
+  if ((rc = upload(c, c->d_up[2], state, (size_t)lvx_state_size(c) * 8))) return rc;
+  if ((rc = upload(c, c->d_up[3], c->lm_uv.data(), (size_t)L * 16))) return rc;
+  if ((rc = upload(c, c->d_up[4], c->lm_t0.data(), (size_t)L * 8))) return rc;
+  if ((rc = dev_alloc(c, c->d_up[6], (size_t)L * 4))) return rc;
+  { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
+    hipLaunchKernelGGL(k_landmark_assoc, dim3((unsigned)((L + 127) / 128)), dim3(128), 0, c->stream, (const double*)c->d_up[2].p, c->N, c->t0, c->dt, c->cam, (const double*)c->d_up[3].p,
+                       (const double*)c->d_up[4].p, L, map_time, mkq(q_LtoC_xyzw[3], q_LtoC_xyzw[0], q_LtoC_xyzw[1], q_LtoC_xyzw[2]), mk(t_LinC3[0], t_LinC3[1], t_LinC3[2]), n_planes,
+                       (const double*)c->d_up[5].p, radius, (int*)c->d_up[6].p); }
+  LVX_HIP(c, hipGetLastError());
+  LVX_HIP(c, hipMemcpyAsync(plane_of_landmark, c->d_up[6].p, (size_t)L * 4, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  return LVX_OK;
 }
 
 int lvx_evaluate_lidar_pose(lvx_ctx* c, const double* state, int n, const double* t, double* q4, double* p3, int32_t* valid) {

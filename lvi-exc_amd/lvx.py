@@ -26,8 +26,9 @@ LOCK_GYRO_BIAS = 1 << 9
 LOCK_LANDMARKS = 1 << 10
 
 EVAL_COST, EVAL_RESIDUALS, EVAL_NORMAL_EQ, EVAL_JACOBIAN = 1, 2, 4, 8
-FAM_GYRO, FAM_ACCEL, FAM_PRIOR, FAM_SURFEL, FAM_REPROJ, FAM_CAMSURF, KERNEL_FOLD, KERNEL_SOLVE, KERNEL_UPSTREAM = range(9)
-KERNEL_NAMES = ["gyro", "accel", "prior", "surfel", "reproj", "camsurf", "fold", "solve", "upstream"]
+(FAM_GYRO, FAM_ACCEL, FAM_PRIOR, FAM_SURFEL, FAM_REPROJ, FAM_CAMSURF, KERNEL_FOLD, KERNEL_SOLVE, KERNEL_UPSTREAM, KERNEL_CLEAR, KERNEL_REP_JAC, KERNEL_REP_OBS,
+ KERNEL_REP_REF, KERNEL_REP_CROSS, KERNEL_REP_LMROWS) = range(15)
+KERNEL_NAMES = ["gyro", "accel", "prior", "surfel", "reproj", "camsurf", "fold", "solve", "upstream", "clear", "reproj_jac", "reproj_obs", "reproj_ref", "reproj_cross", "reproj_lmrows"]
 JAC_WIDTH = 64
 
 
@@ -237,8 +238,8 @@ class Context:
         self._ck(self._l.lvx_set_profiling(self._h, C.c_int((2 + int(only)) if (on and only is not None) else (1 if on else 0))))
 
     def kernel_ms(self):
-        ms = np.zeros(9)
-        n = np.zeros(9, dtype=np.int64)
+        ms = np.zeros(len(KERNEL_NAMES))
+        n = np.zeros(len(KERNEL_NAMES), dtype=np.int64)
         self._ck(self._l.lvx_get_kernel_ms(self._h, _p(ms), _p(n)))
         return ms, n
 
@@ -388,20 +389,62 @@ def surfel_assoc(ctx, scan_hw4, p4, box_min, box_max, radius=0.05, sel=2):
     return flag.reshape(H, W)
 
 
+def surfel_assoc_emit(ctx, scans_map, scans_raw, p4, box_min, box_max, radius=0.05, sel=2):
+    """getAssociation for a batch of scans, on the device end to end: scans_map [S, H, W, 4] float32 (map frame), scans_raw [S, H, W] POINT_XYZIT.
+    Returns (flags [S, H, W], dict(pt, pt_map, t, plane, counts)) — the SurfelPoint list of all scans in chronological order."""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    sm = np.ascontiguousarray(scans_map, np.float32)
+    S, H, W = sm.shape[0], sm.shape[1], sm.shape[2]
+    raw = np.ascontiguousarray(scans_raw, dtype=POINT_XYZIT).reshape(S, H, W)
+    sm_d = torch.from_numpy(sm).to(dev)
+    raw_d = torch.from_numpy(raw.view(np.uint8).reshape(-1)).to(dev)
+    pl_d = torch.from_numpy(np.concatenate([_d(p4).ravel(), _d(box_min).ravel(), _d(box_max).ravel()])).to(dev)
+    flags_d = torch.empty(S * H * W, dtype=torch.int32, device=dev)
+    l = ctx._l
+    ctx._ck(l.lvx_surfel_assoc_batch_d(ctx._h, C.c_int(S), C.c_int(H), C.c_int(W), C.c_void_p(sm_d.data_ptr()), C.c_int(len(p4)), C.c_void_p(pl_d.data_ptr()), C.c_double(radius), C.c_int(sel),
+                                       C.c_void_p(flags_d.data_ptr())))
+    n = C.c_int32(0)
+    counts = np.zeros(S, np.int32)
+    ctx._ck(l.lvx_surfel_emit_d(ctx._h, C.c_int(S), C.c_int(H), C.c_int(W), C.c_void_p(flags_d.data_ptr()), C.c_void_p(sm_d.data_ptr()), C.c_void_p(raw_d.data_ptr()), C.c_int(0),
+                                None, None, None, None, C.byref(n), _p(counts)))
+    k = n.value
+    pt_d = torch.empty(max(k, 1) * 3, dtype=torch.float64, device=dev); pm_d = torch.empty_like(pt_d)
+    t_d = torch.empty(max(k, 1), dtype=torch.float64, device=dev); pid_d = torch.empty(max(k, 1), dtype=torch.int32, device=dev)
+    if k:
+        ctx._ck(l.lvx_surfel_emit_d(ctx._h, C.c_int(S), C.c_int(H), C.c_int(W), C.c_void_p(flags_d.data_ptr()), C.c_void_p(sm_d.data_ptr()), C.c_void_p(raw_d.data_ptr()), C.c_int(k),
+                                    C.c_void_p(pt_d.data_ptr()), C.c_void_p(pm_d.data_ptr()), C.c_void_p(t_d.data_ptr()), C.c_void_p(pid_d.data_ptr()), C.byref(n), _p(counts)))
+    ctx.synchronize()
+    return flags_d.cpu().numpy().reshape(S, H, W), dict(pt=pt_d.cpu().numpy().reshape(-1, 3)[:k], pt_map=pm_d.cpu().numpy().reshape(-1, 3)[:k], t=t_d.cpu().numpy()[:k],
+                                                          plane=pid_d.cpu().numpy()[:k], counts=counts)
+
+
+def landmark_assoc(ctx, state, q_LtoC_xyzw, t_LinC, map_time, p4, box_min, box_max, radius=0.05):
+    """associateVisualPointsWithPlanes: surfel index per landmark (or -1)."""
+    p4, box_min, box_max = _d(p4), _d(box_min), _d(box_max)
+    L = ctx.state_size - 7 * ctx.layout()["n_knots"] - 32
+    out = np.full(max(L, 1), -1, np.int32)
+    ctx._ck(ctx._l.lvx_landmark_assoc(ctx._h, _p(_d(state)), _p(_d(q_LtoC_xyzw)), _p(_d(t_LinC)), C.c_double(map_time), C.c_int(len(p4)), _p(p4), _p(box_min), _p(box_max), C.c_double(radius), _p(out)))
+    return out[:L]
+
+
 def upstream_bench(ctx, kind, arrays, reps=20):
     """Time one upstream kernel with its inputs RESIDENT on the device (torch tensors; `_d` entry points).  Returns seconds per call."""
     import torch
     l = ctx._l
     dev = torch.device("cuda", torch.cuda.current_device())
-    if kind == "surfel_assoc":
+    if kind == "surfel_assoc":   # scan: [H, W, 4] (one scan) or [S, H, W, 4] (a batch per call)
         scan, p4, bmin, bmax = arrays
-        H, W = scan.shape[0], scan.shape[1]
+        scan = np.ascontiguousarray(scan, np.float32)
+        if scan.ndim == 3:
+            scan = scan[None]
+        S, H, W = scan.shape[0], scan.shape[1], scan.shape[2]
         P = len(p4)
-        scan_d = torch.from_numpy(np.ascontiguousarray(scan, np.float32)).to(dev)
+        scan_d = torch.from_numpy(scan).to(dev)
         pl_d = torch.from_numpy(np.concatenate([_d(p4).ravel(), _d(bmin).ravel(), _d(bmax).ravel()])).to(dev)
-        flag_d = torch.empty(H * W, dtype=torch.int32, device=dev)
-        call = lambda: ctx._ck(l.lvx_surfel_assoc_d(ctx._h, C.c_int(H), C.c_int(W), C.c_void_p(scan_d.data_ptr()), C.c_int(P), C.c_void_p(pl_d.data_ptr()),
-                                                    C.c_double(0.05), C.c_int(2), C.c_void_p(flag_d.data_ptr())))
+        flag_d = torch.empty(S * H * W, dtype=torch.int32, device=dev)
+        call = lambda: ctx._ck(l.lvx_surfel_assoc_batch_d(ctx._h, C.c_int(S), C.c_int(H), C.c_int(W), C.c_void_p(scan_d.data_ptr()), C.c_int(P), C.c_void_p(pl_d.data_ptr()),
+                                                          C.c_double(0.05), C.c_int(2), C.c_void_p(flag_d.data_ptr())))
     elif kind == "voxel_build":
         cloud, leaf = arrays
         n = len(cloud)

@@ -5,8 +5,12 @@ Each rank owns one sequence: its trajectory, gravity, biases and landmarks are p
     1. every rank eliminates its private variables (Schur complement onto the 14 shared scalars),
     2. ONE all-reduce (sum) of [S_shared (14x14) | rhs (14) | cost (1)]  — 211 doubles, latency-bound on xGMI / RCCL,
     3. every rank solves the same 14 x 14 system and back-substitutes its private part.
-This module is backend-agnostic (torch.distributed: "nccl" = RCCL on ROCm, "gloo" on CPU for tests).  The dense algebra here is the
-reference formulation the GPU solver's border reduction follows; it runs on whatever (H, g) the caller provides.
+This module is backend-agnostic (torch.distributed: "nccl" = RCCL on ROCm, "gloo" on CPU for tests).  (A dense numpy restatement of the
+reduction, used only as a test reference, lives in tests/sharded_reference.py.)
+
+Second sharding axis: scan-level work — surfel association, scan registration, de-skew — is independent per scan: the scans of
+a sequence are split into contiguous shards, one per rank, each rank runs the batched kernels on its shard against the same surfel map, and the
+per-point results are all-gathered (no arithmetic collective).
 """
 import numpy as np
 
@@ -16,58 +20,6 @@ N_SHARED = 14
 def shared_tangent_indices(n_knots):
     """lidar theta(3) p(3) tau, cam theta(3) p(3) tau in the tangent layout of include/lvx.h."""
     return 6 * n_knots + 8 + np.arange(N_SHARED)
-
-
-def reduce_to_shared(H, g, free, shared, damping):
-    """Schur-eliminate the private free scalars.  Returns (S, rhs, solver closure for the back substitution)."""
-    free = np.asarray(free)
-    shared = np.asarray(shared)
-    is_sh = np.isin(free, shared)
-    priv = free[~is_sh]
-    sh = free[is_sh]
-    App = H[np.ix_(priv, priv)] + np.diag(damping[priv])
-    Aps = H[np.ix_(priv, sh)]
-    Ass = H[np.ix_(sh, sh)]
-    L = np.linalg.cholesky(App)
-    Z = np.linalg.solve(L, Aps)
-    z = np.linalg.solve(L, -g[priv])
-    S = np.zeros((N_SHARED, N_SHARED))
-    r = np.zeros(N_SHARED)
-    pos = np.searchsorted(shared, sh)
-    S[np.ix_(pos, pos)] = Ass - Z.T @ Z
-    r[pos] = -g[sh] - Z.T @ z
-
-    def back_substitute(y_shared):
-        y = np.zeros(H.shape[0])
-        y[sh] = y_shared[pos]
-        y[priv] = np.linalg.solve(L.T, z - Z @ y_shared[pos])
-        return y
-    return S, r, back_substitute, pos
-
-
-def sharded_step(H, g, free, shared, damping, cost, all_reduce):
-    """One joint step.  `all_reduce(vec)` sums a float64 numpy vector over ranks in place.  Shared damping is added once, after the sum."""
-    S, r, back, pos = reduce_to_shared(H, g, free, shared, damping)
-    buf = np.concatenate([S.ravel(), r, [cost]])
-    all_reduce(buf)
-    S = buf[:N_SHARED * N_SHARED].reshape(N_SHARED, N_SHARED)
-    r = buf[N_SHARED * N_SHARED:N_SHARED * N_SHARED + N_SHARED]
-    Sd = S + np.diag(damping[np.asarray(shared)])
-    live = np.zeros(N_SHARED, dtype=bool)
-    live[pos] = True
-    y = np.zeros(N_SHARED)
-    y[live] = np.linalg.solve(Sd[np.ix_(live, live)], r[live])
-    return back(y), float(buf[-1])
-
-
-def torch_all_reduce(dist):
-    import torch
-
-    def fn(vec):
-        t = torch.from_numpy(vec)
-        dist.all_reduce(t)
-        return vec
-    return fn
 
 
 def dist_all_reduce(dist, device=None):
@@ -84,6 +36,30 @@ def dist_all_reduce(dist, device=None):
             dist.all_reduce(t, op=rop)
             vec[:] = t.cpu().numpy()
     return fn
+
+
+def scan_shard(n_scans, rank, world):
+    """Contiguous, balanced shard [lo, hi) of n_scans scans for `rank` of `world` (the first n_scans % world ranks get one scan more)."""
+    base, extra = divmod(int(n_scans), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def all_gather_scan_results(dist, local, n_scans, fill=-1):
+    """All-gather per-scan result rows (torch tensor [n_local, row_len], e.g. the surfel-association flags of this rank's shard) into
+    [n_scans, row_len] in scan order on every rank.  Shards may differ by one scan: they are padded to the largest for the collective."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if world == 1:
+        return local
+    per = [scan_shard(n_scans, r, world) for r in range(world)]
+    nmax = max(hi - lo for lo, hi in per)
+    row = local.shape[1]
+    pad = torch.full((nmax, row), fill, dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    out = torch.empty((world * nmax, row), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad)
+    return torch.cat([out[r * nmax:r * nmax + (hi - lo)] for r, (lo, hi) in enumerate(per)], dim=0)
 
 
 class ThreadAllReduce:

