@@ -315,6 +315,11 @@ typedef struct lvx_point_xyzit { float x, y, z, pad; float intensity; float pad2
  * written then; size the outputs and call again); per_scan_counts[n_scans] may be NULL. */
 int lvx_surfel_emit_d(lvx_ctx* ctx, int n_scans, int H, int W, const int32_t* flags_d, const float* scans_map_d, const lvx_point_xyzit* scans_raw_d, int max_out,
                       double* pt3_d, double* pt_map3_d, double* t_d, int32_t* plane_d, int32_t* n_out, int32_t* per_scan_counts);
+/* getAssociation for n_scans scans with host buffers in and out (what DataAssociation's loop over the scans does, lvi_initialize_surfel_orb.cpp:1192-1199): flags
+ * plane_of_point[n_scans * H * W] (may be NULL) and the concatenated SurfelPoint list; *n_out = its length (nothing is written when it exceeds max_out) */
+int lvx_surfel_assoc_emit(lvx_ctx* ctx, int n_scans, int H, int W, const float* scans_map_xyzi4, const lvx_point_xyzit* scans_raw, int n_planes, const double* plane_p4,
+                          const double* box_min3, const double* box_max3, double radius, int sel_per_ring, int32_t* plane_of_point, int max_out, double* pt3, double* pt_map3, double* t,
+                          int32_t* plane, int32_t* n_out);
 /* SurfelAssociation::associateVisualPointsWithPlanes (surfel_association.cpp:161-214) over the landmark table of lvx_set_landmarks and the inverse depths in `state`:
  * plane_of_landmark[l] = index of the surfel whose AABB strictly contains the landmark (map frame) within 2 * radius of its plane — the highest such index, as the
  * reference's loop leaves it — or -1 (also for rho < 0.05 and for reference views outside the spline).  q_LtoC (x, y, z, w), t_LinC: LiDAR pose in the camera frame. */

@@ -1116,6 +1116,37 @@ int lvx_surfel_emit_d(lvx_ctx* c, int n_scans, int H, int W, const int32_t* flag
   return LVX_OK;
 }
 
+// host-buffer convenience over the two device entry points above: S organised scans (map frame + raw) in, flags and the SurfelPoint list out
+int lvx_surfel_assoc_emit(lvx_ctx* c, int n_scans, int H, int W, const float* scans_map_xyzi4, const lvx_point_xyzit* scans_raw, int n_planes, const double* plane_p4, const double* box_min3,
+                          const double* box_max3, double radius, int sel_per_ring, int32_t* plane_of_point, int max_out, double* pt3, double* pt_map3, double* t, int32_t* plane, int32_t* n_out) {
+  if (!c || n_scans <= 0 || H <= 0 || W <= 0 || W > SA_WMAX || n_planes < 0 || !scans_map_xyzi4 || !scans_raw || !n_out || (n_planes > 0 && (!plane_p4 || !box_min3 || !box_max3))) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  const size_t npt = (size_t)n_scans * H * W;
+  int rc;
+  std::vector<double> pl((size_t)std::max(n_planes, 1) * 10, 0.0);
+  if (n_planes > 0) { std::memcpy(pl.data(), plane_p4, (size_t)n_planes * 32); std::memcpy(pl.data() + 4 * (size_t)n_planes, box_min3, (size_t)n_planes * 24); std::memcpy(pl.data() + 7 * (size_t)n_planes, box_max3, (size_t)n_planes * 24); }
+  if ((rc = upload(c, c->d_up[4], scans_map_xyzi4, npt * 16))) return rc;
+  if ((rc = upload(c, c->d_up[2], scans_raw, npt * 32))) return rc;
+  if ((rc = upload(c, c->d_up[5], pl.data(), pl.size() * 8))) return rc;
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  if ((rc = dev_alloc(c, c->d_up[6], npt * 4))) return rc;
+  if ((rc = lvx_surfel_assoc_batch_d(c, n_scans, H, W, (const float*)c->d_up[4].p, n_planes, (const double*)c->d_up[5].p, radius, sel_per_ring, (int32_t*)c->d_up[6].p))) return rc;
+  if (plane_of_point) LVX_HIP(c, hipMemcpyAsync(plane_of_point, c->d_up[6].p, npt * 4, hipMemcpyDeviceToHost, c->stream));
+  int32_t total = 0;
+  if ((rc = lvx_surfel_emit_d(c, n_scans, H, W, (const int32_t*)c->d_up[6].p, (const float*)c->d_up[4].p, (const lvx_point_xyzit*)c->d_up[2].p, 0, nullptr, nullptr, nullptr, nullptr, &total, nullptr))) return rc;
+  *n_out = total;
+  if (total == 0 || total > max_out || !pt3 || !pt_map3 || !t || !plane) { LVX_HIP(c, hipStreamSynchronize(c->stream)); return LVX_OK; }
+  if ((rc = dev_alloc(c, c->d_up[3], (size_t)total * (24 + 24 + 8 + 4) + 64))) return rc;
+  double* d_pt = (double*)c->d_up[3].p; double* d_pm = d_pt + 3 * (size_t)total; double* d_t = d_pm + 3 * (size_t)total; int32_t* d_pl = (int32_t*)(d_t + total);
+  if ((rc = lvx_surfel_emit_d(c, n_scans, H, W, (const int32_t*)c->d_up[6].p, (const float*)c->d_up[4].p, (const lvx_point_xyzit*)c->d_up[2].p, total, d_pt, d_pm, d_t, d_pl, &total, nullptr))) return rc;
+  LVX_HIP(c, hipMemcpyAsync(pt3, d_pt, (size_t)total * 24, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipMemcpyAsync(pt_map3, d_pm, (size_t)total * 24, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipMemcpyAsync(t, d_t, (size_t)total * 8, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipMemcpyAsync(plane, d_pl, (size_t)total * 4, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  return LVX_OK;
+}
+
 int lvx_landmark_assoc(lvx_ctx* c, const double* state, const double* q_LtoC_xyzw, const double* t_LinC3, double map_time, int n_planes, const double* plane_p4, const double* box_min3,
                        const double* box_max3, double radius, int32_t* plane_of_landmark) {
   if (!c || !state || !q_LtoC_xyzw || !t_LinC3 || n_planes < 0 || (c->L > 0 && !plane_of_landmark) || (n_planes > 0 && (!plane_p4 || !box_min3 || !box_max3))) return LVX_E_ARG;

@@ -446,24 +446,24 @@ RS_POINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad", "<f4"), (
 
 
 def _raycast_room(dirs, origin, half=(10.0, 7.5), z_lo=-1.5, z_hi=1.5, pillars=((3, 2, 0.3), (-4, 3, 0.4), (5, -3, 0.35), (-2, -4, 0.3))):
-    """Range along unit rays to the inside of a box room (20 x 15 x 3 m) with 4 vertical cylinders."""
-    o = np.asarray(origin, dtype=np.float64)
+    """Range along unit rays to the inside of a box room (20 x 15 x 3 m) with 4 vertical cylinders; origin: one point or one per ray."""
     d = dirs.astype(np.float64)
+    o = np.broadcast_to(np.asarray(origin, dtype=np.float64), d.shape)
     t = np.full(len(d), np.inf)
     with np.errstate(divide="ignore", invalid="ignore"):
         for ax, (lo, hi) in enumerate(((-half[0], half[0]), (-half[1], half[1]), (z_lo, z_hi))):
             for wall in (lo, hi):
-                tt = (wall - o[ax]) / d[:, ax]
-                p = o[None, :] + tt[:, None] * d
+                tt = (wall - o[:, ax]) / d[:, ax]
+                p = o + tt[:, None] * d
                 ok = (tt > 0) & (np.abs(p[:, 0]) <= half[0] + 1e-9) & (np.abs(p[:, 1]) <= half[1] + 1e-9) & (p[:, 2] >= z_lo - 1e-9) & (p[:, 2] <= z_hi + 1e-9)
                 t = np.where(ok & (tt < t), tt, t)
         for cx, cy, r in pillars:
             a = d[:, 0] ** 2 + d[:, 1] ** 2
-            b = 2 * ((o[0] - cx) * d[:, 0] + (o[1] - cy) * d[:, 1])
-            c = (o[0] - cx) ** 2 + (o[1] - cy) ** 2 - r * r
+            b = 2 * ((o[:, 0] - cx) * d[:, 0] + (o[:, 1] - cy) * d[:, 1])
+            c = (o[:, 0] - cx) ** 2 + (o[:, 1] - cy) ** 2 - r * r
             disc = b * b - 4 * a * c
             tt = (-b - np.sqrt(np.maximum(disc, 0))) / (2 * a)
-            z = o[2] + tt * d[:, 2]
+            z = o[:, 2] + tt * d[:, 2]
             ok = (disc > 0) & (tt > 0) & (z >= z_lo) & (z <= z_hi)
             t = np.where(ok & (tt < t), tt, t)
     return t
@@ -544,3 +544,61 @@ def make_assoc_problem(seed=5, H=16, W=1800, n_planes=400):
         lo = np.floor(c / 1.0) * 1.0
         bmin[i] = lo + rng.uniform(0, 0.05, 3); bmax[i] = lo + 1.0 - rng.uniform(0, 0.05, 3)
     return scan, p4, bmin, bmax
+
+
+def make_sequence(seed=50, duration=6.0, dt=0.02, imu_rate=400.0, scan_rate=10.0, H=16, W=450, n_reproj=3000, obs_per_frame=50, pad=0.3, t_start=100.0,
+                  range_noise=0.01, lidar_err_deg=1.0, lidar_err_m=0.02, cam_err_deg=2.0, cam_err_m=0.03, cp_noise=(2e-3, 2e-3)):
+    """A recorded-sequence stand-in for the offline calibration driver (lvx_host::Calibrator): IMU stream, organised LiDAR scans of a box room with
+    pillars — every point ray-cast from the pose AT ITS OWN TIMESTAMP (a moving, rolling LiDAR) — and ORB-like visual tracks, all consistent with one
+    ground-truth state.  state0: trajectory slightly off (it must be good enough to de-skew, as after the reference's LOAM / NDT initialisation),
+    extrinsics off by lidar_err / cam_err."""
+    rng = np.random.default_rng(seed)
+    cam = dict(DEFAULT_CAMERA)
+    t0 = t_start - pad
+    t_end = t_start + duration
+    n_knots = int(np.ceil((t_end + pad - t0) / dt)) + 3
+    while t0 + (n_knots - 3) * dt < t_end + pad:
+        n_knots += 1
+    r3, so3 = make_trajectory(n_knots, t0, dt, rng, pos_amp=1.2, rot_amp=0.5)
+    r3[:, 2] *= 0.25                                                     # stay between floor and ceiling
+    sp = Spline(t0, dt, r3, so3)
+    q_LI = q_from_rpy(np.deg2rad(2.0), np.deg2rad(-3.0), np.deg2rad(91.0)); p_LI = np.array([0.05, -0.10, 0.12])
+    q_CI = qmul(q_from_rpy(np.deg2rad(-90.0), 0.0, np.deg2rad(-90.0)), q_from_rotvec(np.deg2rad([2.0, 0, 0]))); p_CI = np.array([-0.22, 0.02, 0.22])
+    roll, pitch = 0.02, -0.015
+    ba = np.array([0.05, 0.02, -0.03]); bg = np.array([0.01, -0.02, 0.005])
+    g = gravity_vec(roll, pitch)
+    n_imu = int(round(duration * imu_rate))
+    t_imu = t_start + (np.arange(n_imu) + 0.37) / imu_rate
+    e = sp.eval(t_imu)
+    gyro = qrot(qconj(e["quat"]), e["angvel"]) + bg + 1.745e-4 * np.sqrt(imu_rate) * rng.standard_normal((n_imu, 3))
+    acc = qrot(qconj(e["quat"]), e["acc"] + g) + ba + 5.88e-4 * np.sqrt(imu_rate) * rng.standard_normal((n_imu, 3))
+    # scans
+    t_map = t_start + 0.05
+    n_scans = int(np.floor((duration - 0.3) * scan_rate))
+    az = np.deg2rad(np.arange(W) * (360.0 / W)); el = np.deg2rad(np.linspace(-15.0, 15.0, H))
+    E, A = np.meshgrid(el, az, indexing="ij")
+    dirs_L = np.stack([np.cos(E) * np.cos(A), np.cos(E) * np.sin(A), np.sin(E)], axis=-1).reshape(-1, 3)     # [H * W], index h * W + w
+    col_dt = np.tile(np.arange(W) / W / scan_rate, H)
+    scans = np.zeros((n_scans, H * W), dtype=np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad", "<f4"), ("intensity", "<f4"), ("pad2", "<f4"), ("timestamp", "<f8")]))
+    for s_ in range(n_scans):
+        ts = t_start + 0.1 + s_ / scan_rate + col_dt
+        ek = sp.eval(ts)
+        org = qrot(ek["quat"], np.broadcast_to(p_LI, (len(ts), 3))) + ek["pos"]
+        dW = qrot(ek["quat"], qrot(np.broadcast_to(q_LI, (len(ts), 4)), dirs_L))
+        rr = _raycast_room(dW, org) + range_noise * rng.standard_normal(len(ts))
+        xyz = (dirs_L * rr[:, None]).astype(np.float32)
+        scans["x"][s_], scans["y"][s_], scans["z"][s_], scans["timestamp"][s_] = xyz[:, 0], xyz[:, 1], xyz[:, 2], ts
+        drop = rng.random(len(ts)) < 0.01
+        scans["x"][s_][drop] = np.nan
+    V = _bench_visual(sp, cam, rng, t_start, t_end, n_reproj, q_CI, p_CI, "orb", 10, 20.0, obs_per_frame)
+    rho = V["rho"]
+    state_true = pack_state(r3, so3, imu_block(roll, pitch, ba, bg), sensor_block(q_LI, p_LI), sensor_block(q_CI, p_CI), rho)
+    r3p = r3 + cp_noise[0] * rng.standard_normal(r3.shape)
+    so3p = qmul(q_from_rotvec(cp_noise[1] * rng.standard_normal((n_knots, 3))), so3); so3p /= np.linalg.norm(so3p, axis=1, keepdims=True)
+    ax = np.array([0.6, -0.5, 0.62]); ax /= np.linalg.norm(ax)
+    dqL = q_from_rotvec(np.deg2rad(lidar_err_deg) * ax); dqC = q_from_rotvec(np.deg2rad(cam_err_deg) * np.array([-0.4, 0.7, 0.59]) / np.linalg.norm([-0.4, 0.7, 0.59]))
+    dL = lidar_err_m * np.array([1, -1, 1]) / np.sqrt(3); dC = cam_err_m * np.array([-1, 1, 1]) / np.sqrt(3)
+    state0 = pack_state(r3p, so3p, imu_block(0.01, 0.01), sensor_block(qmul(dqL, q_LI), p_LI + dL), sensor_block(qmul(dqC, q_CI), p_CI + dC), rho * (1.0 + 0.05 * rng.standard_normal(len(rho))))
+    return dict(t0=t0, dt=dt, n_knots=n_knots, camera=cam, t_imu=t_imu, gyro=gyro, acc=acc, H=H, W=W, scans=scans, t_map=t_map,
+                n_landmarks=V["n_landmarks"], lm_uv=V["lm_uv"], lm_t0=V["lm_t0"], rep_lm=V["rep_lm"], rep_uv=V["rep_uv"], rep_t0=V["rep_t0"],
+                state_true=state_true, state0=state0, t_start=t_start, t_end=t_end)

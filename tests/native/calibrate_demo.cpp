@@ -1,0 +1,57 @@
+// Drives lvx_host::Calibrator (lvi-exc_amd/host/lvx_calibrate.hpp) on a problem read from a flat binary file of doubles — the stand-in for the
+// rosbag / text inputs of the reference's lvi_initialize_surfel_orb — and writes the calibrated state.  Usage: calibrate_demo in.bin out.bin
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+
+#include "lvx_calibrate.hpp"
+
+static std::vector<double> read_all(const char* path) {
+  std::ifstream f(path, std::ios::binary | std::ios::ate);
+  if (!f) throw std::runtime_error(std::string("cannot open ") + path);
+  const std::streamsize n = f.tellg(); f.seekg(0);
+  std::vector<double> v((size_t)n / 8);
+  f.read(reinterpret_cast<char*>(v.data()), n);
+  return v;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) { std::fprintf(stderr, "usage: %s problem.bin result.bin\n", argv[0]); return 2; }
+  try {
+    const std::vector<double> d = read_all(argv[1]);
+    size_t o = 0;
+    auto next = [&]() { return d.at(o++); };
+    auto vec = [&]() { const size_t n = (size_t)next(); std::vector<double> v(d.begin() + o, d.begin() + o + n); o += n; return v; };
+    lvx_host::CalibrateInput in;
+    lvx_host::CalibrateOptions opt;
+    in.t0 = next(); in.dt = next(); in.n_knots = (int)next(); in.map_time = next(); in.H = (int)next(); in.W = (int)next();
+    const int n_scans = (int)next();
+    opt.refine_iterations = (int)next(); opt.lvi_stage = next() != 0; opt.camera_surfel_stage = next() != 0; opt.downsample_step = (int)next(); opt.solve0_so3_from_gyro = next() != 0;
+    in.camera.rows = (int)next(); in.camera.cols = (int)next(); in.camera.readout = next(); in.camera.fx = next(); in.camera.fy = next(); in.camera.cx = next(); in.camera.cy = next();
+    in.camera.k1 = next(); in.camera.k2 = next(); in.camera.p1 = next(); in.camera.p2 = next(); in.camera.k3 = next();
+    std::vector<double> state = vec();
+    in.imu_t = vec(); in.gyro = vec(); in.acc = vec();
+    in.lm_uv = vec(); in.lm_t0 = vec();
+    { const std::vector<double> ol = vec(); in.obs_landmark.assign(ol.begin(), ol.end()); }
+    in.obs_uv = vec(); in.obs_t0 = vec();
+    for (int s = 0; s < n_scans; ++s) {   // per scan: xyz (float values stored as doubles) [HW][3], timestamps [HW]
+      const std::vector<double> xyz = vec(), ts = vec();
+      std::vector<lvx_point_xyzit> pts((size_t)in.H * in.W);
+      for (size_t i = 0; i < pts.size(); ++i) { std::memset(&pts[i], 0, sizeof(pts[i])); pts[i].x = (float)xyz[3 * i]; pts[i].y = (float)xyz[3 * i + 1]; pts[i].z = (float)xyz[3 * i + 2]; pts[i].timestamp = ts[i]; }
+      in.scans.push_back(std::move(pts));
+    }
+    lvx_host::Calibrator cal(0, in, opt);
+    const auto rep = cal.Run(&state);
+    std::vector<double> out;
+    out.push_back((double)rep.size());
+    for (const auto& r : rep) { out.push_back(r.lm.iterations); out.push_back(r.lm.termination); out.push_back(r.lm.initial_cost); out.push_back(r.lm.final_cost); out.push_back(r.n_planes); out.push_back(r.n_surfel_points); out.push_back(r.n_cam_surfel);
+      std::cout << r.name << ": iterations " << r.lm.iterations << " termination " << r.lm.termination << " cost " << r.lm.initial_cost << " -> " << r.lm.final_cost << " planes " << r.n_planes
+                << " surfel points " << r.n_surfel_points << " cam-surfel " << r.n_cam_surfel << "\n"; }
+    out.insert(out.end(), state.begin(), state.end());
+    std::ofstream f(argv[2], std::ios::binary);
+    f.write(reinterpret_cast<const char*>(out.data()), (std::streamsize)out.size() * 8);
+    return 0;
+  } catch (const std::range_error& e) { std::fprintf(stderr, "range_error: %s\n", e.what()); return 4;
+  } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 3; }
+}
