@@ -202,6 +202,7 @@ typedef struct lvx_lm_options {
 #define LVX_LM_GRADIENT_TOLERANCE 3
 #define LVX_LM_MAX_ITERATIONS 4
 #define LVX_LM_FAILURE 5
+#define LVX_LM_MIN_RADIUS 6       /* Ceres: CONVERGENCE, "minimum trust region radius reached" */
 typedef struct lvx_lm_summary {
   int32_t iterations, successful_steps, termination;
   double initial_cost, final_cost, final_radius;
@@ -289,6 +290,19 @@ typedef int (*lvx_allreduce_fn)(void* user, double* buf, int n, int op);   /* in
 /* lvx_solve_step / lvx_lm_solve of the joint problem; fn == NULL degenerates to the single-sequence calls */
 int lvx_solve_step_shared(lvx_ctx* ctx, double radius, int jacobi_scaling, lvx_allreduce_fn fn, void* user, double* delta, double* model_cost_change);
 int lvx_lm_solve_shared(lvx_ctx* ctx, double* state, const lvx_lm_options* opt, lvx_allreduce_fn fn, void* user, lvx_lm_summary* summary);
+
+/* RCCL transport: with a communicator installed the reductions of lvx_solve_step_shared / lvx_lm_solve_shared (fn = NULL) run as ncclAllReduce on the
+ * context's stream — the per-step [S | rhs | votes] block is packed, reduced and solved on the device with no host round trip.  librccl is loaded with
+ * dlopen (no link-time dependency; a process that already loaded RCCL, e.g. through torch, shares it).  Rank 0 creates the 128-byte id, the host
+ * distributes it (any side channel), every rank calls lvx_rccl_init; lvx_rccl_finalize (or lvx_destroy) frees the communicator.
+ * Collectives per LM iteration: one for the step, one for the accept / reject decision, and two more after an accepted step (cost + shared diagonal +
+ * shared gradient; gradient max norm) — the step and the decision cannot merge, the candidate depends on the reduced system's solution.
+ * A rank that fails locally votes in the next collective and EVERY rank returns there (the failing one with its code, the others LVX_E_COMM). */
+int lvx_rccl_unique_id(lvx_ctx* ctx, void* id128);
+int lvx_rccl_init(lvx_ctx* ctx, const void* id128, int rank, int world);
+int lvx_rccl_finalize(lvx_ctx* ctx);
+/* reductions issued by this context since the last reset (either transport) */
+int64_t lvx_collective_count(lvx_ctx* ctx, int reset);
 
 /* NDT registration derivatives ------------------------------------------------------------------------*/
 /* pclomp::NormalDistributionsTransform::computeDerivatives with DIRECT7 search (src/ndt_omp/include/pclomp/ndt_omp_impl.hpp:180-285, 289-430, 484-536)

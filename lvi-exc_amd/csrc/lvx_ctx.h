@@ -141,6 +141,9 @@ struct lvx_ctx {
   // sequence-per-GPU joint solve: host all-reduce hook, shared-extrinsics bookkeeping (lvx_solver.hip)
   lvx_allreduce_fn ar_fn = nullptr;
   void* ar_user = nullptr;
+  void* rccl_comm = nullptr; int comm_rank = 0, comm_world = 1;   // lvx_rccl_init: the reductions run as ncclAllReduce on the context's stream
+  lvx::DevBuf d_comm;                                            // device staging buffer of the reductions
+  int64_t n_collectives = 0;                                     // reductions issued (either transport): lvx_collective_count
   int ns = 0;                 // free shared scalars = the last ns border variables
   int sh_slot[LVX_N_SHARED] = {0};   // canonical slot (0..13: lidar theta p tau, cam theta p tau) of each of them
   double sh_lmd[LVX_N_SHARED] = {0}; // LM diagonal of the shared scalars (from the JOINT diagonal), added once after the reduction

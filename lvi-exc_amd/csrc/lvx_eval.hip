@@ -1951,6 +1951,8 @@ void lvx_destroy(lvx_ctx* c) {
   if (c->d_colfull.p) (void)hipFree(c->d_colfull.p);
   for (DevBuf* b : {&c->d_lmH, &c->d_lm_p0, &c->d_Hr, &c->d_Br, &c->d_red, &c->d_repT}) if (b->p) (void)hipFree(b->p);
   for (DevBuf* b : {&c->vox.misc, &c->vox.keys, &c->vox.vals, &c->vox.runs, &c->vox.cells, &c->vox.tmp, &c->vox.leaf_i, &c->vox.leaf_d, &c->vox.leaf_f}) if (b->p) (void)hipFree(b->p);
+  (void)lvx_rccl_finalize(c);
+  if (c->d_comm.p) (void)hipFree(c->d_comm.p);
   bcr_destroy(c);
   for (DevBuf* b : {&c->d_bcrD, &c->d_bcrG, &c->d_bcrInfo, &c->d_Y2, &c->d_gram}) if (b->p) (void)hipFree(b->p);
   for (auto& e : c->graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.exec);

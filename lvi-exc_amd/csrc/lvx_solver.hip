@@ -20,6 +20,9 @@
 
 #include <chrono>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types only: the entry points are resolved with dlsym (rccl_api)
+
 #include "lvx_ctx.h"
 
 namespace lvx {
@@ -487,11 +490,65 @@ struct SolveWork { double *L, *Z, *S, *rhs, *delta, *diag, *scale, *lmd, *sums, 
                    bool lm;                                   // landmarks are eliminated first (k_lm_schur)
                    const double *Hs, *Bs, *Cs, *gbs, *gcs; };   // what the band / border solve reads: the normal equations, or their copies after the landmark elimination
 
-// host all-reduce hook of the joint (sequence-per-GPU) solve; identity for a single sequence
+// ---------------------------------------------------------------------------------------------------------
+// Reductions of the joint (sequence-per-GPU) solve.  Two transports: RCCL on the context's stream (lvx_rccl_init: librccl is loaded with dlopen, so the
+// library carries no link-time dependency and shares the RCCL a host process may already have loaded, e.g. torch's), or a host callback over host
+// buffers (lvx_allreduce_fn: MPI, torch.distributed, a test harness).  Identity for a single sequence.
+// ---------------------------------------------------------------------------------------------------------
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi* rccl_api(lvx_ctx* c) {
+  static RcclApi api;
+  if (api.lib) return &api;
+  void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) { fail(c, LVX_E_COMM, std::string("cannot load librccl: ") + dlerror()); return nullptr; }
+  api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+  api.CommInitRank = (decltype(api.CommInitRank))dlsym(lib, "ncclCommInitRank");
+  api.CommDestroy = (decltype(api.CommDestroy))dlsym(lib, "ncclCommDestroy");
+  api.AllReduce = (decltype(api.AllReduce))dlsym(lib, "ncclAllReduce");
+  api.GetErrorString = (decltype(api.GetErrorString))dlsym(lib, "ncclGetErrorString");
+  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce) { fail(c, LVX_E_COMM, "librccl lacks the expected entry points"); return nullptr; }
+  api.lib = lib;
+  return &api;
+}
+#define LVX_COMM_BUF 512   // doubles of the device staging buffer of the reductions (the largest message is 212)
+static bool is_joint(const lvx_ctx* c) { return c->ar_fn != nullptr || c->rccl_comm != nullptr; }
+// in place over all ranks on the DEVICE buffer d_comm[0..n), queued on the context's stream
+static int reduce_device(lvx_ctx* c, int n, int op) {
+  RcclApi* api = rccl_api(c); if (!api) return LVX_E_COMM;
+  double* d = (double*)c->d_comm.p;
+  const ncclResult_t r = api->AllReduce(d, d, (size_t)n, ncclDouble, op == LVX_REDUCE_SUM ? ncclSum : ncclMax, (ncclComm_t)c->rccl_comm, c->stream);
+  c->n_collectives++;
+  if (r != ncclSuccess) return fail(c, LVX_E_COMM, std::string("ncclAllReduce: ") + (api->GetErrorString ? api->GetErrorString(r) : "error"));
+  return LVX_OK;
+}
+// in place over all ranks on a HOST buffer
 static int reduce(lvx_ctx* c, double* buf, int n, int op) {
+  if (c->rccl_comm) {
+    if (n > LVX_COMM_BUF) return fail(c, LVX_E_ARG, "reduction larger than the staging buffer");
+    LVX_HIP(c, hipMemcpyAsync(c->d_comm.p, buf, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    int rc = reduce_device(c, n, op); if (rc) return rc;
+    LVX_HIP(c, hipMemcpyAsync(buf, c->d_comm.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    LVX_HIP(c, hipStreamSynchronize(c->stream));
+    return LVX_OK;
+  }
   if (!c->ar_fn) return LVX_OK;
+  c->n_collectives++;
   if (c->ar_fn(c->ar_user, buf, n, op) != 0) return fail(c, LVX_E_COMM, "all-reduce callback failed");
   return LVX_OK;
+}
+// a rank that failed locally keeps meeting the scheduled collectives with its vote set; at the first collective that carries a vote EVERY rank leaves:
+// the failing rank with its own code, the others with LVX_E_COMM — nobody is left waiting inside a reduction
+static int leave_together(lvx_ctx* c, double votes, int lerr) {
+  if (!(votes > 0.0)) return LVX_OK;
+  return lerr ? lerr : fail(c, LVX_E_COMM, "another rank of the joint solve failed");
 }
 
 static int solver_alloc(lvx_ctx* c, SolveWork& w) {
@@ -610,57 +667,105 @@ static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, 
   return LVX_OK;
 }
 
+// ---- the ONE per-step collective on the device: [S (14 x 14, canonical slots) | rhs (14) | not-PD votes | error votes] ----
+struct SharedMap { int ns, np, nbd; int slot[LVX_N_SHARED]; double lmd[LVX_N_SHARED]; };
+#define LVX_R1_N (LVX_N_SHARED * LVX_N_SHARED + LVX_N_SHARED + 2)
+__global__ void k_pack_shared(const double* S, const double* rhs, SharedMap m, double notpd, double err, double* out) {
+  const int e = threadIdx.x;
+  if (e < LVX_R1_N) out[e] = 0.0;
+  __syncthreads();
+  if (notpd == 0.0 && err == 0.0) {
+    for (int k = e; k < m.ns * m.ns; k += blockDim.x) { const int a = k / m.ns, b = k % m.ns; if (b <= a) out[m.slot[a] * LVX_N_SHARED + m.slot[b]] = S[(size_t)(m.np + a) * m.nbd + m.np + b]; }
+    if (e < m.ns) out[LVX_N_SHARED * LVX_N_SHARED + m.slot[e]] = rhs[m.np + e];
+  }
+  if (e == 0) { out[LVX_R1_N - 2] = notpd; out[LVX_R1_N - 1] = err; }
+}
+// the same ns x ns Cholesky on every rank (identical inputs after the sum); shared damping is added once, here.  buf[LVX_R1_N - 2] > 0 afterwards: not positive definite
+__global__ void k_solve_shared(double* buf, SharedMap m, double inv_radius, double* rhs) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (buf[LVX_R1_N - 2] > 0.0 || buf[LVX_R1_N - 1] > 0.0 || m.ns == 0) return;
+  double A[LVX_N_SHARED][LVX_N_SHARED], y[LVX_N_SHARED];
+  for (int a = 0; a < m.ns; ++a) { for (int b = 0; b <= a; ++b) A[a][b] = buf[m.slot[a] * LVX_N_SHARED + m.slot[b]]; A[a][a] += m.lmd[a] * inv_radius; y[a] = buf[LVX_N_SHARED * LVX_N_SHARED + m.slot[a]]; }
+  for (int k = 0; k < m.ns; ++k) {
+    if (!(A[k][k] > 0.0)) { buf[LVX_R1_N - 2] = 1.0; return; }
+    A[k][k] = sqrt(A[k][k]);
+    for (int r = k + 1; r < m.ns; ++r) A[r][k] /= A[k][k];
+    for (int r = k + 1; r < m.ns; ++r) for (int q = k + 1; q <= r; ++q) A[r][q] -= A[r][k] * A[q][k];
+  }
+  for (int i = 0; i < m.ns; ++i) { double t = y[i]; for (int k = 0; k < i; ++k) t -= A[i][k] * y[k]; y[i] = t / A[i][i]; }
+  for (int i = m.ns - 1; i >= 0; --i) { double t = y[i]; for (int k = i + 1; k < m.ns; ++k) t -= A[k][i] * y[k]; y[i] = t / A[i][i]; }
+  for (int i = 0; i < m.ns; ++i) rhs[m.np + i] = y[i];
+}
+
 // Solve the damped, scaled system for the normal equations of the last evaluation.  Leaves delta (tangent layout) on the device.
-// out[0] = model cost change (of the JOINT problem when an all-reduce hook is set), out[1] = g.delta, out[2] = y^T D^2 y
-static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double* out) {
+// m[0] = g.delta, m[1] = delta^T H delta, m[2] = y^T D^2 y of THIS rank (the caller reduces them together with what else it has to reduce);
+// *notpd: the (joint) system was not positive definite.  lerr: a local error of the caller's that has not met a collective yet.
+// Returns != LVX_OK only when every rank returns (an error vote travelled with the collective) or for a purely local failure of a single sequence.
+static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double m[3], bool* notpd_out, int lerr) {
   hipStream_t st = c->stream;
   const int nb = c->nb, bw = c->bw, nbd = c->nbd, nt = lvx_tangent_size(c), ns = c->ns, np = nbd - ns;
   const double ir = 1.0 / radius;
   ProfScope ps(c, LVX_KERNEL_SOLVE);
   bool bcr_used = false;
-  int rc = solve_local(c, w, radius, false, &bcr_used);
+  m[0] = m[1] = m[2] = 0.0; *notpd_out = false;
+  int rc = lerr ? lerr : solve_local(c, w, radius, false, &bcr_used);
   if (rc == LVX_E_NOTPD && w.use_bcr) {
     // the cyclic-reduction elimination order can lose positive definiteness in floating point on nearly singular systems
     // (huge trust radius at convergence); the sequential band Cholesky is the exact fallback.  Purely local: no collective yet.
     rc = solve_local(c, w, radius, true, &bcr_used);
   }
-  if (rc != LVX_OK && rc != LVX_E_NOTPD) return rc;
   bool notpd = rc == LVX_E_NOTPD;
-  if (c->ar_fn) {
-    // [S (14 x 14, canonical slots) | rhs (14) | not-positive-definite votes]: ONE sum over the ranks
-    double buf[LVX_N_SHARED * LVX_N_SHARED + LVX_N_SHARED + 1] = {0};
-    double hs[LVX_N_SHARED * LVX_N_SHARED], hr[LVX_N_SHARED];
-    if (ns > 0 && !notpd) {
-      LVX_HIP(c, hipMemcpy2DAsync(hs, (size_t)ns * 8, w.S + (size_t)np * nbd + np, (size_t)nbd * 8, (size_t)ns * 8, ns, hipMemcpyDeviceToHost, st));
-      LVX_HIP(c, hipMemcpyAsync(hr, w.rhs + np, (size_t)ns * 8, hipMemcpyDeviceToHost, st));
+  int lrc = (rc != LVX_OK && rc != LVX_E_NOTPD) ? rc : LVX_OK;   // a local failure other than "not positive definite": voted, everybody leaves
+  if (!is_joint(c) && lrc) return lrc;
+  if (is_joint(c)) {
+    SharedMap sm{}; sm.ns = ns; sm.np = np; sm.nbd = nbd;
+    for (int a = 0; a < ns; ++a) { sm.slot[a] = c->sh_slot[a]; sm.lmd[a] = c->sh_lmd[a]; }
+    double* dbuf = (double*)c->d_comm.p;
+    if (c->rccl_comm) {   // pack -> ncclAllReduce -> 14 x 14 solve, all queued on the stream: no host round trip for the collective
+      hipLaunchKernelGGL(k_pack_shared, dim3(1), dim3(256), 0, st, (const double*)w.S, (const double*)w.rhs, sm, notpd ? 1.0 : 0.0, lrc ? 1.0 : 0.0, dbuf);
+      int r2 = reduce_device(c, LVX_R1_N, LVX_REDUCE_SUM); if (r2) return r2;
+      hipLaunchKernelGGL(k_solve_shared, dim3(1), dim3(64), 0, st, dbuf, sm, ir, w.rhs);
+      double votes[2];
+      LVX_HIP(c, hipMemcpyAsync(votes, dbuf + LVX_R1_N - 2, 16, hipMemcpyDeviceToHost, st));
       LVX_HIP(c, hipStreamSynchronize(st));
-      for (int a = 0; a < ns; ++a) {
-        for (int b = 0; b <= a; ++b) buf[c->sh_slot[a] * LVX_N_SHARED + c->sh_slot[b]] = hs[a * ns + b];
-        buf[LVX_N_SHARED * LVX_N_SHARED + c->sh_slot[a]] = hr[a];
+      if ((r2 = leave_together(c, votes[1], lrc))) return r2;
+      notpd = votes[0] > 0.0;
+    } else {   // host callback: stage the block through the host
+      double buf[LVX_R1_N] = {0};
+      double hs[LVX_N_SHARED * LVX_N_SHARED], hr[LVX_N_SHARED];
+      if (ns > 0 && !notpd && !lrc) {
+        LVX_HIP(c, hipMemcpy2DAsync(hs, (size_t)ns * 8, w.S + (size_t)np * nbd + np, (size_t)nbd * 8, (size_t)ns * 8, ns, hipMemcpyDeviceToHost, st));
+        LVX_HIP(c, hipMemcpyAsync(hr, w.rhs + np, (size_t)ns * 8, hipMemcpyDeviceToHost, st));
+        LVX_HIP(c, hipStreamSynchronize(st));
+        for (int a = 0; a < ns; ++a) {
+          for (int b = 0; b <= a; ++b) buf[c->sh_slot[a] * LVX_N_SHARED + c->sh_slot[b]] = hs[a * ns + b];
+          buf[LVX_N_SHARED * LVX_N_SHARED + c->sh_slot[a]] = hr[a];
+        }
       }
-    }
-    buf[LVX_N_SHARED * LVX_N_SHARED + LVX_N_SHARED] = notpd ? 1.0 : 0.0;
-    if ((rc = reduce(c, buf, LVX_N_SHARED * LVX_N_SHARED + LVX_N_SHARED + 1, LVX_REDUCE_SUM))) return rc;
-    if (buf[LVX_N_SHARED * LVX_N_SHARED + LVX_N_SHARED] > 0.0) notpd = true;
-    if (!notpd && ns > 0) {
-      // the same ns x ns Cholesky on every rank (identical inputs): shared damping is added once, here
-      double A[LVX_N_SHARED][LVX_N_SHARED], y[LVX_N_SHARED];
-      for (int a = 0; a < ns; ++a) { for (int b = 0; b <= a; ++b) A[a][b] = buf[c->sh_slot[a] * LVX_N_SHARED + c->sh_slot[b]]; A[a][a] += c->sh_lmd[a] * ir; y[a] = buf[LVX_N_SHARED * LVX_N_SHARED + c->sh_slot[a]]; }
-      for (int k = 0; k < ns && !notpd; ++k) {
-        if (!(A[k][k] > 0.0)) { notpd = true; break; }
-        A[k][k] = std::sqrt(A[k][k]);
-        for (int r = k + 1; r < ns; ++r) A[r][k] /= A[k][k];
-        for (int r = k + 1; r < ns; ++r) for (int q = k + 1; q <= r; ++q) A[r][q] -= A[r][k] * A[q][k];
-      }
-      if (!notpd) {
-        for (int i = 0; i < ns; ++i) { double t = y[i]; for (int k = 0; k < i; ++k) t -= A[i][k] * y[k]; y[i] = t / A[i][i]; }
-        for (int i = ns - 1; i >= 0; --i) { double t = y[i]; for (int k = i + 1; k < ns; ++k) t -= A[k][i] * y[k]; y[i] = t / A[i][i]; }
-        LVX_HIP(c, hipMemcpyAsync(w.rhs + np, y, (size_t)ns * 8, hipMemcpyHostToDevice, st));
-        LVX_HIP(c, hipStreamSynchronize(st));   // y lives on this stack frame
+      buf[LVX_R1_N - 2] = notpd ? 1.0 : 0.0; buf[LVX_R1_N - 1] = lrc ? 1.0 : 0.0;
+      int r2 = reduce(c, buf, LVX_R1_N, LVX_REDUCE_SUM); if (r2) return r2;
+      if ((r2 = leave_together(c, buf[LVX_R1_N - 1], lrc))) return r2;
+      if (buf[LVX_R1_N - 2] > 0.0) notpd = true;
+      if (!notpd && ns > 0) {
+        double A[LVX_N_SHARED][LVX_N_SHARED], y[LVX_N_SHARED];
+        for (int a = 0; a < ns; ++a) { for (int b = 0; b <= a; ++b) A[a][b] = buf[c->sh_slot[a] * LVX_N_SHARED + c->sh_slot[b]]; A[a][a] += c->sh_lmd[a] * ir; y[a] = buf[LVX_N_SHARED * LVX_N_SHARED + c->sh_slot[a]]; }
+        for (int k = 0; k < ns && !notpd; ++k) {
+          if (!(A[k][k] > 0.0)) { notpd = true; break; }
+          A[k][k] = std::sqrt(A[k][k]);
+          for (int r = k + 1; r < ns; ++r) A[r][k] /= A[k][k];
+          for (int r = k + 1; r < ns; ++r) for (int q = k + 1; q <= r; ++q) A[r][q] -= A[r][k] * A[q][k];
+        }
+        if (!notpd) {
+          for (int i = 0; i < ns; ++i) { double t = y[i]; for (int k = 0; k < i; ++k) t -= A[i][k] * y[k]; y[i] = t / A[i][i]; }
+          for (int i = ns - 1; i >= 0; --i) { double t = y[i]; for (int k = i + 1; k < ns; ++k) t -= A[k][i] * y[k]; y[i] = t / A[i][i]; }
+          LVX_HIP(c, hipMemcpyAsync(w.rhs + np, y, (size_t)ns * 8, hipMemcpyHostToDevice, st));
+          LVX_HIP(c, hipStreamSynchronize(st));   // y lives on this stack frame
+        }
       }
     }
   }
-  if (notpd) { if (rc == LVX_OK) fail(c, LVX_E_NOTPD, "joint reduced system not positive definite"); out[0] = out[1] = out[2] = 0.0; return LVX_E_NOTPD; }
+  *notpd_out = notpd;
+  if (notpd) { fail(c, LVX_E_NOTPD, "damped normal equations not positive definite"); return LVX_OK; }
   hipLaunchKernelGGL(k_dense_back, dim3(1), dim3(64), 0, st, (const double*)w.S, w.rhs, nbd, np);
   const int ldz = w.ldz;
   double* Zf = w.Z;
@@ -689,35 +794,59 @@ static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double* ou
   LVX_HIP(c, hipStreamSynchronize(st));
   // model_cost_change = -(g.delta + 1/2 delta^T H delta)   (TrustRegionMinimizer: -model_residuals.(residuals + model_residuals / 2));
   // joint problem: H = sum_r H_r, g = sum_r g_r with delta_r = [private_r | shared]  =>  both terms are sums over the ranks
-  double m[3] = {h[0], h[5], h[1]};
-  if ((rc = reduce(c, m, 3, LVX_REDUCE_SUM))) return rc;
-  out[0] = -m[0] - 0.5 * m[1]; out[1] = m[0]; out[2] = m[2];
+  m[0] = h[0]; m[1] = h[5]; m[2] = h[1];
   return LVX_OK;
 }
 
-static int prepare_diag(lvx_ctx* c, SolveWork& w, bool compute_scale, int use_scaling, double mn, double mx) {
-  const int n = c->nb + c->nbd;
+// max |g| over this rank's private free scalars (band, private border, landmarks) -> *g; the shared entries of g_c -> gsh[ns]
+static int local_gmax(lvx_ctx* c, SolveWork& w, double* g, double* gsh) {
   hipStream_t st = c->stream;
-  hipLaunchKernelGGL(k_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)c->d_C.p, c->nb, c->bw, c->nbd, c->nbd_ext, w.diag);
+  LVX_HIP(c, hipMemsetAsync(w.sums + 4, 0, 8, st));
+  const int n = c->nb + c->nbd - c->ns;
+  hipLaunchKernelGGL(k_gmax, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)c->d_gb.p, (const double*)c->d_gc.p, c->nb, c->nbd - c->ns, w.sums);
+  if (w.lm) hipLaunchKernelGGL(k_gmax_lm, dim3((unsigned)((c->L + 255) / 256)), dim3(256), 0, st, (const double*)c->d_lmH.p, c->L, c->lm_ls, c->lm_wl + c->nbd_ext + 1, w.sums);
+  LVX_HIP(c, hipMemcpyAsync(g, w.sums + 4, 8, hipMemcpyDeviceToHost, st));
+  if (c->ns > 0) LVX_HIP(c, hipMemcpyAsync(gsh, (const double*)c->d_gc.p + (c->nbd - c->ns), (size_t)c->ns * 8, hipMemcpyDeviceToHost, st));
+  return LVX_OK;
+}
+// Everything that follows a LVX_EVAL_NORMAL_EQ evaluation: the diagonal (Jacobi scaling at the first iterate, LM damping), the gradient max norm, and —
+// joint solve — what has to agree on every rank: cost, the shared part of the diagonal and of the gradient in ONE sum [cost | diag (14) | g (14) | error
+// votes], the private gradient max norm in one max.  lerr: error of the evaluation that has not met a collective yet.
+static int post_eval(lvx_ctx* c, SolveWork& w, bool compute_scale, int use_scaling, double mn, double mx, double* cost, double* gmax, int lerr) {
+  const int n = c->nb + c->nbd, ns = c->ns;
+  hipStream_t st = c->stream;
   const int nl = w.lm ? c->L : 0;   // landmark diagonal behind the band / border entries
-  if (nl > 0) hipLaunchKernelGGL(k_lm_fetch_diag, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, (const double*)c->d_lmH.p, nl, c->lm_ls, c->lm_wl + c->nbd_ext, w.diag + n);
-  const int ns = c->ns;
   double* dsh = w.diag + (n - ns);
-  if (c->ar_fn) {   // diagonal of the JOINT normal equations at the shared scalars: Jacobi scaling and LM damping must agree on every rank
-    double buf[LVX_N_SHARED] = {0}, h[LVX_N_SHARED];
-    if (ns > 0) { LVX_HIP(c, hipMemcpyAsync(h, dsh, (size_t)ns * 8, hipMemcpyDeviceToHost, st)); LVX_HIP(c, hipStreamSynchronize(st)); }
-    for (int i = 0; i < ns; ++i) buf[c->sh_slot[i]] = h[i];
-    int rc = reduce(c, buf, LVX_N_SHARED, LVX_REDUCE_SUM); if (rc) return rc;
-    for (int i = 0; i < ns; ++i) h[i] = buf[c->sh_slot[i]];
-    if (ns > 0) { LVX_HIP(c, hipMemcpyAsync(dsh, h, (size_t)ns * 8, hipMemcpyHostToDevice, st)); LVX_HIP(c, hipStreamSynchronize(st)); }
+  double hd[LVX_N_SHARED] = {0}, hg[LVX_N_SHARED] = {0}, gm = 0.0;
+  if (!lerr) {
+    hipLaunchKernelGGL(k_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)c->d_C.p, c->nb, c->bw, c->nbd, c->nbd_ext, w.diag);
+    if (nl > 0) hipLaunchKernelGGL(k_lm_fetch_diag, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, (const double*)c->d_lmH.p, nl, c->lm_ls, c->lm_wl + c->nbd_ext, w.diag + n);
+    int rc = local_gmax(c, w, &gm, hg); if (rc) return rc;
+    if (is_joint(c) && ns > 0) LVX_HIP(c, hipMemcpyAsync(hd, dsh, (size_t)ns * 8, hipMemcpyDeviceToHost, st));
+    LVX_HIP(c, hipStreamSynchronize(st));
   }
+  if (is_joint(c)) {
+    double buf[2 * LVX_N_SHARED + 2] = {0};
+    if (!lerr) { buf[0] = *cost; for (int i = 0; i < ns; ++i) { buf[1 + c->sh_slot[i]] = hd[i]; buf[1 + LVX_N_SHARED + c->sh_slot[i]] = hg[i]; } }
+    buf[2 * LVX_N_SHARED + 1] = lerr ? 1.0 : 0.0;
+    int rc = reduce(c, buf, 2 * LVX_N_SHARED + 2, LVX_REDUCE_SUM); if (rc) return rc;
+    if ((rc = reduce(c, &gm, 1, LVX_REDUCE_MAX))) return rc;
+    if ((rc = leave_together(c, buf[2 * LVX_N_SHARED + 1], lerr))) return rc;
+    *cost = buf[0];
+    for (int i = 0; i < ns; ++i) { hd[i] = buf[1 + c->sh_slot[i]]; gm = std::max(gm, std::fabs(buf[1 + LVX_N_SHARED + c->sh_slot[i]])); }
+    if (ns > 0) LVX_HIP(c, hipMemcpyAsync(dsh, hd, (size_t)ns * 8, hipMemcpyHostToDevice, st));   // Jacobi scaling and LM damping use the JOINT diagonal at the shared scalars
+  } else {
+    if (lerr) return lerr;
+    for (int i = 0; i < ns; ++i) gm = std::max(gm, std::fabs(hg[i]));
+  }
+  *gmax = gm;
   if (compute_scale) hipLaunchKernelGGL(k_scale_from_diag, dim3((unsigned)((n + nl + 255) / 256)), dim3(256), 0, st, (const double*)w.diag, n + nl, w.scale, use_scaling);
   hipLaunchKernelGGL(k_lm_diag, dim3((unsigned)((n + nl + 255) / 256)), dim3(256), 0, st, (const double*)w.diag, (const double*)w.scale, n + nl, mn, mx, w.lmd);
-  if (c->ar_fn && ns > 0) {   // shared damping is applied once to the reduced system (solve_step_device), not per rank
+  if (is_joint(c) && ns > 0) {   // shared damping is applied once to the reduced system (solve_step_device), not per rank
     LVX_HIP(c, hipMemcpyAsync(c->sh_lmd, w.lmd + (n - ns), (size_t)ns * 8, hipMemcpyDeviceToHost, st));
-    LVX_HIP(c, hipStreamSynchronize(st));
+    LVX_HIP(c, hipStreamSynchronize(st));   // (also keeps hd alive until the copy above has read it)
     LVX_HIP(c, hipMemsetAsync(w.lmd + (n - ns), 0, (size_t)ns * 8, st));
-  }
+  } else if (is_joint(c)) LVX_HIP(c, hipStreamSynchronize(st));
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
 }
@@ -742,19 +871,18 @@ int lvx_solve_step_shared(lvx_ctx* c, double radius, int jacobi_scaling, lvx_all
   if (!c || !(radius > 0)) return LVX_E_ARG;
   if (!(c->last_what & LVX_EVAL_NORMAL_EQ)) return fail(c, LVX_E_STATE, "lvx_solve_step needs a preceding LVX_EVAL_NORMAL_EQ evaluation");
   LVX_HIP(c, hipSetDevice(c->device));
-  int rc = check_last_eval(c);   // an evaluation queued without a cost pointer has not had its device error word read yet
+  int lerr = check_last_eval(c);   // an evaluation queued without a cost pointer has not had its device error word read yet
   HookScope hook(c, fn, user);
-  if (fn) {   // joint solve: every rank must leave together
-    double e = rc ? 1.0 : 0.0;
-    if (fn(user, &e, 1, LVX_REDUCE_MAX) != 0) return fail(c, LVX_E_COMM, "all-reduce callback failed");
-    if (e != 0.0 && !rc) return fail(c, LVX_E_COMM, "another rank's evaluation failed");
-  }
-  if (rc) return rc;
-  SolveWork w; if ((rc = solver_alloc(c, w))) return rc;
-  if ((rc = prepare_diag(c, w, true, jacobi_scaling, 1e-6, 1e32))) return rc;
-  double out[3];
-  if ((rc = solve_step_device(c, w, radius, out))) return rc;
-  if (model_cost_change) *model_cost_change = out[0];
+  SolveWork w;
+  if (!lerr) lerr = solver_alloc(c, w);
+  if (lerr && !is_joint(c)) return lerr;
+  double cost = 0, gm = 0;
+  int rc = post_eval(c, w, true, jacobi_scaling, 1e-6, 1e32, &cost, &gm, lerr); if (rc) return rc;
+  double m[3]; bool notpd = false;
+  if ((rc = solve_step_device(c, w, radius, m, &notpd, LVX_OK))) return rc;
+  if ((rc = reduce(c, m, 3, LVX_REDUCE_SUM))) return rc;
+  if (notpd) return LVX_E_NOTPD;
+  if (model_cost_change) *model_cost_change = -m[0] - 0.5 * m[1];
   if (delta) LVX_HIP(c, hipMemcpy(delta, w.delta, (size_t)lvx_tangent_size(c) * 8, hipMemcpyDeviceToHost));
   return LVX_OK;
 }
@@ -762,106 +890,93 @@ int lvx_solve_step(lvx_ctx* c, double radius, int jacobi_scaling, double* delta,
   return lvx_solve_step_shared(c, radius, jacobi_scaling, nullptr, nullptr, delta, model_cost_change);
 }
 
+// Collectives of the joint loop per iteration: R1 [S | rhs | votes] inside solve_step_device, R2 [g.delta, delta^T H delta, y^T D^2 y, candidate cost,
+// step norm^2, x norm^2, error votes] after the candidate evaluation, and after an ACCEPTED step the two of post_eval.  (R1 and R2 cannot merge: the
+// candidate is a function of the reduced system's solution.)
 int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in, lvx_allreduce_fn fn, void* user, lvx_lm_summary* sum) {
   if (!c || !state) return LVX_E_ARG;
   lvx_lm_options o; lvx_lm_default_options(&o); if (opt_in) o = *opt_in;
   LVX_HIP(c, hipSetDevice(c->device));
-  int rc = ensure_layout(c); if (rc) return rc;
   HookScope hook(c, fn, user);
-  SolveWork w; if ((rc = solver_alloc(c, w))) return rc;
+  const bool joint = is_joint(c);
+  int rc;
+  int lerr = ensure_layout(c);
+  SolveWork w;
+  if (!lerr) lerr = solver_alloc(c, w);
+  if (lerr && !joint) return lerr;
   hipStream_t st = c->stream;
   const size_t sbytes = (size_t)lvx_state_size(c) * 8;
   double* x = (double*)c->d_state.p;
   double* xt = (double*)c->d_state_try.p;
-  LVX_HIP(c, hipMemcpyAsync(x, state, sbytes, hipMemcpyHostToDevice, st));
   c->lm_cost.clear(); c->lm_radius.clear(); c->lm_accept.clear();
   lvx_lm_summary s{}; s.termination = LVX_LM_NO_CONVERGENCE;
-  const bool joint = fn != nullptr;
-  // cost of the joint problem = sum of the sequences' costs; a rank whose candidate cannot be evaluated contributes +inf
-  auto joint_cost = [&](double* v) -> int { return reduce(c, v, 1, LVX_REDUCE_SUM); };
-  double cost = 0;
-  if ((rc = lvx_evaluate_d(c, x, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &cost))) return rc;
-  if ((rc = joint_cost(&cost))) return rc;
+  double cost = 0, g0 = 0;
+  if (!lerr) { LVX_HIP(c, hipMemcpyAsync(x, state, sbytes, hipMemcpyHostToDevice, st)); lerr = lvx_evaluate_d(c, x, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &cost); }
+  if ((rc = post_eval(c, w, true, o.jacobi_scaling, o.min_lm_diagonal, o.max_lm_diagonal, &cost, &g0, lerr))) return rc;
   s.initial_cost = cost;
-  if ((rc = prepare_diag(c, w, true, o.jacobi_scaling, o.min_lm_diagonal, o.max_lm_diagonal))) return rc;
   double radius = o.initial_radius, decrease_factor = 2.0;
-  bool reuse_diagonal = false;
   int invalid = 0;
   const int N = c->N, L = c->L;
-  // max |g| over the free scalars; joint problem: the shared entries of g are sums over the ranks
-  auto gmax = [&](double* g) -> int {
-    LVX_HIP(c, hipMemsetAsync(w.sums + 4, 0, 8, st));
-    const int n = c->nb + c->nbd - c->ns;
-    hipLaunchKernelGGL(k_gmax, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)c->d_gb.p, (const double*)c->d_gc.p, c->nb, c->nbd - c->ns, w.sums);
-    if (w.lm) hipLaunchKernelGGL(k_gmax_lm, dim3((unsigned)((c->L + 255) / 256)), dim3(256), 0, st, (const double*)c->d_lmH.p, c->L, c->lm_ls, c->lm_wl + c->nbd_ext + 1, w.sums);
-    double gs[LVX_N_SHARED] = {0}, hsh[LVX_N_SHARED];
-    LVX_HIP(c, hipMemcpyAsync(g, w.sums + 4, 8, hipMemcpyDeviceToHost, st));
-    if (c->ns > 0) LVX_HIP(c, hipMemcpyAsync(hsh, (const double*)c->d_gc.p + (c->nbd - c->ns), (size_t)c->ns * 8, hipMemcpyDeviceToHost, st));
-    LVX_HIP(c, hipStreamSynchronize(st));
-    if (joint) {
-      int r2;
-      for (int i = 0; i < c->ns; ++i) gs[c->sh_slot[i]] = hsh[i];
-      if ((r2 = reduce(c, gs, LVX_N_SHARED, LVX_REDUCE_SUM))) return r2;
-      if ((r2 = reduce(c, g, 1, LVX_REDUCE_MAX))) return r2;
-      for (int k = 0; k < LVX_N_SHARED; ++k) *g = std::max(*g, std::fabs(gs[k]));
-    }
-    return LVX_OK;
-  };
-  double g0 = 0; if ((rc = gmax(&g0))) return rc;
   if (g0 <= o.gradient_tolerance) { s.termination = LVX_LM_GRADIENT_TOLERANCE; }
   int it = 0;
   while (s.termination == LVX_LM_NO_CONVERGENCE) {
     if (it >= o.max_iterations) { s.termination = LVX_LM_MAX_ITERATIONS; break; }
     ++it;
-    if (!reuse_diagonal) { if ((rc = prepare_diag(c, w, false, o.jacobi_scaling, o.min_lm_diagonal, o.max_lm_diagonal))) return rc; }
-    double out[3];
-    rc = solve_step_device(c, w, radius, out);
-    bool step_valid = (rc == LVX_OK) && std::isfinite(out[0]) && out[0] > 0.0;
-    if (rc != LVX_OK && rc != LVX_E_NOTPD) return rc;
-    if (!step_valid && o.verbose) fprintf(stderr, "[lvx lm] it %3d invalid step: rc %d (%s) model_cost_change %.6e g.delta %.6e\n", it, rc, c->last_error.c_str(), out[0], out[1]);
+    double m[3]; bool notpd = false;
+    if ((rc = solve_step_device(c, w, radius, m, &notpd, LVX_OK))) return rc;
+    // candidate x (+) delta and its cost; the cost-only evaluation does not touch the normal equations of x
+    double r2[7] = {m[0], m[1], m[2], 0, 0, 0, 0}, h[6] = {0, 0, 0, 0, 0, 0};
+    lerr = LVX_OK;
+    if (!notpd) {
+      LVX_HIP(c, hipMemsetAsync(w.sums + 2, 0, 48, st));
+      hipLaunchKernelGGL(k_plus, dim3((unsigned)((N + 1 + L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, N, L, c->locks, xt, w.sums, joint ? 1 : 0, c->sensor_mto);
+      double cand = 0;
+      const int re = lvx_evaluate_d(c, xt, LVX_EVAL_COST, &cand);
+      if (re == LVX_E_RANGE || re == LVX_E_NONUNIT_QUAT) cand = INFINITY; else if (re) lerr = re;   // a candidate that cannot be evaluated is a rejected step, anything else an error
+      c->last_what |= LVX_EVAL_NORMAL_EQ;
+      if (!lerr && hipMemcpy(h, w.sums + 2, 48, hipMemcpyDeviceToHost) != hipSuccess) lerr = LVX_E_HIP;
+      r2[3] = cand; r2[4] = h[0]; r2[5] = h[1];
+    }
+    if (joint) {   // private blocks summed over the ranks; the shared blocks (identical on every rank) are counted once below
+      r2[6] = lerr ? 1.0 : 0.0;
+      if (lerr) { r2[0] = r2[1] = r2[2] = r2[3] = r2[4] = r2[5] = 0.0; }
+      if ((rc = reduce(c, r2, 7, LVX_REDUCE_SUM))) return rc;
+      if ((rc = leave_together(c, r2[6], lerr))) return rc;
+      r2[4] += h[4]; r2[5] += h[5];
+    } else if (lerr) return lerr;
+    const double model = -r2[0] - 0.5 * r2[1], cand = r2[3];
+    const bool step_valid = !notpd && std::isfinite(model) && model > 0.0;
+    if (!step_valid && o.verbose) fprintf(stderr, "[lvx lm] it %3d invalid step: %s model_cost_change %.6e g.delta %.6e\n", it, notpd ? "not positive definite" : "model", model, r2[0]);
     if (!step_valid) {   // TrustRegionMinimizer::HandleInvalidStep + LevenbergMarquardtStrategy::StepIsInvalid
-      if (++invalid > 5) { s.termination = LVX_LM_FAILURE; break; }
-      radius *= 0.5; reuse_diagonal = true;
+      if (++invalid >= 5) { s.termination = LVX_LM_FAILURE; break; }   // max_num_consecutive_invalid_steps = 5
+      radius *= 0.5;
       c->lm_cost.push_back(cost); c->lm_radius.push_back(radius); c->lm_accept.push_back(-1);
       continue;
     }
     invalid = 0;
-    LVX_HIP(c, hipMemsetAsync(w.sums + 2, 0, 48, st));
-    hipLaunchKernelGGL(k_plus, dim3((unsigned)((N + 1 + L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, N, L, c->locks, xt, w.sums, joint ? 1 : 0, c->sensor_mto);
-    double cand = 0;
-    // cost-only evaluation of the candidate must not clobber the normal equations of x: LVX_EVAL_COST alone leaves them untouched
-    if ((rc = lvx_evaluate_d(c, xt, LVX_EVAL_COST, &cand))) { if (rc == LVX_E_RANGE || rc == LVX_E_NONUNIT_QUAT) cand = INFINITY; else return rc; }
-    c->last_what |= LVX_EVAL_NORMAL_EQ;
-    if ((rc = joint_cost(&cand))) return rc;
-    double h[6];
-    LVX_HIP(c, hipMemcpy(h, w.sums + 2, 48, hipMemcpyDeviceToHost));
-    if (joint) {   // private blocks summed over the ranks, the shared blocks (identical on every rank) counted once
-      double pn[2] = {h[0], h[1]};
-      if ((rc = reduce(c, pn, 2, LVX_REDUCE_SUM))) return rc;
-      h[0] = pn[0] + h[4]; h[1] = pn[1] + h[5];
-    }
-    const double step_norm = std::sqrt(h[0]), x_norm = std::sqrt(h[1]);
+    const double step_norm = std::sqrt(r2[4]), x_norm = std::sqrt(r2[5]);
     if (step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) { s.termination = LVX_LM_PARAMETER_TOLERANCE; c->lm_cost.push_back(cost); c->lm_radius.push_back(radius); c->lm_accept.push_back(0); break; }
     const double cost_change = cost - cand;
     if (std::fabs(cost_change) <= o.function_tolerance * cost) {
       // FunctionToleranceReached is tested before the step is accepted or rejected and returns without applying it (trust_region_minimizer.cc)
       s.termination = LVX_LM_FUNCTION_TOLERANCE; c->lm_cost.push_back(cost); c->lm_radius.push_back(radius); c->lm_accept.push_back(0); break;
     }
-    const double rho = cost_change / out[0];
+    const double rho = cost_change / model;
     if (rho > o.min_relative_decrease) {
       std::swap(c->d_state.p, c->d_state_try.p); x = (double*)c->d_state.p; xt = (double*)c->d_state_try.p;
       cost = cand; s.successful_steps++;
-      double c2 = 0;
-      if ((rc = lvx_evaluate_d(c, x, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &c2))) return rc;
+      double c2 = 0, g = 0;
+      lerr = lvx_evaluate_d(c, x, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &c2);
+      double cj = cost;
+      if ((rc = post_eval(c, w, false, o.jacobi_scaling, o.min_lm_diagonal, o.max_lm_diagonal, joint ? &c2 : &cj, &g, lerr))) return rc;
       radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3));   // LevenbergMarquardtStrategy::StepAccepted
-      radius = std::min(o.max_radius, radius); decrease_factor = 2.0; reuse_diagonal = false;
+      radius = std::min(o.max_radius, radius); decrease_factor = 2.0;
       c->lm_cost.push_back(cost); c->lm_radius.push_back(radius); c->lm_accept.push_back(1);
-      double g = 0; if ((rc = gmax(&g))) return rc;
       if (g <= o.gradient_tolerance) { s.termination = LVX_LM_GRADIENT_TOLERANCE; break; }
     } else {
-      radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;      // StepRejected
+      radius = radius / decrease_factor; decrease_factor *= 2.0;      // StepRejected (the LM diagonal of x is reused)
       c->lm_cost.push_back(cost); c->lm_radius.push_back(radius); c->lm_accept.push_back(0);
-      if (radius < o.min_radius) { s.termination = LVX_LM_FAILURE; break; }
+      if (radius < o.min_radius) { s.termination = LVX_LM_MIN_RADIUS; break; }   // Ceres: CONVERGENCE, "minimum trust region radius reached"
     }
     if (o.verbose) fprintf(stderr, "[lvx lm] it %3d cost %.9e radius %.3e rho %.3f\n", it, cost, radius, rho);
   }
@@ -881,5 +996,35 @@ int lvx_lm_get_history(lvx_ctx* c, int max_n, double* cost, double* radius, int3
   for (int i = 0; i < n; ++i) { if (cost) cost[i] = c->lm_cost[i]; if (radius) radius[i] = c->lm_radius[i]; if (accepted) accepted[i] = c->lm_accept[i]; }
   return n;
 }
+
+// ---- RCCL transport of the joint solve ----
+int lvx_rccl_unique_id(lvx_ctx* c, void* id128) {
+  if (!c || !id128) return LVX_E_ARG;
+  RcclApi* api = rccl_api(c); if (!api) return LVX_E_COMM;
+  ncclUniqueId id;
+  if (api->GetUniqueId(&id) != ncclSuccess) return fail(c, LVX_E_COMM, "ncclGetUniqueId failed");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  std::memcpy(id128, &id, 128);
+  return LVX_OK;
+}
+int lvx_rccl_init(lvx_ctx* c, const void* id128, int rank, int world) {
+  if (!c || !id128 || rank < 0 || world < 1 || rank >= world) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  RcclApi* api = rccl_api(c); if (!api) return LVX_E_COMM;
+  if (c->rccl_comm) { api->CommDestroy((ncclComm_t)c->rccl_comm); c->rccl_comm = nullptr; }
+  ncclUniqueId id; std::memcpy(&id, id128, 128);
+  ncclComm_t comm = nullptr;
+  const ncclResult_t r = api->CommInitRank(&comm, world, id, rank);
+  if (r != ncclSuccess) return fail(c, LVX_E_COMM, std::string("ncclCommInitRank: ") + (api->GetErrorString ? api->GetErrorString(r) : "error"));
+  int rc = dev_alloc(c, c->d_comm, LVX_COMM_BUF * 8); if (rc) { api->CommDestroy(comm); return rc; }
+  c->rccl_comm = comm; c->comm_rank = rank; c->comm_world = world;
+  return LVX_OK;
+}
+int lvx_rccl_finalize(lvx_ctx* c) {
+  if (!c) return LVX_E_ARG;
+  if (c->rccl_comm) { RcclApi* api = rccl_api(c); if (api) api->CommDestroy((ncclComm_t)c->rccl_comm); c->rccl_comm = nullptr; }
+  return LVX_OK;
+}
+int64_t lvx_collective_count(lvx_ctx* c, int reset) { if (!c) return 0; const int64_t n = c->n_collectives; if (reset) c->n_collectives = 0; return n; }
 
 }  // extern "C"

@@ -56,7 +56,7 @@ class LmSummary(C.Structure):
                 ("initial_cost", C.c_double), ("final_cost", C.c_double), ("final_radius", C.c_double)]
 
 
-LM_TERMINATION = ["no_convergence", "function_tolerance", "parameter_tolerance", "gradient_tolerance", "max_iterations", "failure"]
+LM_TERMINATION = ["no_convergence", "function_tolerance", "parameter_tolerance", "gradient_tolerance", "max_iterations", "failure", "min_trust_region_radius"]
 
 
 class LvxError(RuntimeError):
@@ -290,7 +290,8 @@ class Context:
         return delta, mcc.value
 
     def lm_solve_shared(self, state, allreduce, max_iterations=50, **kw):
-        """LM on the JOINT problem of all ranks' sequences; every rank calls this with its own sequence loaded and the same options."""
+        """LM on the JOINT problem of all ranks' sequences; every rank calls this with its own sequence loaded and the same options.
+        allreduce = None: the RCCL communicator installed with rccl_init carries the reductions."""
         opt = LmOptions()
         self._l.lvx_lm_default_options(C.byref(opt))
         opt.max_iterations = max_iterations
@@ -298,7 +299,7 @@ class Context:
             setattr(opt, k, v)
         x = _d(state).copy()
         sm = LmSummary()
-        cb = self._hook(allreduce)
+        cb = self._hook(allreduce) if allreduce is not None else None
         self._ck(self._l.lvx_lm_solve_shared(self._h, _p(x), C.byref(opt), cb, None, C.byref(sm)))
         n = 4 * max_iterations + 8
         cost, rad, acc = np.zeros(n), np.zeros(n), np.zeros(n, dtype=np.int32)
@@ -307,6 +308,23 @@ class Context:
         out["termination"] = LM_TERMINATION[sm.termination]
         out.update(cost_history=cost[:k], radius_history=rad[:k], accepted=acc[:k])
         return x, out
+
+    # ---- RCCL transport of the joint solve (the reductions run as ncclAllReduce on the context's stream) ----
+    def rccl_unique_id(self):
+        buf = (C.c_char * 128)()
+        self._ck(self._l.lvx_rccl_unique_id(self._h, buf))
+        return bytes(buf)
+
+    def rccl_init(self, unique_id, rank, world):
+        buf = (C.c_char * 128).from_buffer_copy(unique_id)
+        self._ck(self._l.lvx_rccl_init(self._h, buf, C.c_int(rank), C.c_int(world)))
+
+    def rccl_finalize(self):
+        self._ck(self._l.lvx_rccl_finalize(self._h))
+
+    def collective_count(self, reset=False):
+        self._l.lvx_collective_count.restype = C.c_int64
+        return int(self._l.lvx_collective_count(self._h, C.c_int(1 if reset else 0)))
 
     def plus(self, state, delta):
         state, delta = _d(state), _d(delta)

@@ -78,7 +78,7 @@ def lm_solve(oracle, state, free, max_iterations=50, initial_radius=1e4, max_rad
             ok = False
         if not ok:
             invalid += 1
-            if invalid > 5:
+            if invalid >= 5:          # max_num_consecutive_invalid_steps = 5
                 term = "failure"
                 break
             radius *= 0.5
@@ -118,7 +118,7 @@ def lm_solve(oracle, state, free, max_iterations=50, initial_radius=1e4, max_rad
             dec *= 2.0
             hist["cost"].append(cost); hist["radius"].append(radius); hist["accepted"].append(0)
             if radius < min_radius:
-                term = "failure"
+                term = "min_trust_region_radius"      # Ceres: CONVERGENCE, "minimum trust region radius reached"
                 break
     return x, dict(termination=term, iterations=it, initial_cost=init_cost, final_cost=cost,
                    cost_history=np.array(hist["cost"]), radius_history=np.array(hist["radius"]), accepted=np.array(hist["accepted"]))

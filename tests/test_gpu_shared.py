@@ -153,3 +153,50 @@ def test_shared_lm_matches_joint_oracle_lm():
         assert 2 * np.arctan2(np.linalg.norm(d[:3]), abs(d[3])) <= 1e-6
         assert np.abs(e[0][off + 4:off + 7] - eo[off + 4:off + 7]).max() <= 1e-4
     assert res[0][1]["final_cost"] < 1e-2 * res[0][1]["initial_cost"]
+
+
+def test_collectives_per_iteration_and_failure_leaves_together():
+    """The joint loop's schedule: two reductions after the first evaluation, two per iteration (step block, decision), two more per accepted step — and
+    a rank whose evaluation fails (a measurement outside its spline) makes EVERY rank return instead of leaving the other inside a reduction."""
+    seqs = _sequences()
+
+    def body(r, g, allreduce):
+        g.collective_count(reset=True)
+        x, s = g.lm_solve_shared(seqs[r][1], allreduce, max_iterations=6)
+        return s, g.collective_count()
+    res = _run_ranks(seqs, body)
+    for s, n in res:
+        acc = int(np.sum(np.asarray(s["accepted"]) == 1))
+        assert n == 2 + 2 * s["iterations"] + 2 * acc
+    # rank 1's sequence has an IMU sample beyond the spline: its evaluation returns LVX_E_RANGE; rank 0 must come back with LVX_E_COMM
+    P1 = dict(seqs[1][0]); P1["t_imu"] = P1["t_imu"].copy(); P1["t_imu"][-1] = P1["t0"] + (P1["n_knots"] - 3) * P1["dt"] + 0.5
+    bad = [seqs[0], (P1, seqs[1][1])]
+    codes = [None, None]
+
+    def body2(r, g, allreduce):
+        try:
+            g.lm_solve_shared(bad[r][1], allreduce, max_iterations=3)
+        except lvx.LvxError as e:
+            codes[r] = e.code
+        return None
+    _run_ranks(bad, body2)
+    assert codes == [lvx.E_RCCL, lvx.E_RANGE]
+
+
+def test_rccl_transport_single_rank_equals_plain_solve():
+    """The RCCL transport (ncclAllReduce on the context's stream; step block packed, reduced and solved on the device) with a world of one rank — all this
+    box has — must reproduce the single-sequence solve; the multi-rank protocol is the one the callback transport tests above."""
+    P, x0 = _sequences()[0]
+    g = lvx.Context(0)
+    lvx.load_problem(g, P, TAU)
+    xa, sa = g.lm_solve(x0, max_iterations=8)
+    g.rccl_init(g.rccl_unique_id(), 0, 1)
+    g.collective_count(reset=True)
+    xb, sb = g.lm_solve_shared(x0, None, max_iterations=8)
+    assert g.collective_count() == 2 + 2 * sb["iterations"] + 2 * int(np.sum(np.asarray(sb["accepted"]) == 1))
+    g.rccl_finalize()
+    assert sa["iterations"] == sb["iterations"] and list(sa["accepted"]) == list(sb["accepted"]) and sa["termination"] == sb["termination"]
+    assert np.abs(sa["cost_history"] - sb["cost_history"]).max() <= 1e-9 * sa["cost_history"].max()
+    N = P["n_knots"]
+    assert np.abs(xa[7 * N:7 * N + 32] - xb[7 * N:7 * N + 32]).max() <= 1e-7
+    g.close()
