@@ -29,6 +29,7 @@ struct DevCommon {
   const int* ord;
   int nb, bw, nbd;   // nbd: assembly border size (solve border + pseudo rows) = leading dimension of C
   int nbd_solve;
+  int hub_lo, hub_hi;   // band positions [hub_lo, hub_hi) of the hub rows of Bd are cleared per pass and accumulated; outside, the fold STORES (see k_clear's HubClear)
   const void* hubs;  // HubShared[2]: surfel (tau_L) and cam-surfel (tau_C) poses at t_map
   const So3Pre* pre; // [N]: u-independent SO3 quantities of the control-point pairs (k, k+1), rebuilt from the state at the start of every pass (k_state_prepass)
   double* Hb;    // [nb][bw+1] lower band, column-major by column
@@ -106,6 +107,7 @@ struct lvx_ctx {
   lvx::DevBuf d_pre;   // So3Pre[N]
   lvx::DevBuf d_repT;   // [rep.n][56] landmark-row records of the reprojection blocks (k_reproj_cross -> k_reproj_lmrows)
   lvx::DevBuf d_lmH, d_lm_p0, d_Hr, d_Br, d_red; int lm_wl = 0, lm_ls = 0; const double* p_Hs = nullptr;   // landmark rows (DevCommon::lmH); solver: band / border rows / [g_b | C | g_c] after the landmark elimination
+  int hub_near_lo = 0, hub_near_hi = 0;   // band positions a residual can couple to a hub knot DIRECTLY (not through the pseudo pose): IMU / LiDAR rows within 4 knots, reprojection blocks within their span
   lvx::DevBuf d_colfull; int clear_npre = 0; std::vector<uint8_t> bd_row_live;   // structural clear of the band / border rows (k_clear)
   lvx::DevBuf d_hubs, d_chunk[LVX_NUM_FAM], d_repB[4];   // reprojection MFMA path: [0] materialised Jacobians + residuals, [1] knot intervals, [2] landmark and [3] observation-order index of the rows in (reference interval, landmark) order
   int chunk_var[LVX_NUM_FAM] = {0};   // != 0: chunks of equal ROW count (first interval of chunk c at d_chunk[n_chunk + 1 + c]) instead of equal interval count

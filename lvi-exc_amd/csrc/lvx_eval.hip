@@ -375,7 +375,8 @@ struct Aux { int wid, xk, lm; const PreWin* pw; };   // pw: the workgroup's prec
 // traits: NK knot columns (4 knots x KPK, at offset LVO of the knot's 6 tangent scalars) | NG global columns; WS knot intervals per MFMA window; GL lanes per panel;
 // SKIP_GG: global x global and the global gradient are assembled by another pass; SECONDARY: no cost / residual output
 struct GyroAcc {
-  enum { NK = 12, NG = 3, NR = 3, HUB = -1, KPK = 3, LVO = 3, WS = 1, GL = 8, SKIP_GG = 0, SECONDARY = 0, LB = 64, NCP = 15, USE_PRE = 1, OCC = 1 };
+  enum { PMAJ = 1 };
+  enum { NK = 12, NG = 3, NR = 3, HUB = -1, KPK = 3, LVO = 3, WS = 1, GL = 32, SKIP_GG = 0, SECONDARY = 0, LB = 64, NCP = 15, USE_PRE = 1, OCC = 1 };
   __device__ static constexpr int jm(int c) { return c; }   // KPK columns per knot at offset LVO of its 6 tangent scalars; WS = knot intervals per MFMA window; GL = lanes per panel
   int n; const double* t; const double* m3; const int* perm; double weight, huber;
   __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared*, int si, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
@@ -385,7 +386,8 @@ struct GyroAcc {
   __device__ static int gcol(int g, int N, int nt) { return 6 * N + 5 + g; }
 };
 struct AccelAcc {
-  enum { NK = 24, NG = 5, NR = 3, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 8, SKIP_GG = 0, SECONDARY = 0, LB = 64, NCP = 29, USE_PRE = 1, OCC = 1 };
+  enum { PMAJ = 1 };
+  enum { NK = 24, NG = 5, NR = 3, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 16, SKIP_GG = 0, SECONDARY = 0, LB = 64, NCP = 29, USE_PRE = 1, OCC = 1 };
   __device__ static constexpr int jm(int c) { return c; }
   int n; const double* t; const double* m3; const int* perm; double weight, huber;
   __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared*, int si, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
@@ -477,7 +479,8 @@ struct CamSurfAcc {
 // per block, bound by the atomic rate: a CU retires one FP64 atomic lane every ~3.75 cycles, tools/probes/atomic_bw.hip).
 struct RepJac { const double* J; const double* r; const int* k; int n; };   // k_reproj_jac output: J[(a * REP_NC + c) * n + i], r[a * n + i], k[i] = ref interval, k[n + i] = obs interval (-1: skipped)
 template <int SIDE> struct RepSideAcc {   // SIDE 0: the reference view's pose, 1: the observation's
-  enum { NK = 24, NG = 6, NR = 2, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 8, SKIP_GG = SIDE, SECONDARY = 1, LB = 16, NCP = 31, USE_PRE = 0, FTAB = 1, OCC = 1 };
+  enum { PMAJ = 1 };
+  enum { NK = 24, NG = 6, NR = 2, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 16, SKIP_GG = SIDE, SECONDARY = 1, LB = 16, NCP = 31, USE_PRE = 0, FTAB = 0, OCC = 1 };
   __device__ static constexpr int jm(int c) { return c; }   // [knots of this side | camera]
   int n; RepJac jac;
   double huber;
@@ -722,6 +725,14 @@ template <class F> struct RowOf<F, std::void_t<typename F::Row>> { using type = 
 template <class F, class = void> struct FlushTab { static constexpr bool on = false; };
 template <class F> struct FlushTab<F, std::enable_if_t<(F::FTAB > 0)>> { static constexpr bool on = true; };
 
+// F::PMAJ (families with WS == 1: every row of a window has the same local columns, no shift): the wavefront writes the rows of GL lanes into its
+// panel ONCE and then walks the windows inside the panel — a window is the set of panel rows whose lanes share a knot interval; its k-steps
+// run over that row span and mask the rows of other windows.  With the window-major loop a panel held one window (8 IMU samples: 8 of 64
+// lanes wrote, 90 ds_write instructions per 8 samples); here all GL lanes write at once.  The end-of-window scatter takes its LDS targets from
+// registers (window-independent for WS == 1: computed once per lane before the batch loop) instead of re-deriving the column classes.
+template <class F, class = void> struct PanelMajor { static constexpr bool on = false; };
+template <class F> struct PanelMajor<F, std::enable_if_t<(F::PMAJ > 0)>> { static constexpr bool on = true; static_assert(F::WS == 1, "panel-major needs shift-free windows"); };
+
 template <class F> struct MfmaGeom {
   static constexpr int NKL = (F::WS + 3) * F::KPK;           // knot columns of a window
   static constexpr int NCL = NKL + F::NG + 1;                // + globals + residual
@@ -815,6 +826,33 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
   auto cls = [](int lc) { return lc < NKL ? 6 * (lc / KPK) + F::LVO + lc % KPK : (lc < NKL + NG ? -1 - (lc - NKL) : (lc == NKL + NG ? -100 : -200)); };
   const int frag_off = (lane >> 4) * LDP + (lane & 15);
   double mycost = 0.0;
+  // panel-major families: where accumulator register (tile pair t, v) of THIS lane goes at the end of a window — LDS index (doubles, relative
+  // to sm) | multiplier of the window base (0: none, 1: wb, 2: wb * ACC_BW) << 16 | largest accumulator row touched (relative to wb) << 18, or -1
+  int rtab[PanelMajor<F>::on ? G::NTP * 4 : 1];
+  if constexpr (PanelMajor<F>::on) {
+    int t = 0;
+#pragma unroll
+    for (int ci = 0; ci < NT; ++ci)
+#pragma unroll
+      for (int cj = ci; cj < NT; ++cj, ++t)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int row = ci * 16 + (lane >> 4) + 4 * v, col = cj * 16 + (lane & 15);
+          int ent = -1;
+          if (!(ci == cj && col < row)) {
+            const int ra = cls(row), cb = cls(col);
+            if (ra >= 0) {
+              if (cb >= 0) { const int d = cb - ra; if (d >= 0 && d < ACC_BW) ent = ((int)(acc_band - sm) + ra * ACC_BW + d) | (2 << 16) | (cb << 18); }
+              else if (cb > -100) ent = ((int)(acc_bd - sm) + (-1 - cb) * ACC_LV + ra) | (1 << 16) | (ra << 18);
+              else if (cb == -100) ent = ((int)(acc_gk - sm) + ra) | (1 << 16) | (ra << 18);
+            } else if (ra > -100 && !F::SKIP_GG) {
+              if (cb > -100 && cb < 0) ent = (int)(acc_gg - sm) + (-1 - ra) * NG + (-1 - cb);
+              else if (cb == -100) ent = (int)(acc_gG - sm) + (-1 - ra);
+            }
+          }
+          rtab[t * 4 + v] = ent;
+        }
+  }
   typename RowOf<F>::type nxt{};
   if constexpr (RowOf<F>::prefetch) { const int s0 = m0 + wv * LB + lane; if (lane < LB && s0 < m1) nxt = fam.load(s0); }
   __syncthreads();
@@ -866,6 +904,88 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
     }
     if (!want_ne) continue;
     KT(1)
+    if constexpr (PanelMajor<F>::on) {
+      const unsigned long long vm = __ballot(valid);
+      for (int g0 = 0; g0 < LB; g0 += GL) {                  // one panel = the rows of GL lanes
+        const unsigned long long pmask = (GL >= 64 ? ~0ull : ((1ull << GL) - 1ull)) << g0;
+        unsigned long long rem = vm & pmask;
+        if (!rem) continue;                                   // wave-uniform
+        if (lane >= g0 && lane < g0 + GL) {
+          const int li = lane - g0;
+#pragma unroll
+          for (int a = 0; a < NR; ++a) {
+            double* prow = P + (li * NR + a) * LDP;
+#pragma unroll
+            for (int c = 0; c < NK; ++c) prow[c] = valid ? J[a][F::jm(c)] : 0.0;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) prow[NKL + g] = valid ? J[a][F::jm(NK + g)] : 0.0;
+            prow[NKL + NG] = valid ? r[a] : 0.0;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        KT(2)
+        while (rem) {                                         // windows inside the panel (wave-uniform control flow)
+          const int l0 = __ffsll((long long)rem) - 1;
+          const int kw = __builtin_amdgcn_readfirstlane(__shfl(key, l0));
+          const unsigned long long wm = __ballot(valid && key == kw) & pmask;
+          rem &= ~wm;
+          const int lhi = 63 - __clzll((long long)wm);
+          const int wb = (kw - k_lo) * 6;
+          const int r_lo = (l0 - g0) * NR, r_hi = (lhi - g0 + 1) * NR;   // the window's row span in the panel
+          const unsigned long long wsh = wm >> g0;
+          d4 D[G::NTP];
+#pragma unroll
+          for (int t = 0; t < G::NTP; ++t) D[t] = d4{0.0, 0.0, 0.0, 0.0};
+          const int nks = (r_hi - r_lo + 3) >> 2;
+          const bool contig = __popcll(wm) == lhi - l0 + 1;   // sorted families: always (wave-uniform)
+          // U k-steps per trip, their LDS reads issued before the first product: one read -> select -> MFMA chain per k-step leaves the LDS
+          // latency exposed (measured: 480 cycles per k-step).  A full interval of 8 IMU samples is 6 k-steps = one trip; a padded k-step
+          // multiplies zeros.
+          auto trip = [&](int ks, auto UC) {
+            constexpr int U = decltype(UC)::value;
+            double f[U][NT];
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+              const int rr = r_lo + 4 * (ks + q) + (lane >> 4);
+              bool mine = rr < r_hi;
+              if (!contig) mine = mine && ((wsh >> (rr / NR)) & 1ull);   // rows of other windows inside the span contribute zeros
+              const double* src = P + min(rr, PR - 1) * LDP + (lane & 15);
+#pragma unroll
+              for (int c = 0; c < NT; ++c) { const double x = src[c * 16]; f[q][c] = mine ? x : 0.0; }
+            }
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+              int t = 0;
+#pragma unroll
+              for (int ci = 0; ci < NT; ++ci)
+#pragma unroll
+                for (int cj = ci; cj < NT; ++cj, ++t) D[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[q][ci], f[q][cj], D[t], 0, 0, 0);
+            }
+          };
+          int ks = 0;
+          for (; ks + 6 <= nks; ks += 6) trip(ks, std::integral_constant<int, 6>{});
+          for (; ks < nks; ks += 2) trip(ks, std::integral_constant<int, 2>{});
+          KT(3)
+          const int wbB = wb * ACC_BW;
+#pragma unroll
+          for (int t = 0; t < G::NTP; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const int te = rtab[t * 4 + v];
+              const double val = D[t][v];
+              if (te < 0 || val == 0.0 || wb + (te >> 18) >= ACC_LV) continue;
+              const int m = (te >> 16) & 3;
+              atomicAdd(&sm[(te & 0xffff) + (m == 2 ? wbB : (m == 1 ? wb : 0))], val);
+            }
+          KT(4)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                      // the next panel overwrites these rows
+      }
+      continue;
+    }
     unsigned long long rem = __ballot(valid);
     while (rem) {                                            // one window per iteration (wave-uniform control flow)
       const int l0 = __ffsll((long long)rem) - 1;
@@ -1009,7 +1129,9 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
 
 // fold the pseudo-pose rows of the border back onto the hub control points: x_pseudo = M_hub x_hub  =>
 //   Bd[hub] += M^T Bd[pseudo],  C <- (I + E) C (I + E)^T,  g_c[hub] += M^T g_c[pseudo]      (E = M^T placed at [hub rows, pseudo cols])
-__device__ __forceinline__ void fold_border_rows_block(const DevCommon& cm, int set, int blk) {
+// store: this set is the first to fold in this pass — outside [hub_lo, hub_hi) the hub rows were NOT cleared (nothing but the fold writes
+// there: 36 MB of the per-pass clear at config 4), so it stores its sums (or zero) instead of adding
+__device__ __forceinline__ void fold_border_rows_block(const DevCommon& cm, int set, int blk, bool store) {
   const HubShared* hub = ((const HubShared*)cm.hubs) + set;
   if (hub->ok != 1) return;
   __shared__ double M[6][24];
@@ -1024,19 +1146,21 @@ __device__ __forceinline__ void fold_border_rows_block(const DevCommon& cm, int 
 #pragma unroll
     for (int p = 0; p < 6; ++p) { P[p] = cm.Bd[(size_t)(cm.nbd_solve + 6 * set + p) * cm.nb + j]; any = any || P[p] != 0.0; }
   }
-  if (any) {
+  const bool far = store && j < cm.nb && (j < cm.hub_lo || j >= cm.hub_hi);
+  if (any || far) {
 #pragma unroll
     for (int c = 0; c < 24; ++c) {
       if (hrow[c] < 0) continue;
       double s = 0.0;
 #pragma unroll
       for (int p = 0; p < 6; ++p) s += M[p][c] * P[p];
-      cm.Bd[(size_t)hrow[c] * cm.nb + j] += s;   // the two sets may share hub rows: a thread folds them one after the other (k_fold_all)
+      double* dst = &cm.Bd[(size_t)hrow[c] * cm.nb + j];
+      if (far) *dst = any ? s : 0.0; else *dst += s;   // the two sets may share hub rows: a thread folds them one after the other (k_fold_all)
     }
   }
   __syncthreads();   // M / hrow are reused by the next set
 }
-__global__ __launch_bounds__(256) void k_fold_border_rows(DevCommon cm, int set) { fold_border_rows_block(cm, set, (int)blockIdx.x); }
+__global__ __launch_bounds__(256) void k_fold_border_rows(DevCommon cm, int set, int store) { fold_border_rows_block(cm, set, (int)blockIdx.x, store != 0); }
 __device__ __forceinline__ void fold_border_dense_block(const DevCommon& cm) {
   extern __shared__ double Cf[];   // full symmetric [n][n] then g[n]
   const int n = cm.nbd;
@@ -1102,7 +1226,7 @@ __global__ void k_fold_replicas(DevCommon cm) { fold_replicas_block(cm, (int)blo
 // and the remaining blocks fold the border rows (both sets in the same thread: they may add into the same hub rows).
 __global__ __launch_bounds__(256) void k_fold_all(DevCommon cm, int nrep, int sets) {
   const int b = blockIdx.x;
-  if (b >= nrep) { if (sets & 1) fold_border_rows_block(cm, 0, b - nrep); if (sets & 2) fold_border_rows_block(cm, 1, b - nrep); return; }
+  if (b >= nrep) { if (sets & 1) fold_border_rows_block(cm, 0, b - nrep, true); if (sets & 2) fold_border_rows_block(cm, 1, b - nrep, !(sets & 1)); return; }
   fold_replicas_block(cm, b);
   __shared__ int last;
   __threadfence();
@@ -1486,6 +1610,13 @@ int ensure_layout(lvx_ctx* ctx) {
   if ((rc = dev_alloc(ctx, ctx->d_lmH, (size_t)std::max(L, 1) * ctx->lm_ls * 8 + 16))) return rc;
   ctx->bw = std::min(std::max(bw, 0), std::max(ctx->nb - 1, 0));
   ctx->clear_npre = std::min(bw_near, ctx->bw) + 1;
+  {   // band positions that couple to a hub knot directly: rows of the 4-knot families within 5 knots of the hub, reprojection blocks within their knot span
+    int reach = 5;
+    for (int i = 0; i < ctx->rep.n; ++i) reach = std::max(reach, rep_kmax[i] - rep_kmin[i] + 2);
+    int lo = 1 << 30, hi = -1;
+    if (nh > 0) span_pos(std::max(0, h0 - reach), std::min(N - 1, h0 + nh + reach), lo, hi);
+    ctx->hub_near_lo = hi >= lo ? lo : 0; ctx->hub_near_hi = hi >= lo ? hi + 1 : 0;
+  }
   if ((rc = upload_tmp(ctx, ctx->d_colfull, colfull.data(), colfull.size()))) return rc;
   ctx->bd_row_live.assign((size_t)ctx->nbd_ext, 0);
   for (int b = 0; b < 6 * nh; ++b) ctx->bd_row_live[b] = 1;
@@ -1538,6 +1669,7 @@ DevCommon make_common(lvx_ctx* ctx, const double* state_d, uint32_t what) {
   cm.Hb = (double*)ctx->d_Hb.p; cm.gb = (double*)ctx->d_gb.p; cm.Bd = (double*)ctx->d_Bd.p; cm.C = (double*)ctx->d_C.p; cm.gc = (double*)ctx->d_gc.p;
   cm.cost = (double*)ctx->d_cost.p; cm.err = (int*)ctx->d_err.p;
   cm.lmH = (double*)ctx->d_lmH.p; cm.lm_p0 = (const int*)ctx->d_lm_p0.p; cm.lm_wl = ctx->lm_wl; cm.lm_ls = ctx->lm_ls;
+  cm.hub_lo = 0; cm.hub_hi = ctx->nb;
   cm.residuals = nullptr; cm.jcols = nullptr; cm.jvals = nullptr;
   return cm;
 }
@@ -1568,7 +1700,7 @@ struct ClearList { uint4* p[16]; size_t words[16]; int n; };
 // The band is cleared STRUCTURALLY: every column's first `npre` entries (what the IMU / LiDAR families can touch: 4 neighbouring knots and
 // the landmarks ordered between them), whole columns only where `colfull` says a reprojection block or a landmark reaches further
 // (ensure_layout).  Everything else was zeroed once at layout time and is never written.  Config 4 with ORB-like tracks: 60 MB instead of 242 MB.
-struct BandClear { double* Hb; const uint8_t* colfull; int nb, ld, npre, nblk; };
+struct BandClear { double* Hb; const uint8_t* colfull; int nb, ld, npre, nblk; double* Bd; int hub_rows, hub_lo, hub_hi, hub_blk; };   // hub rows of Bd: only [hub_lo, hub_hi) (the fold stores the rest)
 // First launch of a pass.  Its first npre blocks do what depends on the state only (control-point-pair table, hub poses: k_state_prepass's
 // work — a separate kernel on a side stream costs a ~30 us cross-stream join before the LiDAR kernels); the rest clear the accumulators.
 __global__ __launch_bounds__(256) void k_clear(ClearList cl, BandClear bc, int npre, DevCommon cm, So3Pre* tab, int nblk_tab, double t_map, int want_surf, int want_cs, HubShared* hubs) {
@@ -1582,7 +1714,13 @@ __global__ __launch_bounds__(256) void k_clear(ClearList cl, BandClear bc, int n
     }
     return;
   }
-  const int first = npre + bc.nblk;
+  if ((int)blockIdx.x < npre + bc.nblk + bc.hub_blk) {   // near range of the hub rows: one row per block
+    const int row = (int)blockIdx.x - npre - bc.nblk;
+    double* dst = bc.Bd + (size_t)row * bc.nb;
+    for (int e = bc.hub_lo + threadIdx.x; e < bc.hub_hi; e += blockDim.x) dst[e] = 0.0;
+    return;
+  }
+  const int first = npre + bc.nblk + bc.hub_blk;
   const size_t stride = (size_t)(gridDim.x - first) * blockDim.x, t0 = (size_t)(blockIdx.x - first) * blockDim.x + threadIdx.x;
   for (int b = 0; b < cl.n; ++b) {   // 4 stores per trip: the prepass code leaves this kernel 2 wavefronts per SIMD, the stores keep HBM busy anyway
     const size_t nw = cl.words[b];
@@ -1634,10 +1772,15 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
         if (ctx->sw.clear_all || ctx->nb == 0) add(cm.Hb, nb1 * (ctx->bw + 1) * 8);
         else { bc.Hb = cm.Hb; bc.colfull = (const uint8_t*)ctx->d_colfull.p; bc.nb = ctx->nb; bc.ld = ctx->bw + 1; bc.npre = ctx->clear_npre; bc.nblk = (ctx->nb + 15) / 16; }
         add(cm.gb, nb1 * 8);
+        // hub rows of Bd: with the fused LiDAR kernels only the fold fills them beyond the near range — it stores there, the clear skips them
+        const bool hub_partial = !ctx->sw.clear_all && !(nb1 & 1) && ctx->nb > 0 && ctx->n_hub > 0 && (fast_surf || fast_cs) && (ctx->surf.n == 0 || fast_surf) && (ctx->cs.n == 0 || fast_cs);
+        cm.hub_lo = hub_partial ? ctx->hub_near_lo : 0; cm.hub_hi = hub_partial ? ctx->hub_near_hi : ctx->nb;
+        if (hub_partial) { bc.Bd = cm.Bd; bc.hub_rows = 6 * ctx->n_hub; bc.hub_lo = cm.hub_lo; bc.hub_hi = cm.hub_hi; bc.hub_blk = cm.hub_hi > cm.hub_lo ? 6 * ctx->n_hub : 0; if (!bc.nb) bc.nb = ctx->nb; }
         // border rows: only the rows some residual can reach (a locked calibration scalar and an unused pseudo-pose set keep their zeros); 16-byte words: whole rows when nb is even
         if (ctx->sw.clear_all || (nb1 & 1)) add(cm.Bd, (size_t)ctx->nbd_ext * nb1 * 8);
         else for (int b0 = 0; b0 < ctx->nbd_ext;) {
-          if (!ctx->bd_row_live[b0]) { ++b0; continue; }
+          const int first_live = hub_partial ? 6 * ctx->n_hub : 0;   // hub rows: HubClear
+          if (b0 < first_live || !ctx->bd_row_live[b0]) { ++b0; continue; }
           int b1 = b0; while (b1 < ctx->nbd_ext && ctx->bd_row_live[b1]) ++b1;
           add(cm.Bd + (size_t)b0 * nb1, (size_t)(b1 - b0) * nb1 * 8);
           b0 = b1;
@@ -1649,7 +1792,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
       size_t total = 0; for (int i = 0; i < cl.n; ++i) total += cl.words[i];
       const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
       ProfScope ps(ctx, LVX_KERNEL_CLEAR, st);
-      hipLaunchKernelGGL(k_clear, dim3(blocks + (unsigned)npre + (unsigned)bc.nblk), dim3(256), 0, st, cl, bc, npre, cm, (So3Pre*)ctx->d_pre.p, nblk_tab, ctx->t_map, fast_surf ? 1 : 0, fast_cs ? 1 : 0,
+      hipLaunchKernelGGL(k_clear, dim3(blocks + (unsigned)npre + (unsigned)bc.nblk + (unsigned)bc.hub_blk), dim3(256), 0, st, cl, bc, npre, cm, (So3Pre*)ctx->d_pre.p, nblk_tab, ctx->t_map, fast_surf ? 1 : 0, fast_cs ? 1 : 0,
                          (HubShared*)ctx->d_hubs.p);
     }
     auto grid = [](int n) { return dim3((unsigned)((n + 63) / 64)); };
@@ -1831,7 +1974,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
       hipStream_t s_side = (sw.serial || sw.fold_inline) ? st : ctx->fam_stream[0];
       if (s_side != st) LVX_HIP(ctx, hipStreamWaitEvent(s_side, ctx->ev_jac, 0));
       for (int set = 0; set < 2; ++set) if (ctx->nb > 0 && ((set == 0 && fast_surf) || (set == 1 && fast_cs)))
-        hipLaunchKernelGGL(k_fold_border_rows, dim3((unsigned)((ctx->nb + 255) / 256)), dim3(256), 0, s_side, cm, set);
+        hipLaunchKernelGGL(k_fold_border_rows, dim3((unsigned)((ctx->nb + 255) / 256)), dim3(256), 0, s_side, cm, set, (set == 0 || !fast_surf) ? 1 : 0);
       const size_t lds = ((size_t)ctx->nbd_ext * ctx->nbd_ext + ctx->nbd_ext) * 8;
       LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_fold_border_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(k_fold_border_dense, dim3(1), dim3(256), lds, st, cm);

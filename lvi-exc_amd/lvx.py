@@ -66,7 +66,8 @@ class LvxError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "liblvx.so")
+    # LVX_LIB: an instrumented build of the same sources (tools/build_kt.sh: per-phase cycle counters), never another implementation
+    return os.environ.get("LVX_LIB") or os.path.join(_HERE, "liblvx.so")
 
 
 def lib():
