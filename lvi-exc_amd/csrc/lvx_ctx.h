@@ -60,7 +60,7 @@ struct DevBuf {
 struct Switches {
   int force_legacy = 0, imu_legacy = 0, reproj_legacy = 0, serial = 0, sched = 2, imu_two_streams = 0, occ = 0, jac_late = 0, fold_one = 0, fold_inline = 0,
       no_graph = 0, sync_nofence = 0, chunk_r = 0, chunk_r_imu = 0, chunk_r_rep = 0, chunk_rows = 0, rep_rows = 0, solver_seq = 0, solver_timing = 0,
-      bcr_rocsolver_potrf = 0, bcr_syrk = 0, deterministic = 0, clear_all = 0, cross_dbg = 0;
+      bcr_rocsolver_potrf = 0, bcr_syrk = 0, deterministic = 0, clear_all = 0, cross_dbg = 0, lm_schur_single = 0;
 };
 struct SwitchName { const char* name; int Switches::*field; bool relayout; };
 const SwitchName* switch_table(int* count);
@@ -106,6 +106,7 @@ struct lvx_ctx {
   bool force_legacy = false;   // set when the fast assembly kernels hit a case only the per-segment kernels handle exactly
   lvx::DevBuf d_pre;   // So3Pre[N]
   lvx::DevBuf d_repT;   // [rep.n][56] landmark-row records of the reprojection blocks (k_reproj_cross -> k_reproj_lmrows)
+  lvx::DevBuf d_lm_grp; int lm_ngrp = 0, lm_gspread = 0;   // landmark groups of the elimination kernel (k_lm_schur_grp): [ngrp + 1 offsets | landmark ids sorted by first band position]
   lvx::DevBuf d_lmH, d_lm_p0, d_Hr, d_Br, d_red; int lm_wl = 0, lm_ls = 0; const double* p_Hs = nullptr;   // landmark rows (DevCommon::lmH); solver: band / border rows / [g_b | C | g_c] after the landmark elimination
   int hub_near_lo = 0, hub_near_hi = 0;   // band positions a residual can couple to a hub knot DIRECTLY (not through the pseudo pose): IMU / LiDAR rows within 4 knots, reprojection blocks within their span
   lvx::DevBuf d_colfull; int clear_npre = 0; std::vector<uint8_t> bd_row_live;   // structural clear of the band / border rows (k_clear)

@@ -1249,7 +1249,7 @@ const SwitchName* switch_table(int* count) {
     {"SYNC_NOFENCE", &Switches::sync_nofence, false}, {"CHUNK_R", &Switches::chunk_r, true}, {"CHUNK_R_IMU", &Switches::chunk_r_imu, true},
     {"CHUNK_R_REP", &Switches::chunk_r_rep, true}, {"CHUNK_ROWS", &Switches::chunk_rows, true}, {"REP_ROWS", &Switches::rep_rows, true},
     {"SOLVER_SEQ", &Switches::solver_seq, false}, {"SOLVER_TIMING", &Switches::solver_timing, false}, {"BCR_ROCSOLVER_POTRF", &Switches::bcr_rocsolver_potrf, false},
-    {"BCR_SYRK", &Switches::bcr_syrk, false}, {"DETERMINISTIC", &Switches::deterministic, true}, {"CLEAR_ALL", &Switches::clear_all, false}, {"CROSS_DBG", &Switches::cross_dbg, false},
+    {"BCR_SYRK", &Switches::bcr_syrk, false}, {"DETERMINISTIC", &Switches::deterministic, true}, {"CLEAR_ALL", &Switches::clear_all, false}, {"CROSS_DBG", &Switches::cross_dbg, false}, {"LM_SCHUR_SINGLE", &Switches::lm_schur_single, false},
   };
   *count = (int)(sizeof(tab) / sizeof(tab[0]));
   return tab;
@@ -1606,6 +1606,22 @@ int ensure_layout(lvx_ctx* ctx) {
     if (hi >= lo) { if (!(locks & LVX_LOCK_LANDMARKS)) bw = std::max(bw, hi - lo); lm_p0[l] = lo; lm_wl = std::max(lm_wl, hi - lo + 1); }
   }
   ctx->lm_wl = lm_wl; ctx->lm_ls = lm_wl + ctx->nbd_ext + 2;
+  {   // groups for the landmark elimination: landmarks of one reference frame start at the same band position and reach the same knots, so their rank-1
+      // updates are summed per group (<= 32 landmarks whose first positions lie within 24 scalars) before they touch the band (k_lm_schur_grp)
+    std::vector<int> order;
+    for (int l = 0; l < L; ++l) if (lm_last[l] >= 0) order.push_back(l);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lm_p0[a] < lm_p0[b]; });
+    std::vector<int> goff;
+    int spread = 0;
+    for (size_t i = 0; i < order.size(); ++i) {
+      if (goff.empty() || (int)i - goff.back() >= 32 || lm_p0[order[i]] - lm_p0[order[goff.back()]] > 24) goff.push_back((int)i);
+      spread = std::max(spread, lm_p0[order[i]] - lm_p0[order[goff.back()]]);
+    }
+    ctx->lm_ngrp = (int)goff.size(); ctx->lm_gspread = spread;
+    goff.push_back((int)order.size());
+    goff.insert(goff.end(), order.begin(), order.end());
+    if ((rc = upload_tmp(ctx, ctx->d_lm_grp, goff.data(), goff.size() * 4))) return rc;
+  }
   if ((rc = upload_tmp(ctx, ctx->d_lm_p0, lm_p0.data(), lm_p0.size() * 4))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_lmH, (size_t)std::max(L, 1) * ctx->lm_ls * 8 + 16))) return rc;
   ctx->bw = std::min(std::max(bw, 0), std::max(ctx->nb - 1, 0));
@@ -2092,7 +2108,7 @@ void lvx_destroy(lvx_ctx* c) {
   if (c->d_hubs.p) (void)hipFree(c->d_hubs.p);
   if (c->d_pre.p) (void)hipFree(c->d_pre.p);
   if (c->d_colfull.p) (void)hipFree(c->d_colfull.p);
-  for (DevBuf* b : {&c->d_lmH, &c->d_lm_p0, &c->d_Hr, &c->d_Br, &c->d_red, &c->d_repT}) if (b->p) (void)hipFree(b->p);
+  for (DevBuf* b : {&c->d_lm_grp, &c->d_lmH, &c->d_lm_p0, &c->d_Hr, &c->d_Br, &c->d_red, &c->d_repT}) if (b->p) (void)hipFree(b->p);
   for (DevBuf* b : {&c->vox.misc, &c->vox.keys, &c->vox.vals, &c->vox.runs, &c->vox.cells, &c->vox.tmp, &c->vox.leaf_i, &c->vox.leaf_d, &c->vox.leaf_f}) if (b->p) (void)hipFree(b->p);
   (void)lvx_rccl_finalize(c);
   if (c->d_comm.p) (void)hipFree(c->d_comm.p);

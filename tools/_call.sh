@@ -1,5 +1,4 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | grep -E "passed|failed|Error|error" | tail -5
-python bench.py --no-secondary --no-cpu-baseline > gpurun_out/b.json 2> gpurun_out/b.err; python tools/bsum.py gpurun_out/b.json
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -o pmc -- python bench.py --steps 5 --warmup 1 --no-secondary --no-cpu-baseline > gpurun_out/pmc_w.log 2>&1
-python tools/pmc_summary.py gpurun_out/pmc_w gpurun_out/pmc_w 2>/dev/null | grep -A3 "k_clear\|fold_border_rows" | cut -c1-140
+rocprofv3 --kernel-trace -d gpurun_out/lm -o kt -- python tools/lm_scale_probe.py > gpurun_out/lm.log 2>&1
+python tools/rocpd_summary.py $(find gpurun_out/lm -name "*.db" | head -1) > gpurun_out/lm_stats.txt
+grep -v "^W2026\|^KT\|^E2026" gpurun_out/lm.log | tail -3 | cut -c1-400; head -24 gpurun_out/lm_stats.txt | cut -c1-60,90-150
