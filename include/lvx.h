@@ -157,6 +157,12 @@ int lvx_set_stream(lvx_ctx* ctx, void* hip_stream);
  * was evaluated): after a sum over the ranks a non-zero value tells EVERY rank that some rank's sums are incomplete, with no host
  * synchronisation in between (lvx_synchronize returns the matching error code on the rank that produced it). */
 int lvx_export_border_d(lvx_ctx* ctx, double* out_d);
+/* debug / repeatability: order-independent 64-bit checksums of the bit patterns of the structured normal equations of the last LVX_EVAL_NORMAL_EQ
+ * evaluation — band, band gradient, border rows, dense border block, border gradient, landmark rows.  With LVX_DETERMINISTIC=1 (lvx_set_switch
+ * "DETERMINISTIC") every addition of a pass happens in a fixed order — one stream, launches of workgroups with pairwise disjoint knot ranges, one
+ * wavefront per workgroup, one replica of the dense accumulators per workgroup — and two evaluations of the same state give identical checksums
+ * (fused locked-offset kernels; the per-segment kernels of a free time offset are not covered).  Several times slower than the default. */
+int lvx_normal_eq_checksum(lvx_ctx* ctx, uint64_t out[6]);
 /* keep `state` resident in the context's device buffer; lvx_evaluate_d(ctx, NULL, ...) then evaluates it without any host traffic */
 int lvx_set_state(lvx_ctx* ctx, const double* state);
 int lvx_get_state(lvx_ctx* ctx, double* state_out);

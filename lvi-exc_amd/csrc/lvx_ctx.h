@@ -29,6 +29,7 @@ struct DevCommon {
   const int* ord;
   int nb, bw, nbd;   // nbd: assembly border size (solve border + pseudo rows) = leading dimension of C
   int nbd_solve;
+  int nrep;          // replicas of C / gc / cost in use: LVX_NREP, or one per workgroup in deterministic mode
   int hub_lo, hub_hi;   // band positions [hub_lo, hub_hi) of the hub rows of Bd are cleared per pass and accumulated; outside, the fold STORES (see k_clear's HubClear)
   const void* hubs;  // HubShared[2]: surfel (tau_L) and cam-surfel (tau_C) poses at t_map
   const So3Pre* pre; // [N]: u-independent SO3 quantities of the control-point pairs (k, k+1), rebuilt from the state at the start of every pass (k_state_prepass)
@@ -111,6 +112,11 @@ struct lvx_ctx {
   int hub_near_lo = 0, hub_near_hi = 0;   // band positions a residual can couple to a hub knot DIRECTLY (not through the pseudo pose): IMU / LiDAR rows within 4 knots, reprojection blocks within their span
   lvx::DevBuf d_colfull; int clear_npre = 0; std::vector<uint8_t> bd_row_live;   // structural clear of the band / border rows (k_clear)
   lvx::DevBuf d_hubs, d_chunk[LVX_NUM_FAM], d_repB[4];   // reprojection MFMA path: [0] materialised Jacobians + residuals, [1] knot intervals, [2] landmark and [3] observation-order index of the rows in (reference interval, landmark) order
+  // deterministic mode (LVX_DETERMINISTIC=1): chunks of every family grouped into colours of pairwise disjoint knot ranges (det_list: chunk ids, colour by colour;
+  // det_col: offsets), launched colour after colour on one stream with one wavefront per workgroup — no two additions to one address can race
+  int nrep = LVX_NREP;
+  std::vector<int> h_chunk_k0[LVX_NUM_FAM], h_chunk_rows[LVX_NUM_FAM], det_col[LVX_NUM_FAM], det_cross_col;
+  lvx::DevBuf d_det_list[LVX_NUM_FAM], d_det_cross, d_chk;
   int chunk_var[LVX_NUM_FAM] = {0};   // != 0: chunks of equal ROW count (first interval of chunk c at d_chunk[n_chunk + 1 + c]) instead of equal interval count
   int n_chunk[LVX_NUM_FAM] = {0}, chunk_r[LVX_NUM_FAM] = {0};   // workgroups and knot intervals per workgroup of the MFMA assembly kernels (pick_chunk)
   lvx::DevBuf d_ord, d_Hb, d_gb, d_Bd, d_C, d_gc, d_cost, d_err, d_state, d_res, d_jcols, d_jvals, d_pairs[LVX_NUM_FAM];

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64 * PW) void k_family(F fam, DevCommon cm, const u
   __shared__ HubShared hub;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int rep = blockIdx.x % LVX_NREP;
+  const int rep = blockIdx.x % cm.nrep;
   __shared__ int nseg_s;
   if (wave == 0) {
   const int si = blockIdx.x * 64 + lane;
@@ -506,7 +506,7 @@ template <int SIDE> struct RepSideAcc {   // SIDE 0: the reference view's pose, 
 // assembly, so the MFMA passes read the rows back instead (2 x 45 MB at config 4, nothing against their atomics).
 __global__ __launch_bounds__(64) void k_reproj_jac(ReprojFam fam, DevCommon cm, double* Jb, double* rb, int* kb, long long row0) {
   const int lane = threadIdx.x, si = blockIdx.x * 64 + lane, n = fam.n;
-  const int rep = blockIdx.x % LVX_NREP;
+  const int rep = blockIdx.x % cm.nrep;
   double mycost = 0.0;
   if (si < n) {
     const SplineRef sp{cm.t0, cm.dt, cm.N, cm.state, cm.state + 3 * (size_t)cm.N};
@@ -541,20 +541,21 @@ __global__ __launch_bounds__(64) void k_reproj_jac(ReprojFam fam, DevCommon cm, 
 // LDS panels; T = J_ref^T J_obs accumulates in 3 x 3 MFMA tiles over the whole group and leaves with one atomic per non-zero entry.
 // The landmark's own row (rho x everything, 56 entries per block) is formed from the same registers with one lane exchange.
 typedef double d4 __attribute__((ext_vector_type(4)));
-struct RepCross { RepJac jac; const int* lm; const int* goff; const int* gw; int ng; int dbg; double* T; };   // T[i][56]: the landmark-row products of block i (k_reproj_lmrows)   // gw[g] = w0, gw[ng + g] = w1
+struct RepCross { RepJac jac; const int* lm; const int* goff; const int* gw; int ng; int dbg; double* T; const int* det_list; };   // det_list: deterministic mode — block b works on group det_list[b] alone   // T[i][56]: the landmark-row products of block i (k_reproj_lmrows)   // gw[g] = w0, gw[ng + g] = w1
 __global__ __launch_bounds__(256) void k_reproj_cross(RepCross rc, DevCommon cm) {
   constexpr int LDP = 49, BR = 16;   // panel: 16 rows (8 blocks x 2 residual rows) x 48 columns, odd stride
   __shared__ double pan[4][2][BR * LDP];
   __shared__ double tbuf[4][8 * 56];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int rep = blockIdx.x % LVX_NREP;
+  const int rep = blockIdx.x % cm.nrep;
+  if (rc.det_list && wv != 0) return;   // (the kernel has wavefront barriers only)
   const int part = lane & 7, b = lane >> 3, side = part >> 2, a = (part >> 1) & 1, h = part & 1;
   const int n = rc.jac.n, N = cm.N;
   double* Pr = pan[wv][0];
   double* Po = pan[wv][1];
   const int frag_off = (lane >> 4) * LDP + (lane & 15);
   const bool lm_free = !(cm.locks & LVX_LOCK_LANDMARKS);
-  for (int g = blockIdx.x * 4 + wv; g < rc.ng; g += gridDim.x * 4) {
+  for (int g = rc.det_list ? rc.det_list[blockIdx.x] : blockIdx.x * 4 + wv; g < rc.ng; g += rc.det_list ? rc.ng : gridDim.x * 4) {
     const int m0 = rc.goff[g], m1 = rc.goff[g + 1], w0 = rc.gw[g], w1 = rc.gw[rc.ng + g];
     d4 D[9];
 #pragma unroll
@@ -750,7 +751,7 @@ template <class F> size_t mfma_lds_bytes(int cr) {
 
 // CR = knot intervals per workgroup, chosen per problem by the host (pick_chunk) so that the workgroup count fills whole rounds of the CUs
 template <class F, int OCC>
-__global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, const int* __restrict__ chunk_off, long long row0, int CR, int var_nch) {
+__global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, const int* __restrict__ chunk_off, long long row0, int CR, int var_nch, const int* __restrict__ det_list) {
   using G = MfmaGeom<F>;
   constexpr int NK = F::NK, NG = F::NG, NC = F::NCP, NR = F::NR, KPK = F::KPK, WS = F::WS, GL = F::GL, LB = F::LB;
   constexpr int NKL = G::NKL, NT = G::NT, LDP = G::LDP, PR = G::PR;
@@ -767,7 +768,8 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
   int* gpos = kpos + ACC_LV;                          // [NG]
   int* ftab = gpos + NG;              // [NTP * 4][64]: where accumulator register (tile pair, v) of each lane goes at the end of a window
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int ch = blockIdx.x;
+  const int ch = det_list ? det_list[blockIdx.x] : blockIdx.x;   // deterministic mode: the chunks of one colour (disjoint knot ranges), one wavefront each
+  const int nwv = det_list ? 1 : 4;
   const int m0 = chunk_off[ch], m1 = chunk_off[ch + 1];
   if (m0 >= m1) return;
 #ifdef LVX_KTIME
@@ -821,7 +823,7 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
   const Cal cal = load_cal(cm);
   const HubShared* hub = F::HUB >= 0 ? ((const HubShared*)cm.hubs) + F::HUB : nullptr;
   double* P = panels + wv * (PR * LDP);
-  const int rep = blockIdx.x % LVX_NREP;
+  const int rep = ch % cm.nrep;
   // class of a window-local column: >= 0 knot scalar (offset inside the window, in units of tangent scalars), -1-g global g, -100 residual, -200 padding
   auto cls = [](int lc) { return lc < NKL ? 6 * (lc / KPK) + F::LVO + lc % KPK : (lc < NKL + NG ? -1 - (lc - NKL) : (lc == NKL + NG ? -100 : -200)); };
   const int frag_off = (lane >> 4) * LDP + (lane & 15);
@@ -854,10 +856,10 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
         }
   }
   typename RowOf<F>::type nxt{};
-  if constexpr (RowOf<F>::prefetch) { const int s0 = m0 + wv * LB + lane; if (lane < LB && s0 < m1) nxt = fam.load(s0); }
+  if constexpr (RowOf<F>::prefetch) { const int s0 = m0 + wv * LB + lane; if (wv < nwv && lane < LB && s0 < m1) nxt = fam.load(s0); }
   __syncthreads();
   KT(0)
-  for (int base = m0 + wv * LB; base < m1; base += 4 * LB) {   // LB rows per wave batch: sparse families spread their rows over the 4 waves
+  for (int base = wv < nwv ? m0 + wv * LB : m1; base < m1; base += nwv * LB) {   // LB rows per wave batch: sparse families spread their rows over the 4 waves
     const int si = base + lane;
     const bool in = lane < LB && si < m1;
     const typename RowOf<F>::type cur = nxt;
@@ -878,7 +880,7 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
       if (valid && (key < k_lo || key - k_lo > CR + 1)) { valid = false; atomicOr(cm.err, LVX_ERR_FALLBACK); }
       else if (!valid && status > 0) atomicOr(cm.err, status);   // status < 0: row skipped (reported by the kernel that produced it)
     }
-    if constexpr (RowOf<F>::prefetch) { const int sn = si + 4 * LB; if (lane < LB && sn < m1) nxt = fam.load(sn); }   // next batch's rows: in flight during this batch's assembly
+    if constexpr (RowOf<F>::prefetch) { const int sn = si + nwv * LB; if (lane < LB && sn < m1) nxt = fam.load(sn); }   // next batch's rows: in flight during this batch's assembly
     if (valid) {
       double s = 0.0;
 #pragma unroll
@@ -1215,10 +1217,10 @@ __device__ __forceinline__ void fold_replicas_block(const DevCommon& cm, int blk
   const int n2 = cm.nbd * cm.nbd;
   const int i = blk * blockDim.x + threadIdx.x;
   if (cm.what & LVX_EVAL_NORMAL_EQ) {
-    if (i < n2) { double s = 0; for (int r = 0; r < LVX_NREP; ++r) s += cm.C[(size_t)r * n2 + i]; cm.C[i] = s; }
-    if (i < cm.nbd) { double s = 0; for (int r = 0; r < LVX_NREP; ++r) s += cm.gc[(size_t)r * cm.nbd + i]; cm.gc[i] = s; }
+    if (i < n2) { double s = 0; for (int r = 0; r < cm.nrep; ++r) s += cm.C[(size_t)r * n2 + i]; cm.C[i] = s; }
+    if (i < cm.nbd) { double s = 0; for (int r = 0; r < cm.nrep; ++r) s += cm.gc[(size_t)r * cm.nbd + i]; cm.gc[i] = s; }
   }
-  if (i == 0) { double s = 0; for (int r = 0; r < LVX_NREP; ++r) s += cm.cost[r]; cm.cost[0] = s; }
+  if (i == 0) { double s = 0; for (int r = 0; r < cm.nrep; ++r) s += cm.cost[r]; cm.cost[0] = s; }
 }
 __global__ void k_fold_replicas(DevCommon cm) { fold_replicas_block(cm, (int)blockIdx.x); }
 // The whole fold in one launch (three kernels on two streams cost a fork and a join on the pass's critical path): blocks [0, nrep) sum the
@@ -1375,6 +1377,7 @@ static int upload_chunks_rows(lvx_ctx* ctx, int fam, const std::vector<int>& sor
   off.push_back(n);
   const int nch = (int)k0.size();
   ctx->n_chunk[fam] = nch; ctx->chunk_r[fam] = rmax; ctx->chunk_var[fam] = 1;
+  ctx->h_chunk_k0[fam] = k0; ctx->h_chunk_rows[fam].assign(nch, 0); for (int c = 0; c < nch; ++c) ctx->h_chunk_rows[fam][c] = off[c + 1] - off[c];
   off.insert(off.end(), k0.begin(), k0.end());
   return upload_tmp(ctx, ctx->d_chunk[fam], off.data(), off.size() * 4);
 }
@@ -1397,6 +1400,7 @@ static int upload_chunks_rows_grouped(lvx_ctx* ctx, int fam, const std::vector<i
   } while (i < n);
   off.push_back(n);
   ctx->n_chunk[fam] = (int)k0.size(); ctx->chunk_r[fam] = rmax; ctx->chunk_var[fam] = 1;
+  ctx->h_chunk_k0[fam] = k0; ctx->h_chunk_rows[fam].assign(k0.size(), 0); for (size_t c = 0; c < k0.size(); ++c) ctx->h_chunk_rows[fam][c] = off[c + 1] - off[c];
   off.insert(off.end(), k0.begin(), k0.end());
   return upload_tmp(ctx, ctx->d_chunk[fam], off.data(), off.size() * 4);
 }
@@ -1408,6 +1412,7 @@ static int upload_chunks(lvx_ctx* ctx, int fam, const std::vector<int>& sorted_k
   off[nch] = (int)sorted_keys.size();
   ctx->n_chunk[fam] = nch;
   ctx->chunk_r[fam] = R; ctx->chunk_var[fam] = 0;
+  ctx->h_chunk_k0[fam].assign(nch, 0); ctx->h_chunk_rows[fam].assign(nch, 0); for (int c = 0; c < nch; ++c) { ctx->h_chunk_k0[fam][c] = c * R; ctx->h_chunk_rows[fam][c] = off[c + 1] - off[c]; }
   return upload_tmp(ctx, ctx->d_chunk[fam], off.data(), off.size() * 4);
 }
 
@@ -1504,6 +1509,24 @@ int ensure_layout(lvx_ctx* ctx) {
         for (int i = 0; i < f.n; ++i) { const int l = f.id0[perm[i]]; if (l >= 0 && l < L) rows[fill[l]++] = i; }
         ptr.insert(ptr.end(), rows.begin(), rows.end());
         if ((rc = upload_tmp(ctx, ctx->d_repB[3], ptr.data(), ptr.size() * 4))) return rc;
+      }
+      ctx->det_cross_col.clear();
+      if (ctx->sw.deterministic && !goff.empty()) {
+        // groups that can add to the same entry must not share a launch: a group touches the unordered pairs of 4-knot blocks {w0, w0 + 1} x {w1, w1 + 1}
+        std::vector<std::vector<uint64_t>> used;   // per colour: sorted block-pair keys
+        std::vector<std::vector<int>> members;
+        for (size_t g = 0; g < goff.size(); ++g) {
+          uint64_t key[4]; int nk = 0;
+          for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) { const uint64_t x = (uint64_t)(gw0[g] + a), y = (uint64_t)(gw1[g] + b); key[nk++] = x < y ? (x << 32) | y : (y << 32) | x; }
+          size_t col = 0;
+          for (; col < used.size(); ++col) { bool hit = false; for (int q = 0; q < 4 && !hit; ++q) hit = std::binary_search(used[col].begin(), used[col].end(), key[q]); if (!hit) break; }
+          if (col == used.size()) { used.emplace_back(); members.emplace_back(); }
+          for (int q = 0; q < 4; ++q) { auto it = std::lower_bound(used[col].begin(), used[col].end(), key[q]); if (it == used[col].end() || *it != key[q]) used[col].insert(it, key[q]); }
+          members[col].push_back((int)g);
+        }
+        std::vector<int> list; ctx->det_cross_col.push_back(0);
+        for (auto& m : members) { list.insert(list.end(), m.begin(), m.end()); ctx->det_cross_col.push_back((int)list.size()); }
+        if ((rc = upload_tmp(ctx, ctx->d_det_cross, list.data(), list.size() * 4))) return rc;
       }
       ctx->rep_groups = (int)goff.size();
       goff.push_back(f.n);
@@ -1638,20 +1661,49 @@ int ensure_layout(lvx_ctx* ctx) {
   for (int b = 0; b < 6 * nh; ++b) ctx->bd_row_live[b] = 1;
   for (int c = 0; c < 22; ++c) if (ctx->ord[6 * N + c] != LVX_DEAD) ctx->bd_row_live[6 * nh + c] = 1;
   for (int p = 0; p < 6; ++p) { ctx->bd_row_live[ctx->nbd + p] = ctx->surf.n > 0; ctx->bd_row_live[ctx->nbd + 6 + p] = ctx->cs.n > 0; }
+  // ---- deterministic mode: colours of chunks with pairwise disjoint knot ranges; one replica of the dense accumulators per workgroup ----
+  ctx->nrep = LVX_NREP;
+  for (auto& v : ctx->det_col) v.clear();
+  if (ctx->sw.deterministic) {
+    int need = std::max(LVX_NREP, (ctx->rep.n + 63) / 64);
+    for (size_t q = 0; q + 1 < ctx->det_cross_col.size(); ++q) need = std::max(need, ctx->det_cross_col[q + 1] - ctx->det_cross_col[q]);
+    for (int slot : {LVX_FAM_GYRO, LVX_FAM_SURFEL, LVX_FAM_CAMSURF, LVX_FAM_REPROJ, LVX_FAM_PRIOR}) {
+      const int nch = ctx->n_chunk[slot];
+      if (nch <= 0 || (int)ctx->h_chunk_k0[slot].size() != nch) continue;
+      const int span = ctx->chunk_r[slot] + 5;
+      std::vector<std::vector<uint8_t>> occ; std::vector<std::vector<int>> members;
+      for (int c = 0; c < nch; ++c) {
+        if (ctx->h_chunk_rows[slot][c] <= 0) continue;
+        const int lo = std::max(0, ctx->h_chunk_k0[slot][c] - 1), hi = std::min(N, ctx->h_chunk_k0[slot][c] - 1 + span);
+        size_t col = 0;
+        for (; col < occ.size(); ++col) { bool hit = false; for (int k = lo; k < hi && !hit; ++k) hit = occ[col][k] != 0; if (!hit) break; }
+        if (col == occ.size()) { occ.emplace_back((size_t)N, (uint8_t)0); members.emplace_back(); }
+        for (int k = lo; k < hi; ++k) occ[col][k] = 1;
+        members[col].push_back(c);
+      }
+      std::vector<int> list; ctx->det_col[slot].push_back(0);
+      for (auto& m : members) { list.insert(list.end(), m.begin(), m.end()); ctx->det_col[slot].push_back((int)list.size()); }
+      if (list.empty()) { ctx->det_col[slot].clear(); continue; }
+      if ((rc = upload_tmp(ctx, ctx->d_det_list[slot], list.data(), list.size() * 4))) return rc;
+      need = std::max(need, nch);
+    }
+    if (need > (1 << 16)) return fail(ctx, LVX_E_STATE, "deterministic mode: more than 65536 workgroups per launch (one replica of the dense accumulators each)");
+    ctx->nrep = need;
+  }
   // ---- buffers ----
   if ((rc = upload_tmp(ctx, ctx->d_ord, ctx->ord.data(), ctx->ord.size() * 4))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_Hb, (size_t)std::max(ctx->nb, 1) * (ctx->bw + 1) * 8 + 16))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_gb, (size_t)std::max(ctx->nb, 1) * 8 + 16))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_Bd, (size_t)ctx->nbd_ext * std::max(ctx->nb, 1) * 8 + 16))) return rc;
-  if ((rc = dev_alloc(ctx, ctx->d_C, (size_t)LVX_NREP * ctx->nbd_ext * ctx->nbd_ext * 8 + 16))) return rc;
-  if ((rc = dev_alloc(ctx, ctx->d_gc, (size_t)LVX_NREP * ctx->nbd_ext * 8 + 16))) return rc;   // + 16 each: k_clear works in 16-byte words
+  if ((rc = dev_alloc(ctx, ctx->d_C, (size_t)ctx->nrep * ctx->nbd_ext * ctx->nbd_ext * 8 + 16))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_gc, (size_t)ctx->nrep * ctx->nbd_ext * 8 + 16))) return rc;   // + 16 each: k_clear works in 16-byte words
   // the per-pass clear is structural (k_clear): what it never touches must be zero from the start
   LVX_HIP(ctx, hipMemsetAsync(ctx->d_Hb.p, 0, ctx->d_Hb.bytes, ctx->stream));
   LVX_HIP(ctx, hipMemsetAsync(ctx->d_Bd.p, 0, ctx->d_Bd.bytes, ctx->stream));
   LVX_HIP(ctx, hipMemsetAsync(ctx->d_lmH.p, 0, ctx->d_lmH.bytes, ctx->stream));
   if ((rc = dev_alloc(ctx, ctx->d_hubs, 2 * sizeof(HubShared)))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_pre, (size_t)std::max(N, 1) * sizeof(So3Pre)))) return rc;
-  if ((rc = dev_alloc(ctx, ctx->d_cost, LVX_NREP * 8))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_cost, (size_t)ctx->nrep * 8))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_err, 16))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_state, (size_t)lvx_state_size(ctx) * 8))) return rc;
   auto range = [](int a, int b) { std::vector<int> v; for (int i = a; i < b; ++i) v.push_back(i); return v; };
@@ -1685,7 +1737,7 @@ DevCommon make_common(lvx_ctx* ctx, const double* state_d, uint32_t what) {
   cm.Hb = (double*)ctx->d_Hb.p; cm.gb = (double*)ctx->d_gb.p; cm.Bd = (double*)ctx->d_Bd.p; cm.C = (double*)ctx->d_C.p; cm.gc = (double*)ctx->d_gc.p;
   cm.cost = (double*)ctx->d_cost.p; cm.err = (int*)ctx->d_err.p;
   cm.lmH = (double*)ctx->d_lmH.p; cm.lm_p0 = (const int*)ctx->d_lm_p0.p; cm.lm_wl = ctx->lm_wl; cm.lm_ls = ctx->lm_ls;
-  cm.hub_lo = 0; cm.hub_hi = ctx->nb;
+  cm.hub_lo = 0; cm.hub_hi = ctx->nb; cm.nrep = ctx->nrep;
   cm.residuals = nullptr; cm.jcols = nullptr; cm.jvals = nullptr;
   return cm;
 }
@@ -1782,7 +1834,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
       ClearList cl{};
       BandClear bc{};
       auto add = [&](void* p, size_t bytes) { if (cl.n < 16) { cl.p[cl.n] = (uint4*)p; cl.words[cl.n] = (bytes + 15) / 16; cl.n++; } };
-      add(cm.cost, LVX_NREP * 8); add(cm.err, 16);
+      add(cm.cost, (size_t)ctx->nrep * 8); add(cm.err, 16);
       if (what & LVX_EVAL_NORMAL_EQ) {
         const size_t nb1 = (size_t)std::max(ctx->nb, 1);
         if (ctx->sw.clear_all || ctx->nb == 0) add(cm.Hb, nb1 * (ctx->bw + 1) * 8);
@@ -1801,7 +1853,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
           add(cm.Bd + (size_t)b0 * nb1, (size_t)(b1 - b0) * nb1 * 8);
           b0 = b1;
         }
-        add(cm.C, (size_t)LVX_NREP * ctx->nbd_ext * ctx->nbd_ext * 8); add(cm.gc, (size_t)LVX_NREP * ctx->nbd_ext * 8);
+        add(cm.C, (size_t)ctx->nrep * ctx->nbd_ext * ctx->nbd_ext * 8); add(cm.gc, (size_t)ctx->nrep * ctx->nbd_ext * 8);
         const bool rep_fast = fast && !(!(ctx->locks & LVX_LOCK_CAM_TAU)) && !ctx->sw.reproj_legacy && ctx->rep_groups > 0;   // k_reproj_lmrows stores whole rows: nothing to clear
         if (ctx->L > 0 && ctx->rep.n > 0 && !(ctx->locks & LVX_LOCK_LANDMARKS) && !rep_fast) add(cm.lmH, (size_t)ctx->L * ctx->lm_ls * 8);
       }
@@ -1819,13 +1871,14 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     // -> observation pass -> fold  stays on the caller's stream and only the kernels that run NEXT to it (gyroscope, accelerometer,
     // reference pass) fork off; they finish before the observation pass does, so the join is already satisfied when the chain gets there.
     const lvx::Switches& sw = ctx->sw;
-    const bool staged = sw.sched == 2 && !sw.serial;
+    const bool det = sw.deterministic != 0;   // fixed order of every addition: one stream, coloured launches, one wavefront per workgroup
+    const bool staged = sw.sched == 2 && !sw.serial && !det;
     hipStream_t s_imu = ctx->fam_stream[0], s_acc = ctx->fam_stream[1], s_surf = staged ? st : ctx->fam_stream[2], s_rep = staged ? st : ctx->fam_stream[3];
     // one side stream (gyroscope, then accelerometer) next to the chain (Jacobian, observation pass, reference pass): both ends finish
     // together and one fan-out / fan-in less than with a stream per IMU kernel (-1.5 % per pass); LVX_IMU_TWO_STREAMS=1 restores that
     const bool one_side = !sw.imu_two_streams;
     if (one_side) s_acc = s_imu;
-    if (sw.serial) s_imu = s_acc = s_surf = s_rep = st;   // profiling aid: solo kernel durations
+    if (sw.serial || det) s_imu = s_acc = s_surf = s_rep = st;   // profiling aid: solo kernel durations
     const hipStream_t side[4] = {s_imu, s_acc, s_surf, s_rep};
     auto first_use = [&](int k) { for (int j = 0; j < k; ++j) if (side[j] == side[k]) return false; return side[k] != st; };   // each side stream forks / joins once
     // staged: the side stream's first operation is its wait for the LiDAR stage (ev_join[2]) — that is its fork; an event record on the
@@ -1839,8 +1892,14 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     do {                                                                                                                                     \
       const size_t lds_ = mfma_lds_bytes<FT>(ctx->chunk_r[chunk_slot]);                                                                      \
       LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_family_mfma<FT, OCCV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));       \
+      if (det && ctx->det_col[chunk_slot].size() > 1) {   /* colour after colour: no two workgroups of a launch touch the same knots */            \
+        const std::vector<int>& dc_ = ctx->det_col[chunk_slot];                                                                              \
+        for (size_t q_ = 0; q_ + 1 < dc_.size(); ++q_)                                                                                       \
+          hipLaunchKernelGGL((k_family_mfma<FT, OCCV>), dim3(dc_[q_ + 1] - dc_[q_]), dim3(256), lds_, stream, fam_obj, cm, (const int*)ctx->d_chunk[chunk_slot].p, (long long)(row0v), \
+                             ctx->chunk_r[chunk_slot], ctx->chunk_var[chunk_slot] ? ctx->n_chunk[chunk_slot] : 0, (const int*)ctx->d_det_list[chunk_slot].p + dc_[q_]); \
+      } else                                                                                                                                 \
       hipLaunchKernelGGL((k_family_mfma<FT, OCCV>), dim3(ctx->n_chunk[chunk_slot]), dim3(256), lds_, stream, fam_obj, cm, (const int*)ctx->d_chunk[chunk_slot].p, (long long)(row0v), \
-                         ctx->chunk_r[chunk_slot], ctx->chunk_var[chunk_slot] ? ctx->n_chunk[chunk_slot] : 0);                                \
+                         ctx->chunk_r[chunk_slot], ctx->chunk_var[chunk_slot] ? ctx->n_chunk[chunk_slot] : 0, (const int*)nullptr);          \
     } while (0)
   #define LVX_LAUNCH_MFMA(FT, fam_obj, chunk_slot, stream, row0v)                                                                               \
     do { if ((occ_env ? occ_env : (int)FT::OCC) == 1) LVX_LAUNCH_MFMA1(FT, 1, fam_obj, chunk_slot, stream, row0v); else LVX_LAUNCH_MFMA1(FT, 2, fam_obj, chunk_slot, stream, row0v); } while (0)
@@ -1931,8 +1990,14 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
               { ProfScope ps(ctx, LVX_KERNEL_REP_REF, s_ref); LVX_LAUNCH_MFMA1(RepSideAcc<0>, 1, rb2, LVX_FAM_PRIOR, s_ref, ctx->fam_row0[4]); }
               if (ctx->rep_groups > 0) {
                 const int* gt = (const int*)ctx->d_repB[2].p;
-                const RepCross rx{jac, r.lm, gt, gt + ctx->rep_groups + 1, ctx->rep_groups, ctx->sw.cross_dbg, (double*)ctx->d_repT.p};
+                RepCross rx{jac, r.lm, gt, gt + ctx->rep_groups + 1, ctx->rep_groups, ctx->sw.cross_dbg, (double*)ctx->d_repT.p, nullptr};
                 { ProfScope ps(ctx, LVX_KERNEL_REP_CROSS, s_ref);
+                  if (det && ctx->det_cross_col.size() > 1) {
+                    for (size_t q = 0; q + 1 < ctx->det_cross_col.size(); ++q) {
+                      rx.det_list = (const int*)ctx->d_det_cross.p + ctx->det_cross_col[q];
+                      hipLaunchKernelGGL(k_reproj_cross, dim3((unsigned)(ctx->det_cross_col[q + 1] - ctx->det_cross_col[q])), dim3(256), 0, s_ref, rx, cm);
+                    }
+                  } else
                   hipLaunchKernelGGL(k_reproj_cross, dim3((unsigned)std::min((ctx->rep_groups + 3) / 4, 256 * 8)), dim3(256), 0, s_ref, rx, cm); }
                 if (ctx->L > 0 && !(ctx->locks & LVX_LOCK_LANDMARKS)) {
                   const int* lp = (const int*)ctx->d_repB[3].p;
@@ -1983,11 +2048,11 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
       LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_fold_all, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(k_fold_all, dim3((unsigned)(nrep + nrows)), dim3(256), lds, st, cm, nrep, (fast_surf ? 1 : 0) | (fast_cs ? 2 : 0));
     } else {
-    if (fold_fast && !sw.serial && !sw.fold_inline) LVX_HIP(ctx, hipEventRecord(ctx->ev_jac, st));   // st has joined every family stream here
+    if (fold_fast && !sw.serial && !sw.fold_inline && !det) LVX_HIP(ctx, hipEventRecord(ctx->ev_jac, st));   // st has joined every family stream here
     hipLaunchKernelGGL(k_fold_replicas, dim3((unsigned)((ctx->nbd_ext * ctx->nbd_ext + 255) / 256)), dim3(256), 0, st, cm);
     if (fold_fast) {
       // the border-row fold (Bd, streaming) and the dense fold (C, g_c; one workgroup, behind k_fold_replicas) touch disjoint buffers: side by side
-      hipStream_t s_side = (sw.serial || sw.fold_inline) ? st : ctx->fam_stream[0];
+      hipStream_t s_side = (sw.serial || sw.fold_inline || det) ? st : ctx->fam_stream[0];
       if (s_side != st) LVX_HIP(ctx, hipStreamWaitEvent(s_side, ctx->ev_jac, 0));
       for (int set = 0; set < 2; ++set) if (ctx->nb > 0 && ((set == 0 && fast_surf) || (set == 1 && fast_cs)))
         hipLaunchKernelGGL(k_fold_border_rows, dim3((unsigned)((ctx->nb + 255) / 256)), dim3(256), 0, s_side, cm, set, (set == 0 || !fast_surf) ? 1 : 0);
@@ -2060,6 +2125,17 @@ int check_last_eval(lvx_ctx* c) {
   return LVX_OK;
 }
 
+// order-independent checksum of a buffer's bit patterns: sum over i of bits[i] * (2 i + 1) mod 2^64 (integer atomics)
+__global__ void k_checksum(const unsigned long long* p, size_t n, unsigned long long* out) {
+  unsigned long long acc = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned long long b = p[i];
+    if (b == 0x8000000000000000ull) b = 0;   // -0.0 == +0.0
+    acc += b * (2ull * i + 1ull);
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
 __global__ void k_export_tail(const double* cost, const int* err, double* out) { out[0] = cost[0]; out[1] = (double)err[0]; }
 
 }  // namespace lvx
@@ -2108,7 +2184,8 @@ void lvx_destroy(lvx_ctx* c) {
   if (c->d_hubs.p) (void)hipFree(c->d_hubs.p);
   if (c->d_pre.p) (void)hipFree(c->d_pre.p);
   if (c->d_colfull.p) (void)hipFree(c->d_colfull.p);
-  for (DevBuf* b : {&c->d_lm_grp, &c->d_lmH, &c->d_lm_p0, &c->d_Hr, &c->d_Br, &c->d_red, &c->d_repT}) if (b->p) (void)hipFree(b->p);
+  for (auto& b : c->d_det_list) if (b.p) (void)hipFree(b.p);
+  for (DevBuf* b : {&c->d_chk, &c->d_det_cross, &c->d_lm_grp, &c->d_lmH, &c->d_lm_p0, &c->d_Hr, &c->d_Br, &c->d_red, &c->d_repT}) if (b->p) (void)hipFree(b->p);
   for (DevBuf* b : {&c->vox.misc, &c->vox.keys, &c->vox.vals, &c->vox.runs, &c->vox.cells, &c->vox.tmp, &c->vox.leaf_i, &c->vox.leaf_d, &c->vox.leaf_f}) if (b->p) (void)hipFree(b->p);
   (void)lvx_rccl_finalize(c);
   if (c->d_comm.p) (void)hipFree(c->d_comm.p);
@@ -2249,6 +2326,23 @@ int lvx_export_border_d(lvx_ctx* c, double* out_d) {
   // rank's sums are incomplete — without a host synchronisation here
   hipLaunchKernelGGL(k_export_tail, dim3(1), dim3(1), 0, c->stream, (const double*)c->d_cost.p, (const int*)c->d_err.p, out_d + n2 + c->nbd_ext);
   LVX_HIP(c, hipGetLastError());
+  return LVX_OK;
+}
+int lvx_normal_eq_checksum(lvx_ctx* c, uint64_t out[6]) {
+  if (!c || !out) return LVX_E_ARG;
+  if (!(c->last_what & LVX_EVAL_NORMAL_EQ)) return fail(c, LVX_E_STATE, "last evaluation did not request LVX_EVAL_NORMAL_EQ");
+  LVX_HIP(c, hipSetDevice(c->device));
+  int rc = check_last_eval(c); if (rc) return rc;
+  if ((rc = dev_alloc(c, c->d_chk, 64))) return rc;
+  LVX_HIP(c, hipMemsetAsync(c->d_chk.p, 0, 48, c->stream));
+  const size_t nb1 = (size_t)std::max(c->nb, 1);
+  const bool lm = c->L > 0 && c->rep.n > 0 && !(c->locks & LVX_LOCK_LANDMARKS);
+  const void* bufs[6] = {c->d_Hb.p, c->d_gb.p, c->d_Bd.p, c->d_C.p, c->d_gc.p, lm ? c->d_lmH.p : nullptr};
+  const size_t cnt[6] = {nb1 * (c->bw + 1), nb1, (size_t)c->nbd * nb1, (size_t)c->nbd_ext * c->nbd_ext, (size_t)c->nbd_ext, lm ? (size_t)c->L * c->lm_ls : 0};
+  for (int i = 0; i < 6; ++i) if (bufs[i] && cnt[i])
+    hipLaunchKernelGGL(k_checksum, dim3((unsigned)std::min<size_t>((cnt[i] + 255) / 256, 4096)), dim3(256), 0, c->stream, (const unsigned long long*)bufs[i], cnt[i], (unsigned long long*)c->d_chk.p + i);
+  LVX_HIP(c, hipMemcpyAsync(out, c->d_chk.p, 48, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
   return LVX_OK;
 }
 int lvx_set_state(lvx_ctx* c, const double* state) {

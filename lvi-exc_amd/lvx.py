@@ -231,6 +231,11 @@ class Context:
     def export_border(self, device_ptr):
         self._ck(self._l.lvx_export_border_d(self._h, C.c_void_p(device_ptr)))
 
+    def normal_eq_checksum(self):
+        out = (C.c_uint64 * 6)()
+        self._ck(self._l.lvx_normal_eq_checksum(self._h, out))
+        return tuple(int(v) for v in out)
+
     def synchronize(self):
         self._ck(self._l.lvx_synchronize(self._h))
 
