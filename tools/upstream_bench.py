@@ -24,10 +24,18 @@ if __name__ == "__main__":
     cloud = synth.make_voxel_cloud(seed=2, n=100_000)
     tv = lvx.upstream_bench(ctx, "voxel_build", (cloud, 0.5), reps)
     tl = lvx.upstream_bench(ctx, "voxel_lookup7", synth.rigid_move(cloud), reps)
+    pts = synth.make_vlp16_sweep(seed=1)
+    import time
+    lvx.scan_register(ctx, pts, 16, 0.3)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        lvx.scan_register(ctx, pts, 16, 0.3)
+    ts = (time.perf_counter() - t0) / reps
     n = scan.shape[0] * scan.shape[1]
     print("surfel_assoc 1 scan  : %.1f us  %.0f Mpts/s" % (1e6 * t1, n / t1 / 1e6))
     print("surfel_assoc 16 scans: %.1f us  %.0f Mpts/s" % (1e6 * t16, 16 * n / t16 / 1e6))
     print("surfel_assoc 64 scans: %.1f us  %.0f Mpts/s" % (1e6 * t64, 64 * n / t64 / 1e6))
     print("voxel_build 100k     : %.1f us  %.0f Mpts/s" % (1e6 * tv, len(cloud) / tv / 1e6))
     print("voxel_lookup7 100k   : %.1f us  %.0f Mq/s" % (1e6 * tl, len(cloud) / tl / 1e6))
+    print("scan_register 28.8k  : %.1f us per sweep (host buffers in and out)" % (1e6 * ts))
     ctx.close()
