@@ -1129,6 +1129,277 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fused IMU kernel: gyroscope + accelerometer blocks of a sample in ONE workgroup pass.  Both residuals evaluate the same SO3 spline at the same
+// time, touch the same 4 knots and flush into the same band entries (the gyroscope's are a subset of the accelerometer's): one pose evaluation,
+// one set of LDS accumulators, one flush, and half the workgroup rounds of the two separate kernels (each of them runs one 4-wavefront workgroup
+// per CU).  Panel-major assembly as in k_family_mfma, once per geometry:
+//   G: 3 rows x [12 rotation columns | b_g (3) | r]  = 16 columns, one MFMA tile;     A: 3 rows x [24 knot columns | roll pitch b_a (5) | r] = 30, three tile pairs.
+// Shared global list: [roll, pitch, b_a (3), b_g (3)] = tangent scalars 6 N + 0 .. 7.
+// ---------------------------------------------------------------------------------------------------------
+struct ImuG { enum { NR = 3, NCJ = GYRO_NC, NK = 12, NG = 3, KPK = 3, LVO = 3, GL = 32, GOFF = 5, NKL = 12, NCL = 16, NT = 1, NTP = 1, LDP = 17, PR = 96 }; };
+struct ImuA { enum { NR = 3, NCJ = ACC_NC, NK = 24, NG = 5, KPK = 6, LVO = 0, GL = 16, GOFF = 0, NKL = 24, NCL = 30, NT = 2, NTP = 3, LDP = 33, PR = 48 }; };
+#define IMU_NGA 8
+struct ImuAccLds { double* band; double* bd; double* gg; double* gk; double* gG; int lv; };
+template <class PG> __device__ __forceinline__ int imu_cls(int lc) {
+  return lc < PG::NKL ? 6 * (lc / PG::KPK) + PG::LVO + lc % PG::KPK : (lc < PG::NKL + PG::NG ? -1 - (PG::GOFF + lc - PG::NKL) : (lc == PG::NKL + PG::NG ? -100 : -200));
+}
+template <class PG> __device__ __forceinline__ void imu_build_rtab(int* rtab, int lane, const double* sm, const ImuAccLds& A) {
+  int t = 0;
+#pragma unroll
+  for (int ci = 0; ci < PG::NT; ++ci)
+#pragma unroll
+    for (int cj = ci; cj < PG::NT; ++cj, ++t)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int row = ci * 16 + (lane >> 4) + 4 * v, col = cj * 16 + (lane & 15);
+        int ent = -1;
+        if (!(ci == cj && col < row)) {
+          const int ra = imu_cls<PG>(row), cb = imu_cls<PG>(col);
+          if (ra >= 0) {
+            if (cb >= 0) { const int d = cb - ra; if (d >= 0 && d < ACC_BW) ent = ((int)(A.band - sm) + ra * ACC_BW + d) | (2 << 16) | (cb << 18); }
+            else if (cb > -100) ent = ((int)(A.bd - sm) + (-1 - cb) * A.lv + ra) | (1 << 16) | (ra << 18);
+            else if (cb == -100) ent = ((int)(A.gk - sm) + ra) | (1 << 16) | (ra << 18);
+          } else if (ra > -100) {
+            if (cb > -100 && cb < 0) ent = (int)(A.gg - sm) + (-1 - ra) * IMU_NGA + (-1 - cb);
+            else if (cb == -100) ent = (int)(A.gG - sm) + (-1 - ra);
+          }
+        }
+        rtab[t * 4 + v] = ent;
+      }
+}
+// rows of this wavefront's 64 lanes -> panel by panel -> windows (runs of equal knot interval) -> MFMA -> LDS accumulators
+template <class PG> __device__ __forceinline__ void imu_assemble(double* sm, double* P, const int* rtab, bool valid, int key, int k_lo, int acc_lv, const double* r, const double (*J)[PG::NCJ], int lane) {
+  constexpr int NR = PG::NR, NT = PG::NT, LDP = PG::LDP, PR = PG::PR, GL = PG::GL;
+  const unsigned long long vm = __ballot(valid);
+  for (int g0 = 0; g0 < 64; g0 += GL) {
+    const unsigned long long pmask = ((1ull << GL) - 1ull) << g0;
+    unsigned long long rem = vm & pmask;
+    if (!rem) continue;
+    if (lane >= g0 && lane < g0 + GL) {
+      const int li = lane - g0;
+#pragma unroll
+      for (int a = 0; a < NR; ++a) {
+        double* prow = P + (li * NR + a) * LDP;
+#pragma unroll
+        for (int c = 0; c < PG::NK + PG::NG; ++c) prow[c] = valid ? J[a][c] : 0.0;
+        prow[PG::NK + PG::NG] = valid ? r[a] : 0.0;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    while (rem) {
+      const int l0 = __ffsll((long long)rem) - 1;
+      const int kw = __builtin_amdgcn_readfirstlane(__shfl(key, l0));
+      const unsigned long long wm = __ballot(valid && key == kw) & pmask;
+      rem &= ~wm;
+      const int lhi = 63 - __clzll((long long)wm);
+      const int wb = (kw - k_lo) * 6;
+      const int r_lo = (l0 - g0) * NR, r_hi = (lhi - g0 + 1) * NR;
+      const unsigned long long wsh = wm >> g0;
+      const bool contig = __popcll(wm) == lhi - l0 + 1;
+      d4 D[PG::NTP];
+#pragma unroll
+      for (int t = 0; t < PG::NTP; ++t) D[t] = d4{0.0, 0.0, 0.0, 0.0};
+      const int nks = (r_hi - r_lo + 3) >> 2;
+      auto trip = [&](int ks, auto UC) {
+        constexpr int U = decltype(UC)::value;
+        double f[U][NT];
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+          const int rr = r_lo + 4 * (ks + q) + (lane >> 4);
+          bool mine = rr < r_hi;
+          if (!contig) mine = mine && ((wsh >> (rr / NR)) & 1ull);
+          const double* src = P + min(rr, PR - 1) * LDP + (lane & 15);
+#pragma unroll
+          for (int c = 0; c < NT; ++c) { const double x = src[c * 16]; f[q][c] = mine ? x : 0.0; }
+        }
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+          int t = 0;
+#pragma unroll
+          for (int ci = 0; ci < NT; ++ci)
+#pragma unroll
+            for (int cj = ci; cj < NT; ++cj, ++t) D[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[q][ci], f[q][cj], D[t], 0, 0, 0);
+        }
+      };
+      int ks = 0;
+      for (; ks + 6 <= nks; ks += 6) trip(ks, std::integral_constant<int, 6>{});
+      for (; ks < nks; ks += 2) trip(ks, std::integral_constant<int, 2>{});
+      const int wbB = wb * ACC_BW;
+#pragma unroll
+      for (int t = 0; t < PG::NTP; ++t)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int te = rtab[t * 4 + v];
+          const double val = D[t][v];
+          if (te < 0 || val == 0.0 || wb + (te >> 18) >= acc_lv) continue;
+          const int m = (te >> 16) & 3;
+          atomicAdd(&sm[(te & 0xffff) + (m == 2 ? wbB : (m == 1 ? wb : 0))], val);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+struct ImuFused { int n; const double* t; const double* gyro; const double* acc; const int* perm; double w_gyro, w_acc; };
+static size_t imu_fused_lds_bytes(int cr) {
+  const int LV = (cr + 5) * 6;
+  const int pan = std::max((int)ImuG::PR * (int)ImuG::LDP, (int)ImuA::PR * (int)ImuA::LDP);
+  return (size_t)(LV * ACC_BW + IMU_NGA * LV + IMU_NGA * IMU_NGA + LV + IMU_NGA + 4 * pan) * 8 + (size_t)(cr + 4) * sizeof(So3Pre) + (size_t)(LV + IMU_NGA) * 4 + 64;
+}
+__global__ __launch_bounds__(256, 1) void k_imu_mfma(ImuFused fam, DevCommon cm, const int* __restrict__ chunk_off, long long row0_g, long long row0_a, int CR, const int* __restrict__ det_list) {
+  constexpr int PAN = (ImuG::PR * ImuG::LDP > ImuA::PR * ImuA::LDP) ? ImuG::PR * ImuG::LDP : ImuA::PR * ImuA::LDP;
+  const int ACC_LV = (CR + 5) * 6;
+  extern __shared__ double sm[];
+  ImuAccLds A;
+  A.band = sm; A.bd = A.band + ACC_LV * ACC_BW; A.gg = A.bd + IMU_NGA * ACC_LV; A.gk = A.gg + IMU_NGA * IMU_NGA; A.gG = A.gk + ACC_LV; A.lv = ACC_LV;
+  double* panels = A.gG + IMU_NGA;
+  So3Pre* pre_tab = (So3Pre*)(panels + 4 * PAN);
+  int* kpos = (int*)(pre_tab + (CR + 4));
+  int* gpos = kpos + ACC_LV;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int ch = det_list ? det_list[blockIdx.x] : blockIdx.x;
+  const int nwv = det_list ? 1 : 4;
+  const int m0 = chunk_off[ch], m1 = chunk_off[ch + 1];
+  if (m0 >= m1) return;
+  const int k_lo = ch * CR - 1;
+  const bool want_ne = (cm.what & LVX_EVAL_NORMAL_EQ) != 0;
+  for (int e = tid; e < ACC_LV * ACC_BW + IMU_NGA * ACC_LV + IMU_NGA * IMU_NGA + ACC_LV + IMU_NGA + 4 * PAN; e += 256) sm[e] = 0.0;
+  for (int e = tid; e < ACC_LV; e += 256) { const int k = k_lo + e / 6; kpos[e] = (k >= 0 && k < cm.N) ? cm.ord[6 * k + e % 6] : LVX_DEAD; }
+  if (tid < IMU_NGA) gpos[tid] = cm.ord[6 * cm.N + tid];
+  if (tid < CR + 4) {
+    const int ka = k_lo + tid;
+    if (ka >= 0 && ka + 1 < cm.N) pre_tab[tid] = cm.pre[ka];
+    else { pre_tab[tid].Om = mk(0, 0, 0); pre_tab[tid].on = 0.0; pre_tab[tid].Jri = m3_identity(); pre_tab[tid].c3 = 1.0 / 12.0; pre_tab[tid].ok = 1; }
+  }
+  const SplineRef sp{cm.t0, cm.dt, cm.N, cm.state, cm.state + 3 * (size_t)cm.N};
+  const Cal cal = load_cal(cm);
+  double* P = panels + wv * PAN;
+  const int rep = ch % cm.nrep;
+  int rtg[ImuG::NTP * 4], rta[ImuA::NTP * 4];
+  imu_build_rtab<ImuG>(rtg, lane, sm, A);
+  imu_build_rtab<ImuA>(rta, lane, sm, A);
+  double mycost = 0.0;
+  __syncthreads();
+  for (int base = wv < nwv ? m0 + wv * 64 : m1; base < m1; base += nwv * 64) {
+    const int si = base + lane;
+    const bool in = si < m1;
+    int key = -1;
+    bool valid = false;
+    So3Eval e;
+    KnotRef k;
+    if (in) {
+      int status = RES_OK;
+      if (!knot_lookup(sp.t0, sp.dt, sp.n, fam.t[si], fam.t[si] + cal.imu.tau, &k)) status = RES_RANGE;
+      else {
+        key = k.i0;
+        const So3Pre* pre = (k.i0 >= k_lo && k.i0 + 2 < k_lo + CR + 4) ? pre_tab + (k.i0 - k_lo) : nullptr;
+        if (!pre) status = RES_OUTSIDE;
+        else {
+          quat c[4]; load_so3_cp(sp, k.i0, c);
+          const int bad = so3_eval_pre<true, true>(c, pre, k.u, sp.dt, &e);
+          if (bad) status = (bad & 1) ? RES_NONUNIT : RES_OUTSIDE;
+        }
+      }
+      valid = status == RES_OK;
+      if (valid && (key < k_lo || key - k_lo > CR + 1)) { valid = false; atomicOr(cm.err, LVX_ERR_FALLBACK); }
+      else if (!valid) atomicOr(cm.err, status);
+    }
+    {   // gyroscope block (gyro_residual, lvx_resid.h)
+      double r[3], J[3][GYRO_NC];
+      if (valid) {
+        const v3 wm = load_v3(fam.gyro + 3 * (size_t)si);
+        const v3 pred = e.w_body + cal.imu.bg;
+        const double w = fam.w_gyro;
+        r[0] = w * (wm.x - pred.x); r[1] = w * (wm.y - pred.y); r[2] = w * (wm.z - pred.z);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) J[a][3 * kk + b] = -w * e.dw[kk].a[3 * a + b];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) J[a][12 + b] = (a == b) ? -w : 0.0;
+        mycost += 0.5 * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        if (cm.residuals) { const long long orow = row0_g + (long long)fam.perm[si] * 3; cm.residuals[orow] = r[0]; cm.residuals[orow + 1] = r[1]; cm.residuals[orow + 2] = r[2]; }
+      }
+      if (want_ne) imu_assemble<ImuG>(sm, P, rtg, valid, key, k_lo, ACC_LV, r, J, lane);
+    }
+    {   // accelerometer block (accel_residual, lvx_resid.h)
+      double r[3], J[3][ACC_NC];
+      if (valid) {
+        R3Basis b; r3_basis(k.u, sp.dt, &b);
+        v3 acc = mk(0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = acc + b.Ba[j] * load_v3(sp.r3 + 3 * (k.i0 + j));
+        const v3 am = load_v3(fam.acc + 3 * (size_t)si);
+        const double w = fam.w_acc;
+        const double G = -9.79;   // imu.h:25
+        const double cr = cos(cal.imu.roll), sr = sin(cal.imu.roll), cp = cos(cal.imu.pitch), sp_ = sin(cal.imu.pitch);
+        const v3 g = mk(-sp_ * cr * G, sr * G, -cr * cp * G);
+        const v3 y = acc + g;
+        const v3 yb = qrot_inv(e.q, y);
+        const v3 pred = yb + cal.imu.ba;
+        r[0] = w * (am.x - pred.x); r[1] = w * (am.y - pred.y); r[2] = w * (am.z - pred.z);
+        const m3 Rt = transpose(rotmat(e.q));
+        const m3 S = skew(yb);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const m3 Mx = S * e.dxi[kk];
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb) { J[a][6 * kk + bb] = -w * b.Ba[kk] * Rt.a[3 * a + bb]; J[a][6 * kk + 3 + bb] = -w * Mx.a[3 * a + bb]; }
+        }
+        const v3 dg_dr = Rt * mk(sp_ * sr * G, cr * G, sr * cp * G);
+        const v3 dg_dp = Rt * mk(-cp * cr * G, 0.0, cr * sp_ * G);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          J[a][24] = -w * comp(dg_dr, a); J[a][25] = -w * comp(dg_dp, a);
+#pragma unroll
+          for (int bb = 0; bb < 3; ++bb) J[a][26 + bb] = (a == bb) ? -w : 0.0;
+        }
+        mycost += 0.5 * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        if (cm.residuals) { const long long orow = row0_a + (long long)fam.perm[si] * 3; cm.residuals[orow] = r[0]; cm.residuals[orow + 1] = r[1]; cm.residuals[orow + 2] = r[2]; }
+      }
+      if (want_ne) imu_assemble<ImuA>(sm, P, rta, valid, key, k_lo, ACC_LV, r, J, lane);
+    }
+  }
+  mycost = wave_sum(mycost);
+  if (lane == 0) atomicAdd(&cm.cost[rep], mycost);
+  if (!want_ne) return;
+  __syncthreads();
+  for (int e = tid; e < ACC_LV * ACC_BW; e += 256) {
+    const double v = A.band[e];
+    if (v == 0.0) continue;
+    const int la = e / ACC_BW, lb = la + e % ACC_BW;
+    if (lb >= ACC_LV) continue;
+    const int pa = kpos[la], pb = kpos[lb];
+    if (pa == LVX_DEAD || pb == LVX_DEAD) continue;
+    add_H(cm, pa, pb, v, rep);
+  }
+  for (int e = tid; e < IMU_NGA * ACC_LV; e += 256) {
+    const double v = A.bd[e];
+    if (v == 0.0) continue;
+    const int pg = gpos[e / ACC_LV], pk2 = kpos[e % ACC_LV];
+    if (pg == LVX_DEAD || pk2 == LVX_DEAD) continue;
+    add_H(cm, pg, pk2, v, rep);
+  }
+  for (int e = tid; e < IMU_NGA * IMU_NGA; e += 256) {
+    const int ga = e / IMU_NGA, gb2 = e % IMU_NGA;
+    if (gb2 < ga) continue;
+    const double v = A.gg[e];
+    if (v == 0.0 || gpos[ga] == LVX_DEAD || gpos[gb2] == LVX_DEAD) continue;
+    add_H(cm, gpos[ga], gpos[gb2], v, rep);
+  }
+  for (int e = tid; e < ACC_LV; e += 256) { const double v = A.gk[e]; if (v != 0.0 && kpos[e] != LVX_DEAD) add_g(cm, kpos[e], v, rep); }
+  if (tid < IMU_NGA) { const double v = A.gG[tid]; if (v != 0.0 && gpos[tid] != LVX_DEAD) add_g(cm, gpos[tid], v, rep); }
+}
+
 // fold the pseudo-pose rows of the border back onto the hub control points: x_pseudo = M_hub x_hub  =>
 //   Bd[hub] += M^T Bd[pseudo],  C <- (I + E) C (I + E)^T,  g_c[hub] += M^T g_c[pseudo]      (E = M^T placed at [hub rows, pseudo cols])
 // store: this set is the first to fold in this pass — outside [hub_lo, hub_hi) the hub rows were NOT cleared (nothing but the fold writes
@@ -1213,14 +1484,27 @@ __device__ __forceinline__ void fold_border_dense_block(const DevCommon& cm) {
 __global__ __launch_bounds__(256) void k_fold_border_dense(DevCommon cm) { fold_border_dense_block(cm); }
 
 // fold the replicas of the dense border accumulators into replica 0
+// sum of n values with stride `stride` in index order, 16 loads in flight (the replica count is a run-time value since deterministic mode: a plain
+// loop became a chain of dependent loads, 47 us instead of 7)
+__device__ __forceinline__ double strided_sum(const double* p, size_t stride, int n) {
+  double s = 0.0;
+  for (int r0 = 0; r0 < n; r0 += 16) {
+    double v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = r0 + q < n ? p[(size_t)(r0 + q) * stride] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += v[q];
+  }
+  return s;
+}
 __device__ __forceinline__ void fold_replicas_block(const DevCommon& cm, int blk) {
   const int n2 = cm.nbd * cm.nbd;
   const int i = blk * blockDim.x + threadIdx.x;
   if (cm.what & LVX_EVAL_NORMAL_EQ) {
-    if (i < n2) { double s = 0; for (int r = 0; r < cm.nrep; ++r) s += cm.C[(size_t)r * n2 + i]; cm.C[i] = s; }
-    if (i < cm.nbd) { double s = 0; for (int r = 0; r < cm.nrep; ++r) s += cm.gc[(size_t)r * cm.nbd + i]; cm.gc[i] = s; }
+    if (i < n2) cm.C[i] = strided_sum(cm.C + i, (size_t)n2, cm.nrep);
+    if (i < cm.nbd) cm.gc[i] = strided_sum(cm.gc + i, (size_t)cm.nbd, cm.nrep);
   }
-  if (i == 0) { double s = 0; for (int r = 0; r < cm.nrep; ++r) s += cm.cost[r]; cm.cost[0] = s; }
+  if (i == 0) cm.cost[0] = strided_sum(cm.cost, 1, cm.nrep);
 }
 __global__ void k_fold_replicas(DevCommon cm) { fold_replicas_block(cm, (int)blockIdx.x); }
 // The whole fold in one launch (three kernels on two streams cost a fork and a join on the pass's critical path): blocks [0, nrep) sum the
@@ -1251,7 +1535,7 @@ const SwitchName* switch_table(int* count) {
     {"SYNC_NOFENCE", &Switches::sync_nofence, false}, {"CHUNK_R", &Switches::chunk_r, true}, {"CHUNK_R_IMU", &Switches::chunk_r_imu, true},
     {"CHUNK_R_REP", &Switches::chunk_r_rep, true}, {"CHUNK_ROWS", &Switches::chunk_rows, true}, {"REP_ROWS", &Switches::rep_rows, true},
     {"SOLVER_SEQ", &Switches::solver_seq, false}, {"SOLVER_TIMING", &Switches::solver_timing, false}, {"BCR_ROCSOLVER_POTRF", &Switches::bcr_rocsolver_potrf, false},
-    {"BCR_SYRK", &Switches::bcr_syrk, false}, {"DETERMINISTIC", &Switches::deterministic, true}, {"CLEAR_ALL", &Switches::clear_all, false}, {"CROSS_DBG", &Switches::cross_dbg, false}, {"LM_SCHUR_SINGLE", &Switches::lm_schur_single, false},
+    {"BCR_SYRK", &Switches::bcr_syrk, false}, {"DETERMINISTIC", &Switches::deterministic, true}, {"CLEAR_ALL", &Switches::clear_all, false}, {"CROSS_DBG", &Switches::cross_dbg, false}, {"LM_SCHUR_SINGLE", &Switches::lm_schur_single, false}, {"IMU_SPLIT", &Switches::imu_split, false}, {"REF_SIDE", &Switches::ref_side, false},
   };
   *count = (int)(sizeof(tab) / sizeof(tab[0]));
   return tab;
@@ -1888,6 +2172,8 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
       for (int k = 0; k < 4; ++k) if (first_use(k)) LVX_HIP(ctx, hipStreamWaitEvent(side[k], ctx->ev_fork, 0));
     }
     const int occ_env = sw.occ;   // 0: the family's own choice (F::OCC wavefronts per SIMD)
+    const bool imu_fused_on = fast && !sw.imu_legacy && ctx->imu.n > 0 && !(ctx->locks & LVX_LOCK_R3) && !sw.imu_split && !ctx->chunk_var[LVX_FAM_GYRO] && imu_fused_lds_bytes(ctx->chunk_r[LVX_FAM_GYRO]) <= 160 * 1024;
+    const bool ref_side = sw.ref_side == 1 || (sw.ref_side < 0 && imu_fused_on);   // with the fused IMU kernel the side stream is the shorter chain: it takes the reference pass
   #define LVX_LAUNCH_MFMA1(FT, OCCV, fam_obj, chunk_slot, stream, row0v)                                                                        \
     do {                                                                                                                                     \
       const size_t lds_ = mfma_lds_bytes<FT>(ctx->chunk_r[chunk_slot]);                                                                      \
@@ -1908,6 +2194,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     // kernels cannot share a CU and only slow each other down), staged like this, or serial (1.64 ms); staged, the dominant kernel's
     // duration is its solo duration.  LVX_SCHED=0 restores "all concurrent".
     const bool jac_early = !sw.jac_late;   // the (small, register-bound) reprojection Jacobian kernel runs next to the LiDAR kernels: -2.5 % per pass, surfel kernel unaffected
+    bool third_ref = false;
     const int order[5] = {2, 4, 0, 1, 3};   // surfel, cam-surfel, imu, prior, reprojection
     for (int ph = 0; ph < 5; ++ph) {
       if (staged && ph == 2) {               // the other streams start when the LiDAR stream has drained
@@ -1919,7 +2206,20 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
       case 0: {
         const bool imu_fast = fast && !sw.imu_legacy;
         if (ctx->imu.n > 0) {
-          if (imu_fast) {
+          if (imu_fused_on) {   // gyroscope + accelerometer blocks in one kernel
+            const ImuFused f{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, ctx->imu.huber /*w_acc*/};
+            const size_t lds_ = imu_fused_lds_bytes(ctx->chunk_r[LVX_FAM_GYRO]);
+            LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_imu_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
+            ProfScope ps(ctx, LVX_FAM_GYRO, s_imu);
+            if (det && ctx->det_col[LVX_FAM_GYRO].size() > 1) {
+              const std::vector<int>& dc = ctx->det_col[LVX_FAM_GYRO];
+              for (size_t q = 0; q + 1 < dc.size(); ++q)
+                hipLaunchKernelGGL(k_imu_mfma, dim3(dc[q + 1] - dc[q]), dim3(256), lds_, s_imu, f, cm, (const int*)ctx->d_chunk[LVX_FAM_GYRO].p, (long long)ctx->fam_row0[0], (long long)ctx->fam_row0[1],
+                                   ctx->chunk_r[LVX_FAM_GYRO], (const int*)ctx->d_det_list[LVX_FAM_GYRO].p + dc[q]);
+            } else
+            hipLaunchKernelGGL(k_imu_mfma, dim3(ctx->n_chunk[LVX_FAM_GYRO]), dim3(256), lds_, s_imu, f, cm, (const int*)ctx->d_chunk[LVX_FAM_GYRO].p, (long long)ctx->fam_row0[0], (long long)ctx->fam_row0[1],
+                               ctx->chunk_r[LVX_FAM_GYRO], (const int*)nullptr);
+          } else if (imu_fast) {
             GyroAcc g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
             { ProfScope ps(ctx, LVX_FAM_GYRO, s_imu); LVX_LAUNCH_MFMA(GyroAcc, g, LVX_FAM_GYRO, s_imu, ctx->fam_row0[0]); }
             if (!(ctx->locks & LVX_LOCK_R3)) {
@@ -1980,14 +2280,19 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
             if (staged && jac_early && s_rep != s_surf) LVX_HIP(ctx, hipStreamWaitEvent(s_rep, ctx->ev_join[2], 0));
             if (what & LVX_EVAL_NORMAL_EQ) {
               hipStream_t s_ref = (one_side && staged) ? s_rep : s_acc;
-              if (s_ref != s_rep) LVX_HIP(ctx, hipEventRecord(ctx->ev_jac, s_rep));   // an event record on the chain is a bubble: only when another stream waits for it
+              // LVX_REF_SIDE=1: the reference pass (it only reads the materialised rows) behind the IMU kernel on the side stream, the cross terms and the
+              // landmark rows stay on the chain
+              const hipStream_t s_refpass = (sw.ref_side == 2 && staged) ? ctx->fam_stream[1] : ((ref_side && staged && s_acc != s_rep) ? s_acc : s_ref);   // 2: a stream of its own (experiment)
+              third_ref = sw.ref_side == 2 && staged && s_refpass != s_acc;
+              if (s_ref != s_rep || s_refpass != s_rep) LVX_HIP(ctx, hipEventRecord(ctx->ev_jac, s_rep));   // an event record on the chain is a bubble: only when another stream waits for it
               const RepJac jac{Jb, rb, kb, r.n};
               RepSideAcc<1> ra{r.n, jac, 0.0};
               { ProfScope ps(ctx, LVX_KERNEL_REP_OBS, s_rep); LVX_LAUNCH_MFMA1(RepSideAcc<1>, 1, ra, LVX_FAM_REPROJ, s_rep, ctx->fam_row0[4]); }
               // the other two passes only read the materialised rows: they can run next to the observation-side pass, behind the accelerometer kernel
               RepSideAcc<0> rb2{r.n, jac, 0.0};
               if (s_ref != s_rep) LVX_HIP(ctx, hipStreamWaitEvent(s_ref, ctx->ev_jac, 0));
-              { ProfScope ps(ctx, LVX_KERNEL_REP_REF, s_ref); LVX_LAUNCH_MFMA1(RepSideAcc<0>, 1, rb2, LVX_FAM_PRIOR, s_ref, ctx->fam_row0[4]); }
+              if (s_refpass != s_ref) LVX_HIP(ctx, hipStreamWaitEvent(s_refpass, ctx->ev_jac, 0));
+              { ProfScope ps(ctx, LVX_KERNEL_REP_REF, s_refpass); LVX_LAUNCH_MFMA1(RepSideAcc<0>, 1, rb2, LVX_FAM_PRIOR, s_refpass, ctx->fam_row0[4]); }
               if (ctx->rep_groups > 0) {
                 const int* gt = (const int*)ctx->d_repB[2].p;
                 RepCross rx{jac, r.lm, gt, gt + ctx->rep_groups + 1, ctx->rep_groups, ctx->sw.cross_dbg, (double*)ctx->d_repT.p, nullptr};
@@ -2035,6 +2340,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
       } break;
       }
     }
+    if (third_ref) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[1], ctx->fam_stream[1])); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[1], 0)); }
     for (int k = 0; k < 4; ++k) if (first_use(k)) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[k], side[k])); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[k], 0)); }
     { ProfScope ps(ctx, LVX_KERNEL_FOLD);
     const bool fold_fast = (what & LVX_EVAL_NORMAL_EQ) && (fast_surf || fast_cs);

@@ -1,5 +1,4 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_upstream.py tests/test_gpu_pipeline.py -m gpu -q -x 2>&1 | tail -5
-rocprofv3 --kernel-trace -d gpurun_out/up -o kt -- python tools/upstream_bench.py 20 > gpurun_out/up.log 2>&1
-python tools/rocpd_summary.py $(find gpurun_out/up -name "*.db" | head -1) > gpurun_out/up_stats.txt
-grep -v "^W2026\|^E2026" gpurun_out/up.log | tail -7; grep "k_sr_" gpurun_out/up_stats.txt | cut -c1-50,90-150
+for e in "X=1" "LVX_REF_SIDE=2" "X=2" "LVX_REF_SIDE=2"; do
+  echo "== $e"; env $e LVX_BENCH_NOPROF=1 python bench.py --no-secondary --no-cpu-baseline --steps 50 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],4))"
+done
