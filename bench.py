@@ -35,8 +35,8 @@ FP64_PEAK_TFLOPS = 78.6      # MI355X FP64: vector 78.6 TFLOP/s = matrix (v_mfma
 # correction was calibrated on).  Reads: 56 B of row inputs per block (t, point, row-ordered plane) = 56 MB would be the cold figure, the
 # counter sees 33 MB (the rest hits the 256 MB Infinity Cache from the previous pass); writes: the accumulator flushes (one atomic per touched
 # band / border entry per workgroup, 1954 workgroups) — the register-spill scratch of the earlier rounds (232 MB) is gone.
-PMC_TRAFFIC_BYTES = 91.8e6   # a constant copied from the profile named below, not measured by this run
-PMC_SOURCE = "profiles/r01j_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per dispatch)"
+PMC_TRAFFIC_BYTES = {"surfel": 89.3e6}   # constants copied from the profile named below, not measured by this run (filled per kernel by tools/profile_round.sh runs)
+PMC_SOURCE = "profiles/r02a_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per dispatch)"
 BYTES_PER_EVAL = {"imu": 32, "surfel": 60, "reproj": 60}
 FLOPS_PER_EVAL = {"imu": 4e3, "surfel": 9e3, "reproj": 11e3}
 
@@ -152,7 +152,13 @@ def secondary_metrics(ctx, P, lo):
         for _ in range(10):
             lvx.scan_register(ctx, pts, 16, 0.3)
         t = (time.perf_counter() - t0) / 10
-        sec["scan_registration"] = {"ms_per_sweep": 1e3 * t, "points": len(pts), "note": "host buffers in/out (PCIe inclusive), reference budget 100 ms per sweep"}
+        t0 = time.perf_counter(); nrep = 0
+        while time.perf_counter() - t0 < 1.0:
+            O.scan_register(pts, 16, 0.3); nrep += 1
+        tcs = (time.perf_counter() - t0) / nrep
+        sec["scan_registration"] = {"ms_per_sweep": 1e3 * t, "points": len(pts), "Mpts_per_s": len(pts) / t / 1e6, "hbm_frac": 28.0 * len(pts) / t / 1e9 / HBM_PEAK_GBS,
+                                    "cpu": {"ms_per_sweep": 1e3 * tcs, "Mpts_per_s": len(pts) / tcs / 1e6, "cores": 1, "kind": "port", "sample": "%d sweeps (the reference's laserCloudHandler is serial)" % nrep},
+                                    "note": "host buffers in/out (PCIe inclusive), reference budget 100 ms per sweep; 28 B per point algorithmic"}
     except Exception as e:   # noqa: BLE001
         sec["upstream_error"] = str(e)[:200]
     return sec
@@ -168,6 +174,39 @@ def usable_cores():
     except Exception:
         pass
     return max(1, n)
+
+
+class Emitter:
+    """Prints the JSON line exactly once.  The side measurements after the timed region (joint solve over ranks, association all-gather, LM legs)
+    run under a watchdog: a collective that never returns must not cost the headline line — on timeout rank 0 prints what it has and every rank exits."""
+
+    def __init__(self, rank):
+        import threading
+        self.rank, self.out, self.done, self.lock, self.timer = rank, None, False, threading.Lock(), None
+
+    def emit(self):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+            if self.rank == 0 and self.out is not None:
+                print(json.dumps(self.out), flush=True)
+
+    def arm(self, seconds):
+        import threading
+
+        def fire():
+            if self.out is not None:
+                self.out.setdefault("secondary", {})["watchdog"] = "side measurements did not finish within %d s; line emitted by the watchdog" % seconds
+            self.emit()
+            os._exit(0)
+        self.timer = threading.Timer(seconds + (0 if self.rank == 0 else 10), fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
 
 
 def cpu_baseline(P, seconds_budget=20.0):
@@ -262,7 +301,19 @@ def main():
     # live HIP-event timing of the dominant kernel (surfel) over the timed region; the other kernels' durations come from a separate
     # profiled run below (an event pair around every launch costs ~5 % of a pass).  LVX_BENCH_NOPROF=1: no events at all (replayed graph).
     live = not os.environ.get("LVX_BENCH_NOPROF")
-    ctx.set_profiling(live, only=lvx.FAM_SURFEL)
+    # which kernel is time-dominant: a short run with an event pair around every launch (untimed), then the timed region carries events around that kernel only
+    live_k = lvx.FAM_SURFEL
+    if live:
+        ctx.set_profiling(True); ctx.kernel_ms()
+        for _ in range(3):
+            ctx.evaluate_resident(what)
+        ctx.synchronize()
+        ms0, l0 = ctx.kernel_ms()
+        ctx.set_profiling(False)
+        cand = [i for i in range(len(ms0)) if l0[i] and lvx.KERNEL_NAMES[i] not in ("fold", "clear", "solve", "upstream")]
+        if cand:
+            live_k = max(cand, key=lambda i: ms0[i] / l0[i])
+    ctx.set_profiling(live, only=live_k)
     ctx.kernel_ms()
     if world > 1:
         dist.barrier()
@@ -284,33 +335,6 @@ def main():
     cost = ctx.evaluate_resident(lvx.EVAL_COST, want_cost=True)
     if world > 1 and float(red[-1].item()) != 0.0:     # summed device error words of the last step: some rank's sums were incomplete
         raise SystemExit("a rank reported a device-side evaluation error (range / non-unit quaternion / fallback)")
-    joint = None
-    if world > 1 and not args.no_secondary:
-        # side measurement (outside the timed region): LM iterations of the JOINT problem — shared rig extrinsics, one sequence per GPU;
-        # per iteration ONE all-reduce of the 14 x 14 reduced system + a few scalars (lvx_lm_solve_shared)
-        try:
-            import sharded
-            sj = P["state0"].copy()
-            Nk = lo["n_knots"]
-            ext = torch.from_numpy(sj[7 * Nk + 16:7 * Nk + 32].copy()).cuda()
-            dist.broadcast(ext, src=0)                      # the shared extrinsics start from rank 0's guess
-            sj[7 * Nk + 16:7 * Nk + 32] = ext.cpu().numpy()
-            dist.barrier(); torch.cuda.synchronize()
-            tj = time.perf_counter()
-            _, smj = ctx.lm_solve_shared(sj, sharded.dist_all_reduce(dist, torch.device("cuda", local_rank)), max_iterations=3)
-            torch.cuda.synchronize(); dist.barrier()
-            tj = time.perf_counter() - tj
-            joint = {"ms_per_iteration": 1e3 * tj / max(1, smj["iterations"]), "iterations": smj["iterations"], "initial_cost": smj["initial_cost"], "final_cost": smj["final_cost"],
-                     "note": "joint LM over %d sequences with shared extrinsics: evaluate + private elimination per GPU, one 211-double all-reduce + 4 scalar reductions per iteration" % world}
-        except Exception as e:   # noqa: BLE001
-            joint = {"error": str(e)[:300]}
-
-    assoc = None
-    if not args.no_secondary:
-        try:
-            assoc = assoc_metric(ctx, world, rank)      # every rank takes part (all-gather of the flags)
-        except Exception as e:   # noqa: BLE001
-            assoc = {"error": str(e)[:300]}
     blocks = lo["n_blocks"]
     value = blocks * world * args.steps / elapsed / 1e6
     out = {
@@ -322,9 +346,12 @@ def main():
                    "locks": "LIDAR_TAU | CAM_TAU (sensor time offsets constant, everything else free: trajInitFromLVIdata with lvi.yaml's opt_time_offset false)",
                    "tracks": P.get("tracks", "orb"), "parallelism": "sequence-per-gpu x%d" % world, "cost": cost},
     }
+    em = Emitter(rank)
+    em.out = out
+    em.arm(300)   # everything below is a side measurement: it must not be able to cost the line
     if rank == 0:
-        k = lvx.FAM_SURFEL
-        surf_ms = ms[k] / max(1, launches[k])
+        k = live_k
+        surf_ms = ms[k] / max(1, launches[k])   # the live-timed (dominant) kernel's mean launch duration inside the timed region
         # durations of every kernel family in the pass's own schedule: a separate run with an event pair around every launch (outside the timed region);
         # the surfel entry is the live one
         ctx.set_profiling(True); ctx.kernel_ms()
@@ -334,7 +361,9 @@ def main():
         msa, la = ctx.kernel_ms()
         ctx.set_profiling(False)
         out["kernel_ms"] = {lvx.KERNEL_NAMES[i]: msa[i] / max(1, la[i]) for i in range(len(msa)) if la[i]}
-        out["kernel_ms"][lvx.KERNEL_NAMES[k]] = surf_ms
+        if launches[k]:
+            out["kernel_ms"][lvx.KERNEL_NAMES[k]] = surf_ms
+        live_name = lvx.KERNEL_NAMES[k]
         solo = dict(out["kernel_ms"])
         if world == 1:   # solo durations: the same step with every family kernel on one stream (outside the timed region)
             ctx.set_switch("SERIAL", 1)
@@ -350,11 +379,20 @@ def main():
         # algorithmic work of every family against its solo duration, and of the whole pass against the step time
         work = {"surfel": (FLOPS_PER_EVAL["surfel"] * n_surf, BYTES_PER_EVAL["surfel"] * n_surf), "gyro": (FLOPS_PER_EVAL["imu"] * n_imu, BYTES_PER_EVAL["imu"] * n_imu),
                 "accel": (FLOPS_PER_EVAL["imu"] * n_imu, BYTES_PER_EVAL["imu"] * n_imu), "reproj": (FLOPS_PER_EVAL["reproj"] * len(P["rep_lm"]), BYTES_PER_EVAL["reproj"] * len(P["rep_lm"]))}
+        if "accel" not in solo and "gyro" in solo:   # fused IMU kernel (k_imu_mfma): one launch evaluates the gyroscope AND the accelerometer block of every sample
+            solo["imu"] = solo.pop("gyro")
+            if "gyro" in out["kernel_ms"]:
+                out["kernel_ms"]["imu"] = out["kernel_ms"].pop("gyro")
+            if "kernel_ms_solo" in out:
+                out["kernel_ms_solo"] = dict(solo)
+            work["imu"] = (2 * FLOPS_PER_EVAL["imu"] * n_imu, (BYTES_PER_EVAL["imu"] + 24) * n_imu)   # t 8 + gyro 24 + accel 24 B per sample
+            del work["gyro"], work["accel"]
         rep_parts = ["reproj", "reproj_jac", "reproj_obs", "reproj_ref", "reproj_cross", "reproj_lmrows"]   # the fused reprojection path is five kernels
         solo["reproj_all"] = sum(solo.get(k2, 0.0) for k2 in rep_parts)
         fam = {}
+        live_fam = {"gyro": "imu" if "imu" in work else "gyro"}.get(live_name, live_name)
         for name, (fl, by) in work.items():
-            d = (surf_ms if name == "surfel" else solo.get("reproj_all" if name == "reproj" else name, 0.0)) * 1e-3
+            d = (surf_ms if (name == live_fam and launches[k]) else solo.get("reproj_all" if name == "reproj" else name, 0.0)) * 1e-3
             if d > 0:
                 fam[name] = {"ms": 1e3 * d, "TFLOPs": fl / d / 1e12, "frac_fp64_peak": fl / d / 1e12 / FP64_PEAK_TFLOPS, "GBps": by / d / 1e9}
         # the time-dominant KERNEL: a family's duration is one kernel's except for reprojection (five kernels, the longest counts)
@@ -362,11 +400,12 @@ def main():
         dominant = max(fam, key=lambda n: longest[n])
         step_s = elapsed / args.steps
         tot_fl = sum(v[0] for v in work.values())
-        names = {"surfel": "k_family_mfma<SurfAcc>", "gyro": "k_family_mfma<GyroAcc>", "accel": "k_family_mfma<AccelAcc>",
+        names = {"surfel": "k_family_mfma<SurfAcc>", "gyro": "k_family_mfma<GyroAcc>", "accel": "k_family_mfma<AccelAcc>", "imu": "k_imu_mfma (gyroscope + accelerometer blocks fused)",
                  "reproj": "reprojection path (k_reproj_jac + k_family_mfma<RepSideAcc<1>> + k_family_mfma<RepSideAcc<0>> + k_reproj_cross + k_reproj_lmrows)"}
         fl_d, by_d = work[dominant]
         out["roofline"] = {"bound": "mfma", "kernel": names[dominant], "achieved": fam[dominant]["TFLOPs"], "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fam[dominant]["frac_fp64_peak"],
-                           "traffic": PMC_TRAFFIC_BYTES if (scale == 1 and dominant == "surfel") else None, "traffic_source": PMC_SOURCE + " — a constant copied from that profile, not measured in this run",
+                           "traffic": PMC_TRAFFIC_BYTES.get(dominant) if scale == 1 else None, "traffic_source": PMC_SOURCE + " — constants copied from that profile, not measured in this run",
+                           "duration_source": "HIP events on the kernel's own stream around every launch of the timed region" if (dominant == live_fam and launches[k]) else "solo duration (every kernel on one stream), profiled run outside the timed region",
                            "avg_launch_ms": fam[dominant]["ms"], "algorithmic_flops_per_launch": fl_d, "algorithmic_bytes_per_launch": by_d,
                            "hbm": {"achieved_GBps": fam[dominant]["GBps"], "peak_GBps": HBM_PEAK_GBS},
                            "families": fam,
@@ -375,15 +414,60 @@ def main():
                                    "ALGORITHMIC FP64 work per block from SURVEY.md 8d (surfel 9 k, IMU 4 k, reprojection 11 k FLOP) over the duration — the kernels execute less than that "
                                    "(hoisted hub pose, precomputed control-point pairs); FP64 matrix = FP64 vector peak = 78.6 TFLOP/s on MI355X; `families` has every family's fraction, "
                                    "`whole_pass` the sum over the step time"}
+    # ---- side measurements that involve every rank ----
+    if world > 1 and not args.no_secondary:
+        # LM iterations of the JOINT problem — shared rig extrinsics, one sequence per GPU (lvx_lm_solve_shared), over both transports
+        import sharded
+        sj = P["state0"].copy()
+        Nk = lo["n_knots"]
+        try:
+            ext = torch.from_numpy(sj[7 * Nk + 16:7 * Nk + 32].copy()).cuda()
+            dist.broadcast(ext, src=0)                      # the shared extrinsics start from rank 0's guess
+            sj[7 * Nk + 16:7 * Nk + 32] = ext.cpu().numpy()
+            dist.barrier(); torch.cuda.synchronize()
+            tj = time.perf_counter()
+            _, smj = ctx.lm_solve_shared(sj, sharded.dist_all_reduce(dist, torch.device("cuda", local_rank)), max_iterations=3)
+            torch.cuda.synchronize(); dist.barrier()
+            tj = time.perf_counter() - tj
+            joint = {"ms_per_iteration": 1e3 * tj / max(1, smj["iterations"]), "iterations": smj["iterations"], "initial_cost": smj["initial_cost"], "final_cost": smj["final_cost"],
+                     "transport": "host callback (torch.distributed all_reduce of <= 211 doubles per reduction)",
+                     "note": "joint LM over %d sequences with shared extrinsics: evaluate + private elimination per GPU, reduced 14 x 14 system + decision scalars over the ranks" % world}
+        except Exception as e:   # noqa: BLE001
+            joint = {"error": str(e)[:300]}
+        out.setdefault("secondary", {})["joint_lm_iteration"] = joint
+        try:   # the same solve with the reductions as ncclAllReduce calls on the context's stream (librccl inside liblvx, no host round trip)
+            if backend != "nccl":
+                raise RuntimeError("skipped: the functional check runs several ranks on one GPU (RCCL needs one device per rank)")
+            uid = torch.tensor(list(ctx.rccl_unique_id()) if rank == 0 else [0] * 128, dtype=torch.uint8, device="cuda")
+            dist.broadcast(uid, src=0)
+            ctx.rccl_init(bytes(uid.cpu().tolist()), rank, world)
+            ctx.collective_count(reset=True)
+            dist.barrier(); torch.cuda.synchronize()
+            tj = time.perf_counter()
+            _, smr = ctx.lm_solve_shared(sj, None, max_iterations=3)
+            torch.cuda.synchronize(); dist.barrier()
+            tj = time.perf_counter() - tj
+            out["secondary"]["joint_lm_iteration_rccl"] = {"ms_per_iteration": 1e3 * tj / max(1, smr["iterations"]), "iterations": smr["iterations"], "final_cost": smr["final_cost"],
+                                                           "collectives": int(ctx.collective_count()), "transport": "RCCL inside liblvx on the context's stream (lvx_rccl_init)"}
+            ctx.rccl_finalize()
+        except Exception as e:   # noqa: BLE001
+            out["secondary"]["joint_lm_iteration_rccl"] = {"error": str(e)[:300]}
+    if not args.no_secondary:
+        try:
+            assoc = assoc_metric(ctx, world, rank)      # every rank takes part (all-gather of the flags)
+        except Exception as e:   # noqa: BLE001
+            assoc = {"error": str(e)[:300]}
+        out.setdefault("secondary", {})["surfel_assoc"] = assoc
+    # ---- rank 0 alone ----
+    if rank == 0:
         if world == 1 and not args.no_secondary:
-            out["secondary"] = secondary_metrics(ctx, P, lo)
-        if joint is not None:
-            out["secondary"] = {"joint_lm_iteration": joint}
-        if assoc is not None:
-            out.setdefault("secondary", {})["surfel_assoc"] = assoc
+            sec = secondary_metrics(ctx, P, lo)
+            sec.update(out.get("secondary", {}))
+            out["secondary"] = sec
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(P)
-        print(json.dumps(out), flush=True)
+    em.disarm()
+    em.emit()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
