@@ -31,6 +31,20 @@ if __name__ == "__main__":
     for _ in range(reps):
         lvx.scan_register(ctx, pts, 16, 0.3)
     ts = (time.perf_counter() - t0) / reps
+    # next-row kernels (host buffers in and out: read their kernel durations from the rocprofv3 trace of this script)
+    src = cloud[::7].copy()
+    lvx.voxel_build(ctx, cloud, 1.0, fetch=False)
+    for _ in range(reps):
+        lvx.ndt_derivatives(ctx, src, src, np.zeros(6))
+    Pq = synth.make_problem(seed=41, duration=1.5, n_surfel=0, n_planes=1, n_landmarks=0)
+    c2 = lvx.Context(0); lvx.load_problem(c2, Pq, lvx.LOCK_LIDAR_TAU | lvx.LOCK_CAM_TAU)
+    rng = np.random.default_rng(3)
+    raw = np.zeros(28800 * 8, dtype=lvx.POINT_XYZIT)
+    raw["x"], raw["y"], raw["z"] = (rng.uniform(-20, 20, (3, len(raw)))).astype(np.float32)
+    raw["timestamp"] = np.sort(rng.uniform(Pq["t_start"], Pq["t_end"], len(raw)))
+    for _ in range(reps):
+        lvx.undistort(c2, Pq["state_true"], raw, np.array([0, 0, 0, 1.0]), np.zeros(3), True)
+    c2.close()
     n = scan.shape[0] * scan.shape[1]
     print("surfel_assoc 1 scan  : %.1f us  %.0f Mpts/s" % (1e6 * t1, n / t1 / 1e6))
     print("surfel_assoc 16 scans: %.1f us  %.0f Mpts/s" % (1e6 * t16, 16 * n / t16 / 1e6))
