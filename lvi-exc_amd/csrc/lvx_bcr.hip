@@ -240,12 +240,12 @@ __global__ __launch_bounds__(256) void k_potrf_batched(double* Dm, int b, long l
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   double* D = Dm + (size_t)blockIdx.x * strideD;
   if (tid == 0) bad = 0;
-  for (int c0 = 0; c0 < b; c0 += 4) {       // lower triangle, 4 columns per step so that the loads are in flight together
-    double v[4];
+  for (int c0 = 0; c0 < b; c0 += 16) {      // lower triangle, 16 columns per step so that the loads are in flight together (4 per step: 53 k of the kernel's 358 k cycles)
+    double v[16];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { const int cc = c0 + q, r = cc + tid; v[q] = (cc < b && r < b) ? D[(size_t)cc * b + r] : 0.0; }
+    for (int q = 0; q < 16; ++q) { const int cc = c0 + q, r = cc + tid; v[q] = (cc < b && r < b) ? D[(size_t)cc * b + r] : 0.0; }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { const int cc = c0 + q, r = cc + tid; if (cc < b && r < b) T[tri(r, cc)] = v[q]; }
+    for (int q = 0; q < 16; ++q) { const int cc = c0 + q, r = cc + tid; if (cc < b && r < b) T[tri(r, cc)] = v[q]; }
   }
   __syncthreads();
   const int fk = lane >> 4, fi = lane & 15;
@@ -337,7 +337,13 @@ __global__ __launch_bounds__(256) void k_potrf_batched(double* Dm, int b, long l
     }
     __syncthreads();
   }
-  for (int cc = 0; cc < b; ++cc) { const int r = cc + tid; if (r < b) D[(size_t)cc * b + r] = T[tri(r, cc)]; }
+  for (int c0 = 0; c0 < b; c0 += 8) {       // write-back, 8 LDS reads in flight per thread
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int cc = c0 + q, r = cc + tid; v[q] = (cc < b && r < b) ? T[tri(r, cc)] : 0.0; }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int cc = c0 + q, r = cc + tid; if (cc < b && r < b) D[(size_t)cc * b + r] = v[q]; }
+  }
   if (tid == 0) info[blockIdx.x] = bad;
 }
 // potrf of `batch` blocks: own kernel when the triangle fits into LDS, rocSOLVER otherwise (or with LVX_BCR_ROCSOLVER_POTRF)
