@@ -1,5 +1,3 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_upstream.py tests/test_gpu_pipeline.py -m gpu -q -x 2>&1 | tail -3
-rocprofv3 --kernel-trace -d gpurun_out/up -o kt -- python tools/upstream_bench.py 20 > gpurun_out/up.log 2>&1
-python tools/rocpd_summary.py $(find gpurun_out/up -name "*.db" | head -1) > gpurun_out/up_stats.txt
-grep -v "^W2026\|^E2026" gpurun_out/up.log | tail -7 | head -3; grep "k_assoc" gpurun_out/up_stats.txt | cut -c1-50,90-150
+LVX_SERIAL=1 LVX_LIB=lvi-exc_amd/liblvx_kt_GyroAcc.so python bench.py --steps 1 --warmup 1 --no-secondary --no-cpu-baseline 2>&1 | grep "^IKT" | tail -3
+LVX_IMU_MFMA=1 LVX_SERIAL=1 LVX_LIB=lvi-exc_amd/liblvx_kt_GyroAcc.so python bench.py --steps 1 --warmup 1 --no-secondary --no-cpu-baseline 2>&1 | grep "^IKT" | tail -2
