@@ -2057,12 +2057,18 @@ struct BandClear { double* Hb; const uint8_t* colfull; int nb, ld, npre, nblk; d
 // work — a separate kernel on a side stream costs a ~30 us cross-stream join before the LiDAR kernels); the rest clear the accumulators.
 __global__ __launch_bounds__(256) void k_clear(ClearList cl, BandClear bc, int npre, DevCommon cm, So3Pre* tab, int nblk_tab, double t_map, int want_surf, int want_cs, HubShared* hubs) {
   if ((int)blockIdx.x < npre) { state_prepass_block(cm, tab, nblk_tab, t_map, want_surf, want_cs, hubs, blockIdx.x); return; }
-  if ((int)blockIdx.x < npre + bc.nblk) {   // 16 lanes per band column, 16 columns per workgroup
-    const int j = ((int)blockIdx.x - npre) * 16 + (threadIdx.x >> 4);
-    if (j < bc.nb) {
+  if ((int)blockIdx.x < npre + bc.nblk) {   // 16 lanes per band column, 16 columns per trip; 16-byte stores when every column starts 16-byte aligned (ld even)
+    const int l16 = threadIdx.x & 15;
+    for (int j = ((int)blockIdx.x - npre) * 16 + (threadIdx.x >> 4); j < bc.nb; j += bc.nblk * 16) {
       const int len = bc.colfull[j] ? bc.ld : bc.npre;
       double* col = bc.Hb + (size_t)j * bc.ld;
-      for (int e = threadIdx.x & 15; e < len; e += 16) col[e] = 0.0;
+      if (!(bc.ld & 1)) {
+        uint4* c4 = (uint4*)col;
+        for (int e = l16; e < (len >> 1); e += 16) c4[e] = make_uint4(0u, 0u, 0u, 0u);
+        if ((len & 1) && l16 == 0) col[len - 1] = 0.0;
+      } else {
+        for (int e = l16; e < len; e += 16) col[e] = 0.0;
+      }
     }
     return;
   }
@@ -2122,7 +2128,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
       if (what & LVX_EVAL_NORMAL_EQ) {
         const size_t nb1 = (size_t)std::max(ctx->nb, 1);
         if (ctx->sw.clear_all || ctx->nb == 0) add(cm.Hb, nb1 * (ctx->bw + 1) * 8);
-        else { bc.Hb = cm.Hb; bc.colfull = (const uint8_t*)ctx->d_colfull.p; bc.nb = ctx->nb; bc.ld = ctx->bw + 1; bc.npre = ctx->clear_npre; bc.nblk = (ctx->nb + 15) / 16; }
+        else { bc.Hb = cm.Hb; bc.colfull = (const uint8_t*)ctx->d_colfull.p; bc.nb = ctx->nb; bc.ld = ctx->bw + 1; bc.npre = ctx->clear_npre; bc.nblk = std::min((ctx->nb + 15) / 16, 2048); }
         add(cm.gb, nb1 * 8);
         // hub rows of Bd: with the fused LiDAR kernels only the fold fills them beyond the near range — it stores there, the clear skips them
         const bool hub_partial = !ctx->sw.clear_all && !(nb1 & 1) && ctx->nb > 0 && ctx->n_hub > 0 && (fast_surf || fast_cs) && (ctx->surf.n == 0 || fast_surf) && (ctx->cs.n == 0 || fast_cs);
