@@ -142,6 +142,61 @@ __device__ __forceinline__ void sr_classify_ring(const SrView<LDSR>& V, unsigned
         __syncthreads();
       }
     for (int t = threadIdx.x; t < len; t += 512) sort_ind[sp + t] = (int)(key[t] & 0xffffffffu);
+    if constexpr (LDSR) {
+      // The reference's greedy pick is serial in its DECISIONS (a pick marks neighbours that later candidates must see) but not in its work: wavefront 0
+      // examines 64 sorted candidates per ballot, takes the first unpicked one beyond the threshold, and evaluates the ten neighbour gaps of a pick in
+      // parallel (the marks of each direction stop at its first gap > 0.05).  One lane doing all of it was a 200 us chain of dependent LDS reads per ring.
+      if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+        auto mark_neighbours = [&](int ind) {   // :374-391 / :407-423: lanes 1..5 -> ind + l, lanes 9..13 -> ind - l
+          bool brk = false; int tgt = -1;
+          if (lane >= 1 && lane <= 5) { brk = V.gap2(ind + lane, ind + lane - 1) > 0.05; tgt = ind + lane; }
+          else if (lane >= 9 && lane <= 13) { const int l = lane - 8; brk = V.gap2(ind - l, ind - l + 1) > 0.05; tgt = ind - l; }
+          const unsigned long long mb = __ballot(brk);
+          const unsigned plus = (unsigned)(mb >> 1) & 0x1fu, minus = (unsigned)(mb >> 9) & 0x1fu;
+          const int fp = plus ? __ffs(plus) : 6, fm = minus ? __ffs(minus) : 6;     // 1-based l of the first break in each direction
+          if (lane == 0) V.set_pk(ind);
+          if (lane >= 1 && lane <= 5 && lane < fp) V.set_pk(tgt);
+          if (lane >= 9 && lane <= 13 && lane - 8 < fm) V.set_pk(tgt);
+          wsync();
+        };
+        int largest = 0;
+        for (int k = ep; k >= sp;) {          // descending curvature
+          const int kk = k - lane;
+          int ind = -1; bool above = false, q = false;
+          if (kk >= sp) { ind = (int)(key[kk - sp] & 0xffffffffu); above = V.cv(ind) > 0.1; q = above && V.pk(ind) == 0; }
+          const unsigned long long mq = __ballot(q), ma = __ballot(above);
+          if (!mq) { if (ma != ~0ull) break; k -= 64; continue; }   // nothing to pick among these 64; below the threshold nothing follows (sorted)
+          const int f = __ffsll((long long)mq) - 1;
+          const int pick = __shfl(ind, f);
+          largest++;
+          if (largest > 20) break;
+          if (lane == 0) {
+            if (largest <= 2) { V.set_lab(pick, 2); sharp_r[r * 16 + cnt[0]++] = pick; lsharp_r[r * 128 + cnt[1]++] = pick; }
+            else { V.set_lab(pick, 1); lsharp_r[r * 128 + cnt[1]++] = pick; }
+          }
+          mark_neighbours(pick);
+          k = k - f - 1;
+        }
+        int smallest = 0;
+        for (int k = sp; k <= ep;) {          // ascending curvature
+          const int kk = k + lane;
+          int ind = -1; bool below = false, q = false;
+          if (kk <= ep) { ind = (int)(key[kk - sp] & 0xffffffffu); below = V.cv(ind) < 0.1; q = below && V.pk(ind) == 0; }
+          const unsigned long long mq = __ballot(q), ma = __ballot(below);
+          if (!mq) { if (ma != ~0ull) break; k += 64; continue; }
+          const int f = __ffsll((long long)mq) - 1;
+          const int pick = __shfl(ind, f);
+          if (lane == 0) { V.set_lab(pick, -1); flat_r[r * 32 + cnt[2]++] = pick; }
+          smallest++;
+          if (smallest >= 4) break;             // before it is marked (:394-403)
+          mark_neighbours(pick);
+          k = k + f + 1;
+        }
+        wsync();
+      }
+    } else
     if (threadIdx.x == 0) {   // the sorted indices are read from LDS (key[k - sp])
       int largest = 0;
       for (int k = ep; k >= sp; k--) {
