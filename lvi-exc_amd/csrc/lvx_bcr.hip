@@ -78,8 +78,14 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // solved tile is exactly its register ks (row (lane >> 4) + 4 ks), so the rank-16 updates read their right-hand operand from registers; only
 // the 16-column panel of L (shared by the 4 wavefronts) lives in LDS (27 KB; the predecessor kept the vectors in LDS, 135 KB).  NT is a compile-time bound on ceil(b / 16); everything is unrolled so that no
 // tile is indexed dynamically.
+// blockIdx.z = 1 selects a second, independent problem set with the same b (p2): the X+ and Y solves of a BCR level share a launch — on the lower levels
+// each of them is one latency-bound wave of workgroups (68 us), side by side they cost it once
+struct TrsmSet { const double* Lm; long long strideL; double* V; long long se, sv, strideV; int nvec, batch, batch0; };   // batch0: batch count of the FIRST set (the grid covers the larger of the two)
 template <bool TRANS, int NT>
-__global__ __launch_bounds__(256, 2) void k_trsm_reg(const double* __restrict__ Lm, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec) {
+__global__ __launch_bounds__(256, 2) void k_trsm_reg(const double* __restrict__ Lm, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, TrsmSet p2) {
+  if (blockIdx.z == 1) { Lm = p2.Lm; strideL = p2.strideL; V = p2.V; se = p2.se; sv = p2.sv; strideV = p2.strideV; nvec = p2.nvec; if ((int)blockIdx.y >= p2.batch) return; }
+  else if ((int)blockIdx.y >= p2.batch0) return;
+  if ((int)(blockIdx.x * 64) >= nvec) return;
   extern __shared__ double lds[];
   constexpr int bp = 16 * NT, PS = bp | 1;
   double* P = lds;                         // [16][PS]
@@ -195,20 +201,22 @@ __global__ __launch_bounds__(256, 2) void k_trsm_reg(const double* __restrict__ 
   }
 }
 template <bool TRANS, int NT>
-static int launch_trsm_reg(lvx_ctx* c, const double* L, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, int batch) {
+static int launch_trsm_reg(lvx_ctx* c, const double* L, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, int batch, const TrsmSet* second) {
   const size_t lds = ((size_t)16 * ((16 * NT) | 1) + 16) * 8;
   LVX_HIP(c, hipFuncSetAttribute((const void*)k_trsm_reg<TRANS, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((k_trsm_reg<TRANS, NT>), dim3((unsigned)((nvec + 63) / 64), (unsigned)batch), dim3(256), lds, c->stream, L, b, strideL, V, se, sv, strideV, nvec);
+  TrsmSet p2{}; p2.batch0 = batch; unsigned gx = (unsigned)((nvec + 63) / 64), gy = (unsigned)batch, gz = 1;
+  if (second && second->batch > 0 && second->nvec > 0) { p2 = *second; p2.batch0 = batch; gx = std::max(gx, (unsigned)((p2.nvec + 63) / 64)); gy = std::max(gy, (unsigned)p2.batch); gz = 2; }
+  hipLaunchKernelGGL((k_trsm_reg<TRANS, NT>), dim3(gx, gy, gz), dim3(256), lds, c->stream, L, b, strideL, V, se, sv, strideV, nvec, p2);
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
 }
 
 template <bool TRANS>
-static int trsv_batched(lvx_ctx* c, const double* L, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, int batch) {
-  if (batch <= 0 || nvec <= 0) return LVX_OK;
-  if (b <= 128) return launch_trsm_reg<TRANS, 8>(c, L, b, strideL, V, se, sv, strideV, nvec, batch);
-  if (b <= 208) return launch_trsm_reg<TRANS, 13>(c, L, b, strideL, V, se, sv, strideV, nvec, batch);
-  if (b <= 256) return launch_trsm_reg<TRANS, 16>(c, L, b, strideL, V, se, sv, strideV, nvec, batch);
+static int trsv_batched(lvx_ctx* c, const double* L, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, int batch, const TrsmSet* second = nullptr) {
+  if (batch <= 0 || nvec <= 0) { if (second && second->batch > 0 && second->nvec > 0) return trsv_batched<TRANS>(c, second->Lm, b, second->strideL, second->V, second->se, second->sv, second->strideV, second->nvec, second->batch); return LVX_OK; }
+  if (b <= 128) return launch_trsm_reg<TRANS, 8>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, second);
+  if (b <= 208) return launch_trsm_reg<TRANS, 13>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, second);
+  if (b <= 256) return launch_trsm_reg<TRANS, 16>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, second);
   return fail(c, LVX_E_ARG, "block size too large for the batched triangular solve (half-bandwidth > 256)");
 }
 
@@ -400,9 +408,9 @@ int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_ra
     if ((rc = potrf_batched(c, h, Dj, b, sD, info + info_pos, n2))) return rc;
     info_pos += n2;
     // X+_k = G[2k] C_k^-T : every ROW x of G[2k] solves C x^T = g^T
-    if ((rc = trsv_batched<false>(c, Dj, b, sD, Gl, /*se*/ b, /*sv*/ 1, sG, b, n2))) return rc;
-    // Y_k = C_k^-1 G[2k-1], k = 1..n2-1 : every COLUMN
-    if (n2 > 1 && (rc = trsv_batched<false>(c, Dj + sD, b, sD, Gl + bb, 1, b, sG, b, n2 - 1))) return rc;
+    // Y_k = C_k^-1 G[2k-1], k = 1..n2-1 : every COLUMN — in the same launch
+    const TrsmSet ysolve{Dj + sD, sD, Gl + bb, 1, b, sG, b, n2 - 1, 0};
+    if ((rc = trsv_batched<false>(c, Dj, b, sD, Gl, /*se*/ b, /*sv*/ 1, sG, b, n2, &ysolve))) return rc;
     // D_{j+s} -= X+ X+^T
     // (full GEMM instead of SYRK: rocBLAS' batched SYRK runs as many small launches; the upper triangle of D is never read)
     if (use_gemm) LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, b, b, b, &mone, Gl, b, sG, Gl, b, sG, &one, Dr, b, sD, n2));
