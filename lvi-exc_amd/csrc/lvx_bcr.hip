@@ -78,12 +78,14 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // solved tile is exactly its register ks (row (lane >> 4) + 4 ks), so the rank-16 updates read their right-hand operand from registers; only
 // the 16-column panel of L (shared by the 4 wavefronts) lives in LDS (27 KB; the predecessor kept the vectors in LDS, 135 KB).  NT is a compile-time bound on ceil(b / 16); everything is unrolled so that no
 // tile is indexed dynamically.
-// blockIdx.z = 1 selects a second, independent problem set with the same b (p2): the X+ and Y solves of a BCR level share a launch — on the lower levels
-// each of them is one latency-bound wave of workgroups (68 us), side by side they cost it once
+// blockIdx.z = 1, 2 select further, independent problem sets with the same b (p2, p3): the X+ and Y solves of a BCR level and the forward substitution of
+// the right-hand sides against the same factors share a launch — on the lower levels each of them is one latency-bound wave of workgroups (68 us), side by
+// side they cost it once
 struct TrsmSet { const double* Lm; long long strideL; double* V; long long se, sv, strideV; int nvec, batch, batch0; };   // batch0: batch count of the FIRST set (the grid covers the larger of the two)
 template <bool TRANS, int NT>
-__global__ __launch_bounds__(256, 2) void k_trsm_reg(const double* __restrict__ Lm, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, TrsmSet p2) {
-  if (blockIdx.z == 1) { Lm = p2.Lm; strideL = p2.strideL; V = p2.V; se = p2.se; sv = p2.sv; strideV = p2.strideV; nvec = p2.nvec; if ((int)blockIdx.y >= p2.batch) return; }
+__global__ __launch_bounds__(256, 2) void k_trsm_reg(const double* __restrict__ Lm, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, TrsmSet p2, TrsmSet p3) {
+  if (blockIdx.z == 2) { Lm = p3.Lm; strideL = p3.strideL; V = p3.V; se = p3.se; sv = p3.sv; strideV = p3.strideV; nvec = p3.nvec; if ((int)blockIdx.y >= p3.batch) return; }
+  else if (blockIdx.z == 1) { Lm = p2.Lm; strideL = p2.strideL; V = p2.V; se = p2.se; sv = p2.sv; strideV = p2.strideV; nvec = p2.nvec; if ((int)blockIdx.y >= p2.batch) return; }
   else if ((int)blockIdx.y >= p2.batch0) return;
   if ((int)(blockIdx.x * 64) >= nvec) return;
   extern __shared__ double lds[];
@@ -201,22 +203,30 @@ __global__ __launch_bounds__(256, 2) void k_trsm_reg(const double* __restrict__ 
   }
 }
 template <bool TRANS, int NT>
-static int launch_trsm_reg(lvx_ctx* c, const double* L, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, int batch, const TrsmSet* second) {
+static int launch_trsm_reg(lvx_ctx* c, const double* L, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, int batch, const TrsmSet* second, const TrsmSet* third) {
   const size_t lds = ((size_t)16 * ((16 * NT) | 1) + 16) * 8;
   LVX_HIP(c, hipFuncSetAttribute((const void*)k_trsm_reg<TRANS, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  TrsmSet p2{}; p2.batch0 = batch; unsigned gx = (unsigned)((nvec + 63) / 64), gy = (unsigned)batch, gz = 1;
-  if (second && second->batch > 0 && second->nvec > 0) { p2 = *second; p2.batch0 = batch; gx = std::max(gx, (unsigned)((p2.nvec + 63) / 64)); gy = std::max(gy, (unsigned)p2.batch); gz = 2; }
-  hipLaunchKernelGGL((k_trsm_reg<TRANS, NT>), dim3(gx, gy, gz), dim3(256), lds, c->stream, L, b, strideL, V, se, sv, strideV, nvec, p2);
+  TrsmSet p2{}, p3{}; p2.batch0 = batch; unsigned gx = (unsigned)((nvec + 63) / 64), gy = (unsigned)batch, gz = 1;
+  auto live = [](const TrsmSet* t) { return t && t->batch > 0 && t->nvec > 0; };
+  if (live(second)) { p2 = *second; p2.batch0 = batch; gz = 2; }
+  if (live(third)) { p3 = *third; gz = 3; }      // an empty second set with a live third: blocks of z = 1 exit at once (batch 0)
+  for (const TrsmSet* t : {&p2, &p3}) if (t->batch > 0 && t->nvec > 0) { gx = std::max(gx, (unsigned)((t->nvec + 63) / 64)); gy = std::max(gy, (unsigned)t->batch); }
+  hipLaunchKernelGGL((k_trsm_reg<TRANS, NT>), dim3(gx, gy, gz), dim3(256), lds, c->stream, L, b, strideL, V, se, sv, strideV, nvec, p2, p3);
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
 }
 
 template <bool TRANS>
-static int trsv_batched(lvx_ctx* c, const double* L, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, int batch, const TrsmSet* second = nullptr) {
-  if (batch <= 0 || nvec <= 0) { if (second && second->batch > 0 && second->nvec > 0) return trsv_batched<TRANS>(c, second->Lm, b, second->strideL, second->V, second->se, second->sv, second->strideV, second->nvec, second->batch); return LVX_OK; }
-  if (b <= 128) return launch_trsm_reg<TRANS, 8>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, second);
-  if (b <= 208) return launch_trsm_reg<TRANS, 13>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, second);
-  if (b <= 256) return launch_trsm_reg<TRANS, 16>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, second);
+static int trsv_batched(lvx_ctx* c, const double* L, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, int batch, const TrsmSet* second = nullptr,
+                        const TrsmSet* third = nullptr) {
+  if (batch <= 0 || nvec <= 0) {   // the first set is empty: promote the next live one
+    for (const TrsmSet* t : {second, third}) if (t && t->batch > 0 && t->nvec > 0)
+      return trsv_batched<TRANS>(c, t->Lm, b, t->strideL, t->V, t->se, t->sv, t->strideV, t->nvec, t->batch, t == second ? third : nullptr);
+    return LVX_OK;
+  }
+  if (b <= 128) return launch_trsm_reg<TRANS, 8>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, second, third);
+  if (b <= 208) return launch_trsm_reg<TRANS, 13>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, second, third);
+  if (b <= 256) return launch_trsm_reg<TRANS, 16>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, second, third);
   return fail(c, LVX_E_ARG, "block size too large for the batched triangular solve (half-bandwidth > 256)");
 }
 
@@ -385,7 +395,9 @@ int bcr_plan(lvx_ctx* c) {
 // start of level l's blocks inside the per-level array (level l holds nblk >> l blocks)
 static inline size_t g_off(int nblk, int l, size_t bb) { size_t o = 0; for (int k = 0; k < l; ++k) o += (size_t)(nblk >> k) * bb; return o; }
 
-int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_radius, int* info_out_d) {
+// Z != null: the forward substitution of the right-hand sides Z [ldz x nrhs] (bcr_forward) rides along — its triangular solves against C_j join the X+ / Y
+// launch of the level, its updates follow the level's GEMMs
+int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_radius, int* info_out_d, double* Z, int ldz, int nrhs) {
   rocblas_handle h; int rc = bcr_handle(c, &h); if (rc) return rc;
   const int b = c->bcr_b, nblk = c->bcr_nblk;
   const size_t bb = (size_t)b * b;
@@ -410,7 +422,11 @@ int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_ra
     // X+_k = G[2k] C_k^-T : every ROW x of G[2k] solves C x^T = g^T
     // Y_k = C_k^-1 G[2k-1], k = 1..n2-1 : every COLUMN — in the same launch
     const TrsmSet ysolve{Dj + sD, sD, Gl + bb, 1, b, sG, b, n2 - 1, 0};
-    if ((rc = trsv_batched<false>(c, Dj, b, sD, Gl, /*se*/ b, /*sv*/ 1, sG, b, n2, &ysolve))) return rc;
+    const long long sZ = (long long)2 * s * b;
+    double* Zj = Z ? Z + (size_t)(s - 1) * b : nullptr;
+    double* Zr = Z ? Z + (size_t)(2 * s - 1) * b : nullptr;
+    const TrsmSet rsolve{Dj, sD, Zj, 1, ldz, sZ, Z ? nrhs : 0, Z ? n2 : 0, 0};                              // y_j = C_j^-1 b_j
+    if ((rc = trsv_batched<false>(c, Dj, b, sD, Gl, /*se*/ b, /*sv*/ 1, sG, b, n2, &ysolve, &rsolve))) return rc;
     // D_{j+s} -= X+ X+^T
     // (full GEMM instead of SYRK: rocBLAS' batched SYRK runs as many small launches; the upper triangle of D is never read)
     if (use_gemm) LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, b, b, b, &mone, Gl, b, sG, Gl, b, sG, &one, Dr, b, sD, n2));
@@ -422,8 +438,14 @@ int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_ra
       // next level's coupling A_{j+s,j-s} = -X+_k Y_k
       LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, b, b, &mone, Gl + 2 * bb, b, sG, Gl + bb, b, sG, &zero, Gn, b, (rocblas_stride)bb, n2 - 1));
     }
+    if (Z) {   // b_{j+s} -= X+ y_j,  b_{j-s} -= Y^T y_j
+      LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, nrhs, b, &mone, Gl, b, sG, Zj, ldz, sZ, &one, Zr, ldz, sZ, n2));
+      if (n2 > 1)
+        LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, nrhs, b, &mone, Gl + bb, b, sG, Zj + sZ, ldz, sZ, &one, Zr, ldz, sZ, n2 - 1));
+    }
   }
   if ((rc = potrf_batched(c, h, D + (size_t)(nblk - 1) * bb, b, (long long)bb, info + info_pos, 1))) return rc;
+  if (Z && (rc = trsv_batched<false>(c, D + (size_t)(nblk - 1) * bb, b, 0, Z + (size_t)(nblk - 1) * b, 1, ldz, 0, nrhs, 1))) return rc;
   info_pos += 1;
   hipLaunchKernelGGL(k_bcr_info, dim3((info_pos + 255) / 256), dim3(256), 0, st, (const int*)info, info_pos, info_out_d);
   LVX_HIP(c, hipGetLastError());

@@ -173,7 +173,7 @@ int ensure_layout(lvx_ctx* ctx);
 int check_last_eval(lvx_ctx* ctx);
 DevCommon make_common(lvx_ctx* ctx, const double* state_d, uint32_t what);
 int bcr_plan(lvx_ctx* c);
-int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_radius, int* info_out_d);
+int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_radius, int* info_out_d, double* Z = nullptr, int ldz = 0, int nrhs = 0);
 int bcr_forward(lvx_ctx* c, double* Zin, double* Zy, int ldz, int nrhs);
 int bcr_backward(lvx_ctx* c, double* Zy, double* Zx, int ldz, int nrhs);
 int bcr_gram(lvx_ctx* c, const double* Z, int ldz, int n, double* M);

@@ -724,10 +724,8 @@ static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, 
     if (use_bcr) {
       int rc2;
       tm.lap("enqueue build_rhs");
-      if ((rc2 = bcr_factor(c, w.scale, w.lmd, ir, w.info))) return rc2;
-      tm.lap("enqueue bcr_factor");
-      if ((rc2 = bcr_forward(c, w.Z, w.Z, ldz, nbd + 1))) return rc2;   // Z <- L^-1 [B^T, f_b] (in place)
-      tm.lap("enqueue bcr_forward");
+      if ((rc2 = bcr_factor(c, w.scale, w.lmd, ir, w.info, w.Z, ldz, nbd + 1))) return rc2;   // factor, and Z <- L^-1 [B^T, f_b] (in place) level by level with it
+      tm.lap("enqueue bcr_factor + forward");
     } else {
       const size_t tot = (size_t)nb * (bw + 1);
       hipLaunchKernelGGL(k_build_band, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, w.Hs, w.scale, w.lmd, ir, nb, bw, w.L);
