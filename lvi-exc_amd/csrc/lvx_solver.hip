@@ -261,28 +261,55 @@ __global__ void k_schur_from_gram(const double* M, const double* C, const double
 // Columns 0..np-1 are eliminated (right-looking, so the trailing (n-np) x (n-np) block ends up holding the Schur complement onto the
 // SHARED variables) and the right-hand side is forward-substituted: rhs[0..np) = L_pp^-1 b_p, rhs[np..n) = b_s - L_sp z_p.
 // np == n is the plain factorisation + forward substitution.
+// (the border block and its right-hand side live in LDS for the whole factorisation: in global memory every one of the ~3 n steps was a round trip
+// to HBM / L2 and the forward substitution a chain of n^2 / 2 dependent loads on one thread — 180 us for n = 52)
 __global__ __launch_bounds__(256) void k_dense_partial(double* S, double* rhs, int n, int np, int* info) {
-  const int tid = threadIdx.x;
+  extern __shared__ double ds[];           // T [n][n + 1] | r [n]
+  const int tid = threadIdx.x, ld = n + 1;
+  double* T = ds; double* r = ds + (size_t)n * ld;
+  for (int e = tid; e < n * n; e += 256) T[(e / n) * ld + e % n] = S[e];
+  for (int e = tid; e < n; e += 256) r[e] = rhs[e];
+  __syncthreads();
   for (int k = 0; k < np; ++k) {
+    if (tid == 0) { const double d = T[k * ld + k]; if (!(d > 0.0)) { if (info[1] == 0) { info[1] = k + 1; ((double*)(info + 2))[0] = d; } T[k * ld + k] = 1.0; } else T[k * ld + k] = sqrt(d); }
     __syncthreads();
-    if (tid == 0) { const double d = S[(size_t)k * n + k]; if (!(d > 0.0)) { if (info[1] == 0) { info[1] = k + 1; ((double*)(info + 2))[0] = d; } S[(size_t)k * n + k] = 1.0; } else S[(size_t)k * n + k] = sqrt(d); }
-    __syncthreads();
-    const double inv = 1.0 / S[(size_t)k * n + k];
-    for (int r = k + 1 + tid; r < n; r += 256) S[(size_t)r * n + k] *= inv;
+    const double inv = 1.0 / T[k * ld + k];
+    for (int rr = k + 1 + tid; rr < n; rr += 256) T[rr * ld + k] *= inv;
     __syncthreads();
     const int m = n - k - 1;
-    for (int e = tid; e < m * m; e += 256) { const int r = k + 1 + e / m, c = k + 1 + e % m; if (r >= c) S[(size_t)r * n + c] -= S[(size_t)r * n + k] * S[(size_t)c * n + k]; }
+    for (int e = tid; e < m * m; e += 256) { const int rr = k + 1 + e / m, c = k + 1 + e % m; if (rr >= c) T[rr * ld + c] -= T[rr * ld + k] * T[c * ld + k]; }
+    __syncthreads();
   }
-  __syncthreads();
-  if (tid == 0) {
-    for (int i = 0; i < np; ++i) { double s = rhs[i]; for (int k = 0; k < i; ++k) s -= S[(size_t)i * n + k] * rhs[k]; rhs[i] = s / S[(size_t)i * n + i]; }
-    for (int i = np; i < n; ++i) { double s = rhs[i]; for (int k = 0; k < np; ++k) s -= S[(size_t)i * n + k] * rhs[k]; rhs[i] = s; }
+  // forward substitution, column by column: y_k = r_k / L_kk, then r_i -= L_ik y_k for every i > k (also the rows of the trailing block)
+  for (int k = 0; k < np; ++k) {
+    if (tid == 0) r[k] = r[k] / T[k * ld + k];
+    __syncthreads();
+    const double yk = r[k];
+    for (int i = k + 1 + tid; i < n; i += 256) r[i] -= T[i * ld + k] * yk;
+    __syncthreads();
   }
+  for (int e = tid; e < n * n; e += 256) S[e] = T[(e / n) * ld + e % n];
+  for (int e = tid; e < n; e += 256) rhs[e] = r[e];
 }
 // backward substitution of the eliminated part given the solution of the trailing (shared) variables in rhs[np..n)
-__global__ void k_dense_back(const double* S, double* rhs, int n, int np) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  for (int i = np - 1; i >= 0; --i) { double s = rhs[i]; for (int k = i + 1; k < n; ++k) s -= S[(size_t)k * n + i] * rhs[k]; rhs[i] = s / S[(size_t)i * n + i]; }
+__global__ __launch_bounds__(256) void k_dense_back(const double* S, double* rhs, int n, int np) {
+  extern __shared__ double ds[];           // T [n][n + 1] | r [n]
+  const int tid = threadIdx.x, ld = n + 1;
+  double* T = ds; double* r = ds + (size_t)n * ld;
+  for (int e = tid; e < n * n; e += 256) T[(e / n) * ld + e % n] = S[e];
+  for (int e = tid; e < n; e += 256) r[e] = rhs[e];
+  __syncthreads();
+  // the trailing variables are known: r_i -= sum_{k >= np} L_ki x_k for i < np, then L^T x = r column by column from the bottom
+  for (int i = tid; i < np; i += 256) { double s = r[i]; for (int k = np; k < n; ++k) s -= T[k * ld + i] * r[k]; r[i] = s; }
+  __syncthreads();
+  for (int i = np - 1; i >= 0; --i) {
+    if (tid == 0) r[i] = r[i] / T[i * ld + i];
+    __syncthreads();
+    const double xi = r[i];
+    for (int k = tid; k < i; k += 256) r[k] -= T[i * ld + k] * xi;
+    __syncthreads();
+  }
+  for (int e = tid; e < np; e += 256) rhs[e] = r[e];
 }
 // z <- z - Z_B^T y_c
 __global__ void k_sub_border(const double* Z, const double* yc, int nb, int nbd, int ldz, double* z) {
@@ -527,24 +554,34 @@ __global__ __launch_bounds__(256) void k_lm_schur_grp(const double* __restrict__
 __global__ __launch_bounds__(256) void k_lm_back(const double* __restrict__ lmH, const int* __restrict__ p0s, int L, int wl, int nbd_solve, int nbd, int ls, const double* __restrict__ scale_l,
                                                  const double* __restrict__ lmd_l, double inv_radius, const double* __restrict__ yb, const double* __restrict__ yc, const double* __restrict__ scale,
                                                  int nb, double* delta_l, double* sums) {
-  const int l = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (l >= L) return;
-  const double* row = lmH + (size_t)l * ls;
-  const int p0 = p0s[l];
-  double dot = 0.0;
-  for (int k = lane; k < wl; k += 64) { const double ev = row[k]; if (ev != 0.0) dot += ev * yb[p0 + k] * scale[p0 + k]; }
-  for (int b = lane; b < nbd_solve; b += 64) { const double ev = row[wl + b]; if (ev != 0.0) dot += ev * yc[b] * scale[nb + b]; }
-  for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
-  if (lane != 0) return;
-  const double Hll = row[wl + nbd], gl = row[wl + nbd + 1];
-  double d = 0.0;
-  if (Hll > 0.0) {
-    const double s = scale_l[l], dmp = lmd_l[l] * inv_radius, w = s * s / (s * s * Hll + dmp);
-    d = -w * (gl + dot);
-    const double y = d / s;
-    atomicAdd(&sums[0], gl * d); atomicAdd(&sums[1], y * y * dmp); atomicAdd(&sums[5], d * (Hll * d + 2.0 * dot));
+  const int wvi = threadIdx.x >> 6, l = blockIdx.x * 4 + wvi, lane = threadIdx.x & 63;
+  __shared__ double red[4][3];   // the workgroup's four landmarks are summed before they reach the three global sums (15 k same-address atomics took 190 us)
+  double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+  if (l < L) {
+    const double* row = lmH + (size_t)l * ls;
+    const int p0 = p0s[l];
+    double dot = 0.0;
+    for (int k = lane; k < wl; k += 64) { const double ev = row[k]; if (ev != 0.0) dot += ev * yb[p0 + k] * scale[p0 + k]; }
+    for (int b = lane; b < nbd_solve; b += 64) { const double ev = row[wl + b]; if (ev != 0.0) dot += ev * yc[b] * scale[nb + b]; }
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+    if (lane == 0) {
+      const double Hll = row[wl + nbd], gl = row[wl + nbd + 1];
+      double d = 0.0;
+      if (Hll > 0.0) {
+        const double s = scale_l[l], dmp = lmd_l[l] * inv_radius, w = s * s / (s * s * Hll + dmp);
+        d = -w * (gl + dot);
+        const double y = d / s;
+        t0 = gl * d; t1 = y * y * dmp; t2 = d * (Hll * d + 2.0 * dot);
+      }
+      delta_l[l] = d;
+    }
   }
-  delta_l[l] = d;
+  if (lane == 0) { red[wvi][0] = t0; red[wvi][1] = t1; red[wvi][2] = t2; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const double v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (v != 0.0) atomicAdd(&sums[threadIdx.x == 2 ? 5 : threadIdx.x], v);
+  }
 }
 __global__ void k_gmax_lm(const double* lmH, int L, int ls, int off, double* sums) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
@@ -748,7 +785,9 @@ static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, 
     hipLaunchKernelGGL(k_schur, dim3(nbd), dim3(256), 0, st, (const double*)Zf, w.Cs, w.gcs, (const double*)w.scale,
                        nb > 0 ? nb : 0, nbd, c->nbd_ext, ldz, (const double*)w.lmd, ir, w.S, w.rhs);
   }
-  hipLaunchKernelGGL(k_dense_partial, dim3(1), dim3(256), 0, st, w.S, w.rhs, nbd, nbd - c->ns, w.info);
+  const size_t lds_dense = ((size_t)nbd * (nbd + 1) + nbd) * 8;
+  LVX_HIP(c, hipFuncSetAttribute((const void*)k_dense_partial, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dense));
+  hipLaunchKernelGGL(k_dense_partial, dim3(1), dim3(256), lds_dense, st, w.S, w.rhs, nbd, nbd - c->ns, w.info);
   LVX_HIP(c, hipGetLastError());
   int info[4] = {0, 0, 0, 0};
   tm.lap("enqueue gram+schur+dense");
@@ -858,7 +897,9 @@ static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double m[3
   }
   *notpd_out = notpd;
   if (notpd) { fail(c, LVX_E_NOTPD, "damped normal equations not positive definite"); return LVX_OK; }
-  hipLaunchKernelGGL(k_dense_back, dim3(1), dim3(64), 0, st, (const double*)w.S, w.rhs, nbd, np);
+  { const size_t lds_dense = ((size_t)nbd * (nbd + 1) + nbd) * 8;
+    LVX_HIP(c, hipFuncSetAttribute((const void*)k_dense_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dense));
+    hipLaunchKernelGGL(k_dense_back, dim3(1), dim3(256), lds_dense, st, (const double*)w.S, w.rhs, nbd, np); }
   const int ldz = w.ldz;
   double* Zf = w.Z;
   double* zb = Zf + (size_t)nbd * std::max(ldz, 1);
