@@ -125,7 +125,7 @@ struct lvx_ctx {
   // block cyclic reduction (lvx_bcr.hip): diagonal blocks, per-level coupling blocks, pivot info; rocBLAS handle
   lvx::DevBuf d_bcrD, d_bcrG, d_bcrInfo, d_Y2, d_gram;
   void* blas = nullptr;
-  int bcr_b = 0, bcr_nblk = 0;
+  int bcr_b = 0, bcr_nblk = 0, bcr_nreal = 0;
   int64_t n_blocks = 0, n_residuals = 0;
   int64_t fam_row0[LVX_NUM_FAM + 1] = {0};
   uint32_t last_what = 0;
