@@ -29,7 +29,7 @@ __global__ void k_bcr_build(const double* __restrict__ Hb, const double* __restr
                             int nb, int bw, int b, int nblk, double* D, double* G0) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t bb = (size_t)b * b;
-  if (e >= 2 * (size_t)nblk * bb) return;
+  if (e >= 2 * (size_t)nblk * bb) return;    // nblk here = the blocks to fill (the real ones: padding is written once by bcr_plan)
   const bool isG = e >= (size_t)nblk * bb;
   const size_t e2 = isG ? e - (size_t)nblk * bb : e;
   const int i = (int)(e2 / bb);
@@ -47,6 +47,12 @@ __global__ void k_bcr_build(const double* __restrict__ Hb, const double* __restr
     if (r < nb && c < nb) { const long long d = r - c; if (d <= bw) v = Hb[(size_t)c * (bw + 1) + d] * scale[r] * scale[c]; }
     G0[e2] = v;
   }
+}
+__global__ void k_bcr_pad_identity(double* D, int b, int first, int nblk) {   // D_i = I for the padding blocks i in [first, nblk)
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x, bb = (size_t)b * b;
+  if (e >= (size_t)(nblk - first) * bb) return;
+  const size_t r = (e % bb) % b, cc = (e % bb) / b;
+  D[(size_t)first * bb + e] = r == cc ? 1.0 : 0.0;
 }
 __global__ void k_bcr_info(const int* info, int n, int* out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -392,6 +398,10 @@ int bcr_plan(lvx_ctx* c) {
   if ((rc = dev_alloc(c, c->d_bcrInfo, guard * (size_t)(2 * nblk + 8) * 4))) return rc;
   // couplings of the levels above 0 that involve a padding block are never computed (level_batch) and must read as zero
   LVX_HIP(c, hipMemsetAsync(c->d_bcrG.p, 0, (size_t)2 * nblk * bb * 8, c->stream));
+  if (c->bcr_nreal < nblk) {   // padding blocks: identity, decoupled — nothing ever changes them (potrf(I) = I, updates with zero couplings)
+    const size_t npad = (size_t)(nblk - c->bcr_nreal) * bb;
+    hipLaunchKernelGGL(k_bcr_pad_identity, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, c->stream, (double*)c->d_bcrD.p, b, c->bcr_nreal, nblk);
+  }
   return LVX_OK;
 }
 // start of level l's blocks inside the per-level array (level l holds nblk >> l blocks)
@@ -413,8 +423,9 @@ int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_ra
   const size_t bb = (size_t)b * b;
   double* D = (double*)c->d_bcrD.p; double* G = (double*)c->d_bcrG.p; int* info = (int*)c->d_bcrInfo.p;
   hipStream_t st = c->stream;
-  const size_t tot = 2 * (size_t)nblk * bb;
-  hipLaunchKernelGGL(k_bcr_build, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, c->p_Hs ? c->p_Hs : (const double*)c->d_Hb.p, scale, lmd, inv_radius, c->nb, c->bw, b, nblk, D, G);
+  const int nfill = std::min(nblk, std::max(c->bcr_nreal, 1));
+  const size_t tot = 2 * (size_t)nfill * bb;
+  hipLaunchKernelGGL(k_bcr_build, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, c->p_Hs ? c->p_Hs : (const double*)c->d_Hb.p, scale, lmd, inv_radius, c->nb, c->bw, b, nfill, D, G);
   LVX_HIP(c, hipMemsetAsync(info, 0, (size_t)(2 * nblk + 8) * 4, st));
   const double one = 1.0, mone = -1.0, zero = 0.0;
   int L = 0; while ((1 << L) < nblk) ++L;

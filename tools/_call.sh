@@ -1,2 +1,3 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | grep -E "passed|failed|Error|error" | tail -5
+timeout 900 python -m pytest tests/test_gpu_solver.py tests/test_gpu_converge.py tests/test_gpu_shared.py tests/test_host_estimator.py tests/test_gpu_pipeline.py -m gpu -q -x 2>&1 | grep -E "passed|failed" | tail -2
+python bench.py --steps 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); s=d['secondary']; print(s['lm_iteration']['ms_per_iteration'], s['converged_solve']['seconds'])"
