@@ -257,7 +257,8 @@ __device__ __forceinline__ double rsqrt_f64(double x) {             // hardware 
   y = y * (1.5 - 0.5 * x * y * y);
   return y;
 }
-__global__ __launch_bounds__(256) void k_potrf_batched(double* Dm, int b, long long strideD, int* info) {
+#define POTRF_NT 512   // 8 wavefronts: the trailing update's tiles are dealt over all of them (one flat list, two tiles in flight per wavefront)
+__global__ __launch_bounds__(POTRF_NT) void k_potrf_batched(double* Dm, int b, long long strideD, int* info) {
   extern __shared__ double T[];             // packed lower triangle, row-major
   double* dinv = T + ((b * (b + 1)) >> 1);  // [16]
   __shared__ int bad;
@@ -320,43 +321,37 @@ __global__ __launch_bounds__(256) void k_potrf_batched(double* Dm, int b, long l
     __syncthreads();
     const int r0 = k0 + 16;
     if (r0 < b) {                           // 3. trailing update on the matrix cores
-      const int m = (b - r0 + 15) >> 4;
-      // tile rows dealt to the wavefronts longest first (row ti has ti + 1 tiles): wave w takes m-1-w, m-1-w-4, ... ; the A fragments of a
-      // row are loaded once, two tiles are in flight so that their MFMA chains interleave
-      for (int ti = m - 1 - wv; ti >= 0; ti -= 4) {
-        const int i0 = r0 + 16 * ti, ai = i0 + fi;
-        const int abase = ai < b ? tri(ai, k0 + fk) : -1;
-        double av[4];
+      const int m = (b - r0 + 15) >> 4, ntile = (m * (m + 1)) >> 1;
+      // tiles (ti, tj <= ti) of the trailing lower triangle as one flat list t = ti (ti + 1) / 2 + tj, dealt round-robin to the wavefronts (rows dealt
+      // whole gave the first wavefront 21 of 66 tiles); two tiles in flight so that their MFMA chains interleave
+      constexpr int NW = POTRF_NT / 64;
+      auto decode = [](int t, int& ti, int& tj) { ti = 0; while (((ti + 1) * (ti + 2)) >> 1 <= t) ++ti; tj = t - ((ti * (ti + 1)) >> 1); };
+      for (int t0 = wv; t0 < ntile; t0 += 2 * NW) {
+        const bool two = t0 + NW < ntile;
+        int ti0, tj0, ti1 = 0, tj1 = 0;
+        decode(t0, ti0, tj0);
+        if (two) decode(t0 + NW, ti1, tj1);
+        const int ia = r0 + 16 * ti0, ja = r0 + 16 * tj0, ib = r0 + 16 * ti1, jb = r0 + 16 * tj1;
+        const int aA = ia + fi < b ? tri(ia + fi, k0 + fk) : -1, bA = ja + fi < b ? tri(ja + fi, k0 + fk) : -1;
+        const int aB = (two && ib + fi < b) ? tri(ib + fi, k0 + fk) : -1, bB = (two && jb + fi < b) ? tri(jb + fi, k0 + fk) : -1;
+        double avA[4], bvA[4], avB[4], bvB[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) av[ks] = abase >= 0 ? -T[abase + 4 * ks] : 0.0;
-        int rowb[4];
+        for (int ks = 0; ks < 4; ++ks) { avA[ks] = aA >= 0 ? -T[aA + 4 * ks] : 0.0; bvA[ks] = bA >= 0 ? T[bA + 4 * ks] : 0.0; avB[ks] = aB >= 0 ? -T[aB + 4 * ks] : 0.0; bvB[ks] = bB >= 0 ? T[bB + 4 * ks] : 0.0; }
+        d4 CA, CB; int xA[4], xB[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) { const int ci = i0 + fk + 4 * v; rowb[v] = ci < b ? tri(ci, 0) : -1; }
-        for (int tj = 0; tj <= ti; tj += 2) {
-          const bool two = tj + 1 <= ti;
-          const int j0 = r0 + 16 * tj, j1 = j0 + 16;
-          const int cj0 = j0 + fi, cj1 = j1 + fi;
-          const int bb0 = cj0 < b ? tri(cj0, k0 + fk) : -1, bb1 = (two && cj1 < b) ? tri(cj1, k0 + fk) : -1;
-          d4 C0, C1;
-          int x0[4], x1[4];
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int ci = i0 + fk + 4 * v;
-            x0[v] = (rowb[v] >= 0 && cj0 <= ci) ? rowb[v] + cj0 : -1;
-            x1[v] = (two && rowb[v] >= 0 && cj1 <= ci) ? rowb[v] + cj1 : -1;
-            C0[v] = x0[v] >= 0 ? T[x0[v]] : 0.0; C1[v] = x1[v] >= 0 ? T[x1[v]] : 0.0;
-          }
-          double b0[4], b1[4];
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) { b0[ks] = bb0 >= 0 ? T[bb0 + 4 * ks] : 0.0; b1[ks] = bb1 >= 0 ? T[bb1 + 4 * ks] : 0.0; }
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            C0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], b0[ks], C0, 0, 0, 0);
-            if (two) C1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], b1[ks], C1, 0, 0, 0);
-          }
-#pragma unroll
-          for (int v = 0; v < 4; ++v) { if (x0[v] >= 0) T[x0[v]] = C0[v]; if (x1[v] >= 0) T[x1[v]] = C1[v]; }
+        for (int v = 0; v < 4; ++v) {
+          const int ciA = ia + fk + 4 * v, cjA = ja + fi, ciB = ib + fk + 4 * v, cjB = jb + fi;
+          xA[v] = (ciA < b && cjA <= ciA) ? tri(ciA, cjA) : -1;
+          xB[v] = (two && ciB < b && cjB <= ciB) ? tri(ciB, cjB) : -1;
+          CA[v] = xA[v] >= 0 ? T[xA[v]] : 0.0; CB[v] = xB[v] >= 0 ? T[xB[v]] : 0.0;
         }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          CA = __builtin_amdgcn_mfma_f64_16x16x4f64(avA[ks], bvA[ks], CA, 0, 0, 0);
+          if (two) CB = __builtin_amdgcn_mfma_f64_16x16x4f64(avB[ks], bvB[ks], CB, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { if (xA[v] >= 0) T[xA[v]] = CA[v]; if (xB[v] >= 0) T[xB[v]] = CB[v]; }
       }
     }
     __syncthreads();
@@ -379,7 +374,7 @@ static int potrf_batched(lvx_ctx* c, rocblas_handle h, double* D, int b, long lo
     return LVX_OK;
   }
   LVX_HIP(c, hipFuncSetAttribute((const void*)k_potrf_batched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_potrf_batched, dim3((unsigned)batch), dim3(256), lds, c->stream, D, b, strideD, info);
+  hipLaunchKernelGGL(k_potrf_batched, dim3((unsigned)batch), dim3(POTRF_NT), lds, c->stream, D, b, strideD, info);
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
 }
