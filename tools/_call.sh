@@ -1,6 +1,7 @@
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_solver.py tests/test_gpu_converge.py tests/test_gpu_shared.py tests/test_host_estimator.py tests/test_gpu_pipeline.py -m gpu -q -x 2>&1 | grep -E "passed|failed" | tail -2
-rocprofv3 --kernel-trace -d gpurun_out/lm -o kt -- python tools/lm_scale_probe.py > gpurun_out/lm.log 2>&1
-python tools/rocpd_summary.py $(find gpurun_out/lm -name "*.db" | head -1) > gpurun_out/lm_stats.txt
-grep "potrf" gpurun_out/lm_stats.txt | cut -c1-60,90-150
-python bench.py --steps 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); s=d['secondary']; print(s['lm_iteration']['ms_per_iteration'], s['converged_solve']['seconds'])"
+timeout 1200 bash tools/profile_round.sh r02c
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace -d gpurun_out/r02c_lm -o kt -- python tools/lm_scale_probe.py > gpurun_out/r02c_lm.log 2>&1
+python tools/rocpd_summary.py $(find gpurun_out/r02c_lm -name "*.db" | head -1) > gpurun_out/r02c_kernel_stats_lm_iteration.txt
+python tools/rocpd_timeline.py $(find gpurun_out/r02c_kt -name "*.db" | head -1) 12 > gpurun_out/r02c_timeline.txt
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed" > gpurun_out/r02c_gputest.log; cat gpurun_out/r02c_gputest.log
+python -c "import __graft_entry__ as g; g.smoke()"
