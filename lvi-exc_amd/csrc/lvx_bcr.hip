@@ -274,29 +274,34 @@ __global__ __launch_bounds__(POTRF_NT) void k_potrf_batched(double* Dm, int b, l
   }
   __syncthreads();
   const int fk = lane >> 4, fi = lane & 15;
+  // 1. a 16 x 16 diagonal block by wavefront 0 (lane = row, columns in registers).  Only the first one is a phase of its own: the block of step k + 1 is
+  // factorised by wavefront 0 DURING the trailing update of step k, right after it has updated that tile — the other seven wavefronts take the rest of the
+  // update, so the serial 16-column chain (7.3 k cycles) leaves the critical path wherever the update is at least as long.
+  auto diag_block = [&](int k0) {
+    const int nk = min(16, b - k0);
+    double a[16];
+    const int r = lane;
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) a[cc] = (r < nk && cc <= r) ? T[tri(k0 + r, k0 + cc)] : ((r == cc) ? 1.0 : 0.0);
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+      double dc = readlane_f64(a[cc], cc);
+      if (!(dc > 0.0)) { if (lane == 0 && cc < nk) atomicCAS(&bad, 0, k0 + cc + 1); dc = 1.0; }
+      const double inv = rsqrt_f64(dc), sq = dc * inv;
+      a[cc] = (r == cc) ? sq : a[cc] * inv;
+      if (lane == 0) dinv[cc] = inv;
+#pragma unroll
+      for (int c2 = cc + 1; c2 < 16; ++c2) { const double l2 = readlane_f64(a[cc], c2); a[c2] -= a[cc] * l2; }
+    }
+    if (r < nk) {
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc) if (cc <= r) T[tri(k0 + r, k0 + cc)] = a[cc];
+    }
+  };
+  if (wv == 0) diag_block(0);
+  __syncthreads();
   for (int k0 = 0; k0 < b; k0 += 16) {
     const int nk = min(16, b - k0);
-    if (wv == 0) {                          // 1. diagonal block
-      double a[16];
-      const int r = lane;
-#pragma unroll
-      for (int cc = 0; cc < 16; ++cc) a[cc] = (r < nk && cc <= r) ? T[tri(k0 + r, k0 + cc)] : ((r == cc) ? 1.0 : 0.0);
-#pragma unroll
-      for (int cc = 0; cc < 16; ++cc) {
-        double dc = readlane_f64(a[cc], cc);
-        if (!(dc > 0.0)) { if (lane == 0 && cc < nk) atomicCAS(&bad, 0, k0 + cc + 1); dc = 1.0; }
-        const double inv = rsqrt_f64(dc), sq = dc * inv;
-        a[cc] = (r == cc) ? sq : a[cc] * inv;
-        if (lane == 0) dinv[cc] = inv;
-#pragma unroll
-        for (int c2 = cc + 1; c2 < 16; ++c2) { const double l2 = readlane_f64(a[cc], c2); a[c2] -= a[cc] * l2; }
-      }
-      if (r < nk) {
-#pragma unroll
-        for (int cc = 0; cc < 16; ++cc) if (cc <= r) T[tri(k0 + r, k0 + cc)] = a[cc];
-      }
-    }
-    __syncthreads();
     {                                       // 2. rows below the diagonal block: x L11^T = a
       const int i = k0 + nk + tid;
       if (i < b) {
@@ -324,10 +329,10 @@ __global__ __launch_bounds__(POTRF_NT) void k_potrf_batched(double* Dm, int b, l
       const int m = (b - r0 + 15) >> 4, ntile = (m * (m + 1)) >> 1;
       // tiles (ti, tj <= ti) of the trailing lower triangle as one flat list t = ti (ti + 1) / 2 + tj, dealt round-robin to the wavefronts (rows dealt
       // whole gave the first wavefront 21 of 66 tiles); two tiles in flight so that their MFMA chains interleave
-      constexpr int NW = POTRF_NT / 64;
+      constexpr int NW = POTRF_NT / 64 - 1;   // wavefronts 1 .. 7 share the tiles 1 .. ntile - 1; wavefront 0: tile 0 (the next diagonal block), then its Cholesky
       auto decode = [](int t, int& ti, int& tj) { ti = 0; while (((ti + 1) * (ti + 2)) >> 1 <= t) ++ti; tj = t - ((ti * (ti + 1)) >> 1); };
-      for (int t0 = wv; t0 < ntile; t0 += 2 * NW) {
-        const bool two = t0 + NW < ntile;
+      for (int t0 = wv == 0 ? 0 : wv; t0 < (wv == 0 ? 1 : ntile); t0 += 2 * NW) {
+        const bool two = wv != 0 && t0 + NW < ntile;
         int ti0, tj0, ti1 = 0, tj1 = 0;
         decode(t0, ti0, tj0);
         if (two) decode(t0 + NW, ti1, tj1);
@@ -352,6 +357,10 @@ __global__ __launch_bounds__(POTRF_NT) void k_potrf_batched(double* Dm, int b, l
         }
 #pragma unroll
         for (int v = 0; v < 4; ++v) { if (xA[v] >= 0) T[xA[v]] = CA[v]; if (xB[v] >= 0) T[xB[v]] = CB[v]; }
+      }
+      if (wv == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        diag_block(r0);
       }
     }
     __syncthreads();
