@@ -1,7 +1,7 @@
-timeout 1200 bash tools/profile_round.sh r02c
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace -d gpurun_out/r02c_lm -o kt -- python tools/lm_scale_probe.py > gpurun_out/r02c_lm.log 2>&1
-python tools/rocpd_summary.py $(find gpurun_out/r02c_lm -name "*.db" | head -1) > gpurun_out/r02c_kernel_stats_lm_iteration.txt
-python tools/rocpd_timeline.py $(find gpurun_out/r02c_kt -name "*.db" | head -1) 12 > gpurun_out/r02c_timeline.txt
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed" > gpurun_out/r02c_gputest.log; cat gpurun_out/r02c_gputest.log
-python -c "import __graft_entry__ as g; g.smoke()"
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | grep -E "passed|failed|Error|error" | tail -5
+for e in "X=1" "LVX_SINGLE_BUFFER=1" "X=2" "LVX_SINGLE_BUFFER=1"; do
+  echo "== $e"; env $e LVX_BENCH_NOPROF=1 python bench.py --no-secondary --no-cpu-baseline --steps 50 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],4), d['config']['cost'])"
+done
+python bench.py --no-secondary --no-cpu-baseline > gpurun_out/b.json 2> gpurun_out/b.err; python tools/bsum.py gpurun_out/b.json
+python tools/stress_parity.py 1500 2>&1 | grep -E "worst|MISMATCH" | tail -3
