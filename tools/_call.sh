@@ -1,7 +1,6 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | grep -E "passed|failed|Error|error" | tail -5
-for e in "X=1" "LVX_SINGLE_BUFFER=1" "X=2" "LVX_SINGLE_BUFFER=1"; do
-  echo "== $e"; env $e LVX_BENCH_NOPROF=1 python bench.py --no-secondary --no-cpu-baseline --steps 50 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],4), d['config']['cost'])"
-done
-python bench.py --no-secondary --no-cpu-baseline > gpurun_out/b.json 2> gpurun_out/b.err; python tools/bsum.py gpurun_out/b.json
-python tools/stress_parity.py 1500 2>&1 | grep -E "worst|MISMATCH" | tail -3
+timeout 900 python -m pytest tests/test_gpu_solver.py tests/test_gpu_converge.py tests/test_gpu_shared.py tests/test_host_estimator.py tests/test_gpu_pipeline.py -m gpu -q -x 2>&1 | grep -E "passed|failed" | tail -2
+rocprofv3 --kernel-trace -d gpurun_out/lm -o kt -- python tools/lm_scale_probe.py > gpurun_out/lm.log 2>&1
+python tools/rocpd_summary.py $(find gpurun_out/lm -name "*.db" | head -1) > gpurun_out/lm_stats.txt
+grep "potrf\|back_level\|trsm_reg<true" gpurun_out/lm_stats.txt | cut -c1-60,90-150
+python bench.py --steps 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); s=d['secondary']; print(s['lm_iteration']['ms_per_iteration'], s['converged_solve']['seconds'])"
