@@ -1184,6 +1184,8 @@ template <class PG> __device__ __forceinline__ void imu_assemble(double* sm, dou
 #pragma unroll
         for (int c = 0; c < PG::NK + PG::NG; ++c) prow[c] = valid ? J[a][c] : 0.0;
         prow[PG::NK + PG::NG] = valid ? r[a] : 0.0;
+#pragma unroll
+        for (int c = PG::NCL; c < 16 * NT; ++c) prow[c] = 0.0;   // tile padding (the two geometries share the panel memory: the other one's data sits here)
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1249,7 +1251,20 @@ static size_t imu_fused_lds_bytes(int cr) {
   const int pan = std::max((int)ImuG::PR * (int)ImuG::LDP, (int)ImuA::PR * (int)ImuA::LDP);
   return (size_t)(LV * ACC_BW + IMU_NGA * LV + IMU_NGA * IMU_NGA + LV + IMU_NGA + 4 * pan) * 8 + (size_t)(cr + 4) * sizeof(So3Pre) + (size_t)(LV + IMU_NGA) * 4 + 64;
 }
-__global__ __launch_bounds__(256, 1) void k_imu_mfma(ImuFused fam, DevCommon cm, const int* __restrict__ chunk_off, long long row0_g, long long row0_a, int CR, const int* __restrict__ det_list) {
+// the per-lane scatter targets of both geometries depend on the chunk size only: built once per layout (64 lanes x 16 entries) instead of by every
+// wavefront of every workgroup (~4 k cycles of integer divisions and branches each)
+__global__ void k_imu_rtab(int CR, int* out) {
+  const int lane = threadIdx.x, ACC_LV = (CR + 5) * 6;
+  const double* sm = (const double*)out;    // only differences of the accumulator addresses enter the table
+  ImuAccLds A;
+  A.band = (double*)sm; A.bd = A.band + ACC_LV * ACC_BW; A.gg = A.bd + IMU_NGA * ACC_LV; A.gk = A.gg + IMU_NGA * IMU_NGA; A.gG = A.gk + ACC_LV; A.lv = ACC_LV;
+  int rtg[ImuG::NTP * 4], rta[ImuA::NTP * 4];
+  imu_build_rtab<ImuG>(rtg, lane, sm, A);
+  imu_build_rtab<ImuA>(rta, lane, sm, A);
+  for (int i = 0; i < ImuG::NTP * 4; ++i) out[i * 64 + lane] = rtg[i];
+  for (int i = 0; i < ImuA::NTP * 4; ++i) out[(ImuG::NTP * 4 + i) * 64 + lane] = rta[i];
+}
+__global__ __launch_bounds__(256, 1) void k_imu_mfma(ImuFused fam, DevCommon cm, const int* __restrict__ chunk_off, long long row0_g, long long row0_a, int CR, const int* __restrict__ det_list, const int* __restrict__ rtab_g) {
   constexpr int PAN = (ImuG::PR * ImuG::LDP > ImuA::PR * ImuA::LDP) ? ImuG::PR * ImuG::LDP : ImuA::PR * ImuA::LDP;
   const int ACC_LV = (CR + 5) * 6;
   extern __shared__ double sm[];
@@ -1266,7 +1281,7 @@ __global__ __launch_bounds__(256, 1) void k_imu_mfma(ImuFused fam, DevCommon cm,
   if (m0 >= m1) return;
   const int k_lo = ch * CR - 1;
   const bool want_ne = (cm.what & LVX_EVAL_NORMAL_EQ) != 0;
-  for (int e = tid; e < ACC_LV * ACC_BW + IMU_NGA * ACC_LV + IMU_NGA * IMU_NGA + ACC_LV + IMU_NGA + 4 * PAN; e += 256) sm[e] = 0.0;
+  for (int e = tid; e < ACC_LV * ACC_BW + IMU_NGA * ACC_LV + IMU_NGA * IMU_NGA + ACC_LV + IMU_NGA; e += 256) sm[e] = 0.0;   // (the panels need no clearing: every row a k-step reads is rewritten, the padding columns with it)
   for (int e = tid; e < ACC_LV; e += 256) { const int k = k_lo + e / 6; kpos[e] = (k >= 0 && k < cm.N) ? cm.ord[6 * k + e % 6] : LVX_DEAD; }
   if (tid < IMU_NGA) gpos[tid] = cm.ord[6 * cm.N + tid];
   if (tid < CR + 4) {
@@ -1279,8 +1294,10 @@ __global__ __launch_bounds__(256, 1) void k_imu_mfma(ImuFused fam, DevCommon cm,
   double* P = panels + wv * PAN;
   const int rep = ch % cm.nrep;
   int rtg[ImuG::NTP * 4], rta[ImuA::NTP * 4];
-  imu_build_rtab<ImuG>(rtg, lane, sm, A);
-  imu_build_rtab<ImuA>(rta, lane, sm, A);
+#pragma unroll
+  for (int i = 0; i < ImuG::NTP * 4; ++i) rtg[i] = rtab_g[i * 64 + lane];
+#pragma unroll
+  for (int i = 0; i < ImuA::NTP * 4; ++i) rta[i] = rtab_g[(ImuG::NTP * 4 + i) * 64 + lane];
   double mycost = 0.0;
   __syncthreads();
   for (int base = wv < nwv ? m0 + wv * 64 : m1; base < m1; base += nwv * 64) {
@@ -2002,6 +2019,8 @@ int ensure_layout(lvx_ctx* ctx) {
   if ((rc = upload_pairs(ctx, ctx->d_pairs[5], CS_NC + tC, cat(range(0, 24), range(48, 60 + tC))))) return rc;
   ctx->force_legacy = false;
   { static const int zero = 0; if ((rc = upload_tmp(ctx, ctx->d_zero, &zero, 4))) return rc; }
+  if ((rc = dev_alloc(ctx, ctx->d_imu_rtab, (size_t)64 * (ImuG::NTP * 4 + ImuA::NTP * 4) * 4))) return rc;
+  hipLaunchKernelGGL(k_imu_rtab, dim3(1), dim3(64), 0, ctx->stream, ctx->chunk_r[LVX_FAM_GYRO], (int*)ctx->d_imu_rtab.p);
   ctx->cfg_version++;   // captured evaluation graphs of the previous layout are stale
   // ---- residual row offsets ----
   const int64_t cnt[LVX_NUM_FAM] = {ctx->imu.n, (locks & LVX_LOCK_R3) ? 0 : ctx->imu.n, ctx->has_prior ? 1 : 0, ctx->surf.n, ctx->rep.n, ctx->cs.n};
@@ -2216,15 +2235,16 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
             const ImuFused f{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, ctx->imu.huber /*w_acc*/};
             const size_t lds_ = imu_fused_lds_bytes(ctx->chunk_r[LVX_FAM_GYRO]);
             LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_imu_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
+            const int* rtab_d = (const int*)ctx->d_imu_rtab.p;
             ProfScope ps(ctx, LVX_FAM_GYRO, s_imu);
             if (det && ctx->det_col[LVX_FAM_GYRO].size() > 1) {
               const std::vector<int>& dc = ctx->det_col[LVX_FAM_GYRO];
               for (size_t q = 0; q + 1 < dc.size(); ++q)
                 hipLaunchKernelGGL(k_imu_mfma, dim3(dc[q + 1] - dc[q]), dim3(256), lds_, s_imu, f, cm, (const int*)ctx->d_chunk[LVX_FAM_GYRO].p, (long long)ctx->fam_row0[0], (long long)ctx->fam_row0[1],
-                                   ctx->chunk_r[LVX_FAM_GYRO], (const int*)ctx->d_det_list[LVX_FAM_GYRO].p + dc[q]);
+                                   ctx->chunk_r[LVX_FAM_GYRO], (const int*)ctx->d_det_list[LVX_FAM_GYRO].p + dc[q], rtab_d);
             } else
             hipLaunchKernelGGL(k_imu_mfma, dim3(ctx->n_chunk[LVX_FAM_GYRO]), dim3(256), lds_, s_imu, f, cm, (const int*)ctx->d_chunk[LVX_FAM_GYRO].p, (long long)ctx->fam_row0[0], (long long)ctx->fam_row0[1],
-                               ctx->chunk_r[LVX_FAM_GYRO], (const int*)nullptr);
+                               ctx->chunk_r[LVX_FAM_GYRO], (const int*)nullptr, rtab_d);
           } else if (imu_fast) {
             GyroAcc g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
             { ProfScope ps(ctx, LVX_FAM_GYRO, s_imu); LVX_LAUNCH_MFMA(GyroAcc, g, LVX_FAM_GYRO, s_imu, ctx->fam_row0[0]); }
@@ -2497,7 +2517,7 @@ void lvx_destroy(lvx_ctx* c) {
   if (c->d_pre.p) (void)hipFree(c->d_pre.p);
   if (c->d_colfull.p) (void)hipFree(c->d_colfull.p);
   for (auto& b : c->d_det_list) if (b.p) (void)hipFree(b.p);
-  for (DevBuf* b : {&c->d_chk, &c->d_det_cross, &c->d_lm_grp, &c->d_lmH, &c->d_lm_p0, &c->d_Hr, &c->d_Br, &c->d_red, &c->d_repT}) if (b->p) (void)hipFree(b->p);
+  for (DevBuf* b : {&c->d_imu_rtab, &c->d_chk, &c->d_det_cross, &c->d_lm_grp, &c->d_lmH, &c->d_lm_p0, &c->d_Hr, &c->d_Br, &c->d_red, &c->d_repT}) if (b->p) (void)hipFree(b->p);
   for (DevBuf* b : {&c->vox.misc, &c->vox.keys, &c->vox.vals, &c->vox.runs, &c->vox.cells, &c->vox.tmp, &c->vox.leaf_i, &c->vox.leaf_d, &c->vox.leaf_f}) if (b->p) (void)hipFree(b->p);
   (void)lvx_rccl_finalize(c);
   if (c->d_comm.p) (void)hipFree(c->d_comm.p);
