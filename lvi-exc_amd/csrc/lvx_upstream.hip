@@ -118,14 +118,17 @@ template <bool LDSR> struct SrView {
   __device__ __forceinline__ void set_lab(int i, int v) const { if (LDSR) L->lab[i - base] = (signed char)v; else label[i] = v; }
 };
 template <bool LDSR>
-__device__ __forceinline__ void sr_classify_ring(const SrView<LDSR>& V, unsigned long long* key, int* cnt, int* wsum, int r, int s0, int e0, int* sort_ind,
+__device__ __forceinline__ void sr_classify_ring(const SrView<LDSR>& V, unsigned long long* key0, int kstride, int* cnt, int* wsum, int r, int s0, int e0, int* sort_ind,
                                                  int* sharp_r, int* lsharp_r, int* flat_r, int* lflat_r, int* err) {
+  // kstride > 0: the six sectors were sorted beforehand, six wavefronts at once, into key0 + j * kstride (k_sr_classify); 0: sorted here, one after the other
   for (int j = 0; j < 6; ++j) {
     const int sp = s0 + (e0 - s0) * j / 6;
     const int ep = s0 + (e0 - s0) * (j + 1) / 6 - 1;
     const int len = ep - sp + 1;
-    if (len > SR_SEC_MAX) { if (threadIdx.x == 0) atomicOr(err, 8); break; }
+    unsigned long long* key = key0 + (size_t)j * kstride;
+    if (len > (kstride > 0 ? kstride : SR_SEC_MAX)) { if (threadIdx.x == 0) atomicOr(err, 8); break; }
     int np2 = 1; while (np2 < len) np2 <<= 1;
+    if (kstride == 0) {
     for (int t = threadIdx.x; t < np2; t += 512)
       key[t] = t < len ? (((unsigned long long)__float_as_uint(V.cv(sp + t))) << 32) | (unsigned)(sp + t) : ~0ull;   // curvature >= 0: bit order == value order
     __syncthreads();
@@ -141,6 +144,7 @@ __device__ __forceinline__ void sr_classify_ring(const SrView<LDSR>& V, unsigned
         }
         __syncthreads();
       }
+    }
     for (int t = threadIdx.x; t < len; t += 512) sort_ind[sp + t] = (int)(key[t] & 0xffffffffu);
     if constexpr (LDSR) {
       // The reference's greedy pick is serial in its DECISIONS (a pick marks neighbours that later candidates must see) but not in its work: wavefront 0
@@ -244,7 +248,8 @@ __device__ __forceinline__ void sr_classify_ring(const SrView<LDSR>& V, unsigned
 }
 __global__ __launch_bounds__(512) void k_sr_classify(const float4* cloud, const float* curv, const int* scan_start, const int* scan_end, int* label, int* sort_ind,
                                                     int* picked, int* sharp_r, int* lsharp_r, int* flat_r, int* lflat_r, int* cnt_r, int* err) {
-  __shared__ unsigned long long key[SR_SEC_MAX];
+#define SR_SEC_LDS 1024   // sector capacity of the LDS path: a ring of <= 4096 points has sectors of <= 683
+  __shared__ unsigned long long key[6 * SR_SEC_LDS];   // (>= SR_SEC_MAX: the global-memory path sorts one sector at a time in its head)
   __shared__ int cnt[4], wsum[8];
   __shared__ SrRingLds ring;
   const int r = blockIdx.x;
@@ -257,12 +262,37 @@ __global__ __launch_bounds__(512) void k_sr_classify(const float4* cloud, const 
       for (int t = threadIdx.x; t < np; t += 512) { const float4 p = cloud[base + t]; ring.x[t] = p.x; ring.y[t] = p.y; ring.z[t] = p.z; ring.c[t] = curv[base + t]; ring.lab[t] = (signed char)label[base + t]; ring.pk[t] = (unsigned char)(picked[base + t] != 0); }
       __syncthreads();
       const SrView<true> V{cloud, curv, label, picked, &ring, base};
-      sr_classify_ring<true>(V, key, cnt, wsum, r, s0, e0, sort_ind, sharp_r, lsharp_r, flat_r, lflat_r, err);
+      {   // the six sector sorts at once: wavefront w sorts sector w on its own (bitonic, wavefront barriers only) — curvatures do not change during the picks
+        const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (w < 6) {
+          const int sp = s0 + (e0 - s0) * w / 6, ep = s0 + (e0 - s0) * (w + 1) / 6 - 1, len = ep - sp + 1;
+          unsigned long long* kw = key + (size_t)w * SR_SEC_LDS;
+          int np2 = 1; while (np2 < len) np2 <<= 1;
+          if (len <= SR_SEC_LDS) {
+            for (int t = lane; t < np2; t += 64) kw[t] = t < len ? (((unsigned long long)__float_as_uint(ring.c[sp + t - base])) << 32) | (unsigned)(sp + t) : ~0ull;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int k = 2; k <= np2; k <<= 1)
+              for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                for (int t = lane; t < np2; t += 64) {
+                  const int x = t ^ jj;
+                  if (x > t) {
+                    const unsigned long long a = kw[t], b = kw[x];
+                    const bool up = (t & k) == 0;
+                    if ((a > b) == up) { kw[t] = b; kw[x] = a; }
+                  }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+              }
+          }
+        }
+        __syncthreads();
+      }
+      sr_classify_ring<true>(V, key, SR_SEC_LDS, cnt, wsum, r, s0, e0, sort_ind, sharp_r, lsharp_r, flat_r, lflat_r, err);
       __syncthreads();
       for (int t = threadIdx.x; t < np; t += 512) { label[base + t] = ring.lab[t]; picked[base + t] = ring.pk[t]; }
     } else {
       const SrView<false> V{cloud, curv, label, picked, nullptr, base};
-      sr_classify_ring<false>(V, key, cnt, wsum, r, s0, e0, sort_ind, sharp_r, lsharp_r, flat_r, lflat_r, err);
+      sr_classify_ring<false>(V, key, 0, cnt, wsum, r, s0, e0, sort_ind, sharp_r, lsharp_r, flat_r, lflat_r, err);
     }
   }
   __syncthreads();
