@@ -282,6 +282,11 @@ int lvx_surfel_assoc_d(lvx_ctx* ctx, int H, int W, const float* scan_d, int n_pl
 int lvx_surfel_assoc_batch_d(lvx_ctx* ctx, int n_scans, int H, int W, const float* scans_d, int n_planes, const double* planes10_d, double radius, int sel_per_ring,
                              int32_t* plane_of_point_d);
 
+/* SurfelAssociation::setSurfelMap happens once per DataAssociation, getAssociation once per scan (lvi_initialize_surfel_orb.cpp:1184-1199): build the association
+ * grid of a surfel table once — later lvx_surfel_assoc_batch_d / lvx_surfel_assoc_d calls with THE SAME planes10_d pointer and n_planes reuse it (the caller
+ * promises the table's contents are unchanged) until the next prepare or a call with another table. */
+int lvx_surfel_map_prepare_d(lvx_ctx* ctx, int n_planes, const double* planes10_d);
+
 /* sequence-per-GPU joint solve (BASELINE config 5) ---------------------------------------------------------*/
 /* Every rank owns one calibration sequence (trajectory, gravity, biases, landmarks are private); the rig extrinsics — lidar theta(3) p(3)
  * tau, camera theta(3) p(3) tau = 14 tangent scalars — are shared.  One LM iteration of the JOINT problem: every rank eliminates its private

@@ -133,6 +133,7 @@ struct lvx_ctx {
   // upstream kernels (lvx_upstream.hip)
   lvx::DevBuf d_up[8];
   size_t assoc_rings = 0; int assoc_wpr = 0;   // shape the association work buffer (d_up[7]) was cleared for
+  const double* assoc_map_planes = nullptr; int assoc_map_P = 0; bool assoc_map_ready = false;   // lvx_surfel_map_prepare_d: the association grid of this plane table is built
   lvx::DevBuf d_assoc[3];   // surfel association: grid geometry + cell counts / offsets, cell lists, emission counters
   int sr_n = 0, sr_rings = 0, sr_m = 0;   // input size, rings and kept points of the last lvx_scan_register (its results stay in d_up[0])
   struct Voxels {

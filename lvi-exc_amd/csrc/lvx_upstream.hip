@@ -1158,6 +1158,25 @@ int lvx_voxel_lookup1_d(lvx_ctx* c, int nq, const float* xyzi4_d, int32_t* leaf_
 }
 
 // S scans [S][H][W] against one plane table; flags [S][H * W].  Work buffers (bitmasks 4 P H ceil(W / 32) bytes per scan, counts) live in d_up[7].
+// geometry, per-cell counts, offsets and lists of the association grid (d_assoc[0], d_assoc[1]); have = it is already built for this table
+static int assoc_grid_build(lvx_ctx* c, int P, const double* planes_d, bool have) {
+  if (have) return LVX_OK;
+  c->assoc_map_ready = false;   // the grid buffers are about to hold another table's grid
+  int rc;
+  if ((rc = dev_alloc(c, c->d_assoc[0], sizeof(AssocGrid) + (size_t)(3 * SA_CELLS + 8) * 4))) return rc;
+  AssocGrid* gd = (AssocGrid*)c->d_assoc[0].p; int* ccnt = (int*)(gd + 1); int* coff = ccnt + SA_CELLS; int* ccur = coff + SA_CELLS + 1;
+  LVX_HIP(c, hipMemsetAsync(ccnt, 0, (size_t)SA_CELLS * 4, c->stream));
+  hipLaunchKernelGGL(k_assoc_grid_geom, dim3(1), dim3(256), 0, c->stream, P, planes_d, gd);
+  hipLaunchKernelGGL(k_assoc_grid_fill, dim3((unsigned)((P + 127) / 128)), dim3(128), 0, c->stream, P, planes_d, (const AssocGrid*)gd, ccnt, ccur, (int*)nullptr, 0);
+  hipLaunchKernelGGL(k_assoc_grid_scan, dim3(1), dim3(1024), 0, c->stream, (const int*)ccnt, coff, ccur);
+  int total = 0;
+  LVX_HIP(c, hipMemcpyAsync(&total, coff + SA_CELLS, 4, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  if ((rc = dev_alloc(c, c->d_assoc[1], (size_t)std::max(total, 1) * 4))) return rc;
+  int* clist = (int*)c->d_assoc[1].p;
+  hipLaunchKernelGGL(k_assoc_grid_fill, dim3((unsigned)((P + 127) / 128)), dim3(128), 0, c->stream, P, planes_d, (const AssocGrid*)gd, ccnt, ccur, clist, 1);
+  return LVX_OK;
+}
 static int assoc_device(lvx_ctx* c, const float4* scans_d, int S, int H, int W, int P, const double* planes_d, double radius, int sel, int* flags_d) {
   LVX_HIP(c, hipMemsetAsync(flags_d, 0xff, (size_t)S * H * W * 4, c->stream));
   if (P <= 0 || H <= 0 || W <= 0 || S <= 0) return LVX_OK;
@@ -1176,19 +1195,10 @@ static int assoc_device(lvx_ctx* c, const float4* scans_d, int S, int H, int W, 
     LVX_HIP(c, hipGetLastError());
     return LVX_OK;
   }
-  // the surfel grid (depends on the plane table only): geometry, per-cell counts, offsets, lists
-  if ((rc = dev_alloc(c, c->d_assoc[0], sizeof(AssocGrid) + (size_t)(3 * SA_CELLS + 8) * 4))) return rc;
-  AssocGrid* gd = (AssocGrid*)c->d_assoc[0].p; int* ccnt = (int*)(gd + 1); int* coff = ccnt + SA_CELLS; int* ccur = coff + SA_CELLS + 1;
-  LVX_HIP(c, hipMemsetAsync(ccnt, 0, (size_t)SA_CELLS * 4, c->stream));
-  hipLaunchKernelGGL(k_assoc_grid_geom, dim3(1), dim3(256), 0, c->stream, P, planes_d, gd);
-  hipLaunchKernelGGL(k_assoc_grid_fill, dim3((unsigned)((P + 127) / 128)), dim3(128), 0, c->stream, P, planes_d, (const AssocGrid*)gd, ccnt, ccur, (int*)nullptr, 0);
-  hipLaunchKernelGGL(k_assoc_grid_scan, dim3(1), dim3(1024), 0, c->stream, (const int*)ccnt, coff, ccur);
-  int total = 0;
-  LVX_HIP(c, hipMemcpyAsync(&total, coff + SA_CELLS, 4, hipMemcpyDeviceToHost, c->stream));
-  LVX_HIP(c, hipStreamSynchronize(c->stream));
-  if ((rc = dev_alloc(c, c->d_assoc[1], (size_t)std::max(total, 1) * 4))) return rc;
-  int* clist = (int*)c->d_assoc[1].p;
-  hipLaunchKernelGGL(k_assoc_grid_fill, dim3((unsigned)((P + 127) / 128)), dim3(128), 0, c->stream, P, planes_d, (const AssocGrid*)gd, ccnt, ccur, clist, 1);
+  // the surfel grid (depends on the plane table only): built here, or once by lvx_surfel_map_prepare_d for every later call with that table
+  if ((rc = assoc_grid_build(c, P, planes_d, c->assoc_map_ready && c->assoc_map_planes == planes_d && c->assoc_map_P == P))) return rc;
+  AssocGrid* gd = (AssocGrid*)c->d_assoc[0].p; int* ccnt = (int*)(gd + 1); int* coff = ccnt + SA_CELLS; int* clist = (int*)c->d_assoc[1].p;
+  (void)ccnt;
   hipLaunchKernelGGL(k_assoc_hits, dim3((unsigned)((H * W + 255) / 256), (unsigned)S), dim3(256), 0, c->stream, scans_d, H, W, P, planes_d, radius, (const AssocGrid*)gd, (const int*)coff, (const int*)clist,
                      bits, counts, wpr);
   hipLaunchKernelGGL(k_assoc_select, dim3((unsigned)((rings + 255) / 256)), dim3(256), 0, c->stream, bits, counts, S, H, W, P, wpr, sel, flags_d);
@@ -1215,6 +1225,16 @@ int lvx_surfel_assoc(lvx_ctx* c, int H, int W, const float* scan_map_xyzi4, int 
 }
 int lvx_surfel_assoc_d(lvx_ctx* c, int H, int W, const float* scan_d, int n_planes, const double* planes10_d, double radius, int sel_per_ring, int32_t* plane_of_point_d) {
   return lvx_surfel_assoc_batch_d(c, 1, H, W, scan_d, n_planes, planes10_d, radius, sel_per_ring, plane_of_point_d);
+}
+int lvx_surfel_map_prepare_d(lvx_ctx* c, int n_planes, const double* planes10_d) {
+  if (!c || n_planes < 0 || (n_planes > 0 && !planes10_d)) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  c->assoc_map_ready = false;
+  if (n_planes == 0) return LVX_OK;
+  int rc = assoc_grid_build(c, n_planes, planes10_d, false);
+  if (rc) return rc;
+  c->assoc_map_planes = planes10_d; c->assoc_map_P = n_planes; c->assoc_map_ready = true;
+  return LVX_OK;
 }
 int lvx_surfel_assoc_batch_d(lvx_ctx* c, int n_scans, int H, int W, const float* scans_d, int n_planes, const double* planes10_d, double radius, int sel_per_ring, int32_t* plane_of_point_d) {
   if (!c || n_scans <= 0 || H <= 0 || W <= 0 || W > SA_WMAX || n_planes < 0 || !scans_d || !plane_of_point_d || (n_planes > 0 && !planes10_d)) return LVX_E_ARG;

@@ -149,6 +149,41 @@ def test_surfel_assoc_batch_and_chronological_emission(ctx):
     assert (eg["t"] != 0).all()
 
 
+def test_surfel_map_prepared_once(ctx):
+    """lvx_surfel_map_prepare_d: the association grid of a surfel table built once (setSurfelMap), batches of scans associated against it by pointer; a call
+    with another table rebuilds and invalidates it."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    scans, want = [], []
+    p4 = bmin = bmax = None
+    for s in range(4):
+        scan, p4s, bmins, bmaxs = synth.make_assoc_problem(seed=60 + s, n_planes=250)
+        if p4 is None:
+            p4, bmin, bmax = p4s, bmins, bmaxs
+        scans.append(scan); want.append(O.surfel_assoc(scan, p4, bmin, bmax, 0.05, 2))
+    H, W, P = scans[0].shape[0], scans[0].shape[1], len(p4)
+    sc = torch.from_numpy(np.ascontiguousarray(np.stack(scans), np.float32)).to(dev)
+    pl = torch.from_numpy(np.concatenate([p4.ravel(), bmin.ravel(), bmax.ravel()])).to(dev)
+    fl = torch.empty((4, H * W), dtype=torch.int32, device=dev)
+    l = ctx._l
+    ctx._ck(l.lvx_surfel_map_prepare_d(ctx._h, C.c_int(P), C.c_void_p(pl.data_ptr())))
+    for _ in range(2):   # twice against the prepared map
+        fl.fill_(7)
+        ctx._ck(l.lvx_surfel_assoc_batch_d(ctx._h, C.c_int(4), C.c_int(H), C.c_int(W), C.c_void_p(sc.data_ptr()), C.c_int(P), C.c_void_p(pl.data_ptr()), C.c_double(0.05), C.c_int(2), C.c_void_p(fl.data_ptr())))
+        ctx.synchronize()
+        assert np.array_equal(fl.cpu().numpy().reshape(4, H, W), np.stack(want))
+    # another table (a copy with fewer planes): rebuilt for it, and the prepared state is gone — the first table is rebuilt on its next use
+    P2 = P // 2
+    pl2 = torch.from_numpy(np.concatenate([p4[:P2].ravel(), bmin[:P2].ravel(), bmax[:P2].ravel()])).to(dev)
+    ctx._ck(l.lvx_surfel_assoc_batch_d(ctx._h, C.c_int(4), C.c_int(H), C.c_int(W), C.c_void_p(sc.data_ptr()), C.c_int(P2), C.c_void_p(pl2.data_ptr()), C.c_double(0.05), C.c_int(2), C.c_void_p(fl.data_ptr())))
+    ctx.synchronize()
+    assert np.array_equal(fl.cpu().numpy().reshape(4, H, W), np.stack([O.surfel_assoc(s_, p4[:P2], bmin[:P2], bmax[:P2], 0.05, 2) for s_ in scans]))
+    ctx._ck(l.lvx_surfel_assoc_batch_d(ctx._h, C.c_int(4), C.c_int(H), C.c_int(W), C.c_void_p(sc.data_ptr()), C.c_int(P), C.c_void_p(pl.data_ptr()), C.c_double(0.05), C.c_int(2), C.c_void_p(fl.data_ptr())))
+    ctx.synchronize()
+    assert np.array_equal(fl.cpu().numpy().reshape(4, H, W), np.stack(want))
+
+
 def test_landmark_plane_association(ctx):
     """associateVisualPointsWithPlanes (surfel_association.cpp:161-214) against the oracle: boxes around some landmarks' map-frame positions,
     overlapping boxes (the highest index stays), a far landmark (rho < 0.05) and one whose box misses by the strict inequality."""
