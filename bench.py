@@ -95,6 +95,7 @@ def assoc_metric(ctx, world, rank, scans_per_gpu=64):
         while time.perf_counter() - t0 < 3.0:
             O.surfel_assoc_omp(scan, p4, bmin, bmax, 0.05, 2, cores); n += 1
         res["cpu_openmp"] = {"Mpts_per_s": H * W * n / (time.perf_counter() - t0) / 1e6, "cores": cores, "kind": "port", "sample": "%d passes over one scan, OpenMP over planes as surfel_association.cpp:122" % n}
+    ctx._ck(ctx._l.lvx_surfel_map_release(ctx._h))   # the table `pl` dies with this frame
     return res
 
 

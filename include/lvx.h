@@ -147,6 +147,9 @@ int lvx_evaluate(lvx_ctx* ctx, const double* state, uint32_t what, double* cost,
 int lvx_evaluate_d(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cost);
 /* debug / parity: expand the structured normal equations into dense host arrays (n_tangent^2 and n_tangent); small problems only */
 int lvx_get_normal_eq_dense(lvx_ctx* ctx, double* H, double* g);
+/* g = J^T r and diag(J^T J) (robustified, tangent layout, 0 for constant scalars) of the last LVX_EVAL_NORMAL_EQ evaluation — what
+ * ceres::Problem::Evaluate returns as `gradient`; any problem size; either pointer may be NULL */
+int lvx_get_gradient(lvx_ctx* ctx, double* g, double* diag);
 /* debug / parity: rows of the last LVX_EVAL_JACOBIAN evaluation: cols[n_residuals][LVX_JAC_WIDTH] (-1 = unused), vals likewise (pre-loss) */
 int lvx_get_jacobian(lvx_ctx* ctx, int32_t* cols, double* vals);
 /* run on a caller-owned HIP stream (e.g. torch's current stream) instead of the context's own; NULL restores the own stream */
@@ -286,6 +289,10 @@ int lvx_surfel_assoc_batch_d(lvx_ctx* ctx, int n_scans, int H, int W, const floa
  * grid of a surfel table once — later lvx_surfel_assoc_batch_d / lvx_surfel_assoc_d calls with THE SAME planes10_d pointer and n_planes reuse it (the caller
  * promises the table's contents are unchanged) until the next prepare or a call with another table. */
 int lvx_surfel_map_prepare_d(lvx_ctx* ctx, int n_planes, const double* planes10_d);
+/* End of the prepared table's lifetime: call it BEFORE the table's memory is freed, reused or rewritten.  The grid is keyed by (address, n_planes) only — a
+ * caching allocator hands the same address to the next table of the same size, and a stale grid would silently miss hits — so a caller that prepares owns
+ * the table until it releases (or prepares another one).  Calls without a preceding prepare build the grid per call and are always safe. */
+int lvx_surfel_map_release(lvx_ctx* ctx);
 
 /* sequence-per-GPU joint solve (BASELINE config 5) ---------------------------------------------------------*/
 /* Every rank owns one calibration sequence (trajectory, gravity, biases, landmarks are private); the rig extrinsics — lidar theta(3) p(3)
@@ -312,6 +319,9 @@ int lvx_lm_solve_shared(lvx_ctx* ctx, double* state, const lvx_lm_options* opt, 
 int lvx_rccl_unique_id(lvx_ctx* ctx, void* id128);
 int lvx_rccl_init(lvx_ctx* ctx, const void* id128, int rank, int world);
 int lvx_rccl_finalize(lvx_ctx* ctx);
+/* number of shared scalars the last joint solve of this context kept out of its local elimination (LVX_N_SHARED when a transport was active, 0 for a
+ * single-sequence solve): lets a caller / test assert that the joint path was taken */
+int lvx_joint_shared_count(lvx_ctx* ctx);
 /* reductions issued by this context since the last reset (either transport) */
 int64_t lvx_collective_count(lvx_ctx* ctx, int reset);
 

@@ -132,9 +132,9 @@ struct lvx_ctx {
   const double* last_state_d = nullptr; bool last_want_res = false, err_unchecked = false;   // see check_last_eval
   // upstream kernels (lvx_upstream.hip)
   lvx::DevBuf d_up[8];
-  size_t assoc_rings = 0; int assoc_wpr = 0;   // shape the association work buffer (d_up[7]) was cleared for
+  size_t assoc_rings = 0; int assoc_wpr = 0;   // shape the association work buffer (d_assoc[3]) was cleared for
   const double* assoc_map_planes = nullptr; int assoc_map_P = 0; bool assoc_map_ready = false;   // lvx_surfel_map_prepare_d: the association grid of this plane table is built
-  lvx::DevBuf d_assoc[3];   // surfel association: grid geometry + cell counts / offsets, cell lists, emission counters
+  lvx::DevBuf d_assoc[4];   // surfel association: grid geometry + cell counts / offsets, cell lists, emission counters, hit bitmasks + counts (private: cleared once per shape)
   int sr_n = 0, sr_rings = 0, sr_m = 0;   // input size, rings and kept points of the last lvx_scan_register (its results stay in d_up[0])
   struct Voxels {
     float leaf = 0; int min_pts = 0, n_points = 0, n_leaves = 0;
@@ -155,6 +155,7 @@ struct lvx_ctx {
   lvx::DevBuf d_comm;                                            // device staging buffer of the reductions
   int64_t n_collectives = 0;                                     // reductions issued (either transport): lvx_collective_count
   int ns = 0;                 // free shared scalars = the last ns border variables
+  int last_ns = 0;            // ns of the last solve (lvx_joint_shared_count)
   int sh_slot[LVX_N_SHARED] = {0};   // canonical slot (0..13: lidar theta p tau, cam theta p tau) of each of them
   double sh_lmd[LVX_N_SHARED] = {0}; // LM diagonal of the shared scalars (from the JOINT diagonal), added once after the reduction
   // profiling: (start, stop) event pairs per launch, read lazily by lvx_get_kernel_ms

@@ -2776,6 +2776,39 @@ int lvx_get_normal_eq_dense(lvx_ctx* c, double* H, double* g) {
   return LVX_OK;
 }
 
+// g = J^T r and diag(J^T J) of the last LVX_EVAL_NORMAL_EQ evaluation in the tangent layout, any problem size (constant scalars: 0)
+int lvx_get_gradient(lvx_ctx* c, double* g, double* diag) {
+  if (!c || (!g && !diag)) return LVX_E_ARG;
+  if (!(c->last_what & LVX_EVAL_NORMAL_EQ)) return fail(c, LVX_E_STATE, "last evaluation did not request LVX_EVAL_NORMAL_EQ");
+  LVX_HIP(c, hipSetDevice(c->device));
+  { const int rce = check_last_eval(c); if (rce) return rce; }
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  const int nt = lvx_tangent_size(c), nb = c->nb, bw = c->bw, nbd = c->nbd, ldc = c->nbd_ext;
+  std::vector<double> gb(std::max(nb, 1)), hd(std::max(nb, 1)), C((size_t)ldc * ldc), gc(std::max(nbd, 1));
+  if (nb > 0) {
+    LVX_HIP(c, hipMemcpy(gb.data(), c->d_gb.p, (size_t)nb * 8, hipMemcpyDeviceToHost));
+    LVX_HIP(c, hipMemcpy2D(hd.data(), 8, c->d_Hb.p, (size_t)(bw + 1) * 8, 8, (size_t)nb, hipMemcpyDeviceToHost));   // Hb[j][0]: the diagonal of the lower band
+  }
+  if (nbd > 0) {
+    LVX_HIP(c, hipMemcpy(C.data(), c->d_C.p, C.size() * 8, hipMemcpyDeviceToHost));
+    LVX_HIP(c, hipMemcpy(gc.data(), c->d_gc.p, (size_t)nbd * 8, hipMemcpyDeviceToHost));
+  }
+  const bool lm = c->L > 0 && c->rep.n > 0 && !(c->locks & LVX_LOCK_LANDMARKS);
+  std::vector<double> R;
+  if (lm) { R.resize((size_t)c->L * c->lm_ls); LVX_HIP(c, hipMemcpy(R.data(), c->d_lmH.p, R.size() * 8, hipMemcpyDeviceToHost)); }
+  for (int v = 0; v < nt; ++v) {
+    const int o = c->ord[v];
+    double gv = 0.0, dv = 0.0;
+    if (o == LVX_DEAD) { }
+    else if (o >= LVX_LM_BASE) { if (lm) { const double* row = &R[(size_t)(o - LVX_LM_BASE) * c->lm_ls]; dv = row[c->lm_wl + ldc]; gv = row[c->lm_wl + ldc + 1]; } }
+    else if (o >= 0) { gv = gb[o]; dv = hd[o]; }
+    else if (-1 - o < nbd) { gv = gc[-1 - o]; dv = C[(size_t)(-1 - o) * ldc + (-1 - o)]; }
+    if (g) g[v] = gv;
+    if (diag) diag[v] = dv;
+  }
+  return LVX_OK;
+}
+
 int lvx_plus(lvx_ctx* c, const double* s, const double* d, double* o) {
   if (!c || !s || !d || !o) return LVX_E_ARG;
   const int N = c->N;

@@ -706,7 +706,7 @@ static int solver_alloc(lvx_ctx* c, SolveWork& w) {
   // shared extrinsics of the joint solve: tangent 6N+8 .. 6N+21 own the LAST 14 border slots (ensure_layout gives every calibration
   // scalar a fixed slot after the hub knots; a locked one keeps an inert slot with S_aa = lmd / radius)
   c->ns = 0;
-  if (c->ar_fn) {
+  if (is_joint(c)) {   // either transport: host callback or RCCL communicator
     c->ns = LVX_N_SHARED;
     for (int k = 0; k < LVX_N_SHARED; ++k) {
       c->sh_slot[k] = k;
@@ -714,6 +714,7 @@ static int solver_alloc(lvx_ctx* c, SolveWork& w) {
       if (o != LVX_DEAD && -1 - o != c->nbd - LVX_N_SHARED + k) return fail(c, LVX_E_STATE, "shared extrinsics are not the tail of the border");
     }
   }
+  c->last_ns = c->ns;
   return LVX_OK;
 }
 
@@ -1158,6 +1159,7 @@ int lvx_rccl_finalize(lvx_ctx* c) {
   if (c->rccl_comm) { RcclApi* api = rccl_api(c); if (api) api->CommDestroy((ncclComm_t)c->rccl_comm); c->rccl_comm = nullptr; }
   return LVX_OK;
 }
+int lvx_joint_shared_count(lvx_ctx* c) { return c ? c->last_ns : 0; }
 int64_t lvx_collective_count(lvx_ctx* c, int reset) { if (!c) return 0; const int64_t n = c->n_collectives; if (reset) c->n_collectives = 0; return n; }
 
 }  // extern "C"

@@ -1157,7 +1157,8 @@ int lvx_voxel_lookup1_d(lvx_ctx* c, int nq, const float* xyzi4_d, int32_t* leaf_
   return lookup_device(c, (const float4*)xyzi4_d, nq, leaf_ids1_d, 1);
 }
 
-// S scans [S][H][W] against one plane table; flags [S][H * W].  Work buffers (bitmasks 4 P H ceil(W / 32) bytes per scan, counts) live in d_up[7].
+// S scans [S][H][W] against one plane table; flags [S][H * W].  Work buffers (bitmasks 4 P H ceil(W / 32) bytes per scan, counts) live in d_assoc[3] — a buffer
+// nothing else writes, because it is cleared only when (re)allocated or re-shaped (k_assoc_select leaves it zero).
 // geometry, per-cell counts, offsets and lists of the association grid (d_assoc[0], d_assoc[1]); have = it is already built for this table
 static int assoc_grid_build(lvx_ctx* c, int P, const double* planes_d, bool have) {
   if (have) return LVX_OK;
@@ -1183,12 +1184,12 @@ static int assoc_device(lvx_ctx* c, const float4* scans_d, int S, int H, int W, 
   const int wpr = (W + 31) / 32;
   const size_t rings = (size_t)S * P * H, bytes = rings * wpr * 4 + rings * 4;
   int rc;
-  if (!c->d_up[7].p || c->d_up[7].bytes < bytes || c->assoc_rings != rings || c->assoc_wpr != wpr) {   // (re)allocated or re-shaped: clear once; k_assoc_select leaves it clean
-    if ((rc = dev_alloc(c, c->d_up[7], bytes))) return rc;
-    LVX_HIP(c, hipMemsetAsync(c->d_up[7].p, 0, c->d_up[7].bytes, c->stream));
+  if (!c->d_assoc[3].p || c->d_assoc[3].bytes < bytes || c->assoc_rings != rings || c->assoc_wpr != wpr) {   // (re)allocated or re-shaped: clear once; k_assoc_select leaves it clean
+    if ((rc = dev_alloc(c, c->d_assoc[3], bytes))) return rc;
+    LVX_HIP(c, hipMemsetAsync(c->d_assoc[3].p, 0, c->d_assoc[3].bytes, c->stream));
     c->assoc_rings = rings; c->assoc_wpr = wpr;
   }
-  unsigned* bits = (unsigned*)c->d_up[7].p; int* counts = (int*)(bits + rings * wpr);
+  unsigned* bits = (unsigned*)c->d_assoc[3].p; int* counts = (int*)(bits + rings * wpr);
   if (S <= 2) {   // a scan or two: all pairs beat the grid build
     hipLaunchKernelGGL(k_assoc_hits_allpairs, dim3((unsigned)((H * W + 255) / 256), (unsigned)((P + SA_PC - 1) / SA_PC), (unsigned)S), dim3(256), 0, c->stream, scans_d, H, W, P, planes_d, radius, bits, counts, wpr);
     hipLaunchKernelGGL(k_assoc_select, dim3((unsigned)((rings + 255) / 256)), dim3(256), 0, c->stream, bits, counts, S, H, W, P, wpr, sel, flags_d);
@@ -1215,6 +1216,7 @@ int lvx_surfel_assoc(lvx_ctx* c, int H, int W, const float* scan_map_xyzi4, int 
   std::vector<double> pl((size_t)n_planes * 10);
   if (n_planes > 0) { std::memcpy(pl.data(), plane_p4, (size_t)n_planes * 32); std::memcpy(pl.data() + 4 * (size_t)n_planes, box_min3, (size_t)n_planes * 24); std::memcpy(pl.data() + 7 * (size_t)n_planes, box_max3, (size_t)n_planes * 24); }
   if ((rc = upload(c, c->d_up[5], pl.data(), pl.size() * 8))) return rc;
+  if (c->assoc_map_planes == (const double*)c->d_up[5].p) lvx_surfel_map_release(c);
   LVX_HIP(c, hipStreamSynchronize(c->stream));   // pl dies with this frame
   if ((rc = dev_alloc(c, c->d_up[6], npt * 4))) return rc;
   { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
@@ -1234,6 +1236,11 @@ int lvx_surfel_map_prepare_d(lvx_ctx* c, int n_planes, const double* planes10_d)
   int rc = assoc_grid_build(c, n_planes, planes10_d, false);
   if (rc) return rc;
   c->assoc_map_planes = planes10_d; c->assoc_map_P = n_planes; c->assoc_map_ready = true;
+  return LVX_OK;
+}
+int lvx_surfel_map_release(lvx_ctx* c) {
+  if (!c) return LVX_E_ARG;
+  c->assoc_map_ready = false; c->assoc_map_planes = nullptr; c->assoc_map_P = 0;
   return LVX_OK;
 }
 int lvx_surfel_assoc_batch_d(lvx_ctx* c, int n_scans, int H, int W, const float* scans_d, int n_planes, const double* planes10_d, double radius, int sel_per_ring, int32_t* plane_of_point_d) {
@@ -1287,7 +1294,12 @@ int lvx_surfel_assoc_emit(lvx_ctx* c, int n_scans, int H, int W, const float* sc
   if ((rc = upload(c, c->d_up[5], pl.data(), pl.size() * 8))) return rc;
   LVX_HIP(c, hipStreamSynchronize(c->stream));
   if ((rc = dev_alloc(c, c->d_up[6], npt * 4))) return rc;
-  if ((rc = lvx_surfel_assoc_batch_d(c, n_scans, H, W, (const float*)c->d_up[4].p, n_planes, (const double*)c->d_up[5].p, radius, sel_per_ring, (int32_t*)c->d_up[6].p))) return rc;
+  // the context-owned table was just overwritten: whatever grid was prepared for this address is stale.  One grid for all chunks of this call.
+  lvx_surfel_map_release(c);
+  if (n_scans > 2 && n_planes > 0 && (rc = lvx_surfel_map_prepare_d(c, n_planes, (const double*)c->d_up[5].p))) return rc;
+  rc = lvx_surfel_assoc_batch_d(c, n_scans, H, W, (const float*)c->d_up[4].p, n_planes, (const double*)c->d_up[5].p, radius, sel_per_ring, (int32_t*)c->d_up[6].p);
+  lvx_surfel_map_release(c);
+  if (rc) return rc;
   if (plane_of_point) LVX_HIP(c, hipMemcpyAsync(plane_of_point, c->d_up[6].p, npt * 4, hipMemcpyDeviceToHost, c->stream));
   int32_t total = 0;
   if ((rc = lvx_surfel_emit_d(c, n_scans, H, W, (const int32_t*)c->d_up[6].p, (const float*)c->d_up[4].p, (const lvx_point_xyzit*)c->d_up[2].p, 0, nullptr, nullptr, nullptr, nullptr, &total, nullptr))) return rc;

@@ -205,6 +205,12 @@ class Context:
             out["H"], out["g"] = H, g
         return out
 
+    def gradient(self):
+        """(g = J^T r, diag(J^T J)) of the last normal-equation evaluation in the tangent layout (any problem size)."""
+        g, d = np.zeros(self.tangent_size), np.zeros(self.tangent_size)
+        self._ck(self._l.lvx_get_gradient(self._h, _p(g), _p(d)))
+        return g, d
+
     def set_state(self, state):
         state = _d(state)
         assert state.size == self.state_size
@@ -328,6 +334,9 @@ class Context:
     def rccl_finalize(self):
         self._ck(self._l.lvx_rccl_finalize(self._h))
 
+    def joint_shared_count(self):
+        return int(self._l.lvx_joint_shared_count(self._h))
+
     def collective_count(self, reset=False):
         self._l.lvx_collective_count.restype = C.c_int64
         return int(self._l.lvx_collective_count(self._h, C.c_int(1 if reset else 0)))
@@ -426,8 +435,13 @@ def surfel_assoc_emit(ctx, scans_map, scans_raw, p4, box_min, box_max, radius=0.
     pl_d = torch.from_numpy(np.concatenate([_d(p4).ravel(), _d(box_min).ravel(), _d(box_max).ravel()])).to(dev)
     flags_d = torch.empty(S * H * W, dtype=torch.int32, device=dev)
     l = ctx._l
-    ctx._ck(l.lvx_surfel_assoc_batch_d(ctx._h, C.c_int(S), C.c_int(H), C.c_int(W), C.c_void_p(sm_d.data_ptr()), C.c_int(len(p4)), C.c_void_p(pl_d.data_ptr()), C.c_double(radius), C.c_int(sel),
-                                       C.c_void_p(flags_d.data_ptr())))
+    if len(p4):   # this call owns pl_d: one grid for all chunks, released before the table can be freed
+        ctx._ck(l.lvx_surfel_map_prepare_d(ctx._h, C.c_int(len(p4)), C.c_void_p(pl_d.data_ptr())))
+    try:
+        ctx._ck(l.lvx_surfel_assoc_batch_d(ctx._h, C.c_int(S), C.c_int(H), C.c_int(W), C.c_void_p(sm_d.data_ptr()), C.c_int(len(p4)), C.c_void_p(pl_d.data_ptr()), C.c_double(radius), C.c_int(sel),
+                                           C.c_void_p(flags_d.data_ptr())))
+    finally:
+        l.lvx_surfel_map_release(ctx._h)
     n = C.c_int32(0)
     counts = np.zeros(S, np.int32)
     ctx._ck(l.lvx_surfel_emit_d(ctx._h, C.c_int(S), C.c_int(H), C.c_int(W), C.c_void_p(flags_d.data_ptr()), C.c_void_p(sm_d.data_ptr()), C.c_void_p(raw_d.data_ptr()), C.c_int(0),

@@ -469,16 +469,23 @@ def _raycast_room(dirs, origin, half=(10.0, 7.5), z_lo=-1.5, z_hi=1.5, pillars=(
     return t
 
 
-def make_vlp16_sweep(seed=1, n_az=1800, n_rings=16, noise=0.02, drop_frac=0.01):
-    """One VLP-16-like sweep, azimuth-major firing order (all rings per azimuth step), range noise, a few NaN and near returns."""
+def make_vlp16_sweep(seed=1, n_az=1800, n_rings=16, noise=0.02, drop_frac=0.01, range_quantum=0.0, xyz_quantum=0.0):
+    """One VLP-16-like sweep, azimuth-major firing order (all rings per azimuth step), range noise, a few NaN and near returns.
+    range_quantum: ranges rounded to a multiple of it (a real VLP-16 reports 2 mm steps); xyz_quantum: coordinates rounded to a lattice (recordings that
+    store millimetre integers) — both make EQUAL curvatures inside a sector common, which the continuous noise never does."""
     rng = np.random.default_rng(seed)
     az = np.deg2rad(np.arange(n_az) * (360.0 / n_az))
     el = np.deg2rad(np.linspace(-15.0, 15.0, n_rings))
     A, E = np.meshgrid(az, el, indexing="ij")   # (n_az, n_rings)
     dirs = np.stack([np.cos(E) * np.cos(A), np.cos(E) * np.sin(A), np.sin(E)], axis=-1).reshape(-1, 3)
     rngs = _raycast_room(dirs, (0.3, -0.2, 0.0)) + noise * rng.standard_normal(len(dirs))
+    if range_quantum > 0:
+        rngs = np.round(rngs / range_quantum) * range_quantum
     pts = np.zeros(len(dirs), dtype=RS_POINT)
-    xyz = (dirs * rngs[:, None]).astype(np.float32)
+    xyz = dirs * rngs[:, None]
+    if xyz_quantum > 0:
+        xyz = np.round(xyz / xyz_quantum) * xyz_quantum
+    xyz = xyz.astype(np.float32)
     pts["x"], pts["y"], pts["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
     pts["ring"] = np.tile(np.arange(n_rings, dtype=np.uint16), n_az)
     pts["intensity"] = rng.integers(0, 255, len(dirs)).astype(np.uint8)

@@ -448,6 +448,91 @@ int orc_evaluate(const orc_problem* p, const double* state, double* cost, double
   return err;
 }
 
+// Matrix-free products with the robustified Jacobian, for problems whose dense J^T J does not fit (config 4: 150 k tangent scalars): one OpenMP pass
+// over the residual blocks (what one ceres::Problem::Evaluate visits, K/kontiki/trajectory_estimator.h:38-68) gives the raw residuals, the cost,
+// g = J^T r, diag(J^T J) and, for n_vec given tangent vectors V[k], HV[k] = J^T (J V[k]) — J and r scaled by sqrt(rho') as the Corrector does.
+// Thread-private accumulators, summed in thread order.  Any output may be NULL.  Returns as orc_evaluate.
+int orc_evaluate_products(const orc_problem* p, const double* state, int n_vec, const double* V, double* cost, double* residuals, double* g, double* diag, double* HV) {
+  const int nt = p->tangent_size();
+#ifdef _OPENMP
+  const int nth = p->threads > 0 ? p->threads : omp_get_max_threads();
+#else
+  const int nth = 1;
+#endif
+  const size_t per = static_cast<size_t>(2 + n_vec) * nt;
+  std::vector<double> acc(per * nth, 0.0);
+  double total = 0.0;
+  int err = 0;
+  int row0 = 0;
+  for (int fam = 0; fam < NUM_FAM; ++fam) {
+    const int cnt = p->family_count(fam);
+    const int nr = Problem::family_nres(fam);
+    const double a = p->family_huber(fam);
+    double fam_cost = 0.0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nth) reduction(+ : fam_cost)
+#endif
+    for (int i = 0; i < cnt; ++i) {
+      if (err) continue;
+#ifdef _OPENMP
+      double* my = acc.data() + per * omp_get_thread_num();
+#else
+      double* my = acc.data();
+#endif
+      try {
+        double r[4];
+        RowSet rows;
+        p->eval_one(fam, i, state, r, &rows);
+        double s = 0; for (int k = 0; k < nr; ++k) s += r[k] * r[k];
+        double rho, sr; huber(a, s, rho, sr);
+        fam_cost += 0.5 * rho;
+        const int row = row0 + i * nr;
+        if (residuals) for (int k = 0; k < nr; ++k) residuals[row + k] = r[k];
+        const int nc = static_cast<int>(rows.cols.size());
+        for (int k = 0; k < nr; ++k) {
+          const double rk = sr * r[k];
+          for (int a1 = 0; a1 < nc; ++a1) { const double ja = sr * rows.vals[k][a1]; my[rows.cols[a1]] += ja * rk; my[nt + rows.cols[a1]] += ja * ja; }
+          for (int v = 0; v < n_vec; ++v) {
+            const double* x = V + static_cast<size_t>(v) * nt;
+            double jx = 0; for (int a1 = 0; a1 < nc; ++a1) jx += sr * rows.vals[k][a1] * x[rows.cols[a1]];
+            double* y = my + static_cast<size_t>(2 + v) * nt;
+            for (int a1 = 0; a1 < nc; ++a1) y[rows.cols[a1]] += sr * rows.vals[k][a1] * jx;
+          }
+        }
+      } catch (const orc::range_error&) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        err = -1;
+      } catch (const orc::nonunit_quat_error&) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        err = -2;
+      } catch (const std::exception&) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        err = -3;
+      }
+    }
+    total += fam_cost;
+    row0 += cnt * nr;
+  }
+  if (cost) *cost = total;
+  for (int j = 0; j < nt; ++j) {
+    double sg = 0, sd = 0;
+    for (int th = 0; th < nth; ++th) { sg += acc[per * th + j]; sd += acc[per * th + nt + j]; }
+    if (g) g[j] = sg;
+    if (diag) diag[j] = sd;
+  }
+  if (HV) for (int v = 0; v < n_vec; ++v) for (int j = 0; j < nt; ++j) {
+    double sy = 0; for (int th = 0; th < nth; ++th) sy += acc[per * th + static_cast<size_t>(2 + v) * nt + j];
+    HV[static_cast<size_t>(v) * nt + j] = sy;
+  }
+  return err;
+}
+
 // x_plus = x (+) delta: Euclidean add for vectors, EigenQuaternionParameterization::Plus for quaternions
 // (q_new = [sin|d|/|d| d, cos|d|] * q; ceres, restated).  delta in the tangent layout.
 void orc_plus(const orc_problem* p, const double* state, const double* delta, double* out) {

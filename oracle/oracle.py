@@ -156,6 +156,26 @@ class Oracle:
             out["H"], out["g"] = H, g
         return out
 
+    def evaluate_products(self, state, V=None):
+        """Matrix-free pass for problems too large for the dense H: dict(cost, residuals, g = J^T r, diag = diag(J^T J)[, HV = J^T J V]) with the
+        robustified J; V: [k, n_tangent] or None.  OpenMP over the blocks (set_threads)."""
+        state = _d(state)
+        assert state.size == self.state_size
+        nt, nr = self.tangent_size, self.num_residuals
+        V = None if V is None else _d(np.atleast_2d(V))
+        k = 0 if V is None else V.shape[0]
+        assert V is None or V.shape[1] == nt
+        cost = C.c_double(0)
+        res, g, diag = np.zeros(nr), np.zeros(nt), np.zeros(nt)
+        HV = np.zeros((k, nt)) if k else None
+        rc = self._l.orc_evaluate_products(self._h, _p(state), C.c_int(k), _p(V), C.byref(cost), _p(res), _p(g), _p(diag), _p(HV))
+        if rc == -1:
+            raise IndexError("oracle: time span out of range for trajectory (std::range_error)")
+        if rc == -2:
+            raise ValueError("oracle: logq of a non-unit quaternion (std::runtime_error)")
+        assert rc == 0
+        return {"cost": cost.value, "residuals": res, "g": g, "diag": diag, "HV": HV}
+
     def plus(self, state, delta):
         state, delta = _d(state), _d(delta)
         out = np.zeros_like(state)

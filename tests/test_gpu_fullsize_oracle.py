@@ -1,0 +1,105 @@
+"""Config 4 at FULL size (1 M surfel + 200 k gyro + 200 k accel + 50 k reprojection blocks, 25 k knots, 150 k tangent scalars) against the CPU oracle,
+matrix-free — the dense J^T J (180 GB) is the only thing that does not fit, so everything else is compared:
+
+(i)   every residual row, the cost, g = J^T r and diag(J^T J) of the HIP pass against the oracle's dual-number evaluation of the same 1.45 M blocks
+      (one OpenMP pass over all host cores: oracle/lvx_oracle.cpp::orc_evaluate_products);
+(ii)  the damped step of the block-cyclic-reduction solver is checked against the linear system IT SHOULD SOLVE, built from the ORACLE's Jacobian:
+      || S J^T (J delta) + D_s S^-1 delta + S g ||  <=  tol * || S g ||, D_s = clamp(S^2 diag(J^T J), 1e-6, 1e32) / radius, with and without Jacobi scaling
+      (what one iteration of ceres::Solve computes: TRUST_REGION / LEVENBERG_MARQUARDT / SPARSE_SCHUR exact step, kontiki/trajectory_estimator.h:38-68);
+(iii) the same step from the sequential band Cholesky (LVX_SOLVER_SEQ=1) — an independent elimination order — agrees with the cyclic-reduction step.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import lvx
+import synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+TAU = lvx.LOCK_LIDAR_TAU | lvx.LOCK_CAM_TAU
+RADIUS = 1e4
+
+
+@pytest.fixture(scope="module")
+def full():
+    P = synth.make_bench_problem(seed=4)
+    g = lvx.Context(0)
+    o = O.Oracle()
+    for obj in (g, o):
+        lvx.load_problem(obj, P, TAU)
+    x = P["state0"]
+    rg = g.evaluate(x, normal_eq=True, dense=False)
+    gg, dg = g.gradient()
+    steps = {}
+    for name, scaling in (("scaled", True), ("unscaled", False)):
+        steps[name] = g.solve_step(RADIUS, scaling)
+    g.set_switch("SOLVER_SEQ", 1)
+    g.evaluate(x, normal_eq=True, dense=False, residuals=False)
+    steps["scaled_seq"] = g.solve_step(RADIUS, True)
+    g.set_switch("SOLVER_SEQ", 0)
+    lo = g.layout()
+    g.close()
+    ro = o.evaluate_products(x, V=np.stack([steps["scaled"][0], steps["unscaled"][0]]))
+    return dict(P=P, rg=rg, gg=gg, dg=dg, steps=steps, ro=ro, lo=lo, n_blocks=o.num_blocks)
+
+
+def test_every_residual_row_and_the_cost_match_the_oracle(full):
+    rg, ro, lo = full["rg"], full["ro"], full["lo"]
+    assert lo["n_blocks"] == full["n_blocks"] >= 1_449_000 and lo["exact_fallback"] == 0
+    assert len(rg["residuals"]) == len(ro["residuals"]) == lo["n_residuals"] >= 2_299_000   # 3 x (200 k + 200 k) IMU rows + 1 M surfel rows + 2 x 50 k reprojection rows
+    err = np.abs(rg["residuals"] - ro["residuals"])
+    scale = np.maximum(np.abs(ro["residuals"]), 1e-3 * np.abs(ro["residuals"]).max())   # relative per row, floored at 1e-3 of the largest row
+    print("residual rows: max rel err %.3e, cost rel err %.3e" % ((err / scale).max(), abs(rg["cost"] - ro["cost"]) / ro["cost"]))
+    assert (err / scale).max() <= 1e-11
+    assert abs(rg["cost"] - ro["cost"]) <= 1e-12 * abs(ro["cost"])
+
+
+def _block_scale(v, n_knots):
+    """max |v| per parameter block kind (positions, rotations, each calibration block, inverse depths): entries are compared relative to their own block's scale."""
+    s = np.empty_like(v)
+    k = v[:6 * n_knots].reshape(n_knots, 6)
+    sk = np.empty_like(k)
+    sk[:, :3] = np.abs(k[:, :3]).max()
+    sk[:, 3:] = np.abs(k[:, 3:]).max()
+    s[:6 * n_knots] = sk.ravel()
+    b = 6 * n_knots
+    for lo_, hi_ in ((0, 2), (2, 5), (5, 8), (8, 11), (11, 14), (14, 15), (15, 18), (18, 21), (21, 22)):
+        s[b + lo_:b + hi_] = max(np.abs(v[b + lo_:b + hi_]).max(), 1e-300)
+    s[b + 22:] = max(np.abs(v[b + 22:]).max(), 1e-300) if len(v) > b + 22 else 1.0
+    return s
+
+
+def test_gradient_and_diagonal_match_the_oracle(full):
+    n = full["lo"]["n_knots"]
+    for name, a, b in (("g", full["gg"], full["ro"]["g"]), ("diag", full["dg"], full["ro"]["diag"])):
+        rel = np.abs(a - b) / _block_scale(b, n)
+        print("%s: max block-scaled err %.3e" % (name, rel.max()))
+        assert rel.max() <= 1e-10
+    assert (full["ro"]["diag"] >= 0).all() and np.count_nonzero(full["ro"]["diag"]) >= 150_000
+
+
+@pytest.mark.parametrize("which,idx,scaling", [("scaled", 0, True), ("unscaled", 1, False)])
+def test_cyclic_reduction_step_solves_the_oracles_damped_system(full, which, idx, scaling):
+    ro = full["ro"]
+    delta, mcc = full["steps"][which]
+    H_delta, g, diag = ro["HV"][idx], ro["g"], ro["diag"]
+    S = 1.0 / (1.0 + np.sqrt(diag)) if scaling else np.ones_like(diag)
+    D = np.clip(S * S * diag, 1e-6, 1e32) / RADIUS
+    res = S * H_delta + D * (delta / S) + S * g
+    rel = np.linalg.norm(res) / np.linalg.norm(S * g)
+    model = -(g @ delta) - 0.5 * (delta @ H_delta)
+    print("%s step: |residual| / |S g| = %.3e, model cost change %.9e (lvx %.9e)" % (which, rel, model, mcc))
+    assert rel <= 1e-8
+    assert abs(model - mcc) <= 1e-8 * abs(model) and model > 0
+
+
+def test_sequential_band_cholesky_gives_the_same_step(full):
+    d1, m1 = full["steps"]["scaled"]
+    d2, m2 = full["steps"]["scaled_seq"]
+    n = full["lo"]["n_knots"]
+    rel = np.abs(d1 - d2) / _block_scale(d2, n)
+    print("BCR vs sequential band Cholesky: max block-scaled step difference %.3e" % rel.max())
+    assert rel.max() <= 1e-7
+    assert abs(m1 - m2) <= 1e-9 * abs(m2)

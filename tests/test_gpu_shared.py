@@ -193,10 +193,34 @@ def test_rccl_transport_single_rank_equals_plain_solve():
     g.rccl_init(g.rccl_unique_id(), 0, 1)
     g.collective_count(reset=True)
     xb, sb = g.lm_solve_shared(x0, None, max_iterations=8)
+    assert g.joint_shared_count() == 14       # the 14 extrinsic scalars stayed out of the local elimination: the reduced 14 x 14 system went through ncclAllReduce
     assert g.collective_count() == 2 + 2 * sb["iterations"] + 2 * int(np.sum(np.asarray(sb["accepted"]) == 1))
     g.rccl_finalize()
     assert sa["iterations"] == sb["iterations"] and list(sa["accepted"]) == list(sb["accepted"]) and sa["termination"] == sb["termination"]
     assert np.abs(sa["cost_history"] - sb["cost_history"]).max() <= 1e-9 * sa["cost_history"].max()
     N = P["n_knots"]
     assert np.abs(xa[7 * N:7 * N + 32] - xb[7 * N:7 * N + 32]).max() <= 1e-7
+    g.close()
+
+
+def test_rccl_and_callback_transports_agree_on_one_rank():
+    """Both transports of the joint solve on the same sequence, world of one: the host-callback transport (an identity all-reduce) and the RCCL transport
+    (pack -> ncclAllReduce -> 14 x 14 solve on the device) run the SAME reduced-system protocol — shared block kept out of the local elimination, shared
+    damping added once after the reduction — so their iterates agree to rounding, and both report 14 shared scalars."""
+    P, x0 = _sequences()[0]
+    N = P["n_knots"]
+    g = lvx.Context(0)
+    lvx.load_problem(g, P, TAU)
+    xa, sa = g.lm_solve_shared(x0, lambda buf, op: None, max_iterations=8)
+    assert g.joint_shared_count() == 14
+    g.rccl_init(g.rccl_unique_id(), 0, 1)
+    xb, sb = g.lm_solve_shared(x0, None, max_iterations=8)
+    assert g.joint_shared_count() == 14
+    g.rccl_finalize()
+    xc, sc = g.lm_solve(x0, max_iterations=8)
+    assert g.joint_shared_count() == 0
+    assert sa["iterations"] == sb["iterations"] and list(sa["accepted"]) == list(sb["accepted"]) and sa["termination"] == sb["termination"]
+    assert np.abs(sa["cost_history"] - sb["cost_history"]).max() <= 1e-12 * sa["cost_history"].max()
+    assert np.abs(xa - xb).max() <= 1e-10
+    assert np.abs(xa[7 * N:7 * N + 32] - xc[7 * N:7 * N + 32]).max() <= 1e-7
     g.close()

@@ -10,6 +10,7 @@ import pytest
 import lvx
 import synth
 from oracle import oracle as O
+from upstream_checks import check_voxels as _check_voxels
 
 pytestmark = pytest.mark.gpu
 
@@ -66,25 +67,6 @@ def test_scan_register_edge_cases(ctx):
     assert r["n"] == 0 and len(r["sharp"]) == 0
     pts = synth.make_vlp16_sweep(seed=6, n_az=200)
     _check_scanreg(ctx, pts, 16, 100.0)                       # min range removes every point
-
-
-def _check_voxels(vg, vo):
-    assert vg["n_leaves"] == vo["n_leaves"] and np.array_equal(vg["grid"], vo["grid"])
-    assert np.array_equal(vg["leaf_key"], vo["leaf_key"]) and np.array_equal(vg["leaf_n"], vo["leaf_n"])
-    assert np.array_equal(vg["offsets"], vo["offsets"]) and np.array_equal(vg["point_ids"][:vo["offsets"][-1]], vo["point_ids"][:vo["offsets"][-1]])
-    assert np.allclose(vg["mean"], vo["mean"], rtol=1e-12, atol=1e-12)
-    assert np.array_equal(vg["centroid"].view(np.uint32), vo["centroid"].view(np.uint32))
-    ok = vo["leaf_n"] >= 6
-    sc = np.abs(vo["cov"][ok]).max(axis=1, keepdims=True)
-    assert (np.abs(vg["cov"][ok] - vo["cov"][ok]) <= 1e-12 * sc + 1e-18).all()
-    assert np.allclose(vg["evals"][ok], vo["evals"][ok], rtol=1e-10, atol=1e-16)
-    si = np.abs(vo["icov"][ok]).max(axis=1, keepdims=True)
-    assert (np.abs(vg["icov"][ok] - vo["icov"][ok]) <= 1e-8 * si).all()
-    Vg, Vo = vg["evecs"][ok].reshape(-1, 3, 3), vo["evecs"][ok].reshape(-1, 3, 3)
-    ev = vo["evals"][ok]
-    sep = (np.diff(ev, axis=1).min(axis=1) > 1e-6 * ev[:, 2])       # eigenvectors only comparable for separated eigenvalues
-    dots = np.abs(np.einsum("nij,nij->nj", Vg[sep], Vo[sep]))
-    assert (dots > 1 - 1e-8).all()
 
 
 def test_voxel_build_and_lookup_config2(ctx):
@@ -182,6 +164,36 @@ def test_surfel_map_prepared_once(ctx):
     ctx._ck(l.lvx_surfel_assoc_batch_d(ctx._h, C.c_int(4), C.c_int(H), C.c_int(W), C.c_void_p(sc.data_ptr()), C.c_int(P), C.c_void_p(pl.data_ptr()), C.c_double(0.05), C.c_int(2), C.c_void_p(fl.data_ptr())))
     ctx.synchronize()
     assert np.array_equal(fl.cpu().numpy().reshape(4, H, W), np.stack(want))
+    # lifetime: prepare -> release -> the SAME address and plane count now hold another table (what a caching allocator hands out): no stale grid
+    ctx._ck(l.lvx_surfel_map_prepare_d(ctx._h, C.c_int(P), C.c_void_p(pl.data_ptr())))
+    ctx._ck(l.lvx_surfel_map_release(ctx._h))
+    _, p4b, bminb, bmaxb = synth.make_assoc_problem(seed=77, n_planes=250)
+    assert len(p4b) == P and not np.array_equal(p4b, p4)
+    pl.copy_(torch.from_numpy(np.concatenate([p4b.ravel(), bminb.ravel(), bmaxb.ravel()])))
+    ctx._ck(l.lvx_surfel_assoc_batch_d(ctx._h, C.c_int(4), C.c_int(H), C.c_int(W), C.c_void_p(sc.data_ptr()), C.c_int(P), C.c_void_p(pl.data_ptr()), C.c_double(0.05), C.c_int(2), C.c_void_p(fl.data_ptr())))
+    ctx.synchronize()
+    assert np.array_equal(fl.cpu().numpy().reshape(4, H, W), np.stack([O.surfel_assoc(s_, p4b, bminb, bmaxb, 0.05, 2) for s_ in scans]))
+
+
+def test_association_work_buffer_is_private(ctx):
+    """The association's hit bitmasks are cleared once per shape and left clean by the selection kernel: nothing else may write that buffer.  De-skew and the
+    batched pose evaluation upload the state vector into a context buffer between two associations of the same shape (what every refinement round of
+    DataAssociation does) — the second association must be unaffected."""
+    P = synth.make_problem(seed=33, duration=1.5, n_surfel=50, n_planes=4, n_landmarks=40, n_camsurf=0)
+    scan, p4, bmin, bmax = synth.make_assoc_problem(seed=61, n_planes=250)
+    want = O.surfel_assoc(scan, p4, bmin, bmax, 0.05, 2)
+    assert np.array_equal(lvx.surfel_assoc(ctx, scan, p4, bmin, bmax, 0.05, 2), want)
+    ctx.set_spline(P["t0"], P["dt"], P["n_knots"])
+    state = P["state_true"].copy()
+    state[:] = np.where(np.arange(len(state)) % 2 == 0, -1.0, state)      # bit patterns with every mask bit set somewhere
+    raw = np.zeros(64, lvx.POINT_XYZIT); raw["timestamp"] = P["t0"] + 0.3
+    for _ in range(2):
+        lvx.eval_lidar_pose(ctx, P["state_true"], np.array([P["t0"] + 0.2]))
+        try:
+            lvx.undistort(ctx, state, raw, [0, 0, 0, 1.0], [0, 0, 0.0])
+        except lvx.LvxError:
+            pass
+        assert np.array_equal(lvx.surfel_assoc(ctx, scan, p4, bmin, bmax, 0.05, 2), want)
 
 
 def test_landmark_plane_association(ctx):

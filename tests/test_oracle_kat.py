@@ -171,3 +171,17 @@ def test_oracle_lm_recovers_extrinsics_on_noise_free_data():
     ut, ux = synth.unpack_state(P["state_true"], P["n_knots"], 0), synth.unpack_state(x, P["n_knots"], 0)
     d = synth.qmul(ux["lidar"][:4], synth.qconj(ut["lidar"][:4]))
     assert 2 * np.arctan2(np.linalg.norm(d[:3]), abs(d[3])) < 5e-3
+
+
+def test_matrix_free_products_equal_the_dense_normal_equations():
+    # orc_evaluate_products (the full-size checker of tests/test_gpu_fullsize_oracle.py) against the dense assembly of orc_evaluate
+    P = synth.make_problem(seed=21, duration=1.0, n_surfel=500, n_planes=8, n_landmarks=20, n_camsurf=5)
+    o = O.Oracle(); lvx.load_problem(o, P, TAU)
+    d = o.evaluate(P["state0"], normal_eq=True)
+    V = np.random.default_rng(0).standard_normal((2, o.tangent_size))
+    m = o.evaluate_products(P["state0"], V)
+    assert abs(m["cost"] - d["cost"]) <= 1e-13 * d["cost"]
+    assert np.array_equal(m["residuals"], d["residuals"])
+    assert np.abs(m["g"] - d["g"]).max() <= 1e-13 * np.abs(d["g"]).max()
+    assert np.abs(m["diag"] - np.diag(d["H"])).max() <= 1e-13 * np.diag(d["H"]).max()
+    assert np.abs(m["HV"] - V @ d["H"]).max() <= 1e-13 * np.abs(V @ d["H"]).max()
