@@ -115,9 +115,8 @@ def secondary_metrics(ctx, P, lo):
                                "note": "evaluate(+J^T J) + landmark elimination + block-cyclic-reduction solve + candidate cost evaluation per iteration; host-synchronised"}
     except Exception as e:   # noqa: BLE001
         sec["lm_iteration"] = {"error": str(e)[:200]}
-    try:   # config 4 "to convergence": the reference's stage schedule to a Ceres termination (tests/calib_stages.py, tests/test_gpu_converge.py)
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import calib_stages as cs
+    try:   # config 4 "to convergence": the reference's stage schedule to a Ceres termination (lvi-exc_amd/stages.py, tests/test_gpu_converge.py)
+        import stages as cs
         x, log = cs.run_stages_gpu(P, P["state0"])
         sec["converged_solve"] = {"seconds": sum(dt for _, _, dt in log), "stages": [{"stage": n, "iterations": s["iterations"], "termination": s["termination"], "final_cost": s["final_cost"], "seconds": dt}
                                                                                         for n, s, dt in log],

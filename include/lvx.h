@@ -355,6 +355,31 @@ int lvx_surfel_emit_d(lvx_ctx* ctx, int n_scans, int H, int W, const int32_t* fl
 int lvx_surfel_assoc_emit(lvx_ctx* ctx, int n_scans, int H, int W, const float* scans_map_xyzi4, const lvx_point_xyzit* scans_raw, int n_planes, const double* plane_p4,
                           const double* box_min3, const double* box_max3, double radius, int sel_per_ring, int32_t* plane_of_point, int max_out, double* pt3, double* pt_map3, double* t,
                           int32_t* plane, int32_t* n_out);
+/* LIinitializer::DataAssociation, refinement branch (src/lvi_exc/test/lvi_initialize_surfel_orb.cpp:1180-1201), device-resident end to end:
+ *   ScanUndistortion::undistortScanInMap (every point of every scan de-skewed into the LiDAR frame at the map time; map cloud = the scans concatenated),
+ *   LiDAROdometry::ndtInit(resolution) + setInputTarget(map cloud) (voxel covariance grid), SurfelAssociation::setSurfelMap, getAssociation per scan.
+ * lvx_set_scans hands over the dataset's organised raw scans once (LioDataset::get_scan_data: [n_scans][H][W], per-point timestamps, NaN x = no return);
+ * lvx_data_association runs one association round at `state` and leaves the surfel map and the chronological SurfelPoint list in the context:
+ * four launches-with-a-count go back to the host (map pose validity, grid extent, leaf count, list length), nothing else does.
+ * averageTimeDownSmaple (every step-th point, surfel_association.cpp:240-244) is the caller's: it picks from the arrays of lvx_get_surfel_points. */
+typedef struct lvx_assoc_options {
+  float ndt_resolution;              /* lvi.yaml:26, 0.5 */
+  int32_t min_points_per_voxel;      /* voxel_grid_covariance_omp.h:207, 6 */
+  double min_covar_eigvalue_mult;    /* :208, 0.01 */
+  double plane_lambda;               /* 0.7 (lvi_initialize_surfel_orb.cpp:1183) */
+  double fit_threshold;              /* RANSAC distance threshold 0.05 (surfel_association.cpp:279) */
+  int32_t min_leaf_points, min_inliers;   /* 10 (:61), 20 (:283) */
+  double radius;                     /* associated_radius_ 0.05 */
+  int32_t selected_per_ring, reserved;    /* getAssociation(..., 2) */
+} lvx_assoc_options;
+int lvx_assoc_default_options(lvx_assoc_options* opt);
+int lvx_set_scans(lvx_ctx* ctx, int n_scans, int H, int W, const lvx_point_xyzit* raw);
+int lvx_data_association(lvx_ctx* ctx, const double* state, double map_time, const lvx_assoc_options* opt, int32_t* n_planes, int32_t* n_points);
+int lvx_get_surfel_map(lvx_ctx* ctx, int max_planes, lvx_surfel_plane* planes);
+int lvx_get_surfel_points(lvx_ctx* ctx, int max_points, double* pt3, double* pt_map3, double* t, int32_t* plane);
+/* parity / debug: the de-skewed scans of the last lvx_data_association, [n_scans][H][W][4] float */
+int lvx_get_scans_in_map(lvx_ctx* ctx, float* xyzi4);
+
 /* SurfelAssociation::associateVisualPointsWithPlanes (surfel_association.cpp:161-214) over the landmark table of lvx_set_landmarks and the inverse depths in `state`:
  * plane_of_landmark[l] = index of the surfel whose AABB strictly contains the landmark (map frame) within 2 * radius of its plane — the highest such index, as the
  * reference's loop leaves it — or -1 (also for rho < 0.05 and for reference views outside the spline).  q_LtoC (x, y, z, w), t_LinC: LiDAR pose in the camera frame. */

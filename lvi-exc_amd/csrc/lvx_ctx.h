@@ -135,6 +135,9 @@ struct lvx_ctx {
   size_t assoc_rings = 0; int assoc_wpr = 0;   // shape the association work buffer (d_assoc[3]) was cleared for
   const double* assoc_map_planes = nullptr; int assoc_map_P = 0; bool assoc_map_ready = false;   // lvx_surfel_map_prepare_d: the association grid of this plane table is built
   lvx::DevBuf d_assoc[4];   // surfel association: grid geometry + cell counts / offsets, cell lists, emission counters, hit bitmasks + counts (private: cleared once per shape)
+  // device-resident DataAssociation (lvx_set_scans / lvx_data_association): [0] raw scans, [1] state, [2] map time, [3] map pose, [4] scans in the map frame = map cloud,
+  // [5] plane table, [6] flags, [7] SurfelPoint arrays
+  lvx::DevBuf d_da[8]; int da_S = 0, da_H = 0, da_W = 0, da_points = 0; std::vector<lvx_surfel_plane> da_planes;
   int sr_n = 0, sr_rings = 0, sr_m = 0;   // input size, rings and kept points of the last lvx_scan_register (its results stay in d_up[0])
   struct Voxels {
     float leaf = 0; int min_pts = 0, n_points = 0, n_leaves = 0;

@@ -156,6 +156,22 @@ LVX_HD quat expq_half(v3 v) {
 // t in [t0_seg, t0_seg + (n-3) dt) and otherwise retries t - 1e-5 (:196-203), then recomputes u against the
 // SEGMENT origin (:153-157).  n_seg = 4 for single-time spans.  Returns false on std::range_error.
 // ---------------------------------------------------------------------------------------------
+// c + a * b in TWO roundings.  The evaluator is compiled with FP contraction on, but time arithmetic must round like the reference's separately
+// rounded expressions: the segment origin t0_seg = t0 + dt * i1 (spline_base.h:399) and the range bounds t0 + (n - 3) * dt (:48-56) decide which knot
+// interval a measurement falls into and its interpolation amount u — fused, t0_seg moves by an ulp of t (6e-14 s at t = 500 s), u by 3e-12, and a
+// gyroscope row of a 500 s trajectory by 1e-11 of the family's scale (found by tests/test_gpu_fullsize_oracle.py; invisible at 10 s).
+// (An empty asm keeps the product in a register of its own: under -ffp-contract=fast the backend fuses any fmul + fadd it sees, whatever the
+// source-level contraction pragmas say.)
+LVX_HD double madd_2r(double a, double b, double c) {
+  double p = a * b;
+#if defined(__AMDGCN__)
+  asm volatile("" : "+v"(p));
+#else
+  asm volatile("" : "+x"(p));
+#endif
+  return c + p;
+}
+
 struct KnotRef { int i0; double u; };   // master index of the first of the four control points; interpolation amount
 
 // x / dt for the knot lookups, whose floor() classifies a measurement into its knot interval and must agree with the division's.
@@ -171,7 +187,7 @@ LVX_HD double quot_dt(double x, double dt) {
 }
 
 LVX_HD bool knot_lookup_seg(double t0_seg, double dt, int n_seg, int i1, double t, KnotRef* out) {
-  const double tmin = t0_seg, tmax = t0_seg + (double)(n_seg - 3) * dt;
+  const double tmin = t0_seg, tmax = madd_2r((double)(n_seg - 3), dt, t0_seg);
   double te = t;
   if (!((te >= tmin) && (te < tmax))) {
     te = t - 0.00001;
@@ -186,10 +202,10 @@ LVX_HD bool knot_lookup_seg(double t0_seg, double dt, int n_seg, int i1, double 
 }
 // single-time span {{t_span, t_span}} evaluated at t_eval (= t_span + time offset): 4-knot segment
 LVX_HD bool knot_lookup(double t0, double dt, int n_knots, double t_span, double t_eval, KnotRef* out) {
-  const double tmax_master = t0 + (double)(n_knots - 3) * dt;
+  const double tmax_master = madd_2r((double)(n_knots - 3), dt, t0);
   if (n_knots < 4 || t_span < t0 || t_span >= tmax_master) return false;   // CheckTimeSpans, trajectory_estimator.h:102-127
   const int i1 = (int)floor(quot_dt(t_span - t0, dt));
-  return knot_lookup_seg(t0 + dt * (double)i1, dt, 4, i1, t_eval, out);
+  return knot_lookup_seg(madd_2r(dt, (double)i1, t0), dt, 4, i1, t_eval, out);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -39,7 +39,7 @@ struct Segs { int nseg; int i1[2]; int n[2]; };
 
 LVX_HD bool build_segments(const SplineRef& sp, const double spans[][2], int nspans, Segs* s) {
   if (sp.n < 4) return false;
-  const double tmin = sp.t0, tmax = sp.t0 + (double)(sp.n - 3) * sp.dt;
+  const double tmin = sp.t0, tmax = madd_2r((double)(sp.n - 3), sp.dt, sp.t0);
   double t1_prev = 0.0;
   // at most two segments: kept in scalars (a dynamically indexed i1[] / n[] would live in scratch memory on the GPU)
   int nseg = 0, i1a = 0, i1b = 0, na = 0, nb = 0;
@@ -71,8 +71,8 @@ LVX_HD bool seg_lookup(const SplineRef& sp, const Segs& s, double t, KnotRef* ou
   for (int k = 0; k < 2; ++k) {   // constant indices: the two segments stay in registers
     if (k >= s.nseg) break;
     const int i1 = k == 0 ? s.i1[0] : s.i1[1], n = k == 0 ? s.n[0] : s.n[1];
-    const double t0s = sp.t0 + sp.dt * (double)i1;
-    const double tmax = t0s + (double)(n - 3) * sp.dt;
+    const double t0s = madd_2r(sp.dt, (double)i1, sp.t0);
+    const double tmax = madd_2r((double)(n - 3), sp.dt, t0s);
     double te = t;
     bool in = (te >= t0s) && (te < tmax);
     if (!in) { te = t - 0.00001; in = (te >= t0s) && (te < tmax); }
@@ -94,7 +94,7 @@ LVX_HD bool seg_lookup(const SplineRef& sp, const Segs& s, double t, KnotRef* ou
 // 2 (seg_lookup(te_b) would fail), or -1: merged / overlapping segments — the caller takes the generic path.
 LVX_HD int two_point_lookup(const SplineRef& sp, double t_a, double t_b, double te_b, KnotRef* kb) {
   if (sp.n < 4) return 1;
-  const double tmin = sp.t0, tmax = sp.t0 + (double)(sp.n - 3) * sp.dt;
+  const double tmin = sp.t0, tmax = madd_2r((double)(sp.n - 3), sp.dt, sp.t0);
   if ((t_a < tmin) || (t_a >= tmax)) return 1;
   if ((t_b < tmin) || (t_b >= tmax)) return 1;
   if (t_b < t_a) return 1;
@@ -102,13 +102,13 @@ LVX_HD int two_point_lookup(const SplineRef& sp, double t_a, double t_b, double 
   const int ib = (int)floor(quot_dt(t_b - sp.t0, sp.dt));
   if (ib <= ia + 3) return -1;
   {
-    const double t0s = sp.t0 + sp.dt * (double)ia, tm = t0s + (double)(4 - 3) * sp.dt;
+    const double t0s = madd_2r(sp.dt, (double)ia, sp.t0), tm = madd_2r((double)(4 - 3), sp.dt, t0s);
     double te = te_b;
     bool in = (te >= t0s) && (te < tm);
     if (!in) { te = te_b - 0.00001; in = (te >= t0s) && (te < tm); }
     if (in) return -1;
   }
-  const double t0s = sp.t0 + sp.dt * (double)ib, tm = t0s + (double)(4 - 3) * sp.dt;
+  const double t0s = madd_2r(sp.dt, (double)ib, sp.t0), tm = madd_2r((double)(4 - 3), sp.dt, t0s);
   double te = te_b;
   bool in = (te >= t0s) && (te < tm);
   if (!in) { te = te_b - 0.00001; in = (te >= t0s) && (te < tm); }
@@ -480,8 +480,8 @@ LVX_HD int reproj_residual(const SplineRef& sp, const CamIntr& ci, const SensorC
   Segs segs;
   if (!build_segments(sp, spans, 2, &segs)) return RES_RANGE;
   const double row_delta = ci.readout / (double)ci.rows;
-  const double t_ref = t0_ref + cam.tau + v_ref * row_delta;
-  const double t_obs = t0_obs + cam.tau + v_obs * row_delta;
+  const double t_ref = madd_2r(v_ref, row_delta, t0_ref + cam.tau);   // (t0 + tau) + v * row_delta, three roundings like the reference's expression (:32-33)
+  const double t_obs = madd_2r(v_obs, row_delta, t0_obs + cam.tau);
   KnotRef kr, ko;
   if (!seg_lookup(sp, segs, t_ref, &kr)) return RES_RANGE;
   if (!seg_lookup(sp, segs, t_obs, &ko)) return RES_RANGE;

@@ -15,6 +15,7 @@
 #include <cstring>
 
 #include "lvx_ctx.h"
+#include "lvx_stdsort.h"
 
 namespace lvx {
 
@@ -95,6 +96,12 @@ __global__ __launch_bounds__(256) void k_sr_curv(const float4* cloud, int m, flo
   curv[i] = dX * dX + dY * dY + dZ * dZ;
 }
 #define SR_SEC_MAX 2048
+// (curvature bits << 32 | point index), ordered by the curvature as the reference's comp does (scanRegistration.cpp:87): float compare, index ignored
+struct SrKeyLess { __device__ __forceinline__ bool operator()(unsigned long long x, unsigned long long y) const { return __uint_as_float((unsigned)(x >> 32)) < __uint_as_float((unsigned)(y >> 32)); } };
+__device__ __forceinline__ bool sr_key_tie(unsigned long long a, unsigned long long b) {   // equal curvatures (or a NaN, which no bit order represents): std::sort's order is not the parallel sort's
+  const unsigned ha = (unsigned)(a >> 32), hb = (unsigned)(b >> 32);
+  return ha == hb || ha > 0x7f800000u || hb > 0x7f800000u;
+}
 __device__ __forceinline__ float sr_gap2(const float4* c, int a, int b) {
   const float dx = c[a].x - c[b].x, dy = c[a].y - c[b].y, dz = c[a].z - c[b].z;
   return dx * dx + dy * dy + dz * dz;
@@ -144,6 +151,16 @@ __device__ __forceinline__ void sr_classify_ring(const SrView<LDSR>& V, unsigned
         }
         __syncthreads();
       }
+    {   // equal curvatures in the sector: the reference's order is libstdc++ introsort's (lvx_stdsort.h) — one lane restates it from the identity order
+      bool tie = false;
+      for (int t = threadIdx.x; t + 1 < len; t += 512) tie |= sr_key_tie(key[t], key[t + 1]);
+      if (__syncthreads_or(tie)) {
+        for (int t = threadIdx.x; t < len; t += 512) key[t] = (((unsigned long long)__float_as_uint(V.cv(sp + t))) << 32) | (unsigned)(sp + t);
+        __syncthreads();
+        if (threadIdx.x == 0) libstdcxx_sort(key, len, SrKeyLess());
+        __syncthreads();
+      }
+    }
     }
     for (int t = threadIdx.x; t < len; t += 512) sort_ind[sp + t] = (int)(key[t] & 0xffffffffu);
     if constexpr (LDSR) {
@@ -283,6 +300,16 @@ __global__ __launch_bounds__(512) void k_sr_classify(const float4* cloud, const 
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
               }
+            // equal curvatures in the sector (quantised ranges, lattice coordinates): std::sort is unstable and the pick order of the tied points is whatever
+            // libstdc++'s introsort leaves — lane 0 restates it from the identity order (lvx_stdsort.h); tie-free sectors keep the parallel result, which is unique
+            bool tie = false;
+            for (int t = lane; t + 1 < len; t += 64) tie |= sr_key_tie(kw[t], kw[t + 1]);
+            if (__ballot(tie)) {
+              for (int t = lane; t < len; t += 64) kw[t] = (((unsigned long long)__float_as_uint(ring.c[sp + t - base])) << 32) | (unsigned)(sp + t);
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+              if (lane == 0) libstdcxx_sort(kw, len, SrKeyLess());
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
           }
         }
         __syncthreads();
@@ -1378,18 +1405,17 @@ int lvx_undistort_scan(lvx_ctx* c, const double* state, int n, const lvx_point_x
   return LVX_OK;
 }
 
-int lvx_surfel_extract(lvx_ctx* c, double p_lambda, double dist_threshold, int min_leaf_points, int min_inliers, int max_planes, lvx_surfel_plane* planes, int32_t* n_planes) {
-  static_assert(sizeof(lvx_surfel_plane) == sizeof(SurfelPlaneDev), "plane record layout");
-  if (!c || !n_planes || max_planes < 0 || (max_planes > 0 && !planes)) return LVX_E_ARG;
-  LVX_HIP(c, hipSetDevice(c->device));
+// setSurfelMap over the leaves of the context's voxel grid: the accepted planes in voxel-key (std::map) order
+static int surfel_extract_device(lvx_ctx* c, double p_lambda, double dist_threshold, int min_leaf_points, int min_inliers, std::vector<SurfelPlaneDev>& out) {
   const lvx_ctx::Voxels& V = c->vox;
-  *n_planes = 0;
+  out.clear();
   const int nl = V.n_leaves, n = V.n_points;
   if (nl == 0) return LVX_OK;
   if (!V.d_pts) return fail(c, LVX_E_STATE, "lvx_voxel_build has not been called");
   int rc;
   if ((rc = dev_alloc(c, c->d_up[4], (size_t)nl * sizeof(SurfelPlaneDev)))) return rc;
   if ((rc = dev_alloc(c, c->d_up[5], (size_t)nl * 4))) return rc;
+  if (c->assoc_map_planes == (const double*)c->d_up[5].p) lvx_surfel_map_release(c);
   const unsigned* counts = (const unsigned*)V.runs.p + n; const unsigned* offs = (const unsigned*)V.runs.p + 2 * (size_t)n;
   const int* lk = (const int*)V.leaf_i.p; const double* d = (const double*)V.leaf_d.p;
   { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
@@ -1400,9 +1426,129 @@ int lvx_surfel_extract(lvx_ctx* c, double p_lambda, double dist_threshold, int m
   LVX_HIP(c, hipMemcpyAsync(all.data(), c->d_up[4].p, (size_t)nl * sizeof(SurfelPlaneDev), hipMemcpyDeviceToHost, c->stream));
   LVX_HIP(c, hipMemcpyAsync(flag.data(), c->d_up[5].p, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
   LVX_HIP(c, hipStreamSynchronize(c->stream));
-  int np = 0;
-  for (int li = 0; li < nl; ++li) if (flag[li]) { if (np < max_planes) std::memcpy(&planes[np], &all[li], sizeof(SurfelPlaneDev)); ++np; }   // leaf order = voxel key order (std::map)
+  for (int li = 0; li < nl; ++li) if (flag[li]) out.push_back(all[li]);   // leaf order = voxel key order (std::map)
+  return LVX_OK;
+}
+int lvx_surfel_extract(lvx_ctx* c, double p_lambda, double dist_threshold, int min_leaf_points, int min_inliers, int max_planes, lvx_surfel_plane* planes, int32_t* n_planes) {
+  static_assert(sizeof(lvx_surfel_plane) == sizeof(SurfelPlaneDev), "plane record layout");
+  if (!c || !n_planes || max_planes < 0 || (max_planes > 0 && !planes)) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  *n_planes = 0;
+  std::vector<SurfelPlaneDev> acc;
+  int rc = surfel_extract_device(c, p_lambda, dist_threshold, min_leaf_points, min_inliers, acc);
+  if (rc) return rc;
+  const int np = (int)acc.size();
+  if (np > 0 && max_planes > 0) std::memcpy(planes, acc.data(), (size_t)std::min(np, max_planes) * sizeof(SurfelPlaneDev));
   *n_planes = np;
+  return LVX_OK;
+}
+
+// ---- LIinitializer::DataAssociation, refinement branch (src/lvi_exc/test/lvi_initialize_surfel_orb.cpp:1180-1201), device-resident -------------------------------
+int lvx_set_scans(lvx_ctx* c, int n_scans, int H, int W, const lvx_point_xyzit* raw) {
+  if (!c || n_scans < 0 || H < 0 || W < 0 || W > SA_WMAX || ((size_t)n_scans * H * W > 0 && !raw)) return c ? fail(c, LVX_E_ARG, "bad lvx_set_scans arguments (W <= 4096)") : LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  c->da_S = n_scans; c->da_H = H; c->da_W = W; c->da_planes.clear(); c->da_points = 0;
+  int rc = upload(c, c->d_da[0], raw, (size_t)n_scans * H * W * 32);
+  if (rc) return rc;
+  LVX_HIP(c, hipStreamSynchronize(c->stream));   // the caller's buffer may go away
+  return LVX_OK;
+}
+int lvx_assoc_default_options(lvx_assoc_options* o) {
+  if (!o) return LVX_E_ARG;
+  o->ndt_resolution = 0.5f; o->min_points_per_voxel = 6; o->min_covar_eigvalue_mult = 0.01; o->plane_lambda = 0.7; o->fit_threshold = 0.05; o->min_leaf_points = 10; o->min_inliers = 20;
+  o->radius = 0.05; o->selected_per_ring = 2; o->reserved = 0;
+  return LVX_OK;
+}
+int lvx_data_association(lvx_ctx* c, const double* state, double map_time, const lvx_assoc_options* opt_in, int32_t* n_planes, int32_t* n_points) {
+  if (!c || !state) return LVX_E_ARG;
+  if (!c->have_spline) return fail(c, LVX_E_STATE, "lvx_set_spline has not been called");
+  if (c->da_S <= 0 || (size_t)c->da_H * c->da_W == 0) return fail(c, LVX_E_STATE, "lvx_set_scans has not been called");
+  lvx_assoc_options o; lvx_assoc_default_options(&o); if (opt_in) o = *opt_in;
+  LVX_HIP(c, hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const int S = c->da_S, H = c->da_H, W = c->da_W;
+  const size_t npt = (size_t)S * H * W;
+  if (npt > 2147483647ull) return fail(c, LVX_E_ARG, "too many scan points for one map cloud");
+  int rc;
+  ProfScope ps(c, LVX_KERNEL_UPSTREAM);
+  c->da_planes.clear(); c->da_points = 0;
+  if (n_planes) *n_planes = 0;
+  if (n_points) *n_points = 0;
+  // 1. ScanUndistortion::undistortScanInMap (scan_undistortion.h:59-74): the LiDAR pose at the map time, then EVERY point of EVERY scan moved with the pose at its own
+  //    timestamp into that frame — one launch over the whole recording; map_cloud_ = the scans concatenated in order
+  if ((rc = upload(c, c->d_da[1], state, (size_t)lvx_state_size(c) * 8))) return rc;
+  if ((rc = upload(c, c->d_da[2], &map_time, 8))) return rc;
+  if ((rc = dev_alloc(c, c->d_da[3], 64 + 8))) return rc;
+  double* dq = (double*)c->d_da[3].p; double* dp = dq + 4; int* dv = (int*)(dp + 3);
+  hipLaunchKernelGGL(k_lidar_pose, dim3(1), dim3(1), 0, st, (const double*)c->d_da[1].p, c->N, c->t0, c->dt, 1, (const double*)c->d_da[2].p, dq, dp, dv);
+  double h[8] = {0}; int hv = 0;
+  LVX_HIP(c, hipMemcpyAsync(h, dq, 56, hipMemcpyDeviceToHost, st));
+  LVX_HIP(c, hipMemcpyAsync(&hv, dv, 4, hipMemcpyDeviceToHost, st));
+  LVX_HIP(c, hipStreamSynchronize(st));
+  if (!hv) return fail(c, LVX_E_RANGE, "map time outside the trajectory");
+  const double qGt[4] = {-h[0], -h[1], -h[2], h[3]};   // q_L0_to_G.conjugate()
+  if ((rc = dev_alloc(c, c->d_da[4], npt * 16))) return rc;
+  hipLaunchKernelGGL(k_undistort, dim3((unsigned)((npt + 255) / 256)), dim3(256), 0, st, (const double*)c->d_da[1].p, c->N, c->t0, c->dt, (int)npt, (const PointXYZIT*)c->d_da[0].p,
+                     load_q(qGt), load_v3(h + 4), 1, (float4*)c->d_da[4].p);
+  // 2. LiDAROdometry::ndtInit(resolution) + setInputTarget(map_cloud): the voxel covariance grid of the map cloud
+  c->vox.d_pts = c->d_da[4].p;
+  if ((rc = voxel_build_device(c, (const float4*)c->d_da[4].p, (int)npt, o.ndt_resolution, o.min_points_per_voxel, o.min_covar_eigvalue_mult))) return rc;
+  // 3. SurfelAssociation::setSurfelMap
+  std::vector<SurfelPlaneDev> acc;
+  if ((rc = surfel_extract_device(c, o.plane_lambda, o.fit_threshold, o.min_leaf_points, o.min_inliers, acc))) return rc;
+  const int P = (int)acc.size();
+  c->da_planes.resize((size_t)P);
+  if (P > 0) std::memcpy(c->da_planes.data(), acc.data(), (size_t)P * sizeof(SurfelPlaneDev));
+  if (n_planes) *n_planes = P;
+  if (P == 0) return LVX_OK;
+  std::vector<double> pl((size_t)P * 10);
+  for (int k = 0; k < P; ++k) { for (int a = 0; a < 4; ++a) pl[4 * (size_t)k + a] = acc[k].p4[a]; for (int a = 0; a < 3; ++a) { pl[4 * (size_t)P + 3 * (size_t)k + a] = acc[k].bmin[a]; pl[7 * (size_t)P + 3 * (size_t)k + a] = acc[k].bmax[a]; } }
+  lvx_surfel_map_release(c);
+  if ((rc = upload(c, c->d_da[5], pl.data(), pl.size() * 8))) return rc;
+  LVX_HIP(c, hipStreamSynchronize(st));   // pl lives on this frame
+  // 4. getAssociation for every scan: flags (one surfel grid for all scans), then the chronological SurfelPoint lists, scans concatenated
+  if ((rc = dev_alloc(c, c->d_da[6], npt * 4))) return rc;
+  if (S > 2 && (rc = lvx_surfel_map_prepare_d(c, P, (const double*)c->d_da[5].p))) return rc;
+  rc = lvx_surfel_assoc_batch_d(c, S, H, W, (const float*)c->d_da[4].p, P, (const double*)c->d_da[5].p, o.radius, o.selected_per_ring, (int32_t*)c->d_da[6].p);
+  lvx_surfel_map_release(c);
+  if (rc) return rc;
+  int32_t total = 0;
+  if ((rc = lvx_surfel_emit_d(c, S, H, W, (const int32_t*)c->d_da[6].p, (const float*)c->d_da[4].p, (const lvx_point_xyzit*)c->d_da[0].p, 0, nullptr, nullptr, nullptr, nullptr, &total, nullptr))) return rc;
+  if (total > 0) {
+    if ((rc = dev_alloc(c, c->d_da[7], (size_t)total * (24 + 24 + 8 + 4) + 64))) return rc;
+    double* d_pt = (double*)c->d_da[7].p; double* d_pm = d_pt + 3 * (size_t)total; double* d_t = d_pm + 3 * (size_t)total; int32_t* d_pl = (int32_t*)(d_t + total);
+    if ((rc = lvx_surfel_emit_d(c, S, H, W, (const int32_t*)c->d_da[6].p, (const float*)c->d_da[4].p, (const lvx_point_xyzit*)c->d_da[0].p, total, d_pt, d_pm, d_t, d_pl, &total, nullptr))) return rc;
+  }
+  c->da_points = total;
+  if (n_points) *n_points = total;
+  return LVX_OK;
+}
+int lvx_get_surfel_map(lvx_ctx* c, int max_planes, lvx_surfel_plane* planes) {
+  if (!c || max_planes < 0 || (max_planes > 0 && !planes)) return LVX_E_ARG;
+  const size_t n = std::min((size_t)max_planes, c->da_planes.size());
+  if (n) std::memcpy(planes, c->da_planes.data(), n * sizeof(lvx_surfel_plane));
+  return LVX_OK;
+}
+int lvx_get_surfel_points(lvx_ctx* c, int max_points, double* pt3, double* pt_map3, double* t, int32_t* plane) {
+  if (!c || max_points < 0) return LVX_E_ARG;
+  const size_t total = (size_t)c->da_points, n = std::min((size_t)max_points, total);
+  if (n == 0) return LVX_OK;
+  LVX_HIP(c, hipSetDevice(c->device));
+  const double* d_pt = (const double*)c->d_da[7].p; const double* d_pm = d_pt + 3 * total; const double* d_t = d_pm + 3 * total; const int32_t* d_pl = (const int32_t*)(d_t + total);
+  if (pt3) LVX_HIP(c, hipMemcpyAsync(pt3, d_pt, n * 24, hipMemcpyDeviceToHost, c->stream));
+  if (pt_map3) LVX_HIP(c, hipMemcpyAsync(pt_map3, d_pm, n * 24, hipMemcpyDeviceToHost, c->stream));
+  if (t) LVX_HIP(c, hipMemcpyAsync(t, d_t, n * 8, hipMemcpyDeviceToHost, c->stream));
+  if (plane) LVX_HIP(c, hipMemcpyAsync(plane, d_pl, n * 4, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  return LVX_OK;
+}
+int lvx_get_scans_in_map(lvx_ctx* c, float* xyzi4) {
+  if (!c || !xyzi4) return LVX_E_ARG;
+  const size_t npt = (size_t)c->da_S * c->da_H * c->da_W;
+  if (npt == 0 || !c->d_da[4].p) return fail(c, LVX_E_STATE, "lvx_data_association has not been called");
+  LVX_HIP(c, hipSetDevice(c->device));
+  LVX_HIP(c, hipMemcpyAsync(xyzi4, c->d_da[4].p, npt * 16, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
   return LVX_OK;
 }
 

@@ -7,8 +7,8 @@
 //     BatchOptimization() / Refinement()  -> trajInitFromSurfel                        (:1212-1243, trajectory_manager_lvi.cpp:311-351)   Solve #1, #1', ...
 //     LVI refinement        -> trajInitFromLVIdata(frames, surfels)                    (trajectory_manager_lvi.cpp:138-195)       Solve #2
 //     camera refinement     -> associateVisualPointsWithPlanes + trajInitFromLVIdata(frames, surfels, lm_splane)  (:197-257)     Solve #3
-// Every step of DataAssociation runs on the GPU: lvx_undistort_scan (de-skew into the map frame at the map time), lvx_voxel_build over the map cloud,
-// lvx_surfel_extract (planarity + plane fit + AABB), lvx_surfel_assoc_emit (all scans in one call), then the solve.
+// DataAssociation is ONE device-resident call (lvx_data_association: de-skew of every scan into the map frame, voxel grid of the map cloud, surfel
+// extraction, association of every scan, chronological SurfelPoint emission); the raw scans are handed to the context once (lvx_set_scans).
 // Not mirrored: the first map (LiDAROdometry / NDT registration of the InitializationDone branch, :1176-1179) — the driver starts from a state whose
 // trajectory is good enough to de-skew (e.g. LOAM poses fitted into the spline, as the reference's TrajectoryManagerLVI::feedLoamPose path does).
 #pragma once
@@ -45,17 +45,32 @@ struct CalibrateOptions {
   double associated_radius = 0.05; int selected_per_ring = 2, downsample_step = 10;
   double w_gyro = 28, w_acc = 18, w_surfel = 10, w_cam = 5, w_cam_surfel = 30;   // SetCalibWeights (lvi_initialize_surfel_orb.cpp:904-928)
   bool opt_time_offset = false;
+  bool keep_history = false, keep_clouds = false;   // AssociationRecord per DataAssociation round (tests, diagnostics)
   int verbose = 1;
 };
-struct StageReport { std::string name; lvx_lm_summary lm; int n_planes = 0, n_surfel_points = 0, n_cam_surfel = 0; };
+struct StageReport { std::string name; lvx_lm_summary lm; int n_planes = 0, n_surfel_points = 0, n_cam_surfel = 0;
+                     std::vector<double> cost_history, radius_history; std::vector<int32_t> accepted;   // per-iteration trace of the stage's solve (lvx_lm_get_history)
+                     std::vector<double> state_in; };   // the state the stage's solve started from (CalibrateOptions::keep_history)
+// what one DataAssociation round produced (kept when CalibrateOptions::keep_history): the state it ran at, the surfel map, the full SurfelPoint list and —
+// keep_clouds — the de-skewed scans [n_scans][H][W][4]
+struct AssociationRecord { std::vector<double> state; std::vector<lvx_surfel_plane> planes; std::vector<double> pt, pt_map, t; std::vector<int32_t> plane; std::vector<float> scans_in_map; };
 
 class Calibrator {
  public:
+  // `in` is copied: the calibrator may outlive the caller's object
   Calibrator(int device, const CalibrateInput& in, const CalibrateOptions& opt) : in_(in), opt_(opt) {
     check(lvx_create(&ctx_, device, 0));
-    check(lvx_set_spline(ctx_, in.t0, in.dt, in.n_knots));
-    check(lvx_set_camera(ctx_, &in.camera));
-    check(lvx_set_landmarks(ctx_, (int)in.lm_t0.size(), in.lm_uv.data(), in.lm_t0.data()));
+    check(lvx_set_spline(ctx_, in_.t0, in_.dt, in_.n_knots));
+    check(lvx_set_camera(ctx_, &in_.camera));
+    check(lvx_set_landmarks(ctx_, (int)in_.lm_t0.size(), in_.lm_uv.data(), in_.lm_t0.data()));
+    // LioDataset::get_scan_data: the organised raw scans go to the device once
+    const size_t HW = (size_t)in_.H * in_.W;
+    std::vector<lvx_point_xyzit> raw(in_.scans.size() * HW);
+    for (size_t s = 0; s < in_.scans.size(); ++s) {
+      if (in_.scans[s].size() != HW) throw std::invalid_argument("scan size does not match H x W");
+      std::copy(in_.scans[s].begin(), in_.scans[s].end(), raw.begin() + s * HW);
+    }
+    if (!raw.empty()) check(lvx_set_scans(ctx_, (int)in_.scans.size(), in_.H, in_.W, raw.data()));
   }
   ~Calibrator() { lvx_destroy(ctx_); }
   Calibrator(const Calibrator&) = delete;
@@ -75,6 +90,7 @@ class Calibrator {
     return rep;
   }
   const std::vector<lvx_surfel_plane>& planes() const { return planes_; }
+  const std::vector<AssociationRecord>& associations() const { return assoc_history_; }
   lvx_ctx* context() { return ctx_; }
 
  private:
@@ -86,34 +102,26 @@ class Calibrator {
     clear_families(true, true, true);
     check(lvx_set_locks(ctx_, StageLocks(Stage::SO3FromGyro, opt_.opt_time_offset)));
     StageReport r{"initialSO3TrajWithGyro", solve(state, 30)};
+    attach_history(&r);
     check(lvx_set_orientation_prior(ctx_, 0, in_.t0, q0, opt_.w_gyro));
     return r;
   }
   // DataAssociation of the refinement branch (lvi_initialize_surfel_orb.cpp:1180-1188, 1192-1201)
   void DataAssociation(const std::vector<double>& state) {
-    const int S = (int)in_.scans.size(), HW = in_.H * in_.W;
-    double qL0[4], pL0[3]; int32_t ok = 0;
-    check(lvx_evaluate_lidar_pose(ctx_, state.data(), 1, &in_.map_time, qL0, pL0, &ok));
-    if (!ok) throw std::range_error("map time outside the trajectory");
-    const double q_G_to_L0[4] = {-qL0[0], -qL0[1], -qL0[2], qL0[3]};
-    scans_map_.assign((size_t)S * HW * 4, 0.f);
-    for (int s = 0; s < S; ++s) check(lvx_undistort_scan(ctx_, state.data(), HW, in_.scans[s].data(), q_G_to_L0, pL0, 1, scans_map_.data() + (size_t)s * HW * 4));
-    lvx_voxel_info vi;
-    check(lvx_voxel_build(ctx_, S * HW, scans_map_.data(), opt_.ndt_resolution, 6, 0.01, &vi));     // map_cloud_ = sum of the de-skewed scans
-    planes_.assign((size_t)std::max(vi.n_leaves, 1), lvx_surfel_plane{});
-    int32_t np = 0;
-    check(lvx_surfel_extract(ctx_, opt_.plane_lambda, opt_.fit_threshold, opt_.min_leaf_points, opt_.min_inliers, (int)planes_.size(), planes_.data(), &np));
-    planes_.resize((size_t)np);
-    std::vector<double> p4((size_t)np * 4), bmin((size_t)np * 3), bmax((size_t)np * 3);
-    for (int k = 0; k < np; ++k) { for (int a = 0; a < 4; ++a) p4[4 * k + a] = planes_[k].p4[a]; for (int a = 0; a < 3; ++a) { bmin[3 * k + a] = planes_[k].box_min[a]; bmax[3 * k + a] = planes_[k].box_max[a]; } }
-    std::vector<lvx_point_xyzit> raw((size_t)S * HW);
-    for (int s = 0; s < S; ++s) std::copy(in_.scans[s].begin(), in_.scans[s].end(), raw.begin() + (size_t)s * HW);
-    int32_t n = 0;
-    check(lvx_surfel_assoc_emit(ctx_, S, in_.H, in_.W, scans_map_.data(), raw.data(), np, p4.data(), bmin.data(), bmax.data(), opt_.associated_radius, opt_.selected_per_ring, nullptr, 0,
-                                nullptr, nullptr, nullptr, nullptr, &n));
+    lvx_assoc_options ao; lvx_assoc_default_options(&ao);
+    ao.ndt_resolution = opt_.ndt_resolution; ao.plane_lambda = opt_.plane_lambda; ao.fit_threshold = opt_.fit_threshold; ao.min_leaf_points = opt_.min_leaf_points;
+    ao.min_inliers = opt_.min_inliers; ao.radius = opt_.associated_radius; ao.selected_per_ring = opt_.selected_per_ring;
+    int32_t np = 0, n = 0;
+    check(lvx_data_association(ctx_, state.data(), in_.map_time, &ao, &np, &n));
+    planes_.assign((size_t)np, lvx_surfel_plane{});
+    if (np > 0) check(lvx_get_surfel_map(ctx_, np, planes_.data()));
     sp_pt_.assign((size_t)n * 3, 0.0); sp_map_.assign((size_t)n * 3, 0.0); sp_t_.assign((size_t)n, 0.0); sp_plane_.assign((size_t)n, 0);
-    if (n > 0) check(lvx_surfel_assoc_emit(ctx_, S, in_.H, in_.W, scans_map_.data(), raw.data(), np, p4.data(), bmin.data(), bmax.data(), opt_.associated_radius, opt_.selected_per_ring, nullptr, n,
-                                           sp_pt_.data(), sp_map_.data(), sp_t_.data(), sp_plane_.data(), &n));
+    if (n > 0) check(lvx_get_surfel_points(ctx_, n, sp_pt_.data(), sp_map_.data(), sp_t_.data(), sp_plane_.data()));
+    if (opt_.keep_history) {
+      AssociationRecord r; r.state = state; r.planes = planes_; r.pt = sp_pt_; r.pt_map = sp_map_; r.t = sp_t_; r.plane = sp_plane_;
+      if (opt_.keep_clouds) { r.scans_in_map.assign(in_.scans.size() * (size_t)in_.H * in_.W * 4, 0.f); check(lvx_get_scans_in_map(ctx_, r.scans_in_map.data())); }
+      assoc_history_.push_back(std::move(r));
+    }
     if (opt_.verbose) std::fprintf(stderr, "[lvx calibrate] association: %d surfels, %d surfel points (every %d-th is used)\n", np, n, opt_.downsample_step);
   }
   void set_surfels() {   // addSurfMeasurement over get_surfel_points() after averageTimeDownSmaple(step) (surfel_association.cpp:240-244)
@@ -134,6 +142,7 @@ class Calibrator {
     clear_families(false, true, true);
     check(lvx_set_locks(ctx_, StageLocks(Stage::TrajFromSurfel, opt_.opt_time_offset)));
     StageReport r{name, solve(state, 30)};
+    attach_history(&r);
     r.n_planes = (int)planes_.size(); r.n_surfel_points = n_surfel_used_;
     return r;
   }
@@ -161,6 +170,7 @@ class Calibrator {
       check(lvx_set_locks(ctx_, StageLocks(Stage::TrajFromLVI, opt_.opt_time_offset)));
     }
     r.lm = solve(state, 80);
+    attach_history(&r);
     r.n_planes = (int)planes_.size(); r.n_surfel_points = n_surfel_used_;
     return r;
   }
@@ -181,10 +191,16 @@ class Calibrator {
   lvx_lm_summary solve(std::vector<double>* state, int max_it) {
     lvx_lm_options o; lvx_lm_default_options(&o); o.max_iterations = max_it; o.verbose = opt_.verbose > 1;
     lvx_lm_summary s{};
+    if (opt_.keep_history) stage_state_in_ = *state;
     check(lvx_lm_solve(ctx_, state->data(), &o, &s));
+    const int cap = 4 * max_it + 8;
+    hist_cost_.assign((size_t)cap, 0.0); hist_radius_.assign((size_t)cap, 0.0); hist_acc_.assign((size_t)cap, 0);
+    const int k = lvx_lm_get_history(ctx_, cap, hist_cost_.data(), hist_radius_.data(), hist_acc_.data());
+    hist_cost_.resize((size_t)std::max(k, 0)); hist_radius_.resize(hist_cost_.size()); hist_acc_.resize(hist_cost_.size());
     if (opt_.verbose) std::fprintf(stderr, "[lvx calibrate] solve: %d iterations, cost %.6e -> %.6e, termination %d\n", s.iterations, s.initial_cost, s.final_cost, s.termination);
     return s;
   }
+  void attach_history(StageReport* r) const { r->cost_history = hist_cost_; r->radius_history = hist_radius_; r->accepted = hist_acc_; r->state_in = stage_state_in_; }
   void check(int rc) {
     if (rc == LVX_OK) return;
     const std::string msg = ctx_ ? lvx_last_error(ctx_) : "lvx error";
@@ -192,9 +208,10 @@ class Calibrator {
     throw std::runtime_error(msg + " (lvx error " + std::to_string(rc) + ")");
   }
   lvx_ctx* ctx_ = nullptr;
-  const CalibrateInput& in_;
+  const CalibrateInput in_;
   CalibrateOptions opt_;
-  std::vector<float> scans_map_;
+  std::vector<AssociationRecord> assoc_history_;
+  std::vector<double> hist_cost_, hist_radius_, stage_state_in_; std::vector<int32_t> hist_acc_;
   std::vector<lvx_surfel_plane> planes_;
   std::vector<double> sp_pt_, sp_map_, sp_t_; std::vector<int32_t> sp_plane_;
   int n_surfel_used_ = 0;

@@ -182,6 +182,12 @@ class Context:
         self._ck(self._l.lvx_get_layout(self._h, C.byref(lo)))
         return {k: getattr(lo, k) for k, _ in Layout._fields_}
 
+    def family_rows(self):
+        """First residual row of every family (FAM_* order) and the total, as lvx_get_family_rows."""
+        r = (C.c_int64 * 7)()
+        self._ck(self._l.lvx_get_family_rows(self._h, r))
+        return [int(v) for v in r]
+
     # --- evaluation ---
     def evaluate(self, state, jac=False, normal_eq=False, dense=True, residuals=True):
         state = _d(state)

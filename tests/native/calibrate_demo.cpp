@@ -1,5 +1,8 @@
 // Drives lvx_host::Calibrator (lvi-exc_amd/host/lvx_calibrate.hpp) on a problem read from a flat binary file of doubles — the stand-in for the
-// rosbag / text inputs of the reference's lvi_initialize_surfel_orb — and writes the calibrated state.  Usage: calibrate_demo in.bin out.bin
+// rosbag / text inputs of the reference's lvi_initialize_surfel_orb — and writes the calibrated state.  Usage: calibrate_demo in.bin out.bin [history.bin]
+// out.bin (doubles): n_stages | 7 per stage | state | per stage: k, cost[k], radius[k], accepted[k], n_state_in, state_in.  history.bin: one record per DataAssociation round
+// (tests/test_gpu_pipeline_oracle.py reads it): 4 doubles (n_state, n_planes, n_points, n_cloud_floats), state, planes (lvx_surfel_plane records), pt, pt_map, t (doubles),
+// plane ids (int32), de-skewed scans (float32).
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -41,6 +44,7 @@ int main(int argc, char** argv) {
       for (size_t i = 0; i < pts.size(); ++i) { std::memset(&pts[i], 0, sizeof(pts[i])); pts[i].x = (float)xyz[3 * i]; pts[i].y = (float)xyz[3 * i + 1]; pts[i].z = (float)xyz[3 * i + 2]; pts[i].timestamp = ts[i]; }
       in.scans.push_back(std::move(pts));
     }
+    if (argc > 3) { opt.keep_history = true; opt.keep_clouds = true; }
     lvx_host::Calibrator cal(0, in, opt);
     const auto rep = cal.Run(&state);
     std::vector<double> out;
@@ -49,8 +53,26 @@ int main(int argc, char** argv) {
       std::cout << r.name << ": iterations " << r.lm.iterations << " termination " << r.lm.termination << " cost " << r.lm.initial_cost << " -> " << r.lm.final_cost << " planes " << r.n_planes
                 << " surfel points " << r.n_surfel_points << " cam-surfel " << r.n_cam_surfel << "\n"; }
     out.insert(out.end(), state.begin(), state.end());
+    for (const auto& r : rep) {
+      out.push_back((double)r.accepted.size());
+      out.insert(out.end(), r.cost_history.begin(), r.cost_history.end());
+      out.insert(out.end(), r.radius_history.begin(), r.radius_history.end());
+      for (int32_t a : r.accepted) out.push_back((double)a);
+      out.push_back((double)r.state_in.size());
+      out.insert(out.end(), r.state_in.begin(), r.state_in.end());
+    }
     std::ofstream f(argv[2], std::ios::binary);
     f.write(reinterpret_cast<const char*>(out.data()), (std::streamsize)out.size() * 8);
+    if (argc > 3) {
+      std::ofstream h(argv[3], std::ios::binary);
+      auto put = [&](const void* p, size_t bytes) { h.write(reinterpret_cast<const char*>(p), (std::streamsize)bytes); };
+      for (const auto& a : cal.associations()) {
+        const double hdr[4] = {(double)a.state.size(), (double)a.planes.size(), (double)a.t.size(), (double)a.scans_in_map.size()};
+        put(hdr, sizeof(hdr)); put(a.state.data(), a.state.size() * 8); put(a.planes.data(), a.planes.size() * sizeof(lvx_surfel_plane));
+        put(a.pt.data(), a.pt.size() * 8); put(a.pt_map.data(), a.pt_map.size() * 8); put(a.t.data(), a.t.size() * 8); put(a.plane.data(), a.plane.size() * 4);
+        put(a.scans_in_map.data(), a.scans_in_map.size() * 4);
+      }
+    }
     return 0;
   } catch (const std::range_error& e) { std::fprintf(stderr, "range_error: %s\n", e.what()); return 4;
   } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 3; }

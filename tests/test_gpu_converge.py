@@ -1,5 +1,5 @@
 """BASELINE.json config 4 (1 M surfel + 200 k IMU + 50 k ORB reprojection blocks, 25 k knots) solved TO A CERES TERMINATION at full size
-through the reference's stage schedule (tests/calib_stages.py), plus the same at 1/64 size against the CPU oracle's LM.
+through the reference's stage schedule (lvi-exc_amd/stages.py; the oracle's side: oracle/pipeline.py), plus the same at 1/64 size against the CPU oracle's LM.
 
 Acceptance (north_star): converged extrinsics within 1e-6 rad / 1e-4 m between implementations solving the same problem from the same start.
   (i)   full size: the FP64-MFMA assembly path and the per-segment kernels (FORCE_LEGACY) — two independent assemblies, same solver;
@@ -13,9 +13,9 @@ import sys
 import numpy as np
 import pytest
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-import calib_stages as cs   # noqa: E402
+import stages as cs   # noqa: E402
 import synth   # noqa: E402
+from oracle import pipeline   # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -54,7 +54,7 @@ def test_config4_small_against_oracle_lm():
     N = P["n_knots"]
     xg, logg = cs.run_stages_gpu(P, P["state0"])
     _report("gpu   ", logg)
-    xo, logo = cs.run_stages_oracle(P, P["state0"])
+    xo, logo = pipeline.run_fixed_stages(P, P["state0"])
     _report("oracle", logo)
     for (_, sg, _), (_, so, _) in zip(logg, logo):
         assert sg["termination"] == so["termination"] and sg["iterations"] == so["iterations"]

@@ -40,9 +40,10 @@ def full():
     steps["scaled_seq"] = g.solve_step(RADIUS, True)
     g.set_switch("SOLVER_SEQ", 0)
     lo = g.layout()
+    rows = g.family_rows()
     g.close()
     ro = o.evaluate_products(x, V=np.stack([steps["scaled"][0], steps["unscaled"][0]]))
-    return dict(P=P, rg=rg, gg=gg, dg=dg, steps=steps, ro=ro, lo=lo, n_blocks=o.num_blocks)
+    return dict(P=P, rg=rg, gg=gg, dg=dg, steps=steps, ro=ro, lo=lo, rows=rows, n_blocks=o.num_blocks)
 
 
 def test_every_residual_row_and_the_cost_match_the_oracle(full):
@@ -50,9 +51,17 @@ def test_every_residual_row_and_the_cost_match_the_oracle(full):
     assert lo["n_blocks"] == full["n_blocks"] >= 1_449_000 and lo["exact_fallback"] == 0
     assert len(rg["residuals"]) == len(ro["residuals"]) == lo["n_residuals"] >= 2_299_000   # 3 x (200 k + 200 k) IMU rows + 1 M surfel rows + 2 x 50 k reprojection rows
     err = np.abs(rg["residuals"] - ro["residuals"])
-    scale = np.maximum(np.abs(ro["residuals"]), 1e-3 * np.abs(ro["residuals"]).max())   # relative per row, floored at 1e-3 of the largest row
-    print("residual rows: max rel err %.3e, cost rel err %.3e" % ((err / scale).max(), abs(rg["cost"] - ro["cost"]) / ro["cost"]))
-    assert (err / scale).max() <= 1e-11
+    rows = full["rows"]
+    for f, name in enumerate(("gyro", "accel", "prior", "surfel", "reproj", "camsurf")):
+        a, b = rows[f], rows[f + 1]
+        if b == a:
+            continue
+        # every row of a family against the family's residual scale (a pixel residual is the difference of two ~600 px numbers: rows near zero carry the
+        # rounding of their operands, not of their own size)
+        fam_scale = np.abs(ro["residuals"][a:b]).max()
+        print("%-7s %8d rows: max |err| / max |r| = %.3e (max |r| %.3e)" % (name, b - a, err[a:b].max() / fam_scale, fam_scale))
+        assert err[a:b].max() <= 1e-11 * fam_scale
+    print("cost rel err %.3e" % (abs(rg["cost"] - ro["cost"]) / ro["cost"]))
     assert abs(rg["cost"] - ro["cost"]) <= 1e-12 * abs(ro["cost"])
 
 

@@ -65,7 +65,7 @@ def test_calibration_schedule_recovers_the_planted_extrinsics(demo_binary, tmp_p
     out = np.fromfile(pout)
     ns = int(out[0])
     rep = out[1:1 + 7 * ns].reshape(ns, 7)
-    x = out[1 + 7 * ns:]
+    x = out[1 + 7 * ns:1 + 7 * ns + len(S["state0"])]
     assert ns >= 4 and len(x) == len(S["state0"])
     assert (rep[:, 1] != 5).all()                                  # no stage ends in FAILURE
     assert (rep[:ns - 1, 4] >= 20).all() and (rep[:ns - 1, 5] >= 200).all()  # surfels found on the walls, surfel points associated
@@ -91,6 +91,6 @@ def test_the_truth_is_a_fixed_point_of_the_schedule(demo_binary, tmp_path):
     assert r.returncode == 0, r.stderr
     out = np.fromfile(pout)
     ns = int(out[0])
-    e = _errors(out[1 + 7 * ns:], S["state_true"], N)
+    e = _errors(out[1 + 7 * ns:1 + 7 * ns + len(S["state_true"])], S["state_true"], N)
     print(e)
     assert e["lidar"][0] < 5e-4 and e["lidar"][1] < 1e-2 and e["cam"][0] < 3e-3 and e["cam"][1] < 1e-2

@@ -1,0 +1,166 @@
+"""f4 parity: lvx_host::Calibrator (lvi-exc_amd/host/lvx_calibrate.hpp, C++ over the C ABI, GPU) against the oracle running THE SAME SCHEDULE
+(oracle/pipeline.py: de-skew -> voxel grid -> surfel map -> association -> trajInitFromSurfel, twice; trajInitFromLVIdata; the camera-surfel stage) on
+synth.make_sequence(seed=50) — reference: src/lvi_exc/test/lvi_initialize_surfel_orb.cpp:1169-1245, src/core/trajectory_manager_lvi.cpp:138-257,311-351.
+
+Stage by stage, each stage fed with the GPU's inputs so that one float of the de-skew that rounds the other way cannot hide a wrong rule downstream:
+  de-skew          GPU vs oracle from the same state: same NaN pattern, every coordinate within 4e-6 m (float32 outputs of FP64 poses), < 0.1 % of them not bit-equal
+  surfel map       oracle voxel grid + setSurfelMap on the GPU's map cloud: same number of surfels, same leaves / point counts / inlier counts / plane types / AABBs
+                   (exact), planes 1e-9
+  association      oracle getAssociation on the GPU's scans and surfels: the SurfelPoint list identical — order, raw points, map points, timestamps, plane ids
+  every solve      oracle LM (oracle/lm.py) from the stage's input state on the same blocks: same accept / reject sequence and termination, cost history 1e-7,
+                   extrinsics after the stage within 1e-6 rad / 1e-4 m
+  landmark <-> plane   the number of camera-landmark-to-surfel blocks equals the oracle's associateVisualPointsWithPlanes
+and once free-running (the oracle chains its own outputs): final extrinsics within 1e-5 rad / 1e-4 m of the Calibrator's.
+"""
+import os
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+import lvx
+import synth
+from oracle import pipeline
+from test_gpu_pipeline import _write
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "native", "calibrate_demo.cpp")
+LIBDIR = os.path.join(ROOT, "lvi-exc_amd")
+REFINE = 2
+
+
+@pytest.fixture(scope="module")
+def run(tmp_path_factory):
+    import build as lvx_build
+    lvx_build.build()
+    d = tmp_path_factory.mktemp("calib_oracle")
+    exe = str(d / "calibrate_demo")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(LIBDIR, "host"), SRC, "-o", exe, "-L" + LIBDIR, "-llvx", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib"])
+    S = synth.make_sequence(seed=50)
+    pin, pout, phist = str(d / "seq.bin"), str(d / "res.bin"), str(d / "hist.bin")
+    _write(pin, S, refine_iterations=REFINE, lvi=1, camsurf=1)
+    t0 = time.perf_counter()
+    r = subprocess.run([exe, pin, pout, phist], capture_output=True, text=True)
+    print(r.stdout, r.stderr[-2000:], "calibrator wall time %.2f s" % (time.perf_counter() - t0))
+    assert r.returncode == 0, r.stderr
+    out = np.fromfile(pout)
+    ns, nst = int(out[0]), len(S["state0"])
+    rep = out[1:1 + 7 * ns].reshape(ns, 7)
+    o = 1 + 7 * ns
+    x_final = out[o:o + nst]; o += nst
+    stages = []
+    for k in range(ns):
+        n = int(out[o]); o += 1
+        cost, radius, acc = out[o:o + n], out[o + n:o + 2 * n], out[o + 2 * n:o + 3 * n].astype(int); o += 3 * n
+        m = int(out[o]); o += 1
+        stages.append(dict(iterations=int(rep[k, 0]), termination=lvx.LM_TERMINATION[int(rep[k, 1])], initial_cost=rep[k, 2], final_cost=rep[k, 3], n_planes=int(rep[k, 4]),
+                           n_used=int(rep[k, 5]), n_camsurf=int(rep[k, 6]), cost_history=cost, accepted=acc, state_in=out[o:o + m])); o += m
+    assert o == len(out) and ns == REFINE + 2
+    for k in range(ns):
+        stages[k]["state_out"] = stages[k + 1]["state_in"] if k + 1 < ns else x_final
+    buf = open(phist, "rb").read()
+    assoc, o = [], 0
+    while o < len(buf):
+        n_state, n_pl, n_pt, n_cl = (int(v) for v in np.frombuffer(buf, np.float64, 4, o)); o += 32
+        rec = dict(state=np.frombuffer(buf, np.float64, n_state, o)); o += 8 * n_state
+        rec["planes"] = np.frombuffer(buf, lvx.SURFEL_PLANE, n_pl, o); o += lvx.SURFEL_PLANE.itemsize * n_pl
+        for key, w in (("pt", 3), ("pt_map", 3), ("t", 1)):
+            rec[key] = np.frombuffer(buf, np.float64, w * n_pt, o).reshape(n_pt, w) if w > 1 else np.frombuffer(buf, np.float64, n_pt, o); o += 8 * w * n_pt
+        rec["plane"] = np.frombuffer(buf, np.int32, n_pt, o); o += 4 * n_pt
+        rec["scans_in_map"] = np.frombuffer(buf, np.float32, n_cl, o).reshape(len(S["scans"]), S["H"], S["W"], 4); o += 4 * n_cl
+        assoc.append(rec)
+    assert len(assoc) == REFINE
+    return dict(S=S, stages=stages, assoc=assoc, x_final=x_final)
+
+
+def _planes_dict(pl):
+    return dict(p4=np.ascontiguousarray(pl["p4"]), Pi=np.ascontiguousarray(pl["Pi"]), box_min=np.ascontiguousarray(pl["box_min"]), box_max=np.ascontiguousarray(pl["box_max"]))
+
+
+def _points_dict(rec):
+    return dict(pt=rec["pt"], pt_map=rec["pt_map"], t=rec["t"], plane=rec["plane"])
+
+
+def _ext_err(a, b, N):
+    out = {}
+    for name, o in (("lidar", 7 * N + 16), ("cam", 7 * N + 24)):
+        d = synth.qmul(a[o:o + 4], synth.qconj(b[o:o + 4]))
+        out[name] = (float(2 * np.arctan2(np.linalg.norm(d[:3]), abs(d[3]))), float(np.linalg.norm(a[o + 4:o + 7] - b[o + 4:o + 7])))
+    return out
+
+
+@pytest.mark.parametrize("k", range(REFINE))
+def test_data_association_round_matches_the_oracle(run, k):
+    S, rec = run["S"], run["assoc"][k]
+    assert np.array_equal(rec["state"], run["stages"][k]["state_in"])            # the association ran at the state the solve then starts from
+    # de-skew
+    so = pipeline.deskew_into_map(S, rec["state"])
+    sg = rec["scans_in_map"]
+    assert np.array_equal(np.isnan(so), np.isnan(sg))
+    m = ~np.isnan(so)
+    diff = np.abs(so[m] - sg[m])
+    frac = np.count_nonzero(so[m].view(np.uint32) != sg[m].view(np.uint32)) / m.sum()
+    print("round %d de-skew: max |diff| %.2e m, %.4f %% of the floats not bit-equal" % (k, diff.max(), 100 * frac))
+    assert diff.max() <= 4e-6 and frac < 1e-3
+    # surfel map on the GPU's map cloud
+    po = pipeline.surfel_map(sg, pipeline.DEFAULTS)
+    pg = rec["planes"]
+    assert len(pg) == len(po["p4"]) == run["stages"][k]["n_planes"] and len(pg) > 100
+    assert np.array_equal(pg["leaf"], po["leaf"]) and np.array_equal(pg["n_points"], po["n_points"]) and np.array_equal(pg["n_inliers"], po["n_inliers"])
+    assert np.array_equal(pg["plane_type"], po["plane_type"])
+    assert np.array_equal(pg["box_min"], po["box_min"]) and np.array_equal(pg["box_max"], po["box_max"])
+    assert np.abs(pg["p4"] - po["p4"]).max() <= 1e-9 and np.abs(pg["Pi"] - po["Pi"]).max() <= 1e-9 * np.abs(po["Pi"]).max()
+    # association of every scan against the GPU's surfels
+    eo = pipeline.associate(S, sg, _planes_dict(pg), pipeline.DEFAULTS)
+    assert len(eo["t"]) == len(rec["t"]) > 1000
+    for key in ("pt", "pt_map", "t", "plane"):
+        assert np.array_equal(eo[key], rec[key]), key
+    # what the solve uses of it: every 10th point at or after the map time
+    assert run["stages"][k]["n_used"] == len(pipeline.select_surfels(eo, S["t_map"], 10)[1])
+
+
+def _check_solve(run, k, stage, planes, points, camsurf=None):
+    S, st = run["S"], run["stages"][k]
+    t0 = time.perf_counter()
+    xo, so = pipeline.solve_stage(S, st["state_in"], stage, planes, points, camsurf=camsurf)
+    print("stage %d %-26s gpu: it %d %s cost %.6e -> %.6e | oracle: it %d %s -> %.6e (%.1f s)" % (k, stage, st["iterations"], st["termination"], st["initial_cost"], st["final_cost"],
+                                                                                                     so["iterations"], so["termination"], so["final_cost"], time.perf_counter() - t0))
+    assert abs(st["initial_cost"] - so["initial_cost"]) <= 1e-10 * so["initial_cost"]
+    assert list(st["accepted"]) == list(so["accepted"]) and st["termination"] == so["termination"] and st["iterations"] == so["iterations"]
+    assert np.abs(st["cost_history"] - so["cost_history"]).max() <= 1e-7 * so["cost_history"].max()
+    e = _ext_err(st["state_out"], xo, S["n_knots"])
+    print("   extrinsics gpu vs oracle after the stage:", e)
+    assert e["lidar"][0] <= 1e-6 and e["cam"][0] <= 1e-6 and e["lidar"][1] <= 1e-4 and e["cam"][1] <= 1e-4
+    return xo
+
+
+@pytest.mark.parametrize("k", range(REFINE))
+def test_surfel_solves_match_the_oracle_lm(run, k):
+    rec = run["assoc"][k]
+    _check_solve(run, k, "TrajFromSurfel", _planes_dict(rec["planes"]), _points_dict(rec))
+
+
+def test_lvi_and_camera_surfel_stages_match_the_oracle_lm(run):
+    S, rec = run["S"], run["assoc"][-1]
+    planes, points = _planes_dict(rec["planes"]), _points_dict(rec)
+    _check_solve(run, REFINE, "TrajFromLVI", planes, points)
+    st = run["stages"][REFINE + 1]
+    cs = pipeline.landmark_planes(S, st["state_in"], planes)
+    assert len(cs[0]) == st["n_camsurf"]
+    print("camera-landmark-to-surfel blocks:", len(cs[0]))
+    _check_solve(run, REFINE + 1, "TrajFromLVILandmarksOnly", planes, points, camsurf=cs)
+
+
+def test_free_running_oracle_schedule_ends_at_the_same_extrinsics(run):
+    S = run["S"]
+    t0 = time.perf_counter()
+    xo, log = pipeline.run_schedule(S, S["state0"], refine_iterations=REFINE, lvi_stage=True, camera_surfel_stage=True)
+    print("oracle schedule %.1f s; surfels per round: oracle %s, gpu %s" % (time.perf_counter() - t0, [len(l["association"]["planes"]["p4"]) for l in log[:REFINE]],
+                                                                              [len(a["planes"]) for a in run["assoc"]]))
+    for lo, st in zip(log, run["stages"]):
+        assert lo["lm"]["termination"] == st["termination"]
+    e = _ext_err(run["x_final"], xo, S["n_knots"])
+    print("free-running, gpu vs oracle:", e)
+    assert e["lidar"][0] <= 1e-5 and e["cam"][0] <= 1e-5 and e["lidar"][1] <= 1e-4 and e["cam"][1] <= 1e-4

@@ -52,9 +52,25 @@ def test_scan_register_vlp16_bit_exact(ctx, seed):
     assert len(ro["sharp"]) > 100 and len(ro["flat"]) > 300
 
 
-def test_scan_register_with_curvature_ties(ctx):
-    """Seed 2 has one pair of equal curvatures in a sector; the GPU orders ties by index (what a stable sort gives)."""
-    _check_scanreg(ctx, synth.make_vlp16_sweep(seed=2), 16, 0.3, strict=False)
+def _tie_sectors(ro):
+    c, n = ro["curvature"], 0
+    for i in range(len(ro["scan_start"])):
+        s, e = ro["scan_start"][i], ro["scan_end"][i]
+        for j in range(6):
+            sp, ep = s + (e - s) * j // 6, s + (e - s) * (j + 1) // 6 - 1
+            n += len(np.unique(c[sp:ep + 1])) < ep - sp + 1
+    return n
+
+
+@pytest.mark.parametrize("kw,min_tie_sectors", [(dict(seed=2), 1), (dict(seed=1, range_quantum=0.002, noise=0.003), 1), (dict(seed=1, xyz_quantum=0.004, noise=0.005), 20),
+                                                (dict(seed=7, xyz_quantum=0.01, noise=0.0), 60), (dict(seed=8, xyz_quantum=0.02, noise=0.001, n_az=900), 60)])
+def test_scan_register_with_curvature_ties_is_bit_exact(ctx, kw, min_tie_sectors):
+    """Equal curvatures inside a sector (quantised ranges; coordinates on a millimetre / centimetre lattice): the reference's std::sort (scanRegistration.cpp:327) is
+    unstable, so which of the tied points is picked first is libstdc++ introsort's business.  The kernel restates it on one lane for such sectors
+    (lvx_stdsort.h) — sorted indices, labels, picked flags and the four lists are compared STRICTLY, as on tie-free sweeps."""
+    pts = synth.make_vlp16_sweep(**kw)
+    ro = _check_scanreg(ctx, pts, 16, 0.3, strict=True)
+    assert _tie_sectors(ro) >= min_tie_sectors
 
 
 def test_scan_register_edge_cases(ctx):

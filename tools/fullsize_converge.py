@@ -3,9 +3,9 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "lvi-exc_amd"), os.path.join(ROOT, "tests")):
+for p in (ROOT, os.path.join(ROOT, "lvi-exc_amd")):
     sys.path.insert(0, p)
-import calib_stages as cs  # noqa: E402
+import stages as cs  # noqa: E402
 import synth  # noqa: E402
 
 if __name__ == "__main__":
