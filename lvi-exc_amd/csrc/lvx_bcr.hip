@@ -87,11 +87,16 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // blockIdx.z = 1, 2 select further, independent problem sets with the same b (p2, p3): the X+ and Y solves of a BCR level and the forward substitution of
 // the right-hand sides against the same factors share a launch — on the lower levels each of them is one latency-bound wave of workgroups (68 us), side by
 // side they cost it once
-struct TrsmSet { const double* Lm; long long strideL; double* V; long long se, sv, strideV; int nvec, batch, batch0; };   // batch0: batch count of the FIRST set (the grid covers the larger of the two)
-template <bool TRANS, int NT>
-__global__ __launch_bounds__(256, 2) void k_trsm_reg(const double* __restrict__ Lm, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, TrsmSet p2, TrsmSet p3) {
-  if (blockIdx.z == 2) { Lm = p3.Lm; strideL = p3.strideL; V = p3.V; se = p3.se; sv = p3.sv; strideV = p3.strideV; nvec = p3.nvec; if ((int)blockIdx.y >= p3.batch) return; }
-  else if (blockIdx.z == 1) { Lm = p2.Lm; strideL = p2.strideL; V = p2.V; se = p2.se; sv = p2.sv; strideV = p2.strideV; nvec = p2.nvec; if ((int)blockIdx.y >= p2.batch) return; }
+// DINV: the Cholesky kernel left the INVERSES of the factor's 16 x 16 diagonal triangles (k_potrf_batched: LI[block][panel][16][16], row-major, zero above the
+// diagonal): a panel's triangular solve is then x = inv(L_pp) w — four MFMAs — instead of a 16-step substitution chain of LDS reads, lane broadcasts and FMAs (2.4 k of
+// the ~5 k cycles a panel costs).  Only the 16 x 16 triangles are inverted: they are the Cholesky factors of diagonal blocks of a Jacobi-scaled SPD matrix, far from
+// the conditioning of a whole b x b block (inverting THOSE lost positive definiteness of the Schur complements).
+struct TrsmSet { const double* Lm; long long strideL; double* V; long long se, sv, strideV; int nvec, batch, batch0; const double* LI; long long strideLI; };   // batch0: batch count of the FIRST set (the grid covers the larger of the two)
+template <bool TRANS, int NT, bool DINV>
+__global__ __launch_bounds__(256, 2) void k_trsm_reg(const double* __restrict__ Lm, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, const double* __restrict__ LIm, long long strideLI,
+                                                     TrsmSet p2, TrsmSet p3) {
+  if (blockIdx.z == 2) { Lm = p3.Lm; strideL = p3.strideL; V = p3.V; se = p3.se; sv = p3.sv; strideV = p3.strideV; nvec = p3.nvec; LIm = p3.LI; strideLI = p3.strideLI; if ((int)blockIdx.y >= p3.batch) return; }
+  else if (blockIdx.z == 1) { Lm = p2.Lm; strideL = p2.strideL; V = p2.V; se = p2.se; sv = p2.sv; strideV = p2.strideV; nvec = p2.nvec; LIm = p2.LI; strideLI = p2.strideLI; if ((int)blockIdx.y >= p2.batch) return; }
   else if ((int)blockIdx.y >= p2.batch0) return;
   if ((int)(blockIdx.x * 64) >= nvec) return;
   extern __shared__ double lds[];
@@ -103,6 +108,7 @@ __global__ __launch_bounds__(256, 2) void k_trsm_reg(const double* __restrict__ 
   const int vec = blockIdx.x * 64 + wv * 16 + fi;
   const bool vact = vec < nvec;
   const double* L = Lm + (size_t)blockIdx.y * strideL;
+  const double* LI = DINV ? LIm + (size_t)blockIdx.y * strideLI : nullptr;
   double* v0 = V + (size_t)blockIdx.y * strideV + (size_t)vec * sv;
   d4 W[NT];
 #pragma unroll
@@ -111,7 +117,10 @@ __global__ __launch_bounds__(256, 2) void k_trsm_reg(const double* __restrict__ 
     for (int v = 0; v < 4; ++v) { const int i = 16 * t + fk + 4 * v; W[t][v] = (vact && i < b) ? v0[(size_t)i * se] : 0.0; }
   constexpr int NPRE = (16 * bp + 255) / 256;
   double pre[NPRE];
+  double pre_li = 0.0;   // DINV: one entry of inv(L_pp) per thread on its way to LDS (Mi[16][17]); a lane's A-operand entries are [fi][4 ks + fk] (forward) / [4 ks + fk][fi] (transposed)
+  double* Mi = dinv + 16;
   auto fetch = [&](int k0) {
+    if (DINV) pre_li = LI[(size_t)(k0 >> 4) * 256 + tid];
 #pragma unroll
     for (int j = 0; j < NPRE; ++j) {
       const int e = tid + 256 * j;
@@ -131,9 +140,10 @@ __global__ __launch_bounds__(256, 2) void k_trsm_reg(const double* __restrict__ 
       if (e < 16 * bp) {
         const int kk = e / bp, i = e - kk * bp;
         P[kk * PS + i] = pre[j];
-        if (i == k0 + kk) dinv[kk] = 1.0 / pre[j];
+        if (!DINV && i == k0 + kk) dinv[kk] = 1.0 / pre[j];
       }
     }
+    if (DINV) Mi[(tid >> 4) * 17 + (tid & 15)] = pre_li;
     __syncthreads();
   };
   if (!TRANS) {
@@ -144,6 +154,12 @@ __global__ __launch_bounds__(256, 2) void k_trsm_reg(const double* __restrict__ 
       if (k0 < b) {                         // uniform
         commit(k0);
         if (k0 + 16 < b) fetch(k0 + 16);
+        if (DINV) {   // w_p <- inv(L_pp) w_p on the matrix cores
+          d4 X = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) X = __builtin_amdgcn_mfma_f64_16x16x4f64(Mi[fi * 17 + 4 * ks + fk], W[p][ks], X, 0, 0, 0);
+          W[p] = X;
+        } else
         {   // 16 x 16 triangular solve in the accumulator layout: the 16 rows of a vector sit in 4 lanes (16 apart) x 4 registers; the
             // solved entry is broadcast to the vector's other 3 lanes and every lane updates its own 4 rows
           double lq[4];
@@ -182,6 +198,14 @@ __global__ __launch_bounds__(256, 2) void k_trsm_reg(const double* __restrict__ 
             if (((t - p) & 1) != 0) Ca = __builtin_amdgcn_mfma_f64_16x16x4f64(av, W[t][ks], Ca, 0, 0, 0);
             else Cb = __builtin_amdgcn_mfma_f64_16x16x4f64(av, W[t][ks], Cb, 0, 0, 0);
           }
+        if (DINV) {   // w_p <- inv(L_pp)^T (v_p - sum)
+          d4 X, Y = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int v = 0; v < 4; ++v) X[v] = Ca[v] + Cb[v];
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(Mi[(4 * ks + fk) * 17 + fi], X[ks], Y, 0, 0, 0);
+          W[p] = Y;
+        } else
         {   // transposed 16 x 16 triangular solve, rows 15 .. 0, in the accumulator layout
           d4 X;
 #pragma unroll
@@ -208,31 +232,37 @@ __global__ __launch_bounds__(256, 2) void k_trsm_reg(const double* __restrict__ 
       for (int v = 0; v < 4; ++v) { const int i = 16 * t + fk + 4 * v; if (i < b) v0[(size_t)i * se] = W[t][v]; }
   }
 }
-template <bool TRANS, int NT>
-static int launch_trsm_reg(lvx_ctx* c, const double* L, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, int batch, const TrsmSet* second, const TrsmSet* third) {
-  const size_t lds = ((size_t)16 * ((16 * NT) | 1) + 16) * 8;
-  LVX_HIP(c, hipFuncSetAttribute((const void*)k_trsm_reg<TRANS, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+template <bool TRANS, int NT, bool DINV>
+static int launch_trsm_reg(lvx_ctx* c, const double* L, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, int batch, const double* LI, long long strideLI,
+                           const TrsmSet* second, const TrsmSet* third) {
+  const size_t lds = ((size_t)16 * ((16 * NT) | 1) + 16 + 16 * 17) * 8;
+  LVX_HIP(c, hipFuncSetAttribute((const void*)k_trsm_reg<TRANS, NT, DINV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   TrsmSet p2{}, p3{}; p2.batch0 = batch; unsigned gx = (unsigned)((nvec + 63) / 64), gy = (unsigned)batch, gz = 1;
   auto live = [](const TrsmSet* t) { return t && t->batch > 0 && t->nvec > 0; };
   if (live(second)) { p2 = *second; p2.batch0 = batch; gz = 2; }
   if (live(third)) { p3 = *third; gz = 3; }      // an empty second set with a live third: blocks of z = 1 exit at once (batch 0)
   for (const TrsmSet* t : {&p2, &p3}) if (t->batch > 0 && t->nvec > 0) { gx = std::max(gx, (unsigned)((t->nvec + 63) / 64)); gy = std::max(gy, (unsigned)t->batch); }
-  hipLaunchKernelGGL((k_trsm_reg<TRANS, NT>), dim3(gx, gy, gz), dim3(256), lds, c->stream, L, b, strideL, V, se, sv, strideV, nvec, p2, p3);
+  hipLaunchKernelGGL((k_trsm_reg<TRANS, NT, DINV>), dim3(gx, gy, gz), dim3(256), lds, c->stream, L, b, strideL, V, se, sv, strideV, nvec, LI, strideLI, p2, p3);
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
 }
 
+// LI / strideLI: the diagonal-triangle inverses of the factors (c->bcr_linv: the own Cholesky kernel produced them), or null
 template <bool TRANS>
-static int trsv_batched(lvx_ctx* c, const double* L, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, int batch, const TrsmSet* second = nullptr,
-                        const TrsmSet* third = nullptr) {
+static int trsv_batched(lvx_ctx* c, const double* L, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, int batch, const double* LI, long long strideLI,
+                        const TrsmSet* second = nullptr, const TrsmSet* third = nullptr) {
   if (batch <= 0 || nvec <= 0) {   // the first set is empty: promote the next live one
     for (const TrsmSet* t : {second, third}) if (t && t->batch > 0 && t->nvec > 0)
-      return trsv_batched<TRANS>(c, t->Lm, b, t->strideL, t->V, t->se, t->sv, t->strideV, t->nvec, t->batch, t == second ? third : nullptr);
+      return trsv_batched<TRANS>(c, t->Lm, b, t->strideL, t->V, t->se, t->sv, t->strideV, t->nvec, t->batch, t->LI, t->strideLI, t == second ? third : nullptr);
     return LVX_OK;
   }
-  if (b <= 128) return launch_trsm_reg<TRANS, 8>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, second, third);
-  if (b <= 208) return launch_trsm_reg<TRANS, 13>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, second, third);
-  if (b <= 256) return launch_trsm_reg<TRANS, 16>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, second, third);
+  if (LI) {
+    if (b <= 128) return launch_trsm_reg<TRANS, 8, true>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, LI, strideLI, second, third);
+    if (b <= 208) return launch_trsm_reg<TRANS, 13, true>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, LI, strideLI, second, third);
+  }
+  if (b <= 128) return launch_trsm_reg<TRANS, 8, false>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, nullptr, 0, second, third);
+  if (b <= 208) return launch_trsm_reg<TRANS, 13, false>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, nullptr, 0, second, third);
+  if (b <= 256) return launch_trsm_reg<TRANS, 16, false>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, nullptr, 0, second, third);
   return fail(c, LVX_E_ARG, "block size too large for the batched triangular solve (half-bandwidth > 256)");
 }
 
@@ -258,12 +288,17 @@ __device__ __forceinline__ double rsqrt_f64(double x) {             // hardware 
   return y;
 }
 #define POTRF_NT 512   // 8 wavefronts: the trailing update's tiles are dealt over all of them (one flat list, two tiles in flight per wavefront)
-__global__ __launch_bounds__(POTRF_NT) void k_potrf_batched(double* Dm, int b, long long strideD, int* info) {
+// LIm != null: the inverse of every 16 x 16 diagonal triangle of the factor goes to LIm[block][panel][16][16] (row-major, zero above the diagonal) for the triangular
+// solves that follow (k_trsm_reg<.., DINV>); the kernel itself uses it too: the rows below a diagonal block are X = A21 inv(L11)^T — MFMA tiles dealt to all
+// wavefronts — instead of one thread per row substituting through 16 columns.
+__global__ __launch_bounds__(POTRF_NT) void k_potrf_batched(double* Dm, int b, long long strideD, int* info, double* LIm, long long strideLI) {
   extern __shared__ double T[];             // packed lower triangle, row-major
   double* dinv = T + ((b * (b + 1)) >> 1);  // [16]
+  double* Minv = dinv + 16;                 // [16][17]: inverse of the current diagonal triangle
   __shared__ int bad;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   double* D = Dm + (size_t)blockIdx.x * strideD;
+  double* LI = LIm ? LIm + (size_t)blockIdx.x * strideLI : nullptr;
   if (tid == 0) bad = 0;
   for (int c0 = 0; c0 < b; c0 += 16) {      // lower triangle, 16 columns per step so that the loads are in flight together (4 per step: 53 k of the kernel's 358 k cycles)
     double v[16];
@@ -279,7 +314,7 @@ __global__ __launch_bounds__(POTRF_NT) void k_potrf_batched(double* Dm, int b, l
   // update, so the serial 16-column chain (7.3 k cycles) leaves the critical path wherever the update is at least as long.
   auto diag_block = [&](int k0) {
     const int nk = min(16, b - k0);
-    double a[16];
+    double a[16], invd[16];
     const int r = lane;
 #pragma unroll
     for (int cc = 0; cc < 16; ++cc) a[cc] = (r < nk && cc <= r) ? T[tri(k0 + r, k0 + cc)] : ((r == cc) ? 1.0 : 0.0);
@@ -288,6 +323,7 @@ __global__ __launch_bounds__(POTRF_NT) void k_potrf_batched(double* Dm, int b, l
       double dc = readlane_f64(a[cc], cc);
       if (!(dc > 0.0)) { if (lane == 0 && cc < nk) atomicCAS(&bad, 0, k0 + cc + 1); dc = 1.0; }
       const double inv = rsqrt_f64(dc), sq = dc * inv;
+      invd[cc] = inv;
       a[cc] = (r == cc) ? sq : a[cc] * inv;
       if (lane == 0) dinv[cc] = inv;
 #pragma unroll
@@ -297,12 +333,46 @@ __global__ __launch_bounds__(POTRF_NT) void k_potrf_batched(double* Dm, int b, l
 #pragma unroll
       for (int cc = 0; cc < 16; ++cc) if (cc <= r) T[tri(k0 + r, k0 + cc)] = a[cc];
     }
+    if (LI) {   // M = inv(L11), lane = row: row k is final once the rows above it have been folded in; it is broadcast and the rows below accumulate L[r][k] M[k][:]
+      double m[16], acc[16];
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc) { m[cc] = 0.0; acc[cc] = 0.0; }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const double ik = invd[k];                        // 1 / L[k][k]
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) if (cc <= k) { const double fin = cc == k ? ik : -acc[cc] * ik; m[cc] = (r == k) ? fin : m[cc]; }
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) if (cc <= k) { const double mk = readlane_f64(m[cc], k); acc[cc] += a[k] * mk; }   // a[k] = L[r][k] (0 for k > r: the rows above take nothing)
+      }
+      if (r < 16) {
+        double* dst = LI + (size_t)(k0 >> 4) * 256 + r * 16;
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) { Minv[r * 17 + cc] = m[cc]; dst[cc] = m[cc]; }
+      }
+    }
   };
   if (wv == 0) diag_block(0);
   __syncthreads();
   for (int k0 = 0; k0 < b; k0 += 16) {
     const int nk = min(16, b - k0);
-    {                                       // 2. rows below the diagonal block: x L11^T = a
+    if (LI) {                               // 2. rows below the diagonal block: X = A21 inv(L11)^T, one 16 x 16 tile (4 MFMAs) per 16 rows
+      const int r0b = k0 + 16;
+      const int mt = r0b < b ? (b - r0b + 15) >> 4 : 0;
+      for (int tt = wv; tt < mt; tt += POTRF_NT / 64) {
+        const int i0 = r0b + 16 * tt;
+        const int ra = i0 + fi < b ? tri(i0 + fi, k0 + fk) : -1;
+        double av[4], bv[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { av[ks] = ra >= 0 ? T[ra + 4 * ks] : 0.0; bv[ks] = Minv[fi * 17 + 4 * ks + fk]; }   // A[i][k] = A21[i0 + fi][k0 + 4 ks + fk]; B[k][c] = M[c = fi][4 ks + fk]
+        d4 X = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) X = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], X, 0, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // every lane has read its A21 entries before the tile is overwritten
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { const int i = i0 + fk + 4 * v; if (i < b) T[tri(i, k0 + fi)] = X[v]; }
+      }
+    } else {                                // 2. rows below the diagonal block: x L11^T = a
       const int i = k0 + nk + tid;
       if (i < b) {
         double x[16];
@@ -375,15 +445,17 @@ __global__ __launch_bounds__(POTRF_NT) void k_potrf_batched(double* Dm, int b, l
   if (tid == 0) info[blockIdx.x] = bad;
 }
 // potrf of `batch` blocks: own kernel when the triangle fits into LDS, rocSOLVER otherwise (or with LVX_BCR_ROCSOLVER_POTRF)
-static int potrf_batched(lvx_ctx* c, rocblas_handle h, double* D, int b, long long strideD, int* info, int batch) {
-  const bool force_lib = c->sw.bcr_rocsolver_potrf != 0;
-  const size_t lds = ((size_t)b * (b + 1) / 2 + 16) * 8;
-  if (force_lib || lds > 159 * 1024) {
+static size_t potrf_lds_bytes(int b) { return ((size_t)b * (b + 1) / 2 + 16 + 16 * 17) * 8; }
+// the own Cholesky kernel serves this block size (and so produces the diagonal-triangle inverses the triangular solves use)
+static bool potrf_own(const lvx_ctx* c, int b) { return c->sw.bcr_rocsolver_potrf == 0 && potrf_lds_bytes(b) <= 159 * 1024; }
+static int potrf_batched(lvx_ctx* c, rocblas_handle h, double* D, int b, long long strideD, int* info, int batch, double* LI, long long strideLI) {
+  const size_t lds = potrf_lds_bytes(b);
+  if (!potrf_own(c, b)) {
     LVX_BLAS(c, rocsolver_dpotrf_strided_batched(h, rocblas_fill_lower, b, D, b, (rocblas_stride)strideD, info, batch));
     return LVX_OK;
   }
   LVX_HIP(c, hipFuncSetAttribute((const void*)k_potrf_batched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_potrf_batched, dim3((unsigned)batch), dim3(POTRF_NT), lds, c->stream, D, b, strideD, info);
+  hipLaunchKernelGGL(k_potrf_batched, dim3((unsigned)batch), dim3(POTRF_NT), lds, c->stream, D, b, strideD, info, LI, strideLI);
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
 }
@@ -400,6 +472,8 @@ int bcr_plan(lvx_ctx* c) {
   if ((rc = dev_alloc(c, c->d_bcrD, guard * (size_t)nblk * bb * 8))) return rc;       // diagonal blocks -> Cholesky factors C_j
   if ((rc = dev_alloc(c, c->d_bcrG, guard * (size_t)2 * nblk * bb * 8))) return rc;   // couplings per level -> X+ (even slots) / Y (odd slots)
   if ((rc = dev_alloc(c, c->d_bcrInfo, guard * (size_t)(2 * nblk + 8) * 4))) return rc;
+  c->bcr_linv = potrf_own(c, b) && b <= 208 && !c->sw.bcr_no_dinv;   // inverses of the factors' 16 x 16 diagonal triangles: [nblk][ceil(b / 16)][16][16]
+  if (c->bcr_linv && (rc = dev_alloc(c, c->d_bcrLinv, (size_t)nblk * ((b + 15) / 16) * 256 * 8))) return rc;
   // couplings of the levels above 0 that involve a padding block are never computed (level_batch) and must read as zero
   LVX_HIP(c, hipMemsetAsync(c->d_bcrG.p, 0, (size_t)2 * nblk * bb * 8, c->stream));
   if (c->bcr_nreal < nblk) {   // padding blocks: identity, decoupled — nothing ever changes them (potrf(I) = I, updates with zero couplings)
@@ -426,6 +500,8 @@ int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_ra
   const int b = c->bcr_b, nblk = c->bcr_nblk;
   const size_t bb = (size_t)b * b;
   double* D = (double*)c->d_bcrD.p; double* G = (double*)c->d_bcrG.p; int* info = (int*)c->d_bcrInfo.p;
+  double* LI = c->bcr_linv ? (double*)c->d_bcrLinv.p : nullptr;
+  const size_t liS = (size_t)((b + 15) / 16) * 256;
   hipStream_t st = c->stream;
   const int nfill = std::min(nblk, std::max(c->bcr_nreal, 1));
   const size_t tot = 2 * (size_t)nfill * bb;
@@ -443,16 +519,18 @@ int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_ra
     double* Dr = D + (size_t)(2 * s - 1) * bb;
     double* Gl = G + g_off(nblk, l, bb);
     double* Gn = G + g_off(nblk, l + 1, bb);
-    if ((rc = potrf_batched(c, h, Dj, b, sD, info + info_pos, n2))) return rc;
+    double* LIj = LI ? LI + (size_t)(s - 1) * liS : nullptr;
+    const long long sLI = (long long)2 * s * liS;
+    if ((rc = potrf_batched(c, h, Dj, b, sD, info + info_pos, n2, LIj, sLI))) return rc;
     info_pos += n2;
     // X+_k = G[2k] C_k^-T : every ROW x of G[2k] solves C x^T = g^T
     // Y_k = C_k^-1 G[2k-1], k = 1..n2-1 : every COLUMN — in the same launch
-    const TrsmSet ysolve{Dj + sD, sD, Gl + bb, 1, b, sG, b, n2 - 1, 0};
+    const TrsmSet ysolve{Dj + sD, sD, Gl + bb, 1, b, sG, b, n2 - 1, 0, LIj ? LIj + sLI : nullptr, sLI};
     const long long sZ = (long long)2 * s * b;
     double* Zj = Z ? Z + (size_t)(s - 1) * b : nullptr;
     double* Zr = Z ? Z + (size_t)(2 * s - 1) * b : nullptr;
-    const TrsmSet rsolve{Dj, sD, Zj, 1, ldz, sZ, Z ? nrhs : 0, Z ? n2 : 0, 0};                              // y_j = C_j^-1 b_j
-    if ((rc = trsv_batched<false>(c, Dj, b, sD, Gl, /*se*/ b, /*sv*/ 1, sG, b, n2, &ysolve, &rsolve))) return rc;
+    const TrsmSet rsolve{Dj, sD, Zj, 1, ldz, sZ, Z ? nrhs : 0, Z ? n2 : 0, 0, LIj, sLI};                    // y_j = C_j^-1 b_j
+    if ((rc = trsv_batched<false>(c, Dj, b, sD, Gl, /*se*/ b, /*sv*/ 1, sG, b, n2, LIj, sLI, &ysolve, &rsolve))) return rc;
     // D_{j+s} -= X+ X+^T
     // (full GEMM instead of SYRK: rocBLAS' batched SYRK runs as many small launches; the upper triangle of D is never read)
     if (use_gemm) LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, b, b, b, &mone, Gl, b, sG, Gl, b, sG, &one, Dr, b, sD, n2));
@@ -470,8 +548,9 @@ int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_ra
         LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, nrhs, b, &mone, Gl + bb, b, sG, Zj + sZ, ldz, sZ, &one, Zr, ldz, sZ, n2 - 1));
     }
   }
-  if ((rc = potrf_batched(c, h, D + (size_t)(nblk - 1) * bb, b, (long long)bb, info + info_pos, 1))) return rc;
-  if (Z && (rc = trsv_batched<false>(c, D + (size_t)(nblk - 1) * bb, b, 0, Z + (size_t)(nblk - 1) * b, 1, ldz, 0, nrhs, 1))) return rc;
+  double* LIlast = LI ? LI + (size_t)(nblk - 1) * liS : nullptr;
+  if ((rc = potrf_batched(c, h, D + (size_t)(nblk - 1) * bb, b, (long long)bb, info + info_pos, 1, LIlast, 0))) return rc;
+  if (Z && (rc = trsv_batched<false>(c, D + (size_t)(nblk - 1) * bb, b, 0, Z + (size_t)(nblk - 1) * b, 1, ldz, 0, nrhs, 1, LIlast, 0))) return rc;
   info_pos += 1;
   hipLaunchKernelGGL(k_bcr_info, dim3((info_pos + 255) / 256), dim3(256), 0, st, (const int*)info, info_pos, info_out_d);
   LVX_HIP(c, hipGetLastError());
@@ -486,6 +565,8 @@ int bcr_forward(lvx_ctx* c, double* Zin, double* Zy, int ldz, int nrhs) {
   const int b = c->bcr_b, nblk = c->bcr_nblk;
   const size_t bb = (size_t)b * b;
   double* D = (double*)c->d_bcrD.p; double* G = (double*)c->d_bcrG.p;
+  const double* LI = c->bcr_linv ? (const double*)c->d_bcrLinv.p : nullptr;
+  const size_t liS = (size_t)((b + 15) / 16) * 256;
   const double one = 1.0, mone = -1.0;
   int L = 0; while ((1 << L) < nblk) ++L;
   for (int l = 0; l < L; ++l) {
@@ -496,12 +577,12 @@ int bcr_forward(lvx_ctx* c, double* Zin, double* Zy, int ldz, int nrhs) {
     double* Gl = G + g_off(nblk, l, bb);
     double* Zj = Z + (size_t)(s - 1) * b;
     double* Zr = Z + (size_t)(2 * s - 1) * b;
-    if ((rc = trsv_batched<false>(c, Dj, b, sD, Zj, 1, ldz, sZ, nrhs, n2))) return rc;                      // y_j = C_j^-1 b_j
+    if ((rc = trsv_batched<false>(c, Dj, b, sD, Zj, 1, ldz, sZ, nrhs, n2, LI ? LI + (size_t)(s - 1) * liS : nullptr, (long long)2 * s * liS))) return rc;                      // y_j = C_j^-1 b_j
     LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, nrhs, b, &mone, Gl, b, sG, Zj, ldz, sZ, &one, Zr, ldz, sZ, n2));
     if (n2 > 1)
       LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, nrhs, b, &mone, Gl + bb, b, sG, Zj + sZ, ldz, sZ, &one, Zr, ldz, sZ, n2 - 1));
   }
-  return trsv_batched<false>(c, D + (size_t)(nblk - 1) * bb, b, 0, Z + (size_t)(nblk - 1) * b, 1, ldz, 0, nrhs, 1);
+  return trsv_batched<false>(c, D + (size_t)(nblk - 1) * bb, b, 0, Z + (size_t)(nblk - 1) * b, 1, ldz, 0, nrhs, 1, LI ? LI + (size_t)(nblk - 1) * liS : nullptr, 0);
 }
 // in place Zy <- L^-T Zy (Zx aliases Zy)
 int bcr_backward(lvx_ctx* c, double* Zy, double* Zx, int ldz, int nrhs) {
@@ -511,9 +592,11 @@ int bcr_backward(lvx_ctx* c, double* Zy, double* Zx, int ldz, int nrhs) {
   const int b = c->bcr_b, nblk = c->bcr_nblk;
   const size_t bb = (size_t)b * b;
   double* D = (double*)c->d_bcrD.p; double* G = (double*)c->d_bcrG.p;
+  const double* LI = c->bcr_linv ? (const double*)c->d_bcrLinv.p : nullptr;
+  const size_t liS = (size_t)((b + 15) / 16) * 256;
   const double one = 1.0, mone = -1.0;
   int L = 0; while ((1 << L) < nblk) ++L;
-  if ((rc = trsv_batched<true>(c, D + (size_t)(nblk - 1) * bb, b, 0, Z + (size_t)(nblk - 1) * b, 1, ldz, 0, nrhs, 1))) return rc;
+  if ((rc = trsv_batched<true>(c, D + (size_t)(nblk - 1) * bb, b, 0, Z + (size_t)(nblk - 1) * b, 1, ldz, 0, nrhs, 1, LI ? LI + (size_t)(nblk - 1) * liS : nullptr, 0))) return rc;
   for (int l = L - 1; l >= 0; --l) {
     const int s = 1 << l, n2 = level_batch(nblk, c->bcr_nreal, l);
     if (n2 <= 0) continue;
@@ -525,7 +608,7 @@ int bcr_backward(lvx_ctx* c, double* Zy, double* Zx, int ldz, int nrhs) {
     LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, nrhs, b, &mone, Gl, b, sG, Zr, ldz, sZ, &one, Zj, ldz, sZ, n2));
     if (n2 > 1)
       LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, nrhs, b, &mone, Gl + bb, b, sG, Zr, ldz, sZ, &one, Zj + sZ, ldz, sZ, n2 - 1));
-    if ((rc = trsv_batched<true>(c, Dj, b, sD, Zj, 1, ldz, sZ, nrhs, n2))) return rc;
+    if ((rc = trsv_batched<true>(c, Dj, b, sD, Zj, 1, ldz, sZ, nrhs, n2, LI ? LI + (size_t)(s - 1) * liS : nullptr, (long long)2 * s * liS))) return rc;
   }
   return LVX_OK;
 }

@@ -61,7 +61,7 @@ struct DevBuf {
 struct Switches {
   int force_legacy = 0, imu_legacy = 0, reproj_legacy = 0, serial = 0, sched = 2, imu_two_streams = 0, occ = 0, jac_late = 0, fold_one = 0, fold_inline = 0,
       no_graph = 0, sync_nofence = 0, chunk_r = 0, chunk_r_imu = 0, chunk_r_rep = 0, chunk_rows = 0, rep_rows = 0, solver_seq = 0, solver_timing = 0,
-      bcr_rocsolver_potrf = 0, bcr_syrk = 0, deterministic = 0, clear_all = 0, cross_dbg = 0, lm_schur_single = 0, imu_split = 0, ref_side = -1;
+      bcr_rocsolver_potrf = 0, bcr_syrk = 0, bcr_no_dinv = 0, deterministic = 0, clear_all = 0, cross_dbg = 0, lm_schur_single = 0, imu_split = 0, ref_side = -1;
 };
 struct SwitchName { const char* name; int Switches::*field; bool relayout; };
 const SwitchName* switch_table(int* count);
@@ -123,7 +123,7 @@ struct lvx_ctx {
   // solver workspace (lvx_solver.hip)
   lvx::DevBuf d_L, d_Y, d_S, d_delta, d_diag, d_scal, d_state_try, d_zero;
   // block cyclic reduction (lvx_bcr.hip): diagonal blocks, per-level coupling blocks, pivot info; rocBLAS handle
-  lvx::DevBuf d_bcrD, d_bcrG, d_bcrInfo, d_Y2, d_gram;
+  lvx::DevBuf d_bcrD, d_bcrG, d_bcrInfo, d_Y2, d_gram, d_bcrLinv; bool bcr_linv = false;   // d_bcrLinv: inverses of the factors' 16 x 16 diagonal triangles (k_potrf_batched -> k_trsm_reg)
   void* blas = nullptr;
   int bcr_b = 0, bcr_nblk = 0, bcr_nreal = 0;
   int64_t n_blocks = 0, n_residuals = 0;

@@ -1552,7 +1552,7 @@ const SwitchName* switch_table(int* count) {
     {"SYNC_NOFENCE", &Switches::sync_nofence, false}, {"CHUNK_R", &Switches::chunk_r, true}, {"CHUNK_R_IMU", &Switches::chunk_r_imu, true},
     {"CHUNK_R_REP", &Switches::chunk_r_rep, true}, {"CHUNK_ROWS", &Switches::chunk_rows, true}, {"REP_ROWS", &Switches::rep_rows, true},
     {"SOLVER_SEQ", &Switches::solver_seq, false}, {"SOLVER_TIMING", &Switches::solver_timing, false}, {"BCR_ROCSOLVER_POTRF", &Switches::bcr_rocsolver_potrf, false},
-    {"BCR_SYRK", &Switches::bcr_syrk, false}, {"DETERMINISTIC", &Switches::deterministic, true}, {"CLEAR_ALL", &Switches::clear_all, false}, {"CROSS_DBG", &Switches::cross_dbg, false}, {"LM_SCHUR_SINGLE", &Switches::lm_schur_single, false}, {"IMU_SPLIT", &Switches::imu_split, false}, {"REF_SIDE", &Switches::ref_side, false},
+    {"BCR_SYRK", &Switches::bcr_syrk, false}, {"BCR_NO_DINV", &Switches::bcr_no_dinv, false}, {"DETERMINISTIC", &Switches::deterministic, true}, {"CLEAR_ALL", &Switches::clear_all, false}, {"CROSS_DBG", &Switches::cross_dbg, false}, {"LM_SCHUR_SINGLE", &Switches::lm_schur_single, false}, {"IMU_SPLIT", &Switches::imu_split, false}, {"REF_SIDE", &Switches::ref_side, false},
   };
   *count = (int)(sizeof(tab) / sizeof(tab[0]));
   return tab;
@@ -2523,7 +2523,7 @@ void lvx_destroy(lvx_ctx* c) {
   (void)lvx_rccl_finalize(c);
   if (c->d_comm.p) (void)hipFree(c->d_comm.p);
   bcr_destroy(c);
-  for (DevBuf* b : {&c->d_bcrD, &c->d_bcrG, &c->d_bcrInfo, &c->d_Y2, &c->d_gram}) if (b->p) (void)hipFree(b->p);
+  for (DevBuf* b : {&c->d_bcrD, &c->d_bcrG, &c->d_bcrInfo, &c->d_Y2, &c->d_gram, &c->d_bcrLinv}) if (b->p) (void)hipFree(b->p);
   for (auto& e : c->graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.exec);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   for (int k = 0; k < 4; ++k) { if (c->fam_stream[k]) (void)hipStreamDestroy(c->fam_stream[k]); if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]); }
