@@ -313,8 +313,8 @@ int lvx_lm_solve_shared(lvx_ctx* ctx, double* state, const lvx_lm_options* opt, 
  * context's stream — the per-step [S | rhs | votes] block is packed, reduced and solved on the device with no host round trip.  librccl is loaded with
  * dlopen (no link-time dependency; a process that already loaded RCCL, e.g. through torch, shares it).  Rank 0 creates the 128-byte id, the host
  * distributes it (any side channel), every rank calls lvx_rccl_init; lvx_rccl_finalize (or lvx_destroy) frees the communicator.
- * Collectives per LM iteration: one for the step, one for the accept / reject decision, and two more after an accepted step (cost + shared diagonal +
- * shared gradient; gradient max norm) — the step and the decision cannot merge, the candidate depends on the reduced system's solution.
+ * Collectives: one after the first evaluation, then exactly two per LM iteration — the reduced 14 x 14 system, and the decision block (candidate cost, model terms,
+ * norms, the candidate's joint diagonal / gradient); the two cannot merge, the candidate depends on the reduced system's solution.
  * A rank that fails locally votes in the next collective and EVERY rank returns there (the failing one with its code, the others LVX_E_COMM). */
 int lvx_rccl_unique_id(lvx_ctx* ctx, void* id128);
 int lvx_rccl_init(lvx_ctx* ctx, const void* id128, int rank, int world);

@@ -943,46 +943,69 @@ static int local_gmax(lvx_ctx* c, SolveWork& w, double* g, double* gsh) {
   if (c->ns > 0) LVX_HIP(c, hipMemcpyAsync(gsh, (const double*)c->d_gc.p + (c->nbd - c->ns), (size_t)c->ns * 8, hipMemcpyDeviceToHost, st));
   return LVX_OK;
 }
-// Everything that follows a LVX_EVAL_NORMAL_EQ evaluation: the diagonal (Jacobi scaling at the first iterate, LM damping), the gradient max norm, and —
-// joint solve — what has to agree on every rank: cost, the shared part of the diagonal and of the gradient in ONE sum [cost | diag (14) | g (14) | error
-// votes], the private gradient max norm in one max.  lerr: error of the evaluation that has not met a collective yet.
-static int post_eval(lvx_ctx* c, SolveWork& w, bool compute_scale, int use_scaling, double mn, double mx, double* cost, double* gmax, int lerr) {
+// What follows a LVX_EVAL_NORMAL_EQ evaluation, in two halves so that the loop can put ONE collective between them.
+// local_after_eval: the diagonal of J^T J into w.diag (the LM damping in w.lmd — what the solver reads — is untouched until apply_diag), this rank's private
+// gradient max norm, and the shared entries of diagonal / gradient on the host.
+struct EvalLocal { double gm = 0.0; double hd[LVX_N_SHARED] = {0}, hg[LVX_N_SHARED] = {0}; };
+static int local_after_eval(lvx_ctx* c, SolveWork& w, EvalLocal* e) {
   const int n = c->nb + c->nbd, ns = c->ns;
   hipStream_t st = c->stream;
   const int nl = w.lm ? c->L : 0;   // landmark diagonal behind the band / border entries
-  double* dsh = w.diag + (n - ns);
-  double hd[LVX_N_SHARED] = {0}, hg[LVX_N_SHARED] = {0}, gm = 0.0;
-  if (!lerr) {
-    hipLaunchKernelGGL(k_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)c->d_C.p, c->nb, c->bw, c->nbd, c->nbd_ext, w.diag);
-    if (nl > 0) hipLaunchKernelGGL(k_lm_fetch_diag, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, (const double*)c->d_lmH.p, nl, c->lm_ls, c->lm_wl + c->nbd_ext, w.diag + n);
-    int rc = local_gmax(c, w, &gm, hg); if (rc) return rc;
-    if (is_joint(c) && ns > 0) LVX_HIP(c, hipMemcpyAsync(hd, dsh, (size_t)ns * 8, hipMemcpyDeviceToHost, st));
-    LVX_HIP(c, hipStreamSynchronize(st));
-  }
-  if (is_joint(c)) {
-    double buf[2 * LVX_N_SHARED + 2] = {0};
-    if (!lerr) { buf[0] = *cost; for (int i = 0; i < ns; ++i) { buf[1 + c->sh_slot[i]] = hd[i]; buf[1 + LVX_N_SHARED + c->sh_slot[i]] = hg[i]; } }
-    buf[2 * LVX_N_SHARED + 1] = lerr ? 1.0 : 0.0;
-    int rc = reduce(c, buf, 2 * LVX_N_SHARED + 2, LVX_REDUCE_SUM); if (rc) return rc;
-    if ((rc = reduce(c, &gm, 1, LVX_REDUCE_MAX))) return rc;
-    if ((rc = leave_together(c, buf[2 * LVX_N_SHARED + 1], lerr))) return rc;
-    *cost = buf[0];
-    for (int i = 0; i < ns; ++i) { hd[i] = buf[1 + c->sh_slot[i]]; gm = std::max(gm, std::fabs(buf[1 + LVX_N_SHARED + c->sh_slot[i]])); }
-    if (ns > 0) LVX_HIP(c, hipMemcpyAsync(dsh, hd, (size_t)ns * 8, hipMemcpyHostToDevice, st));   // Jacobi scaling and LM damping use the JOINT diagonal at the shared scalars
-  } else {
-    if (lerr) return lerr;
-    for (int i = 0; i < ns; ++i) gm = std::max(gm, std::fabs(hg[i]));
-  }
-  *gmax = gm;
+  hipLaunchKernelGGL(k_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)c->d_C.p, c->nb, c->bw, c->nbd, c->nbd_ext, w.diag);
+  if (nl > 0) hipLaunchKernelGGL(k_lm_fetch_diag, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, (const double*)c->d_lmH.p, nl, c->lm_ls, c->lm_wl + c->nbd_ext, w.diag + n);
+  int rc = local_gmax(c, w, &e->gm, e->hg); if (rc) return rc;
+  if (is_joint(c) && ns > 0) LVX_HIP(c, hipMemcpyAsync(e->hd, w.diag + (n - ns), (size_t)ns * 8, hipMemcpyDeviceToHost, st));
+  LVX_HIP(c, hipStreamSynchronize(st));
+  return LVX_OK;
+}
+// Joint quantities of an evaluation as ONE sum block: [shared diagonal (14, canonical slots) | shared gradient (14) | ranks whose private gradient max norm exceeds the
+// tolerance] — the termination test max|g| <= tol needs no MAX reduction: it holds iff no rank reports a violation and the summed shared gradient passes.
+#define LVX_JB_N (2 * LVX_N_SHARED + 1)
+static void joint_block_pack(const lvx_ctx* c, const EvalLocal& e, double grad_tol, double* buf) {
+  for (int i = 0; i < LVX_JB_N; ++i) buf[i] = 0.0;
+  for (int i = 0; i < c->ns; ++i) { buf[c->sh_slot[i]] = e.hd[i]; buf[LVX_N_SHARED + c->sh_slot[i]] = e.hg[i]; }
+  buf[2 * LVX_N_SHARED] = e.gm > grad_tol ? 1.0 : 0.0;
+}
+// apply_diag: Jacobi scaling (first iterate), LM damping from w.diag — with the JOINT diagonal at the shared scalars (buf: the reduced block, or null for a single
+// sequence); *grad_converged: max|g| over the joint problem <= grad_tol
+static int apply_diag(lvx_ctx* c, SolveWork& w, bool compute_scale, int use_scaling, double mn, double mx, const EvalLocal& e, const double* buf, double grad_tol, bool* grad_converged) {
+  const int n = c->nb + c->nbd, ns = c->ns;
+  hipStream_t st = c->stream;
+  const int nl = w.lm ? c->L : 0;
+  double hd[LVX_N_SHARED];
+  bool conv = e.gm <= grad_tol;
+  if (buf) {
+    conv = !(buf[2 * LVX_N_SHARED] > 0.0);
+    for (int i = 0; i < ns; ++i) { hd[i] = buf[c->sh_slot[i]]; if (std::fabs(buf[LVX_N_SHARED + c->sh_slot[i]]) > grad_tol) conv = false; }
+    if (ns > 0) LVX_HIP(c, hipMemcpyAsync(w.diag + (n - ns), hd, (size_t)ns * 8, hipMemcpyHostToDevice, st));   // Jacobi scaling and LM damping use the JOINT diagonal at the shared scalars
+  } else for (int i = 0; i < ns; ++i) if (std::fabs(e.hg[i]) > grad_tol) conv = false;
+  *grad_converged = conv;
   if (compute_scale) hipLaunchKernelGGL(k_scale_from_diag, dim3((unsigned)((n + nl + 255) / 256)), dim3(256), 0, st, (const double*)w.diag, n + nl, w.scale, use_scaling);
   hipLaunchKernelGGL(k_lm_diag, dim3((unsigned)((n + nl + 255) / 256)), dim3(256), 0, st, (const double*)w.diag, (const double*)w.scale, n + nl, mn, mx, w.lmd);
   if (is_joint(c) && ns > 0) {   // shared damping is applied once to the reduced system (solve_step_device), not per rank
     LVX_HIP(c, hipMemcpyAsync(c->sh_lmd, w.lmd + (n - ns), (size_t)ns * 8, hipMemcpyDeviceToHost, st));
     LVX_HIP(c, hipStreamSynchronize(st));   // (also keeps hd alive until the copy above has read it)
     LVX_HIP(c, hipMemsetAsync(w.lmd + (n - ns), 0, (size_t)ns * 8, st));
-  } else if (is_joint(c)) LVX_HIP(c, hipStreamSynchronize(st));
+  } else if (buf) LVX_HIP(c, hipStreamSynchronize(st));
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
+}
+// The first evaluation of a solve (and lvx_solve_step_shared): both halves around one sum [cost | joint block | error votes].  lerr: error of the evaluation that
+// has not met a collective yet.
+static int post_eval(lvx_ctx* c, SolveWork& w, bool compute_scale, int use_scaling, double mn, double mx, double* cost, double grad_tol, bool* grad_converged, int lerr) {
+  EvalLocal e;
+  if (!lerr) lerr = local_after_eval(c, w, &e);
+  if (is_joint(c)) {
+    double buf[LVX_JB_N + 2] = {0};
+    if (!lerr) { joint_block_pack(c, e, grad_tol, buf); buf[LVX_JB_N] = *cost; }
+    buf[LVX_JB_N + 1] = lerr ? 1.0 : 0.0;
+    int rc = reduce(c, buf, LVX_JB_N + 2, LVX_REDUCE_SUM); if (rc) return rc;
+    if ((rc = leave_together(c, buf[LVX_JB_N + 1], lerr))) return rc;
+    *cost = buf[LVX_JB_N];
+    return apply_diag(c, w, compute_scale, use_scaling, mn, mx, e, buf, grad_tol, grad_converged);
+  }
+  if (lerr) return lerr;
+  return apply_diag(c, w, compute_scale, use_scaling, mn, mx, e, nullptr, grad_tol, grad_converged);
 }
 
 struct HookScope {   // installs the all-reduce hook for the duration of one API call
@@ -1010,8 +1033,8 @@ int lvx_solve_step_shared(lvx_ctx* c, double radius, int jacobi_scaling, lvx_all
   SolveWork w;
   if (!lerr) lerr = solver_alloc(c, w);
   if (lerr && !is_joint(c)) return lerr;
-  double cost = 0, gm = 0;
-  int rc = post_eval(c, w, true, jacobi_scaling, 1e-6, 1e32, &cost, &gm, lerr); if (rc) return rc;
+  double cost = 0; bool gconv = false;
+  int rc = post_eval(c, w, true, jacobi_scaling, 1e-6, 1e32, &cost, 0.0, &gconv, lerr); if (rc) return rc;
   double m[3]; bool notpd = false;
   if ((rc = solve_step_device(c, w, radius, m, &notpd, LVX_OK))) return rc;
   if ((rc = reduce(c, m, 3, LVX_REDUCE_SUM))) return rc;
@@ -1024,9 +1047,12 @@ int lvx_solve_step(lvx_ctx* c, double radius, int jacobi_scaling, double* delta,
   return lvx_solve_step_shared(c, radius, jacobi_scaling, nullptr, nullptr, delta, model_cost_change);
 }
 
-// Collectives of the joint loop per iteration: R1 [S | rhs | votes] inside solve_step_device, R2 [g.delta, delta^T H delta, y^T D^2 y, candidate cost,
-// step norm^2, x norm^2, error votes] after the candidate evaluation, and after an ACCEPTED step the two of post_eval.  (R1 and R2 cannot merge: the
-// candidate is a function of the reduced system's solution.)
+// Collectives of the joint loop: one after the first evaluation, then exactly TWO per iteration —
+//   R1 [S | rhs | votes] inside solve_step_device (the reduced 14 x 14 system),
+//   R2 after the candidate evaluation: [g.delta, delta^T H delta, y^T D^2 y, candidate cost, step norm^2, x norm^2, error votes | the candidate's joint block].
+// (R1 and R2 cannot merge: the candidate is a function of the reduced system's solution.)  The candidate is evaluated WITH its normal equations: an accepted step — the
+// rule — needs nothing more (the reference's loop evaluates the Jacobian only after acceptance; here acceptance is what a second pass and two more reductions used to
+// follow), a rejected one restores the normal equations of x with one more pass and no reduction (every rank rejects together).
 int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in, lvx_allreduce_fn fn, void* user, lvx_lm_summary* sum) {
   if (!c || !state) return LVX_E_ARG;
   lvx_lm_options o; lvx_lm_default_options(&o); if (opt_in) o = *opt_in;
@@ -1044,37 +1070,46 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
   double* xt = (double*)c->d_state_try.p;
   c->lm_cost.clear(); c->lm_radius.clear(); c->lm_accept.clear();
   lvx_lm_summary s{}; s.termination = LVX_LM_NO_CONVERGENCE;
-  double cost = 0, g0 = 0;
+  double cost = 0; bool gconv = false;
   if (!lerr) { LVX_HIP(c, hipMemcpyAsync(x, state, sbytes, hipMemcpyHostToDevice, st)); lerr = lvx_evaluate_d(c, x, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &cost); }
-  if ((rc = post_eval(c, w, true, o.jacobi_scaling, o.min_lm_diagonal, o.max_lm_diagonal, &cost, &g0, lerr))) return rc;
+  if ((rc = post_eval(c, w, true, o.jacobi_scaling, o.min_lm_diagonal, o.max_lm_diagonal, &cost, o.gradient_tolerance, &gconv, lerr))) return rc;
   s.initial_cost = cost;
   double radius = o.initial_radius, decrease_factor = 2.0;
   int invalid = 0;
   const int N = c->N, L = c->L;
-  if (g0 <= o.gradient_tolerance) { s.termination = LVX_LM_GRADIENT_TOLERANCE; }
+  if (gconv) { s.termination = LVX_LM_GRADIENT_TOLERANCE; }
   int it = 0;
+  int pending = LVX_OK;   // a local failure (restoring the normal equations of x) that has not met a collective yet: voted in the next R1
+  bool acc_is_x = true;   // the accumulators hold the normal equations of x (not of a candidate that was not accepted)
+  // the accumulators hold the candidate's normal equations: put those of x back (no reduction: every rank takes this branch together)
+  auto restore_x = [&]() { double cx = 0; const int re = lvx_evaluate_d(c, x, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &cx); if (re && !pending) pending = re; acc_is_x = true; };
   while (s.termination == LVX_LM_NO_CONVERGENCE) {
     if (it >= o.max_iterations) { s.termination = LVX_LM_MAX_ITERATIONS; break; }
     ++it;
     double m[3]; bool notpd = false;
-    if ((rc = solve_step_device(c, w, radius, m, &notpd, LVX_OK))) return rc;
-    // candidate x (+) delta and its cost; the cost-only evaluation does not touch the normal equations of x
-    double r2[7] = {m[0], m[1], m[2], 0, 0, 0, 0}, h[6] = {0, 0, 0, 0, 0, 0};
+    if ((rc = solve_step_device(c, w, radius, m, &notpd, pending))) return rc;
+    pending = LVX_OK;
+    // candidate x (+) delta: cost AND normal equations (they replace those of x in the accumulators; the model terms of x were taken by solve_step_device)
+    double r2[7 + LVX_JB_N] = {m[0], m[1], m[2], 0, 0, 0, 0}, h[6] = {0, 0, 0, 0, 0, 0};
     lerr = LVX_OK;
+    bool cand_ne = false;
+    EvalLocal ev;
     if (!notpd) {
       LVX_HIP(c, hipMemsetAsync(w.sums + 2, 0, 48, st));
       hipLaunchKernelGGL(k_plus, dim3((unsigned)((N + 1 + L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, N, L, c->locks, xt, w.sums, joint ? 1 : 0, c->sensor_mto);
       double cand = 0;
-      const int re = lvx_evaluate_d(c, xt, LVX_EVAL_COST, &cand);
+      const int re = lvx_evaluate_d(c, xt, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &cand);
+      cand_ne = true; acc_is_x = false;
       if (re == LVX_E_RANGE || re == LVX_E_NONUNIT_QUAT) cand = INFINITY; else if (re) lerr = re;   // a candidate that cannot be evaluated is a rejected step, anything else an error
-      c->last_what |= LVX_EVAL_NORMAL_EQ;
       if (!lerr && hipMemcpy(h, w.sums + 2, 48, hipMemcpyDeviceToHost) != hipSuccess) lerr = LVX_E_HIP;
+      if (!lerr && std::isfinite(cand)) lerr = local_after_eval(c, w, &ev);   // the candidate's diagonal / gradient: used if the step is accepted (w.lmd, the damping of x, stays)
       r2[3] = cand; r2[4] = h[0]; r2[5] = h[1];
     }
     if (joint) {   // private blocks summed over the ranks; the shared blocks (identical on every rank) are counted once below
       r2[6] = lerr ? 1.0 : 0.0;
-      if (lerr) { r2[0] = r2[1] = r2[2] = r2[3] = r2[4] = r2[5] = 0.0; }
-      if ((rc = reduce(c, r2, 7, LVX_REDUCE_SUM))) return rc;
+      if (lerr) { r2[0] = r2[1] = r2[2] = r2[3] = r2[4] = r2[5] = 0.0; for (int i = 0; i < LVX_JB_N; ++i) r2[7 + i] = 0.0; }
+      else joint_block_pack(c, ev, o.gradient_tolerance, r2 + 7);
+      if ((rc = reduce(c, r2, 7 + LVX_JB_N, LVX_REDUCE_SUM))) return rc;
       if ((rc = leave_together(c, r2[6], lerr))) return rc;
       r2[4] += h[4]; r2[5] += h[5];
     } else if (lerr) return lerr;
@@ -1085,6 +1120,7 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
       if (++invalid >= 5) { s.termination = LVX_LM_FAILURE; break; }   // max_num_consecutive_invalid_steps = 5
       radius *= 0.5;
       c->lm_cost.push_back(cost); c->lm_radius.push_back(radius); c->lm_accept.push_back(-1);
+      if (cand_ne) restore_x();
       continue;
     }
     invalid = 0;
@@ -1098,27 +1134,27 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
     const double rho = cost_change / model;
     if (rho > o.min_relative_decrease) {
       std::swap(c->d_state.p, c->d_state_try.p); x = (double*)c->d_state.p; xt = (double*)c->d_state_try.p;
-      cost = cand; s.successful_steps++;
-      double c2 = 0, g = 0;
-      lerr = lvx_evaluate_d(c, x, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &c2);
-      double cj = cost;
-      if ((rc = post_eval(c, w, false, o.jacobi_scaling, o.min_lm_diagonal, o.max_lm_diagonal, joint ? &c2 : &cj, &g, lerr))) return rc;
+      cost = cand; s.successful_steps++; acc_is_x = true;
+      bool gc = false;
+      if ((rc = apply_diag(c, w, false, o.jacobi_scaling, o.min_lm_diagonal, o.max_lm_diagonal, ev, joint ? r2 + 7 : nullptr, o.gradient_tolerance, &gc))) return rc;
       radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3));   // LevenbergMarquardtStrategy::StepAccepted
       radius = std::min(o.max_radius, radius); decrease_factor = 2.0;
       c->lm_cost.push_back(cost); c->lm_radius.push_back(radius); c->lm_accept.push_back(1);
-      if (g <= o.gradient_tolerance) { s.termination = LVX_LM_GRADIENT_TOLERANCE; break; }
+      if (gc) { s.termination = LVX_LM_GRADIENT_TOLERANCE; break; }
     } else {
       radius = radius / decrease_factor; decrease_factor *= 2.0;      // StepRejected (the LM diagonal of x is reused)
       c->lm_cost.push_back(cost); c->lm_radius.push_back(radius); c->lm_accept.push_back(0);
       if (radius < o.min_radius) { s.termination = LVX_LM_MIN_RADIUS; break; }   // Ceres: CONVERGENCE, "minimum trust region radius reached"
+      restore_x();
     }
     if (o.verbose) fprintf(stderr, "[lvx lm] it %3d cost %.9e radius %.3e rho %.3f\n", it, cost, radius, rho);
   }
   s.iterations = it; s.final_cost = cost; s.final_radius = radius;
+  if (!acc_is_x) c->last_what &= ~LVX_EVAL_NORMAL_EQ;   // a tolerance test ended the loop on a candidate that was not applied: its normal equations are not those of the returned state
   LVX_HIP(c, hipMemcpyAsync(state, x, sbytes, hipMemcpyDeviceToHost, st));
   LVX_HIP(c, hipStreamSynchronize(st));
   if (sum) *sum = s;
-  return LVX_OK;
+  return pending ? pending : LVX_OK;
 }
 int lvx_lm_solve(lvx_ctx* c, double* state, const lvx_lm_options* opt_in, lvx_lm_summary* sum) {
   return lvx_lm_solve_shared(c, state, opt_in, nullptr, nullptr, sum);
