@@ -192,6 +192,18 @@ class Oracle:
         return {"pos": pos, "quat": quat, "vel": vel, "acc": acc, "angvel": w}
 
 
+def analytic_pass(o, state, threads=0):
+    """CPU baseline mode (ii): one OpenMP pass over every gyro / accel / surfel / reprojection block with closed-form Jacobians and the block's J^T J / J^T r
+    products (oracle/orc_analytic.cpp).  Returns (blocks, cost)."""
+    state = _d(state)
+    cost, chk = C.c_double(0), C.c_double(0)
+    lib().orc_analytic_pass.restype = C.c_longlong
+    n = lib().orc_analytic_pass(o._h, _p(state), C.c_int(threads), C.byref(cost), C.byref(chk))
+    if n < 0:
+        raise RuntimeError("orc_analytic_pass: residual error code %d" % (-n))
+    return int(n), cost.value
+
+
 POINT_XYZIT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad", "<f4"), ("intensity", "<f4"), ("pad2", "<f4"), ("timestamp", "<f8")])   # pcl_utils.h:39-44
 
 
