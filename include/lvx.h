@@ -254,10 +254,21 @@ typedef struct lvx_scanreg_out {
   int32_t counts[4];
 } lvx_scanreg_out;
 int lvx_scan_register(lvx_ctx* ctx, int n, const lvx_rs_point* pts, int n_rings, float min_range, lvx_scanreg_out* out);
+/* The same for n_sweeps sweeps in ONE call (laserCloudHandler is invoked once per sweep, scanRegistration.cpp:134; sweeps are independent): pts holds the sweeps
+ * back to back, sweep s = pts[sweep_offsets[s] .. sweep_offsets[s + 1]) (sweep_offsets[0] = 0), outs[s] its caller-owned output buffers (capacity = its input count).
+ * One upload, one launch per stage over all sweeps' rings, one download — a single sweep keeps 16 of 256 CUs busy. */
+int lvx_scan_register_batch(lvx_ctx* ctx, int n_sweeps, const int32_t* sweep_offsets, const lvx_rs_point* pts, int n_rings, float min_range, lvx_scanreg_out* outs);
+/* device-resident variant: the points are already on the device (pts_d, sweeps back to back as above); the results STAY on the device inside the context — only the
+ * kept-point count and the four list lengths per sweep come back (n_kept[n_sweeps], counts4[n_sweeps][4]; either may be NULL) — and lvx_scan_register_get downloads
+ * one sweep's arrays on demand (the buffers of `out` that are not NULL). */
+int lvx_scan_register_batch_d(lvx_ctx* ctx, int n_sweeps, const int32_t* sweep_offsets, const lvx_rs_point* pts_d, int n_rings, float min_range, int32_t* n_kept, int32_t* counts4);
+int lvx_scan_register_get(lvx_ctx* ctx, int sweep, lvx_scanreg_out* out);
 /* The published less-flat cloud: pcl::VoxelGrid (leaf_size 0.2 m) over every ring's less-flat points, rings concatenated (scanRegistration.cpp:425-447),
  * for the sweep of the last lvx_scan_register of this context.  out_xyzi4 [max_out][4], ring_counts [n_rings] (may be NULL), *n_out = total
  * (also when larger than max_out).  Points of a voxel are averaged in their input order (pcl's std::sort leaves the order of equal keys open). */
 int lvx_scan_less_flat_downsample(lvx_ctx* ctx, float leaf_size, int max_out, float* out_xyzi4, int32_t* ring_counts, int32_t* n_out);
+/* the same for sweep `sweep` of the context's last lvx_scan_register_batch (sweep 0 = the call above) */
+int lvx_scan_less_flat_downsample_sweep(lvx_ctx* ctx, int sweep, float leaf_size, int max_out, float* out_xyzi4, int32_t* ring_counts, int32_t* n_out);
 
 /* pclomp::VoxelGridCovariance::applyFilter (src/ndt_omp/include/pclomp/voxel_grid_covariance_omp_impl.hpp:49-374): the grid stays on the
  * device inside the context; leaves are numbered in ascending voxel-key order (std::map iteration order of the reference) */

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <array>
 #include <string>
 #include <vector>
 
@@ -138,7 +139,9 @@ struct lvx_ctx {
   // device-resident DataAssociation (lvx_set_scans / lvx_data_association): [0] raw scans, [1] state, [2] map time, [3] map pose, [4] scans in the map frame = map cloud,
   // [5] plane table, [6] flags, [7] SurfelPoint arrays
   lvx::DevBuf d_da[8]; int da_S = 0, da_H = 0, da_W = 0, da_points = 0; std::vector<lvx_surfel_plane> da_planes;
-  int sr_n = 0, sr_rings = 0, sr_m = 0;   // input size, rings and kept points of the last lvx_scan_register (its results stay in d_up[0])
+  // the last lvx_scan_register / lvx_scan_register_batch (its results stay in d_up[0]): sweeps, rings, points, per-sweep input offsets and kept points, byte offsets of
+  // {cloud, lflat_r, scan_start, cnt} inside the scratch buffer
+  int sr_S = 0, sr_rings = 0; long long sr_N = 0; std::vector<int32_t> sr_off; std::vector<int> sr_m; std::array<size_t, 4> sr_batch_off{}; std::array<size_t, 8> sr_lay{}; std::vector<int32_t> sr_counts;   // sr_lay: {cloud, curv, label, sort, pick, lists, scan_start, scan_end}
   struct Voxels {
     float leaf = 0; int min_pts = 0, n_points = 0, n_leaves = 0;
     const void* d_pts = nullptr;   // the cloud of the last build (device; caller- or context-owned), read again by lvx_surfel_extract

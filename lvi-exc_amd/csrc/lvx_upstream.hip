@@ -30,7 +30,18 @@ __device__ __forceinline__ bool sr_keep(const RsPoint& p, float thr) {   // remo
   if (isnan(p.x) || isnan(p.y) || isnan(p.z)) return false;
   return true;
 }
-__global__ void k_sr_count(const RsPoint* pts, int n, int n_rings, float thr, int* ring_count) {   // per-workgroup histogram in LDS: 28.8 k atomics on 16 addresses took 68 us
+// A batch of sweeps on the device (lvx_scan_register_batch; one sweep = a batch of one): the point arrays of all sweeps are concatenated — sweep s owns
+// [off[s], off[s + 1]) of every per-point array and uses SWEEP-LOCAL indices inside it, as the reference's globals do — the per-ring arrays are [S][n_rings][..].
+// Sweeps are independent: every kernel takes the sweep from blockIdx.y, so 64 sweeps are one launch of 64 x 16 ring workgroups instead of 64 launches of 16.
+struct SrBatch {
+  const RsPoint* pts; const int* off; int n_rings; float thr; long long N;
+  float4* cloud; float* curv; int* label; int* sort_ind; int* picked; int* src; int* lists; int* lflat_r;   // [N] each, lists [4][N]
+  int* rc; int* ss; int* se; int* cnt; int* sharp_r; int* lsharp_r; int* flat_r; int* counts; int* err;     // [S][R], cnt [S][R][4], sharp_r [S][R][16], lsharp_r [S][R][128], flat_r [S][R][32], counts [S][4], err [S]
+};
+__device__ __forceinline__ int sr_kept(const SrBatch& B, int s) { int m = 0; for (int r = 0; r < B.n_rings; ++r) m += B.rc[s * B.n_rings + r]; return m; }
+__global__ void k_sr_count(SrBatch B) {   // per-workgroup histogram in LDS: 28.8 k atomics on 16 addresses took 68 us
+  const int s = blockIdx.y, n = B.off[s + 1] - B.off[s], n_rings = B.n_rings;
+  const RsPoint* pts = B.pts + B.off[s]; const float thr = B.thr; int* ring_count = B.rc + s * n_rings;
   __shared__ int h[128];
   for (int t = threadIdx.x; t < 128; t += blockDim.x) h[t] = 0;
   __syncthreads();
@@ -40,7 +51,11 @@ __global__ void k_sr_count(const RsPoint* pts, int n, int n_rings, float thr, in
   for (int t = threadIdx.x; t < 128 && t < n_rings; t += blockDim.x) if (h[t]) atomicAdd(&ring_count[t], h[t]);
 }
 // one workgroup per ring: order-preserving compaction of the ring's points to src[ring_start + k]
-__global__ __launch_bounds__(1024) void k_sr_bucket(const RsPoint* pts, int n, int n_rings, float thr, const int* ring_count, int* src, int* scan_start, int* scan_end) {
+__global__ __launch_bounds__(1024) void k_sr_bucket(SrBatch B) {
+  const int s = blockIdx.y, n = B.off[s + 1] - B.off[s], n_rings = B.n_rings;
+  const RsPoint* pts = B.pts + B.off[s]; const float thr = B.thr; const int* ring_count = B.rc + s * n_rings;
+  int* src = B.src + B.off[s]; int* scan_start = B.ss + s * n_rings; int* scan_end = B.se + s * n_rings;
+  (void)n_rings;
   const int r = blockIdx.x;
   __shared__ int wsum[16];
   __shared__ int base_s;
@@ -68,7 +83,9 @@ __global__ __launch_bounds__(1024) void k_sr_bucket(const RsPoint* pts, int n, i
     __syncthreads();
   }
 }
-__global__ void k_sr_gather(const RsPoint* pts, const int* src, int m, float4* cloud, float* curv, int* label, int* sort_ind, int* picked) {
+__global__ void k_sr_gather(SrBatch B) {
+  const int s = blockIdx.y, o = B.off[s], m = sr_kept(B, s);
+  const RsPoint* pts = B.pts + o; const int* src = B.src + o; float4* cloud = B.cloud + o; float* curv = B.curv + o; int* label = B.label + o; int* sort_ind = B.sort_ind + o; int* picked = B.picked + o;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= m) return;
   const RsPoint p = pts[src[j]];
@@ -77,9 +94,12 @@ __global__ void k_sr_gather(const RsPoint* pts, const int* src, int m, float4* c
   curv[j] = 0.f; label[j] = 0; sort_ind[j] = j; picked[j] = 0;
 }
 // 11-tap curvature, float, reference evaluation order (:295-305); LDS tile with a halo of 5
-__global__ __launch_bounds__(256) void k_sr_curv(const float4* cloud, int m, float* curv) {
+__global__ __launch_bounds__(256) void k_sr_curv(SrBatch B) {
+  const int s = blockIdx.y, o = B.off[s], m = sr_kept(B, s);
+  const float4* cloud = B.cloud + o; float* curv = B.curv + o;
   __shared__ float sx[256 + 10], sy[256 + 10], sz[256 + 10];
   const int i0 = blockIdx.x * 256;
+  if (i0 >= m) return;
   for (int t = threadIdx.x; t < 266; t += 256) {
     const int j = i0 - 5 + t;
     float4 p = make_float4(0, 0, 0, 0);
@@ -263,8 +283,12 @@ __device__ __forceinline__ void sr_classify_ring(const SrView<LDSR>& V, unsigned
     }
   }
 }
-__global__ __launch_bounds__(512) void k_sr_classify(const float4* cloud, const float* curv, const int* scan_start, const int* scan_end, int* label, int* sort_ind,
-                                                    int* picked, int* sharp_r, int* lsharp_r, int* flat_r, int* lflat_r, int* cnt_r, int* err) {
+__global__ __launch_bounds__(512) void k_sr_classify(SrBatch B) {
+  const int sw = blockIdx.y, o = B.off[sw], R = B.n_rings;
+  const float4* cloud = B.cloud + o; const float* curv = B.curv + o; const int* scan_start = B.ss + sw * R; const int* scan_end = B.se + sw * R;
+  int* label = B.label + o; int* sort_ind = B.sort_ind + o; int* picked = B.picked + o;
+  int* sharp_r = B.sharp_r + (size_t)sw * R * 16; int* lsharp_r = B.lsharp_r + (size_t)sw * R * 128; int* flat_r = B.flat_r + (size_t)sw * R * 32; int* lflat_r = B.lflat_r + o;
+  int* cnt_r = B.cnt + (size_t)sw * R * 4; int* err = B.err + sw;
 #define SR_SEC_LDS 1024   // sector capacity of the LDS path: a ring of <= 4096 points has sectors of <= 683
   __shared__ unsigned long long key[6 * SR_SEC_LDS];   // (>= SR_SEC_MAX: the global-memory path sorts one sector at a time in its head)
   __shared__ int cnt[4], wsum[8];
@@ -326,8 +350,11 @@ __global__ __launch_bounds__(512) void k_sr_classify(const float4* cloud, const 
   if (threadIdx.x < 4) cnt_r[r * 4 + threadIdx.x] = cnt[threadIdx.x];
 }
 // ring-major concatenation of the per-ring lists (reference push order)
-__global__ __launch_bounds__(256) void k_sr_compact(int n_rings, const int* scan_start, const int* cnt_r, const int* sharp_r, const int* lsharp_r, const int* flat_r, const int* lflat_r,
-                             int* sharp, int* lsharp, int* flat, int* lflat, int* counts) {   // one workgroup per ring; every workgroup derives its own offsets
+__global__ __launch_bounds__(256) void k_sr_compact(SrBatch B) {   // one workgroup per ring; every workgroup derives its own offsets
+  const int sw = blockIdx.y, o = B.off[sw], n_rings = B.n_rings;
+  const int* scan_start = B.ss + sw * n_rings; const int* cnt_r = B.cnt + (size_t)sw * n_rings * 4;
+  const int* sharp_r = B.sharp_r + (size_t)sw * n_rings * 16; const int* lsharp_r = B.lsharp_r + (size_t)sw * n_rings * 128; const int* flat_r = B.flat_r + (size_t)sw * n_rings * 32; const int* lflat_r = B.lflat_r + o;
+  int* sharp = B.lists + o; int* lsharp = B.lists + B.N + o; int* flat = B.lists + 2 * B.N + o; int* lflat = B.lists + 3 * B.N + o; int* counts = B.counts + 4 * sw;
   __shared__ int off[4];
   const int r = blockIdx.x;
   if (threadIdx.x < 4) {
@@ -973,64 +1000,139 @@ using namespace lvx;
 
 extern "C" {
 
+// Scan registration of a batch of sweeps: six launches (count, bucket, gather, curvature, classify, compact; grid.y = sweep).  No host round trip in between: the
+// kept-point count of a sweep is re-derived from its ring counts inside the kernels, the grids are sized by the input counts.  pts_d != null: the points are already
+// on the device; otherwise pts (host) is uploaded into the scratch buffer.  Results stay in the scratch buffer (d_up[0]); sr_* describe it.
+struct SrLayout { size_t pts, cloud, curv, label, sort, pick, src, lists, lflat, off, rc, ss, se, cnt, sharp, lsharp, flat, counts, err, end; };
+static SrLayout sr_layout(long long N, int S, int n_rings, bool with_pts) {
+  SrLayout L; size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 15) & ~(size_t)15; return at; };
+  const size_t SR = (size_t)S * n_rings;
+  L.pts = take(with_pts ? (size_t)N * 32 : 0); L.cloud = take((size_t)N * 16); L.curv = take((size_t)N * 4); L.label = take((size_t)N * 4); L.sort = take((size_t)N * 4); L.pick = take((size_t)N * 4);
+  L.src = take((size_t)N * 4); L.lists = take((size_t)N * 16); L.lflat = take((size_t)N * 4); L.off = take((size_t)(S + 1) * 4); L.rc = take(SR * 4); L.ss = take(SR * 4); L.se = take(SR * 4);
+  L.cnt = take(SR * 16); L.sharp = take(SR * 64); L.lsharp = take(SR * 512); L.flat = take(SR * 128); L.counts = take((size_t)S * 16); L.err = take((size_t)S * 4); L.end = o + 64;
+  return L;
+}
+static int scan_register_launch(lvx_ctx* c, int S, const int32_t* off_h, const lvx_rs_point* pts_h, const lvx_rs_point* pts_d, int n_rings, float min_range) {
+  hipStream_t st = c->stream;
+  const long long N = off_h[S];
+  int nmax = 0;
+  for (int s = 0; s < S; ++s) nmax = std::max(nmax, off_h[s + 1] - off_h[s]);
+  c->sr_S = 0;
+  if (N == 0) { c->sr_S = S; c->sr_rings = n_rings; c->sr_N = 0; c->sr_off.assign(off_h, off_h + S + 1); c->sr_m.assign(S, 0); c->sr_counts.assign((size_t)S * 4, 0); return LVX_OK; }
+  int rc;
+  const SrLayout L = sr_layout(N, S, n_rings, pts_d == nullptr);
+  if ((rc = dev_alloc(c, c->d_up[0], L.end))) return rc;
+  char* base = (char*)c->d_up[0].p;
+  const size_t SR = (size_t)S * n_rings;
+  SrBatch B;
+  B.pts = pts_d ? (const RsPoint*)pts_d : (const RsPoint*)(base + L.pts); B.off = (const int*)(base + L.off); B.n_rings = n_rings; B.thr = min_range; B.N = N;
+  B.cloud = (float4*)(base + L.cloud); B.curv = (float*)(base + L.curv); B.label = (int*)(base + L.label); B.sort_ind = (int*)(base + L.sort); B.picked = (int*)(base + L.pick); B.src = (int*)(base + L.src);
+  B.lists = (int*)(base + L.lists); B.lflat_r = (int*)(base + L.lflat); B.rc = (int*)(base + L.rc); B.ss = (int*)(base + L.ss); B.se = (int*)(base + L.se); B.cnt = (int*)(base + L.cnt);
+  B.sharp_r = (int*)(base + L.sharp); B.lsharp_r = (int*)(base + L.lsharp); B.flat_r = (int*)(base + L.flat); B.counts = (int*)(base + L.counts); B.err = (int*)(base + L.err);
+  ProfScope ps(c, LVX_KERNEL_UPSTREAM);
+  if (!pts_d) LVX_HIP(c, hipMemcpyAsync(base + L.pts, pts_h, (size_t)N * 32, hipMemcpyHostToDevice, st));
+  LVX_HIP(c, hipMemcpyAsync(base + L.off, off_h, (size_t)(S + 1) * 4, hipMemcpyHostToDevice, st));
+  LVX_HIP(c, hipMemsetAsync(base + L.rc, 0, SR * 4, st));
+  LVX_HIP(c, hipMemsetAsync(base + L.counts, 0, (L.err - L.counts) + (size_t)S * 4, st));   // counts and err are adjacent
+  const unsigned gx = (unsigned)((nmax + 255) / 256);
+  hipLaunchKernelGGL(k_sr_count, dim3(gx, S), dim3(256), 0, st, B);
+  hipLaunchKernelGGL(k_sr_bucket, dim3(n_rings, S), dim3(1024), 0, st, B);
+  hipLaunchKernelGGL(k_sr_gather, dim3(gx, S), dim3(256), 0, st, B);
+  hipLaunchKernelGGL(k_sr_curv, dim3(gx, S), dim3(256), 0, st, B);
+  hipLaunchKernelGGL(k_sr_classify, dim3(n_rings, S), dim3(512), 0, st, B);
+  hipLaunchKernelGGL(k_sr_compact, dim3(n_rings, S), dim3(256), 0, st, B);
+  LVX_HIP(c, hipGetLastError());
+  std::vector<int> hrc(SR), herr(S);
+  c->sr_counts.assign((size_t)S * 4, 0);
+  LVX_HIP(c, hipMemcpyAsync(hrc.data(), B.rc, SR * 4, hipMemcpyDeviceToHost, st));
+  LVX_HIP(c, hipMemcpyAsync(c->sr_counts.data(), B.counts, (size_t)S * 16, hipMemcpyDeviceToHost, st));
+  LVX_HIP(c, hipMemcpyAsync(herr.data(), B.err, (size_t)S * 4, hipMemcpyDeviceToHost, st));
+  LVX_HIP(c, hipStreamSynchronize(st));
+  c->sr_S = S; c->sr_rings = n_rings; c->sr_N = N; c->sr_off.assign(off_h, off_h + S + 1); c->sr_m.assign(S, 0); c->sr_batch_off = {L.cloud, L.lflat, L.ss, L.cnt};
+  c->sr_lay = {L.cloud, L.curv, L.label, L.sort, L.pick, L.lists, L.ss, L.se};
+  for (int s = 0; s < S; ++s) { int m = 0; for (int r = 0; r < n_rings; ++r) m += hrc[(size_t)s * n_rings + r]; c->sr_m[s] = m; }
+  for (int s = 0; s < S; ++s) if (herr[s] & 8) return fail(c, LVX_E_ARG, "scan sector longer than the LDS sort capacity");
+  return LVX_OK;
+}
+// download: everything the caller asked for — concatenated arrays into host staging (one copy per array over all sweeps), then a copy per sweep
+static int scan_register_fetch(lvx_ctx* c, int s0, int S, lvx_scanreg_out* outs) {
+  hipStream_t st = c->stream;
+  const int n_rings = c->sr_rings;
+  const size_t R = (size_t)n_rings;
+  for (int s = 0; s < S; ++s) { outs[s].n = c->sr_m[s0 + s]; for (int k = 0; k < 4; ++k) outs[s].counts[k] = c->sr_counts[(size_t)(s0 + s) * 4 + k]; }
+  if (c->sr_N == 0) return LVX_OK;
+  const size_t lo = (size_t)c->sr_off[s0], hi = (size_t)c->sr_off[s0 + S], n = hi - lo, N = (size_t)c->sr_N;
+  char* base = (char*)c->d_up[0].p;
+  bool want[9] = {false};   // cloud curvature label sort_ind picked | sharp less_sharp flat less_flat
+  bool want_ss = false, want_se = false;
+  for (int s = 0; s < S; ++s) { const lvx_scanreg_out& q = outs[s]; const void* pp[9] = {q.cloud, q.curvature, q.label, q.sort_ind, q.picked, q.sharp, q.less_sharp, q.flat, q.less_flat};
+    for (int k = 0; k < 9; ++k) want[k] = want[k] || pp[k]; want_ss = want_ss || q.scan_start; want_se = want_se || q.scan_end; }
+  std::vector<float> hcloud(want[0] ? n * 4 : 0), hcurv(want[1] ? n : 0);
+  std::vector<int> hint[7], hss(want_ss ? (size_t)S * R : 0), hse(want_se ? (size_t)S * R : 0);
+  const int* lists = (const int*)(base + c->sr_lay[5]);
+  const void* dsrc[9] = {(const float4*)(base + c->sr_lay[0]) + lo, (const float*)(base + c->sr_lay[1]) + lo, (const int*)(base + c->sr_lay[2]) + lo, (const int*)(base + c->sr_lay[3]) + lo,
+                         (const int*)(base + c->sr_lay[4]) + lo, lists + lo, lists + N + lo, lists + 2 * N + lo, lists + 3 * N + lo};
+  if (n > 0) {
+    if (want[0]) LVX_HIP(c, hipMemcpyAsync(hcloud.data(), dsrc[0], n * 16, hipMemcpyDeviceToHost, st));
+    if (want[1]) LVX_HIP(c, hipMemcpyAsync(hcurv.data(), dsrc[1], n * 4, hipMemcpyDeviceToHost, st));
+    for (int k = 2; k < 9; ++k) if (want[k]) { hint[k - 2].resize(n); LVX_HIP(c, hipMemcpyAsync(hint[k - 2].data(), dsrc[k], n * 4, hipMemcpyDeviceToHost, st)); }
+  }
+  if (want_ss) LVX_HIP(c, hipMemcpyAsync(hss.data(), (const int*)(base + c->sr_lay[6]) + (size_t)s0 * R, (size_t)S * R * 4, hipMemcpyDeviceToHost, st));
+  if (want_se) LVX_HIP(c, hipMemcpyAsync(hse.data(), (const int*)(base + c->sr_lay[7]) + (size_t)s0 * R, (size_t)S * R * 4, hipMemcpyDeviceToHost, st));
+  LVX_HIP(c, hipStreamSynchronize(st));
+  for (int s = 0; s < S; ++s) {
+    lvx_scanreg_out& q = outs[s];
+    const size_t o0 = (size_t)c->sr_off[s0 + s] - lo;
+    const int m = q.n;
+    if (q.scan_start) std::memcpy(q.scan_start, &hss[(size_t)s * R], R * 4);
+    if (q.scan_end) std::memcpy(q.scan_end, &hse[(size_t)s * R], R * 4);
+    if (m > 0) {
+      if (q.cloud) std::memcpy(q.cloud, &hcloud[o0 * 4], (size_t)m * 16);
+      if (q.curvature) std::memcpy(q.curvature, &hcurv[o0], (size_t)m * 4);
+      int32_t* ip[3] = {q.label, q.sort_ind, q.picked};
+      for (int k = 0; k < 3; ++k) if (ip[k]) std::memcpy(ip[k], &hint[k][o0], (size_t)m * 4);
+    }
+    int32_t* lp[4] = {q.sharp, q.less_sharp, q.flat, q.less_flat};
+    for (int k = 0; k < 4; ++k) if (lp[k] && q.counts[k] > 0) std::memcpy(lp[k], &hint[3 + k][o0], (size_t)q.counts[k] * 4);
+  }
+  return LVX_OK;
+}
+static int scan_register_batch(lvx_ctx* c, int S, const int32_t* off_h, const lvx_rs_point* pts, int n_rings, float min_range, lvx_scanreg_out* outs) {
+  for (int s = 0; s < S; ++s) { std::memset(outs[s].counts, 0, sizeof(outs[s].counts)); outs[s].n = 0; }
+  int rc = scan_register_launch(c, S, off_h, pts, nullptr, n_rings, min_range);
+  if (rc) return rc;
+  return scan_register_fetch(c, 0, S, outs);
+}
 int lvx_scan_register(lvx_ctx* c, int n, const lvx_rs_point* pts, int n_rings, float min_range, lvx_scanreg_out* out) {
   if (!c || !out || n < 0 || n_rings <= 0 || n_rings > 1024 || (n > 0 && !pts)) return LVX_E_ARG;
   LVX_HIP(c, hipSetDevice(c->device));
-  std::memset(out->counts, 0, sizeof(out->counts));
-  out->n = 0;
-  if (n == 0) return LVX_OK;
-  hipStream_t st = c->stream;
-  int rc;
-  DevBuf& B = c->d_up[0];
-  // layout of the scratch buffer
-  const size_t o_pts = 0, o_cloud = o_pts + (size_t)n * 32, o_curv = o_cloud + (size_t)n * 16, o_label = o_curv + (size_t)n * 4, o_sort = o_label + (size_t)n * 4,
-               o_pick = o_sort + (size_t)n * 4, o_src = o_pick + (size_t)n * 4, o_lists = o_src + (size_t)n * 4, o_lflat_r = o_lists + (size_t)n * 16,
-               o_ring = o_lflat_r + (size_t)n * 4, o_end = o_ring + (size_t)n_rings * (4 + 4 + 4 + 16 + 64 + 512 + 128) + 64;
-  if ((rc = dev_alloc(c, B, o_end))) return rc;
-  char* base = (char*)B.p;
-  RsPoint* d_pts = (RsPoint*)(base + o_pts); float4* d_cloud = (float4*)(base + o_cloud); float* d_curv = (float*)(base + o_curv);
-  int* d_label = (int*)(base + o_label); int* d_sort = (int*)(base + o_sort); int* d_pick = (int*)(base + o_pick); int* d_src = (int*)(base + o_src);
-  int* d_lists = (int*)(base + o_lists); int* d_lflat_r = (int*)(base + o_lflat_r);
-  int* d_rc = (int*)(base + o_ring); int* d_ss = d_rc + n_rings; int* d_se = d_ss + n_rings; int* d_cnt = d_se + n_rings; int* d_sharp_r = d_cnt + 4 * n_rings;
-  int* d_lsharp_r = d_sharp_r + 16 * n_rings; int* d_flat_r = d_lsharp_r + 128 * n_rings; int* d_counts = d_flat_r + 32 * n_rings; int* d_err = d_counts + 4;
-  ProfScope ps(c, LVX_KERNEL_UPSTREAM);
-  LVX_HIP(c, hipMemcpyAsync(d_pts, pts, (size_t)n * 32, hipMemcpyHostToDevice, st));
-  LVX_HIP(c, hipMemsetAsync(d_rc, 0, (size_t)n_rings * 4, st));
-  LVX_HIP(c, hipMemsetAsync(d_counts, 0, 32, st));
-  hipLaunchKernelGGL(k_sr_count, dim3((n + 255) / 256), dim3(256), 0, st, (const RsPoint*)d_pts, n, n_rings, min_range, d_rc);
-  hipLaunchKernelGGL(k_sr_bucket, dim3(n_rings), dim3(1024), 0, st, (const RsPoint*)d_pts, n, n_rings, min_range, (const int*)d_rc, d_src, d_ss, d_se);
-  std::vector<int> hrc(n_rings);
-  LVX_HIP(c, hipMemcpyAsync(hrc.data(), d_rc, (size_t)n_rings * 4, hipMemcpyDeviceToHost, st));
-  LVX_HIP(c, hipStreamSynchronize(st));
-  int m = 0; for (int v : hrc) m += v;
-  out->n = m;
-  c->sr_n = n; c->sr_rings = n_rings; c->sr_m = m;
-  if (m > 0) {
-    hipLaunchKernelGGL(k_sr_gather, dim3((m + 255) / 256), dim3(256), 0, st, (const RsPoint*)d_pts, (const int*)d_src, m, d_cloud, d_curv, d_label, d_sort, d_pick);
-    hipLaunchKernelGGL(k_sr_curv, dim3((m + 255) / 256), dim3(256), 0, st, (const float4*)d_cloud, m, d_curv);
-    hipLaunchKernelGGL(k_sr_classify, dim3(n_rings), dim3(512), 0, st, (const float4*)d_cloud, (const float*)d_curv, (const int*)d_ss, (const int*)d_se, d_label, d_sort, d_pick,
-                       d_sharp_r, d_lsharp_r, d_flat_r, d_lflat_r, d_cnt, d_err);
-    hipLaunchKernelGGL(k_sr_compact, dim3(n_rings), dim3(256), 0, st, n_rings, (const int*)d_ss, (const int*)d_cnt, (const int*)d_sharp_r, (const int*)d_lsharp_r, (const int*)d_flat_r,
-                       (const int*)d_lflat_r, d_lists, d_lists + n, d_lists + 2 * (size_t)n, d_lists + 3 * (size_t)n, d_counts);
-  }
-  LVX_HIP(c, hipGetLastError());
-  int herr = 0;
-  LVX_HIP(c, hipMemcpyAsync(out->counts, d_counts, 16, hipMemcpyDeviceToHost, st));
-  LVX_HIP(c, hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, st));
-  if (out->scan_start) LVX_HIP(c, hipMemcpyAsync(out->scan_start, d_ss, (size_t)n_rings * 4, hipMemcpyDeviceToHost, st));
-  if (out->scan_end) LVX_HIP(c, hipMemcpyAsync(out->scan_end, d_se, (size_t)n_rings * 4, hipMemcpyDeviceToHost, st));
-  if (m > 0) {
-    if (out->cloud) LVX_HIP(c, hipMemcpyAsync(out->cloud, d_cloud, (size_t)m * 16, hipMemcpyDeviceToHost, st));
-    if (out->curvature) LVX_HIP(c, hipMemcpyAsync(out->curvature, d_curv, (size_t)m * 4, hipMemcpyDeviceToHost, st));
-    if (out->label) LVX_HIP(c, hipMemcpyAsync(out->label, d_label, (size_t)m * 4, hipMemcpyDeviceToHost, st));
-    if (out->sort_ind) LVX_HIP(c, hipMemcpyAsync(out->sort_ind, d_sort, (size_t)m * 4, hipMemcpyDeviceToHost, st));
-    if (out->picked) LVX_HIP(c, hipMemcpyAsync(out->picked, d_pick, (size_t)m * 4, hipMemcpyDeviceToHost, st));
-  }
-  LVX_HIP(c, hipStreamSynchronize(st));
-  if (herr & 8) return fail(c, LVX_E_ARG, "scan sector longer than the LDS sort capacity");
-  int* lists[4] = {out->sharp, out->less_sharp, out->flat, out->less_flat};
-  for (int k = 0; k < 4; ++k) if (lists[k] && out->counts[k] > 0) LVX_HIP(c, hipMemcpy(lists[k], d_lists + (size_t)k * n, (size_t)out->counts[k] * 4, hipMemcpyDeviceToHost));
+  const int32_t off[2] = {0, n};
+  return scan_register_batch(c, 1, off, pts, n_rings, min_range, out);
+}
+int lvx_scan_register_batch_d(lvx_ctx* c, int n_sweeps, const int32_t* sweep_offsets, const lvx_rs_point* pts_d, int n_rings, float min_range, int32_t* n_kept, int32_t* counts4) {
+  if (!c || n_sweeps <= 0 || !sweep_offsets || n_rings <= 0 || n_rings > 1024 || sweep_offsets[0] != 0) return LVX_E_ARG;
+  for (int s = 0; s < n_sweeps; ++s) if (sweep_offsets[s + 1] < sweep_offsets[s]) return LVX_E_ARG;
+  if (sweep_offsets[n_sweeps] > 0 && !pts_d) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  int rc = scan_register_launch(c, n_sweeps, sweep_offsets, nullptr, pts_d, n_rings, min_range);
+  if (rc) return rc;
+  for (int s = 0; s < n_sweeps; ++s) { if (n_kept) n_kept[s] = c->sr_m[s]; if (counts4) for (int k = 0; k < 4; ++k) counts4[4 * s + k] = c->sr_counts[(size_t)s * 4 + k]; }
   return LVX_OK;
+}
+int lvx_scan_register_get(lvx_ctx* c, int sweep, lvx_scanreg_out* out) {
+  if (!c || !out) return LVX_E_ARG;
+  if (c->sr_S <= 0) return fail(c, LVX_E_STATE, "lvx_scan_register has not been called");
+  if (sweep < 0 || sweep >= c->sr_S) return fail(c, LVX_E_ARG, "sweep index outside the last batch");
+  LVX_HIP(c, hipSetDevice(c->device));
+  return scan_register_fetch(c, sweep, 1, out);
+}
+int lvx_scan_register_batch(lvx_ctx* c, int n_sweeps, const int32_t* sweep_offsets, const lvx_rs_point* pts, int n_rings, float min_range, lvx_scanreg_out* outs) {
+  if (!c || !outs || n_sweeps <= 0 || !sweep_offsets || n_rings <= 0 || n_rings > 1024 || sweep_offsets[0] != 0) return LVX_E_ARG;
+  for (int s = 0; s < n_sweeps; ++s) if (sweep_offsets[s + 1] < sweep_offsets[s]) return LVX_E_ARG;
+  if (sweep_offsets[n_sweeps] > 0 && !pts) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  return scan_register_batch(c, n_sweeps, sweep_offsets, pts, n_rings, min_range, outs);
 }
 
 // voxel grid kept on the device in the context
@@ -1601,23 +1703,24 @@ int lvx_ndt_derivatives(lvx_ctx* c, int n, const float* input_xyzi4, const float
   return LVX_OK;
 }
 
-int lvx_scan_less_flat_downsample(lvx_ctx* c, float leaf, int max_out, float* out_xyzi4, int32_t* ring_counts, int32_t* n_out) {
+int lvx_scan_less_flat_downsample_sweep(lvx_ctx* c, int sweep, float leaf, int max_out, float* out_xyzi4, int32_t* ring_counts, int32_t* n_out) {
   if (!c || !n_out || !(leaf > 0) || max_out < 0 || (max_out > 0 && !out_xyzi4)) return LVX_E_ARG;
   *n_out = 0;
-  if (c->sr_rings <= 0 || !c->d_up[0].p) return fail(c, LVX_E_STATE, "lvx_scan_register has not been called");
+  if (c->sr_S <= 0 || !c->d_up[0].p) return fail(c, LVX_E_STATE, "lvx_scan_register has not been called");
+  if (sweep < 0 || sweep >= c->sr_S) return fail(c, LVX_E_ARG, "sweep index outside the last batch");
   LVX_HIP(c, hipSetDevice(c->device));
-  const int n = c->sr_n, n_rings = c->sr_rings, m = c->sr_m;
+  const int n_rings = c->sr_rings, m = c->sr_m[sweep];
+  const size_t o0 = (size_t)c->sr_off[sweep];
+  const int n = c->sr_off[sweep + 1] - c->sr_off[sweep];
   if (ring_counts) for (int r = 0; r < n_rings; ++r) ring_counts[r] = 0;
   if (m == 0) return LVX_OK;
-  // same scratch layout as lvx_scan_register
-  const size_t o_cloud = (size_t)n * 32, o_curv = o_cloud + (size_t)n * 16, o_label = o_curv + (size_t)n * 4, o_sort = o_label + (size_t)n * 4, o_pick = o_sort + (size_t)n * 4,
-               o_src = o_pick + (size_t)n * 4, o_lists = o_src + (size_t)n * 4, o_lflat_r = o_lists + (size_t)n * 16, o_ring = o_lflat_r + (size_t)n * 4;
-  char* base = (char*)c->d_up[0].p;
-  const float4* d_cloud = (const float4*)(base + o_cloud); const int* d_lflat_r = (const int*)(base + o_lflat_r);
-  const int* d_rc = (const int*)(base + o_ring); const int* d_ss = d_rc + n_rings; const int* d_cnt = d_ss + 2 * (size_t)n_rings;
+  char* base = (char*)c->d_up[0].p;   // scratch layout of the batch (scan_register_batch)
+  const float4* d_cloud = (const float4*)(base + c->sr_batch_off[0]) + o0; const int* d_lflat_r = (const int*)(base + c->sr_batch_off[1]) + o0;
+  const int* d_ss = (const int*)(base + c->sr_batch_off[2]) + (size_t)sweep * n_rings; const int* d_cnt = (const int*)(base + c->sr_batch_off[3]) + (size_t)sweep * n_rings * 4;
   int rc;
   if ((rc = dev_alloc(c, c->d_up[4], (size_t)n * 16))) return rc;
   if ((rc = dev_alloc(c, c->d_up[5], (size_t)(n_rings + 1) * 4))) return rc;
+  if (c->assoc_map_planes == (const double*)c->d_up[5].p) lvx_surfel_map_release(c);
   int* d_oc = (int*)c->d_up[5].p; int* d_err = d_oc + n_rings;
   LVX_HIP(c, hipMemsetAsync(d_err, 0, 4, c->stream));
   { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
@@ -1637,6 +1740,9 @@ int lvx_scan_less_flat_downsample(lvx_ctx* c, float leaf, int max_out, float* ou
   }
   *n_out = total;
   return LVX_OK;
+}
+int lvx_scan_less_flat_downsample(lvx_ctx* c, float leaf, int max_out, float* out_xyzi4, int32_t* ring_counts, int32_t* n_out) {
+  return lvx_scan_less_flat_downsample_sweep(c, 0, leaf, max_out, out_xyzi4, ring_counts, n_out);
 }
 
 }  // extern "C"

@@ -391,6 +391,66 @@ def scan_register(ctx, pts, n_rings, min_range):
     return out
 
 
+def scan_register_batch(ctx, sweeps, n_rings, min_range, fetch=True):
+    """lvx_scan_register_batch: a list of RS_POINT arrays (one per sweep) in one call; returns one result dict per sweep (as scan_register).  fetch=False: only the
+    counts come back (timing of the device work)."""
+    sweeps = [np.ascontiguousarray(p, dtype=RS_POINT) for p in sweeps]
+    S = len(sweeps)
+    off = np.zeros(S + 1, np.int32)
+    off[1:] = np.cumsum([len(p) for p in sweeps])
+    allp = np.concatenate(sweeps) if S else np.zeros(0, RS_POINT)
+    outs = (ScanRegOut * S)()
+    res = []
+    for s_, p in enumerate(sweeps):
+        cap = max(len(p), 1)
+        o = dict(scan_start=np.zeros(n_rings, np.int32), scan_end=np.zeros(n_rings, np.int32))
+        if fetch:
+            o.update(cloud=np.zeros((cap, 4), np.float32), curvature=np.zeros(cap, np.float32), label=np.zeros(cap, np.int32), sort_ind=np.zeros(cap, np.int32), picked=np.zeros(cap, np.int32),
+                     sharp=np.zeros(cap, np.int32), less_sharp=np.zeros(cap, np.int32), flat=np.zeros(cap, np.int32), less_flat=np.zeros(cap, np.int32))
+        for k in o:
+            setattr(outs[s_], k, o[k].ctypes.data)
+        res.append(o)
+    ctx._ck(ctx._l.lvx_scan_register_batch(ctx._h, C.c_int(S), _p(off), _p(allp), C.c_int(n_rings), C.c_float(min_range), outs))
+    for s_, o in enumerate(res):
+        m = outs[s_].n
+        o["n"] = m
+        o["counts"] = list(outs[s_].counts)
+        if fetch:
+            for k in ("cloud", "curvature", "label", "sort_ind", "picked"):
+                o[k] = o[k][:m]
+            for i, k in enumerate(("sharp", "less_sharp", "flat", "less_flat")):
+                o[k] = o[k][:outs[s_].counts[i]].copy()
+    return res
+
+
+def scan_register_batch_d(ctx, pts_d_ptr, offsets, n_rings, min_range):
+    """lvx_scan_register_batch_d: points resident on the device (pointer), results stay there; returns (n_kept [S], counts [S, 4])."""
+    off = np.ascontiguousarray(offsets, np.int32)
+    S = len(off) - 1
+    nk, cnt = np.zeros(S, np.int32), np.zeros((S, 4), np.int32)
+    ctx._ck(ctx._l.lvx_scan_register_batch_d(ctx._h, C.c_int(S), _p(off), C.c_void_p(pts_d_ptr), C.c_int(n_rings), C.c_float(min_range), _p(nk), _p(cnt)))
+    return nk, cnt
+
+
+def scan_register_get(ctx, sweep, cap, n_rings):
+    """Download one sweep of the context's last scan_register_batch(_d): result dict as scan_register."""
+    cap = max(cap, 1)
+    out = dict(cloud=np.zeros((cap, 4), np.float32), curvature=np.zeros(cap, np.float32), label=np.zeros(cap, np.int32), sort_ind=np.zeros(cap, np.int32),
+               picked=np.zeros(cap, np.int32), scan_start=np.zeros(n_rings, np.int32), scan_end=np.zeros(n_rings, np.int32),
+               sharp=np.zeros(cap, np.int32), less_sharp=np.zeros(cap, np.int32), flat=np.zeros(cap, np.int32), less_flat=np.zeros(cap, np.int32))
+    so = ScanRegOut()
+    for k in out:
+        setattr(so, k, out[k].ctypes.data)
+    ctx._ck(ctx._l.lvx_scan_register_get(ctx._h, C.c_int(sweep), C.byref(so)))
+    m = so.n
+    for k in ("cloud", "curvature", "label", "sort_ind", "picked"):
+        out[k] = out[k][:m]
+    for i, k in enumerate(("sharp", "less_sharp", "flat", "less_flat")):
+        out[k] = out[k][:so.counts[i]].copy()
+    out["n"] = m
+    return out
+
+
 def voxel_build(ctx, xyzi, leaf, min_pts=6, eig_mult=0.01, fetch=True):
     xyzi = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)
     info = VoxelInfo()
@@ -511,12 +571,12 @@ def upstream_bench(ctx, kind, arrays, reps=20):
     return (time.perf_counter() - t0) / reps
 
 
-def scan_less_flat_downsample(ctx, n_rings, max_out, leaf=0.2):
-    """The published less-flat cloud of the context's last scan_register: (xyzi [n][4], per-ring counts)."""
+def scan_less_flat_downsample(ctx, n_rings, max_out, leaf=0.2, sweep=0):
+    """The published less-flat cloud of sweep `sweep` of the context's last scan_register / scan_register_batch: (xyzi [n][4], per-ring counts)."""
     out = np.zeros((max(max_out, 1), 4), np.float32)
     rc = np.zeros(n_rings, np.int32)
     n = C.c_int32(0)
-    ctx._ck(ctx._l.lvx_scan_less_flat_downsample(ctx._h, C.c_float(leaf), C.c_int(max_out), _p(out), _p(rc), C.byref(n)))
+    ctx._ck(ctx._l.lvx_scan_less_flat_downsample_sweep(ctx._h, C.c_int(sweep), C.c_float(leaf), C.c_int(max_out), _p(out), _p(rc), C.byref(n)))
     return out[:min(n.value, max_out)], rc, n.value
 
 

@@ -73,6 +73,41 @@ def test_scan_register_with_curvature_ties_is_bit_exact(ctx, kw, min_tie_sectors
     assert _tie_sectors(ro) >= min_tie_sectors
 
 
+def test_scan_register_batch_equals_sweep_by_sweep(ctx):
+    """lvx_scan_register_batch: sweeps of different sizes in one call — tie-free, with curvature ties, short rings, an EMPTY sweep, one ring only — every sweep's
+    outputs bit-exact against the oracle run on that sweep alone, and the less-flat down-sampling addressable per sweep."""
+    one_ring = synth.make_vlp16_sweep(seed=5, n_az=300); one_ring["ring"][:] = 3
+    sweeps = [synth.make_vlp16_sweep(seed=1), synth.make_vlp16_sweep(seed=7, xyz_quantum=0.01, noise=0.0), synth.make_vlp16_sweep(seed=4, n_az=40), synth.make_vlp16_sweep(seed=3)[:0],
+              one_ring, synth.make_vlp16_sweep(seed=3, n_az=900), synth.make_vlp16_sweep(seed=9, n_az=1200, xyz_quantum=0.004, noise=0.005)]
+    res = lvx.scan_register_batch(ctx, sweeps, 16, 0.3)
+    assert len(res) == len(sweeps)
+    for k, (pts, rg) in enumerate(zip(sweeps, res)):
+        ro = O.scan_register(pts, 16, 0.3)
+        assert rg["n"] == ro["n"], k
+        if len(pts):
+            assert np.array_equal(rg["scan_start"], ro["scan_start"]) and np.array_equal(rg["scan_end"], ro["scan_end"]), k
+        assert np.array_equal(rg["cloud"].view(np.uint32), ro["cloud"].view(np.uint32)) and np.array_equal(rg["curvature"].view(np.uint32), ro["curvature"].view(np.uint32)), k
+        for key in ("label", "picked", "sort_ind", "sharp", "less_sharp", "flat", "less_flat"):
+            assert np.array_equal(rg[key], ro[key]), (k, key)
+    # device-resident variant: points uploaded once by the caller, results stay in the context, one sweep fetched on demand
+    import torch
+    allp = np.concatenate(sweeps)
+    off = np.concatenate([[0], np.cumsum([len(p) for p in sweeps])]).astype(np.int32)
+    pd = torch.from_numpy(allp.view(np.uint8).reshape(-1)).to("cuda")
+    nk, cnt = lvx.scan_register_batch_d(ctx, pd.data_ptr(), off, 16, 0.3)
+    assert list(nk) == [r_["n"] for r_ in res] and [list(c_) for c_ in cnt] == [[len(r_[k]) for k in ("sharp", "less_sharp", "flat", "less_flat")] for r_ in res]
+    for k in (1, 6, 3):
+        rg = lvx.scan_register_get(ctx, k, len(sweeps[k]), 16)
+        for key in ("cloud", "curvature", "label", "picked", "sort_ind", "sharp", "less_sharp", "flat", "less_flat"):
+            assert np.array_equal(rg[key], res[k][key]), (k, key)
+    for k in (0, 5):
+        ro = O.scan_register(sweeps[k], 16, 0.3)
+        lf = ro["less_flat"]
+        want = np.concatenate([O.voxelgrid_xyzi(ro["cloud"][lf[(lf >= ro["scan_start"][r] - 5) & (lf <= ro["scan_end"][r] + 5)]], 0.2) for r in range(16)])
+        got, rc, n = lvx.scan_less_flat_downsample(ctx, 16, len(sweeps[k]), 0.2, sweep=k)
+        assert n == len(want) and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_scan_register_edge_cases(ctx):
     pts = synth.make_vlp16_sweep(seed=4, n_az=40)           # rings too short for 6 sectors of >= 1 point after the +-5 margin
     _check_scanreg(ctx, pts, 16, 0.3)

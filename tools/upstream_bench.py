@@ -31,6 +31,16 @@ if __name__ == "__main__":
     for _ in range(reps):
         lvx.scan_register(ctx, pts, 16, 0.3)
     ts = (time.perf_counter() - t0) / reps
+    tb = {}
+    for S in (1, 16, 64):   # batched scan registration with the points resident on the device: S sweeps per call, results stay on the device (counts come back)
+        sw = [synth.make_vlp16_sweep(seed=1 + (k % 4)) for k in range(S)]
+        off = np.concatenate([[0], np.cumsum([len(p) for p in sw])]).astype(np.int32)
+        pd = torch.from_numpy(np.concatenate(sw).view(np.uint8).reshape(-1)).to("cuda")
+        lvx.scan_register_batch_d(ctx, pd.data_ptr(), off, 16, 0.3)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            lvx.scan_register_batch_d(ctx, pd.data_ptr(), off, 16, 0.3)
+        tb[S] = ((time.perf_counter() - t0) / reps, int(off[-1]))
     # next-row kernels (host buffers in and out: read their kernel durations from the rocprofv3 trace of this script)
     src = cloud[::7].copy()
     lvx.voxel_build(ctx, cloud, 1.0, fetch=False)
@@ -51,5 +61,7 @@ if __name__ == "__main__":
     print("surfel_assoc 64 scans: %.1f us  %.0f Mpts/s" % (1e6 * t64, 64 * n / t64 / 1e6))
     print("voxel_build 100k     : %.1f us  %.0f Mpts/s" % (1e6 * tv, len(cloud) / tv / 1e6))
     print("voxel_lookup7 100k   : %.1f us  %.0f Mq/s" % (1e6 * tl, len(cloud) / tl / 1e6))
-    print("scan_register 28.8k  : %.1f us per sweep (host buffers in and out)" % (1e6 * ts))
+    print("scan_register 28.8k  : %.1f us per sweep (host buffers in and out)  %.1f Mpts/s" % (1e6 * ts, len(pts) / ts / 1e6))
+    for S, (t, npts) in tb.items():
+        print("scan_register_batch_d %2d sweeps: %.1f us per call, %.1f us per sweep (%d points resident on the device, counts back)  %.1f Mpts/s" % (S, 1e6 * t, 1e6 * t / S, npts, npts / t / 1e6))
     ctx.close()
