@@ -352,7 +352,7 @@ __device__ void hub_eval_thread(const DevCommon& cm, double t_map, int want_surf
   Segs sg; KnotRef kh; hubs[s].ok = 0;
   if (!build_segments(sp, s1, 1, &sg)) return;
   if (!seg_lookup(sp, sg, t_map + tau, &kh)) return;
-  if (!pose_eval<true>(sp, kh, &hubs[s].A)) { hubs[s].ok = -RES_NONUNIT; return; }
+  if (!(tl ? pose_eval<true>(sp, kh, &hubs[s].A) : pose_eval<true, true>(sp, kh, &hubs[s].A))) { hubs[s].ok = -RES_NONUNIT; return; }   // a free offset differentiates through the hub's velocity / angular velocity
   hub_matrix(hubs[s].A, hubs[s].M);   // once here instead of by one thread of each of the fold's ~600 workgroups
   hubs[s].ok = 1;
 }
@@ -396,8 +396,11 @@ struct AccelAcc {
   __device__ static int klv(int c) { return c; }
   __device__ static int gcol(int g, int N, int nt) { return 6 * N + g; }
 };
-struct SurfAcc {
-  enum { NK = 24, NG = 12, NR = 1, HUB = 0, KPK = 6, LVO = 0, WS = 2, GL = 16, SKIP_GG = 0, SECONDARY = 0, LB = 64, NCP = 36, USE_PRE = 1, OCC = 2 };   // reverse-mode Jacobian: fits two wavefronts per SIMD with a few spills, and two workgroups per CU hide its latencies
+// TAU (free LiDAR time offset, the reference's opt_time_offset_ stages: trajectory_manager_lvi.cpp:159-165, sensors.h:70-85): one more global column, d r / d tau_L =
+// g_p (v_k - v_0) + g_xi0 w_0 + g_xik w_k — the pose gradients the row already has, contracted with the spline's velocity and body angular velocity at both poses —
+// and padded spans through the generic segment branch.  The locked instantiation is unchanged.
+template <bool TAU> struct SurfAccT {
+  enum { NK = 24, NG = 12 + (TAU ? 1 : 0), NR = 1, HUB = 0, KPK = 6, LVO = 0, WS = 2, GL = 16, SKIP_GG = 0, SECONDARY = 0, LB = 64, NCP = 36 + (TAU ? 1 : 0), USE_PRE = 1, OCC = 2 };   // reverse-mode Jacobian: fits two wavefronts per SIMD with a few spills, and two workgroups per CU hide its latencies
   __device__ static constexpr int jm(int c) { return c; }
   int n; const double* t; const double* pt; const double* rowpl; const int* perm; double t_map, weight, huber;   // rowpl: the row's plane (gathered at layout time: no dependent load)
   // raw inputs of a row, loaded one batch ahead of their use: the HBM latency hides behind the previous batch's assembly
@@ -416,7 +419,7 @@ struct SurfAcc {
         if (hub->ok != 1) return hub->ok < 0 ? RES_NONUNIT : RES_RANGE;   // the hub's own lookup in its segment is the generic path's first lookup
         if (st == 2) return RES_RANGE;
         LVX_KT(aux.pw, 8)
-        return surfel_residual_pseudo<true>(sp, hub->A, segs, cal.lidar, tk, row.p, row.Pi, weight, &key, r, J, aux.pw, &kr);
+        return surfel_residual_pseudo<true, TAU>(sp, hub->A, segs, cal.lidar, tk, row.p, row.Pi, weight, &key, r, J, aux.pw, &kr);
       }
     }
     const double pad = tl ? 0.0 : cm.sensor_mto;
@@ -427,13 +430,14 @@ struct SurfAcc {
     if (hub->ok != 1) return hub->ok < 0 ? RES_NONUNIT : RES_RANGE;
     if (kh.i0 != hub->A.k.i0 || kh.u != hub->A.k.u) return LVX_ERR_FALLBACK;   // merged-segment corner: only the legacy kernel is exact
     LVX_KT(aux.pw, 8)
-    return surfel_residual_pseudo<true>(sp, hub->A, segs, cal.lidar, tk, row.p, row.Pi, weight, &key, r, J, aux.pw);
+    return surfel_residual_pseudo<true, TAU>(sp, hub->A, segs, cal.lidar, tk, row.p, row.Pi, weight, &key, r, J, aux.pw);
   }
   __device__ static int klv(int c) { return c; }
-  __device__ static int gcol(int g, int N, int nt) { return g < 6 ? nt + g : 6 * N + 8 + (g - 6); }
+  __device__ static int gcol(int g, int N, int nt) { return g < 6 ? nt + g : 6 * N + 8 + (g - 6); }   // g = 12 (TAU): 6 N + 14, the LiDAR time offset
 };
-struct CamSurfAcc {
-  enum { NK = 24, NG = 18, NR = 1, HUB = 1, KPK = 6, LVO = 0, WS = 1, GL = 16, SKIP_GG = 0, SECONDARY = 0, LB = 64, NCP = 42, USE_PRE = 1, OCC = 2 };
+using SurfAcc = SurfAccT<false>;
+template <bool TAU> struct CamSurfAccT {
+  enum { NK = 24, NG = 18 + (TAU ? 1 : 0), NR = 1, HUB = 1, KPK = 6, LVO = 0, WS = 1, GL = 16, SKIP_GG = 0, SECONDARY = 0, LB = 64, NCP = 42 + (TAU ? 1 : 0), USE_PRE = 1, OCC = 2 };
   __device__ static constexpr int jm(int c) { return c; }
   int n; const int* lm; const int* plane; const int* perm; const double* planes; const double* lm_uv; const double* lm_t0; double t_map, weight, huber;
   __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared* hub, int si, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
@@ -448,8 +452,8 @@ struct CamSurfAcc {
         if (st == 1) return RES_RANGE;
         if (hub->ok != 1) return hub->ok < 0 ? RES_NONUNIT : RES_RANGE;
         if (st == 2) return RES_RANGE;
-        return camsurf_residual_pseudo<true>(sp, hub->A, segs, cm.cam, cal.cam, cal.lidar, lm_uv[2 * l], lm_uv[2 * l + 1], tk, cal.rho[l],
-                                             load_v3(planes + 3 * (size_t)plane[si]), weight, &key, r, J, aux.pw, &kr);
+        return camsurf_residual_pseudo<true, TAU>(sp, hub->A, segs, cm.cam, cal.cam, cal.lidar, lm_uv[2 * l], lm_uv[2 * l + 1], tk, cal.rho[l],
+                                                  load_v3(planes + 3 * (size_t)plane[si]), weight, &key, r, J, aux.pw, &kr);
       }
     }
     const double pad = tl ? 0.0 : cm.sensor_mto;
@@ -459,12 +463,13 @@ struct CamSurfAcc {
     if (!seg_lookup(sp, segs, t_map + cal.cam.tau, &kh)) return RES_RANGE;
     if (hub->ok != 1) return hub->ok < 0 ? RES_NONUNIT : RES_RANGE;
     if (kh.i0 != hub->A.k.i0 || kh.u != hub->A.k.u) return LVX_ERR_FALLBACK;
-    return camsurf_residual_pseudo<true>(sp, hub->A, segs, cm.cam, cal.cam, cal.lidar, lm_uv[2 * l], lm_uv[2 * l + 1], tk, cal.rho[l],
-                                         load_v3(planes + 3 * (size_t)plane[si]), weight, &key, r, J, aux.pw);
+    return camsurf_residual_pseudo<true, TAU>(sp, hub->A, segs, cm.cam, cal.cam, cal.lidar, lm_uv[2 * l], lm_uv[2 * l + 1], tk, cal.rho[l],
+                                              load_v3(planes + 3 * (size_t)plane[si]), weight, &key, r, J, aux.pw);
   }
   __device__ static int klv(int c) { return c; }
-  __device__ static int gcol(int g, int N, int nt) { return g < 6 ? nt + 6 + g : (g < 12 ? 6 * N + 15 + (g - 6) : 6 * N + 8 + (g - 12)); }
+  __device__ static int gcol(int g, int N, int nt) { return g < 6 ? nt + 6 + g : (g < 12 ? 6 * N + 15 + (g - 6) : (g < 18 ? 6 * N + 8 + (g - 12) : 6 * N + 21)); }   // g = 18 (TAU): the camera time offset
 };
+using CamSurfAcc = CamSurfAccT<false>;
 
 // Rolling-shutter reprojection on the fast path.  k_reproj_jac evaluates residual + Jacobian of every block once and stores the Huber-scaled
 // rows; three assembly kernels read them back, all in ONE row order — sorted by (observation window, reference window, landmark), a window
@@ -1552,7 +1557,7 @@ const SwitchName* switch_table(int* count) {
     {"SYNC_NOFENCE", &Switches::sync_nofence, false}, {"CHUNK_R", &Switches::chunk_r, true}, {"CHUNK_R_IMU", &Switches::chunk_r_imu, true},
     {"CHUNK_R_REP", &Switches::chunk_r_rep, true}, {"CHUNK_ROWS", &Switches::chunk_rows, true}, {"REP_ROWS", &Switches::rep_rows, true},
     {"SOLVER_SEQ", &Switches::solver_seq, false}, {"SOLVER_TIMING", &Switches::solver_timing, false}, {"BCR_ROCSOLVER_POTRF", &Switches::bcr_rocsolver_potrf, false},
-    {"BCR_SYRK", &Switches::bcr_syrk, false}, {"BCR_NO_DINV", &Switches::bcr_no_dinv, false}, {"DETERMINISTIC", &Switches::deterministic, true}, {"CLEAR_ALL", &Switches::clear_all, false}, {"CROSS_DBG", &Switches::cross_dbg, false}, {"LM_SCHUR_SINGLE", &Switches::lm_schur_single, false}, {"IMU_SPLIT", &Switches::imu_split, false}, {"REF_SIDE", &Switches::ref_side, false},
+    {"BCR_SYRK", &Switches::bcr_syrk, false}, {"BCR_NO_DINV", &Switches::bcr_no_dinv, false}, {"TAU_LEGACY", &Switches::tau_legacy, false}, {"DETERMINISTIC", &Switches::deterministic, true}, {"CLEAR_ALL", &Switches::clear_all, false}, {"CROSS_DBG", &Switches::cross_dbg, false}, {"LM_SCHUR_SINGLE", &Switches::lm_schur_single, false}, {"IMU_SPLIT", &Switches::imu_split, false}, {"REF_SIDE", &Switches::ref_side, false},
   };
   *count = (int)(sizeof(tab) / sizeof(tab[0]));
   return tab;
@@ -2134,9 +2139,10 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
   auto enqueue = [&]() -> int {
     int rc = LVX_OK;
     const bool fast = !ctx->force_legacy && !(what & LVX_EVAL_JACOBIAN) && !ctx->sw.force_legacy;
-    // free time offsets need d pose / d t at both evaluations: those problems take the per-segment kernels (TAU variants)
+    // free time offsets need d pose / d t at both evaluations: one more global column in the fused LiDAR / camera-surfel kernels (SurfAccT<true>, CamSurfAccT<true>);
+    // reprojection with a free camera offset still takes the per-segment kernel (ReprojFamT<true>).  LVX_TAU_LEGACY=1: the per-segment TAU kernels for everything
     const bool tauL = !(ctx->locks & LVX_LOCK_LIDAR_TAU), tauC = !(ctx->locks & LVX_LOCK_CAM_TAU);
-    const bool fast_surf = fast && !tauL && ctx->surf.n > 0, fast_cs = fast && !tauC && ctx->cs.n > 0;
+    const bool fast_surf = fast && !(tauL && ctx->sw.tau_legacy) && ctx->surf.n > 0, fast_cs = fast && !(tauC && ctx->sw.tau_legacy) && ctx->cs.n > 0;
     // the control-point-pair table and the shared t_map poses (one thread, ~25 us) depend on the state only: the first blocks of the clear kernel
     const int nblk_tab = fast ? (ctx->N + 255) / 256 : 0, npre = fast ? nblk_tab + ((fast_surf || fast_cs) ? 1 : 0) : 0;
     {   // one launch clears every accumulator of the pass (cost, error flags, and for the normal equations band, gradient, border rows, dense border)
@@ -2276,7 +2282,11 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
       case 2: {
         if (ctx->surf.n > 0) {
           ProfScope ps(ctx, LVX_FAM_SURFEL, s_surf);
-          if (tauL) {
+          if (tauL && fast_surf) {
+            SurfAccT<true> s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const double*)ctx->surf.d_b3.p, (const int*)ctx->surf.d_perm.p,
+                             ctx->t_map, ctx->surf.weight, ctx->surf.huber};
+            LVX_LAUNCH_MFMA(SurfAccT<true>, s, LVX_FAM_SURFEL, s_surf, ctx->fam_row0[3]);
+          } else if (tauL) {
             SurfFamT<true> s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
                              (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
             hipLaunchKernelGGL((k_family<SurfFamT<true>, 1>), grid(s.n), dim3(64), 0, s_surf, s, cm, (const uint16_t*)ctx->d_pairs[3].p, (long long)ctx->fam_row0[3]);
@@ -2349,7 +2359,11 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
       case 4: {
         if (ctx->cs.n > 0) {
           ProfScope ps(ctx, LVX_FAM_CAMSURF, s_surf);
-          if (tauC) {
+          if (tauC && fast_cs) {
+            CamSurfAccT<true> c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
+                                (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
+            LVX_LAUNCH_MFMA(CamSurfAccT<true>, c, LVX_FAM_CAMSURF, s_surf, ctx->fam_row0[5]);
+          } else if (tauC) {
             CamSurfFamT<true> c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
                                 (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
             hipLaunchKernelGGL((k_family<CamSurfFamT<true>, 1>), grid(c.n), dim3(64), 0, s_surf, c, cm, (const uint16_t*)ctx->d_pairs[5].p, (long long)ctx->fam_row0[5]);

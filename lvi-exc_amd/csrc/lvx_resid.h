@@ -368,9 +368,26 @@ LVX_HD void pose_pull_to_knots(const PoseVal& e, const So3Pre* pre, v3 gpos, v3 
   }
 }
 
-template <bool PRE = false>
+// time derivative of the pose at a knot reference — world velocity and body angular velocity — for the fused kernels' time-offset column (the value path above
+// carries no derivative): the R3 velocity basis and one more pass through the SO3 chain without Jacobians
+template <bool PRE>
+LVX_HD int pose_twist(const SplineRef& sp, const KnotRef& k, const So3Pre* pre, v3* v, v3* w_body) {
+  R3Basis b; r3_basis(k.u, sp.dt, &b);
+  v3 vv = mk(0, 0, 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) vv = vv + b.Bv[j] * load_v3(sp.r3 + 3 * (k.i0 + j));
+  *v = vv;
+  quat c[4]; load_so3_cp(sp, k.i0, c);
+  So3Eval e;
+  if (PRE) { const int bad = so3_eval_pre<true, false, false>(c, pre, k.u, sp.dt, &e); if (bad) return bad; }
+  else if (!so3_eval<true, false, false>(c, k.u, sp.dt, &e)) return 1;
+  *w_body = e.w_body;
+  return 0;
+}
+// TAU: one more column, J[0][SURFP_NC] = d r / d tau_lidar — both poses move with the offset (plane_tau_jac); the hub must carry v and w_body (pose_eval<.., NEED_V>)
+template <bool PRE = false, bool TAU = false>
 LVX_HD int surfel_residual_pseudo(const SplineRef& sp, const PoseEval& hub, const Segs& segs, const SensorCal& lidar, double t_k, v3 p_L, v3 Pi,
-                                  double weight, int* i0_k, double r[1], double J[1][SURFP_NC], const PreWin* pw = nullptr, const KnotRef* kr_in = nullptr) {
+                                  double weight, int* i0_k, double r[1], double J[1][SURFP_NC + (TAU ? 1 : 0)], const PreWin* pw = nullptr, const KnotRef* kr_in = nullptr) {
   KnotRef kr;
   if (kr_in) kr = *kr_in;   // the caller has done the lookup (two_point_lookup)
   else if (!seg_lookup(sp, segs, t_k + lidar.tau, &kr)) return RES_RANGE;
@@ -395,6 +412,12 @@ LVX_HD int surfel_residual_pseudo(const SplineRef& sp, const PoseEval& hub, cons
   const v3 jq = (2.0 * weight) * (cross(pc.nL, pc.x) - cross(pc.m, pLr));
   const v3 jp = weight * (pc.m - pc.nL);
   J[0][30] = jq.x; J[0][31] = jq.y; J[0][32] = jq.z; J[0][33] = jp.x; J[0][34] = jp.y; J[0][35] = jp.z;
+  if (TAU) {
+    v3 vk, wk;
+    const int bad = pose_twist<PRE>(sp, kr, pre, &vk, &wk);
+    if (bad) return (bad & 1) ? RES_NONUNIT : RES_OUTSIDE;
+    J[0][SURFP_NC] = dot(g.gp, vk - hub.v) + dot(g.gx0, hub.so3.w_body) + dot(g.gxk, wk);
+  }
   return RES_OK;
 }
 // M_hub (6 x 24): pseudo pose perturbation (d p_0, xi_0) per unit tangent of the 4 hub control points
@@ -580,9 +603,10 @@ LVX_HD int camsurf_residual(const SplineRef& sp, const PoseEval& hub, const Segs
 
 // pseudo-hub variant: local columns [k knot j: 6j.. (24) | g0 24..29 | cam theta 30..32 | cam p 33..35 | lidar theta 36..38 | lidar p 39..41]
 enum { CSP_NC = 42 };
-template <bool PRE = false>
+// TAU: one more column, J[0][CSP_NC] = d r / d tau_cam (the hub and the landmark's reference pose both move with it)
+template <bool PRE = false, bool TAU = false>
 LVX_HD int camsurf_residual_pseudo(const SplineRef& sp, const PoseEval& hub, const Segs& segs, const CamIntr& ci, const SensorCal& cam, const SensorCal& lidar,
-                                   double u_ref, double v_ref, double t0_ref, double rho, v3 Pi, double weight, int* i0_k, double r[1], double J[1][CSP_NC], const PreWin* pw = nullptr,
+                                   double u_ref, double v_ref, double t0_ref, double rho, v3 Pi, double weight, int* i0_k, double r[1], double J[1][CSP_NC + (TAU ? 1 : 0)], const PreWin* pw = nullptr,
                                    const KnotRef* kr_in = nullptr) {
   KnotRef kr;
   if (kr_in) kr = *kr_in;   // the caller has done the lookup (two_point_lookup)
@@ -610,6 +634,12 @@ LVX_HD int camsurf_residual_pseudo(const SplineRef& sp, const PoseEval& hub, con
   const v3 jlp = (-weight) * pc.nL;
   J[0][30] = jcq.x; J[0][31] = jcq.y; J[0][32] = jcq.z; J[0][33] = jcp.x; J[0][34] = jcp.y; J[0][35] = jcp.z;
   J[0][36] = jlq.x; J[0][37] = jlq.y; J[0][38] = jlq.z; J[0][39] = jlp.x; J[0][40] = jlp.y; J[0][41] = jlp.z;
+  if (TAU) {
+    v3 vk, wk;
+    const int bad = pose_twist<PRE>(sp, kr, pre, &vk, &wk);
+    if (bad) return (bad & 1) ? RES_NONUNIT : RES_OUTSIDE;
+    J[0][CSP_NC] = dot(g.gp, vk - hub.v) + dot(g.gx0, hub.so3.w_body) + dot(g.gxk, wk);
+  }
   return RES_OK;
 }
 
