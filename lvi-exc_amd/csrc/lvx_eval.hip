@@ -482,11 +482,13 @@ using CamSurfAcc = CamSurfAccT<false>;
 // With ORB-like tracks (>= 100 observations per frame, co-visible frame pairs) a group holds tens of blocks and the cross terms cost
 // ~1.8 k atomics per group instead of 576 per block; with one block per frame pair it degenerates to the per-block scatter (576 + 56 atomics
 // per block, bound by the atomic rate: a CU retires one FP64 atomic lane every ~3.75 cycles, tools/probes/atomic_bw.hip).
-struct RepJac { const double* J; const double* r; const int* k; int n; };   // k_reproj_jac output: J[(a * REP_NC + c) * n + i], r[a * n + i], k[i] = ref interval, k[n + i] = obs interval (-1: skipped)
-template <int SIDE> struct RepSideAcc {   // SIDE 0: the reference view's pose, 1: the observation's
+struct RepJac { const double* J; const double* r; const int* k; int n; };   // k_reproj_jac output: J[(a * RJ + c) * n + i] with RJ = REP_NC (+ 1: the camera time-offset column 55 when it is free), r[a * n + i], k[i] = ref interval, k[n + i] = obs interval (-1: skipped)
+// TAU: the camera time offset is free — one more global column (the row's column 55, tangent 6 N + 21) rides with the camera block
+template <int SIDE, bool TAU = false> struct RepSideAcc {   // SIDE 0: the reference view's pose, 1: the observation's
   enum { PMAJ = 1 };
-  enum { NK = 24, NG = 6, NR = 2, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 16, SKIP_GG = SIDE, SECONDARY = 1, LB = 16, NCP = 31, USE_PRE = 0, FTAB = 0, OCC = 1 };
+  enum { NK = 24, NG = 6 + (TAU ? 1 : 0), NR = 2, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 16, SKIP_GG = SIDE, SECONDARY = 1, LB = 16, NCP = 31 + (TAU ? 1 : 0), USE_PRE = 0, FTAB = 0, OCC = 1 };
   __device__ static constexpr int jm(int c) { return c; }   // [knots of this side | camera]
+  static constexpr int RJ = REP_NC + (TAU ? 1 : 0);
   int n; RepJac jac;
   double huber;
   __device__ int eval(const DevCommon&, const SplineRef&, const Cal&, const HubShared*, int si, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
@@ -497,19 +499,22 @@ template <int SIDE> struct RepSideAcc {   // SIDE 0: the reference view's pose, 
     for (int a = 0; a < 2; ++a) {
       r[a] = jac.r[(size_t)a * jac.n + si];
 #pragma unroll
-      for (int c = 0; c < 24; ++c) J[a][c] = jac.J[(size_t)(a * REP_NC + 24 * SIDE + c) * jac.n + si];
+      for (int c = 0; c < 24; ++c) J[a][c] = jac.J[(size_t)(a * RJ + 24 * SIDE + c) * jac.n + si];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) J[a][24 + c] = jac.J[(size_t)(a * REP_NC + 48 + c) * jac.n + si];
+      for (int c = 0; c < 6; ++c) J[a][24 + c] = jac.J[(size_t)(a * RJ + 48 + c) * jac.n + si];
+      if (TAU) J[a][30] = jac.J[(size_t)(a * RJ + 55) * jac.n + si];
     }
     return RES_OK;
   }
-  __device__ static int gcol(int g, int N, int nt) { return 6 * N + 15 + g; }
+  __device__ static int gcol(int g, int N, int nt) { return 6 * N + 15 + g; }   // g = 6 (TAU): 6 N + 21
 };
 
 // Reprojection phase 1 on its own: residual + Jacobian of every block (observation order), Huber-scaled, to HBM (0.9 KB per block);
 // cost and residual output happen here.  The two-pose rolling-shutter residual needs > 512 registers when it shares a kernel with the
 // assembly, so the MFMA passes read the rows back instead (2 x 45 MB at config 4, nothing against their atomics).
-__global__ __launch_bounds__(64) void k_reproj_jac(ReprojFam fam, DevCommon cm, double* Jb, double* rb, int* kb, long long row0) {
+template <bool TAU>
+__global__ __launch_bounds__(64) void k_reproj_jac(ReprojFamT<TAU> fam, DevCommon cm, double* Jb, double* rb, int* kb, long long row0) {
+  constexpr int RJ = REP_NC + (TAU ? 1 : 0);
   const int lane = threadIdx.x, si = blockIdx.x * 64 + lane, n = fam.n;
   const int rep = blockIdx.x % cm.nrep;
   double mycost = 0.0;
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(64) void k_reproj_jac(ReprojFam fam, DevCommon cm, 
     const SplineRef sp{cm.t0, cm.dt, cm.N, cm.state, cm.state + 3 * (size_t)cm.N};
     const Cal cal = load_cal(cm);
     HubShared none;
-    double r[2], J[2][REP_NC];
+    double r[2], J[2][RJ];
     Keys key{-1, -1, -1};
     const int status = fam.eval_pre(cm, sp, cal, si, r, J, key);
     if (status != RES_OK) { atomicOr(cm.err, status); kb[si] = -1; kb[n + si] = -1; }
@@ -531,7 +536,7 @@ __global__ __launch_bounds__(64) void k_reproj_jac(ReprojFam fam, DevCommon cm, 
         for (int a = 0; a < 2; ++a) {
           rb[(size_t)a * n + si] = r[a] * scale;
 #pragma unroll
-          for (int c = 0; c < REP_NC; ++c) Jb[(size_t)(a * REP_NC + c) * n + si] = J[a][c] * scale;
+          for (int c = 0; c < RJ; ++c) Jb[(size_t)(a * RJ + c) * n + si] = J[a][c] * scale;
         }
       }
     }
@@ -547,10 +552,17 @@ __global__ __launch_bounds__(64) void k_reproj_jac(ReprojFam fam, DevCommon cm, 
 // The landmark's own row (rho x everything, 56 entries per block) is formed from the same registers with one lane exchange.
 typedef double d4 __attribute__((ext_vector_type(4)));
 struct RepCross { RepJac jac; const int* lm; const int* goff; const int* gw; int ng; int dbg; double* T; const int* det_list; };   // det_list: deterministic mode — block b works on group det_list[b] alone   // T[i][56]: the landmark-row products of block i (k_reproj_lmrows)   // gw[g] = w0, gw[ng + g] = w1
+// TAU (free camera time offset): rows of RJ = 56 entries, landmark records of RW = 57 (rho x tau last).
+// STRAYS.  The groups are fixed at layout time from the view times at tau = 0; with a non-zero offset (free, or locked at a non-zero value) a view within |tau| of a knot
+// lands in the neighbouring interval and — one row in ~80 at the 1 ms bound — outside its 4-interval window.  Such a block stays out of the group's panels and adds
+// its 24 x 24 cross products one by one (576 atomics; rare), so the pass never has to fall back to the per-segment kernels for it.
+template <bool TAU>
 __global__ __launch_bounds__(256) void k_reproj_cross(RepCross rc, DevCommon cm) {
   constexpr int LDP = 49, BR = 16;   // panel: 16 rows (8 blocks x 2 residual rows) x 48 columns, odd stride
+  constexpr int RJ = REP_NC + (TAU ? 1 : 0), RW = 56 + (TAU ? 1 : 0);
   __shared__ double pan[4][2][BR * LDP];
-  __shared__ double tbuf[4][8 * 56];
+  __shared__ double tbuf[4][8 * RW];
+  __shared__ double sbuf[4][2][48];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int rep = blockIdx.x % cm.nrep;
   if (rc.det_list && wv != 0) return;   // (the kernel has wavefront barriers only)
@@ -569,15 +581,16 @@ __global__ __launch_bounds__(256) void k_reproj_cross(RepCross rc, DevCommon cm)
       const int i = base + b;
       const bool in = i < m1;
       const int k0 = in ? rc.jac.k[i] : -1, k1 = in ? rc.jac.k[(size_t)n + i] : -1;
-      bool valid = in && k1 >= 0;
+      const bool live = in && k1 >= 0;
       const int o0 = k0 - 4 * w0, o1 = k1 - 4 * w1;
-      if (valid && (o0 < 0 || o0 > 3 || o1 < 0 || o1 > 3)) { valid = false; atomicOr(cm.err, LVX_ERR_FALLBACK); }   // a locked camera time offset moved the row out of its window
+      const bool stray = live && (o0 < 0 || o0 > 3 || o1 < 0 || o1 > 3);   // the camera time offset moved a view out of its window
+      const bool valid = live && !stray;
       double v[12], jr = 0.0;
-      if (valid) {
-        const double* src = rc.jac.J + (size_t)(a * REP_NC + 24 * side + 12 * h) * n + i;
+      if (live) {
+        const double* src = rc.jac.J + (size_t)(a * RJ + 24 * side + 12 * h) * n + i;
 #pragma unroll
         for (int c = 0; c < 12; ++c) v[c] = src[(size_t)c * n];
-        jr = rc.jac.J[(size_t)(a * REP_NC + 54) * n + i];
+        jr = rc.jac.J[(size_t)(a * RJ + 54) * n + i];
       } else {
 #pragma unroll
         for (int c = 0; c < 12; ++c) v[c] = 0.0;
@@ -612,12 +625,12 @@ __global__ __launch_bounds__(256) void k_reproj_cross(RepCross rc, DevCommon cm)
         double t[12];
 #pragma unroll
         for (int c = 0; c < 12; ++c) { t[c] = jr * v[c]; t[c] += __shfl_xor(t[c], 2); }
-        double* tb = tbuf[wv] + b * 56;
+        double* tb = tbuf[wv] + b * RW;
         if (a == 0) {
 #pragma unroll
           for (int c = 0; c < 12; ++c) tb[24 * side + 12 * h + c] = t[c];
-        } else if (valid) {
-          const double* J0 = rc.jac.J + i; const double* J1 = rc.jac.J + (size_t)REP_NC * n + i;
+        } else if (live) {
+          const double* J0 = rc.jac.J + i; const double* J1 = rc.jac.J + (size_t)RJ * n + i;
           const double r0 = J0[(size_t)54 * n], r1 = J1[(size_t)54 * n];
           if (side == 0) {
 #pragma unroll
@@ -625,14 +638,41 @@ __global__ __launch_bounds__(256) void k_reproj_cross(RepCross rc, DevCommon cm)
           } else if (h == 0) {
             tb[54] = r0 * r0 + r1 * r1;
             tb[55] = r0 * rc.jac.r[i] + r1 * rc.jac.r[(size_t)n + i];
-          }
+          } else if (TAU) tb[56] = r0 * J0[(size_t)55 * n] + r1 * J1[(size_t)55 * n];
         } else if (side == 0) { tb[48 + 3 * h] = 0.0; tb[49 + 3 * h] = 0.0; tb[50 + 3 * h] = 0.0; }
         else if (h == 0) { tb[54] = 0.0; tb[55] = 0.0; }
+        else if (TAU) tb[56] = 0.0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int nblk8 = min(8, m1 - base);
-        for (int e2 = lane; e2 < nblk8 * 56; e2 += 64) rc.T[(size_t)base * 56 + e2] = tbuf[wv][e2];   // records of consecutive blocks are contiguous
+        for (int e2 = lane; e2 < nblk8 * RW; e2 += 64) rc.T[(size_t)base * RW + e2] = tbuf[wv][e2];   // records of consecutive blocks are contiguous
+      }
+      {   // strays: the 24 x 24 cross block of each, entry by entry
+        unsigned long long sm = __ballot(stray && part == 0);
+        while (sm) {
+          const int sl = __ffsll((long long)sm) - 1; sm &= sm - 1;
+          const int sb = sl >> 3;
+          const int sk0 = __shfl(k0, sl), sk1 = __shfl(k1, sl);
+          __builtin_amdgcn_wave_barrier();
+          if (b == sb) {
+#pragma unroll
+            for (int c = 0; c < 12; ++c) sbuf[wv][a][24 * side + 12 * h + c] = v[c];
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          if (!(rc.dbg & 2)) for (int e2 = lane; e2 < 576; e2 += 64) {
+            const int x = e2 / 24, y = e2 % 24;
+            const double val = sbuf[wv][0][x] * sbuf[wv][0][24 + y] + sbuf[wv][1][x] * sbuf[wv][1][24 + y];
+            if (val == 0.0) continue;
+            const int pa = cm.ord[6 * (sk0 + x / 6) + x % 6], pb = cm.ord[6 * (sk1 + y / 6) + y % 6];
+            if (pa == LVX_DEAD || pb == LVX_DEAD) continue;
+            add_H(cm, pa, pb, pa == pb ? 2.0 * val : val, rep);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -664,7 +704,9 @@ __global__ __launch_bounds__(256) void k_reproj_cross(RepCross rc, DevCommon cm)
 // Landmark rows from the per-block records of k_reproj_cross: a wavefront OWNS landmark l — it sums the records of the landmark's blocks into
 // an LDS image of the row [band couplings | border couplings | H_ll | g_l] and stores the whole row (no atomics, nothing to clear beforehand).
 struct RepLmRows { const double* T; const int* k; int n; const int* ptr; const int* rows; int L; };   // blocks of landmark l: rows[ptr[l] .. ptr[l + 1])
+template <bool TAU>
 __global__ __launch_bounds__(256) void k_reproj_lmrows(RepLmRows q, DevCommon cm) {
+  constexpr int RW = 56 + (TAU ? 1 : 0);   // record: [ref knots 24 | obs knots 24 | camera 6 | H_ll | g_l (| camera time offset)]
   extern __shared__ double rowbuf[];   // 4 x [lm_ls]
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l = blockIdx.x * 4 + wv;
@@ -679,13 +721,13 @@ __global__ __launch_bounds__(256) void k_reproj_lmrows(RepLmRows q, DevCommon cm
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       val[u] = 0.0; pc[u] = LVX_DEAD;
-      if (jb + u < j1 && lane < 56) {
+      if (jb + u < j1 && lane < RW) {
         const int i = q.rows[jb + u];
         const int kr = q.k[i], ko = q.k[(size_t)q.n + i];
         if (ko >= 0) {
-          val[u] = q.T[(size_t)i * 56 + lane];
+          val[u] = q.T[(size_t)i * RW + lane];
           const int c = lane < 24 ? lane : lane - 24;
-          pc[u] = lane < 48 ? cm.ord[6 * ((lane < 24 ? kr : ko) + c / 6) + c % 6] : (lane < 54 ? cm.ord[6 * N + 15 + (lane - 48)] : LVX_LM_BASE);   // 54: H_ll, 55: g_l
+          pc[u] = lane < 48 ? cm.ord[6 * ((lane < 24 ? kr : ko) + c / 6) + c % 6] : (lane < 54 ? cm.ord[6 * N + 15 + (lane - 48)] : (lane < 56 ? LVX_LM_BASE : cm.ord[6 * N + 21]));   // 54: H_ll, 55: g_l, 56: camera time offset
         }
       }
     }
@@ -693,7 +735,7 @@ __global__ __launch_bounds__(256) void k_reproj_lmrows(RepLmRows q, DevCommon cm
     for (int u = 0; u < 4; ++u) {
       if (pc[u] == LVX_DEAD || val[u] == 0.0) continue;
       int slot;
-      if (lane >= 54) slot = cm.lm_wl + cm.nbd + (lane - 54);
+      if (lane == 54 || lane == 55) slot = cm.lm_wl + cm.nbd + (lane - 54);
       else if (pc[u] >= 0) { slot = pc[u] - p0; if (slot < 0 || slot >= cm.lm_wl) { atomicOr(cm.err, 4); continue; } }
       else slot = cm.lm_wl + (-1 - pc[u]);
       atomicAdd(&rb[slot], val[u]);   // LDS: the same variable can appear through both poses of a block
@@ -1844,9 +1886,9 @@ int ensure_layout(lvx_ctx* ctx) {
     if ((rc = upload_tmp(ctx, f.d_a3, uv.data(), uv.size() * 8))) return rc;
     if ((rc = upload_tmp(ctx, f.d_id0, lm.data(), lm.size() * 4))) return rc;
     if ((rc = upload_tmp(ctx, f.d_perm, perm.data(), perm.size() * 4))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->d_repB[0], (size_t)std::max(f.n, 1) * (2 * REP_NC + 2) * 8))) return rc;   // materialised Jacobians + residuals
+    if ((rc = dev_alloc(ctx, ctx->d_repB[0], (size_t)std::max(f.n, 1) * (2 * (REP_NC + 1) + 2) * 8))) return rc;   // materialised Jacobians (+ the time-offset column) + residuals
     if ((rc = dev_alloc(ctx, ctx->d_repB[1], (size_t)std::max(f.n, 1) * 2 * 4))) return rc;                    // knot intervals
-    if ((rc = dev_alloc(ctx, ctx->d_repT, (size_t)std::max(f.n, 1) * 56 * 8))) return rc;                      // landmark-row records
+    if ((rc = dev_alloc(ctx, ctx->d_repT, (size_t)std::max(f.n, 1) * 57 * 8))) return rc;                      // landmark-row records
   }
   {
     Family& f = ctx->cs;
@@ -2169,7 +2211,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
           b0 = b1;
         }
         add(cm.C, (size_t)ctx->nrep * ctx->nbd_ext * ctx->nbd_ext * 8); add(cm.gc, (size_t)ctx->nrep * ctx->nbd_ext * 8);
-        const bool rep_fast = fast && !(!(ctx->locks & LVX_LOCK_CAM_TAU)) && !ctx->sw.reproj_legacy && ctx->rep_groups > 0;   // k_reproj_lmrows stores whole rows: nothing to clear
+        const bool rep_fast = fast && !(tauC && ctx->sw.tau_legacy) && !ctx->sw.reproj_legacy && ctx->rep_groups > 0;   // k_reproj_lmrows stores whole rows: nothing to clear
         if (ctx->L > 0 && ctx->rep.n > 0 && !(ctx->locks & LVX_LOCK_LANDMARKS) && !rep_fast) add(cm.lmH, (size_t)ctx->L * ctx->lm_ls * 8);
       }
       size_t total = 0; for (int i = 0; i < cl.n; ++i) total += cl.words[i];
@@ -2205,6 +2247,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     const int occ_env = sw.occ;   // 0: the family's own choice (F::OCC wavefronts per SIMD)
     const bool imu_fused_on = fast && !sw.imu_legacy && ctx->imu.n > 0 && !(ctx->locks & LVX_LOCK_R3) && !sw.imu_split && !ctx->chunk_var[LVX_FAM_GYRO] && imu_fused_lds_bytes(ctx->chunk_r[LVX_FAM_GYRO]) <= 160 * 1024;
     const bool ref_side = sw.ref_side == 1 || (sw.ref_side < 0 && imu_fused_on);   // with the fused IMU kernel the side stream is the shorter chain: it takes the reference pass
+  #define LVX_T2(...) __VA_ARGS__
   #define LVX_LAUNCH_MFMA1(FT, OCCV, fam_obj, chunk_slot, stream, row0v)                                                                        \
     do {                                                                                                                                     \
       const size_t lds_ = mfma_lds_bytes<FT>(ctx->chunk_r[chunk_slot]);                                                                      \
@@ -2305,14 +2348,14 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
         if (ctx->rep.n > 0) {
           ReprojFam r{ctx->rep.n, (const int*)ctx->rep.d_id0.p, (const double*)ctx->rep.d_a3.p, (const double*)ctx->rep.d_t.p, (const int*)ctx->rep.d_perm.p,
                       (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->rep.weight, ctx->rep.huber};
-          if (tauC) {
-            ProfScope ps(ctx, LVX_FAM_REPROJ, s_rep);
-            ReprojFamT<true> rt{r.n, r.lm, r.uv, r.t0o, r.perm, r.lm_uv, r.lm_t0, r.weight, r.huber};
-            hipLaunchKernelGGL((k_family<ReprojFamT<true>, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, rt, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
-          } else if (fast && !sw.reproj_legacy) {
-            double* Jb = (double*)ctx->d_repB[0].p; double* rb = Jb + (size_t)2 * REP_NC * r.n; int* kb = (int*)ctx->d_repB[1].p;
+          // the fused path (Jacobian rows materialised once, three MFMA assembly passes, landmark rows stored) for a locked AND for a free camera time offset
+          auto rep_fused = [&](auto TAUC) -> int {
+            constexpr bool T = decltype(TAUC)::value;
+            constexpr int RJ = REP_NC + (T ? 1 : 0);
+            double* Jb = (double*)ctx->d_repB[0].p; double* rb = Jb + (size_t)2 * RJ * r.n; int* kb = (int*)ctx->d_repB[1].p;
             { ProfScope ps(ctx, LVX_KERNEL_REP_JAC, s_rep);
-              hipLaunchKernelGGL(k_reproj_jac, grid(r.n), dim3(64), 0, s_rep, r, cm, Jb, rb, kb, (long long)ctx->fam_row0[4]); }
+              const ReprojFamT<T> rf{r.n, r.lm, r.uv, r.t0o, r.perm, r.lm_uv, r.lm_t0, r.weight, r.huber};
+              hipLaunchKernelGGL(k_reproj_jac<T>, grid(r.n), dim3(64), 0, s_rep, rf, cm, Jb, rb, kb, (long long)ctx->fam_row0[4]); }
             if (staged && jac_early && s_rep != s_surf) LVX_HIP(ctx, hipStreamWaitEvent(s_rep, ctx->ev_join[2], 0));
             if (what & LVX_EVAL_NORMAL_EQ) {
               hipStream_t s_ref = (one_side && staged) ? s_rep : s_acc;
@@ -2322,13 +2365,13 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
               third_ref = sw.ref_side == 2 && staged && s_refpass != s_acc;
               if (s_ref != s_rep || s_refpass != s_rep) LVX_HIP(ctx, hipEventRecord(ctx->ev_jac, s_rep));   // an event record on the chain is a bubble: only when another stream waits for it
               const RepJac jac{Jb, rb, kb, r.n};
-              RepSideAcc<1> ra{r.n, jac, 0.0};
-              { ProfScope ps(ctx, LVX_KERNEL_REP_OBS, s_rep); LVX_LAUNCH_MFMA1(RepSideAcc<1>, 1, ra, LVX_FAM_REPROJ, s_rep, ctx->fam_row0[4]); }
+              RepSideAcc<1, T> ra{r.n, jac, 0.0};
+              { ProfScope ps(ctx, LVX_KERNEL_REP_OBS, s_rep); LVX_LAUNCH_MFMA1(LVX_T2(RepSideAcc<1, T>), 1, ra, LVX_FAM_REPROJ, s_rep, ctx->fam_row0[4]); }
               // the other two passes only read the materialised rows: they can run next to the observation-side pass, behind the accelerometer kernel
-              RepSideAcc<0> rb2{r.n, jac, 0.0};
+              RepSideAcc<0, T> rb2{r.n, jac, 0.0};
               if (s_ref != s_rep) LVX_HIP(ctx, hipStreamWaitEvent(s_ref, ctx->ev_jac, 0));
               if (s_refpass != s_ref) LVX_HIP(ctx, hipStreamWaitEvent(s_refpass, ctx->ev_jac, 0));
-              { ProfScope ps(ctx, LVX_KERNEL_REP_REF, s_refpass); LVX_LAUNCH_MFMA1(RepSideAcc<0>, 1, rb2, LVX_FAM_PRIOR, s_refpass, ctx->fam_row0[4]); }
+              { ProfScope ps(ctx, LVX_KERNEL_REP_REF, s_refpass); LVX_LAUNCH_MFMA1(LVX_T2(RepSideAcc<0, T>), 1, rb2, LVX_FAM_PRIOR, s_refpass, ctx->fam_row0[4]); }
               if (ctx->rep_groups > 0) {
                 const int* gt = (const int*)ctx->d_repB[2].p;
                 RepCross rx{jac, r.lm, gt, gt + ctx->rep_groups + 1, ctx->rep_groups, ctx->sw.cross_dbg, (double*)ctx->d_repT.p, nullptr};
@@ -2336,20 +2379,30 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
                   if (det && ctx->det_cross_col.size() > 1) {
                     for (size_t q = 0; q + 1 < ctx->det_cross_col.size(); ++q) {
                       rx.det_list = (const int*)ctx->d_det_cross.p + ctx->det_cross_col[q];
-                      hipLaunchKernelGGL(k_reproj_cross, dim3((unsigned)(ctx->det_cross_col[q + 1] - ctx->det_cross_col[q])), dim3(256), 0, s_ref, rx, cm);
+                      hipLaunchKernelGGL(k_reproj_cross<T>, dim3((unsigned)(ctx->det_cross_col[q + 1] - ctx->det_cross_col[q])), dim3(256), 0, s_ref, rx, cm);
                     }
                   } else
-                  hipLaunchKernelGGL(k_reproj_cross, dim3((unsigned)std::min((ctx->rep_groups + 3) / 4, 256 * 8)), dim3(256), 0, s_ref, rx, cm); }
+                  hipLaunchKernelGGL(k_reproj_cross<T>, dim3((unsigned)std::min((ctx->rep_groups + 3) / 4, 256 * 8)), dim3(256), 0, s_ref, rx, cm); }
                 if (ctx->L > 0 && !(ctx->locks & LVX_LOCK_LANDMARKS)) {
                   const int* lp = (const int*)ctx->d_repB[3].p;
                   const RepLmRows lq{(const double*)ctx->d_repT.p, kb, r.n, lp, lp + ctx->L + 1, ctx->L};
                   const size_t lds = (size_t)4 * ctx->lm_ls * 8;
-                  LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_reproj_lmrows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                  LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_reproj_lmrows<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                   ProfScope ps(ctx, LVX_KERNEL_REP_LMROWS, s_ref);
-                  hipLaunchKernelGGL(k_reproj_lmrows, dim3((unsigned)((ctx->L + 3) / 4)), dim3(256), lds, s_ref, lq, cm);
+                  hipLaunchKernelGGL(k_reproj_lmrows<T>, dim3((unsigned)((ctx->L + 3) / 4)), dim3(256), lds, s_ref, lq, cm);
                 }
               }
             }
+            return LVX_OK;
+          };
+          const bool rep_fused_on = fast && !sw.reproj_legacy && !(tauC && sw.tau_legacy);
+          if (rep_fused_on) {
+            const int rcf = tauC ? rep_fused(std::true_type{}) : rep_fused(std::false_type{});
+            if (rcf) return rcf;
+          } else if (tauC) {
+            ProfScope ps(ctx, LVX_FAM_REPROJ, s_rep);
+            ReprojFamT<true> rt{r.n, r.lm, r.uv, r.t0o, r.perm, r.lm_uv, r.lm_t0, r.weight, r.huber};
+            hipLaunchKernelGGL((k_family<ReprojFamT<true>, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, rt, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
           } else {
             ProfScope ps(ctx, LVX_FAM_REPROJ, s_rep);
             hipLaunchKernelGGL((k_family<ReprojFam, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, r, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);

@@ -81,6 +81,38 @@ def test_bench_generator_shapes_small(tracks):
     g.close()
 
 
+@pytest.mark.parametrize("free", [True, False])
+def test_camera_time_offset_moves_views_out_of_their_cross_term_windows(free):
+    """Non-zero camera time offset on the bench generator's co-visibility tracks: the cross-term groups were fixed at layout time from the view times at tau = 0, and
+    a view within |tau| of a knot now evaluates in the neighbouring interval — for some blocks outside the 4-interval window of their group.  Those blocks take the
+    kernel's entry-by-entry path (k_reproj_cross, "strays") and the pass stays on the fused kernels: H, g and the residuals against the oracle, no fallback;
+    with the offset FREE its column (tangent 6 N + 21) rides along the fused reprojection path, with it LOCKED at that value the spans' +-1 ms margins keep it legal."""
+    P = synth.make_bench_problem(seed=11, n_imu=1200, n_surfel=600, n_reproj=1500, n_planes=10, tracks="orb", obs_per_frame=40)
+    N = P["n_knots"]
+    locks = lvx.LOCK_LIDAR_TAU | (0 if free else lvx.LOCK_CAM_TAU)
+    o, g = _pair(P, locks, prior=False)
+    for tau in (8e-4, -7e-4):
+        s = P["state0"].copy()
+        s[7 * N + 24 + 7] = tau
+        # blocks whose reference or observation view leaves its aligned 4-interval window
+        rd = P["camera"]["readout"] / P["camera"]["rows"]
+        lm = P["rep_lm"]
+        moved = 0
+        for t0v, vv in ((P["lm_t0"][lm], P["lm_uv"][lm, 1]), (P["rep_t0"], P["rep_uv"][:, 1])):
+            k_a = np.floor((t0v + vv * rd - P["t0"]) / P["dt"]); k_b = np.floor((t0v + vv * rd + tau - P["t0"]) / P["dt"])
+            moved += int(np.count_nonzero(k_a // 4 != k_b // 4))
+        assert moved >= 3
+        ro = o.evaluate(s, normal_eq=True)
+        rg = g.evaluate(s, normal_eq=True)
+        assert g.layout()["exact_fallback"] == 0
+        assert np.abs(rg["residuals"] - ro["residuals"]).max() <= 1e-11 * np.abs(ro["residuals"]).max()
+        assert np.abs(rg["H"] - ro["H"]).max() <= 1e-10 * np.abs(ro["H"]).max()
+        assert np.abs(rg["g"] - ro["g"]).max() <= 1e-10 * np.abs(ro["g"]).max()
+        _assert_blockscaled(rg["H"], ro["H"])
+        assert (np.abs(ro["H"][6 * N + 21]).max() > 0) == free
+    g.close()
+
+
 def test_imu_only_config3_shape():
     P = synth.make_problem(seed=3, duration=3.0, n_surfel=0, n_planes=1, n_landmarks=0)
     o, g = _pair(P, TAU_LOCKS, prior=False)
@@ -114,6 +146,7 @@ def test_free_time_offsets(locks):
         if not (locks & lvx.LOCK_CAM_TAU):
             s[7 * N + 24 + 7] = -2e-4     # cam tau
         ro, rg = _compare(o, g, s)
+        assert g.layout()["exact_fallback"] == 0     # free offsets stay on the fused kernels (time-offset column in SurfAccT / CamSurfAccT / the reprojection passes)
         nt = o.tangent_size
         Jo = O.dense_jacobian(ro["jac_cols"], ro["jac_vals"], nt)
         for col, bit in ((6 * N + 14, lvx.LOCK_LIDAR_TAU), (6 * N + 21, lvx.LOCK_CAM_TAU)):
