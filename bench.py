@@ -124,7 +124,7 @@ def secondary_metrics(ctx, P, lo):
                                   "note": "trajInitFromSurfel (<= 30 it) then trajInitFromLVIdata (<= 80 it) from the 3 deg / 3 cm perturbed start, wall time incl. problem upload"}
     except Exception as e:   # noqa: BLE001
         sec["converged_solve"] = {"error": str(e)[:200]}
-    try:   # free LiDAR / camera time offsets (the reference's opt_time_offset_ stages): surfel and reprojection take the per-segment TAU kernels
+    try:   # free LiDAR / camera time offsets (the reference's opt_time_offset_ stages): one more global column on the fused kernels
         g = lvx.Context(0)
         lvx.load_problem(g, P, 0)
         g.set_state(P["state0"])
@@ -137,7 +137,7 @@ def secondary_metrics(ctx, P, lo):
         g.synchronize()
         dtf = (time.perf_counter() - t0) / 5
         g.close()
-        sec["free_time_offsets"] = {"ms_per_step": 1e3 * dtf, "Mevals_per_s": lo["n_blocks"] / dtf / 1e6, "note": "lock mask 0: both sensor time offsets free (not the headline configuration)"}
+        sec["free_time_offsets"] = {"ms_per_step": 1e3 * dtf, "Mevals_per_s": lo["n_blocks"] / dtf / 1e6, "note": "lock mask 0: both sensor time offsets free (not the headline configuration); fused time-offset column in the LiDAR, camera-surfel and reprojection kernels"}
     except Exception as e:   # noqa: BLE001
         sec["free_time_offsets"] = {"error": str(e)[:200]}
     try:
@@ -162,8 +162,45 @@ def secondary_metrics(ctx, P, lo):
         sec["scan_registration"] = {"ms_per_sweep": 1e3 * t, "points": len(pts), "Mpts_per_s": len(pts) / t / 1e6, "hbm_frac": 28.0 * len(pts) / t / 1e9 / HBM_PEAK_GBS,
                                     "cpu": {"ms_per_sweep": 1e3 * tcs, "Mpts_per_s": len(pts) / tcs / 1e6, "cores": 1, "kind": "port", "sample": "%d sweeps (the reference's laserCloudHandler is serial)" % nrep},
                                     "note": "host buffers in/out (PCIe inclusive), reference budget 100 ms per sweep; 28 B per point algorithmic"}
+        import torch
+        batched = {}
+        for S in (1, 16, 64):   # lvx_scan_register_batch_d: S sweeps per call, points resident on the device, results stay there (counts come back)
+            sw = [synth.make_vlp16_sweep(seed=1 + (k % 4)) for k in range(S)]
+            off = np.concatenate([[0], np.cumsum([len(q) for q in sw])]).astype(np.int32)
+            pd = torch.from_numpy(np.concatenate(sw).view(np.uint8).reshape(-1)).to("cuda")
+            lvx.scan_register_batch_d(ctx, pd.data_ptr(), off, 16, 0.3)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                lvx.scan_register_batch_d(ctx, pd.data_ptr(), off, 16, 0.3)
+            tb = (time.perf_counter() - t0) / 10
+            batched["%d_sweeps" % S] = {"ms_per_call": 1e3 * tb, "us_per_sweep": 1e6 * tb / S, "Mpts_per_s": int(off[-1]) / tb / 1e6, "hbm_frac": 28.0 * int(off[-1]) / tb / 1e9 / HBM_PEAK_GBS}
+        sec["scan_registration"]["batched_device_resident"] = batched
     except Exception as e:   # noqa: BLE001
         sec["upstream_error"] = str(e)[:200]
+    try:   # one DataAssociation round of the stage driver, device-resident (lvx_data_association): 57 scans x 16 x 450 points of synth.make_sequence
+        import ctypes as C
+        S = synth.make_sequence(seed=50)
+        g = lvx.Context(0)
+        g.set_spline(S["t0"], S["dt"], S["n_knots"])
+        raw = np.zeros(S["scans"].shape, dtype=lvx.POINT_XYZIT)
+        for k in ("x", "y", "z", "timestamp"):
+            raw[k] = S["scans"][k]
+        nsc = len(raw)
+        g._ck(g._l.lvx_set_scans(g._h, C.c_int(nsc), C.c_int(S["H"]), C.c_int(S["W"]), raw.ctypes.data_as(C.c_void_p)))
+        st = np.ascontiguousarray(S["state0"], np.float64)
+        npl, npt = C.c_int32(0), C.c_int32(0)
+        call = lambda: g._ck(g._l.lvx_data_association(g._h, st.ctypes.data_as(C.c_void_p), C.c_double(S["t_map"]), None, C.byref(npl), C.byref(npt)))
+        call()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            call()
+        tda = (time.perf_counter() - t0) / 5
+        g.close()
+        sec["data_association"] = {"ms": 1e3 * tda, "scans": nsc, "points": int(raw.size), "surfels": int(npl.value), "surfel_points": int(npt.value), "Mpts_per_s": raw.size / tda / 1e6,
+                                   "note": "de-skew of every scan into the map frame + voxel covariance grid of the map cloud + surfel extraction + association of every scan + chronological SurfelPoint "
+                                           "emission, one call, raw scans resident on the device (lvi_initialize_surfel_orb.cpp:1180-1201)"}
+    except Exception as e:   # noqa: BLE001
+        sec["data_association"] = {"error": str(e)[:200]}
     return sec
 
 
