@@ -2,7 +2,12 @@
 """Second, INDEPENDENT restatement of the residual functors of the path — written against the reference's headers, not against oracle/ —
 in the AMBIENT parameterisation Ceres sees (4-wide quaternion blocks, flat state layout of include/lvx.h), evaluated in 50-digit
 arithmetic (mpmath) with Jacobians by central differences (h = 1e-25: truncation and rounding both below 1e-24 relative).
-Writes tests/golden/ambient_small.npz; run here (no GPU, no reference needed): python tests/golden/make_ambient.py
+Writes tests/golden/ambient_{small,tau,radtan,solve0}.npz; run here (no GPU, no reference needed): python tests/golden/make_ambient.py [variant ...]
+  small   every family, time offsets locked (the round-2 fixture, unchanged)
+  tau     free LiDAR and camera time offsets, both non-zero: spans padded by max_time_offset (sensors.h:161-162, trajectory_manager_lvi.h:118-119), the residuals
+          differentiated through the spline time argument (sensors.h:70-85) — the d r / d tau columns
+  radtan  a radial-tangential camera (pinhole_camera.h:131-215: 8 fixed-point iterations of Unproject, distortion in spaceToPlane)
+  solve0  initialSO3TrajWithGyro (trajectory_manager_lvi.cpp:43-62): gyro blocks + one orientation prior on the SO3-only estimator
 
 What is restated, and from where (K/ = src/lvi_exc/thirdparty/Kontiki/include/kontiki/):
   spline bases M, M_cumul                         K/trajectories/spline_base.h:19-29
@@ -112,7 +117,9 @@ def vecmat(u, m):   # row vector times 4 x 4
 # the problem: flat state as in include/lvx.h, measurement arrays as lvx_set_* take them
 # ---------------------------------------------------------------------------------------------------------
 class Problem:
-    def __init__(self, P, locks_tau=True):
+    def __init__(self, P, locks_tau=True, max_time_offset=1e-3):
+        self.free_tau = not locks_tau
+        self.pad = 0.0 if locks_tau else max_time_offset     # a free offset widens every span by its bound (sensors.h:161-162: the sensor adds +- max_time_offset)
         self.t0, self.dt, self.N = float(P["t0"]), float(P["dt"]), int(P["n_knots"])
         self.L = int(P["n_landmarks"])
         self.P = P
@@ -163,17 +170,26 @@ class Problem:
 
     # SplineView::Evaluate dispatch (spline_base.h:194-203) + CalculateIndexAndInterpolationAmount against the SEGMENT origin ------------------
     def locate(self, segs, t):
+        tm = t                                     # mpf when a time offset is a free parameter (the Jet of the reference carries d t / d tau = 1), else a double
+        t = float(t)
         for (i1, n) in segs:
             t0s = self.t0 + self.dt * i1          # SplineSegmentMeta(master_dt, master_t0 + master_dt * i1): double arithmetic
             tmin, tmax = t0s, t0s + (n - 3) * self.dt
-            tt = None
+            tt, shift = None, 0.0
             if tmin <= t < tmax:
                 tt = t
             else:
                 t2 = t - 1e-5
                 if tmin <= t2 < tmax:
-                    tt = t2
+                    tt, shift = t2, 1e-5
             if tt is not None:
+                if self.free_tau:                  # the same expression on the differentiable time: u keeps its dependence on tau (the value differs from the double one by < 1e-15)
+                    s = ((tm - F(shift)) - F(t0s)) / F(self.dt)
+                    i0 = int(np.floor(float(s)))
+                    u = s - i0
+                    if n < 4 or i0 < 0 or i0 > n - 4:
+                        raise IndexError("out of range for spline segment")
+                    return i1 + i0, u, (i1, n)
                 s = (tt - t0s) / self.dt           # double arithmetic, as the reference evaluates it on doubles / Jet value parts
                 i0 = int(np.floor(s))
                 u = s - i0
@@ -290,9 +306,9 @@ class Problem:
     def surfel(self, x, i):
         P = self.P
         tm, tk = float(P["t_map"]), float(P["surf_t"][i])
-        segs = self.segments([(tm, tm), (tk, tk)])
+        segs = self.segments([(tm - self.pad, tm + self.pad), (tk - self.pad, tk + self.pad)])
         ld = self.lidar(x)
-        qL, pL, tau = ld[0:4], ld[4:7], float(ld[7])
+        qL, pL, tau = ld[0:4], ld[4:7], (ld[7] if self.free_tau else float(ld[7]))
         e0, ek = self.pose(x, segs, tm + tau, "pq"), self.pose(x, segs, tk + tau, "pq")
         pI = add(qrot(qL, [F(v) for v in P["surf_pt"][i]]), pL)
         ptmp = qrot(qconj(e0["q"]), sub(add(qrot(ek["q"], pI), ek["p"]), e0["p"]))
@@ -306,9 +322,10 @@ class Problem:
         t0r, t0o = float(P["lm_t0"][l]), float(P["rep_t0"][i])
         t1, t2 = (t0r, t0o) if t0r <= t0o else (t0o, t0r)
         mg, ro = 1e-3, float(c["readout"])
+        t1, t2 = t1 - self.pad, t2 + self.pad      # static_rscamera_measurement.h:160-167: the earlier view's span moves back, the later one's forward
         segs = self.segments([(t1 - mg, t1 + ro + mg), (t2 - mg, t2 + ro + mg)])
         cm = self.camx(x)
-        qC, pC, tau = cm[0:4], cm[4:7], float(cm[7])
+        qC, pC, tau = cm[0:4], cm[4:7], (cm[7] if self.free_tau else float(cm[7]))
         rowd = ro / float(c["rows"])
         uvr, uvo = P["lm_uv"][l], P["rep_uv"][i]
         er = self.pose(x, segs, t0r + tau + float(uvr[1]) * rowd, "pq")
@@ -328,9 +345,9 @@ class Problem:
         P = self.P
         l = int(P["cs_lm"][i])
         tm, tk = float(P["t_map"]), float(P["lm_t0"][l])
-        segs = self.segments([(tm, tm), (tk, tk)])
+        segs = self.segments([(tm - self.pad, tm + self.pad), (tk - self.pad, tk + self.pad)])
         cm, ld = self.camx(x), self.lidar(x)
-        qC, pC, tau = cm[0:4], cm[4:7], float(cm[7])
+        qC, pC, tau = cm[0:4], cm[4:7], (cm[7] if self.free_tau else float(cm[7]))
         qL, pL = ld[0:4], ld[4:7]
         e0, ek = self.pose(x, segs, tm + tau, "pq"), self.pose(x, segs, tk + tau, "pq")
         rho = F(float(self.rho(x, l)))          # read as a constant double (camera_surfel_landmark.h:159-161)
@@ -371,16 +388,29 @@ def jacobian(fn, x, deps, h=F("1e-25")):
     return [float(v) for v in r0], J
 
 
-def main():
+VARIANTS = {
+    # name: (seed, free time offsets, camera overrides, Solve #0 layout)
+    "small": (31, False, {}, False),
+    "tau": (32, True, {}, False),
+    "radtan": (33, False, dict(k1=-0.0397646985948, k2=0.00802944041788, p1=-0.0043042199686, p2=-0.0001040279967, k3=0.00030608999077), False),
+    "solve0": (34, False, {}, True),
+}
+
+
+def make(variant):
     sys.path.insert(0, os.path.join(ROOT, "lvi-exc_amd"))
     import synth   # only the seeded DATA generator; nothing below uses its evaluator
-    P = synth.make_problem(seed=31, duration=0.6, n_surfel=14, n_planes=5, n_landmarks=3, views_per_lm=5, n_camsurf=2, imu_rate=20.0)
+    seed, free_tau, cam_over, solve0 = VARIANTS[variant]
+    cam = dict(synth.DEFAULT_CAMERA, **cam_over)
+    P = synth.make_problem(seed=seed, duration=0.6, n_surfel=0 if solve0 else 14, n_planes=5, n_landmarks=0 if solve0 else 3, views_per_lm=5, n_camsurf=0 if solve0 else 2, imu_rate=20.0, camera=cam)
     # one reprojection block whose two views share a frame already exists (the reference observation); make one landmark's second view the
     # NEXT frame (50 ms: the padded spans of ref and obs merge into one 5-7 knot segment, spline_base.h:398-424)
-    pr = Problem(P)
+    pr = Problem(P, locks_tau=not free_tau)
     N, L = pr.N, pr.L
     state = P["state0"].copy()
     state[7 * N + 8:7 * N + 10] = [0.013, -0.021]          # gravity roll / pitch away from the symmetric default
+    if free_tau:
+        state[7 * N + 23], state[7 * N + 31] = 3e-4, -2e-4   # LiDAR / camera time offsets inside their +- 1e-3 bound
     x = [F(float(v)) for v in state]
     sens = list(range(7 * N, 7 * N + 32))
     blocks = []   # (family, index, residual, J)
@@ -388,9 +418,10 @@ def main():
     for i in range(len(P["t_imu"])):
         fn = lambda xx, i=i: pr.gyro(xx, i)
         blocks.append(("gyro", i) + jacobian(fn, x, pr.deps(fn(x)[1], sens)))
-    for i in range(len(P["t_imu"])):
-        fn = lambda xx, i=i: pr.accel(xx, i)
-        blocks.append(("accel", i) + jacobian(fn, x, pr.deps(fn(x)[1], sens)))
+    if not solve0:
+        for i in range(len(P["t_imu"])):
+            fn = lambda xx, i=i: pr.accel(xx, i)
+            blocks.append(("accel", i) + jacobian(fn, x, pr.deps(fn(x)[1], sens)))
     fn = lambda xx: pr.prior(xx, *prior)
     blocks.append(("prior", 0) + jacobian(fn, x, pr.deps(fn(x)[1], [])))
     for i in range(len(P["surf_t"])):
@@ -410,9 +441,15 @@ def main():
             "lm_uv", "lm_t0", "rep_lm", "rep_uv", "rep_t0", "huber_rep", "w_rep", "cs_lm", "cs_plane", "huber_cs", "w_cs"]
     out = {k: np.asarray(P[k]) for k in keys}
     out.update({"camera_" + k: np.asarray(v) for k, v in P["camera"].items()})
-    out.update(state=state, residuals=res, J_ambient=J, row_family=fam, row_block=blk, prior_t=prior[0], prior_q_wxyz=prior[1], prior_w=prior[2])
-    np.savez_compressed(os.path.join(HERE, "ambient_small.npz"), **out)
-    print("ambient_small.npz: %d blocks, %d residual rows, state size %d, max |r| %.3e, max |J| %.3e" % (len(blocks), len(res), len(state), np.abs(res).max(), np.abs(J).max()))
+    out.update(state=state, residuals=res, J_ambient=J, row_family=fam, row_block=blk, prior_t=prior[0], prior_q_wxyz=prior[1], prior_w=prior[2],
+               free_tau=np.int32(1 if free_tau else 0), so3_only=np.int32(1 if solve0 else 0))
+    np.savez_compressed(os.path.join(HERE, "ambient_%s.npz" % variant), **out)
+    print("ambient_%s.npz: %d blocks, %d residual rows, state size %d, max |r| %.3e, max |J| %.3e" % (variant, len(blocks), len(res), len(state), np.abs(res).max(), np.abs(J).max()))
+
+
+def main():
+    for v in (sys.argv[1:] or list(VARIANTS)):
+        make(v)
 
 
 if __name__ == "__main__":

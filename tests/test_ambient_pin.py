@@ -22,13 +22,23 @@ def _qmul(a, b):
     return synth.qmul(np.asarray(a, float), np.asarray(b, float))
 
 
-def _load():
-    z = np.load(os.path.join(HERE, "golden", "ambient_small.npz"))
+VARIANTS = ["small", "tau", "radtan", "solve0"]   # tests/golden/make_ambient.py: every family | free time offsets | radial-tangential camera | Solve #0 (SO3-only estimator)
+
+
+def _locks(P):
+    if P.get("so3_only"):
+        return lvx.LOCK_R3 | lvx.LOCK_ACC_BIAS | lvx.LOCK_GYRO_BIAS | TAU      # initialSO3TrajWithGyro (trajectory_manager_lvi.cpp:43-62)
+    return 0 if P.get("free_tau") else TAU
+
+
+def _load(variant="small"):
+    z = np.load(os.path.join(HERE, "golden", "ambient_%s.npz" % variant))
     P = {k: z[k] for k in z.files if not k.startswith("camera_")}
     P["camera"] = {k[7:]: (int(z[k]) if k[7:] in ("rows", "cols") else float(z[k])) for k in z.files if k.startswith("camera_")}
     for k in ("t0", "dt", "w_gyro", "w_acc", "t_map", "huber_surf", "w_surf", "huber_rep", "w_rep", "huber_cs", "w_cs", "prior_t", "prior_w"):
         P[k] = float(P[k])
     P["n_knots"], P["n_landmarks"] = int(P["n_knots"]), int(P["n_landmarks"])
+    P["free_tau"], P["so3_only"] = bool(int(P.get("free_tau", 0))), bool(int(P.get("so3_only", 0)))
     return P
 
 
@@ -82,7 +92,7 @@ def _check(ev, dense_jac, P, free, tol_h=1e-9):
     J = dense_jac(ev["jac_cols"], ev["jac_vals"], Jt.shape[1])
     # every row against its own largest entry; rows that vanish analytically (the reference observation reprojected into its own view) against
     # 1e-6 of their family's largest entry, or rounding noise would be divided by rounding noise
-    fmax = np.array([np.abs(Jt[P["row_family"] == f]).max() for f in P["row_family"]])[:, None]
+    fmax = np.array([max(np.abs(Jt[P["row_family"] == f]).max(), 1e-300) for f in P["row_family"]])[:, None]
     scale = np.maximum(np.abs(Jt).max(axis=1, keepdims=True), 1e-6 * fmax)
     assert (np.abs(J - Jt) / scale).max() <= 1e-9, "worst row-relative Jacobian error %.3e" % (np.abs(J - Jt) / scale).max()
     assert abs(ev["cost"] - cost) <= 1e-11 * cost
@@ -105,26 +115,45 @@ def test_fixture_exercises_every_family_and_the_huber_branch():
     assert any(big) and not all(big)                                                        # both branches of the Huber loss
 
 
-def test_oracle_matches_the_ambient_restatement():
+def test_variants_cover_what_they_claim():
+    P = _load("tau")
+    N = P["n_knots"]
+    assert P["free_tau"] and P["state"][7 * N + 23] != 0 and P["state"][7 * N + 31] != 0
+    Jt = P["J_ambient"] @ _tangent_map(P["state"], N, P["n_landmarks"])
+    assert np.abs(Jt[P["row_family"] == 3][:, 6 * N + 14]).max() > 0        # d r / d tau_lidar on the surfel rows
+    assert np.abs(Jt[P["row_family"] >= 4][:, 6 * N + 21]).max() > 0        # d r / d tau_cam on the reprojection / camera-surfel rows
+    P = _load("radtan")
+    assert abs(P["camera"]["k1"]) > 1e-5 and abs(P["camera"]["p2"]) > 0
+    P = _load("solve0")
+    assert P["so3_only"] and set(np.unique(P["row_family"])) == {0, 2}
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_oracle_matches_the_ambient_restatement(variant):
     from oracle import oracle as O
-    P = _load()
+    P = _load(variant)
+    locks = _locks(P)
     o = O.Oracle()
-    lvx.load_problem(o, P, TAU)
+    lvx.load_problem(o, P, locks)
+    o.set_so3_only(P["so3_only"])
     o.set_orientation_prior(P["prior_t"], P["prior_q_wxyz"], P["prior_w"])
     ev = o.evaluate(P["state"], jac=True, normal_eq=True)
-    _check(ev, O.dense_jacobian, P, _free(P, TAU))
+    _check(ev, O.dense_jacobian, P, _free(P, locks))
 
 
 @pytest.mark.gpu
-def test_gpu_matches_the_ambient_restatement():
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_gpu_matches_the_ambient_restatement(variant):
     from oracle import oracle as O   # dense_jacobian helper only
-    P = _load()
+    P = _load(variant)
+    locks = _locks(P)
     g = lvx.Context(0)
-    lvx.load_problem(g, P, TAU)
+    lvx.load_problem(g, P, locks)
     g.set_orientation_prior(P["prior_t"], P["prior_q_wxyz"], P["prior_w"])
     ev = g.evaluate(P["state"], jac=True, normal_eq=True)          # per-segment kernels (debug Jacobian)
-    _check(ev, O.dense_jacobian, P, _free(P, TAU))
+    _check(ev, O.dense_jacobian, P, _free(P, locks))
     ev2 = g.evaluate(P["state"], jac=False, normal_eq=True)        # fused MFMA path: residuals, cost, H, g
     ev2["jac_cols"], ev2["jac_vals"] = ev["jac_cols"], ev["jac_vals"]
-    _check(ev2, O.dense_jacobian, P, _free(P, TAU))
+    _check(ev2, O.dense_jacobian, P, _free(P, locks))
+    assert g.layout()["exact_fallback"] == 0
     g.close()
