@@ -312,6 +312,27 @@ __global__ __launch_bounds__(256) void k_dense_back(const double* S, double* rhs
   for (int e = tid; e < np; e += 256) rhs[e] = r[e];
 }
 // z <- z - Z_B^T y_c
+// Reductions to a single address: a same-address atomic per WAVEFRONT (2 400 of them for 155 k scalars) serialises at the memory side — 25 ns each, 60 us for a
+// kernel that moves 3 MB.  These kernels walk their range with a grid-stride loop of at most RED_BLOCKS workgroups and issue ONE atomic per workgroup.
+#define RED_BLOCKS 256
+__device__ __forceinline__ void block_atomic_add(double v, double* dst) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __shared__ double part_[16];
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) part_[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) { double t = 0.0; for (int k = 0; k < nw; ++k) t += part_[k]; if (t != 0.0) atomicAdd(dst, t); }
+}
+__device__ __forceinline__ void block_atomic_max_nonneg(double v, double* dst) {   // non-negative doubles order like their bit patterns
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  __shared__ double part_[16];
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) part_[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) { double t = 0.0; for (int k = 0; k < nw; ++k) t = fmax(t, part_[k]); atomicMax((unsigned long long*)dst, (unsigned long long)__double_as_longlong(t)); }
+}
 __global__ void k_sub_border(const double* Z, const double* yc, int nb, int nbd, int ldz, double* z) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nb) return;
@@ -322,9 +343,8 @@ __global__ void k_sub_border(const double* Z, const double* yc, int nb, int nbd,
 // delta (tangent layout) from the scaled solution; also accumulates g_s.y and y^T D^2 y for the model cost change
 __global__ void k_unscale(const int* ord, int nt, const double* yb, const double* yc, const double* scale, const double* lmd, double inv_radius,
                           const double* gb, const double* gc, int nb, double* delta, double* sums) {
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
   double gy = 0.0, ydy = 0.0;
-  if (v < nt) {
+  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nt; v += gridDim.x * blockDim.x) {
     const int o = ord[v];
     double d = 0.0;
     if (o != LVX_DEAD && o < LVX_LM_BASE) {   // landmark entries: k_lm_back
@@ -332,34 +352,34 @@ __global__ void k_unscale(const int* ord, int nt, const double* yb, const double
       const double y = o >= 0 ? yb[o] : yc[-1 - o];
       const double g = o >= 0 ? gb[o] : gc[-1 - o];
       d = y * scale[i];
-      gy = g * scale[i] * y;
-      ydy = y * y * lmd[i] * inv_radius;
+      gy += g * scale[i] * y;
+      ydy += y * y * lmd[i] * inv_radius;
     }
     delta[v] = d;
   }
-  for (int o = 32; o > 0; o >>= 1) { gy += __shfl_xor(gy, o); ydy += __shfl_xor(ydy, o); }
-  if ((threadIdx.x & 63) == 0) { atomicAdd(&sums[0], gy); atomicAdd(&sums[1], ydy); }
+  block_atomic_add(gy, &sums[0]);
+  block_atomic_add(ydy, &sums[1]);
 }
 // sums[5] += delta^T H delta for the UNSCALED step (H = J^T J in band / border storage): the model cost change is then
 // -(g.delta + 1/2 delta^T H delta), what ceres computes from J * step — valid for any (also inexact) step
 __global__ void k_quad(const double* __restrict__ Hb, const double* __restrict__ Bd, const double* __restrict__ C, int ldc, const double* yb, const double* yc,
                        const double* scale, int nb, int bw, int nbd, double* sums) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double q = 0.0;
-  if (i < nb) {
-    const double di = yb[i] * scale[i];   // the band part of delta^T H delta is k_quad_band's
-    double u = 0.0;
-    for (int b = 0; b < nbd; ++b) u += Bd[(size_t)b * nb + i] * (yc[b] * scale[nb + b]);
-    q = di * 2.0 * u;
-  } else if (i < nb + nbd) {
-    const int a = i - nb;
-    const double da = yc[a] * scale[nb + a];
-    double t = 0.0;
-    for (int b = 0; b < nbd; ++b) t += (a >= b ? C[(size_t)a * ldc + b] : C[(size_t)b * ldc + a]) * (yc[b] * scale[nb + b]);
-    q = da * t;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb + nbd; i += gridDim.x * blockDim.x) {
+    if (i < nb) {
+      const double di = yb[i] * scale[i];   // the band part of delta^T H delta is k_quad_band's
+      double u = 0.0;
+      for (int b = 0; b < nbd; ++b) u += Bd[(size_t)b * nb + i] * (yc[b] * scale[nb + b]);
+      q += di * 2.0 * u;
+    } else {
+      const int a = i - nb;
+      const double da = yc[a] * scale[nb + a];
+      double t = 0.0;
+      for (int b = 0; b < nbd; ++b) t += (a >= b ? C[(size_t)a * ldc + b] : C[(size_t)b * ldc + a]) * (yc[b] * scale[nb + b]);
+      q += da * t;
+    }
   }
-  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-  if ((threadIdx.x & 63) == 0 && q != 0.0) atomicAdd(&sums[5], q);
+  block_atomic_add(q, &sums[5]);
 }
 // band part: sum_i delta_i (H_ii delta_i + 2 sum_{d >= 1} H(i+d, i) delta_{i+d}) — every stored entry once, a wavefront per band column so
 // that its bw + 1 entries are read as contiguous 512-byte pieces (a thread per column read them 1568 bytes apart: 0.5 ms for 243 MB)
@@ -584,22 +604,16 @@ __global__ __launch_bounds__(256) void k_lm_back(const double* __restrict__ lmH,
   }
 }
 __global__ void k_gmax_lm(const double* lmH, int L, int ls, int off, double* sums) {
-  const int l = blockIdx.x * blockDim.x + threadIdx.x;
-  double v = l < L ? fabs(lmH[(size_t)l * ls + off]) : 0.0;
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-  if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long*)&sums[4], (unsigned long long)__double_as_longlong(v));
+  double v = 0.0;
+  for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < L; l += gridDim.x * blockDim.x) v = fmax(v, fabs(lmH[(size_t)l * ls + off]));
+  block_atomic_max_nonneg(v, &sums[4]);
 }
 
 // max |g| over free scalars
 __global__ void k_gmax(const double* gb, const double* gc, int nb, int nbd, double* sums) {   // nbd: border entries to include (the shared tail is excluded in the joint solve)
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double v = 0.0;
-  if (i < nb) v = fabs(gb[i]); else if (i < nb + nbd) v = fabs(gc[i - nb]);
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-  if ((threadIdx.x & 63) == 0) {   // atomic max on a non-negative double via its bit pattern
-    unsigned long long* p = (unsigned long long*)&sums[4];
-    atomicMax(p, (unsigned long long)__double_as_longlong(v));
-  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb + nbd; i += gridDim.x * blockDim.x) v = fmax(v, i < nb ? fabs(gb[i]) : fabs(gc[i - nb]));
+  block_atomic_max_nonneg(v, &sums[4]);   // atomic max on a non-negative double via its bit pattern
 }
 
 }  // namespace lvx
@@ -914,13 +928,13 @@ static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double m[3
       hipLaunchKernelGGL(k_band_bwd, dim3(1), dim3(64), lds_bw, st, (const double*)w.L, nb, bw, zb);
     }
   }
-  hipLaunchKernelGGL(k_unscale, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, (const int*)c->d_ord.p, nt, (const double*)zb, (const double*)w.rhs, (const double*)w.scale,
+  hipLaunchKernelGGL(k_unscale, dim3((unsigned)std::min(RED_BLOCKS, (nt + 255) / 256)), dim3(256), 0, st, (const int*)c->d_ord.p, nt, (const double*)zb, (const double*)w.rhs, (const double*)w.scale,
                      (const double*)w.lmd, ir, (const double*)c->d_gb.p, (const double*)c->d_gc.p, nb, w.delta, w.sums);
   if (w.lm) hipLaunchKernelGGL(k_lm_back, dim3((unsigned)((c->L + 3) / 4)), dim3(256), 0, st, (const double*)c->d_lmH.p, (const int*)c->d_lm_p0.p, c->L, c->lm_wl, nbd, c->nbd_ext, c->lm_ls,
                                (const double*)(w.scale + (nb + nbd)), (const double*)(w.lmd + (nb + nbd)), ir, (const double*)zb, (const double*)w.rhs, (const double*)w.scale, nb,
                                w.delta + 6 * (size_t)c->N + 22, w.sums);
   if (nb > 0) hipLaunchKernelGGL(k_quad_band, dim3((unsigned)std::min(2048, (nb + 3) / 4)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)zb, (const double*)w.scale, nb, bw, w.sums);
-  hipLaunchKernelGGL(k_quad, dim3((unsigned)((nb + nbd + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)c->d_Bd.p, (const double*)c->d_C.p, c->nbd_ext,
+  hipLaunchKernelGGL(k_quad, dim3((unsigned)std::min(2 * RED_BLOCKS, (nb + nbd + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)c->d_Bd.p, (const double*)c->d_C.p, c->nbd_ext,
                      (const double*)zb, (const double*)w.rhs, (const double*)w.scale, nb, bw, nbd, w.sums);
   LVX_HIP(c, hipGetLastError());
   double h[8];
@@ -937,8 +951,8 @@ static int local_gmax(lvx_ctx* c, SolveWork& w, double* g, double* gsh) {
   hipStream_t st = c->stream;
   LVX_HIP(c, hipMemsetAsync(w.sums + 4, 0, 8, st));
   const int n = c->nb + c->nbd - c->ns;
-  hipLaunchKernelGGL(k_gmax, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)c->d_gb.p, (const double*)c->d_gc.p, c->nb, c->nbd - c->ns, w.sums);
-  if (w.lm) hipLaunchKernelGGL(k_gmax_lm, dim3((unsigned)((c->L + 255) / 256)), dim3(256), 0, st, (const double*)c->d_lmH.p, c->L, c->lm_ls, c->lm_wl + c->nbd_ext + 1, w.sums);
+  hipLaunchKernelGGL(k_gmax, dim3((unsigned)std::min(RED_BLOCKS, (n + 255) / 256)), dim3(256), 0, st, (const double*)c->d_gb.p, (const double*)c->d_gc.p, c->nb, c->nbd - c->ns, w.sums);
+  if (w.lm) hipLaunchKernelGGL(k_gmax_lm, dim3((unsigned)std::min(RED_BLOCKS, (c->L + 255) / 256)), dim3(256), 0, st, (const double*)c->d_lmH.p, c->L, c->lm_ls, c->lm_wl + c->nbd_ext + 1, w.sums);
   LVX_HIP(c, hipMemcpyAsync(g, w.sums + 4, 8, hipMemcpyDeviceToHost, st));
   if (c->ns > 0) LVX_HIP(c, hipMemcpyAsync(gsh, (const double*)c->d_gc.p + (c->nbd - c->ns), (size_t)c->ns * 8, hipMemcpyDeviceToHost, st));
   return LVX_OK;
