@@ -462,6 +462,104 @@ static int potrf_batched(lvx_ctx* c, rocblas_handle h, double* D, int b, long lo
   return LVX_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// One level of the backward sweep for a SINGLE right-hand side (the LM step itself), fused:  z_j <- C_j^-T (z_j - X+_k^T z_{j+s} - Y_k z_{j-s}).
+// Three library launches per level did this (two batched GEMMs with one column, a 64-vector triangular solve with one live vector: ~110 us per level,
+// latency of 13 panel steps each).  Here a workgroup owns block j: both matrix-vector products stream their 180 x 180 operands from HBM with 45 loads in flight
+// per lane, the factor's lower triangle is staged in LDS packed by COLUMNS (the transposed solve walks columns), and a panel's triangle is applied as
+// x_p = inv(L_pp)^T (...) from the inverses the Cholesky kernel left — 12 short steps instead of 180.  (An earlier fused attempt kept the substitution chain: 78 us.)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int coff(int b, int i) { return i * b - ((i * (i - 1)) >> 1); }   // start of column i (rows i .. b - 1) in the column-packed lower triangle
+#define BACK_NT 512
+__global__ __launch_bounds__(BACK_NT) void k_bcr_back_level(const double* __restrict__ Dj, long long sD, const double* __restrict__ LIj, long long sLI, const double* __restrict__ Gl, long long sG,
+                                                        double* Z, long long zj_off, long long zr_off, long long sZ, int b, int n2, long long bb) {
+  extern __shared__ double sh[];
+  const int k = blockIdx.x;
+  if (k >= n2) return;
+  constexpr int NW = BACK_NT / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int ntri = (b * (b + 1)) >> 1;
+  double* T = sh;                 // column-packed lower triangle of C_j
+  double* v = T + ntri;           // [b] right-hand side, then the solution
+  double* zr = v + b;             // [b] z_{j+s}
+  double* zl = zr + b;            // [b] z_{j-s}
+  double* sp = zl + b;            // [16] partial sums of a panel
+  double* Mi = sp + 16;           // [16][17] inv(L_pp)
+  const double* L = Dj + (size_t)k * sD;
+  const double* LI = LIj + (size_t)k * sLI;
+  const double* Xp = Gl + (size_t)k * sG;
+  const double* Y = k >= 1 ? Gl + (size_t)(k - 1) * sG + bb : nullptr;
+  double* zj = Z + zj_off + (size_t)k * sZ;
+  const double* zrg = Z + zr_off + (size_t)k * sZ;
+  const double* zlg = k >= 1 ? Z + zr_off + (size_t)(k - 1) * sZ : nullptr;
+  for (int i = tid; i < b; i += BACK_NT) { v[i] = zj[i]; zr[i] = zrg[i]; zl[i] = zlg ? zlg[i] : 0.0; }
+  __syncthreads();
+  // One sweep over the three operands, a wavefront per column and four columns of EACH operand (up to 48 loads per lane) in flight per trip — one column at a time
+  // waited for every load: 95 us for a single block.
+  //   factor: column i, rows i .. b - 1 -> LDS (contiguous in global memory and in LDS);
+  //   v -= X+^T z_{j+s}: entry i is the dot product of COLUMN i of X+ with z_{j+s};
+  //   v -= Y z_{j-s}: lane = row (coalesced over rows for a fixed column), the columns dealt over the wavefronts, partial sums added in LDS.
+  double ya[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int i0 = wv * 4; i0 < b; i0 += NW * 4) {
+    double tl[4][4], tx[4][4], ty[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + q, r = lane + 64 * u;
+        tl[q][u] = (i < b && i + r < b) ? L[(size_t)i * b + i + r] : 0.0;
+        tx[q][u] = (i < b && r < b) ? Xp[(size_t)i * b + r] : 0.0;
+        ty[q][u] = (Y && i < b && r < b) ? Y[(size_t)i * b + r] : 0.0;
+      }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = i0 + q;
+      double a = 0.0;
+      const double zc = i < b ? zl[i] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = lane + 64 * u;
+        if (i < b && i + r < b) T[coff(b, i) + r] = tl[q][u];
+        if (r < b) a += tx[q][u] * zr[r];
+        ya[u] += ty[q][u] * zc;
+      }
+      for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+      if (lane == 0 && i < b) atomicAdd(&v[i], -a);
+    }
+  }
+  if (Y) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int r = lane + 64 * u; if (r < b) atomicAdd(&v[r], -ya[u]); }   // LDS, one adder per wavefront and entry
+  }
+  // transposed solve, panels from the last to the first
+  const int np = (b + 15) >> 4;
+  double mi_next = tid < 256 ? LI[(size_t)(np - 1) * 256 + tid] : 0.0;
+  __syncthreads();
+  for (int p = np - 1; p >= 0; --p) {
+    const int k0 = 16 * p, nk = min(16, b - k0);
+    if (tid < 256) { Mi[(tid >> 4) * 17 + (tid & 15)] = mi_next; if (p > 0) mi_next = LI[(size_t)(p - 1) * 256 + tid]; }
+    // s_c = sum over the rows below the panel of L[r][k0 + c] x[r]: two columns per wavefront
+#pragma unroll
+    for (int q = 0; q < 16 / NW; ++q) {
+      const int cidx = wv * (16 / NW) + q, i = k0 + cidx;
+      double a = 0.0;
+      if (cidx < nk) { const double* col = T + coff(b, i) - i; for (int r = k0 + 16 + lane; r < b; r += 64) a += col[r] * v[r]; }
+      for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+      if (lane == 0) sp[cidx] = cidx < nk ? v[i] - a : 0.0;
+    }
+    __syncthreads();
+    if (tid < 16) {   // x_p = inv(L_pp)^T w
+      double x = 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) x += Mi[q * 17 + tid] * sp[q];
+      if (tid < nk) v[k0 + tid] = x;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < b; i += BACK_NT) zj[i] = v[i];
+}
+
 int bcr_plan(lvx_ctx* c) {
   const int b = std::max(16, ((c->bw + 3) / 4) * 4);
   int nblk = 1;
@@ -598,6 +696,9 @@ int bcr_backward(lvx_ctx* c, double* Zy, double* Zx, int ldz, int nrhs) {
   const double one = 1.0, mone = -1.0;
   int L = 0; while ((1 << L) < nblk) ++L;
   if ((rc = trsv_batched<true>(c, D + (size_t)(nblk - 1) * bb, b, 0, Z + (size_t)(nblk - 1) * b, 1, ldz, 0, nrhs, 1, LI ? LI + (size_t)(nblk - 1) * liS : nullptr, 0))) return rc;
+  const size_t lds_fused = ((size_t)b * (b + 1) / 2 + 3 * (size_t)b + 16 + 16 * 17) * 8;
+  const bool fused = nrhs == 1 && LI && lds_fused <= 160 * 1024 && !c->sw.bcr_no_fused_back;
+  if (fused) LVX_HIP(c, hipFuncSetAttribute((const void*)k_bcr_back_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fused));
   for (int l = L - 1; l >= 0; --l) {
     const int s = 1 << l, n2 = level_batch(nblk, c->bcr_nreal, l);
     if (n2 <= 0) continue;
@@ -606,6 +707,12 @@ int bcr_backward(lvx_ctx* c, double* Zy, double* Zx, int ldz, int nrhs) {
     double* Gl = G + g_off(nblk, l, bb);
     double* Zj = Z + (size_t)(s - 1) * b;
     double* Zr = Z + (size_t)(2 * s - 1) * b;
+    if (fused) {   // one launch per level: both matrix-vector products and the transposed solve of every eliminated block
+      hipLaunchKernelGGL(k_bcr_back_level, dim3((unsigned)n2), dim3(BACK_NT), lds_fused, c->stream, (const double*)Dj, sD, LI + (size_t)(s - 1) * liS, (long long)2 * s * liS, (const double*)Gl, sG,
+                         Z, (long long)(s - 1) * b, (long long)(2 * s - 1) * b, sZ, b, n2, (long long)bb);
+      LVX_HIP(c, hipGetLastError());
+      continue;
+    }
     LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, nrhs, b, &mone, Gl, b, sG, Zr, ldz, sZ, &one, Zj, ldz, sZ, n2));
     if (n2 > 1)
       LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, nrhs, b, &mone, Gl + bb, b, sG, Zr, ldz, sZ, &one, Zj + sZ, ldz, sZ, n2 - 1));
