@@ -302,12 +302,12 @@ __global__ __launch_bounds__(POTRF_NT) void k_potrf_batched(double* Dm, int b, l
   double* D = Dm + (size_t)blockIdx.x * strideD;
   double* LI = LIm ? LIm + (size_t)blockIdx.x * strideLI : nullptr;
   if (tid == 0) bad = 0;
-  for (int c0 = 0; c0 < b; c0 += 16) {      // lower triangle, 16 columns per step so that the loads are in flight together (4 per step: 53 k of the kernel's 358 k cycles)
-    double v[16];
+  for (int c0 = 0; c0 < b; c0 += 32) {      // lower triangle, 32 columns per step so that the loads are in flight together (every step is one trip to HBM: ~2 us each)
+    double v[32];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { const int cc = c0 + q, r = cc + tid; v[q] = (cc < b && r < b) ? D[(size_t)cc * b + r] : 0.0; }
+    for (int q = 0; q < 32; ++q) { const int cc = c0 + q, r = cc + tid; v[q] = (cc < b && r < b) ? D[(size_t)cc * b + r] : 0.0; }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { const int cc = c0 + q, r = cc + tid; if (cc < b && r < b) T[tri(r, cc)] = v[q]; }
+    for (int q = 0; q < 32; ++q) { const int cc = c0 + q, r = cc + tid; if (cc < b && r < b) T[tri(r, cc)] = v[q]; }
   }
   __syncthreads();
   const int fk = lane >> 4, fi = lane & 15;
@@ -320,6 +320,11 @@ __global__ __launch_bounds__(POTRF_NT) void k_potrf_batched(double* Dm, int b, l
     const int r = lane;
 #pragma unroll
     for (int cc = 0; cc < 16; ++cc) a[cc] = (r < nk && cc <= r) ? T[tri(k0 + r, k0 + cc)] : ((r == cc) ? 1.0 : 0.0);
+    // Factor and inverse in ONE loop: once column cc of L is final (all rows), row cc of M = inv(L11) can be finished in lane cc (it has folded in the rows above)
+    // and folded into the rows below — independent work in the shadow of the factorisation's dependent chain (pivot -> rsqrt -> column update).
+    double m[16], acc[16];
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) { m[cc] = 0.0; acc[cc] = 0.0; }
 #pragma unroll
     for (int cc = 0; cc < 16; ++cc) {
       double dc = readlane_f64(a[cc], cc);
@@ -330,28 +335,21 @@ __global__ __launch_bounds__(POTRF_NT) void k_potrf_batched(double* Dm, int b, l
       if (lane == 0) dinv[cc] = inv;
 #pragma unroll
       for (int c2 = cc + 1; c2 < 16; ++c2) { const double l2 = readlane_f64(a[cc], c2); a[c2] -= a[cc] * l2; }
+      if (LI) {   // row cc of M: M[cc][c] = -acc[c] / L[cc][cc] (c < cc), 1 / L[cc][cc] (c = cc); then acc[c] += L[r][cc] M[cc][c] in the rows below
+#pragma unroll
+        for (int c = 0; c < 16; ++c) if (c <= cc) { const double fin = c == cc ? inv : -acc[c] * inv; m[c] = (r == cc) ? fin : m[c]; }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) if (c <= cc) { const double mk = readlane_f64(m[c], cc); acc[c] += a[cc] * mk; }   // a[cc] = L[r][cc]; the rows above have finished theirs
+      }
     }
     if (r < nk) {
 #pragma unroll
       for (int cc = 0; cc < 16; ++cc) if (cc <= r) T[tri(k0 + r, k0 + cc)] = a[cc];
     }
-    if (LI) {   // M = inv(L11), lane = row: row k is final once the rows above it have been folded in; it is broadcast and the rows below accumulate L[r][k] M[k][:]
-      double m[16], acc[16];
+    if (LI && r < 16) {
+      double* dst = LI + (size_t)(k0 >> 4) * 256 + r * 16;
 #pragma unroll
-      for (int cc = 0; cc < 16; ++cc) { m[cc] = 0.0; acc[cc] = 0.0; }
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const double ik = invd[k];                        // 1 / L[k][k]
-#pragma unroll
-        for (int cc = 0; cc < 16; ++cc) if (cc <= k) { const double fin = cc == k ? ik : -acc[cc] * ik; m[cc] = (r == k) ? fin : m[cc]; }
-#pragma unroll
-        for (int cc = 0; cc < 16; ++cc) if (cc <= k) { const double mk = readlane_f64(m[cc], k); acc[cc] += a[k] * mk; }   // a[k] = L[r][k] (0 for k > r: the rows above take nothing)
-      }
-      if (r < 16) {
-        double* dst = LI + (size_t)(k0 >> 4) * 256 + r * 16;
-#pragma unroll
-        for (int cc = 0; cc < 16; ++cc) { Minv[r * 17 + cc] = m[cc]; dst[cc] = m[cc]; }
-      }
+      for (int cc = 0; cc < 16; ++cc) { Minv[r * 17 + cc] = m[cc]; dst[cc] = m[cc]; }
     }
   };
   if (wv == 0) diag_block(0);
