@@ -13,8 +13,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "lvx_ctx.h"
+#include "lvx_chol16.h"
 
 namespace lvx {
 
@@ -444,14 +446,208 @@ __global__ __launch_bounds__(POTRF_NT) void k_potrf_batched(double* Dm, int b, l
   }
   if (tid == 0) info[blockIdx.x] = bad;
 }
+// ---------------------------------------------------------------------------------------------------------
+// Register-resident batched Cholesky (the default for b <= 208).  The LDS-resident kernel above spends its time on LDS round trips of the trailing
+// matrix (every tile update reads and rewrites its 16 x 16 accumulator) and on a 16-column chain of ~90 instructions per column in the diagonal block.
+// Here the whole (transposed) factor lives in REGISTERS: U = L^T is cut into 16 x 16 tiles (tj, ti), tj <= ti, in the MFMA accumulator layout
+// (row = (lane >> 4) + 4 reg, col = lane & 15), dealt round-robin to the 8 wavefronts of the workgroup (78 tiles at b <= 192: 10 tiles = 80 VGPRs per lane).
+// Per 16-row panel k:
+//   1. diagonal tile: outer-product Cholesky ON THE MATRIX CORES.  The tile is kept as a full symmetric matrix; row cc of it, masked to the 16 lanes that
+//      hold it, is at once the A operand (column cc, by symmetry) and the B operand (row cc) of v_mfma_f64_16x16x4_f64, so one MFMA is the whole rank-1 update
+//      T -= t_cc t_cc^T / d and a second one carries the identity along, F -= t_cc f_cc^T / d, whose row cc, scaled by 1 / sqrt(d), is row cc of inv(L_kk)
+//      (Cholesky of [[A, I], [I, 0]]).  ~12 instructions per column instead of ~90; the chain is pivot -> rsqrt -> MFMA.
+//   2. row panel U[k, ti] = inv(L_kk) A[k, ti]: the register tile is the B operand as it stands (its rows are the contraction index), inv(L_kk) comes from LDS;
+//      the solved tiles go to an LDS row panel [16][16 NT] — the only part of the matrix that ever touches LDS.
+//   3. trailing update A[tj, ti] -= U[k, tj]^T U[k, ti]: both operands from the LDS panel, the accumulator never leaves its registers.
+// The owner of the NEXT diagonal tile updates it first and factorises it while the other wavefronts finish the trailing update.
+// Output as before: L column-major lower in place, inv(L_kk) per panel to LIm (k_trsm_reg<.., DINV>, k_bcr_back_level), info = first bad pivot.
+// ---------------------------------------------------------------------------------------------------------
+template <int K, int N, class Fn> __device__ __forceinline__ void static_for(Fn&& f) {
+  if constexpr (K < N) { f(std::integral_constant<int, K>{}); static_for<K + 1, N>(f); }
+}
+#define POTRF_REG_NW 8
+#ifdef LVX_POTRF_KT
+__device__ __forceinline__ long long pkt_now() { long long t; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
+#define PKT(i) { const long long n_ = pkt_now(); pkt_[i] += n_ - pkt0_; pkt0_ = n_; }
+#else
+#define PKT(i)
+#endif
+template <int NT>
+__global__ __launch_bounds__(64 * POTRF_REG_NW) void k_potrf_reg(double* Dm, int b, long long strideD, int* info, double* LIm, long long strideLI) {
+  // wavefront 0 owns the NT diagonal tiles and nothing else: the factorisation of a diagonal tile is the chain every panel waits for; wavefront 4 (same SIMD)
+  // stays idle; the NT (NT - 1) / 2 off-diagonal tiles are dealt to the other six.  The panel loop is a RUN-TIME loop (the fully unrolled version executed every
+  // instruction once, 160 KB of code: instruction fetch, not arithmetic, set its pace — the 16 x 16 factorisation took 4.7 k cycles inside it and 0.8 k with a
+  // warm instruction cache), so the diagonal wavefront keeps its waiting tiles in LDS in the accumulator layout (every lane touches only its own four words of a
+  // tile: no synchronisation, dynamic tile index); the off-diagonal tiles sit in statically indexed registers.
+  constexpr int NW = POTRF_REG_NW, NCW = 6, NTO = NT * (NT - 1) / 2, NSO = (NTO + NCW - 1) / NCW, PS = (16 * NT) | 1;
+  __shared__ double Pn[2][16 * PS];    // solved row panel U[k, :], double-buffered over k
+  __shared__ double Mi[2][16 * 17];    // inv(L_kk)
+  __shared__ double Dg[NT][4][64];     // diagonal tiles not yet factorised (wavefront 0 only)
+  __shared__ int bad;
+  const int tid = threadIdx.x, lane = tid & 63, fk = lane >> 4, fi = lane & 15;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool fw = wv == 0;
+  const int cw = (wv & 3) == 0 ? -1 : (wv < 4 ? wv - 1 : wv - 2);   // compute wavefront 0 .. 5
+  double* D = Dm + (size_t)blockIdx.x * strideD;
+  double* LI = LIm ? LIm + (size_t)blockIdx.x * strideLI : nullptr;
+  if (tid == 0) bad = 0;
+#ifdef LVX_POTRF_KT
+  long long pkt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long pkt0_ = pkt_now(); const long long pkts_ = pkt0_;
+#endif
+  d4 S[NSO];
+  int ti_[NSO], tj_[NSO];
+#pragma unroll
+  for (int s = 0; s < NSO; ++s) {
+    const int t = s * NCW + cw;
+    int ti = 1; while ((ti * (ti + 1)) >> 1 <= t) ++ti;          // off-diagonal tile t = ti (ti - 1) / 2 + tj, tj < ti
+    const bool ok = cw >= 0 && t < NTO;
+    ti_[s] = ok ? ti : -1; tj_[s] = ok ? t - ((ti * (ti - 1)) >> 1) : NT + 1;
+  }
+  // every tile straight from global memory into its registers: unconditional loads (clamped offsets, selected afterwards), all in flight together; diagonal
+  // tiles are mirrored, padding is the identity.  No barrier: wavefront 0 starts on tile (0, 0) as soon as it is back.
+  auto load_elem = [&](int ti, int tj, int v) {
+    const int cc = 16 * tj + fk + 4 * v, r = 16 * ti + fi;
+    const int lo = min(cc, r), hi = max(cc, r);
+    const bool ok = ti >= 0 && hi < b;
+    const double x = D[ok ? lo * b + hi : 0];
+    return ok ? x : ((ti >= 0 && lo == hi) ? 1.0 : 0.0);
+  };
+  d4 Tcur = d4{0.0, 0.0, 0.0, 0.0}, Mcur = d4{0.0, 0.0, 0.0, 0.0};
+  if (fw) {
+    d4 G[NT];
+#pragma unroll
+    for (int s = 0; s < NT; ++s)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) G[s][v] = load_elem(s, s, v);
+    Tcur = G[0];
+#pragma unroll
+    for (int s = 1; s < NT; ++s)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) Dg[s][v][lane] = G[s][v];
+  } else {
+#pragma unroll
+    for (int s = 0; s < NSO; ++s)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) S[s][v] = load_elem(ti_[s], tj_[s], v);
+  }
+  PKT(0)
+  // a finished tile goes back at once (L column-major lower: U (row cc, col r) = L[r][cc]); the stores drain under the rest of the factorisation
+  auto store_tile = [&](const d4& X, int ti, int tj) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int cc = 16 * tj + fk + 4 * v, r = 16 * ti + fi;
+      if (r < b && cc <= r) D[cc * b + r] = X[v];
+    }
+  };
+  auto factor_diag = [&](d4& T, int k) {
+    d4 Mres;
+#ifdef LVX_POTRF_KT
+    asm volatile("" : "+v"(T[0]), "+v"(T[1]), "+v"(T[2]), "+v"(T[3]));
+    const long long c0_ = pkt_now();
+#endif
+    const int bc = chol16_mfma(T, Mres, fk, fi);
+    if (lane == 0 && bc > 0 && 16 * k + bc <= b) atomicCAS(&bad, 0, 16 * k + bc);   // first non-positive pivot (replaced by 1: nothing turns into NaN)
+#ifdef LVX_POTRF_KT
+    asm volatile("" : "+v"(T[0]), "+v"(Mres[0]), "+v"(Mres[3]), "+v"(T[3]));
+    pkt_[7] += pkt_now() - c0_;
+#endif
+    double* mi = Mi[k & 1];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) mi[(fk + 4 * v) * 17 + fi] = Mres[v];
+    return Mres;
+  };
+  // what the panel solves do not wait for: the factor's inverse and the diagonal tile itself go to global memory behind the barrier
+  auto publish_diag = [&](const d4& T, const d4& Mres, int k) {
+    if (LI && 16 * k < b) {   // ceil(b / 16) panels per block; the tiles beyond are identity padding
+#pragma unroll
+      for (int v = 0; v < 4; ++v) LI[k * 256 + (fk + 4 * v) * 16 + fi] = Mres[v];
+    }
+    store_tile(T, k, k);
+  };
+  if (fw) Mcur = factor_diag(Tcur, 0);
+  PKT(1)
+  __syncthreads();
+  PKT(2)
+#pragma unroll 1
+  for (int k = 0; k + 1 < NT; ++k) {
+    const double* mi = Mi[k & 1];
+    double* pn = Pn[k & 1];
+    if (fw) publish_diag(Tcur, Mcur, k);
+    else {
+      // 2. row panel: U[k, ti] = inv(L_kk) A[k, ti]
+#pragma unroll
+      for (int s = 0; s < NSO; ++s) {
+        if (tj_[s] == k) {    // wave-uniform
+          d4 X = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) X = __builtin_amdgcn_mfma_f64_16x16x4f64(mi[fi * 17 + 4 * ks + fk], S[s][ks], X, 0, 0, 0);
+          S[s] = X;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) pn[(fk + 4 * v) * PS + 16 * ti_[s] + fi] = X[v];
+        }
+      }
+    }
+    PKT(3)
+    __syncthreads();
+    PKT(4)
+    // 3. trailing update; wavefront 0: the next diagonal tile, its factorisation, then its other diagonal tiles
+    auto update = [&](d4& C, int ti, int tj) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) C = __builtin_amdgcn_mfma_f64_16x16x4f64(-pn[(4 * ks + fk) * PS + 16 * tj + fi], pn[(4 * ks + fk) * PS + 16 * ti + fi], C, 0, 0, 0);
+      asm volatile("" ::: "memory");   // the operand loads of the next tile stay behind this one's (all of a wavefront's tiles hoisted at once: spills)
+    };
+    if (fw) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) Tcur[v] = Dg[k + 1][v][lane];
+      update(Tcur, k + 1, k + 1);
+      Mcur = factor_diag(Tcur, k + 1);   // the chain everybody waits for
+      PKT(1)
+      for (int s = k + 2; s < NT; ++s) {
+        d4 C;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) C[v] = Dg[s][v][lane];
+        update(C, s, s);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Dg[s][v][lane] = C[v];
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < NSO; ++s) {
+        if (tj_[s] == k) store_tile(S[s], ti_[s], k);        // the solved panel tile, off the barrier-to-barrier path
+        else if (tj_[s] > k && ti_[s] >= 0) update(S[s], ti_[s], tj_[s]);
+      }
+    }
+    PKT(5)
+    __syncthreads();
+    PKT(2)
+  }
+  if (fw) publish_diag(Tcur, Mcur, NT - 1);
+  if (tid == 0) info[blockIdx.x] = bad;
+#ifdef LVX_POTRF_KT
+  PKT(6)
+  if (lane == 0 && blockIdx.x == 0) printf("PKT b %d wv %d: load %lld factor %lld syncA %lld panel %lld syncB %lld trail %lld store %lld chol16 %lld total %lld\n", b, wv, pkt_[0], pkt_[1], pkt_[2], pkt_[3], pkt_[4], pkt_[5], pkt_[6], pkt_[7], pkt_now() - pkts_);
+#endif
+}
+static bool potrf_reg_ok(const lvx_ctx* c, int b) { return c->sw.bcr_rocsolver_potrf == 0 && c->sw.bcr_potrf_lds == 0 && b <= 208; }
+template <int NT> static void launch_potrf_reg(lvx_ctx* c, double* D, int b, long long strideD, int* info, int batch, double* LI, long long strideLI) {
+  hipLaunchKernelGGL(k_potrf_reg<NT>, dim3((unsigned)batch), dim3(64 * POTRF_REG_NW), 0, c->stream, D, b, strideD, info, LI, strideLI);
+}
 // potrf of `batch` blocks: own kernel when the triangle fits into LDS, rocSOLVER otherwise (or with LVX_BCR_ROCSOLVER_POTRF)
 static size_t potrf_lds_bytes(int b) { return ((size_t)b * (b + 1) / 2 + 16 + 16 * 17) * 8; }
 // the own Cholesky kernel serves this block size (and so produces the diagonal-triangle inverses the triangular solves use)
-static bool potrf_own(const lvx_ctx* c, int b) { return c->sw.bcr_rocsolver_potrf == 0 && potrf_lds_bytes(b) <= 159 * 1024; }
+static bool potrf_own(const lvx_ctx* c, int b) { return potrf_reg_ok(c, b) || (c->sw.bcr_rocsolver_potrf == 0 && potrf_lds_bytes(b) <= 159 * 1024); }
 static int potrf_batched(lvx_ctx* c, rocblas_handle h, double* D, int b, long long strideD, int* info, int batch, double* LI, long long strideLI) {
   const size_t lds = potrf_lds_bytes(b);
   if (!potrf_own(c, b)) {
     LVX_BLAS(c, rocsolver_dpotrf_strided_batched(h, rocblas_fill_lower, b, D, b, (rocblas_stride)strideD, info, batch));
+    return LVX_OK;
+  }
+  if (potrf_reg_ok(c, b)) {
+    if (b <= 64) launch_potrf_reg<4>(c, D, b, strideD, info, batch, LI, strideLI);
+    else if (b <= 128) launch_potrf_reg<8>(c, D, b, strideD, info, batch, LI, strideLI);
+    else if (b <= 192) launch_potrf_reg<12>(c, D, b, strideD, info, batch, LI, strideLI);
+    else launch_potrf_reg<13>(c, D, b, strideD, info, batch, LI, strideLI);
+    LVX_HIP(c, hipGetLastError());
     return LVX_OK;
   }
   LVX_HIP(c, hipFuncSetAttribute((const void*)k_potrf_batched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
