@@ -251,6 +251,189 @@ static int launch_trsm_reg(lvx_ctx* c, const double* L, int b, long long strideL
   return LVX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Forward solve with the factor RESIDENT IN LDS (the default when it fits: b <= 192 and the diagonal-triangle inverses exist).  k_trsm_reg streams L through a
+// 16-column LDS panel: two block barriers per panel, one trip to global memory per panel that the ~1.7 k cycles of a panel's MFMAs do not cover (43 us for a single
+// block = 12 panels x 3.5 us), and every 64 vectors load the factor again.  Here a workgroup of 8 wavefronts (128 vectors) loads the sub-diagonal part of L once
+// (the 16 x 16 diagonal triangles are never needed: their inverses come from the Cholesky kernel, four values per lane and panel straight from global memory), and
+// after ONE barrier every wavefront runs its 12 panels on its own: 4 dependent MFMAs for the panel (x_p = inv(L_pp) w_p), then one rank-16 update per tile below.
+// Vectors that are contiguous along their elements (Y columns, right-hand sides) are loaded with the lanes along the elements and transposed through a per-wave LDS
+// tile (they were 8-byte gathers at 1440-byte stride).  LDS: sum over panels of 16 x (b_pad - 16 (p + 1)) doubles = 118 KB at b = 180, + 17 KB of transpose tiles.
+// ---------------------------------------------------------------------------------------------------------
+// The three problem sets of a BCR level that share the factor C_k: the rows of X+_k, the columns of Y_k (k >= 1) and the right-hand sides of block k.  A set is
+// `nvec` vectors, element i of vector v at V[v * sv + i * se] (+ batch stride).  blockIdx.y = block k, blockIdx.x = split: the block's 16-vector groups (X+ first,
+// then Y, then the right-hand sides) are cut into gridDim.x contiguous shares, and a workgroup runs its share 8 groups (one per wavefront) at a time against the
+// factor it loaded ONCE — on the wide levels two shares per block: one workgroup per (block, 128 vectors) loaded the factor four times per block and ran
+// load -> solve -> store back to back with nothing to overlap them (33 us for 17 us of MFMAs); here the wavefronts drift apart after the first pass and one's
+// loads and stores run under the other's MFMAs.
+struct TrsmVecs { double* V; long long se, sv, strideV; int nvec; int first, cnt; };   // block k's entry of the set is e = k - first (Y: first = 1), present if 0 <= e < cnt
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_trsm_lds(const double* __restrict__ Lm, int b, long long strideL, const double* __restrict__ LIm, long long strideLI, TrsmVecs s0, TrsmVecs s1, TrsmVecs s2, int nblk) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, lane = tid & 63, fk = lane >> 4, fi = lane & 15;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k = blockIdx.y;
+  const int ntb = (b + 15) >> 4, bp = 16 * ntb;
+  double* Tw = lds + wv * (16 * 17);                  // this wavefront's transpose tile
+  double* Lp = lds + NW * 16 * 17;           // panels: [16][R_p | 1], R_p = bp - 16 (p + 1)
+  const double* L = Lm + (size_t)k * strideL;
+  const double* LI = LIm + (size_t)k * strideLI;
+  // this block's 16-vector groups
+  const int g0n = (k - s0.first >= 0 && k - s0.first < s0.cnt && s0.nvec > 0) ? (s0.nvec + 15) >> 4 : 0;
+  const int g1n = (k - s1.first >= 0 && k - s1.first < s1.cnt && s1.nvec > 0) ? (s1.nvec + 15) >> 4 : 0;
+  const int g2n = (k - s2.first >= 0 && k - s2.first < s2.cnt && s2.nvec > 0) ? (s2.nvec + 15) >> 4 : 0;
+  const int ng = g0n + g1n + g2n;
+  const int per = (ng + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int gbeg = blockIdx.x * per, gend = min(ng, gbeg + per);
+  if (gbeg >= gend) return;
+  // 1. the factor's sub-diagonal panels -> LDS.  Thread (kk = tid >> 5, i = tid & 31 + 32 q): 256-byte runs along a column.
+  {
+    const int kk = tid >> 5, i5 = tid & 31;
+    int off = 0;
+#pragma unroll
+    for (int p = 0; p < NT; ++p) {
+      const int R = bp - 16 * (p + 1), PS = R | 1;
+      if (p < ntb && R > 0) {   // uniform
+        const int col = 16 * p + kk;
+        double v[(16 * (NT - 1) + 31) / 32];
+#pragma unroll
+        for (int q = 0; q < (16 * (NT - 1 - p) + 31) / 32; ++q) {
+          const int i = 16 * (p + 1) + i5 + 32 * q;
+          v[q] = (i < b && col < b && kk < 16) ? L[(size_t)col * b + i] : 0.0;   // (wavefronts 8 .. 11 of a 12-wavefront workgroup sit this out)
+        }
+#pragma unroll
+        for (int q = 0; q < (16 * (NT - 1 - p) + 31) / 32; ++q) {
+          const int r = i5 + 32 * q;
+          if (r < R && kk < 16) Lp[off + kk * PS + r] = v[q];
+        }
+        off += 16 * PS;
+      }
+    }
+  }
+  __syncthreads();
+  // every wavefront on its own from here on (measured and dropped: the next group's vectors requested before the current solve and picked up after it —
+  // 96 more live registers, spills, 468 instead of 445 us on the widest level)
+  const int g = gbeg + wv;     // one pass: the launcher gives a workgroup at most 8 groups (a loop over passes here cost 110 more registers and spilled)
+  if (g < gend) {
+    const TrsmVecs& S = g < g0n ? s0 : (g < g0n + g1n ? s1 : s2);
+    const int gl = g < g0n ? g : (g < g0n + g1n ? g - g0n : g - g0n - g1n);
+    const int vbase = 16 * gl, nvec = S.nvec;
+    const long long se = S.se, sv = S.sv;
+    double* Vb = S.V + (size_t)(k - S.first) * S.strideV;
+    auto wave_sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+    // 2. 16 vectors as accumulator tiles (tile t: rows 16 t .. 16 t + 15; col = lane & 15 = vector, row = (lane >> 4) + 4 reg)
+    const bool along_elems = se == 1 && sv != 1;
+    d4 W[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (along_elems) {
+        double x[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { const int vec = vbase + fk + 4 * v, i = 16 * t + fi; x[v] = (vec < nvec && i < b) ? Vb[(size_t)vec * sv + i] : 0.0; }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Tw[(fk + 4 * v) * 17 + fi] = x[v];          // [vector][element]
+        wave_sync();
+#pragma unroll
+        for (int v = 0; v < 4; ++v) W[t][v] = Tw[fi * 17 + fk + 4 * v];
+        wave_sync();
+      } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { const int vec = vbase + fi, i = 16 * t + fk + 4 * v; W[t][v] = (vec < nvec && i < b) ? Vb[(size_t)vec * sv + (size_t)i * se] : 0.0; }
+      }
+    }
+#ifndef LVX_TRSM_NO_COMPUTE
+    // 3. the solve
+    double mi[4], mn[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) mi[ks] = LI[fi * 16 + 4 * ks + fk];
+    int off = 0;
+#pragma unroll
+    for (int p = 0; p < NT; ++p) {
+      if (p < ntb) {   // uniform
+        if (p + 1 < ntb) {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) mn[ks] = LI[(size_t)(p + 1) * 256 + fi * 16 + 4 * ks + fk];
+        }
+        d4 X = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) X = __builtin_amdgcn_mfma_f64_16x16x4f64(mi[ks], W[p][ks], X, 0, 0, 0);
+        W[p] = X;
+        const int R = bp - 16 * (p + 1), PS = R | 1;
+        const double* P = Lp + off;
+#pragma unroll
+        for (int t = p + 1; t < NT; ++t) {
+          if (t < ntb) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) W[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-P[(4 * ks + fk) * PS + 16 * (t - p - 1) + fi], X[ks], W[t], 0, 0, 0);
+          }
+        }
+        if (R > 0) off += 16 * PS;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) mi[ks] = mn[ks];
+      }
+    }
+#endif
+    // 4. back
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (along_elems) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Tw[fi * 17 + fk + 4 * v] = W[t][v];            // [vector][element]
+        wave_sync();
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { const int vec = vbase + fk + 4 * v, i = 16 * t + fi; if (vec < nvec && i < b) Vb[(size_t)vec * sv + i] = Tw[(fk + 4 * v) * 17 + fi]; }
+        wave_sync();
+      } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { const int vec = vbase + fi, i = 16 * t + fk + 4 * v; if (vec < nvec && i < b) Vb[(size_t)vec * sv + (size_t)i * se] = W[t][v]; }
+      }
+    }
+  }
+}
+static size_t trsm_lds_bytes(int b, int NW) {
+  const int ntb = (b + 15) / 16, bp = 16 * ntb;
+  size_t d = (size_t)NW * 16 * 17;
+  for (int p = 0; p < ntb; ++p) { const int R = bp - 16 * (p + 1); if (R > 0) d += (size_t)16 * (R | 1); }
+  return d * 8;
+}
+static bool trsm_lds_ok(const lvx_ctx* c, int b) { return c->sw.bcr_trsm_stream == 0 && b <= 192 && trsm_lds_bytes(b, 8) <= 160 * 1024; }
+// the sets in the TrsmSet convention of trsv_batched (first set: batch entries 0 .. batch - 1 against L + e strideL; a set whose factor pointer starts one block
+// further — the Y solves — belongs to block e + 1)
+template <int NT, int NW>
+static int launch_trsm_lds_nw(lvx_ctx* c, const double* L, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, int batch, const double* LI, long long strideLI,
+                           const TrsmSet* second, const TrsmSet* third) {
+  const size_t lds = trsm_lds_bytes(b, NW);
+  LVX_HIP(c, hipFuncSetAttribute((const void*)k_trsm_lds<NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  auto live = [](const TrsmSet* t) { return t && t->batch > 0 && t->nvec > 0; };
+  TrsmVecs v[3] = {{V, se, sv, strideV, nvec, 0, batch}, {nullptr, 0, 0, 0, 0, 0, 0}, {nullptr, 0, 0, 0, 0, 0, 0}};
+  int nblk = batch, ng = (nvec + 15) / 16;
+  int slot = 1;
+  for (const TrsmSet* t : {second, third}) {
+    if (live(t)) {
+      const int first = strideL ? (int)((t->Lm - L) / strideL) : 0;     // which block this set's first entry solves against
+      v[slot] = TrsmVecs{t->V, t->se, t->sv, t->strideV, t->nvec, first, t->batch};
+      nblk = std::max(nblk, first + t->batch);
+      ng += (t->nvec + 15) / 16;
+    }
+    ++slot;
+  }
+  // shares per block: one pass of the 8 wavefronts per workgroup (measured: fewer, longer shares — the factor loaded once or twice per block instead of four times —
+  // are no faster, 445 vs 428 us on the widest level: with one workgroup per CU its load, solve and store phases do not overlap either way)
+  int splits = std::max(1, (ng + NW - 1) / NW);
+  hipLaunchKernelGGL((k_trsm_lds<NT, NW>), dim3((unsigned)splits, (unsigned)nblk), dim3(64 * NW), lds, c->stream, L, b, strideL, LI, strideLI, v[0], v[1], v[2], nblk);
+  LVX_HIP(c, hipGetLastError());
+  return LVX_OK;
+}
+
+// 12 wavefronts per workgroup (three per SIMD: a wavefront's 4-MFMA panel chains hide behind two others' updates; 140 registers fit) when the LDS holds their
+// transpose tiles next to the factor, 8 otherwise
+template <int NT>
+static int launch_trsm_lds(lvx_ctx* c, const double* L, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, int batch, const double* LI, long long strideLI,
+                           const TrsmSet* second, const TrsmSet* third) {
+  if (trsm_lds_bytes(b, 12) <= 160 * 1024 && c->sw.bcr_trsm_nw != 8) return launch_trsm_lds_nw<NT, 12>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, LI, strideLI, second, third);
+  return launch_trsm_lds_nw<NT, 8>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, LI, strideLI, second, third);
+}
+
 // LI / strideLI: the diagonal-triangle inverses of the factors (c->bcr_linv: the own Cholesky kernel produced them), or null
 template <bool TRANS>
 static int trsv_batched(lvx_ctx* c, const double* L, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, int batch, const double* LI, long long strideLI,
@@ -259,6 +442,11 @@ static int trsv_batched(lvx_ctx* c, const double* L, int b, long long strideL, d
     for (const TrsmSet* t : {second, third}) if (t && t->batch > 0 && t->nvec > 0)
       return trsv_batched<TRANS>(c, t->Lm, b, t->strideL, t->V, t->se, t->sv, t->strideV, t->nvec, t->batch, t->LI, t->strideLI, t == second ? third : nullptr);
     return LVX_OK;
+  }
+  if (LI && !TRANS && trsm_lds_ok(c, b)) {   // every set of the launch has its inverses (bcr_linv is per plan)
+    if (b <= 64) return launch_trsm_lds<4>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, LI, strideLI, second, third);
+    if (b <= 128) return launch_trsm_lds<8>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, LI, strideLI, second, third);
+    return launch_trsm_lds<12>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, LI, strideLI, second, third);
   }
   if (LI) {
     if (b <= 128) return launch_trsm_reg<TRANS, 8, true>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, LI, strideLI, second, third);
