@@ -35,8 +35,8 @@ FP64_PEAK_TFLOPS = 78.6      # MI355X FP64: vector 78.6 TFLOP/s = matrix (v_mfma
 # correction was calibrated on).  Reads: 56 B of row inputs per block (t, point, row-ordered plane) = 56 MB would be the cold figure, the
 # counter sees 33 MB (the rest hits the 256 MB Infinity Cache from the previous pass); writes: the accumulator flushes (one atomic per touched
 # band / border entry per workgroup, 1954 workgroups) — the register-spill scratch of the earlier rounds (232 MB) is gone.
-PMC_TRAFFIC_BYTES = {"surfel": 89.2e6, "imu": 49.9e6}   # surfel: 32.8 MB fetched + 56.5 MB written; fused IMU kernel: 8.95 + 40.96 MB (accumulator flushes)   # constants copied from the profile named below, not measured by this run (filled per kernel by tools/profile_round.sh runs)
-PMC_SOURCE = "profiles/r02c_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per dispatch)"
+PMC_TRAFFIC_BYTES = {"surfel": 89.3e6, "imu": 49.9e6}   # surfel: 32.8 MB fetched + 56.5 MB written (max over dispatches with normal equations); fused IMU kernel: 8.94 + 40.96 MB (accumulator flushes)   # constants copied from the profile named below, not measured by this run (filled per kernel by tools/profile_round.sh runs)
+PMC_SOURCE = "profiles/r03d_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per dispatch)"
 BYTES_PER_EVAL = {"imu": 32, "surfel": 60, "reproj": 60}
 FLOPS_PER_EVAL = {"imu": 4e3, "surfel": 9e3, "reproj": 11e3}
 

@@ -943,15 +943,19 @@ __global__ __launch_bounds__(BACK_NT) void k_bcr_back_level(const double* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Schur updates of a BCR level in ONE launch (five rocBLAS strided-batched GEMMs before: 64 x 64 Tensile tiles at ~17 TFLOP/s, a full GEMM where only the lower
-// triangle of D is read, 8 - 10 us each on the narrow levels):
-//   D_{j+s} -= X+_k X+_k^T + Y_{k+1}^T Y_{k+1}   (both updates of a diagonal block by the same workgroup: one read-modify-write, lower tiles only)
+// Schur updates of a BCR level in ONE launch (five rocBLAS strided-batched GEMMs before: 64 x 64 Tensile tiles, a full GEMM where only the lower triangle of D is
+// read, 8 - 10 us each on the narrow levels):
+//   D_{j+s} -= X+_k X+_k^T + Y_{k+1}^T Y_{k+1}   (both updates of a diagonal block by the same workgroup: one read-modify-write, LOWER tiles only)
 //   A_{j+s,j-s} = -X+_k Y_k                         (next level's coupling)
 //   b_{j+s} -= X+_k y_k + Y_{k+1}^T y_{k+1}         (right-hand sides riding along)
-// A workgroup (8 wavefronts) owns a 64-column panel of one output: the K loop stages a [16][192] row panel and a [16][64] column panel in LDS (register prefetch
-// of the next chunk), wavefront (rg, ch) keeps RT x 2 accumulator tiles (row tiles rg, rg + 4, .. x two 16-column tiles).  The MFMA computes the TRANSPOSED
-// tile (A operand = column panel, B operand = row panel) so that a lane's accumulator entries are contiguous along the rows of the column-major outputs.
-// FP64 MFMA issues once per 64 cycles per SIMD (tools/probes/mfma64_probe.hip): 5 LDS reads per 6 MFMAs keep the pipe, not the LDS, the bound.
+// One workgroup of 12 wavefronts per (block, output): the output's 16 x 16 tiles are dealt round-robin to the wavefronts into statically indexed accumulators
+// (D: 78 lower tiles = 7 per wavefront, coupling: 144 = 12, right-hand sides: 48 = 4), the K loop stages 16-deep chunks of the row panel [16][192] and the column
+// panel in LDS, double-buffered (one barrier per chunk; the next chunk's global loads are issued before the MFMAs of the current one).  X X^T and Y^T Y take both
+// operands from the row panel.  Every MFMA reads its two operands from LDS (no register reuse across tiles: 64 B per clock and CU, half the LDS rate) — what matters
+// is that three wavefronts per SIMD keep the matrix pipe (64 cycles per FP64 MFMA) busy across the barrier.  The MFMA computes the TRANSPOSED tile (A operand = column
+// panel, B operand = row panel) so that a lane's accumulator entries are contiguous along the rows of the column-major outputs.
+// (First version: 64-column output panels, 8 wavefronts with 3 x 2 register-blocked tiles, single-buffered with two barriers per chunk: level with rocBLAS at 32 % of the
+// matrix pipe's rate.)
 // ---------------------------------------------------------------------------------------------------------
 struct SchurArgs {
   const double* Gl; long long sG, bb;       // X+_k = Gl + k sG, Y_k = Gl + (k - 1) sG + bb (k >= 1)
@@ -960,159 +964,130 @@ struct SchurArgs {
   const double* Zj; double* Zr; long long sZ; int ldz, nrhs;   // right-hand sides (null: none)
   int b, n2;
 };
-template <int RT, int CT>
-__global__ __launch_bounds__(512) void k_bcr_schur(SchurArgs a) {
-  // CT column tiles per wavefront: 2 (64-column panels, 2 NP + 1 workgroups per block: the narrow levels need the workgroups) or 6 (one 192-column panel: the operand
-  // traffic per block drops from 352 to 160 KB per 16-deep chunk pair — at 64 columns the wide levels ran at the L2's bandwidth, 2.1 GB per launch, like the Tensile kernels)
-  constexpr int PR = 64 * RT, PSA = PR | 1, CW = 32 * CT, PSB = CW | 1, KC = 16, NRA = PR * KC / 512, NRB = CW * KC / 512;
-  __shared__ double As[KC * PSA];     // row panel    [kk][i]
-  __shared__ double Bs[KC * PSB];     // column panel [kk][j] (D: the row panel serves as both)
-  const int b = a.b, NP = (b + CW - 1) / CW;
-  const int k = blockIdx.y, item = blockIdx.x;
-  const int type = item < NP ? 0 : (item < 2 * NP ? 1 : 2), jp = type == 2 ? 0 : item % NP;
-  if (type == 1 && k == 0) return;
+#define SCHUR_NW 12
+// TYPE 0: D (lower tiles), 1: coupling, 2: right-hand sides.  NTB: 16 x 16 tiles per block side (b <= 16 NTB).  ZT: column tiles of the right-hand sides (nrhs <= 16 ZT)
+template <int NTB, int TYPE, int ZT>
+__device__ __forceinline__ void schur_body(const SchurArgs& a, double* lds) {
+  constexpr int NT = SCHUR_NW * 64, PR = 16 * NTB, PSA = PR | 1, CW = TYPE == 2 ? 16 * ZT : PR, PSB = CW | 1, KC = 16;
+  constexpr int NTILE = TYPE == 0 ? NTB * (NTB + 1) / 2 : (TYPE == 1 ? NTB * NTB : NTB * ZT), NSLOT = (NTILE + SCHUR_NW - 1) / SCHUR_NW;
+  constexpr int NRA = (PR * KC + NT - 1) / NT, NRB = TYPE == 0 ? 0 : (CW * KC + NT - 1) / NT;
+  constexpr int BUF = KC * PSA + (TYPE == 0 ? 0 : KC * PSB);
+  const int b = a.b, k = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, fk = lane >> 4, fi = lane & 15;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ch = wv & 1, rg = wv >> 1;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const double* X = a.Gl + (size_t)k * a.sG;
   const double* Yk = k >= 1 ? a.Gl + (size_t)(k - 1) * a.sG + a.bb : nullptr;
   const double* Yn = k + 1 < a.n2 ? a.Gl + (size_t)k * a.sG + a.bb : nullptr;
-  // products: row source (ptr, ld, transposed), column source (ptr, ld, transposed, valid columns), K = b
-  const double* rsrc[2]; const double* csrc[2]; int rld[2], cld[2]; bool rtr[2], ctr[2]; int np = 1, ncol = b;
+  // products: row source (ptr, transposed?), column source (ptr, ld; always contiguous along K), K = b
+  const double* rsrc[2] = {X, Yn}; const bool rtr[2] = {false, true};
+  const double* csrc[2] = {nullptr, nullptr}; int cld = b, np = 1, ncol = b;
   double* C; int ldc; bool sub;
-  const bool self = type == 0;        // X X^T and Y^T Y: the column panel is a slice of the row panel
-  if (type == 0) {
-    rsrc[0] = X; rld[0] = b; rtr[0] = false; csrc[0] = X; cld[0] = b; ctr[0] = false;
-    if (Yn) { rsrc[1] = Yn; rld[1] = b; rtr[1] = true; csrc[1] = Yn; cld[1] = b; ctr[1] = true; np = 2; }
-    C = a.Dr + (size_t)k * a.sD; ldc = b; sub = true;
-  } else if (type == 1) {
-    rsrc[0] = X; rld[0] = b; rtr[0] = false; csrc[0] = Yk; cld[0] = b; ctr[0] = true;
-    C = a.Gn + (size_t)(k - 1) * a.bb; ldc = b; sub = false;
-  } else {
-    rsrc[0] = X; rld[0] = b; rtr[0] = false; csrc[0] = a.Zj + (size_t)k * a.sZ; cld[0] = a.ldz; ctr[0] = true;
-    if (Yn) { rsrc[1] = Yn; rld[1] = b; rtr[1] = true; csrc[1] = a.Zj + (size_t)(k + 1) * a.sZ; cld[1] = a.ldz; ctr[1] = true; np = 2; }
-    C = a.Zr + (size_t)k * a.sZ; ldc = a.ldz; sub = true; ncol = a.nrhs;
+  if (TYPE == 0) { np = Yn ? 2 : 1; C = a.Dr + (size_t)k * a.sD; ldc = b; sub = true; }
+  else if (TYPE == 1) { csrc[0] = Yk; C = a.Gn + (size_t)(k - 1) * a.bb; ldc = b; sub = false; }
+  else { csrc[0] = a.Zj + (size_t)k * a.sZ; csrc[1] = a.Zj + (size_t)(k + 1) * a.sZ; cld = a.ldz; np = Yn ? 2 : 1; C = a.Zr + (size_t)k * a.sZ; ldc = a.ldz; sub = true; ncol = a.nrhs; }
+  // this wavefront's tiles: slot s <-> tile t = s * 12 + wv -> (rt, ct)
+  int rt_[NSLOT], ct_[NSLOT];
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) {
+    const int t = min(s * SCHUR_NW + wv, NTILE - 1);      // the last slot's spare wavefronts recompute the last tile (and do not store it)
+    if (TYPE == 0) { int r = 0; while (((r + 1) * (r + 2)) >> 1 <= t) ++r; rt_[s] = r; ct_[s] = t - ((r * (r + 1)) >> 1); }
+    else if (TYPE == 1) { rt_[s] = t / NTB; ct_[s] = t % NTB; }
+    else { rt_[s] = t / ZT; ct_[s] = t % ZT; }
   }
-  const int j0 = CW * jp;
-  // tiles this wavefront computes: row tile rt = rg + 4 r, column tile (inside the panel) lt = ch + 2 c — interleaved so that the lower-triangle tiles of D
-  // spread evenly over the two column groups; D: lower tiles only
-  bool need[RT][CT];
+  d4 acc[NSLOT];
 #pragma unroll
-  for (int r = 0; r < RT; ++r)
-#pragma unroll
-    for (int c = 0; c < CT; ++c) {
-      const int rt = rg + 4 * r, ct = (CW / 16) * jp + ch + 2 * c;
-      need[r][c] = 16 * rt < b && 16 * ct < ncol && (type != 0 || rt >= ct);
-    }
-  bool rneed[RT];
-#pragma unroll
-  for (int r = 0; r < RT; ++r) { rneed[r] = false;
-#pragma unroll
-    for (int c = 0; c < CT; ++c) rneed[r] = rneed[r] || need[r][c]; }
-  d4 acc[RT][CT];
-#pragma unroll
-  for (int r = 0; r < RT; ++r)
-#pragma unroll
-    for (int c = 0; c < CT; ++c) acc[r][c] = d4{0.0, 0.0, 0.0, 0.0};
-  double pa[NRA], pb[NRB];
-  // element e of a panel with P indices: natural source (contiguous along the index): i = e % P, kk = e / P; transposed source (contiguous along K): kk = e % 16, i = e / 16
+  for (int s = 0; s < NSLOT; ++s) acc[s] = d4{0.0, 0.0, 0.0, 0.0};
+  double pa[NRA], pb[NRB > 0 ? NRB : 1];
+  // row panel element e: natural source (X: contiguous along the rows): i = e % PR, kk = e / PR; transposed source (Y^T: contiguous along K): kk = e % 16, i = e / 16.
+  // column panel: always contiguous along K (Y_k columns, right-hand sides): kk = e % 16, j = e / 16
   auto fetch = [&](int p, int k0) {
-    const double* rs = rsrc[p]; const double* cs = csrc[p];
-    const int rl = rld[p], cl = cld[p];
-    const bool rt_ = rtr[p], ct_ = ctr[p];
+    const double* rs = rsrc[p];
+    const bool tr = rtr[p];
 #pragma unroll
     for (int q = 0; q < NRA; ++q) {
-      const int e = tid + 512 * q;
-      const int i = rt_ ? e >> 4 : e % PR, kk = rt_ ? e & 15 : e / PR;
-      const bool ok = i < b && k0 + kk < b;
-      const double v = rs[ok ? (rt_ ? (size_t)i * rl + k0 + kk : (size_t)(k0 + kk) * rl + i) : 0];
+      const int e = tid + NT * q;
+      const int i = tr ? e >> 4 : e % PR, kk = tr ? e & 15 : e / PR;
+      const bool ok = e < PR * KC && i < b && k0 + kk < b;
+      const double v = rs[ok ? (tr ? (size_t)i * b + k0 + kk : (size_t)(k0 + kk) * b + i) : 0];
       pa[q] = ok ? v : 0.0;
     }
-    if (!self) {
+    if (TYPE != 0) {
+      const double* cs = csrc[p];
 #pragma unroll
       for (int q = 0; q < NRB; ++q) {
-        const int e = tid + 512 * q;
-        const int j = ct_ ? e >> 4 : e % CW, kk = ct_ ? e & 15 : e / CW;
-        const bool ok = j0 + j < ncol && k0 + kk < b;
-        const double v = cs[ok ? (ct_ ? (size_t)(j0 + j) * cl + k0 + kk : (size_t)(k0 + kk) * cl + j0 + j) : 0];
+        const int e = tid + NT * q;
+        const int j = e >> 4, kk = e & 15;
+        const bool ok = e < CW * KC && j < ncol && k0 + kk < b;
+        const double v = cs[ok ? (size_t)j * cld + k0 + kk : 0];
         pb[q] = ok ? v : 0.0;
       }
     }
   };
-  auto commit = [&](int p) {
-    const bool rt_ = rtr[p], ct_ = ctr[p];
+  auto commit = [&](int p, double* buf) {
+    const bool tr = rtr[p];
+    double* As = buf; double* Bs = buf + KC * PSA;
 #pragma unroll
-    for (int q = 0; q < NRA; ++q) { const int e = tid + 512 * q; const int i = rt_ ? e >> 4 : e % PR, kk = rt_ ? e & 15 : e / PR; As[kk * PSA + i] = pa[q]; }
-    if (!self) {
+    for (int q = 0; q < NRA; ++q) { const int e = tid + NT * q; const int i = tr ? e >> 4 : e % PR, kk = tr ? e & 15 : e / PR; if (e < PR * KC) As[kk * PSA + i] = pa[q]; }
+    if (TYPE != 0) {
 #pragma unroll
-      for (int q = 0; q < NRB; ++q) { const int e = tid + 512 * q; const int j = ct_ ? e >> 4 : e % CW, kk = ct_ ? e & 15 : e / CW; Bs[kk * PSB + j] = pb[q]; }
+      for (int q = 0; q < NRB; ++q) { const int e = tid + NT * q; if (e < CW * KC) Bs[(e & 15) * PSB + (e >> 4)] = pb[q]; }
     }
   };
-  const double* cpan = self ? As + j0 : Bs;
-  const int cps = self ? PSA : PSB;
   const int nchunk = (b + KC - 1) / KC, total = np * nchunk;
   fetch(0, 0);
+  commit(0, lds);
   for (int it = 0; it < total; ++it) {
-    const int p = it >= nchunk ? 1 : 0;
-    __syncthreads();                 // everybody is done with the previous chunk's panels
-    commit(p);
-    __syncthreads();
-    if (it + 1 < total) { const int pn = it + 1 >= nchunk ? 1 : 0; fetch(pn, (it + 1 - pn * nchunk) * KC); }
+    __syncthreads();                 // chunk `it` is in its buffer; everybody is done with the other buffer (chunk it - 1)
+    const bool more = it + 1 < total;
+    if (more) { const int pn = it + 1 >= nchunk ? 1 : 0; fetch(pn, (it + 1 - pn * nchunk) * KC); }
+    const double* As = lds + (it & 1) * BUF;
+    const double* Bs = TYPE == 0 ? As : As + KC * PSA;
+    constexpr int cps = TYPE == 0 ? PSA : PSB;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      double fa[CT], fb[RT];
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int c = 0; c < CT; ++c) fa[c] = cpan[(4 * ks + fk) * cps + 16 * (ch + 2 * c) + fi];
-#pragma unroll
-      for (int r = 0; r < RT; ++r) fb[r] = As[(4 * ks + fk) * PSA + 16 * (rg + 4 * r) + fi];
-      // one uniform branch per row tile, not per MFMA (a branch per MFMA makes every MFMA a basic block of its own: 32 % of the matrix pipe's rate against 48 %);
-      // a row tile with any needed column tile computes all CT of them (the diagonal 64 x 64 block of D wastes 6 of its 16 tiles)
-#pragma unroll
-      for (int r = 0; r < RT; ++r) {
-        if (!rneed[r]) continue;
-#pragma unroll
-        for (int c = 0; c < CT; ++c) acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[c], fb[r], acc[r][c], 0, 0, 0);
-      }
-    }
+      for (int s = 0; s < NSLOT; ++s)
+        acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bs[(4 * ks + fk) * cps + 16 * ct_[s] + fi], As[(4 * ks + fk) * PSA + 16 * rt_[s] + fi], acc[s], 0, 0, 0);
+    if (more) commit(it + 1 >= nchunk ? 1 : 0, lds + ((it + 1) & 1) * BUF);
   }
   // accumulator (reg v, lane (fk, fi)) = sum for column j = 16 ct + fk + 4 v, row i = 16 rt + fi
 #pragma unroll
-  for (int r = 0; r < RT; ++r)
+  for (int s = 0; s < NSLOT; ++s) {
+    if (s * SCHUR_NW + wv >= NTILE) continue;
+    const int i = 16 * rt_[s] + fi;
 #pragma unroll
-    for (int c = 0; c < CT; ++c) {
-      if (!need[r][c]) continue;
-      const int i = 16 * (rg + 4 * r) + fi;
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int j = j0 + 16 * (ch + 2 * c) + fk + 4 * v;
-        if (i < b && j < ncol && (type != 0 || i >= j)) {
-          double* dst = C + (size_t)j * ldc + i;
-          *dst = sub ? *dst - acc[r][c][v] : -acc[r][c][v];
-        }
+    for (int v = 0; v < 4; ++v) {
+      const int j = 16 * ct_[s] + fk + 4 * v;
+      if (i < b && j < ncol && (TYPE != 0 || i >= j)) {
+        double* dst = C + (size_t)j * ldc + i;
+        *dst = sub ? *dst - acc[s][v] : -acc[s][v];
       }
     }
-}
-// off by default: measured level with level against the five rocBLAS launches (1.50 vs 1.35 ms per solve at config 4: 32 - 48 % of the matrix pipe's rate against
-// Tensile's ~75 %, which the halved work on D does not make up for); kept behind LVX_BCR_OWN_SCHUR=1 with its parity test as the base of a tuned version
-static bool schur_own(const lvx_ctx* c, int b) { return c->sw.bcr_own_schur != 0 && !c->sw.bcr_syrk && b <= 256; }
-template <int RT> static void launch_schur(lvx_ctx* c, const SchurArgs& a) {
-  const bool wide = a.n2 * 3 >= 200 || c->sw.bcr_schur_wide > 0;   // enough blocks to fill the chip with one workgroup per output
-  if constexpr (RT <= 3) {
-    if (wide && c->sw.bcr_schur_wide >= 0) {
-      const int NP = (a.b + 191) / 192;
-      hipLaunchKernelGGL((k_bcr_schur<RT, 6>), dim3((unsigned)(2 * NP + (a.Zj ? 1 : 0)), (unsigned)a.n2), dim3(512), 0, c->stream, a);
-      return;
-    }
   }
-  const int NP = (a.b + 63) / 64;
-  hipLaunchKernelGGL((k_bcr_schur<RT, 2>), dim3((unsigned)(2 * NP + (a.Zj ? 1 : 0)), (unsigned)a.n2), dim3(512), 0, c->stream, a);
 }
-static int schur_level(lvx_ctx* c, const SchurArgs& a) {
-  if (a.b <= 64) launch_schur<1>(c, a);
-  else if (a.b <= 128) launch_schur<2>(c, a);
-  else if (a.b <= 192) launch_schur<3>(c, a);
-  else launch_schur<4>(c, a);
+template <int NTB, int ZT>
+__global__ __launch_bounds__(64 * SCHUR_NW) void k_bcr_schur(SchurArgs a) {
+  extern __shared__ double lds[];
+  const int type = blockIdx.x;
+  if (type == 0) schur_body<NTB, 0, ZT>(a, lds);
+  else if (type == 1) { if (blockIdx.y >= 1) schur_body<NTB, 1, ZT>(a, lds); }
+  else schur_body<NTB, 2, ZT>(a, lds);
+}
+// off by default unless measured faster — see DESIGN.md 3.2
+static bool schur_own(const lvx_ctx* c, int b, int nrhs) { return c->sw.bcr_own_schur != 0 && !c->sw.bcr_syrk && b <= 208 && nrhs <= 64; }
+template <int NTB, int ZT> static int launch_schur(lvx_ctx* c, const SchurArgs& a) {
+  constexpr int PR = 16 * NTB, PSA = PR | 1;
+  const size_t lds = (size_t)2 * (16 * PSA + 16 * PSA) * 8;     // the coupling product is the largest: row panel + a full column panel, two buffers
+  LVX_HIP(c, hipFuncSetAttribute((const void*)k_bcr_schur<NTB, ZT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_bcr_schur<NTB, ZT>), dim3(a.Zj ? 3u : 2u, (unsigned)a.n2), dim3(64 * SCHUR_NW), lds, c->stream, a);
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
+}
+static int schur_level(lvx_ctx* c, const SchurArgs& a) {
+  if (a.b <= 64) return launch_schur<4, 4>(c, a);
+  if (a.b <= 128) return launch_schur<8, 4>(c, a);
+  if (a.b <= 192) return launch_schur<12, 4>(c, a);
+  return launch_schur<13, 4>(c, a);
 }
 
 int bcr_plan(lvx_ctx* c) {
@@ -1185,7 +1160,7 @@ int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_ra
     double* Zr = Z ? Z + (size_t)(2 * s - 1) * b : nullptr;
     const TrsmSet rsolve{Dj, sD, Zj, 1, ldz, sZ, Z ? nrhs : 0, Z ? n2 : 0, 0, LIj, sLI};                    // y_j = C_j^-1 b_j
     if ((rc = trsv_batched<false>(c, Dj, b, sD, Gl, /*se*/ b, /*sv*/ 1, sG, b, n2, LIj, sLI, &ysolve, &rsolve))) return rc;
-    if (schur_own(c, b)) {   // every Schur update of the level in one launch
+    if (schur_own(c, b, Z ? nrhs : 0)) {   // every Schur update of the level in one launch
       const SchurArgs sa{Gl, sG, (long long)bb, Dr, sD, Gn, Zj, Zr, sZ, ldz, Z ? nrhs : 0, b, n2};
       if ((rc = schur_level(c, sa))) return rc;
       continue;
