@@ -966,10 +966,10 @@ struct SchurArgs {
 };
 #define SCHUR_NW 12
 // TYPE 0: D (lower tiles), 1: coupling, 2: right-hand sides.  NTB: 16 x 16 tiles per block side (b <= 16 NTB).  ZT: column tiles of the right-hand sides (nrhs <= 16 ZT)
-template <int NTB, int TYPE, int ZT>
+template <int NTB, int TYPE, int ZT, int SPLIT>
 __device__ __forceinline__ void schur_body(const SchurArgs& a, double* lds) {
   constexpr int NT = SCHUR_NW * 64, PR = 16 * NTB, PSA = PR | 1, CW = TYPE == 2 ? 16 * ZT : PR, PSB = CW | 1, KC = 16;
-  constexpr int NTILE = TYPE == 0 ? NTB * (NTB + 1) / 2 : (TYPE == 1 ? NTB * NTB : NTB * ZT), NSLOT = (NTILE + SCHUR_NW - 1) / SCHUR_NW;
+  constexpr int NTILE = TYPE == 0 ? NTB * (NTB + 1) / 2 : (TYPE == 1 ? NTB * NTB : NTB * ZT), NSLOT = (NTILE + SCHUR_NW * SPLIT - 1) / (SCHUR_NW * SPLIT);   // SPLIT workgroups (blockIdx.z) share an output on the narrow levels
   constexpr int NRA = (PR * KC + NT - 1) / NT, NRB = TYPE == 0 ? 0 : (CW * KC + NT - 1) / NT;
   constexpr int BUF = KC * PSA + (TYPE == 0 ? 0 : KC * PSB);
   const int b = a.b, k = blockIdx.y;
@@ -989,7 +989,7 @@ __device__ __forceinline__ void schur_body(const SchurArgs& a, double* lds) {
   int rt_[NSLOT], ct_[NSLOT];
 #pragma unroll
   for (int s = 0; s < NSLOT; ++s) {
-    const int t = min(s * SCHUR_NW + wv, NTILE - 1);      // the last slot's spare wavefronts recompute the last tile (and do not store it)
+    const int t = min((s * SPLIT + (int)blockIdx.z) * SCHUR_NW + wv, NTILE - 1);      // the last slot's spare wavefronts recompute the last tile (and do not store it)
     if (TYPE == 0) { int r = 0; while (((r + 1) * (r + 2)) >> 1 <= t) ++r; rt_[s] = r; ct_[s] = t - ((r * (r + 1)) >> 1); }
     else if (TYPE == 1) { rt_[s] = t / NTB; ct_[s] = t % NTB; }
     else { rt_[s] = t / ZT; ct_[s] = t % ZT; }
@@ -999,38 +999,62 @@ __device__ __forceinline__ void schur_body(const SchurArgs& a, double* lds) {
   for (int s = 0; s < NSLOT; ++s) acc[s] = d4{0.0, 0.0, 0.0, 0.0};
   double pa[NRA], pb[NRB > 0 ? NRB : 1];
   // row panel element e: natural source (X: contiguous along the rows): i = e % PR, kk = e / PR; transposed source (Y^T: contiguous along K): kk = e % 16, i = e / 16.
-  // column panel: always contiguous along K (Y_k columns, right-hand sides): kk = e % 16, j = e / 16
-  auto fetch = [&](int p, int k0) {
-    const double* rs = rsrc[p];
-    const bool tr = rtr[p];
+  // column panel: always contiguous along K (Y_k columns, right-hand sides): kk = e % 16, j = e / 16.
+  // Everything that does not depend on the chunk is formed once (the first version rebuilt 64-bit addresses and bounds behind three branches per load, inside the K loop:
+  // ~40 instructions per load, as long as the chunk's MFMAs): element offset of (index, k = 0), whether the index exists, kk; per chunk only k = min(k0 + kk, b - 1) is added
+  // and a value beyond K is replaced by zero.
+  int ra_off[2][NRA], ra_kk[2][NRA], ra_lds[2][NRA]; bool ra_ok[2][NRA];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
 #pragma unroll
     for (int q = 0; q < NRA; ++q) {
       const int e = tid + NT * q;
+      const bool tr = rtr[p];
       const int i = tr ? e >> 4 : e % PR, kk = tr ? e & 15 : e / PR;
-      const bool ok = e < PR * KC && i < b && k0 + kk < b;
-      const double v = rs[ok ? (tr ? (size_t)i * b + k0 + kk : (size_t)(k0 + kk) * b + i) : 0];
-      pa[q] = ok ? v : 0.0;
+      ra_ok[p][q] = e < PR * KC && i < b;
+      ra_off[p][q] = ra_ok[p][q] ? (tr ? i * b : i) : 0;
+      ra_kk[p][q] = kk;
+      ra_lds[p][q] = e < PR * KC ? kk * PSA + i : -1;
+    }
+  int cb_off[NRB > 0 ? NRB : 1], cb_lds[NRB > 0 ? NRB : 1]; bool cb_ok[NRB > 0 ? NRB : 1];
+  const int ckk = tid & 15;      // NT is a multiple of 16: the same kk for every q
+#pragma unroll
+  for (int q = 0; q < NRB; ++q) {
+    const int e = tid + NT * q, j = e >> 4;
+    cb_ok[q] = e < CW * KC && j < ncol;
+    cb_off[q] = cb_ok[q] ? j * cld : 0;
+    cb_lds[q] = e < CW * KC ? ckk * PSB + j : -1;
+  }
+  // fetch only ISSUES the loads (clamped, always valid addresses) and notes which values count; the values are looked at in commit, after the chunk's MFMAs —
+  // with the select next to the load the compiler waited for every load on the spot (s_waitcnt vmcnt(0) eight times per chunk, nothing overlapped)
+  unsigned pmask = 0;
+  auto fetch = [&](int p, int k0) {
+    const double* rs = rsrc[p];
+    const int kstr = rtr[p] ? 1 : b;
+    pmask = 0;
+#pragma unroll
+    for (int q = 0; q < NRA; ++q) {
+      const int kq = k0 + ra_kk[p][q];
+      pa[q] = rs[ra_off[p][q] + min(kq, b - 1) * kstr];
+      pmask |= (ra_ok[p][q] && kq < b) ? (1u << q) : 0u;
     }
     if (TYPE != 0) {
       const double* cs = csrc[p];
+      const int kq = k0 + ckk, kc = min(kq, b - 1);
 #pragma unroll
       for (int q = 0; q < NRB; ++q) {
-        const int e = tid + NT * q;
-        const int j = e >> 4, kk = e & 15;
-        const bool ok = e < CW * KC && j < ncol && k0 + kk < b;
-        const double v = cs[ok ? (size_t)j * cld + k0 + kk : 0];
-        pb[q] = ok ? v : 0.0;
+        pb[q] = cs[cb_off[q] + kc];
+        pmask |= (cb_ok[q] && kq < b) ? (1u << (16 + q)) : 0u;
       }
     }
   };
   auto commit = [&](int p, double* buf) {
-    const bool tr = rtr[p];
     double* As = buf; double* Bs = buf + KC * PSA;
 #pragma unroll
-    for (int q = 0; q < NRA; ++q) { const int e = tid + NT * q; const int i = tr ? e >> 4 : e % PR, kk = tr ? e & 15 : e / PR; if (e < PR * KC) As[kk * PSA + i] = pa[q]; }
+    for (int q = 0; q < NRA; ++q) if (ra_lds[p][q] >= 0) As[ra_lds[p][q]] = (pmask >> q) & 1u ? pa[q] : 0.0;
     if (TYPE != 0) {
 #pragma unroll
-      for (int q = 0; q < NRB; ++q) { const int e = tid + NT * q; if (e < CW * KC) Bs[(e & 15) * PSB + (e >> 4)] = pb[q]; }
+      for (int q = 0; q < NRB; ++q) if (cb_lds[q] >= 0) Bs[cb_lds[q]] = (pmask >> (16 + q)) & 1u ? pb[q] : 0.0;
     }
   };
   const int nchunk = (b + KC - 1) / KC, total = np * nchunk;
@@ -1053,7 +1077,7 @@ __device__ __forceinline__ void schur_body(const SchurArgs& a, double* lds) {
   // accumulator (reg v, lane (fk, fi)) = sum for column j = 16 ct + fk + 4 v, row i = 16 rt + fi
 #pragma unroll
   for (int s = 0; s < NSLOT; ++s) {
-    if (s * SCHUR_NW + wv >= NTILE) continue;
+    if ((s * SPLIT + (int)blockIdx.z) * SCHUR_NW + wv >= NTILE) continue;
     const int i = 16 * rt_[s] + fi;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -1065,23 +1089,28 @@ __device__ __forceinline__ void schur_body(const SchurArgs& a, double* lds) {
     }
   }
 }
-template <int NTB, int ZT>
+template <int NTB, int ZT, int SPLIT>
 __global__ __launch_bounds__(64 * SCHUR_NW) void k_bcr_schur(SchurArgs a) {
   extern __shared__ double lds[];
   const int type = blockIdx.x;
-  if (type == 0) schur_body<NTB, 0, ZT>(a, lds);
-  else if (type == 1) { if (blockIdx.y >= 1) schur_body<NTB, 1, ZT>(a, lds); }
-  else schur_body<NTB, 2, ZT>(a, lds);
+  if (type == 0) schur_body<NTB, 0, ZT, SPLIT>(a, lds);
+  else if (type == 1) { if (blockIdx.y >= 1) schur_body<NTB, 1, ZT, SPLIT>(a, lds); }
+  else schur_body<NTB, 2, ZT, SPLIT>(a, lds);
 }
-// off by default unless measured faster — see DESIGN.md 3.2
+// LVX_BCR_OWN_SCHUR: 1 own kernel on every level, 0 rocBLAS on every level, default (-1): own kernel
 static bool schur_own(const lvx_ctx* c, int b, int nrhs) { return c->sw.bcr_own_schur != 0 && !c->sw.bcr_syrk && b <= 208 && nrhs <= 64; }
-template <int NTB, int ZT> static int launch_schur(lvx_ctx* c, const SchurArgs& a) {
+template <int NTB, int ZT, int SPLIT> static int launch_schur_s(lvx_ctx* c, const SchurArgs& a) {
   constexpr int PR = 16 * NTB, PSA = PR | 1;
   const size_t lds = (size_t)2 * (16 * PSA + 16 * PSA) * 8;     // the coupling product is the largest: row panel + a full column panel, two buffers
-  LVX_HIP(c, hipFuncSetAttribute((const void*)k_bcr_schur<NTB, ZT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((k_bcr_schur<NTB, ZT>), dim3(a.Zj ? 3u : 2u, (unsigned)a.n2), dim3(64 * SCHUR_NW), lds, c->stream, a);
+  LVX_HIP(c, hipFuncSetAttribute((const void*)k_bcr_schur<NTB, ZT, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_bcr_schur<NTB, ZT, SPLIT>), dim3(a.Zj ? 3u : 2u, (unsigned)a.n2, (unsigned)SPLIT), dim3(64 * SCHUR_NW), lds, c->stream, a);
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
+}
+// one workgroup per (block, output) where that fills the chip; two on the narrow levels (a single block's D update is 47 us of MFMAs on one CU)
+template <int NTB, int ZT> static int launch_schur(lvx_ctx* c, const SchurArgs& a) {
+  if (3 * a.n2 >= 512) return launch_schur_s<NTB, ZT, 1>(c, a);   // measured at config 4: 209 blocks 231 us whole / 280 us split, 104 blocks 150 us whole (312 workgroups on 256 CUs: two rounds for 1.2 rounds of work)
+  return launch_schur_s<NTB, ZT, 2>(c, a);
 }
 static int schur_level(lvx_ctx* c, const SchurArgs& a) {
   if (a.b <= 64) return launch_schur<4, 4>(c, a);

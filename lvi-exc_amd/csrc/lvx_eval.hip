@@ -1599,7 +1599,7 @@ const SwitchName* switch_table(int* count) {
     {"SYNC_NOFENCE", &Switches::sync_nofence, false}, {"CHUNK_R", &Switches::chunk_r, true}, {"CHUNK_R_IMU", &Switches::chunk_r_imu, true},
     {"CHUNK_R_REP", &Switches::chunk_r_rep, true}, {"CHUNK_ROWS", &Switches::chunk_rows, true}, {"REP_ROWS", &Switches::rep_rows, true},
     {"SOLVER_SEQ", &Switches::solver_seq, false}, {"SOLVER_TIMING", &Switches::solver_timing, false}, {"BCR_ROCSOLVER_POTRF", &Switches::bcr_rocsolver_potrf, false},
-    {"BCR_SYRK", &Switches::bcr_syrk, false}, {"BCR_NO_DINV", &Switches::bcr_no_dinv, false}, {"BCR_NO_FUSED_BACK", &Switches::bcr_no_fused_back, false}, {"BCR_POTRF_LDS", &Switches::bcr_potrf_lds, false}, {"BCR_OWN_SCHUR", &Switches::bcr_own_schur, false}, {"BCR_TRSM_STREAM", &Switches::bcr_trsm_stream, false}, {"BCR_TRSM_NW", &Switches::bcr_trsm_nw, false}, {"BCR_SCHUR_WIDE", &Switches::bcr_schur_wide, false}, {"TAU_LEGACY", &Switches::tau_legacy, false}, {"DETERMINISTIC", &Switches::deterministic, true}, {"CLEAR_ALL", &Switches::clear_all, false}, {"CROSS_DBG", &Switches::cross_dbg, false}, {"LM_SCHUR_SINGLE", &Switches::lm_schur_single, false}, {"IMU_SPLIT", &Switches::imu_split, false}, {"REF_SIDE", &Switches::ref_side, false},
+    {"BCR_SYRK", &Switches::bcr_syrk, false}, {"BCR_NO_DINV", &Switches::bcr_no_dinv, false}, {"BCR_NO_FUSED_BACK", &Switches::bcr_no_fused_back, false}, {"BCR_POTRF_LDS", &Switches::bcr_potrf_lds, false}, {"BCR_OWN_SCHUR", &Switches::bcr_own_schur, false}, {"BCR_TRSM_STREAM", &Switches::bcr_trsm_stream, false}, {"BCR_TRSM_NW", &Switches::bcr_trsm_nw, false}, {"TAU_LEGACY", &Switches::tau_legacy, false}, {"DETERMINISTIC", &Switches::deterministic, true}, {"CLEAR_ALL", &Switches::clear_all, false}, {"CROSS_DBG", &Switches::cross_dbg, false}, {"LM_SCHUR_SINGLE", &Switches::lm_schur_single, false}, {"IMU_SPLIT", &Switches::imu_split, false}, {"REF_SIDE", &Switches::ref_side, false},
   };
   *count = (int)(sizeof(tab) / sizeof(tab[0]));
   return tab;
