@@ -970,7 +970,6 @@ template <int NTB, int TYPE, int ZT, int SPLIT>
 __device__ __forceinline__ void schur_body(const SchurArgs& a, double* lds) {
   constexpr int NT = SCHUR_NW * 64, PR = 16 * NTB, PSA = PR | 1, CW = TYPE == 2 ? 16 * ZT : PR, PSB = CW | 1, KC = 16;
   constexpr int NTILE = TYPE == 0 ? NTB * (NTB + 1) / 2 : (TYPE == 1 ? NTB * NTB : NTB * ZT), NSLOT = (NTILE + SCHUR_NW * SPLIT - 1) / (SCHUR_NW * SPLIT);   // SPLIT workgroups (blockIdx.z) share an output on the narrow levels
-  constexpr int NRA = (PR * KC + NT - 1) / NT, NRB = TYPE == 0 ? 0 : (CW * KC + NT - 1) / NT;
   constexpr int BUF = KC * PSA + (TYPE == 0 ? 0 : KC * PSB);
   const int b = a.b, k = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, fk = lane >> 4, fi = lane & 15;
@@ -997,33 +996,35 @@ __device__ __forceinline__ void schur_body(const SchurArgs& a, double* lds) {
   d4 acc[NSLOT];
 #pragma unroll
   for (int s = 0; s < NSLOT; ++s) acc[s] = d4{0.0, 0.0, 0.0, 0.0};
-  double pa[NRA], pb[NRB > 0 ? NRB : 1];
-  // row panel element e: natural source (X: contiguous along the rows): i = e % PR, kk = e / PR; transposed source (Y^T: contiguous along K): kk = e % 16, i = e / 16.
-  // column panel: always contiguous along K (Y_k columns, right-hand sides): kk = e % 16, j = e / 16.
+  // Operand loads are 16 bytes wide: PAIRS of elements (b is a multiple of 4, chunks start at multiples of 16: a pair never straddles K = b or row b).
+  // row panel pair e: natural source (X: contiguous along the rows): i = 2 (e % (PR / 2)), kk = e / (PR / 2); transposed source (Y^T: contiguous along K): kk = 2 (e % 8), i = e / 8.
+  // column panel: always contiguous along K (Y_k columns, right-hand sides): kk = 2 (e % 8), j = e / 8.
   // Everything that does not depend on the chunk is formed once (the first version rebuilt 64-bit addresses and bounds behind three branches per load, inside the K loop:
-  // ~40 instructions per load, as long as the chunk's MFMAs): element offset of (index, k = 0), whether the index exists, kk; per chunk only k = min(k0 + kk, b - 1) is added
-  // and a value beyond K is replaced by zero.
-  int ra_off[2][NRA], ra_kk[2][NRA], ra_lds[2][NRA]; bool ra_ok[2][NRA];
+  // ~40 instructions per load, as long as the chunk's MFMAs): element offset of (index, k = 0), whether the index exists, kk; per chunk only the clamped k is added.
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  constexpr int NPA = (PR * KC / 2 + NT - 1) / NT, NPB = TYPE == 0 ? 0 : (CW * KC / 2 + NT - 1) / NT;
+  d2 pa[NPA], pb[NPB > 0 ? NPB : 1];
+  int ra_off[2][NPA], ra_kk[2][NPA], ra_lds[2][NPA]; bool ra_ok[2][NPA];
 #pragma unroll
   for (int p = 0; p < 2; ++p)
 #pragma unroll
-    for (int q = 0; q < NRA; ++q) {
+    for (int q = 0; q < NPA; ++q) {
       const int e = tid + NT * q;
       const bool tr = rtr[p];
-      const int i = tr ? e >> 4 : e % PR, kk = tr ? e & 15 : e / PR;
-      ra_ok[p][q] = e < PR * KC && i < b;
+      const int i = tr ? e >> 3 : 2 * (e % (PR / 2)), kk = tr ? 2 * (e & 7) : e / (PR / 2);
+      ra_ok[p][q] = e < PR * KC / 2 && i < b;
       ra_off[p][q] = ra_ok[p][q] ? (tr ? i * b : i) : 0;
       ra_kk[p][q] = kk;
-      ra_lds[p][q] = e < PR * KC ? kk * PSA + i : -1;
+      ra_lds[p][q] = e < PR * KC / 2 ? kk * PSA + i : -1;
     }
-  int cb_off[NRB > 0 ? NRB : 1], cb_lds[NRB > 0 ? NRB : 1]; bool cb_ok[NRB > 0 ? NRB : 1];
-  const int ckk = tid & 15;      // NT is a multiple of 16: the same kk for every q
+  int cb_off[NPB > 0 ? NPB : 1], cb_lds[NPB > 0 ? NPB : 1]; bool cb_ok[NPB > 0 ? NPB : 1];
+  const int ckk = 2 * (tid & 7);      // NT is a multiple of 8: the same kk for every q
 #pragma unroll
-  for (int q = 0; q < NRB; ++q) {
-    const int e = tid + NT * q, j = e >> 4;
-    cb_ok[q] = e < CW * KC && j < ncol;
+  for (int q = 0; q < NPB; ++q) {
+    const int e = tid + NT * q, j = e >> 3;
+    cb_ok[q] = e < CW * KC / 2 && j < ncol;
     cb_off[q] = cb_ok[q] ? j * cld : 0;
-    cb_lds[q] = e < CW * KC ? ckk * PSB + j : -1;
+    cb_lds[q] = e < CW * KC / 2 ? ckk * PSB + j : -1;
   }
   // fetch only ISSUES the loads (clamped, always valid addresses) and notes which values count; the values are looked at in commit, after the chunk's MFMAs —
   // with the select next to the load the compiler waited for every load on the spot (s_waitcnt vmcnt(0) eight times per chunk, nothing overlapped)
@@ -1033,28 +1034,35 @@ __device__ __forceinline__ void schur_body(const SchurArgs& a, double* lds) {
     const int kstr = rtr[p] ? 1 : b;
     pmask = 0;
 #pragma unroll
-    for (int q = 0; q < NRA; ++q) {
+    for (int q = 0; q < NPA; ++q) {
       const int kq = k0 + ra_kk[p][q];
-      pa[q] = rs[ra_off[p][q] + min(kq, b - 1) * kstr];
+      pa[q] = *(const d2*)(rs + ra_off[p][q] + min(kq, rtr[p] ? b - 2 : b - 1) * kstr);   // transposed source: the pair is (k, k + 1); natural: (i, i + 1) of column k
       pmask |= (ra_ok[p][q] && kq < b) ? (1u << q) : 0u;
     }
     if (TYPE != 0) {
       const double* cs = csrc[p];
-      const int kq = k0 + ckk, kc = min(kq, b - 1);
+      const int kq = k0 + ckk, kc = min(kq, b - 2);
 #pragma unroll
-      for (int q = 0; q < NRB; ++q) {
-        pb[q] = cs[cb_off[q] + kc];
+      for (int q = 0; q < NPB; ++q) {
+        pb[q] = *(const d2*)(cs + cb_off[q] + kc);
         pmask |= (cb_ok[q] && kq < b) ? (1u << (16 + q)) : 0u;
       }
     }
   };
   auto commit = [&](int p, double* buf) {
     double* As = buf; double* Bs = buf + KC * PSA;
+    const int step = rtr[p] ? PSA : 1;     // the pair's second element: next k (transposed source) or next row (natural)
 #pragma unroll
-    for (int q = 0; q < NRA; ++q) if (ra_lds[p][q] >= 0) As[ra_lds[p][q]] = (pmask >> q) & 1u ? pa[q] : 0.0;
+    for (int q = 0; q < NPA; ++q) if (ra_lds[p][q] >= 0) {
+      const bool on = (pmask >> q) & 1u;
+      As[ra_lds[p][q]] = on ? pa[q][0] : 0.0; As[ra_lds[p][q] + step] = on ? pa[q][1] : 0.0;
+    }
     if (TYPE != 0) {
 #pragma unroll
-      for (int q = 0; q < NRB; ++q) if (cb_lds[q] >= 0) Bs[cb_lds[q]] = (pmask >> (16 + q)) & 1u ? pb[q] : 0.0;
+      for (int q = 0; q < NPB; ++q) if (cb_lds[q] >= 0) {
+        const bool on = (pmask >> (16 + q)) & 1u;
+        Bs[cb_lds[q]] = on ? pb[q][0] : 0.0; Bs[cb_lds[q] + PSB] = on ? pb[q][1] : 0.0;
+      }
     }
   };
   const int nchunk = (b + KC - 1) / KC, total = np * nchunk;
