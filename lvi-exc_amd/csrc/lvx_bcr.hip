@@ -662,8 +662,8 @@ __device__ __forceinline__ long long pkt_now() { long long t; asm volatile("s_wa
 #endif
 template <int NT>
 __global__ __launch_bounds__(64 * POTRF_REG_NW) void k_potrf_reg(double* Dm, int b, long long strideD, int* info, double* LIm, long long strideLI) {
-  // wavefront 0 owns the NT diagonal tiles and nothing else: the factorisation of a diagonal tile is the chain every panel waits for; wavefront 4 (same SIMD)
-  // stays idle; the NT (NT - 1) / 2 off-diagonal tiles are dealt to the other six.  The panel loop is a RUN-TIME loop (the fully unrolled version executed every
+  // wavefront 0 factorises the diagonal tiles and does nothing else: that chain is what every panel waits for; wavefront 4 (same SIMD) keeps the waiting diagonal
+  // tiles up to date; the NT (NT - 1) / 2 off-diagonal tiles are dealt to the other six.  The panel loop is a RUN-TIME loop (the fully unrolled version executed every
   // instruction once, 160 KB of code: instruction fetch, not arithmetic, set its pace — the 16 x 16 factorisation took 4.7 k cycles inside it and 0.8 k with a
   // warm instruction cache), so the diagonal wavefront keeps its waiting tiles in LDS in the accumulator layout (every lane touches only its own four words of a
   // tile: no synchronisation, dynamic tile index); the off-diagonal tiles sit in statically indexed registers.
@@ -790,13 +790,22 @@ __global__ __launch_bounds__(64 * POTRF_REG_NW) void k_potrf_reg(double* Dm, int
       update(Tcur, k + 1, k + 1);
       Mcur = factor_diag(Tcur, k + 1);   // the chain everybody waits for
       PKT(1)
-      for (int s = k + 2; s < NT; ++s) {
-        d4 C;
+    } else if (wv == 4) {
+      // the diagonal wavefront's SIMD-mate keeps the OTHER waiting diagonal tiles up to date (they sat behind the factorisation on wavefront 0: up to ten tile
+      // updates of ~0.5 k cycles before the barrier); its MFMAs fill the gaps of the factorisation's chain (one MFMA per ~140 cycles).  Two tiles at a time: the
+      // 4-MFMA chains of a tile are dependent, two tiles' chains interleave.
+      for (int s = k + 2; s < NT; s += 2) {
+        const bool two = s + 1 < NT;
+        d4 C0, C1;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) C[v] = Dg[s][v][lane];
-        update(C, s, s);
+        for (int v = 0; v < 4; ++v) { C0[v] = Dg[s][v][lane]; C1[v] = two ? Dg[s + 1][v][lane] : 0.0; }
 #pragma unroll
-        for (int v = 0; v < 4; ++v) Dg[s][v][lane] = C[v];
+        for (int ks = 0; ks < 4; ++ks) {
+          C0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-pn[(4 * ks + fk) * PS + 16 * s + fi], pn[(4 * ks + fk) * PS + 16 * s + fi], C0, 0, 0, 0);
+          if (two) C1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-pn[(4 * ks + fk) * PS + 16 * (s + 1) + fi], pn[(4 * ks + fk) * PS + 16 * (s + 1) + fi], C1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { Dg[s][v][lane] = C0[v]; if (two) Dg[s + 1][v][lane] = C1[v]; }
       }
     } else {
 #pragma unroll
