@@ -1464,6 +1464,343 @@ __global__ __launch_bounds__(256, 1) void k_imu_mfma(ImuFused fam, DevCommon cm,
   if (tid < IMU_NGA) { const double v = A.gG[tid]; if (v != 0.0 && gpos[tid] != LVX_DEAD) add_g(cm, gpos[tid], v, rep); }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fused IMU kernel, second form (k_imu_rot, LVX_IMU_ROT=1; NOT the default — measured slower, kept as the worked-out base of the two-wavefronts-per-SIMD design).
+// k_imu_mfma needs 502 registers per lane (the SO3 evaluation with both derivative sets + a 3 x 29 Jacobian block) and 117 KB of LDS (57 KB of band / border accumulators
+// shared by the workgroup + 52 KB of panels), i.e. ONE wavefront per SIMD with every LDS, MFMA and atomic latency exposed.  Here
+//   * no derivative blocks and no Jacobian array: the rows come from reverse-mode pullbacks (so3_pullback_w_pre for the gyroscope, so3_pullback_pre for the accelerometer:
+//     vectors only) and go to the panel as they are computed, one residual component at a time;
+//   * the window accumulators ROTATE in registers: the knot columns of a window sit at slot = knot mod 4, so moving from interval i to i + 1 keeps three of the four
+//     knots in place and the MFMAs simply go on accumulating; when a knot LEAVES exactly the accumulator entries of its slot are final for this wavefront: they are flushed
+//     straight from the registers (one global atomic per entry) and zeroed — no LDS accumulators, no scatter per window, no flush pass;
+//   * globals x globals and the globals' gradient stay in registers for the whole wavefront and are reduced over the workgroup's wavefronts at the end.
+// LDS 64 KB (panels 52, control points, pair table, position and flush tables): two workgroups per CU at 256 registers (68 spilled; 356 without the limit).
+// Result at config 4: bit-for-bit the same normal equations up to summation order (tests/test_gpu_variants.py), 242 us solo against 200 — and 357 us when compiled for
+// one wavefront per SIMD: a wavefront does ~1.8x the work of k_imu_mfma's, because a 13 KB panel holds 16 (accelerometer) / 32 (gyroscope) lanes' rows and the pullbacks
+// are recomputed for every panel group (18 per wavefront instead of 6; the Jacobian array that avoided this is what cost the registers), and the per-window flush is
+// ~16 global-atomic instructions with their address arithmetic.  What would make it pay: panels for all 64 lanes (needs the rows in a compact form) or a flush through
+// LDS once per wavefront instead of once per window.
+// ---------------------------------------------------------------------------------------------------------
+struct RotG { enum { NR = 3, KPK = 3, LVO = 3, NG = 3, GOFF = 5, NKL = 12, NCL = 16, NT = 1, NTP = 1, LDP = 17, GL = 32, PR = 96 }; };
+struct RotA { enum { NR = 3, KPK = 6, LVO = 0, NG = 5, GOFF = 0, NKL = 24, NCL = 30, NT = 2, NTP = 3, LDP = 33, GL = 16, PR = 48 }; };
+// one accumulator register of a lane: what its (row, col) is.  kind: 0 none, 1 knot x knot, 2 knot x global, 3 knot x residual (gradient), 4 global x global, 5 global x residual
+struct RotEnt { int kind, rs, rc, cs, cc; };   // row slot / component (or global index), column slot / component (or global index)
+template <class PG> __device__ __forceinline__ RotEnt rot_entry(int ci, int cj, int v, int lane) {
+  const int row = 16 * ci + (lane >> 4) + 4 * v, col = 16 * cj + (lane & 15);
+  RotEnt e{0, 0, 0, 0, 0};
+  if (ci == cj && col < row) return e;               // lower triangle of a diagonal tile
+  const bool rk = row < PG::NKL, rg = !rk && row < PG::NKL + PG::NG;
+  const bool ck = col < PG::NKL, cg = !ck && col < PG::NKL + PG::NG, cr = col == PG::NKL + PG::NG;
+  if (rk) { e.rs = row / PG::KPK; e.rc = PG::LVO + row % PG::KPK; }
+  else if (rg) e.rc = PG::GOFF + row - PG::NKL;
+  if (ck) { e.cs = col / PG::KPK; e.cc = PG::LVO + col % PG::KPK; }
+  else if (cg) e.cc = PG::GOFF + col - PG::NKL;
+  if (rk) e.kind = ck ? 1 : (cg ? 2 : (cr ? 3 : 0));
+  else if (rg) e.kind = cg ? 4 : (cr ? 5 : 0);
+  return e;
+}
+// packed form of RotEnt, one int per accumulator register of a lane, built once per wavefront (the classification costs ~30 instructions per register: divisions by
+// the slot width, range tests — per flush that was as much VALU work as the evaluation): kind (3 bits) | row index into wpos (5) << 3 | column index into wpos or gpos (5) << 8 |
+// row slot (2) << 13 | column slot (2) << 15
+template <class PG> __device__ __forceinline__ void rot_table(int* tab, int lane) {
+  int t = 0;
+#pragma unroll
+  for (int ci = 0; ci < PG::NT; ++ci)
+#pragma unroll
+    for (int cj = ci; cj < PG::NT; ++cj, ++t)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const RotEnt e = rot_entry<PG>(ci, cj, v, lane);
+        const int ridx = e.kind >= 1 && e.kind <= 3 ? e.rs * 6 + e.rc : e.rc;
+        const int cidx = e.kind == 1 ? e.cs * 6 + e.cc : e.cc;
+        tab[t * 4 + v] = e.kind | (ridx << 3) | (cidx << 8) | (e.rs << 13) | (e.cs << 15);
+      }
+}
+// flush what is final when the knot at slot s leaves (s < 0: everything that involves a knot): wpos[slot * 6 + comp] = position of that tangent scalar (this wavefront's LDS table)
+template <class PG> __device__ __forceinline__ void rot_flush(const DevCommon& cm, d4* D, const int* tab, int s, const int* wpos, const int* gpos, int rep) {
+#pragma unroll
+  for (int t = 0; t < PG::NTP; ++t)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int e = tab[(t * 4 + v) * 64], kind = e & 7;
+      const bool knot_entry = kind >= 1 && kind <= 3;
+      const bool hit = knot_entry && (s < 0 || ((e >> 13) & 3) == s || (kind == 1 && ((e >> 15) & 3) == s));
+      if (!hit) continue;
+      const double val = D[t][v];
+      D[t][v] = 0.0;
+      if (val == 0.0) continue;
+      const int pa = wpos[(e >> 3) & 31];
+      if (pa == LVX_DEAD) continue;
+      if (kind == 3) { add_g(cm, pa, val, rep); continue; }
+      const int pb = kind == 1 ? wpos[(e >> 8) & 31] : gpos[(e >> 8) & 31];
+      if (pb == LVX_DEAD) continue;
+      add_H(cm, pa, pb, val, rep);
+    }
+}
+// the wavefront's global x global block and global gradient -> the workgroup's LDS sums (gsum[8][8], ggrad[8])
+template <class PG> __device__ __forceinline__ void rot_flush_globals(d4* D, const int* tab, double* gsum, double* ggrad) {
+#pragma unroll
+  for (int t = 0; t < PG::NTP; ++t)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int e = tab[(t * 4 + v) * 64], kind = e & 7;
+      if (kind < 4) continue;
+      const double val = D[t][v];
+      if (val == 0.0) continue;
+      if (kind == 4) atomicAdd(&gsum[((e >> 3) & 31) * IMU_NGA + ((e >> 8) & 31)], val); else atomicAdd(&ggrad[(e >> 3) & 31], val);
+    }
+}
+// MFMA assembly of the panel that holds the rows of lanes [g0, g0 + GL): windows in ascending order; a knot that leaves is flushed before the window that follows it
+template <class PG> __device__ __forceinline__ void rot_assemble(const DevCommon& cm, d4* D, const int* tab, const double* P, int g0, bool valid, int key, int& wprev, int k_lo, int acc_lv, const int* kpos,
+                                                               int* wpos, const int* gpos, int rep, int lane) {
+  constexpr int NR = PG::NR, NT = PG::NT, LDP = PG::LDP, PR = PG::PR, GL = PG::GL;
+  const unsigned long long pmask = ((1ull << GL) - 1ull) << g0;
+  unsigned long long rem = __ballot(valid) & pmask;
+  while (rem) {
+    const int l0 = __ffsll((long long)rem) - 1;
+    const int kw = __builtin_amdgcn_readfirstlane(__shfl(key, l0));
+    const unsigned long long wm = __ballot(valid && key == kw) & pmask;
+    rem &= ~wm;
+    if (kw != wprev) {
+      // knots wprev .. min(kw - 1, wprev + 3) leave (their slot's entries are final for this wavefront), then the position table follows the new window
+      if (wprev >= 0) {
+        const int dend = min(kw, wprev + 4);
+        for (int d = wprev; d < dend; ++d) rot_flush<PG>(cm, D, tab, d & 3, wpos, gpos, rep);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+      if (lane < 24) {   // wpos[slot][comp]: the knot at slot sl of window kw is kw + ((sl - kw) & 3)
+        const int sl = lane / 6, cp = lane % 6, kn = kw + ((sl - kw) & 3), e = (kn - k_lo) * 6 + cp;
+        wpos[lane] = (e >= 0 && e < acc_lv) ? kpos[e] : LVX_DEAD;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      wprev = kw;
+    }
+    const int lhi = 63 - __clzll((long long)wm);
+    const int r_lo = (l0 - g0) * NR, r_hi = (lhi - g0 + 1) * NR;
+    const unsigned long long wsh = wm >> g0;
+    const bool contig = __popcll(wm) == lhi - l0 + 1;
+    const int nks = (r_hi - r_lo + 3) >> 2;
+    auto trip = [&](int ks, auto UC) {
+      constexpr int U = decltype(UC)::value;
+      double f[U][NT];
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        const int rr = r_lo + 4 * (ks + q) + (lane >> 4);
+        bool mine = rr < r_hi;
+        if (!contig) mine = mine && ((wsh >> (rr / NR)) & 1ull);
+        const double* src = P + min(rr, PR - 1) * LDP + (lane & 15);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) { const double x = src[c * 16]; f[q][c] = mine ? x : 0.0; }
+      }
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        int t = 0;
+#pragma unroll
+        for (int ci = 0; ci < NT; ++ci)
+#pragma unroll
+          for (int cj = ci; cj < NT; ++cj, ++t) D[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[q][ci], f[q][cj], D[t], 0, 0, 0);
+      }
+    };
+    int ks = 0;
+    for (; ks + 3 <= nks; ks += 3) trip(ks, std::integral_constant<int, 3>{});     // a full interval of 8 samples = 6 k-steps = two trips (six at once: 12 more live registers)
+    for (; ks < nks; ks += 1) trip(ks, std::integral_constant<int, 1>{});
+  }
+}
+static size_t imu_rot_lds_bytes(int cr) {
+  const int LV = (cr + 5) * 6;
+  const int pan = std::max((int)RotG::PR * (int)RotG::LDP, (int)RotA::PR * (int)RotA::LDP);
+  return (size_t)(4 * pan + IMU_NGA * IMU_NGA + IMU_NGA + 4 * (cr + 5)) * 8 + (size_t)(cr + 4) * sizeof(So3Pre) + (size_t)(LV + IMU_NGA + 4 * 24 + 16 * 64) * 4 + 64;
+}
+__global__ __launch_bounds__(256, 2) void k_imu_rot(ImuFused fam, DevCommon cm, const int* __restrict__ chunk_off, long long row0_g, long long row0_a, int CR) {
+  constexpr int PAN = (RotG::PR * RotG::LDP > RotA::PR * RotA::LDP) ? RotG::PR * RotG::LDP : RotA::PR * RotA::LDP;
+  const int ACC_LV = (CR + 5) * 6;
+  extern __shared__ double sm[];
+  double* panels = sm;
+  double* gsum = panels + 4 * PAN;                  // [8][8] globals x globals of the workgroup
+  double* ggrad = gsum + IMU_NGA * IMU_NGA;         // [8]
+  quat* cps = (quat*)(ggrad + IMU_NGA);             // [CR + 5] the chunk's SO3 control points k_lo .. k_lo + CR + 4 (read by every pullback: 32 registers if kept)
+  So3Pre* pre_tab = (So3Pre*)(cps + (CR + 5));
+  int* kpos = (int*)(pre_tab + (CR + 4));           // [ACC_LV]
+  int* gpos = kpos + ACC_LV;                        // [8]
+  int* wpos_all = gpos + IMU_NGA;                   // [4 wavefronts][24]
+  int* tabL = wpos_all + 4 * 24;                    // [4 + 12][64]: the flush tables of both geometries (lane-dependent only; in registers they cost 16 and spilled)
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int ch = blockIdx.x;
+  const int m0 = chunk_off[ch], m1 = chunk_off[ch + 1];
+  if (m0 >= m1) return;
+  const int k_lo = ch * CR - 1;
+  const bool want_ne = (cm.what & LVX_EVAL_NORMAL_EQ) != 0;
+  for (int e = tid; e < IMU_NGA * IMU_NGA + IMU_NGA; e += 256) gsum[e] = 0.0;
+  for (int e = tid; e < ACC_LV; e += 256) { const int k = k_lo + e / 6; kpos[e] = (k >= 0 && k < cm.N) ? cm.ord[6 * k + e % 6] : LVX_DEAD; }
+  if (tid < IMU_NGA) gpos[tid] = cm.ord[6 * cm.N + tid];
+  if (tid < CR + 4) {
+    const int ka = k_lo + tid;
+    if (ka >= 0 && ka + 1 < cm.N) pre_tab[tid] = cm.pre[ka];
+    else { pre_tab[tid].Om = mk(0, 0, 0); pre_tab[tid].on = 0.0; pre_tab[tid].Jri = m3_identity(); pre_tab[tid].c3 = 1.0 / 12.0; pre_tab[tid].ok = 1; }
+  }
+  const SplineRef sp{cm.t0, cm.dt, cm.N, cm.state, cm.state + 3 * (size_t)cm.N};
+  if (tid < CR + 5) { const int ka = min(max(k_lo + tid, 0), cm.N - 1); cps[tid] = load_q(sp.so3 + 4 * (size_t)ka); }
+  const Cal cal = load_cal(cm);
+  double* P = panels + wv * PAN;
+  int* wpos = wpos_all + wv * 24;
+  const int rep = ch % cm.nrep;
+  double mycost = 0.0;
+  if (wv == 0) {
+    int tg[RotG::NTP * 4], ta[RotA::NTP * 4];
+    rot_table<RotG>(tg, lane); rot_table<RotA>(ta, lane);
+#pragma unroll
+    for (int i = 0; i < RotG::NTP * 4; ++i) tabL[i * 64 + lane] = tg[i];
+#pragma unroll
+    for (int i = 0; i < RotA::NTP * 4; ++i) tabL[(RotG::NTP * 4 + i) * 64 + lane] = ta[i];
+  }
+  const int* tabG = tabL + lane; const int* tabA = tabL + RotG::NTP * 4 * 64 + lane;
+  __syncthreads();
+  for (int base = m0 + wv * 64; base < m1; base += 4 * 64) {
+    const int si = base + lane;
+    const bool in = si < m1;
+    int key = -1;
+    bool valid = false;
+    KnotRef k;
+    const So3Pre* pre = pre_tab;
+    So3ValW sv;
+    const quat* c = cps;
+    if (in) {
+      int status = RES_OK;
+      if (!knot_lookup(sp.t0, sp.dt, sp.n, fam.t[si], fam.t[si] + cal.imu.tau, &k)) status = RES_RANGE;
+      else {
+        key = k.i0;
+        if (!(k.i0 >= k_lo && k.i0 + 2 < k_lo + CR + 4)) status = RES_OUTSIDE;
+        else {
+          pre = pre_tab + (k.i0 - k_lo);
+          c = cps + (k.i0 - k_lo);
+          const int bad = so3_value_w_pre(c, pre, k.u, sp.dt, &sv);     // value + what the reverse-mode rows need: vectors only, no 3 x 3 derivative blocks
+          if (bad) status = (bad & 1) ? RES_NONUNIT : RES_OUTSIDE;
+        }
+      }
+      valid = status == RES_OK;
+      if (valid && (key < k_lo || key - k_lo > CR + 1)) { valid = false; atomicOr(cm.err, LVX_ERR_FALLBACK); }
+      else if (!valid) atomicOr(cm.err, status);
+    }
+    {   // gyroscope block (gyro_residual, lvx_resid.h): row a = -w (dw[kk]^T e_a) at slot (key + kk) & 3, -w e_a for b_g, residual
+      double r[3] = {0.0, 0.0, 0.0};
+      const double w = fam.w_gyro;
+      if (valid) {
+        const v3 wm = load_v3(fam.gyro + 3 * (size_t)si);
+        const v3 pred = sv.w_body + cal.imu.bg;
+        r[0] = w * (wm.x - pred.x); r[1] = w * (wm.y - pred.y); r[2] = w * (wm.z - pred.z);
+        mycost += 0.5 * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        if (cm.residuals) { const long long orow = row0_g + (long long)fam.perm[si] * 3; cm.residuals[orow] = r[0]; cm.residuals[orow + 1] = r[1]; cm.residuals[orow + 2] = r[2]; }
+      }
+      if (want_ne) {
+        d4 D[RotG::NTP];
+        D[0] = d4{0.0, 0.0, 0.0, 0.0};
+        int wprev = -1;
+        const unsigned long long vm = __ballot(valid);
+        for (int g0 = 0; g0 < 64; g0 += RotG::GL) {
+          if (!(vm & (((1ull << RotG::GL) - 1ull) << g0))) continue;
+          const bool mine = lane >= g0 && lane < g0 + RotG::GL;
+          const int li = mine ? lane - g0 : 0;
+#pragma unroll 1
+          for (int a = 0; a < 3; ++a) {     // the rows are recomputed for every panel group (two): three pullbacks, no Jacobian array; NOT unrolled: one row's vectors live at a time
+            v3 z[4];
+            if (valid) so3_pullback_w_pre(c, pre, sv, mk(a == 0 ? 1.0 : 0.0, a == 1 ? 1.0 : 0.0, a == 2 ? 1.0 : 0.0), z);
+            if (mine) {
+              double* prow = P + (li * 3 + a) * RotG::LDP;
+#pragma unroll
+              for (int kk = 0; kk < 4; ++kk) {
+                double* pk = prow + 3 * ((key + kk) & 3);
+                pk[0] = valid ? -w * z[kk].x : 0.0; pk[1] = valid ? -w * z[kk].y : 0.0; pk[2] = valid ? -w * z[kk].z : 0.0;
+              }
+#pragma unroll
+              for (int b = 0; b < 3; ++b) prow[12 + b] = (valid && a == b) ? -w : 0.0;
+              prow[15] = valid ? (a == 0 ? r[0] : (a == 1 ? r[1] : r[2])) : 0.0;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          rot_assemble<RotG>(cm, D, tabG, P, g0, valid, key, wprev, k_lo, ACC_LV, kpos, wpos, gpos, rep, lane);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        }
+        if (wprev >= 0) { rot_flush<RotG>(cm, D, tabG, -1, wpos, gpos, rep); rot_flush_globals<RotG>(D, tabG, gsum, ggrad); }
+      }
+    }
+    {   // accelerometer block (accel_residual, lvx_resid.h)
+      double r[3] = {0.0, 0.0, 0.0};
+      const double w = fam.w_acc;
+      double Ba[4] = {0.0, 0.0, 0.0, 0.0};
+      v3 yb = mk(0, 0, 0), dg_dr = mk(0, 0, 0), dg_dp = mk(0, 0, 0);
+      if (valid) {
+        R3Basis bs;
+        r3_basis(k.u, sp.dt, &bs);
+        v3 acc = mk(0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { Ba[j] = bs.Ba[j]; acc = acc + bs.Ba[j] * load_v3(sp.r3 + 3 * (k.i0 + j)); }
+        const v3 am = load_v3(fam.acc + 3 * (size_t)si);
+        const double G = -9.79;   // imu.h:25
+        const double cr = cos(cal.imu.roll), sr = sin(cal.imu.roll), cp = cos(cal.imu.pitch), sp_ = sin(cal.imu.pitch);
+        const v3 g = mk(-sp_ * cr * G, sr * G, -cr * cp * G);
+        yb = qrot_inv(sv.s.q, acc + g);
+        const v3 pred = yb + cal.imu.ba;
+        r[0] = w * (am.x - pred.x); r[1] = w * (am.y - pred.y); r[2] = w * (am.z - pred.z);
+        dg_dr = qrot_inv(sv.s.q, mk(sp_ * sr * G, cr * G, sr * cp * G));
+        dg_dp = qrot_inv(sv.s.q, mk(-cp * cr * G, 0.0, cr * sp_ * G));
+        mycost += 0.5 * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        if (cm.residuals) { const long long orow = row0_a + (long long)fam.perm[si] * 3; cm.residuals[orow] = r[0]; cm.residuals[orow + 1] = r[1]; cm.residuals[orow + 2] = r[2]; }
+      }
+      if (want_ne) {
+        d4 D[RotA::NTP];
+#pragma unroll
+        for (int t = 0; t < RotA::NTP; ++t) D[t] = d4{0.0, 0.0, 0.0, 0.0};
+        int wprev = -1;
+        const unsigned long long vm = __ballot(valid);
+        for (int g0 = 0; g0 < 64; g0 += RotA::GL) {
+          if (!(vm & (((1ull << RotA::GL) - 1ull) << g0))) continue;
+          const bool mine = lane >= g0 && lane < g0 + RotA::GL;
+          const int li = mine ? lane - g0 : 0;
+#pragma unroll 1
+          for (int a = 0; a < 3; ++a) {
+            // row a: position columns -w Ba_kk (R^T)[a][:] = -w Ba_kk R e_a, rotation columns -w (S dxi[kk])[a][:] = -w dxi[kk]^T (S^T e_a), S = skew(y_b)
+            const v3 ea = mk(a == 0 ? 1.0 : 0.0, a == 1 ? 1.0 : 0.0, a == 2 ? 1.0 : 0.0);
+            const v3 ga = a == 0 ? mk(0.0, -yb.z, yb.y) : (a == 1 ? mk(yb.z, 0.0, -yb.x) : mk(-yb.y, yb.x, 0.0));
+            v3 y[4];
+            v3 ra = mk(0, 0, 0);
+            if (valid) { so3_pullback_pre(c, pre, sv.s, ga, y); ra = qrot(sv.s.q, ea); }
+            if (mine) {
+              double* prow = P + (li * 3 + a) * RotA::LDP;
+#pragma unroll
+              for (int kk = 0; kk < 4; ++kk) {
+                double* pk = prow + 6 * ((key + kk) & 3);
+                const double wb = valid ? -w * Ba[kk] : 0.0;
+                pk[0] = wb * ra.x; pk[1] = wb * ra.y; pk[2] = wb * ra.z;
+                pk[3] = valid ? -w * y[kk].x : 0.0; pk[4] = valid ? -w * y[kk].y : 0.0; pk[5] = valid ? -w * y[kk].z : 0.0;
+              }
+              prow[24] = valid ? -w * comp(dg_dr, a) : 0.0; prow[25] = valid ? -w * comp(dg_dp, a) : 0.0;
+#pragma unroll
+              for (int b = 0; b < 3; ++b) prow[26 + b] = (valid && a == b) ? -w : 0.0;
+              prow[29] = valid ? (a == 0 ? r[0] : (a == 1 ? r[1] : r[2])) : 0.0; prow[30] = 0.0; prow[31] = 0.0;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          rot_assemble<RotA>(cm, D, tabA, P, g0, valid, key, wprev, k_lo, ACC_LV, kpos, wpos, gpos, rep, lane);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        }
+        if (wprev >= 0) { rot_flush<RotA>(cm, D, tabA, -1, wpos, gpos, rep); rot_flush_globals<RotA>(D, tabA, gsum, ggrad); }
+      }
+    }
+  }
+  mycost = wave_sum(mycost);
+  if (lane == 0) atomicAdd(&cm.cost[rep], mycost);
+  if (!want_ne) return;
+  __syncthreads();
+  for (int e = tid; e < IMU_NGA * IMU_NGA; e += 256) {
+    const int ga = e / IMU_NGA, gb2 = e % IMU_NGA;
+    if (gb2 < ga) continue;
+    const double v = gsum[e];
+    if (v == 0.0 || gpos[ga] == LVX_DEAD || gpos[gb2] == LVX_DEAD) continue;
+    add_H(cm, gpos[ga], gpos[gb2], v, rep);
+  }
+  if (tid < IMU_NGA) { const double v = ggrad[tid]; if (v != 0.0 && gpos[tid] != LVX_DEAD) add_g(cm, gpos[tid], v, rep); }
+}
+
 // fold the pseudo-pose rows of the border back onto the hub control points: x_pseudo = M_hub x_hub  =>
 //   Bd[hub] += M^T Bd[pseudo],  C <- (I + E) C (I + E)^T,  g_c[hub] += M^T g_c[pseudo]      (E = M^T placed at [hub rows, pseudo cols])
 // store: this set is the first to fold in this pass — outside [hub_lo, hub_hi) the hub rows were NOT cleared (nothing but the fold writes
@@ -1594,7 +1931,7 @@ __global__ __launch_bounds__(256) void k_fold_all(DevCommon cm, int nrep, int se
 const SwitchName* switch_table(int* count) {
   static const SwitchName tab[] = {
     {"FORCE_LEGACY", &Switches::force_legacy, false}, {"IMU_LEGACY", &Switches::imu_legacy, false}, {"REPROJ_LEGACY", &Switches::reproj_legacy, false},
-    {"SERIAL", &Switches::serial, false}, {"SCHED", &Switches::sched, false}, {"IMU_TWO_STREAMS", &Switches::imu_two_streams, false}, {"OCC", &Switches::occ, false},
+    {"SERIAL", &Switches::serial, false}, {"IMU_ROT", &Switches::imu_rot, false}, {"SCHED", &Switches::sched, false}, {"IMU_TWO_STREAMS", &Switches::imu_two_streams, false}, {"OCC", &Switches::occ, false},
     {"JAC_LATE", &Switches::jac_late, false}, {"FOLD_ONE", &Switches::fold_one, false}, {"FOLD_INLINE", &Switches::fold_inline, false}, {"NO_GRAPH", &Switches::no_graph, false},
     {"SYNC_NOFENCE", &Switches::sync_nofence, false}, {"CHUNK_R", &Switches::chunk_r, true}, {"CHUNK_R_IMU", &Switches::chunk_r_imu, true},
     {"CHUNK_R_REP", &Switches::chunk_r_rep, true}, {"CHUNK_ROWS", &Switches::chunk_rows, true}, {"REP_ROWS", &Switches::rep_rows, true},
@@ -2286,6 +2623,12 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
             LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_imu_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
             const int* rtab_d = (const int*)ctx->d_imu_rtab.p;
             ProfScope ps(ctx, LVX_FAM_GYRO, s_imu);
+            if (sw.imu_rot && !det && imu_rot_lds_bytes(ctx->chunk_r[LVX_FAM_GYRO]) <= 80 * 1024) {   // rotating register accumulators, two workgroups per CU
+              const size_t ldr = imu_rot_lds_bytes(ctx->chunk_r[LVX_FAM_GYRO]);
+              LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_imu_rot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldr));
+              hipLaunchKernelGGL(k_imu_rot, dim3(ctx->n_chunk[LVX_FAM_GYRO]), dim3(256), ldr, s_imu, f, cm, (const int*)ctx->d_chunk[LVX_FAM_GYRO].p, (long long)ctx->fam_row0[0], (long long)ctx->fam_row0[1],
+                                 ctx->chunk_r[LVX_FAM_GYRO]);
+            } else
             if (det && ctx->det_col[LVX_FAM_GYRO].size() > 1) {
               const std::vector<int>& dc = ctx->det_col[LVX_FAM_GYRO];
               for (size_t q = 0; q + 1 < dc.size(); ++q)

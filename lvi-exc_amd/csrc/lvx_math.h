@@ -357,7 +357,8 @@ LVX_HD void so3_small_coeffs(double a2, double* kv, double* ka, double* c2) {
         t2 * (1.0 / 1307674368000.0 + t2 * (-1.0 / 355687428096000.0 + t2 * (1.0 / 121645100408832000.0 + t2 * (-1.0 / 51090942171709440000.0)))))))));
 }
 // returns 0, or 1 (a pair failed logq's unit-norm check), or 2 (a pair's angle is beyond the small-angle polynomials: exact fallback)
-template <bool NEED_W, bool NEED_J, bool NEED_DW = (NEED_W && NEED_J)>
+// NEED_XI = false (with NEED_J): only the angular-velocity derivatives dw[] (the gyroscope rows of k_imu_rot, which evaluates twice to halve its live registers)
+template <bool NEED_W, bool NEED_J, bool NEED_DW = (NEED_W && NEED_J), bool NEED_XI = NEED_J>
 LVX_HD int so3_eval_pre(const quat c[4], const So3Pre* pre, double u, double dt, So3Eval* out) {
   const double u2 = u * u, u3 = u2 * u;
   double B[4], dB[4];
@@ -410,10 +411,12 @@ LVX_HD int so3_eval_pre(const quat c[4], const So3Pre* pre, double u, double dt,
   const m3 R32t = tmul(R3, transpose(R2));
   const m3 T1 = R32t * P[1], T2 = R3t * P[2], T3 = P[3];
   m3 Xe[4];
-  Xe[0] = tmul(R1 * (R2 * R3), m3_identity()) - mul_t(T1, pre[0].Jri);
-  Xe[1] = T1 * pre[0].Jri - mul_t(T2, pre[1].Jri);
-  Xe[2] = T2 * pre[1].Jri - mul_t(T3, pre[2].Jri);
-  Xe[3] = T3 * pre[2].Jri;
+  if (NEED_XI) {
+    Xe[0] = tmul(R1 * (R2 * R3), m3_identity()) - mul_t(T1, pre[0].Jri);
+    Xe[1] = T1 * pre[0].Jri - mul_t(T2, pre[1].Jri);
+    Xe[2] = T2 * pre[1].Jri - mul_t(T3, pre[2].Jri);
+    Xe[3] = T3 * pre[2].Jri;
+  }
   m3 We[4];
   if (NEED_DW) {
     const m3 W1 = dB[1] * R32t;
@@ -427,7 +430,7 @@ LVX_HD int so3_eval_pre(const quat c[4], const So3Pre* pre, double u, double dt,
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const m3 Rk = rotmat(c[k]);
-    out->dxi[k] = 2.0 * mul_t(Xe[k], Rk);
+    if (NEED_XI) out->dxi[k] = 2.0 * mul_t(Xe[k], Rk);
     if (NEED_DW) out->dw[k] = 2.0 * mul_t(We[k], Rk);
   }
   return bad;
@@ -487,6 +490,50 @@ LVX_HD void so3_pullback_pre(const quat c[4], const So3Pre* pre, const So3Val& s
   }
   const v3 y0 = uv[0] - fw[1], y1 = bw[1] - fw[2], y2 = bw[2] - fw[3], y3 = bw[3];
   y[0] = 2.0 * qrot(c[0], y0); y[1] = 2.0 * qrot(c[1], y1); y[2] = 2.0 * qrot(c[2], y2); y[3] = 2.0 * qrot(c[3], y3);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reverse mode for the body angular velocity (the gyroscope rows of k_imu_rot): z[k] = dw[k]^T g without the 3 x 3 blocks W_j / We[k] of so3_eval_pre.
+//   w1 = dB1 d1,  w2r = R2^T w1,  w2 = w2r + dB2 d2,  w3r = R3^T w2,  w_body = w3r + dB3 d3                       (value; d_j = 2 Omega_j)
+//   b1 = W1^T g = dB1 R2 R3 g,   b2 = W2^T g = P2^T ((R3 g) x w2r) + dB2 R3 g,   b3 = W3^T g = P3^T (g x w3r) + dB3 g      (skew(w)^T v = v x w)
+//   z0 = -Jri1 b1,  z1 = Jri1^T b1 - Jri2 b2,  z2 = Jri2^T b2 - Jri3 b3,  z3 = Jri3^T b3,      dw[k]^T g = 2 R(c_k) z_k
+// with the same vector forms of P_j^T, J_r^-1 and its transpose as so3_pullback_pre.
+// ---------------------------------------------------------------------------------------------
+struct So3ValW { So3Val s; double dB[4]; v3 w2r, w3r, w_body; };
+LVX_HD int so3_value_w_pre(const quat c[4], const So3Pre* pre, double u, double dt, So3ValW* o) {
+  const int bad = so3_value_pre(c, pre, u, &o->s);
+  const double u2 = u * u, di = 1.0 / dt;
+  const double U1 = di, U2 = di * (2.0 * u), U3 = di * (3.0 * u2);
+  o->dB[0] = 0.0;
+  o->dB[1] = U1 * (3.0 / 6.0) + U2 * (-3.0 / 6.0) + U3 * (1.0 / 6.0);
+  o->dB[2] = U1 * (3.0 / 6.0) + U2 * (3.0 / 6.0) + U3 * (-2.0 / 6.0);
+  o->dB[3] = U3 * (1.0 / 6.0);
+  const v3 w1 = (2.0 * o->dB[1]) * pre[0].Om;
+  o->w2r = qrot_inv(o->s.E[2], w1);
+  const v3 w2 = o->w2r + (2.0 * o->dB[2]) * pre[1].Om;
+  o->w3r = qrot_inv(o->s.E[3], w2);
+  o->w_body = o->w3r + (2.0 * o->dB[3]) * pre[2].Om;
+  return bad;
+}
+LVX_HD void so3_pullback_w_pre(const quat c[4], const So3Pre* pre, const So3ValW& w, v3 g, v3 z[4]) {
+  const So3Val& s = w.s;
+  const double B[4] = {0.0, s.phi[0].x, s.phi[0].y, s.phi[0].z};
+  auto PT = [&](int j, v3 v) { const v3 p1 = cross(s.phi[j], v); return B[j] * v + s.c1[j] * p1 + s.c2[j] * cross(s.phi[j], p1); };
+  const v3 h2 = qrot(s.E[3], g);                       // R3 g
+  v3 b[4];
+  b[1] = w.dB[1] * qrot(s.E[2], h2);
+  b[2] = PT(2, cross(h2, w.w2r)) + w.dB[2] * h2;
+  b[3] = PT(3, cross(g, w.w3r)) + w.dB[3] * g;
+  v3 fw[4], bw[4];
+#pragma unroll
+  for (int j = 1; j < 4; ++j) {
+    const v3 d = 2.0 * pre[j - 1].Om;
+    const v3 k1 = cross(d, b[j]);
+    const v3 k2 = pre[j - 1].c3 * cross(d, k1);
+    fw[j] = b[j] + 0.5 * k1 + k2;
+    bw[j] = b[j] - 0.5 * k1 + k2;
+  }
+  z[0] = 2.0 * qrot(c[0], -1.0 * fw[1]); z[1] = 2.0 * qrot(c[1], bw[1] - fw[2]); z[2] = 2.0 * qrot(c[2], bw[2] - fw[3]); z[3] = 2.0 * qrot(c[3], bw[3]);
 }
 
 }  // namespace lvx

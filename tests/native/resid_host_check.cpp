@@ -173,6 +173,27 @@ extern "C" int hc_so3_pull_diff(const double* cps, double u, double dt, const do
   return oka == okb ? 0 : 1;
 }
 
+// reverse mode for the body angular velocity (so3_value_w_pre + so3_pullback_w_pre: the gyroscope rows of k_imu_rot) vs so3_eval_pre: max |w_body - w|, |dw[k]^T g - z[k]|
+extern "C" int hc_so3_pullw_diff(const double* cps, double u, double dt, const double* g3, double* out2) {
+  quat c[4];
+  for (int j = 0; j < 4; ++j) c[j] = load_q(cps + 4 * j);
+  So3Pre pre[3];
+  for (int j = 0; j < 3; ++j) so3_pre(c[j], c[j + 1], &pre[j]);
+  So3Eval a;
+  const int bada = so3_eval_pre<true, true>(c, pre, u, dt, &a);
+  So3ValW w;
+  const int bad = so3_value_w_pre(c, pre, u, dt, &w);
+  if (bad & 2) return 2;
+  v3 z[4];
+  const v3 g = mk(g3[0], g3[1], g3[2]);
+  so3_pullback_w_pre(c, pre, w, g, z);
+  auto mx = [](double x, double y) { return x > y ? x : y; };
+  out2[0] = mx(mx(std::fabs(a.w_body.x - w.w_body.x), std::fabs(a.w_body.y - w.w_body.y)), std::fabs(a.w_body.z - w.w_body.z));
+  out2[1] = 0.0;
+  for (int k = 0; k < 4; ++k) { const v3 f = tmulv(a.dw[k], g); out2[1] = mx(out2[1], mx(mx(std::fabs(f.x - z[k].x), std::fabs(f.y - z[k].y)), std::fabs(f.z - z[k].z))); }
+  return bada == bad ? 0 : 1;
+}
+
 // two_point_lookup (fast path of the locked-offset LiDAR rows) against build_segments + seg_lookup: 0 = same outcome (or the fast path
 // defers to the generic one), 1 = different status, 2 = different knot reference; *code = the fast path's status
 extern "C" int hc_two_point_check(double t0, double dt, int n, double t_a, double t_b, double tau, int* code) {

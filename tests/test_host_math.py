@@ -119,6 +119,29 @@ def test_so3_reverse_mode_pullback_matches_forward_jacobian(host_check_lib, spre
     assert (n_large < 200 or spread >= 2.0) and (spread < 2.0 or n_large > 0)
 
 
+@pytest.mark.parametrize("spread", [1e-9, 1e-3, 0.05, 0.5])
+def test_so3_angular_velocity_pullback_matches_forward_jacobian(host_check_lib, spread):
+    """so3_pullback_w_pre (the gyroscope rows of k_imu_rot: dw[k]^T g by rotations and cross products) against the 3x3 blocks dw[k] of so3_eval_pre."""
+    import ctypes as C
+    rng = np.random.default_rng(13)
+    out = np.zeros(2)
+    worst = np.zeros(2)
+    n_ok = 0
+    for _ in range(200):
+        base = synth.q_from_rotvec(rng.standard_normal(3))
+        cps = np.stack([synth.qmul(synth.q_from_rotvec(spread * rng.standard_normal(3)), base) for _ in range(4)])
+        cps /= np.linalg.norm(cps, axis=1, keepdims=True)
+        g = rng.standard_normal(3)
+        rc = host_check_lib.hc_so3_pullw_diff(cps.ctypes.data_as(C.c_void_p), C.c_double(rng.uniform(0, 1)), C.c_double(0.02), g.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        assert rc == 0 or (rc == 2 and spread >= 0.5)
+        if rc == 0:
+            n_ok += 1
+            worst = np.maximum(worst, out)
+    assert n_ok > 20
+    # angular velocities are O(spread / dt) = up to 25 rad/s here, their derivatives O(1 / dt) = 50
+    assert worst[0] <= 1e-12 and worst[1] <= 2e-10
+
+
 def test_two_point_lookup_matches_segment_construction(host_check_lib):
     """The locked-offset LiDAR rows skip build_segments / seg_lookup (lvx_resid.h: two_point_lookup): same status and bit-identical knot
     reference on random times, knot-aligned times, offsets that leave the segment, out-of-range and unsorted spans."""
