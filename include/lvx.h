@@ -96,7 +96,7 @@ typedef struct lvx_layout {
   int64_t n_blocks;    /* residual blocks per evaluation */
   int64_t n_residuals; /* residual rows per evaluation */
   int32_t exact_fallback; /* 1 once an evaluation hit a case only the per-segment kernels handle exactly (merged map-time segment): they are used from then on */
-  int32_t reserved;
+  int32_t solver_fallbacks; /* LM steps so far whose cyclic-reduction factorisation lost positive definiteness and were redone by the sequential band Cholesky */
 } lvx_layout;
 
 /* lifetime ------------------------------------------------------------------------------------------------*/

@@ -124,6 +124,7 @@ struct lvx_ctx {
   // solver workspace (lvx_solver.hip)
   lvx::DevBuf d_L, d_Y, d_S, d_delta, d_diag, d_scal, d_state_try, d_zero;
   // block cyclic reduction (lvx_bcr.hip): diagonal blocks, per-level coupling blocks, pivot info; rocBLAS handle
+  int solver_fallbacks = 0;   // lvx_layout::solver_fallbacks
   lvx::DevBuf d_bcrD, d_bcrG, d_bcrInfo, d_Y2, d_gram, d_bcrLinv; bool bcr_linv = false;   // d_bcrLinv: inverses of the factors' 16 x 16 diagonal triangles (k_potrf_batched -> k_trsm_reg)
   void* blas = nullptr;
   int bcr_b = 0, bcr_nblk = 0, bcr_nreal = 0;

@@ -3016,7 +3016,7 @@ int lvx_get_layout(lvx_ctx* c, lvx_layout* o) {
   int rc = ensure_layout(c); if (rc) return rc;
   o->n_knots = c->N; o->n_landmarks = c->L; o->n_tangent = lvx_tangent_size(c); o->n_band = c->nb; o->bandwidth = c->bw; o->n_border = c->nbd; o->border_ld = c->nbd_ext;
   o->n_hub_knots = c->n_hub; o->hub_knot0 = c->hub0; o->n_blocks = c->n_blocks; o->n_residuals = c->n_residuals;
-  o->exact_fallback = c->force_legacy ? 1 : 0; o->reserved = 0;
+  o->exact_fallback = c->force_legacy ? 1 : 0; o->solver_fallbacks = c->solver_fallbacks;
   return LVX_OK;
 }
 

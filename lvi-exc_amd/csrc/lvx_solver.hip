@@ -859,6 +859,7 @@ static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double m[3
     // the cyclic-reduction elimination order can lose positive definiteness in floating point on nearly singular systems
     // (huge trust radius at convergence); the sequential band Cholesky is the exact fallback.  Purely local: no collective yet.
     rc = solve_local(c, w, radius, true, &bcr_used);
+    ++c->solver_fallbacks;
   }
   bool notpd = rc == LVX_E_NOTPD;
   int lrc = (rc != LVX_OK && rc != LVX_E_NOTPD) ? rc : LVX_OK;   // a local failure other than "not positive definite": voted, everybody leaves

@@ -35,6 +35,7 @@ def full():
     steps = {}
     for name, scaling in (("scaled", True), ("unscaled", False)):
         steps[name] = g.solve_step(RADIUS, scaling)
+    assert g.layout()["solver_fallbacks"] == 0
     g.set_switch("SOLVER_SEQ", 1)
     g.evaluate(x, normal_eq=True, dense=False, residuals=False)
     steps["scaled_seq"] = g.solve_step(RADIUS, True)
