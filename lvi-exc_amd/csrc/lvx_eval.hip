@@ -1483,6 +1483,16 @@ __global__ __launch_bounds__(256, 1) void k_imu_mfma(ImuFused fam, DevCommon cm,
 // ---------------------------------------------------------------------------------------------------------
 struct RotG { enum { NR = 3, KPK = 3, LVO = 3, NG = 3, GOFF = 5, NKL = 12, NCL = 16, NT = 1, NTP = 1, LDP = 17, GL = 32, PR = 96 }; };
 struct RotA { enum { NR = 3, KPK = 6, LVO = 0, NG = 5, GOFF = 0, NKL = 24, NCL = 30, NT = 2, NTP = 3, LDP = 33, GL = 16, PR = 48 }; };
+#ifdef LVX_ROT_KT
+__device__ __forceinline__ long long rkt_now() { long long t; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
+#define RKT(i) { const long long n_ = rkt_now(); rkt_[i] += n_ - rkt0_; rkt0_ = n_; }
+#define RKT_ARGS , long long* rkt_, long long& rkt0_
+#define RKT_PASS , rkt_, rkt0_
+#else
+#define RKT(i)
+#define RKT_ARGS
+#define RKT_PASS
+#endif
 // one accumulator register of a lane: what its (row, col) is.  kind: 0 none, 1 knot x knot, 2 knot x global, 3 knot x residual (gradient), 4 global x global, 5 global x residual
 struct RotEnt { int kind, rs, rc, cs, cc; };   // row slot / component (or global index), column slot / component (or global index)
 template <class PG> __device__ __forceinline__ RotEnt rot_entry(int ci, int cj, int v, int lane) {
@@ -1552,7 +1562,7 @@ template <class PG> __device__ __forceinline__ void rot_flush_globals(d4* D, con
 }
 // MFMA assembly of the panel that holds the rows of lanes [g0, g0 + GL): windows in ascending order; a knot that leaves is flushed before the window that follows it
 template <class PG> __device__ __forceinline__ void rot_assemble(const DevCommon& cm, d4* D, const int* tab, const double* P, int g0, bool valid, int key, int& wprev, int k_lo, int acc_lv, const int* kpos,
-                                                               int* wpos, const int* gpos, int rep, int lane) {
+                                                               int* wpos, const int* gpos, int rep, int lane RKT_ARGS) {
   constexpr int NR = PG::NR, NT = PG::NT, LDP = PG::LDP, PR = PG::PR, GL = PG::GL;
   const unsigned long long pmask = ((1ull << GL) - 1ull) << g0;
   unsigned long long rem = __ballot(valid) & pmask;
@@ -1565,7 +1575,9 @@ template <class PG> __device__ __forceinline__ void rot_assemble(const DevCommon
       // knots wprev .. min(kw - 1, wprev + 3) leave (their slot's entries are final for this wavefront), then the position table follows the new window
       if (wprev >= 0) {
         const int dend = min(kw, wprev + 4);
+        RKT(3)
         for (int d = wprev; d < dend; ++d) rot_flush<PG>(cm, D, tab, d & 3, wpos, gpos, rep);
+        RKT(4)
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
       if (lane < 24) {   // wpos[slot][comp]: the knot at slot sl of window kw is kw + ((sl - kw) & 3)
@@ -1655,6 +1667,9 @@ __global__ __launch_bounds__(256, 2) void k_imu_rot(ImuFused fam, DevCommon cm, 
   }
   const int* tabG = tabL + lane; const int* tabA = tabL + RotG::NTP * 4 * 64 + lane;
   __syncthreads();
+#ifdef LVX_ROT_KT
+  long long rkt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long rkt0_ = rkt_now(); const long long rkts_ = rkt0_;
+#endif
   for (int base = m0 + wv * 64; base < m1; base += 4 * 64) {
     const int si = base + lane;
     const bool in = si < m1;
@@ -1681,6 +1696,7 @@ __global__ __launch_bounds__(256, 2) void k_imu_rot(ImuFused fam, DevCommon cm, 
       if (valid && (key < k_lo || key - k_lo > CR + 1)) { valid = false; atomicOr(cm.err, LVX_ERR_FALLBACK); }
       else if (!valid) atomicOr(cm.err, status);
     }
+    RKT(1)
     {   // gyroscope block (gyro_residual, lvx_resid.h): row a = -w (dw[kk]^T e_a) at slot (key + kk) & 3, -w e_a for b_g, residual
       double r[3] = {0.0, 0.0, 0.0};
       const double w = fam.w_gyro;
@@ -1717,10 +1733,13 @@ __global__ __launch_bounds__(256, 2) void k_imu_rot(ImuFused fam, DevCommon cm, 
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          rot_assemble<RotG>(cm, D, tabG, P, g0, valid, key, wprev, k_lo, ACC_LV, kpos, wpos, gpos, rep, lane);
+          RKT(2)
+          rot_assemble<RotG>(cm, D, tabG, P, g0, valid, key, wprev, k_lo, ACC_LV, kpos, wpos, gpos, rep, lane RKT_PASS);
+          RKT(3)
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
         }
         if (wprev >= 0) { rot_flush<RotG>(cm, D, tabG, -1, wpos, gpos, rep); rot_flush_globals<RotG>(D, tabG, gsum, ggrad); }
+        RKT(4)
       }
     }
     {   // accelerometer block (accel_residual, lvx_resid.h)
@@ -1780,13 +1799,19 @@ __global__ __launch_bounds__(256, 2) void k_imu_rot(ImuFused fam, DevCommon cm, 
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          rot_assemble<RotA>(cm, D, tabA, P, g0, valid, key, wprev, k_lo, ACC_LV, kpos, wpos, gpos, rep, lane);
+          RKT(5)
+          rot_assemble<RotA>(cm, D, tabA, P, g0, valid, key, wprev, k_lo, ACC_LV, kpos, wpos, gpos, rep, lane RKT_PASS);
+          RKT(3)
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
         }
         if (wprev >= 0) { rot_flush<RotA>(cm, D, tabA, -1, wpos, gpos, rep); rot_flush_globals<RotA>(D, tabA, gsum, ggrad); }
+        RKT(4)
       }
     }
   }
+#ifdef LVX_ROT_KT
+  if (lane == 0 && blockIdx.x == 100) printf("RKT wv %d: eval %lld Grows %lld Arows %lld mfma %lld flush %lld total %lld\n", wv, rkt_[1], rkt_[2], rkt_[5], rkt_[3], rkt_[4], rkt_now() - rkts_);
+#endif
   mycost = wave_sum(mycost);
   if (lane == 0) atomicAdd(&cm.cost[rep], mycost);
   if (!want_ne) return;
