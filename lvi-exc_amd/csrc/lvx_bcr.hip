@@ -667,7 +667,7 @@ __global__ __launch_bounds__(64 * POTRF_REG_NW) void k_potrf_reg(double* Dm, int
   // instruction once, 160 KB of code: instruction fetch, not arithmetic, set its pace — the 16 x 16 factorisation took 4.7 k cycles inside it and 0.8 k with a
   // warm instruction cache), so the diagonal wavefront keeps its waiting tiles in LDS in the accumulator layout (every lane touches only its own four words of a
   // tile: no synchronisation, dynamic tile index); the off-diagonal tiles sit in statically indexed registers.
-  constexpr int NW = POTRF_REG_NW, NCW = 6, NTO = NT * (NT - 1) / 2, NSO = (NTO + NCW - 1) / NCW, PS = (16 * NT) | 1;
+  constexpr int NCW = 6, NTO = NT * (NT - 1) / 2, NSO = (NTO + NCW - 1) / NCW, PS = (16 * NT) | 1;
   __shared__ double Pn[2][16 * PS];    // solved row panel U[k, :], double-buffered over k
   __shared__ double Mi[2][16 * 17];    // inv(L_kk)
   __shared__ double Dg[NT][4][64];     // diagonal tiles not yet factorised (wavefront 0 only)
