@@ -286,25 +286,30 @@ __global__ __launch_bounds__(64 * NW) void k_trsm_lds(const double* __restrict__
   const int per = (ng + (int)gridDim.x - 1) / (int)gridDim.x;
   const int gbeg = blockIdx.x * per, gend = min(ng, gbeg + per);
   if (gbeg >= gend) return;
-  // 1. the factor's sub-diagonal panels -> LDS.  Thread (kk = tid >> 5, i = tid & 31 + 32 q): 256-byte runs along a column.
+  // 1. the factor's sub-diagonal panels -> LDS.  Thread (kk = tid >> 5, i = tid & 31 + 32 q): 256-byte runs along a column.  ALL loads first, then all LDS stores:
+  // panel by panel (load, wait, store) was eleven trips to memory in a row
   {
     const int kk = tid >> 5, i5 = tid & 31;
+    constexpr int QMAX = (16 * (NT - 1) + 31) / 32;
+    double v[NT > 1 ? NT - 1 : 1][QMAX];
+#pragma unroll
+    for (int p = 0; p + 1 < NT; ++p) {
+      const int col = 16 * p + kk;
+#pragma unroll
+      for (int q = 0; q < (16 * (NT - 1 - p) + 31) / 32; ++q) {
+        const int i = 16 * (p + 1) + i5 + 32 * q;
+        v[p][q] = (p < ntb && i < b && col < b && kk < 16) ? L[(size_t)col * b + i] : 0.0;   // (wavefronts 8 .. 11 of a 12-wavefront workgroup sit this out)
+      }
+    }
     int off = 0;
 #pragma unroll
-    for (int p = 0; p < NT; ++p) {
+    for (int p = 0; p + 1 < NT; ++p) {
       const int R = bp - 16 * (p + 1), PS = R | 1;
       if (p < ntb && R > 0) {   // uniform
-        const int col = 16 * p + kk;
-        double v[(16 * (NT - 1) + 31) / 32];
-#pragma unroll
-        for (int q = 0; q < (16 * (NT - 1 - p) + 31) / 32; ++q) {
-          const int i = 16 * (p + 1) + i5 + 32 * q;
-          v[q] = (i < b && col < b && kk < 16) ? L[(size_t)col * b + i] : 0.0;   // (wavefronts 8 .. 11 of a 12-wavefront workgroup sit this out)
-        }
 #pragma unroll
         for (int q = 0; q < (16 * (NT - 1 - p) + 31) / 32; ++q) {
           const int r = i5 + 32 * q;
-          if (r < R && kk < 16) Lp[off + kk * PS + r] = v[q];
+          if (r < R && kk < 16) Lp[off + kk * PS + r] = v[p][q];
         }
         off += 16 * PS;
       }
@@ -324,21 +329,23 @@ __global__ __launch_bounds__(64 * NW) void k_trsm_lds(const double* __restrict__
     // 2. 16 vectors as accumulator tiles (tile t: rows 16 t .. 16 t + 15; col = lane & 15 = vector, row = (lane >> 4) + 4 reg)
     const bool along_elems = se == 1 && sv != 1;
     d4 W[NT];
+    // every load of the 16 vectors first (tile by tile — load, transpose through LDS, next tile — was twelve trips to memory in a row for the element-contiguous sets)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (along_elems) {
-        double x[4];
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) { const int vec = vbase + fk + 4 * v, i = 16 * t + fi; x[v] = (vec < nvec && i < b) ? Vb[(size_t)vec * sv + i] : 0.0; }
+      for (int v = 0; v < 4; ++v) {
+        const int vec = along_elems ? vbase + fk + 4 * v : vbase + fi, i = along_elems ? 16 * t + fi : 16 * t + fk + 4 * v;
+        W[t][v] = (vec < nvec && i < b) ? Vb[(size_t)vec * sv + (size_t)i * se] : 0.0;
+      }
+    if (along_elems) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) Tw[(fk + 4 * v) * 17 + fi] = x[v];          // [vector][element]
+      for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Tw[(fk + 4 * v) * 17 + fi] = W[t][v];          // [vector][element]
         wave_sync();
 #pragma unroll
         for (int v = 0; v < 4; ++v) W[t][v] = Tw[fi * 17 + fk + 4 * v];
         wave_sync();
-      } else {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) { const int vec = vbase + fi, i = 16 * t + fk + 4 * v; W[t][v] = (vec < nvec && i < b) ? Vb[(size_t)vec * sv + (size_t)i * se] : 0.0; }
       }
     }
 #ifndef LVX_TRSM_NO_COMPUTE
