@@ -288,8 +288,10 @@ __global__ __launch_bounds__(64 * NW) void k_trsm_lds(const double* __restrict__
   if (gbeg >= gend) return;
   // 1. the factor's sub-diagonal panels -> LDS.  Thread (kk = tid >> 5, i = tid & 31 + 32 q): 256-byte runs along a column.  ALL loads first, then all LDS stores:
   // panel by panel (load, wait, store) was eleven trips to memory in a row
-  {
-    const int kk = tid >> 5, i5 = tid & 31;
+  constexpr int KSTEP = 2 * NW < 16 ? 2 * NW : 16;     // columns of a panel the workgroup's threads cover per trip (4 wavefronts: 8, two trips)
+#pragma unroll
+  for (int kh = 0; kh < 16; kh += KSTEP) {
+    const int kk = kh + (tid >> 5), i5 = tid & 31;
     constexpr int QMAX = (16 * (NT - 1) + 31) / 32;
     double v[NT > 1 ? NT - 1 : 1][QMAX];
 #pragma unroll
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(64 * NW) void k_trsm_lds(const double* __restrict__
 #pragma unroll
       for (int q = 0; q < (16 * (NT - 1 - p) + 31) / 32; ++q) {
         const int i = 16 * (p + 1) + i5 + 32 * q;
-        v[p][q] = (p < ntb && i < b && col < b && kk < 16) ? L[(size_t)col * b + i] : 0.0;   // (wavefronts 8 .. 11 of a 12-wavefront workgroup sit this out)
+        v[p][q] = (p < ntb && i < b && col < b && kk < kh + KSTEP) ? L[(size_t)col * b + i] : 0.0;   // (wavefronts 8 .. 11 of a 12-wavefront workgroup sit this out)
       }
     }
     int off = 0;
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(64 * NW) void k_trsm_lds(const double* __restrict__
 #pragma unroll
         for (int q = 0; q < (16 * (NT - 1 - p) + 31) / 32; ++q) {
           const int r = i5 + 32 * q;
-          if (r < R && kk < 16) Lp[off + kk * PS + r] = v[p][q];
+          if (r < R && kk < kh + KSTEP) Lp[off + kk * PS + r] = v[p][q];
         }
         off += 16 * PS;
       }
@@ -437,6 +439,13 @@ static int launch_trsm_lds_nw(lvx_ctx* c, const double* L, int b, long long stri
 template <int NT>
 static int launch_trsm_lds(lvx_ctx* c, const double* L, int b, long long strideL, double* V, long long se, long long sv, long long strideV, int nvec, int batch, const double* LI, long long strideLI,
                            const TrsmSet* second, const TrsmSet* third) {
+  // narrow levels: 4 wavefronts per workgroup (one per SIMD: a block's 28 groups on 7 CUs instead of 3 — a 12-wavefront workgroup is 25 us of MFMAs however few blocks there are)
+  {
+    int ng = (nvec + 15) / 16, nblk = batch;
+    for (const TrsmSet* t : {second, third}) if (t && t->batch > 0 && t->nvec > 0) { ng += (t->nvec + 15) / 16; nblk = std::max(nblk, t->batch + 1); }
+    if (c->sw.bcr_trsm_nw == 4 || (c->sw.bcr_trsm_nw == 0 && (long long)nblk * ((ng + 3) / 4) <= 256))
+      return launch_trsm_lds_nw<NT, 4>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, LI, strideLI, second, third);
+  }
   if (trsm_lds_bytes(b, 12) <= 160 * 1024 && c->sw.bcr_trsm_nw != 8) return launch_trsm_lds_nw<NT, 12>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, LI, strideLI, second, third);
   return launch_trsm_lds_nw<NT, 8>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, LI, strideLI, second, third);
 }
@@ -1134,6 +1143,7 @@ template <int NTB, int ZT, int SPLIT> static int launch_schur_s(lvx_ctx* c, cons
 // one workgroup per (block, output) where that fills the chip; two on the narrow levels (a single block's D update is 47 us of MFMAs on one CU)
 template <int NTB, int ZT> static int launch_schur(lvx_ctx* c, const SchurArgs& a) {
   if (3 * a.n2 >= 512) return launch_schur_s<NTB, ZT, 1>(c, a);   // measured at config 4: 209 blocks 231 us whole / 280 us split, 104 blocks 150 us whole (312 workgroups on 256 CUs: two rounds for 1.2 rounds of work)
+  if (12 * a.n2 <= 256) return launch_schur_s<NTB, ZT, 4>(c, a);   // the narrowest levels: four workgroups per output (a quarter of the tiles each, every one streams the row panel: bandwidth is not what these levels lack)
   return launch_schur_s<NTB, ZT, 2>(c, a);
 }
 static int schur_level(lvx_ctx* c, const SchurArgs& a) {
