@@ -895,12 +895,12 @@ __global__ __launch_bounds__(BACK_NT) void k_bcr_back_level(const double* __rest
   double* Mi = sp + 16;           // [16][17] inv(L_pp)
   const double* L = Dj + (size_t)k * sD;
   const double* LI = LIj + (size_t)k * sLI;
-  const double* Xp = Gl + (size_t)k * sG;
-  const double* Y = k >= 1 ? Gl + (size_t)(k - 1) * sG + bb : nullptr;
+  const double* Xp = Gl ? Gl + (size_t)k * sG : nullptr;      // Gl == null: a block without neighbours (the last one of the chain): the transposed solve only
+  const double* Y = (Gl && k >= 1) ? Gl + (size_t)(k - 1) * sG + bb : nullptr;
   double* zj = Z + zj_off + (size_t)k * sZ;
-  const double* zrg = Z + zr_off + (size_t)k * sZ;
-  const double* zlg = k >= 1 ? Z + zr_off + (size_t)(k - 1) * sZ : nullptr;
-  for (int i = tid; i < b; i += BACK_NT) { v[i] = zj[i]; zr[i] = zrg[i]; zl[i] = zlg ? zlg[i] : 0.0; }
+  const double* zrg = Gl ? Z + zr_off + (size_t)k * sZ : nullptr;
+  const double* zlg = (Gl && k >= 1) ? Z + zr_off + (size_t)(k - 1) * sZ : nullptr;
+  for (int i = tid; i < b; i += BACK_NT) { v[i] = zj[i]; zr[i] = zrg ? zrg[i] : 0.0; zl[i] = zlg ? zlg[i] : 0.0; }
   __syncthreads();
   // One sweep over the three operands, a wavefront per column and four columns of EACH operand (up to 48 loads per lane) in flight per trip — one column at a time
   // waited for every load: 95 us for a single block.
@@ -916,7 +916,7 @@ __global__ __launch_bounds__(BACK_NT) void k_bcr_back_level(const double* __rest
       for (int u = 0; u < 4; ++u) {
         const int i = i0 + q, r = lane + 64 * u;
         tl[q][u] = (i < b && i + r < b) ? L[(size_t)i * b + i + r] : 0.0;
-        tx[q][u] = (i < b && r < b) ? Xp[(size_t)i * b + r] : 0.0;
+        tx[q][u] = (Xp && i < b && r < b) ? Xp[(size_t)i * b + r] : 0.0;
         ty[q][u] = (Y && i < b && r < b) ? Y[(size_t)i * b + r] : 0.0;
       }
 #pragma unroll
@@ -1293,10 +1293,14 @@ int bcr_backward(lvx_ctx* c, double* Zy, double* Zx, int ldz, int nrhs) {
   const size_t liS = (size_t)((b + 15) / 16) * 256;
   const double one = 1.0, mone = -1.0;
   int L = 0; while ((1 << L) < nblk) ++L;
-  if ((rc = trsv_batched<true>(c, D + (size_t)(nblk - 1) * bb, b, 0, Z + (size_t)(nblk - 1) * b, 1, ldz, 0, nrhs, 1, LI ? LI + (size_t)(nblk - 1) * liS : nullptr, 0))) return rc;
   const size_t lds_fused = ((size_t)b * (b + 1) / 2 + 3 * (size_t)b + 16 + 16 * 17) * 8;
   const bool fused = nrhs == 1 && LI && lds_fused <= 160 * 1024 && !c->sw.bcr_no_fused_back;
   if (fused) LVX_HIP(c, hipFuncSetAttribute((const void*)k_bcr_back_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fused));
+  if (fused) {   // the last block of the chain: the same kernel without neighbours (the 64-vector streaming solve took 63 us for this one vector)
+    hipLaunchKernelGGL(k_bcr_back_level, dim3(1), dim3(BACK_NT), lds_fused, c->stream, (const double*)(D + (size_t)(nblk - 1) * bb), 0ll, LI + (size_t)(nblk - 1) * liS, 0ll, (const double*)nullptr, 0ll,
+                       Z, (long long)(nblk - 1) * b, 0ll, 0ll, b, 1, (long long)bb);
+    LVX_HIP(c, hipGetLastError());
+  } else if ((rc = trsv_batched<true>(c, D + (size_t)(nblk - 1) * bb, b, 0, Z + (size_t)(nblk - 1) * b, 1, ldz, 0, nrhs, 1, LI ? LI + (size_t)(nblk - 1) * liS : nullptr, 0))) return rc;
   for (int l = L - 1; l >= 0; --l) {
     const int s = 1 << l, n2 = level_batch(nblk, c->bcr_nreal, l);
     if (n2 <= 0) continue;
