@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <vector>
 #include <cmath>
+#include <string>
 #include "lvx_chol16.h"
 using namespace lvx;
 // VAR 1: the unpacked form (separate identity tile F, two MFMAs per column, no branch); 2: the same with a per-column bad-pivot branch (what the first version did)
@@ -45,7 +46,42 @@ template <int VAR> __global__ void k_probe(const double* A, double* out, long lo
   const long long t1 = __builtin_amdgcn_s_memtime();
   if (lane == 0) cyc[0] = t1 - t0;
 }
-int main() {
+// `chol16_probe check`: the product function on a family of matrices, machine-readable lines for tests/test_gpu_chol16.py:
+//   CHECK <name> <|U^T U - A| / |A|> <|M L - I|> <bad column> <upper part of M>
+static void check_mode() {
+  double *dA, *dO; long long* dC; int* dB;
+  hipMalloc(&dA, 256 * 8); hipMalloc(&dO, 512 * 8); hipMalloc(&dC, 64); hipMalloc(&dB, 4);
+  unsigned long long st = 88172645463325252ull;
+  auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (double)(st >> 11) / 9007199254740992.0 - 0.5; };
+  auto run = [&](const char* name, const std::vector<double>& A) {
+    std::vector<double> O(512); int bad = 0;
+    hipMemcpy(dA, A.data(), 256 * 8, hipMemcpyHostToDevice); hipMemset(dB, 0, 4);
+    hipLaunchKernelGGL(k_probe<0>, dim3(1), dim3(64), 0, 0, dA, dO, dC, dB); hipDeviceSynchronize();
+    hipMemcpy(O.data(), dO, 512 * 8, hipMemcpyDeviceToHost); hipMemcpy(&bad, dB, 4, hipMemcpyDeviceToHost);
+    double e1 = 0, e2 = 0, na = 0, up = 0;
+    for (int i = 0; i < 256; ++i) na = fmax(na, fabs(A[i]));
+    for (int i = 0; i < 16; ++i) for (int j = i; j < 16; ++j) { double s = 0; for (int k = 0; k <= i; ++k) s += O[k * 16 + i] * O[k * 16 + j]; e1 = fmax(e1, fabs(s - A[i * 16 + j])); }
+    for (int i = 0; i < 16; ++i) for (int j = 0; j <= i; ++j) { double s = 0; for (int k = j; k <= i; ++k) s += O[256 + i * 16 + k] * O[j * 16 + k]; e2 = fmax(e2, fabs(s - (i == j ? 1.0 : 0.0))); }
+    for (int i = 0; i < 16; ++i) for (int j = i + 1; j < 16; ++j) up = fmax(up, fabs(O[256 + i * 16 + j]));
+    printf("CHECK %s %.3e %.3e %d %.3e\n", name, e1 / na, e2, bad, up);
+  };
+  auto gram = [&](double diag, double scale) {
+    std::vector<double> B(256), A(256);
+    for (auto& x : B) x = rnd();
+    for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) { double s = (i == j) ? diag : 0.0; for (int k = 0; k < 16; ++k) s += B[i * 16 + k] * B[j * 16 + k]; A[i * 16 + j] = scale * s; }
+    return A;
+  };
+  for (int t = 0; t < 8; ++t) { char nm[32]; snprintf(nm, 32, "random%d", t); run(nm, gram(0.5, 1.0)); }
+  run("jacobi_scaled", gram(1.0, 0.25));                       // what the solver feeds it: unit-ish diagonal
+  run("large_scale", gram(0.5, 1e8));
+  run("small_scale", gram(0.5, 1e-8));
+  run("weak", gram(1e-6, 1.0));                                // smallest eigenvalue ~1e-6: the inverse amplifies
+  { std::vector<double> I(256, 0.0); for (int i = 0; i < 16; ++i) I[i * 16 + i] = 1.0; run("identity", I); }
+  { std::vector<double> A = gram(0.5, 1.0); for (int j = 0; j < 16; ++j) { A[5 * 16 + j] = 0.0; A[j * 16 + 5] = 0.0; } A[5 * 16 + 5] = -1.0; run("negative_pivot_at_6", A); }
+}
+int main(int argc, char** argv) {
+  if (argc > 1 && std::string(argv[1]) == "check") { check_mode(); return 0; }
+
   std::vector<double> A(256), B(256, 0.0);
   for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) B[i * 16 + j] = sin(1.0 + i * 3.1 + j * 1.7);
   for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) { double s = (i == j) ? 4.0 : 0.0; for (int k = 0; k < 16; ++k) s += B[i * 16 + k] * B[j * 16 + k]; A[i * 16 + j] = s; }
