@@ -943,27 +943,30 @@ __global__ __launch_bounds__(BACK_NT) void k_bcr_back_level(const double* __rest
   const int np = (b + 15) >> 4;
   double mi_next = tid < 256 ? LI[(size_t)(np - 1) * 256 + tid] : 0.0;
   __syncthreads();
+  // Right-looking: once a panel's 16 unknowns are out, every EARLIER entry takes its share at once — v[c] -= sum_i L[k0 + i][c] x[k0 + i], a 16-term product per thread from
+  // 16 contiguous words of the column-packed factor — instead of each panel first reducing over all the rows below it (64-lane reductions, two columns per wavefront:
+  // ~4 k cycles per panel); two barriers per panel remain.
   for (int p = np - 1; p >= 0; --p) {
     const int k0 = 16 * p, nk = min(16, b - k0);
     if (tid < 256) { Mi[(tid >> 4) * 17 + (tid & 15)] = mi_next; if (p > 0) mi_next = LI[(size_t)(p - 1) * 256 + tid]; }
-    // s_c = sum over the rows below the panel of L[r][k0 + c] x[r]: two columns per wavefront
-#pragma unroll
-    for (int q = 0; q < 16 / NW; ++q) {
-      const int cidx = wv * (16 / NW) + q, i = k0 + cidx;
-      double a = 0.0;
-      if (cidx < nk) { const double* col = T + coff(b, i) - i; for (int r = k0 + 16 + lane; r < b; r += 64) a += col[r] * v[r]; }
-      for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-      if (lane == 0) sp[cidx] = cidx < nk ? v[i] - a : 0.0;
-    }
-    __syncthreads();
-    if (tid < 16) {   // x_p = inv(L_pp)^T w
+    __syncthreads();                 // Mi in place; v[k0 ..] carries every later panel's update
+    if (tid < 16) {                  // x_p = inv(L_pp)^T w
       double x = 0.0;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) x += Mi[q * 17 + tid] * sp[q];
-      if (tid < nk) v[k0 + tid] = x;
+      for (int q = 0; q < 16; ++q) x += Mi[q * 17 + tid] * (q < nk ? v[k0 + q] : 0.0);
+      sp[tid] = tid < nk ? x : 0.0;
     }
     __syncthreads();
+    if (tid < 16 && tid < nk) v[k0 + tid] = sp[tid];
+    if (tid < k0) {
+      const double* col = T + coff(b, tid) + (k0 - tid);      // L[k0 .. k0 + 15][tid]
+      double a = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a += (i < nk ? col[i] : 0.0) * sp[i];
+      v[tid] -= a;
+    }
   }
+  __syncthreads();
   for (int i = tid; i < b; i += BACK_NT) zj[i] = v[i];
 }
 
