@@ -176,6 +176,32 @@ class Oracle:
         assert rc == 0
         return {"cost": cost.value, "residuals": res, "g": g, "diag": diag, "HV": HV}
 
+    def jacobian_csr(self, state):
+        """The robustified Jacobian of every residual block as one scipy CSR matrix in tangent coordinates (rows family-major like `residuals`; only free scalars
+        have entries) + the robustified residuals that go with it: dict(cost, residuals (raw), r (sqrt(rho') r), J).  OpenMP over the blocks (set_threads)."""
+        import scipy.sparse as sp
+        state = _d(state)
+        assert state.size == self.state_size
+        nt, nr = self.tangent_size, self.num_residuals
+        cost = C.c_double(0)
+        res, rs = np.zeros(nr), np.zeros(nr)
+        ptr = np.zeros(nr + 1, np.int64)
+        pc, pv = C.c_void_p(), C.c_void_p()
+        rc = self._l.orc_jacobian_csr(self._h, _p(state), C.byref(cost), _p(res), _p(rs), _p(ptr), C.byref(pc), C.byref(pv))
+        if rc == -1:
+            raise IndexError("oracle: time span out of range for trajectory (std::range_error)")
+        if rc == -2:
+            raise ValueError("oracle: logq of a non-unit quaternion (std::runtime_error)")
+        assert rc == 0
+        nnz = int(ptr[-1])
+        try:
+            cols = np.ctypeslib.as_array(C.cast(pc, C.POINTER(C.c_int32)), shape=(max(nnz, 1),))[:nnz].copy()
+            vals = np.ctypeslib.as_array(C.cast(pv, C.POINTER(C.c_double)), shape=(max(nnz, 1),))[:nnz].copy()
+        finally:
+            self._l.orc_free(pc); self._l.orc_free(pv)
+        J = sp.csr_matrix((vals, cols, ptr), shape=(nr, nt))
+        return {"cost": cost.value, "residuals": res, "r": rs, "J": J}
+
     def plus(self, state, delta):
         state, delta = _d(state), _d(delta)
         out = np.zeros_like(state)
@@ -190,6 +216,27 @@ class Oracle:
         if rc:
             raise IndexError("oracle: pose evaluation out of range")
         return {"pos": pos, "quat": quat, "vel": vel, "acc": acc, "angvel": w}
+
+
+def ata_lower(A, threads=0):
+    """Lower triangle of A^T A of a scipy CSR matrix as CSC (oracle/orc_sparse.cpp::orc_ata_lower, OpenMP over the columns); duplicates inside a row add."""
+    import scipy.sparse as sp
+    A = A.tocsr()
+    n_rows, n_cols = A.shape
+    ptr = np.ascontiguousarray(A.indptr, np.int64)
+    cols = np.ascontiguousarray(A.indices, np.int32)
+    vals = _d(A.data)
+    cptr = np.zeros(n_cols + 1, np.int64)
+    pr, pv = C.c_void_p(), C.c_void_p()
+    rc = lib().orc_ata_lower(C.c_int64(n_rows), C.c_int32(n_cols), _p(ptr), _p(cols), _p(vals), C.c_int(threads), _p(cptr), C.byref(pr), C.byref(pv))
+    assert rc == 0
+    nnz = int(cptr[-1])
+    try:
+        rows = np.ctypeslib.as_array(C.cast(pr, C.POINTER(C.c_int32)), shape=(max(nnz, 1),))[:nnz].copy()
+        v = np.ctypeslib.as_array(C.cast(pv, C.POINTER(C.c_double)), shape=(max(nnz, 1),))[:nnz].copy()
+    finally:
+        lib().orc_free(pr); lib().orc_free(pv)
+    return sp.csc_matrix((v, rows, cptr), shape=(n_cols, n_cols))
 
 
 def analytic_pass(o, state, threads=0):

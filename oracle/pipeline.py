@@ -169,8 +169,9 @@ def run_schedule(S, state0, refine_iterations=2, lvi_stage=True, camera_surfel_s
     return x, log
 
 
-def run_fixed_stages(P, x0, threads=None):
-    """Config-4 style problem (fixed surfel list, synth.make_bench_problem): trajInitFromSurfel (<= 30) then trajInitFromLVIdata (<= 80) through the oracle LM.
+def run_fixed_stages(P, x0, threads=None, sparse=False, verbose=False):
+    """Config-4 style problem (fixed surfel list, synth.make_bench_problem): trajInitFromSurfel (<= 30) then trajInitFromLVIdata (<= 80) through the oracle LM
+    (sparse=True: oracle/lm_sparse.py — generic sparse normal equations + band Cholesky, any problem size; else the dense numpy LM of oracle/lm.py).
     Returns (state, [(stage, summary, seconds)])."""
     import time
     x, log = np.array(x0, dtype=np.float64), []
@@ -193,6 +194,10 @@ def run_fixed_stages(P, x0, threads=None):
             o.set_threads(threads)
         free = lm.free_tangent_indices(N, L, locks)
         t0 = time.perf_counter()
-        x, s = lm.lm_solve(o, x, free, max_iterations=iters, n_knots=N, n_landmarks=L)
+        if sparse:
+            from . import lm_sparse
+            x, s = lm_sparse.lm_solve(o, x, free, N, L, max_iterations=iters, verbose=verbose)
+        else:
+            x, s = lm.lm_solve(o, x, free, max_iterations=iters, n_knots=N, n_landmarks=L)
         log.append((name, s, time.perf_counter() - t0))
     return x, log
