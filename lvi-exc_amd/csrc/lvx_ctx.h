@@ -118,6 +118,8 @@ struct lvx_ctx {
   int nrep = LVX_NREP;
   std::vector<int> h_chunk_k0[LVX_NUM_FAM], h_chunk_rows[LVX_NUM_FAM], det_col[LVX_NUM_FAM], det_cross_col;
   lvx::DevBuf d_det_list[LVX_NUM_FAM], d_det_cross, d_chk, d_imu_rtab;
+  // owner-computes IMU kernel (k_imu_own): batches [offsets | first interval], first batch of every workgroup, owner of every band column (-1: cleared + atomics)
+  lvx::DevBuf d_imu_chunk, d_imu_wg, d_imu_own; int imu_wg = 0, imu_nch = 0, imu_span = 0, imu_owned_cols = 0; size_t imu_own_k_off = 0; std::vector<int> imu_h_k0, imu_h_wg_c0;
   int chunk_var[LVX_NUM_FAM] = {0};   // != 0: chunks of equal ROW count (first interval of chunk c at d_chunk[n_chunk + 1 + c]) instead of equal interval count
   int n_chunk[LVX_NUM_FAM] = {0}, chunk_r[LVX_NUM_FAM] = {0};   // workgroups and knot intervals per workgroup of the MFMA assembly kernels (pick_chunk)
   lvx::DevBuf d_ord, d_Hb, d_gb, d_Bd, d_C, d_gc, d_cost, d_err, d_state, d_res, d_jcols, d_jvals, d_pairs[LVX_NUM_FAM];

@@ -1293,166 +1293,286 @@ template <class PG> __device__ __forceinline__ void imu_assemble(double* sm, dou
   }
 }
 struct ImuFused { int n; const double* t; const double* gyro; const double* acc; const int* perm; double w_gyro, w_acc; };
-static size_t imu_fused_lds_bytes(int cr) {
-  const int LV = (cr + 5) * 6;
+// OWNER-COMPUTES schedule of the fused kernel (round 4).  Round 3 launched one workgroup per chunk of 32 knot intervals (256 samples) and flushed its LDS accumulators
+// with ~7.1 k FP64 atomics (39 MB of HBM writes for 11 MB of algorithmic traffic), 782 workgroups = 3.05 rounds of the 256 CUs.  Now:
+//   * ONE workgroup per CU owns a contiguous range of samples (boundaries on knot intervals, equal row counts: 781 samples = three batches of 256 + one of 13 whose
+//     assembly is 2 windows — the work quantum of the 64-lane evaluation no longer costs a fourth, nearly empty round);
+//   * it walks its range batch by batch with the SAME LDS accumulators: the window [k_lo, k_lo + IMU_CR + 5) of knots slides with the data, the columns of the knots the
+//     next batch can no longer touch are flushed and the rest carried over — so every band column, gradient entry and IMU-calibration border entry inside the range has
+//     ONE writer, which STORES it (coalesced 16-byte stores, zeros included: these entries need no clear, k_clear reads the same ownership table);
+//   * only the 5 knots either side of a range boundary, knots next to the hub gap and knots no window covers keep the cleared-and-added-atomically protocol;
+//   * everything the batches look up — band positions, owners, the control-point-pair table — is loaded ONCE per workgroup for its whole knot range: between the flush
+//     stores of one batch and the row loads of the next there is no vector-memory load (a load's s_waitcnt vmcnt(0) waits for every store issued before it).
+// The kernel runs FIRST on the band (behind k_clear, before the LiDAR kernels), so the stores cannot overwrite another family's sums; every later family adds.
+#define IMU_CR 32                        // knot intervals a batch may span
+#define IMU_LV ((IMU_CR + 5) * 6)        // tangent scalars of the accumulator window (37 knots)
+struct ImuOwn { const int* wg_c0; const int* own_k; int nch, span; };   // batches of workgroup g: [wg_c0[g], wg_c0[g + 1]); own_k[knot] = the workgroup that stores the knot's six band columns (-1: nobody); span: knots of the widest workgroup range
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for the wave's outstanding global stores (vmcnt(0))
+#define LVX_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+static size_t imu_fused_lds_bytes(int span) {
   const int pan = std::max((int)ImuG::PR * (int)ImuG::LDP, (int)ImuA::PR * (int)ImuA::LDP);
-  return (size_t)(LV * ACC_BW + IMU_NGA * LV + IMU_NGA * IMU_NGA + LV + IMU_NGA + 4 * pan) * 8 + (size_t)(cr + 4) * sizeof(So3Pre) + (size_t)(LV + IMU_NGA) * 4 + 64;
+  return (size_t)(IMU_LV * ACC_BW + IMU_NGA * IMU_LV + IMU_NGA * IMU_NGA + IMU_LV + IMU_NGA + 4 * pan) * 8 + (size_t)span * sizeof(So3Pre) + (size_t)(7 * span + IMU_NGA) * 4 + 64;
 }
-// the per-lane scatter targets of both geometries depend on the chunk size only: built once per layout (64 lanes x 16 entries) instead of by every
+// the per-lane scatter targets of both geometries are constants of the kernel: built once per layout (64 lanes x 16 entries) instead of by every
 // wavefront of every workgroup (~4 k cycles of integer divisions and branches each)
-__global__ void k_imu_rtab(int CR, int* out) {
-  const int lane = threadIdx.x, ACC_LV = (CR + 5) * 6;
+__global__ void k_imu_rtab(int* out) {
+  const int lane = threadIdx.x;
   const double* sm = (const double*)out;    // only differences of the accumulator addresses enter the table
   ImuAccLds A;
-  A.band = (double*)sm; A.bd = A.band + ACC_LV * ACC_BW; A.gg = A.bd + IMU_NGA * ACC_LV; A.gk = A.gg + IMU_NGA * IMU_NGA; A.gG = A.gk + ACC_LV; A.lv = ACC_LV;
+  A.band = (double*)sm; A.bd = A.band + IMU_LV * ACC_BW; A.gg = A.bd + IMU_NGA * IMU_LV; A.gk = A.gg + IMU_NGA * IMU_NGA; A.gG = A.gk + IMU_LV; A.lv = IMU_LV;
   int rtg[ImuG::NTP * 4], rta[ImuA::NTP * 4];
   imu_build_rtab<ImuG>(rtg, lane, sm, A);
   imu_build_rtab<ImuA>(rta, lane, sm, A);
   for (int i = 0; i < ImuG::NTP * 4; ++i) out[i * 64 + lane] = rtg[i];
   for (int i = 0; i < ImuA::NTP * 4; ++i) out[(ImuG::NTP * 4 + i) * 64 + lane] = rta[i];
 }
-__global__ __launch_bounds__(256, 1) void k_imu_mfma(ImuFused fam, DevCommon cm, const int* __restrict__ chunk_off, long long row0_g, long long row0_a, int CR, const int* __restrict__ det_list, const int* __restrict__ rtab_g) {
+__global__ __launch_bounds__(256, 1) void k_imu_own(ImuFused fam, DevCommon cm, const int* __restrict__ chunk_off, ImuOwn ow, long long row0_g, long long row0_a, int det, const int* __restrict__ rtab_g) {
   constexpr int PAN = (ImuG::PR * ImuG::LDP > ImuA::PR * ImuA::LDP) ? ImuG::PR * ImuG::LDP : ImuA::PR * ImuA::LDP;
-  const int ACC_LV = (CR + 5) * 6;
-  extern __shared__ double sm[];
+  constexpr int ACC_LV = IMU_LV, CR = IMU_CR, HB = ACC_BW / 2;
+  extern __shared__ __attribute__((aligned(16))) double smo[];
+  double* sm = smo;
   ImuAccLds A;
   A.band = sm; A.bd = A.band + ACC_LV * ACC_BW; A.gg = A.bd + IMU_NGA * ACC_LV; A.gk = A.gg + IMU_NGA * IMU_NGA; A.gG = A.gk + ACC_LV; A.lv = ACC_LV;
   double* panels = A.gG + IMU_NGA;
-  So3Pre* pre_tab = (So3Pre*)(panels + 4 * PAN);
-  int* kpos = (int*)(pre_tab + (CR + 4));
-  int* gpos = kpos + ACC_LV;
+  So3Pre* pre_all = (So3Pre*)(panels + 4 * PAN);     // [span] pairs (k_base + e, k_base + e + 1)
+  int* kpos_all = (int*)(pre_all + ow.span);         // [6 span] band / border position of every tangent scalar of the range
+  int* kown_all = kpos_all + 6 * ow.span;            // [span] owner of the knot's columns
+  int* gpos = kown_all + ow.span;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int ch = det_list ? det_list[blockIdx.x] : blockIdx.x;
-  const int nwv = det_list ? 1 : 4;
-  const int m0 = chunk_off[ch], m1 = chunk_off[ch + 1];
-  if (m0 >= m1) return;
-  const int k_lo = ch * CR - 1;
+  const int wg = blockIdx.x;
+  const int c0 = ow.wg_c0[wg], c1 = ow.wg_c0[wg + 1];
+  if (c0 >= c1) return;
+  const int nwv = det ? 1 : 4;
   const bool want_ne = (cm.what & LVX_EVAL_NORMAL_EQ) != 0;
-  for (int e = tid; e < ACC_LV * ACC_BW + IMU_NGA * ACC_LV + IMU_NGA * IMU_NGA + ACC_LV + IMU_NGA; e += 256) sm[e] = 0.0;   // (the panels need no clearing: every row a k-step reads is rewritten, the padding columns with it)
-  for (int e = tid; e < ACC_LV; e += 256) { const int k = k_lo + e / 6; kpos[e] = (k >= 0 && k < cm.N) ? cm.ord[6 * k + e % 6] : LVX_DEAD; }
+  constexpr int NACC = ACC_LV * ACC_BW + IMU_NGA * ACC_LV + IMU_NGA * IMU_NGA + ACC_LV + IMU_NGA;
+  for (int e = tid; e < NACC; e += 256) sm[e] = 0.0;   // (the panels need no clearing: every row a k-step reads is rewritten, the padding columns with it)
   if (tid < IMU_NGA) gpos[tid] = cm.ord[6 * cm.N + tid];
-  if (tid < CR + 4) {
-    const int ka = k_lo + tid;
-    if (ka >= 0 && ka + 1 < cm.N) pre_tab[tid] = cm.pre[ka];
-    else { pre_tab[tid].Om = mk(0, 0, 0); pre_tab[tid].on = 0.0; pre_tab[tid].Jri = m3_identity(); pre_tab[tid].c3 = 1.0 / 12.0; pre_tab[tid].ok = 1; }
+  const int k_base = chunk_off[ow.nch + 1 + c0] - 1;   // one interval of slack below the first batch's first interval (a non-zero IMU time offset moves a sample by at most one)
+  for (int e = tid; e < 6 * ow.span; e += 256) { const int kn = k_base + e / 6; kpos_all[e] = (kn >= 0 && kn < cm.N) ? cm.ord[6 * kn + e % 6] : LVX_DEAD; }
+  for (int e = tid; e < ow.span; e += 256) {
+    const int kn = k_base + e;
+    kown_all[e] = (ow.own_k && kn >= 0 && kn < cm.N) ? ow.own_k[kn] : -1;
+    if (kn >= 0 && kn + 1 < cm.N) pre_all[e] = cm.pre[kn];
+    else { pre_all[e].Om = mk(0, 0, 0); pre_all[e].on = 0.0; pre_all[e].Jri = m3_identity(); pre_all[e].c3 = 1.0 / 12.0; pre_all[e].ok = 1; }
   }
   const SplineRef sp{cm.t0, cm.dt, cm.N, cm.state, cm.state + 3 * (size_t)cm.N};
   const Cal cal = load_cal(cm);
+  if (fabs(cal.imu.tau) >= cm.dt && tid == 0) atomicOr(cm.err, LVX_ERR_FALLBACK);   // the ownership rule assumes a sample moves by at most one interval (reference: tau_imu = 0 always)
   double* P = panels + wv * PAN;
-  const int rep = ch % cm.nrep;
+  const int rep = wg % cm.nrep;
   int rtg[ImuG::NTP * 4], rta[ImuA::NTP * 4];
 #pragma unroll
   for (int i = 0; i < ImuG::NTP * 4; ++i) rtg[i] = rtab_g[i * 64 + lane];
 #pragma unroll
   for (int i = 0; i < ImuA::NTP * 4; ++i) rta[i] = rtab_g[(ImuG::NTP * 4 + i) * 64 + lane];
   double mycost = 0.0;
-  __syncthreads();
-  for (int base = wv < nwv ? m0 + wv * 64 : m1; base < m1; base += nwv * 64) {
-    const int si = base + lane;
-    const bool in = si < m1;
-    int key = -1;
-    bool valid = false;
-    So3Eval e;
-    KnotRef k;
-    if (in) {
-      int status = RES_OK;
-      if (!knot_lookup(sp.t0, sp.dt, sp.n, fam.t[si], fam.t[si] + cal.imu.tau, &k)) status = RES_RANGE;
-      else {
-        key = k.i0;
-        const So3Pre* pre = (k.i0 >= k_lo && k.i0 + 2 < k_lo + CR + 4) ? pre_tab + (k.i0 - k_lo) : nullptr;
-        if (!pre) status = RES_OUTSIDE;
+  const int ld = cm.bw + 1;
+#ifdef LVX_KTIME_IMU
+  long long kt_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long kt0_ = __builtin_amdgcn_s_memtime(); const long long kts_ = kt0_;
+#define IKT(i) { const long long n_ = __builtin_amdgcn_s_memtime(); kt_[i] += n_ - kt0_; kt0_ = n_; }
+#else
+#define IKT(i)
+#endif
+  for (int c = c0; c < c1; ++c) {
+    const int m0 = chunk_off[c], m1 = chunk_off[c + 1];
+    const int k_lo = chunk_off[ow.nch + 1 + c] - 1;   // window base knot of this batch
+    const int woff = k_lo - k_base;
+    const So3Pre* pre_tab = pre_all + woff;
+    const int* kpos = kpos_all + 6 * woff;
+    if (c == c0) __syncthreads(); else LVX_LDS_BARRIER();   // the tables (global loads: full barrier) / the previous batch's carry-over are in place
+    IKT(0)
+    for (int base = wv < nwv ? m0 + wv * 64 : m1; base < m1; base += nwv * 64) {
+      const int si = base + lane;
+      const bool in = si < m1;
+      int key = -1;
+      bool valid = false;
+      So3Eval e;
+      KnotRef k;
+      if (in) {
+        int status = RES_OK;
+        if (!knot_lookup(sp.t0, sp.dt, sp.n, fam.t[si], fam.t[si] + cal.imu.tau, &k)) status = RES_RANGE;
         else {
-          quat c[4]; load_so3_cp(sp, k.i0, c);
-          const int bad = so3_eval_pre<true, true>(c, pre, k.u, sp.dt, &e);
-          if (bad) status = (bad & 1) ? RES_NONUNIT : RES_OUTSIDE;
+          key = k.i0;
+          const So3Pre* pre = (k.i0 >= k_lo && k.i0 + 2 < k_lo + CR + 4) ? pre_tab + (k.i0 - k_lo) : nullptr;
+          if (!pre) status = RES_OUTSIDE;
+          else {
+            quat cq[4]; load_so3_cp(sp, k.i0, cq);
+            const int bad = so3_eval_pre<true, true>(cq, pre, k.u, sp.dt, &e);
+            if (bad) status = (bad & 1) ? RES_NONUNIT : RES_OUTSIDE;
+          }
         }
+        valid = status == RES_OK;
+        if (valid && (key < k_lo || key - k_lo > CR + 1)) { valid = false; atomicOr(cm.err, LVX_ERR_FALLBACK); }
+        else if (!valid) atomicOr(cm.err, status);
       }
-      valid = status == RES_OK;
-      if (valid && (key < k_lo || key - k_lo > CR + 1)) { valid = false; atomicOr(cm.err, LVX_ERR_FALLBACK); }
-      else if (!valid) atomicOr(cm.err, status);
-    }
-    {   // gyroscope block (gyro_residual, lvx_resid.h)
-      double r[3], J[3][GYRO_NC];
-      if (valid) {
-        const v3 wm = load_v3(fam.gyro + 3 * (size_t)si);
-        const v3 pred = e.w_body + cal.imu.bg;
-        const double w = fam.w_gyro;
-        r[0] = w * (wm.x - pred.x); r[1] = w * (wm.y - pred.y); r[2] = w * (wm.z - pred.z);
+      IKT(1)
+      {   // gyroscope block (gyro_residual, lvx_resid.h)
+        double r[3], J[3][GYRO_NC];
+        if (valid) {
+          const v3 wm = load_v3(fam.gyro + 3 * (size_t)si);
+          const v3 pred = e.w_body + cal.imu.bg;
+          const double w = fam.w_gyro;
+          r[0] = w * (wm.x - pred.x); r[1] = w * (wm.y - pred.y); r[2] = w * (wm.z - pred.z);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+          for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+              for (int b = 0; b < 3; ++b) J[a][3 * kk + b] = -w * e.dw[kk].a[3 * a + b];
 #pragma unroll
           for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) J[a][3 * kk + b] = -w * e.dw[kk].a[3 * a + b];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int b = 0; b < 3; ++b) J[a][12 + b] = (a == b) ? -w : 0.0;
-        mycost += 0.5 * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
-        if (cm.residuals) { const long long orow = row0_g + (long long)fam.perm[si] * 3; cm.residuals[orow] = r[0]; cm.residuals[orow + 1] = r[1]; cm.residuals[orow + 2] = r[2]; }
-      }
-      if (want_ne) imu_assemble<ImuG>(sm, P, rtg, valid, key, k_lo, ACC_LV, r, J, lane);
-    }
-    {   // accelerometer block (accel_residual, lvx_resid.h)
-      double r[3], J[3][ACC_NC];
-      if (valid) {
-        R3Basis b; r3_basis(k.u, sp.dt, &b);
-        v3 acc = mk(0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc = acc + b.Ba[j] * load_v3(sp.r3 + 3 * (k.i0 + j));
-        const v3 am = load_v3(fam.acc + 3 * (size_t)si);
-        const double w = fam.w_acc;
-        const double G = -9.79;   // imu.h:25
-        const double cr = cos(cal.imu.roll), sr = sin(cal.imu.roll), cp = cos(cal.imu.pitch), sp_ = sin(cal.imu.pitch);
-        const v3 g = mk(-sp_ * cr * G, sr * G, -cr * cp * G);
-        const v3 y = acc + g;
-        const v3 yb = qrot_inv(e.q, y);
-        const v3 pred = yb + cal.imu.ba;
-        r[0] = w * (am.x - pred.x); r[1] = w * (am.y - pred.y); r[2] = w * (am.z - pred.z);
-        const m3 Rt = transpose(rotmat(e.q));
-        const m3 S = skew(yb);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const m3 Mx = S * e.dxi[kk];
-#pragma unroll
-          for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int bb = 0; bb < 3; ++bb) { J[a][6 * kk + bb] = -w * b.Ba[kk] * Rt.a[3 * a + bb]; J[a][6 * kk + 3 + bb] = -w * Mx.a[3 * a + bb]; }
+            for (int b = 0; b < 3; ++b) J[a][12 + b] = (a == b) ? -w : 0.0;
+          mycost += 0.5 * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+          if (cm.residuals) { const long long orow = row0_g + (long long)fam.perm[si] * 3; cm.residuals[orow] = r[0]; cm.residuals[orow + 1] = r[1]; cm.residuals[orow + 2] = r[2]; }
         }
-        const v3 dg_dr = Rt * mk(sp_ * sr * G, cr * G, sr * cp * G);
-        const v3 dg_dp = Rt * mk(-cp * cr * G, 0.0, cr * sp_ * G);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          J[a][24] = -w * comp(dg_dr, a); J[a][25] = -w * comp(dg_dp, a);
-#pragma unroll
-          for (int bb = 0; bb < 3; ++bb) J[a][26 + bb] = (a == bb) ? -w : 0.0;
-        }
-        mycost += 0.5 * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
-        if (cm.residuals) { const long long orow = row0_a + (long long)fam.perm[si] * 3; cm.residuals[orow] = r[0]; cm.residuals[orow + 1] = r[1]; cm.residuals[orow + 2] = r[2]; }
+        if (want_ne) imu_assemble<ImuG>(sm, P, rtg, valid, key, k_lo, ACC_LV, r, J, lane);
+        IKT(2)
       }
-      if (want_ne) imu_assemble<ImuA>(sm, P, rta, valid, key, k_lo, ACC_LV, r, J, lane);
+      {   // accelerometer block (accel_residual, lvx_resid.h)
+        double r[3], J[3][ACC_NC];
+        if (valid) {
+          R3Basis b; r3_basis(k.u, sp.dt, &b);
+          v3 acc = mk(0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc = acc + b.Ba[j] * load_v3(sp.r3 + 3 * (k.i0 + j));
+          const v3 am = load_v3(fam.acc + 3 * (size_t)si);
+          const double w = fam.w_acc;
+          const double G = -9.79;   // imu.h:25
+          const double cr = cos(cal.imu.roll), sr = sin(cal.imu.roll), cp = cos(cal.imu.pitch), sp_ = sin(cal.imu.pitch);
+          const v3 g = mk(-sp_ * cr * G, sr * G, -cr * cp * G);
+          const v3 y = acc + g;
+          const v3 yb = qrot_inv(e.q, y);
+          const v3 pred = yb + cal.imu.ba;
+          r[0] = w * (am.x - pred.x); r[1] = w * (am.y - pred.y); r[2] = w * (am.z - pred.z);
+          const m3 Rt = transpose(rotmat(e.q));
+          const m3 S = skew(yb);
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const m3 Mx = S * e.dxi[kk];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+              for (int bb = 0; bb < 3; ++bb) { J[a][6 * kk + bb] = -w * b.Ba[kk] * Rt.a[3 * a + bb]; J[a][6 * kk + 3 + bb] = -w * Mx.a[3 * a + bb]; }
+          }
+          const v3 dg_dr = Rt * mk(sp_ * sr * G, cr * G, sr * cp * G);
+          const v3 dg_dp = Rt * mk(-cp * cr * G, 0.0, cr * sp_ * G);
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            J[a][24] = -w * comp(dg_dr, a); J[a][25] = -w * comp(dg_dp, a);
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb) J[a][26 + bb] = (a == bb) ? -w : 0.0;
+          }
+          mycost += 0.5 * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+          if (cm.residuals) { const long long orow = row0_a + (long long)fam.perm[si] * 3; cm.residuals[orow] = r[0]; cm.residuals[orow + 1] = r[1]; cm.residuals[orow + 2] = r[2]; }
+        }
+        if (want_ne) imu_assemble<ImuA>(sm, P, rta, valid, key, k_lo, ACC_LV, r, J, lane);
+        IKT(3)
+      }
     }
+    if (!want_ne) continue;
+    // ---- batch end: flush the columns no later batch of this workgroup can touch, carry the others over ----
+    int bt = tid; asm volatile("" : "+v"(bt));   // opaque copy: the index arithmetic below is thread-invariant — hoisted out of the batch loop it would live (spilled) across the hot loop
+    const bool more = c + 1 < c1;
+    const int nfl = more ? min(ACC_LV, max(0, 6 * (chunk_off[ow.nch + 1 + c + 1] - 1 - k_lo))) : ACC_LV;
+    const int* kown = kown_all + woff;   // per knot
+    const int any_unowned = __syncthreads_or(bt < nfl && kpos[bt] != LVX_DEAD && kown[bt / 6] != wg);   // (the barrier: every wavefront's sums are in the LDS accumulators)
+    IKT(4)
+    if (any_unowned) {
+      // rare (a range's first / last batch, the hub gap, hub knots = border rows): columns this workgroup does not store keep the cleared-and-added protocol
+      for (int e = bt; e < nfl * ACC_BW; e += 256) {
+        const int la = e / ACC_BW, lb = la + e % ACC_BW;
+        const int pa = kpos[la], o = kown[la / 6];
+        if (o == wg || pa == LVX_DEAD || lb >= ACC_LV) continue;
+        const double v = A.band[e];
+        if (v == 0.0) continue;
+        if (o >= 0) { atomicOr(cm.err, LVX_ERR_FALLBACK); continue; }   // another workgroup STORES this column: cannot happen while |tau_imu| < dt
+        const int pb = kpos[lb];
+        if (pb != LVX_DEAD) add_H(cm, pa, pb, v, rep);
+      }
+      for (int gi = 0; gi < IMU_NGA; ++gi)
+        for (int la = bt; la < nfl; la += 256) {
+          const int pg = gpos[gi], pa = kpos[la], o = kown[la / 6];
+          if (pg == LVX_DEAD || pa == LVX_DEAD || (o == wg && pg < 0)) continue;
+          const double v = A.bd[gi * ACC_LV + la];
+          if (v == 0.0) continue;
+          if (o >= 0) atomicOr(cm.err, LVX_ERR_FALLBACK); else add_H(cm, pg, pa, v, rep);
+        }
+      if (bt < nfl && kpos[bt] != LVX_DEAD && kown[bt / 6] != wg) {
+        const double v = A.gk[bt];
+        if (v != 0.0) { if (kown[bt / 6] >= 0) atomicOr(cm.err, LVX_ERR_FALLBACK); else add_g(cm, kpos[bt], v, rep); }
+      }
+      LVX_LDS_BARRIER();   // the register pass below zeroes what it reads
+    }
+    IKT(6)
+    {
+      // Every thread takes its share of the accumulators into registers (band: pairs of entries, 16 bytes) together with what it needs to route them, and leaves
+      // ZERO behind; ONE barrier; then each value goes where it belongs: a finished column to HBM (stored by its owner), a live one down by nfl rows in LDS.  The
+      // phase is a chain of dependent LDS reads and branches on one wavefront per SIMD: table reads hoisted in front of the barrier, routing by predication.
+      constexpr int NQB = (ACC_LV * HB + 255) / 256, NQD = (IMU_NGA * ACC_LV + 255) / 256;
+      double2* band2 = (double2*)A.band;
+      double2 vb[NQB]; int pb_[NQB], ob_[NQB];
+#pragma unroll
+      for (int q = 0; q < NQB; ++q) {
+        const int e2 = bt + 256 * q;
+        const bool inr = e2 < ACC_LV * HB;
+        const int la = inr ? e2 / HB : 0;
+        vb[q] = inr ? band2[e2] : make_double2(0.0, 0.0);
+        pb_[q] = kpos[la]; ob_[q] = kown[la / 6];
+        if (inr && more) band2[e2] = make_double2(0.0, 0.0);
+      }
+      double vd[NQD], vg = 0.0; int pd_[NQD], od_[NQD], pg_ = LVX_DEAD, og_ = -1;
+#pragma unroll
+      for (int q = 0; q < NQD; ++q) {
+        const int e = bt + 256 * q;
+        const bool inr = e < IMU_NGA * ACC_LV;
+        const int la = inr ? e % ACC_LV : 0;
+        vd[q] = inr ? A.bd[e] : 0.0;
+        pd_[q] = kpos[la]; od_[q] = kown[la / 6];
+        if (inr && more) A.bd[e] = 0.0;
+      }
+      if (bt < ACC_LV) { vg = A.gk[bt]; pg_ = kpos[bt]; og_ = kown[bt / 6]; if (more) A.gk[bt] = 0.0; }
+      int gp_[NQD];
+#pragma unroll
+      for (int q = 0; q < NQD; ++q) { const int e = bt + 256 * q; gp_[q] = gpos[e < IMU_NGA * ACC_LV ? e / ACC_LV : 0]; }
+      LVX_LDS_BARRIER();
+      IKT(7)
+#pragma unroll
+      for (int q = 0; q < NQB; ++q) {
+        const int e2 = bt + 256 * q;
+        const int la = e2 / HB, d = 2 * (e2 % HB);
+        const bool inr = e2 < ACC_LV * HB;
+        if (inr && la >= nfl) band2[e2 - nfl * HB] = vb[q];
+        if (inr && la < nfl && ob_[q] == wg) {
+          double* dst = cm.Hb + (size_t)pb_[q] * ld + d;
+          if (d + 1 < ld && !(((size_t)pb_[q] * ld + d) & 1)) *(double2*)dst = vb[q];
+          else { if (d < ld) dst[0] = vb[q].x; if (d + 1 < ld) dst[1] = vb[q].y; }
+        }
+      }
+      IKT(8)
+#pragma unroll
+      for (int q = 0; q < NQD; ++q) {
+        const int e = bt + 256 * q;
+        const int la = e % ACC_LV;
+        const bool inr = e < IMU_NGA * ACC_LV;
+        if (inr && la >= nfl) A.bd[e - nfl] = vd[q];
+        if (inr && la < nfl && od_[q] == wg && gp_[q] < 0 && gp_[q] != LVX_DEAD) cm.Bd[(size_t)(-1 - gp_[q]) * cm.nb + pd_[q]] = vd[q];
+      }
+      if (bt < ACC_LV) {
+        if (bt >= nfl) A.gk[bt - nfl] = vg;
+        else if (og_ == wg) cm.gb[pg_] = vg;
+      }
+      IKT(9)
+    }
+    IKT(5)
   }
+#ifdef LVX_KTIME_IMU
+  if (lane == 0 && (wg == 5 || wg == 100)) printf("IKT wg %d wv %d batches %d: sync0 %lld eval %lld G %lld A %lld sync %lld | slow %lld read+bar %lld band %lld bd+gk %lld zero %lld | total %lld\n", wg, wv, c1 - c0, kt_[0], kt_[1], kt_[2], kt_[3], kt_[4], kt_[6], kt_[7], kt_[8], kt_[9], kt_[5],
+                                                   (long long)__builtin_amdgcn_s_memtime() - kts_);
+#endif
   mycost = wave_sum(mycost);
   if (lane == 0) atomicAdd(&cm.cost[rep], mycost);
   if (!want_ne) return;
-  __syncthreads();
-  for (int e = tid; e < ACC_LV * ACC_BW; e += 256) {
-    const double v = A.band[e];
-    if (v == 0.0) continue;
-    const int la = e / ACC_BW, lb = la + e % ACC_BW;
-    if (lb >= ACC_LV) continue;
-    const int pa = kpos[la], pb = kpos[lb];
-    if (pa == LVX_DEAD || pb == LVX_DEAD) continue;
-    add_H(cm, pa, pb, v, rep);
-  }
-  for (int e = tid; e < IMU_NGA * ACC_LV; e += 256) {
-    const double v = A.bd[e];
-    if (v == 0.0) continue;
-    const int pg = gpos[e / ACC_LV], pk2 = kpos[e % ACC_LV];
-    if (pg == LVX_DEAD || pk2 == LVX_DEAD) continue;
-    add_H(cm, pg, pk2, v, rep);
-  }
   for (int e = tid; e < IMU_NGA * IMU_NGA; e += 256) {
     const int ga = e / IMU_NGA, gb2 = e % IMU_NGA;
     if (gb2 < ga) continue;
@@ -1460,370 +1580,7 @@ __global__ __launch_bounds__(256, 1) void k_imu_mfma(ImuFused fam, DevCommon cm,
     if (v == 0.0 || gpos[ga] == LVX_DEAD || gpos[gb2] == LVX_DEAD) continue;
     add_H(cm, gpos[ga], gpos[gb2], v, rep);
   }
-  for (int e = tid; e < ACC_LV; e += 256) { const double v = A.gk[e]; if (v != 0.0 && kpos[e] != LVX_DEAD) add_g(cm, kpos[e], v, rep); }
   if (tid < IMU_NGA) { const double v = A.gG[tid]; if (v != 0.0 && gpos[tid] != LVX_DEAD) add_g(cm, gpos[tid], v, rep); }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Fused IMU kernel, second form (k_imu_rot, LVX_IMU_ROT=1; NOT the default — measured slower, kept as the worked-out base of the two-wavefronts-per-SIMD design).
-// k_imu_mfma needs 502 registers per lane (the SO3 evaluation with both derivative sets + a 3 x 29 Jacobian block) and 117 KB of LDS (57 KB of band / border accumulators
-// shared by the workgroup + 52 KB of panels), i.e. ONE wavefront per SIMD with every LDS, MFMA and atomic latency exposed.  Here
-//   * no derivative blocks and no Jacobian array: the rows come from reverse-mode pullbacks (so3_pullback_w_pre for the gyroscope, so3_pullback_pre for the accelerometer:
-//     vectors only) and go to the panel as they are computed, one residual component at a time;
-//   * the window accumulators ROTATE in registers: the knot columns of a window sit at slot = knot mod 4, so moving from interval i to i + 1 keeps three of the four
-//     knots in place and the MFMAs simply go on accumulating; when a knot LEAVES exactly the accumulator entries of its slot are final for this wavefront: they are flushed
-//     straight from the registers (one global atomic per entry) and zeroed — no LDS accumulators, no scatter per window, no flush pass;
-//   * globals x globals and the globals' gradient stay in registers for the whole wavefront and are reduced over the workgroup's wavefronts at the end.
-// LDS 64 KB (panels 52, control points, pair table, position and flush tables): two workgroups per CU at 256 registers (68 spilled; 356 without the limit).
-// Result at config 4: bit-for-bit the same normal equations up to summation order (tests/test_gpu_variants.py), 242 us solo against 200 — and 357 us when compiled for
-// one wavefront per SIMD: a wavefront does ~1.8x the work of k_imu_mfma's, because a 13 KB panel holds 16 (accelerometer) / 32 (gyroscope) lanes' rows and the pullbacks
-// are recomputed for every panel group (18 per wavefront instead of 6; the Jacobian array that avoided this is what cost the registers), and the per-window flush is
-// ~16 global-atomic instructions with their address arithmetic.  What would make it pay: panels for all 64 lanes (needs the rows in a compact form) or a flush through
-// LDS once per wavefront instead of once per window.
-// ---------------------------------------------------------------------------------------------------------
-struct RotG { enum { NR = 3, KPK = 3, LVO = 3, NG = 3, GOFF = 5, NKL = 12, NCL = 16, NT = 1, NTP = 1, LDP = 17, GL = 32, PR = 96 }; };
-struct RotA { enum { NR = 3, KPK = 6, LVO = 0, NG = 5, GOFF = 0, NKL = 24, NCL = 30, NT = 2, NTP = 3, LDP = 33, GL = 16, PR = 48 }; };
-#ifdef LVX_ROT_KT
-__device__ __forceinline__ long long rkt_now() { long long t; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
-#define RKT(i) { const long long n_ = rkt_now(); rkt_[i] += n_ - rkt0_; rkt0_ = n_; }
-#define RKT_ARGS , long long* rkt_, long long& rkt0_
-#define RKT_PASS , rkt_, rkt0_
-#else
-#define RKT(i)
-#define RKT_ARGS
-#define RKT_PASS
-#endif
-// one accumulator register of a lane: what its (row, col) is.  kind: 0 none, 1 knot x knot, 2 knot x global, 3 knot x residual (gradient), 4 global x global, 5 global x residual
-struct RotEnt { int kind, rs, rc, cs, cc; };   // row slot / component (or global index), column slot / component (or global index)
-template <class PG> __device__ __forceinline__ RotEnt rot_entry(int ci, int cj, int v, int lane) {
-  const int row = 16 * ci + (lane >> 4) + 4 * v, col = 16 * cj + (lane & 15);
-  RotEnt e{0, 0, 0, 0, 0};
-  if (ci == cj && col < row) return e;               // lower triangle of a diagonal tile
-  const bool rk = row < PG::NKL, rg = !rk && row < PG::NKL + PG::NG;
-  const bool ck = col < PG::NKL, cg = !ck && col < PG::NKL + PG::NG, cr = col == PG::NKL + PG::NG;
-  if (rk) { e.rs = row / PG::KPK; e.rc = PG::LVO + row % PG::KPK; }
-  else if (rg) e.rc = PG::GOFF + row - PG::NKL;
-  if (ck) { e.cs = col / PG::KPK; e.cc = PG::LVO + col % PG::KPK; }
-  else if (cg) e.cc = PG::GOFF + col - PG::NKL;
-  if (rk) e.kind = ck ? 1 : (cg ? 2 : (cr ? 3 : 0));
-  else if (rg) e.kind = cg ? 4 : (cr ? 5 : 0);
-  return e;
-}
-// packed form of RotEnt, one int per accumulator register of a lane, built once per wavefront (the classification costs ~30 instructions per register: divisions by
-// the slot width, range tests — per flush that was as much VALU work as the evaluation): kind (3 bits) | row index into wpos (5) << 3 | column index into wpos or gpos (5) << 8 |
-// row slot (2) << 13 | column slot (2) << 15
-template <class PG> __device__ __forceinline__ void rot_table(int* tab, int lane) {
-  int t = 0;
-#pragma unroll
-  for (int ci = 0; ci < PG::NT; ++ci)
-#pragma unroll
-    for (int cj = ci; cj < PG::NT; ++cj, ++t)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const RotEnt e = rot_entry<PG>(ci, cj, v, lane);
-        const int ridx = e.kind >= 1 && e.kind <= 3 ? e.rs * 6 + e.rc : e.rc;
-        const int cidx = e.kind == 1 ? e.cs * 6 + e.cc : e.cc;
-        tab[t * 4 + v] = e.kind | (ridx << 3) | (cidx << 8) | (e.rs << 13) | (e.cs << 15);
-      }
-}
-// flush what is final when the knot at slot s leaves (s < 0: everything that involves a knot): wpos[slot * 6 + comp] = position of that tangent scalar (this wavefront's LDS table)
-template <class PG> __device__ __forceinline__ void rot_flush(const DevCommon& cm, d4* D, const int* tab, int s, const int* wpos, const int* gpos, int rep) {
-#pragma unroll
-  for (int t = 0; t < PG::NTP; ++t)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int e = tab[(t * 4 + v) * 64], kind = e & 7;
-      const bool knot_entry = kind >= 1 && kind <= 3;
-      const bool hit = knot_entry && (s < 0 || ((e >> 13) & 3) == s || (kind == 1 && ((e >> 15) & 3) == s));
-      if (!hit) continue;
-      const double val = D[t][v];
-      D[t][v] = 0.0;
-      if (val == 0.0) continue;
-      const int pa = wpos[(e >> 3) & 31];
-      if (pa == LVX_DEAD) continue;
-      if (kind == 3) { add_g(cm, pa, val, rep); continue; }
-      const int pb = kind == 1 ? wpos[(e >> 8) & 31] : gpos[(e >> 8) & 31];
-      if (pb == LVX_DEAD) continue;
-      add_H(cm, pa, pb, val, rep);
-    }
-}
-// the wavefront's global x global block and global gradient -> the workgroup's LDS sums (gsum[8][8], ggrad[8])
-template <class PG> __device__ __forceinline__ void rot_flush_globals(d4* D, const int* tab, double* gsum, double* ggrad) {
-#pragma unroll
-  for (int t = 0; t < PG::NTP; ++t)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int e = tab[(t * 4 + v) * 64], kind = e & 7;
-      if (kind < 4) continue;
-      const double val = D[t][v];
-      if (val == 0.0) continue;
-      if (kind == 4) atomicAdd(&gsum[((e >> 3) & 31) * IMU_NGA + ((e >> 8) & 31)], val); else atomicAdd(&ggrad[(e >> 3) & 31], val);
-    }
-}
-// MFMA assembly of the panel that holds the rows of lanes [g0, g0 + GL): windows in ascending order; a knot that leaves is flushed before the window that follows it
-template <class PG> __device__ __forceinline__ void rot_assemble(const DevCommon& cm, d4* D, const int* tab, const double* P, int g0, bool valid, int key, int& wprev, int k_lo, int acc_lv, const int* kpos,
-                                                               int* wpos, const int* gpos, int rep, int lane RKT_ARGS) {
-  constexpr int NR = PG::NR, NT = PG::NT, LDP = PG::LDP, PR = PG::PR, GL = PG::GL;
-  const unsigned long long pmask = ((1ull << GL) - 1ull) << g0;
-  unsigned long long rem = __ballot(valid) & pmask;
-  while (rem) {
-    const int l0 = __ffsll((long long)rem) - 1;
-    const int kw = __builtin_amdgcn_readfirstlane(__shfl(key, l0));
-    const unsigned long long wm = __ballot(valid && key == kw) & pmask;
-    rem &= ~wm;
-    if (kw != wprev) {
-      // knots wprev .. min(kw - 1, wprev + 3) leave (their slot's entries are final for this wavefront), then the position table follows the new window
-      if (wprev >= 0) {
-        const int dend = min(kw, wprev + 4);
-        RKT(3)
-        for (int d = wprev; d < dend; ++d) rot_flush<PG>(cm, D, tab, d & 3, wpos, gpos, rep);
-        RKT(4)
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-      if (lane < 24) {   // wpos[slot][comp]: the knot at slot sl of window kw is kw + ((sl - kw) & 3)
-        const int sl = lane / 6, cp = lane % 6, kn = kw + ((sl - kw) & 3), e = (kn - k_lo) * 6 + cp;
-        wpos[lane] = (e >= 0 && e < acc_lv) ? kpos[e] : LVX_DEAD;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      wprev = kw;
-    }
-    const int lhi = 63 - __clzll((long long)wm);
-    const int r_lo = (l0 - g0) * NR, r_hi = (lhi - g0 + 1) * NR;
-    const unsigned long long wsh = wm >> g0;
-    const bool contig = __popcll(wm) == lhi - l0 + 1;
-    const int nks = (r_hi - r_lo + 3) >> 2;
-    auto trip = [&](int ks, auto UC) {
-      constexpr int U = decltype(UC)::value;
-      double f[U][NT];
-#pragma unroll
-      for (int q = 0; q < U; ++q) {
-        const int rr = r_lo + 4 * (ks + q) + (lane >> 4);
-        bool mine = rr < r_hi;
-        if (!contig) mine = mine && ((wsh >> (rr / NR)) & 1ull);
-        const double* src = P + min(rr, PR - 1) * LDP + (lane & 15);
-#pragma unroll
-        for (int c = 0; c < NT; ++c) { const double x = src[c * 16]; f[q][c] = mine ? x : 0.0; }
-      }
-#pragma unroll
-      for (int q = 0; q < U; ++q) {
-        int t = 0;
-#pragma unroll
-        for (int ci = 0; ci < NT; ++ci)
-#pragma unroll
-          for (int cj = ci; cj < NT; ++cj, ++t) D[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[q][ci], f[q][cj], D[t], 0, 0, 0);
-      }
-    };
-    int ks = 0;
-    for (; ks + 3 <= nks; ks += 3) trip(ks, std::integral_constant<int, 3>{});     // a full interval of 8 samples = 6 k-steps = two trips (six at once: 12 more live registers)
-    for (; ks < nks; ks += 1) trip(ks, std::integral_constant<int, 1>{});
-  }
-}
-static size_t imu_rot_lds_bytes(int cr) {
-  const int LV = (cr + 5) * 6;
-  const int pan = std::max((int)RotG::PR * (int)RotG::LDP, (int)RotA::PR * (int)RotA::LDP);
-  return (size_t)(4 * pan + IMU_NGA * IMU_NGA + IMU_NGA + 4 * (cr + 5)) * 8 + (size_t)(cr + 4) * sizeof(So3Pre) + (size_t)(LV + IMU_NGA + 4 * 24 + 16 * 64) * 4 + 64;
-}
-__global__ __launch_bounds__(256, 2) void k_imu_rot(ImuFused fam, DevCommon cm, const int* __restrict__ chunk_off, long long row0_g, long long row0_a, int CR) {
-  constexpr int PAN = (RotG::PR * RotG::LDP > RotA::PR * RotA::LDP) ? RotG::PR * RotG::LDP : RotA::PR * RotA::LDP;
-  const int ACC_LV = (CR + 5) * 6;
-  extern __shared__ double sm[];
-  double* panels = sm;
-  double* gsum = panels + 4 * PAN;                  // [8][8] globals x globals of the workgroup
-  double* ggrad = gsum + IMU_NGA * IMU_NGA;         // [8]
-  quat* cps = (quat*)(ggrad + IMU_NGA);             // [CR + 5] the chunk's SO3 control points k_lo .. k_lo + CR + 4 (read by every pullback: 32 registers if kept)
-  So3Pre* pre_tab = (So3Pre*)(cps + (CR + 5));
-  int* kpos = (int*)(pre_tab + (CR + 4));           // [ACC_LV]
-  int* gpos = kpos + ACC_LV;                        // [8]
-  int* wpos_all = gpos + IMU_NGA;                   // [4 wavefronts][24]
-  int* tabL = wpos_all + 4 * 24;                    // [4 + 12][64]: the flush tables of both geometries (lane-dependent only; in registers they cost 16 and spilled)
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int ch = blockIdx.x;
-  const int m0 = chunk_off[ch], m1 = chunk_off[ch + 1];
-  if (m0 >= m1) return;
-  const int k_lo = ch * CR - 1;
-  const bool want_ne = (cm.what & LVX_EVAL_NORMAL_EQ) != 0;
-  for (int e = tid; e < IMU_NGA * IMU_NGA + IMU_NGA; e += 256) gsum[e] = 0.0;
-  for (int e = tid; e < ACC_LV; e += 256) { const int k = k_lo + e / 6; kpos[e] = (k >= 0 && k < cm.N) ? cm.ord[6 * k + e % 6] : LVX_DEAD; }
-  if (tid < IMU_NGA) gpos[tid] = cm.ord[6 * cm.N + tid];
-  if (tid < CR + 4) {
-    const int ka = k_lo + tid;
-    if (ka >= 0 && ka + 1 < cm.N) pre_tab[tid] = cm.pre[ka];
-    else { pre_tab[tid].Om = mk(0, 0, 0); pre_tab[tid].on = 0.0; pre_tab[tid].Jri = m3_identity(); pre_tab[tid].c3 = 1.0 / 12.0; pre_tab[tid].ok = 1; }
-  }
-  const SplineRef sp{cm.t0, cm.dt, cm.N, cm.state, cm.state + 3 * (size_t)cm.N};
-  if (tid < CR + 5) { const int ka = min(max(k_lo + tid, 0), cm.N - 1); cps[tid] = load_q(sp.so3 + 4 * (size_t)ka); }
-  const Cal cal = load_cal(cm);
-  double* P = panels + wv * PAN;
-  int* wpos = wpos_all + wv * 24;
-  const int rep = ch % cm.nrep;
-  double mycost = 0.0;
-  if (wv == 0) {
-    int tg[RotG::NTP * 4], ta[RotA::NTP * 4];
-    rot_table<RotG>(tg, lane); rot_table<RotA>(ta, lane);
-#pragma unroll
-    for (int i = 0; i < RotG::NTP * 4; ++i) tabL[i * 64 + lane] = tg[i];
-#pragma unroll
-    for (int i = 0; i < RotA::NTP * 4; ++i) tabL[(RotG::NTP * 4 + i) * 64 + lane] = ta[i];
-  }
-  const int* tabG = tabL + lane; const int* tabA = tabL + RotG::NTP * 4 * 64 + lane;
-  __syncthreads();
-#ifdef LVX_ROT_KT
-  long long rkt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long rkt0_ = rkt_now(); const long long rkts_ = rkt0_;
-#endif
-  for (int base = m0 + wv * 64; base < m1; base += 4 * 64) {
-    const int si = base + lane;
-    const bool in = si < m1;
-    int key = -1;
-    bool valid = false;
-    KnotRef k;
-    const So3Pre* pre = pre_tab;
-    So3ValW sv;
-    const quat* c = cps;
-    if (in) {
-      int status = RES_OK;
-      if (!knot_lookup(sp.t0, sp.dt, sp.n, fam.t[si], fam.t[si] + cal.imu.tau, &k)) status = RES_RANGE;
-      else {
-        key = k.i0;
-        if (!(k.i0 >= k_lo && k.i0 + 2 < k_lo + CR + 4)) status = RES_OUTSIDE;
-        else {
-          pre = pre_tab + (k.i0 - k_lo);
-          c = cps + (k.i0 - k_lo);
-          const int bad = so3_value_w_pre(c, pre, k.u, sp.dt, &sv);     // value + what the reverse-mode rows need: vectors only, no 3 x 3 derivative blocks
-          if (bad) status = (bad & 1) ? RES_NONUNIT : RES_OUTSIDE;
-        }
-      }
-      valid = status == RES_OK;
-      if (valid && (key < k_lo || key - k_lo > CR + 1)) { valid = false; atomicOr(cm.err, LVX_ERR_FALLBACK); }
-      else if (!valid) atomicOr(cm.err, status);
-    }
-    RKT(1)
-    {   // gyroscope block (gyro_residual, lvx_resid.h): row a = -w (dw[kk]^T e_a) at slot (key + kk) & 3, -w e_a for b_g, residual
-      double r[3] = {0.0, 0.0, 0.0};
-      const double w = fam.w_gyro;
-      if (valid) {
-        const v3 wm = load_v3(fam.gyro + 3 * (size_t)si);
-        const v3 pred = sv.w_body + cal.imu.bg;
-        r[0] = w * (wm.x - pred.x); r[1] = w * (wm.y - pred.y); r[2] = w * (wm.z - pred.z);
-        mycost += 0.5 * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
-        if (cm.residuals) { const long long orow = row0_g + (long long)fam.perm[si] * 3; cm.residuals[orow] = r[0]; cm.residuals[orow + 1] = r[1]; cm.residuals[orow + 2] = r[2]; }
-      }
-      if (want_ne) {
-        d4 D[RotG::NTP];
-        D[0] = d4{0.0, 0.0, 0.0, 0.0};
-        int wprev = -1;
-        const unsigned long long vm = __ballot(valid);
-        for (int g0 = 0; g0 < 64; g0 += RotG::GL) {
-          if (!(vm & (((1ull << RotG::GL) - 1ull) << g0))) continue;
-          const bool mine = lane >= g0 && lane < g0 + RotG::GL;
-          const int li = mine ? lane - g0 : 0;
-#pragma unroll 1
-          for (int a = 0; a < 3; ++a) {     // the rows are recomputed for every panel group (two): three pullbacks, no Jacobian array; NOT unrolled: one row's vectors live at a time
-            v3 z[4];
-            if (valid) so3_pullback_w_pre(c, pre, sv, mk(a == 0 ? 1.0 : 0.0, a == 1 ? 1.0 : 0.0, a == 2 ? 1.0 : 0.0), z);
-            if (mine) {
-              double* prow = P + (li * 3 + a) * RotG::LDP;
-#pragma unroll
-              for (int kk = 0; kk < 4; ++kk) {
-                double* pk = prow + 3 * ((key + kk) & 3);
-                pk[0] = valid ? -w * z[kk].x : 0.0; pk[1] = valid ? -w * z[kk].y : 0.0; pk[2] = valid ? -w * z[kk].z : 0.0;
-              }
-#pragma unroll
-              for (int b = 0; b < 3; ++b) prow[12 + b] = (valid && a == b) ? -w : 0.0;
-              prow[15] = valid ? (a == 0 ? r[0] : (a == 1 ? r[1] : r[2])) : 0.0;
-            }
-          }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          RKT(2)
-          rot_assemble<RotG>(cm, D, tabG, P, g0, valid, key, wprev, k_lo, ACC_LV, kpos, wpos, gpos, rep, lane RKT_PASS);
-          RKT(3)
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-        }
-        if (wprev >= 0) { rot_flush<RotG>(cm, D, tabG, -1, wpos, gpos, rep); rot_flush_globals<RotG>(D, tabG, gsum, ggrad); }
-        RKT(4)
-      }
-    }
-    {   // accelerometer block (accel_residual, lvx_resid.h)
-      double r[3] = {0.0, 0.0, 0.0};
-      const double w = fam.w_acc;
-      double Ba[4] = {0.0, 0.0, 0.0, 0.0};
-      v3 yb = mk(0, 0, 0), dg_dr = mk(0, 0, 0), dg_dp = mk(0, 0, 0);
-      if (valid) {
-        R3Basis bs;
-        r3_basis(k.u, sp.dt, &bs);
-        v3 acc = mk(0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { Ba[j] = bs.Ba[j]; acc = acc + bs.Ba[j] * load_v3(sp.r3 + 3 * (k.i0 + j)); }
-        const v3 am = load_v3(fam.acc + 3 * (size_t)si);
-        const double G = -9.79;   // imu.h:25
-        const double cr = cos(cal.imu.roll), sr = sin(cal.imu.roll), cp = cos(cal.imu.pitch), sp_ = sin(cal.imu.pitch);
-        const v3 g = mk(-sp_ * cr * G, sr * G, -cr * cp * G);
-        yb = qrot_inv(sv.s.q, acc + g);
-        const v3 pred = yb + cal.imu.ba;
-        r[0] = w * (am.x - pred.x); r[1] = w * (am.y - pred.y); r[2] = w * (am.z - pred.z);
-        dg_dr = qrot_inv(sv.s.q, mk(sp_ * sr * G, cr * G, sr * cp * G));
-        dg_dp = qrot_inv(sv.s.q, mk(-cp * cr * G, 0.0, cr * sp_ * G));
-        mycost += 0.5 * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
-        if (cm.residuals) { const long long orow = row0_a + (long long)fam.perm[si] * 3; cm.residuals[orow] = r[0]; cm.residuals[orow + 1] = r[1]; cm.residuals[orow + 2] = r[2]; }
-      }
-      if (want_ne) {
-        d4 D[RotA::NTP];
-#pragma unroll
-        for (int t = 0; t < RotA::NTP; ++t) D[t] = d4{0.0, 0.0, 0.0, 0.0};
-        int wprev = -1;
-        const unsigned long long vm = __ballot(valid);
-        for (int g0 = 0; g0 < 64; g0 += RotA::GL) {
-          if (!(vm & (((1ull << RotA::GL) - 1ull) << g0))) continue;
-          const bool mine = lane >= g0 && lane < g0 + RotA::GL;
-          const int li = mine ? lane - g0 : 0;
-#pragma unroll 1
-          for (int a = 0; a < 3; ++a) {
-            // row a: position columns -w Ba_kk (R^T)[a][:] = -w Ba_kk R e_a, rotation columns -w (S dxi[kk])[a][:] = -w dxi[kk]^T (S^T e_a), S = skew(y_b)
-            const v3 ea = mk(a == 0 ? 1.0 : 0.0, a == 1 ? 1.0 : 0.0, a == 2 ? 1.0 : 0.0);
-            const v3 ga = a == 0 ? mk(0.0, -yb.z, yb.y) : (a == 1 ? mk(yb.z, 0.0, -yb.x) : mk(-yb.y, yb.x, 0.0));
-            v3 y[4];
-            v3 ra = mk(0, 0, 0);
-            if (valid) { so3_pullback_pre(c, pre, sv.s, ga, y); ra = qrot(sv.s.q, ea); }
-            if (mine) {
-              double* prow = P + (li * 3 + a) * RotA::LDP;
-#pragma unroll
-              for (int kk = 0; kk < 4; ++kk) {
-                double* pk = prow + 6 * ((key + kk) & 3);
-                const double wb = valid ? -w * Ba[kk] : 0.0;
-                pk[0] = wb * ra.x; pk[1] = wb * ra.y; pk[2] = wb * ra.z;
-                pk[3] = valid ? -w * y[kk].x : 0.0; pk[4] = valid ? -w * y[kk].y : 0.0; pk[5] = valid ? -w * y[kk].z : 0.0;
-              }
-              prow[24] = valid ? -w * comp(dg_dr, a) : 0.0; prow[25] = valid ? -w * comp(dg_dp, a) : 0.0;
-#pragma unroll
-              for (int b = 0; b < 3; ++b) prow[26 + b] = (valid && a == b) ? -w : 0.0;
-              prow[29] = valid ? (a == 0 ? r[0] : (a == 1 ? r[1] : r[2])) : 0.0; prow[30] = 0.0; prow[31] = 0.0;
-            }
-          }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          RKT(5)
-          rot_assemble<RotA>(cm, D, tabA, P, g0, valid, key, wprev, k_lo, ACC_LV, kpos, wpos, gpos, rep, lane RKT_PASS);
-          RKT(3)
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-        }
-        if (wprev >= 0) { rot_flush<RotA>(cm, D, tabA, -1, wpos, gpos, rep); rot_flush_globals<RotA>(D, tabA, gsum, ggrad); }
-        RKT(4)
-      }
-    }
-  }
-#ifdef LVX_ROT_KT
-  if (lane == 0 && blockIdx.x == 100) printf("RKT wv %d: eval %lld Grows %lld Arows %lld mfma %lld flush %lld total %lld\n", wv, rkt_[1], rkt_[2], rkt_[5], rkt_[3], rkt_[4], rkt_now() - rkts_);
-#endif
-  mycost = wave_sum(mycost);
-  if (lane == 0) atomicAdd(&cm.cost[rep], mycost);
-  if (!want_ne) return;
-  __syncthreads();
-  for (int e = tid; e < IMU_NGA * IMU_NGA; e += 256) {
-    const int ga = e / IMU_NGA, gb2 = e % IMU_NGA;
-    if (gb2 < ga) continue;
-    const double v = gsum[e];
-    if (v == 0.0 || gpos[ga] == LVX_DEAD || gpos[gb2] == LVX_DEAD) continue;
-    add_H(cm, gpos[ga], gpos[gb2], v, rep);
-  }
-  if (tid < IMU_NGA) { const double v = ggrad[tid]; if (v != 0.0 && gpos[tid] != LVX_DEAD) add_g(cm, gpos[tid], v, rep); }
 }
 
 // fold the pseudo-pose rows of the border back onto the hub control points: x_pseudo = M_hub x_hub  =>
@@ -2148,7 +1905,43 @@ int ensure_layout(lvx_ctx* ctx) {
     for (int i = 0; i < f.n; ++i) key[i] = host_i0(ctx, f.t[i]);
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
-    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if ((rc = upload_chunks(ctx, LVX_FAM_GYRO, sk, pick_chunk_batches(16, 64, ctx->sw.chunk_r_imu, (double)f.n / std::max(1, N - 3), 4 * (int)GyroAcc::LB)))) return rc; }
+    { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]];
+      if ((rc = upload_chunks(ctx, LVX_FAM_GYRO, sk, pick_chunk_batches(16, 64, ctx->sw.chunk_r_imu, (double)f.n / std::max(1, N - 3), 4 * (int)GyroAcc::LB)))) return rc;   // the gyroscope-only kernel of Solve #0
+      // owner-computes schedule (k_imu_own): one workgroup per CU, equal row counts, boundaries on knot intervals; inside a workgroup batches of <= 256 rows spanning <= IMU_CR
+      // intervals.  The workgroup keeps the tables of its whole knot range in LDS: more (smaller) ranges when the widest one does not fit (sparse sample streams).
+      int ncu = 256;
+      { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
+      const int cr = IMU_CR;
+      std::vector<int> off, k0, wg_c0;
+      int G = std::max(1, std::min(ncu, (f.n + 255) / 256)), span = 0;
+      for (;; G *= 2) {
+        off.clear(); k0.clear(); wg_c0.clear(); span = cr + 5;
+        int r = 0;
+        for (int g = 0; g < G; ++g) {
+          wg_c0.push_back((int)k0.size());
+          int r1 = g + 1 == G ? f.n : (int)((long long)f.n * (g + 1) / G);
+          while (r1 < f.n && r1 > 0 && sk[r1] == sk[r1 - 1]) ++r1;   // next interval start
+          r1 = std::max(r1, r);
+          const size_t first = k0.size();
+          for (int i = r; i < r1;) {
+            const int kf = std::max(0, sk[i]);
+            int e = std::min(r1, i + 256);
+            while (e > i + 1 && sk[e - 1] >= kf + cr) --e;
+            off.push_back(i); k0.push_back(kf);
+            i = e;
+          }
+          if (k0.size() > first) span = std::max(span, k0.back() - k0[first] + cr + 5);
+          r = r1;
+        }
+        wg_c0.push_back((int)k0.size());
+        if (imu_fused_lds_bytes(span) <= 160 * 1024 || G >= std::max(1, f.n)) break;
+      }
+      ctx->imu_wg = G; ctx->imu_nch = (int)k0.size(); ctx->imu_span = span; ctx->imu_h_k0 = k0; ctx->imu_h_wg_c0 = wg_c0;
+      off.push_back(f.n);
+      off.insert(off.end(), k0.begin(), k0.end());
+      if ((rc = upload_tmp(ctx, ctx->d_imu_chunk, off.data(), off.size() * 4))) return rc;
+      if ((rc = upload_tmp(ctx, ctx->d_imu_wg, wg_c0.data(), wg_c0.size() * 4))) return rc;
+    }
     auto ts = gather(f.t, perm, 1); auto g = gather(f.a3, perm, 3); auto a = gather(f.b3, perm, 3);
     if ((rc = upload_tmp(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
     if ((rc = upload_tmp(ctx, f.d_a3, g.data(), g.size() * 8))) return rc;
@@ -2367,6 +2160,38 @@ int ensure_layout(lvx_ctx* ctx) {
     ctx->hub_near_lo = hi >= lo ? lo : 0; ctx->hub_near_hi = hi >= lo ? hi + 1 : 0;
   }
   if ((rc = upload_tmp(ctx, ctx->d_colfull, colfull.data(), colfull.size()))) return rc;
+  {   // band columns k_imu_own STORES (ImuOwn::own): knots whose every contribution comes from ONE workgroup's samples and whose 24-entry column maps onto
+      // position-contiguous neighbours.  A sample sorted into interval i evaluates in i - 1 .. i + 1 (|tau_imu| < dt) and touches 4 knots, so a range whose first
+      // interval is B shares the knots [B - 1, B + 3] with its left neighbour: those, knots next to the hub gap or the spline's end and knots no batch window covers stay
+      // -1 = cleared by k_clear and added atomically.
+    std::vector<int> own((size_t)std::max(ctx->nb, 1), -1), own_k((size_t)std::max(N, 1), -1);   // by band position (k_clear) and by knot (k_imu_own)
+    const int G = ctx->imu_wg, cr = IMU_CR;
+    const std::vector<int>& k0 = ctx->imu_h_k0; const std::vector<int>& wc = ctx->imu_h_wg_c0;
+    ctx->imu_owned_cols = 0;
+    if (ctx->nb > 0 && !(locks & LVX_LOCK_R3) && ctx->imu.n > 0 && ctx->dt > ctx->imu_mto) {
+      int prev = -1;
+      for (int g = 0; g < G; ++g) {
+        if (wc[g] >= wc[g + 1]) continue;
+        int nxt = -1; for (int h = g + 1; h < G && nxt < 0; ++h) if (wc[h] < wc[h + 1]) nxt = h;
+        const int lo = prev < 0 ? 0 : k0[wc[g]] + 4, hi = nxt < 0 ? N - 1 : k0[wc[nxt]] - 2;
+        for (int c = wc[g]; c < wc[g + 1]; ++c)
+          for (int k = std::max(lo, k0[c] - 1); k <= std::min(hi, k0[c] - 1 + cr + 4); ++k) {
+            if (k < 0 || k + 4 >= N) continue;
+            const int p0 = ctx->ord[6 * k];
+            if (p0 < 0 || p0 >= LVX_LM_BASE) continue;
+            bool contig = true;
+            for (int e = 0; e < 30 && contig; ++e) contig = ctx->ord[6 * k + e] == p0 + e;
+            if (!contig) continue;
+            for (int d = 0; d < 6; ++d) { if (own[p0 + d] < 0) ctx->imu_owned_cols++; own[p0 + d] = g; }
+            own_k[k] = g;
+          }
+        prev = g;
+      }
+    }
+    ctx->imu_own_k_off = own.size();
+    own.insert(own.end(), own_k.begin(), own_k.end());
+    if ((rc = upload_tmp(ctx, ctx->d_imu_own, own.data(), own.size() * 4))) return rc;
+  }
   ctx->bd_row_live.assign((size_t)ctx->nbd_ext, 0);
   for (int b = 0; b < 6 * nh; ++b) ctx->bd_row_live[b] = 1;
   for (int c = 0; c < 22; ++c) if (ctx->ord[6 * N + c] != LVX_DEAD) ctx->bd_row_live[6 * nh + c] = 1;
@@ -2429,7 +2254,7 @@ int ensure_layout(lvx_ctx* ctx) {
   ctx->force_legacy = false;
   { static const int zero = 0; if ((rc = upload_tmp(ctx, ctx->d_zero, &zero, 4))) return rc; }
   if ((rc = dev_alloc(ctx, ctx->d_imu_rtab, (size_t)64 * (ImuG::NTP * 4 + ImuA::NTP * 4) * 4))) return rc;
-  hipLaunchKernelGGL(k_imu_rtab, dim3(1), dim3(64), 0, ctx->stream, ctx->chunk_r[LVX_FAM_GYRO], (int*)ctx->d_imu_rtab.p);
+  hipLaunchKernelGGL(k_imu_rtab, dim3(1), dim3(64), 0, ctx->stream, (int*)ctx->d_imu_rtab.p);
   ctx->cfg_version++;   // captured evaluation graphs of the previous layout are stale
   // ---- residual row offsets ----
   const int64_t cnt[LVX_NUM_FAM] = {ctx->imu.n, (locks & LVX_LOCK_R3) ? 0 : ctx->imu.n, ctx->has_prior ? 1 : 0, ctx->surf.n, ctx->rep.n, ctx->cs.n};
@@ -2480,7 +2305,8 @@ struct ClearList { uint4* p[16]; size_t words[16]; int n; };
 // The band is cleared STRUCTURALLY: every column's first `npre` entries (what the IMU / LiDAR families can touch: 4 neighbouring knots and
 // the landmarks ordered between them), whole columns only where `colfull` says a reprojection block or a landmark reaches further
 // (ensure_layout).  Everything else was zeroed once at layout time and is never written.  Config 4 with ORB-like tracks: 60 MB instead of 242 MB.
-struct BandClear { double* Hb; const uint8_t* colfull; int nb, ld, npre, nblk; double* Bd; int hub_rows, hub_lo, hub_hi, hub_blk; };   // hub rows of Bd: only [hub_lo, hub_hi) (the fold stores the rest)
+struct BandClear { double* Hb; const uint8_t* colfull; int nb, ld, npre, nblk; double* Bd; int hub_rows, hub_lo, hub_hi, hub_blk;   // hub rows of Bd: only [hub_lo, hub_hi) (the fold stores the rest)
+                   const int* own; double* gb; double* Bd_imu; unsigned imu_rows; };   // own[j] >= 0: k_imu_own STORES the first ACC_BW entries of band column j, gb[j] and the IMU-calibration border rows (Bd_imu: 8 rows, live ones in imu_rows) at j
 // First launch of a pass.  Its first npre blocks do what depends on the state only (control-point-pair table, hub poses: k_state_prepass's
 // work — a separate kernel on a side stream costs a ~30 us cross-stream join before the LiDAR kernels); the rest clear the accumulators.
 __global__ __launch_bounds__(256) void k_clear(ClearList cl, BandClear bc, int npre, DevCommon cm, So3Pre* tab, int nblk_tab, double t_map, int want_surf, int want_cs, HubShared* hubs) {
@@ -2489,13 +2315,21 @@ __global__ __launch_bounds__(256) void k_clear(ClearList cl, BandClear bc, int n
     const int l16 = threadIdx.x & 15;
     for (int j = ((int)blockIdx.x - npre) * 16 + (threadIdx.x >> 4); j < bc.nb; j += bc.nblk * 16) {
       const int len = bc.colfull[j] ? bc.ld : bc.npre;
-      double* col = bc.Hb + (size_t)j * bc.ld;
-      if (!(bc.ld & 1)) {
-        uint4* c4 = (uint4*)col;
-        for (int e = l16; e < (len >> 1); e += 16) c4[e] = make_uint4(0u, 0u, 0u, 0u);
-        if ((len & 1) && l16 == 0) col[len - 1] = 0.0;
-      } else {
-        for (int e = l16; e < len; e += 16) col[e] = 0.0;
+      const bool owned = bc.own && bc.own[j] >= 0;
+      const int beg = owned ? min(ACC_BW, len) : 0;   // (even)
+      if (bc.Hb) {
+        double* col = bc.Hb + (size_t)j * bc.ld;
+        if (!(bc.ld & 1)) {
+          uint4* c4 = (uint4*)col;
+          for (int e = (beg >> 1) + l16; e < (len >> 1); e += 16) c4[e] = make_uint4(0u, 0u, 0u, 0u);
+          if ((len & 1) && l16 == 0 && len > beg) col[len - 1] = 0.0;
+        } else {
+          for (int e = beg + l16; e < len; e += 16) col[e] = 0.0;
+        }
+      }
+      if (bc.own && !owned) {
+        if (l16 == 8) bc.gb[j] = 0.0;
+        else if (l16 < 8 && ((bc.imu_rows >> l16) & 1u)) bc.Bd_imu[(size_t)l16 * bc.nb + j] = 0.0;
       }
     }
     return;
@@ -2549,6 +2383,10 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     const bool fast_surf = fast && !(tauL && ctx->sw.tau_legacy) && ctx->surf.n > 0, fast_cs = fast && !(tauC && ctx->sw.tau_legacy) && ctx->cs.n > 0;
     // the control-point-pair table and the shared t_map poses (one thread, ~25 us) depend on the state only: the first blocks of the clear kernel
     const int nblk_tab = fast ? (ctx->N + 255) / 256 : 0, npre = fast ? nblk_tab + ((fast_surf || fast_cs) ? 1 : 0) : 0;
+    const lvx::Switches& sw = ctx->sw;
+    const bool det = sw.deterministic != 0;   // fixed order of every addition: one stream, coloured launches, one wavefront per workgroup
+    const bool imu_fused_on = fast && !sw.imu_legacy && ctx->imu.n > 0 && !(ctx->locks & LVX_LOCK_R3) && !sw.imu_split && ctx->imu_nch > 0 && imu_fused_lds_bytes(ctx->imu_span) <= 160 * 1024;
+    const bool imu_own = imu_fused_on && (what & LVX_EVAL_NORMAL_EQ) && ctx->nb > 0 && ctx->imu_owned_cols > 0 && !sw.clear_all;   // k_imu_own stores its band columns: they are not cleared
     {   // one launch clears every accumulator of the pass (cost, error flags, and for the normal equations band, gradient, border rows, dense border)
       ClearList cl{};
       BandClear bc{};
@@ -2558,7 +2396,11 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
         const size_t nb1 = (size_t)std::max(ctx->nb, 1);
         if (ctx->sw.clear_all || ctx->nb == 0) add(cm.Hb, nb1 * (ctx->bw + 1) * 8);
         else { bc.Hb = cm.Hb; bc.colfull = (const uint8_t*)ctx->d_colfull.p; bc.nb = ctx->nb; bc.ld = ctx->bw + 1; bc.npre = ctx->clear_npre; bc.nblk = std::min((ctx->nb + 15) / 16, 2048); }
-        add(cm.gb, nb1 * 8);
+        if (imu_own) {   // gradient and the IMU-calibration border rows: cleared column by column where nobody stores (the band loop of k_clear)
+          bc.own = (const int*)ctx->d_imu_own.p; bc.gb = cm.gb; bc.Bd_imu = cm.Bd + (size_t)6 * ctx->n_hub * nb1; bc.imu_rows = 0;
+          for (int c = 0; c < 8; ++c) if (ctx->bd_row_live[6 * ctx->n_hub + c]) bc.imu_rows |= 1u << c;
+          if (!bc.nblk) { bc.colfull = (const uint8_t*)ctx->d_colfull.p; bc.nb = ctx->nb; bc.ld = ctx->bw + 1; bc.npre = ctx->clear_npre; bc.nblk = std::min((ctx->nb + 15) / 16, 2048); }
+        } else add(cm.gb, nb1 * 8);
         // hub rows of Bd: with the fused LiDAR kernels only the fold fills them beyond the near range — it stores there, the clear skips them
         const bool hub_partial = !ctx->sw.clear_all && !(nb1 & 1) && ctx->nb > 0 && ctx->n_hub > 0 && (fast_surf || fast_cs) && (ctx->surf.n == 0 || fast_surf) && (ctx->cs.n == 0 || fast_cs);
         cm.hub_lo = hub_partial ? ctx->hub_near_lo : 0; cm.hub_hi = hub_partial ? ctx->hub_near_hi : ctx->nb;
@@ -2567,8 +2409,9 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
         if (ctx->sw.clear_all || (nb1 & 1)) add(cm.Bd, (size_t)ctx->nbd_ext * nb1 * 8);
         else for (int b0 = 0; b0 < ctx->nbd_ext;) {
           const int first_live = hub_partial ? 6 * ctx->n_hub : 0;   // hub rows: HubClear
-          if (b0 < first_live || !ctx->bd_row_live[b0]) { ++b0; continue; }
-          int b1 = b0; while (b1 < ctx->nbd_ext && ctx->bd_row_live[b1]) ++b1;
+          const int imu0 = imu_own ? 6 * ctx->n_hub : -1;   // the 8 IMU-calibration rows: BandClear
+          if (b0 < first_live || !ctx->bd_row_live[b0] || (imu0 >= 0 && b0 >= imu0 && b0 < imu0 + 8)) { ++b0; continue; }
+          int b1 = b0; while (b1 < ctx->nbd_ext && ctx->bd_row_live[b1] && !(imu0 >= 0 && b1 >= imu0 && b1 < imu0 + 8)) ++b1;
           add(cm.Bd + (size_t)b0 * nb1, (size_t)(b1 - b0) * nb1 * 8);
           b0 = b1;
         }
@@ -2583,14 +2426,20 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
                          (HubShared*)ctx->d_hubs.p);
     }
     auto grid = [](int n) { return dim3((unsigned)((n + 63) / 64)); };
+    if (imu_fused_on) {   // gyroscope + accelerometer blocks in one owner-computes kernel, FIRST on the band: it stores what it owns (k_imu_own)
+      const ImuFused f{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, ctx->imu.huber /*w_acc*/};
+      const size_t lds_ = imu_fused_lds_bytes(ctx->imu_span);
+      LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_imu_own, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
+      const ImuOwn ow{(const int*)ctx->d_imu_wg.p, imu_own ? (const int*)ctx->d_imu_own.p + ctx->imu_own_k_off : nullptr, ctx->imu_nch, ctx->imu_span};
+      ProfScope ps(ctx, LVX_FAM_GYRO, st);
+      hipLaunchKernelGGL(k_imu_own, dim3(ctx->imu_wg), dim3(256), lds_, st, f, cm, (const int*)ctx->d_imu_chunk.p, ow, (long long)ctx->fam_row0[0], (long long)ctx->fam_row0[1], det ? 1 : 0, (const int*)ctx->d_imu_rtab.p);
+    }
     // fast path: LDS-accumulating kernels for the segment-structured families; legacy per-segment kernels for reprojection, the prior,
     // the debug Jacobian, and as the exact fallback for the merged-hub-segment corner
     // Streams.  A hand-over between streams costs 25-40 us inside the replayed graph (rocprofv3 timeline: clear -> hub, LiDAR -> second
     // stage, last kernel -> fold each showed such a gap), so the critical chain  clear -> hub pose -> LiDAR kernels -> reprojection Jacobian
     // -> observation pass -> fold  stays on the caller's stream and only the kernels that run NEXT to it (gyroscope, accelerometer,
     // reference pass) fork off; they finish before the observation pass does, so the join is already satisfied when the chain gets there.
-    const lvx::Switches& sw = ctx->sw;
-    const bool det = sw.deterministic != 0;   // fixed order of every addition: one stream, coloured launches, one wavefront per workgroup
     const bool staged = sw.sched == 2 && !sw.serial && !det;
     hipStream_t s_imu = ctx->fam_stream[0], s_acc = ctx->fam_stream[1], s_surf = staged ? st : ctx->fam_stream[2], s_rep = staged ? st : ctx->fam_stream[3];
     // one side stream (gyroscope, then accelerometer) next to the chain (Jacobian, observation pass, reference pass): both ends finish
@@ -2607,7 +2456,6 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
       for (int k = 0; k < 4; ++k) if (first_use(k)) LVX_HIP(ctx, hipStreamWaitEvent(side[k], ctx->ev_fork, 0));
     }
     const int occ_env = sw.occ;   // 0: the family's own choice (F::OCC wavefronts per SIMD)
-    const bool imu_fused_on = fast && !sw.imu_legacy && ctx->imu.n > 0 && !(ctx->locks & LVX_LOCK_R3) && !sw.imu_split && !ctx->chunk_var[LVX_FAM_GYRO] && imu_fused_lds_bytes(ctx->chunk_r[LVX_FAM_GYRO]) <= 160 * 1024;
     const bool ref_side = sw.ref_side == 1 || (sw.ref_side < 0 && imu_fused_on);   // with the fused IMU kernel the side stream is the shorter chain: it takes the reference pass
   #define LVX_T2(...) __VA_ARGS__
   #define LVX_LAUNCH_MFMA1(FT, OCCV, fam_obj, chunk_slot, stream, row0v)                                                                        \
@@ -2642,26 +2490,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
       case 0: {
         const bool imu_fast = fast && !sw.imu_legacy;
         if (ctx->imu.n > 0) {
-          if (imu_fused_on) {   // gyroscope + accelerometer blocks in one kernel
-            const ImuFused f{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, ctx->imu.huber /*w_acc*/};
-            const size_t lds_ = imu_fused_lds_bytes(ctx->chunk_r[LVX_FAM_GYRO]);
-            LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_imu_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
-            const int* rtab_d = (const int*)ctx->d_imu_rtab.p;
-            ProfScope ps(ctx, LVX_FAM_GYRO, s_imu);
-            if (sw.imu_rot && !det && imu_rot_lds_bytes(ctx->chunk_r[LVX_FAM_GYRO]) <= 80 * 1024) {   // rotating register accumulators, two workgroups per CU
-              const size_t ldr = imu_rot_lds_bytes(ctx->chunk_r[LVX_FAM_GYRO]);
-              LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_imu_rot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldr));
-              hipLaunchKernelGGL(k_imu_rot, dim3(ctx->n_chunk[LVX_FAM_GYRO]), dim3(256), ldr, s_imu, f, cm, (const int*)ctx->d_chunk[LVX_FAM_GYRO].p, (long long)ctx->fam_row0[0], (long long)ctx->fam_row0[1],
-                                 ctx->chunk_r[LVX_FAM_GYRO]);
-            } else
-            if (det && ctx->det_col[LVX_FAM_GYRO].size() > 1) {
-              const std::vector<int>& dc = ctx->det_col[LVX_FAM_GYRO];
-              for (size_t q = 0; q + 1 < dc.size(); ++q)
-                hipLaunchKernelGGL(k_imu_mfma, dim3(dc[q + 1] - dc[q]), dim3(256), lds_, s_imu, f, cm, (const int*)ctx->d_chunk[LVX_FAM_GYRO].p, (long long)ctx->fam_row0[0], (long long)ctx->fam_row0[1],
-                                   ctx->chunk_r[LVX_FAM_GYRO], (const int*)ctx->d_det_list[LVX_FAM_GYRO].p + dc[q], rtab_d);
-            } else
-            hipLaunchKernelGGL(k_imu_mfma, dim3(ctx->n_chunk[LVX_FAM_GYRO]), dim3(256), lds_, s_imu, f, cm, (const int*)ctx->d_chunk[LVX_FAM_GYRO].p, (long long)ctx->fam_row0[0], (long long)ctx->fam_row0[1],
-                               ctx->chunk_r[LVX_FAM_GYRO], (const int*)nullptr, rtab_d);
+          if (imu_fused_on) {   // launched behind the clear
           } else if (imu_fast) {
             GyroAcc g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
             { ProfScope ps(ctx, LVX_FAM_GYRO, s_imu); LVX_LAUNCH_MFMA(GyroAcc, g, LVX_FAM_GYRO, s_imu, ctx->fam_row0[0]); }
