@@ -34,95 +34,154 @@ def sym_from_lower(L):
     return (L + sp.tril(L, -1).T).tocsr()
 
 
-def spd_solve(A_lower, b, eblocks=None, dense_limit=3000, force_sparse=False, stats=None):
-    """Solve A y = b for a sparse SPD A given by its lower triangle (any sparse format).  eblocks: indices of pairwise uncoupled scalars to eliminate first."""
+class ArrowSolver:
+    """Sparse SPD solve  A y = b  (A by its lower triangle) in three generic steps — Schur complement of the e-blocks (pairwise uncoupled scalars), dense border
+    (columns whose degree is far above the median) last, reverse Cuthill-McKee + LAPACK band Cholesky on the rest.  The symbolic part (which columns are border,
+    the RCM order) depends on the sparsity pattern only: it is computed at the first solve and reused while the pattern still fits it (an LM run solves ~20 systems
+    with one pattern)."""
+
+    def __init__(self):
+        self.inv = None
+        self.stats = {}
+
+    def _analyse(self, A_lower, eblocks):
+        n = A_lower.shape[0]
+        A = sym_from_lower(A_lower)
+        is_e = np.zeros(n, bool)
+        if eblocks is not None and len(eblocks):
+            is_e[np.asarray(eblocks)] = True
+        e = np.nonzero(is_e)[0]
+        rest0 = np.nonzero(~is_e)[0]
+        S = A[rest0][:, rest0].tocsr()
+        S.data[:] = 1.0
+        if len(e):
+            E = A[e][:, rest0].tocsr()
+            E.data[:] = 1.0
+            S = (S + sym_from_lower(O.ata_lower(E))).tocsr()     # pattern of B - E^T C^-1 E
+        deg = np.diff(S.indptr)
+        # dense columns: far above the typical column (a calibration scalar that only the rotation part of every knot sees has degree n / 2, the gyroscope bias)
+        is_b = deg > max(10 * int(np.median(deg)), 64)
+        border, band = np.nonzero(is_b)[0], np.nonzero(~is_b)[0]
+        R = S[band][:, band].tocsr()
+        perm = np.asarray(reverse_cuthill_mckee(R, symmetric_mode=True))
+        Rp = R[perm][:, perm].tocoo()
+        bw = int(np.abs(Rp.row - Rp.col).max(initial=0))
+        order = np.concatenate([rest0[band][perm], rest0[border], e])      # new index -> old index
+        self.inv = np.empty(n, np.int64); self.inv[order] = np.arange(n)
+        self.order, self.n, self.nr, self.nb, self.ne, self.bw = order, n, len(band), len(border), len(e), bw
+        if (bw + 1) * self.nr * 8 > 8e9:
+            raise MemoryError("band storage of %d x %d after RCM: the matrix is not an arrowhead" % (bw + 1, self.nr))
+        self.stats.update(n=n - len(e), n_border=len(border), bandwidth=bw, analyses=self.stats.get("analyses", 0) + 1)
+
+    def solve(self, A_lower, b, eblocks=None):
+        A_lower = sp.coo_matrix(A_lower)
+        A_lower.eliminate_zeros()                                  # structural zeros (a Jacobian column that is exactly zero in a block) carry no pattern
+        n = A_lower.shape[0]
+        n_e = 0 if eblocks is None else len(eblocks)
+        fresh = self.inv is None or self.n != n or self.ne != n_e
+        while True:
+            if fresh:
+                self._analyse(A_lower, eblocks)
+            nr, nb, ne, bw = self.nr, self.nb, self.ne, self.bw
+            i, j, v = self.inv[A_lower.row], self.inv[A_lower.col], A_lower.data
+            sw = i < j
+            i, j = np.where(sw, j, i), np.where(sw, i, j)
+            m = nr + nb
+            ee = j >= m                                            # both indices in the e-block range
+            if (i[ee] != j[ee]).any():
+                raise ValueError("e-blocks are not pairwise uncoupled")
+            if not ((i < nr) & (i - j > bw)).any():
+                break
+            if fresh:
+                raise MemoryError("pattern does not fit its own analysis")
+            fresh = True                                           # the pattern outgrew the cached ordering: analyse again
+        bn = b[self.order]
+        if ne:
+            c = np.bincount(i[ee] - m, weights=v[ee], minlength=ne)          # (duplicate entries add, as everywhere below)
+            if not (c > 0).all():
+                raise np.linalg.LinAlgError("non-positive e-block pivot")
+            fe = (i >= m) & ~ee
+            F = sp.csr_matrix((v[fe] / np.sqrt(c[i[fe] - m]), (i[fe] - m, j[fe])), shape=(ne, m))      # C^-1/2 E
+            FtF = O.ata_lower(F).tocoo()
+            keep = i < m
+            i = np.concatenate([i[keep], FtF.row]); j = np.concatenate([j[keep], FtF.col]); v = np.concatenate([v[keep], -FtF.data])
+            fs = ((i < nr) & (i - j > bw)).any()
+            if fs:
+                raise MemoryError("Schur complement of the e-blocks outgrew the cached ordering")
+            be = bn[m:]
+            bs = bn[:m] - F.T @ (be / np.sqrt(c))
+        else:
+            bs = bn
+        # band part -> LAPACK lower band storage, border rows -> dense
+        inb = i < nr
+        ab = np.bincount((i[inb] - j[inb]) * nr + j[inb], weights=v[inb], minlength=(bw + 1) * nr).reshape(bw + 1, nr)
+        cb = sla.cholesky_banded(ab, lower=True, overwrite_ab=True, check_finite=False)
+        rhs = np.empty((nr, 1 + nb))
+        rhs[:, 0] = bs[:nr]
+        if nb:
+            rb = ~inb & (j < nr)
+            Srb = np.bincount(j[rb] * nb + (i[rb] - nr), weights=v[rb], minlength=nr * nb).reshape(nr, nb)
+            rhs[:, 1:] = Srb
+            bb = ~inb & (j >= nr)
+            T = np.bincount((i[bb] - nr) * nb + (j[bb] - nr), weights=v[bb], minlength=nb * nb).reshape(nb, nb)
+            T = T + np.tril(T, -1).T
+        X = sla.cho_solve_banded((cb, True), rhs, overwrite_b=True, check_finite=False)
+        z = X[:, 0]
+        ym = np.empty(nr + nb)
+        if nb:
+            T = T - Srb.T @ X[:, 1:]
+            T = 0.5 * (T + T.T)
+            Lc = np.linalg.cholesky(T)
+            yb = sla.cho_solve((Lc, True), bs[nr:] - Srb.T @ z, check_finite=False)
+            z = z - X[:, 1:] @ yb
+            ym[nr:] = yb
+        ym[:nr] = z
+        yn = np.empty(n)
+        yn[:nr + nb] = ym
+        if ne:
+            yn[nr + nb:] = be / c - (F @ ym) / np.sqrt(c)
+        y = np.empty(n)
+        y[self.order] = yn
+        return y
+
+
+def spd_solve(A_lower, b, eblocks=None, dense_limit=3000, force_sparse=False, stats=None, solver=None):
+    """Solve A y = b for a sparse SPD A given by its lower triangle (any sparse format).  eblocks: indices of pairwise uncoupled scalars to eliminate first
+    (checked); solver: an ArrowSolver whose symbolic analysis is reused."""
     n = A_lower.shape[0]
-    A_lower = sp.csc_matrix(A_lower)
     if n <= dense_limit and not force_sparse:
-        Ad = A_lower.toarray()
+        Ad = sp.csc_matrix(A_lower).toarray()
         Ad = Ad + np.tril(Ad, -1).T
         Lc = np.linalg.cholesky(Ad)
         return sla.solve_triangular(Lc.T, sla.solve_triangular(Lc, b, lower=True, check_finite=False), lower=False, check_finite=False)
-    A = sym_from_lower(A_lower)
-    y = np.zeros(n)
-    if eblocks is not None and len(eblocks):
-        e = np.asarray(eblocks)
-        is_e = np.zeros(n, bool); is_e[e] = True
-        rest = np.nonzero(~is_e)[0]
-        Cee = A[e][:, e]
-        c = Cee.diagonal()
-        if Cee.nnz != np.count_nonzero(c):   # an e-block coupled to another one: not a diagonal block
-            raise ValueError("e-blocks are not pairwise uncoupled")
-        if not (c > 0).all():
-            raise np.linalg.LinAlgError("non-positive e-block pivot")
-        E = A[e][:, rest].tocsr()                                   # [n_e, n_rest]
-        F = sp.diags(1.0 / np.sqrt(c)) @ E
-        B_lower = sp.tril(A[rest][:, rest], 0, format="csc")
-        S_lower = (B_lower - O.ata_lower(F.tocsr())).tocsc()
-        bs = b[rest] - E.T @ (b[e] / c)
-        yr = _arrow_solve(S_lower, bs, stats)
-        y[rest] = yr
-        y[e] = (b[e] - E @ yr) / c
-        return y
-    return _arrow_solve(A_lower, b, stats)
-
-
-def _arrow_solve(S_lower, b, stats=None):
-    """SPD solve by ordering: dense border (degree > 10 x median) last, RCM + LAPACK band Cholesky on the rest."""
-    n = S_lower.shape[0]
-    S = sym_from_lower(S_lower)
-    deg = np.diff(S.indptr)
-    # dense columns: far above the typical column (a calibration scalar that only the rotation part of every knot sees has degree n / 2, the gyroscope bias)
-    border = np.nonzero(deg > max(10 * int(np.median(deg)), 64))[0]
-    is_b = np.zeros(n, bool); is_b[border] = True
-    rest = np.nonzero(~is_b)[0]
-    R = S[rest][:, rest].tocsr()
-    perm = np.asarray(reverse_cuthill_mckee(R, symmetric_mode=True))
-    Rp = R[perm][:, perm].tocoo()
-    lo = Rp.row >= Rp.col
-    i, j, v = Rp.row[lo], Rp.col[lo], Rp.data[lo]
-    bw = int((i - j).max(initial=0))
-    nr = len(rest)
-    if (bw + 1) * nr * 8 > 8e9:
-        raise MemoryError("band storage of %d x %d after RCM: the matrix is not an arrowhead" % (bw + 1, nr))
-    ab = np.zeros((bw + 1, nr))
-    ab[i - j, j] = v
+    solver = solver if solver is not None else ArrowSolver()
+    y = solver.solve(A_lower, b, eblocks)
     if stats is not None:
-        stats.update(n=n, n_border=len(border), bandwidth=bw)
-    cb = sla.cholesky_banded(ab, lower=True, overwrite_ab=True, check_finite=False)
-    rhs = np.empty((nr, 1 + len(border)))
-    rhs[:, 0] = b[rest][perm]
-    if len(border):
-        rhs[:, 1:] = S[rest][:, border].toarray()[perm]
-    X = sla.cho_solve_banded((cb, True), rhs, overwrite_b=True, check_finite=False)
-    y = np.zeros(n)
-    z = X[:, 0]
-    if len(border):
-        Srb = S[rest][:, border].tocsr()[perm]          # [nr, nb]
-        T = S[border][:, border].toarray() - Srb.T @ X[:, 1:]
-        T = 0.5 * (T + T.T)
-        Lc = np.linalg.cholesky(T)
-        yb = sla.cho_solve((Lc, True), b[border] - Srb.T @ z, check_finite=False)
-        z = z - X[:, 1:] @ yb
-        y[border] = yb
-    yr = np.empty(nr); yr[perm] = z
-    y[rest] = yr
+        stats.update(solver.stats)
     return y
 
 
-def solve_step(H_lower, g, free, radius, scale, lm_diag=None, eblocks_free=None, min_diag=1e-6, max_diag=1e32, force_sparse=False, stats=None):
+def solve_step(H_lower, g, free, radius, scale, lm_diag=None, eblocks_free=None, min_diag=1e-6, max_diag=1e32, force_sparse=False, stats=None, solver=None):
     """(S H S + D) y = -S g on the free scalars (H_lower: lower triangle over all tangent scalars); returns (delta, model_cost_change, lm_diag)."""
-    Hf = sp.csc_matrix(H_lower)[free][:, free]
+    nt = H_lower.shape[0]
+    H = sp.coo_matrix(H_lower)
+    pos = np.full(nt, -1, np.int64); pos[free] = np.arange(len(free))
+    i, j = pos[H.row], pos[H.col]
+    k = (i >= 0) & (j >= 0)
+    i, j = i[k], j[k]
     s = scale
-    Hs = (sp.diags(s) @ Hf @ sp.diags(s)).tocsc()
+    v = H.data[k] * s[i] * s[j]                                     # S H S, lower triangle over the free scalars
     gs = g[free] * s
+    dg = np.zeros(len(free)); np.add.at(dg, i[i == j], v[i == j])
     if lm_diag is None:
-        lm_diag = np.clip(Hs.diagonal(), min_diag, max_diag)
-    A = (Hs + sp.diags(lm_diag / radius)).tocsc()
-    y = spd_solve(A, -gs, eblocks=eblocks_free, force_sparse=force_sparse, stats=stats)
-    Hy = Hs @ y + sp.tril(Hs, -1).T @ y
+        lm_diag = np.clip(dg, min_diag, max_diag)
+    nf = len(free)
+    A = sp.coo_matrix((np.concatenate([v, lm_diag / radius]), (np.concatenate([i, np.arange(nf)]), np.concatenate([j, np.arange(nf)]))), shape=(nf, nf))
+    y = spd_solve(A, -gs, eblocks=eblocks_free, force_sparse=force_sparse, stats=stats, solver=solver)
+    off = i != j
+    Hy = np.bincount(i, weights=v * y[j], minlength=nf) + np.bincount(j[off], weights=v[off] * y[i[off]], minlength=nf)
     model = -(gs @ y + 0.5 * (y @ Hy))
-    delta = np.zeros(H_lower.shape[0])
+    delta = np.zeros(nt)
     delta[free] = y * s
     return delta, model, lm_diag
 
@@ -159,11 +218,12 @@ def lm_solve(oracle, state, free, n_knots, n_landmarks, max_iterations=50, initi
         return x, dict(termination="gradient_tolerance", iterations=0, initial_cost=cost, final_cost=cost, **hist)
     init_cost = cost
     stats = {}
+    solver = ArrowSolver()
     while it < max_iterations:
         it += 1
         t0 = time.perf_counter()
         try:
-            delta, model, lm_diag = solve_step(H, g, free, radius, scale, lm_diag, eblocks_free=eb, force_sparse=force_sparse, stats=stats)
+            delta, model, lm_diag = solve_step(H, g, free, radius, scale, lm_diag, eblocks_free=eb, force_sparse=force_sparse, stats=stats, solver=solver)
             ok = np.isfinite(model) and model > 0
         except np.linalg.LinAlgError:
             ok = False
