@@ -30,13 +30,36 @@ sys.path.insert(0, os.path.join(ROOT, "lvi-exc_amd"))
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6      # MI355X FP64: vector 78.6 TFLOP/s = matrix (v_mfma_f64_16x16x4_f64) 78.6 TFLOP/s
 # algorithmic bytes per residual block, SURVEY.md §8(d)
-# HBM bytes per launch of k_family_mfma<SurfAcc> at config 4 from the PMC counters (FETCH_SIZE 32.8 MB + WRITE_SIZE 59.0 MB per dispatch with
-# normal equations; KiB -> bytes; FETCH_SIZE is not doubled: these are 8-byte strided reads, not the 16 B/lane streams the guide's x2
-# correction was calibrated on).  Reads: 56 B of row inputs per block (t, point, row-ordered plane) = 56 MB would be the cold figure, the
-# counter sees 33 MB (the rest hits the 256 MB Infinity Cache from the previous pass); writes: the accumulator flushes (one atomic per touched
-# band / border entry per workgroup, 1954 workgroups) — the register-spill scratch of the earlier rounds (232 MB) is gone.
-PMC_TRAFFIC_BYTES = {"surfel": 89.3e6, "imu": 49.9e6}   # surfel: 32.8 MB fetched + 56.5 MB written (max over dispatches with normal equations); fused IMU kernel: 8.94 + 40.96 MB (accumulator flushes)   # constants copied from the profile named below, not measured by this run (filled per kernel by tools/profile_round.sh runs)
-PMC_SOURCE = "profiles/r03d_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per dispatch)"
+# roofline.traffic = HBM bytes per launch of the dominant kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes).  It is NOT measured by this run (a PMC pass
+# serialises the kernels): tools/profile_round.sh writes profiles/latest_traffic.json next to the counter summary, with the SHA-256 of the kernel sources it was taken
+# from; bench.py reports the figure only while that hash still matches the tree, otherwise `traffic` is null (a constant in this file would go stale silently).
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "latest_traffic.json")
+KERNEL_SOURCES = ("lvx_eval.hip", "lvx_resid.h", "lvx_math.h", "lvx_ctx.h")
+
+
+def kernel_sources_sha():
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "lvi-exc_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
+def measured_traffic(kernel_key):
+    """(bytes per launch, source string) of `kernel_key` ('imu' | 'surfel' | ...) from the committed profile, or (None, why)."""
+    try:
+        d = json.load(open(TRAFFIC_JSON))
+    except Exception:   # noqa: BLE001
+        return None, "no profiles/latest_traffic.json"
+    if d.get("sources_sha256") != kernel_sources_sha():
+        return None, "profiles/latest_traffic.json was taken from other kernel sources (hash mismatch): not reported"
+    k = d.get("kernels", {}).get(kernel_key)
+    if not k:
+        return None, "kernel not in profiles/latest_traffic.json"
+    return k["fetch_bytes"] + k["write_bytes"], "%s: %.1f MB fetched + %.1f MB written per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, mean over dispatches with normal equations)" % (
+        d.get("source", "profiles/"), k["fetch_bytes"] / 1e6, k["write_bytes"] / 1e6)
+
+
 BYTES_PER_EVAL = {"imu": 32, "surfel": 60, "reproj": 60}
 FLOPS_PER_EVAL = {"imu": 4e3, "surfel": 9e3, "reproj": 11e3}   # SURVEY.md §8(d)
 
@@ -113,6 +136,9 @@ def secondary_metrics(ctx, P, lo):
         it = max(1, sm["iterations"])
         sec["lm_iteration"] = {"ms_per_iteration": 1e3 * dt / it, "iterations": it, "Mevals_per_s_incl_solve": lo["n_blocks"] * (it + sm["successful_steps"] + 1) / dt / 1e6,
                                "note": "evaluate(+J^T J) + landmark elimination + block-cyclic-reduction solve + candidate cost evaluation per iteration; host-synchronised"}
+        # the headline counts evaluations per second of the evaluation pass alone; this is what someone who ITERATES gets: blocks per second of whole Gauss-Newton / LM
+        # iterations (one evaluation with normal equations + the exact SPARSE_SCHUR-equivalent step each)
+        sec["gn_iteration_Mevals_per_s"] = lo["n_blocks"] * it / dt / 1e6
     except Exception as e:   # noqa: BLE001
         sec["lm_iteration"] = {"error": str(e)[:200]}
     try:   # config 4 "to convergence": the reference's stage schedule to a Ceres termination (lvi-exc_amd/stages.py, tests/test_gpu_converge.py)
@@ -124,6 +150,38 @@ def secondary_metrics(ctx, P, lo):
                                   "note": "trajInitFromSurfel (<= 30 it) then trajInitFromLVIdata (<= 80 it) from the 3 deg / 3 cm perturbed start, wall time incl. problem upload"}
     except Exception as e:   # noqa: BLE001
         sec["converged_solve"] = {"error": str(e)[:200]}
+    try:   # BASELINE config 3: IMU-only normal equations, 200 k samples (gyroscope + accelerometer block each), its own CPU time
+        from oracle import oracle as O
+        Q = dict(P)
+        Q.update(surf_pt=P["surf_pt"][:0], surf_t=P["surf_t"][:0], surf_plane=P["surf_plane"][:0], rep_lm=P["rep_lm"][:0], rep_uv=P["rep_uv"][:0], rep_t0=P["rep_t0"][:0],
+                 cs_lm=P["cs_lm"][:0], cs_plane=P["cs_plane"][:0])
+        g = lvx.Context(0)
+        lvx.load_problem(g, Q, lvx.LOCK_LIDAR_TAU | lvx.LOCK_CAM_TAU | lvx.LOCK_LIDAR_Q | lvx.LOCK_LIDAR_P | lvx.LOCK_CAM_Q | lvx.LOCK_CAM_P | lvx.LOCK_LANDMARKS)
+        g.set_state(P["state0"])
+        for _ in range(3):
+            g.evaluate_resident(lvx.EVAL_COST | lvx.EVAL_NORMAL_EQ)
+        g.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            g.evaluate_resident(lvx.EVAL_COST | lvx.EVAL_NORMAL_EQ)
+        g.synchronize()
+        t3 = (time.perf_counter() - t0) / 20
+        nb3 = g.layout()["n_blocks"]
+        g.close()
+        o = O.Oracle()
+        lvx.load_problem(o, Q, lvx.LOCK_LIDAR_TAU | lvx.LOCK_CAM_TAU | lvx.LOCK_LIDAR_Q | lvx.LOCK_LIDAR_P | lvx.LOCK_CAM_Q | lvx.LOCK_CAM_P | lvx.LOCK_LANDMARKS)
+        cores = usable_cores(); o.set_threads(cores)
+        o.evaluate_products(P["state0"])
+        t0 = time.perf_counter(); nrep = 0
+        while time.perf_counter() - t0 < 4.0:
+            o.evaluate_products(P["state0"]); nrep += 1
+        tc3 = (time.perf_counter() - t0) / nrep
+        sec["config3_imu_only"] = {"ms_per_step": 1e3 * t3, "blocks": int(nb3), "Mevals_per_s": nb3 / t3 / 1e6, "frac_fp64_peak": FLOPS_PER_EVAL["imu"] * nb3 / t3 / 1e12 / FP64_PEAK_TFLOPS,
+                                   "cpu": {"Mevals_per_s": o.num_blocks / tc3 / 1e6, "ms_per_pass": 1e3 * tc3, "cores": cores, "kind": "port",
+                                           "sample": "%d full passes over the 200 k-sample IMU-only problem: stride-4 dual-number Jacobians + J^T r + diag(J^T J), OpenMP over blocks" % nrep},
+                                   "note": "BASELINE config 3: gyroscope + accelerometer blocks only (k_clear + k_imu_own + fold), whole pass wall time, state resident"}
+    except Exception as e:   # noqa: BLE001
+        sec["config3_imu_only"] = {"error": str(e)[:200]}
     try:   # free LiDAR / camera time offsets (the reference's opt_time_offset_ stages): one more global column on the fused kernels
         g = lvx.Context(0)
         lvx.load_problem(g, P, 0)
@@ -175,6 +233,18 @@ def secondary_metrics(ctx, P, lo):
             tb = (time.perf_counter() - t0) / 10
             batched["%d_sweeps" % S] = {"ms_per_call": 1e3 * tb, "us_per_sweep": 1e6 * tb / S, "Mpts_per_s": int(off[-1]) / tb / 1e6, "hbm_frac": 28.0 * int(off[-1]) / tb / 1e9 / HBM_PEAK_GBS}
         sec["scan_registration"]["batched_device_resident"] = batched
+        # real VLP-16 ranges come in 2 mm steps: equal curvatures inside a sector are then common and the kernel reproduces libstdc++'s std::sort order of equal keys
+        # with a restated introsort on ONE lane per sector (lvx_stdsort.h) — the continuous-noise sweeps above never take that path, these do
+        sw = [synth.make_vlp16_sweep(seed=1 + (k % 4), range_quantum=0.002) for k in range(64)]
+        off = np.concatenate([[0], np.cumsum([len(q) for q in sw])]).astype(np.int32)
+        pd = torch.from_numpy(np.concatenate(sw).view(np.uint8).reshape(-1)).to("cuda")
+        lvx.scan_register_batch_d(ctx, pd.data_ptr(), off, 16, 0.3)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            lvx.scan_register_batch_d(ctx, pd.data_ptr(), off, 16, 0.3)
+        tq = (time.perf_counter() - t0) / 10
+        sec["scan_registration"]["batched_device_resident_quantised_2mm"] = {"sweeps": 64, "ms_per_call": 1e3 * tq, "us_per_sweep": 1e6 * tq / 64, "Mpts_per_s": int(off[-1]) / tq / 1e6,
+                                                                              "hbm_frac": 28.0 * int(off[-1]) / tq / 1e9 / HBM_PEAK_GBS}
     except Exception as e:   # noqa: BLE001
         sec["upstream_error"] = str(e)[:200]
     try:   # one DataAssociation round of the stage driver, device-resident (lvx_data_association): 57 scans x 16 x 450 points of synth.make_sequence
@@ -280,7 +350,7 @@ def cpu_baseline(P, seconds_budget=12.0):
     dt = time.perf_counter() - t0
     out = {"value": blocks * reps / dt / 1e6, "unit": "Mevals/s", "cores": cores, "kind": "port",
            "sample": "%d surfel + %d gyro + %d accel + %d reprojection blocks x %d passes (1/5 of the workload): residual + stride-4 dual-number Jacobian per block "
-                     "(cost profile of ceres::DynamicAutoDiffCostFunction) + J^T r and diag(J^T J), OpenMP over blocks, g++ -O3 -msse4.2" % (len(si), len(ii), len(ii), int(rmask.sum()), reps)}
+                     "(cost profile of ceres::DynamicAutoDiffCostFunction) + J^T r and diag(J^T J) ONLY — not the block products Ceres' SPARSE_SCHUR forms, which flatters the CPU — OpenMP over blocks, g++ -O3 -msse4.2" % (len(si), len(ii), len(ii), int(rmask.sum()), reps)}
     try:   # mode (ii): closed-form Jacobians + every block's J^T J / J^T r products
         n2, _ = O.analytic_pass(o, P["state0"], cores)
         t0 = time.perf_counter(); reps2 = 0
@@ -305,6 +375,8 @@ def main():
     ap.add_argument("--small", action="store_true", help="1/10 size problem (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the LM-iteration and upstream-kernel side measurements")
+    ap.add_argument("--shard-size", choices=("full", "eighth"), default="full",
+                    help="N > 1 (SURVEY 8d config 5): every rank's sequence at full config-4 size (default, weak scaling) or at 1/8 size; the other variant is reported under secondary")
     args = ap.parse_args()
 
     import torch
@@ -331,9 +403,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
 
-    scale = 10 if args.small else 1
+    scale = (10 if args.small else 1) * (8 if args.shard_size == "eighth" else 1)
     n_surf, n_imu, n_rep = 1_000_000 // scale, 200_000 // scale, 50_000 // scale
-    P = synth.make_bench_problem(seed=4 if world == 1 else 40 + rank, n_imu=n_imu, n_surfel=n_surf, n_reproj=n_rep, n_planes=2000 // scale)
+    P = synth.make_bench_problem(seed=4 if world == 1 else 40 + rank, n_imu=n_imu, n_surfel=n_surf, n_reproj=n_rep, n_planes=max(8, 2000 // scale))
     ctx = lvx.Context(local_rank)
     lvx.load_problem(ctx, P, lvx.LOCK_LIDAR_TAU | lvx.LOCK_CAM_TAU)
     lo = ctx.layout()
@@ -399,7 +471,7 @@ def main():
                                "step = residuals + analytic Jacobians + Huber + J^T J/J^T r assembly (no linear solve)" % (n_surf, n_imu, len(P["rep_lm"]), lo["n_knots"]),
                    "blocks_per_step_per_gpu": int(blocks), "n_tangent": lo["n_tangent"], "bandwidth": lo["bandwidth"], "n_border": lo["n_border"],
                    "locks": "LIDAR_TAU | CAM_TAU (sensor time offsets constant, everything else free: trajInitFromLVIdata with lvi.yaml's opt_time_offset false)",
-                   "tracks": P.get("tracks", "orb"), "parallelism": "sequence-per-gpu x%d" % world, "cost": cost},
+                   "tracks": P.get("tracks", "orb"), "parallelism": "sequence-per-gpu x%d" % world, "shard_size": args.shard_size, "cost": cost},
     }
     em = Emitter(rank)
     em.out = out
@@ -434,7 +506,7 @@ def main():
         # algorithmic work of every family against its solo duration, and of the whole pass against the step time
         work = {"surfel": (FLOPS_PER_EVAL["surfel"] * n_surf, BYTES_PER_EVAL["surfel"] * n_surf), "gyro": (FLOPS_PER_EVAL["imu"] * n_imu, BYTES_PER_EVAL["imu"] * n_imu),
                 "accel": (FLOPS_PER_EVAL["imu"] * n_imu, BYTES_PER_EVAL["imu"] * n_imu), "reproj": (FLOPS_PER_EVAL["reproj"] * len(P["rep_lm"]), BYTES_PER_EVAL["reproj"] * len(P["rep_lm"]))}
-        if "accel" not in solo and "gyro" in solo:   # fused IMU kernel (k_imu_mfma): one launch evaluates the gyroscope AND the accelerometer block of every sample
+        if "accel" not in solo and "gyro" in solo:   # fused IMU kernel (k_imu_own): one launch evaluates the gyroscope AND the accelerometer block of every sample
             solo["imu"] = solo.pop("gyro")
             if "gyro" in out["kernel_ms"]:
                 out["kernel_ms"]["imu"] = out["kernel_ms"].pop("gyro")
@@ -455,11 +527,12 @@ def main():
         dominant = max(fam, key=lambda n: longest[n])
         step_s = elapsed / args.steps
         tot_fl = sum(v[0] for v in work.values())
-        names = {"surfel": "k_family_mfma<SurfAcc>", "gyro": "k_family_mfma<GyroAcc>", "accel": "k_family_mfma<AccelAcc>", "imu": "k_imu_mfma (gyroscope + accelerometer blocks fused)",
+        names = {"surfel": "k_family_mfma<SurfAcc>", "gyro": "k_family_mfma<GyroAcc>", "accel": "k_family_mfma<AccelAcc>", "imu": "k_imu_own (gyroscope + accelerometer blocks fused, owner-computes)",
                  "reproj": "reprojection path (k_reproj_jac + k_family_mfma<RepSideAcc<1>> + k_family_mfma<RepSideAcc<0>> + k_reproj_cross + k_reproj_lmrows)"}
         fl_d, by_d = work[dominant]
+        traffic_bytes, traffic_src = measured_traffic(dominant)
         out["roofline"] = {"bound": "mfma", "kernel": names[dominant], "achieved": fam[dominant]["TFLOPs"], "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fam[dominant]["frac_fp64_peak"],
-                           "traffic": PMC_TRAFFIC_BYTES.get(dominant) if scale == 1 else None, "traffic_source": PMC_SOURCE + " — constants copied from that profile, not measured in this run",
+                           "traffic": traffic_bytes if scale == 1 else None, "traffic_source": traffic_src,
                            "duration_source": "HIP events on the kernel's own stream around every launch of the timed region" if (dominant == live_fam and launches[k]) else "solo duration (every kernel on one stream), profiled run outside the timed region",
                            "avg_launch_ms": fam[dominant]["ms"], "algorithmic_flops_per_launch": fl_d, "algorithmic_bytes_per_launch": by_d,
                            "hbm": {"achieved_GBps": fam[dominant]["GBps"], "peak_GBps": HBM_PEAK_GBS},
@@ -471,47 +544,105 @@ def main():
                                    "`whole_pass` the sum over the step time"}
     # ---- side measurements that involve every rank ----
     if world > 1 and not args.no_secondary:
-        # LM iterations of the JOINT problem — shared rig extrinsics, one sequence per GPU (lvx_lm_solve_shared), over both transports
+        # LM iterations of the JOINT problem — shared rig extrinsics, one sequence per GPU (lvx_lm_solve_shared).  Transport: RCCL inside the library on the context's
+        # stream when the job runs on RCCL (no host round trip); the host callback over torch.distributed otherwise, and as the fallback when a second communicator next
+        # to torch's cannot be created.  Which one ran is recorded.
         import sharded
         sj = P["state0"].copy()
         Nk = lo["n_knots"]
+        sec_all = out.setdefault("secondary", {})
         try:
             ext = torch.from_numpy(sj[7 * Nk + 16:7 * Nk + 32].copy()).cuda()
             dist.broadcast(ext, src=0)                      # the shared extrinsics start from rank 0's guess
             sj[7 * Nk + 16:7 * Nk + 32] = ext.cpu().numpy()
-            dist.barrier(); torch.cuda.synchronize()
-            tj = time.perf_counter()
-            _, smj = ctx.lm_solve_shared(sj, sharded.dist_all_reduce(dist, torch.device("cuda", local_rank)), max_iterations=3)
-            torch.cuda.synchronize(); dist.barrier()
-            tj = time.perf_counter() - tj
-            joint = {"ms_per_iteration": 1e3 * tj / max(1, smj["iterations"]), "iterations": smj["iterations"], "initial_cost": smj["initial_cost"], "final_cost": smj["final_cost"],
-                     "transport": "host callback (torch.distributed all_reduce of <= 211 doubles per reduction)",
-                     "note": "joint LM over %d sequences with shared extrinsics: evaluate + private elimination per GPU, reduced 14 x 14 system + decision scalars over the ranks" % world}
         except Exception as e:   # noqa: BLE001
-            joint = {"error": str(e)[:300]}
-        out.setdefault("secondary", {})["joint_lm_iteration"] = joint
-        try:   # the same solve with the reductions as ncclAllReduce calls on the context's stream (librccl inside liblvx, no host round trip)
-            if backend != "nccl":
-                raise RuntimeError("skipped: the functional check runs several ranks on one GPU (RCCL needs one device per rank)")
-            uid = torch.tensor(list(ctx.rccl_unique_id()) if rank == 0 else [0] * 128, dtype=torch.uint8, device="cuda")
-            dist.broadcast(uid, src=0)
-            ctx.rccl_init(bytes(uid.cpu().tolist()), rank, world)
-            ctx.collective_count(reset=True)
-            dist.barrier(); torch.cuda.synchronize()
-            tj = time.perf_counter()
-            _, smr = ctx.lm_solve_shared(sj, None, max_iterations=3)
-            torch.cuda.synchronize(); dist.barrier()
-            tj = time.perf_counter() - tj
-            out["secondary"]["joint_lm_iteration_rccl"] = {"ms_per_iteration": 1e3 * tj / max(1, smr["iterations"]), "iterations": smr["iterations"], "final_cost": smr["final_cost"],
-                                                           "collectives": int(ctx.collective_count()), "transport": "RCCL inside liblvx on the context's stream (lvx_rccl_init)"}
-            ctx.rccl_finalize()
+            sec_all["joint_lm_iteration"] = {"error": str(e)[:300]}
+        rccl_ok = False
+        if backend == "nccl" and "joint_lm_iteration" not in sec_all:
+            try:
+                uid = torch.tensor(list(ctx.rccl_unique_id()) if rank == 0 else [0] * 128, dtype=torch.uint8, device="cuda")
+                dist.broadcast(uid, src=0)
+                ctx.rccl_init(bytes(uid.cpu().tolist()), rank, world)
+                ok = torch.ones(1, device="cuda")
+            except Exception as e:   # noqa: BLE001
+                ok = torch.zeros(1, device="cuda")
+                sec_all["joint_lm_rccl_init_error"] = str(e)[:300]
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)       # every rank takes the same transport
+            rccl_ok = bool(ok.item() > 0)
+            if not rccl_ok:
+                try:
+                    ctx.rccl_finalize()
+                except Exception:   # noqa: BLE001
+                    pass
+        if "joint_lm_iteration" not in sec_all:
+            try:
+                ctx.collective_count(reset=True)
+                dist.barrier(); torch.cuda.synchronize()
+                tj = time.perf_counter()
+                _, smj = ctx.lm_solve_shared(sj, None if rccl_ok else sharded.dist_all_reduce(dist, torch.device("cuda", local_rank)), max_iterations=3)
+                torch.cuda.synchronize(); dist.barrier()
+                tj = time.perf_counter() - tj
+                sec_all["joint_lm_iteration"] = {"ms_per_iteration": 1e3 * tj / max(1, smj["iterations"]), "iterations": smj["iterations"], "initial_cost": smj["initial_cost"], "final_cost": smj["final_cost"],
+                                                 "collectives": int(ctx.collective_count()),
+                                                 "transport": "RCCL inside liblvx on the context's stream (lvx_rccl_init): reduced system packed, reduced and solved on the device" if rccl_ok else
+                                                              "host callback (torch.distributed all_reduce of <= 211 doubles per reduction)",
+                                                 "note": "joint LM over %d sequences with shared extrinsics: evaluate + private elimination per GPU, reduced 14 x 14 system + decision scalars over the ranks" % world}
+            except Exception as e:   # noqa: BLE001
+                sec_all["joint_lm_iteration"] = {"error": str(e)[:300]}
+            if rccl_ok:
+                try:
+                    ctx.rccl_finalize()
+                except Exception:   # noqa: BLE001
+                    pass
+        fail_rank = int(os.environ.get("LVX_BENCH_FAIL_RANK", "-1"))
+        if 0 <= fail_rank < world:   # readiness check (tests/test_gpu_bench_ranks.py): one rank fails locally (non-unit control quaternion) -> EVERY rank must leave the joint solve together
+            try:
+                bad = sj.copy()
+                if rank == fail_rank:
+                    bad[3 * Nk + 4 * (Nk // 2):3 * Nk + 4 * (Nk // 2) + 4] *= 1.5
+                code = 0
+                try:
+                    ctx.lm_solve_shared(bad, sharded.dist_all_reduce(dist, torch.device("cuda", local_rank)), max_iterations=3)
+                except lvx.LvxError as e:
+                    code = int(e.code)
+                codes = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
+                dist.all_gather(codes, torch.tensor([code], dtype=torch.int64, device="cuda"))
+                sec_all["joint_failure_vote"] = {"failing_rank": fail_rank, "return_codes": [int(c.item()) for c in codes]}
+                ctx.set_state(P["state0"]); ctx.evaluate_resident(what, want_cost=True)   # the failing rank's context remembers its last evaluation's device error (lvx_synchronize): replace it
+            except Exception as e:   # noqa: BLE001
+                sec_all["joint_failure_vote"] = {"error": str(e)[:300]}
+        try:   # SURVEY 8d config 5 asks for both shard sizes: the variant that is not the headline, same step (evaluation + all-reduce of the border block), fewer steps
+            oscale = (10 if args.small else 1) * (1 if args.shard_size == "eighth" else 8)
+            P2 = synth.make_bench_problem(seed=40 + rank, n_imu=200_000 // oscale, n_surfel=1_000_000 // oscale, n_reproj=50_000 // oscale, n_planes=max(8, 2000 // oscale))
+            c2 = lvx.Context(local_rank)
+            lvx.load_problem(c2, P2, lvx.LOCK_LIDAR_TAU | lvx.LOCK_CAM_TAU)
+            l2 = c2.layout()
+            c2.set_state(P2["state0"])
+            c2.set_stream(torch.cuda.current_stream().cuda_stream)
+            red2 = torch.zeros(l2["border_ld"] ** 2 + l2["border_ld"] + 2, dtype=torch.float64, device="cuda")
+
+            def step2():
+                c2.evaluate_resident(what); c2.export_border(red2.data_ptr()); dist.all_reduce(red2)
+            for _ in range(2):
+                step2()
+            c2.synchronize(); torch.cuda.synchronize(); dist.barrier()
+            t2 = time.perf_counter()
+            for _ in range(10):
+                step2()
+            c2.synchronize(); torch.cuda.synchronize(); dist.barrier()
+            t2 = torch.tensor([time.perf_counter() - t2], dtype=torch.float64, device="cuda"); dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            nb2 = torch.tensor([float(l2["n_blocks"])], dtype=torch.float64, device="cuda"); dist.all_reduce(nb2)
+            sec_all["other_shard_size"] = {"shard_size": "full" if args.shard_size == "eighth" else "eighth", "value": float(nb2.item()) * 10 / float(t2.item()) / 1e6, "unit": "Mevals/s",
+                                           "ms_per_step": 1e2 * float(t2.item()), "blocks_all_ranks": int(nb2.item())}
+            c2.close()
         except Exception as e:   # noqa: BLE001
-            out["secondary"]["joint_lm_iteration_rccl"] = {"error": str(e)[:300]}
+            sec_all["other_shard_size"] = {"error": str(e)[:300]}
     if not args.no_secondary:
         try:
             assoc = assoc_metric(ctx, world, rank)      # every rank takes part (all-gather of the flags)
         except Exception as e:   # noqa: BLE001
             assoc = {"error": str(e)[:300]}
+            print("[bench rank %d] surfel_assoc: %s" % (rank, str(e)[:300]), file=sys.stderr, flush=True)
         out.setdefault("secondary", {})["surfel_assoc"] = assoc
     # ---- rank 0 alone ----
     if rank == 0:

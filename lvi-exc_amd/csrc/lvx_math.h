@@ -166,8 +166,10 @@ LVX_HD double madd_2r(double a, double b, double c) {
   double p = a * b;
 #if defined(__AMDGCN__)
   asm volatile("" : "+v"(p));
-#else
+#elif defined(__x86_64__)
   asm volatile("" : "+x"(p));
+#else
+  asm volatile("" : "+m"(p));   // any other host (the oracle / host checks build this header with plain g++): through memory, portable
 #endif
   return c + p;
 }

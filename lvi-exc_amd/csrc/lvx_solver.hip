@@ -1097,13 +1097,14 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
   int pending = LVX_OK;   // a local failure (restoring the normal equations of x) that has not met a collective yet: voted in the next R1
   bool acc_is_x = true;   // the accumulators hold the normal equations of x (not of a candidate that was not accepted)
   // the accumulators hold the candidate's normal equations: put those of x back (no reduction: every rank takes this branch together)
-  auto restore_x = [&]() { double cx = 0; const int re = lvx_evaluate_d(c, x, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &cx); if (re && !pending) pending = re; acc_is_x = true; };
+  bool restored = false;  // a restore ran since the last collective: if the loop ends now, its outcome has not been voted on yet
+  auto restore_x = [&]() { double cx = 0; const int re = lvx_evaluate_d(c, x, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &cx); if (re && !pending) pending = re; acc_is_x = re == 0; restored = true; };
   while (s.termination == LVX_LM_NO_CONVERGENCE) {
     if (it >= o.max_iterations) { s.termination = LVX_LM_MAX_ITERATIONS; break; }
     ++it;
     double m[3]; bool notpd = false;
     if ((rc = solve_step_device(c, w, radius, m, &notpd, pending))) return rc;
-    pending = LVX_OK;
+    pending = LVX_OK; restored = false;
     // candidate x (+) delta: cost AND normal equations (they replace those of x in the accumulators; the model terms of x were taken by solve_step_device)
     double r2[7 + LVX_JB_N] = {m[0], m[1], m[2], 0, 0, 0, 0}, h[6] = {0, 0, 0, 0, 0, 0};
     lerr = LVX_OK;
@@ -1165,6 +1166,11 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
     if (o.verbose) fprintf(stderr, "[lvx lm] it %3d cost %.9e radius %.3e rho %.3f\n", it, cost, radius, rho);
   }
   s.iterations = it; s.final_cost = cost; s.final_radius = radius;
+  if (joint && restored) {   // the loop ended (iteration cap) right behind a rejected step: every rank is here (same decisions), the restore's outcome is voted so that all return together
+    double v = pending ? 1.0 : 0.0;
+    if ((rc = reduce(c, &v, 1, LVX_REDUCE_SUM))) return rc;
+    if ((rc = leave_together(c, v, pending))) return rc;
+  }
   if (!acc_is_x) c->last_what &= ~LVX_EVAL_NORMAL_EQ;   // a tolerance test ended the loop on a candidate that was not applied: its normal equations are not those of the returned state
   LVX_HIP(c, hipMemcpyAsync(state, x, sbytes, hipMemcpyDeviceToHost, st));
   LVX_HIP(c, hipStreamSynchronize(st));

@@ -42,3 +42,36 @@ def test_two_rank_bench_line():
     assert "error" not in a, a
     assert a["scans"] == 2 * a["scans_per_gpu"] and a["associated_points"] > 0 and a["Mpts_per_s"] > 0
     assert dt < 300
+
+
+def test_eight_rank_bench_line_with_a_failing_rank():
+    """What the driver's 8-GPU run does, on ONE GPU (gloo, 1/10-size sequences, seeds 40..47): eight ranks evaluate + all-reduce, solve the joint LM, all-gather the
+    sharded association, time the other shard size of SURVEY's config 5 — and when rank 5 fails locally (non-unit quaternion) every rank leaves the joint solve in the same
+    collective: the failing rank with its own code, the others with LVX_E_COMM."""
+    env = dict(os.environ, LVX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", LVX_BENCH_FAIL_RANK="5", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--small"]
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    dt = time.perf_counter() - t0
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    sec = out["secondary"]
+    print("8-rank bench: %.1f s wall, %.1f Mevals/s, joint LM %s, vote %s, other shard size %s" % (dt, out["value"], sec.get("joint_lm_iteration"), sec.get("joint_failure_vote"), sec.get("other_shard_size")))
+    assert out["n_gpus"] == 8 and out["config"]["parallelism"] == "sequence-per-gpu x8" and out["config"]["shard_size"] == "full" and out["value"] > 0
+    j = sec["joint_lm_iteration"]
+    assert "error" not in j, j
+    assert j["iterations"] >= 1 and j["final_cost"] < j["initial_cost"] and j["transport"].startswith("host callback")
+    v = sec["joint_failure_vote"]
+    assert "error" not in v, v
+    codes = v["return_codes"]
+    assert len(codes) == 8 and codes[5] == -2 and all(c == -5 for i, c in enumerate(codes) if i != 5)       # LVX_E_NONUNIT_QUAT on the failing rank, LVX_E_COMM everywhere else
+    a = sec["surfel_assoc"]
+    assert "error" not in a, a
+    assert a["scans"] == 8 * a["scans_per_gpu"] and a["associated_points"] > 0
+    o = sec["other_shard_size"]
+    assert "error" not in o, o
+    assert o["shard_size"] == "eighth" and o["value"] > 0
+    assert dt < 600
