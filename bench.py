@@ -207,6 +207,18 @@ def secondary_metrics(ctx, P, lo):
                               "cpu": {"Mpts_per_s": len(cloud) / tc / 1e6, "cores": 1, "kind": "port", "sample": "one build (the reference's applyFilter is serial)"}}
         t = lvx.upstream_bench(ctx, "voxel_lookup7", synth.rigid_move(cloud))
         sec["voxel_lookup7"] = {"Mqueries_per_s": len(cloud) / t / 1e6, "ms": 1e3 * t, "hbm_frac": 100.0 * len(cloud) / t / 1e9 / HBM_PEAK_GBS}
+        # the sizes the pipeline really builds: the map cloud of a DataAssociation round (~410 k points) and a 4 M-point map; same local density (tiled config-2 cloud).
+        # One launch chain without a host hop, replayed as a HIP graph; algorithmic traffic 36 B per point + 268 B per occupied leaf
+        sizes = {}
+        for tiles in (4, 40):
+            big = synth.tile_voxel_cloud(cloud, tiles)
+            tb = lvx.upstream_bench(ctx, "voxel_build", (big, 0.5), reps=10)
+            nl = ctx.voxel_info()["n_leaves"]
+            by = 36.0 * len(big) + 268.0 * nl
+            tq = lvx.upstream_bench(ctx, "voxel_lookup7", synth.rigid_move(big), reps=10)
+            sizes["%d_points" % len(big)] = {"ms": 1e3 * tb, "Mpts_per_s": len(big) / tb / 1e6, "leaves": int(nl), "GBps": by / tb / 1e9, "hbm_frac": by / tb / 1e9 / HBM_PEAK_GBS,
+                                             "lookup7": {"ms": 1e3 * tq, "Mqueries_per_s": len(big) / tq / 1e6, "GBps": 100.0 * len(big) / tq / 1e9, "hbm_frac": 100.0 * len(big) / tq / 1e9 / HBM_PEAK_GBS}}
+        sec["voxel_build"]["larger_maps"] = sizes
         pts = synth.make_vlp16_sweep(seed=1)
         lvx.scan_register(ctx, pts, 16, 0.3)
         t0 = time.perf_counter()

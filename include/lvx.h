@@ -275,6 +275,10 @@ int lvx_scan_less_flat_downsample_sweep(lvx_ctx* ctx, int sweep, float leaf_size
 typedef struct lvx_voxel_info { int32_t n_leaves, n_points; int32_t min_b[3], max_b[3], div_b[3], divb_mul[3]; } lvx_voxel_info;
 int lvx_voxel_build(lvx_ctx* ctx, int n, const float* xyzi4, float leaf_size, int min_points_per_voxel, double min_covar_eigvalue_mult, lvx_voxel_info* info);
 int lvx_voxel_build_d(lvx_ctx* ctx, int n, const float* xyzi4_d, float leaf_size, int min_points_per_voxel, double min_covar_eigvalue_mult);
+/* lvx_voxel_build_d is ASYNCHRONOUS: the whole build is one launch chain on the context's stream without a host hop (extents, cell table, leaf count stay on the
+ * device; the cloud must stay alive and unchanged until a consumer has run).  This call waits for it and returns what VoxelGridCovariance's getters report after
+ * applyFilter (getMinBoxCoordinates / getMaxBoxCoordinates / getNrDivisions / getDivisionMultiplier, leaves_.size(): pcl/filters/voxel_grid.h, voxel_grid_covariance_omp.h:298-305). */
+int lvx_voxel_get_info(lvx_ctx* ctx, lvx_voxel_info* info);
 /* Leaf fields (voxel_grid_covariance_omp.h:92-190): nr_points (-1 = rejected), mean_, cov_, icov_, evecs_ (columns), evals_, centroid, pointList_
  * as offsets[n_leaves + 1] into point_ids (input indices, input order inside a leaf); any pointer may be NULL */
 int lvx_voxel_get(lvx_ctx* ctx, int32_t* leaf_key, int32_t* leaf_n, double* mean3, double* cov9, double* icov9, double* evecs9, double* evals3, float* centroid3,

@@ -150,6 +150,10 @@ struct lvx_ctx {
     const void* d_pts = nullptr;   // the cloud of the last build (device; caller- or context-owned), read again by lvx_surfel_extract
     int grid[13] = {0};   // VxGrid: min_b, max_b, div_b, mul, inv(float bits)
     lvx::DevBuf misc, keys, vals, runs, cells, tmp, leaf_i, leaf_d, leaf_f;
+    // sync-free build (lvx_upstream.hip: voxel_build_device / vox_info): capacities, the pinned host mirror of the device-computed VxInfo, the captured launch chain
+    double eig_mult = 0; int cap = 0, sort_bits = 32; long long cells_cap = 0; size_t tmp_bytes[3] = {0, 0, 0}; void* h_info = nullptr; bool pending = false;
+    std::array<uint64_t, 16> graph_key{};   // what the chain was captured with: cloud buffer, size, parameters, work buffers, stream
+    void* graph = nullptr; bool graph_failed = false;
   } vox;
   // captured evaluation passes (lvx_eval.hip: run_evaluate), keyed by state buffer / request / flags / configuration version
   struct GraphEntry { const double* state; uint32_t what; int flags; uint64_t cfg; void* exec; };

@@ -2783,6 +2783,8 @@ void lvx_destroy(lvx_ctx* c) {
   if (c->d_colfull.p) (void)hipFree(c->d_colfull.p);
   for (auto& b : c->d_det_list) if (b.p) (void)hipFree(b.p);
   for (DevBuf* b : {&c->d_imu_rtab, &c->d_chk, &c->d_det_cross, &c->d_lm_grp, &c->d_lmH, &c->d_lm_p0, &c->d_Hr, &c->d_Br, &c->d_red, &c->d_repT}) if (b->p) (void)hipFree(b->p);
+  if (c->vox.graph) (void)hipGraphExecDestroy((hipGraphExec_t)c->vox.graph);
+  if (c->vox.h_info) (void)hipHostFree(c->vox.h_info);
   for (DevBuf* b : {&c->vox.misc, &c->vox.keys, &c->vox.vals, &c->vox.runs, &c->vox.cells, &c->vox.tmp, &c->vox.leaf_i, &c->vox.leaf_d, &c->vox.leaf_f}) if (b->p) (void)hipFree(b->p);
   (void)lvx_rccl_finalize(c);
   if (c->d_comm.p) (void)hipFree(c->d_comm.p);

@@ -452,12 +452,41 @@ __global__ __launch_bounds__(256) void k_vx_minmax(const float4* p, int n, int* 
   }
 }
 struct VxGrid { int min_b[3], max_b[3], div_b[3], mul[3]; float inv; };
-__global__ void k_vx_keys(const float4* p, int n, VxGrid g, unsigned* keys, int* vals) {
+// What a build learns about its cloud, computed ON THE DEVICE (k_vx_grid, k_vx_leaf) and mirrored to pinned host memory behind the last kernel: the host reads it
+// when somebody needs it (vox_info), never in the middle of the kernel chain — round 3 stopped the chain twice (extents -> size of the cell table; leaf count -> strides of
+// the leaf arrays).  overflow: 1 = the dense cell table (capacity cells_cap) is too small for this cloud's extents (the host grows it and builds again), 2 = more than
+// 2^31 - 1 cells (the reference's "Leaf size is too small" error, voxel_grid_covariance_omp_impl.hpp:80-85).
+struct VxInfo { VxGrid g; int n_leaves, overflow; long long cells; };
+__global__ void k_vx_init(int* mm, VxInfo* info) {
+  if (threadIdx.x < 3) mm[threadIdx.x] = 0x7fffffff; else if (threadIdx.x < 6) mm[threadIdx.x] = (int)0x80000000;
+  if (threadIdx.x == 0) { info->n_leaves = 0; info->overflow = 0; info->cells = 0; }
+}
+__global__ void k_vx_grid(const int* mm, float leaf, long long cells_cap, VxInfo* info) {   // one thread: :86-95
+  VxGrid g;
+  g.inv = 1.0f / leaf;
+  const bool empty = mm[0] == 0x7fffffff;
+  for (int k = 0; k < 3; ++k) {
+    g.min_b[k] = empty ? 0 : (int)floorf(ord2f(mm[k]) * g.inv); g.max_b[k] = empty ? -1 : (int)floorf(ord2f(mm[3 + k]) * g.inv);
+    g.div_b[k] = g.max_b[k] - g.min_b[k] + 1;
+  }
+  const long long cells = (long long)g.div_b[0] * g.div_b[1] * g.div_b[2];
+  g.mul[0] = 1; g.mul[1] = g.div_b[0]; g.mul[2] = g.div_b[0] * g.div_b[1];
+  info->g = g; info->cells = cells;
+  info->overflow = cells > 2147483647LL ? 2 : (cells > cells_cap ? 1 : 0);
+}
+__global__ void k_vx_cells_clear(int* cells, const VxInfo* info) {
+  if (info->overflow) return;
+  const long long n = info->cells;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) cells[i] = -1;
+}
+// keys: the voxel's linear index, or `invalid` (> every valid key, inside the sorted bit range) for non-finite points
+__global__ void k_vx_keys(const float4* p, int n, const VxInfo* info, unsigned invalid, unsigned* keys, int* vals) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const VxGrid g = info->g;
   const float4 q = p[i];
-  unsigned k = 0xffffffffu;
-  if (isfinite(q.x) && isfinite(q.y) && isfinite(q.z)) {
+  unsigned k = invalid;
+  if (!info->overflow && isfinite(q.x) && isfinite(q.y) && isfinite(q.z)) {
     const int i0 = (int)(floorf(q.x * g.inv) - (float)g.min_b[0]);   // :220-222
     const int i1 = (int)(floorf(q.y * g.inv) - (float)g.min_b[1]);
     const int i2 = (int)(floorf(q.z * g.inv) - (float)g.min_b[2]);
@@ -491,9 +520,12 @@ __device__ void vx_eig3(const double A[9], double ev[3], double V[9]) {   // cyc
 // (coordinates of tens of metres, spreads of centimetres), so only the reference's summation order reproduces it to 1e-12 of its own scale; the float
 // centroid is compared bit for bit — then the finalize of :286-371.  The points are scattered: 8 indices, then 8 points, are in flight at a time
 // (one dependent load per point made this kernel 79 us for 12 k leaves).
-__global__ void k_vx_leaf(const float4* __restrict__ p, const unsigned* ukeys, const unsigned* counts, const unsigned* offs, const int* __restrict__ sorted_ids, int nl, int min_pts, double eig_mult,
-                          int* grid, int* leaf_key, int* leaf_n, double* mean, double* cov, double* icov, double* evecs, double* evals, float* centroid) {
+__global__ void k_vx_leaf(const float4* __restrict__ p, const unsigned* ukeys, const unsigned* counts, const unsigned* offs, const int* __restrict__ sorted_ids, const unsigned* d_nruns, unsigned invalid,
+                          int min_pts, double eig_mult, VxInfo* info, int* grid, int* leaf_key, int* leaf_n, double* mean, double* cov, double* icov, double* evecs, double* evals, float* centroid) {
   const int li = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nruns = (int)*d_nruns;
+  const int nl = info->overflow ? 0 : nruns - ((nruns > 0 && ukeys[nruns - 1] == invalid) ? 1 : 0);   // the last run may be the invalid-key bucket (non-finite points)
+  if (li == 0) info->n_leaves = nl;
   if (li >= nl) return;
   const unsigned key = ukeys[li];
   const int n = (int)counts[li];
@@ -1135,66 +1167,106 @@ int lvx_scan_register_batch(lvx_ctx* c, int n_sweeps, const int32_t* sweep_offse
   return scan_register_batch(c, n_sweeps, sweep_offsets, pts, n_rings, min_range, outs);
 }
 
-// voxel grid kept on the device in the context
+// voxel grid kept on the device in the context.  The whole build is ONE chain of launches without a host hop (k_vx_init -> extents -> grid geometry -> cell-table clear ->
+// keys -> rocPRIM radix sort / run-length encode / scan -> leaves), captured once per (cloud buffer, size, parameters) into a HIP graph and replayed: ten small kernels are
+// bound by launch latency, not by HBM.  Leaf arrays are strided by the CAPACITY (the point count: a leaf holds at least one point), the dense cell table by its own capacity.
+static int vox_info(lvx_ctx* c);
+static int voxel_enqueue(lvx_ctx* c, const float4* d_pts, int n, float leaf, int min_pts, double eig_mult) {
+  hipStream_t st = c->stream;
+  lvx_ctx::Voxels& V = c->vox;
+  int* d_mm = (int*)V.misc.p;
+  VxInfo* d_info = (VxInfo*)((char*)V.misc.p + 64);
+  unsigned* k_in = (unsigned*)V.keys.p; unsigned* k_out = k_in + n;
+  int* v_in = (int*)V.vals.p; int* v_out = v_in + n;
+  unsigned* ukeys = (unsigned*)V.runs.p; unsigned* counts = ukeys + n; unsigned* offs = counts + n; unsigned* d_nruns = offs + n;
+  const size_t cap = (size_t)V.cap;
+  hipLaunchKernelGGL(k_vx_init, dim3(1), dim3(64), 0, st, d_mm, d_info);
+  hipLaunchKernelGGL(k_vx_minmax, dim3((unsigned)std::min((n + 255) / 256, 1024)), dim3(256), 0, st, d_pts, n, d_mm);
+  hipLaunchKernelGGL(k_vx_grid, dim3(1), dim3(1), 0, st, (const int*)d_mm, leaf, (long long)V.cells_cap, d_info);
+  hipLaunchKernelGGL(k_vx_cells_clear, dim3((unsigned)std::min<long long>((V.cells_cap + 1023) / 1024, 2048)), dim3(256), 0, st, (int*)V.cells.p, (const VxInfo*)d_info);
+  const unsigned invalid = (1u << V.sort_bits) - 1u;
+  hipLaunchKernelGGL(k_vx_keys, dim3((n + 255) / 256), dim3(256), 0, st, d_pts, n, (const VxInfo*)d_info, invalid, k_in, v_in);
+  size_t t1 = V.tmp_bytes[0], t2 = V.tmp_bytes[1], t3 = V.tmp_bytes[2];
+  LVX_HIP(c, rocprim::radix_sort_pairs(V.tmp.p, t1, k_in, k_out, v_in, v_out, (size_t)n, 0, (unsigned)V.sort_bits, st));   // stable: input order kept inside a leaf
+  LVX_HIP(c, rocprim::run_length_encode(V.tmp.p, t2, k_out, (size_t)n, ukeys, counts, d_nruns, st));
+  LVX_HIP(c, rocprim::exclusive_scan(V.tmp.p, t3, counts, offs, 0u, (size_t)n, rocprim::plus<unsigned>(), st));   // over all n slots: a prefix only depends on the runs before it
+  int* lk = (int*)V.leaf_i.p; int* ln = lk + cap;
+  double* mean = (double*)V.leaf_d.p; double* cov = mean + 3 * cap; double* icov = cov + 9 * cap; double* evecs = icov + 9 * cap; double* evals = evecs + 9 * cap;
+  hipLaunchKernelGGL(k_vx_leaf, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_pts, (const unsigned*)ukeys, (const unsigned*)counts, (const unsigned*)offs, (const int*)v_out, (const unsigned*)d_nruns, invalid,
+                     min_pts, eig_mult, d_info, (int*)V.cells.p, lk, ln, mean, cov, icov, evecs, evals, (float*)V.leaf_f.p);
+  LVX_HIP(c, hipMemcpyAsync(V.h_info, d_info, sizeof(VxInfo), hipMemcpyDeviceToHost, st));
+  LVX_HIP(c, hipGetLastError());
+  return LVX_OK;
+}
 static int voxel_build_device(lvx_ctx* c, const float4* d_pts, int n, float leaf, int min_pts, double eig_mult) {
   hipStream_t st = c->stream;
   int rc;
   lvx_ctx::Voxels& V = c->vox;
-  V.leaf = leaf; V.min_pts = min_pts; V.n_points = n; V.n_leaves = 0;
-  if ((rc = dev_alloc(c, V.misc, 256))) return rc;
-  int* d_mm = (int*)V.misc.p;
-  const int init[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
-  LVX_HIP(c, hipMemcpyAsync(d_mm, init, 24, hipMemcpyHostToDevice, st));
-  if (n > 0) hipLaunchKernelGGL(k_vx_minmax, dim3((unsigned)std::min((n + 255) / 256, 256)), dim3(256), 0, st, d_pts, n, d_mm);
-  int mm[6];
-  LVX_HIP(c, hipMemcpyAsync(mm, d_mm, 24, hipMemcpyDeviceToHost, st));
-  LVX_HIP(c, hipStreamSynchronize(st));
-  if (n == 0 || mm[0] == 0x7fffffff) { std::memset(&V.grid, 0, sizeof(V.grid)); return LVX_OK; }
-  VxGrid g;
-  g.inv = 1.0f / leaf;
-  for (int k = 0; k < 3; ++k) {
-    g.min_b[k] = (int)std::floor(ord2f(mm[k]) * g.inv); g.max_b[k] = (int)std::floor(ord2f(mm[3 + k]) * g.inv);   // :86-95
-    g.div_b[k] = g.max_b[k] - g.min_b[k] + 1;
-  }
-  const int64_t cells = (int64_t)g.div_b[0] * g.div_b[1] * g.div_b[2];
-  if (cells > 2147483647LL) return fail(c, LVX_E_ARG, "Leaf size is too small for the input dataset. Integer indices would overflow.");   // :80-85
-  g.mul[0] = 1; g.mul[1] = g.div_b[0]; g.mul[2] = g.div_b[0] * g.div_b[1];
-  std::memcpy(&V.grid, &g, sizeof(g));
+  V.leaf = leaf; V.min_pts = min_pts; V.eig_mult = eig_mult; V.n_points = n; V.n_leaves = 0; V.pending = false; V.d_pts = d_pts;
+  std::memset(&V.grid, 0, sizeof(V.grid));
+  if (n == 0) return LVX_OK;
+  if (!V.h_info) LVX_HIP(c, hipHostMalloc(&V.h_info, sizeof(VxInfo), hipHostMallocDefault));
+  if (V.cells_cap < (1 << 22)) V.cells_cap = 1 << 22;   // 4 M cells (16 MB): a 100 m x 100 m x 100 m map at 0.5 m; grown on demand (vox_info)
+  int bits = 1; while ((1ll << bits) - 1 < V.cells_cap + 1 && bits < 32) ++bits;   // keys < cells <= capacity, the invalid key = 2^bits - 1 above them
+  V.sort_bits = bits;
+  if ((rc = dev_alloc(c, V.misc, 64 + sizeof(VxInfo)))) return rc;
   if ((rc = dev_alloc(c, V.keys, (size_t)n * 4 * 2))) return rc;
   if ((rc = dev_alloc(c, V.vals, (size_t)n * 4 * 2))) return rc;
   if ((rc = dev_alloc(c, V.runs, ((size_t)n * 3 + 8) * 4))) return rc;
-  if ((rc = dev_alloc(c, V.cells, (size_t)cells * 4))) return rc;
-  unsigned* k_in = (unsigned*)V.keys.p; unsigned* k_out = k_in + n;
-  int* v_in = (int*)V.vals.p; int* v_out = v_in + n;
-  unsigned* ukeys = (unsigned*)V.runs.p; unsigned* counts = ukeys + n; unsigned* offs = counts + n; unsigned* d_nruns = offs + n;
-  LVX_HIP(c, hipMemsetAsync(V.cells.p, 0xff, (size_t)cells * 4, st));
-  hipLaunchKernelGGL(k_vx_keys, dim3((n + 255) / 256), dim3(256), 0, st, d_pts, n, g, k_in, v_in);
-  size_t tmp1 = 0, tmp2 = 0, tmp3 = 0;
-  LVX_HIP(c, rocprim::radix_sort_pairs(nullptr, tmp1, k_in, k_out, v_in, v_out, (size_t)n, 0, 32, st));
-  LVX_HIP(c, rocprim::run_length_encode(nullptr, tmp2, k_out, (size_t)n, ukeys, counts, d_nruns, st));
-  LVX_HIP(c, rocprim::exclusive_scan(nullptr, tmp3, counts, offs, 0u, (size_t)n, rocprim::plus<unsigned>(), st));
-  if ((rc = dev_alloc(c, V.tmp, std::max(tmp1, std::max(tmp2, tmp3)) + 16))) return rc;
-  LVX_HIP(c, rocprim::radix_sort_pairs(V.tmp.p, tmp1, k_in, k_out, v_in, v_out, (size_t)n, 0, 32, st));   // stable: input order kept inside a leaf
-  LVX_HIP(c, rocprim::run_length_encode(V.tmp.p, tmp2, k_out, (size_t)n, ukeys, counts, d_nruns, st));
-  unsigned nruns = 0;
-  LVX_HIP(c, hipMemcpyAsync(&nruns, d_nruns, 4, hipMemcpyDeviceToHost, st));
-  LVX_HIP(c, hipStreamSynchronize(st));
-  // the last run may be the invalid-key bucket (non-finite points)
-  unsigned last_key = 0;
-  if (nruns > 0) LVX_HIP(c, hipMemcpy(&last_key, ukeys + (nruns - 1), 4, hipMemcpyDeviceToHost));
-  int nl = (int)nruns - ((nruns > 0 && last_key == 0xffffffffu) ? 1 : 0);
-  V.n_leaves = nl;
-  if (nl > 0) {
-    LVX_HIP(c, rocprim::exclusive_scan(V.tmp.p, tmp3, counts, offs, 0u, (size_t)nruns, rocprim::plus<unsigned>(), st));
-    if ((rc = dev_alloc(c, V.leaf_i, (size_t)nl * 2 * 4))) return rc;
-    if ((rc = dev_alloc(c, V.leaf_d, (size_t)nl * 33 * 8))) return rc;
-    if ((rc = dev_alloc(c, V.leaf_f, (size_t)nl * 3 * 4))) return rc;
-    int* lk = (int*)V.leaf_i.p; int* ln = lk + nl;
-    double* mean = (double*)V.leaf_d.p; double* cov = mean + 3 * (size_t)nl; double* icov = cov + 9 * (size_t)nl; double* evecs = icov + 9 * (size_t)nl; double* evals = evecs + 9 * (size_t)nl;
-    hipLaunchKernelGGL(k_vx_leaf, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, st, d_pts, (const unsigned*)ukeys, (const unsigned*)counts, (const unsigned*)offs, (const int*)v_out, nl, min_pts,
-                       eig_mult, (int*)V.cells.p, lk, ln, mean, cov, icov, evecs, evals, (float*)V.leaf_f.p);
+  if ((rc = dev_alloc(c, V.cells, (size_t)V.cells_cap * 4))) return rc;
+  V.cap = n;
+  if ((rc = dev_alloc(c, V.leaf_i, (size_t)n * 2 * 4))) return rc;
+  if ((rc = dev_alloc(c, V.leaf_d, (size_t)n * 33 * 8))) return rc;
+  if ((rc = dev_alloc(c, V.leaf_f, (size_t)n * 3 * 4))) return rc;
+  {
+    unsigned* k_in = (unsigned*)V.keys.p; int* v_in = (int*)V.vals.p; unsigned* ukeys = (unsigned*)V.runs.p;
+    size_t t1 = 0, t2 = 0, t3 = 0;
+    LVX_HIP(c, rocprim::radix_sort_pairs(nullptr, t1, k_in, k_in + n, v_in, v_in + n, (size_t)n, 0, (unsigned)V.sort_bits, st));
+    LVX_HIP(c, rocprim::run_length_encode(nullptr, t2, k_in + n, (size_t)n, ukeys, ukeys + n, ukeys + 3 * (size_t)n, st));
+    LVX_HIP(c, rocprim::exclusive_scan(nullptr, t3, ukeys + n, ukeys + 2 * (size_t)n, 0u, (size_t)n, rocprim::plus<unsigned>(), st));
+    V.tmp_bytes[0] = t1; V.tmp_bytes[1] = t2; V.tmp_bytes[2] = t3;
+    if ((rc = dev_alloc(c, V.tmp, std::max(t1, std::max(t2, t3)) + 16))) return rc;
   }
-  LVX_HIP(c, hipGetLastError());
+  // replay the captured chain when nothing it was captured with has changed
+  uint64_t lb = 0, eb = 0; std::memcpy(&lb, &leaf, 4); std::memcpy(&eb, &eig_mult, 8);
+  const std::array<uint64_t, 16> key{(uint64_t)(uintptr_t)d_pts, (uint64_t)n, lb, (uint64_t)min_pts, eb, (uint64_t)(uintptr_t)V.keys.p, (uint64_t)(uintptr_t)V.vals.p, (uint64_t)(uintptr_t)V.runs.p,
+                                     (uint64_t)(uintptr_t)V.cells.p, (uint64_t)(uintptr_t)V.tmp.p, (uint64_t)(uintptr_t)V.leaf_i.p, (uint64_t)(uintptr_t)V.leaf_d.p, (uint64_t)(uintptr_t)V.leaf_f.p,
+                                     (uint64_t)(uintptr_t)V.misc.p, (uint64_t)V.cells_cap, (uint64_t)(uintptr_t)st};
+  if (V.graph && key != V.graph_key) { (void)hipGraphExecDestroy((hipGraphExec_t)V.graph); V.graph = nullptr; }
+  if (!V.graph && !V.graph_failed && !c->sw.no_graph && !c->profiling) {
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess) {
+      rc = voxel_enqueue(c, d_pts, n, leaf, min_pts, eig_mult);
+      const hipError_t ce = hipStreamEndCapture(st, &graph);
+      hipGraphExec_t exec = nullptr;
+      if (!rc && ce == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) { V.graph = exec; V.graph_key = key; }
+      else { V.graph_failed = true; (void)hipGetLastError(); }   // (rocPRIM could not be captured on this stack: plain launches from now on)
+      if (graph) (void)hipGraphDestroy(graph);
+    } else { V.graph_failed = true; (void)hipGetLastError(); }
+  }
+  if (V.graph) LVX_HIP(c, hipGraphLaunch((hipGraphExec_t)V.graph, st));
+  else if ((rc = voxel_enqueue(c, d_pts, n, leaf, min_pts, eig_mult))) return rc;
+  V.pending = true;
+  return LVX_OK;
+}
+// The host's view of the last build (leaf count, grid geometry): waits for the chain once, when somebody asks; a cell table that was too small is grown and the build repeated.
+static int vox_info(lvx_ctx* c) {
+  lvx_ctx::Voxels& V = c->vox;
+  for (int round = 0; V.pending; ++round) {
+    LVX_HIP(c, hipStreamSynchronize(c->stream));
+    V.pending = false;
+    VxInfo inf; std::memcpy(&inf, V.h_info, sizeof(inf));
+    if (inf.overflow == 2) return fail(c, LVX_E_ARG, "Leaf size is too small for the input dataset. Integer indices would overflow.");   // :80-85
+    if (inf.overflow == 1) {
+      if (round > 0) return fail(c, LVX_E_ALLOC, "voxel cell table could not be grown");
+      V.cells_cap = inf.cells + inf.cells / 4;
+      const int rc = voxel_build_device(c, (const float4*)V.d_pts, V.n_points, V.leaf, V.min_pts, V.eig_mult);
+      if (rc) return rc;
+      continue;
+    }
+    std::memcpy(&V.grid, &inf.g, sizeof(inf.g));
+    V.n_leaves = inf.n_leaves;
+  }
   return LVX_OK;
 }
 
@@ -1205,39 +1277,43 @@ int lvx_voxel_build(lvx_ctx* c, int n, const float* xyzi4, float leaf, int min_p
   if ((rc = upload(c, c->d_up[1], xyzi4, (size_t)n * 16))) return rc;
   { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
     if ((rc = voxel_build_device(c, (const float4*)c->d_up[1].p, n, leaf, min_pts, eig_mult))) return rc; }
-  c->vox.d_pts = c->d_up[1].p;
-  LVX_HIP(c, hipStreamSynchronize(c->stream));
-  if (info) {
-    VxGrid g; std::memcpy(&g, &c->vox.grid, sizeof(g));
-    info->n_leaves = c->vox.n_leaves; info->n_points = n;
-    for (int k = 0; k < 3; ++k) { info->min_b[k] = g.min_b[k]; info->max_b[k] = g.max_b[k]; info->div_b[k] = g.div_b[k]; info->divb_mul[k] = g.mul[k]; }
-  }
+  if ((rc = vox_info(c))) return rc;
+  return info ? lvx_voxel_get_info(c, info) : LVX_OK;
+}
+int lvx_voxel_get_info(lvx_ctx* c, lvx_voxel_info* info) {
+  if (!c || !info) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  const int rc = vox_info(c);
+  if (rc) return rc;
+  VxGrid g; std::memcpy(&g, &c->vox.grid, sizeof(g));
+  info->n_leaves = c->vox.n_leaves; info->n_points = c->vox.n_points;
+  for (int k = 0; k < 3; ++k) { info->min_b[k] = g.min_b[k]; info->max_b[k] = g.max_b[k]; info->div_b[k] = g.div_b[k]; info->divb_mul[k] = g.mul[k]; }
   return LVX_OK;
 }
 int lvx_voxel_build_d(lvx_ctx* c, int n, const float* xyzi4_d, float leaf, int min_pts, double eig_mult) {
   if (!c || n < 0 || !(leaf > 0) || (n > 0 && !xyzi4_d)) return LVX_E_ARG;
   LVX_HIP(c, hipSetDevice(c->device));
   ProfScope ps(c, LVX_KERNEL_UPSTREAM);
-  c->vox.d_pts = xyzi4_d;
-  return voxel_build_device(c, (const float4*)xyzi4_d, n, leaf, min_pts, eig_mult);
+  return voxel_build_device(c, (const float4*)xyzi4_d, n, leaf, min_pts, eig_mult);   // asynchronous: nothing comes back to the host until a consumer asks (vox_info)
 }
 int lvx_voxel_get(lvx_ctx* c, int32_t* leaf_key, int32_t* leaf_n, double* mean, double* cov, double* icov, double* evecs, double* evals, float* centroid,
                   int32_t* offsets, int32_t* point_ids) {
   if (!c) return LVX_E_ARG;
   LVX_HIP(c, hipSetDevice(c->device));
+  { const int rc = vox_info(c); if (rc) return rc; }
   LVX_HIP(c, hipStreamSynchronize(c->stream));
   const lvx_ctx::Voxels& V = c->vox;
-  const size_t nl = (size_t)V.n_leaves, n = (size_t)V.n_points;
+  const size_t nl = (size_t)V.n_leaves, n = (size_t)V.n_points, cap = (size_t)V.cap;
   if (nl == 0) { if (offsets) offsets[0] = 0; return LVX_OK; }
   const int* lk = (const int*)V.leaf_i.p;
   const double* d = (const double*)V.leaf_d.p;
   if (leaf_key) LVX_HIP(c, hipMemcpy(leaf_key, lk, nl * 4, hipMemcpyDeviceToHost));
-  if (leaf_n) LVX_HIP(c, hipMemcpy(leaf_n, lk + nl, nl * 4, hipMemcpyDeviceToHost));
+  if (leaf_n) LVX_HIP(c, hipMemcpy(leaf_n, lk + cap, nl * 4, hipMemcpyDeviceToHost));
   if (mean) LVX_HIP(c, hipMemcpy(mean, d, nl * 24, hipMemcpyDeviceToHost));
-  if (cov) LVX_HIP(c, hipMemcpy(cov, d + 3 * nl, nl * 72, hipMemcpyDeviceToHost));
-  if (icov) LVX_HIP(c, hipMemcpy(icov, d + 12 * nl, nl * 72, hipMemcpyDeviceToHost));
-  if (evecs) LVX_HIP(c, hipMemcpy(evecs, d + 21 * nl, nl * 72, hipMemcpyDeviceToHost));
-  if (evals) LVX_HIP(c, hipMemcpy(evals, d + 30 * nl, nl * 24, hipMemcpyDeviceToHost));
+  if (cov) LVX_HIP(c, hipMemcpy(cov, d + 3 * cap, nl * 72, hipMemcpyDeviceToHost));
+  if (icov) LVX_HIP(c, hipMemcpy(icov, d + 12 * cap, nl * 72, hipMemcpyDeviceToHost));
+  if (evecs) LVX_HIP(c, hipMemcpy(evecs, d + 21 * cap, nl * 72, hipMemcpyDeviceToHost));
+  if (evals) LVX_HIP(c, hipMemcpy(evals, d + 30 * cap, nl * 24, hipMemcpyDeviceToHost));
   if (centroid) LVX_HIP(c, hipMemcpy(centroid, V.leaf_f.p, nl * 12, hipMemcpyDeviceToHost));
   if (offsets) {
     const unsigned* offs = (const unsigned*)V.runs.p + 2 * n;
@@ -1250,11 +1326,12 @@ int lvx_voxel_get(lvx_ctx* c, int32_t* leaf_key, int32_t* leaf_n, double* mean, 
   return LVX_OK;
 }
 static int lookup_device(lvx_ctx* c, const float4* q_d, int nq, int* ids_d, int K) {
+  { const int rc = vox_info(c); if (rc) return rc; }
   const lvx_ctx::Voxels& V = c->vox;
   if (!V.cells.p || V.n_leaves == 0) { LVX_HIP(c, hipMemsetAsync(ids_d, 0xff, (size_t)nq * 4 * K, c->stream)); return LVX_OK; }
   VxGrid g; std::memcpy(&g, &V.grid, sizeof(g));
-  if (K == 7) hipLaunchKernelGGL(k_vx_lookup<7>, dim3((nq + 255) / 256), dim3(256), 0, c->stream, q_d, nq, V.leaf, V.min_pts, g, (const int*)V.cells.p, (const int*)V.leaf_i.p + V.n_leaves, ids_d);
-  else hipLaunchKernelGGL(k_vx_lookup<1>, dim3((nq + 255) / 256), dim3(256), 0, c->stream, q_d, nq, V.leaf, V.min_pts, g, (const int*)V.cells.p, (const int*)V.leaf_i.p + V.n_leaves, ids_d);
+  if (K == 7) hipLaunchKernelGGL(k_vx_lookup<7>, dim3((nq + 255) / 256), dim3(256), 0, c->stream, q_d, nq, V.leaf, V.min_pts, g, (const int*)V.cells.p, (const int*)V.leaf_i.p + V.cap, ids_d);
+  else hipLaunchKernelGGL(k_vx_lookup<1>, dim3((nq + 255) / 256), dim3(256), 0, c->stream, q_d, nq, V.leaf, V.min_pts, g, (const int*)V.cells.p, (const int*)V.leaf_i.p + V.cap, ids_d);
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
 }
@@ -1509,9 +1586,10 @@ int lvx_undistort_scan(lvx_ctx* c, const double* state, int n, const lvx_point_x
 
 // setSurfelMap over the leaves of the context's voxel grid: the accepted planes in voxel-key (std::map) order
 static int surfel_extract_device(lvx_ctx* c, double p_lambda, double dist_threshold, int min_leaf_points, int min_inliers, std::vector<SurfelPlaneDev>& out) {
-  const lvx_ctx::Voxels& V = c->vox;
   out.clear();
-  const int nl = V.n_leaves, n = V.n_points;
+  { const int rc0 = vox_info(c); if (rc0) return rc0; }
+  const lvx_ctx::Voxels& V = c->vox;
+  const int nl = V.n_leaves, n = V.n_points; const size_t cap = (size_t)V.cap;
   if (nl == 0) return LVX_OK;
   if (!V.d_pts) return fail(c, LVX_E_STATE, "lvx_voxel_build has not been called");
   int rc;
@@ -1521,8 +1599,8 @@ static int surfel_extract_device(lvx_ctx* c, double p_lambda, double dist_thresh
   const unsigned* counts = (const unsigned*)V.runs.p + n; const unsigned* offs = (const unsigned*)V.runs.p + 2 * (size_t)n;
   const int* lk = (const int*)V.leaf_i.p; const double* d = (const double*)V.leaf_d.p;
   { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
-    hipLaunchKernelGGL(k_surfel_extract, dim3((nl + 127) / 128), dim3(128), 0, c->stream, (const float4*)V.d_pts, counts, offs, (const int*)V.vals.p + n, nl, lk + nl, d, d + 21 * (size_t)nl,
-                       d + 30 * (size_t)nl, p_lambda, dist_threshold, min_leaf_points, min_inliers, (SurfelPlaneDev*)c->d_up[4].p, (int*)c->d_up[5].p); }
+    hipLaunchKernelGGL(k_surfel_extract, dim3((nl + 127) / 128), dim3(128), 0, c->stream, (const float4*)V.d_pts, counts, offs, (const int*)V.vals.p + n, nl, lk + cap, d, d + 21 * cap,
+                       d + 30 * cap, p_lambda, dist_threshold, min_leaf_points, min_inliers, (SurfelPlaneDev*)c->d_up[4].p, (int*)c->d_up[5].p); }
   LVX_HIP(c, hipGetLastError());
   std::vector<SurfelPlaneDev> all(nl); std::vector<int> flag(nl);
   LVX_HIP(c, hipMemcpyAsync(all.data(), c->d_up[4].p, (size_t)nl * sizeof(SurfelPlaneDev), hipMemcpyDeviceToHost, c->stream));
@@ -1658,6 +1736,7 @@ int lvx_ndt_derivatives(lvx_ctx* c, int n, const float* input_xyzi4, const float
                         double* score, double* gradient6, double* hessian36) {
   if (!c || n < 0 || !p6 || !score || !gradient6 || (compute_hessian && !hessian36) || (n > 0 && (!input_xyzi4 || !trans_xyzi4))) return LVX_E_ARG;
   LVX_HIP(c, hipSetDevice(c->device));
+  { const int rc0 = vox_info(c); if (rc0) return rc0; }
   const lvx_ctx::Voxels& V = c->vox;
   *score = 0.0;
   for (int j = 0; j < 6; ++j) gradient6[j] = 0.0;
@@ -1689,7 +1768,7 @@ int lvx_ndt_derivatives(lvx_ctx* c, int n, const float* input_xyzi4, const float
   LVX_HIP(c, hipMemsetAsync(c->d_up[6].p, 0, 43 * 8, c->stream));
   VxGrid g; std::memcpy(&g, &V.grid, sizeof(g));
   const int* lk = (const int*)V.leaf_i.p; const double* d = (const double*)V.leaf_d.p;
-  const size_t nl = (size_t)V.n_leaves;
+  const size_t nl = (size_t)V.cap;   // leaf arrays are strided by the capacity
   { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
     hipLaunchKernelGGL(k_ndt_derivatives, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const float4*)c->d_up[2].p, (const float4*)c->d_up[3].p, n, V.leaf, V.min_pts, g, (const int*)V.cells.p,
                        lk + nl, d, d + 12 * nl, K, compute_hessian, (double*)c->d_up[6].p); }

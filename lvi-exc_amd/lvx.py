@@ -161,6 +161,12 @@ class Context:
     def set_locks(self, mask):
         self._ck(self._l.lvx_set_locks(self._h, C.c_uint32(mask)))
 
+    def voxel_info(self):
+        """Grid geometry and leaf count of the last voxel build (waits for an asynchronous lvx_voxel_build_d)."""
+        info = VoxelInfo()
+        self._ck(self._l.lvx_voxel_get_info(self._h, C.byref(info)))
+        return dict(n_leaves=info.n_leaves, n_points=info.n_points, min_b=list(info.min_b), max_b=list(info.max_b), div_b=list(info.div_b), divb_mul=list(info.divb_mul))
+
     def set_switch(self, name, value=1):
         """Experiment / debug switch of this context, e.g. set_switch("FORCE_LEGACY", 1)."""
         self._ck(self._l.lvx_set_switch(self._h, C.c_char_p(name.encode()), C.c_int(int(value))))

@@ -518,6 +518,18 @@ def make_voxel_cloud(seed=2, n=100_000):
     return np.concatenate([xyz, rng.uniform(0, 255, (n, 1))], axis=1).astype(np.float32)
 
 
+def tile_voxel_cloud(cloud, tiles, pitch=40.0):
+    """A larger map at the same local density: `tiles` shifted copies of `cloud` on a square grid of `pitch` metres (a 410 k-point map cloud is ~4 tiles of the
+    100 k-point config-2 cloud, a 4 M-point one 40)."""
+    side = int(np.ceil(np.sqrt(tiles)))
+    out = []
+    for k in range(tiles):
+        c = cloud.copy()
+        c[:, 0] += np.float32(pitch * (k % side)); c[:, 1] += np.float32(pitch * (k // side))
+        out.append(c)
+    return np.concatenate(out)
+
+
 def rigid_move(xyzi, t=(0.1, 0.05, 0.02), yaw_deg=1.0):
     c, s = np.cos(np.deg2rad(yaw_deg)), np.sin(np.deg2rad(yaw_deg))
     R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
