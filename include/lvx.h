@@ -329,7 +329,8 @@ int lvx_lm_solve_shared(lvx_ctx* ctx, double* state, const lvx_lm_options* opt, 
  * dlopen (no link-time dependency; a process that already loaded RCCL, e.g. through torch, shares it).  Rank 0 creates the 128-byte id, the host
  * distributes it (any side channel), every rank calls lvx_rccl_init; lvx_rccl_finalize (or lvx_destroy) frees the communicator.
  * Collectives: one after the first evaluation, then exactly two per LM iteration — the reduced 14 x 14 system, and the decision block (candidate cost, model terms,
- * norms, the candidate's joint diagonal / gradient); the two cannot merge, the candidate depends on the reduced system's solution.
+ * norms, the candidate's joint diagonal / gradient); the two cannot merge, the candidate depends on the reduced system's solution.  One more (a vote) when the
+ * iteration cap ends the loop right behind a rejected step: the re-evaluation of x that follows a rejection has met no collective yet.
  * A rank that fails locally votes in the next collective and EVERY rank returns there (the failing one with its code, the others LVX_E_COMM). */
 int lvx_rccl_unique_id(lvx_ctx* ctx, void* id128);
 int lvx_rccl_init(lvx_ctx* ctx, const void* id128, int rank, int world);

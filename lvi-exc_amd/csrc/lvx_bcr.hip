@@ -405,7 +405,7 @@ static size_t trsm_lds_bytes(int b, int NW) {
   for (int p = 0; p < ntb; ++p) { const int R = bp - 16 * (p + 1); if (R > 0) d += (size_t)16 * (R | 1); }
   return d * 8;
 }
-static bool trsm_lds_ok(const lvx_ctx* c, int b) { return c->sw.bcr_trsm_stream == 0 && b <= 192 && trsm_lds_bytes(b, 8) <= 160 * 1024; }
+static bool trsm_lds_ok(const lvx_ctx*, int b) { return b <= 192 && trsm_lds_bytes(b, 8) <= 160 * 1024; }
 // the sets in the TrsmSet convention of trsv_batched (first set: batch entries 0 .. batch - 1 against L + e strideL; a set whose factor pointer starts one block
 // further — the Y solves — belongs to block e + 1)
 template <int NT, int NW>
@@ -443,10 +443,10 @@ static int launch_trsm_lds(lvx_ctx* c, const double* L, int b, long long strideL
   {
     int ng = (nvec + 15) / 16, nblk = batch;
     for (const TrsmSet* t : {second, third}) if (t && t->batch > 0 && t->nvec > 0) { ng += (t->nvec + 15) / 16; nblk = std::max(nblk, t->batch + 1); }
-    if (c->sw.bcr_trsm_nw == 4 || (c->sw.bcr_trsm_nw == 0 && (long long)nblk * ((ng + 3) / 4) <= 256))
+    if ((long long)nblk * ((ng + 3) / 4) <= 256)
       return launch_trsm_lds_nw<NT, 4>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, LI, strideLI, second, third);
   }
-  if (trsm_lds_bytes(b, 12) <= 160 * 1024 && c->sw.bcr_trsm_nw != 8) return launch_trsm_lds_nw<NT, 12>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, LI, strideLI, second, third);
+  if (trsm_lds_bytes(b, 12) <= 160 * 1024) return launch_trsm_lds_nw<NT, 12>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, LI, strideLI, second, third);
   return launch_trsm_lds_nw<NT, 8>(c, L, b, strideL, V, se, sv, strideV, nvec, batch, LI, strideLI, second, third);
 }
 
@@ -494,161 +494,6 @@ __device__ __forceinline__ double rsqrt_f64(double x) {             // hardware 
   y = y * (1.5 - 0.5 * x * y * y);
   y = y * (1.5 - 0.5 * x * y * y);
   return y;
-}
-#define POTRF_NT 512   // 8 wavefronts: the trailing update's tiles are dealt over all of them (one flat list, two tiles in flight per wavefront)
-// LIm != null: the inverse of every 16 x 16 diagonal triangle of the factor goes to LIm[block][panel][16][16] (row-major, zero above the diagonal) for the triangular
-// solves that follow (k_trsm_reg<.., DINV>); the kernel itself uses it too: the rows below a diagonal block are X = A21 inv(L11)^T — MFMA tiles dealt to all
-// wavefronts — instead of one thread per row substituting through 16 columns.
-__global__ __launch_bounds__(POTRF_NT) void k_potrf_batched(double* Dm, int b, long long strideD, int* info, double* LIm, long long strideLI) {
-  extern __shared__ double T[];             // packed lower triangle, row-major
-  double* dinv = T + ((b * (b + 1)) >> 1);  // [16]
-  double* Minv = dinv + 16;                 // [16][17]: inverse of the current diagonal triangle
-  __shared__ int bad;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  double* D = Dm + (size_t)blockIdx.x * strideD;
-  double* LI = LIm ? LIm + (size_t)blockIdx.x * strideLI : nullptr;
-  if (tid == 0) bad = 0;
-  for (int c0 = 0; c0 < b; c0 += 32) {      // lower triangle, 32 columns per step so that the loads are in flight together (every step is one trip to HBM: ~2 us each)
-    double v[32];
-#pragma unroll
-    for (int q = 0; q < 32; ++q) { const int cc = c0 + q, r = cc + tid; v[q] = (cc < b && r < b) ? D[(size_t)cc * b + r] : 0.0; }
-#pragma unroll
-    for (int q = 0; q < 32; ++q) { const int cc = c0 + q, r = cc + tid; if (cc < b && r < b) T[tri(r, cc)] = v[q]; }
-  }
-  __syncthreads();
-  const int fk = lane >> 4, fi = lane & 15;
-  // 1. a 16 x 16 diagonal block by wavefront 0 (lane = row, columns in registers).  Only the first one is a phase of its own: the block of step k + 1 is
-  // factorised by wavefront 0 DURING the trailing update of step k, right after it has updated that tile — the other seven wavefronts take the rest of the
-  // update, so the serial 16-column chain (7.3 k cycles) leaves the critical path wherever the update is at least as long.
-  auto diag_block = [&](int k0) {
-    const int nk = min(16, b - k0);
-    double a[16], invd[16];
-    const int r = lane;
-#pragma unroll
-    for (int cc = 0; cc < 16; ++cc) a[cc] = (r < nk && cc <= r) ? T[tri(k0 + r, k0 + cc)] : ((r == cc) ? 1.0 : 0.0);
-    // Factor and inverse in ONE loop: once column cc of L is final (all rows), row cc of M = inv(L11) can be finished in lane cc (it has folded in the rows above)
-    // and folded into the rows below — independent work in the shadow of the factorisation's dependent chain (pivot -> rsqrt -> column update).
-    double m[16], acc[16];
-#pragma unroll
-    for (int cc = 0; cc < 16; ++cc) { m[cc] = 0.0; acc[cc] = 0.0; }
-#pragma unroll
-    for (int cc = 0; cc < 16; ++cc) {
-      double dc = readlane_f64(a[cc], cc);
-      if (!(dc > 0.0)) { if (lane == 0 && cc < nk) atomicCAS(&bad, 0, k0 + cc + 1); dc = 1.0; }
-      const double inv = rsqrt_f64(dc), sq = dc * inv;
-      invd[cc] = inv;
-      a[cc] = (r == cc) ? sq : a[cc] * inv;
-      if (lane == 0) dinv[cc] = inv;
-#pragma unroll
-      for (int c2 = cc + 1; c2 < 16; ++c2) { const double l2 = readlane_f64(a[cc], c2); a[c2] -= a[cc] * l2; }
-      if (LI) {   // row cc of M: M[cc][c] = -acc[c] / L[cc][cc] (c < cc), 1 / L[cc][cc] (c = cc); then acc[c] += L[r][cc] M[cc][c] in the rows below
-#pragma unroll
-        for (int c = 0; c < 16; ++c) if (c <= cc) { const double fin = c == cc ? inv : -acc[c] * inv; m[c] = (r == cc) ? fin : m[c]; }
-#pragma unroll
-        for (int c = 0; c < 16; ++c) if (c <= cc) { const double mk = readlane_f64(m[c], cc); acc[c] += a[cc] * mk; }   // a[cc] = L[r][cc]; the rows above have finished theirs
-      }
-    }
-    if (r < nk) {
-#pragma unroll
-      for (int cc = 0; cc < 16; ++cc) if (cc <= r) T[tri(k0 + r, k0 + cc)] = a[cc];
-    }
-    if (LI && r < 16) {
-      double* dst = LI + (size_t)(k0 >> 4) * 256 + r * 16;
-#pragma unroll
-      for (int cc = 0; cc < 16; ++cc) { Minv[r * 17 + cc] = m[cc]; dst[cc] = m[cc]; }
-    }
-  };
-  if (wv == 0) diag_block(0);
-  __syncthreads();
-  for (int k0 = 0; k0 < b; k0 += 16) {
-    const int nk = min(16, b - k0);
-    if (LI) {                               // 2. rows below the diagonal block: X = A21 inv(L11)^T, one 16 x 16 tile (4 MFMAs) per 16 rows
-      const int r0b = k0 + 16;
-      const int mt = r0b < b ? (b - r0b + 15) >> 4 : 0;
-      for (int tt = wv; tt < mt; tt += POTRF_NT / 64) {
-        const int i0 = r0b + 16 * tt;
-        const int ra = i0 + fi < b ? tri(i0 + fi, k0 + fk) : -1;
-        double av[4], bv[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { av[ks] = ra >= 0 ? T[ra + 4 * ks] : 0.0; bv[ks] = Minv[fi * 17 + 4 * ks + fk]; }   // A[i][k] = A21[i0 + fi][k0 + 4 ks + fk]; B[k][c] = M[c = fi][4 ks + fk]
-        d4 X = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) X = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], X, 0, 0, 0);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // every lane has read its A21 entries before the tile is overwritten
-#pragma unroll
-        for (int v = 0; v < 4; ++v) { const int i = i0 + fk + 4 * v; if (i < b) T[tri(i, k0 + fi)] = X[v]; }
-      }
-    } else {                                // 2. rows below the diagonal block: x L11^T = a
-      const int i = k0 + nk + tid;
-      if (i < b) {
-        double x[16];
-        double* row = &T[tri(i, k0)];
-#pragma unroll
-        for (int cc = 0; cc < 16; ++cc) x[cc] = cc < nk ? row[cc] : 0.0;
-#pragma unroll
-        for (int cc = 0; cc < 16; ++cc) {
-          if (cc < nk) {
-            const double* lrow = &T[tri(k0 + cc, k0)];
-            double sacc = x[cc];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) if (q < cc) sacc -= x[q] * lrow[q];
-            x[cc] = sacc * dinv[cc];
-          }
-        }
-#pragma unroll
-        for (int cc = 0; cc < 16; ++cc) if (cc < nk) row[cc] = x[cc];
-      }
-    }
-    __syncthreads();
-    const int r0 = k0 + 16;
-    if (r0 < b) {                           // 3. trailing update on the matrix cores
-      const int m = (b - r0 + 15) >> 4, ntile = (m * (m + 1)) >> 1;
-      // tiles (ti, tj <= ti) of the trailing lower triangle as one flat list t = ti (ti + 1) / 2 + tj, dealt round-robin to the wavefronts (rows dealt
-      // whole gave the first wavefront 21 of 66 tiles); two tiles in flight so that their MFMA chains interleave
-      constexpr int NW = POTRF_NT / 64 - 1;   // wavefronts 1 .. 7 share the tiles 1 .. ntile - 1; wavefront 0: tile 0 (the next diagonal block), then its Cholesky
-      auto decode = [](int t, int& ti, int& tj) { ti = 0; while (((ti + 1) * (ti + 2)) >> 1 <= t) ++ti; tj = t - ((ti * (ti + 1)) >> 1); };
-      for (int t0 = wv == 0 ? 0 : wv; t0 < (wv == 0 ? 1 : ntile); t0 += 2 * NW) {
-        const bool two = wv != 0 && t0 + NW < ntile;
-        int ti0, tj0, ti1 = 0, tj1 = 0;
-        decode(t0, ti0, tj0);
-        if (two) decode(t0 + NW, ti1, tj1);
-        const int ia = r0 + 16 * ti0, ja = r0 + 16 * tj0, ib = r0 + 16 * ti1, jb = r0 + 16 * tj1;
-        const int aA = ia + fi < b ? tri(ia + fi, k0 + fk) : -1, bA = ja + fi < b ? tri(ja + fi, k0 + fk) : -1;
-        const int aB = (two && ib + fi < b) ? tri(ib + fi, k0 + fk) : -1, bB = (two && jb + fi < b) ? tri(jb + fi, k0 + fk) : -1;
-        double avA[4], bvA[4], avB[4], bvB[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { avA[ks] = aA >= 0 ? -T[aA + 4 * ks] : 0.0; bvA[ks] = bA >= 0 ? T[bA + 4 * ks] : 0.0; avB[ks] = aB >= 0 ? -T[aB + 4 * ks] : 0.0; bvB[ks] = bB >= 0 ? T[bB + 4 * ks] : 0.0; }
-        d4 CA, CB; int xA[4], xB[4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int ciA = ia + fk + 4 * v, cjA = ja + fi, ciB = ib + fk + 4 * v, cjB = jb + fi;
-          xA[v] = (ciA < b && cjA <= ciA) ? tri(ciA, cjA) : -1;
-          xB[v] = (two && ciB < b && cjB <= ciB) ? tri(ciB, cjB) : -1;
-          CA[v] = xA[v] >= 0 ? T[xA[v]] : 0.0; CB[v] = xB[v] >= 0 ? T[xB[v]] : 0.0;
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          CA = __builtin_amdgcn_mfma_f64_16x16x4f64(avA[ks], bvA[ks], CA, 0, 0, 0);
-          if (two) CB = __builtin_amdgcn_mfma_f64_16x16x4f64(avB[ks], bvB[ks], CB, 0, 0, 0);
-        }
-#pragma unroll
-        for (int v = 0; v < 4; ++v) { if (xA[v] >= 0) T[xA[v]] = CA[v]; if (xB[v] >= 0) T[xB[v]] = CB[v]; }
-      }
-      if (wv == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        diag_block(r0);
-      }
-    }
-    __syncthreads();
-  }
-  for (int c0 = 0; c0 < b; c0 += 8) {       // write-back, 8 LDS reads in flight per thread
-    double v[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { const int cc = c0 + q, r = cc + tid; v[q] = (cc < b && r < b) ? T[tri(r, cc)] : 0.0; }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { const int cc = c0 + q, r = cc + tid; if (cc < b && r < b) D[(size_t)cc * b + r] = v[q]; }
-  }
-  if (tid == 0) info[blockIdx.x] = bad;
 }
 // ---------------------------------------------------------------------------------------------------------
 // Register-resident batched Cholesky (the default for b <= 208).  The LDS-resident kernel above spends its time on LDS round trips of the trailing
@@ -841,30 +686,21 @@ __global__ __launch_bounds__(64 * POTRF_REG_NW) void k_potrf_reg(double* Dm, int
   if (lane == 0 && blockIdx.x == 0) printf("PKT b %d wv %d: load %lld factor %lld syncA %lld panel %lld syncB %lld trail %lld store %lld chol16 %lld total %lld\n", b, wv, pkt_[0], pkt_[1], pkt_[2], pkt_[3], pkt_[4], pkt_[5], pkt_[6], pkt_[7], pkt_now() - pkts_);
 #endif
 }
-static bool potrf_reg_ok(const lvx_ctx* c, int b) { return c->sw.bcr_rocsolver_potrf == 0 && c->sw.bcr_potrf_lds == 0 && b <= 208; }
+static bool potrf_reg_ok(const lvx_ctx*, int b) { return b <= 208; }
 template <int NT> static void launch_potrf_reg(lvx_ctx* c, double* D, int b, long long strideD, int* info, int batch, double* LI, long long strideLI) {
   hipLaunchKernelGGL(k_potrf_reg<NT>, dim3((unsigned)batch), dim3(64 * POTRF_REG_NW), 0, c->stream, D, b, strideD, info, LI, strideLI);
 }
-// potrf of `batch` blocks: own kernel when the triangle fits into LDS, rocSOLVER otherwise (or with LVX_BCR_ROCSOLVER_POTRF)
-static size_t potrf_lds_bytes(int b) { return ((size_t)b * (b + 1) / 2 + 16 + 16 * 17) * 8; }
-// the own Cholesky kernel serves this block size (and so produces the diagonal-triangle inverses the triangular solves use)
-static bool potrf_own(const lvx_ctx* c, int b) { return potrf_reg_ok(c, b) || (c->sw.bcr_rocsolver_potrf == 0 && potrf_lds_bytes(b) <= 159 * 1024); }
+// potrf of `batch` blocks: the register-resident kernel up to b = 208 (it also leaves the inverses of the diagonal triangles for the solves), rocSOLVER beyond
+static bool potrf_own(const lvx_ctx* c, int b) { return potrf_reg_ok(c, b); }
 static int potrf_batched(lvx_ctx* c, rocblas_handle h, double* D, int b, long long strideD, int* info, int batch, double* LI, long long strideLI) {
-  const size_t lds = potrf_lds_bytes(b);
   if (!potrf_own(c, b)) {
     LVX_BLAS(c, rocsolver_dpotrf_strided_batched(h, rocblas_fill_lower, b, D, b, (rocblas_stride)strideD, info, batch));
     return LVX_OK;
   }
-  if (potrf_reg_ok(c, b)) {
-    if (b <= 64) launch_potrf_reg<4>(c, D, b, strideD, info, batch, LI, strideLI);
-    else if (b <= 128) launch_potrf_reg<8>(c, D, b, strideD, info, batch, LI, strideLI);
-    else if (b <= 192) launch_potrf_reg<12>(c, D, b, strideD, info, batch, LI, strideLI);
-    else launch_potrf_reg<13>(c, D, b, strideD, info, batch, LI, strideLI);
-    LVX_HIP(c, hipGetLastError());
-    return LVX_OK;
-  }
-  LVX_HIP(c, hipFuncSetAttribute((const void*)k_potrf_batched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_potrf_batched, dim3((unsigned)batch), dim3(POTRF_NT), lds, c->stream, D, b, strideD, info, LI, strideLI);
+  if (b <= 64) launch_potrf_reg<4>(c, D, b, strideD, info, batch, LI, strideLI);
+  else if (b <= 128) launch_potrf_reg<8>(c, D, b, strideD, info, batch, LI, strideLI);
+  else if (b <= 192) launch_potrf_reg<12>(c, D, b, strideD, info, batch, LI, strideLI);
+  else launch_potrf_reg<13>(c, D, b, strideD, info, batch, LI, strideLI);
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
 }
@@ -1134,7 +970,7 @@ __global__ __launch_bounds__(64 * SCHUR_NW) void k_bcr_schur(SchurArgs a) {
   else schur_body<NTB, 2, ZT, SPLIT>(a, lds);
 }
 // LVX_BCR_OWN_SCHUR: 1 own kernel on every level, 0 rocBLAS on every level, default (-1): own kernel
-static bool schur_own(const lvx_ctx* c, int b, int nrhs) { return c->sw.bcr_own_schur != 0 && !c->sw.bcr_syrk && b <= 208 && nrhs <= 64; }
+static bool schur_own(const lvx_ctx*, int b, int nrhs) { return b <= 208 && nrhs <= 64; }
 template <int NTB, int ZT, int SPLIT> static int launch_schur_s(lvx_ctx* c, const SchurArgs& a) {
   constexpr int PR = 16 * NTB, PSA = PR | 1;
   const size_t lds = (size_t)2 * (16 * PSA + 16 * PSA) * 8;     // the coupling product is the largest: row panel + a full column panel, two buffers
@@ -1168,7 +1004,7 @@ int bcr_plan(lvx_ctx* c) {
   if ((rc = dev_alloc(c, c->d_bcrD, guard * (size_t)nblk * bb * 8))) return rc;       // diagonal blocks -> Cholesky factors C_j
   if ((rc = dev_alloc(c, c->d_bcrG, guard * (size_t)2 * nblk * bb * 8))) return rc;   // couplings per level -> X+ (even slots) / Y (odd slots)
   if ((rc = dev_alloc(c, c->d_bcrInfo, guard * (size_t)(2 * nblk + 8) * 4))) return rc;
-  c->bcr_linv = potrf_own(c, b) && b <= 208 && !c->sw.bcr_no_dinv;   // inverses of the factors' 16 x 16 diagonal triangles: [nblk][ceil(b / 16)][16][16]
+  c->bcr_linv = potrf_own(c, b) && b <= 208;   // inverses of the factors' 16 x 16 diagonal triangles: [nblk][ceil(b / 16)][16][16]
   if (c->bcr_linv && (rc = dev_alloc(c, c->d_bcrLinv, (size_t)nblk * ((b + 15) / 16) * 256 * 8))) return rc;
   // couplings of the levels above 0 that involve a padding block are never computed (level_batch) and must read as zero
   LVX_HIP(c, hipMemsetAsync(c->d_bcrG.p, 0, (size_t)2 * nblk * bb * 8, c->stream));
@@ -1205,7 +1041,6 @@ int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_ra
   const double one = 1.0, mone = -1.0, zero = 0.0;
   int L = 0; while ((1 << L) < nblk) ++L;
   int info_pos = 0;
-  const bool use_gemm = !c->sw.bcr_syrk;
   for (int l = 0; l < L; ++l) {
     const int s = 1 << l, n2 = level_batch(nblk, c->bcr_nreal, l);
     if (n2 <= 0) continue;
@@ -1233,12 +1068,10 @@ int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_ra
     }
     // D_{j+s} -= X+ X+^T
     // (full GEMM instead of SYRK: rocBLAS' batched SYRK runs as many small launches; the upper triangle of D is never read)
-    if (use_gemm) LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, b, b, b, &mone, Gl, b, sG, Gl, b, sG, &one, Dr, b, sD, n2));
-    else LVX_BLAS(c, rocblas_dsyrk_strided_batched(h, rocblas_fill_lower, rocblas_operation_none, b, b, &mone, Gl, b, sG, &one, Dr, b, sD, n2));
+    LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, b, b, b, &mone, Gl, b, sG, Gl, b, sG, &one, Dr, b, sD, n2));
     if (n2 > 1) {
       // D_{j-s} -= Y^T Y   (left neighbour of eliminated k is the right neighbour of eliminated k-1)
-      if (use_gemm) LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, b, b, &mone, Gl + bb, b, sG, Gl + bb, b, sG, &one, Dr, b, sD, n2 - 1));
-      else LVX_BLAS(c, rocblas_dsyrk_strided_batched(h, rocblas_fill_lower, rocblas_operation_transpose, b, b, &mone, Gl + bb, b, sG, &one, Dr, b, sD, n2 - 1));
+      LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, b, b, &mone, Gl + bb, b, sG, Gl + bb, b, sG, &one, Dr, b, sD, n2 - 1));
       // next level's coupling A_{j+s,j-s} = -X+_k Y_k
       LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, b, b, &mone, Gl + 2 * bb, b, sG, Gl + bb, b, sG, &zero, Gn, b, (rocblas_stride)bb, n2 - 1));
     }
@@ -1297,7 +1130,7 @@ int bcr_backward(lvx_ctx* c, double* Zy, double* Zx, int ldz, int nrhs) {
   const double one = 1.0, mone = -1.0;
   int L = 0; while ((1 << L) < nblk) ++L;
   const size_t lds_fused = ((size_t)b * (b + 1) / 2 + 3 * (size_t)b + 16 + 16 * 17) * 8;
-  const bool fused = nrhs == 1 && LI && lds_fused <= 160 * 1024 && !c->sw.bcr_no_fused_back;
+  const bool fused = nrhs == 1 && LI && lds_fused <= 160 * 1024;
   if (fused) LVX_HIP(c, hipFuncSetAttribute((const void*)k_bcr_back_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fused));
   if (fused) {   // the last block of the chain: the same kernel without neighbours (the 64-vector streaming solve took 63 us for this one vector)
     hipLaunchKernelGGL(k_bcr_back_level, dim3(1), dim3(BACK_NT), lds_fused, c->stream, (const double*)(D + (size_t)(nblk - 1) * bb), 0ll, LI + (size_t)(nblk - 1) * liS, 0ll, (const double*)nullptr, 0ll,

@@ -60,9 +60,7 @@ struct DevBuf {
 // Experiment / debug switches: read ONCE from the environment (LVX_<NAME>) when the context is created and changed afterwards only
 // through lvx_set_switch — the evaluation path never calls getenv.
 struct Switches {
-  int force_legacy = 0, imu_legacy = 0, reproj_legacy = 0, serial = 0, imu_rot = 0, sched = 2, imu_two_streams = 0, occ = 0, jac_late = 0, fold_one = 0, fold_inline = 0,
-      no_graph = 0, sync_nofence = 0, chunk_r = 0, chunk_r_imu = 0, chunk_r_rep = 0, chunk_rows = 0, rep_rows = 0, solver_seq = 0, solver_timing = 0,
-      bcr_rocsolver_potrf = 0, bcr_syrk = 0, bcr_no_dinv = 0, bcr_no_fused_back = 0, bcr_potrf_lds = 0, bcr_own_schur = -1, bcr_trsm_stream = 0, bcr_trsm_nw = 0, tau_legacy = 0, deterministic = 0, clear_all = 0, cross_dbg = 0, lm_schur_single = 0, imu_split = 0, ref_side = -1;
+  int force_legacy = 0, serial = 0, no_graph = 0, deterministic = 0, clear_all = 0, solver_seq = 0, solver_timing = 0, chunk_r = 0, chunk_r_imu = 0, chunk_r_rep = 0, chunk_rows = 0, rep_rows = 0;
 };
 struct SwitchName { const char* name; int Switches::*field; bool relayout; };
 const SwitchName* switch_table(int* count);

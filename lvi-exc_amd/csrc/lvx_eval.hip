@@ -385,17 +385,6 @@ struct GyroAcc {
   __device__ static int klv(int c) { return 6 * (c / 3) + 3 + c % 3; }
   __device__ static int gcol(int g, int N, int nt) { return 6 * N + 5 + g; }
 };
-struct AccelAcc {
-  enum { PMAJ = 1 };
-  enum { NK = 24, NG = 5, NR = 3, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 16, SKIP_GG = 0, SECONDARY = 0, LB = 64, NCP = 29, USE_PRE = 1, OCC = 1 };
-  __device__ static constexpr int jm(int c) { return c; }
-  int n; const double* t; const double* m3; const int* perm; double weight, huber;
-  __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared*, int si, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
-    return accel_residual<true, true>(sp, cal.imu, t[si], load_v3(m3 + 3 * (size_t)si), weight, &key, r, J, aux.pw);
-  }
-  __device__ static int klv(int c) { return c; }
-  __device__ static int gcol(int g, int N, int nt) { return 6 * N + g; }
-};
 // TAU (free LiDAR time offset, the reference's opt_time_offset_ stages: trajectory_manager_lvi.cpp:159-165, sensors.h:70-85): one more global column, d r / d tau_L =
 // g_p (v_k - v_0) + g_xi0 w_0 + g_xik w_k — the pose gradients the row already has, contracted with the spline's velocity and body angular velocity at both poses —
 // and padded spans through the generic segment branch.  The locked instantiation is unchanged.
@@ -486,7 +475,7 @@ struct RepJac { const double* J; const double* r; const int* k; int n; };   // k
 // TAU: the camera time offset is free — one more global column (the row's column 55, tangent 6 N + 21) rides with the camera block
 template <int SIDE, bool TAU = false> struct RepSideAcc {   // SIDE 0: the reference view's pose, 1: the observation's
   enum { PMAJ = 1 };
-  enum { NK = 24, NG = 6 + (TAU ? 1 : 0), NR = 2, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 16, SKIP_GG = SIDE, SECONDARY = 1, LB = 16, NCP = 31 + (TAU ? 1 : 0), USE_PRE = 0, FTAB = 0, OCC = 1 };
+  enum { NK = 24, NG = 6 + (TAU ? 1 : 0), NR = 2, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 16, SKIP_GG = SIDE, SECONDARY = 1, LB = 16, NCP = 31 + (TAU ? 1 : 0), USE_PRE = 0, OCC = 1 };
   __device__ static constexpr int jm(int c) { return c; }   // [knots of this side | camera]
   static constexpr int RJ = REP_NC + (TAU ? 1 : 0);
   int n; RepJac jac;
@@ -551,7 +540,7 @@ __global__ __launch_bounds__(64) void k_reproj_jac(ReprojFamT<TAU> fam, DevCommo
 // LDS panels; T = J_ref^T J_obs accumulates in 3 x 3 MFMA tiles over the whole group and leaves with one atomic per non-zero entry.
 // The landmark's own row (rho x everything, 56 entries per block) is formed from the same registers with one lane exchange.
 typedef double d4 __attribute__((ext_vector_type(4)));
-struct RepCross { RepJac jac; const int* lm; const int* goff; const int* gw; int ng; int dbg; double* T; const int* det_list; };   // det_list: deterministic mode — block b works on group det_list[b] alone   // T[i][56]: the landmark-row products of block i (k_reproj_lmrows)   // gw[g] = w0, gw[ng + g] = w1
+struct RepCross { RepJac jac; const int* lm; const int* goff; const int* gw; int ng; double* T; const int* det_list; };   // det_list: deterministic mode — block b works on group det_list[b] alone   // T[i][56]: the landmark-row products of block i (k_reproj_lmrows)   // gw[g] = w0, gw[ng + g] = w1
 // TAU (free camera time offset): rows of RJ = 56 entries, landmark records of RW = 57 (rho x tau last).
 // STRAYS.  The groups are fixed at layout time from the view times at tau = 0; with a non-zero offset (free, or locked at a non-zero value) a view within |tau| of a knot
 // lands in the neighbouring interval and — one row in ~80 at the 1 ms bound — outside its 4-interval window.  Such a block stays out of the group's panels and adds
@@ -621,7 +610,7 @@ __global__ __launch_bounds__(256) void k_reproj_cross(RepCross rc, DevCommon cm)
       // the landmark's row: rho x [ref knots | obs knots | camera | rho | gradient] = 56 products per block.  Every lane forms those of its 12
       // knot columns (summed over the two residual rows: lanes part and part ^ 2), three spare lanes the rest; the 8 x 56 values pass through
       // LDS and leave as one contiguous 448-byte record per block — k_reproj_lmrows sums a landmark's records into its row without atomics
-      if (!(rc.dbg & 1)) {
+      {
         double t[12];
 #pragma unroll
         for (int c = 0; c < 12; ++c) { t[c] = jr * v[c]; t[c] += __shfl_xor(t[c], 2); }
@@ -662,7 +651,7 @@ __global__ __launch_bounds__(256) void k_reproj_cross(RepCross rc, DevCommon cm)
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          if (!(rc.dbg & 2)) for (int e2 = lane; e2 < 576; e2 += 64) {
+          for (int e2 = lane; e2 < 576; e2 += 64) {
             const int x = e2 / 24, y = e2 % 24;
             const double val = sbuf[wv][0][x] * sbuf[wv][0][24 + y] + sbuf[wv][1][x] * sbuf[wv][1][24 + y];
             if (val == 0.0) continue;
@@ -679,7 +668,6 @@ __global__ __launch_bounds__(256) void k_reproj_cross(RepCross rc, DevCommon cm)
     }
     // T[x][y], x in the reference window, y in the observation window: one atomic per non-zero entry.  The same variable can sit in both
     // windows (views closer than 7 knots): both orders of a pair land on the same stored entry, the diagonal takes both.
-    if (rc.dbg & 2) continue;
     int pcol[3], prow[12];
 #pragma unroll
     for (int cj = 0; cj < 3; ++cj) { const int y = cj * 16 + (lane & 15); pcol[cj] = y < 42 ? cm.ord[24 * w1 + y] : LVX_DEAD; }
@@ -768,11 +756,6 @@ struct NoRow {};
 template <class F, class = void> struct RowOf { using type = NoRow; static constexpr bool prefetch = false; };
 template <class F> struct RowOf<F, std::void_t<typename F::Row>> { using type = typename F::Row; static constexpr bool prefetch = true; };
 
-// F::FTAB: the end-of-window scatter of the accumulator tiles reads its LDS targets from a per-workgroup table instead of recomputing
-// the column classes (measured: 3 % faster for the reprojection observation pass, slower for the LiDAR and IMU families — LDS-bound)
-template <class F, class = void> struct FlushTab { static constexpr bool on = false; };
-template <class F> struct FlushTab<F, std::enable_if_t<(F::FTAB > 0)>> { static constexpr bool on = true; };
-
 // F::PMAJ (families with WS == 1: every row of a window has the same local columns, no shift): the wavefront writes the rows of GL lanes into its
 // panel ONCE and then walks the windows inside the panel — a window is the set of panel rows whose lanes share a knot interval; its k-steps
 // run over that row span and mask the rows of other windows.  With the window-major loop a panel held one window (8 IMU samples: 8 of 64
@@ -793,7 +776,7 @@ template <class F> struct MfmaGeom {
 template <class F> size_t mfma_lds_bytes(int cr) {
   const int LV = (cr + 5) * 6;
   return (size_t)(LV * ACC_BW + F::NG * LV + F::NG * F::NG + LV + F::NG + 4 * MfmaGeom<F>::PR * MfmaGeom<F>::LDP) * 8 + (F::USE_PRE ? (size_t)(cr + 4) * sizeof(So3Pre) : 0) +
-         (size_t)(LV + F::NG + (FlushTab<F>::on ? MfmaGeom<F>::NTP * 256 : 0)) * 4 + 64;
+         (size_t)(LV + F::NG) * 4 + 64;
 }
 
 // CR = knot intervals per workgroup, chosen per problem by the host (pick_chunk) so that the workgroup count fills whole rounds of the CUs
@@ -813,7 +796,6 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
   So3Pre* pre_tab = (So3Pre*)(panels + 4 * PR * LDP); // [CR + 4] control-point pairs (k_lo + e, k_lo + e + 1), families with USE_PRE
   int* kpos = (int*)(pre_tab + (F::USE_PRE ? CR + 4 : 0));   // [ACC_LV]
   int* gpos = kpos + ACC_LV;                          // [NG]
-  int* ftab = gpos + NG;              // [NTP * 4][64]: where accumulator register (tile pair, v) of each lane goes at the end of a window
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int ch = det_list ? det_list[blockIdx.x] : blockIdx.x;   // deterministic mode: the chunks of one colour (disjoint knot ranges), one wavefront each
   const int nwv = det_list ? 1 : 4;
@@ -832,30 +814,6 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
   for (int e = tid; e < ACC_LV * ACC_BW + NG * ACC_LV + NG * NG + ACC_LV + NG + 4 * PR * LDP; e += 256) sm[e] = 0.0;
   for (int e = tid; e < ACC_LV; e += 256) { const int k = k_lo + e / 6; kpos[e] = (k >= 0 && k < cm.N) ? cm.ord[6 * k + e % 6] : LVX_DEAD; }
   if (tid < NG) gpos[tid] = cm.ord[F::gcol(tid, cm.N, nt)];
-  if constexpr (FlushTab<F>::on) {
-    // window flush table: entry = LDS index (doubles, relative to sm) | multiplier of the window base (0: none, 1: wb, 2: wb * ACC_BW) << 16 |
-    // largest accumulator row touched (relative to wb) << 18, or -1 (lower triangle, padding, blocks assembled elsewhere)
-    auto cls0 = [](int lc) { return lc < NKL ? 6 * (lc / KPK) + F::LVO + lc % KPK : (lc < NKL + NG ? -1 - (lc - NKL) : (lc == NKL + NG ? -100 : -200)); };
-    for (int e = tid; e < G::NTP * 256; e += 256) {
-      const int l = e & 63, v = (e >> 6) & 3, tp = e >> 8;
-      int ci = 0, cj = 0;
-      { int t = 0; for (int a = 0; a < NT; ++a) for (int b = a; b < NT; ++b, ++t) if (t == tp) { ci = a; cj = b; } }
-      const int row = ci * 16 + (l >> 4) + 4 * v, col = cj * 16 + (l & 15);
-      int ent = -1;
-      if (!(ci == cj && col < row)) {
-        const int ra = cls0(row), cb = cls0(col);
-        if (ra >= 0) {
-          if (cb >= 0) { const int d = cb - ra; if (d >= 0 && d < ACC_BW) ent = ((int)(acc_band - sm) + ra * ACC_BW + d) | (2 << 16) | (cb << 18); }
-          else if (cb > -100) ent = ((int)(acc_bd - sm) + (-1 - cb) * ACC_LV + ra) | (1 << 16) | (ra << 18);
-          else if (cb == -100) ent = ((int)(acc_gk - sm) + ra) | (1 << 16) | (ra << 18);
-        } else if (ra > -100 && !F::SKIP_GG) {
-          if (cb > -100 && cb < 0) ent = (int)(acc_gg - sm) + (-1 - ra) * NG + (-1 - cb);
-          else if (cb == -100) ent = (int)(acc_gG - sm) + (-1 - ra);
-        }
-      }
-      ftab[e] = ent;
-    }
-  }
   const SplineRef sp{cm.t0, cm.dt, cm.N, cm.state, cm.state + 3 * (size_t)cm.N};
   if (F::USE_PRE && tid < CR + 4) {   // this chunk's slice of the pass's control-point-pair table
     const int ka = k_lo + tid;
@@ -1087,19 +1045,7 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
         KT(3)
       }
       // window accumulators -> workgroup accumulators (LDS atomics; other waves work on overlapping windows)
-      if constexpr (FlushTab<F>::on) {
-        const int wbB = wb * ACC_BW;
-#pragma unroll
-        for (int t = 0; t < G::NTP; ++t)
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int te = ftab[(t * 4 + v) * 64 + lane];
-            const double val = D[t][v];
-            if (te < 0 || val == 0.0 || wb + (te >> 18) >= ACC_LV) continue;
-            const int m = (te >> 16) & 3;
-            atomicAdd(&sm[(te & 0xffff) + (m == 2 ? wbB : (m == 1 ? wb : 0))], val);
-          }
-      } else {
+      {
       int t = 0;
 #pragma unroll
       for (int ci = 0; ci < NT; ++ci)
@@ -1690,35 +1636,14 @@ __device__ __forceinline__ void fold_replicas_block(const DevCommon& cm, int blk
   if (i == 0) cm.cost[0] = strided_sum(cm.cost, 1, cm.nrep);
 }
 __global__ void k_fold_replicas(DevCommon cm) { fold_replicas_block(cm, (int)blockIdx.x); }
-// The whole fold in one launch (three kernels on two streams cost a fork and a join on the pass's critical path): blocks [0, nrep) sum the
-// replicas — the last of them to finish (device-scope fence + counter in err[1], cleared with the error flags) then folds the dense block —
-// and the remaining blocks fold the border rows (both sets in the same thread: they may add into the same hub rows).
-__global__ __launch_bounds__(256) void k_fold_all(DevCommon cm, int nrep, int sets) {
-  const int b = blockIdx.x;
-  if (b >= nrep) { if (sets & 1) fold_border_rows_block(cm, 0, b - nrep, true); if (sets & 2) fold_border_rows_block(cm, 1, b - nrep, !(sets & 1)); return; }
-  fold_replicas_block(cm, b);
-  __shared__ int last;
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) last = atomicAdd(&cm.err[1], 1) == nrep - 1;
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
-  fold_border_dense_block(cm);
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
 const SwitchName* switch_table(int* count) {
   static const SwitchName tab[] = {
-    {"FORCE_LEGACY", &Switches::force_legacy, false}, {"IMU_LEGACY", &Switches::imu_legacy, false}, {"REPROJ_LEGACY", &Switches::reproj_legacy, false},
-    {"SERIAL", &Switches::serial, false}, {"IMU_ROT", &Switches::imu_rot, false}, {"SCHED", &Switches::sched, false}, {"IMU_TWO_STREAMS", &Switches::imu_two_streams, false}, {"OCC", &Switches::occ, false},
-    {"JAC_LATE", &Switches::jac_late, false}, {"FOLD_ONE", &Switches::fold_one, false}, {"FOLD_INLINE", &Switches::fold_inline, false}, {"NO_GRAPH", &Switches::no_graph, false},
-    {"SYNC_NOFENCE", &Switches::sync_nofence, false}, {"CHUNK_R", &Switches::chunk_r, true}, {"CHUNK_R_IMU", &Switches::chunk_r_imu, true},
-    {"CHUNK_R_REP", &Switches::chunk_r_rep, true}, {"CHUNK_ROWS", &Switches::chunk_rows, true}, {"REP_ROWS", &Switches::rep_rows, true},
-    {"SOLVER_SEQ", &Switches::solver_seq, false}, {"SOLVER_TIMING", &Switches::solver_timing, false}, {"BCR_ROCSOLVER_POTRF", &Switches::bcr_rocsolver_potrf, false},
-    {"BCR_SYRK", &Switches::bcr_syrk, false}, {"BCR_NO_DINV", &Switches::bcr_no_dinv, false}, {"BCR_NO_FUSED_BACK", &Switches::bcr_no_fused_back, false}, {"BCR_POTRF_LDS", &Switches::bcr_potrf_lds, false}, {"BCR_OWN_SCHUR", &Switches::bcr_own_schur, false}, {"BCR_TRSM_STREAM", &Switches::bcr_trsm_stream, false}, {"BCR_TRSM_NW", &Switches::bcr_trsm_nw, false}, {"TAU_LEGACY", &Switches::tau_legacy, false}, {"DETERMINISTIC", &Switches::deterministic, true}, {"CLEAR_ALL", &Switches::clear_all, false}, {"CROSS_DBG", &Switches::cross_dbg, false}, {"LM_SCHUR_SINGLE", &Switches::lm_schur_single, false}, {"IMU_SPLIT", &Switches::imu_split, false}, {"REF_SIDE", &Switches::ref_side, false},
+    {"FORCE_LEGACY", &Switches::force_legacy, false}, {"SERIAL", &Switches::serial, false}, {"NO_GRAPH", &Switches::no_graph, false}, {"DETERMINISTIC", &Switches::deterministic, true},
+    {"CLEAR_ALL", &Switches::clear_all, false}, {"SOLVER_SEQ", &Switches::solver_seq, false}, {"SOLVER_TIMING", &Switches::solver_timing, false},
+    {"CHUNK_R", &Switches::chunk_r, true}, {"CHUNK_R_IMU", &Switches::chunk_r_imu, true}, {"CHUNK_R_REP", &Switches::chunk_r_rep, true}, {"CHUNK_ROWS", &Switches::chunk_rows, true}, {"REP_ROWS", &Switches::rep_rows, true},
   };
   *count = (int)(sizeof(tab) / sizeof(tab[0]));
   return tab;
@@ -2279,8 +2204,7 @@ DevCommon make_common(lvx_ctx* ctx, const double* state_d, uint32_t what) {
   return cm;
 }
 
-// events that order kernels of this context's streams.  LVX_SYNC_NOFENCE=1 drops their system-scope fence (-2 % per pass; experimental)
-#define LVX_SYNC_EVENT_FLAGS(c) (hipEventDisableTiming | ((c)->sw.sync_nofence ? hipEventDisableSystemFence : 0u))
+#define LVX_SYNC_EVENT_FLAGS(c) hipEventDisableTiming   // events that order kernels of this context's streams
 static size_t next_event(lvx_ctx* c) {
   // timing only: no system-scope fence (cache writeback + invalidation) at every record
   if (c->ev_used == c->ev_pool.size()) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) return (size_t)-1; c->ev_pool.push_back(e); }
@@ -2378,14 +2302,14 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     int rc = LVX_OK;
     const bool fast = !ctx->force_legacy && !(what & LVX_EVAL_JACOBIAN) && !ctx->sw.force_legacy;
     // free time offsets need d pose / d t at both evaluations: one more global column in the fused LiDAR / camera-surfel kernels (SurfAccT<true>, CamSurfAccT<true>);
-    // reprojection with a free camera offset still takes the per-segment kernel (ReprojFamT<true>).  LVX_TAU_LEGACY=1: the per-segment TAU kernels for everything
+    // the reprojection path a time-offset column in its materialised rows; FORCE_LEGACY: the per-segment TAU kernels for everything
     const bool tauL = !(ctx->locks & LVX_LOCK_LIDAR_TAU), tauC = !(ctx->locks & LVX_LOCK_CAM_TAU);
-    const bool fast_surf = fast && !(tauL && ctx->sw.tau_legacy) && ctx->surf.n > 0, fast_cs = fast && !(tauC && ctx->sw.tau_legacy) && ctx->cs.n > 0;
+    const bool fast_surf = fast && ctx->surf.n > 0, fast_cs = fast && ctx->cs.n > 0;
     // the control-point-pair table and the shared t_map poses (one thread, ~25 us) depend on the state only: the first blocks of the clear kernel
     const int nblk_tab = fast ? (ctx->N + 255) / 256 : 0, npre = fast ? nblk_tab + ((fast_surf || fast_cs) ? 1 : 0) : 0;
     const lvx::Switches& sw = ctx->sw;
     const bool det = sw.deterministic != 0;   // fixed order of every addition: one stream, coloured launches, one wavefront per workgroup
-    const bool imu_fused_on = fast && !sw.imu_legacy && ctx->imu.n > 0 && !(ctx->locks & LVX_LOCK_R3) && !sw.imu_split && ctx->imu_nch > 0 && imu_fused_lds_bytes(ctx->imu_span) <= 160 * 1024;
+    const bool imu_fused_on = fast && ctx->imu.n > 0 && !(ctx->locks & LVX_LOCK_R3) && ctx->imu_nch > 0 && imu_fused_lds_bytes(ctx->imu_span) <= 160 * 1024;
     const bool imu_own = imu_fused_on && (what & LVX_EVAL_NORMAL_EQ) && ctx->nb > 0 && ctx->imu_owned_cols > 0 && !sw.clear_all;   // k_imu_own stores its band columns: they are not cleared
     {   // one launch clears every accumulator of the pass (cost, error flags, and for the normal equations band, gradient, border rows, dense border)
       ClearList cl{};
@@ -2416,7 +2340,7 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
           b0 = b1;
         }
         add(cm.C, (size_t)ctx->nrep * ctx->nbd_ext * ctx->nbd_ext * 8); add(cm.gc, (size_t)ctx->nrep * ctx->nbd_ext * 8);
-        const bool rep_fast = fast && !(tauC && ctx->sw.tau_legacy) && !ctx->sw.reproj_legacy && ctx->rep_groups > 0;   // k_reproj_lmrows stores whole rows: nothing to clear
+        const bool rep_fast = fast && ctx->rep_groups > 0;   // k_reproj_lmrows stores whole rows: nothing to clear
         if (ctx->L > 0 && ctx->rep.n > 0 && !(ctx->locks & LVX_LOCK_LANDMARKS) && !rep_fast) add(cm.lmH, (size_t)ctx->L * ctx->lm_ls * 8);
       }
       size_t total = 0; for (int i = 0; i < cl.n; ++i) total += cl.words[i];
@@ -2434,29 +2358,14 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
       ProfScope ps(ctx, LVX_FAM_GYRO, st);
       hipLaunchKernelGGL(k_imu_own, dim3(ctx->imu_wg), dim3(256), lds_, st, f, cm, (const int*)ctx->d_imu_chunk.p, ow, (long long)ctx->fam_row0[0], (long long)ctx->fam_row0[1], det ? 1 : 0, (const int*)ctx->d_imu_rtab.p);
     }
-    // fast path: LDS-accumulating kernels for the segment-structured families; legacy per-segment kernels for reprojection, the prior,
-    // the debug Jacobian, and as the exact fallback for the merged-hub-segment corner
-    // Streams.  A hand-over between streams costs 25-40 us inside the replayed graph (rocprofv3 timeline: clear -> hub, LiDAR -> second
-    // stage, last kernel -> fold each showed such a gap), so the critical chain  clear -> hub pose -> LiDAR kernels -> reprojection Jacobian
-    // -> observation pass -> fold  stays on the caller's stream and only the kernels that run NEXT to it (gyroscope, accelerometer,
-    // reference pass) fork off; they finish before the observation pass does, so the join is already satisfied when the chain gets there.
-    const bool staged = sw.sched == 2 && !sw.serial && !det;
-    hipStream_t s_imu = ctx->fam_stream[0], s_acc = ctx->fam_stream[1], s_surf = staged ? st : ctx->fam_stream[2], s_rep = staged ? st : ctx->fam_stream[3];
-    // one side stream (gyroscope, then accelerometer) next to the chain (Jacobian, observation pass, reference pass): both ends finish
-    // together and one fan-out / fan-in less than with a stream per IMU kernel (-1.5 % per pass); LVX_IMU_TWO_STREAMS=1 restores that
-    const bool one_side = !sw.imu_two_streams;
-    if (one_side) s_acc = s_imu;
-    if (sw.serial || det) s_imu = s_acc = s_surf = s_rep = st;   // profiling aid: solo kernel durations
-    const hipStream_t side[4] = {s_imu, s_acc, s_surf, s_rep};
-    auto first_use = [&](int k) { for (int j = 0; j < k; ++j) if (side[j] == side[k]) return false; return side[k] != st; };   // each side stream forks / joins once
-    // staged: the side stream's first operation is its wait for the LiDAR stage (ev_join[2]) — that is its fork; an event record on the
-    // chain costs a ~13 us bubble (barrier packet + system-scope fence), so no extra fork event there
-    if (!staged) {
-      LVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
-      for (int k = 0; k < 4; ++k) if (first_use(k)) LVX_HIP(ctx, hipStreamWaitEvent(side[k], ctx->ev_fork, 0));
-    }
-    const int occ_env = sw.occ;   // 0: the family's own choice (F::OCC wavefronts per SIMD)
-    const bool ref_side = sw.ref_side == 1 || (sw.ref_side < 0 && imu_fused_on);   // with the fused IMU kernel the side stream is the shorter chain: it takes the reference pass
+    // Schedule.  ONE chain on the caller's stream — clear -> fused IMU kernel (stores its band columns) -> prior -> LiDAR kernels -> reprojection Jacobian -> observation
+    // pass -> cross terms -> landmark rows -> fold — and ONE side stream that takes the reprojection reference pass (it only reads the materialised rows and adds
+    // atomically) behind the Jacobian kernel and joins in front of the fold.  A hand-over between streams costs 10-30 us on this stack, graph or no graph, so nothing
+    // else forks (everything concurrent, a stream per family, the staged two-chain schedule of rounds 1-3 were measured and dropped).  SERIAL and
+    // DETERMINISTIC keep everything on the chain.
+    const bool side_on = !sw.serial && !det;
+    hipStream_t s_side = side_on ? ctx->fam_stream[0] : st;
+    bool side_used = false;
   #define LVX_T2(...) __VA_ARGS__
   #define LVX_LAUNCH_MFMA1(FT, OCCV, fam_obj, chunk_slot, stream, row0v)                                                                        \
     do {                                                                                                                                     \
@@ -2472,191 +2381,131 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
                          ctx->chunk_r[chunk_slot], ctx->chunk_var[chunk_slot] ? ctx->n_chunk[chunk_slot] : 0, (const int*)nullptr);          \
     } while (0)
   #define LVX_LAUNCH_MFMA(FT, fam_obj, chunk_slot, stream, row0v)                                                                               \
-    do { if ((occ_env ? occ_env : (int)FT::OCC) == 1) LVX_LAUNCH_MFMA1(FT, 1, fam_obj, chunk_slot, stream, row0v); else LVX_LAUNCH_MFMA1(FT, 2, fam_obj, chunk_slot, stream, row0v); } while (0)
-    // launch order / overlap: the LiDAR kernels (VALU + MFMA heavy, one workgroup per CU) first and alone, then the IMU kernels and the
-    // reprojection passes next to each other.  Measured at config 4: the pass takes the same 1.55-1.6 ms with everything concurrent (the big
-    // kernels cannot share a CU and only slow each other down), staged like this, or serial (1.64 ms); staged, the dominant kernel's
-    // duration is its solo duration.  LVX_SCHED=0 restores "all concurrent".
-    const bool jac_early = !sw.jac_late;   // the (small, register-bound) reprojection Jacobian kernel runs next to the LiDAR kernels: -2.5 % per pass, surfel kernel unaffected
-    bool third_ref = false;
-    const int order[5] = {2, 4, 0, 1, 3};   // surfel, cam-surfel, imu, prior, reprojection
-    for (int ph = 0; ph < 5; ++ph) {
-      if (staged && ph == 2) {               // the other streams start when the LiDAR stream has drained
-        LVX_HIP(ctx, hipEventRecord(ctx->ev_join[2], s_surf));
-        LVX_HIP(ctx, hipStreamWaitEvent(s_imu, ctx->ev_join[2], 0)); LVX_HIP(ctx, hipStreamWaitEvent(s_acc, ctx->ev_join[2], 0));
-        if (!jac_early && s_rep != s_surf) LVX_HIP(ctx, hipStreamWaitEvent(s_rep, ctx->ev_join[2], 0));
+    do { if ((int)FT::OCC == 1) LVX_LAUNCH_MFMA1(FT, 1, fam_obj, chunk_slot, stream, row0v); else LVX_LAUNCH_MFMA1(FT, 2, fam_obj, chunk_slot, stream, row0v); } while (0)
+    // ---- IMU blocks when the fused kernel does not apply: Solve #0 (no R3 spline: gyroscope blocks only) on the MFMA path, everything else per segment ----
+    if (ctx->imu.n > 0 && !imu_fused_on) {
+      if (fast) {
+        GyroAcc g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
+        ProfScope ps(ctx, LVX_FAM_GYRO, st); LVX_LAUNCH_MFMA(GyroAcc, g, LVX_FAM_GYRO, st, ctx->fam_row0[0]);
+      } else {
+        GyroFam g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
+        ProfScope ps(ctx, LVX_FAM_GYRO, st);
+        hipLaunchKernelGGL((k_family<GyroFam, 1>), grid(g.n), dim3(64), 0, st, g, cm, (const uint16_t*)ctx->d_pairs[0].p, (long long)ctx->fam_row0[0]);
       }
-      switch (order[ph]) {
-      case 0: {
-        const bool imu_fast = fast && !sw.imu_legacy;
-        if (ctx->imu.n > 0) {
-          if (imu_fused_on) {   // launched behind the clear
-          } else if (imu_fast) {
-            GyroAcc g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
-            { ProfScope ps(ctx, LVX_FAM_GYRO, s_imu); LVX_LAUNCH_MFMA(GyroAcc, g, LVX_FAM_GYRO, s_imu, ctx->fam_row0[0]); }
-            if (!(ctx->locks & LVX_LOCK_R3)) {
-              AccelAcc a{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.huber /*w_acc*/, 0.0};
-              ProfScope ps(ctx, LVX_FAM_ACCEL, s_acc);
-              LVX_LAUNCH_MFMA(AccelAcc, a, LVX_FAM_GYRO, s_acc, ctx->fam_row0[1]);
-            }
-          } else {
-            GyroFam g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
-            { ProfScope ps(ctx, LVX_FAM_GYRO, s_imu);
-            hipLaunchKernelGGL((k_family<GyroFam, 1>), grid(g.n), dim3(64), 0, s_imu, g, cm, (const uint16_t*)ctx->d_pairs[0].p, (long long)ctx->fam_row0[0]); }
-            if (!(ctx->locks & LVX_LOCK_R3)) {
-              AccelFam a{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.huber /*w_acc*/, 0.0};
-              ProfScope ps(ctx, LVX_FAM_ACCEL, s_acc);
-              hipLaunchKernelGGL((k_family<AccelFam, LVX_PW>), grid(a.n), dim3(64 * LVX_PW), 0, s_acc, a, cm, (const uint16_t*)ctx->d_pairs[1].p, (long long)ctx->fam_row0[1]);
-            }
-          }
-        }
-      } break;
-      case 1: {
-        if (ctx->has_prior) {
-          DevBuf& pb = ctx->d_zero;   // identity permutation for the single prior block (zeroed by ensure_layout)
-          PriorFam p{1, ctx->prior_t, mkq(ctx->prior_q[0], ctx->prior_q[1], ctx->prior_q[2], ctx->prior_q[3]), (const int*)pb.p, ctx->prior_w, 0.0};
-          ProfScope ps(ctx, LVX_FAM_PRIOR, s_imu);
-          hipLaunchKernelGGL((k_family<PriorFam, 1>), dim3(1), dim3(64), 0, s_imu, p, cm, (const uint16_t*)ctx->d_pairs[2].p, (long long)ctx->fam_row0[2]);
-        }
-      } break;
-      case 2: {
-        if (ctx->surf.n > 0) {
-          ProfScope ps(ctx, LVX_FAM_SURFEL, s_surf);
-          if (tauL && fast_surf) {
-            SurfAccT<true> s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const double*)ctx->surf.d_b3.p, (const int*)ctx->surf.d_perm.p,
-                             ctx->t_map, ctx->surf.weight, ctx->surf.huber};
-            LVX_LAUNCH_MFMA(SurfAccT<true>, s, LVX_FAM_SURFEL, s_surf, ctx->fam_row0[3]);
-          } else if (tauL) {
-            SurfFamT<true> s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
-                             (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
-            hipLaunchKernelGGL((k_family<SurfFamT<true>, 1>), grid(s.n), dim3(64), 0, s_surf, s, cm, (const uint16_t*)ctx->d_pairs[3].p, (long long)ctx->fam_row0[3]);
-          } else if (fast_surf) {
-            SurfAcc s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const double*)ctx->surf.d_b3.p, (const int*)ctx->surf.d_perm.p,
-                      ctx->t_map, ctx->surf.weight, ctx->surf.huber};
-            LVX_LAUNCH_MFMA(SurfAcc, s, LVX_FAM_SURFEL, s_surf, ctx->fam_row0[3]);
-          } else {
-            SurfFam s{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p,
-                      (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
-            hipLaunchKernelGGL((k_family<SurfFam, 1>), grid(s.n), dim3(64), 0, s_surf, s, cm, (const uint16_t*)ctx->d_pairs[3].p, (long long)ctx->fam_row0[3]);
-          }
-        }
-      } break;
-      case 3: {
-        if (ctx->rep.n > 0) {
-          ReprojFam r{ctx->rep.n, (const int*)ctx->rep.d_id0.p, (const double*)ctx->rep.d_a3.p, (const double*)ctx->rep.d_t.p, (const int*)ctx->rep.d_perm.p,
-                      (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->rep.weight, ctx->rep.huber};
-          // the fused path (Jacobian rows materialised once, three MFMA assembly passes, landmark rows stored) for a locked AND for a free camera time offset
-          auto rep_fused = [&](auto TAUC) -> int {
-            constexpr bool T = decltype(TAUC)::value;
-            constexpr int RJ = REP_NC + (T ? 1 : 0);
-            double* Jb = (double*)ctx->d_repB[0].p; double* rb = Jb + (size_t)2 * RJ * r.n; int* kb = (int*)ctx->d_repB[1].p;
-            { ProfScope ps(ctx, LVX_KERNEL_REP_JAC, s_rep);
-              const ReprojFamT<T> rf{r.n, r.lm, r.uv, r.t0o, r.perm, r.lm_uv, r.lm_t0, r.weight, r.huber};
-              hipLaunchKernelGGL(k_reproj_jac<T>, grid(r.n), dim3(64), 0, s_rep, rf, cm, Jb, rb, kb, (long long)ctx->fam_row0[4]); }
-            if (staged && jac_early && s_rep != s_surf) LVX_HIP(ctx, hipStreamWaitEvent(s_rep, ctx->ev_join[2], 0));
-            if (what & LVX_EVAL_NORMAL_EQ) {
-              hipStream_t s_ref = (one_side && staged) ? s_rep : s_acc;
-              // LVX_REF_SIDE=1: the reference pass (it only reads the materialised rows) behind the IMU kernel on the side stream, the cross terms and the
-              // landmark rows stay on the chain
-              const hipStream_t s_refpass = (sw.ref_side == 2 && staged) ? ctx->fam_stream[1] : ((ref_side && staged && s_acc != s_rep) ? s_acc : s_ref);   // 2: a stream of its own (experiment)
-              third_ref = sw.ref_side == 2 && staged && s_refpass != s_acc;
-              if (s_ref != s_rep || s_refpass != s_rep) LVX_HIP(ctx, hipEventRecord(ctx->ev_jac, s_rep));   // an event record on the chain is a bubble: only when another stream waits for it
-              const RepJac jac{Jb, rb, kb, r.n};
-              RepSideAcc<1, T> ra{r.n, jac, 0.0};
-              { ProfScope ps(ctx, LVX_KERNEL_REP_OBS, s_rep); LVX_LAUNCH_MFMA1(LVX_T2(RepSideAcc<1, T>), 1, ra, LVX_FAM_REPROJ, s_rep, ctx->fam_row0[4]); }
-              // the other two passes only read the materialised rows: they can run next to the observation-side pass, behind the accelerometer kernel
-              RepSideAcc<0, T> rb2{r.n, jac, 0.0};
-              if (s_ref != s_rep) LVX_HIP(ctx, hipStreamWaitEvent(s_ref, ctx->ev_jac, 0));
-              if (s_refpass != s_ref) LVX_HIP(ctx, hipStreamWaitEvent(s_refpass, ctx->ev_jac, 0));
-              { ProfScope ps(ctx, LVX_KERNEL_REP_REF, s_refpass); LVX_LAUNCH_MFMA1(LVX_T2(RepSideAcc<0, T>), 1, rb2, LVX_FAM_PRIOR, s_refpass, ctx->fam_row0[4]); }
-              if (ctx->rep_groups > 0) {
-                const int* gt = (const int*)ctx->d_repB[2].p;
-                RepCross rx{jac, r.lm, gt, gt + ctx->rep_groups + 1, ctx->rep_groups, ctx->sw.cross_dbg, (double*)ctx->d_repT.p, nullptr};
-                { ProfScope ps(ctx, LVX_KERNEL_REP_CROSS, s_ref);
-                  if (det && ctx->det_cross_col.size() > 1) {
-                    for (size_t q = 0; q + 1 < ctx->det_cross_col.size(); ++q) {
-                      rx.det_list = (const int*)ctx->d_det_cross.p + ctx->det_cross_col[q];
-                      hipLaunchKernelGGL(k_reproj_cross<T>, dim3((unsigned)(ctx->det_cross_col[q + 1] - ctx->det_cross_col[q])), dim3(256), 0, s_ref, rx, cm);
-                    }
-                  } else
-                  hipLaunchKernelGGL(k_reproj_cross<T>, dim3((unsigned)std::min((ctx->rep_groups + 3) / 4, 256 * 8)), dim3(256), 0, s_ref, rx, cm); }
-                if (ctx->L > 0 && !(ctx->locks & LVX_LOCK_LANDMARKS)) {
-                  const int* lp = (const int*)ctx->d_repB[3].p;
-                  const RepLmRows lq{(const double*)ctx->d_repT.p, kb, r.n, lp, lp + ctx->L + 1, ctx->L};
-                  const size_t lds = (size_t)4 * ctx->lm_ls * 8;
-                  LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_reproj_lmrows<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                  ProfScope ps(ctx, LVX_KERNEL_REP_LMROWS, s_ref);
-                  hipLaunchKernelGGL(k_reproj_lmrows<T>, dim3((unsigned)((ctx->L + 3) / 4)), dim3(256), lds, s_ref, lq, cm);
-                }
-              }
-            }
-            return LVX_OK;
-          };
-          const bool rep_fused_on = fast && !sw.reproj_legacy && !(tauC && sw.tau_legacy);
-          if (rep_fused_on) {
-            const int rcf = tauC ? rep_fused(std::true_type{}) : rep_fused(std::false_type{});
-            if (rcf) return rcf;
-          } else if (tauC) {
-            ProfScope ps(ctx, LVX_FAM_REPROJ, s_rep);
-            ReprojFamT<true> rt{r.n, r.lm, r.uv, r.t0o, r.perm, r.lm_uv, r.lm_t0, r.weight, r.huber};
-            hipLaunchKernelGGL((k_family<ReprojFamT<true>, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, rt, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
-          } else {
-            ProfScope ps(ctx, LVX_FAM_REPROJ, s_rep);
-            hipLaunchKernelGGL((k_family<ReprojFam, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, s_rep, r, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
-          }
-        }
-      } break;
-      case 4: {
-        if (ctx->cs.n > 0) {
-          ProfScope ps(ctx, LVX_FAM_CAMSURF, s_surf);
-          if (tauC && fast_cs) {
-            CamSurfAccT<true> c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
-                                (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
-            LVX_LAUNCH_MFMA(CamSurfAccT<true>, c, LVX_FAM_CAMSURF, s_surf, ctx->fam_row0[5]);
-          } else if (tauC) {
-            CamSurfFamT<true> c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
-                                (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
-            hipLaunchKernelGGL((k_family<CamSurfFamT<true>, 1>), grid(c.n), dim3(64), 0, s_surf, c, cm, (const uint16_t*)ctx->d_pairs[5].p, (long long)ctx->fam_row0[5]);
-          } else if (fast_cs) {
-            CamSurfAcc c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
-                         (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
-            LVX_LAUNCH_MFMA(CamSurfAcc, c, LVX_FAM_CAMSURF, s_surf, ctx->fam_row0[5]);
-          } else {
-            CamSurfFam c{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p,
-                         (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
-            hipLaunchKernelGGL((k_family<CamSurfFam, 1>), grid(c.n), dim3(64), 0, s_surf, c, cm, (const uint16_t*)ctx->d_pairs[5].p, (long long)ctx->fam_row0[5]);
-          }
-        }
-      } break;
+      if (!(ctx->locks & LVX_LOCK_R3)) {
+        AccelFam a{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.huber /*w_acc*/, 0.0};
+        ProfScope ps(ctx, LVX_FAM_ACCEL, st);
+        hipLaunchKernelGGL((k_family<AccelFam, LVX_PW>), grid(a.n), dim3(64 * LVX_PW), 0, st, a, cm, (const uint16_t*)ctx->d_pairs[1].p, (long long)ctx->fam_row0[1]);
       }
     }
-    if (third_ref) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[1], ctx->fam_stream[1])); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[1], 0)); }
-    for (int k = 0; k < 4; ++k) if (first_use(k)) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[k], side[k])); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[k], 0)); }
+    if (ctx->has_prior) {
+      DevBuf& pb = ctx->d_zero;   // identity permutation for the single prior block (zeroed by ensure_layout)
+      PriorFam p{1, ctx->prior_t, mkq(ctx->prior_q[0], ctx->prior_q[1], ctx->prior_q[2], ctx->prior_q[3]), (const int*)pb.p, ctx->prior_w, 0.0};
+      ProfScope ps(ctx, LVX_FAM_PRIOR, st);
+      hipLaunchKernelGGL((k_family<PriorFam, 1>), dim3(1), dim3(64), 0, st, p, cm, (const uint16_t*)ctx->d_pairs[2].p, (long long)ctx->fam_row0[2]);
+    }
+    // ---- LiDAR surfel blocks ----
+    if (ctx->surf.n > 0) {
+      ProfScope ps(ctx, LVX_FAM_SURFEL, st);
+      if (fast_surf && tauL) {
+        SurfAccT<true> f{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const double*)ctx->surf.d_b3.p, (const int*)ctx->surf.d_perm.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
+        LVX_LAUNCH_MFMA(SurfAccT<true>, f, LVX_FAM_SURFEL, st, ctx->fam_row0[3]);
+      } else if (fast_surf) {
+        SurfAcc f{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const double*)ctx->surf.d_b3.p, (const int*)ctx->surf.d_perm.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
+        LVX_LAUNCH_MFMA(SurfAcc, f, LVX_FAM_SURFEL, st, ctx->fam_row0[3]);
+      } else if (tauL) {
+        SurfFamT<true> f{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p, (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
+        hipLaunchKernelGGL((k_family<SurfFamT<true>, 1>), grid(f.n), dim3(64), 0, st, f, cm, (const uint16_t*)ctx->d_pairs[3].p, (long long)ctx->fam_row0[3]);
+      } else {
+        SurfFam f{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p, (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
+        hipLaunchKernelGGL((k_family<SurfFam, 1>), grid(f.n), dim3(64), 0, st, f, cm, (const uint16_t*)ctx->d_pairs[3].p, (long long)ctx->fam_row0[3]);
+      }
+    }
+    // ---- camera-landmark-to-surfel blocks ----
+    if (ctx->cs.n > 0) {
+      ProfScope ps(ctx, LVX_FAM_CAMSURF, st);
+      if (fast_cs && tauC) {
+        CamSurfAccT<true> f{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p, (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
+        LVX_LAUNCH_MFMA(CamSurfAccT<true>, f, LVX_FAM_CAMSURF, st, ctx->fam_row0[5]);
+      } else if (fast_cs) {
+        CamSurfAcc f{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p, (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
+        LVX_LAUNCH_MFMA(CamSurfAcc, f, LVX_FAM_CAMSURF, st, ctx->fam_row0[5]);
+      } else if (tauC) {
+        CamSurfFamT<true> f{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p, (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
+        hipLaunchKernelGGL((k_family<CamSurfFamT<true>, 1>), grid(f.n), dim3(64), 0, st, f, cm, (const uint16_t*)ctx->d_pairs[5].p, (long long)ctx->fam_row0[5]);
+      } else {
+        CamSurfFam f{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p, (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
+        hipLaunchKernelGGL((k_family<CamSurfFam, 1>), grid(f.n), dim3(64), 0, st, f, cm, (const uint16_t*)ctx->d_pairs[5].p, (long long)ctx->fam_row0[5]);
+      }
+    }
+    // ---- reprojection blocks ----
+    if (ctx->rep.n > 0) {
+      ReprojFam r{ctx->rep.n, (const int*)ctx->rep.d_id0.p, (const double*)ctx->rep.d_a3.p, (const double*)ctx->rep.d_t.p, (const int*)ctx->rep.d_perm.p,
+                  (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->rep.weight, ctx->rep.huber};
+      // the fused path (Jacobian rows materialised once, three MFMA assembly passes, landmark rows stored) for a locked AND for a free camera time offset
+      auto rep_fused = [&](auto TAUC) -> int {
+        constexpr bool T = decltype(TAUC)::value;
+        constexpr int RJ = REP_NC + (T ? 1 : 0);
+        double* Jb = (double*)ctx->d_repB[0].p; double* rb = Jb + (size_t)2 * RJ * r.n; int* kb = (int*)ctx->d_repB[1].p;
+        { ProfScope ps(ctx, LVX_KERNEL_REP_JAC, st);
+          const ReprojFamT<T> rf{r.n, r.lm, r.uv, r.t0o, r.perm, r.lm_uv, r.lm_t0, r.weight, r.huber};
+          hipLaunchKernelGGL(k_reproj_jac<T>, grid(r.n), dim3(64), 0, st, rf, cm, Jb, rb, kb, (long long)ctx->fam_row0[4]); }
+        if (!(what & LVX_EVAL_NORMAL_EQ)) return LVX_OK;
+        const RepJac jac{Jb, rb, kb, r.n};
+        if (s_side != st) { LVX_HIP(ctx, hipEventRecord(ctx->ev_jac, st)); LVX_HIP(ctx, hipStreamWaitEvent(s_side, ctx->ev_jac, 0)); side_used = true; }
+        { RepSideAcc<0, T> rr{r.n, jac, 0.0};
+          ProfScope ps(ctx, LVX_KERNEL_REP_REF, s_side); LVX_LAUNCH_MFMA1(LVX_T2(RepSideAcc<0, T>), 1, rr, LVX_FAM_PRIOR, s_side, ctx->fam_row0[4]); }
+        { RepSideAcc<1, T> ro{r.n, jac, 0.0};
+          ProfScope ps(ctx, LVX_KERNEL_REP_OBS, st); LVX_LAUNCH_MFMA1(LVX_T2(RepSideAcc<1, T>), 1, ro, LVX_FAM_REPROJ, st, ctx->fam_row0[4]); }
+        if (ctx->rep_groups > 0) {
+          const int* gt = (const int*)ctx->d_repB[2].p;
+          RepCross rx{jac, r.lm, gt, gt + ctx->rep_groups + 1, ctx->rep_groups, (double*)ctx->d_repT.p, nullptr};
+          { ProfScope ps(ctx, LVX_KERNEL_REP_CROSS, st);
+            if (det && ctx->det_cross_col.size() > 1) {
+              for (size_t q = 0; q + 1 < ctx->det_cross_col.size(); ++q) {
+                rx.det_list = (const int*)ctx->d_det_cross.p + ctx->det_cross_col[q];
+                hipLaunchKernelGGL(k_reproj_cross<T>, dim3((unsigned)(ctx->det_cross_col[q + 1] - ctx->det_cross_col[q])), dim3(256), 0, st, rx, cm);
+              }
+            } else
+            hipLaunchKernelGGL(k_reproj_cross<T>, dim3((unsigned)std::min((ctx->rep_groups + 3) / 4, 256 * 8)), dim3(256), 0, st, rx, cm); }
+          if (ctx->L > 0 && !(ctx->locks & LVX_LOCK_LANDMARKS)) {
+            const int* lp = (const int*)ctx->d_repB[3].p;
+            const RepLmRows lq{(const double*)ctx->d_repT.p, kb, r.n, lp, lp + ctx->L + 1, ctx->L};
+            const size_t lds = (size_t)4 * ctx->lm_ls * 8;
+            LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_reproj_lmrows<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ProfScope ps(ctx, LVX_KERNEL_REP_LMROWS, st);
+            hipLaunchKernelGGL(k_reproj_lmrows<T>, dim3((unsigned)((ctx->L + 3) / 4)), dim3(256), lds, st, lq, cm);
+          }
+        }
+        return LVX_OK;
+      };
+      if (fast) {
+        const int rcf = tauC ? rep_fused(std::true_type{}) : rep_fused(std::false_type{});
+        if (rcf) return rcf;
+      } else if (tauC) {
+        ProfScope ps(ctx, LVX_FAM_REPROJ, st);
+        ReprojFamT<true> rt{r.n, r.lm, r.uv, r.t0o, r.perm, r.lm_uv, r.lm_t0, r.weight, r.huber};
+        hipLaunchKernelGGL((k_family<ReprojFamT<true>, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, st, rt, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
+      } else {
+        ProfScope ps(ctx, LVX_FAM_REPROJ, st);
+        hipLaunchKernelGGL((k_family<ReprojFam, LVX_PW>), grid(r.n), dim3(64 * LVX_PW), 0, st, r, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4]);
+      }
+    }
+    if (side_used) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[0], s_side)); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[0], 0)); }
     { ProfScope ps(ctx, LVX_KERNEL_FOLD);
-    const bool fold_fast = (what & LVX_EVAL_NORMAL_EQ) && (fast_surf || fast_cs);
-    // default: three kernels (replica sums -> dense block, border rows beside them on the side stream).  LVX_FOLD_ONE=1: one launch whose
-    // last replica block folds the dense block (device-scope fence + counter), -0.5 % per pass; kept optional — one unexplained parity
-    // failure in ~45 suite runs while it was the default
-    const bool fold_split = !sw.fold_one;
-    if (fold_fast && ctx->nb > 0 && !fold_split) {
-      const int nrep = (ctx->nbd_ext * ctx->nbd_ext + 255) / 256, nrows = (ctx->nb + 255) / 256;
-      const size_t lds = ((size_t)ctx->nbd_ext * ctx->nbd_ext + ctx->nbd_ext) * 8;
-      LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_fold_all, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k_fold_all, dim3((unsigned)(nrep + nrows)), dim3(256), lds, st, cm, nrep, (fast_surf ? 1 : 0) | (fast_cs ? 2 : 0));
-    } else {
-    if (fold_fast && !sw.serial && !sw.fold_inline && !det) LVX_HIP(ctx, hipEventRecord(ctx->ev_jac, st));   // st has joined every family stream here
-    hipLaunchKernelGGL(k_fold_replicas, dim3((unsigned)((ctx->nbd_ext * ctx->nbd_ext + 255) / 256)), dim3(256), 0, st, cm);
-    if (fold_fast) {
-      // the border-row fold (Bd, streaming) and the dense fold (C, g_c; one workgroup, behind k_fold_replicas) touch disjoint buffers: side by side
-      hipStream_t s_side = (sw.serial || sw.fold_inline || det) ? st : ctx->fam_stream[0];
-      if (s_side != st) LVX_HIP(ctx, hipStreamWaitEvent(s_side, ctx->ev_jac, 0));
-      for (int set = 0; set < 2; ++set) if (ctx->nb > 0 && ((set == 0 && fast_surf) || (set == 1 && fast_cs)))
-        hipLaunchKernelGGL(k_fold_border_rows, dim3((unsigned)((ctx->nb + 255) / 256)), dim3(256), 0, s_side, cm, set, (set == 0 || !fast_surf) ? 1 : 0);
-      const size_t lds = ((size_t)ctx->nbd_ext * ctx->nbd_ext + ctx->nbd_ext) * 8;
-      LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_fold_border_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k_fold_border_dense, dim3(1), dim3(256), lds, st, cm);
-      if (s_side != st) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[0], s_side)); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[0], 0)); }
-    } } }
+      const bool fold_fast = (what & LVX_EVAL_NORMAL_EQ) && (fast_surf || fast_cs);
+      // replica sums -> dense block on the chain, the border-row fold (Bd, streaming; disjoint buffers) beside them on the side stream
+      hipStream_t s_fold = (fold_fast && side_on) ? ctx->fam_stream[0] : st;
+      if (s_fold != st) { LVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st)); LVX_HIP(ctx, hipStreamWaitEvent(s_fold, ctx->ev_fork, 0)); }
+      hipLaunchKernelGGL(k_fold_replicas, dim3((unsigned)((ctx->nbd_ext * ctx->nbd_ext + 255) / 256)), dim3(256), 0, st, cm);
+      if (fold_fast) {
+        for (int set = 0; set < 2; ++set) if (ctx->nb > 0 && ((set == 0 && fast_surf) || (set == 1 && fast_cs)))
+          hipLaunchKernelGGL(k_fold_border_rows, dim3((unsigned)((ctx->nb + 255) / 256)), dim3(256), 0, s_fold, cm, set, (set == 0 || !fast_surf) ? 1 : 0);
+        const size_t lds = ((size_t)ctx->nbd_ext * ctx->nbd_ext + ctx->nbd_ext) * 8;
+        LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_fold_border_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_fold_border_dense, dim3(1), dim3(256), lds, st, cm);
+        if (s_fold != st) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[1], s_fold)); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[1], 0)); }
+      } }
     LVX_HIP(ctx, hipGetLastError());
     return rc;
   };

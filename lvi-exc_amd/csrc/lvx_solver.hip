@@ -759,7 +759,7 @@ static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, 
     LVX_HIP(c, hipMemcpyAsync((void*)w.gcs, c->d_gc.p, ldc * 8, hipMemcpyDeviceToDevice, st));
     const int ne_max = c->lm_wl + c->lm_gspread + c->nbd_ext;
     const size_t lds_g = (size_t)32 * ne_max * 8 + 32 * 8 + (size_t)2 * ne_max * 4 + 16;
-    if (!c->sw.lm_schur_single && c->lm_ngrp > 0 && lds_g <= 160 * 1024) {
+    if (c->lm_ngrp > 0 && lds_g <= 160 * 1024) {
       LVX_HIP(c, hipFuncSetAttribute((const void*)k_lm_schur_grp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
       hipLaunchKernelGGL(k_lm_schur_grp, dim3((unsigned)c->lm_ngrp), dim3(256), lds_g, st, (const double*)c->d_lmH.p, (const int*)c->d_lm_p0.p, (const int*)c->d_lm_grp.p, c->lm_ngrp, c->lm_wl, c->nbd_ext, c->lm_ls,
                          w.scale + (nb + nbd), w.lmd + (nb + nbd), ir, ne_max, (double*)w.Hs, bw, (double*)w.Bs, nb, (double*)w.Cs, c->nbd_ext, (double*)w.gbs, (double*)w.gcs);

@@ -167,7 +167,7 @@ def test_collectives_per_iteration_and_failure_leaves_together():
     res = _run_ranks(seqs, body)
     for s, n in res:
         acc = int(np.sum(np.asarray(s["accepted"]) == 1))
-        assert n == 1 + 2 * s["iterations"] and acc >= 1
+        assert n == 1 + 2 * s["iterations"] + (1 if s["termination"] == "max_iterations" and s["accepted"][-1] != 1 else 0) and acc >= 1
     # rank 1's sequence has an IMU sample beyond the spline: its evaluation returns LVX_E_RANGE; rank 0 must come back with LVX_E_COMM
     P1 = dict(seqs[1][0]); P1["t_imu"] = P1["t_imu"].copy(); P1["t_imu"][-1] = P1["t0"] + (P1["n_knots"] - 3) * P1["dt"] + 0.5
     bad = [seqs[0], (P1, seqs[1][1])]
@@ -194,7 +194,8 @@ def test_rccl_transport_single_rank_equals_plain_solve():
     g.collective_count(reset=True)
     xb, sb = g.lm_solve_shared(x0, None, max_iterations=8)
     assert g.joint_shared_count() == 14       # the 14 extrinsic scalars stayed out of the local elimination: the reduced 14 x 14 system went through ncclAllReduce
-    assert g.collective_count() == 1 + 2 * sb["iterations"]
+    # one reduction after the first evaluation, two per iteration, and one vote when the iteration cap ends the loop right behind a rejected step (its restore has met no collective yet)
+    assert g.collective_count() == 1 + 2 * sb["iterations"] + (1 if sb["termination"] == "max_iterations" and sb["accepted"][-1] != 1 else 0)
     g.rccl_finalize()
     assert sa["iterations"] == sb["iterations"] and list(sa["accepted"]) == list(sb["accepted"]) and sa["termination"] == sb["termination"]
     assert np.abs(sa["cost_history"] - sb["cost_history"]).max() <= 1e-9 * sa["cost_history"].max()
