@@ -811,8 +811,15 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
   const int k_lo = (var_nch ? chunk_off[var_nch + 1 + ch] : ch * CR) - 1;
   const int nt = 6 * cm.N + 22 + cm.L;
   const bool want_ne = (cm.what & LVX_EVAL_NORMAL_EQ) != 0;
-  for (int e = tid; e < ACC_LV * ACC_BW + NG * ACC_LV + NG * NG + ACC_LV + NG + 4 * PR * LDP; e += 256) sm[e] = 0.0;
-  for (int e = tid; e < ACC_LV; e += 256) { const int k = k_lo + e / 6; kpos[e] = (k >= 0 && k < cm.N) ? cm.ord[6 * k + e % 6] : LVX_DEAD; }
+  // the accumulator rows this chunk can touch: its own knot span (+ 1 interval either side for a time offset, + 3 knots), not the launch-wide maximum CR — the
+  // reprojection side passes allow 48 intervals per chunk and typically hold one camera frame (4): clearing and flushing 318 rows for 60 was a third of the kernel
+  const int LVU = var_nch ? min(ACC_LV, (chunk_off[2 * var_nch + 1 + ch] + 6) * 6) : ACC_LV;
+  for (int e = tid; e < LVU * ACC_BW; e += 256) acc_band[e] = 0.0;
+  for (int g = 0; g < NG; ++g) for (int e = tid; e < LVU; e += 256) acc_bd[g * ACC_LV + e] = 0.0;
+  for (int e = tid; e < NG * NG + LVU; e += 256) { if (e < NG * NG) acc_gg[e] = 0.0; else acc_gk[e - NG * NG] = 0.0; }
+  if (tid < NG) acc_gG[tid] = 0.0;
+  for (int e = tid; e < 4 * PR * LDP; e += 256) panels[e] = 0.0;
+  for (int e = tid; e < LVU; e += 256) { const int k = k_lo + e / 6; kpos[e] = (k >= 0 && k < cm.N) ? cm.ord[6 * k + e % 6] : LVX_DEAD; }
   if (tid < NG) gpos[tid] = cm.ord[F::gcol(tid, cm.N, nt)];
   const SplineRef sp{cm.t0, cm.dt, cm.N, cm.state, cm.state + 3 * (size_t)cm.N};
   if (F::USE_PRE && tid < CR + 4) {   // this chunk's slice of the pass's control-point-pair table
@@ -882,7 +889,7 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
       else status = fam.eval(cm, sp, cal, hub, si, r, J, key, aux);
       if (aux.wid < 0) aux.wid = key;
       valid = status == RES_OK;
-      if (valid && (key < k_lo || key - k_lo > CR + 1)) { valid = false; atomicOr(cm.err, LVX_ERR_FALLBACK); }
+      if (valid && (key < k_lo || key - k_lo > CR + 1 || 6 * (key - k_lo + 4) > LVU)) { valid = false; atomicOr(cm.err, LVX_ERR_FALLBACK); }
       else if (!valid && status > 0) atomicOr(cm.err, status);   // status < 0: row skipped (reported by the kernel that produced it)
     }
     if constexpr (RowOf<F>::prefetch) { const int sn = si + nwv * LB; if (lane < LB && sn < m1) nxt = fam.load(sn); }   // next batch's rows: in flight during this batch's assembly
@@ -1086,22 +1093,23 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
   __syncthreads();
   KT(6)
   // flush the workgroup's accumulators: ONE global atomic per touched entry
-  for (int e = tid; e < ACC_LV * ACC_BW; e += 256) {
+  for (int e = tid; e < LVU * ACC_BW; e += 256) {
     const double v = acc_band[e];
     if (v == 0.0) continue;
     const int la = e / ACC_BW, lb = la + e % ACC_BW;
-    if (lb >= ACC_LV) continue;
+    if (lb >= LVU) continue;
     const int pa = kpos[la], pb = kpos[lb];
     if (pa == LVX_DEAD || pb == LVX_DEAD) continue;
     add_H(cm, pa, pb, v, rep);
   }
-  for (int e = tid; e < NG * ACC_LV; e += 256) {
-    const double v = acc_bd[e];
-    if (v == 0.0) continue;
-    const int pg = gpos[e / ACC_LV], pk2 = kpos[e % ACC_LV];
-    if (pg == LVX_DEAD || pk2 == LVX_DEAD) continue;
-    add_H(cm, pg, pk2, v, rep);
-  }
+  for (int g = 0; g < NG; ++g)
+    for (int e = tid; e < LVU; e += 256) {
+      const double v = acc_bd[g * ACC_LV + e];
+      if (v == 0.0) continue;
+      const int pg = gpos[g], pk2 = kpos[e];
+      if (pg == LVX_DEAD || pk2 == LVX_DEAD) continue;
+      add_H(cm, pg, pk2, v, rep);
+    }
   for (int e = tid; e < NG * NG; e += 256) {
     const int ga = e / NG, gb2 = e % NG;
     if (gb2 < ga) continue;
@@ -1109,7 +1117,7 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
     if (v == 0.0 || gpos[ga] == LVX_DEAD || gpos[gb2] == LVX_DEAD) continue;
     add_H(cm, gpos[ga], gpos[gb2], v, rep);
   }
-  for (int e = tid; e < ACC_LV; e += 256) { const double v = acc_gk[e]; if (v != 0.0 && kpos[e] != LVX_DEAD) add_g(cm, kpos[e], v, rep); }
+  for (int e = tid; e < LVU; e += 256) { const double v = acc_gk[e]; if (v != 0.0 && kpos[e] != LVX_DEAD) add_g(cm, kpos[e], v, rep); }
   if (tid < NG) { const double v = acc_gG[tid]; if (v != 0.0 && gpos[tid] != LVX_DEAD) add_g(cm, gpos[tid], v, rep); }
 #ifdef LVX_KTIME
   KT(7)
@@ -1770,7 +1778,10 @@ static int upload_chunks_rows(lvx_ctx* ctx, int fam, const std::vector<int>& sor
   const int nch = (int)k0.size();
   ctx->n_chunk[fam] = nch; ctx->chunk_r[fam] = rmax; ctx->chunk_var[fam] = 1;
   ctx->h_chunk_k0[fam] = k0; ctx->h_chunk_rows[fam].assign(nch, 0); for (int c = 0; c < nch; ++c) ctx->h_chunk_rows[fam][c] = off[c + 1] - off[c];
+  std::vector<int> span(nch, 1);   // knot intervals a chunk's rows cover (k_family_mfma clears / flushes that many accumulator rows)
+  for (int c = 0; c < nch; ++c) if (off[c + 1] > off[c]) span[c] = std::max(1, sorted_keys[off[c + 1] - 1] - k0[c] + 1);
   off.insert(off.end(), k0.begin(), k0.end());
+  off.insert(off.end(), span.begin(), span.end());
   return upload_tmp(ctx, ctx->d_chunk[fam], off.data(), off.size() * 4);
 }
 // Same for rows whose keys are only grouped, not sorted (the reprojection passes share one row order): a chunk is a run of at most `rows` rows
@@ -1779,6 +1790,7 @@ static int upload_chunks_rows_grouped(lvx_ctx* ctx, int fam, const std::vector<i
   const int n = (int)keys.size();
   std::vector<int> off, k0;
   int i = 0;
+  std::vector<int> span;
   do {
     off.push_back(i);
     int lo = 1 << 30, hi = -1, e = i;
@@ -1787,13 +1799,14 @@ static int upload_chunks_rows_grouped(lvx_ctx* ctx, int fam, const std::vector<i
       if (k >= 0) { const int nlo = std::min(lo, k), nhi = std::max(hi, k); if (nhi - nlo + 1 > rmax && e > i) break; lo = nlo; hi = nhi; }
       ++e;
     }
-    k0.push_back(hi >= 0 ? lo : 0);
+    k0.push_back(hi >= 0 ? lo : 0); span.push_back(hi >= 0 ? hi - lo + 1 : 1);
     i = std::max(e, i + (n > 0 ? 1 : 0));
   } while (i < n);
   off.push_back(n);
   ctx->n_chunk[fam] = (int)k0.size(); ctx->chunk_r[fam] = rmax; ctx->chunk_var[fam] = 1;
   ctx->h_chunk_k0[fam] = k0; ctx->h_chunk_rows[fam].assign(k0.size(), 0); for (size_t c = 0; c < k0.size(); ++c) ctx->h_chunk_rows[fam][c] = off[c + 1] - off[c];
   off.insert(off.end(), k0.begin(), k0.end());
+  off.insert(off.end(), span.begin(), span.end());
   return upload_tmp(ctx, ctx->d_chunk[fam], off.data(), off.size() * 4);
 }
 static int upload_chunks(lvx_ctx* ctx, int fam, const std::vector<int>& sorted_keys, int R) {
@@ -1919,8 +1932,9 @@ int ensure_layout(lvx_ctx* ctx) {
       std::vector<int> s1(f.n), s0(f.n);
       for (int i = 0; i < f.n; ++i) { s1[i] = k1[perm[i]]; s0[i] = k0[perm[i]]; }
       const int rows = ctx->sw.rep_rows > 0 ? ctx->sw.rep_rows : 16 * (int)RepSideAcc<1>::LB;   // 256 rows = four batches of 4 wavefronts x LB = 16 rows (measured: 64 rows 73 + 88 us, 256 rows 52 + 62 us)
-      if ((rc = upload_chunks_rows_grouped(ctx, LVX_FAM_REPROJ, s1, 48, rows))) return rc;
-      if ((rc = upload_chunks_rows_grouped(ctx, LVX_FAM_PRIOR /* slot reused: the prior has no chunks */, s0, 48, rows))) return rc;
+      const int rmax = (ctx->sw.chunk_r_rep >= 4 && ctx->sw.chunk_r_rep <= 48) ? ctx->sw.chunk_r_rep : 48;
+      if ((rc = upload_chunks_rows_grouped(ctx, LVX_FAM_REPROJ, s1, rmax, rows))) return rc;
+      if ((rc = upload_chunks_rows_grouped(ctx, LVX_FAM_PRIOR /* slot reused: the prior has no chunks */, s0, rmax, rows))) return rc;
       // groups of the cross-term kernel: runs of equal (reference window, observation window); rows that are out of range form no group
       std::vector<int> goff, gw0, gw1;
       for (int i = 0; i < f.n; ++i) {
@@ -2509,7 +2523,9 @@ static int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, doub
     LVX_HIP(ctx, hipGetLastError());
     return rc;
   };
-  const bool use_graph = !ctx->sw.no_graph && !ctx->profiling && !(what & LVX_EVAL_JACOBIAN);
+  // graph replay pays for small problems (a pass is ~35 API calls: launch-bound at ~0.37 ms issued call by call, 0.26 ms replayed); at config-4 size the kernels are long
+  // enough for the host to stay ahead and the replayed graph is the SLOWER one (0.61 against 0.58 ms: its cross-stream edges become barrier packets between every node)
+  const bool use_graph = !ctx->sw.no_graph && !ctx->profiling && !(what & LVX_EVAL_JACOBIAN) && ctx->n_blocks <= 400000;
   if (!use_graph) { if ((rc = enqueue())) return rc; }
   else {
     const int flags = (want_res_buffer ? 1 : 0) | (ctx->force_legacy ? 2 : 0);   // a switch change bumps cfg_version
