@@ -625,7 +625,9 @@ using namespace lvx;
 // ---------------------------------------------------------------------------------------------------------
 struct SolveWork { double *L, *Z, *S, *rhs, *delta, *diag, *scale, *lmd, *sums, *Z2, *gram; int* info; int ldz; bool use_bcr;
                    bool lm;                                   // landmarks are eliminated first (k_lm_schur)
-                   const double *Hs, *Bs, *Cs, *gbs, *gcs; };   // what the band / border solve reads: the normal equations, or their copies after the landmark elimination
+                   const double *Hs, *Bs, *Cs, *gbs, *gcs;     // what the band / border solve reads: the normal equations, or their copies after the landmark elimination
+                   bool inplace = false, lm_done = false; };   // inplace (LM loop, single sequence): the landmark elimination works on the band / border rows THEMSELVES — no 290 MB copy per
+                                                               // solve; the accumulators no longer hold J^T J afterwards (the loop re-evaluates before it needs them).  lm_done: this step's elimination has run
 
 // ---------------------------------------------------------------------------------------------------------
 // Reductions of the joint (sequence-per-GPU) solve.  Two transports: RCCL on the context's stream (lvx_rccl_init: librccl is loaded with dlopen, so the
@@ -750,10 +752,13 @@ static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, 
   *bcr_used = use_bcr;
   if (!use_bcr && nb > 0) { int rca = dev_alloc(c, c->d_L, (size_t)nb * (bw + 1) * 8); if (rca) return rca; w.L = (double*)c->d_L.p; }
   const int ldz = w.ldz;
-  if (w.lm) {   // copies of the normal equations, then A' = A - sum_l w_l E_l^T E_l, g' = g - sum_l w_l E_l^T g_l
+  if (w.lm && !(w.inplace && w.lm_done)) {   // copies of the normal equations, then A' = A - sum_l w_l E_l^T E_l, g' = g - sum_l w_l E_l^T g_l   (second call of a step = the sequential fallback: everything is eliminated already)
     const size_t nb1 = (size_t)std::max(nb, 1), ldc = c->nbd_ext;
-    LVX_HIP(c, hipMemcpyAsync((void*)w.Hs, c->d_Hb.p, nb1 * (bw + 1) * 8, hipMemcpyDeviceToDevice, st));
-    LVX_HIP(c, hipMemcpyAsync((void*)w.Bs, c->d_Bd.p, (size_t)nbd * nb1 * 8, hipMemcpyDeviceToDevice, st));
+    w.lm_done = true;
+    if (!w.inplace) {
+      LVX_HIP(c, hipMemcpyAsync((void*)w.Hs, c->d_Hb.p, nb1 * (bw + 1) * 8, hipMemcpyDeviceToDevice, st));
+      LVX_HIP(c, hipMemcpyAsync((void*)w.Bs, c->d_Bd.p, (size_t)nbd * nb1 * 8, hipMemcpyDeviceToDevice, st));
+    }
     LVX_HIP(c, hipMemcpyAsync((void*)w.gbs, c->d_gb.p, nb1 * 8, hipMemcpyDeviceToDevice, st));
     LVX_HIP(c, hipMemcpyAsync((void*)w.Cs, c->d_C.p, ldc * ldc * 8, hipMemcpyDeviceToDevice, st));
     LVX_HIP(c, hipMemcpyAsync((void*)w.gcs, c->d_gc.p, ldc * 8, hipMemcpyDeviceToDevice, st));
@@ -854,6 +859,7 @@ static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double m[3
   ProfScope ps(c, LVX_KERNEL_SOLVE);
   bool bcr_used = false;
   m[0] = m[1] = m[2] = 0.0; *notpd_out = false;
+  w.lm_done = false;
   int rc = lerr ? lerr : solve_local(c, w, radius, false, &bcr_used);
   if (rc == LVX_E_NOTPD && w.use_bcr) {
     // the cyclic-reduction elimination order can lose positive definiteness in floating point on nearly singular systems
@@ -934,16 +940,22 @@ static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double m[3
   if (w.lm) hipLaunchKernelGGL(k_lm_back, dim3((unsigned)((c->L + 3) / 4)), dim3(256), 0, st, (const double*)c->d_lmH.p, (const int*)c->d_lm_p0.p, c->L, c->lm_wl, nbd, c->nbd_ext, c->lm_ls,
                                (const double*)(w.scale + (nb + nbd)), (const double*)(w.lmd + (nb + nbd)), ir, (const double*)zb, (const double*)w.rhs, (const double*)w.scale, nb,
                                w.delta + 6 * (size_t)c->N + 22, w.sums);
-  if (nb > 0) hipLaunchKernelGGL(k_quad_band, dim3((unsigned)std::min(2048, (nb + 3) / 4)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)zb, (const double*)w.scale, nb, bw, w.sums);
-  hipLaunchKernelGGL(k_quad, dim3((unsigned)std::min(2 * RED_BLOCKS, (nb + nbd + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)c->d_Bd.p, (const double*)c->d_C.p, c->nbd_ext,
-                     (const double*)zb, (const double*)w.rhs, (const double*)w.scale, nb, bw, nbd, w.sums);
+  // delta^T H delta.  Single sequence: the step solves (H + D) delta = -g EXACTLY (SPARSE_SCHUR semantics; residual 1e-15 of the scale, tests/test_gpu_fullsize_oracle.py),
+  // so delta^T H delta = -g.delta - delta^T D delta comes with the sums k_unscale / k_lm_back form anyway — the explicit product streams the whole band again (216 MB, 0.16 ms).
+  // Joint problem: the identity holds for the SUM over the ranks only and the shared damping is counted once, after the reduction — the explicit product stays.
+  const bool quad_explicit = is_joint(c);
+  if (quad_explicit) {
+    if (nb > 0) hipLaunchKernelGGL(k_quad_band, dim3((unsigned)std::min(2048, (nb + 3) / 4)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)zb, (const double*)w.scale, nb, bw, w.sums);
+    hipLaunchKernelGGL(k_quad, dim3((unsigned)std::min(2 * RED_BLOCKS, (nb + nbd + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)c->d_Bd.p, (const double*)c->d_C.p, c->nbd_ext,
+                       (const double*)zb, (const double*)w.rhs, (const double*)w.scale, nb, bw, nbd, w.sums);
+  }
   LVX_HIP(c, hipGetLastError());
   double h[8];
   LVX_HIP(c, hipMemcpyAsync(h, w.sums, 8 * 8, hipMemcpyDeviceToHost, st));
   LVX_HIP(c, hipStreamSynchronize(st));
   // model_cost_change = -(g.delta + 1/2 delta^T H delta)   (TrustRegionMinimizer: -model_residuals.(residuals + model_residuals / 2));
   // joint problem: H = sum_r H_r, g = sum_r g_r with delta_r = [private_r | shared]  =>  both terms are sums over the ranks
-  m[0] = h[0]; m[1] = h[5]; m[2] = h[1];
+  m[0] = h[0]; m[1] = quad_explicit ? h[5] : -h[0] - h[1]; m[2] = h[1];
   return LVX_OK;
 }
 
@@ -1079,6 +1091,7 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
   SolveWork w;
   if (!lerr) lerr = solver_alloc(c, w);
   if (lerr && !joint) return lerr;
+  if (!lerr && !joint && w.lm && c->nb > 0) { w.inplace = true; w.Hs = (const double*)c->d_Hb.p; w.Bs = (const double*)c->d_Bd.p; c->p_Hs = w.Hs; }
   hipStream_t st = c->stream;
   const size_t sbytes = (size_t)lvx_state_size(c) * 8;
   double* x = (double*)c->d_state.p;
@@ -1105,6 +1118,7 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
     double m[3]; bool notpd = false;
     if ((rc = solve_step_device(c, w, radius, m, &notpd, pending))) return rc;
     pending = LVX_OK; restored = false;
+    if (w.inplace) acc_is_x = false;   // the landmark elimination ran on the band / border rows themselves
     // candidate x (+) delta: cost AND normal equations (they replace those of x in the accumulators; the model terms of x were taken by solve_step_device)
     double r2[7 + LVX_JB_N] = {m[0], m[1], m[2], 0, 0, 0, 0}, h[6] = {0, 0, 0, 0, 0, 0};
     lerr = LVX_OK;
@@ -1136,7 +1150,7 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
       if (++invalid >= 5) { s.termination = LVX_LM_FAILURE; break; }   // max_num_consecutive_invalid_steps = 5
       radius *= 0.5;
       c->lm_cost.push_back(cost); c->lm_radius.push_back(radius); c->lm_accept.push_back(-1);
-      if (cand_ne) restore_x();
+      if (cand_ne || w.inplace) restore_x();
       continue;
     }
     invalid = 0;
