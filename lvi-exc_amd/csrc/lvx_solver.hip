@@ -603,16 +603,37 @@ __global__ __launch_bounds__(256) void k_lm_back(const double* __restrict__ lmH,
     if (v != 0.0) atomicAdd(&sums[threadIdx.x == 2 ? 5 : threadIdx.x], v);
   }
 }
-__global__ void k_gmax_lm(const double* lmH, int L, int ls, int off, double* sums) {
+// rho != null: the PROJECTED gradient of the bounded inverse depths, rho - max(rho - g, 0) (TrustRegionMinimizer::ComputeGradientNorms for a constrained problem)
+__global__ void k_gmax_lm(const double* lmH, int L, int ls, int off, double* sums, const double* rho) {
   double v = 0.0;
-  for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < L; l += gridDim.x * blockDim.x) v = fmax(v, fabs(lmH[(size_t)l * ls + off]));
+  for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < L; l += gridDim.x * blockDim.x) {
+    const double g = lmH[(size_t)l * ls + off];
+    v = fmax(v, rho ? fabs(rho[l] - fmax(rho[l] - g, 0.0)) : fabs(g));
+  }
   block_atomic_max_nonneg(v, &sums[4]);
 }
+// out[0] += g . delta with the gradient of the accumulators (band, border, landmark rows) and a step in the tangent layout
+__global__ void k_gdot(const int* ord, int nt, const double* gb, const double* gc, const double* lmH, int ls, int goff, const double* delta, double* out) {
+  double s = 0.0;
+  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nt; v += gridDim.x * blockDim.x) {
+    const int o = ord[v];
+    if (o == LVX_DEAD) continue;
+    const double g = o >= LVX_LM_BASE ? (lmH ? lmH[(size_t)(o - LVX_LM_BASE) * ls + goff] : 0.0) : (o >= 0 ? gb[o] : gc[-1 - o]);
+    s += g * delta[v];
+  }
+  block_atomic_add(s, out);
+}
+__global__ void k_scal(double* x, int n, double a) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) x[i] *= a; }
 
-// max |g| over free scalars
-__global__ void k_gmax(const double* gb, const double* gc, int nb, int nbd, double* sums) {   // nbd: border entries to include (the shared tail is excluded in the joint solve)
+// max |g| over free scalars; bounded border scalars (a free sensor time offset: border index tb[k], value tx[k], |.| <= bound) enter projected
+struct TauBox { int idx[2]; const double* x[2]; double bound; };
+__global__ void k_gmax(const double* gb, const double* gc, int nb, int nbd, double* sums, TauBox tb) {   // nbd: border entries to include (the shared tail is excluded in the joint solve)
   double v = 0.0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb + nbd; i += gridDim.x * blockDim.x) v = fmax(v, i < nb ? fabs(gb[i]) : fabs(gc[i - nb]));
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb + nbd; i += gridDim.x * blockDim.x) {
+    double g = i < nb ? gb[i] : gc[i - nb];
+    for (int k = 0; k < 2; ++k) if (i - nb == tb.idx[k] && tb.idx[k] >= 0) { const double x = *tb.x[k]; g = x - fmin(fmax(x - g, -tb.bound), tb.bound); }
+    v = fmax(v, fabs(g));
+  }
   block_atomic_max_nonneg(v, &sums[4]);   // atomic max on a non-negative double via its bit pattern
 }
 
@@ -626,7 +647,7 @@ using namespace lvx;
 struct SolveWork { double *L, *Z, *S, *rhs, *delta, *diag, *scale, *lmd, *sums, *Z2, *gram; int* info; int ldz; bool use_bcr;
                    bool lm;                                   // landmarks are eliminated first (k_lm_schur)
                    const double *Hs, *Bs, *Cs, *gbs, *gcs;     // what the band / border solve reads: the normal equations, or their copies after the landmark elimination
-                   bool inplace = false, lm_done = false; };   // inplace (LM loop, single sequence): the landmark elimination works on the band / border rows THEMSELVES — no 290 MB copy per
+                   bool inplace = false, lm_done = false, constrained = false; };   // inplace (LM loop, single sequence): the landmark elimination works on the band / border rows THEMSELVES — no 290 MB copy per
                                                                // solve; the accumulators no longer hold J^T J afterwards (the loop re-evaluates before it needs them).  lm_done: this step's elimination has run
 
 // ---------------------------------------------------------------------------------------------------------
@@ -964,8 +985,17 @@ static int local_gmax(lvx_ctx* c, SolveWork& w, double* g, double* gsh) {
   hipStream_t st = c->stream;
   LVX_HIP(c, hipMemsetAsync(w.sums + 4, 0, 8, st));
   const int n = c->nb + c->nbd - c->ns;
-  hipLaunchKernelGGL(k_gmax, dim3((unsigned)std::min(RED_BLOCKS, (n + 255) / 256)), dim3(256), 0, st, (const double*)c->d_gb.p, (const double*)c->d_gc.p, c->nb, c->nbd - c->ns, w.sums);
-  if (w.lm) hipLaunchKernelGGL(k_gmax_lm, dim3((unsigned)std::min(RED_BLOCKS, (c->L + 255) / 256)), dim3(256), 0, st, (const double*)c->d_lmH.p, c->L, c->lm_ls, c->lm_wl + c->nbd_ext + 1, w.sums);
+  // box constraints of a single sequence (w.constrained): the gradient norm is the projected one, at the state of the last evaluation
+  const double* xs = (w.constrained && c->last_state_d) ? c->last_state_d : nullptr;
+  TauBox tb{{-1, -1}, {nullptr, nullptr}, c->sensor_mto};
+  if (xs) {
+    const int oL = c->ord[6 * c->N + 14], oC = c->ord[6 * c->N + 21];
+    if (oL != LVX_DEAD && oL < 0) { tb.idx[0] = -1 - oL; tb.x[0] = xs + 7 * (size_t)c->N + 23; }
+    if (oC != LVX_DEAD && oC < 0) { tb.idx[1] = -1 - oC; tb.x[1] = xs + 7 * (size_t)c->N + 31; }
+  }
+  hipLaunchKernelGGL(k_gmax, dim3((unsigned)std::min(RED_BLOCKS, (n + 255) / 256)), dim3(256), 0, st, (const double*)c->d_gb.p, (const double*)c->d_gc.p, c->nb, c->nbd - c->ns, w.sums, tb);
+  if (w.lm) hipLaunchKernelGGL(k_gmax_lm, dim3((unsigned)std::min(RED_BLOCKS, (c->L + 255) / 256)), dim3(256), 0, st, (const double*)c->d_lmH.p, c->L, c->lm_ls, c->lm_wl + c->nbd_ext + 1, w.sums,
+                               xs ? xs + 7 * (size_t)c->N + 32 : (const double*)nullptr);
   LVX_HIP(c, hipMemcpyAsync(g, w.sums + 4, 8, hipMemcpyDeviceToHost, st));
   if (c->ns > 0) LVX_HIP(c, hipMemcpyAsync(gsh, (const double*)c->d_gc.p + (c->nbd - c->ns), (size_t)c->ns * 8, hipMemcpyDeviceToHost, st));
   return LVX_OK;
@@ -1035,6 +1065,54 @@ static int post_eval(lvx_ctx* c, SolveWork& w, bool compute_scale, int use_scali
   return apply_diag(c, w, compute_scale, use_scaling, mn, mx, e, nullptr, grad_tol, grad_converged);
 }
 
+// ---- projected Armijo line search of a constrained problem (TrustRegionMinimizer::DoLineSearch; restated from Ceres' public sources, see oracle/lm.py) ----
+struct LsSample { double x, f, df; bool has_df; };
+// coefficients (highest power first) of the lowest-degree polynomial through the samples: Gaussian elimination with partial pivoting, the same operations as
+// oracle/lm.py::interpolating_polynomial
+static std::vector<double> poly_fit(const std::vector<LsSample>& sm) {
+  int n = 0; for (const auto& q : sm) n += 1 + (q.has_df ? 1 : 0);
+  std::vector<double> A((size_t)n * n, 0.0), b(n, 0.0);
+  int r = 0;
+  for (const auto& q : sm) {
+    for (int k = 0; k < n; ++k) A[(size_t)r * n + k] = std::pow(q.x, n - 1 - k);
+    b[r++] = q.f;
+    if (q.has_df) { for (int k = 0; k < n; ++k) A[(size_t)r * n + k] = (n - 1 - k > 0) ? (n - 1 - k) * std::pow(q.x, n - 2 - k) : 0.0; b[r++] = q.df; }
+  }
+  for (int k = 0; k < n; ++k) {
+    int piv = k; for (int i = k + 1; i < n; ++i) if (std::fabs(A[(size_t)i * n + k]) > std::fabs(A[(size_t)piv * n + k])) piv = i;
+    if (piv != k) { for (int j = 0; j < n; ++j) std::swap(A[(size_t)k * n + j], A[(size_t)piv * n + j]); std::swap(b[k], b[piv]); }
+    for (int i = k + 1; i < n; ++i) { const double m = A[(size_t)i * n + k] / A[(size_t)k * n + k]; for (int j = k; j < n; ++j) A[(size_t)i * n + j] -= m * A[(size_t)k * n + j]; b[i] -= m * b[k]; }
+  }
+  std::vector<double> c(n, 0.0);
+  for (int k = n - 1; k >= 0; --k) { double t = b[k]; for (int j = k + 1; j < n; ++j) t -= A[(size_t)k * n + j] * c[j]; c[k] = t / A[(size_t)k * n + k]; }
+  return c;
+}
+// argmin on [lo, hi]: 2001 uniform samples, then 60 golden-section steps on the best bracket (oracle/lm.py::minimize_polynomial)
+static double poly_argmin(const std::vector<double>& c, double lo, double hi) {
+  auto val = [&](double x) { double v = 0.0; for (double a : c) v = v * x + a; return v; };
+  const int n = 2000; double best = 0.0; int bi = 0;
+  for (int i = 0; i <= n; ++i) { const double v = val(lo + (hi - lo) * i / n); if (i == 0 || v < best) { best = v; bi = i; } }
+  double a = lo + (hi - lo) * std::max(bi - 1, 0) / n, b = lo + (hi - lo) * std::min(bi + 1, n) / n;
+  const double g = 0.6180339887498949;
+  double x1 = b - g * (b - a), x2 = a + g * (b - a), f1 = val(x1), f2 = val(x2);
+  for (int it = 0; it < 60; ++it) {
+    if (f1 <= f2) { b = x2; x2 = x1; f2 = f1; x1 = b - g * (b - a); f1 = val(x1); }
+    else { a = x1; x1 = x2; f1 = f2; x2 = a + g * (b - a); f2 = val(x2); }
+  }
+  return 0.5 * (a + b);
+}
+// g . delta with the gradient the accumulators hold now
+static int grad_dot(lvx_ctx* c, SolveWork& w, double* out) {
+  hipStream_t st = c->stream;
+  const int nt = lvx_tangent_size(c);
+  LVX_HIP(c, hipMemsetAsync(w.sums + 8, 0, 8, st));
+  hipLaunchKernelGGL(k_gdot, dim3((unsigned)std::min(RED_BLOCKS, (nt + 255) / 256)), dim3(256), 0, st, (const int*)c->d_ord.p, nt, (const double*)c->d_gb.p, (const double*)c->d_gc.p,
+                     w.lm ? (const double*)c->d_lmH.p : (const double*)nullptr, c->lm_ls, c->lm_wl + c->nbd_ext + 1, (const double*)w.delta, w.sums + 8);
+  LVX_HIP(c, hipMemcpyAsync(out, w.sums + 8, 8, hipMemcpyDeviceToHost, st));
+  LVX_HIP(c, hipStreamSynchronize(st));
+  return LVX_OK;
+}
+
 struct HookScope {   // installs the all-reduce hook for the duration of one API call
   lvx_ctx* c;
   HookScope(lvx_ctx* ctx, lvx_allreduce_fn fn, void* user) : c(ctx) { c->ar_fn = fn; c->ar_user = user; }
@@ -1091,6 +1169,11 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
   SolveWork w;
   if (!lerr) lerr = solver_alloc(c, w);
   if (lerr && !joint) return lerr;
+  // box constraints (free inverse depths: rho >= 0; a free sensor time offset: |tau| <= max) make the problem constrained in Ceres' sense: projected start point,
+  // projected gradient norm, projected Armijo line search on every trust-region step.  Single sequence only (the joint solve projects its candidates, nothing more).
+  const bool free_rho = c->L > 0 && c->rep.n + c->cs.n > 0 && !(c->locks & LVX_LOCK_LANDMARKS);
+  const bool free_tau = (!(c->locks & LVX_LOCK_LIDAR_TAU) && c->surf.n + c->cs.n > 0) || (!(c->locks & LVX_LOCK_CAM_TAU) && c->rep.n + c->cs.n > 0);
+  w.constrained = !joint && !lerr && (free_rho || free_tau);
   if (!lerr && !joint && w.lm && c->nb > 0) { w.inplace = true; w.Hs = (const double*)c->d_Hb.p; w.Bs = (const double*)c->d_Bd.p; c->p_Hs = w.Hs; }
   hipStream_t st = c->stream;
   const size_t sbytes = (size_t)lvx_state_size(c) * 8;
@@ -1099,7 +1182,14 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
   c->lm_cost.clear(); c->lm_radius.clear(); c->lm_accept.clear();
   lvx_lm_summary s{}; s.termination = LVX_LM_NO_CONVERGENCE;
   double cost = 0; bool gconv = false;
-  if (!lerr) { LVX_HIP(c, hipMemcpyAsync(x, state, sbytes, hipMemcpyHostToDevice, st)); lerr = lvx_evaluate_d(c, x, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &cost); }
+  if (!lerr) {
+    LVX_HIP(c, hipMemcpyAsync(x, state, sbytes, hipMemcpyHostToDevice, st));
+    if (w.constrained) {   // TrustRegionMinimizer::IterationZero: x <- Plus(x, 0), the start point projected onto the box
+      LVX_HIP(c, hipMemsetAsync(w.delta, 0, (size_t)lvx_tangent_size(c) * 8, st));
+      hipLaunchKernelGGL(k_plus, dim3((unsigned)((c->N + 1 + c->L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, c->N, c->L, c->locks, x, w.sums, 0, c->sensor_mto);
+    }
+    lerr = lvx_evaluate_d(c, x, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &cost);
+  }
   if ((rc = post_eval(c, w, true, o.jacobi_scaling, o.min_lm_diagonal, o.max_lm_diagonal, &cost, o.gradient_tolerance, &gconv, lerr))) return rc;
   s.initial_cost = cost;
   double radius = o.initial_radius, decrease_factor = 2.0;
@@ -1132,6 +1222,54 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
       cand_ne = true; acc_is_x = false;
       if (re == LVX_E_RANGE || re == LVX_E_NONUNIT_QUAT) cand = INFINITY; else if (re) lerr = re;   // a candidate that cannot be evaluated is a rejected step, anything else an error
       if (!lerr && hipMemcpy(h, w.sums + 2, 48, hipMemcpyDeviceToHost) != hipSuccess) lerr = LVX_E_HIP;
+      // projected Armijo line search (constrained single-sequence problem): the full step stays when it decreases the cost by 1e-4 of the linear prediction — the rule
+      if (!lerr && w.constrained && std::isfinite(cand) && m[0] < 0.0 && cand > cost + 1e-4 * m[0]) {
+        const double f0 = cost, g0 = m[0];
+        double g1 = 0.0;
+        if ((lerr = grad_dot(c, w, &g1))) return lerr;
+        LsSample prev{0, 0, 0, false}, cur{1.0, cand, g1, true};
+        bool have_prev = false, found = false;
+        double alpha = 1.0, fa = cand, ha[6] = {h[0], h[1], 0, 0, 0, 0};
+        const int ntg = lvx_tangent_size(c);
+        std::vector<double> dh((size_t)ntg);
+        LVX_HIP(c, hipMemcpyAsync(dh.data(), w.delta, (size_t)ntg * 8, hipMemcpyDeviceToHost, st));
+        LVX_HIP(c, hipStreamSynchronize(st));
+        std::vector<double> dt((size_t)ntg);
+        for (int trial = 1; trial <= 20 && !found; ++trial) {
+          std::vector<LsSample> sm{{0.0, f0, g0, true}};
+          if (have_prev) sm.push_back(prev);
+          sm.push_back(cur);
+          const double a = poly_argmin(poly_fit(sm), 1e-3 * cur.x, 0.6 * cur.x);
+          if (o.verbose) fprintf(stderr, "[lvx lm] it %3d line search trial %d: f0 %.12e g0 %.12e | last step %.6e f %.12e df %.12e -> step %.12e\n", it, trial, f0, g0, cur.x, cur.f, cur.df, a);
+          if (a < 1e-9) break;
+          for (int i = 0; i < ntg; ++i) dt[i] = a * dh[i];
+          LVX_HIP(c, hipMemcpyAsync(w.delta, dt.data(), (size_t)ntg * 8, hipMemcpyHostToDevice, st));
+          LVX_HIP(c, hipMemsetAsync(w.sums + 2, 0, 48, st));
+          hipLaunchKernelGGL(k_plus, dim3((unsigned)((N + 1 + L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, N, L, c->locks, xt, w.sums, 0, c->sensor_mto);
+          double f = 0;
+          const int re2 = lvx_evaluate_d(c, xt, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &f);
+          if (re2 == LVX_E_RANGE || re2 == LVX_E_NONUNIT_QUAT) { cur.x = a; continue; }   // a trial that cannot be evaluated: contract again without a new sample
+          if (re2) return re2;
+          if (f <= f0 + 1e-4 * a * g0) {
+            if (hipMemcpy(ha, w.sums + 2, 48, hipMemcpyDeviceToHost) != hipSuccess) return LVX_E_HIP;
+            alpha = a; fa = f; found = true; break;
+          }
+          double ga = 0.0;
+          LVX_HIP(c, hipMemcpyAsync(w.delta, dh.data(), (size_t)ntg * 8, hipMemcpyHostToDevice, st));   // directional derivative along the UNSCALED step
+          if ((lerr = grad_dot(c, w, &ga))) return lerr;
+          prev = cur; have_prev = true; cur = LsSample{a, f, ga, true};
+        }
+        if (found) { cand = fa; for (int q = 0; q < 6; ++q) h[q] = ha[q]; }   // delta (device) = alpha x the trust-region step, xt and the accumulators belong to it
+        else {   // no step satisfies Armijo: the full step stays (Ceres leaves delta alone) — put its candidate back
+          LVX_HIP(c, hipMemcpyAsync(w.delta, dh.data(), (size_t)ntg * 8, hipMemcpyHostToDevice, st));
+          LVX_HIP(c, hipMemsetAsync(w.sums + 2, 0, 48, st));
+          hipLaunchKernelGGL(k_plus, dim3((unsigned)((N + 1 + L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, N, L, c->locks, xt, w.sums, 0, c->sensor_mto);
+          const int re3 = lvx_evaluate_d(c, xt, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &cand);
+          if (re3) return re3;
+          if (hipMemcpy(h, w.sums + 2, 48, hipMemcpyDeviceToHost) != hipSuccess) return LVX_E_HIP;
+        }
+        (void)alpha;
+      }
       if (!lerr && std::isfinite(cand)) lerr = local_after_eval(c, w, &ev);   // the candidate's diagonal / gradient: used if the step is accepted (w.lmd, the damping of x, stays)
       r2[3] = cand; r2[4] = h[0]; r2[5] = h[1];
     }

@@ -187,7 +187,7 @@ def solve_step(H_lower, g, free, radius, scale, lm_diag=None, eblocks_free=None,
 
 
 def lm_solve(oracle, state, free, n_knots, n_landmarks, max_iterations=50, initial_radius=1e4, max_radius=1e16, min_radius=1e-32, min_relative_decrease=1e-3,
-             function_tolerance=1e-6, gradient_tolerance=1e-10, parameter_tolerance=1e-8, jacobi_scaling=True, force_sparse=False, verbose=False):
+             function_tolerance=1e-6, gradient_tolerance=1e-10, parameter_tolerance=1e-8, jacobi_scaling=True, force_sparse=False, verbose=False, sensor_mto=1e-3):
     """oracle/lm.py::lm_solve with the step from sparse linear algebra.  Same return value."""
     x = np.array(state, dtype=np.float64)
     free = np.asarray(free)
@@ -205,6 +205,9 @@ def lm_solve(oracle, state, free, n_knots, n_landmarks, max_iterations=50, initi
         timing["jacobian"] += t1 - t0; timing["product"] += time.perf_counter() - t1
         return ev["cost"], H, g
 
+    bnd = lm.bounded_scalars(n_knots, n_landmarks, free, sensor_mto)    # box constraints: Ceres' constrained-problem behaviour (oracle/lm.py header)
+    if bnd:
+        x = oracle.plus(x, np.zeros(oracle.tangent_size))
     cost, H, g = linearise(x)
     diagH = H.diagonal()
     scale = 1.0 / (1.0 + np.sqrt(np.maximum(diagH[free], 0.0))) if jacobi_scaling else np.ones(len(free))
@@ -214,7 +217,7 @@ def lm_solve(oracle, state, free, n_knots, n_landmarks, max_iterations=50, initi
     term = "max_iterations"
     it = 0
     invalid = 0
-    if np.abs(g[free]).max(initial=0.0) <= gradient_tolerance:
+    if lm.projected_gradient_max(x, g, free, bnd) <= gradient_tolerance:
         return x, dict(termination="gradient_tolerance", iterations=0, initial_cost=cost, final_cost=cost, **hist)
     init_cost = cost
     stats = {}
@@ -244,6 +247,20 @@ def lm_solve(oracle, state, free, n_knots, n_landmarks, max_iterations=50, initi
         except (IndexError, ValueError):
             cand = np.inf
         timing["cost"] += time.perf_counter() - t0
+        if bnd:      # projected Armijo line search on the trust-region step (TrustRegionMinimizer::DoLineSearch)
+            g0 = float(g @ delta)
+            if g0 < 0.0 and np.isfinite(cand) and cand > cost + 1e-4 * g0:
+                def eval_fg(a):
+                    try:
+                        e = oracle.jacobian_csr(oracle.plus(x, a * delta))
+                        return e["cost"], float((e["J"].T @ e["r"]) @ delta)
+                    except (IndexError, ValueError):
+                        return np.inf, 0.0
+                a, fa, _ = lm.projected_line_search(eval_fg, cost, g0, cand, eval_fg(1.0)[1])
+                if a != 1.0:
+                    delta = a * delta
+                    xc = oracle.plus(x, delta)
+                    cand = fa
         step_norm = np.linalg.norm((xc - x)[mask])
         x_norm = np.linalg.norm(x[mask])
         if step_norm <= parameter_tolerance * (x_norm + parameter_tolerance):
@@ -265,7 +282,7 @@ def lm_solve(oracle, state, free, n_knots, n_landmarks, max_iterations=50, initi
             dec = 2.0
             lm_diag = None
             hist["cost"].append(cost); hist["radius"].append(radius); hist["accepted"].append(1)
-            if np.abs(g[free]).max(initial=0.0) <= gradient_tolerance:
+            if lm.projected_gradient_max(x, g, free, bnd) <= gradient_tolerance:
                 term = "gradient_tolerance"
                 break
         else:

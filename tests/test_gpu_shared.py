@@ -188,7 +188,9 @@ def test_rccl_transport_single_rank_equals_plain_solve():
     box has — must reproduce the single-sequence solve; the multi-rank protocol is the one the callback transport tests above."""
     P, x0 = _sequences()[0]
     g = lvx.Context(0)
-    lvx.load_problem(g, P, TAU)
+    # inverse depths constant: with free ones the single-sequence solve is CONSTRAINED in Ceres' sense (projected line search, projected gradient norm — lvx_solver.hip,
+    # oracle/lm.py), the joint solve only projects its candidates, and the two legitimately part ways once a step gets contracted
+    lvx.load_problem(g, P, TAU | lvx.LOCK_LANDMARKS)
     xa, sa = g.lm_solve(x0, max_iterations=8)
     g.rccl_init(g.rccl_unique_id(), 0, 1)
     g.collective_count(reset=True)
@@ -211,7 +213,7 @@ def test_rccl_and_callback_transports_agree_on_one_rank():
     P, x0 = _sequences()[0]
     N = P["n_knots"]
     g = lvx.Context(0)
-    lvx.load_problem(g, P, TAU)
+    lvx.load_problem(g, P, TAU | lvx.LOCK_LANDMARKS)   # (free inverse depths would make the plain solve below a constrained one: see the test above)
     xa, sa = g.lm_solve_shared(x0, lambda buf, op: None, max_iterations=8)
     assert g.joint_shared_count() == 14
     g.rccl_init(g.rccl_unique_id(), 0, 1)

@@ -111,3 +111,41 @@ def test_box_constraints_are_enforced_by_projection():
     assert np.abs(sg["cost_history"] - so["cost_history"]).max() <= 1e-7 * so["cost_history"].max()
     assert xo[7 * N + 23] == 0.001 and xg[7 * N + 23] == 0.001          # at the bound exactly, on both
     g.close()
+
+
+def test_constrained_problem_line_search_and_bound_at_the_solution():
+    """Free inverse depths carry rho >= 0 (static_rscamera_measurement.h:184-185): the problem is constrained in Ceres' sense.  Landmarks at infinity whose noisy
+    observations want a NEGATIVE inverse depth: (i) a trust-region step that the projection clips no longer decreases the cost enough — the projected Armijo line search
+    contracts it, and GPU and oracle take the same contracted step (same accept sequence, same costs); (ii) those landmarks end ON the bound, on both sides, and the
+    projected gradient norm — not the raw one, which stays large there — is what the convergence test sees."""
+    P = synth.make_problem(seed=29, duration=2.0, n_surfel=800, n_planes=12, n_landmarks=30, n_camsurf=0)
+    locks = lvx.LOCK_LIDAR_TAU | lvx.LOCK_CAM_TAU
+    N, L = P["n_knots"], P["n_landmarks"]
+    free = lm.free_tangent_indices(N, L, locks)
+    rng = np.random.default_rng(7)
+    # five landmarks at infinity (true inverse depth 0): their observations are regenerated from the oracle's own prediction at rho = 0 plus pixel noise, so the
+    #      unconstrained optimum of each sits at 0 +- noise and about half of them want a negative inverse depth
+    Q = dict(P)
+    xt = P["state_true"].copy()
+    xt[7 * N + 32:7 * N + 32 + 5] = 0.0
+    ot = O.Oracle(); lvx.load_problem(ot, P, locks)
+    r = ot.evaluate(xt)["residuals"]
+    n_imu, n_surf = len(P["t_imu"]), len(P["surf_t"])
+    r_rep = r[6 * n_imu + n_surf:6 * n_imu + n_surf + 2 * len(P["rep_lm"])].reshape(-1, 2)
+    sel = np.isin(P["rep_lm"], np.arange(5))
+    uv = P["rep_uv"].copy()
+    uv[sel] = (P["rep_uv"][sel] - r_rep[sel] / P["w_rep"]) + 0.5 * rng.standard_normal((int(sel.sum()), 2))
+    Q["rep_uv"] = uv
+    o2 = O.Oracle(); g2 = lvx.Context(0)
+    for obj in (o2, g2):
+        lvx.load_problem(obj, Q, locks)
+    xo, so = lm.lm_solve(o2, P["state0"], free, max_iterations=25, n_knots=N, n_landmarks=L)
+    xg, sg = g2.lm_solve(P["state0"], max_iterations=25)
+    rho_o, rho_g = xo[7 * N + 32:7 * N + 32 + L], xg[7 * N + 32:7 * N + 32 + L]
+    print("rho at the solution (first 8): oracle", rho_o[:8], "gpu", rho_g[:8], so["termination"], sg["termination"], so["iterations"], sg["iterations"], "line search trials", so["line_search_trials"])
+    assert sum(so["line_search_trials"]) >= 1                  # the search really contracted a step
+    assert (rho_o >= 0).all() and (rho_g >= 0).all() and (rho_o == 0).any()
+    assert list(rho_o == 0) == list(rho_g == 0)
+    assert list(sg["accepted"]) == list(so["accepted"]) and sg["termination"] == so["termination"]
+    assert np.abs(sg["cost_history"] - so["cost_history"]).max() <= 1e-7 * so["cost_history"].max()
+    g2.close()
