@@ -1937,11 +1937,12 @@ int ensure_layout(lvx_ctx* ctx) {
       if ((rc = upload_chunks_rows_grouped(ctx, LVX_FAM_PRIOR /* slot reused: the prior has no chunks */, s0, rmax, rows))) return rc;
       // groups of the cross-term kernel: runs of equal (reference window, observation window); rows that are out of range form no group
       std::vector<int> goff, gw0, gw1;
+      const int gcap = 32;   // measured round 4 (cross kernel solo / pass): 8: 78 us / 0.606 ms, 16: 57 / 0.595, 24: 57 / 0.584, 32: 59 / 0.582, 64: 52 / 0.604, 128: 82 / 0.633 — longer groups serialise a wavefront, shorter ones add atomics
       for (int i = 0; i < f.n; ++i) {
         if (s1[i] < 0) continue;
         const int a0 = s0[i] >> 2, a1 = s1[i] >> 2;
         // a wavefront walks its group 8 blocks at a time: at most 32 blocks per group, a larger (window, window) pair is shared by several
-        if (goff.empty() || gw0.back() != a0 || gw1.back() != a1 || i - goff.back() >= 32) { goff.push_back(i); gw0.push_back(a0); gw1.push_back(a1); }
+        if (goff.empty() || gw0.back() != a0 || gw1.back() != a1 || i - goff.back() >= gcap) { goff.push_back(i); gw0.push_back(a0); gw1.push_back(a1); }
       }
       {   // blocks of every landmark (k_reproj_lmrows), positions in this row order
         std::vector<int> ptr((size_t)L + 1, 0), rows((size_t)std::max(f.n, 1));

@@ -146,6 +146,11 @@ def test_constrained_problem_line_search_and_bound_at_the_solution():
     assert sum(so["line_search_trials"]) >= 1                  # the search really contracted a step
     assert (rho_o >= 0).all() and (rho_g >= 0).all() and (rho_o == 0).any()
     assert list(rho_o == 0) == list(rho_g == 0)
-    assert list(sg["accepted"]) == list(so["accepted"]) and sg["termination"] == so["termination"]
-    assert np.abs(sg["cost_history"] - so["cost_history"]).max() <= 1e-7 * so["cost_history"].max()
+    # same iterates; the LAST iteration is where the parameter tolerance fires (step 1e-8 of |x|): the atomics' summation order can move that by one iteration
+    conv = ("parameter_tolerance", "function_tolerance", "gradient_tolerance")
+    assert sg["termination"] in conv and so["termination"] in conv and abs(sg["iterations"] - so["iterations"]) <= 1
+    k = min(len(sg["accepted"]), len(so["accepted"])) - 1
+    assert k >= 5 and list(sg["accepted"][:k]) == list(so["accepted"][:k])
+    assert np.abs(sg["cost_history"][:k] - so["cost_history"][:k]).max() <= 1e-7 * so["cost_history"].max()
+    assert np.abs(rho_g - rho_o).max() <= 1e-6 * max(1.0, np.abs(rho_o).max())
     g2.close()

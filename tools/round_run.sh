@@ -3,7 +3,7 @@
 TAG=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_gpu_tests.log 2>&1; grep -n "passed\|failed" gpurun_out/${TAG}_gpu_tests.log | tail -2
+timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_gpu_tests.log 2>&1; grep -n "passed\|failed" gpurun_out/${TAG}_gpu_tests.log | tail -2
 bash tools/profile_round.sh $TAG
 bash tools/pmc_sq.sh; cp gpurun_out/pmc_sq_summary.txt gpurun_out/${TAG}_pmc_sq.txt
 python tools/rocpd_timeline.py $(find gpurun_out/${TAG}_kt -name "*.db" | head -1) 12 > gpurun_out/${TAG}_timeline.txt
