@@ -432,8 +432,16 @@ __global__ __launch_bounds__(256) void k_sr_voxelgrid(const float4* cloud, const
 // ------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int f2ord(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }   // monotone float -> int
 __host__ __device__ __forceinline__ float ord2f(int i) { const int j = i >= 0 ? i : i ^ 0x7fffffff; float f; memcpy(&f, &j, 4); return f; }
-__global__ __launch_bounds__(256) void k_vx_minmax(const float4* p, int n, int* mm) {   // mm[0..2] = min (ordered ints), mm[3..5] = max
-  // per-thread over a grid-stride range, wavefront shuffles, one atomic per workgroup and bound (100 k threads on 6 addresses took 110 us)
+struct VxGrid { int min_b[3], max_b[3], div_b[3], mul[3]; float inv; };
+// What a build learns about its cloud, computed ON THE DEVICE (k_vx_extent, k_vx_leaf) and mirrored to pinned host memory behind the last kernel: the host reads it
+// when somebody needs it (vox_info), never in the middle of the kernel chain — round 3 stopped the chain twice (extents -> size of the cell table; leaf count -> strides of
+// the leaf arrays).  overflow: 1 = the dense cell table (capacity cells_cap) is too small for this cloud's extents (the host grows it and builds again), 2 = more than
+// 2^31 - 1 cells (the reference's "Leaf size is too small" error, voxel_grid_covariance_omp_impl.hpp:80-85).
+struct VxInfo { VxGrid g; int n_leaves, overflow; long long cells; };
+// extents + grid geometry (:86-95) in ONE launch: per-thread min / max over a grid-stride range, wavefront shuffles, one atomic per workgroup and bound; the LAST workgroup
+// to finish (ticket) turns the extents into the grid geometry and leaves mm[] in its start state for the next build (mm = 3 x INT_MAX | 3 x INT_MIN | ticket 0, set when
+// the buffer is allocated).  Was three launches of ~4.6 us each (k_vx_init, k_vx_minmax, k_vx_grid): a launch of a captured graph costs that much whatever it does.
+__global__ __launch_bounds__(256) void k_vx_extent(const float4* p, int n, int* mm, float leaf, long long cells_cap, VxInfo* info) {
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float4 q = p[i];
@@ -443,6 +451,7 @@ __global__ __launch_bounds__(256) void k_vx_minmax(const float4* p, int n, int* 
   }
   for (int s = 32; s > 0; s >>= 1) for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], __shfl_xor(lo[a], s)); hi[a] = max(hi[a], __shfl_xor(hi[a], s)); }
   __shared__ int red[4][6];
+  __shared__ int s_last;
   if ((threadIdx.x & 63) == 0) for (int a = 0; a < 3; ++a) { red[threadIdx.x >> 6][a] = lo[a]; red[threadIdx.x >> 6][3 + a] = hi[a]; }
   __syncthreads();
   if (threadIdx.x < 6) {
@@ -450,43 +459,38 @@ __global__ __launch_bounds__(256) void k_vx_minmax(const float4* p, int n, int* 
     for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? min(v, red[w][threadIdx.x]) : max(v, red[w][threadIdx.x]);
     if (threadIdx.x < 3) atomicMin(&mm[threadIdx.x], v); else atomicMax(&mm[threadIdx.x], v);
   }
-}
-struct VxGrid { int min_b[3], max_b[3], div_b[3], mul[3]; float inv; };
-// What a build learns about its cloud, computed ON THE DEVICE (k_vx_grid, k_vx_leaf) and mirrored to pinned host memory behind the last kernel: the host reads it
-// when somebody needs it (vox_info), never in the middle of the kernel chain — round 3 stopped the chain twice (extents -> size of the cell table; leaf count -> strides of
-// the leaf arrays).  overflow: 1 = the dense cell table (capacity cells_cap) is too small for this cloud's extents (the host grows it and builds again), 2 = more than
-// 2^31 - 1 cells (the reference's "Leaf size is too small" error, voxel_grid_covariance_omp_impl.hpp:80-85).
-struct VxInfo { VxGrid g; int n_leaves, overflow; long long cells; };
-__global__ void k_vx_init(int* mm, VxInfo* info) {
-  if (threadIdx.x < 3) mm[threadIdx.x] = 0x7fffffff; else if (threadIdx.x < 6) mm[threadIdx.x] = (int)0x80000000;
-  if (threadIdx.x == 0) { info->n_leaves = 0; info->overflow = 0; info->cells = 0; }
-}
-__global__ void k_vx_grid(const int* mm, float leaf, long long cells_cap, VxInfo* info) {   // one thread: :86-95
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(&mm[6], 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!s_last || threadIdx.x != 0) return;
+  int e[6];
+  for (int k = 0; k < 6; ++k) e[k] = atomicExch(&mm[k], k < 3 ? 0x7fffffff : (int)0x80000000);   // read at the L2 and reset
+  atomicExch(&mm[6], 0);
   VxGrid g;
   g.inv = 1.0f / leaf;
-  const bool empty = mm[0] == 0x7fffffff;
+  const bool empty = e[0] == 0x7fffffff;
   for (int k = 0; k < 3; ++k) {
-    g.min_b[k] = empty ? 0 : (int)floorf(ord2f(mm[k]) * g.inv); g.max_b[k] = empty ? -1 : (int)floorf(ord2f(mm[3 + k]) * g.inv);
+    g.min_b[k] = empty ? 0 : (int)floorf(ord2f(e[k]) * g.inv); g.max_b[k] = empty ? -1 : (int)floorf(ord2f(e[3 + k]) * g.inv);
     g.div_b[k] = g.max_b[k] - g.min_b[k] + 1;
   }
   const long long cells = (long long)g.div_b[0] * g.div_b[1] * g.div_b[2];
   g.mul[0] = 1; g.mul[1] = g.div_b[0]; g.mul[2] = g.div_b[0] * g.div_b[1];
-  info->g = g; info->cells = cells;
+  info->g = g; info->cells = cells; info->n_leaves = 0;
   info->overflow = cells > 2147483647LL ? 2 : (cells > cells_cap ? 1 : 0);
 }
-__global__ void k_vx_cells_clear(int* cells, const VxInfo* info) {
-  if (info->overflow) return;
-  const long long n = info->cells;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) cells[i] = -1;
-}
-// keys: the voxel's linear index, or `invalid` (> every valid key, inside the sorted bit range) for non-finite points
-__global__ void k_vx_keys(const float4* p, int n, const VxInfo* info, unsigned invalid, unsigned* keys, int* vals) {
+// keys: the voxel's linear index, or `invalid` (> every valid key, inside the sorted bit range) for non-finite points; the same launch empties the part of the dense cell
+// table this cloud's extents span and resets the look-back states of k_vx_leaf (one per tile of 256 sorted positions)
+__global__ __launch_bounds__(256) void k_vx_keys(const float4* p, int n, const VxInfo* info, unsigned invalid, unsigned* keys, int* vals, int* cells, unsigned long long* lb, int n_tiles) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool ovf = info->overflow != 0;
+  if (!ovf) { const long long nc = info->cells; for (long long e = i; e < nc; e += (long long)gridDim.x * blockDim.x) cells[e] = -1; }
+  if (i < n_tiles) lb[i] = 0ull;
   if (i >= n) return;
   const VxGrid g = info->g;
   const float4 q = p[i];
   unsigned k = invalid;
-  if (!info->overflow && isfinite(q.x) && isfinite(q.y) && isfinite(q.z)) {
+  if (!ovf && isfinite(q.x) && isfinite(q.y) && isfinite(q.z)) {
     const int i0 = (int)(floorf(q.x * g.inv) - (float)g.min_b[0]);   // :220-222
     const int i1 = (int)(floorf(q.y * g.inv) - (float)g.min_b[1]);
     const int i2 = (int)(floorf(q.z * g.inv) - (float)g.min_b[2]);
@@ -494,17 +498,21 @@ __global__ void k_vx_keys(const float4* p, int n, const VxInfo* info, unsigned i
   }
   keys[i] = k; vals[i] = i;
 }
-__device__ void vx_eig3(const double A[9], double ev[3], double V[9]) {   // cyclic Jacobi, ascending eigenvalues (Eigen SelfAdjointEigenSolver stand-in)
+// cyclic Jacobi, ascending eigenvalues (Eigen SelfAdjointEigenSolver stand-in).  EARLY: stop once the off-diagonal part is below 1e-18 of the diagonal (further sweeps
+// rotate by angles that no longer change a double: the oracle's loop runs 2-3 more of them until the squares underflow) and take c from one rsqrt instead of sqrt + division.
+template <bool EARLY>
+__device__ void vx_eig3(const double A[9], double ev[3], double V[9]) {
   double a[3][3] = {{A[0], A[1], A[2]}, {A[3], A[4], A[5]}, {A[6], A[7], A[8]}};
   double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
   for (int sweep = 0; sweep < 60; ++sweep) {
     const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
     if (off < 1e-300) break;
+    if (EARLY && off <= 1e-36 * (a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2])) break;
     for (int p = 0; p < 2; ++p) for (int q = p + 1; q < 3; ++q) {
       if (a[p][q] == 0.0) continue;
       const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
       const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-      const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+      const double c = EARLY ? rsqrt(t * t + 1.0) : 1.0 / sqrt(t * t + 1.0), s = t * c;
       for (int k = 0; k < 3; ++k) { const double akp = a[k][p], akq = a[k][q]; a[k][p] = c * akp - s * akq; a[k][q] = s * akp + c * akq; }
       for (int k = 0; k < 3; ++k) { const double apk = a[p][k], aqk = a[q][k]; a[p][k] = c * apk - s * aqk; a[q][k] = s * apk + c * aqk; }
       for (int k = 0; k < 3; ++k) { const double vkp = v[k][p], vkq = v[k][q]; v[k][p] = c * vkp - s * vkq; v[k][q] = s * vkp + c * vkq; }
@@ -516,67 +524,140 @@ __device__ void vx_eig3(const double A[9], double ev[3], double V[9]) {   // cyc
   const int idx[3] = {i0, i1, i2};
   for (int k = 0; k < 3; ++k) { ev[k] = a[idx[k]][idx[k]]; for (int r = 0; r < 3; ++r) V[3 * r + k] = v[r][idx[k]]; }
 }
-// one thread per leaf: sums over the leaf's (stable-sorted) points IN INPUT ORDER — cov = (sum x x^T - 2 sum x mu^T) / n + mu mu^T cancels ~6 digits
-// (coordinates of tens of metres, spreads of centimetres), so only the reference's summation order reproduces it to 1e-12 of its own scale; the float
-// centroid is compared bit for bit — then the finalize of :286-371.  The points are scattered: 8 indices, then 8 points, are in flight at a time
-// (one dependent load per point made this kernel 79 us for 12 k leaves).
-__global__ void k_vx_leaf(const float4* __restrict__ p, const unsigned* ukeys, const unsigned* counts, const unsigned* offs, const int* __restrict__ sorted_ids, const unsigned* d_nruns, unsigned invalid,
-                          int min_pts, double eig_mult, VxInfo* info, int* grid, int* leaf_key, int* leaf_n, double* mean, double* cov, double* icov, double* evecs, double* evals, float* centroid) {
-  const int li = blockIdx.x * blockDim.x + threadIdx.x;
-  const int nruns = (int)*d_nruns;
-  const int nl = info->overflow ? 0 : nruns - ((nruns > 0 && ukeys[nruns - 1] == invalid) ? 1 : 0);   // the last run may be the invalid-key bucket (non-finite points)
-  if (li == 0) info->n_leaves = nl;
-  if (li >= nl) return;
-  const unsigned key = ukeys[li];
-  const int n = (int)counts[li];
-  const int o = (int)offs[li];
-  double s[3] = {0, 0, 0}, c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  float cen[3] = {0, 0, 0};
-  for (int k0 = 0; k0 < n; k0 += 8) {
-    int id[8]; float4 q[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) id[u] = sorted_ids[o + min(k0 + u, n - 1)];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) q[u] = p[id[u]];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (k0 + u >= n) break;
-      const double x[3] = {q[u].x, q[u].y, q[u].z};
-      for (int a = 0; a < 3; ++a) { s[a] += x[a]; for (int b = 0; b < 3; ++b) c[3 * a + b] += x[a] * x[b]; }
-      cen[0] += q[u].x; cen[1] += q[u].y; cen[2] += q[u].z;
+// Leaves from the (stable-)sorted keys in ONE launch — run heads, leaf numbering, point lists, sums, eigen-solve, finalize (:286-371).  A workgroup owns a TILE of 256
+// sorted positions and the leaves whose first point lies in it:
+//   * head = position whose key differs from its predecessor's; the number of heads before the tile comes from a decoupled look-back over the tiles' published counts
+//     (one 64-bit word per tile: flag | count, wavefront 0 looks at 64 predecessors per step) — this replaced rocPRIM's run-length encode + exclusive scan (four launches);
+//   * the sorted ids and points of the tile's leaves are one contiguous range: all 256 threads fetch it (coalesced ids, one gather) into LDS, 1 024 points at a time —
+//     the thread-per-leaf loop of round 3 paid two dependent HBM round trips per 8 points of its LONGEST leaf (35-50 % of that kernel);
+//   * thread r < #heads then sums ITS leaf's points from LDS in input order: cov = (sum x x^T - 2 sum x mu^T) / n + mu mu^T cancels ~6 digits (coordinates of tens of
+//     metres, spreads of centimetres), so only the reference's summation order reproduces it to 1e-12 of its own scale; the float centroid is compared bit for bit.
+#define VX_STAGE 1024
+__device__ __forceinline__ unsigned long long vx_lb_load(const unsigned long long* a) { return __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void vx_lb_store(unsigned long long* a, unsigned long long v) { __hip_atomic_store(a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ __launch_bounds__(256) void k_vx_leaf(const float4* __restrict__ p, const unsigned* __restrict__ skeys, const int* __restrict__ sorted_ids, int n_pts, unsigned invalid, unsigned long long* lb,
+                                                 int min_pts, double eig_mult, VxInfo* info, int* grid, int* leaf_key, int* leaf_n, unsigned* counts, unsigned* offs,
+                                                 double* mean, double* cov, double* icov, double* evecs, double* evals, float* centroid) {
+  __shared__ float4 pts[VX_STAGE];
+  __shared__ int hpos[257];
+  __shared__ int wcnt[4];
+  __shared__ int s_prefix, s_end;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
+  const int tile0 = b * 256, i = tile0 + tid;
+  const bool ovf = info->overflow != 0;
+  const unsigned key_i = i < n_pts ? skeys[i] : invalid;
+  const bool head = !ovf && key_i != invalid && (i == 0 || skeys[i - 1] != key_i);
+  const unsigned long long hm = __ballot(head);
+  if (lane == 0) wcnt[wv] = __popcll(hm);
+  __syncthreads();
+  const int hb = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+  int rank = __popcll(hm & ((1ull << lane) - 1ull));
+  for (int w = 0; w < wv; ++w) rank += wcnt[w];
+  if (head) hpos[rank] = i;
+  // leaves before this tile
+  if (wv == 0) {
+    if (lane == 0) vx_lb_store(&lb[b], ((b == 0 ? 2ull : 1ull) << 32) | (unsigned)hb);
+    int prefix = 0;
+    if (b > 0) {
+      for (int base = b - 1;; base -= 64) {
+        const int j = base - lane;
+        unsigned long long v = 2ull << 32;
+        if (j >= 0) do { v = vx_lb_load(&lb[j]); } while ((v >> 32) == 0ull);
+        const unsigned long long incl = __ballot((v >> 32) == 2ull);
+        const int first = incl ? __ffsll((long long)incl) - 1 : 63;
+        int val = lane <= first ? (int)(unsigned)(v & 0xffffffffull) : 0;
+        for (int o = 32; o > 0; o >>= 1) val += __shfl_xor(val, o);
+        prefix += val;
+        if (incl) break;
+      }
+      if (lane == 0) vx_lb_store(&lb[b], (2ull << 32) | (unsigned)(prefix + hb));
+    }
+    if (lane == 0) { s_prefix = prefix; s_end = -1; if (b == (int)gridDim.x - 1) info->n_leaves = prefix + hb; }
+  }
+  __syncthreads();
+  if (hb == 0) return;
+  // end of the tile's last leaf: the first position behind the tile with another key
+  {
+    const int lasthead = hpos[hb - 1];
+    const unsigned lastkey = skeys[lasthead];
+    for (int pos = tile0;; pos += 256) {   // (from inside the tile: the invalid-key run of the non-finite points may begin there)
+      const int j = pos + tid;
+      const bool stop = j > lasthead && (j >= n_pts || skeys[j] != lastkey);
+      const unsigned long long sm = __ballot(stop);
+      if (lane == 0) wcnt[wv] = sm ? __ffsll((long long)sm) - 1 : 64;
+      __syncthreads();
+      int e = -1;
+      for (int w = 3; w >= 0; --w) if (wcnt[w] < 64) e = pos + 64 * w + wcnt[w];
+      __syncthreads();
+      if (e >= 0) { if (tid == 0) { s_end = min(e, n_pts); hpos[hb] = min(e, n_pts); } break; }
     }
   }
+  __syncthreads();
+  const int S = hpos[0], E = s_end;
+  const bool mine = tid < hb;
+  const int la = mine ? hpos[tid] : 0, le = mine ? hpos[tid + 1] : 0, n = le - la;
+  double s[3] = {0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};   // xx xy xz yy yz zz (x_a x_b == x_b x_a bit for bit)
+  float cen[3] = {0, 0, 0};
+  for (int c0 = S; c0 < E; c0 += VX_STAGE) {
+    int id[VX_STAGE / 256];
+#pragma unroll
+    for (int u = 0; u < VX_STAGE / 256; ++u) { const int j = c0 + tid + 256 * u; id[u] = j < E ? sorted_ids[j] : -1; }
+#pragma unroll
+    for (int u = 0; u < VX_STAGE / 256; ++u) if (id[u] >= 0) pts[tid + 256 * u] = p[id[u]];
+    __syncthreads();
+    if (mine) {
+      const int k0 = max(la, c0), k1 = min(le, c0 + VX_STAGE);
+      for (int k = k0; k < k1; ++k) {
+        const float4 q = pts[k - c0];
+        const double x = q.x, y = q.y, z = q.z;
+        s[0] += x; s[1] += y; s[2] += z;
+        c[0] += x * x; c[1] += x * y; c[2] += x * z; c[3] += y * y; c[4] += y * z; c[5] += z * z;
+        cen[0] += q.x; cen[1] += q.y; cen[2] += q.z;
+      }
+    }
+    __syncthreads();
+  }
+  if (!mine) return;
+  const int li = s_prefix + tid;
+  const unsigned key = skeys[la];
   leaf_key[li] = (int)key;
   grid[key] = li;
+  counts[li] = (unsigned)n; offs[li] = (unsigned)la;
   double* M = mean + 3 * (size_t)li; double* Cv = cov + 9 * (size_t)li; double* IC = icov + 9 * (size_t)li; double* EV = evecs + 9 * (size_t)li; double* EL = evals + 3 * (size_t)li;
-  for (int a = 0; a < 3; ++a) { centroid[3 * (size_t)li + a] = cen[a] / (float)n; M[a] = s[a] / n; EL[a] = 0.0; }
-  for (int a = 0; a < 9; ++a) { Cv[a] = (a % 4 == 0) ? 1.0 : 0.0; IC[a] = 0.0; EV[a] = (a % 4 == 0) ? 1.0 : 0.0; }
+  double mu[3];
+  for (int a = 0; a < 3; ++a) { centroid[3 * (size_t)li + a] = cen[a] / (float)n; mu[a] = s[a] / n; M[a] = mu[a]; }
   int nr = n;
-  if (n >= min_pts) {
+  if (n < min_pts) {
+    for (int a = 0; a < 3; ++a) EL[a] = 0.0;
+    for (int a = 0; a < 9; ++a) { Cv[a] = (a % 4 == 0) ? 1.0 : 0.0; IC[a] = 0.0; EV[a] = (a % 4 == 0) ? 1.0 : 0.0; }
+  } else {
+    const double cs[9] = {c[0], c[1], c[2], c[1], c[3], c[4], c[2], c[4], c[5]};
     double C[9];
-    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[3 * a + b] = (c[3 * a + b] - 2 * (s[a] * M[b])) / n + M[a] * M[b];
+    for (int a = 0; a < 3; ++a) for (int bb = 0; bb < 3; ++bb) C[3 * a + bb] = (cs[3 * a + bb] - 2 * (s[a] * mu[bb])) / n + mu[a] * mu[bb];
     for (int a = 0; a < 9; ++a) C[a] *= (n - 1.0) / n;
     double ev[3], V[9];
-    vx_eig3(C, ev, V);
+    vx_eig3<true>(C, ev, V);
     for (int a = 0; a < 9; ++a) EV[a] = V[a];
-    if (ev[0] < 0 || ev[1] < 0 || ev[2] <= 0) { nr = -1; for (int a = 0; a < 9; ++a) Cv[a] = C[a]; }
+    double el[3] = {0.0, 0.0, 0.0}, ic[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (ev[0] < 0 || ev[1] < 0 || ev[2] <= 0) nr = -1;
     else {
       const double min_ev = eig_mult * ev[2];
       if (ev[0] < min_ev) {
         ev[0] = min_ev; if (ev[1] < min_ev) ev[1] = min_ev;
-        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[3 * a + b] = V[3 * a] * ev[0] * V[3 * b] + V[3 * a + 1] * ev[1] * V[3 * b + 1] + V[3 * a + 2] * ev[2] * V[3 * b + 2];
+        for (int a = 0; a < 3; ++a) for (int bb = 0; bb < 3; ++bb) C[3 * a + bb] = V[3 * a] * ev[0] * V[3 * bb] + V[3 * a + 1] * ev[1] * V[3 * bb + 1] + V[3 * a + 2] * ev[2] * V[3 * bb + 2];
       }
-      for (int a = 0; a < 3; ++a) EL[a] = ev[a];
-      for (int a = 0; a < 9; ++a) Cv[a] = C[a];
+      for (int a = 0; a < 3; ++a) el[a] = ev[a];
       const double c00 = C[4] * C[8] - C[5] * C[7], c01 = C[5] * C[6] - C[3] * C[8], c02 = C[3] * C[7] - C[4] * C[6];
       const double id = 1.0 / (C[0] * c00 + C[1] * c01 + C[2] * c02);
-      IC[0] = c00 * id; IC[1] = (C[2] * C[7] - C[1] * C[8]) * id; IC[2] = (C[1] * C[5] - C[2] * C[4]) * id;
-      IC[3] = c01 * id; IC[4] = (C[0] * C[8] - C[2] * C[6]) * id; IC[5] = (C[2] * C[3] - C[0] * C[5]) * id;
-      IC[6] = c02 * id; IC[7] = (C[1] * C[6] - C[0] * C[7]) * id; IC[8] = (C[0] * C[4] - C[1] * C[3]) * id;
-      double mxv = IC[0], mnv = IC[0];
-      for (int a = 1; a < 9; ++a) { mxv = fmax(mxv, IC[a]); mnv = fmin(mnv, IC[a]); }
+      ic[0] = c00 * id; ic[1] = (C[2] * C[7] - C[1] * C[8]) * id; ic[2] = (C[1] * C[5] - C[2] * C[4]) * id;
+      ic[3] = c01 * id; ic[4] = (C[0] * C[8] - C[2] * C[6]) * id; ic[5] = (C[2] * C[3] - C[0] * C[5]) * id;
+      ic[6] = c02 * id; ic[7] = (C[1] * C[6] - C[0] * C[7]) * id; ic[8] = (C[0] * C[4] - C[1] * C[3]) * id;
+      double mxv = ic[0], mnv = ic[0];
+      for (int a = 1; a < 9; ++a) { mxv = fmax(mxv, ic[a]); mnv = fmin(mnv, ic[a]); }
       if (mxv == (double)INFINITY || mnv == -(double)INFINITY) nr = -1;
     }
+    for (int a = 0; a < 3; ++a) EL[a] = el[a];
+    for (int a = 0; a < 9; ++a) { Cv[a] = C[a]; IC[a] = ic[a]; }
   }
   leaf_n[li] = nr;
 }
@@ -699,7 +780,7 @@ __global__ void k_surfel_extract(const float4* p, const unsigned* counts, const 
     double C[9];
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[3 * a + b] = cc[3 * a + b] / nin - mu[a] * mu[b];
     double e2[3], V2[9];
-    vx_eig3(C, e2, V2);
+    vx_eig3<false>(C, e2, V2);
     nrm[0] = V2[0]; nrm[1] = V2[3]; nrm[2] = V2[6];
     d = -(nrm[0] * mu[0] + nrm[1] * mu[1] + nrm[2] * mu[2]);
   }
@@ -1167,9 +1248,9 @@ int lvx_scan_register_batch(lvx_ctx* c, int n_sweeps, const int32_t* sweep_offse
   return scan_register_batch(c, n_sweeps, sweep_offsets, pts, n_rings, min_range, outs);
 }
 
-// voxel grid kept on the device in the context.  The whole build is ONE chain of launches without a host hop (k_vx_init -> extents -> grid geometry -> cell-table clear ->
-// keys -> rocPRIM radix sort / run-length encode / scan -> leaves), captured once per (cloud buffer, size, parameters) into a HIP graph and replayed: ten small kernels are
-// bound by launch latency, not by HBM.  Leaf arrays are strided by the CAPACITY (the point count: a leaf holds at least one point), the dense cell table by its own capacity.
+// voxel grid kept on the device in the context.  The whole build is ONE chain of launches without a host hop (k_vx_extent: extents + grid geometry -> k_vx_keys: cell-table
+// clear + keys -> rocPRIM radix sort -> k_vx_leaf: run heads, leaf numbering, sums, eigen-solve), captured once per (cloud buffer, size, parameters) into a HIP graph and
+// replayed: a small cloud's build is bound by the NUMBER of launches (~4.6 us each in a replayed graph), not by HBM.  Leaf arrays are strided by the CAPACITY (the point count: a leaf holds at least one point), the dense cell table by its own capacity.
 static int vox_info(lvx_ctx* c);
 static int voxel_enqueue(lvx_ctx* c, const float4* d_pts, int n, float leaf, int min_pts, double eig_mult) {
   hipStream_t st = c->stream;
@@ -1178,22 +1259,19 @@ static int voxel_enqueue(lvx_ctx* c, const float4* d_pts, int n, float leaf, int
   VxInfo* d_info = (VxInfo*)((char*)V.misc.p + 64);
   unsigned* k_in = (unsigned*)V.keys.p; unsigned* k_out = k_in + n;
   int* v_in = (int*)V.vals.p; int* v_out = v_in + n;
-  unsigned* ukeys = (unsigned*)V.runs.p; unsigned* counts = ukeys + n; unsigned* offs = counts + n; unsigned* d_nruns = offs + n;
+  unsigned* counts = (unsigned*)V.runs.p + n; unsigned* offs = counts + n;   // ([0, n) unused since the run-length encode left)
+  unsigned long long* lbs = (unsigned long long*)((unsigned*)V.runs.p + (((size_t)n * 3 + 1) & ~(size_t)1));   // look-back states of k_vx_leaf, one per tile
   const size_t cap = (size_t)V.cap;
-  hipLaunchKernelGGL(k_vx_init, dim3(1), dim3(64), 0, st, d_mm, d_info);
-  hipLaunchKernelGGL(k_vx_minmax, dim3((unsigned)std::min((n + 255) / 256, 1024)), dim3(256), 0, st, d_pts, n, d_mm);
-  hipLaunchKernelGGL(k_vx_grid, dim3(1), dim3(1), 0, st, (const int*)d_mm, leaf, (long long)V.cells_cap, d_info);
-  hipLaunchKernelGGL(k_vx_cells_clear, dim3((unsigned)std::min<long long>((V.cells_cap + 1023) / 1024, 2048)), dim3(256), 0, st, (int*)V.cells.p, (const VxInfo*)d_info);
+  const int n_tiles = (n + 255) / 256;
+  hipLaunchKernelGGL(k_vx_extent, dim3((unsigned)std::min(std::max(n / 4096, 64), 1024)), dim3(256), 0, st, d_pts, n, d_mm, leaf, (long long)V.cells_cap, d_info);   // few workgroups: every one ends in 7 same-address atomics (391 of them took 25 us)
   const unsigned invalid = (1u << V.sort_bits) - 1u;
-  hipLaunchKernelGGL(k_vx_keys, dim3((n + 255) / 256), dim3(256), 0, st, d_pts, n, (const VxInfo*)d_info, invalid, k_in, v_in);
-  size_t t1 = V.tmp_bytes[0], t2 = V.tmp_bytes[1], t3 = V.tmp_bytes[2];
+  hipLaunchKernelGGL(k_vx_keys, dim3((unsigned)std::max(n_tiles, 512)), dim3(256), 0, st, d_pts, n, (const VxInfo*)d_info, invalid, k_in, v_in, (int*)V.cells.p, lbs, n_tiles);
+  size_t t1 = V.tmp_bytes[0];
   LVX_HIP(c, rocprim::radix_sort_pairs(V.tmp.p, t1, k_in, k_out, v_in, v_out, (size_t)n, 0, (unsigned)V.sort_bits, st));   // stable: input order kept inside a leaf
-  LVX_HIP(c, rocprim::run_length_encode(V.tmp.p, t2, k_out, (size_t)n, ukeys, counts, d_nruns, st));
-  LVX_HIP(c, rocprim::exclusive_scan(V.tmp.p, t3, counts, offs, 0u, (size_t)n, rocprim::plus<unsigned>(), st));   // over all n slots: a prefix only depends on the runs before it
   int* lk = (int*)V.leaf_i.p; int* ln = lk + cap;
   double* mean = (double*)V.leaf_d.p; double* cov = mean + 3 * cap; double* icov = cov + 9 * cap; double* evecs = icov + 9 * cap; double* evals = evecs + 9 * cap;
-  hipLaunchKernelGGL(k_vx_leaf, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_pts, (const unsigned*)ukeys, (const unsigned*)counts, (const unsigned*)offs, (const int*)v_out, (const unsigned*)d_nruns, invalid,
-                     min_pts, eig_mult, d_info, (int*)V.cells.p, lk, ln, mean, cov, icov, evecs, evals, (float*)V.leaf_f.p);
+  hipLaunchKernelGGL(k_vx_leaf, dim3((unsigned)n_tiles), dim3(256), 0, st, d_pts, (const unsigned*)k_out, (const int*)v_out, n, invalid, lbs, min_pts, eig_mult, d_info, (int*)V.cells.p, lk, ln,
+                     counts, offs, mean, cov, icov, evecs, evals, (float*)V.leaf_f.p);
   LVX_HIP(c, hipMemcpyAsync(V.h_info, d_info, sizeof(VxInfo), hipMemcpyDeviceToHost, st));
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
@@ -1209,23 +1287,26 @@ static int voxel_build_device(lvx_ctx* c, const float4* d_pts, int n, float leaf
   if (V.cells_cap < (1 << 22)) V.cells_cap = 1 << 22;   // 4 M cells (16 MB): a 100 m x 100 m x 100 m map at 0.5 m; grown on demand (vox_info)
   int bits = 1; while ((1ll << bits) - 1 < V.cells_cap + 1 && bits < 32) ++bits;   // keys < cells <= capacity, the invalid key = 2^bits - 1 above them
   V.sort_bits = bits;
-  if ((rc = dev_alloc(c, V.misc, 64 + sizeof(VxInfo)))) return rc;
+  if (!V.misc.p) {   // extents in their start state (k_vx_extent's last workgroup restores it after every build)
+    if ((rc = dev_alloc(c, V.misc, 64 + sizeof(VxInfo)))) return rc;
+    const int mm0[7] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0};
+    LVX_HIP(c, hipMemcpyAsync(V.misc.p, mm0, sizeof(mm0), hipMemcpyHostToDevice, st));
+    LVX_HIP(c, hipStreamSynchronize(st));
+  }
   if ((rc = dev_alloc(c, V.keys, (size_t)n * 4 * 2))) return rc;
   if ((rc = dev_alloc(c, V.vals, (size_t)n * 4 * 2))) return rc;
-  if ((rc = dev_alloc(c, V.runs, ((size_t)n * 3 + 8) * 4))) return rc;
+  if ((rc = dev_alloc(c, V.runs, ((size_t)n * 3 + 2 + 2 * (((size_t)n + 255) / 256) + 8) * 4))) return rc;
   if ((rc = dev_alloc(c, V.cells, (size_t)V.cells_cap * 4))) return rc;
   V.cap = n;
   if ((rc = dev_alloc(c, V.leaf_i, (size_t)n * 2 * 4))) return rc;
   if ((rc = dev_alloc(c, V.leaf_d, (size_t)n * 33 * 8))) return rc;
   if ((rc = dev_alloc(c, V.leaf_f, (size_t)n * 3 * 4))) return rc;
   {
-    unsigned* k_in = (unsigned*)V.keys.p; int* v_in = (int*)V.vals.p; unsigned* ukeys = (unsigned*)V.runs.p;
-    size_t t1 = 0, t2 = 0, t3 = 0;
+    unsigned* k_in = (unsigned*)V.keys.p; int* v_in = (int*)V.vals.p;
+    size_t t1 = 0;
     LVX_HIP(c, rocprim::radix_sort_pairs(nullptr, t1, k_in, k_in + n, v_in, v_in + n, (size_t)n, 0, (unsigned)V.sort_bits, st));
-    LVX_HIP(c, rocprim::run_length_encode(nullptr, t2, k_in + n, (size_t)n, ukeys, ukeys + n, ukeys + 3 * (size_t)n, st));
-    LVX_HIP(c, rocprim::exclusive_scan(nullptr, t3, ukeys + n, ukeys + 2 * (size_t)n, 0u, (size_t)n, rocprim::plus<unsigned>(), st));
-    V.tmp_bytes[0] = t1; V.tmp_bytes[1] = t2; V.tmp_bytes[2] = t3;
-    if ((rc = dev_alloc(c, V.tmp, std::max(t1, std::max(t2, t3)) + 16))) return rc;
+    V.tmp_bytes[0] = t1;
+    if ((rc = dev_alloc(c, V.tmp, t1 + 16))) return rc;
   }
   // replay the captured chain when nothing it was captured with has changed
   uint64_t lb = 0, eb = 0; std::memcpy(&lb, &leaf, 4); std::memcpy(&eb, &eig_mult, 8);
