@@ -443,25 +443,39 @@ struct VxInfo { VxGrid g; int n_leaves, overflow; long long cells; };
 // the buffer is allocated).  Was three launches of ~4.6 us each (k_vx_init, k_vx_minmax, k_vx_grid): a launch of a captured graph costs that much whatever it does.
 __global__ __launch_bounds__(256) void k_vx_extent(const float4* p, int n, int* mm, float leaf, long long cells_cap, VxInfo* info) {
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const float4 q = p[i];
-    if (!isfinite(q.x) || !isfinite(q.y) || !isfinite(q.z)) continue;
+  // at most 256 workgroups (every one ends in same-address traffic at the memory side: 976 of them took 80-90 us at 4 M points, 256 take 45), four loads in flight per thread
+  const int stride = gridDim.x * blockDim.x;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  auto upd = [&](const float4 q) {
+    if (!isfinite(q.x) || !isfinite(q.y) || !isfinite(q.z)) return;
     const int o[3] = {f2ord(q.x), f2ord(q.y), f2ord(q.z)};
     for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], o[a]); hi[a] = max(hi[a], o[a]); }
+  };
+  for (; (long long)i + 3ll * stride < n; i += 4 * stride) {
+    const float4 q0 = p[i], q1 = p[i + stride], q2 = p[i + 2 * stride], q3 = p[i + 3 * stride];
+    upd(q0); upd(q1); upd(q2); upd(q3);
   }
+  for (; i < n; i += stride) upd(p[i]);
   for (int s = 32; s > 0; s >>= 1) for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], __shfl_xor(lo[a], s)); hi[a] = max(hi[a], __shfl_xor(hi[a], s)); }
   __shared__ int red[4][6];
   __shared__ int s_last;
   if ((threadIdx.x & 63) == 0) for (int a = 0; a < 3; ++a) { red[threadIdx.x >> 6][a] = lo[a]; red[threadIdx.x >> 6][3 + a] = hi[a]; }
   __syncthreads();
-  if (threadIdx.x < 6) {
-    int v = red[0][threadIdx.x];
-    for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? min(v, red[w][threadIdx.x]) : max(v, red[w][threadIdx.x]);
-    if (threadIdx.x < 3) atomicMin(&mm[threadIdx.x], v); else atomicMax(&mm[threadIdx.x], v);
+  if (threadIdx.x == 0) {   // one thread: bounds (only where this workgroup improves them: most cannot any more), then the ticket
+    int cur[6];
+    for (int k = 0; k < 6; ++k) cur[k] = __hip_atomic_load(&mm[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int dep = 0;
+    for (int k = 0; k < 6; ++k) {
+      int v = red[0][k];
+      for (int w = 1; w < 4; ++w) v = k < 3 ? min(v, red[w][k]) : max(v, red[w][k]);
+      if (k < 3) { if (v < cur[k]) dep |= __hip_atomic_fetch_min(&mm[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      else if (v > cur[k]) dep |= __hip_atomic_fetch_max(&mm[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the bounds are device-scope atomics (performed at the memory side, not in this XCD's L2) and they have RETURNED before the ticket is drawn: no fence — an
+    // agent-scope release / acquire writes back and invalidates the XCD's L2 under the other workgroups' streaming reads (976 of them doubled this kernel at 4 M points)
+    asm volatile("s_waitcnt vmcnt(0)" :: "v"(dep) : "memory");
+    s_last = __hip_atomic_fetch_add(&mm[6], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
   }
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = atomicAdd(&mm[6], 1) == (int)gridDim.x - 1;
   __syncthreads();
   if (!s_last || threadIdx.x != 0) return;
   int e[6];
@@ -528,32 +542,46 @@ __device__ void vx_eig3(const double A[9], double ev[3], double V[9]) {
 // sorted positions and the leaves whose first point lies in it:
 //   * head = position whose key differs from its predecessor's; the number of heads before the tile comes from a decoupled look-back over the tiles' published counts
 //     (one 64-bit word per tile: flag | count, wavefront 0 looks at 64 predecessors per step) — this replaced rocPRIM's run-length encode + exclusive scan (four launches);
-//   * the sorted ids and points of the tile's leaves are one contiguous range: all 256 threads fetch it (coalesced ids, one gather) into LDS, 1 024 points at a time —
+//   * the sorted ids and points of the tile's leaves are one contiguous range: all 256 threads fetch it (coalesced ids, one gather) into LDS —
 //     the thread-per-leaf loop of round 3 paid two dependent HBM round trips per 8 points of its LONGEST leaf (35-50 % of that kernel);
 //   * thread r < #heads then sums ITS leaf's points from LDS in input order: cov = (sum x x^T - 2 sum x mu^T) / n + mu mu^T cancels ~6 digits (coordinates of tens of
 //     metres, spreads of centimetres), so only the reference's summation order reproduces it to 1e-12 of its own scale; the float centroid is compared bit for bit.
-#define VX_STAGE 1024
 __device__ __forceinline__ unsigned long long vx_lb_load(const unsigned long long* a) { return __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void vx_lb_store(unsigned long long* a, unsigned long long v) { __hip_atomic_store(a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// PT = sorted positions per thread (tile = 256 PT): 1 for small clouds (many workgroups, the launch is a latency chain), 4 for large ones (a tile then holds ~140 heads:
+// the eigen-solves run on two to three FULL wavefronts per workgroup instead of on half of one — at 4 M points the kernel is bound by resident eigen-solve wavefronts).
+template <int PT>
 __global__ __launch_bounds__(256) void k_vx_leaf(const float4* __restrict__ p, const unsigned* __restrict__ skeys, const int* __restrict__ sorted_ids, int n_pts, unsigned invalid, unsigned long long* lb,
                                                  int min_pts, double eig_mult, VxInfo* info, int* grid, int* leaf_key, int* leaf_n, unsigned* counts, unsigned* offs,
                                                  double* mean, double* cov, double* icov, double* evecs, double* evals, float* centroid) {
-  __shared__ float4 pts[VX_STAGE];
-  __shared__ int hpos[257];
-  __shared__ int wcnt[4];
+  constexpr int TILE = 256 * PT, STAGE = PT == 1 ? 1024 : TILE + 256;   // positions staged in LDS at a time (the tile's leaves normally fit one stage; longer ranges go through in chunks)
+  __shared__ float4 pts[STAGE];
+  __shared__ int hpos[TILE + 1];
+  __shared__ int wcnt[PT * 4 < 4 ? 4 : PT * 4];
   __shared__ int s_prefix, s_end;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
-  const int tile0 = b * 256, i = tile0 + tid;
+  const int tile0 = b * TILE;
   const bool ovf = info->overflow != 0;
-  const unsigned key_i = i < n_pts ? skeys[i] : invalid;
-  const bool head = !ovf && key_i != invalid && (i == 0 || skeys[i - 1] != key_i);
-  const unsigned long long hm = __ballot(head);
-  if (lane == 0) wcnt[wv] = __popcll(hm);
+  bool head[PT]; int rank[PT];
+#pragma unroll
+  for (int u = 0; u < PT; ++u) {
+    const int i = tile0 + 256 * u + tid;
+    const unsigned key_i = i < n_pts ? skeys[i] : invalid;
+    head[u] = !ovf && key_i != invalid && (i == 0 || skeys[i - 1] != key_i);
+    const unsigned long long hm = __ballot(head[u]);
+    if (lane == 0) wcnt[4 * u + wv] = __popcll(hm);
+    rank[u] = __popcll(hm & ((1ull << lane) - 1ull));
+  }
   __syncthreads();
-  const int hb = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-  int rank = __popcll(hm & ((1ull << lane) - 1ull));
-  for (int w = 0; w < wv; ++w) rank += wcnt[w];
-  if (head) hpos[rank] = i;
+  int hb = 0;
+#pragma unroll
+  for (int e = 0; e < 4 * PT; ++e) hb += wcnt[e];
+#pragma unroll
+  for (int u = 0; u < PT; ++u) {
+    int r = rank[u];
+    for (int e = 0; e < 4 * u + wv; ++e) r += wcnt[e];
+    if (head[u]) hpos[r] = tile0 + 256 * u + tid;
+  }
   // leaves before this tile
   if (wv == 0) {
     if (lane == 0) vx_lb_store(&lb[b], ((b == 0 ? 2ull : 1ull) << 32) | (unsigned)hb);
@@ -576,11 +604,11 @@ __global__ __launch_bounds__(256) void k_vx_leaf(const float4* __restrict__ p, c
   }
   __syncthreads();
   if (hb == 0) return;
-  // end of the tile's last leaf: the first position behind the tile with another key
+  // end of the tile's last leaf: the first position behind its head with another key
   {
     const int lasthead = hpos[hb - 1];
     const unsigned lastkey = skeys[lasthead];
-    for (int pos = tile0;; pos += 256) {   // (from inside the tile: the invalid-key run of the non-finite points may begin there)
+    for (int pos = tile0 + ((lasthead - tile0) & ~255);; pos += 256) {   // (from inside the tile: the invalid-key run of the non-finite points may begin there)
       const int j = pos + tid;
       const bool stop = j > lasthead && (j >= n_pts || skeys[j] != lastkey);
       const unsigned long long sm = __ballot(stop);
@@ -594,72 +622,83 @@ __global__ __launch_bounds__(256) void k_vx_leaf(const float4* __restrict__ p, c
   }
   __syncthreads();
   const int S = hpos[0], E = s_end;
-  const bool mine = tid < hb;
-  const int la = mine ? hpos[tid] : 0, le = mine ? hpos[tid + 1] : 0, n = le - la;
+  // Thread t owns the leaves t, t + 256, ... of the tile, in position order; the staged chunk moves over [S, E).  A leaf that crosses the end of a chunk is the LAST one its
+  // thread touches in that chunk, so one set of running sums per thread carries it into the next chunk.  Sums run over the leaf's points IN INPUT ORDER (the sort is
+  // stable): cov = (sum x x^T - 2 sum x mu^T) / n + mu mu^T cancels ~6 digits, only the reference's summation order reproduces it to 1e-12 of its own scale; the float
+  // centroid is compared bit for bit.
+  int r = tid;
   double s[3] = {0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};   // xx xy xz yy yz zz (x_a x_b == x_b x_a bit for bit)
   float cen[3] = {0, 0, 0};
-  for (int c0 = S; c0 < E; c0 += VX_STAGE) {
-    int id[VX_STAGE / 256];
+  for (int c0 = S; c0 < E; c0 += STAGE) {
+    {
+      constexpr int NU = STAGE / 256;
+      int id[NU];
 #pragma unroll
-    for (int u = 0; u < VX_STAGE / 256; ++u) { const int j = c0 + tid + 256 * u; id[u] = j < E ? sorted_ids[j] : -1; }
+      for (int u = 0; u < NU; ++u) { const int j = c0 + tid + 256 * u; id[u] = j < E ? sorted_ids[j] : -1; }
 #pragma unroll
-    for (int u = 0; u < VX_STAGE / 256; ++u) if (id[u] >= 0) pts[tid + 256 * u] = p[id[u]];
+      for (int u = 0; u < NU; ++u) if (id[u] >= 0) pts[tid + 256 * u] = p[id[u]];
+    }
     __syncthreads();
-    if (mine) {
-      const int k0 = max(la, c0), k1 = min(le, c0 + VX_STAGE);
-      for (int k = k0; k < k1; ++k) {
+    while (r < hb) {
+      const int la = hpos[r], le = hpos[r + 1], n = le - la;
+      if (la >= c0 + STAGE) break;
+      const int k1 = min(le, c0 + STAGE);
+      for (int k = max(la, c0); k < k1; ++k) {
         const float4 q = pts[k - c0];
         const double x = q.x, y = q.y, z = q.z;
         s[0] += x; s[1] += y; s[2] += z;
         c[0] += x * x; c[1] += x * y; c[2] += x * z; c[3] += y * y; c[4] += y * z; c[5] += z * z;
         cen[0] += q.x; cen[1] += q.y; cen[2] += q.z;
       }
+      if (le > c0 + STAGE) break;   // continues in the next chunk
+      const int li = s_prefix + r;
+      const unsigned key = skeys[la];
+      leaf_key[li] = (int)key;
+      grid[key] = li;
+      counts[li] = (unsigned)n; offs[li] = (unsigned)la;
+      double* M = mean + 3 * (size_t)li; double* Cv = cov + 9 * (size_t)li; double* IC = icov + 9 * (size_t)li; double* EV = evecs + 9 * (size_t)li; double* EL = evals + 3 * (size_t)li;
+      double mu[3];
+      for (int a = 0; a < 3; ++a) { centroid[3 * (size_t)li + a] = cen[a] / (float)n; mu[a] = s[a] / n; M[a] = mu[a]; }
+      int nr = n;
+      if (n < min_pts) {
+        for (int a = 0; a < 3; ++a) EL[a] = 0.0;
+        for (int a = 0; a < 9; ++a) { Cv[a] = (a % 4 == 0) ? 1.0 : 0.0; IC[a] = 0.0; EV[a] = (a % 4 == 0) ? 1.0 : 0.0; }
+      } else {
+        const double cs[9] = {c[0], c[1], c[2], c[1], c[3], c[4], c[2], c[4], c[5]};
+        double C[9];
+        for (int a = 0; a < 3; ++a) for (int bb = 0; bb < 3; ++bb) C[3 * a + bb] = (cs[3 * a + bb] - 2 * (s[a] * mu[bb])) / n + mu[a] * mu[bb];
+        for (int a = 0; a < 9; ++a) C[a] *= (n - 1.0) / n;
+        double ev[3], V[9];
+        vx_eig3<true>(C, ev, V);
+        for (int a = 0; a < 9; ++a) EV[a] = V[a];
+        double el[3] = {0.0, 0.0, 0.0}, ic[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (ev[0] < 0 || ev[1] < 0 || ev[2] <= 0) nr = -1;
+        else {
+          const double min_ev = eig_mult * ev[2];
+          if (ev[0] < min_ev) {
+            ev[0] = min_ev; if (ev[1] < min_ev) ev[1] = min_ev;
+            for (int a = 0; a < 3; ++a) for (int bb = 0; bb < 3; ++bb) C[3 * a + bb] = V[3 * a] * ev[0] * V[3 * bb] + V[3 * a + 1] * ev[1] * V[3 * bb + 1] + V[3 * a + 2] * ev[2] * V[3 * bb + 2];
+          }
+          for (int a = 0; a < 3; ++a) el[a] = ev[a];
+          const double c00 = C[4] * C[8] - C[5] * C[7], c01 = C[5] * C[6] - C[3] * C[8], c02 = C[3] * C[7] - C[4] * C[6];
+          const double id = 1.0 / (C[0] * c00 + C[1] * c01 + C[2] * c02);
+          ic[0] = c00 * id; ic[1] = (C[2] * C[7] - C[1] * C[8]) * id; ic[2] = (C[1] * C[5] - C[2] * C[4]) * id;
+          ic[3] = c01 * id; ic[4] = (C[0] * C[8] - C[2] * C[6]) * id; ic[5] = (C[2] * C[3] - C[0] * C[5]) * id;
+          ic[6] = c02 * id; ic[7] = (C[1] * C[6] - C[0] * C[7]) * id; ic[8] = (C[0] * C[4] - C[1] * C[3]) * id;
+          double mxv = ic[0], mnv = ic[0];
+          for (int a = 1; a < 9; ++a) { mxv = fmax(mxv, ic[a]); mnv = fmin(mnv, ic[a]); }
+          if (mxv == (double)INFINITY || mnv == -(double)INFINITY) nr = -1;
+        }
+        for (int a = 0; a < 3; ++a) EL[a] = el[a];
+        for (int a = 0; a < 9; ++a) { Cv[a] = C[a]; IC[a] = ic[a]; }
+      }
+      leaf_n[li] = nr;
+      r += 256;
+      for (int a = 0; a < 3; ++a) { s[a] = 0.0; cen[a] = 0.0f; }
+      for (int a = 0; a < 6; ++a) c[a] = 0.0;
     }
     __syncthreads();
   }
-  if (!mine) return;
-  const int li = s_prefix + tid;
-  const unsigned key = skeys[la];
-  leaf_key[li] = (int)key;
-  grid[key] = li;
-  counts[li] = (unsigned)n; offs[li] = (unsigned)la;
-  double* M = mean + 3 * (size_t)li; double* Cv = cov + 9 * (size_t)li; double* IC = icov + 9 * (size_t)li; double* EV = evecs + 9 * (size_t)li; double* EL = evals + 3 * (size_t)li;
-  double mu[3];
-  for (int a = 0; a < 3; ++a) { centroid[3 * (size_t)li + a] = cen[a] / (float)n; mu[a] = s[a] / n; M[a] = mu[a]; }
-  int nr = n;
-  if (n < min_pts) {
-    for (int a = 0; a < 3; ++a) EL[a] = 0.0;
-    for (int a = 0; a < 9; ++a) { Cv[a] = (a % 4 == 0) ? 1.0 : 0.0; IC[a] = 0.0; EV[a] = (a % 4 == 0) ? 1.0 : 0.0; }
-  } else {
-    const double cs[9] = {c[0], c[1], c[2], c[1], c[3], c[4], c[2], c[4], c[5]};
-    double C[9];
-    for (int a = 0; a < 3; ++a) for (int bb = 0; bb < 3; ++bb) C[3 * a + bb] = (cs[3 * a + bb] - 2 * (s[a] * mu[bb])) / n + mu[a] * mu[bb];
-    for (int a = 0; a < 9; ++a) C[a] *= (n - 1.0) / n;
-    double ev[3], V[9];
-    vx_eig3<true>(C, ev, V);
-    for (int a = 0; a < 9; ++a) EV[a] = V[a];
-    double el[3] = {0.0, 0.0, 0.0}, ic[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (ev[0] < 0 || ev[1] < 0 || ev[2] <= 0) nr = -1;
-    else {
-      const double min_ev = eig_mult * ev[2];
-      if (ev[0] < min_ev) {
-        ev[0] = min_ev; if (ev[1] < min_ev) ev[1] = min_ev;
-        for (int a = 0; a < 3; ++a) for (int bb = 0; bb < 3; ++bb) C[3 * a + bb] = V[3 * a] * ev[0] * V[3 * bb] + V[3 * a + 1] * ev[1] * V[3 * bb + 1] + V[3 * a + 2] * ev[2] * V[3 * bb + 2];
-      }
-      for (int a = 0; a < 3; ++a) el[a] = ev[a];
-      const double c00 = C[4] * C[8] - C[5] * C[7], c01 = C[5] * C[6] - C[3] * C[8], c02 = C[3] * C[7] - C[4] * C[6];
-      const double id = 1.0 / (C[0] * c00 + C[1] * c01 + C[2] * c02);
-      ic[0] = c00 * id; ic[1] = (C[2] * C[7] - C[1] * C[8]) * id; ic[2] = (C[1] * C[5] - C[2] * C[4]) * id;
-      ic[3] = c01 * id; ic[4] = (C[0] * C[8] - C[2] * C[6]) * id; ic[5] = (C[2] * C[3] - C[0] * C[5]) * id;
-      ic[6] = c02 * id; ic[7] = (C[1] * C[6] - C[0] * C[7]) * id; ic[8] = (C[0] * C[4] - C[1] * C[3]) * id;
-      double mxv = ic[0], mnv = ic[0];
-      for (int a = 1; a < 9; ++a) { mxv = fmax(mxv, ic[a]); mnv = fmin(mnv, ic[a]); }
-      if (mxv == (double)INFINITY || mnv == -(double)INFINITY) nr = -1;
-    }
-    for (int a = 0; a < 3; ++a) EL[a] = el[a];
-    for (int a = 0; a < 9; ++a) { Cv[a] = C[a]; IC[a] = ic[a]; }
-  }
-  leaf_n[li] = nr;
 }
 // NDT derivatives: one thread per point (float arithmetic in the reference's order of operations), 43 doubles reduced per workgroup
 struct NdtConst { float j_ang[8][3]; float h_ang[15][3]; float gd2; double gauss_d1; };
@@ -741,13 +780,17 @@ __global__ __launch_bounds__(256) void k_ndt_derivatives(const float4* src, cons
   __syncthreads();
   if (threadIdx.x < 43) { const double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]; if (v != 0.0) atomicAdd(&out43[threadIdx.x], v); }
 }
-// surfel map extraction: one thread per leaf (tens to hundreds of points each), three passes over the leaf's points
+// surfel map extraction: one WAVEFRONT per leaf (tens to hundreds of points each).  Round 3 had one thread per leaf walking its points three times with a dependent
+// id -> point gather per point (1.5 ms for the 410 k-point map cloud, more than half of lvx_data_association); now the 64 lanes stride over the leaf's points, the inlier
+// sums are reduced over the lanes in a fixed order (planes agree with the serial restatement to rounding, counts and boxes exactly) and lane 0 does the 3 x 3 work.
 struct SurfelPlaneDev { double p4[4], Pi[3], bmin[3], bmax[3]; int leaf, n_points, n_inliers, plane_type; };
-__global__ void k_surfel_extract(const float4* p, const unsigned* counts, const unsigned* offs, const int* sorted_ids, int nl, const int* leaf_n, const double* mean,
-                                 const double* evecs, const double* evals, double p_lambda, double thr, int min_leaf, int min_inl, SurfelPlaneDev* out, int* flag) {
-  const int li = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ double wave_sum(double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+__global__ __launch_bounds__(256) void k_surfel_extract(const float4* __restrict__ p, const unsigned* counts, const unsigned* offs, const int* __restrict__ sorted_ids, int nl, const int* leaf_n, const double* mean,
+                                                        const double* evecs, const double* evals, double p_lambda, double thr, int min_leaf, int min_inl, SurfelPlaneDev* out, int* flag) {
+  const int lane = threadIdx.x & 63;
+  const int li = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (li >= nl) return;
-  flag[li] = 0;
+  if (lane == 0) flag[li] = 0;
   const int n = leaf_n[li];
   if (n < min_leaf) return;
   const double* ev = evals + 3 * (size_t)li;
@@ -765,33 +808,42 @@ __global__ void k_surfel_extract(const float4* p, const unsigned* counts, const 
   const int o = (int)offs[li], cnt = (int)counts[li];
   double d = -(nrm[0] * mean[3 * (size_t)li] + nrm[1] * mean[3 * (size_t)li + 1] + nrm[2] * mean[3 * (size_t)li + 2]);
   int nin = 0;
+  float bmin[3] = {3.402823466e38f, 3.402823466e38f, 3.402823466e38f}, bmax[3] = {-3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
   for (int pass = 0; pass < 2; ++pass) {
-    double sm[3] = {0, 0, 0}, cc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    nin = 0;
-    for (int k = 0; k < cnt; ++k) {
+    double sm[3] = {0, 0, 0}, cc[6] = {0, 0, 0, 0, 0, 0};
+    int my = 0;
+    for (int k = lane; k < cnt; k += 64) {
       const float4 q = p[sorted_ids[o + k]];
       const double x[3] = {q.x, q.y, q.z};
+      if (pass == 0) {
+        bmin[0] = fminf(bmin[0], q.x); bmin[1] = fminf(bmin[1], q.y); bmin[2] = fminf(bmin[2], q.z);
+        bmax[0] = fmaxf(bmax[0], q.x); bmax[1] = fmaxf(bmax[1], q.y); bmax[2] = fmaxf(bmax[2], q.z);
+      }
       if (!(fabs(nrm[0] * x[0] + nrm[1] * x[1] + nrm[2] * x[2] + d) < thr)) continue;
-      ++nin;
-      for (int a = 0; a < 3; ++a) { sm[a] += x[a]; for (int b = 0; b < 3; ++b) cc[3 * a + b] += x[a] * x[b]; }
+      ++my;
+      if (pass == 0) {
+        sm[0] += x[0]; sm[1] += x[1]; sm[2] += x[2];
+        cc[0] += x[0] * x[0]; cc[1] += x[0] * x[1]; cc[2] += x[0] * x[2]; cc[3] += x[1] * x[1]; cc[4] += x[1] * x[2]; cc[5] += x[2] * x[2];
+      }
     }
+    for (int s = 32; s > 0; s >>= 1) my += __shfl_xor(my, s);
+    nin = my;
     if (pass == 1 || nin < 3) break;
+    for (int a = 0; a < 3; ++a) sm[a] = wave_sum(sm[a]);
+    for (int a = 0; a < 6; ++a) cc[a] = wave_sum(cc[a]);
     const double mu[3] = {sm[0] / nin, sm[1] / nin, sm[2] / nin};
+    const double cs[9] = {cc[0], cc[1], cc[2], cc[1], cc[3], cc[4], cc[2], cc[4], cc[5]};
     double C[9];
-    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[3 * a + b] = cc[3 * a + b] / nin - mu[a] * mu[b];
+    for (int a = 0; a < 3; ++a) for (int bb = 0; bb < 3; ++bb) C[3 * a + bb] = cs[3 * a + bb] / nin - mu[a] * mu[bb];
     double e2[3], V2[9];
-    vx_eig3<false>(C, e2, V2);
+    vx_eig3<false>(C, e2, V2);   // (every lane the same: the sums are wave-uniform after the butterfly)
     nrm[0] = V2[0]; nrm[1] = V2[3]; nrm[2] = V2[6];
     d = -(nrm[0] * mu[0] + nrm[1] * mu[1] + nrm[2] * mu[2]);
   }
   if (nin < min_inl) return;
   if (d > 0 || (d == 0 && (nrm[0] < 0 || (nrm[0] == 0 && (nrm[1] < 0 || (nrm[1] == 0 && nrm[2] < 0)))))) { nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2]; d = -d; }
-  float bmin[3] = {3.402823466e38f, 3.402823466e38f, 3.402823466e38f}, bmax[3] = {-3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
-  for (int k = 0; k < cnt; ++k) {
-    const float4 q = p[sorted_ids[o + k]];
-    bmin[0] = fminf(bmin[0], q.x); bmin[1] = fminf(bmin[1], q.y); bmin[2] = fminf(bmin[2], q.z);
-    bmax[0] = fmaxf(bmax[0], q.x); bmax[1] = fmaxf(bmax[1], q.y); bmax[2] = fmaxf(bmax[2], q.z);
-  }
+  for (int s = 32; s > 0; s >>= 1) for (int a = 0; a < 3; ++a) { bmin[a] = fminf(bmin[a], __shfl_xor(bmin[a], s)); bmax[a] = fmaxf(bmax[a], __shfl_xor(bmax[a], s)); }
+  if (lane != 0) return;
   SurfelPlaneDev& P = out[li];
   for (int a = 0; a < 3; ++a) { P.p4[a] = nrm[a]; P.Pi[a] = -d * nrm[a]; P.bmin[a] = bmin[a]; P.bmax[a] = bmax[a]; }
   P.p4[3] = d; P.leaf = li; P.n_points = n; P.n_inliers = nin; P.plane_type = t2;
@@ -1263,15 +1315,19 @@ static int voxel_enqueue(lvx_ctx* c, const float4* d_pts, int n, float leaf, int
   unsigned long long* lbs = (unsigned long long*)((unsigned*)V.runs.p + (((size_t)n * 3 + 1) & ~(size_t)1));   // look-back states of k_vx_leaf, one per tile
   const size_t cap = (size_t)V.cap;
   const int n_tiles = (n + 255) / 256;
-  hipLaunchKernelGGL(k_vx_extent, dim3((unsigned)std::min(std::max(n / 4096, 64), 1024)), dim3(256), 0, st, d_pts, n, d_mm, leaf, (long long)V.cells_cap, d_info);   // few workgroups: every one ends in 7 same-address atomics (391 of them took 25 us)
+  hipLaunchKernelGGL(k_vx_extent, dim3((unsigned)std::min(std::max(n / 4096, 64), 256)), dim3(256), 0, st, d_pts, n, d_mm, leaf, (long long)V.cells_cap, d_info);
   const unsigned invalid = (1u << V.sort_bits) - 1u;
   hipLaunchKernelGGL(k_vx_keys, dim3((unsigned)std::max(n_tiles, 512)), dim3(256), 0, st, d_pts, n, (const VxInfo*)d_info, invalid, k_in, v_in, (int*)V.cells.p, lbs, n_tiles);
   size_t t1 = V.tmp_bytes[0];
   LVX_HIP(c, rocprim::radix_sort_pairs(V.tmp.p, t1, k_in, k_out, v_in, v_out, (size_t)n, 0, (unsigned)V.sort_bits, st));   // stable: input order kept inside a leaf
   int* lk = (int*)V.leaf_i.p; int* ln = lk + cap;
   double* mean = (double*)V.leaf_d.p; double* cov = mean + 3 * cap; double* icov = cov + 9 * cap; double* evecs = icov + 9 * cap; double* evals = evecs + 9 * cap;
-  hipLaunchKernelGGL(k_vx_leaf, dim3((unsigned)n_tiles), dim3(256), 0, st, d_pts, (const unsigned*)k_out, (const int*)v_out, n, invalid, lbs, min_pts, eig_mult, d_info, (int*)V.cells.p, lk, ln,
-                     counts, offs, mean, cov, icov, evecs, evals, (float*)V.leaf_f.p);
+  if (n > 500000)
+    hipLaunchKernelGGL(k_vx_leaf<4>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, d_pts, (const unsigned*)k_out, (const int*)v_out, n, invalid, lbs, min_pts, eig_mult, d_info, (int*)V.cells.p, lk, ln,
+                       counts, offs, mean, cov, icov, evecs, evals, (float*)V.leaf_f.p);
+  else
+    hipLaunchKernelGGL(k_vx_leaf<1>, dim3((unsigned)n_tiles), dim3(256), 0, st, d_pts, (const unsigned*)k_out, (const int*)v_out, n, invalid, lbs, min_pts, eig_mult, d_info, (int*)V.cells.p, lk, ln,
+                       counts, offs, mean, cov, icov, evecs, evals, (float*)V.leaf_f.p);
   LVX_HIP(c, hipMemcpyAsync(V.h_info, d_info, sizeof(VxInfo), hipMemcpyDeviceToHost, st));
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
@@ -1680,7 +1736,7 @@ static int surfel_extract_device(lvx_ctx* c, double p_lambda, double dist_thresh
   const unsigned* counts = (const unsigned*)V.runs.p + n; const unsigned* offs = (const unsigned*)V.runs.p + 2 * (size_t)n;
   const int* lk = (const int*)V.leaf_i.p; const double* d = (const double*)V.leaf_d.p;
   { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
-    hipLaunchKernelGGL(k_surfel_extract, dim3((nl + 127) / 128), dim3(128), 0, c->stream, (const float4*)V.d_pts, counts, offs, (const int*)V.vals.p + n, nl, lk + cap, d, d + 21 * cap,
+    hipLaunchKernelGGL(k_surfel_extract, dim3((nl + 3) / 4), dim3(256), 0, c->stream, (const float4*)V.d_pts, counts, offs, (const int*)V.vals.p + n, nl, lk + cap, d, d + 21 * cap,
                        d + 30 * cap, p_lambda, dist_threshold, min_leaf_points, min_inliers, (SurfelPlaneDev*)c->d_up[4].p, (int*)c->d_up[5].p); }
   LVX_HIP(c, hipGetLastError());
   std::vector<SurfelPlaneDev> all(nl); std::vector<int> flag(nl);

@@ -131,6 +131,22 @@ def test_voxel_build_and_lookup_config2(ctx):
     assert np.array_equal(lvx.voxel_lookup1(ctx, q), ids7[:, 0])      # getNeighborhoodAtPoint1 = the zero displacement of DIRECT7
 
 
+def test_voxel_build_large_cloud_and_long_leaves(ctx):
+    """> 500 k points take the 1 024-position tiles of k_vx_leaf (four sorted positions per thread); a coarse leaf size makes leaves of thousands of points that
+    cross tiles and leave the staged range (their owner gathers the rest itself); non-finite points in between."""
+    cloud = synth.tile_voxel_cloud(synth.make_voxel_cloud(seed=3, n=100_000), 6)
+    cloud[::1013, 1] = np.nan
+    for leaf in (0.5, 4.0):
+        vo = O.voxel_build(cloud, leaf)
+        vg = lvx.voxel_build(ctx, cloud, leaf)
+        _check_voxels(vg, vo)
+    assert vo["leaf_n"].max() > 1500
+    small = synth.make_voxel_cloud(seed=9, n=30_000)          # the one-position-per-thread tiles with long leaves
+    vo, vg = O.voxel_build(small, 6.0), lvx.voxel_build(ctx, small, 6.0)
+    _check_voxels(vg, vo)
+    assert vo["leaf_n"].max() > 600
+
+
 def test_voxel_edge_cases(ctx):
     cloud = synth.make_voxel_cloud(seed=7, n=5000)
     cloud[::97, 0] = np.nan

@@ -9,7 +9,10 @@ def run(n):
     torch.cuda.init()
     lvx = importlib.import_module("lvi-exc_amd.lvx"); synth = importlib.import_module("lvi-exc_amd.synth")
     ctx = lvx.Context()
-    cloud = synth.make_voxel_cloud(seed=2, n=n)
+    cloud = synth.make_voxel_cloud(seed=2, n=min(n, 100000))
+    if n > 100000:
+        cloud = synth.tile_voxel_cloud(cloud, n // 100000)
+        n = len(cloud)
     t = lvx.upstream_bench(ctx, "voxel_build", (cloud, 0.5), 30)
     print("voxel_build %d: %.1f us" % (n, 1e6 * t), ctx.voxel_info())
 
