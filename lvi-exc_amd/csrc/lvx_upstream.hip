@@ -441,7 +441,7 @@ struct VxInfo { VxGrid g; int n_leaves, overflow; long long cells; };
 // extents + grid geometry (:86-95) in ONE launch: per-thread min / max over a grid-stride range, wavefront shuffles, one atomic per workgroup and bound; the LAST workgroup
 // to finish (ticket) turns the extents into the grid geometry and leaves mm[] in its start state for the next build (mm = 3 x INT_MAX | 3 x INT_MIN | ticket 0, set when
 // the buffer is allocated).  Was three launches of ~4.6 us each (k_vx_init, k_vx_minmax, k_vx_grid): a launch of a captured graph costs that much whatever it does.
-__global__ __launch_bounds__(256) void k_vx_extent(const float4* p, int n, int* mm, float leaf, long long cells_cap, VxInfo* info) {
+__global__ __launch_bounds__(256) void k_vx_extent(const float4* p, int n, int* mm, float leaf, long long cells_cap, VxInfo* info, int* ghist) {
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
   // at most 256 workgroups (every one ends in same-address traffic at the memory side: 976 of them took 80-90 us at 4 M points, 256 take 45), four loads in flight per thread
   const int stride = gridDim.x * blockDim.x;
@@ -461,26 +461,30 @@ __global__ __launch_bounds__(256) void k_vx_extent(const float4* p, int n, int* 
   __shared__ int s_last;
   if ((threadIdx.x & 63) == 0) for (int a = 0; a < 3; ++a) { red[threadIdx.x >> 6][a] = lo[a]; red[threadIdx.x >> 6][3 + a] = hi[a]; }
   __syncthreads();
-  if (threadIdx.x == 0) {   // one thread: bounds (only where this workgroup improves them: most cannot any more), then the ticket
-    int cur[6];
-    for (int k = 0; k < 6; ++k) cur[k] = __hip_atomic_load(&mm[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int dep = 0;
-    for (int k = 0; k < 6; ++k) {
-      int v = red[0][k];
-      for (int w = 1; w < 4; ++w) v = k < 3 ? min(v, red[w][k]) : max(v, red[w][k]);
-      if (k < 3) { if (v < cur[k]) dep |= __hip_atomic_fetch_min(&mm[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-      else if (v > cur[k]) dep |= __hip_atomic_fetch_max(&mm[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // the bounds are device-scope atomics (performed at the memory side, not in this XCD's L2) and they have RETURNED before the ticket is drawn: no fence — an
-    // agent-scope release / acquire writes back and invalidates the XCD's L2 under the other workgroups' streaming reads (976 of them doubled this kernel at 4 M points)
-    asm volatile("s_waitcnt vmcnt(0)" :: "v"(dep) : "memory");
-    s_last = __hip_atomic_fetch_add(&mm[6], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+  // bounds (only where this workgroup improves them: most cannot any more), then the ticket.  The bounds are device-scope atomics (performed at the memory side, not in
+  // this XCD's L2) and they have RETURNED before the ticket is drawn: no fence — an agent-scope release / acquire writes back and invalidates the XCD's L2 under the other
+  // workgroups' streaming reads.
+  __shared__ int ex[8];
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    int v = red[0][k];
+    for (int w = 1; w < 4; ++w) v = k < 3 ? min(v, red[w][k]) : max(v, red[w][k]);
+    const int cur = __hip_atomic_load(&mm[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int old = 0;
+    if (k < 3) { if (v < cur) old = __hip_atomic_fetch_min(&mm[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    else if (v > cur) old = __hip_atomic_fetch_max(&mm[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ex[k] = old;   // (the store waits for the atomic's return)
   }
   __syncthreads();
-  if (!s_last || threadIdx.x != 0) return;
+  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&mm[6], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  if (ghist) for (int e = threadIdx.x; e < 4 * 256; e += 256) ghist[e] = 0;   // digit histograms of the radix sort (k_vx_keys adds to them)
+  if (threadIdx.x < 7) ex[threadIdx.x] = atomicExch(&mm[threadIdx.x], threadIdx.x < 3 ? 0x7fffffff : (threadIdx.x < 6 ? (int)0x80000000 : 0));   // read at the memory side and reset
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   int e[6];
-  for (int k = 0; k < 6; ++k) e[k] = atomicExch(&mm[k], k < 3 ? 0x7fffffff : (int)0x80000000);   // read at the L2 and reset
-  atomicExch(&mm[6], 0);
+  for (int k = 0; k < 6; ++k) e[k] = ex[k];
   VxGrid g;
   g.inv = 1.0f / leaf;
   const bool empty = e[0] == 0x7fffffff;
@@ -494,23 +498,122 @@ __global__ __launch_bounds__(256) void k_vx_extent(const float4* p, int n, int* 
   info->overflow = cells > 2147483647LL ? 2 : (cells > cells_cap ? 1 : 0);
 }
 // keys: the voxel's linear index, or `invalid` (> every valid key, inside the sorted bit range) for non-finite points; the same launch empties the part of the dense cell
-// table this cloud's extents span and resets the look-back states of k_vx_leaf (one per tile of 256 sorted positions)
-__global__ __launch_bounds__(256) void k_vx_keys(const float4* p, int n, const VxInfo* info, unsigned invalid, unsigned* keys, int* vals, int* cells, unsigned long long* lb, int n_tiles) {
+// table this cloud's extents span, resets the look-back states of k_vx_leaf (one per tile of sorted positions) and — for the own radix sort — counts the keys' 8-bit
+// digits (LDS histogram per workgroup, one global atomic per non-empty bin) and clears the per-tile digit counts of the sort passes
+__global__ __launch_bounds__(256) void k_vx_keys(const float4* p, int n, const VxInfo* info, unsigned invalid, unsigned* keys, int* vals, int* cells, unsigned long long* lb, int n_tiles,
+                                                 int* ghist, unsigned* tcnt, int n_tcnt, int passes) {
+  __shared__ int lh[4][256];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool ovf = info->overflow != 0;
   if (!ovf) { const long long nc = info->cells; for (long long e = i; e < nc; e += (long long)gridDim.x * blockDim.x) cells[e] = -1; }
   if (i < n_tiles) lb[i] = 0ull;
-  if (i >= n) return;
+  if (tcnt) for (int e = i; e < n_tcnt; e += gridDim.x * blockDim.x) tcnt[e] = 0u;
+  if (blockIdx.x * 1024 >= n) return;   // (workgroups that only clear)
+  if (ghist) { for (int q = 0; q < passes; ++q) lh[q][threadIdx.x] = 0; __syncthreads(); }
   const VxGrid g = info->g;
-  const float4 q = p[i];
-  unsigned k = invalid;
-  if (!ovf && isfinite(q.x) && isfinite(q.y) && isfinite(q.z)) {
-    const int i0 = (int)(floorf(q.x * g.inv) - (float)g.min_b[0]);   // :220-222
-    const int i1 = (int)(floorf(q.y * g.inv) - (float)g.min_b[1]);
-    const int i2 = (int)(floorf(q.z * g.inv) - (float)g.min_b[2]);
-    k = (unsigned)(i0 * g.mul[0] + i1 * g.mul[1] + i2 * g.mul[2]);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {   // 1 024 points per workgroup: a quarter of the global histogram atomics of 256
+    const int j = blockIdx.x * 1024 + 256 * u + threadIdx.x;
+    if (j >= n) break;
+    const float4 q = p[j];
+    unsigned k = invalid;
+    if (!ovf && isfinite(q.x) && isfinite(q.y) && isfinite(q.z)) {
+      const int i0 = (int)(floorf(q.x * g.inv) - (float)g.min_b[0]);   // :220-222
+      const int i1 = (int)(floorf(q.y * g.inv) - (float)g.min_b[1]);
+      const int i2 = (int)(floorf(q.z * g.inv) - (float)g.min_b[2]);
+      k = (unsigned)(i0 * g.mul[0] + i1 * g.mul[1] + i2 * g.mul[2]);
+    }
+    keys[j] = k; vals[j] = j;
+    if (ghist) for (int qq = 0; qq < passes; ++qq) atomicAdd(&lh[qq][(k >> (8 * qq)) & 255u], 1);
   }
-  keys[i] = k; vals[i] = i;
+  if (ghist) {
+    __syncthreads();
+    for (int q = 0; q < passes; ++q) { const int v = lh[q][threadIdx.x]; if (v) atomicAdd(&ghist[256 * q + threadIdx.x], v); }
+  }
+}
+// One pass of a stable least-significant-digit radix sort (8-bit digit) in ONE launch ("onesweep"), for clouds of up to VX_OWN_SORT_MAX points — rocPRIM's radix sort takes
+// ten launches at this size (histogram / scan / scatter per digit), 56 us of the 105 us build at 100 k points, each launch ~4.6 us whatever it does.  A workgroup owns a
+// tile of 2 048 consecutive positions (striped over the threads: position = tile + 256 u + thread, so (u, wavefront, lane) order IS input order):
+//   1. rank inside the wavefront by eight ballots per key (lanes with the same digit), the group's count goes to hist[u][wavefront][digit];
+//   2. thread d turns the 32 groups of digit d into exclusive offsets and publishes the tile's count of d (flag | count, one word per (tile, digit));
+//   3. first position of digit d in this tile = digits below d in the whole array (the histogram k_vx_keys built) + d's keys in the tiles before this one: a look-back
+//      over the published counts, sixteen words at a time, until a tile that already knows its own inclusive sum;
+//   4. scatter.
+#define VX_OWN_SORT_MAX 1048576   // (measured: 400 k points 195 -> 134 us against rocPRIM, 4 M points 213 -> 284 us: rocPRIM there)
+#define VX_SORT_KPT 4
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_vx_sort_pass(const unsigned* __restrict__ kin, const int* __restrict__ vin, unsigned* __restrict__ kout, int* __restrict__ vout, int n, int shift,
+                                                      const int* __restrict__ ghist, unsigned* tcnt) {
+  constexpr int KPT = VX_SORT_KPT;
+  __shared__ int hist[KPT * 4 * 256];
+  __shared__ int base[256];
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
+  const int tile0 = b * 256 * KPT;
+  for (int e = tid; e < KPT * 4 * 256; e += 256) hist[e] = 0;
+  unsigned key[KPT]; int val[KPT]; int rk[KPT];
+#pragma unroll
+  for (int u = 0; u < KPT; ++u) {
+    const int idx = tile0 + 256 * u + tid;
+    key[u] = idx < n ? kin[idx] : 0xffffffffu;
+    val[u] = FIRST ? idx : (idx < n ? vin[idx] : 0);
+  }
+  __syncthreads();
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int u = 0; u < KPT; ++u) {
+    const bool valid = tile0 + 256 * u + tid < n;
+    const unsigned dg = (key[u] >> shift) & 255u;
+    unsigned long long m = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const bool one = (dg >> bit) & 1u;
+      const unsigned long long bal = __ballot(valid && one);
+      m &= one ? bal : ~bal;
+    }
+    rk[u] = __popcll(m & lt);
+    if (valid && rk[u] == 0) hist[(4 * u + wv) * 256 + dg] = __popcll(m);
+  }
+  __syncthreads();
+  int cnt = 0;
+#pragma unroll 8
+  for (int g = 0; g < 4 * KPT; ++g) { const int t = hist[g * 256 + tid]; hist[g * 256 + tid] = cnt; cnt += t; }
+  __hip_atomic_store(&tcnt[b * 256 + tid], ((b == 0 ? 2u : 1u) << 30) | (unsigned)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // digits below mine in the whole array
+  const int gh = ghist[tid];
+  int incl = gh;
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  int first = incl - gh;
+  for (int w = 0; w < wv; ++w) first += wsum[w];
+  // my digit's keys in the tiles before this one
+  int acc = 0;
+  constexpr int LBW = 16;   // words in flight per thread: a tile walks back LBW tiles per round trip while the inclusive sums advance towards it
+  for (int t = b - 1; t >= 0; t -= LBW) {
+    unsigned v[LBW];
+#pragma unroll
+    for (int j = 0; j < LBW; ++j) v[j] = t - j >= 0 ? __hip_atomic_load(&tcnt[(t - j) * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2u << 30);
+    bool done = false;
+#pragma unroll
+    for (int j = 0; j < LBW; ++j) {
+      if (done) continue;
+      while ((v[j] >> 30) == 0u) v[j] = __hip_atomic_load(&tcnt[(t - j) * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      acc += (int)(v[j] & 0x3fffffffu);
+      if ((v[j] >> 30) == 2u) done = true;
+    }
+    if (done) break;
+  }
+  if (b > 0) __hip_atomic_store(&tcnt[b * 256 + tid], (2u << 30) | (unsigned)(acc + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  base[tid] = first + acc;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < KPT; ++u) {
+    if (tile0 + 256 * u + tid >= n) continue;
+    const unsigned dg = (key[u] >> shift) & 255u;
+    const int pos = base[dg] + hist[(4 * u + wv) * 256 + dg] + rk[u];
+    kout[pos] = key[u]; vout[pos] = val[u];
+  }
 }
 // cyclic Jacobi, ascending eigenvalues (Eigen SelfAdjointEigenSolver stand-in).  EARLY: stop once the off-diagonal part is below 1e-18 of the diagonal (further sweeps
 // rotate by angles that no longer change a double: the oracle's loop runs 2-3 more of them until the squares underflow) and take c from one rsqrt instead of sqrt + division.
@@ -553,7 +656,7 @@ __device__ __forceinline__ void vx_lb_store(unsigned long long* a, unsigned long
 template <int PT>
 __global__ __launch_bounds__(256) void k_vx_leaf(const float4* __restrict__ p, const unsigned* __restrict__ skeys, const int* __restrict__ sorted_ids, int n_pts, unsigned invalid, unsigned long long* lb,
                                                  int min_pts, double eig_mult, VxInfo* info, int* grid, int* leaf_key, int* leaf_n, unsigned* counts, unsigned* offs,
-                                                 double* mean, double* cov, double* icov, double* evecs, double* evals, float* centroid) {
+                                                 double* mean, double* cov, double* icov, double* evecs, double* evals, float* centroid, VxInfo* h_info) {
   constexpr int TILE = 256 * PT, STAGE = PT == 1 ? 1024 : TILE + 256;   // positions staged in LDS at a time (the tile's leaves normally fit one stage; longer ranges go through in chunks)
   __shared__ float4 pts[STAGE];
   __shared__ int hpos[TILE + 1];
@@ -600,7 +703,10 @@ __global__ __launch_bounds__(256) void k_vx_leaf(const float4* __restrict__ p, c
       }
       if (lane == 0) vx_lb_store(&lb[b], (2ull << 32) | (unsigned)(prefix + hb));
     }
-    if (lane == 0) { s_prefix = prefix; s_end = -1; if (b == (int)gridDim.x - 1) info->n_leaves = prefix + hb; }
+    if (lane == 0) {
+      s_prefix = prefix; s_end = -1;
+      if (b == (int)gridDim.x - 1) { info->n_leaves = prefix + hb; VxInfo t = *info; t.n_leaves = prefix + hb; *h_info = t; }   // the host's mirror (pinned memory), read after a stream synchronisation
+    }
   }
   __syncthreads();
   if (hb == 0) return;
@@ -629,7 +735,7 @@ __global__ __launch_bounds__(256) void k_vx_leaf(const float4* __restrict__ p, c
   int r = tid;
   double s[3] = {0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};   // xx xy xz yy yz zz (x_a x_b == x_b x_a bit for bit)
   float cen[3] = {0, 0, 0};
-  for (int c0 = S; c0 < E; c0 += STAGE) {
+  for (int c0 = S; c0 < E; c0 += STAGE) {   // (requesting the first stage before the look-back — from the tile's first position, ids and points held in registers — made the kernel slower: 33 -> 42 us)
     {
       constexpr int NU = STAGE / 256;
       int id[NU];
@@ -1315,20 +1421,36 @@ static int voxel_enqueue(lvx_ctx* c, const float4* d_pts, int n, float leaf, int
   unsigned long long* lbs = (unsigned long long*)((unsigned*)V.runs.p + (((size_t)n * 3 + 1) & ~(size_t)1));   // look-back states of k_vx_leaf, one per tile
   const size_t cap = (size_t)V.cap;
   const int n_tiles = (n + 255) / 256;
-  hipLaunchKernelGGL(k_vx_extent, dim3((unsigned)std::min(std::max(n / 4096, 64), 256)), dim3(256), 0, st, d_pts, n, d_mm, leaf, (long long)V.cells_cap, d_info);
+  // own radix sort up to VX_OWN_SORT_MAX points (one launch per 8-bit digit), rocPRIM above; either way the sorted keys / ids end in the second halves of the buffers
+  const bool own_sort = n <= VX_OWN_SORT_MAX;
+  const int passes = (V.sort_bits + 7) / 8, sort_tiles = (n + 256 * VX_SORT_KPT - 1) / (256 * VX_SORT_KPT);
+  int* ghist = own_sort ? (int*)V.tmp.p : nullptr;
+  unsigned* tcnt = own_sort ? (unsigned*)V.tmp.p + 4 * 256 : nullptr;
+  hipLaunchKernelGGL(k_vx_extent, dim3((unsigned)std::min(std::max(n / 4096, 64), 256)), dim3(256), 0, st, d_pts, n, d_mm, leaf, (long long)V.cells_cap, d_info, ghist);
   const unsigned invalid = (1u << V.sort_bits) - 1u;
-  hipLaunchKernelGGL(k_vx_keys, dim3((unsigned)std::max(n_tiles, 512)), dim3(256), 0, st, d_pts, n, (const VxInfo*)d_info, invalid, k_in, v_in, (int*)V.cells.p, lbs, n_tiles);
-  size_t t1 = V.tmp_bytes[0];
-  LVX_HIP(c, rocprim::radix_sort_pairs(V.tmp.p, t1, k_in, k_out, v_in, v_out, (size_t)n, 0, (unsigned)V.sort_bits, st));   // stable: input order kept inside a leaf
+  unsigned* k_first = (own_sort && passes % 2 == 0) ? k_out : k_in;   // an even number of passes starts in the second buffer
+  hipLaunchKernelGGL(k_vx_keys, dim3((unsigned)std::max((n + 1023) / 1024, 512)), dim3(256), 0, st, d_pts, n, (const VxInfo*)d_info, invalid, k_first, v_in, (int*)V.cells.p, lbs, n_tiles,
+                     ghist, tcnt, passes * sort_tiles * 256, passes);
+  if (own_sort) {
+    unsigned* ka = k_first; unsigned* kb = k_first == k_in ? k_out : k_in;
+    int* va = k_first == k_in ? v_in : v_out; int* vb = k_first == k_in ? v_out : v_in;
+    for (int q = 0; q < passes; ++q) {
+      if (q == 0) hipLaunchKernelGGL(k_vx_sort_pass<true>, dim3((unsigned)sort_tiles), dim3(256), 0, st, (const unsigned*)ka, (const int*)va, kb, vb, n, 0, (const int*)ghist, tcnt);
+      else hipLaunchKernelGGL(k_vx_sort_pass<false>, dim3((unsigned)sort_tiles), dim3(256), 0, st, (const unsigned*)ka, (const int*)va, kb, vb, n, 8 * q, (const int*)ghist + 256 * q, tcnt + (size_t)q * sort_tiles * 256);
+      std::swap(ka, kb); std::swap(va, vb);
+    }
+  } else {
+    size_t t1 = V.tmp_bytes[0];
+    LVX_HIP(c, rocprim::radix_sort_pairs(V.tmp.p, t1, k_in, k_out, v_in, v_out, (size_t)n, 0, (unsigned)V.sort_bits, st));   // stable: input order kept inside a leaf
+  }
   int* lk = (int*)V.leaf_i.p; int* ln = lk + cap;
   double* mean = (double*)V.leaf_d.p; double* cov = mean + 3 * cap; double* icov = cov + 9 * cap; double* evecs = icov + 9 * cap; double* evals = evecs + 9 * cap;
   if (n > 500000)
     hipLaunchKernelGGL(k_vx_leaf<4>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, d_pts, (const unsigned*)k_out, (const int*)v_out, n, invalid, lbs, min_pts, eig_mult, d_info, (int*)V.cells.p, lk, ln,
-                       counts, offs, mean, cov, icov, evecs, evals, (float*)V.leaf_f.p);
+                       counts, offs, mean, cov, icov, evecs, evals, (float*)V.leaf_f.p, (VxInfo*)V.h_info);
   else
     hipLaunchKernelGGL(k_vx_leaf<1>, dim3((unsigned)n_tiles), dim3(256), 0, st, d_pts, (const unsigned*)k_out, (const int*)v_out, n, invalid, lbs, min_pts, eig_mult, d_info, (int*)V.cells.p, lk, ln,
-                       counts, offs, mean, cov, icov, evecs, evals, (float*)V.leaf_f.p);
-  LVX_HIP(c, hipMemcpyAsync(V.h_info, d_info, sizeof(VxInfo), hipMemcpyDeviceToHost, st));
+                       counts, offs, mean, cov, icov, evecs, evals, (float*)V.leaf_f.p, (VxInfo*)V.h_info);
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
 }
@@ -1362,7 +1484,8 @@ static int voxel_build_device(lvx_ctx* c, const float4* d_pts, int n, float leaf
     size_t t1 = 0;
     LVX_HIP(c, rocprim::radix_sort_pairs(nullptr, t1, k_in, k_in + n, v_in, v_in + n, (size_t)n, 0, (unsigned)V.sort_bits, st));
     V.tmp_bytes[0] = t1;
-    if ((rc = dev_alloc(c, V.tmp, t1 + 16))) return rc;
+    const size_t own = (size_t)4 * 256 * 4 + (size_t)4 * ((VX_OWN_SORT_MAX + 256 * VX_SORT_KPT - 1) / (256 * VX_SORT_KPT)) * 256 * 4;   // digit histograms + per-tile digit counts of the own sort
+    if ((rc = dev_alloc(c, V.tmp, std::max(t1 + 16, own)))) return rc;
   }
   // replay the captured chain when nothing it was captured with has changed
   uint64_t lb = 0, eb = 0; std::memcpy(&lb, &leaf, 4); std::memcpy(&eb, &eig_mult, 8);

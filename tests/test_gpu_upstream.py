@@ -145,6 +145,15 @@ def test_voxel_build_large_cloud_and_long_leaves(ctx):
     vo, vg = O.voxel_build(small, 6.0), lvx.voxel_build(ctx, small, 6.0)
     _check_voxels(vg, vo)
     assert vo["leaf_n"].max() > 600
+    # extents of 300 x 300 x 250 cells: the cell table grows past 2^24 entries, the keys need four 8-bit digits (an even number of sort passes)
+    rng = np.random.default_rng(11)
+    wide = np.zeros((20_000, 4), np.float32)
+    wide[:, :3] = rng.uniform([0, 0, 0], [300, 300, 250], (20_000, 3))
+    wide[:6000, :3] = wide[6000:12000, :3] + rng.normal(0, 0.2, (6000, 3)).astype(np.float32)
+    ctx2 = lvx.Context()
+    vo, vg = O.voxel_build(wide, 1.0), lvx.voxel_build(ctx2, wide, 1.0)
+    _check_voxels(vg, vo)
+    assert int(np.prod(vg["grid"][6:9])) > (1 << 24)
 
 
 def test_voxel_edge_cases(ctx):
