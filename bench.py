@@ -350,7 +350,6 @@ def cpu_baseline(P, seconds_budget=12.0):
     cores = usable_cores()
     o.set_threads(cores)
     blocks = o.num_blocks
-    V = np.zeros((0, o.tangent_size))
     o.evaluate_products(P["state0"])  # warm
     t0 = time.perf_counter()
     reps = 0

@@ -623,7 +623,6 @@ __global__ void k_gdot(const int* ord, int nt, const double* gb, const double* g
   }
   block_atomic_add(s, out);
 }
-__global__ void k_scal(double* x, int n, double a) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) x[i] *= a; }
 
 // max |g| over free scalars; bounded border scalars (a free sensor time offset: border index tb[k], value tx[k], |.| <= bound) enter projected
 struct TauBox { int idx[2]; const double* x[2]; double bound; };

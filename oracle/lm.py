@@ -211,7 +211,7 @@ def lm_solve(oracle, state, free, max_iterations=50, initial_radius=1e4, max_rad
                         return e["cost"], float(e["g"] @ delta)
                     except (IndexError, ValueError):
                         return np.inf, 0.0
-                a, fa, trials = projected_line_search(eval_fg, cost, g0, cand, eval_fg(1.0)[1], verbose=bool(__import__("os").environ.get("LVX_LS_VERBOSE")))
+                a, fa, trials = projected_line_search(eval_fg, cost, g0, cand, eval_fg(1.0)[1])
                 line_search_trials.append(trials)
                 if a != 1.0:
                     delta = a * delta
