@@ -653,12 +653,15 @@ __device__ __forceinline__ unsigned long long vx_lb_load(const unsigned long lon
 __device__ __forceinline__ void vx_lb_store(unsigned long long* a, unsigned long long v) { __hip_atomic_store(a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // PT = sorted positions per thread (tile = 256 PT): 1 for small clouds (many workgroups, the launch is a latency chain), 4 for large ones (a tile then holds ~140 heads:
 // the eigen-solves run on two to three FULL wavefronts per workgroup instead of on half of one — at 4 M points the kernel is bound by resident eigen-solve wavefronts).
+#define VX_LONG 128
 template <int PT>
 __global__ __launch_bounds__(256) void k_vx_leaf(const float4* __restrict__ p, const unsigned* __restrict__ skeys, const int* __restrict__ sorted_ids, int n_pts, unsigned invalid, unsigned long long* lb,
                                                  int min_pts, double eig_mult, VxInfo* info, int* grid, int* leaf_key, int* leaf_n, unsigned* counts, unsigned* offs,
                                                  double* mean, double* cov, double* icov, double* evecs, double* evals, float* centroid, VxInfo* h_info) {
-  constexpr int TILE = 256 * PT, STAGE = PT == 1 ? 1024 : TILE + 256;   // positions staged in LDS at a time (the tile's leaves normally fit one stage; longer ranges go through in chunks)
-  __shared__ float4 pts[STAGE];
+  constexpr int TILE = 256 * PT, STAGE = PT == 1 ? 1024 : TILE + 256;   // positions staged in LDS at a time: the tile + VX_LONG fit one stage
+  static_assert(TILE + VX_LONG <= STAGE && TILE / VX_LONG + 2 <= 16, "first stage / long-leaf list");
+  __shared__ float4 pts[2][STAGE];
+  __shared__ int lng[16], n_lng;
   __shared__ int hpos[TILE + 1];
   __shared__ int wcnt[PT * 4 < 4 ? 4 : PT * 4];
   __shared__ int s_prefix, s_end;
@@ -728,82 +731,125 @@ __global__ __launch_bounds__(256) void k_vx_leaf(const float4* __restrict__ p, c
   }
   __syncthreads();
   const int S = hpos[0], E = s_end;
-  // Thread t owns the leaves t, t + 256, ... of the tile, in position order; the staged chunk moves over [S, E).  A leaf that crosses the end of a chunk is the LAST one its
-  // thread touches in that chunk, so one set of running sums per thread carries it into the next chunk.  Sums run over the leaf's points IN INPUT ORDER (the sort is
-  // stable): cov = (sum x x^T - 2 sum x mu^T) / n + mu mu^T cancels ~6 digits, only the reference's summation order reproduces it to 1e-12 of its own scale; the float
-  // centroid is compared bit for bit.
-  int r = tid;
-  double s[3] = {0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};   // xx xy xz yy yz zz (x_a x_b == x_b x_a bit for bit)
-  float cen[3] = {0, 0, 0};
-  for (int c0 = S; c0 < E; c0 += STAGE) {   // (requesting the first stage before the look-back — from the tile's first position, ids and points held in registers — made the kernel slower: 33 -> 42 us)
-    {
-      constexpr int NU = STAGE / 256;
-      int id[NU];
-#pragma unroll
-      for (int u = 0; u < NU; ++u) { const int j = c0 + tid + 256 * u; id[u] = j < E ? sorted_ids[j] : -1; }
-#pragma unroll
-      for (int u = 0; u < NU; ++u) if (id[u] >= 0) pts[tid + 256 * u] = p[id[u]];
-    }
-    __syncthreads();
-    while (r < hb) {
-      const int la = hpos[r], le = hpos[r + 1], n = le - la;
-      if (la >= c0 + STAGE) break;
-      const int k1 = min(le, c0 + STAGE);
-      for (int k = max(la, c0); k < k1; ++k) {
-        const float4 q = pts[k - c0];
-        const double x = q.x, y = q.y, z = q.z;
-        s[0] += x; s[1] += y; s[2] += z;
-        c[0] += x * x; c[1] += x * y; c[2] += x * z; c[3] += y * y; c[4] += y * z; c[5] += z * z;
-        cen[0] += q.x; cen[1] += q.y; cen[2] += q.z;
-      }
-      if (le > c0 + STAGE) break;   // continues in the next chunk
-      const int li = s_prefix + r;
-      const unsigned key = skeys[la];
-      leaf_key[li] = (int)key;
-      grid[key] = li;
-      counts[li] = (unsigned)n; offs[li] = (unsigned)la;
-      double* M = mean + 3 * (size_t)li; double* Cv = cov + 9 * (size_t)li; double* IC = icov + 9 * (size_t)li; double* EV = evecs + 9 * (size_t)li; double* EL = evals + 3 * (size_t)li;
-      double mu[3];
-      for (int a = 0; a < 3; ++a) { centroid[3 * (size_t)li + a] = cen[a] / (float)n; mu[a] = s[a] / n; M[a] = mu[a]; }
-      int nr = n;
-      if (n < min_pts) {
-        for (int a = 0; a < 3; ++a) EL[a] = 0.0;
-        for (int a = 0; a < 9; ++a) { Cv[a] = (a % 4 == 0) ? 1.0 : 0.0; IC[a] = 0.0; EV[a] = (a % 4 == 0) ? 1.0 : 0.0; }
-      } else {
-        const double cs[9] = {c[0], c[1], c[2], c[1], c[3], c[4], c[2], c[4], c[5]};
-        double C[9];
-        for (int a = 0; a < 3; ++a) for (int bb = 0; bb < 3; ++bb) C[3 * a + bb] = (cs[3 * a + bb] - 2 * (s[a] * mu[bb])) / n + mu[a] * mu[bb];
-        for (int a = 0; a < 9; ++a) C[a] *= (n - 1.0) / n;
-        double ev[3], V[9];
-        vx_eig3<true>(C, ev, V);
-        for (int a = 0; a < 9; ++a) EV[a] = V[a];
-        double el[3] = {0.0, 0.0, 0.0}, ic[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (ev[0] < 0 || ev[1] < 0 || ev[2] <= 0) nr = -1;
-        else {
-          const double min_ev = eig_mult * ev[2];
-          if (ev[0] < min_ev) {
-            ev[0] = min_ev; if (ev[1] < min_ev) ev[1] = min_ev;
-            for (int a = 0; a < 3; ++a) for (int bb = 0; bb < 3; ++bb) C[3 * a + bb] = V[3 * a] * ev[0] * V[3 * bb] + V[3 * a + 1] * ev[1] * V[3 * bb + 1] + V[3 * a + 2] * ev[2] * V[3 * bb + 2];
-          }
-          for (int a = 0; a < 3; ++a) el[a] = ev[a];
-          const double c00 = C[4] * C[8] - C[5] * C[7], c01 = C[5] * C[6] - C[3] * C[8], c02 = C[3] * C[7] - C[4] * C[6];
-          const double id = 1.0 / (C[0] * c00 + C[1] * c01 + C[2] * c02);
-          ic[0] = c00 * id; ic[1] = (C[2] * C[7] - C[1] * C[8]) * id; ic[2] = (C[1] * C[5] - C[2] * C[4]) * id;
-          ic[3] = c01 * id; ic[4] = (C[0] * C[8] - C[2] * C[6]) * id; ic[5] = (C[2] * C[3] - C[0] * C[5]) * id;
-          ic[6] = c02 * id; ic[7] = (C[1] * C[6] - C[0] * C[7]) * id; ic[8] = (C[0] * C[4] - C[1] * C[3]) * id;
-          double mxv = ic[0], mnv = ic[0];
-          for (int a = 1; a < 9; ++a) { mxv = fmax(mxv, ic[a]); mnv = fmin(mnv, ic[a]); }
-          if (mxv == (double)INFINITY || mnv == -(double)INFINITY) nr = -1;
+  // finalize of :286-371 for one leaf from its sums
+  auto finalize = [&](int r, int la, int n, const double* s, const double* c, const float* cen) {
+    const int li = s_prefix + r;
+    const unsigned key = skeys[la];
+    leaf_key[li] = (int)key;
+    grid[key] = li;
+    counts[li] = (unsigned)n; offs[li] = (unsigned)la;
+    double* M = mean + 3 * (size_t)li; double* Cv = cov + 9 * (size_t)li; double* IC = icov + 9 * (size_t)li; double* EV = evecs + 9 * (size_t)li; double* EL = evals + 3 * (size_t)li;
+    double mu[3];
+    for (int a = 0; a < 3; ++a) { centroid[3 * (size_t)li + a] = cen[a] / (float)n; mu[a] = s[a] / n; M[a] = mu[a]; }
+    int nr = n;
+    if (n < min_pts) {
+      for (int a = 0; a < 3; ++a) EL[a] = 0.0;
+      for (int a = 0; a < 9; ++a) { Cv[a] = (a % 4 == 0) ? 1.0 : 0.0; IC[a] = 0.0; EV[a] = (a % 4 == 0) ? 1.0 : 0.0; }
+    } else {
+      const double cs[9] = {c[0], c[1], c[2], c[1], c[3], c[4], c[2], c[4], c[5]};
+      double C[9];
+      for (int a = 0; a < 3; ++a) for (int bb = 0; bb < 3; ++bb) C[3 * a + bb] = (cs[3 * a + bb] - 2 * (s[a] * mu[bb])) / n + mu[a] * mu[bb];
+      for (int a = 0; a < 9; ++a) C[a] *= (n - 1.0) / n;
+      double ev[3], V[9];
+      vx_eig3<true>(C, ev, V);
+      for (int a = 0; a < 9; ++a) EV[a] = V[a];
+      double el[3] = {0.0, 0.0, 0.0}, ic[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      if (ev[0] < 0 || ev[1] < 0 || ev[2] <= 0) nr = -1;
+      else {
+        const double min_ev = eig_mult * ev[2];
+        if (ev[0] < min_ev) {
+          ev[0] = min_ev; if (ev[1] < min_ev) ev[1] = min_ev;
+          for (int a = 0; a < 3; ++a) for (int bb = 0; bb < 3; ++bb) C[3 * a + bb] = V[3 * a] * ev[0] * V[3 * bb] + V[3 * a + 1] * ev[1] * V[3 * bb + 1] + V[3 * a + 2] * ev[2] * V[3 * bb + 2];
         }
-        for (int a = 0; a < 3; ++a) EL[a] = el[a];
-        for (int a = 0; a < 9; ++a) { Cv[a] = C[a]; IC[a] = ic[a]; }
+        for (int a = 0; a < 3; ++a) el[a] = ev[a];
+        const double c00 = C[4] * C[8] - C[5] * C[7], c01 = C[5] * C[6] - C[3] * C[8], c02 = C[3] * C[7] - C[4] * C[6];
+        const double id = 1.0 / (C[0] * c00 + C[1] * c01 + C[2] * c02);
+        ic[0] = c00 * id; ic[1] = (C[2] * C[7] - C[1] * C[8]) * id; ic[2] = (C[1] * C[5] - C[2] * C[4]) * id;
+        ic[3] = c01 * id; ic[4] = (C[0] * C[8] - C[2] * C[6]) * id; ic[5] = (C[2] * C[3] - C[0] * C[5]) * id;
+        ic[6] = c02 * id; ic[7] = (C[1] * C[6] - C[0] * C[7]) * id; ic[8] = (C[0] * C[4] - C[1] * C[3]) * id;
+        double mxv = ic[0], mnv = ic[0];
+        for (int a = 1; a < 9; ++a) { mxv = fmax(mxv, ic[a]); mnv = fmin(mnv, ic[a]); }
+        if (mxv == (double)INFINITY || mnv == -(double)INFINITY) nr = -1;
       }
-      leaf_n[li] = nr;
-      r += 256;
-      for (int a = 0; a < 3; ++a) { s[a] = 0.0; cen[a] = 0.0f; }
-      for (int a = 0; a < 6; ++a) c[a] = 0.0;
+      for (int a = 0; a < 3; ++a) EL[a] = el[a];
+      for (int a = 0; a < 9; ++a) { Cv[a] = C[a]; IC[a] = ic[a]; }
     }
+    leaf_n[li] = nr;
+  };
+  // SHORT leaves (<= VX_LONG points; all of them start inside the tile, so they lie in the first stage): one thread per leaf, sums IN INPUT ORDER (the sort is stable) —
+  // cov = (sum x x^T - 2 sum x mu^T) / n + mu mu^T cancels ~6 digits, only the reference's summation order reproduces it to 1e-12 of its own scale; the float centroid
+  // is compared bit for bit.
+  {
+    constexpr int NU = STAGE / 256;
+    int id[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) { const int j = S + tid + 256 * u; id[u] = j < E ? sorted_ids[j] : -1; }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) if (id[u] >= 0) pts[0][tid + 256 * u] = p[id[u]];
+  }
+  if (tid == 0) n_lng = 0;
+  __syncthreads();
+  for (int r = tid; r < hb; r += 256) {
+    const int la = hpos[r], le = hpos[r + 1];
+    if (le - la > VX_LONG) { lng[atomicAdd(&n_lng, 1)] = r; continue; }
+    double s[3] = {0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};   // xx xy xz yy yz zz (x_a x_b == x_b x_a bit for bit)
+    float cen[3] = {0, 0, 0};
+    for (int k = la; k < le; ++k) {
+      const float4 q = pts[0][k - S];
+      const double x = q.x, y = q.y, z = q.z;
+      s[0] += x; s[1] += y; s[2] += z;
+      c[0] += x * x; c[1] += x * y; c[2] += x * z; c[3] += y * y; c[4] += y * z; c[5] += z * z;
+      cen[0] += q.x; cen[1] += q.y; cen[2] += q.z;
+    }
+    finalize(r, la, le - la, s, c, cen);
+  }
+  __syncthreads();
+  // LONG leaves (a map cloud's walls; the pile of zero points the de-skew leaves for dropped returns: 20 k points in one voxel): the twelve running sums of a leaf —
+  // x y z | xx xy xz yy yz zz | float x y z — are twelve independent chains, each in input order: lane j of wavefront 0 takes chain j while wavefronts 1-3 stage the next
+  // 1 024 points into the other LDS buffer.  One thread walking all twelve chains of a 20 k-point leaf took 250 us (k_vx_leaf on the map cloud of lvx_data_association).
+  // x * 1.0 is exact, so the plain sums are the same chains as above.
+  const int nl_long = n_lng;
+  const int comp = tid & 15;
+  const int ia = comp < 3 ? comp : (comp < 6 ? 0 : (comp < 8 ? 1 : (comp < 9 ? 2 : (comp < 12 ? comp - 9 : 0))));
+  const int ib = comp < 3 ? 3 : (comp < 6 ? comp - 3 : (comp < 8 ? comp - 5 : 2));
+  for (int q = 0; q < nl_long; ++q) {
+    const int r = lng[q], la = hpos[r], le = hpos[r + 1];
+    auto load = [&](int c0, int buf) {   // wavefronts 1-3: positions [c0, min(le, c0 + STAGE)) -> pts[buf]
+      if (wv == 0) return;
+      for (int j0 = tid - 64; j0 < STAGE; j0 += 4 * 192) {
+        int id[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int j = j0 + 192 * u; id[u] = (j < STAGE && c0 + j < le) ? sorted_ids[c0 + j] : -1; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (id[u] >= 0) { float4 v = p[id[u]]; v.w = 1.0f; pts[buf][j0 + 192 * u] = v; }
+      }
+    };
+    int buf = 0;
+    load(la, 0);
     __syncthreads();
+    double acc = 0.0; float accf = 0.0f;
+    for (int c0 = la; c0 < le; c0 += STAGE) {
+      if (c0 + STAGE < le) load(c0 + STAGE, buf ^ 1);
+      if (tid < 16) {
+        const int m = min(le - c0, STAGE);
+        const float* pa = (const float*)&pts[buf][0] + ia; const float* pb = (const float*)&pts[buf][0] + ib;
+#pragma unroll 8
+        for (int k = 0; k < m; ++k) {
+          const float fa = pa[4 * k], fb = pb[4 * k];   // the lane's two operands by ADDRESS (w = 1.0f was staged): a per-lane select of components was compiled
+          acc += (double)fa * (double)fb;               // into divergent branches around every conversion, 300 cycles per point
+          accf += fa;
+        }
+      }
+      __syncthreads();
+      buf ^= 1;
+    }
+    if (tid < 16) {
+      double s[3], c[6]; float cen[3];
+      for (int j = 0; j < 3; ++j) s[j] = __shfl(acc, j);
+      for (int j = 0; j < 6; ++j) c[j] = __shfl(acc, 3 + j);
+      for (int j = 0; j < 3; ++j) cen[j] = __shfl(accf, 9 + j);
+      if (tid == 0) finalize(r, la, le - la, s, c, cen);
+    }
   }
 }
 // NDT derivatives: one thread per point (float arithmetic in the reference's order of operations), 43 doubles reduced per workgroup
