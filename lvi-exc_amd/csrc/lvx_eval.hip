@@ -1821,6 +1821,24 @@ static int upload_chunks(lvx_ctx* ctx, int fam, const std::vector<int>& sorted_k
   return upload_tmp(ctx, ctx->d_chunk[fam], off.data(), off.size() * 4);
 }
 
+// stable permutation that sorts small integer keys (knot intervals, -1 = out of range): a counting sort — std::stable_sort over 1 M indirect keys was a large part of
+// the 54 ms a config-4 layout took on the host
+static void stable_perm_by_key(const std::vector<int>& key, std::vector<int>& perm) {
+  const size_t n = key.size();
+  perm.resize(n);
+  if (n == 0) return;
+  int lo = key[0], hi = key[0];
+  for (size_t i = 1; i < n; ++i) { lo = std::min(lo, key[i]); hi = std::max(hi, key[i]); }
+  if ((long long)hi - lo > (long long)(4 * n + 1024)) {   // (sparse keys: comparison sort)
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
+    return;
+  }
+  std::vector<int> cnt((size_t)(hi - lo) + 2, 0);
+  for (size_t i = 0; i < n; ++i) cnt[(size_t)(key[i] - lo) + 1]++;
+  for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
+  for (size_t i = 0; i < n; ++i) perm[(size_t)cnt[(size_t)(key[i] - lo)]++] = (int)i;
+}
 int ensure_layout(lvx_ctx* ctx) {
   if (!ctx->layout_dirty) return LVX_OK;
   if (!ctx->have_spline) return fail(ctx, LVX_E_STATE, "lvx_set_spline has not been called");
@@ -1841,8 +1859,7 @@ int ensure_layout(lvx_ctx* ctx) {
     Family& f = ctx->imu;
     std::vector<int> key(f.n), perm(f.n);
     for (int i = 0; i < f.n; ++i) key[i] = host_i0(ctx, f.t[i]);
-    std::iota(perm.begin(), perm.end(), 0);
-    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
+    stable_perm_by_key(key, perm);
     { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]];
       if ((rc = upload_chunks(ctx, LVX_FAM_GYRO, sk, pick_chunk_batches(16, 64, ctx->sw.chunk_r_imu, (double)f.n / std::max(1, N - 3), 4 * (int)GyroAcc::LB)))) return rc;   // the gyroscope-only kernel of Solve #0
       // owner-computes schedule (k_imu_own): one workgroup per CU, equal row counts, boundaries on knot intervals; inside a workgroup batches of <= 256 rows spanning <= IMU_CR
@@ -1890,8 +1907,7 @@ int ensure_layout(lvx_ctx* ctx) {
     Family& f = ctx->surf;
     std::vector<int> key(f.n), perm(f.n);
     for (int i = 0; i < f.n; ++i) key[i] = host_i0(ctx, f.t[i]);
-    std::iota(perm.begin(), perm.end(), 0);
-    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
+    stable_perm_by_key(key, perm);
     { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if (ctx->sw.chunk_r) rc = upload_chunks(ctx, LVX_FAM_SURFEL, sk, pick_chunk(ctx, 8, 16, ctx->sw.chunk_r, 2, 2.2));
       else rc = upload_chunks_rows(ctx, LVX_FAM_SURFEL, sk, 16, ctx->sw.chunk_rows > 0 ? ctx->sw.chunk_rows : 512);
       if (rc) return rc; }
@@ -1989,8 +2005,7 @@ int ensure_layout(lvx_ctx* ctx) {
     Family& f = ctx->cs;
     std::vector<int> key(f.n), perm(f.n);
     for (int i = 0; i < f.n; ++i) key[i] = (f.id0[i] >= 0 && f.id0[i] < L) ? host_i0(ctx, ctx->lm_t0[f.id0[i]]) : -1;
-    std::iota(perm.begin(), perm.end(), 0);
-    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
+    stable_perm_by_key(key, perm);
     { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if (ctx->sw.chunk_r) rc = upload_chunks(ctx, LVX_FAM_CAMSURF, sk, pick_chunk(ctx, 8, 16, ctx->sw.chunk_r, 2, 2.2));
       else rc = upload_chunks_rows(ctx, LVX_FAM_CAMSURF, sk, 16, ctx->sw.chunk_rows > 0 ? ctx->sw.chunk_rows : 512);
       if (rc) return rc; }
