@@ -13,7 +13,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
+#include <utility>
+#include <vector>
 
 #include "lvx_ctx.h"
 #include "lvx_chol16.h"
@@ -63,8 +66,18 @@ __global__ void k_bcr_info(const int* info, int n, int* out) {
   if (i < n && info[i] != 0) atomicMax(out, 2000000000 + i);   // reported ahead of the dense border pivot codes (1e9 + k)
 }
 
+// rocBLAS handles are pooled per device: creating one costs ~17 ms, and the stage driver makes a new context per stage (34 ms of a 170 ms two-stage solve).  A context
+// takes a handle at its first solve and hands it back when it is destroyed; contexts that live at the same time (one per thread in the joint solve) hold different ones.
+static std::mutex g_blas_mu;
+static std::vector<std::pair<int, rocblas_handle>> g_blas_free;   // (device, handle)
 static int bcr_handle(lvx_ctx* c, rocblas_handle* h) {
-  if (!c->blas) { rocblas_handle hh; LVX_BLAS(c, rocblas_create_handle(&hh)); c->blas = hh; }
+  if (!c->blas) {
+    rocblas_handle hh = nullptr;
+    { std::lock_guard<std::mutex> lk(g_blas_mu);
+      for (size_t i = 0; i < g_blas_free.size(); ++i) if (g_blas_free[i].first == c->device) { hh = g_blas_free[i].second; g_blas_free.erase(g_blas_free.begin() + (long)i); break; } }
+    if (!hh) LVX_BLAS(c, rocblas_create_handle(&hh));
+    c->blas = hh;
+  }
   *h = (rocblas_handle)c->blas;
   LVX_BLAS(c, rocblas_set_stream(*h, c->stream));
   LVX_BLAS(c, rocblas_set_pointer_mode(*h, rocblas_pointer_mode_host));
@@ -1186,6 +1199,11 @@ int bcr_gram(lvx_ctx* c, const double* Z, int ldz, int n, double* M) {
   return LVX_OK;
 }
 
-void bcr_destroy(lvx_ctx* c) { if (c->blas) { (void)rocblas_destroy_handle((rocblas_handle)c->blas); c->blas = nullptr; } }
+void bcr_destroy(lvx_ctx* c) {
+  if (!c->blas) return;
+  std::lock_guard<std::mutex> lk(g_blas_mu);
+  if (g_blas_free.size() < 16) g_blas_free.emplace_back(c->device, (rocblas_handle)c->blas); else (void)rocblas_destroy_handle((rocblas_handle)c->blas);
+  c->blas = nullptr;
+}
 
 }  // namespace lvx

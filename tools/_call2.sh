@@ -1,3 +1,3 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-LVX_LAYOUT_TIMING=1 python tools/probes/stage_times.py 2>&1 | grep "layout\|trajInit"
+timeout 1500 python -m pytest tests/test_gpu_shared.py tests/test_gpu_solver.py tests/test_gpu_converge.py -x -q -m gpu 2>&1 | grep "passed\|failed\|Error" | tail -3
