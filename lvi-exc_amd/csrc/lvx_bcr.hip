@@ -1171,10 +1171,84 @@ int bcr_backward(lvx_ctx* c, double* Zy, double* Zx, int ldz, int nrhs) {
   }
   return LVX_OK;
 }
-// M (n x n, column-major) = Z^T Z for the tall-skinny Z [ldz x n], ldz = nblk * b.  Split-K by hand: one small GEMM per row block
-// (strided batched) into partial[nblk][n*n], then a reduction — rocBLAS' single GEMM picks a one-tile kernel for m = n = 53, k = 2e5.
-// (n*n is a few thousand entries, nparts ~ 800: the parts are split over blockIdx.y and added atomically into the zeroed M — one thread per
-// entry walking all parts was a 250 us latency chain on 11 workgroups)
+// M (n x n, column-major, both triangles) = Z^T Z for the tall-skinny Z [ldz x n] (column-major, ldz = nblk * b rows; n = border + 1 <= 80).  Split-K by hand on the matrix
+// cores: a workgroup takes GRAM_ROWS rows, stages 64 of them at a time in LDS as P[row][col] (coalesced loads along the rows, odd row stride), and every 4 panel rows are
+// one k-step of each upper tile pair — the fragment of column tile c at lane l, P[4 ks + (l >> 4)][16 c + (l & 15)], is the A operand of Z^T and the B operand of Z, as in
+// the evaluation kernels; the tile pairs are dealt to the four wavefronts.  Partial Grams per workgroup, then k_sum_partials.  Replaced rocBLAS' strided-batched GEMM
+// (one small GEMM per row block, 54 us): the last library call of a solve with blocks up to 208.
+#define GRAM_ROWS 256
+#define GRAM_NT 5
+#define GRAM_LDP (16 * GRAM_NT + 1)
+__host__ __device__ constexpr int gram_ci(int nt, int t) { int ci = 0; while (ci < nt && t >= nt - ci) { t -= nt - ci; ++ci; } return ci; }
+__host__ __device__ constexpr int gram_cj(int nt, int t) { int ci = 0; while (ci < nt && t >= nt - ci) { t -= nt - ci; ++ci; } return ci + t; }
+// the 16 k-steps of a staged panel for wavefront WV: its tile pairs are WV, WV + 4, ... of the NT (NT + 1) / 2 upper pairs — compile-time, so every column-tile fragment is
+// read from LDS once per k-step and stays in a named register
+template <int NT, int WV> __device__ __forceinline__ void gram_steps(const double* P, int lane, d4* D) {
+  constexpr int NP = NT * (NT + 1) / 2;
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const double* src = P + (4 * ks + (lane >> 4)) * GRAM_LDP + (lane & 15);
+    double f[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) f[c] = src[16 * c];
+#pragma unroll
+    for (int q = 0; q < (NP - WV + 3) / 4; ++q) D[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[gram_ci(NT, WV + 4 * q)], f[gram_cj(NT, WV + 4 * q)], D[q], 0, 0, 0);
+  }
+}
+template <int NT>
+__global__ __launch_bounds__(256) void k_gram_mfma(const double* __restrict__ Z, int ldz, int m, int n, double* __restrict__ part) {
+  __shared__ double P[64 * GRAM_LDP];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int NP = NT * (NT + 1) / 2, MAXP = (NP + 3) / 4;
+  const int r_begin = blockIdx.x * GRAM_ROWS, r_end = min(m, r_begin + GRAM_ROWS);
+  d4 D[MAXP];
+#pragma unroll
+  for (int q = 0; q < MAXP; ++q) D[q] = d4{0.0, 0.0, 0.0, 0.0};
+  // the next 64 rows are in flight (registers) while the matrix cores work on the staged ones
+  double v[4 * NT];
+  auto fetch = [&](int r0) {
+    const int i = r0 + lane;
+#pragma unroll
+    for (int u = 0; u < 4 * NT; ++u) { const int j = wv + 4 * u; v[u] = (j < n && i < r_end) ? Z[(size_t)i + (size_t)j * ldz] : 0.0; }
+  };
+  fetch(r_begin);
+  for (int r0 = r_begin; r0 < r_end; r0 += 64) {
+#pragma unroll
+    for (int u = 0; u < 4 * NT; ++u) P[lane * GRAM_LDP + wv + 4 * u] = v[u];
+    __syncthreads();
+    if (r0 + 64 < r_end) fetch(r0 + 64);
+    switch (wv) {
+      case 0: gram_steps<NT, 0>(P, lane, D); break;
+      case 1: gram_steps<NT, 1>(P, lane, D); break;
+      case 2: gram_steps<NT, 2>(P, lane, D); break;
+      default: gram_steps<NT, 3>(P, lane, D); break;
+    }
+    __syncthreads();
+  }
+  // partial Gram in TILE layout [pair][register][lane]: coalesced stores (matrix layout scattered 16 four-double segments per instruction: the epilogue of 587
+  // workgroups cost more than their products); k_sum_tiles puts the sums where they belong
+  double* out = part + (size_t)blockIdx.x * NP * 256;
+#pragma unroll
+  for (int q = 0; q < MAXP; ++q) {
+    const int t = wv + 4 * q;
+    if (t >= NP) break;
+#pragma unroll
+    for (int vv = 0; vv < 4; ++vv) out[(t * 4 + vv) * 64 + lane] = D[q][vv];
+  }
+}
+__global__ void k_sum_tiles(const double* P, int nt, int nparts, int per, int n, double* M) {
+  const int np = nt * (nt + 1) / 2, e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= np * 256) return;
+  const int p0 = blockIdx.y * per, p1 = min(nparts, p0 + per);
+  double s = 0.0;
+  for (int p = p0; p < p1; ++p) s += P[(size_t)p * np * 256 + e];
+  if (s == 0.0) return;
+  const int t = e >> 8, vv = (e >> 6) & 3, lane = e & 63, ci = gram_ci(nt, t), cj = gram_cj(nt, t);
+  const int row = 16 * ci + (lane >> 4) + 4 * vv, col = 16 * cj + (lane & 15);
+  if (row >= n || col >= n) return;
+  atomicAdd(&M[row + (size_t)col * n], s);
+  if (ci != cj) atomicAdd(&M[col + (size_t)row * n], s);
+}
 __global__ void k_sum_partials(const double* P, int nn, int nparts, int per, double* M) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nn) return;
@@ -1184,17 +1258,27 @@ __global__ void k_sum_partials(const double* P, int nn, int nparts, int per, dou
   if (s != 0.0) atomicAdd(&M[e], s);
 }
 int bcr_gram(lvx_ctx* c, const double* Z, int ldz, int n, double* M) {
-  rocblas_handle h; int rc = bcr_handle(c, &h); if (rc) return rc;
   const int b = c->bcr_b, nblk = c->bcr_nblk;
   const size_t nn = (size_t)n * n;
-  if ((rc = dev_alloc(c, c->d_Y2, (size_t)nblk * nn * 8))) return rc;
-  double* P = (double*)c->d_Y2.p;
+  const int m = nblk * b;
+  int rc;
   const double one = 1.0, zero = 0.0;
-  LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, n, n, b, &one, Z, ldz, (rocblas_stride)b, Z, ldz, (rocblas_stride)b,
-                                            &zero, P, n, (rocblas_stride)nn, nblk));
   LVX_HIP(c, hipMemsetAsync(M, 0, nn * 8, c->stream));
   const int per = 16;
-  hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((nn + 255) / 256), (unsigned)((nblk + per - 1) / per)), dim3(256), 0, c->stream, (const double*)P, (int)nn, nblk, per, M);
+  if (n <= 16 * GRAM_NT) {
+    const int nparts = (m + GRAM_ROWS - 1) / GRAM_ROWS, nt = n <= 48 ? 3 : (n <= 64 ? 4 : 5), np = nt * (nt + 1) / 2;
+    if ((rc = dev_alloc(c, c->d_Y2, (size_t)nparts * np * 256 * 8))) return rc;
+    if (nt == 3) hipLaunchKernelGGL(k_gram_mfma<3>, dim3((unsigned)nparts), dim3(256), 0, c->stream, Z, ldz, m, n, (double*)c->d_Y2.p);
+    else if (nt == 4) hipLaunchKernelGGL(k_gram_mfma<4>, dim3((unsigned)nparts), dim3(256), 0, c->stream, Z, ldz, m, n, (double*)c->d_Y2.p);
+    else hipLaunchKernelGGL(k_gram_mfma<5>, dim3((unsigned)nparts), dim3(256), 0, c->stream, Z, ldz, m, n, (double*)c->d_Y2.p);
+    hipLaunchKernelGGL(k_sum_tiles, dim3((unsigned)((np * 256 + 255) / 256), (unsigned)((nparts + per - 1) / per)), dim3(256), 0, c->stream, (const double*)c->d_Y2.p, nt, nparts, per, n, M);
+  } else {   // (more than 80 border columns: one small library GEMM per row block)
+    rocblas_handle h; if ((rc = bcr_handle(c, &h))) return rc;
+    if ((rc = dev_alloc(c, c->d_Y2, (size_t)nblk * nn * 8))) return rc;
+    LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, n, n, b, &one, Z, ldz, (rocblas_stride)b, Z, ldz, (rocblas_stride)b,
+                                              &zero, (double*)c->d_Y2.p, n, (rocblas_stride)nn, nblk));
+    hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((nn + 255) / 256), (unsigned)((nblk + per - 1) / per)), dim3(256), 0, c->stream, (const double*)c->d_Y2.p, (int)nn, nblk, per, M);
+  }
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
 }
