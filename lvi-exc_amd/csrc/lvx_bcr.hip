@@ -68,6 +68,8 @@ __global__ void k_bcr_info(const int* info, int n, int* out) {
 
 // rocBLAS handles are pooled per device: creating one costs ~17 ms, and the stage driver makes a new context per stage (34 ms of a 170 ms two-stage solve).  A context
 // takes a handle at its first solve and hands it back when it is destroyed; contexts that live at the same time (one per thread in the joint solve) hold different ones.
+#define LVX_BLAS_H(ctx, h) do { if (!(h)) { const int rh_ = bcr_handle((ctx), &(h)); if (rh_) return rh_; } } while (0)
+static int bcr_handle(lvx_ctx* c, rocblas_handle* h);
 static std::mutex g_blas_mu;
 static std::vector<std::pair<int, rocblas_handle>> g_blas_free;   // (device, handle)
 static int bcr_handle(lvx_ctx* c, rocblas_handle* h) {
@@ -705,9 +707,9 @@ template <int NT> static void launch_potrf_reg(lvx_ctx* c, double* D, int b, lon
 }
 // potrf of `batch` blocks: the register-resident kernel up to b = 208 (it also leaves the inverses of the diagonal triangles for the solves), rocSOLVER beyond
 static bool potrf_own(const lvx_ctx* c, int b) { return potrf_reg_ok(c, b); }
-static int potrf_batched(lvx_ctx* c, rocblas_handle h, double* D, int b, long long strideD, int* info, int batch, double* LI, long long strideLI) {
+static int potrf_batched(lvx_ctx* c, rocblas_handle& h, double* D, int b, long long strideD, int* info, int batch, double* LI, long long strideLI) {
   if (!potrf_own(c, b)) {
-    LVX_BLAS(c, rocsolver_dpotrf_strided_batched(h, rocblas_fill_lower, b, D, b, (rocblas_stride)strideD, info, batch));
+    { LVX_BLAS_H(c, h); LVX_BLAS(c, rocsolver_dpotrf_strided_batched(h, rocblas_fill_lower, b, D, b, (rocblas_stride)strideD, info, batch)); }
     return LVX_OK;
   }
   if (b <= 64) launch_potrf_reg<4>(c, D, b, strideD, info, batch, LI, strideLI);
@@ -1041,7 +1043,7 @@ static inline int level_batch(int nblk, int nreal, int l) {
 }
 
 int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_radius, int* info_out_d, double* Z, int ldz, int nrhs) {
-  rocblas_handle h; int rc = bcr_handle(c, &h); if (rc) return rc;
+  rocblas_handle h = nullptr; int rc = LVX_OK;   // (the handle is fetched only where a library call is really made: blocks wider than 208)
   const int b = c->bcr_b, nblk = c->bcr_nblk;
   const size_t bb = (size_t)b * b;
   double* D = (double*)c->d_bcrD.p; double* G = (double*)c->d_bcrG.p; int* info = (int*)c->d_bcrInfo.p;
@@ -1081,17 +1083,17 @@ int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_ra
     }
     // D_{j+s} -= X+ X+^T
     // (full GEMM instead of SYRK: rocBLAS' batched SYRK runs as many small launches; the upper triangle of D is never read)
-    LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, b, b, b, &mone, Gl, b, sG, Gl, b, sG, &one, Dr, b, sD, n2));
+    { LVX_BLAS_H(c, h); LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, b, b, b, &mone, Gl, b, sG, Gl, b, sG, &one, Dr, b, sD, n2)); }
     if (n2 > 1) {
       // D_{j-s} -= Y^T Y   (left neighbour of eliminated k is the right neighbour of eliminated k-1)
-      LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, b, b, &mone, Gl + bb, b, sG, Gl + bb, b, sG, &one, Dr, b, sD, n2 - 1));
+      { LVX_BLAS_H(c, h); LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, b, b, &mone, Gl + bb, b, sG, Gl + bb, b, sG, &one, Dr, b, sD, n2 - 1)); }
       // next level's coupling A_{j+s,j-s} = -X+_k Y_k
-      LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, b, b, &mone, Gl + 2 * bb, b, sG, Gl + bb, b, sG, &zero, Gn, b, (rocblas_stride)bb, n2 - 1));
+      { LVX_BLAS_H(c, h); LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, b, b, &mone, Gl + 2 * bb, b, sG, Gl + bb, b, sG, &zero, Gn, b, (rocblas_stride)bb, n2 - 1)); }
     }
     if (Z) {   // b_{j+s} -= X+ y_j,  b_{j-s} -= Y^T y_j
-      LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, nrhs, b, &mone, Gl, b, sG, Zj, ldz, sZ, &one, Zr, ldz, sZ, n2));
+      { LVX_BLAS_H(c, h); LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, nrhs, b, &mone, Gl, b, sG, Zj, ldz, sZ, &one, Zr, ldz, sZ, n2)); }
       if (n2 > 1)
-        LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, nrhs, b, &mone, Gl + bb, b, sG, Zj + sZ, ldz, sZ, &one, Zr, ldz, sZ, n2 - 1));
+        { LVX_BLAS_H(c, h); LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, nrhs, b, &mone, Gl + bb, b, sG, Zj + sZ, ldz, sZ, &one, Zr, ldz, sZ, n2 - 1)); }
     }
   }
   double* LIlast = LI ? LI + (size_t)(nblk - 1) * liS : nullptr;
@@ -1105,7 +1107,7 @@ int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_ra
 
 // Zin: column-major [ldz x nrhs] right-hand sides; in place Zin <- L^-1 Zin (Zy aliases Zin; kept in the signature for the caller's bookkeeping)
 int bcr_forward(lvx_ctx* c, double* Zin, double* Zy, int ldz, int nrhs) {
-  rocblas_handle h; int rc = bcr_handle(c, &h); if (rc) return rc;
+  rocblas_handle h = nullptr; int rc = LVX_OK;   // (the handle is fetched only where a library call is really made: blocks wider than 208)
   (void)Zy;
   double* Z = Zin;
   const int b = c->bcr_b, nblk = c->bcr_nblk;
@@ -1124,15 +1126,15 @@ int bcr_forward(lvx_ctx* c, double* Zin, double* Zy, int ldz, int nrhs) {
     double* Zj = Z + (size_t)(s - 1) * b;
     double* Zr = Z + (size_t)(2 * s - 1) * b;
     if ((rc = trsv_batched<false>(c, Dj, b, sD, Zj, 1, ldz, sZ, nrhs, n2, LI ? LI + (size_t)(s - 1) * liS : nullptr, (long long)2 * s * liS))) return rc;                      // y_j = C_j^-1 b_j
-    LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, nrhs, b, &mone, Gl, b, sG, Zj, ldz, sZ, &one, Zr, ldz, sZ, n2));
+    { LVX_BLAS_H(c, h); LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, nrhs, b, &mone, Gl, b, sG, Zj, ldz, sZ, &one, Zr, ldz, sZ, n2)); }
     if (n2 > 1)
-      LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, nrhs, b, &mone, Gl + bb, b, sG, Zj + sZ, ldz, sZ, &one, Zr, ldz, sZ, n2 - 1));
+      { LVX_BLAS_H(c, h); LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, nrhs, b, &mone, Gl + bb, b, sG, Zj + sZ, ldz, sZ, &one, Zr, ldz, sZ, n2 - 1)); }
   }
   return trsv_batched<false>(c, D + (size_t)(nblk - 1) * bb, b, 0, Z + (size_t)(nblk - 1) * b, 1, ldz, 0, nrhs, 1, LI ? LI + (size_t)(nblk - 1) * liS : nullptr, 0);
 }
 // in place Zy <- L^-T Zy (Zx aliases Zy)
 int bcr_backward(lvx_ctx* c, double* Zy, double* Zx, int ldz, int nrhs) {
-  rocblas_handle h; int rc = bcr_handle(c, &h); if (rc) return rc;
+  rocblas_handle h = nullptr; int rc = LVX_OK;   // (the handle is fetched only where a library call is really made: blocks wider than 208)
   (void)Zx;
   double* Z = Zy;
   const int b = c->bcr_b, nblk = c->bcr_nblk;
@@ -1164,9 +1166,9 @@ int bcr_backward(lvx_ctx* c, double* Zy, double* Zx, int ldz, int nrhs) {
       LVX_HIP(c, hipGetLastError());
       continue;
     }
-    LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, nrhs, b, &mone, Gl, b, sG, Zr, ldz, sZ, &one, Zj, ldz, sZ, n2));
+    { LVX_BLAS_H(c, h); LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, nrhs, b, &mone, Gl, b, sG, Zr, ldz, sZ, &one, Zj, ldz, sZ, n2)); }
     if (n2 > 1)
-      LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, nrhs, b, &mone, Gl + bb, b, sG, Zr, ldz, sZ, &one, Zj + sZ, ldz, sZ, n2 - 1));
+      { LVX_BLAS_H(c, h); LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, nrhs, b, &mone, Gl + bb, b, sG, Zr, ldz, sZ, &one, Zj + sZ, ldz, sZ, n2 - 1)); }
     if ((rc = trsv_batched<true>(c, Dj, b, sD, Zj, 1, ldz, sZ, nrhs, n2, LI ? LI + (size_t)(s - 1) * liS : nullptr, (long long)2 * s * liS))) return rc;
   }
   return LVX_OK;
