@@ -1182,17 +1182,27 @@ __global__ void k_assoc_select(unsigned* __restrict__ bits, int* __restrict__ co
   }
 }
 // Chronological SurfelPoint emission (surfel_association.cpp:141-158): column-major (w outer, h inner), points with a flag and a non-zero raw
-// timestamp.  One workgroup per scan; order-preserving compaction by ballots + a running offset.  mode 0: count only; mode 1: write at offs[scan].
+// timestamp.  One workgroup per scan; order-preserving compaction by ballots + a running offset.  mode 0: count only; mode 1: write behind the scans before this one
+// (their counts of the mode-0 launch, summed here: no host hop between the two launches), nothing at all when the list would not fit max_out.
 struct SurfelOut { double* pt; double* pt_map; double* t; int* plane; };
-__global__ __launch_bounds__(1024) void k_assoc_emit(const int* __restrict__ flags, const float4* __restrict__ scans_map, const void* __restrict__ raw_v, int H, int W, int* counts, const int* offs, int mode, SurfelOut o) {
+__global__ __launch_bounds__(1024) void k_assoc_emit(const int* __restrict__ flags, const float4* __restrict__ scans_map, const void* __restrict__ raw_v, int H, int W, int* counts, int n_scans, int max_out, int mode, SurfelOut o) {
   struct Raw { float x, y, z, pad; float intensity; float pad2; double timestamp; };
   const Raw* raw = (const Raw*)raw_v;
   __shared__ int wsum[16];
   __shared__ int running;
   const int sc = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = H * W;
-  if (threadIdx.x == 0) running = 0;
+  __shared__ int s_base, s_total;
+  if (threadIdx.x == 0) { running = 0; s_base = 0; s_total = 0; }
   __syncthreads();
-  const int base_out = mode ? offs[sc] : 0;
+  if (mode) {
+    int mine = 0, all = 0;
+    for (int k = threadIdx.x; k < n_scans; k += blockDim.x) { const int ck = counts[k]; all += ck; if (k < sc) mine += ck; }
+    if (mine) atomicAdd(&s_base, mine);
+    if (all) atomicAdd(&s_total, all);
+    __syncthreads();
+    if (s_total > max_out) return;
+  }
+  const int base_out = s_base;
   for (int e0 = 0; e0 < n; e0 += 1024) {
     const int e = e0 + threadIdx.x;                 // position in the emission order: e = w * H + h
     bool keep = false; int idx = 0, pid = -1;
@@ -1295,12 +1305,15 @@ __global__ void k_lidar_pose(const double* state, int N, double t0, double dt, i
 }
 struct PointXYZIT { float x, y, z, pad; float intensity; float pad2; double timestamp; };
 static_assert(sizeof(PointXYZIT) == 32, "PointXYZIT layout (pcl_utils.h:39-44)");
-__global__ void k_undistort(const double* state, int N, double t0, double dt, int n, const PointXYZIT* raw, quat qGt, v3 pT, int correct_position, float4* out) {
+// pose_d != null: the target frame's pose (q_L0_to_G x y z w | p | valid flag behind them) is still on the device (k_lidar_pose of the same stream): no host hop between the two
+// kernels; an invalid pose (map time outside the trajectory) gives NaN points, the host reports it at its next synchronisation
+__global__ void k_undistort(const double* state, int N, double t0, double dt, int n, const PointXYZIT* raw, quat qGt, v3 pT, int correct_position, float4* out, const double* pose_d = nullptr, const int* pose_ok = nullptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const PointXYZIT r = raw[i];
   float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (isnan(r.x)) { o.x = o.y = o.z = NAN; out[i] = o; return; }
+  if (pose_d) { qGt = quat{-pose_d[0], -pose_d[1], -pose_d[2], pose_d[3]}; pT = mk(pose_d[4], pose_d[5], pose_d[6]); }
+  if (isnan(r.x) || (pose_ok && !*pose_ok)) { o.x = o.y = o.z = NAN; out[i] = o; return; }
   quat q; v3 p;
   if (lidar_pose_dev(state, N, t0, dt, r.timestamp, &q, &p)) {
     const quat qk0 = qmul(qGt, q);
@@ -1772,23 +1785,23 @@ int lvx_surfel_emit_d(lvx_ctx* c, int n_scans, int H, int W, const int32_t* flag
                       double* pt3_d, double* pt_map3_d, double* t_d, int32_t* plane_d, int32_t* n_out, int32_t* per_scan_counts) {
   if (!c || n_scans <= 0 || H <= 0 || W <= 0 || !flags_d || !scans_map_d || !scans_raw_d || !n_out || max_out < 0) return LVX_E_ARG;
   LVX_HIP(c, hipSetDevice(c->device));
-  int rc = dev_alloc(c, c->d_assoc[2], (size_t)n_scans * 8 + 16); if (rc) return rc;
-  int* cnt_d = (int*)c->d_assoc[2].p; int* off_d = cnt_d + n_scans;
+  int rc = dev_alloc(c, c->d_assoc[2], (size_t)n_scans * 4 + 16); if (rc) return rc;
+  int* cnt_d = (int*)c->d_assoc[2].p;
   ProfScope ps(c, LVX_KERNEL_UPSTREAM);
   SurfelOut o{pt3_d, pt_map3_d, t_d, plane_d};
-  hipLaunchKernelGGL(k_assoc_emit, dim3((unsigned)n_scans), dim3(1024), 0, c->stream, flags_d, (const float4*)scans_map_d, (const void*)scans_raw_d, H, W, cnt_d, (const int*)off_d, 0, o);
-  std::vector<int> cnt((size_t)n_scans), off((size_t)n_scans);
+  const bool have_out = pt3_d && pt_map3_d && t_d && plane_d && max_out > 0;
+  hipLaunchKernelGGL(k_assoc_emit, dim3((unsigned)n_scans), dim3(1024), 0, c->stream, flags_d, (const float4*)scans_map_d, (const void*)scans_raw_d, H, W, cnt_d, n_scans, 0, 0, o);
+  if (have_out)   // written only if the whole list fits max_out (decided on the device from the counts): one host synchronisation per call
+    hipLaunchKernelGGL(k_assoc_emit, dim3((unsigned)n_scans), dim3(1024), 0, c->stream, flags_d, (const float4*)scans_map_d, (const void*)scans_raw_d, H, W, cnt_d, n_scans, max_out, 1, o);
+  std::vector<int> cnt((size_t)n_scans);
   LVX_HIP(c, hipMemcpyAsync(cnt.data(), cnt_d, (size_t)n_scans * 4, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipGetLastError());
   LVX_HIP(c, hipStreamSynchronize(c->stream));
   int total = 0;
-  for (int s = 0; s < n_scans; ++s) { off[s] = total; total += cnt[s]; if (per_scan_counts) per_scan_counts[s] = cnt[s]; }
+  for (int s = 0; s < n_scans; ++s) { total += cnt[s]; if (per_scan_counts) per_scan_counts[s] = cnt[s]; }
   *n_out = total;
   if (total > max_out || total == 0) return LVX_OK;   // the caller sizes the outputs from *n_out and calls again
-  if (!pt3_d || !pt_map3_d || !t_d || !plane_d) return LVX_E_ARG;
-  LVX_HIP(c, hipMemcpyAsync(off_d, off.data(), (size_t)n_scans * 4, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_assoc_emit, dim3((unsigned)n_scans), dim3(1024), 0, c->stream, flags_d, (const float4*)scans_map_d, (const void*)scans_raw_d, H, W, cnt_d, (const int*)off_d, 1, o);
-  LVX_HIP(c, hipGetLastError());
-  LVX_HIP(c, hipStreamSynchronize(c->stream));      // off lives on this frame
+  if (!have_out) return LVX_E_ARG;
   return LVX_OK;
 }
 
@@ -1967,21 +1980,16 @@ int lvx_data_association(lvx_ctx* c, const double* state, double map_time, const
   if ((rc = dev_alloc(c, c->d_da[3], 64 + 8))) return rc;
   double* dq = (double*)c->d_da[3].p; double* dp = dq + 4; int* dv = (int*)(dp + 3);
   hipLaunchKernelGGL(k_lidar_pose, dim3(1), dim3(1), 0, st, (const double*)c->d_da[1].p, c->N, c->t0, c->dt, 1, (const double*)c->d_da[2].p, dq, dp, dv);
-  double h[8] = {0}; int hv = 0;
-  LVX_HIP(c, hipMemcpyAsync(h, dq, 56, hipMemcpyDeviceToHost, st));
-  LVX_HIP(c, hipMemcpyAsync(&hv, dv, 4, hipMemcpyDeviceToHost, st));
-  LVX_HIP(c, hipStreamSynchronize(st));
-  if (!hv) return fail(c, LVX_E_RANGE, "map time outside the trajectory");
-  const double qGt[4] = {-h[0], -h[1], -h[2], h[3]};   // q_L0_to_G.conjugate()
   if ((rc = dev_alloc(c, c->d_da[4], npt * 16))) return rc;
   hipLaunchKernelGGL(k_undistort, dim3((unsigned)((npt + 255) / 256)), dim3(256), 0, st, (const double*)c->d_da[1].p, c->N, c->t0, c->dt, (int)npt, (const PointXYZIT*)c->d_da[0].p,
-                     load_q(qGt), load_v3(h + 4), 1, (float4*)c->d_da[4].p);
+                     quat{0, 0, 0, 1}, mk(0, 0, 0), 1, (float4*)c->d_da[4].p, (const double*)dq, (const int*)dv);   // the pose stays on the device (q_L0_to_G.conjugate() is taken there)
   // 2. LiDAROdometry::ndtInit(resolution) + setInputTarget(map_cloud): the voxel covariance grid of the map cloud
   c->vox.d_pts = c->d_da[4].p;
   if ((rc = voxel_build_device(c, (const float4*)c->d_da[4].p, (int)npt, o.ndt_resolution, o.min_points_per_voxel, o.min_covar_eigvalue_mult))) return rc;
   // 3. SurfelAssociation::setSurfelMap
   std::vector<SurfelPlaneDev> acc;
   if ((rc = surfel_extract_device(c, o.plane_lambda, o.fit_threshold, o.min_leaf_points, o.min_inliers, acc))) return rc;
+  { int hv = 0; LVX_HIP(c, hipMemcpy(&hv, dv, 4, hipMemcpyDeviceToHost)); if (!hv) return fail(c, LVX_E_RANGE, "map time outside the trajectory"); }   // (the stream has been waited for above)
   const int P = (int)acc.size();
   c->da_planes.resize((size_t)P);
   if (P > 0) std::memcpy(c->da_planes.data(), acc.data(), (size_t)P * sizeof(SurfelPlaneDev));
@@ -1998,13 +2006,11 @@ int lvx_data_association(lvx_ctx* c, const double* state, double map_time, const
   rc = lvx_surfel_assoc_batch_d(c, S, H, W, (const float*)c->d_da[4].p, P, (const double*)c->d_da[5].p, o.radius, o.selected_per_ring, (int32_t*)c->d_da[6].p);
   lvx_surfel_map_release(c);
   if (rc) return rc;
+  // outputs strided by the CAPACITY (every scan point could be a SurfelPoint): count + write in one call, one host synchronisation
   int32_t total = 0;
-  if ((rc = lvx_surfel_emit_d(c, S, H, W, (const int32_t*)c->d_da[6].p, (const float*)c->d_da[4].p, (const lvx_point_xyzit*)c->d_da[0].p, 0, nullptr, nullptr, nullptr, nullptr, &total, nullptr))) return rc;
-  if (total > 0) {
-    if ((rc = dev_alloc(c, c->d_da[7], (size_t)total * (24 + 24 + 8 + 4) + 64))) return rc;
-    double* d_pt = (double*)c->d_da[7].p; double* d_pm = d_pt + 3 * (size_t)total; double* d_t = d_pm + 3 * (size_t)total; int32_t* d_pl = (int32_t*)(d_t + total);
-    if ((rc = lvx_surfel_emit_d(c, S, H, W, (const int32_t*)c->d_da[6].p, (const float*)c->d_da[4].p, (const lvx_point_xyzit*)c->d_da[0].p, total, d_pt, d_pm, d_t, d_pl, &total, nullptr))) return rc;
-  }
+  if ((rc = dev_alloc(c, c->d_da[7], npt * (24 + 24 + 8 + 4) + 64))) return rc;
+  { double* d_pt = (double*)c->d_da[7].p; double* d_pm = d_pt + 3 * npt; double* d_t = d_pm + 3 * npt; int32_t* d_pl = (int32_t*)(d_t + npt);
+    if ((rc = lvx_surfel_emit_d(c, S, H, W, (const int32_t*)c->d_da[6].p, (const float*)c->d_da[4].p, (const lvx_point_xyzit*)c->d_da[0].p, (int)npt, d_pt, d_pm, d_t, d_pl, &total, nullptr))) return rc; }
   c->da_points = total;
   if (n_points) *n_points = total;
   return LVX_OK;
@@ -2020,7 +2026,8 @@ int lvx_get_surfel_points(lvx_ctx* c, int max_points, double* pt3, double* pt_ma
   const size_t total = (size_t)c->da_points, n = std::min((size_t)max_points, total);
   if (n == 0) return LVX_OK;
   LVX_HIP(c, hipSetDevice(c->device));
-  const double* d_pt = (const double*)c->d_da[7].p; const double* d_pm = d_pt + 3 * total; const double* d_t = d_pm + 3 * total; const int32_t* d_pl = (const int32_t*)(d_t + total);
+  const size_t cap = (size_t)c->da_S * c->da_H * c->da_W;   // the lists are strided by the capacity (lvx_data_association)
+  const double* d_pt = (const double*)c->d_da[7].p; const double* d_pm = d_pt + 3 * cap; const double* d_t = d_pm + 3 * cap; const int32_t* d_pl = (const int32_t*)(d_t + cap);
   if (pt3) LVX_HIP(c, hipMemcpyAsync(pt3, d_pt, n * 24, hipMemcpyDeviceToHost, c->stream));
   if (pt_map3) LVX_HIP(c, hipMemcpyAsync(pt_map3, d_pm, n * 24, hipMemcpyDeviceToHost, c->stream));
   if (t) LVX_HIP(c, hipMemcpyAsync(t, d_t, n * 8, hipMemcpyDeviceToHost, c->stream));
