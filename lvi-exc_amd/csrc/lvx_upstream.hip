@@ -1001,6 +1001,39 @@ __global__ __launch_bounds__(256) void k_surfel_extract(const float4* __restrict
   P.p4[3] = d; P.leaf = li; P.n_points = n; P.n_inliers = nin; P.plane_type = t2;
   flag[li] = 1;
 }
+// accepted planes in leaf (= voxel key = std::map) order, compacted on the device: records first, then — behind them, 16-byte aligned — the association's plane table
+// [p4 (4 P) | box min (3 P) | box max (3 P)]; one workgroup, ballot ranks + a running offset (the host used to fetch every leaf's record and flag, compact, rebuild the
+// table and upload it again)
+__global__ __launch_bounds__(1024) void k_surfel_compact(const SurfelPlaneDev* __restrict__ all, const int* __restrict__ flag, int nl, SurfelPlaneDev* recs, int* count) {
+  __shared__ int wsum[16];
+  __shared__ int running;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0) running = 0;
+  __syncthreads();
+  for (int l0 = 0; l0 < nl; l0 += 1024) {
+    const int li = l0 + threadIdx.x;
+    const bool keep = li < nl && flag[li] != 0;
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) wsum[wv] = __popcll(m);
+    __syncthreads();
+    int before = running;
+    for (int k = 0; k < wv; ++k) before += wsum[k];
+    if (keep) recs[before + __popcll(m & ((1ull << lane) - 1ull))] = all[li];
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = running; for (int k = 0; k < 16; ++k) t += wsum[k]; running = t; }
+    __syncthreads();
+  }
+  const int P = running;
+  if (threadIdx.x == 0) *count = P;
+  __threadfence_block();
+  __syncthreads();
+  double* pl = (double*)((char*)recs + (((size_t)P * sizeof(SurfelPlaneDev) + 15) & ~(size_t)15));
+  for (int k = threadIdx.x; k < P; k += 1024) {
+    const SurfelPlaneDev r = recs[k];
+    for (int a = 0; a < 4; ++a) pl[4 * (size_t)k + a] = r.p4[a];
+    for (int a = 0; a < 3; ++a) { pl[4 * (size_t)P + 3 * (size_t)k + a] = r.bmin[a]; pl[7 * (size_t)P + 3 * (size_t)k + a] = r.bmax[a]; }
+  }
+}
 // K = 7: getNeighborhoodAtPoint7 (:423-438), K = 1: getNeighborhoodAtPoint1 (:440-446, the cell of the point only)
 template <int K>
 __global__ void k_vx_lookup(const float4* q, int nq, float leaf, int min_pts, VxGrid g, const int* grid, const int* leaf_n, int* ids7) {
@@ -1904,7 +1937,7 @@ int lvx_undistort_scan(lvx_ctx* c, const double* state, int n, const lvx_point_x
 }
 
 // setSurfelMap over the leaves of the context's voxel grid: the accepted planes in voxel-key (std::map) order
-static int surfel_extract_device(lvx_ctx* c, double p_lambda, double dist_threshold, int min_leaf_points, int min_inliers, std::vector<SurfelPlaneDev>& out) {
+static int surfel_extract_device(lvx_ctx* c, double p_lambda, double dist_threshold, int min_leaf_points, int min_inliers, std::vector<SurfelPlaneDev>& out, DevBuf& dst) {
   out.clear();
   { const int rc0 = vox_info(c); if (rc0) return rc0; }
   const lvx_ctx::Voxels& V = c->vox;
@@ -1921,11 +1954,15 @@ static int surfel_extract_device(lvx_ctx* c, double p_lambda, double dist_thresh
     hipLaunchKernelGGL(k_surfel_extract, dim3((nl + 3) / 4), dim3(256), 0, c->stream, (const float4*)V.d_pts, counts, offs, (const int*)V.vals.p + n, nl, lk + cap, d, d + 21 * cap,
                        d + 30 * cap, p_lambda, dist_threshold, min_leaf_points, min_inliers, (SurfelPlaneDev*)c->d_up[4].p, (int*)c->d_up[5].p); }
   LVX_HIP(c, hipGetLastError());
-  std::vector<SurfelPlaneDev> all(nl); std::vector<int> flag(nl);
-  LVX_HIP(c, hipMemcpyAsync(all.data(), c->d_up[4].p, (size_t)nl * sizeof(SurfelPlaneDev), hipMemcpyDeviceToHost, c->stream));
-  LVX_HIP(c, hipMemcpyAsync(flag.data(), c->d_up[5].p, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
+  // compaction on the device: [records | plane table] in dst, the count comes back (4 bytes), then the records
+  if ((rc = dev_alloc(c, dst, (size_t)nl * (sizeof(SurfelPlaneDev) + 80) + 64))) return rc;
+  int* d_cnt = (int*)((char*)dst.p + dst.bytes - 16);
+  hipLaunchKernelGGL(k_surfel_compact, dim3(1), dim3(1024), 0, c->stream, (const SurfelPlaneDev*)c->d_up[4].p, (const int*)c->d_up[5].p, nl, (SurfelPlaneDev*)dst.p, d_cnt);
+  int P = 0;
+  LVX_HIP(c, hipMemcpyAsync(&P, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
   LVX_HIP(c, hipStreamSynchronize(c->stream));
-  for (int li = 0; li < nl; ++li) if (flag[li]) out.push_back(all[li]);   // leaf order = voxel key order (std::map)
+  out.resize((size_t)P);
+  if (P > 0) LVX_HIP(c, hipMemcpy(out.data(), dst.p, (size_t)P * sizeof(SurfelPlaneDev), hipMemcpyDeviceToHost));
   return LVX_OK;
 }
 int lvx_surfel_extract(lvx_ctx* c, double p_lambda, double dist_threshold, int min_leaf_points, int min_inliers, int max_planes, lvx_surfel_plane* planes, int32_t* n_planes) {
@@ -1934,7 +1971,7 @@ int lvx_surfel_extract(lvx_ctx* c, double p_lambda, double dist_threshold, int m
   LVX_HIP(c, hipSetDevice(c->device));
   *n_planes = 0;
   std::vector<SurfelPlaneDev> acc;
-  int rc = surfel_extract_device(c, p_lambda, dist_threshold, min_leaf_points, min_inliers, acc);
+  int rc = surfel_extract_device(c, p_lambda, dist_threshold, min_leaf_points, min_inliers, acc, c->d_up[6]);
   if (rc) return rc;
   const int np = (int)acc.size();
   if (np > 0 && max_planes > 0) std::memcpy(planes, acc.data(), (size_t)std::min(np, max_planes) * sizeof(SurfelPlaneDev));
@@ -1988,22 +2025,19 @@ int lvx_data_association(lvx_ctx* c, const double* state, double map_time, const
   if ((rc = voxel_build_device(c, (const float4*)c->d_da[4].p, (int)npt, o.ndt_resolution, o.min_points_per_voxel, o.min_covar_eigvalue_mult))) return rc;
   // 3. SurfelAssociation::setSurfelMap
   std::vector<SurfelPlaneDev> acc;
-  if ((rc = surfel_extract_device(c, o.plane_lambda, o.fit_threshold, o.min_leaf_points, o.min_inliers, acc))) return rc;
+  lvx_surfel_map_release(c);
+  if ((rc = surfel_extract_device(c, o.plane_lambda, o.fit_threshold, o.min_leaf_points, o.min_inliers, acc, c->d_da[5]))) return rc;   // records + the association's plane table stay in d_da[5]
   { int hv = 0; LVX_HIP(c, hipMemcpy(&hv, dv, 4, hipMemcpyDeviceToHost)); if (!hv) return fail(c, LVX_E_RANGE, "map time outside the trajectory"); }   // (the stream has been waited for above)
   const int P = (int)acc.size();
   c->da_planes.resize((size_t)P);
   if (P > 0) std::memcpy(c->da_planes.data(), acc.data(), (size_t)P * sizeof(SurfelPlaneDev));
   if (n_planes) *n_planes = P;
   if (P == 0) return LVX_OK;
-  std::vector<double> pl((size_t)P * 10);
-  for (int k = 0; k < P; ++k) { for (int a = 0; a < 4; ++a) pl[4 * (size_t)k + a] = acc[k].p4[a]; for (int a = 0; a < 3; ++a) { pl[4 * (size_t)P + 3 * (size_t)k + a] = acc[k].bmin[a]; pl[7 * (size_t)P + 3 * (size_t)k + a] = acc[k].bmax[a]; } }
-  lvx_surfel_map_release(c);
-  if ((rc = upload(c, c->d_da[5], pl.data(), pl.size() * 8))) return rc;
-  LVX_HIP(c, hipStreamSynchronize(st));   // pl lives on this frame
+  const double* planes_d = (const double*)((const char*)c->d_da[5].p + (((size_t)P * sizeof(SurfelPlaneDev) + 15) & ~(size_t)15));
   // 4. getAssociation for every scan: flags (one surfel grid for all scans), then the chronological SurfelPoint lists, scans concatenated
   if ((rc = dev_alloc(c, c->d_da[6], npt * 4))) return rc;
-  if (S > 2 && (rc = lvx_surfel_map_prepare_d(c, P, (const double*)c->d_da[5].p))) return rc;
-  rc = lvx_surfel_assoc_batch_d(c, S, H, W, (const float*)c->d_da[4].p, P, (const double*)c->d_da[5].p, o.radius, o.selected_per_ring, (int32_t*)c->d_da[6].p);
+  if (S > 2 && (rc = lvx_surfel_map_prepare_d(c, P, planes_d))) return rc;
+  rc = lvx_surfel_assoc_batch_d(c, S, H, W, (const float*)c->d_da[4].p, P, planes_d, o.radius, o.selected_per_ring, (int32_t*)c->d_da[6].p);
   lvx_surfel_map_release(c);
   if (rc) return rc;
   // outputs strided by the CAPACITY (every scan point could be a SurfelPoint): count + write in one call, one host synchronisation
