@@ -15,6 +15,7 @@
 #include <numeric>
 #include <cstdlib>
 
+#include <thread>
 #include "lvx_ctx.h"
 
 namespace lvx {
@@ -1691,9 +1692,20 @@ int upload_tmp(lvx_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
 
 namespace {
 
+// host loops over a million measurements (keys, gathers, row-ordered plane copies) on a few threads: the layout of a config-4 stage is host time between two solves
+template <class F> void par_for(size_t n, F&& fn) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const size_t nt = n < 200000 ? 1 : std::min<size_t>(8, hw ? hw : 1);
+  if (nt <= 1) { fn((size_t)0, n); return; }
+  std::vector<std::thread> th;
+  const size_t per = (n + nt - 1) / nt;
+  for (size_t t = 1; t < nt; ++t) { const size_t a = std::min(n, t * per), b = std::min(n, a + per); if (a < b) th.emplace_back([&fn, a, b] { fn(a, b); }); }
+  fn((size_t)0, std::min(n, per));
+  for (auto& x : th) x.join();
+}
 template <class T> std::vector<T> gather(const std::vector<T>& v, const std::vector<int>& perm, int width) {
   std::vector<T> o(perm.size() * width);
-  for (size_t i = 0; i < perm.size(); ++i) for (int k = 0; k < width; ++k) o[i * width + k] = v[(size_t)perm[i] * width + k];
+  par_for(perm.size(), [&](size_t a, size_t b) { for (size_t i = a; i < b; ++i) for (int k = 0; k < width; ++k) o[i * width + k] = v[(size_t)perm[i] * width + k]; });
   return o;
 }
 
@@ -1858,7 +1870,7 @@ int ensure_layout(lvx_ctx* ctx) {
   {
     Family& f = ctx->imu;
     std::vector<int> key(f.n), perm(f.n);
-    for (int i = 0; i < f.n; ++i) key[i] = host_i0(ctx, f.t[i]);
+    par_for((size_t)f.n, [&](size_t a, size_t b) { for (size_t i = a; i < b; ++i) key[i] = host_i0(ctx, f.t[i]); });
     stable_perm_by_key(key, perm);
     { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]];
       if ((rc = upload_chunks(ctx, LVX_FAM_GYRO, sk, pick_chunk_batches(16, 64, ctx->sw.chunk_r_imu, (double)f.n / std::max(1, N - 3), 4 * (int)GyroAcc::LB)))) return rc;   // the gyroscope-only kernel of Solve #0
@@ -1906,7 +1918,7 @@ int ensure_layout(lvx_ctx* ctx) {
   {
     Family& f = ctx->surf;
     std::vector<int> key(f.n), perm(f.n);
-    for (int i = 0; i < f.n; ++i) key[i] = host_i0(ctx, f.t[i]);
+    par_for((size_t)f.n, [&](size_t a, size_t b) { for (size_t i = a; i < b; ++i) key[i] = host_i0(ctx, f.t[i]); });
     stable_perm_by_key(key, perm);
     { std::vector<int> sk(f.n); for (int i = 0; i < f.n; ++i) sk[i] = key[perm[i]]; if (ctx->sw.chunk_r) rc = upload_chunks(ctx, LVX_FAM_SURFEL, sk, pick_chunk(ctx, 8, 16, ctx->sw.chunk_r, 2, 2.2));
       else rc = upload_chunks_rows(ctx, LVX_FAM_SURFEL, sk, 16, ctx->sw.chunk_rows > 0 ? ctx->sw.chunk_rows : 512);
@@ -1919,7 +1931,7 @@ int ensure_layout(lvx_ctx* ctx) {
     // the fused kernel reads each row's plane from a row-ordered copy (planes are inputs, fixed between layouts): no dependent gather
     std::vector<double> rowpl((size_t)f.n * 3, 0.0);
     const long long npl = (long long)ctx->planes.size() / 3;
-    for (int i = 0; i < f.n; ++i) if (pl[i] >= 0 && pl[i] < npl) for (int c = 0; c < 3; ++c) rowpl[3 * (size_t)i + c] = ctx->planes[3 * (size_t)pl[i] + c];
+    par_for((size_t)f.n, [&](size_t a, size_t b) { for (size_t i = a; i < b; ++i) if (pl[i] >= 0 && pl[i] < npl) for (int c = 0; c < 3; ++c) rowpl[3 * i + c] = ctx->planes[3 * (size_t)pl[i] + c]; });
     if ((rc = upload_tmp(ctx, f.d_b3, rowpl.data(), rowpl.size() * 8))) return rc;
   }
   {
