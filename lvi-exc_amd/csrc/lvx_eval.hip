@@ -1815,7 +1815,10 @@ static int upload_chunks_rows_grouped(lvx_ctx* ctx, int fam, const std::vector<i
     i = std::max(e, i + (n > 0 ? 1 : 0));
   } while (i < n);
   off.push_back(n);
-  ctx->n_chunk[fam] = (int)k0.size(); ctx->chunk_r[fam] = rmax; ctx->chunk_var[fam] = 1;
+  // the kernel's accumulator window (and its LDS footprint, hence how many of these latency-bound workgroups a CU holds) follows the widest chunk that EXISTS, not the
+  // widest one allowed: a camera frame spans ~4 intervals, rmax is 48 (100 KB of LDS = one workgroup per CU)
+  int smax = 4; for (int v : span) smax = std::max(smax, v);
+  ctx->n_chunk[fam] = (int)k0.size(); ctx->chunk_r[fam] = std::min(rmax, smax); ctx->chunk_var[fam] = 1;
   ctx->h_chunk_k0[fam] = k0; ctx->h_chunk_rows[fam].assign(k0.size(), 0); for (size_t c = 0; c < k0.size(); ++c) ctx->h_chunk_rows[fam][c] = off[c + 1] - off[c];
   off.insert(off.end(), k0.begin(), k0.end());
   off.insert(off.end(), span.begin(), span.end());
