@@ -731,7 +731,7 @@ static int potrf_batched(lvx_ctx* c, rocblas_handle& h, double* D, int b, long l
 __device__ __forceinline__ int coff(int b, int i) { return i * b - ((i * (i - 1)) >> 1); }   // start of column i (rows i .. b - 1) in the column-packed lower triangle
 #define BACK_NT 512
 __global__ __launch_bounds__(BACK_NT) void k_bcr_back_level(const double* __restrict__ Dj, long long sD, const double* __restrict__ LIj, long long sLI, const double* __restrict__ Gl, long long sG,
-                                                        double* Z, long long zj_off, long long zr_off, long long sZ, int b, int n2, long long bb) {
+                                                        double* Z, long long zj_off, long long zr_off, long long sZ, int b, int n2, long long bb, int det) {
   extern __shared__ double sh[];
   const int k = blockIdx.x;
   if (k >= n2) return;
@@ -786,7 +786,12 @@ __global__ __launch_bounds__(BACK_NT) void k_bcr_back_level(const double* __rest
       if (lane == 0 && i < b) atomicAdd(&v[i], -a);
     }
   }
-  if (Y) {
+  if (Y && det) {   // deterministic mode: the wavefronts add their partial sums one after the other, behind the X+ terms
+    for (int w_ = 0; w_ < NW; ++w_) {
+      __syncthreads();
+      if (wv == w_) for (int u = 0; u < 4; ++u) { const int r = lane + 64 * u; if (r < b) v[r] -= ya[u]; }
+    }
+  } else if (Y) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int r = lane + 64 * u; if (r < b) atomicAdd(&v[r], -ya[u]); }   // LDS, one adder per wavefront and entry
   }
@@ -1149,7 +1154,7 @@ int bcr_backward(lvx_ctx* c, double* Zy, double* Zx, int ldz, int nrhs) {
   if (fused) LVX_HIP(c, hipFuncSetAttribute((const void*)k_bcr_back_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fused));
   if (fused) {   // the last block of the chain: the same kernel without neighbours (the 64-vector streaming solve took 63 us for this one vector)
     hipLaunchKernelGGL(k_bcr_back_level, dim3(1), dim3(BACK_NT), lds_fused, c->stream, (const double*)(D + (size_t)(nblk - 1) * bb), 0ll, LI + (size_t)(nblk - 1) * liS, 0ll, (const double*)nullptr, 0ll,
-                       Z, (long long)(nblk - 1) * b, 0ll, 0ll, b, 1, (long long)bb);
+                       Z, (long long)(nblk - 1) * b, 0ll, 0ll, b, 1, (long long)bb, c->sw.deterministic);
     LVX_HIP(c, hipGetLastError());
   } else if ((rc = trsv_batched<true>(c, D + (size_t)(nblk - 1) * bb, b, 0, Z + (size_t)(nblk - 1) * b, 1, ldz, 0, nrhs, 1, LI ? LI + (size_t)(nblk - 1) * liS : nullptr, 0))) return rc;
   for (int l = L - 1; l >= 0; --l) {
@@ -1162,7 +1167,7 @@ int bcr_backward(lvx_ctx* c, double* Zy, double* Zx, int ldz, int nrhs) {
     double* Zr = Z + (size_t)(2 * s - 1) * b;
     if (fused) {   // one launch per level: both matrix-vector products and the transposed solve of every eliminated block
       hipLaunchKernelGGL(k_bcr_back_level, dim3((unsigned)n2), dim3(BACK_NT), lds_fused, c->stream, (const double*)Dj, sD, LI + (size_t)(s - 1) * liS, (long long)2 * s * liS, (const double*)Gl, sG,
-                         Z, (long long)(s - 1) * b, (long long)(2 * s - 1) * b, sZ, b, n2, (long long)bb);
+                         Z, (long long)(s - 1) * b, (long long)(2 * s - 1) * b, sZ, b, n2, (long long)bb, c->sw.deterministic);
       LVX_HIP(c, hipGetLastError());
       continue;
     }
@@ -1266,20 +1271,20 @@ int bcr_gram(lvx_ctx* c, const double* Z, int ldz, int n, double* M) {
   int rc;
   const double one = 1.0, zero = 0.0;
   LVX_HIP(c, hipMemsetAsync(M, 0, nn * 8, c->stream));
-  const int per = 16;
+  const int per = c->sw.deterministic ? (1 << 30) : 16;   // deterministic mode: one adder per entry, the partial Grams in index order
   if (n <= 16 * GRAM_NT) {
     const int nparts = (m + GRAM_ROWS - 1) / GRAM_ROWS, nt = n <= 48 ? 3 : (n <= 64 ? 4 : 5), np = nt * (nt + 1) / 2;
     if ((rc = dev_alloc(c, c->d_Y2, (size_t)nparts * np * 256 * 8))) return rc;
     if (nt == 3) hipLaunchKernelGGL(k_gram_mfma<3>, dim3((unsigned)nparts), dim3(256), 0, c->stream, Z, ldz, m, n, (double*)c->d_Y2.p);
     else if (nt == 4) hipLaunchKernelGGL(k_gram_mfma<4>, dim3((unsigned)nparts), dim3(256), 0, c->stream, Z, ldz, m, n, (double*)c->d_Y2.p);
     else hipLaunchKernelGGL(k_gram_mfma<5>, dim3((unsigned)nparts), dim3(256), 0, c->stream, Z, ldz, m, n, (double*)c->d_Y2.p);
-    hipLaunchKernelGGL(k_sum_tiles, dim3((unsigned)((np * 256 + 255) / 256), (unsigned)((nparts + per - 1) / per)), dim3(256), 0, c->stream, (const double*)c->d_Y2.p, nt, nparts, per, n, M);
+    hipLaunchKernelGGL(k_sum_tiles, dim3((unsigned)((np * 256 + 255) / 256), (unsigned)((nparts + (long long)per - 1) / per)), dim3(256), 0, c->stream, (const double*)c->d_Y2.p, nt, nparts, per, n, M);
   } else {   // (more than 80 border columns: one small library GEMM per row block)
     rocblas_handle h; if ((rc = bcr_handle(c, &h))) return rc;
     if ((rc = dev_alloc(c, c->d_Y2, (size_t)nblk * nn * 8))) return rc;
     LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, n, n, b, &one, Z, ldz, (rocblas_stride)b, Z, ldz, (rocblas_stride)b,
                                               &zero, (double*)c->d_Y2.p, n, (rocblas_stride)nn, nblk));
-    hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((nn + 255) / 256), (unsigned)((nblk + per - 1) / per)), dim3(256), 0, c->stream, (const double*)c->d_Y2.p, (int)nn, nblk, per, M);
+    hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((nn + 255) / 256), (unsigned)((nblk + (long long)per - 1) / per)), dim3(256), 0, c->stream, (const double*)c->d_Y2.p, (int)nn, nblk, per, M);
   }
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;

@@ -315,14 +315,30 @@ __global__ __launch_bounds__(256) void k_dense_back(const double* S, double* rhs
 // Reductions to a single address: a same-address atomic per WAVEFRONT (2 400 of them for 155 k scalars) serialises at the memory side — 25 ns each, 60 us for a
 // kernel that moves 3 MB.  These kernels walk their range with a grid-stride loop of at most RED_BLOCKS workgroups and issue ONE atomic per workgroup.
 #define RED_BLOCKS 256
-__device__ __forceinline__ void block_atomic_add(double v, double* dst) {
+// DETERMINISTIC mode (LVX_DETERMINISTIC): whatever the workgroups of a launch ADD to global memory they add in blockIdx order — a ticket (*tk, one int
+// per reduction, self-resetting) is passed from workgroup to workgroup; everything inside a workgroup already has a fixed order.  Workgroups are dispatched in index
+// order, so the one a workgroup waits for is resident or done.  tk == nullptr: the default (atomics in timing order).
+__device__ __forceinline__ void det_enter(int* tk) {
+  if (!tk) return;
+  if (threadIdx.x == 0) while (__hip_atomic_load(tk, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != (int)blockIdx.x) __builtin_amdgcn_s_sleep(2);
+  __syncthreads();
+}
+__device__ __forceinline__ void det_leave(int* tk) {
+  if (!tk) return;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(tk, blockIdx.x + 1 == gridDim.x ? 0 : (int)blockIdx.x + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void block_atomic_add(double v, double* dst, int* tk = nullptr) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   __shared__ double part_[16];
   const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) part_[w] = v;
   __syncthreads();
-  if (threadIdx.x == 0) { double t = 0.0; for (int k = 0; k < nw; ++k) t += part_[k]; if (t != 0.0) atomicAdd(dst, t); }
+  det_enter(tk);
+  if (threadIdx.x == 0) { double t = 0.0; for (int k = 0; k < nw; ++k) t += part_[k]; if (t != 0.0 || tk) atomicAdd(dst, t); }
+  det_leave(tk);
 }
 __device__ __forceinline__ void block_atomic_max_nonneg(double v, double* dst) {   // non-negative doubles order like their bit patterns
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
@@ -342,7 +358,7 @@ __global__ void k_sub_border(const double* Z, const double* yc, int nb, int nbd,
 }
 // delta (tangent layout) from the scaled solution; also accumulates g_s.y and y^T D^2 y for the model cost change
 __global__ void k_unscale(const int* ord, int nt, const double* yb, const double* yc, const double* scale, const double* lmd, double inv_radius,
-                          const double* gb, const double* gc, int nb, double* delta, double* sums) {
+                          const double* gb, const double* gc, int nb, double* delta, double* sums, int* tk) {
   double gy = 0.0, ydy = 0.0;
   for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nt; v += gridDim.x * blockDim.x) {
     const int o = ord[v];
@@ -357,13 +373,13 @@ __global__ void k_unscale(const int* ord, int nt, const double* yb, const double
     }
     delta[v] = d;
   }
-  block_atomic_add(gy, &sums[0]);
-  block_atomic_add(ydy, &sums[1]);
+  block_atomic_add(gy, &sums[0], tk);
+  block_atomic_add(ydy, &sums[1], tk ? tk + 1 : nullptr);
 }
 // sums[5] += delta^T H delta for the UNSCALED step (H = J^T J in band / border storage): the model cost change is then
 // -(g.delta + 1/2 delta^T H delta), what ceres computes from J * step — valid for any (also inexact) step
 __global__ void k_quad(const double* __restrict__ Hb, const double* __restrict__ Bd, const double* __restrict__ C, int ldc, const double* yb, const double* yc,
-                       const double* scale, int nb, int bw, int nbd, double* sums) {
+                       const double* scale, int nb, int bw, int nbd, double* sums, int* tk) {
   double q = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb + nbd; i += gridDim.x * blockDim.x) {
     if (i < nb) {
@@ -379,11 +395,11 @@ __global__ void k_quad(const double* __restrict__ Hb, const double* __restrict__
       q += da * t;
     }
   }
-  block_atomic_add(q, &sums[5]);
+  block_atomic_add(q, &sums[5], tk);
 }
 // band part: sum_i delta_i (H_ii delta_i + 2 sum_{d >= 1} H(i+d, i) delta_{i+d}) — every stored entry once, a wavefront per band column so
 // that its bw + 1 entries are read as contiguous 512-byte pieces (a thread per column read them 1568 bytes apart: 0.5 ms for 243 MB)
-__global__ __launch_bounds__(256) void k_quad_band(const double* __restrict__ Hb, const double* __restrict__ yb, const double* __restrict__ scale, int nb, int bw, double* sums) {
+__global__ __launch_bounds__(256) void k_quad_band(const double* __restrict__ Hb, const double* __restrict__ yb, const double* __restrict__ scale, int nb, int bw, double* sums, int* tk) {
   const int lane = threadIdx.x & 63;
   double q = 0.0;
   for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < nb; i += gridDim.x * 4) {
@@ -396,7 +412,9 @@ __global__ __launch_bounds__(256) void k_quad_band(const double* __restrict__ Hb
   __shared__ double part[4];   // one atomic per workgroup: thousands of same-address atomics serialise in L2
   if (lane == 0) part[threadIdx.x >> 6] = q;
   __syncthreads();
+  det_enter(tk);
   if (threadIdx.x == 0) { const double t = part[0] + part[1] + part[2] + part[3]; if (t != 0.0) atomicAdd(&sums[5], t); }
+  det_leave(tk);
 }
 __device__ __forceinline__ void qplus_dev(const double* x, const double* d, double* o) {   // EigenQuaternionParameterization::Plus
   const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
@@ -410,7 +428,7 @@ __device__ __forceinline__ void qplus_dev(const double* x, const double* d, doub
 // blocks (shared between sequences in the joint solve) go to sums[6], sums[7] instead when split_shared
 // Box constraints (inverse depth >= 0: static_rscamera_measurement.h:185, camera_surfel_landmark.h:232; |free time offset| <= mto: sensors.h:161-162)
 // are enforced by projection of the candidate, as ceres::ParameterBlock::Plus does.
-__global__ void k_plus(const double* x, const double* delta, int N, int L, uint32_t locks, double* xo, double* sums, int split_shared, double mto) {
+__global__ void k_plus(const double* x, const double* delta, int N, int L, uint32_t locks, double* xo, double* sums, int split_shared, double mto, int* tk) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double dn = 0.0, xn = 0.0;
   if (i < N) {
@@ -438,6 +456,7 @@ __global__ void k_plus(const double* x, const double* delta, int N, int L, uint3
     xo[7 * (size_t)N + 32 + l] = b;
     if (fr) { dn += (b - a) * (b - a); xn += a * a; }
   }
+  if (tk) { block_atomic_add(dn, &sums[2], tk); block_atomic_add(xn, &sums[3], tk + 1); return; }
   for (int o = 32; o > 0; o >>= 1) { dn += __shfl_xor(dn, o); xn += __shfl_xor(xn, o); }
   if ((threadIdx.x & 63) == 0 && (dn != 0.0 || xn != 0.0)) { atomicAdd(&sums[2], dn); atomicAdd(&sums[3], xn); }
 }
@@ -453,7 +472,7 @@ __global__ void k_lm_fetch_diag(const double* lmH, int L, int ls, int off, doubl
   if (l < L) out[l] = lmH[(size_t)l * ls + off];
 }
 __global__ __launch_bounds__(256) void k_lm_schur(const double* __restrict__ lmH, const int* __restrict__ p0s, int wl, int nbd, int ls, const double* __restrict__ scale_l,
-                                                  const double* __restrict__ lmd_l, double inv_radius, double* Hr, int bw, double* Br, int nb, double* Cr, int ldc, double* gbr, double* gcr) {
+                                                  const double* __restrict__ lmd_l, double inv_radius, double* Hr, int bw, double* Br, int nb, double* Cr, int ldc, double* gbr, double* gcr, int* tk) {
   extern __shared__ double e[];            // the landmark's row, then the indices of its non-zero couplings
   const int l = blockIdx.x, ne = wl + nbd;
   int* idx = (int*)(e + ne + 2);
@@ -463,9 +482,10 @@ __global__ __launch_bounds__(256) void k_lm_schur(const double* __restrict__ lmH
   for (int k = threadIdx.x; k < ne + 2; k += 256) e[k] = row[k];
   __syncthreads();
   const double Hll = e[ne], gl = e[ne + 1];
-  if (!(Hll > 0.0)) return;                 // no observation reached this landmark: nothing to eliminate
-  for (int k = threadIdx.x; k < ne; k += 256) if (e[k] != 0.0) idx[atomicAdd(&nn_s, 1)] = k;
+  if (!(Hll > 0.0)) { det_enter(tk); det_leave(tk); return; }   // no observation reached this landmark: nothing to eliminate
+  for (int k = threadIdx.x; k < ne; k += 256) if (e[k] != 0.0) idx[atomicAdd(&nn_s, 1)] = k;   // (any order: every pair of couplings reaches its own address once)
   __syncthreads();
+  det_enter(tk);
   const int nn = nn_s, p0 = p0s[l];
   const double s = scale_l[l], w = s * s / (s * s * Hll + lmd_l[l] * inv_radius);
   for (int t = threadIdx.x; t < nn * nn; t += 256) {
@@ -483,6 +503,7 @@ __global__ __launch_bounds__(256) void k_lm_schur(const double* __restrict__ lmH
     const double val = -w * e[k] * gl;
     if (k < wl) atomicAdd(&gbr[p0 + k], val); else atomicAdd(&gcr[k - wl], val);
   }
+  det_leave(tk);
 }
 // Landmark elimination by GROUPS (the default).  A workgroup owns up to 32 landmarks whose rows start within 24 band positions of each other —
 // the landmarks of one reference frame: same first knot, same co-visible frames — and forms  -sum_l w_l E_l^T E_l  over the union of their
@@ -490,7 +511,7 @@ __global__ __launch_bounds__(256) void k_lm_schur(const double* __restrict__ lmH
 // (k_lm_schur: 42 M atomics at config 4, most of them on the same addresses, 2.5 ms; here 5 M, 0.1 ms).
 __global__ __launch_bounds__(256) void k_lm_schur_grp(const double* __restrict__ lmH, const int* __restrict__ p0s, const int* __restrict__ grp, int ngrp, int wl, int nbd, int ls,
                                                       const double* __restrict__ scale_l, const double* __restrict__ lmd_l, double inv_radius, int ne_max, double* Hr, int bw, double* Br, int nb,
-                                                      double* Cr, int ldc, double* gbr, double* gcr) {
+                                                      double* Cr, int ldc, double* gbr, double* gcr, int* tk) {
   extern __shared__ double sm[];   // E[32][nn] (rows scaled by sqrt(w_l)) | glw[32] | cpos[ne_max] | cols[ne_max]
   const int g = blockIdx.x, j0 = grp[g], j1 = grp[g + 1], G = j1 - j0;
   const int* lms = grp + ngrp + 1;
@@ -536,7 +557,7 @@ __global__ __launch_bounds__(256) void k_lm_schur_grp(const double* __restrict__
   }
   __syncthreads();
   const int nn = nn_s;
-  if (nn == 0) return;
+  if (nn == 0) { det_enter(tk); det_leave(tk); return; }
   for (int e = tid; e < G * nn; e += 256) sm[e] = 0.0;
   __syncthreads();
   for (int gi = wv; gi < G; gi += 4) {
@@ -548,6 +569,7 @@ __global__ __launch_bounds__(256) void k_lm_schur_grp(const double* __restrict__
   }
   __syncthreads();
   // lower triangle of the union block: pair t = ia (ia + 1) / 2 + ib, ib <= ia
+  det_enter(tk);
   const int npair = nn * (nn + 1) / 2;
   for (int t = tid; t < npair + nn; t += 256) {
     if (t >= npair) {   // gradient
@@ -569,11 +591,12 @@ __global__ __launch_bounds__(256) void k_lm_schur_grp(const double* __restrict__
     else if (lo < U) atomicAdd(&Br[(size_t)(hi - U) * nb + pmin + lo], -acc);
     else atomicAdd(&Cr[(size_t)(hi - U) * ldc + (lo - U)], -acc);
   }
+  det_leave(tk);
 }
 // delta_l = -w_l (g_l + E_l . delta) and the landmark's terms of g.delta (sums[0]), y^T D^2 y (sums[1]) and delta^T H delta (sums[5]); a wavefront per landmark
 __global__ __launch_bounds__(256) void k_lm_back(const double* __restrict__ lmH, const int* __restrict__ p0s, int L, int wl, int nbd_solve, int nbd, int ls, const double* __restrict__ scale_l,
                                                  const double* __restrict__ lmd_l, double inv_radius, const double* __restrict__ yb, const double* __restrict__ yc, const double* __restrict__ scale,
-                                                 int nb, double* delta_l, double* sums) {
+                                                 int nb, double* delta_l, double* sums, int* tk) {
   const int wvi = threadIdx.x >> 6, l = blockIdx.x * 4 + wvi, lane = threadIdx.x & 63;
   __shared__ double red[4][3];   // the workgroup's four landmarks are summed before they reach the three global sums (15 k same-address atomics took 190 us)
   double t0 = 0.0, t1 = 0.0, t2 = 0.0;
@@ -598,10 +621,12 @@ __global__ __launch_bounds__(256) void k_lm_back(const double* __restrict__ lmH,
   }
   if (lane == 0) { red[wvi][0] = t0; red[wvi][1] = t1; red[wvi][2] = t2; }
   __syncthreads();
+  det_enter(tk);
   if (threadIdx.x < 3) {
     const double v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
     if (v != 0.0) atomicAdd(&sums[threadIdx.x == 2 ? 5 : threadIdx.x], v);
   }
+  det_leave(tk);
 }
 // rho != null: the PROJECTED gradient of the bounded inverse depths, rho - max(rho - g, 0) (TrustRegionMinimizer::ComputeGradientNorms for a constrained problem)
 __global__ void k_gmax_lm(const double* lmH, int L, int ls, int off, double* sums, const double* rho) {
@@ -613,7 +638,7 @@ __global__ void k_gmax_lm(const double* lmH, int L, int ls, int off, double* sum
   block_atomic_max_nonneg(v, &sums[4]);
 }
 // out[0] += g . delta with the gradient of the accumulators (band, border, landmark rows) and a step in the tangent layout
-__global__ void k_gdot(const int* ord, int nt, const double* gb, const double* gc, const double* lmH, int ls, int goff, const double* delta, double* out) {
+__global__ void k_gdot(const int* ord, int nt, const double* gb, const double* gc, const double* lmH, int ls, int goff, const double* delta, double* out, int* tk) {
   double s = 0.0;
   for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nt; v += gridDim.x * blockDim.x) {
     const int o = ord[v];
@@ -621,7 +646,7 @@ __global__ void k_gdot(const int* ord, int nt, const double* gb, const double* g
     const double g = o >= LVX_LM_BASE ? (lmH ? lmH[(size_t)(o - LVX_LM_BASE) * ls + goff] : 0.0) : (o >= 0 ? gb[o] : gc[-1 - o]);
     s += g * delta[v];
   }
-  block_atomic_add(s, out);
+  block_atomic_add(s, out, tk);
 }
 
 // max |g| over free scalars; bounded border scalars (a free sensor time offset: border index tb[k], value tx[k], |.| <= bound) enter projected
@@ -646,7 +671,8 @@ using namespace lvx;
 struct SolveWork { double *L, *Z, *S, *rhs, *delta, *diag, *scale, *lmd, *sums, *Z2, *gram; int* info; int ldz; bool use_bcr;
                    bool lm;                                   // landmarks are eliminated first (k_lm_schur)
                    const double *Hs, *Bs, *Cs, *gbs, *gcs;     // what the band / border solve reads: the normal equations, or their copies after the landmark elimination
-                   bool inplace = false, lm_done = false, constrained = false; };   // inplace (LM loop, single sequence): the landmark elimination works on the band / border rows THEMSELVES — no 290 MB copy per
+                   bool inplace = false, lm_done = false, constrained = false;
+                   int* tk = nullptr; };                      // deterministic mode: the reductions' tickets (det_enter / det_leave), null otherwise   // inplace (LM loop, single sequence): the landmark elimination works on the band / border rows THEMSELVES — no 290 MB copy per
                                                                // solve; the accumulators no longer hold J^T J afterwards (the loop re-evaluates before it needs them).  lm_done: this step's elimination has run
 
 // ---------------------------------------------------------------------------------------------------------
@@ -739,6 +765,7 @@ static int solver_alloc(lvx_ctx* c, SolveWork& w) {
   w.L = (double*)c->d_L.p; w.Z = (double*)c->d_Y.p; w.S = (double*)c->d_S.p; w.rhs = w.S + nbd * nbd; w.delta = (double*)c->d_delta.p;
   w.diag = (double*)c->d_diag.p; w.scale = w.diag + nall; w.lmd = w.scale + nall;
   w.sums = (double*)c->d_scal.p; w.info = (int*)(w.sums + 32);
+  w.tk = c->sw.deterministic ? (int*)(w.sums + 48) : nullptr;   // (zero = start state; the buffer is cleared at the head of every solve and every ticket resets itself)
   // shared extrinsics of the joint solve: tangent 6N+8 .. 6N+21 own the LAST 14 border slots (ensure_layout gives every calibration
   // scalar a fixed slot after the hub knots; a locked one keeps an inert slot with S_aa = lmd / radius)
   c->ns = 0;
@@ -787,12 +814,12 @@ static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, 
     if (c->lm_ngrp > 0 && lds_g <= 160 * 1024) {
       LVX_HIP(c, hipFuncSetAttribute((const void*)k_lm_schur_grp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
       hipLaunchKernelGGL(k_lm_schur_grp, dim3((unsigned)c->lm_ngrp), dim3(256), lds_g, st, (const double*)c->d_lmH.p, (const int*)c->d_lm_p0.p, (const int*)c->d_lm_grp.p, c->lm_ngrp, c->lm_wl, c->nbd_ext, c->lm_ls,
-                         w.scale + (nb + nbd), w.lmd + (nb + nbd), ir, ne_max, (double*)w.Hs, bw, (double*)w.Bs, nb, (double*)w.Cs, c->nbd_ext, (double*)w.gbs, (double*)w.gcs);
+                         w.scale + (nb + nbd), w.lmd + (nb + nbd), ir, ne_max, (double*)w.Hs, bw, (double*)w.Bs, nb, (double*)w.Cs, c->nbd_ext, (double*)w.gbs, (double*)w.gcs, w.tk ? w.tk + 5 : nullptr);
     } else {
     const size_t lds = (size_t)(c->lm_wl + c->nbd_ext + 2) * 8 + (size_t)(c->lm_wl + c->nbd_ext) * 4 + 16;
     LVX_HIP(c, hipFuncSetAttribute((const void*)k_lm_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_lm_schur, dim3((unsigned)c->L), dim3(256), lds, st, (const double*)c->d_lmH.p, (const int*)c->d_lm_p0.p, c->lm_wl, c->nbd_ext, c->lm_ls, w.scale + (nb + nbd), w.lmd + (nb + nbd), ir,
-                       (double*)w.Hs, bw, (double*)w.Bs, nb, (double*)w.Cs, c->nbd_ext, (double*)w.gbs, (double*)w.gcs);
+                       (double*)w.Hs, bw, (double*)w.Bs, nb, (double*)w.Cs, c->nbd_ext, (double*)w.gbs, (double*)w.gcs, w.tk ? w.tk + 5 : nullptr);
     }
   }
   if (nb > 0) {
@@ -956,18 +983,18 @@ static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double m[3
     }
   }
   hipLaunchKernelGGL(k_unscale, dim3((unsigned)std::min(RED_BLOCKS, (nt + 255) / 256)), dim3(256), 0, st, (const int*)c->d_ord.p, nt, (const double*)zb, (const double*)w.rhs, (const double*)w.scale,
-                     (const double*)w.lmd, ir, (const double*)c->d_gb.p, (const double*)c->d_gc.p, nb, w.delta, w.sums);
+                     (const double*)w.lmd, ir, (const double*)c->d_gb.p, (const double*)c->d_gc.p, nb, w.delta, w.sums, w.tk);
   if (w.lm) hipLaunchKernelGGL(k_lm_back, dim3((unsigned)((c->L + 3) / 4)), dim3(256), 0, st, (const double*)c->d_lmH.p, (const int*)c->d_lm_p0.p, c->L, c->lm_wl, nbd, c->nbd_ext, c->lm_ls,
                                (const double*)(w.scale + (nb + nbd)), (const double*)(w.lmd + (nb + nbd)), ir, (const double*)zb, (const double*)w.rhs, (const double*)w.scale, nb,
-                               w.delta + 6 * (size_t)c->N + 22, w.sums);
+                               w.delta + 6 * (size_t)c->N + 22, w.sums, w.tk ? w.tk + 4 : nullptr);
   // delta^T H delta.  Single sequence: the step solves (H + D) delta = -g EXACTLY (SPARSE_SCHUR semantics; residual 1e-15 of the scale, tests/test_gpu_fullsize_oracle.py),
   // so delta^T H delta = -g.delta - delta^T D delta comes with the sums k_unscale / k_lm_back form anyway — the explicit product streams the whole band again (216 MB, 0.16 ms).
   // Joint problem: the identity holds for the SUM over the ranks only and the shared damping is counted once, after the reduction — the explicit product stays.
   const bool quad_explicit = is_joint(c);
   if (quad_explicit) {
-    if (nb > 0) hipLaunchKernelGGL(k_quad_band, dim3((unsigned)std::min(2048, (nb + 3) / 4)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)zb, (const double*)w.scale, nb, bw, w.sums);
+    if (nb > 0) hipLaunchKernelGGL(k_quad_band, dim3((unsigned)std::min(2048, (nb + 3) / 4)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)zb, (const double*)w.scale, nb, bw, w.sums, w.tk ? w.tk + 2 : nullptr);
     hipLaunchKernelGGL(k_quad, dim3((unsigned)std::min(2 * RED_BLOCKS, (nb + nbd + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)c->d_Bd.p, (const double*)c->d_C.p, c->nbd_ext,
-                       (const double*)zb, (const double*)w.rhs, (const double*)w.scale, nb, bw, nbd, w.sums);
+                       (const double*)zb, (const double*)w.rhs, (const double*)w.scale, nb, bw, nbd, w.sums, w.tk ? w.tk + 3 : nullptr);
   }
   LVX_HIP(c, hipGetLastError());
   double h[8];
@@ -1106,7 +1133,7 @@ static int grad_dot(lvx_ctx* c, SolveWork& w, double* out) {
   const int nt = lvx_tangent_size(c);
   LVX_HIP(c, hipMemsetAsync(w.sums + 8, 0, 8, st));
   hipLaunchKernelGGL(k_gdot, dim3((unsigned)std::min(RED_BLOCKS, (nt + 255) / 256)), dim3(256), 0, st, (const int*)c->d_ord.p, nt, (const double*)c->d_gb.p, (const double*)c->d_gc.p,
-                     w.lm ? (const double*)c->d_lmH.p : (const double*)nullptr, c->lm_ls, c->lm_wl + c->nbd_ext + 1, (const double*)w.delta, w.sums + 8);
+                     w.lm ? (const double*)c->d_lmH.p : (const double*)nullptr, c->lm_ls, c->lm_wl + c->nbd_ext + 1, (const double*)w.delta, w.sums + 8, w.tk ? w.tk + 6 : nullptr);
   LVX_HIP(c, hipMemcpyAsync(out, w.sums + 8, 8, hipMemcpyDeviceToHost, st));
   LVX_HIP(c, hipStreamSynchronize(st));
   return LVX_OK;
@@ -1185,7 +1212,7 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
     LVX_HIP(c, hipMemcpyAsync(x, state, sbytes, hipMemcpyHostToDevice, st));
     if (w.constrained) {   // TrustRegionMinimizer::IterationZero: x <- Plus(x, 0), the start point projected onto the box
       LVX_HIP(c, hipMemsetAsync(w.delta, 0, (size_t)lvx_tangent_size(c) * 8, st));
-      hipLaunchKernelGGL(k_plus, dim3((unsigned)((c->N + 1 + c->L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, c->N, c->L, c->locks, x, w.sums, 0, c->sensor_mto);
+      hipLaunchKernelGGL(k_plus, dim3((unsigned)((c->N + 1 + c->L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, c->N, c->L, c->locks, x, w.sums, 0, c->sensor_mto, w.tk ? w.tk + 7 : nullptr);
     }
     lerr = lvx_evaluate_d(c, x, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &cost);
   }
@@ -1215,7 +1242,7 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
     EvalLocal ev;
     if (!notpd) {
       LVX_HIP(c, hipMemsetAsync(w.sums + 2, 0, 48, st));
-      hipLaunchKernelGGL(k_plus, dim3((unsigned)((N + 1 + L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, N, L, c->locks, xt, w.sums, joint ? 1 : 0, c->sensor_mto);
+      hipLaunchKernelGGL(k_plus, dim3((unsigned)((N + 1 + L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, N, L, c->locks, xt, w.sums, joint ? 1 : 0, c->sensor_mto, w.tk ? w.tk + 7 : nullptr);
       double cand = 0;
       const int re = lvx_evaluate_d(c, xt, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &cand);
       cand_ne = true; acc_is_x = false;
@@ -1244,7 +1271,7 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
           for (int i = 0; i < ntg; ++i) dt[i] = a * dh[i];
           LVX_HIP(c, hipMemcpyAsync(w.delta, dt.data(), (size_t)ntg * 8, hipMemcpyHostToDevice, st));
           LVX_HIP(c, hipMemsetAsync(w.sums + 2, 0, 48, st));
-          hipLaunchKernelGGL(k_plus, dim3((unsigned)((N + 1 + L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, N, L, c->locks, xt, w.sums, 0, c->sensor_mto);
+          hipLaunchKernelGGL(k_plus, dim3((unsigned)((N + 1 + L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, N, L, c->locks, xt, w.sums, 0, c->sensor_mto, w.tk ? w.tk + 7 : nullptr);
           double f = 0;
           const int re2 = lvx_evaluate_d(c, xt, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &f);
           if (re2 == LVX_E_RANGE || re2 == LVX_E_NONUNIT_QUAT) { cur.x = a; continue; }   // a trial that cannot be evaluated: contract again without a new sample
@@ -1262,7 +1289,7 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
         else {   // no step satisfies Armijo: the full step stays (Ceres leaves delta alone) — put its candidate back
           LVX_HIP(c, hipMemcpyAsync(w.delta, dh.data(), (size_t)ntg * 8, hipMemcpyHostToDevice, st));
           LVX_HIP(c, hipMemsetAsync(w.sums + 2, 0, 48, st));
-          hipLaunchKernelGGL(k_plus, dim3((unsigned)((N + 1 + L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, N, L, c->locks, xt, w.sums, 0, c->sensor_mto);
+          hipLaunchKernelGGL(k_plus, dim3((unsigned)((N + 1 + L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, N, L, c->locks, xt, w.sums, 0, c->sensor_mto, w.tk ? w.tk + 7 : nullptr);
           const int re3 = lvx_evaluate_d(c, xt, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &cand);
           if (re3) return re3;
           if (hipMemcpy(h, w.sums + 2, 48, hipMemcpyDeviceToHost) != hipSuccess) return LVX_E_HIP;

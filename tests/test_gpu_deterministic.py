@@ -58,3 +58,32 @@ def test_tenth_of_config4_checksums_repeat():
     d2, _ = h.solve_step(1e4)
     assert np.abs(d1 - d2).max() <= 1e-7 * max(1.0, np.abs(d2).max())
     g.close(); h.close()
+
+
+@pytest.mark.parametrize("size", ["small", "tenth"])
+def test_lm_solve_bitwise_repeatable(size):
+    """The SOLVER in deterministic mode (round 4): the landmark elimination's group products, the norms / dot products, the cyclic reduction's backward sweep and the
+    border Gram add in a fixed order (tickets passed from workgroup to workgroup in blockIdx order) => two LM solves from the same start give the same bits: steps,
+    cost history, final state.  The default path agrees with it to rounding."""
+    if size == "small":
+        P = synth.make_problem(seed=7, duration=2.0, n_surfel=900, n_planes=12, n_landmarks=30, n_camsurf=10)
+    else:
+        P = synth.make_bench_problem(seed=4, n_imu=20000, n_surfel=100000, n_reproj=5000, n_planes=200)
+    runs = []
+    for _ in range(3):
+        g = _ctx(P, True)
+        g.set_state(P["state0"])
+        g.evaluate_resident(lvx.EVAL_COST | lvx.EVAL_NORMAL_EQ, want_cost=True)
+        d, info = g.solve_step(1e4)
+        x, s = g.lm_solve(P["state0"], max_iterations=6)
+        runs.append((d.copy(), x.copy(), [float(v) for v in s["cost_history"]] if "cost_history" in s else [s["initial_cost"], s["final_cost"]], s["iterations"]))
+        g.close()
+    for r in runs[1:]:
+        assert np.array_equal(runs[0][0], r[0]), "solve_step not repeatable: max diff %.3e" % np.abs(runs[0][0] - r[0]).max()
+        assert runs[0][2] == r[2] and runs[0][3] == r[3]
+        assert np.array_equal(runs[0][1], r[1]), "lm_solve not repeatable: max diff %.3e" % np.abs(runs[0][1] - r[1]).max()
+    h = _ctx(P, False)
+    xd, sd = h.lm_solve(P["state0"], max_iterations=6)
+    assert sd["iterations"] == runs[0][3]
+    assert abs(sd["final_cost"] - runs[0][2][-1]) <= 1e-5 * abs(sd["final_cost"])   # (summation order only; six LM iterations amplify the last bits)
+    h.close()
