@@ -1,4 +1,5 @@
 #!/bin/bash
+# tools/da_timeline.sh — on the GPU box: kernel timeline of one lvx_data_association round (from a rocprofv3 kernel trace of tools/upstream_bench.py)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/upkt
 rocprofv3 --kernel-trace -d gpurun_out/upkt -o kt -- python tools/upstream_bench.py 5 > gpurun_out/upkt.log 2>&1
