@@ -184,6 +184,7 @@ int dev_alloc(lvx_ctx* ctx, DevBuf& b, size_t bytes);
 int upload(lvx_ctx* ctx, DevBuf& b, const void* src, size_t bytes);
 int ensure_layout(lvx_ctx* ctx);
 int check_last_eval(lvx_ctx* ctx);
+int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cost, bool want_res_buffer);   // lvx_eval.hip: one evaluation pass
 DevCommon make_common(lvx_ctx* ctx, const double* state_d, uint32_t what);
 int bcr_plan(lvx_ctx* c);
 int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_radius, int* info_out_d, double* Z = nullptr, int ldz = 0, int nrhs = 0);
