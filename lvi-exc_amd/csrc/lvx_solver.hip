@@ -263,21 +263,25 @@ __global__ void k_schur_from_gram(const double* M, const double* C, const double
 // np == n is the plain factorisation + forward substitution.
 // (the border block and its right-hand side live in LDS for the whole factorisation: in global memory every one of the ~3 n steps was a round trip
 // to HBM / L2 and the forward substitution a chain of n^2 / 2 dependent loads on one thread — 180 us for n = 52)
-__global__ __launch_bounds__(256) void k_dense_partial(double* S, double* rhs, int n, int np, int* info) {
+#define DENSE_NT 1024   // (measured, n = 64: 128 threads 95 us, 256: 68, 1024: 50 — the trailing updates, not the barriers)
+__global__ __launch_bounds__(DENSE_NT) void k_dense_partial(double* S, double* rhs, int n, int np, int* info) {
   extern __shared__ double ds[];           // T [n][n + 1] | r [n]
   const int tid = threadIdx.x, ld = n + 1;
   double* T = ds; double* r = ds + (size_t)n * ld;
-  for (int e = tid; e < n * n; e += 256) T[(e / n) * ld + e % n] = S[e];
-  for (int e = tid; e < n; e += 256) r[e] = rhs[e];
+  for (int e = tid; e < n * n; e += DENSE_NT) T[(e / n) * ld + e % n] = S[e];
+  for (int e = tid; e < n; e += DENSE_NT) r[e] = rhs[e];
   __syncthreads();
   for (int k = 0; k < np; ++k) {
     if (tid == 0) { const double d = T[k * ld + k]; if (!(d > 0.0)) { if (info[1] == 0) { info[1] = k + 1; ((double*)(info + 2))[0] = d; } T[k * ld + k] = 1.0; } else T[k * ld + k] = sqrt(d); }
     __syncthreads();
     const double inv = 1.0 / T[k * ld + k];
-    for (int rr = k + 1 + tid; rr < n; rr += 256) T[rr * ld + k] *= inv;
+    for (int rr = k + 1 + tid; rr < n; rr += DENSE_NT) T[rr * ld + k] *= inv;
     __syncthreads();
-    const int m = n - k - 1;
-    for (int e = tid; e < m * m; e += 256) { const int rr = k + 1 + e / m, c = k + 1 + e % m; if (rr >= c) T[rr * ld + c] -= T[rr * ld + k] * T[c * ld + k]; }
+    for (int c0 = k + 1; c0 < n; c0 += 64) {   // lane = column, wavefront = row (no integer divisions: e / m, e % m per entry were most of this kernel)
+      const int cc = c0 + (tid & 63);
+      const double lc = cc < n ? T[cc * ld + k] : 0.0;
+      for (int rr = k + 1 + (tid >> 6); rr < n; rr += DENSE_NT / 64) if (cc < n && rr >= cc) T[rr * ld + cc] -= T[rr * ld + k] * lc;
+    }
     __syncthreads();
   }
   // forward substitution, column by column: y_k = r_k / L_kk, then r_i -= L_ik y_k for every i > k (also the rows of the trailing block)
@@ -285,31 +289,31 @@ __global__ __launch_bounds__(256) void k_dense_partial(double* S, double* rhs, i
     if (tid == 0) r[k] = r[k] / T[k * ld + k];
     __syncthreads();
     const double yk = r[k];
-    for (int i = k + 1 + tid; i < n; i += 256) r[i] -= T[i * ld + k] * yk;
+    for (int i = k + 1 + tid; i < n; i += DENSE_NT) r[i] -= T[i * ld + k] * yk;
     __syncthreads();
   }
-  for (int e = tid; e < n * n; e += 256) S[e] = T[(e / n) * ld + e % n];
-  for (int e = tid; e < n; e += 256) rhs[e] = r[e];
+  for (int e = tid; e < n * n; e += DENSE_NT) S[e] = T[(e / n) * ld + e % n];
+  for (int e = tid; e < n; e += DENSE_NT) rhs[e] = r[e];
 }
 // backward substitution of the eliminated part given the solution of the trailing (shared) variables in rhs[np..n)
-__global__ __launch_bounds__(256) void k_dense_back(const double* S, double* rhs, int n, int np) {
+__global__ __launch_bounds__(DENSE_NT) void k_dense_back(const double* S, double* rhs, int n, int np) {
   extern __shared__ double ds[];           // T [n][n + 1] | r [n]
   const int tid = threadIdx.x, ld = n + 1;
   double* T = ds; double* r = ds + (size_t)n * ld;
-  for (int e = tid; e < n * n; e += 256) T[(e / n) * ld + e % n] = S[e];
-  for (int e = tid; e < n; e += 256) r[e] = rhs[e];
+  for (int e = tid; e < n * n; e += DENSE_NT) T[(e / n) * ld + e % n] = S[e];
+  for (int e = tid; e < n; e += DENSE_NT) r[e] = rhs[e];
   __syncthreads();
   // the trailing variables are known: r_i -= sum_{k >= np} L_ki x_k for i < np, then L^T x = r column by column from the bottom
-  for (int i = tid; i < np; i += 256) { double s = r[i]; for (int k = np; k < n; ++k) s -= T[k * ld + i] * r[k]; r[i] = s; }
+  for (int i = tid; i < np; i += DENSE_NT) { double s = r[i]; for (int k = np; k < n; ++k) s -= T[k * ld + i] * r[k]; r[i] = s; }
   __syncthreads();
   for (int i = np - 1; i >= 0; --i) {
     if (tid == 0) r[i] = r[i] / T[i * ld + i];
     __syncthreads();
     const double xi = r[i];
-    for (int k = tid; k < i; k += 256) r[k] -= T[i * ld + k] * xi;
+    for (int k = tid; k < i; k += DENSE_NT) r[k] -= T[i * ld + k] * xi;
     __syncthreads();
   }
-  for (int e = tid; e < np; e += 256) rhs[e] = r[e];
+  for (int e = tid; e < np; e += DENSE_NT) rhs[e] = r[e];
 }
 // z <- z - Z_B^T y_c
 // Reductions to a single address: a same-address atomic per WAVEFRONT (2 400 of them for 155 k scalars) serialises at the memory side — 25 ns each, 60 us for a
@@ -854,7 +858,7 @@ static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, 
   }
   const size_t lds_dense = ((size_t)nbd * (nbd + 1) + nbd) * 8;
   LVX_HIP(c, hipFuncSetAttribute((const void*)k_dense_partial, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dense));
-  hipLaunchKernelGGL(k_dense_partial, dim3(1), dim3(256), lds_dense, st, w.S, w.rhs, nbd, nbd - c->ns, w.info);
+  hipLaunchKernelGGL(k_dense_partial, dim3(1), dim3(DENSE_NT), lds_dense, st, w.S, w.rhs, nbd, nbd - c->ns, w.info);
   LVX_HIP(c, hipGetLastError());
   int info[4] = {0, 0, 0, 0};
   tm.lap("enqueue gram+schur+dense");
@@ -968,7 +972,7 @@ static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double m[3
   if (notpd) { fail(c, LVX_E_NOTPD, "damped normal equations not positive definite"); return LVX_OK; }
   { const size_t lds_dense = ((size_t)nbd * (nbd + 1) + nbd) * 8;
     LVX_HIP(c, hipFuncSetAttribute((const void*)k_dense_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dense));
-    hipLaunchKernelGGL(k_dense_back, dim3(1), dim3(256), lds_dense, st, (const double*)w.S, w.rhs, nbd, np); }
+    hipLaunchKernelGGL(k_dense_back, dim3(1), dim3(DENSE_NT), lds_dense, st, (const double*)w.S, w.rhs, nbd, np); }
   const int ldz = w.ldz;
   double* Zf = w.Z;
   double* zb = Zf + (size_t)nbd * std::max(ldz, 1);
