@@ -509,6 +509,7 @@ __global__ __launch_bounds__(256) void k_lm_schur(const double* __restrict__ lmH
   }
   det_leave(tk);
 }
+typedef double d4s __attribute__((ext_vector_type(4)));
 // Landmark elimination by GROUPS (the default).  A workgroup owns up to 32 landmarks whose rows start within 24 band positions of each other —
 // the landmarks of one reference frame: same first knot, same co-visible frames — and forms  -sum_l w_l E_l^T E_l  over the union of their
 // non-zero columns in LDS before anything reaches HBM: one atomic per non-zero entry of the union block per GROUP instead of per landmark
@@ -516,12 +517,12 @@ __global__ __launch_bounds__(256) void k_lm_schur(const double* __restrict__ lmH
 __global__ __launch_bounds__(256) void k_lm_schur_grp(const double* __restrict__ lmH, const int* __restrict__ p0s, const int* __restrict__ grp, int ngrp, int wl, int nbd, int ls,
                                                       const double* __restrict__ scale_l, const double* __restrict__ lmd_l, double inv_radius, int ne_max, double* Hr, int bw, double* Br, int nb,
                                                       double* Cr, int ldc, double* gbr, double* gcr, int* tk) {
-  extern __shared__ double sm[];   // E[32][nn] (rows scaled by sqrt(w_l)) | glw[32] | cpos[ne_max] | cols[ne_max]
+  extern __shared__ double sm[];   // E[32][nn | 1] (rows scaled by sqrt(w_l), zero rows behind the group's last landmark) | glw[32] | cpos[ne_max] | cols[ne_max]
   const int g = blockIdx.x, j0 = grp[g], j1 = grp[g + 1], G = j1 - j0;
   const int* lms = grp + ngrp + 1;
   const int pmin = p0s[lms[j0]];
   const int U = wl + (p0s[lms[j1 - 1]] - pmin), ne = U + nbd;
-  double* glw = sm + (size_t)32 * ne_max;
+  double* glw = sm + (size_t)32 * (ne_max + 1);
   int* cpos = (int*)(glw + 32);
   int* cols = cpos + ne_max;
   __shared__ int nn_s;
@@ -562,38 +563,51 @@ __global__ __launch_bounds__(256) void k_lm_schur_grp(const double* __restrict__
   __syncthreads();
   const int nn = nn_s;
   if (nn == 0) { det_enter(tk); det_leave(tk); return; }
-  for (int e = tid; e < G * nn; e += 256) sm[e] = 0.0;
+  const int es = nn | 1;   // odd row stride: the four rows of a k-step land in different banks
+  for (int e = tid; e < 32 * es; e += 256) sm[e] = 0.0;
   __syncthreads();
   for (int gi = wv; gi < G; gi += 4) {
     const double q = sw[gi];
     if (q == 0.0) continue;
     const int l = lms[j0 + gi], sh = p0s[l] - pmin;
     const double* row = lmH + (size_t)l * ls;
-    for (int k = lane; k < wl + nbd; k += 64) { const double v = row[k]; if (v != 0.0) sm[(size_t)gi * nn + cpos[k < wl ? k + sh : U + (k - wl)]] = q * v; }
+    for (int k = lane; k < wl + nbd; k += 64) { const double v = row[k]; if (v != 0.0) sm[(size_t)gi * es + cpos[k < wl ? k + sh : U + (k - wl)]] = q * v; }
   }
   __syncthreads();
-  // lower triangle of the union block: pair t = ia (ia + 1) / 2 + ib, ib <= ia
   det_enter(tk);
-  const int npair = nn * (nn + 1) / 2;
-  for (int t = tid; t < npair + nn; t += 256) {
-    if (t >= npair) {   // gradient
-      const int ia = t - npair, c = cols[ia];
-      double acc = 0.0;
-      for (int gi = 0; gi < G; ++gi) acc += sm[(size_t)gi * nn + ia] * glw[gi];
-      if (acc != 0.0) { if (c < U) atomicAdd(&gbr[pmin + c], -acc); else atomicAdd(&gcr[c - U], -acc); }
-      continue;
-    }
-    int ia = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-    while (ia * (ia + 1) / 2 > t) --ia;
-    while ((ia + 1) * (ia + 2) / 2 <= t) ++ia;
-    const int ib = t - ia * (ia + 1) / 2;
+  // gradient: - sum_l w_l E_l^T g_l
+  for (int ia = tid; ia < nn; ia += 256) {
+    const int c = cols[ia];
     double acc = 0.0;
-    for (int gi = 0; gi < G; ++gi) acc += sm[(size_t)gi * nn + ia] * sm[(size_t)gi * nn + ib];
-    if (acc == 0.0) continue;
-    const int hi = cols[ia], lo = cols[ib];   // cols is ascending: hi >= lo
-    if (hi < U) { if (hi - lo <= bw) atomicAdd(&Hr[(size_t)(pmin + lo) * (bw + 1) + (hi - lo)], -acc); }
-    else if (lo < U) atomicAdd(&Br[(size_t)(hi - U) * nb + pmin + lo], -acc);
-    else atomicAdd(&Cr[(size_t)(hi - U) * ldc + (lo - U)], -acc);
+    for (int gi = 0; gi < G; ++gi) acc += sm[(size_t)gi * es + ia] * glw[gi];
+    if (acc != 0.0) { if (c < U) atomicAdd(&gbr[pmin + c], -acc); else atomicAdd(&gcr[c - U], -acc); }
+  }
+  // E^T E on the matrix cores: E is [32 landmarks][nn columns] in LDS, i.e. already the [k][column] panel whose 16-column fragments are both operands of a tile pair
+  // (lane l: E[4 ks + (l >> 4)][16 c + (l & 15)]); 8 k-steps per pair, the upper tile pairs dealt to the four wavefronts.  A thread per entry walking the 32 landmarks
+  // with two LDS reads per product took 161 us per solve at config 4.
+  const int nt = (nn + 15) >> 4, npair = nt * (nt + 1) / 2;
+  for (int t = wv; t < npair; t += 4) {
+    int ci = 0, r = t;
+    while (r >= nt - ci) { r -= nt - ci; ++ci; }
+    const int cj = ci + r;
+    const int ca = 16 * ci + (lane & 15), cb = 16 * cj + (lane & 15);
+    d4s D = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const double* src = sm + (size_t)(4 * ks + (lane >> 4)) * es;
+      const double fa = ca < nn ? src[ca] : 0.0, fb = cb < nn ? src[cb] : 0.0;
+      D = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, D, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int ia = 16 * ci + (lane >> 4) + 4 * v, ib = 16 * cj + (lane & 15);   // ia <= ib except inside a diagonal tile
+      const double acc = D[v];
+      if (ia >= nn || ib >= nn || acc == 0.0 || (ci == cj && ia > ib)) continue;
+      const int lo = cols[ia], hi = cols[ib];   // cols is ascending: hi >= lo
+      if (hi < U) { if (hi - lo <= bw) atomicAdd(&Hr[(size_t)(pmin + lo) * (bw + 1) + (hi - lo)], -acc); }
+      else if (lo < U) atomicAdd(&Br[(size_t)(hi - U) * nb + pmin + lo], -acc);
+      else atomicAdd(&Cr[(size_t)(hi - U) * ldc + (lo - U)], -acc);
+    }
   }
   det_leave(tk);
 }
@@ -814,7 +828,7 @@ static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, 
     LVX_HIP(c, hipMemcpyAsync((void*)w.Cs, c->d_C.p, ldc * ldc * 8, hipMemcpyDeviceToDevice, st));
     LVX_HIP(c, hipMemcpyAsync((void*)w.gcs, c->d_gc.p, ldc * 8, hipMemcpyDeviceToDevice, st));
     const int ne_max = c->lm_wl + c->lm_gspread + c->nbd_ext;
-    const size_t lds_g = (size_t)32 * ne_max * 8 + 32 * 8 + (size_t)2 * ne_max * 4 + 16;
+    const size_t lds_g = (size_t)32 * (ne_max + 1) * 8 + 32 * 8 + (size_t)2 * ne_max * 4 + 16;
     if (c->lm_ngrp > 0 && lds_g <= 160 * 1024) {
       LVX_HIP(c, hipFuncSetAttribute((const void*)k_lm_schur_grp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
       hipLaunchKernelGGL(k_lm_schur_grp, dim3((unsigned)c->lm_ngrp), dim3(256), lds_g, st, (const double*)c->d_lmH.p, (const int*)c->d_lm_p0.p, (const int*)c->d_lm_grp.p, c->lm_ngrp, c->lm_wl, c->nbd_ext, c->lm_ls,
