@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void k_bcr_build(const double* __restrict__ Hb
   for (int rr = threadIdx.x & 63; rr < b; rr += 64) {
     const long long r = r0 + rr;
     double v = 0.0;
+    if (!isG && rr < cc) continue;   // the strict upper triangle of D is never read (Cholesky, triangular solves and Schur updates work on the lower one): 108 MB less to write
     if (!isG) {
       if (rr >= cc) {
         if (r < nb) { const long long d = r - c; if (d <= bw) { const double hv = col[d]; v = hv * scale[r] * sc; if (d == 0) v = hv == 0.0 ? 1.0 : v + lmd[c] * inv_radius; } }   // untouched variable (zero row, zero gradient): any pivot gives y = 0; use 1 instead of 1e-6/radius
