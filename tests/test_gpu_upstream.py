@@ -438,3 +438,28 @@ def test_less_flat_voxelgrid_downsample(ctx):
     # coarser leaf => fewer points
     _, _, n3 = lvx.scan_less_flat_downsample(ctx, 16, max_out=10, leaf=1.0)
     assert n3 < n
+
+
+def test_data_association_map_time_outside_the_trajectory():
+    """lvx_data_association keeps the map-time pose on the device (no host hop between k_lidar_pose and the de-skew): an invalid pose makes NaN points, and the call reports
+    LVX_E_RANGE at its next synchronisation — with the reference's wording — instead of a surfel map built from garbage; the context is usable afterwards."""
+    import ctypes as C
+    S = synth.make_sequence(seed=50)
+    g = lvx.Context(0)
+    g.set_spline(S["t0"], S["dt"], S["n_knots"])
+    raw = np.zeros(S["scans"].shape, dtype=lvx.POINT_XYZIT)
+    for k in ("x", "y", "z", "timestamp"):
+        raw[k] = S["scans"][k]
+    g._ck(g._l.lvx_set_scans(g._h, C.c_int(len(raw)), C.c_int(S["H"]), C.c_int(S["W"]), raw.ctypes.data_as(C.c_void_p)))
+    st = np.ascontiguousarray(S["state0"], np.float64)
+    npl, npt = C.c_int32(0), C.c_int32(0)
+    call = lambda t: g._ck(g._l.lvx_data_association(g._h, st.ctypes.data_as(C.c_void_p), C.c_double(t), None, C.byref(npl), C.byref(npt)))
+    with pytest.raises(lvx.LvxError) as e:
+        call(S["t0"] - 100.0)
+    assert e.value.code == lvx.E_RANGE and "map time outside the trajectory" in str(e.value)
+    call(S["t_map"])
+    assert npl.value > 100 and npt.value > 1000
+    first = (npl.value, npt.value)
+    call(S["t_map"])
+    assert (npl.value, npt.value) == first
+    g.close()
