@@ -141,6 +141,9 @@ def test_voxel_build_large_cloud_and_long_leaves(ctx):
         vg = lvx.voxel_build(ctx, cloud, leaf)
         _check_voxels(vg, vo)
     assert vo["leaf_n"].max() > 1500
+    big = synth.tile_voxel_cloud(synth.make_voxel_cloud(seed=5, n=100_000), 12)   # 1.2 M points: above the own radix sort's range, rocPRIM's sort feeds the same leaf kernel
+    vo, vg = O.voxel_build(big, 0.5), lvx.voxel_build(ctx, big, 0.5)
+    _check_voxels(vg, vo)
     small = synth.make_voxel_cloud(seed=9, n=30_000)          # the one-position-per-thread tiles with long leaves
     vo, vg = O.voxel_build(small, 6.0), lvx.voxel_build(ctx, small, 6.0)
     _check_voxels(vg, vo)
