@@ -1183,7 +1183,8 @@ int bcr_backward(lvx_ctx* c, double* Zy, double* Zx, int ldz, int nrhs) {
 // cores: a workgroup takes GRAM_ROWS rows, stages 64 of them at a time in LDS as P[row][col] (coalesced loads along the rows, odd row stride), and every 4 panel rows are
 // one k-step of each upper tile pair — the fragment of column tile c at lane l, P[4 ks + (l >> 4)][16 c + (l & 15)], is the A operand of Z^T and the B operand of Z, as in
 // the evaluation kernels; the tile pairs are dealt to the four wavefronts.  Partial Grams per workgroup, then k_sum_partials.  Replaced rocBLAS' strided-batched GEMM
-// (one small GEMM per row block, 54 us): the last library call of a solve with blocks up to 208.
+// (one small GEMM per row block, 54 us): the last library call of a solve with blocks up to 208.  The layouts of this library have 22 (no hub) or 52 border variables: n = 23 / 53,
+// the 3- and 4-tile instances; the 5-tile one and the library path beyond 80 columns are there for completeness.
 #define GRAM_ROWS 256
 #define GRAM_NT 5
 #define GRAM_LDP (16 * GRAM_NT + 1)

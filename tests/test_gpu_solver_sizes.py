@@ -35,3 +35,4 @@ def test_step_of_every_kernel_instance_matches_the_sequential_band_cholesky(view
     assert np.all(np.isfinite(d)) and np.abs(d).max() > 0
     assert np.abs(d - ds).max() <= 1e-7 * max(1.0, np.abs(ds).max())
     assert abs(m - ms) <= 1e-8 * abs(ms)
+
