@@ -1187,31 +1187,49 @@ __global__ __launch_bounds__(256) void k_assoc_hits(const float4* __restrict__ s
   }
 }
 // (it also returns the ring's words and count to zero: the work buffer is cleared once, when it is allocated, not 7 MB per scan and call)
-__global__ void k_assoc_select(unsigned* __restrict__ bits, int* __restrict__ counts, int S, int H, int W, int P, int wpr, int sel, int* flags) {
+// A WAVEFRONT per ring with hits: lane = mask word (coalesced read + clear), set-bit counts prefix-summed over the lanes, the lane whose word holds the target rank finds
+// the bit.  One thread per ring walked its 57 words serially, one load each, with a handful of lanes of the wavefront alive: 99 us for 64 scans x 2 000 surfels.
+__global__ __launch_bounds__(256) void k_assoc_select(unsigned* __restrict__ bits, int* __restrict__ counts, int S, int H, int W, int P, int wpr, int sel, int* flags) {
+  const size_t total = (size_t)S * P * H;
   const size_t ring = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (ring >= (size_t)S * P * H) return;
-  const int cnt = counts[ring];
-  if (cnt == 0) return;
-  counts[ring] = 0;
-  if (cnt < sel * 2) { unsigned* bz = bits + ring * wpr; for (int k = 0; k < wpr; ++k) if (bz[k]) bz[k] = 0u; return; }
-  const int h = (int)(ring % H), pid = (int)((ring / H) % P), sc = (int)(ring / ((size_t)H * P));
-  int step = cnt / (sel + 1);
-  step = step > 1 ? step : 1;
-  unsigned* bw = bits + ring * wpr;
-  int seen = 0, s = 0, target = step - 1;
-  for (int k = 0; k < wpr; ++k) {
-    unsigned word = bw[k];
-    if (word == 0u) continue;
-    bw[k] = 0u;
-    int pc = __popc(word);
-    while (s < sel && target < seen + pc) {       // the (target - seen)-th set bit of this word
-      unsigned t = word;
-      for (int r = target - seen; r > 0; --r) t &= t - 1;
-      const int w = 32 * k + (__ffs(t) - 1);
-      atomicMax(&flags[(size_t)sc * H * W + (size_t)h * W + w], pid);
-      ++s; target = step * (s + 1) - 1;
+  const int lane = threadIdx.x & 63;
+  const size_t wave0 = ring - lane;
+  const int cnt = ring < total ? counts[ring] : 0;
+  if (cnt != 0) counts[ring] = 0;
+  unsigned long long act = __ballot(cnt != 0);
+  while (act) {
+    const int src = __ffsll((long long)act) - 1;
+    act &= act - 1;
+    const size_t rg = wave0 + src;
+    const int c = __shfl(cnt, src);
+    const bool pick = c >= sel * 2;
+    const int h = (int)(rg % H), pid = (int)((rg / H) % P), sc = (int)(rg / ((size_t)H * P));
+    int step = c / (sel + 1);
+    step = step > 1 ? step : 1;
+    unsigned* bw = bits + rg * wpr;
+    int seen = 0, s = 0;   // (wave-uniform)
+    for (int k0 = 0; k0 < wpr; k0 += 64) {
+      const int k = k0 + lane;
+      const unsigned word = k < wpr ? bw[k] : 0u;
+      if (word != 0u) bw[k] = 0u;
+      if (!pick) continue;
+      const int pc = __popc(word);
+      int incl = pc;
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+      const int chunk = __shfl(incl, 63), excl = seen + incl - pc;
+      while (s < sel) {
+        const int target = step * (s + 1) - 1;       // the target-th hit of the ring, in column order
+        if (target >= seen + chunk) break;
+        if (target >= excl && target < excl + pc) {
+          unsigned t = word;
+          for (int r = target - excl; r > 0; --r) t &= t - 1;
+          const int w = 32 * k + (__ffs(t) - 1);
+          atomicMax(&flags[(size_t)sc * H * W + (size_t)h * W + w], pid);
+        }
+        ++s;
+      }
+      seen += chunk;
     }
-    seen += pc;
   }
 }
 // Chronological SurfelPoint emission (surfel_association.cpp:141-158): column-major (w outer, h inner), points with a flag and a non-zero raw
