@@ -1092,10 +1092,14 @@ __global__ __launch_bounds__(256) void k_assoc_grid_geom(int P, const double* pl
   }
 }
 // mode 0: count the cells every box reaches; mode 1: write the box into its cells' lists (cursor = running offsets)
-__global__ void k_assoc_grid_fill(int P, const double* planes10, const AssocGrid* gp, int* cell_cnt, int* cursor, int* list, int mode) {
+__global__ void k_assoc_grid_fill(int P, const double* planes10, const AssocGrid* gp, int* cell_cnt, int* cursor, int* list, int mode, double* aos) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= P) return;
   const AssocGrid g = *gp;
+  if (mode == 0 && aos) {   // one 80-byte record per surfel for the hit kernel: box min | box max | plane (the caller's table is three arrays: ten 8-byte loads from three places per candidate)
+    for (int a = 0; a < 3; ++a) { aos[10 * (size_t)k + a] = planes10[4 * (size_t)P + 3 * (size_t)k + a]; aos[10 * (size_t)k + 3 + a] = planes10[7 * (size_t)P + 3 * (size_t)k + a]; }
+    for (int a = 0; a < 4; ++a) aos[10 * (size_t)k + 6 + a] = planes10[4 * (size_t)k + a];
+  }
   int c0[3], c1[3];
   const int nn[3] = {SA_GX, SA_GY, SA_GZ};
   for (int a = 0; a < 3; ++a) {
@@ -1160,26 +1164,29 @@ __global__ __launch_bounds__(256) void k_assoc_hits_allpairs(const float4* __res
     }
   }
 }
-__global__ __launch_bounds__(256) void k_assoc_hits(const float4* __restrict__ scans, int H, int W, int P, const double* __restrict__ planes10, double radius, const AssocGrid* gp,
+__global__ __launch_bounds__(256) void k_assoc_hits(const float4* __restrict__ scans, int H, int W, int P, const double* __restrict__ aos, double radius, const AssocGrid* gp,
                                                     const int* __restrict__ off, const int* __restrict__ list, unsigned* bits, int* counts, int wpr) {
   const int i = blockIdx.x * 256 + threadIdx.x, sc = blockIdx.y;
   if (i >= H * W) return;
   const float4 q = scans[(size_t)sc * H * W + i];
-  if (isnan(q.x)) return;
   const double x = q.x, y = q.y, z = q.z;
   const AssocGrid g = *gp;
-  // outside the bounds of all boxes: no box can hold the point (sa_cell would clamp it into a border cell)
-  if (!((x - g.g0[0]) * g.inv[0] >= 0.0 && (x - g.g0[0]) * g.inv[0] <= (double)SA_GX && (y - g.g0[1]) * g.inv[1] >= 0.0 && (y - g.g0[1]) * g.inv[1] <= (double)SA_GY &&
-        (z - g.g0[2]) * g.inv[2] >= 0.0 && (z - g.g0[2]) * g.inv[2] <= (double)SA_GZ)) return;
+  // NaN point, or outside the bounds of all boxes: no box can hold the point (sa_cell would clamp it into a border cell).  Tests combined with & (no short circuit): with &&
+  // the compiler loads x, waits, branches, loads y z, waits ... — a memory round trip per condition, here and in the candidate loop below
+  const double gx = (x - g.g0[0]) * g.inv[0], gy = (y - g.g0[1]) * g.inv[1], gz = (z - g.g0[2]) * g.inv[2];
+  const bool in_grid = (!isnan(q.x)) & (gx >= 0.0) & (gx <= (double)SA_GX) & (gy >= 0.0) & (gy <= (double)SA_GY) & (gz >= 0.0) & (gz <= (double)SA_GZ);
+  if (!in_grid) return;
   const int cell = (sa_cell(z, g.g0[2], g.inv[2], SA_GZ) * SA_GY + sa_cell(y, g.g0[1], g.inv[1], SA_GY)) * SA_GX + sa_cell(x, g.g0[0], g.inv[0], SA_GX);
   const int h = i / W, w = i - h * W;
   for (int e = off[cell]; e < off[cell + 1]; ++e) {
     const int k = list[e];
-    const double* lo = planes10 + 4 * (size_t)P + 3 * (size_t)k; const double* hi = planes10 + 7 * (size_t)P + 3 * (size_t)k; const double* pl = planes10 + 4 * (size_t)k;
-    if (!(x > lo[0] && x < hi[0] && y > lo[1] && y < hi[1] && z > lo[2] && z < hi[2])) continue;
+    const double2* rec = (const double2*)(aos + 10 * (size_t)k);   // five 16-byte loads
+    const double2 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
+    const double lo[3] = {r0.x, r0.y, r1.x}, hi[3] = {r1.y, r2.x, r2.y}, pl[4] = {r3.x, r3.y, r4.x, r4.y};
+    const bool inside = (x > lo[0]) & (x < hi[0]) & (y > lo[1]) & (y < hi[1]) & (z > lo[2]) & (z < hi[2]);
     double dist = x * pl[0] + y * pl[1] + z * pl[2] + pl[3];
     dist = dist > 0 ? dist : -dist;
-    if (dist <= radius) {
+    if (inside & (dist <= radius)) {
       const size_t ring = ((size_t)sc * P + k) * H + h;
       atomicOr(&bits[ring * wpr + (w >> 5)], 1u << (w & 31));
       atomicAdd(&counts[ring], 1);
@@ -1740,18 +1747,20 @@ static int assoc_grid_build(lvx_ctx* c, int P, const double* planes_d, bool have
   if (have) return LVX_OK;
   c->assoc_map_ready = false;   // the grid buffers are about to hold another table's grid
   int rc;
-  if ((rc = dev_alloc(c, c->d_assoc[0], sizeof(AssocGrid) + (size_t)(3 * SA_CELLS + 8) * 4))) return rc;
+  const size_t grid_bytes = (sizeof(AssocGrid) + (size_t)(3 * SA_CELLS + 8) * 4 + 15) & ~(size_t)15;
+  if ((rc = dev_alloc(c, c->d_assoc[0], grid_bytes + (size_t)P * 80))) return rc;
   AssocGrid* gd = (AssocGrid*)c->d_assoc[0].p; int* ccnt = (int*)(gd + 1); int* coff = ccnt + SA_CELLS; int* ccur = coff + SA_CELLS + 1;
+  double* aos = (double*)((char*)c->d_assoc[0].p + grid_bytes);
   LVX_HIP(c, hipMemsetAsync(ccnt, 0, (size_t)SA_CELLS * 4, c->stream));
   hipLaunchKernelGGL(k_assoc_grid_geom, dim3(1), dim3(256), 0, c->stream, P, planes_d, gd);
-  hipLaunchKernelGGL(k_assoc_grid_fill, dim3((unsigned)((P + 127) / 128)), dim3(128), 0, c->stream, P, planes_d, (const AssocGrid*)gd, ccnt, ccur, (int*)nullptr, 0);
+  hipLaunchKernelGGL(k_assoc_grid_fill, dim3((unsigned)((P + 127) / 128)), dim3(128), 0, c->stream, P, planes_d, (const AssocGrid*)gd, ccnt, ccur, (int*)nullptr, 0, aos);
   hipLaunchKernelGGL(k_assoc_grid_scan, dim3(1), dim3(1024), 0, c->stream, (const int*)ccnt, coff, ccur);
   int total = 0;
   LVX_HIP(c, hipMemcpyAsync(&total, coff + SA_CELLS, 4, hipMemcpyDeviceToHost, c->stream));
   LVX_HIP(c, hipStreamSynchronize(c->stream));
   if ((rc = dev_alloc(c, c->d_assoc[1], (size_t)std::max(total, 1) * 4))) return rc;
   int* clist = (int*)c->d_assoc[1].p;
-  hipLaunchKernelGGL(k_assoc_grid_fill, dim3((unsigned)((P + 127) / 128)), dim3(128), 0, c->stream, P, planes_d, (const AssocGrid*)gd, ccnt, ccur, clist, 1);
+  hipLaunchKernelGGL(k_assoc_grid_fill, dim3((unsigned)((P + 127) / 128)), dim3(128), 0, c->stream, P, planes_d, (const AssocGrid*)gd, ccnt, ccur, clist, 1, (double*)nullptr);
   return LVX_OK;
 }
 static int assoc_device(lvx_ctx* c, const float4* scans_d, int S, int H, int W, int P, const double* planes_d, double radius, int sel, int* flags_d) {
@@ -1776,7 +1785,8 @@ static int assoc_device(lvx_ctx* c, const float4* scans_d, int S, int H, int W, 
   if ((rc = assoc_grid_build(c, P, planes_d, c->assoc_map_ready && c->assoc_map_planes == planes_d && c->assoc_map_P == P))) return rc;
   AssocGrid* gd = (AssocGrid*)c->d_assoc[0].p; int* ccnt = (int*)(gd + 1); int* coff = ccnt + SA_CELLS; int* clist = (int*)c->d_assoc[1].p;
   (void)ccnt;
-  hipLaunchKernelGGL(k_assoc_hits, dim3((unsigned)((H * W + 255) / 256), (unsigned)S), dim3(256), 0, c->stream, scans_d, H, W, P, planes_d, radius, (const AssocGrid*)gd, (const int*)coff, (const int*)clist,
+  const double* aos = (const double*)((const char*)c->d_assoc[0].p + ((sizeof(AssocGrid) + (size_t)(3 * SA_CELLS + 8) * 4 + 15) & ~(size_t)15));
+  hipLaunchKernelGGL(k_assoc_hits, dim3((unsigned)((H * W + 255) / 256), (unsigned)S), dim3(256), 0, c->stream, scans_d, H, W, P, aos, radius, (const AssocGrid*)gd, (const int*)coff, (const int*)clist,
                      bits, counts, wpr);
   hipLaunchKernelGGL(k_assoc_select, dim3((unsigned)((rings + 255) / 256)), dim3(256), 0, c->stream, bits, counts, S, H, W, P, wpr, sel, flags_d);
   LVX_HIP(c, hipGetLastError());
