@@ -1042,17 +1042,22 @@ __global__ void k_vx_lookup(const float4* q, int nq, float leaf, int min_pts, Vx
   const float4 p = q[i];
   const int ijk[3] = {(int)floorf(p.x / leaf), (int)floorf(p.y / leaf), (int)floorf(p.z / leaf)};   // :383-385
   const int disp[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+  // all K cell probes in flight, then all K leaf counts: two memory round trips per query.  (Probe by probe — load the cell, wait, load its leaf's count, wait, store —
+  // the compiler kept the 2 K loads of a query strictly one behind the other.)
+  bool in[K]; int li[K], cn[K];
+#pragma unroll
   for (int k = 0; k < K; ++k) {
-    int id = -1;
-    bool in = true;
-    for (int a = 0; a < 3; ++a) in = in && (g.min_b[a] - ijk[a] <= disp[k][a]) && (g.max_b[a] - ijk[a] >= disp[k][a]);
-    if (in) {
-      const int key = (ijk[0] + disp[k][0] - g.min_b[0]) * g.mul[0] + (ijk[1] + disp[k][1] - g.min_b[1]) * g.mul[1] + (ijk[2] + disp[k][2] - g.min_b[2]) * g.mul[2];
-      const int li = grid[key];
-      if (li >= 0 && leaf_n[li] >= min_pts) id = li;
-    }
-    ids7[K * (size_t)i + k] = id;
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) ok = ok & (g.min_b[a] - ijk[a] <= disp[k][a]) & (g.max_b[a] - ijk[a] >= disp[k][a]);
+    in[k] = ok;
+    const int key = (ijk[0] + disp[k][0] - g.min_b[0]) * g.mul[0] + (ijk[1] + disp[k][1] - g.min_b[1]) * g.mul[1] + (ijk[2] + disp[k][2] - g.min_b[2]) * g.mul[2];
+    li[k] = grid[ok ? key : 0];                  // (an unconditional load at a clamped address: selected afterwards)
   }
+#pragma unroll
+  for (int k = 0; k < K; ++k) { li[k] = in[k] ? li[k] : -1; cn[k] = leaf_n[li[k] >= 0 ? li[k] : 0]; }
+#pragma unroll
+  for (int k = 0; k < K; ++k) ids7[K * (size_t)i + k] = (li[k] >= 0 && cn[k] >= min_pts) ? li[k] : -1;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
