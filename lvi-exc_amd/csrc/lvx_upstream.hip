@@ -881,13 +881,24 @@ __global__ __launch_bounds__(256) void k_ndt_derivatives(const float4* src, cons
     const int hsel[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
     const int ijk[3] = {(int)floorf(xt.x / leaf), (int)floorf(xt.y / leaf), (int)floorf(xt.z / leaf)};
     const int disp[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+    // the seven cell probes in flight, then the seven leaf counts (as in k_vx_lookup: probe by probe the loads queue up one behind the other); cells are still visited
+    // in the reference's order
+    int lis[7]; bool use[7];
+#pragma unroll
     for (int nb = 0; nb < 7; ++nb) {
       bool in = true;
-      for (int a = 0; a < 3; ++a) in = in && (g.min_b[a] - ijk[a] <= disp[nb][a]) && (g.max_b[a] - ijk[a] >= disp[nb][a]);
-      if (!in) continue;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) in = in & (g.min_b[a] - ijk[a] <= disp[nb][a]) & (g.max_b[a] - ijk[a] >= disp[nb][a]);
       const int key = (ijk[0] + disp[nb][0] - g.min_b[0]) * g.mul[0] + (ijk[1] + disp[nb][1] - g.min_b[1]) * g.mul[1] + (ijk[2] + disp[nb][2] - g.min_b[2]) * g.mul[2];
-      const int li = grid[key];
-      if (li < 0 || leaf_n[li] < min_pts) continue;
+      const int l0 = grid[in ? key : 0];
+      lis[nb] = in ? l0 : -1;
+    }
+#pragma unroll
+    for (int nb = 0; nb < 7; ++nb) { const int cn = leaf_n[lis[nb] >= 0 ? lis[nb] : 0]; use[nb] = lis[nb] >= 0 && cn >= min_pts; }
+#pragma unroll
+    for (int nb = 0; nb < 7; ++nb) {
+      if (!use[nb]) continue;
+      const int li = lis[nb];
       const double* mu = mean + 3 * (size_t)li; const double* ic = icov + 9 * (size_t)li;
       const float x4[3] = {(float)((double)xt.x - mu[0]), (float)((double)xt.y - mu[1]), (float)((double)xt.z - mu[2])};
       float ci[3][3];
