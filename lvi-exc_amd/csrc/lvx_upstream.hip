@@ -1341,13 +1341,17 @@ __device__ __forceinline__ bool camera_pose_dev(const double* state, int N, doub
 // associateVisualPointsWithPlanes (surfel_association.cpp:161-214): thread = landmark; its reference observation is back-projected at depth 1 / rho with the
 // camera pose at the view's t0, moved into the LiDAR map frame (pose of the camera at the map time, q_LtoC / t_LinC), and tested against every surfel:
 // strictly inside the AABB and within 2 radius of the plane; the last (highest) matching surfel stays, as in the reference's loop.
-__global__ void k_landmark_assoc(const double* state, int N, double t0, double dt, CamIntr cam, const double* lm_uv, const double* lm_t0, int L, double map_time,
-                                 quat q_LtoC, v3 t_LinC, int P, const double* planes10, double radius, int* out) {
+// (the plane table goes through LDS 256 planes at a time and the box tests are combined with &: a thread walking the caller's three arrays plane by plane made a memory
+// round trip per condition, 2 000 planes long)
+__global__ __launch_bounds__(256) void k_landmark_assoc(const double* state, int N, double t0, double dt, CamIntr cam, const double* lm_uv, const double* lm_t0, int L, double map_time,
+                                                        quat q_LtoC, v3 t_LinC, int P, const double* planes10, double radius, int* out) {
+  __shared__ double tab[256 * 10];   // box min | box max | plane of 256 planes
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= L) return;
   int res = -1;
+  bool live = false;
+  v3 q = mk(0, 0, 0);
   quat q_CtoG; v3 p_CinG;
-  if (camera_pose_dev(state, N, t0, dt, map_time, &q_CtoG, &p_CinG)) {
+  if (l < L && camera_pose_dev(state, N, t0, dt, map_time, &q_CtoG, &p_CinG)) {
     const quat q_L0_G = qmul(q_CtoG, q_LtoC);
     const v3 t_L0_G = qrot(q_CtoG, t_LinC) + p_CinG;
     const double n2 = q_L0_G.x * q_L0_G.x + q_L0_G.y * q_L0_G.y + q_L0_G.z * q_L0_G.z + q_L0_G.w * q_L0_G.w;
@@ -1356,18 +1360,29 @@ __global__ void k_landmark_assoc(const double* state, int N, double t0, double d
     if (!(rho < 0.05) && camera_pose_dev(state, N, t0, dt, lm_t0[l], &q_CtoG, &p_CinG)) {
       const v3 yu = cam_unproject(cam, lm_uv[2 * (size_t)l], lm_uv[2 * (size_t)l + 1]);
       const v3 p3d_C = mk(yu.x / rho, yu.y / rho, yu.z / rho);
-      const v3 q = qrot(q_inv, (qrot(q_CtoG, p3d_C) + p_CinG) - t_L0_G);
-      for (int k = 0; k < P; ++k) {
-        const double* lo = planes10 + 4 * (size_t)P + 3 * (size_t)k; const double* hi = planes10 + 7 * (size_t)P + 3 * (size_t)k; const double* pl = planes10 + 4 * (size_t)k;
-        if (q.x > lo[0] && q.x < hi[0] && q.y > lo[1] && q.y < hi[1] && q.z > lo[2] && q.z < hi[2]) {
-          double dst = q.x * pl[0] + q.y * pl[1] + q.z * pl[2] + pl[3];
-          dst = dst > 0 ? dst : -dst;
-          if (dst <= radius * 2) res = k;
-        }
-      }
+      q = qrot(q_inv, (qrot(q_CtoG, p3d_C) + p_CinG) - t_L0_G);
+      live = true;
     }
   }
-  out[l] = res;
+  for (int k0 = 0; k0 < P; k0 += 256) {
+    const int k = k0 + threadIdx.x;
+    __syncthreads();
+    if (k < P) {
+      for (int a = 0; a < 3; ++a) { tab[10 * threadIdx.x + a] = planes10[4 * (size_t)P + 3 * (size_t)k + a]; tab[10 * threadIdx.x + 3 + a] = planes10[7 * (size_t)P + 3 * (size_t)k + a]; }
+      for (int a = 0; a < 4; ++a) tab[10 * threadIdx.x + 6 + a] = planes10[4 * (size_t)k + a];
+    }
+    __syncthreads();
+    if (!live) continue;
+    const int m = min(256, P - k0);
+    for (int j = 0; j < m; ++j) {   // ascending: the highest plane index wins, as the reference's loop
+      const double* r = tab + 10 * j;
+      const bool inside = (q.x > r[0]) & (q.x < r[3]) & (q.y > r[1]) & (q.y < r[4]) & (q.z > r[2]) & (q.z < r[5]);
+      double dst = q.x * r[6] + q.y * r[7] + q.z * r[8] + r[9];
+      dst = dst > 0 ? dst : -dst;
+      if (inside & (dst <= radius * 2)) res = k0 + j;
+    }
+  }
+  if (l < L) out[l] = res;
 }
 __global__ void k_lidar_pose(const double* state, int N, double t0, double dt, int n, const double* t, double* q4, double* p3, int* valid) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1934,7 +1949,7 @@ int lvx_landmark_assoc(lvx_ctx* c, const double* state, const double* q_LtoC_xyz
   if ((rc = upload(c, c->d_up[4], c->lm_t0.data(), (size_t)L * 8))) return rc;
   if ((rc = dev_alloc(c, c->d_up[6], (size_t)L * 4))) return rc;
   { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
-    hipLaunchKernelGGL(k_landmark_assoc, dim3((unsigned)((L + 127) / 128)), dim3(128), 0, c->stream, (const double*)c->d_up[2].p, c->N, c->t0, c->dt, c->cam, (const double*)c->d_up[3].p,
+    hipLaunchKernelGGL(k_landmark_assoc, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, c->stream, (const double*)c->d_up[2].p, c->N, c->t0, c->dt, c->cam, (const double*)c->d_up[3].p,
                        (const double*)c->d_up[4].p, L, map_time, mkq(q_LtoC_xyzw[3], q_LtoC_xyzw[0], q_LtoC_xyzw[1], q_LtoC_xyzw[2]), mk(t_LinC3[0], t_LinC3[1], t_LinC3[2]), n_planes,
                        (const double*)c->d_up[5].p, radius, (int*)c->d_up[6].p); }
   LVX_HIP(c, hipGetLastError());
