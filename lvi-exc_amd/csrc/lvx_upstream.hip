@@ -551,6 +551,7 @@ __global__ __launch_bounds__(256) void k_vx_sort_pass(const unsigned* __restrict
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
   const int tile0 = b * 256 * KPT;
   for (int e = tid; e < KPT * 4 * 256; e += 256) hist[e] = 0;
+  const int gh = ghist[tid];   // (requested with the keys: not behind the tile's own counting)
   unsigned key[KPT]; int val[KPT]; int rk[KPT];
 #pragma unroll
   for (int u = 0; u < KPT; ++u) {
@@ -580,7 +581,6 @@ __global__ __launch_bounds__(256) void k_vx_sort_pass(const unsigned* __restrict
   for (int g = 0; g < 4 * KPT; ++g) { const int t = hist[g * 256 + tid]; hist[g * 256 + tid] = cnt; cnt += t; }
   __hip_atomic_store(&tcnt[b * 256 + tid], ((b == 0 ? 2u : 1u) << 30) | (unsigned)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // digits below mine in the whole array
-  const int gh = ghist[tid];
   int incl = gh;
   for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
   if (lane == 63) wsum[wv] = incl;
