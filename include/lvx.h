@@ -289,6 +289,10 @@ int lvx_voxel_lookup7_d(lvx_ctx* ctx, int nq, const float* xyzi4_d, int32_t* lea
 /* getNeighborhoodAtPoint1 (:440-446): the leaf of the query's own cell or -1 */
 int lvx_voxel_lookup1(lvx_ctx* ctx, int nq, const float* xyzi4, int32_t* leaf_ids1);
 int lvx_voxel_lookup1_d(lvx_ctx* ctx, int nq, const float* xyzi4_d, int32_t* leaf_ids1_d);
+/* getNeighborhoodAtPoint(relative_coordinates, reference_point, neighbors) (:378-408), the general form behind the 1- / 7- / 26-cell variants (:411-446):
+ * leaf_ids[q][r] = leaf at displacement rel3[r] = (di, dj, dk) from the query's cell, or -1 (outside the grid, empty, fewer than min_points_per_voxel points).
+ * The reference returns the hits in this order without the misses.  DIRECT26 = pcl::getAllNeighborCellIndices() as rel3. */
+int lvx_voxel_lookup_rel(lvx_ctx* ctx, int nq, const float* xyzi4, int n_rel, const int32_t* rel3, int32_t* leaf_ids);
 /* SurfelAssociation::getAssociation flag pass (src/lvi_exc/src/core/surfel_association.cpp:111-138): plane_of_point[H*W] = surfel id or -1.
  * Conflicts resolve as the reference's SERIAL plane loop (highest plane id wins); W <= 4096 */
 int lvx_surfel_assoc(lvx_ctx* ctx, int H, int W, const float* scan_map_xyzi4, int n_planes, const double* plane_p4, const double* box_min3, const double* box_max3,
@@ -348,6 +352,28 @@ int64_t lvx_collective_count(lvx_ctx* ctx, int reset);
  * (pcl::transformPointCloud, as the caller does before every call).  Per-point arithmetic in float like the reference, accumulation in double. */
 int lvx_ndt_derivatives(lvx_ctx* ctx, int n, const float* input_xyzi4, const float* trans_xyzi4, const double* p6, double outlier_ratio, int compute_hessian,
                         double* score, double* gradient6, double* hessian36);
+
+/* NDT registration (the loop around the derivatives) ---------------------------------------------------------------------------*/
+/* pcl::Registration::align -> pclomp::NormalDistributionsTransform::computeTransformation (src/ndt_omp/include/pclomp/ndt_omp_impl.hpp:81-171): Newton steps
+ * (JacobiSVD solve of the 6 x 6 system :127-129) with the More-Thuente step length (computeStepLengthMT :772-931, updateIntervalMT :648-685, trialValueSelectionMT
+ * :689-768), derivatives by computeDerivatives (:180-285) and, after a line search that moved, computeHessian (:540-645), all against the voxel grid of the last
+ * lvx_voxel_build of this context (= setInputTarget at that resolution, ndt_omp.h:117-122,275-282).  The Newton / line-search bookkeeping (a handful of scalars per
+ * iteration) runs on the host as in the reference; every evaluation over the cloud is one kernel.  Defaults = the reference's constructor (:46-76).
+ * search: 1 = DIRECT1, 7 = DIRECT7, 26 = DIRECT26 (ndt_omp.h:59-64; KDTREE is not offered: the calibration uses DIRECT7, lidar_odometry.cpp:32-43). */
+typedef struct lvx_ndt_options { double step_size, outlier_ratio, transformation_epsilon; int32_t max_iterations, search; } lvx_ndt_options;
+typedef struct lvx_ndt_result {
+  float final_transformation[16];   /* row-major 4 x 4: getFinalTransformation() */
+  double p6[6];                     /* (tx, ty, tz, rx, ry, rz) the loop ended at */
+  double score, trans_probability;  /* the last evaluated score and score / n (getTransformationProbability, :170) */
+  int32_t iterations, converged, n_evaluations, reserved;   /* nr_iterations_, converged_, derivative evaluations over the cloud */
+} lvx_ndt_result;
+int lvx_ndt_default_options(lvx_ndt_options* opt);
+/* src = the input cloud (setInputSource); guess16 = row-major initial guess or NULL (identity, as align(output) passes); aligned_xyzi4 (may be NULL) receives the
+ * source under the final transformation = the `output` cloud of align(). */
+int lvx_ndt_align(lvx_ctx* ctx, int n, const float* src_xyzi4, const float* guess16, const lvx_ndt_options* opt, lvx_ndt_result* result, float* aligned_xyzi4);
+/* pcl::Registration::getFitnessScore(max_range) (what src/ndt_omp/apps/align.cpp:30 prints): mean over the source points of the squared distance from the point
+ * under `transform16` to its nearest target point (float L2, exact search), counting distances <= max_range; DBL_MAX when nothing is counted. */
+int lvx_ndt_fitness(lvx_ctx* ctx, int n_src, const float* src_xyzi4, const float* transform16, int n_tgt, const float* tgt_xyzi4, double max_range, double* fitness);
 
 /* surfel map extraction ------------------------------------------------------------------------------*/
 /* SurfelAssociation::setSurfelMap + checkPlaneType (src/lvi_exc/src/core/surfel_association.cpp:50-86, 246-266) over the leaves of the last

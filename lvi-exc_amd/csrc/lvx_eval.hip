@@ -2077,7 +2077,13 @@ int ensure_layout(lvx_ctx* ctx) {
   int lm_wl = 1;
   for (int l = 0; l < L; ++l) if (lm_last[l] >= 0) {
     int lo = 1 << 30, hi = -1; span_pos(lm_first[l], lm_last[l], lo, hi);
-    if (hi >= lo) { if (!(locks & LVX_LOCK_LANDMARKS)) bw = std::max(bw, hi - lo); lm_p0[l] = lo; lm_wl = std::max(lm_wl, hi - lo + 1); }
+    if (hi >= lo) {
+      lm_p0[l] = lo; lm_wl = std::max(lm_wl, hi - lo + 1);
+      if (!(locks & LVX_LOCK_LANDMARKS)) {   // a free landmark: the in-place elimination writes fill across its WHOLE reach, which may exceed every single block's
+        bw = std::max(bw, hi - lo);
+        if (hi - lo > bw_near) std::fill(colfull.begin() + lo, colfull.begin() + hi + 1, (uint8_t)1);
+      }
+    }
   }
   ctx->lm_wl = lm_wl; ctx->lm_ls = lm_wl + ctx->nbd_ext + 2;
   {   // groups for the landmark elimination: landmarks of one reference frame start at the same band position and reach the same knots, so their rank-1

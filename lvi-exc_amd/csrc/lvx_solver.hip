@@ -779,6 +779,8 @@ static int solver_alloc(lvx_ctx* c, SolveWork& w) {
   }
   c->p_Hs = w.Hs;
   if ((rc = dev_alloc(c, c->d_scal, 64 * 8))) return rc;
+  // sums, error words and (deterministic mode) tickets start from zero: the IterationZero projection of a constrained solve takes a ticket before the first solve_local cleared them
+  LVX_HIP(c, hipMemsetAsync(c->d_scal.p, 0, 64 * 8, c->stream));
   if ((rc = dev_alloc(c, c->d_state_try, (size_t)lvx_state_size(c) * 8))) return rc;
   w.L = (double*)c->d_L.p; w.Z = (double*)c->d_Y.p; w.S = (double*)c->d_S.p; w.rhs = w.S + nbd * nbd; w.delta = (double*)c->d_delta.p;
   w.diag = (double*)c->d_diag.p; w.scale = w.diag + nall; w.lmd = w.scale + nall;

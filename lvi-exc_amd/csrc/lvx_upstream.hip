@@ -13,6 +13,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <limits>
+#include <vector>
 
 #include "lvx_ctx.h"
 #include "lvx_stdsort.h"
@@ -852,16 +854,74 @@ __global__ __launch_bounds__(256) void k_vx_leaf(const float4* __restrict__ p, c
     }
   }
 }
-// NDT derivatives: one thread per point (float arithmetic in the reference's order of operations), 43 doubles reduced per workgroup
+// ------------------------------------------------------------------------------------------------------------------------
+// NDT registration (pclomp::NormalDistributionsTransform, src/ndt_omp/include/pclomp/ndt_omp_impl.hpp): derivative evaluation, Hessian-only pass, fitness.
+// ------------------------------------------------------------------------------------------------------------------------
+// Displacement nb of a neighbourhood of NB cells, in the order the reference pushes them: NB <= 7 = {0, +x, -x, +y, -y, +z, -z} (voxel_grid_covariance_omp_impl.hpp:427-434,
+// NB = 1 its first entry :440-446); NB = 26 = pcl::getAllNeighborCellIndices() (:411-419; pcl/filters/voxel_grid.h: (i, j, -1) for i, j = -1..1, (i, -1, 0), (-1, 0, 0),
+// then their negatives).  Fully unrolled callers fold this into constants.
+template <int NB> __device__ __forceinline__ int ndt_disp(int nb, int a) {
+  if (NB <= 7) { const int d[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}}; return d[nb][a]; }
+  const int h = nb % 13, sg = nb < 13 ? 1 : -1;
+  const int v = h < 9 ? (a == 0 ? h / 3 - 1 : (a == 1 ? h % 3 - 1 : -1)) : (h < 12 ? (a == 0 ? h - 10 : (a == 1 ? -1 : 0)) : (a == 0 ? -1 : 0));
+  return sg * v;
+}
+// pcl::transformPointCloud, dense cloud (PCL <= 1.8 scalar form): M(0..2, 0..2) * p + M(0..2, 3), summed left to right in float (the file is built without contraction)
+struct NdtMat { float m[12]; };
+__device__ __forceinline__ float4 ndt_xf(const NdtMat& M, const float4 p) {
+  float4 o;
+  o.x = ((M.m[0] * p.x + M.m[1] * p.y) + M.m[2] * p.z) + M.m[3];
+  o.y = ((M.m[4] * p.x + M.m[5] * p.y) + M.m[6] * p.z) + M.m[7];
+  o.z = ((M.m[8] * p.x + M.m[9] * p.y) + M.m[10] * p.z) + M.m[11];
+  o.w = p.w;
+  return o;
+}
+__global__ __launch_bounds__(256) void k_ndt_transform(const float4* src, int n, NdtMat M, float4* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = ndt_xf(M, src[i]);
+}
+// Sum of NV doubles per thread over the whole launch, in a FIXED order (run-to-run identical): lanes by butterfly, the four wavefronts in order, workgroups in
+// index order by the last workgroup to arrive (ticket).  part: [gridDim.x][NV]; ticket: one int, zero before the launch and left zero.
+template <int NV>
+__device__ __forceinline__ void ndt_block_reduce(double* acc, double* part, int* ticket, double* out) {
+  __shared__ double red[4][NV];
+  __shared__ int last;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int e = 0; e < NV; ++e) {
+    double v = acc[e];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) red[wv][e] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) part[(size_t)blockIdx.x * NV + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1);
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (threadIdx.x < NV) {
+    double v = 0.0;
+    for (unsigned b = 0; b < gridDim.x; ++b) v += __builtin_nontemporal_load(&part[(size_t)b * NV + threadIdx.x]);
+    out[threadIdx.x] = v;
+  }
+  if (threadIdx.x == 0) *ticket = 0;
+}
+// computeDerivatives (:180-285) with updateDerivatives (:484-536) and the float computePointDerivatives (:398-439): one thread per point, float arithmetic in the
+// reference's order of operations, double accumulation.  XF: the transformed point is computed here from the source point (the loop of lvx_ndt_align); otherwise it is
+// read from trn (lvx_ndt_derivatives: the caller transformed the cloud).
 struct NdtConst { float j_ang[8][3]; float h_ang[15][3]; float gd2; double gauss_d1; };
-__global__ __launch_bounds__(256) void k_ndt_derivatives(const float4* src, const float4* trn, int n, float leaf, int min_pts, VxGrid g, const int* grid, const int* leaf_n,
-                                                         const double* mean, const double* icov, NdtConst K, int compute_hessian, double* out43) {
+template <int NB, bool XF>
+__global__ __launch_bounds__(256) void k_ndt_derivatives(const float4* src, const float4* trn, NdtMat M, int n, float leaf, int min_pts, VxGrid g, const int* grid, const int* leaf_n,
+                                                         const double* mean, const double* icov, NdtConst K, int compute_hessian, double* part, int* ticket, double* out43) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   double acc[43];
 #pragma unroll
   for (int e = 0; e < 43; ++e) acc[e] = 0.0;
   if (idx < n) {
-    const float4 xi = src[idx], xt = trn[idx];
+    const float4 xi = src[idx];
+    const float4 xt = XF ? ndt_xf(M, xi) : trn[idx];
     float pg[3][6] = {{1, 0, 0, 0, 0, 0}, {0, 1, 0, 0, 0, 0}, {0, 0, 1, 0, 0, 0}};
     float xj[8];
 #pragma unroll
@@ -880,23 +940,22 @@ __global__ __launch_bounds__(256) void k_ndt_derivatives(const float4* src, cons
     // second-derivative block (i, j), i, j in 3..5: a b c / b d e / c e f
     const int hsel[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
     const int ijk[3] = {(int)floorf(xt.x / leaf), (int)floorf(xt.y / leaf), (int)floorf(xt.z / leaf)};
-    const int disp[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
-    // the seven cell probes in flight, then the seven leaf counts (as in k_vx_lookup: probe by probe the loads queue up one behind the other); cells are still visited
+    // the NB cell probes in flight, then the NB leaf counts (as in k_vx_lookup: probe by probe the loads queue up one behind the other); cells are still visited
     // in the reference's order
-    int lis[7]; bool use[7];
+    int lis[NB]; bool use[NB];
 #pragma unroll
-    for (int nb = 0; nb < 7; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
       bool in = true;
 #pragma unroll
-      for (int a = 0; a < 3; ++a) in = in & (g.min_b[a] - ijk[a] <= disp[nb][a]) & (g.max_b[a] - ijk[a] >= disp[nb][a]);
-      const int key = (ijk[0] + disp[nb][0] - g.min_b[0]) * g.mul[0] + (ijk[1] + disp[nb][1] - g.min_b[1]) * g.mul[1] + (ijk[2] + disp[nb][2] - g.min_b[2]) * g.mul[2];
+      for (int a = 0; a < 3; ++a) in = in & (g.min_b[a] - ijk[a] <= ndt_disp<NB>(nb, a)) & (g.max_b[a] - ijk[a] >= ndt_disp<NB>(nb, a));
+      const int key = (ijk[0] + ndt_disp<NB>(nb, 0) - g.min_b[0]) * g.mul[0] + (ijk[1] + ndt_disp<NB>(nb, 1) - g.min_b[1]) * g.mul[1] + (ijk[2] + ndt_disp<NB>(nb, 2) - g.min_b[2]) * g.mul[2];
       const int l0 = grid[in ? key : 0];
       lis[nb] = in ? l0 : -1;
     }
 #pragma unroll
-    for (int nb = 0; nb < 7; ++nb) { const int cn = leaf_n[lis[nb] >= 0 ? lis[nb] : 0]; use[nb] = lis[nb] >= 0 && cn >= min_pts; }
+    for (int nb = 0; nb < NB; ++nb) { const int cn = leaf_n[lis[nb] >= 0 ? lis[nb] : 0]; use[nb] = lis[nb] >= 0 && cn >= min_pts; }
 #pragma unroll
-    for (int nb = 0; nb < 7; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
       if (!use[nb]) continue;
       const int li = lis[nb];
       const double* mu = mean + 3 * (size_t)li; const double* ic = icov + 9 * (size_t)li;
@@ -932,16 +991,125 @@ __global__ __launch_bounds__(256) void k_ndt_derivatives(const float4* src, cons
       acc[0] += (double)score_inc;
     }
   }
-  __shared__ double red[4][43];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  ndt_block_reduce<43>(acc, part, ticket, out43);
+}
+// computeHessian (:540-609) with updateHessian (:613-644) and the DOUBLE computePointDerivatives (:443-480): run after a More-Thuente search that moved (:927-928).
+// Everything in double; the angular tables are those of the last computeAngleDerivatives (the vector of the last derivative evaluation).
+struct NdtConstD { double j_ang[8][3]; double h_ang[15][3]; double gd1, gd2; };
+template <int NB>
+__global__ __launch_bounds__(256) void k_ndt_hessian(const float4* src, NdtMat M, int n, float leaf, int min_pts, VxGrid g, const int* grid, const int* leaf_n, const double* mean,
+                                                     const double* icov, NdtConstD K, double* part, int* ticket, double* out36) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  double acc[36];
 #pragma unroll
-  for (int e = 0; e < 43; ++e) {
-    double v = acc[e];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if (lane == 0) red[wv][e] = v;
+  for (int e = 0; e < 36; ++e) acc[e] = 0.0;
+  if (idx < n) {
+    const float4 xi = src[idx];
+    const float4 xt = ndt_xf(M, xi);
+    const double x[3] = {(double)xi.x, (double)xi.y, (double)xi.z};
+    auto dot3 = [](const double* a, const double* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; };
+    double pg[3][6] = {{1, 0, 0, 0, 0, 0}, {0, 1, 0, 0, 0, 0}, {0, 0, 1, 0, 0, 0}};
+    pg[1][3] = dot3(x, K.j_ang[0]); pg[2][3] = dot3(x, K.j_ang[1]); pg[0][4] = dot3(x, K.j_ang[2]); pg[1][4] = dot3(x, K.j_ang[3]); pg[2][4] = dot3(x, K.j_ang[4]);
+    pg[0][5] = dot3(x, K.j_ang[5]); pg[1][5] = dot3(x, K.j_ang[6]); pg[2][5] = dot3(x, K.j_ang[7]);
+    double hv[6][3];
+    hv[0][0] = 0.0; hv[0][1] = dot3(x, K.h_ang[0]); hv[0][2] = dot3(x, K.h_ang[1]);
+    hv[1][0] = 0.0; hv[1][1] = dot3(x, K.h_ang[2]); hv[1][2] = dot3(x, K.h_ang[3]);
+    hv[2][0] = 0.0; hv[2][1] = dot3(x, K.h_ang[4]); hv[2][2] = dot3(x, K.h_ang[5]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { hv[3][r] = dot3(x, K.h_ang[6 + r]); hv[4][r] = dot3(x, K.h_ang[9 + r]); hv[5][r] = dot3(x, K.h_ang[12 + r]); }
+    const int hsel[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+    const int ijk[3] = {(int)floorf(xt.x / leaf), (int)floorf(xt.y / leaf), (int)floorf(xt.z / leaf)};
+    int lis[NB]; bool use[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      bool in = true;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) in = in & (g.min_b[a] - ijk[a] <= ndt_disp<NB>(nb, a)) & (g.max_b[a] - ijk[a] >= ndt_disp<NB>(nb, a));
+      const int key = (ijk[0] + ndt_disp<NB>(nb, 0) - g.min_b[0]) * g.mul[0] + (ijk[1] + ndt_disp<NB>(nb, 1) - g.min_b[1]) * g.mul[1] + (ijk[2] + ndt_disp<NB>(nb, 2) - g.min_b[2]) * g.mul[2];
+      const int l0 = grid[in ? key : 0];
+      lis[nb] = in ? l0 : -1;
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { const int cn = leaf_n[lis[nb] >= 0 ? lis[nb] : 0]; use[nb] = lis[nb] >= 0 && cn >= min_pts; }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      if (!use[nb]) continue;
+      const int li = lis[nb];
+      const double* mu = mean + 3 * (size_t)li; const double* ci = icov + 9 * (size_t)li;
+      const double xd[3] = {(double)xt.x - mu[0], (double)xt.y - mu[1], (double)xt.z - mu[2]};
+      double cxv[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) cxv[r] = (ci[3 * r] * xd[0] + ci[3 * r + 1] * xd[1]) + ci[3 * r + 2] * xd[2];
+      double e_x = K.gd2 * exp(-K.gd2 * dot3(xd, cxv) / 2);                                         // :621
+      if (e_x > 1 || e_x < 0 || e_x != e_x) continue;                                               // :624
+      e_x *= K.gd1;                                                                                 // :628
+      double cpg[6][3], xg[6];   // c_inv * point_gradient.col(j), x_trans . (that)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) cpg[j][r] = (ci[3 * r] * pg[0][j] + ci[3 * r + 1] * pg[1][j]) + ci[3 * r + 2] * pg[2][j];
+        xg[j] = dot3(xd, cpg[j]);
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          double xh = 0.0;   // x_trans . (c_inv * point_hessian.block<3, 1>(3 i, j))
+          if (i >= 3 && j >= 3) {
+            const double* h3 = hv[hsel[i - 3][j - 3]];
+            double cph[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) cph[r] = (ci[3 * r] * h3[0] + ci[3 * r + 1] * h3[1]) + ci[3 * r + 2] * h3[2];
+            xh = dot3(xd, cph);
+          }
+          const double pgj[3] = {pg[0][j], pg[1][j], pg[2][j]};
+          acc[6 * i + j] += e_x * (-K.gd2 * xg[i] * xg[j] + xh + dot3(pgj, cpg[i]));                 // :638-640
+        }
+    }
   }
-  __syncthreads();
-  if (threadIdx.x < 43) { const double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]; if (v != 0.0) atomicAdd(&out43[threadIdx.x], v); }
+  ndt_block_reduce<36>(acc, part, ticket, out36);
+}
+// pcl::Registration::getFitnessScore (align.cpp:30): squared distance of every transformed source point to its nearest target point — float differences, squares summed in
+// order (the L2 of the reference's exact kd-tree search; the minimum over all targets is that search's result).  Targets are split over blockIdx.y and staged through LDS;
+// the minimum of non-negative floats is the minimum of their bit patterns (atomicMin on unsigned; best[] starts at FLT_MAX).  The host sums best[] in index order.
+__global__ __launch_bounds__(256) void k_ndt_fitness(const float4* src, int n_src, NdtMat M, const float4* tgt, int n_tgt, int tgt_per_y, unsigned* best) {
+  __shared__ float4 tile[1024];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const float4 p = ndt_xf(M, src[i < n_src ? i : 0]);
+  const int t0 = blockIdx.y * tgt_per_y, t1 = min(n_tgt, t0 + tgt_per_y);
+  float b = 3.402823466e+38f;
+  for (int c0 = t0; c0 < t1; c0 += 1024) {
+    const int m = min(1024, t1 - c0);
+    __syncthreads();
+    for (int k = threadIdx.x; k < m; k += 256) tile[k] = tgt[c0 + k];
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < m; ++k) {
+      const float4 q = tile[k];
+      const float d0 = p.x - q.x, d1 = p.y - q.y, d2 = p.z - q.z;
+      const float d = (d0 * d0 + d1 * d1) + d2 * d2;
+      b = d < b ? d : b;
+    }
+  }
+  if (i < n_src && t1 > t0) atomicMin(&best[i], __float_as_uint(b));
+}
+// getNeighborhoodAtPoint(relative_coordinates, ...) (:378-408): one thread per (query, displacement); ids[q][r] = leaf or -1
+__global__ __launch_bounds__(256) void k_vx_lookup_rel(const float4* q, int nq, float leaf, int min_pts, VxGrid g, const int* grid, const int* leaf_n, int n_rel, const int* rel3, int* ids) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long long)nq * n_rel) return;
+  const int i = (int)(e / n_rel), r = (int)(e % n_rel);
+  const float4 p = q[i];
+  const int ijk[3] = {(int)floorf(p.x / leaf), (int)floorf(p.y / leaf), (int)floorf(p.z / leaf)};   // :383-385
+  const int d[3] = {rel3[3 * r], rel3[3 * r + 1], rel3[3 * r + 2]};
+  bool ok = true;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) ok = ok & (g.min_b[a] - ijk[a] <= d[a]) & (g.max_b[a] - ijk[a] >= d[a]);   // :386-387, 396
+  int id = -1;
+  if (ok) {
+    const int li = grid[(ijk[0] + d[0] - g.min_b[0]) * g.mul[0] + (ijk[1] + d[1] - g.min_b[1]) * g.mul[1] + (ijk[2] + d[2] - g.min_b[2]) * g.mul[2]];   // :398
+    if (li >= 0 && leaf_n[li] >= min_pts) id = li;                                                                                                       // :399
+  }
+  ids[e] = id;
 }
 // surfel map extraction: one WAVEFRONT per leaf (tens to hundreds of points each).  Round 3 had one thread per leaf walking its points three times with a dependent
 // id -> point gather per point (1.5 ms for the 410 k-point map cloud, more than half of lvx_data_association); now the 64 lanes stride over the leaf's points, the inlier
@@ -1575,7 +1743,7 @@ static int voxel_enqueue(lvx_ctx* c, const float4* d_pts, int n, float leaf, int
   int* ghist = own_sort ? (int*)V.tmp.p : nullptr;
   unsigned* tcnt = own_sort ? (unsigned*)V.tmp.p + 4 * 256 : nullptr;
   hipLaunchKernelGGL(k_vx_extent, dim3((unsigned)std::min(std::max(n / 4096, 64), 256)), dim3(256), 0, st, d_pts, n, d_mm, leaf, (long long)V.cells_cap, d_info, ghist);
-  const unsigned invalid = (1u << V.sort_bits) - 1u;
+  const unsigned invalid = (unsigned)((1ull << V.sort_bits) - 1ull);   // sort_bits <= 31 (cells_cap is clamped), the 64-bit shift keeps even 32 defined
   unsigned* k_first = (own_sort && passes % 2 == 0) ? k_out : k_in;   // an even number of passes starts in the second buffer
   hipLaunchKernelGGL(k_vx_keys, dim3((unsigned)std::max((n + 1023) / 1024, 512)), dim3(256), 0, st, d_pts, n, (const VxInfo*)d_info, invalid, k_first, v_in, (int*)V.cells.p, lbs, n_tiles,
                      ghist, tcnt, passes * sort_tiles * 256, passes);
@@ -1611,7 +1779,7 @@ static int voxel_build_device(lvx_ctx* c, const float4* d_pts, int n, float leaf
   if (n == 0) return LVX_OK;
   if (!V.h_info) LVX_HIP(c, hipHostMalloc(&V.h_info, sizeof(VxInfo), hipHostMallocDefault));
   if (V.cells_cap < (1 << 22)) V.cells_cap = 1 << 22;   // 4 M cells (16 MB): a 100 m x 100 m x 100 m map at 0.5 m; grown on demand (vox_info)
-  int bits = 1; while ((1ll << bits) - 1 < V.cells_cap + 1 && bits < 32) ++bits;   // keys < cells <= capacity, the invalid key = 2^bits - 1 above them
+  int bits = 1; while ((1ll << bits) - 1 < (long long)V.cells_cap && bits < 31) ++bits;   // keys < cells <= capacity <= 2^31 - 1, the invalid key = 2^bits - 1 >= capacity above them
   V.sort_bits = bits;
   if (!V.misc.p) {   // extents in their start state (k_vx_extent's last workgroup restores it after every build)
     if ((rc = dev_alloc(c, V.misc, 64 + sizeof(VxInfo)))) return rc;
@@ -1667,7 +1835,7 @@ static int vox_info(lvx_ctx* c) {
     if (inf.overflow == 2) return fail(c, LVX_E_ARG, "Leaf size is too small for the input dataset. Integer indices would overflow.");   // :80-85
     if (inf.overflow == 1) {
       if (round > 0) return fail(c, LVX_E_ALLOC, "voxel cell table could not be grown");
-      V.cells_cap = inf.cells + inf.cells / 4;
+      V.cells_cap = std::min<long long>(inf.cells + inf.cells / 4, 2147483647LL);   // cells <= 2^31 - 1 (overflow 2 above): keys <= 2^31 - 2 stay below the invalid key of a 31-bit sort
       const int rc = voxel_build_device(c, (const float4*)V.d_pts, V.n_points, V.leaf, V.min_pts, V.eig_mult);
       if (rc) return rc;
       continue;
@@ -2138,23 +2306,18 @@ int lvx_get_scans_in_map(lvx_ctx* c, float* xyzi4) {
   return LVX_OK;
 }
 
-int lvx_ndt_derivatives(lvx_ctx* c, int n, const float* input_xyzi4, const float* trans_xyzi4, const double* p6, double outlier_ratio, int compute_hessian,
-                        double* score, double* gradient6, double* hessian36) {
-  if (!c || n < 0 || !p6 || !score || !gradient6 || (compute_hessian && !hessian36) || (n > 0 && (!input_xyzi4 || !trans_xyzi4))) return LVX_E_ARG;
-  LVX_HIP(c, hipSetDevice(c->device));
-  { const int rc0 = vox_info(c); if (rc0) return rc0; }
-  const lvx_ctx::Voxels& V = c->vox;
-  *score = 0.0;
-  for (int j = 0; j < 6; ++j) gradient6[j] = 0.0;
-  if (hessian36) for (int e = 0; e < 36; ++e) hessian36[e] = 0.0;
-  if (n == 0 || V.n_leaves == 0) return LVX_OK;
-  // Gaussian fitting parameters (eq. 6.8 [Magnusson 2009]; ndt_omp_impl.hpp:63-67), angular derivative tables (:289-383)
-  NdtConst K;
-  const double res = (double)V.leaf;
+}  // extern "C"
+// ---- NDT registration: host side ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct NdtTables { NdtConst f; NdtConstD d; };
+// Gaussian fitting parameters (eq. 6.8 [Magnusson 2009]; ndt_omp_impl.hpp:86-93) and computeAngleDerivatives (:289-394) at the transform vector p6
+NdtTables ndt_tables(const double* p6, double res, double outlier_ratio) {
+  NdtTables T;
   const double gauss_c1 = 10.0 * (1 - outlier_ratio), gauss_c2 = outlier_ratio / std::pow(res, 3);
   const double gauss_d3 = -std::log(gauss_c2);
-  K.gauss_d1 = -std::log(gauss_c1 + gauss_c2) - gauss_d3;
-  K.gd2 = (float)(-2 * std::log((-std::log(gauss_c1 * std::exp(-0.5) + gauss_c2) - gauss_d3) / K.gauss_d1));
+  const double gauss_d1 = -std::log(gauss_c1 + gauss_c2) - gauss_d3;
+  const double gauss_d2 = -2 * std::log((-std::log(gauss_c1 * std::exp(-0.5) + gauss_c2) - gauss_d3) / gauss_d1);
+  T.f.gauss_d1 = gauss_d1; T.f.gd2 = (float)gauss_d2; T.d.gd1 = gauss_d1; T.d.gd2 = gauss_d2;
   double cx, cy, cz, sx, sy, sz;
   if (std::fabs(p6[3]) < 10e-5) { cx = 1.0; sx = 0.0; } else { cx = std::cos(p6[3]); sx = std::sin(p6[3]); }
   if (std::fabs(p6[4]) < 10e-5) { cy = 1.0; sy = 0.0; } else { cy = std::cos(p6[4]); sy = std::sin(p6[4]); }
@@ -2165,26 +2328,352 @@ int lvx_ndt_derivatives(lvx_ctx* c, int n, const float* input_xyzi4, const float
                             {sx * cy * cz, -sx * cy * sz, sx * sy}, {-sx * cz - cx * sy * sz, sx * sz - cx * sy * cz, 0}, {cx * cz - sx * sy * sz, -sx * sy * cz - cx * sz, 0}, {-cy * cz, cy * sz, sy},
                             {-sx * sy * cz, sx * sy * sz, sx * cy}, {cx * sy * cz, -cx * sy * sz, -cx * cy}, {sy * sz, sy * cz, 0}, {-sx * cy * sz, -sx * cy * cz, 0}, {cx * cy * sz, cx * cy * cz, 0},
                             {-cy * cz, cy * sz, 0}, {-cx * sz - sx * sy * cz, -cx * cz + sx * sy * sz, 0}, {-sx * sz + cx * sy * cz, -cx * sy * sz - sx * cz, 0}};
-  for (int r = 0; r < 8; ++r) for (int k = 0; k < 3; ++k) K.j_ang[r][k] = (float)ja[r][k];
-  for (int r = 0; r < 15; ++r) for (int k = 0; k < 3; ++k) K.h_ang[r][k] = (float)ha[r][k];
+  for (int r = 0; r < 8; ++r) for (int k = 0; k < 3; ++k) { T.f.j_ang[r][k] = (float)ja[r][k]; T.d.j_ang[r][k] = ja[r][k]; }
+  for (int r = 0; r < 15; ++r) for (int k = 0; k < 3; ++k) { T.f.h_ang[r][k] = (float)ha[r][k]; T.d.h_ang[r][k] = ha[r][k]; }
+  return T;
+}
+// Eigen::AngleAxis<float>::toRotationMatrix about a coordinate axis, and the float transform of a 6-vector:
+// (Translation<float,3>(p0, p1, p2) * AngleAxis<float>(p3, X) * AngleAxis<float>(p4, Y) * AngleAxis<float>(p5, Z)).matrix()   (ndt_omp_impl.hpp:826-829)
+void ndt_axis_rot(float angle, int axis, float R[3][3]) {
+  const float s = std::sin(angle), c = std::cos(angle);
+  float a[3] = {0, 0, 0}; a[axis] = 1.0f;
+  const float sa[3] = {s * a[0], s * a[1], s * a[2]}, c1[3] = {(1.0f - c) * a[0], (1.0f - c) * a[1], (1.0f - c) * a[2]};
+  float t;
+  t = c1[0] * a[1]; R[0][1] = t - sa[2]; R[1][0] = t + sa[2];
+  t = c1[0] * a[2]; R[0][2] = t + sa[1]; R[2][0] = t - sa[1];
+  t = c1[1] * a[2]; R[1][2] = t - sa[0]; R[2][1] = t + sa[0];
+  for (int i = 0; i < 3; ++i) R[i][i] = c1[i] * a[i] + c;
+}
+void ndt_matrix(const double* p6, float* M16) {
+  float Rx[3][3], Ry[3][3], Rz[3][3], A[3][3], R[3][3];
+  ndt_axis_rot((float)p6[3], 0, Rx); ndt_axis_rot((float)p6[4], 1, Ry); ndt_axis_rot((float)p6[5], 2, Rz);
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A[i][j] = (Rx[i][0] * Ry[0][j] + Rx[i][1] * Ry[1][j]) + Rx[i][2] * Ry[2][j];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[i][j] = (A[i][0] * Rz[0][j] + A[i][1] * Rz[1][j]) + A[i][2] * Rz[2][j];
+  for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) M16[4 * i + j] = R[i][j]; M16[4 * i + 3] = (float)p6[i]; }
+  M16[12] = M16[13] = M16[14] = 0.0f; M16[15] = 1.0f;
+}
+// Matrix3f::eulerAngles(0, 1, 2) of the guess (ndt_omp_impl.hpp:109; Eigen 3.3's algorithm): R = Rx(e0) Ry(e1) Rz(e2)
+void ndt_euler012(const float* M16, float* e3) {
+  auto m = [&](int r, int c) { return M16[4 * r + c]; };
+  const float pi = (float)M_PI;
+  float r0 = std::atan2(m(1, 2), m(2, 2));
+  const float c2 = std::sqrt(m(0, 0) * m(0, 0) + m(0, 1) * m(0, 1));
+  float r1;
+  if (r0 > 0.0f) { r0 -= pi; r1 = std::atan2(-m(0, 2), -c2); } else r1 = std::atan2(-m(0, 2), c2);
+  const float s1 = std::sin(r0), c1 = std::cos(r0);
+  const float r2 = std::atan2(s1 * m(2, 0) - c1 * m(1, 0), c1 * m(1, 1) - s1 * m(2, 1));
+  e3[0] = -r0; e3[1] = -r1; e3[2] = -r2;
+}
+NdtMat ndt_mat12(const float* M16) { NdtMat M; for (int i = 0; i < 12; ++i) M.m[i] = M16[i]; return M; }
+// JacobiSVD<Matrix<double, 6, 6>>(H, FullU | FullV).solve(b) (:127-129): minimum-norm least-squares solution.  One-sided Jacobi (Hestenes): H V = U S with
+// orthogonal columns; singular values below eps * 6 * max are treated as zero (Eigen's default threshold).
+void ndt_svd_solve(const double* H36, const double* b6, double* x6) {
+  double A[6][6], V[6][6];
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) { A[i][j] = H36[6 * i + j]; V[i][j] = i == j ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < 5; ++p) for (int q = p + 1; q < 6; ++q) {
+      double al = 0, be = 0, ga = 0;
+      for (int k = 0; k < 6; ++k) { al += A[k][p] * A[k][p]; be += A[k][q] * A[k][q]; ga += A[k][p] * A[k][q]; }
+      if (ga == 0.0 || al == 0.0 || be == 0.0) continue;
+      off = std::max(off, std::fabs(ga) / std::sqrt(al * be));
+      const double zeta = (be - al) / (2.0 * ga);
+      const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+      const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
+      for (int k = 0; k < 6; ++k) { const double ap = A[k][p], aq = A[k][q]; A[k][p] = cs * ap - sn * aq; A[k][q] = sn * ap + cs * aq; }
+      for (int k = 0; k < 6; ++k) { const double vp = V[k][p], vq = V[k][q]; V[k][p] = cs * vp - sn * vq; V[k][q] = sn * vp + cs * vq; }
+    }
+    if (off < 1e-15) break;
+  }
+  double sv[6], smax = 0.0;
+  for (int j = 0; j < 6; ++j) { double s2 = 0; for (int k = 0; k < 6; ++k) s2 += A[k][j] * A[k][j]; sv[j] = std::sqrt(s2); smax = std::max(smax, sv[j]); }
+  const double thr = smax * 6.0 * 2.220446049250313e-16;
+  for (int i = 0; i < 6; ++i) x6[i] = 0.0;
+  for (int j = 0; j < 6; ++j) {
+    if (!(sv[j] > thr)) continue;
+    double ub = 0; for (int k = 0; k < 6; ++k) ub += A[k][j] * b6[k];   // (U^T b)_j * s_j
+    const double w = ub / (sv[j] * sv[j]);
+    for (int i = 0; i < 6; ++i) x6[i] += V[i][j] * w;
+  }
+}
+struct NdtDev {   // device work area of one registration: the partial sums of the reductions, their ticket, the result; d_up[2] = source cloud
+  double* part; int* ticket; double* out; int blocks;
+};
+int ndt_workspace(lvx_ctx* c, int n, NdtDev* W) {
+  const int blocks = std::max(1, (n + 255) / 256);
+  int rc;
+  if ((rc = dev_alloc(c, c->d_up[6], ((size_t)blocks * 43 + 64) * 8))) return rc;
+  W->blocks = blocks; W->out = (double*)c->d_up[6].p; W->ticket = (int*)(W->out + 48); W->part = W->out + 64;
+  LVX_HIP(c, hipMemsetAsync(W->out, 0, 64 * 8, c->stream));
+  return LVX_OK;
+}
+struct NdtGridArgs { VxGrid g; const int* cells; const int* leaf_n; const double* mean; const double* icov; float leaf; int min_pts; };
+NdtGridArgs ndt_grid(const lvx_ctx* c) {
+  const lvx_ctx::Voxels& V = c->vox;
+  NdtGridArgs G; std::memcpy(&G.g, &V.grid, sizeof(G.g));
+  const size_t nl = (size_t)V.cap;   // leaf arrays are strided by the capacity
+  G.cells = (const int*)V.cells.p; G.leaf_n = (const int*)V.leaf_i.p + nl; G.mean = (const double*)V.leaf_d.p; G.icov = G.mean + 12 * nl; G.leaf = V.leaf; G.min_pts = V.min_pts;
+  return G;
+}
+// one computeDerivatives on the device: score, gradient, Hessian at p6 (transform M16 applied in the kernel, or the caller's transformed cloud trn_d)
+int ndt_eval(lvx_ctx* c, const NdtDev& W, int n, const float4* src_d, const float4* trn_d, const float* M16, const double* p6, double outlier_ratio, int search, int compute_hessian, double* h43) {
+  const NdtGridArgs G = ndt_grid(c);
+  const NdtTables T = ndt_tables(p6, (double)G.leaf, outlier_ratio);
+  const NdtMat M = ndt_mat12(M16);
+  const dim3 grid((unsigned)W.blocks), blk(256);
+  { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
+#define LVX_NDT_LAUNCH(NB, XF) hipLaunchKernelGGL((k_ndt_derivatives<NB, XF>), grid, blk, 0, c->stream, src_d, trn_d, M, n, G.leaf, G.min_pts, G.g, G.cells, G.leaf_n, G.mean, G.icov, T.f, compute_hessian, W.part, W.ticket, W.out)
+    if (trn_d) { if (search == 1) LVX_NDT_LAUNCH(1, false); else if (search == 26) LVX_NDT_LAUNCH(26, false); else LVX_NDT_LAUNCH(7, false); }
+    else { if (search == 1) LVX_NDT_LAUNCH(1, true); else if (search == 26) LVX_NDT_LAUNCH(26, true); else LVX_NDT_LAUNCH(7, true); }
+#undef LVX_NDT_LAUNCH
+  }
+  LVX_HIP(c, hipGetLastError());
+  LVX_HIP(c, hipMemcpyAsync(h43, W.out, 43 * 8, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  return LVX_OK;
+}
+int ndt_hessian(lvx_ctx* c, const NdtDev& W, int n, const float4* src_d, const float* M16, const double* p6, double outlier_ratio, int search, double* h36) {
+  const NdtGridArgs G = ndt_grid(c);
+  const NdtTables T = ndt_tables(p6, (double)G.leaf, outlier_ratio);
+  const NdtMat M = ndt_mat12(M16);
+  const dim3 grid((unsigned)W.blocks), blk(256);
+  { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
+#define LVX_NDT_LAUNCH(NB) hipLaunchKernelGGL((k_ndt_hessian<NB>), grid, blk, 0, c->stream, src_d, M, n, G.leaf, G.min_pts, G.g, G.cells, G.leaf_n, G.mean, G.icov, T.d, W.part, W.ticket, W.out)
+    if (search == 1) LVX_NDT_LAUNCH(1); else if (search == 26) LVX_NDT_LAUNCH(26); else LVX_NDT_LAUNCH(7);
+#undef LVX_NDT_LAUNCH
+  }
+  LVX_HIP(c, hipGetLastError());
+  LVX_HIP(c, hipMemcpyAsync(h36, W.out, 36 * 8, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  return LVX_OK;
+}
+// updateIntervalMT (:648-685)
+bool ndt_update_interval(double& a_l, double& f_l, double& g_l, double& a_u, double& f_u, double& g_u, double a_t, double f_t, double g_t) {
+  if (f_t > f_l) { a_u = a_t; f_u = f_t; g_u = g_t; return false; }
+  if (g_t * (a_l - a_t) > 0) { a_l = a_t; f_l = f_t; g_l = g_t; return false; }
+  if (g_t * (a_l - a_t) < 0) { a_u = a_l; f_u = f_l; g_u = g_l; a_l = a_t; f_l = f_t; g_l = g_t; return false; }
+  return true;
+}
+// trialValueSelectionMT (:689-768)
+double ndt_trial_value(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u, double a_t, double f_t, double g_t) {
+  if (f_t > f_l) {
+    const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = std::sqrt(z * z - g_t * g_l);
+    const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    const double a_q = a_l - 0.5 * (a_l - a_t) * g_l / (g_l - (f_l - f_t) / (a_l - a_t));
+    return std::fabs(a_c - a_l) < std::fabs(a_q - a_l) ? a_c : 0.5 * (a_q + a_c);
+  }
+  if (g_t * g_l < 0) {
+    const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = std::sqrt(z * z - g_t * g_l);
+    const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+    return std::fabs(a_c - a_t) >= std::fabs(a_s - a_t) ? a_c : a_s;
+  }
+  if (std::fabs(g_t) <= std::fabs(g_l)) {
+    const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = std::sqrt(z * z - g_t * g_l);
+    const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+    const double a_next = std::fabs(a_c - a_t) < std::fabs(a_s - a_t) ? a_c : a_s;
+    return a_t > a_l ? std::min(a_t + 0.66 * (a_u - a_t), a_next) : std::max(a_t + 0.66 * (a_u - a_t), a_next);
+  }
+  const double z = 3 * (f_t - f_u) / (a_t - a_u) - g_t - g_u, w = std::sqrt(z * z - g_t * g_u);
+  return a_u + (a_t - a_u) * (w - g_u - z) / (g_t - g_u + 2 * w);
+}
+struct NdtState { double score, grad[6], hess[36]; float final[16]; int mt_iterations, n_eval; };
+double dot6(const double* a, const double* b) { double s = 0; for (int i = 0; i < 6; ++i) s += a[i] * b[i]; return s; }
+// computeStepLengthMT (:772-931); returns the step length through *a_out
+int ndt_step_length(lvx_ctx* c, const NdtDev& W, int n, const float4* src_d, const lvx_ndt_options& o, const double* x, double* step_dir, double step_init, double step_max, double step_min,
+                    NdtState& st, double* a_out) {
+  const double phi_0 = -st.score;
+  double d_phi_0 = -dot6(st.grad, step_dir);
+  st.mt_iterations = 0;
+  if (d_phi_0 >= 0) {
+    if (d_phi_0 == 0) { *a_out = 0; return LVX_OK; }
+    d_phi_0 *= -1;
+    for (int i = 0; i < 6; ++i) step_dir[i] *= -1;
+  }
+  const int max_step_iterations = 10;
+  int step_iterations = 0;
+  const double mu = 1.e-4, nu = 0.9;
+  double a_l = 0, a_u = 0;
+  double f_l = phi_0 - phi_0 - mu * d_phi_0 * a_l, g_l = d_phi_0 - mu * d_phi_0;   // auxilaryFunction_PsiMT / _dPsiMT (ndt_omp.h:430-446)
+  double f_u = phi_0 - phi_0 - mu * d_phi_0 * a_u, g_u = d_phi_0 - mu * d_phi_0;
+  bool interval_converged = (step_max - step_min) < 0, open_interval = true;
+  double a_t = step_init;
+  a_t = std::min(a_t, step_max);
+  a_t = std::max(a_t, step_min);
+  double x_t[6], h43[43];
+  for (int i = 0; i < 6; ++i) x_t[i] = x[i] + step_dir[i] * a_t;
+  ndt_matrix(x_t, st.final);
+  int rc;
+  if ((rc = ndt_eval(c, W, n, src_d, nullptr, st.final, x_t, o.outlier_ratio, o.search, 1, h43))) return rc;
+  ++st.n_eval;
+  st.score = h43[0]; std::memcpy(st.grad, h43 + 1, 48); std::memcpy(st.hess, h43 + 7, 288);
+  double phi_t = -st.score, d_phi_t = -dot6(st.grad, step_dir);
+  double psi_t = phi_t - phi_0 - mu * d_phi_0 * a_t, d_psi_t = d_phi_t - mu * d_phi_0;
+  while (!interval_converged && step_iterations < max_step_iterations && !(psi_t <= 0 && d_phi_t <= -nu * d_phi_0)) {
+    a_t = open_interval ? ndt_trial_value(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t) : ndt_trial_value(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
+    a_t = std::min(a_t, step_max);
+    a_t = std::max(a_t, step_min);
+    for (int i = 0; i < 6; ++i) x_t[i] = x[i] + step_dir[i] * a_t;
+    ndt_matrix(x_t, st.final);
+    if ((rc = ndt_eval(c, W, n, src_d, nullptr, st.final, x_t, o.outlier_ratio, o.search, 0, h43))) return rc;   // score and gradient only; the Hessian comes back zero (:187)
+    ++st.n_eval;
+    st.score = h43[0]; std::memcpy(st.grad, h43 + 1, 48); std::memcpy(st.hess, h43 + 7, 288);
+    phi_t = -st.score; d_phi_t = -dot6(st.grad, step_dir);
+    psi_t = phi_t - phi_0 - mu * d_phi_0 * a_t; d_psi_t = d_phi_t - mu * d_phi_0;
+    if (open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
+      open_interval = false;
+      f_l = f_l + phi_0 - mu * d_phi_0 * a_l; g_l = g_l + mu * d_phi_0;
+      f_u = f_u + phi_0 - mu * d_phi_0 * a_u; g_u = g_u + mu * d_phi_0;
+    }
+    interval_converged = open_interval ? ndt_update_interval(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t) : ndt_update_interval(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
+    step_iterations++;
+  }
+  if (step_iterations) { if ((rc = ndt_hessian(c, W, n, src_d, st.final, x_t, o.outlier_ratio, o.search, st.hess))) return rc; }   // :927-928
+  st.mt_iterations = step_iterations;
+  *a_out = a_t;
+  return LVX_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int lvx_ndt_default_options(lvx_ndt_options* o) {
+  if (!o) return LVX_E_ARG;
+  o->step_size = 0.1; o->outlier_ratio = 0.55; o->transformation_epsilon = 0.1; o->max_iterations = 35; o->search = 7;   // ndt_omp_impl.hpp:46-76
+  return LVX_OK;
+}
+
+int lvx_ndt_derivatives(lvx_ctx* c, int n, const float* input_xyzi4, const float* trans_xyzi4, const double* p6, double outlier_ratio, int compute_hessian,
+                        double* score, double* gradient6, double* hessian36) {
+  if (!c || n < 0 || !p6 || !score || !gradient6 || (compute_hessian && !hessian36) || (n > 0 && (!input_xyzi4 || !trans_xyzi4))) return LVX_E_ARG;
+  LVX_HIP(c, hipSetDevice(c->device));
+  { const int rc0 = vox_info(c); if (rc0) return rc0; }
+  const lvx_ctx::Voxels& V = c->vox;
+  *score = 0.0;
+  for (int j = 0; j < 6; ++j) gradient6[j] = 0.0;
+  if (hessian36) for (int e = 0; e < 36; ++e) hessian36[e] = 0.0;
+  if (n == 0 || V.n_leaves == 0) return LVX_OK;
   int rc;
   if ((rc = upload(c, c->d_up[2], input_xyzi4, (size_t)n * 16))) return rc;
   if ((rc = upload(c, c->d_up[3], trans_xyzi4, (size_t)n * 16))) return rc;
-  if ((rc = dev_alloc(c, c->d_up[6], 43 * 8))) return rc;
-  LVX_HIP(c, hipMemsetAsync(c->d_up[6].p, 0, 43 * 8, c->stream));
-  VxGrid g; std::memcpy(&g, &V.grid, sizeof(g));
-  const int* lk = (const int*)V.leaf_i.p; const double* d = (const double*)V.leaf_d.p;
-  const size_t nl = (size_t)V.cap;   // leaf arrays are strided by the capacity
-  { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
-    hipLaunchKernelGGL(k_ndt_derivatives, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const float4*)c->d_up[2].p, (const float4*)c->d_up[3].p, n, V.leaf, V.min_pts, g, (const int*)V.cells.p,
-                       lk + nl, d, d + 12 * nl, K, compute_hessian, (double*)c->d_up[6].p); }
-  LVX_HIP(c, hipGetLastError());
+  NdtDev W;
+  if ((rc = ndt_workspace(c, n, &W))) return rc;
+  const float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   double h[43];
-  LVX_HIP(c, hipMemcpyAsync(h, c->d_up[6].p, 43 * 8, hipMemcpyDeviceToHost, c->stream));
-  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  if ((rc = ndt_eval(c, W, n, (const float4*)c->d_up[2].p, (const float4*)c->d_up[3].p, I16, p6, outlier_ratio, 7, compute_hessian, h))) return rc;
   *score = h[0];
   for (int j = 0; j < 6; ++j) gradient6[j] = h[1 + j];
   if (hessian36) for (int e = 0; e < 36; ++e) hessian36[e] = h[7 + e];
+  return LVX_OK;
+}
+
+// pcl::Registration::align -> pclomp::NormalDistributionsTransform::computeTransformation (ndt_omp_impl.hpp:81-171) against the voxel grid of the last lvx_voxel_build
+int lvx_ndt_align(lvx_ctx* c, int n, const float* src_xyzi4, const float* guess16, const lvx_ndt_options* opt, lvx_ndt_result* res, float* aligned_xyzi4) {
+  if (!c || n < 0 || !res || (n > 0 && !src_xyzi4)) return LVX_E_ARG;
+  lvx_ndt_options o; lvx_ndt_default_options(&o); if (opt) o = *opt;
+  if (o.search != 1 && o.search != 7 && o.search != 26) return fail(c, LVX_E_ARG, "lvx_ndt_align: search must be 1 (DIRECT1), 7 (DIRECT7) or 26 (DIRECT26)");
+  LVX_HIP(c, hipSetDevice(c->device));
+  { const int rc0 = vox_info(c); if (rc0) return rc0; }
+  if (c->vox.n_leaves == 0 || !c->vox.cells.p) return fail(c, LVX_E_STATE, "lvx_ndt_align needs a target: call lvx_voxel_build first");
+  std::memset(res, 0, sizeof(*res));
+  if (n == 0) {   // no points: gradient and Hessian are zero, the Newton step has norm 0 and the loop leaves converged before its first iteration (:134-139)
+    for (int i = 0; i < 4; ++i) res->final_transformation[5 * i] = 1.0f;
+    if (guess16) std::memcpy(res->final_transformation, guess16, 64);
+    float e0[3]; ndt_euler012(res->final_transformation, e0);
+    res->p6[0] = res->final_transformation[3]; res->p6[1] = res->final_transformation[7]; res->p6[2] = res->final_transformation[11]; res->p6[3] = e0[0]; res->p6[4] = e0[1]; res->p6[5] = e0[2];
+    res->converged = 1;
+    return LVX_OK;
+  }
+  int rc;
+  if ((rc = upload(c, c->d_up[2], src_xyzi4, (size_t)n * 16))) return rc;
+  const float4* src_d = (const float4*)c->d_up[2].p;
+  NdtDev W;
+  if ((rc = ndt_workspace(c, n, &W))) return rc;
+  NdtState st{};
+  const float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  std::memcpy(st.final, I16, sizeof(I16));                                    // Registration::align: final_transformation_ = Identity
+  if (guess16 && std::memcmp(guess16, I16, sizeof(I16)) != 0) std::memcpy(st.final, guess16, sizeof(I16));   // :95-101
+  float e3[3]; ndt_euler012(st.final, e3);
+  double p[6] = {st.final[3], st.final[7], st.final[11], e3[0], e3[1], e3[2]}, h43[43];                      // :106-111
+  if ((rc = ndt_eval(c, W, n, src_d, nullptr, st.final, p, o.outlier_ratio, o.search, 1, h43))) return rc;   // :119
+  st.n_eval = 1;
+  st.score = h43[0]; std::memcpy(st.grad, h43 + 1, 48); std::memcpy(st.hess, h43 + 7, 288);
+  int nr_iterations = 0; bool converged = false;
+  while (!converged) {
+    double delta_p[6], mg[6];
+    for (int i = 0; i < 6; ++i) mg[i] = -st.grad[i];
+    ndt_svd_solve(st.hess, mg, delta_p);                                                                     // :127-129
+    double delta_p_norm = std::sqrt(dot6(delta_p, delta_p));
+    if (delta_p_norm == 0 || delta_p_norm != delta_p_norm) { converged = delta_p_norm == delta_p_norm; break; }   // :134-139
+    for (int i = 0; i < 6; ++i) delta_p[i] /= delta_p_norm;
+    if ((rc = ndt_step_length(c, W, n, src_d, o, p, delta_p, delta_p_norm, o.step_size, o.transformation_epsilon / 2, st, &delta_p_norm))) return rc;
+    for (int i = 0; i < 6; ++i) p[i] += delta_p[i] * delta_p_norm;                                           // :143, 152
+    if (nr_iterations > o.max_iterations || (nr_iterations && std::fabs(delta_p_norm) < o.transformation_epsilon)) converged = true;   // :158-162
+    nr_iterations++;
+  }
+  std::memcpy(res->final_transformation, st.final, sizeof(st.final));
+  for (int i = 0; i < 6; ++i) res->p6[i] = p[i];
+  res->iterations = nr_iterations; res->converged = converged ? 1 : 0; res->n_evaluations = st.n_eval;
+  res->score = st.score; res->trans_probability = n > 0 ? st.score / (double)n : 0.0;                       // :170
+  if (aligned_xyzi4 && n > 0) {   // the output cloud of align(): the source under the final transformation (:832, 877)
+    if ((rc = dev_alloc(c, c->d_up[3], (size_t)n * 16))) return rc;
+    hipLaunchKernelGGL(k_ndt_transform, dim3((n + 255) / 256), dim3(256), 0, c->stream, src_d, n, ndt_mat12(st.final), (float4*)c->d_up[3].p);
+    LVX_HIP(c, hipGetLastError());
+    LVX_HIP(c, hipMemcpyAsync(aligned_xyzi4, c->d_up[3].p, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+    LVX_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  return LVX_OK;
+}
+
+// pcl::Registration::getFitnessScore(max_range) (apps/align.cpp:30)
+int lvx_ndt_fitness(lvx_ctx* c, int n_src, const float* src_xyzi4, const float* transform16, int n_tgt, const float* tgt_xyzi4, double max_range, double* fitness) {
+  if (!c || !fitness || !transform16 || n_src < 0 || n_tgt < 0 || (n_src > 0 && !src_xyzi4) || (n_tgt > 0 && !tgt_xyzi4)) return LVX_E_ARG;
+  *fitness = std::numeric_limits<double>::max();
+  if (n_src == 0 || n_tgt == 0) return LVX_OK;
+  LVX_HIP(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = upload(c, c->d_up[2], src_xyzi4, (size_t)n_src * 16))) return rc;
+  if ((rc = upload(c, c->d_up[3], tgt_xyzi4, (size_t)n_tgt * 16))) return rc;
+  if ((rc = dev_alloc(c, c->d_up[6], (size_t)n_src * 4))) return rc;
+  const int bx = (n_src + 255) / 256;
+  int ny = std::max(1, std::min(64, 2048 / std::max(bx, 1)));           // ~2 k workgroups: the target cloud split into ny slices per source tile
+  const int per_y = (((n_tgt + ny - 1) / ny) + 1023) / 1024 * 1024;
+  ny = (n_tgt + per_y - 1) / per_y;
+  { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
+    LVX_HIP(c, hipMemsetD32Async((hipDeviceptr_t)c->d_up[6].p, 0x7f7fffff, (size_t)n_src, c->stream));   // FLT_MAX
+    hipLaunchKernelGGL(k_ndt_fitness, dim3((unsigned)bx, (unsigned)ny), dim3(256), 0, c->stream, (const float4*)c->d_up[2].p, n_src, ndt_mat12(transform16), (const float4*)c->d_up[3].p, n_tgt, per_y,
+                       (unsigned*)c->d_up[6].p); }
+  LVX_HIP(c, hipGetLastError());
+  std::vector<float> best((size_t)n_src);
+  LVX_HIP(c, hipMemcpyAsync(best.data(), c->d_up[6].p, (size_t)n_src * 4, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
+  double sum = 0.0; int nr = 0;
+  for (int i = 0; i < n_src; ++i) if (best[i] <= max_range) { sum += best[i]; ++nr; }
+  if (nr > 0) *fitness = sum / nr;
+  return LVX_OK;
+}
+
+// VoxelGridCovariance::getNeighborhoodAtPoint(relative_coordinates, reference_point, neighbors) (voxel_grid_covariance_omp_impl.hpp:378-408)
+int lvx_voxel_lookup_rel(lvx_ctx* c, int nq, const float* xyzi4, int n_rel, const int32_t* rel3, int32_t* leaf_ids) {
+  if (!c || nq < 0 || n_rel < 0 || (nq > 0 && n_rel > 0 && (!xyzi4 || !rel3 || !leaf_ids))) return LVX_E_ARG;
+  if (nq == 0 || n_rel == 0) return LVX_OK;
+  LVX_HIP(c, hipSetDevice(c->device));
+  { const int rc0 = vox_info(c); if (rc0) return rc0; }
+  const lvx_ctx::Voxels& V = c->vox;
+  const size_t ne = (size_t)nq * n_rel;
+  if (!V.cells.p || V.n_leaves == 0) { for (size_t e = 0; e < ne; ++e) leaf_ids[e] = -1; return LVX_OK; }
+  int rc;
+  if ((rc = upload(c, c->d_up[2], xyzi4, (size_t)nq * 16))) return rc;
+  if ((rc = upload(c, c->d_up[6], rel3, (size_t)n_rel * 12))) return rc;
+  if ((rc = dev_alloc(c, c->d_up[3], ne * 4))) return rc;
+  const NdtGridArgs G = ndt_grid(c);
+  { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
+    hipLaunchKernelGGL(k_vx_lookup_rel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, c->stream, (const float4*)c->d_up[2].p, nq, G.leaf, G.min_pts, G.g, G.cells, G.leaf_n, n_rel,
+                       (const int*)c->d_up[6].p, (int*)c->d_up[3].p); }
+  LVX_HIP(c, hipGetLastError());
+  LVX_HIP(c, hipMemcpyAsync(leaf_ids, c->d_up[3].p, ne * 4, hipMemcpyDeviceToHost, c->stream));
+  LVX_HIP(c, hipStreamSynchronize(c->stream));
   return LVX_OK;
 }
 

@@ -596,6 +596,61 @@ def ndt_derivatives(ctx, src, trans, p6, outlier_ratio=0.55, compute_hessian=Tru
     return score.value, g, H
 
 
+class NdtOptions(C.Structure):
+    _fields_ = [("step_size", C.c_double), ("outlier_ratio", C.c_double), ("transformation_epsilon", C.c_double), ("max_iterations", C.c_int32), ("search", C.c_int32)]
+
+
+class NdtResult(C.Structure):
+    _fields_ = [("final_transformation", C.c_float * 16), ("p6", C.c_double * 6), ("score", C.c_double), ("trans_probability", C.c_double), ("iterations", C.c_int32),
+                ("converged", C.c_int32), ("n_evaluations", C.c_int32), ("reserved", C.c_int32)]
+
+
+def ndt_align(ctx, src, guess=None, search=7, want_aligned=False, **kw):
+    """pclomp::NormalDistributionsTransform::align against the context's last voxel_build (setInputTarget at that resolution): returns a dict with the final 4 x 4
+    transformation, the 6-vector, iteration / evaluation counts, the last score (and the aligned cloud)."""
+    src = np.ascontiguousarray(src, dtype=np.float32).reshape(-1, 4)
+    opt = NdtOptions()
+    ctx._ck(ctx._l.lvx_ndt_default_options(C.byref(opt)))
+    opt.search = search
+    for k, v in kw.items():
+        setattr(opt, k, v)
+    res = NdtResult()
+    g = None if guess is None else np.ascontiguousarray(guess, dtype=np.float32).reshape(16)
+    out = np.zeros_like(src) if want_aligned else None
+    ctx._ck(ctx._l.lvx_ndt_align(ctx._h, C.c_int(len(src)), _p(src), None if g is None else _p(g), C.byref(opt), C.byref(res), None if out is None else _p(out)))
+    r = dict(final_transformation=np.array(res.final_transformation, np.float32).reshape(4, 4), p=np.array(res.p6), score=res.score, trans_probability=res.trans_probability,
+             iterations=res.iterations, converged=bool(res.converged), n_evaluations=res.n_evaluations)
+    if want_aligned:
+        r["aligned"] = out
+    return r
+
+
+def ndt_fitness(ctx, src, transform, tgt, max_range=float(np.finfo(np.float64).max)):
+    """pcl::Registration::getFitnessScore: mean squared distance of the transformed source points to their nearest target points."""
+    src = np.ascontiguousarray(src, dtype=np.float32).reshape(-1, 4)
+    tgt = np.ascontiguousarray(tgt, dtype=np.float32).reshape(-1, 4)
+    T = np.ascontiguousarray(transform, dtype=np.float32).reshape(16)
+    f = C.c_double(0)
+    ctx._ck(ctx._l.lvx_ndt_fitness(ctx._h, C.c_int(len(src)), _p(src), _p(T), C.c_int(len(tgt)), _p(tgt), C.c_double(max_range), C.byref(f)))
+    return f.value
+
+
+def neighbor_cells_26():
+    """pcl::getAllNeighborCellIndices(): the relative coordinates getNeighborhoodAtPoint(reference_point, neighbors) searches (DIRECT26; the centre cell is not one of them)."""
+    half = [(i, j, -1) for i in (-1, 0, 1) for j in (-1, 0, 1)] + [(i, -1, 0) for i in (-1, 0, 1)] + [(-1, 0, 0)]
+    h = np.array(half, np.int32)
+    return np.concatenate([h, -h], axis=0)
+
+
+def voxel_lookup_rel(ctx, queries, rel):
+    """getNeighborhoodAtPoint(relative_coordinates, point): ids [nq, n_rel], -1 = no usable leaf at that displacement."""
+    q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, 4)
+    rel = np.ascontiguousarray(rel, dtype=np.int32).reshape(-1, 3)
+    ids = np.full((len(q), len(rel)), -1, np.int32)
+    ctx._ck(ctx._l.lvx_voxel_lookup_rel(ctx._h, C.c_int(len(q)), _p(q), C.c_int(len(rel)), _p(rel), _p(ids)))
+    return ids
+
+
 SURFEL_PLANE = np.dtype([("p4", "<f8", 4), ("Pi", "<f8", 3), ("box_min", "<f8", 3), ("box_max", "<f8", 3), ("leaf", "<i4"), ("n_points", "<i4"), ("n_inliers", "<i4"),
                          ("plane_type", "<i4")])
 

@@ -323,8 +323,9 @@ int orc_surfel_extract(int n_leaves, const float* xyzi, const int32_t* leaf_n, c
 // The per-point arithmetic is FLOAT as in the reference (Eigen float matrices; sums here run left to right — Eigen's vectorised order is not
 // restated, so agreement with the real library is to float rounding), the accumulation over cells and points is double, points in index order.
 // ids7: orc_voxel_lookup7 of the TRANSFORMED points; leaf arrays from orc_voxel_build.
-void orc_ndt_derivatives(int n, const float* input_xyzi, const float* trans_xyzi, const int32_t* ids7, const double* mean, const double* icov, const double* p6,
-                         double resolution, double outlier_ratio, int compute_hessian, double* score_out, double* grad6, double* hess36) {
+// n_rel leaf ids per point (the neighbourhood in the reference's push order, -1 = no leaf): 7 for DIRECT7, 1 for DIRECT1, 26 for DIRECT26, any width for a radius search
+void orc_ndt_derivatives_n(int n, const float* input_xyzi, const float* trans_xyzi, int n_rel, const int32_t* ids7, const double* mean, const double* icov, const double* p6,
+                           double resolution, double outlier_ratio, int compute_hessian, double* score_out, double* grad6, double* hess36) {
   const double gauss_c1 = 10.0 * (1 - outlier_ratio), gauss_c2 = outlier_ratio / std::pow(resolution, 3);
   const double gauss_d3 = -std::log(gauss_c2), gauss_d1 = -std::log(gauss_c1 + gauss_c2) - gauss_d3;
   const double gauss_d2 = -2 * std::log((-std::log(gauss_c1 * std::exp(-0.5) + gauss_c2) - gauss_d3) / gauss_d1);
@@ -362,8 +363,8 @@ void orc_ndt_derivatives(int n, const float* input_xyzi, const float* trans_xyzi
     }
     double score_pt = 0.0, g_pt[6] = {0, 0, 0, 0, 0, 0}, h_pt[36];
     for (int e = 0; e < 36; ++e) h_pt[e] = 0.0;
-    for (int nb = 0; nb < 7; ++nb) {
-      const int li = ids7[7 * idx + nb];
+    for (int nb = 0; nb < n_rel; ++nb) {
+      const int li = ids7[static_cast<size_t>(n_rel) * idx + nb];
       if (li < 0) continue;
       const double xd[3] = {(double)xt[0] - mean[3 * li], (double)xt[1] - mean[3 * li + 1], (double)xt[2] - mean[3 * li + 2]};   // x_trans -= cell->getMean() in double
       const float x4[3] = {(float)xd[0], (float)xd[1], (float)xd[2]};
@@ -400,6 +401,10 @@ void orc_ndt_derivatives(int n, const float* input_xyzi, const float* trans_xyzi
   *score_out = score;
   for (int j = 0; j < 6; ++j) grad6[j] = G[j];
   for (int e = 0; e < 36; ++e) hess36[e] = H[e];
+}
+void orc_ndt_derivatives(int n, const float* input_xyzi, const float* trans_xyzi, const int32_t* ids7, const double* mean, const double* icov, const double* p6,
+                         double resolution, double outlier_ratio, int compute_hessian, double* score_out, double* grad6, double* hess36) {
+  orc_ndt_derivatives_n(n, input_xyzi, trans_xyzi, 7, ids7, mean, icov, p6, resolution, outlier_ratio, compute_hessian, score_out, grad6, hess36);
 }
 
 // pcl::VoxelGrid<pcl::PointXYZI>::applyFilter as scanRegistration.cpp:440-444 uses it on one ring's less-flat points (leaf 0.2 m, all fields

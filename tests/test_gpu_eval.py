@@ -252,3 +252,36 @@ def test_large_control_point_rotation_takes_the_exact_fallback():
         assert np.abs(rg["g"] - ro["g"]).max() <= 1e-10 * np.abs(ro["g"]).max()
     assert g.layout()["exact_fallback"] == 1
     g.close()
+
+
+def test_inplace_landmark_fill_is_cleared_between_solves():
+    """Free camera time offset (5-knot segments), frames one knot apart, the reference observation in the MIDDLE of a 3-view track: no single reprojection block
+    reaches further than the IMU band, the landmark's row (first view .. last view) does.  The in-place landmark elimination of a single-sequence solve writes its
+    Schur fill -w E^T E across that whole reach into the band itself; the next evaluation must start from a band where that fill is gone (k_clear's per-column
+    full-height flag covers a free landmark's reach, not only single blocks) — H after a solve against the oracle at the same state."""
+    # frames in the middle of knot intervals (pad 0.21 s = 10.5 intervals) and a 1 ms readout: a view's padded span stays inside ONE interval, a block of two views
+    # one knot apart touches 5 knots (= the reach of the 5-control-point IMU / LiDAR segments), the three-view landmark 6
+    cam = dict(synth.DEFAULT_CAMERA, readout=0.001)
+    P = synth.make_problem(seed=41, duration=1.2, n_surfel=200, n_planes=6, n_landmarks=24, views_per_lm=3, cam_rate=50.0, n_camsurf=0, pad=0.21, camera=cam)
+    lm = P["rep_lm"]
+    P["lm_uv"] = P["lm_uv"].copy(); P["lm_t0"] = P["lm_t0"].copy()
+    n_mid = 0
+    for l in range(P["n_landmarks"]):
+        rows = np.flatnonzero(lm == l)
+        if len(rows) == 3:   # reference := the middle view (the pixel it was seen at there; the depth stays the first view's: consistent enough for a parity test)
+            P["lm_uv"][l] = P["rep_uv"][rows[1]]; P["lm_t0"][l] = P["rep_t0"][rows[1]]; n_mid += 1
+    assert n_mid >= 10
+    locks = lvx.LOCK_LIDAR_TAU
+    o, g = _pair(P, locks, prior=False)
+    s0 = P["state0"].copy()
+    ro = o.evaluate(s0, normal_eq=True)
+    rg = g.evaluate(s0, normal_eq=True)
+    assert np.abs(rg["H"] - ro["H"]).max() <= 1e-10 * np.abs(ro["H"]).max()
+    s1, summ = g.lm_solve(s0, max_iterations=3)
+    for s in (s1, s0):
+        ro = o.evaluate(s, normal_eq=True)
+        rg = g.evaluate(s, normal_eq=True)
+        assert np.abs(rg["H"] - ro["H"]).max() <= 1e-10 * np.abs(ro["H"]).max()
+        assert np.abs(rg["g"] - ro["g"]).max() <= 1e-9 * np.abs(ro["g"]).max()   # (mid-track references with the first view's depth: residuals of tens of pixels, heavy cancellation in g)
+        _assert_blockscaled(rg["H"], ro["H"])
+    g.close()
