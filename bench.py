@@ -60,6 +60,27 @@ def measured_traffic(kernel_key):
         d.get("source", "profiles/"), k["fetch_bytes"] / 1e6, k["write_bytes"] / 1e6)
 
 
+def measured_executed(kernel_key, avg_launch_ms):
+    """What the dominant kernel EXECUTES per launch, from the SQ counter passes of the committed profile (same source-hash rule as the traffic): MFMA instructions x 2 048
+    FLOP (v_mfma_f64_16x16x4_f64), vector instructions (an upper bound of 128 FLOP each if every one were a 64-lane FP64 FMA; moves, integer and LDS address arithmetic are
+    in that count), and the share of the chip's matrix-pipe cycles the MFMAs occupy (64 cycles each, 256 CUs x 4 SIMDs at 2.4 GHz)."""
+    try:
+        d = json.load(open(TRAFFIC_JSON))
+    except Exception:   # noqa: BLE001
+        return None
+    if d.get("sources_sha256") != kernel_sources_sha():
+        return None
+    q = d.get("sq", {}).get(kernel_key)
+    if not q:
+        return None
+    simd_cycles = avg_launch_ms * 1e-3 * 2.4e9 * 1024
+    return {"mfma_insts": q["insts_mfma"], "mfma_flops": q["insts_mfma"] * 2048.0, "mfma_TFLOPs": q["insts_mfma"] * 2048.0 / (avg_launch_ms * 1e-3) / 1e12,
+            "matrix_pipe_frac": q["insts_mfma"] * 64.0 / simd_cycles, "valu_insts": q["insts_valu"], "valu_issue_frac": q["insts_valu"] * 4.0 / simd_cycles,
+            "valu_flops_upper_bound": q["insts_valu"] * 128.0, "source": d.get("sq_source", "profiles/"),
+            "note": "per launch; matrix_pipe_frac = MFMA instructions x 64 cycles / (launch duration x 1024 SIMDs x 2.4 GHz); valu_issue_frac = vector instructions x 4 cycles "
+                    "(a 64-lane wavefront on a 16-lane SIMD) over the same denominator; the algorithmic fraction above divides SURVEY 8d's FLOP count by the FP64 peak instead"}
+
+
 BYTES_PER_EVAL = {"imu": 32, "surfel": 60, "reproj": 60}
 FLOPS_PER_EVAL = {"imu": 4e3, "surfel": 9e3, "reproj": 11e3}   # SURVEY.md §8(d)
 
@@ -350,18 +371,20 @@ def cpu_baseline(P, seconds_budget=12.0):
     cores = usable_cores()
     o.set_threads(cores)
     blocks = o.num_blocks
+    o.set_block_products(True)        # every block's dense J^T J upper triangle is formed too (what mode (ii) below does): the two legs price the same work
     o.evaluate_products(P["state0"])  # warm
     t0 = time.perf_counter()
     reps = 0
     while True:
-        o.evaluate_products(P["state0"])   # residuals + dual-number Jacobians + J^T r + diag(J^T J), OpenMP over the blocks
+        o.evaluate_products(P["state0"])   # residuals + dual-number Jacobians + J^T r + the block's J^T J products, OpenMP over the blocks
         reps += 1
         if time.perf_counter() - t0 > seconds_budget or reps >= 50:
             break
     dt = time.perf_counter() - t0
     out = {"value": blocks * reps / dt / 1e6, "unit": "Mevals/s", "cores": cores, "kind": "port",
            "sample": "%d surfel + %d gyro + %d accel + %d reprojection blocks x %d passes (1/5 of the workload): residual + stride-4 dual-number Jacobian per block "
-                     "(cost profile of ceres::DynamicAutoDiffCostFunction) + J^T r and diag(J^T J) ONLY — not the block products Ceres' SPARSE_SCHUR forms, which flatters the CPU — OpenMP over blocks, g++ -O3 -msse4.2" % (len(si), len(ii), len(ii), int(rmask.sum()), reps)}
+                     "(cost profile of ceres::DynamicAutoDiffCostFunction) + J^T r + the block's dense J^T J upper triangle (formed, folded into a checksum: no sparse assembly), "
+                     "OpenMP over blocks, g++ -O3 -msse4.2" % (len(si), len(ii), len(ii), int(rmask.sum()), reps)}
     try:   # mode (ii): closed-form Jacobians + every block's J^T J / J^T r products
         n2, _ = O.analytic_pass(o, P["state0"], cores)
         t0 = time.perf_counter(); reps2 = 0
@@ -401,8 +424,13 @@ def main():
     backend = os.environ.get("LVX_BENCH_BACKEND", "nccl")   # "gloo": functional check of the N > 1 path with several ranks on one GPU
     if torch.cuda.is_available() and backend != "nccl":
         local_rank %= torch.cuda.device_count()
-    if world > 1:
+    # LVX_BENCH_FORCE_DIST=1: take the N > 1 code path with WORLD_SIZE = 1 (process group, exported border block, all-reduce, in-library RCCL, joint LM) — the readiness
+    # check of tests/test_gpu_bench_ranks.py on a one-GPU box: every line the 8-GPU run executes runs once before that run
+    dist_on = world > 1 or bool(os.environ.get("LVX_BENCH_FORCE_DIST"))
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
@@ -421,17 +449,21 @@ def main():
     lvx.load_problem(ctx, P, lvx.LOCK_LIDAR_TAU | lvx.LOCK_CAM_TAU)
     lo = ctx.layout()
     ctx.set_state(P["state0"])
-    if world > 1:
+    if dist_on:
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)   # evaluation, export and the all-reduce share one stream
     what = lvx.EVAL_COST | lvx.EVAL_NORMAL_EQ
     nbd = lo["border_ld"]
-    red = torch.zeros(nbd * nbd + nbd + 2, dtype=torch.float64, device="cuda") if world > 1 else None
+    red = torch.zeros(nbd * nbd + nbd + 2, dtype=torch.float64, device="cuda") if dist_on else None
+    transport = {"inlib": False}   # the per-step all-reduce: torch.distributed (RCCL behind it) or the library's own communicator (lvx_rccl_allreduce_d)
 
     def step():
         ctx.evaluate_resident(what)
-        if world > 1:
+        if dist_on:
             ctx.export_border(red.data_ptr())   # shared-calibration block of J^T J, J^T r, cost
-            dist.all_reduce(red)
+            if transport["inlib"]:
+                ctx.rccl_allreduce(red.data_ptr(), red.numel())
+            else:
+                dist.all_reduce(red)
 
     for _ in range(args.warmup):
         step()
@@ -453,25 +485,30 @@ def main():
             live_k = max(cand, key=lambda i: ms0[i] / l0[i])
     ctx.set_profiling(live, only=live_k)
     ctx.kernel_ms()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    def timed_region():
+        """EXACTLY args.steps steps between barrier + synchronize on both sides; the maximum over the ranks."""
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist_on:
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
+
+    elapsed = timed_region()
     ms, launches = ctx.kernel_ms()
     ctx.set_profiling(False)
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
     cost = ctx.evaluate_resident(lvx.EVAL_COST, want_cost=True)
-    if world > 1 and float(red[-1].item()) != 0.0:     # summed device error words of the last step: some rank's sums were incomplete
+    if dist_on and float(red[-1].item()) != 0.0:     # summed device error words of the last step: some rank's sums were incomplete
         raise SystemExit("a rank reported a device-side evaluation error (range / non-unit quaternion / fallback)")
     blocks = lo["n_blocks"]
     value = blocks * world * args.steps / elapsed / 1e6
@@ -482,11 +519,54 @@ def main():
                                "step = residuals + analytic Jacobians + Huber + J^T J/J^T r assembly (no linear solve)" % (n_surf, n_imu, len(P["rep_lm"]), lo["n_knots"]),
                    "blocks_per_step_per_gpu": int(blocks), "n_tangent": lo["n_tangent"], "bandwidth": lo["bandwidth"], "n_border": lo["n_border"],
                    "locks": "LIDAR_TAU | CAM_TAU (sensor time offsets constant, everything else free: trajInitFromLVIdata with lvi.yaml's opt_time_offset false)",
-                   "tracks": P.get("tracks", "orb"), "parallelism": "sequence-per-gpu x%d" % world, "shard_size": args.shard_size, "cost": cost},
+                   "tracks": P.get("tracks", "orb"), "parallelism": "sequence-per-gpu x%d" % world, "shard_size": args.shard_size, "cost": cost,
+                   "allreduce_transport": "torch.distributed all_reduce (backend %s) of the exported border block" % backend if dist_on else "none (one sequence)"},
     }
     em = Emitter(rank)
     em.out = out
     em.arm(300)   # everything below is a side measurement: it must not be able to cost the line
+    # ---- the same step over the LIBRARY'S OWN RCCL communicator (lvx_rccl_init / lvx_rccl_allreduce_d).  It runs AFTER the torch-transport measurement above and under the
+    # watchdog: a second communicator that cannot be created, or hangs, costs nothing — the line with the torch transport is already in `out`.  When it works its
+    # measurement becomes the headline (`value`, `ms_per_step`), the torch-transport one is kept beside it. ----
+    rccl_ok = False
+    if dist_on and backend == "nccl":
+        try:
+            uid = torch.tensor(list(ctx.rccl_unique_id()) if rank == 0 else [0] * 128, dtype=torch.uint8, device="cuda")
+            dist.broadcast(uid, src=0)
+            ctx.rccl_init(bytes(uid.cpu().tolist()), rank, world)
+            ok = torch.ones(1, device="cuda")
+        except Exception as e:   # noqa: BLE001
+            ok = torch.zeros(1, device="cuda")
+            out.setdefault("secondary", {})["inlib_rccl_init_error"] = str(e)[:300]
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)       # every rank takes the same transport
+        rccl_ok = bool(ok.item() > 0)
+        if not rccl_ok:
+            try:
+                ctx.rccl_finalize()
+            except Exception:   # noqa: BLE001
+                pass
+        if rccl_ok:
+            try:
+                transport["inlib"] = True
+                ref = red.clone()
+                for _ in range(max(1, args.warmup)):
+                    step()
+                ctx.synchronize(); torch.cuda.synchronize()
+                same = bool(torch.allclose(red[:-2], ref[:-2], rtol=1e-9, atol=0.0)) if world == 1 else None   # one rank: the reduced block is the exported block
+                elapsed_b = timed_region()
+                if float(red[-1].item()) != 0.0:
+                    raise RuntimeError("device-side evaluation error under the in-library transport")
+                hb = {"torch_transport": {"value": value, "ms_per_step": 1e3 * elapsed / args.steps},
+                      "inlib_transport": {"value": blocks * world * args.steps / elapsed_b / 1e6, "ms_per_step": 1e3 * elapsed_b / args.steps}}
+                if same is not None:
+                    hb["single_rank_identity"] = same
+                out.setdefault("secondary", {})["headline_transports"] = hb
+                elapsed, value = elapsed_b, hb["inlib_transport"]["value"]
+                out["value"], out["ms_per_step"] = value, 1e3 * elapsed / args.steps
+                out["config"]["allreduce_transport"] = "RCCL inside liblvx on the context's stream (lvx_rccl_init + lvx_rccl_allreduce_d) of the exported border block; torch's beside it under secondary.headline_transports"
+            except Exception as e:   # noqa: BLE001
+                out.setdefault("secondary", {})["inlib_rccl_step_error"] = str(e)[:300]
+            transport["inlib"] = False
     if rank == 0:
         k = live_k
         surf_ms = ms[k] / max(1, launches[k])   # the live-timed (dominant) kernel's mean launch duration inside the timed region
@@ -554,7 +634,7 @@ def main():
                                    "(hoisted hub pose, precomputed control-point pairs); FP64 matrix = FP64 vector peak = 78.6 TFLOP/s on MI355X; `families` has every family's fraction, "
                                    "`whole_pass` the sum over the step time"}
     # ---- side measurements that involve every rank ----
-    if world > 1 and not args.no_secondary:
+    if dist_on and not args.no_secondary:
         # LM iterations of the JOINT problem — shared rig extrinsics, one sequence per GPU (lvx_lm_solve_shared).  Transport: RCCL inside the library on the context's
         # stream when the job runs on RCCL (no host round trip); the host callback over torch.distributed otherwise, and as the fallback when a second communicator next
         # to torch's cannot be created.  Which one ran is recorded.
@@ -568,23 +648,6 @@ def main():
             sj[7 * Nk + 16:7 * Nk + 32] = ext.cpu().numpy()
         except Exception as e:   # noqa: BLE001
             sec_all["joint_lm_iteration"] = {"error": str(e)[:300]}
-        rccl_ok = False
-        if backend == "nccl" and "joint_lm_iteration" not in sec_all:
-            try:
-                uid = torch.tensor(list(ctx.rccl_unique_id()) if rank == 0 else [0] * 128, dtype=torch.uint8, device="cuda")
-                dist.broadcast(uid, src=0)
-                ctx.rccl_init(bytes(uid.cpu().tolist()), rank, world)
-                ok = torch.ones(1, device="cuda")
-            except Exception as e:   # noqa: BLE001
-                ok = torch.zeros(1, device="cuda")
-                sec_all["joint_lm_rccl_init_error"] = str(e)[:300]
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)       # every rank takes the same transport
-            rccl_ok = bool(ok.item() > 0)
-            if not rccl_ok:
-                try:
-                    ctx.rccl_finalize()
-                except Exception:   # noqa: BLE001
-                    pass
         if "joint_lm_iteration" not in sec_all:
             try:
                 ctx.collective_count(reset=True)
@@ -656,17 +719,22 @@ def main():
             print("[bench rank %d] surfel_assoc: %s" % (rank, str(e)[:300]), file=sys.stderr, flush=True)
         out.setdefault("secondary", {})["surfel_assoc"] = assoc
     # ---- rank 0 alone ----
+    if rccl_ok:
+        try:
+            ctx.rccl_finalize()
+        except Exception:   # noqa: BLE001
+            pass
     if rank == 0:
-        if world == 1 and not args.no_secondary:
+        if world == 1 and not dist_on and not args.no_secondary:
             sec = secondary_metrics(ctx, P, lo)
             sec.update(out.get("secondary", {}))
             out["secondary"] = sec
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not dist_on:
             out["cpu_baseline"] = cpu_baseline(P)
     em.disarm()
     em.emit()
     ctx.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

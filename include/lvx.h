@@ -339,6 +339,9 @@ int lvx_lm_solve_shared(lvx_ctx* ctx, double* state, const lvx_lm_options* opt, 
 int lvx_rccl_unique_id(lvx_ctx* ctx, void* id128);
 int lvx_rccl_init(lvx_ctx* ctx, const void* id128, int rank, int world);
 int lvx_rccl_finalize(lvx_ctx* ctx);
+/* in-place all-reduce (LVX_REDUCE_SUM / LVX_REDUCE_MAX) of a caller's device buffer of n doubles over the installed communicator, queued on the context's stream:
+ * the transport of the per-step border-block reduction of a sequence-per-GPU evaluation (lvx_export_border_d -> this) */
+int lvx_rccl_allreduce_d(lvx_ctx* ctx, double* buf_d, int n, int op);
 /* number of shared scalars the last joint solve of this context kept out of its local elimination (LVX_N_SHARED when a transport was active, 0 for a
  * single-sequence solve): lets a caller / test assert that the joint path was taken */
 int lvx_joint_shared_count(lvx_ctx* ctx);

@@ -1414,6 +1414,18 @@ int lvx_rccl_finalize(lvx_ctx* c) {
   if (c->rccl_comm) { RcclApi* api = rccl_api(c); if (api) api->CommDestroy((ncclComm_t)c->rccl_comm); c->rccl_comm = nullptr; }
   return LVX_OK;
 }
+// in-place all-reduce of a caller's DEVICE buffer over the installed communicator, queued on the context's stream (bench.py --gpus N: the per-step reduction of the
+// exported border block goes through the library's own transport)
+int lvx_rccl_allreduce_d(lvx_ctx* c, double* buf_d, int n, int op) {
+  if (!c || !buf_d || n < 0 || (op != LVX_REDUCE_SUM && op != LVX_REDUCE_MAX)) return LVX_E_ARG;
+  if (!c->rccl_comm) return fail(c, LVX_E_STATE, "lvx_rccl_allreduce_d: no communicator (lvx_rccl_init)");
+  if (n == 0) return LVX_OK;
+  RcclApi* api = rccl_api(c); if (!api) return LVX_E_COMM;
+  const ncclResult_t r = api->AllReduce(buf_d, buf_d, (size_t)n, ncclDouble, op == LVX_REDUCE_SUM ? ncclSum : ncclMax, (ncclComm_t)c->rccl_comm, c->stream);
+  c->n_collectives++;
+  if (r != ncclSuccess) return fail(c, LVX_E_COMM, std::string("ncclAllReduce: ") + (api->GetErrorString ? api->GetErrorString(r) : "error"));
+  return LVX_OK;
+}
 int lvx_joint_shared_count(lvx_ctx* c) { return c ? c->last_ns : 0; }
 int64_t lvx_collective_count(lvx_ctx* c, int reset) { if (!c) return 0; const int64_t n = c->n_collectives; if (reset) c->n_collectives = 0; return n; }
 

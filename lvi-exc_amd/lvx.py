@@ -343,6 +343,10 @@ class Context:
         buf = (C.c_char * 128).from_buffer_copy(unique_id)
         self._ck(self._l.lvx_rccl_init(self._h, buf, C.c_int(rank), C.c_int(world)))
 
+    def rccl_allreduce(self, device_ptr, n, op=0):
+        """In-place all-reduce of n doubles at device_ptr over the library's own communicator, on the context's stream (op 0 = sum, 1 = max)."""
+        self._ck(self._l.lvx_rccl_allreduce_d(self._h, C.c_void_p(device_ptr), C.c_int(n), C.c_int(op)))
+
     def rccl_finalize(self):
         self._ck(self._l.lvx_rccl_finalize(self._h))
 

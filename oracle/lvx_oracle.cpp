@@ -366,6 +366,8 @@ int orc_set_camsurf(orc_problem* p, int n, const int32_t* lm, const int32_t* pla
 int orc_set_locks(orc_problem* p, uint32_t mask) { p->locks = mask; return 0; }
 int orc_set_so3_only(orc_problem* p, int flag) { p->so3_only = flag != 0; return 0; }
 int orc_set_threads(orc_problem* p, int n) { p->threads = n; return 0; }
+int orc_set_block_products(orc_problem* p, int on) { p->block_products = on != 0; p->products_checksum = 0.0; return 0; }
+double orc_products_checksum(const orc_problem* p) { return p->products_checksum; }
 
 int orc_state_size(const orc_problem* p) { return p->state_size(); }
 int orc_tangent_size(const orc_problem* p) { return p->tangent_size(); }
@@ -468,9 +470,9 @@ int orc_evaluate_products(const orc_problem* p, const double* state, int n_vec, 
     const int cnt = p->family_count(fam);
     const int nr = Problem::family_nres(fam);
     const double a = p->family_huber(fam);
-    double fam_cost = 0.0;
+    double fam_cost = 0.0, fam_chk = 0.0;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static) num_threads(nth) reduction(+ : fam_cost)
+#pragma omp parallel for schedule(static) num_threads(nth) reduction(+ : fam_cost, fam_chk)
 #endif
     for (int i = 0; i < cnt; ++i) {
       if (err) continue;
@@ -489,6 +491,12 @@ int orc_evaluate_products(const orc_problem* p, const double* state, int n_vec, 
         const int row = row0 + i * nr;
         if (residuals) for (int k = 0; k < nr; ++k) residuals[row + k] = r[k];
         const int nc = static_cast<int>(rows.cols.size());
+        if (p->block_products) {   // the block's dense J^T J (upper triangle): the flops are spent and folded into a checksum, as orc_analytic_pass does
+          double chk = 0.0;
+          for (int a1 = 0; a1 < nc; ++a1)
+            for (int b1 = a1; b1 < nc; ++b1) { double h = 0.0; for (int k = 0; k < nr; ++k) h += sr * rows.vals[k][a1] * sr * rows.vals[k][b1]; chk += h; }
+          fam_chk += chk;
+        }
         for (int k = 0; k < nr; ++k) {
           const double rk = sr * r[k];
           for (int a1 = 0; a1 < nc; ++a1) { const double ja = sr * rows.vals[k][a1]; my[rows.cols[a1]] += ja * rk; my[nt + rows.cols[a1]] += ja * ja; }
@@ -517,6 +525,7 @@ int orc_evaluate_products(const orc_problem* p, const double* state, int n_vec, 
       }
     }
     total += fam_cost;
+    p->products_checksum += fam_chk;
     row0 += cnt * nr;
   }
   if (cost) *cost = total;

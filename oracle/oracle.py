@@ -115,6 +115,15 @@ class Oracle:
     def set_threads(self, n):
         self._l.orc_set_threads(self._h, C.c_int(n))
 
+    def set_block_products(self, on):
+        """evaluate_products also forms every block's dense J^T J upper triangle (CPU-baseline timing; folded into products_checksum)."""
+        self._l.orc_set_block_products(self._h, C.c_int(1 if on else 0))
+
+    @property
+    def products_checksum(self):
+        self._l.orc_products_checksum.restype = C.c_double
+        return self._l.orc_products_checksum(self._h)
+
     @property
     def state_size(self):
         return self._l.orc_state_size(self._h)

@@ -32,6 +32,8 @@ struct Problem {
   bool so3_only = false;  // Solve #0 runs on TrajectoryEstimator<UniformSO3SplineTrajectory> (L/src/core/trajectory_manager_lvi.cpp:43-62)
   uint32_t locks = LVXO_LOCK_LIDAR_TAU | LVXO_LOCK_CAM_TAU;
   int threads = 0;
+  bool block_products = false;   // orc_evaluate_products also forms every block's J^T J upper triangle (CPU-baseline timing: what a Schur-based solver's assembly starts from)
+  mutable double products_checksum = 0.0;
   double imu_max_time_offset = 0.01;       // sensors.h:109
   double sensor_max_time_offset = 0.001;   // L/include/core/trajectory_manager_lvi.h:118-119
   PinholeMeta cam;

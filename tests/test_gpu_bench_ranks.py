@@ -75,3 +75,32 @@ def test_eight_rank_bench_line_with_a_failing_rank():
     assert "error" not in o, o
     assert o["shard_size"] == "eighth" and o["value"] > 0
     assert dt < 600
+
+
+def test_single_rank_runs_the_nccl_branch_with_the_library_transport():
+    """Every line the driver's 8-GPU run executes, executed once on a one-GPU box: bench.py under torch.distributed.run with ONE rank on the real `nccl` (= RCCL) backend and
+    LVX_BENCH_FORCE_DIST=1 — process group, exported border block, torch all-reduce, then the unique-id broadcast, lvx_rccl_init, the SAME step over the library's own
+    communicator (lvx_rccl_allreduce_d, which becomes the headline transport), the joint LM over in-library RCCL, the association all-gather path and lvx_rccl_finalize."""
+    env = dict(os.environ, LVX_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    env.pop("LVX_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--small"]
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    dt = time.perf_counter() - t0
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    sec = out["secondary"]
+    print("1-rank nccl bench: %.1f s wall, %s, transports %s, joint LM %s" % (dt, out["config"]["allreduce_transport"][:40], sec.get("headline_transports"), sec.get("joint_lm_iteration")))
+    assert "inlib_rccl_init_error" not in sec and "inlib_rccl_step_error" not in sec, sec
+    assert out["config"]["allreduce_transport"].startswith("RCCL inside liblvx")
+    h = sec["headline_transports"]
+    assert h["single_rank_identity"] is True and h["inlib_transport"]["value"] > 0 and h["torch_transport"]["value"] > 0
+    assert out["value"] == h["inlib_transport"]["value"] and out["n_gpus"] == 1
+    j = sec["joint_lm_iteration"]
+    assert "error" not in j, j
+    assert j["transport"].startswith("RCCL inside liblvx") and j["iterations"] >= 1 and j["final_cost"] < j["initial_cost"] and j["collectives"] >= 3
+    assert "error" not in sec["surfel_assoc"] and "watchdog" not in sec
+    assert "roofline" in out and out["roofline"]["frac"] > 0
