@@ -225,9 +225,11 @@ def secondary_metrics(ctx, P, lo):
         t = lvx.upstream_bench(ctx, "voxel_build", (cloud, 0.5))
         t0 = time.perf_counter(); O.voxel_build(cloud, 0.5); tc = time.perf_counter() - t0
         sec["voxel_build"] = {"Mpts_per_s": len(cloud) / t / 1e6, "points": len(cloud), "ms": 1e3 * t, "hbm_frac": (36.0 * len(cloud)) / t / 1e9 / HBM_PEAK_GBS,
+                              "hbm_frac_is_at": "BASELINE config 2 size (100 k points): launch-latency bound, see larger_maps for the saturating size",
                               "cpu": {"Mpts_per_s": len(cloud) / tc / 1e6, "cores": 1, "kind": "port", "sample": "one build (the reference's applyFilter is serial)"}}
         t = lvx.upstream_bench(ctx, "voxel_lookup7", synth.rigid_move(cloud))
-        sec["voxel_lookup7"] = {"Mqueries_per_s": len(cloud) / t / 1e6, "ms": 1e3 * t, "hbm_frac": 100.0 * len(cloud) / t / 1e9 / HBM_PEAK_GBS}
+        sec["voxel_lookup7"] = {"Mqueries_per_s": len(cloud) / t / 1e6, "ms": 1e3 * t, "hbm_frac": 100.0 * len(cloud) / t / 1e9 / HBM_PEAK_GBS,
+                                "hbm_frac_is_at": "BASELINE config 2 size (100 k queries); voxel_build.larger_maps.*.lookup7 has 400 k and 4 M"}
         # the sizes the pipeline really builds: the map cloud of a DataAssociation round (~410 k points) and a 4 M-point map; same local density (tiled config-2 cloud).
         # One launch chain without a host hop, replayed as a HIP graph; algorithmic traffic 36 B per point + 268 B per occupied leaf
         sizes = {}
@@ -240,6 +242,11 @@ def secondary_metrics(ctx, P, lo):
             sizes["%d_points" % len(big)] = {"ms": 1e3 * tb, "Mpts_per_s": len(big) / tb / 1e6, "leaves": int(nl), "GBps": by / tb / 1e9, "hbm_frac": by / tb / 1e9 / HBM_PEAK_GBS,
                                              "lookup7": {"ms": 1e3 * tq, "Mqueries_per_s": len(big) / tq / 1e6, "GBps": 100.0 * len(big) / tq / 1e9, "hbm_frac": 100.0 * len(big) / tq / 1e9 / HBM_PEAK_GBS}}
         sec["voxel_build"]["larger_maps"] = sizes
+        big_key = max(sizes, key=lambda k: int(k.split("_")[0]))
+        sec["upstream_hbm_fractions"] = {   # every streaming upstream kernel at the BASELINE config size AND at a size that saturates the chip, side by side
+            "voxel_build": {"config2_100k_points": sec["voxel_build"]["hbm_frac"], big_key: sizes[big_key]["hbm_frac"]},
+            "voxel_lookup7": {"config2_100k_queries": sec["voxel_lookup7"]["hbm_frac"], big_key: sizes[big_key]["lookup7"]["hbm_frac"]},
+            "note": "fraction of 8 TB/s by ALGORITHMIC bytes (36 B/pt + 268 B/leaf; 100 B/query, SURVEY 8d); the config sizes are bound by launch count / dependent round trips, not by HBM"}
         pts = synth.make_vlp16_sweep(seed=1)
         lvx.scan_register(ctx, pts, 16, 0.3)
         t0 = time.perf_counter()
@@ -280,6 +287,39 @@ def secondary_metrics(ctx, P, lo):
                                                                               "hbm_frac": 28.0 * int(off[-1]) / tq / 1e9 / HBM_PEAK_GBS}
     except Exception as e:   # noqa: BLE001
         sec["upstream_error"] = str(e)[:200]
+    try:   # the reference's ONLY published benchmark (src/ndt_omp/README.md:8-41, apps/align.cpp on its two scans): NDT registration, 0.1 m VoxelGrid, resolution 1.0, identity guess
+        from oracle import ndt_align as NA
+        from oracle import oracle as O
+        gold = os.path.join(ROOT, "tests", "golden")
+        tgt = O.voxelgrid_xyzi(np.load(os.path.join(gold, "ndt_data_251370668.npz"))["xyzi"], 0.1)
+        src = O.voxelgrid_xyzi(np.load(os.path.join(gold, "ndt_data_251371071.npz"))["xyzi"], 0.1)
+        readme = {7: {"fitness": 0.214205, "ms_1_thread": 139.433, "ms_8_threads": 63.1442}, 1: {"fitness": 0.208511, "ms_1_thread": 34.6418, "ms_8_threads": 17.2353}}
+        nd = {"points": {"target": len(tgt), "source": len(src)}, "note": "pclomp::NormalDistributionsTransform::align (setInputTarget = voxel covariance grid at 1.0 m, then the Newton / "
+              "More-Thuente loop) + getFitnessScore; GPU: lvx_voxel_build + lvx_ndt_align + lvx_ndt_fitness with host buffers in and out; README = Core i7-6700K, "
+              "src/ndt_omp/README.md:18-26,33-41; the fitness of the README run is reproduced to 4.5 % / 7.9 % by the restated default loop and to 1.1 % at its fixed point "
+              "(tests/test_ndt_align_oracle.py: the statistic moves 0.8 % per milliradian and the default loop stops 0.12 m short of the optimum)"}
+        for search in (7, 1):
+            lvx.voxel_build(ctx, tgt, 1.0, fetch=False)
+            lvx.ndt_align(ctx, src, search=search)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                r = lvx.ndt_align(ctx, src, search=search)
+            ta = (time.perf_counter() - t0) / 10
+            t0 = time.perf_counter()
+            for _ in range(10):
+                lvx.voxel_build(ctx, tgt, 1.0, fetch=False); ctx.voxel_info()
+            tv = (time.perf_counter() - t0) / 10
+            fg = lvx.ndt_fitness(ctx, src, r["final_transformation"], tgt)
+            a = NA.NdtAligner(tgt, 1.0, search)
+            t0 = time.perf_counter(); a.align(src); tc = time.perf_counter() - t0
+            nd["DIRECT%d" % search] = {"align_ms": 1e3 * ta, "target_grid_ms": 1e3 * tv, "iterations": r["iterations"], "evaluations": r["n_evaluations"], "fitness": fg,
+                                        "readme": readme[search], "speedup_vs_readme_8_threads": readme[search]["ms_8_threads"] / (1e3 * ta),
+                                        "fitness_vs_readme": fg / readme[search]["fitness"],
+                                        "cpu": {"align_ms": 1e3 * tc, "fitness": a.fitness(), "iterations": a.nr_iterations, "cores": 1, "kind": "port",
+                                                "sample": "one align of the oracle's restated loop (scalar C per-point arithmetic, Python loop around it)"}}
+        sec["ndt_align"] = nd
+    except Exception as e:   # noqa: BLE001
+        sec["ndt_align"] = {"error": str(e)[:200]}
     try:   # one DataAssociation round of the stage driver, device-resident (lvx_data_association): 57 scans x 16 x 450 points of synth.make_sequence
         import ctypes as C
         S = synth.make_sequence(seed=50)
@@ -627,6 +667,7 @@ def main():
                            "duration_source": "HIP events on the kernel's own stream around every launch of the timed region" if (dominant == live_fam and launches[k]) else "solo duration (every kernel on one stream), profiled run outside the timed region",
                            "avg_launch_ms": fam[dominant]["ms"], "algorithmic_flops_per_launch": fl_d, "algorithmic_bytes_per_launch": by_d,
                            "hbm": {"achieved_GBps": fam[dominant]["GBps"], "peak_GBps": HBM_PEAK_GBS},
+                           "executed": measured_executed(dominant, fam[dominant]["ms"]) if scale == 1 else None,
                            "families": fam,
                            "whole_pass": {"TFLOPs": tot_fl / step_s / 1e12, "frac_fp64_peak": tot_fl / step_s / 1e12 / FP64_PEAK_TFLOPS, "ms": 1e3 * step_s},
                            "note": "time-dominant kernel family of the pass (solo durations; the surfel kernel's from HIP events on its own stream around every launch of the timed region); "

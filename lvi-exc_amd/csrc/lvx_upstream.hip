@@ -1322,6 +1322,25 @@ __global__ __launch_bounds__(1024) void k_assoc_grid_scan(const int* cnt, int* o
 // all pairs: thread = scan point, the plane table of the block's chunk (256 planes) in LDS, read as broadcasts.  57.6 M exact tests per scan at P = 2000
 // (FP64 VALU bound, 36 us) — cheaper than building the grid when only one or two scans are associated in a call.
 #define SA_PC 256
+// A hit = the point's bit in the (scan, plane, ring) mask + that ring's hit count.  Hits of one surfel come in runs along a ring (a box spans tens of consecutive columns): up
+// to 32 lanes of a wavefront would OR the same mask word and bump the same counter, and same-address atomics of one instruction are served one after the other (round 4: the
+// two atomics were 150 of k_assoc_hits' 200 us).  The lanes of a run — same (plane, ring, mask word); consecutive lanes are consecutive columns — hand their bits to the run's
+// first lane: one OR and one add per run (neither returns a value: a returning add per run, to append first-hit rings to a work list, made the kernel 3.5x slower).
+// Wave-uniform among the lanes that call it together.
+__device__ __forceinline__ void sa_record_hit(bool hit, size_t ring, int w, int lane, int wpr, unsigned* bits, int* counts) {
+  const size_t word = ring * wpr + (w >> 5);
+  unsigned long long pend = __ballot(hit);
+  while (pend) {
+    const int ld = __ffsll((long long)pend) - 1;
+    const size_t wd = __shfl(word, ld);
+    const unsigned long long m = __ballot(hit && word == wd);        // the lanes of this run (ld among them)
+    pend &= ~m;
+    if (lane == ld) {
+      atomicOr(&bits[word], (unsigned)((m >> ld) << (w & 31)));        // lane L holds column w + (L - ld) of the same 32-column word
+      atomicAdd(&counts[ring], __popcll(m));
+    }
+  }
+}
 __global__ __launch_bounds__(256) void k_assoc_hits_allpairs(const float4* __restrict__ scans, int H, int W, int P, const double* __restrict__ planes10, double radius,
                                                              unsigned* bits, int* counts, int wpr) {
   __shared__ double pl[10][SA_PC];
@@ -1336,21 +1355,18 @@ __global__ __launch_bounds__(256) void k_assoc_hits_allpairs(const float4* __res
   const float4 q = scans[(size_t)sc * H * W + i];
   if (isnan(q.x)) return;
   const double x = q.x, y = q.y, z = q.z;
-  const int h = i / W, w = i - h * W;
+  const int h = i / W, w = i - h * W, lane = threadIdx.x & 63;
   for (int k = 0; k < np; ++k) {
-    if (!(x > pl[4][k] && x < pl[7][k] && y > pl[5][k] && y < pl[8][k] && z > pl[6][k] && z < pl[9][k])) continue;
-    double dist = x * pl[0][k] + y * pl[1][k] + z * pl[2][k] + pl[3][k];
+    const bool inside = (x > pl[4][k]) & (x < pl[7][k]) & (y > pl[5][k]) & (y < pl[8][k]) & (z > pl[6][k]) & (z < pl[9][k]);
+    if (!__ballot(inside)) continue;                                   // wave-uniform skip
+    double dist = inside ? x * pl[0][k] + y * pl[1][k] + z * pl[2][k] + pl[3][k] : 1e300;
     dist = dist > 0 ? dist : -dist;
-    if (dist <= radius) {
-      const size_t ring = ((size_t)sc * P + p0 + k) * H + h;
-      atomicOr(&bits[ring * wpr + (w >> 5)], 1u << (w & 31));
-      atomicAdd(&counts[ring], 1);
-    }
+    sa_record_hit(dist <= radius, ((size_t)sc * P + p0 + k) * H + h, w, lane, wpr, bits, counts);
   }
 }
 __global__ __launch_bounds__(256) void k_assoc_hits(const float4* __restrict__ scans, int H, int W, int P, const double* __restrict__ aos, double radius, const AssocGrid* gp,
                                                     const int* __restrict__ off, const int* __restrict__ list, unsigned* bits, int* counts, int wpr) {
-  const int i = blockIdx.x * 256 + threadIdx.x, sc = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x, sc = blockIdx.y, lane = threadIdx.x & 63;
   if (i >= H * W) return;
   const float4 q = scans[(size_t)sc * H * W + i];
   const double x = q.x, y = q.y, z = q.z;
@@ -1362,24 +1378,37 @@ __global__ __launch_bounds__(256) void k_assoc_hits(const float4* __restrict__ s
   if (!in_grid) return;
   const int cell = (sa_cell(z, g.g0[2], g.inv[2], SA_GZ) * SA_GY + sa_cell(y, g.g0[1], g.inv[1], SA_GY)) * SA_GX + sa_cell(x, g.g0[0], g.inv[0], SA_GX);
   const int h = i / W, w = i - h * W;
-  for (int e = off[cell]; e < off[cell + 1]; ++e) {
-    const int k = list[e];
-    const double2* rec = (const double2*)(aos + 10 * (size_t)k);   // five 16-byte loads
-    const double2 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
-    const double lo[3] = {r0.x, r0.y, r1.x}, hi[3] = {r1.y, r2.x, r2.y}, pl[4] = {r3.x, r3.y, r4.x, r4.y};
-    const bool inside = (x > lo[0]) & (x < hi[0]) & (y > lo[1]) & (y < hi[1]) & (z > lo[2]) & (z < hi[2]);
-    double dist = x * pl[0] + y * pl[1] + z * pl[2] + pl[3];
-    dist = dist > 0 ? dist : -dist;
-    if (inside & (dist <= radius)) {
-      const size_t ring = ((size_t)sc * P + k) * H + h;
-      atomicOr(&bits[ring * wpr + (w >> 5)], 1u << (w & 31));
-      atomicAdd(&counts[ring], 1);
+  // SA_U candidates per trip: their list entries are loaded together (clamped addresses, the tail masked afterwards), then their SA_U x 5 record loads — two memory round
+  // trips per SA_U candidates.  One candidate per iteration was two DEPENDENT round trips each (entry, then its record), 11 iterations for the longest list of an average
+  // wavefront: 205 us for 64 scans x 2 000 surfels.
+  constexpr int SA_U = 4;
+  const int e0 = off[cell], e1 = off[cell + 1];
+  for (int e = e0; e < e1; e += SA_U) {
+    int k[SA_U];
+#pragma unroll
+    for (int u = 0; u < SA_U; ++u) k[u] = list[min(e + u, e1 - 1)];
+    double2 r[SA_U][5];
+#pragma unroll
+    for (int u = 0; u < SA_U; ++u) {
+      const double2* rec = (const double2*)(aos + 10 * (size_t)k[u]);   // five 16-byte loads: box min | box max | plane
+#pragma unroll
+      for (int j = 0; j < 5; ++j) r[u][j] = rec[j];
+    }
+#pragma unroll
+    for (int u = 0; u < SA_U; ++u) {
+      const double lo[3] = {r[u][0].x, r[u][0].y, r[u][1].x}, hi[3] = {r[u][1].y, r[u][2].x, r[u][2].y}, pl[4] = {r[u][3].x, r[u][3].y, r[u][4].x, r[u][4].y};
+      const bool inside = (x > lo[0]) & (x < hi[0]) & (y > lo[1]) & (y < hi[1]) & (z > lo[2]) & (z < hi[2]);
+      double dist = x * pl[0] + y * pl[1] + z * pl[2] + pl[3];
+      dist = dist > 0 ? dist : -dist;
+      sa_record_hit((e + u < e1) & inside & (dist <= radius), ((size_t)sc * P + k[u]) * H + h, w, lane, wpr, bits, counts);
     }
   }
 }
 // (it also returns the ring's words and count to zero: the work buffer is cleared once, when it is allocated, not 7 MB per scan and call)
 // A WAVEFRONT per ring with hits: lane = mask word (coalesced read + clear), set-bit counts prefix-summed over the lanes, the lane whose word holds the target rank finds
 // the bit.  One thread per ring walked its 57 words serially, one load each, with a handful of lanes of the wavefront alive: 99 us for 64 scans x 2 000 surfels.
+// (Round 5, measured and dropped: a work list of the rings with hits, appended by the hit kernel when a ring's count leaves zero — two thirds of the (scan, plane, ring)
+// triples of a map-like surfel table have hits, and the returning add per run costs the hit kernel far more than this scan.)
 __global__ __launch_bounds__(256) void k_assoc_select(unsigned* __restrict__ bits, int* __restrict__ counts, int S, int H, int W, int P, int wpr, int sel, int* flags) {
   const size_t total = (size_t)S * P * H;
   const size_t ring = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -13,5 +13,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d gpurun_out/${TAG}_pmc_$c -o pmc -- python bench.py --steps 5 --warmup 1 --no-secondary --no-cpu-baseline > gpurun_out/${TAG}_pmc_$c.log 2>&1
 done
 python tools/pmc_summary.py gpurun_out/${TAG}_pmc_FETCH_SIZE gpurun_out/${TAG}_pmc_WRITE_SIZE > gpurun_out/${TAG}_pmc_hbm.txt
-python tools/make_traffic_json.py gpurun_out/${TAG}_pmc_FETCH_SIZE gpurun_out/${TAG}_pmc_WRITE_SIZE "profiles/${TAG}_pmc_hbm_traffic.txt" > gpurun_out/${TAG}_latest_traffic.json
 tail -1 gpurun_out/${TAG}_bench.json | cut -c1-600
