@@ -28,6 +28,7 @@ _d = O._d
 DIRECT1 = 1
 DIRECT7 = 7
 DIRECT26 = 26
+KDTREE = 0       # radiusSearch over the leaf centroids (ndt_omp_impl.hpp:234-236; voxel_grid_covariance_omp.h:473-502): what pcl::NormalDistributionsTransform itself does
 REL7 = np.array([[0, 0, 0], [1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.int32)   # voxel_grid_covariance_omp_impl.hpp:427-434
 
 
@@ -152,23 +153,46 @@ class NdtAligner:
         self.res, self.search, self.step_size, self.outlier_ratio = float(resolution), search, step_size, outlier_ratio
         self.eps, self.max_iterations, self.min_pts = transformation_epsilon, max_iterations, min_pts
         self.vox = O.voxel_build(self.target, np.float32(resolution), min_pts)
-        self.rel = rel_cells(search)
+        self.rel = rel_cells(search) if search != KDTREE else None
+        if search == KDTREE:
+            # kdtree_ over voxel_centroids_: the float centroids of the leaves that had >= min_points points when the filter ran (voxel_grid_covariance_omp_impl.hpp:301-317;
+            # leaves rejected afterwards by the eigenvalue test stay in the tree with nr_points = -1: none occurs on the demo clouds)
+            from scipy.spatial import cKDTree
+            self.kd_sel = np.flatnonzero(np.abs(self.vox["leaf_n"]) >= min_pts).astype(np.int32)
+            self.kd = cKDTree(self.vox["centroid"][self.kd_sel].astype(np.float64))
         self.mean, self.icov = np.ascontiguousarray(self.vox["mean"]), np.ascontiguousarray(self.vox["icov"])
         self.n_eval = 0
         self.trace = []
 
     # -- the three evaluations of the loop ------------------------------------------------------------------------------------------------------
+    def _neighbourhood(self, trans):
+        """Leaf ids per transformed point, one row per point, -1 = empty slot: the cells of the direct searches, or the leaves whose centroid lies within `resolution` of the
+        point (KDTREE: radiusSearch(x_trans_pt, resolution_, ...), sorted by distance as FLANN returns them)."""
+        if self.search != KDTREE:
+            return voxel_lookup_rel(self.vox, trans, np.float32(self.res), self.rel, self.min_pts)
+        q = trans[:, :3].astype(np.float64)
+        found = self.kd.query_ball_point(q, self.res)
+        width = max(1, max(len(f) for f in found))
+        ids = np.full((len(trans), width), -1, np.int32)
+        cen = self.kd.data
+        for i, f in enumerate(found):
+            if f:
+                f = np.asarray(f)
+                order = np.argsort(((cen[f] - q[i]) ** 2).sum(1), kind="stable")
+                ids[i, :len(f)] = self.kd_sel[f[order]]
+        return ids
+
     def _derivatives(self, trans, p, compute_hessian=True):
         self.n_eval += 1
         score = C.c_double(0)
         g, H = np.zeros(6), np.zeros((6, 6))
-        ids = voxel_lookup_rel(self.vox, trans, np.float32(self.res), self.rel, self.min_pts)
+        ids = self._neighbourhood(trans)
         O.lib().orc_ndt_derivatives_n(C.c_int(len(self.src)), _p(self.src), _p(trans), C.c_int(ids.shape[1]), _p(ids), _p(self.mean), _p(self.icov), _p(_d(p)), C.c_double(self.res),
                                       C.c_double(self.outlier_ratio), C.c_int(1 if compute_hessian else 0), C.byref(score), _p(g), _p(H))
         return score.value, g, H
 
     def _hessian(self, trans, p):
-        ids = voxel_lookup_rel(self.vox, trans, np.float32(self.res), self.rel, self.min_pts)
+        ids = self._neighbourhood(trans)
         H = np.zeros((6, 6))
         O.lib().orc_ndt_hessian(C.c_int(len(self.src)), _p(self.src), _p(trans), C.c_int(ids.shape[1]), _p(ids), _p(self.mean), _p(self.icov), _p(_d(p)), C.c_double(self.res),
                                 C.c_double(self.outlier_ratio), _p(H))

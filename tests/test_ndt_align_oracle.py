@@ -3,7 +3,8 @@ src/ndt_omp/data through apps/align.cpp's settings (0.1 m VoxelGrid, resolution 
 the fitness scores of src/ndt_omp/README.md:8-41 (pcl / KDTREE 0.213937, DIRECT7 0.214205, DIRECT1 0.208511).
 
 What is held, and why not to six digits (measured in this file, numbers in DESIGN.md "NDT pin"):
-  * The restated loop with the reference's defaults stops after 4 (DIRECT7) / 3 (DIRECT1) Newton iterations at fitness 0.204505 / 0.224965: 4.5 % / 7.9 % from the README.
+  * The restated loop with the reference's defaults stops after 4 (DIRECT7) / 3 (DIRECT1) / 4 (KDTREE = pcl's own search) Newton iterations at fitness 0.204505 /
+    0.224965 / 0.206161: 4.5 % / 7.9 % / 3.6 % from the README.
   * Driven to its fixed point (transformation_epsilon 1e-5) the same loop ends at 0.216489 / 0.216469 for BOTH searches: 1.1 % from the README's DIRECT7 / KDTREE
     values.  The README's three values lie between the early stop and the fixed point.
   * The statistic itself is steep: around the optimum it moves 0.5 - 0.9 % per milliradian of rotation and 0.15 % per centimetre (test below), and the default loop stops
@@ -23,7 +24,7 @@ from oracle import ndt_align as NA
 from oracle import oracle as O
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-README = {"pcl": 0.213937, NA.DIRECT7: 0.214205, NA.DIRECT1: 0.208511}     # /root/reference/src/ndt_omp/README.md:11,21,26 (and :16,31,36,41)
+README = {"pcl": 0.213937, NA.KDTREE: 0.213937, NA.DIRECT7: 0.214205, NA.DIRECT1: 0.208511}     # /root/reference/src/ndt_omp/README.md:11,16,21,26 (and :31,36,41)
 
 
 @pytest.fixture(scope="module")
@@ -97,7 +98,7 @@ def test_double_hessian_equals_the_float_one_to_float_rounding(clouds):
     assert np.abs(Hf - Hd).max() <= 1e-6 * np.abs(Hd).max() and np.abs(Hd - Hd.T).max() <= 1e-12 * np.abs(Hd).max()
 
 
-@pytest.mark.parametrize("search,own,iters", [(NA.DIRECT7, 0.204505, 4), (NA.DIRECT1, 0.224965, 3)])
+@pytest.mark.parametrize("search,own,iters", [(NA.DIRECT7, 0.204505, 4), (NA.DIRECT1, 0.224965, 3), (NA.KDTREE, 0.206161, 4)])
 def test_demo_alignment_default_settings(clouds, search, own, iters):
     td, sd = clouds
     a = NA.NdtAligner(td, 1.0, search)
