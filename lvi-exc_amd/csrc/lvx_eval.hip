@@ -771,8 +771,8 @@ template <class F> struct MfmaGeom {
 };
 template <class F> size_t mfma_lds_bytes(int cr) {
   const int LV = (cr + 5) * 6;
-  return (size_t)(LV * ACC_BW + F::NG * LV + F::NG * F::NG + LV + F::NG + 4 * MfmaGeom<F>::PR * MfmaGeom<F>::LDP) * 8 + (F::USE_PRE ? (size_t)(cr + 4) * sizeof(So3Pre) : 0) +
-         (size_t)(LV + F::NG) * 4 + 64;
+  return (size_t)(LV * ACC_BW + F::NG * LV + F::NG * F::NG + LV + F::NG + 64 + 4 * MfmaGeom<F>::PR * MfmaGeom<F>::LDP) * 8 + (F::USE_PRE ? (size_t)(cr + 4) * sizeof(So3Pre) : 0) +
+         (size_t)(LV + F::NG) * 4 + 64;   // + 64 dummy slots of the panel-major families' branch-free scatter
 }
 
 // CR = knot intervals per workgroup, chosen per problem by the host (pick_chunk) so that the workgroup count fills whole rounds of the CUs
@@ -788,7 +788,8 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
   double* acc_gg = acc_bd + NG * ACC_LV;              // [NG][NG]
   double* acc_gk = acc_gg + NG * NG;                  // [ACC_LV]
   double* acc_gG = acc_gk + ACC_LV;                   // [NG]
-  double* panels = acc_gG + NG;                       // 4 x [PR][LDP]
+  const int dummy = (int)(acc_gG + NG - sm);          // 64 doubles: where a lane adds +0.0 when its tile position has no accumulator entry (branch-free scatter)
+  double* panels = acc_gG + NG + 64;                  // 4 x [PR][LDP]
   So3Pre* pre_tab = (So3Pre*)(panels + 4 * PR * LDP); // [CR + 4] control-point pairs (k_lo + e, k_lo + e + 1), families with USE_PRE
   int* kpos = (int*)(pre_tab + (F::USE_PRE ? CR + 4 : 0));   // [ACC_LV]
   int* gpos = kpos + ACC_LV;                          // [NG]
@@ -979,15 +980,16 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
           for (; ks < nks; ks += 2) trip(ks, std::integral_constant<int, 2>{});
           KT(3)
           const int wbB = wb * ACC_BW;
+          // branch-free: every lane issues every LDS add — to its accumulator entry, or +0.0 to a dummy slot of its own (no entry at this tile position, or beyond the
+          // accumulator window).  A `continue` per slot made every slot a basic block: branch + exec-mask juggling + the wait for the MFMA result, slot after slot
 #pragma unroll
           for (int t = 0; t < G::NTP; ++t)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
               const int te = rtab[t * 4 + v];
-              const double val = D[t][v];
-              if (te < 0 || val == 0.0 || wb + (te >> 18) >= ACC_LV) continue;
+              const bool ok = te >= 0 && wb + (te >> 18) < ACC_LV;
               const int m = (te >> 16) & 3;
-              atomicAdd(&sm[(te & 0xffff) + (m == 2 ? wbB : (m == 1 ? wb : 0))], val);
+              atomicAdd(&sm[ok ? (te & 0xffff) + (m == 2 ? wbB : (m == 1 ? wb : 0)) : dummy + lane], ok ? D[t][v] : 0.0);
             }
           KT(4)
         }
@@ -1047,7 +1049,9 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
         __builtin_amdgcn_wave_barrier();
         KT(3)
       }
-      // window accumulators -> workgroup accumulators (LDS atomics; other waves work on overlapping windows)
+      // window accumulators -> workgroup accumulators (LDS atomics; other waves work on overlapping windows).  (Round 5, measured: the table-driven branch-free scatter that
+      // took 6 % off the IMU kernel makes this one 8 % slower — at two wavefronts per SIMD the branches hide behind the other wavefront, while the unconditional adds of the
+      // structurally zero and lower-triangle entries load the LDS atomic unit.)
       {
       int t = 0;
 #pragma unroll
@@ -1166,7 +1170,7 @@ template <class PG> __device__ __forceinline__ void imu_build_rtab(int* rtab, in
       }
 }
 // rows of this wavefront's 64 lanes -> panel by panel -> windows (runs of equal knot interval) -> MFMA -> LDS accumulators
-template <class PG> __device__ __forceinline__ void imu_assemble(double* sm, double* P, const int* rtab, bool valid, int key, int k_lo, int acc_lv, const double* r, const double (*J)[PG::NCJ], int lane) {
+template <class PG> __device__ __forceinline__ void imu_assemble(double* sm, double* P, const int* rtab, bool valid, int key, int k_lo, int acc_lv, const double* r, const double (*J)[PG::NCJ], int lane, int dummy) {
   constexpr int NR = PG::NR, NT = PG::NT, LDP = PG::LDP, PR = PG::PR, GL = PG::GL;
   const unsigned long long vm = __ballot(valid);
   for (int g0 = 0; g0 < 64; g0 += GL) {
@@ -1227,15 +1231,18 @@ template <class PG> __device__ __forceinline__ void imu_assemble(double* sm, dou
       for (; ks + 6 <= nks; ks += 6) trip(ks, std::integral_constant<int, 6>{});
       for (; ks < nks; ks += 2) trip(ks, std::integral_constant<int, 2>{});
       const int wbB = wb * ACC_BW;
+      // BRANCH-FREE scatter: every lane issues every LDS add — to its accumulator entry, or +0.0 to a dummy slot of its own when the tile position has no entry (lower
+      // triangle, padding) or lies beyond the window.  With a `continue` per slot every slot was a basic block of its own: exec-mask juggling, a branch and the 76-cycle
+      // wait for the MFMA result, one slot after the other (180 cycles per slot on the one wavefront per SIMD this kernel runs at).
 #pragma unroll
       for (int t = 0; t < PG::NTP; ++t)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int te = rtab[t * 4 + v];
-          const double val = D[t][v];
-          if (te < 0 || val == 0.0 || wb + (te >> 18) >= acc_lv) continue;
+          const bool ok = te >= 0 && wb + (te >> 18) < acc_lv;
           const int m = (te >> 16) & 3;
-          atomicAdd(&sm[(te & 0xffff) + (m == 2 ? wbB : (m == 1 ? wb : 0))], val);
+          const int idx = ok ? (te & 0xffff) + (m == 2 ? wbB : (m == 1 ? wb : 0)) : dummy + lane;
+          atomicAdd(&sm[idx], ok ? D[t][v] : 0.0);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1261,7 +1268,7 @@ struct ImuOwn { const int* wg_c0; const int* own_k; int nch, span; };   // batch
 #define LVX_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 static size_t imu_fused_lds_bytes(int span) {
   const int pan = std::max((int)ImuG::PR * (int)ImuG::LDP, (int)ImuA::PR * (int)ImuA::LDP);
-  return (size_t)(IMU_LV * ACC_BW + IMU_NGA * IMU_LV + IMU_NGA * IMU_NGA + IMU_LV + IMU_NGA + 4 * pan) * 8 + (size_t)span * sizeof(So3Pre) + (size_t)(7 * span + IMU_NGA) * 4 + 64;
+  return (size_t)(IMU_LV * ACC_BW + IMU_NGA * IMU_LV + IMU_NGA * IMU_NGA + IMU_LV + IMU_NGA + 64 + 4 * pan) * 8 + (size_t)span * sizeof(So3Pre) + (size_t)(7 * span + IMU_NGA) * 4 + 64;
 }
 // the per-lane scatter targets of both geometries are constants of the kernel: built once per layout (64 lanes x 16 entries) instead of by every
 // wavefront of every workgroup (~4 k cycles of integer divisions and branches each)
@@ -1283,7 +1290,7 @@ __global__ __launch_bounds__(256, 1) void k_imu_own(ImuFused fam, DevCommon cm, 
   double* sm = smo;
   ImuAccLds A;
   A.band = sm; A.bd = A.band + ACC_LV * ACC_BW; A.gg = A.bd + IMU_NGA * ACC_LV; A.gk = A.gg + IMU_NGA * IMU_NGA; A.gG = A.gk + ACC_LV; A.lv = ACC_LV;
-  double* panels = A.gG + IMU_NGA;
+  double* panels = A.gG + IMU_NGA + 64;              // (64 dummy slots of the branch-free scatter sit between the accumulators and the panels)
   So3Pre* pre_all = (So3Pre*)(panels + 4 * PAN);     // [span] pairs (k_base + e, k_base + e + 1)
   int* kpos_all = (int*)(pre_all + ow.span);         // [6 span] band / border position of every tangent scalar of the range
   int* kown_all = kpos_all + 6 * ow.span;            // [span] owner of the knot's columns
@@ -1376,7 +1383,7 @@ __global__ __launch_bounds__(256, 1) void k_imu_own(ImuFused fam, DevCommon cm, 
           mycost += 0.5 * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
           if (cm.residuals) { const long long orow = row0_g + (long long)fam.perm[si] * 3; cm.residuals[orow] = r[0]; cm.residuals[orow + 1] = r[1]; cm.residuals[orow + 2] = r[2]; }
         }
-        if (want_ne) imu_assemble<ImuG>(sm, P, rtg, valid, key, k_lo, ACC_LV, r, J, lane);
+        if (want_ne) imu_assemble<ImuG>(sm, P, rtg, valid, key, k_lo, ACC_LV, r, J, lane, NACC);
         IKT(2)
       }
       {   // accelerometer block (accel_residual, lvx_resid.h)
@@ -1416,7 +1423,7 @@ __global__ __launch_bounds__(256, 1) void k_imu_own(ImuFused fam, DevCommon cm, 
           mycost += 0.5 * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
           if (cm.residuals) { const long long orow = row0_a + (long long)fam.perm[si] * 3; cm.residuals[orow] = r[0]; cm.residuals[orow + 1] = r[1]; cm.residuals[orow + 2] = r[2]; }
         }
-        if (want_ne) imu_assemble<ImuA>(sm, P, rta, valid, key, k_lo, ACC_LV, r, J, lane);
+        if (want_ne) imu_assemble<ImuA>(sm, P, rta, valid, key, k_lo, ACC_LV, r, J, lane, NACC);
         IKT(3)
       }
     }
