@@ -1138,8 +1138,10 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
 //   G: 3 rows x [12 rotation columns | b_g (3) | r]  = 16 columns, one MFMA tile;     A: 3 rows x [24 knot columns | roll pitch b_a (5) | r] = 30, three tile pairs.
 // Shared global list: [roll, pitch, b_a (3), b_g (3)] = tangent scalars 6 N + 0 .. 7.
 // ---------------------------------------------------------------------------------------------------------
-struct ImuG { enum { NR = 3, NCJ = GYRO_NC, NK = 12, NG = 3, KPK = 3, LVO = 3, GL = 32, GOFF = 5, NKL = 12, NCL = 16, NT = 1, NTP = 1, LDP = 17, PR = 96 }; };
-struct ImuA { enum { NR = 3, NCJ = ACC_NC, NK = 24, NG = 5, KPK = 6, LVO = 0, GL = 16, GOFF = 0, NKL = 24, NCL = 30, NT = 2, NTP = 3, LDP = 33, PR = 48 }; };
+// LDP (panel row stride in doubles) is EVEN: rows start on 16 bytes and are written two columns per ds_write_b128 (odd strides took one ds_write_b64 per column with a
+// quarter / half of the lanes active; the fragment reads — four rows x 16 consecutive columns per instruction — hit every bank at most three times either way)
+struct ImuG { enum { NR = 3, NCJ = GYRO_NC, NK = 12, NG = 3, KPK = 3, LVO = 3, GL = 32, GOFF = 5, NKL = 12, NCL = 16, NT = 1, NTP = 1, LDP = 18, PR = 96 }; };
+struct ImuA { enum { NR = 3, NCJ = ACC_NC, NK = 24, NG = 5, KPK = 6, LVO = 0, GL = 16, GOFF = 0, NKL = 24, NCL = 30, NT = 2, NTP = 3, LDP = 34, PR = 48 }; };
 #define IMU_NGA 8
 struct ImuAccLds { double* band; double* bd; double* gg; double* gk; double* gG; int lv; };
 template <class PG> __device__ __forceinline__ int imu_cls(int lc) {
@@ -1181,12 +1183,10 @@ template <class PG> __device__ __forceinline__ void imu_assemble(double* sm, dou
       const int li = lane - g0;
 #pragma unroll
       for (int a = 0; a < NR; ++a) {
-        double* prow = P + (li * NR + a) * LDP;
+        double2* prow2 = (double2*)(P + (li * NR + a) * LDP);
+        auto col = [&](int c) { return c < PG::NK + PG::NG ? (valid ? J[a][c] : 0.0) : (c == PG::NK + PG::NG ? (valid ? r[a] : 0.0) : 0.0); };   // [knots | globals | residual | tile padding (the other geometry's data sits there)]
 #pragma unroll
-        for (int c = 0; c < PG::NK + PG::NG; ++c) prow[c] = valid ? J[a][c] : 0.0;
-        prow[PG::NK + PG::NG] = valid ? r[a] : 0.0;
-#pragma unroll
-        for (int c = PG::NCL; c < 16 * NT; ++c) prow[c] = 0.0;   // tile padding (the two geometries share the panel memory: the other one's data sits here)
+        for (int c2 = 0; c2 < 8 * NT; ++c2) prow2[c2] = make_double2(col(2 * c2), col(2 * c2 + 1));
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1303,7 +1303,9 @@ __global__ __launch_bounds__(256, 1) void k_imu_own(ImuFused fam, DevCommon cm, 
   const bool want_ne = (cm.what & LVX_EVAL_NORMAL_EQ) != 0;
   constexpr int NACC = ACC_LV * ACC_BW + IMU_NGA * ACC_LV + IMU_NGA * IMU_NGA + ACC_LV + IMU_NGA;
   for (int e = tid; e < NACC; e += 256) sm[e] = 0.0;   // (the panels need no clearing: every row a k-step reads is rewritten, the padding columns with it)
+  int* urng = gpos + IMU_NGA;                        // [2]: first / last accumulator row of a batch end whose columns this workgroup does not store
   if (tid < IMU_NGA) gpos[tid] = cm.ord[6 * cm.N + tid];
+  if (tid == 0) { urng[0] = 1 << 30; urng[1] = -1; }
   const int k_base = chunk_off[ow.nch + 1 + c0] - 1;   // one interval of slack below the first batch's first interval (a non-zero IMU time offset moves a sample by at most one)
   for (int e = tid; e < 6 * ow.span; e += 256) { const int kn = k_base + e / 6; kpos_all[e] = (kn >= 0 && kn < cm.N) ? cm.ord[6 * kn + e % 6] : LVX_DEAD; }
   for (int e = tid; e < ow.span; e += 256) {
@@ -1433,11 +1435,16 @@ __global__ __launch_bounds__(256, 1) void k_imu_own(ImuFused fam, DevCommon cm, 
     const bool more = c + 1 < c1;
     const int nfl = more ? min(ACC_LV, max(0, 6 * (chunk_off[ow.nch + 1 + c + 1] - 1 - k_lo))) : ACC_LV;
     const int* kown = kown_all + woff;   // per knot
-    const int any_unowned = __syncthreads_or(bt < nfl && kpos[bt] != LVX_DEAD && kown[bt / 6] != wg);   // (the barrier: every wavefront's sums are in the LDS accumulators)
+    const bool un_ = bt < nfl && kpos[bt] != LVX_DEAD && kown[bt / 6] != wg;
+    { const unsigned long long ub = __ballot(un_);
+      if (ub && lane == 0) { atomicMin(&urng[0], wv * 64 + __ffsll((long long)ub) - 1); atomicMax(&urng[1], wv * 64 + 63 - __clzll((long long)ub)); } }
+    const int any_unowned = __syncthreads_or(un_);   // (the barrier: every wavefront's sums are in the LDS accumulators)
     IKT(4)
     if (any_unowned) {
-      // rare (a range's first / last batch, the hub gap, hub knots = border rows): columns this workgroup does not store keep the cleared-and-added protocol
-      for (int e = bt; e < nfl * ACC_BW; e += 256) {
+      // a range's first / last batch, the hub gap, hub knots = border rows: columns this workgroup does not store keep the cleared-and-added protocol.  Only the rows
+      // [r0, r1) between the first and the last such column are walked (a handful of knots at a range boundary; walking all 222 rows cost 17 k cycles per such batch)
+      const int r0 = urng[0], r1 = urng[1] + 1;
+      for (int e = r0 * ACC_BW + bt; e < r1 * ACC_BW; e += 256) {
         const int la = e / ACC_BW, lb = la + e % ACC_BW;
         const int pa = kpos[la], o = kown[la / 6];
         if (o == wg || pa == LVX_DEAD || lb >= ACC_LV) continue;
@@ -1448,7 +1455,7 @@ __global__ __launch_bounds__(256, 1) void k_imu_own(ImuFused fam, DevCommon cm, 
         if (pb != LVX_DEAD) add_H(cm, pa, pb, v, rep);
       }
       for (int gi = 0; gi < IMU_NGA; ++gi)
-        for (int la = bt; la < nfl; la += 256) {
+        for (int la = r0 + bt; la < r1; la += 256) {
           const int pg = gpos[gi], pa = kpos[la], o = kown[la / 6];
           if (pg == LVX_DEAD || pa == LVX_DEAD || (o == wg && pg < 0)) continue;
           const double v = A.bd[gi * ACC_LV + la];
@@ -1460,6 +1467,7 @@ __global__ __launch_bounds__(256, 1) void k_imu_own(ImuFused fam, DevCommon cm, 
         if (v != 0.0) { if (kown[bt / 6] >= 0) atomicOr(cm.err, LVX_ERR_FALLBACK); else add_g(cm, kpos[bt], v, rep); }
       }
       LVX_LDS_BARRIER();   // the register pass below zeroes what it reads
+      if (tid == 0) { urng[0] = 1 << 30; urng[1] = -1; }
     }
     IKT(6)
     {
