@@ -1049,7 +1049,7 @@ static int local_gmax(lvx_ctx* c, SolveWork& w, double* g, double* gsh) {
 // What follows a LVX_EVAL_NORMAL_EQ evaluation, in two halves so that the loop can put ONE collective between them.
 // local_after_eval: the diagonal of J^T J into w.diag (the LM damping in w.lmd — what the solver reads — is untouched until apply_diag), this rank's private
 // gradient max norm, and the shared entries of diagonal / gradient on the host.
-struct EvalLocal { double gm = 0.0; double hd[LVX_N_SHARED] = {0}, hg[LVX_N_SHARED] = {0}; };
+struct EvalLocal { double gm = 0.0; double hd[LVX_N_SHARED] = {0}, hg[LVX_N_SHARED] = {0}; double tau[2] = {0, 0}; bool have_tau = false; };   // tau: the (shared) sensor time offsets of a constrained joint solve
 static int local_after_eval(lvx_ctx* c, SolveWork& w, EvalLocal* e) {
   const int n = c->nb + c->nbd, ns = c->ns;
   hipStream_t st = c->stream;
@@ -1058,6 +1058,11 @@ static int local_after_eval(lvx_ctx* c, SolveWork& w, EvalLocal* e) {
   if (nl > 0) hipLaunchKernelGGL(k_lm_fetch_diag, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, (const double*)c->d_lmH.p, nl, c->lm_ls, c->lm_wl + c->nbd_ext, w.diag + n);
   int rc = local_gmax(c, w, &e->gm, e->hg); if (rc) return rc;
   if (is_joint(c) && ns > 0) LVX_HIP(c, hipMemcpyAsync(e->hd, w.diag + (n - ns), (size_t)ns * 8, hipMemcpyDeviceToHost, st));
+  if (is_joint(c) && w.constrained && c->last_state_d) {   // the shared time offsets' box enters the projected gradient of the SUMMED shared gradient (apply_diag)
+    LVX_HIP(c, hipMemcpyAsync(&e->tau[0], c->last_state_d + 7 * (size_t)c->N + 23, 8, hipMemcpyDeviceToHost, st));
+    LVX_HIP(c, hipMemcpyAsync(&e->tau[1], c->last_state_d + 7 * (size_t)c->N + 31, 8, hipMemcpyDeviceToHost, st));
+    e->have_tau = true;
+  }
   LVX_HIP(c, hipStreamSynchronize(st));
   return LVX_OK;
 }
@@ -1079,7 +1084,16 @@ static int apply_diag(lvx_ctx* c, SolveWork& w, bool compute_scale, int use_scal
   bool conv = e.gm <= grad_tol;
   if (buf) {
     conv = !(buf[2 * LVX_N_SHARED] > 0.0);
-    for (int i = 0; i < ns; ++i) { hd[i] = buf[c->sh_slot[i]]; if (std::fabs(buf[LVX_N_SHARED + c->sh_slot[i]]) > grad_tol) conv = false; }
+    for (int i = 0; i < ns; ++i) {
+      hd[i] = buf[c->sh_slot[i]];
+      double gsh = buf[LVX_N_SHARED + c->sh_slot[i]];
+      // a FREE shared time offset (canonical slots 6: lidar, 13: camera) is bounded: its entry of the projected gradient is x - clamp(x - g, -b, b)
+      if (e.have_tau && (c->sh_slot[i] == 6 || c->sh_slot[i] == 13) && c->ord[6 * (size_t)c->N + (c->sh_slot[i] == 6 ? 14 : 21)] != LVX_DEAD) {
+        const double x = e.tau[c->sh_slot[i] == 6 ? 0 : 1];
+        gsh = x - std::min(std::max(x - gsh, -c->sensor_mto), c->sensor_mto);
+      }
+      if (std::fabs(gsh) > grad_tol) conv = false;
+    }
     if (ns > 0) LVX_HIP(c, hipMemcpyAsync(w.diag + (n - ns), hd, (size_t)ns * 8, hipMemcpyHostToDevice, st));   // Jacobi scaling and LM damping use the JOINT diagonal at the shared scalars
   } else for (int i = 0; i < ns; ++i) if (std::fabs(e.hg[i]) > grad_tol) conv = false;
   *grad_converged = conv;
@@ -1095,14 +1109,16 @@ static int apply_diag(lvx_ctx* c, SolveWork& w, bool compute_scale, int use_scal
 }
 // The first evaluation of a solve (and lvx_solve_step_shared): both halves around one sum [cost | joint block | error votes].  lerr: error of the evaluation that
 // has not met a collective yet.
-static int post_eval(lvx_ctx* c, SolveWork& w, bool compute_scale, int use_scaling, double mn, double mx, double* cost, double grad_tol, bool* grad_converged, int lerr) {
+static int post_eval(lvx_ctx* c, SolveWork& w, bool compute_scale, int use_scaling, double mn, double mx, double* cost, double grad_tol, bool* grad_converged, int lerr, double* votes = nullptr) {
   EvalLocal e;
   if (!lerr) lerr = local_after_eval(c, w, &e);
   if (is_joint(c)) {
-    double buf[LVX_JB_N + 2] = {0};
+    double buf[LVX_JB_N + 3] = {0};
     if (!lerr) { joint_block_pack(c, e, grad_tol, buf); buf[LVX_JB_N] = *cost; }
     buf[LVX_JB_N + 1] = lerr ? 1.0 : 0.0;
-    int rc = reduce(c, buf, LVX_JB_N + 2, LVX_REDUCE_SUM); if (rc) return rc;
+    buf[LVX_JB_N + 2] = votes ? *votes : 0.0;   // rides along: e.g. "this rank's problem is constrained" (summed over the ranks)
+    int rc = reduce(c, buf, LVX_JB_N + 3, LVX_REDUCE_SUM); if (rc) return rc;
+    if (votes) *votes = buf[LVX_JB_N + 2];
     if ((rc = leave_together(c, buf[LVX_JB_N + 1], lerr))) return rc;
     *cost = buf[LVX_JB_N];
     return apply_diag(c, w, compute_scale, use_scaling, mn, mx, e, buf, grad_tol, grad_converged);
@@ -1216,10 +1232,13 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
   if (!lerr) lerr = solver_alloc(c, w);
   if (lerr && !joint) return lerr;
   // box constraints (free inverse depths: rho >= 0; a free sensor time offset: |tau| <= max) make the problem constrained in Ceres' sense: projected start point,
-  // projected gradient norm, projected Armijo line search on every trust-region step.  Single sequence only (the joint solve projects its candidates, nothing more).
+  // projected gradient norm, projected Armijo line search on every trust-region step.  In the JOINT solve (round 5) the problem is constrained when ANY rank's is
+  // (a vote that rides on the first reduction); cost, directional derivatives and trial costs of the search are summed over the ranks, so every rank contracts by the
+  // same factor — one more reduction per iteration to decide on the search, one per trial.
   const bool free_rho = c->L > 0 && c->rep.n + c->cs.n > 0 && !(c->locks & LVX_LOCK_LANDMARKS);
   const bool free_tau = (!(c->locks & LVX_LOCK_LIDAR_TAU) && c->surf.n + c->cs.n > 0) || (!(c->locks & LVX_LOCK_CAM_TAU) && c->rep.n + c->cs.n > 0);
-  w.constrained = !joint && !lerr && (free_rho || free_tau);
+  w.constrained = !lerr && (free_rho || free_tau);   // this rank's own view: its start point and its private gradient entries are projected
+  double cons_votes = w.constrained ? 1.0 : 0.0;
   if (!lerr && !joint && w.lm && c->nb > 0) { w.inplace = true; w.Hs = (const double*)c->d_Hb.p; w.Bs = (const double*)c->d_Bd.p; c->p_Hs = w.Hs; }
   hipStream_t st = c->stream;
   const size_t sbytes = (size_t)lvx_state_size(c) * 8;
@@ -1236,7 +1255,8 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
     }
     lerr = lvx_evaluate_d(c, x, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &cost);
   }
-  if ((rc = post_eval(c, w, true, o.jacobi_scaling, o.min_lm_diagonal, o.max_lm_diagonal, &cost, o.gradient_tolerance, &gconv, lerr))) return rc;
+  if ((rc = post_eval(c, w, true, o.jacobi_scaling, o.min_lm_diagonal, o.max_lm_diagonal, &cost, o.gradient_tolerance, &gconv, lerr, &cons_votes))) return rc;
+  const bool ls_on = cons_votes > 0.0;   // the joint problem (or this single sequence) is constrained: every rank runs the line-search protocol
   s.initial_cost = cost;
   double radius = o.initial_radius, decrease_factor = 2.0;
   int invalid = 0;
@@ -1268,14 +1288,28 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
       cand_ne = true; acc_is_x = false;
       if (re == LVX_E_RANGE || re == LVX_E_NONUNIT_QUAT) cand = INFINITY; else if (re) lerr = re;   // a candidate that cannot be evaluated is a rejected step, anything else an error
       if (!lerr && hipMemcpy(h, w.sums + 2, 48, hipMemcpyDeviceToHost) != hipSuccess) lerr = LVX_E_HIP;
-      // projected Armijo line search (constrained single-sequence problem): the full step stays when it decreases the cost by 1e-4 of the linear prediction — the rule
-      if (!lerr && w.constrained && std::isfinite(cand) && m[0] < 0.0 && cand > cost + 1e-4 * m[0]) {
-        const double f0 = cost, g0 = m[0];
+      // projected Armijo line search (constrained problem): the full step stays when it decreases the cost by 1e-4 of the linear prediction — the rule.  Joint solve:
+      // every quantity the search decides on is the SUM over the ranks (costs, directional derivatives); a rank that fails votes and all leave together.
+      auto jsum = [&](double* v, int n, int err) -> int {   // v[n - 1] is the vote slot
+        if (!joint) return err;
+        v[n - 1] = err ? 1.0 : 0.0;
+        int r_ = reduce(c, v, n, LVX_REDUCE_SUM); if (r_) return r_;
+        return leave_together(c, v[n - 1], err);
+      };
+      double cand_g = cand, m0_g = m[0];
+      if (ls_on && joint) {   // decide together: the candidate's JOINT cost against the joint linear prediction
+        double b4[4] = {std::isfinite(cand) ? cand : 0.0, m[0], std::isfinite(cand) ? 0.0 : 1.0, 0.0};
+        if (lerr) { b4[0] = b4[1] = b4[2] = 0.0; }
+        if ((rc = jsum(b4, 4, lerr))) return rc;
+        cand_g = b4[2] > 0.0 ? INFINITY : b4[0]; m0_g = b4[1];
+      }
+      if (!lerr && ls_on && std::isfinite(cand_g) && m0_g < 0.0 && cand_g > cost + 1e-4 * m0_g) {
+        const double f0 = cost, g0 = m0_g;
         double g1 = 0.0;
-        if ((lerr = grad_dot(c, w, &g1))) return lerr;
-        LsSample prev{0, 0, 0, false}, cur{1.0, cand, g1, true};
+        { int le = grad_dot(c, w, &g1); double b2[2] = {le ? 0.0 : g1, 0.0}; if ((rc = jsum(b2, 2, le))) return rc; g1 = b2[0]; }
+        LsSample prev{0, 0, 0, false}, cur{1.0, cand_g, g1, true};
         bool have_prev = false, found = false;
-        double alpha = 1.0, fa = cand, ha[6] = {h[0], h[1], 0, 0, 0, 0};
+        double alpha = 1.0, fa = cand, ha[6] = {h[0], h[1], 0, 0, h[4], h[5]};
         const int ntg = lvx_tangent_size(c);
         std::vector<double> dh((size_t)ntg);
         LVX_HIP(c, hipMemcpyAsync(dh.data(), w.delta, (size_t)ntg * 8, hipMemcpyDeviceToHost, st));
@@ -1291,28 +1325,38 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
           for (int i = 0; i < ntg; ++i) dt[i] = a * dh[i];
           LVX_HIP(c, hipMemcpyAsync(w.delta, dt.data(), (size_t)ntg * 8, hipMemcpyHostToDevice, st));
           LVX_HIP(c, hipMemsetAsync(w.sums + 2, 0, 48, st));
-          hipLaunchKernelGGL(k_plus, dim3((unsigned)((N + 1 + L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, N, L, c->locks, xt, w.sums, 0, c->sensor_mto, w.tk ? w.tk + 7 : nullptr);
-          double f = 0;
-          const int re2 = lvx_evaluate_d(c, xt, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &f);
-          if (re2 == LVX_E_RANGE || re2 == LVX_E_NONUNIT_QUAT) { cur.x = a; continue; }   // a trial that cannot be evaluated: contract again without a new sample
-          if (re2) return re2;
-          if (f <= f0 + 1e-4 * a * g0) {
-            if (hipMemcpy(ha, w.sums + 2, 48, hipMemcpyDeviceToHost) != hipSuccess) return LVX_E_HIP;
+          hipLaunchKernelGGL(k_plus, dim3((unsigned)((N + 1 + L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, N, L, c->locks, xt, w.sums, joint ? 1 : 0, c->sensor_mto, w.tk ? w.tk + 7 : nullptr);
+          double f = 0, ga = 0.0, htr[6] = {0, 0, 0, 0, 0, 0};
+          int le = lvx_evaluate_d(c, xt, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &f);
+          bool bad = le == LVX_E_RANGE || le == LVX_E_NONUNIT_QUAT;   // a trial that cannot be evaluated: contract again without a new sample
+          if (bad) le = LVX_OK;
+          if (!le && !bad && hipMemcpy(htr, w.sums + 2, 48, hipMemcpyDeviceToHost) != hipSuccess) le = LVX_E_HIP;
+          if (!le && !bad) {   // the directional derivative along the UNSCALED step (needed when the trial fails Armijo; joint: always taken, one reduction per trial)
+            LVX_HIP(c, hipMemcpyAsync(w.delta, dh.data(), (size_t)ntg * 8, hipMemcpyHostToDevice, st));
+            le = grad_dot(c, w, &ga);
+            if (!le) LVX_HIP(c, hipMemcpyAsync(w.delta, dt.data(), (size_t)ntg * 8, hipMemcpyHostToDevice, st));   // delta (device) stays the scaled step of this trial
+          }
+          double f_g = f, ga_g = ga;
+          if (joint) {
+            double b4[4] = {(le || bad) ? 0.0 : f, (le || bad) ? 0.0 : ga, bad ? 1.0 : 0.0, 0.0};
+            if ((rc = jsum(b4, 4, le))) return rc;
+            f_g = b4[0]; ga_g = b4[1]; bad = b4[2] > 0.0;
+          } else if (le) return le;
+          if (bad) { cur.x = a; continue; }
+          if (f_g <= f0 + 1e-4 * a * g0) {
+            for (int q = 0; q < 6; ++q) ha[q] = htr[q];
             alpha = a; fa = f; found = true; break;
           }
-          double ga = 0.0;
-          LVX_HIP(c, hipMemcpyAsync(w.delta, dh.data(), (size_t)ntg * 8, hipMemcpyHostToDevice, st));   // directional derivative along the UNSCALED step
-          if ((lerr = grad_dot(c, w, &ga))) return lerr;
-          prev = cur; have_prev = true; cur = LsSample{a, f, ga, true};
+          prev = cur; have_prev = true; cur = LsSample{a, f_g, ga_g, true};
         }
         if (found) { cand = fa; for (int q = 0; q < 6; ++q) h[q] = ha[q]; }   // delta (device) = alpha x the trust-region step, xt and the accumulators belong to it
         else {   // no step satisfies Armijo: the full step stays (Ceres leaves delta alone) — put its candidate back
           LVX_HIP(c, hipMemcpyAsync(w.delta, dh.data(), (size_t)ntg * 8, hipMemcpyHostToDevice, st));
           LVX_HIP(c, hipMemsetAsync(w.sums + 2, 0, 48, st));
-          hipLaunchKernelGGL(k_plus, dim3((unsigned)((N + 1 + L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, N, L, c->locks, xt, w.sums, 0, c->sensor_mto, w.tk ? w.tk + 7 : nullptr);
-          const int re3 = lvx_evaluate_d(c, xt, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &cand);
-          if (re3) return re3;
-          if (hipMemcpy(h, w.sums + 2, 48, hipMemcpyDeviceToHost) != hipSuccess) return LVX_E_HIP;
+          hipLaunchKernelGGL(k_plus, dim3((unsigned)((N + 1 + L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, N, L, c->locks, xt, w.sums, joint ? 1 : 0, c->sensor_mto, w.tk ? w.tk + 7 : nullptr);
+          int re3 = lvx_evaluate_d(c, xt, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &cand);
+          if (!re3 && hipMemcpy(h, w.sums + 2, 48, hipMemcpyDeviceToHost) != hipSuccess) re3 = LVX_E_HIP;
+          if (joint) { double b1[1] = {0.0}; if ((rc = jsum(b1, 1, re3))) return rc; } else if (re3) return re3;
         }
         (void)alpha;
       }

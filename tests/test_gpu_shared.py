@@ -57,6 +57,10 @@ class JointOracle:
         m1[7 * N1 + 16:7 * N1 + 32] = False     # shared blocks counted once
         self.mask = np.concatenate([m0, m1])
 
+    @property
+    def tangent_size(self):
+        return self.nt[0] + self.nt[1]
+
     def split(self, x):
         return x[:self.ns[0]], x[self.ns[0]:]
 
@@ -85,7 +89,17 @@ class JointOracle:
         return np.concatenate([self.o[0].plus(xs[0], d0), self.o[1].plus(xs[1], d1)])
 
 
-def _run_ranks(seqs, body):
+def _joint_bounds(J, seqs):
+    """The joint problem's box constraints for oracle/lm.py: every free inverse depth of every sequence, rho >= 0 (tangent index, state index, lower, upper)."""
+    bnd = []
+    for r, (P, _) in enumerate(seqs):
+        N, L = P["n_knots"], P["n_landmarks"]
+        t0, s0 = (0, 0) if r == 0 else (J.nt[0], J.ns[0])
+        bnd += [(t0 + 6 * N + 22 + l, s0 + 7 * N + 32 + l, 0.0, np.inf) for l in range(L)]
+    return bnd
+
+
+def _run_ranks(seqs, body, locks=TAU):
     """body(rank, ctx, allreduce) in one thread per rank; returns the per-rank results."""
     ar = sharded.ThreadAllReduce(WORLD)
     res, err = [None] * WORLD, [None] * WORLD
@@ -93,7 +107,7 @@ def _run_ranks(seqs, body):
     def work(r):
         try:
             g = lvx.Context(0)
-            lvx.load_problem(g, seqs[r][0], TAU)
+            lvx.load_problem(g, seqs[r][0], locks)
             res[r] = body(r, g, ar.rank_fn(r))
             g.close()
         except BaseException as e:   # noqa: BLE001
@@ -137,7 +151,7 @@ def test_shared_lm_matches_joint_oracle_lm():
     seqs = _sequences()
     J = JointOracle(seqs)
     x0 = np.concatenate([s for _, s in seqs])
-    xo, so = lm.lm_solve(J, x0, J.free, max_iterations=12, mask=J.mask)
+    xo, so = lm.lm_solve(J, x0, J.free, max_iterations=12, mask=J.mask, constrained=_joint_bounds(J, seqs))   # free inverse depths: the joint problem is constrained (line search)
     res = _run_ranks(seqs, lambda r, g, allreduce: g.lm_solve_shared(seqs[r][1], allreduce, max_iterations=12))
     for r in range(WORLD):
         sg = res[r][1]
@@ -164,10 +178,17 @@ def test_collectives_per_iteration_and_failure_leaves_together():
         g.collective_count(reset=True)
         x, s = g.lm_solve_shared(seqs[r][1], allreduce, max_iterations=6)
         return s, g.collective_count()
-    res = _run_ranks(seqs, body)
+    res = _run_ranks(seqs, body, locks=TAU | lvx.LOCK_LANDMARKS)      # nothing bounded is free: the unconstrained schedule
     for s, n in res:
         acc = int(np.sum(np.asarray(s["accepted"]) == 1))
         assert n == 1 + 2 * s["iterations"] + (1 if s["termination"] == "max_iterations" and s["accepted"][-1] != 1 else 0) and acc >= 1
+    # free inverse depths (rho >= 0): the joint problem is constrained — one more reduction per iteration (the candidate's joint cost decides on the line search), and when a
+    # search runs, one for the directional derivative at the full step and one per trial
+    res = _run_ranks(seqs, body)
+    for s, n in res:
+        base = 1 + 3 * s["iterations"] + (1 if s["termination"] == "max_iterations" and s["accepted"][-1] != 1 else 0)
+        assert n >= base and n <= base + 22 * s["iterations"]
+    assert res[0][1] == res[1][1]                                        # both ranks met the same collectives
     # rank 1's sequence has an IMU sample beyond the spline: its evaluation returns LVX_E_RANGE; rank 0 must come back with LVX_E_COMM
     P1 = dict(seqs[1][0]); P1["t_imu"] = P1["t_imu"].copy(); P1["t_imu"][-1] = P1["t0"] + (P1["n_knots"] - 3) * P1["dt"] + 0.5
     bad = [seqs[0], (P1, seqs[1][1])]
@@ -188,8 +209,8 @@ def test_rccl_transport_single_rank_equals_plain_solve():
     box has — must reproduce the single-sequence solve; the multi-rank protocol is the one the callback transport tests above."""
     P, x0 = _sequences()[0]
     g = lvx.Context(0)
-    # inverse depths constant: with free ones the single-sequence solve is CONSTRAINED in Ceres' sense (projected line search, projected gradient norm — lvx_solver.hip,
-    # oracle/lm.py), the joint solve only projects its candidates, and the two legitimately part ways once a step gets contracted
+    # inverse depths constant: the plain two-reductions-per-iteration schedule asserted below (free ones make the problem CONSTRAINED in Ceres' sense — projected line search,
+    # projected gradient norm — in the single-sequence AND, since round 5, in the joint solve, which then takes a third reduction per iteration)
     lvx.load_problem(g, P, TAU | lvx.LOCK_LANDMARKS)
     xa, sa = g.lm_solve(x0, max_iterations=8)
     g.rccl_init(g.rccl_unique_id(), 0, 1)
@@ -227,3 +248,64 @@ def test_rccl_and_callback_transports_agree_on_one_rank():
     assert np.abs(xa - xb).max() <= 1e-7
     assert np.abs(xa[7 * N:7 * N + 32] - xc[7 * N:7 * N + 32]).max() <= 1e-7
     g.close()
+
+
+def _with_landmarks_at_infinity(P, n_inf, seed):
+    """Landmarks 0 .. n_inf - 1 moved to infinity (true inverse depth 0): their observations are the oracle's own prediction at rho = 0 plus pixel noise, so about half of
+    them want a NEGATIVE inverse depth (tests/test_gpu_solver.py::test_constrained_problem_line_search_and_bound_at_the_solution, here per sequence)."""
+    N = P["n_knots"]
+    rng = np.random.default_rng(seed)
+    xt = P["state_true"].copy()
+    xt[7 * N + 32:7 * N + 32 + n_inf] = 0.0
+    ot = O.Oracle(); lvx.load_problem(ot, P, TAU)
+    r = ot.evaluate(xt)["residuals"]
+    n_imu, n_surf = len(P["t_imu"]), len(P["surf_t"])
+    r_rep = r[6 * n_imu + n_surf:6 * n_imu + n_surf + 2 * len(P["rep_lm"])].reshape(-1, 2)
+    sel = np.isin(P["rep_lm"], np.arange(n_inf))
+    Q = dict(P)
+    uv = P["rep_uv"].copy()
+    uv[sel] = (P["rep_uv"][sel] - r_rep[sel] / P["w_rep"]) + 0.5 * rng.standard_normal((int(sel.sum()), 2))
+    Q["rep_uv"] = uv
+    return Q
+
+
+def test_joint_solve_is_constrained_like_ceres_line_search_and_bound():
+    """Free inverse depths (rho >= 0) make the JOINT problem constrained in Ceres' sense: projected start, projected gradient, projected Armijo line search on the
+    trust-region step — with every quantity the search decides on summed over the ranks.  Two sequences with landmarks at infinity whose observations want negative inverse
+    depths: the joint oracle LM (oracle/lm.py with the joint problem's box constraints) and the two-rank GPU solve take the same contracted steps, and the same landmarks
+    end ON the bound."""
+    seqs = []
+    ref = None
+    for r in range(WORLD):
+        # (one trajectory recorded twice with different pixel noise on the landmarks at infinity: on this pair the joint search contracts a step — 11 trials — and
+        #  4 + 2 landmarks end on the bound; pairs of different trajectories scanned with oracle/lm.py never triggered the search)
+        P = synth.make_problem(seed=29, duration=2.0, n_surfel=800, n_planes=12, n_landmarks=30, n_camsurf=0)
+        P = _with_landmarks_at_infinity(P, 5, 7 + r)
+        N = P["n_knots"]
+        s = P["state0"].copy()
+        if ref is None:
+            ref = s[7 * N + 16:7 * N + 32].copy()
+        s[7 * N + 16:7 * N + 32] = ref
+        seqs.append((P, s))
+    J = JointOracle(seqs)
+    x0 = np.concatenate([s for _, s in seqs])
+    xo, so = lm.lm_solve(J, x0, J.free, max_iterations=30, mask=J.mask, constrained=_joint_bounds(J, seqs))
+    assert sum(so["line_search_trials"]) >= 1                            # the search really contracted a joint step
+    res = _run_ranks(seqs, lambda r, g, allreduce: g.lm_solve_shared(seqs[r][1], allreduce, max_iterations=30))
+    conv = ("parameter_tolerance", "function_tolerance", "gradient_tolerance")
+    xs = J.split(xo)
+    for r in range(WORLD):
+        sg = res[r][1]
+        N, L = seqs[r][0]["n_knots"], seqs[r][0]["n_landmarks"]
+        rho_o, rho_g = xs[r][7 * N + 32:7 * N + 32 + L], res[r][0][7 * N + 32:7 * N + 32 + L]
+        print("rank %d: %s / %s, %d / %d iterations, trials %s, rho on the bound %d / %d" % (r, so["termination"], sg["termination"], so["iterations"], sg["iterations"], so["line_search_trials"],
+                                                                                          int((rho_o == 0).sum()), int((rho_g == 0).sum())))
+        assert sg["termination"] in conv and so["termination"] in conv and abs(sg["iterations"] - so["iterations"]) <= 1
+        k = min(len(sg["accepted"]), len(so["accepted"])) - 1
+        assert k >= 5 and list(sg["accepted"][:k]) == list(so["accepted"][:k])
+        assert np.abs(sg["cost_history"][:k] - so["cost_history"][:k]).max() <= 1e-7 * so["cost_history"].max()
+        assert (rho_g >= 0).all() and list(rho_o == 0) == list(rho_g == 0)
+        assert np.abs(rho_g - rho_o).max() <= 1e-6 * max(1.0, np.abs(rho_o).max())
+    assert (np.concatenate([xs[r][7 * seqs[r][0]["n_knots"] + 32:] for r in range(WORLD)]) == 0).any()
+    N0, N1 = seqs[0][0]["n_knots"], seqs[1][0]["n_knots"]
+    assert np.array_equal(res[0][0][7 * N0 + 16:7 * N0 + 32], res[1][0][7 * N1 + 16:7 * N1 + 32])   # one set of extrinsics
