@@ -404,8 +404,11 @@ int lvx_surfel_assoc_emit(lvx_ctx* ctx, int n_scans, int H, int W, const float* 
  *   ScanUndistortion::undistortScanInMap (every point of every scan de-skewed into the LiDAR frame at the map time; map cloud = the scans concatenated),
  *   LiDAROdometry::ndtInit(resolution) + setInputTarget(map cloud) (voxel covariance grid), SurfelAssociation::setSurfelMap, getAssociation per scan.
  * lvx_set_scans hands over the dataset's organised raw scans once (LioDataset::get_scan_data: [n_scans][H][W], per-point timestamps, NaN x = no return);
- * lvx_data_association runs one association round at `state` and leaves the surfel map and the chronological SurfelPoint list in the context:
- * four launches-with-a-count go back to the host (map pose validity, grid extent, leaf count, list length), nothing else does.
+ * lvx_data_association runs one association round at `state` and leaves the surfel map and the chronological SurfelPoint list in the context.
+ * The FIRST round on a set of scans stops at the host four times (leaf count, plane count, list length of the association grid, SurfelPoint counts); every later round
+ * launches the whole chain over capacities learned from the round before — the kernels read the true counts from device memory — and stops ONCE, at the end; a count that
+ * outgrew its capacity (or a cell table that was too small) discards that attempt and the round runs the four-stop chain (lvx_data_association_stats counts both).
+ * The plane records stay on the device until lvx_get_surfel_map asks for them.
  * averageTimeDownSmaple (every step-th point, surfel_association.cpp:240-244) is the caller's: it picks from the arrays of lvx_get_surfel_points. */
 typedef struct lvx_assoc_options {
   float ndt_resolution;              /* lvi.yaml:26, 0.5 */
@@ -421,6 +424,8 @@ int lvx_assoc_default_options(lvx_assoc_options* opt);
 int lvx_set_scans(lvx_ctx* ctx, int n_scans, int H, int W, const lvx_point_xyzit* raw);
 int lvx_data_association(lvx_ctx* ctx, const double* state, double map_time, const lvx_assoc_options* opt, int32_t* n_planes, int32_t* n_points);
 int lvx_get_surfel_map(lvx_ctx* ctx, int max_planes, lvx_surfel_plane* planes);
+/* rounds that took the one-stop chain since the context was created, and how many of those had to be repeated on the four-stop chain */
+int lvx_data_association_stats(lvx_ctx* ctx, int64_t* one_stop_rounds, int64_t* repeated_rounds);
 int lvx_get_surfel_points(lvx_ctx* ctx, int max_points, double* pt3, double* pt_map3, double* t, int32_t* plane);
 /* parity / debug: the de-skewed scans of the last lvx_data_association, [n_scans][H][W][4] float */
 int lvx_get_scans_in_map(lvx_ctx* ctx, float* xyzi4);

@@ -60,7 +60,7 @@ struct DevBuf {
 // Experiment / debug switches: read ONCE from the environment (LVX_<NAME>) when the context is created and changed afterwards only
 // through lvx_set_switch — the evaluation path never calls getenv.
 struct Switches {
-  int force_legacy = 0, serial = 0, no_graph = 0, deterministic = 0, clear_all = 0, solver_seq = 0, solver_timing = 0, chunk_r = 0, chunk_r_imu = 0, chunk_r_rep = 0, chunk_rows = 0, rep_rows = 0;
+  int force_legacy = 0, serial = 0, no_graph = 0, deterministic = 0, clear_all = 0, solver_seq = 0, solver_timing = 0, chunk_r = 0, chunk_r_imu = 0, chunk_r_rep = 0, chunk_rows = 0, rep_rows = 0, da_sync = 0;
 };
 struct SwitchName { const char* name; int Switches::*field; bool relayout; };
 const SwitchName* switch_table(int* count);
@@ -134,12 +134,15 @@ struct lvx_ctx {
   const double* last_state_d = nullptr; bool last_want_res = false, err_unchecked = false;   // see check_last_eval
   // upstream kernels (lvx_upstream.hip)
   lvx::DevBuf d_up[8];
-  size_t assoc_rings = 0; int assoc_wpr = 0;   // shape the association work buffer (d_assoc[3]) was cleared for
+  size_t assoc_rings = 0; int assoc_wpr = 0, assoc_list_total = 0;   // shape the association work buffer (d_assoc[3]) was cleared for
   const double* assoc_map_planes = nullptr; int assoc_map_P = 0; bool assoc_map_ready = false;   // lvx_surfel_map_prepare_d: the association grid of this plane table is built
   lvx::DevBuf d_assoc[4];   // surfel association: grid geometry + cell counts / offsets, cell lists, emission counters, hit bitmasks + counts (private: cleared once per shape)
   // device-resident DataAssociation (lvx_set_scans / lvx_data_association): [0] raw scans, [1] state, [2] map time, [3] map pose, [4] scans in the map frame = map cloud,
   // [5] plane table, [6] flags, [7] SurfelPoint arrays
   lvx::DevBuf d_da[8]; int da_S = 0, da_H = 0, da_W = 0, da_points = 0; std::vector<lvx_surfel_plane> da_planes;
+  // lvx_data_association without host stops (round 5): capacities learned from the previous call (leaves, planes, association-grid list entries; 0 = none yet, the call
+  // runs the synchronous path), the pinned mirror the device writes its counts into, the planes still to fetch from d_da[5] when somebody asks for them
+  int da_cap_nl = 0, da_cap_P = 0, da_cap_list = 0, da_planes_pending = 0; int* da_pinned = nullptr; long long da_spec_runs = 0, da_spec_misses = 0;
   // the last lvx_scan_register / lvx_scan_register_batch (its results stay in d_up[0]): sweeps, rings, points, per-sweep input offsets and kept points, byte offsets of
   // {cloud, lflat_r, scan_start, cnt} inside the scratch buffer
   int sr_S = 0, sr_rings = 0; long long sr_N = 0; std::vector<int32_t> sr_off; std::vector<int> sr_m; std::array<size_t, 4> sr_batch_off{}; std::array<size_t, 8> sr_lay{}; std::vector<int32_t> sr_counts;   // sr_lay: {cloud, curv, label, sort, pick, lists, scan_start, scan_end}

@@ -1315,13 +1315,17 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
         LVX_HIP(c, hipMemcpyAsync(dh.data(), w.delta, (size_t)ntg * 8, hipMemcpyDeviceToHost, st));
         LVX_HIP(c, hipStreamSynchronize(st));
         std::vector<double> dt((size_t)ntg);
+        // ArmijoLineSearch gives up when step * ||direction||_inf < min_line_search_step_size (1e-9); joint: the norm of the JOINT step (max over the ranks)
+        double dinf = 0.0;
+        for (int i = 0; i < ntg; ++i) dinf = std::max(dinf, std::fabs(dh[i]));
+        if (joint && (rc = reduce(c, &dinf, 1, LVX_REDUCE_MAX))) return rc;
         for (int trial = 1; trial <= 20 && !found; ++trial) {
           std::vector<LsSample> sm{{0.0, f0, g0, true}};
           if (have_prev) sm.push_back(prev);
           sm.push_back(cur);
           const double a = poly_argmin(poly_fit(sm), 1e-3 * cur.x, 0.6 * cur.x);
           if (o.verbose) fprintf(stderr, "[lvx lm] it %3d line search trial %d: f0 %.12e g0 %.12e | last step %.6e f %.12e df %.12e -> step %.12e\n", it, trial, f0, g0, cur.x, cur.f, cur.df, a);
-          if (a < 1e-9) break;
+          if (a * dinf < 1e-9) break;
           for (int i = 0; i < ntg; ++i) dt[i] = a * dh[i];
           LVX_HIP(c, hipMemcpyAsync(w.delta, dt.data(), (size_t)ntg * 8, hipMemcpyHostToDevice, st));
           LVX_HIP(c, hipMemsetAsync(w.sums + 2, 0, 48, st));

@@ -1117,9 +1117,10 @@ __global__ __launch_bounds__(256) void k_vx_lookup_rel(const float4* q, int nq, 
 struct SurfelPlaneDev { double p4[4], Pi[3], bmin[3], bmax[3]; int leaf, n_points, n_inliers, plane_type; };
 __device__ __forceinline__ double wave_sum(double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
 __global__ __launch_bounds__(256) void k_surfel_extract(const float4* __restrict__ p, const unsigned* counts, const unsigned* offs, const int* __restrict__ sorted_ids, int nl, const int* leaf_n, const double* mean,
-                                                        const double* evecs, const double* evals, double p_lambda, double thr, int min_leaf, int min_inl, SurfelPlaneDev* out, int* flag) {
+                                                        const double* evecs, const double* evals, double p_lambda, double thr, int min_leaf, int min_inl, SurfelPlaneDev* out, int* flag, const VxInfo* nl_d) {
   const int lane = threadIdx.x & 63;
   const int li = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (nl_d) nl = min(nl, nl_d->n_leaves);   // launched over a capacity: the leaf count is still on the device (lvx_data_association without host stops)
   if (li >= nl) return;
   if (lane == 0) flag[li] = 0;
   const int n = leaf_n[li];
@@ -1183,10 +1184,11 @@ __global__ __launch_bounds__(256) void k_surfel_extract(const float4* __restrict
 // accepted planes in leaf (= voxel key = std::map) order, compacted on the device: records first, then — behind them, 16-byte aligned — the association's plane table
 // [p4 (4 P) | box min (3 P) | box max (3 P)]; one workgroup, ballot ranks + a running offset (the host used to fetch every leaf's record and flag, compact, rebuild the
 // table and upload it again)
-__global__ __launch_bounds__(1024) void k_surfel_compact(const SurfelPlaneDev* __restrict__ all, const int* __restrict__ flag, int nl, SurfelPlaneDev* recs, int* count) {
+__global__ __launch_bounds__(1024) void k_surfel_compact(const SurfelPlaneDev* __restrict__ all, const int* __restrict__ flag, int nl, SurfelPlaneDev* recs, int* count, const VxInfo* nl_d) {
   __shared__ int wsum[16];
   __shared__ int running;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (nl_d) nl = min(nl, nl_d->n_leaves);
   if (threadIdx.x == 0) running = 0;
   __syncthreads();
   for (int l0 = 0; l0 < nl; l0 += 1024) {
@@ -1261,11 +1263,13 @@ __global__ void k_vx_lookup(const float4* q, int nq, float leaf, int min_pts, Vx
 struct AssocGrid { double g0[3], inv[3]; };
 __device__ __forceinline__ int sa_cell(double v, double g0, double inv, int n) { const double f = floor((v - g0) * inv); return f < 0.0 ? 0 : (f >= (double)n ? n - 1 : (int)f); }
 // one workgroup: bounds of all boxes -> grid geometry
-__global__ __launch_bounds__(256) void k_assoc_grid_geom(int P, const double* planes10, AssocGrid* g) {
+__global__ __launch_bounds__(256) void k_assoc_grid_geom(int P, const double* planes10, AssocGrid* g, const int* P_d) {
   __shared__ double lo[3][256], hi[3][256];
+  if (P_d) { const int Pr = *P_d; planes10 = (const double*)((const char*)planes10 + (((size_t)Pr * sizeof(SurfelPlaneDev) + 15) & ~(size_t)15)); P = min(Pr, P); }   // see k_assoc_grid_fill
   double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
+  const size_t Ps = P_d ? (size_t)*P_d : (size_t)P;
   for (int k = threadIdx.x; k < P; k += 256)
-    for (int a = 0; a < 3; ++a) { l[a] = fmin(l[a], planes10[4 * (size_t)P + 3 * (size_t)k + a]); h[a] = fmax(h[a], planes10[7 * (size_t)P + 3 * (size_t)k + a]); }
+    for (int a = 0; a < 3; ++a) { l[a] = fmin(l[a], planes10[4 * Ps + 3 * (size_t)k + a]); h[a] = fmax(h[a], planes10[7 * Ps + 3 * (size_t)k + a]); }
   for (int a = 0; a < 3; ++a) { lo[a][threadIdx.x] = l[a]; hi[a][threadIdx.x] = h[a]; }
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) for (int a = 0; a < 3; ++a) { lo[a][threadIdx.x] = fmin(lo[a][threadIdx.x], lo[a][threadIdx.x + o]); hi[a][threadIdx.x] = fmax(hi[a][threadIdx.x], hi[a][threadIdx.x + o]); } __syncthreads(); }
@@ -1275,30 +1279,36 @@ __global__ __launch_bounds__(256) void k_assoc_grid_geom(int P, const double* pl
     g->g0[a] = lo[a][0]; g->inv[a] = ext > 0.0 ? (double)n / ext : 0.0;
   }
 }
-// mode 0: count the cells every box reaches; mode 1: write the box into its cells' lists (cursor = running offsets)
-__global__ void k_assoc_grid_fill(int P, const double* planes10, const AssocGrid* gp, int* cell_cnt, int* cursor, int* list, int mode, double* aos) {
+// mode 0: count the cells every box reaches; mode 1: write the box into its cells' lists (cursor = running offsets; entries past list_cap are dropped — the host finds the
+// true total behind the cursors and repeats the call with a larger list).  P_d != nullptr: the plane count is still on the device, P is the capacity the launch covers and
+// planes10 the RECORD array k_surfel_compact filled — its plane table sits right behind the *P_d records, strided by *P_d.
+__global__ void k_assoc_grid_fill(int P, const double* planes10, const AssocGrid* gp, int* cell_cnt, int* cursor, int* list, int mode, double* aos, const int* P_d, int list_cap) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  size_t Ps = (size_t)P;   // stride of the table
+  if (P_d) { const int Pr = *P_d; planes10 = (const double*)((const char*)planes10 + (((size_t)Pr * sizeof(SurfelPlaneDev) + 15) & ~(size_t)15)); Ps = (size_t)Pr; P = min(Pr, P); }
   if (k >= P) return;
   const AssocGrid g = *gp;
   if (mode == 0 && aos) {   // one 80-byte record per surfel for the hit kernel: box min | box max | plane (the caller's table is three arrays: ten 8-byte loads from three places per candidate)
-    for (int a = 0; a < 3; ++a) { aos[10 * (size_t)k + a] = planes10[4 * (size_t)P + 3 * (size_t)k + a]; aos[10 * (size_t)k + 3 + a] = planes10[7 * (size_t)P + 3 * (size_t)k + a]; }
+    for (int a = 0; a < 3; ++a) { aos[10 * (size_t)k + a] = planes10[4 * Ps + 3 * (size_t)k + a]; aos[10 * (size_t)k + 3 + a] = planes10[7 * Ps + 3 * (size_t)k + a]; }
     for (int a = 0; a < 4; ++a) aos[10 * (size_t)k + 6 + a] = planes10[4 * (size_t)k + a];
   }
   int c0[3], c1[3];
   const int nn[3] = {SA_GX, SA_GY, SA_GZ};
   for (int a = 0; a < 3; ++a) {
-    const double lo = planes10[4 * (size_t)P + 3 * (size_t)k + a], hi = planes10[7 * (size_t)P + 3 * (size_t)k + a];
+    const double lo = planes10[4 * Ps + 3 * (size_t)k + a], hi = planes10[7 * Ps + 3 * (size_t)k + a];
     if (!(lo < hi)) return;                          // an empty box holds no point
     c0[a] = sa_cell(lo, g.g0[a], g.inv[a], nn[a]); c1[a] = sa_cell(hi, g.g0[a], g.inv[a], nn[a]);
   }
   for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x) {
     const int cell = (z * SA_GY + y) * SA_GX + x;
-    if (mode == 0) atomicAdd(&cell_cnt[cell], 1); else list[atomicAdd(&cursor[cell], 1)] = k;
+    if (mode == 0) atomicAdd(&cell_cnt[cell], 1);
+    else { const int pos = atomicAdd(&cursor[cell], 1); if (pos < list_cap) list[pos] = k; }
   }
 }
 // exclusive scan of the cell counts (one workgroup: each of its 16 wavefronts owns 2048 consecutive cells, read 64 at a time), total behind the last cell;
-// cursor = copy of the offsets
-__global__ __launch_bounds__(1024) void k_assoc_grid_scan(const int* cnt, int* off, int* cursor) {
+// cursor = copy of the offsets.  The offsets the hit kernel walks are clamped to list_cap (a list that turned out too small is never read past its end); the true
+// total goes behind the cursors, where the host looks.
+__global__ __launch_bounds__(1024) void k_assoc_grid_scan(const int* cnt, int* off, int* cursor, int list_cap) {
   __shared__ int wtot[16];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, base = wv * (SA_CELLS / 16);
   int v[SA_CELLS / 1024], tot = 0;
@@ -1314,10 +1324,10 @@ __global__ __launch_bounds__(1024) void k_assoc_grid_scan(const int* cnt, int* o
     int inc = v[j];
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
     const int ex = running + inc - v[j];
-    off[base + 64 * j + lane] = ex; cursor[base + 64 * j + lane] = ex;
+    off[base + 64 * j + lane] = min(ex, list_cap); cursor[base + 64 * j + lane] = ex;
     running += __shfl(inc, 63);
   }
-  if (threadIdx.x == 1023) off[SA_CELLS] = running;
+  if (threadIdx.x == 1023) { off[SA_CELLS] = min(running, list_cap); cursor[SA_CELLS] = running; }
 }
 // all pairs: thread = scan point, the plane table of the block's chunk (256 planes) in LDS, read as broadcasts.  57.6 M exact tests per scan at P = 2000
 // (FP64 VALU bound, 36 us) — cheaper than building the grid when only one or two scans are associated in a call.
@@ -1980,15 +1990,16 @@ static int assoc_grid_build(lvx_ctx* c, int P, const double* planes_d, bool have
   AssocGrid* gd = (AssocGrid*)c->d_assoc[0].p; int* ccnt = (int*)(gd + 1); int* coff = ccnt + SA_CELLS; int* ccur = coff + SA_CELLS + 1;
   double* aos = (double*)((char*)c->d_assoc[0].p + grid_bytes);
   LVX_HIP(c, hipMemsetAsync(ccnt, 0, (size_t)SA_CELLS * 4, c->stream));
-  hipLaunchKernelGGL(k_assoc_grid_geom, dim3(1), dim3(256), 0, c->stream, P, planes_d, gd);
-  hipLaunchKernelGGL(k_assoc_grid_fill, dim3((unsigned)((P + 127) / 128)), dim3(128), 0, c->stream, P, planes_d, (const AssocGrid*)gd, ccnt, ccur, (int*)nullptr, 0, aos);
-  hipLaunchKernelGGL(k_assoc_grid_scan, dim3(1), dim3(1024), 0, c->stream, (const int*)ccnt, coff, ccur);
+  hipLaunchKernelGGL(k_assoc_grid_geom, dim3(1), dim3(256), 0, c->stream, P, planes_d, gd, (const int*)nullptr);
+  hipLaunchKernelGGL(k_assoc_grid_fill, dim3((unsigned)((P + 127) / 128)), dim3(128), 0, c->stream, P, planes_d, (const AssocGrid*)gd, ccnt, ccur, (int*)nullptr, 0, aos, (const int*)nullptr, 0x7fffffff);
+  hipLaunchKernelGGL(k_assoc_grid_scan, dim3(1), dim3(1024), 0, c->stream, (const int*)ccnt, coff, ccur, 0x7fffffff);
   int total = 0;
   LVX_HIP(c, hipMemcpyAsync(&total, coff + SA_CELLS, 4, hipMemcpyDeviceToHost, c->stream));
   LVX_HIP(c, hipStreamSynchronize(c->stream));
+  c->assoc_list_total = total;
   if ((rc = dev_alloc(c, c->d_assoc[1], (size_t)std::max(total, 1) * 4))) return rc;
   int* clist = (int*)c->d_assoc[1].p;
-  hipLaunchKernelGGL(k_assoc_grid_fill, dim3((unsigned)((P + 127) / 128)), dim3(128), 0, c->stream, P, planes_d, (const AssocGrid*)gd, ccnt, ccur, clist, 1, (double*)nullptr);
+  hipLaunchKernelGGL(k_assoc_grid_fill, dim3((unsigned)((P + 127) / 128)), dim3(128), 0, c->stream, P, planes_d, (const AssocGrid*)gd, ccnt, ccur, clist, 1, (double*)nullptr, (const int*)nullptr, 0x7fffffff);
   return LVX_OK;
 }
 static int assoc_device(lvx_ctx* c, const float4* scans_d, int S, int H, int W, int P, const double* planes_d, double radius, int sel, int* flags_d) {
@@ -2208,12 +2219,12 @@ static int surfel_extract_device(lvx_ctx* c, double p_lambda, double dist_thresh
   const int* lk = (const int*)V.leaf_i.p; const double* d = (const double*)V.leaf_d.p;
   { ProfScope ps(c, LVX_KERNEL_UPSTREAM);
     hipLaunchKernelGGL(k_surfel_extract, dim3((nl + 3) / 4), dim3(256), 0, c->stream, (const float4*)V.d_pts, counts, offs, (const int*)V.vals.p + n, nl, lk + cap, d, d + 21 * cap,
-                       d + 30 * cap, p_lambda, dist_threshold, min_leaf_points, min_inliers, (SurfelPlaneDev*)c->d_up[4].p, (int*)c->d_up[5].p); }
+                       d + 30 * cap, p_lambda, dist_threshold, min_leaf_points, min_inliers, (SurfelPlaneDev*)c->d_up[4].p, (int*)c->d_up[5].p, (const VxInfo*)nullptr); }
   LVX_HIP(c, hipGetLastError());
   // compaction on the device: [records | plane table] in dst, the count comes back (4 bytes), then the records
   if ((rc = dev_alloc(c, dst, (size_t)nl * (sizeof(SurfelPlaneDev) + 80) + 64))) return rc;
   int* d_cnt = (int*)((char*)dst.p + dst.bytes - 16);
-  hipLaunchKernelGGL(k_surfel_compact, dim3(1), dim3(1024), 0, c->stream, (const SurfelPlaneDev*)c->d_up[4].p, (const int*)c->d_up[5].p, nl, (SurfelPlaneDev*)dst.p, d_cnt);
+  hipLaunchKernelGGL(k_surfel_compact, dim3(1), dim3(1024), 0, c->stream, (const SurfelPlaneDev*)c->d_up[4].p, (const int*)c->d_up[5].p, nl, (SurfelPlaneDev*)dst.p, d_cnt, (const VxInfo*)nullptr);
   int P = 0;
   LVX_HIP(c, hipMemcpyAsync(&P, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
   LVX_HIP(c, hipStreamSynchronize(c->stream));
@@ -2239,7 +2250,7 @@ int lvx_surfel_extract(lvx_ctx* c, double p_lambda, double dist_threshold, int m
 int lvx_set_scans(lvx_ctx* c, int n_scans, int H, int W, const lvx_point_xyzit* raw) {
   if (!c || n_scans < 0 || H < 0 || W < 0 || W > SA_WMAX || ((size_t)n_scans * H * W > 0 && !raw)) return c ? fail(c, LVX_E_ARG, "bad lvx_set_scans arguments (W <= 4096)") : LVX_E_ARG;
   LVX_HIP(c, hipSetDevice(c->device));
-  c->da_S = n_scans; c->da_H = H; c->da_W = W; c->da_planes.clear(); c->da_points = 0;
+  c->da_S = n_scans; c->da_H = H; c->da_W = W; c->da_planes.clear(); c->da_points = 0; c->da_planes_pending = 0; c->da_cap_nl = c->da_cap_P = c->da_cap_list = 0;
   int rc = upload(c, c->d_da[0], raw, (size_t)n_scans * H * W * 32);
   if (rc) return rc;
   LVX_HIP(c, hipStreamSynchronize(c->stream));   // the caller's buffer may go away
@@ -2249,6 +2260,90 @@ int lvx_assoc_default_options(lvx_assoc_options* o) {
   if (!o) return LVX_E_ARG;
   o->ndt_resolution = 0.5f; o->min_points_per_voxel = 6; o->min_covar_eigvalue_mult = 0.01; o->plane_lambda = 0.7; o->fit_threshold = 0.05; o->min_leaf_points = 10; o->min_inliers = 20;
   o->radius = 0.05; o->selected_per_ring = 2; o->reserved = 0;
+  return LVX_OK;
+}
+// ---- lvx_data_association without host stops (round 5) ---------------------------------------------------------------------------------------------------
+// The synchronous chain below waits for the device four times: the leaf count of the voxel grid (launch size of the plane extraction), the plane count (shape of the
+// association), the length of the association grid's lists (their allocation), the SurfelPoint counts.  A calibration calls lvx_data_association once per refinement
+// round on the SAME scans with a slightly moved trajectory, so the three intermediate counts barely change: the speculative chain launches everything over CAPACITIES
+// learned from the previous call (kernels read the true counts from device memory and clamp to the capacity), waits ONCE at the end, and looks at what the device
+// mirrored into pinned memory — a count above its capacity (or a cell table that was too small) discards the attempt and the synchronous chain runs.
+__global__ void k_da_counts(int* out, const int* pose_valid, const int* n_planes, const int* list_total) { out[0] = *pose_valid; out[1] = *n_planes; out[2] = *list_total; }
+static int da_capacity(int have, int need, int slack) { return (have >= need && (long long)have <= 4ll * need + 4ll * slack) ? have : need + need / 8 + slack; }
+// returns LVX_OK, an error, or 1 = a capacity was exceeded (nothing of the attempt is kept)
+static int da_speculative(lvx_ctx* c, const lvx_assoc_options& o, int S, int H, int W, size_t npt, const int* dv, int32_t* n_planes, int32_t* n_points) {
+  hipStream_t st = c->stream;
+  int rc;
+  lvx_ctx::Voxels& V = c->vox;
+  if (!c->da_pinned) LVX_HIP(c, hipHostMalloc((void**)&c->da_pinned, 64, hipHostMallocDefault));
+  const int nl_cap = std::min<long long>(c->da_cap_nl, (long long)npt), P_cap = std::min(c->da_cap_P, nl_cap), list_cap = c->da_cap_list;
+  if ((rc = voxel_build_device(c, (const float4*)c->d_da[4].p, (int)npt, o.ndt_resolution, o.min_points_per_voxel, o.min_covar_eigvalue_mult))) return rc;
+  const VxInfo* d_info = (const VxInfo*)((const char*)V.misc.p + 64);
+  const int n = V.n_points; const size_t cap = (size_t)V.cap;
+  // setSurfelMap over the first min(leaves, nl_cap) leaves
+  if ((rc = dev_alloc(c, c->d_up[4], (size_t)nl_cap * sizeof(SurfelPlaneDev)))) return rc;
+  if ((rc = dev_alloc(c, c->d_up[5], (size_t)nl_cap * 4))) return rc;
+  DevBuf& dst = c->d_da[5];
+  if ((rc = dev_alloc(c, dst, (size_t)nl_cap * (sizeof(SurfelPlaneDev) + 80) + 64))) return rc;
+  int* d_cnt = (int*)((char*)dst.p + dst.bytes - 16);
+  { const unsigned* counts = (const unsigned*)V.runs.p + n; const unsigned* offs = (const unsigned*)V.runs.p + 2 * (size_t)n;
+    const int* lk = (const int*)V.leaf_i.p; const double* d = (const double*)V.leaf_d.p;
+    hipLaunchKernelGGL(k_surfel_extract, dim3((nl_cap + 3) / 4), dim3(256), 0, st, (const float4*)V.d_pts, counts, offs, (const int*)V.vals.p + n, nl_cap, lk + cap, d, d + 21 * cap, d + 30 * cap,
+                       o.plane_lambda, o.fit_threshold, o.min_leaf_points, o.min_inliers, (SurfelPlaneDev*)c->d_up[4].p, (int*)c->d_up[5].p, d_info);
+    hipLaunchKernelGGL(k_surfel_compact, dim3(1), dim3(1024), 0, st, (const SurfelPlaneDev*)c->d_up[4].p, (const int*)c->d_up[5].p, nl_cap, (SurfelPlaneDev*)dst.p, d_cnt, d_info); }
+  // the association grid of min(planes, P_cap) planes, lists of list_cap entries
+  const size_t grid_bytes = (sizeof(AssocGrid) + (size_t)(3 * SA_CELLS + 8) * 4 + 15) & ~(size_t)15;
+  c->assoc_map_ready = false;
+  if ((rc = dev_alloc(c, c->d_assoc[0], grid_bytes + (size_t)P_cap * 80))) return rc;
+  if ((rc = dev_alloc(c, c->d_assoc[1], (size_t)std::max(list_cap, 1) * 4))) return rc;
+  AssocGrid* gd = (AssocGrid*)c->d_assoc[0].p; int* ccnt = (int*)(gd + 1); int* coff = ccnt + SA_CELLS; int* ccur = coff + SA_CELLS + 1; int* clist = (int*)c->d_assoc[1].p;
+  double* aos = (double*)((char*)c->d_assoc[0].p + grid_bytes);
+  const double* recs = (const double*)dst.p;
+  LVX_HIP(c, hipMemsetAsync(ccnt, 0, (size_t)SA_CELLS * 4, st));
+  hipLaunchKernelGGL(k_assoc_grid_geom, dim3(1), dim3(256), 0, st, P_cap, recs, gd, (const int*)d_cnt);
+  hipLaunchKernelGGL(k_assoc_grid_fill, dim3((unsigned)((P_cap + 127) / 128)), dim3(128), 0, st, P_cap, recs, (const AssocGrid*)gd, ccnt, ccur, (int*)nullptr, 0, aos, (const int*)d_cnt, list_cap);
+  hipLaunchKernelGGL(k_assoc_grid_scan, dim3(1), dim3(1024), 0, st, (const int*)ccnt, coff, ccur, list_cap);
+  hipLaunchKernelGGL(k_assoc_grid_fill, dim3((unsigned)((P_cap + 127) / 128)), dim3(128), 0, st, P_cap, recs, (const AssocGrid*)gd, ccnt, ccur, clist, 1, (double*)nullptr, (const int*)d_cnt, list_cap);
+  hipLaunchKernelGGL(k_da_counts, dim3(1), dim3(1), 0, st, c->da_pinned, dv, (const int*)d_cnt, (const int*)(ccur + SA_CELLS));
+  // flags of every scan: rings strided by the plane CAPACITY (rings of planes that do not exist stay empty)
+  if ((rc = dev_alloc(c, c->d_da[6], npt * 4))) return rc;
+  LVX_HIP(c, hipMemsetAsync(c->d_da[6].p, 0xff, npt * 4, st));
+  const int wpr = (W + 31) / 32, chunk = 64;
+  { const size_t rings = (size_t)std::min(chunk, S) * P_cap * H, bytes = rings * wpr * 4 + rings * 4;
+    if (!c->d_assoc[3].p || c->d_assoc[3].bytes < bytes || c->assoc_rings != rings || c->assoc_wpr != wpr) {
+      if ((rc = dev_alloc(c, c->d_assoc[3], bytes))) return rc;
+      LVX_HIP(c, hipMemsetAsync(c->d_assoc[3].p, 0, c->d_assoc[3].bytes, st));
+      c->assoc_rings = rings; c->assoc_wpr = wpr;
+    }
+    unsigned* bits = (unsigned*)c->d_assoc[3].p; int* counts = (int*)(bits + rings * wpr);
+    for (int s0 = 0; s0 < S; s0 += chunk) {
+      const int ns = std::min(chunk, S - s0);
+      const float4* sc = (const float4*)c->d_da[4].p + (size_t)s0 * H * W;
+      hipLaunchKernelGGL(k_assoc_hits, dim3((unsigned)((H * W + 255) / 256), (unsigned)ns), dim3(256), 0, st, sc, H, W, P_cap, (const double*)aos, o.radius, (const AssocGrid*)gd, (const int*)coff, (const int*)clist, bits, counts, wpr);
+      hipLaunchKernelGGL(k_assoc_select, dim3((unsigned)(((size_t)ns * P_cap * H + 255) / 256)), dim3(256), 0, st, bits, counts, ns, H, W, P_cap, wpr, o.selected_per_ring, (int*)c->d_da[6].p + (size_t)s0 * H * W);
+    } }
+  LVX_HIP(c, hipGetLastError());
+  // SurfelPoint lists (capacity-strided), then THE host stop
+  int32_t total = 0;
+  if ((rc = dev_alloc(c, c->d_da[7], npt * (24 + 24 + 8 + 4) + 64))) return rc;
+  { double* d_pt = (double*)c->d_da[7].p; double* d_pm = d_pt + 3 * npt; double* d_t = d_pm + 3 * npt; int32_t* d_pl = (int32_t*)(d_t + npt);
+    if ((rc = lvx_surfel_emit_d(c, S, H, W, (const int32_t*)c->d_da[6].p, (const float*)c->d_da[4].p, (const lvx_point_xyzit*)c->d_da[0].p, (int)npt, d_pt, d_pm, d_t, d_pl, &total, nullptr))) return rc; }
+  V.pending = false;
+  VxInfo inf; std::memcpy(&inf, V.h_info, sizeof(inf));
+  const int hv = c->da_pinned[0], P = c->da_pinned[1], ltot = c->da_pinned[2];
+  if (inf.overflow == 2) return fail(c, LVX_E_ARG, "Leaf size is too small for the input dataset. Integer indices would overflow.");
+  if (inf.overflow == 1 || inf.n_leaves > nl_cap || P > P_cap || ltot > list_cap) {
+    if (inf.overflow != 1) { c->da_cap_nl = da_capacity(c->da_cap_nl, inf.n_leaves, 1024); if (inf.n_leaves <= nl_cap) c->da_cap_P = da_capacity(c->da_cap_P, P, 128); if (inf.n_leaves <= nl_cap && P <= P_cap) c->da_cap_list = da_capacity(c->da_cap_list, ltot, 4096); }
+    return 1;
+  }
+  std::memcpy(&V.grid, &inf.g, sizeof(inf.g));
+  V.n_leaves = inf.n_leaves;
+  if (!hv) return fail(c, LVX_E_RANGE, "map time outside the trajectory");
+  c->da_cap_nl = da_capacity(c->da_cap_nl, inf.n_leaves, 1024); c->da_cap_P = da_capacity(c->da_cap_P, P, 128); c->da_cap_list = da_capacity(c->da_cap_list, ltot, 4096);
+  c->da_planes.clear(); c->da_planes_pending = P;   // fetched from d_da[5] when lvx_get_surfel_map asks
+  if (n_planes) *n_planes = P;
+  c->da_points = P > 0 ? total : 0;
+  if (n_points) *n_points = c->da_points;
   return LVX_OK;
 }
 int lvx_data_association(lvx_ctx* c, const double* state, double map_time, const lvx_assoc_options* opt_in, int32_t* n_planes, int32_t* n_points) {
@@ -2263,7 +2358,7 @@ int lvx_data_association(lvx_ctx* c, const double* state, double map_time, const
   if (npt > 2147483647ull) return fail(c, LVX_E_ARG, "too many scan points for one map cloud");
   int rc;
   ProfScope ps(c, LVX_KERNEL_UPSTREAM);
-  c->da_planes.clear(); c->da_points = 0;
+  c->da_planes.clear(); c->da_points = 0; c->da_planes_pending = 0;
   if (n_planes) *n_planes = 0;
   if (n_points) *n_points = 0;
   // 1. ScanUndistortion::undistortScanInMap (scan_undistortion.h:59-74): the LiDAR pose at the map time, then EVERY point of EVERY scan moved with the pose at its own
@@ -2276,8 +2371,17 @@ int lvx_data_association(lvx_ctx* c, const double* state, double map_time, const
   if ((rc = dev_alloc(c, c->d_da[4], npt * 16))) return rc;
   hipLaunchKernelGGL(k_undistort, dim3((unsigned)((npt + 255) / 256)), dim3(256), 0, st, (const double*)c->d_da[1].p, c->N, c->t0, c->dt, (int)npt, (const PointXYZIT*)c->d_da[0].p,
                      quat{0, 0, 0, 1}, mk(0, 0, 0), 1, (float4*)c->d_da[4].p, (const double*)dq, (const int*)dv);   // the pose stays on the device (q_L0_to_G.conjugate() is taken there)
-  // 2. LiDAROdometry::ndtInit(resolution) + setInputTarget(map_cloud): the voxel covariance grid of the map cloud
   c->vox.d_pts = c->d_da[4].p;
+  lvx_surfel_map_release(c);
+  // steps 2-4 over the capacities of the previous call, one host stop (S > 2: one or two scans take the all-pairs kernel, whose launch shape needs the plane count)
+  if (S > 2 && c->da_cap_nl > 0 && c->da_cap_P > 0 && c->da_cap_list > 0 && !c->sw.da_sync) {
+    c->da_spec_runs++;
+    rc = da_speculative(c, o, S, H, W, npt, dv, n_planes, n_points);
+    if (rc <= 0) return rc;
+    c->da_spec_misses++;
+    c->da_planes.clear(); c->da_points = 0; c->da_planes_pending = 0;
+  }
+  // 2. LiDAROdometry::ndtInit(resolution) + setInputTarget(map_cloud): the voxel covariance grid of the map cloud
   if ((rc = voxel_build_device(c, (const float4*)c->d_da[4].p, (int)npt, o.ndt_resolution, o.min_points_per_voxel, o.min_covar_eigvalue_mult))) return rc;
   // 3. SurfelAssociation::setSurfelMap
   std::vector<SurfelPlaneDev> acc;
@@ -2288,11 +2392,13 @@ int lvx_data_association(lvx_ctx* c, const double* state, double map_time, const
   c->da_planes.resize((size_t)P);
   if (P > 0) std::memcpy(c->da_planes.data(), acc.data(), (size_t)P * sizeof(SurfelPlaneDev));
   if (n_planes) *n_planes = P;
+  c->da_cap_nl = da_capacity(c->da_cap_nl, c->vox.n_leaves, 1024); c->da_cap_P = da_capacity(c->da_cap_P, P, 128);
   if (P == 0) return LVX_OK;
   const double* planes_d = (const double*)((const char*)c->d_da[5].p + (((size_t)P * sizeof(SurfelPlaneDev) + 15) & ~(size_t)15));
   // 4. getAssociation for every scan: flags (one surfel grid for all scans), then the chronological SurfelPoint lists, scans concatenated
   if ((rc = dev_alloc(c, c->d_da[6], npt * 4))) return rc;
   if (S > 2 && (rc = lvx_surfel_map_prepare_d(c, P, planes_d))) return rc;
+  if (S > 2) c->da_cap_list = da_capacity(c->da_cap_list, c->assoc_list_total, 4096);
   rc = lvx_surfel_assoc_batch_d(c, S, H, W, (const float*)c->d_da[4].p, P, planes_d, o.radius, o.selected_per_ring, (int32_t*)c->d_da[6].p);
   lvx_surfel_map_release(c);
   if (rc) return rc;
@@ -2305,8 +2411,21 @@ int lvx_data_association(lvx_ctx* c, const double* state, double map_time, const
   if (n_points) *n_points = total;
   return LVX_OK;
 }
+int lvx_data_association_stats(lvx_ctx* c, int64_t* one_stop_rounds, int64_t* repeated_rounds) {
+  if (!c) return LVX_E_ARG;
+  if (one_stop_rounds) *one_stop_rounds = c->da_spec_runs;
+  if (repeated_rounds) *repeated_rounds = c->da_spec_misses;
+  return LVX_OK;
+}
 int lvx_get_surfel_map(lvx_ctx* c, int max_planes, lvx_surfel_plane* planes) {
   if (!c || max_planes < 0 || (max_planes > 0 && !planes)) return LVX_E_ARG;
+  if (c->da_planes_pending > 0) {   // the last lvx_data_association left its records on the device (no host stop for them): fetch them now, once
+    LVX_HIP(c, hipSetDevice(c->device));
+    c->da_planes.resize((size_t)c->da_planes_pending);
+    LVX_HIP(c, hipMemcpyAsync(c->da_planes.data(), c->d_da[5].p, (size_t)c->da_planes_pending * sizeof(lvx_surfel_plane), hipMemcpyDeviceToHost, c->stream));
+    LVX_HIP(c, hipStreamSynchronize(c->stream));
+    c->da_planes_pending = 0;
+  }
   const size_t n = std::min((size_t)max_planes, c->da_planes.size());
   if (n) std::memcpy(planes, c->da_planes.data(), n * sizeof(lvx_surfel_plane));
   return LVX_OK;

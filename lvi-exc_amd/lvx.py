@@ -670,6 +670,59 @@ def surfel_extract(ctx, max_planes, p_lambda=0.7, dist_threshold=0.05, min_leaf_
 POINT_XYZIT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad", "<f4"), ("intensity", "<f4"), ("pad2", "<f4"), ("timestamp", "<f8")])
 
 
+class AssocOptions(C.Structure):
+    """lvx_assoc_options (include/lvx.h): the reference's DataAssociation parameters."""
+    _fields_ = [("ndt_resolution", C.c_float), ("min_points_per_voxel", C.c_int32), ("min_covar_eigvalue_mult", C.c_double), ("plane_lambda", C.c_double), ("fit_threshold", C.c_double),
+                ("min_leaf_points", C.c_int32), ("min_inliers", C.c_int32), ("radius", C.c_double), ("selected_per_ring", C.c_int32), ("reserved", C.c_int32)]
+
+
+def assoc_default_options(ctx, **kw):
+    o = AssocOptions()
+    ctx._ck(ctx._l.lvx_assoc_default_options(C.byref(o)))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def set_scans(ctx, raw, H, W):
+    """The dataset's organised raw scans [n_scans][H][W] (POINT_XYZIT), handed over once (lvx_set_scans)."""
+    raw = np.ascontiguousarray(raw, dtype=POINT_XYZIT)
+    assert raw.size % (H * W) == 0
+    ctx._ck(ctx._l.lvx_set_scans(ctx._h, C.c_int(raw.size // (H * W)), C.c_int(H), C.c_int(W), _p(raw)))
+
+
+def data_association(ctx, state, map_time, options=None):
+    """One DataAssociation round (lvx_data_association): returns (number of surfels, number of SurfelPoints); the lists stay in the context."""
+    npl, npt = C.c_int32(0), C.c_int32(0)
+    ctx._ck(ctx._l.lvx_data_association(ctx._h, _p(_d(state)), C.c_double(map_time), C.byref(options) if options is not None else None, C.byref(npl), C.byref(npt)))
+    return npl.value, npt.value
+
+
+def data_association_stats(ctx):
+    """(rounds that took the one-stop chain, how many of those were repeated on the four-stop chain)."""
+    a, b = C.c_int64(0), C.c_int64(0)
+    ctx._ck(ctx._l.lvx_data_association_stats(ctx._h, C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def get_surfel_map(ctx, n_planes):
+    out = np.zeros(max(n_planes, 1), dtype=SURFEL_PLANE)
+    ctx._ck(ctx._l.lvx_get_surfel_map(ctx._h, C.c_int(n_planes), _p(out)))
+    return out[:n_planes]
+
+
+def get_surfel_points(ctx, n_points):
+    pt, pm, t, pl = np.zeros((max(n_points, 1), 3)), np.zeros((max(n_points, 1), 3)), np.zeros(max(n_points, 1)), np.zeros(max(n_points, 1), np.int32)
+    ctx._ck(ctx._l.lvx_get_surfel_points(ctx._h, C.c_int(n_points), _p(pt), _p(pm), _p(t), _p(pl)))
+    return dict(pt=pt[:n_points], pt_map=pm[:n_points], t=t[:n_points], plane=pl[:n_points])
+
+
+def get_scans_in_map(ctx, n_scans, H, W):
+    out = np.zeros((n_scans, H, W, 4), np.float32)
+    ctx._ck(ctx._l.lvx_get_scans_in_map(ctx._h, _p(out)))
+    return out
+
+
 def eval_lidar_pose(ctx, state, t):
     state, t = _d(state), _d(np.atleast_1d(t))
     n = len(t)

@@ -70,9 +70,10 @@ def minimize_polynomial(c, lo, hi):
     return 0.5 * (a + b)
 
 
-def projected_line_search(eval_fg, f0, g0, f1, g1, max_trials=20, sufficient_decrease=1e-4, max_contraction=1e-3, min_contraction=0.6, min_step=1e-9, verbose=False):
+def projected_line_search(eval_fg, f0, g0, f1, g1, max_trials=20, sufficient_decrease=1e-4, max_contraction=1e-3, min_contraction=0.6, min_step=1e-9, verbose=False, direction_max_norm=1.0):
     """Armijo search along the (projected) step: eval_fg(alpha) -> (cost, directional derivative) at Plus(x, alpha delta).  (f1, g1): the full step, already
-    evaluated.  Returns (alpha, cost at alpha, trials) — alpha = 1 when the full step is kept (it satisfies Armijo, or no step does)."""
+    evaluated.  Returns (alpha, cost at alpha, trials) — alpha = 1 when the full step is kept (it satisfies Armijo, or no step does).  The search gives up when
+    alpha * direction_max_norm (the infinity norm of the step, LineSearchFunction::DirectionInfinityNorm) falls under min_line_search_step_size, as ArmijoLineSearch does."""
     if not (g0 < 0.0) or not np.isfinite(f1) or f1 <= f0 + sufficient_decrease * g0:
         return 1.0, f1, 0
     prev, cur = None, (1.0, f1, g1)
@@ -82,7 +83,7 @@ def projected_line_search(eval_fg, f0, g0, f1, g1, max_trials=20, sufficient_dec
         a = minimize_polynomial(c, max_contraction * cur[0], min_contraction * cur[0])
         if verbose:
             print("  oracle line search trial %d: f0 %.12e g0 %.12e | last step %.6e f %.12e df %.12e -> step %.12e" % (trial, f0, g0, cur[0], cur[1], cur[2], a))
-        if a < min_step:
+        if a * direction_max_norm < min_step:
             break
         f, g = eval_fg(a)
         if np.isfinite(f) and f <= f0 + sufficient_decrease * a * g0:
@@ -211,7 +212,7 @@ def lm_solve(oracle, state, free, max_iterations=50, initial_radius=1e4, max_rad
                         return e["cost"], float(e["g"] @ delta)
                     except (IndexError, ValueError):
                         return np.inf, 0.0
-                a, fa, trials = projected_line_search(eval_fg, cost, g0, cand, eval_fg(1.0)[1])
+                a, fa, trials = projected_line_search(eval_fg, cost, g0, cand, eval_fg(1.0)[1], direction_max_norm=float(np.abs(delta).max()))
                 line_search_trials.append(trials)
                 if a != 1.0:
                     delta = a * delta

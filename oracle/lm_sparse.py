@@ -256,7 +256,7 @@ def lm_solve(oracle, state, free, n_knots, n_landmarks, max_iterations=50, initi
                         return e["cost"], float((e["J"].T @ e["r"]) @ delta)
                     except (IndexError, ValueError):
                         return np.inf, 0.0
-                a, fa, _ = lm.projected_line_search(eval_fg, cost, g0, cand, eval_fg(1.0)[1])
+                a, fa, _ = lm.projected_line_search(eval_fg, cost, g0, cand, eval_fg(1.0)[1], direction_max_norm=float(np.abs(delta).max()))
                 if a != 1.0:
                     delta = a * delta
                     xc = oracle.plus(x, delta)

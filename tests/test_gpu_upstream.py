@@ -466,3 +466,83 @@ def test_data_association_map_time_outside_the_trajectory():
     call(S["t_map"])
     assert (npl.value, npt.value) == first
     g.close()
+
+
+def _da_round(g, S, state, opt=None):
+    npl, npt = lvx.data_association(g, state, S["t_map"], opt)
+    return dict(n=(npl, npt), planes=lvx.get_surfel_map(g, npl), points=lvx.get_surfel_points(g, npt), cloud=lvx.get_scans_in_map(g, len(S["scans"]), S["H"], S["W"]))
+
+
+def _da_same(a, b):
+    assert a["n"] == b["n"]
+    assert np.array_equal(a["cloud"].view(np.uint32), b["cloud"].view(np.uint32))
+    assert a["planes"].tobytes() == b["planes"].tobytes()
+    for k in ("pt", "pt_map", "t", "plane"):
+        assert np.array_equal(a["points"][k], b["points"][k]), k
+
+
+def _da_context(S, sync=False):
+    g = lvx.Context(0)
+    if sync:
+        g.set_switch("DA_SYNC", 1)
+    g.set_spline(S["t0"], S["dt"], S["n_knots"])
+    raw = np.zeros(S["scans"].shape, dtype=lvx.POINT_XYZIT)
+    for k in ("x", "y", "z", "timestamp"):
+        raw[k] = S["scans"][k]
+    lvx.set_scans(g, raw, S["H"], S["W"])
+    return g
+
+
+def test_data_association_one_stop_rounds_equal_the_four_stop_chain():
+    """Round 2 onwards lvx_data_association launches the whole chain over the capacities of the round before and stops at the host once.  Same surfel map,
+    same SurfelPoints, same map cloud — bit for bit — as a context that always runs the four-stop chain (LVX_DA_SYNC), at the same state and at a state moved between
+    the rounds (the refinement's situation: leaf, plane and list counts all change a little)."""
+    S = synth.make_sequence(seed=50)
+    rng = np.random.default_rng(5)
+    N = S["n_knots"]
+    states = [np.ascontiguousarray(S["state0"], np.float64)]
+    for _ in range(3):   # the trajectory moves by millimetres / tenths of a milliradian per refinement round
+        x = states[-1].copy()
+        x[:3 * N] += 2e-3 * rng.standard_normal(3 * N)                      # state = r3_cp[n][3] | so3_cp[n][4] | ... (include/lvx.h)
+        q = x[3 * N:7 * N].reshape(N, 4) + 2e-4 * rng.standard_normal((N, 4))
+        x[3 * N:7 * N] = (q / np.linalg.norm(q, axis=1, keepdims=True)).ravel()
+        states.append(x)
+    g, ref = _da_context(S), _da_context(S, sync=True)
+    counts = []
+    for i, x in enumerate(states + [states[0], states[0]]):
+        a, b = _da_round(g, S, x), _da_round(ref, S, x)
+        _da_same(a, b)
+        counts.append(a["n"])
+    runs, repeats = lvx.data_association_stats(g)
+    print("rounds:", counts, "one-stop rounds %d, repeated %d" % (runs, repeats))
+    assert len(set(counts[:4])) > 1                        # the counts really moved between the rounds
+    assert runs == len(counts) - 1 and repeats == 0        # every round after the first took the one-stop chain and none outgrew its capacities
+    assert lvx.data_association_stats(ref) == (0, 0)
+    assert counts[0][0] > 100 and counts[0][1] > 1000
+    g.close(); ref.close()
+
+
+def test_data_association_outgrown_capacity_repeats_the_round():
+    """Capacities learned from a round with few leaves / planes / list entries (a coarse, strict surfel map), then a round with the defaults: every count outgrows what was
+    planned, the one-stop attempt is discarded and the four-stop chain gives exactly what a fresh context gives; the next round is one-stop again."""
+    S = synth.make_sequence(seed=50)
+    x = np.ascontiguousarray(S["state0"], np.float64)
+    g, ref = _da_context(S), _da_context(S, sync=True)
+    strict = lvx.assoc_default_options(g, ndt_resolution=4.0, min_inliers=60, min_leaf_points=40)
+    a0 = _da_round(g, S, x, strict)
+    _da_same(a0, _da_round(ref, S, x, strict))
+    a1, b1 = _da_round(g, S, x), _da_round(ref, S, x)
+    assert a1["n"][0] > 4 * a0["n"][0]
+    _da_same(a1, b1)
+    assert lvx.data_association_stats(g) == (1, 1)
+    _da_same(_da_round(g, S, x), b1)
+    assert lvx.data_association_stats(g) == (2, 1)
+    # and back to the small map: the capacities shrink when a count falls under a quarter of them — still the same results
+    _da_same(_da_round(g, S, x, strict), a0)
+    _da_same(_da_round(g, S, x, strict), a0)
+    # a map time outside the trajectory on the one-stop chain: the same error, the context stays usable
+    with pytest.raises(lvx.LvxError) as e:
+        lvx.data_association(g, x, S["t0"] - 100.0)
+    assert e.value.code == lvx.E_RANGE and "map time outside the trajectory" in str(e.value)
+    _da_same(_da_round(g, S, x), b1)
+    g.close(); ref.close()
