@@ -660,15 +660,19 @@ template <int PT>
 __global__ __launch_bounds__(256) void k_vx_leaf(const float4* __restrict__ p, const unsigned* __restrict__ skeys, const int* __restrict__ sorted_ids, int n_pts, unsigned invalid, unsigned long long* lb,
                                                  int min_pts, double eig_mult, VxInfo* info, int* grid, int* leaf_key, int* leaf_n, unsigned* counts, unsigned* offs,
                                                  double* mean, double* cov, double* icov, double* evecs, double* evals, float* centroid, VxInfo* h_info) {
-  constexpr int TILE = 256 * PT, STAGE = PT == 1 ? 1024 : TILE + 256;   // positions staged in LDS at a time: the tile + VX_LONG fit one stage
-  static_assert(TILE + VX_LONG <= STAGE && TILE / VX_LONG + 2 <= 16, "first stage / long-leaf list");
-  __shared__ float4 pts[2][STAGE];
-  __shared__ int lng[16], n_lng;
+  constexpr int TILE = 256 * PT;
   __shared__ int hpos[TILE + 1];
   __shared__ int wcnt[PT * 4 < 4 ? 4 : PT * 4];
   __shared__ int s_prefix, s_end;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
   const int tile0 = b * TILE;
+#ifdef VXKT
+  long long kt_[8]; int kti_ = 0; const long long rt0_ = wall_clock64();
+#define VXKT_MARK() { long long t_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); kt_[kti_++] = t_; }
+#else
+#define VXKT_MARK()
+#endif
+  VXKT_MARK()
   const bool ovf = info->overflow != 0;
   bool head[PT]; int rank[PT];
 #pragma unroll
@@ -690,30 +694,34 @@ __global__ __launch_bounds__(256) void k_vx_leaf(const float4* __restrict__ p, c
     for (int e = 0; e < 4 * u + wv; ++e) r += wcnt[e];
     if (head[u]) hpos[r] = tile0 + 256 * u + tid;
   }
-  // leaves before this tile
-  if (wv == 0) {
-    if (lane == 0) vx_lb_store(&lb[b], ((b == 0 ? 2ull : 1ull) << 32) | (unsigned)hb);
-    int prefix = 0;
-    if (b > 0) {
-      for (int base = b - 1;; base -= 64) {
-        const int j = base - lane;
-        unsigned long long v = 2ull << 32;
-        if (j >= 0) do { v = vx_lb_load(&lb[j]); } while ((v >> 32) == 0ull);
-        const unsigned long long incl = __ballot((v >> 32) == 2ull);
-        const int first = incl ? __ffsll((long long)incl) - 1 : 63;
-        int val = lane <= first ? (int)(unsigned)(v & 0xffffffffull) : 0;
-        for (int o = 32; o > 0; o >>= 1) val += __shfl_xor(val, o);
-        prefix += val;
-        if (incl) break;
+  // leaves before this tile: every tile publishes its own count as soon as it has it (one 64-bit word: flag | count) and sums ALL its predecessors' words — every
+  // load in flight together, one round trip once they are out.  (Rounds 3-5a: decoupled look-back over inclusive prefixes, 64 predecessors per step — the last of 400
+  // tiles of a 410 k-point cloud walked seven dependent steps, 14 us of the kernel's 71.)
+  {
+    if (tid == 0) vx_lb_store(&lb[b], (1ull << 32) | (unsigned)hb);
+    int part = 0;
+    for (int j0 = tid; j0 < b; j0 += 256 * 8) {
+      unsigned long long v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = j0 + 256 * u < b ? vx_lb_load(&lb[j0 + 256 * u]) : (1ull << 32);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        while ((v[u] >> 32) == 0ull) v[u] = vx_lb_load(&lb[j0 + 256 * u]);
+        part += (int)(unsigned)(v[u] & 0xffffffffull);
       }
-      if (lane == 0) vx_lb_store(&lb[b], (2ull << 32) | (unsigned)(prefix + hb));
     }
-    if (lane == 0) {
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    __syncthreads();                     // (wcnt was read above by everybody)
+    if (lane == 0) wcnt[wv] = part;
+    __syncthreads();
+    if (tid == 0) {
+      const int prefix = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
       s_prefix = prefix; s_end = -1;
       if (b == (int)gridDim.x - 1) { info->n_leaves = prefix + hb; VxInfo t = *info; t.n_leaves = prefix + hb; *h_info = t; }   // the host's mirror (pinned memory), read after a stream synchronisation
     }
   }
   __syncthreads();
+  VXKT_MARK()
   if (hb == 0) return;
   // end of the tile's last leaf: the first position behind its head with another key
   {
@@ -778,81 +786,110 @@ __global__ __launch_bounds__(256) void k_vx_leaf(const float4* __restrict__ p, c
     }
     leaf_n[li] = nr;
   };
-  // SHORT leaves (<= VX_LONG points; all of them start inside the tile, so they lie in the first stage): one thread per leaf, sums IN INPUT ORDER (the sort is stable) —
-  // cov = (sum x x^T - 2 sum x mu^T) / n + mu mu^T cancels ~6 digits, only the reference's summation order reproduces it to 1e-12 of its own scale; the float centroid
-  // is compared bit for bit.
+  // SUMS.  A leaf needs twelve running sums — x y z | xx xy xz yy yz zz in double, x y z in float — each IN INPUT ORDER (the sort is stable): cov = (sum x x^T - 2 sum x
+  // mu^T) / n + mu mu^T cancels ~6 digits, only the reference's summation order reproduces it to 1e-12 of its own scale, and the float centroid is compared bit for bit.
+  // Twelve independent chains per leaf: a group of 16 lanes takes a leaf, lane j its chain j.  The workgroup walks its positions [S, E) in stages of 256: every thread
+  // fetches one point (ids two stages ahead, points one stage ahead of the walk) and leaves its nine double terms (x * 1.0 and the products of two floats are exact) and
+  // three float terms in LDS; then the groups walk the leaves that intersect the stage, 8 leaves per sub-round; a leaf that continues into the next stage carries its
+  // partial sums in the LDS slot its final sums go to.  Thread-per-leaf finalize (eigen-solve) afterwards, 128 leaves at a time.
+  // (Round 4: thread-per-leaf sums for leaves <= 128 points + one 16-lane group per workgroup for longer ones, 83 us on the map cloud of lvx_data_association — 4 072
+  // leaves, 100 points on average, the longest 2 298 — of which 56 us were the long-leaf path: seven instructions per point and chain, leaf after leaf.)
+  VXKT_MARK()
   {
-    constexpr int NU = STAGE / 256;
-    int id[NU];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) { const int j = S + tid + 256 * u; id[u] = j < E ? sorted_ids[j] : -1; }
-#pragma unroll
-    for (int u = 0; u < NU; ++u) if (id[u] >= 0) pts[0][tid + 256 * u] = p[id[u]];
-  }
-  if (tid == 0) n_lng = 0;
-  __syncthreads();
-  for (int r = tid; r < hb; r += 256) {
-    const int la = hpos[r], le = hpos[r + 1];
-    if (le - la > VX_LONG) { lng[atomicAdd(&n_lng, 1)] = r; continue; }
-    double s[3] = {0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};   // xx xy xz yy yz zz (x_a x_b == x_b x_a bit for bit)
-    float cen[3] = {0, 0, 0};
-    for (int k = la; k < le; ++k) {
-      const float4 q = pts[0][k - S];
-      const double x = q.x, y = q.y, z = q.z;
-      s[0] += x; s[1] += y; s[2] += z;
-      c[0] += x * x; c[1] += x * y; c[2] += x * z; c[3] += y * y; c[4] += y * z; c[5] += z * z;
-      cen[0] += q.x; cen[1] += q.y; cen[2] += q.z;
-    }
-    finalize(r, la, le - la, s, c, cen);
-  }
-  __syncthreads();
-  // LONG leaves (a map cloud's walls; the pile of zero points the de-skew leaves for dropped returns: 20 k points in one voxel): the twelve running sums of a leaf —
-  // x y z | xx xy xz yy yz zz | float x y z — are twelve independent chains, each in input order: lane j of wavefront 0 takes chain j while wavefronts 1-3 stage the next
-  // 1 024 points into the other LDS buffer.  One thread walking all twelve chains of a 20 k-point leaf took 250 us (k_vx_leaf on the map cloud of lvx_data_association).
-  // x * 1.0 is exact, so the plain sums are the same chains as above.
-  const int nl_long = n_lng;
-  const int comp = tid & 15;
-  const int ia = comp < 3 ? comp : (comp < 6 ? 0 : (comp < 8 ? 1 : (comp < 9 ? 2 : (comp < 12 ? comp - 9 : 0))));
-  const int ib = comp < 3 ? 3 : (comp < 6 ? comp - 3 : (comp < 8 ? comp - 5 : 2));
-  for (int q = 0; q < nl_long; ++q) {
-    const int r = lng[q], la = hpos[r], le = hpos[r + 1];
-    auto load = [&](int c0, int buf) {   // wavefronts 1-3: positions [c0, min(le, c0 + STAGE)) -> pts[buf]
-      if (wv == 0) return;
-      for (int j0 = tid - 64; j0 < STAGE; j0 += 4 * 192) {
-        int id[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { const int j = j0 + 192 * u; id[u] = (j < STAGE && c0 + j < le) ? sorted_ids[c0 + j] : -1; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) if (id[u] >= 0) { float4 v = p[id[u]]; v.w = 1.0f; pts[buf][j0 + 192 * u] = v; }
-      }
-    };
-    int buf = 0;
-    load(la, 0);
-    __syncthreads();
-    double acc = 0.0; float accf = 0.0f;
-    for (int c0 = la; c0 < le; c0 += STAGE) {
-      if (c0 + STAGE < le) load(c0 + STAGE, buf ^ 1);
-      if (tid < 16) {
-        const int m = min(le - c0, STAGE);
-        const float* pa = (const float*)&pts[buf][0] + ia; const float* pb = (const float*)&pts[buf][0] + ib;
-#pragma unroll 8
-        for (int k = 0; k < m; ++k) {
-          const float fa = pa[4 * k], fb = pb[4 * k];   // the lane's two operands by ADDRESS (w = 1.0f was staged): a per-lane select of components was compiled
-          acc += (double)fa * (double)fb;               // into divergent branches around every conversion, 300 cycles per point
-          accf += fa;
+    constexpr int LDD = 257;
+    __shared__ double sD[9][LDD];
+    __shared__ float sF[3][256];
+    constexpr int LCH = 128;            // leaves per finalize chunk
+    __shared__ double sumD[9][LCH];
+    __shared__ float sumF[3][LCH];
+    const int g = (tid >> 4) & 7, j = tid & 15;   // leaf slot of the sub-round, chain
+    const bool fchain = wv >= 2;                   // (wave-uniform)
+    const int jd = j < 9 ? j : 0, jf = j < 3 ? j : 0;
+    for (int c0 = 0; c0 < hb; c0 += LCH) {          // leaves [c0, c1) of the tile
+      const int c1 = min(hb, c0 + LCH);
+      const int P0 = hpos[c0], P1 = hpos[c1];
+      auto ld_id = [&](int pos) { return pos + tid < P1 ? sorted_ids[pos + tid] : -1; };
+      auto ld_pt = [&](int id) { return id >= 0 ? p[id] : float4{0.f, 0.f, 0.f, 0.f}; };
+      int id_nx = ld_id(P0);
+      float4 q = ld_pt(id_nx);
+      id_nx = ld_id(P0 + 256);
+      int r_lo = c0;                                 // first leaf not yet complete
+      for (int st0 = P0; st0 < P1; st0 += 256) {
+        const int st1 = min(st0 + 256, P1);
+        {
+          const double x = q.x, y = q.y, z = q.z;
+          sD[0][tid] = x; sD[1][tid] = y; sD[2][tid] = z;
+          sD[3][tid] = x * x; sD[4][tid] = x * y; sD[5][tid] = x * z; sD[6][tid] = y * y; sD[7][tid] = y * z; sD[8][tid] = z * z;
+          sF[0][tid] = q.x; sF[1][tid] = q.y; sF[2][tid] = q.z;
         }
+        // leaves that begin before st1: r_lo .. r_hi (at most 256 begin inside a stage, plus the one that continues into it)
+        const int cand = r_lo + tid;
+        const int nbeg = __syncthreads_count(cand < c1 && hpos[cand] < st1);   // (also the barrier behind the LDS writes)
+        const int r_hi = r_lo + nbeg - 1 + ((nbeg == 256 && r_lo + 256 < c1 && hpos[r_lo + 256] < st1) ? 1 : 0);
+        q = ld_pt(id_nx);                            // next stage's points, next-but-one's ids: in flight during the walk
+        id_nx = ld_id(st0 + 512);
+        // the chain: ONE dependent add per point and lane.  Wavefronts 0-1 walk the nine double chains of leaf slots 0-7 (a 16-lane group per slot), wavefronts 2-3 the
+        // three float chains of the same slots: an FP64 add occupies the SIMD for eight cycles, the float add rode in the same instruction stream for four more.  The
+        // operands of the next eight points are fetched while a batch is added — two batches per trip in named registers, no copies that would wait for the loads just
+        // issued.  (Plain loop: 50 cycles per point, 48 of the kernel's 71 us were the 2 298-point leaf's nine stages; pipelined, both chains in one wavefront: 30.)
+        for (int rb = r_lo; rb <= r_hi; rb += 8) {
+          const int r = rb + g;
+          if (r > r_hi) continue;
+          const int la = hpos[r], le = hpos[r + 1];
+          const int k0 = max(la, st0) - st0, k1 = min(le, st1) - st0;
+          constexpr int WB = 8;
+          const int nfull = (k1 - k0) / WB;
+          auto walk = [&](auto zero, const auto* src) {
+            using T = decltype(zero);
+            T acc = zero;
+            T A[WB], B[WB];
+            auto fetch = [&](T* D_, int k) {   // (past the leaf's end: loaded, never added — LDS reads do not fault)
+#pragma unroll
+              for (int u = 0; u < WB; ++u) D_[u] = src[k + u];
+            };
+            auto add = [&](const T* D_) {
+#pragma unroll
+              for (int u = 0; u < WB; ++u) acc += D_[u];
+            };
+            int i = 0;
+            if (nfull > 0) fetch(A, k0);
+            for (; i + 2 <= nfull; i += 2) {
+              fetch(B, k0 + WB * (i + 1));
+              add(A);
+              fetch(A, k0 + WB * (i + 2));
+              add(B);
+            }
+            if (i < nfull) add(A);
+            for (int k = k0 + WB * nfull; k < k1; ++k) acc += src[k];
+            return acc;
+          };
+          if (!fchain) {
+            const double acc = walk(la < st0 ? sumD[jd][r - c0] : 0.0, &sD[jd][0]);
+            if (j < 9) sumD[j][r - c0] = acc;
+          } else {
+            const float accf = walk(la < st0 ? sumF[jf][r - c0] : 0.0f, &sF[jf][0]);
+            if (j < 3) sumF[j][r - c0] = accf;
+          }
+        }
+        r_lo = hpos[r_hi + 1] <= st1 ? r_hi + 1 : r_hi;   // the last leaf of the stage may continue
+        __syncthreads();
+      }
+      VXKT_MARK()
+      if (c0 + tid < c1) {
+        const int r = c0 + tid;
+        double sm[3], cv[6]; float cen[3];
+        for (int a = 0; a < 3; ++a) { sm[a] = sumD[a][tid]; cen[a] = sumF[a][tid]; }
+        for (int a = 0; a < 6; ++a) cv[a] = sumD[3 + a][tid];
+        finalize(r, hpos[r], hpos[r + 1] - hpos[r], sm, cv, cen);
       }
       __syncthreads();
-      buf ^= 1;
-    }
-    if (tid < 16) {
-      double s[3], c[6]; float cen[3];
-      for (int j = 0; j < 3; ++j) s[j] = __shfl(acc, j);
-      for (int j = 0; j < 6; ++j) c[j] = __shfl(acc, 3 + j);
-      for (int j = 0; j < 3; ++j) cen[j] = __shfl(accf, 9 + j);
-      if (tid == 0) finalize(r, la, le - la, s, c, cen);
+      VXKT_MARK()
     }
   }
+#ifdef VXKT
+  { const long long rt1_ = wall_clock64();
+    if (tid == 0) printf("VXKT b %d hb %d pts %d: heads %lld endsearch %lld sums %lld finalize %lld total %lld rt %lld %lld\n", b, hb, E - S, kt_[1] - kt_[0], kt_[2] - kt_[1], kt_[3] - kt_[2], kt_[4] - kt_[3], kt_[kti_ - 1] - kt_[0], rt0_, rt1_); }
+#endif
 }
 // ------------------------------------------------------------------------------------------------------------------------
 // NDT registration (pclomp::NormalDistributionsTransform, src/ndt_omp/include/pclomp/ndt_omp_impl.hpp): derivative evaluation, Hessian-only pass, fitness.
@@ -1800,12 +1837,16 @@ static int voxel_enqueue(lvx_ctx* c, const float4* d_pts, int n, float leaf, int
   }
   int* lk = (int*)V.leaf_i.p; int* ln = lk + cap;
   double* mean = (double*)V.leaf_d.p; double* cov = mean + 3 * cap; double* icov = cov + 9 * cap; double* evecs = icov + 9 * cap; double* evals = evecs + 9 * cap;
-  if (n > 500000)
-    hipLaunchKernelGGL(k_vx_leaf<4>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, d_pts, (const unsigned*)k_out, (const int*)v_out, n, invalid, lbs, min_pts, eig_mult, d_info, (int*)V.cells.p, lk, ln,
+  // tile = 256 PT sorted positions per workgroup, PT chosen so that the launch is ONE round of resident workgroups (4 per CU at 37 KB of LDS = 1 024) as long as the
+  // cloud allows: the workgroup is a latency chain (keys -> counts of all predecessors -> points -> sums -> eigen-solve) and a second round repeats it
+  auto launch_leaf = [&](auto pt) {
+    constexpr int PT = decltype(pt)::value;
+    hipLaunchKernelGGL(k_vx_leaf<PT>, dim3((unsigned)((n + 256 * PT - 1) / (256 * PT))), dim3(256), 0, st, d_pts, (const unsigned*)k_out, (const int*)v_out, n, invalid, lbs, min_pts, eig_mult, d_info, (int*)V.cells.p, lk, ln,
                        counts, offs, mean, cov, icov, evecs, evals, (float*)V.leaf_f.p, (VxInfo*)V.h_info);
-  else
-    hipLaunchKernelGGL(k_vx_leaf<1>, dim3((unsigned)n_tiles), dim3(256), 0, st, d_pts, (const unsigned*)k_out, (const int*)v_out, n, invalid, lbs, min_pts, eig_mult, d_info, (int*)V.cells.p, lk, ln,
-                       counts, offs, mean, cov, icov, evecs, evals, (float*)V.leaf_f.p, (VxInfo*)V.h_info);
+  };
+  if (n > 524288) launch_leaf(std::integral_constant<int, 4>{});
+  else if (n > 262144) launch_leaf(std::integral_constant<int, 2>{});
+  else launch_leaf(std::integral_constant<int, 1>{});
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
 }

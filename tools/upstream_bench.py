@@ -74,11 +74,12 @@ if __name__ == "__main__":
         st_ = np.ascontiguousarray(S["state0"], np.float64)
         npl, npt = C.c_int32(0), C.c_int32(0)
         da = lambda: g._ck(g._l.lvx_data_association(g._h, st_.ctypes.data_as(C.c_void_p), C.c_double(S["t_map"]), None, C.byref(npl), C.byref(npt)))
-        da()
-        t0 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(3):   # round 1 = the four-stop chain, round 2 sizes the one-stop chain's buffers
             da()
-        tda = (time.perf_counter() - t0) / 5
+        t0 = time.perf_counter()
+        for _ in range(20):
+            da()
+        tda = (time.perf_counter() - t0) / 20
         print("data_association     : %.1f us per round, %d scans x %d points, %d surfels, %d SurfelPoints" % (1e6 * tda, len(rawd), rawd[0].size, npl.value, npt.value))
         g.close()
     except Exception as e:   # noqa: BLE001
