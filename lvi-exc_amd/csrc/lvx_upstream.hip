@@ -1174,25 +1174,41 @@ __global__ __launch_bounds__(256) void k_surfel_extract(const float4* __restrict
   int t0 = 0, t1 = 1, t2 = 2;
   if (an[t1] > an[t0]) { const int t = t0; t0 = t1; t1 = t; }
   if (an[t2] > an[t1]) { const int t = t1; t1 = t2; t2 = t; if (an[t1] > an[t0]) { const int u = t0; t0 = t1; t1 = u; } }
-  const int o = (int)offs[li], cnt = (int)counts[li];
+  const int o = (int)offs[li]; int cnt = (int)counts[li];
   double d = -(nrm[0] * mean[3 * (size_t)li] + nrm[1] * mean[3 * (size_t)li + 1] + nrm[2] * mean[3 * (size_t)li + 2]);
   int nin = 0;
   float bmin[3] = {3.402823466e38f, 3.402823466e38f, 3.402823466e38f}, bmax[3] = {-3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
   for (int pass = 0; pass < 2; ++pass) {
     double sm[3] = {0, 0, 0}, cc[6] = {0, 0, 0, 0, 0, 0};
     int my = 0;
-    for (int k = lane; k < cnt; k += 64) {
-      const float4 q = p[sorted_ids[o + k]];
-      const double x[3] = {q.x, q.y, q.z};
-      if (pass == 0) {
-        bmin[0] = fminf(bmin[0], q.x); bmin[1] = fminf(bmin[1], q.y); bmin[2] = fminf(bmin[2], q.z);
-        bmax[0] = fmaxf(bmax[0], q.x); bmax[1] = fmaxf(bmax[1], q.y); bmax[2] = fmaxf(bmax[2], q.z);
-      }
-      if (!(fabs(nrm[0] * x[0] + nrm[1] * x[1] + nrm[2] * x[2] + d) < thr)) continue;
-      ++my;
-      if (pass == 0) {
-        sm[0] += x[0]; sm[1] += x[1]; sm[2] += x[2];
-        cc[0] += x[0] * x[0]; cc[1] += x[0] * x[1]; cc[2] += x[0] * x[2]; cc[3] += x[1] * x[1]; cc[4] += x[1] * x[2]; cc[5] += x[2] * x[2];
+    // a lane's points k = lane, lane + 64, ... in that order (the sums keep their order), EX_U of them per trip: their ids were fetched with the previous trip's points,
+    // their points leave together — one memory round trip per EX_U points of a lane.  (One point per trip was two dependent round trips each: the 2 298-point leaf of the
+    // DataAssociation map cloud walked 36 of them per pass, 62-77 us for the launch.)
+    constexpr int EX_U = 8;
+    int idn[EX_U];
+#pragma unroll
+    for (int u = 0; u < EX_U; ++u) { const int kk = lane + 64 * u; idn[u] = kk < cnt ? sorted_ids[o + kk] : -1; }
+    for (int k0 = lane; k0 < cnt; k0 += 64 * EX_U) {
+      float4 qq[EX_U]; int idc[EX_U];
+#pragma unroll
+      for (int u = 0; u < EX_U; ++u) { idc[u] = idn[u]; qq[u] = p[max(idc[u], 0)]; }
+#pragma unroll
+      for (int u = 0; u < EX_U; ++u) { const int kk = k0 + 64 * (EX_U + u); idn[u] = kk < cnt ? sorted_ids[o + kk] : -1; }
+#pragma unroll
+      for (int u = 0; u < EX_U; ++u) {
+        if (idc[u] < 0) continue;
+        const float4 q = qq[u];
+        const double x[3] = {q.x, q.y, q.z};
+        if (pass == 0) {
+          bmin[0] = fminf(bmin[0], q.x); bmin[1] = fminf(bmin[1], q.y); bmin[2] = fminf(bmin[2], q.z);
+          bmax[0] = fmaxf(bmax[0], q.x); bmax[1] = fmaxf(bmax[1], q.y); bmax[2] = fmaxf(bmax[2], q.z);
+        }
+        if (!(fabs(nrm[0] * x[0] + nrm[1] * x[1] + nrm[2] * x[2] + d) < thr)) continue;
+        ++my;
+        if (pass == 0) {
+          sm[0] += x[0]; sm[1] += x[1]; sm[2] += x[2];
+          cc[0] += x[0] * x[0]; cc[1] += x[0] * x[1]; cc[2] += x[0] * x[2]; cc[3] += x[1] * x[1]; cc[4] += x[1] * x[2]; cc[5] += x[2] * x[2];
+        }
       }
     }
     for (int s = 32; s > 0; s >>= 1) my += __shfl_xor(my, s);
@@ -1205,7 +1221,9 @@ __global__ __launch_bounds__(256) void k_surfel_extract(const float4* __restrict
     double C[9];
     for (int a = 0; a < 3; ++a) for (int bb = 0; bb < 3; ++bb) C[3 * a + bb] = cs[3 * a + bb] / nin - mu[a] * mu[bb];
     double e2[3], V2[9];
-    vx_eig3<false>(C, e2, V2);   // (every lane the same: the sums are wave-uniform after the butterfly)
+    // (every lane the same: the sums are wave-uniform after the butterfly.  The solve is what the launch costs — 4 072 wave-level solves on 1 024 SIMDs: 56 of 76 us with
+    // the sweeps run until the off-diagonal squares underflow as the oracle's loop does, 28 of 48 us stopping at 1e-18 of the diagonal as k_vx_leaf does)
+    vx_eig3<true>(C, e2, V2);
     nrm[0] = V2[0]; nrm[1] = V2[3]; nrm[2] = V2[6];
     d = -(nrm[0] * mu[0] + nrm[1] * mu[1] + nrm[2] * mu[2]);
   }
@@ -1369,12 +1387,12 @@ __global__ __launch_bounds__(1024) void k_assoc_grid_scan(const int* cnt, int* o
 // all pairs: thread = scan point, the plane table of the block's chunk (256 planes) in LDS, read as broadcasts.  57.6 M exact tests per scan at P = 2000
 // (FP64 VALU bound, 36 us) — cheaper than building the grid when only one or two scans are associated in a call.
 #define SA_PC 256
-// A hit = the point's bit in the (scan, plane, ring) mask + that ring's hit count.  Hits of one surfel come in runs along a ring (a box spans tens of consecutive columns): up
+// A hit = the point's bit in the (scan, plane, ring) mask + the mask word's bit in the ring's 64-bit occupancy word (round 5b; a hit count per ring until then).  Hits of one surfel come in runs along a ring (a box spans tens of consecutive columns): up
 // to 32 lanes of a wavefront would OR the same mask word and bump the same counter, and same-address atomics of one instruction are served one after the other (round 4: the
 // two atomics were 150 of k_assoc_hits' 200 us).  The lanes of a run — same (plane, ring, mask word); consecutive lanes are consecutive columns — hand their bits to the run's
-// first lane: one OR and one add per run (neither returns a value: a returning add per run, to append first-hit rings to a work list, made the kernel 3.5x slower).
+// first lane: two ORs per run (neither returns a value: a returning add per run, to append first-hit rings to a work list, made the kernel 3.5x slower).
 // Wave-uniform among the lanes that call it together.
-__device__ __forceinline__ void sa_record_hit(bool hit, size_t ring, int w, int lane, int wpr, unsigned* bits, int* counts) {
+__device__ __forceinline__ void sa_record_hit(bool hit, size_t ring, int w, int lane, int wpr, unsigned* bits, unsigned long long* occ, int oshift) {
   const size_t word = ring * wpr + (w >> 5);
   unsigned long long pend = __ballot(hit);
   while (pend) {
@@ -1384,12 +1402,12 @@ __device__ __forceinline__ void sa_record_hit(bool hit, size_t ring, int w, int 
     pend &= ~m;
     if (lane == ld) {
       atomicOr(&bits[word], (unsigned)((m >> ld) << (w & 31)));        // lane L holds column w + (L - ld) of the same 32-column word
-      atomicAdd(&counts[ring], __popcll(m));
+      atomicOr(&occ[ring], 1ull << ((w >> 5) >> oshift));              // which of the ring's mask words hold anything (k_assoc_select reads only those)
     }
   }
 }
 __global__ __launch_bounds__(256) void k_assoc_hits_allpairs(const float4* __restrict__ scans, int H, int W, int P, const double* __restrict__ planes10, double radius,
-                                                             unsigned* bits, int* counts, int wpr) {
+                                                             unsigned* bits, unsigned long long* occ, int wpr, int oshift) {
   __shared__ double pl[10][SA_PC];
   const int p0 = blockIdx.y * SA_PC, np = min(SA_PC, P - p0), sc = blockIdx.z;
   for (int e = threadIdx.x; e < 10 * SA_PC; e += 256) {
@@ -1408,11 +1426,11 @@ __global__ __launch_bounds__(256) void k_assoc_hits_allpairs(const float4* __res
     if (!__ballot(inside)) continue;                                   // wave-uniform skip
     double dist = inside ? x * pl[0][k] + y * pl[1][k] + z * pl[2][k] + pl[3][k] : 1e300;
     dist = dist > 0 ? dist : -dist;
-    sa_record_hit(dist <= radius, ((size_t)sc * P + p0 + k) * H + h, w, lane, wpr, bits, counts);
+    sa_record_hit(dist <= radius, ((size_t)sc * P + p0 + k) * H + h, w, lane, wpr, bits, occ, oshift);
   }
 }
 __global__ __launch_bounds__(256) void k_assoc_hits(const float4* __restrict__ scans, int H, int W, int P, const double* __restrict__ aos, double radius, const AssocGrid* gp,
-                                                    const int* __restrict__ off, const int* __restrict__ list, unsigned* bits, int* counts, int wpr) {
+                                                    const int* __restrict__ off, const int* __restrict__ list, unsigned* bits, unsigned long long* occ, int wpr, int oshift) {
   const int i = blockIdx.x * 256 + threadIdx.x, sc = blockIdx.y, lane = threadIdx.x & 63;
   if (i >= H * W) return;
   const float4 q = scans[(size_t)sc * H * W + i];
@@ -1447,57 +1465,53 @@ __global__ __launch_bounds__(256) void k_assoc_hits(const float4* __restrict__ s
       const bool inside = (x > lo[0]) & (x < hi[0]) & (y > lo[1]) & (y < hi[1]) & (z > lo[2]) & (z < hi[2]);
       double dist = x * pl[0] + y * pl[1] + z * pl[2] + pl[3];
       dist = dist > 0 ? dist : -dist;
-      sa_record_hit((e + u < e1) & inside & (dist <= radius), ((size_t)sc * P + k[u]) * H + h, w, lane, wpr, bits, counts);
+      sa_record_hit((e + u < e1) & inside & (dist <= radius), ((size_t)sc * P + k[u]) * H + h, w, lane, wpr, bits, occ, oshift);
     }
   }
 }
-// (it also returns the ring's words and count to zero: the work buffer is cleared once, when it is allocated, not 7 MB per scan and call)
-// A WAVEFRONT per ring with hits: lane = mask word (coalesced read + clear), set-bit counts prefix-summed over the lanes, the lane whose word holds the target rank finds
-// the bit.  One thread per ring walked its 57 words serially, one load each, with a handful of lanes of the wavefront alive: 99 us for 64 scans x 2 000 surfels.
-// (Round 5, measured and dropped: a work list of the rings with hits, appended by the hit kernel when a ring's count leaves zero — two thirds of the (scan, plane, ring)
-// triples of a map-like surfel table have hits, and the returning add per run costs the hit kernel far more than this scan.)
-__global__ __launch_bounds__(256) void k_assoc_select(unsigned* __restrict__ bits, int* __restrict__ counts, int S, int H, int W, int P, int wpr, int sel, int* flags) {
+// Ring selection (surfel_association.cpp:118-139): a (scan, surfel, ring) triple with c >= 2 sel hits keeps the hits of rank step, 2 step, ... (step = c / (sel + 1)) in
+// column order.  One THREAD per ring: its occupancy word says which of the ring's mask words hold hits — a surfel's box spans tens of consecutive columns, two or three
+// words of 57 — and only those are read (counted, walked for the target ranks) and returned to zero with the occupancy word: the work buffer is cleared once, when it is
+// allocated, not 7 MB per scan and call.
+// (Rounds 4-5a: a hit COUNT per ring and a wavefront per ring with hits reading all its words — 342 MB for 57 scans x 2 500 surfels, 34 us; round 3: one thread walking
+// all 57 words serially, 99 us.  A work list of the rings with hits, appended by the hit kernel, was measured and dropped: the returning add per run costs the hit kernel
+// far more than this scan.)
+__global__ __launch_bounds__(256) void k_assoc_select(unsigned* __restrict__ bits, unsigned long long* __restrict__ occ, int S, int H, int W, int P, int wpr, int oshift, int sel, int* flags) {
   const size_t total = (size_t)S * P * H;
-  const size_t ring = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  const size_t wave0 = ring - lane;
-  const int cnt = ring < total ? counts[ring] : 0;
-  if (cnt != 0) counts[ring] = 0;
-  unsigned long long act = __ballot(cnt != 0);
-  while (act) {
-    const int src = __ffsll((long long)act) - 1;
-    act &= act - 1;
-    const size_t rg = wave0 + src;
-    const int c = __shfl(cnt, src);
-    const bool pick = c >= sel * 2;
+  const size_t rg = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (rg >= total) return;
+  const unsigned long long o = occ[rg];
+  if (o == 0ull) return;
+  occ[rg] = 0ull;
+  unsigned* bw = bits + rg * wpr;
+  const int per = 1 << oshift;
+  int c = 0;
+  for (unsigned long long oo = o; oo; oo &= oo - 1)
+    for (int q = 0; q < per; ++q) { const int k = ((__ffsll((long long)oo) - 1) << oshift) + q; if (k < wpr) c += __popc(bw[k]); }
+  if (c >= sel * 2) {
     const int h = (int)(rg % H), pid = (int)((rg / H) % P), sc = (int)(rg / ((size_t)H * P));
     int step = c / (sel + 1);
     step = step > 1 ? step : 1;
-    unsigned* bw = bits + rg * wpr;
-    int seen = 0, s = 0;   // (wave-uniform)
-    for (int k0 = 0; k0 < wpr; k0 += 64) {
-      const int k = k0 + lane;
-      const unsigned word = k < wpr ? bw[k] : 0u;
-      if (word != 0u) bw[k] = 0u;
-      if (!pick) continue;
-      const int pc = __popc(word);
-      int incl = pc;
-      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-      const int chunk = __shfl(incl, 63), excl = seen + incl - pc;
-      while (s < sel) {
-        const int target = step * (s + 1) - 1;       // the target-th hit of the ring, in column order
-        if (target >= seen + chunk) break;
-        if (target >= excl && target < excl + pc) {
+    int seen = 0, s = 0;
+    for (unsigned long long oo = o; oo && s < sel; oo &= oo - 1)
+      for (int q = 0; q < per; ++q) {
+        const int k = ((__ffsll((long long)oo) - 1) << oshift) + q;
+        if (k >= wpr) continue;
+        const unsigned word = bw[k];
+        const int pc = __popc(word);
+        while (s < sel) {
+          const int target = step * (s + 1) - 1;       // the target-th hit of the ring, in column order
+          if (target >= seen + pc) break;
           unsigned t = word;
-          for (int r = target - excl; r > 0; --r) t &= t - 1;
-          const int w = 32 * k + (__ffs(t) - 1);
-          atomicMax(&flags[(size_t)sc * H * W + (size_t)h * W + w], pid);
+          for (int r = target - seen; r > 0; --r) t &= t - 1;
+          atomicMax(&flags[(size_t)sc * H * W + (size_t)h * W + 32 * k + (__ffs(t) - 1)], pid);
+          ++s;
         }
-        ++s;
+        seen += pc;
       }
-      seen += chunk;
-    }
   }
+  for (unsigned long long oo = o; oo; oo &= oo - 1)
+    for (int q = 0; q < per; ++q) { const int k = ((__ffsll((long long)oo) - 1) << oshift) + q; if (k < wpr) bw[k] = 0u; }
 }
 // Chronological SurfelPoint emission (surfel_association.cpp:141-158): column-major (w outer, h inner), points with a flag and a non-zero raw
 // timestamp.  One workgroup per scan; order-preserving compaction by ballots + a running offset.  mode 0: count only; mode 1: write behind the scans before this one
@@ -2047,17 +2061,18 @@ static int assoc_device(lvx_ctx* c, const float4* scans_d, int S, int H, int W, 
   LVX_HIP(c, hipMemsetAsync(flags_d, 0xff, (size_t)S * H * W * 4, c->stream));
   if (P <= 0 || H <= 0 || W <= 0 || S <= 0) return LVX_OK;
   const int wpr = (W + 31) / 32;
-  const size_t rings = (size_t)S * P * H, bytes = rings * wpr * 4 + rings * 4;
+  const size_t rings = (size_t)S * P * H, bits_bytes = (rings * wpr * 4 + 7) & ~(size_t)7, bytes = bits_bytes + rings * 8;
+  const int oshift = wpr > 64 ? 1 : 0;   // (W <= SA_WMAX = 4096: at most 128 mask words per ring, two per occupancy bit)
   int rc;
   if (!c->d_assoc[3].p || c->d_assoc[3].bytes < bytes || c->assoc_rings != rings || c->assoc_wpr != wpr) {   // (re)allocated or re-shaped: clear once; k_assoc_select leaves it clean
     if ((rc = dev_alloc(c, c->d_assoc[3], bytes))) return rc;
     LVX_HIP(c, hipMemsetAsync(c->d_assoc[3].p, 0, c->d_assoc[3].bytes, c->stream));
     c->assoc_rings = rings; c->assoc_wpr = wpr;
   }
-  unsigned* bits = (unsigned*)c->d_assoc[3].p; int* counts = (int*)(bits + rings * wpr);
+  unsigned* bits = (unsigned*)c->d_assoc[3].p; unsigned long long* occ = (unsigned long long*)((char*)c->d_assoc[3].p + bits_bytes);
   if (S <= 2) {   // a scan or two: all pairs beat the grid build
-    hipLaunchKernelGGL(k_assoc_hits_allpairs, dim3((unsigned)((H * W + 255) / 256), (unsigned)((P + SA_PC - 1) / SA_PC), (unsigned)S), dim3(256), 0, c->stream, scans_d, H, W, P, planes_d, radius, bits, counts, wpr);
-    hipLaunchKernelGGL(k_assoc_select, dim3((unsigned)((rings + 255) / 256)), dim3(256), 0, c->stream, bits, counts, S, H, W, P, wpr, sel, flags_d);
+    hipLaunchKernelGGL(k_assoc_hits_allpairs, dim3((unsigned)((H * W + 255) / 256), (unsigned)((P + SA_PC - 1) / SA_PC), (unsigned)S), dim3(256), 0, c->stream, scans_d, H, W, P, planes_d, radius, bits, occ, wpr, oshift);
+    hipLaunchKernelGGL(k_assoc_select, dim3((unsigned)((rings + 255) / 256)), dim3(256), 0, c->stream, bits, occ, S, H, W, P, wpr, oshift, sel, flags_d);
     LVX_HIP(c, hipGetLastError());
     return LVX_OK;
   }
@@ -2067,8 +2082,8 @@ static int assoc_device(lvx_ctx* c, const float4* scans_d, int S, int H, int W, 
   (void)ccnt;
   const double* aos = (const double*)((const char*)c->d_assoc[0].p + ((sizeof(AssocGrid) + (size_t)(3 * SA_CELLS + 8) * 4 + 15) & ~(size_t)15));
   hipLaunchKernelGGL(k_assoc_hits, dim3((unsigned)((H * W + 255) / 256), (unsigned)S), dim3(256), 0, c->stream, scans_d, H, W, P, aos, radius, (const AssocGrid*)gd, (const int*)coff, (const int*)clist,
-                     bits, counts, wpr);
-  hipLaunchKernelGGL(k_assoc_select, dim3((unsigned)((rings + 255) / 256)), dim3(256), 0, c->stream, bits, counts, S, H, W, P, wpr, sel, flags_d);
+                     bits, occ, wpr, oshift);
+  hipLaunchKernelGGL(k_assoc_select, dim3((unsigned)((rings + 255) / 256)), dim3(256), 0, c->stream, bits, occ, S, H, W, P, wpr, oshift, sel, flags_d);
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
 }
@@ -2350,18 +2365,19 @@ static int da_speculative(lvx_ctx* c, const lvx_assoc_options& o, int S, int H, 
   if ((rc = dev_alloc(c, c->d_da[6], npt * 4))) return rc;
   LVX_HIP(c, hipMemsetAsync(c->d_da[6].p, 0xff, npt * 4, st));
   const int wpr = (W + 31) / 32, chunk = 64;
-  { const size_t rings = (size_t)std::min(chunk, S) * P_cap * H, bytes = rings * wpr * 4 + rings * 4;
+  { const size_t rings = (size_t)std::min(chunk, S) * P_cap * H, bits_bytes = (rings * wpr * 4 + 7) & ~(size_t)7, bytes = bits_bytes + rings * 8;
+    const int oshift = wpr > 64 ? 1 : 0;
     if (!c->d_assoc[3].p || c->d_assoc[3].bytes < bytes || c->assoc_rings != rings || c->assoc_wpr != wpr) {
       if ((rc = dev_alloc(c, c->d_assoc[3], bytes))) return rc;
       LVX_HIP(c, hipMemsetAsync(c->d_assoc[3].p, 0, c->d_assoc[3].bytes, st));
       c->assoc_rings = rings; c->assoc_wpr = wpr;
     }
-    unsigned* bits = (unsigned*)c->d_assoc[3].p; int* counts = (int*)(bits + rings * wpr);
+    unsigned* bits = (unsigned*)c->d_assoc[3].p; unsigned long long* occ = (unsigned long long*)((char*)c->d_assoc[3].p + bits_bytes);
     for (int s0 = 0; s0 < S; s0 += chunk) {
       const int ns = std::min(chunk, S - s0);
       const float4* sc = (const float4*)c->d_da[4].p + (size_t)s0 * H * W;
-      hipLaunchKernelGGL(k_assoc_hits, dim3((unsigned)((H * W + 255) / 256), (unsigned)ns), dim3(256), 0, st, sc, H, W, P_cap, (const double*)aos, o.radius, (const AssocGrid*)gd, (const int*)coff, (const int*)clist, bits, counts, wpr);
-      hipLaunchKernelGGL(k_assoc_select, dim3((unsigned)(((size_t)ns * P_cap * H + 255) / 256)), dim3(256), 0, st, bits, counts, ns, H, W, P_cap, wpr, o.selected_per_ring, (int*)c->d_da[6].p + (size_t)s0 * H * W);
+      hipLaunchKernelGGL(k_assoc_hits, dim3((unsigned)((H * W + 255) / 256), (unsigned)ns), dim3(256), 0, st, sc, H, W, P_cap, (const double*)aos, o.radius, (const AssocGrid*)gd, (const int*)coff, (const int*)clist, bits, occ, wpr, oshift);
+      hipLaunchKernelGGL(k_assoc_select, dim3((unsigned)(((size_t)ns * P_cap * H + 255) / 256)), dim3(256), 0, st, bits, occ, ns, H, W, P_cap, wpr, oshift, o.selected_per_ring, (int*)c->d_da[6].p + (size_t)s0 * H * W);
     } }
   LVX_HIP(c, hipGetLastError());
   // SurfelPoint lists (capacity-strided), then THE host stop
