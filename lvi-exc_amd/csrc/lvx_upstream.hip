@@ -1270,6 +1270,58 @@ __global__ __launch_bounds__(1024) void k_surfel_compact(const SurfelPlaneDev* _
     for (int a = 0; a < 3; ++a) { pl[4 * (size_t)P + 3 * (size_t)k + a] = r.bmin[a]; pl[7 * (size_t)P + 3 * (size_t)k + a] = r.bmax[a]; }
   }
 }
+// The same in up to 2 048 workgroups of 1 024 leaves (round 5b; one workgroup walked 5 600 flags in six trips of three barriers and copied every record itself, 30 us of
+// a DataAssociation round, and a 4 M-point map has 556 k leaves): a thread takes four consecutive flags and fetches their records at once, the workgroup publishes its
+// count as (epoch | count) — the epoch changes with every launch, the words are never cleared — and every workgroup sums ALL the published counts: those before it place
+// its records, the total places the plane table behind the records.
+#define SC_MAXB 2048
+__global__ __launch_bounds__(256) void k_surfel_compact_mb(const SurfelPlaneDev* __restrict__ all, const int* __restrict__ flag, int nl, SurfelPlaneDev* recs, int* count, const VxInfo* nl_d,
+                                                           unsigned long long* pub, unsigned epoch) {
+  __shared__ int wsum[4];
+  __shared__ int s_before, s_total;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x, nb = gridDim.x;
+  if (nl_d) nl = min(nl, nl_d->n_leaves);
+  const int l0 = b * 1024 + 4 * tid;
+  int f[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) f[u] = l0 + u < nl ? flag[l0 + u] : 0;
+  int mine = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) mine += f[u] != 0 ? 1 : 0;
+  int incl = mine;
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+  if (lane == 63) wsum[wv] = incl;
+  if (tid == 0) { s_before = 0; s_total = 0; }
+  __syncthreads();
+  int off = incl - mine, tot = 0;
+  for (int k = 0; k < 4; ++k) { if (k < wv) off += wsum[k]; tot += wsum[k]; }
+  if (tid == 0) __hip_atomic_store(&pub[b], ((unsigned long long)epoch << 32) | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  SurfelPlaneDev r[4];   // (the records travel while the counts are collected)
+#pragma unroll
+  for (int u = 0; u < 4; ++u) r[u] = all[max(min(l0 + u, nl - 1), 0)];
+  int sb = 0, st = 0;
+  for (int j = tid; j < nb; j += 256) {
+    unsigned long long v;
+    do { v = __hip_atomic_load(&pub[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((unsigned)(v >> 32) != epoch);
+    const int cnt = (int)(unsigned)(v & 0xffffffffull);
+    st += cnt; if (j < b) sb += cnt;
+  }
+  if (st) atomicAdd(&s_total, st);
+  if (sb) atomicAdd(&s_before, sb);
+  __syncthreads();
+  const int P = s_total;
+  int k = s_before + off;
+  if (b == 0 && tid == 0) *count = P;
+  double* pl = (double*)((char*)recs + (((size_t)P * sizeof(SurfelPlaneDev) + 15) & ~(size_t)15));
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (f[u] == 0) continue;
+    recs[k] = r[u];
+    for (int a = 0; a < 4; ++a) pl[4 * (size_t)k + a] = r[u].p4[a];
+    for (int a = 0; a < 3; ++a) { pl[4 * (size_t)P + 3 * (size_t)k + a] = r[u].bmin[a]; pl[7 * (size_t)P + 3 * (size_t)k + a] = r[u].bmax[a]; }
+    ++k;
+  }
+}
 // K = 7: getNeighborhoodAtPoint7 (:423-438), K = 1: getNeighborhoodAtPoint1 (:440-446, the cell of the point only)
 template <int K>
 __global__ void k_vx_lookup(const float4* q, int nq, float leaf, int min_pts, VxGrid g, const int* grid, const int* leaf_n, int* ids7) {
@@ -1556,6 +1608,86 @@ __global__ __launch_bounds__(1024) void k_assoc_emit(const int* __restrict__ fla
     __syncthreads();
   }
   if (threadIdx.x == 0 && !mode) counts[sc] = running;
+}
+
+// Count and write in ONE launch, a THREAD per column of the organised scan and a workgroup per 128 columns: the emission order is column-major (w outer, h inner), so a
+// thread's H points are consecutive in the list and consecutive threads read consecutive flags / raw points of every ring.  A workgroup counts its columns, publishes
+// (epoch | count) in a 64-bit word — the epoch changes with every launch, the words are never cleared — sums the words of every workgroup before it in (scan, column)
+// order, and writes its points behind them while max_out allows; every workgroup must be resident (SE_MAXWG).  A list that does not fit is reported through the counts
+// as before; what was written of it is unspecified (never past max_out).
+// (Round 4-5a: a workgroup per scan, a thread per POSITION of the emission order, one launch to count and one to write: 2 x 17 us for 57 scans x 16 x 450 — the positions
+// of a wavefront lie W apart, and one CU pulled the scan's 230 KB of timestamps alone: 7 us of each launch.)
+#define SE_HMAX 128
+#define SE_COLS 128
+#define SE_MAXWG 2048
+__global__ __launch_bounds__(SE_COLS) void k_assoc_emit_fused(const int* __restrict__ flags, const float4* __restrict__ scans_map, const void* __restrict__ raw_v, int H, int W, int* counts,
+                                                              unsigned long long* pub, unsigned epoch, int max_out, int write, SurfelOut o) {
+  struct Raw { float x, y, z, pad; float intensity; float pad2; double timestamp; };
+  const int part = blockIdx.x, parts = gridDim.x, sc = blockIdx.y, seg = sc * parts + part;
+  const Raw* __restrict__ raw = (const Raw*)raw_v + (size_t)sc * H * W;
+  const int* __restrict__ fl = flags + (size_t)sc * H * W;
+  const float4* __restrict__ sm = scans_map + (size_t)sc * H * W;
+  __shared__ int wsum[SE_COLS / 64];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int w = part * SE_COLS + tid;
+  unsigned long long km[2];                // keep bits of column w, ring h
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {   // (static register indices: a run-time index would put km into scratch memory)
+    unsigned long long acc = 0ull;
+    for (int h0 = 64 * half; h0 < min(H, 64 * half + 64); h0 += 16) {   // sixteen rings' flags and timestamps in flight
+      int pid[16]; double ts[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { const bool in = w < W && h0 + u < H; pid[u] = in ? fl[(size_t)(h0 + u) * W + w] : -1; }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { const bool in = w < W && h0 + u < H; ts[u] = in ? raw[(size_t)(h0 + u) * W + w].timestamp : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) if (pid[u] != -1 && ts[u] != 0.0) acc |= 1ull << ((h0 + u) & 63);
+    }
+    km[half] = acc;
+  }
+  const int cnt = __popcll(km[0]) + __popcll(km[1]);
+  int incl = cnt;
+  for (int o_ = 1; o_ < 64; o_ <<= 1) { const int v = __shfl_up(incl, o_); if (lane >= o_) incl += v; }
+  if (lane == 63) wsum[wv] = incl;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  int pos = incl - cnt, tot = 0;
+  for (int k = 0; k < SE_COLS / 64; ++k) { const int v = wsum[k]; if (k < wv) pos += v; tot += v; }
+  if (tid == 0) {
+    atomicAdd(&counts[sc], tot);           // (cleared by the host before the launch)
+    __hip_atomic_store(&pub[seg], ((unsigned long long)epoch << 32) | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (!write) return;
+  int before = 0;
+  for (int k0 = tid; k0 < seg; k0 += SE_COLS * 8) {
+    unsigned long long v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = k0 + SE_COLS * u < seg ? __hip_atomic_load(&pub[k0 + SE_COLS * u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)epoch << 32);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      while ((unsigned)(v[u] >> 32) != epoch) v[u] = __hip_atomic_load(&pub[k0 + SE_COLS * u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      before += (int)(unsigned)(v[u] & 0xffffffffull);
+    }
+  }
+  for (int s = 32; s > 0; s >>= 1) before += __shfl_xor(before, s);
+  if (lane == 0 && before) atomicAdd(&s_base, before);
+  __syncthreads();
+  pos += s_base;
+  double* __restrict__ o_pt = o.pt; double* __restrict__ o_pm = o.pt_map; double* __restrict__ o_t = o.t; int* __restrict__ o_pl = o.plane;
+#pragma unroll
+  for (int half = 0; half < 2; ++half)
+    for (unsigned long long m = km[half]; m; m &= m - 1) {
+      const int h = 64 * half + __ffsll((long long)m) - 1;
+      const size_t at = (size_t)h * W + w;
+      if (pos < max_out) {
+        const Raw r = raw[at]; const float4 q = sm[at]; const int pid = fl[at];
+        o_pt[3 * (size_t)pos] = r.x; o_pt[3 * (size_t)pos + 1] = r.y; o_pt[3 * (size_t)pos + 2] = r.z;
+        o_pm[3 * (size_t)pos] = q.x; o_pm[3 * (size_t)pos + 1] = q.y; o_pm[3 * (size_t)pos + 2] = q.z;
+        o_t[pos] = r.timestamp; o_pl[pos] = pid;
+      }
+      ++pos;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -2136,6 +2268,13 @@ int lvx_surfel_assoc_batch_d(lvx_ctx* c, int n_scans, int H, int W, const float*
   }
   return LVX_OK;
 }
+// the publication words of the single-launch compactions (lvx_ctx::d_pub): allocated and cleared once per context
+static int pub_words(lvx_ctx* c) {
+  if (c->d_pub.p) return LVX_OK;
+  int rc = dev_alloc(c, c->d_pub, (SE_MAXWG + SC_MAXB) * 8); if (rc) return rc;
+  LVX_HIP(c, hipMemsetAsync(c->d_pub.p, 0, c->d_pub.bytes, c->stream));
+  return LVX_OK;
+}
 // SurfelPoint lists of S associated scans, concatenated in scan order, every scan in the reference's chronological (column-major) order
 int lvx_surfel_emit_d(lvx_ctx* c, int n_scans, int H, int W, const int32_t* flags_d, const float* scans_map_d, const lvx_point_xyzit* scans_raw_d, int max_out,
                       double* pt3_d, double* pt_map3_d, double* t_d, int32_t* plane_d, int32_t* n_out, int32_t* per_scan_counts) {
@@ -2143,12 +2282,21 @@ int lvx_surfel_emit_d(lvx_ctx* c, int n_scans, int H, int W, const int32_t* flag
   LVX_HIP(c, hipSetDevice(c->device));
   int rc = dev_alloc(c, c->d_assoc[2], (size_t)n_scans * 4 + 16); if (rc) return rc;
   int* cnt_d = (int*)c->d_assoc[2].p;
+  if ((rc = pub_words(c))) return rc;
   ProfScope ps(c, LVX_KERNEL_UPSTREAM);
   SurfelOut o{pt3_d, pt_map3_d, t_d, plane_d};
   const bool have_out = pt3_d && pt_map3_d && t_d && plane_d && max_out > 0;
-  hipLaunchKernelGGL(k_assoc_emit, dim3((unsigned)n_scans), dim3(1024), 0, c->stream, flags_d, (const float4*)scans_map_d, (const void*)scans_raw_d, H, W, cnt_d, n_scans, 0, 0, o);
-  if (have_out)   // written only if the whole list fits max_out (decided on the device from the counts): one host synchronisation per call
-    hipLaunchKernelGGL(k_assoc_emit, dim3((unsigned)n_scans), dim3(1024), 0, c->stream, flags_d, (const float4*)scans_map_d, (const void*)scans_raw_d, H, W, cnt_d, n_scans, max_out, 1, o);
+  const int parts = (W + SE_COLS - 1) / SE_COLS;
+  if ((long long)n_scans * parts <= SE_MAXWG && H <= SE_HMAX) {   // one launch: count, publish, write behind the workgroups before (k_assoc_emit_fused)
+    if (++c->emit_epoch == 0u) c->emit_epoch = 1u;
+    LVX_HIP(c, hipMemsetAsync(cnt_d, 0, (size_t)n_scans * 4, c->stream));
+    hipLaunchKernelGGL(k_assoc_emit_fused, dim3((unsigned)parts, (unsigned)n_scans), dim3(SE_COLS), 0, c->stream, flags_d, (const float4*)scans_map_d, (const void*)scans_raw_d, H, W, cnt_d,
+                       (unsigned long long*)c->d_pub.p, c->emit_epoch, max_out, have_out ? 1 : 0, o);
+  } else {
+    hipLaunchKernelGGL(k_assoc_emit, dim3((unsigned)n_scans), dim3(1024), 0, c->stream, flags_d, (const float4*)scans_map_d, (const void*)scans_raw_d, H, W, cnt_d, n_scans, 0, 0, o);
+    if (have_out)   // written only if the whole list fits max_out (decided on the device from the counts): one host synchronisation per call
+      hipLaunchKernelGGL(k_assoc_emit, dim3((unsigned)n_scans), dim3(1024), 0, c->stream, flags_d, (const float4*)scans_map_d, (const void*)scans_raw_d, H, W, cnt_d, n_scans, max_out, 1, o);
+  }
   std::vector<int> cnt((size_t)n_scans);
   LVX_HIP(c, hipMemcpyAsync(cnt.data(), cnt_d, (size_t)n_scans * 4, hipMemcpyDeviceToHost, c->stream));
   LVX_HIP(c, hipGetLastError());
@@ -2259,6 +2407,18 @@ int lvx_undistort_scan(lvx_ctx* c, const double* state, int n, const lvx_point_x
   return LVX_OK;
 }
 
+// compaction of the accepted planes: [records | plane table] in recs, the count in d_cnt (device)
+static int surfel_compact_launch(lvx_ctx* c, const SurfelPlaneDev* all, const int* flag, int nl, SurfelPlaneDev* recs, int* d_cnt, const VxInfo* info) {
+  const int nb = (nl + 1023) / 1024;
+  if (nb > SC_MAXB) {   // (every workgroup of the multi-block kernel must be resident: 8 x 256 CUs)
+    hipLaunchKernelGGL(k_surfel_compact, dim3(1), dim3(1024), 0, c->stream, all, flag, nl, recs, d_cnt, info);
+    return LVX_OK;
+  }
+  int rc = pub_words(c); if (rc) return rc;
+  if (++c->compact_epoch == 0u) c->compact_epoch = 1u;
+  hipLaunchKernelGGL(k_surfel_compact_mb, dim3((unsigned)std::max(nb, 1)), dim3(256), 0, c->stream, all, flag, nl, recs, d_cnt, info, (unsigned long long*)c->d_pub.p + SE_MAXWG, c->compact_epoch);
+  return LVX_OK;
+}
 // setSurfelMap over the leaves of the context's voxel grid: the accepted planes in voxel-key (std::map) order
 static int surfel_extract_device(lvx_ctx* c, double p_lambda, double dist_threshold, int min_leaf_points, int min_inliers, std::vector<SurfelPlaneDev>& out, DevBuf& dst) {
   out.clear();
@@ -2280,7 +2440,7 @@ static int surfel_extract_device(lvx_ctx* c, double p_lambda, double dist_thresh
   // compaction on the device: [records | plane table] in dst, the count comes back (4 bytes), then the records
   if ((rc = dev_alloc(c, dst, (size_t)nl * (sizeof(SurfelPlaneDev) + 80) + 64))) return rc;
   int* d_cnt = (int*)((char*)dst.p + dst.bytes - 16);
-  hipLaunchKernelGGL(k_surfel_compact, dim3(1), dim3(1024), 0, c->stream, (const SurfelPlaneDev*)c->d_up[4].p, (const int*)c->d_up[5].p, nl, (SurfelPlaneDev*)dst.p, d_cnt, (const VxInfo*)nullptr);
+  if ((rc = surfel_compact_launch(c, (const SurfelPlaneDev*)c->d_up[4].p, (const int*)c->d_up[5].p, nl, (SurfelPlaneDev*)dst.p, d_cnt, nullptr))) return rc;
   int P = 0;
   LVX_HIP(c, hipMemcpyAsync(&P, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
   LVX_HIP(c, hipStreamSynchronize(c->stream));
@@ -2346,7 +2506,7 @@ static int da_speculative(lvx_ctx* c, const lvx_assoc_options& o, int S, int H, 
     const int* lk = (const int*)V.leaf_i.p; const double* d = (const double*)V.leaf_d.p;
     hipLaunchKernelGGL(k_surfel_extract, dim3((nl_cap + 3) / 4), dim3(256), 0, st, (const float4*)V.d_pts, counts, offs, (const int*)V.vals.p + n, nl_cap, lk + cap, d, d + 21 * cap, d + 30 * cap,
                        o.plane_lambda, o.fit_threshold, o.min_leaf_points, o.min_inliers, (SurfelPlaneDev*)c->d_up[4].p, (int*)c->d_up[5].p, d_info);
-    hipLaunchKernelGGL(k_surfel_compact, dim3(1), dim3(1024), 0, st, (const SurfelPlaneDev*)c->d_up[4].p, (const int*)c->d_up[5].p, nl_cap, (SurfelPlaneDev*)dst.p, d_cnt, d_info); }
+    if ((rc = surfel_compact_launch(c, (const SurfelPlaneDev*)c->d_up[4].p, (const int*)c->d_up[5].p, nl_cap, (SurfelPlaneDev*)dst.p, d_cnt, d_info))) return rc; }
   // the association grid of min(planes, P_cap) planes, lists of list_cap entries
   const size_t grid_bytes = (sizeof(AssocGrid) + (size_t)(3 * SA_CELLS + 8) * 4 + 15) & ~(size_t)15;
   c->assoc_map_ready = false;
