@@ -342,7 +342,8 @@ def secondary_metrics(ctx, P, lo):
         g.close()
         sec["data_association"] = {"ms": 1e3 * tda, "scans": nsc, "points": int(raw.size), "surfels": int(npl.value), "surfel_points": int(npt.value), "Mpts_per_s": raw.size / tda / 1e6,
                                    "note": "de-skew of every scan into the map frame + voxel covariance grid of the map cloud + surfel extraction + association of every scan + chronological SurfelPoint "
-                                           "emission, one call, raw scans resident on the device (lvi_initialize_surfel_orb.cpp:1180-1201)"}
+                                           "emission, one call, raw scans resident on the device (lvi_initialize_surfel_orb.cpp:1180-1201); rounds after the first run over the capacities of the "
+                                           "round before with ONE host stop (DESIGN 3.3)"}
     except Exception as e:   # noqa: BLE001
         sec["data_association"] = {"error": str(e)[:200]}
     return sec

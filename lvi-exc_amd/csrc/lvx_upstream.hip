@@ -1370,8 +1370,9 @@ __global__ void k_vx_lookup(const float4* q, int nq, float leaf, int min_pts, Vx
 struct AssocGrid { double g0[3], inv[3]; };
 __device__ __forceinline__ int sa_cell(double v, double g0, double inv, int n) { const double f = floor((v - g0) * inv); return f < 0.0 ? 0 : (f >= (double)n ? n - 1 : (int)f); }
 // one workgroup: bounds of all boxes -> grid geometry
-__global__ __launch_bounds__(256) void k_assoc_grid_geom(int P, const double* planes10, AssocGrid* g, const int* P_d) {
+__global__ __launch_bounds__(256) void k_assoc_grid_geom(int P, const double* planes10, AssocGrid* g, const int* P_d, int* cell_cnt) {
   __shared__ double lo[3][256], hi[3][256];
+  for (int e = threadIdx.x; e < SA_CELLS; e += 256) cell_cnt[e] = 0;   // (k_assoc_grid_fill counts into them next)
   if (P_d) { const int Pr = *P_d; planes10 = (const double*)((const char*)planes10 + (((size_t)Pr * sizeof(SurfelPlaneDev) + 15) & ~(size_t)15)); P = min(Pr, P); }   // see k_assoc_grid_fill
   double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
   const size_t Ps = P_d ? (size_t)*P_d : (size_t)P;
@@ -1389,8 +1390,10 @@ __global__ __launch_bounds__(256) void k_assoc_grid_geom(int P, const double* pl
 // mode 0: count the cells every box reaches; mode 1: write the box into its cells' lists (cursor = running offsets; entries past list_cap are dropped — the host finds the
 // true total behind the cursors and repeats the call with a larger list).  P_d != nullptr: the plane count is still on the device, P is the capacity the launch covers and
 // planes10 the RECORD array k_surfel_compact filled — its plane table sits right behind the *P_d records, strided by *P_d.
-__global__ void k_assoc_grid_fill(int P, const double* planes10, const AssocGrid* gp, int* cell_cnt, int* cursor, int* list, int mode, double* aos, const int* P_d, int list_cap) {
+__global__ void k_assoc_grid_fill(int P, const double* planes10, const AssocGrid* gp, int* cell_cnt, int* cursor, int* list, int mode, double* aos, const int* P_d, int list_cap,
+                                  int* mirror = nullptr, const int* pose_valid = nullptr) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mirror && k == 0) { mirror[0] = *pose_valid; mirror[1] = *P_d; mirror[2] = cursor[SA_CELLS]; }   // what the host of the one-stop chain looks at (pinned memory); cursor[SA_CELLS] = the scan's true total
   size_t Ps = (size_t)P;   // stride of the table
   if (P_d) { const int Pr = *P_d; planes10 = (const double*)((const char*)planes10 + (((size_t)Pr * sizeof(SurfelPlaneDev) + 15) & ~(size_t)15)); Ps = (size_t)Pr; P = min(Pr, P); }
   if (k >= P) return;
@@ -1786,9 +1789,10 @@ struct PointXYZIT { float x, y, z, pad; float intensity; float pad2; double time
 static_assert(sizeof(PointXYZIT) == 32, "PointXYZIT layout (pcl_utils.h:39-44)");
 // pose_d != null: the target frame's pose (q_L0_to_G x y z w | p | valid flag behind them) is still on the device (k_lidar_pose of the same stream): no host hop between the two
 // kernels; an invalid pose (map time outside the trajectory) gives NaN points, the host reports it at its next synchronisation
-__global__ void k_undistort(const double* state, int N, double t0, double dt, int n, const PointXYZIT* raw, quat qGt, v3 pT, int correct_position, float4* out, const double* pose_d = nullptr, const int* pose_ok = nullptr) {
+__global__ void k_undistort(const double* state, int N, double t0, double dt, int n, const PointXYZIT* raw, quat qGt, v3 pT, int correct_position, float4* out, const double* pose_d = nullptr, const int* pose_ok = nullptr, int* flags_init = nullptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (flags_init) flags_init[i] = -1;   // lvx_data_association: the association's "no surfel" start state rides with the de-skew (a 1.6 MB fill launch otherwise)
   const PointXYZIT r = raw[i];
   float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
   if (pose_d) { qGt = quat{-pose_d[0], -pose_d[1], -pose_d[2], pose_d[3]}; pT = mk(pose_d[4], pose_d[5], pose_d[6]); }
@@ -2176,8 +2180,7 @@ static int assoc_grid_build(lvx_ctx* c, int P, const double* planes_d, bool have
   if ((rc = dev_alloc(c, c->d_assoc[0], grid_bytes + (size_t)P * 80))) return rc;
   AssocGrid* gd = (AssocGrid*)c->d_assoc[0].p; int* ccnt = (int*)(gd + 1); int* coff = ccnt + SA_CELLS; int* ccur = coff + SA_CELLS + 1;
   double* aos = (double*)((char*)c->d_assoc[0].p + grid_bytes);
-  LVX_HIP(c, hipMemsetAsync(ccnt, 0, (size_t)SA_CELLS * 4, c->stream));
-  hipLaunchKernelGGL(k_assoc_grid_geom, dim3(1), dim3(256), 0, c->stream, P, planes_d, gd, (const int*)nullptr);
+  hipLaunchKernelGGL(k_assoc_grid_geom, dim3(1), dim3(256), 0, c->stream, P, planes_d, gd, (const int*)nullptr, ccnt);
   hipLaunchKernelGGL(k_assoc_grid_fill, dim3((unsigned)((P + 127) / 128)), dim3(128), 0, c->stream, P, planes_d, (const AssocGrid*)gd, ccnt, ccur, (int*)nullptr, 0, aos, (const int*)nullptr, 0x7fffffff);
   hipLaunchKernelGGL(k_assoc_grid_scan, dim3(1), dim3(1024), 0, c->stream, (const int*)ccnt, coff, ccur, 0x7fffffff);
   int total = 0;
@@ -2484,7 +2487,6 @@ int lvx_assoc_default_options(lvx_assoc_options* o) {
 // round on the SAME scans with a slightly moved trajectory, so the three intermediate counts barely change: the speculative chain launches everything over CAPACITIES
 // learned from the previous call (kernels read the true counts from device memory and clamp to the capacity), waits ONCE at the end, and looks at what the device
 // mirrored into pinned memory — a count above its capacity (or a cell table that was too small) discards the attempt and the synchronous chain runs.
-__global__ void k_da_counts(int* out, const int* pose_valid, const int* n_planes, const int* list_total) { out[0] = *pose_valid; out[1] = *n_planes; out[2] = *list_total; }
 static int da_capacity(int have, int need, int slack) { return (have >= need && (long long)have <= 4ll * need + 4ll * slack) ? have : need + need / 8 + slack; }
 // returns LVX_OK, an error, or 1 = a capacity was exceeded (nothing of the attempt is kept)
 static int da_speculative(lvx_ctx* c, const lvx_assoc_options& o, int S, int H, int W, size_t npt, const int* dv, int32_t* n_planes, int32_t* n_points) {
@@ -2515,16 +2517,13 @@ static int da_speculative(lvx_ctx* c, const lvx_assoc_options& o, int S, int H, 
   AssocGrid* gd = (AssocGrid*)c->d_assoc[0].p; int* ccnt = (int*)(gd + 1); int* coff = ccnt + SA_CELLS; int* ccur = coff + SA_CELLS + 1; int* clist = (int*)c->d_assoc[1].p;
   double* aos = (double*)((char*)c->d_assoc[0].p + grid_bytes);
   const double* recs = (const double*)dst.p;
-  LVX_HIP(c, hipMemsetAsync(ccnt, 0, (size_t)SA_CELLS * 4, st));
-  hipLaunchKernelGGL(k_assoc_grid_geom, dim3(1), dim3(256), 0, st, P_cap, recs, gd, (const int*)d_cnt);
+  hipLaunchKernelGGL(k_assoc_grid_geom, dim3(1), dim3(256), 0, st, P_cap, recs, gd, (const int*)d_cnt, ccnt);
   hipLaunchKernelGGL(k_assoc_grid_fill, dim3((unsigned)((P_cap + 127) / 128)), dim3(128), 0, st, P_cap, recs, (const AssocGrid*)gd, ccnt, ccur, (int*)nullptr, 0, aos, (const int*)d_cnt, list_cap);
   hipLaunchKernelGGL(k_assoc_grid_scan, dim3(1), dim3(1024), 0, st, (const int*)ccnt, coff, ccur, list_cap);
-  hipLaunchKernelGGL(k_assoc_grid_fill, dim3((unsigned)((P_cap + 127) / 128)), dim3(128), 0, st, P_cap, recs, (const AssocGrid*)gd, ccnt, ccur, clist, 1, (double*)nullptr, (const int*)d_cnt, list_cap);
-  hipLaunchKernelGGL(k_da_counts, dim3(1), dim3(1), 0, st, c->da_pinned, dv, (const int*)d_cnt, (const int*)(ccur + SA_CELLS));
+  hipLaunchKernelGGL(k_assoc_grid_fill, dim3((unsigned)((P_cap + 127) / 128)), dim3(128), 0, st, P_cap, recs, (const AssocGrid*)gd, ccnt, ccur, clist, 1, (double*)nullptr, (const int*)d_cnt, list_cap,
+                     c->da_pinned, dv);
   // flags of every scan: rings strided by the plane CAPACITY (rings of planes that do not exist stay empty)
-  if ((rc = dev_alloc(c, c->d_da[6], npt * 4))) return rc;
-  LVX_HIP(c, hipMemsetAsync(c->d_da[6].p, 0xff, npt * 4, st));
-  const int wpr = (W + 31) / 32, chunk = 64;
+  const int wpr = (W + 31) / 32, chunk = 64;   // (flags: d_da[6], set to -1 by the de-skew kernel)
   { const size_t rings = (size_t)std::min(chunk, S) * P_cap * H, bits_bytes = (rings * wpr * 4 + 7) & ~(size_t)7, bytes = bits_bytes + rings * 8;
     const int oshift = wpr > 64 ? 1 : 0;
     if (!c->d_assoc[3].p || c->d_assoc[3].bytes < bytes || c->assoc_rings != rings || c->assoc_wpr != wpr) {
@@ -2586,8 +2585,9 @@ int lvx_data_association(lvx_ctx* c, const double* state, double map_time, const
   double* dq = (double*)c->d_da[3].p; double* dp = dq + 4; int* dv = (int*)(dp + 3);
   hipLaunchKernelGGL(k_lidar_pose, dim3(1), dim3(1), 0, st, (const double*)c->d_da[1].p, c->N, c->t0, c->dt, 1, (const double*)c->d_da[2].p, dq, dp, dv);
   if ((rc = dev_alloc(c, c->d_da[4], npt * 16))) return rc;
+  if ((rc = dev_alloc(c, c->d_da[6], npt * 4))) return rc;
   hipLaunchKernelGGL(k_undistort, dim3((unsigned)((npt + 255) / 256)), dim3(256), 0, st, (const double*)c->d_da[1].p, c->N, c->t0, c->dt, (int)npt, (const PointXYZIT*)c->d_da[0].p,
-                     quat{0, 0, 0, 1}, mk(0, 0, 0), 1, (float4*)c->d_da[4].p, (const double*)dq, (const int*)dv);   // the pose stays on the device (q_L0_to_G.conjugate() is taken there)
+                     quat{0, 0, 0, 1}, mk(0, 0, 0), 1, (float4*)c->d_da[4].p, (const double*)dq, (const int*)dv, (int*)c->d_da[6].p);   // the pose stays on the device (q_L0_to_G.conjugate() is taken there)
   c->vox.d_pts = c->d_da[4].p;
   lvx_surfel_map_release(c);
   // steps 2-4 over the capacities of the previous call, one host stop (S > 2: one or two scans take the all-pairs kernel, whose launch shape needs the plane count)
