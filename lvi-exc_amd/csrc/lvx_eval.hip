@@ -541,13 +541,18 @@ struct RepCross { RepJac jac; const int* lm; const int* goff; const int* gw; int
 // STRAYS.  The groups are fixed at layout time from the view times at tau = 0; with a non-zero offset (free, or locked at a non-zero value) a view within |tau| of a knot
 // lands in the neighbouring interval and — one row in ~80 at the 1 ms bound — outside its 4-interval window.  Such a block stays out of the group's panels and adds
 // its 24 x 24 cross products one by one (576 atomics; rare), so the pass never has to fall back to the per-segment kernels for it.
+// RX_NW wavefronts per workgroup: 51 KB of LDS, three workgroups per CU = 2 304 resident wavefronts — config 4 has 2 108 groups, and with four wavefronts per workgroup
+// (68 KB, two per CU, 2 048 resident) the last 15 workgroups ran as a second round behind the first.
+#ifndef RX_NW
+#define RX_NW 3
+#endif
 template <bool TAU>
-__global__ __launch_bounds__(256) void k_reproj_cross(RepCross rc, DevCommon cm) {
+__global__ __launch_bounds__(64 * RX_NW) void k_reproj_cross(RepCross rc, DevCommon cm) {
   constexpr int LDP = 49, BR = 16;   // panel: 16 rows (8 blocks x 2 residual rows) x 48 columns, odd stride
   constexpr int RJ = REP_NC + (TAU ? 1 : 0), RW = 56 + (TAU ? 1 : 0);
-  __shared__ double pan[4][2][BR * LDP];
-  __shared__ double tbuf[4][8 * RW];
-  __shared__ double sbuf[4][2][48];
+  __shared__ double pan[RX_NW][2][BR * LDP];
+  __shared__ double tbuf[RX_NW][8 * RW];
+  __shared__ double sbuf[RX_NW][2][48];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int rep = blockIdx.x % cm.nrep;
   if (rc.det_list && wv != 0) return;   // (the kernel has wavefront barriers only)
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(256) void k_reproj_cross(RepCross rc, DevCommon cm)
   double* Po = pan[wv][1];
   const int frag_off = (lane >> 4) * LDP + (lane & 15);
   const bool lm_free = !(cm.locks & LVX_LOCK_LANDMARKS);
-  for (int g = rc.det_list ? rc.det_list[blockIdx.x] : blockIdx.x * 4 + wv; g < rc.ng; g += rc.det_list ? rc.ng : gridDim.x * 4) {
+  for (int g = rc.det_list ? rc.det_list[blockIdx.x] : blockIdx.x * RX_NW + wv; g < rc.ng; g += rc.det_list ? rc.ng : gridDim.x * RX_NW) {
     const int m0 = rc.goff[g], m1 = rc.goff[g + 1], w0 = rc.gw[g], w1 = rc.gw[rc.ng + g];
     d4 D[9];
 #pragma unroll
@@ -2507,10 +2512,10 @@ int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cos
             if (det && ctx->det_cross_col.size() > 1) {
               for (size_t q = 0; q + 1 < ctx->det_cross_col.size(); ++q) {
                 rx.det_list = (const int*)ctx->d_det_cross.p + ctx->det_cross_col[q];
-                hipLaunchKernelGGL(k_reproj_cross<T>, dim3((unsigned)(ctx->det_cross_col[q + 1] - ctx->det_cross_col[q])), dim3(256), 0, st, rx, cm);
+                hipLaunchKernelGGL(k_reproj_cross<T>, dim3((unsigned)(ctx->det_cross_col[q + 1] - ctx->det_cross_col[q])), dim3(64 * RX_NW), 0, st, rx, cm);
               }
             } else
-            hipLaunchKernelGGL(k_reproj_cross<T>, dim3((unsigned)std::min((ctx->rep_groups + 3) / 4, 256 * 8)), dim3(256), 0, st, rx, cm); }
+            hipLaunchKernelGGL(k_reproj_cross<T>, dim3((unsigned)std::min((ctx->rep_groups + RX_NW - 1) / RX_NW, 256 * 8)), dim3(64 * RX_NW), 0, st, rx, cm); }
           if (ctx->L > 0 && !(ctx->locks & LVX_LOCK_LANDMARKS)) {
             const int* lp = (const int*)ctx->d_repB[3].p;
             const RepLmRows lq{(const double*)ctx->d_repT.p, kb, r.n, lp, lp + ctx->L + 1, ctx->L};
