@@ -1660,6 +1660,27 @@ __device__ __forceinline__ void fold_replicas_block(const DevCommon& cm, int blk
   if (i == 0) cm.cost[0] = strided_sum(cm.cost, 1, cm.nrep);
 }
 __global__ void k_fold_replicas(DevCommon cm) { fold_replicas_block(cm, (int)blockIdx.x); }
+// The whole fold in ONE launch (round 5b): blocks [0, n_rep) sum the replicas of the dense border accumulators, and the LAST of them to finish (a ticket) folds the dense
+// block; blocks behind them fold the border rows of set `set0` (then of `set1` if >= 0).  Three launches on two streams before — replicas 10 us -> dense 17 us on the chain,
+// border rows 17 us beside them, plus the fork / join packets around the side stream.
+__global__ __launch_bounds__(256) void k_fold_all(DevCommon cm, int n_rep, int n_rows, int set0, int store0, int set1, int store1, int* ticket) {
+  __shared__ int s_last;
+  const int b = blockIdx.x;
+  if (b < n_rep) {
+    fold_replicas_block(cm, b);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) { const int t = atomicAdd(ticket, 1); s_last = t == n_rep - 1; if (s_last) *ticket = 0; }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    fold_border_dense_block(cm);
+    return;
+  }
+  const int r = b - n_rep;
+  fold_border_rows_block(cm, set0, r, store0 != 0);
+  if (set1 >= 0) fold_border_rows_block(cm, set1, r, store1 != 0);   // the two sets may share hub rows: the same thread folds them one after the other
+}
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
@@ -2226,7 +2247,7 @@ int ensure_layout(lvx_ctx* ctx) {
   if ((rc = upload_pairs(ctx, ctx->d_pairs[4], REP_NC + tC, cat(range(48, 54), range(55, 55 + tC))))) return rc;
   if ((rc = upload_pairs(ctx, ctx->d_pairs[5], CS_NC + tC, cat(range(0, 24), range(48, 60 + tC))))) return rc;
   ctx->force_legacy = false;
-  { static const int zero = 0; if ((rc = upload_tmp(ctx, ctx->d_zero, &zero, 4))) return rc; }
+  { static const int zero[2] = {0, 0}; if ((rc = upload_tmp(ctx, ctx->d_zero, zero, 8))) return rc; }   // [0]: identity permutation of the single prior block, [1]: ticket of k_fold_all (returns to zero by itself)
   if ((rc = dev_alloc(ctx, ctx->d_imu_rtab, (size_t)64 * (ImuG::NTP * 4 + ImuA::NTP * 4) * 4))) return rc;
   hipLaunchKernelGGL(k_imu_rtab, dim3(1), dim3(64), 0, ctx->stream, (int*)ctx->d_imu_rtab.p);
   ctx->cfg_version++;   // captured evaluation graphs of the previous layout are stale
@@ -2542,17 +2563,26 @@ int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cos
     if (side_used) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[0], s_side)); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[0], 0)); }
     { ProfScope ps(ctx, LVX_KERNEL_FOLD);
       const bool fold_fast = (what & LVX_EVAL_NORMAL_EQ) && (fast_surf || fast_cs);
-      // replica sums -> dense block on the chain, the border-row fold (Bd, streaming; disjoint buffers) beside them on the side stream
-      hipStream_t s_fold = (fold_fast && side_on) ? ctx->fam_stream[0] : st;
-      if (s_fold != st) { LVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st)); LVX_HIP(ctx, hipStreamWaitEvent(s_fold, ctx->ev_fork, 0)); }
-      hipLaunchKernelGGL(k_fold_replicas, dim3((unsigned)((ctx->nbd_ext * ctx->nbd_ext + 255) / 256)), dim3(256), 0, st, cm);
-      if (fold_fast) {
-        for (int set = 0; set < 2; ++set) if (ctx->nb > 0 && ((set == 0 && fast_surf) || (set == 1 && fast_cs)))
-          hipLaunchKernelGGL(k_fold_border_rows, dim3((unsigned)((ctx->nb + 255) / 256)), dim3(256), 0, s_fold, cm, set, (set == 0 || !fast_surf) ? 1 : 0);
+      // replica sums -> dense block (the last replica block to finish) and the border-row fold (Bd, streaming; disjoint buffers) in one launch
+      const unsigned n_rep_blk = (unsigned)((ctx->nbd_ext * ctx->nbd_ext + 255) / 256);
+      if (fold_fast && ctx->nb > 0 && !sw.serial) {
+        const unsigned n_rows_blk = (unsigned)((ctx->nb + 255) / 256);
+        const int set0 = fast_surf ? 0 : 1, set1 = (fast_surf && fast_cs) ? 1 : -1;
         const size_t lds = ((size_t)ctx->nbd_ext * ctx->nbd_ext + ctx->nbd_ext) * 8;
-        LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_fold_border_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_fold_border_dense, dim3(1), dim3(256), lds, st, cm);
-        if (s_fold != st) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[1], s_fold)); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[1], 0)); }
+        LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_fold_all, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_fold_all, dim3(n_rep_blk + n_rows_blk), dim3(256), lds, st, cm, (int)n_rep_blk, (int)n_rows_blk, set0, 1, set1, 0, (int*)ctx->d_zero.p + 1);
+      } else {
+        hipStream_t s_fold = (fold_fast && side_on) ? ctx->fam_stream[0] : st;
+        if (s_fold != st) { LVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st)); LVX_HIP(ctx, hipStreamWaitEvent(s_fold, ctx->ev_fork, 0)); }
+        hipLaunchKernelGGL(k_fold_replicas, dim3(n_rep_blk), dim3(256), 0, st, cm);
+        if (fold_fast) {
+          for (int set = 0; set < 2; ++set) if (ctx->nb > 0 && ((set == 0 && fast_surf) || (set == 1 && fast_cs)))
+            hipLaunchKernelGGL(k_fold_border_rows, dim3((unsigned)((ctx->nb + 255) / 256)), dim3(256), 0, s_fold, cm, set, (set == 0 || !fast_surf) ? 1 : 0);
+          const size_t lds = ((size_t)ctx->nbd_ext * ctx->nbd_ext + ctx->nbd_ext) * 8;
+          LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_fold_border_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hipLaunchKernelGGL(k_fold_border_dense, dim3(1), dim3(256), lds, st, cm);
+          if (s_fold != st) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[1], s_fold)); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[1], 0)); }
+        }
       } }
     LVX_HIP(ctx, hipGetLastError());
     return rc;

@@ -754,7 +754,8 @@ static int leave_together(lvx_ctx* c, double votes, int lerr) {
   return lerr ? lerr : fail(c, LVX_E_COMM, "another rank of the joint solve failed");
 }
 
-static int solver_alloc(lvx_ctx* c, SolveWork& w) {
+// will_inplace: the caller is going to run the landmark elimination on the band / border rows themselves (LM loop of a single sequence): no reduced copies needed (290 MB at config 4)
+static int solver_alloc(lvx_ctx* c, SolveWork& w, bool will_inplace = false) {
   int rc;
   const size_t nb = (size_t)std::max(c->nb, 1), nbd = c->nbd, nt = (size_t)lvx_tangent_size(c);
   const bool use_bcr = !c->sw.solver_seq;
@@ -772,10 +773,12 @@ static int solver_alloc(lvx_ctx* c, SolveWork& w) {
   w.Hs = (const double*)c->d_Hb.p; w.Bs = (const double*)c->d_Bd.p; w.Cs = (const double*)c->d_C.p; w.gbs = (const double*)c->d_gb.p; w.gcs = (const double*)c->d_gc.p;
   if (w.lm) {
     const size_t ldc = c->nbd_ext;
-    if ((rc = dev_alloc(c, c->d_Hr, c->d_Hb.bytes))) return rc;
-    if ((rc = dev_alloc(c, c->d_Br, (size_t)nbd * nb * 8))) return rc;
+    if (!will_inplace) {
+      if ((rc = dev_alloc(c, c->d_Hr, c->d_Hb.bytes))) return rc;
+      if ((rc = dev_alloc(c, c->d_Br, (size_t)nbd * nb * 8))) return rc;
+    }
     if ((rc = dev_alloc(c, c->d_red, (nb + ldc * ldc + ldc) * 8))) return rc;
-    w.Hs = (const double*)c->d_Hr.p; w.Bs = (const double*)c->d_Br.p; w.gbs = (const double*)c->d_red.p; w.Cs = w.gbs + nb; w.gcs = w.Cs + ldc * ldc;
+    w.Hs = will_inplace ? (const double*)c->d_Hb.p : (const double*)c->d_Hr.p; w.Bs = will_inplace ? (const double*)c->d_Bd.p : (const double*)c->d_Br.p; w.gbs = (const double*)c->d_red.p; w.Cs = w.gbs + nb; w.gcs = w.Cs + ldc * ldc;
   }
   c->p_Hs = w.Hs;
   if ((rc = dev_alloc(c, c->d_scal, 64 * 8))) return rc;
@@ -1229,7 +1232,7 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
   int rc;
   int lerr = ensure_layout(c);
   SolveWork w;
-  if (!lerr) lerr = solver_alloc(c, w);
+  if (!lerr) lerr = solver_alloc(c, w, /*will_inplace=*/!joint && c->nb > 0);   // (matters only with free landmarks: see w.inplace below)
   if (lerr && !joint) return lerr;
   // box constraints (free inverse depths: rho >= 0; a free sensor time offset: |tau| <= max) make the problem constrained in Ceres' sense: projected start point,
   // projected gradient norm, projected Armijo line search on every trust-region step.  In the JOINT solve (round 5) the problem is constrained when ANY rank's is
