@@ -1271,12 +1271,16 @@ __global__ __launch_bounds__(1024) void k_surfel_compact(const SurfelPlaneDev* _
   }
 }
 // The same in up to 2 048 workgroups of 1 024 leaves (round 5b; one workgroup walked 5 600 flags in six trips of three barriers and copied every record itself, 30 us of
-// a DataAssociation round, and a 4 M-point map has 556 k leaves): a thread takes four consecutive flags and fetches their records at once, the workgroup publishes its
+// a DataAssociation round, and a 4 M-point map has 556 k leaves): a thread takes four consecutive flags, the workgroup lists its accepted leaves in LDS and publishes its
 // count as (epoch | count) — the epoch changes with every launch, the words are never cleared — and every workgroup sums ALL the published counts: those before it place
-// its records, the total places the plane table behind the records.
+// its records, the total places the plane table behind the records.  The records are copied word by word by all threads (coalesced; a few registers per thread: every
+// workgroup of the launch must be resident for the exchange of counts, 8 per CU x 256 CUs = SC_MAXB).
 #define SC_MAXB 2048
 __global__ __launch_bounds__(256) void k_surfel_compact_mb(const SurfelPlaneDev* __restrict__ all, const int* __restrict__ flag, int nl, SurfelPlaneDev* recs, int* count, const VxInfo* nl_d,
                                                            unsigned long long* pub, unsigned epoch) {
+  static_assert(sizeof(SurfelPlaneDev) == 15 * 8, "record = 13 doubles + 4 ints");
+  constexpr int RW = 15;
+  __shared__ int idx[1024];
   __shared__ int wsum[4];
   __shared__ int s_before, s_total;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x, nb = gridDim.x;
@@ -1296,9 +1300,8 @@ __global__ __launch_bounds__(256) void k_surfel_compact_mb(const SurfelPlaneDev*
   int off = incl - mine, tot = 0;
   for (int k = 0; k < 4; ++k) { if (k < wv) off += wsum[k]; tot += wsum[k]; }
   if (tid == 0) __hip_atomic_store(&pub[b], ((unsigned long long)epoch << 32) | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  SurfelPlaneDev r[4];   // (the records travel while the counts are collected)
 #pragma unroll
-  for (int u = 0; u < 4; ++u) r[u] = all[max(min(l0 + u, nl - 1), 0)];
+  for (int u = 0; u < 4; ++u) if (f[u] != 0) idx[off++] = l0 + u;
   int sb = 0, st = 0;
   for (int j = tid; j < nb; j += 256) {
     unsigned long long v;
@@ -1309,17 +1312,17 @@ __global__ __launch_bounds__(256) void k_surfel_compact_mb(const SurfelPlaneDev*
   if (st) atomicAdd(&s_total, st);
   if (sb) atomicAdd(&s_before, sb);
   __syncthreads();
-  const int P = s_total;
-  int k = s_before + off;
+  const int P = s_total, k0 = s_before;
   if (b == 0 && tid == 0) *count = P;
   double* pl = (double*)((char*)recs + (((size_t)P * sizeof(SurfelPlaneDev) + 15) & ~(size_t)15));
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    if (f[u] == 0) continue;
-    recs[k] = r[u];
-    for (int a = 0; a < 4; ++a) pl[4 * (size_t)k + a] = r[u].p4[a];
-    for (int a = 0; a < 3; ++a) { pl[4 * (size_t)P + 3 * (size_t)k + a] = r[u].bmin[a]; pl[7 * (size_t)P + 3 * (size_t)k + a] = r[u].bmax[a]; }
-    ++k;
+  const double* src = (const double*)all; double* dst = (double*)recs;
+  for (int e = tid; e < tot * RW; e += 256) {
+    const int r = e / RW, w = e - RW * r, k = k0 + r;
+    const double v = src[(size_t)idx[r] * RW + w];
+    dst[(size_t)k * RW + w] = v;
+    if (w < 4) pl[4 * (size_t)k + w] = v;                                   // p4
+    else if (w >= 7 && w < 10) pl[4 * (size_t)P + 3 * (size_t)k + (w - 7)] = v;    // box min
+    else if (w >= 10 && w < 13) pl[7 * (size_t)P + 3 * (size_t)k + (w - 10)] = v;  // box max
   }
 }
 // K = 7: getNeighborhoodAtPoint7 (:423-438), K = 1: getNeighborhoodAtPoint1 (:440-446, the cell of the point only)
