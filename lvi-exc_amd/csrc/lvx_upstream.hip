@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void k_vx_extent(const float4* p, int n, int* 
   if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&mm[6], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
   __syncthreads();
   if (!s_last) return;
-  if (ghist) for (int e = threadIdx.x; e < 4 * 256; e += 256) ghist[e] = 0;   // digit histograms of the radix sort (k_vx_keys adds to them)
+  if (ghist) for (int e = threadIdx.x; e < 4 * 1024; e += 256) ghist[e] = 0;   // digit histograms of the radix sort, 1 024 bins per pass at most (k_vx_keys adds to them)
   if (threadIdx.x < 7) ex[threadIdx.x] = atomicExch(&mm[threadIdx.x], threadIdx.x < 3 ? 0x7fffffff : (threadIdx.x < 6 ? (int)0x80000000 : 0));   // read at the memory side and reset
   __syncthreads();
   if (threadIdx.x != 0) return;
@@ -503,15 +503,16 @@ __global__ __launch_bounds__(256) void k_vx_extent(const float4* p, int n, int* 
 // table this cloud's extents span, resets the look-back states of k_vx_leaf (one per tile of sorted positions) and — for the own radix sort — counts the keys' 8-bit
 // digits (LDS histogram per workgroup, one global atomic per non-empty bin) and clears the per-tile digit counts of the sort passes
 __global__ __launch_bounds__(256) void k_vx_keys(const float4* p, int n, const VxInfo* info, unsigned invalid, unsigned* keys, int* vals, int* cells, unsigned long long* lb, int n_tiles,
-                                                 int* ghist, unsigned* tcnt, int n_tcnt, int passes) {
-  __shared__ int lh[4][256];
+                                                 int* ghist, unsigned* tcnt, int n_tcnt, int passes, int db) {
+  __shared__ int lh[4][1024];   // per pass: 1 << db bins (db = 8, 9 or 10)
+  const int nbins = 1 << db;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool ovf = info->overflow != 0;
   if (!ovf) { const long long nc = info->cells; for (long long e = i; e < nc; e += (long long)gridDim.x * blockDim.x) cells[e] = -1; }
   if (i < n_tiles) lb[i] = 0ull;
   if (tcnt) for (int e = i; e < n_tcnt; e += gridDim.x * blockDim.x) tcnt[e] = 0u;
   if (blockIdx.x * 1024 >= n) return;   // (workgroups that only clear)
-  if (ghist) { for (int q = 0; q < passes; ++q) lh[q][threadIdx.x] = 0; __syncthreads(); }
+  if (ghist) { for (int q = 0; q < passes; ++q) for (int e = threadIdx.x; e < nbins; e += 256) lh[q][e] = 0; __syncthreads(); }
   const VxGrid g = info->g;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {   // 1 024 points per workgroup: a quarter of the global histogram atomics of 256
@@ -526,11 +527,11 @@ __global__ __launch_bounds__(256) void k_vx_keys(const float4* p, int n, const V
       k = (unsigned)(i0 * g.mul[0] + i1 * g.mul[1] + i2 * g.mul[2]);
     }
     keys[j] = k; vals[j] = j;
-    if (ghist) for (int qq = 0; qq < passes; ++qq) atomicAdd(&lh[qq][(k >> (8 * qq)) & 255u], 1);
+    if (ghist) for (int qq = 0; qq < passes; ++qq) atomicAdd(&lh[qq][(k >> (db * qq)) & (unsigned)(nbins - 1)], 1);
   }
   if (ghist) {
     __syncthreads();
-    for (int q = 0; q < passes; ++q) { const int v = lh[q][threadIdx.x]; if (v) atomicAdd(&ghist[256 * q + threadIdx.x], v); }
+    for (int q = 0; q < passes; ++q) for (int e = threadIdx.x; e < nbins; e += 256) { const int v = lh[q][e]; if (v) atomicAdd(&ghist[1024 * q + e], v); }
   }
 }
 // One pass of a stable least-significant-digit radix sort (8-bit digit) in ONE launch ("onesweep"), for clouds of up to VX_OWN_SORT_MAX points — rocPRIM's radix sort takes
@@ -541,23 +542,27 @@ __global__ __launch_bounds__(256) void k_vx_keys(const float4* p, int n, const V
 //   3. first position of digit d in this tile = digits below d in the whole array (the histogram k_vx_keys built) + d's keys in the tiles before this one: a look-back
 //      over the published counts, sixteen words at a time, until a tile that already knows its own inclusive sum;
 //   4. scatter.
-#define VX_OWN_SORT_MAX 1048576   // (measured: 400 k points 195 -> 134 us against rocPRIM, 4 M points 213 -> 284 us: rocPRIM there)
-#define VX_SORT_KPT 4
-template <bool FIRST>
-__global__ __launch_bounds__(256) void k_vx_sort_pass(const unsigned* __restrict__ kin, const int* __restrict__ vin, unsigned* __restrict__ kout, int* __restrict__ vout, int n, int shift,
-                                                      const int* __restrict__ ghist, unsigned* tcnt) {
-  constexpr int KPT = VX_SORT_KPT;
-  __shared__ int hist[KPT * 4 * 256];
-  __shared__ int base[256];
-  __shared__ int wsum[4];
+#ifndef VX_OWN_SORT_MAX
+#define VX_OWN_SORT_MAX 1048576
+#endif
+// (measured: 400 k points 195 -> 134 us against rocPRIM, 4 M points 213 -> 284 us: rocPRIM there)
+// DB = digit width (round 5b): 1 << DB threads per workgroup, a THREAD per digit value as before, the tile stays 1 024 positions — 8 bits: 256 threads x 4 keys, 9 bits:
+// 512 x 2, 10 bits: 1 024 x 1.  A key range of up to 20 bits (a voxel grid of up to a million cells) sorts in TWO launches instead of three.
+template <bool FIRST, int DB>
+__global__ __launch_bounds__(1 << DB) void k_vx_sort_pass(const unsigned* __restrict__ kin, const int* __restrict__ vin, unsigned* __restrict__ kout, int* __restrict__ vout, int n, int shift,
+                                                          const int* __restrict__ ghist, unsigned* tcnt) {
+  constexpr int NT = 1 << DB, NW = NT / 64, KPT = 1024 / NT;
+  __shared__ int hist[KPT * NW * NT];
+  __shared__ int base[NT];
+  __shared__ int wsum[NW];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
-  const int tile0 = b * 256 * KPT;
-  for (int e = tid; e < KPT * 4 * 256; e += 256) hist[e] = 0;
+  const int tile0 = b * NT * KPT;
+  for (int e = tid; e < KPT * NW * NT; e += NT) hist[e] = 0;
   const int gh = ghist[tid];   // (requested with the keys: not behind the tile's own counting)
   unsigned key[KPT]; int val[KPT]; int rk[KPT];
 #pragma unroll
   for (int u = 0; u < KPT; ++u) {
-    const int idx = tile0 + 256 * u + tid;
+    const int idx = tile0 + NT * u + tid;
     key[u] = idx < n ? kin[idx] : 0xffffffffu;
     val[u] = FIRST ? idx : (idx < n ? vin[idx] : 0);
   }
@@ -565,23 +570,23 @@ __global__ __launch_bounds__(256) void k_vx_sort_pass(const unsigned* __restrict
   const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
   for (int u = 0; u < KPT; ++u) {
-    const bool valid = tile0 + 256 * u + tid < n;
-    const unsigned dg = (key[u] >> shift) & 255u;
+    const bool valid = tile0 + NT * u + tid < n;
+    const unsigned dg = (key[u] >> shift) & (unsigned)(NT - 1);
     unsigned long long m = __ballot(valid);
 #pragma unroll
-    for (int bit = 0; bit < 8; ++bit) {
+    for (int bit = 0; bit < DB; ++bit) {
       const bool one = (dg >> bit) & 1u;
       const unsigned long long bal = __ballot(valid && one);
       m &= one ? bal : ~bal;
     }
     rk[u] = __popcll(m & lt);
-    if (valid && rk[u] == 0) hist[(4 * u + wv) * 256 + dg] = __popcll(m);
+    if (valid && rk[u] == 0) hist[(NW * u + wv) * NT + dg] = __popcll(m);
   }
   __syncthreads();
   int cnt = 0;
 #pragma unroll 8
-  for (int g = 0; g < 4 * KPT; ++g) { const int t = hist[g * 256 + tid]; hist[g * 256 + tid] = cnt; cnt += t; }
-  __hip_atomic_store(&tcnt[b * 256 + tid], ((b == 0 ? 2u : 1u) << 30) | (unsigned)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int g = 0; g < NW * KPT; ++g) { const int t = hist[g * NT + tid]; hist[g * NT + tid] = cnt; cnt += t; }
+  __hip_atomic_store(&tcnt[b * NT + tid], ((b == 0 ? 2u : 1u) << 30) | (unsigned)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // digits below mine in the whole array
   int incl = gh;
   for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
@@ -595,25 +600,25 @@ __global__ __launch_bounds__(256) void k_vx_sort_pass(const unsigned* __restrict
   for (int t = b - 1; t >= 0; t -= LBW) {
     unsigned v[LBW];
 #pragma unroll
-    for (int j = 0; j < LBW; ++j) v[j] = t - j >= 0 ? __hip_atomic_load(&tcnt[(t - j) * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2u << 30);
+    for (int j = 0; j < LBW; ++j) v[j] = t - j >= 0 ? __hip_atomic_load(&tcnt[(t - j) * NT + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2u << 30);
     bool done = false;
 #pragma unroll
     for (int j = 0; j < LBW; ++j) {
       if (done) continue;
-      while ((v[j] >> 30) == 0u) v[j] = __hip_atomic_load(&tcnt[(t - j) * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while ((v[j] >> 30) == 0u) v[j] = __hip_atomic_load(&tcnt[(t - j) * NT + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       acc += (int)(v[j] & 0x3fffffffu);
       if ((v[j] >> 30) == 2u) done = true;
     }
     if (done) break;
   }
-  if (b > 0) __hip_atomic_store(&tcnt[b * 256 + tid], (2u << 30) | (unsigned)(acc + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (b > 0) __hip_atomic_store(&tcnt[b * NT + tid], (2u << 30) | (unsigned)(acc + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   base[tid] = first + acc;
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < KPT; ++u) {
-    if (tile0 + 256 * u + tid >= n) continue;
-    const unsigned dg = (key[u] >> shift) & 255u;
-    const int pos = base[dg] + hist[(4 * u + wv) * 256 + dg] + rk[u];
+    if (tile0 + NT * u + tid >= n) continue;
+    const unsigned dg = (key[u] >> shift) & (unsigned)(NT - 1);
+    const int pos = base[dg] + hist[(NW * u + wv) * NT + dg] + rk[u];
     kout[pos] = key[u]; vout[pos] = val[u];
   }
 }
@@ -1968,20 +1973,30 @@ static int voxel_enqueue(lvx_ctx* c, const float4* d_pts, int n, float leaf, int
   const int n_tiles = (n + 255) / 256;
   // own radix sort up to VX_OWN_SORT_MAX points (one launch per 8-bit digit), rocPRIM above; either way the sorted keys / ids end in the second halves of the buffers
   const bool own_sort = n <= VX_OWN_SORT_MAX;
-  const int passes = (V.sort_bits + 7) / 8, sort_tiles = (n + 256 * VX_SORT_KPT - 1) / (256 * VX_SORT_KPT);
+  // digit width: the narrowest of 8 / 9 / 10 bits that covers the key range in the fewest passes (<= 16 bits: 2 x 8, <= 18: 2 x 9, <= 20: 2 x 10, <= 24: 3 x 8, ...)
+  int db = 8, passes = (V.sort_bits + 7) / 8;
+  for (int d = 9; d <= 10; ++d) if ((V.sort_bits + d - 1) / d < passes) { db = d; passes = (V.sort_bits + d - 1) / d; }
+  const int nbins = 1 << db, sort_tiles = (n + 1023) / 1024;
   int* ghist = own_sort ? (int*)V.tmp.p : nullptr;
-  unsigned* tcnt = own_sort ? (unsigned*)V.tmp.p + 4 * 256 : nullptr;
+  unsigned* tcnt = own_sort ? (unsigned*)V.tmp.p + 4 * 1024 : nullptr;
   hipLaunchKernelGGL(k_vx_extent, dim3((unsigned)std::min(std::max(n / 4096, 64), 256)), dim3(256), 0, st, d_pts, n, d_mm, leaf, (long long)V.cells_cap, d_info, ghist);
   const unsigned invalid = (unsigned)((1ull << V.sort_bits) - 1ull);   // sort_bits <= 31 (cells_cap is clamped), the 64-bit shift keeps even 32 defined
   unsigned* k_first = (own_sort && passes % 2 == 0) ? k_out : k_in;   // an even number of passes starts in the second buffer
   hipLaunchKernelGGL(k_vx_keys, dim3((unsigned)std::max((n + 1023) / 1024, 512)), dim3(256), 0, st, d_pts, n, (const VxInfo*)d_info, invalid, k_first, v_in, (int*)V.cells.p, lbs, n_tiles,
-                     ghist, tcnt, passes * sort_tiles * 256, passes);
+                     ghist, tcnt, passes * sort_tiles * nbins, passes, db);
   if (own_sort) {
     unsigned* ka = k_first; unsigned* kb = k_first == k_in ? k_out : k_in;
     int* va = k_first == k_in ? v_in : v_out; int* vb = k_first == k_in ? v_out : v_in;
     for (int q = 0; q < passes; ++q) {
-      if (q == 0) hipLaunchKernelGGL(k_vx_sort_pass<true>, dim3((unsigned)sort_tiles), dim3(256), 0, st, (const unsigned*)ka, (const int*)va, kb, vb, n, 0, (const int*)ghist, tcnt);
-      else hipLaunchKernelGGL(k_vx_sort_pass<false>, dim3((unsigned)sort_tiles), dim3(256), 0, st, (const unsigned*)ka, (const int*)va, kb, vb, n, 8 * q, (const int*)ghist + 256 * q, tcnt + (size_t)q * sort_tiles * 256);
+      const int* gh_q = (const int*)ghist + 1024 * q; unsigned* tc_q = tcnt + (size_t)q * sort_tiles * nbins;
+      auto pass = [&](auto first, auto width) {
+        constexpr bool F = decltype(first)::value; constexpr int W = decltype(width)::value;
+        hipLaunchKernelGGL((k_vx_sort_pass<F, W>), dim3((unsigned)sort_tiles), dim3(1 << W), 0, st, (const unsigned*)ka, (const int*)va, kb, vb, n, db * q, gh_q, tc_q);
+      };
+      auto by_width = [&](auto first) {
+        if (db == 8) pass(first, std::integral_constant<int, 8>{}); else if (db == 9) pass(first, std::integral_constant<int, 9>{}); else pass(first, std::integral_constant<int, 10>{});
+      };
+      if (q == 0) by_width(std::true_type{}); else by_width(std::false_type{});
       std::swap(ka, kb); std::swap(va, vb);
     }
   } else {
@@ -1997,6 +2012,10 @@ static int voxel_enqueue(lvx_ctx* c, const float4* d_pts, int n, float leaf, int
     hipLaunchKernelGGL(k_vx_leaf<PT>, dim3((unsigned)((n + 256 * PT - 1) / (256 * PT))), dim3(256), 0, st, d_pts, (const unsigned*)k_out, (const int*)v_out, n, invalid, lbs, min_pts, eig_mult, d_info, (int*)V.cells.p, lk, ln,
                        counts, offs, mean, cov, icov, evecs, evals, (float*)V.leaf_f.p, (VxInfo*)V.h_info);
   };
+#ifdef VX_PT_BIG
+  if (n > 2097152) launch_leaf(std::integral_constant<int, VX_PT_BIG>{});
+  else
+#endif
   if (n > 524288) launch_leaf(std::integral_constant<int, 4>{});
   else if (n > 262144) launch_leaf(std::integral_constant<int, 2>{});
   else launch_leaf(std::integral_constant<int, 1>{});
@@ -2011,7 +2030,7 @@ static int voxel_build_device(lvx_ctx* c, const float4* d_pts, int n, float leaf
   std::memset(&V.grid, 0, sizeof(V.grid));
   if (n == 0) return LVX_OK;
   if (!V.h_info) LVX_HIP(c, hipHostMalloc(&V.h_info, sizeof(VxInfo), hipHostMallocDefault));
-  if (V.cells_cap < (1 << 22)) V.cells_cap = 1 << 22;   // 4 M cells (16 MB): a 100 m x 100 m x 100 m map at 0.5 m; grown on demand (vox_info)
+  if (V.cells_cap < (1 << 18) - 1) V.cells_cap = (1 << 18) - 1;   // 262 143 cells (1 MB; 18-bit keys = two 9-bit sort passes): a 32 m x 32 m x 32 m map at 0.5 m; grown on demand (vox_info)
   int bits = 1; while ((1ll << bits) - 1 < (long long)V.cells_cap && bits < 31) ++bits;   // keys < cells <= capacity <= 2^31 - 1, the invalid key = 2^bits - 1 >= capacity above them
   V.sort_bits = bits;
   if (!V.misc.p) {   // extents in their start state (k_vx_extent's last workgroup restores it after every build)
@@ -2033,7 +2052,7 @@ static int voxel_build_device(lvx_ctx* c, const float4* d_pts, int n, float leaf
     size_t t1 = 0;
     LVX_HIP(c, rocprim::radix_sort_pairs(nullptr, t1, k_in, k_in + n, v_in, v_in + n, (size_t)n, 0, (unsigned)V.sort_bits, st));
     V.tmp_bytes[0] = t1;
-    const size_t own = (size_t)4 * 256 * 4 + (size_t)4 * ((VX_OWN_SORT_MAX + 256 * VX_SORT_KPT - 1) / (256 * VX_SORT_KPT)) * 256 * 4;   // digit histograms + per-tile digit counts of the own sort
+    const size_t own = (size_t)4 * 1024 * 4 + (size_t)4 * ((VX_OWN_SORT_MAX + 1023) / 1024) * 1024 * 4;   // digit histograms + per-tile digit counts of the own sort (up to 4 passes x 1 024 bins)
     if ((rc = dev_alloc(c, V.tmp, std::max(t1 + 16, own)))) return rc;
   }
   // replay the captured chain when nothing it was captured with has changed

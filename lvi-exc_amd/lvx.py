@@ -574,6 +574,8 @@ def upstream_bench(ctx, kind, arrays, reps=20):
         raise ValueError(kind)
     import time
     call(); ctx.synchronize()
+    if kind == "voxel_build":   # the first build of a cloud sizes the context's cell table (grown on demand when somebody asks for the result): ask, then build once more
+        ctx.voxel_info(); call(); ctx.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
         call()
