@@ -2012,10 +2012,6 @@ static int voxel_enqueue(lvx_ctx* c, const float4* d_pts, int n, float leaf, int
     hipLaunchKernelGGL(k_vx_leaf<PT>, dim3((unsigned)((n + 256 * PT - 1) / (256 * PT))), dim3(256), 0, st, d_pts, (const unsigned*)k_out, (const int*)v_out, n, invalid, lbs, min_pts, eig_mult, d_info, (int*)V.cells.p, lk, ln,
                        counts, offs, mean, cov, icov, evecs, evals, (float*)V.leaf_f.p, (VxInfo*)V.h_info);
   };
-#ifdef VX_PT_BIG
-  if (n > 2097152) launch_leaf(std::integral_constant<int, VX_PT_BIG>{});
-  else
-#endif
   if (n > 524288) launch_leaf(std::integral_constant<int, 4>{});
   else if (n > 262144) launch_leaf(std::integral_constant<int, 2>{});
   else launch_leaf(std::integral_constant<int, 1>{});
