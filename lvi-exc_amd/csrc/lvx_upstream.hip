@@ -1493,9 +1493,10 @@ __global__ __launch_bounds__(256) void k_assoc_hits_allpairs(const float4* __res
   }
 }
 __global__ __launch_bounds__(256) void k_assoc_hits(const float4* __restrict__ scans, int H, int W, int P, const double* __restrict__ aos, double radius, const AssocGrid* gp,
-                                                    const int* __restrict__ off, const int* __restrict__ list, unsigned* bits, unsigned long long* occ, int wpr, int oshift) {
+                                                    const int* __restrict__ off, const int* __restrict__ list, unsigned* bits, unsigned long long* occ, int wpr, int oshift, int* flags_init) {
   const int i = blockIdx.x * 256 + threadIdx.x, sc = blockIdx.y, lane = threadIdx.x & 63;
   if (i >= H * W) return;
+  if (flags_init) flags_init[(size_t)sc * H * W + i] = -1;   // "no surfel": k_assoc_select (the next launch) raises it — a 7 MB fill launch per call otherwise
   const float4 q = scans[(size_t)sc * H * W + i];
   const double x = q.x, y = q.y, z = q.z;
   const AssocGrid g = *gp;
@@ -2211,7 +2212,7 @@ static int assoc_grid_build(lvx_ctx* c, int P, const double* planes_d, bool have
   return LVX_OK;
 }
 static int assoc_device(lvx_ctx* c, const float4* scans_d, int S, int H, int W, int P, const double* planes_d, double radius, int sel, int* flags_d) {
-  LVX_HIP(c, hipMemsetAsync(flags_d, 0xff, (size_t)S * H * W * 4, c->stream));
+  if (P <= 0 || H <= 0 || W <= 0 || S <= 2) LVX_HIP(c, hipMemsetAsync(flags_d, 0xff, (size_t)std::max(S, 0) * H * W * 4, c->stream));   // (S > 2: k_assoc_hits writes the start state itself)
   if (P <= 0 || H <= 0 || W <= 0 || S <= 0) return LVX_OK;
   const int wpr = (W + 31) / 32;
   const size_t rings = (size_t)S * P * H, bits_bytes = (rings * wpr * 4 + 7) & ~(size_t)7, bytes = bits_bytes + rings * 8;
@@ -2235,7 +2236,7 @@ static int assoc_device(lvx_ctx* c, const float4* scans_d, int S, int H, int W, 
   (void)ccnt;
   const double* aos = (const double*)((const char*)c->d_assoc[0].p + ((sizeof(AssocGrid) + (size_t)(3 * SA_CELLS + 8) * 4 + 15) & ~(size_t)15));
   hipLaunchKernelGGL(k_assoc_hits, dim3((unsigned)((H * W + 255) / 256), (unsigned)S), dim3(256), 0, c->stream, scans_d, H, W, P, aos, radius, (const AssocGrid*)gd, (const int*)coff, (const int*)clist,
-                     bits, occ, wpr, oshift);
+                     bits, occ, wpr, oshift, flags_d);
   hipLaunchKernelGGL(k_assoc_select, dim3((unsigned)((rings + 255) / 256)), dim3(256), 0, c->stream, bits, occ, S, H, W, P, wpr, oshift, sel, flags_d);
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
@@ -2553,7 +2554,7 @@ static int da_speculative(lvx_ctx* c, const lvx_assoc_options& o, int S, int H, 
     for (int s0 = 0; s0 < S; s0 += chunk) {
       const int ns = std::min(chunk, S - s0);
       const float4* sc = (const float4*)c->d_da[4].p + (size_t)s0 * H * W;
-      hipLaunchKernelGGL(k_assoc_hits, dim3((unsigned)((H * W + 255) / 256), (unsigned)ns), dim3(256), 0, st, sc, H, W, P_cap, (const double*)aos, o.radius, (const AssocGrid*)gd, (const int*)coff, (const int*)clist, bits, occ, wpr, oshift);
+      hipLaunchKernelGGL(k_assoc_hits, dim3((unsigned)((H * W + 255) / 256), (unsigned)ns), dim3(256), 0, st, sc, H, W, P_cap, (const double*)aos, o.radius, (const AssocGrid*)gd, (const int*)coff, (const int*)clist, bits, occ, wpr, oshift, (int*)nullptr);
       hipLaunchKernelGGL(k_assoc_select, dim3((unsigned)(((size_t)ns * P_cap * H + 255) / 256)), dim3(256), 0, st, bits, occ, ns, H, W, P_cap, wpr, oshift, o.selected_per_ring, (int*)c->d_da[6].p + (size_t)s0 * H * W);
     } }
   LVX_HIP(c, hipGetLastError());
