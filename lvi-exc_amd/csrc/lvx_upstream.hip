@@ -1406,9 +1406,19 @@ __global__ void k_assoc_grid_fill(int P, const double* planes10, const AssocGrid
   if (P_d) { const int Pr = *P_d; planes10 = (const double*)((const char*)planes10 + (((size_t)Pr * sizeof(SurfelPlaneDev) + 15) & ~(size_t)15)); Ps = (size_t)Pr; P = min(Pr, P); }
   if (k >= P) return;
   const AssocGrid g = *gp;
-  if (mode == 0 && aos) {   // one 80-byte record per surfel for the hit kernel: box min | box max | plane (the caller's table is three arrays: ten 8-byte loads from three places per candidate)
-    for (int a = 0; a < 3; ++a) { aos[10 * (size_t)k + a] = planes10[4 * Ps + 3 * (size_t)k + a]; aos[10 * (size_t)k + 3 + a] = planes10[7 * Ps + 3 * (size_t)k + a]; }
-    for (int a = 0; a < 4; ++a) aos[10 * (size_t)k + 6 + a] = planes10[4 * (size_t)k + a];
+  if (mode == 0 && aos) {   // one 64-byte record per surfel for the hit kernel: box min | box max as FLOATS | plane (the caller's table is three arrays: ten 8-byte loads from three places per candidate)
+    // a scan point is a float: x > lo  <=>  x > (lo rounded DOWN to a float), x < hi  <=>  x < (hi rounded UP) — no float lies between a bound and its directed rounding,
+    // so the float comparison decides exactly what the reference's double comparison decides (the bounds of a surfel map are floats to begin with)
+    float* bf = (float*)(aos + 8 * (size_t)k);
+    for (int a = 0; a < 3; ++a) {
+      const double lo = planes10[4 * Ps + 3 * (size_t)k + a], hi = planes10[7 * Ps + 3 * (size_t)k + a];
+      float fl = (float)lo, fh = (float)hi;
+      if ((double)fl > lo) fl = nextafterf(fl, -INFINITY);
+      if ((double)fh < hi) fh = nextafterf(fh, INFINITY);
+      bf[a] = fl; bf[3 + a] = fh;
+    }
+    bf[6] = 0.f; bf[7] = 0.f;
+    for (int a = 0; a < 4; ++a) aos[8 * (size_t)k + 4 + a] = planes10[4 * (size_t)k + a];
   }
   int c0[3], c1[3];
   const int nn[3] = {SA_GX, SA_GY, SA_GZ};
@@ -1516,17 +1526,18 @@ __global__ __launch_bounds__(256) void k_assoc_hits(const float4* __restrict__ s
     int k[SA_U];
 #pragma unroll
     for (int u = 0; u < SA_U; ++u) k[u] = list[min(e + u, e1 - 1)];
-    double2 r[SA_U][5];
+    float4 bx[SA_U][2]; double2 pq[SA_U][2];
 #pragma unroll
     for (int u = 0; u < SA_U; ++u) {
-      const double2* rec = (const double2*)(aos + 10 * (size_t)k[u]);   // five 16-byte loads: box min | box max | plane
-#pragma unroll
-      for (int j = 0; j < 5; ++j) r[u][j] = rec[j];
+      const float4* rec = (const float4*)(aos + 8 * (size_t)k[u]);   // four 16-byte loads of one 64-byte record: box (6 floats) | plane (4 doubles)
+      bx[u][0] = rec[0]; bx[u][1] = rec[1];
+      pq[u][0] = ((const double2*)rec)[2]; pq[u][1] = ((const double2*)rec)[3];
     }
 #pragma unroll
     for (int u = 0; u < SA_U; ++u) {
-      const double lo[3] = {r[u][0].x, r[u][0].y, r[u][1].x}, hi[3] = {r[u][1].y, r[u][2].x, r[u][2].y}, pl[4] = {r[u][3].x, r[u][3].y, r[u][4].x, r[u][4].y};
-      const bool inside = (x > lo[0]) & (x < hi[0]) & (y > lo[1]) & (y < hi[1]) & (z > lo[2]) & (z < hi[2]);
+      const float lo[3] = {bx[u][0].x, bx[u][0].y, bx[u][0].z}, hi[3] = {bx[u][0].w, bx[u][1].x, bx[u][1].y};
+      const double pl[4] = {pq[u][0].x, pq[u][0].y, pq[u][1].x, pq[u][1].y};
+      const bool inside = (q.x > lo[0]) & (q.x < hi[0]) & (q.y > lo[1]) & (q.y < hi[1]) & (q.z > lo[2]) & (q.z < hi[2]);   // float against float: exact, see k_assoc_grid_fill
       double dist = x * pl[0] + y * pl[1] + z * pl[2] + pl[3];
       dist = dist > 0 ? dist : -dist;
       sa_record_hit((e + u < e1) & inside & (dist <= radius), ((size_t)sc * P + k[u]) * H + h, w, lane, wpr, bits, occ, oshift);
