@@ -1517,10 +1517,10 @@ __global__ __launch_bounds__(256) void k_assoc_hits(const float4* __restrict__ s
   if (!in_grid) return;
   const int cell = (sa_cell(z, g.g0[2], g.inv[2], SA_GZ) * SA_GY + sa_cell(y, g.g0[1], g.inv[1], SA_GY)) * SA_GX + sa_cell(x, g.g0[0], g.inv[0], SA_GX);
   const int h = i / W, w = i - h * W;
-  // SA_U candidates per trip: their list entries are loaded together (clamped addresses, the tail masked afterwards), then their SA_U x 5 record loads — two memory round
+  // SA_U candidates per trip: their list entries are loaded together (clamped addresses, the tail masked afterwards), then their SA_U x 4 record loads — two memory round
   // trips per SA_U candidates.  One candidate per iteration was two DEPENDENT round trips each (entry, then its record), 11 iterations for the longest list of an average
   // wavefront: 205 us for 64 scans x 2 000 surfels.
-  constexpr int SA_U = 4;
+  constexpr int SA_U = 2;   // (round 5b, with 64-byte records: 1 and 2 candidates per trip 17.4-17.7 Gpts/s, 4: 16.8, 8: 14.7; with the 80-byte records and a count atomic per hit, 4 had been the best)
   const int e0 = off[cell], e1 = off[cell + 1];
   for (int e = e0; e < e1; e += SA_U) {
     int k[SA_U];
