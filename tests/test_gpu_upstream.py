@@ -546,3 +546,43 @@ def test_data_association_outgrown_capacity_repeats_the_round():
     assert e.value.code == lvx.E_RANGE and "map time outside the trajectory" in str(e.value)
     _da_same(_da_round(g, S, x), b1)
     g.close(); ref.close()
+
+
+def test_surfel_assoc_wide_scans_and_double_precision_boxes(ctx):
+    """W = 4096 columns (128 mask words per ring: two words per bit of the ring's occupancy word, 32 column blocks of the single-launch emission), H = 32 rings, and
+    surfel boxes whose bounds are NOT floats (the hit kernel compares the float point with the bounds rounded outwards to floats, which must decide exactly what the
+    reference's double comparison decides — some bounds are set to lie between a scan coordinate and its float neighbour)."""
+    S, H, W = 4, 32, 4096
+    rng = np.random.default_rng(3)
+    scans, raws = [], []
+    p4 = bmin = bmax = None
+    for s in range(S):
+        scan, p4s, bmins, bmaxs = synth.make_assoc_problem(seed=90 + s, H=H, W=W, n_planes=500)
+        if p4 is None:
+            p4, bmin, bmax = p4s, bmins.copy(), bmaxs.copy()
+        raw = np.zeros((H, W), dtype=lvx.POINT_XYZIT)
+        raw["x"], raw["y"], raw["z"] = scan[..., 0], scan[..., 1], scan[..., 2]
+        raw["timestamp"] = 50.0 + 0.1 * s + np.tile(np.arange(W) / W * 0.1, (H, 1))
+        raw["timestamp"][rng.random((H, W)) < 0.03] = 0.0
+        scans.append(scan); raws.append(raw)
+    # bounds off the float lattice: a relative 1e-12 nudge either way, and for a tenth of the boxes a bound half a float ulp beside a coordinate of a scan point
+    bmin *= 1.0 + 1e-12 * rng.standard_normal(bmin.shape); bmax *= 1.0 + 1e-12 * rng.standard_normal(bmax.shape)
+    pts = scans[0].reshape(-1, 4)[:, :3]
+    pts = pts[~np.isnan(pts[:, 0])].astype(np.float64)
+    for k in range(0, len(p4), 10):
+        q = pts[rng.integers(len(pts))]
+        a = int(rng.integers(3))
+        half_ulp = 0.5 * abs(float(np.spacing(np.float32(q[a]))))
+        if k % 20 == 0:
+            bmin[k] = q - 0.4; bmax[k] = q + 0.4; bmin[k, a] = q[a] + (half_ulp if k % 40 == 0 else -half_ulp)    # just above / just below the point's coordinate
+        else:
+            bmin[k] = q - 0.4; bmax[k] = q + 0.4; bmax[k, a] = q[a] + (half_ulp if k % 30 == 0 else -half_ulp)
+    assert (bmin.astype(np.float32).astype(np.float64) != bmin).any()
+    fo = [O.surfel_assoc(sc, p4, bmin, bmax, 0.05, 2) for sc in scans]
+    eo = [O.surfel_emit(f, sc, rw) for f, sc, rw in zip(fo, scans, raws)]
+    fg, eg = lvx.surfel_assoc_emit(ctx, np.stack(scans), np.stack(raws), p4, bmin, bmax, 0.05, 2)
+    assert np.array_equal(fg, np.stack(fo))
+    assert sum((f >= 0).sum() for f in fo) > 500
+    assert list(eg["counts"]) == [len(e["t"]) for e in eo]
+    for k in ("pt", "pt_map", "t", "plane"):
+        assert np.array_equal(eg[k], np.concatenate([e[k] for e in eo]))
