@@ -1225,11 +1225,41 @@ __global__ __launch_bounds__(256) void k_surfel_extract(const float4* __restrict
     const double cs[9] = {cc[0], cc[1], cc[2], cc[1], cc[3], cc[4], cc[2], cc[4], cc[5]};
     double C[9];
     for (int a = 0; a < 3; ++a) for (int bb = 0; bb < 3; ++bb) C[3 * a + bb] = cs[3 * a + bb] / nin - mu[a] * mu[bb];
-    double e2[3], V2[9];
-    // (every lane the same: the sums are wave-uniform after the butterfly.  The solve is what the launch costs — 4 072 wave-level solves on 1 024 SIMDs: 56 of 76 us with
-    // the sweeps run until the off-diagonal squares underflow as the oracle's loop does, 28 of 48 us stopping at 1e-18 of the diagonal as k_vx_leaf does)
-    vx_eig3<true>(C, e2, V2);
-    nrm[0] = V2[0]; nrm[1] = V2[3]; nrm[2] = V2[6];
+    // The refit needs ONE eigenvector of C, the smallest one's, and the leaf's own normal is within a few degrees of it: Rayleigh-quotient iteration from there
+    // (y = adj(C - lambda I) n by cross products of the rows: no division, cubic convergence — three rounds reach the last bit), checked to be the SMALLEST eigenvalue
+    // through the characteristic polynomial's other two roots; anything else (a leaf whose inliers turn the plane over) takes the full Jacobi solve as before.
+    // (Every lane computes the same: the sums are wave-uniform after the butterfly.  The full solve was what the launch cost — 4 072 wave-level solves on 1 024 SIMDs:
+    // 56 of 76 us with the sweeps run until the off-diagonal squares underflow as the oracle's loop does, 28 of 48 us stopping at 1e-18 of the diagonal.)
+    bool rq_ok = false;
+    {
+      double nv[3] = {nrm[0], nrm[1], nrm[2]}, lam = 0.0;
+      for (int it = 0; it < 4; ++it) {
+        const double Cn[3] = {C[0] * nv[0] + C[1] * nv[1] + C[2] * nv[2], C[3] * nv[0] + C[4] * nv[1] + C[5] * nv[2], C[6] * nv[0] + C[7] * nv[1] + C[8] * nv[2]};
+        lam = nv[0] * Cn[0] + nv[1] * Cn[1] + nv[2] * Cn[2];
+        const double r0[3] = {C[0] - lam, C[1], C[2]}, r1[3] = {C[3], C[4] - lam, C[5]}, r2[3] = {C[6], C[7], C[8] - lam};
+        const double a0[3] = {r1[1] * r2[2] - r1[2] * r2[1], r1[2] * r2[0] - r1[0] * r2[2], r1[0] * r2[1] - r1[1] * r2[0]};   // r1 x r2
+        const double a1[3] = {r2[1] * r0[2] - r2[2] * r0[1], r2[2] * r0[0] - r2[0] * r0[2], r2[0] * r0[1] - r2[1] * r0[0]};   // r2 x r0
+        const double a2[3] = {r0[1] * r1[2] - r0[2] * r1[1], r0[2] * r1[0] - r0[0] * r1[2], r0[0] * r1[1] - r0[1] * r1[0]};   // r0 x r1
+        double y[3];
+        for (int a = 0; a < 3; ++a) y[a] = a0[a] * nv[0] + a1[a] * nv[1] + a2[a] * nv[2];
+        const double yy = y[0] * y[0] + y[1] * y[1] + y[2] * y[2];
+        if (!(yy > 1e-290)) break;                       // C - lambda I is singular to the last bit: nv is the eigenvector
+        const double sc = rsqrt(yy) * ((y[0] * nv[0] + y[1] * nv[1] + y[2] * nv[2]) < 0.0 ? -1.0 : 1.0);
+        for (int a = 0; a < 3; ++a) nv[a] = y[a] * sc;
+      }
+      // is lambda the smallest eigenvalue?  the other two are the roots of x^2 - s x + p with s = tr C - lambda, p = (sum of the principal 2 x 2 minors) - lambda s
+      const double tr = C[0] + C[4] + C[8], s2 = tr - lam;
+      const double mn = (C[0] * C[4] - C[1] * C[3]) + (C[0] * C[8] - C[2] * C[6]) + (C[4] * C[8] - C[5] * C[7]);
+      const double p2 = mn - lam * s2, disc = s2 * s2 - 4.0 * p2;
+      const double small_other = 0.5 * (s2 - sqrt(disc > 0.0 ? disc : 0.0));
+      const double nn = nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2];
+      if (fabs(nn - 1.0) < 1e-12 && lam < small_other - 1e-9 * fabs(tr)) { nrm[0] = nv[0]; nrm[1] = nv[1]; nrm[2] = nv[2]; rq_ok = true; }
+    }
+    if (!rq_ok) {
+      double e2[3], V2[9];
+      vx_eig3<true>(C, e2, V2);
+      nrm[0] = V2[0]; nrm[1] = V2[3]; nrm[2] = V2[6];
+    }
     d = -(nrm[0] * mu[0] + nrm[1] * mu[1] + nrm[2] * mu[2]);
   }
   if (nin < min_inl) return;

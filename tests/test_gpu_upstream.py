@@ -548,11 +548,12 @@ def test_data_association_outgrown_capacity_repeats_the_round():
     g.close(); ref.close()
 
 
-def test_surfel_assoc_wide_scans_and_double_precision_boxes(ctx):
+def test_surfel_assoc_wide_scans_and_double_precision_boxes():
     """W = 4096 columns (128 mask words per ring: two words per bit of the ring's occupancy word, 32 column blocks of the single-launch emission), H = 32 rings, and
     surfel boxes whose bounds are NOT floats (the hit kernel compares the float point with the bounds rounded outwards to floats, which must decide exactly what the
     reference's double comparison decides — some bounds are set to lie between a scan coordinate and its float neighbour)."""
     S, H, W = 4, 32, 4096
+    ctx = lvx.Context(0)   # (its own context: lvx_synchronize also reports what an earlier asynchronous evaluation of a shared context left in the device error word)
     rng = np.random.default_rng(3)
     scans, raws = [], []
     p4 = bmin = bmax = None
@@ -586,3 +587,4 @@ def test_surfel_assoc_wide_scans_and_double_precision_boxes(ctx):
     assert list(eg["counts"]) == [len(e["t"]) for e in eo]
     for k in ("pt", "pt_map", "t", "plane"):
         assert np.array_equal(eg[k], np.concatenate([e[k] for e in eo]))
+    ctx.close()
