@@ -498,8 +498,10 @@ template <int SIDE, bool TAU = false> struct RepSideAcc {   // SIDE 0: the refer
 // cost and residual output happen here.  The two-pose rolling-shutter residual needs > 512 registers when it shares a kernel with the
 // assembly, so the MFMA passes read the rows back instead (2 x 45 MB at config 4, nothing against their atomics).
 template <bool TAU>
-__global__ __launch_bounds__(64) void k_reproj_jac(ReprojFamT<TAU> fam, DevCommon cm, double* Jb, double* rb, int* kb, long long row0) {
-  constexpr int RJ = REP_NC + (TAU ? 1 : 0);
+__global__ __launch_bounds__(64) void k_reproj_jac(ReprojFamT<TAU> fam, DevCommon cm, double* Jb, double* rb, int* kb, long long row0, double* Trec) {
+  constexpr int RJ = REP_NC + (TAU ? 1 : 0), RW = 56 + (TAU ? 1 : 0);
+  constexpr int RS = RW | 1;           // odd LDS stride: a lane writes its record's words one instruction at a time
+  __shared__ double trec_s[64 * RS];
   const int lane = threadIdx.x, si = blockIdx.x * 64 + lane, n = fam.n;
   const int rep = blockIdx.x % cm.nrep;
   double mycost = 0.0;
@@ -523,8 +525,27 @@ __global__ __launch_bounds__(64) void k_reproj_jac(ReprojFamT<TAU> fam, DevCommo
 #pragma unroll
           for (int c = 0; c < RJ; ++c) Jb[(size_t)(a * RJ + c) * n + si] = J[a][c] * scale;
         }
+        if (Trec) {   // the landmark's own row of this block: rho x [ref knots 24 | obs knots 24 | camera 6 | rho | gradient (| camera time offset)] — one contiguous record per
+          // block for k_reproj_lmrows (round 5b: formed here, where the rows sit in registers; the cross-term kernel read them back for it: 11 of its 58 us).  Through LDS:
+          // the records of the wavefront's 64 blocks are contiguous in memory, a lane's own record is not a coalesced store.
+          double* rec = trec_s + lane * RS;
+          const double j0 = J[0][54] * scale, j1 = J[1][54] * scale;
+#pragma unroll
+          for (int c = 0; c < 54; ++c) rec[c] = j0 * (J[0][c] * scale) + j1 * (J[1][c] * scale);
+          rec[54] = j0 * j0 + j1 * j1;
+          rec[55] = j0 * (r[0] * scale) + j1 * (r[1] * scale);
+          if (TAU) rec[56] = j0 * (J[0][55] * scale) + j1 * (J[1][55] * scale);
+        }
       }
     }
+  }
+  if (Trec && (cm.what & LVX_EVAL_NORMAL_EQ)) {   // (records of skipped blocks are never read: k_reproj_lmrows looks at the block's interval first)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int nrec = min(64, n - (int)blockIdx.x * 64);
+    double* dst = Trec + (size_t)blockIdx.x * 64 * RW;
+    for (int e = lane; e < nrec * RW; e += 64) { const int r_ = e / RW; dst[e] = trec_s[r_ * RS + (e - r_ * RW)]; }
   }
   mycost = wave_sum(mycost);
   if (lane == 0) atomicAdd(&cm.cost[rep], mycost);
@@ -551,7 +572,6 @@ __global__ __launch_bounds__(64 * RX_NW) void k_reproj_cross(RepCross rc, DevCom
   constexpr int LDP = 49, BR = 16;   // panel: 16 rows (8 blocks x 2 residual rows) x 48 columns, odd stride
   constexpr int RJ = REP_NC + (TAU ? 1 : 0), RW = 56 + (TAU ? 1 : 0);
   __shared__ double pan[RX_NW][2][BR * LDP];
-  __shared__ double tbuf[RX_NW][8 * RW];
   __shared__ double sbuf[RX_NW][2][48];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int rep = blockIdx.x % cm.nrep;
@@ -575,12 +595,11 @@ __global__ __launch_bounds__(64 * RX_NW) void k_reproj_cross(RepCross rc, DevCom
       const int o0 = k0 - 4 * w0, o1 = k1 - 4 * w1;
       const bool stray = live && (o0 < 0 || o0 > 3 || o1 < 0 || o1 > 3);   // the camera time offset moved a view out of its window
       const bool valid = live && !stray;
-      double v[12], jr = 0.0;
+      double v[12];
       if (live) {
         const double* src = rc.jac.J + (size_t)(a * RJ + 24 * side + 12 * h) * n + i;
 #pragma unroll
         for (int c = 0; c < 12; ++c) v[c] = src[(size_t)c * n];
-        jr = rc.jac.J[(size_t)(a * RJ + 54) * n + i];
       } else {
 #pragma unroll
         for (int c = 0; c < 12; ++c) v[c] = 0.0;
@@ -607,36 +626,6 @@ __global__ __launch_bounds__(64 * RX_NW) void k_reproj_cross(RepCross rc, DevCom
         for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
           for (int cj = 0; cj < 3; ++cj) D[ci * 3 + cj] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[ci], fo[cj], D[ci * 3 + cj], 0, 0, 0);
-      }
-      // the landmark's row: rho x [ref knots | obs knots | camera | rho | gradient] = 56 products per block.  Every lane forms those of its 12
-      // knot columns (summed over the two residual rows: lanes part and part ^ 2), three spare lanes the rest; the 8 x 56 values pass through
-      // LDS and leave as one contiguous 448-byte record per block — k_reproj_lmrows sums a landmark's records into its row without atomics
-      {
-        double t[12];
-#pragma unroll
-        for (int c = 0; c < 12; ++c) { t[c] = jr * v[c]; t[c] += __shfl_xor(t[c], 2); }
-        double* tb = tbuf[wv] + b * RW;
-        if (a == 0) {
-#pragma unroll
-          for (int c = 0; c < 12; ++c) tb[24 * side + 12 * h + c] = t[c];
-        } else if (live) {
-          const double* J0 = rc.jac.J + i; const double* J1 = rc.jac.J + (size_t)RJ * n + i;
-          const double r0 = J0[(size_t)54 * n], r1 = J1[(size_t)54 * n];
-          if (side == 0) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) { const int cc = 48 + 3 * h + q; tb[cc] = r0 * J0[(size_t)cc * n] + r1 * J1[(size_t)cc * n]; }
-          } else if (h == 0) {
-            tb[54] = r0 * r0 + r1 * r1;
-            tb[55] = r0 * rc.jac.r[i] + r1 * rc.jac.r[(size_t)n + i];
-          } else if (TAU) tb[56] = r0 * J0[(size_t)55 * n] + r1 * J1[(size_t)55 * n];
-        } else if (side == 0) { tb[48 + 3 * h] = 0.0; tb[49 + 3 * h] = 0.0; tb[50 + 3 * h] = 0.0; }
-        else if (h == 0) { tb[54] = 0.0; tb[55] = 0.0; }
-        else if (TAU) tb[56] = 0.0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int nblk8 = min(8, m1 - base);
-        for (int e2 = lane; e2 < nblk8 * RW; e2 += 64) rc.T[(size_t)base * RW + e2] = tbuf[wv][e2];   // records of consecutive blocks are contiguous
       }
       {   // strays: the 24 x 24 cross block of each, entry by entry
         unsigned long long sm = __ballot(stray && part == 0);
@@ -2518,7 +2507,8 @@ int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cos
         double* Jb = (double*)ctx->d_repB[0].p; double* rb = Jb + (size_t)2 * RJ * r.n; int* kb = (int*)ctx->d_repB[1].p;
         { ProfScope ps(ctx, LVX_KERNEL_REP_JAC, st);
           const ReprojFamT<T> rf{r.n, r.lm, r.uv, r.t0o, r.perm, r.lm_uv, r.lm_t0, r.weight, r.huber};
-          hipLaunchKernelGGL(k_reproj_jac<T>, grid(r.n), dim3(64), 0, st, rf, cm, Jb, rb, kb, (long long)ctx->fam_row0[4]); }
+          hipLaunchKernelGGL(k_reproj_jac<T>, grid(r.n), dim3(64), 0, st, rf, cm, Jb, rb, kb, (long long)ctx->fam_row0[4],
+                             (ctx->L > 0 && !(ctx->locks & LVX_LOCK_LANDMARKS) && ctx->rep_groups > 0) ? (double*)ctx->d_repT.p : (double*)nullptr); }
         if (!(what & LVX_EVAL_NORMAL_EQ)) return LVX_OK;
         const RepJac jac{Jb, rb, kb, r.n};
         if (s_side != st) { LVX_HIP(ctx, hipEventRecord(ctx->ev_jac, st)); LVX_HIP(ctx, hipStreamWaitEvent(s_side, ctx->ev_jac, 0)); side_used = true; }
