@@ -590,20 +590,23 @@ __global__ __launch_bounds__(64 * RX_NW) void k_reproj_cross(RepCross rc, DevCom
     for (int base = m0; base < m1; base += 8) {
       const int i = base + b;
       const bool in = i < m1;
-      const int k0 = in ? rc.jac.k[i] : -1, k1 = in ? rc.jac.k[(size_t)n + i] : -1;
+      // intervals AND rows requested together (clamped address, selected afterwards: the rows of a skipped block were never written) — the rows behind the test of the
+      // interval were a second, dependent memory round trip per eight blocks
+      const int ic = min(i, m1 - 1);
+      const int k0r = rc.jac.k[ic], k1r = rc.jac.k[(size_t)n + ic];
+      double v[12];
+      {
+        const double* src = rc.jac.J + (size_t)(a * RJ + 24 * side + 12 * h) * n + ic;
+#pragma unroll
+        for (int c = 0; c < 12; ++c) v[c] = src[(size_t)c * n];
+      }
+      const int k0 = in ? k0r : -1, k1 = in ? k1r : -1;
       const bool live = in && k1 >= 0;
       const int o0 = k0 - 4 * w0, o1 = k1 - 4 * w1;
       const bool stray = live && (o0 < 0 || o0 > 3 || o1 < 0 || o1 > 3);   // the camera time offset moved a view out of its window
       const bool valid = live && !stray;
-      double v[12];
-      if (live) {
-        const double* src = rc.jac.J + (size_t)(a * RJ + 24 * side + 12 * h) * n + i;
 #pragma unroll
-        for (int c = 0; c < 12; ++c) v[c] = src[(size_t)c * n];
-      } else {
-#pragma unroll
-        for (int c = 0; c < 12; ++c) v[c] = 0.0;
-      }
+      for (int c = 0; c < 12; ++c) v[c] = live ? v[c] : 0.0;
       for (int e = lane; e < 2 * BR * LDP; e += 64) Pr[e] = 0.0;   // both panels are contiguous
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
