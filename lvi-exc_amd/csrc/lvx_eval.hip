@@ -2405,7 +2405,7 @@ int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cos
         if (ctx->L > 0 && ctx->rep.n > 0 && !(ctx->locks & LVX_LOCK_LANDMARKS) && !rep_fast) add(cm.lmH, (size_t)ctx->L * ctx->lm_ls * 8);
       }
       size_t total = 0; for (int i = 0; i < cl.n; ++i) total += cl.words[i];
-      const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
+      const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 8);   // 8 per CU (round 5b, 37 MB to clear: 512 blocks 0.540 ms per pass, 1 024 0.542, 2 048 0.5396, 8 192 — one 16-byte store per thread — 0.5478)
       ProfScope ps(ctx, LVX_KERNEL_CLEAR, st);
       hipLaunchKernelGGL(k_clear, dim3(blocks + (unsigned)npre + (unsigned)bc.nblk + (unsigned)bc.hub_blk), dim3(256), 0, st, cl, bc, npre, cm, (So3Pre*)ctx->d_pre.p, nblk_tab, ctx->t_map, fast_surf ? 1 : 0, fast_cs ? 1 : 0,
                          (HubShared*)ctx->d_hubs.p);
