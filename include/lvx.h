@@ -182,7 +182,8 @@ int lvx_synchronize(lvx_ctx* ctx);
 #define LVX_KERNEL_REP_REF 12
 #define LVX_KERNEL_REP_CROSS 13
 #define LVX_KERNEL_REP_LMROWS 14
-#define LVX_NUM_KERNELS 15
+#define LVX_KERNEL_REP_FUSED 15     /* round 6: the single-launch reprojection kernel (k_reproj_fused); the five above then stay at zero */
+#define LVX_NUM_KERNELS 16
 /* enable: 0 off | 1 every launch | 2 + k: only the launches of kernel k (e.g. 2 + LVX_FAM_SURFEL: the dominant kernel — two event
  * records per pass instead of ~20, which cost ~5 % of a config-4 pass).  While profiling is on, passes are issued launch by launch (no graph replay). */
 int lvx_set_profiling(lvx_ctx* ctx, int enable);

@@ -16,7 +16,7 @@ const SwitchName* switch_table(int* count) {
   static const SwitchName tab[] = {
     {"FORCE_LEGACY", &Switches::force_legacy, false}, {"SERIAL", &Switches::serial, false}, {"NO_GRAPH", &Switches::no_graph, false}, {"DETERMINISTIC", &Switches::deterministic, true},
     {"CLEAR_ALL", &Switches::clear_all, false}, {"SOLVER_SEQ", &Switches::solver_seq, false}, {"SOLVER_TIMING", &Switches::solver_timing, false},
-    {"CHUNK_R", &Switches::chunk_r, true}, {"CHUNK_R_IMU", &Switches::chunk_r_imu, true}, {"CHUNK_R_REP", &Switches::chunk_r_rep, true}, {"CHUNK_ROWS", &Switches::chunk_rows, true}, {"REP_ROWS", &Switches::rep_rows, true},
+    {"CHUNK_R", &Switches::chunk_r, true}, {"CHUNK_R_IMU", &Switches::chunk_r_imu, true}, {"CHUNK_R_REP", &Switches::chunk_r_rep, true}, {"CHUNK_ROWS", &Switches::chunk_rows, true}, {"REP_ROWS", &Switches::rep_rows, true}, {"REP_FUSED", &Switches::rep_fused, true},
     {"DA_SYNC", &Switches::da_sync, false},   // lvx_data_association: always the synchronous chain (four host stops), never the speculative one
   };
   *count = (int)(sizeof(tab) / sizeof(tab[0]));
@@ -91,7 +91,7 @@ void lvx_destroy(lvx_ctx* c) {
   if (c->d_pre.p) (void)hipFree(c->d_pre.p);
   if (c->d_colfull.p) (void)hipFree(c->d_colfull.p);
   for (auto& b : c->d_det_list) if (b.p) (void)hipFree(b.p);
-  for (DevBuf* b : {&c->d_imu_rtab, &c->d_chk, &c->d_det_cross, &c->d_lm_grp, &c->d_lmH, &c->d_lm_p0, &c->d_Hr, &c->d_Br, &c->d_red, &c->d_repT}) if (b->p) (void)hipFree(b->p);
+  for (DevBuf* b : {&c->d_imu_rtab, &c->d_chk, &c->d_det_cross, &c->d_lm_grp, &c->d_lmH, &c->d_lm_p0, &c->d_Hr, &c->d_Br, &c->d_red, &c->d_repT, &c->d_repF}) if (b->p) (void)hipFree(b->p);
   if (c->vox.graph) (void)hipGraphExecDestroy((hipGraphExec_t)c->vox.graph);
   if (c->vox.h_info) (void)hipHostFree(c->vox.h_info);
   if (c->da_pinned) (void)hipHostFree(c->da_pinned);

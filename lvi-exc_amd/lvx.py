@@ -27,8 +27,8 @@ LOCK_LANDMARKS = 1 << 10
 
 EVAL_COST, EVAL_RESIDUALS, EVAL_NORMAL_EQ, EVAL_JACOBIAN = 1, 2, 4, 8
 (FAM_GYRO, FAM_ACCEL, FAM_PRIOR, FAM_SURFEL, FAM_REPROJ, FAM_CAMSURF, KERNEL_FOLD, KERNEL_SOLVE, KERNEL_UPSTREAM, KERNEL_CLEAR, KERNEL_REP_JAC, KERNEL_REP_OBS,
- KERNEL_REP_REF, KERNEL_REP_CROSS, KERNEL_REP_LMROWS) = range(15)
-KERNEL_NAMES = ["gyro", "accel", "prior", "surfel", "reproj", "camsurf", "fold", "solve", "upstream", "clear", "reproj_jac", "reproj_obs", "reproj_ref", "reproj_cross", "reproj_lmrows"]
+ KERNEL_REP_REF, KERNEL_REP_CROSS, KERNEL_REP_LMROWS, KERNEL_REP_FUSED) = range(16)
+KERNEL_NAMES = ["gyro", "accel", "prior", "surfel", "reproj", "camsurf", "fold", "solve", "upstream", "clear", "reproj_jac", "reproj_obs", "reproj_ref", "reproj_cross", "reproj_lmrows", "reproj_fused"]
 JAC_WIDTH = 64
 
 
