@@ -60,7 +60,7 @@ struct DevBuf {
 // Experiment / debug switches: read ONCE from the environment (LVX_<NAME>) when the context is created and changed afterwards only
 // through lvx_set_switch — the evaluation path never calls getenv.
 struct Switches {
-  int force_legacy = 0, serial = 0, no_graph = 0, deterministic = 0, clear_all = 0, solver_seq = 0, solver_timing = 0, chunk_r = 0, chunk_r_imu = 0, chunk_r_rep = 0, chunk_rows = 0, rep_rows = 0, da_sync = 0, rep_fused = 0;   // rep_fused: 0 = the layout decides, 1 = fused reprojection kernel whenever it is structurally possible, -1 = never (the five-launch chain)
+  int force_legacy = 0, serial = 0, no_graph = 0, deterministic = 0, clear_all = 0, solver_seq = 0, solver_timing = 0, chunk_r = 0, chunk_r_imu = 0, chunk_r_rep = 0, chunk_rows = 0, rep_rows = 0, da_sync = 0, rep_fused = 0;   // rep_fused: 1 = the single-launch reprojection kernel (k_reproj_fused; measured slower, opt-in), otherwise the five-launch chain
 };
 struct SwitchName { const char* name; int Switches::*field; bool relayout; };
 const SwitchName* switch_table(int* count);
@@ -103,7 +103,7 @@ struct lvx_ctx {
   int nb = 0, bw = 0, nbd = 0, nbd_ext = 0, n_hub = 0, hub0 = 0;   // nbd: solve border (hub knots + 22 calib); nbd_ext = nbd + 12 pseudo rows
   lvx::Switches sw;
   int rep_groups = 0;          // (reference window, observation window) groups of the reprojection cross-term kernel (d_repB[2])
-  int rep_fused_wg = 0, rep_fused_maxlm = 0; lvx::DevBuf d_repF;   // fused reprojection kernel (k_reproj_fused): workgroups (0: the chain runs), most landmarks of one workgroup, [wg_off | wg_lm_off | lm_ids | lml]
+  int rep_fused_wg = 0; lvx::DevBuf d_repF;   // fused reprojection kernel (k_reproj_fused): its groups (0: the five-launch chain runs) and their table [start | count], largest first
   bool force_legacy = false;   // set when the fast assembly kernels hit a case only the per-segment kernels handle exactly
   lvx::DevBuf d_pre;   // So3Pre[N]
   lvx::DevBuf d_repT;   // [rep.n][56] landmark-row records of the reprojection blocks (k_reproj_cross -> k_reproj_lmrows)

@@ -731,210 +731,190 @@ __global__ __launch_bounds__(256) void k_reproj_lmrows(RepLmRows q, DevCommon cm
 
 // ---------------------------------------------------------------------------------------------------------
 // Fused reprojection kernel (round 6): residual + Jacobian + J^T J / J^T r + landmark rows of every block in ONE launch; no Jacobian row ever goes to HBM
-// (the five-launch chain above wrote 0.9 KB of rows and a 448-byte record per block and read them back three times: 176 MB per pass for 3 MB of inputs).
-//   * A workgroup OWNS a set of landmarks — all their blocks, <= 256, laid out by the host in (reference interval, observation interval, landmark) order — so
-//     the landmarks' rows [band couplings | border couplings | H_ll | g_l] are summed in LDS and STORED once (no clear, no atomics), as k_reproj_lmrows did from
-//     the records.
-//   * Wavefront w evaluates its quarter of the blocks, lane = block (the two-pose rolling-shutter residual takes the whole 512-register budget: one wavefront
-//     per SIMD, the rows stay in registers afterwards).
-//   * Assembly per wavefront, panel-major as k_family_mfma: 16 lanes at a time write their two rows into a 32 x 64 LDS panel with the column space
-//       [ref knots 24 | camera 6 | camera time offset | residual | obs knots 24 | 8 zeros]  = four 16-column MFMA tiles, ten upper tile pairs;
-//     a RUN of lanes with the same (reference interval, observation interval) shares these columns exactly (views of one frame pair: tens of blocks with
-//     ORB-like tracks), its k-steps accumulate in registers across panels and leave with one atomic per non-zero entry when the pair changes.  Runs are
-//     formed from the intervals the evaluation RETURNS, so a camera time offset that moves a view into the neighbouring interval needs no special case.
-// The layout falls back to the chain above when runs are short (sparse tracks: a block per frame pair), in deterministic mode, or when a landmark has
-// more than 256 blocks or a row that does not fit in LDS.
+// (the five-launch chain above writes 0.9 KB of rows and a 448-byte record per block and reads them back three times: 176 MB per pass for 3 MB of inputs).
+//   * A WAVEFRONT owns a group = up to 64 blocks of one (reference window, observation window) pair, a window being 4 aligned knot intervals (7 knots, 42 columns) —
+//     the unit k_reproj_cross already owned; the rolling shutter spreads the views of one frame over 3.3 intervals, so exact (interval, interval) pairs hold ~3 blocks
+//     each and were measured hopeless (26 M atomics, 0.6 ms), windows hold tens.
+//   * lane = block: the two-pose residual takes the whole 512-register budget (one wavefront per SIMD), its rows stay in registers.
+//   * 16 lanes at a time write their two rows into a 32 x 96 LDS panel with the column space  [ref knots 42 | camera 6 || obs knots 42 | tau | r | rho | 0 0 0]  = six
+//     16-column MFMA tiles; the 21 upper tile pairs accumulate over the whole group in registers and leave through LDS with ONE atomic per non-zero entry per group:
+//     reference side, observation side, cross block, camera block and gradient together (the chain flushed the sides per 256-row chunk and the cross block per 32 blocks).
+//   * the landmark's own row (rho x everything: 57 products per block) is formed from the panel, (block, column) per lane, and added to the landmark's row in HBM
+//     (cleared by k_clear on this path: a landmark's views sit in different groups, nobody owns its row).
+//   * windows are taken from the intervals the evaluation RETURNS: a camera time offset that moves a view out of its group's window makes that block a group of its own.
+// Code size matters as much as instruction count: at one wavefront per SIMD nothing hides an instruction-cache miss.  The first version — scatter and landmark loops
+// fully unrolled over register arrays, ~40 k instructions executed once per group — spent 260 us in the scatter and 170 in the landmark loop; the loops below read the
+// panel / the dumped tiles back from LDS with a few dozen instructions per trip.
+// MEASURED SLOWER than the chain at config 4 (218 vs ~120 us) and therefore opt-in (switch REP_FUSED = 1): evaluation 63 us (two rounds, 573 spilled registers next to the
+// 21 accumulator tiles), MFMA 30, landmark atomics 51, scatter 69 — at one wavefront per SIMD the 6 M atomics retire at ~50 G/s, the chain's cross kernel (6-9 wavefronts
+// per CU) at twice that.  What it does achieve: one launch, no Jacobian rows in HBM.
 // ---------------------------------------------------------------------------------------------------------
-struct RepFused { const int* wg_off; const int* wg_lm_off; const int* lm_ids; const int* lml; };   // blocks of workgroup g: [wg_off[g], wg_off[g + 1]); its landmarks: lm_ids[wg_lm_off[g] .. wg_lm_off[g + 1]); lml[i]: block i's landmark, index into that list
-#define RF_LDP 65
-#define RF_PR 32
-__host__ __device__ inline size_t rep_fused_lds_bytes(int n_lm, int lm_ls) { return ((size_t)4 * RF_PR * RF_LDP + (size_t)n_lm * lm_ls) * 8; }
+struct RepFused { const int* g_start; const int* g_count; int ng; };   // group g: blocks [g_start[g], g_start[g] + g_count[g]) of the device row order, largest groups first
+#define RF_LDP 97                      // panel row stride (doubles)
+#define RF_WBUF (32 * RF_LDP + 48)     // per-wavefront LDS (doubles): the 32 x 96 panel, reused for 11 accumulator tiles at a time at the end of a group; + 96 column positions (int)
 template <bool TAU>
 __global__ __launch_bounds__(256, 1) void k_reproj_fused(ReprojFamT<TAU> fam, RepFused q, DevCommon cm, long long row0) {
-  constexpr int RJ = REP_NC + (TAU ? 1 : 0), LDP = RF_LDP, PR = RF_PR, GL = 16, RCOL = 31;
-  extern __shared__ double smf[];
-  double* lmrow = smf + 4 * PR * LDP;                   // [landmarks of this workgroup][lm_ls]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int wg = blockIdx.x, rep = wg % cm.nrep, N = cm.N;
-  const int m0 = q.wg_off[wg], m1 = q.wg_off[wg + 1];
-  const int lq0 = q.wg_lm_off[wg], nl = q.wg_lm_off[wg + 1] - lq0;
+  constexpr int RJ = REP_NC + (TAU ? 1 : 0), LDP = RF_LDP, TCOL = 90, RCOL = 91, LCOL = 92;   // panel columns: camera time offset, residual, the landmark's own (rho)
+  __shared__ double smf[4 * RF_WBUF];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int N = cm.N;
   const bool want_ne = (cm.what & LVX_EVAL_NORMAL_EQ) != 0;
   const bool lm_free = want_ne && cm.L > 0 && !(cm.locks & LVX_LOCK_LANDMARKS);
-  double* P = smf + wv * (PR * LDP);
-  if (want_ne) {
-    for (int e = lane; e < PR * LDP; e += 64) P[e] = 0.0;   // columns 56 .. 64 stay zero
-    if (lm_free) for (int e = tid; e < nl * cm.lm_ls; e += 256) lmrow[e] = 0.0;
-    __syncthreads();
-  }
-  const int per = (m1 - m0 + 3) >> 2;                   // blocks per wavefront (<= 64)
-  const int si = m0 + wv * per + lane;
-  const bool in = lane < per && si < m1;
-  double r[2], J[2][RJ];
-  Keys key{-1, -1, -1};
-  bool valid = false;
-  double mycost = 0.0;
-  if (in) {
-    const SplineRef sp{cm.t0, cm.dt, cm.N, cm.state, cm.state + 3 * (size_t)cm.N};
-    const Cal cal = load_cal(cm);
-    const int status = fam.eval_pre(cm, sp, cal, si, r, J, key);
-    if (status != RES_OK) atomicOr(cm.err, status);
-    else {
-      valid = true;
-      double scale;
-      mycost = 0.5 * huber_rho(fam.huber, r[0] * r[0] + r[1] * r[1], &scale);
-      if (cm.residuals) { const long long orow = row0 + (long long)fam.perm[si] * 2; cm.residuals[orow] = r[0]; cm.residuals[orow + 1] = r[1]; }
-      if (scale != 1.0) {
+  double* P = smf + wv * RF_WBUF;
+  int* posL = (int*)(P + 32 * LDP);
+  for (int g = blockIdx.x * 4 + wv; g < q.ng; g += gridDim.x * 4) {
+    const int rep = g % cm.nrep;
+    const int si = q.g_start[g] + lane;
+    const bool in = lane < q.g_count[g];
+    double r[2], J[2][RJ];
+    Keys key{-1, -1, -1};
+    bool valid = false;
+    double mycost = 0.0;
+    if (in) {
+      const SplineRef sp{cm.t0, cm.dt, cm.N, cm.state, cm.state + 3 * (size_t)cm.N};
+      const Cal cal = load_cal(cm);
+      const int status = fam.eval_pre(cm, sp, cal, si, r, J, key);
+      if (status != RES_OK) atomicOr(cm.err, status);
+      else {
+        valid = true;
+        double scale;
+        mycost = 0.5 * huber_rho(fam.huber, r[0] * r[0] + r[1] * r[1], &scale);
+        if (cm.residuals) { const long long orow = row0 + (long long)fam.perm[si] * 2; cm.residuals[orow] = r[0]; cm.residuals[orow + 1] = r[1]; }
+        if (scale != 1.0) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          r[a] *= scale;
+          for (int a = 0; a < 2; ++a) {
+            r[a] *= scale;
 #pragma unroll
-          for (int c = 0; c < RJ; ++c) J[a][c] *= scale;
+            for (int c = 0; c < RJ; ++c) J[a][c] *= scale;
+          }
         }
       }
     }
-  }
-  mycost = wave_sum(mycost);
-  if (lane == 0 && mycost != 0.0) atomicAdd(&cm.cost[rep], mycost);
-  if (!want_ne) return;
-  if (!valid) { key.k0 = -1; key.k1 = -1; }
-  // band / border position of panel column c for the frame pair (k0, k1): lane c holds column c's
-  auto col_pos = [&](int c, int k0, int k1) -> int {
-    int tg;
-    if (c < 24) tg = 6 * k0 + c;
-    else if (c < 30) tg = 6 * N + 15 + (c - 24);
-    else if (c == 30) { if (!TAU) return LVX_DEAD; tg = 6 * N + 21; }
-    else if (c == RCOL || c >= 56) return LVX_DEAD;
-    else tg = 6 * k1 + (c - 32);
-    return cm.ord[tg];
-  };
-  const unsigned long long vm = __ballot(valid);
-  // ---- landmark rows: rho x [ref knots | obs knots | camera | rho | gradient (| camera time offset)] of every block, summed in LDS ----
-  if (lm_free) {
-    const double j0 = valid ? J[0][54] : 0.0, j1 = valid ? J[1][54] : 0.0;
-    double* myrow = lmrow + (size_t)(in ? q.lml[si] : 0) * cm.lm_ls;
-    const int p0 = valid ? cm.lm_p0[key.lm] : 0;
-    unsigned long long rem = vm;
-    while (rem) {
+    mycost = wave_sum(mycost);
+    if (lane == 0 && mycost != 0.0) atomicAdd(&cm.cost[rep], mycost);
+#ifdef RF_EVAL_ONLY
+    if (cm.N > 0) continue;
+#endif
+    if (!want_ne) continue;
+    const int my_w0 = valid ? key.k0 >> 2 : -1, my_w1 = valid ? key.k1 >> 2 : -1;
+    const int my_o0 = 6 * (key.k0 & 3), my_o1 = 48 + 6 * (key.k1 & 3);   // first panel column of this block's reference / observation knots
+    const int my_p0 = (valid && lm_free) ? cm.lm_p0[key.lm] : 0;
+    unsigned long long rem = __ballot(valid);
+    while (rem) {                                        // one (reference window, observation window) pair per trip — the group's own; a second trip only for strays
       const int lf = __ffsll((long long)rem) - 1;
-      const int k0 = __builtin_amdgcn_readfirstlane(__shfl(key.k0, lf)), k1 = __builtin_amdgcn_readfirstlane(__shfl(key.k1, lf));
-      const bool inrun = valid && key.k0 == k0 && key.k1 == k1;
-      rem &= ~__ballot(inrun);
-      const int pos = col_pos(lane, k0, k1);
-#pragma unroll
-      for (int c = 0; c < RJ; ++c) {
-        if (c == 54) continue;
-        const int pc = c < 24 ? c : (c < 48 ? 32 + (c - 24) : (c < 54 ? 24 + (c - 48) : 30));   // row column c -> panel column
-        const int p = __builtin_amdgcn_readlane(pos, pc);
-        if (p == LVX_DEAD) continue;                      // wave-uniform
-        if (inrun) {
-          const double v = j0 * J[0][c] + j1 * J[1][c];
-          int slot;
-          if (p >= 0) { slot = p - p0; if (slot < 0 || slot >= cm.lm_wl) { atomicOr(cm.err, 4); slot = -1; } }
-          else slot = cm.lm_wl + (-1 - p);
-          if (slot >= 0 && v != 0.0) atomicAdd(&myrow[slot], v);   // LDS: several blocks of a landmark, and the same variable through both poses of a block
-        }
+      const int w0 = __builtin_amdgcn_readfirstlane(__shfl(my_w0, lf)), w1 = __builtin_amdgcn_readfirstlane(__shfl(my_w1, lf));
+      const unsigned long long wm = __ballot(valid && my_w0 == w0 && my_w1 == w1);
+      rem &= ~wm;
+      for (int c = lane; c < 96; c += 64) {              // band / border position of panel column c for this pair of windows
+        int tg = -1;
+        if (c < 42) { if (4 * w0 + c / 6 < N) tg = 24 * w0 + c; }
+        else if (c < 48) tg = 6 * N + 15 + (c - 42);
+        else if (c < 90) { if (4 * w1 + (c - 48) / 6 < N) tg = 24 * w1 + (c - 48); }
+        else if (c == TCOL && TAU) tg = 6 * N + 21;
+        posL[c] = tg >= 0 ? cm.ord[tg] : LVX_DEAD;
       }
-    }
-    if (valid) { atomicAdd(&myrow[cm.lm_wl + cm.nbd], j0 * j0 + j1 * j1); atomicAdd(&myrow[cm.lm_wl + cm.nbd + 1], j0 * r[0] + j1 * r[1]); }
-  }
-  // ---- [ref | camera | tau | r | obs]^T [same] per frame pair on the matrix cores ----
-  {
-    d4 D[10];
+      d4 D[21];
 #pragma unroll
-    for (int t = 0; t < 10; ++t) D[t] = d4{0.0, 0.0, 0.0, 0.0};
-    int ck0 = -1, ck1 = -1;
-    auto flush = [&]() {   // one atomic per non-zero entry of the pair's upper triangle; the residual column carries the gradient
-      const int pos = col_pos(lane, ck0, ck1);
-      int prow[16], pcol[4];
+      for (int t = 0; t < 21; ++t) D[t] = d4{0.0, 0.0, 0.0, 0.0};
+      unsigned long long todo = wm;
+      while (todo) {                                     // 16 lanes of the pair at a time through the panel
+        const int l0 = __ffsll((long long)todo) - 1;
+        const int ws = min(l0, 48);                      // the panel always maps 16 existing lanes
+        const unsigned long long chunk = todo & (0xffffull << ws);
+        todo &= ~chunk;
+        for (int e = lane; e < 32 * LDP; e += 64) P[e] = 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if ((chunk >> lane) & 1ull) {
 #pragma unroll
-      for (int ci = 0; ci < 4; ++ci)
+          for (int a = 0; a < 2; ++a) {
+            double* prow_ = P + ((lane - ws) * 2 + a) * LDP;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) prow[ci * 4 + v] = __shfl(pos, ci * 16 + (lane >> 4) + 4 * v);
+            for (int c = 0; c < 24; ++c) prow_[my_o0 + c] = J[a][c];
 #pragma unroll
-      for (int cj = 0; cj < 4; ++cj) pcol[cj] = __shfl(pos, cj * 16 + (lane & 15));
-      int t = 0;
+            for (int c = 0; c < 6; ++c) prow_[42 + c] = J[a][48 + c];
 #pragma unroll
-      for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-        for (int cj = ci; cj < 4; ++cj, ++t)
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const double val = D[t][v];
-            D[t][v] = 0.0;
-            const int row = ci * 16 + (lane >> 4) + 4 * v, col = cj * 16 + (lane & 15);
-            if (val == 0.0 || (ci == cj && col < row)) continue;
-            const int pa = prow[ci * 4 + v], pb = pcol[cj];
-            if (row == RCOL) { if (col != RCOL && pb != LVX_DEAD) add_g(cm, pb, val, rep); continue; }
-            if (col == RCOL) { if (pa != LVX_DEAD) add_g(cm, pa, val, rep); continue; }
-            if (pa == LVX_DEAD || pb == LVX_DEAD) continue;
-            add_H(cm, pa, pb, (pa == pb && row != col) ? 2.0 * val : val, rep);   // the same variable through both poses (views closer than 4 knots)
-          }
-    };
-    for (int g0 = 0; g0 < 64; g0 += GL) {
-      const unsigned long long pmask = ((1ull << GL) - 1ull) << g0;
-      unsigned long long rem = vm & pmask;
-      if (!rem) continue;                                 // wave-uniform
-      if (lane >= g0 && lane < g0 + GL) {
-        const int li = lane - g0;
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          double* prow_ = P + (li * 2 + a) * LDP;
-#pragma unroll
-          for (int c = 0; c < 24; ++c) prow_[c] = valid ? J[a][c] : 0.0;
-#pragma unroll
-          for (int c = 0; c < 6; ++c) prow_[24 + c] = valid ? J[a][48 + c] : 0.0;
-          prow_[30] = (TAU && valid) ? J[a][RJ - 1] : 0.0;
-          prow_[RCOL] = valid ? r[a] : 0.0;
-#pragma unroll
-          for (int c = 0; c < 24; ++c) prow_[32 + c] = valid ? J[a][24 + c] : 0.0;
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      while (rem) {                                       // frame pairs inside the panel (wave-uniform control flow)
-        const int lf = __ffsll((long long)rem) - 1;
-        const int k0 = __builtin_amdgcn_readfirstlane(__shfl(key.k0, lf)), k1 = __builtin_amdgcn_readfirstlane(__shfl(key.k1, lf));
-        const unsigned long long wm = __ballot(valid && key.k0 == k0 && key.k1 == k1) & pmask;
-        rem &= ~wm;
-        if (k0 != ck0 || k1 != ck1) { if (ck0 >= 0) flush(); ck0 = k0; ck1 = k1; }
-        const int lhi = 63 - __clzll((long long)wm);
-        const int r_lo = (lf - g0) * 2, r_hi = (lhi - g0 + 1) * 2;
-        const unsigned long long wsh = wm >> g0;
-        const bool contig = __popcll(wm) == lhi - lf + 1;
-        const int nks = (r_hi - r_lo + 3) >> 2;
-        for (int ks = 0; ks < nks; ks += 2) {
-          double f[2][4];
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int rr = r_lo + 4 * (ks + u) + (lane >> 4);
-            bool mine = rr < r_hi;
-            if (!contig) mine = mine && ((wsh >> (rr >> 1)) & 1ull);   // rows of other pairs inside the span contribute zeros
-            const double* src = P + min(rr, PR - 1) * LDP + (lane & 15);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { const double x = src[c * 16]; f[u][c] = mine ? x : 0.0; }
-          }
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            int t = 0;
-#pragma unroll
-            for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-              for (int cj = ci; cj < 4; ++cj, ++t) D[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[u][ci], f[u][cj], D[t], 0, 0, 0);
+            for (int c = 0; c < 24; ++c) prow_[my_o1 + c] = J[a][24 + c];
+            if (TAU) prow_[TCOL] = J[a][RJ - 1];
+            prow_[RCOL] = r[a];
+            prow_[LCOL] = J[a][54];
           }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifndef RF_NO_LM
+        if (lm_free) {   // landmark rows: rho x [ref | camera | obs | tau | r | rho] of the chunk's blocks, (block, column) per lane
+          for (int e0 = 0; e0 < 16 * (LCOL + 1); e0 += 64) {   // (every lane takes every trip: the lane exchange below reads active lanes only)
+            const int e = e0 + lane;
+            const int li = min(e / (LCOL + 1), 15), c = e - li * (LCOL + 1);
+            const int src = ws + li;
+            const int p0 = __shfl(my_p0, src), l = __shfl(key.lm, src);
+            if (e >= 16 * (LCOL + 1) || !((chunk >> src) & 1ull)) continue;
+            const double* ra = P + (2 * li) * LDP;
+            const double v = ra[LCOL] * ra[c] + ra[LDP + LCOL] * ra[LDP + c];
+            if (v == 0.0) continue;
+            int slot;
+            if (c == RCOL) slot = cm.lm_wl + cm.nbd + 1;
+            else if (c == LCOL) slot = cm.lm_wl + cm.nbd;
+            else {
+              const int p = posL[c];
+              if (p == LVX_DEAD) continue;
+              if (p >= 0) { slot = p - p0; if (slot < 0 || slot >= cm.lm_wl) { atomicOr(cm.err, 4); continue; } }
+              else slot = cm.lm_wl + (-1 - p);
+            }
+            atomicAdd(&cm.lmH[(size_t)l * cm.lm_ls + slot], v);
+          }
+        }
+#endif
+        const int lhi = 63 - __clzll((long long)chunk);
+        const int ks0 = (l0 - ws) >> 1, ks1 = (2 * (lhi - ws + 1) + 3) >> 2;   // k-steps (4 panel rows each) that hold rows of the chunk; rows of other lanes are zero
+#ifndef RF_NO_MFMA
+        for (int ks = ks0; ks < ks1; ++ks) {
+          double f[6];
+          const double* src = P + (4 * ks + (lane >> 4)) * LDP + (lane & 15);
+#pragma unroll
+          for (int c = 0; c < 6; ++c) f[c] = src[c * 16];
+          int t = 0;
+#pragma unroll
+          for (int ci = 0; ci < 6; ++ci)
+#pragma unroll
+            for (int cj = ci; cj < 6; ++cj, ++t) D[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[ci], f[cj], D[t], 0, 0, 0);
+        }
+#endif
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                  // the next chunk / the tile dump overwrites these rows
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();                    // the next panel overwrites these rows
-    }
-    if (ck0 >= 0) flush();
-  }
-  if (lm_free) {   // store the landmarks' rows
-    __syncthreads();
-    for (int j = wv; j < nl; j += 4) {
-      double* dst = cm.lmH + (size_t)q.lm_ids[lq0 + j] * cm.lm_ls;
-      const double* src = lmrow + (size_t)j * cm.lm_ls;
-      for (int k = lane; k < cm.lm_ls; k += 64) dst[k] = src[k];
+      // the pair's accumulator tiles -> LDS (11 at a time, tile at P + 256 (t mod 11), row-major 16 x 16) -> one atomic per non-zero entry of the upper triangle;
+      // the residual column is the gradient, the rho column has no position (its products are the landmark rows above)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int t = 11 * h; t < (h ? 21 : 11); ++t)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) P[(t - 11 * h) * 256 + ((lane >> 4) + 4 * v) * 16 + (lane & 15)] = D[t][v];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifndef RF_NO_FLUSH
+        for (int ci = 0, t = 0; ci < 6; ++ci)
+          for (int cj = ci; cj < 6; ++cj, ++t) {
+            if (t / 11 != h) continue;
+            for (int e = lane; e < 256; e += 64) {
+              const int row = ci * 16 + (e >> 4), col = cj * 16 + (e & 15);
+              const double val = P[(t - 11 * h) * 256 + e];
+              if (val == 0.0 || col < row) continue;
+              const int pa = posL[row], pb = posL[col];
+              if (row == RCOL) { if (col != RCOL && pb != LVX_DEAD) add_g(cm, pb, val, rep); continue; }
+              if (col == RCOL) { if (pa != LVX_DEAD) add_g(cm, pa, val, rep); continue; }
+              if (pa == LVX_DEAD || pb == LVX_DEAD) continue;
+              add_H(cm, pa, pb, (pa == pb && row != col) ? 2.0 * val : val, rep);   // the same variable through both poses (views closer than 7 knots)
+            }
+          }
+#endif
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
     }
   }
 }
@@ -2223,6 +2203,35 @@ int ensure_layout(lvx_ctx* ctx) {
         for (auto& m : members) { list.insert(list.end(), m.begin(), m.end()); ctx->det_cross_col.push_back((int)list.size()); }
         if ((rc = upload_tmp(ctx, ctx->d_det_cross, list.data(), list.size() * 4))) return rc;
       }
+      // groups of the single-launch kernel (k_reproj_fused): the same runs of equal (reference window, observation window), up to 64 blocks (a wavefront's lanes),
+      // largest first — wavefront w of the launch takes groups w, w + W, ...: the second round holds the smallest.  OPT-IN (switch REP_FUSED = 1): measured at config 4
+      // it takes 218 us against the chain's ~120 us critical path (the 512-register evaluation pins the whole kernel at one wavefront per SIMD, where its
+      // 6 M scatter atomics retire at ~50 G/s), so the layout never picks it by itself.
+      ctx->rep_fused_wg = 0;
+      if (f.n > 0 && ctx->sw.rep_fused > 0 && !ctx->sw.deterministic) {
+        std::vector<int> gs, gc;
+        long long npairs = 0;
+        int pa0 = -1, pa1 = -1;
+        for (int i = 0; i < f.n; ++i) {
+          if (s1[i] < 0) continue;
+          const int a0 = s0[i] >> 2, a1 = s1[i] >> 2;
+          const bool newpair = gs.empty() || pa0 != a0 || pa1 != a1;
+          if (newpair) ++npairs;
+          if (newpair || i - gs.back() >= 64 || gs.back() + gc.back() != i) { gs.push_back(i); gc.push_back(0); pa0 = a0; pa1 = a1; }
+          gc.back()++;
+        }
+        (void)npairs;
+        if (!gs.empty()) {
+          std::vector<int> order(gs.size());
+          std::iota(order.begin(), order.end(), 0);
+          std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return gc[a] > gc[b]; });
+          std::vector<int> tab;
+          for (int g : order) tab.push_back(gs[g]);
+          for (int g : order) tab.push_back(gc[g]);
+          if ((rc = upload_tmp(ctx, ctx->d_repF, tab.data(), tab.size() * 4))) return rc;
+          ctx->rep_fused_wg = (int)gs.size();
+        }
+      }
       ctx->rep_groups = (int)goff.size();
       goff.push_back(f.n);
       goff.insert(goff.end(), gw0.begin(), gw0.end()); goff.insert(goff.end(), gw1.begin(), gw1.end());
@@ -2329,67 +2338,6 @@ int ensure_layout(lvx_ctx* ctx) {
     }
   }
   ctx->lm_wl = lm_wl; ctx->lm_ls = lm_wl + ctx->nbd_ext + 2;
-  // ---- fused reprojection kernel (k_reproj_fused): workgroups own landmarks; the device row order becomes (workgroup, reference interval, observation interval, landmark) ----
-  ctx->rep_fused_wg = 0; ctx->rep_fused_maxlm = 0;
-  if (ctx->rep.n > 0 && L > 0 && ctx->sw.rep_fused >= 0 && !ctx->sw.deterministic) {
-    Family& f = ctx->rep;
-    const double row_delta = ctx->cam.rows > 0 ? ctx->cam.readout / (double)ctx->cam.rows : 0.0;
-    std::vector<int> lk0(L, -1), cnt(L, 0), k1(f.n);
-    for (int l = 0; l < L; ++l) lk0[l] = host_i0(ctx, ctx->lm_t0[l] + ctx->lm_uv[2 * (size_t)l + 1] * row_delta);
-    int cmax = 0;
-    for (int i = 0; i < f.n; ++i) { const int l = f.id0[i]; cnt[l]++; cmax = std::max(cmax, cnt[l]); k1[i] = host_i0(ctx, f.t[i] + f.a3[2 * (size_t)i + 1] * row_delta); }
-    int ncu = 256;
-    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
-    const int nl_max = (int)std::min<size_t>(4096, (size_t)(150 * 1024 - rep_fused_lds_bytes(0, 0)) / ((size_t)ctx->lm_ls * 8));
-    if (cmax <= 256 && nl_max >= 1) {
-      // landmarks by reference interval (views of one reference frame share their reference columns: long runs); one workgroup per ~n / CUs blocks, one round of the chip
-      std::vector<int> lord(L);
-      std::iota(lord.begin(), lord.end(), 0);
-      std::stable_sort(lord.begin(), lord.end(), [&](int a, int b) { return lk0[a] < lk0[b]; });
-      const int tgt = std::max(32, std::min(256, (f.n + ncu - 1) / ncu));
-      std::vector<int> wg_lm_off{0}, wg_blocks;
-      int blocks = 0, nlm = 0;
-      for (int li = 0; li < L; ++li) {
-        const int c = cnt[lord[li]];
-        if (nlm > 0 && (blocks + c > 256 || blocks >= tgt || nlm >= nl_max)) { wg_lm_off.push_back(li); wg_blocks.push_back(blocks); blocks = 0; nlm = 0; }
-        blocks += c; ++nlm;
-      }
-      wg_lm_off.push_back(L); wg_blocks.push_back(blocks);
-      const int nwg = (int)wg_blocks.size();
-      std::vector<int> wg_of(L), local_of(L);
-      for (int g = 0; g < nwg; ++g) for (int li = wg_lm_off[g]; li < wg_lm_off[g + 1]; ++li) { wg_of[lord[li]] = g; local_of[lord[li]] = li - wg_lm_off[g]; ctx->rep_fused_maxlm = std::max(ctx->rep_fused_maxlm, wg_lm_off[g + 1] - wg_lm_off[g]); }
-      std::vector<int> perm(f.n);
-      std::iota(perm.begin(), perm.end(), 0);
-      std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) {
-        const int la = f.id0[a], lb = f.id0[b];
-        if (wg_of[la] != wg_of[lb]) return wg_of[la] < wg_of[lb];
-        if (lk0[la] != lk0[lb]) return lk0[la] < lk0[lb];
-        if (k1[a] != k1[b]) return k1[a] < k1[b];
-        return la < lb;
-      });
-      long long runs = 0;   // runs of equal (reference interval, observation interval) inside the workgroups: what a wavefront accumulates before it touches HBM
-      for (int i = 0; i < f.n; ++i) {
-        const int a = perm[i], b = i > 0 ? perm[i - 1] : -1;
-        if (i == 0 || wg_of[f.id0[a]] != wg_of[f.id0[b]] || lk0[f.id0[a]] != lk0[f.id0[b]] || k1[a] != k1[b]) ++runs;
-      }
-      if (ctx->sw.rep_fused > 0 || (double)f.n >= 4.0 * (double)runs) {
-        std::vector<int> tab;
-        std::vector<int> wg_off(nwg + 1, 0);
-        for (int g = 0; g < nwg; ++g) wg_off[g + 1] = wg_off[g] + wg_blocks[g];
-        tab.insert(tab.end(), wg_off.begin(), wg_off.end());
-        tab.insert(tab.end(), wg_lm_off.begin(), wg_lm_off.end());
-        tab.insert(tab.end(), lord.begin(), lord.end());
-        for (int i = 0; i < f.n; ++i) tab.push_back(local_of[f.id0[perm[i]]]);
-        if ((rc = upload_tmp(ctx, ctx->d_repF, tab.data(), tab.size() * 4))) return rc;
-        auto ts = gather(f.t, perm, 1); auto uv = gather(f.a3, perm, 2); auto lm = gather(f.id0, perm, 1);
-        if ((rc = upload_tmp(ctx, f.d_t, ts.data(), ts.size() * 8))) return rc;
-        if ((rc = upload_tmp(ctx, f.d_a3, uv.data(), uv.size() * 8))) return rc;
-        if ((rc = upload_tmp(ctx, f.d_id0, lm.data(), lm.size() * 4))) return rc;
-        if ((rc = upload_tmp(ctx, f.d_perm, perm.data(), perm.size() * 4))) return rc;
-        ctx->rep_fused_wg = nwg;
-      }
-    }
-  }
   {   // groups for the landmark elimination: landmarks of one reference frame start at the same band position and reach the same knots, so their rank-1
       // updates are summed per group (<= 32 landmarks whose first positions lie within 24 scalars) before they touch the band (k_lm_schur_grp)
     std::vector<int> order;
@@ -2672,7 +2620,7 @@ int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cos
           b0 = b1;
         }
         add(cm.C, (size_t)ctx->nrep * ctx->nbd_ext * ctx->nbd_ext * 8); add(cm.gc, (size_t)ctx->nrep * ctx->nbd_ext * 8);
-        const bool rep_fast = fast && (ctx->rep_groups > 0 || ctx->rep_fused_wg > 0);   // k_reproj_lmrows / k_reproj_fused store whole rows: nothing to clear
+        const bool rep_fast = fast && ctx->rep_groups > 0 && ctx->rep_fused_wg == 0;   // k_reproj_lmrows stores whole rows: nothing to clear (k_reproj_fused adds to them)
         if (ctx->L > 0 && ctx->rep.n > 0 && !(ctx->locks & LVX_LOCK_LANDMARKS) && !rep_fast) add(cm.lmH, (size_t)ctx->L * ctx->lm_ls * 8);
       }
       size_t total = 0; for (int i = 0; i < cl.n; ++i) total += cl.words[i];
@@ -2817,12 +2765,12 @@ int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cos
         constexpr bool T = decltype(TAUC)::value;
         const ReprojFamT<T> rf{r.n, r.lm, r.uv, r.t0o, r.perm, r.lm_uv, r.lm_t0, r.weight, r.huber};
         const int* tab = (const int*)ctx->d_repF.p;
-        const int nwg = ctx->rep_fused_wg;
-        const RepFused q{tab, tab + nwg + 1, tab + 2 * (nwg + 1), tab + 2 * (nwg + 1) + ctx->L};
-        const size_t lds = rep_fused_lds_bytes((what & LVX_EVAL_NORMAL_EQ) && !(ctx->locks & LVX_LOCK_LANDMARKS) ? ctx->rep_fused_maxlm : 0, ctx->lm_ls);
-        LVX_HIP(ctx, hipFuncSetAttribute((const void*)k_reproj_fused<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int ng = ctx->rep_fused_wg;
+        const RepFused q{tab, tab + ng, ng};
+        int ncu = 256;
+        { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
         ProfScope ps(ctx, LVX_KERNEL_REP_FUSED, st);
-        hipLaunchKernelGGL(k_reproj_fused<T>, dim3((unsigned)nwg), dim3(256), lds, st, rf, q, cm, (long long)ctx->fam_row0[4]);
+        hipLaunchKernelGGL(k_reproj_fused<T>, dim3((unsigned)std::min((ng + 3) / 4, ncu)), dim3(256), 0, st, rf, q, cm, (long long)ctx->fam_row0[4]);
         return LVX_OK;
       };
       if (fast && ctx->rep_fused_wg > 0) {

@@ -1,6 +1,6 @@
-"""GPU parity of BOTH reprojection paths against the oracle: the single-launch kernel (k_reproj_fused, round 6: landmark-owning workgroups, rows never leave the
-chip) and the five-launch chain it replaces where frame pairs repeat (k_reproj_jac -> side passes -> cross terms -> landmark rows).  The layout picks one from the
-track structure; here each is FORCED (switch REP_FUSED = 1 / -1) on the same problems, and the launch counters prove which one ran.
+"""GPU parity of BOTH reprojection paths against the oracle: the single-launch kernel (k_reproj_fused, round 6: a wavefront per (reference window, observation window)
+group, rows never leave the chip; opt-in, measured slower) and the five-launch chain (k_reproj_jac -> side passes -> cross terms -> landmark rows).  Each is FORCED
+(switch REP_FUSED = 1 / -1) on the same problems, and the launch counters prove which one ran.
 Semantics: kontiki/measurements/static_rscamera_measurement.h:20-60,135-203; tolerances as tests/test_gpu_eval.py."""
 import numpy as np
 import pytest
@@ -30,7 +30,7 @@ def _blockscaled(Hg, Ho, tol=1e-9):
     assert not bad.any(), "worst entry-scaled error %.3e" % (np.abs(Hg - Ho)[bad] / np.maximum(scale[bad], 1e-300)).max()
 
 
-def _check(o, g, state, mode, res_floor=0.0):
+def _check(o, g, state, mode, res_floor=100.0):   # a reprojection residual is the difference of two pixel coordinates of order 1e3: 1e-9 px is their rounding floor
     ro = o.evaluate(state, normal_eq=True)
     g.set_profiling(True); g.kernel_ms()
     rg = g.evaluate(state, normal_eq=True)
@@ -74,17 +74,16 @@ def test_bench_tracks_both_paths(tracks, mode):
     g.close()
 
 
-def test_layout_picks_the_fused_kernel_for_covisible_tracks_and_the_chain_for_sparse_ones():
-    for tracks, want_fused in (("orb", True), ("sparse", False)):
-        P = synth.make_bench_problem(seed=11, n_imu=1200, n_surfel=600, n_reproj=1500, n_planes=10, tracks=tracks, obs_per_frame=40)
-        g = lvx.Context(0)
-        lvx.load_problem(g, P, TAU_LOCKS)
-        g.set_profiling(True); g.kernel_ms()
-        g.evaluate(P["state0"], normal_eq=True)
-        _, launches = g.kernel_ms()
-        assert (launches[lvx.KERNEL_REP_FUSED] == 1) == want_fused
-        assert (launches[lvx.KERNEL_REP_JAC] == 1) == (not want_fused)
-        g.close()
+def test_default_is_the_chain():
+    """The single-launch kernel is opt-in (measured slower at config 4: DESIGN.md 3.1): without the switch the five-launch chain runs."""
+    P = synth.make_bench_problem(seed=11, n_imu=1200, n_surfel=600, n_reproj=1500, n_planes=10, tracks="orb", obs_per_frame=40)
+    g = lvx.Context(0)
+    lvx.load_problem(g, P, TAU_LOCKS)
+    g.set_profiling(True); g.kernel_ms()
+    g.evaluate(P["state0"], normal_eq=True)
+    _, launches = g.kernel_ms()
+    assert launches[lvx.KERNEL_REP_FUSED] == 0 and launches[lvx.KERNEL_REP_JAC] == 1
+    g.close()
 
 
 @pytest.mark.parametrize("mode", [1, -1])
