@@ -424,6 +424,19 @@ typedef struct lvx_assoc_options {
 int lvx_assoc_default_options(lvx_assoc_options* opt);
 int lvx_set_scans(lvx_ctx* ctx, int n_scans, int H, int W, const lvx_point_xyzit* raw);
 int lvx_data_association(lvx_ctx* ctx, const double* state, double map_time, const lvx_assoc_options* opt, int32_t* n_planes, int32_t* n_points);
+/* The FIRST DataAssociation of a calibration — the InitializationDone branch (lvi_initialize_surfel_orb.cpp:1175-1178), where the map comes from per-scan odometry poses
+ * (LOAM's, ReadPoseGT :458-516) and only the SO3 spline of Solve #0 exists:
+ *   Mapping() (:1262-1300) = ScanUndistortion::undistortScan() (scan_undistortion.h:40-57: rotation-only de-skew of every scan into its own start frame, scans whose stamp
+ *     lies outside the spline are dropped) + LiDAROdometry::feedScan(scan_t, scan, pose, update_map = true, using_loam = true) per scan (lidar_odometry.cpp:45-74);
+ *     updateKeyScan / checkKeyScan (:89-128): the first scan, or one > key_dist [m] from the last key scan or turned by > key_angle_deg in yaw / pitch / roll, is moved with
+ *     its pose and appended to the key-scan map = the NDT target (reference: 0.2 m, 5 deg);
+ *   undistortScanInMap(odom_data_map) (scan_undistortion.h:95-116): every de-skewed scan moved with its pose = the scans in the map frame;
+ *   setSurfelMap(lidar_odom->getNDTPtr(), map_time) on the voxel grid of the KEY-SCAN map with opt->plane_lambda (the constructor's 0.6, :127,240); getAssociation per scan.
+ * scan_t[n_scans]: the scans' header stamps; pose16[n_scans][16]: row-major 4 x 4 scan -> map (LiDAROdometry::OdomData::pose); has_pose (may be NULL = all): 0 = no
+ * odometry pose for that stamp (loam_poses_map_.find fails: the scan is skipped).  key_scan (may be NULL): out, 1 where the scan joined the key-scan map.
+ * Results as lvx_data_association: lvx_get_surfel_map / lvx_get_surfel_points / lvx_get_scans_in_map (absent scans: NaN). */
+int lvx_data_association_poses(lvx_ctx* ctx, const double* state, const double* scan_t, const double* pose16, const int32_t* has_pose, double key_dist, double key_angle_deg,
+                               const lvx_assoc_options* opt, int32_t* n_planes, int32_t* n_points, int32_t* key_scan);
 int lvx_get_surfel_map(lvx_ctx* ctx, int max_planes, lvx_surfel_plane* planes);
 /* rounds that took the one-stop chain since the context was created, and how many of those had to be repeated on the four-stop chain */
 int lvx_data_association_stats(lvx_ctx* ctx, int64_t* one_stop_rounds, int64_t* repeated_rounds);

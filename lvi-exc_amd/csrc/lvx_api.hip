@@ -85,6 +85,7 @@ void lvx_destroy(lvx_ctx* c) {
   for (auto& b : c->d_up) if (b.p) (void)hipFree(b.p);
   for (auto& b : c->d_assoc) if (b.p) (void)hipFree(b.p);
   for (auto& b : c->d_da) if (b.p) (void)hipFree(b.p);
+  for (DevBuf* b : {&c->d_da_key, &c->d_da_aux}) if (b->p) (void)hipFree(b->p);
   for (auto& b : c->d_chunk) if (b.p) (void)hipFree(b.p);
   for (auto& b : c->d_repB) if (b.p) (void)hipFree(b.p);
   if (c->d_hubs.p) (void)hipFree(c->d_hubs.p);

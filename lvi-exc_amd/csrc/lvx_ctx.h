@@ -141,6 +141,7 @@ struct lvx_ctx {
   lvx::DevBuf d_assoc[4];   // surfel association: grid geometry + cell counts / offsets, cell lists, emission counters, hit bitmasks + counts (private: cleared once per shape)
   // device-resident DataAssociation (lvx_set_scans / lvx_data_association): [0] raw scans, [1] state, [2] map time, [3] map pose, [4] scans in the map frame = map cloud,
   // [5] plane table, [6] flags, [7] SurfelPoint arrays
+  lvx::DevBuf d_da_key, d_da_aux;   // lvx_data_association_poses (first map): the key-scan map cloud; per-scan [time | q | p | valid | present | pose16 | key list]
   lvx::DevBuf d_da[8]; int da_S = 0, da_H = 0, da_W = 0, da_points = 0; std::vector<lvx_surfel_plane> da_planes;
   // lvx_data_association without host stops (round 5): capacities learned from the previous call (leaves, planes, association-grid list entries; 0 = none yet, the call
   // runs the synchronous path), the pinned mirror the device writes its counts into, the planes still to fetch from d_da[5] when somebody asks for them

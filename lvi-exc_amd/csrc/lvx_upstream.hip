@@ -1857,6 +1857,35 @@ __global__ void k_undistort(const double* state, int N, double t0, double dt, in
   out[i] = o;
 }
 
+// First map of a calibration (LIinitializer::Mapping + undistortScanInMap(odom_data_map), lvi_initialize_surfel_orb.cpp:1262-1300, scan_undistortion.h:40-57,95-116):
+// every point is de-skewed ROTATION-ONLY into its scan's own start frame with the SO3 spline (undistort(..., correct_position = false): q_G_to_target = the LiDAR
+// orientation at the scan's stamp, conjugated) — rounded to float, the VPoint of scan_data_ — and then moved with the scan's odometry pose as pcl::transformPointCloud does
+// with a Matrix4d (double arithmetic on the float coordinates, rounded to float; non-finite points stay as they are).  Scans without a pose or whose stamp lies outside
+// the spline are absent from scan_data_in_map_: their points become NaN here (no association, no map point).
+__global__ void k_deskew_pose(const double* state, int N, double t0, double dt, int HW, int n, const PointXYZIT* raw, const double* q_scan, const int* present, const double* pose16, float4* out, int* flags_init) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  flags_init[i] = -1;
+  const int s = i / HW;
+  const PointXYZIT r = raw[i];
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!present[s] || isnan(r.x)) { o.x = o.y = o.z = NAN; out[i] = o; return; }
+  quat q; v3 p;
+  if (lidar_pose_dev(state, N, t0, dt, r.timestamp, &q, &p)) {   // (a point whose own stamp lies outside the spline keeps the resize()'d zeros, as in the reference)
+    const quat qGt = quat{-q_scan[4 * s], -q_scan[4 * s + 1], -q_scan[4 * s + 2], q_scan[4 * s + 3]};
+    const v3 po = qrot(qmul(qGt, q), mk((double)r.x, (double)r.y, (double)r.z));
+    o = make_float4((float)po.x, (float)po.y, (float)po.z, r.intensity);
+  }
+  const double* T = pose16 + 16 * (size_t)s;
+  const double x = (double)o.x, y = (double)o.y, z = (double)o.z;
+  out[i] = make_float4((float)(T[0] * x + T[1] * y + T[2] * z + T[3]), (float)(T[4] * x + T[5] * y + T[6] * z + T[7]), (float)(T[8] * x + T[9] * y + T[10] * z + T[11]), o.w);
+}
+// the key-scan map (LiDAROdometry::updateKeyScan: *map_cloud_ += scan_in_target): scans key[0], key[1], ... of the scans in the map frame, concatenated
+__global__ void k_gather_scans(const float4* scans, const int* key, int HW, int n, float4* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = scans[(size_t)key[i / HW] * HW + i % HW];
+}
+
 }  // namespace lvx
 
 using namespace lvx;
@@ -2622,6 +2651,41 @@ static int da_speculative(lvx_ctx* c, const lvx_assoc_options& o, int S, int H, 
   if (n_points) *n_points = c->da_points;
   return LVX_OK;
 }
+// steps 2-4 of a DataAssociation round, four host stops: voxel grid of the MAP cloud (the scans in the map frame for a refinement round, the key-scan map for the first
+// one), surfel map, association of every scan in d_da[4], SurfelPoint emission.  dv: device flag of the map pose (null: nothing to check)
+static int da_sync_chain(lvx_ctx* c, const lvx_assoc_options& o, const float4* map_pts, size_t map_n, int S, int H, int W, size_t npt, const int* dv, int32_t* n_planes, int32_t* n_points) {
+  int rc;
+  hipStream_t st = c->stream; (void)st;
+  // 2. LiDAROdometry::ndtInit(resolution) + setInputTarget(map_cloud): the voxel covariance grid of the map cloud
+  if ((rc = voxel_build_device(c, map_pts, (int)map_n, o.ndt_resolution, o.min_points_per_voxel, o.min_covar_eigvalue_mult))) return rc;
+  // 3. SurfelAssociation::setSurfelMap
+  std::vector<SurfelPlaneDev> acc;
+  lvx_surfel_map_release(c);
+  if ((rc = surfel_extract_device(c, o.plane_lambda, o.fit_threshold, o.min_leaf_points, o.min_inliers, acc, c->d_da[5]))) return rc;   // records + the association's plane table stay in d_da[5]
+  if (dv) { int hv = 0; LVX_HIP(c, hipMemcpy(&hv, dv, 4, hipMemcpyDeviceToHost)); if (!hv) return fail(c, LVX_E_RANGE, "map time outside the trajectory"); }   // (the stream has been waited for above)
+  const int P = (int)acc.size();
+  c->da_planes.resize((size_t)P);
+  if (P > 0) std::memcpy(c->da_planes.data(), acc.data(), (size_t)P * sizeof(SurfelPlaneDev));
+  if (n_planes) *n_planes = P;
+  c->da_cap_nl = da_capacity(c->da_cap_nl, c->vox.n_leaves, 1024); c->da_cap_P = da_capacity(c->da_cap_P, P, 128);
+  if (P == 0) return LVX_OK;
+  const double* planes_d = (const double*)((const char*)c->d_da[5].p + (((size_t)P * sizeof(SurfelPlaneDev) + 15) & ~(size_t)15));
+  // 4. getAssociation for every scan: flags (one surfel grid for all scans), then the chronological SurfelPoint lists, scans concatenated
+  if ((rc = dev_alloc(c, c->d_da[6], npt * 4))) return rc;
+  if (S > 2 && (rc = lvx_surfel_map_prepare_d(c, P, planes_d))) return rc;
+  if (S > 2) c->da_cap_list = da_capacity(c->da_cap_list, c->assoc_list_total, 4096);
+  rc = lvx_surfel_assoc_batch_d(c, S, H, W, (const float*)c->d_da[4].p, P, planes_d, o.radius, o.selected_per_ring, (int32_t*)c->d_da[6].p);
+  lvx_surfel_map_release(c);
+  if (rc) return rc;
+  // outputs strided by the CAPACITY (every scan point could be a SurfelPoint): count + write in one call, one host synchronisation
+  int32_t total = 0;
+  if ((rc = dev_alloc(c, c->d_da[7], npt * (24 + 24 + 8 + 4) + 64))) return rc;
+  { double* d_pt = (double*)c->d_da[7].p; double* d_pm = d_pt + 3 * npt; double* d_t = d_pm + 3 * npt; int32_t* d_pl = (int32_t*)(d_t + npt);
+    if ((rc = lvx_surfel_emit_d(c, S, H, W, (const int32_t*)c->d_da[6].p, (const float*)c->d_da[4].p, (const lvx_point_xyzit*)c->d_da[0].p, (int)npt, d_pt, d_pm, d_t, d_pl, &total, nullptr))) return rc; }
+  c->da_points = total;
+  if (n_points) *n_points = total;
+  return LVX_OK;
+}
 int lvx_data_association(lvx_ctx* c, const double* state, double map_time, const lvx_assoc_options* opt_in, int32_t* n_planes, int32_t* n_points) {
   if (!c || !state) return LVX_E_ARG;
   if (!c->have_spline) return fail(c, LVX_E_STATE, "lvx_set_spline has not been called");
@@ -2658,35 +2722,86 @@ int lvx_data_association(lvx_ctx* c, const double* state, double map_time, const
     c->da_spec_misses++;
     c->da_planes.clear(); c->da_points = 0; c->da_planes_pending = 0;
   }
-  // 2. LiDAROdometry::ndtInit(resolution) + setInputTarget(map_cloud): the voxel covariance grid of the map cloud
-  if ((rc = voxel_build_device(c, (const float4*)c->d_da[4].p, (int)npt, o.ndt_resolution, o.min_points_per_voxel, o.min_covar_eigvalue_mult))) return rc;
-  // 3. SurfelAssociation::setSurfelMap
-  std::vector<SurfelPlaneDev> acc;
-  lvx_surfel_map_release(c);
-  if ((rc = surfel_extract_device(c, o.plane_lambda, o.fit_threshold, o.min_leaf_points, o.min_inliers, acc, c->d_da[5]))) return rc;   // records + the association's plane table stay in d_da[5]
-  { int hv = 0; LVX_HIP(c, hipMemcpy(&hv, dv, 4, hipMemcpyDeviceToHost)); if (!hv) return fail(c, LVX_E_RANGE, "map time outside the trajectory"); }   // (the stream has been waited for above)
-  const int P = (int)acc.size();
-  c->da_planes.resize((size_t)P);
-  if (P > 0) std::memcpy(c->da_planes.data(), acc.data(), (size_t)P * sizeof(SurfelPlaneDev));
-  if (n_planes) *n_planes = P;
-  c->da_cap_nl = da_capacity(c->da_cap_nl, c->vox.n_leaves, 1024); c->da_cap_P = da_capacity(c->da_cap_P, P, 128);
-  if (P == 0) return LVX_OK;
-  const double* planes_d = (const double*)((const char*)c->d_da[5].p + (((size_t)P * sizeof(SurfelPlaneDev) + 15) & ~(size_t)15));
-  // 4. getAssociation for every scan: flags (one surfel grid for all scans), then the chronological SurfelPoint lists, scans concatenated
+  return da_sync_chain(c, o, (const float4*)c->d_da[4].p, npt, S, H, W, npt, dv, n_planes, n_points);
+}
+// The FIRST DataAssociation of a calibration: the map comes from per-scan odometry poses (LOAM's: ReadPoseGT, lvi_initialize_surfel_orb.cpp:458-516), not from the spline —
+// the InitializationDone branch (:1175-1178): Mapping() (:1262-1300) = undistortScan() + LiDAROdometry::feedScan(t, scan, pose, update_map, using_loam = true) per scan
+// (src/core/lidar_odometry.cpp:45-74: the pose is taken as given; updateKeyScan / checkKeyScan :89-128: a key scan is the first one, or one further than key_dist from the
+// last key scan, or turned by more than key_angle_deg in yaw, pitch or roll — it joins the key-scan map, the NDT target), undistortScanInMap(odom_data_map)
+// (scan_undistortion.h:95-116), setSurfelMap(lidar_odom->getNDTPtr(), map_time) over the voxel grid of the KEY-SCAN map, getAssociation of every scan.
+static void r2ypr_deg(const double* T, double ypr[3]) {   // mathutils::R2ypr (include/utils/math_utils.h:192-207), T row-major 4 x 4
+  const double n0 = T[0], n1 = T[4], n2 = T[8], o0 = T[1], o1 = T[5], a0 = T[2], a1 = T[6];
+  const double y = std::atan2(n1, n0);
+  const double p = std::atan2(-n2, n0 * std::cos(y) + n1 * std::sin(y));
+  const double r = std::atan2(a0 * std::sin(y) - a1 * std::cos(y), -o0 * std::sin(y) + o1 * std::cos(y));
+  ypr[0] = y / M_PI * 180.0; ypr[1] = p / M_PI * 180.0; ypr[2] = r / M_PI * 180.0;
+}
+int lvx_data_association_poses(lvx_ctx* c, const double* state, const double* scan_t, const double* pose16, const int32_t* has_pose, double key_dist, double key_angle_deg,
+                               const lvx_assoc_options* opt_in, int32_t* n_planes, int32_t* n_points, int32_t* key_scan) {
+  if (!c || !state || !scan_t || !pose16) return LVX_E_ARG;
+  if (!c->have_spline) return fail(c, LVX_E_STATE, "lvx_set_spline has not been called");
+  if (c->da_S <= 0 || (size_t)c->da_H * c->da_W == 0) return fail(c, LVX_E_STATE, "lvx_set_scans has not been called");
+  lvx_assoc_options o; lvx_assoc_default_options(&o); if (opt_in) o = *opt_in;
+  LVX_HIP(c, hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const int S = c->da_S, H = c->da_H, W = c->da_W, HW = H * W;
+  const size_t npt = (size_t)S * HW;
+  if (npt > 2147483647ull) return fail(c, LVX_E_ARG, "too many scan points for one map cloud");
+  int rc;
+  ProfScope ps(c, LVX_KERNEL_UPSTREAM);
+  c->da_planes.clear(); c->da_points = 0; c->da_planes_pending = 0;
+  if (n_planes) *n_planes = 0;
+  if (n_points) *n_points = 0;
+  // per-scan block on the device: [t S | q 4S | p 3S | pose 16S] doubles, then [valid S | present S | key S] ints
+  const size_t nd = (size_t)S * (1 + 4 + 3 + 16);
+  if ((rc = dev_alloc(c, c->d_da_aux, nd * 8 + (size_t)S * 12 + 64))) return rc;
+  double* d_t = (double*)c->d_da_aux.p; double* d_q = d_t + S; double* d_p = d_q + 4 * (size_t)S; double* d_pose = d_p + 3 * (size_t)S;
+  int* d_valid = (int*)(d_pose + 16 * (size_t)S); int* d_present = d_valid + S; int* d_key = d_present + S;
+  if ((rc = upload(c, c->d_da[1], state, (size_t)lvx_state_size(c) * 8))) return rc;
+  LVX_HIP(c, hipMemcpyAsync(d_t, scan_t, (size_t)S * 8, hipMemcpyHostToDevice, st));
+  LVX_HIP(c, hipMemcpyAsync(d_pose, pose16, (size_t)S * 128, hipMemcpyHostToDevice, st));
+  // ScanUndistortion::undistortScan: the target frame of scan s is the LiDAR orientation at its stamp; a stamp outside the spline drops the scan ("pass")
+  hipLaunchKernelGGL(k_lidar_pose, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, (const double*)c->d_da[1].p, c->N, c->t0, c->dt, S, (const double*)d_t, d_q, d_p, d_valid);
+  std::vector<int> present((size_t)S), key;
+  LVX_HIP(c, hipMemcpyAsync(present.data(), d_valid, (size_t)S * 4, hipMemcpyDeviceToHost, st));
+  LVX_HIP(c, hipStreamSynchronize(st));
+  // Mapping(): scans in order; feedScan needs the scan's pose (loam_poses_map_.find(stamp)); checkKeyScan against the LAST KEY scan
+  double pos_last[3] = {0, 0, 0}, ypr_last[3] = {0, 0, 0};
+  for (int s = 0; s < S; ++s) {
+    present[s] = (present[s] && (!has_pose || has_pose[s])) ? 1 : 0;
+    if (key_scan) key_scan[s] = 0;
+    if (!present[s]) continue;
+    const double* T = pose16 + 16 * (size_t)s;
+    const double dx = T[3] - pos_last[0], dy = T[7] - pos_last[1], dz = T[11] - pos_last[2];
+    const double dist = std::sqrt(dx * dx + dy * dy + dz * dz);
+    double ypr[3]; r2ypr_deg(T, ypr);
+    bool turned = false;
+    for (int a = 0; a < 3; ++a) {
+      double d = ypr[a] - ypr_last[a];
+      if (d > 180) d -= 360;           // LiDAROdometry::normalize_angle (include/core/lidar_odometry.h:95-102)
+      if (d < -180) d += 360;
+      if (std::fabs(d) > key_angle_deg) turned = true;
+    }
+    if (key.empty() || dist > key_dist || turned) {
+      pos_last[0] = T[3]; pos_last[1] = T[7]; pos_last[2] = T[11]; ypr_last[0] = ypr[0]; ypr_last[1] = ypr[1]; ypr_last[2] = ypr[2];
+      key.push_back(s);
+      if (key_scan) key_scan[s] = 1;
+    }
+  }
+  if (key.empty()) return LVX_OK;   // no scan with a pose inside the spline: an empty map
+  LVX_HIP(c, hipMemcpyAsync(d_present, present.data(), (size_t)S * 4, hipMemcpyHostToDevice, st));
+  LVX_HIP(c, hipMemcpyAsync(d_key, key.data(), key.size() * 4, hipMemcpyHostToDevice, st));
+  if ((rc = dev_alloc(c, c->d_da[4], npt * 16))) return rc;
   if ((rc = dev_alloc(c, c->d_da[6], npt * 4))) return rc;
-  if (S > 2 && (rc = lvx_surfel_map_prepare_d(c, P, planes_d))) return rc;
-  if (S > 2) c->da_cap_list = da_capacity(c->da_cap_list, c->assoc_list_total, 4096);
-  rc = lvx_surfel_assoc_batch_d(c, S, H, W, (const float*)c->d_da[4].p, P, planes_d, o.radius, o.selected_per_ring, (int32_t*)c->d_da[6].p);
+  hipLaunchKernelGGL(k_deskew_pose, dim3((unsigned)((npt + 255) / 256)), dim3(256), 0, st, (const double*)c->d_da[1].p, c->N, c->t0, c->dt, HW, (int)npt, (const PointXYZIT*)c->d_da[0].p,
+                     (const double*)d_q, (const int*)d_present, (const double*)d_pose, (float4*)c->d_da[4].p, (int*)c->d_da[6].p);
+  const size_t nmap = key.size() * (size_t)HW;
+  if ((rc = dev_alloc(c, c->d_da_key, nmap * 16))) return rc;
+  hipLaunchKernelGGL(k_gather_scans, dim3((unsigned)((nmap + 255) / 256)), dim3(256), 0, st, (const float4*)c->d_da[4].p, (const int*)d_key, HW, (int)nmap, (float4*)c->d_da_key.p);
+  LVX_HIP(c, hipGetLastError());
+  LVX_HIP(c, hipStreamSynchronize(st));   // (the host vectors above go out of scope)
   lvx_surfel_map_release(c);
-  if (rc) return rc;
-  // outputs strided by the CAPACITY (every scan point could be a SurfelPoint): count + write in one call, one host synchronisation
-  int32_t total = 0;
-  if ((rc = dev_alloc(c, c->d_da[7], npt * (24 + 24 + 8 + 4) + 64))) return rc;
-  { double* d_pt = (double*)c->d_da[7].p; double* d_pm = d_pt + 3 * npt; double* d_t = d_pm + 3 * npt; int32_t* d_pl = (int32_t*)(d_t + npt);
-    if ((rc = lvx_surfel_emit_d(c, S, H, W, (const int32_t*)c->d_da[6].p, (const float*)c->d_da[4].p, (const lvx_point_xyzit*)c->d_da[0].p, (int)npt, d_pt, d_pm, d_t, d_pl, &total, nullptr))) return rc; }
-  c->da_points = total;
-  if (n_points) *n_points = total;
-  return LVX_OK;
+  return da_sync_chain(c, o, (const float4*)c->d_da_key.p, nmap, S, H, W, npt, nullptr, n_planes, n_points);
 }
 int lvx_data_association_stats(lvx_ctx* c, int64_t* one_stop_rounds, int64_t* repeated_rounds) {
   if (!c) return LVX_E_ARG;

@@ -9,8 +9,10 @@
 //     camera refinement     -> associateVisualPointsWithPlanes + trajInitFromLVIdata(frames, surfels, lm_splane)  (:197-257)     Solve #3
 // DataAssociation is ONE device-resident call (lvx_data_association: de-skew of every scan into the map frame, voxel grid of the map cloud, surfel
 // extraction, association of every scan, chronological SurfelPoint emission); the raw scans are handed to the context once (lvx_set_scans).
-// Not mirrored: the first map (LiDAROdometry / NDT registration of the InitializationDone branch, :1176-1179) — the driver starts from a state whose
-// trajectory is good enough to de-skew (e.g. LOAM poses fitted into the spline, as the reference's TrajectoryManagerLVI::feedLoamPose path does).
+// The FIRST DataAssociation (InitializationDone branch, :1175-1178) takes its map from per-scan odometry poses — LOAM's, ReadPoseGT (lvx_loaders.hpp) — exactly as the
+// reference with using_loam: CalibrateInput::loam + scan_stamps select it (lvx_data_association_poses: rotation-only de-skew with the SO3 spline of Solve #0, key-scan
+// map, surfel map, association), so a recorded dataset starts from the reference's initial state (identity rotations, zero positions) with nothing hand-fitted.
+// Not mirrored: LiDAROdometry's own NDT scan-to-map registration (using_loam = false; lvx_ndt_align is its align()).
 #pragma once
 #include <array>
 #include <cmath>
@@ -32,6 +34,9 @@ struct CalibrateInput {
   int H = 0, W = 0;                                                // organised scans
   std::vector<std::vector<lvx_point_xyzit>> scans;                 // raw LiDAR scans, [H * W] each (row-major h * W + w), per-point timestamps
   double map_time = 0;
+  // first map from odometry poses (optional): the scans' header stamps and the LOAM pose file (ReadPoseGT); simulation = the reference's flag: a scan takes the pose with
+  // EXACTLY its stamp (loam_poses_map_.find, :1283-1290) instead of the nearest of the poses idx - 5 .. idx + 4 (findAssociatedPose, :1246-1260)
+  std::vector<double> scan_stamps; LoamPoses loam; bool simulation = true;
   // ORB results (lvx_loaders.hpp: LoadOrbResults): landmark table + observations
   std::vector<double> lm_uv, lm_t0; std::vector<int32_t> obs_landmark; std::vector<double> obs_uv, obs_t0;
 };
@@ -42,6 +47,7 @@ struct CalibrateOptions {
   bool camera_surfel_stage = false;      // the third stage with camera-landmark-to-surfel blocks
   float ndt_resolution = 0.5f;           // lvi.yaml:26
   double plane_lambda = 0.7, fit_threshold = 0.05; int min_leaf_points = 10, min_inliers = 20;
+  double first_map_plane_lambda = 0.6, key_scan_dist = 0.2, key_scan_angle_deg = 5.0;   // plane_lambda_ of the constructor (:127); checkKeyScan (lidar_odometry.cpp:121-122)
   double associated_radius = 0.05; int selected_per_ring = 2, downsample_step = 10;
   double w_gyro = 28, w_acc = 18, w_surfel = 10, w_cam = 5, w_cam_surfel = 30;   // SetCalibWeights (lvi_initialize_surfel_orb.cpp:904-928)
   bool opt_time_offset = false;
@@ -82,6 +88,7 @@ class Calibrator {
     std::vector<StageReport> rep;
     if (opt_.solve0_so3_from_gyro) rep.push_back(Solve0(state));
     for (int it = 0; it < opt_.refine_iterations; ++it) {
+      if (it == 0 && !in_.loam.all.empty()) FirstDataAssociation(*state); else
       DataAssociation(*state);
       rep.push_back(SolveSurfel(state, it == 0 ? "BatchOptimization" : "Refinement"));
     }
@@ -91,6 +98,7 @@ class Calibrator {
   }
   const std::vector<lvx_surfel_plane>& planes() const { return planes_; }
   const std::vector<AssociationRecord>& associations() const { return assoc_history_; }
+  const std::vector<int32_t>& key_scans() const { return key_scans_; }   // of the first-map association: 1 where the scan joined the key-scan map
   lvx_ctx* context() { return ctx_; }
 
  private:
@@ -106,13 +114,58 @@ class Calibrator {
     check(lvx_set_orientation_prior(ctx_, 0, in_.t0, q0, opt_.w_gyro));
     return r;
   }
+  // the pose Mapping() feeds with scan idx (lvi_initialize_surfel_orb.cpp:1283-1295): simulation — the pose with exactly the scan's stamp; otherwise the nearest in time of
+  // loam_poses_[idx - 5 .. idx + 4] (the last pose is never looked at: `idx >= size - 1`, :1252), used even when it is further than 0.02 s away (`ok` is not looked at)
+  bool pose_of_scan(int idx, double scan_t, double T[16]) const {
+    const PoseStamped* hit = nullptr;
+    if (in_.simulation) {
+      const int64_t stamp = (int64_t)(scan_t * 1e9);
+      for (const PoseStamped& ps : in_.loam.all) if (ps.stamp_ns == stamp) hit = &ps;   // (std::map::operator[]: the last pose with that stamp wins)
+    } else {
+      double best = 1.7976931348623157e308;
+      for (int i = -5; i < 5; ++i) {
+        const long long k = (long long)i + idx;
+        if (k < 0 || k >= (long long)in_.loam.all.size() - 1) continue;
+        const double d = std::fabs((double)in_.loam.all[(size_t)k].stamp_ns * 1e-9 - scan_t);
+        if (d < best) { best = d; hit = &in_.loam.all[(size_t)k]; }
+      }
+    }
+    if (!hit) return false;
+    // Eigen::Quaterniond(w, x, y, z).toRotationMatrix() of the file's (unnormalised) quaternion
+    const double w = hit->q_wxyz[0], x = hit->q_wxyz[1], y = hit->q_wxyz[2], z = hit->q_wxyz[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    const double R[9] = {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy)};
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T[4 * r + c] = R[3 * r + c]; T[4 * r + 3] = hit->p[r]; }
+    T[12] = T[13] = T[14] = 0; T[15] = 1;
+    return true;
+  }
+  lvx_assoc_options assoc_options(double plane_lambda) const {
+    lvx_assoc_options ao; lvx_assoc_default_options(&ao);
+    ao.ndt_resolution = opt_.ndt_resolution; ao.plane_lambda = plane_lambda; ao.fit_threshold = opt_.fit_threshold; ao.min_leaf_points = opt_.min_leaf_points;
+    ao.min_inliers = opt_.min_inliers; ao.radius = opt_.associated_radius; ao.selected_per_ring = opt_.selected_per_ring;
+    return ao;
+  }
+  // DataAssociation of the InitializationDone branch (lvi_initialize_surfel_orb.cpp:1175-1178): Mapping() with the LOAM poses, undistortScanInMap(odom_data_map), setSurfelMap
+  // on the key-scan map's NDT grid, getAssociation per scan
+  void FirstDataAssociation(const std::vector<double>& state) {
+    const size_t S = in_.scans.size();
+    if (in_.scan_stamps.size() != S) throw std::invalid_argument("scan_stamps: one header stamp per scan is needed for the first map");
+    std::vector<double> poses(S * 16, 0.0); std::vector<int32_t> has(S, 0);
+    for (size_t s = 0; s < S; ++s) has[s] = pose_of_scan((int)s, in_.scan_stamps[s], &poses[16 * s]) ? 1 : 0;
+    const lvx_assoc_options ao = assoc_options(opt_.first_map_plane_lambda);
+    int32_t np = 0, n = 0;
+    key_scans_.assign(S, 0);
+    check(lvx_data_association_poses(ctx_, state.data(), in_.scan_stamps.data(), poses.data(), has.data(), opt_.key_scan_dist, opt_.key_scan_angle_deg, &ao, &np, &n, key_scans_.data()));
+    fetch_association(state, np, n);
+  }
   // DataAssociation of the refinement branch (lvi_initialize_surfel_orb.cpp:1180-1188, 1192-1201)
   void DataAssociation(const std::vector<double>& state) {
-    lvx_assoc_options ao; lvx_assoc_default_options(&ao);
-    ao.ndt_resolution = opt_.ndt_resolution; ao.plane_lambda = opt_.plane_lambda; ao.fit_threshold = opt_.fit_threshold; ao.min_leaf_points = opt_.min_leaf_points;
-    ao.min_inliers = opt_.min_inliers; ao.radius = opt_.associated_radius; ao.selected_per_ring = opt_.selected_per_ring;
+    const lvx_assoc_options ao = assoc_options(opt_.plane_lambda);
     int32_t np = 0, n = 0;
     check(lvx_data_association(ctx_, state.data(), in_.map_time, &ao, &np, &n));
+    fetch_association(state, np, n);
+  }
+  void fetch_association(const std::vector<double>& state, int32_t np, int32_t n) {
     planes_.assign((size_t)np, lvx_surfel_plane{});
     if (np > 0) check(lvx_get_surfel_map(ctx_, np, planes_.data()));
     sp_pt_.assign((size_t)n * 3, 0.0); sp_map_.assign((size_t)n * 3, 0.0); sp_t_.assign((size_t)n, 0.0); sp_plane_.assign((size_t)n, 0);
@@ -213,6 +266,7 @@ class Calibrator {
   std::vector<AssociationRecord> assoc_history_;
   std::vector<double> hist_cost_, hist_radius_, stage_state_in_; std::vector<int32_t> hist_acc_;
   std::vector<lvx_surfel_plane> planes_;
+  std::vector<int32_t> key_scans_;
   std::vector<double> sp_pt_, sp_map_, sp_t_; std::vector<int32_t> sp_plane_;
   int n_surfel_used_ = 0;
 };

@@ -700,6 +700,18 @@ def data_association(ctx, state, map_time, options=None):
     return npl.value, npt.value
 
 
+def data_association_poses(ctx, state, scan_t, poses16, has_pose=None, key_dist=0.2, key_angle_deg=5.0, options=None):
+    """The first DataAssociation of a calibration, map from per-scan odometry poses (lvx_data_association_poses): (surfels, SurfelPoints, key-scan flags)."""
+    scan_t, poses16 = _d(scan_t), _d(np.asarray(poses16, dtype=np.float64).reshape(-1, 16))
+    assert len(poses16) == len(scan_t)
+    hp = np.ascontiguousarray(has_pose, dtype=np.int32) if has_pose is not None else None
+    key = np.zeros(len(scan_t), np.int32)
+    npl, npt = C.c_int32(0), C.c_int32(0)
+    ctx._ck(ctx._l.lvx_data_association_poses(ctx._h, _p(_d(state)), _p(scan_t), _p(poses16), _p(hp) if hp is not None else None, C.c_double(key_dist), C.c_double(key_angle_deg),
+                                              C.byref(options) if options is not None else None, C.byref(npl), C.byref(npt), _p(key)))
+    return npl.value, npt.value, key
+
+
 def data_association_stats(ctx):
     """(rounds that took the one-stop chain, how many of those were repeated on the four-stop chain)."""
     a, b = C.c_int64(0), C.c_int64(0)

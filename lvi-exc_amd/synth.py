@@ -621,3 +621,46 @@ def make_sequence(seed=50, duration=6.0, dt=0.02, imu_rate=400.0, scan_rate=10.0
     return dict(t0=t0, dt=dt, n_knots=n_knots, camera=cam, t_imu=t_imu, gyro=gyro, acc=acc, H=H, W=W, scans=scans, t_map=t_map,
                 n_landmarks=V["n_landmarks"], lm_uv=V["lm_uv"], lm_t0=V["lm_t0"], rep_lm=V["rep_lm"], rep_uv=V["rep_uv"], rep_t0=V["rep_t0"],
                 state_true=state_true, state0=state0, t_start=t_start, t_end=t_end)
+
+
+def sequence_loam_poses(S, noise_m=0.0, noise_rad=0.0, seed=0):
+    """What LOAM hands the reference for a recorded sequence (ReadPoseGT, lvi_initialize_surfel_orb.cpp:458-516): one LiDAR pose per scan, stamped with the scan's header
+    stamp, in the frame of the LiDAR at the map time — from the ground-truth trajectory of make_sequence(), optionally perturbed.  Returns (scan_t [n], stamp_ns [n] int64,
+    p [n, 3], q_wxyz [n, 4], T [n, 16] row-major scan -> map as Eigen builds it from the written numbers)."""
+    N = S["n_knots"]
+    u = unpack_state(S["state_true"], N, S["n_landmarks"])
+    sp = Spline(S["t0"], S["dt"], u["r3"], u["so3"])
+    lidar = u["lidar"]
+    q_LI, p_LI = lidar[:4], lidar[4:7]
+    scan_t = np.array([sc["timestamp"][0] for sc in S["scans"]], dtype=np.float64)
+    stamp = (scan_t * 1e9).astype(np.int64)
+
+    def lidar_pose(t):
+        e = sp.eval(t)
+        return qmul(e["quat"], np.broadcast_to(q_LI, e["quat"].shape)), qrot(e["quat"], np.broadcast_to(p_LI, e["pos"].shape)) + e["pos"]
+    q0, p0 = lidar_pose(np.array([S["t_map"]]))
+    qk, pk = lidar_pose(scan_t)
+    q = qmul(np.broadcast_to(qconj(q0[0]), qk.shape), qk)
+    p = qrot(np.broadcast_to(qconj(q0[0]), qk.shape), pk - p0[0])
+    if noise_m or noise_rad:
+        rng = np.random.default_rng(seed)
+        q = qmul(q_from_rotvec(noise_rad * rng.standard_normal((len(q), 3))), q)
+        p = p + noise_m * rng.standard_normal(p.shape)
+    q_wxyz = np.stack([q[:, 3], q[:, 0], q[:, 1], q[:, 2]], axis=1)
+    # the file holds '%.9f'-style decimals; T is built from what a reader gets back (write_loam_pose_file writes repr-exact doubles, so this is the identity here)
+    T = np.zeros((len(q), 16))
+    for i in range(len(q)):
+        w, x, y, z = q_wxyz[i]
+        tx, ty, tz = 2 * x, 2 * y, 2 * z
+        twx, twy, twz, txx, txy, txz, tyy, tyz, tzz = tx * w, ty * w, tz * w, tx * x, ty * x, tz * x, ty * y, tz * y, tz * z
+        R = np.array([[1 - (tyy + tzz), txy - twz, txz + twy], [txy + twz, 1 - (txx + tzz), tyz - twx], [txz - twy, tyz + twx, 1 - (txx + tyy)]])
+        M = np.eye(4); M[:3, :3] = R; M[:3, 3] = p[i]
+        T[i] = M.ravel()
+    return scan_t, stamp, p, q_wxyz, T
+
+
+def write_loam_pose_file(path, stamp_ns, p, q_wxyz):
+    """A-LOAM laserMapping's pose dump as ReadPoseGT reads it: `stamp_ns x y z qw qx qy qz`, one pose per line (repr-exact doubles: atof gives the same bits back)."""
+    with open(path, "w") as f:
+        for s, pp, qq in zip(stamp_ns, p, q_wxyz):
+            f.write("%d %s %s\n" % (int(s), " ".join(repr(float(v)) for v in pp), " ".join(repr(float(v)) for v in qq)))

@@ -7,6 +7,10 @@ What it restates (stage machine of LIinitializer, src/lvi_exc/test/lvi_initializ
       SurfelAssociation::setSurfelMap        (src/core/surfel_association.cpp:50-108)           -> oracle.surfel_extract (deterministic plane fit, DESIGN.md)
       getAssociation per scan                (:111-158)                                         -> oracle.surfel_assoc + oracle.surfel_emit
       averageTimeDownSmaple(10)              (:240-244)                                         -> every 10th SurfelPoint
+  DataAssociation, FIRST-MAP branch (InitializationDone, :1175-1178) -> first_data_association below:
+      Mapping() (:1262-1300): ScanUndistortion::undistortScan (scan_undistortion.h:40-57, rotation only) + LiDAROdometry::feedScan(..., using_loam = true) with
+      updateKeyScan / checkKeyScan (src/core/lidar_odometry.cpp:45-74, 89-128), undistortScanInMap(odom_data_map) (scan_undistortion.h:95-116),
+      setSurfelMap over the voxel grid of the KEY-SCAN map, getAssociation per scan
   BatchOptimization / Refinement (:1212-1243) -> trajInitFromSurfel (src/core/trajectory_manager_lvi.cpp:311-351)
   trajInitFromLVIdata(frames, surfels)        (:138-195), trajInitFromLVIdata(frames, surfels, lm_splane) (:197-257) with associateVisualPointsWithPlanes (:161-214)
 every solve through oracle/lm.py (numpy LM on the oracle's dense J^T J).  The product-side mirror is lvx_host::Calibrator (lvi-exc_amd/host/lvx_calibrate.hpp);
@@ -92,6 +96,73 @@ def data_association(S, state, opt=None):
     planes = surfel_map(sim, opt)
     pts = associate(S, sim, planes, opt) if len(planes["p4"]) else dict(pt=np.zeros((0, 3)), pt_map=np.zeros((0, 3)), t=np.zeros(0), plane=np.zeros(0, np.int32))
     return dict(scans_in_map=sim, planes=planes, points=pts)
+
+
+def r2ypr_deg(R):
+    """mathutils::R2ypr (include/utils/math_utils.h:192-207): yaw, pitch, roll in degrees."""
+    n, o, a = R[:, 0], R[:, 1], R[:, 2]
+    y = np.arctan2(n[1], n[0])
+    p = np.arctan2(-n[2], n[0] * np.cos(y) + n[1] * np.sin(y))
+    r = np.arctan2(a[0] * np.sin(y) - a[1] * np.cos(y), -o[0] * np.sin(y) + o[1] * np.cos(y))
+    return np.array([y, p, r]) / np.pi * 180.0
+
+
+def key_scans(poses, present, key_dist=0.2, key_angle_deg=5.0):
+    """LiDAROdometry::checkKeyScan over the scans that were fed, in order (src/core/lidar_odometry.cpp:107-128): the first one, or > key_dist from the LAST KEY scan, or
+    turned by > key_angle_deg in yaw / pitch / roll (differences wrapped once by +-360: normalize_angle, include/core/lidar_odometry.h:95-102)."""
+    pos_last, ypr_last, key = np.zeros(3), np.zeros(3), []
+    for s in range(len(poses)):
+        if not present[s]:
+            continue
+        T = np.asarray(poses[s], dtype=np.float64).reshape(4, 4)
+        dist = np.linalg.norm(T[:3, 3] - pos_last)
+        ypr = r2ypr_deg(T[:3, :3])
+        d = ypr - ypr_last
+        d = np.where(d > 180, d - 360, d)
+        d = np.where(d < -180, d + 360, d)
+        if not key or dist > key_dist or (np.abs(d) > key_angle_deg).any():
+            pos_last, ypr_last = T[:3, 3].copy(), ypr
+            key.append(s)
+    return key
+
+
+def transform_cloud(xyzi, T):
+    """pcl::transformPointCloud(cloud, out, Eigen::Matrix4d) on a non-dense cloud (PCL <= 1.8 scalar form): double arithmetic on the float coordinates, the sum taken left
+    to right, rounded to float; points with a non-finite coordinate are copied as they are."""
+    T = np.asarray(T, dtype=np.float64).reshape(4, 4)
+    x, y, z = (xyzi[:, k].astype(np.float64) for k in range(3))
+    out = xyzi.copy()
+    fin = np.isfinite(x) & np.isfinite(y) & np.isfinite(z)
+    for r in range(3):
+        v = ((T[r, 0] * x + T[r, 1] * y) + T[r, 2] * z) + T[r, 3]
+        out[fin, r] = v[fin].astype(np.float32)
+    return out
+
+
+def first_data_association(S, state, scan_t, poses, has_pose=None, opt=None, key_dist=0.2, key_angle_deg=5.0):
+    """The FIRST DataAssociation (lvi_initialize_surfel_orb.cpp:1175-1178): map from per-scan odometry poses [n_scans][16] (row-major scan -> map), only the SO3 spline of
+    `state` is used.  Returns scans_in_map (absent scans NaN), key scan list, planes, points."""
+    opt = dict(DEFAULTS, plane_lambda=0.6, **(opt or {}))      # SurfelAssociation is constructed with plane_lambda_ = 0.6 (:127, 240); 0.7 is set for the refinement rounds (:1182)
+    o = _base_oracle(S)
+    raw = _raw_scans(S)
+    n = len(raw)
+    q, p, ok = O.eval_lidar_pose(o, state, np.asarray(scan_t, dtype=np.float64))
+    present = [bool(ok[s]) and (has_pose is None or bool(has_pose[s])) for s in range(n)]
+    sim = np.full((n, S["H"] * S["W"], 4), np.nan, np.float32)
+    sim[:, :, 3] = 0.0
+    for s in range(n):
+        if not present[s]:
+            continue
+        q_G_to_L0 = np.array([-q[s, 0], -q[s, 1], -q[s, 2], q[s, 3]])
+        und = O.undistort(o, state, raw[s], q_G_to_L0, p[s], False)      # ScanUndistortion::undistortScan(correct_position = false)
+        sim[s] = transform_cloud(und, poses[s])                          # undistortScanInMap(odom_data_map) / updateKeyScan: the same transformPointCloud
+    key = key_scans(poses, present, key_dist, key_angle_deg)
+    sim = sim.reshape(n, S["H"], S["W"], 4)
+    if not key:
+        return dict(scans_in_map=sim, key=key, planes=None, points=None)
+    planes = surfel_map(sim[key], opt)                                   # map_cloud_ of LiDAROdometry: the key scans, in order
+    pts = associate(S, sim, planes, opt) if len(planes["p4"]) else dict(pt=np.zeros((0, 3)), pt_map=np.zeros((0, 3)), t=np.zeros(0), plane=np.zeros(0, np.int32))
+    return dict(scans_in_map=sim, key=key, planes=planes, points=pts)
 
 
 def select_surfels(points, t_map, step):

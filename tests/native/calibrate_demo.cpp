@@ -2,7 +2,8 @@
 // rosbag / text inputs of the reference's lvi_initialize_surfel_orb — and writes the calibrated state.  Usage: calibrate_demo in.bin out.bin [history.bin]
 // out.bin (doubles): n_stages | 7 per stage | state | per stage: k, cost[k], radius[k], accepted[k], n_state_in, state_in.  history.bin: one record per DataAssociation round
 // (tests/test_gpu_pipeline_oracle.py reads it): 4 doubles (n_state, n_planes, n_points, n_cloud_floats), state, planes (lvx_surfel_plane records), pt, pt_map, t (doubles),
-// plane ids (int32), de-skewed scans (float32).
+// plane ids (int32), de-skewed scans (float32).  A fourth argument names a LOAM pose file (ReadPoseGT format: stamp_ns x y z qw qx qy qz per line): the first DataAssociation
+// then takes its map from those poses (the reference's default route); the scans' header stamps follow the scans in in.bin.
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -44,6 +45,8 @@ int main(int argc, char** argv) {
       for (size_t i = 0; i < pts.size(); ++i) { std::memset(&pts[i], 0, sizeof(pts[i])); pts[i].x = (float)xyz[3 * i]; pts[i].y = (float)xyz[3 * i + 1]; pts[i].z = (float)xyz[3 * i + 2]; pts[i].timestamp = ts[i]; }
       in.scans.push_back(std::move(pts));
     }
+    if (o < d.size()) in.scan_stamps = vec();
+    if (argc > 4) { if (!lvx_host::ReadPoseGT(argv[4], &in.loam)) throw std::runtime_error(std::string("cannot read pose file ") + argv[4]); }
     if (argc > 3) { opt.keep_history = true; opt.keep_clouds = true; }
     lvx_host::Calibrator cal(0, in, opt);
     const auto rep = cal.Run(&state);

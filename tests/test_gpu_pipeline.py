@@ -25,7 +25,7 @@ def demo_binary(tmp_path_factory):
     return out
 
 
-def _write(path, S, refine_iterations=2, lvi=1, camsurf=0, step=10, solve0=0):
+def _write(path, S, refine_iterations=2, lvi=1, camsurf=0, step=10, solve0=0, state=None, scan_stamps=None):
     c = S["camera"]
     parts = [np.array([S["t0"], S["dt"], S["n_knots"], S["t_map"], S["H"], S["W"], len(S["scans"]), refine_iterations, lvi, camsurf, step, solve0,
                        c["rows"], c["cols"], c["readout"], c["fx"], c["fy"], c["cx"], c["cy"], c["k1"], c["k2"], c["p1"], c["p2"], c["k3"]], dtype=np.float64)]
@@ -33,10 +33,13 @@ def _write(path, S, refine_iterations=2, lvi=1, camsurf=0, step=10, solve0=0):
     def vec(a):
         a = np.asarray(a, dtype=np.float64).ravel()
         parts.extend([np.array([len(a)], dtype=np.float64), a])
-    for k in ("state0", "t_imu", "gyro", "acc", "lm_uv", "lm_t0", "rep_lm", "rep_uv", "rep_t0"):
+    vec(S["state0"] if state is None else state)
+    for k in ("t_imu", "gyro", "acc", "lm_uv", "lm_t0", "rep_lm", "rep_uv", "rep_t0"):
         vec(S[k])
     for sc in S["scans"]:
         vec(np.stack([sc["x"], sc["y"], sc["z"]], axis=1)); vec(sc["timestamp"])
+    if scan_stamps is not None:
+        vec(scan_stamps)
     np.concatenate(parts).tofile(path)
 
 

@@ -31,18 +31,20 @@ LIBDIR = os.path.join(ROOT, "lvi-exc_amd")
 REFINE = 2
 
 
-@pytest.fixture(scope="module")
-def run(tmp_path_factory):
+def _build_demo(d):
     import build as lvx_build
     lvx_build.build()
-    d = tmp_path_factory.mktemp("calib_oracle")
     exe = str(d / "calibrate_demo")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(LIBDIR, "host"), SRC, "-o", exe, "-L" + LIBDIR, "-llvx", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib"])
-    S = synth.make_sequence(seed=50)
+    return exe
+
+
+def _run_demo(exe, d, S, n_stages, n_assoc, pose_file=None, **wkw):
+    """Run the C++ Calibrator on S (tests/native/calibrate_demo.cpp) and parse its result + history files: stages (with state_in / state_out), association records, final state."""
     pin, pout, phist = str(d / "seq.bin"), str(d / "res.bin"), str(d / "hist.bin")
-    _write(pin, S, refine_iterations=REFINE, lvi=1, camsurf=1)
+    _write(pin, S, **wkw)
     t0 = time.perf_counter()
-    r = subprocess.run([exe, pin, pout, phist], capture_output=True, text=True)
+    r = subprocess.run([exe, pin, pout, phist] + ([pose_file] if pose_file else []), capture_output=True, text=True)
     print(r.stdout, r.stderr[-2000:], "calibrator wall time %.2f s" % (time.perf_counter() - t0))
     assert r.returncode == 0, r.stderr
     out = np.fromfile(pout)
@@ -57,7 +59,7 @@ def run(tmp_path_factory):
         m = int(out[o]); o += 1
         stages.append(dict(iterations=int(rep[k, 0]), termination=lvx.LM_TERMINATION[int(rep[k, 1])], initial_cost=rep[k, 2], final_cost=rep[k, 3], n_planes=int(rep[k, 4]),
                            n_used=int(rep[k, 5]), n_camsurf=int(rep[k, 6]), cost_history=cost, accepted=acc, state_in=out[o:o + m])); o += m
-    assert o == len(out) and ns == REFINE + 2
+    assert o == len(out) and ns == n_stages
     for k in range(ns):
         stages[k]["state_out"] = stages[k + 1]["state_in"] if k + 1 < ns else x_final
     buf = open(phist, "rb").read()
@@ -71,8 +73,16 @@ def run(tmp_path_factory):
         rec["plane"] = np.frombuffer(buf, np.int32, n_pt, o); o += 4 * n_pt
         rec["scans_in_map"] = np.frombuffer(buf, np.float32, n_cl, o).reshape(len(S["scans"]), S["H"], S["W"], 4); o += 4 * n_cl
         assoc.append(rec)
-    assert len(assoc) == REFINE
+    assert len(assoc) == n_assoc
     return dict(S=S, stages=stages, assoc=assoc, x_final=x_final)
+
+
+@pytest.fixture(scope="module")
+def run(tmp_path_factory):
+    d = tmp_path_factory.mktemp("calib_oracle")
+    exe = _build_demo(d)
+    S = synth.make_sequence(seed=50)
+    return _run_demo(exe, d, S, REFINE + 2, REFINE, refine_iterations=REFINE, lvi=1, camsurf=1)
 
 
 def _planes_dict(pl):
@@ -164,3 +174,83 @@ def test_free_running_oracle_schedule_ends_at_the_same_extrinsics(run):
     e = _ext_err(run["x_final"], xo, S["n_knots"])
     print("free-running, gpu vs oracle:", e)
     assert e["lidar"][0] <= 1e-5 and e["cam"][0] <= 1e-5 and e["lidar"][1] <= 1e-4 and e["cam"][1] <= 1e-4
+
+
+# ---- the reference's DEFAULT route: first map from LOAM poses (lvi_initialize_surfel_orb.cpp:1175-1178, 1262-1300) ----
+def _reference_initial_state(S):
+    """What the reference starts from (trajectory_manager_lvi.cpp:31-36, imu.h:126-127): every R3 control point 0, every SO3 control point identity, roll = pitch = 0.01,
+    zero biases; the extrinsics' initial guesses and the inverse depths of the ORB map as make_sequence's state0 has them."""
+    N = S["n_knots"]
+    x = np.array(S["state0"], dtype=np.float64)
+    x[:3 * N] = 0.0
+    x[3 * N:7 * N] = np.tile([0.0, 0.0, 0.0, 1.0], N)
+    return x
+
+
+@pytest.fixture(scope="module")
+def run_loam(tmp_path_factory):
+    d = tmp_path_factory.mktemp("calib_loam")
+    exe = _build_demo(d)
+    S = synth.make_sequence(seed=53, duration=4.0, n_reproj=1500)
+    scan_t, stamp, p, q_wxyz, T = synth.sequence_loam_poses(S, noise_m=2e-3, noise_rad=5e-4, seed=7)
+    stamp, p, q_wxyz, T = stamp[:-1], p[:-1], q_wxyz[:-1], T[:-1]      # LOAM lost the last scan: it has no pose (loam_poses_map_.find fails) and is skipped
+    pose_file = str(d / "loam_poses.txt")
+    synth.write_loam_pose_file(pose_file, stamp, p, q_wxyz)
+    x0 = _reference_initial_state(S)
+    out = _run_demo(exe, d, S, 2, 1, pose_file=pose_file, refine_iterations=1, lvi=0, camsurf=0, solve0=1, state=x0, scan_stamps=scan_t)
+    out.update(x0=x0, scan_t=scan_t, T=T, has_pose=np.r_[np.ones(len(T), np.int32), 0], poses=np.vstack([T, np.zeros((1, 16))]))
+    return out
+
+
+def test_solve0_from_the_reference_initial_state_matches_the_oracle_lm(run_loam):
+    S, st = run_loam["S"], run_loam["stages"][0]
+    assert np.array_equal(st["state_in"], run_loam["x0"])
+    xo, so = pipeline.solve_stage(S, st["state_in"], "SO3FromGyro", None, None)
+    print("Solve #0 gpu: it %d %s cost %.6e -> %.6e | oracle: it %d %s -> %.6e" % (st["iterations"], st["termination"], st["initial_cost"], st["final_cost"], so["iterations"], so["termination"], so["final_cost"]))
+    assert st["termination"] == so["termination"] and st["iterations"] == so["iterations"] and list(st["accepted"]) == list(so["accepted"])
+    assert np.abs(st["cost_history"] - so["cost_history"]).max() <= 1e-7 * so["cost_history"].max()
+    N = S["n_knots"]
+    assert np.abs(st["state_out"][3 * N:7 * N] - xo[3 * N:7 * N]).max() <= 1e-7      # the SO3 control points the first map is de-skewed with
+
+
+def test_first_map_association_from_loam_poses_matches_the_oracle(run_loam):
+    S, rec = run_loam["S"], run_loam["assoc"][0]
+    assert np.array_equal(rec["state"], run_loam["stages"][1]["state_in"])            # it ran at Solve #0's result: zero positions, SO3 from the gyroscope
+    assert np.count_nonzero(rec["state"][:3 * S["n_knots"]]) == 0
+    fo = pipeline.first_data_association(S, rec["state"], run_loam["scan_t"], run_loam["poses"], run_loam["has_pose"])
+    so, sg = fo["scans_in_map"], rec["scans_in_map"]
+    assert np.isnan(sg[-1, :, :, :3]).all() and not np.isnan(sg[0, :, :, 0]).all()    # the scan without a pose is absent
+    assert np.array_equal(np.isnan(so), np.isnan(sg))
+    m = ~np.isnan(so)
+    diff = np.abs(so[m] - sg[m])
+    frac = np.count_nonzero(so[m].view(np.uint32) != sg[m].view(np.uint32)) / m.sum()
+    print("first map: %d key scans of %d; scans in the map frame: max |diff| %.2e m, %.4f %% of the floats not bit-equal" % (len(fo["key"]), len(sg), diff.max(), 100 * frac))
+    assert diff.max() <= 4e-6 and frac < 1e-3
+    assert 1 < len(fo["key"]) < len(sg) - 1                                           # the key-scan rule selects: not every scan, not only the first
+    # the surfel map of the KEY-SCAN cloud, from the GPU's scans (lambda 0.6: the constructor's)
+    opt = dict(pipeline.DEFAULTS, plane_lambda=0.6)
+    po = pipeline.surfel_map(sg[fo["key"]], opt)
+    pg = rec["planes"]
+    assert len(pg) == len(po["p4"]) == run_loam["stages"][1]["n_planes"] and len(pg) > 50
+    assert np.array_equal(pg["leaf"], po["leaf"]) and np.array_equal(pg["n_points"], po["n_points"]) and np.array_equal(pg["n_inliers"], po["n_inliers"])
+    assert np.array_equal(pg["plane_type"], po["plane_type"])
+    assert np.array_equal(pg["box_min"], po["box_min"]) and np.array_equal(pg["box_max"], po["box_max"])
+    assert np.abs(pg["p4"] - po["p4"]).max() <= 1e-9 and np.abs(pg["Pi"] - po["Pi"]).max() <= 1e-9 * np.abs(po["Pi"]).max()
+    # a map of ALL scans would be another map: the key-scan selection is really what the GPU used
+    assert len(pipeline.surfel_map(sg[:-1], opt)["p4"]) != len(pg)
+    # association of every scan against the GPU's surfels: the SurfelPoint list identical
+    eo = pipeline.associate(S, sg, _planes_dict(pg), opt)
+    assert len(eo["t"]) == len(rec["t"]) > 500
+    for key in ("pt", "pt_map", "t", "plane"):
+        assert np.array_equal(eo[key], rec[key]), key
+    assert run_loam["stages"][1]["n_used"] == len(pipeline.select_surfels(eo, S["t_map"], 10)[1])
+
+
+def test_batch_optimization_after_the_first_map_matches_the_oracle_lm(run_loam):
+    """trajInitFromSurfel from ZERO positions on the first map's SurfelPoints: the GPU's LM against the oracle's from the same state on the same blocks."""
+    rec = run_loam["assoc"][0]
+    xo = _check_solve(run_loam, 1, "TrajFromSurfel", _planes_dict(rec["planes"]), _points_dict(rec))
+    S, N = run_loam["S"], run_loam["S"]["n_knots"]
+    e = _ext_err(xo, S["state_true"], N)
+    print("after the batch optimisation, oracle vs ground truth (LiDAR):", e["lidar"], " start:", _ext_err(run_loam["x0"], S["state_true"], N)["lidar"])
+    assert np.abs(xo[:3 * N]).max() > 0.1                                             # the positions left zero

@@ -185,3 +185,35 @@ def test_matrix_free_products_equal_the_dense_normal_equations():
     assert np.abs(m["g"] - d["g"]).max() <= 1e-13 * np.abs(d["g"]).max()
     assert np.abs(m["diag"] - np.diag(d["H"])).max() <= 1e-13 * np.diag(d["H"]).max()
     assert np.abs(m["HV"] - V @ d["H"]).max() <= 1e-13 * np.abs(V @ d["H"]).max()
+
+
+# ---- first map from odometry poses (oracle/pipeline.py: first_data_association) ----
+def test_key_scan_rule_known_answers():
+    """LiDAROdometry::checkKeyScan (src/core/lidar_odometry.cpp:107-128): first scan; > 0.2 m from the LAST KEY scan (not the last scan); > 5 deg in yaw / pitch / roll,
+    the difference wrapped once by 360 (so a 358 deg jump is a 2 deg turn); scans that were not fed do not count."""
+    from oracle import pipeline
+
+    def pose(x=0.0, yaw_deg=0.0):
+        c, s = np.cos(np.deg2rad(yaw_deg)), np.sin(np.deg2rad(yaw_deg))
+        T = np.eye(4); T[:3, :3] = [[c, -s, 0], [s, c, 0], [0, 0, 1]]; T[0, 3] = x
+        return T.ravel()
+    P = [pose(5.0), pose(5.15), pose(5.19), pose(5.21), pose(5.3), pose(5.3, 4.0), pose(5.3, 5.5), pose(5.3, 179.0), pose(5.3, -179.0), pose(9.0)]
+    present = [1, 1, 1, 1, 1, 1, 1, 1, 1, 0]
+    # 0: first; 3: 0.21 m from scan 0; 4: only 0.09 from scan 3; 6: 5.5 deg from key 3's yaw 0; 7: 173.5 deg; 8: 179 -> -179 is 2 deg after the wrap; 9: absent
+    assert pipeline.key_scans(P, present) == [0, 3, 6, 7]
+    assert np.allclose(pipeline.r2ypr_deg(np.array(pose(0, 30.0)).reshape(4, 4)[:3, :3]), [30.0, 0.0, 0.0])
+
+
+def test_transform_cloud_is_the_scalar_pcl_form():
+    """pcl::transformPointCloud(Matrix4d) on float points: double products summed left to right, rounded to float once; non-finite points untouched."""
+    from oracle import pipeline
+    rng = np.random.default_rng(3)
+    pts = np.zeros((50, 4), np.float32); pts[:, :3] = rng.uniform(-30, 30, (50, 3)); pts[:, 3] = 7.0
+    pts[4, 0] = np.nan
+    T = np.eye(4); T[:3, :3] = np.linalg.qr(rng.standard_normal((3, 3)))[0]; T[:3, 3] = [1.5, -2.25, 0.125]
+    out = pipeline.transform_cloud(pts, T.ravel())
+    ref = (pts[:, :3].astype(np.float64) @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+    ok = np.arange(50) != 4
+    assert np.abs(out[ok, :3] - ref[ok]).max() <= 4e-6 and np.array_equal(out[:, 3], pts[:, 3])
+    assert np.isnan(out[4, 0]) and np.array_equal(out[4, 1:], pts[4, 1:])
+    assert out.dtype == np.float32
