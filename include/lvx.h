@@ -95,8 +95,10 @@ typedef struct lvx_layout {
   int32_t n_hub_knots, hub_knot0;
   int64_t n_blocks;    /* residual blocks per evaluation */
   int64_t n_residuals; /* residual rows per evaluation */
-  int32_t exact_fallback; /* 1 once an evaluation hit a case only the per-segment kernels handle exactly (merged map-time segment): they are used from then on */
+  int32_t exact_fallback; /* 1 once an evaluation needed the per-segment kernels for EVERYTHING (more rows than the fallback lists hold, |tau_imu| >= dt): they are used from then on */
   int32_t solver_fallbacks; /* LM steps so far whose cyclic-reduction factorisation lost positive definiteness and were redone by the sequential band Cholesky */
+  int32_t fallback_rows;    /* blocks of the last evaluation whose cost was read that the fused kernels handed, row by row, to the exact per-segment kernel (a control-point
+                             * pair beyond 0.8 rad, the merged map-time segment corner): the pass stays on the fused kernels for everything else */
 } lvx_layout;
 
 /* lifetime ------------------------------------------------------------------------------------------------*/
@@ -183,7 +185,8 @@ int lvx_synchronize(lvx_ctx* ctx);
 #define LVX_KERNEL_REP_CROSS 13
 #define LVX_KERNEL_REP_LMROWS 14
 #define LVX_KERNEL_REP_FUSED 15     /* round 6: the single-launch reprojection kernel (k_reproj_fused); the five above then stay at zero */
-#define LVX_NUM_KERNELS 16
+#define LVX_KERNEL_FIXUP 16         /* the exact per-segment kernel over the fused kernels' fallback lists (lvx_layout::fallback_rows), all families */
+#define LVX_NUM_KERNELS 17
 /* enable: 0 off | 1 every launch | 2 + k: only the launches of kernel k (e.g. 2 + LVX_FAM_SURFEL: the dominant kernel — two event
  * records per pass instead of ~20, which cost ~5 % of a config-4 pass).  While profiling is on, passes are issued launch by launch (no graph replay). */
 int lvx_set_profiling(lvx_ctx* ctx, int enable);

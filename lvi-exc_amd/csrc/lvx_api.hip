@@ -68,6 +68,7 @@ int lvx_create(lvx_ctx** out, int device, uint32_t /*flags*/) {
   for (int k = 0; k < 4; ++k) { if (hipStreamCreateWithFlags(&c->fam_stream[k], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_join[k], LVX_SYNC_EVENT_FLAGS(c)) != hipSuccess) { delete c; return LVX_E_HIP; } }
   if (hipEventCreateWithFlags(&c->ev_fork, LVX_SYNC_EVENT_FLAGS(c)) != hipSuccess) { delete c; return LVX_E_HIP; }
   if (hipEventCreateWithFlags(&c->ev_jac, LVX_SYNC_EVENT_FLAGS(c)) != hipSuccess) { delete c; return LVX_E_HIP; }
+  for (int k = 0; k < 2; ++k) if (hipEventCreateWithFlags(&c->ev_fb[k], LVX_SYNC_EVENT_FLAGS(c)) != hipSuccess) { delete c; return LVX_E_HIP; }
   *out = c;
   return LVX_OK;
 }
@@ -92,7 +93,7 @@ void lvx_destroy(lvx_ctx* c) {
   if (c->d_pre.p) (void)hipFree(c->d_pre.p);
   if (c->d_colfull.p) (void)hipFree(c->d_colfull.p);
   for (auto& b : c->d_det_list) if (b.p) (void)hipFree(b.p);
-  for (DevBuf* b : {&c->d_imu_rtab, &c->d_chk, &c->d_det_cross, &c->d_lm_grp, &c->d_lmH, &c->d_lm_p0, &c->d_Hr, &c->d_Br, &c->d_red, &c->d_repT, &c->d_repF}) if (b->p) (void)hipFree(b->p);
+  for (DevBuf* b : {&c->d_imu_rtab, &c->d_chk, &c->d_det_cross, &c->d_lm_grp, &c->d_lmH, &c->d_lm_p0, &c->d_Hr, &c->d_Br, &c->d_red, &c->d_repT, &c->d_repF, &c->d_fb}) if (b->p) (void)hipFree(b->p);
   if (c->vox.graph) (void)hipGraphExecDestroy((hipGraphExec_t)c->vox.graph);
   if (c->vox.h_info) (void)hipHostFree(c->vox.h_info);
   if (c->da_pinned) (void)hipHostFree(c->da_pinned);
@@ -106,6 +107,7 @@ void lvx_destroy(lvx_ctx* c) {
   for (int k = 0; k < 4; ++k) { if (c->fam_stream[k]) (void)hipStreamDestroy(c->fam_stream[k]); if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_jac) (void)hipEventDestroy(c->ev_jac);
+  for (int k = 0; k < 2; ++k) if (c->ev_fb[k]) (void)hipEventDestroy(c->ev_fb[k]);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -183,7 +185,7 @@ int lvx_get_layout(lvx_ctx* c, lvx_layout* o) {
   int rc = ensure_layout(c); if (rc) return rc;
   o->n_knots = c->N; o->n_landmarks = c->L; o->n_tangent = lvx_tangent_size(c); o->n_band = c->nb; o->bandwidth = c->bw; o->n_border = c->nbd; o->border_ld = c->nbd_ext;
   o->n_hub_knots = c->n_hub; o->hub_knot0 = c->hub0; o->n_blocks = c->n_blocks; o->n_residuals = c->n_residuals;
-  o->exact_fallback = c->force_legacy ? 1 : 0; o->solver_fallbacks = c->solver_fallbacks;
+  o->exact_fallback = c->force_legacy ? 1 : 0; o->solver_fallbacks = c->solver_fallbacks; o->fallback_rows = c->fallback_rows;
   return LVX_OK;
 }
 
@@ -276,10 +278,16 @@ int lvx_synchronize(lvx_ctx* c) {
   LVX_HIP(c, hipSetDevice(c->device));
   LVX_HIP(c, hipStreamSynchronize(c->stream));
   if (!c->d_err.p) return LVX_OK;
-  int err = 0;
-  LVX_HIP(c, hipMemcpy(&err, c->d_err.p, 4, hipMemcpyDeviceToHost));
+  int errw[4 + LVX_NUM_FAM] = {0};
+  LVX_HIP(c, hipMemcpy(errw, c->d_err.p, sizeof(errw), hipMemcpyDeviceToHost));
+  const int err = errw[0];
   c->err_unchecked = false;
-  if (err & LVX_ERR_FALLBACK) { c->force_legacy = true; return fail(c, LVX_E_STATE, "fast assembly kernels hit the merged-hub-segment corner: evaluate again (the exact per-segment kernels are now selected)"); }
+  c->fallback_rows = 0; for (int f = 0; f < LVX_NUM_FAM; ++f) c->fallback_rows += errw[4 + f];
+  if (err & LVX_ERR_FALLBACK) {
+    { int need = 0; for (int f = 0; f < LVX_NUM_FAM; ++f) if (errw[4 + f] > 0) need |= 1 << f;
+      if (!c->sw.force_legacy && need && (need & ~c->fb_mask)) { c->fb_on = true; c->fb_mask |= need; } else c->force_legacy = true; }   // row-level fallback lists first, the per-segment kernels for everything after that
+    return fail(c, LVX_E_STATE, "fused assembly kernels met rows only the per-segment kernels evaluate exactly: evaluate again (the exact fallback is now selected)");
+  }
   if (err & RES_RANGE) return fail(c, LVX_E_RANGE, "time span out of range for trajectory");
   if (err & RES_NONUNIT) return fail(c, LVX_E_NONUNIT_QUAT, "logq: only implemented for unit quaternions");
   if (err & 4) return fail(c, LVX_E_STATE, "normal-equation entry outside the computed bandwidth");

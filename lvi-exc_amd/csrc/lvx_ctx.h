@@ -45,7 +45,8 @@ struct DevCommon {
   // lmH[l * lm_ls + ...] = [ band couplings (lm_wl) | border couplings (nbd) | H_ll | g_l ]
   double* lmH; const int* lm_p0; int lm_wl, lm_ls;
   double* cost;  // [LVX_NREP]
-  int* err;      // bit0 range, bit1 non-unit quaternion, bit2 band overflow
+  int* err;      // bit0 range, bit1 non-unit quaternion, bit2 band overflow; err[4 + f]: rows of family f on the fallback list
+  int* fb_list; int fb_cap;   // [LVX_NUM_FAM][fb_cap] rows a fused kernel handed to the exact per-segment kernel (null: a row it cannot take sets LVX_ERR_FALLBACK)
   // outputs (may be null)
   double* residuals;
   int32_t* jcols;
@@ -83,6 +84,7 @@ struct lvx_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t fam_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // concurrent family kernels
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr}, ev_jac = nullptr;   // ev_jac: reprojection Jacobians materialised
+  hipEvent_t ev_fb[2] = {nullptr, nullptr};   // row-level fallback: a fused kernel's list is complete (the exact kernels over it run on fam_stream[1], beside the rest of the pass)
   std::string last_error;
   // problem
   bool have_spline = false;
@@ -104,6 +106,7 @@ struct lvx_ctx {
   lvx::Switches sw;
   int rep_groups = 0;          // (reference window, observation window) groups of the reprojection cross-term kernel (d_repB[2])
   int rep_fused_wg = 0; lvx::DevBuf d_repF;   // fused reprojection kernel (k_reproj_fused): its groups (0: the five-launch chain runs) and their table [start | count], largest first
+  bool fb_on = false; int fb_mask = 0, fallback_rows = 0; lvx::DevBuf d_fb;   // row-level exact fallback (run_evaluate): lists enabled after the first pass that needed them; rows on them in the last checked pass
   bool force_legacy = false;   // set when the fast assembly kernels hit a case only the per-segment kernels handle exactly
   lvx::DevBuf d_pre;   // So3Pre[N]
   lvx::DevBuf d_repT;   // [rep.n][56] landmark-row records of the reprojection blocks (k_reproj_cross -> k_reproj_lmrows)

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <numeric>
 #include <cstdlib>
 
@@ -189,6 +190,16 @@ __device__ __forceinline__ void add_g(const DevCommon& cm, int pc, double v, int
   else atomicAdd(&cm.gc[(size_t)rep * cm.nbd + (-1 - pc)], v);
 }
 
+// a row a fused kernel cannot take exactly (control-point pair beyond the small-angle polynomials, merged map-time segment corner, interval outside the chunk's window):
+// onto the family's fallback list — the exact per-segment kernel evaluates the listed rows right behind the fused kernel — or, without lists / beyond their capacity,
+// the whole pass is redone by the per-segment kernels
+#define LVX_FB_CAP 4096
+__device__ __forceinline__ void fallback_row(const DevCommon& cm, int fam, int si) {
+  const int i = atomicAdd(&cm.err[4 + fam], 1);   // counted either way: the host learns which families need a list
+  if (cm.fb_list && ((cm.fb_cap >> 16) >> fam & 1) && i < (cm.fb_cap & 0xffff)) { cm.fb_list[(size_t)fam * (cm.fb_cap & 0xffff) + i] = si; return; }
+  atomicOr(cm.err, LVX_ERR_FALLBACK);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
@@ -196,7 +207,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // PW = wavefronts per workgroup: wave 0 evaluates the 64 measurements (phase 1), all PW waves share the pair work of phase 2
 template <class F, int PW>
-__global__ __launch_bounds__(64 * PW) void k_family(F fam, DevCommon cm, const uint16_t* __restrict__ pairs, long long row0) {
+__global__ __launch_bounds__(64 * PW) void k_family(F fam, DevCommon cm, const uint16_t* __restrict__ pairs, long long row0, const int* __restrict__ rows = nullptr, const int* __restrict__ nrows = nullptr) {
   constexpr int NC = F::NC, NR = F::NR, TS = NR * 64 + 1, NP = NC * (NC + 1) / 2;
   __shared__ double Jt[NC * TS];
   __shared__ double rs[NR * 64];
@@ -208,9 +219,12 @@ __global__ __launch_bounds__(64 * PW) void k_family(F fam, DevCommon cm, const u
   const int wave = threadIdx.x >> 6;
   const int rep = blockIdx.x % cm.nrep;
   __shared__ int nseg_s;
+  const int nlist = rows ? min(*nrows, cm.fb_cap & 0xffff) : 0;   // rows != null: the rows of a fallback list instead of all of them
+  if (rows && (int)blockIdx.x * 64 >= nlist) return;
   if (wave == 0) {
-  const int si = blockIdx.x * 64 + lane;
-  const bool in = si < fam.n;
+  const int idx = blockIdx.x * 64 + lane;
+  const bool in = rows ? idx < nlist : idx < fam.n;
+  const int si = rows ? (in ? rows[idx] : 0) : idx;
   const SplineRef sp{cm.t0, cm.dt, cm.N, cm.state, cm.state + 3 * (size_t)cm.N};
   const Cal cal = load_cal(cm);
   if (F::USES_HUB) {
@@ -372,7 +386,7 @@ struct Aux { int wid, xk, lm; const PreWin* pw; };   // pw: the workgroup's prec
 // SKIP_GG: global x global and the global gradient are assembled by another pass; SECONDARY: no cost / residual output
 struct GyroAcc {
   enum { PMAJ = 1 };
-  enum { NK = 12, NG = 3, NR = 3, HUB = -1, KPK = 3, LVO = 3, WS = 1, GL = 32, SKIP_GG = 0, SECONDARY = 0, LB = 64, NCP = 15, USE_PRE = 1, OCC = 1 };
+  enum { NK = 12, NG = 3, NR = 3, HUB = -1, KPK = 3, LVO = 3, WS = 1, GL = 32, SKIP_GG = 0, SECONDARY = 0, LB = 64, NCP = 15, USE_PRE = 1, OCC = 1, FAM = LVX_FAM_GYRO };
   __device__ static constexpr int jm(int c) { return c; }   // KPK columns per knot at offset LVO of its 6 tangent scalars; WS = knot intervals per MFMA window; GL = lanes per panel
   int n; const double* t; const double* m3; const int* perm; double weight, huber;
   __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared*, int si, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
@@ -385,7 +399,7 @@ struct GyroAcc {
 // g_p (v_k - v_0) + g_xi0 w_0 + g_xik w_k — the pose gradients the row already has, contracted with the spline's velocity and body angular velocity at both poses —
 // and padded spans through the generic segment branch.  The locked instantiation is unchanged.
 template <bool TAU> struct SurfAccT {
-  enum { NK = 24, NG = 12 + (TAU ? 1 : 0), NR = 1, HUB = 0, KPK = 6, LVO = 0, WS = 2, GL = 16, SKIP_GG = 0, SECONDARY = 0, LB = 64, NCP = 36 + (TAU ? 1 : 0), USE_PRE = 1, OCC = 2 };   // reverse-mode Jacobian: fits two wavefronts per SIMD with a few spills, and two workgroups per CU hide its latencies
+  enum { NK = 24, NG = 12 + (TAU ? 1 : 0), NR = 1, HUB = 0, KPK = 6, LVO = 0, WS = 2, GL = 16, SKIP_GG = 0, SECONDARY = 0, LB = 64, NCP = 36 + (TAU ? 1 : 0), USE_PRE = 1, OCC = 2, FAM = LVX_FAM_SURFEL };   // reverse-mode Jacobian: fits two wavefronts per SIMD with a few spills, and two workgroups per CU hide its latencies
   __device__ static constexpr int jm(int c) { return c; }
   int n; const double* t; const double* pt; const double* rowpl; const int* perm; double t_map, weight, huber;   // rowpl: the row's plane (gathered at layout time: no dependent load)
   // raw inputs of a row, loaded one batch ahead of their use: the HBM latency hides behind the previous batch's assembly
@@ -422,7 +436,7 @@ template <bool TAU> struct SurfAccT {
 };
 using SurfAcc = SurfAccT<false>;
 template <bool TAU> struct CamSurfAccT {
-  enum { NK = 24, NG = 18 + (TAU ? 1 : 0), NR = 1, HUB = 1, KPK = 6, LVO = 0, WS = 1, GL = 16, SKIP_GG = 0, SECONDARY = 0, LB = 64, NCP = 42 + (TAU ? 1 : 0), USE_PRE = 1, OCC = 2 };
+  enum { NK = 24, NG = 18 + (TAU ? 1 : 0), NR = 1, HUB = 1, KPK = 6, LVO = 0, WS = 1, GL = 16, SKIP_GG = 0, SECONDARY = 0, LB = 64, NCP = 42 + (TAU ? 1 : 0), USE_PRE = 1, OCC = 2, FAM = LVX_FAM_CAMSURF };
   __device__ static constexpr int jm(int c) { return c; }
   int n; const int* lm; const int* plane; const int* perm; const double* planes; const double* lm_uv; const double* lm_t0; double t_map, weight, huber;
   __device__ int eval(const DevCommon& cm, const SplineRef& sp, const Cal& cal, const HubShared* hub, int si, double r[NR], double (*J)[NCP], int& key, Aux& aux) const {
@@ -471,7 +485,7 @@ struct RepJac { const double* J; const double* r; const int* k; int n; };   // k
 // TAU: the camera time offset is free — one more global column (the row's column 55, tangent 6 N + 21) rides with the camera block
 template <int SIDE, bool TAU = false> struct RepSideAcc {   // SIDE 0: the reference view's pose, 1: the observation's
   enum { PMAJ = 1 };
-  enum { NK = 24, NG = 6 + (TAU ? 1 : 0), NR = 2, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 16, SKIP_GG = SIDE, SECONDARY = 1, LB = 16, NCP = 31 + (TAU ? 1 : 0), USE_PRE = 0, OCC = 1 };
+  enum { NK = 24, NG = 6 + (TAU ? 1 : 0), NR = 2, HUB = -1, KPK = 6, LVO = 0, WS = 1, GL = 16, SKIP_GG = SIDE, SECONDARY = 1, LB = 16, NCP = 31 + (TAU ? 1 : 0), USE_PRE = 0, OCC = 1, FAM = LVX_FAM_REPROJ };
   __device__ static constexpr int jm(int c) { return c; }   // [knots of this side | camera]
   static constexpr int RJ = REP_NC + (TAU ? 1 : 0);
   int n; RepJac jac;
@@ -512,7 +526,7 @@ __global__ __launch_bounds__(64) void k_reproj_jac(ReprojFamT<TAU> fam, DevCommo
     double r[2], J[2][RJ];
     Keys key{-1, -1, -1};
     const int status = fam.eval_pre(cm, sp, cal, si, r, J, key);
-    if (status != RES_OK) { atomicOr(cm.err, status); kb[si] = -1; kb[n + si] = -1; }
+    if (status != RES_OK) { if (status == RES_OUTSIDE) fallback_row(cm, LVX_FAM_REPROJ, si); else atomicOr(cm.err, status); kb[si] = -1; kb[n + si] = -1; }
     else {
       double scale;
       mycost = 0.5 * huber_rho(fam.huber, r[0] * r[0] + r[1] * r[1], &scale);
@@ -774,7 +788,8 @@ __global__ __launch_bounds__(256, 1) void k_reproj_fused(ReprojFamT<TAU> fam, Re
       const SplineRef sp{cm.t0, cm.dt, cm.N, cm.state, cm.state + 3 * (size_t)cm.N};
       const Cal cal = load_cal(cm);
       const int status = fam.eval_pre(cm, sp, cal, si, r, J, key);
-      if (status != RES_OK) atomicOr(cm.err, status);
+      if (status == RES_OUTSIDE) fallback_row(cm, LVX_FAM_REPROJ, si);
+      else if (status != RES_OK) atomicOr(cm.err, status);
       else {
         valid = true;
         double scale;
@@ -1073,7 +1088,8 @@ __global__ __launch_bounds__(256, OCC) void k_family_mfma(F fam, DevCommon cm, c
       else status = fam.eval(cm, sp, cal, hub, si, r, J, key, aux);
       if (aux.wid < 0) aux.wid = key;
       valid = status == RES_OK;
-      if (valid && (key < k_lo || key - k_lo > CR + 1 || 6 * (key - k_lo + 4) > LVU)) { valid = false; atomicOr(cm.err, LVX_ERR_FALLBACK); }
+      if (valid && (key < k_lo || key - k_lo > CR + 1 || 6 * (key - k_lo + 4) > LVU)) { valid = false; fallback_row(cm, F::FAM, si); }
+      else if (!valid && status == LVX_ERR_FALLBACK) fallback_row(cm, F::FAM, si);
       else if (!valid && status > 0) atomicOr(cm.err, status);   // status < 0: row skipped (reported by the kernel that produced it)
     }
     if constexpr (RowOf<F>::prefetch) { const int sn = si + nwv * LB; if (lane < LB && sn < m1) nxt = fam.load(sn); }   // next batch's rows: in flight during this batch's assembly
@@ -1548,7 +1564,8 @@ __global__ __launch_bounds__(256, 1) void k_imu_own(ImuFused fam, DevCommon cm, 
           }
         }
         valid = status == RES_OK;
-        if (valid && (key < k_lo || key - k_lo > CR + 1)) { valid = false; atomicOr(cm.err, LVX_ERR_FALLBACK); }
+        if (valid && (key < k_lo || key - k_lo > CR + 1)) { valid = false; fallback_row(cm, LVX_FAM_GYRO, si); }
+        else if (!valid && status == RES_OUTSIDE) fallback_row(cm, LVX_FAM_GYRO, si);   // (the sample: its gyroscope AND accelerometer block go to the exact kernels)
         else if (!valid) atomicOr(cm.err, status);
       }
       IKT(1)
@@ -2445,7 +2462,8 @@ int ensure_layout(lvx_ctx* ctx) {
   if ((rc = dev_alloc(ctx, ctx->d_hubs, 2 * sizeof(HubShared)))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_pre, (size_t)std::max(N, 1) * sizeof(So3Pre)))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_cost, (size_t)ctx->nrep * 8))) return rc;
-  if ((rc = dev_alloc(ctx, ctx->d_err, 16))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_err, 64))) return rc;   // [error bits, -, -, - | fallback rows per family (6) | -]
+  if ((rc = dev_alloc(ctx, ctx->d_fb, (size_t)LVX_NUM_FAM * LVX_FB_CAP * 4))) return rc;
   if ((rc = dev_alloc(ctx, ctx->d_state, (size_t)lvx_state_size(ctx) * 8))) return rc;
   auto range = [](int a, int b) { std::vector<int> v; for (int i = a; i < b; ++i) v.push_back(i); return v; };
   auto cat = [](std::vector<int> a, const std::vector<int>& b) { a.insert(a.end(), b.begin(), b.end()); return a; };
@@ -2457,7 +2475,7 @@ int ensure_layout(lvx_ctx* ctx) {
   if ((rc = upload_pairs(ctx, ctx->d_pairs[3], SURF_NC + tL, cat(range(0, 24), range(48, 54 + tL))))) return rc;
   if ((rc = upload_pairs(ctx, ctx->d_pairs[4], REP_NC + tC, cat(range(48, 54), range(55, 55 + tC))))) return rc;
   if ((rc = upload_pairs(ctx, ctx->d_pairs[5], CS_NC + tC, cat(range(0, 24), range(48, 60 + tC))))) return rc;
-  ctx->force_legacy = false;
+  ctx->force_legacy = false; ctx->fb_on = false; ctx->fb_mask = 0; ctx->fallback_rows = 0;
   { static const int zero[2] = {0, 0}; if ((rc = upload_tmp(ctx, ctx->d_zero, zero, 8))) return rc; }   // [0]: identity permutation of the single prior block, [1]: ticket of k_fold_all (returns to zero by itself)
   if ((rc = dev_alloc(ctx, ctx->d_imu_rtab, (size_t)64 * (ImuG::NTP * 4 + ImuA::NTP * 4) * 4))) return rc;
   hipLaunchKernelGGL(k_imu_rtab, dim3(1), dim3(64), 0, ctx->stream, (int*)ctx->d_imu_rtab.p);
@@ -2479,6 +2497,7 @@ DevCommon make_common(lvx_ctx* ctx, const double* state_d, uint32_t what) {
   cm.ord = (const int*)ctx->d_ord.p; cm.nb = ctx->nb; cm.bw = ctx->bw; cm.nbd = ctx->nbd_ext; cm.nbd_solve = ctx->nbd; cm.hubs = ctx->d_hubs.p; cm.pre = (const So3Pre*)ctx->d_pre.p;
   cm.Hb = (double*)ctx->d_Hb.p; cm.gb = (double*)ctx->d_gb.p; cm.Bd = (double*)ctx->d_Bd.p; cm.C = (double*)ctx->d_C.p; cm.gc = (double*)ctx->d_gc.p;
   cm.cost = (double*)ctx->d_cost.p; cm.err = (int*)ctx->d_err.p;
+  cm.fb_list = ctx->fb_on ? (int*)ctx->d_fb.p : nullptr; cm.fb_cap = LVX_FB_CAP | (ctx->fb_mask << 16);   // (capacity | families with a list << 16)
   cm.lmH = (double*)ctx->d_lmH.p; cm.lm_p0 = (const int*)ctx->d_lm_p0.p; cm.lm_wl = ctx->lm_wl; cm.lm_ls = ctx->lm_ls;
   cm.hub_lo = 0; cm.hub_hi = ctx->nb; cm.nrep = ctx->nrep;
   cm.residuals = nullptr; cm.jcols = nullptr; cm.jvals = nullptr;
@@ -2557,6 +2576,7 @@ __global__ __launch_bounds__(256) void k_clear(ClearList cl, BandClear bc, int n
   }
 }
 
+static bool fast_fb(const lvx_ctx* ctx, uint32_t what) { return ctx->fb_on && !ctx->force_legacy && !(what & LVX_EVAL_JACOBIAN) && !ctx->sw.force_legacy; }
 int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cost, bool want_res_buffer) {
   int rc = ensure_layout(ctx);
   if (rc) return rc;
@@ -2581,6 +2601,7 @@ int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cos
   auto enqueue = [&]() -> int {
     int rc = LVX_OK;
     const bool fast = !ctx->force_legacy && !(what & LVX_EVAL_JACOBIAN) && !ctx->sw.force_legacy;
+    const bool fb = fast_fb(ctx, what);   // row-level exact fallback: the per-segment kernel follows every fused kernel over its fallback list
     // free time offsets need d pose / d t at both evaluations: one more global column in the fused LiDAR / camera-surfel kernels (SurfAccT<true>, CamSurfAccT<true>);
     // the reprojection path a time-offset column in its materialised rows; FORCE_LEGACY: the per-segment TAU kernels for everything
     const bool tauL = !(ctx->locks & LVX_LOCK_LIDAR_TAU), tauC = !(ctx->locks & LVX_LOCK_CAM_TAU);
@@ -2595,7 +2616,7 @@ int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cos
       ClearList cl{};
       BandClear bc{};
       auto add = [&](void* p, size_t bytes) { if (cl.n < 16) { cl.p[cl.n] = (uint4*)p; cl.words[cl.n] = (bytes + 15) / 16; cl.n++; } };
-      add(cm.cost, (size_t)ctx->nrep * 8); add(cm.err, 16);
+      add(cm.cost, (size_t)ctx->nrep * 8); add(cm.err, 64);
       if (what & LVX_EVAL_NORMAL_EQ) {
         const size_t nb1 = (size_t)std::max(ctx->nb, 1);
         if (ctx->sw.clear_all || ctx->nb == 0) add(cm.Hb, nb1 * (ctx->bw + 1) * 8);
@@ -2606,7 +2627,8 @@ int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cos
           if (!bc.nblk) { bc.colfull = (const uint8_t*)ctx->d_colfull.p; bc.nb = ctx->nb; bc.ld = ctx->bw + 1; bc.npre = ctx->clear_npre; bc.nblk = std::min((ctx->nb + 15) / 16, 2048); }
         } else add(cm.gb, nb1 * 8);
         // hub rows of Bd: with the fused LiDAR kernels only the fold fills them beyond the near range — it stores there, the clear skips them
-        const bool hub_partial = !ctx->sw.clear_all && !(nb1 & 1) && ctx->nb > 0 && ctx->n_hub > 0 && (fast_surf || fast_cs) && (ctx->surf.n == 0 || fast_surf) && (ctx->cs.n == 0 || fast_cs);
+        const bool fb_lidar = fb && (ctx->fb_mask & ((1 << LVX_FAM_SURFEL) | (1 << LVX_FAM_CAMSURF)));   // listed LiDAR rows add to the hub rows directly, anywhere
+        const bool hub_partial = !fb_lidar && !ctx->sw.clear_all && !(nb1 & 1) && ctx->nb > 0 && ctx->n_hub > 0 && (fast_surf || fast_cs) && (ctx->surf.n == 0 || fast_surf) && (ctx->cs.n == 0 || fast_cs);
         cm.hub_lo = hub_partial ? ctx->hub_near_lo : 0; cm.hub_hi = hub_partial ? ctx->hub_near_hi : ctx->nb;
         if (hub_partial) { bc.Bd = cm.Bd; bc.hub_rows = 6 * ctx->n_hub; bc.hub_lo = cm.hub_lo; bc.hub_hi = cm.hub_hi; bc.hub_blk = cm.hub_hi > cm.hub_lo ? 6 * ctx->n_hub : 0; if (!bc.nb) bc.nb = ctx->nb; }
         // border rows: only the rows some residual can reach (a locked calibration scalar and an unused pseudo-pose set keep their zeros); 16-byte words: whole rows when nb is even
@@ -2630,6 +2652,20 @@ int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cos
                          (HubShared*)ctx->d_hubs.p);
     }
     auto grid = [](int n) { return dim3((unsigned)((n + 63) / 64)); };
+    // exact per-segment kernel over the rows a fused kernel put on family f's fallback list (row-level fallback: enabled after the first pass that needed it)
+    const dim3 fb_grid((unsigned)(LVX_FB_CAP / 64));
+    const int* fb_rows_base = (const int*)ctx->d_fb.p;
+    auto fb_rows = [&](int f) { return fb_rows_base + (size_t)f * LVX_FB_CAP; };
+    auto fb_cnt = [&](int f) { return (const int*)cm.err + 4 + f; };
+    auto fb_fam = [&](int f) { return fb && ((ctx->fb_mask >> f) & 1); };
+    // The listed rows are evaluated by the (slow: 40-100 us for a single block) per-segment kernels on a SIDE stream, right behind the fused kernel that filled the list and
+    // beside the rest of the pass; they join in front of the fold and add to the same accumulators as everything else.  What the pass STORES instead of adding to is
+    // arranged accordingly: k_imu_own's columns are stored before the IMU lists run, the fold's store of the far hub rows is switched off when a LiDAR family has a list
+    // (hub_partial below), the landmark rows are stored by k_reproj_lmrows on the chain before the reprojection list runs there.
+    hipStream_t s_fb = (sw.serial || det) ? st : ctx->fam_stream[1];
+    bool fb_used = false;
+    int fb_ev = 0;
+    auto fb_fork = [&]() -> int { if (s_fb != st) { LVX_HIP(ctx, hipEventRecord(ctx->ev_fb[fb_ev], st)); LVX_HIP(ctx, hipStreamWaitEvent(s_fb, ctx->ev_fb[fb_ev], 0)); fb_ev ^= 1; fb_used = true; } return LVX_OK; };
     if (imu_fused_on) {   // gyroscope + accelerometer blocks in one owner-computes kernel, FIRST on the band: it stores what it owns (k_imu_own)
       const ImuFused f{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, ctx->imu.huber /*w_acc*/};
       const size_t lds_ = imu_fused_lds_bytes(ctx->imu_span);
@@ -2637,6 +2673,14 @@ int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cos
       const ImuOwn ow{(const int*)ctx->d_imu_wg.p, imu_own ? (const int*)ctx->d_imu_own.p + ctx->imu_own_k_off : nullptr, ctx->imu_nch, ctx->imu_span};
       ProfScope ps(ctx, LVX_FAM_GYRO, st);
       hipLaunchKernelGGL(k_imu_own, dim3(ctx->imu_wg), dim3(256), lds_, st, f, cm, (const int*)ctx->d_imu_chunk.p, ow, (long long)ctx->fam_row0[0], (long long)ctx->fam_row0[1], det ? 1 : 0, (const int*)ctx->d_imu_rtab.p);
+      if (fb_fam(LVX_FAM_GYRO)) {   // listed samples: both blocks by the exact kernels (they ADD to what k_imu_own stored)
+        if ((rc = fb_fork())) return rc;
+        ProfScope psf(ctx, LVX_KERNEL_FIXUP, s_fb);
+        GyroFam gf{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
+        hipLaunchKernelGGL((k_family<GyroFam, 1>), fb_grid, dim3(64), 0, s_fb, gf, cm, (const uint16_t*)ctx->d_pairs[0].p, (long long)ctx->fam_row0[0], fb_rows(LVX_FAM_GYRO), fb_cnt(LVX_FAM_GYRO));
+        AccelFam af{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_b3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.huber /*w_acc*/, 0.0};
+        hipLaunchKernelGGL((k_family<AccelFam, LVX_PW>), fb_grid, dim3(64 * LVX_PW), 0, s_fb, af, cm, (const uint16_t*)ctx->d_pairs[1].p, (long long)ctx->fam_row0[1], fb_rows(LVX_FAM_GYRO), fb_cnt(LVX_FAM_GYRO));
+      }
     }
     // Schedule.  ONE chain on the caller's stream — clear -> fused IMU kernel (stores its band columns) -> prior -> LiDAR kernels -> reprojection Jacobian -> observation
     // pass -> cross terms -> landmark rows -> fold — and ONE side stream that takes the reprojection reference pass (it only reads the materialised rows and adds
@@ -2667,6 +2711,10 @@ int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cos
       if (fast) {
         GyroAcc g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
         ProfScope ps(ctx, LVX_FAM_GYRO, st); LVX_LAUNCH_MFMA(GyroAcc, g, LVX_FAM_GYRO, st, ctx->fam_row0[0]);
+        if (fb_fam(LVX_FAM_GYRO)) { if ((rc = fb_fork())) return rc;
+          ProfScope psf(ctx, LVX_KERNEL_FIXUP, s_fb);
+          GyroFam gf{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
+          hipLaunchKernelGGL((k_family<GyroFam, 1>), fb_grid, dim3(64), 0, s_fb, gf, cm, (const uint16_t*)ctx->d_pairs[0].p, (long long)ctx->fam_row0[0], fb_rows(LVX_FAM_GYRO), fb_cnt(LVX_FAM_GYRO)); }
       } else {
         GyroFam g{ctx->imu.n, (const double*)ctx->imu.d_t.p, (const double*)ctx->imu.d_a3.p, (const int*)ctx->imu.d_perm.p, ctx->imu.weight, 0.0};
         ProfScope ps(ctx, LVX_FAM_GYRO, st);
@@ -2690,9 +2738,13 @@ int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cos
       if (fast_surf && tauL) {
         SurfAccT<true> f{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const double*)ctx->surf.d_b3.p, (const int*)ctx->surf.d_perm.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
         LVX_LAUNCH_MFMA(SurfAccT<true>, f, LVX_FAM_SURFEL, st, ctx->fam_row0[3]);
+        if (fb_fam(LVX_FAM_SURFEL)) { if ((rc = fb_fork())) return rc; ProfScope psf(ctx, LVX_KERNEL_FIXUP, s_fb); SurfFamT<true> ff{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p, (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
+          hipLaunchKernelGGL((k_family<SurfFamT<true>, LVX_PW>), fb_grid, dim3(64 * LVX_PW), 0, s_fb, ff, cm, (const uint16_t*)ctx->d_pairs[3].p, (long long)ctx->fam_row0[3], fb_rows(LVX_FAM_SURFEL), fb_cnt(LVX_FAM_SURFEL)); }
       } else if (fast_surf) {
         SurfAcc f{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const double*)ctx->surf.d_b3.p, (const int*)ctx->surf.d_perm.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
         LVX_LAUNCH_MFMA(SurfAcc, f, LVX_FAM_SURFEL, st, ctx->fam_row0[3]);
+        if (fb_fam(LVX_FAM_SURFEL)) { if ((rc = fb_fork())) return rc; ProfScope psf(ctx, LVX_KERNEL_FIXUP, s_fb); SurfFam ff{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p, (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
+          hipLaunchKernelGGL((k_family<SurfFam, LVX_PW>), fb_grid, dim3(64 * LVX_PW), 0, s_fb, ff, cm, (const uint16_t*)ctx->d_pairs[3].p, (long long)ctx->fam_row0[3], fb_rows(LVX_FAM_SURFEL), fb_cnt(LVX_FAM_SURFEL)); }
       } else if (tauL) {
         SurfFamT<true> f{ctx->surf.n, (const double*)ctx->surf.d_t.p, (const double*)ctx->surf.d_a3.p, (const int*)ctx->surf.d_id0.p, (const int*)ctx->surf.d_perm.p, (const double*)ctx->d_planes.p, ctx->t_map, ctx->surf.weight, ctx->surf.huber};
         hipLaunchKernelGGL((k_family<SurfFamT<true>, 1>), grid(f.n), dim3(64), 0, st, f, cm, (const uint16_t*)ctx->d_pairs[3].p, (long long)ctx->fam_row0[3]);
@@ -2707,9 +2759,13 @@ int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cos
       if (fast_cs && tauC) {
         CamSurfAccT<true> f{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p, (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
         LVX_LAUNCH_MFMA(CamSurfAccT<true>, f, LVX_FAM_CAMSURF, st, ctx->fam_row0[5]);
+        if (fb_fam(LVX_FAM_CAMSURF)) { if ((rc = fb_fork())) return rc; ProfScope psf(ctx, LVX_KERNEL_FIXUP, s_fb); CamSurfFamT<true> ff{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p, (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
+          hipLaunchKernelGGL((k_family<CamSurfFamT<true>, LVX_PW>), fb_grid, dim3(64 * LVX_PW), 0, s_fb, ff, cm, (const uint16_t*)ctx->d_pairs[5].p, (long long)ctx->fam_row0[5], fb_rows(LVX_FAM_CAMSURF), fb_cnt(LVX_FAM_CAMSURF)); }
       } else if (fast_cs) {
         CamSurfAcc f{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p, (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
         LVX_LAUNCH_MFMA(CamSurfAcc, f, LVX_FAM_CAMSURF, st, ctx->fam_row0[5]);
+        if (fb_fam(LVX_FAM_CAMSURF)) { if ((rc = fb_fork())) return rc; ProfScope psf(ctx, LVX_KERNEL_FIXUP, s_fb); CamSurfFam ff{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p, (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
+          hipLaunchKernelGGL((k_family<CamSurfFam, LVX_PW>), fb_grid, dim3(64 * LVX_PW), 0, s_fb, ff, cm, (const uint16_t*)ctx->d_pairs[5].p, (long long)ctx->fam_row0[5], fb_rows(LVX_FAM_CAMSURF), fb_cnt(LVX_FAM_CAMSURF)); }
       } else if (tauC) {
         CamSurfFamT<true> f{ctx->cs.n, (const int*)ctx->cs.d_id0.p, (const int*)ctx->cs.d_id1.p, (const int*)ctx->cs.d_perm.p, (const double*)ctx->d_planes.p, (const double*)ctx->d_lm_uv.p, (const double*)ctx->d_lm_t0.p, ctx->t_map, ctx->cs.weight, ctx->cs.huber};
         hipLaunchKernelGGL((k_family<CamSurfFamT<true>, 1>), grid(f.n), dim3(64), 0, st, f, cm, (const uint16_t*)ctx->d_pairs[5].p, (long long)ctx->fam_row0[5]);
@@ -2773,12 +2829,21 @@ int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cos
         hipLaunchKernelGGL(k_reproj_fused<T>, dim3((unsigned)std::min((ng + 3) / 4, ncu)), dim3(256), 0, st, rf, q, cm, (long long)ctx->fam_row0[4]);
         return LVX_OK;
       };
+      auto rep_fixup = [&]() {   // listed blocks by the exact kernel, behind the landmark rows' stores
+        if (!fb_fam(LVX_FAM_REPROJ)) return;
+        ProfScope psf(ctx, LVX_KERNEL_FIXUP, st);
+        if (tauC) { ReprojFamT<true> rt{r.n, r.lm, r.uv, r.t0o, r.perm, r.lm_uv, r.lm_t0, r.weight, r.huber};
+          hipLaunchKernelGGL((k_family<ReprojFamT<true>, LVX_PW>), fb_grid, dim3(64 * LVX_PW), 0, st, rt, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4], fb_rows(LVX_FAM_REPROJ), fb_cnt(LVX_FAM_REPROJ)); }
+        else hipLaunchKernelGGL((k_family<ReprojFam, LVX_PW>), fb_grid, dim3(64 * LVX_PW), 0, st, r, cm, (const uint16_t*)ctx->d_pairs[4].p, (long long)ctx->fam_row0[4], fb_rows(LVX_FAM_REPROJ), fb_cnt(LVX_FAM_REPROJ));
+      };
       if (fast && ctx->rep_fused_wg > 0) {
         const int rcf = tauC ? rep_one(std::true_type{}) : rep_one(std::false_type{});
         if (rcf) return rcf;
+        rep_fixup();
       } else if (fast) {
         const int rcf = tauC ? rep_fused(std::true_type{}) : rep_fused(std::false_type{});
         if (rcf) return rcf;
+        rep_fixup();
       } else if (tauC) {
         ProfScope ps(ctx, LVX_FAM_REPROJ, st);
         ReprojFamT<true> rt{r.n, r.lm, r.uv, r.t0o, r.perm, r.lm_uv, r.lm_t0, r.weight, r.huber};
@@ -2789,6 +2854,7 @@ int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cos
       }
     }
     if (side_used) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[0], s_side)); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[0], 0)); }
+    if (fb_used) { LVX_HIP(ctx, hipEventRecord(ctx->ev_join[2], s_fb)); LVX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[2], 0)); }
     { ProfScope ps(ctx, LVX_KERNEL_FOLD);
       const bool fold_fast = (what & LVX_EVAL_NORMAL_EQ) && (fast_surf || fast_cs);
       // replica sums -> dense block (the last replica block to finish) and the border-row fold (Bd, streaming; disjoint buffers) in one launch
@@ -2820,7 +2886,7 @@ int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cos
   const bool use_graph = !ctx->sw.no_graph && !ctx->profiling && !(what & LVX_EVAL_JACOBIAN) && ctx->n_blocks <= 400000;
   if (!use_graph) { if ((rc = enqueue())) return rc; }
   else {
-    const int flags = (want_res_buffer ? 1 : 0) | (ctx->force_legacy ? 2 : 0);   // a switch change bumps cfg_version
+    const int flags = (want_res_buffer ? 1 : 0) | (ctx->force_legacy ? 2 : 0) | (ctx->fb_on ? 4 : 0) | (ctx->fb_mask << 3);   // a switch change bumps cfg_version
     hipGraphExec_t exec = nullptr;
     for (const auto& e : ctx->graphs) if (e.state == state_d && e.what == what && e.flags == flags && e.cfg == ctx->cfg_version) { exec = (hipGraphExec_t)e.exec; break; }
     if (!exec) {
@@ -2842,13 +2908,19 @@ int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cos
   ctx->last_state_d = state_d; ctx->last_want_res = want_res_buffer;
   ctx->err_unchecked = cost == nullptr;   // the device error word of this pass has not been looked at yet (check_last_eval)
   if (cost) {
-    double c = 0; int err[4] = {0, 0, 0, 0};
+    double c = 0; int err[16] = {0};
     LVX_HIP(ctx, hipMemcpyAsync(&c, cm.cost, 8, hipMemcpyDeviceToHost, st));
-    LVX_HIP(ctx, hipMemcpyAsync(err, cm.err, 4, hipMemcpyDeviceToHost, st));
+    LVX_HIP(ctx, hipMemcpyAsync(err, cm.err, 4 * (4 + LVX_NUM_FAM), hipMemcpyDeviceToHost, st));
     LVX_HIP(ctx, hipStreamSynchronize(st));
     *cost = c;
-    if ((err[0] & LVX_ERR_FALLBACK) && !ctx->force_legacy) {   // corner only the per-segment kernels handle exactly: redo this evaluation with them
-      ctx->force_legacy = true;
+    ctx->fallback_rows = 0; for (int f = 0; f < LVX_NUM_FAM; ++f) ctx->fallback_rows += err[4 + f];
+    if ((err[0] & LVX_ERR_FALLBACK) && !ctx->force_legacy) {
+      // rows the fused kernels cannot take exactly.  First the ROW-LEVEL fallback: the same pass with fallback lists — the fused kernels skip those rows, the exact
+      // per-segment kernel evaluates just them (a few small launches more per pass from now on).  Only when the lists overflow, or for a corner that is not a row's
+      // (|tau_imu| >= dt), everything goes to the per-segment kernels.
+      int need = 0; for (int f = 0; f < LVX_NUM_FAM; ++f) if (err[4 + f] > 0) need |= 1 << f;
+      if (!ctx->sw.force_legacy && need && (need & ~ctx->fb_mask)) { ctx->fb_on = true; ctx->fb_mask |= need; }   // a family without a list yet: give it one
+      else ctx->force_legacy = true;                                                                              // a list overflowed, or the corner is not a row's
       return run_evaluate(ctx, state_d, what, cost, want_res_buffer);
     }
     if (err[0] & RES_RANGE) return fail(ctx, LVX_E_RANGE, "time span out of range for trajectory");
@@ -2868,7 +2940,10 @@ int check_last_eval(lvx_ctx* c) {
   LVX_HIP(c, hipStreamSynchronize(c->stream));
   c->err_unchecked = false;
   if ((err & LVX_ERR_FALLBACK) && !c->force_legacy) {
-    c->force_legacy = true;
+    int errw[4 + LVX_NUM_FAM] = {0}, need = 0;
+    LVX_HIP(c, hipMemcpy(errw, c->d_err.p, sizeof(errw), hipMemcpyDeviceToHost));
+    for (int f = 0; f < LVX_NUM_FAM; ++f) if (errw[4 + f] > 0) need |= 1 << f;
+    if (!c->sw.force_legacy && need && (need & ~c->fb_mask)) { c->fb_on = true; c->fb_mask |= need; } else c->force_legacy = true;
     double cost = 0;
     return run_evaluate(c, c->last_state_d, c->last_what, &cost, c->last_want_res);
   }

@@ -27,8 +27,8 @@ LOCK_LANDMARKS = 1 << 10
 
 EVAL_COST, EVAL_RESIDUALS, EVAL_NORMAL_EQ, EVAL_JACOBIAN = 1, 2, 4, 8
 (FAM_GYRO, FAM_ACCEL, FAM_PRIOR, FAM_SURFEL, FAM_REPROJ, FAM_CAMSURF, KERNEL_FOLD, KERNEL_SOLVE, KERNEL_UPSTREAM, KERNEL_CLEAR, KERNEL_REP_JAC, KERNEL_REP_OBS,
- KERNEL_REP_REF, KERNEL_REP_CROSS, KERNEL_REP_LMROWS, KERNEL_REP_FUSED) = range(16)
-KERNEL_NAMES = ["gyro", "accel", "prior", "surfel", "reproj", "camsurf", "fold", "solve", "upstream", "clear", "reproj_jac", "reproj_obs", "reproj_ref", "reproj_cross", "reproj_lmrows", "reproj_fused"]
+ KERNEL_REP_REF, KERNEL_REP_CROSS, KERNEL_REP_LMROWS, KERNEL_REP_FUSED, KERNEL_FIXUP) = range(17)
+KERNEL_NAMES = ["gyro", "accel", "prior", "surfel", "reproj", "camsurf", "fold", "solve", "upstream", "clear", "reproj_jac", "reproj_obs", "reproj_ref", "reproj_cross", "reproj_lmrows", "reproj_fused", "fixup"]
 JAC_WIDTH = 64
 
 
@@ -41,7 +41,7 @@ class Pinhole(C.Structure):
 class Layout(C.Structure):
     _fields_ = [("n_knots", C.c_int32), ("n_landmarks", C.c_int32), ("n_tangent", C.c_int32), ("n_band", C.c_int32),
                 ("bandwidth", C.c_int32), ("n_border", C.c_int32), ("border_ld", C.c_int32), ("n_hub_knots", C.c_int32), ("hub_knot0", C.c_int32),
-                ("n_blocks", C.c_int64), ("n_residuals", C.c_int64), ("exact_fallback", C.c_int32), ("solver_fallbacks", C.c_int32)]
+                ("n_blocks", C.c_int64), ("n_residuals", C.c_int64), ("exact_fallback", C.c_int32), ("solver_fallbacks", C.c_int32), ("fallback_rows", C.c_int32)]
 
 
 class LmOptions(C.Structure):

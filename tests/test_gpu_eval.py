@@ -227,7 +227,8 @@ def test_merged_hub_segment_corner_takes_the_exact_fallback():
         assert abs(rg["cost"] - ro["cost"]) <= 1e-12 * abs(ro["cost"])
         assert np.abs(rg["residuals"] - ro["residuals"]).max() <= 1e-11 * np.abs(ro["residuals"]).max()
         assert np.abs(rg["H"] - ro["H"]).max() <= 1e-10 * np.abs(ro["H"]).max()
-    assert g.layout()["exact_fallback"] == 1          # the corner was detected, not missed
+    lo = g.layout()
+    assert lo["exact_fallback"] == 0 and 0 < lo["fallback_rows"] <= 40   # the corner was detected, not missed — and only ITS rows left the fused kernels
     g.close()
 
 
@@ -250,7 +251,29 @@ def test_large_control_point_rotation_takes_the_exact_fallback():
         assert np.abs(rg["residuals"] - ro["residuals"]).max() <= 1e-11 * np.abs(ro["residuals"]).max()
         assert np.abs(rg["H"] - ro["H"]).max() <= 1e-10 * np.abs(ro["H"]).max()
         assert np.abs(rg["g"] - ro["g"]).max() <= 1e-10 * np.abs(ro["g"]).max()
+    lo = g.layout()
+    # the rows whose 4-knot window holds the wide pair — IMU samples, surfel points, views — went to the exact kernel one by one; everything else stayed fused
+    assert lo["exact_fallback"] == 0 and 0 < lo["fallback_rows"] < 0.2 * lo["n_blocks"]
+    g.close()
+
+
+def test_more_fallback_rows_than_the_lists_hold_take_the_per_segment_kernels():
+    """Every control point turned by 2 rad against its neighbour: every row of every family is beyond the fused kernels' polynomials, the lists (4 096 rows per family)
+    overflow and the whole pass is redone by the per-segment kernels — same numbers."""
+    P = synth.make_problem(seed=34, duration=12.0, n_surfel=300, n_planes=6, n_landmarks=10, n_camsurf=0)
+    assert len(P["t_imu"]) > 4096
+    o, g = _pair(P, TAU_LOCKS, prior=False)
+    N = P["n_knots"]
+    s = P["state0"].copy()
+    for k in range(1, N, 2):
+        q = s[3 * N + 4 * k:3 * N + 4 * k + 4].copy()
+        s[3 * N + 4 * k:3 * N + 4 * k + 4] = synth.qmul(synth.q_from_rotvec(np.array([0.0, 0.0, 2.0])), q)
+    ro = o.evaluate(s, normal_eq=True)
+    rg = g.evaluate(s, normal_eq=True)
     assert g.layout()["exact_fallback"] == 1
+    assert abs(rg["cost"] - ro["cost"]) <= 1e-12 * abs(ro["cost"])
+    assert np.abs(rg["residuals"] - ro["residuals"]).max() <= 1e-11 * np.abs(ro["residuals"]).max()
+    assert np.abs(rg["H"] - ro["H"]).max() <= 1e-10 * np.abs(ro["H"]).max()
     g.close()
 
 

@@ -103,3 +103,47 @@ def test_one_lm_step_reduces_the_cost_as_predicted(bench_problem):
     c1 = g.evaluate(g.plus(P["state0"], d))["cost"]
     assert 0.5 < (c0 - c1) / m < 1.5          # gain ratio of the first (strongly nonlinear) step
     g.close()
+
+
+def test_one_wide_control_point_pair_does_not_slow_the_pass(bench_problem):
+    """one control-point pair beyond the fused kernels' small-angle polynomials (0.8 rad) used to send EVERY family of EVERY later pass to the per-segment
+    kernels (5-9 x slower), silently.  Now only the rows whose 4-knot window holds that pair leave the fused kernels (row-level fallback lists, lvx_layout::fallback_rows):
+    the pass must cost less than 10 % more than without the wide pair, and agree with the per-segment kernels' result."""
+    import time
+    P = bench_problem
+    N = P["n_knots"]
+    s = P["state0"].copy()
+    k = N // 2
+    q = s[3 * N + 4 * k:3 * N + 4 * k + 4].copy()
+    s[3 * N + 4 * k:3 * N + 4 * k + 4] = synth.qmul(synth.q_from_rotvec(np.array([0.0, 0.0, 2.0])), q)
+    what = lvx.EVAL_COST | lvx.EVAL_NORMAL_EQ
+
+    def timed(ctx, passes=30):
+        for _ in range(3):
+            ctx.evaluate_resident(what)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            ctx.evaluate_resident(what)
+        ctx.synchronize()
+        return (time.perf_counter() - t0) / passes
+    g = lvx.Context(0)
+    lvx.load_problem(g, P, TAU)
+    g.set_state(P["state0"])
+    g.evaluate_resident(what, want_cost=True)
+    assert g.layout()["fallback_rows"] == 0
+    t_plain = min(timed(g) for _ in range(3))
+    g.set_state(s)
+    c_fast = g.evaluate_resident(what, want_cost=True)          # discovers the wide pair, switches the lists on, repeats the pass
+    d_fast, m_fast = g.solve_step(1e4, True)
+    lo = g.layout()
+    assert lo["exact_fallback"] == 0 and 0 < lo["fallback_rows"] < 2000      # ~4 intervals of IMU samples, surfel points and views
+    t_wide = min(timed(g) for _ in range(3))
+    print("pass %.4f ms, with one wide pair %.4f ms (%d rows on the fallback lists)" % (1e3 * t_plain, 1e3 * t_wide, lo["fallback_rows"]))
+    assert t_wide < 1.10 * t_plain
+    g.set_switch("FORCE_LEGACY", 1)
+    c_ref = g.evaluate_resident(what, want_cost=True)
+    d_ref, m_ref = g.solve_step(1e4, True)
+    assert abs(c_fast - c_ref) <= 1e-12 * abs(c_ref) and abs(m_fast - m_ref) <= 1e-9 * abs(m_ref)
+    assert np.abs(d_fast - d_ref).max() <= 1e-7 * np.abs(d_ref).max()
+    g.close()

@@ -113,3 +113,66 @@ def test_sequential_band_cholesky_gives_the_same_step(full):
     print("BCR vs sequential band Cholesky: max block-scaled step difference %.3e" % rel.max())
     assert rel.max() <= 1e-7
     assert abs(m1 - m2) <= 1e-9 * abs(m2)
+
+
+# ---- BASELINE config 3 at full size: the IMU-only layout bench.py times (secondary.config3_imu_only) — no hub knots, k_imu_own owns every band column ----
+C3_LOCKS = lvx.LOCK_LIDAR_TAU | lvx.LOCK_CAM_TAU | lvx.LOCK_LIDAR_Q | lvx.LOCK_LIDAR_P | lvx.LOCK_CAM_Q | lvx.LOCK_CAM_P | lvx.LOCK_LANDMARKS
+
+
+@pytest.fixture(scope="module")
+def config3():
+    P = synth.make_bench_problem(seed=4)
+    Q = dict(P)
+    Q.update(surf_pt=P["surf_pt"][:0], surf_t=P["surf_t"][:0], surf_plane=P["surf_plane"][:0], rep_lm=P["rep_lm"][:0], rep_uv=P["rep_uv"][:0], rep_t0=P["rep_t0"][:0],
+             cs_lm=P["cs_lm"][:0], cs_plane=P["cs_plane"][:0])      # exactly bench.py's construction
+    g = lvx.Context(0)
+    o = O.Oracle()
+    for obj in (g, o):
+        lvx.load_problem(obj, Q, C3_LOCKS)
+    x = P["state0"]
+    rg = g.evaluate(x, normal_eq=True, dense=False)
+    gg, dg = g.gradient()
+    step = g.solve_step(RADIUS, True)
+    lo, rows = g.layout(), g.family_rows()
+    g.close()
+    ro = o.evaluate_products(x, V=np.stack([step[0]]))
+    return dict(rg=rg, gg=gg, dg=dg, step=step, ro=ro, lo=lo, rows=rows, n_blocks=o.num_blocks)
+
+
+def test_config3_full_size_matches_the_oracle(config3):
+    """200 k gyroscope + 200 k accelerometer blocks on 25 k knots: every residual row, the cost, g = J^T r and diag(J^T J) of the HIP pass against the oracle's
+    dual-number evaluation (kontiki/measurements/gyroscope_measurement.h:36-38, accelerometer_measurement.h:39-41, sensors/imu.h:61-101)."""
+    rg, ro, lo = config3["rg"], config3["ro"], config3["lo"]
+    assert lo["n_blocks"] == config3["n_blocks"] == 400_000 and lo["exact_fallback"] == 0 and lo["n_hub_knots"] == 0
+    assert len(rg["residuals"]) == len(ro["residuals"]) == 1_200_000
+    err = np.abs(rg["residuals"] - ro["residuals"])
+    rows = config3["rows"]
+    for f, name in ((0, "gyro"), (1, "accel")):
+        a, b = rows[f], rows[f + 1]
+        scale = np.abs(ro["residuals"][a:b]).max()
+        print("%-5s %7d rows: max |err| / max |r| = %.3e" % (name, b - a, err[a:b].max() / scale))
+        assert b - a == 600_000 and err[a:b].max() <= 1e-11 * scale
+    assert abs(rg["cost"] - ro["cost"]) <= 1e-12 * abs(ro["cost"])
+    n = lo["n_knots"]
+    for name, a, b in (("g", config3["gg"], ro["g"]), ("diag", config3["dg"], ro["diag"])):
+        rel = np.abs(a - b) / _block_scale(b, n)
+        print("%s: max block-scaled err %.3e" % (name, rel.max()))
+        assert rel.max() <= 1e-10
+    # locked blocks stay out: LiDAR / camera extrinsics and the landmarks have no gradient, the IMU calibration has
+    base = 6 * n
+    assert not config3["gg"][base + 8:].any() and config3["gg"][base:base + 8].all()
+
+
+def test_config3_step_solves_the_oracles_damped_system(config3):
+    ro = config3["ro"]
+    delta, mcc = config3["step"]
+    H_delta, g, diag = ro["HV"][0], ro["g"], ro["diag"]
+    S = 1.0 / (1.0 + np.sqrt(diag))
+    D = np.clip(S * S * diag, 1e-6, 1e32) / RADIUS
+    res = S * H_delta + D * (delta / S) + S * g
+    free = diag > 0
+    rel = np.linalg.norm(res[free]) / np.linalg.norm((S * g)[free])
+    model = -(g @ delta) - 0.5 * (delta @ H_delta)
+    print("config 3 step: |residual| / |S g| = %.3e, model cost change %.9e (lvx %.9e)" % (rel, model, mcc))
+    assert rel <= 1e-8 and not delta[~free].any()
+    assert abs(model - mcc) <= 1e-8 * abs(model) and model > 0
