@@ -139,6 +139,7 @@ struct lvx_ctx {
   // upstream kernels (lvx_upstream.hip)
   lvx::DevBuf d_up[8];
   size_t assoc_rings = 0; int assoc_wpr = 0, assoc_list_total = 0;
+  int coresident_compact = -1, coresident_emit = -1;   // workgroups of k_surfel_compact_mb / k_assoc_emit_fused the device holds at once (occupancy API x CUs, with a margin): both spin on words published by every other workgroup of their launch
   lvx::DevBuf d_pub; unsigned emit_epoch = 0, compact_epoch = 0;   // publication words (epoch | count) of the single-launch compactions: [0, 2048) k_assoc_emit_fused, [2048, 4096) k_surfel_compact_mb; zero once   // shape the association work buffer (d_assoc[3]) was cleared for
   const double* assoc_map_planes = nullptr; int assoc_map_P = 0; bool assoc_map_ready = false;   // lvx_surfel_map_prepare_d: the association grid of this plane table is built
   lvx::DevBuf d_assoc[4];   // surfel association: grid geometry + cell counts / offsets, cell lists, emission counters, hit bitmasks + counts (private: cleared once per shape)

@@ -515,7 +515,7 @@ template <bool TAU>
 __global__ __launch_bounds__(64) void k_reproj_jac(ReprojFamT<TAU> fam, DevCommon cm, double* Jb, double* rb, int* kb, long long row0, double* Trec) {
   constexpr int RJ = REP_NC + (TAU ? 1 : 0), RW = 56 + (TAU ? 1 : 0);
   constexpr int RS = RW | 1;           // odd LDS stride: a lane writes its record's words one instruction at a time
-  __shared__ double trec_s[64 * RS];
+  extern __shared__ double trec_s[];   // [64 * RS] when there are records to stage (Trec != null), nothing otherwise (29 KB of static LDS capped every launch at 5 workgroups per CU)
   const int lane = threadIdx.x, si = blockIdx.x * 64 + lane, n = fam.n;
   const int rep = blockIdx.x % cm.nrep;
   double mycost = 0.0;
@@ -2785,8 +2785,8 @@ int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cos
         double* Jb = (double*)ctx->d_repB[0].p; double* rb = Jb + (size_t)2 * RJ * r.n; int* kb = (int*)ctx->d_repB[1].p;
         { ProfScope ps(ctx, LVX_KERNEL_REP_JAC, st);
           const ReprojFamT<T> rf{r.n, r.lm, r.uv, r.t0o, r.perm, r.lm_uv, r.lm_t0, r.weight, r.huber};
-          hipLaunchKernelGGL(k_reproj_jac<T>, grid(r.n), dim3(64), 0, st, rf, cm, Jb, rb, kb, (long long)ctx->fam_row0[4],
-                             (ctx->L > 0 && !(ctx->locks & LVX_LOCK_LANDMARKS) && ctx->rep_groups > 0) ? (double*)ctx->d_repT.p : (double*)nullptr); }
+          double* trec = (ctx->L > 0 && !(ctx->locks & LVX_LOCK_LANDMARKS) && ctx->rep_groups > 0 && (what & LVX_EVAL_NORMAL_EQ)) ? (double*)ctx->d_repT.p : (double*)nullptr;
+          hipLaunchKernelGGL(k_reproj_jac<T>, grid(r.n), dim3(64), trec ? (size_t)64 * ((56 + (T ? 1 : 0)) | 1) * 8 : 0, st, rf, cm, Jb, rb, kb, (long long)ctx->fam_row0[4], trec); }
         if (!(what & LVX_EVAL_NORMAL_EQ)) return LVX_OK;
         const RepJac jac{Jb, rb, kb, r.n};
         if (s_side != st) { LVX_HIP(ctx, hipEventRecord(ctx->ev_jac, st)); LVX_HIP(ctx, hipStreamWaitEvent(s_side, ctx->ev_jac, 0)); side_used = true; }

@@ -1061,7 +1061,10 @@ static int local_after_eval(lvx_ctx* c, SolveWork& w, EvalLocal* e) {
   if (nl > 0) hipLaunchKernelGGL(k_lm_fetch_diag, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, (const double*)c->d_lmH.p, nl, c->lm_ls, c->lm_wl + c->nbd_ext, w.diag + n);
   int rc = local_gmax(c, w, &e->gm, e->hg); if (rc) return rc;
   if (is_joint(c) && ns > 0) LVX_HIP(c, hipMemcpyAsync(e->hd, w.diag + (n - ns), (size_t)ns * 8, hipMemcpyDeviceToHost, st));
-  if (is_joint(c) && w.constrained && c->last_state_d) {   // the shared time offsets' box enters the projected gradient of the SUMMED shared gradient (apply_diag)
+  // (keyed on the LOCKS, which every rank shares — a rank whose own sequence has no block that makes it constrained must project the summed shared gradient
+  // exactly as its peers do, or they disagree on gradient_tolerance convergence and part ways before the next collective)
+  const bool tau_free = !(c->locks & LVX_LOCK_LIDAR_TAU) || !(c->locks & LVX_LOCK_CAM_TAU);
+  if (is_joint(c) && (w.constrained || tau_free) && c->last_state_d) {   // the shared time offsets' box enters the projected gradient of the SUMMED shared gradient (apply_diag)
     LVX_HIP(c, hipMemcpyAsync(&e->tau[0], c->last_state_d + 7 * (size_t)c->N + 23, 8, hipMemcpyDeviceToHost, st));
     LVX_HIP(c, hipMemcpyAsync(&e->tau[1], c->last_state_d + 7 * (size_t)c->N + 31, 8, hipMemcpyDeviceToHost, st));
     e->have_tau = true;
@@ -1315,13 +1318,23 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
         double alpha = 1.0, fa = cand, ha[6] = {h[0], h[1], 0, 0, h[4], h[5]};
         const int ntg = lvx_tangent_size(c);
         std::vector<double> dh((size_t)ntg);
-        LVX_HIP(c, hipMemcpyAsync(dh.data(), w.delta, (size_t)ntg * 8, hipMemcpyDeviceToHost, st));
-        LVX_HIP(c, hipStreamSynchronize(st));
+        //  inside the joint protocol a local HIP error must not `return`: the peers would wait in the next reduction for ever.  It is kept (hip_ls), voted in
+        // the next collective, and every rank leaves together.
+        int hip_ls = LVX_OK;
+        auto hip_keep = [&](hipError_t e) { if (e != hipSuccess && !hip_ls) hip_ls = fail(c, LVX_E_HIP, std::string("line search: ") + hipGetErrorString(e)); };
+        hip_keep(hipMemcpyAsync(dh.data(), w.delta, (size_t)ntg * 8, hipMemcpyDeviceToHost, st));
+        hip_keep(hipStreamSynchronize(st));
         std::vector<double> dt((size_t)ntg);
-        // ArmijoLineSearch gives up when step * ||direction||_inf < min_line_search_step_size (1e-9); joint: the norm of the JOINT step (max over the ranks)
+        // ArmijoLineSearch gives up when step * ||direction||_inf < min_line_search_step_size (1e-9); joint: the norm of the JOINT step (max over the ranks; the second
+        // slot carries the vote of a rank that failed)
         double dinf = 0.0;
         for (int i = 0; i < ntg; ++i) dinf = std::max(dinf, std::fabs(dh[i]));
-        if (joint && (rc = reduce(c, &dinf, 1, LVX_REDUCE_MAX))) return rc;
+        if (joint) {
+          double dv[2] = {dinf, hip_ls ? 1.0 : 0.0};
+          if ((rc = reduce(c, dv, 2, LVX_REDUCE_MAX))) return rc;
+          if ((rc = leave_together(c, dv[1], hip_ls))) return rc;
+          dinf = dv[0];
+        } else if (hip_ls) return hip_ls;
         for (int trial = 1; trial <= 20 && !found; ++trial) {
           std::vector<LsSample> sm{{0.0, f0, g0, true}};
           if (have_prev) sm.push_back(prev);
@@ -1330,19 +1343,27 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
           if (o.verbose) fprintf(stderr, "[lvx lm] it %3d line search trial %d: f0 %.12e g0 %.12e | last step %.6e f %.12e df %.12e -> step %.12e\n", it, trial, f0, g0, cur.x, cur.f, cur.df, a);
           if (a * dinf < 1e-9) break;
           for (int i = 0; i < ntg; ++i) dt[i] = a * dh[i];
-          LVX_HIP(c, hipMemcpyAsync(w.delta, dt.data(), (size_t)ntg * 8, hipMemcpyHostToDevice, st));
-          LVX_HIP(c, hipMemsetAsync(w.sums + 2, 0, 48, st));
-          hipLaunchKernelGGL(k_plus, dim3((unsigned)((N + 1 + L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, N, L, c->locks, xt, w.sums, joint ? 1 : 0, c->sensor_mto, w.tk ? w.tk + 7 : nullptr);
+          int le = LVX_OK;
+          hip_ls = LVX_OK;
+          hip_keep(hipMemcpyAsync(w.delta, dt.data(), (size_t)ntg * 8, hipMemcpyHostToDevice, st));
+          hip_keep(hipMemsetAsync(w.sums + 2, 0, 48, st));
+          le = hip_ls;
+          if (!le) hipLaunchKernelGGL(k_plus, dim3((unsigned)((N + 1 + L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, N, L, c->locks, xt, w.sums, joint ? 1 : 0, c->sensor_mto, w.tk ? w.tk + 7 : nullptr);
           double f = 0, ga = 0.0, htr[6] = {0, 0, 0, 0, 0, 0};
-          int le = lvx_evaluate_d(c, xt, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &f);
+          if (!le) le = lvx_evaluate_d(c, xt, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &f);
           bool bad = le == LVX_E_RANGE || le == LVX_E_NONUNIT_QUAT;   // a trial that cannot be evaluated: contract again without a new sample
           if (bad) le = LVX_OK;
           if (!le && !bad && hipMemcpy(htr, w.sums + 2, 48, hipMemcpyDeviceToHost) != hipSuccess) le = LVX_E_HIP;
-          if (!le && !bad) {   // the directional derivative along the UNSCALED step (needed when the trial fails Armijo; joint: always taken, one reduction per trial)
-            LVX_HIP(c, hipMemcpyAsync(w.delta, dh.data(), (size_t)ntg * 8, hipMemcpyHostToDevice, st));
-            le = grad_dot(c, w, &ga);
-            if (!le) LVX_HIP(c, hipMemcpyAsync(w.delta, dt.data(), (size_t)ntg * 8, hipMemcpyHostToDevice, st));   // delta (device) stays the scaled step of this trial
-          }
+          // the directional derivative along the UNSCALED step is needed only when the trial fails Armijo.  Joint: taken with every trial, its sum rides on the trial's one
+          // reduction; single sequence: taken AFTER the test, by the trials that fail it — two copies of the step, a k_gdot launch and a stream sync less per
+          // accepted trial
+          auto take_ga = [&]() {
+            hip_ls = LVX_OK;
+            hip_keep(hipMemcpyAsync(w.delta, dh.data(), (size_t)ntg * 8, hipMemcpyHostToDevice, st));
+            if (!hip_ls) le = grad_dot(c, w, &ga); else le = hip_ls;
+            if (!le) { hip_keep(hipMemcpyAsync(w.delta, dt.data(), (size_t)ntg * 8, hipMemcpyHostToDevice, st)); le = hip_ls; }   // delta (device) stays the scaled step of this trial
+          };
+          if (joint && !le && !bad) take_ga();
           double f_g = f, ga_g = ga;
           if (joint) {
             double b4[4] = {(le || bad) ? 0.0 : f, (le || bad) ? 0.0 : ga, bad ? 1.0 : 0.0, 0.0};
@@ -1354,14 +1375,16 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
             for (int q = 0; q < 6; ++q) ha[q] = htr[q];
             alpha = a; fa = f; found = true; break;
           }
+          if (!joint) { take_ga(); if (le) return le; ga_g = ga; }
           prev = cur; have_prev = true; cur = LsSample{a, f_g, ga_g, true};
         }
         if (found) { cand = fa; for (int q = 0; q < 6; ++q) h[q] = ha[q]; }   // delta (device) = alpha x the trust-region step, xt and the accumulators belong to it
         else {   // no step satisfies Armijo: the full step stays (Ceres leaves delta alone) — put its candidate back
-          LVX_HIP(c, hipMemcpyAsync(w.delta, dh.data(), (size_t)ntg * 8, hipMemcpyHostToDevice, st));
-          LVX_HIP(c, hipMemsetAsync(w.sums + 2, 0, 48, st));
-          hipLaunchKernelGGL(k_plus, dim3((unsigned)((N + 1 + L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, N, L, c->locks, xt, w.sums, joint ? 1 : 0, c->sensor_mto, w.tk ? w.tk + 7 : nullptr);
-          int re3 = lvx_evaluate_d(c, xt, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &cand);
+          hip_ls = LVX_OK;
+          hip_keep(hipMemcpyAsync(w.delta, dh.data(), (size_t)ntg * 8, hipMemcpyHostToDevice, st));
+          hip_keep(hipMemsetAsync(w.sums + 2, 0, 48, st));
+          if (!hip_ls) hipLaunchKernelGGL(k_plus, dim3((unsigned)((N + 1 + L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, N, L, c->locks, xt, w.sums, joint ? 1 : 0, c->sensor_mto, w.tk ? w.tk + 7 : nullptr);
+          int re3 = hip_ls ? hip_ls : lvx_evaluate_d(c, xt, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &cand);
           if (!re3 && hipMemcpy(h, w.sums + 2, 48, hipMemcpyDeviceToHost) != hipSuccess) re3 = LVX_E_HIP;
           if (joint) { double b1[1] = {0.0}; if ((rc = jsum(b1, 1, re3))) return rc; } else if (re3) return re3;
         }
