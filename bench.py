@@ -696,11 +696,16 @@ def main():
                 ctx.collective_count(reset=True)
                 dist.barrier(); torch.cuda.synchronize()
                 tj = time.perf_counter()
-                _, smj = ctx.lm_solve_shared(sj, None if rccl_ok else sharded.dist_all_reduce(dist, torch.device("cuda", local_rank)), max_iterations=3)
+                xj, smj = ctx.lm_solve_shared(sj, None if rccl_ok else sharded.dist_all_reduce(dist, torch.device("cuda", local_rank)), max_iterations=3)
                 torch.cuda.synchronize(); dist.barrier()
                 tj = time.perf_counter() - tj
+                # the shared extrinsics every rank ended with: they must be THE SAME numbers (each rank solves the same reduced 14 x 14 system from the same reduction)
+                ext_all = [torch.zeros(16, dtype=torch.float64, device="cuda") for _ in range(world)]
+                dist.all_gather(ext_all, torch.from_numpy(np.ascontiguousarray(xj[7 * Nk + 16:7 * Nk + 32])).cuda())
+                ext_all = torch.stack(ext_all).cpu().numpy()
+                ext_spread = float(np.abs(ext_all - ext_all[0]).max())
                 sec_all["joint_lm_iteration"] = {"ms_per_iteration": 1e3 * tj / max(1, smj["iterations"]), "iterations": smj["iterations"], "initial_cost": smj["initial_cost"], "final_cost": smj["final_cost"],
-                                                 "collectives": int(ctx.collective_count()),
+                                                 "collectives": int(ctx.collective_count()), "ranks": world, "shared_extrinsics_max_spread_over_ranks": ext_spread,
                                                  "transport": "RCCL inside liblvx on the context's stream (lvx_rccl_init): reduced system packed, reduced and solved on the device" if rccl_ok else
                                                               "host callback (torch.distributed all_reduce of <= 211 doubles per reduction)",
                                                  "note": "joint LM over %d sequences with shared extrinsics: evaluate + private elimination per GPU, reduced 14 x 14 system + decision scalars over the ranks" % world}

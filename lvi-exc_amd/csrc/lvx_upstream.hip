@@ -2365,7 +2365,7 @@ int lvx_surfel_assoc_batch_d(lvx_ctx* c, int n_scans, int H, int W, const float*
 // resident at once.  The bound is asked of the runtime for THIS device (occupancy API x compute units; a partition or a smaller part has fewer) and taken with a margin of
 // one workgroup per CU (the API is a block high near a register-file edge: MI355X_MICROARCH.md), never above the size of the publication table; larger launches take the
 // single-workgroup / two-launch path.  (the bound was a hard-coded 8 x 256 CUs.)
-template <class K> static int coresident_bound(lvx_ctx* c, K kernel, int block, int table) {
+static int coresident_bound(lvx_ctx* c, const void* kernel, int block, int table) {
   int per_cu = 0, ncu = 0;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) ncu = prop.multiProcessorCount;
@@ -2391,7 +2391,7 @@ int lvx_surfel_emit_d(lvx_ctx* c, int n_scans, int H, int W, const int32_t* flag
   SurfelOut o{pt3_d, pt_map3_d, t_d, plane_d};
   const bool have_out = pt3_d && pt_map3_d && t_d && plane_d && max_out > 0;
   const int parts = (W + SE_COLS - 1) / SE_COLS;
-  if (c->coresident_emit < 0) c->coresident_emit = coresident_bound(c, k_assoc_emit_fused, SE_COLS, SE_MAXWG);
+  if (c->coresident_emit < 0) c->coresident_emit = coresident_bound(c, (const void*)k_assoc_emit_fused, SE_COLS, SE_MAXWG);
   if ((long long)n_scans * parts <= c->coresident_emit && H <= SE_HMAX) {   // one launch: count, publish, write behind the workgroups before (k_assoc_emit_fused); every workgroup resident
     if (++c->emit_epoch == 0u) c->emit_epoch = 1u;
     LVX_HIP(c, hipMemsetAsync(cnt_d, 0, (size_t)n_scans * 4, c->stream));
@@ -2515,7 +2515,7 @@ int lvx_undistort_scan(lvx_ctx* c, const double* state, int n, const lvx_point_x
 // compaction of the accepted planes: [records | plane table] in recs, the count in d_cnt (device)
 static int surfel_compact_launch(lvx_ctx* c, const SurfelPlaneDev* all, const int* flag, int nl, SurfelPlaneDev* recs, int* d_cnt, const VxInfo* info) {
   const int nb = (nl + 1023) / 1024;
-  if (c->coresident_compact < 0) c->coresident_compact = coresident_bound(c, k_surfel_compact_mb, 256, SC_MAXB);
+  if (c->coresident_compact < 0) c->coresident_compact = coresident_bound(c, (const void*)k_surfel_compact_mb, 256, SC_MAXB);
   if (nb > c->coresident_compact) {   // (every workgroup of the multi-block kernel must be resident on THIS device)
     hipLaunchKernelGGL(k_surfel_compact, dim3(1), dim3(1024), 0, c->stream, all, flag, nl, recs, d_cnt, info);
     return LVX_OK;

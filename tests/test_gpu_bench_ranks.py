@@ -104,3 +104,35 @@ def test_single_rank_runs_the_nccl_branch_with_the_library_transport():
     assert j["transport"].startswith("RCCL inside liblvx") and j["iterations"] >= 1 and j["final_cost"] < j["initial_cost"] and j["collectives"] >= 3
     assert "error" not in sec["surfel_assoc"] and "watchdog" not in sec
     assert "roofline" in out and out["roofline"]["frac"] > 0
+
+
+def test_every_visible_device_runs_the_rccl_bench():
+    """The day a multi-GPU box runs this suite, it proves that RCCL saw N ranks BEFORE the driver's scaling run: bench.py --gpus N (N = min(visible devices, 8)) on the real
+    `nccl` backend, one rank per device — the step over torch's all-reduce and over the library's own communicator (lvx_rccl_init across N ranks), the joint LM over in-library
+    RCCL with its collectives counted, and every rank ending with bit-identical shared extrinsics.  One visible device: skipped (test_single_rank_... covers the code path)."""
+    import torch
+    n = min(torch.cuda.device_count(), 8)
+    if n < 2:
+        pytest.skip("one visible device: the N-rank RCCL run needs a device per rank")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    env.pop("LVX_BENCH_BACKEND", None); env.pop("LVX_BENCH_FORCE_DIST", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "2", "--small"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    sec = out["secondary"]
+    print("%d-rank RCCL bench: %.1f Mevals/s, transports %s, joint LM %s" % (n, out["value"], sec.get("headline_transports"), sec.get("joint_lm_iteration")))
+    assert out["n_gpus"] == n and out["config"]["parallelism"] == "sequence-per-gpu x%d" % n and out["scaling"] == "weak"
+    assert "inlib_rccl_init_error" not in sec and "inlib_rccl_step_error" not in sec, sec
+    h = sec["headline_transports"]
+    assert h["inlib_transport"]["value"] > 0 and h["torch_transport"]["value"] > 0 and out["value"] == h["inlib_transport"]["value"]
+    j = sec["joint_lm_iteration"]
+    assert "error" not in j, j
+    assert j["transport"].startswith("RCCL inside liblvx") and j["ranks"] == n and j["collectives"] >= 3 and j["final_cost"] < j["initial_cost"]
+    assert j["shared_extrinsics_max_spread_over_ranks"] == 0.0
+    a = sec["surfel_assoc"]
+    assert "error" not in a, a
+    assert a["scans"] == n * a["scans_per_gpu"] and a["associated_points"] > 0
