@@ -700,9 +700,10 @@ def main():
                 torch.cuda.synchronize(); dist.barrier()
                 tj = time.perf_counter() - tj
                 # the shared extrinsics every rank ended with: they must be THE SAME numbers (each rank solves the same reduced 14 x 14 system from the same reduction)
-                ext_all = [torch.zeros(16, dtype=torch.float64, device="cuda") for _ in range(world)]
-                dist.all_gather(ext_all, torch.from_numpy(np.ascontiguousarray(xj[7 * Nk + 16:7 * Nk + 32])).cuda())
-                ext_all = torch.stack(ext_all).cpu().numpy()
+                ext_all = torch.zeros(world, 16, dtype=torch.float64, device="cuda")       # (a sum of one-hot rows: all_reduce is what both backends offer on device tensors)
+                ext_all[rank] = torch.from_numpy(np.ascontiguousarray(xj[7 * Nk + 16:7 * Nk + 32])).cuda()
+                dist.all_reduce(ext_all)
+                ext_all = ext_all.cpu().numpy()
                 ext_spread = float(np.abs(ext_all - ext_all[0]).max())
                 sec_all["joint_lm_iteration"] = {"ms_per_iteration": 1e3 * tj / max(1, smj["iterations"]), "iterations": smj["iterations"], "initial_cost": smj["initial_cost"], "final_cost": smj["final_cost"],
                                                  "collectives": int(ctx.collective_count()), "ranks": world, "shared_extrinsics_max_spread_over_ranks": ext_spread,
