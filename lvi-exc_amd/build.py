@@ -43,7 +43,7 @@ def build(force=False, verbose=False):
     for p, cmd in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-L/opt/rocm/lib", "-lrocblas", "-lrocsolver", "-ldl", "-Wl,-rpath,/opt/rocm/lib"]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl", "-Wl,-rpath,/opt/rocm/lib"]   # rocBLAS / rocSOLVER are dlopen'ed on demand (bands wider than 208: lvx_bcr.hip), librccl likewise
     subprocess.check_call(cmd)
     return OUT
 

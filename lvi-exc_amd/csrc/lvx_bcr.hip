@@ -4,11 +4,12 @@
 // n_blk blocks is eliminated in log2(n_blk) levels: at level l the blocks j = 2^l - 1 + 2^(l+1) k are eliminated in parallel,
 //     C_j C_j^T = D_j,   X+_k = A_{j+s,j} C_j^-T,   Y_k = C_j^-1 A_{j,j-s},
 //     D_{j+s} -= X+ X+^T,   D_{j-s} -= Y^T Y,   A_{j+s,j-s} = -X+ Y        (s = 2^l)
-// which replaces a 155 k-long sequential dependency chain by ~10 rounds of BATCHED dense b x b operations — plain library
-// BLAS-3, executed with rocSOLVER potrf_strided_batched and rocBLAS trsm / syrk / gemm_strided_batched (FP64).
+// which replaces a 155 k-long sequential dependency chain by ~10 rounds of BATCHED dense b x b operations — own MFMA kernels for blocks up to 208 wide (Cholesky,
+// triangular solves, Schur updates: below); wider blocks go to rocSOLVER potrf_strided_batched / rocBLAS gemm_strided_batched, loaded on demand (vendor_blas).
 // This is what Ceres' SPARSE_SCHUR + sparse Cholesky does for the reference (kontiki/trajectory_estimator.h:44), restructured for a GPU.
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -28,6 +29,40 @@ namespace lvx {
     rocblas_status s_ = (expr);                                                                                 \
     if (s_ != rocblas_status_success) return fail(ctx, LVX_E_HIP, std::string(#expr) + ": rocblas status " + std::to_string((int)s_)); \
   } while (0)
+
+// rocBLAS / rocSOLVER serve ONLY bands wider than 208 (free time offsets with very wide co-visibility; config 4 and every reference stage run on the kernels below).  They are
+// loaded the first time such a band is factorised (dlopen, as librccl is): liblvx.so does not link them, a host without them keeps everything but that case
+// (the library hard-linked librocblas / librocsolver and through them hipblaslt / rocroller for a path the headline never takes).
+struct VendorBlas {
+  void* hb = nullptr; void* hs = nullptr; bool tried = false;
+  decltype(&rocblas_create_handle) create_handle = nullptr;
+  decltype(&rocblas_destroy_handle) destroy_handle = nullptr;
+  decltype(&rocblas_set_stream) set_stream = nullptr;
+  decltype(&rocblas_set_pointer_mode) set_pointer_mode = nullptr;
+  decltype(&rocblas_dgemm_strided_batched) dgemm_strided_batched = nullptr;
+  decltype(&rocsolver_dpotrf_strided_batched) dpotrf_strided_batched = nullptr;
+  bool ok() const { return create_handle && destroy_handle && set_stream && set_pointer_mode && dgemm_strided_batched && dpotrf_strided_batched; }
+};
+static VendorBlas g_vb;
+static std::mutex g_vb_mu;
+static int vendor_blas(lvx_ctx* c) {
+  std::lock_guard<std::mutex> lk(g_vb_mu);
+  if (!g_vb.tried) {
+    g_vb.tried = true;
+    for (const char* n : {"librocblas.so", "librocblas.so.5", "librocblas.so.4", "/opt/rocm/lib/librocblas.so"}) if ((g_vb.hb = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    for (const char* n : {"librocsolver.so", "librocsolver.so.0", "/opt/rocm/lib/librocsolver.so"}) if ((g_vb.hs = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (g_vb.hb && g_vb.hs) {
+      g_vb.create_handle = (decltype(g_vb.create_handle))dlsym(g_vb.hb, "rocblas_create_handle");
+      g_vb.destroy_handle = (decltype(g_vb.destroy_handle))dlsym(g_vb.hb, "rocblas_destroy_handle");
+      g_vb.set_stream = (decltype(g_vb.set_stream))dlsym(g_vb.hb, "rocblas_set_stream");
+      g_vb.set_pointer_mode = (decltype(g_vb.set_pointer_mode))dlsym(g_vb.hb, "rocblas_set_pointer_mode");
+      g_vb.dgemm_strided_batched = (decltype(g_vb.dgemm_strided_batched))dlsym(g_vb.hb, "rocblas_dgemm_strided_batched");
+      g_vb.dpotrf_strided_batched = (decltype(g_vb.dpotrf_strided_batched))dlsym(g_vb.hs, "rocsolver_dpotrf_strided_batched");
+    }
+  }
+  if (!g_vb.ok()) return fail(c, LVX_E_STATE, "band wider than 208 needs rocBLAS / rocSOLVER, which could not be loaded (librocblas.so, librocsolver.so)");
+  return LVX_OK;
+}
 
 // band (scaled + damped) -> dense blocks.  D_i lower triangle (column-major b x b), G0_i = A_{i+1,i}; padding blocks are identity / zero
 __global__ __launch_bounds__(256) void k_bcr_build(const double* __restrict__ Hb, const double* __restrict__ scale, const double* __restrict__ lmd, double inv_radius,
@@ -78,12 +113,13 @@ static int bcr_handle(lvx_ctx* c, rocblas_handle* h) {
     rocblas_handle hh = nullptr;
     { std::lock_guard<std::mutex> lk(g_blas_mu);
       for (size_t i = 0; i < g_blas_free.size(); ++i) if (g_blas_free[i].first == c->device) { hh = g_blas_free[i].second; g_blas_free.erase(g_blas_free.begin() + (long)i); break; } }
-    if (!hh) LVX_BLAS(c, rocblas_create_handle(&hh));
+    if (!hh) { const int rv_ = vendor_blas(c); if (rv_) return rv_; LVX_BLAS(c, g_vb.create_handle(&hh)); }
     c->blas = hh;
   }
   *h = (rocblas_handle)c->blas;
-  LVX_BLAS(c, rocblas_set_stream(*h, c->stream));
-  LVX_BLAS(c, rocblas_set_pointer_mode(*h, rocblas_pointer_mode_host));
+  { const int rv_ = vendor_blas(c); if (rv_) return rv_; }
+  LVX_BLAS(c, g_vb.set_stream(*h, c->stream));
+  LVX_BLAS(c, g_vb.set_pointer_mode(*h, rocblas_pointer_mode_host));
   return LVX_OK;
 }
 
@@ -710,7 +746,7 @@ template <int NT> static void launch_potrf_reg(lvx_ctx* c, double* D, int b, lon
 static bool potrf_own(const lvx_ctx* c, int b) { return potrf_reg_ok(c, b); }
 static int potrf_batched(lvx_ctx* c, rocblas_handle& h, double* D, int b, long long strideD, int* info, int batch, double* LI, long long strideLI) {
   if (!potrf_own(c, b)) {
-    { LVX_BLAS_H(c, h); LVX_BLAS(c, rocsolver_dpotrf_strided_batched(h, rocblas_fill_lower, b, D, b, (rocblas_stride)strideD, info, batch)); }
+    { LVX_BLAS_H(c, h); LVX_BLAS(c, g_vb.dpotrf_strided_batched(h, rocblas_fill_lower, b, D, b, (rocblas_stride)strideD, info, batch)); }
     return LVX_OK;
   }
   if (b <= 64) launch_potrf_reg<4>(c, D, b, strideD, info, batch, LI, strideLI);
@@ -1089,17 +1125,17 @@ int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_ra
     }
     // D_{j+s} -= X+ X+^T
     // (full GEMM instead of SYRK: rocBLAS' batched SYRK runs as many small launches; the upper triangle of D is never read)
-    { LVX_BLAS_H(c, h); LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, b, b, b, &mone, Gl, b, sG, Gl, b, sG, &one, Dr, b, sD, n2)); }
+    { LVX_BLAS_H(c, h); LVX_BLAS(c, g_vb.dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, b, b, b, &mone, Gl, b, sG, Gl, b, sG, &one, Dr, b, sD, n2)); }
     if (n2 > 1) {
       // D_{j-s} -= Y^T Y   (left neighbour of eliminated k is the right neighbour of eliminated k-1)
-      { LVX_BLAS_H(c, h); LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, b, b, &mone, Gl + bb, b, sG, Gl + bb, b, sG, &one, Dr, b, sD, n2 - 1)); }
+      { LVX_BLAS_H(c, h); LVX_BLAS(c, g_vb.dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, b, b, &mone, Gl + bb, b, sG, Gl + bb, b, sG, &one, Dr, b, sD, n2 - 1)); }
       // next level's coupling A_{j+s,j-s} = -X+_k Y_k
-      { LVX_BLAS_H(c, h); LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, b, b, &mone, Gl + 2 * bb, b, sG, Gl + bb, b, sG, &zero, Gn, b, (rocblas_stride)bb, n2 - 1)); }
+      { LVX_BLAS_H(c, h); LVX_BLAS(c, g_vb.dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, b, b, &mone, Gl + 2 * bb, b, sG, Gl + bb, b, sG, &zero, Gn, b, (rocblas_stride)bb, n2 - 1)); }
     }
     if (Z) {   // b_{j+s} -= X+ y_j,  b_{j-s} -= Y^T y_j
-      { LVX_BLAS_H(c, h); LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, nrhs, b, &mone, Gl, b, sG, Zj, ldz, sZ, &one, Zr, ldz, sZ, n2)); }
+      { LVX_BLAS_H(c, h); LVX_BLAS(c, g_vb.dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, nrhs, b, &mone, Gl, b, sG, Zj, ldz, sZ, &one, Zr, ldz, sZ, n2)); }
       if (n2 > 1)
-        { LVX_BLAS_H(c, h); LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, nrhs, b, &mone, Gl + bb, b, sG, Zj + sZ, ldz, sZ, &one, Zr, ldz, sZ, n2 - 1)); }
+        { LVX_BLAS_H(c, h); LVX_BLAS(c, g_vb.dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, nrhs, b, &mone, Gl + bb, b, sG, Zj + sZ, ldz, sZ, &one, Zr, ldz, sZ, n2 - 1)); }
     }
   }
   double* LIlast = LI ? LI + (size_t)(nblk - 1) * liS : nullptr;
@@ -1132,9 +1168,9 @@ int bcr_forward(lvx_ctx* c, double* Zin, double* Zy, int ldz, int nrhs) {
     double* Zj = Z + (size_t)(s - 1) * b;
     double* Zr = Z + (size_t)(2 * s - 1) * b;
     if ((rc = trsv_batched<false>(c, Dj, b, sD, Zj, 1, ldz, sZ, nrhs, n2, LI ? LI + (size_t)(s - 1) * liS : nullptr, (long long)2 * s * liS))) return rc;                      // y_j = C_j^-1 b_j
-    { LVX_BLAS_H(c, h); LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, nrhs, b, &mone, Gl, b, sG, Zj, ldz, sZ, &one, Zr, ldz, sZ, n2)); }
+    { LVX_BLAS_H(c, h); LVX_BLAS(c, g_vb.dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, nrhs, b, &mone, Gl, b, sG, Zj, ldz, sZ, &one, Zr, ldz, sZ, n2)); }
     if (n2 > 1)
-      { LVX_BLAS_H(c, h); LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, nrhs, b, &mone, Gl + bb, b, sG, Zj + sZ, ldz, sZ, &one, Zr, ldz, sZ, n2 - 1)); }
+      { LVX_BLAS_H(c, h); LVX_BLAS(c, g_vb.dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, nrhs, b, &mone, Gl + bb, b, sG, Zj + sZ, ldz, sZ, &one, Zr, ldz, sZ, n2 - 1)); }
   }
   return trsv_batched<false>(c, D + (size_t)(nblk - 1) * bb, b, 0, Z + (size_t)(nblk - 1) * b, 1, ldz, 0, nrhs, 1, LI ? LI + (size_t)(nblk - 1) * liS : nullptr, 0);
 }
@@ -1172,9 +1208,9 @@ int bcr_backward(lvx_ctx* c, double* Zy, double* Zx, int ldz, int nrhs) {
       LVX_HIP(c, hipGetLastError());
       continue;
     }
-    { LVX_BLAS_H(c, h); LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, nrhs, b, &mone, Gl, b, sG, Zr, ldz, sZ, &one, Zj, ldz, sZ, n2)); }
+    { LVX_BLAS_H(c, h); LVX_BLAS(c, g_vb.dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, b, nrhs, b, &mone, Gl, b, sG, Zr, ldz, sZ, &one, Zj, ldz, sZ, n2)); }
     if (n2 > 1)
-      { LVX_BLAS_H(c, h); LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, nrhs, b, &mone, Gl + bb, b, sG, Zr, ldz, sZ, &one, Zj + sZ, ldz, sZ, n2 - 1)); }
+      { LVX_BLAS_H(c, h); LVX_BLAS(c, g_vb.dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, b, nrhs, b, &mone, Gl + bb, b, sG, Zr, ldz, sZ, &one, Zj + sZ, ldz, sZ, n2 - 1)); }
     if ((rc = trsv_batched<true>(c, Dj, b, sD, Zj, 1, ldz, sZ, nrhs, n2, LI ? LI + (size_t)(s - 1) * liS : nullptr, (long long)2 * s * liS))) return rc;
   }
   return LVX_OK;
@@ -1284,7 +1320,7 @@ int bcr_gram(lvx_ctx* c, const double* Z, int ldz, int n, double* M) {
   } else {   // (more than 80 border columns: one small library GEMM per row block)
     rocblas_handle h; if ((rc = bcr_handle(c, &h))) return rc;
     if ((rc = dev_alloc(c, c->d_Y2, (size_t)nblk * nn * 8))) return rc;
-    LVX_BLAS(c, rocblas_dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, n, n, b, &one, Z, ldz, (rocblas_stride)b, Z, ldz, (rocblas_stride)b,
+    LVX_BLAS(c, g_vb.dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, n, n, b, &one, Z, ldz, (rocblas_stride)b, Z, ldz, (rocblas_stride)b,
                                               &zero, (double*)c->d_Y2.p, n, (rocblas_stride)nn, nblk));
     hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((nn + 255) / 256), (unsigned)((nblk + (long long)per - 1) / per)), dim3(256), 0, c->stream, (const double*)c->d_Y2.p, (int)nn, nblk, per, M);
   }
@@ -1295,7 +1331,7 @@ int bcr_gram(lvx_ctx* c, const double* Z, int ldz, int n, double* M) {
 void bcr_destroy(lvx_ctx* c) {
   if (!c->blas) return;
   std::lock_guard<std::mutex> lk(g_blas_mu);
-  if (g_blas_free.size() < 16) g_blas_free.emplace_back(c->device, (rocblas_handle)c->blas); else (void)rocblas_destroy_handle((rocblas_handle)c->blas);
+  if (g_blas_free.size() < 16) g_blas_free.emplace_back(c->device, (rocblas_handle)c->blas); else if (g_vb.destroy_handle) (void)g_vb.destroy_handle((rocblas_handle)c->blas);
   c->blas = nullptr;
 }
 

@@ -46,6 +46,10 @@ def test_product_library_does_not_link_the_oracle(liblvx):
     import lvx
     out = subprocess.run(["ldd", lvx.library_path()], capture_output=True, text=True).stdout
     assert "oracle" not in out
+    # and no vendor BLAS either: rocBLAS / rocSOLVER (bands wider than 208 only) and RCCL are dlopen'ed on demand — the library's link-time dependencies are the HIP runtime
+    # and the C / C++ runtimes
+    for lib in ("rocblas", "rocsolver", "hipblas", "rccl", "rocroller"):
+        assert lib not in out, lib
     syms = subprocess.run(["nm", "-D", "--defined-only", lvx.library_path()], capture_output=True, text=True).stdout
     assert "orc_" not in syms
 

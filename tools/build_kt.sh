@@ -7,5 +7,5 @@ cd "$(dirname "$0")/../lvi-exc_amd"
 python build.py > /dev/null
 TAG=$(echo "$FAM" | tr -cd 'A-Za-z0-9')
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -fno-gpu-rdc -Wno-unused-result -ffp-contract=fast -DLVX_KTIME "-DLVX_KTIME_FAM=$FAM" -c csrc/lvx_eval.hip -o /tmp/lvx_eval_kt_$TAG.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o liblvx_kt_$TAG.so /tmp/lvx_eval_kt_$TAG.o csrc/lvx_api.o csrc/lvx_bcr.o csrc/lvx_solver.o csrc/lvx_upstream.o -L/opt/rocm/lib -lrocblas -lrocsolver -ldl -Wl,-rpath,/opt/rocm/lib
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o liblvx_kt_$TAG.so /tmp/lvx_eval_kt_$TAG.o csrc/lvx_api.o csrc/lvx_bcr.o csrc/lvx_solver.o csrc/lvx_upstream.o -ldl -Wl,-rpath,/opt/rocm/lib
 echo liblvx_kt_$TAG.so

@@ -11,5 +11,5 @@ OBJS=""
 for f in lvx_api lvx_bcr lvx_eval lvx_solver lvx_upstream; do
   if [ "$f" = "$FILE" ]; then OBJS="$OBJS /tmp/${FILE}_var_$TAG.o"; else OBJS="$OBJS csrc/$f.o"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o liblvx_var_$TAG.so $OBJS -L/opt/rocm/lib -lrocblas -lrocsolver -ldl -Wl,-rpath,/opt/rocm/lib
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o liblvx_var_$TAG.so $OBJS -ldl -Wl,-rpath,/opt/rocm/lib
 echo liblvx_var_$TAG.so
