@@ -109,7 +109,7 @@ def assoc_metric(ctx, world, rank, scans_per_gpu=64):
     def step():
         ctx._ck(ctx._l.lvx_surfel_assoc_batch_d(ctx._h, C.c_int(hi - lo), C.c_int(H), C.c_int(W), C.c_void_p(local.data_ptr()), C.c_int(P), C.c_void_p(pl.data_ptr()), C.c_double(0.05), C.c_int(2),
                                                 C.c_void_p(flags.data_ptr())))
-        return sharded.all_gather_scan_results(dist, flags, n_scans) if world > 1 else flags
+        return sharded.all_gather_scan_hits(dist, flags, n_scans) if world > 1 else flags   # hits only: ~1/8 of the dense flags' bytes per rank
     for _ in range(3):
         step()
     ctx.synchronize(); torch.cuda.synchronize()

@@ -62,6 +62,42 @@ def all_gather_scan_results(dist, local, n_scans, fill=-1):
     return torch.cat([out[r * nmax:r * nmax + (hi - lo)] for r, (lo, hi) in enumerate(per)], dim=0)
 
 
+def all_gather_scan_hits(dist, local, n_scans, fill=-1, capacity_frac=0.125):
+    """The same result as all_gather_scan_results, gathered COMPACTLY: an association flags ~4 % of a scan's points (<= 2 points per ring and surfel), so each rank sends
+    its hits as (flat index in its shard, value) pairs in a fixed-capacity buffer — capacity_frac of the shard's points + the count — instead of every point's flag:
+    64 scans x 28 800 points are 7.4 MB of flags per rank and 0.9 MB of hits at the default capacity (1.8 MB incl. indices), and at N = 8 the gather, not the 0.11 ms kernel,
+    sets the rate.  A rank whose hits outgrow the capacity makes every rank fall back to the dense gather (decided by the gathered counts themselves: no
+    extra collective).  Returns [n_scans, row_len] in scan order on every rank, `fill` where nothing was flagged."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if world == 1:
+        return local
+    per = [scan_shard(n_scans, r, world) for r in range(world)]
+    nmax = max(hi - lo for lo, hi in per)
+    row = local.shape[1]
+    cap = max(16, int(capacity_frac * nmax * row))
+    flat = local.reshape(-1)
+    idx = torch.nonzero(flat != fill).reshape(-1)                      # (one host synchronisation: the count)
+    n = int(idx.numel())
+    buf = torch.full((cap + 1, 2), -1, dtype=torch.int64, device=local.device)
+    buf[0, 0] = n
+    if n <= cap:
+        buf[1:n + 1, 0] = idx
+        buf[1:n + 1, 1] = flat[idx].to(torch.int64)
+    out = torch.empty((world * (cap + 1), 2), dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(out, buf)
+    out = out.view(world, cap + 1, 2)
+    counts = out[:, 0, 0]
+    if bool((counts > cap).any()):                                     # every rank sees the same counts: all take the dense path together
+        return all_gather_scan_results(dist, local, n_scans, fill)
+    res = torch.full((n_scans, row), fill, dtype=local.dtype, device=local.device)
+    for r, (lo, hi) in enumerate(per):
+        k = int(counts[r])
+        if k > 0:
+            res[lo:hi].reshape(-1)[out[r, 1:k + 1, 0]] = out[r, 1:k + 1, 1].to(local.dtype)
+    return res
+
+
 class ThreadAllReduce:
     """In-process all-reduce between `world` threads (one lvx.Context per thread): used to drive several sequences on ONE GPU,
     e.g. the single-GPU parity test of the joint solve."""

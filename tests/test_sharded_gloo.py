@@ -138,7 +138,11 @@ def _scan_worker(rank, world, port, out):
     _, p4, bmin, bmax = synth.make_assoc_problem(seed=70, H=4, W=300, n_planes=60)
     lo, hi = sharded.scan_shard(n_scans, rank, world)
     local = [O.surfel_assoc(synth.make_assoc_problem(seed=70 + s, H=4, W=300, n_planes=60)[0], p4, bmin, bmax, 0.05, 2).ravel() for s in range(lo, hi)]
-    flags = sharded.all_gather_scan_results(dist, torch.from_numpy(np.stack(local).astype(np.int32)), n_scans)
+    mine = torch.from_numpy(np.stack(local).astype(np.int32))
+    flags = sharded.all_gather_scan_results(dist, mine, n_scans)
+    compact = sharded.all_gather_scan_hits(dist, mine, n_scans)                           # the same table from (index, value) pairs of the hits only
+    tiny = sharded.all_gather_scan_hits(dist, mine, n_scans, capacity_frac=1e-4)           # capacity outgrown on some rank: every rank takes the dense gather
+    assert torch.equal(compact, flags) and torch.equal(tiny, flags)
     out.put((rank, (lo, hi), flags.numpy()))
     dist.barrier()
     dist.destroy_process_group()
