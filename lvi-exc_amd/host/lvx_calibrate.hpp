@@ -114,31 +114,7 @@ class Calibrator {
     check(lvx_set_orientation_prior(ctx_, 0, in_.t0, q0, opt_.w_gyro));
     return r;
   }
-  // the pose Mapping() feeds with scan idx (lvi_initialize_surfel_orb.cpp:1283-1295): simulation — the pose with exactly the scan's stamp; otherwise the nearest in time of
-  // loam_poses_[idx - 5 .. idx + 4] (the last pose is never looked at: `idx >= size - 1`, :1252), used even when it is further than 0.02 s away (`ok` is not looked at)
-  bool pose_of_scan(int idx, double scan_t, double T[16]) const {
-    const PoseStamped* hit = nullptr;
-    if (in_.simulation) {
-      const int64_t stamp = (int64_t)(scan_t * 1e9);
-      for (const PoseStamped& ps : in_.loam.all) if (ps.stamp_ns == stamp) hit = &ps;   // (std::map::operator[]: the last pose with that stamp wins)
-    } else {
-      double best = 1.7976931348623157e308;
-      for (int i = -5; i < 5; ++i) {
-        const long long k = (long long)i + idx;
-        if (k < 0 || k >= (long long)in_.loam.all.size() - 1) continue;
-        const double d = std::fabs((double)in_.loam.all[(size_t)k].stamp_ns * 1e-9 - scan_t);
-        if (d < best) { best = d; hit = &in_.loam.all[(size_t)k]; }
-      }
-    }
-    if (!hit) return false;
-    // Eigen::Quaterniond(w, x, y, z).toRotationMatrix() of the file's (unnormalised) quaternion
-    const double w = hit->q_wxyz[0], x = hit->q_wxyz[1], y = hit->q_wxyz[2], z = hit->q_wxyz[3];
-    const double tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
-    const double R[9] = {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy)};
-    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T[4 * r + c] = R[3 * r + c]; T[4 * r + 3] = hit->p[r]; }
-    T[12] = T[13] = T[14] = 0; T[15] = 1;
-    return true;
-  }
+  bool pose_of_scan(int idx, double scan_t, double T[16]) const { return PoseOfScan(in_.loam, in_.simulation, idx, scan_t, T); }
   lvx_assoc_options assoc_options(double plane_lambda) const {
     lvx_assoc_options ao; lvx_assoc_default_options(&ao);
     ao.ndt_resolution = opt_.ndt_resolution; ao.plane_lambda = plane_lambda; ao.fit_threshold = opt_.fit_threshold; ao.min_leaf_points = opt_.min_leaf_points;

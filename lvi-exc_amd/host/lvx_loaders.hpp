@@ -133,6 +133,34 @@ inline bool ReadPoseGT(const std::string& path, LoamPoses* out) {
   return true;
 }
 
+// The pose Mapping() feeds LiDAROdometry with for scan `idx` (lvi_initialize_surfel_orb.cpp:1283-1295), as the row-major 4 x 4 Eigen builds from the file's numbers
+// (Quaterniond(w, x, y, z).toRotationMatrix() of the UNNORMALISED quaternion).  simulation: the pose with exactly the scan's stamp — int64(scan_t * 1e9) looked up in
+// loam_poses_map_, whose operator[] keeps the LAST pose of a stamp; false when there is none (the scan is skipped).  Otherwise findAssociatedPose (:1246-1260): the nearest in
+// time of loam_poses_[idx - 5 .. idx + 4], the last pose of the file never looked at (`idx >= size() - 1`), and used even when it is further than 0.02 s away (the reference
+// computes `ok` and does not look at it); false only when the window holds no pose at all (the reference would then feed an uninitialised matrix).
+inline bool PoseOfScan(const LoamPoses& loam, bool simulation, int idx, double scan_t, double T[16]) {
+  const PoseStamped* hit = nullptr;
+  if (simulation) {
+    const int64_t stamp = (int64_t)(scan_t * 1e9);
+    for (const PoseStamped& ps : loam.all) if (ps.stamp_ns == stamp) hit = &ps;
+  } else {
+    double best = 1.7976931348623157e308;
+    for (int i = -5; i < 5; ++i) {
+      const long long k = (long long)i + idx;
+      if (k < 0 || k >= (long long)loam.all.size() - 1) continue;
+      const double d = std::fabs((double)loam.all[(size_t)k].stamp_ns * 1e-9 - scan_t);
+      if (d < best) { best = d; hit = &loam.all[(size_t)k]; }
+    }
+  }
+  if (!hit) return false;
+  const double w = hit->q_wxyz[0], x = hit->q_wxyz[1], y = hit->q_wxyz[2], z = hit->q_wxyz[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  const double R[9] = {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy)};
+  for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T[4 * r + c] = R[3 * r + c]; T[4 * r + 3] = hit->p[r]; }
+  T[12] = T[13] = T[14] = 0; T[15] = 1;
+  return true;
+}
+
 // Lock masks of the reference's solve stages (TrajectoryManagerLVI, src/lvi_exc/src/core/trajectory_manager_lvi.cpp): which Lock* calls each
 // stage makes before building its estimator.  opt_time_offset = calib_param_manager->opt_time_offset (lvi.yaml:32).
 enum class Stage { SO3FromGyro, TrajFromSurfel, TrajFromLVI, TrajFromLVILandmarksOnly };

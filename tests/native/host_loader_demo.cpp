@@ -13,6 +13,16 @@ int main(int argc, char** argv) {
   if (!lvx_host::ReadPoseGT(argv[2], &p)) return 4;
   std::printf("poses %zu key %zu\n", p.all.size(), p.key.size());
   for (const auto& k : p.key) std::printf("K %lld\n", (long long)k.stamp_ns);
+  // the pose Mapping() associates with scan idx (PoseOfScan): scans are stamped like the poses (scan idx <-> pose idx), scan 3 a little late, scan 7 without a pose of its stamp
+  for (int mode = 0; mode < 2; ++mode)
+    for (size_t idx = 0; idx < p.all.size(); ++idx) {
+      double t = (double)p.all[idx].stamp_ns * 1e-9;
+      if (idx == 3) t += 0.004;
+      if (idx == 7) t += 0.06;
+      double T[16];
+      const bool ok = lvx_host::PoseOfScan(p, mode == 0, (int)idx, t, T);
+      std::printf("A %d %zu %d %.17g %.17g %.17g %.17g\n", mode, idx, ok ? 1 : 0, ok ? T[3] : 0.0, ok ? T[7] : 0.0, ok ? T[0] : 0.0, ok ? T[1] : 0.0);
+    }
   std::printf("locks %u %u %u %u\n", lvx_host::StageLocks(lvx_host::Stage::SO3FromGyro, false), lvx_host::StageLocks(lvx_host::Stage::TrajFromSurfel, false),
               lvx_host::StageLocks(lvx_host::Stage::TrajFromLVI, false), lvx_host::StageLocks(lvx_host::Stage::TrajFromLVILandmarksOnly, true));
   return 0;

@@ -79,6 +79,31 @@ def test_orb_results_and_pose_files(demo, tmp_path):
         key.append((s, p, q))
     assert "poses %d key %d" % (len(poses), len(key)) in out
     assert [int(ln.split()[1]) for ln in out if ln.startswith("K ")] == [s for s, _, _ in key]
+    # PoseOfScan: simulation = exact stamp (int64(t * 1e9)); otherwise the nearest of poses idx - 5 .. idx + 4, never the file's last pose
+    assoc = {(int(m), int(i)): (int(ok), float(x), float(y), float(r00), float(r01)) for m, i, ok, x, y, r00, r01 in (ln.split()[1:] for ln in out if ln.startswith("A "))}
+    n = len(poses)
+
+    def R01(q):
+        w, x, y, z = q
+        return 1 - 2 * (y * y + z * z), 2 * (x * y - z * w)
+    for i in range(n):
+        t = poses[i][0] * 1e-9 + (0.004 if i == 3 else 0.0) + (0.06 if i == 7 else 0.0)
+        hit = [k for k in range(n) if poses[k][0] == int(t * 1e9)]
+        exp = hit[-1] if hit else None
+        ok, x, y, r00, r01 = assoc[(0, i)]
+        assert ok == (exp is not None)
+        if exp is not None:
+            assert np.allclose([x, y], [float("%.7g" % poses[exp][1][0]), float("%.7g" % poses[exp][1][1])], rtol=0, atol=1e-12)
+        cand = [k for k in range(i - 5, i + 5) if 0 <= k < n - 1]
+        ok, x, y, r00, r01 = assoc[(1, i)]
+        assert ok == (1 if cand else 0)
+        if cand:
+            best = min(cand, key=lambda k: (abs(poses[k][0] * 1e-9 - t), k))
+            q = [float("%.7g" % v) for v in poses[best][2]]
+            assert np.allclose([x, y], [float("%.7g" % poses[best][1][0]), float("%.7g" % poses[best][1][1])], rtol=0, atol=1e-12)
+            assert np.allclose([r00, r01], R01(q), rtol=0, atol=1e-12)
+    assert assoc[(0, 3)][0] == 0 and assoc[(0, 7)][0] == 0 and assoc[(1, 3)][0] == 1      # a late stamp has no exact pose but a nearest one
+    assert assoc[(1, n - 1)][1] == float("%.7g" % poses[n - 2][1][0])                      # the last pose of the file is never taken: scan n - 1 gets pose n - 2
     tau = lvx.LOCK_LIDAR_TAU | lvx.LOCK_CAM_TAU
     assert out[-1] == "locks %d %d %d %d" % (lvx.LOCK_R3 | lvx.LOCK_ACC_BIAS | lvx.LOCK_GYRO_BIAS | tau, lvx.LOCK_CAM_Q | lvx.LOCK_CAM_P | lvx.LOCK_LANDMARKS | tau, tau,
                                               lvx.LOCK_TRAJ | lvx.LOCK_LIDAR_Q | lvx.LOCK_LIDAR_P)
