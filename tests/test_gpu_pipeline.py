@@ -97,3 +97,35 @@ def test_the_truth_is_a_fixed_point_of_the_schedule(demo_binary, tmp_path):
     e = _errors(out[1 + 7 * ns:1 + 7 * ns + len(S["state_true"])], S["state_true"], N)
     print(e)
     assert e["lidar"][0] < 5e-4 and e["lidar"][1] < 1e-2 and e["cam"][0] < 3e-3 and e["cam"][1] < 1e-2
+
+
+@pytest.mark.gpu
+def test_default_route_from_loam_poses_recovers_the_planted_extrinsics(demo_binary, tmp_path):
+    """The reference's DEFAULT route end to end (lvi_initialize_surfel_orb.cpp: Initialization -> DataAssociation with Mapping() from LOAM poses -> BatchOptimization ->
+    Refinement x 2 -> trajInitFromLVIdata) from the reference's INITIAL state — every position control point 0, every rotation the identity — with a LOAM pose file
+    (ReadPoseGT format; 2 mm / 0.5 mrad of odometry noise): nothing is hand-fitted, the planted extrinsics must come back."""
+    S = synth.make_sequence(seed=50)
+    N = S["n_knots"]
+    scan_t, stamp, p, q, _ = synth.sequence_loam_poses(S, noise_m=2e-3, noise_rad=5e-4, seed=7)
+    pose_file = str(tmp_path / "loam_poses.txt")
+    synth.write_loam_pose_file(pose_file, stamp, p, q)
+    x0 = np.array(S["state0"], dtype=np.float64)
+    x0[:3 * N] = 0.0
+    x0[3 * N:7 * N] = np.tile([0.0, 0.0, 0.0, 1.0], N)
+    pin, pout, phist = str(tmp_path / "seq.bin"), str(tmp_path / "res.bin"), str(tmp_path / "hist.bin")
+    _write(pin, S, refine_iterations=3, lvi=1, camsurf=0, solve0=1, state=x0, scan_stamps=scan_t)
+    r = subprocess.run([demo_binary, pin, pout, phist, pose_file], capture_output=True, text=True)
+    print(r.stdout); print(r.stderr[-2000:])
+    assert r.returncode == 0, r.stderr
+    out = np.fromfile(pout)
+    ns = int(out[0])
+    rep = out[1:1 + 7 * ns].reshape(ns, 7)
+    x = out[1 + 7 * ns:1 + 7 * ns + len(x0)]
+    assert ns == 5 and (rep[:, 1] != 5).all()                       # Solve #0, batch, two refinements, LVI: no stage ends in FAILURE
+    assert rep[0, 4] == 0 and (rep[1:, 4] >= 500).all() and (rep[1:, 5] >= 2000).all()   # the first map already yields surfels and surfel points
+    e0, e1 = _errors(x0, S["state_true"], N), _errors(x, S["state_true"], N)
+    print("start:", e0, "\nend:  ", e1)
+    assert e1["lidar"][0] < 5e-3 and e1["lidar"][1] < 1.5e-2         # from 1.7e-2 rad / 2e-2 m
+    assert e1["cam"][0] < 4e-3 and e1["cam"][1] < 1.5e-2             # from 3.5e-2 rad / 3e-2 m
+    assert e1["lidar"][0] < 0.3 * e0["lidar"][0] and e1["cam"][0] < 0.12 * e0["cam"][0]
+    assert np.abs(x[:3 * N]).max() > 0.1                              # the trajectory left the origin
