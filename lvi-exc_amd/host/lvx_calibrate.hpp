@@ -96,6 +96,15 @@ class Calibrator {
     if (opt_.camera_surfel_stage) rep.push_back(SolveLVI(state, true));
     return rep;
   }
+  // LIinitializer::CIoptimize (lvi_initialize_surfel_orb.cpp:519-537): camera-IMU calibration alone — initialSO3TrajWithGyro, then trajInitFromVisualFrames
+  // (trajectory_manager_lvi.cpp:99-136: gyroscope + accelerometer + reprojection blocks, <= 200 iterations, LiDAR extrinsics locked)
+  std::vector<StageReport> RunCameraImu(std::vector<double>* state) {
+    if ((int)state->size() != lvx_state_size(ctx_)) throw std::invalid_argument("state size does not match the problem");
+    std::vector<StageReport> rep;
+    rep.push_back(Solve0(state));
+    rep.push_back(SolveVisual(state));
+    return rep;
+  }
   const std::vector<lvx_surfel_plane>& planes() const { return planes_; }
   const std::vector<AssociationRecord>& associations() const { return assoc_history_; }
   const std::vector<int32_t>& key_scans() const { return key_scans_; }   // of the first-map association: 1 where the scan joined the key-scan map
@@ -173,6 +182,15 @@ class Calibrator {
     StageReport r{name, solve(state, 30)};
     attach_history(&r);
     r.n_planes = (int)planes_.size(); r.n_surfel_points = n_surfel_used_;
+    return r;
+  }
+  StageReport SolveVisual(std::vector<double>* state) {   // trajInitFromVisualFrames
+    check(lvx_set_imu(ctx_, (int)in_.imu_t.size(), in_.imu_t.data(), in_.gyro.data(), in_.acc.data(), opt_.w_gyro, opt_.w_acc));
+    clear_families(true, false, true);
+    check(lvx_set_reproj(ctx_, (int)in_.obs_landmark.size(), in_.obs_landmark.data(), in_.obs_uv.data(), in_.obs_t0.data(), /*huber*/ opt_.w_cam, /*weight*/ 1.0));   // argument swap of :525
+    check(lvx_set_locks(ctx_, StageLocks(Stage::TrajFromVisualFrames, opt_.opt_time_offset)));
+    StageReport r{"trajInitFromVisualFrames", solve(state, 200)};
+    attach_history(&r);
     return r;
   }
   StageReport SolveLVI(std::vector<double>* state, bool camera_surfel) {   // trajInitFromLVIdata

@@ -163,7 +163,7 @@ inline bool PoseOfScan(const LoamPoses& loam, bool simulation, int idx, double s
 
 // Lock masks of the reference's solve stages (TrajectoryManagerLVI, src/lvi_exc/src/core/trajectory_manager_lvi.cpp): which Lock* calls each
 // stage makes before building its estimator.  opt_time_offset = calib_param_manager->opt_time_offset (lvi.yaml:32).
-enum class Stage { SO3FromGyro, TrajFromSurfel, TrajFromLVI, TrajFromLVILandmarksOnly };
+enum class Stage { SO3FromGyro, TrajFromSurfel, TrajFromLVI, TrajFromLVILandmarksOnly, TrajFromVisualFrames };
 inline uint32_t StageLocks(Stage s, bool opt_time_offset) {
   const uint32_t tau = opt_time_offset ? 0u : (LVX_LOCK_LIDAR_TAU | LVX_LOCK_CAM_TAU);
   switch (s) {
@@ -175,6 +175,8 @@ inline uint32_t StageLocks(Stage s, bool opt_time_offset) {
       return tau;
     case Stage::TrajFromLVILandmarksOnly: // same with `traj_->Lock(true)`: trajectory and lidar locked, camera + landmarks refined (:148-152, 208-212)
       return tau | LVX_LOCK_TRAJ | LVX_LOCK_LIDAR_Q | LVX_LOCK_LIDAR_P;
+    case Stage::TrajFromVisualFrames:     // trajInitFromVisualFrames (:99-136; LIinitializer::CIoptimize): IMU + reprojection blocks only, LiDAR extrinsics locked, its offset untouched (locked)
+      return LVX_LOCK_LIDAR_Q | LVX_LOCK_LIDAR_P | LVX_LOCK_LIDAR_TAU | (opt_time_offset ? 0u : LVX_LOCK_CAM_TAU);
   }
   return tau;
 }

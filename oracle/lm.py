@@ -132,6 +132,18 @@ def bounded_scalars(n_knots, n_landmarks, free, sensor_mto=1e-3):
     return out
 
 
+def bounds_in_problem(oracle, bnd, n_knots):
+    """A bounded block makes the problem constrained only if it is PART of the problem: Ceres' Program holds the parameter blocks some residual block uses, and
+    Program::IsBoundsConstrained looks at those.  Solve #0 (gyroscope + prior) leaves the landmarks formally unlocked but no reprojection block exists — round 6: with them
+    counted, the oracle ran Ceres' projected line search on Solve #0's rejected steps and accepted what the real minimizer (and the GPU's loop) rejects.  Inverse depths need
+    a reprojection or camera-surfel block, the LiDAR offset a surfel or camera-surfel block, the camera offset a reprojection or camera-surfel block."""
+    if not hasattr(oracle, "n_reproj"):
+        return bnd
+    has_rho = oracle.n_reproj + oracle.n_camsurf > 0
+    has_tau = {6 * n_knots + 14: oracle.n_surfel + oracle.n_camsurf > 0, 6 * n_knots + 21: oracle.n_reproj + oracle.n_camsurf > 0}
+    return [b for b in bnd if (has_tau[b[0]] if b[0] in has_tau else has_rho)]
+
+
 def projected_gradient_max(x, g, free, bnd):
     """|| x - Plus(x, -g) ||_inf over the free scalars: bounded ones projected onto their box, unbounded ones |g| (TrustRegionMinimizer::ComputeGradientNorms for a
     constrained problem; the ambient difference of a quaternion block equals |g| to third order)."""
@@ -167,6 +179,8 @@ def lm_solve(oracle, state, free, max_iterations=50, initial_radius=1e4, max_rad
     if mask is None:   # ambient entries of the free parameter blocks (a joint multi-sequence problem passes its own)
         mask = free_state_mask(n_knots, n_landmarks, free)
     bnd = bounded_scalars(n_knots, n_landmarks, free, sensor_mto) if (constrained is None and n_knots is not None) else (constrained or [])
+    if constrained is None and n_knots is not None:
+        bnd = bounds_in_problem(oracle, bnd, n_knots)
     if bnd:
         x = oracle.plus(x, np.zeros(oracle.tangent_size))      # IterationZero: the start point projected onto the box
     ev = oracle.evaluate(x, normal_eq=True)

@@ -205,7 +205,7 @@ def lm_solve(oracle, state, free, n_knots, n_landmarks, max_iterations=50, initi
         timing["jacobian"] += t1 - t0; timing["product"] += time.perf_counter() - t1
         return ev["cost"], H, g
 
-    bnd = lm.bounded_scalars(n_knots, n_landmarks, free, sensor_mto)    # box constraints: Ceres' constrained-problem behaviour (oracle/lm.py header)
+    bnd = lm.bounds_in_problem(oracle, lm.bounded_scalars(n_knots, n_landmarks, free, sensor_mto), n_knots)    # box constraints of the blocks that are in the problem: Ceres' constrained-problem behaviour (oracle/lm.py header)
     if bnd:
         x = oracle.plus(x, np.zeros(oracle.tangent_size))
     cost, H, g = linearise(x)

@@ -64,6 +64,7 @@ class Oracle:
         self._l = lib()
         self._h = C.c_void_p(self._l.orc_create())
         self._keep = []
+        self.n_surfel = self.n_reproj = self.n_camsurf = 0    # blocks per family: which bounded parameter blocks are part of the problem at all (oracle/lm.py)
 
     def __del__(self):
         try:
@@ -91,6 +92,7 @@ class Oracle:
 
     def set_surfel(self, pt, t, plane_id, t_map, huber, w):
         pt, t, plane_id = _d(pt), _d(t), _i(plane_id)
+        self.n_surfel = len(t)
         self._l.orc_set_surfel(self._h, C.c_int(len(t)), _p(pt), _p(t), _p(plane_id), C.c_double(t_map), C.c_double(huber), C.c_double(w))
 
     def set_landmarks(self, uv_ref, t0_ref):
@@ -100,10 +102,12 @@ class Oracle:
 
     def set_reproj(self, lm, uv_obs, t0_obs, huber, w):
         lm, uv_obs, t0_obs = _i(lm), _d(uv_obs), _d(t0_obs)
+        self.n_reproj = len(lm)
         self._l.orc_set_reproj(self._h, C.c_int(len(lm)), _p(lm), _p(uv_obs), _p(t0_obs), C.c_double(huber), C.c_double(w))
 
     def set_camsurf(self, lm, plane_id, t_map, huber, w):
         lm, plane_id = _i(lm), _i(plane_id)
+        self.n_camsurf = len(lm)
         self._l.orc_set_camsurf(self._h, C.c_int(len(lm)), _p(lm), _p(plane_id), C.c_double(t_map), C.c_double(huber), C.c_double(w))
 
     def set_locks(self, mask):

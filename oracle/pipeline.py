@@ -38,6 +38,8 @@ def stage_locks(stage, opt_time_offset=False):
         return tau
     if stage == "TrajFromLVILandmarksOnly":  # :197-257 with lock_traj_lidar_in_3rd_stage
         return tau | LOCK["TRAJ"] | LOCK["LIDAR_Q"] | LOCK["LIDAR_P"]
+    if stage == "TrajFromVisualFrames":     # :99-136 (LIinitializer::CIoptimize): camera-IMU only, LiDAR extrinsics locked
+        return LOCK["LIDAR_Q"] | LOCK["LIDAR_P"] | LOCK["LIDAR_TAU"] | (0 if opt_time_offset else LOCK["CAM_TAU"])
     raise ValueError(stage)
 
 
@@ -182,6 +184,9 @@ def solve_stage(S, state, stage, planes, points, opt=None, camsurf=None, max_ite
         o.set_imu(S["t_imu"], S["gyro"], np.zeros_like(S["acc"]), opt["w_gyro"], opt["w_acc"])
         o.set_so3_only(True)
         o.set_orientation_prior(S["t0"], [np.cos(0.5e-4), 0, 0, np.sin(0.5e-4)], opt["w_gyro"])
+    elif stage == "TrajFromVisualFrames":
+        o.set_imu(S["t_imu"], S["gyro"], S["acc"], opt["w_gyro"], opt["w_acc"])
+        o.set_reproj(S["rep_lm"], S["rep_uv"], S["rep_t0"], opt["w_cam"], 1.0)
     else:
         o.set_imu(S["t_imu"], S["gyro"], S["acc"], opt["w_gyro"], opt["w_acc"])
         o.set_planes(planes["Pi"])
@@ -194,7 +199,7 @@ def solve_stage(S, state, stage, planes, points, opt=None, camsurf=None, max_ite
     o.set_locks(locks)
     free = lm.free_tangent_indices(N, L, locks)
     if max_iterations is None:
-        max_iterations = 30 if stage in ("SO3FromGyro", "TrajFromSurfel") else 80
+        max_iterations = 30 if stage in ("SO3FromGyro", "TrajFromSurfel") else (200 if stage == "TrajFromVisualFrames" else 80)
     return lm.lm_solve(o, state, free, max_iterations=max_iterations, n_knots=N, n_landmarks=L)
 
 

@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
     if (argc > 4) { if (!lvx_host::ReadPoseGT(argv[4], &in.loam)) throw std::runtime_error(std::string("cannot read pose file ") + argv[4]); }
     if (argc > 3) { opt.keep_history = true; opt.keep_clouds = true; }
     lvx_host::Calibrator cal(0, in, opt);
-    const auto rep = cal.Run(&state);
+    const auto rep = opt.refine_iterations < 0 ? cal.RunCameraImu(&state) : cal.Run(&state);   // refine_iterations = -1: the camera-IMU route (CIoptimize)
     std::vector<double> out;
     out.push_back((double)rep.size());
     for (const auto& r : rep) { out.push_back(r.lm.iterations); out.push_back(r.lm.termination); out.push_back(r.lm.initial_cost); out.push_back(r.lm.final_cost); out.push_back(r.n_planes); out.push_back(r.n_surfel_points); out.push_back(r.n_cam_surfel);

@@ -254,3 +254,30 @@ def test_batch_optimization_after_the_first_map_matches_the_oracle_lm(run_loam):
     e = _ext_err(xo, S["state_true"], N)
     print("after the batch optimisation, oracle vs ground truth (LiDAR):", e["lidar"], " start:", _ext_err(run_loam["x0"], S["state_true"], N)["lidar"])
     assert np.abs(xo[:3 * N]).max() > 0.1                                             # the positions left zero
+
+
+# ---- LIinitializer::CIoptimize (lvi_initialize_surfel_orb.cpp:519-537): camera-IMU calibration alone ----
+def test_camera_imu_route_matches_the_oracle_lm(tmp_path_factory):
+    """initialSO3TrajWithGyro, then trajInitFromVisualFrames (trajectory_manager_lvi.cpp:99-136: gyroscope + accelerometer + reprojection blocks, LiDAR extrinsics locked,
+    <= 200 iterations) through lvx_host::Calibrator::RunCameraImu, each solve against the oracle LM from the same state: accept / reject sequence, termination, cost
+    history, camera extrinsics."""
+    d = tmp_path_factory.mktemp("calib_ci")
+    exe = _build_demo(d)
+    S = synth.make_sequence(seed=53, duration=4.0, n_reproj=1500)
+    N = S["n_knots"]
+    x0 = np.array(S["state0"], dtype=np.float64)
+    x0[3 * N:7 * N] = np.tile([0.0, 0.0, 0.0, 1.0], N)      # Solve #0 starts from identity rotations, as the reference does (from rotations already near the truth the gyro-only
+    #                                                          problem is a 1e11-conditioned plateau on which two correct LMs part ways within a few iterations)
+    out = _run_demo(exe, d, S, 2, 0, refine_iterations=-1, lvi=0, camsurf=0, solve0=1, state=x0)
+    for k, stage in ((0, "SO3FromGyro"), (1, "TrajFromVisualFrames")):
+        st = out["stages"][k]
+        xo, so = pipeline.solve_stage(S, st["state_in"], stage, None, None)
+        print("%-22s gpu: it %d %s cost %.6e -> %.6e | oracle: it %d %s -> %.6e" % (stage, st["iterations"], st["termination"], st["initial_cost"], st["final_cost"], so["iterations"], so["termination"], so["final_cost"]))
+        assert abs(st["initial_cost"] - so["initial_cost"]) <= 1e-10 * so["initial_cost"]
+        assert list(st["accepted"]) == list(so["accepted"]) and st["termination"] == so["termination"] and st["iterations"] == so["iterations"]
+        assert np.abs(st["cost_history"] - so["cost_history"]).max() <= 1e-7 * so["cost_history"].max()
+        e = _ext_err(st["state_out"], xo, N)
+        assert e["cam"][0] <= 1e-6 and e["cam"][1] <= 1e-4 and e["lidar"] == (0.0, 0.0)      # the LiDAR extrinsics are locked: untouched on both sides
+    e0, e1 = _ext_err(x0, S["state_true"], N), _ext_err(out["x_final"], S["state_true"], N)
+    print("camera extrinsics vs ground truth: start", e0["cam"], "end", e1["cam"])
+    assert e1["cam"][0] < 0.2 * e0["cam"][0]
