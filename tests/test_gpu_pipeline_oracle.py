@@ -281,3 +281,43 @@ def test_camera_imu_route_matches_the_oracle_lm(tmp_path_factory):
     e0, e1 = _ext_err(x0, S["state_true"], N), _ext_err(out["x_final"], S["state_true"], N)
     print("camera extrinsics vs ground truth: start", e0["cam"], "end", e1["cam"])
     assert e1["cam"][0] < 0.2 * e0["cam"][0]
+
+
+# ---- lvi.yaml's opt_time_offset = true: the sensor time offsets are parameter blocks of the stages (trajectory_manager_lvi.cpp:159-165, 327-335) ----
+@pytest.mark.parametrize("stage", ["TrajFromSurfel", "TrajFromLVI"])
+def test_stages_with_free_time_offsets_match_the_oracle_lm(run, stage):
+    """The same surfels and SurfelPoints as the first association round of the schedule, the stage solved with `opt_time_offset`: the LiDAR (and, with the
+    reprojection blocks, the camera) time offset is free, bounded by +- 1 ms (sensors.h:161-162) — the fused kernels' time-offset column, 5-control-point
+    segments, the projected line search of the constrained problem — against the oracle LM from the same state."""
+    S, rec = run["S"], run["assoc"][0]
+    opt = dict(pipeline.DEFAULTS, opt_time_offset=True)
+    planes, points = _planes_dict(rec["planes"]), _points_dict(rec)
+    x0 = np.array(run["stages"][0]["state_in"])
+    N, L = S["n_knots"], len(S["lm_t0"])
+    locks = pipeline.stage_locks(stage, True)
+    g = lvx.Context(0)
+    g.set_spline(S["t0"], S["dt"], N)
+    c = S["camera"]
+    g.set_camera(c["rows"], c["cols"], c["readout"], c["fx"], c["fy"], c["cx"], c["cy"], c["k1"], c["k2"], c["p1"], c["p2"], c["k3"])
+    g.set_landmarks(S["lm_uv"], S["lm_t0"])
+    g.set_imu(S["t_imu"], S["gyro"], S["acc"], opt["w_gyro"], opt["w_acc"])
+    g.set_planes(planes["Pi"])
+    pt, t, pid = pipeline.select_surfels(points, S["t_map"], opt["downsample_step"])
+    g.set_surfel(pt, t, pid, S["t_map"], 5.0, opt["w_surfel"])
+    if stage != "TrajFromSurfel":
+        g.set_reproj(S["rep_lm"], S["rep_uv"], S["rep_t0"], opt["w_cam"], 1.0)
+    g.set_locks(locks)
+    iters = 30 if stage == "TrajFromSurfel" else 80
+    xg, sg = g.lm_solve(x0, max_iterations=iters)
+    assert g.layout()["exact_fallback"] == 0
+    g.close()
+    xo, so = pipeline.solve_stage(S, x0, stage, planes, points, opt)
+    print("%s, free offsets: gpu it %d %s cost %.6e -> %.6e | oracle it %d %s -> %.6e; tau_L %.3e tau_C %.3e" % (stage, sg["iterations"], sg["termination"], sg["initial_cost"], sg["final_cost"],
+                                                                                                                 so["iterations"], so["termination"], so["final_cost"], xg[7 * N + 23], xg[7 * N + 31]))
+    assert list(sg["accepted"]) == list(so["accepted"]) and sg["termination"] == so["termination"] and sg["iterations"] == so["iterations"]
+    assert np.abs(np.asarray(sg["cost_history"]) - so["cost_history"]).max() <= 1e-7 * so["cost_history"].max()
+    e = _ext_err(xg, xo, N)
+    assert e["lidar"][0] <= 1e-6 and e["cam"][0] <= 1e-6 and e["lidar"][1] <= 1e-4 and e["cam"][1] <= 1e-4
+    assert abs(xg[7 * N + 23] - xo[7 * N + 23]) <= 1e-9 and abs(xg[7 * N + 31] - xo[7 * N + 31]) <= 1e-9
+    assert abs(xg[7 * N + 23]) <= 1e-3 + 1e-15 and abs(xg[7 * N + 31]) <= 1e-3 + 1e-15       # inside the box
+    assert xg[7 * N + 23] != 0.0                                                            # the LiDAR offset moved
