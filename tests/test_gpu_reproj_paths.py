@@ -139,3 +139,27 @@ def test_fused_kernel_solves_like_the_chain():
     ca, cb = np.asarray(a["cost_history"]), np.asarray(b["cost_history"])
     assert np.abs(ca - cb).max() <= 1e-9 * np.abs(cb).max()
     assert np.abs(a["state"] - b["state"]).max() <= 1e-9 * max(1.0, np.abs(b["state"]).max())
+
+
+@pytest.mark.parametrize("mode", [1, -1])
+def test_wide_control_point_pair_under_a_camera_frame_both_paths(mode):
+    """A control point turned by 2 rad against its neighbours in the middle of a co-visibility window: the reprojection blocks whose views touch it cannot use the
+    control-point-pair table (small-angle polynomials) — k_reproj_jac / k_reproj_fused put them on the reprojection fallback list, the exact per-segment kernel adds them
+    behind the landmark rows; IMU samples and surfel points around the same knot take their own lists.  Same numbers as the oracle, the pass stays on the fused kernels."""
+    P = synth.make_bench_problem(seed=11, n_imu=1200, n_surfel=600, n_reproj=1500, n_planes=10, tracks="orb", obs_per_frame=40)
+    N = P["n_knots"]
+    k = int((P["lm_t0"][0] - P["t0"]) / P["dt"]) + 2
+    s = P["state0"].copy()
+    s[3 * N + 4 * k:3 * N + 4 * k + 4] = synth.qmul(synth.q_from_rotvec(np.array([0.0, 0.0, 2.0])), s[3 * N + 4 * k:3 * N + 4 * k + 4].copy())
+    o, g = _pair(P, TAU_LOCKS, mode)
+    g.evaluate(s, normal_eq=True)      # the pass that discovers the rows switches the lists on and is repeated: _check counts the launches of a settled pass
+    _check(o, g, s, mode)
+    lo = g.layout()
+    assert lo["exact_fallback"] == 0 and lo["fallback_rows"] > 50      # IMU samples + surfel points + the views of the frames around knot k
+    # the reprojection blocks were among them: with the reprojection family alone the list is not empty either
+    Q = dict(P, t_imu=P["t_imu"][:0], gyro=P["gyro"][:0], acc=P["acc"][:0], surf_pt=P["surf_pt"][:0], surf_t=P["surf_t"][:0], surf_plane=P["surf_plane"][:0])
+    o2, g2 = _pair(Q, TAU_LOCKS, mode)
+    g2.evaluate(s, normal_eq=True)
+    _check(o2, g2, s, mode)
+    assert g2.layout()["fallback_rows"] > 0
+    g.close(); g2.close()
