@@ -176,3 +176,46 @@ def test_config3_step_solves_the_oracles_damped_system(config3):
     print("config 3 step: |residual| / |S g| = %.3e, model cost change %.9e (lvx %.9e)" % (rel, model, mcc))
     assert rel <= 1e-8 and not delta[~free].any()
     assert abs(model - mcc) <= 1e-8 * abs(model) and model > 0
+
+
+# ---- the camera-landmark-to-surfel family at scale: config 4 + 20 000 cam-surfel blocks, the third stage's lock mask and everything free ----
+@pytest.mark.parametrize("locks_name", ["all_free", "stage3"])
+def test_config4_with_camera_surfel_blocks_matches_the_oracle(locks_name):
+    """The fused cam-surfel kernel (k_family_mfma<CamSurfAcc>) is otherwise only compared on small problems: here 20 000 blocks (every landmark against four surfels) ride on
+    the full config-4 problem — residual rows, cost, gradient and diag(J^T J) against the oracle's dual-number pass; `stage3` = trajInitFromLVIdata with lm_splane
+    (trajectory_manager_lvi.cpp:197-257: trajectory and LiDAR extrinsics locked, camera extrinsics + inverse depths + IMU calibration free)."""
+    P = dict(synth.make_bench_problem(seed=4))
+    rng = np.random.default_rng(9)
+    L = P["n_landmarks"]
+    P["cs_lm"] = np.repeat(np.arange(L, dtype=np.int32), 4)[:20_000]
+    P["cs_plane"] = rng.integers(0, len(P["planes"]), len(P["cs_lm"])).astype(np.int32)
+    locks = TAU if locks_name == "all_free" else (TAU | lvx.LOCK_TRAJ | lvx.LOCK_LIDAR_Q | lvx.LOCK_LIDAR_P)
+    g = lvx.Context(0)
+    o = O.Oracle()
+    for obj in (g, o):
+        lvx.load_problem(obj, P, locks)
+    x = P["state0"]
+    rg = g.evaluate(x, normal_eq=True, dense=False)
+    gg, dg = g.gradient()
+    lo, rows = g.layout(), g.family_rows()
+    g.close()
+    ro = o.evaluate_products(x)
+    assert lo["exact_fallback"] == 0 and lo["fallback_rows"] == 0 and rows[6] - rows[5] == len(P["cs_lm"])
+    err = np.abs(rg["residuals"] - ro["residuals"])
+    for f, name in enumerate(("gyro", "accel", "prior", "surfel", "reproj", "camsurf")):
+        a, b = rows[f], rows[f + 1]
+        if b > a:
+            scale = np.abs(ro["residuals"][a:b]).max()
+            print("%-7s %8d rows: max |err| / max |r| = %.3e" % (name, b - a, err[a:b].max() / scale))
+            assert err[a:b].max() <= 1e-11 * scale
+    assert abs(rg["cost"] - ro["cost"]) <= 1e-12 * abs(ro["cost"])
+    n = lo["n_knots"]
+    for name, a, b in (("g", gg, ro["g"]), ("diag", dg, ro["diag"])):
+        sc = _block_scale(b, n)
+        live = sc > 0                                   # (a locked block kind has scale 0: it must be exactly zero on both sides)
+        assert not a[~live].any() and not b[~live].any()
+        rel = np.abs(a - b)[live] / sc[live]
+        print("%s (%s): max block-scaled err %.3e" % (name, locks_name, rel.max()))
+        assert rel.max() <= 1e-10
+    if locks_name == "stage3":
+        assert not gg[:6 * n].any() and not gg[6 * n + 8:6 * n + 14].any() and gg[6 * n + 15:6 * n + 21].any()   # knots and LiDAR extrinsics constant, camera extrinsics live
