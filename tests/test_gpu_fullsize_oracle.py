@@ -219,3 +219,58 @@ def test_config4_with_camera_surfel_blocks_matches_the_oracle(locks_name):
         assert rel.max() <= 1e-10
     if locks_name == "stage3":
         assert not gg[:6 * n].any() and not gg[6 * n + 8:6 * n + 14].any() and gg[6 * n + 15:6 * n + 21].any()   # knots and LiDAR extrinsics constant, camera extrinsics live
+
+
+# ---- variants of config 4 at full size that the default fixture does not reach ----
+@pytest.mark.parametrize("variant", ["free_time_offsets", "radtan", "solve0"])
+def test_config4_variants_match_the_oracle_at_full_size(variant):
+    """free_time_offsets: lvi.yaml's opt_time_offset — both sensor offsets free and NON-ZERO (the fused kernels' time-offset column, 5-control-point segments, views that
+    change knot interval); radtan: the distortion model of lvi.yaml:54-78 (8 fixed-point iterations in Unproject); solve0: initialSO3TrajWithGyro — 200 k gyroscope blocks +
+    the orientation prior on the SO3 spline alone (k_family_mfma<GyroAcc>).  Residual rows 1e-11 per family, cost 1e-12, g and diag(J^T J) 1e-10 block-scaled."""
+    if variant == "radtan":
+        P = dict(synth.make_bench_problem(seed=4))
+        P["camera"] = dict(P["camera"], k1=-0.0397646985948, k2=0.00802944041788, p1=-0.0043042199686, p2=-0.0001040279967, k3=0.00030608999077)
+    else:
+        P = dict(synth.make_bench_problem(seed=4))
+    N = P["n_knots"]
+    x = P["state0"].copy()
+    locks = TAU
+    if variant == "free_time_offsets":
+        locks = 0
+        x[7 * N + 23], x[7 * N + 31] = 6.5e-4, -8e-4
+    g = lvx.Context(0)
+    o = O.Oracle()
+    for obj in (g, o):
+        if variant == "solve0":
+            Q = dict(P, surf_pt=P["surf_pt"][:0], surf_t=P["surf_t"][:0], surf_plane=P["surf_plane"][:0], rep_lm=P["rep_lm"][:0], rep_uv=P["rep_uv"][:0], rep_t0=P["rep_t0"][:0],
+                     acc=np.zeros_like(P["acc"]))
+            lvx.load_problem(obj, Q, lvx.LOCK_R3 | lvx.LOCK_ACC_BIAS | lvx.LOCK_GYRO_BIAS | TAU)
+            obj.set_so3_only(True)
+            obj.set_orientation_prior(P["t0"], np.array([np.cos(5e-5), 0, 0, np.sin(5e-5)]), 28.0)
+        else:
+            lvx.load_problem(obj, P, locks)
+    rg = g.evaluate(x, normal_eq=True, dense=False)
+    gg, dg = g.gradient()
+    lo, rows = g.layout(), g.family_rows()
+    g.close()
+    ro = o.evaluate_products(x)
+    assert lo["exact_fallback"] == 0 and lo["fallback_rows"] == 0
+    err = np.abs(rg["residuals"] - ro["residuals"])
+    for f, name in enumerate(("gyro", "accel", "prior", "surfel", "reproj", "camsurf")):
+        a, b = rows[f], rows[f + 1]
+        if b > a:
+            scale = max(np.abs(ro["residuals"][a:b]).max(), 100.0 if name == "reproj" else 0.0)   # (a pixel residual is the difference of two ~1e3 px numbers)
+            print("%-18s %-7s %8d rows: max |err| / scale = %.3e" % (variant, name, b - a, err[a:b].max() / scale))
+            assert err[a:b].max() <= 1e-11 * scale
+    assert abs(rg["cost"] - ro["cost"]) <= 1e-12 * abs(ro["cost"])
+    for name, a, b in (("g", gg, ro["g"]), ("diag", dg, ro["diag"])):
+        sc = _block_scale(b, N)
+        live = sc > 0
+        assert not a[~live].any() and not b[~live].any()
+        rel = np.abs(a - b)[live] / sc[live]
+        print("%-18s %s: max block-scaled err %.3e" % (variant, name, rel.max()))
+        assert rel.max() <= 1e-10
+    if variant == "free_time_offsets":
+        assert gg[6 * N + 14] != 0.0 and gg[6 * N + 21] != 0.0 and dg[6 * N + 14] > 0 and dg[6 * N + 21] > 0
+    if variant == "solve0":
+        assert rows[1] - rows[0] == 600_000 and rows[3] - rows[2] == 1 and not gg[:6 * N].reshape(N, 6)[:, :3].any()
