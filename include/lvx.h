@@ -99,6 +99,9 @@ typedef struct lvx_layout {
   int32_t solver_fallbacks; /* LM steps so far whose cyclic-reduction factorisation lost positive definiteness and were redone by the sequential band Cholesky */
   int32_t fallback_rows;    /* blocks of the last evaluation whose cost was read that the fused kernels handed, row by row, to the exact per-segment kernel (a control-point
                              * pair beyond 0.8 rad, the merged map-time segment corner): the pass stays on the fused kernels for everything else */
+  int32_t solver_separators; /* the last solver plan: separators of the leaves + separators elimination of the band (a band that is narrow except for isolated wide runs:
+                              * csrc/lvx_nd.h); 0: the uniform block chain (block cyclic reduction with b = bandwidth) runs */
+  int32_t solver_leaves;     /* ... and its leaves (narrow stretches and wide runs) */
 } lvx_layout;
 
 /* lifetime ------------------------------------------------------------------------------------------------*/

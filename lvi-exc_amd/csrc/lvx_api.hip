@@ -16,7 +16,7 @@ const SwitchName* switch_table(int* count) {
   static const SwitchName tab[] = {
     {"FORCE_LEGACY", &Switches::force_legacy, false}, {"SERIAL", &Switches::serial, false}, {"NO_GRAPH", &Switches::no_graph, false}, {"DETERMINISTIC", &Switches::deterministic, true},
     {"CLEAR_ALL", &Switches::clear_all, false}, {"SOLVER_SEQ", &Switches::solver_seq, false}, {"SOLVER_TIMING", &Switches::solver_timing, false},
-    {"CHUNK_R", &Switches::chunk_r, true}, {"CHUNK_R_IMU", &Switches::chunk_r_imu, true}, {"CHUNK_R_REP", &Switches::chunk_r_rep, true}, {"CHUNK_ROWS", &Switches::chunk_rows, true}, {"REP_ROWS", &Switches::rep_rows, true}, {"REP_FUSED", &Switches::rep_fused, true},
+    {"CHUNK_R", &Switches::chunk_r, true}, {"CHUNK_R_IMU", &Switches::chunk_r_imu, true}, {"CHUNK_R_REP", &Switches::chunk_r_rep, true}, {"CHUNK_ROWS", &Switches::chunk_rows, true}, {"REP_ROWS", &Switches::rep_rows, true}, {"REP_FUSED", &Switches::rep_fused, true}, {"SOLVER_ND", &Switches::solver_nd, false},
     {"DA_SYNC", &Switches::da_sync, false},   // lvx_data_association: always the synchronous chain (four host stops), never the speculative one
   };
   *count = (int)(sizeof(tab) / sizeof(tab[0]));
@@ -186,6 +186,7 @@ int lvx_get_layout(lvx_ctx* c, lvx_layout* o) {
   o->n_knots = c->N; o->n_landmarks = c->L; o->n_tangent = lvx_tangent_size(c); o->n_band = c->nb; o->bandwidth = c->bw; o->n_border = c->nbd; o->border_ld = c->nbd_ext;
   o->n_hub_knots = c->n_hub; o->hub_knot0 = c->hub0; o->n_blocks = c->n_blocks; o->n_residuals = c->n_residuals;
   o->exact_fallback = c->force_legacy ? 1 : 0; o->solver_fallbacks = c->solver_fallbacks; o->fallback_rows = c->fallback_rows;
+  nd_counts(c, &o->solver_separators, &o->solver_leaves);
   return LVX_OK;
 }
 

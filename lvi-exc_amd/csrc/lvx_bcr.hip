@@ -1084,22 +1084,33 @@ static inline int level_batch(int nblk, int nreal, int l) {
   return std::min(full, (nreal - (s - 1) + 2 * s - 1) / (2 * s));
 }
 
+// A chain of nblk (power of two; nreal live) b x b blocks: diagonal blocks D (-> factors), per-level couplings G, the factors' diagonal-triangle inverses LI (or null), pivot codes.
+// The band itself (bcr_factor) and the separator system of the leaves + separators elimination (lvx_nd.h) are both such chains.
+struct BcrChain { int b, nblk, nreal; double *D, *G, *LI; int* info; };
+static BcrChain ctx_chain(lvx_ctx* c) {
+  return BcrChain{c->bcr_b, c->bcr_nblk, c->bcr_nreal, (double*)c->d_bcrD.p, (double*)c->d_bcrG.p, c->bcr_linv ? (double*)c->d_bcrLinv.p : nullptr, (int*)c->d_bcrInfo.p};
+}
+static int chain_factor(lvx_ctx* c, const BcrChain& ch, int* info_out_d, double* Z, int ldz, int nrhs);
 int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_radius, int* info_out_d, double* Z, int ldz, int nrhs) {
+  const BcrChain ch = ctx_chain(c);
+  const int nfill = std::min(ch.nblk, std::max(ch.nreal, 1));
+  hipLaunchKernelGGL(k_bcr_build, dim3((unsigned)((ch.b + 3) / 4), (unsigned)nfill, 2), dim3(256), 0, c->stream, c->p_Hs ? c->p_Hs : (const double*)c->d_Hb.p, scale, lmd, inv_radius, c->nb, c->bw, ch.b, nfill, ch.D, ch.G);
+  return chain_factor(c, ch, info_out_d, Z, ldz, nrhs);
+}
+static int chain_factor(lvx_ctx* c, const BcrChain& ch, int* info_out_d, double* Z, int ldz, int nrhs) {
   rocblas_handle h = nullptr; int rc = LVX_OK;   // (the handle is fetched only where a library call is really made: blocks wider than 208)
-  const int b = c->bcr_b, nblk = c->bcr_nblk;
+  const int b = ch.b, nblk = ch.nblk, nreal = ch.nreal;
   const size_t bb = (size_t)b * b;
-  double* D = (double*)c->d_bcrD.p; double* G = (double*)c->d_bcrG.p; int* info = (int*)c->d_bcrInfo.p;
-  double* LI = c->bcr_linv ? (double*)c->d_bcrLinv.p : nullptr;
+  double* D = ch.D; double* G = ch.G; int* info = ch.info;
+  double* LI = ch.LI;
   const size_t liS = (size_t)((b + 15) / 16) * 256;
   hipStream_t st = c->stream;
-  const int nfill = std::min(nblk, std::max(c->bcr_nreal, 1));
-  hipLaunchKernelGGL(k_bcr_build, dim3((unsigned)((b + 3) / 4), (unsigned)nfill, 2), dim3(256), 0, st, c->p_Hs ? c->p_Hs : (const double*)c->d_Hb.p, scale, lmd, inv_radius, c->nb, c->bw, b, nfill, D, G);
   LVX_HIP(c, hipMemsetAsync(info, 0, (size_t)(2 * nblk + 8) * 4, st));
   const double one = 1.0, mone = -1.0, zero = 0.0;
   int L = 0; while ((1 << L) < nblk) ++L;
   int info_pos = 0;
   for (int l = 0; l < L; ++l) {
-    const int s = 1 << l, n2 = level_batch(nblk, c->bcr_nreal, l);
+    const int s = 1 << l, n2 = level_batch(nblk, nreal, l);
     if (n2 <= 0) continue;
     const long long sD = (long long)2 * s * bb, sG = (long long)2 * bb;
     double* Dj = D + (size_t)(s - 1) * bb;
@@ -1175,14 +1186,14 @@ int bcr_forward(lvx_ctx* c, double* Zin, double* Zy, int ldz, int nrhs) {
   return trsv_batched<false>(c, D + (size_t)(nblk - 1) * bb, b, 0, Z + (size_t)(nblk - 1) * b, 1, ldz, 0, nrhs, 1, LI ? LI + (size_t)(nblk - 1) * liS : nullptr, 0);
 }
 // in place Zy <- L^-T Zy (Zx aliases Zy)
-int bcr_backward(lvx_ctx* c, double* Zy, double* Zx, int ldz, int nrhs) {
+static int chain_backward(lvx_ctx* c, const BcrChain& ch, double* Z, int ldz, int nrhs);
+int bcr_backward(lvx_ctx* c, double* Zy, double* Zx, int ldz, int nrhs) { (void)Zx; return chain_backward(c, ctx_chain(c), Zy, ldz, nrhs); }
+static int chain_backward(lvx_ctx* c, const BcrChain& ch, double* Z, int ldz, int nrhs) {
   rocblas_handle h = nullptr; int rc = LVX_OK;   // (the handle is fetched only where a library call is really made: blocks wider than 208)
-  (void)Zx;
-  double* Z = Zy;
-  const int b = c->bcr_b, nblk = c->bcr_nblk;
+  const int b = ch.b, nblk = ch.nblk, nreal = ch.nreal;
   const size_t bb = (size_t)b * b;
-  double* D = (double*)c->d_bcrD.p; double* G = (double*)c->d_bcrG.p;
-  const double* LI = c->bcr_linv ? (const double*)c->d_bcrLinv.p : nullptr;
+  double* D = ch.D; double* G = ch.G;
+  const double* LI = ch.LI;
   const size_t liS = (size_t)((b + 15) / 16) * 256;
   const double one = 1.0, mone = -1.0;
   int L = 0; while ((1 << L) < nblk) ++L;
@@ -1195,7 +1206,7 @@ int bcr_backward(lvx_ctx* c, double* Zy, double* Zx, int ldz, int nrhs) {
     LVX_HIP(c, hipGetLastError());
   } else if ((rc = trsv_batched<true>(c, D + (size_t)(nblk - 1) * bb, b, 0, Z + (size_t)(nblk - 1) * b, 1, ldz, 0, nrhs, 1, LI ? LI + (size_t)(nblk - 1) * liS : nullptr, 0))) return rc;
   for (int l = L - 1; l >= 0; --l) {
-    const int s = 1 << l, n2 = level_batch(nblk, c->bcr_nreal, l);
+    const int s = 1 << l, n2 = level_batch(nblk, nreal, l);
     if (n2 <= 0) continue;
     const long long sD = (long long)2 * s * bb, sG = (long long)2 * bb, sZ = (long long)2 * s * b;
     double* Dj = D + (size_t)(s - 1) * bb;
@@ -1241,7 +1252,7 @@ template <int NT, int WV> __device__ __forceinline__ void gram_steps(const doubl
   }
 }
 template <int NT>
-__global__ __launch_bounds__(256) void k_gram_mfma(const double* __restrict__ Z, int ldz, int m, int n, double* __restrict__ part) {
+__global__ __launch_bounds__(256) void k_gram_mfma(const double* __restrict__ Z, int ldz, int m, int n, double* __restrict__ part, int nz) {   // nz != 0: Z row-major [m][nz]
   __shared__ double P[64 * GRAM_LDP];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   constexpr int NP = NT * (NT + 1) / 2, MAXP = (NP + 3) / 4;
@@ -1252,14 +1263,24 @@ __global__ __launch_bounds__(256) void k_gram_mfma(const double* __restrict__ Z,
   // the next 64 rows are in flight (registers) while the matrix cores work on the staged ones
   double v[4 * NT];
   auto fetch = [&](int r0) {
+    if (nz) {   // row-major: consecutive threads take consecutive columns of a row (element tid + 256 u of the 64 x 16 NT stage)
+#pragma unroll
+      for (int u = 0; u < 4 * NT; ++u) { const int e = tid + 256 * u, row = e / (16 * NT), j = e % (16 * NT), i = r0 + row; v[u] = (j < n && i < r_end) ? Z[(size_t)i * nz + j] : 0.0; }
+      return;
+    }
     const int i = r0 + lane;
 #pragma unroll
     for (int u = 0; u < 4 * NT; ++u) { const int j = wv + 4 * u; v[u] = (j < n && i < r_end) ? Z[(size_t)i + (size_t)j * ldz] : 0.0; }
   };
   fetch(r_begin);
   for (int r0 = r_begin; r0 < r_end; r0 += 64) {
+    if (nz) {
+#pragma unroll
+      for (int u = 0; u < 4 * NT; ++u) { const int e = tid + 256 * u; P[(e / (16 * NT)) * GRAM_LDP + e % (16 * NT)] = v[u]; }
+    } else {
 #pragma unroll
     for (int u = 0; u < 4 * NT; ++u) P[lane * GRAM_LDP + wv + 4 * u] = v[u];
+    }
     __syncthreads();
     if (r0 + 64 < r_end) fetch(r0 + 64);
     switch (wv) {
@@ -1302,10 +1323,10 @@ __global__ void k_sum_partials(const double* P, int nn, int nparts, int per, dou
   for (int p = p0; p < p1; ++p) s += P[(size_t)p * nn + e];
   if (s != 0.0) atomicAdd(&M[e], s);
 }
-int bcr_gram(lvx_ctx* c, const double* Z, int ldz, int n, double* M) {
+int bcr_gram(lvx_ctx* c, const double* Z, int ldz, int n, double* M, int row_major_nz) {
   const int b = c->bcr_b, nblk = c->bcr_nblk;
   const size_t nn = (size_t)n * n;
-  const int m = nblk * b;
+  const int m = ldz;   // rows of Z: nblk * b for the chain of the band, nd_ldz for the leaves + separators elimination (rows past the band are zero)
   int rc;
   const double one = 1.0, zero = 0.0;
   LVX_HIP(c, hipMemsetAsync(M, 0, nn * 8, c->stream));
@@ -1313,11 +1334,12 @@ int bcr_gram(lvx_ctx* c, const double* Z, int ldz, int n, double* M) {
   if (n <= 16 * GRAM_NT) {
     const int nparts = (m + GRAM_ROWS - 1) / GRAM_ROWS, nt = n <= 48 ? 3 : (n <= 64 ? 4 : 5), np = nt * (nt + 1) / 2;
     if ((rc = dev_alloc(c, c->d_Y2, (size_t)nparts * np * 256 * 8))) return rc;
-    if (nt == 3) hipLaunchKernelGGL(k_gram_mfma<3>, dim3((unsigned)nparts), dim3(256), 0, c->stream, Z, ldz, m, n, (double*)c->d_Y2.p);
-    else if (nt == 4) hipLaunchKernelGGL(k_gram_mfma<4>, dim3((unsigned)nparts), dim3(256), 0, c->stream, Z, ldz, m, n, (double*)c->d_Y2.p);
-    else hipLaunchKernelGGL(k_gram_mfma<5>, dim3((unsigned)nparts), dim3(256), 0, c->stream, Z, ldz, m, n, (double*)c->d_Y2.p);
+    if (nt == 3) hipLaunchKernelGGL(k_gram_mfma<3>, dim3((unsigned)nparts), dim3(256), 0, c->stream, Z, ldz, m, n, (double*)c->d_Y2.p, row_major_nz);
+    else if (nt == 4) hipLaunchKernelGGL(k_gram_mfma<4>, dim3((unsigned)nparts), dim3(256), 0, c->stream, Z, ldz, m, n, (double*)c->d_Y2.p, row_major_nz);
+    else hipLaunchKernelGGL(k_gram_mfma<5>, dim3((unsigned)nparts), dim3(256), 0, c->stream, Z, ldz, m, n, (double*)c->d_Y2.p, row_major_nz);
     hipLaunchKernelGGL(k_sum_tiles, dim3((unsigned)((np * 256 + 255) / 256), (unsigned)((nparts + (long long)per - 1) / per)), dim3(256), 0, c->stream, (const double*)c->d_Y2.p, nt, nparts, per, n, M);
   } else {   // (more than 80 border columns: one small library GEMM per row block)
+    if (row_major_nz) return fail(c, LVX_E_STATE, "row-major right-hand sides with more than 80 columns");
     rocblas_handle h; if ((rc = bcr_handle(c, &h))) return rc;
     if ((rc = dev_alloc(c, c->d_Y2, (size_t)nblk * nn * 8))) return rc;
     LVX_BLAS(c, g_vb.dgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, n, n, b, &one, Z, ldz, (rocblas_stride)b, Z, ldz, (rocblas_stride)b,
@@ -1328,7 +1350,10 @@ int bcr_gram(lvx_ctx* c, const double* Z, int ldz, int n, double* M) {
   return LVX_OK;
 }
 
+#include "lvx_nd.h"
+
 void bcr_destroy(lvx_ctx* c) {
+  nd_destroy(c);
   if (!c->blas) return;
   std::lock_guard<std::mutex> lk(g_blas_mu);
   if (g_blas_free.size() < 16) g_blas_free.emplace_back(c->device, (rocblas_handle)c->blas); else if (g_vb.destroy_handle) (void)g_vb.destroy_handle((rocblas_handle)c->blas);

@@ -61,7 +61,7 @@ struct DevBuf {
 // Experiment / debug switches: read ONCE from the environment (LVX_<NAME>) when the context is created and changed afterwards only
 // through lvx_set_switch — the evaluation path never calls getenv.
 struct Switches {
-  int force_legacy = 0, serial = 0, no_graph = 0, deterministic = 0, clear_all = 0, solver_seq = 0, solver_timing = 0, chunk_r = 0, chunk_r_imu = 0, chunk_r_rep = 0, chunk_rows = 0, rep_rows = 0, da_sync = 0, rep_fused = 0;   // rep_fused: 1 = the single-launch reprojection kernel (k_reproj_fused; measured slower, opt-in), otherwise the five-launch chain
+  int force_legacy = 0, serial = 0, no_graph = 0, deterministic = 0, clear_all = 0, solver_seq = 0, solver_timing = 0, chunk_r = 0, chunk_r_imu = 0, chunk_r_rep = 0, chunk_rows = 0, rep_rows = 0, da_sync = 0, rep_fused = 0, solver_nd = 0;   // rep_fused: 1 = the single-launch reprojection kernel (k_reproj_fused; measured slower, opt-in), otherwise the five-launch chain
 };
 struct SwitchName { const char* name; int Switches::*field; bool relayout; };
 const SwitchName* switch_table(int* count);
@@ -113,6 +113,7 @@ struct lvx_ctx {
   lvx::DevBuf d_lm_grp; int lm_ngrp = 0, lm_gspread = 0;   // landmark groups of the elimination kernel (k_lm_schur_grp): [ngrp + 1 offsets | landmark ids sorted by first band position]
   lvx::DevBuf d_lmH, d_lm_p0, d_Hr, d_Br, d_red; int lm_wl = 0, lm_ls = 0; const double* p_Hs = nullptr;   // landmark rows (DevCommon::lmH); solver: band / border rows / [g_b | C | g_c] after the landmark elimination
   int hub_near_lo = 0, hub_near_hi = 0;   // band positions a residual can couple to a hub knot DIRECTLY (not through the pseudo pose): IMU / LiDAR rows within 4 knots, reprojection blocks within their span
+  std::vector<int> h_colhi; std::vector<uint8_t> h_colfull; int bw_near = 0, layout_epoch = 0;   // band column profile (ensure_layout) for the elimination plan of lvx_nd.h
   lvx::DevBuf d_colfull; int clear_npre = 0; std::vector<uint8_t> bd_row_live;   // structural clear of the band / border rows (k_clear)
   lvx::DevBuf d_hubs, d_chunk[LVX_NUM_FAM], d_repB[4];   // reprojection MFMA path: [0] materialised Jacobians + residuals, [1] knot intervals, [2] landmark and [3] observation-order index of the rows in (reference interval, landmark) order
   // deterministic mode (LVX_DETERMINISTIC=1): chunks of every family grouped into colours of pairwise disjoint knot ranges (det_list: chunk ids, colour by colour;
@@ -132,6 +133,7 @@ struct lvx_ctx {
   lvx::DevBuf d_bcrD, d_bcrG, d_bcrInfo, d_Y2, d_gram, d_bcrLinv; bool bcr_linv = false;   // d_bcrLinv: inverses of the factors' 16 x 16 diagonal triangles (k_potrf_batched -> k_trsm_reg)
   void* blas = nullptr;
   int bcr_b = 0, bcr_nblk = 0, bcr_nreal = 0;
+  void* nd = nullptr;   // lvx::NdPlan (lvx_nd.h): leaves + separators elimination of a band that is narrow except for isolated wide runs
   int64_t n_blocks = 0, n_residuals = 0;
   int64_t fam_row0[LVX_NUM_FAM + 1] = {0};
   uint32_t last_what = 0;
@@ -192,6 +194,7 @@ namespace lvx {
 int fail(lvx_ctx* ctx, int code, const std::string& msg);
 int dev_alloc(lvx_ctx* ctx, DevBuf& b, size_t bytes);
 int upload(lvx_ctx* ctx, DevBuf& b, const void* src, size_t bytes);
+int upload_tmp(lvx_ctx* ctx, DevBuf& b, const void* src, size_t bytes);
 int ensure_layout(lvx_ctx* ctx);
 int check_last_eval(lvx_ctx* ctx);
 int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cost, bool want_res_buffer);   // lvx_eval.hip: one evaluation pass
@@ -200,8 +203,16 @@ int bcr_plan(lvx_ctx* c);
 int bcr_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_radius, int* info_out_d, double* Z = nullptr, int ldz = 0, int nrhs = 0);
 int bcr_forward(lvx_ctx* c, double* Zin, double* Zy, int ldz, int nrhs);
 int bcr_backward(lvx_ctx* c, double* Zy, double* Zx, int ldz, int nrhs);
-int bcr_gram(lvx_ctx* c, const double* Z, int ldz, int n, double* M);
+int bcr_gram(lvx_ctx* c, const double* Z, int ldz, int n, double* M, int row_major_nz = 0);
 void bcr_destroy(lvx_ctx* c);
+// leaves + separators elimination (lvx_nd.h): nd_plan decides from the column profile whether it applies (nd_active afterwards) and sizes its buffers
+int nd_plan(lvx_ctx* c, int nrhs);
+bool nd_active(const lvx_ctx* c);
+int nd_ldz(const lvx_ctx* c);
+int nd_nz(const lvx_ctx* c);   // right-hand sides of the leaves + separators elimination are ROW-major [nd_ldz][nd_nz]
+void nd_counts(const lvx_ctx* c, int* separators, int* leaves);
+int nd_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_radius, int* info_out_d, double* Z, int ldz, int nrhs);
+int nd_backward(lvx_ctx* c, double* zb);
 // profiling scope: records a (start, stop) HIP event pair on ctx->stream around a launch when profiling is on
 struct ProfScope {
   lvx_ctx* c; int kernel; size_t e0 = 0; bool on; hipStream_t st;

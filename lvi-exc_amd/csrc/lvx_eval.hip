@@ -2333,13 +2333,16 @@ int ensure_layout(lvx_ctx* ctx) {
     for (int k = ka; k <= kb && k < N; ++k) for (int d = 0; d < 6; ++d) { const int o = ctx->ord[6 * k + d]; if (o >= 0) { lo = std::min(lo, o); hi = std::max(hi, o); } }
   };
   const int kspan = (!(locks & LVX_LOCK_LIDAR_TAU) || !(locks & LVX_LOCK_CAM_TAU)) ? 4 : 3;   // a free time offset pads the spans: segments of up to 5 control points
-  for (int k = 0; k + 3 < N; ++k) { int lo = 1 << 30, hi = -1; span_pos(k, k + kspan, lo, hi); if (hi >= lo) bw = std::max(bw, hi - lo); }
+  std::vector<int> top((size_t)std::max(ctx->nb, 1), -1);   // furthest band position a span that STARTS at a position reaches (-> h_colhi: the column profile of the band, lvx_nd.h)
+  auto mark_span = [&](int lo, int hi) { if (hi >= lo && lo < (int)top.size()) top[lo] = std::max(top[lo], hi); };
+  for (int k = 0; k + 3 < N; ++k) { int lo = 1 << 30, hi = -1; span_pos(k, k + kspan, lo, hi); if (hi >= lo) bw = std::max(bw, hi - lo); mark_span(lo, hi); }
   const int bw_near = bw;   // reach of the families that touch 4 neighbouring knots only (IMU, LiDAR, prior)
   std::vector<uint8_t> colfull((size_t)std::max(ctx->nb, 1), 0);   // band columns a reprojection block / a landmark reaches further from (k_clear)
   for (int i = 0; i < ctx->rep.n; ++i) {
     int lo = 1 << 30, hi = -1;
     span_pos(rep_kmin[i], rep_kmax[i], lo, hi);
     if (hi >= lo) { bw = std::max(bw, hi - lo); if (hi - lo > bw_near) std::fill(colfull.begin() + lo, colfull.begin() + hi + 1, (uint8_t)1); }
+    mark_span(lo, hi);
   }
   // the landmark elimination couples everything a landmark touches (fill of the reduced band); a landmark's row covers the same positions
   std::vector<int> lm_p0((size_t)std::max(L, 1), 0);
@@ -2351,6 +2354,7 @@ int ensure_layout(lvx_ctx* ctx) {
       if (!(locks & LVX_LOCK_LANDMARKS)) {   // a free landmark: the in-place elimination writes fill across its WHOLE reach, which may exceed every single block's
         bw = std::max(bw, hi - lo);
         if (hi - lo > bw_near) std::fill(colfull.begin() + lo, colfull.begin() + hi + 1, (uint8_t)1);
+        mark_span(lo, hi);
       }
     }
   }
@@ -2383,6 +2387,14 @@ int ensure_layout(lvx_ctx* ctx) {
     ctx->hub_near_lo = hi >= lo ? lo : 0; ctx->hub_near_hi = hi >= lo ? hi + 1 : 0;
   }
   if ((rc = upload_tmp(ctx, ctx->d_colfull, colfull.data(), colfull.size()))) return rc;
+  {   // column profile for the solver's elimination plan: h_colhi[j] = last band position column j couples to (j itself if none)
+    ctx->h_colhi.assign((size_t)std::max(ctx->nb, 0), 0);
+    int run = -1;
+    for (int j = 0; j < ctx->nb; ++j) { run = std::max(run, top[j]); ctx->h_colhi[j] = std::max(run, j); }
+    ctx->h_colfull.assign(colfull.begin(), colfull.begin() + std::max(ctx->nb, 0));
+    ctx->bw_near = std::min(bw_near, ctx->bw);
+    ++ctx->layout_epoch;
+  }
   {   // band columns k_imu_own STORES (ImuOwn::own): knots whose every contribution comes from ONE workgroup's samples and whose 24-entry column maps onto
       // position-contiguous neighbours.  A sample sorted into interval i evaluates in i - 1 .. i + 1 (|tau_imu| < dt) and touches 4 knots, so a range whose first
       // interval is B shares the knots [B - 1, B + 3] with its left neighbour: those, knots next to the hub gap or the spline's end and knots no batch window covers stay

@@ -353,6 +353,32 @@ __device__ __forceinline__ void block_atomic_max_nonneg(double v, double* dst) {
   __syncthreads();
   if (threadIdx.x == 0) { double t = 0.0; for (int k = 0; k < nw; ++k) t = fmax(t, part_[k]); atomicMax((unsigned long long*)dst, (unsigned long long)__double_as_longlong(t)); }
 }
+// the same on the ROW-major right-hand sides of the leaves + separators elimination (lvx_nd.h): Z [ldz][nz], the band's own column is column nbd; 16 lanes per row
+__global__ __launch_bounds__(256) void k_sub_border_rm(const double* Z, const double* yc, int nb, int nbd, int nz, double* z) {
+  const int j = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+  double s = 0.0;
+  if (j < nb) {
+    const double* row = Z + (size_t)j * nz;
+    for (int b = l; b < nbd; b += 16) s -= row[b] * yc[b];
+    if (l == 0) s += row[nbd];
+  }
+  for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (j < nb && l == 0) z[j] = s;
+}
+// Z row-major [ldz][nz] = [B^T | -g_b] scaled, zero rows past the band: 64 band positions per workgroup through LDS (the border rows are read along the band, the
+// right-hand sides written along their rows)
+__global__ __launch_bounds__(256) void k_build_rhs_rm(const double* Bd, const double* gb, const double* scale, int nb, int nbd, int ldz, int nz, double* Z) {
+  __shared__ double T[64][81];
+  const int j0 = blockIdx.x * 64, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = j0 + lane;
+  const double sj = j < nb ? scale[j] : 0.0;
+  for (int r = wv; r < nz; r += 4) {
+    double v = 0.0;
+    if (j < nb) { if (r < nbd) v = Bd[(size_t)r * nb + j] * scale[nb + r] * sj; else if (r == nbd) v = -gb[j] * sj; }
+    T[lane][r] = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * nz; e += 256) { const int row = e / nz, col = e % nz; if (j0 + row < ldz) Z[(size_t)(j0 + row) * nz + col] = T[row][col]; }
+}
 __global__ void k_sub_border(const double* Z, const double* yc, int nb, int nbd, int ldz, double* z) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nb) return;
@@ -760,9 +786,13 @@ static int solver_alloc(lvx_ctx* c, SolveWork& w, bool will_inplace = false) {
   const size_t nb = (size_t)std::max(c->nb, 1), nbd = c->nbd, nt = (size_t)lvx_tangent_size(c);
   const bool use_bcr = !c->sw.solver_seq;
   size_t ldz = nb;
-  if (use_bcr && c->nb > 0) { if ((rc = bcr_plan(c))) return rc; ldz = (size_t)c->bcr_nblk * c->bcr_b; }
+  if (use_bcr && c->nb > 0) {
+    if ((rc = nd_plan(c, (int)nbd + 1))) return rc;      // leaves + separators elimination when the band's column profile allows it (lvx_nd.h), the uniform chain otherwise
+    if (nd_active(c)) ldz = (size_t)nd_ldz(c);
+    else { if ((rc = bcr_plan(c))) return rc; ldz = (size_t)c->bcr_nblk * c->bcr_b; }
+  }
   w.ldz = (int)ldz; w.use_bcr = use_bcr && c->nb > 0;
-  if ((rc = dev_alloc(c, c->d_Y, (nbd + 1) * ldz * 8))) return rc;
+  if ((rc = dev_alloc(c, c->d_Y, std::max((nbd + 1) * ldz, nd_active(c) ? ((size_t)nd_nz(c) + 1) * ldz : (size_t)0) * 8))) return rc;   // (row-major [ldz][nd_nz] + the band's vector on the leaves + separators path)
   if (w.use_bcr) { if ((rc = dev_alloc(c, c->d_gram, (nbd + 1) * (nbd + 1) * 8))) return rc; }
   w.Z2 = (double*)c->d_Y2.p; w.gram = (double*)c->d_gram.p;
   if ((rc = dev_alloc(c, c->d_S, (nbd * nbd + nbd + 16) * 8))) return rc;
@@ -847,11 +877,13 @@ static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, 
   }
   if (nb > 0) {
     const size_t tr = (size_t)(nbd + 1) * ldz;
-    hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)((tr + 255) / 256)), dim3(256), 0, st, w.Bs, w.gbs, w.scale, nb, nbd, ldz, w.Z);
+    if (use_bcr && nd_active(c)) hipLaunchKernelGGL(k_build_rhs_rm, dim3((unsigned)((ldz + 63) / 64)), dim3(256), 0, st, w.Bs, w.gbs, w.scale, nb, nbd, ldz, nd_nz(c), w.Z);
+    else hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)((tr + 255) / 256)), dim3(256), 0, st, w.Bs, w.gbs, w.scale, nb, nbd, ldz, w.Z);
     if (use_bcr) {
       int rc2;
       tm.lap("enqueue build_rhs");
-      if ((rc2 = bcr_factor(c, w.scale, w.lmd, ir, w.info, w.Z, ldz, nbd + 1))) return rc2;   // factor, and Z <- L^-1 [B^T, f_b] (in place) level by level with it
+      if (nd_active(c)) { if ((rc2 = nd_factor(c, w.scale, w.lmd, ir, w.info, w.Z, ldz, nbd + 1))) return rc2; }
+      else if ((rc2 = bcr_factor(c, w.scale, w.lmd, ir, w.info, w.Z, ldz, nbd + 1))) return rc2;   // factor, and Z <- L^-1 [B^T, f_b] (in place) level by level with it
       tm.lap("enqueue bcr_factor + forward");
     } else {
       const size_t tot = (size_t)nb * (bw + 1);
@@ -868,7 +900,7 @@ static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, 
   double* Zf = w.Z;   // forward-substituted right-hand sides
   if (use_bcr && nb > 0) {
     int rc2;
-    if ((rc2 = bcr_gram(c, Zf, ldz, nbd + 1, w.gram))) return rc2;
+    if ((rc2 = bcr_gram(c, Zf, ldz, nbd + 1, w.gram, nd_active(c) ? nd_nz(c) : 0))) return rc2;
     hipLaunchKernelGGL(k_schur_from_gram, dim3((unsigned)((nbd * (nbd + 1) + 255) / 256)), dim3(256), 0, st, (const double*)w.gram, w.Cs, w.gcs,
                        (const double*)w.scale, nb, nbd, c->nbd_ext, (const double*)w.lmd, ir, w.S, w.rhs);
   } else {
@@ -994,12 +1026,15 @@ static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double m[3
     hipLaunchKernelGGL(k_dense_back, dim3(1), dim3(DENSE_NT), lds_dense, st, (const double*)w.S, w.rhs, nbd, np); }
   const int ldz = w.ldz;
   double* Zf = w.Z;
-  double* zb = Zf + (size_t)nbd * std::max(ldz, 1);
+  const bool zrm = bcr_used && nd_active(c);   // row-major right-hand sides; the band's vector lives behind them
+  double* zb = zrm ? Zf + (size_t)nd_nz(c) * ldz : Zf + (size_t)nbd * std::max(ldz, 1);
   if (nb > 0) {
-    hipLaunchKernelGGL(k_sub_border, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const double*)Zf, (const double*)w.rhs, nb, nbd, ldz, zb);
+    if (zrm) hipLaunchKernelGGL(k_sub_border_rm, dim3((unsigned)((nb + 15) / 16)), dim3(256), 0, st, (const double*)Zf, (const double*)w.rhs, nb, nbd, nd_nz(c), zb);
+    else hipLaunchKernelGGL(k_sub_border, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const double*)Zf, (const double*)w.rhs, nb, nbd, ldz, zb);
     if (bcr_used) {
       int rc2;
-      if ((rc2 = bcr_backward(c, zb, zb, ldz, 1))) return rc2;
+      if (nd_active(c)) { if ((rc2 = nd_backward(c, zb))) return rc2; }
+      else if ((rc2 = bcr_backward(c, zb, zb, ldz, 1))) return rc2;
     } else {
       const size_t lds_bw = (size_t)(bw + 1) * 8;
       hipLaunchKernelGGL(k_band_bwd, dim3(1), dim3(64), lds_bw, st, (const double*)w.L, nb, bw, zb);

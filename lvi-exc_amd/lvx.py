@@ -41,7 +41,7 @@ class Pinhole(C.Structure):
 class Layout(C.Structure):
     _fields_ = [("n_knots", C.c_int32), ("n_landmarks", C.c_int32), ("n_tangent", C.c_int32), ("n_band", C.c_int32),
                 ("bandwidth", C.c_int32), ("n_border", C.c_int32), ("border_ld", C.c_int32), ("n_hub_knots", C.c_int32), ("hub_knot0", C.c_int32),
-                ("n_blocks", C.c_int64), ("n_residuals", C.c_int64), ("exact_fallback", C.c_int32), ("solver_fallbacks", C.c_int32), ("fallback_rows", C.c_int32)]
+                ("n_blocks", C.c_int64), ("n_residuals", C.c_int64), ("exact_fallback", C.c_int32), ("solver_fallbacks", C.c_int32), ("fallback_rows", C.c_int32), ("solver_separators", C.c_int32), ("solver_leaves", C.c_int32)]
 
 
 class LmOptions(C.Structure):

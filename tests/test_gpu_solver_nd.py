@@ -1,0 +1,107 @@
+"""The leaves + separators elimination of the band (csrc/lvx_nd.h: narrow band leaves, dense leaves for the co-visibility windows, a chain of 32-wide separators) against
+the uniform block chain (SOLVER_ND = -1: block cyclic reduction with b = bandwidth) and the sequential band Cholesky (SOLVER_SEQ) on the SAME normal equations: three
+elimination orders of one SPD system.  Reference semantics of the step: Ceres' SPARSE_SCHUR LM step (kontiki/trajectory_estimator.h:38-68)."""
+import numpy as np
+import pytest
+
+import lvx
+import synth
+
+pytestmark = pytest.mark.gpu
+TAU = lvx.LOCK_LIDAR_TAU | lvx.LOCK_CAM_TAU
+RADIUS = 1e4
+
+
+def _step(P, locks, x, nd, seq=False, leaf=None, radius=RADIUS):
+    g = lvx.Context(0)
+    g.set_switch("SOLVER_ND", nd)
+    if seq:
+        g.set_switch("SOLVER_SEQ", 1)
+    lvx.load_problem(g, P, locks)
+    g.evaluate(x, normal_eq=True, dense=False, residuals=False)
+    d, m = g.solve_step(radius, True)
+    lo = g.layout()
+    g.close()
+    return d, m, lo
+
+
+def _same(d, m, dr, mr, tol=1e-7):
+    assert np.all(np.isfinite(d)) and np.abs(d).max() > 0
+    assert np.abs(d - dr).max() <= tol * max(1.0, np.abs(dr).max()), "step differs by %.3e" % (np.abs(d - dr).max() / max(1.0, np.abs(dr).max()))
+    assert abs(m - mr) <= 1e-8 * abs(mr)
+
+
+@pytest.mark.parametrize("seed,n_reproj,obs", [(31, 2400, 40), (32, 1200, 60), (33, 4000, 40)])
+def test_step_matches_the_uniform_chain_and_the_sequential_solver(seed, n_reproj, obs):
+    """Narrow stretches + co-visibility windows (dense leaves) + hub border (53 right-hand sides)."""
+    P = synth.make_bench_problem(seed=seed, n_imu=16000, n_surfel=40000, n_reproj=n_reproj, n_planes=60, obs_per_frame=obs)
+    x = P["state0"]
+    d, m, lo = _step(P, TAU, x, 1)
+    assert lo["solver_separators"] > 2 and lo["solver_leaves"] == lo["solver_separators"] + 1 and lo["solver_fallbacks"] == 0
+    du, mu, lou = _step(P, TAU, x, -1)
+    assert lou["solver_separators"] == 0 and lou["solver_fallbacks"] == 0
+    ds, ms, _ = _step(P, TAU, x, -1, seq=True)
+    _same(d, m, ds, ms)
+    _same(du, mu, ds, ms)
+    _same(d, m, du, mu)
+
+
+def test_imu_only_band_has_narrow_leaves_only():
+    """Config 3's shape: no camera, no LiDAR — no wide run, no hub knots (23 right-hand sides: the two-tile instance)."""
+    P = synth.make_problem(seed=7, duration=40.0, n_surfel=0, n_landmarks=0, n_camsurf=0)
+    locks = TAU | lvx.LOCK_LIDAR_Q | lvx.LOCK_LIDAR_P | lvx.LOCK_CAM_Q | lvx.LOCK_CAM_P
+    x = P["state0"]
+    d, m, lo = _step(P, locks, x, 1)
+    assert lo["solver_separators"] >= 2 and lo["n_border"] == 22
+    ds, ms, _ = _step(P, locks, x, -1, seq=True)
+    _same(d, m, ds, ms)
+
+
+def test_free_time_offsets_widen_the_separators_to_30_columns():
+    P = synth.make_bench_problem(seed=34, n_imu=16000, n_surfel=40000, n_reproj=2400, n_planes=60, obs_per_frame=40)
+    N = P["n_knots"]
+    x = P["state0"].copy()
+    x[7 * N + 23], x[7 * N + 31] = 4e-4, -5e-4
+    d, m, lo = _step(P, 0, x, 1)
+    assert lo["solver_separators"] > 2
+    ds, ms, _ = _step(P, 0, x, -1, seq=True)
+    _same(d, m, ds, ms)
+
+
+def test_small_radius_and_locked_landmarks():
+    P = synth.make_bench_problem(seed=35, n_imu=16000, n_surfel=40000, n_reproj=2400, n_planes=60, obs_per_frame=40)
+    x = P["state0"]
+    for locks, radius in ((TAU | lvx.LOCK_LANDMARKS, 1e4), (TAU, 3.0)):
+        d, m, lo = _step(P, locks, x, 1, radius=radius)
+        assert lo["solver_separators"] > 2
+        ds, ms, _ = _step(P, locks, x, -1, seq=True, radius=radius)
+        _same(d, m, ds, ms)
+
+
+def test_lm_loop_takes_the_same_path_with_either_elimination():
+    P = synth.make_bench_problem(seed=36, n_imu=16000, n_surfel=40000, n_reproj=2400, n_planes=60, obs_per_frame=40)
+    out = []
+    for nd in (1, -1):
+        g = lvx.Context(0)
+        g.set_switch("SOLVER_ND", nd)
+        lvx.load_problem(g, P, TAU)
+        x, res = g.lm_solve(P["state0"], max_iterations=8)
+        res["state"] = x
+        res["layout"] = g.layout()
+        out.append(res)
+        g.close()
+    a, b = out
+    assert a["layout"]["solver_separators"] > 2 and b["layout"]["solver_separators"] == 0
+    assert a["iterations"] == b["iterations"] and a["termination"] == b["termination"]
+    ca, cb = np.asarray(a["cost_history"]), np.asarray(b["cost_history"])
+    assert np.abs(ca - cb).max() <= 1e-9 * np.abs(cb).max()
+    assert np.abs(a["state"] - b["state"]).max() <= 1e-8 * max(1.0, np.abs(b["state"]).max())
+
+
+def test_profile_that_does_not_fit_keeps_the_uniform_chain():
+    """A continuous camera stream ('sparse' tracks: every column is wide): no plan, the chain of b = bandwidth blocks runs and nothing changes."""
+    P = synth.make_bench_problem(seed=37, n_imu=6000, n_surfel=20000, n_reproj=3000, n_planes=40, tracks="sparse")
+    d, m, lo = _step(P, TAU, P["state0"], 1)
+    assert lo["solver_separators"] == 0 and lo["solver_fallbacks"] == 0
+    ds, ms, _ = _step(P, TAU, P["state0"], -1, seq=True)
+    _same(d, m, ds, ms)
