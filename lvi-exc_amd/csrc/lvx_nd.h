@@ -39,7 +39,7 @@ struct NdPlan {
   int epoch = -1, mode = 0, nrhs = 0, zt = 0, nc = 0, ldz = 0;
   int nleaf = 0, nnar = 0, nden = 0, nsep = 0, ntile = 0, bd = 0, maxnt = 0, nblk2 = 0;
   std::vector<NdLeaf> leaves; std::vector<NdSep> seps;
-  DevBuf leaf, sep, nar, den, U, WL, WR, GO, Dc, Rc, LIc, info, D2, G2, LI2, Z2, info2, zb2, tc;
+  DevBuf leaf, sep, nar, den, U, WL, WR, GO, Dc, Rc, LIc, info, D2, G2, F2, Z2, Y2, info2, zb2, tc;
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 struct NdArgs {
@@ -299,19 +299,21 @@ __global__ __launch_bounds__(64 * (4 + ZT), 4) void k_nd_solve(NdArgs a) {   // 
   const int li = a.nar[blockIdx.x];
   const NdLeaf lf = a.leaf[li];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // two workgroups share a CU (a wavefront's SIMD is its index mod 4): the W_L wavefronts carry twice the products of the others, so every other workgroup deals its
+  // roles two places on — SIMDs 0, 1 get the heavy pair of one workgroup, SIMDs 2, 3 that of the other
+  const int wv = (__builtin_amdgcn_readfirstlane(tid >> 6) + (((blockIdx.x >> 8) & 1) ? 2 : 0)) % (4 + ZT);
   if (wv < 2) nd_solve_role<0>(a, lf, li, wv, lane, xch, ubuf);
   else if (wv < 2 + ZT) nd_solve_role<1>(a, lf, li, wv - 2, lane, xch, ubuf);
   else nd_solve_role<2>(a, lf, li, wv - 2 - ZT, lane, xch, ubuf);
 }
 
 // dense leaves: D_c (bd x bd, lower, column-major; identity padding) and the right-hand sides R_c [bd x nc] = [A_L | A_R | Z rows], column-major
-__global__ __launch_bounds__(256) void k_nd_cbuild(NdArgs a, double* Dc, double* Rc, int bd, int bw) {
+__global__ __launch_bounds__(256) void k_nd_cbuild(NdArgs a, double* Dc, double* Rc, int bd, int bw, int which) {   // which 0: D_c, 1: R_c
   const NdLeaf lf = a.leaf[a.den[blockIdx.x]];
   double* D = Dc + (size_t)blockIdx.x * bd * bd;
   double* R = Rc + (size_t)blockIdx.x * bd * a.nc;
-  const int ncol = bd + a.nc;
-  for (int cc = blockIdx.y * 4 + (threadIdx.x >> 6); cc < ncol; cc += gridDim.y * 4) {
+  const int cbeg = which ? bd : 0, ncol = which ? bd + a.nc : bd;
+  for (int cc = cbeg + blockIdx.y * 4 + (threadIdx.x >> 6); cc < ncol; cc += gridDim.y * 4) {
     const int lane = threadIdx.x & 63;
     if (cc < bd) {
       const double sc = cc < lf.m ? a.scale[lf.c0 + cc] : 0.0;
@@ -343,38 +345,44 @@ __global__ __launch_bounds__(256) void k_nd_cbuild(NdArgs a, double* Dc, double*
     }
   }
 }
-// GO of a dense leaf from its solved right-hand sides, and its rows of Z back in place
+// GO of a dense leaf from its solved right-hand sides R_c [bd x nc] (column-major), and its rows of Z back in place.  64 rows at a time through LDS (a column of R_c is
+// contiguous: coalesced loads, row-major stage), a wavefront per 16 columns: G [64 x 16] += W^T X with both fragments read from the stage as in k_gram_mfma.
+// (A wavefront loading its tiles straight from the column-major array: sixteen 32-byte pieces per load, one exposed round trip per tile row — 62 us for 50 leaves.)
+#define CG_LDP 145   // >= 64 + 16 * 5, odd
 template <int ZT>
 __global__ __launch_bounds__(64 * (4 + ZT)) void k_nd_cgram(NdArgs a, const double* Rc, int bd) {
+  __shared__ double S[64 * CG_LDP];
   const int li = a.den[blockIdx.x];
   const NdLeaf lf = a.leaf[li];
   const double* R = Rc + (size_t)blockIdx.x * bd * a.nc;
-  const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, j = lane & 15;
+  constexpr int NW = 4 + ZT;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int t = __builtin_amdgcn_readfirstlane(tid >> 6);
   d4 G[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) G[g] = d4{0.0, 0.0, 0.0, 0.0};
-  for (int p = 0; p < bd / 16; ++p) {
-    d4 X, W[4];
+  for (int r0 = 0; r0 < bd; r0 += 64) {
+    for (int c = t; c < a.nc; c += NW) S[lane * CG_LDP + c] = r0 + lane < bd ? R[(size_t)c * bd + r0 + lane] : 0.0;
+    __syncthreads();
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks) {
+      const double* src = S + (4 * ks + (lane >> 4)) * CG_LDP + (lane & 15);
+      const double x = src[16 * t];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const size_t row = (size_t)16 * p + q + 4 * r;
-      X[r] = R[(size_t)(16 * t + j) * bd + row];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) W[g][r] = R[(size_t)(16 * g + j) * bd + row];
+      for (int g = 0; g < 4; ++g) G[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(src[16 * g], x, G[g], 0, 0, 0);
     }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) G[g] = nd_mm(W[g], X, G[g]);
+    // the solved right-hand sides of these rows back to the solver's (row-major) array
+    for (int e = tid; e < 64 * a.nz; e += 64 * NW) {
+      const int row = e / a.nz, z = e % a.nz, i = r0 + row;
+      if (i < lf.m && z < a.nrhs) a.Z[(size_t)(lf.c0 + i) * a.nz + z] = S[row * CG_LDP + 64 + z];
+    }
+    __syncthreads();
   }
-  double* go = a.GO + (size_t)li * 64 * a.nc + 16 * t + j;
+  double* go = a.GO + (size_t)li * 64 * a.nc + 16 * t + (lane & 15);
 #pragma unroll
   for (int g = 0; g < 4; ++g)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) go[(size_t)(16 * g + q + 4 * r) * a.nc] = G[g][r];
-  for (int e = tid; e < lf.m * a.nrhs; e += blockDim.x) {
-    const int i = e % lf.m, z = e / lf.m;
-    a.Z[(size_t)(lf.c0 + i) * a.nz + z] = R[(size_t)(64 + z) * bd + i];
-  }
+    for (int r = 0; r < 4; ++r) go[(size_t)(16 * g + (lane >> 4) + 4 * r) * a.nc] = G[g][r];
 }
 
 // separator k of the reduced chain: D2_k = H (S_k, S_k) - W_R^T W_R (left leaf) - W_L^T W_L (right leaf), A_{k+1,k} = -W_R^T W_L (right leaf), its rows of the right-hand sides
@@ -407,14 +415,14 @@ __global__ __launch_bounds__(256) void k_nd_assemble(NdArgs a, double* D2, doubl
       if (GoL) v -= GoL[(size_t)(32 + i) * a.nc + 64 + z];
       if (GoR) v -= GoR[(size_t)i * a.nc + 64 + z];
     }
-    Z2[(size_t)k * 32 + i + (size_t)z * ldz2] = v;
+    Z2[((size_t)k * 32 + i) * ldz2 + z] = v;   // (ldz2: columns of the row-major separator right-hand sides)
   }
 }
 __global__ __launch_bounds__(256) void k_nd_scatter(NdArgs a, const double* Z2, int ldz2) {
   const NdSep sp = a.sep[blockIdx.x];
   for (int e = threadIdx.x; e < 32 * a.nrhs; e += 256) {
     const int i = e & 31, z = e >> 5;
-    if (i < sp.w) a.Z[(size_t)(sp.c0 + i) * a.nz + z] = Z2[(size_t)blockIdx.x * 32 + i + (size_t)z * ldz2];
+    if (i < sp.w) a.Z[(size_t)(sp.c0 + i) * a.nz + z] = Z2[((size_t)blockIdx.x * 32 + i) * ldz2 + z];
   }
 }
 __global__ void k_nd_gather1(const NdSep* sep, int nsep, int nblk2, const double* zb, double* zb2) {
@@ -512,6 +520,254 @@ __global__ __launch_bounds__(256) void k_nd_cscatter(NdArgs a, int bd, const dou
   for (int i = threadIdx.x; i < lf.m; i += 256) zb[lf.c0 + i] = tc[(size_t)blockIdx.x * bd + i];
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The separator chain: block cyclic reduction with b = 32, ONE launch per level (the general level kernels of lvx_bcr.hip — Cholesky, triangular solves, Schur updates:
+// three launches of kernels shaped for b ~ 180 — cost 13 + 8 + 9 us per level on these 32 x 32 blocks, 0.3 ms per solve for the nine levels).
+// Level l: the workgroup of the REMAINING block r = j + s (s = 2^l) factorises its left eliminated neighbour j (and keeps it: factor, solved couplings and right-hand
+// sides for the backward sweep) and, once more, its right one j + 2 s (which the workgroup of r + 2 s keeps) — two 32 x 32 factorisations instead of a grid-wide
+// dependency —, solves their couplings and right-hand sides and applies
+//     D_r -= X+ X+^T + Y_R^T Y_R,   A (r, r - 2 s) = -X+ Y_L,   z_r -= X+ y_L + Y_R^T y_R.
+// Tiles in the accumulator layout through LDS as in the leaves; Xt = X+^T = inv(C_L) A (r, j)^T is what is solved and kept.  Right-hand sides row-major [nblk * 32][nz];
+// the solved ones go to a SECOND array (the right neighbour's workgroup still reads the unsolved rows).  Couplings per level in the layout of the general chain (g_off).
+// F [nblk][13][256]: per eliminated block U00, U01, U11, inv(L0)^T, inv(L1)^T, Xt (4 tiles: 5 + 2 rowtile + coltile), Y_L (9 + ...).
+// ---------------------------------------------------------------------------------------------------------
+struct C32 { double* D; double* G; double* Z; double* Y; double* F; int* info; int nblk, nz, zt; };
+__device__ __forceinline__ size_t c32_goff(int nblk, int l) { size_t o = 0; for (int k = 0; k < l; ++k) o += (size_t)(nblk >> k) * 1024; return o; }
+// Cholesky of a 32 x 32 block (column-major lower in global memory) by one wavefront: tiles [U00 | U01 | U11 | inv(L0)^T | inv(L1)^T] to LDS (as they stand) and, if
+// keep, to global memory; returns the 1-based first bad pivot (0: none)
+__device__ __forceinline__ int c32_factor(const double* D, double (*fac)[256], double* keep, double* tr, int lane) {
+  const int q = lane >> 4, j = lane & 15;
+  const d4 zero4 = d4{0.0, 0.0, 0.0, 0.0};
+  d4 T00, A01, T11;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = q + 4 * r, lo = min(row, j), hi = max(row, j);
+    T00[r] = D[lo * 32 + hi]; A01[r] = D[row * 32 + 16 + j]; T11[r] = D[(16 + lo) * 32 + 16 + hi];
+  }
+  d4 M0, M1;
+  int bad = chol16_mfma(T00, M0, q, j);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tr[(q + 4 * r) * 17 + j] = M0[r];
+  ND_WAVE_LDS();
+  d4 LIT0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) LIT0[r] = tr[j * 17 + q + 4 * r];
+  ND_WAVE_LDS();
+  const d4 U01 = nd_mm(LIT0, A01, zero4);
+  T11 = nd_mmn(U01, U01, T11);
+  const int b1 = chol16_mfma(T11, M1, q, j);
+  bad = bad ? bad : (b1 ? 16 + b1 : 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tr[(q + 4 * r) * 17 + j] = M1[r];
+  ND_WAVE_LDS();
+  d4 LIT1;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) LIT1[r] = tr[j * 17 + q + 4 * r];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int e = r * 64 + lane;
+    fac[0][e] = T00[r]; fac[1][e] = U01[r]; fac[2][e] = T11[r]; fac[3][e] = LIT0[r]; fac[4][e] = LIT1[r];
+    if (keep) { keep[e] = T00[r]; keep[256 + e] = U01[r]; keep[512 + e] = T11[r]; keep[768 + e] = LIT0[r]; keep[1024 + e] = LIT1[r]; }
+  }
+  return bad;
+}
+__device__ __forceinline__ d4 c32_lds(const double* t, int lane) { d4 X;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) X[r] = t[r * 64 + lane];
+  return X; }
+// V = inv(C) R for a 32 x 16 column tile R = [R0; R1]: V0 = inv(L0) R0, V1 = inv(L1) (R1 - U01^T V0)
+__device__ __forceinline__ void c32_solve(const double (*fac)[256], const d4& R0, const d4& R1, d4& V0, d4& V1, int lane) {
+  const d4 zero4 = d4{0.0, 0.0, 0.0, 0.0};
+  V0 = nd_mm(c32_lds(fac[3], lane), R0, zero4);
+  V1 = nd_mm(c32_lds(fac[4], lane), nd_mmn(c32_lds(fac[1], lane), V0, R1), zero4);
+}
+#define C32_MAXT 16
+__global__ __launch_bounds__(512) void k_c32_level(C32 c, int l, int last) {
+  extern __shared__ double sh[];
+  double (*facL)[256] = (double (*)[256])sh;                 // [5][256]
+  double (*facR)[256] = (double (*)[256])(sh + 5 * 256);     // [5][256]
+  double (*V)[2][256] = (double (*)[2][256])(sh + 10 * 256); // [tasks][2][256]
+  double* tr = sh + 10 * 256 + C32_MAXT * 512;               // [8][16 * 17]
+  const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, j = lane & 15;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k = blockIdx.x, s = 1 << l, count = c.nblk >> l;
+  const int jL = s - 1 + 2 * s * k, r = jL + s, jR = r + s;
+  const bool hasR = 2 * k + 2 < count, hasYL = k >= 1;
+  const double* Gl = c.G + c32_goff(c.nblk, l);
+  double* Gn = c.G + c32_goff(c.nblk, l + 1);
+  const int zt = c.zt, nz = c.nz;
+  double* FL = c.F + (size_t)jL * 13 * 256;
+  const d4 zero4 = d4{0.0, 0.0, 0.0, 0.0};
+  // every global load of the kernel is issued up front — the right-hand sides of the (up to two) solves of this wavefront and the tiles its (up to two) outputs update —
+  // so the three phases share ONE memory round trip (three, one per phase: 16 us per level)
+  const int ntL = 4 + zt, ntask = hasR ? ntL + 2 + zt : ntL;   // tasks: 0, 1 Xt | 2, 3 Y_L | 4 .. 3 + zt y_L | then Y_R (2), y_R (zt)
+  auto task_load = [&](int t, d4& R0, d4& R1) {
+    R0 = zero4; R1 = zero4;
+    if (t >= ntask) return;
+    const bool right = t >= ntL;
+    const int tt = right ? t - ntL + 2 : t;
+    const int kind = tt < 2 ? 0 : (tt < 4 ? 1 : 2), ct = kind == 0 ? tt : (kind == 1 ? tt - 2 : tt - 4);
+    if (kind == 0) {
+      const double* g = Gl + (size_t)(2 * k) * 1024;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) { R0[rr] = g[(q + 4 * rr) * 32 + 16 * ct + j]; R1[rr] = g[(16 + q + 4 * rr) * 32 + 16 * ct + j]; }
+    } else if (kind == 1) {
+      if (right || hasYL) {
+        const double* g = Gl + (size_t)(right ? 2 * k + 1 : 2 * k - 1) * 1024;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) { R0[rr] = g[(16 * ct + j) * 32 + q + 4 * rr]; R1[rr] = g[(16 * ct + j) * 32 + 16 + q + 4 * rr]; }
+      }
+    } else {
+      const double* z = c.Z + (size_t)(right ? jR : jL) * 32 * nz + 16 * ct + j;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) { R0[rr] = z[(size_t)(q + 4 * rr) * nz]; R1[rr] = z[(size_t)(16 + q + 4 * rr) * nz]; }
+    }
+  };
+  // outputs: 0 .. 2 D_r tiles (0,0), (1,0), (1,1) | 3 .. 6 coupling (ti, tc) | 7 .. z_r tiles (ti, ct)
+  const int nout = 7 + 2 * zt;
+  auto out_ptr = [&](int o, int rr) -> double* {
+    if (o < 3) { const int ti = o == 0 ? 0 : 1, tc = o == 2 ? 1 : 0; return c.D + (size_t)r * 1024 + (16 * tc + j) * 32 + 16 * ti + q + 4 * rr; }
+    if (o < 7) { const int ti = (o - 3) >> 1, tc = (o - 3) & 1; return Gn + (size_t)(hasYL ? k - 1 : 0) * 1024 + (16 * tc + j) * 32 + 16 * ti + q + 4 * rr; }
+    const int ti = (o - 7) / zt, ct = (o - 7) % zt;
+    return c.Z + ((size_t)r * 32 + 16 * ti + q + 4 * rr) * nz + 16 * ct + j;
+  };
+  auto out_load = [&](int o) {
+    d4 X = zero4;
+    if (o < nout && (o < 3 || o >= 7)) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) X[rr] = *out_ptr(o, rr);
+    }
+    return X;
+  };
+  d4 Ra0, Ra1, Rb0, Rb1;
+  task_load(wv, Ra0, Ra1); task_load(wv + 8, Rb0, Rb1);
+  d4 Oa = out_load(wv), Ob = out_load(wv + 8);
+  if (wv == 0) { const int bad = c32_factor(c.D + (size_t)jL * 1024, facL, FL, tr, lane); if (lane == 0) c.info[jL] = bad; }
+  else if (wv == 1 && hasR) (void)c32_factor(c.D + (size_t)jR * 1024, facR, nullptr, tr + 16 * 17, lane);
+  __syncthreads();
+  // solves
+  for (int t = wv, it = 0; t < ntask; t += 8, ++it) {
+    const bool right = t >= ntL;
+    const int tt = right ? t - ntL + 2 : t;            // 0, 1 Xt | 2, 3 Y | 4 .. y
+    const int kind = tt < 2 ? 0 : (tt < 4 ? 1 : 2), ct = kind == 0 ? tt : (kind == 1 ? tt - 2 : tt - 4);
+    d4 V0, V1;
+    c32_solve(right ? facR : facL, it == 0 ? Ra0 : Rb0, it == 0 ? Ra1 : Rb1, V0, V1, lane);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) { V[t][0][rr * 64 + lane] = V0[rr]; V[t][1][rr * 64 + lane] = V1[rr]; }
+    if (!right) {   // what the backward sweep needs of the eliminated block j_L
+      if (kind < 2) {
+        double* f = FL + (size_t)(kind == 0 ? 5 : 9) * 256;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) { f[(0 + ct) * 256 + rr * 64 + lane] = V0[rr]; f[(2 + ct) * 256 + rr * 64 + lane] = V1[rr]; }
+      } else {
+        double* y = c.Y + (size_t)jL * 32 * nz + 16 * ct + j;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) { y[(size_t)(q + 4 * rr) * nz] = V0[rr]; y[(size_t)(16 + q + 4 * rr) * nz] = V1[rr]; }
+      }
+    }
+  }
+  ND_LDS_BARRIER();
+  // products
+  for (int o = wv, it = 0; o < nout; o += 8, ++it) {
+    d4 acc = zero4;
+    const d4 old = it == 0 ? Oa : (it == 1 ? Ob : out_load(o));   // (a third round only with five column tiles of right-hand sides)
+    if (o < 3) {
+      const int ti = o == 0 ? 0 : 1, tc = o == 2 ? 1 : 0;
+#pragma unroll
+      for (int ka = 0; ka < 2; ++ka) {
+        acc = nd_mm(c32_lds(V[ti][ka], lane), c32_lds(V[tc][ka], lane), acc);
+        if (hasR) acc = nd_mm(c32_lds(V[ntL + ti][ka], lane), c32_lds(V[ntL + tc][ka], lane), acc);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) { const int row = 16 * ti + q + 4 * rr, col = 16 * tc + j; if (row >= col) *out_ptr(o, rr) = old[rr] - acc[rr]; }
+    } else if (o < 7) {
+      if (hasYL) {
+        const int ti = (o - 3) >> 1, tc = (o - 3) & 1;
+#pragma unroll
+        for (int ka = 0; ka < 2; ++ka) acc = nd_mm(c32_lds(V[ti][ka], lane), c32_lds(V[2 + tc][ka], lane), acc);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) *out_ptr(o, rr) = -acc[rr];
+      }
+    } else {
+      const int ct = (o - 7) % zt, ti = (o - 7) / zt;
+#pragma unroll
+      for (int ka = 0; ka < 2; ++ka) {
+        acc = nd_mm(c32_lds(V[ti][ka], lane), c32_lds(V[4 + ct][ka], lane), acc);
+        if (hasR) acc = nd_mm(c32_lds(V[ntL + ti][ka], lane), c32_lds(V[ntL + 2 + ct][ka], lane), acc);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) *out_ptr(o, rr) = old[rr] - acc[rr];
+    }
+  }
+  if (!last) return;
+  // the last level leaves ONE block: factor it and solve its right-hand sides here
+  __syncthreads();
+  double* FR = c.F + (size_t)r * 13 * 256;
+  if (wv == 0) { const int bad = c32_factor(c.D + (size_t)r * 1024, facL, FR, tr, lane); if (lane == 0) c.info[r] = bad; }
+  __syncthreads();
+  for (int ct = wv; ct < zt; ct += 8) {
+    const double* z = c.Z + (size_t)r * 32 * nz + 16 * ct + j;
+    d4 R0, R1, V0, V1;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) { R0[rr] = z[(size_t)(q + 4 * rr) * nz]; R1[rr] = z[(size_t)(16 + q + 4 * rr) * nz]; }
+    c32_solve(facL, R0, R1, V0, V1, lane);
+    double* y = c.Y + (size_t)r * 32 * nz + 16 * ct + j;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) { y[(size_t)(q + 4 * rr) * nz] = V0[rr]; y[(size_t)(16 + q + 4 * rr) * nz] = V1[rr]; }
+  }
+}
+// backward sweep of a level for ONE vector, a wavefront per eliminated block: x_j = U^-1 (x_j - Xt x_r - Y_L x_{j - s}); top: the last block first
+__device__ __forceinline__ double c32_mv(const double* tile, const double* x16, int lane) {   // (tile . x) [lane & 15], the tile as it stands in memory
+  const int part = lane >> 4, i = lane & 15;
+  const double* t = tile + (i >> 2) * 64 + (i & 3) * 16 + 4 * part;
+  double s = t[0] * x16[4 * part] + t[1] * x16[4 * part + 1] + t[2] * x16[4 * part + 2] + t[3] * x16[4 * part + 3];
+  s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+  return s;
+}
+__device__ __forceinline__ void c32_usolve(const double* F, double* v, int lane) {   // v [32] (LDS) <- U^-1 v
+  const int i = lane & 15;
+  const double x1 = c32_mv(F + 4 * 256, v + 16, lane);
+  ND_WAVE_LDS();
+  if (lane < 16) v[16 + i] = x1;
+  ND_WAVE_LDS();
+  const double t0 = v[i] - c32_mv(F + 1 * 256, v + 16, lane);
+  ND_WAVE_LDS();
+  if (lane < 16) v[i] = t0;
+  ND_WAVE_LDS();
+  const double x0 = c32_mv(F + 3 * 256, v, lane);
+  ND_WAVE_LDS();
+  if (lane < 16) v[i] = x0;
+  ND_WAVE_LDS();
+}
+__global__ __launch_bounds__(64) void k_c32_back(C32 c, int l, int top, double* zb) {
+  __shared__ double xr[32], xl[32], v[32];
+  const int lane = threadIdx.x, i = lane & 15;
+  const int k = blockIdx.x, s = 1 << l;
+  const int jL = s - 1 + 2 * s * k, r = jL + s;
+  const double* F = c.F + (size_t)jL * 13 * 256;
+  if (top) {
+    if (lane < 32) v[lane] = zb[r * 32 + lane];
+    ND_WAVE_LDS();
+    c32_usolve(c.F + (size_t)r * 13 * 256, v, lane);
+    if (lane < 32) zb[r * 32 + lane] = v[lane];
+    ND_WAVE_LDS();
+  }
+  if (lane < 32) { xr[lane] = zb[r * 32 + lane]; xl[lane] = k >= 1 ? zb[(jL - s) * 32 + lane] : 0.0; v[lane] = zb[jL * 32 + lane]; }
+  ND_WAVE_LDS();
+  // v -= Xt x_r + Y_L x_l   (tiles 5 + 2 a + b: rows 16 a .., columns 16 b ..)
+  double a0 = c32_mv(F + 5 * 256, xr, lane) + c32_mv(F + 6 * 256, xr + 16, lane);
+  double a1 = c32_mv(F + 7 * 256, xr, lane) + c32_mv(F + 8 * 256, xr + 16, lane);
+  if (k >= 1) {
+    a0 += c32_mv(F + 9 * 256, xl, lane) + c32_mv(F + 10 * 256, xl + 16, lane);
+    a1 += c32_mv(F + 11 * 256, xl, lane) + c32_mv(F + 12 * 256, xl + 16, lane);
+  }
+  ND_WAVE_LDS();
+  if (lane < 16) { v[i] -= a0; v[16 + i] -= a1; }
+  ND_WAVE_LDS();
+  c32_usolve(F, v, lane);
+  if (lane < 32) zb[jL * 32 + lane] = v[lane];
+}
+
 // ---- the plan: leaves and separators from the column profile ----
 static NdPlan* nd_get(lvx_ctx* c) { if (!c->nd) c->nd = new NdPlan; return (NdPlan*)c->nd; }
 bool nd_active(const lvx_ctx* c) { return c->nd && ((const NdPlan*)c->nd)->active; }
@@ -521,7 +777,7 @@ void nd_counts(const lvx_ctx* c, int* separators, int* leaves) { const bool on =
 void nd_destroy(lvx_ctx* c) {
   NdPlan* P = (NdPlan*)c->nd;
   if (!P) return;
-  for (DevBuf* b : {&P->leaf, &P->sep, &P->nar, &P->den, &P->U, &P->WL, &P->WR, &P->GO, &P->Dc, &P->Rc, &P->LIc, &P->info, &P->D2, &P->G2, &P->LI2, &P->Z2, &P->info2, &P->zb2, &P->tc})
+  for (DevBuf* b : {&P->leaf, &P->sep, &P->nar, &P->den, &P->U, &P->WL, &P->WR, &P->GO, &P->Dc, &P->Rc, &P->LIc, &P->info, &P->D2, &P->G2, &P->F2, &P->Z2, &P->Y2, &P->info2, &P->zb2, &P->tc})
     if (b->p) (void)hipFree(b->p);
   if (P->side) (void)hipStreamDestroy(P->side);
   if (P->ev_fork) (void)hipEventDestroy(P->ev_fork);
@@ -653,18 +909,20 @@ int nd_plan(lvx_ctx* c, int nrhs) {
   if ((rc = dev_alloc(c, P->info, (size_t)(P->nleaf + 8) * 4))) return rc;
   if ((rc = dev_alloc(c, P->D2, (size_t)nblk2 * 1024 * 8))) return rc;
   if ((rc = dev_alloc(c, P->G2, (size_t)2 * nblk2 * 1024 * 8))) return rc;
-  if ((rc = dev_alloc(c, P->LI2, (size_t)nblk2 * 2 * 256 * 8))) return rc;
-  if ((rc = dev_alloc(c, P->Z2, (size_t)nblk2 * 32 * nrhs * 8))) return rc;
+  const int nz = P->nc - 64;
+  if ((rc = dev_alloc(c, P->F2, (size_t)nblk2 * 13 * 256 * 8))) return rc;
+  if ((rc = dev_alloc(c, P->Z2, (size_t)nblk2 * 32 * nz * 8))) return rc;
+  if ((rc = dev_alloc(c, P->Y2, (size_t)nblk2 * 32 * nz * 8))) return rc;
   if ((rc = dev_alloc(c, P->zb2, ((size_t)nblk2 * 32 + 64) * 8))) return rc;   // (+ 64 trash words: NdArgs::trash)
   if ((rc = dev_alloc(c, P->info2, (size_t)(2 * nblk2 + 8) * 4))) return rc;
   LVX_HIP(c, hipMemsetAsync(P->G2.p, 0, (size_t)2 * nblk2 * 1024 * 8, c->stream));
-  LVX_HIP(c, hipMemsetAsync(P->Z2.p, 0, (size_t)nblk2 * 32 * nrhs * 8, c->stream));
+  LVX_HIP(c, hipMemsetAsync(P->Z2.p, 0, (size_t)nblk2 * 32 * nz * 8, c->stream));
   if (P->nsep < nblk2) {
     const size_t npad = (size_t)(nblk2 - P->nsep) * 1024;
     hipLaunchKernelGGL(k_bcr_pad_identity, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, c->stream, (double*)P->D2.p, 32, P->nsep, nblk2);
   }
   if (!P->side) {
-    LVX_HIP(c, hipStreamCreateWithFlags(&P->side, hipStreamNonBlocking));
+    LVX_HIP(c, hipStreamCreateWithFlags(&P->side, hipStreamNonBlocking));   // (a high-priority stream for the few long dense-leaf workgroups made EVERY kernel of the solve slower: 1.15 -> 1.65 ms per step)
     LVX_HIP(c, hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
     LVX_HIP(c, hipEventCreateWithFlags(&P->ev_join, hipEventDisableTiming));
   }
@@ -679,9 +937,29 @@ static NdArgs nd_args(lvx_ctx* c, NdPlan* P, const double* scale, const double* 
   a.Z = Z; a.ldz = ldz; a.nz = P->nc - 64; a.info = (int*)P->info.p; a.trash = (double*)P->zb2.p + (size_t)P->nblk2 * 32;
   return a;
 }
-static BcrChain nd_chain(NdPlan* P) { return BcrChain{32, P->nblk2, P->nsep, (double*)P->D2.p, (double*)P->G2.p, (double*)P->LI2.p, (int*)P->info2.p}; }
+static C32 nd_c32(NdPlan* P) { return C32{(double*)P->D2.p, (double*)P->G2.p, (double*)P->Z2.p, (double*)P->Y2.p, (double*)P->F2.p, (int*)P->info2.p, P->nblk2, P->nc - 64, P->zt}; }
+static size_t c32_lds_bytes() { return (size_t)(10 * 256 + C32_MAXT * 512 + 8 * 16 * 17) * 8; }
 
-// factor + Z <- L^-1 Z (in the elimination order, in place)
+// The dense leaves' Cholesky, started on the side stream BEFORE the solver builds its right-hand sides: a workgroup of k_potrf_reg<12> takes the whole register file of a
+// CU, and once the narrow leaves' wavefronts sit on every CU (one per leaf, k_nd_factor) it waits for a CU to drain — 115 us for the 50 blocks against 55 alone.
+int nd_dense_start(lvx_ctx* c, const double* scale, const double* lmd, double inv_radius) {
+  NdPlan* P = (NdPlan*)c->nd;
+  if (!P || !P->active) return fail(c, LVX_E_STATE, "nd_dense_start without a plan");
+  if (P->nden == 0) return LVX_OK;
+  hipStream_t st = c->stream;
+  NdArgs ad = nd_args(c, P, scale, lmd, inv_radius, nullptr, P->ldz);
+  ad.info = ad.info + P->nnar;
+  const int bd = P->bd;
+  LVX_HIP(c, hipEventRecord(P->ev_fork, st));
+  LVX_HIP(c, hipStreamWaitEvent(P->side, P->ev_fork, 0));
+  hipLaunchKernelGGL(k_nd_cbuild, dim3((unsigned)P->nden, 16), dim3(256), 0, P->side, ad, (double*)P->Dc.p, (double*)P->Rc.p, bd, c->bw, 0);
+  c->stream = P->side;
+  rocblas_handle h = nullptr;
+  const int rc = potrf_batched(c, h, (double*)P->Dc.p, bd, (long long)bd * bd, ad.info, P->nden, (double*)P->LIc.p, (long long)(bd / 16) * 256);
+  c->stream = st;
+  return rc;
+}
+// factor + Z <- L^-1 Z (in the elimination order, in place); nd_dense_start has run
 int nd_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_radius, int* info_out_d, double* Z, int ldz, int nrhs) {
   NdPlan* P = (NdPlan*)c->nd;
   if (!P || !P->active || nrhs != P->nrhs || ldz != P->ldz) return fail(c, LVX_E_STATE, "nd_factor without a matching plan");
@@ -689,16 +967,14 @@ int nd_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_rad
   int rc;
   NdArgs a = nd_args(c, P, scale, lmd, inv_radius, Z, ldz);
   const int bd = P->bd, zt = P->zt;
-  if (P->nden > 0) {   // dense leaves on the side stream
+  if (P->nden > 0) {   // dense leaves on the side stream: right-hand sides (they need the solver's Z), triangular solves, products for the separators
     LVX_HIP(c, hipEventRecord(P->ev_fork, st));
     LVX_HIP(c, hipStreamWaitEvent(P->side, P->ev_fork, 0));
     c->stream = P->side;
     NdArgs ad = a; ad.info = a.info + P->nnar;
-    hipLaunchKernelGGL(k_nd_cbuild, dim3((unsigned)P->nden, 16), dim3(256), 0, P->side, ad, (double*)P->Dc.p, (double*)P->Rc.p, bd, c->bw);
-    rocblas_handle h = nullptr;
+    hipLaunchKernelGGL(k_nd_cbuild, dim3((unsigned)P->nden, 16), dim3(256), 0, P->side, ad, (double*)P->Dc.p, (double*)P->Rc.p, bd, c->bw, 1);
     const long long sD = (long long)bd * bd, sLI = (long long)(bd / 16) * 256;
-    rc = potrf_batched(c, h, (double*)P->Dc.p, bd, sD, ad.info, P->nden, (double*)P->LIc.p, sLI);
-    if (!rc) rc = trsv_batched<false>(c, (const double*)P->Dc.p, bd, sD, (double*)P->Rc.p, 1, bd, (long long)bd * P->nc, P->nc, P->nden, (const double*)P->LIc.p, sLI);
+    rc = trsv_batched<false>(c, (const double*)P->Dc.p, bd, sD, (double*)P->Rc.p, 1, bd, (long long)bd * P->nc, P->nc, P->nden, (const double*)P->LIc.p, sLI);
     if (!rc) {
       if (zt == 2) hipLaunchKernelGGL(k_nd_cgram<2>, dim3((unsigned)P->nden), dim3(64 * 6), 0, P->side, ad, (const double*)P->Rc.p, bd);
       else if (zt == 3) hipLaunchKernelGGL(k_nd_cgram<3>, dim3((unsigned)P->nden), dim3(64 * 7), 0, P->side, ad, (const double*)P->Rc.p, bd);
@@ -717,11 +993,17 @@ int nd_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_rad
     else hipLaunchKernelGGL(k_nd_solve<5>, dim3((unsigned)P->nnar), dim3(64 * 9), 0, st, a);
   }
   if (P->nden > 0) LVX_HIP(c, hipStreamWaitEvent(st, P->ev_join, 0));
-  const int ldz2 = P->nblk2 * 32;
-  hipLaunchKernelGGL(k_nd_assemble, dim3((unsigned)P->nsep), dim3(256), 0, st, a, (double*)P->D2.p, (double*)P->G2.p, (double*)P->Z2.p, ldz2, P->nsep);
+  const int nz = P->nc - 64;
+  hipLaunchKernelGGL(k_nd_assemble, dim3((unsigned)P->nsep), dim3(256), 0, st, a, (double*)P->D2.p, (double*)P->G2.p, (double*)P->Z2.p, nz, P->nsep);
   hipLaunchKernelGGL(k_bcr_info, dim3((unsigned)((P->nleaf + 255) / 256)), dim3(256), 0, st, (const int*)P->info.p, P->nleaf, info_out_d);
-  if ((rc = chain_factor(c, nd_chain(P), info_out_d, (double*)P->Z2.p, ldz2, nrhs))) return rc;
-  hipLaunchKernelGGL(k_nd_scatter, dim3((unsigned)P->nsep), dim3(256), 0, st, a, (const double*)P->Z2.p, ldz2);
+  {   // the separator chain, one launch per level
+    const C32 ch = nd_c32(P);
+    LVX_HIP(c, hipFuncSetAttribute((const void*)k_c32_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c32_lds_bytes()));
+    int L = 0; while ((1 << L) < P->nblk2) ++L;
+    for (int l = 0; l < L; ++l) hipLaunchKernelGGL(k_c32_level, dim3((unsigned)(P->nblk2 >> (l + 1))), dim3(512), c32_lds_bytes(), st, ch, l, l == L - 1 ? 1 : 0);
+    hipLaunchKernelGGL(k_bcr_info, dim3((unsigned)((P->nblk2 + 255) / 256)), dim3(256), 0, st, (const int*)P->info2.p, P->nblk2, info_out_d);
+  }
+  hipLaunchKernelGGL(k_nd_scatter, dim3((unsigned)P->nsep), dim3(256), 0, st, a, (const double*)P->Y2.p, nz);
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
 }
@@ -734,7 +1016,11 @@ int nd_backward(lvx_ctx* c, double* zb) {
   NdArgs a = nd_args(c, P, nullptr, nullptr, 0.0, nullptr, P->ldz);
   double* zb2 = (double*)P->zb2.p;
   hipLaunchKernelGGL(k_nd_gather1, dim3((unsigned)((P->nblk2 * 32 + 255) / 256)), dim3(256), 0, st, a.sep, P->nsep, P->nblk2, (const double*)zb, zb2);
-  if ((rc = chain_backward(c, nd_chain(P), zb2, P->nblk2 * 32, 1))) return rc;
+  {
+    const C32 ch = nd_c32(P);
+    int L = 0; while ((1 << L) < P->nblk2) ++L;
+    for (int l = L - 1; l >= 0; --l) hipLaunchKernelGGL(k_c32_back, dim3((unsigned)(P->nblk2 >> (l + 1))), dim3(64), 0, st, ch, l, l == L - 1 ? 1 : 0, zb2);
+  }
   if (P->nden > 0) {
     const int bd = P->bd;
     LVX_HIP(c, hipEventRecord(P->ev_fork, st));

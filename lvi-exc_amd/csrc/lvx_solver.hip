@@ -877,6 +877,7 @@ static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, 
   }
   if (nb > 0) {
     const size_t tr = (size_t)(nbd + 1) * ldz;
+    if (use_bcr && nd_active(c)) { const int rcd = nd_dense_start(c, w.scale, w.lmd, ir); if (rcd) return rcd; }
     if (use_bcr && nd_active(c)) hipLaunchKernelGGL(k_build_rhs_rm, dim3((unsigned)((ldz + 63) / 64)), dim3(256), 0, st, w.Bs, w.gbs, w.scale, nb, nbd, ldz, nd_nz(c), w.Z);
     else hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)((tr + 255) / 256)), dim3(256), 0, st, w.Bs, w.gbs, w.scale, nb, nbd, ldz, w.Z);
     if (use_bcr) {
