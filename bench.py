@@ -156,7 +156,16 @@ def secondary_metrics(ctx, P, lo):
         dt = time.perf_counter() - t0
         it = max(1, sm["iterations"])
         sec["lm_iteration"] = {"ms_per_iteration": 1e3 * dt / it, "iterations": it, "Mevals_per_s_incl_solve": lo["n_blocks"] * (it + sm["successful_steps"] + 1) / dt / 1e6,
-                               "note": "evaluate(+J^T J) + landmark elimination + block-cyclic-reduction solve + candidate cost evaluation per iteration; host-synchronised"}
+                               "note": "evaluate(+J^T J) + landmark elimination + band solve (leaves + separators elimination where the band's column profile allows it, else the uniform block chain) + candidate cost evaluation per iteration; host-synchronised",
+                               "solver_plan": {k: ctx.layout()[k] for k in ("solver_separators", "solver_leaves", "bandwidth", "n_band")}}
+        try:   # the same iterations on the uniform block chain (block cyclic reduction with b = bandwidth: the solver of rounds 2-5), for the record
+            ctx.set_switch("SOLVER_ND", -1)
+            ctx.lm_solve(P["state0"], max_iterations=1)
+            t0 = time.perf_counter()
+            _, smu = ctx.lm_solve(P["state0"], max_iterations=3)
+            sec["lm_iteration"]["uniform_chain_ms_per_iteration"] = 1e3 * (time.perf_counter() - t0) / max(1, smu["iterations"])
+        finally:
+            ctx.set_switch("SOLVER_ND", 0)
         # the headline counts evaluations per second of the evaluation pass alone; this is what someone who ITERATES gets: blocks per second of whole Gauss-Newton / LM
         # iterations (one evaluation with normal equations + the exact SPARSE_SCHUR-equivalent step each)
         sec["gn_iteration_Mevals_per_s"] = lo["n_blocks"] * it / dt / 1e6

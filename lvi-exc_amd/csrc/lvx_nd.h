@@ -12,8 +12,8 @@
 //   * dense leaves (a wide run of <= 208 columns: one co-visibility window): the register-resident Cholesky and the LDS triangular solves of the chain kernels,
 //     batched over the runs, on a second stream beside the narrow leaves;
 //   * the separators: a block tridiagonal system with 32 x 32 blocks, D_k -= W_R^T W_R (leaf on the left) + W_L^T W_L (leaf on the right), A_{k+1,k} = -W_R^T W_L —
-//     a BcrChain with b = 32, solved by the level kernels of lvx_bcr.hip.
-// Backward: separators first (chain_backward), then every leaf on its own, x_I = U^-1 (y_I - W_L x_left - W_R x_right).
+//     block cyclic reduction again, but with level kernels of its own for this block size (k_c32_level: one launch per level; k_c32_back).
+// Backward: separators first (k_c32_back, level by level), then every leaf on its own, x_I = U^-1 (y_I - W_L x_left - W_R x_right).
 // Every tile lives in the MFMA accumulator layout (row = (lane >> 4) + 4 reg, col = lane & 15) and is stored as it stands (index = reg * 64 + lane: 512-byte coalesced
 // rows); such a tile is the A operand of its TRANSPOSE and the B operand of itself, so U^T Y, W^T Y and inv(L) X (from the stored TRANSPOSE of the triangle's inverse)
 // need no data movement between the products.

@@ -105,3 +105,69 @@ def test_profile_that_does_not_fit_keeps_the_uniform_chain():
     assert lo["solver_separators"] == 0 and lo["solver_fallbacks"] == 0
     ds, ms, _ = _step(P, TAU, P["state0"], -1, seq=True)
     _same(d, m, ds, ms)
+
+
+def test_deterministic_mode_is_bitwise_reproducible_on_this_path():
+    """No atomics anywhere in the leaves + separators elimination: with the deterministic evaluation (one adder per accumulator entry) two steps are bit-identical."""
+    P = synth.make_bench_problem(seed=38, n_imu=16000, n_surfel=40000, n_reproj=2400, n_planes=60, obs_per_frame=40)
+    out = []
+    for _ in range(2):
+        g = lvx.Context(0)
+        g.set_switch("DETERMINISTIC", 1)
+        g.set_switch("SOLVER_ND", 1)
+        lvx.load_problem(g, P, TAU)
+        g.evaluate(P["state0"], normal_eq=True, dense=False, residuals=False)
+        d, m = g.solve_step(RADIUS, True)
+        assert g.layout()["solver_separators"] > 2
+        out.append((d, m))
+        g.close()
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+
+
+def test_joint_step_of_two_sequences_is_the_same_with_either_elimination():
+    """lvx_solve_step_shared (sequence per GPU, shared rig extrinsics): the band of every rank goes through its own elimination plan; the 14 shared columns sit in the
+    border and ride through it as right-hand sides.  Two ranks in two threads, in-process all-reduce (tests/test_gpu_shared.py)."""
+    import threading
+    import sharded
+    seqs = []
+    ref = None
+    for r in range(2):
+        P = synth.make_bench_problem(seed=50 + r, n_imu=12000 + 4000 * r, n_surfel=30000, n_reproj=2000, n_planes=50, obs_per_frame=40)
+        N = P["n_knots"]
+        s = P["state0"].copy()
+        if ref is None:
+            ref = s[7 * N + 16:7 * N + 32].copy()
+        s[7 * N + 16:7 * N + 32] = ref
+        seqs.append((P, s))
+
+    def run(nd):
+        ar = sharded.ThreadAllReduce(2)
+        res, err = [None, None], [None, None]
+
+        def work(r):
+            try:
+                g = lvx.Context(0)
+                g.set_switch("SOLVER_ND", nd)
+                lvx.load_problem(g, seqs[r][0], TAU)
+                g.evaluate(seqs[r][1], normal_eq=True, dense=False, residuals=False)
+                d, m = g.solve_step_shared(RADIUS, ar.rank_fn(r))
+                res[r] = (d, m, g.layout()["solver_separators"])
+                g.close()
+            except BaseException as e:   # noqa: BLE001
+                err[r] = e
+                ar.bar.abort()
+        th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=600)
+        for e in err:
+            if e is not None:
+                raise e
+        return res
+    a, b = run(1), run(-1)
+    for r in range(2):
+        assert a[r][2] > 2 and b[r][2] == 0
+        _same(a[r][0], a[r][1], b[r][0], b[r][1])
+    sh0, sh1 = sharded.shared_tangent_indices(seqs[0][0]["n_knots"]), sharded.shared_tangent_indices(seqs[1][0]["n_knots"])
+    assert np.array_equal(a[0][0][sh0], a[1][0][sh1])      # the shared step is bitwise identical on both ranks
