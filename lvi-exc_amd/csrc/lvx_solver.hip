@@ -842,7 +842,7 @@ struct StageTimer {   // LVX_SOLVER_TIMING=1: host wall time per stage (enqueue 
   void lap(const char* what) { if (!on) return; const auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[lvx solver] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count()); t = n; }
 };
 
-static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, bool* bcr_used) {
+static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, bool* bcr_used, bool defer_check = false) {   // defer_check: the caller reads the pivot codes with the step's sums
   hipStream_t st = c->stream;
   StageTimer tm(c);
   const int nb = c->nb, bw = c->bw, nbd = c->nbd;
@@ -914,6 +914,7 @@ static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, 
   LVX_HIP(c, hipGetLastError());
   int info[4] = {0, 0, 0, 0};
   tm.lap("enqueue gram+schur+dense");
+  if (defer_check) return LVX_OK;
   LVX_HIP(c, hipMemcpyAsync(info, w.info, 16, hipMemcpyDeviceToHost, st));
   LVX_HIP(c, hipStreamSynchronize(st));
   tm.lap("sync (GPU drain)");
@@ -963,7 +964,11 @@ static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double m[3
   bool bcr_used = false;
   m[0] = m[1] = m[2] = 0.0; *notpd_out = false;
   w.lm_done = false;
-  int rc = lerr ? lerr : solve_local(c, w, radius, false, &bcr_used);
+  // Single sequence: the pivot codes of the factorisations travel to the host WITH the step's sums — the back substitution is queued right behind the elimination and the
+  // solve stops the host once, not twice (a failed pivot voids the step, which is then redone by the sequential solver as before).  The joint solve votes on the
+  // pivots in its collective, in the middle: it keeps the early check.
+  const bool defer = !is_joint(c) && !lerr && w.use_bcr;
+  int rc = lerr ? lerr : solve_local(c, w, radius, false, &bcr_used, defer);
   if (rc == LVX_E_NOTPD && w.use_bcr) {
     // the cyclic-reduction elimination order can lose positive definiteness in floating point on nearly singular systems
     // (huge trust radius at convergence); the sequential band Cholesky is the exact fallback.  Purely local: no collective yet.
@@ -1022,6 +1027,9 @@ static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double m[3
   }
   *notpd_out = notpd;
   if (notpd) { fail(c, LVX_E_NOTPD, "damped normal equations not positive definite"); return LVX_OK; }
+  double h[8]; int info4[4] = {0, 0, 0, 0};
+  const bool quad_explicit = is_joint(c);   // (see the tail)
+  auto tail = [&]() -> int {
   { const size_t lds_dense = ((size_t)nbd * (nbd + 1) + nbd) * 8;
     LVX_HIP(c, hipFuncSetAttribute((const void*)k_dense_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dense));
     hipLaunchKernelGGL(k_dense_back, dim3(1), dim3(DENSE_NT), lds_dense, st, (const double*)w.S, w.rhs, nbd, np); }
@@ -1049,16 +1057,25 @@ static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double m[3
   // delta^T H delta.  Single sequence: the step solves (H + D) delta = -g EXACTLY (SPARSE_SCHUR semantics; residual 1e-15 of the scale, tests/test_gpu_fullsize_oracle.py),
   // so delta^T H delta = -g.delta - delta^T D delta comes with the sums k_unscale / k_lm_back form anyway — the explicit product streams the whole band again (216 MB, 0.16 ms).
   // Joint problem: the identity holds for the SUM over the ranks only and the shared damping is counted once, after the reduction — the explicit product stays.
-  const bool quad_explicit = is_joint(c);
   if (quad_explicit) {
     if (nb > 0) hipLaunchKernelGGL(k_quad_band, dim3((unsigned)std::min(2048, (nb + 3) / 4)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)zb, (const double*)w.scale, nb, bw, w.sums, w.tk ? w.tk + 2 : nullptr);
     hipLaunchKernelGGL(k_quad, dim3((unsigned)std::min(2 * RED_BLOCKS, (nb + nbd + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)c->d_Bd.p, (const double*)c->d_C.p, c->nbd_ext,
                        (const double*)zb, (const double*)w.rhs, (const double*)w.scale, nb, bw, nbd, w.sums, w.tk ? w.tk + 3 : nullptr);
   }
   LVX_HIP(c, hipGetLastError());
-  double h[8];
   LVX_HIP(c, hipMemcpyAsync(h, w.sums, 8 * 8, hipMemcpyDeviceToHost, st));
+  if (defer) LVX_HIP(c, hipMemcpyAsync(info4, w.info, 16, hipMemcpyDeviceToHost, st));
   LVX_HIP(c, hipStreamSynchronize(st));
+  return LVX_OK;
+  };
+  { const int rt = tail(); if (rt) return rt; }
+  if (defer && (info4[0] || info4[1])) {   // a pivot failed in the elimination this step came from: redo it with the sequential band Cholesky (checked at once)
+    ++c->solver_fallbacks;
+    rc = solve_local(c, w, radius, true, &bcr_used, false);
+    if (rc == LVX_E_NOTPD) { *notpd_out = true; return LVX_OK; }
+    if (rc) return rc;
+    const int rt = tail(); if (rt) return rt;
+  }
   // model_cost_change = -(g.delta + 1/2 delta^T H delta)   (TrustRegionMinimizer: -model_residuals.(residuals + model_residuals / 2));
   // joint problem: H = sum_r H_r, g = sum_r g_r with delta_r = [private_r | shared]  =>  both terms are sums over the ranks
   m[0] = h[0]; m[1] = quad_explicit ? h[5] : -h[0] - h[1]; m[2] = h[1];
