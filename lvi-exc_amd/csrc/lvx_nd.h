@@ -9,7 +9,7 @@
 //   * narrow leaves (a few hundred columns of reach <= 32): band Cholesky in 16 x 16 tiles, U = L^T with three tiles per tile column, ONE wavefront per leaf walks the
 //     chain (k_nd_factor); the right-hand sides — the coupling to the left separator (32 columns), to the right one (last rows only) and the solver's own columns — are
 //     solved against it by a workgroup per leaf, a wavefront per 16 columns, and the products the separators need are summed on the way (k_nd_solve);
-//   * dense leaves (a wide run of <= 208 columns: one co-visibility window): the register-resident Cholesky and the LDS triangular solves of the chain kernels,
+//   * dense leaves (a wide run of <= 192 columns: one co-visibility window): the register-resident Cholesky and the LDS triangular solves of the chain kernels,
 //     batched over the runs, on a second stream beside the narrow leaves;
 //   * the separators: a block tridiagonal system with 32 x 32 blocks, D_k -= W_R^T W_R (leaf on the left) + W_L^T W_L (leaf on the right), A_{k+1,k} = -W_R^T W_L —
 //     block cyclic reduction again, but with level kernels of its own for this block size (k_c32_level: one launch per level; k_c32_back).
@@ -26,6 +26,7 @@ struct NdLeaf { int c0, m, nt, sl, sr, cl, wl, cr, wr, toff, pr0, slot, dense; }
                                                                                    // tile column in the tile storage; first tile row the right separator couples to; index among its kind
 struct NdSep { int c0, w, lf, rt; };                                                // columns [c0, c0 + w), w <= 32; leaf on the left / right (-1: none)
 #define ND_WS 32
+#define ND_DENSE_MAX 192   // columns of a dense leaf: what the LDS-resident triangular solves and the fused backward kernel of the chain kernels hold (k_trsm_lds, k_bcr_back_level)
 // LDS-only synchronisation: __syncthreads() also waits for every outstanding GLOBAL load and store (s_waitcnt vmcnt(0)) — the prefetched tiles and the results on their way
 // out, once per tile row: 5 - 10 us each.  ND_WAVE_LDS: one wavefront, its own LDS writes before its reads; ND_LDS_BARRIER: workgroup.
 // ND_KEEP4: a prefetched tile stays a LOADED value until here — without it the compiler forms next iteration's products (scaling, the negated MFMA operand) right behind the
@@ -825,7 +826,7 @@ int nd_plan(lvx_ctx* c, int nrhs) {
       const int a0 = r < runs.size() ? runs[r].first : nb;
       if (a0 > cur || r == runs.size()) { if (a0 > cur && !stretch(cur, a0, r > 0, r < runs.size())) return false; }
       else if (r > 0) return false;   // (cannot happen: runs are maximal)
-      if (r < runs.size()) { if (runs[r].second - runs[r].first > 208) return false; els.push_back({1, runs[r].first, runs[r].second - runs[r].first}); cur = runs[r].second; }
+      if (r < runs.size()) { if (runs[r].second - runs[r].first > ND_DENSE_MAX) return false; els.push_back({1, runs[r].first, runs[r].second - runs[r].first}); cur = runs[r].second; }
     }
     return true;
   };
@@ -880,7 +881,7 @@ int nd_plan(lvx_ctx* c, int nrhs) {
       for (int j = s.c0; j < s.c0 + s.w; ++j) if (full[j]) ND_NO(15);
     }
     for (const NdLeaf& l : P->leaves) {
-      if (l.dense) { if (l.m > 208) ND_NO(16); continue; }
+      if (l.dense) { if (l.m > ND_DENSE_MAX) ND_NO(16); continue; }
       for (int j = l.c0; j < l.c0 + l.m; ++j) if (full[j] || hi[j] - j > c->bw_near) ND_NO(17);
     }
   }

@@ -171,3 +171,20 @@ def test_joint_step_of_two_sequences_is_the_same_with_either_elimination():
         _same(a[r][0], a[r][1], b[r][0], b[r][1])
     sh0, sh1 = sharded.shared_tangent_indices(seqs[0][0]["n_knots"]), sharded.shared_tangent_indices(seqs[1][0]["n_knots"])
     assert np.array_equal(a[0][0][sh0], a[1][0][sh1])      # the shared step is bitwise identical on both ranks
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_window_layouts_agree_with_the_sequential_solver(seed):
+    """Co-visibility windows of different widths and spacings (views per landmark 3 .. 8 at 10 .. 20 Hz: dense leaves of ~70 .. 190 columns; wider or merged windows: no plan, the uniform chain; windows close to the ends of the
+    sequence, narrow stretches of very different lengths), different trust radii; whatever plan comes out — or none — the step is the sequential solver's."""
+    rng = np.random.default_rng(900 + seed)
+    views = int(rng.integers(3, 9))
+    P = synth.make_bench_problem(seed=60 + seed, n_imu=int(rng.integers(9000, 20000)), n_surfel=30000, n_reproj=int(rng.integers(300, 1500)), n_planes=50,
+                                 views_per_lm=views, cam_rate=float(rng.choice([10.0, 15.0, 20.0])), obs_per_frame=int(rng.integers(20, 60)), pad=float(rng.choice([0.1, 0.2, 0.4])))
+    radius = float(rng.choice([3.0, 1e2, 1e4, 1e6]))
+    x = P["state0"]
+    d, m, lo = _step(P, TAU, x, 1, radius=radius)
+    ds, ms, _ = _step(P, TAU, x, -1, seq=True, radius=radius)
+    print("seed %d: views %d, band %d x %d, %d separators / %d leaves, radius %g" % (seed, views, lo["n_band"], lo["bandwidth"], lo["solver_separators"], lo["solver_leaves"], radius))
+    assert lo["solver_fallbacks"] == 0
+    _same(d, m, ds, ms)
