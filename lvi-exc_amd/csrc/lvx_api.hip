@@ -97,6 +97,7 @@ void lvx_destroy(lvx_ctx* c) {
   if (c->vox.graph) (void)hipGraphExecDestroy((hipGraphExec_t)c->vox.graph);
   if (c->vox.h_info) (void)hipHostFree(c->vox.h_info);
   if (c->da_pinned) (void)hipHostFree(c->da_pinned);
+  if (c->pin) (void)hipHostFree(c->pin);
   for (DevBuf* b : {&c->vox.misc, &c->vox.keys, &c->vox.vals, &c->vox.runs, &c->vox.cells, &c->vox.tmp, &c->vox.leaf_i, &c->vox.leaf_d, &c->vox.leaf_f}) if (b->p) (void)hipFree(b->p);
   (void)lvx_rccl_finalize(c);
   if (c->d_comm.p) (void)hipFree(c->d_comm.p);

@@ -5,6 +5,7 @@
 
 #include <array>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "../../include/lvx.h"
@@ -107,6 +108,12 @@ struct lvx_ctx {
   int rep_groups = 0;          // (reference window, observation window) groups of the reprojection cross-term kernel (d_repB[2])
   int rep_fused_wg = 0; lvx::DevBuf d_repF;   // fused reprojection kernel (k_reproj_fused): its groups (0: the five-launch chain runs) and their table [start | count], largest first
   bool fb_on = false; int fb_mask = 0, fallback_rows = 0; lvx::DevBuf d_fb;   // row-level exact fallback (run_evaluate): lists enabled after the first pass that needed them; rows on them in the last checked pass
+  // Small device -> host reads of the evaluation / LM loop go through PINNED words: hipMemcpyAsync into pageable memory (a stack variable) is staged and returns only when
+  // the copy is done — every such "asynchronous" read was a host stop of its own (three per LM iteration between the pass and the solve).  Slots (doubles): 0 cost,
+  // 1 .. 8 the pass's error words, 16 .. 21 k_plus' sums, 24 gradient max norm, 25 .. 38 shared gradient, 40 .. 47 the step's sums, 48 .. 49 pivot codes,
+  // 50 .. 63 shared diagonal, 70 .. 71 shared time offsets.
+  double* pin = nullptr;
+  std::function<void()> before_eval_sync;   // run_evaluate calls it right before it waits for the pass's cost: what the caller wants on the host after the SAME host stop (the LM loop: step norms, the candidate's diagonal and gradient norm)
   bool force_legacy = false;   // set when the fast assembly kernels hit a case only the per-segment kernels handle exactly
   lvx::DevBuf d_pre;   // So3Pre[N]
   lvx::DevBuf d_repT;   // [rep.n][56] landmark-row records of the reprojection blocks (k_reproj_cross -> k_reproj_lmrows)

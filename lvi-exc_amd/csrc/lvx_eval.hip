@@ -2920,10 +2920,14 @@ int run_evaluate(lvx_ctx* ctx, const double* state_d, uint32_t what, double* cos
   ctx->last_state_d = state_d; ctx->last_want_res = want_res_buffer;
   ctx->err_unchecked = cost == nullptr;   // the device error word of this pass has not been looked at yet (check_last_eval)
   if (cost) {
-    double c = 0; int err[16] = {0};
-    LVX_HIP(ctx, hipMemcpyAsync(&c, cm.cost, 8, hipMemcpyDeviceToHost, st));
-    LVX_HIP(ctx, hipMemcpyAsync(err, cm.err, 4 * (4 + LVX_NUM_FAM), hipMemcpyDeviceToHost, st));
+    if (!ctx->pin) { LVX_HIP(ctx, hipHostMalloc((void**)&ctx->pin, 128 * 8, hipHostMallocDefault)); std::memset(ctx->pin, 0, 128 * 8); }
+    int err[16] = {0};
+    LVX_HIP(ctx, hipMemcpyAsync(ctx->pin, cm.cost, 8, hipMemcpyDeviceToHost, st));
+    LVX_HIP(ctx, hipMemcpyAsync(ctx->pin + 1, cm.err, 4 * (4 + LVX_NUM_FAM), hipMemcpyDeviceToHost, st));
+    if (ctx->before_eval_sync) ctx->before_eval_sync();   // (a pass repeated below calls it again: it then reads the repeated pass's results)
     LVX_HIP(ctx, hipStreamSynchronize(st));
+    const double c = ctx->pin[0];
+    std::memcpy(err, ctx->pin + 1, 4 * (4 + LVX_NUM_FAM));
     *cost = c;
     ctx->fallback_rows = 0; for (int f = 0; f < LVX_NUM_FAM; ++f) ctx->fallback_rows += err[4 + f];
     if ((err[0] & LVX_ERR_FALLBACK) && !ctx->force_legacy) {

@@ -1063,9 +1063,12 @@ static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double m[3
                        (const double*)zb, (const double*)w.rhs, (const double*)w.scale, nb, bw, nbd, w.sums, w.tk ? w.tk + 3 : nullptr);
   }
   LVX_HIP(c, hipGetLastError());
-  LVX_HIP(c, hipMemcpyAsync(h, w.sums, 8 * 8, hipMemcpyDeviceToHost, st));
-  if (defer) LVX_HIP(c, hipMemcpyAsync(info4, w.info, 16, hipMemcpyDeviceToHost, st));
+  if (!c->pin) { LVX_HIP(c, hipHostMalloc((void**)&c->pin, 128 * 8, hipHostMallocDefault)); std::memset(c->pin, 0, 128 * 8); }
+  LVX_HIP(c, hipMemcpyAsync(c->pin + 40, w.sums, 8 * 8, hipMemcpyDeviceToHost, st));
+  if (defer) LVX_HIP(c, hipMemcpyAsync(c->pin + 48, w.info, 16, hipMemcpyDeviceToHost, st));
   LVX_HIP(c, hipStreamSynchronize(st));
+  for (int q = 0; q < 8; ++q) h[q] = c->pin[40 + q];
+  if (defer) std::memcpy(info4, c->pin + 48, 16);
   return LVX_OK;
   };
   { const int rt = tail(); if (rt) return rt; }
@@ -1098,31 +1101,40 @@ static int local_gmax(lvx_ctx* c, SolveWork& w, double* g, double* gsh) {
   hipLaunchKernelGGL(k_gmax, dim3((unsigned)std::min(RED_BLOCKS, (n + 255) / 256)), dim3(256), 0, st, (const double*)c->d_gb.p, (const double*)c->d_gc.p, c->nb, c->nbd - c->ns, w.sums, tb);
   if (w.lm) hipLaunchKernelGGL(k_gmax_lm, dim3((unsigned)std::min(RED_BLOCKS, (c->L + 255) / 256)), dim3(256), 0, st, (const double*)c->d_lmH.p, c->L, c->lm_ls, c->lm_wl + c->nbd_ext + 1, w.sums,
                                xs ? xs + 7 * (size_t)c->N + 32 : (const double*)nullptr);
-  LVX_HIP(c, hipMemcpyAsync(g, w.sums + 4, 8, hipMemcpyDeviceToHost, st));
-  if (c->ns > 0) LVX_HIP(c, hipMemcpyAsync(gsh, (const double*)c->d_gc.p + (c->nbd - c->ns), (size_t)c->ns * 8, hipMemcpyDeviceToHost, st));
+  // into the pinned words (lvx_ctx::pin); local_collect moves them to *g / gsh after the host stop
+  (void)g; (void)gsh;
+  if (!c->pin) { LVX_HIP(c, hipHostMalloc((void**)&c->pin, 128 * 8, hipHostMallocDefault)); std::memset(c->pin, 0, 128 * 8); }
+  LVX_HIP(c, hipMemcpyAsync(c->pin + 24, w.sums + 4, 8, hipMemcpyDeviceToHost, st));
+  if (c->ns > 0) LVX_HIP(c, hipMemcpyAsync(c->pin + 25, (const double*)c->d_gc.p + (c->nbd - c->ns), (size_t)c->ns * 8, hipMemcpyDeviceToHost, st));
   return LVX_OK;
 }
 // What follows a LVX_EVAL_NORMAL_EQ evaluation, in two halves so that the loop can put ONE collective between them.
 // local_after_eval: the diagonal of J^T J into w.diag (the LM damping in w.lmd — what the solver reads — is untouched until apply_diag), this rank's private
 // gradient max norm, and the shared entries of diagonal / gradient on the host.
 struct EvalLocal { double gm = 0.0; double hd[LVX_N_SHARED] = {0}, hg[LVX_N_SHARED] = {0}; double tau[2] = {0, 0}; bool have_tau = false; };   // tau: the (shared) sensor time offsets of a constrained joint solve
-static int local_after_eval(lvx_ctx* c, SolveWork& w, EvalLocal* e) {
+// after the host stop behind local_after_eval's copies: the pinned words into *e
+static void local_collect(const lvx_ctx* c, EvalLocal* e) {
+  e->gm = c->pin[24];
+  for (int i = 0; i < c->ns && i < LVX_N_SHARED; ++i) { e->hg[i] = c->pin[25 + i]; e->hd[i] = c->pin[50 + i]; }
+  if (e->have_tau) { e->tau[0] = c->pin[70]; e->tau[1] = c->pin[71]; }
+}
+static int local_after_eval(lvx_ctx* c, SolveWork& w, EvalLocal* e, bool sync = true) {   // sync = false: queued only (the caller's next host stop completes the copies into *e)
   const int n = c->nb + c->nbd, ns = c->ns;
   hipStream_t st = c->stream;
   const int nl = w.lm ? c->L : 0;   // landmark diagonal behind the band / border entries
   hipLaunchKernelGGL(k_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)c->d_C.p, c->nb, c->bw, c->nbd, c->nbd_ext, w.diag);
   if (nl > 0) hipLaunchKernelGGL(k_lm_fetch_diag, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, (const double*)c->d_lmH.p, nl, c->lm_ls, c->lm_wl + c->nbd_ext, w.diag + n);
   int rc = local_gmax(c, w, &e->gm, e->hg); if (rc) return rc;
-  if (is_joint(c) && ns > 0) LVX_HIP(c, hipMemcpyAsync(e->hd, w.diag + (n - ns), (size_t)ns * 8, hipMemcpyDeviceToHost, st));
+  if (is_joint(c) && ns > 0) LVX_HIP(c, hipMemcpyAsync(c->pin + 50, w.diag + (n - ns), (size_t)ns * 8, hipMemcpyDeviceToHost, st));
   // (keyed on the LOCKS, which every rank shares — a rank whose own sequence has no block that makes it constrained must project the summed shared gradient
   // exactly as its peers do, or they disagree on gradient_tolerance convergence and part ways before the next collective)
   const bool tau_free = !(c->locks & LVX_LOCK_LIDAR_TAU) || !(c->locks & LVX_LOCK_CAM_TAU);
   if (is_joint(c) && (w.constrained || tau_free) && c->last_state_d) {   // the shared time offsets' box enters the projected gradient of the SUMMED shared gradient (apply_diag)
-    LVX_HIP(c, hipMemcpyAsync(&e->tau[0], c->last_state_d + 7 * (size_t)c->N + 23, 8, hipMemcpyDeviceToHost, st));
-    LVX_HIP(c, hipMemcpyAsync(&e->tau[1], c->last_state_d + 7 * (size_t)c->N + 31, 8, hipMemcpyDeviceToHost, st));
+    LVX_HIP(c, hipMemcpyAsync(c->pin + 70, c->last_state_d + 7 * (size_t)c->N + 23, 8, hipMemcpyDeviceToHost, st));
+    LVX_HIP(c, hipMemcpyAsync(c->pin + 71, c->last_state_d + 7 * (size_t)c->N + 31, 8, hipMemcpyDeviceToHost, st));
     e->have_tau = true;
   }
-  LVX_HIP(c, hipStreamSynchronize(st));
+  if (sync) { LVX_HIP(c, hipStreamSynchronize(st)); local_collect(c, e); }
   return LVX_OK;
 }
 // Joint quantities of an evaluation as ONE sum block: [shared diagonal (14, canonical slots) | shared gradient (14) | ranks whose private gradient max norm exceeds the
@@ -1343,10 +1355,23 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
       LVX_HIP(c, hipMemsetAsync(w.sums + 2, 0, 48, st));
       hipLaunchKernelGGL(k_plus, dim3((unsigned)((N + 1 + L + 255) / 256)), dim3(256), 0, st, (const double*)x, (const double*)w.delta, N, L, c->locks, xt, w.sums, joint ? 1 : 0, c->sensor_mto, w.tk ? w.tk + 7 : nullptr);
       double cand = 0;
+      // Single sequence: what the loop wants on the host after the candidate's pass — its cost and error words, the step norms k_plus left in w.sums, the candidate's
+      // diagonal and gradient norm (local_after_eval: used if the step is accepted) — arrives with ONE host stop: the copies and the small kernels are queued from inside
+      // the evaluation call, right before it waits (lvx_ctx::before_eval_sync).  The joint solve keeps its stops (its collectives sit between them).
+      bool hooked = false; int hook_rc = LVX_OK;
+      if (!joint) c->before_eval_sync = [&]() {
+        hooked = true; hook_rc = LVX_OK;
+        if (hipMemcpyAsync(c->pin + 16, w.sums + 2, 48, hipMemcpyDeviceToHost, st) != hipSuccess) hook_rc = LVX_E_HIP;
+        if (!hook_rc) hook_rc = local_after_eval(c, w, &ev, false);
+      };
       const int re = lvx_evaluate_d(c, xt, LVX_EVAL_COST | LVX_EVAL_NORMAL_EQ, &cand);
+      c->before_eval_sync = nullptr;
       cand_ne = true; acc_is_x = false;
       if (re == LVX_E_RANGE || re == LVX_E_NONUNIT_QUAT) cand = INFINITY; else if (re) lerr = re;   // a candidate that cannot be evaluated is a rejected step, anything else an error
-      if (!lerr && hipMemcpy(h, w.sums + 2, 48, hipMemcpyDeviceToHost) != hipSuccess) lerr = LVX_E_HIP;
+      if (!lerr && hooked && hook_rc) lerr = hook_rc;
+      if (hooked && !hook_rc) { for (int q = 0; q < 6; ++q) h[q] = c->pin[16 + q]; local_collect(c, &ev); }
+      if (!lerr && !hooked && hipMemcpy(h, w.sums + 2, 48, hipMemcpyDeviceToHost) != hipSuccess) lerr = LVX_E_HIP;
+      bool ev_done = hooked && !hook_rc;   // (a line search below evaluates again: its last pass is what local_after_eval must see)
       // projected Armijo line search (constrained problem): the full step stays when it decreases the cost by 1e-4 of the linear prediction — the rule.  Joint solve:
       // every quantity the search decides on is the SUM over the ranks (costs, directional derivatives); a rank that fails votes and all leave together.
       auto jsum = [&](double* v, int n, int err) -> int {   // v[n - 1] is the vote slot
@@ -1363,6 +1388,7 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
         cand_g = b4[2] > 0.0 ? INFINITY : b4[0]; m0_g = b4[1];
       }
       if (!lerr && ls_on && std::isfinite(cand_g) && m0_g < 0.0 && cand_g > cost + 1e-4 * m0_g) {
+        ev_done = false;   // the search evaluates again: the diagonal / gradient norm queued with the full step's pass are not the accepted point's
         const double f0 = cost, g0 = m0_g;
         double g1 = 0.0;
         { int le = grad_dot(c, w, &g1); double b2[2] = {le ? 0.0 : g1, 0.0}; if ((rc = jsum(b2, 2, le))) return rc; g1 = b2[0]; }
@@ -1443,7 +1469,7 @@ int lvx_lm_solve_shared(lvx_ctx* c, double* state, const lvx_lm_options* opt_in,
         }
         (void)alpha;
       }
-      if (!lerr && std::isfinite(cand)) lerr = local_after_eval(c, w, &ev);   // the candidate's diagonal / gradient: used if the step is accepted (w.lmd, the damping of x, stays)
+      if (!lerr && std::isfinite(cand) && !ev_done) lerr = local_after_eval(c, w, &ev);   // the candidate's diagonal / gradient: used if the step is accepted (w.lmd, the damping of x, stays)
       r2[3] = cand; r2[4] = h[0]; r2[5] = h[1];
     }
     if (joint) {   // private blocks summed over the ranks; the shared blocks (identical on every rank) are counted once below
