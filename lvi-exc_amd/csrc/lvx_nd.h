@@ -535,41 +535,58 @@ __global__ __launch_bounds__(256) void k_nd_cscatter(NdArgs a, int bd, const dou
 struct C32 { double* D; double* G; double* Z; double* Y; double* F; int* info; int nblk, nz, zt; };
 __device__ __forceinline__ size_t c32_goff(int nblk, int l) { size_t o = 0; for (int k = 0; k < l; ++k) o += (size_t)(nblk >> k) * 1024; return o; }
 // Cholesky of a 32 x 32 block (column-major lower in global memory) by one wavefront: tiles [U00 | U01 | U11 | inv(L0)^T | inv(L1)^T] to LDS (as they stand) and, if
-// keep, to global memory; returns the 1-based first bad pivot (0: none)
-__device__ __forceinline__ int c32_factor(const double* D, double (*fac)[256], double* keep, double* tr, int lane) {
+// keep, to global memory; returns the 1-based first bad pivot (0: none).  ONE copy of the 16 x 16 factorisation's ~800 instructions, run twice by a loop and shared by
+// every call (noinline): executed once from a cold instruction cache it costs 4.7 k cycles against 0.8 k warm (docs/HISTORY.md, round 3) — two inlined copies per call
+// made this function 15 k cycles, more than half of a level's kernel.
+__device__ __attribute__((noinline)) int c32_factor(const double* D, double (*fac)[256], double* keep, double* tr, int lane) {
   const int q = lane >> 4, j = lane & 15;
   const d4 zero4 = d4{0.0, 0.0, 0.0, 0.0};
-  d4 T00, A01, T11;
+  d4 T, A01, T11;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = q + 4 * r, lo = min(row, j), hi = max(row, j);
-    T00[r] = D[lo * 32 + hi]; A01[r] = D[row * 32 + 16 + j]; T11[r] = D[(16 + lo) * 32 + 16 + hi];
+    T[r] = D[lo * 32 + hi]; A01[r] = D[row * 32 + 16 + j]; T11[r] = D[(16 + lo) * 32 + 16 + hi];
   }
-  d4 M0, M1;
-  int bad = chol16_mfma(T00, M0, q, j);
+  d4 U01 = zero4;
+  int bad = 0;
+#ifdef LVX_ND_KT
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  long long fk[6]; int fki = 0; fk[fki++] = __builtin_amdgcn_s_memtime();
+#endif
+#pragma nounroll
+  for (int p = 0; p < 2; ++p) {
+    d4 M;
+    const int b = chol16_mfma(T, M, q, j);
+#ifdef LVX_ND_KT
+    { const int u_ = __builtin_amdgcn_readfirstlane(__double2hiint(M[0])); asm volatile("" :: "s"(u_)); fk[fki++] = __builtin_amdgcn_s_memtime(); }
+#endif
+    bad = bad ? bad : (b ? 16 * p + b : 0);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) tr[(q + 4 * r) * 17 + j] = M0[r];
-  ND_WAVE_LDS();
-  d4 LIT0;
+    for (int r = 0; r < 4; ++r) tr[(q + 4 * r) * 17 + j] = M[r];
+    ND_WAVE_LDS();
+    d4 LIT;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) LIT0[r] = tr[j * 17 + q + 4 * r];
-  ND_WAVE_LDS();
-  const d4 U01 = nd_mm(LIT0, A01, zero4);
-  T11 = nd_mmn(U01, U01, T11);
-  const int b1 = chol16_mfma(T11, M1, q, j);
-  bad = bad ? bad : (b1 ? 16 + b1 : 0);
+    for (int r = 0; r < 4; ++r) LIT[r] = tr[j * 17 + q + 4 * r];
+    ND_WAVE_LDS();
 #pragma unroll
-  for (int r = 0; r < 4; ++r) tr[(q + 4 * r) * 17 + j] = M1[r];
-  ND_WAVE_LDS();
-  d4 LIT1;
+    for (int r = 0; r < 4; ++r) {
+      const int e = r * 64 + lane;
+      fac[2 * p][e] = T[r]; fac[3 + p][e] = LIT[r];            // U00 / U11, inv(L0)^T / inv(L1)^T
+      if (keep) { keep[2 * p * 256 + e] = T[r]; keep[(3 + p) * 256 + e] = LIT[r]; }
+    }
+    if (p == 0) {
+      U01 = nd_mm(LIT, A01, zero4);
+      T = nd_mmn(U01, U01, T11);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) LIT1[r] = tr[j * 17 + q + 4 * r];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int e = r * 64 + lane;
-    fac[0][e] = T00[r]; fac[1][e] = U01[r]; fac[2][e] = T11[r]; fac[3][e] = LIT0[r]; fac[4][e] = LIT1[r];
-    if (keep) { keep[e] = T00[r]; keep[256 + e] = U01[r]; keep[512 + e] = T11[r]; keep[768 + e] = LIT0[r]; keep[1024 + e] = LIT1[r]; }
+      for (int r = 0; r < 4; ++r) { fac[1][r * 64 + lane] = U01[r]; if (keep) keep[256 + r * 64 + lane] = U01[r]; }
+    }
+#ifdef LVX_ND_KT
+    { const int u_ = __builtin_amdgcn_readfirstlane(__double2hiint(T[0])); asm volatile("" :: "s"(u_)); fk[fki++] = __builtin_amdgcn_s_memtime(); }
+#endif
   }
+#ifdef LVX_ND_KT
+  if (lane == 0 && blockIdx.x == 0 && keep) printf("FKT chol0 %lld rest0 %lld chol1 %lld rest1 %lld\n", fk[1] - fk[0], fk[2] - fk[1], fk[3] - fk[2], fk[4] - fk[3]);
+#endif
   return bad;
 }
 __device__ __forceinline__ d4 c32_lds(const double* t, int lane) { d4 X;
@@ -640,12 +657,21 @@ __global__ __launch_bounds__(512) void k_c32_level(C32 c, int l, int last) {
     }
     return X;
   };
+#ifdef LVX_ND_KT
+  const long long ck0 = __builtin_amdgcn_s_memtime();
+#endif
   d4 Ra0, Ra1, Rb0, Rb1;
   task_load(wv, Ra0, Ra1); task_load(wv + 8, Rb0, Rb1);
   d4 Oa = out_load(wv), Ob = out_load(wv + 8);
   if (wv == 0) { const int bad = c32_factor(c.D + (size_t)jL * 1024, facL, FL, tr, lane); if (lane == 0) c.info[jL] = bad; }
   else if (wv == 1 && hasR) (void)c32_factor(c.D + (size_t)jR * 1024, facR, nullptr, tr + 16 * 17, lane);
+#ifdef LVX_ND_KT
+  const long long ck1 = __builtin_amdgcn_s_memtime();
+#endif
   __syncthreads();
+#ifdef LVX_ND_KT
+  const long long ck2 = __builtin_amdgcn_s_memtime();
+#endif
   // solves
   for (int t = wv, it = 0; t < ntask; t += 8, ++it) {
     const bool right = t >= ntL;
@@ -667,7 +693,13 @@ __global__ __launch_bounds__(512) void k_c32_level(C32 c, int l, int last) {
       }
     }
   }
+#ifdef LVX_ND_KT
+  const long long ck3 = __builtin_amdgcn_s_memtime();
+#endif
   ND_LDS_BARRIER();
+#ifdef LVX_ND_KT
+  const long long ck4 = __builtin_amdgcn_s_memtime();
+#endif
   // products
   for (int o = wv, it = 0; o < nout; o += 8, ++it) {
     d4 acc = zero4;
@@ -700,6 +732,9 @@ __global__ __launch_bounds__(512) void k_c32_level(C32 c, int l, int last) {
       for (int rr = 0; rr < 4; ++rr) *out_ptr(o, rr) = old[rr] - acc[rr];
     }
   }
+#ifdef LVX_ND_KT
+  if (lane == 0 && k == 0 && (wv == 0 || wv == 3) && l < 3) printf("C32KT l %d wv %d: to-factor-end %lld barrier %lld solves %lld barrier %lld products %lld\n", l, wv, ck1 - ck0, ck2 - ck1, ck3 - ck2, ck4 - ck3, (long long)__builtin_amdgcn_s_memtime() - ck4);
+#endif
   if (!last) return;
   // the last level leaves ONE block: factor it and solve its right-hand sides here
   __syncthreads();
