@@ -775,10 +775,9 @@ __device__ __forceinline__ void c32_usolve(const double* F, double* v, int lane)
   if (lane < 16) v[i] = x0;
   ND_WAVE_LDS();
 }
-__global__ __launch_bounds__(64) void k_c32_back(C32 c, int l, int top, double* zb) {
-  __shared__ double xr[32], xl[32], v[32];
-  const int lane = threadIdx.x, i = lane & 15;
-  const int k = blockIdx.x, s = 1 << l;
+__device__ __forceinline__ void c32_back_block(const C32& c, int l, int k, int top, double* zb, double* xr, double* xl, double* v, int lane) {
+  const int i = lane & 15;
+  const int s = 1 << l;
   const int jL = s - 1 + 2 * s * k, r = jL + s;
   const double* F = c.F + (size_t)jL * 13 * 256;
   if (top) {
@@ -788,7 +787,9 @@ __global__ __launch_bounds__(64) void k_c32_back(C32 c, int l, int top, double* 
     if (lane < 32) zb[r * 32 + lane] = v[lane];
     ND_WAVE_LDS();
   }
-  if (lane < 32) { xr[lane] = zb[r * 32 + lane]; xl[lane] = k >= 1 ? zb[(jL - s) * 32 + lane] : 0.0; v[lane] = zb[jL * 32 + lane]; }
+  if (lane < 32) { xr[lane] = top ? v[lane] : zb[r * 32 + lane]; xl[lane] = k >= 1 ? zb[(jL - s) * 32 + lane] : 0.0; }
+  ND_WAVE_LDS();
+  if (lane < 32) v[lane] = zb[jL * 32 + lane];
   ND_WAVE_LDS();
   // v -= Xt x_r + Y_L x_l   (tiles 5 + 2 a + b: rows 16 a .., columns 16 b ..)
   double a0 = c32_mv(F + 5 * 256, xr, lane) + c32_mv(F + 6 * 256, xr + 16, lane);
@@ -802,6 +803,21 @@ __global__ __launch_bounds__(64) void k_c32_back(C32 c, int l, int top, double* 
   ND_WAVE_LDS();
   c32_usolve(F, v, lane);
   if (lane < 32) zb[jL * 32 + lane] = v[lane];
+}
+__global__ __launch_bounds__(64) void k_c32_back(C32 c, int l, int top, double* zb) {
+  __shared__ double xr[32], xl[32], v[32];
+  c32_back_block(c, l, blockIdx.x, top, zb, xr, xl, v, threadIdx.x);
+}
+// the levels with at most eight eliminated blocks (the top of the tree: 8, 4, 2, 1 — or fewer) in ONE launch: a wavefront per block, a workgroup barrier between the
+// levels (four launches of 4 us with as much again between them otherwise)
+__global__ __launch_bounds__(512) void k_c32_back_top(C32 c, int l_hi, int l_lo, double* zb) {
+  __shared__ double xr[8][32], xl[8][32], v[8][32];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int l = l_hi; l >= l_lo; --l) {
+    const int n2 = c.nblk >> (l + 1);
+    if (wv < n2) c32_back_block(c, l, wv, l == l_hi ? 1 : 0, zb, xr[wv], xl[wv], v[wv], lane);
+    __syncthreads();
+  }
 }
 
 // ---- the plan: leaves and separators from the column profile ----
@@ -1055,7 +1071,9 @@ int nd_backward(lvx_ctx* c, double* zb) {
   {
     const C32 ch = nd_c32(P);
     int L = 0; while ((1 << L) < P->nblk2) ++L;
-    for (int l = L - 1; l >= 0; --l) hipLaunchKernelGGL(k_c32_back, dim3((unsigned)(P->nblk2 >> (l + 1))), dim3(64), 0, st, ch, l, l == L - 1 ? 1 : 0, zb2);
+    int l_lo = L - 1; while (l_lo > 0 && (P->nblk2 >> l_lo) <= 8) --l_lo;      // levels l_lo .. L - 1 have <= 8 eliminated blocks each
+    hipLaunchKernelGGL(k_c32_back_top, dim3(1), dim3(512), 0, st, ch, L - 1, l_lo, zb2);
+    for (int l = l_lo - 1; l >= 0; --l) hipLaunchKernelGGL(k_c32_back, dim3((unsigned)(P->nblk2 >> (l + 1))), dim3(64), 0, st, ch, l, 0, zb2);
   }
   if (P->nden > 0) {
     const int bd = P->bd;
