@@ -47,7 +47,7 @@ struct NdArgs {
   const NdLeaf* leaf; const NdSep* sep; const int* nar; const int* den;
   const double* Hs; const double* scale; const double* lmd; double ir; int ld, npre, nb;
   double *U, *WL, *WR, *GO; int nc, nrhs;
-  double* Z; int ldz, nz;   // Z row-major [ldz rows][nz]: a 16 x 16 tile is four 128-byte rows per load (column-major: sixteen 32-byte pieces, and the address pipe set the kernel's pace)
+  double* Z; int ldz, nz;   // Z row-major [ldz rows][nz]: a 16 x 16 tile is four 128-byte rows per load (column-major: sixteen 32-byte pieces — measured: NOT what bounded k_nd_solve; kept, the Gram and the border subtraction read rows as well)
   int* info; double* trash;   // trash: 64 words nobody reads (the target of masked stores that stay unconditional)
 };
 

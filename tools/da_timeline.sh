@@ -1,17 +1,18 @@
-#!/bin/bash
-# tools/da_timeline.sh — on the GPU box: kernel timeline of one lvx_data_association round (from a rocprofv3 kernel trace of tools/upstream_bench.py)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rm -rf gpurun_out/upkt
-rocprofv3 --kernel-trace -d gpurun_out/upkt -o kt -- python tools/upstream_bench.py 5 > gpurun_out/upkt.log 2>&1
-DB=$(find gpurun_out/upkt -name "*.db" | head -1)
-python - $DB <<'PY'
-import sqlite3, sys
-db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
-rows = cur.execute("select name, start, end from kernels order by start").fetchall()
-idx = [i for i, r in enumerate(rows) if "k_lidar_pose" in r[0]]
-a, b = idx[-2], idx[-1]
+mkdir -p gpurun_out; rm -rf gpurun_out/da_tl
+timeout 300 rocprofv3 --kernel-trace -d gpurun_out/da_tl -o kt -- python tools/probes/da_probe.py > gpurun_out/da_tl.log 2>&1
+python - <<'PY'
+import sqlite3, glob
+db = sqlite3.connect(glob.glob("gpurun_out/da_tl/**/*.db", recursive=True)[0])
+cur = db.cursor()
+cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+rows = cur.execute("select %s, start, end from kernels order by start" % name_col).fetchall()
+marks = [i for i, r in enumerate(rows) if "k_lidar_pose" in r[0]]
+a, b = marks[-2], marks[-1]
 t0 = rows[a][1]
 for r in rows[a:b]:
-    print("%-70s %9.1f %8.1f" % (r[0][:70], (r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3))
+    print("%-70s %9.1f %8.1f %9.1f" % (r[0][:70], (r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, (r[2] - t0) / 1e3))
+print("launches", b - a, "span %.1f us" % ((rows[b - 1][2] - t0) / 1e3))
 PY
-rm -rf gpurun_out/upkt
+rm -rf gpurun_out/da_tl
