@@ -1924,7 +1924,14 @@ static int scan_register_launch(lvx_ctx* c, int S, const int32_t* off_h, const l
   B.sharp_r = (int*)(base + L.sharp); B.lsharp_r = (int*)(base + L.lsharp); B.flat_r = (int*)(base + L.flat); B.counts = (int*)(base + L.counts); B.err = (int*)(base + L.err);
   ProfScope ps(c, LVX_KERNEL_UPSTREAM);
   if (!pts_d) LVX_HIP(c, hipMemcpyAsync(base + L.pts, pts_h, (size_t)N * 32, hipMemcpyHostToDevice, st));
-  LVX_HIP(c, hipMemcpyAsync(base + L.off, off_h, (size_t)(S + 1) * 4, hipMemcpyHostToDevice, st));
+  // The small words of a call — sweep offsets up, ring counts / list counts / error words back — go through the context's pinned words when they fit (a single sweep, a few):
+  // hipMemcpyAsync to or from pageable memory is staged and returns when the copy is done, so the three "asynchronous" reads behind the kernels were three host stops of
+  // ~20 us each on top of the final one (a third of a single sweep's 258 us).  Larger batches keep the pageable path: per sweep the stops are noise there.
+  const size_t pin_need = (size_t)(S + 1) + SR + (size_t)S * 4 + (size_t)S;   // ints
+  if (!c->pin) { LVX_HIP(c, hipHostMalloc((void**)&c->pin, 128 * 8, hipHostMallocDefault)); std::memset(c->pin, 0, 128 * 8); }
+  int* pin = pin_need <= 256 ? (int*)c->pin : nullptr;
+  if (pin) { std::memcpy(pin, off_h, (size_t)(S + 1) * 4); LVX_HIP(c, hipMemcpyAsync(base + L.off, pin, (size_t)(S + 1) * 4, hipMemcpyHostToDevice, st)); }
+  else LVX_HIP(c, hipMemcpyAsync(base + L.off, off_h, (size_t)(S + 1) * 4, hipMemcpyHostToDevice, st));
   LVX_HIP(c, hipMemsetAsync(base + L.rc, 0, SR * 4, st));
   LVX_HIP(c, hipMemsetAsync(base + L.counts, 0, (L.err - L.counts) + (size_t)S * 4, st));   // counts and err are adjacent
   const unsigned gx = (unsigned)((nmax + 255) / 256);
@@ -1937,10 +1944,19 @@ static int scan_register_launch(lvx_ctx* c, int S, const int32_t* off_h, const l
   LVX_HIP(c, hipGetLastError());
   std::vector<int> hrc(SR), herr(S);
   c->sr_counts.assign((size_t)S * 4, 0);
+  if (pin) {
+    int* prc = pin + (S + 1); int* pcnt = prc + SR; int* perr = pcnt + (size_t)S * 4;
+    LVX_HIP(c, hipMemcpyAsync(prc, B.rc, SR * 4, hipMemcpyDeviceToHost, st));
+    LVX_HIP(c, hipMemcpyAsync(pcnt, B.counts, (size_t)S * 16, hipMemcpyDeviceToHost, st));
+    LVX_HIP(c, hipMemcpyAsync(perr, B.err, (size_t)S * 4, hipMemcpyDeviceToHost, st));
+    LVX_HIP(c, hipStreamSynchronize(st));
+    std::memcpy(hrc.data(), prc, SR * 4); std::memcpy(c->sr_counts.data(), pcnt, (size_t)S * 16); std::memcpy(herr.data(), perr, (size_t)S * 4);
+  } else {
   LVX_HIP(c, hipMemcpyAsync(hrc.data(), B.rc, SR * 4, hipMemcpyDeviceToHost, st));
   LVX_HIP(c, hipMemcpyAsync(c->sr_counts.data(), B.counts, (size_t)S * 16, hipMemcpyDeviceToHost, st));
   LVX_HIP(c, hipMemcpyAsync(herr.data(), B.err, (size_t)S * 4, hipMemcpyDeviceToHost, st));
   LVX_HIP(c, hipStreamSynchronize(st));
+  }
   c->sr_S = S; c->sr_rings = n_rings; c->sr_N = N; c->sr_off.assign(off_h, off_h + S + 1); c->sr_m.assign(S, 0); c->sr_batch_off = {L.cloud, L.lflat, L.ss, L.cnt};
   c->sr_lay = {L.cloud, L.curv, L.label, L.sort, L.pick, L.lists, L.ss, L.se};
   for (int s = 0; s < S; ++s) { int m = 0; for (int r = 0; r < n_rings; ++r) m += hrc[(size_t)s * n_rings + r]; c->sr_m[s] = m; }
