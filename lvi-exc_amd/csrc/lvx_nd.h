@@ -40,7 +40,7 @@ struct NdPlan {
   int epoch = -1, mode = 0, nrhs = 0, zt = 0, nc = 0, ldz = 0;
   int nleaf = 0, nnar = 0, nden = 0, nsep = 0, ntile = 0, bd = 0, maxnt = 0, nblk2 = 0;
   std::vector<NdLeaf> leaves; std::vector<NdSep> seps;
-  DevBuf leaf, sep, nar, den, U, WL, WR, GO, Dc, Rc, LIc, info, D2, G2, F2, Z2, Y2, info2, zb2, tc;
+  DevBuf leaf, sep, nar, den, U, WL, WR, GO, Dc, Rc, LIc, info, D2, G2, F2, Z2, Y2, info2, zb2, tc, Fd;   // Fd: tiles of the dense border's factor (k_dense_tiles)
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 struct NdArgs {
@@ -820,6 +820,110 @@ __global__ __launch_bounds__(512) void k_c32_back_top(C32 c, int l_hi, int l_lo,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The dense border system (n <= 64: hub knots + calibration scalars of a single sequence) on the same tiles: Cholesky and forward substitution by ONE wavefront
+// (k_dense_tiles), backward substitution by one (k_dense_tiles_back).  The LDS-resident column-by-column kernel of lvx_solver.hip (k_dense_partial: three workgroup
+// barriers per column, 50 us at n = 52) stays for the joint solve, which eliminates only the private part of the border.
+// S: row-major lower triangle; F [NT * NT + NT][256]: U (p, q), q >= p, at p * NT + q, inv(L_p)^T at NT * NT + p — tiles as they stand.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double nd_colsum(const d4& T, const double* x16, int lane) {   // (T^T x) [lane & 15] from a register tile
+  const int q = lane >> 4;
+  double s = T[0] * x16[q] + T[1] * x16[q + 4] + T[2] * x16[q + 8] + T[3] * x16[q + 12];
+  s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+  return s;
+}
+template <int NT>
+__global__ __launch_bounds__(64) void k_dense_tiles(const double* __restrict__ S, double* rhs, int n, int* info, double* F) {
+  __shared__ double tr[16 * 17], yv[16 * NT], vt[16];
+  const int lane = threadIdx.x, q = lane >> 4, j = lane & 15;
+  const d4 zero4 = d4{0.0, 0.0, 0.0, 0.0};
+  d4 U[NT][NT], LIT[NT];
+#pragma unroll
+  for (int p = 0; p < NT; ++p)
+#pragma unroll
+    for (int c = p; c < NT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * p + q + 4 * r, col = 16 * c + j, lo = min(row, col), hi = max(row, col);
+        const double v = S[hi < n ? (size_t)hi * n + lo : 0];
+        U[p][c][r] = hi < n ? v : (row == col ? 1.0 : 0.0);
+      }
+  for (int e = lane; e < 16 * NT; e += 64) yv[e] = e < n ? rhs[e] : 0.0;
+  int bad = 0;
+#pragma unroll
+  for (int p = 0; p < NT; ++p) {
+    d4 T = U[p][p];
+#pragma unroll
+    for (int r2 = 0; r2 < p; ++r2) T = nd_mmn(U[r2][p], U[r2][p], T);
+    d4 M;
+    const int b = chol16_mfma(T, M, q, j);
+    bad = (bad == 0 && b > 0 && 16 * p + b <= n) ? 16 * p + b : bad;
+    U[p][p] = T;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tr[(q + 4 * r) * 17 + j] = M[r];
+    ND_WAVE_LDS();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) LIT[p][r] = tr[j * 17 + q + 4 * r];
+    ND_WAVE_LDS();
+#pragma unroll
+    for (int c = p + 1; c < NT; ++c) {
+      d4 X = U[p][c];
+#pragma unroll
+      for (int r2 = 0; r2 < p; ++r2) X = nd_mmn(U[r2][p], U[r2][c], X);
+      U[p][c] = nd_mm(LIT[p], X, zero4);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NT; ++p) {
+#pragma unroll
+    for (int c = p; c < NT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) F[(size_t)(p * NT + c) * 256 + r * 64 + lane] = U[p][c][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) F[(size_t)(NT * NT + p) * 256 + r * 64 + lane] = LIT[p][r];
+  }
+  // forward substitution: y_p = inv(L_p) (r_p - sum_{c < p} U (c, p)^T y_c)
+  ND_WAVE_LDS();
+#pragma unroll
+  for (int p = 0; p < NT; ++p) {
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < p; ++c) s += nd_colsum(U[c][p], yv + 16 * c, lane);
+    const double v = yv[16 * p + j] - s;
+    ND_WAVE_LDS();
+    if (q == 0) vt[j] = v;
+    ND_WAVE_LDS();
+    const double y = nd_colsum(LIT[p], vt, lane);
+    ND_WAVE_LDS();
+    if (q == 0) yv[16 * p + j] = y;
+    ND_WAVE_LDS();
+  }
+  for (int e = lane; e < n; e += 64) rhs[e] = yv[e];
+  if (lane == 0 && bad && info[1] == 0) { info[1] = bad; info[2] = 0; info[3] = 0; }
+}
+template <int NT>
+__global__ __launch_bounds__(64) void k_dense_tiles_back(const double* __restrict__ F, double* rhs, int n) {
+  __shared__ double yv[16 * NT], vt[16];
+  const int lane = threadIdx.x, i = lane & 15;
+  for (int e = lane; e < 16 * NT; e += 64) yv[e] = e < n ? rhs[e] : 0.0;
+  ND_WAVE_LDS();
+#pragma unroll
+  for (int p = NT - 1; p >= 0; --p) {
+    double s = 0.0;
+#pragma unroll
+    for (int c = p + 1; c < NT; ++c) s += c32_mv(F + (size_t)(p * NT + c) * 256, yv + 16 * c, lane);
+    const double v = yv[16 * p + i] - s;
+    ND_WAVE_LDS();
+    if (lane < 16) vt[i] = v;
+    ND_WAVE_LDS();
+    const double x = c32_mv(F + (size_t)(NT * NT + p) * 256, vt, lane);
+    ND_WAVE_LDS();
+    if (lane < 16) yv[16 * p + i] = x;
+    ND_WAVE_LDS();
+  }
+  for (int e = lane; e < n; e += 64) rhs[e] = yv[e];
+}
+
 // ---- the plan: leaves and separators from the column profile ----
 static NdPlan* nd_get(lvx_ctx* c) { if (!c->nd) c->nd = new NdPlan; return (NdPlan*)c->nd; }
 bool nd_active(const lvx_ctx* c) { return c->nd && ((const NdPlan*)c->nd)->active; }
@@ -829,7 +933,7 @@ void nd_counts(const lvx_ctx* c, int* separators, int* leaves) { const bool on =
 void nd_destroy(lvx_ctx* c) {
   NdPlan* P = (NdPlan*)c->nd;
   if (!P) return;
-  for (DevBuf* b : {&P->leaf, &P->sep, &P->nar, &P->den, &P->U, &P->WL, &P->WR, &P->GO, &P->Dc, &P->Rc, &P->LIc, &P->info, &P->D2, &P->G2, &P->F2, &P->Z2, &P->Y2, &P->info2, &P->zb2, &P->tc})
+  for (DevBuf* b : {&P->leaf, &P->sep, &P->nar, &P->den, &P->U, &P->WL, &P->WR, &P->GO, &P->Dc, &P->Rc, &P->LIc, &P->info, &P->D2, &P->G2, &P->F2, &P->Z2, &P->Y2, &P->info2, &P->zb2, &P->tc, &P->Fd})
     if (b->p) (void)hipFree(b->p);
   if (P->side) (void)hipStreamDestroy(P->side);
   if (P->ev_fork) (void)hipEventDestroy(P->ev_fork);
@@ -1092,6 +1196,33 @@ int nd_backward(lvx_ctx* c, double* zb) {
   if (lds > 64 * 1024) LVX_HIP(c, hipFuncSetAttribute((const void*)k_nd_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_nd_back, dim3((unsigned)(P->nnar + P->nsep)), dim3(64), lds, st, a, P->nnar, (const double*)zb2, zb);
   if (P->nden > 0) LVX_HIP(c, hipStreamWaitEvent(st, P->ev_join, 0));
+  LVX_HIP(c, hipGetLastError());
+  return LVX_OK;
+}
+
+// dense border of a single sequence (n <= 64): see k_dense_tiles
+bool dense_tiles_ok(const lvx_ctx* c, int n) { return c->ns == 0 && n >= 1 && n <= 64; }
+int dense_tiles_factor(lvx_ctx* c, const double* S, double* rhs, int n, int* info) {
+  NdPlan* P = nd_get(c);
+  int rc = dev_alloc(c, P->Fd, (size_t)20 * 256 * 8); if (rc) return rc;
+  double* F = (double*)P->Fd.p;
+  const int nt = (n + 15) / 16;
+  if (nt == 1) hipLaunchKernelGGL(k_dense_tiles<1>, dim3(1), dim3(64), 0, c->stream, S, rhs, n, info, F);
+  else if (nt == 2) hipLaunchKernelGGL(k_dense_tiles<2>, dim3(1), dim3(64), 0, c->stream, S, rhs, n, info, F);
+  else if (nt == 3) hipLaunchKernelGGL(k_dense_tiles<3>, dim3(1), dim3(64), 0, c->stream, S, rhs, n, info, F);
+  else hipLaunchKernelGGL(k_dense_tiles<4>, dim3(1), dim3(64), 0, c->stream, S, rhs, n, info, F);
+  LVX_HIP(c, hipGetLastError());
+  return LVX_OK;
+}
+int dense_tiles_back(lvx_ctx* c, double* rhs, int n) {
+  NdPlan* P = nd_get(c);
+  if (!P->Fd.p) return fail(c, LVX_E_STATE, "dense_tiles_back without a factorisation");
+  const double* F = (const double*)P->Fd.p;
+  const int nt = (n + 15) / 16;
+  if (nt == 1) hipLaunchKernelGGL(k_dense_tiles_back<1>, dim3(1), dim3(64), 0, c->stream, F, rhs, n);
+  else if (nt == 2) hipLaunchKernelGGL(k_dense_tiles_back<2>, dim3(1), dim3(64), 0, c->stream, F, rhs, n);
+  else if (nt == 3) hipLaunchKernelGGL(k_dense_tiles_back<3>, dim3(1), dim3(64), 0, c->stream, F, rhs, n);
+  else hipLaunchKernelGGL(k_dense_tiles_back<4>, dim3(1), dim3(64), 0, c->stream, F, rhs, n);
   LVX_HIP(c, hipGetLastError());
   return LVX_OK;
 }

@@ -26,6 +26,10 @@
 #include "lvx_ctx.h"
 
 namespace lvx {
+// dense border of a single sequence on 16 x 16 tiles (lvx_nd.h, in lvx_bcr.hip's translation unit)
+bool dense_tiles_ok(const lvx_ctx* c, int n);
+int dense_tiles_factor(lvx_ctx* c, const double* S, double* rhs, int n, int* info);
+int dense_tiles_back(lvx_ctx* c, double* rhs, int n);
 
 // ---------------------------------------------------------------------------------------------------------
 // small kernels
@@ -908,9 +912,12 @@ static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, 
     hipLaunchKernelGGL(k_schur, dim3(nbd), dim3(256), 0, st, (const double*)Zf, w.Cs, w.gcs, (const double*)w.scale,
                        nb > 0 ? nb : 0, nbd, c->nbd_ext, ldz, (const double*)w.lmd, ir, w.S, w.rhs);
   }
+  if (dense_tiles_ok(c, nbd)) { const int rcd = dense_tiles_factor(c, w.S, w.rhs, nbd, w.info); if (rcd) return rcd; }   // single sequence: one wavefront on 16 x 16 tiles (10 us against 50)
+  else {
   const size_t lds_dense = ((size_t)nbd * (nbd + 1) + nbd) * 8;
   LVX_HIP(c, hipFuncSetAttribute((const void*)k_dense_partial, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dense));
   hipLaunchKernelGGL(k_dense_partial, dim3(1), dim3(DENSE_NT), lds_dense, st, w.S, w.rhs, nbd, nbd - c->ns, w.info);
+  }
   LVX_HIP(c, hipGetLastError());
   int info[4] = {0, 0, 0, 0};
   tm.lap("enqueue gram+schur+dense");
@@ -1030,7 +1037,8 @@ static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double m[3
   double h[8]; int info4[4] = {0, 0, 0, 0};
   const bool quad_explicit = is_joint(c);   // (see the tail)
   auto tail = [&]() -> int {
-  { const size_t lds_dense = ((size_t)nbd * (nbd + 1) + nbd) * 8;
+  if (dense_tiles_ok(c, nbd)) { const int rcd = dense_tiles_back(c, w.rhs, nbd); if (rcd) return rcd; }
+  else { const size_t lds_dense = ((size_t)nbd * (nbd + 1) + nbd) * 8;
     LVX_HIP(c, hipFuncSetAttribute((const void*)k_dense_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dense));
     hipLaunchKernelGGL(k_dense_back, dim3(1), dim3(DENSE_NT), lds_dense, st, (const double*)w.S, w.rhs, nbd, np); }
   const int ldz = w.ldz;
