@@ -708,6 +708,43 @@ __global__ void k_gmax(const double* gb, const double* gc, int nb, int nbd, doub
   }
   block_atomic_max_nonneg(v, &sums[4]);   // atomic max on a non-negative double via its bit pattern
 }
+// k_diag + k_lm_fetch_diag + k_gmax + k_gmax_lm in ONE launch (each was ~5 us of launch for microseconds of work, between the pass and the solve of every LM iteration):
+// the diagonal of J^T J (band, border, landmarks behind them) and the max norm of the (projected) gradient over band, private border and landmarks
+struct PostEval { const double *Hb, *C, *lmH, *gb, *gc, *rho; double* diag; double* sums; int nb, bw, nbd, ldc, nl, ls, off_d, off_g, nbd_g; TauBox tb; };
+__global__ __launch_bounds__(256) void k_post_eval(PostEval q) {
+  double v = 0.0;
+  const int n = q.nb + q.nbd, tot = n + q.nl;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += gridDim.x * blockDim.x) {
+    if (i < q.nb) { q.diag[i] = q.Hb[(size_t)i * (q.bw + 1)]; v = fmax(v, fabs(q.gb[i])); }
+    else if (i < n) {
+      const int b = i - q.nb;
+      q.diag[i] = q.C[(size_t)b * q.ldc + b];
+      if (b < q.nbd_g) {
+        double g = q.gc[b];
+        for (int k = 0; k < 2; ++k) if (b == q.tb.idx[k] && q.tb.idx[k] >= 0) { const double x = *q.tb.x[k]; g = x - fmin(fmax(x - g, -q.tb.bound), q.tb.bound); }
+        v = fmax(v, fabs(g));
+      }
+    } else {
+      const int l = i - n;
+      const double* row = q.lmH + (size_t)l * q.ls;
+      q.diag[i] = row[q.off_d];
+      const double g = row[q.off_g];
+      v = fmax(v, q.rho ? fabs(q.rho[l] - fmax(q.rho[l] - g, 0.0)) : fabs(g));
+    }
+  }
+  block_atomic_max_nonneg(v, &q.sums[4]);
+}
+// what the solve reads of the normal equations beside the band and the border rows — g_b, C, g_c — copied for the landmark elimination to work on, and the solver's
+// sums / pivot codes / tickets cleared: one launch for a fill and three copies
+__global__ __launch_bounds__(256) void k_pre_solve(const double* gb, double* gbs, int nb, const double* C, double* Cs, int nc2, const double* gc, double* gcs, int ldc, double* sums) {
+  const int tot = nb + nc2 + ldc;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += gridDim.x * blockDim.x) {
+    if (i < nb) gbs[i] = gb[i];
+    else if (i < nb + nc2) Cs[i - nb] = C[i - nb];
+    else gcs[i - nb - nc2] = gc[i - nb - nc2];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 64) sums[threadIdx.x] = 0.0;
+}
 
 }  // namespace lvx
 
@@ -851,7 +888,7 @@ static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, 
   StageTimer tm(c);
   const int nb = c->nb, bw = c->bw, nbd = c->nbd;
   const double ir = 1.0 / radius;
-  LVX_HIP(c, hipMemsetAsync(w.sums, 0, 64 * 8, st));
+  bool sums_cleared = false;   // (k_pre_solve clears them with its copies; otherwise the fill below)
   const bool use_bcr = w.use_bcr && !force_seq;
   *bcr_used = use_bcr;
   if (!use_bcr && nb > 0) { int rca = dev_alloc(c, c->d_L, (size_t)nb * (bw + 1) * 8); if (rca) return rca; w.L = (double*)c->d_L.p; }
@@ -863,9 +900,9 @@ static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, 
       LVX_HIP(c, hipMemcpyAsync((void*)w.Hs, c->d_Hb.p, nb1 * (bw + 1) * 8, hipMemcpyDeviceToDevice, st));
       LVX_HIP(c, hipMemcpyAsync((void*)w.Bs, c->d_Bd.p, (size_t)nbd * nb1 * 8, hipMemcpyDeviceToDevice, st));
     }
-    LVX_HIP(c, hipMemcpyAsync((void*)w.gbs, c->d_gb.p, nb1 * 8, hipMemcpyDeviceToDevice, st));
-    LVX_HIP(c, hipMemcpyAsync((void*)w.Cs, c->d_C.p, ldc * ldc * 8, hipMemcpyDeviceToDevice, st));
-    LVX_HIP(c, hipMemcpyAsync((void*)w.gcs, c->d_gc.p, ldc * 8, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_pre_solve, dim3((unsigned)std::min<size_t>(RED_BLOCKS, (nb1 + ldc * ldc + ldc + 255) / 256)), dim3(256), 0, st, (const double*)c->d_gb.p, (double*)w.gbs, (int)nb1,
+                       (const double*)c->d_C.p, (double*)w.Cs, (int)(ldc * ldc), (const double*)c->d_gc.p, (double*)w.gcs, (int)ldc, w.sums);
+    sums_cleared = true;
     const int ne_max = c->lm_wl + c->lm_gspread + c->nbd_ext;
     const size_t lds_g = (size_t)32 * (ne_max + 1) * 8 + 32 * 8 + (size_t)2 * ne_max * 4 + 16;
     if (c->lm_ngrp > 0 && lds_g <= 160 * 1024) {
@@ -879,6 +916,7 @@ static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, 
                        (double*)w.Hs, bw, (double*)w.Bs, nb, (double*)w.Cs, c->nbd_ext, (double*)w.gbs, (double*)w.gcs, w.tk ? w.tk + 5 : nullptr);
     }
   }
+  if (!sums_cleared) LVX_HIP(c, hipMemsetAsync(w.sums, 0, 64 * 8, st));
   if (nb > 0) {
     const size_t tr = (size_t)(nbd + 1) * ldz;
     if (use_bcr && nd_active(c)) { const int rcd = nd_dense_start(c, w.scale, w.lmd, ir); if (rcd) return rcd; }
@@ -1094,10 +1132,9 @@ static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double m[3
 }
 
 // max |g| over this rank's private free scalars (band, private border, landmarks) -> *g; the shared entries of g_c -> gsh[ns]
-static int local_gmax(lvx_ctx* c, SolveWork& w, double* g, double* gsh) {
+static int local_gmax(lvx_ctx* c, SolveWork& w, double* g, double* gsh) {   // (with the diagonal of J^T J, which the same launch fetches: k_post_eval)
   hipStream_t st = c->stream;
   LVX_HIP(c, hipMemsetAsync(w.sums + 4, 0, 8, st));
-  const int n = c->nb + c->nbd - c->ns;
   // box constraints of a single sequence (w.constrained): the gradient norm is the projected one, at the state of the last evaluation
   const double* xs = (w.constrained && c->last_state_d) ? c->last_state_d : nullptr;
   TauBox tb{{-1, -1}, {nullptr, nullptr}, c->sensor_mto};
@@ -1106,9 +1143,13 @@ static int local_gmax(lvx_ctx* c, SolveWork& w, double* g, double* gsh) {
     if (oL != LVX_DEAD && oL < 0) { tb.idx[0] = -1 - oL; tb.x[0] = xs + 7 * (size_t)c->N + 23; }
     if (oC != LVX_DEAD && oC < 0) { tb.idx[1] = -1 - oC; tb.x[1] = xs + 7 * (size_t)c->N + 31; }
   }
-  hipLaunchKernelGGL(k_gmax, dim3((unsigned)std::min(RED_BLOCKS, (n + 255) / 256)), dim3(256), 0, st, (const double*)c->d_gb.p, (const double*)c->d_gc.p, c->nb, c->nbd - c->ns, w.sums, tb);
-  if (w.lm) hipLaunchKernelGGL(k_gmax_lm, dim3((unsigned)std::min(RED_BLOCKS, (c->L + 255) / 256)), dim3(256), 0, st, (const double*)c->d_lmH.p, c->L, c->lm_ls, c->lm_wl + c->nbd_ext + 1, w.sums,
-                               xs ? xs + 7 * (size_t)c->N + 32 : (const double*)nullptr);
+  PostEval q{};
+  q.Hb = (const double*)c->d_Hb.p; q.C = (const double*)c->d_C.p; q.lmH = (const double*)c->d_lmH.p; q.gb = (const double*)c->d_gb.p; q.gc = (const double*)c->d_gc.p;
+  q.rho = xs ? xs + 7 * (size_t)c->N + 32 : nullptr; q.diag = w.diag; q.sums = w.sums;
+  q.nb = c->nb; q.bw = c->bw; q.nbd = c->nbd; q.ldc = c->nbd_ext; q.nl = w.lm ? c->L : 0; q.ls = c->lm_ls; q.off_d = c->lm_wl + c->nbd_ext; q.off_g = c->lm_wl + c->nbd_ext + 1;
+  q.nbd_g = c->nbd - c->ns; q.tb = tb;
+  const int tot = c->nb + c->nbd + q.nl;
+  hipLaunchKernelGGL(k_post_eval, dim3((unsigned)std::min(RED_BLOCKS, (tot + 255) / 256)), dim3(256), 0, st, q);
   // into the pinned words (lvx_ctx::pin); local_collect moves them to *g / gsh after the host stop
   (void)g; (void)gsh;
   if (!c->pin) { LVX_HIP(c, hipHostMalloc((void**)&c->pin, 128 * 8, hipHostMallocDefault)); std::memset(c->pin, 0, 128 * 8); }
@@ -1130,9 +1171,8 @@ static int local_after_eval(lvx_ctx* c, SolveWork& w, EvalLocal* e, bool sync = 
   const int n = c->nb + c->nbd, ns = c->ns;
   hipStream_t st = c->stream;
   const int nl = w.lm ? c->L : 0;   // landmark diagonal behind the band / border entries
-  hipLaunchKernelGGL(k_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)c->d_Hb.p, (const double*)c->d_C.p, c->nb, c->bw, c->nbd, c->nbd_ext, w.diag);
-  if (nl > 0) hipLaunchKernelGGL(k_lm_fetch_diag, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, (const double*)c->d_lmH.p, nl, c->lm_ls, c->lm_wl + c->nbd_ext, w.diag + n);
-  int rc = local_gmax(c, w, &e->gm, e->hg); if (rc) return rc;
+  (void)nl;
+  int rc = local_gmax(c, w, &e->gm, e->hg); if (rc) return rc;   // k_post_eval: the diagonal (band, border, landmarks behind them) and the gradient norm in one launch
   if (is_joint(c) && ns > 0) LVX_HIP(c, hipMemcpyAsync(c->pin + 50, w.diag + (n - ns), (size_t)ns * 8, hipMemcpyDeviceToHost, st));
   // (keyed on the LOCKS, which every rank shares — a rank whose own sequence has no block that makes it constrained must project the summed shared gradient
   // exactly as its peers do, or they disagree on gradient_tolerance convergence and part ways before the next collective)
