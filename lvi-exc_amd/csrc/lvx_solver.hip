@@ -35,11 +35,6 @@ int dense_tiles_back(lvx_ctx* c, double* rhs, int n);
 // small kernels
 // ---------------------------------------------------------------------------------------------------------
 // diag[0..nb) from the band, diag[nb..nb+nbd) from C
-__global__ void k_diag(const double* Hb, const double* C, int nb, int bw, int nbd, int ldc, double* diag) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nb) diag[i] = Hb[(size_t)i * (bw + 1)];
-  else if (i < nb + nbd) { const int b = i - nb; diag[i] = C[(size_t)b * ldc + b]; }
-}
 // Jacobi scaling 1/(1+sqrt(diag)) (ceres TrustRegionMinimizer, jacobi_scaling = true; computed at the first iterate only)
 __global__ void k_scale_from_diag(const double* diag, int n, double* scale, int use_scaling) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -501,10 +496,6 @@ __global__ void k_plus(const double* x, const double* delta, int N, int L, uint3
 // on the UNSCALED band / border rows / dense border / gradients (copies: a rejected step solves the same normal equations again with another
 // radius), and after the reduced solve  delta_l = -w_l (g_l + E_l . delta).
 // ---------------------------------------------------------------------------------------------------------
-__global__ void k_lm_fetch_diag(const double* lmH, int L, int ls, int off, double* out) {
-  const int l = blockIdx.x * blockDim.x + threadIdx.x;
-  if (l < L) out[l] = lmH[(size_t)l * ls + off];
-}
 __global__ __launch_bounds__(256) void k_lm_schur(const double* __restrict__ lmH, const int* __restrict__ p0s, int wl, int nbd, int ls, const double* __restrict__ scale_l,
                                                   const double* __restrict__ lmd_l, double inv_radius, double* Hr, int bw, double* Br, int nb, double* Cr, int ldc, double* gbr, double* gcr, int* tk) {
   extern __shared__ double e[];            // the landmark's row, then the indices of its non-zero couplings
@@ -677,14 +668,6 @@ __global__ __launch_bounds__(256) void k_lm_back(const double* __restrict__ lmH,
   det_leave(tk);
 }
 // rho != null: the PROJECTED gradient of the bounded inverse depths, rho - max(rho - g, 0) (TrustRegionMinimizer::ComputeGradientNorms for a constrained problem)
-__global__ void k_gmax_lm(const double* lmH, int L, int ls, int off, double* sums, const double* rho) {
-  double v = 0.0;
-  for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < L; l += gridDim.x * blockDim.x) {
-    const double g = lmH[(size_t)l * ls + off];
-    v = fmax(v, rho ? fabs(rho[l] - fmax(rho[l] - g, 0.0)) : fabs(g));
-  }
-  block_atomic_max_nonneg(v, &sums[4]);
-}
 // out[0] += g . delta with the gradient of the accumulators (band, border, landmark rows) and a step in the tangent layout
 __global__ void k_gdot(const int* ord, int nt, const double* gb, const double* gc, const double* lmH, int ls, int goff, const double* delta, double* out, int* tk) {
   double s = 0.0;
@@ -699,16 +682,8 @@ __global__ void k_gdot(const int* ord, int nt, const double* gb, const double* g
 
 // max |g| over free scalars; bounded border scalars (a free sensor time offset: border index tb[k], value tx[k], |.| <= bound) enter projected
 struct TauBox { int idx[2]; const double* x[2]; double bound; };
-__global__ void k_gmax(const double* gb, const double* gc, int nb, int nbd, double* sums, TauBox tb) {   // nbd: border entries to include (the shared tail is excluded in the joint solve)
-  double v = 0.0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb + nbd; i += gridDim.x * blockDim.x) {
-    double g = i < nb ? gb[i] : gc[i - nb];
-    for (int k = 0; k < 2; ++k) if (i - nb == tb.idx[k] && tb.idx[k] >= 0) { const double x = *tb.x[k]; g = x - fmin(fmax(x - g, -tb.bound), tb.bound); }
-    v = fmax(v, fabs(g));
-  }
-  block_atomic_max_nonneg(v, &sums[4]);   // atomic max on a non-negative double via its bit pattern
-}
-// k_diag + k_lm_fetch_diag + k_gmax + k_gmax_lm in ONE launch (each was ~5 us of launch for microseconds of work, between the pass and the solve of every LM iteration):
+// One launch for what four did until round 6 (diagonal of the band / border, of the landmarks, gradient max norm of band + border, of the landmarks — each ~5 us of launch
+// for microseconds of work, between the pass and the solve of every LM iteration):
 // the diagonal of J^T J (band, border, landmarks behind them) and the max norm of the (projected) gradient over band, private border and landmarks
 struct PostEval { const double *Hb, *C, *lmH, *gb, *gc, *rho; double* diag; double* sums; int nb, bw, nbd, ldc, nl, ls, off_d, off_g, nbd_g; TauBox tb; };
 __global__ __launch_bounds__(256) void k_post_eval(PostEval q) {
