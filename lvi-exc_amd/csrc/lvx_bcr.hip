@@ -1326,7 +1326,7 @@ __global__ void k_sum_partials(const double* P, int nn, int nparts, int per, dou
 int bcr_gram(lvx_ctx* c, const double* Z, int ldz, int n, double* M, int row_major_nz) {
   const int b = c->bcr_b, nblk = c->bcr_nblk;
   const size_t nn = (size_t)n * n;
-  const int m = ldz;   // rows of Z: nblk * b for the chain of the band, nd_ldz for the leaves + separators elimination (rows past the band are zero)
+  const int m = row_major_nz ? c->nb : ldz;   // rows of Z: nblk * b for the chain of the band (rows past the band are zero); the band's own for the leaves + separators elimination (nothing writes the rows behind them)
   int rc;
   const double one = 1.0, zero = 0.0;
   LVX_HIP(c, hipMemsetAsync(M, 0, nn * 8, c->stream));

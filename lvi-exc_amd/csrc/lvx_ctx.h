@@ -218,8 +218,8 @@ bool nd_active(const lvx_ctx* c);
 int nd_ldz(const lvx_ctx* c);
 int nd_nz(const lvx_ctx* c);   // right-hand sides of the leaves + separators elimination are ROW-major [nd_ldz][nd_nz]
 void nd_counts(const lvx_ctx* c, int* separators, int* leaves);
-int nd_dense_start(lvx_ctx* c, const double* scale, const double* lmd, double inv_radius);   // before the right-hand sides are built (see there)
-int nd_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_radius, int* info_out_d, double* Z, int ldz, int nrhs);
+int nd_dense_start(lvx_ctx* c, const double* scale, const double* lmd, double inv_radius, const double* Bs, const double* gbs, double* Z, int ldz);   // the dense leaves, on their own stream
+int nd_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_radius, int* info_out_d, const double* Bs, const double* gbs, double* Z, int ldz, int nrhs);   // Z is OUTPUT: L^-1 of the right-hand sides formed from the border rows Bs and g_b
 int nd_backward(lvx_ctx* c, double* zb);
 // profiling scope: records a (start, stop) HIP event pair on ctx->stream around a launch when profiling is on
 struct ProfScope {

@@ -17,8 +17,9 @@
 // Every tile lives in the MFMA accumulator layout (row = (lane >> 4) + 4 reg, col = lane & 15) and is stored as it stands (index = reg * 64 + lane: 512-byte coalesced
 // rows); such a tile is the A operand of its TRANSPOSE and the B operand of itself, so U^T Y, W^T Y and inv(L) X (from the stored TRANSPOSE of the triangle's inverse)
 // need no data movement between the products.
-// What the solver sees: Z <- L^-1 Z in place (in the elimination order: a row permutation the Gram Z^T Z does not see), then one vector back — with Z ROW-major
-// [nd_ldz rows][nd_nz] on this path (k_build_rhs_rm, bcr_gram's row-major staging, k_sub_border_rm in lvx_solver.hip).
+// What the solver sees: Z = L^-1 [B^T | -g_b] S (in the elimination order: a row permutation the Gram Z^T Z does not see) as OUTPUT — the right-hand sides themselves are never
+// built: every kernel forms its entries from the border rows where it loads them (nd_rhs) —, ROW-major [nd_ldz rows][nd_nz] (bcr_gram's row-major staging,
+// k_sub_border_rm in lvx_solver.hip), then one vector back.
 // Applies when the profile allows it (nd_plan); otherwise, and as the reference in the tests (switch SOLVER_ND = -1), the uniform chain runs.
 #pragma once
 
@@ -41,12 +42,13 @@ struct NdPlan {
   int nleaf = 0, nnar = 0, nden = 0, nsep = 0, ntile = 0, bd = 0, maxnt = 0, nblk2 = 0;
   std::vector<NdLeaf> leaves; std::vector<NdSep> seps;
   DevBuf leaf, sep, nar, den, U, WL, WR, GO, Dc, Rc, LIc, info, D2, G2, F2, Z2, Y2, info2, zb2, tc, Fd;   // Fd: tiles of the dense border's factor (k_dense_tiles)
-  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_trsm = nullptr, ev_rc = nullptr;
 };
 struct NdArgs {
   const NdLeaf* leaf; const NdSep* sep; const int* nar; const int* den;
   const double* Hs; const double* scale; const double* lmd; double ir; int ld, npre, nb;
   double *U, *WL, *WR, *GO; int nc, nrhs;
+  const double* Bs; const double* gbs; int nbd;   // the right-hand sides are formed where they are loaded (nd_rhs): [B^T | -g_b] scaled — no array of them is built first
   double* Z; int ldz, nz;   // Z row-major [ldz rows][nz]: a 16 x 16 tile is four 128-byte rows per load (column-major: sixteen 32-byte pieces — measured: NOT what bounded k_nd_solve; kept, the Gram and the border subtraction read rows as well)
   int* info; double* trash;   // trash: 64 words nobody reads (the target of masked stores that stay unconditional)
 };
@@ -60,6 +62,11 @@ __device__ __forceinline__ d4 nd_mmn(const d4& A, const d4& B, d4 C) {   // C - 
 #pragma unroll
   for (int r = 0; r < 4; ++r) C = __builtin_amdgcn_mfma_f64_16x16x4f64(-A[r], B[r], C, 0, 0, 0);
   return C;
+}
+// entry (band position row, column col) of the solver's right-hand sides: columns 0 .. nbd - 1 the border rows (S B^T S), column nbd the band's own -S g_b
+__device__ __forceinline__ double nd_rhs(const NdArgs& a, int row, int col) {
+  if (col < a.nbd) return a.Bs[(size_t)col * a.nb + row] * a.scale[a.nb + col] * a.scale[row];
+  return col == a.nbd ? -a.gbs[row] * a.scale[row] : 0.0;
 }
 // Entries of tile (rows 16 pr .., columns 16 pc ..), pr <= pc, of a narrow leaf as they lie in the band storage (the diagonal tile mirrored).  nd_leaf_raw only LOADS
 // (clamped index, unconditional: a conditional load becomes a branch with its own s_waitcnt, and thirty of them in a row were 8 us per tile column); nd_leaf_ok says
@@ -88,10 +95,15 @@ __device__ __forceinline__ d4 nd_rows4(const double* v, int c0, int m, int p, in
 // One wavefront per narrow leaf: U (p-2, p) = inv(L_{p-2}) A (p-2, p),  U (p-1, p) = inv(L_{p-1}) (A (p-1, p) - U (p-2, p-1)^T U (p-2, p)),
 // U (p, p) = chol (A (p, p) - U (p-2, p)^T U (p-2, p) - U (p-1, p)^T U (p-1, p)); per tile column [U (p-2, p) | U (p-1, p) | U (p, p) | inv(L_p)^T] goes to a.U.
 // A = S H S + diag(lmd) / radius as k_bcr_build forms it (an untouched variable — zero diagonal — gets the pivot 1: any pivot gives y = 0).
-__global__ __launch_bounds__(64) void k_nd_factor(NdArgs a) {
-  __shared__ double tr[16 * 17];
-  const NdLeaf lf = a.leaf[a.nar[blockIdx.x]];
-  const int lane = threadIdx.x, q = lane >> 4, j = lane & 15;
+// Four leaves per workgroup, a wavefront each (no workgroup barrier anywhere): 109 workgroups sit on 109 CUs and leave the others EMPTY for the dense leaves' Cholesky, whose
+// workgroups need a whole CU's register file (a wavefront per workgroup spread the 436 over every CU: k_potrf_reg<12> then waited for CUs to drain).
+__global__ __launch_bounds__(256) void k_nd_factor(NdArgs a, int nnar) {
+  __shared__ double tr4[4][16 * 17];
+  const int wv_ = threadIdx.x >> 6, leaf_i = blockIdx.x * 4 + wv_;
+  if (leaf_i >= nnar) return;
+  double* tr = tr4[wv_];
+  const NdLeaf lf = a.leaf[a.nar[leaf_i]];
+  const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
   const int c0 = lf.c0, m = lf.m;
   const d4 zero4 = d4{0.0, 0.0, 0.0, 0.0};
   d4 U1p = zero4, LIT1 = zero4, LIT2 = zero4;
@@ -136,7 +148,7 @@ __global__ __launch_bounds__(64) void k_nd_factor(NdArgs a) {
     ND_KEEP4(K0); ND_KEEP4(K1); ND_KEEP4(K2); ND_KEEP4(KS); ND_KEEP1(k1); ND_KEEP1(k2);
     U1p = U1; LIT2 = LIT1; LIT1 = LIT; H0 = K0; H1 = K1; H2 = K2; S0 = S1; S1 = S2; S2 = KS; sc = k1; lc = k2;
   }
-  if (lane == 0) a.info[blockIdx.x] = bad;
+  if (lane == 0) a.info[leaf_i] = bad;
 }
 
 // A workgroup per narrow leaf, a wavefront per 16 right-hand sides: wavefronts 0, 1 the coupling to the left separator (W_L, dense: the forward substitution fills it
@@ -161,11 +173,16 @@ __device__ __forceinline__ void nd_solve_role(const NdArgs& a, const NdLeaf& lf,
     const int d = ROLE == 0 ? lf.c0 + R - (lf.cl + col) : lf.cr + col - (lf.c0 + R);
     return in && d < a.npre && d >= 0;
   };
-  auto rhs_raw = [&](int p) {
-    d4 X;
+  // (ROLE 1) raw entry of [B^T | -g_b] and the row's scale; the column's scale (and sign) is scol1
+  const double scol1 = ROLE == 1 ? (col < a.nbd ? a.scale[a.nb + min(col, a.nbd - 1)] : -1.0) : 0.0;
+  auto rhs_raw = [&](int p, d4& X, d4& S) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { const int R = 16 * p + q + 4 * r; X[r] = a.Z[rhs_ok(p, r) ? (size_t)(lf.c0 + R) * a.nz + col : 0]; }
-    return X;
+    for (int r = 0; r < 4; ++r) {
+      const int R = 16 * p + q + 4 * r;
+      const bool ok = rhs_ok(p, r);
+      X[r] = col < a.nbd ? a.Bs[ok ? (size_t)col * a.nb + lf.c0 + R : 0] : a.gbs[ok ? lf.c0 + R : 0];
+      S[r] = a.scale[ok ? lf.c0 + R : 0];
+    }
   };
   auto coupling_tile = [&](int p) {
     d4 X;
@@ -208,15 +225,15 @@ __device__ __forceinline__ void nd_solve_role(const NdArgs& a, const NdLeaf& lf,
 #define NKT(i)
 #define NKT_USE(x)
 #endif
-  d4 X = zero4;
-  if (ROLE == 1) X = rhs_raw(0);
+  d4 X = zero4, XS = zero4;
+  if (ROLE == 1) rhs_raw(0, X, XS);
   double w0, w1;
   u_fetch(0, w0, w1); u_put(0, w0, w1);
   u_fetch(1, w0, w1);
   ND_LDS_BARRIER();
   for (int p = 0; p < lf.nt; ++p) {
-    d4 Xn = zero4;
-    if (ROLE == 1) Xn = rhs_raw(p + 1);
+    d4 Xn = zero4, XSn = zero4;
+    if (ROLE == 1) rhs_raw(p + 1, Xn, XSn);
     double w0n, w1n;
     u_fetch(p + 2, w0n, w1n);
     __builtin_amdgcn_sched_barrier(0);   // (keep the next row's loads up here, ahead of this row's products)
@@ -225,7 +242,7 @@ __device__ __forceinline__ void nd_solve_role(const NdArgs& a, const NdLeaf& lf,
     if (ROLE != 2 || p >= lf.pr0) {
       d4 acc;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = ROLE == 1 ? (rhs_ok(p, r) ? X[r] : 0.0) : (p == cbase ? C0[r] : (p == cbase + 1 ? C1[r] : (p == cbase + 2 ? C2[r] : 0.0)));
+      for (int r = 0; r < 4; ++r) acc[r] = ROLE == 1 ? (rhs_ok(p, r) ? X[r] * XS[r] * scol1 : 0.0) : (p == cbase ? C0[r] : (p == cbase + 1 ? C1[r] : (p == cbase + 2 ? C2[r] : 0.0)));
       if (p >= 2) acc = nd_mmn(u_tile(p, 0), Y2, acc);
       if (p >= 1) acc = nd_mmn(u_tile(p, 1), Y1, acc);
       Y = nd_mm(u_tile(p, 2), acc, zero4);
@@ -273,10 +290,10 @@ __device__ __forceinline__ void nd_solve_role(const NdArgs& a, const NdLeaf& lf,
       GR1 = nd_mm(W, Y, GR1);
     }
     NKT_USE(GL1[0]); NKT_USE(GR1[0]); NKT(4)
-    d4 KX = Xn;
-    if (ROLE == 1) ND_KEEP4(KX);
+    d4 KX = Xn, KS = XSn;
+    if (ROLE == 1) { ND_KEEP4(KX); ND_KEEP4(KS); }
     ND_KEEP1(w0n); ND_KEEP1(w1n);
-    Y2 = Y1; Y1 = Y; X = KX; w0 = w0n; w1 = w1n;
+    Y2 = Y1; Y1 = Y; X = KX; XS = KS; w0 = w0n; w1 = w1n;
 #ifdef LVX_ND_KT
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 #endif
@@ -313,7 +330,7 @@ __global__ __launch_bounds__(256) void k_nd_cbuild(NdArgs a, double* Dc, double*
   const NdLeaf lf = a.leaf[a.den[blockIdx.x]];
   double* D = Dc + (size_t)blockIdx.x * bd * bd;
   double* R = Rc + (size_t)blockIdx.x * bd * a.nc;
-  const int cbeg = which ? bd : 0, ncol = which ? bd + a.nc : bd;
+  const int cbeg = which == 1 ? bd : 0, ncol = which == 0 ? bd : bd + a.nc;   // which 0: D_c, 1: R_c, 2: both
   for (int cc = cbeg + blockIdx.y * 4 + (threadIdx.x >> 6); cc < ncol; cc += gridDim.y * 4) {
     const int lane = threadIdx.x & 63;
     if (cc < bd) {
@@ -339,7 +356,7 @@ __global__ __launch_bounds__(256) void k_nd_cbuild(NdArgs a, double* Dc, double*
           } else if (c < 64) {
             const int gs = lf.cr + c - 32, d = gs - (lf.c0 + i);
             if (lf.sr >= 0 && c - 32 < lf.wr && d <= bw) v = a.Hs[(size_t)(lf.c0 + i) * a.ld + d] * a.scale[lf.c0 + i] * a.scale[gs];
-          } else if (c - 64 < a.nrhs) v = a.Z[(size_t)(lf.c0 + i) * a.nz + (c - 64)];
+          } else if (c - 64 < a.nrhs) v = nd_rhs(a, lf.c0 + i, c - 64);
         }
         R[(size_t)c * bd + i] = v;
       }
@@ -412,7 +429,7 @@ __global__ __launch_bounds__(256) void k_nd_assemble(NdArgs a, double* D2, doubl
     const int i = e & 31, z = e >> 5;
     double v = 0.0;
     if (i < sp.w) {
-      v = a.Z[(size_t)(sp.c0 + i) * a.nz + z];
+      v = nd_rhs(a, sp.c0 + i, z);
       if (GoL) v -= GoL[(size_t)(32 + i) * a.nc + 64 + z];
       if (GoR) v -= GoR[(size_t)i * a.nc + 64 + z];
     }
@@ -938,6 +955,8 @@ void nd_destroy(lvx_ctx* c) {
   if (P->side) (void)hipStreamDestroy(P->side);
   if (P->ev_fork) (void)hipEventDestroy(P->ev_fork);
   if (P->ev_join) (void)hipEventDestroy(P->ev_join);
+  if (P->ev_trsm) (void)hipEventDestroy(P->ev_trsm);
+  if (P->ev_rc) (void)hipEventDestroy(P->ev_rc);
   delete P; c->nd = nullptr;
 }
 // SOLVER_ND: -1 never, 0 when the profile suits (a band of >= 8192 columns, at most half of them in wide runs), 1 whenever the profile allows it (tests on small problems).
@@ -1081,68 +1100,70 @@ int nd_plan(lvx_ctx* c, int nrhs) {
     LVX_HIP(c, hipStreamCreateWithFlags(&P->side, hipStreamNonBlocking));   // (a high-priority stream for the few long dense-leaf workgroups made EVERY kernel of the solve slower: 1.15 -> 1.65 ms per step)
     LVX_HIP(c, hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
     LVX_HIP(c, hipEventCreateWithFlags(&P->ev_join, hipEventDisableTiming));
+    LVX_HIP(c, hipEventCreateWithFlags(&P->ev_trsm, hipEventDisableTiming));
+    LVX_HIP(c, hipEventCreateWithFlags(&P->ev_rc, hipEventDisableTiming));
   }
   P->active = true;
   return LVX_OK;
 }
-static NdArgs nd_args(lvx_ctx* c, NdPlan* P, const double* scale, const double* lmd, double ir, double* Z, int ldz) {
+static NdArgs nd_args(lvx_ctx* c, NdPlan* P, const double* scale, const double* lmd, double ir, double* Z, int ldz, const double* Bs = nullptr, const double* gbs = nullptr) {
   NdArgs a{};
   a.leaf = (const NdLeaf*)P->leaf.p; a.sep = (const NdSep*)P->sep.p; a.nar = (const int*)P->nar.p; a.den = (const int*)P->den.p;
   a.Hs = c->p_Hs ? c->p_Hs : (const double*)c->d_Hb.p; a.scale = scale; a.lmd = lmd; a.ir = ir; a.ld = c->bw + 1; a.npre = c->clear_npre; a.nb = c->nb;
   a.U = (double*)P->U.p; a.WL = (double*)P->WL.p; a.WR = (double*)P->WR.p; a.GO = (double*)P->GO.p; a.nc = P->nc; a.nrhs = P->nrhs;
+  a.Bs = Bs; a.gbs = gbs; a.nbd = P->nrhs - 1;
   a.Z = Z; a.ldz = ldz; a.nz = P->nc - 64; a.info = (int*)P->info.p; a.trash = (double*)P->zb2.p + (size_t)P->nblk2 * 32;
   return a;
 }
 static C32 nd_c32(NdPlan* P) { return C32{(double*)P->D2.p, (double*)P->G2.p, (double*)P->Z2.p, (double*)P->Y2.p, (double*)P->F2.p, (int*)P->info2.p, P->nblk2, P->nc - 64, P->zt}; }
 static size_t c32_lds_bytes() { return (size_t)(10 * 256 + C32_MAXT * 512 + 8 * 16 * 17) * 8; }
 
-// The dense leaves' Cholesky, started on the side stream BEFORE the solver builds its right-hand sides: a workgroup of k_potrf_reg<12> takes the whole register file of a
-// CU, and once the narrow leaves' wavefronts sit on every CU (one per leaf, k_nd_factor) it waits for a CU to drain — 115 us for the 50 blocks against 55 alone.
-int nd_dense_start(lvx_ctx* c, const double* scale, const double* lmd, double inv_radius) {
+// The dense leaves, on the side stream, from their matrices to their products for the separators (nothing here waits for the narrow leaves; the right-hand sides are
+// formed from the border rows where they are loaded: nd_rhs).  k_potrf_reg<12> needs whole CUs: k_nd_factor's four-leaf workgroups leave it more than half of them.
+int nd_dense_start(lvx_ctx* c, const double* scale, const double* lmd, double inv_radius, const double* Bs, const double* gbs, double* Z, int ldz) {
   NdPlan* P = (NdPlan*)c->nd;
-  if (!P || !P->active) return fail(c, LVX_E_STATE, "nd_dense_start without a plan");
+  if (!P || !P->active || ldz != P->ldz) return fail(c, LVX_E_STATE, "nd_dense_start without a matching plan");
   if (P->nden == 0) return LVX_OK;
   hipStream_t st = c->stream;
-  NdArgs ad = nd_args(c, P, scale, lmd, inv_radius, nullptr, P->ldz);
+  NdArgs ad = nd_args(c, P, scale, lmd, inv_radius, Z, ldz, Bs, gbs);
   ad.info = ad.info + P->nnar;
-  const int bd = P->bd;
+  const int bd = P->bd, zt = P->zt;
   LVX_HIP(c, hipEventRecord(P->ev_fork, st));
   LVX_HIP(c, hipStreamWaitEvent(P->side, P->ev_fork, 0));
-  hipLaunchKernelGGL(k_nd_cbuild, dim3((unsigned)P->nden, 16), dim3(256), 0, P->side, ad, (double*)P->Dc.p, (double*)P->Rc.p, bd, c->bw, 0);
+  // matrices on the side stream (the Cholesky, 60 us, starts behind them at once); right-hand sides on the caller's stream, ahead of the narrow leaves' factorisation
+  // (which has 25 us to spare against the dense leaves' chain) — the triangular solve waits for both
+  hipLaunchKernelGGL(k_nd_cbuild, dim3((unsigned)P->nden, (unsigned)((bd + 3) / 4)), dim3(256), 0, P->side, ad, (double*)P->Dc.p, (double*)P->Rc.p, bd, c->bw, 0);   // a wavefront per column
+  hipLaunchKernelGGL(k_nd_cbuild, dim3((unsigned)P->nden, (unsigned)((P->nc + 3) / 4)), dim3(256), 0, st, ad, (double*)P->Dc.p, (double*)P->Rc.p, bd, c->bw, 1);
+  LVX_HIP(c, hipEventRecord(P->ev_rc, st));
   c->stream = P->side;
   rocblas_handle h = nullptr;
-  const int rc = potrf_batched(c, h, (double*)P->Dc.p, bd, (long long)bd * bd, ad.info, P->nden, (double*)P->LIc.p, (long long)(bd / 16) * 256);
+  const long long sD = (long long)bd * bd, sLI = (long long)(bd / 16) * 256;
+  int rc = potrf_batched(c, h, (double*)P->Dc.p, bd, sD, ad.info, P->nden, (double*)P->LIc.p, sLI);
+  // (the streaming solve k_trsm_reg, which could share CUs with k_nd_solve, is slower still: 136 us beside it)
+  if (!rc) LVX_HIP(c, hipStreamWaitEvent(P->side, P->ev_rc, 0));
+  if (!rc) rc = trsv_batched<false>(c, (const double*)P->Dc.p, bd, sD, (double*)P->Rc.p, 1, bd, (long long)bd * P->nc, P->nc, P->nden, (const double*)P->LIc.p, sLI);
+  if (!rc) LVX_HIP(c, hipEventRecord(P->ev_trsm, P->side));   // k_nd_solve starts behind it: the LDS-resident solve (130 KB per workgroup) cannot share a CU with its workgroups and waited for CUs to drain (102 us against 38)
+  if (!rc) {
+    if (zt == 2) hipLaunchKernelGGL(k_nd_cgram<2>, dim3((unsigned)P->nden), dim3(64 * 6), 0, P->side, ad, (const double*)P->Rc.p, bd);
+    else if (zt == 3) hipLaunchKernelGGL(k_nd_cgram<3>, dim3((unsigned)P->nden), dim3(64 * 7), 0, P->side, ad, (const double*)P->Rc.p, bd);
+    else if (zt == 4) hipLaunchKernelGGL(k_nd_cgram<4>, dim3((unsigned)P->nden), dim3(64 * 8), 0, P->side, ad, (const double*)P->Rc.p, bd);
+    else hipLaunchKernelGGL(k_nd_cgram<5>, dim3((unsigned)P->nden), dim3(64 * 9), 0, P->side, ad, (const double*)P->Rc.p, bd);
+  }
   c->stream = st;
-  return rc;
+  if (rc) return rc;
+  LVX_HIP(c, hipEventRecord(P->ev_join, P->side));
+  return LVX_OK;
 }
-// factor + Z <- L^-1 Z (in the elimination order, in place); nd_dense_start has run
-int nd_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_radius, int* info_out_d, double* Z, int ldz, int nrhs) {
+// factor + Z <- L^-1 [B^T | -g_b] S (in the elimination order; Z is written, never read before); nd_dense_start has run
+int nd_factor(lvx_ctx* c, const double* scale, const double* lmd, double inv_radius, int* info_out_d, const double* Bs, const double* gbs, double* Z, int ldz, int nrhs) {
   NdPlan* P = (NdPlan*)c->nd;
   if (!P || !P->active || nrhs != P->nrhs || ldz != P->ldz) return fail(c, LVX_E_STATE, "nd_factor without a matching plan");
   hipStream_t st = c->stream;
-  int rc;
-  NdArgs a = nd_args(c, P, scale, lmd, inv_radius, Z, ldz);
-  const int bd = P->bd, zt = P->zt;
-  if (P->nden > 0) {   // dense leaves on the side stream: right-hand sides (they need the solver's Z), triangular solves, products for the separators
-    LVX_HIP(c, hipEventRecord(P->ev_fork, st));
-    LVX_HIP(c, hipStreamWaitEvent(P->side, P->ev_fork, 0));
-    c->stream = P->side;
-    NdArgs ad = a; ad.info = a.info + P->nnar;
-    hipLaunchKernelGGL(k_nd_cbuild, dim3((unsigned)P->nden, 16), dim3(256), 0, P->side, ad, (double*)P->Dc.p, (double*)P->Rc.p, bd, c->bw, 1);
-    const long long sD = (long long)bd * bd, sLI = (long long)(bd / 16) * 256;
-    rc = trsv_batched<false>(c, (const double*)P->Dc.p, bd, sD, (double*)P->Rc.p, 1, bd, (long long)bd * P->nc, P->nc, P->nden, (const double*)P->LIc.p, sLI);
-    if (!rc) {
-      if (zt == 2) hipLaunchKernelGGL(k_nd_cgram<2>, dim3((unsigned)P->nden), dim3(64 * 6), 0, P->side, ad, (const double*)P->Rc.p, bd);
-      else if (zt == 3) hipLaunchKernelGGL(k_nd_cgram<3>, dim3((unsigned)P->nden), dim3(64 * 7), 0, P->side, ad, (const double*)P->Rc.p, bd);
-      else if (zt == 4) hipLaunchKernelGGL(k_nd_cgram<4>, dim3((unsigned)P->nden), dim3(64 * 8), 0, P->side, ad, (const double*)P->Rc.p, bd);
-      else hipLaunchKernelGGL(k_nd_cgram<5>, dim3((unsigned)P->nden), dim3(64 * 9), 0, P->side, ad, (const double*)P->Rc.p, bd);
-    }
-    c->stream = st;
-    if (rc) return rc;
-    LVX_HIP(c, hipEventRecord(P->ev_join, P->side));
-  }
+  NdArgs a = nd_args(c, P, scale, lmd, inv_radius, Z, ldz, Bs, gbs);
+  const int zt = P->zt;
   if (P->nnar > 0) {
-    hipLaunchKernelGGL(k_nd_factor, dim3((unsigned)P->nnar), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_nd_factor, dim3((unsigned)((P->nnar + 3) / 4)), dim3(256), 0, st, a, P->nnar);
+    if (P->nden > 0) LVX_HIP(c, hipStreamWaitEvent(st, P->ev_trsm, 0));
     if (zt == 2) hipLaunchKernelGGL(k_nd_solve<2>, dim3((unsigned)P->nnar), dim3(64 * 6), 0, st, a);
     else if (zt == 3) hipLaunchKernelGGL(k_nd_solve<3>, dim3((unsigned)P->nnar), dim3(64 * 7), 0, st, a);
     else if (zt == 4) hipLaunchKernelGGL(k_nd_solve<4>, dim3((unsigned)P->nnar), dim3(64 * 8), 0, st, a);

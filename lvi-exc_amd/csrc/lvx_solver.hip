@@ -364,20 +364,6 @@ __global__ __launch_bounds__(256) void k_sub_border_rm(const double* Z, const do
   for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
   if (j < nb && l == 0) z[j] = s;
 }
-// Z row-major [ldz][nz] = [B^T | -g_b] scaled, zero rows past the band: 64 band positions per workgroup through LDS (the border rows are read along the band, the
-// right-hand sides written along their rows)
-__global__ __launch_bounds__(256) void k_build_rhs_rm(const double* Bd, const double* gb, const double* scale, int nb, int nbd, int ldz, int nz, double* Z) {
-  __shared__ double T[64][81];
-  const int j0 = blockIdx.x * 64, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = j0 + lane;
-  const double sj = j < nb ? scale[j] : 0.0;
-  for (int r = wv; r < nz; r += 4) {
-    double v = 0.0;
-    if (j < nb) { if (r < nbd) v = Bd[(size_t)r * nb + j] * scale[nb + r] * sj; else if (r == nbd) v = -gb[j] * sj; }
-    T[lane][r] = v;
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < 64 * nz; e += 256) { const int row = e / nz, col = e % nz; if (j0 + row < ldz) Z[(size_t)(j0 + row) * nz + col] = T[row][col]; }
-}
 __global__ void k_sub_border(const double* Z, const double* yc, int nb, int nbd, int ldz, double* z) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nb) return;
@@ -894,13 +880,13 @@ static int solve_local(lvx_ctx* c, SolveWork& w, double radius, bool force_seq, 
   if (!sums_cleared) LVX_HIP(c, hipMemsetAsync(w.sums, 0, 64 * 8, st));
   if (nb > 0) {
     const size_t tr = (size_t)(nbd + 1) * ldz;
-    if (use_bcr && nd_active(c)) { const int rcd = nd_dense_start(c, w.scale, w.lmd, ir); if (rcd) return rcd; }
-    if (use_bcr && nd_active(c)) hipLaunchKernelGGL(k_build_rhs_rm, dim3((unsigned)((ldz + 63) / 64)), dim3(256), 0, st, w.Bs, w.gbs, w.scale, nb, nbd, ldz, nd_nz(c), w.Z);
+    // leaves + separators elimination: no array of right-hand sides is built — its kernels form [B^T | -g_b] S from the border rows where they load them (lvx_nd.h: nd_rhs)
+    if (use_bcr && nd_active(c)) { const int rcd = nd_dense_start(c, w.scale, w.lmd, ir, w.Bs, w.gbs, w.Z, ldz); if (rcd) return rcd; }
     else hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)((tr + 255) / 256)), dim3(256), 0, st, w.Bs, w.gbs, w.scale, nb, nbd, ldz, w.Z);
     if (use_bcr) {
       int rc2;
       tm.lap("enqueue build_rhs");
-      if (nd_active(c)) { if ((rc2 = nd_factor(c, w.scale, w.lmd, ir, w.info, w.Z, ldz, nbd + 1))) return rc2; }
+      if (nd_active(c)) { if ((rc2 = nd_factor(c, w.scale, w.lmd, ir, w.info, w.Bs, w.gbs, w.Z, ldz, nbd + 1))) return rc2; }
       else if ((rc2 = bcr_factor(c, w.scale, w.lmd, ir, w.info, w.Z, ldz, nbd + 1))) return rc2;   // factor, and Z <- L^-1 [B^T, f_b] (in place) level by level with it
       tm.lap("enqueue bcr_factor + forward");
     } else {
