@@ -1079,7 +1079,8 @@ static int solve_step_device(lvx_ctx* c, SolveWork& w, double radius, double m[3
   return LVX_OK;
   };
   { const int rt = tail(); if (rt) return rt; }
-  if (defer && (info4[0] || info4[1])) {   // a pivot failed in the elimination this step came from: redo it with the sequential band Cholesky (checked at once)
+  // (LVX_TEST_BAD_PIVOT in the environment: the tests' way into this branch — a pivot failure is declared where there was none)
+  if (defer && (info4[0] || info4[1] || std::getenv("LVX_TEST_BAD_PIVOT"))) {   // a pivot failed in the elimination this step came from: redo it with the sequential band Cholesky (checked at once)
     ++c->solver_fallbacks;
     rc = solve_local(c, w, radius, true, &bcr_used, false);
     if (rc == LVX_E_NOTPD) { *notpd_out = true; return LVX_OK; }

@@ -188,3 +188,33 @@ def test_random_window_layouts_agree_with_the_sequential_solver(seed):
     print("seed %d: views %d, band %d x %d, %d separators / %d leaves, radius %g" % (seed, views, lo["n_band"], lo["bandwidth"], lo["solver_separators"], lo["solver_leaves"], radius))
     assert lo["solver_fallbacks"] == 0
     _same(d, m, ds, ms)
+
+
+def test_failed_pivot_sends_the_step_to_the_sequential_solver(monkeypatch):
+    """The pivot codes of the elimination reach the host with the step's sums; a failure voids the step, which the sequential band Cholesky redoes (counted in
+    lvx_layout::solver_fallbacks).  LVX_TEST_BAD_PIVOT declares a failure where there is none: the redone step is the step."""
+    P = synth.make_bench_problem(seed=39, n_imu=16000, n_surfel=40000, n_reproj=2400, n_planes=60, obs_per_frame=40)
+    x = P["state0"]
+    d0, m0, lo0 = _step(P, TAU, x, 1)
+    assert lo0["solver_fallbacks"] == 0 and lo0["solver_separators"] > 2
+    monkeypatch.setenv("LVX_TEST_BAD_PIVOT", "1")
+    d1, m1, lo1 = _step(P, TAU, x, 1)
+    monkeypatch.delenv("LVX_TEST_BAD_PIVOT")
+    assert lo1["solver_fallbacks"] == 1
+    _same(d1, m1, d0, m0)
+    # and the LM loop keeps going through such steps
+    monkeypatch.setenv("LVX_TEST_BAD_PIVOT", "1")
+    g = lvx.Context(0)
+    g.set_switch("SOLVER_ND", 1)
+    lvx.load_problem(g, P, TAU)
+    xs, res = g.lm_solve(x, max_iterations=3)
+    n_fb = g.layout()["solver_fallbacks"]
+    g.close()
+    monkeypatch.delenv("LVX_TEST_BAD_PIVOT")
+    g = lvx.Context(0)
+    g.set_switch("SOLVER_ND", 1)
+    lvx.load_problem(g, P, TAU)
+    xr, ref = g.lm_solve(x, max_iterations=3)
+    g.close()
+    assert n_fb == res["iterations"] and res["iterations"] == ref["iterations"]
+    assert np.abs(np.asarray(res["cost_history"]) - np.asarray(ref["cost_history"])).max() <= 1e-9 * np.abs(np.asarray(ref["cost_history"])).max()
